@@ -1,0 +1,110 @@
+"""Oracle: model-level compositions (reference models/cirim.py, vn.py, unet.py, zf.py).  Test infrastructure.
+
+The reference model classes subclass a pytorch-lightning base and cannot be imported where the
+goldens are generated; their `forward` bodies are ~20 lines each and are restated here over the
+block oracles.  Weight dicts use the reference state_dict keys (`cirim.{i}.*`, `cascades.{i}.*`, `unet.*`).
+"""
+import math
+
+import torch
+
+from . import fft as offt
+from . import rim as orim
+from . import unet as ounet
+from . import utils as outils
+from . import varnet as ovn
+
+
+def _sub(p, prefix):
+    return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
+
+
+def cirim_time_steps(time_steps):
+    """cirim.py:50-51: rounded up to a multiple of 8."""
+    return 8 * math.ceil(time_steps / 8)
+
+
+def process_intermediate_pred(pred, sensitivity_maps, target, no_dc, fft_centered, fft_normalization, spatial_dims,
+                              coil_dim, coil_combination_method="SENSE", do_coil_combination=False):
+    """cirim.py:167-197."""
+    if not no_dc or do_coil_combination:
+        pred = offt.ifft2(pred, fft_centered, fft_normalization, spatial_dims)
+        pred = outils.coil_combination(pred, sensitivity_maps, method=coil_combination_method, dim=coil_dim)
+    pred = torch.view_as_complex(pred.contiguous())
+    _, pred = outils.center_crop_to_smallest(target, pred)
+    return pred
+
+
+def cirim_forward(p, cfg, y, sensitivity_maps, mask, init_pred, target):
+    """cirim.py:146-165.  `cfg` is a dict with the reference's YAML keys.  Returns list[cascade][time_step]."""
+    rcfg = orim.RIMConfig(
+        recurrent_layer=cfg["recurrent_layer"], conv_filters=cfg["conv_filters"], conv_kernels=cfg["conv_kernels"],
+        conv_dilations=cfg["conv_dilations"], conv_bias=cfg["conv_bias"], recurrent_filters=cfg["recurrent_filters"],
+        recurrent_kernels=cfg["recurrent_kernels"], recurrent_dilations=cfg["recurrent_dilations"],
+        recurrent_bias=cfg["recurrent_bias"], depth=cfg.get("depth", 2), time_steps=cirim_time_steps(cfg["time_steps"]),
+        conv_dim=cfg.get("conv_dim", 2), no_dc=cfg["no_dc"], fft_centered=cfg["fft_centered"],
+        fft_normalization=cfg["fft_normalization"], spatial_dims=cfg.get("spatial_dims"), coil_dim=cfg.get("coil_dim", 1),
+        dimensionality=cfg.get("dimensionality", 2))
+    prediction = y.clone()
+    init_pred = None if init_pred is None or init_pred.dim() < 4 else init_pred
+    out = []
+    for i in range(cfg["num_cascades"]):
+        prediction, _ = orim.rim_block_forward(
+            _sub(p, f"cirim.{i}."), rcfg, prediction, y, sensitivity_maps, mask, init_pred, None, 1.0,
+            keep_eta=False if i == 0 else cfg["keep_eta"])
+        out.append([process_intermediate_pred(e, sensitivity_maps, target, cfg["no_dc"], rcfg.fft_centered,
+                                              rcfg.fft_normalization, rcfg.spatial_dims, rcfg.coil_dim,
+                                              cfg.get("coil_combination_method", "SENSE")) for e in prediction])
+    return out
+
+
+def cirim_process_loss(target, pred, loss_fn, time_steps, num_cascades):
+    """cirim.py:199-247 with accumulate_estimates=True and a non-SSIM loss (l1 / mse).
+
+    Reproduces the weighting quirk: every scalar loss is multiplied by the whole logspace vector.
+    """
+    target = torch.abs(target / torch.max(torch.abs(target)))
+    cascades_loss = []
+    for cascade_pred in pred:
+        ls = [loss_fn(target, torch.abs(t / torch.max(torch.abs(t)))) for t in cascade_pred]
+        w = torch.logspace(-1, 0, steps=time_steps).to(ls[0])
+        cascades_loss.append(sum(sum([x * w for x in ls]) / time_steps))
+    return sum(cascades_loss) / num_cascades
+
+
+def varnet_forward(p, cfg, y, sensitivity_maps, mask, init_pred, target):
+    """vn.py:125-142."""
+    est = y.clone()
+    for i in range(cfg["num_cascades"]):
+        est = ovn.varnet_block_forward(
+            p, est, y, sensitivity_maps, mask, cfg["pooling_layers"], cfg["padding_size"], cfg.get("normalize", True),
+            cfg["fft_centered"], cfg["fft_normalization"], cfg.get("spatial_dims"), cfg.get("coil_dim", 1),
+            cfg["no_dc"], prefix=f"cascades.{i}.")
+    est = offt.ifft2(est, cfg["fft_centered"], cfg["fft_normalization"], cfg.get("spatial_dims"))
+    est = outils.coil_combination(est, sensitivity_maps, method=cfg.get("coil_combination_method", "SENSE"),
+                                  dim=cfg.get("coil_dim", 1))
+    est = torch.view_as_complex(est.contiguous())
+    _, est = outils.center_crop_to_smallest(target, est)
+    return est
+
+
+def unet_model_forward(p, cfg, y, sensitivity_maps, mask, init_pred, target):
+    """unet.py:108-121."""
+    cd = cfg.get("coil_dim", 1)
+    eta = torch.view_as_complex(outils.coil_combination(
+        offt.ifft2(y, cfg["fft_centered"], cfg["fft_normalization"], cfg.get("spatial_dims")),
+        sensitivity_maps, method=cfg.get("coil_combination_method", "SENSE"), dim=cd).contiguous())
+    _, eta = outils.center_crop_to_smallest(target, eta)
+    out = ounet.norm_unet_forward(p, torch.view_as_real(eta.unsqueeze(cd)), cfg["pooling_layers"],
+                                  cfg["padding_size"], cfg.get("normalize", True), prefix="unet.unet.")
+    return torch.view_as_complex(out).squeeze(cd)
+
+
+def zf_forward(cfg, y, sensitivity_maps, mask, target=None):
+    """zf.py:90-100."""
+    pred = outils.coil_combination(
+        offt.ifft2(y, cfg["fft_centered"], cfg["fft_normalization"], cfg.get("spatial_dims")),
+        sensitivity_maps, method=cfg.get("coil_combination_method", "SENSE").upper(), dim=cfg.get("coil_dim", 1))
+    pred = outils.check_stacked_complex(pred.contiguous())
+    _, pred = outils.center_crop_to_smallest(target, pred)
+    return pred

@@ -1,0 +1,68 @@
+"""Shared helpers for the parity tests (tolerances follow SURVEY.md appendix C)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Stated tolerances (fp32 path): per-operator rel-L2 <= 1e-5 and |err| <= 1e-5 * max|ref| + rtol 1e-4;
+# full 64-step fp32 CIRIM chain rel-L2 <= 1e-4.  Index/mask/select work: bit-exact.
+OP_REL_L2 = 1e-5
+CHAIN_REL_L2 = 1e-4
+
+
+class Golden:
+    def __init__(self):
+        self._cache = {}
+
+    def __call__(self, name):
+        if name not in self._cache:
+            self._cache[name] = np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+        return self._cache[name]
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def meta(z, key):
+    return json.loads(str(z[key]))
+
+
+def weights(z, prefix):
+    return {k[len(prefix):]: T(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def rel_l2(a, b):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, dtype=np.float64)
+    d = np.linalg.norm((a - b).ravel())
+    n = np.linalg.norm(b.ravel())
+    return d / n if n > 0 else d
+
+
+def assert_close(got, ref, rel=OP_REL_L2, what=""):
+    """Norm-relative criterion (elementwise rtol is wrong for FFT outputs)."""
+    g = got.detach().cpu() if isinstance(got, torch.Tensor) else torch.as_tensor(got)
+    r = ref.detach().cpu() if isinstance(ref, torch.Tensor) else torch.as_tensor(ref)
+    if g.is_complex():
+        g = torch.view_as_real(g)
+    if r.is_complex():
+        r = torch.view_as_real(r)
+    assert tuple(g.shape) == tuple(r.shape), f"{what}: shape {tuple(g.shape)} vs {tuple(r.shape)}"
+    assert torch.isfinite(g).all(), f"{what}: non-finite values"
+    e = rel_l2(g, r)
+    assert e <= rel, f"{what}: rel-L2 {e:.3e} > {rel:.1e}"
+    peak = float(r.abs().max()) if r.numel() else 0.0
+    mx = float((g.double() - r.double()).abs().max()) if r.numel() else 0.0
+    assert mx <= 1e-4 * peak * max(1.0, rel / OP_REL_L2) + 1e-30, f"{what}: max-abs {mx:.3e} vs peak {peak:.3e}"
+    return e
+
+
+def assert_exact(got, ref, what=""):
+    g = got.detach().cpu() if isinstance(got, torch.Tensor) else torch.as_tensor(got)
+    r = ref.detach().cpu() if isinstance(ref, torch.Tensor) else torch.as_tensor(ref)
+    assert tuple(g.shape) == tuple(r.shape), f"{what}: shape {tuple(g.shape)} vs {tuple(r.shape)}"
+    assert torch.equal(g, r.to(g.dtype)), f"{what}: not bit-exact"

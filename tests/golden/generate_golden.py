@@ -1,0 +1,484 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own leaf modules.
+
+Runs only where /root/reference exists (the build container).  The reference is imported from
+where it lies through `_refshim` (no reference source is copied); the outputs are plain data
+(.npz: inputs, expected outputs, randomly initialised reference weights, config as JSON).
+
+    python tests/golden/generate_golden.py            # writes tests/golden/g*.npz
+
+Fixture ids follow SURVEY.md section 8c (G1..G11).  Model-level compositions (CIRIM / VarNet /
+UNet / ZF) are produced by composing the imported reference blocks exactly as the reference
+`forward` bodies do (cirim.py:146-165, vn.py:125-142, unet.py:108-121, zf.py:90-100), because the
+model classes subclass a pytorch-lightning base that is not installed here.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refshim  # noqa: E402
+
+fft = _refshim.load("mridc.collections.common.parts.fft")
+utils = _refshim.load("mridc.collections.common.parts.utils")
+rim_utils = _refshim.load("mridc.collections.reconstruction.models.rim.rim_utils")
+rim_block = _refshim.load("mridc.collections.reconstruction.models.rim.rim_block")
+vn_block = _refshim.load("mridc.collections.reconstruction.models.varnet.vn_block")
+unet_block = _refshim.load("mridc.collections.reconstruction.models.unet_base.unet_block")
+ssim_mod = _refshim.load("mridc.collections.common.losses.ssim")
+subsample = _refshim.load("mridc.collections.reconstruction.data.subsample")
+
+torch.set_num_threads(4)
+
+
+def arange_input(shape):
+    # tests/collections/reconstruction/fastmri/conftest.py:16-29 (np.product -> np.prod)
+    return torch.from_numpy(np.arange(np.prod(shape)).reshape(shape)).float()
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def save(name, d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays")
+
+
+def sd(module, prefix="w/"):
+    return {prefix + k: v.detach().clone() for k, v in module.state_dict().items()}
+
+
+NORMS = ["backward", "ortho", "forward", "none"]
+
+
+def g1_fft():
+    d = {}
+    cases = {"a33": arange_input([3, 3, 2]), "a46": arange_input([4, 6, 2]), "a1084": arange_input([10, 8, 4, 2]),
+             "r1318": rnd([2, 3, 13, 18, 2], 11), "r1512": rnd([1, 2, 15, 12, 2], 12), "r1719": rnd([1, 2, 17, 19, 2], 13),
+             "r3124": rnd([1, 2, 31, 24, 2], 14)}
+    for cn, x in cases.items():
+        d[f"{cn}/x"] = x
+        for c in (0, 1):
+            for n in NORMS:
+                d[f"{cn}/fft2/c{c}/{n}"] = fft.fft2(x, centered=bool(c), normalization=n, spatial_dims=[-2, -1])
+                d[f"{cn}/ifft2/c{c}/{n}"] = fft.ifft2(x, centered=bool(c), normalization=n, spatial_dims=[-2, -1])
+    # spatial_dims other than the last two (interpreted on the complex view, fft.py:66-72)
+    x = rnd([2, 6, 5, 4, 2], 15)
+    d["sd/x"] = x
+    d["sd/fft2_m3m2"] = fft.fft2(x, centered=True, normalization="ortho", spatial_dims=[-3, -2])
+    d["sd/ifft2_12"] = fft.ifft2(x, centered=False, normalization="backward", spatial_dims=[1, 2])
+    # already-complex input (appendix D.18): last dim != 2 -> no view_as_complex, real view returned
+    xc = torch.view_as_complex(rnd([2, 7, 6, 2], 16))
+    d["cplx/x"] = torch.view_as_real(xc)
+    d["cplx/fft2"] = fft.fft2(xc, centered=True, normalization="ortho")
+    # large case: strided sample + norms only (keeps the fixture small)
+    xl = rnd([1, 15, 640, 372, 2], 17)
+    for c, n in ((0, "backward"), (1, "ortho")):
+        for nm, fn in (("fft2", fft.fft2), ("ifft2", fft.ifft2)):
+            y = fn(xl, centered=bool(c), normalization=n).reshape(-1)
+            d[f"big/{nm}/c{c}/{n}/sample"] = y[::9973].clone()
+            d[f"big/{nm}/c{c}/{n}/l2"] = y.double().norm().reshape(1)
+    d["big/seed_shape"] = np.array([17, 1, 15, 640, 372, 2])
+    save("g1_fft.npz", d)
+
+
+def g2_shift():
+    d = {}
+    for nm, shape in (("s56", [5, 6]), ("s732", [7, 3, 2]), ("s4152", [4, 1, 5, 2]), ("s9", [9])):
+        x = arange_input(shape)
+        d[f"{nm}/x"] = x
+        d[f"{nm}/fftshift_all"] = fft.fftshift(x)
+        d[f"{nm}/ifftshift_all"] = fft.ifftshift(x)
+        for dim in range(len(shape)):
+            d[f"{nm}/fftshift/{dim}"] = fft.fftshift(x, dim=[dim])
+            d[f"{nm}/ifftshift/{dim}"] = fft.ifftshift(x, dim=[dim])
+            for s in (-3, 0, 1, 2, 11):
+                d[f"{nm}/roll/{dim}/{s}"] = fft.roll(x, [s], [dim])
+    x = arange_input([5, 6, 3])
+    d["multi/x"] = x
+    d["multi/roll_0_2"] = fft.roll(x, [2, 1], [0, 2])
+    d["multi/fftshift_m2m1"] = fft.fftshift(x, dim=[-2, -1])
+    d["multi/ifftshift_01"] = fft.ifftshift(x, dim=[0, 1])
+    save("g2_shift.npz", d)
+
+
+def g3_complex():
+    d = {}
+    x = rnd([2, 4, 9, 7, 2], 21)
+    y = rnd([2, 4, 9, 7, 2], 22)
+    e = rnd([2, 1, 9, 7, 2], 23)
+    d.update(x=x, y=y, e=e)
+    d["complex_mul"] = utils.complex_mul(x, y)
+    d["complex_mul_bcast"] = utils.complex_mul(e, y)
+    d["complex_conj"] = utils.complex_conj(x)
+    d["complex_abs"] = utils.complex_abs(x)
+    d["complex_abs_sq"] = utils.complex_abs_sq(x)
+    for dim in (0, 1):
+        d[f"rss/{dim}"] = utils.rss(x, dim)
+        d[f"rss_complex/{dim}"] = utils.rss_complex(x, dim)
+        d[f"sense/{dim}"] = utils.sense(x, y, dim)
+        d[f"cc_sense/{dim}"] = utils.coil_combination(x, y, "SENSE", dim)
+        d[f"cc_rss/{dim}"] = utils.coil_combination(x, y, "RSS", dim)
+    img = rnd([2, 3, 11, 14], 24)
+    d["crop/x"] = img
+    d["crop/center_7_8"] = utils.center_crop(img, (7, 8))
+    d["crop/center_10_13"] = utils.center_crop(img, (10, 13))
+    cimg = rnd([2, 11, 14, 2], 25)
+    d["crop/cx"] = cimg
+    d["crop/complex_6_9"] = utils.complex_center_crop(cimg, (6, 9))
+    a, b = utils.center_crop_to_smallest(rnd([2, 9, 14], 26), img[:, 0])
+    d["crop/smallest_a"], d["crop/smallest_b"] = a, b
+    save("g3_complex.npz", d)
+
+
+def make_mask(shape, seed=123, cf=0.08, acc=4):
+    """RandomMaskFunc through apply_mask exactly as the reference model tests do (test_cirim.py:307-318)."""
+    mf = subsample.RandomMaskFunc([cf], [acc])
+    x = arange_input(shape)
+    outs, masks = [], []
+    for i in range(x.shape[0]):
+        o, m, _ = utils.apply_mask(x[i: i + 1], mf, seed=seed)
+        outs.append(o)
+        masks.append(m)
+    return torch.cat(outs), torch.cat(masks)
+
+
+def g11_masks():
+    d = {}
+    for nm, shape in (("s32x16", [1, 3, 32, 16, 2]), ("s15x12", [1, 5, 15, 12, 2]), ("s13x18", [1, 8, 13, 18, 2]),
+                      ("s17x19", [1, 2, 17, 19, 2]), ("b2", [2, 3, 12, 10, 2])):
+        o, m = make_mask(shape)
+        d[f"{nm}/shape"] = np.array(shape)
+        d[f"{nm}/masked"] = o
+        d[f"{nm}/mask"] = m
+    mf = subsample.RandomMaskFunc([0.08], [4])
+    m, acc = mf([1, 640, 372, 2], seed=123)
+    d["knee/mask_372"] = m
+    mf = subsample.Equispaced1DMaskFunc([0.08], [4])
+    m, acc = mf([1, 640, 372, 2], seed=123)
+    d["knee/equi_372"] = m
+    save("g11_masks.npz", d)
+
+
+def synth(B, C, H, W, seed):
+    """Small smooth-ish multicoil problem: image, sens maps (sum |S|^2 = 1), full k-space (centred ortho)."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 1, H, W, 2, generator=g)
+    S = torch.randn(B, C, H, W, 2, generator=g)
+    S = S / utils.complex_abs_sq(S).sum(1, keepdim=True).sqrt().unsqueeze(-1)
+    return img, S
+
+
+def g4_llg():
+    d = {}
+    B, C, H, W = 2, 3, 12, 10
+    img, S = synth(B, C, H, W, 41)
+    eta = rnd([B, H, W, 2], 42)
+    d.update(eta=eta, S=S)
+    i = 0
+    for centered, norm in ((True, "ortho"), (False, "backward"), (True, "forward"), (False, "none")):
+        k = fft.fft2(utils.complex_mul(img, S), centered=centered, normalization=norm)
+        _, m1 = make_mask([1, C, H, W, 2])            # [1,1,1,W,1] fp32
+        mB = torch.cat([m1, torch.roll(m1, 3, dims=-2)], 0)   # [B,1,1,W,1]
+        g2 = torch.Generator().manual_seed(43)
+        m2d = (torch.rand(1, 1, H, W, 1, generator=g2) < 0.4).float()
+        for mname, m in (("m1", m1), ("mB", mB), ("m2d", m2d)):
+            y = k * m
+            for dt in ("bool", "uint8", "float32"):
+                mm = m.to(getattr(torch, dt))
+                for cd in (0, 1):
+                    for sigma in (1.0, 0.5):
+                        if sigma != 1.0 and (dt != "float32" or cd != 1):
+                            continue
+                        key = f"case{i}"
+                        out = rim_utils.log_likelihood_gradient(eta, y, S, mm, sigma, centered, norm, [-2, -1], cd)
+                        d[key + "/y"] = y
+                        d[key + "/mask"] = mm
+                        d[key + "/out"] = out
+                        d[key + "/meta"] = np.array(json.dumps(dict(centered=centered, norm=norm, mask=mname, dtype=dt,
+                                                                   coil_dim=cd, sigma=sigma)))
+                        i += 1
+    d["ncases"] = np.array(i)
+    # big single-step checksum at the headline size
+    img, S = synth(1, 15, 640, 372, 44)
+    eta = rnd([1, 640, 372, 2], 45, 0.1)
+    k = fft.fft2(utils.complex_mul(img, S), centered=False, normalization="backward")
+    mk = subsample.RandomMaskFunc([0.08], [4])([1, 640, 372, 2], seed=123)[0].reshape(1, 1, 1, 372, 1).bool()
+    out = rim_utils.log_likelihood_gradient(eta, k * mk, S, mk, 1.0, False, "backward", [-2, -1], 1).reshape(-1)
+    d["big/sample"] = out[::4999].clone()
+    d["big/l2"] = out.double().norm().reshape(1)
+    save("g4_llg.npz", d)
+
+
+RIM_CFG = dict(recurrent_layer="IndRNN", conv_filters=[64, 64, 2], conv_kernels=[5, 3, 3], conv_dilations=[1, 2, 1],
+               conv_bias=[True, True, False], recurrent_filters=[64, 64, 0], recurrent_kernels=[1, 1, 0],
+               recurrent_dilations=[1, 1, 0], recurrent_bias=[True, True, False], depth=2, time_steps=8, conv_dim=2,
+               no_dc=True, fft_centered=True, fft_normalization="ortho", spatial_dims=[-2, -1], coil_dim=1,
+               dimensionality=2)
+
+
+def scale_weights(mod, factor):
+    # reference init makes the IndRNN net nearly linear (ih / hh std = 1/(hid*(1+k^2)), rnn_cells.py:306,319;
+    # SURVEY appendix C) -> scale those two so the ReLUs and the recurrence actually shape the output
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if n.endswith("rnn.ih.weight") or n.endswith("rnn.hh"):
+                p.mul_(factor)
+
+
+def g5_rimblock():
+    d = {}
+    cases = []
+    # (name, cfg overrides, shape, keep_eta, pred_is_list, weight scale)
+    cases.append(("ind64", dict(time_steps=3), [1, 3, 16, 12, 2], False, False, 1.0))
+    cases.append(("ind64_keep", dict(time_steps=2, fft_centered=False, fft_normalization="backward"), [1, 3, 16, 12, 2], True, False, 8.0))
+    cases.append(("ind16_dc", dict(time_steps=3, no_dc=False, conv_filters=[16, 16, 2], recurrent_filters=[16, 16, 0]), [2, 4, 13, 18, 2], False, False, 5.0))
+    cases.append(("ind16_list", dict(time_steps=2, conv_filters=[16, 16, 2], recurrent_filters=[16, 16, 0]), [1, 5, 15, 12, 2], True, True, 5.0))
+    cases.append(("gru16", dict(time_steps=3, recurrent_layer="GRU", conv_filters=[16, 16, 2], recurrent_filters=[16, 16, 0], recurrent_kernels=[3, 3, 0]), [1, 3, 16, 12, 2], False, False, 1.0))
+    cases.append(("gru8_k1", dict(time_steps=2, recurrent_layer="GRU", conv_filters=[8, 8, 2], recurrent_filters=[8, 8, 0]), [2, 2, 9, 11, 2], False, False, 1.0))
+    cases.append(("mgu16", dict(time_steps=3, recurrent_layer="MGU", conv_filters=[16, 16, 2], recurrent_filters=[16, 16, 0], recurrent_kernels=[3, 3, 0], recurrent_dilations=[1, 2, 0]), [1, 3, 16, 12, 2], False, False, 1.0))
+    for i, (nm, ov, shape, keep, aslist, wscale) in enumerate(cases):
+        cfg = dict(RIM_CFG)
+        cfg.update(ov)
+        torch.manual_seed(500 + i)
+        blk = rim_block.RIMBlock(**cfg).eval()
+        scale_weights(blk, wscale)
+        B, C, H, W, _ = shape
+        img, S = synth(B, C, H, W, 510 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=cfg["fft_centered"], normalization=cfg["fft_normalization"])
+        _, m = make_mask([1, C, H, W, 2])
+        m = m.bool()
+        y = k * m
+        if keep:
+            p0 = utils.sense(fft.ifft2(y, centered=cfg["fft_centered"], normalization=cfg["fft_normalization"]), S, 1)
+            pred = [p0 * 0.5, p0] if aslist else p0
+        else:
+            pred = y
+        with torch.no_grad():
+            outs, hx = blk(pred, y, S, m, None, None, 1.0, keep_eta=keep)
+        d[f"{nm}/cfg"] = np.array(json.dumps(cfg))
+        d[f"{nm}/meta"] = np.array(json.dumps(dict(keep_eta=keep, pred_is_list=aslist)))
+        d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"] = y, S, m
+        if keep:
+            d[f"{nm}/pred"] = p0
+        d[f"{nm}/outs"] = torch.stack(outs)
+        for j, h in enumerate(hx):
+            d[f"{nm}/hx{j}"] = h
+        d.update(sd(blk, f"{nm}/w/"))
+    d["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g5_rimblock.npz", d)
+
+
+def compose_cirim(blocks, cfg, y, S, mask, init_pred, target):
+    # restates cirim.py:146-165 + process_intermediate_pred :187-197 over imported RIMBlocks
+    prediction = y.clone()
+    init_pred = None if init_pred is None or init_pred.dim() < 4 else init_pred
+    cascades = []
+    for i, cascade in enumerate(blocks):
+        prediction, _ = cascade(prediction, y, S, mask, init_pred, None, 1.0,
+                                keep_eta=False if i == 0 else cfg["keep_eta"])
+        steps = []
+        for pred in prediction:
+            if not cfg["no_dc"]:
+                pred = fft.ifft2(pred, centered=cfg["fft_centered"], normalization=cfg["fft_normalization"],
+                                 spatial_dims=cfg["spatial_dims"])
+                pred = utils.coil_combination(pred, S, method=cfg["coil_combination_method"], dim=cfg["coil_dim"])
+            pred = torch.view_as_complex(pred)
+            _, pred = utils.center_crop_to_smallest(target, pred)
+            steps.append(pred)
+        cascades.append(steps)
+    return cascades
+
+
+def g6_cirim():
+    import math
+    d = {}
+    cases = [
+        ("c8f16", dict(conv_filters=[16, 16, 2], recurrent_filters=[16, 16, 0], num_cascades=8, time_steps=5,
+                       fft_centered=False, fft_normalization="backward", keep_eta=True, no_dc=True),
+         [1, 6, 32, 24, 2], 3.0, (28, 20)),
+        ("c2f64", dict(num_cascades=2, time_steps=8, keep_eta=True, no_dc=True), [1, 4, 24, 20, 2], 6.0, None),
+        ("c2f16dc", dict(conv_filters=[16, 16, 2], recurrent_filters=[16, 16, 0], num_cascades=2, time_steps=8,
+                         keep_eta=False, no_dc=False), [2, 3, 15, 12, 2], 4.0, None),
+    ]
+    for i, (nm, ov, shape, wscale, crop) in enumerate(cases):
+        cfg = dict(RIM_CFG)
+        cfg.update(coil_combination_method="SENSE", keep_eta=True, num_cascades=1)
+        cfg.update(ov)
+        T = 8 * math.ceil(cfg["time_steps"] / 8)       # cirim.py:51
+        bcfg = {k: v for k, v in cfg.items() if k not in ("coil_combination_method", "keep_eta", "num_cascades")}
+        bcfg["time_steps"] = T
+        torch.manual_seed(600 + i)
+        blocks = [rim_block.RIMBlock(**bcfg).eval() for _ in range(cfg["num_cascades"])]
+        for b in blocks:
+            scale_weights(b, wscale)
+        B, C, H, W, _ = shape
+        img, S = synth(B, C, H, W, 610 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=cfg["fft_centered"], normalization=cfg["fft_normalization"])
+        _, m = make_mask([1, C, H, W, 2])
+        m = m.bool()
+        y = k * m
+        target = utils.complex_abs(utils.sense(fft.ifft2(k, centered=cfg["fft_centered"],
+                                                         normalization=cfg["fft_normalization"]), S, 1))
+        if crop is not None:
+            target = utils.center_crop(target, crop)
+        with torch.no_grad():
+            out = compose_cirim(blocks, cfg, y, S, m, None, target)
+        d[f"{nm}/cfg"] = np.array(json.dumps(cfg))
+        d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"], d[f"{nm}/target"] = y, S, m, target
+        d[f"{nm}/out"] = torch.view_as_real(torch.stack([torch.stack(c) for c in out]))
+        for ci, b in enumerate(blocks):
+            d.update(sd(b, f"{nm}/w/cirim.{ci}."))
+        # loss with the reference's weighting (cirim.py:218-247), l1
+        l1 = torch.nn.L1Loss()
+        tgt = torch.abs(target / torch.max(torch.abs(target)))
+        closs = []
+        for cp in out:
+            ls = [l1(tgt, torch.abs(t / torch.max(torch.abs(t)))) for t in cp]
+            _l = [x * torch.logspace(-1, 0, steps=T).to(ls[0]) for x in ls]
+            closs.append(sum(sum(_l) / T))
+        d[f"{nm}/loss_l1"] = (sum(closs) / len(blocks)).reshape(1)
+    d["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g6_cirim.npz", d)
+
+
+def g7_varnet():
+    d = {}
+    cases = [("u14p2", 14, 2, 11, [1, 3, 32, 16, 2], True, False), ("u14p2_odd", 14, 2, 11, [1, 5, 15, 12, 2], False, False),
+             ("u4p4", 4, 4, 15, [1, 2, 17, 19, 2], True, True), ("u6p3_nonorm", 6, 3, 7, [2, 2, 21, 26, 2], False, False)]
+    for i, (nm, ch, pools, pad, shape, centered, no_dc) in enumerate(cases):
+        torch.manual_seed(700 + i)
+        normalize = "nonorm" not in nm
+        nu = unet_block.NormUnet(ch, pools, padding_size=pad, normalize=normalize)
+        norm = "ortho" if centered else "backward"
+        blk = vn_block.VarNetBlock(nu, fft_centered=centered, fft_normalization=norm, spatial_dims=[-2, -1],
+                                   coil_dim=1, no_dc=no_dc).eval()
+        with torch.no_grad():
+            blk.dc_weight.fill_(0.7)
+        B, C, H, W, _ = shape
+        img, S = synth(B, C, H, W, 710 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=centered, normalization=norm)
+        _, m = make_mask([1, C, H, W, 2])
+        y = k * m
+        pred = y + 0.1 * rnd(list(y.shape), 720 + i)
+        mm = m.byte() if i % 2 == 0 else m.bool()       # pipeline emits uint8 (transforms.py:467)
+        with torch.no_grad():
+            eta_in = blk.sens_reduce(pred, S)
+            nu_out = nu(eta_in)
+            out = blk(pred, y, S, mm)
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(chans=ch, num_pools=pools, padding_size=pad, normalize=normalize,
+                                                  fft_centered=centered, fft_normalization=norm, no_dc=no_dc)))
+        d[f"{nm}/pred"], d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"] = pred, y, S, mm
+        d[f"{nm}/eta_in"], d[f"{nm}/normunet_out"], d[f"{nm}/out"] = eta_in, nu_out, out
+        d.update(sd(blk, f"{nm}/w/"))
+    d["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g7_varnet.npz", d)
+
+
+def g8_models():
+    d = {}
+    # VarNet: 3 cascades (ch 8, pools 2, pad 11), vn.py:125-142
+    torch.manual_seed(800)
+    cfg = dict(num_cascades=3, channels=8, pooling_layers=2, padding_size=11, normalize=True, no_dc=False,
+               fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1,
+               coil_combination_method="SENSE")
+    blocks = [vn_block.VarNetBlock(unet_block.NormUnet(8, 2, padding_size=11, normalize=True), fft_centered=False,
+                                   fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1, no_dc=False).eval()
+              for _ in range(3)]
+    B, C, H, W = 1, 4, 30, 22
+    img, S = synth(B, C, H, W, 810)
+    k = fft.fft2(utils.complex_mul(img, S), centered=False, normalization="backward")
+    _, m = make_mask([1, C, H, W, 2])
+    m = m.byte()
+    y = k * m
+    target = utils.complex_abs(utils.sense(fft.ifft2(k, centered=False, normalization="backward"), S, 1))
+    target = utils.center_crop(target, (26, 20))
+    with torch.no_grad():
+        est = y.clone()
+        for b in blocks:
+            est = b(est, y, S, m)
+        est = fft.ifft2(est, centered=False, normalization="backward", spatial_dims=[-2, -1])
+        est = utils.coil_combination(est, S, method="SENSE", dim=1)
+        est = torch.view_as_complex(est)
+        _, est = utils.center_crop_to_smallest(target, est)
+    d["vn/cfg"] = np.array(json.dumps(cfg))
+    d["vn/y"], d["vn/S"], d["vn/mask"], d["vn/target"] = y, S, m, target
+    d["vn/out"] = torch.view_as_real(est)
+    for ci, b in enumerate(blocks):
+        d.update(sd(b, f"vn/w/cascades.{ci}."))
+    # RSS variant of the final combine (same cascades)
+    with torch.no_grad():
+        est = y.clone()
+        for b in blocks:
+            est = b(est, y, S, m)
+        est = utils.coil_combination(fft.ifft2(est, centered=False, normalization="backward"), S, method="RSS", dim=1)
+    d["vn/out_rss_realview"] = est
+
+    # UNet model: unet.py:108-121
+    torch.manual_seed(801)
+    ucfg = dict(channels=8, pooling_layers=2, padding_size=11, normalize=True, fft_centered=True,
+                fft_normalization="ortho", spatial_dims=[-2, -1], coil_dim=1, coil_combination_method="SENSE")
+    nu = unet_block.NormUnet(8, 2, padding_size=11, normalize=True).eval()
+    k2 = fft.fft2(utils.complex_mul(img, S), centered=True, normalization="ortho")
+    y2 = k2 * m
+    with torch.no_grad():
+        eta = torch.view_as_complex(utils.coil_combination(fft.ifft2(y2, centered=True, normalization="ortho"), S,
+                                                           method="SENSE", dim=1))
+        _, eta = utils.center_crop_to_smallest(target, eta)
+        out = torch.view_as_complex(nu(torch.view_as_real(eta.unsqueeze(1)))).squeeze(1)
+    d["unet/cfg"] = np.array(json.dumps(ucfg))
+    d["unet/y"] = y2
+    d["unet/out"] = torch.view_as_real(out)
+    d.update(sd(nu, "unet/w/unet."))
+
+    # ZF: zf.py:90-100, both methods
+    for meth in ("SENSE", "RSS"):
+        pred = utils.coil_combination(fft.ifft2(y2, centered=True, normalization="ortho"), S, method=meth, dim=1)
+        pred = utils.check_stacked_complex(pred)
+        _, pred = utils.center_crop_to_smallest(target, pred)
+        d[f"zf/out_{meth}"] = torch.view_as_real(pred) if pred.is_complex() else pred
+    # C1: ZF + single soft-DC step on 1-coil 320x320 (checksums only)
+    img1, S1 = synth(1, 1, 320, 320, 820)
+    k1 = fft.fft2(utils.complex_mul(img1, S1), centered=False, normalization="backward")
+    m1 = subsample.RandomMaskFunc([0.08], [4])([1, 320, 320, 2], seed=123)[0].reshape(1, 1, 1, 320, 1).bool()
+    y1 = k1 * m1
+    zf = utils.sense(fft.ifft2(y1, centered=False, normalization="backward"), S1, 1)
+    kk = fft.fft2(utils.complex_mul(zf.unsqueeze(1), S1), centered=False, normalization="backward")
+    dc = torch.where(m1, kk - y1, torch.zeros(1, 1, 1, 1, 1))
+    d["c1/zf_sample"] = zf.reshape(-1)[::997].clone()
+    d["c1/zf_l2"] = zf.double().norm().reshape(1)
+    d["c1/dc_sample"] = dc.reshape(-1)[::997].clone()
+    d["c1/dc_l2"] = dc.double().norm().reshape(1)
+    save("g8_models.npz", d)
+
+
+def g10_ssim():
+    d = {}
+    loss = ssim_mod.SSIMLoss()
+    X = torch.rand(2, 1, 20, 17, generator=torch.Generator().manual_seed(1001))
+    Y = (X + 0.1 * torch.rand(2, 1, 20, 17, generator=torch.Generator().manual_seed(1002))).clamp(0, 1)
+    dr = torch.tensor([1.0, 0.8])
+    d.update(X=X, Y=Y, data_range=dr)
+    d["loss"] = loss(X, Y, dr).reshape(1)
+    d["loss_same"] = loss(X, X, dr).reshape(1)
+    save("g10_ssim.npz", d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g10"]
+    fns = dict(g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+               g7=g7_varnet, g8=g8_models, g10=g10_ssim)
+    for w in which:
+        fns[w]()
