@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: CIRIM inference throughput (slices/sec) on synthetic fastMRI-knee-shaped data.
+
+Workload (BASELINE.json `metric`): CIRIM, 8 cascades x 8 time-steps (config time_steps 5 is rounded up to 8 by the model,
+reference cirim.py:50-51), IndRNN 64 filters, 15 coils, 640x372, fp32, batch 1 slice per GPU (the reference default).
+A "step" is one full reconstruction of one batch through the HIP path (64 RIM steps = 384 kernel launches).
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); slices shard across ranks with no data-path
+collective ("weak" scaling); timing is barrier + synchronize on both sides, max over ranks.
+
+Prints ONE JSON line with the contract fields plus
+  roofline      dominant kernel (fused conv3x3(d2)+IndRNN layer, fp32 MFMA): algorithmic FLOPs / HIP-event time
+  roofline_fft  the FFT+DC step (log_likelihood_gradient) against the HBM roofline, (25+16C)*H*W bytes per slice-step
+  cpu_baseline  the CPU oracle (restatement of the reference's torch-CPU path) on a bounded sample, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBS = 8000.0           # HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="slices per GPU per step")
+    ap.add_argument("--coils", type=int, default=15)
+    ap.add_argument("--height", type=int, default=640)
+    ap.add_argument("--width", type=int, default=372)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cascades", type=int, default=1, help="cascades of the CPU-baseline sample")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP events around every launch of selected ops (recorded on the stream the kernels are launched on)."""
+
+    def __init__(self):
+        self.events = {}
+        self.enabled = False
+
+    def wrap(self, module, name, key_fn):
+        orig = getattr(module, name)
+        timer = self
+
+        def wrapped(*a, **k):
+            key = key_fn(*a, **k) if timer.enabled else None
+            if key is None:
+                return orig(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a, **k)
+            e.record()
+            timer.events.setdefault(key, []).append((s, e))
+            return r
+
+        setattr(module, name, wrapped)
+
+    def mean_ms(self, key):
+        ev = self.events.get(key, [])
+        if not ev:
+            return None, 0
+        return sum(s.elapsed_time(e) for s, e in ev) / len(ev), len(ev)
+
+
+def cpu_baseline(cfg, state_dict, data, gpu_out, n_cascades):
+    """Time the oracle (CPU restatement of the reference path, torch CPU ops) on a bounded sample of the same slice."""
+    import oracle
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    sub_cfg = dict(cfg, num_cascades=n_cascades)
+    sd = {k: v for k, v in state_dict.items()}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref = oracle.models.cirim_forward(sd, sub_cfg, data["y"], data["sensitivity_maps"], data["mask"], None,
+                                          data["target"])
+        dt = time.perf_counter() - t0
+    T_ = oracle.models.cirim_time_steps(cfg["time_steps"])
+    sec_per_slice = dt * cfg["num_cascades"] / n_cascades
+    # parity of the GPU result with the oracle on the sampled cascades (same weights, same inputs)
+    got = gpu_out[n_cascades - 1][-1][0].cpu()
+    want = ref[n_cascades - 1][-1][0]
+    rel = float((torch.view_as_real(got).double() - torch.view_as_real(want).double()).norm()
+                / torch.view_as_real(want).double().norm())
+    o1, _ = oracle.metrics.postprocess(got[None], data["target"])
+    o2, _ = oracle.metrics.postprocess(want[None], data["target"])
+    ssim = oracle.metrics.ssim(o2.numpy(), o1.numpy(), maxval=float(o2.max() - o2.min()))
+    return dict(value=1.0 / sec_per_slice, unit="slices/s", cores=ncores, kind="port",
+                sample=f"{n_cascades} of {cfg['num_cascades']} cascades ({n_cascades * T_} of {cfg['num_cascades'] * T_} RIM "
+                       f"steps) of one slice on the oracle (torch CPU ops, {ncores} threads), {dt:.1f} s, extrapolated "
+                       f"x{cfg['num_cascades'] / n_cascades:g}"), rel, ssim
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mridc_amd import ops, synthetic
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG)
+    torch.manual_seed(0)                                # reference-identical initialisation (tests/test_host_logic.py)
+    model = CIRIM(cfg).eval()
+    state_dict = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    B, C, H, W = args.batch, args.coils, args.height, args.width
+    # each rank reconstructs its own slices (slice index = rank*B + i): embarrassingly parallel, no collective
+    slices = [synthetic.make_slice(C, H, W, slice_idx=rank * B + i) for i in range(B)]
+    host = {k: torch.cat([s[k] for s in slices], 0) for k in ("y", "sensitivity_maps", "target")}
+    host["mask"] = slices[0]["mask"]
+    data = {k: v.to(dev) for k, v in host.items()}
+    from mridc_amd import _lib
+    _lib.check(_lib.lib().mrx_fft_prepare(H, W), "mrx_fft_prepare")
+
+    timer = KernelTimer()
+    F_hidden = cfg["recurrent_filters"][0]
+    timer.wrap(ops, "rim_layer_indrnn", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
+    timer.wrap(ops, "llg", lambda *a, **k: "llg")
+    timer.wrap(ops, "rim_final", lambda *a, **k: "final")
+
+    def step():
+        with torch.no_grad():
+            return next(model(data["y"], data["sensitivity_maps"], data["mask"], None, data["target"]))
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    timer.enabled = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        T_ = model.time_steps
+        npix = H * W
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        # dominant kernel: fused layer 2 = conv3x3 dil2 (64->64) + 1x1 ih (64->64): 2*(64*64*9 + 64*64) flop / pixel
+        flops2 = 2.0 * (F_hidden * F_hidden * 9 + F_hidden * F_hidden) * npix * B
+        ms2, n2 = timer.mean_ms("conv_layer2")
+        roofline = dict(bound="mfma", kernel="k_conv_mfma<2,true> (conv3x3 d2 64->64 + IndRNN 1x1, fp32 MFMA 32x32x2)",
+                        achieved=(flops2 / (ms2 * 1e-3) / 1e12) if ms2 else None, peak=PEAK_FP32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=(flops2 / (ms2 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms2 else None,
+                        traffic=None, launches=n2, avg_ms=ms2, flops_per_launch=flops2)
+        bytes_llg = (25.0 + 16.0 * C) * npix * B     # compulsory bytes of one log_likelihood_gradient
+        msl, nl = timer.mean_ms("llg")
+        roofline_fft = dict(bound="hbm", kernel="mrx_llg (3 launches: rows expand+FFT, cols FFT+DC+IFFT, rows IFFT+reduce)",
+                            achieved=(bytes_llg / (msl * 1e-3) / 1e9) if msl else None, peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=(bytes_llg / (msl * 1e-3) / 1e9 / PEAK_HBM_GBS) if msl else None, traffic=None,
+                            launches=nl, avg_ms=msl, bytes_per_call=bytes_llg)
+        ms1, _ = timer.mean_ms("conv_layer1")
+        msf, _ = timer.mean_ms("final")
+        res = dict(metric="slices/sec (inference), CIRIM 8-cascade 15-coil 640x372", value=value, unit="slices/s",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=f"CIRIM {cfg['num_cascades']} cascades x {T_} time-steps (config time_steps "
+                                        f"{cfg['time_steps']} rounded up as the reference does), IndRNN {F_hidden} filters, "
+                                        f"{C} coils, {H}x{W}, batch {B} slice(s) per GPU, random-init weights (seed 0)",
+                               global_batch=world * B, coils=C, height=H, width=W, parallelism=f"slice-sharded x{world}"),
+                   roofline=roofline, roofline_fft=roofline_fft,
+                   breakdown_ms=dict(llg=msl, conv_layer1=ms1, conv_layer2=ms2, final=msf,
+                                     rim_steps_per_slice=cfg["num_cascades"] * T_))
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb, rel, ssim = cpu_baseline(cfg, state_dict, {k: v[:1] if k != "mask" else v for k, v in host.items()},
+                                             out, args.cpu_cascades)
+                res["cpu_baseline"] = cb
+                res["parity_vs_oracle"] = dict(rel_l2=rel, ssim=ssim, at=f"cascade {args.cpu_cascades}, last time-step")
+            except Exception as ex:  # noqa: BLE001
+                res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port",
+                                           sample=f"failed: {ex}")
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+/*
+ * mridc_amd.h -- C ABI of libmridc_amd.so: the MI355X (gfx950) implementation of the mridc
+ * unrolled-reconstruction hot path.
+ *
+ * The reference (wdika/mridc) has no FFI: its boundary is Python call signatures over torch tensors.
+ * Each entry point below replaces the PyTorch op sequence of the cited reference function and is
+ * what a ctypes / cffi binding on the reference side would call.  Reference
+ * paths are relative to the reference root.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 data unless stated; complex tensors use the
+ *     reference's real view [..., 2] (re, im interleaved);
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library allocates device memory
+ *     only for small read-only twiddle tables, once per FFT length, outside any launch sequence
+ *     (mrx_fft_prepare does it eagerly, e.g. before hipGraph capture);
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered and asynchronous;
+ *   - return 0 on success, a negative MRX_E* code otherwise; mrx_last_error() returns the message
+ *     (thread-local).  Nothing throws across the ABI.
+ */
+#ifndef MRIDC_AMD_H
+#define MRIDC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRX_OK 0
+#define MRX_EINVAL (-1)   /* bad argument (shape, enum, null pointer) */
+#define MRX_EUNSUP (-2)   /* valid request the library does not implement (size limits) */
+#define MRX_EHIP (-3)     /* a HIP runtime call failed */
+
+/* normalization, as the reference's `fft_normalization` strings (fft.py:13-18): */
+#define MRX_NORM_BACKWARD 0
+#define MRX_NORM_ORTHO 1
+#define MRX_NORM_FORWARD 2
+#define MRX_NORM_NONE 3 /* "none" -> torch default = backward (fft.py:80) */
+
+/* mask element kinds */
+#define MRX_MASK_U8 0  /* torch.bool or torch.uint8, one byte per element */
+#define MRX_MASK_F32 1
+
+/* activations */
+#define MRX_ACT_NONE 0
+#define MRX_ACT_RELU 1
+#define MRX_ACT_LEAKY 2 /* slope passed separately */
+
+/* padding modes for mrx_conv2d */
+#define MRX_PAD_ZERO 0
+#define MRX_PAD_REPLICATE 1
+
+int mrx_version(void);
+const char* mrx_last_error(void);
+
+/* Create (and cache) the twiddle tables for lengths h and w.  Optional; every FFT entry point does
+ * it lazily.  Call it before capturing a hipGraph. */
+int mrx_fft_prepare(int h, int w);
+/* Largest supported 1-D FFT length (LDS-resident transform). */
+int mrx_fft_max_len(void);
+
+/* A1/A2  fft2 / ifft2 (common/parts/fft.py:13-88, :91-166) over the last two dims of [batch,H,W,2].
+ * centered: ifftshift before / fftshift after folded into index math (fft.py:74-75,83-84, :279,:320).
+ * in == out is allowed. */
+int mrx_fft2(const float* in, float* out, int64_t batch, int H, int W, int inverse, int norm, int centered,
+             void* stream);
+
+/* A3  roll / fftshift / ifftshift (fft.py:169-322): out[i] = in[(i - shift) mod n] along every listed dim.
+ * Bit-exact copy of `elem_bytes`-sized elements (1,2,4,8,16).  ndim <= 8.  shifts[d] = 0 for untouched dims. */
+int mrx_roll(const void* in, void* out, int elem_bytes, int ndim, const int64_t* shape, const int64_t* shifts,
+             void* stream);
+
+/* A4  complex_mul with broadcasting (common/parts/utils.py:96-118).  Shapes/strides are in COMPLEX
+ * elements over ndim <= 6 leading dims (the trailing [2] is implicit); stride 0 broadcasts. */
+int mrx_complex_mul(const float* x, const float* y, float* out, int ndim, const int64_t* shape,
+                    const int64_t* xstride, const int64_t* ystride, int conj_y, void* stream);
+/* A5  complex_conj / complex_abs / complex_abs_sq (utils.py:121-175) over n complex elements. */
+int mrx_complex_conj(const float* x, float* out, int64_t n, void* stream);
+int mrx_complex_abs(const float* x, float* out, int64_t n, int squared, void* stream);
+
+/* A6  coil combination (utils.py:194-272) over a middle dim: input viewed as [outer, R, inner].
+ *   mrx_rss:          out[o,i] = sqrt(sum_r x[o,r,i]^2), x is the REAL view (inner counts floats)   (utils.py:209)
+ *   mrx_rss_complex:  out[o,i] = sqrt(sum_r |x[o,r,i]|^2), inner counts complex elements            (utils.py:227)
+ *   mrx_sense:        out[o,i] = sum_r x[o,r,i] * conj(s[o,r,i]), complex                           (utils.py:248) */
+int mrx_rss(const float* x, float* out, int64_t outer, int64_t R, int64_t inner, void* stream);
+int mrx_rss_complex(const float* x, float* out, int64_t outer, int64_t R, int64_t inner, void* stream);
+int mrx_sense(const float* x, const float* s, float* out, int64_t outer, int64_t R, int64_t inner, void* stream);
+
+/* A8  apply_mask's arithmetic (utils.py:341): out = data * mask + 0.0, mask fp32 broadcast over
+ * [B,C,H,W] with element strides mstride[4] (0 = broadcast). */
+int mrx_apply_mask(const float* data, const float* mask, float* out, int B, int C, int H, int W,
+                   const int64_t* mstride, void* stream);
+
+/* K1  sens_expand: fft2(complex_mul(x[B,1,H,W], S[B,C,H,W]))  (vn_block.py:51-69, rim_utils.py:44-51,
+ * rim_block.py:260-265).  x is [B,H,W,2]; out is [B,C,H,W,2]. */
+int mrx_sens_expand(const float* x, const float* S, float* out, int B, int C, int H, int W, int norm,
+                    int centered, void* stream);
+/* K3  sens_reduce: sum_c ifft2(k)[c] * conj(S[c])  (vn_block.py:71-87, rim_block.py:199-210, utils.py:230-248
+ * after ifft2).  k,S [B,C,H,W,2]; out [B,H,W,2]; work: caller scratch of B*C*H*W*2 floats (may alias k:
+ * then k is destroyed). */
+int mrx_sens_reduce(const float* k, const float* S, float* out, float* work, int B, int C, int H, int W,
+                    int norm, int centered, void* stream);
+
+/* A9  log_likelihood_gradient (models/rim/rim_utils.py:11-67), three launches:
+ *     rows: eta*S -> FFT_W ; cols: FFT_H -> mask*(k - y) -> IFFT_H ; rows: IFFT_W -> sum_c conj(S) -> /sigma^2.
+ * eta [B,H,W,2]; y,S [B,C,H,W,2]; mask element (b,c,h,w) at mask[b*ms[0]+c*ms[1]+h*ms[2]+w*ms[3]];
+ * out4 [B,4,H,W] = (eta_re, eta_im, grad_re, grad_im); work: B*C*H*W*2 floats. */
+int mrx_llg(const float* eta, const float* y, const float* S, const void* mask, int mask_kind,
+            const int64_t* mstride, float* out4, float* work, int B, int C, int H, int W, float inv_sigma2,
+            int norm, int centered, void* stream);
+
+/* K2  soft data consistency: out = where(mask, pred - ref, 0) * dc_weight[0]   (vn_block.py:109-110,
+ * rim_block.py:256).  dc_weight is a device pointer (it is an nn.Parameter). */
+int mrx_soft_dc(const float* pred, const float* ref, const void* mask, int mask_kind, const int64_t* mstride,
+                const float* dc_weight, float* out, int B, int C, int H, int W, void* stream);
+/* out = base - where(mask, pred - ref, 0) * dc_weight[0] - eta_k.  VarNet: base = pred (vn_block.py:109-117);
+ * RIM DC tail: base = ref = masked_kspace (rim_block.py:256-267). */
+int mrx_dc_combine(const float* base, const float* pred, const float* ref, const void* mask, int mask_kind,
+                   const int64_t* mstride, const float* dc_weight, const float* eta_k, float* out, int B, int C,
+                   int H, int W, void* stream);
+
+/* A10 ConvNonlinear / nn.Conv2d (models/rim/conv_layers.py:72-85,121-123; rnn_cells.py:23-38;
+ * unet_block.py:251,255,185): NCHW fp32, stride 1, "same" output size, square kernel k, dilation dil,
+ * padding dil*(k-1)/2 in `pad_mode`.  bias may be NULL.  fp32-input MFMA (exact fp32 fma chains). */
+int mrx_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H,
+               int W, int k, int dil, int pad_mode, int act, float slope, void* stream);
+
+/* A10+A11 fused RIM layer (conv_layers.py:121-123 + rnn_cells.py:384-391):
+ *     h_new = ReLU( Wih (1x1) * ReLU(conv_reppad(x) + b_conv) + b_ih + hh * h_prev )
+ * x [B,Cin,H,W]; h_prev,h_new [B,F,H,W] (F = conv out = hidden, multiple of 32, <= 64); h_prev may be NULL
+ * (zeros: rim_block.py:188-193).  b_conv / b_ih may be NULL. */
+int mrx_rim_layer_indrnn(const float* x, const float* w_conv, const float* b_conv, const float* w_ih,
+                         const float* b_ih, const float* hh, const float* h_prev, float* h_new, int B, int Cin,
+                         int F, int H, int W, int k, int dil, void* stream);
+/* A11 stand-alone IndRNN cell (rnn_cells.py:295-312,384-391): h_new = ReLU(conv_zero_pad(x; w_ih, b_ih) + hh*h_prev). */
+int mrx_indrnn_cell(const float* x, const float* w_ih, const float* b_ih, const float* hh, const float* h_prev,
+                    float* h_new, int B, int Cin, int F, int H, int W, int k, int dil, void* stream);
+
+/* K8  final conv + eta update (rim_block.py:239-248): eta_out[B,H,W,2] = eta + permute(conv_reppad(h)),
+ * conv F -> 2 channels, kernel k, dilation dil, bias optional. */
+int mrx_rim_final(const float* h, const float* w, const float* bias, const float* eta, float* eta_out, int B,
+                  int F, int H, int W, int k, int dil, void* stream);
+
+/* A12 GRU / MGU gate math (rnn_cells.py:118-127, :255-261) on precomputed ih / hh conv outputs
+ * ([B,3F,H,W] / [B,2F,H,W]); out may alias h. */
+int mrx_gru_gates(const float* ih, const float* hh, const float* h, float* out, int B, int F, int64_t HW,
+                  void* stream);
+int mrx_mgu_gates(const float* ih, const float* hh, const float* h, float* out, int B, int F, int64_t HW,
+                  void* stream);
+
+/* A17 NormUnet support (models/unet_base/unet_block.py).  Planes are [B*C] images of H*W floats.
+ *   mrx_instance_norm_act   InstanceNorm2d (biased var, eps, no affine) + activation, in place allowed   (:252-253,:294-295)
+ *   mrx_group_norm_stats    per-group mean and UNBIASED std over n contiguous floats                       (:78-79)
+ *   mrx_group_norm_apply    inverse=0: (x-mean)/std ; inverse=1: x*std+mean                               (:81,:91)
+ *   mrx_pad2d               out[y][x] = in[y-top][x-left]; mode 0 zeros (negative pads crop = unpad), 1 reflect (:93-111,:215-222)
+ *   mrx_avg_pool2x2         avg_pool2d(kernel 2, stride 2)                                                 (:206)
+ *   mrx_conv_transpose2x2   ConvTranspose2d(k=2, s=2, bias=False), weight [Cin,Cout,2,2]                   (:293)
+ *   mrx_copy_channels       dst[:, c0:c0+C] = src for the skip concat                                      (:224) */
+int mrx_instance_norm_act(const float* x, float* out, int64_t planes, int64_t HW, float eps, int act, float slope,
+                          void* stream);
+int mrx_group_norm_stats(const float* x, float* mean, float* std_, int64_t groups, int64_t n, void* stream);
+int mrx_group_norm_apply(const float* x, const float* mean, const float* std_, float* out, int64_t groups, int64_t n,
+                         int inverse, void* stream);
+int mrx_pad2d(const float* in, float* out, int64_t planes, int H, int W, int top, int bottom, int left, int right,
+              int mode, void* stream);
+int mrx_avg_pool2x2(const float* in, float* out, int64_t planes, int H, int W, void* stream);
+int mrx_conv_transpose2x2(const float* x, const float* w, float* out, int B, int Cin, int Cout, int H, int W,
+                          void* stream);
+int mrx_copy_channels(const float* src, float* dst, int B, int C, int64_t HW, int Ctot, int c0, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRIDC_AMD_H */

@@ -1,0 +1,61 @@
+"""Build libmridc_amd.so (HIP, gfx950) in-tree with hipcc.  Called by __graft_entry__.build() and `python -m mridc_amd._build`."""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libmridc_amd.so")
+
+# (source, extra flags).  elementwise.hip is built without fp contraction so that the pointwise complex
+# operators round exactly like the reference's separate torch ops (mul, mul, sub).
+SOURCES = [
+    ("api.cpp", []),
+    ("fft.hip", []),
+    ("elementwise.hip", ["-ffp-contract=off"]),
+    ("conv.hip", []),
+    ("unet.hip", []),
+]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _deps(src):
+    return [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+        os.path.join(os.path.dirname(PKG), "include", "mridc_amd.h")]
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs, rebuilt = [], False
+    for name, extra in SOURCES:
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(LIBDIR, os.path.splitext(name)[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
+            cmd = [hipcc] + COMMON + extra + ["-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

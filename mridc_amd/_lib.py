@@ -1,0 +1,142 @@
+"""ctypes binding of libmridc_amd.so (C ABI in include/mridc_amd.h).
+
+There is NO CPU fallback: if the shared library is missing or a tensor is not on the GPU the call
+raises.  Tensors are passed as raw device pointers plus the current torch HIP stream; torch is used
+only to own memory and streams.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmridc_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "mridc_amd.h")
+
+NORM = {"backward": 0, "ortho": 1, "forward": 2, "none": 3}
+MASK_U8, MASK_F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+PAD_ZERO, PAD_REPLICATE = 0, 1
+
+_p, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+_SIGNATURES = {
+    "mrx_version": ([], _i),
+    "mrx_last_error": ([], ctypes.c_char_p),
+    "mrx_fft_prepare": ([_i, _i], _i),
+    "mrx_fft_max_len": ([], _i),
+    "mrx_fft2": ([_p, _p, _i64, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_roll": ([_p, _p, _i, _i, _p, _p, _p], _i),
+    "mrx_complex_mul": ([_p, _p, _p, _i, _p, _p, _p, _i, _p], _i),
+    "mrx_complex_conj": ([_p, _p, _i64, _p], _i),
+    "mrx_complex_abs": ([_p, _p, _i64, _i, _p], _i),
+    "mrx_rss": ([_p, _p, _i64, _i64, _i64, _p], _i),
+    "mrx_rss_complex": ([_p, _p, _i64, _i64, _i64, _p], _i),
+    "mrx_sense": ([_p, _p, _p, _i64, _i64, _i64, _p], _i),
+    "mrx_apply_mask": ([_p, _p, _p, _i, _i, _i, _i, _p, _p], _i),
+    "mrx_sens_expand": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_sens_reduce": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_llg": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p], _i),
+    "mrx_soft_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_conv2d": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
+    "mrx_rim_layer_indrnn": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_indrnn_cell": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_rim_final": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_gru_gates": ([_p, _p, _p, _p, _i, _i, _i64, _p], _i),
+    "mrx_mgu_gates": ([_p, _p, _p, _p, _i, _i, _i64, _p], _i),
+    "mrx_instance_norm_act": ([_p, _p, _i64, _i64, _f, _i, _f, _p], _i),
+    "mrx_group_norm_stats": ([_p, _p, _p, _i64, _i64, _p], _i),
+    "mrx_group_norm_apply": ([_p, _p, _p, _p, _i64, _i64, _i, _p], _i),
+    "mrx_pad2d": ([_p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_avg_pool2x2": ([_p, _p, _i64, _i, _i, _p], _i),
+    "mrx_conv_transpose2x2": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_copy_channels": ([_p, _p, _i, _i, _i64, _i, _i, _p], _i),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Function names declared in include/mridc_amd.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrx_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load libmridc_amd.so (once).  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m mridc_amd._build` (hipcc, gfx950). "
+                "mridc_amd has no CPU or PyTorch fallback path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+            fn.argtypes = args
+            fn.restype = res
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mrx_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libmridc_amd {what} failed ({rc}): {msg}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "mridc_amd operators run on the MI355X HIP path only: got a tensor on "
+                f"'{t.device}'. There is no CPU fallback; move inputs to the GPU (tensor.cuda()).")
+
+
+def f32c(t):
+    """Contiguous fp32 device tensor (the reference calls .contiguous()/.float() the same way at its boundaries)."""
+    require_gpu(t)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def i64_array(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def mask_args(mask, B, C, H, W):
+    """Mask tensor broadcastable to [B,C,H,W,1] -> (contiguous tensor, kind, element strides over (b,c,h,w))."""
+    require_gpu(mask)
+    m = mask
+    if m.dim() == 5 and m.shape[-1] == 1:
+        m = m[..., 0]
+    while m.dim() < 4:
+        m = m.unsqueeze(0)
+    if m.dim() != 4:
+        raise ValueError(f"mask of shape {tuple(mask.shape)} is not broadcastable to [B,C,H,W,1]")
+    for d, n in zip(m.shape, (B, C, H, W)):
+        if d not in (1, n):
+            raise ValueError(f"mask of shape {tuple(mask.shape)} is not broadcastable to {(B, C, H, W, 1)}")
+    if m.dtype in (torch.bool, torch.uint8):
+        kind = MASK_U8
+        m = m.contiguous()
+        if m.dtype == torch.bool:
+            m = m.view(torch.uint8)
+    else:
+        kind = MASK_F32
+        m = m.float().contiguous()
+    st = [m.stride(i) if m.shape[i] != 1 else 0 for i in range(4)]
+    return m, kind, i64_array(st)

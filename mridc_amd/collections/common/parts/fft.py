@@ -1,0 +1,119 @@
+"""FFT operators -- drop-in for `mridc.collections.common.parts.fft` (reference fft.py:10), HIP backed.
+
+fft2 / ifft2 run as an LDS-resident mixed-radix row pass + column pass (csrc/fft.hip); centred shifts are index
+math inside the kernels, never materialised rolls.  roll / fftshift / ifftshift are one bit-exact gather kernel.
+"""
+from typing import List, Sequence, Union
+
+import numpy as np
+import torch
+
+from mridc_amd import _lib
+
+__all__ = ["fft2", "ifft2", "fftshift", "ifftshift", "roll", "roll_one_dim", "fft2c", "ifft2c"]
+
+
+def _norm_code(normalization: str) -> int:
+    key = str(normalization).lower()
+    if key not in _lib.NORM:
+        raise ValueError(f"Unknown fft normalization '{normalization}' (expected backward, ortho, forward or none)")
+    return _lib.NORM[key]
+
+
+def _xform(data: torch.Tensor, centered: bool, normalization: str, spatial_dims, inverse: bool) -> torch.Tensor:
+    _lib.require_gpu(data)
+    if data.shape[-1] == 2 and not data.is_complex():       # fft.py:66-67
+        real = data
+    elif data.is_complex():                                  # appendix D.18: already-complex input
+        real = torch.view_as_real(data)
+    else:
+        raise ValueError("fft2/ifft2 expect a real view [...,2] or a complex tensor")
+    real = _lib.f32c(real)
+    nd = real.dim() - 1                                      # dims of the complex view
+    dims = [-2, -1] if spatial_dims is None else list(spatial_dims)   # fft.py:69-72 (applied on the complex view)
+    if len(dims) != 2:
+        raise ValueError("spatial_dims must name exactly two dimensions")
+    dims = [d % nd for d in dims]
+    if dims[0] == dims[1]:
+        raise ValueError("spatial_dims must be distinct")
+    norm = _norm_code(normalization)
+    perm = None
+    if sorted(dims) != [nd - 2, nd - 1]:
+        rest = [d for d in range(nd) if d not in dims]
+        perm = rest + sorted(dims) + [nd]
+        real = real.permute(perm).contiguous()
+    H, W = int(real.shape[-3]), int(real.shape[-2])
+    batch = int(real.numel() // (2 * H * W)) if H * W > 0 else 0
+    out = torch.empty_like(real)
+    L = _lib.lib()
+    _lib.check(L.mrx_fft2(_lib.ptr(real), _lib.ptr(out), batch, H, W, int(inverse), norm, int(bool(centered)),
+                          _lib.stream_ptr()), "mrx_fft2")
+    if perm is not None:
+        inv = [0] * len(perm)
+        for i, p in enumerate(perm):
+            inv[p] = i
+        out = out.permute(inv).contiguous()
+    return out
+
+
+def fft2(data: torch.Tensor, centered: bool = False, normalization: str = "backward",
+         spatial_dims: Sequence[int] = None) -> torch.Tensor:
+    """Reference fft.py:13-88.  Returns the real view [...,2]."""
+    return _xform(data, centered, normalization, spatial_dims, inverse=False)
+
+
+def ifft2(data: torch.Tensor, centered: bool = False, normalization: str = "backward",
+          spatial_dims: Sequence[int] = None) -> torch.Tensor:
+    """Reference fft.py:91-166."""
+    return _xform(data, centered, normalization, spatial_dims, inverse=True)
+
+
+def fft2c(data, normalization="ortho", spatial_dims=None):
+    """fastMRI/ATOMMIC-style alias named by BASELINE.json: centred fft2."""
+    return fft2(data, centered=True, normalization=normalization, spatial_dims=spatial_dims)
+
+
+def ifft2c(data, normalization="ortho", spatial_dims=None):
+    return ifft2(data, centered=True, normalization=normalization, spatial_dims=spatial_dims)
+
+
+def _roll_many(data: torch.Tensor, shifts: List[int], dims: List[int]) -> torch.Tensor:
+    _lib.require_gpu(data)
+    x = data.contiguous()
+    nd = x.dim()
+    total = [0] * nd
+    for s, d in zip(shifts, dims):                           # successive rolls compose additively per dim
+        total[d % nd] += int(s)
+    if x.numel() == 0 or all(t % n == 0 for t, n in zip(total, x.shape)):
+        return data                                          # fft.py:196-197 returns the input itself
+    if nd > 8:
+        raise ValueError("roll supports at most 8 dimensions")
+    out = torch.empty_like(x)
+    L = _lib.lib()
+    _lib.check(L.mrx_roll(_lib.ptr(x), _lib.ptr(out), x.element_size(), nd, _lib.i64_array(x.shape),
+                          _lib.i64_array(total), _lib.stream_ptr()), "mrx_roll")
+    return out
+
+
+def roll_one_dim(data: torch.Tensor, shift: int, dim: int) -> torch.Tensor:
+    """Reference fft.py:169-202."""
+    return _roll_many(data, [shift], [dim])
+
+
+def roll(data: torch.Tensor, shift: List[int], dim: Union[List[int], Sequence[int]]) -> torch.Tensor:
+    """Reference fft.py:205-240."""
+    if len(shift) != len(dim):
+        raise ValueError("len(shift) must match len(dim)")
+    return _roll_many(data, list(shift), list(dim))
+
+
+def fftshift(data: torch.Tensor, dim: Union[List[int], Sequence[int]] = None) -> torch.Tensor:
+    """Reference fft.py:243-281: shift n//2."""
+    dim = list(range(data.dim())) if dim is None else list(dim)
+    return roll(data, [int(np.floor_divide(data.shape[d], 2)) for d in dim], dim)
+
+
+def ifftshift(data: torch.Tensor, dim: Union[List[int], Sequence[int]] = None) -> torch.Tensor:
+    """Reference fft.py:284-322: shift (n+1)//2."""
+    dim = list(range(data.dim())) if dim is None else list(dim)
+    return roll(data, [int(np.floor_divide(data.shape[d] + 1, 2)) for d in dim], dim)

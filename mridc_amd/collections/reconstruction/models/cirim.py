@@ -1,0 +1,79 @@
+"""Drop-in for `mridc.collections.reconstruction.models.cirim.CIRIM` (reference cirim.py:25-249), inference path.
+
+The reference class subclasses a pytorch-lightning base (training/validation harness, out of scope: SURVEY 8a row H);
+this mirror is a plain nn.Module with the same constructor config keys, parameter names (`cirim.{i}.*`, `dc_weight`)
+and `forward` contract (a generator yielding list[cascade][time_step] of complex [B,h,w]).
+"""
+import math
+from typing import Generator, Union
+
+import torch
+
+import mridc_amd.collections.common.parts.fft as fft
+import mridc_amd.collections.common.parts.utils as utils
+from mridc_amd.collections.reconstruction.models import _cfg
+from mridc_amd.collections.reconstruction.models.rim import rim_block
+
+__all__ = ["CIRIM"]
+
+
+class CIRIM(torch.nn.Module):
+    def __init__(self, cfg, trainer=None):
+        super().__init__()
+        cfg_dict = _cfg.to_dict(cfg)
+        self.recurrent_filters = cfg_dict.get("recurrent_filters")
+        # make time-steps size divisible by 8 (cirim.py:50-51)
+        self.time_steps = 8 * math.ceil(cfg_dict.get("time_steps") / 8)
+        self.no_dc = cfg_dict.get("no_dc")
+        self.fft_centered = cfg_dict.get("fft_centered")
+        self.fft_normalization = cfg_dict.get("fft_normalization")
+        self.spatial_dims = cfg_dict.get("spatial_dims")
+        self.coil_dim = cfg_dict.get("coil_dim")
+        self.num_cascades = cfg_dict.get("num_cascades")
+        self.cirim = torch.nn.ModuleList([
+            rim_block.RIMBlock(
+                recurrent_layer=cfg_dict.get("recurrent_layer"), conv_filters=cfg_dict.get("conv_filters"),
+                conv_kernels=cfg_dict.get("conv_kernels"), conv_dilations=cfg_dict.get("conv_dilations"),
+                conv_bias=cfg_dict.get("conv_bias"), recurrent_filters=self.recurrent_filters,
+                recurrent_kernels=cfg_dict.get("recurrent_kernels"), recurrent_dilations=cfg_dict.get("recurrent_dilations"),
+                recurrent_bias=cfg_dict.get("recurrent_bias"), depth=cfg_dict.get("depth"), time_steps=self.time_steps,
+                conv_dim=cfg_dict.get("conv_dim"), no_dc=self.no_dc, fft_centered=self.fft_centered,
+                fft_normalization=self.fft_normalization, spatial_dims=self.spatial_dims, coil_dim=self.coil_dim,
+                dimensionality=cfg_dict.get("dimensionality"))
+            for _ in range(self.num_cascades)])                      # cirim.py:60-84
+        self.keep_eta = cfg_dict.get("keep_eta")
+        self.coil_combination_method = cfg_dict.get("coil_combination_method")
+        # cirim.py:91-93 applies rnn_weights_init, a no-op for conv layers (common/parts/rnn_utils.py:21-32)
+        self.train_loss_fn = _cfg.make_loss(cfg_dict.get("train_loss_fn", "l1"))
+        self.val_loss_fn = _cfg.make_loss(cfg_dict.get("val_loss_fn", "l1"))
+        self.dc_weight = torch.nn.Parameter(torch.ones(1))          # cirim.py:112
+        self.accumulate_estimates = True
+
+    def forward(self, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask: torch.Tensor, init_pred: torch.Tensor,
+                target: torch.Tensor) -> Union[Generator, torch.Tensor]:
+        """cirim.py:115-165."""
+        prediction = y.clone()
+        init_pred = None if init_pred is None or init_pred.dim() < 4 else init_pred
+        hx = None
+        sigma = 1.0
+        cascades_etas = []
+        for i, cascade in enumerate(self.cirim):
+            prediction, _ = cascade(prediction, y, sensitivity_maps, mask, init_pred, hx, sigma,
+                                    keep_eta=False if i == 0 else self.keep_eta)
+            time_steps_etas = [self.process_intermediate_pred(pred, sensitivity_maps, target) for pred in prediction]
+            cascades_etas.append(time_steps_etas)
+        yield cascades_etas
+
+    # fastMRI/ATOMMIC-style alias named by BASELINE.json
+    def forward_step(self, y, sensitivity_maps, mask, init_pred=None, target=None):
+        return next(self.forward(y, sensitivity_maps, mask, init_pred, target))
+
+    def process_intermediate_pred(self, pred, sensitivity_maps, target, do_coil_combination=False):
+        """cirim.py:167-197."""
+        if not self.no_dc or do_coil_combination:
+            pred = fft.ifft2(pred, centered=self.fft_centered, normalization=self.fft_normalization,
+                             spatial_dims=self.spatial_dims)
+            pred = utils.coil_combination(pred, sensitivity_maps, method=self.coil_combination_method, dim=self.coil_dim)
+        pred = torch.view_as_complex(pred)
+        _, pred = utils.center_crop_to_smallest(target, pred)
+        return pred

@@ -1,0 +1,118 @@
+"""Drop-in for `mridc.collections.reconstruction.models.rim.rim_block.RIMBlock` (reference rim_block.py:15-269)."""
+from typing import Any, Optional, Tuple, Union
+
+import torch
+
+from mridc_amd import ops
+from mridc_amd.collections.reconstruction.models.rim import conv_layers, rim_utils, rnn_cells
+
+
+class RIMBlock(torch.nn.Module):
+    """Recurrent Inference Machine cascade.  2-D mode only (dimensionality=2, conv_dim=2, consecutive_slices=1).
+
+    Per time-step the HIP path is six launches: three for log_likelihood_gradient (mrx_llg), one fused
+    conv+IndRNN launch per recurrent layer (mrx_rim_layer_indrnn) and one for the final conv + eta update
+    (mrx_rim_final).  GRU / MGU layers and IndRNN layers whose shape the fused kernel does not cover run through
+    the unfused kernels (conv2d + cell).
+    """
+
+    def __init__(self, recurrent_layer=None, conv_filters=None, conv_kernels=None, conv_dilations=None, conv_bias=None,
+                 recurrent_filters=None, recurrent_kernels=None, recurrent_dilations=None, recurrent_bias=None,
+                 depth: int = 2, time_steps: int = 8, conv_dim: int = 2, no_dc: bool = False, fft_centered: bool = True,
+                 fft_normalization: str = "ortho", spatial_dims: Optional[Tuple[int, int]] = None, coil_dim: int = 1,
+                 dimensionality: int = 2, consecutive_slices: int = 1):
+        super().__init__()
+        if dimensionality != 2 or conv_dim != 2 or consecutive_slices != 1:
+            raise NotImplementedError("mridc_amd.RIMBlock implements dimensionality=2 / conv_dim=2 / consecutive_slices=1; "
+                                      "the reference's 3-D mode (rim_block.py:168-180) is out of the HIP path's scope")
+        self.input_size = depth * 2                                   # rim_block.py:67
+        self.time_steps = time_steps
+        self.layers = torch.nn.ModuleList()
+        conv_layer = None
+        for ((conv_features, conv_k_size, conv_dilation, l_conv_bias, nonlinear),
+             (rnn_features, rnn_k_size, rnn_dilation, rnn_bias, rnn_type)) in zip(
+                zip(conv_filters, conv_kernels, conv_dilations, conv_bias, ["relu", "relu", None]),
+                zip(recurrent_filters, recurrent_kernels, recurrent_dilations, recurrent_bias,
+                    [recurrent_layer, recurrent_layer, None])):           # rim_block.py:71-83
+            conv_layer = None
+            if conv_features != 0:
+                conv_layer = conv_layers.ConvNonlinear(self.input_size, conv_features, conv_dim=conv_dim,
+                                                       kernel_size=conv_k_size, dilation=conv_dilation, bias=l_conv_bias,
+                                                       nonlinear=nonlinear)
+                self.input_size = conv_features
+            if rnn_features != 0 and rnn_type is not None:
+                if rnn_type.upper() == "GRU":
+                    rnn_cls = rnn_cells.ConvGRUCell
+                elif rnn_type.upper() == "MGU":
+                    rnn_cls = rnn_cells.ConvMGUCell
+                elif rnn_type.upper() == "INDRNN":
+                    rnn_cls = rnn_cells.IndRNNCell
+                else:
+                    raise ValueError("Please specify a proper recurrent layer type.")
+                rnn_layer = rnn_cls(self.input_size, rnn_features, conv_dim=conv_dim, kernel_size=rnn_k_size,
+                                    dilation=rnn_dilation, bias=rnn_bias)
+                self.input_size = rnn_features
+                self.layers.append(conv_layers.ConvRNNStack(conv_layer, rnn_layer))
+        self.final_layer = torch.nn.Sequential(conv_layer)            # rim_block.py:121
+        self.recurrent_filters = recurrent_filters
+        self.fft_centered = fft_centered
+        self.fft_normalization = fft_normalization
+        self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
+        self.coil_dim = coil_dim
+        self.no_dc = no_dc
+        if not self.no_dc:
+            self.dc_weight = torch.nn.Parameter(torch.ones(1))          # rim_block.py:132-134
+        self.dimensionality = dimensionality
+        self.consecutive_slices = consecutive_slices
+
+    @staticmethod
+    def _fusable(stack):
+        c, r = stack.convs, stack.rnn
+        return (isinstance(r, rnn_cells.IndRNNCell) and r.kernel_size == 1 and c is not None and c.act == ops.ACT_RELU
+                and c.features == r.hidden_size and r.hidden_size in (32, 64) and r.input_size == c.features)
+
+    def _layer(self, stack, x, h):
+        if self._fusable(stack):
+            c, r = stack.convs, stack.rnn
+            return ops.rim_layer_indrnn(x, c.conv_layer.weight, c.conv_layer.bias, c.kernel_size, c.dilation,
+                                        r.ih.weight, r.ih.bias, r.hh, h)
+        return stack(x, h)
+
+    def forward(self, pred: torch.Tensor, masked_kspace: torch.Tensor, sense: torch.Tensor, mask: torch.Tensor,
+                eta: torch.Tensor = None, hx: torch.Tensor = None, sigma: float = 1.0, keep_eta: bool = False,
+                ) -> Tuple[Any, Union[list, torch.Tensor, None]]:
+        """rim_block.py:139-269.  Returns (list of time_steps estimates, hx)."""
+        if isinstance(pred, list):                                   # rim_block.py:185-186
+            pred = pred[-1].detach()
+        if hx is None:                                               # rim_block.py:188-193
+            hx = [masked_kspace.new_zeros((masked_kspace.size(0), f, *masked_kspace.size()[2:-1]))
+                  for f in self.recurrent_filters if f != 0]
+        else:
+            hx = list(hx)
+        if eta is None or eta.ndim < 3:                              # rim_block.py:195-211
+            eta = pred if keep_eta else ops.sens_reduce(pred, sense, self.fft_centered, self.fft_normalization,
+                                                        self.spatial_dims)
+        final = self.final_layer[0]
+        work = torch.empty_like(masked_kspace, dtype=torch.float32)
+        etas = []
+        for _ in range(self.time_steps):                             # rim_block.py:217-249
+            grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
+                               self.spatial_dims, work=work)
+            for h, convrnn in enumerate(self.layers):
+                hx[h] = self._layer(convrnn, grad_eta, hx[h])
+                grad_eta = hx[h]
+            eta = ops.rim_final(grad_eta, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size,
+                                final.dilation, eta)                 # final conv, permute(0,2,3,1), eta + grad
+            etas.append(eta)
+        if self.no_dc:                                               # rim_block.py:253-254
+            return etas, hx
+        if mask.dtype != torch.bool:
+            # torch.where(mask, ...) at rim_block.py:256 requires a bool condition in the reference too
+            raise RuntimeError("where expected condition to be a boolean tensor, but got a tensor with dtype "
+                               f"{mask.dtype}")
+        current_kspace = [
+            ops.dc_combine(masked_kspace, pred, masked_kspace, mask, self.dc_weight,
+                           ops.sens_expand(e, sense, self.fft_centered, self.fft_normalization, self.spatial_dims))
+            for e in etas
+        ]                                                            # rim_block.py:256-267
+        return current_kspace, hx

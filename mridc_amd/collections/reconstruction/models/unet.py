@@ -1,0 +1,36 @@
+"""Drop-in for `mridc.collections.reconstruction.models.unet.UNet` (reference unet.py:22-121), inference path."""
+import torch
+
+import mridc_amd.collections.common.parts.fft as fft
+import mridc_amd.collections.common.parts.utils as utils
+from mridc_amd.collections.reconstruction.models import _cfg
+from mridc_amd.collections.reconstruction.models.unet_base import unet_block
+
+__all__ = ["UNet"]
+
+
+class UNet(torch.nn.Module):
+    def __init__(self, cfg, trainer=None):
+        super().__init__()
+        cfg_dict = _cfg.to_dict(cfg)
+        self.fft_centered = cfg_dict.get("fft_centered")
+        self.fft_normalization = cfg_dict.get("fft_normalization")
+        self.spatial_dims = cfg_dict.get("spatial_dims")
+        self.coil_dim = cfg_dict.get("coil_dim")
+        self.unet = unet_block.NormUnet(chans=cfg_dict.get("channels"), num_pools=cfg_dict.get("pooling_layers"),
+                                        padding_size=cfg_dict.get("padding_size"), normalize=cfg_dict.get("normalize"))
+        self.coil_combination_method = cfg_dict.get("coil_combination_method")
+        self.train_loss_fn = _cfg.make_loss(cfg_dict.get("train_loss_fn", "l1"))
+        self.val_loss_fn = _cfg.make_loss(cfg_dict.get("val_loss_fn", "l1"))
+        self.accumulate_estimates = False
+
+    def forward(self, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask: torch.Tensor, init_pred: torch.Tensor,
+                target: torch.Tensor) -> torch.Tensor:
+        """unet.py:77-121."""
+        eta = torch.view_as_complex(utils.coil_combination(
+            fft.ifft2(y, centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims),
+            sensitivity_maps, method=self.coil_combination_method, dim=self.coil_dim))
+        _, eta = utils.center_crop_to_smallest(target, eta)
+        return torch.view_as_complex(self.unet(torch.view_as_real(eta.unsqueeze(self.coil_dim)))).squeeze(self.coil_dim)
+
+    forward_step = forward

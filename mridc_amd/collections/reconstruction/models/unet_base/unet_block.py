@@ -1,0 +1,172 @@
+"""Drop-in for `mridc.collections.reconstruction.models.unet_base.unet_block` (reference unet_block.py:11-308).
+
+Parameter containers are the same torch modules as the reference (identical state_dict keys and default init); the
+forward pass runs on the HIP kernels: MFMA conv (csrc/conv.hip), InstanceNorm+LeakyReLU, pooling, pad, transpose conv
+(csrc/unet.hip).
+"""
+import math
+from typing import List, Tuple
+
+import torch
+
+from mridc_amd import ops
+
+
+class ConvBlock(torch.nn.Module):
+    """unet_block.py:230-271: [Conv3x3 no bias -> InstanceNorm -> LeakyReLU(0.2) -> Dropout2d] x 2."""
+
+    def __init__(self, in_chans: int, out_chans: int, drop_prob: float):
+        super().__init__()
+        self.in_chans = in_chans
+        self.out_chans = out_chans
+        self.drop_prob = drop_prob
+        self.layers = torch.nn.Sequential(
+            torch.nn.Conv2d(in_chans, out_chans, kernel_size=3, padding=1, bias=False),
+            torch.nn.InstanceNorm2d(out_chans),
+            torch.nn.LeakyReLU(negative_slope=0.2, inplace=True),
+            torch.nn.Dropout2d(drop_prob),
+            torch.nn.Conv2d(out_chans, out_chans, kernel_size=3, padding=1, bias=False),
+            torch.nn.InstanceNorm2d(out_chans),
+            torch.nn.LeakyReLU(negative_slope=0.2, inplace=True),
+            torch.nn.Dropout2d(drop_prob),
+        )
+
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        if self.training and self.drop_prob > 0:
+            raise NotImplementedError("Dropout2d in training mode is not part of the HIP inference path")
+        x = ops.conv2d(image, self.layers[0].weight, None, 1, ops.PAD_ZERO)
+        x = ops.instance_norm_act(x, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
+        x = ops.conv2d(x, self.layers[4].weight, None, 1, ops.PAD_ZERO)
+        return ops.instance_norm_act(x, self.layers[5].eps, ops.ACT_LEAKY, 0.2)
+
+
+class TransposeConvBlock(torch.nn.Module):
+    """unet_block.py:274-308."""
+
+    def __init__(self, in_chans: int, out_chans: int):
+        super().__init__()
+        self.in_chans = in_chans
+        self.out_chans = out_chans
+        self.layers = torch.nn.Sequential(
+            torch.nn.ConvTranspose2d(in_chans, out_chans, kernel_size=2, stride=2, bias=False),
+            torch.nn.InstanceNorm2d(out_chans),
+            torch.nn.LeakyReLU(negative_slope=0.2, inplace=True),
+        )
+
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        x = ops.conv_transpose2x2(image, self.layers[0].weight)
+        return ops.instance_norm_act(x, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
+
+
+class Unet(torch.nn.Module):
+    """unet_block.py:139-227."""
+
+    def __init__(self, in_chans: int, out_chans: int, chans: int = 32, num_pool_layers: int = 4, drop_prob: float = 0.0):
+        super().__init__()
+        self.in_chans = in_chans
+        self.out_chans = out_chans
+        self.chans = chans
+        self.num_pool_layers = num_pool_layers
+        self.drop_prob = drop_prob
+        self.down_sample_layers = torch.nn.ModuleList([ConvBlock(in_chans, chans, drop_prob)])
+        ch = chans
+        for _ in range(num_pool_layers - 1):
+            self.down_sample_layers.append(ConvBlock(ch, ch * 2, drop_prob))
+            ch *= 2
+        self.conv = ConvBlock(ch, ch * 2, drop_prob)
+        self.up_conv = torch.nn.ModuleList()
+        self.up_transpose_conv = torch.nn.ModuleList()
+        for _ in range(num_pool_layers - 1):
+            self.up_transpose_conv.append(TransposeConvBlock(ch * 2, ch))
+            self.up_conv.append(ConvBlock(ch * 2, ch, drop_prob))
+            ch //= 2
+        self.up_transpose_conv.append(TransposeConvBlock(ch * 2, ch))
+        self.up_conv.append(torch.nn.Sequential(ConvBlock(ch * 2, ch, drop_prob),
+                                                torch.nn.Conv2d(ch, self.out_chans, kernel_size=1, stride=1)))
+
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        stack = []
+        output = image
+        for layer in self.down_sample_layers:                        # unet_block.py:203-206
+            output = layer(output)
+            stack.append(output)
+            output = ops.avg_pool2x2(output)
+        output = self.conv(output)
+        for transpose_conv, conv in zip(self.up_transpose_conv, self.up_conv):
+            downsample_layer = stack.pop()
+            output = transpose_conv(output)
+            pad_r = 1 if output.shape[-1] != downsample_layer.shape[-1] else 0     # unet_block.py:215-222
+            pad_b = 1 if output.shape[-2] != downsample_layer.shape[-2] else 0
+            if pad_r or pad_b:
+                output = ops.pad2d(output, 0, pad_b, 0, pad_r, mode=1)
+            output = ops.concat_channels(output, downsample_layer)
+            if isinstance(conv, torch.nn.Sequential):
+                output = conv[0](output)
+                output = ops.conv2d(output, conv[1].weight, conv[1].bias, 1, ops.PAD_ZERO)
+            else:
+                output = conv(output)
+        return output
+
+
+class NormUnet(torch.nn.Module):
+    """unet_block.py:11-136."""
+
+    def __init__(self, chans: int, num_pools: int, in_chans: int = 2, out_chans: int = 2, drop_prob: float = 0.0,
+                 padding_size: int = 15, normalize: bool = True, norm_groups: int = 2):
+        super().__init__()
+        self.unet = Unet(in_chans=in_chans, out_chans=out_chans, chans=chans, num_pool_layers=num_pools,
+                         drop_prob=drop_prob)
+        self.padding_size = padding_size
+        self.normalize = normalize
+        self.norm_groups = norm_groups
+
+    @staticmethod
+    def complex_to_chan_dim(x: torch.Tensor) -> torch.Tensor:
+        b, c, h, w, two = x.shape
+        if two != 2:
+            raise AssertionError
+        return x.permute(0, 4, 1, 2, 3).reshape(b, 2 * c, h, w)
+
+    @staticmethod
+    def chan_complex_to_last_dim(x: torch.Tensor) -> torch.Tensor:
+        b, c2, h, w = x.shape
+        if c2 % 2 != 0:
+            raise AssertionError
+        c = c2 // 2
+        return x.view(b, 2, c, h, w).permute(0, 2, 3, 4, 1).contiguous()
+
+    def norm(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        return ops.group_norm(x, self.norm_groups)
+
+    def unnorm(self, x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+        return ops.group_unnorm(x, mean, std, self.norm_groups)
+
+    def pad(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[List[int], List[int], int, int]]:
+        _, _, h, w = x.shape
+        w_mult = ((w - 1) | self.padding_size) + 1
+        h_mult = ((h - 1) | self.padding_size) + 1
+        w_pad = [math.floor((w_mult - w) / 2), math.ceil((w_mult - w) / 2)]
+        h_pad = [math.floor((h_mult - h) / 2), math.ceil((h_mult - h) / 2)]
+        x = ops.pad2d(x, h_pad[0], h_pad[1], w_pad[0], w_pad[1], mode=0)
+        return x, (h_pad, w_pad, h_mult, w_mult)
+
+    @staticmethod
+    def unpad(x: torch.Tensor, h_pad: List[int], w_pad: List[int], h_mult: int, w_mult: int) -> torch.Tensor:
+        return ops.pad2d(x, -h_pad[0], -h_pad[1], -w_pad[0], -w_pad[1], mode=0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        iscomplex = False
+        if x.shape[-1] == 2:
+            x = self.complex_to_chan_dim(x)
+            iscomplex = True
+        mean = std = None
+        if self.normalize:
+            x, mean, std = self.norm(x)
+        x, pad_sizes = self.pad(x)
+        x = self.unet(x)
+        x = self.unpad(x, *pad_sizes)
+        if self.normalize:
+            x = self.unnorm(x, mean, std)
+        if iscomplex:
+            x = self.chan_complex_to_last_dim(x)
+        return x

@@ -1,0 +1,39 @@
+"""Drop-in for `mridc.collections.reconstruction.models.varnet.vn_block.VarNetBlock` (reference vn_block.py:12-119)."""
+from typing import Optional, Tuple
+
+import torch
+
+from mridc_amd import ops
+
+
+class VarNetBlock(torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, fft_centered: bool = True, fft_normalization: str = "ortho",
+                 spatial_dims: Optional[Tuple[int, int]] = None, coil_dim: int = 1, no_dc: bool = False):
+        super().__init__()
+        self.model = model
+        self.fft_centered = fft_centered
+        self.fft_normalization = fft_normalization
+        self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
+        self.coil_dim = coil_dim
+        self.no_dc = no_dc
+        self.dc_weight = torch.nn.Parameter(torch.ones(1))
+        if coil_dim != 1:
+            raise NotImplementedError("the HIP path expects the coil dimension at index 1")
+
+    def sens_expand(self, x: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        """vn_block.py:51-69 (mrx_sens_expand)."""
+        return ops.sens_expand(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims)
+
+    def sens_reduce(self, x: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        """vn_block.py:71-87 (mrx_sens_reduce), keepdim on the coil axis."""
+        return ops.sens_reduce(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims).unsqueeze(1)
+
+    def forward(self, pred: torch.Tensor, ref_kspace: torch.Tensor, sens_maps: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """vn_block.py:89-119."""
+        eta = self.sens_reduce(pred, sens_maps)
+        eta = self.model(eta)
+        eta = self.sens_expand(eta, sens_maps)
+        if not self.no_dc:
+            # pred - where(mask.bool(), pred - ref, 0) * dc_weight - eta, one launch
+            eta = ops.dc_combine(pred, pred, ref_kspace, mask, self.dc_weight, eta)
+        return eta

@@ -1,0 +1,50 @@
+"""Drop-in for `mridc.collections.reconstruction.models.vn.VarNet` (reference vn.py:22-142), inference path."""
+import torch
+
+import mridc_amd.collections.common.parts.fft as fft
+import mridc_amd.collections.common.parts.utils as utils
+from mridc_amd.collections.reconstruction.models import _cfg
+from mridc_amd.collections.reconstruction.models.unet_base import unet_block
+from mridc_amd.collections.reconstruction.models.varnet import vn_block
+
+__all__ = ["VarNet"]
+
+
+class VarNet(torch.nn.Module):
+    def __init__(self, cfg, trainer=None):
+        super().__init__()
+        cfg_dict = _cfg.to_dict(cfg)
+        self.no_dc = cfg_dict.get("no_dc")
+        self.fft_centered = cfg_dict.get("fft_centered")
+        self.fft_normalization = cfg_dict.get("fft_normalization")
+        self.spatial_dims = cfg_dict.get("spatial_dims")
+        self.coil_dim = cfg_dict.get("coil_dim")
+        self.num_cascades = cfg_dict.get("num_cascades")
+        self.cascades = torch.nn.ModuleList([
+            vn_block.VarNetBlock(
+                unet_block.NormUnet(chans=cfg_dict.get("channels"), num_pools=cfg_dict.get("pooling_layers"),
+                                    padding_size=cfg_dict.get("padding_size"), normalize=cfg_dict.get("normalize")),
+                fft_centered=self.fft_centered, fft_normalization=self.fft_normalization, spatial_dims=self.spatial_dims,
+                coil_dim=self.coil_dim, no_dc=self.no_dc)
+            for _ in range(self.num_cascades)])                      # vn.py:50-67
+        self.coil_combination_method = cfg_dict.get("coil_combination_method")
+        self.train_loss_fn = _cfg.make_loss(cfg_dict.get("train_loss_fn", "l1"))
+        self.val_loss_fn = _cfg.make_loss(cfg_dict.get("val_loss_fn", "l1"))
+        self.dc_weight = torch.nn.Parameter(torch.ones(1))          # vn.py:91
+        self.accumulate_estimates = False
+
+    def forward(self, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask: torch.Tensor, init_pred: torch.Tensor,
+                target: torch.Tensor) -> torch.Tensor:
+        """vn.py:94-142."""
+        estimation = y.clone()
+        for cascade in self.cascades:
+            estimation = cascade(estimation, y, sensitivity_maps, mask)
+        estimation = fft.ifft2(estimation, centered=self.fft_centered, normalization=self.fft_normalization,
+                               spatial_dims=self.spatial_dims)
+        estimation = utils.coil_combination(estimation, sensitivity_maps, method=self.coil_combination_method,
+                                            dim=self.coil_dim)
+        estimation = torch.view_as_complex(estimation)
+        _, estimation = utils.center_crop_to_smallest(target, estimation)
+        return estimation
+
+    forward_step = forward

@@ -1,0 +1,485 @@
+// conv.hip -- convolutional regulariser kernels for gfx950 (NCHW fp32, stride 1, "same" size):
+//   mrx_conv2d            generic implicit-GEMM conv on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact
+//                         fp32 fma chains), replicate or zero border handled in the LDS tile loader
+//                         (reference models/rim/conv_layers.py:72-85, rnn_cells.py:23-38, unet_block.py:251,255)
+//   mrx_rim_layer_indrnn  ConvNonlinear + IndRNNCell fused: the conv accumulators (D[cout][pixel]) are re-used
+//                         *in registers* as the B operand of the 1x1 `ih` GEMM -- the contraction index of the second
+//                         GEMM is enumerated in the order the first one's C/D layout delivers it, so the 64-channel
+//                         activation never leaves the register file (conv_layers.py:121-123 + rnn_cells.py:384-391)
+//   mrx_indrnn_cell       stand-alone IndRNN cell (zero-padded ih conv + hh*h + ReLU epilogue)
+//   mrx_rim_final         F->2 conv + eta update on the vector ALUs (rim_block.py:239-248)
+//
+// GEMM roles: D[M = 32 couts][N = 32 consecutive pixels of one image row] += A[cout][k] * B[k][pixel] with
+// k = (cin, tap); one MFMA consumes two cins at one tap (lanes 0-31: cin c, lanes 32-63: cin c+1).
+// A workgroup (4 waves) owns an 8-row x 32-column output tile for up to 64 couts; each wave owns 2 rows x 2 cout
+// tiles = 4 independent accumulators, which is what the 64-cycle MFMA needs to issue back to back.
+#include "mrx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CV_NT 256
+#define CV_TW 32
+#define CV_TH 8
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    const float* hh;     // optional per-channel recurrent weight (IndRNN epilogue), plain mode
+    const float* hprev;  // optional previous hidden state [B,Cout,H,W]
+    const float* w_ih;   // fused mode: 1x1 weights [F][F]
+    const float* b_ih;
+    int B, Cin, Cout, H, W, k, dil, pad, pad_mode, act;
+    float slope;
+    int tiles_x, CK, PH, PW;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    if (act == MRX_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MRX_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+// Stage CK input channels of the halo'd tile into LDS (border: clamp = ReplicationPad2d, or zeros).
+__device__ __forceinline__ void stage_x(float* Xs, const ConvArgs& a, const float* xb, int c0, int h0, int w0) {
+    const int plane = a.PH * a.PW;
+    const int total = a.CK * plane;
+    for (int idx = threadIdx.x; idx < total; idx += CV_NT) {
+        const int ci = idx / plane;
+        const int rem = idx - ci * plane;
+        const int ty = rem / a.PW, tx = rem - ty * a.PW;
+        const int gc = c0 + ci;
+        int gy = h0 + ty - a.pad, gx = w0 + tx - a.pad;
+        float v = 0.f;
+        if (gc < a.Cin) {
+            if (a.pad_mode == MRX_PAD_REPLICATE) {
+                gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                v = xb[((long long)gc * a.H + gy) * a.W + gx];
+            } else if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                v = xb[((long long)gc * a.H + gy) * a.W + gx];
+            }
+        }
+        Xs[idx] = v;
+    }
+}
+
+template <int NCT, bool FUSE>
+__global__ __launch_bounds__(CV_NT, 2) void k_conv_mfma(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int WP = NCT * 32 + 1;  // cout pitch (+1: conflict-free transposing writes)
+    const int taps = a.k * a.k;
+    float* Xs = smem_f;
+    float* Ws = smem_f + a.CK * a.PH * a.PW;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tile = blockIdx.x;
+    const int ty0 = tile / a.tiles_x;
+    const int h0 = ty0 * CV_TH, w0 = (tile - ty0 * a.tiles_x) * CV_TW;
+    const int co0 = blockIdx.y * (NCT * 32);
+    const int b = blockIdx.z;
+    const float* xb = a.x + (long long)b * a.Cin * a.H * a.W;
+
+    f32x16 acc[NCT][2];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += a.CK) {
+        __syncthreads();
+        stage_x(Xs, a, xb, c0, h0, w0);
+        {
+            const int per_co = a.CK * taps;
+            const int total = NCT * 32 * per_co;
+            for (int idx = threadIdx.x; idx < total; idx += CV_NT) {
+                const int col = idx / per_co;
+                const int rem = idx - col * per_co;  // = ci*taps + tap
+                const int ci = rem / taps;
+                const int gco = co0 + col, gc = c0 + ci;
+                float v = 0.f;
+                if (gco < a.Cout && gc < a.Cin) v = a.w[((long long)gco * a.Cin + c0) * taps + rem];
+                Ws[rem * WP + col] = v;
+            }
+        }
+        __syncthreads();
+        for (int tap = 0; tap < taps; ++tap) {
+            const int ky = tap / a.k, kx = tap - ky * a.k;
+            const float* xrow = Xs + (wave * 2 + ky * a.dil) * a.PW + kx * a.dil + l31;
+            for (int cp = 0; cp < a.CK; cp += 2) {
+                const int ci = cp + lhi;
+                const float* wp = Ws + (ci * taps + tap) * WP + l31;
+                const float* xp = xrow + ci * a.PH * a.PW;
+                float av[NCT], bv[2];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) av[ct] = wp[ct * 32];
+                bv[0] = xp[0];
+                bv[1] = xp[a.PW];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv[pt], acc[ct][pt], 0, 0, 0);
+            }
+        }
+    }
+
+    const int ox = w0 + l31;
+    const long long plane = (long long)a.H * a.W;
+
+    if (!FUSE) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int oy = h0 + wave * 2 + pt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (co < a.Cout && oy < a.H && ox < a.W) {
+                        const long long o = ((long long)b * a.Cout + co) * plane + (long long)oy * a.W + ox;
+                        float v = acc[ct][pt][r];
+                        if (a.bias) v += a.bias[co];
+                        if (a.hh) v += a.hh[co] * (a.hprev ? a.hprev[o] : 0.f);
+                        a.y[o] = act_apply(v, a.act, a.slope);
+                    }
+                }
+            }
+        return;
+    }
+
+    // ---- fused IndRNN: g = ReLU(conv + b_conv) stays in registers and feeds the 1x1 GEMM as the B operand ----------
+    constexpr int F = NCT * 32;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const float bc = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const float v = acc[ct][pt][r] + bc;
+                acc[ct][pt][r] = v > 0.f ? v : 0.f;
+            }
+        }
+    __syncthreads();  // all waves are done reading Xs / Ws
+    constexpr int WP2 = F + 1;
+    float* Wi = smem_f;  // [c][co2], pitch WP2
+    for (int idx = threadIdx.x; idx < F * F; idx += CV_NT) {
+        const int co2 = idx / F, c = idx - co2 * F;
+        Wi[c * WP2 + co2] = a.w_ih[idx];
+    }
+    __syncthreads();
+    f32x16 acc2[NCT][2];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[ct][pt][r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // the channel this lane's register r of tile ct holds (C/D layout of the 32x32 MFMA)
+            const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            float a2[NCT];
+#pragma unroll
+            for (int ct2 = 0; ct2 < NCT; ++ct2) a2[ct2] = Wi[c * WP2 + ct2 * 32 + l31];
+#pragma unroll
+            for (int ct2 = 0; ct2 < NCT; ++ct2)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+                    acc2[ct2][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ct2], acc[ct][pt][r], acc2[ct2][pt], 0, 0, 0);
+        }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int oy = h0 + wave * 2 + pt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (oy < a.H && ox < a.W) {
+                    const long long o = ((long long)b * F + co) * plane + (long long)oy * a.W + ox;
+                    float v = acc2[ct][pt][r];
+                    if (a.b_ih) v += a.b_ih[co];
+                    if (a.hprev) v += a.hh[co] * a.hprev[o];
+                    a.y[o] = v > 0.f ? v : 0.f;
+                }
+            }
+        }
+}
+
+// ---- small-Cout conv on the vector ALUs (final RIM layer, U-Net 1x1 head) ----------------------------------------
+struct SmallArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* eta;  // MODE 1: [B,H,W,CO] added to the conv output
+    float* y;
+    int B, Cin, H, W, k, dil, pad, pad_mode;
+    int tiles_x, CK, PH, PW;
+};
+// MODE 0: y[B,CO,H,W] = conv + bias ; MODE 1: y[B,H,W,CO] = eta + conv (+ bias)   (rim_block.py:239-248)
+template <int CO, int MODE>
+__global__ __launch_bounds__(CV_NT) void k_conv_small(SmallArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Xs = smem_f;
+    const int taps = s.k * s.k;
+    const int tile = blockIdx.x;
+    const int ty0 = tile / s.tiles_x;
+    const int h0 = ty0 * CV_TH, w0 = (tile - ty0 * s.tiles_x) * CV_TW;
+    const int b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    ConvArgs a;  // reuse the tile loader
+    a.Cin = s.Cin;
+    a.H = s.H;
+    a.W = s.W;
+    a.pad = s.pad;
+    a.pad_mode = s.pad_mode;
+    a.CK = s.CK;
+    a.PH = s.PH;
+    a.PW = s.PW;
+    const float* xb = s.x + (long long)b * s.Cin * s.H * s.W;
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+    for (int c0 = 0; c0 < s.Cin; c0 += s.CK) {
+        __syncthreads();
+        stage_x(Xs, a, xb, c0, h0, w0);
+        __syncthreads();
+        const int nc = min(s.CK, s.Cin - c0);
+        for (int ci = 0; ci < nc; ++ci) {
+            const float* xp = Xs + (ci * s.PH + ty) * s.PW + tx;
+            const float* wp = s.w + (long long)(c0 + ci) * taps;  // w[o][cin][tap]: + o*Cin*taps (wave-uniform -> scalar loads)
+            for (int ky = 0; ky < s.k; ++ky)
+                for (int kx = 0; kx < s.k; ++kx) {
+                    const float xv = xp[ky * s.dil * s.PW + kx * s.dil];
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) acc[o] += wp[(long long)o * s.Cin * taps + ky * s.k + kx] * xv;
+                }
+        }
+    }
+    const int oy = h0 + ty, ox = w0 + tx;
+    if (oy >= s.H || ox >= s.W) return;
+    if (MODE == 0) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o)
+            s.y[(((long long)b * CO + o) * s.H + oy) * s.W + ox] = acc[o] + (s.bias ? s.bias[o] : 0.f);
+    } else {
+        const long long base = (((long long)b * s.H + oy) * s.W + ox) * CO;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) s.y[base + o] = s.eta[base + o] + (acc[o] + (s.bias ? s.bias[o] : 0.f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+static int conv_geometry(int Cin, int k, int dil, int wp, int* CK, int* PH, int* PW, int* pad, size_t* lds) {
+    MRX_REQUIRE(k >= 1 && (k & 1) == 1, MRX_EUNSUP, "conv: kernel size %d must be odd", k);
+    MRX_REQUIRE(dil >= 1, MRX_EINVAL, "conv: dilation %d", dil);
+    *pad = dil * (k - 1) / 2;
+    *PH = CV_TH + 2 * *pad;
+    *PW = CV_TW + 2 * *pad;
+    int ck = 16;
+    const int cin_even = (Cin + 1) & ~1;
+    if (ck > cin_even) ck = cin_even;
+    for (;;) {
+        const size_t bytes = sizeof(float) * ((size_t)ck * *PH * *PW + (size_t)ck * k * k * wp);
+        if (bytes <= 40 * 1024 || ck <= 2) {
+            *lds = bytes;
+            break;
+        }
+        ck = (ck / 2 + 1) & ~1;
+        if (ck < 2) ck = 2;
+    }
+    *CK = ck;
+    MRX_REQUIRE(*lds <= 160 * 1024, MRX_EUNSUP, "conv: tile needs %zu bytes of LDS (k=%d dil=%d)", *lds, k, dil);
+    return MRX_OK;
+}
+
+template <typename K>
+static int conv_set_lds(K kern, size_t bytes) {
+    if (bytes > 48 * 1024)
+        MRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MRX_OK;
+}
+
+static int launch_conv(const ConvArgs& a0, int fuse, hipStream_t st) {
+    ConvArgs a = a0;
+    const int nct = (fuse || a.Cout > 32) ? 2 : 1;
+    const int wp = nct * 32 + 1;
+    size_t lds;
+    int rc = conv_geometry(a.Cin, a.k, a.dil, wp, &a.CK, &a.PH, &a.PW, &a.pad, &lds);
+    if (rc) return rc;
+    if (fuse) {
+        const size_t l2 = sizeof(float) * (size_t)a.Cout * (a.Cout + 1);
+        if (l2 > lds) lds = l2;
+    }
+    a.tiles_x = mrx_cdiv(a.W, CV_TW);
+    const int tiles_y = mrx_cdiv(a.H, CV_TH);
+    MRX_REQUIRE(a.B <= 65535, MRX_EUNSUP, "conv: batch %d too large", a.B);
+    dim3 grid(a.tiles_x * tiles_y, mrx_cdiv(a.Cout, nct * 32), a.B);
+    if (fuse) {
+        if (a.Cout == 64) {
+            if ((rc = conv_set_lds(k_conv_mfma<2, true>, lds))) return rc;
+            hipLaunchKernelGGL((k_conv_mfma<2, true>), grid, dim3(CV_NT), lds, st, a);
+        } else {
+            if ((rc = conv_set_lds(k_conv_mfma<1, true>, lds))) return rc;
+            hipLaunchKernelGGL((k_conv_mfma<1, true>), grid, dim3(CV_NT), lds, st, a);
+        }
+    } else if (nct == 2) {
+        if ((rc = conv_set_lds(k_conv_mfma<2, false>, lds))) return rc;
+        hipLaunchKernelGGL((k_conv_mfma<2, false>), grid, dim3(CV_NT), lds, st, a);
+    } else {
+        if ((rc = conv_set_lds(k_conv_mfma<1, false>, lds))) return rc;
+        hipLaunchKernelGGL((k_conv_mfma<1, false>), grid, dim3(CV_NT), lds, st, a);
+    }
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+static int conv_common_checks(const char* who, int B, int Cin, int Cout, int H, int W) {
+    MRX_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "%s: bad dims B=%d Cin=%d Cout=%d H=%d W=%d",
+                who, B, Cin, Cout, H, W);
+    return MRX_OK;
+}
+
+static int launch_small(const float* x, const float* w, const float* bias, const float* eta, float* y, int B, int Cin,
+                        int Cout, int H, int W, int k, int dil, int pad_mode, int mode, hipStream_t st) {
+    SmallArgs s;
+    s.x = x;
+    s.w = w;
+    s.bias = bias;
+    s.eta = eta;
+    s.y = y;
+    s.B = B;
+    s.Cin = Cin;
+    s.H = H;
+    s.W = W;
+    s.k = k;
+    s.dil = dil;
+    s.pad_mode = pad_mode;
+    size_t lds;
+    int rc = conv_geometry(Cin, k, dil, 0, &s.CK, &s.PH, &s.PW, &s.pad, &lds);
+    if (rc) return rc;
+    s.tiles_x = mrx_cdiv(W, CV_TW);
+    dim3 grid(s.tiles_x * mrx_cdiv(H, CV_TH), 1, B);
+#define SMALL_CASE(CO, MODE)                                                             \
+    do {                                                                                 \
+        if ((rc = conv_set_lds(k_conv_small<CO, MODE>, lds))) return rc;                 \
+        hipLaunchKernelGGL((k_conv_small<CO, MODE>), grid, dim3(CV_NT), lds, st, s);     \
+    } while (0)
+    if (mode == 1) {
+        MRX_REQUIRE(Cout == 2, MRX_EUNSUP, "rim_final: Cout must be 2 (got %d)", Cout);
+        SMALL_CASE(2, 1);
+    } else if (Cout == 1) {
+        SMALL_CASE(1, 0);
+    } else if (Cout == 2) {
+        SMALL_CASE(2, 0);
+    } else if (Cout == 3) {
+        SMALL_CASE(3, 0);
+    } else {
+        SMALL_CASE(4, 0);
+    }
+#undef SMALL_CASE
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+extern "C" int mrx_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H,
+                          int W, int k, int dil, int pad_mode, int act, float slope, void* stream) {
+    MRX_REQUIRE(x && w && y, MRX_EINVAL, "mrx_conv2d: null pointer");
+    int rc = conv_common_checks("mrx_conv2d", B, Cin, Cout, H, W);
+    if (rc) return rc;
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv2d: bad pad mode %d", pad_mode);
+    MRX_REQUIRE(act >= 0 && act <= 2, MRX_EINVAL, "mrx_conv2d: bad activation %d", act);
+    if (B == 0) return MRX_OK;
+    if (Cout <= 4 && act == MRX_ACT_NONE)
+        return launch_small(x, w, bias, nullptr, y, B, Cin, Cout, H, W, k, dil, pad_mode, 0, (hipStream_t)stream);
+    ConvArgs a = {};
+    a.x = x;
+    a.w = w;
+    a.bias = bias;
+    a.y = y;
+    a.B = B;
+    a.Cin = Cin;
+    a.Cout = Cout;
+    a.H = H;
+    a.W = W;
+    a.k = k;
+    a.dil = dil;
+    a.pad_mode = pad_mode;
+    a.act = act;
+    a.slope = slope;
+    return launch_conv(a, 0, (hipStream_t)stream);
+}
+
+extern "C" int mrx_indrnn_cell(const float* x, const float* w_ih, const float* b_ih, const float* hh, const float* h_prev,
+                               float* h_new, int B, int Cin, int F, int H, int W, int k, int dil, void* stream) {
+    MRX_REQUIRE(x && w_ih && hh && h_new, MRX_EINVAL, "mrx_indrnn_cell: null pointer");
+    int rc = conv_common_checks("mrx_indrnn_cell", B, Cin, F, H, W);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    ConvArgs a = {};
+    a.x = x;
+    a.w = w_ih;
+    a.bias = b_ih;
+    a.y = h_new;
+    a.hh = hh;
+    a.hprev = h_prev;
+    a.B = B;
+    a.Cin = Cin;
+    a.Cout = F;
+    a.H = H;
+    a.W = W;
+    a.k = k;
+    a.dil = dil;
+    a.pad_mode = MRX_PAD_ZERO;  // rnn_cells.py:299: the ih conv zero-pads
+    a.act = MRX_ACT_RELU;
+    return launch_conv(a, 0, (hipStream_t)stream);
+}
+
+extern "C" int mrx_rim_layer_indrnn(const float* x, const float* w_conv, const float* b_conv, const float* w_ih,
+                                    const float* b_ih, const float* hh, const float* h_prev, float* h_new, int B, int Cin,
+                                    int F, int H, int W, int k, int dil, void* stream) {
+    MRX_REQUIRE(x && w_conv && w_ih && hh && h_new, MRX_EINVAL, "mrx_rim_layer_indrnn: null pointer");
+    int rc = conv_common_checks("mrx_rim_layer_indrnn", B, Cin, F, H, W);
+    if (rc) return rc;
+    MRX_REQUIRE(F == 32 || F == 64, MRX_EUNSUP, "mrx_rim_layer_indrnn: hidden size %d not in {32, 64}", F);
+    if (B == 0) return MRX_OK;
+    ConvArgs a = {};
+    a.x = x;
+    a.w = w_conv;
+    a.bias = b_conv;
+    a.y = h_new;
+    a.hh = hh;
+    a.hprev = h_prev;
+    a.w_ih = w_ih;
+    a.b_ih = b_ih;
+    a.B = B;
+    a.Cin = Cin;
+    a.Cout = F;
+    a.H = H;
+    a.W = W;
+    a.k = k;
+    a.dil = dil;
+    a.pad_mode = MRX_PAD_REPLICATE;
+    a.act = MRX_ACT_RELU;
+    return launch_conv(a, 1, (hipStream_t)stream);
+}
+
+extern "C" int mrx_rim_final(const float* h, const float* w, const float* bias, const float* eta, float* eta_out, int B,
+                             int F, int H, int W, int k, int dil, void* stream) {
+    MRX_REQUIRE(h && w && eta && eta_out, MRX_EINVAL, "mrx_rim_final: null pointer");
+    int rc = conv_common_checks("mrx_rim_final", B, F, 2, H, W);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    return launch_small(h, w, bias, eta, eta_out, B, F, 2, H, W, k, dil, MRX_PAD_REPLICATE, 1, (hipStream_t)stream);
+}

@@ -1,0 +1,364 @@
+// elementwise.hip -- HBM-bound pointwise / small-reduction operators of the hot path (gfx950):
+// roll/fftshift, complex arithmetic, coil combination, mask application, soft data consistency, GRU/MGU gates.
+// All are grid-stride kernels with contiguous per-lane accesses; reductions over the coil dim keep `inner`
+// as the fastest index so a wave reads 64 consecutive elements per coil.
+#include "mrx_common.h"
+
+#define EW_NT 256
+static inline int ew_grid(long long n) {
+    long long g = (n + EW_NT - 1) / EW_NT;
+    if (g > 256 * 16) g = 256 * 16;  // 256 CUs x 16 blocks, grid-stride for the rest
+    return g < 1 ? 1 : (int)g;
+}
+
+// ---- roll (fft.py:169-240) ---------------------------------------------------------------------------------
+struct RollArgs {
+    int ndim;
+    long long shape[8];
+    long long shift[8];  // normalised to [0, n)
+    long long total;
+};
+template <typename T>
+__global__ void k_roll(const T* __restrict__ in, T* __restrict__ out, RollArgs a) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.total;
+         o += (long long)gridDim.x * blockDim.x) {
+        long long rem = o, src = 0, mul = 1;
+        for (int d = a.ndim - 1; d >= 0; --d) {
+            const long long n = a.shape[d];
+            const long long i = rem % n;
+            rem /= n;
+            long long j = i - a.shift[d];  // out[i] = in[(i - shift) mod n]
+            if (j < 0) j += n;
+            src += j * mul;
+            mul *= n;
+        }
+        out[o] = in[src];
+    }
+}
+
+extern "C" int mrx_roll(const void* in, void* out, int elem_bytes, int ndim, const int64_t* shape,
+                        const int64_t* shifts, void* stream) {
+    MRX_REQUIRE(in && out && shape && shifts, MRX_EINVAL, "mrx_roll: null pointer");
+    MRX_REQUIRE(ndim >= 1 && ndim <= 8, MRX_EINVAL, "mrx_roll: ndim %d outside [1,8]", ndim);
+    MRX_REQUIRE(in != out, MRX_EINVAL, "mrx_roll: in-place roll is not supported");
+    RollArgs a;
+    a.ndim = ndim;
+    a.total = 1;
+    for (int d = 0; d < ndim; ++d) {
+        MRX_REQUIRE(shape[d] >= 0, MRX_EINVAL, "mrx_roll: negative dim");
+        a.shape[d] = shape[d];
+        a.total *= shape[d];
+        long long s = shape[d] > 0 ? shifts[d] % shape[d] : 0;
+        if (s < 0) s += shape[d];
+        a.shift[d] = s;
+    }
+    if (a.total == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = ew_grid(a.total);
+    switch (elem_bytes) {
+        case 1: hipLaunchKernelGGL(k_roll<unsigned char>, dim3(g), dim3(EW_NT), 0, st, (const unsigned char*)in, (unsigned char*)out, a); break;
+        case 2: hipLaunchKernelGGL(k_roll<unsigned short>, dim3(g), dim3(EW_NT), 0, st, (const unsigned short*)in, (unsigned short*)out, a); break;
+        case 4: hipLaunchKernelGGL(k_roll<unsigned int>, dim3(g), dim3(EW_NT), 0, st, (const unsigned int*)in, (unsigned int*)out, a); break;
+        case 8: hipLaunchKernelGGL(k_roll<uint2>, dim3(g), dim3(EW_NT), 0, st, (const uint2*)in, (uint2*)out, a); break;
+        case 16: hipLaunchKernelGGL(k_roll<uint4>, dim3(g), dim3(EW_NT), 0, st, (const uint4*)in, (uint4*)out, a); break;
+        default: MRX_REQUIRE(false, MRX_EINVAL, "mrx_roll: unsupported element size %d", elem_bytes);
+    }
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- complex_mul with broadcasting (utils.py:96-118) ----------------------------------------------------------
+struct BcastArgs {
+    int ndim;
+    long long shape[6], xs[6], ys[6];
+    long long total;
+    int conj_y;
+};
+__global__ void k_complex_mul(const float2* __restrict__ x, const float2* __restrict__ y, float2* __restrict__ out,
+                              BcastArgs a) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.total;
+         o += (long long)gridDim.x * blockDim.x) {
+        long long rem = o, xo = 0, yo = 0;
+        for (int d = a.ndim - 1; d >= 0; --d) {
+            const long long n = a.shape[d];
+            const long long i = rem % n;
+            rem /= n;
+            xo += i * a.xs[d];
+            yo += i * a.ys[d];
+        }
+        const float2 p = x[xo];
+        float2 q = y[yo];
+        if (a.conj_y) q.y = -q.y;
+        out[o] = make_float2(p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x);
+    }
+}
+extern "C" int mrx_complex_mul(const float* x, const float* y, float* out, int ndim, const int64_t* shape,
+                               const int64_t* xstride, const int64_t* ystride, int conj_y, void* stream) {
+    MRX_REQUIRE(x && y && out && shape && xstride && ystride, MRX_EINVAL, "mrx_complex_mul: null pointer");
+    MRX_REQUIRE(ndim >= 1 && ndim <= 6, MRX_EINVAL, "mrx_complex_mul: ndim %d outside [1,6]", ndim);
+    BcastArgs a;
+    a.ndim = ndim;
+    a.total = 1;
+    a.conj_y = conj_y;
+    for (int d = 0; d < ndim; ++d) {
+        MRX_REQUIRE(shape[d] >= 0, MRX_EINVAL, "mrx_complex_mul: negative dim");
+        a.shape[d] = shape[d];
+        a.xs[d] = xstride[d];
+        a.ys[d] = ystride[d];
+        a.total *= shape[d];
+    }
+    if (a.total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_complex_mul, dim3(ew_grid(a.total)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)x,
+                       (const float2*)y, (float2*)out, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- complex_conj / abs / abs_sq (utils.py:121-175) -------------------------------------------------------------
+__global__ void k_conj(const float2* __restrict__ x, float2* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = x[i];
+        out[i] = make_float2(v.x, -v.y);
+    }
+}
+template <bool SQ>
+__global__ void k_abs(const float2* __restrict__ x, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = x[i];
+        const float s = __fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y));  // (data**2).sum(-1): two rounded squares, one add
+        out[i] = SQ ? s : __fsqrt_rn(s);
+    }
+}
+extern "C" int mrx_complex_conj(const float* x, float* out, int64_t n, void* stream) {
+    MRX_REQUIRE(x && out && n >= 0, MRX_EINVAL, "mrx_complex_conj: bad argument");
+    if (n == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_conj, dim3(ew_grid(n)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)x, (float2*)out, (long long)n);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_complex_abs(const float* x, float* out, int64_t n, int squared, void* stream) {
+    MRX_REQUIRE(x && out && n >= 0, MRX_EINVAL, "mrx_complex_abs: bad argument");
+    if (n == 0) return MRX_OK;
+    if (squared)
+        hipLaunchKernelGGL(k_abs<true>, dim3(ew_grid(n)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)x, out, (long long)n);
+    else
+        hipLaunchKernelGGL(k_abs<false>, dim3(ew_grid(n)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)x, out, (long long)n);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- coil combination over a middle dim (utils.py:194-248) ------------------------------------------------------
+__global__ void k_rss(const float* __restrict__ x, float* __restrict__ out, long long outer, long long R, long long inner) {
+    const long long total = outer * inner;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long ob = o / inner, i = o - ob * inner;
+        const float* p = x + ob * R * inner + i;
+        float s = 0.f;
+        for (long long r = 0; r < R; ++r) {
+            const float v = p[r * inner];
+            s += v * v;
+        }
+        out[o] = sqrtf(s);
+    }
+}
+__global__ void k_rss_complex(const float2* __restrict__ x, float* __restrict__ out, long long outer, long long R, long long inner) {
+    const long long total = outer * inner;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long ob = o / inner, i = o - ob * inner;
+        const float2* p = x + ob * R * inner + i;
+        float s = 0.f;
+        for (long long r = 0; r < R; ++r) {
+            const float2 v = p[r * inner];
+            s += v.x * v.x + v.y * v.y;
+        }
+        out[o] = sqrtf(s);
+    }
+}
+__global__ void k_sense(const float2* __restrict__ x, const float2* __restrict__ sm, float2* __restrict__ out, long long outer,
+                        long long R, long long inner) {
+    const long long total = outer * inner;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long ob = o / inner, i = o - ob * inner;
+        const long long base = ob * R * inner + i;
+        float re = 0.f, im = 0.f;
+        for (long long r = 0; r < R; ++r) {
+            const float2 v = x[base + r * inner];
+            const float2 s = sm[base + r * inner];
+            re += v.x * s.x + v.y * s.y;
+            im += v.y * s.x - v.x * s.y;
+        }
+        out[o] = make_float2(re, im);
+    }
+}
+#define REDUCE_ENTRY(name, kern, TIN, TOUT, extra_decl, extra_arg)                                                          \
+    extern "C" int name(const float* x, extra_decl float* out, int64_t outer, int64_t R, int64_t inner, void* stream) {      \
+        MRX_REQUIRE(x && out && outer >= 0 && R >= 0 && inner >= 0, MRX_EINVAL, #name ": bad argument");                     \
+        if (outer * inner == 0) return MRX_OK;                                                                               \
+        hipLaunchKernelGGL(kern, dim3(ew_grid(outer* inner)), dim3(EW_NT), 0, (hipStream_t)stream, (const TIN*)x, extra_arg  \
+                           (TOUT*)out, (long long)outer, (long long)R, (long long)inner);                                    \
+        MRX_LAUNCH_CHECK();                                                                                                  \
+        return MRX_OK;                                                                                                       \
+    }
+REDUCE_ENTRY(mrx_rss, k_rss, float, float, , )
+REDUCE_ENTRY(mrx_rss_complex, k_rss_complex, float2, float, , )
+extern "C" int mrx_sense(const float* x, const float* s, float* out, int64_t outer, int64_t R, int64_t inner, void* stream) {
+    MRX_REQUIRE(x && s && out && outer >= 0 && R >= 0 && inner >= 0, MRX_EINVAL, "mrx_sense: bad argument");
+    if (outer * inner == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_sense, dim3(ew_grid(outer * inner)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)x,
+                       (const float2*)s, (float2*)out, (long long)outer, (long long)R, (long long)inner);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- apply_mask arithmetic (utils.py:341) -------------------------------------------------------------------------
+struct Dims4 {
+    long long B, C, H, W, total;
+};
+__global__ void k_apply_mask(const float2* __restrict__ d, MrxMask m, float2* __restrict__ out, Dims4 s) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < s.total; o += (long long)gridDim.x * blockDim.x) {
+        long long r = o;
+        const long long w = r % s.W;
+        r /= s.W;
+        const long long h = r % s.H;
+        r /= s.H;
+        const long long c = r % s.C;
+        const long long b = r / s.C;
+        const float mv = mrx_mask_val(m, b, c, h, w);
+        const float2 v = d[o];
+        out[o] = make_float2(__fadd_rn(__fmul_rn(v.x, mv), 0.0f), __fadd_rn(__fmul_rn(v.y, mv), 0.0f));  // + 0.0 kills -0
+    }
+}
+static int fill_mask(MrxMask* m, const void* mask, int kind, const int64_t* ms, const char* who) {
+    MRX_REQUIRE(mask && ms, MRX_EINVAL, "%s: null mask", who);
+    MRX_REQUIRE(kind == MRX_MASK_U8 || kind == MRX_MASK_F32, MRX_EINVAL, "%s: bad mask kind %d", who, kind);
+    m->p = mask;
+    m->kind = kind;
+    for (int i = 0; i < 4; ++i) m->s[i] = ms[i];
+    return MRX_OK;
+}
+static int fill_dims(Dims4* s, int B, int C, int H, int W, const char* who) {
+    MRX_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0, MRX_EINVAL, "%s: negative dim", who);
+    s->B = B;
+    s->C = C;
+    s->H = H;
+    s->W = W;
+    s->total = (long long)B * C * H * W;
+    return MRX_OK;
+}
+extern "C" int mrx_apply_mask(const float* data, const float* mask, float* out, int B, int C, int H, int W,
+                              const int64_t* mstride, void* stream) {
+    MRX_REQUIRE(data && out, MRX_EINVAL, "mrx_apply_mask: null pointer");
+    MrxMask m;
+    Dims4 s;
+    int rc;
+    if ((rc = fill_mask(&m, mask, MRX_MASK_F32, mstride, "mrx_apply_mask"))) return rc;
+    if ((rc = fill_dims(&s, B, C, H, W, "mrx_apply_mask"))) return rc;
+    if (s.total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_apply_mask, dim3(ew_grid(s.total)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)data, m, (float2*)out, s);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- soft data consistency (vn_block.py:109-117, rim_block.py:256-259) ------------------------------------------
+// MODE 0: out = where(mask, pred - ref, 0) * w ; MODE 1: out = base - where(mask, pred - ref, 0) * w - eta_k
+template <int MODE>
+__global__ void k_soft_dc(const float2* __restrict__ base, const float2* __restrict__ pred, const float2* __restrict__ ref,
+                          MrxMask m, const float* __restrict__ dcw, const float2* __restrict__ etak,
+                          float2* __restrict__ out, Dims4 s) {
+    const float w8 = dcw[0];
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < s.total; o += (long long)gridDim.x * blockDim.x) {
+        long long r = o;
+        const long long w = r % s.W;
+        r /= s.W;
+        const long long h = r % s.H;
+        r /= s.H;
+        const long long c = r % s.C;
+        const long long b = r / s.C;
+        const float2 p = pred[o];
+        float2 d = make_float2(0.f, 0.f);
+        if (mrx_mask_true(m, b, c, h, w)) {
+            const float2 q = ref[o];
+            d = make_float2(p.x - q.x, p.y - q.y);
+        }
+        d.x = __fmul_rn(d.x, w8);
+        d.y = __fmul_rn(d.y, w8);
+        if (MODE == 0) {
+            out[o] = d;
+        } else {
+            const float2 e = etak[o];
+            const float2 a = base[o];
+            out[o] = make_float2(__fsub_rn(__fsub_rn(a.x, d.x), e.x), __fsub_rn(__fsub_rn(a.y, d.y), e.y));
+        }
+    }
+}
+extern "C" int mrx_soft_dc(const float* pred, const float* ref, const void* mask, int mask_kind, const int64_t* mstride,
+                           const float* dc_weight, float* out, int B, int C, int H, int W, void* stream) {
+    MRX_REQUIRE(pred && ref && dc_weight && out, MRX_EINVAL, "mrx_soft_dc: null pointer");
+    MrxMask m;
+    Dims4 s;
+    int rc;
+    if ((rc = fill_mask(&m, mask, mask_kind, mstride, "mrx_soft_dc"))) return rc;
+    if ((rc = fill_dims(&s, B, C, H, W, "mrx_soft_dc"))) return rc;
+    if (s.total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_soft_dc<0>, dim3(ew_grid(s.total)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)nullptr,
+                       (const float2*)pred, (const float2*)ref, m, dc_weight, (const float2*)nullptr, (float2*)out, s);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_dc_combine(const float* base, const float* pred, const float* ref, const void* mask, int mask_kind,
+                              const int64_t* mstride, const float* dc_weight, const float* eta_k, float* out, int B, int C,
+                              int H, int W, void* stream) {
+    MRX_REQUIRE(base && pred && ref && dc_weight && eta_k && out, MRX_EINVAL, "mrx_dc_combine: null pointer");
+    MrxMask m;
+    Dims4 s;
+    int rc;
+    if ((rc = fill_mask(&m, mask, mask_kind, mstride, "mrx_dc_combine"))) return rc;
+    if ((rc = fill_dims(&s, B, C, H, W, "mrx_dc_combine"))) return rc;
+    if (s.total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_soft_dc<1>, dim3(ew_grid(s.total)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)base,
+                       (const float2*)pred, (const float2*)ref, m, dc_weight, (const float2*)eta_k, (float2*)out, s);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- GRU / MGU gate math (rnn_cells.py:118-127, :255-261) --------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__global__ void k_gru(const float* __restrict__ ih, const float* __restrict__ hh, const float* h, float* out, int F, long long HW,
+                      long long total) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long b = o / (F * HW), r = o - b * F * HW;  // r = f*HW + p
+        const long long g = b * 3 * F * HW + r;
+        const float rg = sigmoidf_(ih[g] + hh[g]);
+        const float z = sigmoidf_(ih[g + F * HW] + hh[g + F * HW]);
+        const float n = tanhf(ih[g + 2 * F * HW] + rg * hh[g + 2 * F * HW]);
+        const float hv = h[o];
+        out[o] = n * (1.0f - z) + z * hv;
+    }
+}
+__global__ void k_mgu(const float* __restrict__ ih, const float* __restrict__ hh, const float* h, float* out, int F, long long HW,
+                      long long total) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long b = o / (F * HW), r = o - b * F * HW;
+        const long long g = b * 2 * F * HW + r;
+        const float f = sigmoidf_(ih[g] + hh[g]);
+        const float c = tanhf(ih[g + F * HW] + f * hh[g + F * HW]);
+        const float hv = h[o];
+        out[o] = c + f * (hv - c);
+    }
+}
+extern "C" int mrx_gru_gates(const float* ih, const float* hh, const float* h, float* out, int B, int F, int64_t HW, void* stream) {
+    MRX_REQUIRE(ih && hh && h && out && B >= 0 && F >= 0 && HW >= 0, MRX_EINVAL, "mrx_gru_gates: bad argument");
+    const long long total = (long long)B * F * HW;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_gru, dim3(ew_grid(total)), dim3(EW_NT), 0, (hipStream_t)stream, ih, hh, h, out, F, (long long)HW, total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_mgu_gates(const float* ih, const float* hh, const float* h, float* out, int B, int F, int64_t HW, void* stream) {
+    MRX_REQUIRE(ih && hh && h && out && B >= 0 && F >= 0 && HW >= 0, MRX_EINVAL, "mrx_mgu_gates: bad argument");
+    const long long total = (long long)B * F * HW;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_mgu, dim3(ew_grid(total)), dim3(EW_NT), 0, (hipStream_t)stream, ih, hh, h, out, F, (long long)HW, total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

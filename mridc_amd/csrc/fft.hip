@@ -1,0 +1,513 @@
+// fft.hip -- LDS-resident mixed-radix 2-D FFT kernels for gfx950 and the fused MRI operators built on them:
+//   mrx_fft2          fft2 / ifft2                      (reference common/parts/fft.py:13-166)
+//   mrx_sens_expand   fft2(x * S)                       (vn_block.py:51-69, rim_utils.py:44-51)
+//   mrx_sens_reduce   sum_c ifft2(k) * conj(S)          (vn_block.py:71-87, rim_block.py:199-210)
+//   mrx_llg           log_likelihood_gradient           (rim_utils.py:11-67)
+//
+// A 2-D transform is a row pass (contiguous rows staged in LDS, several rows per workgroup) and a column pass
+// (a tile of adjacent columns staged in LDS with the column index fastest, so global accesses stay contiguous and
+// all lanes of a wave run the same butterfly on neighbouring columns).  Centred transforms fold ifftshift/fftshift
+// into the load/store index: LDS position p <-> global index (p + n/2) mod n on both sides (fft.py:279,:320).
+// The data-consistency step of log_likelihood_gradient happens between the forward and the inverse column
+// transform while the column tile is still in LDS, so the coil stack makes one HBM round trip fewer per pass.
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+#include <cmath>
+
+#include "fft_core.h"
+#include "mrx_common.h"
+
+#define MRX_FFT_NT 256
+#define MRX_FFT_MAX_LEN 4096
+#define MRX_FFT_TILE_ELEMS 2048  // target complex elements staged per workgroup
+
+// ------------------------------------------------------------------------------------------------------------
+// plan cache (host)
+// ------------------------------------------------------------------------------------------------------------
+struct MrxFftEntry {
+    MrxFftPlan plan;
+    float2* d_tw;
+};
+static std::mutex g_plan_mu;
+static std::unordered_map<long long, MrxFftEntry> g_plans;  // key: device * 2^32 + n
+
+static int mrx_get_plan(int n, MrxFftEntry* out) {
+    MRX_REQUIRE(n >= 1 && n <= MRX_FFT_MAX_LEN, MRX_EUNSUP, "FFT length %d outside [1, %d]", n, MRX_FFT_MAX_LEN);
+    int dev = 0;
+    MRX_HIP(hipGetDevice(&dev));
+    const long long key = ((long long)dev << 32) | (long long)n;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) {
+        *out = it->second;
+        return MRX_OK;
+    }
+    MrxFftEntry e;
+    MRX_REQUIRE(mrx_make_plan(n, &e.plan) == 0, MRX_EUNSUP, "cannot factor FFT length %d", n);
+    std::vector<float2> tw(n);
+    for (int m = 0; m < n; ++m) {
+        const double a = -2.0 * M_PI * (double)m / (double)n;
+        tw[m] = make_float2((float)cos(a), (float)sin(a));
+    }
+    MRX_HIP(hipMalloc((void**)&e.d_tw, sizeof(float2) * n));
+    MRX_HIP(hipMemcpy(e.d_tw, tw.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    g_plans[key] = e;
+    *out = e;
+    return MRX_OK;
+}
+
+static inline float mrx_scale(int n, int inverse, int norm) {
+    // fft.py:77-81,155-159: "backward" scales the inverse by 1/n, "forward" the forward, "ortho" both by 1/sqrt(n)
+    if (norm == MRX_NORM_ORTHO) return (float)(1.0 / sqrt((double)n));
+    if (norm == MRX_NORM_FORWARD) return inverse ? 1.0f : (float)(1.0 / (double)n);
+    return inverse ? (float)(1.0 / (double)n) : 1.0f;  // backward / none
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// device: run all stages over `nseq` sequences held in LDS.  Returns the buffer holding the result.
+// ------------------------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ float2* fft_lds_run(float2* a, float2* b, const float2* tw, const MrxFftPlan& p, int nseq,
+                                               int seq_stride, int es, bool seq_fastest) {
+    int Ns = 1;
+    for (int s = 0; s < p.nstages; ++s) {
+        const int r = p.radix[s];
+        const int ips = mrx_stage_items(p.n, r);
+        const int total = ips * nseq;
+        for (int w = threadIdx.x; w < total; w += MRX_FFT_NT) {
+            int seq, item;
+            if (seq_fastest) {
+                item = w / nseq;
+                seq = w - item * nseq;
+            } else {
+                seq = w / ips;
+                item = w - seq * ips;
+            }
+            mrx_fft_stage_item<INV>(a + seq * seq_stride, b + seq * seq_stride, tw, p.n, Ns, r, item, es);
+        }
+        __syncthreads();
+        float2* t = a;
+        a = b;
+        b = t;
+        Ns *= r;
+    }
+    return a;
+}
+
+__device__ __forceinline__ int shifted(int p, int half, int n) {
+    int g = p + half;
+    return g >= n ? g - n : g;
+}
+
+struct RowArgs {
+    MrxFftPlan plan;
+    const float2* tw;
+    long long rows_total;  // number of length-W rows
+    int W, rpb, halfW;
+    float scale;
+    int C, H;  // expand mode: rows are [B][C][H]
+};
+
+// MODE 0: out[row] = FFT(in[row]);  MODE 1: out[b,c,h] = FFT(x[b,h] * S[b,c,h])
+template <bool INV, int MODE>
+__global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const float2* __restrict__ S,
+                                                         float2* out, RowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int W = a.W;
+    float2* tw = smem;
+    float2* A = smem + W;
+    float2* B = A + a.rpb * W;
+    const long long row0 = (long long)blockIdx.x * a.rpb;
+    const int nrows = (int)min((long long)a.rpb, a.rows_total - row0);
+    for (int i = threadIdx.x; i < W; i += MRX_FFT_NT) tw[i] = a.tw[i];
+    for (int idx = threadIdx.x; idx < nrows * W; idx += MRX_FFT_NT) {
+        const int r = idx / W, x = idx - r * W;
+        const int g = shifted(x, a.halfW, W);
+        const long long ro = row0 + r;
+        float2 v;
+        if (MODE == 0) {
+            v = in[ro * W + g];
+        } else {
+            const long long b = ro / ((long long)a.C * a.H);
+            const int h = (int)(ro % a.H);
+            const float2 e = in[(b * a.H + h) * W + g];
+            const float2 s = S[ro * W + g];
+            v = make_float2(e.x * s.x - e.y * s.y, e.x * s.y + e.y * s.x);  // utils.py:115-116
+        }
+        A[idx] = v;
+    }
+    __syncthreads();
+    float2* res = fft_lds_run<INV>(A, B, tw, a.plan, nrows, W, 1, false);
+    for (int idx = threadIdx.x; idx < nrows * W; idx += MRX_FFT_NT) {
+        const int r = idx / W, x = idx - r * W;
+        const int g = shifted(x, a.halfW, W);
+        float2 v = res[idx];
+        out[(row0 + r) * W + g] = make_float2(v.x * a.scale, v.y * a.scale);
+    }
+}
+
+struct ColArgs {
+    MrxFftPlan plan;
+    const float2* tw;
+    int H, W, ct, halfH;
+    float scale;      // applied after the (first) transform
+    float scale2;     // DC kernel: applied after the inverse transform
+    int C;            // DC kernel: images are [B][C]
+};
+
+template <bool INV>
+__global__ __launch_bounds__(MRX_FFT_NT) void k_fft_cols(const float2* in, float2* out, ColArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int H = a.H, W = a.W, CT = a.ct;
+    float2* tw = smem;
+    float2* A = smem + H;
+    float2* B = A + H * CT;
+    const int w0 = blockIdx.x * CT;
+    const long long img = (long long)blockIdx.y * H * W;
+    for (int i = threadIdx.x; i < H; i += MRX_FFT_NT) tw[i] = a.tw[i];
+    for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
+        const int p = idx / CT, c = idx - p * CT;
+        const int w = w0 + c;
+        A[idx] = w < W ? in[img + (long long)shifted(p, a.halfH, H) * W + w] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    float2* res = fft_lds_run<INV>(A, B, tw, a.plan, CT, 1, CT, true);
+    for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
+        const int p = idx / CT, c = idx - p * CT;
+        const int w = w0 + c;
+        if (w < W) {
+            float2 v = res[idx];
+            out[img + (long long)shifted(p, a.halfH, H) * W + w] = make_float2(v.x * a.scale, v.y * a.scale);
+        }
+    }
+}
+
+// forward column FFT -> mask * (k - y) -> inverse column FFT, all in LDS (rim_utils.py:51-58)
+__global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc(const float2* in, const float2* __restrict__ y, MrxMask mask,
+                                                        float2* out, ColArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int H = a.H, W = a.W, CT = a.ct;
+    float2* tw = smem;
+    float2* A = smem + H;
+    float2* B = A + H * CT;
+    const int w0 = blockIdx.x * CT;
+    const long long bc = blockIdx.y;
+    const long long b = bc / a.C, c_ = bc % a.C;
+    const long long img = bc * H * W;
+    for (int i = threadIdx.x; i < H; i += MRX_FFT_NT) tw[i] = a.tw[i];
+    for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
+        const int p = idx / CT, c = idx - p * CT;
+        const int w = w0 + c;
+        A[idx] = w < W ? in[img + (long long)shifted(p, a.halfH, H) * W + w] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    float2* res = fft_lds_run<false>(A, B, tw, a.plan, CT, 1, CT, true);
+    float2* oth = (res == A) ? B : A;
+    for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
+        const int p = idx / CT, c = idx - p * CT;
+        const int w = w0 + c;
+        float2 r = make_float2(0.f, 0.f);
+        if (w < W) {
+            const int hk = shifted(p, a.halfH, H);
+            const float2 k = res[idx];
+            const float2 yv = y[img + (long long)hk * W + w];
+            const float m = mrx_mask_val(mask, b, c_, hk, w);
+            r = make_float2(m * (k.x * a.scale - yv.x), m * (k.y * a.scale - yv.y));  // rim_utils.py:54
+        }
+        res[idx] = r;
+    }
+    __syncthreads();
+    float2* res2 = fft_lds_run<true>(res, oth, tw, a.plan, CT, 1, CT, true);
+    for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
+        const int p = idx / CT, c = idx - p * CT;
+        const int w = w0 + c;
+        if (w < W) {
+            float2 v = res2[idx];
+            out[img + (long long)shifted(p, a.halfH, H) * W + w] = make_float2(v.x * a.scale2, v.y * a.scale2);
+        }
+    }
+}
+
+struct ReduceArgs {
+    MrxFftPlan plan;
+    const float2* tw;
+    int C, H, W, g, halfW;
+    float scale;
+    float post;  // llg: 1/sigma^2
+};
+
+// inverse row FFT of every coil row (b, :, h), times conj(S), summed over coils (rim_utils.py:59-62, vn_block.py:87).
+// OUT 0: out[b,h,w] complex.  OUT 1: out4[b,0:4,h,w] = (eta_re, eta_im, g_re, g_im) (rim_utils.py:67).
+template <int OUT>
+__global__ __launch_bounds__(MRX_FFT_NT) void k_rows_reduce(const float2* __restrict__ k, const float2* __restrict__ S,
+                                                            const float2* __restrict__ eta, float* __restrict__ out,
+                                                            ReduceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int W = a.W, H = a.H, C = a.C, G = a.g;
+    float2* tw = smem;
+    float2* acc = smem + W;
+    float2* A = acc + W;
+    float2* B = A + G * W;
+    const int h = blockIdx.x;
+    const long long b = blockIdx.y;
+    for (int i = threadIdx.x; i < W; i += MRX_FFT_NT) {
+        tw[i] = a.tw[i];
+        acc[i] = make_float2(0.f, 0.f);
+    }
+    for (int c0 = 0; c0 < C; c0 += G) {
+        const int nrows = min(G, C - c0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nrows * W; idx += MRX_FFT_NT) {
+            const int r = idx / W, x = idx - r * W;
+            A[idx] = k[(((b * C + c0 + r) * H) + h) * W + shifted(x, a.halfW, W)];
+        }
+        __syncthreads();
+        float2* res = fft_lds_run<true>(A, B, tw, a.plan, nrows, W, 1, false);
+        for (int x = threadIdx.x; x < W; x += MRX_FFT_NT) {
+            const int g = shifted(x, a.halfW, W);
+            float2 s_acc = acc[x];
+            for (int r = 0; r < nrows; ++r) {
+                float2 v = res[r * W + x];
+                v.x *= a.scale;
+                v.y *= a.scale;
+                const float2 s = S[(((b * C + c0 + r) * H) + h) * W + g];
+                s_acc.x += v.x * s.x + v.y * s.y;  // re: rim_utils.py:61
+                s_acc.y += v.y * s.x - v.x * s.y;  // im: rim_utils.py:62
+            }
+            acc[x] = s_acc;
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += MRX_FFT_NT) {
+        const int g = shifted(x, a.halfW, W);
+        const float2 v = acc[x];
+        if (OUT == 0) {
+            ((float2*)out)[(b * H + h) * W + g] = v;
+        } else {
+            const float2 e = eta[(b * H + h) * W + g];
+            const long long plane = (long long)H * W;
+            float* o = out + b * 4 * plane + (long long)h * W + g;
+            o[0] = e.x;
+            o[plane] = e.y;
+            o[2 * plane] = v.x * a.post;
+            o[3 * plane] = v.y * a.post;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host launch helpers
+// ------------------------------------------------------------------------------------------------------------
+static inline int pick_rows(int W) {
+    int r = MRX_FFT_TILE_ELEMS / W;
+    return r < 1 ? 1 : (r > 16 ? 16 : r);
+}
+static inline int pick_cols(int H) {
+    int ct = 16;
+    while (ct > 1 && ct * H > MRX_FFT_TILE_ELEMS + 512) ct >>= 1;
+    return ct;
+}
+
+template <typename K>
+static int set_lds(K kern, size_t bytes) {
+    MRX_REQUIRE(bytes <= 160 * 1024, MRX_EUNSUP, "FFT tile needs %zu bytes of LDS", bytes);
+    if (bytes > 48 * 1024) MRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MRX_OK;
+}
+
+static int launch_rows(const float2* in, const float2* S, float2* out, long long rows_total, int W, int C, int H,
+                       int inverse, int norm, int centered, int expand, hipStream_t st) {
+    MrxFftEntry e;
+    int rc = mrx_get_plan(W, &e);
+    if (rc) return rc;
+    RowArgs a;
+    a.plan = e.plan;
+    a.tw = e.d_tw;
+    a.rows_total = rows_total;
+    a.W = W;
+    a.rpb = pick_rows(W);
+    a.halfW = centered ? W / 2 : 0;
+    a.scale = mrx_scale(W, inverse, norm);
+    a.C = C;
+    a.H = H;
+    const size_t lds = sizeof(float2) * ((size_t)W + 2 * (size_t)a.rpb * W);
+    const int grid = mrx_cdiv(rows_total, a.rpb);
+    if (expand) {
+        if ((rc = set_lds(k_fft_rows<false, 1>, lds))) return rc;
+        hipLaunchKernelGGL((k_fft_rows<false, 1>), dim3(grid), dim3(MRX_FFT_NT), lds, st, in, S, out, a);
+    } else if (inverse) {
+        if ((rc = set_lds(k_fft_rows<true, 0>, lds))) return rc;
+        hipLaunchKernelGGL((k_fft_rows<true, 0>), dim3(grid), dim3(MRX_FFT_NT), lds, st, in, S, out, a);
+    } else {
+        if ((rc = set_lds(k_fft_rows<false, 0>, lds))) return rc;
+        hipLaunchKernelGGL((k_fft_rows<false, 0>), dim3(grid), dim3(MRX_FFT_NT), lds, st, in, S, out, a);
+    }
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+static int make_col_args(ColArgs* a, int H, int W, int inverse, int norm, int centered) {
+    MrxFftEntry e;
+    int rc = mrx_get_plan(H, &e);
+    if (rc) return rc;
+    a->plan = e.plan;
+    a->tw = e.d_tw;
+    a->H = H;
+    a->W = W;
+    a->ct = pick_cols(H);
+    a->halfH = centered ? H / 2 : 0;
+    a->scale = mrx_scale(H, inverse, norm);
+    a->scale2 = 1.0f;
+    a->C = 1;
+    return MRX_OK;
+}
+
+static int launch_cols(const float2* in, float2* out, long long nimg, int H, int W, int inverse, int norm, int centered,
+                       hipStream_t st) {
+    ColArgs a;
+    int rc = make_col_args(&a, H, W, inverse, norm, centered);
+    if (rc) return rc;
+    MRX_REQUIRE(nimg <= 65535LL * 1, MRX_EUNSUP, "too many images in one column launch (%lld)", nimg);
+    const size_t lds = sizeof(float2) * ((size_t)H + 2 * (size_t)a.ct * H);
+    dim3 grid(mrx_cdiv(W, a.ct), (unsigned)nimg);
+    if (inverse) {
+        if ((rc = set_lds(k_fft_cols<true>, lds))) return rc;
+        hipLaunchKernelGGL(k_fft_cols<true>, grid, dim3(MRX_FFT_NT), lds, st, in, out, a);
+    } else {
+        if ((rc = set_lds(k_fft_cols<false>, lds))) return rc;
+        hipLaunchKernelGGL(k_fft_cols<false>, grid, dim3(MRX_FFT_NT), lds, st, in, out, a);
+    }
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+static int launch_reduce(const float2* k, const float2* S, const float2* eta, float* out, int B, int C, int H, int W,
+                         int norm, int centered, float post, int out_mode, hipStream_t st) {
+    MrxFftEntry e;
+    int rc = mrx_get_plan(W, &e);
+    if (rc) return rc;
+    ReduceArgs a;
+    a.plan = e.plan;
+    a.tw = e.d_tw;
+    a.C = C;
+    a.H = H;
+    a.W = W;
+    a.g = pick_rows(W);
+    if (a.g > C) a.g = C;
+    a.halfW = centered ? W / 2 : 0;
+    a.scale = mrx_scale(W, 1, norm);
+    a.post = post;
+    MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "batch %d too large", B);
+    const size_t lds = sizeof(float2) * (2 * (size_t)W + 2 * (size_t)a.g * W);
+    dim3 grid(H, B);
+    if (out_mode == 0) {
+        if ((rc = set_lds(k_rows_reduce<0>, lds))) return rc;
+        hipLaunchKernelGGL(k_rows_reduce<0>, grid, dim3(MRX_FFT_NT), lds, st, k, S, eta, out, a);
+    } else {
+        if ((rc = set_lds(k_rows_reduce<1>, lds))) return rc;
+        hipLaunchKernelGGL(k_rows_reduce<1>, grid, dim3(MRX_FFT_NT), lds, st, k, S, eta, out, a);
+    }
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int mrx_fft_max_len(void) { return MRX_FFT_MAX_LEN; }
+
+extern "C" int mrx_fft_prepare(int h, int w) {
+    MrxFftEntry e;
+    int rc = mrx_get_plan(h, &e);
+    if (rc) return rc;
+    return mrx_get_plan(w, &e);
+}
+
+static int norm_valid(int norm) { return norm >= 0 && norm <= 3; }
+
+extern "C" int mrx_fft2(const float* in, float* out, int64_t batch, int H, int W, int inverse, int norm, int centered,
+                        void* stream) {
+    MRX_REQUIRE(in && out, MRX_EINVAL, "mrx_fft2: null pointer");
+    MRX_REQUIRE(batch >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_fft2: bad dims batch=%lld H=%d W=%d", (long long)batch, H, W);
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_fft2: bad normalization %d", norm);
+    if (batch == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_rows((const float2*)in, nullptr, (float2*)out, batch * H, W, 1, H, inverse, norm, centered, 0, st);
+    if (rc) return rc;
+    for (int64_t i0 = 0; i0 < batch; i0 += 65535) {
+        const int64_t n = batch - i0 < 65535 ? batch - i0 : 65535;
+        float2* o = (float2*)out + i0 * H * W;
+        if ((rc = launch_cols(o, o, n, H, W, inverse, norm, centered, st))) return rc;
+    }
+    return MRX_OK;
+}
+
+extern "C" int mrx_sens_expand(const float* x, const float* S, float* out, int B, int C, int H, int W, int norm,
+                               int centered, void* stream) {
+    MRX_REQUIRE(x && S && out, MRX_EINVAL, "mrx_sens_expand: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_sens_expand: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_sens_expand: bad normalization %d", norm);
+    if (B == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_rows((const float2*)x, (const float2*)S, (float2*)out, (long long)B * C * H, W, C, H, 0, norm,
+                         centered, 1, st);
+    if (rc) return rc;
+    const long long nimg = (long long)B * C;
+    for (long long i0 = 0; i0 < nimg; i0 += 65535) {
+        const long long n = nimg - i0 < 65535 ? nimg - i0 : 65535;
+        float2* o = (float2*)out + i0 * H * W;
+        if ((rc = launch_cols(o, o, n, H, W, 0, norm, centered, st))) return rc;
+    }
+    return MRX_OK;
+}
+
+extern "C" int mrx_sens_reduce(const float* k, const float* S, float* out, float* work, int B, int C, int H, int W,
+                               int norm, int centered, void* stream) {
+    MRX_REQUIRE(k && S && out && work, MRX_EINVAL, "mrx_sens_reduce: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_sens_reduce: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_sens_reduce: bad normalization %d", norm);
+    if (B == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const long long nimg = (long long)B * C;
+    for (long long i0 = 0; i0 < nimg; i0 += 65535) {
+        const long long n = nimg - i0 < 65535 ? nimg - i0 : 65535;
+        if ((rc = launch_cols((const float2*)k + i0 * H * W, (float2*)work + i0 * H * W, n, H, W, 1, norm, centered, st)))
+            return rc;
+    }
+    return launch_reduce((const float2*)work, (const float2*)S, nullptr, out, B, C, H, W, norm, centered, 1.0f, 0, st);
+}
+
+extern "C" int mrx_llg(const float* eta, const float* y, const float* S, const void* mask, int mask_kind,
+                       const int64_t* mstride, float* out4, float* work, int B, int C, int H, int W, float inv_sigma2,
+                       int norm, int centered, void* stream) {
+    MRX_REQUIRE(eta && y && S && mask && mstride && out4 && work, MRX_EINVAL, "mrx_llg: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_llg: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_llg: bad normalization %d", norm);
+    MRX_REQUIRE(mask_kind == MRX_MASK_U8 || mask_kind == MRX_MASK_F32, MRX_EINVAL, "mrx_llg: bad mask kind %d", mask_kind);
+    MRX_REQUIRE((long long)B * C <= 65535, MRX_EUNSUP, "mrx_llg: B*C = %lld > 65535", (long long)B * C);
+    if (B == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // 1) rows: eta * S -> FFT_W                                   (rim_utils.py:44-51)
+    int rc = launch_rows((const float2*)eta, (const float2*)S, (float2*)work, (long long)B * C * H, W, C, H, 0, norm,
+                         centered, 1, st);
+    if (rc) return rc;
+    // 2) cols: FFT_H -> mask*(k - y) -> IFFT_H                    (rim_utils.py:51-58)
+    ColArgs a;
+    if ((rc = make_col_args(&a, H, W, 0, norm, centered))) return rc;
+    a.scale2 = mrx_scale(H, 1, norm);
+    a.C = C;
+    MrxMask m;
+    m.p = mask;
+    m.kind = mask_kind;
+    for (int i = 0; i < 4; ++i) m.s[i] = mstride[i];
+    const size_t lds = sizeof(float2) * ((size_t)H + 2 * (size_t)a.ct * H);
+    if ((rc = set_lds(k_cols_dc, lds))) return rc;
+    hipLaunchKernelGGL(k_cols_dc, dim3(mrx_cdiv(W, a.ct), B * C), dim3(MRX_FFT_NT), lds, st, (const float2*)work,
+                       (const float2*)y, m, (float2*)work, a);
+    MRX_LAUNCH_CHECK();
+    // 3) rows: IFFT_W -> sum_c conj(S) -> /sigma^2 -> [B,4,H,W]   (rim_utils.py:59-67)
+    return launch_reduce((const float2*)work, (const float2*)S, (const float2*)eta, out4, B, C, H, W, norm, centered,
+                         inv_sigma2, 1, st);
+}

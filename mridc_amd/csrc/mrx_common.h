@@ -1,0 +1,53 @@
+// mrx_common.h -- shared host-side helpers of libmridc_amd (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/mridc_amd.h"
+
+void mrx_set_error(const char* fmt, ...);
+
+#define MRX_REQUIRE(cond, code, ...)  \
+    do {                              \
+        if (!(cond)) {                \
+            mrx_set_error(__VA_ARGS__); \
+            return (code);            \
+        }                             \
+    } while (0)
+
+#define MRX_HIP(call)                                                                     \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            mrx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return MRX_EHIP;                                                              \
+        }                                                                                 \
+    } while (0)
+
+#define MRX_LAUNCH_CHECK()                                                                 \
+    do {                                                                                   \
+        hipError_t e__ = hipGetLastError();                                                \
+        if (e__ != hipSuccess) {                                                           \
+            mrx_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+            return MRX_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+static inline int mrx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// mask value as the multiplicative factor torch's type promotion gives (bool/uint8 -> float)
+struct MrxMask {
+    const void* p;
+    int kind;  // MRX_MASK_U8 / MRX_MASK_F32
+    long long s[4];
+};
+__device__ __forceinline__ float mrx_mask_val(const MrxMask& m, long long b, long long c, long long h, long long w) {
+    const long long off = b * m.s[0] + c * m.s[1] + h * m.s[2] + w * m.s[3];
+    return m.kind == MRX_MASK_U8 ? (float)((const unsigned char*)m.p)[off] : ((const float*)m.p)[off];
+}
+__device__ __forceinline__ bool mrx_mask_true(const MrxMask& m, long long b, long long c, long long h, long long w) {
+    const long long off = b * m.s[0] + c * m.s[1] + h * m.s[2] + w * m.s[3];
+    return m.kind == MRX_MASK_U8 ? ((const unsigned char*)m.p)[off] != 0 : ((const float*)m.p)[off] != 0.0f;
+}

@@ -1,0 +1,213 @@
+// unet.hip -- NormUnet support kernels (reference models/unet_base/unet_block.py): group-norm statistics with the
+// unbiased std (:71-91), zero / reflect / crop padding (:93-111, :215-222), InstanceNorm2d + LeakyReLU (:252-253),
+// 2x2 average pooling (:206), ConvTranspose2d(k=2, s=2) (:293), channel-block copy for the skip concat (:224).
+// The 3x3 / 1x1 convolutions themselves go through conv.hip.
+#include "mrx_common.h"
+
+#define UN_NT 256
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// block-wide sum, result broadcast to every thread (red: 4-float LDS scratch + 1)
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < UN_NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// ---- InstanceNorm2d (biased variance, eps) + activation, one workgroup per (b, c) plane -------------------------------
+__global__ __launch_bounds__(UN_NT) void k_instance_norm_act(const float* x, float* out, long long HW, float eps, int act,
+                                                             float slope) {
+    __shared__ float red[UN_NT / 64];
+    const float* p = x + (long long)blockIdx.x * HW;
+    float* q = out + (long long)blockIdx.x * HW;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < HW; i += UN_NT) s += p[i];
+    const float mean = block_sum(s, red) / (float)HW;
+    float v = 0.f;
+    for (long long i = threadIdx.x; i < HW; i += UN_NT) {
+        const float d = p[i] - mean;
+        v += d * d;
+    }
+    const float var = block_sum(v, red) / (float)HW;
+    const float inv = 1.0f / sqrtf(var + eps);
+    for (long long i = threadIdx.x; i < HW; i += UN_NT) {
+        float y = (p[i] - mean) * inv;
+        if (act == MRX_ACT_RELU)
+            y = y > 0.f ? y : 0.f;
+        else if (act == MRX_ACT_LEAKY)
+            y = y > 0.f ? y : y * slope;
+        q[i] = y;
+    }
+}
+extern "C" int mrx_instance_norm_act(const float* x, float* out, int64_t planes, int64_t HW, float eps, int act, float slope,
+                                     void* stream) {
+    MRX_REQUIRE(x && out && planes >= 0 && HW >= 1, MRX_EINVAL, "mrx_instance_norm_act: bad argument");
+    if (planes == 0) return MRX_OK;
+    MRX_REQUIRE(planes < (1LL << 31), MRX_EUNSUP, "mrx_instance_norm_act: too many planes");
+    hipLaunchKernelGGL(k_instance_norm_act, dim3((unsigned)planes), dim3(UN_NT), 0, (hipStream_t)stream, x, out, (long long)HW, eps,
+                       act, slope);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- group norm statistics: mean and UNBIASED std per group (unet_block.py:78-79) ---------------------------------------
+__global__ __launch_bounds__(UN_NT) void k_group_stats(const float* x, float* mean_o, float* std_o, long long n) {
+    __shared__ float red[UN_NT / 64];
+    const float* p = x + (long long)blockIdx.x * n;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += UN_NT) s += p[i];
+    const float mean = block_sum(s, red) / (float)n;
+    float v = 0.f;
+    for (long long i = threadIdx.x; i < n; i += UN_NT) {
+        const float d = p[i] - mean;
+        v += d * d;
+    }
+    const float ss = block_sum(v, red);
+    if (threadIdx.x == 0) {
+        mean_o[blockIdx.x] = mean;
+        std_o[blockIdx.x] = sqrtf(ss / (float)(n - 1));
+    }
+}
+extern "C" int mrx_group_norm_stats(const float* x, float* mean, float* std_, int64_t groups, int64_t n, void* stream) {
+    MRX_REQUIRE(x && mean && std_ && groups >= 0 && n >= 1, MRX_EINVAL, "mrx_group_norm_stats: bad argument");
+    if (groups == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_group_stats, dim3((unsigned)groups), dim3(UN_NT), 0, (hipStream_t)stream, x, mean, std_, (long long)n);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// inverse == 0: (x - mean) / std  (:81) ; inverse == 1: x * std + mean  (:91)
+__global__ void k_group_apply(const float* x, const float* mean, const float* std_, float* out, long long n, long long total,
+                              int inverse) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long g = o / n;
+        const float m = mean[g], s = std_[g];
+        out[o] = inverse ? x[o] * s + m : (x[o] - m) / s;
+    }
+}
+static inline int un_grid(long long n) {
+    long long g = (n + UN_NT - 1) / UN_NT;
+    if (g > 4096) g = 4096;
+    return g < 1 ? 1 : (int)g;
+}
+extern "C" int mrx_group_norm_apply(const float* x, const float* mean, const float* std_, float* out, int64_t groups, int64_t n,
+                                    int inverse, void* stream) {
+    MRX_REQUIRE(x && mean && std_ && out && groups >= 0 && n >= 1, MRX_EINVAL, "mrx_group_norm_apply: bad argument");
+    const long long total = groups * n;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_group_apply, dim3(un_grid(total)), dim3(UN_NT), 0, (hipStream_t)stream, x, mean, std_, out, (long long)n,
+                       total, inverse);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- pad / crop: out[y][x] = in[y - top][x - left]; outside: 0 (mode 0) or reflect (mode 1).  Negative pads crop. --------
+__global__ void k_pad2d(const float* in, float* out, long long planes, int H, int W, int top, int left, int OH, int OW, int mode) {
+    const long long total = planes * OH * OW;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(o % OW);
+        const long long r = o / OW;
+        const int oy = (int)(r % OH);
+        const long long p = r / OH;
+        int iy = oy - top, ix = ox - left;
+        float v = 0.f;
+        if (mode == 1) {
+            iy = iy < 0 ? -iy : (iy >= H ? 2 * (H - 1) - iy : iy);
+            ix = ix < 0 ? -ix : (ix >= W ? 2 * (W - 1) - ix : ix);
+            v = in[(p * H + iy) * W + ix];
+        } else if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            v = in[(p * H + iy) * W + ix];
+        }
+        out[o] = v;
+    }
+}
+extern "C" int mrx_pad2d(const float* in, float* out, int64_t planes, int H, int W, int top, int bottom, int left, int right,
+                         int mode, void* stream) {
+    MRX_REQUIRE(in && out && planes >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_pad2d: bad argument");
+    const int OH = H + top + bottom, OW = W + left + right;
+    MRX_REQUIRE(OH >= 1 && OW >= 1, MRX_EINVAL, "mrx_pad2d: empty output");
+    MRX_REQUIRE(mode == 0 || (top < H && bottom < H && left < W && right < W), MRX_EINVAL, "mrx_pad2d: reflect pad too large");
+    if (planes == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_pad2d, dim3(un_grid(planes * OH * OW)), dim3(UN_NT), 0, (hipStream_t)stream, in, out, (long long)planes, H,
+                       W, top, left, OH, OW, mode);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- avg_pool2d(kernel 2, stride 2, no padding): floor sizes (unet_block.py:206) ------------------------------------------
+__global__ void k_avgpool(const float* in, float* out, long long planes, int H, int W, int OH, int OW) {
+    const long long total = planes * OH * OW;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(o % OW);
+        const long long r = o / OW;
+        const int oy = (int)(r % OH);
+        const long long p = r / OH;
+        const float* q = in + (p * H + 2 * oy) * W + 2 * ox;
+        out[o] = (q[0] + q[1] + q[W] + q[W + 1]) * 0.25f;
+    }
+}
+extern "C" int mrx_avg_pool2x2(const float* in, float* out, int64_t planes, int H, int W, void* stream) {
+    MRX_REQUIRE(in && out && planes >= 0 && H >= 2 && W >= 2, MRX_EINVAL, "mrx_avg_pool2x2: bad argument");
+    if (planes == 0) return MRX_OK;
+    const int OH = H / 2, OW = W / 2;
+    hipLaunchKernelGGL(k_avgpool, dim3(un_grid(planes * OH * OW)), dim3(UN_NT), 0, (hipStream_t)stream, in, out, (long long)planes,
+                       H, W, OH, OW);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- ConvTranspose2d(kernel 2, stride 2, no bias): out[b,co,2y+dy,2x+dx] = sum_ci x[b,ci,y,x] * w[ci,co,dy,dx] --------------
+__global__ void k_convT2x2(const float* x, const float* w, float* out, int B, int Cin, int Cout, int H, int W) {
+    const int OH = 2 * H, OW = 2 * W;
+    const long long total = (long long)B * Cout * OH * OW;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(o % OW);
+        long long r = o / OW;
+        const int oy = (int)(r % OH);
+        r /= OH;
+        const int co = (int)(r % Cout);
+        const int b = (int)(r / Cout);
+        const int y = oy >> 1, dy = oy & 1, xx = ox >> 1, dx = ox & 1;
+        const float* xp = x + ((long long)b * Cin * H + y) * W + xx;
+        const float* wp = w + ((long long)co * 2 + dy) * 2 + dx;
+        float acc = 0.f;
+        for (int ci = 0; ci < Cin; ++ci) acc += xp[(long long)ci * H * W] * wp[(long long)ci * Cout * 4];
+        out[o] = acc;
+    }
+}
+extern "C" int mrx_conv_transpose2x2(const float* x, const float* w, float* out, int B, int Cin, int Cout, int H, int W,
+                                     void* stream) {
+    MRX_REQUIRE(x && w && out && B >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_transpose2x2: bad argument");
+    if (B == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_convT2x2, dim3(un_grid((long long)B * Cout * 4 * H * W)), dim3(UN_NT), 0, (hipStream_t)stream, x, w, out, B,
+                       Cin, Cout, H, W);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- copy a [B,C,HW] tensor into channels [c0, c0+C) of a [B,Ctot,HW] tensor (skip concat, unet_block.py:224) -------------
+__global__ void k_copy_channels(const float* src, float* dst, int C, long long HW, int Ctot, int c0, long long total) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long per_b = (long long)C * HW;
+        const long long b = o / per_b, r = o - b * per_b;
+        dst[(b * Ctot + c0) * HW + r] = src[o];
+    }
+}
+extern "C" int mrx_copy_channels(const float* src, float* dst, int B, int C, int64_t HW, int Ctot, int c0, void* stream) {
+    MRX_REQUIRE(src && dst && B >= 0 && C >= 0 && HW >= 0 && c0 >= 0 && c0 + C <= Ctot, MRX_EINVAL, "mrx_copy_channels: bad argument");
+    const long long total = (long long)B * C * HW;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_copy_channels, dim3(un_grid(total)), dim3(UN_NT), 0, (hipStream_t)stream, src, dst, C, (long long)HW, Ctot, c0,
+                       total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

@@ -1,0 +1,270 @@
+"""Thin tensor-level wrappers over the C ABI (include/mridc_amd.h) used by the model mirrors.
+
+Each wrapper validates shapes, allocates the output with torch (torch owns device memory), and launches the HIP
+kernels on the current stream.  No arithmetic happens in Python/torch here.
+"""
+import torch
+
+from mridc_amd import _lib
+from mridc_amd._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, PAD_REPLICATE, PAD_ZERO  # noqa: F401
+
+
+def _norm(normalization):
+    key = str(normalization).lower()
+    if key not in _lib.NORM:
+        raise ValueError(f"Unknown fft normalization '{normalization}'")
+    return _lib.NORM[key]
+
+
+def _check_last_two(spatial_dims, ndim_complex):
+    dims = [-2, -1] if spatial_dims is None else [int(d) for d in spatial_dims]
+    dims = sorted(d % ndim_complex for d in dims)
+    if dims != [ndim_complex - 2, ndim_complex - 1]:
+        raise NotImplementedError("the fused MRI operators transform the last two spatial dims only "
+                                  f"(got spatial_dims={list(spatial_dims)})")
+
+
+def _bchw(t):
+    if t.dim() != 5 or t.shape[-1] != 2:
+        raise ValueError(f"expected a [B,C,H,W,2] tensor, got {tuple(t.shape)}")
+    return int(t.shape[0]), int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
+
+
+def sens_expand(x, sens, centered, normalization, spatial_dims=None):
+    """fft2(complex_mul(x, S)).  x [B,H,W,2] or [B,1,H,W,2]; S [B,C,H,W,2] -> [B,C,H,W,2]."""
+    sens = _lib.f32c(sens)
+    B, C, H, W = _bchw(sens)
+    _check_last_two(spatial_dims, 4)
+    x = _lib.f32c(x)
+    if x.dim() == 5 and x.shape[1] == 1:
+        x = x.reshape(B, H, W, 2)
+    if tuple(x.shape) != (B, H, W, 2):
+        raise ValueError(f"sens_expand: image shape {tuple(x.shape)} does not match maps {tuple(sens.shape)}")
+    out = torch.empty_like(sens)
+    _lib.check(_lib.lib().mrx_sens_expand(_lib.ptr(x), _lib.ptr(sens), _lib.ptr(out), B, C, H, W, _norm(normalization),
+                                          int(bool(centered)), _lib.stream_ptr()), "mrx_sens_expand")
+    return out
+
+
+def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None):
+    """sum_c ifft2(k) * conj(S) -> [B,H,W,2]."""
+    k, sens = _lib.f32c(k), _lib.f32c(sens)
+    B, C, H, W = _bchw(k)
+    if sens.shape != k.shape:
+        raise ValueError(f"sens_reduce: k-space {tuple(k.shape)} vs maps {tuple(sens.shape)}")
+    _check_last_two(spatial_dims, 4)
+    if work is None:
+        work = torch.empty_like(k)
+    out = torch.empty(B, H, W, 2, dtype=torch.float32, device=k.device)
+    _lib.check(_lib.lib().mrx_sens_reduce(_lib.ptr(k), _lib.ptr(sens), _lib.ptr(out), _lib.ptr(work), B, C, H, W,
+                                          _norm(normalization), int(bool(centered)), _lib.stream_ptr()), "mrx_sens_reduce")
+    return out
+
+
+def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, out=None, work=None):
+    """log_likelihood_gradient -> [B,4,H,W]."""
+    y, sens, eta = _lib.f32c(y), _lib.f32c(sens), _lib.f32c(eta)
+    B, C, H, W = _bchw(y)
+    if sens.shape != y.shape:
+        raise ValueError(f"log_likelihood_gradient: k-space {tuple(y.shape)} vs maps {tuple(sens.shape)}")
+    if tuple(eta.shape) != (B, H, W, 2):
+        raise ValueError(f"log_likelihood_gradient: eta {tuple(eta.shape)} does not match {(B, H, W, 2)}")
+    _check_last_two(spatial_dims, 4)
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    if out is None:
+        out = torch.empty(B, 4, H, W, dtype=torch.float32, device=y.device)
+    if work is None:
+        work = torch.empty_like(y)
+    _lib.check(_lib.lib().mrx_llg(_lib.ptr(eta), _lib.ptr(y), _lib.ptr(sens), _lib.ptr(m), kind, ms, _lib.ptr(out),
+                                  _lib.ptr(work), B, C, H, W, float(1.0 / (float(sigma) ** 2.0)), _norm(normalization),
+                                  int(bool(centered)), _lib.stream_ptr()), "mrx_llg")
+    return out
+
+
+def soft_dc(pred, ref, mask, dc_weight):
+    """where(mask, pred - ref, 0) * dc_weight."""
+    pred, ref = _lib.f32c(pred), _lib.f32c(ref)
+    B, C, H, W = _bchw(pred)
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    w = _lib.f32c(dc_weight.detach().reshape(-1))
+    out = torch.empty_like(pred)
+    _lib.check(_lib.lib().mrx_soft_dc(_lib.ptr(pred), _lib.ptr(ref), _lib.ptr(m), kind, ms, _lib.ptr(w), _lib.ptr(out),
+                                      B, C, H, W, _lib.stream_ptr()), "mrx_soft_dc")
+    return out
+
+
+def dc_combine(base, pred, ref, mask, dc_weight, eta_k):
+    """base - where(mask, pred - ref, 0) * dc_weight - eta_k."""
+    base, pred, ref, eta_k = _lib.f32c(base), _lib.f32c(pred), _lib.f32c(ref), _lib.f32c(eta_k)
+    B, C, H, W = _bchw(pred)
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    w = _lib.f32c(dc_weight.detach().reshape(-1))
+    out = torch.empty_like(pred)
+    _lib.check(_lib.lib().mrx_dc_combine(_lib.ptr(base), _lib.ptr(pred), _lib.ptr(ref), _lib.ptr(m), kind, ms, _lib.ptr(w),
+                                         _lib.ptr(eta_k), _lib.ptr(out), B, C, H, W, _lib.stream_ptr()), "mrx_dc_combine")
+    return out
+
+
+def _nchw(x):
+    if x.dim() != 4:
+        raise ValueError(f"expected a [B,C,H,W] tensor, got {tuple(x.shape)}")
+    return [int(v) for v in x.shape]
+
+
+def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
+    """'same' conv, stride 1, square odd kernel (mrx_conv2d)."""
+    x, weight = _lib.f32c(x), _lib.f32c(weight.detach())
+    B, Cin, H, W = _nchw(x)
+    Cout, Cin_w, kh, kw = [int(v) for v in weight.shape]
+    if Cin_w != Cin:
+        raise RuntimeError(f"input has inconsistent input_size: got {Cin}, expected {Cin_w}")
+    if kh != kw:
+        raise NotImplementedError("square kernels only")
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    if out is None:
+        out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_conv2d(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W, kh,
+                                     int(dilation), int(pad_mode), int(act), float(slope), _lib.stream_ptr()), "mrx_conv2d")
+    return out
+
+
+def indrnn_cell(x, w_ih, b_ih, hh, h_prev, dilation=1, out=None):
+    x, w_ih = _lib.f32c(x), _lib.f32c(w_ih.detach())
+    B, Cin, H, W = _nchw(x)
+    F, Cin_w, k, _ = [int(v) for v in w_ih.shape]
+    if Cin_w != Cin:
+        raise RuntimeError(f"input has inconsistent input_size: got {Cin}, expected {Cin_w}")
+    b = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    if out is None:
+        out = torch.empty(B, F, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_indrnn_cell(_lib.ptr(x), _lib.ptr(w_ih), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out),
+                                          B, Cin, F, H, W, k, int(dilation), _lib.stream_ptr()), "mrx_indrnn_cell")
+    return out
+
+
+def rim_layer_indrnn(x, w_conv, b_conv, k, dilation, w_ih, b_ih, hh, h_prev, out=None):
+    """Fused ConvNonlinear(ReLU, replicate pad) + IndRNNCell(1x1)."""
+    x, w_conv, w_ih = _lib.f32c(x), _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
+    B, Cin, H, W = _nchw(x)
+    F = int(w_conv.shape[0])
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    if out is None:
+        out = torch.empty(B, F, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_rim_layer_indrnn(_lib.ptr(x), _lib.ptr(w_conv), _lib.ptr(bc), _lib.ptr(w_ih), _lib.ptr(bi),
+                                               _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), B, Cin, F, H, W, int(k),
+                                               int(dilation), _lib.stream_ptr()), "mrx_rim_layer_indrnn")
+    return out
+
+
+def rim_final(h, weight, bias, k, dilation, eta):
+    """eta + permute(conv_reppad(h)) with a 2-channel conv -> [B,H,W,2]."""
+    h, weight, eta = _lib.f32c(h), _lib.f32c(weight.detach()), _lib.f32c(eta)
+    B, F, H, W = _nchw(h)
+    if int(weight.shape[0]) != 2 or tuple(eta.shape) != (B, H, W, 2):
+        raise ValueError("rim_final expects a 2-channel final conv and eta of shape [B,H,W,2]")
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    out = torch.empty_like(eta)
+    _lib.check(_lib.lib().mrx_rim_final(_lib.ptr(h), _lib.ptr(weight), _lib.ptr(b), _lib.ptr(eta), _lib.ptr(out), B, F, H, W,
+                                        int(k), int(dilation), _lib.stream_ptr()), "mrx_rim_final")
+    return out
+
+
+def gru_gates(ih, hh, h):
+    ih, hh, h = _lib.f32c(ih), _lib.f32c(hh), _lib.f32c(h)
+    B, F, H, W = _nchw(h)
+    out = torch.empty_like(h)
+    _lib.check(_lib.lib().mrx_gru_gates(_lib.ptr(ih), _lib.ptr(hh), _lib.ptr(h), _lib.ptr(out), B, F, H * W, _lib.stream_ptr()),
+               "mrx_gru_gates")
+    return out
+
+
+def mgu_gates(ih, hh, h):
+    ih, hh, h = _lib.f32c(ih), _lib.f32c(hh), _lib.f32c(h)
+    B, F, H, W = _nchw(h)
+    out = torch.empty_like(h)
+    _lib.check(_lib.lib().mrx_mgu_gates(_lib.ptr(ih), _lib.ptr(hh), _lib.ptr(h), _lib.ptr(out), B, F, H * W, _lib.stream_ptr()),
+               "mrx_mgu_gates")
+    return out
+
+
+# ---- NormUnet pieces -------------------------------------------------------------------------------------------
+def instance_norm_act(x, eps=1e-5, act=ACT_LEAKY, slope=0.2, inplace=True):
+    x = _lib.f32c(x)
+    B, C, H, W = _nchw(x)
+    out = x if inplace else torch.empty_like(x)
+    _lib.check(_lib.lib().mrx_instance_norm_act(_lib.ptr(x), _lib.ptr(out), B * C, H * W, float(eps), int(act), float(slope),
+                                                _lib.stream_ptr()), "mrx_instance_norm_act")
+    return out
+
+
+def group_norm(x, groups):
+    """(x - mean)/std per (b, group) with the unbiased std.  Returns (normalised, mean[B,G,1], std[B,G,1])."""
+    x = _lib.f32c(x)
+    B, C, H, W = _nchw(x)
+    n = (C * H * W) // groups
+    mean = torch.empty(B, groups, 1, dtype=torch.float32, device=x.device)
+    std = torch.empty_like(mean)
+    out = torch.empty_like(x)
+    L = _lib.lib()
+    _lib.check(L.mrx_group_norm_stats(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(std), B * groups, n, _lib.stream_ptr()),
+               "mrx_group_norm_stats")
+    _lib.check(L.mrx_group_norm_apply(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(out), B * groups, n, 0,
+                                      _lib.stream_ptr()), "mrx_group_norm_apply")
+    return out, mean, std
+
+
+def group_unnorm(x, mean, std, groups):
+    x = _lib.f32c(x)
+    B, C, H, W = _nchw(x)
+    n = (C * H * W) // groups
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().mrx_group_norm_apply(_lib.ptr(x), _lib.ptr(_lib.f32c(mean)), _lib.ptr(_lib.f32c(std)), _lib.ptr(out),
+                                               B * groups, n, 1, _lib.stream_ptr()), "mrx_group_norm_apply")
+    return out
+
+
+def pad2d(x, top, bottom, left, right, mode=0):
+    """Zero (mode 0; negative values crop) or reflect (mode 1) padding of the last two dims."""
+    x = _lib.f32c(x)
+    B, C, H, W = _nchw(x)
+    out = torch.empty(B, C, H + top + bottom, W + left + right, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_pad2d(_lib.ptr(x), _lib.ptr(out), B * C, H, W, int(top), int(bottom), int(left), int(right),
+                                    int(mode), _lib.stream_ptr()), "mrx_pad2d")
+    return out
+
+
+def avg_pool2x2(x):
+    x = _lib.f32c(x)
+    B, C, H, W = _nchw(x)
+    out = torch.empty(B, C, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_avg_pool2x2(_lib.ptr(x), _lib.ptr(out), B * C, H, W, _lib.stream_ptr()), "mrx_avg_pool2x2")
+    return out
+
+
+def conv_transpose2x2(x, weight):
+    x, weight = _lib.f32c(x), _lib.f32c(weight.detach())
+    B, Cin, H, W = _nchw(x)
+    Cin_w, Cout, kh, kw = [int(v) for v in weight.shape]
+    if Cin_w != Cin or kh != 2 or kw != 2:
+        raise ValueError("conv_transpose2x2 expects weight [Cin,Cout,2,2]")
+    out = torch.empty(B, Cout, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_conv_transpose2x2(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(out), B, Cin, Cout, H, W,
+                                                _lib.stream_ptr()), "mrx_conv_transpose2x2")
+    return out
+
+
+def concat_channels(a, b):
+    """torch.cat([a, b], dim=1) as two device copies into one buffer."""
+    a, b = _lib.f32c(a), _lib.f32c(b)
+    B, Ca, H, W = _nchw(a)
+    Cb = int(b.shape[1])
+    out = torch.empty(B, Ca + Cb, H, W, dtype=torch.float32, device=a.device)
+    L = _lib.lib()
+    _lib.check(L.mrx_copy_channels(_lib.ptr(a), _lib.ptr(out), B, Ca, H * W, Ca + Cb, 0, _lib.stream_ptr()), "mrx_copy_channels")
+    _lib.check(L.mrx_copy_channels(_lib.ptr(b), _lib.ptr(out), B, Cb, H * W, Ca + Cb, Ca, _lib.stream_ptr()), "mrx_copy_channels")
+    return out

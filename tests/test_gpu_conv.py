@@ -1,0 +1,138 @@
+"""GPU parity: the MFMA convolution / recurrent-cell / NormUnet kernels against plain torch fp32 CPU references
+(the oracle's building blocks).  Tolerance: rel-L2 <= 1e-5 (fp32 fma chains in a different summation order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from tests._util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+CASES = [  # B, Cin, Cout, H, W, k, dil
+    (1, 4, 64, 16, 12, 5, 1), (2, 64, 64, 13, 18, 3, 2), (1, 64, 64, 40, 70, 3, 2), (1, 3, 5, 9, 33, 3, 1),
+    (2, 7, 33, 17, 19, 3, 1), (1, 2, 14, 32, 16, 3, 1), (1, 28, 14, 15, 12, 3, 1), (1, 16, 48, 16, 12, 3, 1),
+    (1, 64, 64, 8, 32, 1, 1), (1, 5, 96, 10, 37, 5, 2), (1, 1, 1, 1, 1, 3, 1), (1, 18, 130, 9, 9, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("pad_mode", ["zero", "replicate"])
+def test_conv2d_vs_torch(case, pad_mode, dev):
+    from mridc_amd import ops
+    B, Cin, Cout, H, W, k, dil = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    p = dil * (k - 1) // 2
+    if pad_mode == "replicate":
+        ref = F.conv2d(F.pad(x, (p, p, p, p), mode="replicate") if p else x, w, b, dilation=dil)
+        got = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), dil, ops.PAD_REPLICATE, ops.ACT_RELU)
+        ref = F.relu(ref)
+    else:
+        ref = F.leaky_relu(F.conv2d(x, w, None, padding=p, dilation=dil), 0.2)
+        got = ops.conv2d(x.to(dev), w.to(dev), None, dil, ops.PAD_ZERO, ops.ACT_LEAKY, 0.2)
+    assert_close(got, ref, 1e-5, f"conv2d {case} {pad_mode}")
+
+
+def test_conv2d_small_cout_and_identity(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for (Cin, Cout, k) in ((14, 2, 1), (64, 2, 3), (8, 4, 3), (6, 1, 5), (5, 3, 3)):
+        x = torch.randn(2, Cin, 11, 35, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g)
+        b = torch.randn(Cout, generator=g)
+        ref = F.conv2d(x, w, b, padding=(k - 1) // 2)
+        assert_close(ops.conv2d(x.to(dev), w.to(dev), b.to(dev), 1, ops.PAD_ZERO), ref, 1e-5, f"small conv {Cin}->{Cout}")
+    # transpose-detecting check: identity kernel with an asymmetric input must return the input
+    x = torch.arange(2 * 33 * 9 * 40, dtype=torch.float32).reshape(2, 33, 9, 40) / 1000
+    w = torch.zeros(33, 33, 3, 3)
+    for c in range(33):
+        w[c, c, 1, 1] = 1.0
+    assert_close(ops.conv2d(x.to(dev), w.to(dev), None, 1, ops.PAD_ZERO), x, 1e-7, "identity conv")
+
+
+@pytest.mark.parametrize("F_", [32, 64])
+@pytest.mark.parametrize("shape", [(1, 4, 16, 12, 5, 1), (2, 64, 13, 18, 3, 2), (1, 64, 24, 70, 3, 2)])
+def test_fused_rim_layer_vs_unfused_reference(F_, shape, dev):
+    from mridc_amd import ops
+    B, Cin, H, W, k, dil = shape
+    g = torch.Generator().manual_seed(F_ + sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wc = torch.randn(F_, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bc = torch.randn(F_, generator=g) * 0.1
+    wi = torch.randn(F_, F_, 1, 1, generator=g) / F_ ** 0.5
+    bi = torch.randn(F_, generator=g) * 0.1
+    hh = torch.randn(1, F_, 1, 1, generator=g) * 0.5
+    hp = torch.randn(B, F_, H, W, generator=g)
+    ref = oracle.rim.indrnn_cell(oracle.rim.conv_nonlinear(x, wc, bc, k, dil, "relu"), hp, wi, bi, hh, 1, 1)
+    got = ops.rim_layer_indrnn(x.to(dev), wc.to(dev), bc.to(dev), k, dil, wi.to(dev), bi.to(dev), hh.to(dev), hp.to(dev))
+    assert_close(got, ref, 1e-5, f"fused layer F={F_} {shape}")
+    ref0 = oracle.rim.indrnn_cell(oracle.rim.conv_nonlinear(x, wc, None, k, dil, "relu"), torch.zeros_like(hp), wi, None, hh, 1, 1)
+    got0 = ops.rim_layer_indrnn(x.to(dev), wc.to(dev), None, k, dil, wi.to(dev), None, hh.to(dev), None)
+    assert_close(got0, ref0, 1e-5, "fused layer, no biases, h_prev = None")
+
+
+def test_cells_vs_oracle(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, Cin, Fh, H, W = 2, 16, 16, 13, 18
+    x = torch.randn(B, Cin, H, W, generator=g)
+    h = torch.randn(B, Fh, H, W, generator=g)
+    for k, d in ((1, 1), (3, 1), (3, 2)):
+        wi = torch.randn(Fh, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        bi = torch.randn(Fh, generator=g)
+        hh = torch.randn(1, Fh, 1, 1, generator=g)
+        assert_close(ops.indrnn_cell(x.to(dev), wi.to(dev), bi.to(dev), hh.to(dev), h.to(dev), d),
+                     oracle.rim.indrnn_cell(x, h, wi, bi, hh, k, d), 1e-5, f"indrnn k={k} d={d}")
+        w3 = torch.randn(3 * Fh, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        b3 = torch.randn(3 * Fh, generator=g)
+        u3 = torch.randn(3 * Fh, Fh, k, k, generator=g) / (Fh * k * k) ** 0.5
+        ih = ops.conv2d(x.to(dev), w3.to(dev), b3.to(dev), d, ops.PAD_ZERO)
+        hhc = ops.conv2d(h.to(dev), u3.to(dev), None, d, ops.PAD_ZERO)
+        assert_close(ops.gru_gates(ih, hhc, h.to(dev)), oracle.rim.convgru_cell(x, h, w3, b3, u3, k, d), 1e-5, "gru")
+        ih2 = ops.conv2d(x.to(dev), w3[:2 * Fh].to(dev), b3[:2 * Fh].to(dev), d, ops.PAD_ZERO)
+        hh2 = ops.conv2d(h.to(dev), u3[:2 * Fh].to(dev), None, d, ops.PAD_ZERO)
+        assert_close(ops.mgu_gates(ih2, hh2, h.to(dev)), oracle.rim.convmgu_cell(x, h, w3[:2 * Fh], b3[:2 * Fh], u3[:2 * Fh], k, d),
+                     1e-5, "mgu")
+
+
+def test_rim_final_vs_oracle(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for (B, Fh, H, W, k, d) in ((1, 64, 16, 12, 3, 1), (2, 16, 13, 37, 3, 1), (1, 8, 9, 9, 5, 2)):
+        h = torch.randn(B, Fh, H, W, generator=g)
+        w = torch.randn(2, Fh, k, k, generator=g) / (Fh * k * k) ** 0.5
+        eta = torch.randn(B, H, W, 2, generator=g)
+        ref = eta + oracle.rim.conv_nonlinear(h, w, None, k, d, None).permute(0, 2, 3, 1)
+        assert_close(ops.rim_final(h.to(dev), w.to(dev), None, k, d, eta.to(dev)), ref, 1e-5, "rim_final")
+
+
+def test_unet_pieces_vs_torch(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 6, 17, 22, generator=g) * 3 + 1
+    assert_close(ops.instance_norm_act(x.to(dev), 1e-5, ops.ACT_LEAKY, 0.2, inplace=False),
+                 F.leaky_relu(F.instance_norm(x, eps=1e-5), 0.2), 1e-5, "instance norm + leaky")
+    xn, mean, std = ops.group_norm(x.to(dev), 2)
+    gx = x.reshape(2, 2, -1)
+    assert_close(mean, gx.mean(-1, keepdim=True), 1e-6, "group mean")
+    assert_close(std, gx.std(-1, keepdim=True), 1e-6, "group std (unbiased)")
+    assert_close(xn, ((gx - gx.mean(-1, keepdim=True)) / gx.std(-1, keepdim=True)).reshape(x.shape), 1e-5, "group norm")
+    assert_close(ops.group_unnorm(xn, mean, std, 2), x, 1e-5, "group unnorm")
+    assert_close(ops.pad2d(x.to(dev), 2, 3, 1, 4, 0), F.pad(x, (1, 4, 2, 3)), 0.0 + 1e-12, "zero pad")
+    assert_close(ops.pad2d(x.to(dev), 0, 1, 0, 1, 1), F.pad(x, (0, 1, 0, 1), "reflect"), 1e-12, "reflect pad")
+    assert_close(ops.pad2d(ops.pad2d(x.to(dev), 2, 3, 1, 4, 0), -2, -3, -1, -4, 0), x, 1e-12, "unpad")
+    assert_close(ops.avg_pool2x2(x.to(dev)), F.avg_pool2d(x, 2, 2), 1e-6, "avg pool")
+    w = torch.randn(6, 4, 2, 2, generator=g)
+    assert_close(ops.conv_transpose2x2(x.to(dev), w.to(dev)), F.conv_transpose2d(x, w, stride=2), 1e-5, "conv transpose")
+    y = torch.randn(2, 3, 17, 22, generator=g)
+    assert_close(ops.concat_channels(x.to(dev), y.to(dev)), torch.cat([x, y], 1), 1e-12, "concat")

@@ -1,0 +1,212 @@
+"""GPU parity: the HIP operators (through the C ABI) against the committed goldens and the oracle on the same inputs.
+
+Tolerances: operators rel-L2 <= 1e-5 (norm-relative); index / mask-select work bit-exact;
+pointwise complex arithmetic bit-exact (elementwise.hip is built without fp contraction)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests._util import T, assert_close, assert_exact, meta
+
+pytestmark = pytest.mark.gpu
+
+NORMS = ["backward", "ortho", "forward", "none"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from mridc_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def test_g1_fft_goldens(golden, dev):
+    import mridc_amd.collections.common.parts.fft as fft
+    z = golden("g1_fft.npz")
+    for cn in ("a33", "a46", "a1084", "r1318", "r1512", "r1719", "r3124"):
+        x = T(z[f"{cn}/x"]).to(dev)
+        for c in (0, 1):
+            for n in NORMS:
+                assert_close(fft.fft2(x, bool(c), n, [-2, -1]), T(z[f"{cn}/fft2/c{c}/{n}"]), 1e-5, f"{cn} fft2 c{c} {n}")
+                assert_close(fft.ifft2(x, bool(c), n, [-2, -1]), T(z[f"{cn}/ifft2/c{c}/{n}"]), 1e-5, f"{cn} ifft2 c{c} {n}")
+    x = T(z["sd/x"]).to(dev)
+    assert_close(fft.fft2(x, True, "ortho", [-3, -2]), T(z["sd/fft2_m3m2"]), 1e-5, "spatial_dims [-3,-2]")
+    assert_close(fft.ifft2(x, False, "backward", [1, 2]), T(z["sd/ifft2_12"]), 1e-5, "spatial_dims [1,2]")
+    xc = torch.view_as_complex(T(z["cplx/x"])).to(dev)
+    assert_close(fft.fft2(xc, True, "ortho"), T(z["cplx/fft2"]), 1e-5, "complex input")
+    assert_close(fft.fft2c(T(z["cplx/x"]).to(dev)), T(z["cplx/fft2"]), 1e-5, "fft2c alias")
+
+
+def test_g1_fft_headline_size(golden, dev):
+    """[1,15,640,372] against the reference's strided samples + l2 (fixture holds checksums only)."""
+    import mridc_amd.collections.common.parts.fft as fft
+    z = golden("g1_fft.npz")
+    x = torch.randn(1, 15, 640, 372, 2, generator=torch.Generator().manual_seed(17)).to(dev)
+    for c, n in ((0, "backward"), (1, "ortho")):
+        for nm, fn in (("fft2", fft.fft2), ("ifft2", fft.ifft2)):
+            y = fn(x, centered=bool(c), normalization=n).reshape(-1).cpu()
+            ref_s = T(z[f"big/{nm}/c{c}/{n}/sample"])
+            got_s = y[::9973]
+            assert np.linalg.norm((got_s - ref_s).double().numpy()) <= 1e-5 * np.linalg.norm(ref_s.double().numpy()), (nm, c, n)
+            assert abs(float(y.double().norm()) - float(z[f"big/{nm}/c{c}/{n}/l2"][0])) <= 1e-5 * float(z[f"big/{nm}/c{c}/{n}/l2"][0])
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 1, 7), (2, 7, 1), (1, 49, 121), (1, 127, 64), (2, 100, 77), (1, 320, 320),
+                                   (1, 256, 256), (1, 1024, 6), (1, 5, 2310)])
+def test_fft_vs_float64(shape, dev):
+    """Awkward lengths (primes, prime powers, long) against numpy float64; round trip ifft2(fft2(x)) == x."""
+    import mridc_amd.collections.common.parts.fft as fft
+    b, h, w = shape
+    x = torch.randn(b, h, w, 2, generator=torch.Generator().manual_seed(h * 1000 + w))
+    xc = oracle.utils.tensor_to_complex_np(x)
+    for centered, norm in ((False, "backward"), (True, "ortho")):
+        got = oracle.utils.tensor_to_complex_np(fft.fft2(x.to(dev), centered, norm).cpu())
+        ref = oracle.fft.fft2_np64(xc, centered, norm)
+        assert np.linalg.norm(got - ref) <= 2e-6 * np.linalg.norm(ref), (shape, centered, norm)
+        back = fft.ifft2(fft.fft2(x.to(dev), centered, norm), centered, norm).cpu()
+        assert_close(back, x, 2e-6, f"round trip {shape}")
+
+
+def test_fft_linearity_and_batch_independence(dev):
+    import mridc_amd.collections.common.parts.fft as fft
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(3, 2, 24, 20, 2, generator=g).to(dev)
+    b = torch.randn(3, 2, 24, 20, 2, generator=g).to(dev)
+    fa, fb, fab = fft.fft2(a, True, "ortho"), fft.fft2(b, True, "ortho"), fft.fft2(a + 2 * b, True, "ortho")
+    assert_close(fab, fa + 2 * fb, 2e-6, "linearity")
+    assert_exact(fft.fft2(a[1:2], True, "ortho"), fa[1:2], "batch element independent of its neighbours")
+
+
+def test_fft_errors(dev):
+    import mridc_amd.collections.common.parts.fft as fft
+    with pytest.raises(ValueError):
+        fft.fft2(torch.zeros(2, 4, 4, 2, device=dev), normalization="bogus")
+    with pytest.raises(RuntimeError, match="FFT length"):
+        fft.fft2(torch.zeros(1, 4, 5000, 2, device=dev))
+    assert fft.fft2(torch.zeros(0, 4, 4, 2, device=dev)).shape == (0, 4, 4, 2)      # empty batch
+
+
+def test_g2_shift_goldens(golden, dev):
+    import mridc_amd.collections.common.parts.fft as fft
+    z = golden("g2_shift.npz")
+    for nm in ("s56", "s732", "s4152", "s9"):
+        x = T(z[f"{nm}/x"]).to(dev)
+        assert_exact(fft.fftshift(x), T(z[f"{nm}/fftshift_all"]))
+        assert_exact(fft.ifftshift(x), T(z[f"{nm}/ifftshift_all"]))
+        for dim in range(x.dim()):
+            assert_exact(fft.fftshift(x, [dim]), T(z[f"{nm}/fftshift/{dim}"]))
+            assert_exact(fft.ifftshift(x, [dim]), T(z[f"{nm}/ifftshift/{dim}"]))
+            for s in (-3, 0, 1, 2, 11):
+                assert_exact(fft.roll(x, [s], [dim]), T(z[f"{nm}/roll/{dim}/{s}"]))
+                assert_exact(fft.roll_one_dim(x, s, dim), T(z[f"{nm}/roll/{dim}/{s}"]))
+    x = T(z["multi/x"]).to(dev)
+    assert_exact(fft.roll(x, [2, 1], [0, 2]), T(z["multi/roll_0_2"]))
+    assert_exact(fft.fftshift(x, [-2, -1]), T(z["multi/fftshift_m2m1"]))
+    assert_exact(fft.ifftshift(x, [0, 1]), T(z["multi/ifftshift_01"]))
+    # other dtypes are pure byte moves
+    for dt in (torch.uint8, torch.int16, torch.float64, torch.complex64, torch.bool):
+        v = (torch.arange(5 * 7).reshape(5, 7) % 2 == 0) if dt == torch.bool else torch.arange(5 * 7).reshape(5, 7).to(dt)
+        assert torch.equal(fft.fftshift(v.to(dev)).cpu(), oracle.fft.fftshift(v)), dt
+
+
+def test_g3_complex_goldens_bit_exact(golden, dev):
+    import mridc_amd.collections.common.parts.utils as u
+    z = golden("g3_complex.npz")
+    x, y, e = T(z["x"]).to(dev), T(z["y"]).to(dev), T(z["e"]).to(dev)
+    assert_exact(u.complex_mul(x, y), T(z["complex_mul"]), "complex_mul")
+    assert_exact(u.complex_mul(e, y), T(z["complex_mul_bcast"]), "complex_mul broadcast")
+    assert_exact(u.complex_conj(x), T(z["complex_conj"]), "complex_conj")
+    assert_exact(u.complex_abs(x), T(z["complex_abs"]), "complex_abs")
+    assert_exact(u.complex_abs_sq(x), T(z["complex_abs_sq"]), "complex_abs_sq")
+    for dim in (0, 1):
+        assert_close(u.rss(x, dim), T(z[f"rss/{dim}"]), 1e-6, "rss")
+        assert_close(u.rss_complex(x, dim), T(z[f"rss_complex/{dim}"]), 1e-6, "rss_complex")
+        assert_close(u.sense(x, y, dim), T(z[f"sense/{dim}"]), 1e-6, "sense")
+        assert_close(u.coil_combination(x, y, "SENSE", dim), T(z[f"cc_sense/{dim}"]), 1e-6, "cc sense")
+        assert_close(u.coil_combination(x, y, "RSS", dim), T(z[f"cc_rss/{dim}"]), 1e-6, "cc rss")
+    with pytest.raises(ValueError, match="Output type not supported."):
+        u.coil_combination(x, y, "FOO", 0)
+
+
+def test_g11_apply_mask_bit_exact(golden, dev):
+    import mridc_amd.collections.common.parts.utils as u
+    z = golden("g11_masks.npz")
+    for nm in ("s32x16", "s15x12", "s13x18", "s17x19", "b2"):
+        shape = [int(v) for v in z[f"{nm}/shape"]]
+        x = torch.from_numpy(np.arange(np.prod(shape)).reshape(shape)).float()
+        mask = T(z[f"{nm}/mask"])
+        outs = [u.apply_mask(x[i:i + 1].to(dev), existing_mask=mask[i:i + 1])[0] for i in range(shape[0])]
+        assert_exact(torch.cat(outs), T(z[f"{nm}/masked"]), nm)
+    neg = -torch.ones(1, 2, 4, 6, 2)
+    out = u.apply_mask(neg.to(dev), existing_mask=torch.zeros(1, 1, 6, 1))[0].cpu()
+    assert not torch.signbit(out).any()                    # "+ 0.0" kills negative zeros (utils.py:341)
+
+
+def test_g4_llg_goldens(golden, dev):
+    from mridc_amd.collections.reconstruction.models.rim.rim_utils import log_likelihood_gradient
+    z = golden("g4_llg.npz")
+    eta, S = T(z["eta"]).to(dev), T(z["S"]).to(dev)
+    for i in range(int(z["ncases"])):
+        m = meta(z, f"case{i}/meta")
+        out = log_likelihood_gradient(eta, T(z[f"case{i}/y"]).to(dev), S, T(z[f"case{i}/mask"]).to(dev), m["sigma"],
+                                      m["centered"], m["norm"], [-2, -1], m["coil_dim"])
+        assert_close(out, T(z[f"case{i}/out"]), 1e-5, f"llg case{i} {m}")
+        assert_exact(out[:, :2], eta.permute(0, 3, 1, 2), "eta channels are copies")
+
+
+def test_llg_headline_size(golden, dev):
+    """[1,15,640,372] single step against the reference's checksums and the oracle."""
+    from mridc_amd import ops
+    z = golden("g4_llg.npz")
+    g = torch.Generator().manual_seed(44)
+    img = torch.randn(1, 1, 640, 372, 2, generator=g)
+    S = torch.randn(1, 15, 640, 372, 2, generator=g)
+    S = S / oracle.utils.complex_abs_sq(S).sum(1, keepdim=True).sqrt().unsqueeze(-1)
+    eta = torch.randn(1, 640, 372, 2, generator=torch.Generator().manual_seed(45)) * 0.1
+    k = oracle.fft.fft2(oracle.utils.complex_mul(img, S), False, "backward")
+    mk = T(golden("g11_masks.npz")["knee/mask_372"]).reshape(1, 1, 1, 372, 1).bool()
+    out = ops.llg(eta.to(dev), (k * mk).to(dev), S.to(dev), mk.to(dev), 1.0, False, "backward").cpu().reshape(-1)
+    ref_s = T(z["big/sample"])
+    assert np.linalg.norm((out[::4999] - ref_s).double().numpy()) <= 1e-5 * np.linalg.norm(ref_s.double().numpy())
+    assert abs(float(out.double().norm()) - float(z["big/l2"][0])) <= 1e-5 * float(z["big/l2"][0])
+
+
+def test_sens_expand_reduce_vs_oracle(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (B, C, H, W) in ((2, 3, 13, 18), (1, 5, 32, 24), (1, 2, 31, 7)):
+        x = torch.randn(B, H, W, 2, generator=g)
+        S = torch.randn(B, C, H, W, 2, generator=g)
+        k = torch.randn(B, C, H, W, 2, generator=g)
+        for centered, norm in ((True, "ortho"), (False, "backward"), (True, "forward")):
+            ref = oracle.varnet.sens_expand(x.unsqueeze(1), S, centered, norm, [-2, -1])
+            assert_close(ops.sens_expand(x.to(dev), S.to(dev), centered, norm), ref, 1e-5, "sens_expand")
+            ref = oracle.varnet.sens_reduce(k, S, centered, norm, [-2, -1], 1).squeeze(1)
+            assert_close(ops.sens_reduce(k.to(dev), S.to(dev), centered, norm), ref, 1e-5, "sens_reduce")
+    # adjointness <A x, k> == <x, A^H k> (size-independent property)
+    B, C, H, W = 1, 15, 64, 48
+    x = torch.randn(B, H, W, 2, generator=g)
+    S = torch.randn(B, C, H, W, 2, generator=g)
+    k = torch.randn(B, C, H, W, 2, generator=g)
+    Ax = torch.view_as_complex(ops.sens_expand(x.to(dev), S.to(dev), True, "ortho").cpu())
+    AHk = torch.view_as_complex(ops.sens_reduce(k.to(dev), S.to(dev), True, "ortho").cpu())
+    lhs = torch.sum(Ax * torch.view_as_complex(k).conj())
+    rhs = torch.sum(torch.view_as_complex(x) * AHk.conj())
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+
+
+def test_soft_dc_select_bit_exact(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(3)
+    pred = torch.randn(2, 3, 9, 11, 2, generator=g)
+    ref = torch.randn(2, 3, 9, 11, 2, generator=g)
+    eta_k = torch.randn(2, 3, 9, 11, 2, generator=g)
+    w = torch.tensor([0.7])
+    for mask in ((torch.rand(1, 1, 1, 11, 1, generator=g) < 0.4), (torch.rand(2, 1, 9, 11, 1, generator=g) < 0.5).byte(),
+                 (torch.rand(1, 1, 9, 11, 1, generator=g) < 0.5).float()):
+        want = oracle.varnet.soft_dc(pred, ref, mask, w)
+        assert_exact(ops.soft_dc(pred.to(dev), ref.to(dev), mask.to(dev), w.to(dev)), want, "soft_dc")
+        assert_exact(ops.dc_combine(pred.to(dev), pred.to(dev), ref.to(dev), mask.to(dev), w.to(dev), eta_k.to(dev)),
+                     pred - want - eta_k, "dc_combine")

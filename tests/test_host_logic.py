@@ -1,0 +1,135 @@
+"""CPU: host-side logic of the product package -- library loads and exports every declared symbol, reference-compatible
+constructor / state_dict layout / init, config quirks (time_steps rounding), error behaviour, and the no-CPU-fallback rule."""
+import json
+import os
+
+import pytest
+import torch
+
+from mridc_amd import _lib
+from tests._util import T, meta, weights
+
+CIRIM_CFG = dict(recurrent_layer="IndRNN", conv_filters=[64, 64, 2], conv_kernels=[5, 3, 3], conv_dilations=[1, 2, 1],
+                 conv_bias=[True, True, False], recurrent_filters=[64, 64, 0], recurrent_kernels=[1, 1, 0],
+                 recurrent_dilations=[1, 1, 0], recurrent_bias=[True, True, False], depth=2, time_steps=5, conv_dim=2,
+                 num_cascades=8, no_dc=True, keep_eta=True, fft_centered=False, fft_normalization="backward",
+                 spatial_dims=[-2, -1], coil_dim=1, dimensionality=2, coil_combination_method="SENSE",
+                 train_loss_fn="l1", val_loss_fn="l1")
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -m mridc_amd._build"
+    L = _lib.lib()
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/mridc_amd.h but not exported"
+    assert set(declared) == set(_lib._SIGNATURES), "ctypes signature table out of sync with the header"
+    assert L.mrx_version() >= 100
+    assert L.mrx_fft_max_len() >= 640
+
+
+def test_no_cpu_fallback():
+    import mridc_amd.collections.common.parts.fft as fft
+    import mridc_amd.collections.common.parts.utils as utils
+    x = torch.zeros(2, 4, 4, 2)
+    for fn in (lambda: fft.fft2(x), lambda: fft.ifft2(x), lambda: fft.fftshift(x), lambda: utils.complex_mul(x, x),
+               lambda: utils.complex_abs(x), lambda: utils.rss(x, 0), lambda: utils.sense(x, x, 0)):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            fn()
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dp, _, files in os.walk(os.path.join(root, "mridc_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f"{f} imports the oracle"
+
+
+def test_error_behaviour_matches_reference():
+    import mridc_amd.collections.common.parts.fft as fft
+    import mridc_amd.collections.common.parts.utils as utils
+    x3 = torch.zeros(2, 4, 4, 3)
+    x = torch.zeros(2, 4, 4, 2)
+    with pytest.raises(ValueError, match="separate complex dim"):
+        utils.complex_mul(x3, x3)
+    with pytest.raises(ValueError, match="separate complex dim"):
+        utils.complex_conj(x3)
+    with pytest.raises(ValueError, match="separate complex dim"):
+        utils.complex_abs(x3)
+    with pytest.raises(ValueError, match="separate complex dim"):
+        utils.complex_abs_sq(x3)
+    with pytest.raises(ValueError, match="Output type not supported."):
+        utils.coil_combination(x, x, "FOO", 0)
+    with pytest.raises(ValueError, match="len\\(shift\\) must match len\\(dim\\)"):
+        fft.roll(x, [1, 2], [0])
+    with pytest.raises(ValueError, match="Invalid shapes."):
+        utils.center_crop(x[..., 0], (5, 1))
+    with pytest.raises(ValueError, match="Invalid shapes."):
+        utils.complex_center_crop(x, (1, 9))
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    cfg = {k: CIRIM_CFG[k] for k in ("conv_filters", "conv_kernels", "conv_dilations", "conv_bias", "recurrent_filters",
+                                     "recurrent_kernels", "recurrent_dilations", "recurrent_bias")}
+    with pytest.raises(ValueError, match="Please specify a proper recurrent layer type."):
+        RIMBlock(recurrent_layer="LSTM", **cfg)
+    from mridc_amd.collections.reconstruction.models.unet_base.unet_block import NormUnet
+    with pytest.raises(AssertionError):
+        NormUnet.complex_to_chan_dim(torch.zeros(1, 1, 4, 4, 3))
+    assert utils.is_none(None) and utils.is_none("None") and not utils.is_none(0)
+
+
+def test_crops_are_views_with_reference_offsets(golden):
+    import mridc_amd.collections.common.parts.utils as utils
+    z = golden("g3_complex.npz")
+    img = T(z["crop/x"])
+    assert torch.equal(utils.center_crop(img, (7, 8)), T(z["crop/center_7_8"]))
+    assert torch.equal(utils.center_crop(img, (10, 13)), T(z["crop/center_10_13"]))
+    assert torch.equal(utils.complex_center_crop(T(z["crop/cx"]), (6, 9)), T(z["crop/complex_6_9"]))
+
+
+def test_cirim_config_quirks_and_state_dict_layout():
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    m = CIRIM(CIRIM_CFG)
+    assert m.time_steps == 8                               # 5 -> 8 (cirim.py:50-51)
+    assert all(b.time_steps == 8 for b in m.cirim)
+    assert CIRIM(dict(CIRIM_CFG, time_steps=9, num_cascades=1)).time_steps == 16
+    assert sum(p.numel() for p in m.parameters()) == 423_937
+    keys = set(m.state_dict().keys())
+    assert "dc_weight" in keys and "cirim.7.final_layer.0.conv_layer.weight" in keys
+    assert tuple(m.state_dict()["cirim.0.layers.0.rnn.hh"].shape) == (1, 64, 1, 1)
+    assert tuple(m.state_dict()["cirim.0.layers.1.convs.conv_layer.weight"].shape) == (64, 64, 3, 3)
+    import types
+    assert isinstance(m.forward(None, None, None, None, None), types.GeneratorType)     # cirim.py:165 yields
+
+
+def test_rimblock_init_is_bit_identical_to_reference(golden):
+    """Same module hierarchy + same init calls in the same order => same weights under the same seed as the reference
+    (golden g5 'ind64' was created with torch.manual_seed(500), 'gru16' with 504, 'mgu16' with 506; IndRNN cases then
+    had ih/hh scaled, so compare the unscaled parameters only)."""
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    z = golden("g5_rimblock.npz")
+    for nm, seed in (("ind64", 500), ("gru16", 504), ("mgu16", 506)):
+        cfg = meta(z, f"{nm}/cfg")
+        torch.manual_seed(seed)
+        blk = RIMBlock(**cfg)
+        ref = weights(z, f"{nm}/w/")
+        sd = blk.state_dict()
+        assert set(sd.keys()) == set(ref.keys()), nm
+        for k, v in ref.items():
+            assert torch.equal(sd[k], v), f"{nm}: {k} differs from the reference initialisation"
+        blk.load_state_dict(ref)                            # reference checkpoints drop in
+
+
+def test_varnet_state_dict_loads_reference_weights(golden):
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    from mridc_amd.collections.reconstruction.models.unet import UNet
+    z = golden("g8_models.npz")
+    cfg = meta(z, "vn/cfg")
+    m = VarNet(cfg)
+    sd = weights(z, "vn/w/")
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert unexpected == [] and missing == ["dc_weight"]      # model-level dc_weight (vn.py:91) is not in the block dumps
+    u = UNet(meta(z, "unet/cfg"))
+    u.load_state_dict(weights(z, "unet/w/"))
