@@ -78,7 +78,9 @@ class KernelTimer:
 def cpu_baseline(cfg, state_dict, data, gpu_out, n_cascades):
     """Time the oracle (CPU restatement of the reference path, torch CPU ops) on a bounded sample of the same slice."""
     import oracle
-    ncores = os.cpu_count() or 1
+    # the reference's CPU path is torch intra-op threading; beyond ~32 threads these op sizes slow down (measured:
+    # 256 threads on the GPU box's host ran 36x slower than 8 threads), so cap the pool and report what was used
+    ncores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(ncores)
     sub_cfg = dict(cfg, num_cascades=n_cascades)
     sd = {k: v for k, v in state_dict.items()}

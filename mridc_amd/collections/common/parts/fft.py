@@ -46,8 +46,9 @@ def _xform(data: torch.Tensor, centered: bool, normalization: str, spatial_dims,
     batch = int(real.numel() // (2 * H * W)) if H * W > 0 else 0
     out = torch.empty_like(real)
     L = _lib.lib()
-    _lib.check(L.mrx_fft2(_lib.ptr(real), _lib.ptr(out), batch, H, W, int(inverse), norm, int(bool(centered)),
-                          _lib.stream_ptr()), "mrx_fft2")
+    if batch > 0:
+        _lib.check(L.mrx_fft2(_lib.ptr(real), _lib.ptr(out), batch, H, W, int(inverse), norm, int(bool(centered)),
+                              _lib.stream_ptr()), "mrx_fft2")
     if perm is not None:
         inv = [0] * len(perm)
         for i, p in enumerate(perm):

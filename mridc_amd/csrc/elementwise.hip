@@ -126,7 +126,7 @@ __global__ void k_abs(const float2* __restrict__ x, float* __restrict__ out, lon
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float2 v = x[i];
         const float s = __fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y));  // (data**2).sum(-1): two rounded squares, one add
-        out[i] = SQ ? s : __fsqrt_rn(s);
+        out[i] = SQ ? s : sqrtf(s);  // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
     }
 }
 extern "C" int mrx_complex_conj(const float* x, float* out, int64_t n, void* stream) {

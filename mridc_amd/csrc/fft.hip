@@ -428,10 +428,10 @@ static int norm_valid(int norm) { return norm >= 0 && norm <= 3; }
 
 extern "C" int mrx_fft2(const float* in, float* out, int64_t batch, int H, int W, int inverse, int norm, int centered,
                         void* stream) {
-    MRX_REQUIRE(in && out, MRX_EINVAL, "mrx_fft2: null pointer");
     MRX_REQUIRE(batch >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_fft2: bad dims batch=%lld H=%d W=%d", (long long)batch, H, W);
     MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_fft2: bad normalization %d", norm);
     if (batch == 0) return MRX_OK;
+    MRX_REQUIRE(in && out, MRX_EINVAL, "mrx_fft2: null pointer");
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_rows((const float2*)in, nullptr, (float2*)out, batch * H, W, 1, H, inverse, norm, centered, 0, st);
     if (rc) return rc;

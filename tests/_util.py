@@ -65,4 +65,9 @@ def assert_exact(got, ref, what=""):
     g = got.detach().cpu() if isinstance(got, torch.Tensor) else torch.as_tensor(got)
     r = ref.detach().cpu() if isinstance(ref, torch.Tensor) else torch.as_tensor(ref)
     assert tuple(g.shape) == tuple(r.shape), f"{what}: shape {tuple(g.shape)} vs {tuple(r.shape)}"
-    assert torch.equal(g, r.to(g.dtype)), f"{what}: not bit-exact"
+    r = r.to(g.dtype)
+    if not torch.equal(g, r):
+        bad = (g != r)
+        diff = (g.double() - r.double()).abs()
+        raise AssertionError(f"{what}: not bit-exact: {int(bad.sum())} of {g.numel()} elements differ, max |diff| "
+                             f"{float(diff.max()):.3e} (max |ref| {float(r.double().abs().max()):.3e})")

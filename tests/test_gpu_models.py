@@ -130,8 +130,13 @@ def test_c1_zero_filled_plus_dc_320(golden, dev):
     zf = ops.sens_reduce(y.to(dev), S.to(dev), False, "backward")
     kk = ops.sens_expand(zf, S.to(dev), False, "backward")
     dc = ops.soft_dc(kk, y.to(dev), m1.to(dev), torch.ones(1, device=dev))
-    for name, t in (("zf", zf), ("dc", dc)):
-        v = t.cpu().reshape(-1)
-        ref_s = T(z[f"c1/{name}_sample"])
-        assert np.linalg.norm((v[::997] - ref_s).double().numpy()) <= 2e-5 * np.linalg.norm(ref_s.double().numpy()), name
-        assert abs(float(v.double().norm()) - float(z[f"c1/{name}_l2"][0])) <= 2e-5 * float(z[f"c1/{name}_l2"][0]), name
+    v = zf.cpu().reshape(-1)
+    ref_s = T(z["c1/zf_sample"])
+    assert np.linalg.norm((v[::997] - ref_s).double().numpy()) <= 2e-5 * np.linalg.norm(ref_s.double().numpy())
+    assert abs(float(v.double().norm()) - float(z["c1/zf_l2"][0])) <= 2e-5 * float(z["c1/zf_l2"][0])
+    # with one coil and |S| = 1 the DC residual A A^H y - y is pure round-off (~1e-7 |y|) on the sampled columns and
+    # exactly zero elsewhere: compare on the scale of the k-space, and require the select to be exact
+    d = dc.cpu()
+    scale = float(y.abs().max())
+    assert float(d.abs().max()) <= 2e-5 * scale and float(T(z["c1/dc_sample"]).abs().max()) <= 2e-5 * scale
+    assert torch.count_nonzero(d[:, :, :, ~m1.reshape(-1)]) == 0
