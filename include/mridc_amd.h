@@ -133,6 +133,18 @@ int mrx_conv2d(const float* x, const float* w, const float* bias, float* y, int 
 int mrx_rim_layer_indrnn(const float* x, const float* w_conv, const float* b_conv, const float* w_ih,
                          const float* b_ih, const float* hh, const float* h_prev, float* h_new, int B, int Cin,
                          int F, int H, int W, int k, int dil, void* stream);
+/* Tuned variant of the fused layer for F = 64 and (k, dil) in {(5,1), (3,2), (3,1), (1,1)}: weights are packed once
+ * (per weight update) into the MFMA operand order, then the packed buffer is passed to every step.
+ *   mrx_rim_layer_pack_floats  size of the packed buffer in floats (-1 if unsupported)
+ *   mrx_rim_layer_pack         w_conv [F,Cin,k,k] + w_ih [F,F,1,1] -> packed
+ *   mrx_rim_layer_supported    1 if a tuned kernel exists for the shape */
+int64_t mrx_rim_layer_pack_floats(int Cin, int F, int k);
+int mrx_rim_layer_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, int F, int k, void* stream);
+int mrx_rim_layer_supported(int Cin, int F, int k, int dil);
+int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, const float* b_conv, const float* b_ih,
+                                const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H,
+                                int W, int k, int dil, void* stream);
+
 /* A11 stand-alone IndRNN cell (rnn_cells.py:295-312,384-391): h_new = ReLU(conv_zero_pad(x; w_ih, b_ih) + hh*h_prev). */
 int mrx_indrnn_cell(const float* x, const float* w_ih, const float* b_ih, const float* hh, const float* h_prev,
                     float* h_new, int B, int Cin, int F, int H, int W, int k, int dil, void* stream);

@@ -16,6 +16,7 @@ SOURCES = [
     ("fft.hip", []),
     ("elementwise.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
+    ("rim_layer.hip", []),
     ("unet.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

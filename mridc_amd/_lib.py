@@ -42,6 +42,10 @@ _SIGNATURES = {
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_conv2d": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_rim_layer_indrnn": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_rim_layer_pack_floats": ([_i, _i, _i], _i64),
+    "mrx_rim_layer_pack": ([_p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_rim_layer_supported": ([_i, _i, _i, _i], _i),
+    "mrx_rim_layer_indrnn_packed": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_indrnn_cell": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_rim_final": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_gru_gates": ([_p, _p, _p, _p, _i, _i, _i64, _p], _i),

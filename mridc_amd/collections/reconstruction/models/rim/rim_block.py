@@ -64,6 +64,7 @@ class RIMBlock(torch.nn.Module):
             self.dc_weight = torch.nn.Parameter(torch.ones(1))          # rim_block.py:132-134
         self.dimensionality = dimensionality
         self.consecutive_slices = consecutive_slices
+        self._pack_cache = {}
 
     @staticmethod
     def _fusable(stack):
@@ -71,9 +72,22 @@ class RIMBlock(torch.nn.Module):
         return (isinstance(r, rnn_cells.IndRNNCell) and r.kernel_size == 1 and c is not None and c.act == ops.ACT_RELU
                 and c.features == r.hidden_size and r.hidden_size in (32, 64) and r.input_size == c.features)
 
-    def _layer(self, stack, x, h):
+    def _packed(self, idx, c, r):
+        """Packed weights of layer `idx` for the tuned kernel, re-packed only when the parameters change."""
+        w, wi = c.conv_layer.weight, r.ih.weight
+        key = (w.data_ptr(), w._version, wi.data_ptr(), wi._version, str(w.device))
+        hit = self._pack_cache.get(idx)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.rim_layer_pack(w, wi))
+            self._pack_cache[idx] = hit
+        return hit[1]
+
+    def _layer(self, idx, stack, x, h):
         if self._fusable(stack):
             c, r = stack.convs, stack.rnn
+            if ops.rim_layer_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation):
+                return ops.rim_layer_indrnn_packed(x, self._packed(idx, c, r), r.hidden_size, c.kernel_size, c.dilation,
+                                                   c.conv_layer.bias, r.ih.bias, r.hh, h)
             return ops.rim_layer_indrnn(x, c.conv_layer.weight, c.conv_layer.bias, c.kernel_size, c.dilation,
                                         r.ih.weight, r.ih.bias, r.hh, h)
         return stack(x, h)
@@ -99,7 +113,7 @@ class RIMBlock(torch.nn.Module):
             grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
                                self.spatial_dims, work=work)
             for h, convrnn in enumerate(self.layers):
-                hx[h] = self._layer(convrnn, grad_eta, hx[h])
+                hx[h] = self._layer(h, convrnn, grad_eta, hx[h])
                 grad_eta = hx[h]
             eta = ops.rim_final(grad_eta, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size,
                                 final.dilation, eta)                 # final conv, permute(0,2,3,1), eta + grad

@@ -475,11 +475,18 @@ extern "C" int mrx_rim_layer_indrnn(const float* x, const float* w_conv, const f
     return launch_conv(a, 1, (hipStream_t)stream);
 }
 
+int mrx_rim_final_tuned(const float* h, const float* w, const float* bias, const float* eta, float* eta_out, int B, int F,
+                        int H, int W, int k, int dil, hipStream_t st, int* handled);  // rim_layer.hip
+
 extern "C" int mrx_rim_final(const float* h, const float* w, const float* bias, const float* eta, float* eta_out, int B,
                              int F, int H, int W, int k, int dil, void* stream) {
     MRX_REQUIRE(h && w && eta && eta_out, MRX_EINVAL, "mrx_rim_final: null pointer");
     int rc = conv_common_checks("mrx_rim_final", B, F, 2, H, W);
     if (rc) return rc;
     if (B == 0) return MRX_OK;
+    MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "mrx_rim_final: batch %d too large", B);
+    int handled = 0;
+    rc = mrx_rim_final_tuned(h, w, bias, eta, eta_out, B, F, H, W, k, dil, (hipStream_t)stream, &handled);
+    if (handled || rc) return rc;
     return launch_small(h, w, bias, eta, eta_out, B, F, 2, H, W, k, dil, MRX_PAD_REPLICATE, 1, (hipStream_t)stream);
 }

@@ -1,0 +1,424 @@
+// rim_layer.hip -- tuned fused RIM layer for gfx950: ConvNonlinear(ReLU, replicate pad) + IndRNNCell(1x1)
+// (reference models/rim/conv_layers.py:121-123 + rnn_cells.py:384-391), fp32 in / fp32 out on v_mfma_f32_32x32x2_f32.
+//
+// Differences from the generic kernel in conv.hip (kept as the fallback and as a cross-check):
+//   * kernel size / dilation / channel chunk are template parameters: the (tap, channel-pair) loop is fully unrolled
+//     with immediate LDS offsets, no integer division anywhere in the hot loop or in the staging code;
+//   * 8 waves per workgroup, one image row x 64 couts (2 accumulators) each, on an 8x32 tile: the weight chunk in LDS
+//     is shared by 8 waves, 2 workgroups per CU give 4 waves per SIMD to cover LDS/global latency;
+//   * weights are pre-packed once (mrx_rim_layer_pack) into the exact order the MFMA A-operand is read:
+//     [chunk][tap][channel pair][lane half][cout] -- staging is a linear float4 copy, reads are conflict-free;
+//   * the next channel chunk (input tile and weights) is prefetched into registers while the current one feeds the
+//     matrix cores (issue-early / write-late staging);
+//   * the 1x1 `ih` GEMM consumes the conv accumulators in registers (contraction index enumerated in C/D-layout order),
+//     its packed weights sit in their own LDS region from kernel start.
+#include "mrx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RL_NT 512
+#define RL_TH 8
+#define RL_TW 32
+#define RL_F 64
+
+struct RimLayerArgs {
+    const float* x;        // [B,Cin,H,W]
+    const float* packed;   // conv chunks then ih block (mrx_rim_layer_pack)
+    const float* b_conv;   // [F] or null
+    const float* b_ih;     // [F] or null
+    const float* hh;       // [F]
+    const float* hprev;    // [B,F,H,W] or null
+    float* hnew;           // [B,F,H,W]
+    int B, Cin, H, W, tiles_x, ntiles;
+};
+
+__host__ __device__ constexpr int rl_pad(int K, int DIL) { return DIL * (K - 1) / 2; }
+
+// ---- weight packing ------------------------------------------------------------------------------------------------
+// conv part : index (((q*TAPS + tap)*(CK/2) + pair)*2 + half)*F + o  <-  w[o][q*CK + 2*pair + half][tap]   (0 beyond Cin)
+// ih part   : index ((ct*16 + r)*2 + half)*F + o                     <-  w_ih[o][32*ct + (r&3) + 8*(r>>2) + 4*half]
+__global__ void k_rim_pack(const float* __restrict__ w, const float* __restrict__ w_ih, float* __restrict__ out, int Cin,
+                           int taps, int CK, int nchunks) {
+    const int conv_elems = nchunks * taps * CK * RL_F;
+    const int total = conv_elems + RL_F * RL_F;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < conv_elems) {
+            const int o = i % RL_F;
+            int r = i / RL_F;
+            const int half = r & 1;
+            r >>= 1;
+            const int pair = r % (CK / 2);
+            r /= (CK / 2);
+            const int tap = r % taps;
+            const int q = r / taps;
+            const int ci = q * CK + 2 * pair + half;
+            if (ci < Cin) v = w[((long long)o * Cin + ci) * taps + tap];
+        } else {
+            const int j = i - conv_elems;
+            const int o = j % RL_F;
+            int r = j / RL_F;
+            const int half = r & 1;
+            r >>= 1;  // r = ct*16 + reg
+            const int ct = r >> 4, reg = r & 15;
+            const int c = 32 * ct + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            v = w_ih[o * RL_F + c];
+        }
+        out[i] = v;
+    }
+}
+
+static int rl_ck(int Cin) { return Cin <= 4 ? 4 : 8; }
+
+extern "C" int64_t mrx_rim_layer_pack_floats(int Cin, int F, int k) {
+    if (F != RL_F || Cin < 1 || k < 1) return -1;
+    const int CK = rl_ck(Cin);
+    const int nchunks = (Cin + CK - 1) / CK;
+    return (int64_t)nchunks * k * k * CK * RL_F + RL_F * RL_F;
+}
+
+extern "C" int mrx_rim_layer_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, int F, int k, void* stream) {
+    MRX_REQUIRE(w_conv && w_ih && packed, MRX_EINVAL, "mrx_rim_layer_pack: null pointer");
+    MRX_REQUIRE(F == RL_F, MRX_EUNSUP, "mrx_rim_layer_pack: hidden size %d (only %d is packed)", F, RL_F);
+    MRX_REQUIRE(Cin >= 1 && k >= 1 && (k & 1), MRX_EINVAL, "mrx_rim_layer_pack: bad Cin=%d k=%d", Cin, k);
+    const int CK = rl_ck(Cin);
+    const int nchunks = (Cin + CK - 1) / CK;
+    const int total = nchunks * k * k * CK * RL_F + RL_F * RL_F;
+    hipLaunchKernelGGL(k_rim_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, packed, Cin, k * k,
+                       CK, nchunks);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- the fused layer -----------------------------------------------------------------------------------------------
+template <int K, int DIL, int CK>
+__global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
+    constexpr int PAD = rl_pad(K, DIL);
+    constexpr int PH = RL_TH + 2 * PAD, PW = RL_TW + 2 * PAD, PLANE = PH * PW;
+    constexpr int TAPS = K * K;
+    constexpr int WCHUNK = TAPS * CK * RL_F;               // floats of packed weights per chunk
+    constexpr int XSLOTS = (PLANE + RL_NT - 1) / RL_NT;    // input-tile elements per thread per channel
+    constexpr int WVEC = (WCHUNK / 4 + RL_NT - 1) / RL_NT;  // float4 per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Xs = smem_f;                  // [CK][PLANE]
+    float* Ws = Xs + CK * PLANE;         // [TAPS][CK/2][2][F]   (16-byte aligned: CK*PLANE is a multiple of 4)
+    float* Wi = Ws + WCHUNK;             // [32][2][F]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous band of tiles so halo rows of
+    // neighbouring tiles are served by the same L2 (speed only; any order is correct)
+    int tile = blockIdx.x;
+    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
+    const int ty0 = tile / a.tiles_x;
+    const int h0 = ty0 * RL_TH, w0 = (tile - ty0 * a.tiles_x) * RL_TW;
+    const int b = blockIdx.y;
+    const long long plane = (long long)a.H * a.W;
+    const float* xb = a.x + (long long)b * a.Cin * plane;
+
+    // per-thread staging slots (replicate border = clamp, conv_layers.py:72-76)
+    int goff[XSLOTS];
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) {
+        const int e = tid + s * RL_NT;
+        const int ty = e / PW, tx = e - ty * PW;           // PW is a compile-time constant
+        int gy = h0 + ty - PAD, gx = w0 + tx - PAD;
+        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+        gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+        goff[s] = gy * a.W + gx;
+    }
+    const int nchunks = (a.Cin + CK - 1) / CK;
+
+    float xr[CK][XSLOTS];
+    float4 wr[WVEC];
+    auto prefetch = [&](int q) {
+#pragma unroll
+        for (int ci = 0; ci < CK; ++ci) {
+            const int gc = q * CK + ci;
+#pragma unroll
+            for (int s = 0; s < XSLOTS; ++s) {
+                const int e = tid + s * RL_NT;
+                xr[ci][s] = (e < PLANE && gc < a.Cin) ? xb[(long long)gc * plane + goff[s]] : 0.f;
+            }
+        }
+        const float4* wsrc = reinterpret_cast<const float4*>(a.packed + (long long)q * WCHUNK);
+#pragma unroll
+        for (int v = 0; v < WVEC; ++v) {
+            const int i = tid + v * RL_NT;
+            wr[v] = (i < WCHUNK / 4) ? wsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    // ih weights: own LDS region, filled once
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.packed + (long long)nchunks * WCHUNK);
+        float4* dst = reinterpret_cast<float4*>(Wi);
+        for (int i = tid; i < RL_F * RL_F / 4; i += RL_NT) dst[i] = src[i];
+    }
+    prefetch(0);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+    for (int q = 0; q < nchunks; ++q) {
+        __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+        for (int ci = 0; ci < CK; ++ci)
+#pragma unroll
+            for (int s = 0; s < XSLOTS; ++s) {
+                const int e = tid + s * RL_NT;
+                if (e < PLANE) Xs[ci * PLANE + e] = xr[ci][s];
+            }
+#pragma unroll
+        for (int v = 0; v < WVEC; ++v) {
+            const int i = tid + v * RL_NT;
+            if (i < WCHUNK / 4) reinterpret_cast<float4*>(Ws)[i] = wr[v];
+        }
+        __syncthreads();
+        if (q + 1 < nchunks) prefetch(q + 1);  // loads fly while the matrix cores work on chunk q
+        const float* xw = Xs + lhi * PLANE + wave * PW + l31;
+        const float* ww = Ws + lhi * RL_F + l31;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / K, kx = tap % K;  // folded: tap is an unrolled constant
+#pragma unroll
+            for (int pair = 0; pair < CK / 2; ++pair) {
+                const float bv = xw[(2 * pair) * PLANE + ky * DIL * PW + kx * DIL];
+                const float a0 = ww[((tap * (CK / 2) + pair) * 2) * RL_F];
+                const float a1 = ww[((tap * (CK / 2) + pair) * 2) * RL_F + 32];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- g = ReLU(conv + b_conv), kept in registers; h = ReLU(Wih g + b_ih + hh * h_prev) -----------------------------
+    const int oy = h0 + wave, ox = w0 + l31;
+    const bool inside = oy < a.H && ox < a.W;
+    const long long obase = (long long)b * RL_F * plane + (long long)oy * a.W + ox;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const float v = acc[ct][r] + (a.b_conv ? a.b_conv[co] : 0.f);
+            acc[ct][r] = v > 0.f ? v : 0.f;
+        }
+    f32x16 acc2[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[ct][r] = 0.f;
+    const float* wi = Wi + lhi * RL_F + l31;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a0 = wi[((ct * 16 + r) * 2) * RL_F];
+            const float a1 = wi[((ct * 16 + r) * 2) * RL_F + 32];
+            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, acc[ct][r], acc2[0], 0, 0, 0);
+            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, acc[ct][r], acc2[1], 0, 0, 0);
+        }
+    if (!inside) return;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const long long o = obase + (long long)co * plane;
+            float v = acc2[ct][r];
+            if (a.b_ih) v += a.b_ih[co];
+            if (a.hprev) v += a.hh[co] * a.hprev[o];
+            a.hnew[o] = v > 0.f ? v : 0.f;
+        }
+}
+
+template <int K, int DIL, int CK>
+static int launch_rim_layer(const RimLayerArgs& a, hipStream_t st) {
+    constexpr int PAD = rl_pad(K, DIL);
+    constexpr int PLANE = (RL_TH + 2 * PAD) * (RL_TW + 2 * PAD);
+    constexpr size_t lds = sizeof(float) * ((size_t)CK * PLANE + (size_t)K * K * CK * RL_F + RL_F * RL_F);
+    static_assert((CK * PLANE) % 4 == 0, "weight region must stay 16-byte aligned");
+    if (lds > 48 * 1024)
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer<K, DIL, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_rim_layer<K, DIL, CK>), dim3(a.ntiles, a.B), dim3(RL_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// returns 1 when (F, k, dil) has a tuned instantiation
+extern "C" int mrx_rim_layer_supported(int Cin, int F, int k, int dil) {
+    if (F != RL_F || Cin < 1) return 0;
+    return (k == 5 && dil == 1) || (k == 3 && dil == 2) || (k == 3 && dil == 1) || (k == 1 && dil == 1);
+}
+
+extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, const float* b_conv, const float* b_ih,
+                                           const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H,
+                                           int W, int k, int dil, void* stream) {
+    MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer_indrnn_packed: null pointer");
+    MRX_REQUIRE(B >= 0 && Cin >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer_indrnn_packed: bad dims");
+    MRX_REQUIRE(mrx_rim_layer_supported(Cin, F, k, dil), MRX_EUNSUP,
+                "mrx_rim_layer_indrnn_packed: no tuned kernel for F=%d k=%d dil=%d (use mrx_rim_layer_indrnn)", F, k, dil);
+    MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "mrx_rim_layer_indrnn_packed: batch %d too large", B);
+    if (B == 0) return MRX_OK;
+    RimLayerArgs a;
+    a.x = x;
+    a.packed = packed;
+    a.b_conv = b_conv;
+    a.b_ih = b_ih;
+    a.hh = hh;
+    a.hprev = h_prev;
+    a.hnew = h_new;
+    a.B = B;
+    a.Cin = Cin;
+    a.H = H;
+    a.W = W;
+    a.tiles_x = mrx_cdiv(W, RL_TW);
+    a.ntiles = a.tiles_x * mrx_cdiv(H, RL_TH);
+    hipStream_t st = (hipStream_t)stream;
+    const bool small = rl_ck(Cin) == 4;
+#define RL_CASE(KK, DD)                                                       \
+    if (k == KK && dil == DD)                                                 \
+        return small ? launch_rim_layer<KK, DD, 4>(a, st) : launch_rim_layer<KK, DD, 8>(a, st);
+    RL_CASE(5, 1)
+    RL_CASE(3, 2)
+    RL_CASE(3, 1)
+    RL_CASE(1, 1)
+#undef RL_CASE
+    MRX_REQUIRE(false, MRX_EUNSUP, "unreachable");
+}
+
+// ---- tuned final layer: F -> 2 conv (replicate pad) + eta update on the vector ALUs (rim_block.py:239-248) ---------------
+// 16x32 pixel tile, one pixel per thread; both output channels share every input read; weights live in LDS as (w0, w1)
+// pairs and are read with wave-uniform (broadcast) addresses.
+#define RF_NT 512
+#define RF_TH 16
+#define RF_CK 16
+struct RimFinalArgs {
+    const float* h;     // [B,F,H,W]
+    const float* w;     // [2,F,K,K]
+    const float* bias;  // [2] or null
+    const float* eta;   // [B,H,W,2]
+    float* out;         // [B,H,W,2]
+    int B, F, H, W, tiles_x, ntiles;
+};
+template <int K, int DIL>
+__global__ __launch_bounds__(RF_NT) void k_rim_final(RimFinalArgs a) {
+    constexpr int PAD = rl_pad(K, DIL);
+    constexpr int PH = RF_TH + 2 * PAD, PW = RL_TW + 2 * PAD, PLANE = PH * PW;
+    constexpr int TAPS = K * K;
+    constexpr int XSLOTS = (PLANE + RF_NT - 1) / RF_NT;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Xs = smem_f;                                       // [RF_CK][PLANE]
+    float2* W2 = reinterpret_cast<float2*>(Xs + RF_CK * PLANE);  // [F][TAPS] (w0, w1)
+    const int tid = threadIdx.x;
+    int tile = blockIdx.x;
+    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
+    const int ty0 = tile / a.tiles_x;
+    const int h0 = ty0 * RF_TH, w0 = (tile - ty0 * a.tiles_x) * RL_TW;
+    const int b = blockIdx.y;
+    const long long plane = (long long)a.H * a.W;
+    const float* hb = a.h + (long long)b * a.F * plane;
+    const int Fpad = (a.F + RF_CK - 1) / RF_CK * RF_CK;
+    for (int i = tid; i < Fpad * TAPS; i += RF_NT)
+        W2[i] = i < a.F * TAPS ? make_float2(a.w[i], a.w[a.F * TAPS + i]) : make_float2(0.f, 0.f);
+    int goff[XSLOTS];
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) {
+        const int e = tid + s * RF_NT;
+        const int ty = e / PW, tx = e - ty * PW;
+        int gy = h0 + ty - PAD, gx = w0 + tx - PAD;
+        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+        gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+        goff[s] = gy * a.W + gx;
+    }
+    float xr[RF_CK][XSLOTS];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int ci = 0; ci < RF_CK; ++ci)
+#pragma unroll
+            for (int s = 0; s < XSLOTS; ++s) {
+                const int e = tid + s * RF_NT;
+                xr[ci][s] = (e < PLANE && c0 + ci < a.F) ? hb[(long long)(c0 + ci) * plane + goff[s]] : 0.f;
+            }
+    };
+    prefetch(0);
+    const int tx = tid & 31, ty = tid >> 5;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int c0 = 0; c0 < a.F; c0 += RF_CK) {
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < RF_CK; ++ci)
+#pragma unroll
+            for (int s = 0; s < XSLOTS; ++s) {
+                const int e = tid + s * RF_NT;
+                if (e < PLANE) Xs[ci * PLANE + e] = xr[ci][s];
+            }
+        __syncthreads();
+        if (c0 + RF_CK < a.F) prefetch(c0 + RF_CK);
+        const float* xp = Xs + ty * PW + tx;
+        const float2* wp = W2 + c0 * TAPS;
+#pragma unroll 4
+        for (int ci = 0; ci < RF_CK; ++ci) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int ky = tap / K, kx = tap % K;
+                const float xv = xp[ci * PLANE + ky * DIL * PW + kx * DIL];
+                const float2 wv = wp[ci * TAPS + tap];
+                acc0 += wv.x * xv;
+                acc1 += wv.y * xv;
+            }
+        }
+    }
+    const int oy = h0 + ty, ox = w0 + tx;
+    if (oy >= a.H || ox >= a.W) return;
+    const long long o = ((long long)b * a.H + oy) * a.W + ox;
+    const float2 e = reinterpret_cast<const float2*>(a.eta)[o];
+    if (a.bias) {
+        acc0 += a.bias[0];
+        acc1 += a.bias[1];
+    }
+    reinterpret_cast<float2*>(a.out)[o] = make_float2(e.x + acc0, e.y + acc1);
+}
+
+template <int K, int DIL>
+static int launch_rim_final(const RimFinalArgs& a, hipStream_t st) {
+    constexpr int PAD = rl_pad(K, DIL);
+    constexpr int PLANE = (RF_TH + 2 * PAD) * (RL_TW + 2 * PAD);
+    const size_t lds = sizeof(float) * ((size_t)RF_CK * PLANE + 2 * (size_t)((a.F + RF_CK - 1) / RF_CK * RF_CK) * K * K);
+    MRX_REQUIRE(lds <= 160 * 1024, MRX_EUNSUP, "rim_final: %zu bytes of LDS", lds);
+    if (lds > 48 * 1024)
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_final<K, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_rim_final<K, DIL>), dim3(a.ntiles, a.B), dim3(RF_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// returns MRX_EUNSUP (without setting an error the caller must report) when no tuned instantiation exists
+int mrx_rim_final_tuned(const float* h, const float* w, const float* bias, const float* eta, float* eta_out, int B, int F,
+                        int H, int W, int k, int dil, hipStream_t st, int* handled) {
+    *handled = 0;
+    if (!((k == 3 && dil == 1) || (k == 1 && dil == 1) || (k == 3 && dil == 2) || (k == 5 && dil == 1))) return MRX_OK;
+    if ((RF_CK * (RF_TH + 2 * rl_pad(k, dil)) * (RL_TW + 2 * rl_pad(k, dil))) % 2) return MRX_OK;
+    RimFinalArgs a;
+    a.h = h;
+    a.w = w;
+    a.bias = bias;
+    a.eta = eta;
+    a.out = eta_out;
+    a.B = B;
+    a.F = F;
+    a.H = H;
+    a.W = W;
+    a.tiles_x = mrx_cdiv(W, RL_TW);
+    a.ntiles = a.tiles_x * mrx_cdiv(H, RF_TH);
+    *handled = 1;
+    if (k == 3 && dil == 1) return launch_rim_final<3, 1>(a, st);
+    if (k == 1 && dil == 1) return launch_rim_final<1, 1>(a, st);
+    if (k == 3 && dil == 2) return launch_rim_final<3, 2>(a, st);
+    return launch_rim_final<5, 1>(a, st);
+}

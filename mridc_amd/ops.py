@@ -161,6 +161,39 @@ def rim_layer_indrnn(x, w_conv, b_conv, k, dilation, w_ih, b_ih, hh, h_prev, out
     return out
 
 
+def rim_layer_supported(Cin, F, k, dilation):
+    return bool(_lib.lib().mrx_rim_layer_supported(int(Cin), int(F), int(k), int(dilation)))
+
+
+def rim_layer_pack(w_conv, w_ih):
+    """Pack conv [F,Cin,k,k] + ih [F,F,1,1] weights into the MFMA operand order of the tuned fused layer."""
+    w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
+    F, Cin, k, _ = [int(v) for v in w_conv.shape]
+    n = int(_lib.lib().mrx_rim_layer_pack_floats(Cin, F, k))
+    if n < 0:
+        raise ValueError("rim_layer_pack: unsupported shape")
+    packed = torch.empty(n, dtype=torch.float32, device=w_conv.device)
+    _lib.check(_lib.lib().mrx_rim_layer_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(packed), Cin, F, k, _lib.stream_ptr()),
+               "mrx_rim_layer_pack")
+    return packed
+
+
+def rim_layer_indrnn_packed(x, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None):
+    """Tuned fused ConvNonlinear(ReLU, replicate pad) + IndRNNCell(1x1) on pre-packed weights."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    if out is None:
+        out = torch.empty(B, F, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_rim_layer_indrnn_packed(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc),
+                                                      _lib.ptr(hp), _lib.ptr(out), B, Cin, int(F), H, W, int(k), int(dilation),
+                                                      _lib.stream_ptr()), "mrx_rim_layer_indrnn_packed")
+    return out
+
+
 def rim_final(h, weight, bias, k, dilation, eta):
     """eta + permute(conv_reppad(h)) with a 2-channel conv -> [B,H,W,2]."""
     h, weight, eta = _lib.f32c(h), _lib.f32c(weight.detach()), _lib.f32c(eta)

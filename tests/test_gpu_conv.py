@@ -81,6 +81,33 @@ def test_fused_rim_layer_vs_unfused_reference(F_, shape, dev):
     assert_close(got0, ref0, 1e-5, "fused layer, no biases, h_prev = None")
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 16, 12, 5, 1), (2, 64, 13, 18, 3, 2), (1, 64, 24, 70, 3, 2), (1, 16, 9, 33, 3, 1),
+                                   (1, 64, 8, 32, 1, 1), (1, 7, 17, 19, 3, 2), (2, 3, 1, 1, 5, 1), (1, 12, 40, 100, 5, 1)])
+def test_tuned_fused_rim_layer_packed(shape, dev):
+    """The tuned kernel (pre-packed weights, 8 waves, register-chained 1x1) against the oracle and the generic kernel."""
+    from mridc_amd import ops
+    B, Cin, H, W, k, dil = shape
+    F_ = 64
+    assert ops.rim_layer_supported(Cin, F_, k, dil)
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wc = torch.randn(F_, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bc = torch.randn(F_, generator=g) * 0.1
+    wi = torch.randn(F_, F_, 1, 1, generator=g) / F_ ** 0.5
+    bi = torch.randn(F_, generator=g) * 0.1
+    hh = torch.randn(1, F_, 1, 1, generator=g) * 0.5
+    hp = torch.randn(B, F_, H, W, generator=g)
+    ref = oracle.rim.indrnn_cell(oracle.rim.conv_nonlinear(x, wc, bc, k, dil, "relu"), hp, wi, bi, hh, 1, 1)
+    packed = ops.rim_layer_pack(wc.to(dev), wi.to(dev))
+    got = ops.rim_layer_indrnn_packed(x.to(dev), packed, F_, k, dil, bc.to(dev), bi.to(dev), hh.to(dev), hp.to(dev))
+    assert_close(got, ref, 1e-5, f"tuned fused layer {shape}")
+    gen = ops.rim_layer_indrnn(x.to(dev), wc.to(dev), bc.to(dev), k, dil, wi.to(dev), bi.to(dev), hh.to(dev), hp.to(dev))
+    assert_close(got, gen, 2e-6, "tuned vs generic kernel")
+    ref0 = oracle.rim.indrnn_cell(oracle.rim.conv_nonlinear(x, wc, None, k, dil, "relu"), torch.zeros_like(hp), wi, None, hh, 1, 1)
+    got0 = ops.rim_layer_indrnn_packed(x.to(dev), packed, F_, k, dil, None, None, hh.to(dev), None)
+    assert_close(got0, ref0, 1e-5, "tuned fused layer, no biases, h_prev = None")
+
+
 def test_cells_vs_oracle(dev):
     from mridc_amd import ops
     g = torch.Generator().manual_seed(2)
@@ -108,7 +135,8 @@ def test_cells_vs_oracle(dev):
 def test_rim_final_vs_oracle(dev):
     from mridc_amd import ops
     g = torch.Generator().manual_seed(4)
-    for (B, Fh, H, W, k, d) in ((1, 64, 16, 12, 3, 1), (2, 16, 13, 37, 3, 1), (1, 8, 9, 9, 5, 2)):
+    for (B, Fh, H, W, k, d) in ((1, 64, 16, 12, 3, 1), (2, 16, 13, 37, 3, 1), (1, 8, 9, 9, 5, 2), (1, 20, 33, 70, 3, 1),
+                                (1, 128, 17, 40, 3, 1), (1, 64, 8, 8, 1, 1), (1, 24, 12, 12, 5, 1)):
         h = torch.randn(B, Fh, H, W, generator=g)
         w = torch.randn(2, Fh, k, k, generator=g) / (Fh * k * k) ** 0.5
         eta = torch.randn(B, H, W, 2, generator=g)
