@@ -139,6 +139,7 @@ def main():
     timer = KernelTimer()
     F_hidden = cfg["recurrent_filters"][0]
     timer.wrap(ops, "rim_layer_indrnn", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
+    timer.wrap(ops, "rim_layer_indrnn_packed", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
     timer.wrap(ops, "rim_final", lambda *a, **k: "final")
 
@@ -177,7 +178,7 @@ def main():
         # dominant kernel: fused layer 2 = conv3x3 dil2 (64->64) + 1x1 ih (64->64): 2*(64*64*9 + 64*64) flop / pixel
         flops2 = 2.0 * (F_hidden * F_hidden * 9 + F_hidden * F_hidden) * npix * B
         ms2, n2 = timer.mean_ms("conv_layer2")
-        roofline = dict(bound="mfma", kernel="k_conv_mfma<2,true> (conv3x3 d2 64->64 + IndRNN 1x1, fp32 MFMA 32x32x2)",
+        roofline = dict(bound="mfma", kernel="k_rim_layer<3,2,8> (conv3x3 d2 64->64 + IndRNN 1x1 fused, fp32 MFMA 32x32x2)",
                         achieved=(flops2 / (ms2 * 1e-3) / 1e12) if ms2 else None, peak=PEAK_FP32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=(flops2 / (ms2 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms2 else None,
                         traffic=None, launches=n2, avg_ms=ms2, flops_per_launch=flops2)

@@ -5,6 +5,9 @@
 #include "mrx_common.h"
 
 #define EW_NT 256
+// correctly rounded fp32 square root (what torch's CPU sqrt returns): the double-precision root rounded once more to
+// float is exact because 53 >= 2*24 + 2 bits (double rounding is innocuous for sqrt)
+__device__ __forceinline__ float sqrt_rn(float s) { return (float)sqrt((double)s); }
 static inline int ew_grid(long long n) {
     long long g = (n + EW_NT - 1) / EW_NT;
     if (g > 256 * 16) g = 256 * 16;  // 256 CUs x 16 blocks, grid-stride for the rest
@@ -126,7 +129,7 @@ __global__ void k_abs(const float2* __restrict__ x, float* __restrict__ out, lon
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float2 v = x[i];
         const float s = __fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y));  // (data**2).sum(-1): two rounded squares, one add
-        out[i] = SQ ? s : sqrtf(s);  // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
+        out[i] = SQ ? s : sqrt_rn(s);
     }
 }
 extern "C" int mrx_complex_conj(const float* x, float* out, int64_t n, void* stream) {
@@ -158,7 +161,7 @@ __global__ void k_rss(const float* __restrict__ x, float* __restrict__ out, long
             const float v = p[r * inner];
             s += v * v;
         }
-        out[o] = sqrtf(s);
+        out[o] = sqrt_rn(s);
     }
 }
 __global__ void k_rss_complex(const float2* __restrict__ x, float* __restrict__ out, long long outer, long long R, long long inner) {
@@ -171,7 +174,7 @@ __global__ void k_rss_complex(const float2* __restrict__ x, float* __restrict__ 
             const float2 v = p[r * inner];
             s += v.x * v.x + v.y * v.y;
         }
-        out[o] = sqrtf(s);
+        out[o] = sqrt_rn(s);
     }
 }
 __global__ void k_sense(const float2* __restrict__ x, const float2* __restrict__ sm, float2* __restrict__ out, long long outer,

@@ -70,27 +70,25 @@ static inline float mrx_scale(int n, int inverse, int norm) {
 template <bool INV>
 __device__ __forceinline__ float2* fft_lds_run(float2* a, float2* b, const float2* tw, const MrxFftPlan& p, int nseq,
                                                int seq_stride, int es, bool seq_fastest) {
-    int Ns = 1;
+    const float inv_nseq = 1.0f / (float)nseq;
     for (int s = 0; s < p.nstages; ++s) {
-        const int r = p.radix[s];
-        const int ips = mrx_stage_items(p.n, r);
-        const int total = ips * nseq;
+        const MrxFftStage& S = p.st[s];
+        const int total = S.ips * nseq;
         for (int w = threadIdx.x; w < total; w += MRX_FFT_NT) {
             int seq, item;
             if (seq_fastest) {
-                item = w / nseq;
+                item = mrx_fdiv(w, inv_nseq);
                 seq = w - item * nseq;
             } else {
-                seq = w / ips;
-                item = w - seq * ips;
+                seq = mrx_fdiv(w, S.inv_ips);
+                item = w - seq * S.ips;
             }
-            mrx_fft_stage_item<INV>(a + seq * seq_stride, b + seq * seq_stride, tw, p.n, Ns, r, item, es);
+            mrx_fft_stage_item<INV>(a + seq * seq_stride, b + seq * seq_stride, tw, p.n, S, item, es);
         }
         __syncthreads();
         float2* t = a;
         a = b;
         b = t;
-        Ns *= r;
     }
     return a;
 }
@@ -103,10 +101,9 @@ __device__ __forceinline__ int shifted(int p, int half, int n) {
 struct RowArgs {
     MrxFftPlan plan;
     const float2* tw;
-    long long rows_total;  // number of length-W rows
     int W, rpb, halfW;
     float scale;
-    int C, H;  // expand mode: rows are [B][C][H]
+    int C, H;  // images are [.., C][H rows]; expand mode reads the image x[b] for every coil c of batch element b
 };
 
 // MODE 0: out[row] = FFT(in[row]);  MODE 1: out[b,c,h] = FFT(x[b,h] * S[b,c,h])
@@ -118,20 +115,22 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const
     float2* tw = smem;
     float2* A = smem + W;
     float2* B = A + a.rpb * W;
-    const long long row0 = (long long)blockIdx.x * a.rpb;
-    const int nrows = (int)min((long long)a.rpb, a.rows_total - row0);
+    const long long img = blockIdx.x;             // image index (b*C + c in expand mode)
+    const int hrow0 = blockIdx.y * a.rpb;
+    const int nrows = min(a.rpb, a.H - hrow0);
+    const long long row0 = img * a.H + hrow0;
+    const long long bimg = MODE == 1 ? img / a.C : 0;   // one division per workgroup
+    const float invW = 1.0f / (float)W;
     for (int i = threadIdx.x; i < W; i += MRX_FFT_NT) tw[i] = a.tw[i];
     for (int idx = threadIdx.x; idx < nrows * W; idx += MRX_FFT_NT) {
-        const int r = idx / W, x = idx - r * W;
+        const int r = mrx_fdiv(idx, invW), x = idx - r * W;
         const int g = shifted(x, a.halfW, W);
         const long long ro = row0 + r;
         float2 v;
         if (MODE == 0) {
             v = in[ro * W + g];
         } else {
-            const long long b = ro / ((long long)a.C * a.H);
-            const int h = (int)(ro % a.H);
-            const float2 e = in[(b * a.H + h) * W + g];
+            const float2 e = in[(bimg * a.H + hrow0 + r) * W + g];
             const float2 s = S[ro * W + g];
             v = make_float2(e.x * s.x - e.y * s.y, e.x * s.y + e.y * s.x);  // utils.py:115-116
         }
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const
     __syncthreads();
     float2* res = fft_lds_run<INV>(A, B, tw, a.plan, nrows, W, 1, false);
     for (int idx = threadIdx.x; idx < nrows * W; idx += MRX_FFT_NT) {
-        const int r = idx / W, x = idx - r * W;
+        const int r = mrx_fdiv(idx, invW), x = idx - r * W;
         const int g = shifted(x, a.halfW, W);
         float2 v = res[idx];
         out[(row0 + r) * W + g] = make_float2(v.x * a.scale, v.y * a.scale);
@@ -160,6 +159,7 @@ template <bool INV>
 __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_cols(const float2* in, float2* out, ColArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     const int H = a.H, W = a.W, CT = a.ct;
+    const float invCT = 1.0f / (float)CT;
     float2* tw = smem;
     float2* A = smem + H;
     float2* B = A + H * CT;
@@ -167,14 +167,14 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_cols(const float2* in, float
     const long long img = (long long)blockIdx.y * H * W;
     for (int i = threadIdx.x; i < H; i += MRX_FFT_NT) tw[i] = a.tw[i];
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = idx / CT, c = idx - p * CT;
+        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         A[idx] = w < W ? in[img + (long long)shifted(p, a.halfH, H) * W + w] : make_float2(0.f, 0.f);
     }
     __syncthreads();
     float2* res = fft_lds_run<INV>(A, B, tw, a.plan, CT, 1, CT, true);
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = idx / CT, c = idx - p * CT;
+        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         if (w < W) {
             float2 v = res[idx];
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc(const float2* in, const 
                                                         float2* out, ColArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     const int H = a.H, W = a.W, CT = a.ct;
+    const float invCT = 1.0f / (float)CT;
     float2* tw = smem;
     float2* A = smem + H;
     float2* B = A + H * CT;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc(const float2* in, const 
     const long long img = bc * H * W;
     for (int i = threadIdx.x; i < H; i += MRX_FFT_NT) tw[i] = a.tw[i];
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = idx / CT, c = idx - p * CT;
+        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         A[idx] = w < W ? in[img + (long long)shifted(p, a.halfH, H) * W + w] : make_float2(0.f, 0.f);
     }
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc(const float2* in, const 
     float2* res = fft_lds_run<false>(A, B, tw, a.plan, CT, 1, CT, true);
     float2* oth = (res == A) ? B : A;
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = idx / CT, c = idx - p * CT;
+        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         float2 r = make_float2(0.f, 0.f);
         if (w < W) {
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc(const float2* in, const 
     __syncthreads();
     float2* res2 = fft_lds_run<true>(res, oth, tw, a.plan, CT, 1, CT, true);
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = idx / CT, c = idx - p * CT;
+        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         if (w < W) {
             float2 v = res2[idx];
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_rows_reduce(const float2* __rest
     float2* B = A + G * W;
     const int h = blockIdx.x;
     const long long b = blockIdx.y;
+    const float invW = 1.0f / (float)W;
     for (int i = threadIdx.x; i < W; i += MRX_FFT_NT) {
         tw[i] = a.tw[i];
         acc[i] = make_float2(0.f, 0.f);
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_rows_reduce(const float2* __rest
         const int nrows = min(G, C - c0);
         __syncthreads();
         for (int idx = threadIdx.x; idx < nrows * W; idx += MRX_FFT_NT) {
-            const int r = idx / W, x = idx - r * W;
+            const int r = mrx_fdiv(idx, invW), x = idx - r * W;
             A[idx] = k[(((b * C + c0 + r) * H) + h) * W + shifted(x, a.halfW, W)];
         }
         __syncthreads();
@@ -316,7 +318,7 @@ static int set_lds(K kern, size_t bytes) {
     return MRX_OK;
 }
 
-static int launch_rows(const float2* in, const float2* S, float2* out, long long rows_total, int W, int C, int H,
+static int launch_rows(const float2* in, const float2* S, float2* out, long long nimg, int W, int C, int H,
                        int inverse, int norm, int centered, int expand, hipStream_t st) {
     MrxFftEntry e;
     int rc = mrx_get_plan(W, &e);
@@ -324,7 +326,6 @@ static int launch_rows(const float2* in, const float2* S, float2* out, long long
     RowArgs a;
     a.plan = e.plan;
     a.tw = e.d_tw;
-    a.rows_total = rows_total;
     a.W = W;
     a.rpb = pick_rows(W);
     a.halfW = centered ? W / 2 : 0;
@@ -332,16 +333,17 @@ static int launch_rows(const float2* in, const float2* S, float2* out, long long
     a.C = C;
     a.H = H;
     const size_t lds = sizeof(float2) * ((size_t)W + 2 * (size_t)a.rpb * W);
-    const int grid = mrx_cdiv(rows_total, a.rpb);
+    MRX_REQUIRE(nimg < (1LL << 31), MRX_EUNSUP, "too many images (%lld)", nimg);
+    const dim3 grid((unsigned)nimg, mrx_cdiv(H, a.rpb));
     if (expand) {
         if ((rc = set_lds(k_fft_rows<false, 1>, lds))) return rc;
-        hipLaunchKernelGGL((k_fft_rows<false, 1>), dim3(grid), dim3(MRX_FFT_NT), lds, st, in, S, out, a);
+        hipLaunchKernelGGL((k_fft_rows<false, 1>), grid, dim3(MRX_FFT_NT), lds, st, in, S, out, a);
     } else if (inverse) {
         if ((rc = set_lds(k_fft_rows<true, 0>, lds))) return rc;
-        hipLaunchKernelGGL((k_fft_rows<true, 0>), dim3(grid), dim3(MRX_FFT_NT), lds, st, in, S, out, a);
+        hipLaunchKernelGGL((k_fft_rows<true, 0>), grid, dim3(MRX_FFT_NT), lds, st, in, S, out, a);
     } else {
         if ((rc = set_lds(k_fft_rows<false, 0>, lds))) return rc;
-        hipLaunchKernelGGL((k_fft_rows<false, 0>), dim3(grid), dim3(MRX_FFT_NT), lds, st, in, S, out, a);
+        hipLaunchKernelGGL((k_fft_rows<false, 0>), grid, dim3(MRX_FFT_NT), lds, st, in, S, out, a);
     }
     MRX_LAUNCH_CHECK();
     return MRX_OK;
@@ -433,7 +435,7 @@ extern "C" int mrx_fft2(const float* in, float* out, int64_t batch, int H, int W
     if (batch == 0) return MRX_OK;
     MRX_REQUIRE(in && out, MRX_EINVAL, "mrx_fft2: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_rows((const float2*)in, nullptr, (float2*)out, batch * H, W, 1, H, inverse, norm, centered, 0, st);
+    int rc = launch_rows((const float2*)in, nullptr, (float2*)out, batch, W, 1, H, inverse, norm, centered, 0, st);
     if (rc) return rc;
     for (int64_t i0 = 0; i0 < batch; i0 += 65535) {
         const int64_t n = batch - i0 < 65535 ? batch - i0 : 65535;
@@ -450,7 +452,7 @@ extern "C" int mrx_sens_expand(const float* x, const float* S, float* out, int B
     MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_sens_expand: bad normalization %d", norm);
     if (B == 0) return MRX_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_rows((const float2*)x, (const float2*)S, (float2*)out, (long long)B * C * H, W, C, H, 0, norm,
+    int rc = launch_rows((const float2*)x, (const float2*)S, (float2*)out, (long long)B * C, W, C, H, 0, norm,
                          centered, 1, st);
     if (rc) return rc;
     const long long nimg = (long long)B * C;
@@ -490,7 +492,7 @@ extern "C" int mrx_llg(const float* eta, const float* y, const float* S, const v
     if (B == 0) return MRX_OK;
     hipStream_t st = (hipStream_t)stream;
     // 1) rows: eta * S -> FFT_W                                   (rim_utils.py:44-51)
-    int rc = launch_rows((const float2*)eta, (const float2*)S, (float2*)work, (long long)B * C * H, W, C, H, 0, norm,
+    int rc = launch_rows((const float2*)eta, (const float2*)S, (float2*)work, (long long)B * C, W, C, H, 0, norm,
                          centered, 1, st);
     if (rc) return rc;
     // 2) cols: FFT_H -> mask*(k - y) -> IFFT_H                    (rim_utils.py:51-58)

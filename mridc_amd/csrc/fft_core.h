@@ -24,11 +24,22 @@ struct mrx_c32 {
 
 #define MRX_FFT_MAX_STAGES 16
 
+// Per-stage constants are precomputed on the host so the device code has no integer division:
+// q = floor(j / d) is computed as (int)((j + 0.5f) * (1.0f / d)), exact for j < 2^22.
+struct MrxFftStage {
+    int r;        // radix
+    int Ns;       // product of the previous radices
+    int M;        // n / r  (butterflies per sequence)
+    int tmul;     // n / (Ns * r): twiddle index step per unit of k
+    int ips;      // work items per sequence
+    float inv_Ns, inv_half, inv_ips;
+};
 struct MrxFftPlan {
     int n;
     int nstages;
-    int radix[MRX_FFT_MAX_STAGES];
+    MrxFftStage st[MRX_FFT_MAX_STAGES];
 };
+MRX_HD int mrx_fdiv(int a, float inv_d) { return (int)(((float)a + 0.5f) * inv_d); }
 
 MRX_HD mrx_c32 mrx_mk(float x, float y) {
     mrx_c32 r;
@@ -57,14 +68,14 @@ MRX_HD int mrx_stage_items(int n, int r) { return mrx_is_small_radix(r) ? n / r 
 
 // One work item of one stage.  `es` = element stride (in complex elements) inside `in`/`out`.
 template <bool INV>
-MRX_HD void mrx_fft_stage_item(const mrx_c32* in, mrx_c32* out, const mrx_c32* tw, int N, int Ns, int r, int item,
+MRX_HD void mrx_fft_stage_item(const mrx_c32* in, mrx_c32* out, const mrx_c32* tw, int N, const MrxFftStage& S, int item,
                                int es) {
-    const int M = N / r;  // butterflies per sequence
+    const int M = S.M, Ns = S.Ns, r = S.r;
     if (mrx_is_small_radix(r)) {
         const int j = item;
-        const int k = j % Ns;
+        const int k = j - Ns * mrx_fdiv(j, S.inv_Ns);
         const int ob = (j - k) * r + k;
-        const int tstep = k * (N / (Ns * r));  // twiddle index step: w^(t*k) = tw[t*tstep]
+        const int tstep = k * S.tmul;  // twiddle index step: w^(t*k) = tw[t*tstep]
         mrx_c32 a0 = in[(j)*es];
         if (r == 2) {
             mrx_c32 a1 = in[(j + M) * es];
@@ -124,12 +135,12 @@ MRX_HD void mrx_fft_stage_item(const mrx_c32* in, mrx_c32* out, const mrx_c32* t
     }
     // generic odd prime radix p = r
     const int half = (r + 1) / 2;
-    const int j = item / half;
+    const int j = mrx_fdiv(item, S.inv_half);
     const int q = item - j * half;
-    const int k = j % Ns;
+    const int k = j - Ns * mrx_fdiv(j, S.inv_Ns);
     const int ob = (j - k) * r + k;
-    const int tstep = k * (N / (Ns * r));
-    const int rstep = N / r;  // tw[m*rstep] = exp(-2 pi i m / r)
+    const int tstep = k * S.tmul;
+    const int rstep = M;  // n / r: tw[m*rstep] = exp(-2 pi i m / r)
     mrx_c32 x0 = in[j * es];
     if (q == 0) {
         mrx_c32 acc = x0;
@@ -208,7 +219,19 @@ inline int mrx_make_plan(int n, MrxFftPlan* p) {
     for (int i = 0; i < c2 / 2; ++i) small[ns++] = 4;
     if (c2 % 2) small[ns++] = 2;
     if (ns > MRX_FFT_MAX_STAGES) return -1;
-    for (int i = 0; i < ns; ++i) p->radix[i] = small[i];
+    int Ns = 1;
+    for (int i = 0; i < ns; ++i) {
+        MrxFftStage& S = p->st[i];
+        S.r = small[i];
+        S.Ns = Ns;
+        S.M = n / S.r;
+        S.tmul = n / (Ns * S.r);
+        S.ips = mrx_stage_items(n, S.r);
+        S.inv_Ns = 1.0f / (float)Ns;
+        S.inv_half = 1.0f / (float)((S.r + 1) / 2);
+        S.inv_ips = 1.0f / (float)S.ips;
+        Ns *= S.r;
+    }
     p->nstages = ns;
     return 0;
 }

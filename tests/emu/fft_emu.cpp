@@ -10,7 +10,7 @@
 extern "C" int emu_plan(int n, int* radices) {
     MrxFftPlan p;
     if (mrx_make_plan(n, &p) != 0) return -1;
-    for (int i = 0; i < p.nstages; ++i) radices[i] = p.radix[i];
+    for (int i = 0; i < p.nstages; ++i) radices[i] = p.st[i].r;
     return p.nstages;
 }
 
@@ -27,21 +27,18 @@ extern "C" int emu_fft(float* data, int n, int nseq, int seq_stride, int es, int
     std::vector<mrx_c32> A(total), B(total);
     memcpy(A.data(), data, sizeof(mrx_c32) * total);
     mrx_c32 *a = A.data(), *b = B.data();
-    int Ns = 1;
     for (int s = 0; s < p.nstages; ++s) {
-        int r = p.radix[s];
-        int items = mrx_stage_items(n, r);
+        const MrxFftStage& S = p.st[s];
         for (int seq = 0; seq < nseq; ++seq)
-            for (int it = 0; it < items; ++it) {
+            for (int it = 0; it < S.ips; ++it) {
                 if (inverse)
-                    mrx_fft_stage_item<true>(a + seq * seq_stride, b + seq * seq_stride, tw.data(), n, Ns, r, it, es);
+                    mrx_fft_stage_item<true>(a + seq * seq_stride, b + seq * seq_stride, tw.data(), n, S, it, es);
                 else
-                    mrx_fft_stage_item<false>(a + seq * seq_stride, b + seq * seq_stride, tw.data(), n, Ns, r, it, es);
+                    mrx_fft_stage_item<false>(a + seq * seq_stride, b + seq * seq_stride, tw.data(), n, S, it, es);
             }
         mrx_c32* t = a;
         a = b;
         b = t;
-        Ns *= r;
     }
     memcpy(data, a, sizeof(mrx_c32) * total);
     return 0;

@@ -118,8 +118,14 @@ def test_g3_complex_goldens_bit_exact(golden, dev):
     assert_exact(u.complex_mul(x, y), T(z["complex_mul"]), "complex_mul")
     assert_exact(u.complex_mul(e, y), T(z["complex_mul_bcast"]), "complex_mul broadcast")
     assert_exact(u.complex_conj(x), T(z["complex_conj"]), "complex_conj")
-    assert_exact(u.complex_abs(x), T(z["complex_abs"]), "complex_abs")
     assert_exact(u.complex_abs_sq(x), T(z["complex_abs_sq"]), "complex_abs_sq")
+    # sqrt: the HIP path returns the correctly rounded root; torch's vectorised CPU sqrt (what the golden holds) is itself
+    # 1 ulp off the correctly rounded value on 1 of these 504 elements (checked against numpy), so allow 1 ulp here and
+    # require exact agreement with the correctly rounded float64 root
+    got = u.complex_abs(x).cpu()
+    assert float(((got - T(z["complex_abs"])).abs() / T(z["complex_abs"])).max()) <= 1.2e-7
+    want = torch.from_numpy(np.sqrt(z["complex_abs_sq"].astype(np.float64)).astype(np.float32))
+    assert_exact(got, want, "complex_abs vs correctly rounded sqrt")
     for dim in (0, 1):
         assert_close(u.rss(x, dim), T(z[f"rss/{dim}"]), 1e-6, "rss")
         assert_close(u.rss_complex(x, dim), T(z[f"rss_complex/{dim}"]), 1e-6, "rss_complex")
