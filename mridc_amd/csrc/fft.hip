@@ -16,6 +16,7 @@
 #include <cmath>
 
 #include "fft_core.h"
+#include "fft_ct.h"
 #include "mrx_common.h"
 
 #define MRX_FFT_NT 256
@@ -65,7 +66,8 @@ static inline float mrx_scale(int n, int inverse, int norm) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// device: run all stages over `nseq` sequences held in LDS.  Returns the buffer holding the result.
+// device: run all stages over the sequences held in LDS.  Returns the buffer holding the result.
+// Two policies: PlanRT (runtime plan, any length) and PlanCT<N, radices...> (compile-time plan for the hot lengths).
 // ------------------------------------------------------------------------------------------------------------
 template <bool INV>
 __device__ __forceinline__ float2* fft_lds_run(float2* a, float2* b, const float2* tw, const MrxFftPlan& p, int nseq,
@@ -93,6 +95,86 @@ __device__ __forceinline__ float2* fft_lds_run(float2* a, float2* b, const float
     return a;
 }
 
+struct PlanRT {
+    static constexpr bool kCT = false;
+    static constexpr int N = 0;
+};
+template <int N_, int... Rs>
+struct PlanCT {
+    static constexpr bool kCT = true;
+    static constexpr int N = N_;
+};
+
+// compile-time stage recursion.  COLS: sequences are columns (sequence index fastest, element stride NSEQ);
+// otherwise rows (element stride 1, sequence stride N).
+template <bool INV, int N, int NSEQ, bool COLS, int NS, int... Rs>
+struct RunCT;
+template <bool INV, int N, int NSEQ, bool COLS, int NS>
+struct RunCT<INV, N, NSEQ, COLS, NS> {
+    static __device__ __forceinline__ float2* run(float2* a, float2*, const float2*) { return a; }
+};
+template <bool INV, int N, int NSEQ, bool COLS, int NS, int R, int... Rest>
+struct RunCT<INV, N, NSEQ, COLS, NS, R, Rest...> {
+    static __device__ __forceinline__ float2* run(float2* a, float2* b, const float2* tw) {
+        constexpr int SEQ_STRIDE = COLS ? 1 : N;
+        constexpr int ES = COLS ? NSEQ : 1;
+        constexpr int M = N / R;
+        if constexpr (!mrx_ct_small(R) && NS == 1) {
+            // in-register prime butterflies: output-pair subset `part` is wave-uniform, butterflies spread over lanes
+            constexpr int QS = mrx_ct_qsplit(R);
+            constexpr int NWAVES = MRX_FFT_NT / 64;
+            static_assert(NWAVES % QS == 0, "q-split must divide the wave count");
+            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            const int part = wave % QS;
+            for (int bf = (threadIdx.x & 63) + 64 * (wave / QS); bf < M * NSEQ; bf += 64 * (NWAVES / QS)) {
+                int seq, j;
+                if (COLS) {
+                    j = bf / NSEQ;
+                    seq = bf - j * NSEQ;
+                } else {
+                    seq = bf / M;
+                    j = bf - seq * M;
+                }
+                const float2* in = a + seq * SEQ_STRIDE;
+                float2* out = b + seq * SEQ_STRIDE;
+                if (part == 0) mrx_ct_prime_first<INV, N, R, 0>(in, out, j, ES);
+                if constexpr (QS > 1) {
+                    if (part == 1) mrx_ct_prime_first<INV, N, R, 1>(in, out, j, ES);
+                }
+                if constexpr (QS > 2) {
+                    if (part == 2) mrx_ct_prime_first<INV, N, R, 2>(in, out, j, ES);
+                    if (part == 3) mrx_ct_prime_first<INV, N, R, 3>(in, out, j, ES);
+                }
+            }
+        } else {
+            constexpr int IPS = mrx_ct_ips(N, R, NS);
+            constexpr int TOTAL = IPS * NSEQ;
+#pragma unroll 1
+            for (int w = threadIdx.x; w < TOTAL; w += MRX_FFT_NT) {
+                int seq, item;
+                if (COLS) {
+                    item = w / NSEQ;
+                    seq = w - item * NSEQ;
+                } else {
+                    seq = w / IPS;
+                    item = w - seq * IPS;
+                }
+                mrx_ct_item<INV, N, R, NS>(a + seq * SEQ_STRIDE, b + seq * SEQ_STRIDE, tw, item, ES);
+            }
+        }
+        __syncthreads();
+        return RunCT<INV, N, NSEQ, COLS, NS * R, Rest...>::run(b, a, tw);
+    }
+};
+template <bool INV, int NSEQ, bool COLS, class P>
+struct RunPlan;
+template <bool INV, int NSEQ, bool COLS, int N, int... Rs>
+struct RunPlan<INV, NSEQ, COLS, PlanCT<N, Rs...>> {
+    static __device__ __forceinline__ float2* run(float2* a, float2* b, const float2* tw) {
+        return RunCT<INV, N, NSEQ, COLS, 1, Rs...>::run(a, b, tw);
+    }
+};
+
 __device__ __forceinline__ int shifted(int p, int half, int n) {
     int g = p + half;
     return g >= n ? g - n : g;
@@ -106,40 +188,47 @@ struct RowArgs {
     int C, H;  // images are [.., C][H rows]; expand mode reads the image x[b] for every coil c of batch element b
 };
 
-// MODE 0: out[row] = FFT(in[row]);  MODE 1: out[b,c,h] = FFT(x[b,h] * S[b,c,h])
-template <bool INV, int MODE>
-__global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const float2* __restrict__ S,
-                                                         float2* out, RowArgs a) {
+// MODE 0: out[row] = FFT(in[row]);  MODE 1: out[b,c,h] = FFT(x[b,h] * S[b,c,h]).  NSEQ rows per workgroup (CT plans).
+template <bool INV, int MODE, class P, int NSEQ>
+__global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const float2* __restrict__ S, float2* out,
+                                                         RowArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    const int W = a.W;
+    const int W = P::kCT ? P::N : a.W;
+    const int RPB = P::kCT ? NSEQ : a.rpb;
     float2* tw = smem;
     float2* A = smem + W;
-    float2* B = A + a.rpb * W;
-    const long long img = blockIdx.x;             // image index (b*C + c in expand mode)
-    const int hrow0 = blockIdx.y * a.rpb;
-    const int nrows = min(a.rpb, a.H - hrow0);
+    float2* B = A + RPB * W;
+    const long long img = blockIdx.x;  // image index (b*C + c in expand mode)
+    const int hrow0 = blockIdx.y * RPB;
+    const int nrows = min(RPB, a.H - hrow0);
     const long long row0 = img * a.H + hrow0;
-    const long long bimg = MODE == 1 ? img / a.C : 0;   // one division per workgroup
+    const long long bimg = MODE == 1 ? img / a.C : 0;  // one division per workgroup
     const float invW = 1.0f / (float)W;
     for (int i = threadIdx.x; i < W; i += MRX_FFT_NT) tw[i] = a.tw[i];
-    for (int idx = threadIdx.x; idx < nrows * W; idx += MRX_FFT_NT) {
-        const int r = mrx_fdiv(idx, invW), x = idx - r * W;
+    for (int idx = threadIdx.x; idx < RPB * W; idx += MRX_FFT_NT) {
+        const int r = P::kCT ? idx / W : mrx_fdiv(idx, invW), x = idx - r * W;
         const int g = shifted(x, a.halfW, W);
-        const long long ro = row0 + r;
-        float2 v;
-        if (MODE == 0) {
-            v = in[ro * W + g];
-        } else {
-            const float2 e = in[(bimg * a.H + hrow0 + r) * W + g];
-            const float2 s = S[ro * W + g];
-            v = make_float2(e.x * s.x - e.y * s.y, e.x * s.y + e.y * s.x);  // utils.py:115-116
+        float2 v = make_float2(0.f, 0.f);
+        if (r < nrows) {
+            const long long ro = row0 + r;
+            if (MODE == 0) {
+                v = in[ro * W + g];
+            } else {
+                const float2 e = in[(bimg * a.H + hrow0 + r) * W + g];
+                const float2 s = S[ro * W + g];
+                v = make_float2(e.x * s.x - e.y * s.y, e.x * s.y + e.y * s.x);  // utils.py:115-116
+            }
         }
         A[idx] = v;
     }
     __syncthreads();
-    float2* res = fft_lds_run<INV>(A, B, tw, a.plan, nrows, W, 1, false);
+    float2* res;
+    if constexpr (P::kCT)
+        res = RunPlan<INV, NSEQ, false, P>::run(A, B, tw);
+    else
+        res = fft_lds_run<INV>(A, B, tw, a.plan, RPB, W, 1, false);
     for (int idx = threadIdx.x; idx < nrows * W; idx += MRX_FFT_NT) {
-        const int r = mrx_fdiv(idx, invW), x = idx - r * W;
+        const int r = P::kCT ? idx / W : mrx_fdiv(idx, invW), x = idx - r * W;
         const int g = shifted(x, a.halfW, W);
         float2 v = res[idx];
         out[(row0 + r) * W + g] = make_float2(v.x * a.scale, v.y * a.scale);
@@ -150,31 +239,48 @@ struct ColArgs {
     MrxFftPlan plan;
     const float2* tw;
     int H, W, ct, halfH;
-    float scale;      // applied after the (first) transform
-    float scale2;     // DC kernel: applied after the inverse transform
-    int C;            // DC kernel: images are [B][C]
+    float scale;   // applied after the (first) transform
+    float scale2;  // DC kernel: applied after the inverse transform
+    int C;         // DC kernel: images are [B][C]
+    int ntx;       // column tiles per image
+    long long nblocks;
 };
 
-template <bool INV>
+// workgroup id -> (image, column tile).  Workgroup b runs on XCD b % 8: hand every XCD a contiguous band of tiles so
+// the 128-byte lines shared by neighbouring column tiles are fetched into one L2 only (speed, not correctness).
+__device__ __forceinline__ void col_tile(const ColArgs& a, long long& img, int& w0) {
+    long long t = blockIdx.x;
+    if ((a.nblocks & 7) == 0) t = (long long)(blockIdx.x & 7) * (a.nblocks >> 3) + (blockIdx.x >> 3);
+    img = t / a.ntx;
+    w0 = (int)(t - img * a.ntx) * a.ct;
+}
+
+template <bool INV, class P, int NSEQ>
 __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_cols(const float2* in, float2* out, ColArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    const int H = a.H, W = a.W, CT = a.ct;
+    const int H = P::kCT ? P::N : a.H, W = a.W, CT = P::kCT ? NSEQ : a.ct;
     const float invCT = 1.0f / (float)CT;
     float2* tw = smem;
     float2* A = smem + H;
     float2* B = A + H * CT;
-    const int w0 = blockIdx.x * CT;
-    const long long img = (long long)blockIdx.y * H * W;
+    long long im;
+    int w0;
+    col_tile(a, im, w0);
+    const long long img = im * H * W;
     for (int i = threadIdx.x; i < H; i += MRX_FFT_NT) tw[i] = a.tw[i];
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
+        const int p = P::kCT ? idx / CT : mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         A[idx] = w < W ? in[img + (long long)shifted(p, a.halfH, H) * W + w] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    float2* res = fft_lds_run<INV>(A, B, tw, a.plan, CT, 1, CT, true);
+    float2* res;
+    if constexpr (P::kCT)
+        res = RunPlan<INV, NSEQ, true, P>::run(A, B, tw);
+    else
+        res = fft_lds_run<INV>(A, B, tw, a.plan, CT, 1, CT, true);
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
+        const int p = P::kCT ? idx / CT : mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         if (w < W) {
             float2 v = res[idx];
@@ -184,29 +290,35 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_cols(const float2* in, float
 }
 
 // forward column FFT -> mask * (k - y) -> inverse column FFT, all in LDS (rim_utils.py:51-58)
+template <class P, int NSEQ>
 __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc(const float2* in, const float2* __restrict__ y, MrxMask mask,
                                                         float2* out, ColArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    const int H = a.H, W = a.W, CT = a.ct;
+    const int H = P::kCT ? P::N : a.H, W = a.W, CT = P::kCT ? NSEQ : a.ct;
     const float invCT = 1.0f / (float)CT;
     float2* tw = smem;
     float2* A = smem + H;
     float2* B = A + H * CT;
-    const int w0 = blockIdx.x * CT;
-    const long long bc = blockIdx.y;
-    const long long b = bc / a.C, c_ = bc % a.C;
+    long long bc;
+    int w0;
+    col_tile(a, bc, w0);
+    const long long b = bc / a.C, c_ = bc - b * a.C;
     const long long img = bc * H * W;
     for (int i = threadIdx.x; i < H; i += MRX_FFT_NT) tw[i] = a.tw[i];
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
+        const int p = P::kCT ? idx / CT : mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         A[idx] = w < W ? in[img + (long long)shifted(p, a.halfH, H) * W + w] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    float2* res = fft_lds_run<false>(A, B, tw, a.plan, CT, 1, CT, true);
+    float2* res;
+    if constexpr (P::kCT)
+        res = RunPlan<false, NSEQ, true, P>::run(A, B, tw);
+    else
+        res = fft_lds_run<false>(A, B, tw, a.plan, CT, 1, CT, true);
     float2* oth = (res == A) ? B : A;
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
+        const int p = P::kCT ? idx / CT : mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         float2 r = make_float2(0.f, 0.f);
         if (w < W) {
@@ -219,9 +331,13 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc(const float2* in, const 
         res[idx] = r;
     }
     __syncthreads();
-    float2* res2 = fft_lds_run<true>(res, oth, tw, a.plan, CT, 1, CT, true);
+    float2* res2;
+    if constexpr (P::kCT)
+        res2 = RunPlan<true, NSEQ, true, P>::run(res, oth, tw);
+    else
+        res2 = fft_lds_run<true>(res, oth, tw, a.plan, CT, 1, CT, true);
     for (int idx = threadIdx.x; idx < H * CT; idx += MRX_FFT_NT) {
-        const int p = mrx_fdiv(idx, invCT), c = idx - p * CT;
+        const int p = P::kCT ? idx / CT : mrx_fdiv(idx, invCT), c = idx - p * CT;
         const int w = w0 + c;
         if (w < W) {
             float2 v = res2[idx];
@@ -240,12 +356,12 @@ struct ReduceArgs {
 
 // inverse row FFT of every coil row (b, :, h), times conj(S), summed over coils (rim_utils.py:59-62, vn_block.py:87).
 // OUT 0: out[b,h,w] complex.  OUT 1: out4[b,0:4,h,w] = (eta_re, eta_im, g_re, g_im) (rim_utils.py:67).
-template <int OUT>
+template <int OUT, class P, int NSEQ>
 __global__ __launch_bounds__(MRX_FFT_NT) void k_rows_reduce(const float2* __restrict__ k, const float2* __restrict__ S,
                                                             const float2* __restrict__ eta, float* __restrict__ out,
                                                             ReduceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    const int W = a.W, H = a.H, C = a.C, G = a.g;
+    const int W = P::kCT ? P::N : a.W, H = a.H, C = a.C, G = P::kCT ? NSEQ : a.g;
     float2* tw = smem;
     float2* acc = smem + W;
     float2* A = acc + W;
@@ -260,12 +376,16 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_rows_reduce(const float2* __rest
     for (int c0 = 0; c0 < C; c0 += G) {
         const int nrows = min(G, C - c0);
         __syncthreads();
-        for (int idx = threadIdx.x; idx < nrows * W; idx += MRX_FFT_NT) {
-            const int r = mrx_fdiv(idx, invW), x = idx - r * W;
-            A[idx] = k[(((b * C + c0 + r) * H) + h) * W + shifted(x, a.halfW, W)];
+        for (int idx = threadIdx.x; idx < G * W; idx += MRX_FFT_NT) {
+            const int r = P::kCT ? idx / W : mrx_fdiv(idx, invW), x = idx - r * W;
+            A[idx] = r < nrows ? k[(((b * C + c0 + r) * H) + h) * W + shifted(x, a.halfW, W)] : make_float2(0.f, 0.f);
         }
         __syncthreads();
-        float2* res = fft_lds_run<true>(A, B, tw, a.plan, nrows, W, 1, false);
+        float2* res;
+        if constexpr (P::kCT)
+            res = RunPlan<true, NSEQ, false, P>::run(A, B, tw);
+        else
+            res = fft_lds_run<true>(A, B, tw, a.plan, G, W, 1, false);
         for (int x = threadIdx.x; x < W; x += MRX_FFT_NT) {
             const int g = shifted(x, a.halfW, W);
             float2 s_acc = acc[x];
@@ -299,13 +419,32 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_rows_reduce(const float2* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// host launch helpers
+// host launch helpers.  Compile-time plans for the lengths of the named configs (640x372 knee, 320x320, 256x256);
+// every other length runs the runtime-plan kernels.
 // ------------------------------------------------------------------------------------------------------------
+typedef PlanCT<372, 31, 3, 4> P372;
+typedef PlanCT<640, 5, 8, 4, 4> P640;
+typedef PlanCT<320, 5, 8, 8> P320;
+typedef PlanCT<256, 8, 8, 4> P256;
+// rows per workgroup (row kernels) / columns per workgroup (column kernels) for the compile-time plans
+#define NSEQ_ROW_372 5
+#define NSEQ_ROW_320 6
+#define NSEQ_ROW_256 8
+#define NSEQ_COL_640 4
+#define NSEQ_COL_320 8
+#define NSEQ_COL_256 8
+
 static inline int pick_rows(int W) {
+    if (W == 372) return NSEQ_ROW_372;
+    if (W == 320) return NSEQ_ROW_320;
+    if (W == 256) return NSEQ_ROW_256;
     int r = MRX_FFT_TILE_ELEMS / W;
     return r < 1 ? 1 : (r > 16 ? 16 : r);
 }
 static inline int pick_cols(int H) {
+    if (H == 640) return NSEQ_COL_640;
+    if (H == 320) return NSEQ_COL_320;
+    if (H == 256) return NSEQ_COL_256;
     int ct = 16;
     while (ct > 1 && ct * H > MRX_FFT_TILE_ELEMS + 512) ct >>= 1;
     return ct;
@@ -316,6 +455,22 @@ static int set_lds(K kern, size_t bytes) {
     MRX_REQUIRE(bytes <= 160 * 1024, MRX_EUNSUP, "FFT tile needs %zu bytes of LDS", bytes);
     if (bytes > 48 * 1024) MRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return MRX_OK;
+}
+
+template <bool INV, int MODE, class P, int NSEQ>
+static int launch_rows_t(const float2* in, const float2* S, float2* out, dim3 grid, size_t lds, const RowArgs& a, hipStream_t st) {
+    int rc = set_lds(k_fft_rows<INV, MODE, P, NSEQ>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_fft_rows<INV, MODE, P, NSEQ>), grid, dim3(MRX_FFT_NT), lds, st, in, S, out, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+template <class P, int NSEQ>
+static int launch_rows_p(const float2* in, const float2* S, float2* out, dim3 grid, size_t lds, const RowArgs& a, int inverse,
+                         int expand, hipStream_t st) {
+    if (expand) return launch_rows_t<false, 1, P, NSEQ>(in, S, out, grid, lds, a, st);
+    if (inverse) return launch_rows_t<true, 0, P, NSEQ>(in, S, out, grid, lds, a, st);
+    return launch_rows_t<false, 0, P, NSEQ>(in, S, out, grid, lds, a, st);
 }
 
 static int launch_rows(const float2* in, const float2* S, float2* out, long long nimg, int W, int C, int H,
@@ -335,21 +490,13 @@ static int launch_rows(const float2* in, const float2* S, float2* out, long long
     const size_t lds = sizeof(float2) * ((size_t)W + 2 * (size_t)a.rpb * W);
     MRX_REQUIRE(nimg < (1LL << 31), MRX_EUNSUP, "too many images (%lld)", nimg);
     const dim3 grid((unsigned)nimg, mrx_cdiv(H, a.rpb));
-    if (expand) {
-        if ((rc = set_lds(k_fft_rows<false, 1>, lds))) return rc;
-        hipLaunchKernelGGL((k_fft_rows<false, 1>), grid, dim3(MRX_FFT_NT), lds, st, in, S, out, a);
-    } else if (inverse) {
-        if ((rc = set_lds(k_fft_rows<true, 0>, lds))) return rc;
-        hipLaunchKernelGGL((k_fft_rows<true, 0>), grid, dim3(MRX_FFT_NT), lds, st, in, S, out, a);
-    } else {
-        if ((rc = set_lds(k_fft_rows<false, 0>, lds))) return rc;
-        hipLaunchKernelGGL((k_fft_rows<false, 0>), grid, dim3(MRX_FFT_NT), lds, st, in, S, out, a);
-    }
-    MRX_LAUNCH_CHECK();
-    return MRX_OK;
+    if (W == 372) return launch_rows_p<P372, NSEQ_ROW_372>(in, S, out, grid, lds, a, inverse, expand, st);
+    if (W == 320) return launch_rows_p<P320, NSEQ_ROW_320>(in, S, out, grid, lds, a, inverse, expand, st);
+    if (W == 256) return launch_rows_p<P256, NSEQ_ROW_256>(in, S, out, grid, lds, a, inverse, expand, st);
+    return launch_rows_p<PlanRT, 1>(in, S, out, grid, lds, a, inverse, expand, st);
 }
 
-static int make_col_args(ColArgs* a, int H, int W, int inverse, int norm, int centered) {
+static int make_col_args(ColArgs* a, long long nimg, int H, int W, int inverse, int norm, int centered) {
     MrxFftEntry e;
     int rc = mrx_get_plan(H, &e);
     if (rc) return rc;
@@ -362,23 +509,58 @@ static int make_col_args(ColArgs* a, int H, int W, int inverse, int norm, int ce
     a->scale = mrx_scale(H, inverse, norm);
     a->scale2 = 1.0f;
     a->C = 1;
+    a->ntx = mrx_cdiv(W, a->ct);
+    a->nblocks = nimg * a->ntx;
+    MRX_REQUIRE(a->nblocks < (1LL << 31), MRX_EUNSUP, "too many column tiles (%lld)", a->nblocks);
+    return MRX_OK;
+}
+
+template <class P, int NSEQ>
+static int launch_cols_p(const float2* in, float2* out, const ColArgs& a, size_t lds, int inverse, hipStream_t st) {
+    int rc;
+    if (inverse) {
+        if ((rc = set_lds(k_fft_cols<true, P, NSEQ>, lds))) return rc;
+        hipLaunchKernelGGL((k_fft_cols<true, P, NSEQ>), dim3((unsigned)a.nblocks), dim3(MRX_FFT_NT), lds, st, in, out, a);
+    } else {
+        if ((rc = set_lds(k_fft_cols<false, P, NSEQ>, lds))) return rc;
+        hipLaunchKernelGGL((k_fft_cols<false, P, NSEQ>), dim3((unsigned)a.nblocks), dim3(MRX_FFT_NT), lds, st, in, out, a);
+    }
+    MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 
 static int launch_cols(const float2* in, float2* out, long long nimg, int H, int W, int inverse, int norm, int centered,
                        hipStream_t st) {
     ColArgs a;
-    int rc = make_col_args(&a, H, W, inverse, norm, centered);
+    int rc = make_col_args(&a, nimg, H, W, inverse, norm, centered);
     if (rc) return rc;
-    MRX_REQUIRE(nimg <= 65535LL * 1, MRX_EUNSUP, "too many images in one column launch (%lld)", nimg);
     const size_t lds = sizeof(float2) * ((size_t)H + 2 * (size_t)a.ct * H);
-    dim3 grid(mrx_cdiv(W, a.ct), (unsigned)nimg);
-    if (inverse) {
-        if ((rc = set_lds(k_fft_cols<true>, lds))) return rc;
-        hipLaunchKernelGGL(k_fft_cols<true>, grid, dim3(MRX_FFT_NT), lds, st, in, out, a);
+    if (H == 640) return launch_cols_p<P640, NSEQ_COL_640>(in, out, a, lds, inverse, st);
+    if (H == 320) return launch_cols_p<P320, NSEQ_COL_320>(in, out, a, lds, inverse, st);
+    if (H == 256) return launch_cols_p<P256, NSEQ_COL_256>(in, out, a, lds, inverse, st);
+    return launch_cols_p<PlanRT, 1>(in, out, a, lds, inverse, st);
+}
+
+template <class P, int NSEQ>
+static int launch_dc_p(const float2* in, const float2* y, const MrxMask& m, float2* out, const ColArgs& a, size_t lds,
+                       hipStream_t st) {
+    int rc = set_lds(k_cols_dc<P, NSEQ>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_cols_dc<P, NSEQ>), dim3((unsigned)a.nblocks), dim3(MRX_FFT_NT), lds, st, in, y, m, out, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+template <class P, int NSEQ>
+static int launch_reduce_p(const float2* k, const float2* S, const float2* eta, float* out, dim3 grid, size_t lds,
+                           const ReduceArgs& a, int out_mode, hipStream_t st) {
+    int rc;
+    if (out_mode == 0) {
+        if ((rc = set_lds(k_rows_reduce<0, P, NSEQ>, lds))) return rc;
+        hipLaunchKernelGGL((k_rows_reduce<0, P, NSEQ>), grid, dim3(MRX_FFT_NT), lds, st, k, S, eta, out, a);
     } else {
-        if ((rc = set_lds(k_fft_cols<false>, lds))) return rc;
-        hipLaunchKernelGGL(k_fft_cols<false>, grid, dim3(MRX_FFT_NT), lds, st, in, out, a);
+        if ((rc = set_lds(k_rows_reduce<1, P, NSEQ>, lds))) return rc;
+        hipLaunchKernelGGL((k_rows_reduce<1, P, NSEQ>), grid, dim3(MRX_FFT_NT), lds, st, k, S, eta, out, a);
     }
     MRX_LAUNCH_CHECK();
     return MRX_OK;
@@ -396,22 +578,18 @@ static int launch_reduce(const float2* k, const float2* S, const float2* eta, fl
     a.H = H;
     a.W = W;
     a.g = pick_rows(W);
-    if (a.g > C) a.g = C;
+    const bool ct = (W == 372 || W == 320 || W == 256);
+    if (!ct && a.g > C) a.g = C;
     a.halfW = centered ? W / 2 : 0;
     a.scale = mrx_scale(W, 1, norm);
     a.post = post;
     MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "batch %d too large", B);
     const size_t lds = sizeof(float2) * (2 * (size_t)W + 2 * (size_t)a.g * W);
     dim3 grid(H, B);
-    if (out_mode == 0) {
-        if ((rc = set_lds(k_rows_reduce<0>, lds))) return rc;
-        hipLaunchKernelGGL(k_rows_reduce<0>, grid, dim3(MRX_FFT_NT), lds, st, k, S, eta, out, a);
-    } else {
-        if ((rc = set_lds(k_rows_reduce<1>, lds))) return rc;
-        hipLaunchKernelGGL(k_rows_reduce<1>, grid, dim3(MRX_FFT_NT), lds, st, k, S, eta, out, a);
-    }
-    MRX_LAUNCH_CHECK();
-    return MRX_OK;
+    if (W == 372) return launch_reduce_p<P372, NSEQ_ROW_372>(k, S, eta, out, grid, lds, a, out_mode, st);
+    if (W == 320) return launch_reduce_p<P320, NSEQ_ROW_320>(k, S, eta, out, grid, lds, a, out_mode, st);
+    if (W == 256) return launch_reduce_p<P256, NSEQ_ROW_256>(k, S, eta, out, grid, lds, a, out_mode, st);
+    return launch_reduce_p<PlanRT, 1>(k, S, eta, out, grid, lds, a, out_mode, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -437,12 +615,7 @@ extern "C" int mrx_fft2(const float* in, float* out, int64_t batch, int H, int W
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_rows((const float2*)in, nullptr, (float2*)out, batch, W, 1, H, inverse, norm, centered, 0, st);
     if (rc) return rc;
-    for (int64_t i0 = 0; i0 < batch; i0 += 65535) {
-        const int64_t n = batch - i0 < 65535 ? batch - i0 : 65535;
-        float2* o = (float2*)out + i0 * H * W;
-        if ((rc = launch_cols(o, o, n, H, W, inverse, norm, centered, st))) return rc;
-    }
-    return MRX_OK;
+    return launch_cols((float2*)out, (float2*)out, batch, H, W, inverse, norm, centered, st);
 }
 
 extern "C" int mrx_sens_expand(const float* x, const float* S, float* out, int B, int C, int H, int W, int norm,
@@ -455,13 +628,7 @@ extern "C" int mrx_sens_expand(const float* x, const float* S, float* out, int B
     int rc = launch_rows((const float2*)x, (const float2*)S, (float2*)out, (long long)B * C, W, C, H, 0, norm,
                          centered, 1, st);
     if (rc) return rc;
-    const long long nimg = (long long)B * C;
-    for (long long i0 = 0; i0 < nimg; i0 += 65535) {
-        const long long n = nimg - i0 < 65535 ? nimg - i0 : 65535;
-        float2* o = (float2*)out + i0 * H * W;
-        if ((rc = launch_cols(o, o, n, H, W, 0, norm, centered, st))) return rc;
-    }
-    return MRX_OK;
+    return launch_cols((float2*)out, (float2*)out, (long long)B * C, H, W, 0, norm, centered, st);
 }
 
 extern "C" int mrx_sens_reduce(const float* k, const float* S, float* out, float* work, int B, int C, int H, int W,
@@ -471,13 +638,8 @@ extern "C" int mrx_sens_reduce(const float* k, const float* S, float* out, float
     MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_sens_reduce: bad normalization %d", norm);
     if (B == 0) return MRX_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc;
-    const long long nimg = (long long)B * C;
-    for (long long i0 = 0; i0 < nimg; i0 += 65535) {
-        const long long n = nimg - i0 < 65535 ? nimg - i0 : 65535;
-        if ((rc = launch_cols((const float2*)k + i0 * H * W, (float2*)work + i0 * H * W, n, H, W, 1, norm, centered, st)))
-            return rc;
-    }
+    int rc = launch_cols((const float2*)k, (float2*)work, (long long)B * C, H, W, 1, norm, centered, st);
+    if (rc) return rc;
     return launch_reduce((const float2*)work, (const float2*)S, nullptr, out, B, C, H, W, norm, centered, 1.0f, 0, st);
 }
 
@@ -488,7 +650,6 @@ extern "C" int mrx_llg(const float* eta, const float* y, const float* S, const v
     MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_llg: bad dims");
     MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_llg: bad normalization %d", norm);
     MRX_REQUIRE(mask_kind == MRX_MASK_U8 || mask_kind == MRX_MASK_F32, MRX_EINVAL, "mrx_llg: bad mask kind %d", mask_kind);
-    MRX_REQUIRE((long long)B * C <= 65535, MRX_EUNSUP, "mrx_llg: B*C = %lld > 65535", (long long)B * C);
     if (B == 0) return MRX_OK;
     hipStream_t st = (hipStream_t)stream;
     // 1) rows: eta * S -> FFT_W                                   (rim_utils.py:44-51)
@@ -497,7 +658,7 @@ extern "C" int mrx_llg(const float* eta, const float* y, const float* S, const v
     if (rc) return rc;
     // 2) cols: FFT_H -> mask*(k - y) -> IFFT_H                    (rim_utils.py:51-58)
     ColArgs a;
-    if ((rc = make_col_args(&a, H, W, 0, norm, centered))) return rc;
+    if ((rc = make_col_args(&a, (long long)B * C, H, W, 0, norm, centered))) return rc;
     a.scale2 = mrx_scale(H, 1, norm);
     a.C = C;
     MrxMask m;
@@ -505,10 +666,15 @@ extern "C" int mrx_llg(const float* eta, const float* y, const float* S, const v
     m.kind = mask_kind;
     for (int i = 0; i < 4; ++i) m.s[i] = mstride[i];
     const size_t lds = sizeof(float2) * ((size_t)H + 2 * (size_t)a.ct * H);
-    if ((rc = set_lds(k_cols_dc, lds))) return rc;
-    hipLaunchKernelGGL(k_cols_dc, dim3(mrx_cdiv(W, a.ct), B * C), dim3(MRX_FFT_NT), lds, st, (const float2*)work,
-                       (const float2*)y, m, (float2*)work, a);
-    MRX_LAUNCH_CHECK();
+    if (H == 640)
+        rc = launch_dc_p<P640, NSEQ_COL_640>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    else if (H == 320)
+        rc = launch_dc_p<P320, NSEQ_COL_320>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    else if (H == 256)
+        rc = launch_dc_p<P256, NSEQ_COL_256>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    else
+        rc = launch_dc_p<PlanRT, 1>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    if (rc) return rc;
     // 3) rows: IFFT_W -> sum_c conj(S) -> /sigma^2 -> [B,4,H,W]   (rim_utils.py:59-67)
     return launch_reduce((const float2*)work, (const float2*)S, (const float2*)eta, out4, B, C, H, W, norm, centered,
                          inv_sigma2, 1, st);

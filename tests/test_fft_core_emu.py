@@ -20,6 +20,7 @@ def emu(tmp_path_factory):
     lib.emu_fft.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                             ctypes.c_long]
     lib.emu_plan.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    lib.emu_fft_ct.argtypes = lib.emu_fft.argtypes
     return lib
 
 
@@ -49,4 +50,20 @@ def test_emulated_fft_matches_numpy(emu, n, inverse):
     # column layout: batch-fastest, element stride nseq
     buf = np.ascontiguousarray(x.T.copy())
     assert emu.emu_fft(buf.ctypes.data, n, nseq, 1, nseq, inverse, buf.size) == 0
+    assert np.linalg.norm(buf.T - ref) <= 3e-6 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("n", [372, 640, 320, 256, 512, 384, 368, 77, 30, 16, 13])
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_compile_time_plans_match_numpy(emu, n, inverse):
+    """fft_ct.h: the compile-time plans the HIP kernels instantiate (radix 8, in-register prime butterflies)."""
+    rng = np.random.default_rng(7 * n + inverse)
+    nseq = 3
+    x = (rng.standard_normal((nseq, n)) + 1j * rng.standard_normal((nseq, n))).astype(np.complex64)
+    ref = (np.fft.ifft(x.astype(np.complex128), axis=1) * n) if inverse else np.fft.fft(x.astype(np.complex128), axis=1)
+    buf = np.ascontiguousarray(x.copy())
+    assert emu.emu_fft_ct(buf.ctypes.data, n, nseq, n, 1, inverse, buf.size) == 0
+    assert np.linalg.norm(buf - ref) <= 3e-6 * np.linalg.norm(ref)
+    buf = np.ascontiguousarray(x.T.copy())
+    assert emu.emu_fft_ct(buf.ctypes.data, n, nseq, 1, nseq, inverse, buf.size) == 0
     assert np.linalg.norm(buf.T - ref) <= 3e-6 * np.linalg.norm(ref)

@@ -54,7 +54,8 @@ def test_g1_fft_headline_size(golden, dev):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 1), (3, 1, 7), (2, 7, 1), (1, 49, 121), (1, 127, 64), (2, 100, 77), (1, 320, 320),
-                                   (1, 256, 256), (1, 1024, 6), (1, 5, 2310)])
+                                   (1, 256, 256), (1, 1024, 6), (1, 5, 2310), (3, 640, 372), (2, 372, 640), (5, 256, 320),
+                                   (1, 3, 372), (1, 640, 3)])
 def test_fft_vs_float64(shape, dev):
     """Awkward lengths (primes, prime powers, long) against numpy float64; round trip ifft2(fft2(x)) == x."""
     import mridc_amd.collections.common.parts.fft as fft
@@ -182,7 +183,7 @@ def test_llg_headline_size(golden, dev):
 def test_sens_expand_reduce_vs_oracle(dev):
     from mridc_amd import ops
     g = torch.Generator().manual_seed(9)
-    for (B, C, H, W) in ((2, 3, 13, 18), (1, 5, 32, 24), (1, 2, 31, 7)):
+    for (B, C, H, W) in ((2, 3, 13, 18), (1, 5, 32, 24), (1, 2, 31, 7), (2, 3, 320, 256), (1, 7, 256, 372), (1, 2, 640, 320)):
         x = torch.randn(B, H, W, 2, generator=g)
         S = torch.randn(B, C, H, W, 2, generator=g)
         k = torch.randn(B, C, H, W, 2, generator=g)
