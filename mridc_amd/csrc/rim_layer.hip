@@ -12,6 +12,9 @@
 //     matrix cores (issue-early / write-late staging);
 //   * the 1x1 `ih` GEMM consumes the conv accumulators in registers (contraction index enumerated in C/D-layout order),
 //     its packed weights sit in their own LDS region from kernel start.
+#include <cstdlib>
+#include <vector>
+
 #include "mrx_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -30,6 +33,9 @@ struct RimLayerArgs {
     const float* hprev;    // [B,F,H,W] or null
     float* hnew;           // [B,F,H,W]
     int B, Cin, H, W, tiles_x, ntiles;
+    int stagger;  // s_sleep argument for odd dispatch rounds (0 = off)
+    unsigned long long* trace;  // debug only (env MRX_TRACE): 6 s_memtime stamps per workgroup
+    int ablate;  // debug only (env MRX_ABLATE): 1 no h_prev loads, 2 no stores, 4 no main-loop MFMA, 8 no chunk staging, 16 no 1x1 GEMM
 };
 
 __host__ __device__ constexpr int rl_pad(int K, int DIL) { return DIL * (K - 1) / 2; }
@@ -91,6 +97,10 @@ extern "C" int mrx_rim_layer_pack(const float* w_conv, const float* w_ih, float*
 }
 
 // ---- the fused layer -----------------------------------------------------------------------------------------------
+// LDS: two buffers, each [CK][PLANE] input tile + [TAPS][CK/2][2][F] weights.  Iteration q runs the matrix cores on buffer
+// q&1 while the global loads of chunk q+1 are in flight; afterwards every wave writes its prefetched registers into the
+// other buffer and the workgroup meets at ONE barrier per chunk.  After the last chunk the free buffer receives the packed
+// 1x1 `ih` weights (prefetched through registers the same way).
 template <int K, int DIL, int CK>
 __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
     constexpr int PAD = rl_pad(K, DIL);
@@ -99,10 +109,9 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
     constexpr int WCHUNK = TAPS * CK * RL_F;               // floats of packed weights per chunk
     constexpr int XSLOTS = (PLANE + RL_NT - 1) / RL_NT;    // input-tile elements per thread per channel
     constexpr int WVEC = (WCHUNK / 4 + RL_NT - 1) / RL_NT;  // float4 per thread per chunk
+    constexpr int BUF = (CK * PLANE + WCHUNK) > RL_F * RL_F ? (CK * PLANE + WCHUNK) : RL_F * RL_F;
+    constexpr int WIVEC = RL_F * RL_F / 4 / RL_NT;         // float4 of ih weights per thread (= 2)
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    float* Xs = smem_f;                  // [CK][PLANE]
-    float* Ws = Xs + CK * PLANE;         // [TAPS][CK/2][2][F]   (16-byte aligned: CK*PLANE is a multiple of 4)
-    float* Wi = Ws + WCHUNK;             // [32][2][F]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -132,6 +141,7 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
 
     float xr[CK][XSLOTS];
     float4 wr[WVEC];
+    float4 wir[WIVEC];
     auto prefetch = [&](int q) {
 #pragma unroll
         for (int ci = 0; ci < CK; ++ci) {
@@ -149,14 +159,43 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
             wr[v] = (i < WCHUNK / 4) ? wsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-
-    // ih weights: own LDS region, filled once
-    {
+    auto commit = [&](float* buf) {  // prefetched registers -> LDS buffer
+#pragma unroll
+        for (int ci = 0; ci < CK; ++ci)
+#pragma unroll
+            for (int s = 0; s < XSLOTS; ++s) {
+                const int e = tid + s * RL_NT;
+                if (e < PLANE) buf[ci * PLANE + e] = xr[ci][s];
+            }
+        float4* wdst = reinterpret_cast<float4*>(buf + CK * PLANE);
+#pragma unroll
+        for (int v = 0; v < WVEC; ++v) {
+            const int i = tid + v * RL_NT;
+            if (i < WCHUNK / 4) wdst[i] = wr[v];
+        }
+    };
+    auto prefetch_wi = [&]() {
         const float4* src = reinterpret_cast<const float4*>(a.packed + (long long)nchunks * WCHUNK);
-        float4* dst = reinterpret_cast<float4*>(Wi);
-        for (int i = tid; i < RL_F * RL_F / 4; i += RL_NT) dst[i] = src[i];
-    }
+#pragma unroll
+        for (int v = 0; v < WIVEC; ++v) wir[v] = src[tid + v * RL_NT];
+    };
+
+    // The two workgroups sharing a CU start together and would stay in lockstep (both staging, then both on the matrix
+    // cores at half rate).  A one-time stagger of every other dispatch round lets one stage while the other computes;
+    // the out-of-phase schedule is self-sustaining because the computing block gets the whole MFMA pipe meanwhile.
+#define RL_STAMP(i)                                                                          \
+    if (a.trace && tid == 0) a.trace[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter();
+    RL_STAMP(0)
+    if (a.stagger && ((blockIdx.x >> 8) & 1))
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(8);  // 512 cycles each
     prefetch(0);
+    commit(smem_f);
+    if (nchunks > 1)
+        prefetch(1);
+    else
+        prefetch_wi();
+    __syncthreads();
+    RL_STAMP(1)
 
     f32x16 acc[2];
 #pragma unroll
@@ -165,23 +204,11 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 
     for (int q = 0; q < nchunks; ++q) {
-        __syncthreads();  // previous chunk fully consumed
-#pragma unroll
-        for (int ci = 0; ci < CK; ++ci)
-#pragma unroll
-            for (int s = 0; s < XSLOTS; ++s) {
-                const int e = tid + s * RL_NT;
-                if (e < PLANE) Xs[ci * PLANE + e] = xr[ci][s];
-            }
-#pragma unroll
-        for (int v = 0; v < WVEC; ++v) {
-            const int i = tid + v * RL_NT;
-            if (i < WCHUNK / 4) reinterpret_cast<float4*>(Ws)[i] = wr[v];
-        }
-        __syncthreads();
-        if (q + 1 < nchunks) prefetch(q + 1);  // loads fly while the matrix cores work on chunk q
-        const float* xw = Xs + lhi * PLANE + wave * PW + l31;
-        const float* ww = Ws + lhi * RL_F + l31;
+        const float* cur = smem_f + (q & 1) * BUF;
+        float* oth = smem_f + ((q + 1) & 1) * BUF;
+        const float* xw = cur + lhi * PLANE + wave * PW + l31;
+        const float* ww = cur + CK * PLANE + lhi * RL_F + l31;
+        if (!(a.ablate & 4))
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int ky = tap / K, kx = tap % K;  // folded: tap is an unrolled constant
@@ -194,12 +221,41 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
             }
         }
+        // fill the other buffer (its readers all passed the previous barrier), then one barrier per chunk
+        if (q + 1 < nchunks) {
+            if (!(a.ablate & 8)) commit(oth);
+        } else {
+            float4* dst = reinterpret_cast<float4*>(oth);
+#pragma unroll
+            for (int v = 0; v < WIVEC; ++v) dst[tid + v * RL_NT] = wir[v];
+        }
+        __syncthreads();
+        if (q + 2 < nchunks) {
+            if (!(a.ablate & 8)) prefetch(q + 2);
+        } else if (q + 2 == nchunks)
+            prefetch_wi();
     }
+    const float* Wi = smem_f + (nchunks & 1) * BUF;  // [32][2][F], written during the last iteration
+    RL_STAMP(2)
 
     // ---- g = ReLU(conv + b_conv), kept in registers; h = ReLU(Wih g + b_ih + hh * h_prev) -----------------------------
     const int oy = h0 + wave, ox = w0 + l31;
     const bool inside = oy < a.H && ox < a.W;
     const long long obase = (long long)b * RL_F * plane + (long long)oy * a.W + ox;
+    // Wide epilogue (W % 4 == 0): the 64x32 result tile of this wave is transposed through LDS so that every lane owns
+    // 4 consecutive pixels of one channel: 8 float4 loads of h_prev and 8 float4 stores per lane instead of 32 + 32 scalar
+    // accesses (the scalar store tail is instruction-issue bound).  Lane L, iteration i: channel i*8 + L/8, pixels 4*(L%8)..+3.
+    const bool wide = (a.W & 3) == 0;
+    const int wch = lane >> 3, wpx = (lane & 7) * 4;
+    const long long wbase = (long long)b * RL_F * plane + (long long)oy * a.W + w0 + wpx;
+    const bool winside = oy < a.H && (w0 + wpx) < a.W;
+    float4 hp4[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hp4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wide && a.hprev && winside && !(a.ablate & 1))
+            hp4[i] = *reinterpret_cast<const float4*>(a.hprev + wbase + (long long)(i * 8 + wch) * plane);
+    }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -214,6 +270,7 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[ct][r] = 0.f;
     const float* wi = Wi + lhi * RL_F + l31;
+    if (!(a.ablate & 16))
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -223,30 +280,110 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
             acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, acc[ct][r], acc2[0], 0, 0, 0);
             acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, acc[ct][r], acc2[1], 0, 0, 0);
         }
-    if (!inside) return;
+    RL_STAMP(3)
+    if (wide) {
+        __syncthreads();  // every wave is done with Wi and the chunk buffers: LDS becomes 8 x [64][32] transpose tiles
+        float* T = smem_f + wave * (RL_F * RL_TW);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            const long long o = obase + (long long)co * plane;
-            float v = acc2[ct][r];
-            if (a.b_ih) v += a.b_ih[co];
-            if (a.hprev) v += a.hh[co] * a.hprev[o];
-            a.hnew[o] = v > 0.f ? v : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                T[co * RL_TW + l31] = acc2[ct][r];
+            }
+        // same-wave LDS traffic is ordered; no workgroup barrier needed for a wave-private tile
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = i * 8 + wch;
+            float4 v = *reinterpret_cast<const float4*>(T + ch * RL_TW + wpx);
+            const float bi = a.b_ih ? a.b_ih[ch] : 0.f;
+            const float hw = a.hh[ch];
+            v.x = v.x + bi + hw * hp4[i].x;
+            v.y = v.y + bi + hw * hp4[i].y;
+            v.z = v.z + bi + hw * hp4[i].z;
+            v.w = v.w + bi + hw * hp4[i].w;
+            v.x = v.x > 0.f ? v.x : 0.f;
+            v.y = v.y > 0.f ? v.y : 0.f;
+            v.z = v.z > 0.f ? v.z : 0.f;
+            v.w = v.w > 0.f ? v.w : 0.f;
+            if (winside && (!(a.ablate & 2) || v.x == 12345.678f))
+                *reinterpret_cast<float4*>(a.hnew + wbase + (long long)ch * plane) = v;
         }
+    } else if (inside) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc2[ct][r];
+                if (a.b_ih) v += a.b_ih[co];
+                if (a.hprev && !(a.ablate & 1)) v += a.hh[co] * a.hprev[obase + (long long)co * plane];
+                v = v > 0.f ? v : 0.f;
+                if (!(a.ablate & 2) || v == 12345.678f) a.hnew[obase + (long long)co * plane] = v;
+            }
+    }
+    RL_STAMP(4)
+    if (a.trace && tid == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        a.trace[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = hwid;
+    }
 }
 
 template <int K, int DIL, int CK>
-static int launch_rim_layer(const RimLayerArgs& a, hipStream_t st) {
+static int launch_rim_layer(const RimLayerArgs& a_in, hipStream_t st) {
     constexpr int PAD = rl_pad(K, DIL);
     constexpr int PLANE = (RL_TH + 2 * PAD) * (RL_TW + 2 * PAD);
-    constexpr size_t lds = sizeof(float) * ((size_t)CK * PLANE + (size_t)K * K * CK * RL_F + RL_F * RL_F);
-    static_assert((CK * PLANE) % 4 == 0, "weight region must stay 16-byte aligned");
+    constexpr size_t per_buf = ((size_t)CK * PLANE + (size_t)K * K * CK * RL_F) > (size_t)RL_F * RL_F
+                                   ? ((size_t)CK * PLANE + (size_t)K * K * CK * RL_F)
+                                   : (size_t)RL_F * RL_F;
+    // two staging buffers; the wide epilogue re-uses the space as 8 wave-private [64][32] transpose tiles
+    constexpr size_t lds_floats = 2 * per_buf > (size_t)(RL_NT / 64) * RL_F * RL_TW ? 2 * per_buf : (size_t)(RL_NT / 64) * RL_F * RL_TW;
+    constexpr size_t lds = sizeof(float) * lds_floats;
+    static_assert((CK * PLANE) % 4 == 0 && per_buf % 4 == 0, "weight regions must stay 16-byte aligned");
     if (lds > 48 * 1024)
         MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer<K, DIL, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static unsigned long long* d_trace = nullptr;
+    RimLayerArgs a = a_in;
+    a.trace = nullptr;
+    if (getenv("MRX_TRACE")) {
+        if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 8 * 65536);
+        (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 8 * 65536, st);
+        a.trace = d_trace;
+    }
+    if (getenv("MRX_DEBUG_OCC")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_rim_layer<K, DIL, CK>, RL_NT, lds);
+        fprintf(stderr, "[mrx] k_rim_layer<%d,%d,%d>: lds %zu B, occupancy API: %d blocks/CU\n", K, DIL, CK, lds, nb);
+    }
     hipLaunchKernelGGL((k_rim_layer<K, DIL, CK>), dim3(a.ntiles, a.B), dim3(RL_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
+    if (a.trace && getenv("MRX_TRACE_DUMP")) {
+        (void)hipStreamSynchronize(st);
+        const int nb = a.ntiles * a.B;
+        std::vector<unsigned long long> h((size_t)nb * 8);
+        (void)hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * 8 * nb, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double ph[4] = {0, 0, 0, 0};
+        for (int i = 0; i < nb; ++i) {
+            const unsigned long long* r = &h[(size_t)i * 8];
+            if (r[0] < t0) t0 = r[0];
+            if (r[4] > t1) t1 = r[4];
+            for (int k = 0; k < 4; ++k) ph[k] += (double)(r[k + 1] - r[k]);
+        }
+        fprintf(stderr, "[mrx-trace] k_rim_layer<%d,%d,%d> %d blocks: span %llu cyc; mean per block: prologue %.0f main %.0f "
+                        "1x1 %.0f epilogue %.0f (sum %.0f)\n", K, DIL, CK, nb, t1 - t0, ph[0] / nb, ph[1] / nb, ph[2] / nb, ph[3] / nb,
+                (ph[0] + ph[1] + ph[2] + ph[3]) / nb);
+        // start-time histogram: how many blocks start in each 10% of the span, and CU sharing
+        int hist[10] = {0};
+        for (int i = 0; i < nb; ++i) hist[(int)((double)(h[(size_t)i * 8] - t0) * 10 / (double)(t1 - t0 + 1))]++;
+        fprintf(stderr, "[mrx-trace] start histogram:");
+        for (int k = 0; k < 10; ++k) fprintf(stderr, " %d", hist[k]);
+        fprintf(stderr, "\n");
+        for (int i = 0; i < 6 && i < nb; ++i)
+            fprintf(stderr, "[mrx-trace] block %d hwid %08llx start %llu dur %llu\n", i, h[(size_t)i * 8 + 5], h[(size_t)i * 8] - t0,
+                    h[(size_t)i * 8 + 4] - h[(size_t)i * 8]);
+    }
     return MRX_OK;
 }
 
@@ -279,6 +416,10 @@ extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, 
     a.W = W;
     a.tiles_x = mrx_cdiv(W, RL_TW);
     a.ntiles = a.tiles_x * mrx_cdiv(H, RL_TH);
+    static const int ablate = getenv("MRX_ABLATE") ? atoi(getenv("MRX_ABLATE")) : 0;
+    a.ablate = ablate;
+    static const int stagger = getenv("MRX_STAGGER") ? atoi(getenv("MRX_STAGGER")) : 0;
+    a.stagger = stagger;
     hipStream_t st = (hipStream_t)stream;
     const bool small = rl_ck(Cin) == 4;
 #define RL_CASE(KK, DD)                                                       \
