@@ -128,8 +128,10 @@ def main():
     state_dict = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     B, C, H, W = args.batch, args.coils, args.height, args.width
-    # each rank reconstructs its own slices (slice index = rank*B + i): embarrassingly parallel, no collective
-    slices = [synthetic.make_slice(C, H, W, slice_idx=rank * B + i) for i in range(B)]
+    # each rank reconstructs its own contiguous share of the world*B slices: embarrassingly parallel, no collective
+    from mridc_amd.sharding import shard_range
+    s0, s1 = shard_range(world * B, rank, world)
+    slices = [synthetic.make_slice(C, H, W, slice_idx=i) for i in range(s0, s1)]
     host = {k: torch.cat([s[k] for s in slices], 0) for k in ("y", "sensitivity_maps", "target")}
     host["mask"] = slices[0]["mask"]
     data = {k: v.to(dev) for k, v in host.items()}
