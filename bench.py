@@ -143,6 +143,7 @@ def main():
     timer.wrap(ops, "rim_layer_indrnn", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
     timer.wrap(ops, "rim_layer_indrnn_packed", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
+    timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
     timer.wrap(ops, "rim_final", lambda *a, **k: "final")
 
     def step():
@@ -186,7 +187,8 @@ def main():
                         traffic=None, launches=n2, avg_ms=ms2, flops_per_launch=flops2)
         bytes_llg = (25.0 + 16.0 * C) * npix * B     # compulsory bytes of one log_likelihood_gradient
         msl, nl = timer.mean_ms("llg")
-        roofline_fft = dict(bound="hbm", kernel="mrx_llg (3 launches: rows expand+FFT, cols FFT+DC+IFFT, rows IFFT+reduce)",
+        roofline_fft = dict(bound="hbm", kernel="mrx_llg_hinv (1-D column mask: H transforms cancel, ONE launch of row FFTs per step on "
+                                                "yt = IFFT_H(y); 2-D masks use the 3-launch mrx_llg)",
                             achieved=(bytes_llg / (msl * 1e-3) / 1e9) if msl else None, peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=(bytes_llg / (msl * 1e-3) / 1e9 / PEAK_HBM_GBS) if msl else None, traffic=None,
                             launches=nl, avg_ms=msl, bytes_per_call=bytes_llg)

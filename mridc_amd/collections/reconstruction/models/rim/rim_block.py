@@ -107,11 +107,20 @@ class RIMBlock(torch.nn.Module):
             eta = pred if keep_eta else ops.sens_reduce(pred, sense, self.fft_centered, self.fft_normalization,
                                                         self.spatial_dims)
         final = self.final_layer[0]
-        work = torch.empty_like(masked_kspace, dtype=torch.float32)
+        # 1-D column masks: the H transforms of log_likelihood_gradient cancel (csrc/fft.hip: k_llg_rows_hinv) -- one
+        # launch per step on yt = IFFT_H(y); any other mask takes the general three-launch path
+        hinv = ops.mask_is_row_invariant(mask) and self.coil_dim == 1
+        if hinv:
+            yt = ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        else:
+            work = torch.empty_like(masked_kspace, dtype=torch.float32)
         etas = []
         for _ in range(self.time_steps):                             # rim_block.py:217-249
-            grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
-                               self.spatial_dims, work=work)
+            if hinv:
+                grad_eta = ops.llg_hinv(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
+            else:
+                grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
+                                   self.spatial_dims, work=work)
             for h, convrnn in enumerate(self.layers):
                 hx[h] = self._layer(h, convrnn, grad_eta, hx[h])
                 grad_eta = hx[h]

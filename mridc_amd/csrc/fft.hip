@@ -418,6 +418,97 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_rows_reduce(const float2* __rest
     }
 }
 
+// log_likelihood_gradient for masks that do not depend on the row index h (mstride_h == 0: 1-D column masks).  Then
+//   IFFT_H( m(w) * (FFT_H(FFT_W(eta S)) - y) ) = m(w) * (FFT_W(eta S) - IFFT_H(y))
+// (the H transforms cancel for every normalisation, centred or not), so with yt = IFFT_H(y) precomputed once the whole
+// step is row transforms only and fuses into ONE kernel per (b, h) row: eta*S -> FFT_W -> m*(. - yt) -> IFFT_W ->
+// sum_c conj(S) -> /sigma^2.  HBM traffic = the algorithmic (25 + 16 C) H W bytes; no work buffer.
+template <class P, int NSEQ>
+__global__ __launch_bounds__(MRX_FFT_NT) void k_llg_rows_hinv(const float2* __restrict__ eta, const float2* __restrict__ yt,
+                                                              const float2* __restrict__ S, MrxMask mask,
+                                                              float* __restrict__ out, ReduceArgs a, float scale_f) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int W = P::kCT ? P::N : a.W, H = a.H, C = a.C, G = P::kCT ? NSEQ : a.g;
+    float2* tw = smem;
+    float2* acc = smem + W;
+    float2* E = acc + W;
+    float2* Sb = E + W;
+    float2* A = Sb + G * W;
+    float2* B = A + G * W;
+    const int h = blockIdx.x;
+    const long long b = blockIdx.y;
+    const float invW = 1.0f / (float)W;
+    for (int i = threadIdx.x; i < W; i += MRX_FFT_NT) {
+        tw[i] = a.tw[i];
+        acc[i] = make_float2(0.f, 0.f);
+        E[i] = eta[(b * H + h) * W + shifted(i, a.halfW, W)];
+    }
+    for (int c0 = 0; c0 < C; c0 += G) {
+        const int nrows = min(G, C - c0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < G * W; idx += MRX_FFT_NT) {
+            const int r = P::kCT ? idx / W : mrx_fdiv(idx, invW), x = idx - r * W;
+            float2 s = make_float2(0.f, 0.f), v = make_float2(0.f, 0.f);
+            if (r < nrows) {
+                s = S[(((b * C + c0 + r) * H) + h) * W + shifted(x, a.halfW, W)];
+                const float2 e = E[x];
+                v = make_float2(e.x * s.x - e.y * s.y, e.x * s.y + e.y * s.x);  // rim_utils.py:47-48
+            }
+            Sb[idx] = s;
+            A[idx] = v;
+        }
+        __syncthreads();
+        float2* res;
+        if constexpr (P::kCT)
+            res = RunPlan<false, NSEQ, false, P>::run(A, B, tw);
+        else
+            res = fft_lds_run<false>(A, B, tw, a.plan, G, W, 1, false);
+        float2* oth = (res == A) ? B : A;
+        for (int idx = threadIdx.x; idx < G * W; idx += MRX_FFT_NT) {
+            const int r = P::kCT ? idx / W : mrx_fdiv(idx, invW), x = idx - r * W;
+            float2 d = make_float2(0.f, 0.f);
+            if (r < nrows) {
+                const int g = shifted(x, a.halfW, W);
+                const float2 k = res[idx];
+                const float2 yv = yt[(((b * C + c0 + r) * H) + h) * W + g];
+                const float m = mrx_mask_val(mask, b, c0 + r, 0, g);
+                d = make_float2(m * (k.x * scale_f - yv.x), m * (k.y * scale_f - yv.y));  // rim_utils.py:54 in hybrid space
+            }
+            res[idx] = d;
+        }
+        __syncthreads();
+        float2* res2;
+        if constexpr (P::kCT)
+            res2 = RunPlan<true, NSEQ, false, P>::run(res, oth, tw);
+        else
+            res2 = fft_lds_run<true>(res, oth, tw, a.plan, G, W, 1, false);
+        for (int x = threadIdx.x; x < W; x += MRX_FFT_NT) {
+            float2 s_acc = acc[x];
+            for (int r = 0; r < nrows; ++r) {
+                float2 v = res2[r * W + x];
+                v.x *= a.scale;
+                v.y *= a.scale;
+                const float2 s = Sb[r * W + x];
+                s_acc.x += v.x * s.x + v.y * s.y;  // rim_utils.py:61
+                s_acc.y += v.y * s.x - v.x * s.y;  // rim_utils.py:62
+            }
+            acc[x] = s_acc;
+        }
+    }
+    __syncthreads();
+    const long long plane = (long long)H * W;
+    for (int x = threadIdx.x; x < W; x += MRX_FFT_NT) {
+        const int g = shifted(x, a.halfW, W);
+        const float2 v = acc[x];
+        const float2 e = E[x];
+        float* o = out + b * 4 * plane + (long long)h * W + g;
+        o[0] = e.x;
+        o[plane] = e.y;
+        o[2 * plane] = v.x * a.post;
+        o[3 * plane] = v.y * a.post;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host launch helpers.  Compile-time plans for the lengths of the named configs (640x372 knee, 320x320, 256x256);
 // every other length runs the runtime-plan kernels.
@@ -678,4 +769,64 @@ extern "C" int mrx_llg(const float* eta, const float* y, const float* S, const v
     // 3) rows: IFFT_W -> sum_c conj(S) -> /sigma^2 -> [B,4,H,W]   (rim_utils.py:59-67)
     return launch_reduce((const float2*)work, (const float2*)S, (const float2*)eta, out4, B, C, H, W, norm, centered,
                          inv_sigma2, 1, st);
+}
+
+template <class P, int NSEQ>
+static int launch_hinv_p(const float2* eta, const float2* yt, const float2* S, const MrxMask& m, float* out, dim3 grid,
+                         size_t lds, const ReduceArgs& a, float scale_f, hipStream_t st) {
+    int rc = set_lds(k_llg_rows_hinv<P, NSEQ>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_llg_rows_hinv<P, NSEQ>), grid, dim3(MRX_FFT_NT), lds, st, eta, yt, S, m, out, a, scale_f);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+extern "C" int mrx_fft_cols(const float* in, float* out, int64_t nimg, int H, int W, int inverse, int norm, int centered,
+                            void* stream) {
+    MRX_REQUIRE(nimg >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_fft_cols: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_fft_cols: bad normalization %d", norm);
+    if (nimg == 0) return MRX_OK;
+    MRX_REQUIRE(in && out, MRX_EINVAL, "mrx_fft_cols: null pointer");
+    return launch_cols((const float2*)in, (float2*)out, nimg, H, W, inverse, norm, centered, (hipStream_t)stream);
+}
+
+extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
+                            const int64_t* mstride, float* out4, int B, int C, int H, int W, float inv_sigma2, int norm,
+                            int centered, void* stream) {
+    MRX_REQUIRE(eta && yt && S && mask && mstride && out4, MRX_EINVAL, "mrx_llg_hinv: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_llg_hinv: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_llg_hinv: bad normalization %d", norm);
+    MRX_REQUIRE(mask_kind == MRX_MASK_U8 || mask_kind == MRX_MASK_F32, MRX_EINVAL, "mrx_llg_hinv: bad mask kind %d", mask_kind);
+    MRX_REQUIRE(mstride[2] == 0, MRX_EINVAL, "mrx_llg_hinv: the mask must not depend on the row index (mstride[2] = %lld)",
+                (long long)mstride[2]);
+    MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "mrx_llg_hinv: batch %d too large", B);
+    if (B == 0) return MRX_OK;
+    MrxFftEntry e;
+    int rc = mrx_get_plan(W, &e);
+    if (rc) return rc;
+    ReduceArgs a;
+    a.plan = e.plan;
+    a.tw = e.d_tw;
+    a.C = C;
+    a.H = H;
+    a.W = W;
+    a.g = pick_rows(W);
+    const bool ct = (W == 372 || W == 320 || W == 256);
+    if (!ct && a.g > C) a.g = C;
+    a.halfW = centered ? W / 2 : 0;
+    a.scale = mrx_scale(W, 1, norm);
+    a.post = inv_sigma2;
+    const float scale_f = mrx_scale(W, 0, norm);
+    MrxMask m;
+    m.p = mask;
+    m.kind = mask_kind;
+    for (int i = 0; i < 4; ++i) m.s[i] = mstride[i];
+    const size_t lds = sizeof(float2) * (3 * (size_t)W + 3 * (size_t)a.g * W);
+    dim3 grid(H, B);
+    hipStream_t st = (hipStream_t)stream;
+    const float2 *pe = (const float2*)eta, *py = (const float2*)yt, *ps = (const float2*)S;
+    if (W == 372) return launch_hinv_p<P372, NSEQ_ROW_372>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
+    if (W == 320) return launch_hinv_p<P320, NSEQ_ROW_320>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
+    if (W == 256) return launch_hinv_p<P256, NSEQ_ROW_256>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
+    return launch_hinv_p<PlanRT, 1>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
 }

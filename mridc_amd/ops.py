@@ -81,6 +81,38 @@ def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, o
     return out
 
 
+def mask_is_row_invariant(mask):
+    """True when the mask does not depend on the row (H) index, e.g. [B|1,1,1,W,1] 1-D column masks."""
+    m = mask[..., 0] if (mask.dim() == 5 and mask.shape[-1] == 1) else mask
+    return m.dim() >= 2 and m.shape[-2] == 1
+
+
+def llg_prepare(y, centered, normalization, spatial_dims=None):
+    """yt = IFFT_H(y): the hybrid-space data the row-invariant-mask gradient needs (once per cascade)."""
+    y = _lib.f32c(y)
+    B, C, H, W = _bchw(y)
+    _check_last_two(spatial_dims, 4)
+    out = torch.empty_like(y)
+    _lib.check(_lib.lib().mrx_fft_cols(_lib.ptr(y), _lib.ptr(out), B * C, H, W, 1, _norm(normalization), int(bool(centered)),
+                                       _lib.stream_ptr()), "mrx_fft_cols")
+    return out
+
+
+def llg_hinv(eta, yt, sens, mask, sigma, centered, normalization, out=None):
+    """log_likelihood_gradient for a row-invariant mask, one launch (yt from llg_prepare)."""
+    yt, sens, eta = _lib.f32c(yt), _lib.f32c(sens), _lib.f32c(eta)
+    B, C, H, W = _bchw(yt)
+    if sens.shape != yt.shape or tuple(eta.shape) != (B, H, W, 2):
+        raise ValueError("llg_hinv: inconsistent shapes")
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    if out is None:
+        out = torch.empty(B, 4, H, W, dtype=torch.float32, device=yt.device)
+    _lib.check(_lib.lib().mrx_llg_hinv(_lib.ptr(eta), _lib.ptr(yt), _lib.ptr(sens), _lib.ptr(m), kind, ms, _lib.ptr(out),
+                                       B, C, H, W, float(1.0 / (float(sigma) ** 2.0)), _norm(normalization),
+                                       int(bool(centered)), _lib.stream_ptr()), "mrx_llg_hinv")
+    return out
+
+
 def soft_dc(pred, ref, mask, dc_weight):
     """where(mask, pred - ref, 0) * dc_weight."""
     pred, ref = _lib.f32c(pred), _lib.f32c(ref)

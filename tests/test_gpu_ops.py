@@ -217,3 +217,28 @@ def test_soft_dc_select_bit_exact(dev):
         assert_exact(ops.soft_dc(pred.to(dev), ref.to(dev), mask.to(dev), w.to(dev)), want, "soft_dc")
         assert_exact(ops.dc_combine(pred.to(dev), pred.to(dev), ref.to(dev), mask.to(dev), w.to(dev), eta_k.to(dev)),
                      pred - want - eta_k, "dc_combine")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 12, 10), (1, 5, 13, 18), (1, 15, 64, 372), (2, 4, 33, 320), (1, 3, 17, 256), (1, 2, 9, 31)])
+def test_llg_row_invariant_mask_fast_path(shape, dev):
+    """mrx_llg_hinv (column transforms cancelled analytically, one launch) == the oracle's full 2-D formulation."""
+    from mridc_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    eta = torch.randn(B, H, W, 2, generator=g)
+    S = torch.randn(B, C, H, W, 2, generator=g)
+    k = torch.randn(B, C, H, W, 2, generator=g)
+    for mask in ((torch.rand(1, 1, 1, W, 1, generator=g) < 0.4), (torch.rand(B, 1, 1, W, 1, generator=g) < 0.5).byte(),
+                 (torch.rand(1, 1, 1, W, 1, generator=g) < 0.5).float() * 0.5):
+        y = k * mask
+        assert ops.mask_is_row_invariant(mask)
+        for centered, norm, sigma in ((True, "ortho", 1.0), (False, "backward", 0.5), (True, "forward", 1.0), (False, "none", 1.0)):
+            ref = oracle.rim.log_likelihood_gradient(eta, y, S, mask, sigma, centered, norm, [-2, -1], 1)
+            yt = ops.llg_prepare(y.to(dev), centered, norm)
+            got = ops.llg_hinv(eta.to(dev), yt, S.to(dev), mask.to(dev), sigma, centered, norm)
+            assert_close(got, ref, 1e-5, f"llg_hinv {shape} {centered} {norm}")
+            gen = ops.llg(eta.to(dev), y.to(dev), S.to(dev), mask.to(dev), sigma, centered, norm)
+            assert_close(got, gen, 5e-6, "fast path vs general path")
+    assert not ops.mask_is_row_invariant(torch.zeros(1, 1, H, W, 1))
+    with pytest.raises(RuntimeError, match="row index"):
+        ops.llg_hinv(eta.to(dev), k.to(dev), S.to(dev), torch.ones(1, 1, H, W, 1, device=dev), 1.0, True, "ortho")
