@@ -192,6 +192,23 @@ int mrx_conv_transpose2x2(const float* x, const float* w, float* out, int B, int
                           void* stream);
 int mrx_copy_channels(const float* src, float* dst, int B, int C, int64_t HW, int Ctot, int c0, void* stream);
 
+/* A19 quantitative MRI (mridc/collections/quantitative/models/qrim/utils.py, qrim_block.py).
+ *   mrx_dc_residual  out[b] = sum_c conj(S[b/sdiv,c]) ifft2(mask (fft2(x[b] S[b/sdiv,c]) - y[b,c]));  b = batch x echoes,
+ *                    sdiv = echoes sharing one set of maps (utils.py:235-248).  x,out [B,H,W,2]; y,work [B,C,H,W,2]; S [B/sdiv,C,H,W,2]
+ *   mrx_qmri_signal  MEGRE signal model (utils.py:71-121): maps [N,HW] x4 -> [N,E,HW,2]; `tes` is a HOST array of E echo times
+ *   mrx_qmri_grad    analytic gradient (utils.py:250-295) from the coil-combined residual: -> [N,4,HW] = mean over echoes of
+ *                    (R2*_re, S0_re, R2*_im, S0_im) * post, NaN -> 0 (qrim_block.py:223-224)
+ *   mrx_scale        mode bit0: |x| first; bit1: divide instead of multiply   (qrim_block.py:198-201, qcirim.py:248-251,:334)
+ *   mrx_qrim_update  out = eta + delta, channel 0 clamped at 0   (qrim_block.py:233-236) */
+int mrx_dc_residual(const float* x, const float* y, const float* S, const void* mask, int mask_kind, const int64_t* mstride,
+                    float* out, float* work, int B, int C, int H, int W, int sdiv, int norm, int centered, void* stream);
+int mrx_qmri_signal(const float* r2, const float* s0, const float* b0, const float* phi, const float* tes, int E, float* out,
+                    int64_t N, int64_t HW, float scaling, void* stream);
+int mrx_qmri_grad(const float* dinv, const float* r2, const float* s0, const float* b0, const float* phi, const float* tes,
+                  int E, float* out, int64_t N, int64_t HW, float scaling, float post, void* stream);
+int mrx_scale(const float* x, float* out, int64_t n, float s, int mode, void* stream);
+int mrx_qrim_update(const float* eta, const float* delta, float* out, int B, int Cc, int64_t HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ SOURCES = [
     ("conv.hip", []),
     ("rim_layer.hip", []),
     ("unet.hip", []),
+    ("qmri.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -58,6 +58,11 @@ _SIGNATURES = {
     "mrx_pad2d": ([_p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_avg_pool2x2": ([_p, _p, _i64, _i, _i, _p], _i),
     "mrx_conv_transpose2x2": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_dc_residual": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_qmri_signal": ([_p, _p, _p, _p, _p, _i, _p, _i64, _i64, _f, _p], _i),
+    "mrx_qmri_grad": ([_p, _p, _p, _p, _p, _p, _i, _p, _i64, _i64, _f, _f, _p], _i),
+    "mrx_scale": ([_p, _p, _i64, _f, _i, _p], _i),
+    "mrx_qrim_update": ([_p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_copy_channels": ([_p, _p, _i, _i, _i64, _i, _i, _p], _i),
 }
 

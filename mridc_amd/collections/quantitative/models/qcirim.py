@@ -1,0 +1,83 @@
+"""Drop-in for `mridc.collections.quantitative.models.qcirim.qCIRIM` (reference qcirim.py:27-341), inference path with
+`use_reconstruction_module: false` (the model-zoo default, projects/quantitative/model_zoo/conf/base_qcirim_run.yaml:7)."""
+from typing import Generator, List, Union
+
+import torch
+
+from mridc_amd import ops
+from mridc_amd.collections.quantitative.models.qrim import qrim_block, utils as qrim_utils
+from mridc_amd.collections.reconstruction.models import _cfg
+
+__all__ = ["qCIRIM"]
+
+
+class qCIRIM(torch.nn.Module):
+    def __init__(self, cfg, trainer=None):
+        super().__init__()
+        cfg_dict = _cfg.to_dict(cfg)
+        if cfg_dict.get("quantitative_module_dimensionality") != 2:
+            raise ValueError(f"Only 2D is currently supported for qMRI models.Found {cfg_dict.get('quantitative_module_dimensionality')}")
+        if not cfg_dict.get("quantitative_module_no_dc"):
+            raise ValueError("qCIRIM does not support explicit DC component.")            # qcirim.py:51-53
+        self.fft_centered = cfg_dict.get("fft_centered")
+        self.fft_normalization = cfg_dict.get("fft_normalization")
+        self.spatial_dims = cfg_dict.get("spatial_dims")
+        self.coil_dim = cfg_dict.get("coil_dim")
+        self.coil_combination_method = cfg_dict.get("coil_combination_method")
+        self.use_reconstruction_module = cfg_dict.get("use_reconstruction_module")
+        if self.use_reconstruction_module:
+            raise NotImplementedError("use_reconstruction_module=true needs the LSQ R2*/B0 initial fit "
+                                      "(quantitative/parts/transforms.py:921, skimage unwrap_phase) -- outside the HIP path")
+        self.cirim = torch.nn.ModuleList([])
+        self.qcirim = torch.nn.ModuleList([
+            qrim_block.qRIMBlock(
+                recurrent_layer=cfg_dict.get("quantitative_module_recurrent_layer"),
+                conv_filters=cfg_dict.get("quantitative_module_conv_filters"),
+                conv_kernels=cfg_dict.get("quantitative_module_conv_kernels"),
+                conv_dilations=cfg_dict.get("quantitative_module_conv_dilations"),
+                conv_bias=cfg_dict.get("quantitative_module_conv_bias"),
+                recurrent_filters=cfg_dict.get("quantitative_module_recurrent_filters"),
+                recurrent_kernels=cfg_dict.get("quantitative_module_recurrent_kernels"),
+                recurrent_dilations=cfg_dict.get("quantitative_module_recurrent_dilations"),
+                recurrent_bias=cfg_dict.get("quantitative_module_recurrent_bias"),
+                depth=cfg_dict.get("quantitative_module_depth"), time_steps=cfg_dict.get("quantitative_module_time_steps"),
+                conv_dim=cfg_dict.get("quantitative_module_conv_dim", 2), no_dc=cfg_dict.get("quantitative_module_no_dc"),
+                linear_forward_model=qrim_utils.SignalForwardModel(
+                    sequence=cfg_dict.get("quantitative_module_signal_forward_model_sequence")),
+                fft_centered=self.fft_centered, fft_normalization=self.fft_normalization, spatial_dims=self.spatial_dims,
+                coil_dim=self.coil_dim, coil_combination_method=self.coil_combination_method, dimensionality=2)
+            for _ in range(cfg_dict.get("quantitative_module_num_cascades"))])             # qcirim.py:108-137
+        self.accumulate_estimates = cfg_dict.get("quantitative_module_accumulate_estimates")
+        self.gamma = torch.tensor(cfg_dict.get("quantitative_module_gamma_regularization_factors"), dtype=torch.float32)
+        self.preprocessor = qrim_utils.RescaleByMax
+
+    def forward(self, R2star_map_init: torch.Tensor, S0_map_init: torch.Tensor, B0_map_init: torch.Tensor,
+                phi_map_init: torch.Tensor, TEs: List, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask_brain: torch.Tensor,
+                sampling_mask: torch.Tensor) -> Union[Generator, torch.Tensor]:
+        """qcirim.py:144-312 (quantitative cascades)."""
+        g = [float(v) for v in self.gamma]
+        R2star_map_pred = ops.scale(R2star_map_init, g[0], divide=True)     # qcirim.py:248-251
+        S0_map_pred = ops.scale(S0_map_init, g[1], divide=True)
+        B0_map_pred = ops.scale(B0_map_init, g[2], divide=True)
+        phi_map_pred = ops.scale(phi_map_init, g[3], divide=True)
+        prediction = y
+        eta, hx = None, None
+        cascades = [[], [], [], []]
+        for i, cascade in enumerate(self.qcirim):
+            prediction, hx = cascade(prediction, y, R2star_map_pred, S0_map_pred, B0_map_pred, phi_map_pred, TEs, sensitivity_maps,
+                                     sampling_mask, eta, hx, self.gamma, keep_eta=i != 0)
+            R2star_map_pred, S0_map_pred, B0_map_pred, phi_map_pred = (prediction[-1][:, 0], prediction[-1][:, 1],
+                                                                       prediction[-1][:, 2], prediction[-1][:, 3])
+            steps = [[], [], [], []]
+            for pred in prediction:
+                maps = self.process_intermediate_pred(ops.scale(pred, 1.0, take_abs=True), None, None, False)
+                for m in range(4):
+                    steps[m].append(maps[m])
+            for m in range(4):
+                cascades[m].append(steps[m])
+        yield [torch.empty([])] + cascades
+
+    def process_intermediate_pred(self, pred, sensitivity_maps, target, do_coil_combination=False):
+        """qcirim.py:314-341."""
+        x = self.preprocessor.reverse(pred, self.gamma)
+        return x[:, 0, ...], x[:, 1, ...], x[:, 2, ...], x[:, 3, ...]

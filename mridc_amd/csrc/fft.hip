@@ -186,6 +186,7 @@ struct RowArgs {
     int W, rpb, halfW;
     float scale;
     int C, H;  // images are [.., C][H rows]; expand mode reads the image x[b] for every coil c of batch element b
+    int sdiv;  // expand mode: batch element b uses the maps of element b / sdiv (qMRI: echoes share one set of maps)
 };
 
 // MODE 0: out[row] = FFT(in[row]);  MODE 1: out[b,c,h] = FFT(x[b,h] * S[b,c,h]).  NSEQ rows per workgroup (CT plans).
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const
     const int nrows = min(RPB, a.H - hrow0);
     const long long row0 = img * a.H + hrow0;
     const long long bimg = MODE == 1 ? img / a.C : 0;  // one division per workgroup
+    const long long srow0 = MODE == 1 ? ((bimg / a.sdiv) * a.C + (img - bimg * a.C)) * a.H + hrow0 : 0;
     const float invW = 1.0f / (float)W;
     for (int i = threadIdx.x; i < W; i += MRX_FFT_NT) tw[i] = a.tw[i];
     for (int idx = threadIdx.x; idx < RPB * W; idx += MRX_FFT_NT) {
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const
                 v = in[ro * W + g];
             } else {
                 const float2 e = in[(bimg * a.H + hrow0 + r) * W + g];
-                const float2 s = S[ro * W + g];
+                const float2 s = S[(srow0 + r) * W + g];
                 v = make_float2(e.x * s.x - e.y * s.y, e.x * s.y + e.y * s.x);  // utils.py:115-116
             }
         }
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc(const float2* in, const 
 struct ReduceArgs {
     MrxFftPlan plan;
     const float2* tw;
+    int sdiv;  // batch element b uses the maps of element b / sdiv
     int C, H, W, g, halfW;
     float scale;
     float post;  // llg: 1/sigma^2
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_rows_reduce(const float2* __rest
                 float2 v = res[r * W + x];
                 v.x *= a.scale;
                 v.y *= a.scale;
-                const float2 s = S[(((b * C + c0 + r) * H) + h) * W + g];
+                const float2 s = S[((((b / a.sdiv) * C + c0 + r) * H) + h) * W + g];
                 s_acc.x += v.x * s.x + v.y * s.y;  // re: rim_utils.py:61
                 s_acc.y += v.y * s.x - v.x * s.y;  // im: rim_utils.py:62
             }
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_llg_rows_hinv(const float2* __re
             const int r = P::kCT ? idx / W : mrx_fdiv(idx, invW), x = idx - r * W;
             float2 s = make_float2(0.f, 0.f), v = make_float2(0.f, 0.f);
             if (r < nrows) {
-                s = S[(((b * C + c0 + r) * H) + h) * W + shifted(x, a.halfW, W)];
+                s = S[((((b / a.sdiv) * C + c0 + r) * H) + h) * W + shifted(x, a.halfW, W)];
                 const float2 e = E[x];
                 v = make_float2(e.x * s.x - e.y * s.y, e.x * s.y + e.y * s.x);  // rim_utils.py:47-48
             }
@@ -565,7 +568,7 @@ static int launch_rows_p(const float2* in, const float2* S, float2* out, dim3 gr
 }
 
 static int launch_rows(const float2* in, const float2* S, float2* out, long long nimg, int W, int C, int H,
-                       int inverse, int norm, int centered, int expand, hipStream_t st) {
+                       int inverse, int norm, int centered, int expand, hipStream_t st, int sdiv = 1) {
     MrxFftEntry e;
     int rc = mrx_get_plan(W, &e);
     if (rc) return rc;
@@ -578,6 +581,7 @@ static int launch_rows(const float2* in, const float2* S, float2* out, long long
     a.scale = mrx_scale(W, inverse, norm);
     a.C = C;
     a.H = H;
+    a.sdiv = sdiv < 1 ? 1 : sdiv;
     const size_t lds = sizeof(float2) * ((size_t)W + 2 * (size_t)a.rpb * W);
     MRX_REQUIRE(nimg < (1LL << 31), MRX_EUNSUP, "too many images (%lld)", nimg);
     const dim3 grid((unsigned)nimg, mrx_cdiv(H, a.rpb));
@@ -658,13 +662,14 @@ static int launch_reduce_p(const float2* k, const float2* S, const float2* eta, 
 }
 
 static int launch_reduce(const float2* k, const float2* S, const float2* eta, float* out, int B, int C, int H, int W,
-                         int norm, int centered, float post, int out_mode, hipStream_t st) {
+                         int norm, int centered, float post, int out_mode, hipStream_t st, int sdiv = 1) {
     MrxFftEntry e;
     int rc = mrx_get_plan(W, &e);
     if (rc) return rc;
     ReduceArgs a;
     a.plan = e.plan;
     a.tw = e.d_tw;
+    a.sdiv = sdiv < 1 ? 1 : sdiv;
     a.C = C;
     a.H = H;
     a.W = W;
@@ -807,6 +812,7 @@ extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, c
     ReduceArgs a;
     a.plan = e.plan;
     a.tw = e.d_tw;
+    a.sdiv = 1;
     a.C = C;
     a.H = H;
     a.W = W;
@@ -829,4 +835,38 @@ extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, c
     if (W == 320) return launch_hinv_p<P320, NSEQ_ROW_320>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
     if (W == 256) return launch_hinv_p<P256, NSEQ_ROW_256>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
     return launch_hinv_p<PlanRT, 1>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
+}
+
+// Data-consistency residual in image space with shared maps:  out[b] = sum_c conj(S[b/sdiv,c]) * ifft2( mask * (fft2(x[b] * S[b/sdiv,c]) - y[b,c]) )
+// (the linear-operator core of quantitative/models/qrim/utils.py:235-248; b runs over batch x echoes, sdiv = echoes).
+extern "C" int mrx_dc_residual(const float* x, const float* y, const float* S, const void* mask, int mask_kind,
+                               const int64_t* mstride, float* out, float* work, int B, int C, int H, int W, int sdiv, int norm,
+                               int centered, void* stream) {
+    MRX_REQUIRE(x && y && S && mask && mstride && out && work, MRX_EINVAL, "mrx_dc_residual: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1 && sdiv >= 1, MRX_EINVAL, "mrx_dc_residual: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_dc_residual: bad normalization %d", norm);
+    MRX_REQUIRE(mask_kind == MRX_MASK_U8 || mask_kind == MRX_MASK_F32, MRX_EINVAL, "mrx_dc_residual: bad mask kind %d", mask_kind);
+    if (B == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_rows((const float2*)x, (const float2*)S, (float2*)work, (long long)B * C, W, C, H, 0, norm, centered, 1, st, sdiv);
+    if (rc) return rc;
+    ColArgs a;
+    if ((rc = make_col_args(&a, (long long)B * C, H, W, 0, norm, centered))) return rc;
+    a.scale2 = mrx_scale(H, 1, norm);
+    a.C = C;
+    MrxMask m;
+    m.p = mask;
+    m.kind = mask_kind;
+    for (int i = 0; i < 4; ++i) m.s[i] = mstride[i];
+    const size_t lds = sizeof(float2) * ((size_t)H + 2 * (size_t)a.ct * H);
+    if (H == 640)
+        rc = launch_dc_p<P640, NSEQ_COL_640>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    else if (H == 320)
+        rc = launch_dc_p<P320, NSEQ_COL_320>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    else if (H == 256)
+        rc = launch_dc_p<P256, NSEQ_COL_256>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    else
+        rc = launch_dc_p<PlanRT, 1>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    if (rc) return rc;
+    return launch_reduce((const float2*)work, (const float2*)S, nullptr, out, B, C, H, W, norm, centered, 1.0f, 0, st, sdiv);
 }

@@ -333,3 +333,68 @@ def concat_channels(a, b):
     _lib.check(L.mrx_copy_channels(_lib.ptr(a), _lib.ptr(out), B, Ca, H * W, Ca + Cb, 0, _lib.stream_ptr()), "mrx_copy_channels")
     _lib.check(L.mrx_copy_channels(_lib.ptr(b), _lib.ptr(out), B, Cb, H * W, Ca + Cb, Ca, _lib.stream_ptr()), "mrx_copy_channels")
     return out
+
+
+# ---- quantitative MRI (A19) -----------------------------------------------------------------------------------
+def _tes_host(TEs):
+    import ctypes
+    vals = [float(t) for t in TEs]
+    return (ctypes.c_float * len(vals))(*vals), len(vals)
+
+
+def qmri_signal(r2, s0, b0, phi, TEs, scaling=1e-3):
+    """MEGRE signal model: maps [N,H,W] -> [N,E,H,W,2]."""
+    r2, s0, b0, phi = (_lib.f32c(t) for t in (r2, s0, b0, phi))
+    N, H, W = [int(v) for v in r2.shape]
+    tes, E = _tes_host(TEs)
+    out = torch.empty(N, E, H, W, 2, dtype=torch.float32, device=r2.device)
+    _lib.check(_lib.lib().mrx_qmri_signal(_lib.ptr(r2), _lib.ptr(s0), _lib.ptr(b0), _lib.ptr(phi), tes, E, _lib.ptr(out), N, H * W,
+                                          float(scaling), _lib.stream_ptr()), "mrx_qmri_signal")
+    return out
+
+
+def dc_residual(x, y, sens, mask, sdiv, centered, normalization):
+    """sum_c conj(S) ifft2(mask (fft2(x S) - y)) with maps shared by groups of `sdiv` batch entries.
+    x [B',H,W,2]; y [B',C,H,W,2]; sens [B'/sdiv,C,H,W,2]; mask broadcastable to [B',C,H,W,1] -> [B',H,W,2]."""
+    x, y, sens = _lib.f32c(x), _lib.f32c(y), _lib.f32c(sens)
+    Bp, C, H, W = _bchw(y)
+    if tuple(x.shape) != (Bp, H, W, 2) or tuple(sens.shape) != (Bp // sdiv, C, H, W, 2) or Bp % sdiv:
+        raise ValueError("dc_residual: inconsistent shapes")
+    m, kind, ms = _lib.mask_args(mask, Bp, C, H, W)
+    out = torch.empty(Bp, H, W, 2, dtype=torch.float32, device=y.device)
+    work = torch.empty_like(y)
+    _lib.check(_lib.lib().mrx_dc_residual(_lib.ptr(x), _lib.ptr(y), _lib.ptr(sens), _lib.ptr(m), kind, ms, _lib.ptr(out),
+                                          _lib.ptr(work), Bp, C, H, W, int(sdiv), _norm(normalization), int(bool(centered)),
+                                          _lib.stream_ptr()), "mrx_dc_residual")
+    return out
+
+
+def qmri_grad(dinv, r2, s0, b0, phi, TEs, scaling=1e-3, post=1.0):
+    """Analytic gradient from the coil-combined residual dinv [N,E,H,W,2] -> [N,4,H,W]."""
+    dinv = _lib.f32c(dinv)
+    r2, s0, b0, phi = (_lib.f32c(t) for t in (r2, s0, b0, phi))
+    N, H, W = [int(v) for v in r2.shape]
+    tes, E = _tes_host(TEs)
+    if tuple(dinv.shape) != (N, E, H, W, 2):
+        raise ValueError("qmri_grad: inconsistent shapes")
+    out = torch.empty(N, 4, H, W, dtype=torch.float32, device=r2.device)
+    _lib.check(_lib.lib().mrx_qmri_grad(_lib.ptr(dinv), _lib.ptr(r2), _lib.ptr(s0), _lib.ptr(b0), _lib.ptr(phi), tes, E,
+                                        _lib.ptr(out), N, H * W, float(scaling), float(post), _lib.stream_ptr()), "mrx_qmri_grad")
+    return out
+
+
+def scale(x, s, take_abs=False, divide=False):
+    x = _lib.f32c(x)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().mrx_scale(_lib.ptr(x), _lib.ptr(out), x.numel(), float(s), int(bool(take_abs)) | (2 if divide else 0),
+                                    _lib.stream_ptr()), "mrx_scale")
+    return out
+
+
+def qrim_update(eta, delta):
+    eta, delta = _lib.f32c(eta), _lib.f32c(delta)
+    B, Cc, H, W = _nchw(eta)
+    out = torch.empty_like(eta)
+    _lib.check(_lib.lib().mrx_qrim_update(_lib.ptr(eta), _lib.ptr(delta), _lib.ptr(out), B, Cc, H * W, _lib.stream_ptr()),
+               "mrx_qrim_update")
+    return out

@@ -84,6 +84,7 @@ class RIMConfig:
         self.recurrent_filters, self.recurrent_kernels = list(recurrent_filters), list(recurrent_kernels)
         self.recurrent_dilations, self.recurrent_bias = list(recurrent_dilations), list(recurrent_bias)
         self.depth, self.time_steps, self.no_dc = depth, time_steps, no_dc
+        self.input_size = None
         self.fft_centered, self.fft_normalization = fft_centered, fft_normalization
         self.spatial_dims = [-2, -1] if spatial_dims is None else list(spatial_dims)
         self.coil_dim = coil_dim

@@ -464,6 +464,74 @@ def g8_models():
     save("g8_models.npz", d)
 
 
+def g9_qrim():
+    """qRIMBlock + analytical_log_likelihood_gradient + a 2-cascade qCIRIM composition (qcirim.py:248-312)."""
+    qrim_block = _refshim.load("mridc.collections.quantitative.models.qrim.qrim_block")
+    qutils = _refshim.load("mridc.collections.quantitative.models.qrim.utils")
+    d = {}
+    B, E, C, H, W = 2, 4, 3, 16, 12
+    TEs = [3.0, 11.5, 20.0, 28.5]
+    g = torch.Generator().manual_seed(900)
+    r2 = torch.rand(B, H, W, generator=g) * 60 + 5
+    s0 = torch.rand(B, H, W, generator=g) * 2 + 0.2
+    b0 = (torch.rand(B, H, W, generator=g) - 0.5) * 80
+    ph = (torch.rand(B, H, W, generator=g) - 0.5) * 1.0
+    _, S = synth(B, C, H, W, 901)
+    fm = qutils.SignalForwardModel(sequence="MEGRE")
+    sig = fm(r2, s0, b0, ph, TEs)                                        # [B,E,H,W,2]
+    k = fft.fft2(utils.complex_mul(sig.unsqueeze(2), S.unsqueeze(1)), centered=True, normalization="ortho")   # [B,E,C,H,W,2]
+    _, m = make_mask([1, C, H, W, 2])
+    m = torch.cat([m, torch.roll(m, 2, dims=-2)], 0).unsqueeze(1)          # [B,1,1,1,W,1]
+    y = k * m + 0.01 * rnd([B, E, C, H, W, 2], 902) * m
+    d.update(r2=r2, s0=s0, b0=b0, ph=ph, S=S, y=y, mask=m, TEs=np.array(TEs, dtype=np.float32), signal=sig)
+    # perturbed initial maps -> non-trivial gradient
+    r2i, s0i, b0i, phi_i = r2 * 0.8 + 3, s0 * 1.1, b0 * 0.9 + 2, ph * 0.7
+    for cen, norm in ((True, "ortho"), (False, "backward")):
+        kk = fft.fft2(utils.complex_mul(sig.unsqueeze(2), S.unsqueeze(1)), centered=cen, normalization=norm)
+        yy = kk * m
+        grads = torch.stack([qutils.analytical_log_likelihood_gradient(fm, r2i[i], s0i[i], b0i[i], phi_i[i], TEs, S[i], yy[i],
+                                                                      m[i], cen, norm, [-2, -1], 2) for i in range(B)])
+        d[f"grad/{int(cen)}_{norm}/y"] = yy
+        d[f"grad/{int(cen)}_{norm}/out"] = grads
+    d.update(r2i=r2i, s0i=s0i, b0i=b0i, phi_i=phi_i)
+    gamma = [150.0, 150.0, 1000.0, 150.0]
+    cfg = dict(quantitative_module_recurrent_layer="IndRNN", quantitative_module_conv_filters=[32, 32, 4],
+               quantitative_module_conv_kernels=[5, 3, 3], quantitative_module_conv_dilations=[1, 2, 1],
+               quantitative_module_conv_bias=[True, True, False], quantitative_module_recurrent_filters=[32, 32, 0],
+               quantitative_module_recurrent_kernels=[1, 1, 0], quantitative_module_recurrent_dilations=[1, 1, 0],
+               quantitative_module_recurrent_bias=[True, True, False], quantitative_module_depth=2,
+               quantitative_module_time_steps=3, quantitative_module_num_cascades=2, quantitative_module_no_dc=True,
+               quantitative_module_signal_forward_model_sequence="MEGRE", quantitative_module_dimensionality=2,
+               quantitative_module_gamma_regularization_factors=gamma, use_reconstruction_module=False,
+               fft_centered=True, fft_normalization="ortho", spatial_dims=[-2, -1], coil_dim=2, coil_combination_method="SENSE")
+    torch.manual_seed(910)
+    blocks = [qrim_block.qRIMBlock(
+        recurrent_layer="IndRNN", conv_filters=[32, 32, 4], conv_kernels=[5, 3, 3], conv_dilations=[1, 2, 1],
+        conv_bias=[True, True, False], recurrent_filters=[32, 32, 0], recurrent_kernels=[1, 1, 0], recurrent_dilations=[1, 1, 0],
+        recurrent_bias=[True, True, False], depth=2, time_steps=3, conv_dim=2, no_dc=True, linear_forward_model=fm,
+        fft_centered=True, fft_normalization="ortho", spatial_dims=[-2, -1], coil_dim=2, coil_combination_method="SENSE",
+        dimensionality=2).eval() for _ in range(2)]
+    for b in blocks:
+        scale_weights(b, 6.0)
+    gm = torch.tensor(gamma)
+    with torch.no_grad():
+        # qcirim.py:248-312
+        r2p, s0p, b0p, php = r2i / gm[0], s0i / gm[1], b0i / gm[2], phi_i / gm[3]
+        eta, hx = None, None
+        outs = []
+        for i, cas in enumerate(blocks):
+            prediction, hx = cas(y.clone(), y, r2p, s0p, b0p, php, TEs, S, m, eta, hx, gm, keep_eta=i != 0)
+            r2p, s0p, b0p, php = (prediction[-1][:, 0], prediction[-1][:, 1], prediction[-1][:, 2], prediction[-1][:, 3])
+            outs.append(torch.stack([qutils.RescaleByMax.reverse(torch.abs(pp), gm) for pp in prediction]))
+            if i == 0:
+                d["block0/etas"] = torch.stack(prediction)
+    d["qcirim/cfg"] = np.array(json.dumps(cfg))
+    d["qcirim/out"] = torch.stack(outs)                                   # [cascade, step, B, 4, H, W]
+    for ci, b in enumerate(blocks):
+        d.update(sd(b, f"qcirim/w/qcirim.{ci}."))
+    save("g9_qrim.npz", d)
+
+
 def g10_ssim():
     d = {}
     loss = ssim_mod.SSIMLoss()
@@ -477,8 +545,8 @@ def g10_ssim():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g10"]
-    fns = dict(g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    fns = dict(g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

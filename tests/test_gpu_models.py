@@ -140,3 +140,34 @@ def test_c1_zero_filled_plus_dc_320(golden, dev):
     scale = float(y.abs().max())
     assert float(d.abs().max()) <= 2e-5 * scale and float(T(z["c1/dc_sample"]).abs().max()) <= 2e-5 * scale
     assert torch.count_nonzero(d[:, :, :, ~m1.reshape(-1)]) == 0
+
+
+def test_g9_qrim_qcirim(golden, dev):
+    """A19: MEGRE signal model, analytic gradient and the 2-cascade qCIRIM composition on the HIP path."""
+    from mridc_amd import ops
+    from mridc_amd.collections.quantitative.models.qcirim import qCIRIM
+    from mridc_amd.collections.quantitative.models.qrim.utils import SignalForwardModel, analytical_log_likelihood_gradient
+    z = golden("g9_qrim.npz")
+    TEs = [float(t) for t in z["TEs"]]
+    r2, s0, b0, ph = (T(z[k]).to(dev) for k in ("r2", "s0", "b0", "ph"))
+    fm = SignalForwardModel(sequence="MEGRE")
+    assert_close(fm(r2, s0, b0, ph, TEs), T(z["signal"]), 1e-5, "MEGRE signal")
+    S, mask = T(z["S"]).to(dev), T(z["mask"]).to(dev)
+    r2i, s0i, b0i, phi_i = (T(z[k]).to(dev) for k in ("r2i", "s0i", "b0i", "phi_i"))
+    for cen, norm in ((True, "ortho"), (False, "backward")):
+        yy = T(z[f"grad/{int(cen)}_{norm}/y"]).to(dev)
+        got = torch.stack([analytical_log_likelihood_gradient(fm, r2i[i], s0i[i], b0i[i], phi_i[i], TEs, S[i], yy[i], mask[i],
+                                                              cen, norm, [-2, -1], 2) for i in range(2)])
+        assert_close(got, T(z[f"grad/{int(cen)}_{norm}/out"]), 2e-5, f"analytic gradient {cen} {norm}")
+    cfg = meta(z, "qcirim/cfg")
+    model = qCIRIM(cfg)
+    model.load_state_dict(weights(z, "qcirim/w/"))
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        out = next(model(r2i, s0i, b0i, phi_i, TEs, T(z["y"]).to(dev), S, None, mask))
+    ref = T(z["qcirim/out"])
+    for m in range(4):
+        got = torch.stack([torch.stack(c) for c in out[1 + m]])
+        assert_close(got, ref[:, :, :, m], 1e-4, f"qcirim map {m}")
+    with pytest.raises(ValueError, match="explicit DC"):
+        qCIRIM(dict(cfg, quantitative_module_no_dc=False))

@@ -73,3 +73,24 @@ def test_g8_models(golden):
         out = oracle.models.zf_forward(c, T(z["unet/y"]), S, mask, target)
         out = torch.view_as_real(out) if out.is_complex() else out
         assert_close(out, T(z[f"zf/out_{meth}"]), 1e-6, f"zf {meth}")
+
+
+def test_g9_qrim(golden):
+    """qMRI: signal model, analytical gradient, qRIMBlock and the 2-cascade qCIRIM composition (A19)."""
+    z = golden("g9_qrim.npz")
+    TEs = [float(t) for t in z["TEs"]]
+    r2, s0, b0, ph = T(z["r2"]), T(z["s0"]), T(z["b0"]), T(z["ph"])
+    assert_close(oracle.qrim.megre_signal(r2, s0, b0, ph, TEs), T(z["signal"]), 1e-6, "MEGRE signal")
+    S, mask = T(z["S"]), T(z["mask"])
+    r2i, s0i, b0i, phi_i = T(z["r2i"]), T(z["s0i"]), T(z["b0i"]), T(z["phi_i"])
+    for cen, norm in ((True, "ortho"), (False, "backward")):
+        yy = T(z[f"grad/{int(cen)}_{norm}/y"])
+        got = torch.stack([oracle.qrim.analytical_log_likelihood_gradient(r2i[i], s0i[i], b0i[i], phi_i[i], TEs, S[i], yy[i],
+                                                                          mask[i], cen, norm, [-2, -1], 2) for i in range(2)])
+        assert_close(got, T(z[f"grad/{int(cen)}_{norm}/out"]), 2e-6, f"analytical gradient {cen} {norm}")
+    cfg = meta(z, "qcirim/cfg")
+    out = oracle.qrim.qcirim_forward(weights(z, "qcirim/w/"), cfg, r2i, s0i, b0i, phi_i, TEs, T(z["y"]), S, None, mask)
+    ref = T(z["qcirim/out"])                                   # [cascade, step, B, 4, H, W]
+    for m in range(4):
+        got = torch.stack([torch.stack(c) for c in out[1 + m]])
+        assert_close(got, ref[:, :, :, m], 1e-5, f"qcirim map {m}")
