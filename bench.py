@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--height", type=int, default=640)
     ap.add_argument("--width", type=int, default=372)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="cirim", choices=["cirim", "e2evn"],
+                    help="cirim = the headline workload (BASELINE.json metric); e2evn = configs[1], reported for reference")
+    ap.add_argument("--mask", default="1d", choices=["1d", "2d"],
+                    help="1d: random columns R=4 (SURVEY 8d primary); 2d: random 2-D points R=10 (stands in for the YAML's Poisson-2D)")
     ap.add_argument("--cpu-cascades", type=int, default=1, help="cascades of the CPU-baseline sample")
     return ap.parse_args()
 
@@ -105,6 +109,42 @@ def cpu_baseline(cfg, state_dict, data, gpu_out, n_cascades):
                        f"x{cfg['num_cascades'] / n_cascades:g}"), rel, ssim
 
 
+def bench_e2evn(args, world, rank, dev):
+    """configs[1]: E2EVN 6 cascades, NormUnet(14, 2, pad 11), 15 coils 640x372 (reported next to the headline number)."""
+    from mridc_amd import synthetic
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    from mridc_amd.sharding import shard_range
+    cfg = dict(synthetic.E2EVN_BASELINE_CFG)
+    torch.manual_seed(0)
+    model = VarNet(cfg).eval().to(dev)
+    B, C, H, W = args.batch, args.coils, args.height, args.width
+    s0, s1 = shard_range(world * B, rank, world)
+    slices = [synthetic.make_slice(C, H, W, slice_idx=i, mask_dtype=torch.uint8) for i in range(s0, s1)]
+    data = {k: torch.cat([s[k] for s in slices], 0).to(dev) for k in ("y", "sensitivity_maps", "target")}
+    data["mask"] = slices[0]["mask"].to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(data["y"], data["sensitivity_maps"], data["mask"], None, data["target"])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps(dict(metric="slices/sec (inference), E2EVN 6-cascade 15-coil 640x372", value=world * B * args.steps / elapsed,
+                              unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                              ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                              dtype="f32", data="synthetic",
+                              config=dict(workload="E2EVN 6 cascades, NormUnet(chans 14, pools 2, pad 11), 15 coils, 640x372, batch "
+                                                   f"{B} per GPU, random-init weights (seed 0)", parallelism=f"slice-sharded x{world}"))),
+              flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +162,8 @@ def main():
     from mridc_amd import ops, synthetic
     from mridc_amd.collections.reconstruction.models.cirim import CIRIM
 
+    if args.model == "e2evn":
+        return bench_e2evn(args, world, rank, dev)
     cfg = dict(synthetic.CIRIM_BASELINE_CFG)
     torch.manual_seed(0)                                # reference-identical initialisation (tests/test_host_logic.py)
     model = CIRIM(cfg).eval()
@@ -134,6 +176,15 @@ def main():
     slices = [synthetic.make_slice(C, H, W, slice_idx=i) for i in range(s0, s1)]
     host = {k: torch.cat([s[k] for s in slices], 0) for k in ("y", "sensitivity_maps", "target")}
     host["mask"] = slices[0]["mask"]
+    if args.mask == "2d":                               # k-space re-masked with a 2-D pattern (keeps a fully sampled centre)
+        g2 = torch.Generator().manual_seed(7)
+        m2 = torch.rand(1, 1, H, W, 1, generator=g2) < 0.08
+        m2[:, :, :16, :16] = True
+        m2[:, :, -16:, :16] = True
+        m2[:, :, :16, -16:] = True
+        m2[:, :, -16:, -16:] = True
+        host["mask"] = m2
+        host["y"] = torch.cat([s["kspace"] for s in slices], 0) * m2
     data = {k: v.to(dev) for k, v in host.items()}
     from mridc_amd import _lib
     _lib.check(_lib.lib().mrx_fft_prepare(H, W), "mrx_fft_prepare")
@@ -200,7 +251,9 @@ def main():
                    config=dict(workload=f"CIRIM {cfg['num_cascades']} cascades x {T_} time-steps (config time_steps "
                                         f"{cfg['time_steps']} rounded up as the reference does), IndRNN {F_hidden} filters, "
                                         f"{C} coils, {H}x{W}, batch {B} slice(s) per GPU, random-init weights (seed 0)",
-                               global_batch=world * B, coils=C, height=H, width=W, parallelism=f"slice-sharded x{world}"),
+                               global_batch=world * B, coils=C, height=H, width=W, parallelism=f"slice-sharded x{world}",
+                               mask=("1-D random columns R=4 (row-invariant: one-launch gradient)" if args.mask == "1d" else
+                                     "2-D random points R~10 (general three-launch gradient)")),
                    roofline=roofline, roofline_fft=roofline_fft,
                    breakdown_ms=dict(llg=msl, conv_layer1=ms1, conv_layer2=ms2, final=msf,
                                      rim_steps_per_slice=cfg["num_cascades"] * T_))
