@@ -13,6 +13,9 @@
 // k = (cin, tap); one MFMA consumes two cins at one tap (lanes 0-31: cin c, lanes 32-63: cin c+1).
 // A workgroup (4 waves) owns an 8-row x 32-column output tile for up to 64 couts; each wave owns 2 rows x 2 cout
 // tiles = 4 independent accumulators, which is what the 64-cycle MFMA needs to issue back to back.
+#include <mutex>
+#include <unordered_map>
+
 #include "mrx_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -306,8 +309,16 @@ static int conv_geometry(int Cin, int k, int dil, int wp, int* CK, int* PH, int*
 
 template <typename K>
 static int conv_set_lds(K kern, size_t bytes) {
-    if (bytes > 48 * 1024)
-        MRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> done;
+    if (bytes > 48 * 1024) {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t& cur = done[(const void*)kern];
+        if (cur < bytes) {
+            MRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            cur = bytes;
+        }
+    }
     return MRX_OK;
 }
 

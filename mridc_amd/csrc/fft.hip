@@ -544,10 +544,20 @@ static inline int pick_cols(int H) {
     return ct;
 }
 
+// raises the dynamic-LDS limit of a kernel once (not on every launch: keeps launches legal under hipGraph capture)
 template <typename K>
 static int set_lds(K kern, size_t bytes) {
     MRX_REQUIRE(bytes <= 160 * 1024, MRX_EUNSUP, "FFT tile needs %zu bytes of LDS", bytes);
-    if (bytes > 48 * 1024) MRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> done;
+    if (bytes > 48 * 1024) {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t& cur = done[(const void*)kern];
+        if (cur < bytes) {
+            MRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            cur = bytes;
+        }
+    }
     return MRX_OK;
 }
 

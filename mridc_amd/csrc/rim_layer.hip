@@ -13,6 +13,8 @@
 //   * the 1x1 `ih` GEMM consumes the conv accumulators in registers (contraction index enumerated in C/D-layout order),
 //     its packed weights sit in their own LDS region from kernel start.
 #include <cstdlib>
+#include <algorithm>
+#include <map>
 #include <vector>
 
 #include "mrx_common.h"
@@ -23,6 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define RL_TH 8
 #define RL_TW 32
 #define RL_F 64
+#define RL_PF 3  // operand prefetch distance (MFMA steps)
 
 struct RimLayerArgs {
     const float* x;        // [B,Cin,H,W]
@@ -208,17 +211,27 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
         float* oth = smem_f + ((q + 1) & 1) * BUF;
         const float* xw = cur + lhi * PLANE + wave * PW + l31;
         const float* ww = cur + CK * PLANE + lhi * RL_F + l31;
-        if (!(a.ablate & 4))
+        if (!(a.ablate & 4)) {
+            // Operand reads run RL_PF steps ahead of the MFMAs that consume them (register ring, all indices constant after
+            // unrolling): a wave no longer serialises "ds_read -> wait -> 2 MFMAs" per step, so it can keep its SIMD's
+            // matrix pipe busy on its own and the LDS round trip is covered by RL_PF * 128 cycles of MFMA work.
+            constexpr int NS = TAPS * (CK / 2);
+            float ra0[RL_PF + 1], ra1[RL_PF + 1], rb[RL_PF + 1];
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = tap / K, kx = tap % K;  // folded: tap is an unrolled constant
-#pragma unroll
-            for (int pair = 0; pair < CK / 2; ++pair) {
-                const float bv = xw[(2 * pair) * PLANE + ky * DIL * PW + kx * DIL];
-                const float a0 = ww[((tap * (CK / 2) + pair) * 2) * RL_F];
-                const float a1 = ww[((tap * (CK / 2) + pair) * 2) * RL_F + 32];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+            for (int s = 0; s < NS + RL_PF; ++s) {
+                if (s < NS) {
+                    const int tap = s / (CK / 2), pair = s % (CK / 2);
+                    const int ky = tap / K, kx = tap % K;
+                    rb[s % (RL_PF + 1)] = xw[(2 * pair) * PLANE + ky * DIL * PW + kx * DIL];
+                    ra0[s % (RL_PF + 1)] = ww[(s * 2) * RL_F];
+                    ra1[s % (RL_PF + 1)] = ww[(s * 2) * RL_F + 32];
+                }
+                if (s >= RL_PF) {
+                    const int c = (s - RL_PF) % (RL_PF + 1);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], rb[c], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], rb[c], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads RL_PF steps ahead (the scheduler would sink them)
             }
         }
         // fill the other buffer (its readers all passed the previous barrier), then one barrier per chunk
@@ -270,16 +283,22 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[ct][r] = 0.f;
     const float* wi = Wi + lhi * RL_F + l31;
-    if (!(a.ablate & 16))
+    if (!(a.ablate & 16)) {
+        float qa0[RL_PF + 1], qa1[RL_PF + 1];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a0 = wi[((ct * 16 + r) * 2) * RL_F];
-            const float a1 = wi[((ct * 16 + r) * 2) * RL_F + 32];
-            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, acc[ct][r], acc2[0], 0, 0, 0);
-            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, acc[ct][r], acc2[1], 0, 0, 0);
+        for (int s = 0; s < 32 + RL_PF; ++s) {
+            if (s < 32) {
+                qa0[s % (RL_PF + 1)] = wi[(s * 2) * RL_F];
+                qa1[s % (RL_PF + 1)] = wi[(s * 2) * RL_F + 32];
+            }
+            if (s >= RL_PF) {
+                const int t = s - RL_PF, c = t % (RL_PF + 1);
+                acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa0[c], acc[t >> 4][t & 15], acc2[0], 0, 0, 0);
+                acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[c], acc[t >> 4][t & 15], acc2[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
     RL_STAMP(3)
     if (wide) {
         __syncthreads();  // every wave is done with Wi and the chunk buffers: LDS becomes 8 x [64][32] transpose tiles
@@ -324,9 +343,11 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
     }
     RL_STAMP(4)
     if (a.trace && tid == 0) {
-        unsigned hwid;
+        unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         a.trace[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = hwid;
+        a.trace[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = xcc & 0xf;
     }
 }
 
@@ -341,8 +362,11 @@ static int launch_rim_layer(const RimLayerArgs& a_in, hipStream_t st) {
     constexpr size_t lds_floats = 2 * per_buf > (size_t)(RL_NT / 64) * RL_F * RL_TW ? 2 * per_buf : (size_t)(RL_NT / 64) * RL_F * RL_TW;
     constexpr size_t lds = sizeof(float) * lds_floats;
     static_assert((CK * PLANE) % 4 == 0 && per_buf % 4 == 0, "weight regions must stay 16-byte aligned");
-    if (lds > 48 * 1024)
+    static bool attr_done = false;  // once per instantiation: keeps launches legal under hipGraph capture
+    if (lds > 48 * 1024 && !attr_done) {
         MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer<K, DIL, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
     static unsigned long long* d_trace = nullptr;
     RimLayerArgs a = a_in;
     a.trace = nullptr;
@@ -380,9 +404,24 @@ static int launch_rim_layer(const RimLayerArgs& a_in, hipStream_t st) {
         fprintf(stderr, "[mrx-trace] start histogram:");
         for (int k = 0; k < 10; ++k) fprintf(stderr, " %d", hist[k]);
         fprintf(stderr, "\n");
-        for (int i = 0; i < 6 && i < nb; ++i)
-            fprintf(stderr, "[mrx-trace] block %d hwid %08llx start %llu dur %llu\n", i, h[(size_t)i * 8 + 5], h[(size_t)i * 8] - t0,
-                    h[(size_t)i * 8 + 4] - h[(size_t)i * 8]);
+        // co-residency: group blocks by (xcc, se, sh, cu) and list them in start order (per-XCC clocks are comparable)
+        struct Rec { int blk; unsigned long long st, en; };
+        std::map<unsigned, std::vector<Rec>> cus;
+        for (int i = 0; i < nb; ++i) {
+            const unsigned hw = (unsigned)h[(size_t)i * 8 + 5];
+            const unsigned key = ((unsigned)h[(size_t)i * 8 + 6] << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+            cus[key].push_back({i, h[(size_t)i * 8], h[(size_t)i * 8 + 4]});
+        }
+        fprintf(stderr, "[mrx-trace] %zu distinct CUs\n", cus.size());
+        int shown = 0;
+        for (auto& kv : cus) {
+            if (shown++ >= 4) break;
+            auto& v = kv.second;
+            std::sort(v.begin(), v.end(), [](const Rec& x, const Rec& y) { return x.st < y.st; });
+            fprintf(stderr, "[mrx-trace] cu %06x:", kv.first);
+            for (auto& r : v) fprintf(stderr, " blk%d[%llu..%llu]", r.blk, (r.st - v[0].st) / 1000, (r.en - v[0].st) / 1000);
+            fprintf(stderr, "  (kcycles)\n");
+        }
     }
     return MRX_OK;
 }
@@ -532,8 +571,11 @@ static int launch_rim_final(const RimFinalArgs& a, hipStream_t st) {
     constexpr int PLANE = (RF_TH + 2 * PAD) * (RL_TW + 2 * PAD);
     const size_t lds = sizeof(float) * ((size_t)RF_CK * PLANE + 2 * (size_t)((a.F + RF_CK - 1) / RF_CK * RF_CK) * K * K);
     MRX_REQUIRE(lds <= 160 * 1024, MRX_EUNSUP, "rim_final: %zu bytes of LDS", lds);
-    if (lds > 48 * 1024)
+    static size_t attr_bytes = 0;
+    if (lds > 48 * 1024 && attr_bytes < lds) {
         MRX_HIP(hipFuncSetAttribute((const void*)k_rim_final<K, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
     hipLaunchKernelGGL((k_rim_final<K, DIL>), dim3(a.ntiles, a.B), dim3(RF_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
