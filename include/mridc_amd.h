@@ -180,9 +180,11 @@ int mrx_mgu_gates(const float* ih, const float* hh, const float* h, float* out, 
  *   mrx_avg_pool2x2         avg_pool2d(kernel 2, stride 2)                                                 (:206)
  *   mrx_conv_transpose2x2   ConvTranspose2d(k=2, s=2, bias=False), weight [Cin,Cout,2,2]                   (:293)
  *   mrx_copy_channels       dst[:, c0:c0+C] = src for the skip concat                                      (:224) */
-int mrx_instance_norm_act(const float* x, float* out, int64_t planes, int64_t HW, float eps, int act, float slope,
-                          void* stream);
-int mrx_group_norm_stats(const float* x, float* mean, float* std_, int64_t groups, int64_t n, void* stream);
+/* work: caller scratch of mrx_norm_work_floats(planes|groups, HW|n) floats (statistics are reduced by many workgroups per plane) */
+int64_t mrx_norm_work_floats(int64_t planes, int64_t n);
+int mrx_instance_norm_act(const float* x, float* out, float* work, int64_t planes, int64_t HW, float eps, int act,
+                          float slope, void* stream);
+int mrx_group_norm_stats(const float* x, float* mean, float* std_, float* work, int64_t groups, int64_t n, void* stream);
 int mrx_group_norm_apply(const float* x, const float* mean, const float* std_, float* out, int64_t groups, int64_t n,
                          int inverse, void* stream);
 int mrx_pad2d(const float* in, float* out, int64_t planes, int H, int W, int top, int bottom, int left, int right,

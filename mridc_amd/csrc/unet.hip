@@ -24,23 +24,61 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-// ---- InstanceNorm2d (biased variance, eps) + activation, one workgroup per (b, c) plane -------------------------------
-__global__ __launch_bounds__(UN_NT) void k_instance_norm_act(const float* x, float* out, long long HW, float eps, int act,
-                                                             float slope) {
+// ---- plane statistics, split over many workgroups (a 640x380 plane is 243k floats; one workgroup per plane would leave
+// most of the chip idle).  Three deterministic passes, no atomics: partial sums -> partial squared deviations -> apply.
+// Workspace: 2 * planes * nsplit floats owned by the caller (mrx_norm_work_floats).
+#define UN_CHUNK 8192
+static inline int un_nsplit(long long n) {
+    long long s = (n + UN_CHUNK - 1) / UN_CHUNK;
+    return s < 1 ? 1 : (s > 64 ? 64 : (int)s);
+}
+extern "C" int64_t mrx_norm_work_floats(int64_t planes, int64_t n) { return planes < 0 || n < 1 ? -1 : 2 * planes * un_nsplit(n); }
+
+__device__ __forceinline__ void split_range(long long n, int nsplit, int s, long long& a, long long& b) {
+    const long long per = (n + nsplit - 1) / nsplit;
+    a = (long long)s * per;
+    b = a + per < n ? a + per : n;
+}
+__global__ __launch_bounds__(UN_NT) void k_plane_sum(const float* x, float* part, long long n, int nsplit) {
     __shared__ float red[UN_NT / 64];
-    const float* p = x + (long long)blockIdx.x * HW;
-    float* q = out + (long long)blockIdx.x * HW;
+    long long a, b;
+    split_range(n, nsplit, blockIdx.y, a, b);
+    const float* p = x + (long long)blockIdx.x * n;
     float s = 0.f;
-    for (long long i = threadIdx.x; i < HW; i += UN_NT) s += p[i];
-    const float mean = block_sum(s, red) / (float)HW;
+    for (long long i = a + threadIdx.x; i < b; i += UN_NT) s += p[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[(long long)blockIdx.x * nsplit + blockIdx.y] = s;
+}
+__device__ __forceinline__ float combine(const float* part, int nsplit) {
+    double t = 0.0;
+    for (int i = 0; i < nsplit; ++i) t += (double)part[i];
+    return (float)t;
+}
+__global__ __launch_bounds__(UN_NT) void k_plane_sqdev(const float* x, const float* psum, float* psq, long long n, int nsplit) {
+    __shared__ float red[UN_NT / 64];
+    long long a, b;
+    split_range(n, nsplit, blockIdx.y, a, b);
+    const float* p = x + (long long)blockIdx.x * n;
+    const float mean = combine(psum + (long long)blockIdx.x * nsplit, nsplit) / (float)n;
     float v = 0.f;
-    for (long long i = threadIdx.x; i < HW; i += UN_NT) {
+    for (long long i = a + threadIdx.x; i < b; i += UN_NT) {
         const float d = p[i] - mean;
         v += d * d;
     }
-    const float var = block_sum(v, red) / (float)HW;
+    v = block_sum(v, red);
+    if (threadIdx.x == 0) psq[(long long)blockIdx.x * nsplit + blockIdx.y] = v;
+}
+// InstanceNorm2d (biased variance, eps) + activation   (unet_block.py:252-253, :294-295)
+__global__ __launch_bounds__(UN_NT) void k_plane_norm_act(const float* x, float* out, const float* psum, const float* psq, long long n,
+                                                          int nsplit, float eps, int act, float slope) {
+    long long a, b;
+    split_range(n, nsplit, blockIdx.y, a, b);
+    const float* p = x + (long long)blockIdx.x * n;
+    float* q = out + (long long)blockIdx.x * n;
+    const float mean = combine(psum + (long long)blockIdx.x * nsplit, nsplit) / (float)n;
+    const float var = combine(psq + (long long)blockIdx.x * nsplit, nsplit) / (float)n;
     const float inv = 1.0f / sqrtf(var + eps);
-    for (long long i = threadIdx.x; i < HW; i += UN_NT) {
+    for (long long i = a + threadIdx.x; i < b; i += UN_NT) {
         float y = (p[i] - mean) * inv;
         if (act == MRX_ACT_RELU)
             y = y > 0.f ? y : 0.f;
@@ -49,39 +87,44 @@ __global__ __launch_bounds__(UN_NT) void k_instance_norm_act(const float* x, flo
         q[i] = y;
     }
 }
-extern "C" int mrx_instance_norm_act(const float* x, float* out, int64_t planes, int64_t HW, float eps, int act, float slope,
-                                     void* stream) {
-    MRX_REQUIRE(x && out && planes >= 0 && HW >= 1, MRX_EINVAL, "mrx_instance_norm_act: bad argument");
+extern "C" int mrx_instance_norm_act(const float* x, float* out, float* work, int64_t planes, int64_t HW, float eps, int act,
+                                     float slope, void* stream) {
+    MRX_REQUIRE(x && out && work && planes >= 0 && HW >= 1, MRX_EINVAL, "mrx_instance_norm_act: bad argument");
     if (planes == 0) return MRX_OK;
     MRX_REQUIRE(planes < (1LL << 31), MRX_EUNSUP, "mrx_instance_norm_act: too many planes");
-    hipLaunchKernelGGL(k_instance_norm_act, dim3((unsigned)planes), dim3(UN_NT), 0, (hipStream_t)stream, x, out, (long long)HW, eps,
-                       act, slope);
+    const int ns = un_nsplit(HW);
+    float* psum = work;
+    float* psq = work + planes * ns;
+    dim3 grid((unsigned)planes, ns);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_plane_sum, grid, dim3(UN_NT), 0, st, x, psum, (long long)HW, ns);
+    hipLaunchKernelGGL(k_plane_sqdev, grid, dim3(UN_NT), 0, st, x, (const float*)psum, psq, (long long)HW, ns);
+    hipLaunchKernelGGL(k_plane_norm_act, grid, dim3(UN_NT), 0, st, x, out, (const float*)psum, (const float*)psq, (long long)HW, ns,
+                       eps, act, slope);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 
 // ---- group norm statistics: mean and UNBIASED std per group (unet_block.py:78-79) ---------------------------------------
-__global__ __launch_bounds__(UN_NT) void k_group_stats(const float* x, float* mean_o, float* std_o, long long n) {
-    __shared__ float red[UN_NT / 64];
-    const float* p = x + (long long)blockIdx.x * n;
-    float s = 0.f;
-    for (long long i = threadIdx.x; i < n; i += UN_NT) s += p[i];
-    const float mean = block_sum(s, red) / (float)n;
-    float v = 0.f;
-    for (long long i = threadIdx.x; i < n; i += UN_NT) {
-        const float d = p[i] - mean;
-        v += d * d;
-    }
-    const float ss = block_sum(v, red);
-    if (threadIdx.x == 0) {
-        mean_o[blockIdx.x] = mean;
-        std_o[blockIdx.x] = sqrtf(ss / (float)(n - 1));
-    }
+__global__ void k_group_finalize(const float* psum, const float* psq, float* mean_o, float* std_o, long long groups, long long n,
+                                 int nsplit) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    mean_o[g] = combine(psum + g * nsplit, nsplit) / (float)n;
+    std_o[g] = sqrtf(combine(psq + g * nsplit, nsplit) / (float)(n - 1));
 }
-extern "C" int mrx_group_norm_stats(const float* x, float* mean, float* std_, int64_t groups, int64_t n, void* stream) {
-    MRX_REQUIRE(x && mean && std_ && groups >= 0 && n >= 1, MRX_EINVAL, "mrx_group_norm_stats: bad argument");
+extern "C" int mrx_group_norm_stats(const float* x, float* mean, float* std_, float* work, int64_t groups, int64_t n, void* stream) {
+    MRX_REQUIRE(x && mean && std_ && work && groups >= 0 && n >= 1, MRX_EINVAL, "mrx_group_norm_stats: bad argument");
     if (groups == 0) return MRX_OK;
-    hipLaunchKernelGGL(k_group_stats, dim3((unsigned)groups), dim3(UN_NT), 0, (hipStream_t)stream, x, mean, std_, (long long)n);
+    const int ns = un_nsplit(n);
+    float* psum = work;
+    float* psq = work + groups * ns;
+    dim3 grid((unsigned)groups, ns);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_plane_sum, grid, dim3(UN_NT), 0, st, x, psum, (long long)n, ns);
+    hipLaunchKernelGGL(k_plane_sqdev, grid, dim3(UN_NT), 0, st, x, (const float*)psum, psq, (long long)n, ns);
+    hipLaunchKernelGGL(k_group_finalize, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, st, (const float*)psum, (const float*)psq,
+                       mean, std_, (long long)groups, (long long)n, ns);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

@@ -262,8 +262,9 @@ def instance_norm_act(x, eps=1e-5, act=ACT_LEAKY, slope=0.2, inplace=True):
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
     out = x if inplace else torch.empty_like(x)
-    _lib.check(_lib.lib().mrx_instance_norm_act(_lib.ptr(x), _lib.ptr(out), B * C, H * W, float(eps), int(act), float(slope),
-                                                _lib.stream_ptr()), "mrx_instance_norm_act")
+    work = torch.empty(int(_lib.lib().mrx_norm_work_floats(B * C, H * W)), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_instance_norm_act(_lib.ptr(x), _lib.ptr(out), _lib.ptr(work), B * C, H * W, float(eps), int(act),
+                                                float(slope), _lib.stream_ptr()), "mrx_instance_norm_act")
     return out
 
 
@@ -276,8 +277,9 @@ def group_norm(x, groups):
     std = torch.empty_like(mean)
     out = torch.empty_like(x)
     L = _lib.lib()
-    _lib.check(L.mrx_group_norm_stats(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(std), B * groups, n, _lib.stream_ptr()),
-               "mrx_group_norm_stats")
+    work = torch.empty(int(L.mrx_norm_work_floats(B * groups, n)), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_group_norm_stats(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(work), B * groups, n,
+                                      _lib.stream_ptr()), "mrx_group_norm_stats")
     _lib.check(L.mrx_group_norm_apply(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(out), B * groups, n, 0,
                                       _lib.stream_ptr()), "mrx_group_norm_apply")
     return out, mean, std
