@@ -194,6 +194,12 @@ int mrx_conv_transpose2x2(const float* x, const float* w, float* out, int B, int
                           void* stream);
 int mrx_copy_channels(const float* src, float* dst, int B, int C, int64_t HW, int Ctot, int c0, void* stream);
 
+/* A20 SSIMLoss.forward (mridc/collections/common/losses/ssim.py:28-61): X,Y [B,1,h,w], data_range [B] -> out[0] = 1 - mean(S).
+ * work: mrx_ssim_work_floats(B,h,w) floats. */
+int64_t mrx_ssim_work_floats(int B, int h, int w);
+int mrx_ssim_loss(const float* X, const float* Y, const float* data_range, float* out, float* work, int B, int h, int w, int win,
+                  float k1, float k2, void* stream);
+
 /* A19 quantitative MRI (mridc/collections/quantitative/models/qrim/utils.py, qrim_block.py).
  *   mrx_dc_residual  out[b] = sum_c conj(S[b/sdiv,c]) ifft2(mask (fft2(x[b] S[b/sdiv,c]) - y[b,c]));  b = batch x echoes,
  *                    sdiv = echoes sharing one set of maps (utils.py:235-248).  x,out [B,H,W,2]; y,work [B,C,H,W,2]; S [B/sdiv,C,H,W,2]

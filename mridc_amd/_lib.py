@@ -64,6 +64,8 @@ _SIGNATURES = {
     "mrx_qmri_grad": ([_p, _p, _p, _p, _p, _p, _i, _p, _i64, _i64, _f, _f, _p], _i),
     "mrx_scale": ([_p, _p, _i64, _f, _i, _p], _i),
     "mrx_qrim_update": ([_p, _p, _p, _i, _i, _i64, _p], _i),
+    "mrx_ssim_work_floats": ([_i, _i, _i], _i64),
+    "mrx_ssim_loss": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p], _i),
     "mrx_copy_channels": ([_p, _p, _i, _i, _i64, _i, _i, _p], _i),
 }
 

@@ -1,11 +1,9 @@
-"""SSIM loss -- drop-in for `mridc.collections.common.losses.ssim.SSIMLoss` (reference ssim.py:11-61).
-
-Used for reporting ("SSIM vs ref") on small [B,1,h,w] magnitude images after the reconstruction; the five
-7x7 box filters run through torch's conv2d on whatever device the images are on (metric plumbing, not the hot path).
-"""
+"""SSIM loss -- drop-in for `mridc.collections.common.losses.ssim.SSIMLoss` (reference ssim.py:11-61), HIP backed (inference /
+metric use: no autograd)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
+
+from mridc_amd import _lib
 
 
 class SSIMLoss(nn.Module):
@@ -18,15 +16,16 @@ class SSIMLoss(nn.Module):
         self.cov_norm = NP / (NP - 1)
 
     def forward(self, X: torch.Tensor, Y: torch.Tensor, data_range: torch.Tensor):
-        w = self.w.to(X)
-        data_range = data_range[:, None, None, None]
-        C1 = (self.k1 * data_range) ** 2
-        C2 = (self.k2 * data_range) ** 2
-        ux, uy = F.conv2d(X, w), F.conv2d(Y, w)
-        uxx, uyy, uxy = F.conv2d(X * X, w), F.conv2d(Y * Y, w), F.conv2d(X * Y, w)
-        vx = self.cov_norm * (uxx - ux * ux)
-        vy = self.cov_norm * (uyy - uy * uy)
-        vxy = self.cov_norm * (uxy - ux * uy)
-        A1, A2, B1, B2 = (2 * ux * uy + C1, 2 * vxy + C2, ux ** 2 + uy ** 2 + C1, vx + vy + C2)
-        S = (A1 * A2) / (B1 * B2)
-        return 1 - S.mean()
+        """X, Y: [B,1,h,w]; data_range: [B].  Returns 1 - mean(SSIM map) (a 0-d tensor)."""
+        if X.dim() != 4 or X.shape[1] != 1 or X.shape != Y.shape:
+            raise ValueError(f"SSIMLoss expects X and Y of shape [B,1,h,w], got {tuple(X.shape)} and {tuple(Y.shape)}")
+        X, Y, dr = _lib.f32c(X), _lib.f32c(Y), _lib.f32c(data_range.reshape(-1))
+        B, _, h, w = [int(v) for v in X.shape]
+        if dr.numel() != B:
+            dr = dr.expand(B).contiguous()
+        L = _lib.lib()
+        out = torch.empty(1, dtype=torch.float32, device=X.device)
+        work = torch.empty(int(L.mrx_ssim_work_floats(B, h, w)), dtype=torch.float32, device=X.device)
+        _lib.check(L.mrx_ssim_loss(_lib.ptr(X), _lib.ptr(Y), _lib.ptr(dr), _lib.ptr(out), _lib.ptr(work), B, h, w, self.win_size,
+                                   float(self.k1), float(self.k2), _lib.stream_ptr()), "mrx_ssim_loss")
+        return out[0]

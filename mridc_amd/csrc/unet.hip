@@ -254,3 +254,84 @@ extern "C" int mrx_copy_channels(const float* src, float* dst, int B, int C, int
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
+
+// ---- SSIM (reference common/losses/ssim.py:46-61): 7x7 uniform window (valid), cov_norm = NP/(NP-1), 1 - mean(S) ----------
+// One thread per output pixel of a 16x16 tile, both images staged in LDS with their halo; per-workgroup partial sums of S
+// are reduced by a second single-workgroup kernel in double (deterministic, no atomics).
+#define SS_T 16
+__global__ __launch_bounds__(SS_T* SS_T) void k_ssim_partial(const float* __restrict__ X, const float* __restrict__ Y,
+                                                            const float* __restrict__ data_range, float* __restrict__ part,
+                                                            int h, int w, int win, float k1, float k2, int tiles_x) {
+    extern __shared__ float ssm[];
+    const int P = SS_T + win - 1;
+    float* xs = ssm;
+    float* ys = ssm + P * P;
+    __shared__ float red[UN_NT / 64];
+    const int b = blockIdx.y;
+    const int ty0 = (blockIdx.x / tiles_x) * SS_T, tx0 = (blockIdx.x % tiles_x) * SS_T;
+    const float* xb = X + (long long)b * h * w;
+    const float* yb = Y + (long long)b * h * w;
+    for (int i = threadIdx.x; i < P * P; i += SS_T * SS_T) {
+        const int py = i / P, px = i - py * P;
+        const int gy = ty0 + py, gx = tx0 + px;
+        const bool ok = gy < h && gx < w;
+        xs[i] = ok ? xb[(long long)gy * w + gx] : 0.f;
+        ys[i] = ok ? yb[(long long)gy * w + gx] : 0.f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / SS_T, lx = threadIdx.x % SS_T;
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    const int oh = h - win + 1, ow = w - win + 1;
+    float S = 0.f;
+    if (oy < oh && ox < ow) {
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+        for (int dy = 0; dy < win; ++dy)
+            for (int dx = 0; dx < win; ++dx) {
+                const float xv = xs[(ly + dy) * P + lx + dx], yv = ys[(ly + dy) * P + lx + dx];
+                sx += xv;
+                sy += yv;
+                sxx += xv * xv;
+                syy += yv * yv;
+                sxy += xv * yv;
+            }
+        const float np = (float)(win * win), wgt = 1.0f / np, cov = np / (np - 1.0f);
+        const float ux = sx * wgt, uy = sy * wgt, uxx = sxx * wgt, uyy = syy * wgt, uxy = sxy * wgt;
+        const float dr = data_range[b];
+        const float C1 = (k1 * dr) * (k1 * dr), C2 = (k2 * dr) * (k2 * dr);
+        const float vx = cov * (uxx - ux * ux), vy = cov * (uyy - uy * uy), vxy = cov * (uxy - ux * uy);
+        const float A1 = 2 * ux * uy + C1, A2 = 2 * vxy + C2, B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
+        S = (A1 * A2) / (B1 * B2);
+    }
+    S = block_sum(S, red);
+    if (threadIdx.x == 0) part[(long long)b * gridDim.x + blockIdx.x] = S;
+}
+__global__ __launch_bounds__(UN_NT) void k_ssim_final(const float* part, float* out, long long nparts, double count) {
+    __shared__ double dred[UN_NT];
+    double t = 0.0;
+    for (long long i = threadIdx.x; i < nparts; i += UN_NT) t += (double)part[i];
+    dred[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = UN_NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) dred[threadIdx.x] += dred[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(1.0 - dred[0] / count);
+}
+extern "C" int64_t mrx_ssim_work_floats(int B, int h, int w) {
+    if (B < 0 || h < 1 || w < 1) return -1;
+    return (int64_t)B * ((h + SS_T - 1) / SS_T) * ((w + SS_T - 1) / SS_T);
+}
+extern "C" int mrx_ssim_loss(const float* X, const float* Y, const float* data_range, float* out, float* work, int B, int h, int w,
+                             int win, float k1, float k2, void* stream) {
+    MRX_REQUIRE(X && Y && data_range && out && work, MRX_EINVAL, "mrx_ssim_loss: null pointer");
+    MRX_REQUIRE(B >= 1 && win >= 1 && h >= win && w >= win && win <= 31, MRX_EINVAL, "mrx_ssim_loss: bad dims B=%d h=%d w=%d win=%d", B, h, w, win);
+    const int tiles_x = (w + SS_T - 1) / SS_T, tiles_y = (h + SS_T - 1) / SS_T;
+    const int P = SS_T + win - 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_ssim_partial, dim3(tiles_x * tiles_y, B), dim3(SS_T * SS_T), sizeof(float) * 2 * P * P, st, X, Y, data_range,
+                       work, h, w, win, k1, k2, tiles_x);
+    hipLaunchKernelGGL(k_ssim_final, dim3(1), dim3(UN_NT), 0, st, (const float*)work, out, (long long)B * tiles_x * tiles_y,
+                       (double)B * (h - win + 1) * (w - win + 1));
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

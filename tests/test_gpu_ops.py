@@ -242,3 +242,17 @@ def test_llg_row_invariant_mask_fast_path(shape, dev):
     assert not ops.mask_is_row_invariant(torch.zeros(1, 1, H, W, 1))
     with pytest.raises(RuntimeError, match="row index"):
         ops.llg_hinv(eta.to(dev), k.to(dev), S.to(dev), torch.ones(1, 1, H, W, 1, device=dev), 1.0, True, "ortho")
+
+
+def test_g10_ssim_loss(golden, dev):
+    from mridc_amd.collections.common.losses.ssim import SSIMLoss
+    z = golden("g10_ssim.npz")
+    X, Y, dr = T(z["X"]).to(dev), T(z["Y"]).to(dev), T(z["data_range"]).to(dev)
+    loss = SSIMLoss()
+    assert abs(float(loss(X, Y, dr)) - float(z["loss"][0])) < 2e-6
+    assert abs(float(loss(X, X, dr)) - float(z["loss_same"][0])) < 2e-6
+    g = torch.Generator().manual_seed(8)
+    A = torch.rand(3, 1, 45, 70, generator=g)
+    Bm = (A + 0.2 * torch.rand(3, 1, 45, 70, generator=g)).clamp(0, 1)
+    d = torch.tensor([1.0, 0.5, 2.0])
+    assert abs(float(loss(A.to(dev), Bm.to(dev), d.to(dev))) - float(oracle.metrics.ssim_loss(A, Bm, d))) < 2e-6
