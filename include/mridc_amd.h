@@ -114,11 +114,13 @@ int mrx_llg(const float* eta, const float* y, const float* S, const void* mask, 
  * yt = IFFT_H(y) (mrx_fft_cols, inverse, once per cascade) every step is ONE launch of row transforms that moves exactly
  * the algorithmic (25+16C)HW bytes.  Same result as mrx_llg up to fp32 rounding.
  *   mrx_fft_cols   1-D transform along H of [nimg,H,W,2] (the column pass of mrx_fft2); in == out allowed
- *   mrx_llg_hinv   eta [B,H,W,2], yt/S [B,C,H,W,2] -> out4 [B,4,H,W] */
+ *   mrx_llg_hinv   eta [B,H,W,2], yt/S [B,C,H,W,2] -> out4 [B,4,H,W]; `work` (mrx_llg_hinv_work_floats floats, may be NULL)
+ *                  lets small grids split the coil sum over several workgroups per row (partial sums + combine) */
+int64_t mrx_llg_hinv_work_floats(int B, int C, int H, int W);
 int mrx_fft_cols(const float* in, float* out, int64_t nimg, int H, int W, int inverse, int norm, int centered,
                  void* stream);
 int mrx_llg_hinv(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
-                 const int64_t* mstride, float* out4, int B, int C, int H, int W, float inv_sigma2, int norm,
+                 const int64_t* mstride, float* out4, float* work, int B, int C, int H, int W, float inv_sigma2, int norm,
                  int centered, void* stream);
 
 /* K2  soft data consistency: out = where(mask, pred - ref, 0) * dc_weight[0]   (vn_block.py:109-110,

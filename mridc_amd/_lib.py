@@ -39,7 +39,8 @@ _SIGNATURES = {
     "mrx_sens_reduce": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_llg": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_fft_cols": ([_p, _p, _i64, _i, _i, _i, _i, _i, _p], _i),
-    "mrx_llg_hinv": ([_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p], _i),
+    "mrx_llg_hinv_work_floats": ([_i, _i, _i, _i], _i64),
+    "mrx_llg_hinv": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_soft_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_conv2d": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),

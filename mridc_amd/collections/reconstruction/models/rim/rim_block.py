@@ -112,6 +112,7 @@ class RIMBlock(torch.nn.Module):
         hinv = ops.mask_is_row_invariant(mask) and self.coil_dim == 1
         if hinv:
             yt = ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization, self.spatial_dims)
+            work = None
         else:
             work = torch.empty_like(masked_kspace, dtype=torch.float32)
         etas = []

@@ -426,7 +426,10 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_rows_reduce(const float2* __rest
 // (the H transforms cancel for every normalisation, centred or not), so with yt = IFFT_H(y) precomputed once the whole
 // step is row transforms only and fuses into ONE kernel per (b, h) row: eta*S -> FFT_W -> m*(. - yt) -> IFFT_W ->
 // sum_c conj(S) -> /sigma^2.  HBM traffic = the algorithmic (25 + 16 C) H W bytes; no work buffer.
-template <class P, int NSEQ>
+// PART = true: one workgroup per (row, coil chunk) -- blockIdx.z is the chunk -- writing the un-scaled partial coil sum to
+// part[chunk][b][h][w]; k_llg_combine adds the chunks.  Gives 3x the workgroups at C = 15 (1920 instead of 640 at B = 1), which
+// is what a latency-bound kernel needs on 256 CUs.
+template <class P, int NSEQ, bool PART>
 __global__ __launch_bounds__(MRX_FFT_NT) void k_llg_rows_hinv(const float2* __restrict__ eta, const float2* __restrict__ yt,
                                                               const float2* __restrict__ S, MrxMask mask,
                                                               float* __restrict__ out, ReduceArgs a, float scale_f) {
@@ -446,7 +449,9 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_llg_rows_hinv(const float2* __re
         acc[i] = make_float2(0.f, 0.f);
         E[i] = eta[(b * H + h) * W + shifted(i, a.halfW, W)];
     }
-    for (int c0 = 0; c0 < C; c0 += G) {
+    const int c_begin = PART ? (int)blockIdx.z * G : 0;
+    const int c_end = PART ? min(C, c_begin + G) : C;
+    for (int c0 = c_begin; c0 < c_end; c0 += G) {
         const int nrows = min(G, C - c0);
         __syncthreads();
         for (int idx = threadIdx.x; idx < G * W; idx += MRX_FFT_NT) {
@@ -500,6 +505,11 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_llg_rows_hinv(const float2* __re
     }
     __syncthreads();
     const long long plane = (long long)H * W;
+    if (PART) {
+        float2* po = reinterpret_cast<float2*>(out) + ((long long)blockIdx.z * gridDim.y + b) * plane + (long long)h * W;
+        for (int x = threadIdx.x; x < W; x += MRX_FFT_NT) po[shifted(x, a.halfW, W)] = acc[x];
+        return;
+    }
     for (int x = threadIdx.x; x < W; x += MRX_FFT_NT) {
         const int g = shifted(x, a.halfW, W);
         const float2 v = acc[x];
@@ -509,6 +519,117 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_llg_rows_hinv(const float2* __re
         o[plane] = e.y;
         o[2 * plane] = v.x * a.post;
         o[3 * plane] = v.y * a.post;
+    }
+}
+
+// Compile-time-plan, one-chunk-per-workgroup variant of the PART kernel: both global operands of every element (maps S and
+// hybrid-space data yt) are fetched into registers with all loads issued back to back at kernel start (one memory round
+// trip per workgroup instead of one per element and phase), S never goes through LDS, the mask row is staged in LDS.
+// LDS = (2.5 + 2 G) W float2 (36 KB at W = 372, G = 5): 4 workgroups per CU.
+template <class P, int NSEQ>
+__global__ __launch_bounds__(MRX_FFT_NT, 4) void k_llg_rows_hinv_part(const float2* __restrict__ eta, const float2* __restrict__ yt,
+                                                                      const float2* __restrict__ S, MrxMask mask,
+                                                                      float2* __restrict__ part, ReduceArgs a, float scale_f) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    constexpr int W = P::N, G = NSEQ;
+    constexpr int NE = (G * W + MRX_FFT_NT - 1) / MRX_FFT_NT;
+    const int H = a.H, C = a.C;
+    float2* tw = smem;
+    float2* E = smem + W;
+    float* Mk = reinterpret_cast<float*>(E + W);
+    float2* A = E + W + (W + 1) / 2;
+    float2* B = A + G * W;
+    const int h = blockIdx.x;
+    const long long b = blockIdx.y;
+    const int c0 = (int)blockIdx.z * G;
+    const bool mask_lds = mask.s[1] == 0;
+    float2 sv[NE], yv[NE];
+    {
+        const long long base = (((b / a.sdiv) * C + c0) * H + h) * (long long)W;
+        const long long ybase = ((b * C + c0) * H + h) * (long long)W;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = threadIdx.x + e * MRX_FFT_NT;
+            const int r = idx / W, x = idx - r * W;
+            const bool ok = idx < G * W && c0 + r < C;
+            const long long off = (long long)r * H * W + shifted(x, a.halfW, W);
+            sv[e] = ok ? S[base + off] : make_float2(0.f, 0.f);
+            yv[e] = ok ? yt[ybase + off] : make_float2(0.f, 0.f);
+        }
+    }
+    for (int i = threadIdx.x; i < W; i += MRX_FFT_NT) {
+        const int g = shifted(i, a.halfW, W);
+        tw[i] = a.tw[i];
+        E[i] = eta[(b * H + h) * W + g];
+        if (mask_lds) Mk[i] = mrx_mask_val(mask, b, 0, 0, g);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int idx = threadIdx.x + e * MRX_FFT_NT;
+        if (idx < G * W) {
+            const int r = idx / W, x = idx - r * W;
+            const float2 ev = E[x];
+            A[idx] = make_float2(ev.x * sv[e].x - ev.y * sv[e].y, ev.x * sv[e].y + ev.y * sv[e].x);  // rim_utils.py:47-48
+        }
+    }
+    __syncthreads();
+    float2* res = RunPlan<false, NSEQ, false, P>::run(A, B, tw);
+    float2* oth = (res == A) ? B : A;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int idx = threadIdx.x + e * MRX_FFT_NT;
+        if (idx < G * W) {
+            const int r = idx / W, x = idx - r * W;
+            const float m = mask_lds ? Mk[x] : mrx_mask_val(mask, b, c0 + r, 0, shifted(x, a.halfW, W));
+            const float2 k = res[idx];
+            res[idx] = make_float2(m * (k.x * scale_f - yv[e].x), m * (k.y * scale_f - yv[e].y));  // rim_utils.py:54
+        }
+    }
+    __syncthreads();
+    float2* res2 = RunPlan<true, NSEQ, false, P>::run(res, oth, tw);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int idx = threadIdx.x + e * MRX_FFT_NT;
+        if (idx < G * W) {
+            float2 v = res2[idx];
+            v.x *= a.scale;
+            v.y *= a.scale;
+            res2[idx] = make_float2(v.x * sv[e].x + v.y * sv[e].y, v.y * sv[e].x - v.x * sv[e].y);  // rim_utils.py:61-62
+        }
+    }
+    __syncthreads();
+    float2* po = part + ((long long)blockIdx.z * gridDim.y + b) * (long long)H * W + (long long)h * W;
+    for (int x = threadIdx.x; x < W; x += MRX_FFT_NT) {
+        float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+            const float2 v = res2[r * W + x];   // rows beyond C are zero
+            sum.x += v.x;
+            sum.y += v.y;
+        }
+        po[shifted(x, a.halfW, W)] = sum;
+    }
+}
+
+// out4[b] = (eta_re, eta_im, post * sum_k part_k.re, post * sum_k part_k.im)   (rim_utils.py:61-67)
+__global__ void k_llg_combine(const float2* __restrict__ eta, const float2* __restrict__ part, float* __restrict__ out, int nparts,
+                              long long B, long long plane, float post) {
+    const long long total = B * plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / plane, p = i - b * plane;
+        float2 s = part[i];
+        for (int k = 1; k < nparts; ++k) {
+            const float2 v = part[(long long)k * total + i];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        const float2 e = eta[i];
+        float* o = out + b * 4 * plane + p;
+        o[0] = e.x;
+        o[plane] = e.y;
+        o[2 * plane] = s.x * post;
+        o[3 * plane] = s.y * post;
     }
 }
 
@@ -787,11 +908,32 @@ extern "C" int mrx_llg(const float* eta, const float* y, const float* S, const v
 }
 
 template <class P, int NSEQ>
-static int launch_hinv_p(const float2* eta, const float2* yt, const float2* S, const MrxMask& m, float* out, dim3 grid,
-                         size_t lds, const ReduceArgs& a, float scale_f, hipStream_t st) {
-    int rc = set_lds(k_llg_rows_hinv<P, NSEQ>, lds);
+static int launch_hinv_p(const float2* eta, const float2* yt, const float2* S, const MrxMask& m, float* out, float* part,
+                         dim3 grid, size_t lds, const ReduceArgs& a, float scale_f, hipStream_t st) {
+    const int nchunks = mrx_cdiv(a.C, a.g);
+    if (part && nchunks > 1) {
+        dim3 g3(grid.x, grid.y, nchunks);
+        if constexpr (P::kCT) {
+            const size_t lds_p = sizeof(float2) * (2 * (size_t)P::N + (P::N + 1) / 2 + 2 * (size_t)NSEQ * P::N);
+            int rc = set_lds(k_llg_rows_hinv_part<P, NSEQ>, lds_p);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_llg_rows_hinv_part<P, NSEQ>), g3, dim3(MRX_FFT_NT), lds_p, st, eta, yt, S, m, (float2*)part, a, scale_f);
+        } else {
+            int rc = set_lds(k_llg_rows_hinv<P, NSEQ, true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_llg_rows_hinv<P, NSEQ, true>), g3, dim3(MRX_FFT_NT), lds, st, eta, yt, S, m, part, a, scale_f);
+        }
+        const long long plane = (long long)a.H * a.W, total = plane * grid.y;
+        long long nb = (total + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(k_llg_combine, dim3((unsigned)nb), dim3(256), 0, st, eta, (const float2*)part, out, nchunks,
+                           (long long)grid.y, plane, a.post);
+        MRX_LAUNCH_CHECK();
+        return MRX_OK;
+    }
+    int rc = set_lds(k_llg_rows_hinv<P, NSEQ, false>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_llg_rows_hinv<P, NSEQ>), grid, dim3(MRX_FFT_NT), lds, st, eta, yt, S, m, out, a, scale_f);
+    hipLaunchKernelGGL((k_llg_rows_hinv<P, NSEQ, false>), grid, dim3(MRX_FFT_NT), lds, st, eta, yt, S, m, out, a, scale_f);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -805,9 +947,17 @@ extern "C" int mrx_fft_cols(const float* in, float* out, int64_t nimg, int H, in
     return launch_cols((const float2*)in, (float2*)out, nimg, H, W, inverse, norm, centered, (hipStream_t)stream);
 }
 
+extern "C" int64_t mrx_llg_hinv_work_floats(int B, int C, int H, int W) {
+    if (B < 0 || C < 1 || H < 1 || W < 1) return -1;
+    int g = pick_rows(W);
+    const bool ct = (W == 372 || W == 320 || W == 256);
+    if (!ct && g > C) g = C;
+    return (int64_t)mrx_cdiv(C, g) * B * H * W * 2;
+}
+
 extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
-                            const int64_t* mstride, float* out4, int B, int C, int H, int W, float inv_sigma2, int norm,
-                            int centered, void* stream) {
+                            const int64_t* mstride, float* out4, float* work, int B, int C, int H, int W, float inv_sigma2,
+                            int norm, int centered, void* stream) {
     MRX_REQUIRE(eta && yt && S && mask && mstride && out4, MRX_EINVAL, "mrx_llg_hinv: null pointer");
     MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_llg_hinv: bad dims");
     MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_llg_hinv: bad normalization %d", norm);
@@ -841,10 +991,12 @@ extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, c
     dim3 grid(H, B);
     hipStream_t st = (hipStream_t)stream;
     const float2 *pe = (const float2*)eta, *py = (const float2*)yt, *ps = (const float2*)S;
-    if (W == 372) return launch_hinv_p<P372, NSEQ_ROW_372>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
-    if (W == 320) return launch_hinv_p<P320, NSEQ_ROW_320>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
-    if (W == 256) return launch_hinv_p<P256, NSEQ_ROW_256>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
-    return launch_hinv_p<PlanRT, 1>(pe, py, ps, m, out4, grid, lds, a, scale_f, st);
+    // split the coil sum over workgroups only while the grid is small (rows x batch below ~4 workgroups per CU)
+    float* part = (work && (long long)H * B < 1024) ? work : nullptr;
+    if (W == 372) return launch_hinv_p<P372, NSEQ_ROW_372>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
+    if (W == 320) return launch_hinv_p<P320, NSEQ_ROW_320>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
+    if (W == 256) return launch_hinv_p<P256, NSEQ_ROW_256>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
+    return launch_hinv_p<PlanRT, 1>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
 }
 
 // Data-consistency residual in image space with shared maps:  out[b] = sum_c conj(S[b/sdiv,c]) * ifft2( mask * (fft2(x[b] * S[b/sdiv,c]) - y[b,c]) )

@@ -98,8 +98,8 @@ def llg_prepare(y, centered, normalization, spatial_dims=None):
     return out
 
 
-def llg_hinv(eta, yt, sens, mask, sigma, centered, normalization, out=None):
-    """log_likelihood_gradient for a row-invariant mask, one launch (yt from llg_prepare)."""
+def llg_hinv(eta, yt, sens, mask, sigma, centered, normalization, out=None, work=None):
+    """log_likelihood_gradient for a row-invariant mask (yt from llg_prepare): row transforms only."""
     yt, sens, eta = _lib.f32c(yt), _lib.f32c(sens), _lib.f32c(eta)
     B, C, H, W = _bchw(yt)
     if sens.shape != yt.shape or tuple(eta.shape) != (B, H, W, 2):
@@ -107,8 +107,10 @@ def llg_hinv(eta, yt, sens, mask, sigma, centered, normalization, out=None):
     m, kind, ms = _lib.mask_args(mask, B, C, H, W)
     if out is None:
         out = torch.empty(B, 4, H, W, dtype=torch.float32, device=yt.device)
+    if work is None:
+        work = torch.empty(int(_lib.lib().mrx_llg_hinv_work_floats(B, C, H, W)), dtype=torch.float32, device=yt.device)
     _lib.check(_lib.lib().mrx_llg_hinv(_lib.ptr(eta), _lib.ptr(yt), _lib.ptr(sens), _lib.ptr(m), kind, ms, _lib.ptr(out),
-                                       B, C, H, W, float(1.0 / (float(sigma) ** 2.0)), _norm(normalization),
+                                       _lib.ptr(work), B, C, H, W, float(1.0 / (float(sigma) ** 2.0)), _norm(normalization),
                                        int(bool(centered)), _lib.stream_ptr()), "mrx_llg_hinv")
     return out
 

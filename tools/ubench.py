@@ -55,6 +55,9 @@ def main():
         work, out = torch.empty_like(y), torch.empty(B, 4, H, W, device=dev)
         t = timeit(lambda: ops.llg(eta, y, S, mask, 1.0, False, "backward", out=out, work=work))
         print(f"llg: {t:.1f} us  {(25 + 16 * C) * H * W * B / t / 1e3:.1f} GB/s (algorithmic)")
+        yt = ops.llg_prepare(y, False, "backward")
+        t = timeit(lambda: ops.llg_hinv(eta, yt, S, mask, 1.0, False, "backward", out=out))
+        print(f"llg_hinv: {t:.1f} us  {(25 + 16 * C) * H * W * B / t / 1e3:.1f} GB/s (algorithmic)")
         t = timeit(lambda: ops.sens_expand(eta, S, False, "backward"))
         print(f"sens_expand: {t:.1f} us")
 
