@@ -158,6 +158,17 @@ int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, const float
                                 const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H,
                                 int W, int k, int dil, void* stream);
 
+/* Winograd F(2x2,3x3) variant of the tuned fused layer for the dilated middle layer of the RIM (k = 3, dil = 2, F = 64;
+ * rim_block.py:70-121 with conv_kernels[1] = 3, conv_dilations[1] = 2): the dilation-2 convolution is four plain 3x3
+ * convolutions on the (row, column) parity sub-lattices, each evaluated with 16 instead of 36 multiplies per 2x2 outputs.
+ * Same contract as mrx_rim_layer_indrnn_packed; results differ from the direct form by fp32 round-off only (the transforms
+ * use +-1 and 1/2 coefficients).  The packed buffer holds G g G^T per (cout, cin) and the 1x1 weights. */
+int64_t mrx_rim_layer_wino_pack_floats(int Cin, int F);
+int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, int F, void* stream);
+int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, const float* b_conv, const float* b_ih,
+                              const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H, int W,
+                              void* stream);
+
 /* A11 stand-alone IndRNN cell (rnn_cells.py:295-312,384-391): h_new = ReLU(conv_zero_pad(x; w_ih, b_ih) + hh*h_prev). */
 int mrx_indrnn_cell(const float* x, const float* w_ih, const float* b_ih, const float* hh, const float* h_prev,
                     float* h_new, int B, int Cin, int F, int H, int W, int k, int dil, void* stream);

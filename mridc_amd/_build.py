@@ -17,6 +17,7 @@ SOURCES = [
     ("elementwise.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
     ("rim_layer.hip", []),
+    ("rim_layer_wino.hip", []),
     ("unet.hip", []),
     ("qmri.hip", ["-ffp-contract=off"]),
 ]

@@ -49,6 +49,9 @@ _SIGNATURES = {
     "mrx_rim_layer_pack": ([_p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_layer_supported": ([_i, _i, _i, _i], _i),
     "mrx_rim_layer_indrnn_packed": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_rim_layer_wino_pack_floats": ([_i, _i], _i64),
+    "mrx_rim_layer_wino_pack": ([_p, _p, _p, _i, _i, _p], _i),
+    "mrx_rim_layer_indrnn_wino": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_indrnn_cell": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_rim_final": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_gru_gates": ([_p, _p, _p, _p, _i, _i, _i64, _p], _i),

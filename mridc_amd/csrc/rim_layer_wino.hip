@@ -1,0 +1,498 @@
+// rim_layer_wino.hip -- Winograd F(2x2, 3x3) version of the fused RIM layer for the dilated 3x3 convolution
+// (conv_layers.py:121-123 with k = 3, dilation = 2, 64 -> 64 channels) + IndRNNCell(1x1) (rnn_cells.py:384-391).
+//
+// A dilation-2 3x3 convolution is four independent plain 3x3 convolutions on the four (row parity, column parity)
+// sub-lattices of the image.  On each sub-lattice F(2x2,3x3) produces a 2x2 output tile from a 4x4 input patch with 16
+// multiplies instead of 36: per input-channel chunk the kernel forms V = B^T d B for every (tile, channel) on the vector ALUs,
+// runs 16 independent [64 couts x channels] x [channels x tiles] products on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32, exact fp32 fma chains) -- 2.25x fewer MFMA cycles than the direct form -- and finishes with
+// Y = A^T M A per lane in registers (all 16 transform positions of one (cout, tile) element live in the same lane).
+// Replicate padding is resolved when the raw halo'd tile is gathered (clamped coordinates), exactly as in the direct kernel;
+// the sub-lattices only index that tile.  The 1x1 `ih` GEMM and the wide epilogue are the direct kernel's, fed from LDS.
+//
+// Workgroup: 512 threads, 8x32 output pixels = 64 Winograd tiles (16 per parity).  Wave w: couts 32*(w&1)..+31, parity w>>1.
+// Pipeline (one barrier per 8-channel chunk, everything double-buffered in 156.5 KB of LDS, one workgroup per CU):
+//   iteration q:  LDS-DMA  packed U(q+1) and raw X(q+2) global -> LDS (global_load_lds, no staging registers),
+//                 transform X(q+1) -> V(q+1),   matrix cores on U(q), V(q).
+// The two waves that share a SIMD (w, w+4) run {transform, MFMA} in opposite orders, so the matrix pipe of every SIMD has
+// MFMAs to issue while the other wave is on the vector ALUs / LDS.
+// LDS images: U and V are [xi][k pair j][column ^ 16*(j&1)][2 k] so one ds_read_b64 gives a lane its operand for two
+// MFMA k-steps, conflict-free (64 banks per 32 lanes); the raw tile rows have stride 38 so the 4x4 patch gathers are too.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "mrx_common.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WN_NT 512
+#define WN_F 64
+#define WN_CK 8
+#define WN_PH 12
+// Raw tile geometry.  X4 (W % 4 == 0, 16-byte aligned x): rows of 10 aligned float4 starting 4 columns left of the tile, fetched
+// with 15 dwordx4 DMA instructions per chunk; the column part of the replicate border is applied when the patch is gathered.
+// Otherwise: rows of 36 (+2 pad, conflict-free gathers) fetched element-wise with 57 dword DMA instructions, clamped at the source.
+#define WN_XS(X4) ((X4) ? 40 : 38)
+#define WN_OX(X4) ((X4) ? 4 : 2)
+#define WN_PLANE(X4) (WN_PH * WN_XS(X4))
+#define WN_XBUF(X4) (WN_CK * WN_PLANE(X4))  // 3840 / 3648 floats
+#define WN_UCHUNK (16 * 4 * WN_F * 2)  // 8192 floats = 32 DMA wave-instructions of 1 KB
+#define WN_VBUF WN_UCHUNK
+#define WN_LDS_FLOATS(X4) (2 * WN_XBUF(X4) + 2 * WN_UCHUNK + 2 * WN_VBUF)
+#define WN_PF 3
+
+struct WinoArgs {
+    const float* x;       // [B,Cin,H,W]
+    const float* packed;  // per chunk the LDS image of G g G^T, then the ih block [32][2][F] (rim_layer.hip order)
+    const float* b_conv;
+    const float* b_ih;
+    const float* hh;
+    const float* hprev;
+    float* hnew;
+    int B, Cin, H, W, tiles_x, ntiles;
+    unsigned long long* trace;  // debug only (env MRX_TRACE): cycle stamps per workgroup
+};
+
+// U = G g G^T per (cout, cin); per chunk q the image [xi = 4i+j'][k pair j][p = co ^ 16*(j&1)][kb], cin = 8q + 2j + kb
+// (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]])
+__global__ void k_wino_pack(const float* __restrict__ w, const float* __restrict__ w_ih, float* __restrict__ out, int Cin, int nchunks) {
+    const int conv_elems = nchunks * WN_UCHUNK;
+    const int total = conv_elems + WN_F * WN_F;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (idx < conv_elems) {
+            const int kb = idx & 1;
+            int r = idx >> 1;
+            const int p = r % WN_F;
+            r /= WN_F;
+            const int j = r & 3;
+            r >>= 2;
+            const int xi = r % 16;
+            const int q = r / 16;
+            const int co = p ^ (16 * (j & 1));
+            const int ci = q * WN_CK + 2 * j + kb;
+            if (ci < Cin) {
+                const float* g = w + ((long long)co * Cin + ci) * 9;
+                const int i = xi >> 2, jj = xi & 3;
+                float acc = 0.f;
+                for (int k = 0; k < 3; ++k)
+                    for (int l = 0; l < 3; ++l) acc += G[i][k] * g[k * 3 + l] * G[jj][l];
+                v = acc;
+            }
+        } else {
+            const int jdx = idx - conv_elems;
+            const int o = jdx % WN_F;
+            int r = jdx / WN_F;
+            const int half = r & 1;
+            r >>= 1;
+            const int ct = r >> 4, reg = r & 15;
+            const int c = 32 * ct + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            v = w_ih[o * WN_F + c];
+        }
+        out[idx] = v;
+    }
+}
+
+extern "C" int64_t mrx_rim_layer_wino_pack_floats(int Cin, int F) {
+    if (F != WN_F || Cin < 1) return -1;
+    return (int64_t)((Cin + WN_CK - 1) / WN_CK) * WN_UCHUNK + WN_F * WN_F;
+}
+extern "C" int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, int F, void* stream) {
+    MRX_REQUIRE(w_conv && w_ih && packed, MRX_EINVAL, "mrx_rim_layer_wino_pack: null pointer");
+    MRX_REQUIRE(F == WN_F && Cin >= 1, MRX_EUNSUP, "mrx_rim_layer_wino_pack: F=%d Cin=%d", F, Cin);
+    const int nchunks = (Cin + WN_CK - 1) / WN_CK;
+    const int total = nchunks * WN_UCHUNK + WN_F * WN_F;
+    hipLaunchKernelGGL(k_wino_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, packed, Cin, nchunks);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+#define WN_GLOBAL(p) ((const __attribute__((address_space(1))) void*)(p))
+#define WN_SHARED(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int ABL, bool X4>
+__global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Xs = smem_f;                          // [2][CK][12][38] raw halo'd tiles
+    constexpr int XS = WN_XS(X4), OX = WN_OX(X4), PLANE = WN_PLANE(X4), XBUF = WN_XBUF(X4);
+    float* Us = Xs + 2 * XBUF;                   // [2][16][4][64][2]
+    float* Vs = Us + 2 * WN_UCHUNK;              // [2][16][4][64][2]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;  // 16x16x4 operand lane split: column / k index
+    const int cot = wave & 1, par = wave >> 1;
+    const int py = par >> 1, px = par & 1;
+
+    int tile = blockIdx.x;
+    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
+    const int ty0 = tile / a.tiles_x;
+    const int h0 = ty0 * 8, w0 = (tile - ty0 * a.tiles_x) * 32;
+    const int b = blockIdx.y;
+    const long long plane = (long long)a.H * a.W;
+    const float* xb = a.x + (long long)b * a.Cin * plane;
+    const int nchunks = (a.Cin + WN_CK - 1) / WN_CK;
+
+#define WN_STAMP(i) \
+    if (a.trace && tid == 0) a.trace[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter();
+    WN_STAMP(0)
+
+    // ---- LDS-DMA work list of this wave: 4 copies of 1 KB of the packed U image (n = wave + 8 m) and its share of the raw tile
+    // (replicate border = clamped coordinates, conv_layers.py:72-76).  xsrc[m] = (channel << 28) | element offset in the plane.
+    constexpr int NXI = X4 ? XBUF / 256 : XBUF / 64;  // raw-tile DMA instructions per chunk (15 / 57)
+    constexpr int NXM = (NXI + 7) / 8;                // ... per wave (2 / 8)
+    unsigned xsrc[NXM];
+#pragma unroll
+    for (int m = 0; m < NXM; ++m) {
+        const int e = (wave + 8 * m) * 64 + lane;  // float4 (X4) or element index in the [CK][12][XS] tile
+        int ci, gy, gx;
+        if (X4) {
+            ci = e / (PLANE / 4);
+            const int rem = e - ci * (PLANE / 4);
+            const int ry = rem / (XS / 4), c4 = rem - ry * (XS / 4);
+            gy = h0 + ry - 2;
+            gx = w0 - OX + 4 * c4;  // whole groups outside the image fetch the nearest inside one; the gather never reads them
+            gx = gx < 0 ? 0 : (gx > a.W - 4 ? a.W - 4 : gx);
+        } else {
+            ci = e / PLANE;
+            const int slot = e - ci * PLANE;
+            const int ry = slot / XS, rx = slot - ry * XS;
+            gy = h0 + ry - 2;
+            gx = w0 + rx - OX;
+            gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+        }
+        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+        xsrc[m] = ((unsigned)(ci & 7) << 28) | (unsigned)(gy * a.W + gx);
+    }
+    auto dma_u = [&](int q, int m) {  // m in 0..3
+        const int n = wave + 8 * m;
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL(a.packed + (long long)q * WN_UCHUNK + n * 256 + lane * 4),
+                                         WN_SHARED(Us + (q & 1) * WN_UCHUNK + n * 256), 16, 0, 0);
+    };
+    auto dma_x = [&](int q, int m) {  // channels past Cin re-read the last one (their packed weights are zero)
+        const int n = wave + 8 * m;
+        if (n < NXI) {
+            int gc = q * WN_CK + (int)(xsrc[m] >> 28);
+            gc = gc < a.Cin ? gc : a.Cin - 1;
+            const float* src = xb + (long long)gc * plane + (xsrc[m] & 0x0fffffffu);
+            if (X4) __builtin_amdgcn_global_load_lds(WN_GLOBAL(src), WN_SHARED(Xs + (q & 1) * XBUF + n * 256), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds(WN_GLOBAL(src), WN_SHARED(Xs + (q & 1) * XBUF + n * 64), 4, 0, 0);
+        }
+    };
+
+    // ---- input transform: lane -> tile (tbx = lane&7, px = lane>>3 &1, py = lane>>4 &1, tby = lane>>5), wave -> channel.
+    // V = B^T d B with d[i][j] = raw[4 tby + py + 2i][4 tbx + px + 2j]; written to column pos(tile) of row (xi, j = ci>>1).
+    int t_col[4];  // LDS offsets of the four patch columns in the first patch row (X4: column replicate border applied here)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = 4 * (lane & 7) + ((lane >> 3) & 1) + 2 * j + OX - 2;  // tile column of image column w0 - OX + c
+        if (X4) {
+            const int lo = OX - w0, hi = a.W - 1 - w0 + OX;
+            c = c < lo ? lo : (c > hi ? hi : c);
+        }
+        t_col[j] = wave * PLANE + (4 * (lane >> 5) + ((lane >> 4) & 1)) * XS + c;
+    }
+    const int t_pos = (lane & 7) + 8 * (((lane >> 3) & 1) ^ (lane >> 5)) + 16 * ((lane >> 4) & 1) + 32 * (lane >> 5);
+    const int t_dst = ((wave >> 1) * WN_F + (t_pos ^ (16 * ((wave >> 1) & 1)))) * 2 + (wave & 1);
+    auto transform = [&](int q) {
+        const float* src = Xs + (q & 1) * XBUF;
+        float d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = src[t_col[j] + (2 * i) * XS];
+        float e[4][4];  // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[0][j] = d[0][j] - d[2][j];
+            e[1][j] = d[1][j] + d[2][j];
+            e[2][j] = d[2][j] - d[1][j];
+            e[3][j] = d[1][j] - d[3][j];
+        }
+        float* dst = Vs + (q & 1) * WN_VBUF + t_dst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // (B^T d) B : columns the same way
+            dst[(4 * i + 0) * 512] = e[i][0] - e[i][2];
+            dst[(4 * i + 1) * 512] = e[i][1] + e[i][2];
+            dst[(4 * i + 2) * 512] = e[i][2] - e[i][1];
+            dst[(4 * i + 3) * 512] = e[i][1] - e[i][3];
+        }
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[xi][h][r] = 0.f;
+
+    // ---- matrix-core phase on chunk q, with the DMA for the following chunks issued one instruction per step ------------
+    const int m_sw = 16 * (lg & 1);
+    const int m_a0 = (lg * WN_F + ((32 * cot + l15) ^ m_sw)) * 2;
+    const int m_a1 = (lg * WN_F + ((32 * cot + 16 + l15) ^ m_sw)) * 2;
+    const int m_b = (lg * WN_F + (((l15 & 7) + 8 * (px ^ (l15 >> 3)) + 16 * py + 32 * (l15 >> 3)) ^ m_sw)) * 2;
+    auto mma = [&](int q) {
+        const float* ua0 = Us + (q & 1) * WN_UCHUNK + m_a0;
+        const float* ua1 = Us + (q & 1) * WN_UCHUNK + m_a1;
+        const float* vb = Vs + (q & 1) * WN_VBUF + m_b;
+        const bool more_u = q + 1 < nchunks, more_x = q + 2 < nchunks;
+        f32x2 ra0[WN_PF + 1], ra1[WN_PF + 1], rb[WN_PF + 1];
+        if (ABL & 2)
+            for (int i = 0; i <= WN_PF; ++i) ra0[i] = ra1[i] = rb[i] = (f32x2){(float)tid, (float)i};
+#pragma unroll
+        for (int s = 0; s < 16 + WN_PF; ++s) {
+            if (s < 16 && !(ABL & 2)) {
+                rb[s % (WN_PF + 1)] = *reinterpret_cast<const f32x2*>(vb + s * 512);
+                ra0[s % (WN_PF + 1)] = *reinterpret_cast<const f32x2*>(ua0 + s * 512);
+                ra1[s % (WN_PF + 1)] = *reinterpret_cast<const f32x2*>(ua1 + s * 512);
+            }
+            if (!(ABL & 4)) {
+                if (s < 4) {
+                    if (more_u) dma_u(q + 1, s);
+                } else if (s < 4 + NXM) {
+                    if (more_x) dma_x(q + 2, s - 4);
+                }
+            }
+            if (s >= WN_PF && !(ABL & 8)) {
+                const int xi = s - WN_PF, c = xi % (WN_PF + 1);
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[c][0], rb[c][0], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[c][0], rb[c][0], acc[xi][1], 0, 0, 0);
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[c][1], rb[c][1], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[c][1], rb[c][1], acc[xi][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: U(0), X(0), X(1) -> LDS, V(0) ---------------------------------------------------------------------
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dma_u(0, m);
+#pragma unroll
+    for (int m = 0; m < NXM; ++m) dma_x(0, m);
+    if (nchunks > 1) {
+#pragma unroll
+        for (int m = 0; m < NXM; ++m) dma_x(1, m);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    transform(0);
+    const bool t_first = wave < 4;  // waves w and w+4 share a SIMD: opposite phase orders keep its matrix pipe fed
+    for (int q = 0; q < nchunks; ++q) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for U(q), X(q+1) has landed
+        __syncthreads();                                   // ... everyone's, and V(q) is written; buffers of q-1 are free
+        const bool tr = q + 1 < nchunks && !(ABL & 1);
+        if (tr && t_first) transform(q + 1);
+        mma(q);
+        if (tr && !t_first) transform(q + 1);
+    }
+    __syncthreads();  // all waves done with U / V: LDS becomes Y[64][256] (ReLU(conv + b)) followed by the ih weights
+    WN_STAMP(1)
+
+    // ---- output transform Y = A^T M A per lane, bias, ReLU -> Ys[cout][8 rows x 32 cols] ------------------------------
+    float* Ys = smem_f;
+    float* Wi = smem_f + WN_F * 256;
+    {
+        const int tby = l15 >> 3, tbx = l15 & 7;
+        const int prow = 4 * tby + py, pcol = 4 * tbx + px;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s0[4], s1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0[j] = acc[0 + j][h][r] + acc[4 + j][h][r] + acc[8 + j][h][r];
+                    s1[j] = acc[4 + j][h][r] - acc[8 + j][h][r] - acc[12 + j][h][r];
+                }
+                const int co = 32 * cot + 16 * h + 4 * lg + r;
+                const float bc = a.b_conv ? a.b_conv[co] : 0.f;
+                float y00 = s0[0] + s0[1] + s0[2] + bc, y01 = s0[1] - s0[2] - s0[3] + bc;
+                float y10 = s1[0] + s1[1] + s1[2] + bc, y11 = s1[1] - s1[2] - s1[3] + bc;
+                y00 = y00 > 0.f ? y00 : 0.f;
+                y01 = y01 > 0.f ? y01 : 0.f;
+                y10 = y10 > 0.f ? y10 : 0.f;
+                y11 = y11 > 0.f ? y11 : 0.f;
+                float* yo = Ys + co * 256 + prow * 32 + pcol;
+                yo[0] = y00;
+                yo[2] = y01;
+                yo[64] = y10;
+                yo[66] = y11;
+            }
+    }
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.packed + (long long)nchunks * WN_UCHUNK);
+        float4* dst = reinterpret_cast<float4*>(Wi);
+        for (int i = tid; i < WN_F * WN_F / 4; i += WN_NT) dst[i] = src[i];
+    }
+    __syncthreads();
+    WN_STAMP(2)
+
+    // ---- 1x1 ih GEMM (32x32x2 MFMA, wave = image row) + wide epilogue: same as k_rim_layer, B operand read from Ys ------
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int oy = h0 + wave;
+    const bool wide = (a.W & 3) == 0;
+    const int wch = lane >> 3, wpx = (lane & 7) * 4;
+    const long long wbase = (long long)b * WN_F * plane + (long long)oy * a.W + w0 + wpx;
+    const bool winside = oy < a.H && (w0 + wpx) < a.W;
+    float4 hp4[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hp4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wide && a.hprev && winside) hp4[i] = *reinterpret_cast<const float4*>(a.hprev + wbase + (long long)(i * 8 + wch) * plane);
+    }
+    f32x16 acc2[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[ct][r] = 0.f;
+    {
+        const float* wi = Wi + lhi * WN_F + l31;
+        const float* yb = Ys + wave * 32 + l31;
+        float qa0[WN_PF + 1], qa1[WN_PF + 1], qb[WN_PF + 1];
+#pragma unroll
+        for (int s = 0; s < 32 + WN_PF; ++s) {
+            if (s < 32) {
+                const int ct = s >> 4, r = s & 15;
+                const int c_lo = 32 * ct + (r & 3) + 8 * (r >> 2);  // k enumeration of the packed ih block (C/D order)
+                qb[s % (WN_PF + 1)] = yb[(c_lo + 4 * lhi) * 256];
+                qa0[s % (WN_PF + 1)] = wi[(s * 2) * WN_F];
+                qa1[s % (WN_PF + 1)] = wi[(s * 2) * WN_F + 32];
+            }
+            if (s >= WN_PF) {
+                const int c = (s - WN_PF) % (WN_PF + 1);
+                acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa0[c], qb[c], acc2[0], 0, 0, 0);
+                acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[c], qb[c], acc2[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();  // Ys / Wi consumed by every wave: LDS becomes 8 wave-private [64][32] transpose tiles
+    WN_STAMP(3)
+    const int ox = w0 + l31;
+    if (wide) {
+        float* T = smem_f + wave * (WN_F * 32);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                T[co * 32 + l31] = acc2[ct][r];
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = i * 8 + wch;
+            float4 v = *reinterpret_cast<const float4*>(T + ch * 32 + wpx);
+            const float bi = a.b_ih ? a.b_ih[ch] : 0.f;
+            const float hw = a.hh[ch];
+            v.x = v.x + bi + hw * hp4[i].x;
+            v.y = v.y + bi + hw * hp4[i].y;
+            v.z = v.z + bi + hw * hp4[i].z;
+            v.w = v.w + bi + hw * hp4[i].w;
+            v.x = v.x > 0.f ? v.x : 0.f;
+            v.y = v.y > 0.f ? v.y : 0.f;
+            v.z = v.z > 0.f ? v.z : 0.f;
+            v.w = v.w > 0.f ? v.w : 0.f;
+            if (winside) *reinterpret_cast<float4*>(a.hnew + wbase + (long long)ch * plane) = v;
+        }
+    } else if (oy < a.H && ox < a.W) {
+        const long long obase = (long long)b * WN_F * plane + (long long)oy * a.W + ox;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc2[ct][r];
+                if (a.b_ih) v += a.b_ih[co];
+                if (a.hprev) v += a.hh[co] * a.hprev[obase + (long long)co * plane];
+                a.hnew[obase + (long long)co * plane] = v > 0.f ? v : 0.f;
+            }
+    }
+    WN_STAMP(4)
+    if (a.trace && tid == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.trace[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] =
+            ((unsigned long long)(xcc & 0xf) << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 12) & 1) << 4) | ((hwid >> 8) & 15);
+    }
+}
+
+extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, const float* b_conv, const float* b_ih,
+                                         const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H, int W,
+                                         void* stream) {
+    MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer_indrnn_wino: null pointer");
+    MRX_REQUIRE(B >= 0 && Cin >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer_indrnn_wino: bad dims");
+    MRX_REQUIRE(F == WN_F, MRX_EUNSUP, "mrx_rim_layer_indrnn_wino: hidden size %d (only %d)", F, WN_F);
+    MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "mrx_rim_layer_indrnn_wino: batch %d too large", B);
+    if (B == 0) return MRX_OK;
+    WinoArgs a;
+    a.x = x;
+    a.packed = packed;
+    a.b_conv = b_conv;
+    a.b_ih = b_ih;
+    a.hh = hh;
+    a.hprev = h_prev;
+    a.hnew = h_new;
+    a.B = B;
+    a.Cin = Cin;
+    a.H = H;
+    a.W = W;
+    a.tiles_x = mrx_cdiv(W, 32);
+    a.ntiles = a.tiles_x * mrx_cdiv(H, 8);
+    MRX_REQUIRE((long long)H * W < (1ll << 28), MRX_EUNSUP, "mrx_rim_layer_indrnn_wino: plane %d x %d too large", H, W);
+    static_assert(WN_LDS_FLOATS(false) >= WN_F * 256 + WN_F * WN_F, "Y + ih weights must fit the staging region");
+    static_assert(WN_LDS_FLOATS(true) * sizeof(float) <= 160 * 1024, "one workgroup owns the CU's LDS");
+    static_assert((2 * WN_XBUF(true)) % 4 == 0 && (2 * WN_XBUF(false)) % 4 == 0, "U image 16-byte aligned");
+    static_assert(WN_XBUF(true) % 256 == 0 && WN_XBUF(false) % 64 == 0, "raw tile = a whole number of DMA instructions");
+    const bool x4 = (W & 3) == 0 && W >= 4 && ((uintptr_t)x & 15) == 0;
+    const size_t lds = sizeof(float) * (x4 ? WN_LDS_FLOATS(true) : WN_LDS_FLOATS(false));
+    static const int abl = getenv("MRX_ABLATE") ? atoi(getenv("MRX_ABLATE")) : 0;  // debug: skip 1 transform, 2 operand reads, 4 DMA, 8 MFMA
+    auto kern = x4 ? (abl == 1 ? k_rim_layer_wino<1, true> : abl == 2 ? k_rim_layer_wino<2, true> : abl == 4 ? k_rim_layer_wino<4, true>
+                      : abl == 8 ? k_rim_layer_wino<8, true> : k_rim_layer_wino<0, true>)
+                   : k_rim_layer_wino<0, false>;
+    static bool attr_done[2] = {false, false};  // once per variant: keeps launches legal under hipGraph capture
+    if (!attr_done[x4]) {
+        MRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[x4] = true;
+    }
+    static unsigned long long* d_trace = nullptr;
+    a.trace = nullptr;
+    if (getenv("MRX_TRACE")) {
+        if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 8 * 65536);
+        (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 8 * 65536, (hipStream_t)stream);
+        a.trace = d_trace;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.ntiles, a.B), dim3(WN_NT), lds, (hipStream_t)stream, a);
+    MRX_LAUNCH_CHECK();
+    if (a.trace && getenv("MRX_TRACE_DUMP")) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        const int nb = a.ntiles * a.B;
+        std::vector<unsigned long long> h((size_t)nb * 8);
+        (void)hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * 8 * nb, hipMemcpyDeviceToHost);
+        double ph[4] = {0, 0, 0, 0};
+        std::map<unsigned long long, std::pair<unsigned long long, unsigned long long>> cu;  // per-CU busy span (one XCC clock each)
+        for (int i = 0; i < nb; ++i) {
+            const unsigned long long* r = &h[(size_t)i * 8];
+            for (int k = 0; k < 4; ++k) ph[k] += (double)(r[k + 1] - r[k]);
+            auto it = cu.find(r[6]);
+            if (it == cu.end()) cu[r[6]] = {r[0], r[4]};
+            else {
+                if (r[0] < it->second.first) it->second.first = r[0];
+                if (r[4] > it->second.second) it->second.second = r[4];
+            }
+        }
+        double spn = 0;
+        for (auto& kv : cu) spn += (double)(kv.second.second - kv.second.first);
+        fprintf(stderr, "[mrx-trace] k_rim_layer_wino %d blocks on %zu CUs: mean CU span %.0f cyc; mean per block: main %.0f Y %.0f 1x1 %.0f "
+                        "epilogue %.0f (sum %.0f)\n", nb, cu.size(), spn / cu.size(), ph[0] / nb, ph[1] / nb, ph[2] / nb, ph[3] / nb,
+                (ph[0] + ph[1] + ph[2] + ph[3]) / nb);
+    }
+    return MRX_OK;
+}

@@ -228,6 +228,40 @@ def rim_layer_indrnn_packed(x, packed, F, k, dilation, b_conv, b_ih, hh, h_prev,
     return out
 
 
+def rim_layer_wino_supported(Cin, F, k, dilation):
+    """Winograd F(2x2,3x3) fused layer: dilation-2 3x3 convolution into 64 features."""
+    return int(k) == 3 and int(dilation) == 2 and int(F) == 64 and int(Cin) >= 1
+
+
+def rim_layer_wino_pack(w_conv, w_ih):
+    """Transform conv [64,Cin,3,3] weights to G g G^T and pack them with the ih [64,64,1,1] weights for mrx_rim_layer_indrnn_wino."""
+    w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
+    F, Cin, k, _ = [int(v) for v in w_conv.shape]
+    n = int(_lib.lib().mrx_rim_layer_wino_pack_floats(Cin, F)) if k == 3 else -1
+    if n < 0:
+        raise ValueError("rim_layer_wino_pack: unsupported shape")
+    packed = torch.empty(n, dtype=torch.float32, device=w_conv.device)
+    _lib.check(_lib.lib().mrx_rim_layer_wino_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(packed), Cin, F, _lib.stream_ptr()),
+               "mrx_rim_layer_wino_pack")
+    return packed
+
+
+def rim_layer_indrnn_wino(x, packed, F, b_conv, b_ih, hh, h_prev, out=None):
+    """Winograd fused ConvNonlinear(3x3, dilation 2, ReLU, replicate pad) + IndRNNCell(1x1) on pre-transformed weights."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    if out is None:
+        out = torch.empty(B, F, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_rim_layer_indrnn_wino(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc),
+                                                    _lib.ptr(hp), _lib.ptr(out), B, Cin, int(F), H, W, _lib.stream_ptr()),
+               "mrx_rim_layer_indrnn_wino")
+    return out
+
+
 def rim_final(h, weight, bias, k, dilation, eta):
     """eta + permute(conv_reppad(h)) with a 2-channel conv -> [B,H,W,2]."""
     h, weight, eta = _lib.f32c(h), _lib.f32c(weight.detach()), _lib.f32c(eta)

@@ -108,6 +108,36 @@ def test_tuned_fused_rim_layer_packed(shape, dev):
     assert_close(got0, ref0, 1e-5, "tuned fused layer, no biases, h_prev = None")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 13, 18), (1, 64, 24, 70), (1, 7, 17, 19), (1, 64, 8, 32), (3, 20, 1, 1), (1, 64, 40, 128),
+                                   (1, 9, 2, 3), (1, 64, 33, 61), (1, 64, 24, 72), (2, 16, 19, 36), (1, 8, 9, 4), (1, 12, 5, 100),
+                                   (1, 64, 64, 372)])
+def test_winograd_fused_rim_layer(shape, dev):
+    """Winograd F(2x2,3x3) on the dilation-2 parity sub-lattices against the oracle and the direct tuned kernel.
+    Tolerance: 1e-5 of the output norm against the oracle (same bar as the direct kernel), 5e-6 against the direct kernel."""
+    from mridc_amd import ops
+    B, Cin, H, W = shape
+    F_, k, dil = 64, 3, 2
+    assert ops.rim_layer_wino_supported(Cin, F_, k, dil)
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wc = torch.randn(F_, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bc = torch.randn(F_, generator=g) * 0.1
+    wi = torch.randn(F_, F_, 1, 1, generator=g) / F_ ** 0.5
+    bi = torch.randn(F_, generator=g) * 0.1
+    hh = torch.randn(1, F_, 1, 1, generator=g) * 0.5
+    hp = torch.randn(B, F_, H, W, generator=g)
+    ref = oracle.rim.indrnn_cell(oracle.rim.conv_nonlinear(x, wc, bc, k, dil, "relu"), hp, wi, bi, hh, 1, 1)
+    packed = ops.rim_layer_wino_pack(wc.to(dev), wi.to(dev))
+    got = ops.rim_layer_indrnn_wino(x.to(dev), packed, F_, bc.to(dev), bi.to(dev), hh.to(dev), hp.to(dev))
+    assert_close(got, ref, 1e-5, f"winograd fused layer {shape}")
+    direct = ops.rim_layer_indrnn_packed(x.to(dev), ops.rim_layer_pack(wc.to(dev), wi.to(dev)), F_, k, dil, bc.to(dev), bi.to(dev),
+                                         hh.to(dev), hp.to(dev))
+    assert_close(got, direct, 5e-6, "winograd vs direct kernel")
+    ref0 = oracle.rim.indrnn_cell(oracle.rim.conv_nonlinear(x, wc, None, k, dil, "relu"), torch.zeros_like(hp), wi, None, hh, 1, 1)
+    got0 = ops.rim_layer_indrnn_wino(x.to(dev), packed, F_, None, None, hh.to(dev), None)
+    assert_close(got0, ref0, 1e-5, "winograd fused layer, no biases, h_prev = None")
+
+
 def test_cells_vs_oracle(dev):
     from mridc_amd import ops
     g = torch.Generator().manual_seed(2)

@@ -37,6 +37,17 @@ def main():
         t = timeit(lambda: ops.rim_layer_indrnn_packed(x, packed, F, 3, 2, bc, bi, hh, hp, out=out))
         fl = 2.0 * (F * F * 9 + F * F) * H * W * B
         print(f"layer2 (3x3 d2 64->64 + ih): {t:.1f} us  {fl / t / 1e6:.1f} TFLOP/s  ablate={os.environ.get('MRX_ABLATE', '0')}")
+    if what in ("wino", "layer2", "all"):
+        x, hp = r(B, F, H, W), r(B, F, H, W)
+        wc, wi = r(F, F, 3, 3) / 24, r(F, F, 1, 1) / 8
+        packed = ops.rim_layer_wino_pack(wc, wi)
+        bc, bi, hh = r(F), r(F), r(1, F, 1, 1)
+        out = torch.empty_like(hp)
+        t = timeit(lambda: ops.rim_layer_indrnn_wino(x, packed, F, bc, bi, hh, hp, out=out))
+        fl = 2.0 * (F * F * 9 + F * F) * H * W * B
+        direct = ops.rim_layer_indrnn_packed(x, ops.rim_layer_pack(wc, wi), F, 3, 2, bc, bi, hh, hp)
+        err = ((out - direct).norm() / direct.norm()).item()
+        print(f"layer2 winograd: {t:.1f} us  {fl / t / 1e6:.1f} direct-equivalent TFLOP/s  rel-L2 vs direct {err:.2e}")
     if what in ("layer1", "all"):
         x, hp = r(B, 4, H, W), r(B, F, H, W)
         packed = ops.rim_layer_pack(r(F, 4, 5, 5) / 10, r(F, F, 1, 1) / 8)
