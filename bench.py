@@ -194,6 +194,7 @@ def main():
     F_hidden = cfg["recurrent_filters"][0]
     timer.wrap(ops, "rim_layer_indrnn", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
     timer.wrap(ops, "rim_layer_indrnn_packed", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
+    timer.wrap(ops, "rim_layer_indrnn_wino", lambda x, *a, **k: "conv_layer2_wino")
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
     timer.wrap(ops, "rim_final", lambda *a, **k: "final")
@@ -260,10 +261,21 @@ def main():
         # dominant kernel: fused layer 2 = conv3x3 dil2 (64->64) + 1x1 ih (64->64): 2*(64*64*9 + 64*64) flop / pixel
         flops2 = 2.0 * (F_hidden * F_hidden * 9 + F_hidden * F_hidden) * npix * B
         ms2, n2 = timer.mean_ms("conv_layer2")
-        roofline = dict(bound="mfma", kernel="k_rim_layer<3,2,8> (conv3x3 d2 64->64 + IndRNN 1x1 fused, fp32 MFMA 32x32x2)",
+        kname = "k_rim_layer<3,2,8> (conv3x3 d2 64->64 + IndRNN 1x1 fused, fp32 MFMA 32x32x2)"
+        executed = flops2
+        msw, nw = timer.mean_ms("conv_layer2_wino")
+        if msw:
+            # Winograd F(2x2,3x3): 16 instead of 36 multiplies per 2x2 outputs of the 3x3 part; `achieved` stays in algorithmic
+            # (direct-form) flops as section 8(d) defines them, `mfma_frac` is the share of fp32-MFMA peak actually issued
+            ms2, n2 = msw, nw
+            kname = ("k_rim_layer_wino (conv3x3 d2 64->64 as Winograd F(2x2,3x3) on the parity sub-lattices + IndRNN 1x1 fused, "
+                     "fp32 MFMA 16x16x4 / 32x32x2)")
+            executed = 2.0 * (F_hidden * F_hidden * 4 + F_hidden * F_hidden) * npix * B
+        roofline = dict(bound="mfma", kernel=kname,
                         achieved=(flops2 / (ms2 * 1e-3) / 1e12) if ms2 else None, peak=PEAK_FP32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=(flops2 / (ms2 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms2 else None,
-                        traffic=None, launches=n2, avg_ms=ms2, flops_per_launch=flops2)
+                        traffic=None, launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
+                        mfma_frac=(executed / (ms2 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms2 else None)
         bytes_llg = (25.0 + 16.0 * C) * npix * B     # compulsory bytes of one log_likelihood_gradient
         msl, nl = timer.mean_ms("llg")
         roofline_fft = dict(bound="hbm", kernel="mrx_llg_hinv (1-D column mask: H transforms cancel, ONE launch of row FFTs per step on "

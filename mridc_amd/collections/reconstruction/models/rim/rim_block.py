@@ -1,4 +1,5 @@
 """Drop-in for `mridc.collections.reconstruction.models.rim.rim_block.RIMBlock` (reference rim_block.py:15-269)."""
+import os
 from typing import Any, Optional, Tuple, Union
 
 import torch
@@ -14,7 +15,12 @@ class RIMBlock(torch.nn.Module):
     conv+IndRNN launch per recurrent layer (mrx_rim_layer_indrnn) and one for the final conv + eta update
     (mrx_rim_final).  GRU / MGU layers and IndRNN layers whose shape the fused kernel does not cover run through
     the unfused kernels (conv2d + cell).
+
+    `winograd` (default on; env MRIDC_AMD_WINOGRAD=0 turns it off): 3x3 dilation-2 layers into 64 features use the
+    Winograd F(2x2,3x3) form of the fused kernel (mrx_rim_layer_indrnn_wino).  It differs from the direct form by fp32
+    round-off only (~2e-7 of the output norm per layer).
     """
+    winograd = os.environ.get("MRIDC_AMD_WINOGRAD", "1") != "0"
 
     def __init__(self, recurrent_layer=None, conv_filters=None, conv_kernels=None, conv_dilations=None, conv_bias=None,
                  recurrent_filters=None, recurrent_kernels=None, recurrent_dilations=None, recurrent_bias=None,
@@ -75,16 +81,19 @@ class RIMBlock(torch.nn.Module):
     def _packed(self, idx, c, r):
         """Packed weights of layer `idx` for the tuned kernel, re-packed only when the parameters change."""
         w, wi = c.conv_layer.weight, r.ih.weight
-        key = (w.data_ptr(), w._version, wi.data_ptr(), wi._version, str(w.device))
+        wino = self.winograd and ops.rim_layer_wino_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation)
+        key = (w.data_ptr(), w._version, wi.data_ptr(), wi._version, str(w.device), wino)
         hit = self._pack_cache.get(idx)
         if hit is None or hit[0] != key:
-            hit = (key, ops.rim_layer_pack(w, wi))
+            hit = (key, ops.rim_layer_wino_pack(w, wi) if wino else ops.rim_layer_pack(w, wi))
             self._pack_cache[idx] = hit
         return hit[1]
 
     def _layer(self, idx, stack, x, h):
         if self._fusable(stack):
             c, r = stack.convs, stack.rnn
+            if self.winograd and ops.rim_layer_wino_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation):
+                return ops.rim_layer_indrnn_wino(x, self._packed(idx, c, r), r.hidden_size, c.conv_layer.bias, r.ih.bias, r.hh, h)
             if ops.rim_layer_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation):
                 return ops.rim_layer_indrnn_packed(x, self._packed(idx, c, r), r.hidden_size, c.kernel_size, c.dilation,
                                                    c.conv_layer.bias, r.ih.bias, r.hh, h)

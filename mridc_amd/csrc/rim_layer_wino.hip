@@ -201,6 +201,7 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     const int t_pos = (lane & 7) + 8 * (((lane >> 3) & 1) ^ (lane >> 5)) + 16 * ((lane >> 4) & 1) + 32 * (lane >> 5);
     const int t_dst = ((wave >> 1) * WN_F + (t_pos ^ (16 * ((wave >> 1) & 1)))) * 2 + (wave & 1);
     auto transform = [&](int q) {
+        if (ABL & 16) __builtin_amdgcn_s_setprio(3);
         const float* src = Xs + (q & 1) * XBUF;
         float d[4][4];
 #pragma unroll
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             dst[(4 * i + 2) * 512] = e[i][2] - e[i][1];
             dst[(4 * i + 3) * 512] = e[i][1] - e[i][3];
         }
+        if (ABL & 16) __builtin_amdgcn_s_setprio(0);
     };
 
     f32x4 acc[16][2];
@@ -238,21 +240,46 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     const int m_a0 = (lg * WN_F + ((32 * cot + l15) ^ m_sw)) * 2;
     const int m_a1 = (lg * WN_F + ((32 * cot + 16 + l15) ^ m_sw)) * 2;
     const int m_b = (lg * WN_F + (((l15 & 7) + 8 * (px ^ (l15 >> 3)) + 16 * py + 32 * (l15 >> 3)) ^ m_sw)) * 2;
+    // One chunk: 16 steps of {operand reads 3 steps ahead, 4 MFMAs}; the DMA for the following chunks and the input transform
+    // of the next one ride along as single instructions between the MFMAs of the SAME wave (a wave whose SIMD partner is
+    // MFMA-bound gets about one issue slot per MFMA, so a stand-alone transform phase would take 3x longer).
+    constexpr bool FUSE_T = !(ABL & 256);
     auto mma = [&](int q) {
         const float* ua0 = Us + (q & 1) * WN_UCHUNK + m_a0;
         const float* ua1 = Us + (q & 1) * WN_UCHUNK + m_a1;
         const float* vb = Vs + (q & 1) * WN_VBUF + m_b;
         const bool more_u = q + 1 < nchunks, more_x = q + 2 < nchunks;
-        f32x2 ra0[WN_PF + 1], ra1[WN_PF + 1], rb[WN_PF + 1];
+        const bool tr = FUSE_T && q + 1 < nchunks && !(ABL & 1);
+        const float* tsrc = Xs + ((q + 1) & 1) * XBUF;
+        float* tdst = Vs + ((q + 1) & 1) * WN_VBUF + t_dst;
+        float d[4][4], e[4][4];
+        constexpr int PF = (ABL & 32) ? 5 : WN_PF;
+        f32x2 ra0[PF + 1], ra1[PF + 1], rb[PF + 1];
         if (ABL & 2)
-            for (int i = 0; i <= WN_PF; ++i) ra0[i] = ra1[i] = rb[i] = (f32x2){(float)tid, (float)i};
+            for (int i = 0; i <= PF; ++i) ra0[i] = ra1[i] = rb[i] = (f32x2){(float)tid, (float)i};
 #pragma unroll
-        for (int s = 0; s < 16 + WN_PF; ++s) {
-            if (s < 16 && !(ABL & 2)) {
-                rb[s % (WN_PF + 1)] = *reinterpret_cast<const f32x2*>(vb + s * 512);
-                ra0[s % (WN_PF + 1)] = *reinterpret_cast<const f32x2*>(ua0 + s * 512);
-                ra1[s % (WN_PF + 1)] = *reinterpret_cast<const f32x2*>(ua1 + s * 512);
+        for (int s = 0; s < 16 + PF; ++s) {
+            const int xi = s - PF, c = (xi < 0 ? 0 : xi) % (PF + 1), w = s % (PF + 1);
+            // each MFMA is followed by its share of the step's other instructions, so they issue in the shadow of the MFMA
+            // ---- sub-step 0
+            if (s >= PF && !(ABL & 8)) acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[c][0], rb[c][0], acc[xi][0], 0, 0, 0);
+            if (tr && s < 2) {  // patch column 2s
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i][2 * s] = tsrc[t_col[2 * s] + (2 * i) * XS];
             }
+            if (tr && s >= 3 && s < 7) {  // B^T d, one column per step
+                const int j = s - 3;
+                e[0][j] = d[0][j] - d[2][j];
+                e[1][j] = d[1][j] + d[2][j];
+            }
+            if (tr && s >= 7 && s < 15) {  // (B^T d) B, half a row per step
+                const int i = (s - 7) >> 1;
+                if (((s - 7) & 1) == 0) tdst[(4 * i + 0) * 512] = e[i][0] - e[i][2];
+                else tdst[(4 * i + 2) * 512] = e[i][2] - e[i][1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- sub-step 1
+            if (s >= PF && !(ABL & 8)) acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[c][0], rb[c][0], acc[xi][1], 0, 0, 0);
             if (!(ABL & 4)) {
                 if (s < 4) {
                     if (more_u) dma_u(q + 1, s);
@@ -260,12 +287,30 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
                     if (more_x) dma_x(q + 2, s - 4);
                 }
             }
-            if (s >= WN_PF && !(ABL & 8)) {
-                const int xi = s - WN_PF, c = xi % (WN_PF + 1);
-                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[c][0], rb[c][0], acc[xi][0], 0, 0, 0);
-                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[c][0], rb[c][0], acc[xi][1], 0, 0, 0);
-                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[c][1], rb[c][1], acc[xi][0], 0, 0, 0);
-                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[c][1], rb[c][1], acc[xi][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- sub-step 2
+            if (s >= PF && !(ABL & 8)) acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[c][1], rb[c][1], acc[xi][0], 0, 0, 0);
+            if (tr && s < 2) {  // patch column 2s+1
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i][2 * s + 1] = tsrc[t_col[2 * s + 1] + (2 * i) * XS];
+            }
+            if (tr && s >= 3 && s < 7) {
+                const int j = s - 3;
+                e[2][j] = d[2][j] - d[1][j];
+                e[3][j] = d[1][j] - d[3][j];
+            }
+            if (tr && s >= 7 && s < 15) {
+                const int i = (s - 7) >> 1;
+                if (((s - 7) & 1) == 0) tdst[(4 * i + 1) * 512] = e[i][1] + e[i][2];
+                else tdst[(4 * i + 3) * 512] = e[i][1] - e[i][3];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- sub-step 3: operands of step s (consumed PF steps later; slot w was last read by the MFMAs of step s - 1)
+            if (s >= PF && !(ABL & 8)) acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[c][1], rb[c][1], acc[xi][1], 0, 0, 0);
+            if (s < 16 && !(ABL & 2)) {
+                rb[w] = *reinterpret_cast<const f32x2*>(vb + s * 512);
+                ra0[w] = *reinterpret_cast<const f32x2*>(ua0 + s * 512);
+                ra1[w] = *reinterpret_cast<const f32x2*>(ua1 + s * 512);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -283,14 +328,32 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     transform(0);
-    const bool t_first = wave < 4;  // waves w and w+4 share a SIMD: opposite phase orders keep its matrix pipe fed
+    const bool t_first = (ABL & 64) ? true : (ABL & 128) ? false : wave < 4;  // waves w and w+4 share a SIMD: opposite phase orders keep its matrix pipe fed
     for (int q = 0; q < nchunks; ++q) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for U(q), X(q+1) has landed
         __syncthreads();                                   // ... everyone's, and V(q) is written; buffers of q-1 are free
-        const bool tr = q + 1 < nchunks && !(ABL & 1);
+        const bool tr = !FUSE_T && q + 1 < nchunks && !(ABL & 1);
+        unsigned long long w0s = 0, w1s = 0, w2s = 0, w3s = 0;
+        const bool wt = a.trace && q == 3;
+        if (wt) w0s = __builtin_readcyclecounter();
         if (tr && t_first) transform(q + 1);
+        if (wt) w1s = __builtin_readcyclecounter();
         mma(q);
+        if (wt) w2s = __builtin_readcyclecounter();
         if (tr && !t_first) transform(q + 1);
+        if (wt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            w3s = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long w4s = __builtin_readcyclecounter();
+            if (lane == 0) {
+                unsigned long long* wv = a.trace + 8 * 65536 + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+                wv[0] = w0s;
+                wv[1] = w1s;
+                wv[2] = w2s;
+                wv[3] = (w3s << 20) | ((w4s - w3s) & 0xfffff);
+            }
+        }
     }
     __syncthreads();  // all waves done with U / V: LDS becomes Y[64][256] (ReLU(conv + b)) followed by the ih weights
     WN_STAMP(1)
@@ -455,7 +518,10 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
     const size_t lds = sizeof(float) * (x4 ? WN_LDS_FLOATS(true) : WN_LDS_FLOATS(false));
     static const int abl = getenv("MRX_ABLATE") ? atoi(getenv("MRX_ABLATE")) : 0;  // debug: skip 1 transform, 2 operand reads, 4 DMA, 8 MFMA
     auto kern = x4 ? (abl == 1 ? k_rim_layer_wino<1, true> : abl == 2 ? k_rim_layer_wino<2, true> : abl == 4 ? k_rim_layer_wino<4, true>
-                      : abl == 8 ? k_rim_layer_wino<8, true> : k_rim_layer_wino<0, true>)
+                      : abl == 8 ? k_rim_layer_wino<8, true> : abl == 16 ? k_rim_layer_wino<16, true> : abl == 32 ? k_rim_layer_wino<32, true>
+                      : abl == 48 ? k_rim_layer_wino<48, true> : abl == 64 ? k_rim_layer_wino<64, true> : abl == 128 ? k_rim_layer_wino<128, true>
+                      : abl == 256 ? k_rim_layer_wino<256, true>
+                      : k_rim_layer_wino<0, true>)
                    : k_rim_layer_wino<0, false>;
     static bool attr_done[2] = {false, false};  // once per variant: keeps launches legal under hipGraph capture
     if (!attr_done[x4]) {
@@ -465,7 +531,7 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
     static unsigned long long* d_trace = nullptr;
     a.trace = nullptr;
     if (getenv("MRX_TRACE")) {
-        if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 8 * 65536);
+        if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 40 * 65536);
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 8 * 65536, (hipStream_t)stream);
         a.trace = d_trace;
     }
@@ -477,6 +543,20 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
         std::vector<unsigned long long> h((size_t)nb * 8);
         (void)hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * 8 * nb, hipMemcpyDeviceToHost);
         double ph[4] = {0, 0, 0, 0};
+        {
+            std::vector<unsigned long long> wv((size_t)32 * 4);
+            (void)hipMemcpy(wv.data(), d_trace + 8 * 65536 + 300 * 32, sizeof(unsigned long long) * 32 * 4, hipMemcpyDeviceToHost);
+            for (int bk = 0; bk < 4; ++bk) {
+                fprintf(stderr, "[mrx-trace] blk %d chunk 3, per wave stamps rel. first barrier exit (phase1 end, mma end, all landed):", 300 + bk);
+                unsigned long long base = ~0ull;
+                for (int w = 0; w < 8; ++w) base = wv[(bk * 8 + w) * 4] < base ? wv[(bk * 8 + w) * 4] : base;
+                for (int w = 0; w < 8; ++w) {
+                    const unsigned long long* r = &wv[(bk * 8 + w) * 4];
+                    fprintf(stderr, " w%d(%lld: %lld %lld %lld +%lld)", w, (long long)(r[0] - base), (long long)(r[1] - base), (long long)(r[2] - base), (long long)((r[3] >> 20) - (base & 0xfffffffffffull)), (long long)(r[3] & 0xfffff));
+                }
+                fprintf(stderr, "\n");
+            }
+        }
         std::map<unsigned long long, std::pair<unsigned long long, unsigned long long>> cu;  // per-CU busy span (one XCC clock each)
         for (int i = 0; i < nb; ++i) {
             const unsigned long long* r = &h[(size_t)i * 8];
