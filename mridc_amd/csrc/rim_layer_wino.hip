@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <type_traits>
 #include <vector>
 
 #include "mrx_common.h"
@@ -34,16 +35,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WN_F 64
 #define WN_CK 8
 #define WN_PH 12
-// Raw tile geometry.  X4 (W % 4 == 0, 16-byte aligned x): rows of 10 aligned float4 starting 4 columns left of the tile, fetched
-// with 15 dwordx4 DMA instructions per chunk; the column part of the replicate border is applied when the patch is gathered.
-// Otherwise: rows of 36 (+2 pad, conflict-free gathers) fetched element-wise with 57 dword DMA instructions, clamped at the source.
+// Raw tile geometry: one 512-float plane per channel (whole DMA instructions, one channel each).  X4 (W % 4 == 0, 16-byte
+// aligned x): rows of 10 aligned float4 starting 4 columns left of the tile, two dwordx4 DMA instructions per channel; the
+// column part of the replicate border is applied when the patch is gathered.  Otherwise: rows of 36 (+2 pad, conflict-free
+// gathers) fetched element-wise with eight dword DMA instructions per channel, clamped at the source.
 #define WN_XS(X4) ((X4) ? 40 : 38)
 #define WN_OX(X4) ((X4) ? 4 : 2)
-#define WN_PLANE(X4) (WN_PH * WN_XS(X4))
-#define WN_XBUF(X4) (WN_CK * WN_PLANE(X4))  // 3840 / 3648 floats
+#define WN_XPLANE 512
+#define WN_XBUF (WN_CK * WN_XPLANE)    // 4096 floats
 #define WN_UCHUNK (16 * 4 * WN_F * 2)  // 8192 floats = 32 DMA wave-instructions of 1 KB
 #define WN_VBUF WN_UCHUNK
-#define WN_LDS_FLOATS(X4) (2 * WN_XBUF(X4) + 2 * WN_UCHUNK + 2 * WN_VBUF)
+#define WN_LDS_FLOATS (2 * WN_XBUF + 2 * WN_UCHUNK + 2 * WN_VBUF)  // 40960 = the CU's whole 160 KB
 #define WN_PF 3
 
 struct WinoArgs {
@@ -119,9 +121,9 @@ extern "C" int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, f
 template <int ABL, bool X4>
 __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    float* Xs = smem_f;                          // [2][CK][12][38] raw halo'd tiles
-    constexpr int XS = WN_XS(X4), OX = WN_OX(X4), PLANE = WN_PLANE(X4), XBUF = WN_XBUF(X4);
-    float* Us = Xs + 2 * XBUF;                   // [2][16][4][64][2]
+    float* Xs = smem_f;                          // [2][CK][512] raw halo'd tiles (12 rows of XS)
+    constexpr int XS = WN_XS(X4), OX = WN_OX(X4);
+    float* Us = Xs + 2 * WN_XBUF;                // [2][16][4][64][2]
     float* Vs = Us + 2 * WN_UCHUNK;              // [2][16][4][64][2]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -143,47 +145,43 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     if (a.trace && tid == 0) a.trace[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter();
     WN_STAMP(0)
 
-    // ---- LDS-DMA work list of this wave: 4 copies of 1 KB of the packed U image (n = wave + 8 m) and its share of the raw tile
-    // (replicate border = clamped coordinates, conv_layers.py:72-76).  xsrc[m] = (channel << 28) | element offset in the plane.
-    constexpr int NXI = X4 ? XBUF / 256 : XBUF / 64;  // raw-tile DMA instructions per chunk (15 / 57)
-    constexpr int NXM = (NXI + 7) / 8;                // ... per wave (2 / 8)
-    unsigned xsrc[NXM];
+    // ---- LDS-DMA work list of this wave: 4 copies of 1 KB of the packed U image (n = wave + 8 m) and the raw tile of channel
+    // `wave` of the chunk (replicate border = clamped coordinates, conv_layers.py:72-76).  Sources are a wave-uniform base
+    // (scalar registers, advanced on the scalar unit) plus a fixed per-lane byte offset: no vector instructions per copy.
+    constexpr int NXM = X4 ? 2 : 8;  // raw-tile DMA instructions per wave and chunk
+    unsigned xoff[NXM];
 #pragma unroll
     for (int m = 0; m < NXM; ++m) {
-        const int e = (wave + 8 * m) * 64 + lane;  // float4 (X4) or element index in the [CK][12][XS] tile
-        int ci, gy, gx;
+        int sl = m * 64 + lane, gy, gx;  // float4 (X4) or element slot of the plane; slots past the tile repeat its last one
         if (X4) {
-            ci = e / (PLANE / 4);
-            const int rem = e - ci * (PLANE / 4);
-            const int ry = rem / (XS / 4), c4 = rem - ry * (XS / 4);
+            sl = sl < 12 * (XS / 4) ? sl : 12 * (XS / 4) - 1;
+            const int ry = sl / (XS / 4), c4 = sl - ry * (XS / 4);
             gy = h0 + ry - 2;
             gx = w0 - OX + 4 * c4;  // whole groups outside the image fetch the nearest inside one; the gather never reads them
             gx = gx < 0 ? 0 : (gx > a.W - 4 ? a.W - 4 : gx);
         } else {
-            ci = e / PLANE;
-            const int slot = e - ci * PLANE;
-            const int ry = slot / XS, rx = slot - ry * XS;
+            sl = sl < 12 * XS ? sl : 12 * XS - 1;
+            const int ry = sl / XS, rx = sl - ry * XS;
             gy = h0 + ry - 2;
             gx = w0 + rx - OX;
             gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
         }
         gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-        xsrc[m] = ((unsigned)(ci & 7) << 28) | (unsigned)(gy * a.W + gx);
+        xoff[m] = (unsigned)(gy * a.W + gx) * 4u;
     }
+    const unsigned uoff = (unsigned)lane * 16u;
     auto dma_u = [&](int q, int m) {  // m in 0..3
         const int n = wave + 8 * m;
-        __builtin_amdgcn_global_load_lds(WN_GLOBAL(a.packed + (long long)q * WN_UCHUNK + n * 256 + lane * 4),
-                                         WN_SHARED(Us + (q & 1) * WN_UCHUNK + n * 256), 16, 0, 0);
+        const char* src = reinterpret_cast<const char*>(a.packed + (long long)q * WN_UCHUNK + n * 256);
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL(src + uoff), WN_SHARED(Us + (q & 1) * WN_UCHUNK + n * 256), 16, 0, 0);
     };
     auto dma_x = [&](int q, int m) {  // channels past Cin re-read the last one (their packed weights are zero)
-        const int n = wave + 8 * m;
-        if (n < NXI) {
-            int gc = q * WN_CK + (int)(xsrc[m] >> 28);
-            gc = gc < a.Cin ? gc : a.Cin - 1;
-            const float* src = xb + (long long)gc * plane + (xsrc[m] & 0x0fffffffu);
-            if (X4) __builtin_amdgcn_global_load_lds(WN_GLOBAL(src), WN_SHARED(Xs + (q & 1) * XBUF + n * 256), 16, 0, 0);
-            else __builtin_amdgcn_global_load_lds(WN_GLOBAL(src), WN_SHARED(Xs + (q & 1) * XBUF + n * 64), 4, 0, 0);
-        }
+        int gc = q * WN_CK + wave;
+        gc = gc < a.Cin ? gc : a.Cin - 1;
+        const char* src = reinterpret_cast<const char*>(xb + (long long)gc * plane);
+        float* dst = Xs + (q & 1) * WN_XBUF + wave * WN_XPLANE;
+        if (X4) __builtin_amdgcn_global_load_lds(WN_GLOBAL(src + xoff[m]), WN_SHARED(dst + m * 256), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds(WN_GLOBAL(src + xoff[m]), WN_SHARED(dst + m * 64), 4, 0, 0);
     };
 
     // ---- input transform: lane -> tile (tbx = lane&7, px = lane>>3 &1, py = lane>>4 &1, tby = lane>>5), wave -> channel.
@@ -196,13 +194,12 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             const int lo = OX - w0, hi = a.W - 1 - w0 + OX;
             c = c < lo ? lo : (c > hi ? hi : c);
         }
-        t_col[j] = wave * PLANE + (4 * (lane >> 5) + ((lane >> 4) & 1)) * XS + c;
+        t_col[j] = wave * WN_XPLANE + (4 * (lane >> 5) + ((lane >> 4) & 1)) * XS + c;
     }
     const int t_pos = (lane & 7) + 8 * (((lane >> 3) & 1) ^ (lane >> 5)) + 16 * ((lane >> 4) & 1) + 32 * (lane >> 5);
     const int t_dst = ((wave >> 1) * WN_F + (t_pos ^ (16 * ((wave >> 1) & 1)))) * 2 + (wave & 1);
-    auto transform = [&](int q) {
-        if (ABL & 16) __builtin_amdgcn_s_setprio(3);
-        const float* src = Xs + (q & 1) * XBUF;
+    auto transform = [&](int q) {  // stand-alone form (prologue only; later chunks ride inside the MFMA loop)
+        const float* src = Xs + (q & 1) * WN_XBUF;
         float d[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -224,7 +221,6 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             dst[(4 * i + 2) * 512] = e[i][2] - e[i][1];
             dst[(4 * i + 3) * 512] = e[i][1] - e[i][3];
         }
-        if (ABL & 16) __builtin_amdgcn_s_setprio(0);
     };
 
     f32x4 acc[16][2];
@@ -235,32 +231,31 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[xi][h][r] = 0.f;
 
-    // ---- matrix-core phase on chunk q, with the DMA for the following chunks issued one instruction per step ------------
+    // ---- one chunk: 16 steps of {4 MFMAs, operand reads for 3 steps ahead}.  The fp32 matrix pipe is the SIMD's fp32 vector
+    // pipe (157 TFLOP/s either way): every other VALU instruction costs it 3-4 cycles (measured: tools/probe/filler_probe*),
+    // LDS and scalar instructions almost nothing.  So the DMA for the following chunks and the input transform of the next one
+    // ride along inside the loop with almost no address arithmetic (immediate offsets, scalar bases).
     const int m_sw = 16 * (lg & 1);
     const int m_a0 = (lg * WN_F + ((32 * cot + l15) ^ m_sw)) * 2;
     const int m_a1 = (lg * WN_F + ((32 * cot + 16 + l15) ^ m_sw)) * 2;
     const int m_b = (lg * WN_F + (((l15 & 7) + 8 * (px ^ (l15 >> 3)) + 16 * py + 32 * (l15 >> 3)) ^ m_sw)) * 2;
-    // One chunk: 16 steps of {operand reads 3 steps ahead, 4 MFMAs}; the DMA for the following chunks and the input transform
-    // of the next one ride along as single instructions between the MFMAs of the SAME wave (a wave whose SIMD partner is
-    // MFMA-bound gets about one issue slot per MFMA, so a stand-alone transform phase would take 3x longer).
-    constexpr bool FUSE_T = !(ABL & 256);
-    auto mma = [&](int q) {
-        const float* ua0 = Us + (q & 1) * WN_UCHUNK + m_a0;
-        const float* ua1 = Us + (q & 1) * WN_UCHUNK + m_a1;
-        const float* vb = Vs + (q & 1) * WN_VBUF + m_b;
+    auto chunk = [&](int q) {
+        const int PAR = q & 1;
+        const float* ua0 = Us + PAR * WN_UCHUNK + m_a0;
+        const float* ua1 = Us + PAR * WN_UCHUNK + m_a1;
+        const float* vb = Vs + PAR * WN_VBUF + m_b;
         const bool more_u = q + 1 < nchunks, more_x = q + 2 < nchunks;
-        const bool tr = FUSE_T && q + 1 < nchunks && !(ABL & 1);
-        const float* tsrc = Xs + ((q + 1) & 1) * XBUF;
-        float* tdst = Vs + ((q + 1) & 1) * WN_VBUF + t_dst;
+        const bool tr = q + 1 < nchunks && !(ABL & 1);
+        const float* tsrc = Xs + (PAR ^ 1) * WN_XBUF;
+        float* tdst = Vs + (PAR ^ 1) * WN_VBUF + t_dst;
         float d[4][4], e[4][4];
-        constexpr int PF = (ABL & 32) ? 5 : WN_PF;
+        constexpr int PF = WN_PF;
         f32x2 ra0[PF + 1], ra1[PF + 1], rb[PF + 1];
         if (ABL & 2)
             for (int i = 0; i <= PF; ++i) ra0[i] = ra1[i] = rb[i] = (f32x2){(float)tid, (float)i};
 #pragma unroll
         for (int s = 0; s < 16 + PF; ++s) {
             const int xi = s - PF, c = (xi < 0 ? 0 : xi) % (PF + 1), w = s % (PF + 1);
-            // each MFMA is followed by its share of the step's other instructions, so they issue in the shadow of the MFMA
             // ---- sub-step 0
             if (s >= PF && !(ABL & 8)) acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[c][0], rb[c][0], acc[xi][0], 0, 0, 0);
             if (tr && s < 2) {  // patch column 2s
@@ -315,6 +310,10 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed
+        __syncthreads();                                   // ... everyone's, and V(q) is written; the buffers of q - 1 are free
+    };
 
     // ---- prologue: U(0), X(0), X(1) -> LDS, V(0) ---------------------------------------------------------------------
 #pragma unroll
@@ -325,35 +324,12 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
 #pragma unroll
         for (int m = 0; m < NXM; ++m) dma_x(1, m);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    sync();
     transform(0);
-    const bool t_first = (ABL & 64) ? true : (ABL & 128) ? false : wave < 4;  // waves w and w+4 share a SIMD: opposite phase orders keep its matrix pipe fed
-    for (int q = 0; q < nchunks; ++q) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for U(q), X(q+1) has landed
-        __syncthreads();                                   // ... everyone's, and V(q) is written; buffers of q-1 are free
-        const bool tr = !FUSE_T && q + 1 < nchunks && !(ABL & 1);
-        unsigned long long w0s = 0, w1s = 0, w2s = 0, w3s = 0;
-        const bool wt = a.trace && q == 3;
-        if (wt) w0s = __builtin_readcyclecounter();
-        if (tr && t_first) transform(q + 1);
-        if (wt) w1s = __builtin_readcyclecounter();
-        mma(q);
-        if (wt) w2s = __builtin_readcyclecounter();
-        if (tr && !t_first) transform(q + 1);
-        if (wt) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            w3s = __builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long w4s = __builtin_readcyclecounter();
-            if (lane == 0) {
-                unsigned long long* wv = a.trace + 8 * 65536 + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
-                wv[0] = w0s;
-                wv[1] = w1s;
-                wv[2] = w2s;
-                wv[3] = (w3s << 20) | ((w4s - w3s) & 0xfffff);
-            }
-        }
+#pragma nounroll
+    for (int q = 0; q < nchunks; ++q) {  // one body for all chunks: the accumulators stay in place
+        sync();
+        chunk(q);
     }
     __syncthreads();  // all waves done with U / V: LDS becomes Y[64][256] (ReLU(conv + b)) followed by the ih weights
     WN_STAMP(1)
@@ -510,18 +486,14 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
     a.tiles_x = mrx_cdiv(W, 32);
     a.ntiles = a.tiles_x * mrx_cdiv(H, 8);
     MRX_REQUIRE((long long)H * W < (1ll << 28), MRX_EUNSUP, "mrx_rim_layer_indrnn_wino: plane %d x %d too large", H, W);
-    static_assert(WN_LDS_FLOATS(false) >= WN_F * 256 + WN_F * WN_F, "Y + ih weights must fit the staging region");
-    static_assert(WN_LDS_FLOATS(true) * sizeof(float) <= 160 * 1024, "one workgroup owns the CU's LDS");
-    static_assert((2 * WN_XBUF(true)) % 4 == 0 && (2 * WN_XBUF(false)) % 4 == 0, "U image 16-byte aligned");
-    static_assert(WN_XBUF(true) % 256 == 0 && WN_XBUF(false) % 64 == 0, "raw tile = a whole number of DMA instructions");
+    static_assert(WN_LDS_FLOATS >= WN_F * 256 + WN_F * WN_F, "Y + ih weights must fit the staging region");
+    static_assert(WN_LDS_FLOATS * sizeof(float) <= 160 * 1024, "one workgroup owns the CU's LDS");
+    static_assert(12 * WN_XS(true) <= WN_XPLANE && 12 * WN_XS(false) <= WN_XPLANE, "raw tile fits its plane");
     const bool x4 = (W & 3) == 0 && W >= 4 && ((uintptr_t)x & 15) == 0;
-    const size_t lds = sizeof(float) * (x4 ? WN_LDS_FLOATS(true) : WN_LDS_FLOATS(false));
+    const size_t lds = sizeof(float) * WN_LDS_FLOATS;
     static const int abl = getenv("MRX_ABLATE") ? atoi(getenv("MRX_ABLATE")) : 0;  // debug: skip 1 transform, 2 operand reads, 4 DMA, 8 MFMA
     auto kern = x4 ? (abl == 1 ? k_rim_layer_wino<1, true> : abl == 2 ? k_rim_layer_wino<2, true> : abl == 4 ? k_rim_layer_wino<4, true>
-                      : abl == 8 ? k_rim_layer_wino<8, true> : abl == 16 ? k_rim_layer_wino<16, true> : abl == 32 ? k_rim_layer_wino<32, true>
-                      : abl == 48 ? k_rim_layer_wino<48, true> : abl == 64 ? k_rim_layer_wino<64, true> : abl == 128 ? k_rim_layer_wino<128, true>
-                      : abl == 256 ? k_rim_layer_wino<256, true>
-                      : k_rim_layer_wino<0, true>)
+                      : abl == 8 ? k_rim_layer_wino<8, true> : k_rim_layer_wino<0, true>)
                    : k_rim_layer_wino<0, false>;
     static bool attr_done[2] = {false, false};  // once per variant: keeps launches legal under hipGraph capture
     if (!attr_done[x4]) {
