@@ -90,6 +90,9 @@ class RIMBlock(torch.nn.Module):
         return hit[1]
 
     def _layer(self, idx, stack, x, h):
+        """One conv+RNN stack.  `h` None = the zero initial state (rim_block.py:188-193) without materialising it."""
+        if h is None and not self._fusable(stack):
+            h = x.new_zeros((x.size(0), stack.rnn.hidden_size, *x.size()[2:]))
         if self._fusable(stack):
             c, r = stack.convs, stack.rnn
             if self.winograd and ops.rim_layer_wino_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation):
@@ -103,13 +106,12 @@ class RIMBlock(torch.nn.Module):
 
     def forward(self, pred: torch.Tensor, masked_kspace: torch.Tensor, sense: torch.Tensor, mask: torch.Tensor,
                 eta: torch.Tensor = None, hx: torch.Tensor = None, sigma: float = 1.0, keep_eta: bool = False,
-                ) -> Tuple[Any, Union[list, torch.Tensor, None]]:
+                _hybrid: torch.Tensor = None) -> Tuple[Any, Union[list, torch.Tensor, None]]:
         """rim_block.py:139-269.  Returns (list of time_steps estimates, hx)."""
         if isinstance(pred, list):                                   # rim_block.py:185-186
             pred = pred[-1].detach()
-        if hx is None:                                               # rim_block.py:188-193
-            hx = [masked_kspace.new_zeros((masked_kspace.size(0), f, *masked_kspace.size()[2:-1]))
-                  for f in self.recurrent_filters if f != 0]
+        if hx is None:                                               # rim_block.py:188-193 (zeros; kernels take NULL for that)
+            hx = [None for f in self.recurrent_filters if f != 0]
         else:
             hx = list(hx)
         if eta is None or eta.ndim < 3:                              # rim_block.py:195-211
@@ -120,7 +122,9 @@ class RIMBlock(torch.nn.Module):
         # launch per step on yt = IFFT_H(y); any other mask takes the general three-launch path
         hinv = ops.mask_is_row_invariant(mask) and self.coil_dim == 1
         if hinv:
-            yt = ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization, self.spatial_dims)
+            # yt = IFFT_H(y) depends on the measured data only: a caller running several cascades on the same y (CIRIM) passes it
+            yt = _hybrid if _hybrid is not None else ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization,
+                                                                     self.spatial_dims)
             work = None
         else:
             work = torch.empty_like(masked_kspace, dtype=torch.float32)

@@ -12,6 +12,7 @@
 //     matrix cores (issue-early / write-late staging);
 //   * the 1x1 `ih` GEMM consumes the conv accumulators in registers (contraction index enumerated in C/D-layout order),
 //     its packed weights sit in their own LDS region from kernel start.
+#include <cstdint>
 #include <cstdlib>
 #include <algorithm>
 #include <map>
@@ -485,6 +486,7 @@ struct RimFinalArgs {
     const float* eta;   // [B,H,W,2]
     float* out;         // [B,H,W,2]
     int B, F, H, W, tiles_x, ntiles;
+    unsigned long long* trace;  // debug only (env MRX_TRACE)
 };
 template <int K, int DIL>
 __global__ __launch_bounds__(RF_NT) void k_rim_final(RimFinalArgs a) {
@@ -581,6 +583,182 @@ static int launch_rim_final(const RimFinalArgs& a, hipStream_t st) {
     return MRX_OK;
 }
 
+// ---- final 3x3 conv, W % 4 == 0: four pixels per thread on the vector ALUs --------------------------------------------------
+// Cout = 2 leaves the matrix cores idle (2 of 16 rows), so the FMAs run on the VALU, whose cost is the instruction count:
+// 18 FMAs per (pixel, channel) are irreducible, everything else is overhead.  A thread owns 4 adjacent pixels (8 accumulators) so
+// one patch row is three LDS reads for 24 FMAs; the four waves of a workgroup share the 8x32 tile and split the channels
+// (wave w takes channels 2w, 2w+1 of every chunk of 8), their partial sums meet in LDS at the end.  The raw tile arrives by
+// LDS-DMA (global_load_lds_dwordx4, aligned float4 groups starting 4 columns left of the tile; rows clamped at the source, the
+// column border fixed up after the read in the two border tile columns only); weights are (w0, w1) pairs broadcast from LDS.
+#define RF4_NT 256
+#define RF4_TH 8
+#define RF4_TW 32
+#define RF4_XS 40                       // tile row: w0-4 .. w0+35
+#define RF4_ROWS (RF4_TH + 2)
+#define RF4_PLANE4 128                  // float4 slots per channel plane (10 rows x 10 = 100 used): 2 DMA instructions
+#define RF4_RING 4                      // channel planes in flight per wave
+#define RF4_BUF (4 * RF4_RING * RF4_PLANE4 * 4 / 2)  // floats of half the staging area (4 waves x ring)
+typedef float rf4_f2 __attribute__((ext_vector_type(2)));
+typedef float rf4_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(RF4_NT, 4) void k_rim_final4(RimFinalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Wp = smem_f + 2 * RF4_BUF;  // [F][9] pairs (w[0][ci][tap], w[1][ci][tap])
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x;
+    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
+    const int ty0 = tile / a.tiles_x;
+    const int h0 = ty0 * RF4_TH, w0 = (tile - ty0 * a.tiles_x) * RF4_TW;
+    const int b = blockIdx.y;
+    const long long plane = (long long)a.H * a.W;
+    const float* hb = a.h + (long long)b * a.F * plane;
+    unsigned off[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        int sl = m * 64 + lane;
+        sl = sl < RF4_ROWS * (RF4_XS / 4) ? sl : RF4_ROWS * (RF4_XS / 4) - 1;
+        const int ry = sl / (RF4_XS / 4), c4 = sl - ry * (RF4_XS / 4);
+        int gy = h0 + ry - 1, gx = w0 - 4 + 4 * c4;
+        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+        gx = gx < 0 ? 0 : (gx > a.W - 4 ? a.W - 4 : gx);
+        off[m] = (unsigned)(gy * a.W + gx) * 4u;
+    }
+    // wave-private ring of RF4_RING channel planes: wave w streams channels w, w+4, w+8, ... three channels ahead of the one it
+    // is consuming, waiting on its own vmcnt only -- no workgroup barrier inside the channel loop, so the waves of the (up to four)
+    // co-resident workgroups drift apart and cover each other's memory latency
+    float* ring = smem_f + wave * (RF4_RING * RF4_PLANE4 * 4);
+    auto dma = [&](int k) {  // k-th channel of this wave -> ring slot k % RF4_RING
+        const char* src = reinterpret_cast<const char*>(hb + (long long)(wave + 4 * k) * plane);
+        float* dst = ring + (k % RF4_RING) * RF4_PLANE4 * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off[0]),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        if (lane < RF4_ROWS * (RF4_XS / 4) - 64)  // the plane has 100 float4: the second copy moves 36 (lanes write base + 16 lane)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off[1]),
+                                             (__attribute__((address_space(3))) void*)(dst + 256), 16, 0, 0);
+    };
+    const int nch = a.F / 4;  // channels per wave
+    unsigned long long t_s = 0, t_w = 0, t_c = 0, t_x = 0;
+    if (a.trace) t_s = __builtin_readcyclecounter();
+#pragma unroll
+    for (int k = 0; k < RF4_RING - 1; ++k)
+        if (k < nch) dma(k);
+    for (int i = tid; i < a.F * 9; i += RF4_NT) {
+        Wp[2 * i] = a.w[i];
+        Wp[2 * i + 1] = a.w[a.F * 9 + i];
+    }
+    const int tx = lane & 7, ty = lane >> 3;
+    const int x0 = w0 + 4 * tx;                         // first of this thread's 4 pixels
+    const bool fix_l = x0 == 0, fix_r = x0 + 4 >= a.W;  // replicate border columns (conv_layers.py:72-76)
+    const bool border = w0 == 0 || w0 + RF4_TW >= a.W;
+    float acc[2][4];
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[co][i] = 0.f;
+    __syncthreads();  // weights staged
+    for (int k = 0; k < nch; ++k) {
+        // the ring slot refilled below was read by iteration k - 1, whose LDS reads have returned (their FMAs are issued in order)
+        if (a.trace) t_x = __builtin_readcyclecounter();
+        if (k + RF4_RING - 1 < nch) {
+            dma(k + RF4_RING - 1);
+            if (a.trace) t_c -= __builtin_readcyclecounter() - t_x;  // (issue cost goes to t_w below; t_c accumulates the rest)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RF4_RING - 1)) : "memory");  // all but the newest 3 channels landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (a.trace) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            t_w += t - t_x;
+        }
+        const float* xp = ring + (k % RF4_RING) * RF4_PLANE4 * 4 + ty * RF4_XS + 4 * tx;
+        const float* wp = Wp + (wave + 4 * k) * 18;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* row = xp + r * RF4_XS;
+            const rf4_f4 v1 = *reinterpret_cast<const rf4_f4*>(row + 4);
+            float v[6] = {row[3], v1[0], v1[1], v1[2], v1[3], row[8]};  // image columns x0-1 .. x0+4
+            if (border) {
+                if (fix_l) v[0] = v[1];
+                if (fix_r) v[5] = v[4];  // W % 4 == 0: the last image column is this thread's 4th pixel
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const rf4_f2 wv = *reinterpret_cast<const rf4_f2*>(wp + (r * 3 + kx) * 2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0][i] += wv[0] * v[i + kx];
+                    acc[1][i] += wv[1] * v[i + kx];
+                }
+            }
+        }
+    }
+    if (a.trace && lane == 0) {
+        unsigned long long* tr = a.trace + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+        tr[0] = __builtin_readcyclecounter() - t_s;  // whole channel loop incl. prologue
+        tr[1] = t_w;                                  // DMA issue + wait for the channel to land
+        tr[2] = (unsigned long long)(-(long long)t_c);  // of which DMA issue
+    }
+    __syncthreads();  // all tiles consumed: LDS becomes the partial-sum exchange [wave 1..3][lane][8]
+    float* Rx = smem_f;
+    if (wave > 0) {
+        rf4_f4* dst = reinterpret_cast<rf4_f4*>(Rx + ((wave - 1) * 64 + lane) * 8);
+        dst[0] = (rf4_f4){acc[0][0], acc[1][0], acc[0][1], acc[1][1]};
+        dst[1] = (rf4_f4){acc[0][2], acc[1][2], acc[0][3], acc[1][3]};
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int oy = h0 + ty;
+    if (oy >= a.H || x0 >= a.W) return;
+    rf4_f4 s0 = (rf4_f4){acc[0][0], acc[1][0], acc[0][1], acc[1][1]}, s1 = (rf4_f4){acc[0][2], acc[1][2], acc[0][3], acc[1][3]};
+#pragma unroll
+    for (int wv = 0; wv < 3; ++wv) {
+        const rf4_f4* src = reinterpret_cast<const rf4_f4*>(Rx + (wv * 64 + lane) * 8);
+        s0 += src[0];
+        s1 += src[1];
+    }
+    const long long o = (((long long)b * a.H + oy) * a.W + x0) * 2;
+    const float b0 = a.bias ? a.bias[0] : 0.f, b1 = a.bias ? a.bias[1] : 0.f;
+    const rf4_f4 bb = (rf4_f4){b0, b1, b0, b1};
+    const rf4_f4 e0 = *reinterpret_cast<const rf4_f4*>(a.eta + o), e1 = *reinterpret_cast<const rf4_f4*>(a.eta + o + 4);
+    *reinterpret_cast<rf4_f4*>(a.out + o) = e0 + (s0 + bb);
+    *reinterpret_cast<rf4_f4*>(a.out + o + 4) = e1 + (s1 + bb);
+}
+
+static int launch_rim_final4(RimFinalArgs a, hipStream_t st) {
+    a.tiles_x = mrx_cdiv(a.W, RF4_TW);
+    a.ntiles = a.tiles_x * mrx_cdiv(a.H, RF4_TH);
+    const size_t lds = sizeof(float) * (2 * RF4_BUF + (size_t)a.F * 18);
+    MRX_REQUIRE(lds <= 64 * 1024, MRX_EUNSUP, "rim_final: %zu bytes of LDS", lds);
+    static size_t attr_bytes = 0;
+    if (lds > 48 * 1024 && attr_bytes < lds) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_final4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    static unsigned long long* d_trace = nullptr;
+    a.trace = nullptr;
+    if (getenv("MRX_TRACE")) {
+        if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 16 * 65536);
+        a.trace = d_trace;
+    }
+    hipLaunchKernelGGL(k_rim_final4, dim3(a.ntiles, a.B), dim3(RF4_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    if (a.trace && getenv("MRX_TRACE_DUMP")) {
+        (void)hipStreamSynchronize(st);
+        const int nw = a.ntiles * a.B * 4;
+        std::vector<unsigned long long> h((size_t)nw * 4);
+        (void)hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * 4 * nw, hipMemcpyDeviceToHost);
+        double tot = 0, wait = 0, issue = 0;
+        for (int i = 0; i < nw; ++i) {
+            tot += (double)h[(size_t)i * 4];
+            wait += (double)h[(size_t)i * 4 + 1];
+            issue += (double)h[(size_t)i * 4 + 2];
+        }
+        fprintf(stderr, "[mrx-trace] k_rim_final4 %d waves: mean channel loop %.0f cyc, of which DMA issue + landing wait %.0f (issue %.0f)\n", nw,
+                tot / nw, wait / nw, issue / nw);
+    }
+    return MRX_OK;
+}
+
 // returns MRX_EUNSUP (without setting an error the caller must report) when no tuned instantiation exists
 int mrx_rim_final_tuned(const float* h, const float* w, const float* bias, const float* eta, float* eta_out, int B, int F,
                         int H, int W, int k, int dil, hipStream_t st, int* handled) {
@@ -588,6 +766,7 @@ int mrx_rim_final_tuned(const float* h, const float* w, const float* bias, const
     if (!((k == 3 && dil == 1) || (k == 1 && dil == 1) || (k == 3 && dil == 2) || (k == 5 && dil == 1))) return MRX_OK;
     if ((RF_CK * (RF_TH + 2 * rl_pad(k, dil)) * (RL_TW + 2 * rl_pad(k, dil))) % 2) return MRX_OK;
     RimFinalArgs a;
+    a.trace = nullptr;
     a.h = h;
     a.w = w;
     a.bias = bias;
@@ -600,6 +779,9 @@ int mrx_rim_final_tuned(const float* h, const float* w, const float* bias, const
     a.tiles_x = mrx_cdiv(W, RL_TW);
     a.ntiles = a.tiles_x * mrx_cdiv(H, RF_TH);
     *handled = 1;
+    if (k == 3 && dil == 1 && (W & 3) == 0 && W >= 8 && F % 4 == 0 && (long long)H * W < (1ll << 30) && !getenv("MRX_FINAL_OLD") &&
+        (((uintptr_t)h | (uintptr_t)eta | (uintptr_t)eta_out) & 15) == 0)
+        return launch_rim_final4(a, st);
     if (k == 3 && dil == 1) return launch_rim_final<3, 1>(a, st);
     if (k == 1 && dil == 1) return launch_rim_final<1, 1>(a, st);
     if (k == 3 && dil == 2) return launch_rim_final<3, 2>(a, st);

@@ -166,12 +166,17 @@ def test_rim_final_vs_oracle(dev):
     from mridc_amd import ops
     g = torch.Generator().manual_seed(4)
     for (B, Fh, H, W, k, d) in ((1, 64, 16, 12, 3, 1), (2, 16, 13, 37, 3, 1), (1, 8, 9, 9, 5, 2), (1, 20, 33, 70, 3, 1),
-                                (1, 128, 17, 40, 3, 1), (1, 64, 8, 8, 1, 1), (1, 24, 12, 12, 5, 1)):
+                                (1, 128, 17, 40, 3, 1), (1, 64, 8, 8, 1, 1), (1, 24, 12, 12, 5, 1),
+                                # W % 4 == 0 and F % 8 == 0: the 4-pixels-per-thread kernel (k = 3), all border cases
+                                (1, 64, 24, 72, 3, 1), (2, 8, 9, 8, 3, 1), (1, 64, 40, 372, 3, 1), (1, 16, 1, 32, 3, 1), (1, 32, 19, 100, 3, 1)):
         h = torch.randn(B, Fh, H, W, generator=g)
         w = torch.randn(2, Fh, k, k, generator=g) / (Fh * k * k) ** 0.5
         eta = torch.randn(B, H, W, 2, generator=g)
+        bias = torch.randn(2, generator=g)
         ref = eta + oracle.rim.conv_nonlinear(h, w, None, k, d, None).permute(0, 2, 3, 1)
-        assert_close(ops.rim_final(h.to(dev), w.to(dev), None, k, d, eta.to(dev)), ref, 1e-5, "rim_final")
+        assert_close(ops.rim_final(h.to(dev), w.to(dev), None, k, d, eta.to(dev)), ref, 1e-5, f"rim_final {(B, Fh, H, W, k, d)}")
+        refb = eta + oracle.rim.conv_nonlinear(h, w, bias, k, d, None).permute(0, 2, 3, 1)
+        assert_close(ops.rim_final(h.to(dev), w.to(dev), bias.to(dev), k, d, eta.to(dev)), refb, 1e-5, "rim_final with bias")
 
 
 def test_unet_pieces_vs_torch(dev):
