@@ -612,6 +612,374 @@ __global__ __launch_bounds__(MRX_FFT_NT, 4) void k_llg_rows_hinv_part(const floa
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// W = 372 on the matrix pipe.  The butterflies of the Stockham kernels above are vector-ALU work (16 fp32 FMA / clk / SIMD,
+// packed ops take two passes); the fp32-input MFMA runs at 32.  372 = 31 x 12 (Cooley-Tukey, n = 12 n1 + n2, k = k1 + 31 k2):
+//   A) 12 x 31-point DFTs per sequence as MFMA products with the real cos / sin matrices of the symmetric form
+//        X_k = x0 + A_k -+ i B_k,  A_k = sum_t cos(2 pi k t / 31) (x_t + x_{31-t}),  B_k = sum_t sin(.) (x_t - x_{31-t}),  t = 1..15
+//      (a 16th matrix row of ones delivers X_0 - x0 = sum_t a_t); the MFMA columns are (coil, n2, re|im), so the two halves of a
+//      complex number sit in neighbouring lanes and meet through DPP quad swaps;
+//   B) twiddle w^(n2 k1) on the way to LDS;
+//   C) 31 x 12-point DFTs per sequence as one real [24 x 24] matrix (rows (k2, re|im), contraction (n2, re|im)).
+// 46 MFMA 16x16x4 per sequence and direction; the VALU is left with the pre-adds, the sign/twiddle fix-ups and addresses.
+// Same contract, grid and partial-sum layout as k_llg_rows_hinv_part<P372, 5>.
+// ------------------------------------------------------------------------------------------------------------
+typedef float mfx4 __attribute__((ext_vector_type(4)));
+#define M372_G 5
+#define M372_TS 49                     // stride of the (n2, re|im) rows of the intermediate array (conflict-free both ways)
+#define M372_TC (24 * M372_TS)         // floats per coil in the intermediate array
+struct M372Tables {
+    const float* ca;   // [4][64]  step A cos operand per lane
+    const float* sa;   // [4][64]  step A sin operand per lane
+    const float* m24;  // [2 inverse][2 tiles][6][64]  step C operand per lane
+};
+
+__device__ __forceinline__ float m372_swap(float v) {  // value of the neighbouring lane (lane ^ 1): quad_perm [1,0,3,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+// twT = the step-B twiddles as a [12][33] table (33: rows land on different banks): twT[n2 * 33 + k1] = w^(n2 k1), so a lane's
+// eight factors sit at immediate offsets from two bases.
+template <bool INV>
+__device__ __forceinline__ void m372_step_a(const float* __restrict__ X, float* __restrict__ T, const float2* __restrict__ twT,
+                                            const float (&cA)[4], const float (&sA)[4], int wave, int lane) {
+    const int l15 = lane & 15, lg = lane >> 4;
+    // both tiles of the wave side by side: two independent dependency chains (loads -> MFMA -> DPP fix-ups -> stores)
+    bool valid[2];
+    int c[2];
+    const float2* wlo[2];  // &twT[n2][4 lg + 1]: factors of rows k = 4 lg + 1 + r
+    const float2* whi[2];  // &twT[n2][30 - 4 lg]: factors of rows 31 - k
+    float* Tc[2];
+    float xa[2][4], xb[2][4], x0[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int col_raw = (wave + 4 * tt) * 16 + l15;
+        valid[tt] = col_raw < 2 * 12 * M372_G;
+        const int col = valid[tt] ? col_raw : 2 * 12 * M372_G - 1;  // idle columns of the last tile repeat column 119 (not stored)
+        const int cc = col >> 1;
+        c[tt] = col & 1;
+        const int coil = cc / 12, n2 = cc - 12 * coil;
+        const float* Xc = X + (coil * 372 + n2) * 2 + c[tt] + 24 * (lg + 1);
+        const float* Xd = X + (coil * 372 + n2) * 2 + c[tt] + 24 * (30 - lg);
+        Tc[tt] = T + coil * M372_TC + (2 * n2 + c[tt]) * M372_TS + 4 * lg + 1;
+        wlo[tt] = twT + n2 * 33 + 4 * lg + 1;
+        whi[tt] = twT + n2 * 33 + 30 - 4 * lg;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {  // t = 4 ks + lg + 1; t = 16 (ks = lg = 3) is a real element whose matrix column is zero
+            xa[tt][ks] = Xc[96 * ks];
+            xb[tt][ks] = Xd[-96 * ks];
+        }
+        x0[tt] = Xc[-24 * (lg + 1)];
+    }
+    mfx4 accA[2], accB[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        accA[tt] = (mfx4){0.f, 0.f, 0.f, 0.f};
+        accB[tt] = (mfx4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            accA[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cA[ks], xa[tt][ks] + xb[tt][ks], accA[tt], 0, 0, 0);
+            accB[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sA[ks], xa[tt][ks] - xb[tt][ks], accB[tt], 0, 0, 0);
+        }
+    const bool ones_row = lg == 3;  // this lane's r = 3 is matrix row 16 (the row of ones): X_0 = x0 + sum_t a_t, twiddle 1
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        // forward: X_k = x0 + A - i B (re: + B_im, im: - B_re), X_{31-k} = x0 + A + i B; inverse: signs of B exchanged
+        const float sgn = ((c[tt] == 0) != INV) ? 1.f : -1.f;
+        const float tsg = ((c[tt] == 0) != INV) ? -1.f : 1.f;  // y * w (w conjugated for the inverse)
+        float o1[4], o2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float2 w1 = wlo[tt][r], w2 = whi[tt][-r];
+            const float bs = sgn * m372_swap(accB[tt][r]);
+            const float t0 = x0[tt] + accA[tt][r];
+            const float y1 = t0 + bs, y2 = t0 - bs;
+            o1[r] = y1 * w1.x + tsg * (m372_swap(y1) * w1.y);
+            o2[r] = y2 * w2.x + tsg * (m372_swap(y2) * w2.y);
+            if (r == 3 && ones_row) o1[r] = t0;
+        }
+        if (valid[tt]) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                Tc[tt][r] = o1[r];
+                Tc[tt][29 - 8 * lg - r] = o2[r];  // 31 - k relative to the base 4 lg + 1
+            }
+            // r = 3: rows k = 4 lg + 4 and 31 - k, except in the lg = 3 lanes, which hold X_0 (slot 0) and nothing else (slot 31: pad)
+            Tc[tt][ones_row ? -13 : 3] = o1[3];
+            Tc[tt][ones_row ? 18 : 26 - 8 * lg] = o2[3];
+        }
+    }
+}
+
+template <bool INV>
+__device__ __forceinline__ void m372_step_c(const float* __restrict__ T, float2* __restrict__ X, const float* __restrict__ m24l, int wave, int lane) {
+    const int l15 = lane & 15, lg = lane >> 4;
+    float m24[2][6];  // per-lane operand constants from LDS (lane-linear, conflict-free)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) m24[t][ks] = m24l[(((INV ? 2 : 0) + t) * 6 + ks) * 64 + lane];
+    for (int tile = wave; tile < 10; tile += 4) {
+        const int col_raw = tile * 16 + l15;
+        const bool valid = col_raw < 31 * M372_G;
+        const int col = valid ? col_raw : 31 * M372_G - 1;
+        const int coil = col / 31, k1 = col - 31 * coil;
+        const float* Tc = T + coil * M372_TC + k1;
+        float v[6];
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) v[ks] = Tc[(4 * ks + lg) * M372_TS];
+        mfx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(m24[0][ks], v[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(m24[1][ks], v[ks], acc1, 0, 0, 0);
+        }
+        if (valid) {
+            float2* Xc = X + coil * 372 + k1;
+            Xc[31 * (2 * lg)] = make_float2(acc0[0], acc0[1]);
+            Xc[31 * (2 * lg + 1)] = make_float2(acc0[2], acc0[3]);
+            if (lg < 2) {
+                Xc[31 * (8 + 2 * lg)] = make_float2(acc1[0], acc1[1]);
+                Xc[31 * (9 + 2 * lg)] = make_float2(acc1[2], acc1[3]);
+            }
+        }
+    }
+}
+
+__device__ unsigned long long* g_m372_trace = nullptr;  // debug only (env MRX_TRACE): 8 cycle stamps per workgroup (first item)
+#define M372_STAMP(i) \
+    if (trc && threadIdx.x == 0 && first) trc[(long long)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();
+// Persistent: gridDim.x workgroups (3 per CU) walk the (row, batch) pairs and, inside a row, its coil chunks, keeping the coil sum
+// in registers (no partial sums in memory, no combine launch); the maps of the NEXT chunk and the hybrid-space data of the
+// current one are fetched into registers while the matrix pipe is busy.  Everything that depends on
+// the thread only (element -> (coil row, column, byte offset)) is computed once per workgroup; per item the global operands are
+// addressed as scalar base + 32-bit lane offset, so the element-wise steps are loads, 4-6 FMAs and an LDS access each.
+__global__ __launch_bounds__(MRX_FFT_NT, 3) void k_llg_rows_hinv_mfma372(const float2* __restrict__ eta, const float2* __restrict__ yt,
+                                                                          const float2* __restrict__ S, MrxMask mask,
+                                                                          float* __restrict__ out4, ReduceArgs a, float scale_f,
+                                                                          M372Tables tb, int nB, int nchunks, int abl) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    constexpr int W = 372, G = M372_G;
+    constexpr int NE = (G * W + MRX_FFT_NT - 1) / MRX_FFT_NT;  // 8; elements tid + 256 e, all < G W except e = 7 for tid >= 68
+    const int H = a.H, C = a.C;
+    unsigned long long* trc = g_m372_trace;
+    float2* tw = smem;  // [12][33] step-B twiddles
+    float* Mk = reinterpret_cast<float*>(tw + 12 * 33);
+    float2* E = tw + 12 * 33 + W / 2;
+    float2* Xa = E + W;
+    float* T = reinterpret_cast<float*>(Xa + G * W);
+    float* M24 = T + G * M372_TC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool mask_lds = mask.s[1] == 0;
+    const int nitems = H * nB * nchunks;  // item = (row pair index) * nchunks + chunk; a workgroup owns whole rows
+    float cA[4], sA[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        cA[ks] = tb.ca[ks * 64 + lane];
+        sA[ks] = tb.sa[ks * 64 + lane];
+    }
+    for (int i = tid; i < 12 * 33; i += MRX_FFT_NT) tw[i] = a.tw[((i / 33) * (i % 33)) % W];  // twT[n2][k1] = w^(n2 k1)
+    for (int i = tid; i < 4 * 6 * 64; i += MRX_FFT_NT) M24[i] = tb.m24[i];
+    // per-thread element table
+    unsigned goff[NE];   // byte offset of element e inside the (b, c0, h) operand block: (r H W + shifted(x)) * 8
+    unsigned short xe[NE];  // column x of element e
+    unsigned rpack = 0;  // coil row r of element e (3 bits each)
+    const bool last_ok = tid + (NE - 1) * MRX_FFT_NT < G * W;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        int idx = tid + e * MRX_FFT_NT;
+        idx = idx < G * W ? idx : G * W - 1;
+        const int r = idx / W, x = idx - r * W;
+        goff[e] = (unsigned)((long long)r * H * W + shifted(x, a.halfW, W)) * 8u;
+        xe[e] = (unsigned short)x;
+        rpack |= (unsigned)r << (3 * e);
+    }
+    const unsigned eoff0 = (unsigned)shifted(tid, a.halfW, W) * 8u;
+    const unsigned eoff1 = (unsigned)shifted(tid + MRX_FFT_NT < W ? tid + MRX_FFT_NT : W - 1, a.halfW, W) * 8u;
+    auto decode = [&](int item, int& h, long long& b, int& z) {
+        z = item % nchunks;
+        const int row = item / nchunks;
+        h = row % H;
+        b = row / H;
+    };
+    // sequence of this workgroup: rows blockIdx.x, blockIdx.x + gridDim.x, ...; all chunks of a row back to back
+    auto next_item = [&](int item) { return (item % nchunks) + 1 < nchunks ? item + 1 : (item / nchunks + (int)gridDim.x) * nchunks; };
+    // maps sv (live for the whole item), hybrid-space data yv (fetched after the expansion, consumed by the mask step), the next
+    // item's maps sn + eta row en (fetched after the mask step, when yv is dead): two sets of NE registers at any time
+    float2 sv[NE], ev[2];
+    auto fetch_s = [&](int item, float2 (&s_)[NE], float2 (&e_)[2]) {
+        int h, z;
+        long long b;
+        decode(item, h, b, z);
+        const int c0 = z * G;
+        const char* sb = reinterpret_cast<const char*>(S + (((b / a.sdiv) * C + c0) * H + h) * (long long)W);
+        const char* eb = reinterpret_cast<const char*>(eta + (b * H + h) * (long long)W);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const bool ok = c0 + (int)((rpack >> (3 * e)) & 7u) < C && (e < NE - 1 || last_ok);
+            s_[e] = ok ? *reinterpret_cast<const float2*>(sb + goff[e]) : make_float2(0.f, 0.f);
+        }
+        e_[0] = *reinterpret_cast<const float2*>(eb + eoff0);
+        e_[1] = *reinterpret_cast<const float2*>(eb + eoff1);
+    };
+    bool first = true;
+    long long b_mask = -1;
+    int item = blockIdx.x * nchunks;
+    float2 gsum[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};  // coil sum of columns tid, tid + 256 over the chunks of the row
+    M372_STAMP(0)
+    if (item < nitems) fetch_s(item, sv, ev);
+    for (; item < nitems; item = next_item(item)) {
+        int h, z;
+        long long b;
+        decode(item, h, b, z);
+        const int c0 = z * G;
+        // the previous item's readers of E / Mk / Xa are past the barrier that ended it
+        E[tid] = ev[0];
+        if (tid + MRX_FFT_NT < W) E[tid + MRX_FFT_NT] = ev[1];
+        if (mask_lds && b != b_mask) {
+            for (int i = tid; i < W; i += MRX_FFT_NT) Mk[i] = mrx_mask_val(mask, b, 0, 0, shifted(i, a.halfW, W));
+            b_mask = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (e < NE - 1 || last_ok) {
+                const float2 e2 = E[xe[e]];
+                Xa[tid + e * MRX_FFT_NT] = make_float2(e2.x * sv[e].x - e2.y * sv[e].y, e2.x * sv[e].y + e2.y * sv[e].x);  // rim_utils.py:47-48
+            }
+        }
+        float2 yv[NE];  // in flight during the forward transform
+        {
+            const char* yb = reinterpret_cast<const char*>(yt + ((b * C + c0) * H + h) * (long long)W);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const bool ok = c0 + (int)((rpack >> (3 * e)) & 7u) < C && (e < NE - 1 || last_ok);
+                yv[e] = ok ? *reinterpret_cast<const float2*>(yb + goff[e]) : make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        M372_STAMP(1)
+        int lane_o = lane;  // opaque per call: the per-lane LDS addresses of the steps are recomputed, not kept across items
+        asm volatile("" : "+v"(lane_o));
+        if (!(abl & 1)) m372_step_a<false>(reinterpret_cast<const float*>(Xa), T, tw, cA, sA, wave, lane_o);
+        __syncthreads();
+        M372_STAMP(2)
+        asm volatile("" : "+v"(lane_o));
+        if (!(abl & 2)) m372_step_c<false>(T, Xa, M24, wave, lane_o);
+        __syncthreads();
+        M372_STAMP(3)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (e < NE - 1 || last_ok) {
+                const float m = mask_lds ? Mk[xe[e]]
+                                         : mrx_mask_val(mask, b, c0 + (int)((rpack >> (3 * e)) & 7u), 0, shifted(xe[e], a.halfW, W));
+                const float2 k = Xa[tid + e * MRX_FFT_NT];
+                Xa[tid + e * MRX_FFT_NT] = make_float2(m * (k.x * scale_f - yv[e].x), m * (k.y * scale_f - yv[e].y));  // rim_utils.py:54
+            }
+        }
+        float2 sn[NE], en[2];  // next item's maps and eta row: in flight during the inverse transform
+        const bool more = next_item(item) < nitems;
+        if (more) fetch_s(next_item(item), sn, en);
+        __syncthreads();
+        M372_STAMP(4)
+        asm volatile("" : "+v"(lane_o));
+        if (!(abl & 1)) m372_step_a<true>(reinterpret_cast<const float*>(Xa), T, tw, cA, sA, wave, lane_o);
+        __syncthreads();
+        M372_STAMP(5)
+        asm volatile("" : "+v"(lane_o));
+        if (!(abl & 2)) m372_step_c<true>(T, Xa, M24, wave, lane_o);
+        __syncthreads();
+        M372_STAMP(6)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (e < NE - 1 || last_ok) {
+                float2 v = Xa[tid + e * MRX_FFT_NT];
+                v.x *= a.scale;
+                v.y *= a.scale;
+                Xa[tid + e * MRX_FFT_NT] = make_float2(v.x * sv[e].x + v.y * sv[e].y, v.y * sv[e].x - v.x * sv[e].y);  // rim_utils.py:61-62
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int x = tid + e * MRX_FFT_NT;
+            if (x < W) {
+                float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < G; ++r) {
+                    const float2 v = Xa[r * W + x];   // rows beyond C are zero
+                    sum.x += v.x;
+                    sum.y += v.y;
+                }
+                gsum[e].x = z == 0 ? sum.x : gsum[e].x + sum.x;
+                gsum[e].y = z == 0 ? sum.y : gsum[e].y + sum.y;
+                if (z == nchunks - 1) {  // (eta_re, eta_im, g_re / sigma^2, g_im / sigma^2)   rim_utils.py:61-67
+                    const float2 e2 = E[x];
+                    const long long plane = (long long)H * W;
+                    float* o = out4 + b * 4 * plane + (long long)h * W + shifted(x, a.halfW, W);
+                    o[0] = e2.x;
+                    o[plane] = e2.y;
+                    o[2 * plane] = gsum[e].x * a.post;
+                    o[3 * plane] = gsum[e].y * a.post;
+                }
+            }
+        }
+        M372_STAMP(7)
+        first = false;
+        if (more) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) sv[e] = sn[e];
+            ev[0] = en[0];
+            ev[1] = en[1];
+        }
+        __syncthreads();  // Xa / E free for the next item
+    }
+}
+
+// per-lane MFMA operand tables of the kernel above (built once, device-resident)
+static int m372_tables(M372Tables* out) {
+    static M372Tables t = {nullptr, nullptr, nullptr};
+    if (!t.ca) {
+        std::vector<float> ca(4 * 64), sa(4 * 64), m24(2 * 2 * 6 * 64);
+        for (int ks = 0; ks < 4; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int k = (lane & 15) + 1, tt = 4 * ks + (lane >> 4) + 1;
+                const double th = 2.0 * M_PI * (double)((k * tt) % 31) / 31.0;
+                ca[ks * 64 + lane] = tt > 15 ? 0.f : (k == 16 ? 1.f : (float)cos(th));
+                sa[ks * 64 + lane] = (tt > 15 || k == 16) ? 0.f : (float)sin(th);
+            }
+        for (int inv = 0; inv < 2; ++inv)
+            for (int tile = 0; tile < 2; ++tile)
+                for (int ks = 0; ks < 6; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = tile * 16 + (lane & 15), rho = 4 * ks + (lane >> 4);
+                        float v = 0.f;
+                        if (m < 24) {
+                            const int k2 = m >> 1, co = m & 1, n2 = rho >> 1, ci = rho & 1;
+                            const double ph = 2.0 * M_PI * (double)((k2 * n2) % 12) / 12.0;
+                            const double fr = cos(ph), fi = inv ? sin(ph) : -sin(ph);
+                            v = (float)(co == ci ? fr : (co == 0 ? -fi : fi));
+                        }
+                        m24[((inv * 2 + tile) * 6 + ks) * 64 + lane] = v;
+                    }
+        float *d_ca, *d_sa, *d_m;
+        MRX_HIP(hipMalloc((void**)&d_ca, sizeof(float) * ca.size()));
+        MRX_HIP(hipMalloc((void**)&d_sa, sizeof(float) * sa.size()));
+        MRX_HIP(hipMalloc((void**)&d_m, sizeof(float) * m24.size()));
+        MRX_HIP(hipMemcpy(d_ca, ca.data(), sizeof(float) * ca.size(), hipMemcpyHostToDevice));
+        MRX_HIP(hipMemcpy(d_sa, sa.data(), sizeof(float) * sa.size(), hipMemcpyHostToDevice));
+        MRX_HIP(hipMemcpy(d_m, m24.data(), sizeof(float) * m24.size(), hipMemcpyHostToDevice));
+        t.ca = d_ca;
+        t.sa = d_sa;
+        t.m24 = d_m;
+    }
+    *out = t;
+    return MRX_OK;
+}
+
 // out4[b] = (eta_re, eta_im, post * sum_k part_k.re, post * sum_k part_k.im)   (rim_utils.py:61-67)
 __global__ void k_llg_combine(const float2* __restrict__ eta, const float2* __restrict__ part, float* __restrict__ out, int nparts,
                               long long B, long long plane, float post) {
@@ -828,6 +1196,10 @@ extern "C" int mrx_fft_prepare(int h, int w) {
     MrxFftEntry e;
     int rc = mrx_get_plan(h, &e);
     if (rc) return rc;
+    if (w == 372) {
+        M372Tables tb;
+        if ((rc = m372_tables(&tb))) return rc;
+    }
     return mrx_get_plan(w, &e);
 }
 
@@ -911,6 +1283,46 @@ template <class P, int NSEQ>
 static int launch_hinv_p(const float2* eta, const float2* yt, const float2* S, const MrxMask& m, float* out, float* part,
                          dim3 grid, size_t lds, const ReduceArgs& a, float scale_f, hipStream_t st) {
     const int nchunks = mrx_cdiv(a.C, a.g);
+    // experimental (MRX_LLG_MFMA=1): measured 46.8 us vs 44.2 us for the vector-ALU kernels below at 15 x 640 x 372 -- kept selectable
+    if (P::kCT && P::N == 372 && NSEQ == M372_G && getenv("MRX_LLG_MFMA")) {
+            M372Tables tb;
+            int rc = m372_tables(&tb);  // (first call allocates: mrx_fft_prepare does it eagerly, before any graph capture)
+            if (rc) return rc;
+            const size_t lds_m = sizeof(float2) * (12 * 33 + 372 + 372 / 2 + (size_t)M372_G * 372) + sizeof(float) * (M372_G * M372_TC + 4 * 6 * 64);
+            rc = set_lds(k_llg_rows_hinv_mfma372, lds_m);
+            if (rc) return rc;
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                MRX_HIP(hipGetDevice(&dev));
+                MRX_HIP(hipGetDeviceProperties(&prop, dev));
+                n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            }
+            const long long nrows = (long long)grid.x * grid.y;
+            const unsigned nblk = (unsigned)(nrows < 3ll * n_cu ? nrows : 3ll * n_cu);
+            static unsigned long long* d_trace = nullptr;
+            if (getenv("MRX_TRACE") && !d_trace) {
+                (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 8 * 65536);
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_m372_trace), &d_trace, sizeof(d_trace));
+            }
+            hipLaunchKernelGGL(k_llg_rows_hinv_mfma372, dim3(nblk), dim3(MRX_FFT_NT), lds_m, st, eta, yt, S, m, out, a, scale_f, tb,
+                               (int)grid.y, nchunks, getenv("MRX_ABLATE") ? atoi(getenv("MRX_ABLATE")) : 0);
+            if (d_trace && getenv("MRX_TRACE_DUMP")) {
+                (void)hipStreamSynchronize(st);
+                const int nb = (int)nblk;
+                std::vector<unsigned long long> hh((size_t)nb * 8);
+                (void)hipMemcpy(hh.data(), d_trace, sizeof(unsigned long long) * 8 * nb, hipMemcpyDeviceToHost);
+                double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < nb; ++i)
+                    for (int k = 0; k < 7; ++k) ph[k] += (double)(hh[(size_t)i * 8 + k + 1] - hh[(size_t)i * 8 + k]);
+                fprintf(stderr, "[mrx-trace] k_llg_rows_hinv_mfma372 %d workgroups (first item), mean cycles: load+expand %.0f | A %.0f | C %.0f | "
+                                "mask %.0f | A^-1 %.0f | C^-1 %.0f | conj(S) sum + store %.0f\n", nb, ph[0] / nb, ph[1] / nb, ph[2] / nb, ph[3] / nb,
+                        ph[4] / nb, ph[5] / nb, ph[6] / nb);
+            }
+        MRX_LAUNCH_CHECK();
+        return MRX_OK;
+    }
     if (part && nchunks > 1) {
         dim3 g3(grid.x, grid.y, nchunks);
         if constexpr (P::kCT) {
