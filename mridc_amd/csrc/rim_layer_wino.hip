@@ -126,23 +126,41 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     float* Us = Xs + 2 * WN_XBUF;                // [2][16][4][64][2]
     float* Vs = Us + 2 * WN_UCHUNK;              // [2][16][4][64][2]
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, lg = lane >> 4;  // 16x16x4 operand lane split: column / k index
     const int cot = wave & 1, par = wave >> 1;
     const int py = par >> 1, px = par & 1;
+    // Everything that depends on the lane only is re-derived per tile from a laundered copy of the lane id (refresh_lane): left to
+    // the compiler it is all hoisted out of the persistent tile loop, and the ~90 extra live registers spill.
+    int lane = tid & 63;
+    int l15, lg;  // 16x16x4 operand lane split: column / k index
+    unsigned uoff;
+    int t_pos, t_dst, m_a0, m_a1, m_b;
+    auto refresh_lane = [&]() {
+        asm volatile("" : "+v"(lane));
+        l15 = lane & 15;
+        lg = lane >> 4;
+        uoff = (unsigned)lane * 16u;
+        // input transform: lane -> tile (tbx = lane&7, px = lane>>3 &1, py = lane>>4 &1, tby = lane>>5), wave -> channel
+        t_pos = (lane & 7) + 8 * (((lane >> 3) & 1) ^ (lane >> 5)) + 16 * ((lane >> 4) & 1) + 32 * (lane >> 5);
+        t_dst = ((wave >> 1) * WN_F + (t_pos ^ (16 * ((wave >> 1) & 1)))) * 2 + (wave & 1);
+        const int m_sw = 16 * (lg & 1);
+        m_a0 = (lg * WN_F + ((32 * cot + l15) ^ m_sw)) * 2;
+        m_a1 = (lg * WN_F + ((32 * cot + 16 + l15) ^ m_sw)) * 2;
+        m_b = (lg * WN_F + (((l15 & 7) + 8 * (px ^ (l15 >> 3)) + 16 * py + 32 * (l15 >> 3)) ^ m_sw)) * 2;
+    };
+    refresh_lane();
 
-    int tile = blockIdx.x;
-    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
-    const int ty0 = tile / a.tiles_x;
-    const int h0 = ty0 * 8, w0 = (tile - ty0 * a.tiles_x) * 32;
-    const int b = blockIdx.y;
+    // Persistent: gridDim.x workgroups (one per CU: the kernel owns all 160 KB of LDS) walk the tiles; virtual index v -> tile keeps
+    // every XCD (v & 7 = blockIdx.x & 7 when gridDim.x % 8 == 0) on its own contiguous band of tiles (halo reuse in its L2).
     const long long plane = (long long)a.H * a.W;
-    const float* xb = a.x + (long long)b * a.Cin * plane;
     const int nchunks = (a.Cin + WN_CK - 1) / WN_CK;
+    const int nt_total = a.ntiles * a.B;
+    int h0 = 0, w0 = 0, b = 0;
+    const float* xb = a.x;
+    bool first = true;
 
 #define WN_STAMP(i) \
-    if (a.trace && tid == 0) a.trace[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter();
+    if (a.trace && tid == 0 && first) a.trace[(long long)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();
     WN_STAMP(0)
 
     // ---- LDS-DMA work list of this wave: 4 copies of 1 KB of the packed U image (n = wave + 8 m) and the raw tile of channel
@@ -150,26 +168,44 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     // (scalar registers, advanced on the scalar unit) plus a fixed per-lane byte offset: no vector instructions per copy.
     constexpr int NXM = X4 ? 2 : 8;  // raw-tile DMA instructions per wave and chunk
     unsigned xoff[NXM];
+    int t_col[4];  // LDS offsets of the four patch columns in the first patch row (X4: column replicate border applied here)
+    auto set_tile = [&](int v) {  // tile coordinates and the per-lane DMA / gather offsets that depend on them
+        b = v / a.ntiles;
+        int t = v - b * a.ntiles;
+        if ((a.ntiles & 7) == 0 && (gridDim.x & 7) == 0) t = (t & 7) * (a.ntiles >> 3) + (t >> 3);
+        const int ty0 = t / a.tiles_x;
+        h0 = ty0 * 8;
+        w0 = (t - ty0 * a.tiles_x) * 32;
+        xb = a.x + (long long)b * a.Cin * plane;
 #pragma unroll
-    for (int m = 0; m < NXM; ++m) {
-        int sl = m * 64 + lane, gy, gx;  // float4 (X4) or element slot of the plane; slots past the tile repeat its last one
-        if (X4) {
-            sl = sl < 12 * (XS / 4) ? sl : 12 * (XS / 4) - 1;
-            const int ry = sl / (XS / 4), c4 = sl - ry * (XS / 4);
-            gy = h0 + ry - 2;
-            gx = w0 - OX + 4 * c4;  // whole groups outside the image fetch the nearest inside one; the gather never reads them
-            gx = gx < 0 ? 0 : (gx > a.W - 4 ? a.W - 4 : gx);
-        } else {
-            sl = sl < 12 * XS ? sl : 12 * XS - 1;
-            const int ry = sl / XS, rx = sl - ry * XS;
-            gy = h0 + ry - 2;
-            gx = w0 + rx - OX;
-            gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+        for (int m = 0; m < NXM; ++m) {
+            int sl = m * 64 + lane, gy, gx;  // float4 (X4) or element slot of the plane; slots past the tile repeat its last one
+            if (X4) {
+                sl = sl < 12 * (XS / 4) ? sl : 12 * (XS / 4) - 1;
+                const int ry = sl / (XS / 4), c4 = sl - ry * (XS / 4);
+                gy = h0 + ry - 2;
+                gx = w0 - OX + 4 * c4;  // whole groups outside the image fetch the nearest inside one; the gather never reads them
+                gx = gx < 0 ? 0 : (gx > a.W - 4 ? a.W - 4 : gx);
+            } else {
+                sl = sl < 12 * XS ? sl : 12 * XS - 1;
+                const int ry = sl / XS, rx = sl - ry * XS;
+                gy = h0 + ry - 2;
+                gx = w0 + rx - OX;
+                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+            }
+            gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+            xoff[m] = (unsigned)(gy * a.W + gx) * 4u;
         }
-        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-        xoff[m] = (unsigned)(gy * a.W + gx) * 4u;
-    }
-    const unsigned uoff = (unsigned)lane * 16u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = 4 * (lane & 7) + ((lane >> 3) & 1) + 2 * j + OX - 2;  // tile column of image column w0 - OX + c
+            if (X4) {
+                const int lo = OX - w0, hi = a.W - 1 - w0 + OX;
+                c = c < lo ? lo : (c > hi ? hi : c);
+            }
+            t_col[j] = wave * WN_XPLANE + (4 * (lane >> 5) + ((lane >> 4) & 1)) * XS + c;
+        }
+    };
     auto dma_u = [&](int q, int m) {  // m in 0..3
         const int n = wave + 8 * m;
         const char* src = reinterpret_cast<const char*>(a.packed + (long long)q * WN_UCHUNK + n * 256);
@@ -186,18 +222,6 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
 
     // ---- input transform: lane -> tile (tbx = lane&7, px = lane>>3 &1, py = lane>>4 &1, tby = lane>>5), wave -> channel.
     // V = B^T d B with d[i][j] = raw[4 tby + py + 2i][4 tbx + px + 2j]; written to column pos(tile) of row (xi, j = ci>>1).
-    int t_col[4];  // LDS offsets of the four patch columns in the first patch row (X4: column replicate border applied here)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int c = 4 * (lane & 7) + ((lane >> 3) & 1) + 2 * j + OX - 2;  // tile column of image column w0 - OX + c
-        if (X4) {
-            const int lo = OX - w0, hi = a.W - 1 - w0 + OX;
-            c = c < lo ? lo : (c > hi ? hi : c);
-        }
-        t_col[j] = wave * WN_XPLANE + (4 * (lane >> 5) + ((lane >> 4) & 1)) * XS + c;
-    }
-    const int t_pos = (lane & 7) + 8 * (((lane >> 3) & 1) ^ (lane >> 5)) + 16 * ((lane >> 4) & 1) + 32 * (lane >> 5);
-    const int t_dst = ((wave >> 1) * WN_F + (t_pos ^ (16 * ((wave >> 1) & 1)))) * 2 + (wave & 1);
     auto transform = [&](int q) {  // stand-alone form (prologue only; later chunks ride inside the MFMA loop)
         const float* src = Xs + (q & 1) * WN_XBUF;
         float d[4][4];
@@ -224,21 +248,11 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     };
 
     f32x4 acc[16][2];
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[xi][h][r] = 0.f;
 
     // ---- one chunk: 16 steps of {4 MFMAs, operand reads for 3 steps ahead}.  The fp32 matrix pipe is the SIMD's fp32 vector
     // pipe (157 TFLOP/s either way): every other VALU instruction costs it 3-4 cycles (measured: tools/probe/filler_probe*),
     // LDS and scalar instructions almost nothing.  So the DMA for the following chunks and the input transform of the next one
     // ride along inside the loop with almost no address arithmetic (immediate offsets, scalar bases).
-    const int m_sw = 16 * (lg & 1);
-    const int m_a0 = (lg * WN_F + ((32 * cot + l15) ^ m_sw)) * 2;
-    const int m_a1 = (lg * WN_F + ((32 * cot + 16 + l15) ^ m_sw)) * 2;
-    const int m_b = (lg * WN_F + (((l15 & 7) + 8 * (px ^ (l15 >> 3)) + 16 * py + 32 * (l15 >> 3)) ^ m_sw)) * 2;
     auto chunk = [&](int q) {
         const int PAR = q & 1;
         const float* ua0 = Us + PAR * WN_UCHUNK + m_a0;
@@ -315,28 +329,55 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
         __syncthreads();                                   // ... everyone's, and V(q) is written; the buffers of q - 1 are free
     };
 
-    // ---- prologue: U(0), X(0), X(1) -> LDS, V(0) ---------------------------------------------------------------------
+    auto prologue = [&]() {  // U(0), X(0), X(1) of the tile set by set_tile -> LDS
 #pragma unroll
-    for (int m = 0; m < 4; ++m) dma_u(0, m);
+        for (int m = 0; m < 4; ++m) dma_u(0, m);
 #pragma unroll
-    for (int m = 0; m < NXM; ++m) dma_x(0, m);
-    if (nchunks > 1) {
+        for (int m = 0; m < NXM; ++m) dma_x(0, m);
+        if (nchunks > 1) {
 #pragma unroll
-        for (int m = 0; m < NXM; ++m) dma_x(1, m);
+            for (int m = 0; m < NXM; ++m) dma_x(1, m);
+        }
+    };
+    int v = blockIdx.x;
+    if (v < nt_total) {
+        set_tile(v);
+        prologue();
     }
-    sync();
+#pragma nounroll
+    for (; v < nt_total; v += gridDim.x) {
+    refresh_lane();
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[xi][h][r] = 0.f;
+    sync();  // prologue data landed; the previous tile's epilogue is out of LDS
     transform(0);
 #pragma nounroll
     for (int q = 0; q < nchunks; ++q) {  // one body for all chunks: the accumulators stay in place
         sync();
         chunk(q);
     }
-    __syncthreads();  // all waves done with U / V: LDS becomes Y[64][256] (ReLU(conv + b)) followed by the ih weights
+    __syncthreads();  // all waves done with U / V
     WN_STAMP(1)
+    // The tail of this tile lives in the upper LDS (ih weights in U[1], Y and the transpose tiles in V[0..1]); the lower 64 KB
+    // (raw tiles, U[0]) take the next tile's prologue DMA now, so its latency hides behind the tail.
+    const int ch0 = h0, cw0 = w0, cb = b;
+    float* Ys = Vs;
+    float* Wi = Us + WN_UCHUNK;
+    {
+        const char* src = reinterpret_cast<const char*>(a.packed + (long long)nchunks * WN_UCHUNK + wave * 512);
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL(src + uoff), WN_SHARED(Wi + wave * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL(src + 1024 + uoff), WN_SHARED(Wi + wave * 512 + 256), 16, 0, 0);
+    }
+    if (v + (int)gridDim.x < nt_total) {
+        set_tile(v + gridDim.x);
+        prologue();
+    }
 
     // ---- output transform Y = A^T M A per lane, bias, ReLU -> Ys[cout][8 rows x 32 cols] ------------------------------
-    float* Ys = smem_f;
-    float* Wi = smem_f + WN_F * 256;
     {
         const int tby = l15 >> 3, tbx = l15 & 7;
         const int prow = 4 * tby + py, pcol = 4 * tbx + px;
@@ -365,21 +406,17 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
                 yo[66] = y11;
             }
     }
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.packed + (long long)nchunks * WN_UCHUNK);
-        float4* dst = reinterpret_cast<float4*>(Wi);
-        for (int i = tid; i < WN_F * WN_F / 4; i += WN_NT) dst[i] = src[i];
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ih weights landed (and, long before they are needed, the next prologue)
     __syncthreads();
     WN_STAMP(2)
 
     // ---- 1x1 ih GEMM (32x32x2 MFMA, wave = image row) + wide epilogue: same as k_rim_layer, B operand read from Ys ------
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int oy = h0 + wave;
+    const int oy = ch0 + wave;
     const bool wide = (a.W & 3) == 0;
     const int wch = lane >> 3, wpx = (lane & 7) * 4;
-    const long long wbase = (long long)b * WN_F * plane + (long long)oy * a.W + w0 + wpx;
-    const bool winside = oy < a.H && (w0 + wpx) < a.W;
+    const long long wbase = (long long)cb * WN_F * plane + (long long)oy * a.W + cw0 + wpx;
+    const bool winside = oy < a.H && (cw0 + wpx) < a.W;
     float4 hp4[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -414,9 +451,9 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     }
     __syncthreads();  // Ys / Wi consumed by every wave: LDS becomes 8 wave-private [64][32] transpose tiles
     WN_STAMP(3)
-    const int ox = w0 + l31;
+    const int ox = cw0 + l31;
     if (wide) {
-        float* T = smem_f + wave * (WN_F * 32);
+        float* T = Ys + wave * (WN_F * 32);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -441,7 +478,7 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             if (winside) *reinterpret_cast<float4*>(a.hnew + wbase + (long long)ch * plane) = v;
         }
     } else if (oy < a.H && ox < a.W) {
-        const long long obase = (long long)b * WN_F * plane + (long long)oy * a.W + ox;
+        const long long obase = (long long)cb * WN_F * plane + (long long)oy * a.W + ox;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -454,13 +491,15 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             }
     }
     WN_STAMP(4)
-    if (a.trace && tid == 0) {
+    if (a.trace && tid == 0 && first) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        a.trace[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] =
+        a.trace[(long long)blockIdx.x * 8 + 6] =
             ((unsigned long long)(xcc & 0xf) << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 12) & 1) << 4) | ((hwid >> 8) & 15);
     }
+    first = false;
+    }  // tile loop
 }
 
 extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, const float* b_conv, const float* b_ih,
@@ -469,7 +508,6 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
     MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer_indrnn_wino: null pointer");
     MRX_REQUIRE(B >= 0 && Cin >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer_indrnn_wino: bad dims");
     MRX_REQUIRE(F == WN_F, MRX_EUNSUP, "mrx_rim_layer_indrnn_wino: hidden size %d (only %d)", F, WN_F);
-    MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "mrx_rim_layer_indrnn_wino: batch %d too large", B);
     if (B == 0) return MRX_OK;
     WinoArgs a;
     a.x = x;
@@ -507,11 +545,22 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 8 * 65536, (hipStream_t)stream);
         a.trace = d_trace;
     }
-    hipLaunchKernelGGL(kern, dim3(a.ntiles, a.B), dim3(WN_NT), lds, (hipStream_t)stream, a);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MRX_HIP(hipGetDevice(&dev));
+        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long nt_total = (long long)a.ntiles * a.B;
+    MRX_REQUIRE(nt_total < (1ll << 31), MRX_EUNSUP, "mrx_rim_layer_indrnn_wino: %lld tiles", nt_total);
+    const unsigned nblk = (unsigned)(nt_total < n_cu ? nt_total : n_cu);  // persistent: one workgroup per CU walks the tiles
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(WN_NT), lds, (hipStream_t)stream, a);
     MRX_LAUNCH_CHECK();
     if (a.trace && getenv("MRX_TRACE_DUMP")) {
         (void)hipStreamSynchronize((hipStream_t)stream);
-        const int nb = a.ntiles * a.B;
+        const int nb = (int)nblk;
         std::vector<unsigned long long> h((size_t)nb * 8);
         (void)hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * 8 * nb, hipMemcpyDeviceToHost);
         double ph[4] = {0, 0, 0, 0};
