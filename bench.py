@@ -35,7 +35,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1, help="slices per GPU per step")
+    ap.add_argument("--batch", type=int, default=1, help="slices per stream per step")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent slice batches reconstructed concurrently per GPU, one HIP stream + one captured hipGraph each "
+                         "(slices are independent: two in flight fill each other's launch tails and stalls; 1 = single stream)")
     ap.add_argument("--coils", type=int, default=15)
     ap.add_argument("--height", type=int, default=640)
     ap.add_argument("--width", type=int, default=372)
@@ -171,22 +174,31 @@ def main():
     state_dict = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     B, C, H, W = args.batch, args.coils, args.height, args.width
-    # each rank reconstructs its own contiguous share of the world*B slices: embarrassingly parallel, no collective
+    NS = max(1, args.streams)
+    # each rank reconstructs its own contiguous share of the world*NS*B slices: embarrassingly parallel, no collective
     from mridc_amd.sharding import shard_range
-    s0, s1 = shard_range(world * B, rank, world)
-    slices = [synthetic.make_slice(C, H, W, slice_idx=i) for i in range(s0, s1)]
-    host = {k: torch.cat([s[k] for s in slices], 0) for k in ("y", "sensitivity_maps", "target")}
-    host["mask"] = slices[0]["mask"]
-    if args.mask == "2d":                               # k-space re-masked with a 2-D pattern (keeps a fully sampled centre)
-        g2 = torch.Generator().manual_seed(7)
-        m2 = torch.rand(1, 1, H, W, 1, generator=g2) < 0.08
-        m2[:, :, :16, :16] = True
-        m2[:, :, -16:, :16] = True
-        m2[:, :, :16, -16:] = True
-        m2[:, :, -16:, -16:] = True
-        host["mask"] = m2
-        host["y"] = torch.cat([s["kspace"] for s in slices], 0) * m2
-    data = {k: v.to(dev) for k, v in host.items()}
+    s0, s1 = shard_range(world * NS * B, rank, world)
+
+    def make_host(first):
+        slices = [synthetic.make_slice(C, H, W, slice_idx=i) for i in range(first, first + B)]
+        h_ = {k: torch.cat([s[k] for s in slices], 0) for k in ("y", "sensitivity_maps", "target")}
+        h_["mask"] = slices[0]["mask"]
+        if args.mask == "2d":                           # k-space re-masked with a 2-D pattern (keeps a fully sampled centre)
+            g2 = torch.Generator().manual_seed(7)
+            m2 = torch.rand(1, 1, H, W, 1, generator=g2) < 0.08
+            m2[:, :, :16, :16] = True
+            m2[:, :, -16:, :16] = True
+            m2[:, :, :16, -16:] = True
+            m2[:, :, -16:, -16:] = True
+            h_["mask"] = m2
+            h_["y"] = torch.cat([s["kspace"] for s in slices], 0) * m2
+        return h_
+
+    hosts = [make_host(s0 + i * B) for i in range(NS)]
+    assert s0 + NS * B == s1
+    host = hosts[0]
+    datas = [{k: v.to(dev) for k, v in h_.items()} for h_ in hosts]
+    data = datas[0]
     from mridc_amd import _lib
     _lib.check(_lib.lib().mrx_fft_prepare(H, W), "mrx_fft_prepare")
 
@@ -199,9 +211,10 @@ def main():
     timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
     timer.wrap(ops, "rim_final", lambda *a, **k: "final")
 
-    def step():
+    def step(d=None):
+        d = data if d is None else d
         with torch.no_grad():
-            return next(model(data["y"], data["sensitivity_maps"], data["mask"], None, data["target"]))
+            return next(model(d["y"], d["sensitivity_maps"], d["mask"], None, d["target"]))
 
     def barrier():
         if world > 1:
@@ -220,31 +233,42 @@ def main():
         step()
     barrier()
     timer.enabled = False
-    graph, graphed = None, False
+    # One captured hipGraph per stream (392 dependent kernels per slice are launch-bound when issued eagerly).  Per-kernel HIP
+    # events cannot be recorded inside a replay, so the kernel breakdown above was measured on eager steps.
+    streams = [torch.cuda.Stream() for _ in range(NS)]
+    graphs, graphed, outs = [], False, [None] * NS
     if args.graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = step()
-            graph.replay()
+            for i, (d, st) in enumerate(zip(datas, streams)):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    step(d)
+                torch.cuda.current_stream().wait_stream(st)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=st):
+                    outs[i] = step(d)
+                graphs.append(g_)
+            for g_, st in zip(graphs, streams):
+                with torch.cuda.stream(st):
+                    g_.replay()
             torch.cuda.synchronize()
             graphed = True
+            out = outs[0]
         except Exception as ex:  # noqa: BLE001
             print(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
-            graph = None
+            graphs = []
             torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            out = step()
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                if graphs:
+                    graphs[i].replay()
+                else:
+                    o_ = step(datas[i])
+                    if i == 0:
+                        out = o_
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -257,7 +281,7 @@ def main():
         T_ = model.time_steps
         npix = H * W
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * B * args.steps / elapsed
+        value = world * NS * B * args.steps / elapsed
         # dominant kernel: fused layer 2 = conv3x3 dil2 (64->64) + 1x1 ih (64->64): 2*(64*64*9 + 64*64) flop / pixel
         flops2 = 2.0 * (F_hidden * F_hidden * 9 + F_hidden * F_hidden) * npix * B
         ms2, n2 = timer.mean_ms("conv_layer2")
@@ -290,8 +314,9 @@ def main():
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload=f"CIRIM {cfg['num_cascades']} cascades x {T_} time-steps (config time_steps "
                                         f"{cfg['time_steps']} rounded up as the reference does), IndRNN {F_hidden} filters, "
-                                        f"{C} coils, {H}x{W}, batch {B} slice(s) per GPU, random-init weights (seed 0)",
-                               global_batch=world * B, coils=C, height=H, width=W, parallelism=f"slice-sharded x{world}",
+                                        f"{C} coils, {H}x{W}, {NS * B} slice(s) per GPU and step ({NS} concurrent HIP stream(s) x batch {B}, "
+                                        f"one hipGraph each), random-init weights (seed 0)",
+                               global_batch=world * NS * B, streams_per_gpu=NS, coils=C, height=H, width=W, parallelism=f"slice-sharded x{world}",
                                mask=("1-D random columns R=4 (row-invariant: one-launch gradient)" if args.mask == "1d" else
                                      "2-D random points R~10 (general three-launch gradient)")),
                    launch="hipGraph replay" if graphed else "eager", roofline=roofline, roofline_fft=roofline_fft,
