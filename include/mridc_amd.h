@@ -230,6 +230,15 @@ int mrx_qmri_grad(const float* dinv, const float* r2, const float* s0, const flo
 int mrx_scale(const float* x, float* out, int64_t n, float s, int mode, void* stream);
 int mrx_qrim_update(const float* eta, const float* delta, float* out, int B, int Cc, int64_t HW, void* stream);
 
+/* N1 per-sample preprocessing on the device (reconstruction/parts/transforms.py:286-288 target scaling, :527-617 max
+ * normalisation).  The reductions keep their result on the device so the chain needs no host synchronisation.
+ *   mrx_max_abs               out[0] = max |x_i| over n floats (mode 0: torch.max(torch.abs(x)) of a real view) or max complex
+ *                             modulus over n complex values (mode 1); NaN propagates; work = mrx_max_abs_work_floats() floats
+ *   mrx_div_by_device_scalar  out = x / d[0] (mode 0, n floats) or out[i] = |x_c[i] / d[0]| (mode 1: n complex -> n floats) */
+int64_t mrx_max_abs_work_floats(void);
+int mrx_max_abs(const float* x, int64_t n, int mode, float* out, float* work, void* stream);
+int mrx_div_by_device_scalar(const float* x, const float* d, float* out, int64_t n, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,6 +150,80 @@ extern "C" int mrx_complex_abs(const float* x, float* out, int64_t n, int square
     return MRX_OK;
 }
 
+// ---- per-sample normalisation on the device (reconstruction/parts/transforms.py:286-288,527-617) -------------------------
+// max over a whole tensor of |x| (mode 0: every float, the reference's torch.max(torch.abs(real view))) or of the complex modulus
+// (mode 1: torch.abs of a complex tensor = sqrt(fl(re^2) + fl(im^2)) in fp32); NaN propagates like torch.max.  Two launches, the
+// result stays on the device (no host synchronisation inside the preprocessing chain).
+__device__ __forceinline__ float nan_max(float a, float b) { return (a > b || a != a) ? a : b; }
+template <int MODE>
+__global__ void k_max_abs_partial(const float* __restrict__ x, float* __restrict__ part, long long n) {
+    __shared__ float red[EW_NT / 64];
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v;
+        if (MODE == 0) {
+            v = fabsf(x[i]);
+        } else {
+            const float2 c = reinterpret_cast<const float2*>(x)[i];
+            v = sqrt_rn(__fadd_rn(__fmul_rn(c.x, c.x), __fmul_rn(c.y, c.y)));
+        }
+        m = nan_max(v, m);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = nan_max(__shfl_xor(m, off, 64), m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < EW_NT / 64; ++w) m = nan_max(red[w], m);
+        part[blockIdx.x] = m;
+    }
+}
+__global__ void k_max_final(const float* __restrict__ part, int np, float* __restrict__ out) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < np; i += 64) m = nan_max(part[i], m);
+    for (int off = 32; off > 0; off >>= 1) m = nan_max(__shfl_xor(m, off, 64), m);
+    if (threadIdx.x == 0) out[0] = m;
+}
+#define MAXABS_BLOCKS 1024
+extern "C" int64_t mrx_max_abs_work_floats(void) { return MAXABS_BLOCKS; }
+extern "C" int mrx_max_abs(const float* x, int64_t n, int mode, float* out, float* work, void* stream) {
+    MRX_REQUIRE(x && out && work && n >= 1, MRX_EINVAL, "mrx_max_abs: bad argument");
+    MRX_REQUIRE(mode == 0 || mode == 1, MRX_EINVAL, "mrx_max_abs: bad mode %d", mode);
+    int nb = (int)((n + EW_NT - 1) / EW_NT);
+    if (nb > MAXABS_BLOCKS) nb = MAXABS_BLOCKS;
+    if (mode == 0)
+        hipLaunchKernelGGL(k_max_abs_partial<0>, dim3(nb), dim3(EW_NT), 0, (hipStream_t)stream, x, work, (long long)n);
+    else
+        hipLaunchKernelGGL(k_max_abs_partial<1>, dim3(nb), dim3(EW_NT), 0, (hipStream_t)stream, x, work, (long long)n);
+    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)work, nb, out);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// out = x / d[0] (mode 0, n floats) or out[i] = | x_c[i] / d[0] | (mode 1, n complex -> n floats): the divisor is read on the device
+template <int MODE>
+__global__ void k_div_dev(const float* __restrict__ x, const float* __restrict__ d, float* __restrict__ out, long long n) {
+    const float den = d[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (MODE == 0) {
+            out[i] = x[i] / den;
+        } else {
+            const float2 c = reinterpret_cast<const float2*>(x)[i];
+            const float re = c.x / den, im = c.y / den;
+            out[i] = sqrt_rn(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));
+        }
+    }
+}
+extern "C" int mrx_div_by_device_scalar(const float* x, const float* d, float* out, int64_t n, int mode, void* stream) {
+    MRX_REQUIRE(x && d && out && n >= 0, MRX_EINVAL, "mrx_div_by_device_scalar: bad argument");
+    MRX_REQUIRE(mode == 0 || mode == 1, MRX_EINVAL, "mrx_div_by_device_scalar: bad mode %d", mode);
+    if (n == 0) return MRX_OK;
+    if (mode == 0)
+        hipLaunchKernelGGL(k_div_dev<0>, dim3(ew_grid(n)), dim3(EW_NT), 0, (hipStream_t)stream, x, d, out, (long long)n);
+    else
+        hipLaunchKernelGGL(k_div_dev<1>, dim3(ew_grid(n)), dim3(EW_NT), 0, (hipStream_t)stream, x, d, out, (long long)n);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 // ---- coil combination over a middle dim (utils.py:194-248) ------------------------------------------------------
 __global__ void k_rss(const float* __restrict__ x, float* __restrict__ out, long long outer, long long R, long long inner) {
     const long long total = outer * inner;

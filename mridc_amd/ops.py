@@ -429,6 +429,35 @@ def scale(x, s, take_abs=False, divide=False):
     return out
 
 
+def max_abs(x, complex_modulus=False):
+    """0-dim device tensor: max |x| over every float of x, or (complex_modulus) max modulus over the complex values x[..., 2]."""
+    x = _lib.f32c(x)
+    n = x.numel() // 2 if complex_modulus else x.numel()
+    if n < 1 or (complex_modulus and x.shape[-1] != 2):
+        raise ValueError("max_abs: empty tensor or not a [..., 2] complex view")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    work = torch.empty(int(_lib.lib().mrx_max_abs_work_floats()), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_max_abs(_lib.ptr(x), n, int(bool(complex_modulus)), _lib.ptr(out), _lib.ptr(work), _lib.stream_ptr()),
+               "mrx_max_abs")
+    return out.reshape(())
+
+
+def div_by_device_scalar(x, d, modulus=False):
+    """x / d with d a 1-element device tensor (no host read); `modulus`: |x_c / d| of the complex view x[..., 2] -> real tensor."""
+    x, d = _lib.f32c(x), _lib.f32c(d.reshape(1))
+    if modulus:
+        if x.shape[-1] != 2:
+            raise ValueError("div_by_device_scalar: modulus needs a [..., 2] complex view")
+        out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        n = out.numel()
+    else:
+        out = torch.empty_like(x)
+        n = x.numel()
+    _lib.check(_lib.lib().mrx_div_by_device_scalar(_lib.ptr(x), _lib.ptr(d), _lib.ptr(out), n, int(bool(modulus)), _lib.stream_ptr()),
+               "mrx_div_by_device_scalar")
+    return out
+
+
 def qrim_update(eta, delta):
     eta, delta = _lib.f32c(eta), _lib.f32c(delta)
     B, Cc, H, W = _nchw(eta)

@@ -32,7 +32,7 @@ def install():
     pkgs = [
         "mridc", "mridc.collections", "mridc.collections.common", "mridc.collections.common.parts",
         "mridc.collections.common.losses",
-        "mridc.collections.reconstruction", "mridc.collections.reconstruction.data",
+        "mridc.collections.reconstruction", "mridc.collections.reconstruction.data", "mridc.collections.reconstruction.parts",
         "mridc.collections.reconstruction.models", "mridc.collections.reconstruction.models.rim",
         "mridc.collections.reconstruction.models.varnet", "mridc.collections.reconstruction.models.unet_base",
         "mridc.collections.reconstruction.models.conv",

@@ -172,6 +172,104 @@ def g11_masks():
     save("g11_masks.npz", d)
 
 
+def g12_mask_generators():
+    """N2: every reproducible mask generator of the reference, bit for bit (masks stored packed, 1 bit per sample).
+
+    Random / Equispaced draw from the object's own RandomState under `temp_seed`; the Gaussian ones use the global np.random
+    (subsample.py:353,438), so the generator seeds that explicitly -- the test does the same before calling the build's functions.
+    """
+    d, cases = {}, []
+    combos = {"random1d": [([0.08], [4]), ([0.08, 0.04], [4, 8]), ([0.04], [8])],
+              "equispaced1d": [([0.08], [4]), ([0.08, 0.04], [4, 8]), ([0.04], [8])],
+              "equispaced2d": [([0.08], [4]), ([0.04], [8]), ([0.7], [10])],
+              "gaussian1d": [([0.7], [4]), ([0.7, 0.5], [4, 8])],
+              "gaussian2d": [([0.7], [10]), ([0.5], [4])]}
+    shapes = [(1, 640, 372, 2), (15, 64, 48, 2), (3, 17, 19, 2), (1, 320, 320, 2)]
+    seeds = [123, (102, 105, 108, 101, 95, 49, 46, 104, 53)]       # an int and tuple(map(ord, "file_1.h5"))
+    for name, cfs in combos.items():
+        for ci, (cf, acc) in enumerate(cfs):
+            for si, shape in enumerate(shapes):
+                if name.startswith("gaussian") and shape[1] == 640:
+                    continue                                            # np.random.choice over 238 080 cells: slow and adds nothing
+                for ki, seed in enumerate(seeds):
+                    fn = subsample.create_mask_for_mask_type(name, cf, acc)
+                    fn.rng.seed(2024)                                   # state of the object's generator outside temp_seed
+                    half = 0.25 if (name.startswith("gaussian") and si == 1) else 0.0
+                    if name.startswith("gaussian"):
+                        np.random.seed(4321 + ki)
+                        m, a = fn(np.array(shape), seed, half, 0.02)
+                    else:
+                        m, a = fn(shape, seed)
+                    key = f"{name}/{ci}/{si}/{ki}"
+                    d[key + "/bits"] = np.packbits(m.numpy().astype(np.uint8).ravel())
+                    d[key + "/shape"] = np.array(m.shape)
+                    d[key + "/acc"] = np.array(float(a))
+                    cases.append(dict(key=key, name=name, cf=cf, acc=acc, shape=list(shape), seed=seed, half=half,
+                                      global_seed=4321 + ki, rng_seed=2024))
+    d["cases"] = np.array(json.dumps(cases))
+    save("g12_mask_generators.npz", d)
+
+
+def g13_transforms():
+    """N1: the reference's MRIDataTransforms on small synthetic slices (inputs, constructor kwargs, every tensor output)."""
+    T = _refshim.load("mridc.collections.reconstruction.parts.transforms")
+    rng = np.random.default_rng(77)
+
+    def cplx(*shape):
+        return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+
+    base = dict(fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1, use_seed=True)
+    cases = [
+        ("sense_norm", dict(base, normalize_inputs=True, max_norm=True, mask=("random1d", [0.08], [4])), (4, 16, 12), None),
+        ("rss_ortho_centered", dict(base, coil_combination_method="RSS", fft_centered=True, fft_normalization="ortho",
+                                    normalize_inputs=True, mask=("equispaced1d", [0.08], [4])), (5, 17, 19), None),
+        ("crop_before", dict(base, crop_size=(12, 10), normalize_inputs=True, mask=("random1d", [0.08], [4])), (4, 20, 16), None),
+        ("crop_after_kspace", dict(base, crop_size=(12, 10), kspace_crop=True, crop_before_masking=False, normalize_inputs=True,
+                                   mask=("equispaced2d", [0.08], [4]), mask_as_tuple=True), (4, 20, 16), None),
+        ("stored_mask_shift", dict(base, shift_mask=True, normalize_inputs=True, fft_normalization="forward"), (3, 14, 18), "stored"),
+        ("none_norm", dict(base, fft_normalization="none", normalize_inputs=True, mask=("equispaced2d", [0.08], [4])), (4, 16, 16), None),
+        ("two_masks", dict(base, normalize_inputs=True, mask=[("random1d", [0.08], [4]), ("equispaced1d", [0.04], [8])]),
+         (3, 16, 24), None),
+        ("fully_sampled", dict(base, normalize_inputs=False), (3, 10, 12), None),
+    ]
+    d, meta = {}, []
+    for name, kw, shape, stored in cases:
+        kw = dict(kw)
+        spec = kw.pop("mask", None)
+        as_tuple = kw.pop("mask_as_tuple", False)   # a non-list container takes the single-mask branch (transforms.py:468-478)
+        mask_func = None
+        if spec is not None:
+            specs = spec if isinstance(spec, list) else [spec]
+            mask_func = [subsample.create_mask_for_mask_type(*s_) for s_ in specs]
+            if as_tuple:
+                mask_func = tuple(mask_func)
+        k, S, eta = cplx(*shape), cplx(*shape), cplx(*shape[1:])
+        mask_in = None
+        if stored:
+            mask_in = [(rng.random(shape[1:]) < 0.4).astype(np.float32)]
+        t = T.MRIDataTransforms(mask_func=mask_func, **kw)
+        out = t(k, S, mask_in, eta if name != "fully_sampled" else np.array([]), np.array([]), {}, "file_1.h5", 3)
+        ks, y, Sm, m, e, tgt, _, _, acc = out
+        d[f"{name}/in/kspace"], d[f"{name}/in/sens"], d[f"{name}/in/eta"] = k, S, eta
+        if mask_in is not None:
+            d[f"{name}/in/mask"] = mask_in[0]
+        d[f"{name}/kspace"], d[f"{name}/sens"], d[f"{name}/target"] = ks, Sm, tgt
+        if e is not None and torch.is_tensor(e) and e.numel():
+            d[f"{name}/eta"] = e
+        ys = y if isinstance(y, list) else [y]
+        ms = m if isinstance(m, list) else [m]
+        for i, (yy, mm) in enumerate(zip(ys, ms)):
+            d[f"{name}/y{i}"] = yy
+            d[f"{name}/mask{i}"] = mm
+        accs = acc if isinstance(acc, list) else [acc]
+        d[f"{name}/acc"] = np.array([float(a if not torch.is_tensor(a) else a.item()) for a in accs])
+        meta.append(dict(name=name, kwargs={k_: (list(v) if isinstance(v, tuple) else v) for k_, v in kw.items()},
+                         mask=spec, mask_as_tuple=as_tuple, shape=list(shape), stored_mask=bool(stored), n_masks=len(ys),
+                         list_outputs=isinstance(y, list)))
+    d["cases"] = np.array(json.dumps(meta))
+    save("g13_transforms.npz", d)
+
+
 def synth(B, C, H, W, seed):
     """Small smooth-ish multicoil problem: image, sens maps (sum |S|^2 = 1), full k-space (centred ortho)."""
     g = torch.Generator().manual_seed(seed)
@@ -545,8 +643,8 @@ def g10_ssim():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
-    fns = dict(g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13"]
+    fns = dict(g12=g12_mask_generators, g13=g13_transforms, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

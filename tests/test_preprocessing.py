@@ -1,0 +1,185 @@
+"""SURVEY section 8f rows N1 (per-sample preprocessing on the device) and N2 (bit-identical mask generators).
+
+CPU: the build's mask generators against the reference's masks (g12, bit for bit) and the oracle's restatement of
+`MRIDataTransforms.__call__` against the reference's outputs (g13).  GPU: the device-side `MRIDataTransforms` (HIP operators
+through the C ABI) against the same goldens and, at the knee size, against the oracle.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests._util import T, assert_close, assert_exact
+
+
+def _mask_funcs():
+    from mridc_amd.collections.reconstruction.data import subsample
+    return subsample
+
+
+# ---- N2 -----------------------------------------------------------------------------------------------------------------------
+def test_g12_mask_generators_bit_identical(golden):
+    sub = _mask_funcs()
+    z = golden("g12_mask_generators.npz")
+    cases = json.loads(str(z["cases"]))
+    assert len(cases) >= 80
+    for c in cases:
+        fn = sub.create_mask_for_mask_type(c["name"], c["cf"], c["acc"])
+        fn.rng.seed(c["rng_seed"])
+        seed = tuple(c["seed"]) if isinstance(c["seed"], list) else c["seed"]
+        if c["name"].startswith("gaussian"):
+            np.random.seed(c["global_seed"])
+            m, a = fn(np.array(c["shape"]), seed, c["half"], 0.02)
+        else:
+            m, a = fn(tuple(c["shape"]), seed)
+        assert list(m.shape) == list(z[c["key"] + "/shape"]), c["key"]
+        assert m.dtype == torch.float32
+        bits = np.packbits(m.numpy().astype(np.uint8).ravel())
+        assert np.array_equal(bits, z[c["key"] + "/bits"]), f"mask bits differ: {c}"
+        assert float(a) == float(z[c["key"] + "/acc"]), c["key"]
+
+
+def test_mask_generator_interface():
+    sub = _mask_funcs()
+    with pytest.raises(ValueError, match="Number of center fractions"):
+        sub.RandomMaskFunc([0.08, 0.04], [4])
+    with pytest.raises(ValueError, match="3 or more dimensions"):
+        sub.RandomMaskFunc([0.08], [4])((10, 2), seed=1)
+    with pytest.raises(NotImplementedError, match="not supported"):
+        sub.create_mask_for_mask_type("spiral", [0.08], [4])
+    with pytest.raises(NotImplementedError, match="Numba"):
+        sub.create_mask_for_mask_type("poisson2d", [0.7], [10])((1, 32, 32, 2))
+    fn = sub.RandomMaskFunc([0.08], [4])
+    state = fn.rng.get_state()[1].copy()
+    a, _ = fn((1, 64, 48, 2), seed=(1, 2, 3))
+    b, _ = fn((1, 64, 48, 2), seed=(1, 2, 3))
+    assert torch.equal(a, b) and np.array_equal(state, fn.rng.get_state()[1])   # seeded call leaves the generator untouched
+    m, acc = sub.Equispaced2DMaskFunc([0.08], [4])((1, 32, 40, 2), seed=5)
+    assert m.shape == (1, 32, 40, 1) and acc == 4
+
+
+# ---- N1: oracle vs the reference's outputs -------------------------------------------------------------------------------------
+def _case_inputs(z, c):
+    name = c["name"]
+    sub = _mask_funcs()
+    spec = c["mask"]
+    mask_func = None
+    if spec is not None:
+        specs = spec if isinstance(spec[0], list) else [spec]
+        mask_func = [sub.create_mask_for_mask_type(*s_) for s_ in specs]
+        if c["mask_as_tuple"]:
+            mask_func = tuple(mask_func)
+    k, S = z[f"{name}/in/kspace"], z[f"{name}/in/sens"]
+    eta = z[f"{name}/in/eta"] if f"{name}/eta" in z.files else np.array([])
+    mask_in = [z[f"{name}/in/mask"]] if c["stored_mask"] else None
+    kw = dict(c["kwargs"])
+    if kw.get("crop_size") is not None:
+        kw["crop_size"] = tuple(kw["crop_size"])
+    return k, S, eta, mask_in, mask_func, kw
+
+
+def _check_outputs(z, c, ks, y, Sm, m, e, tgt, acc, tol, what):
+    name = c["name"]
+    assert_close(ks, T(z[f"{name}/kspace"]), tol, f"{what} {name}: kspace")
+    assert_close(Sm, T(z[f"{name}/sens"]), tol, f"{what} {name}: sensitivity maps")
+    assert_close(tgt, T(z[f"{name}/target"]), tol, f"{what} {name}: target")
+    if f"{name}/eta" in z.files:
+        assert_close(e, T(z[f"{name}/eta"]), tol, f"{what} {name}: eta")
+    assert isinstance(y, list) == c["list_outputs"], f"{what} {name}: list-valued outputs"
+    ys = y if isinstance(y, list) else [y]
+    ms = m if isinstance(m, list) else [m]
+    accs = acc if isinstance(acc, list) else [acc]
+    assert len(ys) == c["n_masks"]
+    for i, (yy, mm) in enumerate(zip(ys, ms)):
+        assert_close(yy, T(z[f"{name}/y{i}"]), tol, f"{what} {name}: masked k-space {i}")
+        ref_m = T(z[f"{name}/mask{i}"])
+        assert tuple(mm.shape) == tuple(ref_m.shape) and mm.dtype == ref_m.dtype, f"{what} {name}: mask {i} {mm.shape} {mm.dtype}"
+        assert_exact(mm.cpu(), ref_m, f"{what} {name}: mask {i}")
+    got_acc = [float(a_.item() if torch.is_tensor(a_) else a_) for a_ in accs]
+    assert got_acc == [float(v) for v in z[f"{name}/acc"]], f"{what} {name}: acceleration"
+
+
+def test_g13_oracle_transforms_vs_reference(golden):
+    z = golden("g13_transforms.npz")
+    for c in json.loads(str(z["cases"])):
+        k, S, eta, mask_in, mask_func, kw = _case_inputs(z, c)
+        ks, y, Sm, m, e, tgt, acc = oracle.transforms.preprocess(k, S, mask_in, eta, fname="file_1.h5", mask_func=mask_func, **kw)
+        _check_outputs(z, c, ks, y, Sm, m, e, tgt, acc, 2e-6, "oracle")
+
+
+# ---- N1: the device path -----------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_max_abs_and_device_division(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for shape in ((7,), (5, 9, 2), (15, 64, 48, 2), (3, 640, 372, 2)):
+        x = torch.randn(*shape, generator=g) * 3
+        m = ops.max_abs(x.to(dev))
+        assert m.shape == () and float(m) == float(x.abs().max())                        # max is exact
+        if shape[-1] == 2:
+            mc = ops.max_abs(x.to(dev), complex_modulus=True)
+            ref = torch.view_as_complex(x).abs().max()
+            assert abs(float(mc) - float(ref)) <= 2e-7 * float(ref)                        # modulus: 1 ulp (rounded squares, then the root)
+            q = ops.div_by_device_scalar(x.to(dev), mc, modulus=True).cpu()
+            assert_close(q, (torch.view_as_complex(x) / ref).abs(), 1e-6, "|x / max|")
+        assert_exact(ops.div_by_device_scalar(x.to(dev), m).cpu(), x / x.abs().max(), "x / max")   # IEEE division, same divisor
+    xn = torch.tensor([1.0, float("nan"), 2.0])
+    assert torch.isnan(ops.max_abs(xn.to(dev)))                                           # torch.max propagates NaN
+    with pytest.raises(RuntimeError):
+        ops.max_abs(torch.ones(4))                                                         # CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+def test_g13_device_transforms_vs_reference(golden, dev):
+    from mridc_amd.collections.reconstruction.parts.transforms import MRIDataTransforms
+    z = golden("g13_transforms.npz")
+    for c in json.loads(str(z["cases"])):
+        k, S, eta, mask_in, mask_func, kw = _case_inputs(z, c)
+        t = MRIDataTransforms(mask_func=mask_func, **kw)
+        ks, y, Sm, m, e, tgt, fname, sl, acc = t(k, S, mask_in, eta, np.array([]), {}, "file_1.h5", 3)
+        assert (fname, sl) == ("file_1.h5", 3)
+        for v in [ks, Sm, tgt] + (y if isinstance(y, list) else [y]):
+            assert v.device.type == "cuda"
+        _check_outputs(z, c, ks.cpu(), [v.cpu() for v in y] if isinstance(y, list) else y.cpu(), Sm.cpu(), m, e.cpu() if e.numel() else e,
+                       tgt.cpu(), acc, 1e-5, "device")
+
+
+@pytest.mark.gpu
+def test_device_transforms_knee_size_vs_oracle(dev):
+    """15 coils, 640 x 372: the shape of the headline workload; random-1-D mask seeded from the file name like the reference."""
+    from mridc_amd.collections.reconstruction.data import subsample
+    from mridc_amd.collections.reconstruction.parts.transforms import MRIDataTransforms
+    rng = np.random.default_rng(5)
+    C, H, W = 15, 640, 372
+    k = (rng.standard_normal((C, H, W)) + 1j * rng.standard_normal((C, H, W))).astype(np.complex64)
+    S = (rng.standard_normal((C, H, W)) + 1j * rng.standard_normal((C, H, W))).astype(np.complex64)
+    kw = dict(normalize_inputs=True, max_norm=True, fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1)
+    t = MRIDataTransforms(mask_func=[subsample.RandomMaskFunc([0.08], [4])], **kw)
+    ks, y, Sm, m, e, tgt, _, _, acc = t(k, S, None, np.array([]), np.array([]), {}, "file_7.h5", 0)
+    rk, ry, rS, rm, re_, rt, racc = oracle.transforms.preprocess(k, S, None, np.array([]), fname="file_7.h5",
+                                                                 mask_func=[subsample.RandomMaskFunc([0.08], [4])], **kw)
+    assert_close(ks.cpu(), rk, 1e-5, "knee: kspace")
+    assert_close(y[0].cpu(), ry[0], 1e-5, "knee: masked kspace")
+    assert_close(Sm.cpu(), rS, 1e-6, "knee: maps")
+    assert_close(tgt.cpu(), rt, 1e-5, "knee: target")
+    assert_exact(m[0].cpu(), rm[0], "knee: mask")
+    assert acc == racc == [4]
+    # the output feeds the cascades directly: already on the device, contiguous, fp32
+    assert y[0].is_contiguous() and y[0].dtype == torch.float32 and y[0].device.type == "cuda"
+
+
+@pytest.mark.gpu
+def test_device_transforms_rejects_unsupported():
+    from mridc_amd.collections.reconstruction.parts.transforms import MRIDataTransforms
+    for kw in (dict(apply_prewhitening=True), dict(apply_gcc=True), dict(kspace_zero_filling_size=(32, 32)), dict(dimensionality=3)):
+        with pytest.raises(NotImplementedError):
+            MRIDataTransforms(**kw)
