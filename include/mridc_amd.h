@@ -235,6 +235,9 @@ int mrx_qrim_update(const float* eta, const float* delta, float* out, int B, int
  *   mrx_max_abs               out[0] = max |x_i| over n floats (mode 0: torch.max(torch.abs(x)) of a real view) or max complex
  *                             modulus over n complex values (mode 1); NaN propagates; work = mrx_max_abs_work_floats() floats
  *   mrx_div_by_device_scalar  out = x / d[0] (mode 0, n floats) or out[i] = |x_c[i] / d[0]| (mode 1: n complex -> n floats) */
+/* N3 BaseSensitivityModel.divide_root_sum_of_squares (models/base.py:824-840): out[o,r,i] = x[o,r,i] / sqrt(sum_r |x[o,r,i]|^2),
+ * x, out [outer, R, inner] complex. */
+int mrx_div_rss_complex(const float* x, float* out, int64_t outer, int64_t R, int64_t inner, void* stream);
 int64_t mrx_max_abs_work_floats(void);
 int mrx_max_abs(const float* x, int64_t n, int mode, float* out, float* work, void* stream);
 int mrx_div_by_device_scalar(const float* x, const float* d, float* out, int64_t n, int mode, void* stream);

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "mrx_rim_layer_pack": ([_p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_layer_supported": ([_i, _i, _i, _i], _i),
     "mrx_rim_layer_indrnn_packed": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_div_rss_complex": ([_p, _p, _i64, _i64, _i64, _p], _i),
     "mrx_max_abs_work_floats": ([], _i64),
     "mrx_max_abs": ([_p, _i64, _i, _p, _p, _p], _i),
     "mrx_div_by_device_scalar": ([_p, _p, _p, _i64, _i, _p], _i),

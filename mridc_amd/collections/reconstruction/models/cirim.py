@@ -17,6 +17,8 @@ from mridc_amd.collections.reconstruction.models.rim import rim_block
 
 __all__ = ["CIRIM"]
 
+from mridc_amd.collections.reconstruction.models.base import build_sens_net
+
 
 class CIRIM(torch.nn.Module):
     def __init__(self, cfg, trainer=None):
@@ -30,6 +32,9 @@ class CIRIM(torch.nn.Module):
         self.fft_normalization = cfg_dict.get("fft_normalization")
         self.spatial_dims = cfg_dict.get("spatial_dims")
         self.coil_dim = cfg_dict.get("coil_dim")
+        self.use_sens_net = cfg_dict.get("use_sens_net")
+        if self.use_sens_net:                                          # models/base.py:81-95 (applied by the caller's step, :234)
+            self.sens_net = build_sens_net(cfg_dict, self.fft_centered, self.fft_normalization, self.spatial_dims, self.coil_dim)
         self.num_cascades = cfg_dict.get("num_cascades")
         self.cirim = torch.nn.ModuleList([
             rim_block.RIMBlock(

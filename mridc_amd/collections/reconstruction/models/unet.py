@@ -8,6 +8,8 @@ from mridc_amd.collections.reconstruction.models.unet_base import unet_block
 
 __all__ = ["UNet"]
 
+from mridc_amd.collections.reconstruction.models.base import build_sens_net
+
 
 class UNet(torch.nn.Module):
     def __init__(self, cfg, trainer=None):
@@ -17,6 +19,9 @@ class UNet(torch.nn.Module):
         self.fft_normalization = cfg_dict.get("fft_normalization")
         self.spatial_dims = cfg_dict.get("spatial_dims")
         self.coil_dim = cfg_dict.get("coil_dim")
+        self.use_sens_net = cfg_dict.get("use_sens_net")
+        if self.use_sens_net:                                          # models/base.py:81-95 (applied by the caller's step, :234)
+            self.sens_net = build_sens_net(cfg_dict, self.fft_centered, self.fft_normalization, self.spatial_dims, self.coil_dim)
         self.unet = unet_block.NormUnet(chans=cfg_dict.get("channels"), num_pools=cfg_dict.get("pooling_layers"),
                                         padding_size=cfg_dict.get("padding_size"), normalize=cfg_dict.get("normalize"))
         self.coil_combination_method = cfg_dict.get("coil_combination_method")

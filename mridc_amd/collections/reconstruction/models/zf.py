@@ -7,6 +7,8 @@ from mridc_amd.collections.reconstruction.models import _cfg
 
 __all__ = ["ZF"]
 
+from mridc_amd.collections.reconstruction.models.base import build_sens_net
+
 
 class ZF(torch.nn.Module):
     def __init__(self, cfg, trainer=None):
@@ -18,8 +20,8 @@ class ZF(torch.nn.Module):
         self.spatial_dims = cfg_dict.get("spatial_dims")
         self.coil_dim = cfg_dict.get("coil_dim")
         self.use_sens_net = cfg_dict.get("use_sens_net")
-        if self.use_sens_net:
-            raise NotImplementedError("BaseSensitivityModel (models/base.py:715-932) is a 'next' row (SURVEY 8f N3)")
+        if self.use_sens_net:                                          # models/base.py:81-95
+            self.sens_net = build_sens_net(cfg_dict, self.fft_centered, self.fft_normalization, self.spatial_dims, self.coil_dim)
 
     def forward(self, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask: torch.Tensor, target: torch.Tensor = None):
         """zf.py:61-100."""

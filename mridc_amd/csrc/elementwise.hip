@@ -251,6 +251,34 @@ __global__ void k_rss_complex(const float2* __restrict__ x, float* __restrict__ 
         out[o] = sqrt_rn(s);
     }
 }
+// x / rss_complex(x, dim) broadcast back over the reduced dim (models/base.py:824-840, BaseSensitivityModel): same summation order
+// as k_rss_complex, then one IEEE division per component
+__global__ void k_div_rss_complex(const float2* __restrict__ x, float2* __restrict__ out, long long outer, long long R, long long inner) {
+    const long long total = outer * inner;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long ob = o / inner, i = o - ob * inner;
+        const long long base = ob * R * inner + i;
+        float s = 0.f;
+        for (long long r = 0; r < R; ++r) {
+            const float2 v = x[base + r * inner];
+            s += v.x * v.x + v.y * v.y;
+        }
+        const float den = sqrt_rn(s);
+        for (long long r = 0; r < R; ++r) {
+            const float2 v = x[base + r * inner];
+            out[base + r * inner] = make_float2(v.x / den, v.y / den);
+        }
+    }
+}
+extern "C" int mrx_div_rss_complex(const float* x, float* out, int64_t outer, int64_t R, int64_t inner, void* stream) {
+    MRX_REQUIRE(outer >= 0 && R >= 1 && inner >= 0, MRX_EINVAL, "mrx_div_rss_complex: bad dims");
+    if (outer * inner == 0) return MRX_OK;
+    MRX_REQUIRE(x && out, MRX_EINVAL, "mrx_div_rss_complex: null pointer");
+    hipLaunchKernelGGL(k_div_rss_complex, dim3(ew_grid(outer * inner)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)x, (float2*)out,
+                       (long long)outer, (long long)R, (long long)inner);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
 __global__ void k_sense(const float2* __restrict__ x, const float2* __restrict__ sm, float2* __restrict__ out, long long outer,
                         long long R, long long inner) {
     const long long total = outer * inner;

@@ -108,3 +108,49 @@ def zf_forward(cfg, y, sensitivity_maps, mask, target=None):
     pred = outils.check_stacked_complex(pred.contiguous())
     _, pred = outils.center_crop_to_smallest(target, pred)
     return pred
+
+
+def sens_net_pad_and_low_freqs(mask, num_low_frequencies=None):
+    """base.py:842-884: (pad, num_low_frequencies) per batch element from the mask's contiguous centre block."""
+    if num_low_frequencies is None or num_low_frequencies == 0:
+        squeezed = mask[:, 0, 0, :, 0].to(torch.int8)
+        cent = squeezed.shape[1] // 2
+        left = torch.argmin(squeezed[:, :cent].flip(1), dim=1)     # first zero walking outwards = length of the run of ones
+        right = torch.argmin(squeezed[:, cent:], dim=1)
+        nlf = torch.max(2 * torch.min(left, right), torch.ones_like(left))
+    else:
+        nlf = num_low_frequencies * torch.ones(mask.shape[0], dtype=mask.dtype, device=mask.device)
+    pad = torch.div(mask.shape[-2] - nlf + 1, 2, rounding_mode="trunc")
+    return pad, nlf
+
+
+def batched_mask_center(x, mask_from, mask_to, mask_type="2D"):
+    """utils.py:346-410."""
+    out = torch.zeros_like(x)
+    if mask_from.shape[0] == 1:
+        a, b = int(mask_from), int(mask_to)
+        if mask_type == "1D":
+            out[:, :, :, a:b] = x[:, :, :, a:b]
+        else:
+            out[:, :, a:b] = x[:, :, a:b]
+        return out
+    for i, (a, b) in enumerate(zip(mask_from, mask_to)):
+        out[i, :, :, a:b] = x[i, :, :, a:b]
+    return out
+
+
+def sens_net_forward(p, cfg, masked_kspace, mask, num_low_frequencies=None):
+    """BaseSensitivityModel.forward, base.py:886-932.  `p` holds the NormUnet weights under `norm_unet.unet.`;
+    cfg keys: sens_pools, sens_mask_type, sens_normalize, sens_mask_center, padding_size (15), fft_*, spatial_dims, coil_dim."""
+    cd = cfg.get("coil_dim", 1)
+    if cfg.get("sens_mask_center", True):
+        pad, nlf = sens_net_pad_and_low_freqs(mask, num_low_frequencies)
+        masked_kspace = batched_mask_center(masked_kspace, pad, pad + nlf, cfg.get("sens_mask_type", "2D"))
+    img = offt.ifft2(masked_kspace, cfg["fft_centered"], cfg["fft_normalization"], cfg.get("spatial_dims"))
+    b, c, h, w, two = img.shape
+    out = ounet.norm_unet_forward(p, img.reshape(b * c, 1, h, w, two), cfg["sens_pools"], cfg.get("sens_padding_size", 15),
+                                  cfg.get("sens_normalize", True), prefix="norm_unet.unet.")
+    out = out.reshape(b, c, h, w, two)
+    if cfg.get("sens_normalize", True):
+        out = out / outils.rss_complex(out, dim=cd).unsqueeze(-1).unsqueeze(cd)      # base.py:824-840
+    return out

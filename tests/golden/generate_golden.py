@@ -270,6 +270,61 @@ def g13_transforms():
     save("g13_transforms.npz", d)
 
 
+def g14_sensnet():
+    """N3: BaseSensitivityModel.  models/base.py imports pytorch-lightning, so the forward body (base.py:886-932) is composed from
+    the imported reference pieces exactly as those lines do: get_pad_and_num_low_freqs (:842-884, restated line by line below),
+    utils.batched_mask_center, fft.ifft2, unet_block.NormUnet on the coils-as-batch view, utils.rss_complex."""
+    def pad_and_nlf(mask, num_low_frequencies=None):
+        if num_low_frequencies is None or num_low_frequencies == 0:
+            squeezed_mask = mask[:, 0, 0, :, 0].to(torch.int8)
+            cent = torch.div(squeezed_mask.shape[1], 2, rounding_mode="trunc")
+            left = torch.argmin(squeezed_mask[:, :cent].flip(1), dim=1)
+            right = torch.argmin(squeezed_mask[:, cent:], dim=1)
+            nlf = torch.max(2 * torch.min(left, right), torch.ones_like(left))
+        else:
+            nlf = num_low_frequencies * torch.ones(mask.shape[0], dtype=mask.dtype, device=mask.device)
+        return torch.div(mask.shape[-2] - nlf + 1, 2, rounding_mode="trunc"), nlf
+
+    cases = [("default", dict(sens_chans=4, sens_pools=2, sens_mask_type="2D", sens_normalize=True, sens_mask_center=True,
+                              fft_centered=False, fft_normalization="backward", coil_dim=1), (1, 4, 20, 24), None, 1),
+             ("ortho_1d_nlf", dict(sens_chans=4, sens_pools=2, sens_mask_type="1D", sens_normalize=True, sens_mask_center=True,
+                                   fft_centered=True, fft_normalization="ortho", coil_dim=1), (1, 3, 17, 18), 4, 1),
+             ("no_center_no_norm", dict(sens_chans=6, sens_pools=1, sens_mask_type="2D", sens_normalize=False, sens_mask_center=False,
+                                        fft_centered=False, fft_normalization="backward", coil_dim=1), (1, 5, 12, 16), None, 1),
+             ("per_batch_masks", dict(sens_chans=4, sens_pools=2, sens_mask_type="2D", sens_normalize=True, sens_mask_center=True,
+                                      fft_centered=False, fft_normalization="backward", coil_dim=1), (2, 3, 16, 20), None, 2)]
+    d = {}
+    for i, (nm, cfg, shape, nlf_arg, mask_batch) in enumerate(cases):
+        B, C, H, W = shape
+        torch.manual_seed(700 + i)
+        net = unet_block.NormUnet(cfg["sens_chans"], cfg["sens_pools"], in_chans=2, out_chans=2, drop_prob=0.0, padding_size=15,
+                                  normalize=cfg["sens_normalize"])
+        k = rnd([B, C, H, W, 2], 710 + i)
+        masks = []
+        for b_ in range(mask_batch):
+            mf = subsample.RandomMaskFunc([0.2 + 0.1 * b_], [2])
+            m, _ = mf([1, H, W, 2], seed=11 + b_)
+            masks.append(m.reshape(1, 1, 1, W, 1))
+        mask = torch.cat(masks, 0)
+        y = k * mask
+        with torch.no_grad():
+            x = y
+            if cfg["sens_mask_center"]:
+                pad, nlf = pad_and_nlf(mask, nlf_arg)
+                x = utils.batched_mask_center(x, pad, pad + nlf, mask_type=cfg["sens_mask_type"])
+            img = fft.ifft2(x, centered=cfg["fft_centered"], normalization=cfg["fft_normalization"], spatial_dims=[-2, -1])
+            b, c, h, w, comp = img.shape
+            out = net(img.view(b * c, 1, h, w, comp))
+            out = out.view(b, c, h, w, comp)
+            if cfg["sens_normalize"]:
+                out = out / utils.rss_complex(out, dim=cfg["coil_dim"]).unsqueeze(-1).unsqueeze(cfg["coil_dim"])
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(cfg, num_low_frequencies=nlf_arg)))
+        d[f"{nm}/y"], d[f"{nm}/mask"], d[f"{nm}/out"] = y, mask, out
+        d.update(sd(net, f"{nm}/w/norm_unet."))
+    d["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g14_sensnet.npz", d)
+
+
 def synth(B, C, H, W, seed):
     """Small smooth-ish multicoil problem: image, sens maps (sum |S|^2 = 1), full k-space (centred ortho)."""
     g = torch.Generator().manual_seed(seed)
@@ -643,8 +698,8 @@ def g10_ssim():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13"]
-    fns = dict(g12=g12_mask_generators, g13=g13_transforms, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14"]
+    fns = dict(g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

@@ -183,3 +183,47 @@ def test_device_transforms_rejects_unsupported():
     for kw in (dict(apply_prewhitening=True), dict(apply_gcc=True), dict(kspace_zero_filling_size=(32, 32)), dict(dimensionality=3)):
         with pytest.raises(NotImplementedError):
             MRIDataTransforms(**kw)
+
+
+# ---- N3: BaseSensitivityModel --------------------------------------------------------------------------------------------------
+def _sens_cases(golden):
+    from tests._util import weights
+    z = golden("g14_sensnet.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg = json.loads(str(z[nm + "/cfg"]))
+        yield nm, cfg, weights(z, nm + "/w/"), T(z[nm + "/y"]), T(z[nm + "/mask"]), T(z[nm + "/out"])
+
+
+def test_g14_oracle_sens_net_vs_reference(golden):
+    for nm, cfg, p, y, mask, want in _sens_cases(golden):
+        got = oracle.models.sens_net_forward(p, cfg, y, mask, cfg["num_low_frequencies"])
+        assert_close(got, want, 2e-6, f"oracle sens_net {nm}")
+
+
+def test_sens_net_state_dict_layout_and_config_keys():
+    from mridc_amd import synthetic
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    cfg = dict(synthetic.E2EVN_BASELINE_CFG, use_sens_net=True, sens_chans=4, sens_pools=2, sens_mask_type="2D", sens_normalize=True,
+               sens_mask_center=True)
+    keys = [k for k in VarNet(cfg).state_dict() if k.startswith("sens_net.")]
+    assert "sens_net.norm_unet.unet.down_sample_layers.0.layers.0.weight" in keys and len(keys) == 14
+    assert not any(k.startswith("sens_net.") for k in VarNet(dict(synthetic.E2EVN_BASELINE_CFG)).state_dict())
+
+
+@pytest.mark.gpu
+def test_g14_device_sens_net_vs_reference(golden, dev):
+    from mridc_amd.collections.reconstruction.models.base import BaseSensitivityModel
+    for nm, cfg, p, y, mask, want in _sens_cases(golden):
+        net = BaseSensitivityModel(cfg["sens_chans"], cfg["sens_pools"], fft_centered=cfg["fft_centered"],
+                                   fft_normalization=cfg["fft_normalization"], spatial_dims=[-2, -1], coil_dim=cfg["coil_dim"],
+                                   mask_type=cfg["sens_mask_type"], normalize=cfg["sens_normalize"], mask_center=cfg["sens_mask_center"])
+        net.load_state_dict(p)                                        # the reference's key layout, strict
+        net = net.to(dev).eval()
+        with torch.no_grad():
+            got = net(y.to(dev), mask.to(dev), cfg["num_low_frequencies"])
+        assert_close(got.cpu(), want, 2e-5, f"device sens_net {nm}")
+        if cfg["sens_normalize"]:                                     # unit root-sum-of-squares over coils, exactly what the division is for
+            rss = torch.view_as_complex(got).abs().pow(2).sum(1).sqrt()
+            assert float((rss - 1).abs().max()) < 1e-5
+    with pytest.raises(RuntimeError):
+        net.cpu()(y, mask)                                            # no CPU fallback
