@@ -122,30 +122,59 @@ def bench_e2evn(args, world, rank, dev):
     torch.manual_seed(0)
     model = VarNet(cfg).eval().to(dev)
     B, C, H, W = args.batch, args.coils, args.height, args.width
-    s0, s1 = shard_range(world * B, rank, world)
-    slices = [synthetic.make_slice(C, H, W, slice_idx=i, mask_dtype=torch.uint8) for i in range(s0, s1)]
-    data = {k: torch.cat([s[k] for s in slices], 0).to(dev) for k in ("y", "sensitivity_maps", "target")}
-    data["mask"] = slices[0]["mask"].to(dev)
+    NS = max(1, args.streams)
+    s0, s1 = shard_range(world * NS * B, rank, world)
+    datas = []
+    for i in range(NS):
+        slices = [synthetic.make_slice(C, H, W, slice_idx=j, mask_dtype=torch.uint8) for j in range(s0 + i * B, s0 + (i + 1) * B)]
+        d = {k: torch.cat([s[k] for s in slices], 0).to(dev) for k in ("y", "sensitivity_maps", "target")}
+        d["mask"] = slices[0]["mask"].to(dev)
+        datas.append(d)
 
-    def step():
+    def step(d):
         with torch.no_grad():
-            return model(data["y"], data["sensitivity_maps"], data["mask"], None, data["target"])
+            return model(d["y"], d["sensitivity_maps"], d["mask"], None, d["target"])
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(max(args.warmup, 1)):
+        step(datas[0])
     torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(NS)]
+    graphs = []
+    if args.graph:
+        try:
+            for d, st in zip(datas, streams):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    step(d)
+                torch.cuda.current_stream().wait_stream(st)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=st):
+                    step(d)
+                graphs.append(g_)
+            torch.cuda.synchronize()
+        except Exception as ex:  # noqa: BLE001
+            print(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
+            graphs = []
+            torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                if graphs:
+                    graphs[i].replay()
+                else:
+                    step(datas[i])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    B = NS * B
     if rank == 0:
         print(json.dumps(dict(metric="slices/sec (inference), E2EVN 6-cascade 15-coil 640x372", value=world * B * args.steps / elapsed,
                               unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                               ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                               dtype="f32", data="synthetic",
                               config=dict(workload="E2EVN 6 cascades, NormUnet(chans 14, pools 2, pad 11), 15 coils, 640x372, batch "
-                                                   f"{B} per GPU, random-init weights (seed 0)", parallelism=f"slice-sharded x{world}"))),
+                                                   f"{B} per GPU ({NS} concurrent HIP stream(s), {'one hipGraph each' if graphs else 'eager'}), random-init weights "
+                                                   "(seed 0)", parallelism=f"slice-sharded x{world}"))),
               flush=True)
 
 
