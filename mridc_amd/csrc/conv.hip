@@ -13,6 +13,7 @@
 // k = (cin, tap); one MFMA consumes two cins at one tap (lanes 0-31: cin c, lanes 32-63: cin c+1).
 // A workgroup (4 waves) owns an 8-row x 32-column output tile for up to 64 couts; each wave owns 2 rows x 2 cout
 // tiles = 4 independent accumulators, which is what the 64-cycle MFMA needs to issue back to back.
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -404,6 +405,145 @@ static int launch_small(const float* x, const float* w, const float* bias, const
     return MRX_OK;
 }
 
+// ---- tuned 3x3, dilation 1 (NormUnet: unet_block.py:251,255) --------------------------------------------------------------
+// Small channel counts (2 / 14 / 28 / 56) make these convolutions memory- and latency-bound, not MFMA-bound: the tile is built
+// from 16-wide MFMA blocks (v_mfma_f32_16x16x4_f32: 16 couts x 16 pixels x 4 input channels = one tap of one channel group), so a
+// 14-channel layer wastes 1/8 of the block instead of 9/16 of a 32-wide one; the raw halo'd tile arrives by LDS-DMA (one dword per
+// lane; lanes outside the image are masked off and keep the zeros -- or, for replicate padding, fetch the clamped element) into
+// double-buffered planes; the weights of the next channel group are fetched into registers while the matrix pipe works on the
+// current one.  256 threads = 4 waves, 8 x 32 output pixels; wave w: rows 2w, 2w+1 (4 pixel blocks) x NCOT cout blocks.
+typedef float c3_f4 __attribute__((ext_vector_type(4)));
+#define C3_PW 34
+#define C3_PLANE 368   // 10 rows x 34 used (340); 368 = 16 mod 32: the four channel planes of an MFMA land on different banks
+#define C3_XBUF (4 * C3_PLANE)
+template <int NCOT>
+__global__ __launch_bounds__(CV_NT, NCOT >= 4 ? 3 : 4) void k_conv3x3_t(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Xs = smem_f;                   // [2][4][C3_PLANE]
+    float* Ws = smem_f + 2 * C3_XBUF;     // [2][9][NCOT][64]: MFMA A operand per lane
+    constexpr int WBUF = 9 * NCOT * 64;
+    constexpr int NWL = (WBUF + CV_NT - 1) / CV_NT;  // weight values staged per thread and chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int tile = blockIdx.x;
+    const int ty0 = tile / a.tiles_x;
+    const int h0 = ty0 * CV_TH, w0 = (tile - ty0 * a.tiles_x) * CV_TW;
+    const int b = blockIdx.z;
+    const long long plane = (long long)a.H * a.W;
+    const float* xb = a.x + (long long)b * a.Cin * plane;
+    const int nchunks = (a.Cin + 3) / 4;
+    for (int i = tid; i < 2 * C3_XBUF; i += CV_NT) Xs[i] = 0.f;  // zero padding = the slots no copy ever writes
+    // raw-tile slots of this wave: channel `wave` of the chunk, 6 copies of 64 elements
+    unsigned xoff[6];
+    unsigned xok = 0;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        const int sl = m * 64 + lane;
+        const int ry = sl / C3_PW, rx = sl - ry * C3_PW;
+        int gy = h0 + ry - 1, gx = w0 + rx - 1;
+        bool ok = sl < 10 * C3_PW;
+        if (a.pad_mode == MRX_PAD_REPLICATE) {
+            gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+            gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+        } else {
+            ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        }
+        xoff[m] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0u;
+        xok |= (ok ? 1u : 0u) << m;
+    }
+    auto dma_x = [&](int q) {
+        int gc = 4 * q + wave;
+        gc = gc < a.Cin ? gc : a.Cin - 1;  // channels past Cin repeat the last one; their weights are staged as zeros
+        const char* src = reinterpret_cast<const char*>(xb + (long long)gc * plane);
+        float* dst = Xs + (q & 1) * C3_XBUF + wave * C3_PLANE;
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+            if ((xok >> m) & 1u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + xoff[m]),
+                                                 (__attribute__((address_space(3))) void*)(dst + m * 64), 4, 0, 0);
+    };
+    // weight staging: element i of the chunk image = (tap, ct, lane') -> w[16 ct + (lane' & 15)][4 q + (lane' >> 4)][tap]
+    float wr[NWL];
+    auto load_w = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) {
+            const int i = tid + j * CV_NT;
+            const int ln = i & 63, ct = (i >> 6) % NCOT, tap = (i >> 6) / NCOT;
+            const int co = 16 * ct + (ln & 15), ci = 4 * q + (ln >> 4);
+            wr[j] = (i < WBUF && co < a.Cout && ci < a.Cin) ? a.w[((long long)co * a.Cin + ci) * 9 + tap] : 0.f;
+        }
+    };
+    auto store_w = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) {
+            const int i = tid + j * CV_NT;
+            if (i < WBUF) Ws[(q & 1) * WBUF + i] = wr[j];
+        }
+    };
+    c3_f4 acc[4][NCOT];
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+        for (int ct = 0; ct < NCOT; ++ct) acc[sg][ct] = (c3_f4){0.f, 0.f, 0.f, 0.f};
+    load_w(0);
+    __syncthreads();  // tile zeroed before any copy lands
+    dma_x(0);
+    store_w(0);
+    for (int q = 0; q < nchunks; ++q) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // chunk q staged (tile + weights); buffers of chunk q - 1 free
+        if (q + 1 < nchunks) {
+            dma_x(q + 1);
+            load_w(q + 1);
+        }
+        const float* xq = Xs + (q & 1) * C3_XBUF + lg * C3_PLANE + l15;
+        const float* wq = Ws + (q & 1) * WBUF + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            float av[NCOT];
+#pragma unroll
+            for (int ct = 0; ct < NCOT; ++ct) av[ct] = wq[(tap * NCOT + ct) * 64];
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const float bv = xq[(2 * wave + (sg >> 1) + ky) * C3_PW + (sg & 1) * 16 + kx];
+#pragma unroll
+                for (int ct = 0; ct < NCOT; ++ct) acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct], bv, acc[sg][ct], 0, 0, 0);
+            }
+        }
+        if (q + 1 < nchunks) store_w(q + 1);
+    }
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+        const int oy = h0 + 2 * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
+        if (oy < a.H && ox < a.W) {
+#pragma unroll
+            for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 16 * ct + 4 * lg + r;
+                    if (co < a.Cout) {
+                        float v = acc[sg][ct][r];
+                        if (a.bias) v += a.bias[co];
+                        a.y[((long long)b * a.Cout + co) * plane + (long long)oy * a.W + ox] = act_apply(v, a.act, a.slope);
+                    }
+                }
+        }
+    }
+}
+
+template <int NCOT>
+static int launch_conv3x3_t(ConvArgs a, hipStream_t st) {
+    a.tiles_x = mrx_cdiv(a.W, CV_TW);
+    const int ntiles = a.tiles_x * mrx_cdiv(a.H, CV_TH);
+    constexpr size_t lds = sizeof(float) * (2 * C3_XBUF + 2 * 9 * NCOT * 64);
+    static_assert(lds <= 48 * 1024, "fits the default dynamic LDS limit");
+    hipLaunchKernelGGL((k_conv3x3_t<NCOT>), dim3(ntiles, 1, a.B), dim3(CV_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 extern "C" int mrx_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H,
                           int W, int k, int dil, int pad_mode, int act, float slope, void* stream) {
     MRX_REQUIRE(x && w && y, MRX_EINVAL, "mrx_conv2d: null pointer");
@@ -429,6 +569,13 @@ extern "C" int mrx_conv2d(const float* x, const float* w, const float* bias, flo
     a.pad_mode = pad_mode;
     a.act = act;
     a.slope = slope;
+    if (k == 3 && dil == 1 && Cout <= 64 && (long long)H * W < (1ll << 30) && B <= 65535 && !getenv("MRX_CONV_GENERIC")) {
+        const int ncot = (Cout + 15) / 16;
+        if (ncot == 1) return launch_conv3x3_t<1>(a, (hipStream_t)stream);
+        if (ncot == 2) return launch_conv3x3_t<2>(a, (hipStream_t)stream);
+        if (ncot == 3) return launch_conv3x3_t<3>(a, (hipStream_t)stream);
+        return launch_conv3x3_t<4>(a, (hipStream_t)stream);
+    }
     return launch_conv(a, 0, (hipStream_t)stream);
 }
 

@@ -20,6 +20,9 @@ CASES = [  # B, Cin, Cout, H, W, k, dil
     (1, 4, 64, 16, 12, 5, 1), (2, 64, 64, 13, 18, 3, 2), (1, 64, 64, 40, 70, 3, 2), (1, 3, 5, 9, 33, 3, 1),
     (2, 7, 33, 17, 19, 3, 1), (1, 2, 14, 32, 16, 3, 1), (1, 28, 14, 15, 12, 3, 1), (1, 16, 48, 16, 12, 3, 1),
     (1, 64, 64, 8, 32, 1, 1), (1, 5, 96, 10, 37, 5, 2), (1, 1, 1, 1, 1, 3, 1), (1, 18, 130, 9, 9, 3, 1),
+    # NormUnet shapes: the tuned 3x3 kernel (16-wide MFMA blocks, LDS-DMA tile), 1..4 cout blocks, ragged tiles, batch
+    (1, 14, 14, 24, 100, 3, 1), (1, 56, 56, 20, 24, 3, 1), (1, 56, 28, 17, 21, 3, 1), (2, 28, 28, 9, 95, 3, 1),
+    (1, 14, 28, 33, 47, 3, 1), (1, 2, 14, 64, 380, 3, 1), (1, 64, 64, 8, 32, 3, 1), (3, 6, 40, 5, 7, 3, 1),
 ]
 
 
