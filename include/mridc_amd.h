@@ -195,6 +195,16 @@ int mrx_mgu_gates(const float* ih, const float* hh, const float* h, float* out, 
  *   mrx_copy_channels       dst[:, c0:c0+C] = src for the skip concat                                      (:224) */
 /* work: caller scratch of mrx_norm_work_floats(planes|groups, HW|n) floats (statistics are reduced by many workgroups per plane) */
 int64_t mrx_norm_work_floats(int64_t planes, int64_t n);
+/* Conv3x3 + InstanceNorm statistics in one pass over the conv accumulators (unet_block.py:251-253: Conv2d -> InstanceNorm2d):
+ *   mrx_conv2d_stats          y = conv(x) (no activation) and stats[b][co] = (mean, sum of squared deviations) of every output plane;
+ *                             3x3, dilation 1, Cout <= 64 only (mrx_conv2d_stats_supported); work = mrx_conv2d_stats_work_floats floats
+ *   mrx_instance_norm_apply   out = act((x - mean) / sqrt(M2 / HW + eps)) from those statistics, in place allowed */
+int64_t mrx_conv2d_stats_work_floats(int B, int Cout, int H, int W);
+int mrx_conv2d_stats_supported(int B, int Cout, int H, int W, int k, int dil);
+int mrx_conv2d_stats(const float* x, const float* w, const float* bias, float* y, float* stats, float* work, int B, int Cin, int Cout,
+                     int H, int W, int k, int dil, int pad_mode, void* stream);
+int mrx_instance_norm_apply(const float* x, float* out, const float* stats, int64_t planes, int64_t HW, float eps, int act, float slope,
+                            void* stream);
 int mrx_instance_norm_act(const float* x, float* out, float* work, int64_t planes, int64_t HW, float eps, int act,
                           float slope, void* stream);
 int mrx_group_norm_stats(const float* x, float* mean, float* std_, float* work, int64_t groups, int64_t n, void* stream);

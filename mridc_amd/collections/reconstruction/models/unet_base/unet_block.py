@@ -34,10 +34,8 @@ class ConvBlock(torch.nn.Module):
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         if self.training and self.drop_prob > 0:
             raise NotImplementedError("Dropout2d in training mode is not part of the HIP inference path")
-        x = ops.conv2d(image, self.layers[0].weight, None, 1, ops.PAD_ZERO)
-        x = ops.instance_norm_act(x, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
-        x = ops.conv2d(x, self.layers[4].weight, None, 1, ops.PAD_ZERO)
-        return ops.instance_norm_act(x, self.layers[5].eps, ops.ACT_LEAKY, 0.2)
+        x = ops.conv_instance_norm_act(image, self.layers[0].weight, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
+        return ops.conv_instance_norm_act(x, self.layers[4].weight, self.layers[5].eps, ops.ACT_LEAKY, 0.2)
 
 
 class TransposeConvBlock(torch.nn.Module):

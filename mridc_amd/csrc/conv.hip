@@ -34,6 +34,7 @@ struct ConvArgs {
     const float* hprev;  // optional previous hidden state [B,Cout,H,W]
     const float* w_ih;   // fused mode: 1x1 weights [F][F]
     const float* b_ih;
+    float* tstats;       // tuned 3x3 with fused InstanceNorm statistics: per-tile (mean, M2) per cout, [B][ntiles][Cout][2]
     int B, Cin, Cout, H, W, k, dil, pad, pad_mode, act;
     float slope;
     int tiles_x, CK, PH, PW;
@@ -416,7 +417,7 @@ typedef float c3_f4 __attribute__((ext_vector_type(4)));
 #define C3_PW 34
 #define C3_PLANE 368   // 10 rows x 34 used (340); 368 = 16 mod 32: the four channel planes of an MFMA land on different banks
 #define C3_XBUF (4 * C3_PLANE)
-template <int NCOT>
+template <int NCOT, bool STATS>
 __global__ __launch_bounds__(CV_NT, NCOT >= 4 ? 3 : 4) void k_conv3x3_t(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float* Xs = smem_f;                   // [2][4][C3_PLANE]
@@ -514,10 +515,12 @@ __global__ __launch_bounds__(CV_NT, NCOT >= 4 ? 3 : 4) void k_conv3x3_t(ConvArgs
         }
         if (q + 1 < nchunks) store_w(q + 1);
     }
+    bool ok[4];
 #pragma unroll
     for (int sg = 0; sg < 4; ++sg) {
         const int oy = h0 + 2 * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
-        if (oy < a.H && ox < a.W) {
+        ok[sg] = oy < a.H && ox < a.W;
+        if (ok[sg]) {
 #pragma unroll
             for (int ct = 0; ct < NCOT; ++ct)
 #pragma unroll
@@ -531,17 +534,109 @@ __global__ __launch_bounds__(CV_NT, NCOT >= 4 ? 3 : 4) void k_conv3x3_t(ConvArgs
                 }
         }
     }
+    if (STATS) {
+        // InstanceNorm statistics of this tile, per cout: mean over its valid pixels, then the sum of squared deviations from that
+        // mean (two exact-order block reductions); k_conv_stats_finalize merges the tiles with the parallel-variance formula.
+        __syncthreads();  // the staging buffers become the reduction scratch
+        float* red = smem_f;  // [4 waves][NCOT * 16]
+        const int nrow = a.H - h0 < CV_TH ? a.H - h0 : CV_TH, ncol = a.W - w0 < CV_TW ? a.W - w0 : CV_TW;
+        const float inv_n = 1.0f / (float)(nrow * ncol);
+        float mean[NCOT][4];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) {
+                        const float v = acc[sg][ct][r] + ((a.bias && 16 * ct + 4 * lg + r < a.Cout) ? a.bias[16 * ct + 4 * lg + r] : 0.f);
+                        const float d = pass == 0 ? v : (v - mean[ct][r]) * (v - mean[ct][r]);
+                        t += ok[sg] ? d : 0.f;
+                    }
+                    for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);  // over the 16 pixels lanes of this channel group
+                    if (l15 == 0) red[wave * (NCOT * 16) + 16 * ct + 4 * lg + r] = t;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * ct + 4 * lg + r;
+                    const float t = (red[c] + red[NCOT * 16 + c]) + (red[2 * NCOT * 16 + c] + red[3 * NCOT * 16 + c]);
+                    if (pass == 0) {
+                        mean[ct][r] = t * inv_n;
+                    } else if (wave == 0 && l15 == 0 && c < a.Cout) {
+                        float* o = a.tstats + ((((long long)b * gridDim.x + tile) * a.Cout) + c) * 2;
+                        o[0] = mean[ct][r];
+                        o[1] = t;
+                    }
+                }
+            __syncthreads();
+        }
+    }
+}
+
+// merge the per-tile (mean, M2) of k_conv3x3_t<., true> into per-plane (mean, M2): one wave per (b, cout), Chan et al. pairwise
+// updates in double; tile sizes follow from the tile index
+__global__ __launch_bounds__(64) void k_conv_stats_finalize(const float* __restrict__ tstats, float* __restrict__ stats, int ntiles,
+                                                           int tiles_x, int Cout, int H, int W) {
+    const int plane_id = blockIdx.x;  // b * Cout + co
+    const int b = plane_id / Cout, co = plane_id - b * Cout;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 64) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int nr = H - ty * CV_TH < CV_TH ? H - ty * CV_TH : CV_TH, nc = W - tx * CV_TW < CV_TW ? W - tx * CV_TW : CV_TW;
+        const double nb = (double)(nr * nc);
+        const float* p = tstats + (((long long)b * ntiles + t) * Cout + co) * 2;
+        const double mb = (double)p[0], qb = (double)p[1];
+        const double tot = n + nb, delta = mb - mean;
+        mean += delta * nb / tot;
+        m2 += qb + delta * delta * n * nb / tot;
+        n = tot;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double nb = __shfl_xor(n, off, 64), mb = __shfl_xor(mean, off, 64), qb = __shfl_xor(m2, off, 64);
+        const double tot = n + nb;
+        if (tot > 0.0) {
+            const double delta = mb - mean;
+            mean += delta * nb / tot;
+            m2 += qb + delta * delta * n * nb / tot;
+        }
+        n = tot;
+    }
+    if (threadIdx.x == 0) {
+        stats[(long long)plane_id * 2] = (float)mean;
+        stats[(long long)plane_id * 2 + 1] = (float)m2;
+    }
 }
 
 template <int NCOT>
-static int launch_conv3x3_t(ConvArgs a, hipStream_t st) {
+static int launch_conv3x3_t(ConvArgs a, hipStream_t st, float* stats = nullptr) {
     a.tiles_x = mrx_cdiv(a.W, CV_TW);
     const int ntiles = a.tiles_x * mrx_cdiv(a.H, CV_TH);
     constexpr size_t lds = sizeof(float) * (2 * C3_XBUF + 2 * 9 * NCOT * 64);
     static_assert(lds <= 48 * 1024, "fits the default dynamic LDS limit");
-    hipLaunchKernelGGL((k_conv3x3_t<NCOT>), dim3(ntiles, 1, a.B), dim3(CV_NT), lds, st, a);
+    if (a.tstats) {
+        hipLaunchKernelGGL((k_conv3x3_t<NCOT, true>), dim3(ntiles, 1, a.B), dim3(CV_NT), lds, st, a);
+        hipLaunchKernelGGL(k_conv_stats_finalize, dim3(a.B * a.Cout), dim3(64), 0, st, (const float*)a.tstats, stats, ntiles, a.tiles_x,
+                           a.Cout, a.H, a.W);
+    } else {
+        hipLaunchKernelGGL((k_conv3x3_t<NCOT, false>), dim3(ntiles, 1, a.B), dim3(CV_NT), lds, st, a);
+    }
     MRX_LAUNCH_CHECK();
     return MRX_OK;
+}
+static bool conv3x3_tuned_ok(int B, int Cout, int H, int W, int k, int dil) {
+    return k == 3 && dil == 1 && Cout <= 64 && (long long)H * W < (1ll << 30) && B <= 65535 && !getenv("MRX_CONV_GENERIC");
+}
+static int dispatch_conv3x3_t(const ConvArgs& a, hipStream_t st, float* stats) {
+    const int ncot = (a.Cout + 15) / 16;
+    if (ncot == 1) return launch_conv3x3_t<1>(a, st, stats);
+    if (ncot == 2) return launch_conv3x3_t<2>(a, st, stats);
+    if (ncot == 3) return launch_conv3x3_t<3>(a, st, stats);
+    return launch_conv3x3_t<4>(a, st, stats);
 }
 
 extern "C" int mrx_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H,
@@ -569,14 +664,43 @@ extern "C" int mrx_conv2d(const float* x, const float* w, const float* bias, flo
     a.pad_mode = pad_mode;
     a.act = act;
     a.slope = slope;
-    if (k == 3 && dil == 1 && Cout <= 64 && (long long)H * W < (1ll << 30) && B <= 65535 && !getenv("MRX_CONV_GENERIC")) {
-        const int ncot = (Cout + 15) / 16;
-        if (ncot == 1) return launch_conv3x3_t<1>(a, (hipStream_t)stream);
-        if (ncot == 2) return launch_conv3x3_t<2>(a, (hipStream_t)stream);
-        if (ncot == 3) return launch_conv3x3_t<3>(a, (hipStream_t)stream);
-        return launch_conv3x3_t<4>(a, (hipStream_t)stream);
-    }
+    if (conv3x3_tuned_ok(B, Cout, H, W, k, dil)) return dispatch_conv3x3_t(a, (hipStream_t)stream, nullptr);
     return launch_conv(a, 0, (hipStream_t)stream);
+}
+
+// conv (no activation) + the InstanceNorm statistics of its output in one pass over the accumulators (unet_block.py:251-253):
+// stats[b][co] = (mean, sum of squared deviations) over the H x W plane.  work: mrx_conv2d_stats_work_floats() floats.
+// Only the tuned 3x3 shapes; returns MRX_EUNSUP (no error text) otherwise so the caller takes mrx_conv2d + mrx_instance_norm_act.
+extern "C" int64_t mrx_conv2d_stats_work_floats(int B, int Cout, int H, int W) {
+    if (B < 0 || Cout < 1 || H < 1 || W < 1) return -1;
+    return (int64_t)B * mrx_cdiv(W, CV_TW) * mrx_cdiv(H, CV_TH) * Cout * 2;
+}
+extern "C" int mrx_conv2d_stats_supported(int B, int Cout, int H, int W, int k, int dil) { return conv3x3_tuned_ok(B, Cout, H, W, k, dil) ? 1 : 0; }
+extern "C" int mrx_conv2d_stats(const float* x, const float* w, const float* bias, float* y, float* stats, float* work, int B, int Cin,
+                                int Cout, int H, int W, int k, int dil, int pad_mode, void* stream) {
+    MRX_REQUIRE(x && w && y && stats && work, MRX_EINVAL, "mrx_conv2d_stats: null pointer");
+    int rc = conv_common_checks("mrx_conv2d_stats", B, Cin, Cout, H, W);
+    if (rc) return rc;
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv2d_stats: bad pad mode %d", pad_mode);
+    MRX_REQUIRE(conv3x3_tuned_ok(B, Cout, H, W, k, dil), MRX_EUNSUP, "mrx_conv2d_stats: only 3x3, dilation 1, Cout <= 64 (got k=%d dil=%d Cout=%d)",
+                k, dil, Cout);
+    if (B == 0) return MRX_OK;
+    ConvArgs a = {};
+    a.x = x;
+    a.w = w;
+    a.bias = bias;
+    a.y = y;
+    a.tstats = work;
+    a.B = B;
+    a.Cin = Cin;
+    a.Cout = Cout;
+    a.H = H;
+    a.W = W;
+    a.k = k;
+    a.dil = dil;
+    a.pad_mode = pad_mode;
+    a.act = MRX_ACT_NONE;
+    return dispatch_conv3x3_t(a, (hipStream_t)stream, stats);
 }
 
 extern "C" int mrx_indrnn_cell(const float* x, const float* w_ih, const float* b_ih, const float* hh, const float* h_prev,

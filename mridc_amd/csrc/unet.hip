@@ -105,6 +105,38 @@ extern "C" int mrx_instance_norm_act(const float* x, float* out, float* work, in
     return MRX_OK;
 }
 
+// InstanceNorm2d + activation from ready per-plane statistics (mean, sum of squared deviations) -- the second half of
+// mrx_instance_norm_act for producers that computed the statistics themselves (mrx_conv2d_stats)
+__global__ __launch_bounds__(UN_NT) void k_plane_norm_apply(const float* x, float* out, const float* stats, long long n, int nsplit, float eps,
+                                                            int act, float slope) {
+    long long a, b;
+    split_range(n, nsplit, blockIdx.y, a, b);
+    const float* p = x + (long long)blockIdx.x * n;
+    float* q = out + (long long)blockIdx.x * n;
+    const float mean = stats[(long long)blockIdx.x * 2];
+    const float var = stats[(long long)blockIdx.x * 2 + 1] / (float)n;
+    const float inv = 1.0f / sqrtf(var + eps);
+    for (long long i = a + threadIdx.x; i < b; i += UN_NT) {
+        float y = (p[i] - mean) * inv;
+        if (act == MRX_ACT_RELU)
+            y = y > 0.f ? y : 0.f;
+        else if (act == MRX_ACT_LEAKY)
+            y = y > 0.f ? y : y * slope;
+        q[i] = y;
+    }
+}
+extern "C" int mrx_instance_norm_apply(const float* x, float* out, const float* stats, int64_t planes, int64_t HW, float eps, int act,
+                                       float slope, void* stream) {
+    MRX_REQUIRE(x && out && stats && planes >= 0 && HW >= 1, MRX_EINVAL, "mrx_instance_norm_apply: bad argument");
+    if (planes == 0) return MRX_OK;
+    MRX_REQUIRE(planes < (1LL << 31), MRX_EUNSUP, "mrx_instance_norm_apply: too many planes");
+    const int ns = un_nsplit(HW);
+    hipLaunchKernelGGL(k_plane_norm_apply, dim3((unsigned)planes, ns), dim3(UN_NT), 0, (hipStream_t)stream, x, out, stats, (long long)HW, ns,
+                       eps, act, slope);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 // ---- group norm statistics: mean and UNBIASED std per group (unet_block.py:78-79) ---------------------------------------
 __global__ void k_group_finalize(const float* psum, const float* psq, float* mean_o, float* std_o, long long groups, long long n,
                                  int nsplit) {

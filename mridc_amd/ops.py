@@ -304,6 +304,27 @@ def instance_norm_act(x, eps=1e-5, act=ACT_LEAKY, slope=0.2, inplace=True):
     return out
 
 
+def conv_instance_norm_act(x, weight, eps=1e-5, act=ACT_LEAKY, slope=0.2, pad_mode=PAD_ZERO):
+    """Conv2d(3x3, no bias) -> InstanceNorm2d -> activation (unet_block.py:251-254).  Tuned shapes: the statistics come out of the conv's
+    own accumulators (mrx_conv2d_stats) and one more pass applies them; other shapes: conv, then the three-pass instance norm."""
+    x, weight = _lib.f32c(x), _lib.f32c(weight.detach())
+    B, Cin, H, W = _nchw(x)
+    Cout, Cin_w, kh, kw = [int(v) for v in weight.shape]
+    if Cin_w != Cin:
+        raise RuntimeError(f"input has inconsistent input_size: got {Cin}, expected {Cin_w}")
+    L = _lib.lib()
+    if kh != kw or not L.mrx_conv2d_stats_supported(B, Cout, H, W, kh, 1):
+        return instance_norm_act(conv2d(x, weight, None, 1, pad_mode), eps, act, slope)
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    stats = torch.empty(B * Cout * 2, dtype=torch.float32, device=x.device)
+    work = torch.empty(int(L.mrx_conv2d_stats_work_floats(B, Cout, H, W)), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_conv2d_stats(_lib.ptr(x), _lib.ptr(weight), None, _lib.ptr(y), _lib.ptr(stats), _lib.ptr(work), B, Cin, Cout, H, W,
+                                  kh, 1, int(pad_mode), _lib.stream_ptr()), "mrx_conv2d_stats")
+    _lib.check(L.mrx_instance_norm_apply(_lib.ptr(y), _lib.ptr(y), _lib.ptr(stats), B * Cout, H * W, float(eps), int(act), float(slope),
+                                         _lib.stream_ptr()), "mrx_instance_norm_apply")
+    return y
+
+
 def group_norm(x, groups):
     """(x - mean)/std per (b, group) with the unbiased std.  Returns (normalised, mean[B,G,1], std[B,G,1])."""
     x = _lib.f32c(x)

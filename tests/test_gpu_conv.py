@@ -46,6 +46,23 @@ def test_conv2d_vs_torch(case, pad_mode, dev):
     assert_close(got, ref, 1e-5, f"conv2d {case} {pad_mode}")
 
 
+@pytest.mark.parametrize("shape", [(1, 14, 14, 24, 100), (2, 2, 14, 64, 380), (1, 56, 56, 20, 24), (1, 28, 56, 17, 21), (2, 28, 28, 9, 95),
+                                   (1, 14, 28, 33, 47), (1, 6, 40, 5, 7), (1, 8, 100, 12, 12), (1, 3, 9, 1, 2)])
+def test_conv_instance_norm_fused_statistics(shape, dev):
+    """Conv3x3 -> InstanceNorm2d -> LeakyReLU(0.2) with the statistics taken from the conv accumulators (per-tile mean / M2 merged
+    with the parallel-variance formula) against torch's conv + instance_norm (which accumulates its statistics in double)."""
+    from mridc_amd import ops
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g) + 0.5
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5 + 0.05       # non-zero output mean: M2 is not just E[x^2]
+    ref = F.leaky_relu(F.instance_norm(F.conv2d(x, w, None, padding=1), eps=1e-5), 0.2)
+    got = ops.conv_instance_norm_act(x.to(dev), w.to(dev), 1e-5, ops.ACT_LEAKY, 0.2)
+    assert_close(got, ref, 1e-5, f"conv + instance norm {shape}")
+    sep = ops.instance_norm_act(ops.conv2d(x.to(dev), w.to(dev), None, 1, ops.PAD_ZERO), 1e-5, ops.ACT_LEAKY, 0.2)
+    assert_close(got, sep, 5e-6, "fused statistics vs the three-pass instance norm")
+
+
 def test_conv2d_small_cout_and_identity(dev):
     from mridc_amd import ops
     g = torch.Generator().manual_seed(1)
