@@ -2,6 +2,8 @@
 // unbiased std (:71-91), zero / reflect / crop padding (:93-111, :215-222), InstanceNorm2d + LeakyReLU (:252-253),
 // 2x2 average pooling (:206), ConvTranspose2d(k=2, s=2) (:293), channel-block copy for the skip concat (:224).
 // The 3x3 / 1x1 convolutions themselves go through conv.hip.
+#include <cstdint>
+
 #include "mrx_common.h"
 
 #define UN_NT 256
@@ -259,10 +261,59 @@ __global__ void k_convT2x2(const float* x, const float* w, float* out, int B, in
         out[o] = acc;
     }
 }
+// Tuned form: one thread per INPUT pixel and group of COG output channels (4 COG accumulators); the input plane is read once per
+// channel group (coalesced), the weights sit in LDS as float4 (dy, dx) quads read by broadcast, every output row gets float2 stores
+// that are contiguous across the wave.  The generic kernel above re-reads every input Cout*4 times.
+typedef float ct_f2 __attribute__((ext_vector_type(2)));
+typedef float ct_f4 __attribute__((ext_vector_type(4)));
+template <int COG>
+__global__ __launch_bounds__(UN_NT) void k_convT2x2_t(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int Cin,
+                                                      int Cout, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];  // [Cin][COG] quads of this channel group
+    const int g0 = blockIdx.y * COG, b = blockIdx.z;
+    for (int i = threadIdx.x; i < Cin * COG * 4; i += UN_NT) {
+        const int q = i & 3, co = (i >> 2) % COG, ci = (i >> 2) / COG;
+        wsm[i] = w[((long long)ci * Cout + g0 + co) * 4 + q];
+    }
+    __syncthreads();
+    const long long HW = (long long)H * W;
+    const long long pix = (long long)blockIdx.x * UN_NT + threadIdx.x;
+    if (pix >= HW) return;
+    const int y = (int)(pix / W), xx = (int)(pix - (long long)y * W);
+    const float* xp = x + (long long)b * Cin * HW + pix;
+    ct_f4 acc[COG];
+#pragma unroll
+    for (int co = 0; co < COG; ++co) acc[co] = (ct_f4){0.f, 0.f, 0.f, 0.f};
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float v = xp[(long long)ci * HW];
+        const ct_f4* wq = reinterpret_cast<const ct_f4*>(wsm) + ci * COG;
+#pragma unroll
+        for (int co = 0; co < COG; ++co) acc[co] += v * wq[co];  // same accumulation order over ci as the generic kernel
+    }
+    const int OW = 2 * W;
+    float* op = out + (((long long)b * Cout + g0) * 2 * H + 2 * y) * OW + 2 * xx;
+#pragma unroll
+    for (int co = 0; co < COG; ++co) {
+        float* o = op + (long long)co * 4 * HW;
+        *reinterpret_cast<ct_f2*>(o) = (ct_f2){acc[co][0], acc[co][1]};
+        *reinterpret_cast<ct_f2*>(o + OW) = (ct_f2){acc[co][2], acc[co][3]};
+    }
+}
+template <int COG>
+static int launch_convT2x2_t(const float* x, const float* w, float* out, int B, int Cin, int Cout, int H, int W, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)Cin * COG * 4;
+    hipLaunchKernelGGL((k_convT2x2_t<COG>), dim3((unsigned)(((long long)H * W + UN_NT - 1) / UN_NT), Cout / COG, B), dim3(UN_NT), lds, st, x, w,
+                       out, Cin, Cout, H, W);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
 extern "C" int mrx_conv_transpose2x2(const float* x, const float* w, float* out, int B, int Cin, int Cout, int H, int W,
                                      void* stream) {
     MRX_REQUIRE(x && w && out && B >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_transpose2x2: bad argument");
     if (B == 0) return MRX_OK;
+    const bool tuned = B <= 65535 && Cout <= 65535 * 8 && (size_t)Cin * 14 * 16 <= 48 * 1024 && (((uintptr_t)out) & 7) == 0;
+    if (tuned && Cout % 14 == 0) return launch_convT2x2_t<14>(x, w, out, B, Cin, Cout, H, W, (hipStream_t)stream);
+    if (tuned && Cout % 8 == 0) return launch_convT2x2_t<8>(x, w, out, B, Cin, Cout, H, W, (hipStream_t)stream);
     hipLaunchKernelGGL(k_convT2x2, dim3(un_grid((long long)B * Cout * 4 * H * W)), dim3(UN_NT), 0, (hipStream_t)stream, x, w, out, B,
                        Cin, Cout, H, W);
     MRX_LAUNCH_CHECK();

@@ -217,5 +217,10 @@ def test_unet_pieces_vs_torch(dev):
     assert_close(ops.avg_pool2x2(x.to(dev)), F.avg_pool2d(x, 2, 2), 1e-6, "avg pool")
     w = torch.randn(6, 4, 2, 2, generator=g)
     assert_close(ops.conv_transpose2x2(x.to(dev), w.to(dev)), F.conv_transpose2d(x, w, stride=2), 1e-5, "conv transpose")
+    for (B_, Ci, Co, H_, W_) in ((1, 28, 14, 33, 47), (2, 56, 28, 9, 23), (1, 16, 8, 5, 70), (1, 7, 3, 4, 4), (1, 28, 14, 320, 190)):
+        xt = torch.randn(B_, Ci, H_, W_, generator=g)
+        wt = torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5
+        assert_close(ops.conv_transpose2x2(xt.to(dev), wt.to(dev)), F.conv_transpose2d(xt, wt, stride=2), 1e-5,
+                     f"conv transpose {(B_, Ci, Co, H_, W_)} (channel-group kernel for Cout % 14 == 0 or % 8 == 0)")
     y = torch.randn(2, 3, 17, 22, generator=g)
     assert_close(ops.concat_channels(x.to(dev), y.to(dev)), torch.cat([x, y], 1), 1e-12, "concat")
