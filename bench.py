@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--width", type=int, default=372)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="replay the step as a captured hipGraph (falls back to eager)")
-    ap.add_argument("--model", default="cirim", choices=["cirim", "e2evn"],
+    ap.add_argument("--model", default="cirim", choices=["cirim", "e2evn", "qcirim"],
                     help="cirim = the headline workload (BASELINE.json metric); e2evn = configs[1], reported for reference")
     ap.add_argument("--mask", default="1d", choices=["1d", "2d"],
                     help="1d: random columns R=4 (SURVEY 8d primary); 2d: random 2-D points R=10 (stands in for the YAML's Poisson-2D)")
@@ -111,6 +111,78 @@ def cpu_baseline(cfg, state_dict, data, gpu_out, n_cascades):
                 sample=f"{n_cascades} of {cfg['num_cascades']} cascades ({n_cascades * T_} of {cfg['num_cascades'] * T_} RIM "
                        f"steps) of one slice on the oracle (torch CPU ops, {ncores} threads), {dt:.1f} s, extrapolated "
                        f"x{cfg['num_cascades'] / n_cascades:g}"), rel, ssim
+
+
+def bench_qcirim(args, world, rank, dev):
+    """configs[4]: qCIRIM (quantitative R2*/S0/B0/phi mapping), 4 echoes, 32 coils, 256x256, IndRNN 128 filters, 1 cascade x 8 time-steps
+    (projects/quantitative/model_zoo/conf/base_qcirim_run.yaml defaults).  Random maps and data: throughput only."""
+    from mridc_amd.collections.quantitative.models.qcirim import qCIRIM
+    cfg = {"quantitative_module_recurrent_layer": "IndRNN", "quantitative_module_conv_filters": [128, 128, 4],
+           "quantitative_module_conv_kernels": [5, 3, 3], "quantitative_module_conv_dilations": [1, 2, 1],
+           "quantitative_module_conv_bias": [True, True, False], "quantitative_module_recurrent_filters": [128, 128, 0],
+           "quantitative_module_recurrent_kernels": [1, 1, 0], "quantitative_module_recurrent_dilations": [1, 1, 0],
+           "quantitative_module_recurrent_bias": [True, True, False], "quantitative_module_depth": 2,
+           "quantitative_module_time_steps": 8, "quantitative_module_num_cascades": 1, "quantitative_module_no_dc": True,
+           "quantitative_module_signal_forward_model_sequence": "MEGRE", "quantitative_module_dimensionality": 2,
+           "quantitative_module_gamma_regularization_factors": [150.0, 150.0, 1000.0, 150.0], "use_reconstruction_module": False,
+           "fft_centered": False, "fft_normalization": "backward", "spatial_dims": [-2, -1], "coil_dim": 2,
+           "coil_combination_method": "SENSE"}
+    torch.manual_seed(0)
+    model = qCIRIM(cfg).eval().to(dev)
+    E, C, H, W = 4, 32, 256, 256
+    TEs = [3.0, 11.5, 20.0, 28.5]
+    NS = max(1, args.streams)
+    datas = []
+    for i in range(NS):
+        g = torch.Generator().manual_seed(100 + rank * NS + i)
+        maps = [torch.rand(1, H, W, generator=g) * s for s in (0.3, 1.0, 0.1, 0.5)]
+        S = torch.randn(1, C, H, W, 2, generator=g) / C ** 0.5
+        mask = (torch.rand(1, 1, 1, 1, W, 1, generator=g) < 0.3)
+        y = torch.randn(1, E, C, H, W, 2, generator=g) * mask
+        datas.append([t.to(dev) for t in maps] + [y.to(dev), S.to(dev), mask.to(dev)])
+
+    def step(d):
+        with torch.no_grad():
+            return next(model(d[0], d[1], d[2], d[3], TEs, d[4], d[5], None, d[6]))
+
+    for _ in range(max(args.warmup, 1)):
+        step(datas[0])
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(NS)]
+    graphs = []
+    if args.graph:
+        try:
+            for d, st in zip(datas, streams):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    step(d)
+                torch.cuda.current_stream().wait_stream(st)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=st):
+                    step(d)
+                graphs.append(g_)
+            torch.cuda.synchronize()
+        except Exception as ex:  # noqa: BLE001
+            print(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
+            graphs = []
+            torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                if graphs:
+                    graphs[i].replay()
+                else:
+                    step(datas[i])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps(dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256", value=world * NS * args.steps / elapsed,
+                              unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
+                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                              config=dict(workload=f"qCIRIM 1 cascade x 8 time-steps, IndRNN 128 filters, 4 echoes, 32 coils, 256x256, {NS} slice(s) "
+                                                   f"per GPU and step ({NS} HIP stream(s), {'hipGraph' if graphs else 'eager'}), random-init weights",
+                                          parallelism=f"slice-sharded x{world}"))), flush=True)
 
 
 def bench_e2evn(args, world, rank, dev):
@@ -197,6 +269,8 @@ def main():
 
     if args.model == "e2evn":
         return bench_e2evn(args, world, rank, dev)
+    if args.model == "qcirim":
+        return bench_qcirim(args, world, rank, dev)
     cfg = dict(synthetic.CIRIM_BASELINE_CFG)
     torch.manual_seed(0)                                # reference-identical initialisation (tests/test_host_logic.py)
     model = CIRIM(cfg).eval()
