@@ -431,6 +431,7 @@ __global__ __launch_bounds__(CV_NT, NCOT >= 4 ? 3 : 4) void k_conv3x3_t(ConvArgs
     const int ty0 = tile / a.tiles_x;
     const int h0 = ty0 * CV_TH, w0 = (tile - ty0 * a.tiles_x) * CV_TW;
     const int b = blockIdx.z;
+    const int co0 = blockIdx.y * (NCOT * 16);  // small images: the cout blocks are spread over workgroups (grid.y) to fill the chip
     const long long plane = (long long)a.H * a.W;
     const float* xb = a.x + (long long)b * a.Cin * plane;
     const int nchunks = (a.Cin + 3) / 4;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(CV_NT, NCOT >= 4 ? 3 : 4) void k_conv3x3_t(ConvArgs
         for (int j = 0; j < NWL; ++j) {
             const int i = tid + j * CV_NT;
             const int ln = i & 63, ct = (i >> 6) % NCOT, tap = (i >> 6) / NCOT;
-            const int co = 16 * ct + (ln & 15), ci = 4 * q + (ln >> 4);
+            const int co = co0 + 16 * ct + (ln & 15), ci = 4 * q + (ln >> 4);
             wr[j] = (i < WBUF && co < a.Cout && ci < a.Cin) ? a.w[((long long)co * a.Cin + ci) * 9 + tap] : 0.f;
         }
     };
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(CV_NT, NCOT >= 4 ? 3 : 4) void k_conv3x3_t(ConvArgs
             for (int ct = 0; ct < NCOT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = 16 * ct + 4 * lg + r;
+                    const int co = co0 + 16 * ct + 4 * lg + r;
                     if (co < a.Cout) {
                         float v = acc[sg][ct][r];
                         if (a.bias) v += a.bias[co];
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(CV_NT, NCOT >= 4 ? 3 : 4) void k_conv3x3_t(ConvArgs
                     float t = 0.f;
 #pragma unroll
                     for (int sg = 0; sg < 4; ++sg) {
-                        const float v = acc[sg][ct][r] + ((a.bias && 16 * ct + 4 * lg + r < a.Cout) ? a.bias[16 * ct + 4 * lg + r] : 0.f);
+                        const float v = acc[sg][ct][r] + ((a.bias && co0 + 16 * ct + 4 * lg + r < a.Cout) ? a.bias[co0 + 16 * ct + 4 * lg + r] : 0.f);
                         const float d = pass == 0 ? v : (v - mean[ct][r]) * (v - mean[ct][r]);
                         t += ok[sg] ? d : 0.f;
                     }
@@ -567,8 +568,8 @@ __global__ __launch_bounds__(CV_NT, NCOT >= 4 ? 3 : 4) void k_conv3x3_t(ConvArgs
                     const float t = (red[c] + red[NCOT * 16 + c]) + (red[2 * NCOT * 16 + c] + red[3 * NCOT * 16 + c]);
                     if (pass == 0) {
                         mean[ct][r] = t * inv_n;
-                    } else if (wave == 0 && l15 == 0 && c < a.Cout) {
-                        float* o = a.tstats + ((((long long)b * gridDim.x + tile) * a.Cout) + c) * 2;
+                    } else if (wave == 0 && l15 == 0 && co0 + c < a.Cout) {
+                        float* o = a.tstats + ((((long long)b * gridDim.x + tile) * a.Cout) + co0 + c) * 2;
                         o[0] = mean[ct][r];
                         o[1] = t;
                     }
@@ -616,14 +617,15 @@ template <int NCOT>
 static int launch_conv3x3_t(ConvArgs a, hipStream_t st, float* stats = nullptr) {
     a.tiles_x = mrx_cdiv(a.W, CV_TW);
     const int ntiles = a.tiles_x * mrx_cdiv(a.H, CV_TH);
+    const int gy = mrx_cdiv(a.Cout, NCOT * 16);
     constexpr size_t lds = sizeof(float) * (2 * C3_XBUF + 2 * 9 * NCOT * 64);
     static_assert(lds <= 48 * 1024, "fits the default dynamic LDS limit");
     if (a.tstats) {
-        hipLaunchKernelGGL((k_conv3x3_t<NCOT, true>), dim3(ntiles, 1, a.B), dim3(CV_NT), lds, st, a);
+        hipLaunchKernelGGL((k_conv3x3_t<NCOT, true>), dim3(ntiles, gy, a.B), dim3(CV_NT), lds, st, a);
         hipLaunchKernelGGL(k_conv_stats_finalize, dim3(a.B * a.Cout), dim3(64), 0, st, (const float*)a.tstats, stats, ntiles, a.tiles_x,
                            a.Cout, a.H, a.W);
     } else {
-        hipLaunchKernelGGL((k_conv3x3_t<NCOT, false>), dim3(ntiles, 1, a.B), dim3(CV_NT), lds, st, a);
+        hipLaunchKernelGGL((k_conv3x3_t<NCOT, false>), dim3(ntiles, gy, a.B), dim3(CV_NT), lds, st, a);
     }
     MRX_LAUNCH_CHECK();
     return MRX_OK;
@@ -633,7 +635,9 @@ static bool conv3x3_tuned_ok(int B, int Cout, int H, int W, int k, int dil) {
 }
 static int dispatch_conv3x3_t(const ConvArgs& a, hipStream_t st, float* stats) {
     const int ncot = (a.Cout + 15) / 16;
-    if (ncot == 1) return launch_conv3x3_t<1>(a, st, stats);
+    // few tiles (the pooled levels of the U-Net): one cout block per workgroup, cout blocks across grid.y, so ~4x the workgroups
+    const long long tiles = (long long)mrx_cdiv(a.W, CV_TW) * mrx_cdiv(a.H, CV_TH) * a.B;
+    if (ncot == 1 || tiles < 1024) return launch_conv3x3_t<1>(a, st, stats);
     if (ncot == 2) return launch_conv3x3_t<2>(a, st, stats);
     if (ncot == 3) return launch_conv3x3_t<3>(a, st, stats);
     return launch_conv3x3_t<4>(a, st, stats);
