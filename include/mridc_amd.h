@@ -205,6 +205,10 @@ int mrx_conv2d_stats(const float* x, const float* w, const float* bias, float* y
                      int H, int W, int k, int dil, int pad_mode, void* stream);
 int mrx_instance_norm_apply(const float* x, float* out, const float* stats, int64_t planes, int64_t HW, float eps, int act, float slope,
                             void* stream);
+/*   mrx_instance_norm_apply_tiles   the same from the per-tile statistics mrx_conv2d_stats leaves in `work` when called with
+ *                                   stats = NULL (every workgroup merges the tiles of its plane itself: one launch fewer) */
+int mrx_instance_norm_apply_tiles(const float* x, float* out, const float* tile_stats, int B, int C, int H, int W, float eps, int act,
+                                  float slope, void* stream);
 int mrx_instance_norm_act(const float* x, float* out, float* work, int64_t planes, int64_t HW, float eps, int act,
                           float slope, void* stream);
 int mrx_group_norm_stats(const float* x, float* mean, float* std_, float* work, int64_t groups, int64_t n, void* stream);

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "mrx_conv2d_stats_supported": ([_i, _i, _i, _i, _i, _i], _i),
     "mrx_conv2d_stats": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_instance_norm_apply": ([_p, _p, _p, _i64, _i64, _f, _i, _f, _p], _i),
+    "mrx_instance_norm_apply_tiles": ([_p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _p], _i),
     "mrx_group_norm_stats": ([_p, _p, _p, _p, _i64, _i64, _p], _i),
     "mrx_group_norm_apply": ([_p, _p, _p, _p, _i64, _i64, _i, _p], _i),
     "mrx_pad2d": ([_p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p], _i),

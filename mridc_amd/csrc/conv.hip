@@ -22,8 +22,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CV_NT 256
-#define CV_TW 32
-#define CV_TH 8
+#define CV_TW MRX_CONV_TILE_W
+#define CV_TH MRX_CONV_TILE_H
 
 struct ConvArgs {
     const float* x;
@@ -622,8 +622,9 @@ static int launch_conv3x3_t(ConvArgs a, hipStream_t st, float* stats = nullptr) 
     static_assert(lds <= 48 * 1024, "fits the default dynamic LDS limit");
     if (a.tstats) {
         hipLaunchKernelGGL((k_conv3x3_t<NCOT, true>), dim3(ntiles, gy, a.B), dim3(CV_NT), lds, st, a);
-        hipLaunchKernelGGL(k_conv_stats_finalize, dim3(a.B * a.Cout), dim3(64), 0, st, (const float*)a.tstats, stats, ntiles, a.tiles_x,
-                           a.Cout, a.H, a.W);
+        if (stats)  // (stats == nullptr: the caller merges the tile statistics itself -- mrx_instance_norm_apply_tiles)
+            hipLaunchKernelGGL(k_conv_stats_finalize, dim3(a.B * a.Cout), dim3(64), 0, st, (const float*)a.tstats, stats, ntiles,
+                               a.tiles_x, a.Cout, a.H, a.W);
     } else {
         hipLaunchKernelGGL((k_conv3x3_t<NCOT, false>), dim3(ntiles, gy, a.B), dim3(CV_NT), lds, st, a);
     }
@@ -682,7 +683,7 @@ extern "C" int64_t mrx_conv2d_stats_work_floats(int B, int Cout, int H, int W) {
 extern "C" int mrx_conv2d_stats_supported(int B, int Cout, int H, int W, int k, int dil) { return conv3x3_tuned_ok(B, Cout, H, W, k, dil) ? 1 : 0; }
 extern "C" int mrx_conv2d_stats(const float* x, const float* w, const float* bias, float* y, float* stats, float* work, int B, int Cin,
                                 int Cout, int H, int W, int k, int dil, int pad_mode, void* stream) {
-    MRX_REQUIRE(x && w && y && stats && work, MRX_EINVAL, "mrx_conv2d_stats: null pointer");
+    MRX_REQUIRE(x && w && y && work, MRX_EINVAL, "mrx_conv2d_stats: null pointer");
     int rc = conv_common_checks("mrx_conv2d_stats", B, Cin, Cout, H, W);
     if (rc) return rc;
     MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv2d_stats: bad pad mode %d", pad_mode);

@@ -35,6 +35,10 @@ void mrx_set_error(const char* fmt, ...);
         }                                                                                  \
     } while (0)
 
+// output tile of the convolution kernels (also the granule of the fused InstanceNorm tile statistics)
+#define MRX_CONV_TILE_H 8
+#define MRX_CONV_TILE_W 32
+
 static inline int mrx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // mask value as the multiplicative factor torch's type promotion gives (bool/uint8 -> float)

@@ -142,6 +142,85 @@ __global__ __launch_bounds__(UN_NT) void k_plane_norm_apply(const float* x, floa
         for (long long i = a + threadIdx.x; i < b; i += UN_NT) q[i] = un_act((p[i] - mean) * inv, act, slope);
     }
 }
+// the same pass fed by the per-tile statistics of mrx_conv2d_stats directly: every workgroup first merges the tiles of its plane
+// (one wave, parallel-variance update in double -- the arithmetic of k_conv_stats_finalize), which costs ~1 us per workgroup and
+// saves a dependent launch per convolution
+template <bool VEC>
+__global__ __launch_bounds__(UN_NT) void k_plane_norm_apply_tiles(const float* x, float* out, const float* tstats, int Cc, int H, int W,
+                                                                  int nsplit, float eps, int act, float slope) {
+    __shared__ float s_stat[2];
+    const long long n = (long long)H * W;
+    const int plane_id = blockIdx.x, b = plane_id / Cc, co = plane_id - b * Cc;
+    if (threadIdx.x < 64) {
+        const int tiles_x = (W + MRX_CONV_TILE_W - 1) / MRX_CONV_TILE_W, ntiles = tiles_x * ((H + MRX_CONV_TILE_H - 1) / MRX_CONV_TILE_H);
+        double cnt = 0.0, mean = 0.0, m2 = 0.0;
+        for (int t = threadIdx.x; t < ntiles; t += 64) {
+            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+            const int nr = H - ty * MRX_CONV_TILE_H < MRX_CONV_TILE_H ? H - ty * MRX_CONV_TILE_H : MRX_CONV_TILE_H;
+            const int nc = W - tx * MRX_CONV_TILE_W < MRX_CONV_TILE_W ? W - tx * MRX_CONV_TILE_W : MRX_CONV_TILE_W;
+            const double nb = (double)(nr * nc);
+            const float* p = tstats + (((long long)b * ntiles + t) * Cc + co) * 2;
+            const double mb = (double)p[0], qb = (double)p[1];
+            const double tot = cnt + nb, delta = mb - mean;
+            mean += delta * nb / tot;
+            m2 += qb + delta * delta * cnt * nb / tot;
+            cnt = tot;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double nb = __shfl_xor(cnt, off, 64), mb = __shfl_xor(mean, off, 64), qb = __shfl_xor(m2, off, 64);
+            const double tot = cnt + nb;
+            if (tot > 0.0) {
+                const double delta = mb - mean;
+                mean += delta * nb / tot;
+                m2 += qb + delta * delta * cnt * nb / tot;
+            }
+            cnt = tot;
+        }
+        if (threadIdx.x == 0) {
+            s_stat[0] = (float)mean;
+            s_stat[1] = (float)m2;
+        }
+    }
+    __syncthreads();
+    const float mean = s_stat[0];
+    const float inv = 1.0f / sqrtf(s_stat[1] / (float)n + eps);
+    const float* p = x + (long long)plane_id * n;
+    float* q = out + (long long)plane_id * n;
+    if (VEC) {
+        long long a, e;
+        split_range(n >> 2, nsplit, blockIdx.y, a, e);
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        float4* q4 = reinterpret_cast<float4*>(q);
+        for (long long i = a + threadIdx.x; i < e; i += UN_NT) {
+            float4 v = p4[i];
+            v.x = un_act((v.x - mean) * inv, act, slope);
+            v.y = un_act((v.y - mean) * inv, act, slope);
+            v.z = un_act((v.z - mean) * inv, act, slope);
+            v.w = un_act((v.w - mean) * inv, act, slope);
+            q4[i] = v;
+        }
+    } else {
+        long long a, e;
+        split_range(n, nsplit, blockIdx.y, a, e);
+        for (long long i = a + threadIdx.x; i < e; i += UN_NT) q[i] = un_act((p[i] - mean) * inv, act, slope);
+    }
+}
+extern "C" int mrx_instance_norm_apply_tiles(const float* x, float* out, const float* tile_stats, int B, int Cc, int H, int W, float eps,
+                                             int act, float slope, void* stream) {
+    MRX_REQUIRE(x && out && tile_stats && B >= 0 && Cc >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_instance_norm_apply_tiles: bad argument");
+    if (B == 0) return MRX_OK;
+    const long long HW = (long long)H * W, planes = (long long)B * Cc;
+    MRX_REQUIRE(planes < (1LL << 31), MRX_EUNSUP, "mrx_instance_norm_apply_tiles: too many planes");
+    const int ns = un_nsplit(HW);
+    if ((HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0)
+        hipLaunchKernelGGL(k_plane_norm_apply_tiles<true>, dim3((unsigned)planes, ns), dim3(UN_NT), 0, (hipStream_t)stream, x, out, tile_stats,
+                           Cc, H, W, ns, eps, act, slope);
+    else
+        hipLaunchKernelGGL(k_plane_norm_apply_tiles<false>, dim3((unsigned)planes, ns), dim3(UN_NT), 0, (hipStream_t)stream, x, out, tile_stats,
+                           Cc, H, W, ns, eps, act, slope);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
 extern "C" int mrx_instance_norm_apply(const float* x, float* out, const float* stats, int64_t planes, int64_t HW, float eps, int act,
                                        float slope, void* stream) {
     MRX_REQUIRE(x && out && stats && planes >= 0 && HW >= 1, MRX_EINVAL, "mrx_instance_norm_apply: bad argument");

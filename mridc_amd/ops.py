@@ -316,13 +316,36 @@ def conv_instance_norm_act(x, weight, eps=1e-5, act=ACT_LEAKY, slope=0.2, pad_mo
     if kh != kw or not L.mrx_conv2d_stats_supported(B, Cout, H, W, kh, 1):
         return instance_norm_act(conv2d(x, weight, None, 1, pad_mode), eps, act, slope)
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
-    stats = torch.empty(B * Cout * 2, dtype=torch.float32, device=x.device)
+    work = torch.empty(int(L.mrx_conv2d_stats_work_floats(B, Cout, H, W)), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_conv2d_stats(_lib.ptr(x), _lib.ptr(weight), None, _lib.ptr(y), None, _lib.ptr(work), B, Cin, Cout, H, W,
+                                  kh, 1, int(pad_mode), _lib.stream_ptr()), "mrx_conv2d_stats")
+    _lib.check(L.mrx_instance_norm_apply_tiles(_lib.ptr(y), _lib.ptr(y), _lib.ptr(work), B, Cout, H, W, float(eps), int(act),
+                                               float(slope), _lib.stream_ptr()), "mrx_instance_norm_apply_tiles")
+    return y
+
+
+def conv2d_stats(x, weight, pad_mode=PAD_ZERO):
+    """(conv3x3(x), per-plane (mean, sum of squared deviations) [B, Cout, 2]) in one pass (mrx_conv2d_stats, tuned shapes only)."""
+    x, weight = _lib.f32c(x), _lib.f32c(weight.detach())
+    B, Cin, H, W = _nchw(x)
+    Cout, _, kh, _ = [int(v) for v in weight.shape]
+    L = _lib.lib()
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    stats = torch.empty(B, Cout, 2, dtype=torch.float32, device=x.device)
     work = torch.empty(int(L.mrx_conv2d_stats_work_floats(B, Cout, H, W)), dtype=torch.float32, device=x.device)
     _lib.check(L.mrx_conv2d_stats(_lib.ptr(x), _lib.ptr(weight), None, _lib.ptr(y), _lib.ptr(stats), _lib.ptr(work), B, Cin, Cout, H, W,
                                   kh, 1, int(pad_mode), _lib.stream_ptr()), "mrx_conv2d_stats")
-    _lib.check(L.mrx_instance_norm_apply(_lib.ptr(y), _lib.ptr(y), _lib.ptr(stats), B * Cout, H * W, float(eps), int(act), float(slope),
-                                         _lib.stream_ptr()), "mrx_instance_norm_apply")
-    return y
+    return y, stats
+
+
+def instance_norm_apply(x, stats, eps=1e-5, act=ACT_LEAKY, slope=0.2):
+    """act((x - mean) / sqrt(M2 / HW + eps)) from ready per-plane statistics [B, C, 2]."""
+    x, stats = _lib.f32c(x), _lib.f32c(stats)
+    B, C, H, W = _nchw(x)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().mrx_instance_norm_apply(_lib.ptr(x), _lib.ptr(out), _lib.ptr(stats), B * C, H * W, float(eps), int(act),
+                                                  float(slope), _lib.stream_ptr()), "mrx_instance_norm_apply")
+    return out
 
 
 def group_norm(x, groups):

@@ -61,6 +61,12 @@ def test_conv_instance_norm_fused_statistics(shape, dev):
     assert_close(got, ref, 1e-5, f"conv + instance norm {shape}")
     sep = ops.instance_norm_act(ops.conv2d(x.to(dev), w.to(dev), None, 1, ops.PAD_ZERO), 1e-5, ops.ACT_LEAKY, 0.2)
     assert_close(got, sep, 5e-6, "fused statistics vs the three-pass instance norm")
+    # the two-launch form of the same thing: merged statistics as a tensor, then the apply pass
+    y, stats = ops.conv2d_stats(x.to(dev), w.to(dev))
+    conv = F.conv2d(x, w, None, padding=1).double()
+    assert_close(stats[..., 0].cpu(), conv.mean((2, 3)).float(), 1e-5, "plane means")
+    assert_close(stats[..., 1].cpu(), ((conv - conv.mean((2, 3), keepdim=True)) ** 2).sum((2, 3)).float(), 1e-5, "plane M2")
+    assert_close(ops.instance_norm_apply(y, stats, 1e-5, ops.ACT_LEAKY, 0.2), got, 1e-6, "apply from merged statistics")
 
 
 def test_conv2d_small_cout_and_identity(dev):
