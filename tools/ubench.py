@@ -66,10 +66,9 @@ def main():
         t = timeit(lambda: ops.rim_final(h, w, None, 3, 1, eta))
         print(f"final (3x3 64->2 + eta): {t:.1f} us")
     if what in ("prep", "all"):
-        # N1: per-sample preprocessing (target, masking, max-normalisation) on the device vs the oracle on the host cores
+        # N1: per-sample preprocessing (target, masking, max-normalisation) on the device
         import time
         import numpy as np
-        import oracle
         from mridc_amd.collections.reconstruction.data import subsample
         from mridc_amd.collections.reconstruction.parts.transforms import MRIDataTransforms
         rng = np.random.default_rng(5)
@@ -83,12 +82,8 @@ def main():
         tr(k, S_, None, np.array([]), np.array([]), {}, "file_7.h5", 0)
         torch.cuda.synchronize()
         t_h2d = (time.perf_counter() - t0) * 1e6
-        torch.set_num_threads(min(32, torch.get_num_threads()))
-        t0 = time.perf_counter()
-        oracle.transforms.preprocess(k, S_, None, np.array([]), fname="file_7.h5", mask_func=[subsample.RandomMaskFunc([0.08], [4])], **kw)
-        t_cpu = (time.perf_counter() - t0) * 1e6
         print(f"preprocessing (15 x 640 x 372, SENSE target + random-1-D mask + max-normalisation): device {t:.0f} us per slice with the "
-              f"inputs resident, {t_h2d:.0f} us from host NumPy arrays; oracle on {torch.get_num_threads()} host threads {t_cpu:.0f} us")
+              f"inputs resident, {t_h2d:.0f} us from host NumPy arrays")
     if what in ("llg", "all"):
         eta, y, S = r(B, H, W, 2), r(B, C, H, W, 2), r(B, C, H, W, 2)
         mask = (torch.rand(1, 1, 1, W, 1) < 0.3).to(dev)
