@@ -1011,6 +1011,7 @@ typedef PlanCT<320, 5, 8, 8> P320;
 typedef PlanCT<256, 8, 8, 4> P256;
 // rows per workgroup (row kernels) / columns per workgroup (column kernels) for the compile-time plans
 #define NSEQ_ROW_372 5
+#define NSEQ_HINV_372 4  // one-launch gradient: 4 coils per workgroup = 4 chunks at C = 15, 5 workgroups per CU, exactly two dispatch rounds (measured 40.6 vs 44.0 us)
 #define NSEQ_ROW_320 6
 #define NSEQ_ROW_256 8
 #define NSEQ_COL_640 4
@@ -1361,7 +1362,7 @@ extern "C" int mrx_fft_cols(const float* in, float* out, int64_t nimg, int H, in
 
 extern "C" int64_t mrx_llg_hinv_work_floats(int B, int C, int H, int W) {
     if (B < 0 || C < 1 || H < 1 || W < 1) return -1;
-    int g = pick_rows(W);
+    int g = W == 372 ? NSEQ_HINV_372 : pick_rows(W);
     const bool ct = (W == 372 || W == 320 || W == 256);
     if (!ct && g > C) g = C;
     return (int64_t)mrx_cdiv(C, g) * B * H * W * 2;
@@ -1388,7 +1389,8 @@ extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, c
     a.C = C;
     a.H = H;
     a.W = W;
-    a.g = pick_rows(W);
+    const bool mfma372 = W == 372 && getenv("MRX_LLG_MFMA");  // experimental matrix-pipe kernel: fixed at 5 coils per workgroup
+    a.g = W == 372 ? (mfma372 ? M372_G : NSEQ_HINV_372) : pick_rows(W);
     const bool ct = (W == 372 || W == 320 || W == 256);
     if (!ct && a.g > C) a.g = C;
     a.halfW = centered ? W / 2 : 0;
@@ -1405,7 +1407,8 @@ extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, c
     const float2 *pe = (const float2*)eta, *py = (const float2*)yt, *ps = (const float2*)S;
     // split the coil sum over workgroups only while the grid is small (rows x batch below ~4 workgroups per CU)
     float* part = (work && (long long)H * B < 1024) ? work : nullptr;
-    if (W == 372) return launch_hinv_p<P372, NSEQ_ROW_372>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
+    if (W == 372 && mfma372) return launch_hinv_p<P372, M372_G>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
+    if (W == 372) return launch_hinv_p<P372, NSEQ_HINV_372>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
     if (W == 320) return launch_hinv_p<P320, NSEQ_ROW_320>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
     if (W == 256) return launch_hinv_p<P256, NSEQ_ROW_256>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
     return launch_hinv_p<PlanRT, 1>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
