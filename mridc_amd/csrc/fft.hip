@@ -1010,7 +1010,7 @@ typedef PlanCT<640, 5, 8, 4, 4> P640;
 typedef PlanCT<320, 5, 8, 8> P320;
 typedef PlanCT<256, 8, 8, 4> P256;
 // rows per workgroup (row kernels) / columns per workgroup (column kernels) for the compile-time plans
-#define NSEQ_ROW_372 5
+#define NSEQ_ROW_372 4
 #define NSEQ_HINV_372 4  // one-launch gradient: 4 coils per workgroup = 4 chunks at C = 15, 5 workgroups per CU, exactly two dispatch rounds (measured 40.6 vs 44.0 us)
 #define NSEQ_ROW_320 6
 #define NSEQ_ROW_256 8
