@@ -145,7 +145,9 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
 
     float xr[CK][XSLOTS];
     float4 wr[WVEC];
-    float4 wir[WIVEC];
+    static_assert(WIVEC == 2, "ih weights: two float4 per thread");
+    typedef float wi4_t __attribute__((ext_vector_type(4)));
+    wi4_t wir0 = {0.f, 0.f, 0.f, 0.f}, wir1 = wir0;  // scalars, not an array: the array form stayed in scratch memory
     auto prefetch = [&](int q) {
 #pragma unroll
         for (int ci = 0; ci < CK; ++ci) {
@@ -179,9 +181,9 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
         }
     };
     auto prefetch_wi = [&]() {
-        const float4* src = reinterpret_cast<const float4*>(a.packed + (long long)nchunks * WCHUNK);
-#pragma unroll
-        for (int v = 0; v < WIVEC; ++v) wir[v] = src[tid + v * RL_NT];
+        const wi4_t* src = reinterpret_cast<const wi4_t*>(a.packed + (long long)nchunks * WCHUNK);
+        wir0 = src[tid];
+        wir1 = src[tid + RL_NT];
     };
 
     // The two workgroups sharing a CU start together and would stay in lockstep (both staging, then both on the matrix
@@ -201,11 +203,13 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
     __syncthreads();
     RL_STAMP(1)
 
+    // the accumulators start at the conv bias (loaded here, behind the staging latency) instead of adding it in the tail,
+    // where 32 more live registers would not fit
     f32x16 acc[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[ct][r] = a.b_conv ? a.b_conv[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
 
     for (int q = 0; q < nchunks; ++q) {
         const float* cur = smem_f + (q & 1) * BUF;
@@ -239,9 +243,9 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
         if (q + 1 < nchunks) {
             if (!(a.ablate & 8)) commit(oth);
         } else {
-            float4* dst = reinterpret_cast<float4*>(oth);
-#pragma unroll
-            for (int v = 0; v < WIVEC; ++v) dst[tid + v * RL_NT] = wir[v];
+            wi4_t* dst = reinterpret_cast<wi4_t*>(oth);
+            dst[tid] = wir0;
+            dst[tid + RL_NT] = wir1;
         }
         __syncthreads();
         if (q + 2 < nchunks) {
@@ -263,19 +267,24 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
     const int wch = lane >> 3, wpx = (lane & 7) * 4;
     const long long wbase = (long long)b * RL_F * plane + (long long)oy * a.W + w0 + wpx;
     const bool winside = oy < a.H && (w0 + wpx) < a.W;
+    // h_prev arrives in two halves: channels 0-31 before the ih GEMM, channels 32-63 halfway through it, when the first
+    // half of g is consumed and its 16 registers are free (all 32 up front overflowed the 128-register budget of 4 waves
+    // per SIMD: 80 B/lane of scratch, ~40 MB of spill traffic per launch at 640x372)
     float4 hp4[8];
+    const bool hp_live = wide && a.hprev && winside && !(a.ablate & 1);
+    auto load_hp = [&](int i0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        hp4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (wide && a.hprev && winside && !(a.ablate & 1))
-            hp4[i] = *reinterpret_cast<const float4*>(a.hprev + wbase + (long long)(i * 8 + wch) * plane);
-    }
+        for (int i = i0; i < i0 + 4; ++i) {
+            hp4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp_live) hp4[i] = *reinterpret_cast<const float4*>(a.hprev + wbase + (long long)(i * 8 + wch) * plane);
+        }
+    };
+    load_hp(0);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            const float v = acc[ct][r] + (a.b_conv ? a.b_conv[co] : 0.f);
+            const float v = acc[ct][r];
             acc[ct][r] = v > 0.f ? v : 0.f;
         }
     f32x16 acc2[2];
@@ -297,9 +306,11 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
                 acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa0[c], acc[t >> 4][t & 15], acc2[0], 0, 0, 0);
                 acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[c], acc[t >> 4][t & 15], acc2[1], 0, 0, 0);
             }
+            if (s == 16 + RL_PF) load_hp(4);
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    } else
+        load_hp(4);
     RL_STAMP(3)
     if (wide) {
         __syncthreads();  // every wave is done with Wi and the chunk buffers: LDS becomes 8 x [64][32] transpose tiles
