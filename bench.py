@@ -250,6 +250,23 @@ def bench_e2evn(args, world, rank, dev):
               flush=True)
 
 
+def measured_traffic(B, C, H, W, F):
+    """HBM bytes per launch of the hot kernels from the committed PMC passes (profiles/r01_v7_traffic.json: FETCH_SIZE and
+    WRITE_SIZE, one counter per rocprofv3 pass, gfx950 correction applied).  Counter collection cannot run inside the timed
+    bench (~0.3 s per dispatch), so the numbers are only reported when this run has the shape they were measured at."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v7_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except OSError:
+        return {}
+    if t["shape"] != dict(batch=B, coils=C, height=H, width=W, features=F):
+        return {}
+    out = {k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()}
+    out["_source"] = "profiles/r01_v7_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)"
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -398,17 +415,21 @@ def main():
             kname = ("k_rim_layer_wino (conv3x3 d2 64->64 as Winograd F(2x2,3x3) on the parity sub-lattices + IndRNN 1x1 fused, "
                      "fp32 MFMA 16x16x4 / 32x32x2)")
             executed = 2.0 * (F_hidden * F_hidden * 4 + F_hidden * F_hidden) * npix * B
+        traffic = measured_traffic(B, C, H, W, F_hidden)
         roofline = dict(bound="mfma", kernel=kname,
                         achieved=(flops2 / (ms2 * 1e-3) / 1e12) if ms2 else None, peak=PEAK_FP32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=(flops2 / (ms2 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms2 else None,
-                        traffic=None, launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
+                        traffic=traffic.get("conv_layer2_wino" if msw else "-"), traffic_unit="bytes/launch",
+                        traffic_source=traffic.get("_source"), algorithmic_bytes=3.0 * F_hidden * npix * B * 4,
+                        launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
                         mfma_frac=(executed / (ms2 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms2 else None)
         bytes_llg = (25.0 + 16.0 * C) * npix * B     # compulsory bytes of one log_likelihood_gradient
         msl, nl = timer.mean_ms("llg")
         roofline_fft = dict(bound="hbm", kernel="mrx_llg_hinv (1-D column mask: H transforms cancel, ONE launch of row FFTs per step on "
                                                 "yt = IFFT_H(y); 2-D masks use the 3-launch mrx_llg)",
                             achieved=(bytes_llg / (msl * 1e-3) / 1e9) if msl else None, peak=PEAK_HBM_GBS, unit="GB/s",
-                            frac=(bytes_llg / (msl * 1e-3) / 1e9 / PEAK_HBM_GBS) if msl else None, traffic=None,
+                            frac=(bytes_llg / (msl * 1e-3) / 1e9 / PEAK_HBM_GBS) if msl else None,
+                            traffic=traffic.get("llg") if args.mask == "1d" else None, traffic_unit="bytes/launch",
                             launches=nl, avg_ms=msl, bytes_per_call=bytes_llg)
         ms1, _ = timer.mean_ms("conv_layer1")
         msf, _ = timer.mean_ms("final")
