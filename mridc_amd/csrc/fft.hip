@@ -251,8 +251,8 @@ struct ColArgs {
 // workgroup id -> (image, column tile).  Workgroup b runs on XCD b % 8: hand every XCD a contiguous band of tiles so
 // the 128-byte lines shared by neighbouring column tiles are fetched into one L2 only (speed, not correctness).
 __device__ __forceinline__ void col_tile(const ColArgs& a, long long& img, int& w0) {
-    long long t = blockIdx.x;
-    if ((a.nblocks & 7) == 0) t = (long long)(blockIdx.x & 7) * (a.nblocks >> 3) + (blockIdx.x >> 3);
+    // 4-column tiles use 32 B of every 64-B request: the neighbour tile must hit the same L2 (PMC: FETCH_SIZE was 2x the input)
+    const long long t = mrx_xcd_band(blockIdx.x, a.nblocks);
     img = t / a.ntx;
     w0 = (int)(t - img * a.ntx) * a.ct;
 }

@@ -47,6 +47,14 @@ struct MrxMask {
     int kind;  // MRX_MASK_U8 / MRX_MASK_F32
     long long s[4];
 };
+// XCD-aware work order: workgroup b of a launch runs on XCD b % 8 (8 XCDs, one L2 each).  Returns the work item of
+// workgroup b such that every XCD walks one contiguous band of the n items, for any n (speed only; any order is correct):
+// neighbouring items, which share cache lines / halo rows, then meet in the same L2 at about the same time.
+__device__ __forceinline__ long long mrx_xcd_band(long long b, long long n) {
+    const long long x = b & 7, i = b >> 3, q = n >> 3, r = n & 7;
+    return x * q + (x < r ? x : r) + i;
+}
+
 __device__ __forceinline__ float mrx_mask_val(const MrxMask& m, long long b, long long c, long long h, long long w) {
     const long long off = b * m.s[0] + c * m.s[1] + h * m.s[2] + w * m.s[3];
     return m.kind == MRX_MASK_U8 ? (float)((const unsigned char*)m.p)[off] : ((const float*)m.p)[off];

@@ -122,8 +122,7 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous band of tiles so halo rows of
     // neighbouring tiles are served by the same L2 (speed only; any order is correct)
-    int tile = blockIdx.x;
-    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
+    const int tile = (int)mrx_xcd_band(blockIdx.x, a.ntiles);
     const int ty0 = tile / a.tiles_x;
     const int h0 = ty0 * RL_TH, w0 = (tile - ty0 * a.tiles_x) * RL_TW;
     const int b = blockIdx.y;
@@ -509,8 +508,7 @@ __global__ __launch_bounds__(RF_NT) void k_rim_final(RimFinalArgs a) {
     float* Xs = smem_f;                                       // [RF_CK][PLANE]
     float2* W2 = reinterpret_cast<float2*>(Xs + RF_CK * PLANE);  // [F][TAPS] (w0, w1)
     const int tid = threadIdx.x;
-    int tile = blockIdx.x;
-    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
+    const int tile = (int)mrx_xcd_band(blockIdx.x, a.ntiles);
     const int ty0 = tile / a.tiles_x;
     const int h0 = ty0 * RF_TH, w0 = (tile - ty0 * a.tiles_x) * RL_TW;
     const int b = blockIdx.y;
@@ -616,8 +614,7 @@ __global__ __launch_bounds__(RF4_NT, 4) void k_rim_final4(RimFinalArgs a) {
     float* Wp = smem_f + 2 * RF4_BUF;  // [F][9] pairs (w[0][ci][tap], w[1][ci][tap])
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = blockIdx.x;
-    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
+    const int tile = (int)mrx_xcd_band(blockIdx.x, a.ntiles);
     const int ty0 = tile / a.tiles_x;
     const int h0 = ty0 * RF4_TH, w0 = (tile - ty0 * a.tiles_x) * RF4_TW;
     const int b = blockIdx.y;
