@@ -48,6 +48,9 @@ def parse():
                     help="cirim = the headline workload (BASELINE.json metric); e2evn = configs[1], reported for reference")
     ap.add_argument("--mask", default="1d", choices=["1d", "2d"],
                     help="1d: random columns R=4 (SURVEY 8d primary); 2d: random 2-D points R=10 (stands in for the YAML's Poisson-2D)")
+    ap.add_argument("--rnn", default="IndRNN", choices=["IndRNN", "GRU", "MGU"],
+                    help="recurrent layer of the CIRIM cascades (headline: IndRNN; GRU with --cascades 1 is the reference's RIM config)")
+    ap.add_argument("--cascades", type=int, default=0, help="override num_cascades (0 = the headline's 8)")
     ap.add_argument("--cpu-cascades", type=int, default=1, help="cascades of the CPU-baseline sample")
     return ap.parse_args()
 
@@ -289,6 +292,9 @@ def main():
     if args.model == "qcirim":
         return bench_qcirim(args, world, rank, dev)
     cfg = dict(synthetic.CIRIM_BASELINE_CFG)
+    cfg["recurrent_layer"] = args.rnn
+    if args.cascades:
+        cfg["num_cascades"] = args.cascades
     torch.manual_seed(0)                                # reference-identical initialisation (tests/test_host_logic.py)
     model = CIRIM(cfg).eval()
     state_dict = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -433,11 +439,12 @@ def main():
                             launches=nl, avg_ms=msl, bytes_per_call=bytes_llg)
         ms1, _ = timer.mean_ms("conv_layer1")
         msf, _ = timer.mean_ms("final")
-        res = dict(metric="slices/sec (inference), CIRIM 8-cascade 15-coil 640x372", value=value, unit="slices/s",
+        res = dict(metric=f"slices/sec (inference), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}"
+                          + ("" if args.rnn == "IndRNN" else f" ({args.rnn})"), value=value, unit="slices/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload=f"CIRIM {cfg['num_cascades']} cascades x {T_} time-steps (config time_steps "
-                                        f"{cfg['time_steps']} rounded up as the reference does), IndRNN {F_hidden} filters, "
+                                        f"{cfg['time_steps']} rounded up as the reference does), {args.rnn} {F_hidden} filters, "
                                         f"{C} coils, {H}x{W}, {NS * B} slice(s) per GPU and step ({NS} concurrent HIP stream(s) x batch {B}, "
                                         f"one hipGraph each), random-init weights (seed 0)",
                                global_batch=world * NS * B, streams_per_gpu=NS, coils=C, height=H, width=W, parallelism=f"slice-sharded x{world}",

@@ -185,6 +185,17 @@ int mrx_gru_gates(const float* ih, const float* hh, const float* h, float* out, 
 int mrx_mgu_gates(const float* ih, const float* hh, const float* h, float* out, int B, int F, int64_t HW,
                   void* stream);
 
+/* A12 whole ConvGRUCell (gates = 3, rnn_cells.py:112-127) / ConvMGUCell (gates = 2, rnn_cells.py:249-261) with 1x1 `ih` and `hh`
+ * kernels in ONE launch: both per-pixel GEMMs on the matrix cores and the gate math on the accumulators; the gates*F-channel conv
+ * outputs are never materialised.  x [B,Cin,HW], h [B,F,HW] or NULL (zero state), out [B,F,HW] (must not alias x or h).
+ * Cin = F = 64 only (mrx_gated_cell_supported); other shapes: mrx_conv2d x2 + mrx_gru_gates / mrx_mgu_gates.
+ *   mrx_gated_cell_pack   w_ih [gates*F,Cin,1,1] and w_hh [gates*F,F,1,1] -> packed, mrx_gated_cell_pack_floats floats */
+int mrx_gated_cell_supported(int Cin, int F, int k, int gates);
+int64_t mrx_gated_cell_pack_floats(int Cin, int F, int gates);
+int mrx_gated_cell_pack(const float* w_ih, const float* w_hh, float* packed, int Cin, int F, int gates, void* stream);
+int mrx_gated_cell_1x1(const float* x, const float* h, const float* packed, const float* b_ih, float* out, int B, int Cin,
+                       int F, int64_t HW, int gates, void* stream);
+
 /* A17 NormUnet support (models/unet_base/unet_block.py).  Planes are [B*C] images of H*W floats.
  *   mrx_instance_norm_act   InstanceNorm2d (biased var, eps, no affine) + activation, in place allowed   (:252-253,:294-295)
  *   mrx_group_norm_stats    per-group mean and UNBIASED std over n contiguous floats                       (:78-79)

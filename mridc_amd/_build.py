@@ -18,6 +18,7 @@ SOURCES = [
     ("conv.hip", []),
     ("rim_layer.hip", []),
     ("rim_layer_wino.hip", []),
+    ("gated_cell.hip", []),
     ("unet.hip", []),
     ("qmri.hip", ["-ffp-contract=off"]),
 ]

@@ -13,8 +13,9 @@ class RIMBlock(torch.nn.Module):
 
     Per time-step the HIP path is six launches: three for log_likelihood_gradient (mrx_llg), one fused
     conv+IndRNN launch per recurrent layer (mrx_rim_layer_indrnn) and one for the final conv + eta update
-    (mrx_rim_final).  GRU / MGU layers and IndRNN layers whose shape the fused kernel does not cover run through
-    the unfused kernels (conv2d + cell).
+    (mrx_rim_final).  GRU / MGU layers with 1x1 gate kernels on 64 features (the model-zoo RIM config) are two launches: the
+    fused layer kernel with an identity `ih` as conv + ReLU, then the whole cell in one launch (mrx_gated_cell_1x1).  Other
+    shapes run through the unfused kernels (conv2d + cell).
 
     `winograd` (default on; env MRIDC_AMD_WINOGRAD=0 turns it off): 3x3 dilation-2 layers into 64 features use the
     Winograd F(2x2,3x3) form of the fused kernel (mrx_rim_layer_indrnn_wino).  It differs from the direct form by fp32
@@ -78,6 +79,31 @@ class RIMBlock(torch.nn.Module):
         return (isinstance(r, rnn_cells.IndRNNCell) and r.kernel_size == 1 and c is not None and c.act == ops.ACT_RELU
                 and c.features == r.hidden_size and r.hidden_size in (32, 64) and r.input_size == c.features)
 
+    @staticmethod
+    def _gated(stack):
+        """GRU / MGU stack the one-launch cell covers: 1x1 gate kernels on 64 features after a ReLU conv the fused layer covers."""
+        c, r = stack.convs, stack.rnn
+        return (isinstance(r, (rnn_cells.ConvGRUCell, rnn_cells.ConvMGUCell)) and c is not None and c.act == ops.ACT_RELU
+                and r.dilation == 1 and r.input_size == c.features
+                and ops.gated_cell_supported(c.features, r.hidden_size, r.kernel_size, r.GATES)
+                and (ops.rim_layer_wino_supported(c.input_size, c.features, c.kernel_size, c.dilation)
+                     or ops.rim_layer_supported(c.input_size, c.features, c.kernel_size, c.dilation)))
+
+    def _packed_gated(self, idx, c, r):
+        """(packed conv weights with an identity `ih`, packed cell weights, zero `hh`) of a gated stack, cached by version."""
+        w, wi, wh = c.conv_layer.weight, r.ih.weight, r.hh.weight
+        wino = self.winograd and ops.rim_layer_wino_supported(c.input_size, c.features, c.kernel_size, c.dilation)
+        key = (w.data_ptr(), w._version, wi.data_ptr(), wi._version, wh.data_ptr(), wh._version, str(w.device), wino)
+        hit = self._pack_cache.get(("gated", idx))
+        if hit is None or hit[0] != key:
+            # the fused layer kernel computes ReLU(I g + 0 * h_prev) = g = ReLU(conv(x)) exactly: a conv + ReLU launch
+            eye = torch.eye(c.features, dtype=torch.float32, device=w.device).reshape(c.features, c.features, 1, 1)
+            conv_pk = ops.rim_layer_wino_pack(w, eye) if wino else ops.rim_layer_pack(w, eye)
+            hit = (key, conv_pk, ops.gated_cell_pack(wi, wh, r.GATES),
+                   torch.zeros(c.features, dtype=torch.float32, device=w.device), wino)
+            self._pack_cache[("gated", idx)] = hit
+        return hit[1:]
+
     def _packed(self, idx, c, r):
         """Packed weights of layer `idx` for the tuned kernel, re-packed only when the parameters change."""
         w, wi = c.conv_layer.weight, r.ih.weight
@@ -91,6 +117,14 @@ class RIMBlock(torch.nn.Module):
 
     def _layer(self, idx, stack, x, h):
         """One conv+RNN stack.  `h` None = the zero initial state (rim_block.py:188-193) without materialising it."""
+        if self._gated(stack):
+            c, r = stack.convs, stack.rnn
+            conv_pk, cell_pk, hh0, wino = self._packed_gated(idx, c, r)
+            if wino:
+                g = ops.rim_layer_indrnn_wino(x, conv_pk, c.features, c.conv_layer.bias, None, hh0, None)
+            else:
+                g = ops.rim_layer_indrnn_packed(x, conv_pk, c.features, c.kernel_size, c.dilation, c.conv_layer.bias, None, hh0, None)
+            return ops.gated_cell_1x1(g, h, cell_pk, r.ih.bias, r.GATES, r.hidden_size)
         if h is None and not self._fusable(stack):
             h = x.new_zeros((x.size(0), stack.rnn.hidden_size, *x.size()[2:]))
         if self._fusable(stack):

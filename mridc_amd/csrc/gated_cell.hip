@@ -1,0 +1,222 @@
+// gated_cell.hip -- ConvGRUCell / ConvMGUCell with 1x1 kernels for gfx950 (reference models/rim/rnn_cells.py:112-127 and
+// :249-261; the RIM / CIRIM model-zoo configs use recurrent_kernels [1, 1, 0]), fp32 in / fp32 out on v_mfma_f32_32x32x2_f32.
+//
+// The reference runs two convolutions (`ih`: Cin -> GATES*F, `hh`: F -> GATES*F), chunks them and applies the gate math.
+// With 1x1 kernels both are per-pixel GEMMs, so the whole cell is ONE launch here: nothing of the GATES*F-channel
+// intermediates (183 MB each at 640x372) is ever written.
+//
+//   * a wave owns 32 consecutive pixels (the 1x1 cell has no spatial structure: the image is a flat run of H*W pixels);
+//     x and h_prev are read straight from HBM into the MFMA B-operand layout (lane = pixel, register = channel pair):
+//     32 coalesced 128-byte rows per operand, no LDS hop;
+//   * the packed weights of all 2*GATES matrices (96 KB for GRU) stay in LDS for the life of the persistent workgroup:
+//     one ds_read_b32 per lane per MFMA, conflict-free, read RL-style a few steps ahead of the MFMA that consumes them;
+//   * accumulators: the reset/update (GRU) or forget (MGU) pre-activations sum their ih and hh parts in one accumulator;
+//     the candidate keeps ih and hh apart (the gate multiplies only the hh part).  They start at the ih bias;
+//   * the gate math runs on the accumulators in registers; h_prev is re-read in accumulator layout (an L2 hit).
+#include <cstdint>
+#include <cstdlib>
+
+#include "mrx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GC_NT 512
+#define GC_F 64
+#define GC_PF 3  // operand prefetch distance (MFMA steps)
+
+struct GatedArgs {
+    const float* x;       // [B,64,P]
+    const float* h;       // [B,64,P] or null (= zeros)
+    const float* packed;  // mrx_gated_cell_pack
+    const float* b_ih;    // [GATES*64] or null
+    float* out;           // [B,64,P]
+    long long P, nsegb, nseg;  // pixels per image, 32-pixel segments per image, segments in total
+};
+
+// packed index (((mat*2 + mb)*32 + s)*2 + half)*32 + m  <-  W_mat[mb*32 + m][2*s + half],  mat = gate (ih) | GATES + gate (hh)
+__global__ void k_gated_pack(const float* __restrict__ w_ih, const float* __restrict__ w_hh, float* __restrict__ out, int gates) {
+    const int total = 2 * gates * GC_F * GC_F;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int m = i & 31, half = (i >> 5) & 1, s = (i >> 6) & 31, mb = (i >> 11) & 1, mat = i >> 12;
+        const int row = mb * 32 + m, col = 2 * s + half;
+        const float* w = mat < gates ? w_ih : w_hh;
+        const int g = mat < gates ? mat : mat - gates;
+        out[i] = w[(long long)(g * GC_F + row) * GC_F + col];
+    }
+}
+
+extern "C" int64_t mrx_gated_cell_pack_floats(int Cin, int F, int gates) {
+    if (Cin != GC_F || F != GC_F || (gates != 2 && gates != 3)) return -1;
+    return (int64_t)2 * gates * GC_F * GC_F;
+}
+
+extern "C" int mrx_gated_cell_supported(int Cin, int F, int k, int gates) {
+    return Cin == GC_F && F == GC_F && k == 1 && (gates == 2 || gates == 3);
+}
+
+extern "C" int mrx_gated_cell_pack(const float* w_ih, const float* w_hh, float* packed, int Cin, int F, int gates, void* stream) {
+    MRX_REQUIRE(w_ih && w_hh && packed, MRX_EINVAL, "mrx_gated_cell_pack: null pointer");
+    MRX_REQUIRE(mrx_gated_cell_supported(Cin, F, 1, gates), MRX_EUNSUP, "mrx_gated_cell_pack: Cin=%d F=%d gates=%d (64/64, 2|3 only)",
+                Cin, F, gates);
+    const int total = 2 * gates * GC_F * GC_F;
+    hipLaunchKernelGGL(k_gated_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh, packed, gates);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+__device__ __forceinline__ float gc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int GATES>  // 3 = GRU, 2 = MGU
+__global__ __launch_bounds__(GC_NT, 2) void k_gated_cell(GatedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [2*GATES][2][32][2][32]
+    constexpr int NMAT = 2 * GATES, MATF = GC_F * GC_F;
+    const int tid = threadIdx.x;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.packed);
+        float4* dst = reinterpret_cast<float4*>(Ws);
+        for (int i = tid; i < NMAT * MATF / 4; i += GC_NT) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* wl = Ws + lane;  // lane = half*32 + m
+
+    // accumulator d: 0 .. GATES-2 = gates whose ih and hh parts add up; GATES-1 = candidate ih part; GATES = candidate hh part
+    for (long long sg = (long long)blockIdx.x * (GC_NT / 64) + wave; sg < a.nseg; sg += (long long)gridDim.x * (GC_NT / 64)) {
+        // per-lane constants pass through an empty asm each round: the compiler would otherwise hoist the 64 channel
+        // offsets out of this loop and spill them
+        int l31 = lane & 31, lhi = lane >> 5;
+        asm volatile("" : "+v"(l31), "+v"(lhi));
+        const long long b = sg / a.nsegb;
+        const long long px = (sg - b * a.nsegb) * 32 + l31;
+        const bool valid = px < a.P;
+        // wave-uniform image base + 32-bit per-lane element offsets (64 * P < 2^30 is checked by the host): one offset register
+        // per load in flight instead of 32 live 64-bit addresses
+        const long long base = __builtin_amdgcn_readfirstlane((int)b) * (long long)GC_F * a.P;
+        const unsigned P32 = (unsigned)a.P;
+        const unsigned pxo = valid ? (unsigned)px : 0u;
+        const float* xb = a.x + base;
+        const float* hb = a.h ? a.h + base : nullptr;
+        float xg[32], hg[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) xg[s] = xb[(unsigned)(2 * s + lhi) * P32 + pxo];  // lanes past the end read pixel 0
+        if (hb) {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) hg[s] = hb[(unsigned)(2 * s + lhi) * P32 + pxo];
+        }
+        f32x16 acc[GATES + 1][2];
+#pragma unroll
+        for (int d = 0; d < GATES + 1; ++d)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[d][ct][r] = (d < GATES && a.b_ih) ? a.b_ih[d * GC_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
+
+        // ---- ih matrices over x ----------------------------------------------------------------------------------
+        {
+            constexpr int NS = GATES * 32;
+            float ra0[GC_PF + 1], ra1[GC_PF + 1];
+#pragma unroll
+            for (int t = 0; t < NS + GC_PF; ++t) {
+                if (t < NS) {
+                    const int mat = t >> 5, s = t & 31;
+                    ra0[t % (GC_PF + 1)] = wl[((mat * 2 + 0) * 32 + s) * 64];
+                    ra1[t % (GC_PF + 1)] = wl[((mat * 2 + 1) * 32 + s) * 64];
+                }
+                if (t >= GC_PF) {
+                    const int u = t - GC_PF, c = u % (GC_PF + 1);
+                    const int g = u >> 5, s = u & 31;  // destination: gate g (the candidate's ih part is accumulator GATES-1)
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], xg[s], acc[g][0], 0, 0, 0);
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], xg[s], acc[g][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- hh matrices over h_prev (all zero when there is no previous state) ----------------------------------
+        if (hb) {
+            constexpr int NS = GATES * 32;
+            float ra0[GC_PF + 1], ra1[GC_PF + 1];
+#pragma unroll
+            for (int t = 0; t < NS + GC_PF; ++t) {
+                if (t < NS) {
+                    const int mat = GATES + (t >> 5), s = t & 31;
+                    ra0[t % (GC_PF + 1)] = wl[((mat * 2 + 0) * 32 + s) * 64];
+                    ra1[t % (GC_PF + 1)] = wl[((mat * 2 + 1) * 32 + s) * 64];
+                }
+                if (t >= GC_PF) {
+                    const int u = t - GC_PF, c = u % (GC_PF + 1);
+                    const int g = u >> 5, s = u & 31;
+                    constexpr int LAST = GATES - 1;
+                    const int d = g < LAST ? g : GATES;  // the candidate's hh part stays separate
+                    acc[d][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], hg[s], acc[d][0], 0, 0, 0);
+                    acc[d][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], hg[s], acc[d][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- gate math in accumulator layout: row (r, lane half) = channel, column = pixel ---------------------------
+        float* ob = a.out + base;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const float hv = hb ? hb[(unsigned)co * P32 + pxo] : 0.f;
+                float o;
+                if constexpr (GATES == 3) {  // rnn_cells.py:118-127
+                    const float rg = gc_sigmoid(acc[0][ct][r]);
+                    const float z = gc_sigmoid(acc[1][ct][r]);
+                    const float n = tanhf(acc[2][ct][r] + rg * acc[3][ct][r]);
+                    o = n * (1.0f - z) + z * hv;
+                } else {  // rnn_cells.py:255-261
+                    const float f = gc_sigmoid(acc[0][ct][r]);
+                    const float c = tanhf(acc[1][ct][r] + f * acc[2][ct][r]);
+                    o = c + f * (hv - c);
+                }
+                if (valid) ob[(unsigned)co * P32 + pxo] = o;
+            }
+    }
+}
+
+template <int GATES>
+static int launch_gated(const GatedArgs& a, hipStream_t st) {
+    constexpr size_t lds = sizeof(float) * 2 * GATES * GC_F * GC_F;
+    static bool attr_done = false;  // once per instantiation: keeps launches legal under hipGraph capture
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_gated_cell<GATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MRX_HIP(hipGetDevice(&dev));
+        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long nblk_need = (a.nseg + GC_NT / 64 - 1) / (GC_NT / 64);
+    const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);  // persistent: the weights are staged once per workgroup
+    hipLaunchKernelGGL((k_gated_cell<GATES>), dim3(nblk), dim3(GC_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+extern "C" int mrx_gated_cell_1x1(const float* x, const float* h, const float* packed, const float* b_ih, float* out, int B,
+                                  int Cin, int F, int64_t HW, int gates, void* stream) {
+    MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_gated_cell_1x1: null pointer");
+    MRX_REQUIRE(B >= 0 && HW >= 0 && HW < (1ll << 24) && B < (1 << 30), MRX_EINVAL, "mrx_gated_cell_1x1: bad dims");
+    MRX_REQUIRE(mrx_gated_cell_supported(Cin, F, 1, gates), MRX_EUNSUP,
+                "mrx_gated_cell_1x1: Cin=%d F=%d gates=%d (64/64 and 2|3 gates only; use conv2d + mrx_gru_gates)", Cin, F, gates);
+    MRX_REQUIRE(out != x && out != h, MRX_EINVAL, "mrx_gated_cell_1x1: out must not alias an input");
+    if (B == 0 || HW == 0) return MRX_OK;
+    GatedArgs a;
+    a.x = x;
+    a.h = h;
+    a.packed = packed;
+    a.b_ih = b_ih;
+    a.out = out;
+    a.P = HW;
+    a.nsegb = (HW + 31) / 32;
+    a.nseg = a.nsegb * B;
+    return gates == 3 ? launch_gated<3>(a, (hipStream_t)stream) : launch_gated<2>(a, (hipStream_t)stream);
+}

@@ -284,6 +284,35 @@ def gru_gates(ih, hh, h):
     return out
 
 
+def gated_cell_supported(cin, F, k, gates):
+    return bool(_lib.lib().mrx_gated_cell_supported(int(cin), int(F), int(k), int(gates)))
+
+
+def gated_cell_pack(w_ih, w_hh, gates):
+    """Pack the 1x1 `ih` [gates*F,Cin,1,1] and `hh` [gates*F,F,1,1] weights of a ConvGRUCell / ConvMGUCell for gated_cell_1x1."""
+    w_ih, w_hh = _lib.f32c(w_ih.detach()), _lib.f32c(w_hh.detach())
+    F, Cin = int(w_hh.shape[1]), int(w_ih.shape[1])
+    n = int(_lib.lib().mrx_gated_cell_pack_floats(Cin, F, int(gates)))
+    if n < 0 or w_ih.shape[0] != gates * F or w_hh.shape[0] != gates * F:
+        raise ValueError("gated_cell_pack: unsupported shape")
+    packed = torch.empty(n, dtype=torch.float32, device=w_ih.device)
+    _lib.check(_lib.lib().mrx_gated_cell_pack(_lib.ptr(w_ih), _lib.ptr(w_hh), _lib.ptr(packed), Cin, F, int(gates), _lib.stream_ptr()),
+               "mrx_gated_cell_pack")
+    return packed
+
+
+def gated_cell_1x1(x, h, packed, b_ih, gates, F=64):
+    """Whole ConvGRUCell (gates=3) / ConvMGUCell (gates=2) with 1x1 kernels in one launch.  h None = zero state."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    h = None if h is None else _lib.f32c(h)
+    b_ih = None if b_ih is None else _lib.f32c(b_ih.detach())
+    out = torch.empty((B, F, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_gated_cell_1x1(_lib.ptr(x), _lib.ptr(h), _lib.ptr(packed), _lib.ptr(b_ih), _lib.ptr(out), B, Cin, F,
+                                             H * W, int(gates), _lib.stream_ptr()), "mrx_gated_cell_1x1")
+    return out
+
+
 def mgu_gates(ih, hh, h):
     ih, hh, h = _lib.f32c(ih), _lib.f32c(hh), _lib.f32c(h)
     B, F, H, W = _nchw(h)

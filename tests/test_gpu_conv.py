@@ -192,6 +192,70 @@ def test_cells_vs_oracle(dev):
                      1e-5, "mgu")
 
 
+@pytest.mark.parametrize("shape", [(2, 13, 18), (1, 33, 70), (1, 64, 32), (3, 1, 5)])
+def test_gated_cell_1x1_vs_oracle(dev, shape):
+    """One-launch ConvGRUCell / ConvMGUCell (1x1 gate kernels, 64 -> 64) against the oracle cells; pixel counts that are not
+    multiples of the 32-pixel wave segment, with and without bias, zero initial state as h = None."""
+    from mridc_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(11 + H)
+    F_ = 64
+    x, h = torch.randn(B, F_, H, W, generator=g), torch.randn(B, F_, H, W, generator=g)
+    for gates, cell in ((3, oracle.rim.convgru_cell), (2, oracle.rim.convmgu_cell)):
+        wi = torch.randn(gates * F_, F_, 1, 1, generator=g) / 8
+        wh = torch.randn(gates * F_, F_, 1, 1, generator=g) / 8
+        bi = torch.randn(gates * F_, generator=g)
+        assert ops.gated_cell_supported(F_, F_, 1, gates) and not ops.gated_cell_supported(F_, F_, 3, gates)
+        packed = ops.gated_cell_pack(wi.to(dev), wh.to(dev), gates)
+        assert_close(ops.gated_cell_1x1(x.to(dev), h.to(dev), packed, bi.to(dev), gates), cell(x, h, wi, bi, wh, 1, 1), 1e-5,
+                     f"gated cell gates={gates} {shape}")
+        assert_close(ops.gated_cell_1x1(x.to(dev), None, packed, None, gates), cell(x, torch.zeros_like(h), wi, None, wh, 1, 1), 1e-5,
+                     f"gated cell gates={gates} {shape}, no bias, h = None")
+        # the unfused route (two convs + gate kernel) is the same function
+        ih = ops.conv2d(x.to(dev), wi.to(dev), bi.to(dev), 1, ops.PAD_ZERO)
+        hh = ops.conv2d(h.to(dev), wh.to(dev), None, 1, ops.PAD_ZERO)
+        unfused = (ops.gru_gates if gates == 3 else ops.mgu_gates)(ih, hh, h.to(dev))
+        assert_close(ops.gated_cell_1x1(x.to(dev), h.to(dev), packed, bi.to(dev), gates), unfused, 1e-5, "one launch vs unfused")
+    with pytest.raises(ValueError):
+        ops.gated_cell_pack(torch.randn(48, 16, 1, 1).to(dev), torch.randn(48, 16, 1, 1).to(dev), 3)
+
+
+@pytest.mark.parametrize("layer", ["GRU", "MGU"])
+def test_rimblock_gated64_vs_oracle(dev, layer):
+    """RIMBlock with the model-zoo RIM layout (5x5 -> GRU, 3x3 d2 -> GRU, 64 features, 1x1 gates): conv as the fused layer kernel
+    with an identity ih + the one-launch cell, against the oracle block; second call continues from the returned hx."""
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    cfg = dict(recurrent_layer=layer, conv_filters=[64, 64, 2], conv_kernels=[5, 3, 3], conv_dilations=[1, 2, 1],
+               conv_bias=[True, True, False], recurrent_filters=[64, 64, 0], recurrent_kernels=[1, 1, 0],
+               recurrent_dilations=[1, 1, 0], recurrent_bias=[True, True, False], depth=2, time_steps=3, conv_dim=2, no_dc=True,
+               fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1)
+    torch.manual_seed(21)
+    blk = RIMBlock(**cfg).eval()
+    with torch.no_grad():
+        for n_, p_ in blk.named_parameters():
+            if n_.endswith("bias"):
+                p_.normal_(0, 0.1)
+    p = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 1, 3, 24, 36
+    S = torch.randn(B, C, H, W, 2, generator=g) / C ** 0.5
+    mask = (torch.rand(1, 1, 1, W, 1, generator=g) < 0.4)
+    y = torch.randn(B, C, H, W, 2, generator=g) * mask
+    ocfg = oracle.rim.RIMConfig(**{k: v for k, v in cfg.items()})
+    ref, ref_hx = oracle.rim.rim_block_forward(p, ocfg, y, y, S, mask, None, None, 1.0, False)
+    blk = blk.to(dev)
+    assert all(RIMBlock._gated(st) for st in blk.layers), "the test must exercise the one-launch cell"
+    with torch.no_grad():
+        outs, hx = blk(y.to(dev), y.to(dev), S.to(dev), mask.to(dev), None, None, 1.0, False)
+    assert_close(torch.stack(outs), torch.stack(ref), 2e-5, f"{layer}-64 RIMBlock outs")
+    for j in range(2):
+        assert_close(hx[j], ref_hx[j], 2e-5, f"{layer}-64 hx{j}")
+    ref2, _ = oracle.rim.rim_block_forward(p, ocfg, ref, y, S, mask, ref[-1], ref_hx, 1.0, False)
+    with torch.no_grad():
+        outs2, _ = blk(outs, y.to(dev), S.to(dev), mask.to(dev), outs[-1], hx, 1.0, False)
+    assert_close(torch.stack(outs2), torch.stack(ref2), 5e-5, f"{layer}-64 RIMBlock, second call with hx")
+
+
 def test_rim_final_vs_oracle(dev):
     from mridc_amd import ops
     g = torch.Generator().manual_seed(4)
