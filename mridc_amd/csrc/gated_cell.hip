@@ -64,7 +64,14 @@ extern "C" int mrx_gated_cell_pack(const float* w_ih, const float* w_hh, float* 
     return MRX_OK;
 }
 
-__device__ __forceinline__ float gc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1/(1+e^-x) and 1 - 2/(e^2x + 1) on the hardware exp2 / reciprocal: both saturate correctly (exp2 -> inf or 0), absolute error
+// ~1e-7, which is what the accumulators carry anyway
+__device__ __forceinline__ float gc_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float gc_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 template <int GATES>  // 3 = GRU, 2 = MGU
 __global__ __launch_bounds__(GC_NT, 2) void k_gated_cell(GatedArgs a) {
@@ -81,28 +88,43 @@ __global__ __launch_bounds__(GC_NT, 2) void k_gated_cell(GatedArgs a) {
     const float* wl = Ws + lane;  // lane = half*32 + m
 
     // accumulator d: 0 .. GATES-2 = gates whose ih and hh parts add up; GATES-1 = candidate ih part; GATES = candidate hh part
-    for (long long sg = (long long)blockIdx.x * (GC_NT / 64) + wave; sg < a.nseg; sg += (long long)gridDim.x * (GC_NT / 64)) {
-        // per-lane constants pass through an empty asm each round: the compiler would otherwise hoist the 64 channel
-        // offsets out of this loop and spill them
-        int l31 = lane & 31, lhi = lane >> 5;
+    const long long stride = (long long)gridDim.x * (GC_NT / 64);
+    const unsigned P32 = (unsigned)a.P;
+    float xg[32], hg[32];
+    const float* xb = nullptr;
+    const float* hb = nullptr;
+    long long base = 0;
+    unsigned pxo = 0;
+    bool valid = false;
+    int lhi = 0;
+    // operand loads of one segment: wave-uniform image base + 32-bit per-lane element offsets (64 * P < 2^30 is checked by the
+    // host).  The per-lane constants pass through an empty asm every time: the compiler would otherwise hoist the 64 channel
+    // offsets out of the segment loop and spill them.
+    auto load = [&](long long sg) {
+        int l31 = lane & 31;
+        lhi = lane >> 5;
         asm volatile("" : "+v"(l31), "+v"(lhi));
         const long long b = sg / a.nsegb;
         const long long px = (sg - b * a.nsegb) * 32 + l31;
-        const bool valid = px < a.P;
-        // wave-uniform image base + 32-bit per-lane element offsets (64 * P < 2^30 is checked by the host): one offset register
-        // per load in flight instead of 32 live 64-bit addresses
-        const long long base = __builtin_amdgcn_readfirstlane((int)b) * (long long)GC_F * a.P;
-        const unsigned P32 = (unsigned)a.P;
-        const unsigned pxo = valid ? (unsigned)px : 0u;
-        const float* xb = a.x + base;
-        const float* hb = a.h ? a.h + base : nullptr;
-        float xg[32], hg[32];
+        valid = px < a.P;
+        base = __builtin_amdgcn_readfirstlane((int)b) * (long long)GC_F * a.P;
+        pxo = valid ? (unsigned)px : 0u;  // lanes past the end read pixel 0 and store nothing
+        xb = a.x + base;
+        hb = a.h ? a.h + base : nullptr;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) xg[s] = xb[(unsigned)(2 * s + lhi) * P32 + pxo];  // lanes past the end read pixel 0
+        for (int s = 0; s < 32; ++s) xg[s] = xb[(unsigned)(2 * s + lhi) * P32 + pxo];
+    };
+    // h_prev operand of the current segment: issued right before the ih GEMMs, which cover its latency
+    auto load_h = [&]() {
         if (hb) {
 #pragma unroll
             for (int s = 0; s < 32; ++s) hg[s] = hb[(unsigned)(2 * s + lhi) * P32 + pxo];
         }
+    };
+    long long sg = (long long)blockIdx.x * (GC_NT / 64) + wave;
+    if (sg < a.nseg) load(sg);
+    while (sg < a.nseg) {
+        load_h();
         f32x16 acc[GATES + 1][2];
 #pragma unroll
         for (int d = 0; d < GATES + 1; ++d)
@@ -154,26 +176,39 @@ __global__ __launch_bounds__(GC_NT, 2) void k_gated_cell(GatedArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- gate math in accumulator layout: row (r, lane half) = channel, column = pixel ---------------------------
+        // ---- h_prev again, in accumulator layout (row (r, lane half) = channel, column = pixel): an L2 hit ---------------
+        float hv[2][16];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hv[ct][r] = hb ? hb[(unsigned)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo] : 0.f;
         float* ob = a.out + base;
+        const unsigned o_pxo = pxo;
+        const int o_lhi = lhi;
+        const bool o_valid = valid;
+        // the x operand registers are free: the next segment's x loads fly while this one's gates are evaluated
+        sg += stride;
+        if (sg < a.nseg) load(sg);
+        // ---- gate math on the accumulators.  Sigmoid and tanh through v_exp_f32 / v_rcp_f32 (1 ulp each): the accurate libm
+        // forms cost ~100 VALU instructions per element, on the pipe the fp32 MFMAs run on -- as much time as the GEMMs
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const float hv = hb ? hb[(unsigned)co * P32 + pxo] : 0.f;
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lhi;
                 float o;
                 if constexpr (GATES == 3) {  // rnn_cells.py:118-127
                     const float rg = gc_sigmoid(acc[0][ct][r]);
                     const float z = gc_sigmoid(acc[1][ct][r]);
-                    const float n = tanhf(acc[2][ct][r] + rg * acc[3][ct][r]);
-                    o = n * (1.0f - z) + z * hv;
+                    const float n = gc_tanh(acc[2][ct][r] + rg * acc[3][ct][r]);
+                    o = n * (1.0f - z) + z * hv[ct][r];
                 } else {  // rnn_cells.py:255-261
                     const float f = gc_sigmoid(acc[0][ct][r]);
-                    const float c = tanhf(acc[1][ct][r] + f * acc[2][ct][r]);
-                    o = c + f * (hv - c);
+                    const float c = gc_tanh(acc[1][ct][r] + f * acc[2][ct][r]);
+                    o = c + f * (hv[ct][r] - c);
                 }
-                if (valid) ob[(unsigned)co * P32 + pxo] = o;
+                if (o_valid) ob[(unsigned)co * P32 + o_pxo] = o;
             }
     }
 }
