@@ -36,9 +36,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1, help="slices per stream per step")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="independent slice batches reconstructed concurrently per GPU, one HIP stream + one captured hipGraph each "
-                         "(slices are independent: two in flight fill each other's launch tails and stalls; 1 = single stream)")
+                         "(slices are independent: two in flight fill each other's launch tails and stalls; 1 = single stream; "
+                         "0 = the measured best per model: 2 for CIRIM / qCIRIM, 3 for the launch-bound E2EVN: 374 -> 441 slices/s)")
     ap.add_argument("--coils", type=int, default=15)
     ap.add_argument("--height", type=int, default=640)
     ap.add_argument("--width", type=int, default=372)
@@ -52,7 +53,10 @@ def parse():
                     help="recurrent layer of the CIRIM cascades (headline: IndRNN; GRU with --cascades 1 is the reference's RIM config)")
     ap.add_argument("--cascades", type=int, default=0, help="override num_cascades (0 = the headline's 8)")
     ap.add_argument("--cpu-cascades", type=int, default=1, help="cascades of the CPU-baseline sample")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.streams <= 0:
+        args.streams = 3 if args.model == "e2evn" else 2
+    return args
 
 
 class KernelTimer:
