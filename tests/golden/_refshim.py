@@ -35,7 +35,8 @@ def install():
         "mridc.collections.reconstruction", "mridc.collections.reconstruction.data", "mridc.collections.reconstruction.parts",
         "mridc.collections.reconstruction.models", "mridc.collections.reconstruction.models.rim",
         "mridc.collections.reconstruction.models.varnet", "mridc.collections.reconstruction.models.unet_base",
-        "mridc.collections.reconstruction.models.conv",
+        "mridc.collections.reconstruction.models.conv", "mridc.collections.reconstruction.models.cascadenet",
+        "mridc.collections.reconstruction.models.variablesplittingnet", "mridc.collections.reconstruction.models.sigmanet",
         "mridc.collections.quantitative", "mridc.collections.quantitative.models",
         "mridc.collections.quantitative.models.qrim",
     ]

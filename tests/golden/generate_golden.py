@@ -697,9 +697,152 @@ def g10_ssim():
     save("g10_ssim.npz", d)
 
 
+def _randomize_bn(mod, seed):
+    """Non-trivial BatchNorm running statistics / affine (eval mode uses them)."""
+    g = torch.Generator().manual_seed(seed)
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.weight.copy_(torch.randn(m.num_features, generator=g) * 0.3 + 1.0)
+                m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+
+def g15_cascadenet():
+    """N4: conv/conv2d.py:8-69, cascadenet/ccnn_block.py:10-139, ccnn.py:116-142 (model forward composed from the blocks)."""
+    conv2d = _refshim.load("mridc.collections.reconstruction.models.conv.conv2d")
+    ccnn_block = _refshim.load("mridc.collections.reconstruction.models.cascadenet.ccnn_block")
+    d = {}
+    cases = [("h16n3", 16, 3, False, [1, 3, 32, 16, 2], True, False), ("h8n4_bn", 8, 4, True, [1, 5, 15, 12, 2], False, False),
+             ("h12n2_nodc", 12, 2, False, [2, 2, 21, 26, 2], False, True)]
+    for i, (nm, hid, nconv, bn, shape, centered, no_dc) in enumerate(cases):
+        torch.manual_seed(1500 + i)
+        act = torch.nn.PReLU()
+        with torch.no_grad():
+            act.weight.fill_(0.25 - 0.05 * i)
+        net = conv2d.Conv2d(2, 2, hid, n_convs=nconv, activation=act, batchnorm=bn)
+        _randomize_bn(net, 1510 + i)
+        norm = "ortho" if centered else "backward"
+        blk = ccnn_block.CascadeNetBlock(net, fft_centered=centered, fft_normalization=norm, spatial_dims=[-2, -1], coil_dim=1,
+                                         no_dc=no_dc).eval()
+        with torch.no_grad():
+            blk.dc_weight.fill_(0.8)
+        B, C, H, W, _ = shape
+        img, S = synth(B, C, H, W, 1520 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=centered, normalization=norm)
+        _, m = make_mask([1, C, H, W, 2])
+        y = k * m
+        pred = y + 0.1 * rnd(list(y.shape), 1530 + i)
+        mm = m.byte() if i % 2 == 0 else m.bool()
+        with torch.no_grad():
+            x_in = rnd([B, 2, H, W], 1540 + i)
+            d[f"{nm}/conv_in"], d[f"{nm}/conv_out"] = x_in, net(x_in)
+            d[f"{nm}/conv_out_5d"] = net(x_in.permute(0, 2, 3, 1).unsqueeze(1).contiguous())     # conv2d.py:64-67
+            out = blk(pred, y, S, mm)
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(hidden_channels=hid, n_convs=nconv, batchnorm=bn, fft_centered=centered,
+                                                  fft_normalization=norm, no_dc=no_dc)))
+        d[f"{nm}/pred"], d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"], d[f"{nm}/out"] = pred, y, S, mm, out
+        d.update(sd(blk, f"{nm}/w/"))
+    # model: ccnn.py:116-142 with 3 cascades
+    torch.manual_seed(1550)
+    cfg = dict(num_cascades=3, hidden_channels=10, n_convs=3, batchnorm=False, no_dc=False, fft_centered=False,
+               fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1, coil_combination_method="SENSE")
+    blocks = [ccnn_block.CascadeNetBlock(conv2d.Conv2d(2, 2, 10, n_convs=3, activation=torch.nn.PReLU(), batchnorm=False),
+                                         fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1,
+                                         no_dc=False).eval() for _ in range(3)]
+    B, C, H, W = 1, 4, 30, 22
+    img, S = synth(B, C, H, W, 1560)
+    k = fft.fft2(utils.complex_mul(img, S), centered=False, normalization="backward")
+    _, m = make_mask([1, C, H, W, 2])
+    m = m.byte()
+    y = k * m
+    target = utils.center_crop(utils.complex_abs(utils.sense(fft.ifft2(k, centered=False, normalization="backward"), S, 1)), (26, 20))
+    with torch.no_grad():
+        pred = y.clone()
+        for b in blocks:
+            pred = b(pred, y, S, m)
+        pred = torch.view_as_complex(utils.coil_combination(fft.ifft2(pred, centered=False, normalization="backward",
+                                                                      spatial_dims=[-2, -1]), S, method="SENSE", dim=1))
+        _, pred = utils.center_crop_to_smallest(target, pred)
+    d["model/cfg"] = np.array(json.dumps(cfg))
+    d["model/y"], d["model/S"], d["model/mask"], d["model/target"] = y, S, m, target
+    d["model/out"] = torch.view_as_real(pred)
+    for ci, b in enumerate(blocks):
+        d.update(sd(b, f"model/w/cascades.{ci}."))
+    d["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g15_cascadenet.npz", d)
+
+
+def g16_vsnet():
+    """N4: variablesplittingnet/vsnet_block.py:12-146 and vsnet.py:143-167 (CONV denoiser shared by all cascades, vsnet.py:81-83)."""
+    conv2d = _refshim.load("mridc.collections.reconstruction.models.conv.conv2d")
+    vsb = _refshim.load("mridc.collections.reconstruction.models.variablesplittingnet.vsnet_block")
+    d = {}
+    cases = [("c3", 3, 12, 3, [1, 3, 24, 16, 2], False), ("c2_centered", 2, 8, 2, [1, 4, 15, 18, 2], True)]
+    for i, (nm, ncasc, hid, nconv, shape, centered) in enumerate(cases):
+        torch.manual_seed(1600 + i)
+        norm = "ortho" if centered else "backward"
+        den = conv2d.Conv2d(2, 2, hid, n_convs=nconv, activation=torch.nn.PReLU(), batchnorm=False)
+        dcl, wat = vsb.DataConsistencyLayer(), vsb.WeightedAverageTerm()
+        with torch.no_grad():
+            dcl.dc_weight.fill_(0.9)
+            wat.param.fill_(0.6)
+        blk = vsb.VSNetBlock(torch.nn.ModuleList([den] * ncasc), torch.nn.ModuleList([dcl] * ncasc),
+                             torch.nn.ModuleList([wat] * ncasc), num_cascades=ncasc, fft_centered=centered, fft_normalization=norm,
+                             spatial_dims=[-2, -1], coil_dim=1).eval()
+        B, C, H, W, _ = shape
+        img, S = synth(B, C, H, W, 1610 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=centered, normalization=norm)
+        _, m = make_mask([1, C, H, W, 2])
+        y = k * m
+        target = utils.complex_abs(utils.sense(fft.ifft2(k, centered=centered, normalization=norm), S, 1))
+        with torch.no_grad():
+            out = blk(y, S, m)
+            d[f"{nm}/dc"] = dcl(out, y, m)
+            d[f"{nm}/wa"] = wat(out, y)
+            image = torch.view_as_complex(utils.coil_combination(fft.ifft2(out, centered=centered, normalization=norm,
+                                                                           spatial_dims=[-2, -1]), S, method="SENSE", dim=1))
+            _, image = utils.center_crop_to_smallest(target, image)
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(num_cascades=ncasc, imspace_model_architecture="CONV", imspace_conv_hidden_channels=hid,
+                                                  imspace_conv_n_convs=nconv, imspace_conv_batchnorm=False, fft_centered=centered,
+                                                  fft_normalization=norm, spatial_dims=[-2, -1], coil_dim=1,
+                                                  coil_combination_method="SENSE")))
+        d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"], d[f"{nm}/target"] = y, S, m, target
+        d[f"{nm}/block_out"], d[f"{nm}/model_out"] = out, torch.view_as_real(image)
+        d.update(sd(blk, f"{nm}/w/model."))
+    d["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g16_vsnet.npz", d)
+
+
+def g17_dc_layers():
+    """N4: sigmanet/dc_layers.py:22-478 forward passes (batch 1: the layers index the coil axis as -4 and the batch axis as -5)."""
+    dcl = _refshim.load("mridc.collections.reconstruction.models.sigmanet.dc_layers")
+    d = {}
+    cases = [("uncentered", False, "backward", [1, 3, 20, 16]), ("centered", True, "ortho", [1, 4, 15, 18])]
+    for i, (nm, centered, norm, (B, C, H, W)) in enumerate(cases):
+        img, S = synth(B, C, H, W, 1700 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=centered, normalization=norm)
+        _, m = make_mask([1, C, H, W, 2])
+        y = k * m
+        x = utils.sense(fft.ifft2(y, centered=centered, normalization=norm), S, 1) + 0.05 * rnd([B, H, W, 2], 1710 + i)
+        kw = dict(fft_centered=centered, fft_normalization=norm, spatial_dims=[-2, -1])
+        with torch.no_grad():
+            d[f"{nm}/gd"] = dcl.DataGDLayer(0.3, **kw)(x, y, S, m)
+            d[f"{nm}/vs"] = dcl.DataVSLayer(0.4, 0.7, **kw)(x, y, S, m)
+            d[f"{nm}/dc_single"] = dcl.DCLayer(0.2, **kw)(x, y[:, 0], m[:, 0])
+            for it in (3, 10):
+                # the CG layer only runs with a 5-D image [B,1,H,W,2] (its solver reshapes alpha to 5-D, dc_layers.py:191-192)
+                d[f"{nm}/prox{it}"] = dcl.DataProxCGLayer(0.5, tol=1e-6, iter=it, **kw)(x.unsqueeze(1), y, S, m)
+        d[f"{nm}/x"], d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"] = x, y, S, m
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(fft_centered=centered, fft_normalization=norm)))
+    d["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g17_dc_layers.npz", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14"]
-    fns = dict(g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17"]
+    fns = dict(g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

@@ -1,0 +1,62 @@
+"""the other cascades / data-consistency formulations that reuse the hot-path kernels -- CascadeNet
+(conv/conv2d.py, cascadenet/ccnn_block.py, ccnn.py), VSNet (variablesplittingnet/vsnet_block.py, vsnet.py) and the sigmanet
+data-consistency layers (sigmanet/dc_layers.py).  CPU: the oracle restatement against the reference-generated goldens
+G15-G17.  GPU: the HIP-backed drop-ins against the same goldens."""
+import json
+
+import pytest
+import torch
+
+import oracle
+from tests._util import T, assert_close, meta, weights
+
+
+# ---- CPU: oracle vs goldens -------------------------------------------------------------------------------------------
+def test_oracle_cascadenet_vs_golden(golden):
+    z = golden("g15_cascadenet.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg, p = meta(z, f"{nm}/cfg"), weights(z, f"{nm}/w/")
+        conv_p = {k[len("model."):]: v for k, v in p.items() if k.startswith("model.")}
+        out = oracle.cascadenet.conv2d_stack_forward(conv_p, T(z[f"{nm}/conv_in"]), cfg["n_convs"], cfg["batchnorm"])
+        assert_close(out, T(z[f"{nm}/conv_out"]), 1e-6, f"{nm} conv stack")
+        x5 = T(z[f"{nm}/conv_in"]).permute(0, 2, 3, 1).unsqueeze(1).contiguous()
+        assert_close(oracle.cascadenet.conv2d_stack_forward(conv_p, x5, cfg["n_convs"], cfg["batchnorm"]), T(z[f"{nm}/conv_out_5d"]),
+                     1e-6, f"{nm} conv stack, 5-D input")
+        got = oracle.cascadenet.cascadenet_block_forward(p, T(z[f"{nm}/pred"]), T(z[f"{nm}/y"]), T(z[f"{nm}/S"]), T(z[f"{nm}/mask"]),
+                                                         cfg["n_convs"], cfg["batchnorm"], cfg["fft_centered"],
+                                                         cfg["fft_normalization"], [-2, -1], 1, cfg["no_dc"])
+        assert_close(got, T(z[f"{nm}/out"]), 2e-6, f"{nm} block")
+    cfg = meta(z, "model/cfg")
+    got = oracle.cascadenet.cascadenet_forward(weights(z, "model/w/"), cfg, T(z["model/y"]), T(z["model/S"]), T(z["model/mask"]), None,
+                                               T(z["model/target"]))
+    assert_close(got, T(z["model/out"]), 5e-6, "CascadeNet model")
+
+
+def test_oracle_vsnet_vs_golden(golden):
+    z = golden("g16_vsnet.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg, p = meta(z, f"{nm}/cfg"), weights(z, f"{nm}/w/")
+        y, S, mask = T(z[f"{nm}/y"]), T(z[f"{nm}/S"]), T(z[f"{nm}/mask"])
+        got = oracle.vsnet.vsnet_block_forward(p, y, S, mask, cfg["num_cascades"], cfg["imspace_conv_n_convs"], cfg["fft_centered"],
+                                               cfg["fft_normalization"], [-2, -1], 1, prefix="model.")
+        assert_close(got, T(z[f"{nm}/block_out"]), 5e-6, f"{nm} VSNet block")
+        assert_close(oracle.vsnet.data_consistency(got, y, mask, p["model.data_consistency_block.0.dc_weight"]), T(z[f"{nm}/dc"]), 5e-6,
+                     f"{nm} hard DC")
+        assert_close(oracle.vsnet.weighted_average(got, y, p["model.weighted_average_block.0.param"]), T(z[f"{nm}/wa"]), 5e-6,
+                     f"{nm} weighted average")
+        out = oracle.vsnet.vsnet_forward(p, cfg, y, S, mask, None, T(z[f"{nm}/target"]))
+        assert_close(out, T(z[f"{nm}/model_out"]), 5e-6, f"{nm} VSNet model")
+
+
+def test_oracle_dc_layers_vs_golden(golden):
+    z = golden("g17_dc_layers.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg = meta(z, f"{nm}/cfg")
+        c, n = cfg["fft_centered"], cfg["fft_normalization"]
+        x, y, S, mask = (T(z[f"{nm}/{k}"]) for k in ("x", "y", "S", "mask"))
+        assert_close(oracle.dc_layers.data_gd(x, y, S, mask, 0.3, c, n, [-2, -1]), T(z[f"{nm}/gd"]), 2e-6, f"{nm} GD")
+        assert_close(oracle.dc_layers.data_vs(x, y, S, mask, 0.4, 0.7, c, n, [-2, -1]), T(z[f"{nm}/vs"]), 2e-6, f"{nm} VS")
+        assert_close(oracle.dc_layers.dc_single(x, y[:, 0], mask[:, 0], 0.2, c, n, [-2, -1]), T(z[f"{nm}/dc_single"]), 2e-6, f"{nm} DCLayer")
+        for it in (3, 10):
+            got = oracle.dc_layers.data_prox_cg(x.unsqueeze(1), y, S, mask, 0.5, 1e-6, it, c, n, [-2, -1])
+            assert_close(got, T(z[f"{nm}/prox{it}"]), 2e-5, f"{nm} prox-CG {it} iterations")
