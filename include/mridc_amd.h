@@ -133,6 +133,15 @@ int mrx_dc_combine(const float* base, const float* pred, const float* ref, const
                    const int64_t* mstride, const float* dc_weight, const float* eta_k, float* out, int B, int C,
                    int H, int W, void* stream);
 
+/* N4  VSNet (models/variablesplittingnet/vsnet_block.py):
+ *   mrx_hard_dc     out = ((1 - mask) * pred + mask * ref) * dc_weight[0]                               (:23-25)
+ *   mrx_vs_average  out[b,c] = param[0] * (kspace[b,c] + pred[b,c]) + (1 - param[0]) * sx[b]            (:35-36 as called at :145;
+ *                   sx [B,H,W,2] is broadcast over the coil axis) */
+int mrx_hard_dc(const float* pred, const float* ref, const void* mask, int mask_kind, const int64_t* mstride,
+                const float* dc_weight, float* out, int B, int C, int H, int W, void* stream);
+int mrx_vs_average(const float* kspace, const float* pred, const float* sx, const float* param, float* out, int B, int C,
+                   int H, int W, void* stream);
+
 /* A10 ConvNonlinear / nn.Conv2d (models/rim/conv_layers.py:72-85,121-123; rnn_cells.py:23-38;
  * unet_block.py:251,255,185): NCHW fp32, stride 1, "same" output size, square kernel k, dilation dil,
  * padding dil*(k-1)/2 in `pad_mode`.  bias may be NULL.  fp32-input MFMA (exact fp32 fma chains). */

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "mrx_llg_hinv_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_llg_hinv": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_soft_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_hard_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_vs_average": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_conv2d": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_rim_layer_indrnn": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),

@@ -1,0 +1,43 @@
+"""Drop-in for `mridc.collections.reconstruction.models.cascadenet.ccnn_block.CascadeNetBlock` (reference ccnn_block.py:10-139)."""
+from typing import Optional, Tuple
+
+import torch
+
+from mridc_amd import ops
+
+
+class CascadeNetBlock(torch.nn.Module):
+    """Soft data consistency with the input model as regulariser: the same cascade as VarNetBlock (sens_reduce -> model ->
+    sens_expand -> pred - soft_dc - eta, mrx_sens_reduce / mrx_sens_expand / mrx_dc_combine) around a channels-first model."""
+
+    def __init__(self, model: torch.nn.Module, fft_centered: bool = True, fft_normalization: str = "ortho",
+                 spatial_dims: Optional[Tuple[int, int]] = None, coil_dim: int = 1, no_dc: bool = False):
+        super().__init__()
+        self.model = model
+        self.fft_centered = fft_centered
+        self.fft_normalization = fft_normalization
+        self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
+        self.coil_dim = coil_dim
+        self.no_dc = no_dc
+        self.dc_weight = torch.nn.Parameter(torch.ones(1))
+        if coil_dim != 1:
+            raise NotImplementedError("the HIP path expects the coil dimension at index 1")
+
+    def sens_expand(self, x: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        """ccnn_block.py:56-77."""
+        return ops.sens_expand(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims)
+
+    def sens_reduce(self, x: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        """ccnn_block.py:79-99 (keepdim on the coil axis)."""
+        return ops.sens_reduce(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims).unsqueeze(1)
+
+    def forward(self, pred: torch.Tensor, ref_kspace: torch.Tensor, sens_maps: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """ccnn_block.py:101-139."""
+        eta = self.sens_reduce(pred, sens_maps)
+        eta = self.model(eta.squeeze(self.coil_dim).permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        if eta.dim() < sens_maps.dim():
+            eta = eta.unsqueeze(1)
+        eta = self.sens_expand(eta, sens_maps)
+        if not self.no_dc:
+            eta = ops.dc_combine(pred, pred, ref_kspace, mask, self.dc_weight, eta)   # pred - where(mask, pred - ref, 0) * w - eta
+        return eta

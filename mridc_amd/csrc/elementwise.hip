@@ -426,6 +426,62 @@ extern "C" int mrx_dc_combine(const float* base, const float* pred, const float*
     return MRX_OK;
 }
 
+// ---- VSNet hard data consistency and weighted average (variablesplittingnet/vsnet_block.py:23-25, :35-36) ---------
+// Operation order and rounding follow the reference's separate torch ops (no contraction).
+__global__ void k_hard_dc(const float2* __restrict__ pred, const float2* __restrict__ ref, MrxMask m, const float* __restrict__ dcw,
+                          float2* __restrict__ out, Dims4 s) {
+    const float w8 = dcw[0];
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < s.total; o += (long long)gridDim.x * blockDim.x) {
+        long long r = o;
+        const long long w = r % s.W;
+        r /= s.W;
+        const long long h = r % s.H;
+        r /= s.H;
+        const long long c = r % s.C;
+        const long long b = r / s.C;
+        const float mv = mrx_mask_val(m, b, c, h, w), om = __fsub_rn(1.0f, mv);
+        const float2 p = pred[o], q = ref[o];
+        out[o] = make_float2(__fmul_rn(__fadd_rn(__fmul_rn(om, p.x), __fmul_rn(mv, q.x)), w8),
+                             __fmul_rn(__fadd_rn(__fmul_rn(om, p.y), __fmul_rn(mv, q.y)), w8));
+    }
+}
+// out[b,c] = param * (k[b,c] + pred[b,c]) + (1 - param) * sx[b]   (sx: one image per batch element, broadcast over coils)
+__global__ void k_vs_average(const float2* __restrict__ k, const float2* __restrict__ pred, const float2* __restrict__ sx,
+                             const float* __restrict__ param, float2* __restrict__ out, long long C, long long HW, long long total) {
+    const float pa = param[0], pb = __fsub_rn(1.0f, pa);
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long bc = o / HW, px = o - bc * HW, b = bc / C;
+        const float2 a = k[o], p = pred[o], x = sx[b * HW + px];
+        out[o] = make_float2(__fadd_rn(__fmul_rn(pa, __fadd_rn(a.x, p.x)), __fmul_rn(pb, x.x)),
+                             __fadd_rn(__fmul_rn(pa, __fadd_rn(a.y, p.y)), __fmul_rn(pb, x.y)));
+    }
+}
+extern "C" int mrx_hard_dc(const float* pred, const float* ref, const void* mask, int mask_kind, const int64_t* mstride,
+                           const float* dc_weight, float* out, int B, int C, int H, int W, void* stream) {
+    MRX_REQUIRE(pred && ref && dc_weight && out, MRX_EINVAL, "mrx_hard_dc: null pointer");
+    MrxMask m;
+    Dims4 s;
+    int rc;
+    if ((rc = fill_mask(&m, mask, mask_kind, mstride, "mrx_hard_dc"))) return rc;
+    if ((rc = fill_dims(&s, B, C, H, W, "mrx_hard_dc"))) return rc;
+    if (s.total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_hard_dc, dim3(ew_grid(s.total)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)pred, (const float2*)ref, m,
+                       dc_weight, (float2*)out, s);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_vs_average(const float* kspace, const float* pred, const float* sx, const float* param, float* out, int B, int C,
+                              int H, int W, void* stream) {
+    MRX_REQUIRE(kspace && pred && sx && param && out, MRX_EINVAL, "mrx_vs_average: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0, MRX_EINVAL, "mrx_vs_average: negative dim");
+    const long long total = (long long)B * C * H * W;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_vs_average, dim3(ew_grid(total)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)kspace, (const float2*)pred,
+                       (const float2*)sx, param, (float2*)out, (long long)C, (long long)H * W, total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 // ---- GRU / MGU gate math (rnn_cells.py:118-127, :255-261) --------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __global__ void k_gru(const float* __restrict__ ih, const float* __restrict__ hh, const float* h, float* out, int F, long long HW,

@@ -139,6 +139,37 @@ def dc_combine(base, pred, ref, mask, dc_weight, eta_k):
     return out
 
 
+def hard_dc(pred, ref, mask, dc_weight):
+    """VSNet DataConsistencyLayer: ((1 - mask) * pred + mask * ref) * dc_weight (vsnet_block.py:23-25)."""
+    pred, ref = _lib.f32c(pred), _lib.f32c(ref)
+    B, C, H, W = _bchw(pred)
+    if ref.shape != pred.shape:
+        raise ValueError(f"hard_dc: {tuple(pred.shape)} vs {tuple(ref.shape)}")
+    if mask.dtype == torch.bool:   # `1 - mask` (vsnet_block.py:25) is not defined for bool tensors in torch either
+        raise RuntimeError("Subtraction, the `-` operator, with a bool tensor is not supported. If you are trying to invert a mask, "
+                           "use the `~` or `logical_not()` operator instead.")
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    w = _lib.f32c(dc_weight.detach().reshape(-1))
+    out = torch.empty_like(pred)
+    _lib.check(_lib.lib().mrx_hard_dc(_lib.ptr(pred), _lib.ptr(ref), _lib.ptr(m), kind, ms, _lib.ptr(w), _lib.ptr(out), B, C, H, W,
+                                      _lib.stream_ptr()), "mrx_hard_dc")
+    return out
+
+
+def vs_average(kspace, pred, sx, param):
+    """VSNet WeightedAverageTerm as called by the block: param * (kspace + pred) + (1 - param) * sx, sx [B,H,W,2] broadcast
+    over the coils (vsnet_block.py:35-36,145)."""
+    kspace, pred, sx = _lib.f32c(kspace), _lib.f32c(pred), _lib.f32c(sx)
+    B, C, H, W = _bchw(kspace)
+    if pred.shape != kspace.shape or tuple(sx.shape) != (B, H, W, 2):
+        raise ValueError(f"vs_average: {tuple(kspace.shape)}, {tuple(pred.shape)}, {tuple(sx.shape)}")
+    p = _lib.f32c(param.detach().reshape(-1))
+    out = torch.empty_like(kspace)
+    _lib.check(_lib.lib().mrx_vs_average(_lib.ptr(kspace), _lib.ptr(pred), _lib.ptr(sx), _lib.ptr(p), _lib.ptr(out), B, C, H, W,
+                                         _lib.stream_ptr()), "mrx_vs_average")
+    return out
+
+
 def _nchw(x):
     if x.dim() != 4:
         raise ValueError(f"expected a [B,C,H,W] tensor, got {tuple(x.shape)}")

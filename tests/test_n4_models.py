@@ -60,3 +60,78 @@ def test_oracle_dc_layers_vs_golden(golden):
         for it in (3, 10):
             got = oracle.dc_layers.data_prox_cg(x.unsqueeze(1), y, S, mask, 0.5, 1e-6, it, c, n, [-2, -1])
             assert_close(got, T(z[f"{nm}/prox{it}"]), 2e-5, f"{nm} prox-CG {it} iterations")
+
+
+# ---- GPU: the HIP-backed drop-ins vs the same goldens ----------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_cascadenet_vs_golden(golden, dev):
+    from mridc_amd.collections.reconstruction.models.cascadenet.ccnn_block import CascadeNetBlock
+    from mridc_amd.collections.reconstruction.models.ccnn import CascadeNet
+    from mridc_amd.collections.reconstruction.models.conv.conv2d import Conv2d
+    z = golden("g15_cascadenet.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg = meta(z, f"{nm}/cfg")
+        net = Conv2d(2, 2, cfg["hidden_channels"], n_convs=cfg["n_convs"], activation=torch.nn.PReLU(), batchnorm=cfg["batchnorm"])
+        blk = CascadeNetBlock(net, fft_centered=cfg["fft_centered"], fft_normalization=cfg["fft_normalization"],
+                              spatial_dims=[-2, -1], coil_dim=1, no_dc=cfg["no_dc"])
+        blk.load_state_dict(weights(z, f"{nm}/w/"))
+        blk = blk.to(dev).eval()
+        with torch.no_grad():
+            x = T(z[f"{nm}/conv_in"]).to(dev)
+            assert_close(blk.model(x), T(z[f"{nm}/conv_out"]), 1e-5, f"{nm} conv stack")
+            assert_close(blk.model(x.permute(0, 2, 3, 1).unsqueeze(1).contiguous()), T(z[f"{nm}/conv_out_5d"]), 1e-5,
+                         f"{nm} conv stack, 5-D input")
+            out = blk(T(z[f"{nm}/pred"]).to(dev), T(z[f"{nm}/y"]).to(dev), T(z[f"{nm}/S"]).to(dev), T(z[f"{nm}/mask"]).to(dev))
+        assert_close(out, T(z[f"{nm}/out"]), 2e-5, f"{nm} CascadeNetBlock")
+        if cfg["batchnorm"]:
+            blk.train()
+            with pytest.raises(NotImplementedError):
+                blk.model(x)
+    cfg = meta(z, "model/cfg")
+    model = CascadeNet(cfg)
+    missing, unexpected = model.load_state_dict(weights(z, "model/w/"), strict=False)
+    assert unexpected == [] and missing == ["dc_weight"]
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        out = model(T(z["model/y"]).to(dev), T(z["model/S"]).to(dev), T(z["model/mask"]).to(dev), None, T(z["model/target"]).to(dev))
+    assert_close(out, T(z["model/out"]), 5e-5, "CascadeNet model")
+
+
+@pytest.mark.gpu
+def test_vsnet_vs_golden(golden, dev):
+    from mridc_amd import ops
+    from mridc_amd.collections.reconstruction.models.vsnet import VSNet
+    z = golden("g16_vsnet.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg = meta(z, f"{nm}/cfg")
+        model = VSNet(cfg)
+        sd_ = weights(z, f"{nm}/w/")
+        assert set(sd_) == set(model.state_dict()), "state_dict layout (shared modules repeat under every cascade index)"
+        model.load_state_dict(sd_)
+        model = model.to(dev).eval()
+        y, S, mask, target = (T(z[f"{nm}/{k}"]).to(dev) for k in ("y", "S", "mask", "target"))
+        with torch.no_grad():
+            blk_out = model.model(y, S, mask)
+            out = model(y, S, mask, None, target)
+            dc = model.model.data_consistency_block[0](blk_out, y, mask)
+            wa = model.model.weighted_average_block[0](blk_out, y)
+        assert_close(blk_out, T(z[f"{nm}/block_out"]), 5e-5, f"{nm} VSNetBlock")
+        assert_close(out, T(z[f"{nm}/model_out"]), 5e-5, f"{nm} VSNet")
+        assert_close(dc, T(z[f"{nm}/dc"]), 5e-5, f"{nm} hard DC")
+        assert_close(wa, T(z[f"{nm}/wa"]), 5e-5, f"{nm} weighted average")
+        # the two pointwise kernels round exactly like the reference's separate torch ops
+        w = model.model.data_consistency_block[0].dc_weight
+        ref_dc = ((1 - mask) * blk_out + mask * y) * w
+        assert torch.equal(dc, ref_dc), "hard DC is bit-exact vs the torch expression"
+        p = model.model.weighted_average_block[0].param
+        sx = model.model.sens_reduce(dc, S)
+        ref_wa = p * (y + blk_out) + (1 - p) * sx
+        assert torch.equal(ops.vs_average(y, blk_out, sx, p), ref_wa), "weighted average is bit-exact vs the torch expression"
+        with pytest.raises(RuntimeError):
+            ops.hard_dc(blk_out, y, mask.bool(), w)
