@@ -165,7 +165,7 @@ def bench_qcirim(args, world, rank, dev):
                     step(d)
                 torch.cuda.current_stream().wait_stream(st)
                 g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_, stream=st):
+                with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
                     step(d)
                 graphs.append(g_)
             torch.cuda.synchronize()
@@ -173,6 +173,7 @@ def bench_qcirim(args, world, rank, dev):
             print(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
             graphs = []
             torch.cuda.synchronize()
+    dist_barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for i, st in enumerate(streams):
@@ -181,8 +182,8 @@ def bench_qcirim(args, world, rank, dev):
                     graphs[i].replay()
                 else:
                     step(datas[i])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    dist_barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         print(json.dumps(dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256", value=world * NS * args.steps / elapsed,
                               unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
@@ -227,7 +228,7 @@ def bench_e2evn(args, world, rank, dev):
                     step(d)
                 torch.cuda.current_stream().wait_stream(st)
                 g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_, stream=st):
+                with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
                     step(d)
                 graphs.append(g_)
             torch.cuda.synchronize()
@@ -235,6 +236,7 @@ def bench_e2evn(args, world, rank, dev):
             print(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
             graphs = []
             torch.cuda.synchronize()
+    dist_barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for i, st in enumerate(streams):
@@ -243,8 +245,8 @@ def bench_e2evn(args, world, rank, dev):
                     graphs[i].replay()
                 else:
                     step(datas[i])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    dist_barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
     B = NS * B
     if rank == 0:
         print(json.dumps(dict(metric="slices/sec (inference), E2EVN 6-cascade 15-coil 640x372", value=world * B * args.steps / elapsed,
@@ -255,6 +257,23 @@ def bench_e2evn(args, world, rank, dev):
                                                    f"{B} per GPU ({NS} concurrent HIP stream(s), {'one hipGraph each' if graphs else 'eager'}), random-init weights "
                                                    "(seed 0)", parallelism=f"slice-sharded x{world}"))),
               flush=True)
+
+
+def dist_barrier():
+    """Barrier over the ranks (when a process group exists) + device synchronize."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(elapsed, dev):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
 
 
 def measured_traffic(B, C, H, W, F):
@@ -283,18 +302,23 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # MRX_BENCH_FORCE_DIST=1: run the RCCL init / barrier / max-reduce path with a single rank too (a 1-GPU box can then check
+    # that the process group and the hipGraph capture get along)
+    use_dist = world > 1 or os.environ.get("MRX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mridc_amd import ops, synthetic
     from mridc_amd.collections.reconstruction.models.cirim import CIRIM
 
-    if args.model == "e2evn":
-        return bench_e2evn(args, world, rank, dev)
-    if args.model == "qcirim":
-        return bench_qcirim(args, world, rank, dev)
+    if args.model in ("e2evn", "qcirim"):
+        (bench_e2evn if args.model == "e2evn" else bench_qcirim)(args, world, rank, dev)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     cfg = dict(synthetic.CIRIM_BASELINE_CFG)
     cfg["recurrent_layer"] = args.rnn
     if args.cascades:
@@ -347,7 +371,7 @@ def main():
             return next(model(d["y"], d["sensitivity_maps"], d["mask"], None, d["target"]))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -375,7 +399,7 @@ def main():
                     step(d)
                 torch.cuda.current_stream().wait_stream(st)
                 g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_, stream=st):
+                with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
                     outs[i] = step(d)
                 graphs.append(g_)
             for g_, st in zip(graphs, streams):
@@ -401,7 +425,7 @@ def main():
                         out = o_
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -467,7 +491,7 @@ def main():
                 res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port",
                                            sample=f"failed: {ex}")
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 
