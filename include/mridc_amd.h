@@ -142,6 +142,29 @@ int mrx_hard_dc(const float* pred, const float* ref, const void* mask, int mask_
 int mrx_vs_average(const float* kspace, const float* pred, const float* sx, const float* param, float* out, int B, int C,
                    int H, int W, void* stream);
 
+/* N4  sigmanet data-consistency layers (models/sigmanet/dc_layers.py), the pointwise pieces between the FFT / sensitivity kernels:
+ *   mrx_coil_sum   out[b,h,w] = sum_c k[b,c,h,w] * mask (mask NULL = no mask): the layers sum k-space over axis -4  (:69-81,:368-378)
+ *   mrx_dc_bcast   mode 0: out[b,c] = (a - y[b,c]) * mask                                                            (:82-87)
+ *                  mode 1: out[b,c] = (1 - mask) * a + mask * (alpha[0] * a + (1 - alpha[0]) * y[b,c])              (:381, :463)
+ *                  a: [B,H,W,2] broadcast over the coils (a_coils = 0) or [B,C,H,W,2] (a_coils = 1)
+ *   mrx_lincomb    mode 0: out[i] = x[i % nx] - p[0] * g[i % ng]; mode 1: p[0] * x[i % nx] + (1 - p[0]) * g[i % ng]  (:96, :402) */
+int mrx_coil_sum(const float* k, const void* mask, int mask_kind, const int64_t* mstride, float* out, int B, int C, int H,
+                 int W, void* stream);
+int mrx_dc_bcast(const float* a, int a_coils, const float* y, const void* mask, int mask_kind, const int64_t* mstride,
+                 const float* alpha, int mode, float* out, int B, int C, int H, int W, void* stream);
+int mrx_lincomb(const float* x, int64_t nx, const float* g, int64_t ng, const float* p, int mode, float* out, int64_t n,
+                void* stream);
+/* Conjugate-gradient pieces of the proximal layer (dc_layers.py:156-196), n complex elements per batch element:
+ *   mrx_cdot     out[b] = (re, im) of sum a * conj(b); work: mrx_cdot_work_floats(B) floats; fixed-order reduction
+ *   mrx_cg_step  alpha = rr * conj(pq) / |pq|^2;  x += alpha * p;  r -= alpha * q      (rr, pq: device [B][2])
+ *   mrx_cg_dir   p = r + (rr_new / rr) * p
+ * mrx_lincomb mode 2: out[i] = p[0] * g[i % ng] + x[i % nx]                            (:250, :254) */
+int64_t mrx_cdot_work_floats(int B);
+int mrx_cdot(const float* a, const float* b, float* out, float* work, int B, int64_t n, void* stream);
+int mrx_cg_step(float* x, float* r, const float* p, const float* q, const float* rr, const float* pq, int B, int64_t n,
+                void* stream);
+int mrx_cg_dir(float* p, const float* r, const float* rr_new, const float* rr, int B, int64_t n, void* stream);
+
 /* A10 ConvNonlinear / nn.Conv2d (models/rim/conv_layers.py:72-85,121-123; rnn_cells.py:23-38;
  * unet_block.py:251,255,185): NCHW fp32, stride 1, "same" output size, square kernel k, dilation dil,
  * padding dil*(k-1)/2 in `pad_mode`.  bias may be NULL.  fp32-input MFMA (exact fp32 fma chains). */

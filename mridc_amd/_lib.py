@@ -42,6 +42,13 @@ _SIGNATURES = {
     "mrx_llg_hinv_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_llg_hinv": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_soft_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_coil_sum": ([_p, _p, _i, _p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_dc_bcast": ([_p, _i, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_lincomb": ([_p, _i64, _p, _i64, _p, _i, _p, _i64, _p], _i),
+    "mrx_cdot_work_floats": ([_i], _i64),
+    "mrx_cdot": ([_p, _p, _p, _p, _i, _i64, _p], _i),
+    "mrx_cg_step": ([_p, _p, _p, _p, _p, _p, _i, _i64, _p], _i),
+    "mrx_cg_dir": ([_p, _p, _p, _p, _i, _i64, _p], _i),
     "mrx_hard_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_vs_average": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),

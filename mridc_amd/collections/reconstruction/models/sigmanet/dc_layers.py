@@ -1,0 +1,168 @@
+"""Drop-ins for `mridc.collections.reconstruction.models.sigmanet.dc_layers` (reference dc_layers.py:15-478), forward passes.
+
+The reference indexes the coil axis as -4 and the batch axis as -5 of the 5-D maps.  With the 4-D image `x` [B,H,W,2] these
+layers are called with, `x.unsqueeze(-5).expand_as(smaps)` only broadcasts for batch 1, `sum(-4)` adds the coils' k-space up and
+`sum(-5)` removes the (size-1) batch axis, so the gradient-descent and variable-splitting layers return one image per coil
+[C,H,W,2].  That behaviour is reproduced (goldens g17), not corrected.  FFTs / sensitivity products are the hot-path kernels
+(mrx_sens_expand, mrx_fft2, mrx_complex_mul); the pointwise pieces are mrx_coil_sum / mrx_dc_bcast / mrx_lincomb."""
+from typing import Optional, Tuple
+
+import torch
+
+import mridc_amd.collections.common.parts.fft as fft
+import mridc_amd.collections.common.parts.utils as utils
+from mridc_amd import ops
+
+
+def _batch1(x, smaps, who):
+    if x.dim() != 4 or smaps.dim() != 5 or x.shape[0] != 1 or smaps.shape[0] != 1:
+        raise NotImplementedError(f"{who}: the reference's axis conventions are only defined for x [1,H,W,2] and smaps [1,C,H,W,2] "
+                                  f"(got {tuple(x.shape)} and {tuple(smaps.shape)})")
+
+
+class DataIDLayer(torch.nn.Module):
+    """Placeholder for the data layer (dc_layers.py:15-19)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+
+class DataGDLayer(torch.nn.Module):
+    """Gradient step on the L2 data term (dc_layers.py:22-96): x - lambda * A^H(M(A x) - y)."""
+
+    def __init__(self, lambda_init, learnable=True, fft_centered: bool = True, fft_normalization: str = "ortho",
+                 spatial_dims: Optional[Tuple[int, int]] = None):
+        super().__init__()
+        self.lambda_init = lambda_init
+        self.data_weight = torch.nn.Parameter(torch.Tensor(1))
+        self.data_weight.data = torch.tensor(lambda_init, dtype=self.data_weight.dtype)
+        self.data_weight.requires_grad = learnable
+        self.fft_centered = fft_centered
+        self.fft_normalization = fft_normalization
+        self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
+
+    def forward(self, x, y, smaps, mask):
+        _batch1(x, smaps, "DataGDLayer")
+        k = ops.sens_expand(x, smaps, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        A_x_y_m = ops.dc_bcast(ops.coil_sum(k, mask), y, mask)                       # (sum_c(fft2(x S) * mask) - y) * mask
+        img = fft.ifft2(A_x_y_m, centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims)
+        gradD_x = utils.complex_mul(img, utils.complex_conj(smaps)).squeeze(0)       # .sum(-5) over the size-1 batch axis
+        return ops.lincomb(x, gradD_x, self.data_weight, 0)
+
+
+class DataVSLayer(torch.nn.Module):
+    """Variable-splitting data layer (dc_layers.py:327-414)."""
+
+    def __init__(self, alpha_init, beta_init, learnable=True, fft_centered: bool = True, fft_normalization: str = "ortho",
+                 spatial_dims: Optional[Tuple[int, int]] = None):
+        super().__init__()
+        self.alpha = torch.nn.Parameter(torch.Tensor(1))
+        self.alpha.data = torch.tensor(alpha_init, dtype=self.alpha.dtype)
+        self.beta = torch.nn.Parameter(torch.Tensor(1))
+        self.beta.data = torch.tensor(beta_init, dtype=self.beta.dtype)
+        self.learnable = learnable
+        self.set_learnable(learnable)
+        self.fft_centered = fft_centered
+        self.fft_normalization = fft_normalization
+        self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
+
+    def forward(self, x, y, smaps, mask):
+        _batch1(x, smaps, "DataVSLayer")
+        k = ops.sens_expand(x, smaps, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        k_dc = ops.dc_bcast(ops.coil_sum(k), y, mask, self.alpha)     # (1 - mask) A_x + mask (alpha A_x + (1 - alpha) y)
+        img = fft.ifft2(k_dc, centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims)
+        x_dc = utils.complex_mul(img, utils.complex_conj(smaps)).squeeze(0)
+        return ops.lincomb(x, x_dc, self.beta, 1)                     # beta x + (1 - beta) x_dc
+
+    def set_learnable(self, flag):
+        self.learnable = flag
+        self.alpha.requires_grad = self.learnable
+        self.beta.requires_grad = self.learnable
+
+
+class DCLayer(torch.nn.Module):
+    """Single-coil lambda-blend data consistency from DC-CNN (dc_layers.py:416-478)."""
+
+    def __init__(self, lambda_init=0.0, learnable=True, fft_centered: bool = True, fft_normalization: str = "ortho",
+                 spatial_dims: Optional[Tuple[int, int]] = None):
+        super().__init__()
+        self.lambda_ = torch.nn.Parameter(torch.Tensor(1))
+        self.lambda_.data = torch.tensor(lambda_init, dtype=self.lambda_.dtype)
+        self.learnable = learnable
+        self.set_learnable(learnable)
+        self.fft_centered = fft_centered
+        self.fft_normalization = fft_normalization
+        self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
+
+    def forward(self, x, y, mask):
+        if x.dim() != 4 or y.shape != x.shape:
+            raise NotImplementedError(f"DCLayer: x and y [B,H,W,2] expected, got {tuple(x.shape)} and {tuple(y.shape)}")
+        A_x = fft.fft2(x, centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims)
+        m = mask.unsqueeze(1) if mask.dim() == 4 else mask
+        k_dc = ops.dc_bcast(A_x.unsqueeze(1), y.unsqueeze(1), m, self.lambda_).squeeze(1)
+        return fft.ifft2(k_dc, centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims)
+
+    def set_learnable(self, flag):
+        self.learnable = flag
+        self.lambda_.requires_grad = self.learnable
+
+
+class DataProxCGLayer(torch.nn.Module):
+    """Proximal data layer solved by conjugate gradient (dc_layers.py:98-257, forward): (lambda A^H A + I) x = lambda A^H y + z.
+
+    The reference's solver reshapes alpha to 5-D, so it only runs with a 5-D image z [1,1,H,W,2]; its A^H drops the size-1 batch
+    axis and keeps the coils, so the unknown is one image per coil [1,C,H,W,2] and A sums the coils' k-space.  Reproduced as is.
+    Per iteration: complex_mul + fft2 + mrx_coil_sum (A), mrx_apply_mask + ifft2 + complex_mul (A^H), mrx_lincomb, two mrx_cdot,
+    mrx_cg_step, mrx_cg_dir; the stopping test reads the residual norm back, as the reference does (:177)."""
+
+    def __init__(self, lambda_init, tol=1e-6, iter=10, learnable=True, fft_centered: bool = True, fft_normalization: str = "ortho",
+                 spatial_dims: Optional[Tuple[int, int]] = None):
+        super().__init__()
+        self.lambdaa = torch.nn.Parameter(torch.Tensor(1))
+        self.lambdaa.data = torch.tensor(lambda_init)
+        self.lambdaa_init = lambda_init
+        self.lambdaa.requires_grad = learnable
+        self.tol = tol
+        self.iter = iter
+        self.fft_centered = fft_centered
+        self.fft_normalization = fft_normalization
+        self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
+
+    def forward(self, x, f, smaps, mask):
+        if x.dim() != 5 or smaps.dim() != 5 or x.shape[0] != 1 or x.shape[1] != 1 or smaps.shape[0] != 1:
+            raise NotImplementedError("DataProxCGLayer: the reference's solver is only defined for z [1,1,H,W,2] and smaps "
+                                      f"[1,C,H,W,2] (got {tuple(x.shape)} and {tuple(smaps.shape)})")
+        kw = dict(centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims)
+        lam = self.lambdaa.reshape(1)
+        conj_s = utils.complex_conj(smaps)
+
+        def A(p):                                   # [1,C,H,W,2] -> [1,H,W,2]      (dc_layers.py:217-228)
+            return ops.coil_sum(fft.fft2(utils.complex_mul(p, smaps), **kw), mask)
+
+        def AT(k):                                  # [1,C|1,H,W,2] -> [1,C,H,W,2]   (:230-238; sum(-5) drops the size-1 batch axis)
+            return utils.complex_mul(fft.ifft2(ops.mul_mask(k, mask), **kw), conj_s)
+
+        def M(p):                                   # :240-241
+            return ops.lincomb(p, AT(A(p).unsqueeze(1)), lam, 2)
+
+        x0 = ops.lincomb(x, AT(f), lam, 2)          # lambda A^H y + z               (:243)
+        return self._solve(x0, M)
+
+    def _solve(self, x0, M):
+        """dc_layers.py:167-196."""
+        xs = torch.zeros_like(x0)
+        r, p = x0.clone(), x0.clone()
+        x0x0 = ops.cdot(x0, x0)[:, 0]
+        rr = ops.cdot(r, r)
+        it = 0
+        while bool(torch.min(rr[:, 0] / x0x0) > self.tol) and it < self.iter:
+            it += 1
+            q = M(p)
+            ops.cg_step(xs, r, p, q, rr, ops.cdot(p, q))
+            rr_new = ops.cdot(r, r)
+            ops.cg_dir(p, r, rr_new, rr)
+            rr = rr_new
+        return xs
+
+    def set_learnable(self, flag):
+        self.lambdaa.requires_grad = flag

@@ -482,6 +482,201 @@ extern "C" int mrx_vs_average(const float* kspace, const float* pred, const floa
     return MRX_OK;
 }
 
+// ---- sigmanet data-consistency layers (sigmanet/dc_layers.py): the pointwise pieces between the FFT / sensitivity kernels ------
+// coil sum of (optionally masked) k-space: out[b,h,w] = sum_c k[b,c,h,w] * mask   (dc_layers.py:69-81: `fft2(x S) * mask` summed
+// over axis -4 -- the reference really sums k-space over the coils)
+__global__ void k_coil_sum(const float2* __restrict__ k, MrxMask m, int use_mask, float2* __restrict__ out, Dims4 s) {
+    const long long HW = s.H * s.W, n = s.B * HW;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long long)gridDim.x * blockDim.x) {
+        const long long b = o / HW, px = o - b * HW, h = px / s.W, w = px - h * s.W;
+        float ax = 0.f, ay = 0.f;
+        for (long long c = 0; c < s.C; ++c) {
+            const float2 v = k[(b * s.C + c) * HW + px];
+            const float mv = use_mask ? mrx_mask_val(m, b, c, h, w) : 1.0f;
+            ax = __fadd_rn(ax, __fmul_rn(v.x, mv));
+            ay = __fadd_rn(ay, __fmul_rn(v.y, mv));
+        }
+        out[o] = make_float2(ax, ay);
+    }
+}
+// MODE 0: out[b,c] = (a[b] - y[b,c]) * mask                                              (gradient-descent layer, dc_layers.py:82-87)
+// MODE 1: out[b,c] = (1 - mask) * a + mask * (alpha * a + (1 - alpha) * y[b,c])          (variable splitting :381 / DCLayer :463)
+//         a is one image per batch element (a_coils = 0, broadcast over the coils) or one per (b, c) (a_coils = 1)
+template <int MODE>
+__global__ void k_dc_bcast(const float2* __restrict__ a, int a_coils, const float2* __restrict__ y, MrxMask m,
+                           const float* __restrict__ alpha, float2* __restrict__ out, Dims4 s) {
+    const long long HW = s.H * s.W;
+    const float al = MODE == 1 ? alpha[0] : 0.f, oal = __fsub_rn(1.0f, al);
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < s.total; o += (long long)gridDim.x * blockDim.x) {
+        const long long bc = o / HW, px = o - bc * HW, b = bc / s.C, c = bc - b * s.C, h = px / s.W, w = px - h * s.W;
+        const float mv = mrx_mask_val(m, b, c, h, w);
+        const float2 av = a[(a_coils ? bc : b) * HW + px], yv = y[o];
+        if (MODE == 0) {
+            out[o] = make_float2(__fmul_rn(__fsub_rn(av.x, yv.x), mv), __fmul_rn(__fsub_rn(av.y, yv.y), mv));
+        } else {
+            const float om = __fsub_rn(1.0f, mv);
+            out[o] = make_float2(
+                __fadd_rn(__fmul_rn(om, av.x), __fmul_rn(mv, __fadd_rn(__fmul_rn(al, av.x), __fmul_rn(oal, yv.x)))),
+                __fadd_rn(__fmul_rn(om, av.y), __fmul_rn(mv, __fadd_rn(__fmul_rn(al, av.y), __fmul_rn(oal, yv.y)))));
+        }
+    }
+}
+// out[i] = x[i % nx] - p * g[i % ng] (mode 0, dc_layers.py:96)  |  p * x[i % nx] + (1 - p) * g[i % ng] (mode 1, :402)
+//        | p * g[i % ng] + x[i % nx] (mode 2, :250,:254)
+__global__ void k_lincomb(const float* __restrict__ x, long long nx, const float* __restrict__ g, long long ng,
+                          const float* __restrict__ p, int mode, float* __restrict__ out, long long n) {
+    const float pv = p[0], op = __fsub_rn(1.0f, pv);
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long long)gridDim.x * blockDim.x) {
+        const float xv = x[o % nx], gv = g[o % ng];
+        out[o] = mode == 0 ? __fsub_rn(xv, __fmul_rn(pv, gv)) : mode == 1 ? __fadd_rn(__fmul_rn(pv, xv), __fmul_rn(op, gv)) : __fadd_rn(__fmul_rn(pv, gv), xv);
+    }
+}
+extern "C" int mrx_coil_sum(const float* k, const void* mask, int mask_kind, const int64_t* mstride, float* out, int B, int C, int H,
+                            int W, void* stream) {
+    MRX_REQUIRE(k && out, MRX_EINVAL, "mrx_coil_sum: null pointer");
+    MrxMask m;
+    Dims4 s;
+    int rc;
+    m.p = nullptr;
+    m.kind = MRX_MASK_F32;
+    for (int i = 0; i < 4; ++i) m.s[i] = 0;
+    if (mask && (rc = fill_mask(&m, mask, mask_kind, mstride, "mrx_coil_sum"))) return rc;
+    if ((rc = fill_dims(&s, B, C, H, W, "mrx_coil_sum"))) return rc;
+    const long long n = (long long)B * H * W;
+    if (n == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_coil_sum, dim3(ew_grid(n)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)k, m, mask ? 1 : 0, (float2*)out, s);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_dc_bcast(const float* a, int a_coils, const float* y, const void* mask, int mask_kind, const int64_t* mstride,
+                            const float* alpha, int mode, float* out, int B, int C, int H, int W, void* stream) {
+    MRX_REQUIRE(a && y && out && (mode == 0 || (mode == 1 && alpha)), MRX_EINVAL, "mrx_dc_bcast: bad argument");
+    MrxMask m;
+    Dims4 s;
+    int rc;
+    if ((rc = fill_mask(&m, mask, mask_kind, mstride, "mrx_dc_bcast"))) return rc;
+    if ((rc = fill_dims(&s, B, C, H, W, "mrx_dc_bcast"))) return rc;
+    if (s.total == 0) return MRX_OK;
+    if (mode == 0)
+        hipLaunchKernelGGL(k_dc_bcast<0>, dim3(ew_grid(s.total)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)a, a_coils,
+                           (const float2*)y, m, alpha, (float2*)out, s);
+    else
+        hipLaunchKernelGGL(k_dc_bcast<1>, dim3(ew_grid(s.total)), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)a, a_coils,
+                           (const float2*)y, m, alpha, (float2*)out, s);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_lincomb(const float* x, int64_t nx, const float* g, int64_t ng, const float* p, int mode, float* out, int64_t n,
+                           void* stream) {
+    MRX_REQUIRE(x && g && p && out && nx > 0 && ng > 0 && n >= 0 && mode >= 0 && mode <= 2, MRX_EINVAL, "mrx_lincomb: bad argument");
+    if (n == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_lincomb, dim3(ew_grid(n)), dim3(EW_NT), 0, (hipStream_t)stream, x, (long long)nx, g, (long long)ng, p, mode, out,
+                       (long long)n);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- conjugate-gradient pieces of the proximal data layer (sigmanet/dc_layers.py:156-196) -------------------------------------
+// complex dot product per batch element, out[b] = (sum re, sum im) of a * conj(b): fixed-order two-stage reduction (per-workgroup
+// partials in fp32, combined in double), so results do not depend on scheduling.
+#define CDOT_BLOCKS 256
+__global__ void k_cdot_partial(const float2* __restrict__ a, const float2* __restrict__ b, float* __restrict__ work, long long n) {
+    // grid (CDOT_BLOCKS, B); work[(batch*CDOT_BLOCKS + block)*2 + {0,1}]
+    const long long base = (long long)blockIdx.y * n;
+    float sr = 0.f, si = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 x = a[base + i], y = b[base + i];
+        sr += x.x * y.x + x.y * y.y;
+        si += x.y * y.x - x.x * y.y;
+    }
+    __shared__ float shr[EW_NT], shi[EW_NT];
+    shr[threadIdx.x] = sr;
+    shi[threadIdx.x] = si;
+    __syncthreads();
+    for (int st = EW_NT / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            shr[threadIdx.x] += shr[threadIdx.x + st];
+            shi[threadIdx.x] += shi[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        work[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 + 0] = shr[0];
+        work[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 + 1] = shi[0];
+    }
+}
+__global__ void k_cdot_final(const float* __restrict__ work, int nb, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        double r = 0.0, i = 0.0;
+        for (int k = 0; k < nb; ++k) {
+            r += (double)work[((long long)blockIdx.x * nb + k) * 2];
+            i += (double)work[((long long)blockIdx.x * nb + k) * 2 + 1];
+        }
+        out[blockIdx.x * 2] = (float)r;
+        out[blockIdx.x * 2 + 1] = (float)i;
+    }
+}
+// alpha = rr * conj(pq) / |pq|^2 (dc_layers.py:186-189);  x += alpha * p;  r -= alpha * q     (:191-192)
+__global__ void k_cg_step(float2* __restrict__ x, float2* __restrict__ r, const float2* __restrict__ p, const float2* __restrict__ q,
+                          const float* __restrict__ rr, const float* __restrict__ pq, long long n, long long total) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long b = o / n;
+        const float re1 = rr[2 * b], im1 = rr[2 * b + 1], re2 = pq[2 * b], im2 = pq[2 * b + 1];
+        const float ab = sqrtf(__fadd_rn(__fmul_rn(re2, re2), __fmul_rn(im2, im2)));
+        const float den = __fmul_rn(ab, ab);
+        const float ar = __fadd_rn(__fmul_rn(re1, re2), __fmul_rn(im1, im2)) / den;
+        const float ai = __fsub_rn(__fmul_rn(im1, re2), __fmul_rn(re1, im2)) / den;
+        const float2 pv = p[o], qv = q[o];
+        float2 xv = x[o], rv = r[o];
+        xv.x = __fadd_rn(xv.x, __fsub_rn(__fmul_rn(ar, pv.x), __fmul_rn(ai, pv.y)));
+        xv.y = __fadd_rn(xv.y, __fadd_rn(__fmul_rn(ar, pv.y), __fmul_rn(ai, pv.x)));
+        rv.x = __fsub_rn(rv.x, __fsub_rn(__fmul_rn(ar, qv.x), __fmul_rn(ai, qv.y)));
+        rv.y = __fsub_rn(rv.y, __fadd_rn(__fmul_rn(ar, qv.y), __fmul_rn(ai, qv.x)));
+        x[o] = xv;
+        r[o] = rv;
+    }
+}
+// beta = rr_new / rr (real);  p = r + beta * p   (dc_layers.py:193-195)
+__global__ void k_cg_dir(float2* __restrict__ p, const float2* __restrict__ r, const float* __restrict__ rr_new,
+                         const float* __restrict__ rr, long long n, long long total) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long b = o / n;
+        const float beta = rr_new[2 * b] / rr[2 * b];
+        const float2 pv = p[o], rv = r[o];
+        p[o] = make_float2(__fadd_rn(rv.x, __fmul_rn(beta, pv.x)), __fadd_rn(rv.y, __fmul_rn(beta, pv.y)));
+    }
+}
+extern "C" int64_t mrx_cdot_work_floats(int B) { return (int64_t)2 * CDOT_BLOCKS * (B > 0 ? B : 1); }
+extern "C" int mrx_cdot(const float* a, const float* b, float* out, float* work, int B, int64_t n, void* stream) {
+    MRX_REQUIRE(a && b && out && work && B >= 1 && B <= 65535 && n >= 1, MRX_EINVAL, "mrx_cdot: bad argument");
+    const long long nbl = (n + EW_NT - 1) / EW_NT;
+    const int nb = (int)(nbl < CDOT_BLOCKS ? nbl : CDOT_BLOCKS);
+    hipLaunchKernelGGL(k_cdot_partial, dim3(nb, B), dim3(EW_NT), 0, (hipStream_t)stream, (const float2*)a, (const float2*)b, work,
+                       (long long)n);
+    hipLaunchKernelGGL(k_cdot_final, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)work, nb, out);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_cg_step(float* x, float* r, const float* p, const float* q, const float* rr, const float* pq, int B, int64_t n,
+                           void* stream) {
+    MRX_REQUIRE(x && r && p && q && rr && pq && B >= 0 && n >= 0, MRX_EINVAL, "mrx_cg_step: bad argument");
+    const long long total = (long long)B * n;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_cg_step, dim3(ew_grid(total)), dim3(EW_NT), 0, (hipStream_t)stream, (float2*)x, (float2*)r, (const float2*)p,
+                       (const float2*)q, rr, pq, (long long)n, total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_cg_dir(float* p, const float* r, const float* rr_new, const float* rr, int B, int64_t n, void* stream) {
+    MRX_REQUIRE(p && r && rr_new && rr && B >= 0 && n >= 0, MRX_EINVAL, "mrx_cg_dir: bad argument");
+    const long long total = (long long)B * n;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_cg_dir, dim3(ew_grid(total)), dim3(EW_NT), 0, (hipStream_t)stream, (float2*)p, (const float2*)r, rr_new, rr,
+                       (long long)n, total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 // ---- GRU / MGU gate math (rnn_cells.py:118-127, :255-261) --------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __global__ void k_gru(const float* __restrict__ ih, const float* __restrict__ hh, const float* h, float* out, int F, long long HW,

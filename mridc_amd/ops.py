@@ -170,6 +170,100 @@ def vs_average(kspace, pred, sx, param):
     return out
 
 
+def coil_sum(k, mask=None):
+    """sum_c k[b,c] * mask -> [B,H,W,2] (the sigmanet layers sum k-space over the coil axis, dc_layers.py:69-81)."""
+    k = _lib.f32c(k)
+    B, C, H, W = _bchw(k)
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W) if mask is not None else (None, 0, _lib.i64_array([0, 0, 0, 0]))
+    out = torch.empty(B, H, W, 2, dtype=torch.float32, device=k.device)
+    _lib.check(_lib.lib().mrx_coil_sum(_lib.ptr(k), _lib.ptr(m), kind, ms, _lib.ptr(out), B, C, H, W, _lib.stream_ptr()), "mrx_coil_sum")
+    return out
+
+
+def dc_bcast(a, y, mask, alpha=None):
+    """alpha None: (a - y) * mask; else (1 - mask) * a + mask * (alpha * a + (1 - alpha) * y).  y [B,C,H,W,2]; a [B,H,W,2]
+    (broadcast over the coils) or [B,C,H,W,2]."""
+    a, y = _lib.f32c(a), _lib.f32c(y)
+    B, C, H, W = _bchw(y)
+    if tuple(a.shape) == (B, H, W, 2):
+        a_coils = 0
+    elif a.shape == y.shape:
+        a_coils = 1
+    else:
+        raise ValueError(f"dc_bcast: {tuple(a.shape)} vs {tuple(y.shape)}")
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    al = None if alpha is None else _lib.f32c(alpha.detach().reshape(-1))
+    out = torch.empty_like(y)
+    _lib.check(_lib.lib().mrx_dc_bcast(_lib.ptr(a), a_coils, _lib.ptr(y), _lib.ptr(m), kind, ms, _lib.ptr(al), 0 if alpha is None else 1,
+                                       _lib.ptr(out), B, C, H, W, _lib.stream_ptr()), "mrx_dc_bcast")
+    return out
+
+
+def lincomb(x, g, p, mode):
+    """mode 0: x - p * g; mode 1: p * x + (1 - p) * g, with torch broadcasting of x against g restricted to "the smaller one
+    repeats over the leading axes of the larger" (what the sigmanet layers need)."""
+    x, g = _lib.f32c(x), _lib.f32c(g)
+    shape = torch.broadcast_shapes(x.shape, g.shape)
+    n = 1
+    for v in shape:
+        n *= int(v)
+    for t in (x, g):
+        sh = list(t.shape)
+        while sh and sh[0] == 1:
+            sh.pop(0)
+        if tuple(shape[len(shape) - len(sh):]) != tuple(sh):     # the operand must repeat over the leading axes only
+            raise NotImplementedError(f"lincomb: broadcast of {tuple(x.shape)} with {tuple(g.shape)}")
+    pv = _lib.f32c(p.detach().reshape(-1))
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_lincomb(_lib.ptr(x), x.numel(), _lib.ptr(g), g.numel(), _lib.ptr(pv), int(mode), _lib.ptr(out), n,
+                                      _lib.stream_ptr()), "mrx_lincomb")
+    return out
+
+
+def mul_mask(x, mask):
+    """x * mask for a [B,C,H,W,2] tensor and a mask broadcastable to [B,C,H,W,1] (dc_layers.py:214,227: `x * mask`)."""
+    x = _lib.f32c(x)
+    B, C, H, W = _bchw(x)
+    m, _, ms = _lib.mask_args(mask.float(), B, C, H, W)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().mrx_apply_mask(_lib.ptr(x), _lib.ptr(m), _lib.ptr(out), B, C, H, W, ms, _lib.stream_ptr()), "mrx_apply_mask")
+    return out
+
+
+def cdot(a, b):
+    """Per-batch complex dot product sum(a * conj(b)) over everything but axis 0 -> [B,2] (dc_layers.py:160-165)."""
+    a, b = _lib.f32c(a), _lib.f32c(b)
+    if a.shape != b.shape or a.shape[-1] != 2:
+        raise ValueError(f"cdot: {tuple(a.shape)} vs {tuple(b.shape)}")
+    B = int(a.shape[0])
+    n = a.numel() // (2 * B)
+    out = torch.empty(B, 2, dtype=torch.float32, device=a.device)
+    work = torch.empty(int(_lib.lib().mrx_cdot_work_floats(B)), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().mrx_cdot(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(work), B, n, _lib.stream_ptr()), "mrx_cdot")
+    return out
+
+
+def cg_step(x, r, p, q, rr, pq):
+    """In place: alpha = rr * conj(pq) / |pq|^2; x += alpha * p; r -= alpha * q (dc_layers.py:186-192)."""
+    for t in (x, r, p, q):
+        if not (t.is_contiguous() and t.dtype == torch.float32 and t.shape == x.shape):
+            raise ValueError("cg_step: contiguous fp32 tensors of one shape expected")
+    _lib.require_gpu(x)
+    B = int(x.shape[0])
+    _lib.check(_lib.lib().mrx_cg_step(_lib.ptr(x), _lib.ptr(r), _lib.ptr(p), _lib.ptr(q), _lib.ptr(_lib.f32c(rr)), _lib.ptr(_lib.f32c(pq)),
+                                      B, x.numel() // (2 * B), _lib.stream_ptr()), "mrx_cg_step")
+
+
+def cg_dir(p, r, rr_new, rr):
+    """In place: p = r + (rr_new / rr) * p (dc_layers.py:193-195)."""
+    if not (p.is_contiguous() and r.is_contiguous() and p.shape == r.shape and p.dtype == torch.float32):
+        raise ValueError("cg_dir: contiguous fp32 tensors of one shape expected")
+    _lib.require_gpu(p)
+    B = int(p.shape[0])
+    _lib.check(_lib.lib().mrx_cg_dir(_lib.ptr(p), _lib.ptr(r), _lib.ptr(_lib.f32c(rr_new)), _lib.ptr(_lib.f32c(rr)), B,
+                                     p.numel() // (2 * B), _lib.stream_ptr()), "mrx_cg_dir")
+
+
 def _nchw(x):
     if x.dim() != 4:
         raise ValueError(f"expected a [B,C,H,W] tensor, got {tuple(x.shape)}")

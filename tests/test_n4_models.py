@@ -135,3 +135,47 @@ def test_vsnet_vs_golden(golden, dev):
         assert torch.equal(ops.vs_average(y, blk_out, sx, p), ref_wa), "weighted average is bit-exact vs the torch expression"
         with pytest.raises(RuntimeError):
             ops.hard_dc(blk_out, y, mask.bool(), w)
+
+
+@pytest.mark.gpu
+def test_sigmanet_dc_layers_vs_golden(golden, dev):
+    from mridc_amd import ops
+    from mridc_amd.collections.reconstruction.models.sigmanet import dc_layers
+    z = golden("g17_dc_layers.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg = meta(z, f"{nm}/cfg")
+        kw = dict(fft_centered=cfg["fft_centered"], fft_normalization=cfg["fft_normalization"], spatial_dims=[-2, -1])
+        x, y, S, mask = (T(z[f"{nm}/{k}"]).to(dev) for k in ("x", "y", "S", "mask"))
+        with torch.no_grad():
+            gd = dc_layers.DataGDLayer(0.3, **kw).to(dev)(x, y, S, mask)
+            vs = dc_layers.DataVSLayer(0.4, 0.7, **kw).to(dev)(x, y, S, mask)
+            dc = dc_layers.DCLayer(0.2, **kw).to(dev)(x, y[:, 0], mask[:, 0])
+        assert_close(gd, T(z[f"{nm}/gd"]), 1e-5, f"{nm} DataGDLayer")
+        assert_close(vs, T(z[f"{nm}/vs"]), 1e-5, f"{nm} DataVSLayer")
+        assert_close(dc, T(z[f"{nm}/dc_single"]), 1e-5, f"{nm} DCLayer")
+        # pointwise kernels vs the torch expressions they replace
+        k = torch.randn(1, 3, 9, 7, 2, device=dev)
+        m = (torch.rand(1, 1, 9, 7, 1, device=dev) < 0.5).float()
+        assert_close(ops.coil_sum(k, m), (k * m).sum(1), 1e-6, "coil_sum")
+        a = torch.randn(1, 9, 7, 2, device=dev)
+        assert torch.equal(ops.dc_bcast(a, k, m), (a.unsqueeze(1) - k) * m)
+        al = torch.tensor([0.3], device=dev)
+        assert torch.equal(ops.dc_bcast(a, k, m, al), (1 - m) * a.unsqueeze(1) + m * (al * a.unsqueeze(1) + (1 - al) * k))
+        g = torch.randn(3, 9, 7, 2, device=dev)
+        assert torch.equal(ops.lincomb(a, g, al, 0), a - al * g)
+        assert torch.equal(ops.lincomb(a, g, al, 1), al * a + (1 - al) * g)
+        with pytest.raises(NotImplementedError):
+            dc_layers.DataGDLayer(0.3, **kw).to(dev)(x.repeat(2, 1, 1, 1), y, S, mask)
+        for it in (3, 10):
+            with torch.no_grad():
+                px = dc_layers.DataProxCGLayer(0.5, tol=1e-6, iter=it, **kw).to(dev)(x.unsqueeze(1), y, S, mask)
+            assert_close(px, T(z[f"{nm}/prox{it}"]), 1e-4, f"{nm} DataProxCGLayer, {it} iterations")
+        with pytest.raises(NotImplementedError):
+            dc_layers.DataProxCGLayer(0.5, **kw).to(dev)(x, y, S, mask)
+        a5, b5 = torch.randn(2, 3, 9, 7, 2, device=dev), torch.randn(2, 3, 9, 7, 2, device=dev)
+        ca, cb = torch.view_as_complex(a5), torch.view_as_complex(b5)
+        assert_close(ops.cdot(a5, b5), torch.view_as_real((ca * cb.conj()).reshape(2, -1).sum(-1)), 1e-5, "cdot")
+    assert list(dc_layers.DataGDLayer(0.3).state_dict()) == ["data_weight"]
+    assert list(dc_layers.DataVSLayer(0.1, 0.2).state_dict()) == ["alpha", "beta"]
+    assert list(dc_layers.DCLayer(0.1).state_dict()) == ["lambda_"]
+    assert list(dc_layers.DataProxCGLayer(0.1).state_dict()) == ["lambdaa"]
