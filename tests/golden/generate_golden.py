@@ -840,9 +840,87 @@ def g17_dc_layers():
     save("g17_dc_layers.npz", d)
 
 
+def g18_rvn():
+    """N4: recurrentvarnet/conv2gru.py:10-163, recurrentvarnet/recurrentvarnet.py:17-240, rvn.py:163-226 (model forward composed
+    from the imported blocks; hidden size 16 keeps the fixture small)."""
+    c2g = _refshim.load("mridc.collections.reconstruction.models.recurrentvarnet.conv2gru")
+    rv = _refshim.load("mridc.collections.reconstruction.models.recurrentvarnet.recurrentvarnet")
+    d = {}
+    # Conv2dGRU alone: zero state (None) and a given state; gru kernel 1 (the block's) and 3
+    for i, (nm, cin, hid, nl, gk, shape) in enumerate([("gru_h16_l2", 2, 16, 2, 1, [2, 13, 18]), ("gru_h8_l4", 2, 8, 4, 1, [1, 20, 16]),
+                                                      ("gru_h8_l2_k3", 3, 8, 2, 3, [1, 9, 11])]):
+        torch.manual_seed(1800 + i)
+        net = c2g.Conv2dGRU(cin, hid, num_layers=nl, gru_kernel_size=gk, replication_padding=True).eval()
+        B, H, W = shape
+        x = rnd([B, cin, H, W], 1810 + i)
+        st = rnd([B, hid, H, W, nl], 1820 + i, 0.5)
+        with torch.no_grad():
+            o0, s0 = net(x, None)
+            o1, s1 = net(x, st)
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(in_channels=cin, hidden_channels=hid, num_layers=nl, gru_kernel_size=gk)))
+        d[f"{nm}/x"], d[f"{nm}/state"] = x, st
+        d[f"{nm}/out0"], d[f"{nm}/state0"], d[f"{nm}/out1"], d[f"{nm}/state1"] = o0, s0, o1, s1
+        d.update(sd(net, f"{nm}/w/"))
+    # RecurrentInit
+    for i, (nm, chans, dils, depth, ms) in enumerate([("init_ms1", (8, 8, 16, 16), (1, 1, 2, 4), 4, 1), ("init_ms3", (4, 6, 8), (1, 2, 1), 2, 3)]):
+        torch.manual_seed(1830 + i)
+        ini = rv.RecurrentInit(2, 12, channels=chans, dilations=dils, depth=depth, multiscale_depth=ms).eval()
+        x = rnd([1, 2, 17, 14], 1840 + i)
+        with torch.no_grad():
+            out = ini(x)
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(in_channels=2, out_channels=12, channels=list(chans), dilations=list(dils), depth=depth,
+                                                  multiscale_depth=ms)))
+        d[f"{nm}/x"], d[f"{nm}/out"] = x, out
+        d.update(sd(ini, f"{nm}/w/"))
+    # block + model (rvn.py:163-226): learned initializer "sense", 8 steps, shared and unshared parameters
+    for i, (nm, share, centered, (B, C, H, W)) in enumerate([("model_shared", True, False, (1, 3, 24, 16)),
+                                                             ("model_unshared", False, True, (1, 4, 15, 18))]):
+        torch.manual_seed(1850 + i)
+        norm = "ortho" if centered else "backward"
+        hid, nl, steps = 12, 3, 8
+        ini = rv.RecurrentInit(2, hid, channels=(6, 6, 8, 8), dilations=(1, 1, 2, 4), depth=nl, multiscale_depth=1).eval()
+        blocks = [rv.RecurrentVarNetBlock(in_channels=2, hidden_channels=hid, num_layers=nl, fft_centered=centered,
+                                          fft_normalization=norm, spatial_dims=[-2, -1], coil_dim=1).eval()
+                  for _ in range(1 if share else steps)]
+        for b_ in blocks:
+            with torch.no_grad():
+                b_.learning_rate.fill_(0.8)
+        img, S = synth(B, C, H, W, 1860 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=centered, normalization=norm)
+        _, m = make_mask([1, C, H, W, 2])
+        y = k * m
+        target = utils.complex_abs(utils.sense(fft.ifft2(k, centered=centered, normalization=norm), S, 1))
+        with torch.no_grad():
+            init_img = utils.complex_mul(fft.ifft2(y, centered=centered, normalization=norm, spatial_dims=[-2, -1]),
+                                         utils.complex_conj(S)).sum(1).unsqueeze(1)
+            state = ini(fft.fft2(init_img, centered=centered, normalization=norm, spatial_dims=[-2, -1]).sum(1).permute(0, 3, 1, 2))
+            d[f"{nm}/init_state"] = state
+            kp = y.clone()
+            for step in range(steps):
+                kp, state = blocks[0 if share else step](kp, y, m, S, state)
+                if step == 0:
+                    d[f"{nm}/k_step0"], d[f"{nm}/state_step0"] = kp, state
+            eta = fft.ifft2(kp, centered=centered, normalization=norm, spatial_dims=[-2, -1])
+            eta = torch.view_as_complex(utils.coil_combination(eta, S, method="SENSE", dim=1))
+            _, eta = utils.center_crop_to_smallest(target, eta)
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(in_channels=2, recurrent_hidden_channels=hid, recurrent_num_layers=nl, num_steps=steps,
+                                                  no_parameter_sharing=not share, learned_initializer=True,
+                                                  initializer_initialization="sense", initializer_channels=[6, 6, 8, 8],
+                                                  initializer_dilations=[1, 1, 2, 4], initializer_multiscale=1, fft_centered=centered,
+                                                  fft_normalization=norm, spatial_dims=[-2, -1], coil_dim=1,
+                                                  coil_combination_method="SENSE", pretrained=True)))
+        d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"], d[f"{nm}/target"] = y, S, m, target
+        d[f"{nm}/k_final"], d[f"{nm}/out"] = kp, torch.view_as_real(eta)
+        d.update(sd(ini, f"{nm}/w/initializer."))
+        for bi, b_ in enumerate(blocks):
+            d.update(sd(b_, f"{nm}/w/block_list.{bi}."))
+    d["names"] = np.array(json.dumps(["gru_h16_l2", "gru_h8_l4", "gru_h8_l2_k3", "init_ms1", "init_ms3", "model_shared", "model_unshared"]))
+    save("g18_rvn.npz", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17"]
-    fns = dict(g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    fns = dict(g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

@@ -62,6 +62,31 @@ def test_oracle_dc_layers_vs_golden(golden):
             assert_close(got, T(z[f"{nm}/prox{it}"]), 2e-5, f"{nm} prox-CG {it} iterations")
 
 
+def test_oracle_rvn_vs_golden(golden):
+    z = golden("g18_rvn.npz")
+    for nm in ("gru_h16_l2", "gru_h8_l4", "gru_h8_l2_k3"):
+        cfg, p = meta(z, f"{nm}/cfg"), weights(z, f"{nm}/w/")
+        x, st = T(z[f"{nm}/x"]), T(z[f"{nm}/state"])
+        o0, s0 = oracle.rvn.conv2dgru_forward(p, x, None, cfg["num_layers"], cfg["hidden_channels"])
+        o1, s1 = oracle.rvn.conv2dgru_forward(p, x, st, cfg["num_layers"], cfg["hidden_channels"])
+        for got, key in ((o0, "out0"), (s0, "state0"), (o1, "out1"), (s1, "state1")):
+            assert_close(got, T(z[f"{nm}/{key}"]), 2e-6, f"{nm} {key}")
+    for nm in ("init_ms1", "init_ms3"):
+        cfg = meta(z, f"{nm}/cfg")
+        got = oracle.rvn.recurrent_init_forward(weights(z, f"{nm}/w/"), T(z[f"{nm}/x"]), cfg["dilations"], cfg["depth"],
+                                                cfg["multiscale_depth"])
+        assert_close(got, T(z[f"{nm}/out"]), 2e-6, nm)
+    for nm in ("model_shared", "model_unshared"):
+        cfg, p = meta(z, f"{nm}/cfg"), weights(z, f"{nm}/w/")
+        y, S, mask, target = (T(z[f"{nm}/{k}"]) for k in ("y", "S", "mask", "target"))
+        k0, st0 = oracle.rvn.rvn_block_forward(p, y, y, mask, S, T(z[f"{nm}/init_state"]), cfg["recurrent_num_layers"],
+                                               cfg["recurrent_hidden_channels"], cfg["fft_centered"], cfg["fft_normalization"],
+                                               [-2, -1], 1, prefix="block_list.0.")
+        assert_close(k0, T(z[f"{nm}/k_step0"]), 5e-6, f"{nm} block, step 0")
+        assert_close(st0, T(z[f"{nm}/state_step0"]), 5e-6, f"{nm} state, step 0")
+        assert_close(oracle.rvn.rvn_forward(p, cfg, y, S, mask, None, target), T(z[f"{nm}/out"]), 2e-5, f"{nm} RecurrentVarNet")
+
+
 # ---- GPU: the HIP-backed drop-ins vs the same goldens ----------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def dev():
