@@ -228,6 +228,21 @@ int mrx_gated_cell_pack(const float* w_ih, const float* w_hh, float* packed, int
 int mrx_gated_cell_1x1(const float* x, const float* h, const float* packed, const float* b_ih, float* out, int B, int Cin,
                        int F, int64_t HW, int gates, void* stream);
 
+/* N4  Conv2dGRU layer of the Recurrent Variational Network (models/recurrentvarnet/conv2gru.py:139-157):
+ *   update = sigmoid(Wu [x;h] + bu), reset = sigmoid(Wr [x;h] + br), delta = tanh(Wo [x; h*reset] + bo),
+ *   h_new = h * (1 - update) + delta * update; out_relu (optional) = ReLU(h_new), the next layer's input.
+ * mrx_conv2dgru_cell_1x1: one launch for 1x1 gates on 64 features (x, h [B,64,HW]; h NULL = zero state; bias [3][64] in the order
+ *   update, reset, out, or NULL); mrx_conv2dgru_pack packs the three [64,128,1,1] gate weights (mrx_conv2dgru_pack_floats floats).
+ * Other shapes: mrx_conv2d on the concatenated inputs + mrx_mul_sigmoid (h * sigmoid(pre), h NULL = zeros) + mrx_gru_blend. */
+int mrx_conv2dgru_supported(int Cin, int F, int k);
+int64_t mrx_conv2dgru_pack_floats(int F);
+int mrx_conv2dgru_pack(const float* w_update, const float* w_reset, const float* w_out, float* packed, int F, void* stream);
+int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const float* packed, const float* bias, float* out,
+                           float* out_relu, int B, int F, int64_t HW, void* stream);
+int mrx_mul_sigmoid(const float* h, const float* pre, float* out, int64_t n, void* stream);
+int mrx_gru_blend(const float* h, const float* pre_update, const float* pre_out, float* out, float* out_relu, int64_t n,
+                  void* stream);
+
 /* A17 NormUnet support (models/unet_base/unet_block.py).  Planes are [B*C] images of H*W floats.
  *   mrx_instance_norm_act   InstanceNorm2d (biased var, eps, no affine) + activation, in place allowed   (:252-253,:294-295)
  *   mrx_group_norm_stats    per-group mean and UNBIASED std over n contiguous floats                       (:78-79)

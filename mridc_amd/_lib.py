@@ -49,6 +49,12 @@ _SIGNATURES = {
     "mrx_cdot": ([_p, _p, _p, _p, _i, _i64, _p], _i),
     "mrx_cg_step": ([_p, _p, _p, _p, _p, _p, _i, _i64, _p], _i),
     "mrx_cg_dir": ([_p, _p, _p, _p, _i, _i64, _p], _i),
+    "mrx_conv2dgru_supported": ([_i, _i, _i], _i),
+    "mrx_conv2dgru_pack_floats": ([_i], _i64),
+    "mrx_conv2dgru_pack": ([_p, _p, _p, _p, _i, _p], _i),
+    "mrx_conv2dgru_cell_1x1": ([_p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
+    "mrx_mul_sigmoid": ([_p, _p, _p, _i64, _p], _i),
+    "mrx_gru_blend": ([_p, _p, _p, _p, _p, _i64, _p], _i),
     "mrx_hard_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_vs_average": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),

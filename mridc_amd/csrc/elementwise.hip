@@ -702,6 +702,38 @@ __global__ void k_mgu(const float* __restrict__ ih, const float* __restrict__ hh
         out[o] = c + f * (hv - c);
     }
 }
+// Conv2dGRU (recurrentvarnet/conv2gru.py:147-157), the pointwise steps of the unfused route:
+//   k_mul_sigmoid   out = h * sigmoid(pre)                                   (state * reset, :151)
+//   k_gru_blend     o = h * (1 - sigmoid(pu)) + tanh(po) * sigmoid(pu); out = o, out_relu = ReLU(o)   (:154-157)
+__global__ void k_mul_sigmoid(const float* __restrict__ h, const float* __restrict__ pre, float* __restrict__ out, long long n) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long long)gridDim.x * blockDim.x)
+        out[o] = (h ? h[o] : 0.f) * sigmoidf_(pre[o]);
+}
+__global__ void k_gru_blend(const float* __restrict__ h, const float* __restrict__ pu, const float* __restrict__ po,
+                            float* __restrict__ out, float* __restrict__ out_relu, long long n) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long long)gridDim.x * blockDim.x) {
+        const float u = sigmoidf_(pu[o]);
+        const float v = (h ? h[o] : 0.f) * (1.0f - u) + tanhf(po[o]) * u;
+        out[o] = v;
+        if (out_relu) out_relu[o] = v > 0.f ? v : 0.f;
+    }
+}
+extern "C" int mrx_mul_sigmoid(const float* h, const float* pre, float* out, int64_t n, void* stream) {
+    MRX_REQUIRE(pre && out && n >= 0, MRX_EINVAL, "mrx_mul_sigmoid: bad argument");
+    if (n == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_mul_sigmoid, dim3(ew_grid(n)), dim3(EW_NT), 0, (hipStream_t)stream, h, pre, out, (long long)n);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_gru_blend(const float* h, const float* pre_update, const float* pre_out, float* out, float* out_relu, int64_t n,
+                             void* stream) {
+    MRX_REQUIRE(pre_update && pre_out && out && n >= 0, MRX_EINVAL, "mrx_gru_blend: bad argument");
+    if (n == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_gru_blend, dim3(ew_grid(n)), dim3(EW_NT), 0, (hipStream_t)stream, h, pre_update, pre_out, out, out_relu,
+                       (long long)n);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
 extern "C" int mrx_gru_gates(const float* ih, const float* hh, const float* h, float* out, int B, int F, int64_t HW, void* stream) {
     MRX_REQUIRE(ih && hh && h && out && B >= 0 && F >= 0 && HW >= 0, MRX_EINVAL, "mrx_gru_gates: bad argument");
     const long long total = (long long)B * F * HW;

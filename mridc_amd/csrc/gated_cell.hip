@@ -255,3 +255,203 @@ extern "C" int mrx_gated_cell_1x1(const float* x, const float* h, const float* p
     a.nseg = a.nsegb * B;
     return gates == 3 ? launch_gated<3>(a, (hipStream_t)stream) : launch_gated<2>(a, (hipStream_t)stream);
 }
+
+// ---- Conv2dGRU layer of the Recurrent Variational Network (recurrentvarnet/conv2gru.py:139-157), 1x1 gates on 64 features ------
+//   update = sigmoid(Wu [x; h] + bu)   reset = sigmoid(Wr [x; h] + br)   delta = tanh(Wo [x; h * reset] + bo)
+//   h_new  = h * (1 - update) + delta * update          (also written as ReLU(h_new): the next layer's input, :157)
+// Unlike the RIM's ConvGRUCell the reset gate multiplies the state BEFORE the candidate's GEMM.  h * reset is formed in the
+// accumulator layout (reset lives there) and fed to that GEMM as it is: an accumulator register of the 32x32 MFMA holds one
+// channel per lane half, which is exactly a B operand, so the candidate's hh weights are packed with their contraction index
+// enumerated in accumulator order (channel of step t, lane half l: 32(t>>4) + (t&3) + 8((t&15)>>2) + 4l) -- the same trick the
+// fused RIM layer uses for its ih GEMM.  Six 64x64 GEMMs per 32 pixels, all operands from HBM/LDS once.
+struct Conv2dGruArgs {
+    const float* x;       // [B,64,P] layer input (after its conv + ReLU)
+    const float* h;       // [B,64,P] previous state of this layer or null (= zeros)
+    const float* packed;  // mrx_conv2dgru_pack
+    const float* bias;    // [3][64]: update, reset, out
+    float* out;           // [B,64,P] new state
+    float* out_relu;      // [B,64,P] ReLU(new state) or null
+    long long P, nsegb, nseg;
+};
+
+// mats 0..2: Wu, Wr, Wo columns 0..63 (x part); 3, 4: Wu, Wr columns 64..127 (h part); 5: Wo columns 64..127 in accumulator order
+__global__ void k_conv2dgru_pack(const float* __restrict__ wu, const float* __restrict__ wr, const float* __restrict__ wo,
+                                 float* __restrict__ out) {
+    const int total = 6 * GC_F * GC_F;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int m = i & 31, half = (i >> 5) & 1, s = (i >> 6) & 31, mb = (i >> 11) & 1, mat = i >> 12;
+        const int row = mb * 32 + m;
+        const float* w = (mat == 0 || mat == 3) ? wu : (mat == 1 || mat == 4) ? wr : wo;
+        int col;
+        if (mat < 3)
+            col = 2 * s + half;
+        else if (mat < 5)
+            col = GC_F + 2 * s + half;
+        else
+            col = GC_F + 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * half;
+        out[i] = w[(long long)row * (2 * GC_F) + col];
+    }
+}
+
+__global__ __launch_bounds__(GC_NT, 2) void k_conv2dgru_cell(Conv2dGruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [6][2][32][2][32]
+    constexpr int MATF = GC_F * GC_F;
+    const int tid = threadIdx.x;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.packed);
+        float4* dst = reinterpret_cast<float4*>(Ws);
+        for (int i = tid; i < 6 * MATF / 4; i += GC_NT) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* wl = Ws + lane;
+    const long long stride = (long long)gridDim.x * (GC_NT / 64);
+    const unsigned P32 = (unsigned)a.P;
+    float xg[32], hg[32];
+    const float* xb = nullptr;
+    const float* hb = nullptr;
+    long long base = 0;
+    unsigned pxo = 0;
+    bool valid = false;
+    int lhi = 0;
+    auto load = [&](long long sg) {  // see k_gated_cell
+        int l31 = lane & 31;
+        lhi = lane >> 5;
+        asm volatile("" : "+v"(l31), "+v"(lhi));
+        const long long b = sg / a.nsegb;
+        const long long px = (sg - b * a.nsegb) * 32 + l31;
+        valid = px < a.P;
+        base = __builtin_amdgcn_readfirstlane((int)b) * (long long)GC_F * a.P;
+        pxo = valid ? (unsigned)px : 0u;
+        xb = a.x + base;
+        hb = a.h ? a.h + base : nullptr;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) xg[s] = xb[(unsigned)(2 * s + lhi) * P32 + pxo];
+    };
+    auto load_h = [&]() {
+        if (hb) {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) hg[s] = hb[(unsigned)(2 * s + lhi) * P32 + pxo];
+        }
+    };
+    // one GEMM group: NM matrices starting at MAT0, B operand SRC[s], destinations acc[D0 + mat]
+#define GC_GEMM(NM, MAT0, SRCEXPR, D0)                                                                   \
+    {                                                                                                    \
+        constexpr int NS = (NM) * 32;                                                                    \
+        float ra0[GC_PF + 1], ra1[GC_PF + 1];                                                            \
+        _Pragma("unroll") for (int t = 0; t < NS + GC_PF; ++t) {                                         \
+            if (t < NS) {                                                                                \
+                const int mat = (MAT0) + (t >> 5), s = t & 31;                                           \
+                ra0[t % (GC_PF + 1)] = wl[((mat * 2 + 0) * 32 + s) * 64];                                \
+                ra1[t % (GC_PF + 1)] = wl[((mat * 2 + 1) * 32 + s) * 64];                                \
+            }                                                                                            \
+            if (t >= GC_PF) {                                                                            \
+                const int u = t - GC_PF, c = u % (GC_PF + 1);                                            \
+                const int g = (D0) + (u >> 5), s = u & 31;                                               \
+                acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], SRCEXPR, acc[g][0], 0, 0, 0);   \
+                acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], SRCEXPR, acc[g][1], 0, 0, 0);   \
+            }                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+        }                                                                                                \
+    }
+    long long sg = (long long)blockIdx.x * (GC_NT / 64) + wave;
+    if (sg < a.nseg) load(sg);
+    while (sg < a.nseg) {
+        load_h();
+        f32x16 acc[3][2];  // 0 update, 1 reset (then h * reset), 2 candidate
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[d][ct][r] = a.bias ? a.bias[d * GC_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
+        GC_GEMM(3, 0, xg[s], 0)
+        if (hb) GC_GEMM(2, 3, hg[s], 0)
+        float hv[2][16];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hv[ct][r] = hb ? hb[(unsigned)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo] : 0.f;
+        float* ob = a.out + base;
+        float* orl = a.out_relu ? a.out_relu + base : nullptr;
+        const unsigned o_pxo = pxo;
+        const int o_lhi = lhi;
+        const bool o_valid = valid, have_h = hb != nullptr;
+        sg += stride;
+        if (sg < a.nseg) load(sg);  // next segment's x loads fly during the rest of this one
+        if (have_h) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[1][ct][r] = hv[ct][r] * gc_sigmoid(acc[1][ct][r]);
+            GC_GEMM(1, 5, acc[1][s >> 4][s & 15], 2)
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lhi;
+                const float u = gc_sigmoid(acc[0][ct][r]);
+                const float dl = gc_tanh(acc[2][ct][r]);
+                const float o = hv[ct][r] * (1.0f - u) + dl * u;
+                if (o_valid) {
+                    ob[(unsigned)co * P32 + o_pxo] = o;
+                    if (orl) orl[(unsigned)co * P32 + o_pxo] = o > 0.f ? o : 0.f;
+                }
+            }
+    }
+#undef GC_GEMM
+}
+
+extern "C" int64_t mrx_conv2dgru_pack_floats(int F) { return F == GC_F ? (int64_t)6 * GC_F * GC_F : -1; }
+extern "C" int mrx_conv2dgru_supported(int Cin, int F, int k) { return Cin == GC_F && F == GC_F && k == 1; }
+
+extern "C" int mrx_conv2dgru_pack(const float* w_update, const float* w_reset, const float* w_out, float* packed, int F, void* stream) {
+    MRX_REQUIRE(w_update && w_reset && w_out && packed, MRX_EINVAL, "mrx_conv2dgru_pack: null pointer");
+    MRX_REQUIRE(F == GC_F, MRX_EUNSUP, "mrx_conv2dgru_pack: hidden size %d (only %d)", F, GC_F);
+    hipLaunchKernelGGL(k_conv2dgru_pack, dim3((6 * GC_F * GC_F + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_update, w_reset, w_out,
+                       packed);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+extern "C" int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const float* packed, const float* bias, float* out,
+                                      float* out_relu, int B, int F, int64_t HW, void* stream) {
+    MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv2dgru_cell_1x1: null pointer");
+    MRX_REQUIRE(B >= 0 && HW >= 0 && HW < (1ll << 24) && B < (1 << 30), MRX_EINVAL, "mrx_conv2dgru_cell_1x1: bad dims");
+    MRX_REQUIRE(F == GC_F, MRX_EUNSUP, "mrx_conv2dgru_cell_1x1: hidden size %d (only %d; use the unfused route)", F, GC_F);
+    MRX_REQUIRE(out != x && out != h && out_relu != x && out_relu != h && out != out_relu, MRX_EINVAL,
+                "mrx_conv2dgru_cell_1x1: outputs must not alias inputs or each other");
+    if (B == 0 || HW == 0) return MRX_OK;
+    Conv2dGruArgs a;
+    a.x = x;
+    a.h = h;
+    a.packed = packed;
+    a.bias = bias;
+    a.out = out;
+    a.out_relu = out_relu;
+    a.P = HW;
+    a.nsegb = (HW + 31) / 32;
+    a.nseg = a.nsegb * B;
+    constexpr size_t lds = sizeof(float) * 6 * GC_F * GC_F;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv2dgru_cell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MRX_HIP(hipGetDevice(&dev));
+        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long nblk_need = (a.nseg + GC_NT / 64 - 1) / (GC_NT / 64);
+    const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);
+    hipLaunchKernelGGL(k_conv2dgru_cell, dim3(nblk), dim3(GC_NT), lds, (hipStream_t)stream, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

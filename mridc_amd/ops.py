@@ -438,6 +438,56 @@ def gated_cell_1x1(x, h, packed, b_ih, gates, F=64):
     return out
 
 
+def conv2dgru_supported(cin, F, k):
+    return bool(_lib.lib().mrx_conv2dgru_supported(int(cin), int(F), int(k)))
+
+
+def conv2dgru_pack(w_update, w_reset, w_out):
+    """Pack the three 1x1 gate weights [64,128,1,1] of a Conv2dGRU layer for conv2dgru_cell_1x1."""
+    ws = [_lib.f32c(w.detach()) for w in (w_update, w_reset, w_out)]
+    F = int(ws[0].shape[0])
+    n = int(_lib.lib().mrx_conv2dgru_pack_floats(F))
+    if n < 0 or any(tuple(w.shape) != (F, 2 * F, 1, 1) for w in ws):
+        raise ValueError("conv2dgru_pack: unsupported shape")
+    packed = torch.empty(n, dtype=torch.float32, device=ws[0].device)
+    _lib.check(_lib.lib().mrx_conv2dgru_pack(_lib.ptr(ws[0]), _lib.ptr(ws[1]), _lib.ptr(ws[2]), _lib.ptr(packed), F, _lib.stream_ptr()),
+               "mrx_conv2dgru_pack")
+    return packed
+
+
+def conv2dgru_cell_1x1(x, h, packed, bias, relu_out=True):
+    """One Conv2dGRU layer's GRU (1x1 gates, 64 features) in one launch -> (new state, ReLU(new state) | None)."""
+    x = _lib.f32c(x)
+    B, F, H, W = _nchw(x)
+    h = None if h is None else _lib.f32c(h)
+    bias = None if bias is None else _lib.f32c(bias)
+    out = torch.empty_like(x)
+    out_relu = torch.empty_like(x) if relu_out else None
+    _lib.check(_lib.lib().mrx_conv2dgru_cell_1x1(_lib.ptr(x), _lib.ptr(h), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(out),
+                                                 _lib.ptr(out_relu), B, F, H * W, _lib.stream_ptr()), "mrx_conv2dgru_cell_1x1")
+    return out, out_relu
+
+
+def mul_sigmoid(h, pre):
+    """h * sigmoid(pre); h None = zeros."""
+    pre = _lib.f32c(pre)
+    h = None if h is None else _lib.f32c(h)
+    out = torch.empty_like(pre)
+    _lib.check(_lib.lib().mrx_mul_sigmoid(_lib.ptr(h), _lib.ptr(pre), _lib.ptr(out), pre.numel(), _lib.stream_ptr()), "mrx_mul_sigmoid")
+    return out
+
+
+def gru_blend(h, pre_update, pre_out, relu_out=True):
+    """h * (1 - sigmoid(pre_update)) + tanh(pre_out) * sigmoid(pre_update) -> (new state, ReLU(new state) | None); h None = zeros."""
+    pu, po = _lib.f32c(pre_update), _lib.f32c(pre_out)
+    h = None if h is None else _lib.f32c(h)
+    out = torch.empty_like(pu)
+    out_relu = torch.empty_like(pu) if relu_out else None
+    _lib.check(_lib.lib().mrx_gru_blend(_lib.ptr(h), _lib.ptr(pu), _lib.ptr(po), _lib.ptr(out), _lib.ptr(out_relu), pu.numel(),
+                                        _lib.stream_ptr()), "mrx_gru_blend")
+    return out, out_relu
+
+
 def mgu_gates(ih, hh, h):
     ih, hh, h = _lib.f32c(ih), _lib.f32c(hh), _lib.f32c(h)
     B, F, H, W = _nchw(h)
