@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--width", type=int, default=372)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="replay the step as a captured hipGraph (falls back to eager)")
-    ap.add_argument("--model", default="cirim", choices=["cirim", "e2evn", "qcirim"],
+    ap.add_argument("--model", default="cirim", choices=["cirim", "e2evn", "qcirim", "rvn", "ccnn", "vsnet"],
                     help="cirim = the headline workload (BASELINE.json metric); e2evn = configs[1], reported for reference")
     ap.add_argument("--mask", default="1d", choices=["1d", "2d"],
                     help="1d: random columns R=4 (SURVEY 8d primary); 2d: random 2-D points R=10 (stands in for the YAML's Poisson-2D)")
@@ -196,17 +196,37 @@ def bench_qcirim(args, world, rank, dev):
 def bench_e2evn(args, world, rank, dev):
     """configs[1]: E2EVN 6 cascades, NormUnet(14, 2, pad 11), 15 coils 640x372 (reported next to the headline number)."""
     from mridc_amd import synthetic
-    from mridc_amd.collections.reconstruction.models.vn import VarNet
     from mridc_amd.sharding import shard_range
-    cfg = dict(synthetic.E2EVN_BASELINE_CFG)
+    common = dict(fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1, coil_combination_method="SENSE",
+                  use_sens_net=False)
     torch.manual_seed(0)
-    model = VarNet(cfg).eval().to(dev)
+    if args.model == "e2evn":
+        from mridc_amd.collections.reconstruction.models.vn import VarNet
+        model = VarNet(dict(synthetic.E2EVN_BASELINE_CFG))
+        label, desc = "E2EVN 6-cascade", "E2EVN 6 cascades, NormUnet(chans 14, pools 2, pad 11)"
+    elif args.model == "rvn":       # SURVEY 8f N4; the reference's base_rvn_run.yaml
+        from mridc_amd.collections.reconstruction.models.rvn import RecurrentVarNet
+        model = RecurrentVarNet(dict(common, in_channels=2, recurrent_hidden_channels=64, recurrent_num_layers=4, num_steps=8,
+                                     no_parameter_sharing=True, learned_initializer=True, initializer_initialization="sense",
+                                     initializer_channels=[32, 32, 64, 64], initializer_dilations=[1, 1, 2, 4], initializer_multiscale=1))
+        label, desc = "RecurrentVarNet 8-step", "RecurrentVarNet 8 steps x 4 Conv2dGRU layers (64 features), learned initializer"
+    elif args.model == "ccnn":      # base_ccnn_run.yaml
+        from mridc_amd.collections.reconstruction.models.ccnn import CascadeNet
+        model = CascadeNet(dict(common, num_cascades=10, hidden_channels=64, n_convs=5, batchnorm=False, no_dc=True))
+        label, desc = "CascadeNet 10-cascade", "CascadeNet 10 cascades x 5 convs (64 channels), no_dc as in the model zoo"
+    else:                           # base_vsnet_run.yaml
+        from mridc_amd.collections.reconstruction.models.vsnet import VSNet
+        model = VSNet(dict(common, num_cascades=10, imspace_model_architecture="CONV", imspace_conv_hidden_channels=64,
+                           imspace_conv_n_convs=4, imspace_conv_batchnorm=False))
+        label, desc = "VSNet 10-cascade", "VSNet 10 cascades, CONV denoiser (4 convs, 64 channels, shared)"
+    model = model.eval().to(dev)
     B, C, H, W = args.batch, args.coils, args.height, args.width
     NS = max(1, args.streams)
     s0, s1 = shard_range(world * NS * B, rank, world)
     datas = []
     for i in range(NS):
-        slices = [synthetic.make_slice(C, H, W, slice_idx=j, mask_dtype=torch.uint8) for j in range(s0 + i * B, s0 + (i + 1) * B)]
+        slices = [synthetic.make_slice(C, H, W, slice_idx=j, mask_dtype=torch.float32 if args.model == "vsnet" else torch.uint8)
+                  for j in range(s0 + i * B, s0 + (i + 1) * B)]
         d = {k: torch.cat([s[k] for s in slices], 0).to(dev) for k in ("y", "sensitivity_maps", "target")}
         d["mask"] = slices[0]["mask"].to(dev)
         datas.append(d)
@@ -249,11 +269,11 @@ def bench_e2evn(args, world, rank, dev):
     elapsed = max_over_ranks(time.perf_counter() - t0, dev)
     B = NS * B
     if rank == 0:
-        print(json.dumps(dict(metric="slices/sec (inference), E2EVN 6-cascade 15-coil 640x372", value=world * B * args.steps / elapsed,
+        print(json.dumps(dict(metric=f"slices/sec (inference), {label} {C}-coil {H}x{W}", value=world * B * args.steps / elapsed,
                               unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                               ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                               dtype="f32", data="synthetic",
-                              config=dict(workload="E2EVN 6 cascades, NormUnet(chans 14, pools 2, pad 11), 15 coils, 640x372, batch "
+                              config=dict(workload=f"{desc}, {C} coils, {H}x{W}, batch "
                                                    f"{B} per GPU ({NS} concurrent HIP stream(s), {'one hipGraph each' if graphs else 'eager'}), random-init weights "
                                                    "(seed 0)", parallelism=f"slice-sharded x{world}"))),
               flush=True)
@@ -314,8 +334,8 @@ def main():
     from mridc_amd import ops, synthetic
     from mridc_amd.collections.reconstruction.models.cirim import CIRIM
 
-    if args.model in ("e2evn", "qcirim"):
-        (bench_e2evn if args.model == "e2evn" else bench_qcirim)(args, world, rank, dev)
+    if args.model != "cirim":
+        (bench_qcirim if args.model == "qcirim" else bench_e2evn)(args, world, rank, dev)
         if use_dist:
             dist.destroy_process_group()
         return

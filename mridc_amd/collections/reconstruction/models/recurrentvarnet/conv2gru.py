@@ -56,12 +56,18 @@ class Conv2dGRU(nn.Module):
                 nn.init.constant_(update_gate[-1].bias, 0.0)
                 nn.init.constant_(out_gate[-1].bias, 0.0)
         self._pack_cache = {}
+        self._fused_conv = ops.FusedConvReLU()
 
     def _conv(self, idx, x, relu):
         conv = self.conv_blocks[idx][-1]
         if not self.replication_padding and idx == 1:
             raise NotImplementedError("mridc_amd Conv2dGRU: the reference's zero-padded dilated layer (padding 1, dilation 2) shrinks "
                                       "the image; only replication_padding=True is on the HIP path")
+        if relu and self.replication_padding and conv.kernel_size[0] == 3 and conv.in_channels == conv.out_channels:
+            # 3x3 64 -> 64 layers: the fused RIM layer kernels (Winograd for the dilated one) with an identity 1x1 stage
+            y = self._fused_conv(idx, conv.weight, conv.bias, conv.dilation[0], x)
+            if y is not None:
+                return y
         return ops.conv2d(x, conv.weight, conv.bias, conv.dilation[0], ops.PAD_REPLICATE if self.replication_padding else ops.PAD_ZERO,
                           ops.ACT_RELU if relu else ops.ACT_NONE)
 
