@@ -200,6 +200,12 @@ int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, float* packe
 int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, const float* b_conv, const float* b_ih,
                               const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H, int W,
                               void* stream);
+/* Plain 3x3 convolution into 64 channels on the Winograd kernel (no 1x1 stage): dilation 1 or 2, MRX_PAD_ZERO or
+ * MRX_PAD_REPLICATE, bias (or NULL) and MRX_ACT_* fused.  packed = mrx_rim_layer_wino_pack(w, NULL, ...).  Replaces nn.Conv2d
+ * (3x3, 64 out channels) in conv/conv2d.py:36-43, recurrentvarnet/conv2gru.py:71-79, recurrentvarnet.py:68-71. */
+int mrx_conv3x3_wino_supported(int Cin, int Cout, int k, int dil);
+int mrx_conv3x3_wino(const float* x, const float* packed, const float* bias, float* out, int B, int Cin, int Cout, int H,
+                     int W, int dil, int pad_mode, int act, float slope, void* stream);
 
 /* A11 stand-alone IndRNN cell (rnn_cells.py:295-312,384-391): h_new = ReLU(conv_zero_pad(x; w_ih, b_ih) + hh*h_prev). */
 int mrx_indrnn_cell(const float* x, const float* w_ih, const float* b_ih, const float* hh, const float* h_prev,
@@ -209,6 +215,13 @@ int mrx_indrnn_cell(const float* x, const float* w_ih, const float* b_ih, const 
  * conv F -> 2 channels, kernel k, dilation dil, bias optional. */
 int mrx_rim_final(const float* h, const float* w, const float* bias, const float* eta, float* eta_out, int B,
                   int F, int H, int W, int k, int dil, void* stream);
+
+/* out[B,H,W,2] = permute(conv3x3(h; w [2,F,3,3], bias), (0,2,3,1)): a convolution into one complex image, zero or replicate padding
+ * (the last layer of the CascadeNet / VSNet / Recurrent VarNet regularisers: conv/conv2d.py:36-43 + ccnn_block.py:133,
+ * conv2gru.py:158-162 + recurrentvarnet.py:221).  3x3, dilation 1, W % 4 == 0, F % 4 == 0, 16-byte aligned pointers; other
+ * shapes return MRX_EUNSUP (use mrx_conv2d and permute). */
+int mrx_conv_to_complex(const float* h, const float* w, const float* bias, float* out, int B, int F, int H, int W, int k,
+                        int dil, int pad_mode, void* stream);
 
 /* A12 GRU / MGU gate math (rnn_cells.py:118-127, :255-261) on precomputed ih / hh conv outputs
  * ([B,3F,H,W] / [B,2F,H,W]); out may alias h. */

@@ -55,6 +55,9 @@ _SIGNATURES = {
     "mrx_conv2dgru_cell_1x1": ([_p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_mul_sigmoid": ([_p, _p, _p, _i64, _p], _i),
     "mrx_gru_blend": ([_p, _p, _p, _p, _p, _i64, _p], _i),
+    "mrx_conv3x3_wino_supported": ([_i, _i, _i, _i], _i),
+    "mrx_conv3x3_wino": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
+    "mrx_conv_to_complex": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_hard_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_vs_average": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),

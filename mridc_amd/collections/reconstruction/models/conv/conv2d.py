@@ -63,8 +63,9 @@ class Conv2d(nn.Module):
             self._cache[key] = (w.contiguous(), b.contiguous())
         return self._cache[key]
 
-    def forward(self, x):
-        """conv2d.py:54-69."""
+    def forward(self, x, _complex_last=False):
+        """conv2d.py:54-69.  `_complex_last` (used by the cascade blocks of this package): return permute(out, (0, 2, 3, 1)) --
+        what every caller does next -- with the last convolution writing that layout directly (2 output channels)."""
         if x.dim() == 5:
             x = x.squeeze(1)
             if x.shape[-1] == 2:
@@ -82,6 +83,8 @@ class Conv2d(nn.Module):
             if j < len(mods) and not isinstance(mods[j], nn.Conv2d):
                 act, slope = self._activation(mods[j])
                 j += 1
+            if _complex_last and j >= len(mods) and act == ops.ACT_NONE and conv.out_channels == 2:
+                return ops.conv_to_complex(x, w, b, 1, ops.PAD_ZERO)
             x = ops.conv2d(x, w, b, 1, ops.PAD_ZERO, act, slope)
             i = j
-        return x
+        return x.permute(0, 2, 3, 1) if _complex_last else x

@@ -1,7 +1,8 @@
 """Drop-in for `mridc.collections.reconstruction.models.recurrentvarnet.conv2gru.Conv2dGRU` (reference conv2gru.py:10-163),
 inference path.
 
-Per layer: conv (5x5 / 3x3 dilation 2 / 3x3, replicate or zero padding) + ReLU is one mrx_conv2d launch; the GRU on
+Per layer: conv (5x5 / 3x3 dilation 2 / 3x3, replicate or zero padding) + ReLU is one launch (mrx_conv2d; the 3x3 layers into 64
+features take its Winograd form, mrx_conv3x3_wino); the GRU on
 cat(input, state) is ONE launch for the Recurrent VarNet's shape (1x1 gates, 64 features: mrx_conv2dgru_cell_1x1) and
 conv + mrx_mul_sigmoid + conv + mrx_gru_blend otherwise.  `previous_state` is the reference's [B,hidden,H,W,layers] tensor;
 a list of per-layer contiguous tensors is accepted as well (and then returned), which is what the RecurrentVarNet drop-in
@@ -56,18 +57,12 @@ class Conv2dGRU(nn.Module):
                 nn.init.constant_(update_gate[-1].bias, 0.0)
                 nn.init.constant_(out_gate[-1].bias, 0.0)
         self._pack_cache = {}
-        self._fused_conv = ops.FusedConvReLU()
 
     def _conv(self, idx, x, relu):
         conv = self.conv_blocks[idx][-1]
         if not self.replication_padding and idx == 1:
             raise NotImplementedError("mridc_amd Conv2dGRU: the reference's zero-padded dilated layer (padding 1, dilation 2) shrinks "
                                       "the image; only replication_padding=True is on the HIP path")
-        if relu and self.replication_padding and conv.kernel_size[0] == 3 and conv.in_channels == conv.out_channels:
-            # 3x3 64 -> 64 layers: the fused RIM layer kernels (Winograd for the dilated one) with an identity 1x1 stage
-            y = self._fused_conv(idx, conv.weight, conv.bias, conv.dilation[0], x)
-            if y is not None:
-                return y
         return ops.conv2d(x, conv.weight, conv.bias, conv.dilation[0], ops.PAD_REPLICATE if self.replication_padding else ops.PAD_ZERO,
                           ops.ACT_RELU if relu else ops.ACT_NONE)
 
@@ -81,9 +76,9 @@ class Conv2dGRU(nn.Module):
             self._pack_cache[idx] = hit
         return hit[1], hit[2]
 
-    def forward(self, cell_input: torch.Tensor, previous_state: Union[None, torch.Tensor, List[torch.Tensor]]
-                ) -> Tuple[torch.Tensor, Union[torch.Tensor, List[torch.Tensor]]]:
-        """conv2gru.py:112-163."""
+    def forward(self, cell_input: torch.Tensor, previous_state: Union[None, torch.Tensor, List[torch.Tensor]],
+                _complex_last: bool = False) -> Tuple[torch.Tensor, Union[torch.Tensor, List[torch.Tensor]]]:
+        """conv2gru.py:112-163.  `_complex_last` (used by RecurrentVarNetBlock): the output as [B,H,W,2] instead of [B,2,H,W]."""
         as_list = isinstance(previous_state, (list, tuple))
         if previous_state is None:
             states = [None] * self.num_layers                          # zeros (conv2gru.py:134-137) without materialising them
@@ -110,5 +105,11 @@ class Conv2dGRU(nn.Module):
                 pre_o = ops.conv2d(torch.cat([x, ops.mul_sigmoid(h, pre_r)], dim=1), og.weight, og.bias, 1, ops.PAD_ZERO)
                 new, x = ops.gru_blend(h, pre_u, pre_o, True)
             new_states.append(new)
-        out = self._conv(self.num_layers, x, False)
+        last = self.conv_blocks[self.num_layers][-1]
+        if _complex_last and last.out_channels == 2 and self.replication_padding:
+            out = ops.conv_to_complex(x, last.weight, last.bias, last.dilation[0], ops.PAD_REPLICATE)
+        else:
+            out = self._conv(self.num_layers, x, False)
+            if _complex_last:
+                out = out.permute(0, 2, 3, 1)
         return out, (new_states if as_list else torch.stack(new_states, dim=-1))

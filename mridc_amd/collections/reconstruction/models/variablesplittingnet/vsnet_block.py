@@ -4,6 +4,7 @@ from typing import Any, List, Optional, Tuple, Union
 import torch
 
 from mridc_amd import ops
+from mridc_amd.collections.reconstruction.models.conv import conv2d
 
 
 class DataConsistencyLayer(torch.nn.Module):
@@ -70,7 +71,11 @@ class VSNetBlock(torch.nn.Module):
         """vsnet_block.py:118-146."""
         for idx in range(self.num_cascades):
             pred = self.sens_reduce(kspace, sens_maps)
-            pred = self.denoiser_block[idx](pred.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+            den = self.denoiser_block[idx]
+            if isinstance(den, conv2d.Conv2d):
+                pred = den(pred.permute(0, 3, 1, 2), _complex_last=True)
+            else:
+                pred = den(pred.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
             pred = self.sens_expand(pred, sens_maps)
             sx = self.data_consistency_block[idx](pred, kspace, mask)
             sx = self.sens_reduce(sx, sens_maps)

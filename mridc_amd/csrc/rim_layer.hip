@@ -493,9 +493,10 @@ struct RimFinalArgs {
     const float* h;     // [B,F,H,W]
     const float* w;     // [2,F,K,K]
     const float* bias;  // [2] or null
-    const float* eta;   // [B,H,W,2]
+    const float* eta;   // [B,H,W,2] (k_rim_final4: null = nothing added)
     float* out;         // [B,H,W,2]
     int B, F, H, W, tiles_x, ntiles;
+    int pad_zero;       // k_rim_final4 only: zero padding instead of the RIM's replicate padding
     unsigned long long* trace;  // debug only (env MRX_TRACE)
 };
 template <int K, int DIL>
@@ -658,6 +659,14 @@ __global__ __launch_bounds__(RF4_NT, 4) void k_rim_final4(RimFinalArgs a) {
     const int x0 = w0 + 4 * tx;                         // first of this thread's 4 pixels
     const bool fix_l = x0 == 0, fix_r = x0 + 4 >= a.W;  // replicate border columns (conv_layers.py:72-76)
     const bool border = w0 == 0 || w0 + RF4_TW >= a.W;
+    // zero padding: rows of the 3-row patch outside the image (the DMA fetched the clamped row instead) contribute nothing
+    const bool zrows = a.pad_zero && (h0 == 0 || h0 + RF4_TH >= a.H);
+    unsigned rowok = 7u;
+    if (zrows) {
+        rowok = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) rowok |= (h0 + ty - 1 + r >= 0 && h0 + ty - 1 + r < a.H) ? (1u << r) : 0u;
+    }
     float acc[2][4];
 #pragma unroll
     for (int co = 0; co < 2; ++co)
@@ -686,8 +695,12 @@ __global__ __launch_bounds__(RF4_NT, 4) void k_rim_final4(RimFinalArgs a) {
             const rf4_f4 v1 = *reinterpret_cast<const rf4_f4*>(row + 4);
             float v[6] = {row[3], v1[0], v1[1], v1[2], v1[3], row[8]};  // image columns x0-1 .. x0+4
             if (border) {
-                if (fix_l) v[0] = v[1];
-                if (fix_r) v[5] = v[4];  // W % 4 == 0: the last image column is this thread's 4th pixel
+                if (fix_l) v[0] = a.pad_zero ? 0.f : v[1];
+                if (fix_r) v[5] = a.pad_zero ? 0.f : v[4];  // W % 4 == 0: the last image column is this thread's 4th pixel
+            }
+            if (zrows && !((rowok >> r) & 1u)) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) v[i] = 0.f;
             }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
@@ -727,9 +740,14 @@ __global__ __launch_bounds__(RF4_NT, 4) void k_rim_final4(RimFinalArgs a) {
     const long long o = (((long long)b * a.H + oy) * a.W + x0) * 2;
     const float b0 = a.bias ? a.bias[0] : 0.f, b1 = a.bias ? a.bias[1] : 0.f;
     const rf4_f4 bb = (rf4_f4){b0, b1, b0, b1};
-    const rf4_f4 e0 = *reinterpret_cast<const rf4_f4*>(a.eta + o), e1 = *reinterpret_cast<const rf4_f4*>(a.eta + o + 4);
-    *reinterpret_cast<rf4_f4*>(a.out + o) = e0 + (s0 + bb);
-    *reinterpret_cast<rf4_f4*>(a.out + o + 4) = e1 + (s1 + bb);
+    if (a.eta) {
+        const rf4_f4 e0 = *reinterpret_cast<const rf4_f4*>(a.eta + o), e1 = *reinterpret_cast<const rf4_f4*>(a.eta + o + 4);
+        *reinterpret_cast<rf4_f4*>(a.out + o) = e0 + (s0 + bb);
+        *reinterpret_cast<rf4_f4*>(a.out + o + 4) = e1 + (s1 + bb);
+    } else {
+        *reinterpret_cast<rf4_f4*>(a.out + o) = s0 + bb;
+        *reinterpret_cast<rf4_f4*>(a.out + o + 4) = s1 + bb;
+    }
 }
 
 static int launch_rim_final4(RimFinalArgs a, hipStream_t st) {
@@ -775,6 +793,7 @@ int mrx_rim_final_tuned(const float* h, const float* w, const float* bias, const
     if ((RF_CK * (RF_TH + 2 * rl_pad(k, dil)) * (RL_TW + 2 * rl_pad(k, dil))) % 2) return MRX_OK;
     RimFinalArgs a;
     a.trace = nullptr;
+    a.pad_zero = 0;
     a.h = h;
     a.w = w;
     a.bias = bias;
@@ -794,4 +813,31 @@ int mrx_rim_final_tuned(const float* h, const float* w, const float* bias, const
     if (k == 1 && dil == 1) return launch_rim_final<1, 1>(a, st);
     if (k == 3 && dil == 2) return launch_rim_final<3, 2>(a, st);
     return launch_rim_final<5, 1>(a, st);
+}
+
+// permute(conv3x3(h), (0, 2, 3, 1)) for a convolution into 2 channels, zero or replicate padding, as [B,H,W,2] (one complex image):
+// the tail of the CascadeNet / VSNet / Recurrent VarNet regularisers (conv/conv2d.py:36-43 + ccnn_block.py:133; conv2gru.py:158-162
+// + recurrentvarnet.py:221) on the 4-pixels-per-thread kernel of the RIM's final layer.  Returns MRX_EUNSUP for other shapes.
+extern "C" int mrx_conv_to_complex(const float* h, const float* w, const float* bias, float* out, int B, int F, int H, int W, int k,
+                                   int dil, int pad_mode, void* stream) {
+    MRX_REQUIRE(h && w && out, MRX_EINVAL, "mrx_conv_to_complex: null pointer");
+    MRX_REQUIRE(B >= 0 && F >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_to_complex: bad dims");
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv_to_complex: pad mode %d", pad_mode);
+    MRX_REQUIRE(k == 3 && dil == 1 && (W & 3) == 0 && W >= 8 && F % 4 == 0 && (long long)H * W < (1ll << 30) && B <= 65535 &&
+                    (((uintptr_t)h | (uintptr_t)out) & 15) == 0,
+                MRX_EUNSUP, "mrx_conv_to_complex: shape not covered (3x3, dilation 1, W %% 4 == 0, F %% 4 == 0, 16-byte aligned)");
+    if (B == 0) return MRX_OK;
+    RimFinalArgs a;
+    a.trace = nullptr;
+    a.pad_zero = pad_mode == MRX_PAD_ZERO;
+    a.h = h;
+    a.w = w;
+    a.bias = bias;
+    a.eta = nullptr;
+    a.out = out;
+    a.B = B;
+    a.F = F;
+    a.H = H;
+    a.W = W;
+    return launch_rim_final4(a, (hipStream_t)stream);
 }

@@ -58,6 +58,8 @@ struct WinoArgs {
     float* hnew;
     int B, Cin, H, W, tiles_x, ntiles;
     unsigned long long* trace;  // debug only (env MRX_TRACE): cycle stamps per workgroup
+    int act;      // plain-convolution form (TAIL = false) only: MRX_ACT_* applied to conv + bias
+    float slope;  // leaky slope of that activation
 };
 
 // U = G g G^T per (cout, cin); per chunk q the image [xi = 4i+j'][k pair j][p = co ^ 16*(j&1)][kb], cin = 8q + 2j + kb
@@ -95,7 +97,7 @@ __global__ void k_wino_pack(const float* __restrict__ w, const float* __restrict
             r >>= 1;
             const int ct = r >> 4, reg = r & 15;
             const int c = 32 * ct + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            v = w_ih[o * WN_F + c];
+            v = w_ih ? w_ih[o * WN_F + c] : 0.f;
         }
         out[idx] = v;
     }
@@ -106,7 +108,7 @@ extern "C" int64_t mrx_rim_layer_wino_pack_floats(int Cin, int F) {
     return (int64_t)((Cin + WN_CK - 1) / WN_CK) * WN_UCHUNK + WN_F * WN_F;
 }
 extern "C" int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, int F, void* stream) {
-    MRX_REQUIRE(w_conv && w_ih && packed, MRX_EINVAL, "mrx_rim_layer_wino_pack: null pointer");
+    MRX_REQUIRE(w_conv && packed, MRX_EINVAL, "mrx_rim_layer_wino_pack: null pointer");  // w_ih may be null (plain convolution)
     MRX_REQUIRE(F == WN_F && Cin >= 1, MRX_EUNSUP, "mrx_rim_layer_wino_pack: F=%d Cin=%d", F, Cin);
     const int nchunks = (Cin + WN_CK - 1) / WN_CK;
     const int total = nchunks * WN_UCHUNK + WN_F * WN_F;
@@ -118,7 +120,11 @@ extern "C" int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, f
 #define WN_GLOBAL(p) ((const __attribute__((address_space(1))) void*)(p))
 #define WN_SHARED(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int ABL, bool X4>
+// DIL = 2: the four parity sub-lattices (above).  DIL = 1: the same 64 tiles are the 4 x 16 plain 2x2 tiles of the 8 x 32 pixel
+// block (tile row 2 tby + py, tile column 2 tbx + px): only the patch gather and the output scatter differ.
+// TAIL = false: plain convolution + bias + activation, no 1x1 stage (rows go from Y straight to HBM).
+// ZP: zero padding instead of replicate: patch elements outside the image are zeroed when gathered (border tiles only).
+template <int ABL, bool X4, int DIL = 2, bool TAIL = true, bool ZP = false>
 __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float* Xs = smem_f;                          // [2][CK][512] raw halo'd tiles (12 rows of XS)
@@ -169,6 +175,8 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     constexpr int NXM = X4 ? 2 : 8;  // raw-tile DMA instructions per wave and chunk
     unsigned xoff[NXM];
     int t_col[4];  // LDS offsets of the four patch columns in the first patch row (X4: column replicate border applied here)
+    unsigned zp_ok = 0xffffu;  // ZP: bit 4 i + j set = patch element (i, j) of this lane's tile lies inside the image
+    bool zp_border = false;    // ZP: this tile touches the image border (wave-uniform)
     auto set_tile = [&](int v) {  // tile coordinates and the per-lane DMA / gather offsets that depend on them
         b = v / a.ntiles;
         int t = v - b * a.ntiles;
@@ -196,14 +204,28 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
             xoff[m] = (unsigned)(gy * a.W + gx) * 4u;
         }
+        // first patch row / column of this lane's tile in the raw tile (origin: image (h0 - 2, w0 - OX))
+        const int prow0 = DIL == 2 ? 4 * (lane >> 5) + ((lane >> 4) & 1) : 4 * (lane >> 5) + 2 * ((lane >> 4) & 1) + 1;
+        const int pcol0 = (DIL == 2 ? 4 * (lane & 7) + ((lane >> 3) & 1) : 4 * (lane & 7) + 2 * ((lane >> 3) & 1) + 1) + OX - 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int c = 4 * (lane & 7) + ((lane >> 3) & 1) + 2 * j + OX - 2;  // tile column of image column w0 - OX + c
+            int c = pcol0 + DIL * j;  // tile column of image column w0 - OX + c
             if (X4) {
                 const int lo = OX - w0, hi = a.W - 1 - w0 + OX;
                 c = c < lo ? lo : (c > hi ? hi : c);
             }
-            t_col[j] = wave * WN_XPLANE + (4 * (lane >> 5) + ((lane >> 4) & 1)) * XS + c;
+            t_col[j] = wave * WN_XPLANE + prow0 * XS + c;
+        }
+        if constexpr (ZP) {
+            zp_border = h0 < 2 || h0 + 10 > a.H || w0 < 2 || w0 + 34 > a.W;
+            zp_ok = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gy = h0 - 2 + prow0 + DIL * i, gx = w0 - OX + pcol0 + DIL * j;
+                    zp_ok |= (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (1u << (4 * i + j)) : 0u;
+                }
         }
     };
     auto dma_u = [&](int q, int m) {  // m in 0..3
@@ -228,7 +250,10 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[i][j] = src[t_col[j] + (2 * i) * XS];
+            for (int j = 0; j < 4; ++j) {
+                d[i][j] = src[t_col[j] + (DIL * i) * XS];
+                if (ZP && zp_border) d[i][j] = (zp_ok >> (4 * i + j)) & 1u ? d[i][j] : 0.f;
+            }
         float e[4][4];  // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -274,7 +299,10 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             if (s >= PF && !(ABL & 8)) acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[c][0], rb[c][0], acc[xi][0], 0, 0, 0);
             if (tr && s < 2) {  // patch column 2s
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d[i][2 * s] = tsrc[t_col[2 * s] + (2 * i) * XS];
+                for (int i = 0; i < 4; ++i) {
+                    d[i][2 * s] = tsrc[t_col[2 * s] + (DIL * i) * XS];
+                    if (ZP && zp_border) d[i][2 * s] = (zp_ok >> (4 * i + 2 * s)) & 1u ? d[i][2 * s] : 0.f;
+                }
             }
             if (tr && s >= 3 && s < 7) {  // B^T d, one column per step
                 const int j = s - 3;
@@ -301,7 +329,10 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             if (s >= PF && !(ABL & 8)) acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra0[c][1], rb[c][1], acc[xi][0], 0, 0, 0);
             if (tr && s < 2) {  // patch column 2s+1
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d[i][2 * s + 1] = tsrc[t_col[2 * s + 1] + (2 * i) * XS];
+                for (int i = 0; i < 4; ++i) {
+                    d[i][2 * s + 1] = tsrc[t_col[2 * s + 1] + (DIL * i) * XS];
+                    if (ZP && zp_border) d[i][2 * s + 1] = (zp_ok >> (4 * i + 2 * s + 1)) & 1u ? d[i][2 * s + 1] : 0.f;
+                }
             }
             if (tr && s >= 3 && s < 7) {
                 const int j = s - 3;
@@ -367,7 +398,7 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     const int ch0 = h0, cw0 = w0, cb = b;
     float* Ys = Vs;
     float* Wi = Us + WN_UCHUNK;
-    {
+    if constexpr (TAIL) {
         const char* src = reinterpret_cast<const char*>(a.packed + (long long)nchunks * WN_UCHUNK + wave * 512);
         __builtin_amdgcn_global_load_lds(WN_GLOBAL(src + uoff), WN_SHARED(Wi + wave * 512), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(WN_GLOBAL(src + 1024 + uoff), WN_SHARED(Wi + wave * 512 + 256), 16, 0, 0);
@@ -380,7 +411,9 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     // ---- output transform Y = A^T M A per lane, bias, ReLU -> Ys[cout][8 rows x 32 cols] ------------------------------
     {
         const int tby = l15 >> 3, tbx = l15 & 7;
-        const int prow = 4 * tby + py, pcol = 4 * tbx + px;
+        const int prow = DIL == 2 ? 4 * tby + py : 4 * tby + 2 * py, pcol = DIL == 2 ? 4 * tbx + px : 4 * tbx + 2 * px;
+        const int act = TAIL ? MRX_ACT_RELU : a.act;
+        const float neg = act == MRX_ACT_RELU ? 0.f : (act == MRX_ACT_LEAKY ? a.slope : 1.f);  // factor applied to negative values
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -395,15 +428,22 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
                 const float bc = a.b_conv ? a.b_conv[co] : 0.f;
                 float y00 = s0[0] + s0[1] + s0[2] + bc, y01 = s0[1] - s0[2] - s0[3] + bc;
                 float y10 = s1[0] + s1[1] + s1[2] + bc, y11 = s1[1] - s1[2] - s1[3] + bc;
-                y00 = y00 > 0.f ? y00 : 0.f;
-                y01 = y01 > 0.f ? y01 : 0.f;
-                y10 = y10 > 0.f ? y10 : 0.f;
-                y11 = y11 > 0.f ? y11 : 0.f;
+                if constexpr (TAIL) {
+                    y00 = y00 > 0.f ? y00 : 0.f;
+                    y01 = y01 > 0.f ? y01 : 0.f;
+                    y10 = y10 > 0.f ? y10 : 0.f;
+                    y11 = y11 > 0.f ? y11 : 0.f;
+                } else {
+                    y00 = y00 > 0.f ? y00 : y00 * neg;
+                    y01 = y01 > 0.f ? y01 : y01 * neg;
+                    y10 = y10 > 0.f ? y10 : y10 * neg;
+                    y11 = y11 > 0.f ? y11 : y11 * neg;
+                }
                 float* yo = Ys + co * 256 + prow * 32 + pcol;
                 yo[0] = y00;
-                yo[2] = y01;
-                yo[64] = y10;
-                yo[66] = y11;
+                yo[DIL] = y01;
+                yo[32 * DIL] = y10;
+                yo[33 * DIL] = y11;
             }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ih weights landed (and, long before they are needed, the next prologue)
@@ -417,6 +457,28 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     const int wch = lane >> 3, wpx = (lane & 7) * 4;
     const long long wbase = (long long)cb * WN_F * plane + (long long)oy * a.W + cw0 + wpx;
     const bool winside = oy < a.H && (cw0 + wpx) < a.W;
+    if constexpr (!TAIL) {
+        // plain convolution: wave = image row `wave` of the tile, Ys already holds [cout][row][32 columns]
+        const float* yr = Ys + wave * 32;
+        if (wide) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ch = i * 8 + wch;
+                const float4 v = *reinterpret_cast<const float4*>(yr + ch * 256 + wpx);
+                if (winside) *reinterpret_cast<float4*>(a.hnew + wbase + (long long)ch * plane) = v;
+            }
+        } else if (oy < a.H && cw0 + l31 < a.W) {
+            const long long obase = (long long)cb * WN_F * plane + (long long)oy * a.W + cw0 + l31;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int co = 2 * i + lhi;
+                a.hnew[obase + (long long)co * plane] = yr[co * 256 + l31];
+            }
+        }
+        WN_STAMP(4)
+        first = false;
+        continue;  // the barrier at the top of the next tile separates these reads of Ys from its new contents
+    }
     float4 hp4[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -521,6 +583,8 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
     a.Cin = Cin;
     a.H = H;
     a.W = W;
+    a.act = MRX_ACT_RELU;
+    a.slope = 0.f;
     a.tiles_x = mrx_cdiv(W, 32);
     a.ntiles = a.tiles_x * mrx_cdiv(H, 8);
     MRX_REQUIRE((long long)H * W < (1ll << 28), MRX_EUNSUP, "mrx_rim_layer_indrnn_wino: plane %d x %d too large", H, W);
@@ -596,4 +660,72 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
                 (ph[0] + ph[1] + ph[2] + ph[3]) / nb);
     }
     return MRX_OK;
+}
+
+// ---- plain 3x3 convolution into 64 channels on the same kernel (TAIL = false): dilation 1 or 2, zero or replicate padding,
+// bias + activation in the output transform.  `packed` = mrx_rim_layer_wino_pack(w, NULL, ...).
+extern "C" int mrx_conv3x3_wino_supported(int Cin, int Cout, int k, int dil) {
+    return Cout == WN_F && Cin >= 1 && k == 3 && (dil == 1 || dil == 2);
+}
+
+template <bool X4, int DIL, bool ZP>
+static int launch_conv_wino(const WinoArgs& a, hipStream_t st, unsigned nblk) {
+    constexpr size_t lds = sizeof(float) * WN_LDS_FLOATS;
+    static bool attr_done = false;  // once per instantiation: keeps launches legal under hipGraph capture
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer_wino<0, X4, DIL, false, ZP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_rim_layer_wino<0, X4, DIL, false, ZP>), dim3(nblk), dim3(WN_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+extern "C" int mrx_conv3x3_wino(const float* x, const float* packed, const float* bias, float* out, int B, int Cin, int Cout, int H,
+                                int W, int dil, int pad_mode, int act, float slope, void* stream) {
+    MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv3x3_wino: null pointer");
+    MRX_REQUIRE(B >= 0 && Cin >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv3x3_wino: bad dims");
+    MRX_REQUIRE(mrx_conv3x3_wino_supported(Cin, Cout, 3, dil), MRX_EUNSUP, "mrx_conv3x3_wino: Cout=%d dil=%d (64 and 1|2 only)", Cout, dil);
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv3x3_wino: pad mode %d", pad_mode);
+    MRX_REQUIRE(act == MRX_ACT_NONE || act == MRX_ACT_RELU || act == MRX_ACT_LEAKY, MRX_EINVAL, "mrx_conv3x3_wino: activation %d", act);
+    MRX_REQUIRE((long long)H * W < (1ll << 28), MRX_EUNSUP, "mrx_conv3x3_wino: plane %d x %d too large", H, W);
+    MRX_REQUIRE(out != x, MRX_EINVAL, "mrx_conv3x3_wino: out must not alias x");
+    if (B == 0) return MRX_OK;
+    WinoArgs a;
+    a.x = x;
+    a.packed = packed;
+    a.b_conv = bias;
+    a.b_ih = nullptr;
+    a.hh = nullptr;
+    a.hprev = nullptr;
+    a.hnew = out;
+    a.B = B;
+    a.Cin = Cin;
+    a.H = H;
+    a.W = W;
+    a.act = act;
+    a.slope = slope;
+    a.trace = nullptr;
+    a.tiles_x = mrx_cdiv(W, 32);
+    a.ntiles = a.tiles_x * mrx_cdiv(H, 8);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MRX_HIP(hipGetDevice(&dev));
+        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long nt_total = (long long)a.ntiles * a.B;
+    MRX_REQUIRE(nt_total < (1ll << 31), MRX_EUNSUP, "mrx_conv3x3_wino: %lld tiles", nt_total);
+    const unsigned nblk = (unsigned)(nt_total < n_cu ? nt_total : n_cu);
+    const bool x4 = (W & 3) == 0 && W >= 4 && ((uintptr_t)x & 15) == 0;
+    const bool zp = pad_mode == MRX_PAD_ZERO;
+    hipStream_t st = (hipStream_t)stream;
+    if (x4) {
+        if (dil == 2) return zp ? launch_conv_wino<true, 2, true>(a, st, nblk) : launch_conv_wino<true, 2, false>(a, st, nblk);
+        return zp ? launch_conv_wino<true, 1, true>(a, st, nblk) : launch_conv_wino<true, 1, false>(a, st, nblk);
+    }
+    if (dil == 2) return zp ? launch_conv_wino<false, 2, true>(a, st, nblk) : launch_conv_wino<false, 2, false>(a, st, nblk);
+    return zp ? launch_conv_wino<false, 1, true>(a, st, nblk) : launch_conv_wino<false, 1, false>(a, st, nblk);
 }

@@ -3,6 +3,8 @@
 Each wrapper validates shapes, allocates the output with torch (torch owns device memory), and launches the HIP
 kernels on the current stream.  No arithmetic happens in Python/torch here.
 """
+import os
+
 import torch
 
 from mridc_amd import _lib
@@ -270,20 +272,85 @@ def _nchw(x):
     return [int(v) for v in x.shape]
 
 
+# Winograd form of 3x3 convolutions into 64 channels (mrx_conv3x3_wino): transformed weights per (storage, version), oldest out
+WINOGRAD_CONV = os.environ.get("MRIDC_AMD_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_CIN = 16          # below this the 8-channel chunks are mostly padding and the direct kernels win
+_WINO_PACKS = {}
+
+
+def _wino_conv_pack(weight):
+    """Transformed + packed weights of `weight`, cached per (storage address, version).  The entry keeps a reference to the tensor
+    it was made from, so the address cannot be recycled for other weights while the entry lives."""
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()))
+    hit = _WINO_PACKS.get(key)
+    if hit is None:
+        if len(_WINO_PACKS) >= 128:
+            _WINO_PACKS.pop(next(iter(_WINO_PACKS)))
+        w = _lib.f32c(weight.detach())
+        F, Cin = int(w.shape[0]), int(w.shape[1])
+        packed = torch.empty(int(_lib.lib().mrx_rim_layer_wino_pack_floats(Cin, F)), dtype=torch.float32, device=w.device)
+        _lib.check(_lib.lib().mrx_rim_layer_wino_pack(_lib.ptr(w), None, _lib.ptr(packed), Cin, F, _lib.stream_ptr()),
+                   "mrx_rim_layer_wino_pack")
+        hit = _WINO_PACKS[key] = (packed, weight)
+    return hit[0]
+
+
+def conv3x3_wino_supported(Cin, Cout, k, dilation):
+    return bool(_lib.lib().mrx_conv3x3_wino_supported(int(Cin), int(Cout), int(k), int(dilation)))
+
+
+def conv3x3_wino(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
+    """3x3 convolution into 64 channels as Winograd F(2x2,3x3) on the matrix cores (differs from the direct form by fp32
+    round-off, ~2e-7 of the output norm)."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    Cout = int(weight.shape[0])
+    packed = _wino_conv_pack(weight)
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    if out is None:
+        out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_conv3x3_wino(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W, int(dilation),
+                                           int(pad_mode), int(act), float(slope), _lib.stream_ptr()), "mrx_conv3x3_wino")
+    return out
+
+
 def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
-    """'same' conv, stride 1, square odd kernel (mrx_conv2d)."""
-    x, weight = _lib.f32c(x), _lib.f32c(weight.detach())
+    """'same' conv, stride 1, square odd kernel (mrx_conv2d; 3x3 into 64 channels: mrx_conv3x3_wino)."""
+    x = _lib.f32c(x)
+    _lib.require_gpu(weight)
     B, Cin, H, W = _nchw(x)
     Cout, Cin_w, kh, kw = [int(v) for v in weight.shape]
     if Cin_w != Cin:
         raise RuntimeError(f"input has inconsistent input_size: got {Cin}, expected {Cin_w}")
     if kh != kw:
         raise NotImplementedError("square kernels only")
+    if (WINOGRAD_CONV and kh == 3 and Cin >= WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
+            and conv3x3_wino_supported(Cin, Cout, kh, dilation) and (out is None or out.data_ptr() != x.data_ptr())):
+        return conv3x3_wino(x, weight, bias, dilation, pad_mode, act, slope, out)
+    weight = _lib.f32c(weight.detach())
     b = _lib.f32c(bias.detach()) if bias is not None else None
     if out is None:
         out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().mrx_conv2d(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W, kh,
                                      int(dilation), int(pad_mode), int(act), float(slope), _lib.stream_ptr()), "mrx_conv2d")
+    return out
+
+
+def conv_to_complex(x, weight, bias, dilation=1, pad_mode=PAD_ZERO):
+    """permute(conv(x), (0, 2, 3, 1)) for a convolution into 2 channels -> [B,H,W,2] (one complex image).  The tuned kernel covers
+    3x3, dilation 1, W % 4 == 0, Cin % 4 == 0; other shapes run conv2d and permute."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    Cout, Cin_w, kh, kw = [int(v) for v in weight.shape]
+    if Cout != 2 or Cin_w != Cin:
+        raise ValueError(f"conv_to_complex: weight {tuple(weight.shape)} for input {tuple(x.shape)}")
+    if not (kh == 3 and kw == 3 and int(dilation) == 1 and W % 4 == 0 and W >= 8 and Cin % 4 == 0 and x.data_ptr() % 16 == 0):
+        return conv2d(x, weight, bias, dilation, pad_mode).permute(0, 2, 3, 1).contiguous()
+    w = _lib.f32c(weight.detach())
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    out = torch.empty(B, H, W, 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_conv_to_complex(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), B, Cin, H, W, 3, 1, int(pad_mode),
+                                              _lib.stream_ptr()), "mrx_conv_to_complex")
     return out
 
 

@@ -298,3 +298,61 @@ def test_unet_pieces_vs_torch(dev):
                      f"conv transpose {(B_, Ci, Co, H_, W_)} (channel-group kernel for Cout % 14 == 0 or % 8 == 0)")
     y = torch.randn(2, 3, 17, 22, generator=g)
     assert_close(ops.concat_channels(x.to(dev), y.to(dev)), torch.cat([x, y], 1), 1e-12, "concat")
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 16, 32), (2, 16, 13, 37), (1, 24, 24, 72), (1, 20, 9, 8), (1, 64, 40, 372), (1, 32, 7, 100),
+                                   (1, 64, 64, 30)])
+@pytest.mark.parametrize("dil", [1, 2])
+@pytest.mark.parametrize("pad_mode", ["zero", "replicate"])
+def test_conv3x3_wino_vs_oracle(dev, shape, dil, pad_mode):
+    """Plain 3x3 convolution into 64 channels on the Winograd kernel: both dilations, zero / replicate padding, bias, the three
+    activations, widths with and without the 16-byte-aligned tile path, ragged tiles, channel counts off the 8-channel chunk."""
+    from mridc_amd import ops
+    B, Cin, H, W = shape
+    g = torch.Generator().manual_seed(100 * dil + H + W + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(64, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(64, generator=g)
+    xp = F.pad(x, (dil, dil, dil, dil), mode="constant" if pad_mode == "zero" else "replicate")
+    ref = F.conv2d(xp, w, b, dilation=dil)
+    pm = ops.PAD_ZERO if pad_mode == "zero" else ops.PAD_REPLICATE
+    assert ops.conv3x3_wino_supported(Cin, 64, 3, dil) and not ops.conv3x3_wino_supported(Cin, 48, 3, dil)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    assert_close(ops.conv3x3_wino(xd, wd, bd, dil, pm), ref, 1e-5, f"wino conv {shape} dil {dil} {pad_mode}")
+    assert_close(ops.conv3x3_wino(xd, wd, bd, dil, pm, ops.ACT_RELU), F.relu(ref), 1e-5, "relu")
+    assert_close(ops.conv3x3_wino(xd, wd, None, dil, pm, ops.ACT_LEAKY, 0.25), F.leaky_relu(ref - b.view(1, -1, 1, 1), 0.25), 1e-5,
+                 "leaky, no bias")
+    # ops.conv2d routes these shapes here (Cin >= 16) and agrees with the direct kernels
+    got = ops.conv2d(xd, wd, bd, dil, pm, ops.ACT_RELU)
+    assert_close(got, F.relu(ref), 1e-5, "conv2d dispatch")
+    old = ops.WINOGRAD_CONV
+    ops.WINOGRAD_CONV = False
+    try:
+        direct = ops.conv2d(xd, wd, bd, dil, pm, ops.ACT_RELU)
+    finally:
+        ops.WINOGRAD_CONV = old
+    assert_close(got, direct, 5e-6, "winograd vs direct kernel")
+    # a changed weight (new version, same storage) is re-packed
+    with torch.no_grad():
+        wd.mul_(0.5)
+    assert_close(ops.conv3x3_wino(xd, wd, bd, dil, pm), F.conv2d(xp, w * 0.5, b, dilation=dil), 1e-5, "re-pack after an in-place update")
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 16, 32), (2, 16, 13, 36), (1, 8, 9, 8), (1, 64, 40, 372), (1, 12, 5, 100), (1, 64, 8, 30)])
+@pytest.mark.parametrize("pad_mode", ["zero", "replicate"])
+def test_conv_to_complex_vs_oracle(dev, shape, pad_mode):
+    """3x3 convolution into one complex image written as [B,H,W,2] (the tail of the CascadeNet / VSNet / RVN regularisers) on the
+    RIM final-layer kernel: zero and replicate padding, every border case; W % 4 != 0 takes conv2d + permute."""
+    from mridc_amd import ops
+    B, Cin, H, W = shape
+    g = torch.Generator().manual_seed(7 + H + W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(2, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(2, generator=g)
+    xp = F.pad(x, (1, 1, 1, 1), mode="constant" if pad_mode == "zero" else "replicate")
+    pm = ops.PAD_ZERO if pad_mode == "zero" else ops.PAD_REPLICATE
+    for bias in (b, None):
+        ref = F.conv2d(xp, w, bias).permute(0, 2, 3, 1)
+        got = ops.conv_to_complex(x.to(dev), w.to(dev), None if bias is None else bias.to(dev), 1, pm)
+        assert got.is_contiguous()
+        assert_close(got, ref, 1e-5, f"conv_to_complex {shape} {pad_mode} bias={bias is not None}")
