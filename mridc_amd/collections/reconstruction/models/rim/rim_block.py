@@ -120,7 +120,10 @@ class RIMBlock(torch.nn.Module):
         if self._gated(stack):
             c, r = stack.convs, stack.rnn
             conv_pk, cell_pk, hh0, wino = self._packed_gated(idx, c, r)
-            if wino:
+            if self.winograd and c.kernel_size == 3 and ops.conv3x3_wino_supported(c.input_size, c.features, 3, c.dilation) \
+                    and c.input_size >= ops.WINOGRAD_MIN_CIN:
+                g = ops.conv3x3_wino(x, c.conv_layer.weight, c.conv_layer.bias, c.dilation, ops.PAD_REPLICATE, ops.ACT_RELU)
+            elif wino:
                 g = ops.rim_layer_indrnn_wino(x, conv_pk, c.features, c.conv_layer.bias, None, hh0, None)
             else:
                 g = ops.rim_layer_indrnn_packed(x, conv_pk, c.features, c.kernel_size, c.dilation, c.conv_layer.bias, None, hh0, None)
