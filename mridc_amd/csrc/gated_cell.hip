@@ -75,13 +75,15 @@ __device__ __forceinline__ float gc_tanh(float x) {
 
 template <int GATES>  // 3 = GRU, 2 = MGU
 __global__ __launch_bounds__(GC_NT, 2) void k_gated_cell(GatedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [2*GATES][2][32][2][32]
+    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [2*GATES][2][32][2][32], then the ih bias [GATES][64]
     constexpr int NMAT = 2 * GATES, MATF = GC_F * GC_F;
     const int tid = threadIdx.x;
+    float* Bs = Ws + NMAT * MATF;
     {
         const float4* src = reinterpret_cast<const float4*>(a.packed);
         float4* dst = reinterpret_cast<float4*>(Ws);
         for (int i = tid; i < NMAT * MATF / 4; i += GC_NT) dst[i] = src[i];
+        if (tid < GATES * GC_F) Bs[tid] = a.b_ih ? a.b_ih[tid] : 0.f;
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(GC_NT, 2) void k_gated_cell(GatedArgs a) {
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[d][ct][r] = (d < GATES && a.b_ih) ? a.b_ih[d * GC_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
+                    acc[d][ct][r] = d < GATES ? Bs[d * GC_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
 
         // ---- ih matrices over x ----------------------------------------------------------------------------------
         {
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(GC_NT, 2) void k_gated_cell(GatedArgs a) {
 
 template <int GATES>
 static int launch_gated(const GatedArgs& a, hipStream_t st) {
-    constexpr size_t lds = sizeof(float) * 2 * GATES * GC_F * GC_F;
+    constexpr size_t lds = sizeof(float) * (2 * GATES * GC_F * GC_F + GATES * GC_F);
     static bool attr_done = false;  // once per instantiation: keeps launches legal under hipGraph capture
     if (!attr_done) {
         MRX_HIP(hipFuncSetAttribute((const void*)k_gated_cell<GATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -294,13 +296,15 @@ __global__ void k_conv2dgru_pack(const float* __restrict__ wu, const float* __re
 }
 
 __global__ __launch_bounds__(GC_NT, 2) void k_conv2dgru_cell(Conv2dGruArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [6][2][32][2][32]
+    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [6][2][32][2][32], then the biases [3][64]
     constexpr int MATF = GC_F * GC_F;
     const int tid = threadIdx.x;
+    float* Bs = Ws + 6 * MATF;
     {
         const float4* src = reinterpret_cast<const float4*>(a.packed);
         float4* dst = reinterpret_cast<float4*>(Ws);
         for (int i = tid; i < 6 * MATF / 4; i += GC_NT) dst[i] = src[i];
+        if (tid < 3 * GC_F) Bs[tid] = a.bias ? a.bias[tid] : 0.f;
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(GC_NT, 2) void k_conv2dgru_cell(Conv2dGruArgs a) {
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[d][ct][r] = a.bias ? a.bias[d * GC_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
+                    acc[d][ct][r] = Bs[d * GC_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
         GC_GEMM(3, 0, xg[s], 0)
         if (hb) GC_GEMM(2, 3, hg[s], 0)
         float hv[2][16];
@@ -435,7 +439,7 @@ extern "C" int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const floa
     a.P = HW;
     a.nsegb = (HW + 31) / 32;
     a.nseg = a.nsegb * B;
-    constexpr size_t lds = sizeof(float) * 6 * GC_F * GC_F;
+    constexpr size_t lds = sizeof(float) * (6 * GC_F * GC_F + 3 * GC_F);
     static bool attr_done = false;
     if (!attr_done) {
         MRX_HIP(hipFuncSetAttribute((const void*)k_conv2dgru_cell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
