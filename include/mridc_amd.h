@@ -256,6 +256,23 @@ int mrx_mul_sigmoid(const float* h, const float* pre, float* out, int64_t n, voi
 int mrx_gru_blend(const float* h, const float* pre_update, const float* pre_out, float* out, float* out_relu, int64_t n,
                   void* stream);
 
+/* Training path: backward kernels of the convolutional regulariser.  The reference differentiates
+ * rim_block.py:217-249 through torch autograd (backward of Conv2d with ReplicationPad2d, ReLU, the IndRNN cell).
+ *   mrx_conv_wgrad     dw[Cout,Cin,k,k] (= or +=) sum_{b,pixel} dy[b,co,pixel] * pad(x)[b,ci,pixel + tap*dil]; Cout = 64 on the matrix
+ *                      cores, Cout <= 8 on the vector ALUs; work: mrx_conv_wgrad_work_floats floats; fixed-order reduction
+ *   mrx_reppad_fold    adjoint of ReplicationPad2d(pad): g [planes,H+2pad,W+2pad] -> out [planes,H,W].  The data gradient of a
+ *                      replicate-padded conv is mrx_conv2d (zero 'same' padding, flipped + transposed weights) of dy zero-extended by
+ *                      pad on every side, folded by this kernel
+ *   mrx_relu_bwd       dpre = dy * (y > 0); sums[c] = (sum dpre, sum dpre * h_prev); with h_prev also dh_prev = dpre * hh[c]
+ *                      (IndRNN cell, rnn_cells.py:384-391); work: mrx_relu_bwd_work_floats(C) floats */
+int64_t mrx_conv_wgrad_work_floats(int B, int Cin, int Cout, int H, int W, int k);
+int mrx_conv_wgrad(const float* x, const float* dy, float* dw, float* work, int B, int Cin, int Cout, int H, int W, int k,
+                   int dil, int pad_mode, int accumulate, void* stream);
+int mrx_reppad_fold(const float* g, float* out, int64_t planes, int H, int W, int pad, void* stream);
+int64_t mrx_relu_bwd_work_floats(int C);
+int mrx_relu_bwd(const float* dy, const float* y, const float* h_prev, const float* hh, float* dpre, float* dh_prev,
+                 float* sums, float* work, int B, int C, int64_t HW, void* stream);
+
 /* A17 NormUnet support (models/unet_base/unet_block.py).  Planes are [B*C] images of H*W floats.
  *   mrx_instance_norm_act   InstanceNorm2d (biased var, eps, no affine) + activation, in place allowed   (:252-253,:294-295)
  *   mrx_group_norm_stats    per-group mean and UNBIASED std over n contiguous floats                       (:78-79)

@@ -19,6 +19,7 @@ SOURCES = [
     ("rim_layer.hip", []),
     ("rim_layer_wino.hip", []),
     ("gated_cell.hip", []),
+    ("conv_bwd.hip", []),
     ("unet.hip", []),
     ("qmri.hip", ["-ffp-contract=off"]),
 ]

@@ -58,6 +58,11 @@ _SIGNATURES = {
     "mrx_conv3x3_wino_supported": ([_i, _i, _i, _i], _i),
     "mrx_conv3x3_wino": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_conv_to_complex": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_conv_wgrad_work_floats": ([_i, _i, _i, _i, _i, _i], _i64),
+    "mrx_conv_wgrad": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_reppad_fold": ([_p, _p, _i64, _i, _i, _i, _p], _i),
+    "mrx_relu_bwd_work_floats": ([_i], _i64),
+    "mrx_relu_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_hard_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_vs_average": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),

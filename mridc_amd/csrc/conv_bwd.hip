@@ -1,0 +1,359 @@
+// conv_bwd.hip -- backward kernels of the convolutional regulariser for the training path (the reference
+// trains through torch autograd -- cuDNN / MIOpen backward of Conv2d, ReLU and the IndRNN cell, rim_block.py:217-249).
+//
+//   mrx_conv_wgrad        dW[co][ci][tap] = sum over (b, pixel) of dy[b,co,pixel] * xpad[b,ci,pixel + tap*dil]    (weight gradient)
+//                         Cout = 64: fp32 matrix cores (v_mfma_f32_32x32x2_f32), one pass over dy and x;
+//                         other Cout: a reduction kernel on the vector ALUs (final RIM layer: Cout = 2).
+//   mrx_reppad_fold       adjoint of replicate padding: gradient on the padded domain [H+2p, W+2p] -> [H, W]
+//                         (the data gradient itself is a zero-padded 'same' convolution of the zero-extended dy with the flipped,
+//                         transposed weights -- the forward kernels, incl. the Winograd one)
+//   mrx_relu_bwd          dpre = dy * (y > 0), per-channel sums of dpre (bias gradient) and, for the IndRNN cell, dpre * hh -> dh_prev
+//                         and per-channel sums of dpre * h_prev (gradient of hh)
+// All reductions are two-stage with a fixed order (per-workgroup partials, then one workgroup per output), so gradients do not
+// depend on scheduling.
+#include <cstdint>
+#include <cstdlib>
+
+#include "mrx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- weight gradient, Cout = 64, matrix cores --------------------------------------------------------------------------------
+// GEMM view: D[co][n] += A[co][pixel] * B[pixel][n], n = ci * taps + tap (the natural [co][ci][ky][kx] order of the weights).
+// Workgroup: 512 threads, a 4 x 32 pixel tile per step of a persistent loop.  LDS: the dy tile [64][128 (+1)] and the halo'd x tile
+// [Cin][4 + 2 pad][32 + 2 pad (+pad to odd)].  Wave w owns the 32-column blocks w, w + 8, ... of n and both halves of co; one MFMA
+// takes two pixels: A = dy (lane = channel, lane half = pixel parity), B = x gathered at the lane's (ci, tap) offset.
+#define WG_NT 512
+#define WG_TH 4
+#define WG_TW 32
+#define WG_PX (WG_TH * WG_TW)
+#define WG_DYS (WG_PX + 1)
+#define WG_MAXNB 3  // 32-column blocks per wave: N <= 8 * 3 * 32 = 768 (64 channels x 9 taps = 576)
+
+struct WgradArgs {
+    const float* x;   // [B,Cin,H,W]
+    const float* dy;  // [B,64,H,W]
+    float* part;      // [gridDim.x][64][N]
+    int B, Cin, H, W, k, dil, pad, pad_mode, N, tiles_x, ntiles, XS, PH;
+};
+
+__global__ __launch_bounds__(WG_NT, 2) void k_conv_wgrad64(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Dy = smem_f;                 // [64][WG_DYS]
+    float* Xs = smem_f + 64 * WG_DYS;   // [Cin][PH][XS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int taps = a.k * a.k, PLANE = a.PH * a.XS;
+    const int nblocks = (a.N + 31) / 32;
+    // per-lane gather base of every n-block of this wave: (ci, tap) -> ci * PLANE + ky * dil * XS + kx * dil, plus the pixel parity
+    int bbase[WG_MAXNB];
+#pragma unroll
+    for (int j = 0; j < WG_MAXNB; ++j) {
+        int n = (wave + 8 * j) * 32 + l31;
+        n = n < a.N ? n : a.N - 1;  // columns past N are computed on a valid address and never stored
+        const int ci = n / taps, tap = n - ci * taps, ky = tap / a.k, kx = tap - ky * a.k;
+        bbase[j] = ci * PLANE + ky * a.dil * a.XS + kx * a.dil + lhi;
+    }
+    f32x16 acc[WG_MAXNB][2];
+#pragma unroll
+    for (int j = 0; j < WG_MAXNB; ++j)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][ct][r] = 0.f;
+    const long long plane = (long long)a.H * a.W;
+    const long long nt_total = (long long)a.ntiles * a.B;
+    for (long long v = blockIdx.x; v < nt_total; v += gridDim.x) {
+        const int b = (int)(v / a.ntiles), t = (int)(v - (long long)b * a.ntiles);
+        const int ty0 = t / a.tiles_x, h0 = ty0 * WG_TH, w0 = (t - ty0 * a.tiles_x) * WG_TW;
+        __syncthreads();  // the previous tile's operands are consumed
+        // dy tile: zeros outside the image (ragged tiles contribute nothing)
+        const float* dyb = a.dy + (long long)b * 64 * plane;
+        for (int i = tid; i < 64 * WG_PX; i += WG_NT) {
+            const int co = i / WG_PX, px = i - co * WG_PX, r = px >> 5, c = px & 31;
+            const int gy = h0 + r, gx = w0 + c;
+            Dy[co * WG_DYS + px] = (gy < a.H && gx < a.W) ? dyb[(long long)co * plane + (long long)gy * a.W + gx] : 0.f;
+        }
+        // x tile with its halo: replicate (clamped) or zero border
+        const float* xb = a.x + (long long)b * a.Cin * plane;
+        const int PW = WG_TW + 2 * a.pad;
+        for (int i = tid; i < a.Cin * a.PH * PW; i += WG_NT) {
+            const int ci = i / (a.PH * PW), rem = i - ci * (a.PH * PW), r = rem / PW, c = rem - r * PW;
+            int gy = h0 + r - a.pad, gx = w0 + c - a.pad;
+            float vv = 0.f;
+            if (a.pad_mode == MRX_PAD_REPLICATE) {
+                gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                vv = xb[(long long)ci * plane + (long long)gy * a.W + gx];
+            } else if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                vv = xb[(long long)ci * plane + (long long)gy * a.W + gx];
+            }
+            Xs[ci * PLANE + r * a.XS + c] = vv;
+        }
+        __syncthreads();
+        const float* ap0 = Dy + l31 * WG_DYS + lhi;
+        const float* ap1 = Dy + (32 + l31) * WG_DYS + lhi;
+#pragma unroll
+        for (int j = 0; j < WG_MAXNB; ++j) {
+            if (wave + 8 * j >= nblocks) break;  // wave-uniform
+            const float* bp = Xs + bbase[j];
+#pragma unroll 8
+            for (int s = 0; s < WG_PX / 2; ++s) {  // pixels 2s, 2s+1: row s >> 4, columns 2 (s & 15) + parity
+                const float a0 = ap0[2 * s], a1 = ap1[2 * s];
+                const float bv = bp[(s >> 4) * a.XS + 2 * (s & 15)];
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[j][1], 0, 0, 0);
+            }
+        }
+    }
+    float* pb = a.part + (long long)blockIdx.x * 64 * a.N;
+#pragma unroll
+    for (int j = 0; j < WG_MAXNB; ++j) {
+        if (wave + 8 * j >= nblocks) break;
+        const int n = (wave + 8 * j) * 32 + l31;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (n < a.N) pb[(long long)co * a.N + n] = acc[j][ct][r];
+            }
+    }
+}
+
+// dW[i] (= or +=) sum over the workgroup partials, in order, in double
+__global__ void k_wgrad_reduce(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int p = 0; p < nparts; ++p) s += (double)part[(long long)p * n + i];
+        dw[i] = accumulate ? dw[i] + (float)s : (float)s;
+    }
+}
+
+// ---- weight gradient, any Cout (small ones in practice): one workgroup per (ci, tap) and slab of rows, all Cout at once -----------
+#define WS_NT 256
+#define WS_MAXCO 8
+struct WsmallArgs {
+    const float* x;
+    const float* dy;
+    float* part;  // [nslab][Cout][Cin*taps]
+    int B, Cin, Cout, H, W, k, dil, pad, pad_mode, rows_per_slab;
+};
+__global__ __launch_bounds__(WS_NT) void k_conv_wgrad_small(WsmallArgs a) {
+    const int taps = a.k * a.k, n = blockIdx.x, ci = n / taps, tap = n - ci * taps, ky = tap / a.k, kx = tap - ky * a.k;
+    const int slab = blockIdx.y, r0 = slab * a.rows_per_slab;
+    const int r1 = r0 + a.rows_per_slab < a.B * a.H ? r0 + a.rows_per_slab : a.B * a.H;  // rows enumerate (b, h)
+    const long long plane = (long long)a.H * a.W;
+    float acc[WS_MAXCO];
+#pragma unroll
+    for (int o = 0; o < WS_MAXCO; ++o) acc[o] = 0.f;
+    for (int row = r0; row < r1; ++row) {
+        const int b = row / a.H, h = row - b * a.H;
+        int gy = h + ky * a.dil - a.pad;
+        bool rok = gy >= 0 && gy < a.H;
+        if (a.pad_mode == MRX_PAD_REPLICATE) {
+            gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+            rok = true;
+        }
+        if (!rok) continue;
+        const float* xr = a.x + ((long long)b * a.Cin + ci) * plane + (long long)gy * a.W;
+        const float* dr = a.dy + (long long)b * a.Cout * plane + (long long)h * a.W;
+        for (int w = threadIdx.x; w < a.W; w += WS_NT) {
+            int gx = w + kx * a.dil - a.pad;
+            float xv;
+            if (a.pad_mode == MRX_PAD_REPLICATE) {
+                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                xv = xr[gx];
+            } else {
+                xv = (gx >= 0 && gx < a.W) ? xr[gx] : 0.f;
+            }
+#pragma unroll
+            for (int o = 0; o < WS_MAXCO; ++o)
+                if (o < a.Cout) acc[o] += dr[(long long)o * plane + w] * xv;
+        }
+    }
+    __shared__ float sh[WS_NT];
+    for (int o = 0; o < a.Cout && o < WS_MAXCO; ++o) {
+        sh[threadIdx.x] = acc[o];
+        __syncthreads();
+        for (int st = WS_NT / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.part[((long long)slab * a.Cout + o) * (a.Cin * taps) + n] = sh[0];
+        __syncthreads();
+    }
+}
+
+static int wgrad_nparts64(int n_cu, long long nt_total) { return (int)(nt_total < n_cu ? nt_total : n_cu); }
+static int g_n_cu = 0;
+static int query_cus() {
+    if (!g_n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_n_cu;
+}
+#define WS_SLABS 64
+
+extern "C" int64_t mrx_conv_wgrad_work_floats(int B, int Cin, int Cout, int H, int W, int k) {
+    const long long n = (long long)Cout * Cin * k * k;
+    if (Cout == 64 && (long long)Cin * k * k <= 8 * WG_MAXNB * 32) return (int64_t)1024 * n;  // upper bound on the workgroup count
+    return (int64_t)WS_SLABS * n;
+}
+
+extern "C" int mrx_conv_wgrad(const float* x, const float* dy, float* dw, float* work, int B, int Cin, int Cout, int H, int W, int k,
+                              int dil, int pad_mode, int accumulate, void* stream) {
+    MRX_REQUIRE(x && dy && dw && work, MRX_EINVAL, "mrx_conv_wgrad: null pointer");
+    MRX_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && k >= 1 && (k & 1) && dil >= 1, MRX_EINVAL, "mrx_conv_wgrad: bad dims");
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv_wgrad: pad mode %d", pad_mode);
+    hipStream_t st = (hipStream_t)stream;
+    const int pad = dil * (k - 1) / 2;
+    const long long N = (long long)Cin * k * k, total = (long long)Cout * N;
+    int nparts;
+    if (Cout == 64 && N <= 8 * WG_MAXNB * 32) {
+        WgradArgs a;
+        a.x = x;
+        a.dy = dy;
+        a.part = work;
+        a.B = B;
+        a.Cin = Cin;
+        a.H = H;
+        a.W = W;
+        a.k = k;
+        a.dil = dil;
+        a.pad = pad;
+        a.pad_mode = pad_mode;
+        a.N = (int)N;
+        a.tiles_x = mrx_cdiv(W, WG_TW);
+        a.ntiles = a.tiles_x * mrx_cdiv(H, WG_TH);
+        a.PH = WG_TH + 2 * pad;
+        a.XS = (WG_TW + 2 * pad) | 1;  // odd row stride
+        const size_t lds = sizeof(float) * ((size_t)64 * WG_DYS + (size_t)Cin * a.PH * a.XS);
+        MRX_REQUIRE(lds <= 160 * 1024, MRX_EUNSUP, "mrx_conv_wgrad: %zu bytes of LDS (Cin=%d k=%d dil=%d)", lds, Cin, k, dil);
+        static size_t attr_bytes = 0;
+        if (lds > 48 * 1024 && attr_bytes < lds) {
+            MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_bytes = lds;
+        }
+        nparts = wgrad_nparts64(query_cus() < 1024 ? query_cus() : 1024, (long long)a.ntiles * B);
+        hipLaunchKernelGGL(k_conv_wgrad64, dim3(nparts), dim3(WG_NT), lds, st, a);
+    } else {
+        MRX_REQUIRE(Cout <= WS_MAXCO, MRX_EUNSUP, "mrx_conv_wgrad: Cout=%d (64 or <= %d)", Cout, WS_MAXCO);
+        WsmallArgs a;
+        a.x = x;
+        a.dy = dy;
+        a.part = work;
+        a.B = B;
+        a.Cin = Cin;
+        a.Cout = Cout;
+        a.H = H;
+        a.W = W;
+        a.k = k;
+        a.dil = dil;
+        a.pad = pad;
+        a.pad_mode = pad_mode;
+        const int rows = B * H;
+        a.rows_per_slab = (rows + WS_SLABS - 1) / WS_SLABS;
+        nparts = (rows + a.rows_per_slab - 1) / a.rows_per_slab;
+        hipLaunchKernelGGL(k_conv_wgrad_small, dim3((unsigned)N, nparts), dim3(WS_NT), 0, st, a);
+    }
+    MRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)work, nparts, total, dw,
+                       accumulate);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- adjoint of replicate padding ---------------------------------------------------------------------------------------------
+// out[p][h][w] = sum of g[p][i][j] over the padded positions (i, j) that clamp to (h, w); planes = B*C.
+__global__ void k_reppad_fold(const float* __restrict__ g, float* __restrict__ out, long long planes, int H, int W, int pad) {
+    const long long total = planes * H * W;
+    const int PW = W + 2 * pad, PH = H + 2 * pad;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long p = o / ((long long)H * W);
+        const int rem = (int)(o - p * (long long)H * W), h = rem / W, w = rem - h * W;
+        const int i0 = h == 0 ? 0 : h + pad, i1 = h == H - 1 ? PH - 1 : h + pad;
+        const int j0 = w == 0 ? 0 : w + pad, j1 = w == W - 1 ? PW - 1 : w + pad;
+        const float* gp = g + p * (long long)PH * PW;
+        float s = 0.f;
+        for (int i = i0; i <= i1; ++i)
+            for (int j = j0; j <= j1; ++j) s += gp[(long long)i * PW + j];
+        out[o] = s;
+    }
+}
+extern "C" int mrx_reppad_fold(const float* g, float* out, int64_t planes, int H, int W, int pad, void* stream) {
+    MRX_REQUIRE(g && out && planes >= 0 && H >= 1 && W >= 1 && pad >= 0, MRX_EINVAL, "mrx_reppad_fold: bad argument");
+    const long long total = planes * H * W;
+    if (total == 0) return MRX_OK;
+    const long long nb = (total + 255) / 256;
+    hipLaunchKernelGGL(k_reppad_fold, dim3((unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, (hipStream_t)stream, g, out, (long long)planes,
+                       H, W, pad);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- ReLU backward (+ IndRNN cell pieces) with per-channel sums ------------------------------------------------------------------
+// dpre = dy * (y > 0).  sums[c][0] = sum dpre; with h_prev: dh_prev = dpre * hh[c] and sums[c][1] = sum dpre * h_prev.
+// One workgroup per (channel, slab); partials work[(c*RB_SLABS + slab)*2 + {0,1}], combined in order in double.
+#define RB_NT 256
+#define RB_SLABS 32
+__global__ __launch_bounds__(RB_NT) void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ hprev,
+                                                    const float* __restrict__ hh, float* __restrict__ dpre, float* __restrict__ dhprev,
+                                                    float* __restrict__ work, int B, int C, long long HW) {
+    const int c = blockIdx.x, slab = blockIdx.y;
+    const long long per = (HW + RB_SLABS - 1) / RB_SLABS, p0 = slab * per, p1 = p0 + per < HW ? p0 + per : HW;
+    const float hw = hh ? hh[c] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const long long base = ((long long)b * C + c) * HW;
+        for (long long p = p0 + threadIdx.x; p < p1; p += RB_NT) {
+            const float d = y[base + p] > 0.f ? dy[base + p] : 0.f;
+            dpre[base + p] = d;
+            s0 += d;
+            if (hprev) {
+                s1 += d * hprev[base + p];
+                dhprev[base + p] = d * hw;
+            }
+        }
+    }
+    __shared__ float sh0[RB_NT], sh1[RB_NT];
+    sh0[threadIdx.x] = s0;
+    sh1[threadIdx.x] = s1;
+    __syncthreads();
+    for (int st = RB_NT / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            sh0[threadIdx.x] += sh0[threadIdx.x + st];
+            sh1[threadIdx.x] += sh1[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        work[((long long)c * RB_SLABS + slab) * 2] = sh0[0];
+        work[((long long)c * RB_SLABS + slab) * 2 + 1] = sh1[0];
+    }
+}
+__global__ void k_relu_bwd_final(const float* __restrict__ work, float* __restrict__ sums, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < RB_SLABS; ++s) {
+        a += (double)work[((long long)c * RB_SLABS + s) * 2];
+        b += (double)work[((long long)c * RB_SLABS + s) * 2 + 1];
+    }
+    sums[2 * c] = (float)a;
+    sums[2 * c + 1] = (float)b;
+}
+extern "C" int64_t mrx_relu_bwd_work_floats(int C) { return (int64_t)2 * RB_SLABS * (C > 0 ? C : 1); }
+extern "C" int mrx_relu_bwd(const float* dy, const float* y, const float* h_prev, const float* hh, float* dpre, float* dh_prev,
+                            float* sums, float* work, int B, int C, int64_t HW, void* stream) {
+    MRX_REQUIRE(dy && y && dpre && sums && work && B >= 1 && C >= 1 && C <= 65535 && HW >= 1, MRX_EINVAL, "mrx_relu_bwd: bad argument");
+    MRX_REQUIRE(!h_prev || (hh && dh_prev), MRX_EINVAL, "mrx_relu_bwd: h_prev needs hh and dh_prev");
+    hipLaunchKernelGGL(k_relu_bwd, dim3(C, RB_SLABS), dim3(RB_NT), 0, (hipStream_t)stream, dy, y, h_prev, hh, dpre, dh_prev, work, B, C,
+                       (long long)HW);
+    hipLaunchKernelGGL(k_relu_bwd_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)work, sums, C);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

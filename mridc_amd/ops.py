@@ -454,6 +454,58 @@ def rim_layer_indrnn_wino(x, packed, F, b_conv, b_ih, hh, h_prev, out=None):
     return out
 
 
+# ---- training path: backward pieces of the convolutional regulariser ---------------------------------------------------------
+def conv_wgrad(x, dy, k, dilation=1, pad_mode=PAD_REPLICATE, out=None, accumulate=False):
+    """Weight gradient of a 'same' convolution: dw[Cout,Cin,k,k] = sum_{b,pixel} dy * pad(x) (mrx_conv_wgrad)."""
+    x, dy = _lib.f32c(x), _lib.f32c(dy)
+    B, Cin, H, W = _nchw(x)
+    Cout = int(dy.shape[1])
+    if tuple(dy.shape) != (B, Cout, H, W):
+        raise ValueError(f"conv_wgrad: dy {tuple(dy.shape)} vs x {tuple(x.shape)}")
+    if out is None:
+        out = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device=x.device)
+        accumulate = False
+    L = _lib.lib()
+    work = torch.empty(int(L.mrx_conv_wgrad_work_floats(B, Cin, Cout, H, W, int(k))), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_conv_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(out), _lib.ptr(work), B, Cin, Cout, H, W, int(k), int(dilation),
+                                int(pad_mode), int(bool(accumulate)), _lib.stream_ptr()), "mrx_conv_wgrad")
+    return out
+
+
+def conv_dgrad(dy, weight, dilation=1, pad_mode=PAD_REPLICATE):
+    """Data gradient of y = conv(pad(x), weight): a zero-padded 'same' convolution of dy with the flipped, transposed weights; for
+    replicate padding on the domain extended by the padding, folded back onto the image (mrx_reppad_fold)."""
+    dy = _lib.f32c(dy)
+    B, Cout, H, W = _nchw(dy)
+    k = int(weight.shape[-1])
+    pad = int(dilation) * (k - 1) // 2
+    wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()          # [Cin,Cout,k,k] (parameter-sized host-side prep)
+    if pad_mode == PAD_ZERO or pad == 0:
+        return conv2d(dy, wt, None, dilation, PAD_ZERO)
+    big = pad2d(dy, pad, pad, pad, pad, 0)                                # dy zero-extended to [H+2p, W+2p]
+    g = conv2d(big, wt, None, dilation, PAD_ZERO)
+    Cin = int(wt.shape[0])
+    out = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().mrx_reppad_fold(_lib.ptr(g), _lib.ptr(out), B * Cin, H, W, pad, _lib.stream_ptr()), "mrx_reppad_fold")
+    return out
+
+
+def relu_bwd(dy, y, h_prev=None, hh=None):
+    """dpre = dy * (y > 0) and the per-channel sums [C,2] = (sum dpre, sum dpre * h_prev); with h_prev also dh_prev = dpre * hh."""
+    dy, y = _lib.f32c(dy), _lib.f32c(y)
+    B, C, H, W = _nchw(y)
+    hp = None if h_prev is None else _lib.f32c(h_prev)
+    hhc = None if hh is None else _lib.f32c(hh.detach().reshape(-1))
+    dpre = torch.empty_like(y)
+    dhp = torch.empty_like(y) if hp is not None else None
+    sums = torch.empty(C, 2, dtype=torch.float32, device=y.device)
+    L = _lib.lib()
+    work = torch.empty(int(L.mrx_relu_bwd_work_floats(C)), dtype=torch.float32, device=y.device)
+    _lib.check(L.mrx_relu_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(hp), _lib.ptr(hhc), _lib.ptr(dpre), _lib.ptr(dhp), _lib.ptr(sums),
+                              _lib.ptr(work), B, C, H * W, _lib.stream_ptr()), "mrx_relu_bwd")
+    return dpre, dhp, sums
+
+
 class FusedConvReLU:
     """ReLU(conv_reppad(x)) into 64 features through the fused RIM layer kernels with an identity `ih` (ReLU(I g + 0 h) = g
     exactly): the Winograd kernel for 3x3 dilation 2, the direct tuned kernel for the other tuned shapes.  Holds the packed
