@@ -273,6 +273,18 @@ int64_t mrx_relu_bwd_work_floats(int C);
 int mrx_relu_bwd(const float* dy, const float* y, const float* h_prev, const float* hh, float* dpre, float* dh_prev,
                  float* sums, float* work, int B, int C, int64_t HW, void* stream);
 
+/*   mrx_absl1_loss      the l1 training loss of one prediction (cirim.py:218-237): out2[0] = mean |target - |p| / max|p||, out2[1] = an
+ *                      intermediate the backward needs; p complex [n], target real [n], maxabs = device scalar from mrx_max_abs (mode 1);
+ *                      work: mrx_absl1_work_floats floats.  mrx_absl1_loss_bwd: dp = gout * gscale * d(loss)/dp incl. the path through the max
+ *   mrx_adam_step      torch.optim.Adam (weight_decay 0, amsgrad off) on flat buffers; `step` counts from 1; grad_scale multiplies the
+ *                      gradient first (1 / world size after the all-reduce(sum) of data-parallel training) */
+int64_t mrx_absl1_work_floats(void);
+int mrx_absl1_loss(const float* p, const float* target, const float* maxabs, float* out2, float* work, int64_t n, void* stream);
+int mrx_absl1_loss_bwd(const float* p, const float* target, const float* maxabs, const float* fwd_out2, const float* gout,
+                       float gscale, float* dp, int64_t n, void* stream); /* gout: device scalar (upstream gradient) or NULL = 1 */
+int mrx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float grad_scale, void* stream);
+
 /* A17 NormUnet support (models/unet_base/unet_block.py).  Planes are [B*C] images of H*W floats.
  *   mrx_instance_norm_act   InstanceNorm2d (biased var, eps, no affine) + activation, in place allowed   (:252-253,:294-295)
  *   mrx_group_norm_stats    per-group mean and UNBIASED std over n contiguous floats                       (:78-79)

@@ -63,6 +63,10 @@ _SIGNATURES = {
     "mrx_reppad_fold": ([_p, _p, _i64, _i, _i, _i, _p], _i),
     "mrx_relu_bwd_work_floats": ([_i], _i64),
     "mrx_relu_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
+    "mrx_absl1_work_floats": ([], _i64),
+    "mrx_absl1_loss": ([_p, _p, _p, _p, _p, _i64, _p], _i),
+    "mrx_absl1_loss_bwd": ([_p, _p, _p, _p, _p, _f, _p, _i64, _p], _i),
+    "mrx_adam_step": ([_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _f, _p], _i),
     "mrx_hard_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_vs_average": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),

@@ -141,6 +141,30 @@ class RIMBlock(torch.nn.Module):
                                         r.ih.weight, r.ih.bias, r.hh, h)
         return stack(x, h)
 
+    def _forward_train(self, pred, masked_kspace, sense, mask, eta, hx, sigma):
+        """The same cascade with every step recorded for the backward pass (mridc_amd/autograd.py): conv + ReLU and the IndRNN
+        cell as two launches each (their outputs are the activations the backward kernels need), gradients through the
+        log-likelihood gradient by its own kernel.  no_dc cascades with 1x1 IndRNN cells (the CIRIM training config)."""
+        from mridc_amd import autograd as ag
+        if not self.no_dc:
+            raise NotImplementedError("mridc_amd training path: no_dc=True cascades only (base_cirim_train.yaml)")
+        final = self.final_layer[0]
+        hinv = ops.mask_is_row_invariant(mask) and self.coil_dim == 1
+        data = ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization, self.spatial_dims) if hinv else masked_kspace
+        etas = []
+        for _ in range(self.time_steps):
+            g = ag.LogLikelihoodGradient.apply(eta, data, sense, mask, sigma, self.fft_centered, self.fft_normalization, hinv)
+            for li, stack in enumerate(self.layers):
+                c, r = stack.convs, stack.rnn
+                if not (isinstance(r, rnn_cells.IndRNNCell) and r.kernel_size == 1 and c is not None and c.act == ops.ACT_RELU):
+                    raise NotImplementedError("mridc_amd training path: ConvNonlinear(ReLU) + IndRNNCell(1x1) layers only")
+                a = ag.ConvReLU.apply(g, c.conv_layer.weight, c.conv_layer.bias, c.dilation)
+                hx[li] = ag.IndRNN1x1.apply(a, r.ih.weight, r.ih.bias, r.hh, hx[li])
+                g = hx[li]
+            eta = ag.RimFinal.apply(g, final.conv_layer.weight, final.conv_layer.bias, final.dilation, eta)
+            etas.append(eta)
+        return etas, hx
+
     def forward(self, pred: torch.Tensor, masked_kspace: torch.Tensor, sense: torch.Tensor, mask: torch.Tensor,
                 eta: torch.Tensor = None, hx: torch.Tensor = None, sigma: float = 1.0, keep_eta: bool = False,
                 _hybrid: torch.Tensor = None) -> Tuple[Any, Union[list, torch.Tensor, None]]:
@@ -155,6 +179,9 @@ class RIMBlock(torch.nn.Module):
             eta = pred if keep_eta else ops.sens_reduce(pred, sense, self.fft_centered, self.fft_normalization,
                                                         self.spatial_dims)
         final = self.final_layer[0]
+        train = self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if train:
+            return self._forward_train(pred, masked_kspace, sense, mask, eta, hx, sigma)
         # 1-D column masks: the H transforms of log_likelihood_gradient cancel (csrc/fft.hip: k_llg_rows_hinv) -- one
         # launch per step on yt = IFFT_H(y); any other mask takes the general three-launch path
         hinv = ops.mask_is_row_invariant(mask) and self.coil_dim == 1

@@ -357,3 +357,106 @@ extern "C" int mrx_relu_bwd(const float* dy, const float* y, const float* h_prev
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
+
+// ---- training loss of the CIRIM (cirim.py:199-247, l1): L = mean | target - |p| / max|p| | over one complex image ---------------
+// forward:  parts[0] = sum |target - |p|/M|, parts[1] = sum sign(|p|/M - target) * |p|   (M = max |p|, a device scalar from mrx_max_abs)
+// backward: dp = gscale/n * sign * (1/M) * p/|p|, and the element(s) with |p| = M also receive -(gscale/n) * parts[1] / M^2 * p/|p|
+//           (the gradient of the max), exactly what torch autograd produces for abs(t / max(abs(t))).
+#define LS_NT 256
+#define LS_BLOCKS 128
+__global__ __launch_bounds__(LS_NT) void k_absl1_partial(const float2* __restrict__ p, const float* __restrict__ target,
+                                                         const float* __restrict__ M, float* __restrict__ work, long long n) {
+    const float inv = 1.0f / M[0];
+    float s0 = 0.f, s1 = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = p[i];
+        const float a = sqrtf(v.x * v.x + v.y * v.y), d = a * inv - target[i];
+        s0 += fabsf(d);
+        s1 += (d > 0.f ? a : (d < 0.f ? -a : 0.f));
+    }
+    __shared__ float sh0[LS_NT], sh1[LS_NT];
+    sh0[threadIdx.x] = s0;
+    sh1[threadIdx.x] = s1;
+    __syncthreads();
+    for (int st = LS_NT / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            sh0[threadIdx.x] += sh0[threadIdx.x + st];
+            sh1[threadIdx.x] += sh1[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        work[2 * blockIdx.x] = sh0[0];
+        work[2 * blockIdx.x + 1] = sh1[0];
+    }
+}
+__global__ void k_absl1_final(const float* __restrict__ work, int nb, long long n, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nb; ++k) {
+            a += (double)work[2 * k];
+            b += (double)work[2 * k + 1];
+        }
+        out[0] = (float)(a / (double)n);  // the loss
+        out[1] = (float)b;                // sum sign * |p|
+    }
+}
+__global__ void k_absl1_bwd(const float2* __restrict__ p, const float* __restrict__ target, const float* __restrict__ M,
+                            const float* __restrict__ fw, const float* __restrict__ gout, float gscale, float2* __restrict__ dp,
+                            long long n) {
+    const float m = M[0], inv = 1.0f / m, g = (gout ? gout[0] : 1.0f) * gscale / (float)n;
+    const float corr = g * fw[1] * inv * inv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = p[i];
+        const float a = sqrtf(v.x * v.x + v.y * v.y), d = a * inv - target[i];
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        float c = g * sg * inv;
+        if (a == m) c -= corr;
+        const float ia = a > 0.f ? 1.0f / a : 0.f;
+        dp[i] = make_float2(c * v.x * ia, c * v.y * ia);
+    }
+}
+extern "C" int64_t mrx_absl1_work_floats(void) { return 2 * LS_BLOCKS; }
+extern "C" int mrx_absl1_loss(const float* p, const float* target, const float* maxabs, float* out2, float* work, int64_t n,
+                              void* stream) {
+    MRX_REQUIRE(p && target && maxabs && out2 && work && n >= 1, MRX_EINVAL, "mrx_absl1_loss: bad argument");
+    const long long nbl = (n + LS_NT - 1) / LS_NT;
+    const int nb = (int)(nbl < LS_BLOCKS ? nbl : LS_BLOCKS);
+    hipLaunchKernelGGL(k_absl1_partial, dim3(nb), dim3(LS_NT), 0, (hipStream_t)stream, (const float2*)p, target, maxabs, work, (long long)n);
+    hipLaunchKernelGGL(k_absl1_final, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)work, nb, (long long)n, out2);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_absl1_loss_bwd(const float* p, const float* target, const float* maxabs, const float* fwd_out2, const float* gout,
+                                  float gscale, float* dp, int64_t n, void* stream) {
+    MRX_REQUIRE(p && target && maxabs && fwd_out2 && dp && n >= 1, MRX_EINVAL, "mrx_absl1_loss_bwd: bad argument");
+    const long long nbl = (n + 255) / 256;
+    hipLaunchKernelGGL(k_absl1_bwd, dim3((unsigned)(nbl < 4096 ? nbl : 4096)), dim3(256), 0, (hipStream_t)stream, (const float2*)p, target,
+                       maxabs, fwd_out2, gout, gscale, (float2*)dp, (long long)n);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- Adam on a flat parameter buffer (torch.optim.Adam semantics, weight_decay = 0, amsgrad = False; base_cirim_train.yaml) -----
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                       float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+extern "C" int mrx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int step, float grad_scale, void* stream) {
+    MRX_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, MRX_EINVAL, "mrx_adam_step: bad argument");
+    if (n == 0) return MRX_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    const long long nbl = (n + 255) / 256;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)(nbl < 4096 ? nbl : 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                       (long long)n, lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

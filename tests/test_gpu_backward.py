@@ -68,3 +68,73 @@ def test_relu_and_indrnn_backward_vs_autograd(dev, shape):
     assert_close(sums[:, 1], hh.grad.reshape(-1), 1e-5, "hh gradient")
     dpre2, none, sums2 = ops.relu_bwd(dy.to(dev), y.detach().to(dev))
     assert none is None and torch.equal(dpre2, dpre) and torch.equal(sums2[:, 0], sums[:, 0])
+
+
+def _small_cirim(dev, cascades=2):
+    from mridc_amd import synthetic
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG)
+    cfg["num_cascades"] = cascades
+    torch.manual_seed(3)
+    model = CIRIM(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("bias"):
+                p_.normal_(0, 0.05)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    s = synthetic.make_slice(3, 24, 20, slice_idx=1)
+    return cfg, model.to(dev), state, s
+
+
+def test_cirim_training_gradients_vs_oracle_autograd(dev):
+    """Loss and every parameter gradient of a 2-cascade x 8-step CIRIM (IndRNN, no_dc) on the HIP training path against torch
+    autograd of the CPU oracle with the reference's loss (cirim.py:199-247)."""
+    import oracle
+    from mridc_amd import training
+    cfg, model, state, s = _small_cirim(dev)
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    pred = oracle.models.cirim_forward(p, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"])
+    T_ = oracle.models.cirim_time_steps(cfg["time_steps"])
+    ref_loss = oracle.models.cirim_process_loss(s["target"], pred, torch.nn.L1Loss(), T_, cfg["num_cascades"])
+    ref_loss.backward()
+    model.train()
+    batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    etas = next(model(batch["y"], batch["sensitivity_maps"], batch["mask"], None, batch["target"]))
+    loss = training.cirim_l1_loss(etas, batch["target"], model.time_steps, len(model.cirim))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-5 * abs(float(ref_loss.detach())), (float(loss.detach()), float(ref_loss.detach()))
+    checked = 0
+    for name, prm in model.named_parameters():
+        if name.endswith("dc_weight"):
+            continue                                  # unused by no_dc cascades: no gradient on either side
+        ref = p[name].grad
+        assert ref is not None and prm.grad is not None, name
+        assert_close(prm.grad, ref, 2e-3, f"gradient of {name}")
+        checked += 1
+    assert checked == 2 * 11
+    # the inference path is untouched by train(): same outputs in eval mode under no_grad
+    model.eval()
+    with torch.no_grad():
+        out = next(model(batch["y"], batch["sensitivity_maps"], batch["mask"], None, batch["target"]))
+    assert_close(torch.view_as_real(out[-1][-1]), torch.view_as_real(etas[-1][-1].detach()), 1e-4, "train vs eval forward")
+
+
+def test_training_step_matches_torch_adam(dev):
+    """FlatParameters + AdamFlat: two training steps move the parameters exactly as torch.optim.Adam does on the same gradients."""
+    from mridc_amd import training
+    cfg, model, state, s = _small_cirim(dev, cascades=1)
+    batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    flat = training.FlatParameters(model)
+    opt = training.AdamFlat(flat, lr=1e-3, betas=(0.9, 0.98))
+    shadow = [p.detach().clone().requires_grad_(True) for p in flat.params]
+    ref_opt = torch.optim.Adam(shadow, lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+    losses = []
+    for _ in range(2):
+        losses.append(float(training.training_step(model, flat, opt, batch)))
+        for sp, p in zip(shadow, flat.params):
+            sp.grad = p.grad.detach().clone()
+        ref_opt.step()
+        for sp, p in zip(shadow, flat.params):
+            assert_close(p.data, sp.data, 1e-6, "parameter after the Adam step")
+    assert losses[1] < losses[0], losses
+    assert flat.flat.numel() == sum(p.numel() for p in model.parameters())
