@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--rnn", default="IndRNN", choices=["IndRNN", "GRU", "MGU"],
                     help="recurrent layer of the CIRIM cascades (headline: IndRNN; GRU with --cascades 1 is the reference's RIM config)")
     ap.add_argument("--cascades", type=int, default=0, help="override num_cascades (0 = the headline's 8)")
+    ap.add_argument("--train", action="store_true",
+                    help="config C4: data-parallel TRAINING steps of the CIRIM (forward, l1 loss, backward through the HIP kernels, one "
+                         "flat-gradient all-reduce, Adam) instead of inference; fp32")
     ap.add_argument("--cpu-cascades", type=int, default=1, help="cascades of the CPU-baseline sample")
     args = ap.parse_args()
     if args.streams <= 0:
@@ -279,6 +282,43 @@ def bench_e2evn(args, world, rank, dev):
               flush=True)
 
 
+def bench_train(args, world, rank, dev):
+    """BASELINE config C4 (CIRIM training, DDP gradient all-reduce): one slice per rank and step, fp32."""
+    from mridc_amd import synthetic, training
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG)
+    cfg["recurrent_layer"] = "IndRNN"
+    if args.cascades:
+        cfg["num_cascades"] = args.cascades
+    torch.manual_seed(0)
+    model = CIRIM(cfg).to(dev)
+    C, H, W = args.coils, args.height, args.width
+    s = synthetic.make_slice(C, H, W, slice_idx=rank)
+    batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    flat = training.FlatParameters(model)
+    opt = training.AdamFlat(flat, lr=1e-3, betas=(0.9, 0.98))
+    losses = []
+    for _ in range(max(args.warmup, 1)):
+        losses.append(float(training.training_step(model, flat, opt, batch)))
+    dist_barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = training.training_step(model, flat, opt, batch)
+    dist_barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    losses.append(float(loss))
+    if rank == 0:
+        print(json.dumps(dict(metric=f"slices/sec (training), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}",
+                              value=world * args.steps / elapsed, unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                              ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                              dtype="f32", data="synthetic",
+                              config=dict(workload=f"CIRIM {cfg['num_cascades']} cascades x {model.time_steps} time-steps, IndRNN 64, {C} coils, "
+                                                   f"{H}x{W}: forward + l1 loss + backward (HIP kernels) + one all-reduce of the flat gradient "
+                                                   f"({flat.numel * 4 / 1e6:.2f} MB) + Adam, 1 slice per GPU and step",
+                                          global_batch=world, parallelism=f"data-parallel x{world}", gradient_bytes=flat.numel * 4),
+                              loss_first=losses[0], loss_last=losses[-1])), flush=True)
+
+
 def dist_barrier():
     """Barrier over the ranks (when a process group exists) + device synchronize."""
     import torch.distributed as dist
@@ -334,6 +374,11 @@ def main():
     from mridc_amd import ops, synthetic
     from mridc_amd.collections.reconstruction.models.cirim import CIRIM
 
+    if args.train:
+        bench_train(args, world, rank, dev)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     if args.model != "cirim":
         (bench_qcirim if args.model == "qcirim" else bench_e2evn)(args, world, rank, dev)
         if use_dist:

@@ -259,7 +259,7 @@ int mrx_gru_blend(const float* h, const float* pre_update, const float* pre_out,
 /* Training path: backward kernels of the convolutional regulariser.  The reference differentiates
  * rim_block.py:217-249 through torch autograd (backward of Conv2d with ReplicationPad2d, ReLU, the IndRNN cell).
  *   mrx_conv_wgrad     dw[Cout,Cin,k,k] (= or +=) sum_{b,pixel} dy[b,co,pixel] * pad(x)[b,ci,pixel + tap*dil]; Cout = 64 on the matrix
- *                      cores, Cout <= 8 on the vector ALUs; work: mrx_conv_wgrad_work_floats floats; fixed-order reduction
+ *                      cores, Cout <= 4 (k = 1, 3, 5) on the vector ALUs; work: mrx_conv_wgrad_work_floats floats; fixed-order reduction
  *   mrx_reppad_fold    adjoint of ReplicationPad2d(pad): g [planes,H+2pad,W+2pad] -> out [planes,H,W].  The data gradient of a
  *                      replicate-padded conv is mrx_conv2d (zero 'same' padding, flipped + transposed weights) of dy zero-extended by
  *                      pad on every side, folded by this kernel

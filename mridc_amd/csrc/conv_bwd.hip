@@ -130,59 +130,71 @@ __global__ void k_wgrad_reduce(const float* __restrict__ part, int nparts, long 
     }
 }
 
-// ---- weight gradient, any Cout (small ones in practice): one workgroup per (ci, tap) and slab of rows, all Cout at once -----------
+// ---- weight gradient, small Cout (final RIM layer: 2): one workgroup per (input channel, slab of rows), all taps and all Cout at
+// once -- every x row is read once per tap row (L1/L2 hits) and dy once per input channel instead of once per (channel, tap).
 #define WS_NT 256
-#define WS_MAXCO 8
+#define WS_MAXCO 4
 struct WsmallArgs {
     const float* x;
     const float* dy;
     float* part;  // [nslab][Cout][Cin*taps]
     int B, Cin, Cout, H, W, k, dil, pad, pad_mode, rows_per_slab;
 };
+template <int K>
 __global__ __launch_bounds__(WS_NT) void k_conv_wgrad_small(WsmallArgs a) {
-    const int taps = a.k * a.k, n = blockIdx.x, ci = n / taps, tap = n - ci * taps, ky = tap / a.k, kx = tap - ky * a.k;
-    const int slab = blockIdx.y, r0 = slab * a.rows_per_slab;
+    constexpr int TAPS = K * K;
+    const int ci = blockIdx.x, slab = blockIdx.y, r0 = slab * a.rows_per_slab;
     const int r1 = r0 + a.rows_per_slab < a.B * a.H ? r0 + a.rows_per_slab : a.B * a.H;  // rows enumerate (b, h)
     const long long plane = (long long)a.H * a.W;
-    float acc[WS_MAXCO];
+    const bool rep = a.pad_mode == MRX_PAD_REPLICATE;
+    float acc[WS_MAXCO][TAPS];
 #pragma unroll
-    for (int o = 0; o < WS_MAXCO; ++o) acc[o] = 0.f;
+    for (int o = 0; o < WS_MAXCO; ++o)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[o][t] = 0.f;
     for (int row = r0; row < r1; ++row) {
         const int b = row / a.H, h = row - b * a.H;
-        int gy = h + ky * a.dil - a.pad;
-        bool rok = gy >= 0 && gy < a.H;
-        if (a.pad_mode == MRX_PAD_REPLICATE) {
-            gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-            rok = true;
-        }
-        if (!rok) continue;
-        const float* xr = a.x + ((long long)b * a.Cin + ci) * plane + (long long)gy * a.W;
+        const float* xc = a.x + ((long long)b * a.Cin + ci) * plane;
         const float* dr = a.dy + (long long)b * a.Cout * plane + (long long)h * a.W;
         for (int w = threadIdx.x; w < a.W; w += WS_NT) {
-            int gx = w + kx * a.dil - a.pad;
-            float xv;
-            if (a.pad_mode == MRX_PAD_REPLICATE) {
-                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-                xv = xr[gx];
-            } else {
-                xv = (gx >= 0 && gx < a.W) ? xr[gx] : 0.f;
-            }
+            float d[WS_MAXCO];
 #pragma unroll
-            for (int o = 0; o < WS_MAXCO; ++o)
-                if (o < a.Cout) acc[o] += dr[(long long)o * plane + w] * xv;
+            for (int o = 0; o < WS_MAXCO; ++o) d[o] = o < a.Cout ? dr[(long long)o * plane + w] : 0.f;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                int gy = h + ky * a.dil - a.pad;
+                const bool rok = rep || (gy >= 0 && gy < a.H);
+                gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    int gx = w + kx * a.dil - a.pad;
+                    const bool ok = rok && (rep || (gx >= 0 && gx < a.W));
+                    gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                    const float xv = ok ? xc[(long long)gy * a.W + gx] : 0.f;
+#pragma unroll
+                    for (int o = 0; o < WS_MAXCO; ++o) acc[o][ky * K + kx] += d[o] * xv;
+                }
+            }
         }
     }
     __shared__ float sh[WS_NT];
-    for (int o = 0; o < a.Cout && o < WS_MAXCO; ++o) {
-        sh[threadIdx.x] = acc[o];
-        __syncthreads();
-        for (int st = WS_NT / 2; st > 0; st >>= 1) {
-            if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    for (int o = 0; o < a.Cout; ++o)
+        for (int t = 0; t < TAPS; ++t) {
+            float v = 0.f;
+#pragma unroll
+            for (int oo = 0; oo < WS_MAXCO; ++oo)
+#pragma unroll
+                for (int tt = 0; tt < TAPS; ++tt)
+                    if (oo == o && tt == t) v = acc[oo][tt];  // compile-time indexed registers
+            sh[threadIdx.x] = v;
+            __syncthreads();
+            for (int st = WS_NT / 2; st > 0; st >>= 1) {
+                if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) a.part[((long long)slab * a.Cout + o) * (a.Cin * TAPS) + ci * TAPS + t] = sh[0];
             __syncthreads();
         }
-        if (threadIdx.x == 0) a.part[((long long)slab * a.Cout + o) * (a.Cin * taps) + n] = sh[0];
-        __syncthreads();
-    }
 }
 
 static int wgrad_nparts64(int n_cu, long long nt_total) { return (int)(nt_total < n_cu ? nt_total : n_cu); }
@@ -258,7 +270,10 @@ extern "C" int mrx_conv_wgrad(const float* x, const float* dy, float* dw, float*
         const int rows = B * H;
         a.rows_per_slab = (rows + WS_SLABS - 1) / WS_SLABS;
         nparts = (rows + a.rows_per_slab - 1) / a.rows_per_slab;
-        hipLaunchKernelGGL(k_conv_wgrad_small, dim3((unsigned)N, nparts), dim3(WS_NT), 0, st, a);
+        MRX_REQUIRE(k == 1 || k == 3 || k == 5, MRX_EUNSUP, "mrx_conv_wgrad: kernel size %d with Cout=%d (1, 3, 5)", k, Cout);
+        if (k == 1) hipLaunchKernelGGL(k_conv_wgrad_small<1>, dim3(Cin, nparts), dim3(WS_NT), 0, st, a);
+        else if (k == 3) hipLaunchKernelGGL(k_conv_wgrad_small<3>, dim3(Cin, nparts), dim3(WS_NT), 0, st, a);
+        else hipLaunchKernelGGL(k_conv_wgrad_small<5>, dim3(Cin, nparts), dim3(WS_NT), 0, st, a);
     }
     MRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)work, nparts, total, dw,

@@ -67,3 +67,43 @@ def test_two_rank_sharding_union_equals_single_rank():
         assert abs(elapsed - 0.2) < 1e-12                    # max over ranks
         assert sums[0] == sum(float(i * i + 1) for i in range(n)) and sums[1] == n
     assert union == {i: float(i * i + 1) for i in range(n)}  # slice-for-slice identical to the single-rank result
+
+
+def _grad_worker(rank, world, port, q):
+    """Training exchange: every rank holds the flat gradient of its own slices; ONE all-reduce(sum) then the 1/world scale."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mridc_amd import training
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 3), torch.nn.Conv2d(3, 2, 1))     # host tensors: the exchange is device-agnostic
+    flat = training.FlatParameters(net)
+    n0 = flat.numel
+    # parameters and gradients are views of the two flat buffers
+    assert all(p.data.data_ptr() >= flat.flat.data_ptr() for p in flat.params)
+    for i, p in enumerate(flat.params):
+        p.grad.fill_(float((rank + 1) * (i + 1)))
+    world_seen = training.allreduce_gradients(flat.grad)
+    q.put((rank, n0, world_seen, flat.grad.clone(), [float(p.grad.reshape(-1)[0]) for p in flat.params]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_flat_gradient_allreduce():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, w0, g0, v0), (_, n1, w1, g1, v1) = res
+    assert n0 == n1 == 2 * 3 * 9 + 3 + 3 * 2 + 2 and w0 == w1 == 2
+    assert torch.equal(g0, g1)                                   # both ranks hold the same summed gradient
+    assert v0 == [3.0 * (i + 1) for i in range(4)]               # (1 + 2) * (i + 1): the sum over the two ranks, seen through the views
+    from mridc_amd import training
+    assert training.allreduce_gradients(torch.zeros(3)) == 1     # no process group: a no-op
+    lrs = [training.inverse_sqrt_lr(s, 100, 1e-3) for s in range(100)]
+    assert lrs[0] < lrs[5] < lrs[9] and lrs[10] >= lrs[50] >= lrs[99] > 0
