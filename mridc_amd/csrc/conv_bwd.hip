@@ -37,22 +37,32 @@ struct WgradArgs {
     int B, Cin, H, W, k, dil, pad, pad_mode, N, tiles_x, ntiles, XS, PH;
 };
 
+template <int PAD>
 __global__ __launch_bounds__(WG_NT, 2) void k_conv_wgrad64(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int XS = (WG_TW + 2 * PAD) | 1, PH = WG_TH + 2 * PAD, PLANE = PH * XS, PW = WG_TW + 2 * PAD;  // odd row stride
     float* Dy = smem_f;                 // [64][WG_DYS]
     float* Xs = smem_f + 64 * WG_DYS;   // [Cin][PH][XS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int taps = a.k * a.k, PLANE = a.PH * a.XS;
+    const int taps = a.k * a.k;
     const int nblocks = (a.N + 31) / 32;
+    // Few column blocks (1x1 layers: 2, the 5x5 layer on 4 channels: 4): the waves that would idle split the pixels instead.
+    // groups = 8 / nblocks (a power of two) wave groups each take 64 / groups of the 64 two-pixel steps of a tile and write
+    // their own partial; with >= 8 blocks every wave owns blocks w, w + 8, ... and all steps.
+    const int groups = nblocks >= 8 ? 1 : (nblocks > 4 ? 1 : (nblocks > 2 ? 2 : (nblocks > 1 ? 4 : 8)));
+    const int wblk = groups == 1 ? wave : wave % (8 / groups);          // first column block of this wave
+    const int grp = groups == 1 ? 0 : wave / (8 / groups);              // its pixel group
+    const int gshift = groups == 1 ? 6 : (groups == 2 ? 5 : (groups == 4 ? 4 : 3));  // steps per group = 1 << gshift
+    const int nbw = wblk < nblocks ? (groups == 1 ? (nblocks - wblk + 7) / 8 : 1) : 0;  // column blocks of this wave (wave-uniform)
     // per-lane gather base of every n-block of this wave: (ci, tap) -> ci * PLANE + ky * dil * XS + kx * dil, plus the pixel parity
     int bbase[WG_MAXNB];
 #pragma unroll
     for (int j = 0; j < WG_MAXNB; ++j) {
-        int n = (wave + 8 * j) * 32 + l31;
+        int n = (wblk + 8 * j) * 32 + l31;
         n = n < a.N ? n : a.N - 1;  // columns past N are computed on a valid address and never stored
         const int ci = n / taps, tap = n - ci * taps, ky = tap / a.k, kx = tap - ky * a.k;
-        bbase[j] = ci * PLANE + ky * a.dil * a.XS + kx * a.dil + lhi;
+        bbase[j] = ci * PLANE + ky * a.dil * XS + kx * a.dil + lhi;
     }
     f32x16 acc[WG_MAXNB][2];
 #pragma unroll
@@ -76,10 +86,9 @@ __global__ __launch_bounds__(WG_NT, 2) void k_conv_wgrad64(WgradArgs a) {
         }
         // x tile with its halo: replicate (clamped) or zero border
         const float* xb = a.x + (long long)b * a.Cin * plane;
-        const int PW = WG_TW + 2 * a.pad;
-        for (int i = tid; i < a.Cin * a.PH * PW; i += WG_NT) {
-            const int ci = i / (a.PH * PW), rem = i - ci * (a.PH * PW), r = rem / PW, c = rem - r * PW;
-            int gy = h0 + r - a.pad, gx = w0 + c - a.pad;
+        for (int i = tid; i < a.Cin * PH * PW; i += WG_NT) {
+            const int ci = i / (PH * PW), rem = i - ci * (PH * PW), r = rem / PW, c = rem - r * PW;
+            int gy = h0 + r - PAD, gx = w0 + c - PAD;
             float vv = 0.f;
             if (a.pad_mode == MRX_PAD_REPLICATE) {
                 gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
@@ -88,29 +97,51 @@ __global__ __launch_bounds__(WG_NT, 2) void k_conv_wgrad64(WgradArgs a) {
             } else if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
                 vv = xb[(long long)ci * plane + (long long)gy * a.W + gx];
             }
-            Xs[ci * PLANE + r * a.XS + c] = vv;
+            Xs[ci * PLANE + r * XS + c] = vv;
         }
         __syncthreads();
+        // 64 steps of two pixels (row s >> 4, columns 2 (s & 15) + parity): the dy operands are shared by the wave's column blocks;
+        // all LDS offsets are immediates and the reads run WG_PF steps ahead of the MFMAs that consume them
         const float* ap0 = Dy + l31 * WG_DYS + lhi;
         const float* ap1 = Dy + (32 + l31) * WG_DYS + lhi;
+        const float* bp0 = Xs + bbase[0];
+        const float* bp1 = Xs + bbase[1];
+        const float* bp2 = Xs + bbase[2];
+        constexpr int PF = 3;
+        float ra0[PF + 1], ra1[PF + 1], rb0[PF + 1], rb1[PF + 1], rb2[PF + 1];
+        if (nbw > 0) {
 #pragma unroll
-        for (int j = 0; j < WG_MAXNB; ++j) {
-            if (wave + 8 * j >= nblocks) break;  // wave-uniform
-            const float* bp = Xs + bbase[j];
-#pragma unroll 8
-            for (int s = 0; s < WG_PX / 2; ++s) {  // pixels 2s, 2s+1: row s >> 4, columns 2 (s & 15) + parity
-                const float a0 = ap0[2 * s], a1 = ap1[2 * s];
-                const float bv = bp[(s >> 4) * a.XS + 2 * (s & 15)];
-                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[j][1], 0, 0, 0);
+            for (int s = 0; s < WG_PX / 2 + PF; ++s) {
+                if (s < WG_PX / 2 && (s >> gshift) == grp) {
+                    const int w = s % (PF + 1), xo = (s >> 4) * XS + 2 * (s & 15);
+                    ra0[w] = ap0[2 * s];
+                    ra1[w] = ap1[2 * s];
+                    rb0[w] = bp0[xo];
+                    if (nbw > 1) rb1[w] = bp1[xo];
+                    if (nbw > 2) rb2[w] = bp2[xo];
+                }
+                if (s >= PF && ((s - PF) >> gshift) == grp) {
+                    const int c = (s - PF) % (PF + 1);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], rb0[c], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], rb0[c], acc[0][1], 0, 0, 0);
+                    if (nbw > 1) {
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], rb1[c], acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], rb1[c], acc[1][1], 0, 0, 0);
+                    }
+                    if (nbw > 2) {
+                        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], rb2[c], acc[2][0], 0, 0, 0);
+                        acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], rb2[c], acc[2][1], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    float* pb = a.part + (long long)blockIdx.x * 64 * a.N;
+    float* pb = a.part + ((long long)blockIdx.x * groups + grp) * 64 * a.N;
 #pragma unroll
     for (int j = 0; j < WG_MAXNB; ++j) {
-        if (wave + 8 * j >= nblocks) break;
-        const int n = (wave + 8 * j) * 32 + l31;
+        if (j >= nbw) break;
+        const int n = (wblk + 8 * j) * 32 + l31;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -121,12 +152,23 @@ __global__ __launch_bounds__(WG_NT, 2) void k_conv_wgrad64(WgradArgs a) {
     }
 }
 
-// dW[i] (= or +=) sum over the workgroup partials, in order, in double
-__global__ void k_wgrad_reduce(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw, int accumulate) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int p = 0; p < nparts; ++p) s += (double)part[(long long)p * n + i];
-        dw[i] = accumulate ? dw[i] + (float)s : (float)s;
+// dW[i] (= or +=) sum over the workgroup partials in a fixed order, in double: a workgroup takes 16 consecutive outputs, 16 threads
+// per output stride through the partials (coalesced 64-byte rows of `part`), then their 16 sums are added in order
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw,
+                                                      int accumulate) {
+    __shared__ double sh[16][17];
+    const int li = threadIdx.x & 15, lp = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + li;
+    double s = 0.0;
+    if (i < n)
+        for (int p = lp; p < nparts; p += 16) s += (double)part[(long long)p * n + i];
+    sh[lp][li] = s;
+    __syncthreads();
+    if (lp == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][li];
+        dw[i] = accumulate ? dw[i] + (float)t : (float)t;
     }
 }
 
@@ -212,7 +254,7 @@ static int query_cus() {
 
 extern "C" int64_t mrx_conv_wgrad_work_floats(int B, int Cin, int Cout, int H, int W, int k) {
     const long long n = (long long)Cout * Cin * k * k;
-    if (Cout == 64 && (long long)Cin * k * k <= 8 * WG_MAXNB * 32) return (int64_t)1024 * n;  // upper bound on the workgroup count
+    if (Cout == 64 && (long long)Cin * k * k <= 8 * WG_MAXNB * 32) return (int64_t)8 * 1024 * n;  // bound: workgroups x pixel groups
     return (int64_t)WS_SLABS * n;
 }
 
@@ -241,17 +283,23 @@ extern "C" int mrx_conv_wgrad(const float* x, const float* dy, float* dw, float*
         a.N = (int)N;
         a.tiles_x = mrx_cdiv(W, WG_TW);
         a.ntiles = a.tiles_x * mrx_cdiv(H, WG_TH);
+        MRX_REQUIRE(pad <= 2, MRX_EUNSUP, "mrx_conv_wgrad: padding %d (k=%d dil=%d; up to 2)", pad, k, dil);
         a.PH = WG_TH + 2 * pad;
         a.XS = (WG_TW + 2 * pad) | 1;  // odd row stride
         const size_t lds = sizeof(float) * ((size_t)64 * WG_DYS + (size_t)Cin * a.PH * a.XS);
         MRX_REQUIRE(lds <= 160 * 1024, MRX_EUNSUP, "mrx_conv_wgrad: %zu bytes of LDS (Cin=%d k=%d dil=%d)", lds, Cin, k, dil);
-        static size_t attr_bytes = 0;
-        if (lds > 48 * 1024 && attr_bytes < lds) {
-            MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_bytes = lds;
+        static size_t attr_bytes[3] = {0, 0, 0};
+        const void* kern = pad == 0 ? (const void*)k_conv_wgrad64<0> : pad == 1 ? (const void*)k_conv_wgrad64<1> : (const void*)k_conv_wgrad64<2>;
+        if (lds > 48 * 1024 && attr_bytes[pad] < lds) {
+            MRX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_bytes[pad] = lds;
         }
         nparts = wgrad_nparts64(query_cus() < 1024 ? query_cus() : 1024, (long long)a.ntiles * B);
-        hipLaunchKernelGGL(k_conv_wgrad64, dim3(nparts), dim3(WG_NT), lds, st, a);
+        const int nblk64 = nparts, nbl = (int)((N + 31) / 32);
+        nparts *= nbl >= 5 ? 1 : (nbl > 2 ? 2 : (nbl > 1 ? 4 : 8));   // pixel groups of the kernel (few column blocks)
+        if (pad == 0) hipLaunchKernelGGL(k_conv_wgrad64<0>, dim3(nblk64), dim3(WG_NT), lds, st, a);
+        else if (pad == 1) hipLaunchKernelGGL(k_conv_wgrad64<1>, dim3(nblk64), dim3(WG_NT), lds, st, a);
+        else hipLaunchKernelGGL(k_conv_wgrad64<2>, dim3(nblk64), dim3(WG_NT), lds, st, a);
     } else {
         MRX_REQUIRE(Cout <= WS_MAXCO, MRX_EUNSUP, "mrx_conv_wgrad: Cout=%d (64 or <= %d)", Cout, WS_MAXCO);
         WsmallArgs a;
@@ -276,7 +324,7 @@ extern "C" int mrx_conv_wgrad(const float* x, const float* dy, float* dw, float*
         else hipLaunchKernelGGL(k_conv_wgrad_small<5>, dim3(Cin, nparts), dim3(WS_NT), 0, st, a);
     }
     MRX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)work, nparts, total, dw,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nparts, total, dw,
                        accumulate);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
