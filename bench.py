@@ -428,6 +428,8 @@ def main():
     timer.wrap(ops, "rim_layer_indrnn_wino", lambda x, *a, **k: "conv_layer2_wino")
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
+    timer.wrap(ops, "llg_hinv_parts", lambda *a, **k: "llg")     # gradient whose last pass is done by layer 1's tile loader
+    timer.wrap(ops, "rim_layer_indrnn_packed_llg", lambda *a, **k: "conv_layer1")
     timer.wrap(ops, "rim_final", lambda *a, **k: "final")
 
     def step(d=None):

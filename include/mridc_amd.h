@@ -122,6 +122,15 @@ int mrx_fft_cols(const float* in, float* out, int64_t nimg, int H, int W, int in
 int mrx_llg_hinv(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
                  const int64_t* mstride, float* out4, float* work, int B, int C, int H, int W, float inv_sigma2, int norm,
                  int centered, void* stream);
+/* mrx_llg_hinv with the sum over the coil-chunk partials left to the consumer: *nparts (host) = number of partial planes
+ * work[k][B][H][W][2] still to be added and scaled by inv_sigma2 (then out4 is NOT written), or 0 (out4 complete).
+ * mrx_rim_layer_indrnn_packed_llg is that consumer: the fused first RIM layer reading (eta, partials) in its tile loader. */
+int mrx_llg_hinv_parts(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
+                       const int64_t* mstride, float* out4, float* work, int* nparts, int B, int C, int H, int W,
+                       float inv_sigma2, int norm, int centered, void* stream);
+int mrx_rim_layer_indrnn_packed_llg(const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,
+                                    const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                                    float* h_new, int B, int F, int H, int W, int k, int dil, void* stream);
 
 /* K2  soft data consistency: out = where(mask, pred - ref, 0) * dc_weight[0]   (vn_block.py:109-110,
  * rim_block.py:256).  dc_weight is a device pointer (it is an nn.Parameter). */

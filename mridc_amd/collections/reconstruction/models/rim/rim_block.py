@@ -193,8 +193,27 @@ class RIMBlock(torch.nn.Module):
         else:
             work = torch.empty_like(masked_kspace, dtype=torch.float32)
         etas = []
+        # first layer reading (eta, partial coil sums) itself: the gradient's last pass (sum + 1/sigma^2 + channel split) is free in
+        # its tile loader and the [B,4,H,W] tensor is never written
+        l0 = self.layers[0] if len(self.layers) else None
+        defer = (hinv and l0 is not None and self._fusable(l0) and l0.convs.input_size == 4
+                 and ops.rim_layer_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)
+                 and not (self.winograd and ops.rim_layer_wino_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)))
         for _ in range(self.time_steps):                             # rim_block.py:217-249
-            if hinv:
+            if defer:
+                grad_eta, part, nparts = ops.llg_hinv_parts(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
+                if nparts > 0:
+                    c, r = l0.convs, l0.rnn
+                    hx[0] = ops.rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, self._packed(0, c, r), r.hidden_size, c.kernel_size,
+                                                            c.dilation, c.conv_layer.bias, r.ih.bias, r.hh, hx[0])
+                    grad_eta = hx[0]
+                    for h in range(1, len(self.layers)):
+                        hx[h] = self._layer(h, self.layers[h], grad_eta, hx[h])
+                        grad_eta = hx[h]
+                    eta = ops.rim_final(grad_eta, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size, final.dilation, eta)
+                    etas.append(eta)
+                    continue
+            elif hinv:
                 grad_eta = ops.llg_hinv(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
             else:
                 grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,

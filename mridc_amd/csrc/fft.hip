@@ -1281,9 +1281,12 @@ extern "C" int mrx_llg(const float* eta, const float* y, const float* S, const v
 }
 
 template <class P, int NSEQ>
+// defer != nullptr: the caller adds the coil-chunk partials itself (the fused layer-1 kernel does it in its tile loader);
+// *defer = number of partial planes left in `part` (0: `out` is complete)
 static int launch_hinv_p(const float2* eta, const float2* yt, const float2* S, const MrxMask& m, float* out, float* part,
-                         dim3 grid, size_t lds, const ReduceArgs& a, float scale_f, hipStream_t st) {
+                         dim3 grid, size_t lds, const ReduceArgs& a, float scale_f, hipStream_t st, int* defer = nullptr) {
     const int nchunks = mrx_cdiv(a.C, a.g);
+    if (defer) *defer = 0;
     // experimental (MRX_LLG_MFMA=1): measured 46.8 us vs 44.2 us for the vector-ALU kernels below at 15 x 640 x 372 -- kept selectable
     if (P::kCT && P::N == 372 && NSEQ == M372_G && getenv("MRX_LLG_MFMA")) {
             M372Tables tb;
@@ -1336,6 +1339,11 @@ static int launch_hinv_p(const float2* eta, const float2* yt, const float2* S, c
             if (rc) return rc;
             hipLaunchKernelGGL((k_llg_rows_hinv<P, NSEQ, true>), g3, dim3(MRX_FFT_NT), lds, st, eta, yt, S, m, part, a, scale_f);
         }
+        if (defer) {
+            *defer = nchunks;
+            MRX_LAUNCH_CHECK();
+            return MRX_OK;
+        }
         const long long plane = (long long)a.H * a.W, total = plane * grid.y;
         long long nb = (total + 255) / 256;
         if (nb > 2048) nb = 2048;
@@ -1368,9 +1376,9 @@ extern "C" int64_t mrx_llg_hinv_work_floats(int B, int C, int H, int W) {
     return (int64_t)mrx_cdiv(C, g) * B * H * W * 2;
 }
 
-extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
-                            const int64_t* mstride, float* out4, float* work, int B, int C, int H, int W, float inv_sigma2,
-                            int norm, int centered, void* stream) {
+static int llg_hinv_impl(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
+                         const int64_t* mstride, float* out4, float* work, int B, int C, int H, int W, float inv_sigma2,
+                         int norm, int centered, void* stream, int* defer) {
     MRX_REQUIRE(eta && yt && S && mask && mstride && out4, MRX_EINVAL, "mrx_llg_hinv: null pointer");
     MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_llg_hinv: bad dims");
     MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_llg_hinv: bad normalization %d", norm);
@@ -1407,11 +1415,27 @@ extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, c
     const float2 *pe = (const float2*)eta, *py = (const float2*)yt, *ps = (const float2*)S;
     // split the coil sum over workgroups only while the grid is small (rows x batch below ~4 workgroups per CU)
     float* part = (work && (long long)H * B < 1024) ? work : nullptr;
-    if (W == 372 && mfma372) return launch_hinv_p<P372, M372_G>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
-    if (W == 372) return launch_hinv_p<P372, NSEQ_HINV_372>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
-    if (W == 320) return launch_hinv_p<P320, NSEQ_ROW_320>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
-    if (W == 256) return launch_hinv_p<P256, NSEQ_ROW_256>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
-    return launch_hinv_p<PlanRT, 1>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st);
+    if (W == 372 && mfma372) return launch_hinv_p<P372, M372_G>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st, nullptr);
+    if (W == 372) return launch_hinv_p<P372, NSEQ_HINV_372>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st, defer);
+    if (W == 320) return launch_hinv_p<P320, NSEQ_ROW_320>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st, defer);
+    if (W == 256) return launch_hinv_p<P256, NSEQ_ROW_256>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st, defer);
+    return launch_hinv_p<PlanRT, 1>(pe, py, ps, m, out4, part, grid, lds, a, scale_f, st, defer);
+}
+
+extern "C" int mrx_llg_hinv(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
+                            const int64_t* mstride, float* out4, float* work, int B, int C, int H, int W, float inv_sigma2,
+                            int norm, int centered, void* stream) {
+    return llg_hinv_impl(eta, yt, S, mask, mask_kind, mstride, out4, work, B, C, H, W, inv_sigma2, norm, centered, stream, nullptr);
+}
+// Same, but the sum over the coil-chunk partials is left to the consumer: *nparts (host) = number of partial planes
+// work[k][B][H][W][2] still to be added and scaled by inv_sigma2 (0: out4 is complete).  mrx_rim_layer_indrnn_packed_llg consumes them.
+extern "C" int mrx_llg_hinv_parts(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
+                                  const int64_t* mstride, float* out4, float* work, int* nparts, int B, int C, int H, int W,
+                                  float inv_sigma2, int norm, int centered, void* stream) {
+    MRX_REQUIRE(nparts, MRX_EINVAL, "mrx_llg_hinv_parts: null pointer");
+    *nparts = 0;
+    if (getenv("MRX_LLG_MFMA")) return llg_hinv_impl(eta, yt, S, mask, mask_kind, mstride, out4, work, B, C, H, W, inv_sigma2, norm, centered, stream, nullptr);
+    return llg_hinv_impl(eta, yt, S, mask, mask_kind, mstride, out4, work, B, C, H, W, inv_sigma2, norm, centered, stream, nparts);
 }
 
 // Data-consistency residual in image space with shared maps:  out[b] = sum_c conj(S[b/sdiv,c]) * ifft2( mask * (fft2(x[b] * S[b/sdiv,c]) - y[b,c]) )

@@ -37,6 +37,13 @@ struct RimLayerArgs {
     const float* hprev;    // [B,F,H,W] or null
     float* hnew;           // [B,F,H,W]
     int B, Cin, H, W, tiles_x, ntiles;
+    // input given as (eta, partial gradients) instead of x (Cin = 4): x = (eta.re, eta.im, post * sum_k part_k.re, post * sum_k part_k.im),
+    // the last step of log_likelihood_gradient (rim_utils.py:61-67) done by the tile loader (mrx_rim_layer_indrnn_packed_llg)
+    const float2* eta2;   // [B,H,W] complex or null
+    const float2* part;   // [nparts][B][H][W] complex
+    long long part_stride;
+    int nparts;
+    float post;
     int stagger;  // s_sleep argument for odd dispatch rounds (0 = off)
     unsigned long long* trace;  // debug only (env MRX_TRACE): 6 s_memtime stamps per workgroup
     int ablate;  // debug only (env MRX_ABLATE): 1 no h_prev loads, 2 no stores, 4 no main-loop MFMA, 8 no chunk staging, 16 no 1x1 GEMM
@@ -148,6 +155,29 @@ __global__ __launch_bounds__(RL_NT, 4) void k_rim_layer(RimLayerArgs a) {
     typedef float wi4_t __attribute__((ext_vector_type(4)));
     wi4_t wir0 = {0.f, 0.f, 0.f, 0.f}, wir1 = wir0;  // scalars, not an array: the array form stayed in scratch memory
     auto prefetch = [&](int q) {
+        if (CK == 4 && a.eta2) {  // Cin = 4, one chunk: channels from eta and the partial coil sums (same order of additions as k_llg_combine)
+#pragma unroll
+            for (int s = 0; s < XSLOTS; ++s) {
+                const int e = tid + s * RL_NT;
+                float2 ev = make_float2(0.f, 0.f), sv = make_float2(0.f, 0.f);
+                if (e < PLANE) {
+                    const long long o = (long long)b * plane + goff[s];
+                    ev = a.eta2[o];
+                    sv = a.part[o];
+                    for (int k = 1; k < a.nparts; ++k) {
+                        const float2 v = a.part[(long long)k * a.part_stride + o];
+                        sv.x += v.x;
+                        sv.y += v.y;
+                    }
+                    sv.x *= a.post;
+                    sv.y *= a.post;
+                }
+                xr[0][s] = ev.x;
+                xr[1 % CK][s] = ev.y;
+                xr[2 % CK][s] = sv.x;
+                xr[3 % CK][s] = sv.y;
+            }
+        } else
 #pragma unroll
         for (int ci = 0; ci < CK; ++ci) {
             const int gc = q * CK + ci;
@@ -443,6 +473,14 @@ extern "C" int mrx_rim_layer_supported(int Cin, int F, int k, int dil) {
     return (k == 5 && dil == 1) || (k == 3 && dil == 2) || (k == 3 && dil == 1) || (k == 1 && dil == 1);
 }
 
+struct LlgSrc {
+    const float2* eta;
+    const float2* part;
+    int nparts;
+    float post;
+};
+static thread_local LlgSrc g_llg_src = {nullptr, nullptr, 0, 0.f};
+
 extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, const float* b_conv, const float* b_ih,
                                            const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H,
                                            int W, int k, int dil, void* stream) {
@@ -453,6 +491,18 @@ extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, 
     MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "mrx_rim_layer_indrnn_packed: batch %d too large", B);
     if (B == 0) return MRX_OK;
     RimLayerArgs a;
+    a.eta2 = nullptr;
+    a.part = nullptr;
+    a.part_stride = 0;
+    a.nparts = 0;
+    a.post = 0.f;
+    if (g_llg_src.eta) {  // set by mrx_rim_layer_indrnn_packed_llg around this call
+        a.eta2 = g_llg_src.eta;
+        a.part = g_llg_src.part;
+        a.part_stride = (long long)B * H * W;
+        a.nparts = g_llg_src.nparts;
+        a.post = g_llg_src.post;
+    }
     a.x = x;
     a.packed = packed;
     a.b_conv = b_conv;
@@ -840,4 +890,18 @@ extern "C" int mrx_conv_to_complex(const float* h, const float* w, const float* 
     a.H = H;
     a.W = W;
     return launch_rim_final4(a, (hipStream_t)stream);
+}
+
+// The fused layer on the output of log_likelihood_gradient without materialising it: input channels (eta.re, eta.im, grad.re, grad.im)
+// with grad = inv_sigma2 * sum of the `nparts` coil-chunk partials mrx_llg_hinv_parts left in `part` (rim_utils.py:61-67 +
+// conv_layers.py:121-123 + rnn_cells.py:384-391).  Cin is 4 by construction.
+extern "C" int mrx_rim_layer_indrnn_packed_llg(const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,
+                                               const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                                               float* h_new, int B, int F, int H, int W, int k, int dil, void* stream) {
+    MRX_REQUIRE(eta && part && nparts >= 1, MRX_EINVAL, "mrx_rim_layer_indrnn_packed_llg: bad argument");
+    g_llg_src = {(const float2*)eta, (const float2*)part, nparts, inv_sigma2};
+    const int rc = mrx_rim_layer_indrnn_packed(eta /* non-null placeholder, not read */, packed, b_conv, b_ih, hh, h_prev, h_new, B, 4, F, H,
+                                               W, k, dil, stream);
+    g_llg_src = {nullptr, nullptr, 0, 0.f};
+    return rc;
 }

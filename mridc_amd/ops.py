@@ -117,6 +117,43 @@ def llg_hinv(eta, yt, sens, mask, sigma, centered, normalization, out=None, work
     return out
 
 
+def llg_hinv_parts(eta, yt, sens, mask, sigma, centered, normalization, out=None, work=None):
+    """llg_hinv with the coil-chunk partial sums left for the consumer (rim_layer_indrnn_packed_llg).  Returns (out4, work, nparts):
+    nparts > 0: `work` holds that many partial planes and out4 was not written; nparts == 0: out4 is the complete gradient."""
+    import ctypes
+    yt, sens, eta = _lib.f32c(yt), _lib.f32c(sens), _lib.f32c(eta)
+    B, C, H, W = _bchw(yt)
+    if sens.shape != yt.shape or tuple(eta.shape) != (B, H, W, 2):
+        raise ValueError("llg_hinv_parts: inconsistent shapes")
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    if out is None:
+        out = torch.empty(B, 4, H, W, dtype=torch.float32, device=yt.device)
+    if work is None:
+        work = torch.empty(int(_lib.lib().mrx_llg_hinv_work_floats(B, C, H, W)), dtype=torch.float32, device=yt.device)
+    n = ctypes.c_int(0)
+    _lib.check(_lib.lib().mrx_llg_hinv_parts(_lib.ptr(eta), _lib.ptr(yt), _lib.ptr(sens), _lib.ptr(m), kind, ms, _lib.ptr(out),
+                                             _lib.ptr(work), ctypes.byref(n), B, C, H, W, float(1.0 / (float(sigma) ** 2.0)),
+                                             _norm(normalization), int(bool(centered)), _lib.stream_ptr()), "mrx_llg_hinv_parts")
+    return out, work, int(n.value)
+
+
+def rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None):
+    """The tuned fused first RIM layer reading log_likelihood_gradient's pieces (eta and the partial coil sums) directly."""
+    eta = _lib.f32c(eta)
+    B, H, W, _ = [int(v) for v in eta.shape]
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    if out is None:
+        out = torch.empty(B, F, H, W, dtype=torch.float32, device=eta.device)
+    _lib.check(_lib.lib().mrx_rim_layer_indrnn_packed_llg(_lib.ptr(eta), _lib.ptr(part), int(nparts), float(1.0 / (float(sigma) ** 2.0)),
+                                                          _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp),
+                                                          _lib.ptr(out), B, int(F), H, W, int(k), int(dilation), _lib.stream_ptr()),
+               "mrx_rim_layer_indrnn_packed_llg")
+    return out
+
+
 def soft_dc(pred, ref, mask, dc_weight):
     """where(mask, pred - ref, 0) * dc_weight."""
     pred, ref = _lib.f32c(pred), _lib.f32c(ref)
