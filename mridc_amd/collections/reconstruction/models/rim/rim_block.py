@@ -11,11 +11,13 @@ from mridc_amd.collections.reconstruction.models.rim import conv_layers, rim_uti
 class RIMBlock(torch.nn.Module):
     """Recurrent Inference Machine cascade.  2-D mode only (dimensionality=2, conv_dim=2, consecutive_slices=1).
 
-    Per time-step the HIP path is six launches: three for log_likelihood_gradient (mrx_llg), one fused
-    conv+IndRNN launch per recurrent layer (mrx_rim_layer_indrnn) and one for the final conv + eta update
-    (mrx_rim_final).  GRU / MGU layers with 1x1 gate kernels on 64 features (the model-zoo RIM config) are two launches: the
-    fused layer kernel with an identity `ih` as conv + ReLU, then the whole cell in one launch (mrx_gated_cell_1x1).  Other
-    shapes run through the unfused kernels (conv2d + cell).
+    Per time-step the HIP path is four launches for 1-D column masks: the one-launch log_likelihood_gradient
+    (mrx_llg_hinv_parts; its last pass -- coil-chunk sum, 1/sigma^2, channel split -- happens in the first layer's tile loader),
+    one fused conv+IndRNN launch per recurrent layer (mrx_rim_layer_indrnn_packed_llg, mrx_rim_layer_indrnn_wino) and one for the
+    final conv + eta update (mrx_rim_final); any other mask takes the general three-launch gradient (mrx_llg).  GRU / MGU layers
+    with 1x1 gate kernels on 64 features (the model-zoo RIM config) are two launches: a conv + ReLU launch, then the whole cell in
+    one launch (mrx_gated_cell_1x1).  Other shapes run through the unfused kernels (conv2d + cell).  In train() mode with gradients
+    enabled the cascade is recorded for the backward kernels instead (mridc_amd/autograd.py).
 
     `winograd` (default on; env MRIDC_AMD_WINOGRAD=0 turns it off): 3x3 dilation-2 layers into 64 features use the
     Winograd F(2x2,3x3) form of the fused kernel (mrx_rim_layer_indrnn_wino).  It differs from the direct form by fp32
