@@ -294,6 +294,13 @@ int mrx_absl1_loss_bwd(const float* p, const float* target, const float* maxabs,
 int mrx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale, void* stream);
 
+/* 1x1 convolution 64 -> 64 as a per-pixel GEMM on the matrix cores, HBM-bound: out = act(W x + bias [+ hh * h_prev]) with x, out,
+ * h_prev [B,64,HW]; the IndRNN cell with a 1x1 `ih` when hh / h_prev are given (rnn_cells.py:384-391), RecurrentInit's heads
+ * (recurrentvarnet.py:73-76), data gradients of 1x1 layers.  packed: 4096 floats from mrx_conv1x1_64_pack(w [64,64,1,1]). */
+int mrx_conv1x1_64_pack(const float* w, float* packed, void* stream);
+int mrx_conv1x1_64(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
+                   int B, int64_t HW, int act, float slope, void* stream);
+
 /* A17 NormUnet support (models/unet_base/unet_block.py).  Planes are [B*C] images of H*W floats.
  *   mrx_instance_norm_act   InstanceNorm2d (biased var, eps, no affine) + activation, in place allowed   (:252-253,:294-295)
  *   mrx_group_norm_stats    per-group mean and UNBIASED std over n contiguous floats                       (:78-79)

@@ -459,3 +459,140 @@ extern "C" int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const floa
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
+
+// ---- 1x1 convolution 64 -> 64 (a per-pixel 64x64 GEMM) with the IndRNN cell as an optional epilogue ---------------------------------
+//   out = act(W x + bias [+ hh * h_prev])      act: MRX_ACT_NONE / RELU / LEAKY
+// The ih stage of the IndRNN cell run on its own (training forward: rnn_cells.py:384-391), the data gradient of 1x1 layers (W^T as
+// weights), RecurrentInit's 1x1 heads (recurrentvarnet.py:73-76).  Same skeleton as the gated cells: x straight from HBM into the
+// B-operand layout, the 16 KB of packed weights in LDS for the life of the persistent workgroup, 64 MFMAs per 32 pixels -- the
+// kernel is HBM-bound (two or three 61 MB tensors at 640x372).
+struct Conv1x1Args {
+    const float* x;       // [B,64,P]
+    const float* packed;  // mrx_conv1x1_64_pack
+    const float* bias;    // [64] or null
+    const float* hh;      // [64] or null (IndRNN: + hh * h_prev)
+    const float* hprev;   // [B,64,P] or null
+    float* out;           // [B,64,P]
+    long long P, nsegb, nseg;
+    int act;
+    float slope;
+};
+__global__ void k_conv1x1_pack(const float* __restrict__ w, float* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < GC_F * GC_F; i += gridDim.x * blockDim.x) {
+        const int m = i & 31, half = (i >> 5) & 1, s = (i >> 6) & 31, mb = (i >> 11) & 1;
+        out[i] = w[(long long)(mb * 32 + m) * GC_F + 2 * s + half];
+    }
+}
+__global__ __launch_bounds__(GC_NT, 4) void k_conv1x1_64(Conv1x1Args a) {
+    __shared__ __attribute__((aligned(16))) float Ws[GC_F * GC_F + 2 * GC_F];
+    const int tid = threadIdx.x;
+    float* Bs = Ws + GC_F * GC_F;  // bias, hh
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.packed);
+        float4* dst = reinterpret_cast<float4*>(Ws);
+        for (int i = tid; i < GC_F * GC_F / 4; i += GC_NT) dst[i] = src[i];
+        if (tid < GC_F) {
+            Bs[tid] = a.bias ? a.bias[tid] : 0.f;
+            Bs[GC_F + tid] = a.hh ? a.hh[tid] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* wl = Ws + lane;
+    const long long stride = (long long)gridDim.x * (GC_NT / 64);
+    const unsigned P32 = (unsigned)a.P;
+    const float neg = a.act == MRX_ACT_RELU ? 0.f : (a.act == MRX_ACT_LEAKY ? a.slope : 1.f);
+    for (long long sg = (long long)blockIdx.x * (GC_NT / 64) + wave; sg < a.nseg; sg += stride) {
+        int l31 = lane & 31, lhi = lane >> 5;
+        asm volatile("" : "+v"(l31), "+v"(lhi));  // keep the channel offsets out of loop-invariant hoisting (spills)
+        const long long b = sg / a.nsegb;
+        const long long px = (sg - b * a.nsegb) * 32 + l31;
+        const bool valid = px < a.P;
+        const long long base = __builtin_amdgcn_readfirstlane((int)b) * (long long)GC_F * a.P;
+        const unsigned pxo = valid ? (unsigned)px : 0u;
+        const float* xb = a.x + base;
+        float xg[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) xg[s] = xb[(unsigned)(2 * s + lhi) * P32 + pxo];
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = Bs[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+        {
+            float ra0[GC_PF + 1], ra1[GC_PF + 1];
+#pragma unroll
+            for (int t = 0; t < 32 + GC_PF; ++t) {
+                if (t < 32) {
+                    ra0[t % (GC_PF + 1)] = wl[(0 * 32 + t) * 64];
+                    ra1[t % (GC_PF + 1)] = wl[(1 * 32 + t) * 64];
+                }
+                if (t >= GC_PF) {
+                    const int u = t - GC_PF, c = u % (GC_PF + 1);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], xg[u], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], xg[u], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float hv[2][16];  // loaded after the GEMM, into the registers x occupied (128-register budget: two workgroups per CU)
+        if (a.hprev) {
+            const float* hb = a.hprev + base;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hv[ct][r] = hb[(unsigned)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo];
+        }
+        float* ob = a.out + base;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc[ct][r];
+                if (a.hprev) v += Bs[GC_F + co] * hv[ct][r];
+                v = v > 0.f ? v : v * neg;
+                if (valid) ob[(unsigned)co * P32 + pxo] = v;
+            }
+    }
+}
+extern "C" int mrx_conv1x1_64_pack(const float* w, float* packed, void* stream) {
+    MRX_REQUIRE(w && packed, MRX_EINVAL, "mrx_conv1x1_64_pack: null pointer");
+    hipLaunchKernelGGL(k_conv1x1_pack, dim3(16), dim3(256), 0, (hipStream_t)stream, w, packed);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_conv1x1_64(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
+                              int B, int64_t HW, int act, float slope, void* stream) {
+    MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv1x1_64: null pointer");
+    MRX_REQUIRE(B >= 0 && HW >= 0 && HW < (1ll << 24) && B < (1 << 30), MRX_EINVAL, "mrx_conv1x1_64: bad dims");
+    MRX_REQUIRE(!h_prev || hh, MRX_EINVAL, "mrx_conv1x1_64: h_prev needs hh");
+    MRX_REQUIRE(act == MRX_ACT_NONE || act == MRX_ACT_RELU || act == MRX_ACT_LEAKY, MRX_EINVAL, "mrx_conv1x1_64: activation %d", act);
+    MRX_REQUIRE(out != x && out != h_prev, MRX_EINVAL, "mrx_conv1x1_64: out must not alias an input");
+    if (B == 0 || HW == 0) return MRX_OK;
+    Conv1x1Args a;
+    a.x = x;
+    a.packed = packed;
+    a.bias = bias;
+    a.hh = hh;
+    a.hprev = h_prev;
+    a.out = out;
+    a.P = HW;
+    a.nsegb = (HW + 31) / 32;
+    a.nseg = a.nsegb * B;
+    a.act = act;
+    a.slope = slope;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MRX_HIP(hipGetDevice(&dev));
+        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long nblk_need = (a.nseg + GC_NT / 64 - 1) / (GC_NT / 64);
+    const long long cap = 2ll * n_cu;  // two persistent workgroups per CU (16 KB of LDS, <= 128 registers)
+    hipLaunchKernelGGL(k_conv1x1_64, dim3((unsigned)(nblk_need < cap ? nblk_need : cap)), dim3(GC_NT), 0, (hipStream_t)stream, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

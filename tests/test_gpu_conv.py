@@ -356,3 +356,22 @@ def test_conv_to_complex_vs_oracle(dev, shape, pad_mode):
         got = ops.conv_to_complex(x.to(dev), w.to(dev), None if bias is None else bias.to(dev), 1, pm)
         assert got.is_contiguous()
         assert_close(got, ref, 1e-5, f"conv_to_complex {shape} {pad_mode} bias={bias is not None}")
+
+
+@pytest.mark.parametrize("shape", [(2, 13, 18), (1, 33, 70), (1, 40, 372), (3, 1, 5)])
+def test_conv1x1_64_vs_oracle(dev, shape):
+    """1x1 convolution 64 -> 64 as a per-pixel GEMM: plain, with bias + each activation, and as the IndRNN cell (hh * h_prev + ReLU);
+    ops.conv2d and ops.indrnn_cell route this shape to it."""
+    from mridc_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(3 + H)
+    x, hp = torch.randn(B, 64, H, W, generator=g), torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(64, 64, 1, 1, generator=g) / 8
+    b, hh = torch.randn(64, generator=g), torch.randn(1, 64, 1, 1, generator=g)
+    ref = F.conv2d(x, w, b)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    assert_close(ops.conv1x1_64(xd, wd, bd), ref, 1e-5, f"1x1 {shape}")
+    assert_close(ops.conv2d(xd, wd, None, 1, ops.PAD_ZERO), F.conv2d(x, w), 1e-5, "conv2d dispatch, no bias")
+    assert_close(ops.conv2d(xd, wd, bd, 1, ops.PAD_ZERO, ops.ACT_LEAKY, 0.1), F.leaky_relu(ref, 0.1), 1e-5, "leaky")
+    assert_close(ops.indrnn_cell(xd, wd, bd, hh.to(dev), hp.to(dev), 1), oracle.rim.indrnn_cell(x, hp, w, b, hh, 1, 1), 1e-5, "IndRNN cell")
+    assert_close(ops.indrnn_cell(xd, wd, None, hh.to(dev), None, 1), F.relu(F.conv2d(x, w)), 1e-5, "IndRNN cell, zero state")
