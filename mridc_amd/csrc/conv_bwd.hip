@@ -35,6 +35,7 @@ struct WgradArgs {
     const float* dy;  // [B,64,H,W]
     float* part;      // [gridDim.x][64][N]
     int B, Cin, H, W, k, dil, pad, pad_mode, N, tiles_x, ntiles, XS, PH;
+    int vec;  // W % 4 == 0 and 16-byte aligned x / dy: float4 tile loads
 };
 
 template <int PAD>
@@ -77,27 +78,81 @@ __global__ __launch_bounds__(WG_NT, 2) void k_conv_wgrad64(WgradArgs a) {
         const int b = (int)(v / a.ntiles), t = (int)(v - (long long)b * a.ntiles);
         const int ty0 = t / a.tiles_x, h0 = ty0 * WG_TH, w0 = (t - ty0 * a.tiles_x) * WG_TW;
         __syncthreads();  // the previous tile's operands are consumed
-        // dy tile: zeros outside the image (ragged tiles contribute nothing)
+        // dy tile: zeros outside the image (ragged tiles contribute nothing).  W % 4 == 0 (a.vec): aligned float4 loads
         const float* dyb = a.dy + (long long)b * 64 * plane;
-        for (int i = tid; i < 64 * WG_PX; i += WG_NT) {
-            const int co = i / WG_PX, px = i - co * WG_PX, r = px >> 5, c = px & 31;
-            const int gy = h0 + r, gx = w0 + c;
-            Dy[co * WG_DYS + px] = (gy < a.H && gx < a.W) ? dyb[(long long)co * plane + (long long)gy * a.W + gx] : 0.f;
+        if (a.vec) {
+            for (int i = tid; i < 64 * WG_PX / 4; i += WG_NT) {
+                const int co = i >> 5, q = i & 31, r = q >> 3, c = (q & 7) * 4;
+                const int gy = h0 + r, gx = w0 + c;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy < a.H && gx < a.W) v = *reinterpret_cast<const float4*>(dyb + (long long)co * plane + (long long)gy * a.W + gx);
+                float* d = Dy + co * WG_DYS + r * 32 + c;
+                d[0] = v.x;
+                d[1] = v.y;
+                d[2] = v.z;
+                d[3] = v.w;
+            }
+        } else {
+            for (int i = tid; i < 64 * WG_PX; i += WG_NT) {
+                const int co = i / WG_PX, px = i - co * WG_PX, r = px >> 5, c = px & 31;
+                const int gy = h0 + r, gx = w0 + c;
+                Dy[co * WG_DYS + px] = (gy < a.H && gx < a.W) ? dyb[(long long)co * plane + (long long)gy * a.W + gx] : 0.f;
+            }
         }
         // x tile with its halo: replicate (clamped) or zero border
         const float* xb = a.x + (long long)b * a.Cin * plane;
-        for (int i = tid; i < a.Cin * PH * PW; i += WG_NT) {
-            const int ci = i / (PH * PW), rem = i - ci * (PH * PW), r = rem / PW, c = rem - r * PW;
-            int gy = h0 + r - PAD, gx = w0 + c - PAD;
-            float vv = 0.f;
-            if (a.pad_mode == MRX_PAD_REPLICATE) {
+        const bool rep = a.pad_mode == MRX_PAD_REPLICATE;
+        if (a.vec) {
+            // interior columns [w0, w0 + 32): 8 aligned float4 per row (rows clamped or zeroed); a group straddling the right image
+            // edge cannot exist (W % 4 == 0), a group past it is the replicated last column or zero
+            for (int i = tid; i < a.Cin * PH * 8; i += WG_NT) {
+                const int ci = i / (PH * 8), rem = i - ci * (PH * 8), r = rem >> 3, c = (rem & 7) * 4;
+                int gy = h0 + r - PAD;
+                const int gx = w0 + c;
+                const bool rok = gy >= 0 && gy < a.H;
                 gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-                vv = xb[(long long)ci * plane + (long long)gy * a.W + gx];
-            } else if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                vv = xb[(long long)ci * plane + (long long)gy * a.W + gx];
+                const float* row = xb + (long long)ci * plane + (long long)gy * a.W;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rep || rok) {
+                    if (gx < a.W) v = *reinterpret_cast<const float4*>(row + gx);
+                    else if (rep) v.x = v.y = v.z = v.w = row[a.W - 1];
+                }
+                float* d = Xs + ci * PLANE + r * XS + PAD + c;
+                d[0] = v.x;
+                d[1] = v.y;
+                d[2] = v.z;
+                d[3] = v.w;
             }
-            Xs[ci * PLANE + r * XS + c] = vv;
+            if (PAD > 0) {  // the 2 * PAD halo columns of every row
+                for (int i = tid; i < a.Cin * PH * 2 * PAD; i += WG_NT) {
+                    const int ci = i / (PH * 2 * PAD), rem = i - ci * (PH * 2 * PAD), r = rem / (2 * PAD), j = rem - r * (2 * PAD);
+                    const int c = j < PAD ? j : WG_TW + j;  // tile column
+                    int gy = h0 + r - PAD, gx = w0 + c - PAD;
+                    float vv = 0.f;
+                    if (rep) {
+                        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                        gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                        vv = xb[(long long)ci * plane + (long long)gy * a.W + gx];
+                    } else if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                        vv = xb[(long long)ci * plane + (long long)gy * a.W + gx];
+                    }
+                    Xs[ci * PLANE + r * XS + c] = vv;
+                }
+            }
+        } else {
+            for (int i = tid; i < a.Cin * PH * PW; i += WG_NT) {
+                const int ci = i / (PH * PW), rem = i - ci * (PH * PW), r = rem / PW, c = rem - r * PW;
+                int gy = h0 + r - PAD, gx = w0 + c - PAD;
+                float vv = 0.f;
+                if (rep) {
+                    gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                    gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                    vv = xb[(long long)ci * plane + (long long)gy * a.W + gx];
+                } else if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    vv = xb[(long long)ci * plane + (long long)gy * a.W + gx];
+                }
+                Xs[ci * PLANE + r * XS + c] = vv;
+            }
         }
         __syncthreads();
         // 64 steps of two pixels (row s >> 4, columns 2 (s & 15) + parity): the dy operands are shared by the wave's column blocks;
@@ -283,6 +338,7 @@ extern "C" int mrx_conv_wgrad(const float* x, const float* dy, float* dw, float*
         a.N = (int)N;
         a.tiles_x = mrx_cdiv(W, WG_TW);
         a.ntiles = a.tiles_x * mrx_cdiv(H, WG_TH);
+        a.vec = (W & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
         MRX_REQUIRE(pad <= 2, MRX_EUNSUP, "mrx_conv_wgrad: padding %d (k=%d dil=%d; up to 2)", pad, k, dil);
         a.PH = WG_TH + 2 * pad;
         a.XS = (WG_TW + 2 * pad) | 1;  // odd row stride
