@@ -283,6 +283,97 @@ __global__ __launch_bounds__(CV_NT) void k_conv_small(SmallArgs s) {
     }
 }
 
+// ---- small-Cout conv, four pixels per thread (K = 3 or 5, dilation 1; the data gradient of the first RIM layer: 64 -> 4, 5x5) ----
+// Workgroup = 4 waves on an 8 x 32 pixel tile.  A lane owns 4 consecutive pixels of a row and all CO outputs; the four waves
+// split the input channels of a chunk (partial sums meet in LDS at the end), so the grid keeps ~4 waves per 256 pixels.  Per
+// channel a lane reads its K x 12 patch window from LDS as float4s (15 reads for K = 5) and issues 4 * K * K * CO FMAs with the
+// weights in scalar registers (wave-uniform loads): 1 LDS access per ~27 FMAs instead of 1 per CO.
+#define P4_NT 256
+#define P4_TH 8
+#define P4_TW 32
+#define P4_CK 16
+template <int CO, int K>
+__global__ __launch_bounds__(P4_NT) void k_conv_small_px4(SmallArgs s) {
+    constexpr int PAD = (K - 1) / 2, PH = P4_TH + 2 * PAD, XS = P4_TW + 8;  // tile columns [w0 - 4, w0 + 36): float4-aligned rows
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Xs = smem_f;  // [P4_CK][PH][XS]; afterwards the partial-sum exchange [3][64][CO * 4]
+    const int tile = blockIdx.x, ty0 = tile / s.tiles_x;
+    const int h0 = ty0 * P4_TH, w0 = (tile - ty0 * s.tiles_x) * P4_TW;
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = lane & 7, ty = lane >> 3;
+    const long long plane = (long long)s.H * s.W;
+    const float* xb = s.x + (long long)b * s.Cin * plane;
+    const bool rep = s.pad_mode == MRX_PAD_REPLICATE;
+    float acc[CO][4];
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[o][i] = 0.f;
+    for (int c0 = 0; c0 < s.Cin; c0 += P4_CK) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < P4_CK * PH * XS; idx += P4_NT) {
+            const int ci = idx / (PH * XS), rem = idx - ci * (PH * XS), r = rem / XS, c = rem - r * XS;
+            int gy = h0 + r - PAD, gx = w0 + c - 4;
+            float v = 0.f;
+            if (c0 + ci < s.Cin) {
+                if (rep) {
+                    gy = gy < 0 ? 0 : (gy >= s.H ? s.H - 1 : gy);
+                    gx = gx < 0 ? 0 : (gx >= s.W ? s.W - 1 : gx);
+                    v = xb[(long long)(c0 + ci) * plane + (long long)gy * s.W + gx];
+                } else if (gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) {
+                    v = xb[(long long)(c0 + ci) * plane + (long long)gy * s.W + gx];
+                }
+            }
+            Xs[idx] = v;
+        }
+        __syncthreads();
+        for (int cj = wave; cj < P4_CK && c0 + cj < s.Cin; cj += 4) {  // this wave's channels of the chunk
+            const float* xp = Xs + (cj * PH + ty) * XS + 4 * tx;  // tile column 4 tx = image column w0 + 4 tx - 4
+            const float* wp = s.w + (long long)(c0 + cj) * (K * K);  // w[o][cin][tap]: + o * Cin * K * K (wave-uniform -> scalar loads)
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const float4 v0 = *reinterpret_cast<const float4*>(xp + ky * XS);
+                const float4 v1 = *reinterpret_cast<const float4*>(xp + ky * XS + 4);
+                const float4 v2 = *reinterpret_cast<const float4*>(xp + ky * XS + 8);
+                const float v[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) {
+                        const float wv = wp[(long long)o * s.Cin * (K * K) + ky * K + kx];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[o][i] += wv * v[4 - PAD + kx + i];  // output pixel i, tap kx: column 4 + i + kx - PAD
+                    }
+            }
+        }
+    }
+    __syncthreads();  // tiles consumed: LDS becomes the partial-sum exchange
+    float* Rx = smem_f;
+    if (wave > 0) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Rx[(((wave - 1) * 64 + lane) * CO + o) * 4 + i] = acc[o][i];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int oy = h0 + ty, ox = w0 + 4 * tx;
+    if (oy >= s.H) return;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        const float bv = s.bias ? s.bias[o] : 0.f;
+        float* yo = s.y + (((long long)b * CO + o) * s.H + oy) * s.W + ox;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[o][i];
+#pragma unroll
+            for (int wv = 0; wv < 3; ++wv) v += Rx[((wv * 64 + lane) * CO + o) * 4 + i];
+            if (ox + i < s.W) yo[i] = v + bv;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
@@ -382,6 +473,23 @@ static int launch_small(const float* x, const float* w, const float* bias, const
     size_t lds;
     int rc = conv_geometry(Cin, k, dil, 0, &s.CK, &s.PH, &s.PW, &s.pad, &lds);
     if (rc) return rc;
+    if (mode == 0 && dil == 1 && (k == 3 || k == 5) && (Cout == 2 || Cout == 4) && Cin >= 8 && !getenv("MRX_CONV_SMALL_OLD")) {
+        s.tiles_x = mrx_cdiv(W, P4_TW);
+        dim3 g4(s.tiles_x * mrx_cdiv(H, P4_TH), 1, B);
+        const size_t lds4 = sizeof(float) * P4_CK * (P4_TH + k - 1) * (P4_TW + 8);
+#define PX4_CASE(CO, KK)                                                                   \
+    do {                                                                                   \
+        if ((rc = conv_set_lds(k_conv_small_px4<CO, KK>, lds4))) return rc;                \
+        hipLaunchKernelGGL((k_conv_small_px4<CO, KK>), g4, dim3(P4_NT), lds4, st, s);      \
+    } while (0)
+        if (Cout == 2 && k == 3) PX4_CASE(2, 3);
+        else if (Cout == 2) PX4_CASE(2, 5);
+        else if (k == 3) PX4_CASE(4, 3);
+        else PX4_CASE(4, 5);
+#undef PX4_CASE
+        MRX_LAUNCH_CHECK();
+        return MRX_OK;
+    }
     s.tiles_x = mrx_cdiv(W, CV_TW);
     dim3 grid(s.tiles_x * mrx_cdiv(H, CV_TH), 1, B);
 #define SMALL_CASE(CO, MODE)                                                             \
