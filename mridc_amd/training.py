@@ -75,6 +75,10 @@ class AdamFlat:
         _lib.check(_lib.lib().mrx_adam_step(_lib.ptr(f.flat), _lib.ptr(f.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), f.numel,
                                             self.lr, self.betas[0], self.betas[1], self.eps, self.steps, float(grad_scale),
                                             _lib.stream_ptr()), "mrx_adam_step")
+        # the kernel wrote the parameters behind torch's back: bump their version counters, which is what the packed-weight caches
+        # (Winograd / 1x1 / fused-layer packs) and autograd's saved-tensor checks key on
+        for p in f.params:
+            torch.autograd.graph.increment_version(p)
 
 
 def inverse_sqrt_lr(step, max_steps, base_lr, warmup_ratio=0.1, min_lr=0.0):

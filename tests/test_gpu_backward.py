@@ -138,3 +138,13 @@ def test_training_step_matches_torch_adam(dev):
             assert_close(p.data, sp.data, 1e-6, "parameter after the Adam step")
     assert losses[1] < losses[0], losses
     assert flat.flat.numel() == sum(p.numel() for p in model.parameters())
+    # the updated weights are the ones the kernels use next (packed-weight caches are keyed on the parameter versions the
+    # optimizer bumps): the eval forward equals the oracle's on the current state_dict
+    import oracle
+    model.eval()
+    cur = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        out = next(model(batch["y"], batch["sensitivity_maps"], batch["mask"], None, batch["target"]))
+    ref = oracle.models.cirim_forward(cur, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"])
+    assert_close(torch.view_as_real(out[-1][-1]), torch.view_as_real(ref[-1][-1]), 1e-4, "forward after two optimizer steps")
+    assert any(not torch.equal(cur[k], state[k]) for k in state), "the optimizer moved the parameters"
