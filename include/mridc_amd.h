@@ -101,6 +101,14 @@ int mrx_sens_expand(const float* x, const float* S, float* out, int B, int C, in
  * then k is destroyed). */
 int mrx_sens_reduce(const float* k, const float* S, float* out, float* work, int B, int C, int H, int W,
                     int norm, int centered, void* stream);
+/* Row-transform-only forms for row-invariant (1-D column) masks, on k-space kept in hybrid space kh = IFFT_H(k) (mrx_fft_cols once
+ * per slice): masked data consistency commutes with the H transform, so a cascade (vn_block.py:89-119, ccnn_block.py:101-139) runs
+ * as mrx_sens_reduce_rows -> regulariser -> mrx_sens_expand_rows -> mrx_dc_combine on kh, and the final SENSE combination of
+ * ifft2(k) is mrx_sens_reduce_rows(kh). */
+int mrx_sens_expand_rows(const float* x, const float* S, float* out, int B, int C, int H, int W, int norm, int centered,
+                         void* stream);
+int mrx_sens_reduce_rows(const float* kh, const float* S, float* out, int B, int C, int H, int W, int norm, int centered,
+                         void* stream);
 
 /* A9  log_likelihood_gradient (models/rim/rim_utils.py:11-67), three launches:
  *     rows: eta*S -> FFT_W ; cols: FFT_H -> mask*(k - y) -> IFFT_H ; rows: IFFT_W -> sum_c conj(S) -> /sigma^2.

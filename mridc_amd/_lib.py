@@ -71,6 +71,8 @@ _SIGNATURES = {
     "mrx_rim_layer_indrnn_packed_llg": ([_p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_conv1x1_64_pack": ([_p, _p, _p], _i),
     "mrx_conv1x1_64": ([_p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p], _i),
+    "mrx_sens_expand_rows": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_sens_reduce_rows": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_hard_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_vs_average": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),

@@ -21,16 +21,18 @@ class CascadeNetBlock(torch.nn.Module):
         self.coil_dim = coil_dim
         self.no_dc = no_dc
         self.dc_weight = torch.nn.Parameter(torch.ones(1))
+        self._hybrid = False   # set by the model for row-invariant masks: k-space arguments are IFFT_H(k), row transforms only
         if coil_dim != 1:
             raise NotImplementedError("the HIP path expects the coil dimension at index 1")
 
     def sens_expand(self, x: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
         """ccnn_block.py:56-77."""
-        return ops.sens_expand(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        return ops.sens_expand(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims, hybrid=self._hybrid)
 
     def sens_reduce(self, x: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
         """ccnn_block.py:79-99 (keepdim on the coil axis)."""
-        return ops.sens_reduce(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims).unsqueeze(1)
+        return ops.sens_reduce(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims,
+                               hybrid=self._hybrid).unsqueeze(1)
 
     def forward(self, pred: torch.Tensor, ref_kspace: torch.Tensor, sens_maps: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         """ccnn_block.py:101-139."""

@@ -1,6 +1,7 @@
 """Drop-in for `mridc.collections.reconstruction.models.vn.VarNet` (reference vn.py:22-142), inference path."""
 import torch
 
+from mridc_amd import ops
 import mridc_amd.collections.common.parts.fft as fft
 import mridc_amd.collections.common.parts.utils as utils
 from mridc_amd.collections.reconstruction.models import _cfg
@@ -38,16 +39,40 @@ class VarNet(torch.nn.Module):
         self.dc_weight = torch.nn.Parameter(torch.ones(1))          # vn.py:91
         self.accumulate_estimates = False
 
+
+    def _hybrid_ok(self, mask):
+        """Row-invariant (1-D column) mask + SENSE combination: the masked data consistency commutes with the H transform, so the
+        cascades can run on IFFT_H(k) with row transforms only (`MRIDC_AMD_HYBRID=0` turns this off)."""
+        import os
+        return (os.environ.get("MRIDC_AMD_HYBRID", "1") != "0" and self.coil_dim == 1
+                and str(self.coil_combination_method).upper() == "SENSE" and ops.mask_is_row_invariant(mask))
+
+    def _forward_hybrid(self, y, sensitivity_maps, mask):
+        """The cascades on kh = IFFT_H(k): every block is sens_reduce_rows -> regulariser -> sens_expand_rows -> dc_combine, and the
+        SENSE combination of ifft2(k) at the end is one more sens_reduce_rows.  Same function as the k-space form, half the FFT work."""
+        yh = ops.llg_prepare(y, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        est = yh
+        for cascade in self.cascades:
+            cascade._hybrid = True
+            try:
+                est = cascade(est, yh, sensitivity_maps, mask)
+            finally:
+                cascade._hybrid = False
+        return ops.sens_reduce(est, sensitivity_maps, self.fft_centered, self.fft_normalization, self.spatial_dims, hybrid=True)
+
     def forward(self, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask: torch.Tensor, init_pred: torch.Tensor,
                 target: torch.Tensor) -> torch.Tensor:
         """vn.py:94-142."""
-        estimation = y.clone()
-        for cascade in self.cascades:
-            estimation = cascade(estimation, y, sensitivity_maps, mask)
-        estimation = fft.ifft2(estimation, centered=self.fft_centered, normalization=self.fft_normalization,
-                               spatial_dims=self.spatial_dims)
-        estimation = utils.coil_combination(estimation, sensitivity_maps, method=self.coil_combination_method,
-                                            dim=self.coil_dim)
+        if self._hybrid_ok(mask):
+            estimation = self._forward_hybrid(y, sensitivity_maps, mask)
+        else:
+            estimation = y.clone()
+            for cascade in self.cascades:
+                estimation = cascade(estimation, y, sensitivity_maps, mask)
+            estimation = fft.ifft2(estimation, centered=self.fft_centered, normalization=self.fft_normalization,
+                                   spatial_dims=self.spatial_dims)
+            estimation = utils.coil_combination(estimation, sensitivity_maps, method=self.coil_combination_method,
+                                                dim=self.coil_dim)
         estimation = torch.view_as_complex(estimation)
         _, estimation = utils.center_crop_to_smallest(target, estimation)
         return estimation

@@ -1231,6 +1231,27 @@ extern "C" int mrx_sens_expand(const float* x, const float* S, float* out, int B
     return launch_cols((float2*)out, (float2*)out, (long long)B * C, H, W, 0, norm, centered, st);
 }
 
+// Hybrid-space forms for row-invariant (1-D column) masks: with k-space kept as kh = IFFT_H(k) (mrx_fft_cols, once per slice), every
+// masked data-consistency step commutes with the H transform, so the cascades need row transforms only:
+//   mrx_sens_expand_rows   out = FFT_W(x * S)            (= IFFT_H of mrx_sens_expand)
+//   mrx_sens_reduce_rows   out = sum_c IFFT_W(kh) conj(S) (= mrx_sens_reduce of the k-space kh stands for)
+extern "C" int mrx_sens_expand_rows(const float* x, const float* S, float* out, int B, int C, int H, int W, int norm, int centered,
+                                    void* stream) {
+    MRX_REQUIRE(x && S && out, MRX_EINVAL, "mrx_sens_expand_rows: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_sens_expand_rows: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_sens_expand_rows: bad normalization %d", norm);
+    if (B == 0) return MRX_OK;
+    return launch_rows((const float2*)x, (const float2*)S, (float2*)out, (long long)B * C, W, C, H, 0, norm, centered, 1,
+                       (hipStream_t)stream);
+}
+extern "C" int mrx_sens_reduce_rows(const float* kh, const float* S, float* out, int B, int C, int H, int W, int norm, int centered,
+                                    void* stream) {
+    MRX_REQUIRE(kh && S && out, MRX_EINVAL, "mrx_sens_reduce_rows: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_sens_reduce_rows: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_sens_reduce_rows: bad normalization %d", norm);
+    if (B == 0) return MRX_OK;
+    return launch_reduce((const float2*)kh, (const float2*)S, nullptr, out, B, C, H, W, norm, centered, 1.0f, 0, (hipStream_t)stream);
+}
 extern "C" int mrx_sens_reduce(const float* k, const float* S, float* out, float* work, int B, int C, int H, int W,
                                int norm, int centered, void* stream) {
     MRX_REQUIRE(k && S && out && work, MRX_EINVAL, "mrx_sens_reduce: null pointer");

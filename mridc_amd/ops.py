@@ -32,8 +32,9 @@ def _bchw(t):
     return int(t.shape[0]), int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
 
 
-def sens_expand(x, sens, centered, normalization, spatial_dims=None):
-    """fft2(complex_mul(x, S)).  x [B,H,W,2] or [B,1,H,W,2]; S [B,C,H,W,2] -> [B,C,H,W,2]."""
+def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=False):
+    """fft2(complex_mul(x, S)).  x [B,H,W,2] or [B,1,H,W,2]; S [B,C,H,W,2] -> [B,C,H,W,2].  `hybrid`: the W transform only
+    (k-space kept as IFFT_H(k) for row-invariant masks: mrx_sens_expand_rows)."""
     sens = _lib.f32c(sens)
     B, C, H, W = _bchw(sens)
     _check_last_two(spatial_dims, 4)
@@ -43,18 +44,24 @@ def sens_expand(x, sens, centered, normalization, spatial_dims=None):
     if tuple(x.shape) != (B, H, W, 2):
         raise ValueError(f"sens_expand: image shape {tuple(x.shape)} does not match maps {tuple(sens.shape)}")
     out = torch.empty_like(sens)
-    _lib.check(_lib.lib().mrx_sens_expand(_lib.ptr(x), _lib.ptr(sens), _lib.ptr(out), B, C, H, W, _norm(normalization),
-                                          int(bool(centered)), _lib.stream_ptr()), "mrx_sens_expand")
+    fn = _lib.lib().mrx_sens_expand_rows if hybrid else _lib.lib().mrx_sens_expand
+    _lib.check(fn(_lib.ptr(x), _lib.ptr(sens), _lib.ptr(out), B, C, H, W, _norm(normalization), int(bool(centered)), _lib.stream_ptr()),
+               "mrx_sens_expand")
     return out
 
 
-def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None):
-    """sum_c ifft2(k) * conj(S) -> [B,H,W,2]."""
+def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None, hybrid=False):
+    """sum_c ifft2(k) * conj(S) -> [B,H,W,2].  `hybrid`: k is IFFT_H of the k-space already (mrx_sens_reduce_rows)."""
     k, sens = _lib.f32c(k), _lib.f32c(sens)
     B, C, H, W = _bchw(k)
     if sens.shape != k.shape:
         raise ValueError(f"sens_reduce: k-space {tuple(k.shape)} vs maps {tuple(sens.shape)}")
     _check_last_two(spatial_dims, 4)
+    if hybrid:
+        out = torch.empty(B, H, W, 2, dtype=torch.float32, device=k.device)
+        _lib.check(_lib.lib().mrx_sens_reduce_rows(_lib.ptr(k), _lib.ptr(sens), _lib.ptr(out), B, C, H, W, _norm(normalization),
+                                                   int(bool(centered)), _lib.stream_ptr()), "mrx_sens_reduce_rows")
+        return out
     if work is None:
         work = torch.empty_like(k)
     out = torch.empty(B, H, W, 2, dtype=torch.float32, device=k.device)

@@ -275,3 +275,30 @@ def test_conv2dgru_64_one_launch_cell(dev, monkeypatch):
         assert_close(gs, rs, 2e-5, f"Conv2dGRU-64 states, {what}")
     assert_close(got1[0], unf1[0], 2e-5, "one launch vs unfused, output")
     assert_close(got1[1], unf1[1], 2e-5, "one launch vs unfused, states")
+
+
+@pytest.mark.gpu
+def test_hybrid_space_cascades_equal_kspace_cascades(golden, dev, monkeypatch):
+    """Row-invariant masks: VarNet / CascadeNet run their cascades on IFFT_H(k) with row transforms only.  Same outputs as the k-space
+    form (MRIDC_AMD_HYBRID=0), which is the one the goldens pin; a 2-D mask takes the k-space form by itself."""
+    from mridc_amd import ops
+    from mridc_amd.collections.reconstruction.models.ccnn import CascadeNet
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    z8, z15 = golden("g8_models.npz"), golden("g15_cascadenet.npz")
+    for cls, z, pre in ((VarNet, z8, "vn"), (CascadeNet, z15, "model")):
+        cfg = meta(z, f"{pre}/cfg")
+        model = cls(cfg)
+        model.load_state_dict(weights(z, f"{pre}/w/"), strict=False)
+        model = model.to(dev).eval()
+        y, S, mask, target = (T(z[f"{pre}/{k}"]).to(dev) for k in ("y", "S", "mask", "target"))
+        assert model._hybrid_ok(mask)
+        with torch.no_grad():
+            hyb = model(y, S, mask, None, target)
+            monkeypatch.setenv("MRIDC_AMD_HYBRID", "0")
+            assert not model._hybrid_ok(mask)
+            ksp = model(y, S, mask, None, target)
+            monkeypatch.delenv("MRIDC_AMD_HYBRID")
+        assert_close(hyb, ksp, 2e-5, f"{cls.__name__}: hybrid-space vs k-space cascades")
+        assert_close(hyb, T(z[f"{pre}/out"]), 1e-4, f"{cls.__name__}: hybrid-space cascades vs the reference")
+        m2 = (torch.rand(1, 1, y.shape[2], y.shape[3], 1, device=dev) < 0.4)
+        assert not model._hybrid_ok(m2) and not ops.mask_is_row_invariant(m2)
