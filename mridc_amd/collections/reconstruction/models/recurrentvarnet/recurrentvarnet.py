@@ -60,16 +60,19 @@ class RecurrentVarNetBlock(nn.Module):
         self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
         self.coil_dim = coil_dim
         self.learning_rate = nn.Parameter(torch.tensor([1.0]))
+        self._hybrid = False   # set by RecurrentVarNet for row-invariant masks: k-space arguments are IFFT_H(k), row transforms only
         self.regularizer = conv2gru.Conv2dGRU(in_channels=in_channels, hidden_channels=hidden_channels, num_layers=num_layers,
                                               replication_padding=True)
 
     def forward(self, current_kspace: torch.Tensor, masked_kspace: torch.Tensor, sampling_mask: torch.Tensor,
                 sensitivity_map: torch.Tensor, hidden_state: Union[None, torch.Tensor, List[torch.Tensor]]):
-        img = ops.sens_reduce(current_kspace, sensitivity_map, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        img = ops.sens_reduce(current_kspace, sensitivity_map, self.fft_centered, self.fft_normalization, self.spatial_dims,
+                              hybrid=self._hybrid)
         term, hidden_state = self.regularizer(img.permute(0, 3, 1, 2), hidden_state, _complex_last=True)   # [B,H,W,2]
         # the update needs "+ F(S w)": the transform is linear, so expand -w and let the data-consistency kernel subtract it
         # (k - alpha * err - (-t) rounds exactly like k - alpha * err + t)
         neg = ops.scale(term, -1.0)
-        minus_term = ops.sens_expand(neg, sensitivity_map, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        minus_term = ops.sens_expand(neg, sensitivity_map, self.fft_centered, self.fft_normalization, self.spatial_dims,
+                                     hybrid=self._hybrid)
         new_kspace = ops.dc_combine(current_kspace, current_kspace, masked_kspace, sampling_mask != 0, self.learning_rate, minus_term)
         return new_kspace, hidden_state

@@ -74,12 +74,25 @@ class RecurrentVarNet(torch.nn.Module):
             previous_state = self.initializer(k.permute(0, 3, 1, 2), as_list=True)
         if previous_state is None:
             previous_state = [None] * self.recurrent_num_layers          # zero state, kept as a per-layer list between the blocks
-        kspace_prediction = y.clone()
+        import os
+        hybrid = (os.environ.get("MRIDC_AMD_HYBRID", "1") != "0" and self.coil_dim == 1
+                  and str(self.coil_combination_method).upper() == "SENSE" and ops.mask_is_row_invariant(mask))
+        # row-invariant mask: the k-space update commutes with the H transform -- the steps run on IFFT_H(k) with row transforms only
+        y_k = ops.llg_prepare(y, self.fft_centered, self.fft_normalization, self.spatial_dims) if hybrid else y
+        kspace_prediction = y_k.clone()
         for step in range(self.num_steps):
             block = self.block_list[step] if self.no_parameter_sharing else self.block_list[0]
-            kspace_prediction, previous_state = block(kspace_prediction, y, mask, sensitivity_maps, previous_state)
-        eta = fft.ifft2(kspace_prediction, **kw)
-        eta = utils.coil_combination(eta, sensitivity_maps, method=self.coil_combination_method, dim=self.coil_dim)
+            block._hybrid = hybrid
+            try:
+                kspace_prediction, previous_state = block(kspace_prediction, y_k, mask, sensitivity_maps, previous_state)
+            finally:
+                block._hybrid = False
+        if hybrid:
+            eta = ops.sens_reduce(kspace_prediction, sensitivity_maps, self.fft_centered, self.fft_normalization, self.spatial_dims,
+                                  hybrid=True)
+        else:
+            eta = fft.ifft2(kspace_prediction, **kw)
+            eta = utils.coil_combination(eta, sensitivity_maps, method=self.coil_combination_method, dim=self.coil_dim)
         eta = torch.view_as_complex(eta)
         _, eta = utils.center_crop_to_smallest(target, eta)
         return eta

@@ -52,6 +52,7 @@ class VSNetBlock(torch.nn.Module):
         self.fft_normalization = fft_normalization
         self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
         self.coil_dim = coil_dim
+        self._hybrid = False   # set by VSNet for row-invariant masks: k-space arguments are IFFT_H(k), row transforms only
         if coil_dim != 1:
             raise NotImplementedError("the HIP path expects the coil dimension at index 1")
 
@@ -61,11 +62,11 @@ class VSNetBlock(torch.nn.Module):
         if x.dim() == 4 and x.shape[0] != 1:
             raise NotImplementedError("VSNetBlock: the reference's [B,H,W,2] x [B,C,H,W,2] broadcast is only defined for batch 1 "
                                       "(or batch == coils, which is not reproduced)")
-        return ops.sens_expand(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        return ops.sens_expand(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims, hybrid=self._hybrid)
 
     def sens_reduce(self, x: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
         """vsnet_block.py:103-116 (no keepdim)."""
-        return ops.sens_reduce(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        return ops.sens_reduce(x, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims, hybrid=self._hybrid)
 
     def forward(self, kspace: torch.Tensor, sens_maps: torch.Tensor, mask: torch.Tensor) -> List[Union[torch.Tensor, Any]]:
         """vsnet_block.py:118-146."""

@@ -56,6 +56,8 @@ class VSNet(torch.nn.Module):
                 target: torch.Tensor) -> torch.Tensor:
         """vsnet.py:115-167."""
         sensitivity_maps = self.sens_net(y, mask) if self.use_sens_net else sensitivity_maps
+        # (no hybrid-space form here: the block adds the coil-combined IMAGE sx to K-SPACE, vsnet_block.py:145, which does not
+        # commute with a transform along H)
         image = self.model(y, sensitivity_maps, mask)
         image = torch.view_as_complex(utils.coil_combination(
             fft.ifft2(image, centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims),

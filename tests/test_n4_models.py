@@ -302,3 +302,17 @@ def test_hybrid_space_cascades_equal_kspace_cascades(golden, dev, monkeypatch):
         assert_close(hyb, T(z[f"{pre}/out"]), 1e-4, f"{cls.__name__}: hybrid-space cascades vs the reference")
         m2 = (torch.rand(1, 1, y.shape[2], y.shape[3], 1, device=dev) < 0.4)
         assert not model._hybrid_ok(m2) and not ops.mask_is_row_invariant(m2)
+    # the Recurrent VarNet takes the same route (VSNet cannot: it adds an image to k-space, vsnet_block.py:145)
+    from mridc_amd.collections.reconstruction.models.rvn import RecurrentVarNet
+    for cls, z, pre in ((RecurrentVarNet, golden("g18_rvn.npz"), "model_shared"), (RecurrentVarNet, golden("g18_rvn.npz"), "model_unshared")):
+        cfg = meta(z, f"{pre}/cfg")
+        model = cls(cfg)
+        model.load_state_dict(weights(z, f"{pre}/w/"))
+        model = model.to(dev).eval()
+        y, S, mask, target = (T(z[f"{pre}/{k}"]).to(dev) for k in ("y", "S", "mask", "target"))
+        with torch.no_grad():
+            hyb = model(y, S, mask, None, target)
+            monkeypatch.setenv("MRIDC_AMD_HYBRID", "0")
+            ksp = model(y, S, mask, None, target)
+            monkeypatch.delenv("MRIDC_AMD_HYBRID")
+        assert_close(hyb, ksp, 5e-5, f"{cls.__name__}: hybrid-space vs k-space")
