@@ -109,6 +109,11 @@ int mrx_sens_expand_rows(const float* x, const float* S, float* out, int B, int 
                          void* stream);
 int mrx_sens_reduce_rows(const float* kh, const float* S, float* out, int B, int C, int H, int W, int norm, int centered,
                          void* stream);
+/* mrx_sens_expand_rows with the data-consistency combination as its epilogue (bit-identical to the two separate launches):
+ * out = pred - where(mask, pred - ref, 0) * dc_weight[0] - FFT_W(x * S); out may alias pred. */
+int mrx_sens_expand_rows_dc(const float* x, const float* S, const float* pred, const float* ref, const void* mask,
+                            int mask_kind, const int64_t* mstride, const float* dc_weight, float* out, int B, int C, int H,
+                            int W, int norm, int centered, void* stream);
 
 /* A9  log_likelihood_gradient (models/rim/rim_utils.py:11-67), three launches:
  *     rows: eta*S -> FFT_W ; cols: FFT_H -> mask*(k - y) -> IFFT_H ; rows: IFFT_W -> sum_c conj(S) -> /sigma^2.

@@ -44,6 +44,9 @@ class CascadeNetBlock(torch.nn.Module):
             eta = self.model(x).permute(0, 2, 3, 1)
         if eta.dim() < sens_maps.dim():
             eta = eta.unsqueeze(1)
+        if self._hybrid and not self.no_dc:      # expand + data consistency in one pass over the coil stack
+            return ops.sens_expand_dc_hybrid(eta, sens_maps, pred, ref_kspace, mask, self.dc_weight, self.fft_centered,
+                                             self.fft_normalization)
         eta = self.sens_expand(eta, sens_maps)
         if not self.no_dc:
             eta = ops.dc_combine(pred, pred, ref_kspace, mask, self.dc_weight, eta)   # pred - where(mask, pred - ref, 0) * w - eta

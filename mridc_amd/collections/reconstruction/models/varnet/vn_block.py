@@ -34,6 +34,9 @@ class VarNetBlock(torch.nn.Module):
         """vn_block.py:89-119."""
         eta = self.sens_reduce(pred, sens_maps)
         eta = self.model(eta)
+        if self._hybrid and not self.no_dc:      # expand + data consistency in one pass over the coil stack
+            return ops.sens_expand_dc_hybrid(eta, sens_maps, pred, ref_kspace, mask, self.dc_weight, self.fft_centered,
+                                             self.fft_normalization)
         eta = self.sens_expand(eta, sens_maps)
         if not self.no_dc:
             # pred - where(mask.bool(), pred - ref, 0) * dc_weight - eta, one launch

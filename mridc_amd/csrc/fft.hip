@@ -189,10 +189,18 @@ struct RowArgs {
     int sdiv;  // expand mode: batch element b uses the maps of element b / sdiv (qMRI: echoes share one set of maps)
 };
 
-// MODE 0: out[row] = FFT(in[row]);  MODE 1: out[b,c,h] = FFT(x[b,h] * S[b,c,h]).  NSEQ rows per workgroup (CT plans).
+// soft data consistency fused into the expand pass (MODE 2): out = pred - where(mask, pred - ref, 0) * w - FFT(x S)   (vn_block.py:109-117)
+struct RowDc {
+    const float2* pred;
+    const float2* ref;
+    const float* w;
+    MrxMask m;
+};
+// MODE 0: out[row] = FFT(in[row]);  MODE 1: out[b,c,h] = FFT(x[b,h] * S[b,c,h]);  MODE 2: MODE 1 + the data-consistency combination.
+// NSEQ rows per workgroup (CT plans).
 template <bool INV, int MODE, class P, int NSEQ>
 __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const float2* __restrict__ S, float2* out,
-                                                         RowArgs a) {
+                                                         RowArgs a, RowDc dc) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     const int W = P::kCT ? P::N : a.W;
     const int RPB = P::kCT ? NSEQ : a.rpb;
@@ -203,8 +211,8 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const
     const int hrow0 = blockIdx.y * RPB;
     const int nrows = min(RPB, a.H - hrow0);
     const long long row0 = img * a.H + hrow0;
-    const long long bimg = MODE == 1 ? img / a.C : 0;  // one division per workgroup
-    const long long srow0 = MODE == 1 ? ((bimg / a.sdiv) * a.C + (img - bimg * a.C)) * a.H + hrow0 : 0;
+    const long long bimg = MODE >= 1 ? img / a.C : 0;  // one division per workgroup
+    const long long srow0 = MODE >= 1 ? ((bimg / a.sdiv) * a.C + (img - bimg * a.C)) * a.H + hrow0 : 0;
     const float invW = 1.0f / (float)W;
     for (int i = threadIdx.x; i < W; i += MRX_FFT_NT) tw[i] = a.tw[i];
     for (int idx = threadIdx.x; idx < RPB * W; idx += MRX_FFT_NT) {
@@ -233,7 +241,23 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const
         const int r = P::kCT ? idx / W : mrx_fdiv(idx, invW), x = idx - r * W;
         const int g = shifted(x, a.halfW, W);
         float2 v = res[idx];
-        out[(row0 + r) * W + g] = make_float2(v.x * a.scale, v.y * a.scale);
+        if (MODE == 2) {  // same operations and roundings as k_soft_dc<1> on the separately written transform
+            const long long o = (row0 + r) * W + g;
+            const float ex = __fmul_rn(v.x, a.scale), ey = __fmul_rn(v.y, a.scale);
+            const float2 p = dc.pred[o];
+            float dx = 0.f, dy = 0.f;
+            if (mrx_mask_true(dc.m, bimg, img - bimg * a.C, hrow0 + r, g)) {
+                const float2 q = dc.ref[o];
+                dx = __fsub_rn(p.x, q.x);
+                dy = __fsub_rn(p.y, q.y);
+            }
+            const float w8 = dc.w[0];
+            dx = __fmul_rn(dx, w8);
+            dy = __fmul_rn(dy, w8);
+            out[o] = make_float2(__fsub_rn(__fsub_rn(p.x, dx), ex), __fsub_rn(__fsub_rn(p.y, dy), ey));
+        } else {
+            out[(row0 + r) * W + g] = make_float2(v.x * a.scale, v.y * a.scale);
+        }
     }
 }
 
@@ -1052,23 +1076,34 @@ static int set_lds(K kern, size_t bytes) {
 }
 
 template <bool INV, int MODE, class P, int NSEQ>
-static int launch_rows_t(const float2* in, const float2* S, float2* out, dim3 grid, size_t lds, const RowArgs& a, hipStream_t st) {
+static int launch_rows_t(const float2* in, const float2* S, float2* out, dim3 grid, size_t lds, const RowArgs& a, hipStream_t st,
+                         const RowDc* dcp = nullptr) {
     int rc = set_lds(k_fft_rows<INV, MODE, P, NSEQ>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_fft_rows<INV, MODE, P, NSEQ>), grid, dim3(MRX_FFT_NT), lds, st, in, S, out, a);
+    RowDc dc;
+    if (dcp) dc = *dcp;
+    else {
+        dc.pred = dc.ref = nullptr;
+        dc.w = nullptr;
+        dc.m.p = nullptr;
+        dc.m.kind = MRX_MASK_F32;
+        for (int i = 0; i < 4; ++i) dc.m.s[i] = 0;
+    }
+    hipLaunchKernelGGL((k_fft_rows<INV, MODE, P, NSEQ>), grid, dim3(MRX_FFT_NT), lds, st, in, S, out, a, dc);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 template <class P, int NSEQ>
 static int launch_rows_p(const float2* in, const float2* S, float2* out, dim3 grid, size_t lds, const RowArgs& a, int inverse,
-                         int expand, hipStream_t st) {
+                         int expand, hipStream_t st, const RowDc* dc = nullptr) {
+    if (expand && dc) return launch_rows_t<false, 2, P, NSEQ>(in, S, out, grid, lds, a, st, dc);
     if (expand) return launch_rows_t<false, 1, P, NSEQ>(in, S, out, grid, lds, a, st);
     if (inverse) return launch_rows_t<true, 0, P, NSEQ>(in, S, out, grid, lds, a, st);
     return launch_rows_t<false, 0, P, NSEQ>(in, S, out, grid, lds, a, st);
 }
 
 static int launch_rows(const float2* in, const float2* S, float2* out, long long nimg, int W, int C, int H,
-                       int inverse, int norm, int centered, int expand, hipStream_t st, int sdiv = 1) {
+                       int inverse, int norm, int centered, int expand, hipStream_t st, int sdiv = 1, const RowDc* dc = nullptr) {
     MrxFftEntry e;
     int rc = mrx_get_plan(W, &e);
     if (rc) return rc;
@@ -1085,10 +1120,10 @@ static int launch_rows(const float2* in, const float2* S, float2* out, long long
     const size_t lds = sizeof(float2) * ((size_t)W + 2 * (size_t)a.rpb * W);
     MRX_REQUIRE(nimg < (1LL << 31), MRX_EUNSUP, "too many images (%lld)", nimg);
     const dim3 grid((unsigned)nimg, mrx_cdiv(H, a.rpb));
-    if (W == 372) return launch_rows_p<P372, NSEQ_ROW_372>(in, S, out, grid, lds, a, inverse, expand, st);
-    if (W == 320) return launch_rows_p<P320, NSEQ_ROW_320>(in, S, out, grid, lds, a, inverse, expand, st);
-    if (W == 256) return launch_rows_p<P256, NSEQ_ROW_256>(in, S, out, grid, lds, a, inverse, expand, st);
-    return launch_rows_p<PlanRT, 1>(in, S, out, grid, lds, a, inverse, expand, st);
+    if (W == 372) return launch_rows_p<P372, NSEQ_ROW_372>(in, S, out, grid, lds, a, inverse, expand, st, dc);
+    if (W == 320) return launch_rows_p<P320, NSEQ_ROW_320>(in, S, out, grid, lds, a, inverse, expand, st, dc);
+    if (W == 256) return launch_rows_p<P256, NSEQ_ROW_256>(in, S, out, grid, lds, a, inverse, expand, st, dc);
+    return launch_rows_p<PlanRT, 1>(in, S, out, grid, lds, a, inverse, expand, st, dc);
 }
 
 static int make_col_args(ColArgs* a, long long nimg, int H, int W, int inverse, int norm, int centered) {
@@ -1243,6 +1278,27 @@ extern "C" int mrx_sens_expand_rows(const float* x, const float* S, float* out, 
     if (B == 0) return MRX_OK;
     return launch_rows((const float2*)x, (const float2*)S, (float2*)out, (long long)B * C, W, C, H, 0, norm, centered, 1,
                        (hipStream_t)stream);
+}
+// mrx_sens_expand_rows + mrx_dc_combine in one pass: out = pred - where(mask, pred - ref, 0) * dc_weight - FFT_W(x * S), all k-space
+// arguments in hybrid space (vn_block.py:109-117 / ccnn_block.py:127-138 for row-invariant masks)
+extern "C" int mrx_sens_expand_rows_dc(const float* x, const float* S, const float* pred, const float* ref, const void* mask,
+                                       int mask_kind, const int64_t* mstride, const float* dc_weight, float* out, int B, int C, int H,
+                                       int W, int norm, int centered, void* stream) {
+    MRX_REQUIRE(x && S && pred && ref && mask && mstride && dc_weight && out, MRX_EINVAL, "mrx_sens_expand_rows_dc: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_sens_expand_rows_dc: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_sens_expand_rows_dc: bad normalization %d", norm);
+    MRX_REQUIRE(mask_kind == MRX_MASK_U8 || mask_kind == MRX_MASK_F32, MRX_EINVAL, "mrx_sens_expand_rows_dc: bad mask kind %d", mask_kind);
+    MRX_REQUIRE(out != (float*)x, MRX_EINVAL, "mrx_sens_expand_rows_dc: out must not alias x");
+    if (B == 0) return MRX_OK;
+    RowDc dc;
+    dc.pred = (const float2*)pred;
+    dc.ref = (const float2*)ref;
+    dc.w = dc_weight;
+    dc.m.p = mask;
+    dc.m.kind = mask_kind;
+    for (int i = 0; i < 4; ++i) dc.m.s[i] = mstride[i];
+    return launch_rows((const float2*)x, (const float2*)S, (float2*)out, (long long)B * C, W, C, H, 0, norm, centered, 1,
+                       (hipStream_t)stream, 1, &dc);
 }
 extern "C" int mrx_sens_reduce_rows(const float* kh, const float* S, float* out, int B, int C, int H, int W, int norm, int centered,
                                     void* stream) {

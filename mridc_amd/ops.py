@@ -50,6 +50,25 @@ def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=Fals
     return out
 
 
+def sens_expand_dc_hybrid(x, sens, pred, ref, mask, dc_weight, centered, normalization):
+    """pred - where(mask, pred - ref, 0) * dc_weight - FFT_W(x * S), everything in hybrid space: the cascade's last two steps
+    (sens_expand, soft data consistency) as one pass (mrx_sens_expand_rows_dc)."""
+    sens, pred, ref = _lib.f32c(sens), _lib.f32c(pred), _lib.f32c(ref)
+    B, C, H, W = _bchw(sens)
+    x = _lib.f32c(x)
+    if x.dim() == 5 and x.shape[1] == 1:
+        x = x.reshape(B, H, W, 2)
+    if tuple(x.shape) != (B, H, W, 2) or pred.shape != sens.shape or ref.shape != sens.shape:
+        raise ValueError("sens_expand_dc_hybrid: inconsistent shapes")
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    w = _lib.f32c(dc_weight.detach().reshape(-1))
+    out = torch.empty_like(sens)
+    _lib.check(_lib.lib().mrx_sens_expand_rows_dc(_lib.ptr(x), _lib.ptr(sens), _lib.ptr(pred), _lib.ptr(ref), _lib.ptr(m), kind, ms,
+                                                  _lib.ptr(w), _lib.ptr(out), B, C, H, W, _norm(normalization), int(bool(centered)),
+                                                  _lib.stream_ptr()), "mrx_sens_expand_rows_dc")
+    return out
+
+
 def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None, hybrid=False):
     """sum_c ifft2(k) * conj(S) -> [B,H,W,2].  `hybrid`: k is IFFT_H of the k-space already (mrx_sens_reduce_rows)."""
     k, sens = _lib.f32c(k), _lib.f32c(sens)

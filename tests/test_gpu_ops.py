@@ -265,3 +265,26 @@ def test_g10_ssim_loss(golden, dev):
     Bm = (A + 0.2 * torch.rand(3, 1, 45, 70, generator=g)).clamp(0, 1)
     d = torch.tensor([1.0, 0.5, 2.0])
     assert abs(float(loss(A.to(dev), Bm.to(dev), d.to(dev))) - float(oracle.metrics.ssim_loss(A, Bm, d))) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 13, 18), (2, 4, 24, 372), (1, 15, 64, 372), (1, 2, 9, 320)])
+def test_hybrid_rows_ops(dev, shape):
+    """Row-transform-only forms for row-invariant masks: sens_reduce / sens_expand on IFFT_H(k) equal the 2-D forms, and the fused
+    expand + data-consistency pass is bit-identical to the two launches it replaces."""
+    from mridc_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    k = torch.randn(B, C, H, W, 2, generator=g).to(dev)
+    S = (torch.randn(B, C, H, W, 2, generator=g) / C ** 0.5).to(dev)
+    x = torch.randn(B, H, W, 2, generator=g).to(dev)
+    mask = (torch.rand(1, 1, 1, W, 1, generator=g) < 0.4).to(dev)
+    w = torch.tensor([0.7], device=dev)
+    for centered, norm in ((False, "backward"), (True, "ortho")):
+        kh = ops.llg_prepare(k, centered, norm)                               # IFFT_H(k)
+        assert_close(ops.sens_reduce(kh, S, centered, norm, hybrid=True), ops.sens_reduce(k, S, centered, norm), 1e-5, "sens_reduce rows")
+        full = ops.sens_expand(x, S, centered, norm)
+        assert_close(ops.sens_expand(x, S, centered, norm, hybrid=True), ops.llg_prepare(full, centered, norm), 1e-5, "sens_expand rows")
+        e = ops.sens_expand(x, S, centered, norm, hybrid=True)
+        two = ops.dc_combine(kh, kh, k, mask, w, e)
+        one = ops.sens_expand_dc_hybrid(x, S, kh, k, mask, w, centered, norm)
+        assert torch.equal(one, two), "fused expand + data consistency is bit-identical to the two launches"
