@@ -109,7 +109,7 @@ int mrx_sens_expand_rows(const float* x, const float* S, float* out, int B, int 
                          void* stream);
 int mrx_sens_reduce_rows(const float* kh, const float* S, float* out, int B, int C, int H, int W, int norm, int centered,
                          void* stream);
-/* mrx_sens_expand_rows with the data-consistency combination as its epilogue (bit-identical to the two separate launches):
+/* mrx_sens_expand_rows with the data-consistency combination as its epilogue (the same operations as the two separate launches):
  * out = pred - where(mask, pred - ref, 0) * dc_weight[0] - FFT_W(x * S); out may alias pred. */
 int mrx_sens_expand_rows_dc(const float* x, const float* S, const float* pred, const float* ref, const void* mask,
                             int mask_kind, const int64_t* mstride, const float* dc_weight, float* out, int B, int C, int H,

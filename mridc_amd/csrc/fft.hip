@@ -241,7 +241,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_fft_rows(const float2* in, const
         const int r = P::kCT ? idx / W : mrx_fdiv(idx, invW), x = idx - r * W;
         const int g = shifted(x, a.halfW, W);
         float2 v = res[idx];
-        if (MODE == 2) {  // same operations and roundings as k_soft_dc<1> on the separately written transform
+        if (MODE == 2) {  // same operations as k_soft_dc<1> on the separately written transform
             const long long o = (row0 + r) * W + g;
             const float ex = __fmul_rn(v.x, a.scale), ey = __fmul_rn(v.y, a.scale);
             const float2 p = dc.pred[o];
