@@ -609,34 +609,6 @@ def relu_bwd(dy, y, h_prev=None, hh=None):
     return dpre, dhp, sums
 
 
-class FusedConvReLU:
-    """ReLU(conv_reppad(x)) into 64 features through the fused RIM layer kernels with an identity `ih` (ReLU(I g + 0 h) = g
-    exactly): the Winograd kernel for 3x3 dilation 2, the direct tuned kernel for the other tuned shapes.  Holds the packed
-    weights of the convolutions it has seen, re-packed when a parameter version changes.  Returns None for shapes the fused
-    kernels do not cover."""
-
-    def __init__(self):
-        self._cache = {}
-
-    def __call__(self, key, weight, bias, dilation, x, winograd=True):
-        F, Cin, k, k2 = [int(v) for v in weight.shape]
-        if k != k2:
-            return None
-        wino = winograd and rim_layer_wino_supported(Cin, F, k, dilation)
-        if not (wino or rim_layer_supported(Cin, F, k, dilation)):
-            return None
-        ver = (weight.data_ptr(), weight._version, str(weight.device), wino)
-        hit = self._cache.get(key)
-        if hit is None or hit[0] != ver:
-            eye = torch.eye(F, dtype=torch.float32, device=weight.device).reshape(F, F, 1, 1)
-            hit = (ver, rim_layer_wino_pack(weight, eye) if wino else rim_layer_pack(weight, eye),
-                   torch.zeros(F, dtype=torch.float32, device=weight.device))
-            self._cache[key] = hit
-        if wino:
-            return rim_layer_indrnn_wino(x, hit[1], F, bias, None, hit[2], None)
-        return rim_layer_indrnn_packed(x, hit[1], F, k, dilation, bias, None, hit[2], None)
-
-
 def rim_final(h, weight, bias, k, dilation, eta):
     """eta + permute(conv_reppad(h)) with a 2-channel conv -> [B,H,W,2]."""
     h, weight, eta = _lib.f32c(h), _lib.f32c(weight.detach()), _lib.f32c(eta)
