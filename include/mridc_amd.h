@@ -222,7 +222,8 @@ int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, float* packe
 int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, const float* b_conv, const float* b_ih,
                               const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H, int W,
                               void* stream);
-/* Plain 3x3 convolution into 64 channels on the Winograd kernel (no 1x1 stage): dilation 1 or 2, MRX_PAD_ZERO or
+/* Plain 3x3 convolution into 64 channels (or a multiple: one launch per block of 64, `packed` = the blocks' packs back to back) on the
+ * Winograd kernel (no 1x1 stage): dilation 1 or 2, MRX_PAD_ZERO or
  * MRX_PAD_REPLICATE, bias (or NULL) and MRX_ACT_* fused.  packed = mrx_rim_layer_wino_pack(w, NULL, ...).  Replaces nn.Conv2d
  * (3x3, 64 out channels) in conv/conv2d.py:36-43, recurrentvarnet/conv2gru.py:71-79, recurrentvarnet.py:68-71. */
 int mrx_conv3x3_wino_supported(int Cin, int Cout, int k, int dil);

@@ -60,6 +60,7 @@ struct WinoArgs {
     unsigned long long* trace;  // debug only (env MRX_TRACE): cycle stamps per workgroup
     int act;      // plain-convolution form (TAIL = false) only: MRX_ACT_* applied to conv + bias
     float slope;  // leaky slope of that activation
+    long long out_bstride;  // elements between the batch entries of hnew / hprev (64 * H * W unless a wider tensor is written in 64-channel blocks)
 };
 
 // U = G g G^T per (cout, cin); per chunk q the image [xi = 4i+j'][k pair j][p = co ^ 16*(j&1)][kb], cin = 8q + 2j + kb
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     const int oy = ch0 + wave;
     const bool wide = (a.W & 3) == 0;
     const int wch = lane >> 3, wpx = (lane & 7) * 4;
-    const long long wbase = (long long)cb * WN_F * plane + (long long)oy * a.W + cw0 + wpx;
+    const long long wbase = (long long)cb * a.out_bstride + (long long)oy * a.W + cw0 + wpx;
     const bool winside = oy < a.H && (cw0 + wpx) < a.W;
     if constexpr (!TAIL) {
         // plain convolution: wave = image row `wave` of the tile, Ys already holds [cout][row][32 columns]
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
                 if (winside) *reinterpret_cast<float4*>(a.hnew + wbase + (long long)ch * plane) = v;
             }
         } else if (oy < a.H && cw0 + l31 < a.W) {
-            const long long obase = (long long)cb * WN_F * plane + (long long)oy * a.W + cw0 + l31;
+            const long long obase = (long long)cb * a.out_bstride + (long long)oy * a.W + cw0 + l31;
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 const int co = 2 * i + lhi;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
             if (winside) *reinterpret_cast<float4*>(a.hnew + wbase + (long long)ch * plane) = v;
         }
     } else if (oy < a.H && ox < a.W) {
-        const long long obase = (long long)cb * WN_F * plane + (long long)oy * a.W + ox;
+        const long long obase = (long long)cb * a.out_bstride + (long long)oy * a.W + ox;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -585,6 +586,7 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
     a.W = W;
     a.act = MRX_ACT_RELU;
     a.slope = 0.f;
+    a.out_bstride = (long long)WN_F * H * W;
     a.tiles_x = mrx_cdiv(W, 32);
     a.ntiles = a.tiles_x * mrx_cdiv(H, 8);
     MRX_REQUIRE((long long)H * W < (1ll << 28), MRX_EUNSUP, "mrx_rim_layer_indrnn_wino: plane %d x %d too large", H, W);
@@ -665,7 +667,7 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
 // ---- plain 3x3 convolution into 64 channels on the same kernel (TAIL = false): dilation 1 or 2, zero or replicate padding,
 // bias + activation in the output transform.  `packed` = mrx_rim_layer_wino_pack(w, NULL, ...).
 extern "C" int mrx_conv3x3_wino_supported(int Cin, int Cout, int k, int dil) {
-    return Cout == WN_F && Cin >= 1 && k == 3 && (dil == 1 || dil == 2);
+    return Cout >= WN_F && Cout % WN_F == 0 && Cin >= 1 && k == 3 && (dil == 1 || dil == 2);  // wider outputs: one launch per 64 channels
 }
 
 template <bool X4, int DIL, bool ZP>
@@ -685,7 +687,7 @@ extern "C" int mrx_conv3x3_wino(const float* x, const float* packed, const float
                                 int W, int dil, int pad_mode, int act, float slope, void* stream) {
     MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv3x3_wino: null pointer");
     MRX_REQUIRE(B >= 0 && Cin >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv3x3_wino: bad dims");
-    MRX_REQUIRE(mrx_conv3x3_wino_supported(Cin, Cout, 3, dil), MRX_EUNSUP, "mrx_conv3x3_wino: Cout=%d dil=%d (64 and 1|2 only)", Cout, dil);
+    MRX_REQUIRE(mrx_conv3x3_wino_supported(Cin, Cout, 3, dil), MRX_EUNSUP, "mrx_conv3x3_wino: Cout=%d dil=%d (multiples of 64, 1|2)", Cout, dil);
     MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv3x3_wino: pad mode %d", pad_mode);
     MRX_REQUIRE(act == MRX_ACT_NONE || act == MRX_ACT_RELU || act == MRX_ACT_LEAKY, MRX_EINVAL, "mrx_conv3x3_wino: activation %d", act);
     MRX_REQUIRE((long long)H * W < (1ll << 28), MRX_EUNSUP, "mrx_conv3x3_wino: plane %d x %d too large", H, W);
@@ -722,10 +724,22 @@ extern "C" int mrx_conv3x3_wino(const float* x, const float* packed, const float
     const bool x4 = (W & 3) == 0 && W >= 4 && ((uintptr_t)x & 15) == 0;
     const bool zp = pad_mode == MRX_PAD_ZERO;
     hipStream_t st = (hipStream_t)stream;
-    if (x4) {
-        if (dil == 2) return zp ? launch_conv_wino<true, 2, true>(a, st, nblk) : launch_conv_wino<true, 2, false>(a, st, nblk);
-        return zp ? launch_conv_wino<true, 1, true>(a, st, nblk) : launch_conv_wino<true, 1, false>(a, st, nblk);
+    // one launch per block of 64 output channels: `packed` holds the blocks back to back (each mrx_rim_layer_wino_pack_floats(Cin, 64))
+    const long long blk_floats = mrx_rim_layer_wino_pack_floats(Cin, WN_F), plane = (long long)H * W;
+    a.out_bstride = (long long)Cout * plane;
+    for (int ob = 0; ob < Cout / WN_F; ++ob) {
+        a.packed = packed + ob * blk_floats;
+        a.b_conv = bias ? bias + ob * WN_F : nullptr;
+        a.hnew = out + (long long)ob * WN_F * plane;
+        int rc;
+        if (x4) {
+            if (dil == 2) rc = zp ? launch_conv_wino<true, 2, true>(a, st, nblk) : launch_conv_wino<true, 2, false>(a, st, nblk);
+            else rc = zp ? launch_conv_wino<true, 1, true>(a, st, nblk) : launch_conv_wino<true, 1, false>(a, st, nblk);
+        } else {
+            if (dil == 2) rc = zp ? launch_conv_wino<false, 2, true>(a, st, nblk) : launch_conv_wino<false, 2, false>(a, st, nblk);
+            else rc = zp ? launch_conv_wino<false, 1, true>(a, st, nblk) : launch_conv_wino<false, 1, false>(a, st, nblk);
+        }
+        if (rc) return rc;
     }
-    if (dil == 2) return zp ? launch_conv_wino<false, 2, true>(a, st, nblk) : launch_conv_wino<false, 2, false>(a, st, nblk);
-    return zp ? launch_conv_wino<false, 1, true>(a, st, nblk) : launch_conv_wino<false, 1, false>(a, st, nblk);
+    return MRX_OK;
 }

@@ -351,9 +351,11 @@ def _wino_conv_pack(weight):
             _WINO_PACKS.pop(next(iter(_WINO_PACKS)))
         w = _lib.f32c(weight.detach())
         F, Cin = int(w.shape[0]), int(w.shape[1])
-        packed = torch.empty(int(_lib.lib().mrx_rim_layer_wino_pack_floats(Cin, F)), dtype=torch.float32, device=w.device)
-        _lib.check(_lib.lib().mrx_rim_layer_wino_pack(_lib.ptr(w), None, _lib.ptr(packed), Cin, F, _lib.stream_ptr()),
-                   "mrx_rim_layer_wino_pack")
+        blk = int(_lib.lib().mrx_rim_layer_wino_pack_floats(Cin, 64))
+        packed = torch.empty(blk * (F // 64), dtype=torch.float32, device=w.device)
+        for ob in range(F // 64):                                        # one packed block per 64 output channels
+            _lib.check(_lib.lib().mrx_rim_layer_wino_pack(_lib.ptr(w[ob * 64:(ob + 1) * 64]), None, _lib.ptr(packed[ob * blk:]), Cin, 64,
+                                                          _lib.stream_ptr()), "mrx_rim_layer_wino_pack")
         hit = _WINO_PACKS[key] = (packed, weight)
     return hit[0]
 
@@ -397,8 +399,8 @@ def conv3x3_wino_supported(Cin, Cout, k, dilation):
 
 
 def conv3x3_wino(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
-    """3x3 convolution into 64 channels as Winograd F(2x2,3x3) on the matrix cores (differs from the direct form by fp32
-    round-off, ~2e-7 of the output norm)."""
+    """3x3 convolution into 64 (or a multiple of 64) channels as Winograd F(2x2,3x3) on the matrix cores (differs from the direct form by
+    fp32 round-off, ~2e-7 of the output norm)."""
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     Cout = int(weight.shape[0])

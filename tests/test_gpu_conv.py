@@ -317,6 +317,11 @@ def test_conv3x3_wino_vs_oracle(dev, shape, dil, pad_mode):
     ref = F.conv2d(xp, w, b, dilation=dil)
     pm = ops.PAD_ZERO if pad_mode == "zero" else ops.PAD_REPLICATE
     assert ops.conv3x3_wino_supported(Cin, 64, 3, dil) and not ops.conv3x3_wino_supported(Cin, 48, 3, dil)
+    if (H, W) == (13, 37) or (H, W) == (16, 32):            # 128 output channels: two 64-channel launches into one tensor (B = 2 too)
+        w2 = torch.randn(128, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+        b2 = torch.randn(128, generator=g)
+        assert_close(ops.conv2d(x.to(dev), w2.to(dev), b2.to(dev), dil, pm0 := (ops.PAD_ZERO if pad_mode == "zero" else ops.PAD_REPLICATE),
+                                ops.ACT_RELU), F.relu(F.conv2d(xp, w2, b2, dilation=dil)), 1e-5, "128 output channels")
     xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
     assert_close(ops.conv3x3_wino(xd, wd, bd, dil, pm), ref, 1e-5, f"wino conv {shape} dil {dil} {pad_mode}")
     assert_close(ops.conv3x3_wino(xd, wd, bd, dil, pm, ops.ACT_RELU), F.relu(ref), 1e-5, "relu")
