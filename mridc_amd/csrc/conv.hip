@@ -284,11 +284,11 @@ __global__ __launch_bounds__(CV_NT) void k_conv_small(SmallArgs s) {
 }
 
 // ---- small-Cout conv, four pixels per thread (K = 3 or 5, dilation 1; the data gradient of the first RIM layer: 64 -> 4, 5x5) ----
-// Workgroup = 4 waves on an 8 x 32 pixel tile.  A lane owns 4 consecutive pixels of a row and all CO outputs; the four waves
-// split the input channels of a chunk (partial sums meet in LDS at the end), so the grid keeps ~4 waves per 256 pixels.  Per
+// Workgroup = 8 waves on an 8 x 32 pixel tile.  A lane owns 4 consecutive pixels of a row and all CO outputs; the eight waves
+// split the input channels of a chunk (partial sums meet in LDS at the end), so the grid keeps 8 waves per 256 pixels (small images stay latency-tolerant).  Per
 // channel a lane reads its K x 12 patch window from LDS as float4s (15 reads for K = 5) and issues 4 * K * K * CO FMAs with the
 // weights in scalar registers (wave-uniform loads): 1 LDS access per ~27 FMAs instead of 1 per CO.
-#define P4_NT 256
+#define P4_NT 512
 #define P4_TH 8
 #define P4_TW 32
 #define P4_CK 16
@@ -296,7 +296,7 @@ template <int CO, int K>
 __global__ __launch_bounds__(P4_NT) void k_conv_small_px4(SmallArgs s) {
     constexpr int PAD = (K - 1) / 2, PH = P4_TH + 2 * PAD, XS = P4_TW + 8;  // tile columns [w0 - 4, w0 + 36): float4-aligned rows
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    float* Xs = smem_f;  // [P4_CK][PH][XS]; afterwards the partial-sum exchange [3][64][CO * 4]
+    float* Xs = smem_f;  // [P4_CK][PH][XS]; afterwards the partial-sum exchange [7][64][CO * 4]
     const int tile = blockIdx.x, ty0 = tile / s.tiles_x;
     const int h0 = ty0 * P4_TH, w0 = (tile - ty0 * s.tiles_x) * P4_TW;
     const int b = blockIdx.z;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(P4_NT) void k_conv_small_px4(SmallArgs s) {
             Xs[idx] = v;
         }
         __syncthreads();
-        for (int cj = wave; cj < P4_CK && c0 + cj < s.Cin; cj += 4) {  // this wave's channels of the chunk
+        for (int cj = wave; cj < P4_CK && c0 + cj < s.Cin; cj += P4_NT / 64) {  // this wave's channels of the chunk
             const float* xp = Xs + (cj * PH + ty) * XS + 4 * tx;  // tile column 4 tx = image column w0 + 4 tx - 4
             const float* wp = s.w + (long long)(c0 + cj) * (K * K);  // w[o][cin][tap]: + o * Cin * K * K (wave-uniform -> scalar loads)
 #pragma unroll
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(P4_NT) void k_conv_small_px4(SmallArgs s) {
         for (int i = 0; i < 4; ++i) {
             float v = acc[o][i];
 #pragma unroll
-            for (int wv = 0; wv < 3; ++wv) v += Rx[((wv * 64 + lane) * CO + o) * 4 + i];
+            for (int wv = 0; wv < P4_NT / 64 - 1; ++wv) v += Rx[((wv * 64 + lane) * CO + o) * 4 + i];
             if (ox + i < s.W) yo[i] = v + bv;
         }
     }
@@ -476,7 +476,9 @@ static int launch_small(const float* x, const float* w, const float* bias, const
     if (mode == 0 && dil == 1 && (k == 3 || k == 5) && (Cout == 2 || Cout == 4) && Cin >= 8 && !getenv("MRX_CONV_SMALL_OLD")) {
         s.tiles_x = mrx_cdiv(W, P4_TW);
         dim3 g4(s.tiles_x * mrx_cdiv(H, P4_TH), 1, B);
-        const size_t lds4 = sizeof(float) * P4_CK * (P4_TH + k - 1) * (P4_TW + 8);
+        size_t lds4 = sizeof(float) * P4_CK * (P4_TH + k - 1) * (P4_TW + 8);
+        const size_t xch = sizeof(float) * (P4_NT / 64 - 1) * 64 * Cout * 4;  // partial-sum exchange of the waves
+        if (lds4 < xch) lds4 = xch;
 #define PX4_CASE(CO, KK)                                                                   \
     do {                                                                                   \
         if ((rc = conv_set_lds(k_conv_small_px4<CO, KK>, lds4))) return rc;                \
