@@ -312,6 +312,11 @@ int mrx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * h_prev [B,64,HW]; the IndRNN cell with a 1x1 `ih` when hh / h_prev are given (rnn_cells.py:384-391), RecurrentInit's heads
  * (recurrentvarnet.py:73-76), data gradients of 1x1 layers.  packed: 4096 floats from mrx_conv1x1_64_pack(w [64,64,1,1]). */
 int mrx_conv1x1_64_pack(const float* w, float* packed, void* stream);
+/* the same for C = 64 or 128 channels (qCIRIM's 128-feature IndRNN cells): packed = C*C floats */
+int mrx_conv1x1_sq_supported(int Cin, int Cout);
+int mrx_conv1x1_sq_pack(const float* w, float* packed, int C, void* stream);
+int mrx_conv1x1_sq(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
+                   int B, int C, int64_t HW, int act, float slope, void* stream);
 int mrx_conv1x1_64(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
                    int B, int64_t HW, int act, float slope, void* stream);
 

@@ -460,40 +460,45 @@ extern "C" int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const floa
     return MRX_OK;
 }
 
-// ---- 1x1 convolution 64 -> 64 (a per-pixel 64x64 GEMM) with the IndRNN cell as an optional epilogue ---------------------------------
+// ---- 1x1 convolution C -> C, C = 64 or 128 (a per-pixel GEMM) with the IndRNN cell as an optional epilogue ------------------------------
 //   out = act(W x + bias [+ hh * h_prev])      act: MRX_ACT_NONE / RELU / LEAKY
-// The ih stage of the IndRNN cell run on its own (training forward: rnn_cells.py:384-391), the data gradient of 1x1 layers (W^T as
-// weights), RecurrentInit's 1x1 heads (recurrentvarnet.py:73-76).  Same skeleton as the gated cells: x straight from HBM into the
-// B-operand layout, the 16 KB of packed weights in LDS for the life of the persistent workgroup, 64 MFMAs per 32 pixels -- the
-// kernel is HBM-bound (two or three 61 MB tensors at 640x372).
+// The ih stage of the IndRNN cell run on its own (training forward: rnn_cells.py:384-391; the 128-feature cells of the qCIRIM), the
+// data gradient of 1x1 layers (W^T as weights), RecurrentInit's 1x1 heads (recurrentvarnet.py:73-76).  Same skeleton as the gated
+// cells: x straight from HBM into the B-operand layout (64 channels at a time), the packed weights (16 / 64 KB) in LDS for the life
+// of the persistent workgroup, 64 MFMAs per 32 pixels and 64x64 block -- HBM-bound at C = 64 (two or three 61 MB tensors at 640x372).
 struct Conv1x1Args {
-    const float* x;       // [B,64,P]
-    const float* packed;  // mrx_conv1x1_64_pack
-    const float* bias;    // [64] or null
-    const float* hh;      // [64] or null (IndRNN: + hh * h_prev)
-    const float* hprev;   // [B,64,P] or null
-    float* out;           // [B,64,P]
+    const float* x;       // [B,C,P]
+    const float* packed;  // mrx_conv1x1_sq_pack
+    const float* bias;    // [C] or null
+    const float* hh;      // [C] or null (IndRNN: + hh * h_prev)
+    const float* hprev;   // [B,C,P] or null
+    float* out;           // [B,C,P]
     long long P, nsegb, nseg;
     int act;
     float slope;
 };
-__global__ void k_conv1x1_pack(const float* __restrict__ w, float* __restrict__ out) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < GC_F * GC_F; i += gridDim.x * blockDim.x) {
-        const int m = i & 31, half = (i >> 5) & 1, s = (i >> 6) & 31, mb = (i >> 11) & 1;
-        out[i] = w[(long long)(mb * 32 + m) * GC_F + 2 * s + half];
+// packed index ((((ob*CB + ib)*2 + mb)*32 + s)*2 + half)*32 + m  <-  W[ob*64 + mb*32 + m][ib*64 + 2*s + half]
+__global__ void k_conv1x1_pack(const float* __restrict__ w, float* __restrict__ out, int C) {
+    const int CB = C / GC_F;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * C; i += gridDim.x * blockDim.x) {
+        const int m = i & 31, half = (i >> 5) & 1, s = (i >> 6) & 31, mb = (i >> 11) & 1, blk = i >> 12;
+        const int ob = blk / CB, ib = blk - ob * CB;
+        out[i] = w[(long long)(ob * GC_F + mb * 32 + m) * C + ib * GC_F + 2 * s + half];
     }
 }
-__global__ __launch_bounds__(GC_NT, 4) void k_conv1x1_64(Conv1x1Args a) {
-    __shared__ __attribute__((aligned(16))) float Ws[GC_F * GC_F + 2 * GC_F];
+template <int CB>
+__global__ __launch_bounds__(GC_NT, (CB == 1 ? 4 : 2)) void k_conv1x1_sq(Conv1x1Args a) {
+    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [CB][CB][2][32][2][32], then bias [C], hh [C]
+    constexpr int C = CB * GC_F;
     const int tid = threadIdx.x;
-    float* Bs = Ws + GC_F * GC_F;  // bias, hh
+    float* Bs = Ws + C * C;
     {
         const float4* src = reinterpret_cast<const float4*>(a.packed);
         float4* dst = reinterpret_cast<float4*>(Ws);
-        for (int i = tid; i < GC_F * GC_F / 4; i += GC_NT) dst[i] = src[i];
-        if (tid < GC_F) {
+        for (int i = tid; i < C * C / 4; i += GC_NT) dst[i] = src[i];
+        if (tid < C) {
             Bs[tid] = a.bias ? a.bias[tid] : 0.f;
-            Bs[GC_F + tid] = a.hh ? a.hh[tid] : 0.f;
+            Bs[C + tid] = a.hh ? a.hh[tid] : 0.f;
         }
     }
     __syncthreads();
@@ -508,67 +513,81 @@ __global__ __launch_bounds__(GC_NT, 4) void k_conv1x1_64(Conv1x1Args a) {
         const long long b = sg / a.nsegb;
         const long long px = (sg - b * a.nsegb) * 32 + l31;
         const bool valid = px < a.P;
-        const long long base = __builtin_amdgcn_readfirstlane((int)b) * (long long)GC_F * a.P;
+        const long long base = __builtin_amdgcn_readfirstlane((int)b) * (long long)C * a.P;
         const unsigned pxo = valid ? (unsigned)px : 0u;
         const float* xb = a.x + base;
-        float xg[32];
+        f32x16 acc[CB][2];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) xg[s] = xb[(unsigned)(2 * s + lhi) * P32 + pxo];
-        f32x16 acc[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = Bs[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
-        {
-            float ra0[GC_PF + 1], ra1[GC_PF + 1];
-#pragma unroll
-            for (int t = 0; t < 32 + GC_PF; ++t) {
-                if (t < 32) {
-                    ra0[t % (GC_PF + 1)] = wl[(0 * 32 + t) * 64];
-                    ra1[t % (GC_PF + 1)] = wl[(1 * 32 + t) * 64];
-                }
-                if (t >= GC_PF) {
-                    const int u = t - GC_PF, c = u % (GC_PF + 1);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], xg[u], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], xg[u], acc[1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        float hv[2][16];  // loaded after the GEMM, into the registers x occupied (128-register budget: two workgroups per CU)
-        if (a.hprev) {
-            const float* hb = a.hprev + base;
+        for (int ob = 0; ob < CB; ++ob)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hv[ct][r] = hb[(unsigned)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo];
-        }
-        float* ob = a.out + base;
+                for (int r = 0; r < 16; ++r) acc[ob][ct][r] = Bs[ob * GC_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ib = 0; ib < CB; ++ib) {
+            float xg[32];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                float v = acc[ct][r];
-                if (a.hprev) v += Bs[GC_F + co] * hv[ct][r];
-                v = v > 0.f ? v : v * neg;
-                if (valid) ob[(unsigned)co * P32 + pxo] = v;
+            for (int s = 0; s < 32; ++s) xg[s] = xb[(unsigned)(ib * GC_F + 2 * s + lhi) * P32 + pxo];
+#pragma unroll
+            for (int ob = 0; ob < CB; ++ob) {
+                const float* wb = wl + (ob * CB + ib) * (GC_F * GC_F);
+                float ra0[GC_PF + 1], ra1[GC_PF + 1];
+#pragma unroll
+                for (int t = 0; t < 32 + GC_PF; ++t) {
+                    if (t < 32) {
+                        ra0[t % (GC_PF + 1)] = wb[(0 * 32 + t) * 64];
+                        ra1[t % (GC_PF + 1)] = wb[(1 * 32 + t) * 64];
+                    }
+                    if (t >= GC_PF) {
+                        const int u = t - GC_PF, c = u % (GC_PF + 1);
+                        acc[ob][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[c], xg[u], acc[ob][0], 0, 0, 0);
+                        acc[ob][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[c], xg[u], acc[ob][1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+        }
+        float* ob_ = a.out + base;
+#pragma unroll
+        for (int ob = 0; ob < CB; ++ob) {
+            float hv[2][16];  // h_prev in accumulator layout, loaded after the GEMM (register budget)
+            if (a.hprev) {
+                const float* hb = a.hprev + base;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        hv[ct][r] = hb[(unsigned)(ob * GC_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo];
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = ob * GC_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float v = acc[ob][ct][r];
+                    if (a.hprev) v += Bs[C + co] * hv[ct][r];
+                    v = v > 0.f ? v : v * neg;
+                    if (valid) ob_[(unsigned)co * P32 + pxo] = v;
+                }
+        }
     }
 }
-extern "C" int mrx_conv1x1_64_pack(const float* w, float* packed, void* stream) {
-    MRX_REQUIRE(w && packed, MRX_EINVAL, "mrx_conv1x1_64_pack: null pointer");
-    hipLaunchKernelGGL(k_conv1x1_pack, dim3(16), dim3(256), 0, (hipStream_t)stream, w, packed);
+extern "C" int mrx_conv1x1_sq_supported(int Cin, int Cout) { return Cin == Cout && (Cin == 64 || Cin == 128); }
+extern "C" int mrx_conv1x1_sq_pack(const float* w, float* packed, int C, void* stream) {
+    MRX_REQUIRE(w && packed, MRX_EINVAL, "mrx_conv1x1_sq_pack: null pointer");
+    MRX_REQUIRE(mrx_conv1x1_sq_supported(C, C), MRX_EUNSUP, "mrx_conv1x1_sq_pack: C=%d (64 or 128)", C);
+    hipLaunchKernelGGL(k_conv1x1_pack, dim3(C * C / 256), dim3(256), 0, (hipStream_t)stream, w, packed, C);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
-extern "C" int mrx_conv1x1_64(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
-                              int B, int64_t HW, int act, float slope, void* stream) {
-    MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv1x1_64: null pointer");
-    MRX_REQUIRE(B >= 0 && HW >= 0 && HW < (1ll << 24) && B < (1 << 30), MRX_EINVAL, "mrx_conv1x1_64: bad dims");
-    MRX_REQUIRE(!h_prev || hh, MRX_EINVAL, "mrx_conv1x1_64: h_prev needs hh");
-    MRX_REQUIRE(act == MRX_ACT_NONE || act == MRX_ACT_RELU || act == MRX_ACT_LEAKY, MRX_EINVAL, "mrx_conv1x1_64: activation %d", act);
-    MRX_REQUIRE(out != x && out != h_prev, MRX_EINVAL, "mrx_conv1x1_64: out must not alias an input");
+extern "C" int mrx_conv1x1_sq(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
+                              int B, int C, int64_t HW, int act, float slope, void* stream) {
+    MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv1x1_sq: null pointer");
+    MRX_REQUIRE(mrx_conv1x1_sq_supported(C, C), MRX_EUNSUP, "mrx_conv1x1_sq: C=%d (64 or 128)", C);
+    MRX_REQUIRE(B >= 0 && HW >= 0 && HW < (1ll << 24) && B < (1 << 30), MRX_EINVAL, "mrx_conv1x1_sq: bad dims");
+    MRX_REQUIRE(!h_prev || hh, MRX_EINVAL, "mrx_conv1x1_sq: h_prev needs hh");
+    MRX_REQUIRE(act == MRX_ACT_NONE || act == MRX_ACT_RELU || act == MRX_ACT_LEAKY, MRX_EINVAL, "mrx_conv1x1_sq: activation %d", act);
+    MRX_REQUIRE(out != x && out != h_prev, MRX_EINVAL, "mrx_conv1x1_sq: out must not alias an input");
     if (B == 0 || HW == 0) return MRX_OK;
     Conv1x1Args a;
     a.x = x;
@@ -591,8 +610,25 @@ extern "C" int mrx_conv1x1_64(const float* x, const float* packed, const float* 
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const long long nblk_need = (a.nseg + GC_NT / 64 - 1) / (GC_NT / 64);
-    const long long cap = 2ll * n_cu;  // two persistent workgroups per CU (16 KB of LDS, <= 128 registers)
-    hipLaunchKernelGGL(k_conv1x1_64, dim3((unsigned)(nblk_need < cap ? nblk_need : cap)), dim3(GC_NT), 0, (hipStream_t)stream, a);
+    const size_t lds = sizeof(float) * ((size_t)C * C + 2 * C);
+    if (C == 64) {
+        const long long cap = 2ll * n_cu;  // two persistent workgroups per CU (16 KB of LDS, <= 128 registers)
+        hipLaunchKernelGGL(k_conv1x1_sq<1>, dim3((unsigned)(nblk_need < cap ? nblk_need : cap)), dim3(GC_NT), lds, (hipStream_t)stream, a);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            MRX_HIP(hipFuncSetAttribute((const void*)k_conv1x1_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        const long long cap = n_cu;
+        hipLaunchKernelGGL(k_conv1x1_sq<2>, dim3((unsigned)(nblk_need < cap ? nblk_need : cap)), dim3(GC_NT), lds, (hipStream_t)stream, a);
+    }
     MRX_LAUNCH_CHECK();
     return MRX_OK;
+}
+// 64-channel forms kept as named entry points
+extern "C" int mrx_conv1x1_64_pack(const float* w, float* packed, void* stream) { return mrx_conv1x1_sq_pack(w, packed, 64, stream); }
+extern "C" int mrx_conv1x1_64(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
+                              int B, int64_t HW, int act, float slope, void* stream) {
+    return mrx_conv1x1_sq(x, packed, bias, hh, h_prev, out, B, 64, HW, act, slope, stream);
 }

@@ -364,33 +364,38 @@ _PACKS_1X1 = {}
 
 
 def _conv1x1_pack(weight):
-    """Packed [64,64,1,1] weights for mrx_conv1x1_64, cached like the Winograd packs (the entry keeps the source tensor alive)."""
-    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.stride()))
+    """Packed [C,C,1,1] weights (C = 64 | 128) for mrx_conv1x1_sq, cached like the Winograd packs (the entry keeps the source alive)."""
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()))
     hit = _PACKS_1X1.get(key)
     if hit is None:
         if len(_PACKS_1X1) >= 128:
             _PACKS_1X1.pop(next(iter(_PACKS_1X1)))
         w = _lib.f32c(weight.detach())
-        packed = torch.empty(64 * 64, dtype=torch.float32, device=w.device)
-        _lib.check(_lib.lib().mrx_conv1x1_64_pack(_lib.ptr(w), _lib.ptr(packed), _lib.stream_ptr()), "mrx_conv1x1_64_pack")
+        C = int(w.shape[0])
+        packed = torch.empty(C * C, dtype=torch.float32, device=w.device)
+        _lib.check(_lib.lib().mrx_conv1x1_sq_pack(_lib.ptr(w), _lib.ptr(packed), C, _lib.stream_ptr()), "mrx_conv1x1_sq_pack")
         hit = _PACKS_1X1[key] = (packed, weight)
     return hit[0]
 
 
+def conv1x1_sq_supported(cin, cout):
+    return bool(_lib.lib().mrx_conv1x1_sq_supported(int(cin), int(cout)))
+
+
 def conv1x1_64(x, weight, bias=None, act=ACT_NONE, slope=0.0, hh=None, h_prev=None, out=None):
-    """act(W x + bias [+ hh * h_prev]) for a 1x1 convolution 64 -> 64 (mrx_conv1x1_64)."""
+    """act(W x + bias [+ hh * h_prev]) for a 1x1 convolution C -> C, C = 64 or 128 (mrx_conv1x1_sq)."""
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
-    if Cin != 64 or tuple(weight.shape) != (64, 64, 1, 1):
-        raise ValueError(f"conv1x1_64: x {tuple(x.shape)}, weight {tuple(weight.shape)}")
+    if not conv1x1_sq_supported(Cin, int(weight.shape[0])) or tuple(weight.shape) != (Cin, Cin, 1, 1):
+        raise ValueError(f"conv1x1: x {tuple(x.shape)}, weight {tuple(weight.shape)}")
     packed = _conv1x1_pack(weight)
     b = _lib.f32c(bias.detach()) if bias is not None else None
     hhc = _lib.f32c(hh.detach().reshape(-1)) if hh is not None and h_prev is not None else None
     hp = _lib.f32c(h_prev) if h_prev is not None else None
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(_lib.lib().mrx_conv1x1_64(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), B, H * W,
-                                         int(act), float(slope), _lib.stream_ptr()), "mrx_conv1x1_64")
+    _lib.check(_lib.lib().mrx_conv1x1_sq(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), B, Cin,
+                                         H * W, int(act), float(slope), _lib.stream_ptr()), "mrx_conv1x1_sq")
     return out
 
 
@@ -426,7 +431,7 @@ def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0
     if (WINOGRAD_CONV and kh == 3 and Cin >= WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
             and conv3x3_wino_supported(Cin, Cout, kh, dilation) and (out is None or out.data_ptr() != x.data_ptr())):
         return conv3x3_wino(x, weight, bias, dilation, pad_mode, act, slope, out)
-    if (kh == 1 and Cin == 64 and Cout == 64 and act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
+    if (kh == 1 and conv1x1_sq_supported(Cin, Cout) and act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
             and (out is None or out.data_ptr() != x.data_ptr())):
         return conv1x1_64(x, weight, bias, act, slope, out=out)          # per-pixel 64x64 GEMM, HBM-bound
     weight = _lib.f32c(weight.detach())
@@ -462,7 +467,7 @@ def indrnn_cell(x, w_ih, b_ih, hh, h_prev, dilation=1, out=None):
     F, Cin_w, k, _ = [int(v) for v in w_ih.shape]
     if Cin_w != Cin:
         raise RuntimeError(f"input has inconsistent input_size: got {Cin}, expected {Cin_w}")
-    if k == 1 and F == 64 and Cin == 64 and out is None:
+    if k == 1 and conv1x1_sq_supported(Cin, F) and out is None:
         return conv1x1_64(x, w_ih, b_ih, ACT_RELU, 0.0, hh, h_prev)      # ReLU(W x + b + hh * h_prev) in one HBM-bound launch
     w_ih = _lib.f32c(w_ih.detach())
     b = _lib.f32c(b_ih.detach()) if b_ih is not None else None

@@ -380,3 +380,11 @@ def test_conv1x1_64_vs_oracle(dev, shape):
     assert_close(ops.conv2d(xd, wd, bd, 1, ops.PAD_ZERO, ops.ACT_LEAKY, 0.1), F.leaky_relu(ref, 0.1), 1e-5, "leaky")
     assert_close(ops.indrnn_cell(xd, wd, bd, hh.to(dev), hp.to(dev), 1), oracle.rim.indrnn_cell(x, hp, w, b, hh, 1, 1), 1e-5, "IndRNN cell")
     assert_close(ops.indrnn_cell(xd, wd, None, hh.to(dev), None, 1), F.relu(F.conv2d(x, w)), 1e-5, "IndRNN cell, zero state")
+    # 128 channels (the qCIRIM's cells): 2 x 2 blocks of the same GEMM
+    x2, hp2 = torch.randn(B, 128, H, W, generator=g), torch.randn(B, 128, H, W, generator=g)
+    w2 = torch.randn(128, 128, 1, 1, generator=g) / 11
+    b2, hh2 = torch.randn(128, generator=g), torch.randn(1, 128, 1, 1, generator=g)
+    assert ops.conv1x1_sq_supported(128, 128) and not ops.conv1x1_sq_supported(64, 128) and not ops.conv1x1_sq_supported(96, 96)
+    assert_close(ops.conv2d(x2.to(dev), w2.to(dev), b2.to(dev), 1, ops.PAD_ZERO), F.conv2d(x2, w2, b2), 1e-5, "1x1 128 -> 128")
+    assert_close(ops.indrnn_cell(x2.to(dev), w2.to(dev), b2.to(dev), hh2.to(dev), hp2.to(dev), 1),
+                 oracle.rim.indrnn_cell(x2, hp2, w2, b2, hh2, 1, 1), 1e-5, "IndRNN cell, 128 features")
