@@ -291,7 +291,7 @@ __global__ __launch_bounds__(CV_NT) void k_conv_small(SmallArgs s) {
 #define P4_NT 512
 #define P4_TH 8
 #define P4_TW 32
-#define P4_CK 16
+#define P4_CK 32
 template <int CO, int K>
 __global__ __launch_bounds__(P4_NT) void k_conv_small_px4(SmallArgs s) {
     constexpr int PAD = (K - 1) / 2, PH = P4_TH + 2 * PAD, XS = P4_TW + 8;  // tile columns [w0 - 4, w0 + 36): float4-aligned rows
