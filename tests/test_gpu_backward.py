@@ -148,3 +148,31 @@ def test_training_step_matches_torch_adam(dev):
     ref = oracle.models.cirim_forward(cur, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"])
     assert_close(torch.view_as_real(out[-1][-1]), torch.view_as_real(ref[-1][-1]), 1e-4, "forward after two optimizer steps")
     assert any(not torch.equal(cur[k], state[k]) for k in state), "the optimizer moved the parameters"
+
+
+@pytest.mark.parametrize("mask_kind", ["1d", "2d"])
+def test_llg_backward_is_its_own_adjoint(dev, mask_kind):
+    """log_likelihood_gradient's backward (the forward kernel on the incoming gradient with y = 0) against torch autograd of the
+    oracle, for the one-launch row-invariant form and the general three-launch form."""
+    import oracle
+    from mridc_amd import autograd as ag
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 1, 3, 20, 24
+    eta = torch.randn(B, H, W, 2, generator=g, requires_grad=True)
+    y = torch.randn(B, C, H, W, 2, generator=g)
+    S = torch.randn(B, C, H, W, 2, generator=g) / C ** 0.5
+    mask = (torch.rand(1, 1, 1, W, 1, generator=g) < 0.4) if mask_kind == "1d" else (torch.rand(1, 1, H, W, 1, generator=g) < 0.4)
+    y = y * mask
+    dout = torch.randn(B, 4, H, W, generator=g)
+    for centered, norm in ((False, "backward"), (True, "ortho")):
+        eta.grad = None
+        ref = oracle.rim.log_likelihood_gradient(eta, y, S, mask, 1.3, centered, norm, [-2, -1], 1)
+        ref.backward(dout)
+        e = eta.detach().to(dev).requires_grad_(True)
+        hinv = mask_kind == "1d"
+        data = ops.llg_prepare(y.to(dev), centered, norm) if hinv else y.to(dev)
+        out = ag.LogLikelihoodGradient.apply(e, data, S.to(dev), mask.to(dev), 1.3, centered, norm, hinv)
+        assert_close(out, ref.detach(), 1e-5, f"llg forward {mask_kind} {norm}")
+        out.backward(dout.to(dev))
+        assert_close(e.grad, eta.grad, 1e-5, f"llg backward {mask_kind} {norm}")
