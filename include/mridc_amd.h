@@ -355,6 +355,8 @@ int mrx_avg_pool2x2(const float* in, float* out, int64_t planes, int H, int W, v
 int mrx_conv_transpose2x2(const float* x, const float* w, float* out, int B, int Cin, int Cout, int H, int W,
                           void* stream);
 int mrx_copy_channels(const float* src, float* dst, int B, int C, int64_t HW, int Ctot, int c0, void* stream);
+/* torch.cat([a, b], dim=1) of [B,Ca,HW] and [B,Cb,HW] in one launch (the skip concat, unet_block.py:224) */
+int mrx_concat_channels(const float* a, const float* b, float* out, int B, int Ca, int Cb, int64_t HW, void* stream);
 
 /* A20 SSIMLoss.forward (mridc/collections/common/losses/ssim.py:28-61): X,Y [B,1,h,w], data_range [B] -> out[0] = 1 - mean(S).
  * work: mrx_ssim_work_floats(B,h,w) floats. */

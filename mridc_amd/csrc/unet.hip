@@ -436,6 +436,25 @@ extern "C" int mrx_copy_channels(const float* src, float* dst, int B, int C, int
     return MRX_OK;
 }
 
+// torch.cat([a, b], dim=1) in one launch (unet_block.py:224): out[b] = (a[b] (Ca planes), b[b] (Cb planes))
+__global__ void k_concat2(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long na, long long nb,
+                          long long total) {
+    const long long per = na + nb;  // floats per batch element of the result
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long bi = o / per, r = o - bi * per;
+        out[o] = r < na ? a[bi * na + r] : b[bi * nb + (r - na)];
+    }
+}
+extern "C" int mrx_concat_channels(const float* a, const float* b, float* out, int B, int Ca, int Cb, int64_t HW, void* stream) {
+    MRX_REQUIRE(a && b && out && B >= 0 && Ca >= 0 && Cb >= 0 && HW >= 0, MRX_EINVAL, "mrx_concat_channels: bad argument");
+    const long long total = (long long)B * (Ca + Cb) * HW;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_concat2, dim3(un_grid(total)), dim3(UN_NT), 0, (hipStream_t)stream, a, b, out, (long long)Ca * HW,
+                       (long long)Cb * HW, total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 // ---- SSIM (reference common/losses/ssim.py:46-61): 7x7 uniform window (valid), cov_norm = NP/(NP-1), 1 - mean(S) ----------
 // One thread per output pixel of a 16x16 tile, both images staged in LDS with their halo; per-workgroup partial sums of S
 // are reduced by a second single-workgroup kernel in double (deterministic, no atomics).

@@ -839,14 +839,13 @@ def conv_transpose2x2(x, weight):
 
 
 def concat_channels(a, b):
-    """torch.cat([a, b], dim=1) as two device copies into one buffer."""
+    """torch.cat([a, b], dim=1) in one launch."""
     a, b = _lib.f32c(a), _lib.f32c(b)
     B, Ca, H, W = _nchw(a)
     Cb = int(b.shape[1])
     out = torch.empty(B, Ca + Cb, H, W, dtype=torch.float32, device=a.device)
-    L = _lib.lib()
-    _lib.check(L.mrx_copy_channels(_lib.ptr(a), _lib.ptr(out), B, Ca, H * W, Ca + Cb, 0, _lib.stream_ptr()), "mrx_copy_channels")
-    _lib.check(L.mrx_copy_channels(_lib.ptr(b), _lib.ptr(out), B, Cb, H * W, Ca + Cb, Ca, _lib.stream_ptr()), "mrx_copy_channels")
+    _lib.check(_lib.lib().mrx_concat_channels(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), B, Ca, Cb, H * W, _lib.stream_ptr()),
+               "mrx_concat_channels")
     return out
 
 
