@@ -74,7 +74,14 @@ __global__ __launch_bounds__(WG_NT, 2) void k_conv_wgrad64(WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[j][ct][r] = 0.f;
     const long long plane = (long long)a.H * a.W;
     const long long nt_total = (long long)a.ntiles * a.B;
-    for (long long v = blockIdx.x; v < nt_total; v += gridDim.x) {
+    // Tile order: workgroup g runs on XCD g % 8 (one L2 each).  With a grid that is a multiple of 8 every XCD walks its own contiguous
+    // band of tiles, so the halo rows two neighbouring tiles share are fetched into one L2 (PMC: FETCH_SIZE was 2.4x the input).
+    const bool banded = (gridDim.x & 7) == 0;
+    const long long per_xcd = (nt_total + 7) >> 3;
+    const long long i_step = banded ? (gridDim.x >> 3) : gridDim.x;
+    for (long long i = banded ? (blockIdx.x >> 3) : blockIdx.x; i < (banded ? per_xcd : nt_total); i += i_step) {
+        const long long v = banded ? (long long)(blockIdx.x & 7) * per_xcd + i : i;
+        if (v >= nt_total) break;
         const int b = (int)(v / a.ntiles), t = (int)(v - (long long)b * a.ntiles);
         const int ty0 = t / a.tiles_x, h0 = ty0 * WG_TH, w0 = (t - ty0 * a.tiles_x) * WG_TW;
         __syncthreads();  // the previous tile's operands are consumed
