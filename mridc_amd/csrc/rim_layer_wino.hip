@@ -179,9 +179,11 @@ __global__ __launch_bounds__(WN_NT, 2) void k_rim_layer_wino(WinoArgs a) {
     unsigned zp_ok = 0xffffu;  // ZP: bit 4 i + j set = patch element (i, j) of this lane's tile lies inside the image
     bool zp_border = false;    // ZP: this tile touches the image border (wave-uniform)
     auto set_tile = [&](int v) {  // tile coordinates and the per-lane DMA / gather offsets that depend on them
-        b = v / a.ntiles;
-        int t = v - b * a.ntiles;
-        if ((a.ntiles & 7) == 0 && (gridDim.x & 7) == 0) t = (t & 7) * (a.ntiles >> 3) + (t >> 3);
+        // workgroup g runs on XCD g % 8 and v % 8 = g % 8 when the grid is a multiple of 8: every XCD walks one contiguous band of
+        // the (batch x tile) list, for any tile count
+        const int vb = (gridDim.x & 7) == 0 ? (int)mrx_xcd_band(v, nt_total) : v;
+        b = vb / a.ntiles;
+        const int t = vb - b * a.ntiles;
         const int ty0 = t / a.tiles_x;
         h0 = ty0 * 8;
         w0 = (t - ty0 * a.tiles_x) * 32;
