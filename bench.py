@@ -6,8 +6,11 @@ reference cirim.py:50-51), IndRNN 64 filters, 15 coils, 640x372, fp32, batch 1 s
 A "step" is one full reconstruction of one batch through the HIP path (64 RIM steps = 384 kernel launches).
 
     python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); slices shard across ranks with no data-path
-collective ("weak" scaling); timing is barrier + synchronize on both sides, max over ranks.
+One process per GPU (the reference: pytorch-lightning `strategy: ddp`, base_cirim_train.yaml:175).  Under torch.distributed.run the
+ranks exist already (WORLD_SIZE / RANK / LOCAL_RANK in the environment); a bare `python bench.py --gpus N` with N > 1 spawns the N
+rank processes itself -- from a parent that never touches the GPU -- and exits with their status.  Slices shard across ranks with
+no data-path collective ("weak" scaling); timing is barrier + synchronize on both sides, max over ranks; rank 0 prints the line,
+with the world size RCCL reported and every rank's own time so a straggler is visible.
 
 Prints ONE JSON line with the contract fields plus
   roofline      dominant kernel (fused conv3x3(d2)+IndRNN layer, fp32 MFMA): algorithmic FLOPs / HIP-event time
@@ -55,11 +58,84 @@ def parse():
     ap.add_argument("--train", action="store_true",
                     help="config C4: data-parallel TRAINING steps of the CIRIM (forward, l1 loss, backward through the HIP kernels, one "
                          "flat-gradient all-reduce, Adam) instead of inference; fp32")
-    ap.add_argument("--cpu-cascades", type=int, default=1, help="cascades of the CPU-baseline sample")
+    ap.add_argument("--cpu-cascades", type=int, default=0,
+                    help="cascades of the CPU-baseline sample (0 = all of them: one whole slice, about 20 s on the GPU box's host)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="--train only: bf16 = convolution / IndRNN GEMM operands in bf16 with fp32 accumulation (the reference's "
+                         "`precision: 16` AMP, base_cirim_train.yaml:180), FFT / data consistency / eta accumulation stay fp32")
+    ap.add_argument("--dist-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.streams <= 0:
         args.streams = 3 if args.model == "e2evn" else 2
     return args
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def rank_launch_plan(n_gpus, argv, environ):
+    """The N child (command, environment) pairs of a bare `--gpus N` run, or None when this process is a rank already (a launcher
+    set WORLD_SIZE) or N == 1.  Pure host logic: nothing here may touch the GPU (the children initialise it, never the parent)."""
+    if n_gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    port = environ.get("MASTER_PORT") or str(_free_port())
+    plan = []
+    for r in range(n_gpus):
+        env = dict(environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+        plan.append(([sys.executable, os.path.abspath(__file__)] + list(argv), env))
+    return plan
+
+
+def spawn_ranks(plan):
+    """Start every rank as a fresh child, wait for all; if one fails stop the others (exact PIDs) and return its status."""
+    import subprocess
+    procs = [subprocess.Popen(cmd, env=env) for cmd, env in plan]
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p_ in list(pending):
+                r = p_.poll()
+                if r is None:
+                    continue
+                pending.remove(p_)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    return rc
+
+
+def dist_selftest(args):
+    """`--dist-selftest`: the rank plumbing of this file (process-group init, barrier, max over ranks, per-rank times) on the gloo
+    backend with no GPU work -- what tests/test_sharding_gloo.py runs to cover the spawn path on a CPU-only machine."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mridc_amd.sharding import shard_range
+    s0, s1 = shard_range(world * 2, rank, world)
+    dist_barrier(sync=False)
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dist_barrier(sync=False)
+    elapsed, per_rank = rank_times(time.perf_counter() - t0, None)
+    if rank == 0:
+        print(json.dumps(dict(selftest="dist", n_gpus=world, gpus_flag=args.gpus, world_size_seen=dist.get_world_size() if world > 1 else 1,
+                              per_rank_ms=[1e3 * t for t in per_rank], max_ms=1e3 * elapsed, slices_rank0=[s0, s1])), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 class KernelTimer:
@@ -93,34 +169,73 @@ class KernelTimer:
         return sum(s.elapsed_time(e) for s, e in ev) / len(ev), len(ev)
 
 
-def cpu_baseline(cfg, state_dict, data, gpu_out, n_cascades):
-    """Time the oracle (CPU restatement of the reference path, torch CPU ops) on a bounded sample of the same slice."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, state_dict, data, n_cascades):
+    """Time the oracle (CPU restatement of the reference path, torch CPU ops) on the same slice the GPU reconstructed, per BASELINE.md
+    section 3: one untimed warm-up cascade, then `n_cascades` cascades timed one by one (all of them by default = one whole slice),
+    plus the FFT+DC step on its own.  Returns (cpu_baseline dict, the oracle's list[cascade][time_step] output)."""
     import oracle
-    # the reference's CPU path is torch intra-op threading; beyond ~32 threads these op sizes slow down (measured:
-    # 256 threads on the GPU box's host ran 36x slower than 8 threads), so cap the pool and report what was used
-    ncores = min(os.cpu_count() or 1, 32)
+    # the reference's CPU path is torch intra-op threading; beyond ~32 threads these op sizes slow down (measured: 256 threads on the
+    # GPU box's host ran 36x slower than 8), so the pool is capped; both numbers are reported
+    box_cores = os.cpu_count() or 1
+    ncores = min(box_cores, 32)
     torch.set_num_threads(ncores)
-    sub_cfg = dict(cfg, num_cascades=n_cascades)
-    sd = {k: v for k, v in state_dict.items()}
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        ref = oracle.models.cirim_forward(sd, sub_cfg, data["y"], data["sensitivity_maps"], data["mask"], None,
-                                          data["target"])
-        dt = time.perf_counter() - t0
     T_ = oracle.models.cirim_time_steps(cfg["time_steps"])
+    y, S, mask, target = data["y"], data["sensitivity_maps"], data["mask"], data["target"]
+    with torch.no_grad():
+        oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=1), y, S, mask, None, target)       # warm-up, untimed
+        stamps = [time.perf_counter()]
+        ref = oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=n_cascades), y, S, mask, None, target,
+                                          cascade_stamps=stamps)
+        eta = torch.zeros(1, y.shape[2], y.shape[3], 2)
+        oracle.rim.log_likelihood_gradient(eta, y, S, mask, 1.0, cfg["fft_centered"], cfg["fft_normalization"], cfg["spatial_dims"],
+                                           cfg["coil_dim"])
+        t0 = time.perf_counter()
+        for _ in range(3):
+            oracle.rim.log_likelihood_gradient(eta, y, S, mask, 1.0, cfg["fft_centered"], cfg["fft_normalization"],
+                                               cfg["spatial_dims"], cfg["coil_dim"])
+        llg_s = (time.perf_counter() - t0) / 3
+    per = [b_ - a_ for a_, b_ in zip(stamps[:-1], stamps[1:])]
+    dt = sum(per)
     sec_per_slice = dt * cfg["num_cascades"] / n_cascades
-    # parity of the GPU result with the oracle on the sampled cascades (same weights, same inputs)
-    got = gpu_out[n_cascades - 1][-1][0].cpu()
-    want = ref[n_cascades - 1][-1][0]
-    rel = float((torch.view_as_real(got).double() - torch.view_as_real(want).double()).norm()
-                / torch.view_as_real(want).double().norm())
-    o1, _ = oracle.metrics.postprocess(got[None], data["target"])
-    o2, _ = oracle.metrics.postprocess(want[None], data["target"])
-    ssim = oracle.metrics.ssim(o2.numpy(), o1.numpy(), maxval=float(o2.max() - o2.min()))
-    return dict(value=1.0 / sec_per_slice, unit="slices/s", cores=ncores, kind="port",
-                sample=f"{n_cascades} of {cfg['num_cascades']} cascades ({n_cascades * T_} of {cfg['num_cascades'] * T_} RIM "
-                       f"steps) of one slice on the oracle (torch CPU ops, {ncores} threads), {dt:.1f} s, extrapolated "
-                       f"x{cfg['num_cascades'] / n_cascades:g}"), rel, ssim
+    step_s = dt / (n_cascades * T_)
+    whole = n_cascades == cfg["num_cascades"]
+    return dict(value=1.0 / sec_per_slice, unit="slices/s", cores=ncores, kind="port", box_cores=box_cores, cpu_model=cpu_model_name(),
+                sec_per_cascade_mean=dt / n_cascades, sec_per_cascade_min=min(per), sec_per_cascade=per,
+                split_ms_per_rim_step=dict(fft_dc=1e3 * llg_s, regulariser=1e3 * max(step_s - llg_s, 0.0)),
+                sample=(f"after one untimed warm-up cascade: {n_cascades} of {cfg['num_cascades']} cascades ({n_cascades * T_} of "
+                        f"{cfg['num_cascades'] * T_} RIM steps) of one slice on the oracle (torch CPU ops, {ncores} threads of the box's "
+                        f"{box_cores}), timed per cascade, {dt:.1f} s in all"
+                        + ("" if whole else f", extrapolated x{cfg['num_cascades'] / n_cascades:g}"))), ref
+
+
+def parity_vs_oracle(gpu_pred, ref_pred, target, at):
+    """The GPU reconstruction against the oracle's on the same weights and inputs: rel-L2 of the complex images and the metric's
+    "SSIM vs ref" -- SSIM (harness formula, models/base.py:415-436) of the two `abs / max` images, computed by the PRODUCT
+    (mridc_amd.runner on the device); the oracle's own SSIM of the same pair is the checker next to it."""
+    import oracle
+    from mridc_amd import runner
+    got, want = gpu_pred.cpu(), ref_pred
+    rel = float((torch.view_as_real(got).double() - torch.view_as_real(want).double()).norm() / torch.view_as_real(want).double().norm())
+    dev = gpu_pred.device
+    o_gpu, o_ref = runner.postprocess(gpu_pred, want.to(dev))                     # both through the product's post-processing
+    m = runner.metrics_to_dict(runner.slice_metrics(o_gpu, o_ref))
+    c1, _ = oracle.metrics.postprocess(got, want)
+    c2, _ = oracle.metrics.postprocess(want, want)
+    ssim_chk = oracle.metrics.ssim(c2.numpy(), c1.numpy(), maxval=float(c1.max() - c1.min()))
+    vs_target = runner.metrics_to_dict(runner.slice_metrics(*runner.postprocess(gpu_pred, target.to(dev))))
+    vs_target.pop("maxval")
+    return dict(rel_l2=rel, ssim=m["SSIM"], ssim_oracle_check=ssim_chk, nmse=m["NMSE"], at=at, metrics_vs_target=vs_target)
 
 
 def bench_qcirim(args, world, rank, dev):
@@ -186,11 +301,12 @@ def bench_qcirim(args, world, rank, dev):
                 else:
                     step(datas[i])
     dist_barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
     if rank == 0:
         print(json.dumps(dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256", value=world * NS * args.steps / elapsed,
                               unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
-                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                              higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
+                              per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank], dtype="f32", data="synthetic",
                               config=dict(workload=f"qCIRIM 1 cascade x 8 time-steps, IndRNN 128 filters, 4 echoes, 32 coils, 256x256, {NS} slice(s) "
                                                    f"per GPU and step ({NS} HIP stream(s), {'hipGraph' if graphs else 'eager'}), random-init weights",
                                           parallelism=f"slice-sharded x{world}"))), flush=True)
@@ -269,12 +385,13 @@ def bench_e2evn(args, world, rank, dev):
                 else:
                     step(datas[i])
     dist_barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
     B = NS * B
     if rank == 0:
         print(json.dumps(dict(metric=f"slices/sec (inference), {label} {C}-coil {H}x{W}", value=world * B * args.steps / elapsed,
                               unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                              ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                              ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
+                              per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
                               dtype="f32", data="synthetic",
                               config=dict(workload=f"{desc}, {C} coils, {H}x{W}, batch "
                                                    f"{B} per GPU ({NS} concurrent HIP stream(s), {'one hipGraph each' if graphs else 'eager'}), random-init weights "
@@ -305,12 +422,13 @@ def bench_train(args, world, rank, dev):
     for _ in range(args.steps):
         loss = training.training_step(model, flat, opt, batch)
     dist_barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
     losses.append(float(loss))
     if rank == 0:
         print(json.dumps(dict(metric=f"slices/sec (training), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}",
                               value=world * args.steps / elapsed, unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                              ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                              ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
+                              per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
                               dtype="f32", data="synthetic",
                               config=dict(workload=f"CIRIM {cfg['num_cascades']} cascades x {model.time_steps} time-steps, IndRNN 64, {C} coils, "
                                                    f"{H}x{W}: forward + l1 loss + backward (HIP kernels) + one all-reduce of the flat gradient "
@@ -319,45 +437,72 @@ def bench_train(args, world, rank, dev):
                               loss_first=losses[0], loss_last=losses[-1])), flush=True)
 
 
-def dist_barrier():
+def dist_barrier(sync=True):
     """Barrier over the ranks (when a process group exists) + device synchronize."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
-    torch.cuda.synchronize()
+    if sync:
+        torch.cuda.synchronize()
 
 
-def max_over_ranks(elapsed, dev):
+def rank_times(elapsed, dev):
+    """(max over ranks, [every rank's elapsed seconds]) -- one all-gather of a double per rank."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)
+        per_rank = [float(v.item()) for v in every]
+        return max(per_rank), per_rank
+    return elapsed, [elapsed]
+
+
+def max_over_ranks(elapsed, dev):
+    return rank_times(elapsed, dev)[0]
+
+
+def world_seen():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def measured_traffic(B, C, H, W, F):
-    """HBM bytes per launch of the hot kernels from the committed PMC passes (profiles/r01_v7_traffic.json: FETCH_SIZE and
-    WRITE_SIZE, one counter per rocprofv3 pass, gfx950 correction applied).  Counter collection cannot run inside the timed
-    bench (~0.3 s per dispatch), so the numbers are only reported when this run has the shape they were measured at."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v7_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-    except OSError:
-        return {}
-    if t["shape"] != dict(batch=B, coils=C, height=H, width=W, features=F):
-        return {}
-    out = {k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()}
-    out["_source"] = "profiles/r01_v7_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)"
-    return out
+    """HBM bytes per launch of the hot kernels from the newest committed PMC passes (profiles/r*_traffic.json: FETCH_SIZE and
+    WRITE_SIZE, one counter per rocprofv3 pass, gfx950 correction applied; written by tools/traffic_json.py).  Counter collection
+    cannot run inside the timed bench (~0.3 s per dispatch), so the numbers are reported only when this run has the shape AND the
+    library version (mrx_version: bumped with every kernel change) they were measured with -- otherwise `traffic` is null."""
+    import glob
+    from mridc_amd import _lib
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+    for path in reversed(paths):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if t.get("shape") != dict(batch=B, coils=C, height=H, width=W, features=F) or t.get("lib_version") != int(_lib.lib().mrx_version()):
+            continue
+        out = {k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()}
+        out["_kernels"] = {k: v["kernel"] for k, v in t["kernels"].items()}
+        out["_source"] = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)"
+        return out
+    return {}
 
 
 def main():
     args = parse()
+    plan = rank_launch_plan(args.gpus, sys.argv[1:], os.environ)
+    if plan is not None:                                  # bare `--gpus N`: this parent only spawns and waits (no GPU call before this)
+        sys.exit(spawn_ranks(plan))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
+    if args.dist_selftest:
+        dist_selftest(args)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -437,11 +582,7 @@ def main():
         with torch.no_grad():
             return next(model(d["y"], d["sensitivity_maps"], d["mask"], None, d["target"]))
 
-    def barrier():
-        if use_dist:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = dist_barrier
 
     out = None
     for _ in range(max(args.warmup, 1)):
@@ -491,49 +632,59 @@ def main():
                     if i == 0:
                         out = o_
     barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
 
     if rank == 0:
         T_ = model.time_steps
         npix = H * W
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * NS * B * args.steps / elapsed
-        # dominant kernel: fused layer 2 = conv3x3 dil2 (64->64) + 1x1 ih (64->64): 2*(64*64*9 + 64*64) flop / pixel
+        # dominant kernel: fused layer 2 = conv3x3 dil2 (64->64) + 1x1 ih (64->64): 2*(64*64*9 + 64*64) flop / pixel (SURVEY 8d,
+        # direct-form count).  The Winograd form issues 2*(64*64*4 + 64*64) of MFMA work for it: `achieved` / `frac` are what the
+        # matrix pipe actually executes (a fraction of the fp32-MFMA peak, never above 1); the direct-form rate is kept beside them
+        # as `algorithmic_*` (the saving of the algorithm, not pipe utilisation).
         flops2 = 2.0 * (F_hidden * F_hidden * 9 + F_hidden * F_hidden) * npix * B
         ms2, n2 = timer.mean_ms("conv_layer2")
         kname = "k_rim_layer<3,2,8> (conv3x3 d2 64->64 + IndRNN 1x1 fused, fp32 MFMA 32x32x2)"
         executed = flops2
         msw, nw = timer.mean_ms("conv_layer2_wino")
         if msw:
-            # Winograd F(2x2,3x3): 16 instead of 36 multiplies per 2x2 outputs of the 3x3 part; `achieved` stays in algorithmic
-            # (direct-form) flops as section 8(d) defines them, `mfma_frac` is the share of fp32-MFMA peak actually issued
             ms2, n2 = msw, nw
             kname = ("k_rim_layer_wino (conv3x3 d2 64->64 as Winograd F(2x2,3x3) on the parity sub-lattices + IndRNN 1x1 fused, "
                      "fp32 MFMA 16x16x4 / 32x32x2)")
             executed = 2.0 * (F_hidden * F_hidden * 4 + F_hidden * F_hidden) * npix * B
         traffic = measured_traffic(B, C, H, W, F_hidden)
-        roofline = dict(bound="mfma", kernel=kname,
-                        achieved=(flops2 / (ms2 * 1e-3) / 1e12) if ms2 else None, peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=(flops2 / (ms2 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms2 else None,
-                        traffic=traffic.get("conv_layer2_wino" if msw else "-"), traffic_unit="bytes/launch",
-                        traffic_source=traffic.get("_source"), algorithmic_bytes=3.0 * F_hidden * npix * B * 4,
-                        launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
-                        mfma_frac=(executed / (ms2 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms2 else None)
-        bytes_llg = (25.0 + 16.0 * C) * npix * B     # SURVEY 8d: compulsory bytes of one log_likelihood_gradient
-        msl, nl = timer.mean_ms("llg")
-        roofline_fft = dict(bound="hbm", kernel="mrx_llg_hinv (1-D column mask: H transforms cancel, ONE launch of row FFTs per step on "
-                                                "yt = IFFT_H(y); 2-D masks use the 3-launch mrx_llg)",
-                            achieved=(bytes_llg / (msl * 1e-3) / 1e9) if msl else None, peak=PEAK_HBM_GBS, unit="GB/s",
-                            frac=(bytes_llg / (msl * 1e-3) / 1e9 / PEAK_HBM_GBS) if msl else None,
-                            traffic=traffic.get("llg") if args.mask == "1d" else None, traffic_unit="bytes/launch",
-                            launches=nl, avg_ms=msl, bytes_per_call=bytes_llg)
+        tf = (lambda fl: fl / (ms2 * 1e-3) / 1e12) if ms2 else (lambda fl: None)
         ms1, _ = timer.mean_ms("conv_layer1")
         msf, _ = timer.mean_ms("final")
+        msl, nl = timer.mean_ms("llg")
+        # whole regulariser (layer 1 + layer 2 + final conv) as issued on the matrix / vector pipes against the fp32 peak
+        flops_reg = 105216.0 * npix * B                     # 25.05 GFLOP per slice-step (direct form)
+        issued_reg = flops_reg - (flops2 - executed)
+        t_reg = (ms1 or 0) + (ms2 or 0) + (msf or 0)
+        roofline = dict(bound="mfma", kernel=kname,
+                        achieved=tf(executed), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=(tf(executed) / PEAK_FP32_MFMA_TFLOPS) if ms2 else None,
+                        frac_meaning="MFMA FLOPs the kernel issues / fp32-MFMA peak (pipe utilisation)",
+                        algorithmic_achieved=tf(flops2), algorithmic_frac=(tf(flops2) / PEAK_FP32_MFMA_TFLOPS) if ms2 else None,
+                        algorithmic_note="direct-form FLOPs of SURVEY 8d / time: above `frac` by the Winograd saving (2.0x), not a pipe figure",
+                        traffic=traffic.get("conv_layer2_wino" if msw else "conv_layer2"), traffic_unit="bytes/launch",
+                        traffic_kernel=traffic.get("_kernels", {}).get("conv_layer2_wino" if msw else "conv_layer2"),
+                        traffic_source=traffic.get("_source"), algorithmic_bytes=3.0 * F_hidden * npix * B * 4,
+                        launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
+                        regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_gflop=issued_reg / 1e9,
+                                         frac_issued=(issued_reg / (t_reg * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if t_reg else None))
+        bytes_llg = (25.0 + 16.0 * C) * npix * B     # SURVEY 8d: compulsory bytes of one log_likelihood_gradient
+        # the formulation executed for 1-D masks reads yt = IFFT_H(y) instead of y: the same (25+16C)N compulsory bytes per step
+        # (plus one column pass per slice, outside the step, to make yt)
+        roofline_fft = dict(bound="hbm", kernel=("mrx_llg_hinv_parts (1-D column mask: H transforms cancel, ONE launch of row FFTs per step on "
+                                                 "yt = IFFT_H(y), coil-chunk sum finished by layer 1's tile loader)" if args.mask == "1d"
+                                                 else "mrx_llg (general mask: rows, columns + DC in LDS, rows: three launches)"),
+                            achieved=(bytes_llg / (msl * 1e-3) / 1e9) if msl else None, peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=(bytes_llg / (msl * 1e-3) / 1e9 / PEAK_HBM_GBS) if msl else None,
+                            traffic=traffic.get("llg") if args.mask == "1d" else traffic.get("llg_2d"), traffic_unit="bytes/launch",
+                            traffic_kernel=traffic.get("_kernels", {}).get("llg" if args.mask == "1d" else "llg_2d"),
+                            launches=nl, avg_ms=msl, bytes_per_call=bytes_llg)
         res = dict(metric=f"slices/sec (inference), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}"
                           + ("" if args.rnn == "IndRNN" else f" ({args.rnn})"), value=value, unit="slices/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
@@ -545,18 +696,22 @@ def main():
                                global_batch=world * NS * B, streams_per_gpu=NS, coils=C, height=H, width=W, parallelism=f"slice-sharded x{world}",
                                mask=("1-D random columns R=4 (row-invariant: one-launch gradient)" if args.mask == "1d" else
                                      "2-D random points R~10 (general three-launch gradient)")),
+                   world_size_seen=world_seen(), per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
                    launch="hipGraph replay" if graphed else "eager", roofline=roofline, roofline_fft=roofline_fft,
                    breakdown_ms=dict(llg=msl, conv_layer1=ms1, conv_layer2=ms2, final=msf,
                                      rim_steps_per_slice=cfg["num_cascades"] * T_))
         if world == 1 and not args.no_cpu_baseline:
+            n_cpu = args.cpu_cascades if 0 < args.cpu_cascades <= cfg["num_cascades"] else cfg["num_cascades"]
             try:
-                cb, rel, ssim = cpu_baseline(cfg, state_dict, {k: v[:1] if k != "mask" else v for k, v in host.items()},
-                                             out, args.cpu_cascades)
+                host1 = {k: v[:1] if k != "mask" else v for k, v in host.items()}
+                cb, ref = cpu_baseline(cfg, state_dict, host1, n_cpu)
                 res["cpu_baseline"] = cb
-                res["parity_vs_oracle"] = dict(rel_l2=rel, ssim=ssim, at=f"cascade {args.cpu_cascades}, last time-step")
+                res["parity_vs_oracle"] = parity_vs_oracle(out[n_cpu - 1][-1][0:1], ref[n_cpu - 1][-1][0:1], host1["target"],
+                                                           at=f"cascade {n_cpu} of {cfg['num_cascades']}, last time-step"
+                                                              + (" (the final image)" if n_cpu == cfg["num_cascades"] else ""))
             except Exception as ex:  # noqa: BLE001
                 res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port",
-                                           sample=f"failed: {ex}")
+                                           sample=f"failed: {type(ex).__name__}: {ex}")
         print(json.dumps(res), flush=True)
     if use_dist:
         import torch.distributed as dist

@@ -393,6 +393,13 @@ int64_t mrx_max_abs_work_floats(void);
 int mrx_max_abs(const float* x, int64_t n, int mode, float* out, float* work, void* stream);
 int mrx_div_by_device_scalar(const float* x, const float* d, float* out, int64_t n, int mode, void* stream);
 
+/* Row H, the per-slice metrics of the reference's test harness (models/base.py:415-436 with
+ * common/metrics/reconstruction_metrics.py:11-25): target, output = the `abs / max` images [n] ->
+ * out5 = { MSE, NMSE, maxval = max(output) - min(output), PSNR = 10 log10(maxval^2 / MSE), sum target^2 }, all on the device
+ * (out5[2] is the data_range mrx_ssim_loss takes for the SSIM value).  work: mrx_recon_metrics_work_floats() floats, 8-byte aligned. */
+int64_t mrx_recon_metrics_work_floats(void);
+int mrx_recon_metrics(const float* target, const float* output, float* out5, float* work, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

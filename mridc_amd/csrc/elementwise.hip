@@ -224,6 +224,69 @@ extern "C" int mrx_div_by_device_scalar(const float* x, const float* d, float* o
     return MRX_OK;
 }
 
+// ---- per-slice evaluation metrics of the test harness (models/base.py:415-436, common/metrics/reconstruction_metrics.py:11-25) ------
+// target, output: the `abs / max` images [n].  out5 = { MSE = mean (t - o)^2,  NMSE = sum (t - o)^2 / sum t^2,
+// maxval = max(o) - min(o) (the data range base.py:429-436 hands to SSIM and PSNR),  PSNR = 10 log10(maxval^2 / MSE),  sum t^2 }.
+// Differences in fp32 (as numpy does on float32 arrays), sums in double with a fixed order: results are reproducible.
+#define METRIC_BLOCKS 256
+__global__ void k_metric_partial(const float* __restrict__ t, const float* __restrict__ o, double* __restrict__ part, long long n) {
+    __shared__ double red[EW_NT / 64][4];
+    double sd = 0.0, st = 0.0;
+    float mn = INFINITY, mx = -INFINITY;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float tv = t[i], ov = o[i];
+        const float d = __fsub_rn(tv, ov);
+        sd += (double)__fmul_rn(d, d);
+        st += (double)__fmul_rn(tv, tv);
+        mn = fminf(mn, ov);
+        mx = fmaxf(mx, ov);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sd += __shfl_xor(sd, off, 64);
+        st += __shfl_xor(st, off, 64);
+        mn = fminf(mn, __shfl_xor(mn, off, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        double* r = red[threadIdx.x >> 6];
+        r[0] = sd, r[1] = st, r[2] = (double)mn, r[3] = (double)mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < EW_NT / 64; ++w) {
+            sd += red[w][0], st += red[w][1];
+            mn = fminf(mn, (float)red[w][2]), mx = fmaxf(mx, (float)red[w][3]);
+        }
+        double* p = part + 4ll * blockIdx.x;
+        p[0] = sd, p[1] = st, p[2] = (double)mn, p[3] = (double)mx;
+    }
+}
+__global__ void k_metric_final(const double* __restrict__ part, int np, long long n, float* __restrict__ out5) {
+    if (threadIdx.x != 0) return;
+    double sd = 0.0, st = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (int i = 0; i < np; ++i) {
+        sd += part[4 * i], st += part[4 * i + 1];
+        mn = fmin(mn, part[4 * i + 2]), mx = fmax(mx, part[4 * i + 3]);
+    }
+    const double mse = sd / (double)n, range = (double)((float)mx - (float)mn);
+    out5[0] = (float)mse;
+    out5[1] = (float)(sd / st);
+    out5[2] = (float)range;
+    out5[3] = (float)(10.0 * log10(range * range / mse));
+    out5[4] = (float)st;
+}
+extern "C" int64_t mrx_recon_metrics_work_floats(void) { return 2 * 4 * METRIC_BLOCKS; }
+extern "C" int mrx_recon_metrics(const float* target, const float* output, float* out5, float* work, int64_t n, void* stream) {
+    MRX_REQUIRE(target && output && out5 && work && n >= 1, MRX_EINVAL, "mrx_recon_metrics: bad argument");
+    MRX_REQUIRE(((uintptr_t)work & 7) == 0, MRX_EINVAL, "mrx_recon_metrics: work must be 8-byte aligned");
+    int nb = (int)((n + EW_NT - 1) / EW_NT);
+    if (nb > METRIC_BLOCKS) nb = METRIC_BLOCKS;
+    hipLaunchKernelGGL(k_metric_partial, dim3(nb), dim3(EW_NT), 0, (hipStream_t)stream, target, output, (double*)work, (long long)n);
+    hipLaunchKernelGGL(k_metric_final, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)work, nb, (long long)n, out5);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 // ---- coil combination over a middle dim (utils.py:194-248) ------------------------------------------------------
 __global__ void k_rss(const float* __restrict__ x, float* __restrict__ out, long long outer, long long R, long long inner) {
     const long long total = outer * inner;

@@ -934,6 +934,20 @@ def div_by_device_scalar(x, d, modulus=False):
     return out
 
 
+def recon_metrics(target, output):
+    """Per-slice harness metrics of two `abs / max` images of one shape (models/base.py:427-436) -> device tensor
+    [MSE, NMSE, maxval = max(output) - min(output), PSNR, sum target^2] (mrx_recon_metrics; no host read)."""
+    target, output = _lib.f32c(target), _lib.f32c(output)
+    if target.shape != output.shape or target.numel() < 1:
+        raise ValueError(f"recon_metrics: target {tuple(target.shape)} vs output {tuple(output.shape)}")
+    L = _lib.lib()
+    out5 = torch.empty(5, dtype=torch.float32, device=target.device)
+    work = torch.empty(int(L.mrx_recon_metrics_work_floats()), dtype=torch.float32, device=target.device)
+    _lib.check(L.mrx_recon_metrics(_lib.ptr(target), _lib.ptr(output), _lib.ptr(out5), _lib.ptr(work), target.numel(), _lib.stream_ptr()),
+               "mrx_recon_metrics")
+    return out5
+
+
 def qrim_update(eta, delta):
     eta, delta = _lib.f32c(eta), _lib.f32c(delta)
     B, Cc, H, W = _nchw(eta)

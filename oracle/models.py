@@ -35,8 +35,9 @@ def process_intermediate_pred(pred, sensitivity_maps, target, no_dc, fft_centere
     return pred
 
 
-def cirim_forward(p, cfg, y, sensitivity_maps, mask, init_pred, target):
-    """cirim.py:146-165.  `cfg` is a dict with the reference's YAML keys.  Returns list[cascade][time_step]."""
+def cirim_forward(p, cfg, y, sensitivity_maps, mask, init_pred, target, cascade_stamps=None):
+    """cirim.py:146-165.  `cfg` is a dict with the reference's YAML keys.  Returns list[cascade][time_step].
+    `cascade_stamps`: optional list that receives a time.perf_counter() stamp after every cascade (bench.py's cpu_baseline leg)."""
     rcfg = orim.RIMConfig(
         recurrent_layer=cfg["recurrent_layer"], conv_filters=cfg["conv_filters"], conv_kernels=cfg["conv_kernels"],
         conv_dilations=cfg["conv_dilations"], conv_bias=cfg["conv_bias"], recurrent_filters=cfg["recurrent_filters"],
@@ -55,6 +56,9 @@ def cirim_forward(p, cfg, y, sensitivity_maps, mask, init_pred, target):
         out.append([process_intermediate_pred(e, sensitivity_maps, target, cfg["no_dc"], rcfg.fft_centered,
                                               rcfg.fft_normalization, rcfg.spatial_dims, rcfg.coil_dim,
                                               cfg.get("coil_combination_method", "SENSE")) for e in prediction])
+        if cascade_stamps is not None:
+            import time
+            cascade_stamps.append(time.perf_counter())
     return out
 
 

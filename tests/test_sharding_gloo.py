@@ -107,3 +107,51 @@ def test_two_rank_flat_gradient_allreduce():
     assert training.allreduce_gradients(torch.zeros(3)) == 1     # no process group: a no-op
     lrs = [training.inverse_sqrt_lr(s, 100, 1e-3) for s in range(100)]
     assert lrs[0] < lrs[5] < lrs[9] and lrs[10] >= lrs[50] >= lrs[99] > 0
+
+
+# ---- bench.py --gpus N: the bare command spawns its own ranks (one process per GPU, the reference's `strategy: ddp`) ---------------------
+def test_bench_rank_launch_plan_is_host_logic_only():
+    import bench
+    assert bench.rank_launch_plan(1, ["--gpus", "1"], {}) is None                       # N = 1 stays in-process
+    assert bench.rank_launch_plan(4, ["--gpus", "4"], {"WORLD_SIZE": "4", "RANK": "2"}) is None   # already a rank of a launcher
+    plan = bench.rank_launch_plan(2, ["--gpus", "2", "--steps", "3"], {"PATH": os.environ.get("PATH", "")})
+    assert len(plan) == 2
+    ports = set()
+    for r, (cmd, env) in enumerate(plan):
+        assert cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "2", "--steps", "3"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"]) == (str(r), str(r), "2", "127.0.0.1")
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        ports.add(env["MASTER_PORT"])
+    assert len(ports) == 1
+
+
+def test_bench_gpus2_without_world_size_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher environment takes the spawn path: two rank processes rendezvous (gloo here, RCCL
+    on the GPU box), rank 0 prints ONE line with n_gpus = 2, the world size the process group reported and both ranks' times."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-selftest"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size_seen"] == 2 and len(rec["per_rank_ms"]) == 2
+    assert rec["max_ms"] == max(rec["per_rank_ms"]) and rec["per_rank_ms"][1] > rec["per_rank_ms"][0] * 0.5
+    assert rec["slices_rank0"] == [0, 2]
+
+
+def test_bench_spawn_propagates_a_failing_rank():
+    """A rank that dies (here: no GPU in this container) makes the parent exit non-zero instead of hanging or printing a line."""
+    import subprocess
+    import sys
+    import torch as _t
+    if _t.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
