@@ -507,6 +507,56 @@ def g6_cirim():
     save("g6_cirim.npz", d)
 
 
+def g19_cirim_spec():
+    """G6 exactly as SURVEY 8c specifies it -- the model-zoo CIRIM (8 cascades x time_steps 5 -> 8, IndRNN, 64 filters, base_cirim_run.yaml)
+    at [1,15,64,48,2], the full 64-step chain -- plus the row-H harness outputs of the final estimate: the `abs / max` image
+    (models/base.py:415-419) and MSE / NMSE / PSNR / SSIM with maxval = output.max() - output.min() (base.py:427-436; formulas of
+    common/metrics/reconstruction_metrics.py:11-41, SSIM through the reference's own SSIMLoss: skimage's 7x7 uniform-window SSIM with
+    the sample covariance and the border cropped is 1 - SSIMLoss on the valid region)."""
+    import math
+    d = {}
+    cfg = dict(RIM_CFG)
+    cfg.update(coil_combination_method="SENSE", keep_eta=True, num_cascades=8, time_steps=5, fft_centered=False,
+               fft_normalization="backward", no_dc=True)
+    T = 8 * math.ceil(cfg["time_steps"] / 8)
+    bcfg = {k: v for k, v in cfg.items() if k not in ("coil_combination_method", "keep_eta", "num_cascades")}
+    bcfg["time_steps"] = T
+    torch.manual_seed(1900)
+    blocks = [rim_block.RIMBlock(**bcfg).eval() for _ in range(cfg["num_cascades"])]
+    for b in blocks:
+        scale_weights(b, 4.0)
+    B, C, H, W = 1, 15, 64, 48
+    img, S = synth(B, C, H, W, 1910)
+    k = fft.fft2(utils.complex_mul(img, S), centered=False, normalization="backward")
+    _, m = make_mask([1, C, H, W, 2])
+    m = m.bool()
+    y = k * m
+    target = utils.complex_abs(utils.sense(fft.ifft2(k, centered=False, normalization="backward"), S, 1))
+    with torch.no_grad():
+        out = compose_cirim(blocks, cfg, y, S, m, None, target)
+    d["cfg"] = np.array(json.dumps(cfg))
+    d["y"], d["S"], d["mask"], d["target"] = y, S, m, target
+    d["out"] = torch.view_as_real(torch.stack([torch.stack(c) for c in out]))
+    for ci, b in enumerate(blocks):
+        d.update(sd(b, f"w/cirim.{ci}."))
+    # harness post-processing + metrics of the final estimate (test_step, base.py:394-436)
+    preds = out[-1][-1]
+    output = torch.abs(preds).detach().cpu()
+    output = output / output.max()
+    tgt = torch.abs(target).detach().cpu()
+    tgt = tgt / tgt.max()
+    o, t = output.numpy(), tgt.numpy()
+    maxval = o.max() - o.min()
+    mse = np.mean((t - o) ** 2)
+    nmse = np.linalg.norm(t - o) ** 2 / np.linalg.norm(t) ** 2
+    psnr = 10 * np.log10(float(maxval) ** 2 / np.mean((t.astype(np.float64) - o.astype(np.float64)) ** 2))
+    loss = ssim_mod.SSIMLoss().double()
+    ssim = 1.0 - float(loss(tgt[:, None].double(), output[:, None].double(), torch.tensor([float(maxval)], dtype=torch.float64)))
+    d["harness/output"], d["harness/target"] = output, tgt
+    d["harness/metrics"] = np.array([mse, nmse, ssim, psnr, maxval], dtype=np.float64)     # MSE, NMSE, SSIM, PSNR, maxval
+    save("g19_cirim_spec.npz", d)
+
+
 def g7_varnet():
     d = {}
     cases = [("u14p2", 14, 2, 11, [1, 3, 32, 16, 2], True, False), ("u14p2_odd", 14, 2, 11, [1, 5, 15, 12, 2], False, False),
@@ -919,8 +969,8 @@ def g18_rvn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
-    fns = dict(g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    fns = dict(g19=g19_cirim_spec, g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

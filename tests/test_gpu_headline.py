@@ -1,0 +1,258 @@
+"""GPU parity AT THE HEADLINE SHAPES: the exact kernels bench.py's timed loop runs (BASELINE.json configs[1], [2], [4]) against the
+oracle on the same seeded inputs.
+
+The small golden fixtures (W <= 48) take the runtime FFT plans, one coil chunk and single-tile convolutions; the timed loop at
+15 x 640 x 372 takes the compile-time 372-point plan, four coil chunks whose partial sums are finished by the first RIM layer's tile
+loader (`mrx_llg_hinv_parts` + `mrx_rim_layer_indrnn_packed_llg`, rim_block.py:217-249 / rim_utils.py:11-67), the 960-tile
+persistent Winograd loop with the XCD band order and the 4-pixel final conv.  These tests pin exactly that path.
+Tolerances (fp32): operators 1e-5, one 8-step block 2e-5, the 64-step chain 1e-4 and SSIM >= 0.9999."""
+import os
+
+import pytest
+import torch
+
+import oracle
+from mridc_amd import synthetic
+from tests._util import T, assert_close, meta, rel_l2, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    return torch.device("cuda:0")
+
+
+def _problem(B, C, H, W, seed, centered, norm, mask_dtype=torch.bool):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 1, H, W, 2, generator=g)
+    S = torch.randn(B, C, H, W, 2, generator=g)
+    S = S / oracle.utils.complex_abs_sq(S).sum(1, keepdim=True).sqrt().unsqueeze(-1)
+    k = oracle.fft.fft2(oracle.utils.complex_mul(img, S), centered, norm)
+    k = k / k.abs().max()
+    m = torch.from_numpy(synthetic.random_mask_1d(W, seed=seed)).reshape(1, 1, 1, W, 1)
+    y = k * m
+    eta = torch.randn(B, H, W, 2, generator=g) * 0.3
+    return y, S, (m if mask_dtype == torch.bool else m.to(mask_dtype)), eta
+
+
+def _layer1(seed, F=64):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(F, 4, 5, 5, generator=g) * 0.15
+    b = torch.randn(F, generator=g) * 0.1
+    wi = torch.randn(F, F, 1, 1, generator=g) * 0.2
+    bi = torch.randn(F, generator=g) * 0.1
+    hh = torch.randn(1, F, 1, 1, generator=g) * 0.5
+    return w, b, wi, bi, hh
+
+
+# (B, C, H, W, centered, norm, sigma, mask dtype, expect the deferred route)
+DEFERRED_CASES = [
+    (1, 15, 640, 372, False, "backward", 1.0, torch.bool, True),       # the headline launch itself
+    (1, 15, 64, 372, True, "ortho", 0.7, torch.uint8, True),
+    (2, 5, 40, 372, False, "backward", 1.3, torch.float32, True),      # B > 1, two chunks (4 + 1 coils), ragged tile rows
+    (1, 32, 44, 372, True, "forward", 1.0, torch.bool, True),          # eight chunks, rows not a multiple of the 8-row tile
+    (1, 15, 72, 320, False, "backward", 0.9, torch.bool, True),
+    (3, 5, 24, 320, True, "ortho", 1.0, torch.uint8, True),
+    (1, 32, 256, 256, False, "backward", 1.1, torch.bool, True),       # the qCIRIM slice shape
+    (1, 15, 48, 256, True, "ortho", 1.0, torch.float32, True),
+    (2, 15, 512, 372, False, "backward", 1.0, torch.bool, False),      # H * B = 1024: the coil sum stays inside one workgroup
+    (1, 15, 1024, 256, False, "none", 1.0, torch.bool, False),
+]
+
+
+@pytest.mark.parametrize("case", DEFERRED_CASES, ids=lambda c: f"B{c[0]}C{c[1]}_{c[2]}x{c[3]}_{'c' if c[4] else 'n'}_{c[5]}")
+def test_llg_parts_and_layer1_loader(dev, case):
+    """(a) `mrx_llg_hinv_parts` + `mrx_rim_layer_indrnn_packed_llg` vs oracle.rim.log_likelihood_gradient + conv5x5 + IndRNN."""
+    from mridc_amd import ops
+    B, C, H, W, centered, norm, sigma, mdt, want_defer = case
+    y, S, mask, eta = _problem(B, C, H, W, 1000 + H + W + C, centered, norm, mdt)
+    w, b, wi, bi, hh = _layer1(77)
+    h_prev = torch.randn(B, 64, H, W, generator=torch.Generator().manual_seed(5)).relu()
+    with torch.no_grad():
+        g_ref = oracle.rim.log_likelihood_gradient(eta, y, S, mask, sigma, centered, norm, [-2, -1], 1).contiguous()
+        a_ref = oracle.rim.conv_nonlinear(g_ref, w, b, 5, 1, "relu")
+        h_ref = oracle.rim.indrnn_cell(a_ref, h_prev, wi, bi, hh, 1, 1)
+    yd, Sd, md, ed, hp = y.to(dev), S.to(dev), mask.to(dev), eta.to(dev), h_prev.to(dev)
+    wd, bd, wid, bid, hhd = (t.to(dev) for t in (w, b, wi, bi, hh))
+    yt = ops.llg_prepare(yd, centered, norm)
+    packed = ops.rim_layer_pack(wd, wid)
+    out4, part, nparts = ops.llg_hinv_parts(ed, yt, Sd, md, sigma, centered, norm)
+    assert (nparts > 0) == want_defer, f"nparts = {nparts}"
+    full = ops.llg_hinv(ed, yt, Sd, md, sigma, centered, norm)                     # the same gradient with the combine done
+    assert_close(full, g_ref, 1e-5, "llg_hinv vs oracle")
+    h_plain = ops.rim_layer_indrnn_packed(full, packed, 64, 5, 1, bd, bid, hhd, hp)
+    assert_close(h_plain, h_ref, 1e-5, "layer 1 (complete gradient) vs oracle")
+    if nparts > 0:
+        assert nparts == -(-C // 4) or W != 372                                     # 372: four coils per workgroup
+        h_def = ops.rim_layer_indrnn_packed_llg(ed, part, nparts, sigma, packed, 64, 5, 1, bd, bid, hhd, hp)
+        assert_close(h_def, h_ref, 1e-5, "layer 1 reading the coil-chunk partial sums vs oracle")
+        assert rel_l2(h_def, h_plain) <= 2e-6
+        h0 = ops.rim_layer_indrnn_packed_llg(ed, part, nparts, sigma, packed, 64, 5, 1, bd, bid, hhd, None)   # zero initial state
+        with torch.no_grad():
+            h0_ref = oracle.rim.indrnn_cell(a_ref, torch.zeros_like(h_prev), wi, bi, hh, 1, 1)
+        assert_close(h0, h0_ref, 1e-5, "layer 1 (deferred, zero state) vs oracle")
+    else:
+        assert_close(out4, g_ref, 1e-5, "llg_hinv_parts complete output vs oracle")
+
+
+def _cirim(cfg_over, scale, seed=0):
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG, **cfg_over)
+    torch.manual_seed(seed)
+    model = CIRIM(cfg).eval()
+    if scale != 1.0:
+        with torch.no_grad():                          # the reference init is nearly linear: make the ReLUs bite
+            for n, p in model.named_parameters():
+                if n.endswith("rnn.ih.weight") or n.endswith("rnn.hh"):
+                    p.mul_(scale)
+    return cfg, model, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+@pytest.mark.parametrize("scale", [1.0, 5.0], ids=["reference_init", "x5_recurrent_weights"])
+def test_full_size_rim_block_winograd_on_and_off(dev, scale):
+    """(b) one whole RIMBlock (8 steps, IndRNN 64) at 1 x 15 x 640 x 372 vs the oracle, with the Winograd layer-2 kernel and with the
+    direct one; both hidden states too."""
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    cfg, model, sd = _cirim(dict(num_cascades=1), scale)
+    d = synthetic.make_slice(15, 640, 372, slice_idx=3)
+    rc = oracle.rim.RIMConfig(**{k: cfg[k] for k in ("recurrent_layer", "conv_filters", "conv_kernels", "conv_dilations", "conv_bias",
+                                                     "recurrent_filters", "recurrent_kernels", "recurrent_dilations", "recurrent_bias",
+                                                     "depth", "no_dc", "fft_centered", "fft_normalization", "spatial_dims", "coil_dim")},
+                              time_steps=8)
+    p = {k[len("cirim.0."):]: v for k, v in sd.items() if k.startswith("cirim.0.")}
+    with torch.no_grad():
+        ref, ref_hx = oracle.rim.rim_block_forward(p, rc, d["y"], d["y"], d["sensitivity_maps"], d["mask"], None, None, 1.0, False)
+    blk = model.cirim[0].to(dev)
+    y, S, m = d["y"].to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev)
+    outs = {}
+    for wino in (True, False):
+        RIMBlock.winograd, keep = wino, RIMBlock.winograd
+        try:
+            blk._pack_cache.clear()
+            with torch.no_grad():
+                etas, hx = blk(y, y, S, m, None, None, 1.0, keep_eta=False)
+        finally:
+            RIMBlock.winograd = keep
+        assert len(etas) == 8
+        assert_close(torch.stack(etas), torch.stack(ref), 2e-5, f"8-step block, winograd={wino}")
+        for j in range(2):
+            assert_close(hx[j], ref_hx[j], 2e-5, f"hidden state {j}, winograd={wino}")
+        outs[wino] = etas[-1]
+    assert rel_l2(outs[True], outs[False]) <= 5e-6
+
+
+def test_eight_cascades_w372_final_image_ssim(dev):
+    """(c) all 8 cascades x 8 steps at 1 x 15 x 64 x 372 (the 372-point plan, four coil chunks, deferred route) vs the oracle; SSIM vs
+    ref on the FINAL image through the product's harness (mridc_amd.runner) with the oracle's SSIM as the checker."""
+    from mridc_amd import runner
+    cfg, model, sd = _cirim({}, 4.0, seed=1)
+    d = synthetic.make_slice(15, 64, 372, slice_idx=1)
+    with torch.no_grad():
+        ref = oracle.models.cirim_forward(sd, cfg, d["y"], d["sensitivity_maps"], d["mask"], None, d["target"])
+    model = model.to(dev)
+    with torch.no_grad():
+        out = next(model(d["y"].to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev), None, d["target"].to(dev)))
+    got = torch.view_as_real(torch.stack([torch.stack(c) for c in out]))
+    want = torch.view_as_real(torch.stack([torch.stack(c) for c in ref]))
+    assert_close(got, want, 1e-4, "8 x 8 chain at W = 372")
+    o_gpu, o_ref = runner.postprocess(out[-1][-1], ref[-1][-1].to(dev))
+    ssim = runner.metrics_to_dict(runner.slice_metrics(o_gpu, o_ref))["SSIM"]
+    c1, c2 = oracle.metrics.postprocess(out[-1][-1].cpu(), ref[-1][-1])
+    chk = oracle.metrics.ssim(c2.numpy(), c1.numpy(), maxval=float(c1.max() - c1.min()))
+    assert ssim >= 0.9999 and abs(ssim - chk) <= 1e-5, (ssim, chk)
+
+
+def test_g19_spec_fixture_and_harness_metrics(golden, dev):
+    """The G6 fixture as SURVEY 8c specifies it ([1,15,64,48], 8 cascades, 64 filters; generated by the reference) through the model
+    AND through the harness runner: post-processed image + MSE / NMSE / SSIM / PSNR (models/base.py:415-436)."""
+    from mridc_amd import runner
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    z = golden("g19_cirim_spec.npz")
+    cfg = meta(z, "cfg")
+    model = CIRIM(cfg)
+    missing, unexpected = model.load_state_dict(weights(z, "w/"), strict=False)
+    assert unexpected == [] and missing == ["dc_weight"]
+    model = model.to(dev).eval()
+    y, S, mask, target = (T(z[k]).to(dev) for k in ("y", "S", "mask", "target"))
+    with torch.no_grad():
+        out = next(model(y, S, mask, None, target))
+    got = torch.view_as_real(torch.stack([torch.stack(c) for c in out]))
+    assert_close(got, T(z["out"]), 1e-4, "g19 chain")
+    r = runner.ReconstructionRunner(model)
+    name, sl, pred = r.test_step((y, y, S, mask, None, target, ["vol_a"], 7, 4.0))
+    assert (name, sl) == ("vol_a", 7) and pred.shape == (1, 64, 48)
+    r.test_step((y, y, S, mask, None, target, ["vol_b"], 0, 4.0))
+    want = z["harness/metrics"]                                                    # MSE, NMSE, SSIM, PSNR, maxval
+    m = runner.metrics_to_dict(r.metric_vals["vol_a"][7])
+    for k, w in zip(("MSE", "NMSE", "SSIM", "PSNR", "maxval"), want):
+        assert abs(m[k] - float(w)) <= 2e-4 * max(1.0, abs(float(w))), (k, m[k], float(w))
+    o, t = runner.postprocess(out[-1][-1], target)
+    assert_close(o, T(z["harness/output"]), 1e-4, "abs / max image")
+    assert_close(t, T(z["harness/target"]), 1e-6, "abs / max target")
+    agg = r.test_epoch_end()
+    assert agg["TotExamples"] == 2 and abs(agg["SSIM"] - float(want[2])) <= 2e-4 and abs(agg["PSNR"] - float(want[3])) <= 2e-3
+
+
+def test_qcirim_128_filters_c32_256(dev):
+    """(d) configs[4]: one qCIRIM cascade (8 steps, IndRNN 128 filters) at 4 echoes x 32 coils x 256 x 256 vs the oracle."""
+    from mridc_amd.collections.quantitative.models.qcirim import qCIRIM
+    cfg = {"quantitative_module_recurrent_layer": "IndRNN", "quantitative_module_conv_filters": [128, 128, 4],
+           "quantitative_module_conv_kernels": [5, 3, 3], "quantitative_module_conv_dilations": [1, 2, 1],
+           "quantitative_module_conv_bias": [True, True, False], "quantitative_module_recurrent_filters": [128, 128, 0],
+           "quantitative_module_recurrent_kernels": [1, 1, 0], "quantitative_module_recurrent_dilations": [1, 1, 0],
+           "quantitative_module_recurrent_bias": [True, True, False], "quantitative_module_depth": 2,
+           "quantitative_module_time_steps": 8, "quantitative_module_num_cascades": 1, "quantitative_module_no_dc": True,
+           "quantitative_module_signal_forward_model_sequence": "MEGRE", "quantitative_module_dimensionality": 2,
+           "quantitative_module_gamma_regularization_factors": [150.0, 150.0, 1000.0, 150.0], "use_reconstruction_module": False,
+           "fft_centered": False, "fft_normalization": "backward", "spatial_dims": [-2, -1], "coil_dim": 2,
+           "coil_combination_method": "SENSE"}
+    torch.manual_seed(0)
+    model = qCIRIM(cfg).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("rnn.ih.weight") or n.endswith("rnn.hh"):
+                p.mul_(4.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    E, C, H, W = 4, 32, 256, 256
+    TEs = [3.0, 11.5, 20.0, 28.5]
+    g = torch.Generator().manual_seed(42)
+    maps = [torch.rand(1, H, W, generator=g) * s for s in (60.0, 1.0, 30.0, 0.5)]         # R2* [1/s], S0, B0 [Hz], phi
+    S = torch.randn(1, C, H, W, 2, generator=g) / C ** 0.5
+    mask = (torch.rand(1, 1, 1, 1, W, 1, generator=g) < 0.3)
+    y = torch.randn(1, E, C, H, W, 2, generator=g) * mask
+    with torch.no_grad():
+        ref = oracle.qrim.qcirim_forward(sd, cfg, maps[0], maps[1], maps[2], maps[3], TEs, y, S, None, mask)
+    model = model.to(dev)
+    with torch.no_grad():
+        out = next(model(*[m_.to(dev) for m_ in maps], TEs, y.to(dev), S.to(dev), None, mask.to(dev)))
+    for m_ in range(4):
+        got = torch.stack([torch.stack(c) for c in out[1 + m_]])
+        want = torch.stack([torch.stack(c) for c in ref[1 + m_]])
+        assert_close(got, want, 5e-5, f"qCIRIM map {m_} (128 filters, 32 coils, 256 x 256)")
+
+
+@pytest.mark.parametrize("chans,pools,pad", [(14, 2, 11), (18, 4, 15)], ids=["unet14x2", "unet18x4"])
+def test_e2evn_cascade_full_size(dev, chans, pools, pad):
+    """(e) configs[1]: one E2EVN cascade (VarNetBlock around NormUnet(14, 2, pad 11); and the (18, 4, pad 15) variant of the reference's
+    default yaml) at 15 x 640 x 372 vs the oracle, in k-space and in the hybrid space the model runs its cascades in."""
+    from mridc_amd.collections.reconstruction.models.unet_base.unet_block import NormUnet
+    from mridc_amd.collections.reconstruction.models.varnet.vn_block import VarNetBlock
+    torch.manual_seed(3)
+    blk = VarNetBlock(NormUnet(chans, pools, padding_size=pad, normalize=True), fft_centered=False, fft_normalization="backward",
+                      spatial_dims=[-2, -1], coil_dim=1, no_dc=False).eval()
+    with torch.no_grad():
+        blk.dc_weight.fill_(0.8)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    d = synthetic.make_slice(15, 640, 372, slice_idx=2, mask_dtype=torch.uint8)
+    g = torch.Generator().manual_seed(9)
+    pred = d["y"] + 0.05 * torch.randn(d["y"].shape, generator=g) * d["y"].abs().max()
+    with torch.no_grad():
+        ref = oracle.varnet.varnet_block_forward(sd, pred, d["y"], d["sensitivity_maps"], d["mask"], pools, pad, True, False, "backward",
+                                                 [-2, -1], 1, False)
+    blk = blk.to(dev)
+    with torch.no_grad():
+        got = blk(pred.to(dev), d["y"].to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev))
+    assert_close(got, ref, 5e-5, f"E2EVN cascade NormUnet({chans},{pools}) at 15 x 640 x 372")

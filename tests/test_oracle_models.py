@@ -94,3 +94,23 @@ def test_g9_qrim(golden):
     for m in range(4):
         got = torch.stack([torch.stack(c) for c in out[1 + m]])
         assert_close(got, ref[:, :, :, m], 1e-5, f"qcirim map {m}")
+
+
+def test_g19_cirim_spec_and_harness_metrics(golden):
+    """The fixture SURVEY 8c specifies for G6 (model-zoo CIRIM, 8 cascades x 8 steps, 64 filters, [1,15,64,48,2]) and the row-H harness
+    outputs: `abs / max` image and MSE / NMSE / SSIM / PSNR with maxval = output.max() - output.min() (models/base.py:415-436)."""
+    z = golden("g19_cirim_spec.npz")
+    cfg = meta(z, "cfg")
+    p = weights(z, "w/")
+    y, S, mask, target = T(z["y"]), T(z["S"]), T(z["mask"]), T(z["target"])
+    out = oracle.models.cirim_forward(p, cfg, y, S, mask, None, target)
+    assert len(out) == 8 and len(out[0]) == 8
+    got = torch.view_as_real(torch.stack([torch.stack(c) for c in out]))
+    assert_close(got, T(z["out"]), 5e-6, "g19 cirim chain")
+    o, t = oracle.metrics.postprocess(out[-1][-1], target)
+    assert_close(o, T(z["harness/output"]), 1e-6, "harness output")
+    assert_close(t, T(z["harness/target"]), 1e-6, "harness target")
+    m = oracle.metrics.slice_metrics(out[-1][-1], target)
+    want = z["harness/metrics"]                                     # MSE, NMSE, SSIM, PSNR, maxval
+    for k, w in zip(("mse", "nmse", "ssim", "psnr"), want[:4]):
+        assert abs(m[k] - float(w)) <= 1e-5 * max(1.0, abs(float(w))), (k, m[k], float(w))
