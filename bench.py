@@ -235,6 +235,7 @@ def parity_vs_oracle(gpu_pred, ref_pred, target, at):
     ssim_chk = oracle.metrics.ssim(c2.numpy(), c1.numpy(), maxval=float(c1.max() - c1.min()))
     vs_target = runner.metrics_to_dict(runner.slice_metrics(*runner.postprocess(gpu_pred, target.to(dev))))
     vs_target.pop("maxval")
+    vs_target["note"] = "random-init weights (no checkpoint can be fetched here): quality against the ground truth is not meaningful"
     return dict(rel_l2=rel, ssim=m["SSIM"], ssim_oracle_check=ssim_chk, nmse=m["NMSE"], at=at, metrics_vs_target=vs_target)
 
 

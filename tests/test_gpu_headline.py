@@ -55,7 +55,8 @@ DEFERRED_CASES = [
     (2, 5, 40, 372, False, "backward", 1.3, torch.float32, True),      # B > 1, two chunks (4 + 1 coils), ragged tile rows
     (1, 32, 44, 372, True, "forward", 1.0, torch.bool, True),          # eight chunks, rows not a multiple of the 8-row tile
     (1, 15, 72, 320, False, "backward", 0.9, torch.bool, True),
-    (3, 5, 24, 320, True, "ortho", 1.0, torch.uint8, True),
+    (3, 15, 24, 320, True, "ortho", 1.0, torch.uint8, True),       # B > 1; 320: six coils per workgroup -> 3 chunks
+    (2, 5, 24, 320, False, "ortho", 1.0, torch.bool, False),         # C <= 6: one chunk, nothing to defer
     (1, 32, 256, 256, False, "backward", 1.1, torch.bool, True),       # the qCIRIM slice shape
     (1, 15, 48, 256, True, "ortho", 1.0, torch.float32, True),
     (2, 15, 512, 372, False, "backward", 1.0, torch.bool, False),      # H * B = 1024: the coil sum stays inside one workgroup
