@@ -575,6 +575,7 @@ def main():
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv_parts", lambda *a, **k: "llg")     # gradient whose last pass is done by layer 1's tile loader
+    timer.wrap(ops, "llg372", lambda *a, **k: "llg372")          # W = 372: wave-private prime-factor transforms, one launch
     timer.wrap(ops, "rim_layer_indrnn_packed_llg", lambda *a, **k: "conv_layer1")
     timer.wrap(ops, "rim_final", lambda *a, **k: "final")
 
@@ -659,6 +660,9 @@ def main():
         ms1, _ = timer.mean_ms("conv_layer1")
         msf, _ = timer.mean_ms("final")
         msl, nl = timer.mean_ms("llg")
+        ms372, n372 = timer.mean_ms("llg372")
+        if ms372:
+            msl, nl = ms372, n372
         # whole regulariser (layer 1 + layer 2 + final conv) as issued on the matrix / vector pipes against the fp32 peak
         flops_reg = 105216.0 * npix * B                     # 25.05 GFLOP per slice-step (direct form)
         issued_reg = flops_reg - (flops2 - executed)
@@ -678,7 +682,10 @@ def main():
         bytes_llg = (25.0 + 16.0 * C) * npix * B     # compulsory bytes of one log_likelihood_gradient
         # the formulation executed for 1-D masks reads yt = IFFT_H(y) instead of y: the same (25+16C)N compulsory bytes per step
         # (plus one column pass per slice, outside the step, to make yt)
-        roofline_fft = dict(bound="hbm", kernel=("mrx_llg_hinv_parts (1-D column mask: H transforms cancel, ONE launch of row FFTs per step on "
+        roofline_fft = dict(bound="hbm", kernel=("mrx_llg372 (1-D column mask: H transforms cancel; ONE launch per step of wave-private prime-factor "
+                                                 "12 x 31 row transforms on lane-ordered yt = IFFT_H(y), S and mask; coil-group sum finished by layer 1's "
+                                                 "tile loader)" if ms372 else
+                                                 "mrx_llg_hinv_parts (1-D column mask: H transforms cancel, ONE launch of row FFTs per step on "
                                                  "yt = IFFT_H(y), coil-chunk sum finished by layer 1's tile loader)" if args.mask == "1d"
                                                  else "mrx_llg (general mask: rows, columns + DC in LDS, rows: three launches)"),
                             achieved=(bytes_llg / (msl * 1e-3) / 1e9) if msl else None, peak=PEAK_HBM_GBS, unit="GB/s",

@@ -141,6 +141,22 @@ int mrx_llg_hinv(const float* eta, const float* yt, const float* S, const void* 
 int mrx_llg_hinv_parts(const float* eta, const float* yt, const float* S, const void* mask, int mask_kind,
                        const int64_t* mstride, float* out4, float* work, int* nparts, int B, int C, int H, int W,
                        float inv_sigma2, int norm, int centered, void* stream);
+
+/* A9 at the fastMRI knee width (W = 372), row-invariant masks: the same gradient as mrx_llg_hinv from ONE launch of wave-private
+ * prime-factor (12 x 31) row transforms (csrc/llg372.hip, pfa372.h).  The loop-invariant operands are laid out once per slice in the
+ * order the lanes consume them:
+ *   mrx_llg372_prepare  yt (= IFFT_H(y), mrx_fft_cols), S [B,C,H,372,2], mask (column / batch dependent only) ->
+ *                       ytp, Sp (mrx_llg372_operand_floats(B,C,H) floats each), maskp (B*372 floats)
+ *   mrx_llg372          eta [B,H,372,2] -> nparts != NULL: *nparts = ceil(C/5) partial planes work[k][B][H][372][2] left for the
+ *                       consumer (mrx_rim_layer_indrnn_packed_llg), out4 untouched; nparts == NULL: out4 [B,4,H,372] complete.
+ *                       work: mrx_llg372_work_floats(B,C,H) floats. */
+int mrx_llg372_supported(int W);
+int64_t mrx_llg372_operand_floats(int B, int C, int H);
+int64_t mrx_llg372_work_floats(int B, int C, int H);
+int mrx_llg372_prepare(const float* yt, const float* S, const void* mask, int mask_kind, const int64_t* mstride, float* ytp,
+                       float* Sp, float* maskp, int B, int C, int H, int centered, void* stream);
+int mrx_llg372(const float* eta, const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* out4, float* work,
+               int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream);
 int mrx_rim_layer_indrnn_packed_llg(const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,
                                     const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
                                     float* h_new, int B, int F, int H, int W, int k, int dil, void* stream);

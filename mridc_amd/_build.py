@@ -14,6 +14,7 @@ LIB = os.path.join(LIBDIR, "libmridc_amd.so")
 SOURCES = [
     ("api.cpp", []),
     ("fft.hip", []),
+    ("llg372.hip", []),
     ("elementwise.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
     ("rim_layer.hip", []),

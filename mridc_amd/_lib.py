@@ -68,6 +68,11 @@ _SIGNATURES = {
     "mrx_absl1_loss_bwd": ([_p, _p, _p, _p, _p, _f, _p, _i64, _p], _i),
     "mrx_adam_step": ([_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _f, _p], _i),
     "mrx_llg_hinv_parts": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _p], _i),
+    "mrx_llg372_supported": ([_i], _i),
+    "mrx_llg372_operand_floats": ([_i, _i, _i], _i64),
+    "mrx_llg372_work_floats": ([_i, _i, _i], _i64),
+    "mrx_llg372_prepare": ([_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_llg372": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_rim_layer_indrnn_packed_llg": ([_p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_conv1x1_64_pack": ([_p, _p, _p], _i),
     "mrx_conv1x1_64": ([_p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p], _i),

@@ -187,10 +187,17 @@ class RIMBlock(torch.nn.Module):
         # 1-D column masks: the H transforms of log_likelihood_gradient cancel (csrc/fft.hip: k_llg_rows_hinv) -- one
         # launch per step on yt = IFFT_H(y); any other mask takes the general three-launch path
         hinv = ops.mask_is_row_invariant(mask) and self.coil_dim == 1
+        op372 = None
         if hinv:
-            # yt = IFFT_H(y) depends on the measured data only: a caller running several cascades on the same y (CIRIM) passes it
-            yt = _hybrid if _hybrid is not None else ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization,
-                                                                     self.spatial_dims)
+            # yt = IFFT_H(y) depends on the measured data only: a caller running several cascades on the same y (CIRIM) passes it,
+            # together with the lane-ordered operands of the W = 372 kernel (mrx_llg372), which also hold the maps and the mask
+            if isinstance(_hybrid, tuple):
+                yt, op372 = _hybrid
+            else:
+                yt = _hybrid if _hybrid is not None else ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization,
+                                                                         self.spatial_dims)
+                if ops.llg372_supported(yt, mask):
+                    op372 = ops.llg372_prepare(yt, sense, mask, self.fft_centered)
             work = None
         else:
             work = torch.empty_like(masked_kspace, dtype=torch.float32)
@@ -203,7 +210,10 @@ class RIMBlock(torch.nn.Module):
                  and not (self.winograd and ops.rim_layer_wino_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)))
         for _ in range(self.time_steps):                             # rim_block.py:217-249
             if defer:
-                grad_eta, part, nparts = ops.llg_hinv_parts(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
+                if op372 is not None:
+                    part, nparts = ops.llg372(eta, op372, sigma, self.fft_normalization, parts=True)
+                else:
+                    grad_eta, part, nparts = ops.llg_hinv_parts(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
                 if nparts > 0:
                     c, r = l0.convs, l0.rnn
                     hx[0] = ops.rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, self._packed(0, c, r), r.hidden_size, c.kernel_size,
@@ -215,6 +225,8 @@ class RIMBlock(torch.nn.Module):
                     eta = ops.rim_final(grad_eta, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size, final.dilation, eta)
                     etas.append(eta)
                     continue
+            elif op372 is not None:
+                grad_eta = ops.llg372(eta, op372, sigma, self.fft_normalization)
             elif hinv:
                 grad_eta = ops.llg_hinv(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
             else:

@@ -1,0 +1,249 @@
+// llg372.hip -- log_likelihood_gradient (reference models/rim/rim_utils.py:11-67) for row-invariant masks at the fastMRI knee width
+// W = 372, one launch per RIM step, wave-private prime-factor transforms (pfa372.h).
+//
+// With yt = IFFT_H(y) the gradient is row transforms only (fft.hip: the H transforms cancel for a mask that does not depend on the
+// row):   g[h, :] = sum_c conj(S_c) * IFFT_W( m * (FFT_W(eta * S_c) - yt_c) ).
+// The Stockham kernel this replaces (k_llg_rows_hinv_part<P372>) spent its time in workgroup barriers and in a radix-31 stage that
+// ran 48 butterflies on 256 threads by giving every wave the same pre-additions (0.22 of the HBM roofline).  Here one wavefront owns
+// five coil rows end to end:
+//   * 60 lanes each run ONE whole 31-point DFT on registers (1050 VALU operations, no redundancy, 94 % of the lanes busy);
+//   * the 155 12-point DFTs, the data-consistency step and the inverse 12-point DFTs run in registers, 64 at a time;
+//   * the two transposes between them go through 17 KB of wave-private LDS -- no __syncthreads between waves, no twiddle table;
+//   * S, yt and the mask are read in the order the lanes consume them (laid out once per slice by mrx_llg372_prepare), so every
+//     global access is one contiguous row per wave instruction and S stays in registers from the expand to the reduce.
+// Eight single-wave workgroups per CU; the 1920 tasks of a 15-coil 640-row slice are one dispatch round.
+#include "mrx_common.h"
+#include "pfa372.h"
+
+#define L372_TASK_C2 (PFA_N * PFA_G)   // 1860 float2 per task in Sp and in ytp
+#define L372_LDS_BYTES (sizeof(float2) * PFA_LDS_C2 + sizeof(float) * PFA_N)
+
+struct L372Args {
+    int B, C, H, T;       // batch, coils, rows, tasks (groups of 5 coils) per row
+    int halfW;            // 186 for centred transforms (ifftshift / fftshift folded into the index maps), else 0
+    int mask_bstride;     // floats between the batch entries of maskp (0: one mask for the whole batch)
+    long long ntasks;     // B * H * T
+    float scale_f, scale_i;
+};
+
+// ---- once per slice: operands in lane order ------------------------------------------------------------------------------------------
+__global__ void k_llg372_prep(const float2* __restrict__ yt, const float2* __restrict__ S, float2* __restrict__ ytp,
+                              float2* __restrict__ Sp, L372Args a) {
+    const long long total = a.ntasks * L372_TASK_C2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long task = i / L372_TASK_C2;
+        const int e = (int)(i - task * L372_TASK_C2);
+        const long long row = task / a.T;
+        const int z = (int)(task - row * a.T);
+        const long long b = row / a.H, h = row - b * a.H;
+        int g, w;
+        {
+            const int n2 = e / PFA_L1, lane = e - n2 * PFA_L1;
+            pfa372_sp_src(n2, lane, a.halfW, &g, &w);
+            const int c = z * PFA_G + g;
+            Sp[i] = c < a.C ? S[((b * a.C + c) * a.H + h) * PFA_N + w] : make_float2(0.f, 0.f);
+        }
+        {
+            const int k1 = e / PFA_D, d = e - k1 * PFA_D;
+            pfa372_yt_src(k1, d, a.halfW, &g, &w);
+            const int c = z * PFA_G + g;
+            ytp[i] = c < a.C ? yt[((b * a.C + c) * a.H + h) * PFA_N + w] : make_float2(0.f, 0.f);
+        }
+    }
+}
+__global__ void k_llg372_prep_mask(MrxMask mask, float* __restrict__ maskp, int nb, int halfW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb * PFA_N) return;
+    const int b = i / PFA_N, e = i - b * PFA_N;
+    const int k1 = e / PFA_N2, k2 = e - k1 * PFA_N2;
+    maskp[i] = mrx_mask_val(mask, b, 0, 0, pfa372_mask_src(k1, k2, halfW));
+}
+
+// ---- the per-step kernel: one wavefront = one task (row, five coils) ----------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta, const float2* __restrict__ ytp,
+                                                   const float2* __restrict__ Sp, const float* __restrict__ maskp,
+                                                   float2* __restrict__ part, L372Args a) {
+    extern __shared__ __attribute__((aligned(16))) float2 X[];
+    float* Mk = reinterpret_cast<float*>(X + PFA_LDS_C2);
+    const int l = threadIdx.x;
+    // every XCD walks one contiguous band of tasks: the tasks of an image row (which share the eta row) meet in one L2
+    const unsigned task = (unsigned)mrx_xcd_band(blockIdx.x, a.ntasks);      // ntasks < 2^31 (checked by the launcher)
+    const unsigned row = task / (unsigned)a.T;
+    const int z = (int)(task - row * (unsigned)a.T);
+    const unsigned b = row / (unsigned)a.H;
+    const int Cg = min(PFA_G, a.C - z * PFA_G);
+    const bool laneA = l < PFA_L1;
+    const int g1 = l / PFA_N1, n1 = l - g1 * PFA_N1;
+
+    // all global operands of the task requested up front, unconditionally (idle lanes repeat a neighbour's address): eta row + mask
+    // (6 + 6 loads), S (31), first yt pass (12)
+    float2 ev[6];
+    float mv[6];
+    const float2* erow = eta + (long long)row * PFA_N;
+    const float* mrow = maskp + (long long)b * a.mask_bstride;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int n = min(l + 64 * i, PFA_N - 1);
+        ev[i] = erow[pfa372_shift(n, a.halfW)];
+        mv[i] = mrow[n];
+    }
+    Pfa372Lane L;
+    {
+        const float2* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
+#pragma unroll
+        for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = sp[n2 * PFA_L1];
+    }
+    const float2* ytask = ytp + (long long)task * L372_TASK_C2;
+    float2 yv[12];
+#pragma unroll
+    for (int k1 = 0; k1 < 12; ++k1) yv[k1] = ytask[k1 * PFA_D + l];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int n = l + 64 * i;
+        if (n < PFA_N) {
+            X[n] = ev[i];
+            Mk[n] = mv[i];
+        }
+    }
+    __syncthreads();
+    if (laneA) pfa372_expand(L, X, n1);
+    __syncthreads();
+    if (laneA) pfa372_stage_a(L, X, g1, n1);
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        const int d = pass * 64 + l;
+        float2 yn[12];
+        if (pass < 2) {
+            const int dn = min(d + 64, PFA_D - 1);
+#pragma unroll
+            for (int k1 = 0; k1 < 12; ++k1) yn[k1] = ytask[k1 * PFA_D + dn];
+        }
+        if (d < Cg * PFA_N2) {
+            const int g2 = d / PFA_N2;
+            pfa372_stage_b(X, Mk, yv, g2, d - g2 * PFA_N2, a.scale_f);
+        }
+        if (pass < 2) {
+#pragma unroll
+            for (int k1 = 0; k1 < 12; ++k1) yv[k1] = yn[k1];
+        }
+    }
+    __syncthreads();
+    if (laneA) pfa372_gather_a(L, X, g1, n1);
+    __syncthreads();
+    if (laneA) pfa372_stage_a_inv(L, X, g1, n1, a.scale_i);
+    __syncthreads();
+    float2* po = part + (((long long)z * a.B * a.H) + row) * PFA_N;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int n = l + 64 * i;
+        if (n < PFA_N) {
+            float2 s = X[n];
+#pragma unroll
+            for (int g = 1; g < PFA_G; ++g) {
+                const float2 v = X[g * PFA_RS + n];
+                s.x += v.x;
+                s.y += v.y;
+            }
+            po[pfa372_shift(n, a.halfW)] = s;
+        }
+    }
+}
+
+// out4[b, 0:4] = (eta_re, eta_im, post * sum_k part_k re, im)   (rim_utils.py:61-67)
+__global__ void k_llg372_combine(const float2* __restrict__ eta, const float2* __restrict__ part, float* __restrict__ out, int nparts,
+                                 long long B, long long plane, float post) {
+    const long long total = B * plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / plane, p = i - b * plane;
+        float2 s = part[i];
+        for (int k = 1; k < nparts; ++k) {
+            const float2 v = part[(long long)k * total + i];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        const float2 e = eta[i];
+        float* o = out + b * 4 * plane + p;
+        o[0] = e.x;
+        o[plane] = e.y;
+        o[2 * plane] = s.x * post;
+        o[3 * plane] = s.y * post;
+    }
+}
+
+static inline float l372_scale(int inverse, int norm) {   // fft.py:77-81,155-159 (same rule as fft.hip)
+    if (norm == MRX_NORM_ORTHO) return (float)(1.0 / sqrt((double)PFA_N));
+    if (norm == MRX_NORM_FORWARD) return inverse ? 1.0f : (float)(1.0 / (double)PFA_N);
+    return inverse ? (float)(1.0 / (double)PFA_N) : 1.0f;
+}
+static int l372_args(L372Args* a, int B, int C, int H, int norm, int centered, int mask_batched) {
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1, MRX_EINVAL, "mrx_llg372: bad dims B=%d C=%d H=%d", B, C, H);
+    MRX_REQUIRE(norm >= 0 && norm <= 3, MRX_EINVAL, "mrx_llg372: bad normalization %d", norm);
+    a->B = B, a->C = C, a->H = H, a->T = pfa372_tasks(C);
+    a->halfW = centered ? PFA_N / 2 : 0;
+    a->mask_bstride = mask_batched ? PFA_N : 0;
+    a->ntasks = (long long)B * H * a->T;
+    a->scale_f = l372_scale(0, norm);
+    a->scale_i = l372_scale(1, norm);
+    return MRX_OK;
+}
+
+extern "C" int mrx_llg372_supported(int W) { return W == PFA_N; }
+extern "C" int64_t mrx_llg372_operand_floats(int B, int C, int H) {
+    if (B < 0 || C < 1 || H < 1) return -1;
+    return (int64_t)B * H * pfa372_tasks(C) * L372_TASK_C2 * 2;
+}
+extern "C" int64_t mrx_llg372_work_floats(int B, int C, int H) {
+    if (B < 0 || C < 1 || H < 1) return -1;
+    return (int64_t)pfa372_tasks(C) * B * H * PFA_N * 2;
+}
+extern "C" int mrx_llg372_prepare(const float* yt, const float* S, const void* mask, int mask_kind, const int64_t* mstride, float* ytp,
+                                  float* Sp, float* maskp, int B, int C, int H, int centered, void* stream) {
+    MRX_REQUIRE(yt && S && mask && mstride && ytp && Sp && maskp, MRX_EINVAL, "mrx_llg372_prepare: null pointer");
+    MRX_REQUIRE(mask_kind == MRX_MASK_U8 || mask_kind == MRX_MASK_F32, MRX_EINVAL, "mrx_llg372_prepare: bad mask kind %d", mask_kind);
+    MRX_REQUIRE(mstride[1] == 0 && mstride[2] == 0, MRX_EUNSUP,
+                "mrx_llg372_prepare: the mask must depend on the column (and batch) index only (strides %lld %lld)", (long long)mstride[1],
+                (long long)mstride[2]);
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, 0, centered, mstride[0] != 0);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = a.ntasks * L372_TASK_C2;
+    long long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_llg372_prep, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)yt, (const float2*)S, (float2*)ytp, (float2*)Sp, a);
+    MrxMask m;
+    m.p = mask;
+    m.kind = mask_kind;
+    for (int i = 0; i < 4; ++i) m.s[i] = mstride[i];
+    const int nbm = mstride[0] != 0 ? B : 1;
+    hipLaunchKernelGGL(k_llg372_prep_mask, dim3(mrx_cdiv((long long)nbm * PFA_N, 256)), dim3(256), 0, st, m, maskp, nbm, a.halfW);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* out4,
+                          float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream) {
+    MRX_REQUIRE(eta && ytp && Sp && maskp && work && (out4 || nparts), MRX_EINVAL, "mrx_llg372: null pointer");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, mask_batched);
+    if (rc) return rc;
+    if (nparts) *nparts = 0;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_llg372: too many tasks");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_llg372, dim3((unsigned)a.ntasks), dim3(64), L372_LDS_BYTES, st, (const float2*)eta, (const float2*)ytp,
+                       (const float2*)Sp, maskp, (float2*)work, a);
+    if (nparts) {
+        *nparts = a.T;
+        MRX_LAUNCH_CHECK();
+        return MRX_OK;
+    }
+    const long long plane = (long long)H * PFA_N, total = plane * B;
+    long long nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_llg372_combine, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)eta, (const float2*)work, out4, a.T,
+                       (long long)B, plane, inv_sigma2);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

@@ -126,6 +126,64 @@ def llg_prepare(y, centered, normalization, spatial_dims=None):
     return out
 
 
+class Llg372Operands:
+    """The loop-invariant operands of the W = 372 one-launch gradient (mrx_llg372) in lane order: yt = IFFT_H(y), the sensitivity
+    maps and the mask, laid out once per slice by `llg372_prepare`; `work` is the partial-sum workspace reused by every step."""
+    __slots__ = ("ytp", "sp", "maskp", "mask_batched", "B", "C", "H", "centered", "work")
+
+    def __init__(self, ytp, sp, maskp, mask_batched, B, C, H, centered, work):
+        self.ytp, self.sp, self.maskp, self.mask_batched = ytp, sp, maskp, mask_batched
+        self.B, self.C, self.H, self.centered, self.work = B, C, H, centered, work
+
+
+LLG372 = os.environ.get("MRIDC_AMD_LLG372", "1") != "0"
+
+
+def llg372_supported(yt, mask):
+    """The prime-factor kernel covers W = 372 and masks that depend on the column (and batch) index only."""
+    if not (LLG372 and yt.dim() == 5 and int(yt.shape[3]) == 372 and _lib.lib().mrx_llg372_supported(372)):
+        return False
+    m = mask[..., 0] if (mask.dim() == 5 and mask.shape[-1] == 1) else mask
+    while m.dim() < 4:
+        m = m.unsqueeze(0)
+    return m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1
+
+
+def llg372_prepare(yt, sens, mask, centered):
+    """(yt, S, mask) -> Llg372Operands (mrx_llg372_prepare): once per slice, shared by every cascade and time-step."""
+    yt, sens = _lib.f32c(yt), _lib.f32c(sens)
+    B, C, H, W = _bchw(yt)
+    if sens.shape != yt.shape or W != 372:
+        raise ValueError(f"llg372_prepare: yt {tuple(yt.shape)} vs maps {tuple(sens.shape)}")
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    L = _lib.lib()
+    n = int(L.mrx_llg372_operand_floats(B, C, H))
+    ytp = torch.empty(n, dtype=torch.float32, device=yt.device)
+    sp = torch.empty(n, dtype=torch.float32, device=yt.device)
+    maskp = torch.empty(B * 372, dtype=torch.float32, device=yt.device)
+    work = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=yt.device)
+    _lib.check(L.mrx_llg372_prepare(_lib.ptr(yt), _lib.ptr(sens), _lib.ptr(m), kind, ms, _lib.ptr(ytp), _lib.ptr(sp), _lib.ptr(maskp),
+                                    B, C, H, int(bool(centered)), _lib.stream_ptr()), "mrx_llg372_prepare")
+    return Llg372Operands(ytp, sp, maskp, int(ms[0] != 0), B, C, H, bool(centered), work)
+
+
+def llg372(eta, op, sigma, normalization, out=None, parts=False):
+    """log_likelihood_gradient from prepared operands.  parts=False -> out4 [B,4,H,372]; parts=True -> (work, nparts) for
+    rim_layer_indrnn_packed_llg (the coil-group partial sums, 1/sigma^2 not yet applied)."""
+    import ctypes
+    eta = _lib.f32c(eta)
+    if tuple(eta.shape) != (op.B, op.H, 372, 2):
+        raise ValueError(f"llg372: eta {tuple(eta.shape)} does not match {(op.B, op.H, 372, 2)}")
+    n = ctypes.c_int(0)
+    if not parts and out is None:
+        out = torch.empty(op.B, 4, op.H, 372, dtype=torch.float32, device=eta.device)
+    _lib.check(_lib.lib().mrx_llg372(_lib.ptr(eta), _lib.ptr(op.ytp), _lib.ptr(op.sp), _lib.ptr(op.maskp), op.mask_batched,
+                                     None if parts else _lib.ptr(out), _lib.ptr(op.work), ctypes.byref(n) if parts else None,
+                                     op.B, op.C, op.H, float(1.0 / (float(sigma) ** 2.0)), _norm(normalization), int(op.centered),
+                                     _lib.stream_ptr()), "mrx_llg372")
+    return (op.work, int(n.value)) if parts else out
+
+
 def llg_hinv(eta, yt, sens, mask, sigma, centered, normalization, out=None, work=None):
     """log_likelihood_gradient for a row-invariant mask (yt from llg_prepare): row transforms only."""
     yt, sens, eta = _lib.f32c(yt), _lib.f32c(sens), _lib.f32c(eta)

@@ -95,3 +95,74 @@ extern "C" int emu_fft_ct(float* data, int n, int nseq, int seq_stride, int es, 
         default: return -1;
     }
 }
+
+// ---- the 372-point prime-factor pipeline (pfa372.h): one task = up to 5 coil rows, the 64 lanes emulated by loops ----------------------
+#include "../../mridc_amd/csrc/pfa372.h"
+
+// plain 372-point transform through the 12 x 31 maps (checks the index maps and the two small DFTs)
+extern "C" void emu_pfa372_fft(const float* in, float* out, int inverse) {
+    const mrx_c32* x = reinterpret_cast<const mrx_c32*>(in);
+    mrx_c32* y = reinterpret_cast<mrx_c32*>(out);
+    std::vector<mrx_c32> Y(12 * 31);
+    for (int n1 = 0; n1 < 12; ++n1) {
+        mrx_c32 v[31];
+        for (int n2 = 0; n2 < 31; ++n2) v[n2] = x[pfa372_n(n1, n2)];
+        auto st = [&](int q, mrx_c32 val) { Y[q * 12 + n1] = val; };
+        if (inverse) pfa_dft31<true>(v, st); else pfa_dft31<false>(v, st);
+    }
+    for (int k2 = 0; k2 < 31; ++k2) {
+        mrx_c32 v[12];
+        for (int i = 0; i < 12; ++i) v[i] = Y[k2 * 12 + i];
+        if (inverse) pfa_dft12<true>(v); else pfa_dft12<false>(v);
+        for (int k1 = 0; k1 < 12; ++k1) y[pfa372_k(k1, k2)] = v[k1];
+    }
+}
+
+// one task of the gradient pipeline exactly as the kernel runs it (same phases, same LDS buffer and index maps):
+// eta [372], S / yt [Cg][372] (natural column order), mask [372] -> out [372] = sum_c conj(S_c) IFFT(m (s FFT(eta S_c) - yt_c)) * scale_i
+extern "C" void emu_pfa372_task(const float* eta_, const float* S_, const float* yt_, const float* mask, float* out_, int Cg, int half,
+                                float scale_f, float scale_i) {
+    const mrx_c32 *eta = reinterpret_cast<const mrx_c32*>(eta_), *S = reinterpret_cast<const mrx_c32*>(S_),
+                  *yt = reinterpret_cast<const mrx_c32*>(yt_);
+    mrx_c32* out = reinterpret_cast<mrx_c32*>(out_);
+    // once-per-slice operand layouts
+    std::vector<mrx_c32> Sp(31 * PFA_L1), ytp(12 * PFA_D);
+    std::vector<float> Mk(12 * 31);
+    for (int n2 = 0; n2 < 31; ++n2)
+        for (int l = 0; l < PFA_L1; ++l) {
+            int g, w;
+            pfa372_sp_src(n2, l, half, &g, &w);
+            Sp[n2 * PFA_L1 + l] = g < Cg ? S[g * PFA_N + w] : mrx_mk(0.f, 0.f);
+        }
+    for (int k1 = 0; k1 < 12; ++k1)
+        for (int d = 0; d < PFA_D; ++d) {
+            int g, w;
+            pfa372_yt_src(k1, d, half, &g, &w);
+            ytp[k1 * PFA_D + d] = g < Cg ? yt[g * PFA_N + w] : mrx_mk(0.f, 0.f);
+        }
+    for (int k1 = 0; k1 < 12; ++k1)
+        for (int k2 = 0; k2 < 31; ++k2) Mk[k1 * 31 + k2] = mask[pfa372_mask_src(k1, k2, half)];
+    std::vector<mrx_c32> X(PFA_LDS_C2);
+    std::vector<Pfa372Lane> L(64);
+    for (int n = 0; n < PFA_N; ++n) X[n] = eta[pfa372_shift(n, half)];
+    for (int l = 0; l < PFA_L1; ++l) {
+        for (int n2 = 0; n2 < 31; ++n2) L[l].s[n2] = Sp[n2 * PFA_L1 + l];
+        pfa372_expand(L[l], X.data(), l % 12);
+    }
+    for (int l = 0; l < PFA_L1; ++l) pfa372_stage_a(L[l], X.data(), l / 12, l % 12);
+    for (int pass = 0; pass < 3; ++pass)
+        for (int l = 0; l < 64; ++l) {
+            const int d = pass * 64 + l;
+            if (d >= PFA_D) continue;
+            mrx_c32 yv[12];
+            for (int k1 = 0; k1 < 12; ++k1) yv[k1] = ytp[k1 * PFA_D + d];
+            pfa372_stage_b(X.data(), Mk.data(), yv, d / 31, d % 31, scale_f);
+        }
+    for (int l = 0; l < PFA_L1; ++l) pfa372_gather_a(L[l], X.data(), l / 12, l % 12);
+    for (int l = 0; l < PFA_L1; ++l) pfa372_stage_a_inv(L[l], X.data(), l / 12, l % 12, scale_i);
+    for (int n = 0; n < PFA_N; ++n) {
+        mrx_c32 s = mrx_mk(0.f, 0.f);
+        for (int g = 0; g < PFA_G; ++g) s = mrx_add(s, X[g * PFA_RS + n]);
+        out[pfa372_shift(n, half)] = s;
+    }
+}

@@ -67,3 +67,45 @@ def test_compile_time_plans_match_numpy(emu, n, inverse):
     buf = np.ascontiguousarray(x.T.copy())
     assert emu.emu_fft_ct(buf.ctypes.data, n, nseq, 1, nseq, inverse, buf.size) == 0
     assert np.linalg.norm(buf.T - ref) <= 3e-6 * np.linalg.norm(ref)
+
+
+# ---- pfa372.h: the prime-factor 12 x 31 form of the 372-point row transform and the gradient pipeline built on it -------------------
+@pytest.fixture(scope="module")
+def pfa(emu):
+    emu.emu_pfa372_fft.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    emu.emu_pfa372_task.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
+    return emu
+
+
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_pfa372_transform_matches_numpy(pfa, inverse):
+    rng = np.random.default_rng(372 + inverse)
+    x = (rng.standard_normal(372) + 1j * rng.standard_normal(372)).astype(np.complex64)
+    out = np.zeros(372, np.complex64)
+    pfa.emu_pfa372_fft(x.ctypes.data, out.ctypes.data, inverse)
+    ref = np.fft.ifft(x.astype(np.complex128)) * 372 if inverse else np.fft.fft(x.astype(np.complex128))
+    assert np.linalg.norm(out - ref) <= 2e-6 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("Cg", [5, 3, 1])
+@pytest.mark.parametrize("centered", [0, 1])
+def test_pfa372_gradient_task_matches_numpy(pfa, Cg, centered):
+    """One task (<= 5 coils of one row) of the kernel's pipeline, lane by lane on the host, against the definition
+    sum_c conj(S_c) IFFT_W(m (FFT_W(eta S_c) - yt_c)) (rim_utils.py:44-62 with the H transforms cancelled) in float64."""
+    rng = np.random.default_rng(10 * Cg + centered)
+    W = 372
+    c64 = lambda *s: (rng.standard_normal(s) + 1j * rng.standard_normal(s)).astype(np.complex64)  # noqa: E731
+    eta, S, yt = c64(W), c64(Cg, W), c64(Cg, W) * 5
+    mask = (rng.uniform(size=W) < 0.3).astype(np.float32)
+    half = W // 2 if centered else 0
+    scale_f, scale_i = 1.0 / np.sqrt(W), 1.0 / np.sqrt(W)
+    out = np.zeros(W, np.complex64)
+    pfa.emu_pfa372_task(eta.ctypes.data, S.ctypes.data, yt.ctypes.data, mask.ctypes.data, out.ctypes.data, Cg, half,
+                        ctypes.c_float(scale_f), ctypes.c_float(scale_i))
+    sh = (lambda a: np.fft.ifftshift(a, axes=-1)) if centered else (lambda a: a)
+    ush = (lambda a: np.fft.fftshift(a, axes=-1)) if centered else (lambda a: a)
+    e, s_, y_ = eta.astype(np.complex128), S.astype(np.complex128), yt.astype(np.complex128)
+    k = ush(np.fft.fft(sh(e[None] * s_), axis=-1)) * scale_f
+    r = ush(np.fft.ifft(sh(mask[None] * (k - y_)), axis=-1)) * W * scale_i
+    ref = (r * np.conj(s_)).sum(0)
+    assert np.linalg.norm(out - ref) <= 3e-6 * np.linalg.norm(ref)

@@ -97,6 +97,33 @@ def test_llg_parts_and_layer1_loader(dev, case):
         assert_close(h0, h0_ref, 1e-5, "layer 1 (deferred, zero state) vs oracle")
     else:
         assert_close(out4, g_ref, 1e-5, "llg_hinv_parts complete output vs oracle")
+    if W == 372:
+        # the prime-factor kernel (mrx_llg372: lane-ordered operands prepared once per slice), complete and deferred forms
+        assert ops.llg372_supported(yt, md)
+        op = ops.llg372_prepare(yt, Sd, md, centered)
+        assert_close(ops.llg372(ed, op, sigma, norm), g_ref, 1e-5, "llg372 vs oracle")
+        part3, n3 = ops.llg372(ed, op, sigma, norm, parts=True)
+        assert n3 == -(-C // 5)
+        h3 = ops.rim_layer_indrnn_packed_llg(ed, part3, n3, sigma, packed, 64, 5, 1, bd, bid, hhd, hp)
+        assert_close(h3, h_ref, 1e-5, "layer 1 reading the llg372 partial sums vs oracle")
+
+
+def test_llg372_batched_mask_and_ragged_coils(dev):
+    """mrx_llg372 with one mask per batch element ([B,1,1,W,1]) and coil counts that leave the last task partly empty."""
+    from mridc_amd import ops
+    for B, C, H, centered, norm in ((2, 7, 9, True, "ortho"), (3, 1, 5, False, "backward"), (1, 16, 33, False, "forward")):
+        y, S, mask, eta = _problem(B, C, H, 372, 4000 + C, centered, norm)
+        mB = torch.cat([torch.roll(mask, 7 * i, dims=3) for i in range(B)], 0)
+        k = oracle.fft.fft2(oracle.utils.complex_mul(torch.randn(B, 1, H, 372, 2, generator=torch.Generator().manual_seed(C)), S),
+                            centered, norm)
+        y = (k / k.abs().max()) * mB
+        with torch.no_grad():
+            g_ref = oracle.rim.log_likelihood_gradient(eta, y, S, mB, 0.8, centered, norm, [-2, -1], 1).contiguous()
+        yd, Sd, md, ed = y.to(dev), S.to(dev), mB.to(dev), eta.to(dev)
+        yt = ops.llg_prepare(yd, centered, norm)
+        op = ops.llg372_prepare(yt, Sd, md, centered)
+        assert_close(ops.llg372(ed, op, 0.8, norm), g_ref, 1e-5, f"llg372 B={B} C={C}")
+        assert_close(ops.llg_hinv(ed, yt, Sd, md, 0.8, centered, norm), g_ref, 1e-5, f"llg_hinv B={B} C={C}")
 
 
 def _cirim(cfg_over, scale, seed=0):
