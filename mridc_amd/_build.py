@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libmridc_amd.so")
 SOURCES = [
     ("api.cpp", []),
     ("fft.hip", []),
-    ("llg372.hip", []),
+    ("llg372.hip", ["-fno-slp-vectorize"]),   # complex values are explicit packed pairs (pfa372.h); no extra pairing of scalar code
     ("elementwise.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
     ("rim_layer.hip", []),

@@ -12,11 +12,18 @@
 //   * S, yt and the mask are read in the order the lanes consume them (laid out once per slice by mrx_llg372_prepare), so every
 //     global access is one contiguous row per wave instruction and S stays in registers from the expand to the reduce.
 // Eight single-wave workgroups per CU; the 1920 tasks of a 15-coil 640-row slice are one dispatch round.
+#include <cstdlib>
+
 #include "mrx_common.h"
 #include "pfa372.h"
 
 #define L372_TASK_C2 (PFA_N * PFA_G)   // 1860 float2 per task in Sp and in ytp
 #define L372_LDS_BYTES (sizeof(float2) * PFA_LDS_C2 + sizeof(float) * PFA_N)
+
+// diagnostics (MRX_LLG372_ABLATE=3): s_memtime stamps of every wave's phases
+__device__ unsigned long long* g_l372_trace = nullptr;
+#define L372_STAMP(i) \
+    if (ABL == 3 && l == 0) g_l372_trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();
 
 struct L372Args {
     int B, C, H, T;       // batch, coils, rows, tasks (groups of 5 coils) per row
@@ -60,12 +67,24 @@ __global__ void k_llg372_prep_mask(MrxMask mask, float* __restrict__ maskp, int 
 }
 
 // ---- the per-step kernel: one wavefront = one task (row, five coils) ----------------------------------------------------------------
-__global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta, const float2* __restrict__ ytp,
-                                                   const float2* __restrict__ Sp, const float* __restrict__ maskp,
-                                                   float2* __restrict__ part, L372Args a) {
-    extern __shared__ __attribute__((aligned(16))) float2 X[];
+// ABL (diagnostics, MRX_LLG372_ABLATE): 0 the kernel; 1 memory only (loads, LDS staging, reduce, stores: no transforms); 2 compute only
+// (operands not loaded from HBM); 3 the kernel with s_memtime stamps per phase (tools/probe/llg372_trace.py).  Measured at 15 x 640 x 372:
+// memory only 11.1 us, compute only 12.3 us, the kernel 17.3 us (rocprofv3) -- every wave waits ~8 us for its first operands (the whole
+// launch requests its 63 MB at once) and the two waves of a SIMD then share the vector ALU for ~8.7 us.
+template <int ABL>
+__global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta_, const float2* __restrict__ ytp_,
+                                                   const float2* __restrict__ Sp_, const float* __restrict__ maskp,
+                                                   float2* __restrict__ part_, L372Args a) {
+    // complex values travel as packed register pairs (pfa_c); the float2 of the interface is the same 8 bytes
+    const pfa_c* __restrict__ eta = reinterpret_cast<const pfa_c*>(eta_);
+    const pfa_c* __restrict__ ytp = reinterpret_cast<const pfa_c*>(ytp_);
+    const pfa_c* __restrict__ Sp = reinterpret_cast<const pfa_c*>(Sp_);
+    pfa_c* __restrict__ part = reinterpret_cast<pfa_c*>(part_);
+    extern __shared__ __attribute__((aligned(16))) float2 X_[];
+    pfa_c* X = reinterpret_cast<pfa_c*>(X_);
     float* Mk = reinterpret_cast<float*>(X + PFA_LDS_C2);
     const int l = threadIdx.x;
+    L372_STAMP(0)
     // every XCD walks one contiguous band of tasks: the tasks of an image row (which share the eta row) meet in one L2
     const unsigned task = (unsigned)mrx_xcd_band(blockIdx.x, a.ntasks);      // ntasks < 2^31 (checked by the launcher)
     const unsigned row = task / (unsigned)a.T;
@@ -77,77 +96,89 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
 
     // all global operands of the task requested up front, unconditionally (idle lanes repeat a neighbour's address): eta row + mask
     // (6 + 6 loads), S (31), first yt pass (12)
-    float2 ev[6];
+    pfa_c ev[6];
     float mv[6];
-    const float2* erow = eta + (long long)row * PFA_N;
+    const pfa_c* erow = eta + (long long)row * PFA_N;
     const float* mrow = maskp + (long long)b * a.mask_bstride;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int n = min(l + 64 * i, PFA_N - 1);
-        ev[i] = erow[pfa372_shift(n, a.halfW)];
-        mv[i] = mrow[n];
+        ev[i] = ABL == 2 ? pfa_mk(0.5f, (float)n) : erow[pfa372_shift(n, a.halfW)];
+        mv[i] = ABL == 2 ? 1.f : mrow[n];
     }
     Pfa372Lane L;
     {
-        const float2* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
+        const pfa_c* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
 #pragma unroll
-        for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = sp[n2 * PFA_L1];
+        for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = ABL == 2 ? pfa_mk((float)(l + n2), 0.25f) : sp[n2 * PFA_L1];
     }
-    const float2* ytask = ytp + (long long)task * L372_TASK_C2;
-    float2 yv[12];
+    // yt of the first two passes of stage B is requested before stage A, the third as soon as stage A has freed its registers: the
+    // whole HBM stream of the task is in flight while the 31-point DFTs run
+    const pfa_c* ytask = ytp + (long long)task * L372_TASK_C2;
+    pfa_c yv0[12], yv1[12], yv2[12];
+    const int d2 = min(l + 128, PFA_D - 1);
 #pragma unroll
-    for (int k1 = 0; k1 < 12; ++k1) yv[k1] = ytask[k1 * PFA_D + l];
+    for (int k1 = 0; k1 < 12; ++k1) yv0[k1] = ABL == 2 ? pfa_mk((float)k1, 1.f) : ytask[k1 * PFA_D + l];
+#pragma unroll
+    for (int k1 = 0; k1 < 12; ++k1) yv1[k1] = ABL == 2 ? pfa_mk((float)k1, 2.f) : ytask[k1 * PFA_D + l + 64];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int n = l + 64 * i;
         if (n < PFA_N) {
             X[n] = ev[i];
+            if (n < PFA_ETA_C2 - PFA_N) X[n + PFA_N] = ev[i];     // second copy: the expand reads unwrapped indices
             Mk[n] = mv[i];
         }
     }
     __syncthreads();
+    L372_STAMP(1)
+    if (ABL == 1) {   // memory only: every loaded value still reaches the output
+        pfa_c acc = pfa_mk(0.f, 0.f);
+#pragma unroll
+        for (int n2 = 0; n2 < 31; ++n2) acc = pfa_add(acc, L.s[n2]);
+#pragma unroll
+        for (int k1 = 0; k1 < 12; ++k1) acc = pfa_add(acc, pfa_add(yv0[k1], yv1[k1]));
+#pragma unroll
+        for (int k1 = 0; k1 < 12; ++k1) acc = pfa_add(acc, ytask[k1 * PFA_D + d2]);
+        __syncthreads();
+        X[PFA_RS + l] = acc;
+        __syncthreads();
+    } else {
     if (laneA) pfa372_expand(L, X, n1);
     __syncthreads();
+    L372_STAMP(2)
     if (laneA) pfa372_stage_a(L, X, g1, n1);
+    L372_STAMP(3)
+#pragma unroll
+    for (int k1 = 0; k1 < 12; ++k1) yv2[k1] = ABL == 2 ? pfa_mk((float)k1, 3.f) : ytask[k1 * PFA_D + d2];
     __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {
-        const int d = pass * 64 + l;
-        float2 yn[12];
-        if (pass < 2) {
-            const int dn = min(d + 64, PFA_D - 1);
-#pragma unroll
-            for (int k1 = 0; k1 < 12; ++k1) yn[k1] = ytask[k1 * PFA_D + dn];
-        }
-        if (d < Cg * PFA_N2) {
-            const int g2 = d / PFA_N2;
-            pfa372_stage_b(X, Mk, yv, g2, d - g2 * PFA_N2, a.scale_f);
-        }
-        if (pass < 2) {
-#pragma unroll
-            for (int k1 = 0; k1 < 12; ++k1) yv[k1] = yn[k1];
-        }
+    {
+        const int nd = Cg * PFA_N2;
+        const int ga = l / PFA_N2, gb = (l + 64) / PFA_N2, gc = (l + 128) / PFA_N2;
+        if (l < nd) pfa372_stage_b(X, Mk, yv0, ga, l - ga * PFA_N2, a.scale_f);
+        if (l + 64 < nd) pfa372_stage_b(X, Mk, yv1, gb, l + 64 - gb * PFA_N2, a.scale_f);
+        if (l + 128 < nd) pfa372_stage_b(X, Mk, yv2, gc, l + 128 - gc * PFA_N2, a.scale_f);
     }
     __syncthreads();
+    L372_STAMP(4)
     if (laneA) pfa372_gather_a(L, X, g1, n1);
     __syncthreads();
     if (laneA) pfa372_stage_a_inv(L, X, g1, n1, a.scale_i);
     __syncthreads();
-    float2* po = part + (((long long)z * a.B * a.H) + row) * PFA_N;
+    L372_STAMP(5)
+    }
+    pfa_c* po = part + (((long long)z * a.B * a.H) + row) * PFA_N;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int n = l + 64 * i;
         if (n < PFA_N) {
-            float2 s = X[n];
+            pfa_c s = X[n];
 #pragma unroll
-            for (int g = 1; g < PFA_G; ++g) {
-                const float2 v = X[g * PFA_RS + n];
-                s.x += v.x;
-                s.y += v.y;
-            }
+            for (int g = 1; g < PFA_G; ++g) s = pfa_add(s, X[g * PFA_RS + n]);
             po[pfa372_shift(n, a.halfW)] = s;
         }
     }
+    L372_STAMP(6)
 }
 
 // out4[b, 0:4] = (eta_re, eta_im, post * sum_k part_k re, im)   (rim_utils.py:61-67)
@@ -232,8 +263,48 @@ extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, c
     if (B == 0) return MRX_OK;
     MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_llg372: too many tasks");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_llg372, dim3((unsigned)a.ntasks), dim3(64), L372_LDS_BYTES, st, (const float2*)eta, (const float2*)ytp,
-                       (const float2*)Sp, maskp, (float2*)work, a);
+    static const int ablate = getenv("MRX_LLG372_ABLATE") ? atoi(getenv("MRX_LLG372_ABLATE")) : 0;
+    const dim3 grid((unsigned)a.ntasks), blk(64);
+    const float2 *pe = (const float2*)eta, *py = (const float2*)ytp, *ps = (const float2*)Sp;
+    if (ablate == 1)
+        hipLaunchKernelGGL((k_llg372<1>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+    else if (ablate == 2)
+        hipLaunchKernelGGL((k_llg372<2>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+    else if (ablate == 3) {
+        static unsigned long long* d_trace = nullptr;
+        if (!d_trace) {
+            (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 8 * (size_t)a.ntasks);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_l372_trace), &d_trace, sizeof(d_trace));
+        }
+        hipLaunchKernelGGL((k_llg372<3>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+        if (getenv("MRX_LLG372_TRACE_DUMP")) {
+            (void)hipStreamSynchronize(st);
+            const size_t nt = (size_t)a.ntasks;
+            unsigned long long* h = (unsigned long long*)malloc(sizeof(unsigned long long) * 8 * nt);
+            (void)hipMemcpy(h, d_trace, sizeof(unsigned long long) * 8 * nt, hipMemcpyDeviceToHost);
+            const char* names[6] = {"operands requested -> eta staged in LDS", "expand (waits for S)", "stage A (31-point DFTs)",
+                                    "stage B (waits for yt; 12-point DFTs + DC)", "stage A' (inverse 31-point DFTs, conj(S))",
+                                    "coil-group sum + store"};
+            for (int k = 0; k < 6; ++k) {
+                double mn = 1e30, mx = 0, sum = 0;
+                for (size_t i = 0; i < nt; ++i) {
+                    const double v = (double)(h[i * 8 + k + 1] - h[i * 8 + k]);   // s_memtime is per XCD: differences within a wave only
+                    mn = v < mn ? v : mn, mx = v > mx ? v : mx, sum += v;
+                }
+                fprintf(stderr, "[llg372-trace] %-48s min %7.0f  mean %7.0f  max %7.0f cycles\n", names[k], mn, sum / nt, mx);
+            }
+            {
+                double sum = 0, mx = 0;
+                for (size_t i = 0; i < nt; ++i) {
+                    const double v = (double)(h[i * 8 + 6] - h[i * 8]);
+                    sum += v, mx = v > mx ? v : mx;
+                }
+                fprintf(stderr, "[llg372-trace] whole wave: mean %.0f  max %.0f cycles over %zu waves\n", sum / nt, mx, nt);
+            }
+            free(h);
+        }
+    } else
+        hipLaunchKernelGGL((k_llg372<0>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
     if (nparts) {
         *nparts = a.T;
         MRX_LAUNCH_CHECK();

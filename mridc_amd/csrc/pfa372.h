@@ -34,60 +34,114 @@ MRX_HD int pfa372_n(int n1, int n2) {
 }
 MRX_HD int pfa372_k(int k1, int k2) { return (217 * k1 + 156 * k2) % PFA_N; }
 
+// ---- complex arithmetic layer ---------------------------------------------------------------------------------------------------------
+// Device: a complex number is one aligned VGPR pair (ext_vector_type(2)) and every operation below is ONE packed-fp32 instruction
+// (v_pk_add / v_pk_mul / v_pk_fma; the swaps and sign flips of "times +-i", complex and conjugate multiplication ride in the
+// op_sel / neg modifiers).  Measured on gfx950 (tools/probe/valu_probe.hip): a packed op issues in ~4.7 cycles for two lanes' worth
+// of work with any operand kind, a scalar-fp32 VALU op in ~2.6 cycles -- but ~4.3 when one source is an SGPR, which is where dense
+// DFT coefficients live; so the constant-coefficient FMAs must be packed.  Host (tests/emu): the same functions in plain C++.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float pfa_c __attribute__((ext_vector_type(2)));
+#define PFA_FN __device__ __forceinline__
+PFA_FN pfa_c pfa_mk(float x, float y) { return (pfa_c){x, y}; }
+PFA_FN pfa_c pfa_add(pfa_c a, pfa_c b) { return a + b; }
+PFA_FN pfa_c pfa_sub(pfa_c a, pfa_c b) { return a - b; }
+PFA_FN pfa_c pfa_scale(pfa_c a, float s) { return a * (pfa_c){s, s}; }
+PFA_FN pfa_c pfa_fma_r(pfa_c x, float c, pfa_c acc) { return __builtin_elementwise_fma(x, (pfa_c){c, c}, acc); }   // x * c + acc, c real
+// a + (-i b) [INV false] / a + (+i b) [INV true]; pfa_sub_rot: a - (...)
+template <bool INV>
+PFA_FN pfa_c pfa_add_rot(pfa_c a, pfa_c b) {
+    pfa_c d;
+    if (INV)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <bool INV>
+PFA_FN pfa_c pfa_sub_rot(pfa_c a, pfa_c b) { return pfa_add_rot<!INV>(a, b); }
+PFA_FN pfa_c pfa_cmul(pfa_c e, pfa_c s) {        // e * s
+    pfa_c t, x;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(e), "v"(s));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(x) : "v"(e), "v"(s), "v"(t));
+    return x;
+}
+PFA_FN pfa_c pfa_cmul_conj(pfa_c v, pfa_c s) {   // v * conj(s)
+    pfa_c t, x;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(v), "v"(s));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(x) : "v"(v), "v"(s), "v"(t));
+    return x;
+}
+#else
+typedef mrx_c32 pfa_c;
+#define PFA_FN MRX_HD
+PFA_FN pfa_c pfa_mk(float x, float y) { return mrx_mk(x, y); }
+PFA_FN pfa_c pfa_add(pfa_c a, pfa_c b) { return mrx_add(a, b); }
+PFA_FN pfa_c pfa_sub(pfa_c a, pfa_c b) { return mrx_sub(a, b); }
+PFA_FN pfa_c pfa_scale(pfa_c a, float s) { return mrx_mk(a.x * s, a.y * s); }
+PFA_FN pfa_c pfa_fma_r(pfa_c x, float c, pfa_c acc) { return mrx_mk(x.x * c + acc.x, x.y * c + acc.y); }
+template <bool INV>
+PFA_FN pfa_c pfa_add_rot(pfa_c a, pfa_c b) { return mrx_add(a, mrx_rot<INV>(b)); }
+template <bool INV>
+PFA_FN pfa_c pfa_sub_rot(pfa_c a, pfa_c b) { return mrx_sub(a, mrx_rot<INV>(b)); }
+PFA_FN pfa_c pfa_cmul(pfa_c e, pfa_c s) { return mrx_cmul(e, s); }
+PFA_FN pfa_c pfa_cmul_conj(pfa_c v, pfa_c s) { return mrx_mk(v.x * s.x + v.y * s.y, v.y * s.x - v.x * s.y); }
+#endif
+
 // 31-point DFT of x (destroyed) with every output handed to st(q, value) as soon as it exists (q = 0, then the pairs (q, 31 - q)).
+//   X_q = x_0 + sum_{t=1..15} (x_t + x_{31-t}) cos(2 pi t q / 31)  -/+ i  sum_t (x_t - x_{31-t}) sin(2 pi t q / 31)
+// 45 packed additions, then per output pair 30 packed FMAs with compile-time coefficients and 2 packed "a +- i b" additions.
 template <bool INV, class Store>
-MRX_HD void pfa_dft31(mrx_c32 (&x)[31], Store&& st) {
+PFA_FN void pfa_dft31(pfa_c (&x)[31], Store&& st) {
     constexpr MrxPrimeTable<31> T = mrx_make_prime_table<31>();
-    mrx_c32 sum = x[0];
+    pfa_c sum = x[0];
 #pragma unroll
     for (int t = 1; t <= 15; ++t) {
-        const mrx_c32 a = mrx_add(x[t], x[31 - t]), b = mrx_sub(x[t], x[31 - t]);
+        const pfa_c a = pfa_add(x[t], x[31 - t]), b = pfa_sub(x[t], x[31 - t]);
         x[t] = a;
         x[31 - t] = b;
-        sum = mrx_add(sum, a);
+        sum = pfa_add(sum, a);
     }
     st(0, sum);
 #pragma unroll
     for (int q = 1; q <= 15; ++q) {
-        mrx_c32 accR = x[0], accI = mrx_mk(0.f, 0.f);
+        pfa_c accR = x[0];
+        pfa_c accI = pfa_scale(x[30], T.s[q % 31]);          // t = 1
+        accR = pfa_fma_r(x[1], T.c[q % 31], accR);
 #pragma unroll
-        for (int t = 1; t <= 15; ++t) {
+        for (int t = 2; t <= 15; ++t) {
             const int m = (t * q) % 31;
-            accR.x += x[t].x * T.c[m];
-            accR.y += x[t].y * T.c[m];
-            accI.x += x[31 - t].x * T.s[m];
-            accI.y += x[31 - t].y * T.s[m];
+            accR = pfa_fma_r(x[t], T.c[m], accR);
+            accI = pfa_fma_r(x[31 - t], T.s[m], accI);
         }
-        const mrx_c32 ri = mrx_rot<INV>(accI);
-        st(q, mrx_add(accR, ri));
-        st(31 - q, mrx_sub(accR, ri));
+        st(q, pfa_add_rot<INV>(accR, accI));
+        st(31 - q, pfa_sub_rot<INV>(accR, accI));
     }
 }
 
 // 12-point DFT in place, twiddle-free 3 x 4 prime-factor form: n1 = (4 a + 3 b) mod 12, k1 = (4 ka + 9 kb) mod 12.
 template <bool INV>
-MRX_HD void pfa_dft12(mrx_c32 (&v)[12]) {
+PFA_FN void pfa_dft12(pfa_c (&v)[12]) {
     const float s3 = 0.86602540378443864676f;
-    mrx_c32 u[3][4];
+    pfa_c u[3][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const mrx_c32 a0 = v[(3 * b) % 12], a1 = v[(4 + 3 * b) % 12], a2 = v[(8 + 3 * b) % 12];
-        const mrx_c32 t1 = mrx_add(a1, a2);
-        const mrx_c32 t2 = mrx_mk(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
-        const mrx_c32 d = mrx_sub(a1, a2);
-        const mrx_c32 t3 = mrx_rot<INV>(mrx_mk(s3 * d.x, s3 * d.y));
-        u[0][b] = mrx_add(a0, t1);
-        u[1][b] = mrx_add(t2, t3);
-        u[2][b] = mrx_sub(t2, t3);
+        const pfa_c a0 = v[(3 * b) % 12], a1 = v[(4 + 3 * b) % 12], a2 = v[(8 + 3 * b) % 12];
+        const pfa_c t1 = pfa_add(a1, a2);
+        const pfa_c t2 = pfa_fma_r(t1, -0.5f, a0);
+        const pfa_c d = pfa_scale(pfa_sub(a1, a2), s3);
+        u[0][b] = pfa_add(a0, t1);
+        u[1][b] = pfa_add_rot<INV>(t2, d);
+        u[2][b] = pfa_sub_rot<INV>(t2, d);
     }
 #pragma unroll
     for (int ka = 0; ka < 3; ++ka) {
-        mrx_c32 y0, y1, y2, y3;
-        mrx_dft4<INV>(u[ka][0], u[ka][1], u[ka][2], u[ka][3], y0, y1, y2, y3);
-        v[(4 * ka) % 12] = y0;
-        v[(4 * ka + 9) % 12] = y1;
-        v[(4 * ka + 18) % 12] = y2;
-        v[(4 * ka + 27) % 12] = y3;
+        const pfa_c b0 = pfa_add(u[ka][0], u[ka][2]), b1 = pfa_sub(u[ka][0], u[ka][2]);
+        const pfa_c b2 = pfa_add(u[ka][1], u[ka][3]), d = pfa_sub(u[ka][1], u[ka][3]);
+        v[(4 * ka) % 12] = pfa_add(b0, b2);
+        v[(4 * ka + 9) % 12] = pfa_add_rot<INV>(b1, d);
+        v[(4 * ka + 18) % 12] = pfa_sub(b0, b2);
+        v[(4 * ka + 27) % 12] = pfa_sub_rot<INV>(b1, d);
     }
 }
 
@@ -103,52 +157,51 @@ MRX_HD int pfa372_shift(int p, int half) {
 }
 
 // ---- the per-lane phases of the gradient pipeline -----------------------------------------------------------------------------------
-// All LDS indices are in float2 units inside the wave-private buffer `X`; Mk is the [12][31] mask table.
+// All LDS indices are in complex units inside the wave-private buffer `X`; Mk is the [12][31] mask table.
 struct Pfa372Lane {
-    mrx_c32 s[31];   // this lane's 31 sensitivity values (stage A layout), kept for the whole pipeline
-    mrx_c32 x[31];   // working registers of the 31-point DFTs
+    pfa_c s[31];   // this lane's 31 sensitivity values (stage A layout), kept for the whole pipeline
+    pfa_c x[31];   // working registers of the 31-point DFTs
 };
 
-// phase 1: x = eta * S at the lane's 31 pixels (eta row staged at X[0..372) in transform order)
-MRX_HD void pfa372_expand(Pfa372Lane& L, const mrx_c32* X, int n1) {
+// phase 1: x = eta * S at the lane's 31 pixels.  The eta row is staged at X[0..702) in transform order AND once more shifted by 372,
+// so pixel (31 n1 + 12 n2) mod 372 is read at the unwrapped index: one base address per lane, immediate offsets per element.
+#define PFA_ETA_C2 (31 * 11 + 12 * 30 + 1)   // 702
+PFA_FN void pfa372_expand(Pfa372Lane& L, const pfa_c* X, int n1) {
+    const pfa_c* e = X + 31 * n1;
 #pragma unroll
-    for (int n2 = 0; n2 < 31; ++n2) L.x[n2] = mrx_cmul(X[pfa372_n(n1, n2)], L.s[n2]);  // rim_utils.py:47-48
+    for (int n2 = 0; n2 < 31; ++n2) L.x[n2] = pfa_cmul(e[12 * n2], L.s[n2]);  // rim_utils.py:47-48
 }
 // phase 2: forward 31-point DFT -> exchange buffer [g][k2][n1]
-MRX_HD void pfa372_stage_a(Pfa372Lane& L, mrx_c32* X, int g, int n1) {
-    mrx_c32* o = X + g * PFA_GS + n1;
-    pfa_dft31<false>(L.x, [&](int q, mrx_c32 v) { o[q * PFA_KS] = v; });
+PFA_FN void pfa372_stage_a(Pfa372Lane& L, pfa_c* X, int g, int n1) {
+    pfa_c* o = X + g * PFA_GS + n1;
+    pfa_dft31<false>(L.x, [&](int q, pfa_c v) { o[q * PFA_KS] = v; });
 }
 // phase 3 (one of the three passes): 12-point DFT, m (s X - yt), inverse 12-point DFT, in place in the exchange buffer
-MRX_HD void pfa372_stage_b(mrx_c32* X, const float* Mk, const mrx_c32 (&yv)[12], int g, int k2, float scale_f) {
-    mrx_c32* p = X + g * PFA_GS + k2 * PFA_KS;
-    mrx_c32 v[12];
+PFA_FN void pfa372_stage_b(pfa_c* X, const float* Mk, const pfa_c (&yv)[12], int g, int k2, float scale_f) {
+    pfa_c* p = X + g * PFA_GS + k2 * PFA_KS;
+    pfa_c v[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) v[i] = p[i];
     pfa_dft12<false>(v);
 #pragma unroll
-    for (int k1 = 0; k1 < 12; ++k1) {
-        const float m = Mk[k1 * 31 + k2];
-        v[k1] = mrx_mk(m * (v[k1].x * scale_f - yv[k1].x), m * (v[k1].y * scale_f - yv[k1].y));  // rim_utils.py:54
-    }
+    for (int k1 = 0; k1 < 12; ++k1)
+        v[k1] = pfa_scale(pfa_sub(pfa_scale(v[k1], scale_f), yv[k1]), Mk[k1 * 31 + k2]);  // rim_utils.py:54: m (s X - yt)
     pfa_dft12<true>(v);
 #pragma unroll
     for (int i = 0; i < 12; ++i) p[i] = v[i];
 }
 // phase 4a: fetch the inverse 31-point DFT's inputs
-MRX_HD void pfa372_gather_a(Pfa372Lane& L, const mrx_c32* X, int g, int n1) {
-    const mrx_c32* p = X + g * PFA_GS + n1;
+PFA_FN void pfa372_gather_a(Pfa372Lane& L, const pfa_c* X, int g, int n1) {
+    const pfa_c* p = X + g * PFA_GS + n1;
 #pragma unroll
     for (int k2 = 0; k2 < 31; ++k2) L.x[k2] = p[k2 * PFA_KS];
 }
-// phase 4b: inverse 31-point DFT, conj(S), into the reduction buffer [g][n]
-MRX_HD void pfa372_stage_a_inv(Pfa372Lane& L, mrx_c32* X, int g, int n1, float scale_i) {
-    mrx_c32* o = X + g * PFA_RS;
-    const mrx_c32* s = L.s;
-    pfa_dft31<true>(L.x, [&](int q, mrx_c32 v) {
-        v.x *= scale_i;
-        v.y *= scale_i;
-        o[pfa372_n(n1, q)] = mrx_mk(v.x * s[q].x + v.y * s[q].y, v.y * s[q].x - v.x * s[q].y);  // rim_utils.py:61-62
+// phase 4b: inverse 31-point DFT, scale, conj(S), into the reduction buffer [g][n]
+PFA_FN void pfa372_stage_a_inv(Pfa372Lane& L, pfa_c* X, int g, int n1, float scale_i) {
+    pfa_c* o = X + g * PFA_RS;
+    const pfa_c* s = L.s;
+    pfa_dft31<true>(L.x, [&](int q, pfa_c v) {
+        o[pfa372_n(n1, q)] = pfa_cmul_conj(pfa_scale(v, scale_i), s[q]);  // rim_utils.py:61-62
     });
 }
 

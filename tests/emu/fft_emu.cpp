@@ -144,7 +144,7 @@ extern "C" void emu_pfa372_task(const float* eta_, const float* S_, const float*
         for (int k2 = 0; k2 < 31; ++k2) Mk[k1 * 31 + k2] = mask[pfa372_mask_src(k1, k2, half)];
     std::vector<mrx_c32> X(PFA_LDS_C2);
     std::vector<Pfa372Lane> L(64);
-    for (int n = 0; n < PFA_N; ++n) X[n] = eta[pfa372_shift(n, half)];
+    for (int n = 0; n < PFA_ETA_C2; ++n) X[n] = eta[pfa372_shift(n % PFA_N, half)];
     for (int l = 0; l < PFA_L1; ++l) {
         for (int n2 = 0; n2 < 31; ++n2) L[l].s[n2] = Sp[n2 * PFA_L1 + l];
         pfa372_expand(L[l], X.data(), l % 12);
