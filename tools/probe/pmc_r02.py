@@ -1,0 +1,33 @@
+"""Three launches of every kernel of the headline loop at 1 x 15 x 640 x 372 x 64 features, for the rocprofv3 --pmc passes
+(FETCH_SIZE and WRITE_SIZE, one counter per pass; counter collection costs ~0.3 s per dispatch on this pool, so the bench itself
+is out of reach).  tools/traffic_json.py turns the two CSVs into profiles/rNN_traffic.json, which bench.py reports as `traffic`."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from mridc_amd import ops
+dev = torch.device("cuda:0")
+B, C, H, W, F = 1, 15, 640, 372, 64
+g = torch.Generator().manual_seed(0)
+r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+x, hp = r(B, F, H, W), r(B, F, H, W)
+wc, wi = r(F, F, 3, 3) / 24, r(F, F, 1, 1) / 8
+bc, bi, hh = r(F), r(F), r(1, F, 1, 1)
+pk = ops.rim_layer_wino_pack(wc, wi)
+pk1 = ops.rim_layer_pack(r(F, 4, 5, 5) / 10, wi)
+eta, y, S = r(B, H, W, 2), r(B, C, H, W, 2), r(B, C, H, W, 2)
+mask = (torch.rand(1, 1, 1, W, 1) < 0.3).to(dev)
+mask2d = (torch.rand(1, 1, H, W, 1) < 0.1).to(dev)
+yt = ops.llg_prepare(y, False, "backward")
+op = ops.llg372_prepare(yt, S, mask, False)
+wf = r(2, F, 3, 3) / 24
+work = torch.empty_like(y)
+torch.cuda.synchronize()
+for _ in range(3):
+    part, n = ops.llg372(eta, op, 1.0, "backward", parts=True)
+    ops.rim_layer_indrnn_packed_llg(eta, part, n, 1.0, pk1, F, 5, 1, bc, bi, hh, hp)
+    ops.rim_layer_indrnn_wino(x, pk, F, bc, bi, hh, hp)
+    ops.rim_final(x, wf, None, 3, 1, eta)
+    ops.llg(eta, y, S, mask2d, 1.0, False, "backward", work=work)
+torch.cuda.synchronize()
+print("done")

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""profiles/rNN_traffic.json from the two rocprofv3 --pmc passes over tools/probe/pmc_r02.py (FETCH_SIZE, WRITE_SIZE: per-dispatch means
+in KiB).  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64
+bytes, so it is doubled; WRITE_SIZE is used as is.
+
+    python tools/traffic_json.py FETCH.csv WRITE.csv LIB_VERSION > profiles/r02_traffic.json
+"""
+import collections
+import csv
+import json
+import sys
+
+KEYS = {            # key in the JSON -> substrings of the kernel names it sums (one "launch" of the operator)
+    "llg": ["k_llg372<"],
+    "conv_layer1": ["k_rim_layer<5, 1, 4"],
+    "conv_layer2_wino": ["k_rim_layer_wino<0, true, 2, true"],
+    "final": ["k_rim_final4"],
+    "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_rows_reduce<1"],
+}
+
+
+def per_kernel(path):
+    acc, cnt = collections.defaultdict(float), collections.defaultdict(set)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            acc[row["Kernel_Name"]] += float(row["Counter_Value"])
+            cnt[row["Kernel_Name"]].add(row["Dispatch_Id"])
+    return {k: acc[k] / len(cnt[k]) for k in acc}
+
+
+def main(fetch_csv, write_csv, lib_version):
+    fe, wr = per_kernel(fetch_csv), per_kernel(write_csv)
+    out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass) -- python3 tools/probe/pmc_r02.py; "
+                      "per-dispatch means in KiB",
+           "_correction": "gfx950: FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B -> doubled; WRITE_SIZE as is",
+           "lib_version": int(lib_version), "shape": dict(batch=1, coils=15, height=640, width=372, features=64), "kernels": {}}
+    for key, pats in KEYS.items():
+        names = [k for k in set(fe) | set(wr) if any(p in k for p in pats)]
+        if not names:
+            continue
+        f = sum(fe.get(k, 0.0) for k in names)
+        w = sum(wr.get(k, 0.0) for k in names)
+        out["kernels"][key] = dict(kernel=" + ".join(sorted(n.split("(")[0][:70] for n in names)), fetch_kib=f, write_kib=w,
+                                   hbm_bytes_per_launch=(2.0 * f + w) * 1024.0)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
