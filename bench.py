@@ -402,8 +402,10 @@ def bench_e2evn(args, world, rank, dev):
 
 def bench_train(args, world, rank, dev):
     """BASELINE config C4 (CIRIM training, DDP gradient all-reduce): one slice per rank and step, fp32."""
+    from mridc_amd import autograd as ag
     from mridc_amd import synthetic, training
     from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    ag.set_precision(args.dtype)       # bf16: convolution / IndRNN GEMM operands in bf16, fp32 accumulation, forward and backward
     cfg = dict(synthetic.CIRIM_BASELINE_CFG)
     cfg["recurrent_layer"] = "IndRNN"
     if args.cascades:
@@ -430,10 +432,13 @@ def bench_train(args, world, rank, dev):
                               value=world * args.steps / elapsed, unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                               ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
                               per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
-                              dtype="f32", data="synthetic",
+                              dtype=args.dtype, data="synthetic",
                               config=dict(workload=f"CIRIM {cfg['num_cascades']} cascades x {model.time_steps} time-steps, IndRNN 64, {C} coils, "
                                                    f"{H}x{W}: forward + l1 loss + backward (HIP kernels) + one all-reduce of the flat gradient "
-                                                   f"({flat.numel * 4 / 1e6:.2f} MB) + Adam, 1 slice per GPU and step",
+                                                   f"({flat.numel * 4 / 1e6:.2f} MB) + Adam, 1 slice per GPU and step"
+                                                   + ("; convolutions and IndRNN GEMMs on bf16 operands with fp32 accumulation (forward, data and "
+                                                      "weight gradients), FFT / data consistency / eta / loss / Adam in fp32" if args.dtype == "bf16"
+                                                      else ""),
                                           global_batch=world, parallelism=f"data-parallel x{world}", gradient_bytes=flat.numel * 4),
                               loss_first=losses[0], loss_last=losses[-1])), flush=True)
 

@@ -312,6 +312,26 @@ int64_t mrx_relu_bwd_work_floats(int C);
 int mrx_relu_bwd(const float* dy, const float* y, const float* h_prev, const float* hh, float* dpre, float* dh_prev,
                  float* sums, float* work, int B, int C, int64_t HW, void* stream);
 
+/* Mixed precision for the training path (BASELINE config 4; the reference trains under AMP, base_cirim_train.yaml:180): convolutions with
+ * bf16 operands and fp32 accumulation (v_mfma_f32_32x32x16_bf16) on the same fp32 NCHW tensors -- the tile loader rounds activations to
+ * bf16, the weights are packed to bf16 once per version.
+ *   mrx_conv_bf16_pack   w [Cout,Cin,k,k] fp32 -> packed (mrx_conv_bf16_pack_bytes bytes); transposed = 1 packs the flipped, channel-
+ *                        transposed weights of the data gradient (then Cin / Cout are those of the GRADIENT convolution: w is [Cin,Cout,k,k])
+ *   mrx_conv2d_bf16      out = act(conv(x) + bias [+ hh * hprev]), 'same' size, stride 1 (conv_layers.py:121-123; with hprev the
+ *                        IndRNN cell of rnn_cells.py:384-391); shapes: mrx_conv_bf16_supported */
+int mrx_conv_bf16_supported(int Cin, int Cout, int k, int dil);
+int64_t mrx_conv_bf16_pack_bytes(int Cin, int Cout, int k);
+int mrx_conv_bf16_pack(const float* w, void* packed, int Cin, int Cout, int k, int transposed, void* stream);
+int mrx_conv2d_bf16(const float* x, const void* packed, const float* bias, const float* hh, const float* hprev, float* out, int B,
+                    int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, void* stream);
+/*   mrx_conv_wgrad_bf16  dw [64,64,k,k] (= or +=) sum over (b, pixel) of dy * padded x (the weight gradient of a 64 -> 64 'same' convolution),
+ *                        bf16 operands, fp32 accumulation per workgroup, fixed-order double sum of the workgroup partials; k = 1, or k = 3 with
+ *                        dilation 2 (mrx_conv_wgrad_bf16_supported); work: mrx_conv_wgrad_bf16_work_floats floats */
+int mrx_conv_wgrad_bf16_supported(int Cin, int Cout, int k, int dil);
+int64_t mrx_conv_wgrad_bf16_work_floats(int B, int H, int W, int k);
+int mrx_conv_wgrad_bf16(const float* x, const float* dy, float* dw, float* work, int B, int H, int W, int k, int dil, int pad_mode,
+                        int accumulate, void* stream);
+
 /*   mrx_absl1_loss      the l1 training loss of one prediction (cirim.py:218-237): out2[0] = mean |target - |p| / max|p||, out2[1] = an
  *                      intermediate the backward needs; p complex [n], target real [n], maxabs = device scalar from mrx_max_abs (mode 1);
  *                      work: mrx_absl1_work_floats floats.  mrx_absl1_loss_bwd: dp = gout * gscale * d(loss)/dp incl. the path through the max

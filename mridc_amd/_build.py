@@ -21,6 +21,7 @@ SOURCES = [
     ("rim_layer_wino.hip", []),
     ("gated_cell.hip", []),
     ("conv_bwd.hip", []),
+    ("conv_bf16.hip", []),
     ("unet.hip", []),
     ("qmri.hip", ["-ffp-contract=off"]),
 ]

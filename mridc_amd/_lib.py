@@ -63,6 +63,13 @@ _SIGNATURES = {
     "mrx_reppad_fold": ([_p, _p, _i64, _i, _i, _i, _p], _i),
     "mrx_relu_bwd_work_floats": ([_i], _i64),
     "mrx_relu_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
+    "mrx_conv_bf16_supported": ([_i, _i, _i, _i], _i),
+    "mrx_conv_bf16_pack_bytes": ([_i, _i, _i], _i64),
+    "mrx_conv_bf16_pack": ([_p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_conv2d_bf16": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
+    "mrx_conv_wgrad_bf16_supported": ([_i, _i, _i, _i], _i),
+    "mrx_conv_wgrad_bf16_work_floats": ([_i, _i, _i, _i], _i64),
+    "mrx_conv_wgrad_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_absl1_work_floats": ([], _i64),
     "mrx_absl1_loss": ([_p, _p, _p, _p, _p, _i64, _p], _i),
     "mrx_absl1_loss_bwd": ([_p, _p, _p, _p, _p, _f, _p, _i64, _p], _i),

@@ -10,6 +10,46 @@ import torch
 
 from mridc_amd import _lib, ops
 
+# Arithmetic of the convolutional regulariser on the training path: "f32" (fp32 matrix cores, the inference kernels' arithmetic) or
+# "bf16" -- BASELINE config 4: bf16 operands with fp32 accumulation for every convolution / IndRNN GEMM, forward and backward (the
+# reference trains under AMP, base_cirim_train.yaml:180), while the FFTs, the data consistency, the eta accumulation, the loss and the
+# optimizer stay fp32.  Set through `set_precision`; each Function records the mode it ran its forward in.
+PRECISION = "f32"
+
+
+def set_precision(mode):
+    global PRECISION
+    if mode not in ("f32", "bf16"):
+        raise ValueError(f"precision must be 'f32' or 'bf16', got {mode!r}")
+    PRECISION = mode
+
+
+def _bf16(cin, cout, k, dilation):
+    return PRECISION == "bf16" and ops.conv_bf16_supported(cin, cout, k, dilation)
+
+
+def _dgrad(dy, weight, dilation, pad_mode, bf16):
+    """Data gradient of y = conv(pad(x), weight).  bf16: the zero-padded convolution with the flipped, transposed weights on bf16 operands
+    (mrx_conv2d_bf16 with a transposed pack), folded back by mrx_reppad_fold for replicate padding."""
+    if not bf16:
+        return ops.conv_dgrad(dy, weight, dilation, pad_mode)
+    k = int(weight.shape[-1])
+    pad = int(dilation) * (k - 1) // 2
+    if pad_mode == ops.PAD_ZERO or pad == 0:
+        return ops.conv2d_bf16(dy, weight, None, dilation, ops.PAD_ZERO, transposed=True)
+    big = ops.pad2d(dy, pad, pad, pad, pad, 0)
+    g = ops.conv2d_bf16(big, weight, None, dilation, ops.PAD_ZERO, transposed=True)
+    B, Cin, H, W = int(dy.shape[0]), int(weight.shape[1]), int(dy.shape[2]), int(dy.shape[3])
+    out = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().mrx_reppad_fold(_lib.ptr(g), _lib.ptr(out), B * Cin, H, W, pad, _lib.stream_ptr()), "mrx_reppad_fold")
+    return out
+
+
+def _wgrad(x, dy, k, dilation, pad_mode, bf16):
+    if bf16 and ops.conv_wgrad_bf16_supported(int(x.shape[1]), int(dy.shape[1]), k, dilation):
+        return ops.conv_wgrad_bf16(x, dy, k, dilation, pad_mode)
+    return ops.conv_wgrad(x, dy, k, dilation, pad_mode)
+
 
 _ZEROS = {}
 
@@ -30,7 +70,11 @@ class ConvReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, dilation):
-        g = ops.conv2d(x, w, b, dilation, ops.PAD_REPLICATE, ops.ACT_RELU)
+        ctx.bf16 = _bf16(int(w.shape[1]), int(w.shape[0]), int(w.shape[-1]), int(dilation))
+        if ctx.bf16:
+            g = ops.conv2d_bf16(x, w, b, dilation, ops.PAD_REPLICATE, ops.ACT_RELU)
+        else:
+            g = ops.conv2d(x, w, b, dilation, ops.PAD_REPLICATE, ops.ACT_RELU)
         ctx.save_for_backward(x, w, g)
         ctx.dilation, ctx.has_bias = int(dilation), b is not None
         return g
@@ -39,8 +83,8 @@ class ConvReLU(torch.autograd.Function):
     def backward(ctx, dg):
         x, w, g = ctx.saved_tensors
         dpre, _, sums = ops.relu_bwd(dg, g)
-        dw = ops.conv_wgrad(x, dpre, int(w.shape[-1]), ctx.dilation, ops.PAD_REPLICATE)
-        dx = ops.conv_dgrad(dpre, w, ctx.dilation, ops.PAD_REPLICATE) if ctx.needs_input_grad[0] else None
+        dw = _wgrad(x, dpre, int(w.shape[-1]), ctx.dilation, ops.PAD_REPLICATE, ctx.bf16)
+        dx = _dgrad(dpre, w, ctx.dilation, ops.PAD_REPLICATE, ctx.bf16) if ctx.needs_input_grad[0] else None
         return dx, dw, (sums[:, 0].contiguous() if ctx.has_bias else None), None
 
 
@@ -49,7 +93,11 @@ class IndRNN1x1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, g, w_ih, b_ih, hh, h_prev):
-        h = ops.indrnn_cell(g, w_ih, b_ih, hh, h_prev, 1)
+        ctx.bf16 = _bf16(int(w_ih.shape[1]), int(w_ih.shape[0]), 1, 1)
+        if ctx.bf16:
+            h = ops.conv2d_bf16(g, w_ih, b_ih, 1, ops.PAD_ZERO, ops.ACT_RELU, hh=hh if h_prev is not None else None, h_prev=h_prev)
+        else:
+            h = ops.indrnn_cell(g, w_ih, b_ih, hh, h_prev, 1)
         ctx.save_for_backward(g, w_ih, hh, h_prev if h_prev is not None else torch.empty(0, device=g.device), h)
         ctx.has_bias, ctx.has_prev = b_ih is not None, h_prev is not None
         return h
@@ -59,8 +107,8 @@ class IndRNN1x1(torch.autograd.Function):
         g, w_ih, hh, h_prev, h = ctx.saved_tensors
         hp = h_prev if ctx.has_prev else None
         dpre, dhp, sums = ops.relu_bwd(dh, h, hp, hh if ctx.has_prev else None)
-        dw = ops.conv_wgrad(g, dpre, 1, 1, ops.PAD_ZERO)
-        dg = ops.conv_dgrad(dpre, w_ih, 1, ops.PAD_ZERO)
+        dw = _wgrad(g, dpre, 1, 1, ops.PAD_ZERO, ctx.bf16)
+        dg = _dgrad(dpre, w_ih, 1, ops.PAD_ZERO, ctx.bf16)
         dhh = sums[:, 1].reshape(hh.shape).contiguous() if ctx.has_prev else torch.zeros_like(hh)
         return dg, dw, (sums[:, 0].contiguous() if ctx.has_bias else None), dhh, dhp
 
@@ -70,6 +118,9 @@ class RimFinal(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, w, b, dilation, eta):
+        # the 64 -> 2 convolution and the eta accumulation stay fp32 in both modes (a VALU / HBM-bound layer: 0.55 of 25 GFLOP); its
+        # data gradient (2 -> 64 channels) runs on the bf16 matrix cores in bf16 mode
+        ctx.bf16 = _bf16(2, int(w.shape[1]), int(w.shape[-1]), int(dilation))
         out = ops.rim_final(h, w, b, int(w.shape[-1]), dilation, eta)
         ctx.save_for_backward(h, w)
         ctx.dilation, ctx.has_bias = int(dilation), b is not None
@@ -80,7 +131,7 @@ class RimFinal(torch.autograd.Function):
         h, w = ctx.saved_tensors
         d2 = dout.permute(0, 3, 1, 2).contiguous()                      # [B,2,H,W]
         dw = ops.conv_wgrad(h, d2, int(w.shape[-1]), ctx.dilation, ops.PAD_REPLICATE)
-        dh = ops.conv_dgrad(d2, w, ctx.dilation, ops.PAD_REPLICATE)
+        dh = _dgrad(d2, w, ctx.dilation, ops.PAD_REPLICATE, ctx.bf16)
         db = d2.sum(dim=(0, 2, 3)) if ctx.has_bias else None            # 2 numbers (the model-zoo final conv has no bias)
         return dh, dw, db, None, dout
 

@@ -1,0 +1,447 @@
+// conv_bf16.hip -- convolutions with bf16 operands and fp32 accumulation on v_mfma_f32_32x32x16_bf16: the mixed-precision mode of the
+// training path (BASELINE config 4, "CIRIM bf16 training"; the reference trains under pytorch-lightning AMP, `precision: 16`,
+// base_cirim_train.yaml:180 / ptl_overrides.py:10-15: autocast runs every convolution on half-precision operands with fp32
+// accumulation and leaves FFTs, data consistency and the eta accumulation in fp32).
+//
+// Tensors stay fp32 NCHW in HBM (the same buffers, autograd tape and fp32 kernels on either side); the tile loader rounds the
+// activations to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way into LDS and the weights are packed to bf16 once per
+// weight version.  One kernel covers the forward convolutions, the IndRNN 1x1 `ih` GEMM with its epilogue and -- with flipped,
+// transposed weights -- every data gradient:
+//   * GEMM roles  D[32 couts][32 pixels of a row] += A[cout][k] B[k][pixel],  k = (tap, channel);  one MFMA consumes 16 k-values: the
+//     lower half-wave eight channels of one (tap, channel-group), the upper half-wave the next group (the next eight channels of the same
+//     tap for Cin >= 16, the next tap for Cin <= 8);
+//   * input tile in LDS as [pixel][channel] bf16 (pixel stride 144 B for 64 channels: every 16-lane group of a ds_read_b128 covers all
+//     64 banks exactly once), so a B operand is ONE 16-byte LDS read per lane;
+//   * A operands (packed [step][cout block][lane][8 bf16], 1 KiB per wave instruction) come straight from L2 into registers: at 16x the
+//     fp32 matrix rate the kernel is bound by HBM and by operand delivery, not by the matrix pipe, so LDS is spent on pixels, not weights.
+#include "mrx_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CB_NT 512
+#define CB_TH 8
+#define CB_TW 32
+
+__device__ __forceinline__ unsigned cb_pk(float lo, float hi) {   // two fp32 -> packed bf16 pair, round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+struct ConvBfArgs {
+    const float* x;        // [B,Cin,H,W]
+    const u32x4* packed;   // [NSTEP][NCT][64 lanes] x 8 bf16
+    const float* bias;     // [Cout] or null
+    const float* hh;       // [Cout] or null: IndRNN epilogue  act(acc + bias + hh * hprev)
+    const float* hprev;    // [B,Cout,H,W] or null
+    float* out;            // [B,Cout,H,W]
+    int B, Cin, Cout, H, W, tiles_x, ntiles, pad_mode, act;
+    float slope;
+};
+
+__host__ __device__ constexpr int cb_ps(int CPAD) { return CPAD == 8 ? 16 : CPAD * 2 + 16; }   // bytes per pixel in the LDS tile
+__host__ __device__ constexpr int cb_nstep(int K, int CPAD) { return (K * K * (CPAD / 8) + 1) / 2; }
+
+template <int K, int DIL, int CPAD, int NCT>
+__global__ __launch_bounds__(CB_NT, 4) void k_conv_bf16(ConvBfArgs a) {
+    constexpr int PAD = DIL * (K - 1) / 2;
+    constexpr int PH = CB_TH + 2 * PAD, PW = CB_TW + 2 * PAD, NPIX = PH * PW;
+    constexpr int NC8 = CPAD / 8, PS = cb_ps(CPAD), NG = K * K * NC8, NSTEP = cb_nstep(K, CPAD);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int tile = (int)mrx_xcd_band(blockIdx.x, a.ntiles);
+    const int ty0 = tile / a.tiles_x;
+    const int h0 = ty0 * CB_TH, w0 = (tile - ty0 * a.tiles_x) * CB_TW;
+    const int b = blockIdx.y;
+    const long long plane = (long long)a.H * a.W;
+    const float* xb = a.x + (long long)b * a.Cin * plane;
+
+    // ---- stage the halo'd tile: 8 channels of one pixel per item, fp32 -> bf16, one 16-byte LDS write ----------------------------------
+    constexpr int ITEMS = NPIX * NC8, ITERS = (ITEMS + CB_NT - 1) / CB_NT;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = tid + it * CB_NT;
+        if (i < ITEMS) {
+            const int cg = i / NPIX, e = i - cg * NPIX;
+            const int ty = e / PW, tx = e - ty * PW;
+            int gy = h0 + ty - PAD, gx = w0 + tx - PAD;
+            bool inb = true;
+            if (a.pad_mode == MRX_PAD_REPLICATE) {
+                gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+            } else {
+                inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                gy = inb ? gy : 0;
+                gx = inb ? gx : 0;
+            }
+            const float* src = xb + (long long)gy * a.W + gx;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = cg * 8 + j;
+                v[j] = (inb && c < a.Cin) ? src[(long long)c * plane] : 0.f;
+            }
+            u32x4 p = {cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
+            *reinterpret_cast<u32x4*>(smem_b + e * PS + cg * 16) = p;
+        }
+    }
+    __syncthreads();
+
+    // ---- the matrix loop: one 16-byte LDS read (B) and NCT 16-byte L2 reads (A) per MFMA step ---------------------------------------------
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    const unsigned char* bx = smem_b + (wave * PW + l31) * PS + (NC8 >= 2 ? lhi * 16 : 0);
+    const u32x4* wp = a.packed + lane;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        int off;
+        if (NC8 >= 2) {                       // both halves: the same tap, neighbouring channel groups (the +16 B is in bx)
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int G0 = 2 * s, tap = G0 / NC8, cg0 = G0 % NC8;
+            off = ((tap / K) * DIL * PW + (tap % K) * DIL) * PS + cg0 * 16;
+        } else {                              // one channel group per tap: the upper half-wave takes the next tap
+            const int t0 = 2 * s, t1 = (2 * s + 1 < NG) ? 2 * s + 1 : NG - 1;
+            const int o0 = ((t0 / K) * DIL * PW + (t0 % K) * DIL) * PS, o1 = ((t1 / K) * DIL * PW + (t1 % K) * DIL) * PS;
+            off = lhi ? o1 : o0;
+        }
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + off);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const u32x4 aw = wp[(s * NCT + ct) * 64];
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw), bv, acc[ct], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias, optional IndRNN term, activation ---------------------------------------------------------------------------------
+    const int oy = h0 + wave, ox = w0 + l31;
+    if (oy < a.H && ox < a.W) {
+        const long long obase = (long long)b * a.Cout * plane + (long long)oy * a.W + ox;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (co < a.Cout) {
+                    float v = acc[ct][r];
+                    if (a.bias) v += a.bias[co];
+                    if (a.hprev) v += a.hh[co] * a.hprev[obase + (long long)co * plane];
+                    if (a.act == MRX_ACT_RELU)
+                        v = v > 0.f ? v : 0.f;
+                    else if (a.act == MRX_ACT_LEAKY)
+                        v = v > 0.f ? v : v * a.slope;
+                    a.out[obase + (long long)co * plane] = v;
+                }
+            }
+    }
+}
+
+// packed[(s * NCT + ct) * 64 + lane][j] = bf16(w_fwd[cout = 32 ct + lane % 32][channel = 8 (G % NC8) + j][tap = G / NC8]),  G = 2 s + lane / 32;
+// transposed (data gradient): w_fwd[co][c][tap] = w[c][co][TAPS - 1 - tap] (flipped taps, in/out channels swapped)
+__global__ void k_conv_bf16_pack(const float* __restrict__ w, u32x4* __restrict__ out, int Cin, int Cout, int K, int CPAD, int NCT,
+                                 int transposed) {
+    const int NC8 = CPAD / 8, TAPS = K * K, NG = TAPS * NC8, NSTEP = (NG + 1) / 2;
+    const int total = NSTEP * NCT * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63, ct = (i >> 6) % NCT, s = (i >> 6) / NCT;
+        const int G = 2 * s + (lane >> 5), co = ct * 32 + (lane & 31);
+        const int tap = G / NC8, cg = G - tap * NC8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+            v[j] = 0.f;
+            if (G < NG && c < Cin && co < Cout)
+                v[j] = transposed ? w[((long long)c * Cout + co) * TAPS + (TAPS - 1 - tap)] : w[((long long)co * Cin + c) * TAPS + tap];
+        }
+        out[i] = (u32x4){cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
+    }
+}
+
+static int cb_cpad(int Cin) { return Cin <= 8 ? 8 : (Cin <= 64 ? 64 : -1); }
+static bool cb_shape_ok(int Cin, int Cout, int K, int DIL) {
+    if (cb_cpad(Cin) < 0 || Cout < 1 || Cout > 64) return false;
+    const int cp = cb_cpad(Cin);
+    if (K == 1 && DIL == 1) return cp == 64;
+    if (K == 3 && DIL == 1) return true;
+    if (K == 3 && DIL == 2) return cp == 64;
+    if (K == 5 && DIL == 1) return true;
+    return false;
+}
+extern "C" int mrx_conv_bf16_supported(int Cin, int Cout, int k, int dil) { return cb_shape_ok(Cin, Cout, k, dil) ? 1 : 0; }
+extern "C" int64_t mrx_conv_bf16_pack_bytes(int Cin, int Cout, int k) {
+    const int cp = cb_cpad(Cin);
+    if (cp < 0 || Cout < 1 || Cout > 64 || k < 1) return -1;
+    return (int64_t)cb_nstep(k, cp) * ((Cout + 31) / 32) * 64 * 16;
+}
+extern "C" int mrx_conv_bf16_pack(const float* w, void* packed, int Cin, int Cout, int k, int transposed, void* stream) {
+    MRX_REQUIRE(w && packed, MRX_EINVAL, "mrx_conv_bf16_pack: null pointer");
+    const int cp = cb_cpad(Cin);
+    MRX_REQUIRE(cp > 0 && Cout >= 1 && Cout <= 64 && k >= 1 && (k & 1), MRX_EUNSUP, "mrx_conv_bf16_pack: Cin=%d Cout=%d k=%d", Cin, Cout, k);
+    const int nct = (Cout + 31) / 32, total = cb_nstep(k, cp) * nct * 64;
+    hipLaunchKernelGGL(k_conv_bf16_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)packed, Cin, Cout, k, cp,
+                       nct, transposed);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+template <int K, int DIL, int CPAD, int NCT>
+static int cb_launch(const ConvBfArgs& a, hipStream_t st) {
+    constexpr int PAD = DIL * (K - 1) / 2;
+    constexpr size_t lds = (size_t)(CB_TH + 2 * PAD) * (CB_TW + 2 * PAD) * cb_ps(CPAD);
+    static bool attr_done = false;
+    if (lds > 48 * 1024 && !attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_bf16<K, DIL, CPAD, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_conv_bf16<K, DIL, CPAD, NCT>), dim3(a.ntiles, a.B), dim3(CB_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+template <int K, int DIL, int CPAD>
+static int cb_launch_nct(const ConvBfArgs& a, hipStream_t st) {
+    return a.Cout <= 32 ? cb_launch<K, DIL, CPAD, 1>(a, st) : cb_launch<K, DIL, CPAD, 2>(a, st);
+}
+
+// act(conv(x; w) + bias [+ hh * hprev]) with bf16 operands; 'same' size, stride 1; packed from mrx_conv_bf16_pack
+extern "C" int mrx_conv2d_bf16(const float* x, const void* packed, const float* bias, const float* hh, const float* hprev, float* out, int B,
+                               int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, void* stream) {
+    MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv2d_bf16: null pointer");
+    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv2d_bf16: bad dims");
+    MRX_REQUIRE(cb_shape_ok(Cin, Cout, k, dil), MRX_EUNSUP, "mrx_conv2d_bf16: Cin=%d Cout=%d k=%d dilation=%d not instantiated", Cin, Cout, k, dil);
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv2d_bf16: bad pad mode %d", pad_mode);
+    MRX_REQUIRE(!hprev || hh, MRX_EINVAL, "mrx_conv2d_bf16: hprev without hh");
+    MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "mrx_conv2d_bf16: batch %d too large", B);
+    if (B == 0) return MRX_OK;
+    ConvBfArgs a;
+    a.x = x, a.packed = (const u32x4*)packed, a.bias = bias, a.hh = hh, a.hprev = hprev, a.out = out;
+    a.B = B, a.Cin = Cin, a.Cout = Cout, a.H = H, a.W = W;
+    a.tiles_x = mrx_cdiv(W, CB_TW);
+    a.ntiles = a.tiles_x * mrx_cdiv(H, CB_TH);
+    a.pad_mode = pad_mode, a.act = act, a.slope = slope;
+    hipStream_t st = (hipStream_t)stream;
+    const int cp = cb_cpad(Cin);
+    if (k == 1) return cb_launch_nct<1, 1, 64>(a, st);
+    if (k == 3 && dil == 2) return cb_launch_nct<3, 2, 64>(a, st);
+    if (k == 3 && cp == 64) return cb_launch_nct<3, 1, 64>(a, st);
+    if (k == 3) return cb_launch_nct<3, 1, 8>(a, st);
+    if (cp == 64) return cb_launch_nct<5, 1, 64>(a, st);
+    return cb_launch_nct<5, 1, 8>(a, st);
+}
+
+// ---- weight gradient, 64 -> 64 channels, bf16 operands ------------------------------------------------------------------------------
+// dW[co][ci][tap] = sum over (b, pixel) dy[b,co,pixel] * xpad[b,ci,pixel + tap * dil]   as the GEMM  D[co][ci] += A[co][pixel] B[pixel][ci]
+// per tap, contraction over pixels: one MFMA takes 16 consecutive pixels of a tile row (lower half-wave 8, upper half-wave the next 8).
+//   * persistent workgroups (one per CU) walk the 8 x 32 pixel tiles; per tile the dy tile [64][8][32] and the halo'd x tile
+//     [64][8 + 2 pad][32 + 2 pad] are rounded to bf16 on their way into LDS, pixel-fastest -- the natural NCHW order;
+//   * 3x3: nine waves, wave t owns tap t and keeps its whole [64 x 64] block (4 accumulators) in registers over all tiles; the tap shift is
+//     a constant offset of the B read.  Even dilations keep the shifted 16-byte reads 4-byte aligned (dword LDS reads); the rows of
+//     both tiles are padded so that the 32 channel-lanes of a read fall on distinct banks;
+//   * 1x1: eight waves split the rows of the tile and add their blocks in LDS (fixed order) at the end;
+//   * every workgroup leaves one partial [64][64][taps]; a second launch adds the partials in a fixed order in double, so the gradient
+//     does not depend on scheduling (the same second stage as the fp32 kernel in conv_bwd.hip).
+#define WB_TH 8
+#define WB_TW 32
+#define WB_DYS 528   // bytes per dy channel in LDS: 8 x 32 px x 2 B + 16 (132 dwords = 4 mod 64)
+
+struct WgradBfArgs {
+    const float* x;    // [B,64,H,W]
+    const float* dy;   // [B,64,H,W]
+    float* part;       // [gridDim.x][64][64][taps]
+    int B, H, W, tiles_x, tiles_y, ntiles, pad_mode;
+};
+
+__host__ __device__ constexpr int wb_xs(int K, int DIL) {   // bytes per x channel in LDS, = 16 mod 256 (4 mod 64 dwords)
+    const int pad = DIL * (K - 1) / 2, raw = (WB_TH + 2 * pad) * (WB_TW + 2 * pad) * 2;
+    return ((raw + 255 - 16) / 256) * 256 + 16;
+}
+
+template <int K, int DIL>
+__global__ __launch_bounds__(K == 1 ? 512 : 576, 1) void k_conv_wgrad_bf16(WgradBfArgs a) {
+    constexpr int PAD = DIL * (K - 1) / 2, PH = WB_TH + 2 * PAD, PW = WB_TW + 2 * PAD, TAPS = K * K;
+    constexpr int NT = K == 1 ? 512 : 576, XS = wb_xs(K, DIL);
+    static_assert((DIL & 1) == 0 || K == 1, "shifted reads must stay 4-byte aligned");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* Dy = smem_b;                 // [64][WB_DYS]
+    unsigned char* Xs = smem_b + 64 * WB_DYS;   // [64][XS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const long long plane = (long long)a.H * a.W;
+    const int tap = K == 1 ? 0 : wave, ky = tap / K, kx = tap % K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int total_tiles = a.ntiles * a.B;
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const int b = t / a.ntiles, tt = t - b * a.ntiles;
+        const int ty0 = tt / a.tiles_x, h0 = ty0 * WB_TH, w0 = (tt - ty0 * a.tiles_x) * WB_TW;
+        const float* dyb = a.dy + (long long)b * 64 * plane;
+        const float* xb = a.x + (long long)b * 64 * plane;
+        __syncthreads();   // the previous tile's readers are done
+        // dy tile: item = (co, row, 8-pixel group); pixels outside the image contribute zero
+        for (int i = tid; i < 64 * WB_TH * 4; i += NT) {
+            const int pg = i & 3, r = (i >> 2) & 7, co = i >> 5;
+            const int gy = h0 + r, gx = w0 + pg * 8;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (gy < a.H && gx + j < a.W) ? dyb[(long long)co * plane + (long long)gy * a.W + gx + j] : 0.f;
+            *reinterpret_cast<u32x4*>(Dy + co * WB_DYS + (r * WB_TW + pg * 8) * 2) =
+                (u32x4){cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
+        }
+        // x tile with halo: item = (ci, row, 4-pixel group)
+        constexpr int XG = PW / 4;
+        for (int i = tid; i < 64 * PH * XG; i += NT) {
+            const int g4 = i % XG, r = (i / XG) % PH, ci = i / (XG * PH);
+            const int gy0 = h0 + r - PAD, gx0 = w0 + g4 * 4 - PAD;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int gy = gy0, gx = gx0 + j;
+                bool inb = true;
+                if (a.pad_mode == MRX_PAD_REPLICATE) {
+                    gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                    gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                } else {
+                    inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    gy = inb ? gy : 0, gx = inb ? gx : 0;
+                }
+                v[j] = inb ? xb[(long long)ci * plane + (long long)gy * a.W + gx] : 0.f;
+            }
+            *reinterpret_cast<uint2*>(Xs + ci * XS + (r * PW + g4 * 4) * 2) = make_uint2(cb_pk(v[0], v[1]), cb_pk(v[2], v[3]));
+        }
+        __syncthreads();
+        const unsigned char* ap = Dy + l31 * WB_DYS + lhi * 16;
+        const unsigned char* bp = Xs + l31 * XS + ((ky * DIL) * PW + kx * DIL + lhi * 8) * 2;
+#pragma unroll
+        for (int r = 0; r < WB_TH; ++r) {
+            if (K == 1 && r != wave) continue;   // 1x1: the eight waves split the rows
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + (r * WB_TW + kk * 16) * 2);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * WB_DYS + (r * WB_TW + kk * 16) * 2);
+                const unsigned* q0 = reinterpret_cast<const unsigned*>(bp + (r * PW + kk * 16) * 2);
+                const unsigned* q1 = reinterpret_cast<const unsigned*>(bp + 32 * XS + (r * PW + kk * 16) * 2);
+                const u32x4 b0 = {q0[0], q0[1], q0[2], q0[3]}, b1 = {q1[0], q1[1], q1[2], q1[3]};
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, b0), acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, b1), acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, b0), acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, b1), acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    float* po = a.part + (long long)blockIdx.x * 64 * 64 * TAPS;
+    if (K == 1) {
+        // add the eight waves' blocks in LDS, halving the number of live blocks each round (fixed order), wave 0 stores
+        __syncthreads();
+        float* R = reinterpret_cast<float*>(smem_b);   // [4 waves][4096]
+        for (int half = 4; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) R[(wave - half) * 4096 + ((i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+            }
+            __syncthreads();
+            if (wave < half) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += R[wave * 4096 + ((i * 2 + j) * 16 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wave != 0) return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi, ci = 32 * j + l31;
+                po[((long long)co * 64 + ci) * TAPS + tap] = acc[i][j][r];
+            }
+}
+
+// dW[i] (= or +=) sum of the workgroup partials in a fixed order, in double (the second stage of conv_bwd.hip's weight gradient)
+__global__ __launch_bounds__(256) void k_wgrad_bf16_reduce(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw,
+                                                           int accumulate) {
+    __shared__ double sh[16][17];
+    const int li = threadIdx.x & 15, lp = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + li;
+    double s = 0.0;
+    if (i < n)
+        for (int p = lp; p < nparts; p += 16) s += (double)part[(long long)p * n + i];
+    sh[lp][li] = s;
+    __syncthreads();
+    if (lp == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][li];
+        dw[i] = accumulate ? dw[i] + (float)t : (float)t;
+    }
+}
+
+static int wb_nwg(int B, int H, int W) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n_cu = prop.multiProcessorCount;
+        else
+            n_cu = 256;
+    }
+    const long long tiles = (long long)mrx_cdiv(W, WB_TW) * mrx_cdiv(H, WB_TH) * B;
+    return (int)(tiles < n_cu ? tiles : n_cu);
+}
+extern "C" int mrx_conv_wgrad_bf16_supported(int Cin, int Cout, int k, int dil) {
+    return Cin == 64 && Cout == 64 && ((k == 1 && dil == 1) || (k == 3 && dil == 2));
+}
+extern "C" int64_t mrx_conv_wgrad_bf16_work_floats(int B, int H, int W, int k) {
+    if (B < 1 || H < 1 || W < 1 || (k != 1 && k != 3)) return -1;
+    return (int64_t)wb_nwg(B, H, W) * 64 * 64 * k * k;
+}
+template <int K, int DIL>
+static int wb_launch(const WgradBfArgs& a, int nwg, hipStream_t st) {
+    constexpr size_t lds = (size_t)64 * WB_DYS + (size_t)64 * wb_xs(K, DIL);
+    static_assert(lds >= 4 * 4096 * sizeof(float) || K != 1, "1x1: LDS also holds the wave reduction");
+    static bool attr_done = false;
+    if (lds > 48 * 1024 && !attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<K, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_conv_wgrad_bf16<K, DIL>), dim3(nwg), dim3(K == 1 ? 512 : 576), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_conv_wgrad_bf16(const float* x, const float* dy, float* dw, float* work, int B, int H, int W, int k, int dil, int pad_mode,
+                                   int accumulate, void* stream) {
+    MRX_REQUIRE(x && dy && dw && work, MRX_EINVAL, "mrx_conv_wgrad_bf16: null pointer");
+    MRX_REQUIRE(B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_wgrad_bf16: bad dims");
+    MRX_REQUIRE(mrx_conv_wgrad_bf16_supported(64, 64, k, dil), MRX_EUNSUP, "mrx_conv_wgrad_bf16: k=%d dilation=%d not instantiated", k, dil);
+    WgradBfArgs a;
+    a.x = x, a.dy = dy, a.part = work, a.B = B, a.H = H, a.W = W;
+    a.tiles_x = mrx_cdiv(W, WB_TW), a.tiles_y = mrx_cdiv(H, WB_TH), a.ntiles = a.tiles_x * a.tiles_y, a.pad_mode = pad_mode;
+    const int nwg = wb_nwg(B, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = k == 1 ? wb_launch<1, 1>(a, nwg, st) : wb_launch<3, 2>(a, nwg, st);
+    if (rc) return rc;
+    const long long total = 64ll * 64 * k * k;
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

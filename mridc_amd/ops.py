@@ -501,6 +501,74 @@ def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0
     return out
 
 
+_PACKS_BF16 = {}
+
+
+def conv_bf16_supported(Cin, Cout, k, dilation):
+    return bool(_lib.lib().mrx_conv_bf16_supported(int(Cin), int(Cout), int(k), int(dilation)))
+
+
+def _conv_bf16_pack(weight, transposed):
+    """bf16 MFMA operand pack of a [Cout,Cin,k,k] weight (or of its flipped, channel-transposed form: the data gradient's weights),
+    cached per (storage, version) like the other packs (the entry keeps the source tensor alive)."""
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()), bool(transposed))
+    hit = _PACKS_BF16.get(key)
+    if hit is None:
+        if len(_PACKS_BF16) >= 256:
+            _PACKS_BF16.pop(next(iter(_PACKS_BF16)))
+        w = _lib.f32c(weight.detach())
+        d0, d1, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+        cin, cout = (d0, d1) if transposed else (d1, d0)          # of the convolution the pack is for
+        L = _lib.lib()
+        packed = torch.empty(int(L.mrx_conv_bf16_pack_bytes(cin, cout, k)), dtype=torch.uint8, device=w.device)
+        _lib.check(L.mrx_conv_bf16_pack(_lib.ptr(w), _lib.ptr(packed), cin, cout, k, int(bool(transposed)), _lib.stream_ptr()),
+                   "mrx_conv_bf16_pack")
+        hit = _PACKS_BF16[key] = (packed, weight)
+    return hit[0]
+
+
+def conv2d_bf16(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, hh=None, h_prev=None, transposed=False):
+    """'same' convolution with bf16 operands and fp32 accumulation (mrx_conv2d_bf16) on fp32 tensors: act(conv(x) + bias [+ hh * h_prev]).
+    `transposed`: x is an output gradient and `weight` the forward weight [Cout,Cin,k,k] -- the zero-padded data-gradient convolution."""
+    x = _lib.f32c(x)
+    B, Cx, H, W = _nchw(x)
+    d0, d1, kh, kw = [int(v) for v in weight.shape]
+    cin, cout = (d0, d1) if transposed else (d1, d0)
+    if cin != Cx:
+        raise RuntimeError(f"input has inconsistent input_size: got {Cx}, expected {cin}")
+    if kh != kw or not conv_bf16_supported(cin, cout, kh, dilation):
+        raise NotImplementedError(f"conv2d_bf16: Cin={cin} Cout={cout} k={kh}x{kw} dilation={dilation}")
+    packed = _conv_bf16_pack(weight, transposed)
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1)) if hh is not None and h_prev is not None else None
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    out = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_conv2d_bf16(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), B, cin, cout,
+                                          H, W, kh, int(dilation), int(pad_mode), int(act), float(slope), _lib.stream_ptr()),
+               "mrx_conv2d_bf16")
+    return out
+
+
+def conv_wgrad_bf16_supported(Cin, Cout, k, dilation):
+    return bool(_lib.lib().mrx_conv_wgrad_bf16_supported(int(Cin), int(Cout), int(k), int(dilation)))
+
+
+def conv_wgrad_bf16(x, dy, k, dilation=1, pad_mode=PAD_REPLICATE, out=None, accumulate=False):
+    """Weight gradient of a 64 -> 64 'same' convolution with bf16 operands (mrx_conv_wgrad_bf16): dw [64,64,k,k]."""
+    x, dy = _lib.f32c(x), _lib.f32c(dy)
+    B, Cin, H, W = _nchw(x)
+    if tuple(dy.shape) != (B, 64, H, W) or Cin != 64:
+        raise ValueError(f"conv_wgrad_bf16: x {tuple(x.shape)}, dy {tuple(dy.shape)}")
+    if out is None:
+        out = torch.empty(64, 64, k, k, dtype=torch.float32, device=x.device)
+        accumulate = False
+    L = _lib.lib()
+    work = torch.empty(int(L.mrx_conv_wgrad_bf16_work_floats(B, H, W, int(k))), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_conv_wgrad_bf16(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(out), _lib.ptr(work), B, H, W, int(k), int(dilation), int(pad_mode),
+                                     int(bool(accumulate)), _lib.stream_ptr()), "mrx_conv_wgrad_bf16")
+    return out
+
+
 def conv_to_complex(x, weight, bias, dilation=1, pad_mode=PAD_ZERO):
     """permute(conv(x), (0, 2, 3, 1)) for a convolution into 2 channels -> [B,H,W,2] (one complex image).  The tuned kernel covers
     3x3, dilation 1, W % 4 == 0, Cin % 4 == 0; other shapes run conv2d and permute."""

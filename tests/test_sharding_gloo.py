@@ -105,8 +105,20 @@ def test_two_rank_flat_gradient_allreduce():
     assert v0 == [3.0 * (i + 1) for i in range(4)]               # (1 + 2) * (i + 1): the sum over the two ranks, seen through the views
     from mridc_amd import training
     assert training.allreduce_gradients(torch.zeros(3)) == 1     # no process group: a no-op
-    lrs = [training.inverse_sqrt_lr(s, 100, 1e-3) for s in range(100)]
-    assert lrs[0] < lrs[5] < lrs[9] and lrs[10] >= lrs[50] >= lrs[99] > 0
+
+
+def test_inverse_sqrt_lr_matches_the_reference_scheduler():
+    """InverseSquareRootAnnealing under WarmupPolicy (core/optim/lr_scheduler.py:68-88,664-671): values worked out from those lines for
+    max_steps 100, warmup_ratio 0.1 (10 warm-up steps), base lr 1e-3, min_lr 1e-5."""
+    import math
+    from mridc_amd import training
+    f = lambda s: training.inverse_sqrt_lr(s, 100, 1e-3, 0.1, 1e-5)  # noqa: E731
+    assert math.isclose(f(0), 1e-3 * 1 / 11) and math.isclose(f(4), 1e-3 * 5 / 11) and math.isclose(f(10), 1e-3)     # linear warm-up, step <= 10
+    assert math.isclose(f(11), 1e-3 / math.sqrt(12 / 11)) and math.isclose(f(43), 5e-4) and math.isclose(f(100), 1e-3 / math.sqrt(101 / 11))
+    assert f(101) == 1e-5 and f(5000) == 1e-5                                                # past max_steps: min_lr
+    assert math.isclose(training.inverse_sqrt_lr(3, 100, 1e-3, warmup_steps=0), 1e-3 / 2.0)  # no warm-up: base / sqrt(step + 1)
+    lrs = [f(s) for s in range(100)]
+    assert all(a < b for a, b in zip(lrs[:10], lrs[1:11])) and all(a > b for a, b in zip(lrs[10:99], lrs[11:100]))
 
 
 # ---- bench.py --gpus N: the bare command spawns its own ranks (one process per GPU, the reference's `strategy: ddp`) ---------------------
