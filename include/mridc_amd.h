@@ -311,6 +311,17 @@ int mrx_reppad_fold(const float* g, float* out, int64_t planes, int H, int W, in
 int64_t mrx_relu_bwd_work_floats(int C);
 int mrx_relu_bwd(const float* dy, const float* y, const float* h_prev, const float* hh, float* dpre, float* dh_prev,
                  float* sums, float* work, int B, int C, int64_t HW, void* stream);
+/* The explicit training tape (mridc_amd/training.py; the reference gets these steps from torch autograd over rim_block.py:217-249):
+ *   mrx_relu_bwd_acc   mrx_relu_bwd with the upstream gradient given as two addends (dy + dy2, dy2 may be null) and the per-channel sums ADDED
+ *                      into the gradient buffers: acc_bias[c] += sum dpre, acc_hh[c] += sum dpre * h_prev (either may be null)
+ *   mrx_eta_grad_in    tot [B,H,W,2] = carry (or 0) + gl;  d2 [B,2,H,W] = tot channel-first (the gradient entering the final convolution)
+ *   mrx_g4_to_complex  dz [B,H,W,2] = channels 2, 3 of g4 [B,4,H,W]
+ *   mrx_eta_grad_out   out [B,H,W,2] = tot + channels 0, 1 of g4 + channels 2, 3 of t4 (identity path, eta channels, adjoint log-likelihood gradient) */
+int mrx_relu_bwd_acc(const float* dy, const float* dy2, const float* y, const float* h_prev, const float* hh, float* dpre, float* dh_prev,
+                     float* acc_bias, float* acc_hh, float* work, int B, int C, int64_t HW, void* stream);
+int mrx_eta_grad_in(const float* carry, const float* gl, float* tot, float* d2, int B, int64_t plane, void* stream);
+int mrx_g4_to_complex(const float* g4, float* dz, int B, int64_t plane, void* stream);
+int mrx_eta_grad_out(const float* tot, const float* g4, const float* t4, float* out, int B, int64_t plane, void* stream);
 
 /* Mixed precision for the training path (BASELINE config 4; the reference trains under AMP, base_cirim_train.yaml:180): convolutions with
  * bf16 operands and fp32 accumulation (v_mfma_f32_32x32x16_bf16) on the same fp32 NCHW tensors -- the tile loader rounds activations to

@@ -426,9 +426,9 @@ extern "C" int mrx_reppad_fold(const float* g, float* out, int64_t planes, int H
 // One workgroup per (channel, slab); partials work[(c*RB_SLABS + slab)*2 + {0,1}], combined in order in double.
 #define RB_NT 256
 #define RB_SLABS 32
-__global__ __launch_bounds__(RB_NT) void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ hprev,
-                                                    const float* __restrict__ hh, float* __restrict__ dpre, float* __restrict__ dhprev,
-                                                    float* __restrict__ work, int B, int C, long long HW) {
+__global__ __launch_bounds__(RB_NT) void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ dy2, const float* __restrict__ y,
+                                                    const float* __restrict__ hprev, const float* __restrict__ hh, float* __restrict__ dpre,
+                                                    float* __restrict__ dhprev, float* __restrict__ work, int B, int C, long long HW) {
     const int c = blockIdx.x, slab = blockIdx.y;
     const long long per = (HW + RB_SLABS - 1) / RB_SLABS, p0 = slab * per, p1 = p0 + per < HW ? p0 + per : HW;
     const float hw = hh ? hh[c] : 0.f;
@@ -436,7 +436,8 @@ __global__ __launch_bounds__(RB_NT) void k_relu_bwd(const float* __restrict__ dy
     for (int b = 0; b < B; ++b) {
         const long long base = ((long long)b * C + c) * HW;
         for (long long p = p0 + threadIdx.x; p < p1; p += RB_NT) {
-            const float d = y[base + p] > 0.f ? dy[base + p] : 0.f;
+            const float up = dy2 ? dy[base + p] + dy2[base + p] : dy[base + p];   // two gradient paths into y (next layer, next time-step)
+            const float d = y[base + p] > 0.f ? up : 0.f;
             dpre[base + p] = d;
             s0 += d;
             if (hprev) {
@@ -461,7 +462,8 @@ __global__ __launch_bounds__(RB_NT) void k_relu_bwd(const float* __restrict__ dy
         work[((long long)c * RB_SLABS + slab) * 2 + 1] = sh1[0];
     }
 }
-__global__ void k_relu_bwd_final(const float* __restrict__ work, float* __restrict__ sums, int C) {
+__global__ void k_relu_bwd_final(const float* __restrict__ work, float* __restrict__ sums, float* __restrict__ acc0, float* __restrict__ acc1,
+                                 int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double a = 0.0, b = 0.0;
@@ -469,17 +471,99 @@ __global__ void k_relu_bwd_final(const float* __restrict__ work, float* __restri
         a += (double)work[((long long)c * RB_SLABS + s) * 2];
         b += (double)work[((long long)c * RB_SLABS + s) * 2 + 1];
     }
-    sums[2 * c] = (float)a;
-    sums[2 * c + 1] = (float)b;
+    if (sums) {
+        sums[2 * c] = (float)a;
+        sums[2 * c + 1] = (float)b;
+    }
+    if (acc0) acc0[c] += (float)a;     // bias gradient accumulated in place (one writer per element: deterministic)
+    if (acc1) acc1[c] += (float)b;     // hh gradient
 }
 extern "C" int64_t mrx_relu_bwd_work_floats(int C) { return (int64_t)2 * RB_SLABS * (C > 0 ? C : 1); }
 extern "C" int mrx_relu_bwd(const float* dy, const float* y, const float* h_prev, const float* hh, float* dpre, float* dh_prev,
                             float* sums, float* work, int B, int C, int64_t HW, void* stream) {
     MRX_REQUIRE(dy && y && dpre && sums && work && B >= 1 && C >= 1 && C <= 65535 && HW >= 1, MRX_EINVAL, "mrx_relu_bwd: bad argument");
     MRX_REQUIRE(!h_prev || (hh && dh_prev), MRX_EINVAL, "mrx_relu_bwd: h_prev needs hh and dh_prev");
-    hipLaunchKernelGGL(k_relu_bwd, dim3(C, RB_SLABS), dim3(RB_NT), 0, (hipStream_t)stream, dy, y, h_prev, hh, dpre, dh_prev, work, B, C,
+    hipLaunchKernelGGL(k_relu_bwd, dim3(C, RB_SLABS), dim3(RB_NT), 0, (hipStream_t)stream, dy, (const float*)nullptr, y, h_prev, hh, dpre,
+                       dh_prev, work, B, C, (long long)HW);
+    hipLaunchKernelGGL(k_relu_bwd_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)work, sums, (float*)nullptr,
+                       (float*)nullptr, C);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// The same step for the explicit training tape (mridc_amd/training.py): the upstream gradient may arrive as two addends (dy + dy2: the
+// paths through the next layer and through the next time-step), and the per-channel sums are ADDED into the bias / hh gradient buffers
+// (acc_bias[c] += sum dpre, acc_hh[c] += sum dpre * h_prev; either may be null) -- no separate accumulation launches.
+extern "C" int mrx_relu_bwd_acc(const float* dy, const float* dy2, const float* y, const float* h_prev, const float* hh, float* dpre,
+                                float* dh_prev, float* acc_bias, float* acc_hh, float* work, int B, int C, int64_t HW, void* stream) {
+    MRX_REQUIRE(dy && y && dpre && work && B >= 1 && C >= 1 && C <= 65535 && HW >= 1, MRX_EINVAL, "mrx_relu_bwd_acc: bad argument");
+    MRX_REQUIRE(!h_prev || (hh && dh_prev), MRX_EINVAL, "mrx_relu_bwd_acc: h_prev needs hh and dh_prev");
+    MRX_REQUIRE(!acc_hh || h_prev, MRX_EINVAL, "mrx_relu_bwd_acc: acc_hh without h_prev");
+    hipLaunchKernelGGL(k_relu_bwd, dim3(C, RB_SLABS), dim3(RB_NT), 0, (hipStream_t)stream, dy, dy2, y, h_prev, hh, dpre, dh_prev, work, B, C,
                        (long long)HW);
-    hipLaunchKernelGGL(k_relu_bwd_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)work, sums, C);
+    hipLaunchKernelGGL(k_relu_bwd_final, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)work, (float*)nullptr, acc_bias,
+                       acc_hh, C);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- eta-side glue of the explicit tape (rim_block.py:239-248 and rim_utils.py:67 backwards) --------------------------------------------
+// mrx_eta_grad_in:   tot = carry (or 0) + gl;  d2[b, c, h, w] = tot[b, h, w, c]   (gradient entering the final conv, NCHW with 2 channels)
+// mrx_g4_to_complex: dz[b, h, w, :] = (g4[b, 2], g4[b, 3])                        (the gradient w.r.t. the log-likelihood-gradient channels)
+// mrx_eta_grad_out:  out[b, h, w, :] = tot + (g4[b, 0], g4[b, 1]) + (t4[b, 2], t4[b, 3])   (identity path + eta channels + adjoint gradient)
+__global__ void k_eta_grad_in(const float2* __restrict__ carry, const float2* __restrict__ gl, float2* __restrict__ tot, float* __restrict__ d2,
+                              long long B, long long plane) {
+    const long long total = B * plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float2 v = gl[i];
+        if (carry) {
+            const float2 c = carry[i];
+            v.x += c.x, v.y += c.y;
+        }
+        tot[i] = v;
+        const long long b = i / plane, p = i - b * plane;
+        d2[(b * 2) * plane + p] = v.x;
+        d2[(b * 2 + 1) * plane + p] = v.y;
+    }
+}
+__global__ void k_g4_to_complex(const float* __restrict__ g4, float2* __restrict__ dz, long long B, long long plane) {
+    const long long total = B * plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / plane, p = i - b * plane;
+        dz[i] = make_float2(g4[(b * 4 + 2) * plane + p], g4[(b * 4 + 3) * plane + p]);
+    }
+}
+__global__ void k_eta_grad_out(const float2* __restrict__ tot, const float* __restrict__ g4, const float* __restrict__ t4, float2* __restrict__ out,
+                               long long B, long long plane) {
+    const long long total = B * plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / plane, p = i - b * plane;
+        const float2 v = tot[i];
+        out[i] = make_float2(v.x + g4[(b * 4) * plane + p] + t4[(b * 4 + 2) * plane + p],
+                             v.y + g4[(b * 4 + 1) * plane + p] + t4[(b * 4 + 3) * plane + p]);
+    }
+}
+static inline unsigned tape_grid(long long n) {
+    long long g = (n + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+extern "C" int mrx_eta_grad_in(const float* carry, const float* gl, float* tot, float* d2, int B, int64_t plane, void* stream) {
+    MRX_REQUIRE(gl && tot && d2 && B >= 1 && plane >= 1, MRX_EINVAL, "mrx_eta_grad_in: bad argument");
+    hipLaunchKernelGGL(k_eta_grad_in, dim3(tape_grid((long long)B * plane)), dim3(256), 0, (hipStream_t)stream, (const float2*)carry,
+                       (const float2*)gl, (float2*)tot, d2, (long long)B, (long long)plane);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_g4_to_complex(const float* g4, float* dz, int B, int64_t plane, void* stream) {
+    MRX_REQUIRE(g4 && dz && B >= 1 && plane >= 1, MRX_EINVAL, "mrx_g4_to_complex: bad argument");
+    hipLaunchKernelGGL(k_g4_to_complex, dim3(tape_grid((long long)B * plane)), dim3(256), 0, (hipStream_t)stream, g4, (float2*)dz, (long long)B,
+                       (long long)plane);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_eta_grad_out(const float* tot, const float* g4, const float* t4, float* out, int B, int64_t plane, void* stream) {
+    MRX_REQUIRE(tot && g4 && t4 && out && B >= 1 && plane >= 1, MRX_EINVAL, "mrx_eta_grad_out: bad argument");
+    hipLaunchKernelGGL(k_eta_grad_out, dim3(tape_grid((long long)B * plane)), dim3(256), 0, (hipStream_t)stream, (const float2*)tot, g4, t4,
+                       (float2*)out, (long long)B, (long long)plane);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

@@ -8,7 +8,7 @@ import math
 
 import torch
 
-from mridc_amd import _lib
+from mridc_amd import _lib, ops
 from mridc_amd import autograd as ag
 
 
@@ -33,7 +33,8 @@ class FlatParameters:
     the gradient exchange is a single collective and the optimizer a single launch."""
 
     def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        named = [(n_, p) for n_, p in module.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
@@ -46,6 +47,22 @@ class FlatParameters:
             p.grad = self.grad[o:o + k].view_as(p.data)
             o += k
         self.numel = n
+        # contiguous [start, stop) of every cascade's parameters (`cirim.{i}.*` are registered cascade by cascade) and of the others
+        self.cascade_slices, self.rest_slices = [], []
+        o, ok = 0, True
+        for name, p in named:
+            parts = name.split(".")
+            idx = int(parts[1]) if len(parts) > 2 and parts[0] == "cirim" and parts[1].isdigit() else None
+            if idx is None:
+                self.rest_slices.append((o, o + p.numel()))
+            elif idx == len(self.cascade_slices) - 1:
+                self.cascade_slices[-1][1] = o + p.numel()
+            elif idx == len(self.cascade_slices):
+                self.cascade_slices.append([o, o + p.numel()])
+            else:
+                ok = False
+            o += p.numel()
+        self.cascade_slices = [tuple(v) for v in self.cascade_slices] if ok else []
 
     def zero_grad(self):
         self.grad.zero_()
@@ -96,7 +113,194 @@ def inverse_sqrt_lr(step, max_steps, base_lr, warmup_ratio=0.1, min_lr=0.0, warm
     return base_lr / math.sqrt((step + 1) / (warmup_steps + 1))
 
 
-def training_step(model, flat, optimizer, batch, time_steps=None, schedule=None):
+# ---- the explicit tape ------------------------------------------------------------------------------------------------------------------
+# The CIRIM recurrence is a fixed sequence (rim_block.py:217-249), so its backward pass is written out instead of recorded: forward saves the
+# activations of one cascade, the backward walks the time-steps in reverse calling the kernels directly.  What that buys over the autograd
+# tape (mridc_amd/autograd.py, kept for masks / layers this path does not cover):
+#   * no torch kernel anywhere in the step: gradient accumulation happens INSIDE the kernels (weight gradients with accumulate = 1 into the
+#     flat gradient buffer, bias / hh sums added by mrx_relu_bwd_acc), the two gradient paths into a hidden state are the two addends of
+#     mrx_relu_bwd_acc, permutes and channel splits ride in three small glue kernels;
+#   * cascades are detached from each other (cirim.py:146-165 hands `pred[-1].detach()` on), so each cascade's backward runs right after
+#     its forward: activations of ONE cascade are alive at a time (~2 GB instead of ~16 GB at 640 x 372), and its slice of the flat
+#     gradient is final at that point -- the all-reduce of cascade c overlaps the forward/backward of cascade c + 1.
+def _tape_supported(model, batch):
+    from mridc_amd.collections.reconstruction.models.rim import rnn_cells
+    if not (model.no_dc and model.coil_dim == 1 and ops.mask_is_row_invariant(batch["mask"])):
+        return False
+    tgt = batch["target"]
+    if tuple(tgt.shape[-2:]) != tuple(batch["y"].shape[2:4]):
+        return False                                   # a cropped target needs the crop's adjoint: left to the autograd path
+    for blk in model.cirim:
+        if len(blk.layers) < 1 or blk.final_layer[0] is None:
+            return False
+        for st in blk.layers:
+            c, r = st.convs, st.rnn
+            if not (isinstance(r, rnn_cells.IndRNNCell) and r.kernel_size == 1 and c is not None and c.act == ops.ACT_RELU):
+                return False
+    return True
+
+
+def _grad_of(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _relu_bwd_acc(dy, dy2, y, h_prev, hh, acc_bias, acc_hh):
+    B, C, H, W = [int(v) for v in y.shape]
+    L = _lib.lib()
+    dpre = torch.empty_like(y)
+    dhp = torch.empty_like(y) if h_prev is not None else None
+    work = torch.empty(int(L.mrx_relu_bwd_work_floats(C)), dtype=torch.float32, device=y.device)
+    hhc = None if h_prev is None else hh.detach().reshape(-1)
+    _lib.check(L.mrx_relu_bwd_acc(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(h_prev), _lib.ptr(hhc), _lib.ptr(dpre), _lib.ptr(dhp),
+                                  _lib.ptr(acc_bias), _lib.ptr(acc_hh if h_prev is not None else None), _lib.ptr(work), B, C, H * W,
+                                  _lib.stream_ptr()), "mrx_relu_bwd_acc")
+    return dpre, dhp
+
+
+def _wgrad_into(x, dy, k, dilation, pad_mode, grad, bf16):
+    if bf16 and ops.conv_wgrad_bf16_supported(int(x.shape[1]), int(dy.shape[1]), k, dilation):
+        ops.conv_wgrad_bf16(x, dy, k, dilation, pad_mode, out=grad, accumulate=True)
+    else:
+        ops.conv_wgrad(x, dy, k, dilation, pad_mode, out=grad, accumulate=True)
+
+
+class _Llg:
+    """log_likelihood_gradient and its adjoint for one slice (row-invariant mask): the W = 372 prime-factor kernel when it applies."""
+
+    def __init__(self, blk, y, sense, mask, hybrid):
+        self.cfg = (blk.fft_centered, blk.fft_normalization)
+        self.sense, self.mask = sense, mask
+        if isinstance(hybrid, tuple):
+            self.yt, self.op = hybrid
+        else:
+            self.yt, self.op = hybrid, None
+        self.zero_op, self.zero_yt = None, None
+
+    def forward(self, eta, sigma):
+        if self.op is not None:
+            return ops.llg372(eta, self.op, sigma, self.cfg[1])
+        return ops.llg_hinv(eta, self.yt, self.sense, self.mask, sigma, self.cfg[0], self.cfg[1])
+
+    def adjoint(self, dz, sigma):
+        """The linear part applied to dz (the map eta -> gradient is affine and self-adjoint: the same kernel with yt = 0)."""
+        if self.op is not None:
+            if self.zero_op is None:
+                o = self.op
+                self.zero_op = ops.Llg372Operands(torch.zeros_like(o.ytp), o.sp, o.maskp, o.mask_batched, o.B, o.C, o.H, o.centered, o.work)
+            return ops.llg372(dz, self.zero_op, sigma, self.cfg[1])
+        if self.zero_yt is None:
+            self.zero_yt = torch.zeros_like(self.yt)
+        return ops.llg_hinv(dz, self.zero_yt, self.sense, self.mask, sigma, self.cfg[0], self.cfg[1])
+
+
+def _cascade_forward_backward(blk, eta, llg, tgt, wdev, sigma, bf16):
+    """Forward of one RIMBlock cascade (training arithmetic: conv + ReLU and the IndRNN cell as separate launches, their outputs saved),
+    its share of the loss, and its backward.  Returns (list of etas, sum of the per-step l1 terms as a device scalar tensor list)."""
+    L_ = _lib.lib()
+    final = blk.final_layer[0]
+    nl = len(blk.layers)
+    B, H, W = int(eta.shape[0]), int(eta.shape[1]), int(eta.shape[2])
+    plane = H * W
+    hx = [None] * nl
+    saved, etas, losses = [], [], []
+    for _ in range(blk.time_steps):
+        g4 = llg.forward(eta, sigma)
+        x, acts = g4, []
+        for li, st in enumerate(blk.layers):
+            c, r = st.convs, st.rnn
+            cw, cb = c.conv_layer.weight, c.conv_layer.bias
+            use16 = bf16 and ops.conv_bf16_supported(int(cw.shape[1]), int(cw.shape[0]), c.kernel_size, c.dilation)
+            a = (ops.conv2d_bf16 if use16 else ops.conv2d)(x, cw, cb, c.dilation, ops.PAD_REPLICATE, ops.ACT_RELU)
+            if bf16 and ops.conv_bf16_supported(int(r.ih.weight.shape[1]), int(r.ih.weight.shape[0]), 1, 1):
+                h = ops.conv2d_bf16(a, r.ih.weight, r.ih.bias, 1, ops.PAD_ZERO, ops.ACT_RELU, hh=r.hh if hx[li] is not None else None,
+                                    h_prev=hx[li])
+            else:
+                h = ops.indrnn_cell(a, r.ih.weight, r.ih.bias, r.hh, hx[li], 1)
+            acts.append((x, a, h, hx[li]))
+            hx[li] = h
+            x = h
+        eta_new = ops.rim_final(x, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size, final.dilation, eta)
+        # loss term of this estimate (cirim.py:218-237, l1): mean | target - |eta| / max |eta| |
+        m = ops.max_abs(eta_new, complex_modulus=True).reshape(1)
+        out2 = torch.empty(2, dtype=torch.float32, device=eta.device)
+        work = torch.empty(int(L_.mrx_absl1_work_floats()), dtype=torch.float32, device=eta.device)
+        _lib.check(L_.mrx_absl1_loss(_lib.ptr(eta_new), _lib.ptr(tgt), _lib.ptr(m), _lib.ptr(out2), _lib.ptr(work), B * plane, _lib.stream_ptr()),
+                   "mrx_absl1_loss")
+        saved.append((g4, acts, eta_new, m, out2))
+        etas.append(eta_new)
+        losses.append(out2)
+        eta = eta_new
+    # ---- backward, last time-step first -------------------------------------------------------------------------------------------------
+    carry, dH = None, [None] * nl
+    fw, fb = final.conv_layer.weight, final.conv_layer.bias
+    for g4, acts, eta_t, m, out2 in reversed(saved):
+        gl = torch.empty_like(eta_t)
+        _lib.check(L_.mrx_absl1_loss_bwd(_lib.ptr(eta_t), _lib.ptr(tgt), _lib.ptr(m), _lib.ptr(out2), _lib.ptr(wdev), 1.0, _lib.ptr(gl),
+                                         B * plane, _lib.stream_ptr()), "mrx_absl1_loss_bwd")
+        tot = torch.empty_like(eta_t)
+        d2 = torch.empty(B, 2, H, W, dtype=torch.float32, device=eta_t.device)
+        _lib.check(L_.mrx_eta_grad_in(_lib.ptr(carry), _lib.ptr(gl), _lib.ptr(tot), _lib.ptr(d2), B, plane, _lib.stream_ptr()), "mrx_eta_grad_in")
+        h_top = acts[-1][2]
+        ops.conv_wgrad(h_top, d2, final.kernel_size, final.dilation, ops.PAD_REPLICATE, out=_grad_of(fw), accumulate=True)
+        if fb is not None:
+            _grad_of(fb).add_(d2.sum(dim=(0, 2, 3)))                  # two numbers; the model-zoo final conv has no bias
+        dh = ag._dgrad(d2, fw, final.dilation, ops.PAD_REPLICATE, bf16 and ops.conv_bf16_supported(2, int(fw.shape[1]), final.kernel_size,
+                                                                                                 final.dilation))
+        for li in range(nl - 1, -1, -1):
+            st = blk.layers[li]
+            c, r = st.convs, st.rnn
+            x_in, a, h, h_prev = acts[li]
+            use16_r = bf16 and ops.conv_bf16_supported(int(r.ih.weight.shape[1]), int(r.ih.weight.shape[0]), 1, 1)
+            dpre, dhp = _relu_bwd_acc(dh, dH[li], h, h_prev, r.hh, _grad_of(r.ih.bias) if r.ih.bias is not None else None,
+                                      _grad_of(r.hh).reshape(-1) if h_prev is not None else None)
+            dH[li] = dhp
+            _wgrad_into(a, dpre, 1, 1, ops.PAD_ZERO, _grad_of(r.ih.weight), use16_r)
+            da = ag._dgrad(dpre, r.ih.weight, 1, ops.PAD_ZERO, use16_r)
+            cw, cb = c.conv_layer.weight, c.conv_layer.bias
+            use16_c = bf16 and ops.conv_bf16_supported(int(cw.shape[1]), int(cw.shape[0]), c.kernel_size, c.dilation)
+            dpre2, _ = _relu_bwd_acc(da, None, a, None, None, _grad_of(cb) if cb is not None else None, None)
+            _wgrad_into(x_in, dpre2, c.kernel_size, c.dilation, ops.PAD_REPLICATE, _grad_of(cw), use16_c)
+            dh = ag._dgrad(dpre2, cw, c.dilation, ops.PAD_REPLICATE, use16_c)
+        dg4 = dh                                                       # [B,4,H,W]: gradient w.r.t. cat(eta, log-likelihood gradient)
+        dz = torch.empty_like(eta_t)
+        _lib.check(L_.mrx_g4_to_complex(_lib.ptr(dg4), _lib.ptr(dz), B, plane, _lib.stream_ptr()), "mrx_g4_to_complex")
+        t4 = llg.adjoint(dz, sigma)
+        carry = torch.empty_like(eta_t)
+        _lib.check(L_.mrx_eta_grad_out(_lib.ptr(tot), _lib.ptr(dg4), _lib.ptr(t4), _lib.ptr(carry), B, plane, _lib.stream_ptr()),
+                   "mrx_eta_grad_out")
+    return etas, losses
+
+
+def cirim_forward_backward(model, batch, precision="f32", on_cascade_done=None):
+    """Forward, l1 loss (cirim.py:199-247 with accumulate_estimates) and backward of the whole CIRIM on the explicit tape.  Gradients are
+    ADDED into `p.grad` of the parameters (zero them first).  `on_cascade_done(i)` is called when cascade i's gradients are final.
+    Returns the loss as a 0-dim device tensor."""
+    y, S, mask, target = batch["y"], batch["sensitivity_maps"], batch["mask"], batch["target"]
+    tgt = target.abs() if target.is_complex() else target
+    tgt = (tgt / tgt.abs().max()).abs().float().contiguous()
+    T_, nc = model.time_steps, len(model.cirim)
+    w = float(torch.logspace(-1, 0, steps=T_).sum()) / T_ / nc          # the reference's weighting quirk (see cirim_l1_loss)
+    wdev = torch.full((1,), w, dtype=torch.float32, device=y.device)
+    blk0 = model.cirim[0]
+    yt = ops.llg_prepare(y, blk0.fft_centered, blk0.fft_normalization, blk0.spatial_dims)
+    hybrid = (yt, ops.llg372_prepare(yt, S, mask, blk0.fft_centered)) if ops.llg372_supported(yt, mask) else yt
+    eta = ops.sens_reduce(y, S, blk0.fft_centered, blk0.fft_normalization, blk0.spatial_dims)     # cascade 0: keep_eta False (rim_block.py:195-211)
+    terms = []
+    bf16 = precision == "bf16"
+    for i, blk in enumerate(model.cirim):
+        llg = _Llg(blk, y, S, mask, hybrid)
+        etas, losses = _cascade_forward_backward(blk, eta, llg, tgt, wdev, 1.0, bf16)
+        terms += losses
+        eta = etas[-1]                                                    # keep_eta: the next cascade starts from pred[-1].detach()
+        if on_cascade_done is not None:
+            on_cascade_done(i)
+    total = torch.stack(terms)[:, 0].sum() * w
+    return total
+
+
+def training_step(model, flat, optimizer, batch, time_steps=None, schedule=None, use_tape=None):
     """One data-parallel step: forward (recorded), l1 loss, backward through the HIP kernels, ONE all-reduce of the flat gradient,
     Adam.  `batch`: dict with y, sensitivity_maps, mask, target.  `schedule`: optional dict(max_steps, base_lr, warmup_ratio | warmup_steps,
     min_lr) -- the learning rate of this step is then the reference's InverseSquareRootAnnealing value (inverse_sqrt_lr at the number of
@@ -106,6 +310,32 @@ def training_step(model, flat, optimizer, batch, time_steps=None, schedule=None)
         optimizer.lr = inverse_sqrt_lr(optimizer.steps, schedule["max_steps"], schedule["base_lr"], schedule.get("warmup_ratio", 0.1),
                                        schedule.get("min_lr", 0.0), schedule.get("warmup_steps"))
     flat.zero_grad()
+    if use_tape is None:
+        use_tape = _tape_supported(model, batch)
+    if use_tape:
+        # explicit tape: each cascade's slice of the flat gradient is final when its backward ends -- its all-reduce is issued right
+        # there (async) and overlaps the next cascade; everything is waited for before the optimizer
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        handles = []
+
+        def reduce_cascade(i):
+            if multi:
+                o0, o1 = flat.cascade_slices[i]
+                handles.append(dist.all_reduce(flat.grad[o0:o1], op=dist.ReduceOp.SUM, async_op=True))
+
+        loss = cirim_forward_backward(model, batch, ag.PRECISION, reduce_cascade if flat.cascade_slices else None)
+        if multi:
+            if not flat.cascade_slices:
+                handles.append(dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                for o0, o1 in flat.rest_slices:
+                    handles.append(dist.all_reduce(flat.grad[o0:o1], op=dist.ReduceOp.SUM, async_op=True))
+            for h in handles:
+                h.wait()
+        world = dist.get_world_size() if multi else 1
+        optimizer.step(grad_scale=1.0 / world)
+        return loss.detach()
     etas = next(model(batch["y"], batch["sensitivity_maps"], batch["mask"], None, batch["target"]))
     loss = cirim_l1_loss(etas, batch["target"], model.time_steps, len(model.cirim))
     loss.backward()

@@ -176,3 +176,47 @@ def test_llg_backward_is_its_own_adjoint(dev, mask_kind):
         assert_close(out, ref.detach(), 1e-5, f"llg forward {mask_kind} {norm}")
         out.backward(dout.to(dev))
         assert_close(e.grad, eta.grad, 1e-5, f"llg backward {mask_kind} {norm}")
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_explicit_tape_matches_autograd_tape(dev, precision):
+    """training.cirim_forward_backward (the written-out backward: accumulation inside the kernels, one cascade alive at a time) against the
+    torch-autograd tape over the same kernels: same loss, same gradients up to the order of the fp32 additions."""
+    from mridc_amd import autograd as ag
+    from mridc_amd import training
+    cfg, model, state, s = _small_cirim(dev)
+    batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    assert training._tape_supported(model, batch)
+    ag.set_precision(precision)
+    try:
+        model.train()
+        etas = next(model(batch["y"], batch["sensitivity_maps"], batch["mask"], None, batch["target"]))
+        loss = training.cirim_l1_loss(etas, batch["target"], model.time_steps, len(model.cirim))
+        loss.backward()
+        want = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        for p in model.parameters():
+            p.grad = None
+        done = []
+        got_loss = training.cirim_forward_backward(model, batch, precision, done.append)
+        assert done == list(range(len(model.cirim)))
+        assert abs(float(got_loss) - float(loss.detach())) <= 2e-6 * abs(float(loss.detach()))
+        for n, g in want.items():
+            assert_close(dict(model.named_parameters())[n].grad, g, 2e-5, f"{precision} tape gradient of {n}")
+        # through training_step: FlatParameters slices per cascade, Adam on the accumulated buffer
+        flat = training.FlatParameters(model)
+        assert len(flat.cascade_slices) == len(model.cirim) and flat.cascade_slices[0][0] == 1      # dc_weight comes first
+        assert sum(b - a for a, b in flat.cascade_slices) + sum(b - a for a, b in flat.rest_slices) == flat.numel
+        import copy
+        model_b = copy.deepcopy(model)
+        flat_b = training.FlatParameters(model_b)
+        opt = training.AdamFlat(flat, lr=1e-4, betas=(0.9, 0.98))
+        opt_b = training.AdamFlat(flat_b, lr=1e-4, betas=(0.9, 0.98))
+        for _ in range(2):                                   # two optimizer steps: explicit tape vs autograd tape from the same state
+            la = float(training.training_step(model, flat, opt, batch, use_tape=True))
+            lb = float(training.training_step(model_b, flat_b, opt_b, batch, use_tape=False))
+            assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)
+        # Adam turns gradients into +-lr steps: parameters whose gradient is round-off noise may step differently, all others agree
+        close = ((flat.flat - flat_b.flat).abs() <= 1e-6).float().mean()
+        assert float(close) >= 0.98, float(close)
+    finally:
+        ag.set_precision("f32")
