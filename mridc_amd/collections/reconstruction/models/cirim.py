@@ -80,6 +80,47 @@ class CIRIM(torch.nn.Module):
     def forward_step(self, y, sensitivity_maps, mask, init_pred=None, target=None):
         return next(self.forward(y, sensitivity_maps, mask, init_pred, target))
 
+    def process_loss(self, target, pred, _loss_fn=None, mask=None):
+        """cirim.py:199-249: the (validation / training) loss of the estimates against the target for the three configurable losses
+        (`l1`, `mse`, `ssim`: cirim.py:95-110), evaluated on the device by libmridc_amd (mrx_absl1_loss, mrx_recon_metrics,
+        mrx_ssim_loss) -- a generator, like the reference.  With accumulate_estimates every time-step loss is multiplied by the whole
+        logspace(-1, 0, time_steps) vector and summed (the reference's weighting), cascades are averaged.  Gradients of the l1 form are
+        what mridc_amd.training back-propagates; this method itself records no tape."""
+        from mridc_amd import _lib
+        from mridc_amd import runner
+        _loss_fn = self.train_loss_fn if _loss_fn is None else _loss_fn
+        kind = "ssim" if "ssim" in str(_loss_fn).lower() else ("mse" if "mse" in str(_loss_fn).lower() else "l1")
+        tgt = runner._magnitude(target)
+        tgt = ops.div_by_device_scalar(tgt, ops.max_abs(tgt))                  # |target / max |target||
+        L = _lib.lib()
+
+        def loss_fn(y):
+            yc = y if y.is_complex() else torch.view_as_complex(_lib.f32c(y))  # estimates are complex [B,h,w] (or their [..., 2] view)
+            y = _lib.f32c(torch.view_as_real(yc))
+            if kind == "l1":
+                m = ops.max_abs(y, complex_modulus=True).reshape(1)
+                out2 = torch.empty(2, dtype=torch.float32, device=y.device)
+                work = torch.empty(int(L.mrx_absl1_work_floats()), dtype=torch.float32, device=y.device)
+                _lib.check(L.mrx_absl1_loss(_lib.ptr(y), _lib.ptr(tgt), _lib.ptr(m), _lib.ptr(out2), _lib.ptr(work), tgt.numel(),
+                                            _lib.stream_ptr()), "mrx_absl1_loss")
+                return out2[0]
+            yn = runner._magnitude(yc)
+            yn = ops.div_by_device_scalar(yn, ops.max_abs(yn))
+            if kind == "mse":
+                return ops.recon_metrics(tgt, yn)[0]
+            x4, y4 = tgt.unsqueeze(self.coil_dim), yn.unsqueeze(self.coil_dim)   # [B,1,h,w]
+            return _loss_fn(x4, y4, data_range=ops.max_abs(tgt).reshape(1))
+
+        if self.accumulate_estimates:
+            w = float(torch.logspace(-1, 0, steps=self.time_steps).sum()) / self.time_steps
+            cascades_loss = []
+            for cascade_pred in pred:
+                terms = torch.stack([loss_fn(p) for p in cascade_pred])
+                cascades_loss.append(terms.sum() * w)
+            yield sum(cascades_loss) / len(self.cirim)
+        else:
+            yield loss_fn(pred)
+
     def process_intermediate_pred(self, pred, sensitivity_maps, target, do_coil_combination=False):
         """cirim.py:167-197."""
         if not self.no_dc or do_coil_combination:
