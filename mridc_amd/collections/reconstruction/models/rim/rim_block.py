@@ -9,7 +9,9 @@ from mridc_amd.collections.reconstruction.models.rim import conv_layers, rim_uti
 
 
 class RIMBlock(torch.nn.Module):
-    """Recurrent Inference Machine cascade.  2-D mode only (dimensionality=2, conv_dim=2, consecutive_slices=1).
+    """Recurrent Inference Machine cascade.  The 2-D mode (dimensionality=2, conv_dim=2) is the HIP hot path; the reference's 3-D mode
+    (dimensionality=3 / conv_dim=3, rim_block.py:168-180,230-246) runs its data-consistency gradient on the same HIP kernels (slices folded
+    into the batch) and its Conv3d regulariser as torch device ops.
 
     Per time-step the HIP path is four launches for 1-D column masks: the one-launch log_likelihood_gradient
     (mrx_llg_hinv_parts; its last pass -- coil-chunk sum, 1/sigma^2, channel split -- happens in the first layer's tile loader),
@@ -31,9 +33,9 @@ class RIMBlock(torch.nn.Module):
                  fft_normalization: str = "ortho", spatial_dims: Optional[Tuple[int, int]] = None, coil_dim: int = 1,
                  dimensionality: int = 2, consecutive_slices: int = 1):
         super().__init__()
-        if dimensionality != 2 or conv_dim != 2 or consecutive_slices != 1:
-            raise NotImplementedError("mridc_amd.RIMBlock implements dimensionality=2 / conv_dim=2 / consecutive_slices=1; "
-                                      "the reference's 3-D mode (rim_block.py:168-180) is out of the HIP path's scope")
+        if (dimensionality, conv_dim) not in ((2, 2), (3, 3)) or consecutive_slices != 1:
+            raise NotImplementedError("mridc_amd.RIMBlock implements dimensionality = conv_dim = 2 (HIP kernels) and "
+                                      "dimensionality = conv_dim = 3 (HIP data consistency + torch Conv3d layers), consecutive_slices = 1")
         self.input_size = depth * 2                                   # rim_block.py:67
         self.time_steps = time_steps
         self.layers = torch.nn.ModuleList()
@@ -167,10 +169,57 @@ class RIMBlock(torch.nn.Module):
             etas.append(eta)
         return etas, hx
 
+    def _forward_3d(self, pred, masked_kspace, sense, mask, eta, hx, sigma, keep_eta):
+        """rim_block.py:168-180,217-249 for dimensionality = 3: [batch, slices, coils, H, W, 2] inputs, slices folded into the batch for
+        log_likelihood_gradient (HIP kernels), the layers as 3-D convolutions over (batch * slices, H, W) (torch device ops)."""
+        batch, slices = masked_kspace.shape[0], masked_kspace.shape[1]
+
+        def fold(t):
+            return t.reshape([t.shape[0] * t.shape[1], *t.shape[2:]])
+
+        pred = pred[-1].detach() if isinstance(pred, (tuple, list)) else fold(pred)
+        masked_kspace, mask, sense = fold(masked_kspace), fold(mask), fold(sense)
+        if hx is None:
+            hx = [masked_kspace.new_zeros((masked_kspace.size(0), f, *masked_kspace.size()[2:-1])) for f in self.recurrent_filters if f != 0]
+        else:
+            hx = list(hx)
+        if eta is None or eta.ndim < 3:
+            eta = pred if keep_eta else ops.sens_reduce(pred, sense, self.fft_centered, self.fft_normalization, self.spatial_dims)
+        if eta.dim() == 5:
+            eta = fold(eta)
+        hinv = ops.mask_is_row_invariant(mask) and self.coil_dim == 1
+        yt = ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization, self.spatial_dims) if hinv else None
+        work = None if hinv else torch.empty_like(masked_kspace, dtype=torch.float32)
+        etas = []
+        for _ in range(self.time_steps):
+            if hinv:
+                grad_eta = ops.llg_hinv(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
+            else:
+                grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization, self.spatial_dims,
+                                   work=work)
+            grad_eta = grad_eta.view([batch * slices, 4, grad_eta.shape[2], grad_eta.shape[3]]).permute(1, 0, 2, 3)
+            for h, convrnn in enumerate(self.layers):
+                hx[h] = convrnn(grad_eta, hx[h]).squeeze(0)
+                grad_eta = hx[h]
+            grad_eta = self.final_layer(grad_eta).permute(1, 2, 3, 0)
+            for h in range(len(hx)):
+                hx[h] = hx[h].permute(1, 0, 2, 3)
+            eta = eta + grad_eta
+            etas.append(eta)
+        if self.no_dc:
+            return etas, hx
+        if mask.dtype != torch.bool:
+            raise RuntimeError(f"where expected condition to be a boolean tensor, but got a tensor with dtype {mask.dtype}")
+        return [ops.dc_combine(masked_kspace, pred, masked_kspace, mask, self.dc_weight,
+                               ops.sens_expand(e.contiguous(), sense, self.fft_centered, self.fft_normalization, self.spatial_dims))
+                for e in etas], hx
+
     def forward(self, pred: torch.Tensor, masked_kspace: torch.Tensor, sense: torch.Tensor, mask: torch.Tensor,
                 eta: torch.Tensor = None, hx: torch.Tensor = None, sigma: float = 1.0, keep_eta: bool = False,
                 _hybrid: torch.Tensor = None) -> Tuple[Any, Union[list, torch.Tensor, None]]:
         """rim_block.py:139-269.  Returns (list of time_steps estimates, hx)."""
+        if self.dimensionality == 3:
+            return self._forward_3d(pred, masked_kspace, sense, mask, eta, hx, sigma, keep_eta)
         if isinstance(pred, list):                                   # rim_block.py:185-186
             pred = pred[-1].detach()
         if hx is None:                                               # rim_block.py:188-193 (zeros; kernels take NULL for that)

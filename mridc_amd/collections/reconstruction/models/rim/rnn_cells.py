@@ -86,17 +86,17 @@ class IndRNNCell(nn.Module):
 
     def __init__(self, input_size, hidden_size, conv_dim, kernel_size, dilation=1, bias=True):
         super().__init__()
-        if conv_dim != 2:
-            raise NotImplementedError("mridc_amd implements the 2-D convolutional path (conv_dim=2) only")
+        if conv_dim not in (2, 3):
+            raise NotImplementedError("mridc_amd implements conv_dim = 2 (HIP kernels) and conv_dim = 3 (torch device ops)")
         self.input_size = input_size
         self.hidden_size = hidden_size
         self.kernel_size = kernel_size
         self.dilation = dilation
         self.bias = bias
         self.conv_dim = conv_dim
-        self.ih = nn.Conv2d(input_size, hidden_size, kernel_size, padding=int(dilation * (kernel_size - 1) / 2),
-                            dilation=dilation, bias=bias)
-        self.hh = nn.Parameter(nn.init.normal_(torch.empty(1, hidden_size, 1, 1),
+        self.ih = (nn.Conv2d if conv_dim == 2 else nn.Conv3d)(input_size, hidden_size, kernel_size,
+                                                              padding=int(dilation * (kernel_size - 1) / 2), dilation=dilation, bias=bias)
+        self.hh = nn.Parameter(nn.init.normal_(torch.empty(*([1, hidden_size] + [1] * conv_dim)),
                                                std=1.0 / (hidden_size * (1 + kernel_size ** 2))))
         self.reset_parameters()
 
@@ -112,4 +112,8 @@ class IndRNNCell(nn.Module):
             raise RuntimeError(f"input has inconsistent input_size: got {_input.size(1)}, expected {self.input_size}")
 
     def forward(self, _input, hx):
+        if self.conv_dim == 3:                                        # rnn_cells.py:384-391 (torch device ops: outside the HIP hot path)
+            _input = _input.unsqueeze(0)
+            hx = hx.permute(1, 0, 2, 3).unsqueeze(0)
+            return torch.relu(self.ih(_input) + self.hh * hx)
         return ops.indrnn_cell(_input, self.ih.weight, self.ih.bias, self.hh, hx, self.dilation)

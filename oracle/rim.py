@@ -2,7 +2,7 @@
 
 Functional restatement: weights are passed as a plain dict keyed exactly like the reference
 `RIMBlock.state_dict()`, so golden fixtures can carry reference weights as data.
-Only the 2-D mode (conv_dim == 2, dimensionality == 2) is restated.
+The 2-D mode (conv_dim == 2, dimensionality == 2) and the 3-D mode (conv_dim == dimensionality == 3, IndRNN layers) are restated.
 """
 import torch
 import torch.nn.functional as F
@@ -76,8 +76,9 @@ class RIMConfig:
                  recurrent_kernels=(1, 1, 0), recurrent_dilations=(1, 1, 0), recurrent_bias=(True, True, False),
                  depth=2, time_steps=8, conv_dim=2, no_dc=False, fft_centered=True, fft_normalization="ortho",
                  spatial_dims=None, coil_dim=1, dimensionality=2):
-        if conv_dim != 2 or dimensionality != 2:
-            raise NotImplementedError("oracle restates the 2-D mode only")
+        if (conv_dim, dimensionality) not in ((2, 2), (3, 3)):
+            raise NotImplementedError("oracle restates the 2-D mode and the 3-D mode (conv_dim = dimensionality = 3)")
+        self.conv_dim, self.dimensionality = conv_dim, dimensionality
         self.recurrent_layer = recurrent_layer
         self.conv_filters, self.conv_kernels = list(conv_filters), list(conv_kernels)
         self.conv_dilations, self.conv_bias = list(conv_dilations), list(conv_bias)
@@ -113,8 +114,66 @@ def _rnn_apply(p, pre, spec, x, h):
     return convmgu_cell(x, h, p[pre + "ih.weight"], p.get(pre + "ih.bias"), p[pre + "hh.weight"], spec["k"], spec["d"])
 
 
+def _conv3d_nonlinear(x, weight, bias, kernel_size, dilation, nonlinear):
+    """conv_layers.py:72-85,121-123 with conv_dim = 3 on an unbatched [C, D, H, W] input: ReplicationPad3d, Conv3d(padding=0), activation."""
+    p = int(dilation * (kernel_size - 1) / 2)
+    x = F.pad(x.unsqueeze(0), (p, p, p, p, p, p), mode="replicate") if p > 0 else x.unsqueeze(0)
+    x = F.conv3d(x, weight, bias, padding=0, dilation=dilation).squeeze(0)
+    return x if nonlinear is None else (F.relu(x) if nonlinear.upper() == "RELU" else F.leaky_relu(x))
+
+
+def rim_block_forward_3d(p, cfg, pred, masked_kspace, sense, mask, eta=None, hx=None, sigma=1.0, keep_eta=False):
+    """rim_block.py:168-180,217-249 with dimensionality = 3 (IndRNN layers): slices folded into the batch for the data-consistency
+    gradient, the regulariser a 3-D convolution over (batch * slices, H, W).  Returns (list of etas [B*S,H,W,2], hx [B*S,f,H,W])."""
+    batch, slices = masked_kspace.shape[0], masked_kspace.shape[1]
+    fold = lambda t: t.reshape([t.shape[0] * t.shape[1], *t.shape[2:]])  # noqa: E731
+    pred = pred[-1].detach() if isinstance(pred, (tuple, list)) else fold(pred)
+    masked_kspace, mask, sense = fold(masked_kspace), fold(mask), fold(sense)
+    if hx is None:
+        hx = [masked_kspace.new_zeros((masked_kspace.size(0), f, *masked_kspace.size()[2:-1])) for f in cfg.recurrent_filters if f != 0]
+    else:
+        hx = list(hx)
+    if eta is None or eta.ndim < 3:
+        if keep_eta:
+            eta = pred
+        else:
+            img = offt.ifft2(pred, cfg.fft_centered, cfg.fft_normalization, cfg.spatial_dims)
+            eta = outils.complex_mul(img, outils.complex_conj(sense)).sum(cfg.coil_dim)
+    if eta.dim() == 5:
+        eta = fold(eta)
+    layers, final = cfg.layer_table()
+    etas = []
+    for _ in range(cfg.time_steps):
+        g = log_likelihood_gradient(eta, masked_kspace, sense, mask, sigma, cfg.fft_centered, cfg.fft_normalization, cfg.spatial_dims,
+                                    cfg.coil_dim).contiguous()
+        g = g.view([batch * slices, 4, g.shape[2], g.shape[3]]).permute(1, 0, 2, 3)                # :230-231 -> [4, D, H, W]
+        for li, (conv, rnn) in enumerate(layers):
+            pre = f"layers.{li}."
+            g = _conv3d_nonlinear(g, p[pre + "convs.conv_layer.weight"], p.get(pre + "convs.conv_layer.bias"), conv["k"], conv["d"], conv["nl"])
+            if rnn["type"] != "INDRNN":
+                raise NotImplementedError("3-D oracle: IndRNN layers")
+            hprev = hx[li].permute(1, 0, 2, 3).unsqueeze(0)                                      # rnn_cells.py:386-389
+            pz = _zero_pad(rnn["k"], rnn["d"])
+            h = F.relu(F.conv3d(g.unsqueeze(0), p[pre + "rnn.ih.weight"], p.get(pre + "rnn.ih.bias"), padding=pz, dilation=rnn["d"])
+                       + p[pre + "rnn.hh"] * hprev)
+            hx[li] = h.squeeze(0)                                                                 # :235-236
+            g = hx[li]
+        g = _conv3d_nonlinear(g, p["final_layer.0.conv_layer.weight"], p.get("final_layer.0.conv_layer.bias"), final["k"], final["d"],
+                              final["nl"])
+        g = g.permute(1, 2, 3, 0)                                                                 # :242-243
+        for li in range(len(hx)):
+            hx[li] = hx[li].permute(1, 0, 2, 3)                                                   # :244-245
+        eta = eta + g
+        etas.append(eta)
+    if not cfg.no_dc:
+        raise NotImplementedError("3-D oracle: no_dc cascades")
+    return etas, hx
+
+
 def rim_block_forward(p, cfg, pred, masked_kspace, sense, mask, eta=None, hx=None, sigma=1.0, keep_eta=False):
-    """rim_block.py:139-269 (2-D branch).  Returns (list of etas | list of k-spaces, hx)."""
+    """rim_block.py:139-269 (2-D branch; dimensionality 3 -> rim_block_forward_3d).  Returns (list of etas | list of k-spaces, hx)."""
+    if getattr(cfg, "dimensionality", 2) == 3:
+        return rim_block_forward_3d(p, cfg, pred, masked_kspace, sense, mask, eta, hx, sigma, keep_eta)
     if isinstance(pred, list):                      # :185-186
         pred = pred[-1].detach()
     B = masked_kspace.shape[0]

@@ -557,6 +557,39 @@ def g19_cirim_spec():
     save("g19_cirim_spec.npz", d)
 
 
+def g20_rim3d():
+    """A14, 3-D mode of RIMBlock (rim_block.py:168-180,230-246; the cases of tests/collections/reconstruction/models/test_cirim.py:155-290):
+    [batch, slices, coils, H, W, 2] inputs, Conv3d / ReplicationPad3d layers over (slices folded with batch, H, W)."""
+    d = {}
+    cases = [("s1", [1, 1, 3, 15, 12, 2], dict(time_steps=2), 5.0), ("b3s2", [3, 2, 5, 15, 12, 2], dict(time_steps=2), 5.0),
+             ("s2_16", [1, 2, 4, 12, 10, 2], dict(time_steps=3, conv_filters=[16, 16, 2], recurrent_filters=[16, 16, 0], fft_centered=False,
+                                                  fft_normalization="backward"), 5.0)]
+    for i, (nm, shape, ov, wscale) in enumerate(cases):
+        cfg = dict(RIM_CFG)
+        cfg.update(conv_dim=3, dimensionality=3)
+        cfg.update(ov)
+        torch.manual_seed(2000 + i)
+        blk = rim_block.RIMBlock(**cfg).eval()
+        scale_weights(blk, wscale)
+        B, S, C, H, W, _ = shape
+        img, Smap = synth(B * S, C, H, W, 2010 + i)
+        k = fft.fft2(utils.complex_mul(img, Smap), centered=cfg["fft_centered"], normalization=cfg["fft_normalization"])
+        _, m = make_mask([1, C, H, W, 2])
+        y = (k * m).reshape(B, S, C, H, W, 2)
+        Smap = Smap.reshape(B, S, C, H, W, 2)
+        mask = m.reshape(1, 1, 1, 1, W, 1).expand(B, S, 1, 1, W, 1).contiguous()
+        with torch.no_grad():
+            outs, hx = blk(y, y, Smap, mask, None, None, 1.0, keep_eta=False)
+        d[f"{nm}/cfg"] = np.array(json.dumps(cfg))
+        d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"] = y, Smap, mask
+        d[f"{nm}/outs"] = torch.stack(outs)
+        for j, h in enumerate(hx):
+            d[f"{nm}/hx{j}"] = h
+        d.update(sd(blk, f"{nm}/w/"))
+    d["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g20_rim3d.npz", d)
+
+
 def g7_varnet():
     d = {}
     cases = [("u14p2", 14, 2, 11, [1, 3, 32, 16, 2], True, False), ("u14p2_odd", 14, 2, 11, [1, 5, 15, 12, 2], False, False),
@@ -969,8 +1002,8 @@ def g18_rvn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
-    fns = dict(g19=g19_cirim_spec, g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    fns = dict(g20=g20_rim3d, g19=g19_cirim_spec, g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

@@ -197,3 +197,21 @@ def test_cirim_process_loss_all_three_losses(golden, dev, kind):
     assert abs(float(got) - float(want)) <= 2e-5 * abs(float(want)) + 1e-7, (kind, float(got), float(want))
     if kind == "l1":
         assert abs(float(got) - float(z[f"{nm}/loss_l1"][0])) <= 2e-5 * float(z[f"{nm}/loss_l1"][0])     # the reference's own number
+
+
+def test_g20_rimblock_3d_mode(golden, dev):
+    """A14: the reference's 3-D mode ([batch, slices, coils, H, W, 2], Conv3d layers) -- data-consistency gradient on the HIP kernels with
+    the slices folded into the batch, the 3-D regulariser as torch device ops -- against the reference-generated fixture."""
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    z = golden("g20_rim3d.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg = meta(z, f"{nm}/cfg")
+        blk = RIMBlock(**cfg)
+        blk.load_state_dict(weights(z, f"{nm}/w/"))
+        blk = blk.to(dev).eval()
+        y, S, mask = T(z[f"{nm}/y"]).to(dev), T(z[f"{nm}/S"]).to(dev), T(z[f"{nm}/mask"]).to(dev)
+        with torch.no_grad():
+            outs, hx = blk(y, y, S, mask, None, None, 1.0, keep_eta=False)
+        assert_close(torch.stack(outs), T(z[f"{nm}/outs"]), 2e-5, f"{nm} outs")
+        for j, h in enumerate(hx):
+            assert_close(h, T(z[f"{nm}/hx{j}"]), 2e-5, f"{nm} hx{j}")

@@ -114,3 +114,17 @@ def test_g19_cirim_spec_and_harness_metrics(golden):
     want = z["harness/metrics"]                                     # MSE, NMSE, SSIM, PSNR, maxval
     for k, w in zip(("mse", "nmse", "ssim", "psnr"), want[:4]):
         assert abs(m[k] - float(w)) <= 1e-5 * max(1.0, abs(float(w))), (k, m[k], float(w))
+
+
+def test_g20_rimblock_3d(golden):
+    """A14: the 3-D mode of RIMBlock (Conv3d layers over the folded slices) against the reference-generated fixture."""
+    z = golden("g20_rim3d.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg = meta(z, f"{nm}/cfg")
+        rc = oracle.rim.RIMConfig(**cfg)
+        p = weights(z, f"{nm}/w/")
+        y, S, mask = T(z[f"{nm}/y"]), T(z[f"{nm}/S"]), T(z[f"{nm}/mask"])
+        outs, hx = oracle.rim.rim_block_forward(p, rc, y, y, S, mask, None, None, 1.0, keep_eta=False)
+        assert_close(torch.stack(outs), T(z[f"{nm}/outs"]), 2e-6, f"{nm} outs")
+        for j, h in enumerate(hx):
+            assert_close(h, T(z[f"{nm}/hx{j}"]), 2e-6, f"{nm} hx{j}")
