@@ -162,11 +162,31 @@ class KernelTimer:
 
         setattr(module, name, wrapped)
 
+    def calibrate(self, n=64):
+        """Half the elapsed time of an EMPTY event pair = the closing event's own processing time on the command processor (~2.4 us on this
+        stack: an empty pair reads 4.8 us).  Every bracketed launch carries exactly that much on top of the kernel; mean_ms subtracts it, so
+        the event figures agree with rocprofv3's kernel durations (the raw mean is kept as raw_ms)."""
+        pairs = []
+        for _ in range(n):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            e.record()
+            pairs.append((s, e))
+        torch.cuda.synchronize()
+        t = sorted(s.elapsed_time(e) for s, e in pairs)
+        self.pair_ms = t[len(t) // 2]
+        return self.pair_ms
+
+    def raw_ms(self, key):
+        ev = self.events.get(key, [])
+        return (sum(s.elapsed_time(e) for s, e in ev) / len(ev)) if ev else None
+
     def mean_ms(self, key):
         ev = self.events.get(key, [])
         if not ev:
             return None, 0
-        return sum(s.elapsed_time(e) for s, e in ev) / len(ev), len(ev)
+        raw = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+        return max(raw - 0.5 * getattr(self, "pair_ms", 0.0), 0.0), len(ev)
 
 
 def cpu_model_name():
@@ -606,6 +626,7 @@ def main():
         pass
     for _ in range(2):
         step()
+    timer.calibrate()
     barrier()
     timer.enabled = False
     # One captured hipGraph per stream (392 dependent kernels per slice are launch-bound when issued eagerly).  Per-kernel HIP
@@ -689,7 +710,14 @@ def main():
                         traffic_source=traffic.get("_source"), algorithmic_bytes=3.0 * F_hidden * npix * B * 4,
                         launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
                         regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_gflop=issued_reg / 1e9,
-                                         frac_issued=(issued_reg / (t_reg * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if t_reg else None))
+                                         frac_issued=(issued_reg / (t_reg * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if t_reg else None,
+                                         note="all three kernels of a step (layer 1, layer 2, final conv); the 64->2 final conv runs on the "
+                                              "vector ALUs (2 of 32 MFMA rows would be used), its 0.55 GFLOP and its time are included here",
+                                         # the two kernels that run on the matrix cores, on their own
+                                         mfma_kernels_ms=(ms1 or 0) + (ms2 or 0),
+                                         mfma_kernels_issued_gflop=(issued_reg - 2.0 * F_hidden * 2 * 9 * npix * B) / 1e9,
+                                         mfma_kernels_frac_issued=((issued_reg - 2.0 * F_hidden * 2 * 9 * npix * B) / (((ms1 or 0) + (ms2 or 0)) * 1e-3)
+                                                                   / 1e12 / PEAK_FP32_MFMA_TFLOPS) if (ms1 and ms2) else None))
         bytes_llg = (25.0 + 16.0 * C) * npix * B     # compulsory bytes of one log_likelihood_gradient
         # the formulation executed for 1-D masks reads yt = IFFT_H(y) instead of y: the same (25+16C)N compulsory bytes per step
         # (plus one column pass per slice, outside the step, to make yt)
@@ -718,7 +746,14 @@ def main():
                    world_size_seen=world_seen(), per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
                    launch="hipGraph replay" if graphed else "eager", roofline=roofline, roofline_fft=roofline_fft,
                    breakdown_ms=dict(llg=msl, conv_layer1=ms1, conv_layer2=ms2, final=msf,
-                                     rim_steps_per_slice=cfg["num_cascades"] * T_))
+                                     rim_steps_per_slice=cfg["num_cascades"] * T_),
+                   event_timing=dict(method="HIP events around every launch of two eager steps (host enqueues ahead of a parked GPU); each figure "
+                                            "is the event-pair time minus half an EMPTY pair, i.e. minus the closing event's own processing time, "
+                                            "calibrated in this run -- this is what makes the figures agree with rocprofv3's kernel durations",
+                                     empty_pair_ms=getattr(timer, "pair_ms", None),
+                                     raw_ms=dict(llg=timer.raw_ms("llg372") or timer.raw_ms("llg"), conv_layer1=timer.raw_ms("conv_layer1"),
+                                                 conv_layer2=timer.raw_ms("conv_layer2_wino") or timer.raw_ms("conv_layer2"),
+                                                 final=timer.raw_ms("final"))))
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_cascades if 0 < args.cpu_cascades <= cfg["num_cascades"] else cfg["num_cascades"]
             try:
