@@ -157,6 +157,18 @@ int mrx_llg372_prepare(const float* yt, const float* S, const void* mask, int ma
                        float* Sp, float* maskp, int B, int C, int H, int centered, void* stream);
 int mrx_llg372(const float* eta, const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* out4, float* work,
                int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream);
+/* The two halves of that pipeline as row operators at W = 372 (natural k-space layout on the far side; Sp from mrx_llg372_prepare or
+ * mrx_pfa372_prepare_maps): the W transforms of sens_expand / sens_reduce (vn_block.py:51-87) in the hybrid space, and the first / last pass
+ * of the general log_likelihood_gradient around mrx_llg_cols_dc (the column pass of mrx_llg on its own, in place).
+ *   mrx_pfa372_expand   out [B,C,H,372,2] = FFT_W(x * S); with pred != NULL: out = pred - where(mask, pred - ref, 0) * dc_weight[0] - that
+ *   mrx_pfa372_reduce   sum_c conj(S) IFFT_W(k): out [B,H,372,2], or out4 [B,4,H,372] = (eta, post * sum); work: mrx_llg372_work_floats */
+int mrx_pfa372_prepare_maps(const float* S, float* Sp, int B, int C, int H, int centered, void* stream);
+int mrx_pfa372_expand(const float* x, const float* Sp, float* out, const float* pred, const float* ref, const void* mask, int mask_kind,
+                      const int64_t* mstride, const float* dc_weight, int B, int C, int H, int norm, int centered, void* stream);
+int mrx_pfa372_reduce(const float* k, const float* Sp, const float* eta, float* out, float* out4, float* work, int B, int C, int H,
+                      float post, int norm, int centered, void* stream);
+int mrx_llg_cols_dc(float* work, const float* y, const void* mask, int mask_kind, const int64_t* mstride, int B, int C, int H, int W,
+                    int norm, int centered, void* stream);
 int mrx_rim_layer_indrnn_packed_llg(const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,
                                     const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
                                     float* h_new, int B, int F, int H, int W, int k, int dil, void* stream);

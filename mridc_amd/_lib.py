@@ -84,6 +84,10 @@ _SIGNATURES = {
     "mrx_llg372_work_floats": ([_i, _i, _i], _i64),
     "mrx_llg372_prepare": ([_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_llg372": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
+    "mrx_pfa372_prepare_maps": ([_p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_pfa372_expand": ([_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_pfa372_reduce": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
+    "mrx_llg_cols_dc": ([_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_rim_layer_indrnn_packed_llg": ([_p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_conv1x1_64_pack": ([_p, _p, _p], _i),
     "mrx_conv1x1_64": ([_p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p], _i),

@@ -1357,6 +1357,32 @@ extern "C" int mrx_llg(const float* eta, const float* y, const float* S, const v
                          inv_sigma2, 1, st);
 }
 
+// The middle pass of mrx_llg on its own (in place on `work` = FFT_W(eta * S)): FFT_H -> mask * (k - y) -> IFFT_H.  Lets the W = 372 row passes
+// run on the prime-factor kernels (mrx_pfa372_expand / mrx_pfa372_reduce) around it.
+extern "C" int mrx_llg_cols_dc(float* work, const float* y, const void* mask, int mask_kind, const int64_t* mstride, int B, int C, int H, int W,
+                               int norm, int centered, void* stream) {
+    MRX_REQUIRE(work && y && mask && mstride, MRX_EINVAL, "mrx_llg_cols_dc: null pointer");
+    MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_llg_cols_dc: bad dims");
+    MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_llg_cols_dc: bad normalization %d", norm);
+    MRX_REQUIRE(mask_kind == MRX_MASK_U8 || mask_kind == MRX_MASK_F32, MRX_EINVAL, "mrx_llg_cols_dc: bad mask kind %d", mask_kind);
+    if (B == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ColArgs a;
+    int rc;
+    if ((rc = make_col_args(&a, (long long)B * C, H, W, 0, norm, centered))) return rc;
+    a.scale2 = mrx_scale(H, 1, norm);
+    a.C = C;
+    MrxMask m;
+    m.p = mask;
+    m.kind = mask_kind;
+    for (int i = 0; i < 4; ++i) m.s[i] = mstride[i];
+    const size_t lds = sizeof(float2) * ((size_t)H + 2 * (size_t)a.ct * H);
+    if (H == 640) return launch_dc_p<P640, NSEQ_COL_640>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    if (H == 320) return launch_dc_p<P320, NSEQ_COL_320>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    if (H == 256) return launch_dc_p<P256, NSEQ_COL_256>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+    return launch_dc_p<PlanRT, 1>((const float2*)work, (const float2*)y, m, (float2*)work, a, lds, st);
+}
+
 template <class P, int NSEQ>
 // defer != nullptr: the caller adds the coil-chunk partials itself (the fused layer-1 kernel does it in its tile loader);
 // *defer = number of partial planes left in `part` (0: `out` is complete)

@@ -183,6 +183,194 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
     L372_STAMP(6)
 }
 
+// ---- the two halves of the pipeline as stand-alone row operators (natural k-space layout on the far side) ----------------------------------
+// k_pfa372_expand:  out[b, c, h, :] = FFT_W(x[b, h, :] * S[b, c, h, :]) * scale_f            (sens_expand restricted to the W transform:
+//                   vn_block.py:51-69 in the hybrid space of fft.hip, and the first pass of the general log_likelihood_gradient)
+//                   DC epilogue (a.dc): out = pred - where(mask, pred - ref, 0) * w - that      (vn_block.py:109-119)
+// k_pfa372_reduce:  part[z][b, h, :] = sum over the task's coils of conj(S) * IFFT_W(k[b, c, h, :]) * scale_i      (vn_block.py:71-87, the
+//                   last pass of log_likelihood_gradient); the T partial planes are added by k_pfa372_sum / k_llg372_combine
+// Same wave-private transforms and lane-ordered maps (Sp) as k_llg372; the k-space rows are read / written contiguously through the
+// wave's LDS buffer, in transform order [coil][k].
+struct L372Dc {
+    const float2* pred;
+    const float2* ref;
+    const float* w;     // dc_weight (device scalar)
+    MrxMask mask;
+    int on;
+};
+
+__global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restrict__ x_, const float2* __restrict__ Sp_,
+                                                          float2* __restrict__ out_, L372Args a, L372Dc dc) {
+    const pfa_c* __restrict__ xin = reinterpret_cast<const pfa_c*>(x_);
+    const pfa_c* __restrict__ Sp = reinterpret_cast<const pfa_c*>(Sp_);
+    extern __shared__ __attribute__((aligned(16))) float2 X_[];
+    pfa_c* X = reinterpret_cast<pfa_c*>(X_);
+    const int l = threadIdx.x;
+    const unsigned task = (unsigned)mrx_xcd_band(blockIdx.x, a.ntasks);
+    const unsigned row = task / (unsigned)a.T;
+    const int z = (int)(task - row * (unsigned)a.T);
+    const unsigned b = row / (unsigned)a.H, h = row - b * (unsigned)a.H;
+    const int Cg = min(PFA_G, a.C - z * PFA_G);
+    const bool laneA = l < PFA_L1;
+    const int g1 = l / PFA_N1, n1 = l - g1 * PFA_N1;
+    pfa_c ev[6];
+    const pfa_c* erow = xin + (long long)row * PFA_N;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ev[i] = erow[pfa372_shift(min(l + 64 * i, PFA_N - 1), a.halfW)];
+    Pfa372Lane L;
+    {
+        const pfa_c* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
+#pragma unroll
+        for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = sp[n2 * PFA_L1];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int n = l + 64 * i;
+        if (n < PFA_N) {
+            X[n] = ev[i];
+            if (n < PFA_ETA_C2 - PFA_N) X[n + PFA_N] = ev[i];
+        }
+    }
+    __syncthreads();
+    if (laneA) pfa372_expand(L, X, n1);
+    __syncthreads();
+    if (laneA) pfa372_stage_a(L, X, g1, n1);
+    __syncthreads();
+    // forward 12-point DFTs: all three passes read their inputs first (the natural-order result aliases the exchange buffer)
+    pfa_c v[3][12];
+    int kb[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int d = min(l + 64 * p, PFA_D - 1), g2 = d / PFA_N2, k2 = d - g2 * PFA_N2;
+        const pfa_c* q = X + g2 * PFA_GS + k2 * PFA_KS;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[p][i] = q[i];
+        kb[p] = g2 * PFA_RS + (156 * k2) % PFA_N;           // natural-order base of this lane's outputs: k = (217 k1 + 156 k2) mod 372
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (l + 64 * p < Cg * PFA_N2) {
+            pfa_dft12<false>(v[p]);
+            const int g2 = (l + 64 * p) / PFA_N2, base = kb[p] - g2 * PFA_RS;
+#pragma unroll
+            for (int k1 = 0; k1 < 12; ++k1) {
+                int k = base + (217 * k1) % PFA_N;
+                k = k >= PFA_N ? k - PFA_N : k;
+                X[g2 * PFA_RS + k] = pfa_scale(v[p][k1], a.scale_f);
+            }
+        }
+    }
+    __syncthreads();
+    const float w = dc.on ? dc.w[0] : 0.f;
+    for (int g = 0; g < Cg; ++g) {
+        const int c = z * PFA_G + g;
+        const long long base = (((long long)b * a.C + c) * a.H + h) * PFA_N;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int n = l + 64 * i;
+            if (n < PFA_N) {
+                const int wcol = pfa372_shift(n, a.halfW);
+                pfa_c r = X[g * PFA_RS + n];
+                if (dc.on) {
+                    const float2 p_ = dc.pred[base + wcol], rf = dc.ref[base + wcol];
+                    const bool m = mrx_mask_val(dc.mask, b, c, h, wcol) != 0.f;
+                    const float sx = m ? (p_.x - rf.x) * w : 0.f, sy = m ? (p_.y - rf.y) * w : 0.f;   // vn_block.py:109-110
+                    r = pfa_mk(p_.x - sx - r[0], p_.y - sy - r[1]);                                      // vn_block.py:119
+                }
+                reinterpret_cast<pfa_c*>(out_)[base + wcol] = r;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64, 2) void k_pfa372_reduce(const float2* __restrict__ k_, const float2* __restrict__ Sp_,
+                                                          float2* __restrict__ part_, L372Args a) {
+    const pfa_c* __restrict__ kin = reinterpret_cast<const pfa_c*>(k_);
+    const pfa_c* __restrict__ Sp = reinterpret_cast<const pfa_c*>(Sp_);
+    pfa_c* __restrict__ part = reinterpret_cast<pfa_c*>(part_);
+    extern __shared__ __attribute__((aligned(16))) float2 X_[];
+    pfa_c* X = reinterpret_cast<pfa_c*>(X_);
+    const int l = threadIdx.x;
+    const unsigned task = (unsigned)mrx_xcd_band(blockIdx.x, a.ntasks);
+    const unsigned row = task / (unsigned)a.T;
+    const int z = (int)(task - row * (unsigned)a.T);
+    const unsigned b = row / (unsigned)a.H, h = row - b * (unsigned)a.H;
+    const int Cg = min(PFA_G, a.C - z * PFA_G);
+    const bool laneA = l < PFA_L1;
+    const int g1 = l / PFA_N1, n1 = l - g1 * PFA_N1;
+    // the task's k-space rows, contiguous per coil -> LDS in transform order
+    for (int g = 0; g < PFA_G; ++g) {
+        const int c = min(z * PFA_G + g, a.C - 1);
+        const pfa_c* krow = kin + (((long long)b * a.C + c) * a.H + h) * PFA_N;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int n = l + 64 * i;
+            if (n < PFA_N) X[g * PFA_RS + n] = g < Cg ? krow[pfa372_shift(n, a.halfW)] : pfa_mk(0.f, 0.f);
+        }
+    }
+    Pfa372Lane L;
+    {
+        const pfa_c* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
+#pragma unroll
+        for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = sp[n2 * PFA_L1];
+    }
+    __syncthreads();
+    pfa_c v[3][12];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int d = min(l + 64 * p, PFA_D - 1), g2 = d / PFA_N2, k2 = d - g2 * PFA_N2;
+        const int base = (156 * k2) % PFA_N;
+#pragma unroll
+        for (int k1 = 0; k1 < 12; ++k1) {
+            int k = base + (217 * k1) % PFA_N;
+            k = k >= PFA_N ? k - PFA_N : k;
+            v[p][k1] = X[g2 * PFA_RS + k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int d = l + 64 * p;
+        if (d < PFA_D) {
+            pfa_dft12<true>(v[p]);
+            const int g2 = d / PFA_N2, k2 = d - g2 * PFA_N2;
+            pfa_c* q = X + g2 * PFA_GS + k2 * PFA_KS;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) q[i] = v[p][i];
+        }
+    }
+    __syncthreads();
+    if (laneA) pfa372_gather_a(L, X, g1, n1);
+    __syncthreads();
+    if (laneA) pfa372_stage_a_inv(L, X, g1, n1, a.scale_i);
+    __syncthreads();
+    pfa_c* po = part + (((long long)z * a.B * a.H) + row) * PFA_N;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int n = l + 64 * i;
+        if (n < PFA_N) {
+            pfa_c s = X[n];
+#pragma unroll
+            for (int g = 1; g < PFA_G; ++g) s = pfa_add(s, X[g * PFA_RS + n]);
+            po[pfa372_shift(n, a.halfW)] = s;
+        }
+    }
+}
+
+// out[i] = sum_k part_k[i]   (complex image [B,H,372])
+__global__ void k_pfa372_sum(const float2* __restrict__ part, float2* __restrict__ out, int nparts, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float2 s = part[i];
+        for (int k = 1; k < nparts; ++k) {
+            const float2 v = part[(long long)k * total + i];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        out[i] = s;
+    }
+}
+
 // out4[b, 0:4] = (eta_re, eta_im, post * sum_k part_k re, im)   (rim_utils.py:61-67)
 __global__ void k_llg372_combine(const float2* __restrict__ eta, const float2* __restrict__ part, float* __restrict__ out, int nparts,
                                  long long B, long long plane, float post) {
@@ -317,6 +505,82 @@ extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, c
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_llg372_combine, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)eta, (const float2*)work, out4, a.T,
                        (long long)B, plane, inv_sigma2);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// maps only (E2EVN / general-mask paths): Sp as in mrx_llg372_prepare
+__global__ void k_pfa372_prep_maps(const float2* __restrict__ S, float2* __restrict__ Sp, L372Args a) {
+    const long long total = a.ntasks * L372_TASK_C2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long task = i / L372_TASK_C2;
+        const int e = (int)(i - task * L372_TASK_C2);
+        const long long row = task / a.T;
+        const int z = (int)(task - row * a.T);
+        const long long b = row / a.H, h = row - b * a.H;
+        int g, w;
+        const int n2 = e / PFA_L1, lane = e - n2 * PFA_L1;
+        pfa372_sp_src(n2, lane, a.halfW, &g, &w);
+        const int c = z * PFA_G + g;
+        Sp[i] = c < a.C ? S[((b * a.C + c) * a.H + h) * PFA_N + w] : make_float2(0.f, 0.f);
+    }
+}
+extern "C" int mrx_pfa372_prepare_maps(const float* S, float* Sp, int B, int C, int H, int centered, void* stream) {
+    MRX_REQUIRE(S && Sp, MRX_EINVAL, "mrx_pfa372_prepare_maps: null pointer");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, 0, centered, 0);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    const long long total = a.ntasks * L372_TASK_C2;
+    long long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_pfa372_prep_maps, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float2*)S, (float2*)Sp, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// out [B,C,H,372,2] = FFT_W(x * S) (W transform only), optionally with the soft data-consistency combination as the epilogue:
+// out = pred - where(mask, pred - ref, 0) * dc_weight[0] - FFT_W(x * S)   (pred may alias out)
+extern "C" int mrx_pfa372_expand(const float* x, const float* Sp, float* out, const float* pred, const float* ref, const void* mask,
+                                 int mask_kind, const int64_t* mstride, const float* dc_weight, int B, int C, int H, int norm, int centered,
+                                 void* stream) {
+    MRX_REQUIRE(x && Sp && out, MRX_EINVAL, "mrx_pfa372_expand: null pointer");
+    MRX_REQUIRE(!pred || (ref && mask && mstride && dc_weight), MRX_EINVAL, "mrx_pfa372_expand: the DC epilogue needs pred, ref, mask and dc_weight");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, 0);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_pfa372_expand: too many tasks");
+    L372Dc dc;
+    dc.on = pred != nullptr;
+    dc.pred = (const float2*)pred, dc.ref = (const float2*)ref, dc.w = dc_weight;
+    dc.mask.p = mask, dc.mask.kind = mask_kind;
+    for (int i = 0; i < 4; ++i) dc.mask.s[i] = (dc.on ? mstride[i] : 0);
+    hipLaunchKernelGGL(k_pfa372_expand, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
+                       (const float2*)Sp, (float2*)out, a, dc);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// sum_c conj(S) * IFFT_W(k) (W transform only).  out4 != NULL: [B,4,H,372] = (eta, post * sum) as log_likelihood_gradient returns it (eta
+// required); else out [B,H,372,2] = the sum.  work: mrx_llg372_work_floats(B,C,H) floats.
+extern "C" int mrx_pfa372_reduce(const float* k, const float* Sp, const float* eta, float* out, float* out4, float* work, int B, int C, int H,
+                                 float post, int norm, int centered, void* stream) {
+    MRX_REQUIRE(k && Sp && work && (out || (out4 && eta)), MRX_EINVAL, "mrx_pfa372_reduce: null pointer");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, 0);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_pfa372_reduce: too many tasks");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_pfa372_reduce, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, st, (const float2*)k, (const float2*)Sp,
+                       (float2*)work, a);
+    const long long plane = (long long)H * PFA_N, total = plane * B;
+    long long nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (out4)
+        hipLaunchKernelGGL(k_llg372_combine, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)eta, (const float2*)work, out4, a.T,
+                           (long long)B, plane, post);
+    else
+        hipLaunchKernelGGL(k_pfa372_sum, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)work, (float2*)out, a.T, total);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

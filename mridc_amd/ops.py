@@ -32,6 +32,30 @@ def _bchw(t):
     return int(t.shape[0]), int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
 
 
+PFA372 = os.environ.get("MRIDC_AMD_PFA372", "1") != "0"
+_SP372 = {}
+
+
+def _sp372(sens, centered):
+    """The sensitivity maps in the lane order of the W = 372 prime-factor kernels (mrx_pfa372_prepare_maps), cached per (storage, version):
+    the maps are constant over the cascades of a slice.  The entry keeps the source tensor alive so its address cannot be recycled."""
+    key = (sens.data_ptr(), sens._version, str(sens.device), tuple(sens.shape), bool(centered))
+    hit = _SP372.get(key)
+    if hit is None:
+        if len(_SP372) >= 4:
+            _SP372.pop(next(iter(_SP372)))
+        B, C, H, W = _bchw(sens)
+        sp = torch.empty(int(_lib.lib().mrx_llg372_operand_floats(B, C, H)), dtype=torch.float32, device=sens.device)
+        _lib.check(_lib.lib().mrx_pfa372_prepare_maps(_lib.ptr(sens), _lib.ptr(sp), B, C, H, int(bool(centered)), _lib.stream_ptr()),
+                   "mrx_pfa372_prepare_maps")
+        hit = _SP372[key] = (sp, sens)
+    return hit[0]
+
+
+def _pfa372_ok(sens):
+    return PFA372 and sens.dim() == 5 and int(sens.shape[3]) == 372
+
+
 def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=False):
     """fft2(complex_mul(x, S)).  x [B,H,W,2] or [B,1,H,W,2]; S [B,C,H,W,2] -> [B,C,H,W,2].  `hybrid`: the W transform only
     (k-space kept as IFFT_H(k) for row-invariant masks: mrx_sens_expand_rows)."""
@@ -44,6 +68,10 @@ def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=Fals
     if tuple(x.shape) != (B, H, W, 2):
         raise ValueError(f"sens_expand: image shape {tuple(x.shape)} does not match maps {tuple(sens.shape)}")
     out = torch.empty_like(sens)
+    if hybrid and _pfa372_ok(sens):                                  # W = 372: wave-private prime-factor row transforms
+        _lib.check(_lib.lib().mrx_pfa372_expand(_lib.ptr(x), _lib.ptr(_sp372(sens, centered)), _lib.ptr(out), None, None, None, 0, None, None,
+                                                B, C, H, _norm(normalization), int(bool(centered)), _lib.stream_ptr()), "mrx_pfa372_expand")
+        return out
     fn = _lib.lib().mrx_sens_expand_rows if hybrid else _lib.lib().mrx_sens_expand
     _lib.check(fn(_lib.ptr(x), _lib.ptr(sens), _lib.ptr(out), B, C, H, W, _norm(normalization), int(bool(centered)), _lib.stream_ptr()),
                "mrx_sens_expand")
@@ -63,6 +91,11 @@ def sens_expand_dc_hybrid(x, sens, pred, ref, mask, dc_weight, centered, normali
     m, kind, ms = _lib.mask_args(mask, B, C, H, W)
     w = _lib.f32c(dc_weight.detach().reshape(-1))
     out = torch.empty_like(sens)
+    if _pfa372_ok(sens):
+        _lib.check(_lib.lib().mrx_pfa372_expand(_lib.ptr(x), _lib.ptr(_sp372(sens, centered)), _lib.ptr(out), _lib.ptr(pred), _lib.ptr(ref),
+                                                _lib.ptr(m), kind, ms, _lib.ptr(w), B, C, H, _norm(normalization), int(bool(centered)),
+                                                _lib.stream_ptr()), "mrx_pfa372_expand")
+        return out
     _lib.check(_lib.lib().mrx_sens_expand_rows_dc(_lib.ptr(x), _lib.ptr(sens), _lib.ptr(pred), _lib.ptr(ref), _lib.ptr(m), kind, ms,
                                                   _lib.ptr(w), _lib.ptr(out), B, C, H, W, _norm(normalization), int(bool(centered)),
                                                   _lib.stream_ptr()), "mrx_sens_expand_rows_dc")
@@ -76,6 +109,13 @@ def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None, 
     if sens.shape != k.shape:
         raise ValueError(f"sens_reduce: k-space {tuple(k.shape)} vs maps {tuple(sens.shape)}")
     _check_last_two(spatial_dims, 4)
+    if hybrid and _pfa372_ok(sens):
+        L = _lib.lib()
+        out = torch.empty(B, H, W, 2, dtype=torch.float32, device=k.device)
+        wk = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=k.device)
+        _lib.check(L.mrx_pfa372_reduce(_lib.ptr(k), _lib.ptr(_sp372(sens, centered)), None, _lib.ptr(out), None, _lib.ptr(wk), B, C, H, 1.0,
+                                       _norm(normalization), int(bool(centered)), _lib.stream_ptr()), "mrx_pfa372_reduce")
+        return out
     if hybrid:
         out = torch.empty(B, H, W, 2, dtype=torch.float32, device=k.device)
         _lib.check(_lib.lib().mrx_sens_reduce_rows(_lib.ptr(k), _lib.ptr(sens), _lib.ptr(out), B, C, H, W, _norm(normalization),
@@ -103,6 +143,18 @@ def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, o
         out = torch.empty(B, 4, H, W, dtype=torch.float32, device=y.device)
     if work is None:
         work = torch.empty_like(y)
+    if _pfa372_ok(sens):
+        # W = 372: the two row passes on the prime-factor kernels (maps in lane order, cached per slice), the column pass + DC between them
+        L = _lib.lib()
+        sp = _sp372(sens, centered)
+        nrm, cen, st = _norm(normalization), int(bool(centered)), _lib.stream_ptr()
+        _lib.check(L.mrx_pfa372_expand(_lib.ptr(eta), _lib.ptr(sp), _lib.ptr(work), None, None, None, 0, None, None, B, C, H, nrm, cen, st),
+                   "mrx_pfa372_expand")
+        _lib.check(L.mrx_llg_cols_dc(_lib.ptr(work), _lib.ptr(y), _lib.ptr(m), kind, ms, B, C, H, W, nrm, cen, st), "mrx_llg_cols_dc")
+        wk = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=y.device)
+        _lib.check(L.mrx_pfa372_reduce(_lib.ptr(work), _lib.ptr(sp), _lib.ptr(eta), None, _lib.ptr(out), _lib.ptr(wk), B, C, H,
+                                       float(1.0 / (float(sigma) ** 2.0)), nrm, cen, st), "mrx_pfa372_reduce")
+        return out
     _lib.check(_lib.lib().mrx_llg(_lib.ptr(eta), _lib.ptr(y), _lib.ptr(sens), _lib.ptr(m), kind, ms, _lib.ptr(out),
                                   _lib.ptr(work), B, C, H, W, float(1.0 / (float(sigma) ** 2.0)), _norm(normalization),
                                   int(bool(centered)), _lib.stream_ptr()), "mrx_llg")

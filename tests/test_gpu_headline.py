@@ -284,3 +284,39 @@ def test_e2evn_cascade_full_size(dev, chans, pools, pad):
     with torch.no_grad():
         got = blk(pred.to(dev), d["y"].to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev))
     assert_close(got, ref, 5e-5, f"E2EVN cascade NormUnet({chans},{pools}) at 15 x 640 x 372")
+
+
+@pytest.mark.parametrize("case", [(1, 15, 640, True, "ortho"), (2, 7, 21, False, "backward"), (1, 3, 9, True, "forward")],
+                         ids=lambda c: f"B{c[0]}C{c[1]}H{c[2]}_{'c' if c[3] else 'n'}_{c[4]}")
+def test_pfa372_row_operators_and_general_mask_gradient(dev, case):
+    """The W = 372 prime-factor row operators against the oracle: the hybrid-space sens_expand / sens_reduce / expand + soft DC of the
+    E2EVN cascades (vn_block.py:51-119 with k-space kept as IFFT_H(k)), and log_likelihood_gradient for a 2-D (row-dependent) mask, whose
+    row passes run on the same kernels around the column pass (rim_utils.py:11-67)."""
+    from mridc_amd import ops
+    B, C, H, centered, norm = case
+    W = 372
+    y, S, mask1d, eta = _problem(B, C, H, W, 7000 + C, centered, norm)
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, H, W, 2, generator=g)
+    yd, Sd, ed, xd = y.to(dev), S.to(dev), eta.to(dev), x.to(dev)
+    # the W-only transforms: FFT_W(x S) and sum_c conj(S) IFFT_W(k), defined through the full transforms of the oracle
+    full = oracle.fft.fft2(oracle.utils.complex_mul(x.unsqueeze(1), S), centered, norm)              # fft2(x S)
+    yt_full = ops.llg_prepare(full.to(dev), centered, norm)                                           # IFFT_H of it = FFT_W(x S)
+    got = ops.sens_expand(xd, Sd, centered, norm, hybrid=True)
+    assert_close(got, yt_full, 1e-5, "sens_expand (W transform only)")
+    kh = ops.llg_prepare(yd, centered, norm)                                                          # hybrid-space data
+    want_red = oracle.varnet.sens_reduce(y, S, centered, norm, [-2, -1], 1).squeeze(1)
+    assert_close(ops.sens_reduce(kh, Sd, centered, norm, hybrid=True), want_red, 1e-5, "sens_reduce from hybrid space")
+    w = torch.tensor([0.7])
+    pred = yd + 0.1 * torch.randn(yd.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+    m8 = mask1d.to(torch.uint8).to(dev)
+    predh, refh = ops.llg_prepare(pred, centered, norm), kh
+    got = ops.sens_expand_dc_hybrid(xd, Sd, predh, refh, m8, w.to(dev), centered, norm)
+    want = predh - torch.where(m8.bool(), predh - refh, torch.zeros(1, device=dev)) * 0.7 - yt_full
+    assert_close(got, want, 1e-5, "expand + soft DC in hybrid space")
+    # general (row-dependent) mask
+    m2d = (torch.rand(1, 1, H, W, 1, generator=g) < 0.3)
+    y2 = full * m2d + 0.05 * y
+    with torch.no_grad():
+        g_ref = oracle.rim.log_likelihood_gradient(eta, y2, S, m2d, 1.2, centered, norm, [-2, -1], 1).contiguous()
+    assert_close(ops.llg(ed, y2.to(dev), Sd, m2d.to(dev), 1.2, centered, norm), g_ref, 1e-5, "log_likelihood_gradient, 2-D mask, W = 372")
