@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="--train only: bf16 = convolution / IndRNN GEMM operands in bf16 with fp32 accumulation (the reference's "
                          "`precision: 16` AMP, base_cirim_train.yaml:180), FFT / data consistency / eta accumulation stay fp32")
+    ap.add_argument("--unet", default="14x2", choices=["14x2", "18x4"],
+                    help="--model e2evn: NormUnet(chans x pools): 14x2 pad 11 = BASELINE configs[1]; 18x4 pad 15 = the reference yaml's default")
     ap.add_argument("--dist-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.streams <= 0:
@@ -342,8 +344,12 @@ def bench_e2evn(args, world, rank, dev):
     torch.manual_seed(0)
     if args.model == "e2evn":
         from mridc_amd.collections.reconstruction.models.vn import VarNet
-        model = VarNet(dict(synthetic.E2EVN_BASELINE_CFG))
-        label, desc = "E2EVN 6-cascade", "E2EVN 6 cascades, NormUnet(chans 14, pools 2, pad 11)"
+        ucfg = dict(synthetic.E2EVN_BASELINE_CFG)
+        if args.unet == "18x4":
+            ucfg.update(channels=18, pooling_layers=4, padding_size=15)
+        model = VarNet(ucfg)
+        label = "E2EVN 6-cascade" + ("" if args.unet == "14x2" else " (NormUnet 18x4)")
+        desc = f"E2EVN 6 cascades, NormUnet(chans {ucfg['channels']}, pools {ucfg['pooling_layers']}, pad {ucfg['padding_size']})"
     elif args.model == "rvn":       # SURVEY 8f N4; the reference's base_rvn_run.yaml
         from mridc_amd.collections.reconstruction.models.rvn import RecurrentVarNet
         model = RecurrentVarNet(dict(common, in_channels=2, recurrent_hidden_channels=64, recurrent_num_layers=4, num_steps=8,
