@@ -242,29 +242,32 @@ extern "C" int mrx_conv2d_bf16(const float* x, const void* packed, const float* 
 //   * 3x3: nine waves, wave t owns tap t and keeps its whole [64 x 64] block (4 accumulators) in registers over all tiles; the tap shift is
 //     a constant offset of the B read.  Even dilations keep the shifted 16-byte reads 4-byte aligned (dword LDS reads); the rows of
 //     both tiles are padded so that the 32 channel-lanes of a read fall on distinct banks;
-//   * 1x1: eight waves split the rows of the tile and add their blocks in LDS (fixed order) at the end;
+//   * 1x1: four waves split the rows of the tile and add their blocks in LDS (fixed order) at the end;
 //   * every workgroup leaves one partial [64][64][taps]; a second launch adds the partials in a fixed order in double, so the gradient
 //     does not depend on scheduling (the same second stage as the fp32 kernel in conv_bwd.hip).
-#define WB_TH 8
 #define WB_TW 32
-#define WB_DYS 528   // bytes per dy channel in LDS: 8 x 32 px x 2 B + 16 (132 dwords = 4 mod 64)
+// tile rows: 8 for the 3x3 (halo 1.5x, one workgroup of nine waves per CU), 4 for the 1x1 (two 4-wave workgroups per CU cover each other's loads)
+__host__ __device__ constexpr int wb_th(int K) { return K == 1 ? 4 : 8; }
+__host__ __device__ constexpr int wb_dys(int K) { return wb_th(K) * WB_TW * 2 + 16; }   // bytes per dy channel in LDS (+16: = 4 mod 64 dwords)
 
 struct WgradBfArgs {
     const float* x;    // [B,64,H,W]
     const float* dy;   // [B,64,H,W]
     float* part;       // [gridDim.x][64][64][taps]
     int B, H, W, tiles_x, tiles_y, ntiles, pad_mode;
+    int vec;   // W % 4 == 0 and 16-byte aligned x / dy: vector tile loads
 };
 
 __host__ __device__ constexpr int wb_xs(int K, int DIL) {   // bytes per x channel in LDS, = 16 mod 256 (4 mod 64 dwords)
-    const int pad = DIL * (K - 1) / 2, raw = (WB_TH + 2 * pad) * (WB_TW + 2 * pad) * 2;
+    const int pad = DIL * (K - 1) / 2, raw = (wb_th(K) + 2 * pad) * (WB_TW + 2 * pad) * 2;
     return ((raw + 255 - 16) / 256) * 256 + 16;
 }
 
 template <int K, int DIL>
-__global__ __launch_bounds__(K == 1 ? 512 : 576, 1) void k_conv_wgrad_bf16(WgradBfArgs a) {
+__global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(WgradBfArgs a) {
+    constexpr int WB_TH = wb_th(K), WB_DYS = wb_dys(K);
     constexpr int PAD = DIL * (K - 1) / 2, PH = WB_TH + 2 * PAD, PW = WB_TW + 2 * PAD, TAPS = K * K;
-    constexpr int NT = K == 1 ? 512 : 576, XS = wb_xs(K, DIL);
+    constexpr int NT = K == 1 ? 64 * WB_TH : 576, XS = wb_xs(K, DIL);
     static_assert((DIL & 1) == 0 || K == 1, "shifted reads must stay 4-byte aligned");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* Dy = smem_b;                 // [64][WB_DYS]
@@ -289,11 +292,17 @@ __global__ __launch_bounds__(K == 1 ? 512 : 576, 1) void k_conv_wgrad_bf16(Wgrad
         __syncthreads();   // the previous tile's readers are done
         // dy tile: item = (co, row, 8-pixel group); pixels outside the image contribute zero
         for (int i = tid; i < 64 * WB_TH * 4; i += NT) {
-            const int pg = i & 3, r = (i >> 2) & 7, co = i >> 5;
+            const int pg = i & 3, r = (i >> 2) % WB_TH, co = i / (4 * WB_TH);
             const int gy = h0 + r, gx = w0 + pg * 8;
             float v[8];
+            const float* src = dyb + (long long)co * plane + (long long)gy * a.W + gx;
+            if (a.vec && gy < a.H && gx + 8 <= a.W) {
+                const float4 q0 = *reinterpret_cast<const float4*>(src), q1 = *reinterpret_cast<const float4*>(src + 4);
+                v[0] = q0.x, v[1] = q0.y, v[2] = q0.z, v[3] = q0.w, v[4] = q1.x, v[5] = q1.y, v[6] = q1.z, v[7] = q1.w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (gy < a.H && gx + j < a.W) ? dyb[(long long)co * plane + (long long)gy * a.W + gx + j] : 0.f;
+                for (int j = 0; j < 8; ++j) v[j] = (gy < a.H && gx + j < a.W) ? src[j] : 0.f;
+            }
             *reinterpret_cast<u32x4*>(Dy + co * WB_DYS + (r * WB_TW + pg * 8) * 2) =
                 (u32x4){cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
         }
@@ -303,18 +312,26 @@ __global__ __launch_bounds__(K == 1 ? 512 : 576, 1) void k_conv_wgrad_bf16(Wgrad
             const int g4 = i % XG, r = (i / XG) % PH, ci = i / (XG * PH);
             const int gy0 = h0 + r - PAD, gx0 = w0 + g4 * 4 - PAD;
             float v[4];
+            int gyc = gy0 < 0 ? 0 : (gy0 >= a.H ? a.H - 1 : gy0);
+            const bool rowin = gy0 >= 0 && gy0 < a.H;
+            const float* rowp = xb + (long long)ci * plane + (long long)gyc * a.W;
+            if (a.vec && (PAD & 1) == 0 && gx0 >= 0 && gx0 + 4 <= a.W && (rowin || a.pad_mode == MRX_PAD_REPLICATE)) {
+                // interior: two 8-byte loads (w0 and the even padding keep the pair aligned)
+                const float2 q0 = *reinterpret_cast<const float2*>(rowp + gx0), q1 = *reinterpret_cast<const float2*>(rowp + gx0 + 2);
+                v[0] = q0.x, v[1] = q0.y, v[2] = q1.x, v[3] = q1.y;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int gy = gy0, gx = gx0 + j;
-                bool inb = true;
-                if (a.pad_mode == MRX_PAD_REPLICATE) {
-                    gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-                    gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-                } else {
-                    inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                    gy = inb ? gy : 0, gx = inb ? gx : 0;
+                for (int j = 0; j < 4; ++j) {
+                    int gx = gx0 + j;
+                    bool inb = true;
+                    if (a.pad_mode == MRX_PAD_REPLICATE) {
+                        gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                    } else {
+                        inb = rowin && gx >= 0 && gx < a.W;
+                        gx = inb ? gx : 0;
+                    }
+                    v[j] = inb ? rowp[gx] : 0.f;
                 }
-                v[j] = inb ? xb[(long long)ci * plane + (long long)gy * a.W + gx] : 0.f;
             }
             *reinterpret_cast<uint2*>(Xs + ci * XS + (r * PW + g4 * 4) * 2) = make_uint2(cb_pk(v[0], v[1]), cb_pk(v[2], v[3]));
         }
@@ -323,7 +340,7 @@ __global__ __launch_bounds__(K == 1 ? 512 : 576, 1) void k_conv_wgrad_bf16(Wgrad
         const unsigned char* bp = Xs + l31 * XS + ((ky * DIL) * PW + kx * DIL + lhi * 8) * 2;
 #pragma unroll
         for (int r = 0; r < WB_TH; ++r) {
-            if (K == 1 && r != wave) continue;   // 1x1: the eight waves split the rows
+            if (K == 1 && r != wave) continue;   // 1x1: the waves split the rows of the tile
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + (r * WB_TW + kk * 16) * 2);
@@ -340,10 +357,10 @@ __global__ __launch_bounds__(K == 1 ? 512 : 576, 1) void k_conv_wgrad_bf16(Wgrad
     }
     float* po = a.part + (long long)blockIdx.x * 64 * 64 * TAPS;
     if (K == 1) {
-        // add the eight waves' blocks in LDS, halving the number of live blocks each round (fixed order), wave 0 stores
+        // add the waves' blocks in LDS, halving the number of live blocks each round (fixed order), wave 0 stores
         __syncthreads();
-        float* R = reinterpret_cast<float*>(smem_b);   // [4 waves][4096]
-        for (int half = 4; half >= 1; half >>= 1) {
+        float* R = reinterpret_cast<float*>(smem_b);   // [WB_TH / 2 waves][4096]
+        for (int half = WB_TH / 2; half >= 1; half >>= 1) {
             if (wave >= half && wave < 2 * half) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -395,7 +412,7 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_reduce(const float* __restri
     }
 }
 
-static int wb_nwg(int B, int H, int W) {
+static int wb_nwg(int B, int H, int W, int k) {
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -405,26 +422,27 @@ static int wb_nwg(int B, int H, int W) {
         else
             n_cu = 256;
     }
-    const long long tiles = (long long)mrx_cdiv(W, WB_TW) * mrx_cdiv(H, WB_TH) * B;
-    return (int)(tiles < n_cu ? tiles : n_cu);
+    const int per_cu = k == 1 ? 2 : 1;
+    const long long tiles = (long long)mrx_cdiv(W, WB_TW) * mrx_cdiv(H, wb_th(k)) * B;
+    return (int)(tiles < (long long)per_cu * n_cu ? tiles : (long long)per_cu * n_cu);
 }
 extern "C" int mrx_conv_wgrad_bf16_supported(int Cin, int Cout, int k, int dil) {
     return Cin == 64 && Cout == 64 && ((k == 1 && dil == 1) || (k == 3 && dil == 2));
 }
 extern "C" int64_t mrx_conv_wgrad_bf16_work_floats(int B, int H, int W, int k) {
     if (B < 1 || H < 1 || W < 1 || (k != 1 && k != 3)) return -1;
-    return (int64_t)wb_nwg(B, H, W) * 64 * 64 * k * k;
+    return (int64_t)wb_nwg(B, H, W, k) * 64 * 64 * k * k;
 }
 template <int K, int DIL>
 static int wb_launch(const WgradBfArgs& a, int nwg, hipStream_t st) {
-    constexpr size_t lds = (size_t)64 * WB_DYS + (size_t)64 * wb_xs(K, DIL);
-    static_assert(lds >= 4 * 4096 * sizeof(float) || K != 1, "1x1: LDS also holds the wave reduction");
+    constexpr size_t lds = (size_t)64 * wb_dys(K) + (size_t)64 * wb_xs(K, DIL);
+    static_assert(lds >= (wb_th(K) / 2) * 4096 * sizeof(float) || K != 1, "1x1: LDS also holds the wave reduction");
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
         MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<K, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_bf16<K, DIL>), dim3(nwg), dim3(K == 1 ? 512 : 576), lds, st, a);
+    hipLaunchKernelGGL((k_conv_wgrad_bf16<K, DIL>), dim3(nwg), dim3(K == 1 ? 64 * wb_th(K) : 576), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -435,8 +453,9 @@ extern "C" int mrx_conv_wgrad_bf16(const float* x, const float* dy, float* dw, f
     MRX_REQUIRE(mrx_conv_wgrad_bf16_supported(64, 64, k, dil), MRX_EUNSUP, "mrx_conv_wgrad_bf16: k=%d dilation=%d not instantiated", k, dil);
     WgradBfArgs a;
     a.x = x, a.dy = dy, a.part = work, a.B = B, a.H = H, a.W = W;
-    a.tiles_x = mrx_cdiv(W, WB_TW), a.tiles_y = mrx_cdiv(H, WB_TH), a.ntiles = a.tiles_x * a.tiles_y, a.pad_mode = pad_mode;
-    const int nwg = wb_nwg(B, H, W);
+    a.tiles_x = mrx_cdiv(W, WB_TW), a.tiles_y = mrx_cdiv(H, wb_th(k)), a.ntiles = a.tiles_x * a.tiles_y, a.pad_mode = pad_mode;
+    a.vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) % 16 == 0);
+    const int nwg = wb_nwg(B, H, W, k);
     hipStream_t st = (hipStream_t)stream;
     int rc = k == 1 ? wb_launch<1, 1>(a, nwg, st) : wb_launch<3, 2>(a, nwg, st);
     if (rc) return rc;

@@ -61,10 +61,7 @@ def test_conv_instance_norm_fused_statistics(shape, dev):
     assert_close(got, ref, 1e-5, f"conv + instance norm {shape}")
     sep = ops.instance_norm_act(ops.conv2d(x.to(dev), w.to(dev), None, 1, ops.PAD_ZERO), 1e-5, ops.ACT_LEAKY, 0.2)
     assert_close(got, sep, 5e-6, "fused statistics vs the three-pass instance norm")
-    if Cout > 64:                                                                       # not a tuned shape: fell back above; the
-        with pytest.raises(RuntimeError, match="only 3x3, dilation 1, Cout <= 64"):     # statistics entry point itself refuses
-            ops.conv2d_stats(x.to(dev), w.to(dev))
-        return
+    # (Cout > 64 -- the (18, 4) U-Net reaches 288 channels -- runs the same tuned kernel with its cout blocks spread over grid.y)
     # the two-launch form of the same thing: merged statistics as a tensor, then the apply pass
     y, stats = ops.conv2d_stats(x.to(dev), w.to(dev))
     conv = F.conv2d(x, w, None, padding=1).double()
