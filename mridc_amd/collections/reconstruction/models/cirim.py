@@ -67,8 +67,9 @@ class CIRIM(torch.nn.Module):
         hybrid = None
         if ops.mask_is_row_invariant(mask) and self.coil_dim == 1:
             hybrid = ops.llg_prepare(y, self.fft_centered, self.fft_normalization, self.spatial_dims)
-            if ops.llg372_supported(hybrid, mask):          # W = 372: maps, data and mask in the lane order of mrx_llg372, once per slice
-                hybrid = (hybrid, ops.llg372_prepare(hybrid, sensitivity_maps, mask, self.fft_centered))
+            m1 = ops.row_invariant_view(mask)
+            if ops.llg372_supported(hybrid, m1):            # W = 372: maps, data and mask in the lane order of mrx_llg372, once per slice
+                hybrid = (hybrid, ops.llg372_prepare(hybrid, sensitivity_maps, m1, self.fft_centered))
         for i, cascade in enumerate(self.cirim):
             prediction, _ = cascade(prediction, y, sensitivity_maps, mask, init_pred, hx, sigma,
                                     keep_eta=False if i == 0 else self.keep_eta, _hybrid=hybrid)

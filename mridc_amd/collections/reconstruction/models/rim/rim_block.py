@@ -154,6 +154,8 @@ class RIMBlock(torch.nn.Module):
             raise NotImplementedError("mridc_amd training path: no_dc=True cascades only (base_cirim_train.yaml)")
         final = self.final_layer[0]
         hinv = ops.mask_is_row_invariant(mask) and self.coil_dim == 1
+        if hinv:
+            mask = ops.row_invariant_view(mask)
         data = ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization, self.spatial_dims) if hinv else masked_kspace
         etas = []
         for _ in range(self.time_steps):
@@ -237,7 +239,9 @@ class RIMBlock(torch.nn.Module):
         # launch per step on yt = IFFT_H(y); any other mask takes the general three-launch path
         hinv = ops.mask_is_row_invariant(mask) and self.coil_dim == 1
         op372 = None
+        full_mask = mask
         if hinv:
+            mask = ops.row_invariant_view(mask)                      # a column mask stored with all its rows: index one row
             # yt = IFFT_H(y) depends on the measured data only: a caller running several cascades on the same y (CIRIM) passes it,
             # together with the lane-ordered operands of the W = 372 kernel (mrx_llg372), which also hold the maps and the mask
             if isinstance(_hybrid, tuple):
@@ -287,6 +291,7 @@ class RIMBlock(torch.nn.Module):
             eta = ops.rim_final(grad_eta, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size,
                                 final.dilation, eta)                 # final conv, permute(0,2,3,1), eta + grad
             etas.append(eta)
+        mask = full_mask
         if self.no_dc:                                               # rim_block.py:253-254
             return etas, hx
         if mask.dtype != torch.bool:

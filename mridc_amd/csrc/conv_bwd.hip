@@ -314,9 +314,21 @@ static int query_cus() {
 }
 #define WS_SLABS 64
 
+static int wgrad_nparts64(int n_cu, long long nt_total);
+static int query_cus();
+// partial planes the matrix-core kernel writes: persistent workgroups (min(CUs, tiles)) x pixel groups (few column blocks) -- the same
+// formula the launcher below uses, so the caller allocates what is written (38 MB for the 64 -> 64 3x3 layer, not a 1.2 GB bound)
+static int wgrad_parts64(int B, int H, int W, long long N) {
+    const long long ntiles = (long long)mrx_cdiv(W, WG_TW) * mrx_cdiv(H, WG_TH) * B;
+    const int cus = query_cus();
+    int nparts = wgrad_nparts64(cus < 1024 ? cus : 1024, ntiles);
+    const int nbl = (int)((N + 31) / 32);
+    return nparts * (nbl >= 5 ? 1 : (nbl > 2 ? 2 : (nbl > 1 ? 4 : 8)));
+}
 extern "C" int64_t mrx_conv_wgrad_work_floats(int B, int Cin, int Cout, int H, int W, int k) {
-    const long long n = (long long)Cout * Cin * k * k;
-    if (Cout == 64 && (long long)Cin * k * k <= 8 * WG_MAXNB * 32) return (int64_t)8 * 1024 * n;  // bound: workgroups x pixel groups
+    const long long N = (long long)Cin * k * k, n = (long long)Cout * N;
+    if (B < 1 || H < 1 || W < 1) return -1;
+    if (Cout == 64 && N <= 8 * WG_MAXNB * 32) return (int64_t)wgrad_parts64(B, H, W, N) * n;
     return (int64_t)WS_SLABS * n;
 }
 

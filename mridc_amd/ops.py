@@ -161,10 +161,34 @@ def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, o
     return out
 
 
+_ROW_INV = {}
+
+
 def mask_is_row_invariant(mask):
-    """True when the mask does not depend on the row (H) index, e.g. [B|1,1,1,W,1] 1-D column masks."""
+    """True when the mask does not depend on the row (H) index: [B|1,1,1,W,1] 1-D column masks by shape, and full-size [.,.,H,W,1] masks
+    whose rows are all equal (a column mask stored expanded) by content -- one device reduction per mask tensor, cached per
+    (storage, version); never evaluated while a hipGraph is being captured (then only the shape decides)."""
     m = mask[..., 0] if (mask.dim() == 5 and mask.shape[-1] == 1) else mask
-    return m.dim() >= 2 and m.shape[-2] == 1
+    if m.dim() < 2:
+        return False
+    if m.shape[-2] == 1:
+        return True
+    if not mask.is_cuda or torch.cuda.is_current_stream_capturing():
+        return False
+    key = (mask.data_ptr(), mask._version, tuple(mask.shape), tuple(mask.stride()), str(mask.dtype))
+    hit = _ROW_INV.get(key)
+    if hit is None:
+        if len(_ROW_INV) >= 16:
+            _ROW_INV.pop(next(iter(_ROW_INV)))
+        hit = _ROW_INV[key] = (bool((m == m.narrow(-2, 0, 1)).all()), mask)      # the entry keeps the tensor (and its address) alive
+    return hit[0]
+
+
+def row_invariant_view(mask):
+    """The one-row view of a mask `mask_is_row_invariant` accepted (what the row-invariant kernels index)."""
+    if mask.dim() == 5 and mask.shape[-1] == 1:
+        return mask if mask.shape[-3] == 1 else mask.narrow(-3, 0, 1)
+    return mask if mask.shape[-2] == 1 else mask.narrow(-2, 0, 1)
 
 
 def llg_prepare(y, centered, normalization, spatial_dims=None):

@@ -277,7 +277,7 @@ def cirim_forward_backward(model, batch, precision="f32", on_cascade_done=None):
     """Forward, l1 loss (cirim.py:199-247 with accumulate_estimates) and backward of the whole CIRIM on the explicit tape.  Gradients are
     ADDED into `p.grad` of the parameters (zero them first).  `on_cascade_done(i)` is called when cascade i's gradients are final.
     Returns the loss as a 0-dim device tensor."""
-    y, S, mask, target = batch["y"], batch["sensitivity_maps"], batch["mask"], batch["target"]
+    y, S, mask, target = batch["y"], batch["sensitivity_maps"], ops.row_invariant_view(batch["mask"]), batch["target"]
     tgt = target.abs() if target.is_complex() else target
     tgt = (tgt / tgt.abs().max()).abs().float().contiguous()
     T_, nc = model.time_steps, len(model.cirim)

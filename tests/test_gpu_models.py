@@ -215,3 +215,28 @@ def test_g20_rimblock_3d_mode(golden, dev):
         assert_close(torch.stack(outs), T(z[f"{nm}/outs"]), 2e-5, f"{nm} outs")
         for j, h in enumerate(hx):
             assert_close(h, T(z[f"{nm}/hx{j}"]), 2e-5, f"{nm} hx{j}")
+
+
+def test_expanded_column_mask_takes_the_row_invariant_path(golden, dev):
+    """A 1-D column mask stored with all its rows ([1,1,H,W,1]) is recognised by content and runs the one-launch gradient: same result as the
+    [1,1,1,W,1] form (and as the oracle through the G6 fixture)."""
+    from mridc_amd import ops
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    z = golden("g6_cirim.npz")
+    nm = "c2f64"
+    cfg = meta(z, f"{nm}/cfg")
+    model = CIRIM(cfg)
+    model.load_state_dict(weights(z, f"{nm}/w/"), strict=False)
+    model = model.to(dev).eval()
+    y, S, mask, target = (T(z[f"{nm}/{k}"]).to(dev) for k in ("y", "S", "mask", "target"))
+    H = y.shape[2]
+    mfull = mask.expand(-1, -1, H, -1, -1).contiguous()
+    assert ops.mask_is_row_invariant(mask) and ops.mask_is_row_invariant(mfull)
+    m2d = mfull.clone()
+    m2d[0, 0, 0, 0, 0] = ~m2d[0, 0, 0, 0, 0]
+    assert not ops.mask_is_row_invariant(m2d)
+    with torch.no_grad():
+        a = next(model(y, S, mask, None, target))
+        b = next(model(y, S, mfull, None, target))
+    assert_close(torch.view_as_real(b[-1][-1]), torch.view_as_real(a[-1][-1]), 1e-6, "expanded column mask")
+    assert_close(torch.view_as_real(torch.stack([torch.stack(c) for c in b])), T(z[f"{nm}/out"]), 1e-4, "vs the reference fixture")
