@@ -326,13 +326,13 @@ def bench_qcirim(args, world, rank, dev):
     dist_barrier()
     elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
     if rank == 0:
-        print(json.dumps(dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256", value=world * NS * args.steps / elapsed,
+        emit(dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256", value=world * NS * args.steps / elapsed,
                               unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
                               higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
                               per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank], dtype="f32", data="synthetic",
                               config=dict(workload=f"qCIRIM 1 cascade x 8 time-steps, IndRNN 128 filters, 4 echoes, 32 coils, 256x256, {NS} slice(s) "
                                                    f"per GPU and step ({NS} HIP stream(s), {'hipGraph' if graphs else 'eager'}), random-init weights",
-                                          parallelism=f"slice-sharded x{world}"))), flush=True)
+                                          parallelism=f"slice-sharded x{world}")))
 
 
 def bench_e2evn(args, world, rank, dev):
@@ -415,15 +415,14 @@ def bench_e2evn(args, world, rank, dev):
     elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
     B = NS * B
     if rank == 0:
-        print(json.dumps(dict(metric=f"slices/sec (inference), {label} {C}-coil {H}x{W}", value=world * B * args.steps / elapsed,
+        emit(dict(metric=f"slices/sec (inference), {label} {C}-coil {H}x{W}", value=world * B * args.steps / elapsed,
                               unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                               ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
                               per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
                               dtype="f32", data="synthetic",
                               config=dict(workload=f"{desc}, {C} coils, {H}x{W}, batch "
                                                    f"{B} per GPU ({NS} concurrent HIP stream(s), {'one hipGraph each' if graphs else 'eager'}), random-init weights "
-                                                   "(seed 0)", parallelism=f"slice-sharded x{world}"))),
-              flush=True)
+                                                   "(seed 0)", parallelism=f"slice-sharded x{world}")))
 
 
 def bench_train(args, world, rank, dev):
@@ -454,7 +453,7 @@ def bench_train(args, world, rank, dev):
     elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
     losses.append(float(loss))
     if rank == 0:
-        print(json.dumps(dict(metric=f"slices/sec (training), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}",
+        emit(dict(metric=f"slices/sec (training), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}",
                               value=world * args.steps / elapsed, unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                               ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
                               per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
@@ -466,7 +465,27 @@ def bench_train(args, world, rank, dev):
                                                       "weight gradients), FFT / data consistency / eta / loss / Adam in fp32" if args.dtype == "bf16"
                                                       else ""),
                                           global_batch=world, parallelism=f"data-parallel x{world}", gradient_bytes=flat.numel * 4),
-                              loss_first=losses[0], loss_last=losses[-1])), flush=True)
+                              loss_first=losses[0], loss_last=losses[-1]))
+
+
+_RESULT = []
+
+
+def emit(res):
+    """Keep the result line until the very end of the run: it is printed after the process group is gone and the C runtime's buffered
+    output (RCCL prints its library path through stdio) has been flushed, so the JSON line is the last line on stdout."""
+    _RESULT.append(res)
+
+
+def flush_result():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    for res in _RESULT:
+        print(json.dumps(res), flush=True)
+    _RESULT.clear()
 
 
 def dist_barrier(sync=True):
@@ -555,11 +574,13 @@ def main():
         bench_train(args, world, rank, dev)
         if use_dist:
             dist.destroy_process_group()
+        flush_result()
         return
     if args.model != "cirim":
         (bench_qcirim if args.model == "qcirim" else bench_e2evn)(args, world, rank, dev)
         if use_dist:
             dist.destroy_process_group()
+        flush_result()
         return
     cfg = dict(synthetic.CIRIM_BASELINE_CFG)
     cfg["recurrent_layer"] = args.rnn
@@ -772,10 +793,11 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port",
                                            sample=f"failed: {type(ex).__name__}: {ex}")
-        print(json.dumps(res), flush=True)
+        emit(res)
     if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
+    flush_result()
 
 
 if __name__ == "__main__":
