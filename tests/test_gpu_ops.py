@@ -288,3 +288,28 @@ def test_hybrid_rows_ops(dev, shape):
         two = ops.dc_combine(kh, kh, k, mask, w, e)
         one = ops.sens_expand_dc_hybrid(x, S, kh, k, mask, w, centered, norm)
         assert_close(one, two, 1e-6, "fused expand + data consistency vs the two launches")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8192), (1, 4100, 24), (1, 5, 5000), (1, 6144, 4608)], ids=str)
+def test_fft_lengths_beyond_the_lds_limit(dev, shape):
+    """Lengths > 4096 (the reference's torch.fft has no limit, fft.py:77-81): the four-step composition over the LDS-resident kernels,
+    all normalisations, centred and not, forward and inverse, against numpy float64."""
+    import numpy as np
+    from mridc_amd.collections.common.parts import fft
+    B, H, W = shape
+    rng = np.random.default_rng(H + W)
+    x = (rng.standard_normal((B, H, W)) + 1j * rng.standard_normal((B, H, W))).astype(np.complex64)
+    xd = torch.view_as_real(torch.from_numpy(x)).to(dev)
+    cases = [(False, "backward"), (True, "ortho")] if H * W > 4e6 else [(False, "backward"), (True, "ortho"), (False, "forward"), (True, "none")]
+    for centered, norm in cases:
+        npn = None if norm == "none" else norm
+        sh = (lambda a: np.fft.ifftshift(a, axes=(-2, -1))) if centered else (lambda a: a)
+        ush = (lambda a: np.fft.fftshift(a, axes=(-2, -1))) if centered else (lambda a: a)
+        ref = ush(np.fft.fft2(sh(x.astype(np.complex128)), norm=npn))
+        got = torch.view_as_complex(fft.fft2(xd, centered=centered, normalization=norm).cpu()).numpy()
+        assert np.linalg.norm(got - ref) <= 1e-5 * np.linalg.norm(ref), ("fft2", shape, centered, norm)
+        ref = ush(np.fft.ifft2(sh(x.astype(np.complex128)), norm=npn))
+        got = torch.view_as_complex(fft.ifft2(xd, centered=centered, normalization=norm).cpu()).numpy()
+        assert np.linalg.norm(got - ref) <= 1e-5 * np.linalg.norm(ref), ("ifft2", shape, centered, norm)
+    with pytest.raises(NotImplementedError, match="no factorisation"):
+        fft.fft2(torch.zeros(1, 2, 4099, 2, device=dev))
