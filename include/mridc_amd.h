@@ -347,6 +347,10 @@ int64_t mrx_conv_bf16_pack_bytes(int Cin, int Cout, int k);
 int mrx_conv_bf16_pack(const float* w, void* packed, int Cin, int Cout, int k, int transposed, void* stream);
 int mrx_conv2d_bf16(const float* x, const void* packed, const float* bias, const float* hh, const float* hprev, float* out, int B,
                     int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, void* stream);
+/*   mrx_conv2d_bf16_ext  the zero-padded convolution of x [B,Cin,H,W] read as if zero-extended by `ext` pixels on every side ->
+ *                        out [B,Cout,H + 2 ext,W + 2 ext]: with a transposed pack, the data gradient on the padded domain (then mrx_reppad_fold) */
+int mrx_conv2d_bf16_ext(const float* x, const void* packed, float* out, int B, int Cin, int Cout, int H, int W, int k, int dil, int ext,
+                        void* stream);
 /*   mrx_conv_wgrad_bf16  dw [64,64,k,k] (= or +=) sum over (b, pixel) of dy * padded x (the weight gradient of a 64 -> 64 'same' convolution),
  *                        bf16 operands, fp32 accumulation per workgroup, fixed-order double sum of the workgroup partials; k = 1, or k = 3 with
  *                        dilation 2 (mrx_conv_wgrad_bf16_supported); work: mrx_conv_wgrad_bf16_work_floats floats */

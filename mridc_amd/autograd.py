@@ -37,8 +37,7 @@ def _dgrad(dy, weight, dilation, pad_mode, bf16):
     pad = int(dilation) * (k - 1) // 2
     if pad_mode == ops.PAD_ZERO or pad == 0:
         return ops.conv2d_bf16(dy, weight, None, dilation, ops.PAD_ZERO, transposed=True)
-    big = ops.pad2d(dy, pad, pad, pad, pad, 0)
-    g = ops.conv2d_bf16(big, weight, None, dilation, ops.PAD_ZERO, transposed=True)
+    g = ops.conv_dgrad_bf16_ext(dy, weight, dilation, pad)              # dy read as if zero-extended: no padded copy
     B, Cin, H, W = int(dy.shape[0]), int(weight.shape[1]), int(dy.shape[2]), int(dy.shape[3])
     out = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dy.device)
     _lib.check(_lib.lib().mrx_reppad_fold(_lib.ptr(g), _lib.ptr(out), B * Cin, H, W, pad, _lib.stream_ptr()), "mrx_reppad_fold")

@@ -39,6 +39,7 @@ struct ConvBfArgs {
     float* out;            // [B,Cout,H,W]
     int B, Cin, Cout, H, W, tiles_x, ntiles, pad_mode, act;
     float slope;
+    int ext, Hin, Win;     // the input is [Hin, Win] = [H - 2 ext, W - 2 ext], read as if zero-extended by `ext` on every side (data gradients)
 };
 
 __host__ __device__ constexpr int cb_ps(int CPAD) { return CPAD == 8 ? 16 : CPAD * 2 + 16; }   // bytes per pixel in the LDS tile
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(CB_NT, 4) void k_conv_bf16(ConvBfArgs a) {
     const int ty0 = tile / a.tiles_x;
     const int h0 = ty0 * CB_TH, w0 = (tile - ty0 * a.tiles_x) * CB_TW;
     const int b = blockIdx.y;
-    const long long plane = (long long)a.H * a.W;
-    const float* xb = a.x + (long long)b * a.Cin * plane;
+    const long long plane = (long long)a.H * a.W, iplane = (long long)a.Hin * a.Win;
+    const float* xb = a.x + (long long)b * a.Cin * iplane;
 
     // ---- stage the halo'd tile: 8 channels of one pixel per item, fp32 -> bf16, one 16-byte LDS write ----------------------------------
     constexpr int ITEMS = NPIX * NC8, ITERS = (ITEMS + CB_NT - 1) / CB_NT;
@@ -66,22 +67,22 @@ __global__ __launch_bounds__(CB_NT, 4) void k_conv_bf16(ConvBfArgs a) {
         if (i < ITEMS) {
             const int cg = i / NPIX, e = i - cg * NPIX;
             const int ty = e / PW, tx = e - ty * PW;
-            int gy = h0 + ty - PAD, gx = w0 + tx - PAD;
+            int gy = h0 + ty - PAD - a.ext, gx = w0 + tx - PAD - a.ext;
             bool inb = true;
             if (a.pad_mode == MRX_PAD_REPLICATE) {
-                gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                gy = gy < 0 ? 0 : (gy >= a.Hin ? a.Hin - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= a.Win ? a.Win - 1 : gx);
             } else {
-                inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                inb = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
                 gy = inb ? gy : 0;
                 gx = inb ? gx : 0;
             }
-            const float* src = xb + (long long)gy * a.W + gx;
+            const float* src = xb + (long long)gy * a.Win + gx;
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = cg * 8 + j;
-                v[j] = (inb && c < a.Cin) ? src[(long long)c * plane] : 0.f;
+                v[j] = (inb && c < a.Cin) ? src[(long long)c * iplane] : 0.f;
             }
             u32x4 p = {cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
             *reinterpret_cast<u32x4*>(smem_b + e * PS + cg * 16) = p;
@@ -209,10 +210,25 @@ static int cb_launch_nct(const ConvBfArgs& a, hipStream_t st) {
 }
 
 // act(conv(x; w) + bias [+ hh * hprev]) with bf16 operands; 'same' size, stride 1; packed from mrx_conv_bf16_pack
+static int conv2d_bf16_impl(const float* x, const void* packed, const float* bias, const float* hh, const float* hprev, float* out, int B,
+                           int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, int ext, void* stream);
 extern "C" int mrx_conv2d_bf16(const float* x, const void* packed, const float* bias, const float* hh, const float* hprev, float* out, int B,
                                int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, void* stream) {
+    return conv2d_bf16_impl(x, packed, bias, hh, hprev, out, B, Cin, Cout, H, W, k, dil, pad_mode, act, slope, 0, stream);
+}
+// The zero-padded convolution of x [B,Cin,H,W] read as if zero-extended by `ext` pixels on every side: out [B,Cout,H + 2 ext,W + 2 ext].
+// With a transposed pack and ext = dilation (k - 1) / 2 this is the data gradient on the padded domain that mrx_reppad_fold folds back --
+// without materialising the extended gradient.
+extern "C" int mrx_conv2d_bf16_ext(const float* x, const void* packed, float* out, int B, int Cin, int Cout, int H, int W, int k, int dil,
+                                   int ext, void* stream) {
+    MRX_REQUIRE(ext >= 0, MRX_EINVAL, "mrx_conv2d_bf16_ext: bad extension %d", ext);
+    return conv2d_bf16_impl(x, packed, nullptr, nullptr, nullptr, out, B, Cin, Cout, H + 2 * ext, W + 2 * ext, k, dil, MRX_PAD_ZERO, MRX_ACT_NONE,
+                            0.f, ext, stream);
+}
+static int conv2d_bf16_impl(const float* x, const void* packed, const float* bias, const float* hh, const float* hprev, float* out, int B,
+                           int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, int ext, void* stream) {
     MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv2d_bf16: null pointer");
-    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv2d_bf16: bad dims");
+    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1 && H > 2 * ext && W > 2 * ext, MRX_EINVAL, "mrx_conv2d_bf16: bad dims");
     MRX_REQUIRE(cb_shape_ok(Cin, Cout, k, dil), MRX_EUNSUP, "mrx_conv2d_bf16: Cin=%d Cout=%d k=%d dilation=%d not instantiated", Cin, Cout, k, dil);
     MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv2d_bf16: bad pad mode %d", pad_mode);
     MRX_REQUIRE(!hprev || hh, MRX_EINVAL, "mrx_conv2d_bf16: hprev without hh");
@@ -224,6 +240,7 @@ extern "C" int mrx_conv2d_bf16(const float* x, const void* packed, const float* 
     a.tiles_x = mrx_cdiv(W, CB_TW);
     a.ntiles = a.tiles_x * mrx_cdiv(H, CB_TH);
     a.pad_mode = pad_mode, a.act = act, a.slope = slope;
+    a.ext = ext, a.Hin = H - 2 * ext, a.Win = W - 2 * ext;
     hipStream_t st = (hipStream_t)stream;
     const int cp = cb_cpad(Cin);
     if (k == 1) return cb_launch_nct<1, 1, 64>(a, st);

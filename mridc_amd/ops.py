@@ -48,7 +48,7 @@ def _sp372(sens, centered):
         sp = torch.empty(int(_lib.lib().mrx_llg372_operand_floats(B, C, H)), dtype=torch.float32, device=sens.device)
         _lib.check(_lib.lib().mrx_pfa372_prepare_maps(_lib.ptr(sens), _lib.ptr(sp), B, C, H, int(bool(centered)), _lib.stream_ptr()),
                    "mrx_pfa372_prepare_maps")
-        hit = _SP372[key] = (sp, sens)
+        hit = _SP372[key] = (sp, sens.detach())
     return hit[0]
 
 
@@ -180,7 +180,7 @@ def mask_is_row_invariant(mask):
     if hit is None:
         if len(_ROW_INV) >= 16:
             _ROW_INV.pop(next(iter(_ROW_INV)))
-        hit = _ROW_INV[key] = (bool((m == m.narrow(-2, 0, 1)).all()), mask)      # the entry keeps the tensor (and its address) alive
+        hit = _ROW_INV[key] = (bool((m == m.narrow(-2, 0, 1)).all()), mask.detach())      # the entry keeps the tensor (and its address) alive
     return hit[0]
 
 
@@ -476,8 +476,9 @@ _WINO_PACKS = {}
 
 
 def _wino_conv_pack(weight):
-    """Transformed + packed weights of `weight`, cached per (storage address, version).  The entry keeps a reference to the tensor
-    it was made from, so the address cannot be recycled for other weights while the entry lives."""
+    """Transformed + packed weights of `weight`, cached per (storage address, version).  The entry keeps a detached alias of the tensor
+    it was made from -- i.e. its STORAGE -- so the address cannot be recycled for other weights while the entry lives, even if the
+    parameter's `.data` is re-pointed (training.FlatParameters does that)."""
     key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()))
     hit = _WINO_PACKS.get(key)
     if hit is None:
@@ -490,7 +491,7 @@ def _wino_conv_pack(weight):
         for ob in range(F // 64):                                        # one packed block per 64 output channels
             _lib.check(_lib.lib().mrx_rim_layer_wino_pack(_lib.ptr(w[ob * 64:(ob + 1) * 64]), None, _lib.ptr(packed[ob * blk:]), Cin, 64,
                                                           _lib.stream_ptr()), "mrx_rim_layer_wino_pack")
-        hit = _WINO_PACKS[key] = (packed, weight)
+        hit = _WINO_PACKS[key] = (packed, weight.detach())   # the detached alias pins the STORAGE (p.data may be re-pointed later)
     return hit[0]
 
 
@@ -508,7 +509,7 @@ def _conv1x1_pack(weight):
         C = int(w.shape[0])
         packed = torch.empty(C * C, dtype=torch.float32, device=w.device)
         _lib.check(_lib.lib().mrx_conv1x1_sq_pack(_lib.ptr(w), _lib.ptr(packed), C, _lib.stream_ptr()), "mrx_conv1x1_sq_pack")
-        hit = _PACKS_1X1[key] = (packed, weight)
+        hit = _PACKS_1X1[key] = (packed, weight.detach())
     return hit[0]
 
 
@@ -599,7 +600,7 @@ def _conv_bf16_pack(weight, transposed):
         packed = torch.empty(int(L.mrx_conv_bf16_pack_bytes(cin, cout, k)), dtype=torch.uint8, device=w.device)
         _lib.check(L.mrx_conv_bf16_pack(_lib.ptr(w), _lib.ptr(packed), cin, cout, k, int(bool(transposed)), _lib.stream_ptr()),
                    "mrx_conv_bf16_pack")
-        hit = _PACKS_BF16[key] = (packed, weight)
+        hit = _PACKS_BF16[key] = (packed, weight.detach())
     return hit[0]
 
 
@@ -622,6 +623,21 @@ def conv2d_bf16(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, sl
     _lib.check(_lib.lib().mrx_conv2d_bf16(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), B, cin, cout,
                                           H, W, kh, int(dilation), int(pad_mode), int(act), float(slope), _lib.stream_ptr()),
                "mrx_conv2d_bf16")
+    return out
+
+
+def conv_dgrad_bf16_ext(dy, weight, dilation, ext):
+    """Data gradient on the padded domain: the zero-padded convolution of dy (read as if zero-extended by `ext`) with the flipped,
+    transposed `weight` [Cout,Cin,k,k] -> [B,Cin,H + 2 ext,W + 2 ext] (mrx_conv2d_bf16_ext; no extended copy of dy is made)."""
+    dy = _lib.f32c(dy)
+    B, C, H, W = _nchw(dy)
+    cout_w, cin_w, k = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+    if C != cout_w:
+        raise RuntimeError(f"input has inconsistent input_size: got {C}, expected {cout_w}")
+    packed = _conv_bf16_pack(weight, True)
+    out = torch.empty(B, cin_w, H + 2 * ext, W + 2 * ext, dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().mrx_conv2d_bf16_ext(_lib.ptr(dy), _lib.ptr(packed), _lib.ptr(out), B, cout_w, cin_w, H, W, k, int(dilation), int(ext),
+                                              _lib.stream_ptr()), "mrx_conv2d_bf16_ext")
     return out
 
 
