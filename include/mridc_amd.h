@@ -358,6 +358,11 @@ int mrx_conv_wgrad_bf16_supported(int Cin, int Cout, int k, int dil);
 int64_t mrx_conv_wgrad_bf16_work_floats(int B, int H, int W, int k);
 int mrx_conv_wgrad_bf16(const float* x, const float* dy, float* dw, float* work, int B, int H, int W, int k, int dil, int pad_mode,
                         int accumulate, void* stream);
+/* ... and for every shape of mrx_conv_wgrad_bf16_supported: the 64 -> 64 layers above plus the two thin dilation-1 layers of the RIM
+ * (3x3 64 -> Cout <= 32: the final conv; 5x5 Cin <= 32 -> 64: the first conv); dw [Cout,Cin,k,k] */
+int64_t mrx_conv_wgrad_bf16_any_work_floats(int B, int Cin, int Cout, int H, int W, int k);
+int mrx_conv_wgrad_bf16_any(const float* x, const float* dy, float* dw, float* work, int B, int Cin, int Cout, int H, int W, int k, int dil,
+                            int pad_mode, int accumulate, void* stream);
 
 /*   mrx_absl1_loss      the l1 training loss of one prediction (cirim.py:218-237): out2[0] = mean |target - |p| / max|p||, out2[1] = an
  *                      intermediate the backward needs; p complex [n], target real [n], maxabs = device scalar from mrx_max_abs (mode 1);

@@ -75,6 +75,8 @@ _SIGNATURES = {
     "mrx_eta_grad_in": ([_p, _p, _p, _p, _i, _i64, _p], _i),
     "mrx_g4_to_complex": ([_p, _p, _i, _i64, _p], _i),
     "mrx_eta_grad_out": ([_p, _p, _p, _p, _i, _i64, _p], _i),
+    "mrx_conv_wgrad_bf16_any_work_floats": ([_i, _i, _i, _i, _i, _i], _i64),
+    "mrx_conv_wgrad_bf16_any": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_absl1_work_floats": ([], _i64),
     "mrx_absl1_loss": ([_p, _p, _p, _p, _p, _i64, _p], _i),
     "mrx_absl1_loss_bwd": ([_p, _p, _p, _p, _p, _f, _p, _i64, _p], _i),

@@ -45,7 +45,7 @@ def _dgrad(dy, weight, dilation, pad_mode, bf16):
 
 
 def _wgrad(x, dy, k, dilation, pad_mode, bf16):
-    if bf16 and ops.conv_wgrad_bf16_supported(int(x.shape[1]), int(dy.shape[1]), k, dilation):
+    if bf16 and ops.conv_wgrad_bf16_preferred(int(x.shape[1]), int(dy.shape[1]), k, dilation):
         return ops.conv_wgrad_bf16(x, dy, k, dilation, pad_mode)
     return ops.conv_wgrad(x, dy, k, dilation, pad_mode)
 
@@ -129,7 +129,7 @@ class RimFinal(torch.autograd.Function):
     def backward(ctx, dout):
         h, w = ctx.saved_tensors
         d2 = dout.permute(0, 3, 1, 2).contiguous()                      # [B,2,H,W]
-        dw = ops.conv_wgrad(h, d2, int(w.shape[-1]), ctx.dilation, ops.PAD_REPLICATE)
+        dw = _wgrad(h, d2, int(w.shape[-1]), ctx.dilation, ops.PAD_REPLICATE, ctx.bf16)
         dh = _dgrad(d2, w, ctx.dilation, ops.PAD_REPLICATE, ctx.bf16)
         db = d2.sum(dim=(0, 2, 3)) if ctx.has_bias else None            # 2 numbers (the model-zoo final conv has no bias)
         return dh, dw, db, None, dout

@@ -410,6 +410,140 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(Wgrad
             }
 }
 
+// ---- the same contraction for the two thin layers of the RIM (dilation 1): 3x3 64 -> 2 (final conv) and 5x5 4 -> 64 (first conv) -----------
+// Only Cout (resp. Cin) rows of dy (x) exist in LDS plus one row of zeros that the idle channel-lanes read; a wave owns TPW taps
+// (nine waves x 1 tap, thirteen waves x 2 taps).  Dilation 1 makes every other tap shift odd: those B operands are five dword reads
+// funnel-shifted by 16 bits (v_alignbit_b32) instead of four.
+struct WgradBfGArgs {
+    const float* x;    // [B,Cin,H,W]
+    const float* dy;   // [B,Cout,H,W]
+    float* part;       // [gridDim.x][Cout][Cin][taps]
+    int B, Cin, Cout, H, W, tiles_x, ntiles, pad_mode, vec;
+};
+template <int K, int NCO, int NCI, int TPW>
+__global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgrad_bf16_g(WgradBfGArgs a) {
+    constexpr int TH = 8, DYS = TH * WB_TW * 2 + 16, PAD = (K - 1) / 2, PH = TH + 2 * PAD, PW = WB_TW + 2 * PAD, TAPS = K * K;
+    constexpr int NW = (TAPS + TPW - 1) / TPW, NT = 64 * NW, XS = ((PH * PW * 2 + 255 - 16) / 256) * 256 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* Dy = smem_b;                                // [Cout + 1][DYS], the last row zeros
+    unsigned char* Xs = smem_b + (size_t)(a.Cout + 1) * DYS;   // [Cin + 1][XS], the last row zeros
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const long long plane = (long long)a.H * a.W;
+    f32x16 acc[TPW][NCO][NCI];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int i = 0; i < NCO; ++i)
+#pragma unroll
+            for (int j = 0; j < NCI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+    for (int i = tid; i < DYS / 4; i += NT) reinterpret_cast<unsigned*>(Dy + (size_t)a.Cout * DYS)[i] = 0u;
+    for (int i = tid; i < XS / 4; i += NT) reinterpret_cast<unsigned*>(Xs + (size_t)a.Cin * XS)[i] = 0u;
+    // per-lane operand rows: channel-lanes beyond the real channel count read the zero row
+    int arow[NCO], brow[NCI];
+#pragma unroll
+    for (int i = 0; i < NCO; ++i) arow[i] = (32 * i + l31 < a.Cout ? 32 * i + l31 : a.Cout) * DYS + lhi * 16;
+#pragma unroll
+    for (int j = 0; j < NCI; ++j) brow[j] = (32 * j + l31 < a.Cin ? 32 * j + l31 : a.Cin) * XS;
+
+    const int total_tiles = a.ntiles * a.B;
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const int b = t / a.ntiles, tt = t - b * a.ntiles;
+        const int ty0 = tt / a.tiles_x, h0 = ty0 * TH, w0 = (tt - ty0 * a.tiles_x) * WB_TW;
+        const float* dyb = a.dy + (long long)b * a.Cout * plane;
+        const float* xb = a.x + (long long)b * a.Cin * plane;
+        __syncthreads();
+        for (int i = tid; i < a.Cout * TH * 4; i += NT) {
+            const int pg = i & 3, r = (i >> 2) % TH, co = i / (4 * TH);
+            const int gy = h0 + r, gx = w0 + pg * 8;
+            float v[8];
+            const float* src = dyb + (long long)co * plane + (long long)gy * a.W + gx;
+            if (a.vec && gy < a.H && gx + 8 <= a.W) {
+                const float4 q0 = *reinterpret_cast<const float4*>(src), q1 = *reinterpret_cast<const float4*>(src + 4);
+                v[0] = q0.x, v[1] = q0.y, v[2] = q0.z, v[3] = q0.w, v[4] = q1.x, v[5] = q1.y, v[6] = q1.z, v[7] = q1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (gy < a.H && gx + j < a.W) ? src[j] : 0.f;
+            }
+            *reinterpret_cast<u32x4*>(Dy + co * DYS + (r * WB_TW + pg * 8) * 2) =
+                (u32x4){cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
+        }
+        constexpr int XG = PW / 2;
+        for (int i = tid; i < a.Cin * PH * XG; i += NT) {
+            const int g2 = i % XG, r = (i / XG) % PH, ci = i / (XG * PH);
+            const int gy0 = h0 + r - PAD, gx0 = w0 + g2 * 2 - PAD;
+            const bool rowin = gy0 >= 0 && gy0 < a.H;
+            const int gyc = gy0 < 0 ? 0 : (gy0 >= a.H ? a.H - 1 : gy0);
+            const float* rowp = xb + (long long)ci * plane + (long long)gyc * a.W;
+            float v[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int gx = gx0 + j;
+                bool inb = true;
+                if (a.pad_mode == MRX_PAD_REPLICATE) {
+                    gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                } else {
+                    inb = rowin && gx >= 0 && gx < a.W;
+                    gx = inb ? gx : 0;
+                }
+                v[j] = inb ? rowp[gx] : 0.f;
+            }
+            *reinterpret_cast<unsigned*>(Xs + ci * XS + (r * PW + g2 * 2) * 2) = cb_pk(v[0], v[1]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tw = 0; tw < TPW; ++tw) {
+            const int tap = wave * TPW + tw;
+            if (tap >= TAPS) break;
+            const int ky = tap / K, kx = tap - ky * K;
+            const int boff = (ky * PW + (kx & ~1) + lhi * 8) * 2;      // even part of the shift; an odd kx adds one element below
+#pragma unroll
+            for (int r = 0; r < TH; ++r) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 av[NCO], bv[NCI];
+#pragma unroll
+                    for (int i = 0; i < NCO; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Dy + arow[i] + (r * WB_TW + kk * 16) * 2);
+#pragma unroll
+                    for (int j = 0; j < NCI; ++j) {
+                        const unsigned* q = reinterpret_cast<const unsigned*>(Xs + brow[j] + boff + (r * PW + kk * 16) * 2);
+                        u32x4 w4;
+                        if (kx & 1) {
+                            const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                            w4 = (u32x4){__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                                         __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)};
+                        } else {
+                            w4 = (u32x4){q[0], q[1], q[2], q[3]};
+                        }
+                        bv[j] = __builtin_bit_cast(bf16x8, w4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NCO; ++i)
+#pragma unroll
+                        for (int j = 0; j < NCI; ++j)
+                            acc[tw][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[tw][i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* po = a.part + (long long)blockIdx.x * a.Cout * a.Cin * TAPS;
+#pragma unroll
+    for (int tw = 0; tw < TPW; ++tw) {
+        const int tap = wave * TPW + tw;
+        if (tap >= TAPS) break;
+#pragma unroll
+        for (int i = 0; i < NCO; ++i)
+#pragma unroll
+            for (int j = 0; j < NCI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi, ci = 32 * j + l31;
+                    if (co < a.Cout && ci < a.Cin) po[((long long)co * a.Cin + ci) * TAPS + tap] = acc[tw][i][j][r];
+                }
+    }
+}
+
 // dW[i] (= or +=) sum of the workgroup partials in a fixed order, in double (the second stage of conv_bwd.hip's weight gradient)
 __global__ __launch_bounds__(256) void k_wgrad_bf16_reduce(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw,
                                                            int accumulate) {
@@ -443,12 +577,15 @@ static int wb_nwg(int B, int H, int W, int k) {
     const long long tiles = (long long)mrx_cdiv(W, WB_TW) * mrx_cdiv(H, wb_th(k)) * B;
     return (int)(tiles < (long long)per_cu * n_cu ? tiles : (long long)per_cu * n_cu);
 }
+static bool wb_thin(int Cin, int Cout, int k, int dil) {   // the two thin dilation-1 layers of the RIM
+    return dil == 1 && ((k == 3 && Cin == 64 && Cout >= 1 && Cout <= 32) || (k == 5 && Cout == 64 && Cin >= 1 && Cin <= 32));
+}
 extern "C" int mrx_conv_wgrad_bf16_supported(int Cin, int Cout, int k, int dil) {
-    return Cin == 64 && Cout == 64 && ((k == 1 && dil == 1) || (k == 3 && dil == 2));
+    return (Cin == 64 && Cout == 64 && ((k == 1 && dil == 1) || (k == 3 && dil == 2))) || wb_thin(Cin, Cout, k, dil);
 }
 extern "C" int64_t mrx_conv_wgrad_bf16_work_floats(int B, int H, int W, int k) {
-    if (B < 1 || H < 1 || W < 1 || (k != 1 && k != 3)) return -1;
-    return (int64_t)wb_nwg(B, H, W, k) * 64 * 64 * k * k;
+    if (B < 1 || H < 1 || W < 1 || (k != 1 && k != 3 && k != 5)) return -1;
+    return (int64_t)wb_nwg(B, H, W, k) * 64 * 64 * k * k;      // an upper bound for the thin layers
 }
 template <int K, int DIL>
 static int wb_launch(const WgradBfArgs& a, int nwg, hipStream_t st) {
@@ -463,11 +600,50 @@ static int wb_launch(const WgradBfArgs& a, int nwg, hipStream_t st) {
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
+extern "C" int64_t mrx_conv_wgrad_bf16_any_work_floats(int B, int Cin, int Cout, int H, int W, int k) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (k != 1 && k != 3 && k != 5)) return -1;
+    return (int64_t)wb_nwg(B, H, W, k) * Cout * Cin * k * k;
+}
+template <int K, int NCO, int NCI, int TPW>
+static int wbg_launch(const WgradBfGArgs& a, int nwg, hipStream_t st) {
+    constexpr int PAD = (K - 1) / 2, PH = 8 + 2 * PAD, PW = WB_TW + 2 * PAD, XS = ((PH * PW * 2 + 255 - 16) / 256) * 256 + 16;
+    constexpr int NW = (K * K + TPW - 1) / TPW;
+    const size_t lds = (size_t)(a.Cout + 1) * (8 * WB_TW * 2 + 16) + (size_t)(a.Cin + 1) * XS;
+    static size_t attr = 0;
+    if (lds > 48 * 1024 && attr < lds) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_g<K, NCO, NCI, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    hipLaunchKernelGGL((k_conv_wgrad_bf16_g<K, NCO, NCI, TPW>), dim3(nwg), dim3(64 * NW), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// dw [Cout,Cin,k,k] for the shapes of mrx_conv_wgrad_bf16_supported (the 64 -> 64 layers and the two thin dilation-1 layers of the RIM)
+extern "C" int mrx_conv_wgrad_bf16_any(const float* x, const float* dy, float* dw, float* work, int B, int Cin, int Cout, int H, int W, int k,
+                                       int dil, int pad_mode, int accumulate, void* stream) {
+    MRX_REQUIRE(x && dy && dw && work, MRX_EINVAL, "mrx_conv_wgrad_bf16_any: null pointer");
+    MRX_REQUIRE(B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_wgrad_bf16_any: bad dims");
+    MRX_REQUIRE(mrx_conv_wgrad_bf16_supported(Cin, Cout, k, dil), MRX_EUNSUP, "mrx_conv_wgrad_bf16_any: Cin=%d Cout=%d k=%d dilation=%d", Cin, Cout,
+                k, dil);
+    if (!wb_thin(Cin, Cout, k, dil)) return mrx_conv_wgrad_bf16(x, dy, dw, work, B, H, W, k, dil, pad_mode, accumulate, stream);
+    WgradBfGArgs a;
+    a.x = x, a.dy = dy, a.part = work, a.B = B, a.Cin = Cin, a.Cout = Cout, a.H = H, a.W = W;
+    a.tiles_x = mrx_cdiv(W, WB_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, 8), a.pad_mode = pad_mode;
+    a.vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) % 16 == 0);
+    const int nwg = wb_nwg(B, H, W, k);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = k == 3 ? wbg_launch<3, 1, 2, 1>(a, nwg, st) : wbg_launch<5, 2, 1, 2>(a, nwg, st);
+    if (rc) return rc;
+    const long long total = (long long)Cout * Cin * k * k;
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
 extern "C" int mrx_conv_wgrad_bf16(const float* x, const float* dy, float* dw, float* work, int B, int H, int W, int k, int dil, int pad_mode,
                                    int accumulate, void* stream) {
     MRX_REQUIRE(x && dy && dw && work, MRX_EINVAL, "mrx_conv_wgrad_bf16: null pointer");
     MRX_REQUIRE(B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_wgrad_bf16: bad dims");
-    MRX_REQUIRE(mrx_conv_wgrad_bf16_supported(64, 64, k, dil), MRX_EUNSUP, "mrx_conv_wgrad_bf16: k=%d dilation=%d not instantiated", k, dil);
+    MRX_REQUIRE((k == 1 && dil == 1) || (k == 3 && dil == 2), MRX_EUNSUP, "mrx_conv_wgrad_bf16: k=%d dilation=%d not instantiated", k, dil);
     WgradBfArgs a;
     a.x = x, a.dy = dy, a.part = work, a.B = B, a.H = H, a.W = W;
     a.tiles_x = mrx_cdiv(W, WB_TW), a.tiles_y = mrx_cdiv(H, wb_th(k)), a.ntiles = a.tiles_x * a.tiles_y, a.pad_mode = pad_mode;

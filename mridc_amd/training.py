@@ -160,7 +160,7 @@ def _relu_bwd_acc(dy, dy2, y, h_prev, hh, acc_bias, acc_hh):
 
 
 def _wgrad_into(x, dy, k, dilation, pad_mode, grad, bf16):
-    if bf16 and ops.conv_wgrad_bf16_supported(int(x.shape[1]), int(dy.shape[1]), k, dilation):
+    if bf16 and ops.conv_wgrad_bf16_preferred(int(x.shape[1]), int(dy.shape[1]), k, dilation):
         ops.conv_wgrad_bf16(x, dy, k, dilation, pad_mode, out=grad, accumulate=True)
     else:
         ops.conv_wgrad(x, dy, k, dilation, pad_mode, out=grad, accumulate=True)
@@ -243,7 +243,7 @@ def _cascade_forward_backward(blk, eta, llg, tgt, wdev, sigma, bf16):
         d2 = torch.empty(B, 2, H, W, dtype=torch.float32, device=eta_t.device)
         _lib.check(L_.mrx_eta_grad_in(_lib.ptr(carry), _lib.ptr(gl), _lib.ptr(tot), _lib.ptr(d2), B, plane, _lib.stream_ptr()), "mrx_eta_grad_in")
         h_top = acts[-1][2]
-        ops.conv_wgrad(h_top, d2, final.kernel_size, final.dilation, ops.PAD_REPLICATE, out=_grad_of(fw), accumulate=True)
+        _wgrad_into(h_top, d2, final.kernel_size, final.dilation, ops.PAD_REPLICATE, _grad_of(fw), bf16)
         if fb is not None:
             _grad_of(fb).add_(d2.sum(dim=(0, 2, 3)))                  # two numbers; the model-zoo final conv has no bias
         dh = ag._dgrad(d2, fw, final.dilation, ops.PAD_REPLICATE, bf16 and ops.conv_bf16_supported(2, int(fw.shape[1]), final.kernel_size,

@@ -81,18 +81,22 @@ def test_indrnn_1x1_bf16_and_data_gradient(dev):
 
 
 @pytest.mark.parametrize("case", [(1, 19, 45, 3, 2, True), (2, 24, 64, 3, 2, False), (2, 13, 37, 1, 1, False), (1, 640, 372, 3, 2, True),
-                                  (1, 640, 372, 1, 1, False)], ids=lambda c: f"B{c[0]}_{c[1]}x{c[2]}_k{c[3]}d{c[4]}")
+                                  (1, 640, 372, 1, 1, False), (2, 19, 45, 3, 1, True, 64, 2), (1, 21, 70, 5, 1, True, 4, 64),
+                                  (1, 17, 33, 3, 1, False, 64, 7), (1, 640, 372, 3, 1, True, 64, 2), (1, 640, 372, 5, 1, True, 4, 64)],
+                         ids=lambda c: f"B{c[0]}_{c[1]}x{c[2]}_k{c[3]}d{c[4]}" + (f"_{c[6]}to{c[7]}" if len(c) > 6 else ""))
 def test_conv_wgrad_bf16(dev, case):
-    """dW of a 64 -> 64 convolution: bf16-rounded operands, exact products, fp32 tile sums, fixed-order double reduction."""
+    """dW of the RIM's convolutions (64 -> 64; the thin final 64 -> 2 and first 4 -> 64 layers with their odd tap shifts): bf16-rounded
+    operands, exact products, fp32 tile sums, fixed-order double reduction."""
     from mridc_amd import ops
-    B, H, W, k, dil, rep = case
+    B, H, W, k, dil, rep = case[:6]
+    cin, cout = (case[6], case[7]) if len(case) > 6 else (64, 64)
     g = torch.Generator().manual_seed(H + k)
-    x, dy = torch.randn(B, 64, H, W, generator=g), torch.randn(B, 64, H, W, generator=g)
+    x, dy = torch.randn(B, cin, H, W, generator=g), torch.randn(B, cout, H, W, generator=g)
     p = dil * (k - 1) // 2
 
     def ref(xx, dd):
         xx = xx.clone().requires_grad_(False)
-        w = torch.zeros(64, 64, k, k, dtype=xx.dtype, requires_grad=True)
+        w = torch.zeros(cout, cin, k, k, dtype=xx.dtype, requires_grad=True)
         xp = F.pad(xx, (p, p, p, p), mode="replicate" if rep else "constant") if p else xx
         F.conv2d(xp, w, None, dilation=dil).backward(dd)
         return w.grad

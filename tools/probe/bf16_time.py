@@ -47,3 +47,8 @@ print("wgrad 3x3 d2 64->64  : bf16 %.1f us | fp32 %.1f us" % (
     timeit(lambda: ops.conv_wgrad_bf16(x, dy, 3, 2, ops.PAD_REPLICATE), 30), timeit(lambda: ops.conv_wgrad(x, dy, 3, 2, ops.PAD_REPLICATE), 30)))
 print("wgrad 1x1 64->64     : bf16 %.1f us | fp32 %.1f us" % (
     timeit(lambda: ops.conv_wgrad_bf16(x, dy, 1, 1, ops.PAD_ZERO), 30), timeit(lambda: ops.conv_wgrad(x, dy, 1, 1, ops.PAD_ZERO), 30)))
+dy2, dy64 = r(B, 2, H, W), dy
+print("wgrad 3x3 64->2      : bf16 %.1f us | fp32 %.1f us" % (
+    timeit(lambda: ops.conv_wgrad_bf16(x, dy2, 3, 1, ops.PAD_REPLICATE), 30), timeit(lambda: ops.conv_wgrad(x, dy2, 3, 1, ops.PAD_REPLICATE), 30)))
+print("wgrad 5x5 4->64      : bf16 %.1f us | fp32 %.1f us" % (
+    timeit(lambda: ops.conv_wgrad_bf16(x4, dy64, 5, 1, ops.PAD_REPLICATE), 30), timeit(lambda: ops.conv_wgrad(x4, dy64, 5, 1, ops.PAD_REPLICATE), 30)))
