@@ -320,6 +320,9 @@ int64_t mrx_conv_wgrad_work_floats(int B, int Cin, int Cout, int H, int W, int k
 int mrx_conv_wgrad(const float* x, const float* dy, float* dw, float* work, int B, int Cin, int Cout, int H, int W, int k,
                    int dil, int pad_mode, int accumulate, void* stream);
 int mrx_reppad_fold(const float* g, float* out, int64_t planes, int H, int W, int pad, void* stream);
+/* the same fold when the interior of the gradient is in `out` already and only the frame of width pad is in g [planes, H + 2 pad, W + 2 pad]
+ * (mrx_conv2d_bf16_dgrad_rep): adds the frame onto the 2 (H + W) - 4 edge pixels of every plane */
+int mrx_reppad_fold_edges(const float* g, float* out, int64_t planes, int H, int W, int pad, void* stream);
 int64_t mrx_relu_bwd_work_floats(int C);
 int mrx_relu_bwd(const float* dy, const float* y, const float* h_prev, const float* hh, float* dpre, float* dh_prev,
                  float* sums, float* work, int B, int C, int64_t HW, void* stream);
@@ -351,6 +354,10 @@ int mrx_conv2d_bf16(const float* x, const void* packed, const float* bias, const
  *                        out [B,Cout,H + 2 ext,W + 2 ext]: with a transposed pack, the data gradient on the padded domain (then mrx_reppad_fold) */
 int mrx_conv2d_bf16_ext(const float* x, const void* packed, float* out, int B, int Cin, int Cout, int H, int W, int k, int dil, int ext,
                         void* stream);
+/*   mrx_conv2d_bf16_dgrad_rep  data gradient of a replicate-padded 'same' convolution: interior written straight into dx [B,Cout,H,W], the frame
+ *                        of width dil (k - 1) / 2 into frame [B,Cout,H + 2 p,W + 2 p]; follow with mrx_reppad_fold_edges(frame, dx, ...) */
+int mrx_conv2d_bf16_dgrad_rep(const float* dy, const void* packed, float* dx, float* frame, int B, int Cin, int Cout, int H, int W, int k,
+                              int dil, void* stream);
 /*   mrx_conv_wgrad_bf16  dw [64,64,k,k] (= or +=) sum over (b, pixel) of dy * padded x (the weight gradient of a 64 -> 64 'same' convolution),
  *                        bf16 operands, fp32 accumulation per workgroup, fixed-order double sum of the workgroup partials; k = 1, or k = 3 with
  *                        dilation 2 (mrx_conv_wgrad_bf16_supported); work: mrx_conv_wgrad_bf16_work_floats floats */

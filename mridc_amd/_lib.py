@@ -68,6 +68,8 @@ _SIGNATURES = {
     "mrx_conv_bf16_pack": ([_p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_conv2d_bf16": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_conv2d_bf16_ext": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_conv2d_bf16_dgrad_rep": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_reppad_fold_edges": ([_p, _p, _i64, _i, _i, _i, _p], _i),
     "mrx_conv_wgrad_bf16_supported": ([_i, _i, _i, _i], _i),
     "mrx_conv_wgrad_bf16_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_conv_wgrad_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),

@@ -37,10 +37,18 @@ def _dgrad(dy, weight, dilation, pad_mode, bf16):
     pad = int(dilation) * (k - 1) // 2
     if pad_mode == ops.PAD_ZERO or pad == 0:
         return ops.conv2d_bf16(dy, weight, None, dilation, ops.PAD_ZERO, transposed=True)
-    g = ops.conv_dgrad_bf16_ext(dy, weight, dilation, pad)              # dy read as if zero-extended: no padded copy
-    B, Cin, H, W = int(dy.shape[0]), int(weight.shape[1]), int(dy.shape[2]), int(dy.shape[3])
+    # replicate padding: interior of the gradient straight into dx, its frame into a side buffer, then the edge pixels (2 launches; the
+    # frame buffer's interior is never written or read)
+    dy = _lib.f32c(dy)
+    B, Cout_w, H, W = int(dy.shape[0]), int(weight.shape[0]), int(dy.shape[2]), int(dy.shape[3])
+    Cin = int(weight.shape[1])
+    packed = ops._conv_bf16_pack(weight, True)
     out = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dy.device)
-    _lib.check(_lib.lib().mrx_reppad_fold(_lib.ptr(g), _lib.ptr(out), B * Cin, H, W, pad, _lib.stream_ptr()), "mrx_reppad_fold")
+    frame = torch.empty(B, Cin, H + 2 * pad, W + 2 * pad, dtype=torch.float32, device=dy.device)
+    L = _lib.lib()
+    _lib.check(L.mrx_conv2d_bf16_dgrad_rep(_lib.ptr(dy), _lib.ptr(packed), _lib.ptr(out), _lib.ptr(frame), B, Cout_w, Cin, H, W, k, int(dilation),
+                                           _lib.stream_ptr()), "mrx_conv2d_bf16_dgrad_rep")
+    _lib.check(L.mrx_reppad_fold_edges(_lib.ptr(frame), _lib.ptr(out), B * Cin, H, W, pad, _lib.stream_ptr()), "mrx_reppad_fold_edges")
     return out
 
 

@@ -40,6 +40,8 @@ struct ConvBfArgs {
     int B, Cin, Cout, H, W, tiles_x, ntiles, pad_mode, act;
     float slope;
     int ext, Hin, Win;     // the input is [Hin, Win] = [H - 2 ext, W - 2 ext], read as if zero-extended by `ext` on every side (data gradients)
+    float* interior;       // not null: outputs inside the original image go to interior [B,Cout,Hin,Win] (the replicate-padding fold leaves
+                           // them unchanged), only the frame of width ext goes to `out` [B,Cout,H,W] for mrx_reppad_fold_edges
 };
 
 __host__ __device__ constexpr int cb_ps(int CPAD) { return CPAD == 8 ? 16 : CPAD * 2 + 16; }   // bytes per pixel in the LDS tile
@@ -122,7 +124,17 @@ __global__ __launch_bounds__(CB_NT, 4) void k_conv_bf16(ConvBfArgs a) {
     // ---- epilogue: bias, optional IndRNN term, activation ---------------------------------------------------------------------------------
     const int oy = h0 + wave, ox = w0 + l31;
     if (oy < a.H && ox < a.W) {
-        const long long obase = (long long)b * a.Cout * plane + (long long)oy * a.W + ox;
+        long long obase = (long long)b * a.Cout * plane + (long long)oy * a.W + ox;
+        long long cstride = plane;
+        float* dst = a.out;
+        if (a.interior) {
+            const int iy = oy - a.ext, ix = ox - a.ext;
+            if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                dst = a.interior;
+                cstride = iplane;
+                obase = (long long)b * a.Cout * iplane + (long long)iy * a.Win + ix;
+            }
+        }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(CB_NT, 4) void k_conv_bf16(ConvBfArgs a) {
                         v = v > 0.f ? v : 0.f;
                     else if (a.act == MRX_ACT_LEAKY)
                         v = v > 0.f ? v : v * a.slope;
-                    a.out[obase + (long long)co * plane] = v;
+                    dst[obase + (long long)co * cstride] = v;
                 }
             }
     }
@@ -211,7 +223,8 @@ static int cb_launch_nct(const ConvBfArgs& a, hipStream_t st) {
 
 // act(conv(x; w) + bias [+ hh * hprev]) with bf16 operands; 'same' size, stride 1; packed from mrx_conv_bf16_pack
 static int conv2d_bf16_impl(const float* x, const void* packed, const float* bias, const float* hh, const float* hprev, float* out, int B,
-                           int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, int ext, void* stream);
+                           int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, int ext, void* stream,
+                           float* interior = nullptr);
 extern "C" int mrx_conv2d_bf16(const float* x, const void* packed, const float* bias, const float* hh, const float* hprev, float* out, int B,
                                int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, void* stream) {
     return conv2d_bf16_impl(x, packed, bias, hh, hprev, out, B, Cin, Cout, H, W, k, dil, pad_mode, act, slope, 0, stream);
@@ -225,8 +238,19 @@ extern "C" int mrx_conv2d_bf16_ext(const float* x, const void* packed, float* ou
     return conv2d_bf16_impl(x, packed, nullptr, nullptr, nullptr, out, B, Cin, Cout, H + 2 * ext, W + 2 * ext, k, dil, MRX_PAD_ZERO, MRX_ACT_NONE,
                             0.f, ext, stream);
 }
+// Data gradient of a replicate-padded convolution in two launches: this one writes the gradient's interior straight into dx [B,Cout,H,W] and
+// its frame of width ext into `frame` [B,Cout,H + 2 ext,W + 2 ext] (interior of `frame` untouched); mrx_reppad_fold_edges then adds the
+// frame onto the edge pixels.  Replaces conv_ext + mrx_reppad_fold (which re-reads and re-writes the whole gradient).
+extern "C" int mrx_conv2d_bf16_dgrad_rep(const float* dy, const void* packed, float* dx, float* frame, int B, int Cin, int Cout, int H, int W,
+                                         int k, int dil, void* stream) {
+    const int ext = dil * (k - 1) / 2;
+    MRX_REQUIRE(dx && frame, MRX_EINVAL, "mrx_conv2d_bf16_dgrad_rep: null pointer");
+    return conv2d_bf16_impl(dy, packed, nullptr, nullptr, nullptr, frame, B, Cin, Cout, H + 2 * ext, W + 2 * ext, k, dil, MRX_PAD_ZERO,
+                            MRX_ACT_NONE, 0.f, ext, stream, dx);
+}
 static int conv2d_bf16_impl(const float* x, const void* packed, const float* bias, const float* hh, const float* hprev, float* out, int B,
-                           int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, int ext, void* stream) {
+                           int Cin, int Cout, int H, int W, int k, int dil, int pad_mode, int act, float slope, int ext, void* stream,
+                           float* interior) {
     MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv2d_bf16: null pointer");
     MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1 && H > 2 * ext && W > 2 * ext, MRX_EINVAL, "mrx_conv2d_bf16: bad dims");
     MRX_REQUIRE(cb_shape_ok(Cin, Cout, k, dil), MRX_EUNSUP, "mrx_conv2d_bf16: Cin=%d Cout=%d k=%d dilation=%d not instantiated", Cin, Cout, k, dil);
@@ -240,7 +264,7 @@ static int conv2d_bf16_impl(const float* x, const void* packed, const float* bia
     a.tiles_x = mrx_cdiv(W, CB_TW);
     a.ntiles = a.tiles_x * mrx_cdiv(H, CB_TH);
     a.pad_mode = pad_mode, a.act = act, a.slope = slope;
-    a.ext = ext, a.Hin = H - 2 * ext, a.Win = W - 2 * ext;
+    a.ext = ext, a.Hin = H - 2 * ext, a.Win = W - 2 * ext, a.interior = interior;
     hipStream_t st = (hipStream_t)stream;
     const int cp = cb_cpad(Cin);
     if (k == 1) return cb_launch_nct<1, 1, 64>(a, st);

@@ -422,6 +422,45 @@ __global__ void k_reppad_fold(const float* __restrict__ g, float* __restrict__ o
         out[o] = s;
     }
 }
+// The same fold when the interior of the gradient is in `out` already (mrx_conv2d_bf16_dgrad_rep): only the edge pixels change, each
+// receives the frame positions of g that clamp to it (the interior position itself excluded).  2 (H + W) - 4 pixels per plane.
+__global__ void k_reppad_fold_edges(const float* __restrict__ g, float* __restrict__ out, long long planes, int H, int W, int pad) {
+    const int per = 2 * W + 2 * (H - 2 > 0 ? H - 2 : 0);
+    const long long total = planes * per;
+    const int PW = W + 2 * pad, PH = H + 2 * pad;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long p = o / per;
+        int e = (int)(o - p * per), h, w;
+        if (e < W) {
+            h = 0, w = e;
+        } else if (e < 2 * W) {
+            h = H - 1, w = e - W;
+        } else {
+            e -= 2 * W;
+            h = 1 + (e >> 1), w = (e & 1) ? W - 1 : 0;
+        }
+        if (H == 1 && e >= W && e < 2 * W) continue;          // a single row is listed once
+        if (W == 1 && e >= 2 * W && (e & 1)) continue;        // a single column is listed once
+        const int i0 = h == 0 ? 0 : h + pad, i1 = h == H - 1 ? PH - 1 : h + pad;
+        const int j0 = w == 0 ? 0 : w + pad, j1 = w == W - 1 ? PW - 1 : w + pad;
+        const float* gp = g + p * (long long)PH * PW;
+        float s = 0.f;
+        for (int i = i0; i <= i1; ++i)
+            for (int j = j0; j <= j1; ++j)
+                if (i != h + pad || j != w + pad) s += gp[(long long)i * PW + j];
+        out[p * (long long)H * W + (long long)h * W + w] += s;
+    }
+}
+extern "C" int mrx_reppad_fold_edges(const float* g, float* out, int64_t planes, int H, int W, int pad, void* stream) {
+    MRX_REQUIRE(g && out && planes >= 0 && H >= 1 && W >= 1 && pad >= 0, MRX_EINVAL, "mrx_reppad_fold_edges: bad argument");
+    const long long total = planes * (2ll * W + 2ll * (H - 2 > 0 ? H - 2 : 0));
+    if (total == 0 || pad == 0) return MRX_OK;
+    const long long nb = (total + 255) / 256;
+    hipLaunchKernelGGL(k_reppad_fold_edges, dim3((unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, (hipStream_t)stream, g, out,
+                       (long long)planes, H, W, pad);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
 extern "C" int mrx_reppad_fold(const float* g, float* out, int64_t planes, int H, int W, int pad, void* stream) {
     MRX_REQUIRE(g && out && planes >= 0 && H >= 1 && W >= 1 && pad >= 0, MRX_EINVAL, "mrx_reppad_fold: bad argument");
     const long long total = planes * H * W;

@@ -80,6 +80,27 @@ def test_indrnn_1x1_bf16_and_data_gradient(dev):
     assert rel_l2(got, exact) <= 2e-6
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 19, 45, 3, 2), (1, 64, 4, 24, 40, 5, 1), (1, 2, 64, 11, 37, 3, 1), (1, 64, 64, 1, 40, 3, 2),
+                                  (1, 64, 64, 33, 1, 3, 1), (1, 64, 64, 2, 2, 5, 1), (1, 64, 64, 640, 372, 3, 2)],
+                         ids=lambda c: f"{c[1]}to{c[2]}_k{c[5]}d{c[6]}_{c[3]}x{c[4]}")
+def test_bf16_data_gradient_replicate_padding(dev, case):
+    """dx of y = conv(replicate_pad(x), w): interior written by the convolution, frame folded onto the edge pixels
+    (mrx_conv2d_bf16_dgrad_rep + mrx_reppad_fold_edges) -- against autograd of the same convolution on bf16-rounded operands, and against the
+    fp32 data-gradient kernel with its full-plane fold; planes of one row, one column and smaller than the padding included."""
+    from mridc_amd import autograd as ag, ops
+    B, Cout, Cin, H, W, k, dil = case        # the forward layer maps Cin -> Cout; dy has Cout channels
+    g = torch.Generator().manual_seed(H * 7 + W)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    p = dil * (k - 1) // 2
+    x = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(F.pad(x, (p, p, p, p), mode="replicate"), _bf(w), dilation=dil)
+    (exact,) = torch.autograd.grad(y, x, _bf(dy))
+    got = ag._dgrad(dy.to(dev), w.to(dev), dil, ops.PAD_REPLICATE, True)
+    assert rel_l2(got, exact) <= 2e-6, rel_l2(got, exact)
+    assert_close(got, ops.conv_dgrad(dy.to(dev), w.to(dev), dil, ops.PAD_REPLICATE), 1e-2, "bf16 data gradient vs the fp32 kernel")
+
+
 @pytest.mark.parametrize("case", [(1, 19, 45, 3, 2, True), (2, 24, 64, 3, 2, False), (2, 13, 37, 1, 1, False), (1, 640, 372, 3, 2, True),
                                   (1, 640, 372, 1, 1, False), (2, 19, 45, 3, 1, True, 64, 2), (1, 21, 70, 5, 1, True, 4, 64),
                                   (1, 17, 33, 3, 1, False, 64, 7), (1, 640, 372, 3, 1, True, 64, 2), (1, 640, 372, 5, 1, True, 4, 64)],
