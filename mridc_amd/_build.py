@@ -19,6 +19,7 @@ SOURCES = [
     ("conv.hip", []),
     ("rim_layer.hip", []),
     ("rim_layer_wino.hip", []),
+    ("rim_layer1_sb.hip", []),
     ("gated_cell.hip", []),
     ("conv_bwd.hip", []),
     ("conv_bf16.hip", []),

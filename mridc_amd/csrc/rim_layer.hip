@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "mrx_common.h"
+#include "rim_layer1_sb.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -86,12 +87,16 @@ __global__ void k_rim_pack(const float* __restrict__ w, const float* __restrict_
 }
 
 static int rl_ck(int Cin) { return Cin <= 4 ? 4 : 8; }
+// the first RIM layer's shape (5x5, <= 4 input channels): its pack carries a second section for k_rim_layer1_sb (rim_layer1_sb.hip)
+static bool rl_sb_shape(int Cin, int k) { return Cin <= 4 && k == 5; }
+static int64_t rl_fp32_pack_floats(int Cin, int k) {
+    const int CK = rl_ck(Cin);
+    return (int64_t)((Cin + CK - 1) / CK) * k * k * CK * RL_F + RL_F * RL_F;
+}
 
 extern "C" int64_t mrx_rim_layer_pack_floats(int Cin, int F, int k) {
     if (F != RL_F || Cin < 1 || k < 1) return -1;
-    const int CK = rl_ck(Cin);
-    const int nchunks = (Cin + CK - 1) / CK;
-    return (int64_t)nchunks * k * k * CK * RL_F + RL_F * RL_F;
+    return rl_fp32_pack_floats(Cin, k) + (rl_sb_shape(Cin, k) ? MRX_L1SB_PACK_FLOATS : 0);
 }
 
 extern "C" int mrx_rim_layer_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, int F, int k, void* stream) {
@@ -104,6 +109,7 @@ extern "C" int mrx_rim_layer_pack(const float* w_conv, const float* w_ih, float*
     hipLaunchKernelGGL(k_rim_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, packed, Cin, k * k,
                        CK, nchunks);
     MRX_LAUNCH_CHECK();
+    if (rl_sb_shape(Cin, k)) return mrx_l1sb_pack(w_conv, w_ih, packed + rl_fp32_pack_floats(Cin, k), Cin, (hipStream_t)stream);
     return MRX_OK;
 }
 
@@ -522,6 +528,16 @@ extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, 
     a.stagger = stagger;
     hipStream_t st = (hipStream_t)stream;
     const bool small = rl_ck(Cin) == 4;
+    if (rl_sb_shape(Cin, k) && dil == 1 && !ablate && !getenv("MRX_TRACE")) {
+        const char* e = getenv("MRX_LAYER1_FP32");   // 1: the fp32-MFMA kernel (cross-check)
+        if (!(e && atoi(e))) {
+            MrxL1sbArgs s;
+            s.x = x, s.packed = packed + rl_fp32_pack_floats(Cin, k), s.b_conv = b_conv, s.b_ih = b_ih, s.hh = hh, s.hprev = h_prev, s.hnew = h_new;
+            s.B = B, s.Cin = Cin, s.H = H, s.W = W, s.tiles_x = a.tiles_x, s.ntiles = a.tiles_x * mrx_cdiv(H, MRX_L1SB_TH);
+            s.eta2 = a.eta2, s.part = a.part, s.part_stride = a.part_stride, s.nparts = a.nparts, s.post = a.post;
+            return mrx_l1sb_launch(s, st);
+        }
+    }
 #define RL_CASE(KK, DD)                                                       \
     if (k == KK && dil == DD)                                                 \
         return small ? launch_rim_layer<KK, DD, 4>(a, st) : launch_rim_layer<KK, DD, 8>(a, st);

@@ -1,0 +1,25 @@
+// rim_layer1_sb.h -- internal interface of the split-bf16 first RIM layer (rim_layer1_sb.hip), used by rim_layer.hip's C entry points.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define MRX_L1SB_PACK_FLOATS 16896   // three bf16 terms of the 5x5 (28 taps x 4 channels) and 1x1 weights in A-operand lane order
+
+struct MrxL1sbArgs {
+    const float* x;        // [B,Cin,H,W], Cin <= 4 (unused when eta2 is set)
+    const float* packed;   // mrx_l1sb_pack
+    const float* b_conv;   // [64] or null
+    const float* b_ih;     // [64] or null
+    const float* hh;       // [64]
+    const float* hprev;    // [B,64,H,W] or null
+    float* hnew;           // [B,64,H,W]
+    int B, Cin, H, W, tiles_x, ntiles;
+    const float2* eta2;    // [B,H,W] complex or null: input = (eta, post * sum_k part_k), the gradient's last pass done by the tile loader
+    const float2* part;    // [nparts][B][H][W] complex
+    long long part_stride;
+    int nparts;
+    float post;
+};
+
+int mrx_l1sb_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, hipStream_t st);
+#define MRX_L1SB_TH 16   // image rows per workgroup tile (ntiles / tiles_x are counted in 16 x 32 tiles)
+int mrx_l1sb_launch(const MrxL1sbArgs& a, hipStream_t st);

@@ -135,6 +135,39 @@ def test_tuned_fused_rim_layer_packed(shape, dev):
     assert_close(got0, ref0, 1e-5, "tuned fused layer, no biases, h_prev = None")
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 640, 372), (2, 4, 37, 75), (1, 2, 19, 33), (3, 1, 16, 32), (1, 4, 5, 3), (1, 3, 130, 320)])
+def test_first_rim_layer_split_bf16_has_fp32_accuracy(shape, dev, monkeypatch):
+    """The first RIM layer on the bf16 matrix pipe (k_rim_layer1_sb: every fp32 operand as the exact sum of three bf16 terms, six term
+    products per multiply) against a float64 reference: its error must be that of the fp32-MFMA kernel (MRX_LAYER1_FP32=1), and the two
+    kernels must agree to fp32 round-off.  Ragged tiles (W % 32, H % 16), fewer than four input channels, batches, no h_prev."""
+    import torch.nn.functional as Fn
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    B, Cin, H, W = shape
+    F_ = 64
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wc = torch.randn(F_, Cin, 5, 5, generator=g) / (Cin * 25) ** 0.5
+    bc = torch.randn(F_, generator=g) * 0.1
+    wi = torch.randn(F_, F_, 1, 1, generator=g) / F_ ** 0.5
+    bi = torch.randn(F_, generator=g) * 0.1
+    hh = torch.randn(1, F_, 1, 1, generator=g) * 0.5
+    hp = torch.randn(B, F_, H, W, generator=g).relu()
+    packed = ops.rim_layer_pack(wc.to(dev), wi.to(dev))
+    for with_state in (True, False):
+        ref = Fn.relu(Fn.conv2d(Fn.pad(x.double(), (2, 2, 2, 2), mode="replicate"), wc.double(), bc.double()))
+        ref = Fn.conv2d(ref, wi.double(), bi.double())
+        ref = Fn.relu(ref + hh.double() * hp.double() if with_state else ref)
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("MRX_LAYER1_FP32", mode)
+            out[mode] = ops.rim_layer_indrnn_packed(x.to(dev), packed, F_, 5, 1, bc.to(dev), bi.to(dev), hh.to(dev),
+                                                    hp.to(dev) if with_state else None).cpu()
+        e_sb, e_fp = rel_l2(out["0"], ref), rel_l2(out["1"], ref)
+        assert e_fp <= 4e-7 and e_sb <= 4e-7 and e_sb <= 1.5 * e_fp + 2e-8, (e_sb, e_fp)
+        assert rel_l2(out["0"], out["1"]) <= 5e-7
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 13, 18), (1, 64, 24, 70), (1, 7, 17, 19), (1, 64, 8, 32), (3, 20, 1, 1), (1, 64, 40, 128),
                                    (1, 9, 2, 3), (1, 64, 33, 61), (1, 64, 24, 72), (2, 16, 19, 36), (1, 8, 9, 4), (1, 12, 5, 100),
                                    (1, 64, 64, 372)])

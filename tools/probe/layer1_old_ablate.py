@@ -1,0 +1,19 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from mridc_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+B, F, H, W = 1, 64, 640, 372
+r = lambda *s: torch.randn(*s, generator=g).to(dev)
+eta, part, hp = r(B, H, W, 2), r(3, B, H, W, 2), r(B, F, H, W).relu()
+pk1 = ops.rim_layer_pack(r(F, 4, 5, 5) / 10, r(F, F, 1, 1) / 8)
+bc, bi, hh = r(F), r(F), r(1, F, 1, 1)
+fn = lambda: ops.rim_layer_indrnn_packed_llg(eta, part, 3, 1.0, pk1, F, 5, 1, bc, bi, hh, hp)
+for _ in range(10): fn()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(200): fn()
+e.record(); torch.cuda.synchronize()
+print("MRX_ABLATE=%s: %.2f us" % (os.environ.get("MRX_ABLATE"), 5 * s.elapsed_time(e)))
