@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16), no sparsity
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak
 
 
@@ -722,9 +723,17 @@ def main():
         ms372, n372 = timer.mean_ms("llg372")
         if ms372:
             msl, nl = ms372, n372
-        # whole regulariser (layer 1 + layer 2 + final conv) as issued on the matrix / vector pipes against the fp32 peak
+        # whole regulariser (layer 1 + layer 2 + final conv) as issued on the matrix / vector pipes.  Layer 1 runs on the bf16 matrix pipe
+        # (k_rim_layer1_sb: three-term bf16 operand split, 6 term products per multiply, 132 MFMAs of 32x32x16 per 32 pixels) unless
+        # MRX_LAYER1_FP32=1 selects the fp32-MFMA kernel: its issued work is priced against the dense bf16 peak, the rest against the
+        # fp32 peak, and `frac_issued` is the pipe time so priced over the measured time.
         flops_reg = 105216.0 * npix * B                     # 25.05 GFLOP per slice-step (direct form)
-        issued_reg = flops_reg - (flops2 - executed)
+        flops1 = 2.0 * (F_hidden * 4 * 25 + F_hidden * F_hidden) * npix * B
+        l1_bf16 = F_hidden == 64 and os.environ.get("MRX_LAYER1_FP32", "0") in ("", "0")
+        issued1_bf16 = (132 * 32 * 32 * 16 * 2 / 32.0) * npix * B if l1_bf16 else 0.0
+        issued_reg = flops_reg - (flops2 - executed) - (flops1 if l1_bf16 else 0.0)      # fp32 part
+        pipe_ms = lambda f32, b16: 1e3 * (f32 / (PEAK_FP32_MFMA_TFLOPS * 1e12) + b16 / (PEAK_BF16_MFMA_TFLOPS * 1e12))  # noqa: E731
+        final_flops = 2.0 * F_hidden * 2 * 9 * npix * B
         t_reg = (ms1 or 0) + (ms2 or 0) + (msf or 0)
         roofline = dict(bound="mfma", kernel=kname,
                         achieved=tf(executed), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
@@ -736,15 +745,20 @@ def main():
                         traffic_kernel=traffic.get("_kernels", {}).get("conv_layer2_wino" if msw else "conv_layer2"),
                         traffic_source=traffic.get("_source"), algorithmic_bytes=3.0 * F_hidden * npix * B * 4,
                         launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
-                        regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_gflop=issued_reg / 1e9,
-                                         frac_issued=(issued_reg / (t_reg * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if t_reg else None,
-                                         note="all three kernels of a step (layer 1, layer 2, final conv); the 64->2 final conv runs on the "
-                                              "vector ALUs (2 of 32 MFMA rows would be used), its 0.55 GFLOP and its time are included here",
+                        regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_fp32_gflop=issued_reg / 1e9,
+                                         issued_bf16_gflop=issued1_bf16 / 1e9,
+                                         frac_issued=(pipe_ms(issued_reg, issued1_bf16) / t_reg) if t_reg else None,
+                                         note="all three kernels of a step: layer 1 (bf16 matrix pipe, fp32 results via the three-term split), "
+                                              "layer 2 (fp32 MFMA, Winograd), final conv 64->2 on the vector ALUs (2 of 32 MFMA rows would be "
+                                              "used; its 0.55 GFLOP counted at the fp32 rate).  frac_issued = (fp32 work / fp32 peak + bf16 work / "
+                                              "dense bf16 peak) / measured time",
+                                         layer1_ms=ms1, layer1_kernel="k_rim_layer1_sb" if l1_bf16 else "k_rim_layer<5,1,4>",
+                                         layer1_frac_issued=(pipe_ms(0.0 if l1_bf16 else flops1, issued1_bf16) / ms1) if ms1 else None,
+                                         layer1_hbm_frac=((2.0 * F_hidden + 8.0) * 4 * npix * B / (ms1 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms1 else None,   # h_prev in, h out, (eta, partial sums)
                                          # the two kernels that run on the matrix cores, on their own
                                          mfma_kernels_ms=(ms1 or 0) + (ms2 or 0),
-                                         mfma_kernels_issued_gflop=(issued_reg - 2.0 * F_hidden * 2 * 9 * npix * B) / 1e9,
-                                         mfma_kernels_frac_issued=((issued_reg - 2.0 * F_hidden * 2 * 9 * npix * B) / (((ms1 or 0) + (ms2 or 0)) * 1e-3)
-                                                                   / 1e12 / PEAK_FP32_MFMA_TFLOPS) if (ms1 and ms2) else None))
+                                         mfma_kernels_frac_issued=(pipe_ms(issued_reg - final_flops, issued1_bf16) / ((ms1 or 0) + (ms2 or 0)))
+                                         if (ms1 and ms2) else None))
         bytes_llg = (25.0 + 16.0 * C) * npix * B     # compulsory bytes of one log_likelihood_gradient
         # the formulation executed for 1-D masks reads yt = IFFT_H(y) instead of y: the same (25+16C)N compulsory bytes per step
         # (plus one column pass per slice, outside the step, to make yt)
