@@ -1,0 +1,170 @@
+"""Drop-in for `mridc.collections.reconstruction.models.didn.didn` (reference didn/didn.py:10-325): Subpixel, ReconBlock, DUB, DIDN --
+inference path.  The containers are the reference's (`nn.Conv2d` / `nn.PReLU` under the same attribute names, so state_dicts are
+interchangeable, including the doubled entries of `Sequential(*[conv, PReLU] * 2)`); every convolution runs on the HIP kernels
+(`ops.conv2d`: Winograd 3x3 into 64-channel blocks, the generic MFMA kernel otherwise) with bias and PReLU in the kernel's epilogue.
+Stride-2 convolutions are the stride-1 convolution sampled at even positions (3x3, padding 1: identical values)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mridc_amd import ops
+
+_SLOPES = {}
+
+
+def _prelu_slope(mod):
+    """Slope of a single-parameter PReLU as a host float, read back once per parameter version."""
+    if mod.weight.numel() != 1:
+        raise NotImplementedError("mridc_amd DIDN: per-channel PReLU is not on the HIP path")
+    key = (id(mod), mod.weight.data_ptr(), mod.weight._version)
+    hit = _SLOPES.get(id(mod))
+    if hit is None or hit[0] != key:
+        hit = (key, float(mod.weight.detach().reshape(-1)[0]))
+        _SLOPES[id(mod)] = hit
+    return hit[1]
+
+
+def _conv(conv, x, prelu=None):
+    """One nn.Conv2d container (3x3 padding 1 or 1x1 padding 0; stride 1 or 2) on the HIP kernel, optionally followed by a PReLU."""
+    k, s = conv.kernel_size[0], conv.stride[0]
+    if conv.kernel_size[0] != conv.kernel_size[1] or conv.padding[0] != (k - 1) // 2 or conv.dilation[0] != 1 or s not in (1, 2):
+        raise NotImplementedError(f"mridc_amd DIDN: convolution {conv} is not on the HIP path")
+    act, slope = (ops.ACT_LEAKY, _prelu_slope(prelu)) if prelu is not None else (ops.ACT_NONE, 0.0)
+    out = ops.conv2d(x, conv.weight, conv.bias, 1, ops.PAD_ZERO, act, slope)
+    return out[:, :, ::2, ::2].contiguous() if s == 2 else out
+
+
+def _seq(seq, x):
+    """A Sequential of (conv, PReLU) pairs."""
+    mods = list(seq)
+    for i in range(0, len(mods), 2):
+        x = _conv(mods[i], x, mods[i + 1])
+    return x
+
+
+class Subpixel(nn.Module):
+    """didn.py:10-39: convolution into upscale_factor^2 x the channels, PixelShuffle."""
+
+    def __init__(self, in_channels, out_channels, upscale_factor, kernel_size, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels * upscale_factor ** 2, kernel_size=kernel_size, padding=padding)
+        self.pixelshuffle = nn.PixelShuffle(upscale_factor)
+
+    def forward(self, x):
+        return self.pixelshuffle(_conv(self.conv, x))
+
+
+class ReconBlock(nn.Module):
+    """didn.py:42-86."""
+
+    def __init__(self, in_channels, num_convs):
+        super().__init__()
+        self.convs = nn.ModuleList([nn.Sequential(*[nn.Conv2d(in_channels, in_channels, kernel_size=3, padding=1), nn.PReLU()])
+                                    for _ in range(num_convs - 1)])
+        self.convs.append(nn.Conv2d(in_channels, in_channels, kernel_size=3, padding=1))
+        self.num_convs = num_convs
+
+    def forward(self, input_data):
+        output = input_data
+        for idx in range(self.num_convs - 1):
+            output = _seq(self.convs[idx], output)
+        return input_data + _conv(self.convs[self.num_convs - 1], output)
+
+
+class DUB(nn.Module):
+    """Down-up block, didn.py:89-208."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        c = in_channels
+        self.conv1_1 = nn.Sequential(*[nn.Conv2d(c, c, kernel_size=3, padding=1), nn.PReLU()] * 2)   # the same pair twice (didn.py:115)
+        self.down1 = nn.Conv2d(c, c * 2, kernel_size=3, stride=2, padding=1)
+        self.conv2_1 = nn.Sequential(*[nn.Conv2d(c * 2, c * 2, kernel_size=3, padding=1), nn.PReLU()])
+        self.down2 = nn.Conv2d(c * 2, c * 4, kernel_size=3, stride=2, padding=1)
+        self.conv3_1 = nn.Sequential(*[nn.Conv2d(c * 4, c * 4, kernel_size=3, padding=1), nn.PReLU()])
+        self.up1 = nn.Sequential(*[Subpixel(c * 4, c * 2, 2, 1, 0)])
+        self.conv_agg_1 = nn.Conv2d(c * 4, c * 2, kernel_size=1)
+        self.conv2_2 = nn.Sequential(*[nn.Conv2d(c * 2, c * 2, kernel_size=3, padding=1), nn.PReLU()])
+        self.up2 = nn.Sequential(*[Subpixel(c * 2, c, 2, 1, 0)])
+        self.conv_agg_2 = nn.Conv2d(c * 2, c, kernel_size=1)
+        self.conv1_2 = nn.Sequential(*[nn.Conv2d(c, c, kernel_size=3, padding=1), nn.PReLU()] * 2)
+        self.conv_out = nn.Sequential(*[nn.Conv2d(c, c, kernel_size=3, padding=1), nn.PReLU()])
+
+    @staticmethod
+    def pad(x):
+        """didn.py:143-162: reflect-pad odd heights / widths by one."""
+        padding = [0, 0, 0, 0]
+        if x.shape[-2] % 2 != 0:
+            padding[3] = 1
+        if x.shape[-1] % 2 != 0:
+            padding[1] = 1
+        if sum(padding) != 0:
+            x = F.pad(x, padding, "reflect")
+        return x
+
+    @staticmethod
+    def crop_to_shape(x, shape):
+        """didn.py:164-183."""
+        h, w = x.shape[-2:]
+        if h > shape[0]:
+            x = x[:, :, : shape[0], :]
+        if w > shape[1]:
+            x = x[:, :, :, : shape[1]]
+        return x
+
+    def forward(self, x):
+        x1 = self.pad(x)
+        x1 = x1 + _seq(self.conv1_1, x1)
+        x2 = _conv(self.down1, x1)
+        x2 = x2 + _seq(self.conv2_1, x2)
+        out = _conv(self.down2, x2)
+        out = out + _seq(self.conv3_1, out)
+        out = self.up1(out)
+        out = torch.cat([x2, self.crop_to_shape(out, x2.shape[-2:])], dim=1)
+        out = _conv(self.conv_agg_1, out)
+        out = out + _seq(self.conv2_2, out)
+        out = self.up2(out)
+        out = torch.cat([x1, self.crop_to_shape(out, x1.shape[-2:])], dim=1)
+        out = _conv(self.conv_agg_2, out)
+        out = out + _seq(self.conv1_2, out)
+        return x + self.crop_to_shape(_seq(self.conv_out, out), x.shape[-2:])
+
+
+class DIDN(nn.Module):
+    """Deep iterative down-up network, didn.py:211-325."""
+
+    def __init__(self, in_channels: int, out_channels: int, hidden_channels: int = 128, num_dubs: int = 6, num_convs_recon: int = 9,
+                 skip_connection: bool = False):
+        super().__init__()
+        h = hidden_channels
+        self.conv_in = nn.Sequential(*[nn.Conv2d(in_channels, h, kernel_size=3, padding=1), nn.PReLU()])
+        self.down = nn.Conv2d(h, h, kernel_size=3, stride=2, padding=1)
+        self.dubs = nn.ModuleList([DUB(in_channels=h, out_channels=h) for _ in range(num_dubs)])
+        self.recon_block = ReconBlock(in_channels=h, num_convs=num_convs_recon)
+        self.recon_agg = nn.Conv2d(h * num_dubs, h, kernel_size=1)
+        self.conv = nn.Sequential(*[nn.Conv2d(h, h, kernel_size=3, padding=1), nn.PReLU()])
+        self.up2 = Subpixel(h, h, 2, 1)
+        self.conv_out = nn.Conv2d(h, out_channels, kernel_size=3, padding=1)
+        self.num_dubs = num_dubs
+        self.skip_connection = (in_channels == out_channels) and skip_connection
+
+    crop_to_shape = staticmethod(DUB.crop_to_shape)
+
+    def forward(self, x, channel_dim=1):
+        out = _seq(self.conv_in, x)
+        out = _conv(self.down, out)
+        dub_outs = []
+        for dub in self.dubs:
+            out = dub(out)
+            dub_outs.append(out)
+        out = [self.recon_block(dub_out) for dub_out in dub_outs]
+        out = _conv(self.recon_agg, torch.cat(out, dim=channel_dim))
+        out = _seq(self.conv, out)
+        out = self.up2(out)
+        out = _conv(self.conv_out, out)
+        out = self.crop_to_shape(out, x.shape[-2:])
+        if self.skip_connection:
+            out = x + out
+        return out

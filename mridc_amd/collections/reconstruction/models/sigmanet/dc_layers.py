@@ -110,7 +110,7 @@ class DCLayer(torch.nn.Module):
 class DataProxCGLayer(torch.nn.Module):
     """Proximal data layer solved by conjugate gradient (dc_layers.py:98-257, forward): (lambda A^H A + I) x = lambda A^H y + z.
 
-    The reference's solver reshapes alpha to 5-D, so it only runs with a 5-D image z [1,1,H,W,2]; its A^H drops the size-1 batch
+    The reference's solver reshapes alpha to 5-D, so it only runs with a 5-D image z [1,1,H,W,2] (or [1,C,H,W,2]); its A^H drops the size-1 batch
     axis and keeps the coils, so the unknown is one image per coil [1,C,H,W,2] and A sums the coils' k-space.  Reproduced as is.
     Per iteration: complex_mul + fft2 + mrx_coil_sum (A), mrx_apply_mask + ifft2 + complex_mul (A^H), mrx_lincomb, two mrx_cdot,
     mrx_cg_step, mrx_cg_dir; the stopping test reads the residual norm back, as the reference does (:177)."""
@@ -129,8 +129,10 @@ class DataProxCGLayer(torch.nn.Module):
         self.spatial_dims = spatial_dims if spatial_dims is not None else [-2, -1]
 
     def forward(self, x, f, smaps, mask):
-        if x.dim() != 5 or smaps.dim() != 5 or x.shape[0] != 1 or x.shape[1] != 1 or smaps.shape[0] != 1:
-            raise NotImplementedError("DataProxCGLayer: the reference's solver is only defined for z [1,1,H,W,2] and smaps "
+        # z is [1,1,H,W,2] (a coil-combined image: the first iterate of SensitivityNetwork) or [1,C,H,W,2] (this layer's own output
+        # fed back: later iterates)
+        if x.dim() != 5 or smaps.dim() != 5 or x.shape[0] != 1 or x.shape[1] not in (1, smaps.shape[1]) or smaps.shape[0] != 1:
+            raise NotImplementedError("DataProxCGLayer: the reference's solver is only defined for z [1,1|C,H,W,2] and smaps "
                                       f"[1,C,H,W,2] (got {tuple(x.shape)} and {tuple(smaps.shape)})")
         kw = dict(centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims)
         lam = self.lambdaa.reshape(1)

@@ -37,7 +37,7 @@ def install():
         "mridc.collections.reconstruction.models.varnet", "mridc.collections.reconstruction.models.unet_base",
         "mridc.collections.reconstruction.models.conv", "mridc.collections.reconstruction.models.cascadenet",
         "mridc.collections.reconstruction.models.variablesplittingnet", "mridc.collections.reconstruction.models.sigmanet",
-        "mridc.collections.reconstruction.models.recurrentvarnet",
+        "mridc.collections.reconstruction.models.recurrentvarnet", "mridc.collections.reconstruction.models.didn",
         "mridc.collections.quantitative", "mridc.collections.quantitative.models",
         "mridc.collections.quantitative.models.qrim",
     ]

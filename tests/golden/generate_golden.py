@@ -923,6 +923,63 @@ def g17_dc_layers():
     save("g17_dc_layers.npz", d)
 
 
+def g21_dunet():
+    """N4: didn/didn.py:10-325, sigmanet/sensitivity_net.py:17-212 and the model forward dunet.py:162-176, composed from the imported
+    blocks as DUNet.__init__ does (dunet.py:47-107: ONE DIDN and ONE data layer, wrapped / listed num_iter times).  Batch 1 and the
+    proximal-CG data term, as in the reference's own test: the other data layers do not accept the 5-D image the wrapper produces."""
+    didn = _refshim.load("mridc.collections.reconstruction.models.didn.didn")
+    snet = _refshim.load("mridc.collections.reconstruction.models.sigmanet.sensitivity_net")
+    dcl = _refshim.load("mridc.collections.reconstruction.models.sigmanet.dc_layers")
+    d = {}
+    # the regulariser on its own: odd sizes (reflect padding inside the down-up blocks), batch 2, with and without the skip connection
+    for i, (nm, hid, dubs, convs, shape, skip) in enumerate([("didn_a", 8, 2, 3, [2, 2, 17, 19], False), ("didn_b", 16, 1, 1, [1, 2, 24, 32], True)]):
+        torch.manual_seed(2100 + i)
+        net = didn.DIDN(2, 2, hidden_channels=hid, num_dubs=dubs, num_convs_recon=convs, skip_connection=skip).eval()
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, torch.nn.PReLU):
+                    m.weight.uniform_(0.05, 0.45)
+        x = rnd(shape, 2110 + i)
+        with torch.no_grad():
+            d[f"{nm}/out"] = net(x)
+        d[f"{nm}/x"] = x
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(hidden_channels=hid, num_dubs=dubs, num_convs_recon=convs, skip_connection=skip)))
+        d.update(sd(net, f"{nm}/w/"))
+    cases = [("prox_unshared", [1, 3, 32, 16], dict(num_iter=2, didn_hidden_channels=8, didn_num_dubs=1, didn_num_convs_recon=1,
+                                                    data_consistency_iterations=4, shared_params=False), True, "ortho"),
+             ("prox_shared", [1, 2, 17, 19], dict(num_iter=3, didn_hidden_channels=8, didn_num_dubs=2, didn_num_convs_recon=2,
+                                                  data_consistency_iterations=6, shared_params=True), False, "backward")]
+    for i, (nm, (B, C, H, W), c, centered, norm) in enumerate(cases):
+        torch.manual_seed(2150 + i)
+        cfg = dict(c, reg_model_architecture="DIDN", data_consistency_term="PROX", data_consistency_lambda_init=0.1, fft_centered=centered,
+                   fft_normalization=norm, spatial_dims=[-2, -1], coil_dim=1, use_sens_net=False, coil_combination_method="SENSE",
+                   train_loss_fn="l1", val_loss_fn="l1")
+        reg = didn.DIDN(2, 2, hidden_channels=cfg["didn_hidden_channels"], num_dubs=cfg["didn_num_dubs"],
+                        num_convs_recon=cfg["didn_num_convs_recon"])
+        dc = dcl.DataProxCGLayer(lambda_init=0.1, iter=cfg["data_consistency_iterations"], fft_centered=centered, fft_normalization=norm,
+                                 spatial_dims=[-2, -1])
+        net = snet.SensitivityNetwork(cfg["num_iter"], reg, dc, shared_params=cfg["shared_params"], save_space=False, reset_cache=False).eval()
+        img, S = synth(B, C, H, W, 2160 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=centered, normalization=norm)
+        _, m = make_mask([1, C, H, W, 2])
+        y = k * m
+        target = utils.complex_abs(utils.sense(fft.ifft2(k, centered=centered, normalization=norm), S, 1))
+        with torch.no_grad():
+            init_pred = torch.sum(utils.complex_mul(fft.ifft2(y, centered=centered, normalization=norm, spatial_dims=[-2, -1]),
+                                                    utils.complex_conj(S)), 1)
+            x_net = net(init_pred, y, S, m)
+            image = torch.sum(utils.complex_mul(x_net, utils.complex_conj(S)), 1)
+            image = torch.view_as_complex(image)
+            _, image = utils.center_crop_to_smallest(target, image)
+            d[f"{nm}/reg0"] = net.gradR[0](init_pred)                      # the normalisation wrapper on the 4-D first iterate
+        d[f"{nm}/cfg"] = np.array(json.dumps(cfg))
+        d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"], d[f"{nm}/target"] = y, S, m, target
+        d[f"{nm}/init_pred"], d[f"{nm}/net_out"], d[f"{nm}/model_out"] = init_pred, x_net, torch.view_as_real(image)
+        d.update(sd(net, f"{nm}/w/model."))
+    d["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g21_dunet.npz", d)
+
+
 def g18_rvn():
     """N4: recurrentvarnet/conv2gru.py:10-163, recurrentvarnet/recurrentvarnet.py:17-240, rvn.py:163-226 (model forward composed
     from the imported blocks; hidden size 16 keeps the fixture small)."""
@@ -1002,8 +1059,8 @@ def g18_rvn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
-    fns = dict(g20=g20_rim3d, g19=g19_cirim_spec, g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
+    fns = dict(g21=g21_dunet, g20=g20_rim3d, g19=g19_cirim_spec, g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

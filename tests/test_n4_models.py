@@ -62,6 +62,25 @@ def test_oracle_dc_layers_vs_golden(golden):
             assert_close(got, T(z[f"{nm}/prox{it}"]), 2e-5, f"{nm} prox-CG {it} iterations")
 
 
+def test_oracle_dunet_vs_golden(golden):
+    z = golden("g21_dunet.npz")
+    for nm in ("didn_a", "didn_b"):
+        cfg, p = meta(z, f"{nm}/cfg"), weights(z, f"{nm}/w/")
+        got = oracle.dunet.didn_forward(p, T(z[f"{nm}/x"]), cfg["num_dubs"], cfg["num_convs_recon"], skip_connection=cfg["skip_connection"])
+        assert_close(got, T(z[f"{nm}/out"]), 2e-6, f"{nm} DIDN")
+    for nm in json.loads(str(z["names"])):
+        cfg, p = meta(z, f"{nm}/cfg"), weights(z, f"{nm}/w/")
+        y, S, mask = T(z[f"{nm}/y"]), T(z[f"{nm}/S"]), T(z[f"{nm}/mask"])
+        reg0 = oracle.dunet.complex_norm_wrapper(
+            lambda t: oracle.dunet.didn_forward(p, t, cfg["didn_num_dubs"], cfg["didn_num_convs_recon"], prefix="model.gradR.0.model."),
+            T(z[f"{nm}/init_pred"]))
+        assert_close(reg0, T(z[f"{nm}/reg0"]), 5e-6, f"{nm} normalisation wrapper, 4-D iterate")
+        net = oracle.dunet.sensitivity_network_forward(p, cfg, T(z[f"{nm}/init_pred"]), y, S, mask)
+        assert_close(net, T(z[f"{nm}/net_out"]), 2e-5, f"{nm} SensitivityNetwork")
+        out = oracle.dunet.dunet_forward(p, cfg, y, S, mask, None, T(z[f"{nm}/target"]))
+        assert_close(out, T(z[f"{nm}/model_out"]), 2e-5, f"{nm} DUNet")
+
+
 def test_oracle_rvn_vs_golden(golden):
     z = golden("g18_rvn.npz")
     for nm in ("gru_h16_l2", "gru_h8_l4", "gru_h8_l2_k3"):
@@ -204,6 +223,44 @@ def test_sigmanet_dc_layers_vs_golden(golden, dev):
     assert list(dc_layers.DataVSLayer(0.1, 0.2).state_dict()) == ["alpha", "beta"]
     assert list(dc_layers.DCLayer(0.1).state_dict()) == ["lambda_"]
     assert list(dc_layers.DataProxCGLayer(0.1).state_dict()) == ["lambdaa"]
+
+
+@pytest.mark.gpu
+def test_dunet_vs_golden(golden, dev):
+    """N4: DIDN, the complex-instance-norm wrapper, SensitivityNetwork and the DUNet forward against the reference-generated G21."""
+    from mridc_amd.collections.reconstruction.models.didn.didn import DIDN
+    from mridc_amd.collections.reconstruction.models.dunet import DUNet
+    z = golden("g21_dunet.npz")
+    for nm in ("didn_a", "didn_b"):
+        cfg = meta(z, f"{nm}/cfg")
+        net = DIDN(2, 2, **cfg)
+        sd_ = weights(z, f"{nm}/w/")
+        assert set(sd_) == set(net.state_dict()), "DIDN state_dict layout (the doubled conv / PReLU pairs included)"
+        net.load_state_dict(sd_)
+        net = net.to(dev).eval()
+        with torch.no_grad():
+            out = net(T(z[f"{nm}/x"]).to(dev))
+        assert_close(out, T(z[f"{nm}/out"]), 2e-5, f"{nm} DIDN")
+    for nm in json.loads(str(z["names"])):
+        cfg = meta(z, f"{nm}/cfg")
+        model = DUNet(cfg)
+        sd_ = weights(z, f"{nm}/w/")
+        sd_["dc_weight"] = torch.ones(1)
+        assert set(sd_) == set(model.state_dict())
+        model.load_state_dict(sd_)
+        model = model.to(dev).eval()
+        y, S, mask, target = (T(z[f"{nm}/{k}"]).to(dev) for k in ("y", "S", "mask", "target"))
+        with torch.no_grad():
+            reg0 = model.model.gradR[0](T(z[f"{nm}/init_pred"]).to(dev))
+            net_out = model.model(T(z[f"{nm}/init_pred"]).to(dev), y, S, mask)
+            out = model(y, S, mask, None, target)
+        assert_close(reg0, T(z[f"{nm}/reg0"]), 5e-5, f"{nm} normalisation wrapper")
+        assert_close(net_out, T(z[f"{nm}/net_out"]), 2e-4, f"{nm} SensitivityNetwork")
+        assert_close(out, T(z[f"{nm}/model_out"]), 2e-4, f"{nm} DUNet")
+    with pytest.raises(NotImplementedError):
+        DUNet(dict(meta(z, "prox_shared/cfg"), reg_model_architecture="MWCNN"))
+    with pytest.raises(ValueError):
+        DUNet(dict(meta(z, "prox_shared/cfg"), train_loss_fn="huber"))
 
 
 @pytest.mark.gpu
