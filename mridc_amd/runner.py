@@ -123,9 +123,26 @@ class ReconstructionRunner:
         preds = preds.detach()
         return name, slice_num, (preds.cpu().numpy() if self.to_numpy else preds)
 
-    def test_epoch_end(self, device=None):
+    @staticmethod
+    def save_outputs(outputs, out_dir):
+        """base.py:575-587: the (fname, slice, output) triples of `test_step`, stacked per volume in slice order and written as
+        `<out_dir>/reconstructions/<fname>` with one `reconstruction` dataset each (HDF5 through this package's writer)."""
+        import os
+
+        from mridc_amd.collections.common.parts.utils import save_reconstructions
+        reconstructions = defaultdict(list)
+        for fname, slice_num, output in outputs:
+            reconstructions[fname].append((slice_num, output.detach().cpu().numpy() if torch.is_tensor(output) else np.asarray(output)))
+        stacked = {fname: np.stack([out for _, out in sorted(v, key=lambda t: t[0])]) for fname, v in reconstructions.items()}
+        save_reconstructions(stacked, os.path.join(str(out_dir), "reconstructions"))
+        return stacked
+
+    def test_epoch_end(self, device=None, outputs=None, out_dir=None):
         """base.py:490-517: mean over the slices of every volume, summed over volumes, all-reduced (sum) over the ranks together
-        with the volume count, divided by the total count."""
+        with the volume count, divided by the total count.  With `outputs` (the list of `test_step` results) and `out_dir`, the
+        reconstructions are written as the reference does at the end of the same method (:575-587)."""
+        if outputs is not None and out_dir is not None:
+            self.save_outputs(outputs, out_dir)
         names = sorted(self.metric_vals)
         sums = torch.zeros(5, dtype=torch.float64)
         for fname in names:
