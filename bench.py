@@ -437,22 +437,43 @@ def bench_train(args, world, rank, dev):
     if args.cascades:
         cfg["num_cascades"] = args.cascades
     torch.manual_seed(0)
-    model = CIRIM(cfg).to(dev)
     C, H, W = args.coils, args.height, args.width
     s = synthetic.make_slice(C, H, W, slice_idx=rank)
     batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    if args.model == "e2evn":           # E2EVN under the same trainer (vn.py): forward recorded through mridc_amd.diff
+        from mridc_amd.collections.reconstruction.models.vn import VarNet
+        ucfg = dict(synthetic.E2EVN_BASELINE_CFG)
+        if args.unet == "18x4":
+            ucfg.update(channels=18, pooling_layers=4, padding_size=15)
+        model = VarNet(ucfg).to(dev)
+        step_fn = training.model_training_step
+    else:
+        model = CIRIM(cfg).to(dev)
+        step_fn = training.training_step
     flat = training.FlatParameters(model)
     opt = training.AdamFlat(flat, lr=1e-3, betas=(0.9, 0.98))
     losses = []
     for _ in range(max(args.warmup, 1)):
-        losses.append(float(training.training_step(model, flat, opt, batch)))
+        losses.append(float(step_fn(model, flat, opt, batch)))
     dist_barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = training.training_step(model, flat, opt, batch)
+        loss = step_fn(model, flat, opt, batch)
     dist_barrier()
     elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
     losses.append(float(loss))
+    if rank == 0 and args.model == "e2evn":
+        emit(dict(metric=f"slices/sec (training), E2EVN {ucfg['num_cascades']}-cascade {C}-coil {H}x{W}", value=world * args.steps / elapsed,
+                  unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
+                  higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
+                  per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank], dtype="f32", data="synthetic",
+                  config=dict(workload=f"E2EVN {ucfg['num_cascades']} cascades, NormUnet({ucfg['channels']}, {ucfg['pooling_layers']}), {C} coils, "
+                                       f"{H}x{W}: forward + l1 loss + backward (convolution / transposed-convolution / FFT gradients on the HIP "
+                                       f"kernels, normalisation and pointwise derivatives as torch device ops) + one all-reduce of the flat "
+                                       f"gradient ({flat.numel * 4 / 1e6:.2f} MB) + Adam, 1 slice per GPU and step",
+                              global_batch=world, parallelism=f"data-parallel x{world}", gradient_bytes=flat.numel * 4),
+                  loss_first=losses[0], loss_last=losses[-1]))
+        return
     if rank == 0:
         emit(dict(metric=f"slices/sec (training), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}",
                               value=world * args.steps / elapsed, unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -162,8 +162,16 @@ class RIMBlock(torch.nn.Module):
             g = ag.LogLikelihoodGradient.apply(eta, data, sense, mask, sigma, self.fft_centered, self.fft_normalization, hinv)
             for li, stack in enumerate(self.layers):
                 c, r = stack.convs, stack.rnn
+                if isinstance(r, (rnn_cells.ConvGRUCell, rnn_cells.ConvMGUCell)) and c is not None:
+                    # gated cells: convolutions with their HIP backward kernels (mridc_amd/diff.py), gates recorded by torch
+                    from mridc_amd import diff
+                    a = diff.conv2d(g, c.conv_layer.weight, c.conv_layer.bias, c.dilation, ops.PAD_REPLICATE, c.act, c.slope)
+                    h = hx[li] if hx[li] is not None else a.new_zeros((a.size(0), r.hidden_size, *a.size()[2:]))
+                    hx[li] = r(a, h)
+                    g = hx[li]
+                    continue
                 if not (isinstance(r, rnn_cells.IndRNNCell) and r.kernel_size == 1 and c is not None and c.act == ops.ACT_RELU):
-                    raise NotImplementedError("mridc_amd training path: ConvNonlinear(ReLU) + IndRNNCell(1x1) layers only")
+                    raise NotImplementedError("mridc_amd training path: ConvNonlinear(ReLU) + IndRNNCell(1x1) or gated-cell layers only")
                 a = ag.ConvReLU.apply(g, c.conv_layer.weight, c.conv_layer.bias, c.dilation)
                 hx[li] = ag.IndRNN1x1.apply(a, r.ih.weight, r.ih.bias, r.hh, hx[li])
                 g = hx[li]

@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from mridc_amd import ops
+from mridc_amd import diff, ops
 
 
 def _orthogonalize(weights, chunks=1):
@@ -37,9 +37,14 @@ class _GatedCellBase(nn.Module):
         if hx.size(1) != self.hidden_size:
             raise RuntimeError(f"hidden{hidden_label} has inconsistent hidden_size: got {hx.size(1)}, expected {self.hidden_size}")
 
+    def _ns(self, _input, hx):
+        """`diff` (training: convolutions with HIP backward kernels, gates recorded by torch) or `ops`."""
+        return diff if diff.active(_input, hx, *self.parameters()) else ops
+
     def _convs(self, _input, hx):
-        ih = ops.conv2d(_input, self.ih.weight, self.ih.bias, self.dilation, ops.PAD_ZERO)
-        hh = ops.conv2d(hx, self.hh.weight, None, self.dilation, ops.PAD_ZERO)
+        o = self._ns(_input, hx)
+        ih = o.conv2d(_input, self.ih.weight, self.ih.bias, self.dilation, ops.PAD_ZERO)
+        hh = o.conv2d(hx, self.hh.weight, None, self.dilation, ops.PAD_ZERO)
         return ih, hh
 
 
@@ -58,7 +63,7 @@ class ConvGRUCell(_GatedCellBase):
 
     def forward(self, _input, hx):
         ih, hh = self._convs(_input, hx)
-        return ops.gru_gates(ih, hh, hx)          # rnn_cells.py:118-127
+        return self._ns(_input, hx).gru_gates(ih, hh, hx)          # rnn_cells.py:118-127
 
 
 class ConvMGUCell(_GatedCellBase):
@@ -78,7 +83,7 @@ class ConvMGUCell(_GatedCellBase):
 
     def forward(self, _input, hx):
         ih, hh = self._convs(_input, hx)
-        return ops.mgu_gates(ih, hh, hx)          # rnn_cells.py:255-261
+        return self._ns(_input, hx).mgu_gates(ih, hh, hx)          # rnn_cells.py:255-261
 
 
 class IndRNNCell(nn.Module):

@@ -9,7 +9,12 @@ from typing import List, Tuple
 
 import torch
 
-from mridc_amd import ops
+from mridc_amd import diff, ops
+
+
+def _ns(x, *params):
+    """`diff` (differentiable forms, training) when gradients are being recorded through x or the parameters, else `ops`."""
+    return diff if diff.active(x, *params) else ops
 
 
 class ConvBlock(torch.nn.Module):
@@ -34,8 +39,9 @@ class ConvBlock(torch.nn.Module):
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         if self.training and self.drop_prob > 0:
             raise NotImplementedError("Dropout2d in training mode is not part of the HIP inference path")
-        x = ops.conv_instance_norm_act(image, self.layers[0].weight, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
-        return ops.conv_instance_norm_act(x, self.layers[4].weight, self.layers[5].eps, ops.ACT_LEAKY, 0.2)
+        o = _ns(image, self.layers[0].weight, self.layers[4].weight)
+        x = o.conv_instance_norm_act(image, self.layers[0].weight, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
+        return o.conv_instance_norm_act(x, self.layers[4].weight, self.layers[5].eps, ops.ACT_LEAKY, 0.2)
 
 
 class TransposeConvBlock(torch.nn.Module):
@@ -52,8 +58,9 @@ class TransposeConvBlock(torch.nn.Module):
         )
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
-        x = ops.conv_transpose2x2(image, self.layers[0].weight)
-        return ops.instance_norm_act(x, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
+        o = _ns(image, self.layers[0].weight)
+        x = o.conv_transpose2x2(image, self.layers[0].weight)
+        return o.instance_norm_act(x, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
 
 
 class Unet(torch.nn.Module):
@@ -85,10 +92,11 @@ class Unet(torch.nn.Module):
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         stack = []
         output = image
+        o = _ns(image, *self.parameters())
         for layer in self.down_sample_layers:                        # unet_block.py:203-206
             output = layer(output)
             stack.append(output)
-            output = ops.avg_pool2x2(output)
+            output = o.avg_pool2x2(output)
         output = self.conv(output)
         for transpose_conv, conv in zip(self.up_transpose_conv, self.up_conv):
             downsample_layer = stack.pop()
@@ -96,11 +104,11 @@ class Unet(torch.nn.Module):
             pad_r = 1 if output.shape[-1] != downsample_layer.shape[-1] else 0     # unet_block.py:215-222
             pad_b = 1 if output.shape[-2] != downsample_layer.shape[-2] else 0
             if pad_r or pad_b:
-                output = ops.pad2d(output, 0, pad_b, 0, pad_r, mode=1)
-            output = ops.concat_channels(output, downsample_layer)
+                output = o.pad2d(output, 0, pad_b, 0, pad_r, mode=1)
+            output = o.concat_channels(output, downsample_layer)
             if isinstance(conv, torch.nn.Sequential):
                 output = conv[0](output)
-                output = ops.conv2d(output, conv[1].weight, conv[1].bias, 1, ops.PAD_ZERO)
+                output = o.conv2d(output, conv[1].weight, conv[1].bias, 1, ops.PAD_ZERO)
             else:
                 output = conv(output)
         return output
@@ -134,10 +142,10 @@ class NormUnet(torch.nn.Module):
         return x.view(b, 2, c, h, w).permute(0, 2, 3, 4, 1).contiguous()
 
     def norm(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        return ops.group_norm(x, self.norm_groups)
+        return _ns(x).group_norm(x, self.norm_groups)
 
     def unnorm(self, x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
-        return ops.group_unnorm(x, mean, std, self.norm_groups)
+        return _ns(x, mean).group_unnorm(x, mean, std, self.norm_groups)
 
     def pad(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[List[int], List[int], int, int]]:
         _, _, h, w = x.shape
@@ -145,12 +153,12 @@ class NormUnet(torch.nn.Module):
         h_mult = ((h - 1) | self.padding_size) + 1
         w_pad = [math.floor((w_mult - w) / 2), math.ceil((w_mult - w) / 2)]
         h_pad = [math.floor((h_mult - h) / 2), math.ceil((h_mult - h) / 2)]
-        x = ops.pad2d(x, h_pad[0], h_pad[1], w_pad[0], w_pad[1], mode=0)
+        x = _ns(x).pad2d(x, h_pad[0], h_pad[1], w_pad[0], w_pad[1], mode=0)
         return x, (h_pad, w_pad, h_mult, w_mult)
 
     @staticmethod
     def unpad(x: torch.Tensor, h_pad: List[int], w_pad: List[int], h_mult: int, w_mult: int) -> torch.Tensor:
-        return ops.pad2d(x, -h_pad[0], -h_pad[1], -w_pad[0], -w_pad[1], mode=0)
+        return _ns(x).pad2d(x, -h_pad[0], -h_pad[1], -w_pad[0], -w_pad[1], mode=0)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         iscomplex = False

@@ -3,7 +3,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from mridc_amd import ops
+from mridc_amd import diff, ops
 
 
 class VarNetBlock(torch.nn.Module):
@@ -32,6 +32,11 @@ class VarNetBlock(torch.nn.Module):
 
     def forward(self, pred: torch.Tensor, ref_kspace: torch.Tensor, sens_maps: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         """vn_block.py:89-119."""
+        if diff.active(pred, *self.parameters()):            # training: the differentiable forms (k-space formulation, no fusion)
+            kw = (self.fft_centered, self.fft_normalization, self.spatial_dims)
+            eta = diff.sens_reduce(pred, sens_maps, *kw).unsqueeze(1)
+            eta = diff.sens_expand(self.model(eta), sens_maps, *kw)
+            return eta if self.no_dc else diff.dc_combine(pred, pred, ref_kspace, mask, self.dc_weight, eta)
         eta = self.sens_reduce(pred, sens_maps)
         eta = self.model(eta)
         if self._hybrid and not self.no_dc:      # expand + data consistency in one pass over the coil stack

@@ -1,7 +1,8 @@
-"""Drop-in for `mridc.collections.reconstruction.models.vn.VarNet` (reference vn.py:22-142), inference path."""
+"""Drop-in for `mridc.collections.reconstruction.models.vn.VarNet` (reference vn.py:22-142): inference on the fused HIP path, training
+(gradients recorded) on the differentiable operator forms of `mridc_amd.diff`."""
 import torch
 
-from mridc_amd import ops
+from mridc_amd import diff, ops
 import mridc_amd.collections.common.parts.fft as fft
 import mridc_amd.collections.common.parts.utils as utils
 from mridc_amd.collections.reconstruction.models import _cfg
@@ -63,7 +64,13 @@ class VarNet(torch.nn.Module):
     def forward(self, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask: torch.Tensor, init_pred: torch.Tensor,
                 target: torch.Tensor) -> torch.Tensor:
         """vn.py:94-142."""
-        if self._hybrid_ok(mask):
+        if diff.active(y, *self.parameters()):                # training: k-space formulation on the differentiable forms
+            estimation = y.clone()
+            for cascade in self.cascades:
+                estimation = cascade(estimation, y, sensitivity_maps, mask)
+            estimation = diff.ifft2(estimation, self.fft_centered, self.fft_normalization, self.spatial_dims)
+            estimation = diff.coil_combination(estimation, sensitivity_maps, method=self.coil_combination_method, dim=self.coil_dim)
+        elif self._hybrid_ok(mask):
             estimation = self._forward_hybrid(y, sensitivity_maps, mask)
         else:
             estimation = y.clone()

@@ -301,6 +301,138 @@ __global__ __launch_bounds__(WS_NT) void k_conv_wgrad_small(WsmallArgs a) {
         }
 }
 
+// ---- weight gradient, any channel counts (NormUnet 14 / 28 / 56 ..., gate convolutions into 3 F channels): k = 1, 3 or 5, any dilation ------
+// dW[co][ci, tap] = sum over pixels of dy[co][p] * pad(x)[ci][p + tap] as a GEMM over pixels on v_mfma_f32_32x32x2_f32: A = dy (32 couts x
+// 2 pixels), B = the shifted x (2 pixels x 32 columns; a column block is floor(32 / taps) input channels x taps: 3 x 9 for 3x3 -- 27 of 32
+// columns used --, 32 channels for 1x1, one channel for 5x5).  A workgroup owns a group of (cout block, column block) pairs (<= 64: 8 waves x 8 accumulators) and walks the 8 x 32
+// pixel tiles of its slab with the x tile of the group's channels and the dy tile of the group's couts in LDS; partial sums per slab are
+// summed in fixed order by k_wgrad_reduce (bit-reproducible).
+#define WGN_NT 512
+#define WGN_TH 8
+#define WGN_TW 32
+#define WGN_DS 257
+typedef float wgn_f32x16 __attribute__((ext_vector_type(16)));
+struct WgenArgs {
+    const float* x;
+    const float* dy;
+    float* part;            // [slab][Cout][Cin * taps]
+    int B, Cin, Cout, H, W, k, dil, pad, pad_mode, tiles_x, ntiles;
+    int cpb;                // input channels per column block
+    int co_grp, nb_grp;     // couts / column blocks per workgroup group
+    int n_nbgrp, nb_total;
+};
+template <int SLOTS>
+__global__ __launch_bounds__(WGN_NT, 1) void k_conv_wgrad_gen(WgenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_wgn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int cg = blockIdx.y / a.n_nbgrp, ng = blockIdx.y - cg * a.n_nbgrp;
+    const int co0 = cg * a.co_grp, co_cnt = a.Cout - co0 < a.co_grp ? a.Cout - co0 : a.co_grp, CB = (co_cnt + 31) / 32;
+    const int nb0 = ng * a.nb_grp, nb_cnt = a.nb_total - nb0 < a.nb_grp ? a.nb_total - nb0 : a.nb_grp;
+    const int ci0 = nb0 * a.cpb, ci_cnt = a.Cin - ci0 < nb_cnt * a.cpb ? a.Cin - ci0 : nb_cnt * a.cpb;
+    const int P = CB * nb_cnt, taps = a.k * a.k;
+    const int PH = WGN_TH + 2 * a.pad, PS = (WGN_TW + 2 * a.pad) | 1, PW = WGN_TW + 2 * a.pad;
+    float* xs = smem_wgn;                                   // [ci_cnt][PH][PS]
+    float* dys = smem_wgn + ((ci_cnt * PH * PS + 3) & ~3);  // [CB * 32][WGN_DS]
+    const long long plane = (long long)a.H * a.W;
+    const bool rep = a.pad_mode == MRX_PAD_REPLICATE;
+
+    // per slot: the pair's A / B lane offsets and whether this lane's column exists
+    int aoff[SLOTS], boff[SLOTS], gcol[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int p = wave + 8 * s;
+        const int cb = p % CB, nb = p / CB;
+        aoff[s] = (cb * 32 + l31) * WGN_DS;
+        const int cil = l31 / taps, tap = l31 - cil * taps;
+        const int cl = nb * a.cpb + cil;                    // channel within the group
+        const bool ok = p < P && cl < ci_cnt && cil < a.cpb;
+        boff[s] = ok ? (cl * PH + (tap / a.k) * a.dil) * PS + (tap % a.k) * a.dil : 0;
+        gcol[s] = ok ? (ci0 + cl) * taps + tap : -1;
+    }
+    wgn_f32x16 acc[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+    const int total_tiles = a.ntiles * a.B;
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const int b = t / a.ntiles, tile = t - b * a.ntiles, ty0 = tile / a.tiles_x;
+        const int h0 = ty0 * WGN_TH, w0 = (tile - ty0 * a.tiles_x) * WGN_TW;
+        __syncthreads();                                    // the previous tile is consumed
+        for (int i = tid; i < ci_cnt * PH * PW; i += WGN_NT) {
+            const int c = i / (PH * PW), e = i - c * (PH * PW), ty = e / PW, tx = e - ty * PW;
+            int gy = h0 + ty - a.pad, gx = w0 + tx - a.pad;
+            const bool ok = rep || (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W);
+            gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+            gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+            xs[(c * PH + ty) * PS + tx] = ok ? a.x[((long long)b * a.Cin + ci0 + c) * plane + (long long)gy * a.W + gx] : 0.f;
+        }
+        for (int i = tid; i < CB * 32 * WGN_TH * WGN_TW; i += WGN_NT) {
+            const int co = i >> 8, e = i & 255, gy = h0 + (e >> 5), gx = w0 + (e & 31);
+            const bool ok = co < co_cnt && gy < a.H && gx < a.W;
+            dys[co * WGN_DS + e] = ok ? a.dy[((long long)b * a.Cout + co0 + co) * plane + (long long)gy * a.W + gx] : 0.f;
+        }
+        __syncthreads();
+        for (int row = 0; row < WGN_TH; ++row)
+#pragma unroll 4
+            for (int st = 0; st < WGN_TW / 2; ++st) {
+                const int px = 2 * st + lhi;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    if (wave + 8 * s < P) {                 // wave-uniform
+                        const float av = dys[aoff[s] + row * WGN_TW + px];
+                        const float bv = xs[boff[s] + row * PS + px];
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[s], 0, 0, 0);
+                    }
+                }
+            }
+    }
+    const long long N = (long long)a.Cin * taps;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int p = wave + 8 * s;
+        if (p < P && gcol[s] >= 0) {
+            const int cb = p % CB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (co < co_cnt) a.part[((long long)blockIdx.x * a.Cout + co0 + co) * N + gcol[s]] = acc[s][r];
+            }
+        }
+    }
+}
+
+struct WgenPlan {
+    int cpb, co_grp, nb_grp, n_cogrp, n_nbgrp, nb_total, slots, slabs;
+    size_t lds;
+};
+static int query_cus();
+static WgenPlan wgen_plan(int B, int Cin, int Cout, int H, int W, int k, int dil) {
+    WgenPlan p;
+    const int pad = dil * (k - 1) / 2;
+    p.cpb = 32 / (k * k);
+    p.nb_total = (Cin + p.cpb - 1) / p.cpb;
+    p.co_grp = Cout < 64 ? Cout : 64;
+    p.n_cogrp = (Cout + p.co_grp - 1) / p.co_grp;
+    const int CBg = (p.co_grp + 31) / 32;
+    const size_t dy_bytes = (size_t)CBg * 32 * WGN_DS * 4, xch = (size_t)(WGN_TH + 2 * pad) * ((WGN_TW + 2 * pad) | 1) * 4;
+    int nb = (int)((150 * 1024 - dy_bytes) / (xch * p.cpb));
+    if (nb > 64 / CBg) nb = 64 / CBg;
+    if (nb > p.nb_total) nb = p.nb_total;
+    if (nb < 1) nb = 1;
+    p.nb_grp = nb;
+    p.n_nbgrp = (p.nb_total + nb - 1) / nb;
+    const int pairs = CBg * nb;
+    p.slots = pairs <= 8 ? 1 : (pairs <= 16 ? 2 : (pairs <= 32 ? 4 : 8));
+    int chans = nb * p.cpb < Cin ? nb * p.cpb : Cin;
+    p.lds = (((size_t)chans * xch / 4 + 3) & ~(size_t)3) * 4 + dy_bytes;
+    const long long tiles = (long long)mrx_cdiv(W, WGN_TW) * mrx_cdiv(H, WGN_TH) * B;
+    const int cus = query_cus();
+    p.slabs = (int)(tiles < cus ? tiles : cus);
+    return p;
+}
+
 static int wgrad_nparts64(int n_cu, long long nt_total) { return (int)(nt_total < n_cu ? nt_total : n_cu); }
 static int g_n_cu = 0;
 static int query_cus() {
@@ -329,6 +461,7 @@ extern "C" int64_t mrx_conv_wgrad_work_floats(int B, int Cin, int Cout, int H, i
     const long long N = (long long)Cin * k * k, n = (long long)Cout * N;
     if (B < 1 || H < 1 || W < 1) return -1;
     if (Cout == 64 && N <= 8 * WG_MAXNB * 32) return (int64_t)wgrad_parts64(B, H, W, N) * n;
+    if (Cout > WS_MAXCO && (k == 1 || k == 3 || k == 5)) return (int64_t)wgen_plan(B, Cin, Cout, H, W, k, 1).slabs * n;   // slabs do not depend on the dilation
     return (int64_t)WS_SLABS * n;
 }
 
@@ -375,6 +508,28 @@ extern "C" int mrx_conv_wgrad(const float* x, const float* dy, float* dw, float*
         if (pad == 0) hipLaunchKernelGGL(k_conv_wgrad64<0>, dim3(nblk64), dim3(WG_NT), lds, st, a);
         else if (pad == 1) hipLaunchKernelGGL(k_conv_wgrad64<1>, dim3(nblk64), dim3(WG_NT), lds, st, a);
         else hipLaunchKernelGGL(k_conv_wgrad64<2>, dim3(nblk64), dim3(WG_NT), lds, st, a);
+    } else if (Cout > WS_MAXCO) {
+        MRX_REQUIRE(k == 1 || k == 3 || k == 5, MRX_EUNSUP, "mrx_conv_wgrad: Cout=%d with k=%d (generic kernel: k 1, 3 or 5)", Cout, k);
+        const WgenPlan pl = wgen_plan(B, Cin, Cout, H, W, k, dil);
+        MRX_REQUIRE(pl.lds <= 160 * 1024, MRX_EUNSUP, "mrx_conv_wgrad: %zu bytes of LDS (k=%d dil=%d)", pl.lds, k, dil);
+        WgenArgs a;
+        a.x = x, a.dy = dy, a.part = work;
+        a.B = B, a.Cin = Cin, a.Cout = Cout, a.H = H, a.W = W, a.k = k, a.dil = dil, a.pad = pad, a.pad_mode = pad_mode;
+        a.tiles_x = mrx_cdiv(W, WGN_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, WGN_TH);
+        a.cpb = pl.cpb, a.co_grp = pl.co_grp, a.nb_grp = pl.nb_grp, a.n_nbgrp = pl.n_nbgrp, a.nb_total = pl.nb_total;
+        const void* kern = pl.slots == 1 ? (const void*)k_conv_wgrad_gen<1> : pl.slots == 2 ? (const void*)k_conv_wgrad_gen<2>
+                         : pl.slots == 4 ? (const void*)k_conv_wgrad_gen<4> : (const void*)k_conv_wgrad_gen<8>;
+        static size_t attr_bytes[9] = {0};
+        if (attr_bytes[pl.slots] < pl.lds) {
+            MRX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+            attr_bytes[pl.slots] = pl.lds;
+        }
+        nparts = pl.slabs;
+        const dim3 grid(pl.slabs, pl.n_cogrp * pl.n_nbgrp);
+        if (pl.slots == 1) hipLaunchKernelGGL(k_conv_wgrad_gen<1>, grid, dim3(WGN_NT), pl.lds, st, a);
+        else if (pl.slots == 2) hipLaunchKernelGGL(k_conv_wgrad_gen<2>, grid, dim3(WGN_NT), pl.lds, st, a);
+        else if (pl.slots == 4) hipLaunchKernelGGL(k_conv_wgrad_gen<4>, grid, dim3(WGN_NT), pl.lds, st, a);
+        else hipLaunchKernelGGL(k_conv_wgrad_gen<8>, grid, dim3(WGN_NT), pl.lds, st, a);
     } else {
         MRX_REQUIRE(Cout <= WS_MAXCO, MRX_EUNSUP, "mrx_conv_wgrad: Cout=%d (64 or <= %d)", Cout, WS_MAXCO);
         WsmallArgs a;

@@ -1,0 +1,239 @@
+"""Differentiable forms of the operators the NormUnet / VarNetBlock / gated-cell forward passes call (training under the
+reference's trainer covers E2EVN, models/vn.py:94-142, and RIMs with GRU / MGU cells, rim_block.py:217-249, beside CIRIM).
+
+Same names and arguments as `mridc_amd.ops`; a module picks this namespace instead of `ops` when gradients are being recorded
+(`diff.active(...)`).  Everything heavy stays on the HIP kernels in both directions: convolutions (forward `mrx_conv2d` / Winograd, data
+gradient `mrx_conv2d` on flipped weights with the replicate-padding fold, weight gradient `mrx_conv_wgrad` -- the generic matrix-core
+kernel for arbitrary channel counts), the transposed 2x2 convolution (its gradients are 1x1 convolutions of the pixel-unshuffled output
+gradient), FFTs (the adjoint of a transform is the opposite transform times N^(+-1) for the unnormalised conventions).  Normalisation
+statistics, activations' derivatives, pooling, padding, concatenation and the pointwise complex arithmetic are torch device ops inside
+the backward (a few passes over the activations; the FLOPs are in the convolutions)."""
+import torch
+import torch.nn.functional as F
+
+import mridc_amd.collections.common.parts.fft as fft
+from mridc_amd import ops
+
+PAD_ZERO, PAD_REPLICATE = ops.PAD_ZERO, ops.PAD_REPLICATE
+ACT_NONE, ACT_RELU, ACT_LEAKY = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY
+
+
+def active(*tensors):
+    """True when torch is recording gradients and one of the tensors takes part."""
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
+def _act_grad(dy, y, act, slope):
+    if act == ACT_NONE:
+        return dy
+    return torch.where(y > 0, dy, dy * (slope if act == ACT_LEAKY else 0.0))
+
+
+class _Conv2d(torch.autograd.Function):
+    """act(conv(pad(x), w) + b), 'same' size."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dilation, pad_mode, act, slope):
+        y = ops.conv2d(x, w, b, dilation, pad_mode, act, slope)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.cfg = (int(dilation), int(pad_mode), int(act), float(slope), b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dilation, pad_mode, act, slope, has_b = ctx.cfg
+        g = _act_grad(dy.contiguous(), y, act, slope)
+        k = int(w.shape[-1])
+        dx = ops.conv_dgrad(g, w, dilation, pad_mode) if ctx.needs_input_grad[0] else None
+        dw = ops.conv_wgrad(x, g, k, dilation, pad_mode) if ctx.needs_input_grad[1] else None
+        db = g.sum((0, 2, 3)) if (has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
+    return _Conv2d.apply(x, weight, bias, dilation, pad_mode, act, slope)
+
+
+class _InstanceNormAct(torch.autograd.Function):
+    """act((x - mean) / sqrt(var + eps)) per (b, c) plane, biased variance (InstanceNorm2d without affine)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, act, slope):
+        rstd = torch.rsqrt(x.var((2, 3), unbiased=False, keepdim=True) + eps)
+        out = ops.instance_norm_act(x, eps, act, slope, inplace=False)
+        ctx.save_for_backward(out, rstd)
+        ctx.cfg = (int(act), float(slope))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        out, rstd = ctx.saved_tensors
+        act, slope = ctx.cfg
+        if act == ACT_LEAKY:
+            yhat = torch.where(out > 0, out, out / slope)
+        elif act == ACT_NONE:
+            yhat = out
+        else:
+            raise NotImplementedError("instance norm + ReLU backward (the normalised value is not recoverable from the output)")
+        g = _act_grad(dy, out, act, slope)
+        gm = g.mean((2, 3), keepdim=True)
+        gy = (g * yhat).mean((2, 3), keepdim=True)
+        return rstd * (g - gm - yhat * gy), None, None, None
+
+
+def instance_norm_act(x, eps=1e-5, act=ACT_LEAKY, slope=0.2, inplace=True):
+    return _InstanceNormAct.apply(x, eps, act, slope)
+
+
+def conv_instance_norm_act(x, weight, eps=1e-5, act=ACT_LEAKY, slope=0.2, pad_mode=PAD_ZERO):
+    return instance_norm_act(conv2d(x, weight, None, 1, pad_mode), eps, act, slope)
+
+
+class _ConvTranspose2x2(torch.autograd.Function):
+    """ConvTranspose2d(kernel 2, stride 2, no bias): out[b,co,2h+i,2w+j] = sum_ci x[b,ci,h,w] w[ci,co,i,j]."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return ops.conv_transpose2x2(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        cin, cout = int(w.shape[0]), int(w.shape[1])
+        dyu = F.pixel_unshuffle(dy.contiguous(), 2)                      # [B, cout * 4, H, W], channel (co, i, j)
+        dx = ops.conv2d(dyu, w.detach().reshape(cin, cout * 4, 1, 1), None) if ctx.needs_input_grad[0] else None
+        dw = ops.conv_wgrad(dyu, x, 1, 1, PAD_ZERO).reshape(cin, cout, 2, 2) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def conv_transpose2x2(x, weight):
+    return _ConvTranspose2x2.apply(x, weight)
+
+
+class _AvgPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (int(x.shape[-2]), int(x.shape[-1]))
+        return ops.avg_pool2x2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        H, W = ctx.hw
+        g = F.interpolate(dy, scale_factor=2, mode="nearest") * 0.25
+        return F.pad(g, (0, W - g.shape[-1], 0, H - g.shape[-2]))         # an odd last row / column is not pooled
+
+
+def avg_pool2x2(x):
+    return _AvgPool2x2.apply(x)
+
+
+def pad2d(x, top, bottom, left, right, mode=0):
+    """Zero (negative: crop) or reflect padding, recorded by torch."""
+    return F.pad(x, (left, right, top, bottom), mode="constant" if mode == 0 else "reflect")
+
+
+def concat_channels(a, b):
+    return torch.cat([a, b], dim=1)
+
+
+def group_norm(x, groups):
+    """unet_block.py:71-84."""
+    b, c, h, w = x.shape
+    xg = x.reshape(b, groups, -1)
+    mean = xg.mean(-1, keepdim=True)
+    std = xg.std(-1, keepdim=True)
+    return ((xg - mean) / std).reshape(b, c, h, w), mean, std
+
+
+def group_unnorm(x, mean, std, groups):
+    """unet_block.py:86-90."""
+    b, c, h, w = x.shape
+    return (x.reshape(b, groups, -1) * std + mean).reshape(b, c, h, w)
+
+
+# ---- Fourier transforms and the coil operators -------------------------------------------------------------------------------------------
+def _ratio(x, normalization, spatial_dims):
+    """adjoint(fft2_n) = r * ifft2_n and adjoint(ifft2_n) = fft2_n / r with r = N ("backward"), 1 ("ortho"), 1 / N ("forward")."""
+    dims = spatial_dims if spatial_dims is not None else [-2, -1]
+    xc = x.shape[:-1]
+    n = 1
+    for d in dims:
+        n *= int(xc[d])
+    return {"backward": float(n), "ortho": 1.0, "forward": 1.0 / n}[normalization or "backward"]
+
+
+class _Fft2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, centered, normalization, spatial_dims, inverse):
+        ctx.cfg = (centered, normalization, spatial_dims, inverse)
+        f = fft.ifft2 if inverse else fft.fft2
+        return f(x, centered=centered, normalization=normalization, spatial_dims=spatial_dims)
+
+    @staticmethod
+    def backward(ctx, dy):
+        centered, normalization, spatial_dims, inverse = ctx.cfg
+        r = _ratio(dy, normalization, spatial_dims)
+        f = fft.fft2 if inverse else fft.ifft2
+        g = f(dy.contiguous(), centered=centered, normalization=normalization, spatial_dims=spatial_dims)
+        return g * (1.0 / r if inverse else r), None, None, None, None
+
+
+def fft2(x, centered=False, normalization="backward", spatial_dims=None):
+    return _Fft2.apply(x, centered, normalization, spatial_dims, False)
+
+
+def ifft2(x, centered=False, normalization="backward", spatial_dims=None):
+    return _Fft2.apply(x, centered, normalization, spatial_dims, True)
+
+
+def complex_mul(a, b):
+    return torch.stack([a[..., 0] * b[..., 0] - a[..., 1] * b[..., 1], a[..., 0] * b[..., 1] + a[..., 1] * b[..., 0]], -1)
+
+
+def complex_conj(a):
+    return torch.stack([a[..., 0], -a[..., 1]], -1)
+
+
+def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=False):
+    """vn_block.py:51-69: fft2(x * S)."""
+    return fft2(complex_mul(x, sens), centered, normalization, spatial_dims)
+
+
+def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None, hybrid=False):
+    """vn_block.py:71-87 without the keepdim: sum_c conj(S_c) * ifft2(k)_c."""
+    return complex_mul(ifft2(k, centered, normalization, spatial_dims), complex_conj(sens)).sum(1)
+
+
+def dc_combine(base, pred, ref, mask, dc_weight, eta_k):
+    """vn_block.py:113-119: base - where(mask, pred - ref, 0) * dc_weight - eta_k."""
+    zero = torch.zeros(1, 1, 1, 1, 1, dtype=pred.dtype, device=pred.device)
+    return base - torch.where(mask.bool(), pred - ref, zero) * dc_weight - eta_k
+
+
+def coil_combination(data, sens, method="SENSE", dim=1):
+    """utils.py:251-272."""
+    if method == "SENSE":
+        return complex_mul(data, complex_conj(sens)).sum(dim)
+    if method == "RSS":
+        return torch.sqrt((data ** 2).sum(dim))
+    raise ValueError("Output type not supported.")
+
+
+# ---- gated recurrent cells (rnn_cells.py:112-127, 249-261): convolutions on the HIP kernels, gates recorded by torch ------------------------
+def gru_gates(ih, hh, hx):
+    i_r, i_z, i_n = ih.chunk(3, 1)
+    h_r, h_z, h_n = hh.chunk(3, 1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return n * (1 - z) + z * hx
+
+
+def mgu_gates(ih, hh, hx):
+    i_f, i_c = ih.chunk(2, 1)
+    h_f, h_c = hh.chunk(2, 1)
+    f = torch.sigmoid(i_f + h_f)
+    c = torch.tanh(i_c + f * h_c)
+    return c + f * (hx - c)

@@ -342,3 +342,27 @@ def training_step(model, flat, optimizer, batch, time_steps=None, schedule=None,
     world = allreduce_gradients(flat.grad)
     optimizer.step(grad_scale=1.0 / world)
     return loss.detach()
+
+
+def magnitude_l1_loss(pred, target):
+    """mean | |pred| / max(target) - target / max(target) | on a complex prediction [B,h,w] (the l1 branch of the reference's
+    process_loss for a single estimate, vn.py training_step -> base.py:188-254)."""
+    t = torch.abs(target / torch.max(torch.abs(target)))
+    p = torch.abs(pred) / torch.max(torch.abs(target))
+    return (p - t).abs().mean()
+
+
+def model_training_step(model, flat, optimizer, batch, loss_fn=magnitude_l1_loss, schedule=None):
+    """One data-parallel step of a model whose forward is recorded through `mridc_amd.diff` (E2EVN / VarNet, UNet, RIMs with gated
+    cells): forward, loss, backward on the HIP kernels, one all-reduce of the flat gradient, Adam.  Returns the loss."""
+    model.train()
+    if schedule is not None:
+        optimizer.lr = inverse_sqrt_lr(optimizer.steps, schedule["max_steps"], schedule["base_lr"], schedule.get("warmup_ratio", 0.1),
+                                       schedule.get("min_lr", 0.0), schedule.get("warmup_steps"))
+    flat.zero_grad()
+    pred = model(batch["y"], batch["sensitivity_maps"], batch["mask"], batch.get("init_pred"), batch["target"])
+    loss = loss_fn(pred, batch["target"])
+    loss.backward()
+    world = allreduce_gradients(flat.grad)
+    optimizer.step(grad_scale=1.0 / world)
+    return loss.detach()

@@ -220,3 +220,118 @@ def test_explicit_tape_matches_autograd_tape(dev, precision):
         assert float(close) >= 0.98, float(close)
     finally:
         ag.set_precision("f32")
+
+
+@pytest.mark.parametrize("case", [(1, 2, 14, 37, 45, 3), (2, 14, 14, 20, 33, 3), (1, 28, 56, 16, 40, 3), (1, 56, 28, 19, 21, 3), (1, 64, 192, 12, 40, 1),
+                                  (1, 192, 96, 9, 33, 1), (1, 288, 144, 10, 12, 3), (1, 18, 36, 640, 372, 3), (1, 7, 5, 8, 32, 3), (3, 33, 130, 5, 7, 1), (1, 4, 16, 20, 18, 5), (1, 16, 16, 20, 18, 3, 2), (2, 6, 24, 13, 35, 5, 2)],
+                         ids=lambda c: f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" + (f"d{c[6]}" if len(c) > 6 else ""))
+def test_conv_wgrad_any_channels(dev, case):
+    """The generic weight-gradient kernel (k_conv_wgrad_gen: NormUnet 14 / 28 / 56 ... channels, gate convolutions into 3 F channels; every
+    Cout other than 64 and <= 4) against autograd in float64, zero and replicate padding, with and without accumulation."""
+    import torch.nn.functional as F
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    B, Cin, Cout, H, W, k = case[:6]
+    dil = case[6] if len(case) > 6 else 1
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    p = dil * (k - 1) // 2
+    for mode, pm in (("constant", ops.PAD_ZERO), ("replicate", ops.PAD_REPLICATE)):
+        w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+        xp = F.pad(x.double(), (p, p, p, p), mode=mode) if p else x.double()
+        (ref,) = torch.autograd.grad(F.conv2d(xp, w, dilation=dil), w, dy.double())
+        got = ops.conv_wgrad(x.to(dev), dy.to(dev), k, dil, pm)
+        assert rel_l2(got, ref) <= 2e-6, (mode, rel_l2(got, ref))
+        if p == 0:
+            break
+    acc = torch.ones(Cout, Cin, k, k, device=dev)
+    ops.conv_wgrad(x.to(dev), dy.to(dev), k, dil, pm, out=acc, accumulate=True)
+    assert rel_l2(acc.cpu().double() - 1.0, ref) <= 5e-6
+
+
+@pytest.mark.parametrize("case", [("backward", False, "SENSE", True), ("ortho", True, "RSS", False)], ids=lambda c: f"{c[0]}_{c[2]}")
+def test_e2evn_training_gradients_vs_oracle_autograd(dev, case):
+    """SURVEY 8 row T, E2EVN (vn.py:94-142 under the reference's trainer): loss and EVERY parameter gradient of a 2-cascade VarNet
+    (NormUnet 8 channels, 2 pooling levels, odd sizes so the reflect pad / crop branches run) on the HIP training path (mridc_amd/diff.py:
+    convolution, transposed-convolution and FFT backward on the kernels) against torch autograd of the CPU oracle."""
+    import oracle
+    from mridc_amd import synthetic
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    norm, centered, comb, normalize = case
+    cfg = dict(num_cascades=2, channels=8, pooling_layers=2, padding_size=11, normalize=normalize, no_dc=False, use_sens_net=False,
+               fft_centered=centered, fft_normalization=norm, spatial_dims=[-2, -1], coil_dim=1, coil_combination_method=comb,
+               train_loss_fn="l1", val_loss_fn="l1")
+    torch.manual_seed(5)
+    model = VarNet(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("dc_weight"):
+                p_.fill_(0.7)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    s = synthetic.make_slice(3, 26, 21, slice_idx=2)
+    y = s["y"] * 50.0                                   # O(1) magnitudes through the normalisations
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    ref_out = oracle.models.varnet_forward(p, cfg, y, s["sensitivity_maps"], s["mask"], None, s["target"])
+    tgt = s["target"] * 50.0
+    ref_mag = torch.abs(ref_out) if comb == "SENSE" else torch.view_as_real(ref_out).abs().sum(-1)
+    ref_loss = (ref_mag - tgt).abs().mean()
+    ref_loss.backward()
+    model = model.to(dev).train()
+    out = model(y.to(dev), s["sensitivity_maps"].to(dev), s["mask"].to(dev), None, s["target"].to(dev))
+    mag = torch.abs(out) if comb == "SENSE" else torch.view_as_real(out).abs().sum(-1)
+    loss = (mag - tgt.to(dev)).abs().mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * abs(float(ref_loss.detach())), (float(loss.detach()), float(ref_loss.detach()))
+    checked = 0
+    for name, prm in model.named_parameters():
+        ref = p[name].grad
+        if name == "dc_weight":                        # the model-level parameter is unused by forward (vn.py:91)
+            assert ref is None and prm.grad is None
+            continue
+        assert ref is not None and prm.grad is not None, name
+        assert_close(prm.grad, ref, 2e-3, f"gradient of {name}")
+        checked += 1
+    assert checked == len(list(model.parameters())) - 1
+    # inference is unchanged: eval + no_grad takes the fused kernels and agrees with the recorded forward
+    model.eval()
+    with torch.no_grad():
+        out2 = model(y.to(dev), s["sensitivity_maps"].to(dev), s["mask"].to(dev), None, s["target"].to(dev))
+    assert_close(torch.view_as_real(out2), torch.view_as_real(out.detach()), 1e-4, "train vs eval forward")
+
+
+@pytest.mark.parametrize("cell", ["GRU", "MGU"])
+def test_gated_rim_training_gradients_vs_oracle_autograd(dev, cell):
+    """RIM with ConvGRU / ConvMGU cells (rim_block.py:217-249, rnn_cells.py:112-127 / 249-261; the reference's base_rim configuration):
+    gradients of every parameter of one no_dc cascade on the HIP training path against torch autograd of the CPU oracle."""
+    import oracle
+    from mridc_amd import synthetic
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    kw = dict(recurrent_layer=cell, conv_filters=[16, 16, 2], conv_kernels=[5, 3, 3], conv_dilations=[1, 2, 1], conv_bias=[True, True, False],
+              recurrent_filters=[16, 16, 0], recurrent_kernels=[1, 1, 0], recurrent_dilations=[1, 1, 0], recurrent_bias=[True, True, False],
+              depth=2, time_steps=4, conv_dim=2, no_dc=True, fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1)
+    torch.manual_seed(11)
+    blk = RIMBlock(**kw)
+    state = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    s = synthetic.make_slice(3, 20, 18, slice_idx=0)
+    y, S, m = s["y"] * 50.0, s["sensitivity_maps"], s["mask"]
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    cfg = oracle.rim.RIMConfig(**kw)
+    etas_ref, _ = oracle.rim.rim_block_forward(p, cfg, y, y, S, m, None, None, 1.0, False)
+    w = torch.linspace(0.2, 1.0, len(etas_ref))
+    ref_loss = sum(wi * e.abs().mean() for wi, e in zip(w, etas_ref))
+    ref_loss.backward()
+    blk = blk.to(dev).train()
+    etas, _ = blk(y.to(dev), y.to(dev), S.to(dev), m.to(dev), None, None, 1.0, False)
+    loss = sum(wi * e.abs().mean() for wi, e in zip(w.tolist(), etas))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * abs(float(ref_loss.detach()))
+    checked = 0
+    for name, prm in blk.named_parameters():
+        ref = p[name].grad
+        if name.endswith("dc_weight"):
+            continue
+        assert ref is not None and prm.grad is not None, name
+        assert_close(prm.grad, ref, 2e-3, f"{cell}: gradient of {name}")
+        checked += 1
+    assert checked >= 9
