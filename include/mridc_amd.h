@@ -429,6 +429,12 @@ int mrx_pad2d(const float* in, float* out, int64_t planes, int H, int W, int top
 int mrx_avg_pool2x2(const float* in, float* out, int64_t planes, int H, int W, void* stream);
 int mrx_conv_transpose2x2(const float* x, const float* w, float* out, int B, int Cin, int Cout, int H, int W,
                           void* stream);
+/* the same + the InstanceNorm statistics (mean, sum of squared deviations) [B,Cout,2] of its output out of the same accumulators
+ * (unet_block.py:296-299: ConvTranspose2d -> InstanceNorm2d -> LeakyReLU becomes this + mrx_instance_norm_apply); even Cout, tuned
+ * shapes only (MRX_EUNSUP otherwise).  work: mrx_conv_transpose2x2_stats_work_floats() floats. */
+int64_t mrx_conv_transpose2x2_stats_work_floats(int B, int Cout, int H, int W);
+int mrx_conv_transpose2x2_stats(const float* x, const float* w, float* out, float* stats, float* work, int B, int Cin, int Cout, int H, int W,
+                                void* stream);
 int mrx_copy_channels(const float* src, float* dst, int B, int C, int64_t HW, int Ctot, int c0, void* stream);
 /* torch.cat([a, b], dim=1) of [B,Ca,HW] and [B,Cb,HW] in one launch (the skip concat, unet_block.py:224) */
 int mrx_concat_channels(const float* a, const float* b, float* out, int B, int Ca, int Cb, int64_t HW, void* stream);

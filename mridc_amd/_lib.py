@@ -140,6 +140,8 @@ _SIGNATURES = {
     "mrx_group_norm_apply": ([_p, _p, _p, _p, _i64, _i64, _i, _p], _i),
     "mrx_pad2d": ([_p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_avg_pool2x2": ([_p, _p, _i64, _i, _i, _p], _i),
+    "mrx_conv_transpose2x2_stats_work_floats": ([_i, _i, _i, _i], _i64),
+    "mrx_conv_transpose2x2_stats": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_conv_transpose2x2": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_dc_residual": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_qmri_signal": ([_p, _p, _p, _p, _p, _i, _p, _i64, _i64, _f, _p], _i),

@@ -58,9 +58,9 @@ class TransposeConvBlock(torch.nn.Module):
         )
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
-        o = _ns(image, self.layers[0].weight)
-        x = o.conv_transpose2x2(image, self.layers[0].weight)
-        return o.instance_norm_act(x, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
+        if diff.active(image, self.layers[0].weight):
+            return diff.instance_norm_act(diff.conv_transpose2x2(image, self.layers[0].weight), self.layers[1].eps, ops.ACT_LEAKY, 0.2)
+        return ops.conv_transpose2x2_instance_norm_act(image, self.layers[0].weight, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
 
 
 class Unet(torch.nn.Module):

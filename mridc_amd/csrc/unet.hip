@@ -364,9 +364,12 @@ __global__ void k_convT2x2(const float* x, const float* w, float* out, int B, in
 // that are contiguous across the wave.  The generic kernel above re-reads every input Cout*4 times.
 typedef float ct_f2 __attribute__((ext_vector_type(2)));
 typedef float ct_f4 __attribute__((ext_vector_type(4)));
-template <int COG>
+// STATS: the InstanceNorm statistics of the output come out of the same accumulators -- per workgroup (256 input pixels = 1024 outputs of
+// one plane) and cout the mean, then the sum of squared deviations from it (two fixed-order block reductions) into
+// tstats[b][tile][cout][2]; k_tile_stats_finalize merges the tiles (unet_block.py:296-299: ConvTranspose2d -> InstanceNorm2d -> LeakyReLU).
+template <int COG, bool STATS>
 __global__ __launch_bounds__(UN_NT) void k_convT2x2_t(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int Cin,
-                                                      int Cout, int H, int W) {
+                                                      int Cout, int H, int W, float* __restrict__ tstats) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];  // [Cin][COG] quads of this channel group
     const int g0 = blockIdx.y * COG, b = blockIdx.z;
     for (int i = threadIdx.x; i < Cin * COG * 4; i += UN_NT) {
@@ -375,33 +378,140 @@ __global__ __launch_bounds__(UN_NT) void k_convT2x2_t(const float* __restrict__ 
     }
     __syncthreads();
     const long long HW = (long long)H * W;
-    const long long pix = (long long)blockIdx.x * UN_NT + threadIdx.x;
-    if (pix >= HW) return;
+    const long long pix_raw = (long long)blockIdx.x * UN_NT + threadIdx.x;
+    const bool live = pix_raw < HW;
+    if (!STATS && !live) return;
+    const long long pix = live ? pix_raw : HW - 1;         // (STATS: idle threads stay for the block reductions)
     const int y = (int)(pix / W), xx = (int)(pix - (long long)y * W);
     const float* xp = x + (long long)b * Cin * HW + pix;
     ct_f4 acc[COG];
 #pragma unroll
     for (int co = 0; co < COG; ++co) acc[co] = (ct_f4){0.f, 0.f, 0.f, 0.f};
-    for (int ci = 0; ci < Cin; ++ci) {
+    int ci = 0;
+    for (; ci + 4 <= Cin; ci += 4) {                    // four input planes in flight per step (the loads are the latency of this kernel)
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = xp[(long long)(ci + u) * HW];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const ct_f4* wq = reinterpret_cast<const ct_f4*>(wsm) + (ci + u) * COG;
+#pragma unroll
+            for (int co = 0; co < COG; ++co) acc[co] += v[u] * wq[co];  // same accumulation order over ci as the generic kernel
+        }
+    }
+    for (; ci < Cin; ++ci) {
         const float v = xp[(long long)ci * HW];
         const ct_f4* wq = reinterpret_cast<const ct_f4*>(wsm) + ci * COG;
 #pragma unroll
-        for (int co = 0; co < COG; ++co) acc[co] += v * wq[co];  // same accumulation order over ci as the generic kernel
+        for (int co = 0; co < COG; ++co) acc[co] += v * wq[co];
     }
     const int OW = 2 * W;
     float* op = out + (((long long)b * Cout + g0) * 2 * H + 2 * y) * OW + 2 * xx;
+    if (live) {
 #pragma unroll
-    for (int co = 0; co < COG; ++co) {
-        float* o = op + (long long)co * 4 * HW;
-        *reinterpret_cast<ct_f2*>(o) = (ct_f2){acc[co][0], acc[co][1]};
-        *reinterpret_cast<ct_f2*>(o + OW) = (ct_f2){acc[co][2], acc[co][3]};
+        for (int co = 0; co < COG; ++co) {
+            float* o = op + (long long)co * 4 * HW;
+            *reinterpret_cast<ct_f2*>(o) = (ct_f2){acc[co][0], acc[co][1]};
+            *reinterpret_cast<ct_f2*>(o + OW) = (ct_f2){acc[co][2], acc[co][3]};
+        }
+    }
+    if (STATS) {
+        __shared__ float red[UN_NT / 64];
+        const long long rem = HW - (long long)blockIdx.x * UN_NT;
+        const float inv_n = 1.0f / (4.0f * (float)(rem < UN_NT ? rem : UN_NT));
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int co = 0; co < COG; ++co) {
+            float mean = 0.f;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                float t = 0.f;
+                if (live) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t += pass == 0 ? acc[co][q] : (acc[co][q] - mean) * (acc[co][q] - mean);
+                }
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+                __syncthreads();                   // the previous round's readers are done with `red`
+                if (lane == 0) red[wv] = t;
+                __syncthreads();
+                const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+                if (pass == 0)
+                    mean = tot * inv_n;
+                else if (threadIdx.x == 0) {
+                    float* ts = tstats + (((long long)b * gridDim.x + blockIdx.x) * Cout + g0 + co) * 2;
+                    ts[0] = mean;
+                    ts[1] = tot;
+                }
+            }
+        }
+    }
+}
+// merge per-tile (mean, M2) into per-plane (mean, M2): one wave per (b, cout), Chan et al. pairwise updates in double; every tile holds
+// n_tile values except the last (n_last)
+__global__ __launch_bounds__(64) void k_tile_stats_finalize(const float* __restrict__ tstats, float* __restrict__ stats, int ntiles, int Cout,
+                                                           double n_tile, double n_last) {
+    const int plane_id = blockIdx.x, b = plane_id / Cout, co = plane_id - b * Cout;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 64) {
+        const double nb = t == ntiles - 1 ? n_last : n_tile;
+        const float* p = tstats + (((long long)b * ntiles + t) * Cout + co) * 2;
+        const double mb = (double)p[0], qb = (double)p[1];
+        const double tot = n + nb, delta = mb - mean;
+        mean += delta * nb / tot;
+        m2 += qb + delta * delta * n * nb / tot;
+        n = tot;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double nb = __shfl_xor(n, off, 64), mb = __shfl_xor(mean, off, 64), qb = __shfl_xor(m2, off, 64);
+        const double tot = n + nb;
+        if (tot > 0.0) {
+            const double delta = mb - mean;
+            mean += delta * nb / tot;
+            m2 += qb + delta * delta * n * nb / tot;
+        }
+        n = tot;
+    }
+    if (threadIdx.x == 0) {
+        stats[(long long)plane_id * 2] = (float)mean;
+        stats[(long long)plane_id * 2 + 1] = (float)m2;
     }
 }
 template <int COG>
-static int launch_convT2x2_t(const float* x, const float* w, float* out, int B, int Cin, int Cout, int H, int W, hipStream_t st) {
+static int launch_convT2x2_t(const float* x, const float* w, float* out, int B, int Cin, int Cout, int H, int W, hipStream_t st,
+                             float* tstats = nullptr) {
     const size_t lds = sizeof(float) * (size_t)Cin * COG * 4;
-    hipLaunchKernelGGL((k_convT2x2_t<COG>), dim3((unsigned)(((long long)H * W + UN_NT - 1) / UN_NT), Cout / COG, B), dim3(UN_NT), lds, st, x, w,
-                       out, Cin, Cout, H, W);
+    const dim3 grid((unsigned)(((long long)H * W + UN_NT - 1) / UN_NT), Cout / COG, B);
+    if (tstats)
+        hipLaunchKernelGGL((k_convT2x2_t<COG, true>), grid, dim3(UN_NT), lds, st, x, w, out, Cin, Cout, H, W, tstats);
+    else
+        hipLaunchKernelGGL((k_convT2x2_t<COG, false>), grid, dim3(UN_NT), lds, st, x, w, out, Cin, Cout, H, W, tstats);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+static bool convT_tuned(const float* out, int B, int Cin, int Cout) {
+    return B <= 65535 && Cout <= 65535 * 8 && (size_t)Cin * 14 * 16 <= 48 * 1024 && (((uintptr_t)out) & 7) == 0;
+}
+// the transposed convolution + the InstanceNorm statistics (mean, sum of squared deviations) [B, Cout, 2] of its output in one pass;
+// tuned shapes only (even Cout), MRX_EUNSUP otherwise so the caller takes mrx_conv_transpose2x2 + mrx_instance_norm_act
+extern "C" int64_t mrx_conv_transpose2x2_stats_work_floats(int B, int Cout, int H, int W) {
+    if (B < 0 || Cout < 1 || H < 1 || W < 1) return -1;
+    return (int64_t)B * (((long long)H * W + UN_NT - 1) / UN_NT) * Cout * 2;
+}
+extern "C" int mrx_conv_transpose2x2_stats(const float* x, const float* w, float* out, float* stats, float* work, int B, int Cin, int Cout,
+                                           int H, int W, void* stream) {
+    MRX_REQUIRE(x && w && out && stats && work && B >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL,
+                "mrx_conv_transpose2x2_stats: bad argument");
+    MRX_REQUIRE(convT_tuned(out, B, Cin, Cout) && Cout % 2 == 0, MRX_EUNSUP, "mrx_conv_transpose2x2_stats: Cout=%d Cin=%d", Cout, Cin);
+    if (B == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long HW = (long long)H * W, ntiles = (HW + UN_NT - 1) / UN_NT;
+    int rc;
+    if (Cout % 14 == 0 && ntiles * B * (Cout / 14) >= 2048) rc = launch_convT2x2_t<14>(x, w, out, B, Cin, Cout, H, W, st, work);
+    else if (Cout % 8 == 0 && ntiles * B * (Cout / 8) >= 2048) rc = launch_convT2x2_t<8>(x, w, out, B, Cin, Cout, H, W, st, work);
+    else rc = launch_convT2x2_t<2>(x, w, out, B, Cin, Cout, H, W, st, work);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tile_stats_finalize, dim3(B * Cout), dim3(64), 0, st, (const float*)work, stats, (int)ntiles, Cout, 4.0 * UN_NT,
+                       4.0 * (double)(HW - (ntiles - 1) * UN_NT));
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -409,7 +519,12 @@ extern "C" int mrx_conv_transpose2x2(const float* x, const float* w, float* out,
                                      void* stream) {
     MRX_REQUIRE(x && w && out && B >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_transpose2x2: bad argument");
     if (B == 0) return MRX_OK;
-    const bool tuned = B <= 65535 && Cout <= 65535 * 8 && (size_t)Cin * 14 * 16 <= 48 * 1024 && (((uintptr_t)out) & 7) == 0;
+    const bool tuned = convT_tuned(out, B, Cin, Cout);
+    // few pixels per channel group would leave most CUs idle (28 -> 14 channels at 320 x 192: 240 workgroups): narrower groups then
+    const long long wgs = ((long long)H * W + UN_NT - 1) / UN_NT * B;
+    if (tuned && Cout % 14 == 0 && wgs * (Cout / 14) >= 2048) return launch_convT2x2_t<14>(x, w, out, B, Cin, Cout, H, W, (hipStream_t)stream);
+    if (tuned && Cout % 8 == 0 && wgs * (Cout / 8) >= 2048) return launch_convT2x2_t<8>(x, w, out, B, Cin, Cout, H, W, (hipStream_t)stream);
+    if (tuned && Cout % 2 == 0) return launch_convT2x2_t<2>(x, w, out, B, Cin, Cout, H, W, (hipStream_t)stream);
     if (tuned && Cout % 14 == 0) return launch_convT2x2_t<14>(x, w, out, B, Cin, Cout, H, W, (hipStream_t)stream);
     if (tuned && Cout % 8 == 0) return launch_convT2x2_t<8>(x, w, out, B, Cin, Cout, H, W, (hipStream_t)stream);
     hipLaunchKernelGGL(k_convT2x2, dim3(un_grid((long long)B * Cout * 4 * H * W)), dim3(UN_NT), 0, (hipStream_t)stream, x, w, out, B,

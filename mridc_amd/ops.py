@@ -1064,6 +1064,27 @@ def conv_transpose2x2(x, weight):
     return out
 
 
+def conv_transpose2x2_instance_norm_act(x, weight, eps=1e-5, act=ACT_LEAKY, slope=0.2):
+    """ConvTranspose2d(k 2, s 2, no bias) -> InstanceNorm2d -> activation (unet_block.py:296-299): the statistics come out of the transposed
+    convolution's accumulators (mrx_conv_transpose2x2_stats), one more pass applies them; shapes without the tuned kernel take the three-pass norm."""
+    x, weight = _lib.f32c(x), _lib.f32c(weight.detach())
+    B, Cin, H, W = _nchw(x)
+    Cin_w, Cout, kh, kw = [int(v) for v in weight.shape]
+    if Cin_w != Cin or kh != 2 or kw != 2:
+        raise ValueError("conv_transpose2x2 expects weight [Cin,Cout,2,2]")
+    L = _lib.lib()
+    if Cout % 2 or Cin * 14 * 16 > 48 * 1024:
+        return instance_norm_act(conv_transpose2x2(x, weight), eps, act, slope)
+    out = torch.empty(B, Cout, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    stats = torch.empty(B, Cout, 2, dtype=torch.float32, device=x.device)
+    work = torch.empty(int(L.mrx_conv_transpose2x2_stats_work_floats(B, Cout, H, W)), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_conv_transpose2x2_stats(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(out), _lib.ptr(stats), _lib.ptr(work), B, Cin, Cout, H, W,
+                                             _lib.stream_ptr()), "mrx_conv_transpose2x2_stats")
+    _lib.check(L.mrx_instance_norm_apply(_lib.ptr(out), _lib.ptr(out), _lib.ptr(stats), B * Cout, 4 * H * W, float(eps), int(act),
+                                         float(slope), _lib.stream_ptr()), "mrx_instance_norm_apply")
+    return out
+
+
 def concat_channels(a, b):
     """torch.cat([a, b], dim=1) in one launch."""
     a, b = _lib.f32c(a), _lib.f32c(b)

@@ -326,6 +326,14 @@ def test_unet_pieces_vs_torch(dev):
         wt = torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5
         assert_close(ops.conv_transpose2x2(xt.to(dev), wt.to(dev)), F.conv_transpose2d(xt, wt, stride=2), 1e-5,
                      f"conv transpose {(B_, Ci, Co, H_, W_)} (channel-group kernel for Cout % 14 == 0 or % 8 == 0)")
+        # TransposeConvBlock (unet_block.py:296-299): statistics out of the transposed convolution's accumulators (odd Cout: three-pass norm)
+        ref_t = F.leaky_relu(F.instance_norm(F.conv_transpose2d(xt.double(), wt.double(), stride=2), eps=1e-5), 0.2)
+        assert_close(ops.conv_transpose2x2_instance_norm_act(xt.to(dev), wt.to(dev), 1e-5, ops.ACT_LEAKY, 0.2), ref_t, 1e-5,
+                     f"conv transpose + instance norm + leaky {(B_, Ci, Co, H_, W_)}")
+    xo = torch.randn(1, 14, 40, 40, generator=g) + 300.0           # a large mean: the tile-wise (mean, M2) merge keeps the variance
+    wo = torch.randn(14, 14, 2, 2, generator=g).abs() / 14
+    assert_close(ops.conv_transpose2x2_instance_norm_act(xo.to(dev), wo.to(dev), 1e-5, ops.ACT_LEAKY, 0.2),
+                 F.leaky_relu(F.instance_norm(F.conv_transpose2d(xo.double(), wo.double(), stride=2), eps=1e-5), 0.2), 2e-4, "large-mean planes")
     y = torch.randn(2, 3, 17, 22, generator=g)
     assert_close(ops.concat_channels(x.to(dev), y.to(dev)), torch.cat([x, y], 1), 1e-12, "concat")
 
