@@ -16,6 +16,7 @@ for m in "--model e2evn" "--model e2evn --unet 18x4" "--model qcirim" "--model r
 done
 python3 bench.py --train --steps 6 --warmup 2 2>/dev/null | tail -1 > $O/train_bench.json
 python3 bench.py --train --dtype bf16 --steps 6 --warmup 2 2>/dev/null | tail -1 >> $O/train_bench.json
+python3 bench.py --train --model e2evn --steps 6 --warmup 2 2>/dev/null | tail -1 >> $O/train_bench.json
 rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python3 bench.py --train --dtype bf16 --steps 3 --warmup 1 > $O/prof_train.log 2>&1
 python3 tools/rocpd_summary.py $O/prof_train/*results.db > $O/train_bf16_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $O/prof_e2evn -o e -- python3 bench.py --model e2evn --steps 4 --warmup 1 --graph 0 --streams 1 > $O/prof_e2evn.log 2>&1
