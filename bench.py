@@ -646,6 +646,7 @@ def main():
     timer.wrap(ops, "rim_layer_indrnn", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
     timer.wrap(ops, "rim_layer_indrnn_packed", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
     timer.wrap(ops, "rim_layer_indrnn_wino", lambda x, *a, **k: "conv_layer2_wino")
+    timer.wrap(ops, "rim_layer2_sb", lambda x, *a, **k: "conv_layer2_sb")
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv_parts", lambda *a, **k: "llg")     # gradient whose last pass is done by layer 1's tile loader
@@ -736,6 +737,14 @@ def main():
             kname = ("k_rim_layer_wino (conv3x3 d2 64->64 as Winograd F(2x2,3x3) on the parity sub-lattices + IndRNN 1x1 fused, "
                      "fp32 MFMA 16x16x4 / 32x32x2)")
             executed = 2.0 * (F_hidden * F_hidden * 4 + F_hidden * F_hidden) * npix * B
+        peak2, l2_bf16 = PEAK_FP32_MFMA_TFLOPS, False
+        mss, nss = timer.mean_ms("conv_layer2_sb")
+        if mss:                               # the default: direct convolution on the bf16 matrix pipe, fp32 results (three-term operand split)
+            ms2, n2, l2_bf16, peak2 = mss, nss, True, PEAK_BF16_MFMA_TFLOPS
+            kname = ("k_rim_layer2_sb (conv3x3 d2 64->64 direct form + IndRNN 1x1 fused; every fp32 operand = 3 bf16 terms, 6 term products per "
+                     "multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32-accurate results; 8 chunks x 5 steps (one of ten tap slots is "
+                     "padding) + 4 steps of the 1x1 stage = 528 MFMAs per 32 pixels)")
+            executed = (528 * 32 * 32 * 16 * 2 / 32.0) * npix * B
         traffic = measured_traffic(B, C, H, W, F_hidden)
         tf = (lambda fl: fl / (ms2 * 1e-3) / 1e12) if ms2 else (lambda fl: None)
         ms1, _ = timer.mean_ms("conv_layer1")
@@ -752,25 +761,30 @@ def main():
         flops1 = 2.0 * (F_hidden * 4 * 25 + F_hidden * F_hidden) * npix * B
         l1_bf16 = F_hidden == 64 and os.environ.get("MRX_LAYER1_FP32", "0") in ("", "0")
         issued1_bf16 = (132 * 32 * 32 * 16 * 2 / 32.0) * npix * B if l1_bf16 else 0.0
-        issued_reg = flops_reg - (flops2 - executed) - (flops1 if l1_bf16 else 0.0)      # fp32 part
+        issued2_bf16 = executed if l2_bf16 else 0.0
+        issued1_bf16 += issued2_bf16             # everything issued on the bf16 pipe
+        issued_reg = flops_reg - (flops2 if l2_bf16 else flops2 - executed) - (flops1 if l1_bf16 else 0.0)      # fp32 part
         pipe_ms = lambda f32, b16: 1e3 * (f32 / (PEAK_FP32_MFMA_TFLOPS * 1e12) + b16 / (PEAK_BF16_MFMA_TFLOPS * 1e12))  # noqa: E731
         final_flops = 2.0 * F_hidden * 2 * 9 * npix * B
         t_reg = (ms1 or 0) + (ms2 or 0) + (msf or 0)
         roofline = dict(bound="mfma", kernel=kname,
-                        achieved=tf(executed), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=(tf(executed) / PEAK_FP32_MFMA_TFLOPS) if ms2 else None,
-                        frac_meaning="MFMA FLOPs the kernel issues / fp32-MFMA peak (pipe utilisation)",
+                        achieved=tf(executed), peak=peak2, unit="TFLOP/s",
+                        frac=(tf(executed) / peak2) if ms2 else None,
+                        frac_meaning=("bf16 MFMA FLOPs the kernel issues (6 term products per fp32 multiply, padding included) / dense bf16 MFMA "
+                                      "peak (pipe utilisation)" if l2_bf16 else "MFMA FLOPs the kernel issues / fp32-MFMA peak (pipe utilisation)"),
                         algorithmic_achieved=tf(flops2), algorithmic_frac=(tf(flops2) / PEAK_FP32_MFMA_TFLOPS) if ms2 else None,
-                        algorithmic_note="direct-form FLOPs of SURVEY 8d / time: above `frac` by the Winograd saving (2.0x), not a pipe figure",
-                        traffic=traffic.get("conv_layer2_wino" if msw else "conv_layer2"), traffic_unit="bytes/launch",
-                        traffic_kernel=traffic.get("_kernels", {}).get("conv_layer2_wino" if msw else "conv_layer2"),
+                        algorithmic_note=("fp32 direct-form FLOPs of SURVEY 8d / time, against the fp32-MFMA peak: what the layer delivers in the units "
+                                          "of the fp32 pipe it no longer uses (may exceed 1; not a pipe figure)" if l2_bf16 else
+                                          "direct-form FLOPs of SURVEY 8d / time: above `frac` by the Winograd saving (2.0x), not a pipe figure"),
+                        traffic=traffic.get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"), traffic_unit="bytes/launch",
+                        traffic_kernel=traffic.get("_kernels", {}).get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"),
                         traffic_source=traffic.get("_source"), algorithmic_bytes=3.0 * F_hidden * npix * B * 4,
                         launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
                         regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_fp32_gflop=issued_reg / 1e9,
                                          issued_bf16_gflop=issued1_bf16 / 1e9,
                                          frac_issued=(pipe_ms(issued_reg, issued1_bf16) / t_reg) if t_reg else None,
-                                         note="all three kernels of a step: layer 1 (bf16 matrix pipe, fp32 results via the three-term split), "
-                                              "layer 2 (fp32 MFMA, Winograd), final conv 64->2 on the vector ALUs (2 of 32 MFMA rows would be "
+                                         note="all three kernels of a step: layer 1 and (unless MRIDC_AMD_LAYER2_SB=0: then fp32 MFMA, Winograd) layer 2 on "
+                                              "the bf16 matrix pipe with fp32 results via the three-term split, final conv 64->2 on the vector ALUs (2 of 32 MFMA rows would be "
                                               "used; its 0.55 GFLOP counted at the fp32 rate).  frac_issued = (fp32 work / fp32 peak + bf16 work / "
                                               "dense bf16 peak) / measured time",
                                          layer1_ms=ms1, layer1_kernel="k_rim_layer1_sb" if l1_bf16 else "k_rim_layer<5,1,4>",
@@ -814,7 +828,7 @@ def main():
                                             "calibrated in this run -- this is what makes the figures agree with rocprofv3's kernel durations",
                                      empty_pair_ms=getattr(timer, "pair_ms", None),
                                      raw_ms=dict(llg=timer.raw_ms("llg372") or timer.raw_ms("llg"), conv_layer1=timer.raw_ms("conv_layer1"),
-                                                 conv_layer2=timer.raw_ms("conv_layer2_wino") or timer.raw_ms("conv_layer2"),
+                                                 conv_layer2=timer.raw_ms("conv_layer2_sb") or timer.raw_ms("conv_layer2_wino") or timer.raw_ms("conv_layer2"),
                                                  final=timer.raw_ms("final"))))
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_cascades if 0 < args.cpu_cascades <= cfg["num_cascades"] else cfg["num_cascades"]

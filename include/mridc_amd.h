@@ -245,6 +245,13 @@ int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, const float
  * convolutions on the (row, column) parity sub-lattices, each evaluated with 16 instead of 36 multiplies per 2x2 outputs.
  * Same contract as mrx_rim_layer_indrnn_packed; results differ from the direct form by fp32 round-off only (the transforms
  * use +-1 and 1/2 coefficients).  The packed buffer holds G g G^T per (cout, cin) and the 1x1 weights. */
+/* The same layer (3x3, dilation 2, 64 -> 64 + IndRNN 1x1) as a DIRECT convolution on the bf16 matrix pipe with fp32 results: every fp32
+ * operand is the exact sum of three bf16 terms, six term products per multiply (error O(2^-24), as an fp32 FMA chain).  Same contract as
+ * mrx_rim_layer_indrnn_wino (rim_block.py:233-238); packed = mrx_rim_layer2_sb_pack(w_conv [64,64,3,3], w_ih [64,64,1,1]). */
+int64_t mrx_rim_layer2_sb_pack_floats(void);
+int mrx_rim_layer2_sb_pack(const float* w_conv, const float* w_ih, float* packed, void* stream);
+int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                      float* h_new, int B, int H, int W, void* stream);
 int64_t mrx_rim_layer_wino_pack_floats(int Cin, int F);
 int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, int F, void* stream);
 int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, const float* b_conv, const float* b_ih,

@@ -20,6 +20,7 @@ SOURCES = [
     ("rim_layer.hip", []),
     ("rim_layer_wino.hip", []),
     ("rim_layer1_sb.hip", []),
+    ("rim_layer2_sb.hip", []),
     ("gated_cell.hip", []),
     ("conv_bwd.hip", []),
     ("conv_bf16.hip", []),

@@ -1,0 +1,381 @@
+// rim_layer2_sb.hip -- the second RIM layer (ConvNonlinear 3x3 dilation 2, 64 -> 64, replicate padding, ReLU + IndRNNCell 1x1 64 -> 64;
+// reference models/rim/conv_layers.py:121-123 + rnn_cells.py:384-391) with fp32 results on the bf16 matrix pipe: the three-term operand
+// split of rim_layer1_sb.hip (x = x1 + x2 + x3 in bf16, six term products per multiply, error O(2^-24)) applied to the DIRECT form of the
+// convolution.  19.5 GFLOP x 6 products on v_mfma_f32_32x32x16_bf16 is 44 % of the fp32-MFMA time of the direct form and 87 % of the
+// Winograd form's -- and, unlike fp32 MFMA, it co-issues with the vector ALU, which here only splits operands.
+//
+//   * one persistent workgroup per CU, 8 waves = a 16 x 32 pixel tile, wave = two image rows x 64 couts (4 accumulators: every A operand
+//     read from LDS feeds two MFMAs, every B operand two -- 0.5 LDS reads per MFMA); operands of step s + 1 are read before the MFMAs of step s;
+//   * the contraction runs over 8 chunks of 8 input channels; per chunk five MFMA steps of 16 = 2 taps x 8 channels (lower half-wave tap
+//     2s, upper half-wave tap 2s + 1; the tenth tap slot carries zero weights); the chunk's halo'd tile sits in LDS as three bf16 term
+//     planes [term][pixel][8 channels] (16 B per pixel: one conflict-free ds_read_b128 per B operand), its split weights (30 KB) beside it;
+//   * both are double-buffered: the fp32 values of chunk q + 1 and its weights are requested before the MFMAs of chunk q, split / written
+//     after them; one barrier per chunk;
+//   * ReLU(conv + b) stays in registers and feeds the 1x1 GEMM eight channels at a time (weights resident in LDS), epilogue with
+//     lane = pixel as in rim_layer1_sb.hip.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "mrx_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define S2_NT 512
+#define S2_TH 16
+#define S2_TW 32
+#define S2_F 64
+#define S2_PAD 2
+#define S2_PH (S2_TH + 2 * S2_PAD)          // 20
+#define S2_PW (S2_TW + 2 * S2_PAD)          // 36
+#define S2_NPIX (S2_PH * S2_PW)             // 720
+#define S2_NCH 8                            // channel chunks
+#define S2_KS 5                             // MFMA steps per chunk (10 tap slots, 9 used)
+#define S2_WCH (S2_KS * 3 * 2 * 64)         // 16-byte A operands per chunk (30 KB)
+#define S2_WIH (4 * 3 * 2 * 64)             // 1x1 stage (24 KB)
+#define S2_PACK_U4 (S2_NCH * S2_WCH + S2_WIH)
+
+struct L2sbArgs {
+    const float* x;        // [B,64,H,W]
+    const u32x4* packed;   // mrx_rim_layer2_sb_pack
+    const float* b_conv;   // [64] or null
+    const float* b_ih;     // [64] or null
+    const float* hh;       // [64]
+    const float* hprev;    // [B,64,H,W] or null
+    float* hnew;           // [B,64,H,W]
+    int B, H, W, tiles_x, ntiles;
+    unsigned long long* trace;   // debug (env MRX_L2SB_TRACE): cycle stamps [workgroup][wave][tile 0..1][4]
+};
+
+__device__ __forceinline__ unsigned s2_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void s2_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = s2_pk(a, b);
+    float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = s2_pk(ra, rb);
+    ra -= __uint_as_float(p2 << 16);
+    rb -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = s2_pk(ra, rb);
+}
+__host__ __device__ constexpr int s2_chan(int R, int half) { return 32 * (R >> 4) + (R & 3) + 8 * ((R & 15) >> 2) + 4 * half; }
+
+// conv: out[q * S2_WCH + ((s*3 + t)*2 + blk)*64 + lane][j] = term_t( w[32 blk + lane%32][8 q + j][tap = 2 s + lane/32] )   (0 for tap 9)
+// ih  : out[S2_NCH * S2_WCH + ((s*3 + t)*2 + blk)*64 + lane][j] = term_t( w_ih[32 blk + lane%32][s2_chan(8 s + j, lane/32)] )
+__global__ void k_l2sb_pack(const float* __restrict__ w, const float* __restrict__ w_ih, u32x4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S2_PACK_U4) return;
+    const bool conv = i < S2_NCH * S2_WCH;
+    int r = conv ? i % S2_WCH : i - S2_NCH * S2_WCH;
+    const int q = conv ? i / S2_WCH : 0;
+    const int lane = r & 63;
+    r >>= 6;
+    const int blk = r & 1;
+    r >>= 1;
+    const int t = r % 3, s = r / 3;
+    const int o = 32 * blk + (lane & 31), half = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (conv) {
+            const int tap = 2 * s + half;
+            v[j] = tap < 9 ? w[((long long)o * S2_F + 8 * q + j) * 9 + tap] : 0.f;
+        } else
+            v[j] = w_ih[o * S2_F + s2_chan(8 * s + j, half)];
+    }
+    unsigned p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned p1, p2, p3;
+        s2_split2(v[2 * k], v[2 * k + 1], p1, p2, p3);
+        p[k] = t == 0 ? p1 : (t == 1 ? p2 : p3);
+    }
+    out[i] = u32x4{p[0], p[1], p[2], p[3]};
+}
+
+#define S2_MFMA12(ACC, A, B1, B2, B3)                                                             \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][2], B1, ACC[0], 0, 0, 0);               \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][2], B1, ACC[1], 0, 0, 0);               \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][0], B3, ACC[0], 0, 0, 0);               \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][0], B3, ACC[1], 0, 0, 0);               \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][1], B2, ACC[0], 0, 0, 0);               \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][1], B2, ACC[1], 0, 0, 0);               \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][1], B1, ACC[0], 0, 0, 0);               \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][1], B1, ACC[1], 0, 0, 0);               \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][0], B2, ACC[0], 0, 0, 0);               \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][0], B2, ACC[1], 0, 0, 0);               \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][0], B1, ACC[0], 0, 0, 0);               \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][0], B1, ACC[1], 0, 0, 0);
+
+// LDS (bytes): ih weights 24576 | tables 1024 | 2 x conv weights 30720 | 2 x planes 3 * 720 * 16 = 34560   -> 156 KB
+#define S2_OFF_TAB (S2_WIH * 16)
+#define S2_OFF_W (S2_OFF_TAB + 1024)
+#define S2_OFF_X (S2_OFF_W + 2 * S2_WCH * 16)
+#define S2_LDS (S2_OFF_X + 2 * 3 * S2_NPIX * 16)
+
+__global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
+    u32x4* Wih = reinterpret_cast<u32x4*>(smem_s2);
+    float* tabl = reinterpret_cast<float*>(smem_s2 + S2_OFF_TAB);      // hh, b_conv, b_ih in register order [R][half]
+    u32x4* Wc = reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_W);          // [2][S2_WCH]
+    u32x4* Xp = reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_X);          // [2][3 terms][S2_NPIX]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const long long plane = (long long)a.H * a.W;
+    const int total = a.ntiles * a.B;
+
+    // once per workgroup: 1x1 weights and tables
+    for (int i = tid; i < S2_WIH; i += S2_NT) Wih[i] = a.packed[S2_NCH * S2_WCH + i];
+    if (tid < 64) {
+        const int tc = s2_chan(tid >> 1, tid & 1);
+        tabl[tid] = a.hh[tc];
+        tabl[64 + tid] = a.b_conv ? a.b_conv[tc] : 0.f;
+        tabl[128 + tid] = a.b_ih ? a.b_ih[tc] : 0.f;
+    }
+
+    // staging roles: thread i owns pixels i and i + 512 of the halo'd tile (8 channels of the chunk) and copies <= 4 weight operands
+    constexpr int XV = (S2_NPIX + S2_NT - 1) / S2_NT;                 // 2
+    constexpr int WV = (S2_WCH + S2_NT - 1) / S2_NT;                  // 4
+
+    // The staging pipeline runs two chunks ahead of the MFMAs and across tile boundaries: while chunk q of a tile is multiplied, chunk q + 1
+    // is split and written (mid-chunk: the vector ALU work rides under the other wave's MFMAs) and chunk q + 2 is requested; the first
+    // chunks of the next tile are staged during the last chunks of this one, so the 1x1 stage and the epilogue hide that latency.
+    int st_t = blockIdx.x, st_q = 0;                 // the next chunk to request: tile index, chunk
+    const float* st_xb = a.x;
+    long long goff[XV];
+    auto st_coords = [&]() {
+        if (st_t >= total) return;
+        const int tt = (int)mrx_xcd_band(st_t, total);
+        const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
+        const int h0 = ty0 * S2_TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
+        st_xb = a.x + (long long)b * S2_F * plane;
+#pragma unroll
+        for (int v = 0; v < XV; ++v) {
+            int p = tid + v * S2_NT;
+            p = p < S2_NPIX ? p : S2_NPIX - 1;
+            const int ty = p / S2_PW, tx = p - ty * S2_PW;
+            int gy = h0 + ty - S2_PAD, gx = w0 + tx - S2_PAD;            // replicate border = clamp (conv_layers.py:72-76)
+            gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+            gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+            goff[v] = (long long)gy * a.W + gx;
+        }
+    };
+    float xr[XV][8];
+    u32x4 wr[WV];
+    bool pending = false;
+    auto request_next = [&]() {                      // fp32 values of this thread's pixels and its weight operands of the next chunk
+        pending = st_t < total;
+        if (!pending) return;
+#pragma unroll
+        for (int v = 0; v < XV; ++v)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[v][j] = st_xb[(long long)(8 * st_q + j) * plane + goff[v]];
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+            const int i = tid + v * S2_NT;
+            wr[v] = a.packed[(long long)st_q * S2_WCH + (i < S2_WCH ? i : S2_WCH - 1)];
+        }
+        if (++st_q == S2_NCH) {
+            st_q = 0;
+            st_t += gridDim.x;
+            st_coords();
+        }
+    };
+    auto commit_next = [&](int buf) {                // split into the three bf16 terms, write the planes and the weights
+        if (!pending) return;
+#pragma unroll
+        for (int v = 0; v < XV; ++v) {
+            const int p = tid + v * S2_NT;
+            unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s2_split2(xr[v][2 * k], xr[v][2 * k + 1], p1[k], p2[k], p3[k]);
+            if (p < S2_NPIX) {
+                u32x4* dst = Xp + buf * (3 * S2_NPIX) + p;
+                dst[0] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+                dst[S2_NPIX] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+                dst[2 * S2_NPIX] = u32x4{p3[0], p3[1], p3[2], p3[3]};
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+            const int i = tid + v * S2_NT;
+            if (i < S2_WCH) Wc[buf * S2_WCH + i] = wr[v];
+        }
+    };
+    st_coords();
+    request_next();
+    commit_next(0);
+    request_next();
+    __syncthreads();                                 // chunk 0 of the first tile, the 1x1 weights and the tables are in place
+
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int tt = (int)mrx_xcd_band(t, total);
+        const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
+        const int h0 = ty0 * S2_TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
+
+#define S2_STAMP(i) if (a.trace && lane == 0 && (t - (int)blockIdx.x) / (int)gridDim.x < 2) a.trace[(((long long)blockIdx.x * 8 + wave) * 2 + (t - blockIdx.x) / gridDim.x) * 4 + (i)] = __builtin_readcyclecounter();
+        S2_STAMP(0)
+        // acc[row][ct]: rows 2 wave and 2 wave + 1 of the tile
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rw][ct][r] = tabl[64 + 2 * (ct * 16 + r) + lhi];
+
+        float hp[2][32];
+        auto load_hp = [&](int rw) {              // lanes outside the image read a valid element (clamped) and store nothing
+            const int oy = h0 + 2 * wave + rw, ox = w0 + l31;
+            const int cy = oy < a.H ? oy : a.H - 1, cx = ox < a.W ? ox : a.W - 1;
+            const float* hb = (a.hprev ? a.hprev : a.hnew) + (long long)b * S2_F * plane + (long long)cy * a.W + cx + 4ll * lhi * plane;
+#pragma unroll
+            for (int R = 0; R < 32; ++R) hp[rw][R] = hb[(long long)s2_chan(R, 0) * plane];
+        };
+        auto toff = [](int tp) { return tp < 9 ? (tp / 3) * 2 * S2_PW + (tp % 3) * 2 : 0; };      // dilation 2; the zero-weight slot reads pixel 0
+        for (int q = 0; q < S2_NCH; ++q) {
+            const u32x4* xw = Xp + (q & 1) * (3 * S2_NPIX) + (2 * wave) * S2_PW + l31;
+            const u32x4* wl = Wc + (q & 1) * S2_WCH + lane;
+            u32x4 bt[2][2][3], at[2][2][3];       // [buffer][row | ct][term]
+            auto fetch = [&](int s, int bf) {
+                const int off = lhi ? toff(2 * s + 1) : toff(2 * s);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    bt[bf][0][k] = xw[k * S2_NPIX + off];
+                    bt[bf][1][k] = xw[k * S2_NPIX + off + S2_PW];
+                    at[bf][0][k] = wl[((s * 3 + k) * 2 + 0) * 64];
+                    at[bf][1][k] = wl[((s * 3 + k) * 2 + 1) * 64];
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int s = 0; s < S2_KS; ++s) {
+                const int bf = s & 1;
+                if (s + 1 < S2_KS) fetch(s + 1, bf ^ 1);
+                // the six term pairs of weight >= 2^-16, smallest first; the four accumulators alternate
+#define S2_P(TA, TB)                                                                                                                       \
+    _Pragma("unroll") for (int rw = 0; rw < 2; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at[bf][ct][TA]), __builtin_bit_cast(bf16x8, bt[bf][rw][TB]), acc[rw][ct], 0, 0, 0);
+                S2_P(2, 0) S2_P(0, 2) S2_P(1, 1) S2_P(1, 0) S2_P(0, 1) S2_P(0, 0)
+#undef S2_P
+                if (s == 1) {                     // the readers of the other buffer passed the previous barrier
+                    commit_next((q + 1) & 1);
+                    request_next();
+                }
+                if (s == 2 && q == S2_NCH - 1) load_hp(0);
+            }
+            __syncthreads();
+        }
+
+        S2_STAMP(1)
+        // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev), one of the wave's two rows at a time ------------------
+        // (h_prev of row 0 was requested inside the last chunk; row 1's request goes out now and hides under row 0's tail)
+        load_hp(1);
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw) {
+            const int oy = h0 + 2 * wave + rw, ox = w0 + l31;
+            f32x16 acc2[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[ct][r] = tabl[128 + 2 * (ct * 16 + r) + lhi];
+            const u32x4* wl = Wih + lane;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                unsigned g1[4], g2[4], g3[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int R0 = 8 * s + 2 * k, R1 = R0 + 1;
+                    float v0 = acc[rw][R0 >> 4][R0 & 15], v1 = acc[rw][R1 >> 4][R1 & 15];
+                    v0 = v0 > 0.f ? v0 : 0.f;
+                    v1 = v1 > 0.f ? v1 : 0.f;
+                    s2_split2(v0, v1, g1[k], g2[k], g3[k]);
+                }
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
+                const bf16x8 b3 = __builtin_bit_cast(bf16x8, (u32x4{g3[0], g3[1], g3[2], g3[3]}));
+                bf16x8 at[2][3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) at[ct][k] = __builtin_bit_cast(bf16x8, wl[((s * 3 + k) * 2 + ct) * 64]);
+                S2_MFMA12(acc2, at, b1, b2, b3)
+            }
+            if (oy < a.H && ox < a.W) {
+                float* ob = a.hnew + (long long)b * S2_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
+                const bool first = a.hprev == nullptr;
+#pragma unroll
+                for (int R = 0; R < 32; ++R) {
+                    float v = acc2[R >> 4][R & 15] + tabl[2 * R + lhi] * (first ? 0.f : hp[rw][R]);
+                    v = v > 0.f ? v : 0.f;
+                    ob[(long long)s2_chan(R, 0) * plane] = v;
+                }
+            }
+            if (rw == 0) { S2_STAMP(2) } else { S2_STAMP(3) }
+        }
+    }
+}
+
+extern "C" int64_t mrx_rim_layer2_sb_pack_floats(void) { return (int64_t)S2_PACK_U4 * 4; }
+
+// w_conv [64,64,3,3] (dilation 2, replicate padding), w_ih [64,64,1,1] -> the split-bf16 operand pack of mrx_rim_layer2_sb
+extern "C" int mrx_rim_layer2_sb_pack(const float* w_conv, const float* w_ih, float* packed, void* stream) {
+    MRX_REQUIRE(w_conv && w_ih && packed, MRX_EINVAL, "mrx_rim_layer2_sb_pack: null pointer");
+    hipLaunchKernelGGL(k_l2sb_pack, dim3((S2_PACK_U4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, reinterpret_cast<u32x4*>(packed));
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// h_new = ReLU(W_ih ReLU(conv3x3_d2(replicate_pad(x)) + b_conv) + b_ih + hh * h_prev), F = 64 (rim_block.py:233-238 for the second layer)
+extern "C" int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
+                                 const float* h_prev, float* h_new, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer2_sb: null pointer");
+    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer2_sb: bad dims");
+    if (B == 0) return MRX_OK;
+    static bool attr_done = false;   // once: keeps launches legal under hipGraph capture
+    static int ncu = 0;
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MRX_HIP(hipGetDevice(&dev));
+        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        attr_done = true;
+    }
+    L2sbArgs a;
+    a.x = x, a.packed = reinterpret_cast<const u32x4*>(packed), a.b_conv = b_conv, a.b_ih = b_ih, a.hh = hh, a.hprev = h_prev, a.hnew = h_new;
+    a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
+    const long long total = (long long)a.ntiles * B;
+    const int grid = (int)(total < ncu ? total : ncu);
+    a.trace = nullptr;
+    static unsigned long long* d_trace = nullptr;
+    if (getenv("MRX_L2SB_TRACE")) {
+        if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 512 * 8 * 8);
+        (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, (hipStream_t)stream);
+        a.trace = d_trace;
+    }
+    hipLaunchKernelGGL(k_rim_layer2_sb, dim3(grid), dim3(S2_NT), S2_LDS, (hipStream_t)stream, a);
+    MRX_LAUNCH_CHECK();
+    if (a.trace) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        std::vector<unsigned long long> h((size_t)grid * 64);
+        (void)hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+        double ph[3] = {0, 0, 0}, gap = 0;
+        long n = 0, ng = 0;
+        for (int i = 0; i < grid * 8; ++i)
+            for (int k = 0; k < 2; ++k) {
+                const unsigned long long* r = &h[((size_t)i * 2 + k) * 4];
+                if (!r[0] || !r[3]) continue;
+                ph[0] += (double)(r[1] - r[0]), ph[1] += (double)(r[2] - r[1]), ph[2] += (double)(r[3] - r[2]);
+                ++n;
+                if (k == 1 && h[(size_t)i * 8 + 3]) gap += (double)(r[0] - h[(size_t)i * 8 + 3]), ++ng;
+            }
+        fprintf(stderr, "[l2sb-trace] %ld wave-tiles: chunk loop %.0f, row 0 tail %.0f, row 1 tail %.0f cycles; gap between tiles %.0f\n", n, ph[0] / n,
+                ph[1] / n, ph[2] / n, ng ? gap / ng : 0.0);
+    }
+    return MRX_OK;
+}

@@ -761,6 +761,31 @@ def rim_layer_wino_supported(Cin, F, k, dilation):
     return int(k) == 3 and int(dilation) == 2 and int(F) == 64 and int(Cin) >= 1
 
 
+def rim_layer2_sb_pack(w_conv, w_ih):
+    """Split-bf16 operand pack of the second RIM layer (w_conv [64,64,3,3], w_ih [64,64,1,1]) for rim_layer2_sb."""
+    w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
+    if tuple(w_conv.shape) != (64, 64, 3, 3) or tuple(w_ih.shape) != (64, 64, 1, 1):
+        raise NotImplementedError(f"rim_layer2_sb_pack: {tuple(w_conv.shape)} / {tuple(w_ih.shape)}")
+    packed = torch.empty(int(_lib.lib().mrx_rim_layer2_sb_pack_floats()), dtype=torch.float32, device=w_conv.device)
+    _lib.check(_lib.lib().mrx_rim_layer2_sb_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(packed), _lib.stream_ptr()), "mrx_rim_layer2_sb_pack")
+    return packed
+
+
+def rim_layer2_sb(x, packed, b_conv, b_ih, hh, h_prev):
+    """ReLU(W_ih ReLU(conv3x3 dilation 2 (replicate pad)(x) + b_conv) + b_ih + hh * h_prev), 64 features, on the bf16 matrix pipe with fp32
+    results (mrx_rim_layer2_sb)."""
+    x = _lib.f32c(x)
+    B, C, H, W = _nchw(x)
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    out = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_rim_layer2_sb(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out),
+                                            B, H, W, _lib.stream_ptr()), "mrx_rim_layer2_sb")
+    return out
+
+
 def rim_layer_wino_pack(w_conv, w_ih):
     """Transform conv [64,Cin,3,3] weights to G g G^T and pack them with the ih [64,64,1,1] weights for mrx_rim_layer_indrnn_wino."""
     w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())

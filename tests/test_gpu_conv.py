@@ -135,6 +135,38 @@ def test_tuned_fused_rim_layer_packed(shape, dev):
     assert_close(got0, ref0, 1e-5, "tuned fused layer, no biases, h_prev = None")
 
 
+@pytest.mark.parametrize("shape", [(1, 640, 372), (2, 37, 75), (1, 19, 33), (3, 16, 32), (1, 5, 3), (1, 130, 320), (1, 33, 64)])
+def test_second_rim_layer_split_bf16_has_fp32_accuracy(shape, dev):
+    """The dominant layer (3x3 dilation 2, 64 -> 64, + IndRNN 1x1) as a direct convolution on the bf16 matrix pipe (k_rim_layer2_sb: three-term
+    bf16 operand split, six term products per multiply) against a float64 reference: fp32-level error, and agreement with the fp32 Winograd
+    kernel to fp32 round-off.  Ragged tiles (H % 16, W % 32), images smaller than a tile, batches, no h_prev, no biases."""
+    import torch.nn.functional as Fn
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    B, H, W = shape
+    F_ = 64
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, F_, H, W, generator=g).relu()
+    wc = torch.randn(F_, F_, 3, 3, generator=g) / 24
+    bc = torch.randn(F_, generator=g) * 0.1
+    wi = torch.randn(F_, F_, 1, 1, generator=g) / 8
+    bi = torch.randn(F_, generator=g) * 0.1
+    hh = torch.randn(1, F_, 1, 1, generator=g) * 0.5
+    hp = torch.randn(B, F_, H, W, generator=g).relu()
+    pk_s, pk_w = ops.rim_layer2_sb_pack(wc.to(dev), wi.to(dev)), ops.rim_layer_wino_pack(wc.to(dev), wi.to(dev))
+    for with_state, with_bias in ((True, True), (False, True), (True, False)):
+        b1, b2 = (bc, bi) if with_bias else (None, None)
+        ref = Fn.conv2d(Fn.pad(x.double(), (2, 2, 2, 2), mode="replicate"), wc.double(), None if b1 is None else b1.double(), dilation=2).relu()
+        ref = Fn.conv2d(ref, wi.double(), None if b2 is None else b2.double())
+        ref = Fn.relu(ref + hh.double() * hp.double() if with_state else ref)
+        d = lambda t: None if t is None else t.to(dev)  # noqa: E731
+        got = ops.rim_layer2_sb(x.to(dev), pk_s, d(b1), d(b2), hh.to(dev), hp.to(dev) if with_state else None)
+        win = ops.rim_layer_indrnn_wino(x.to(dev), pk_w, F_, d(b1), d(b2), hh.to(dev), hp.to(dev) if with_state else None)
+        e_sb, e_w = rel_l2(got, ref), rel_l2(win, ref)
+        assert e_sb <= 6e-7 and e_sb <= 2.5 * e_w + 5e-8, (e_sb, e_w)
+        assert rel_l2(got, win) <= 8e-7
+
+
 @pytest.mark.parametrize("shape", [(1, 4, 640, 372), (2, 4, 37, 75), (1, 2, 19, 33), (3, 1, 16, 32), (1, 4, 5, 3), (1, 3, 130, 320)])
 def test_first_rim_layer_split_bf16_has_fp32_accuracy(shape, dev, monkeypatch):
     """The first RIM layer on the bf16 matrix pipe (k_rim_layer1_sb: every fp32 operand as the exact sum of three bf16 terms, six term
