@@ -647,6 +647,8 @@ def main():
     timer.wrap(ops, "rim_layer_indrnn_packed", lambda x, *a, **k: "conv_layer2" if x.shape[1] == F_hidden else "conv_layer1")
     timer.wrap(ops, "rim_layer_indrnn_wino", lambda x, *a, **k: "conv_layer2_wino")
     timer.wrap(ops, "rim_layer2_sb", lambda x, *a, **k: "conv_layer2_sb")
+    timer.wrap(ops, "rim_layer2_sb_taps", lambda x, *a, **k: "conv_layer2_sbt")     # + the final convolution's channel contraction in its tail
+    timer.wrap(ops, "rim_final_gather", lambda *a, **k: "final_gather")
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv_parts", lambda *a, **k: "llg")     # gradient whose last pass is done by layer 1's tile loader
@@ -745,10 +747,22 @@ def main():
                      "multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32-accurate results; 8 chunks x 5 steps (one of ten tap slots is "
                      "padding) + 4 steps of the 1x1 stage = 528 MFMAs per 32 pixels)")
             executed = (528 * 32 * 32 * 16 * 2 / 32.0) * npix * B
+        mst, nst = timer.mean_ms("conv_layer2_sbt")
+        l2_taps = bool(mst)
+        if mst:                               # the same kernel with the final 64 -> 2 convolution's channel contraction in its tail (+ 24 MFMAs per 32 pixels)
+            ms2, n2, l2_bf16, peak2 = mst, nst, True, PEAK_BF16_MFMA_TFLOPS
+            kname = ("k_rim_layer2_sb (conv3x3 d2 64->64 direct form + IndRNN 1x1 fused + the channel contraction of the final 3x3 64->2 convolution "
+                     "on the new state (18 tap-product planes; mrx_rim_final_gather adds the shifted taps); every fp32 operand = 3 bf16 terms, 6 term "
+                     "products per multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32-accurate results; 8 chunks x 5 steps (one of ten tap "
+                     "slots is padding) + 4 steps of the 1x1 stage + 4 steps of the tap stage (18 of 32 rows used) = 552 MFMAs per 32 pixels)")
+            executed = (552 * 32 * 32 * 16 * 2 / 32.0) * npix * B
+            flops2 += 2.0 * F_hidden * 2 * 9 * npix * B      # the final convolution's multiply-adds now belong to this launch
         traffic = measured_traffic(B, C, H, W, F_hidden)
         tf = (lambda fl: fl / (ms2 * 1e-3) / 1e12) if ms2 else (lambda fl: None)
         ms1, _ = timer.mean_ms("conv_layer1")
         msf, _ = timer.mean_ms("final")
+        if l2_taps:
+            msf, _ = timer.mean_ms("final_gather")
         msl, nl = timer.mean_ms("llg")
         ms372, n372 = timer.mean_ms("llg372")
         if ms372:
@@ -763,9 +777,10 @@ def main():
         issued1_bf16 = (132 * 32 * 32 * 16 * 2 / 32.0) * npix * B if l1_bf16 else 0.0
         issued2_bf16 = executed if l2_bf16 else 0.0
         issued1_bf16 += issued2_bf16             # everything issued on the bf16 pipe
-        issued_reg = flops_reg - (flops2 if l2_bf16 else flops2 - executed) - (flops1 if l1_bf16 else 0.0)      # fp32 part
+        issued_reg = flops_reg - (flops2 if l2_bf16 else flops2 - executed) - (flops1 if l1_bf16 else 0.0)      # fp32 part (none left with the final conv in layer 2's tail)
         pipe_ms = lambda f32, b16: 1e3 * (f32 / (PEAK_FP32_MFMA_TFLOPS * 1e12) + b16 / (PEAK_BF16_MFMA_TFLOPS * 1e12))  # noqa: E731
-        final_flops = 2.0 * F_hidden * 2 * 9 * npix * B
+        final_flops = 0.0 if l2_taps else 2.0 * F_hidden * 2 * 9 * npix * B      # (in layer 2's launch when its tail does the contraction)
+        issued_reg = max(issued_reg, 0.0)
         t_reg = (ms1 or 0) + (ms2 or 0) + (msf or 0)
         roofline = dict(bound="mfma", kernel=kname,
                         achieved=tf(executed), peak=peak2, unit="TFLOP/s",
@@ -784,8 +799,8 @@ def main():
                                          issued_bf16_gflop=issued1_bf16 / 1e9,
                                          frac_issued=(pipe_ms(issued_reg, issued1_bf16) / t_reg) if t_reg else None,
                                          note="all three kernels of a step: layer 1 and (unless MRIDC_AMD_LAYER2_SB=0: then fp32 MFMA, Winograd) layer 2 on "
-                                              "the bf16 matrix pipe with fp32 results via the three-term split, final conv 64->2 on the vector ALUs (2 of 32 MFMA rows would be "
-                                              "used; its 0.55 GFLOP counted at the fp32 rate).  frac_issued = (fp32 work / fp32 peak + bf16 work / "
+                                              "the bf16 matrix pipe with fp32 results via the three-term split; final conv 64->2: its channel contraction in layer 2's tail on the "
+                                              "matrix pipe + a 9-tap gather (default), or -- MRIDC_AMD_FUSED_FINAL=0 -- on the vector ALUs (its 0.55 GFLOP counted at the fp32 rate).  frac_issued = (fp32 work / fp32 peak + bf16 work / "
                                               "dense bf16 peak) / measured time",
                                          layer1_ms=ms1, layer1_kernel="k_rim_layer1_sb" if l1_bf16 else "k_rim_layer<5,1,4>",
                                          layer1_frac_issued=(pipe_ms(0.0 if l1_bf16 else flops1, issued1_bf16) / ms1) if ms1 else None,
@@ -828,8 +843,8 @@ def main():
                                             "calibrated in this run -- this is what makes the figures agree with rocprofv3's kernel durations",
                                      empty_pair_ms=getattr(timer, "pair_ms", None),
                                      raw_ms=dict(llg=timer.raw_ms("llg372") or timer.raw_ms("llg"), conv_layer1=timer.raw_ms("conv_layer1"),
-                                                 conv_layer2=timer.raw_ms("conv_layer2_sb") or timer.raw_ms("conv_layer2_wino") or timer.raw_ms("conv_layer2"),
-                                                 final=timer.raw_ms("final"))))
+                                                 conv_layer2=timer.raw_ms("conv_layer2_sbt") or timer.raw_ms("conv_layer2_sb") or timer.raw_ms("conv_layer2_wino") or timer.raw_ms("conv_layer2"),
+                                                 final=timer.raw_ms("final_gather") or timer.raw_ms("final"))))
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_cascades if 0 < args.cpu_cascades <= cfg["num_cascades"] else cfg["num_cascades"]
             try:

@@ -249,9 +249,18 @@ int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, const float
  * operand is the exact sum of three bf16 terms, six term products per multiply (error O(2^-24), as an fp32 FMA chain).  Same contract as
  * mrx_rim_layer_indrnn_wino (rim_block.py:233-238); packed = mrx_rim_layer2_sb_pack(w_conv [64,64,3,3], w_ih [64,64,1,1]). */
 int64_t mrx_rim_layer2_sb_pack_floats(void);
-int mrx_rim_layer2_sb_pack(const float* w_conv, const float* w_ih, float* packed, void* stream);
+int mrx_rim_layer2_sb_pack(const float* w_conv, const float* w_ih, const float* w_final /* [2,64,3,3] or NULL */, float* packed, void* stream);
 int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
                       float* h_new, int B, int H, int W, void* stream);
+/* The second layer AND the final convolution of a RIM step (rim_block.py:233-246; conv_layers.py:121-123 with kernel 3, dilation 1, no
+ * activation) in two calls: mrx_rim_layer2_sb_taps is mrx_rim_layer2_sb that also runs the 64 -> 2 convolution's channel contraction on
+ * h_new while the kernel still holds it in registers (taps [B][18][H][W]: taps[b][tap * 2 + co] = sum_c w_final[co][c][tap] h_new[b][c];
+ * packed must hold w_final); mrx_rim_final_gather adds the nine shifted taps (replicate padding = clamped coordinates), the bias and eta:
+ * eta_out [B,H,W,2] = eta + permute(conv(h_new) + b_final).  eta may be NULL (nothing added).
+ * In mrx_rim_layer2_sb and mrx_rim_layer2_sb_taps h_new may be h_prev itself (every element is read by the lane that writes it). */
+int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
+                           const float* h_prev, float* h_new, float* taps, int B, int H, int W, void* stream);
+int mrx_rim_final_gather(const float* taps, const float* b_final, const float* eta, float* eta_out, int B, int H, int W, void* stream);
 int64_t mrx_rim_layer_wino_pack_floats(int Cin, int F);
 int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, int F, void* stream);
 int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, const float* b_conv, const float* b_ih,

@@ -119,7 +119,9 @@ _SIGNATURES = {
     "mrx_recon_metrics_work_floats": ([], _i64),
     "mrx_recon_metrics": ([_p, _p, _p, _p, _i64, _p], _i),
     "mrx_rim_layer2_sb_pack_floats": ([], _i64),
-    "mrx_rim_layer2_sb_pack": ([_p, _p, _p, _p], _i),
+    "mrx_rim_layer2_sb_pack": ([_p, _p, _p, _p, _p], _i),
+    "mrx_rim_layer2_sb_taps": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_rim_final_gather": ([_p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_layer2_sb": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_layer_wino_pack_floats": ([_i, _i], _i64),
     "mrx_rim_layer_wino_pack": ([_p, _p, _p, _i, _i, _p], _i),

@@ -32,6 +32,8 @@ class RIMBlock(torch.nn.Module):
     """
     winograd = os.environ.get("MRIDC_AMD_WINOGRAD", "1") != "0"
     layer2_sb = os.environ.get("MRIDC_AMD_LAYER2_SB", "1") != "0"
+    fused_final = os.environ.get("MRIDC_AMD_FUSED_FINAL", "1") != "0"
+    inplace_state = os.environ.get("MRIDC_AMD_INPLACE_STATE", "1") != "0"
 
     def __init__(self, recurrent_layer=None, conv_filters=None, conv_kernels=None, conv_dilations=None, conv_bias=None,
                  recurrent_filters=None, recurrent_kernels=None, recurrent_dilations=None, recurrent_bias=None,
@@ -125,18 +127,51 @@ class RIMBlock(torch.nn.Module):
             self._pack_cache[idx] = hit
         return hit[1]
 
-    def _packed_sb(self, idx, c, r):
-        """Split-bf16 operand pack of layer `idx` (mrx_rim_layer2_sb), re-packed only when the parameters change."""
+    def _packed_sb(self, idx, c, r, final=None):
+        """Split-bf16 operand pack of layer `idx` (mrx_rim_layer2_sb), re-packed only when the parameters change; with `final` the pack
+        also holds the final convolution's operands (mrx_rim_layer2_sb_final)."""
         w, wi = c.conv_layer.weight, r.ih.weight
-        key = (w.data_ptr(), w._version, wi.data_ptr(), wi._version, str(w.device))
+        wf = final.conv_layer.weight if final is not None else None
+        key = (w.data_ptr(), w._version, wi.data_ptr(), wi._version, str(w.device),
+               None if wf is None else (wf.data_ptr(), wf._version))
         hit = self._pack_cache.get(("sb", idx))
         if hit is None or hit[0] != key:
-            hit = (key, ops.rim_layer2_sb_pack(w, wi))
+            hit = (key, ops.rim_layer2_sb_pack(w, wi, wf))
             self._pack_cache[("sb", idx)] = hit
         return hit[1]
 
-    def _layer(self, idx, stack, x, h):
-        """One conv+RNN stack.  `h` None = the zero initial state (rim_block.py:188-193) without materialising it."""
+    def _sb_layer(self, stack):
+        c, r = stack.convs, stack.rnn
+        return (self.layer2_sb and self._fusable(stack) and c.input_size == 64 and r.hidden_size == 64 and c.kernel_size == 3
+                and c.dilation == 2 and r.kernel_size == 1)
+
+    def _tail_fused(self):
+        """The last stack is the split-bf16 layer and the final layer a plain 3x3 64 -> 2 convolution: one call does both."""
+        if not self.fused_final or len(self.layers) < 1 or len(self.final_layer) != 1:
+            return False
+        f = self.final_layer[0]
+        return (self._sb_layer(self.layers[-1]) and f is not None and f.act == ops.ACT_NONE and f.kernel_size == 3 and f.dilation == 1
+                and tuple(f.conv_layer.weight.shape) == (2, 64, 3, 3))
+
+    def _layers_and_final(self, first, grad_eta, hx, eta, final, own=False):
+        """Stacks `first`.. on grad_eta, then eta + permute(final conv) (rim_block.py:230-246)."""
+        n = len(self.layers)
+        fused = self._tail_fused() and n - 1 >= first
+        for h in range(first, n - 1 if fused else n):
+            hx[h] = self._layer(h, self.layers[h], grad_eta, hx[h], own)
+            grad_eta = hx[h]
+        if fused:
+            c, r = self.layers[-1].convs, self.layers[-1].rnn
+            # (the 18 tap-product planes are per-call scratch from the caching allocator: slices in flight on other streams have their own)
+            hx[n - 1], eta = ops.rim_layer2_sb_final(grad_eta, self._packed_sb(n - 1, c, r, final), c.conv_layer.bias, r.ih.bias, r.hh,
+                                                     hx[n - 1], final.conv_layer.bias, eta,
+                                                     out=hx[n - 1] if (own and self.inplace_state and hx[n - 1] is not None) else None)
+            return eta
+        return ops.rim_final(grad_eta, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size, final.dilation, eta)
+
+    def _layer(self, idx, stack, x, h, own=False):
+        """One conv+RNN stack.  `h` None = the zero initial state (rim_block.py:188-193) without materialising it.  `own`: h was created by
+        this forward call, so the split-bf16 kernels may overwrite it with the new state (one buffer per layer instead of two alive)."""
         if self._gated(stack):
             c, r = stack.convs, stack.rnn
             conv_pk, cell_pk, hh0, wino = self._packed_gated(idx, c, r)
@@ -152,9 +187,9 @@ class RIMBlock(torch.nn.Module):
             h = x.new_zeros((x.size(0), stack.rnn.hidden_size, *x.size()[2:]))
         if self._fusable(stack):
             c, r = stack.convs, stack.rnn
-            if (self.layer2_sb and c.input_size == 64 and r.hidden_size == 64 and c.kernel_size == 3 and c.dilation == 2
-                    and r.kernel_size == 1):
-                return ops.rim_layer2_sb(x, self._packed_sb(idx, c, r), c.conv_layer.bias, r.ih.bias, r.hh, h)
+            if self._sb_layer(stack):
+                return ops.rim_layer2_sb(x, self._packed_sb(idx, c, r), c.conv_layer.bias, r.ih.bias, r.hh, h,
+                                         out=h if (own and self.inplace_state and h is not None) else None)
             if self.winograd and ops.rim_layer_wino_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation):
                 return ops.rim_layer_indrnn_wino(x, self._packed(idx, c, r), r.hidden_size, c.conv_layer.bias, r.ih.bias, r.hh, h)
             if ops.rim_layer_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation):
@@ -288,7 +323,8 @@ class RIMBlock(torch.nn.Module):
         defer = (hinv and l0 is not None and self._fusable(l0) and l0.convs.input_size == 4
                  and ops.rim_layer_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)
                  and not (self.winograd and ops.rim_layer_wino_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)))
-        for _ in range(self.time_steps):                             # rim_block.py:217-249
+        for step in range(self.time_steps):                          # rim_block.py:217-249
+            own = step > 0                                           # the states of step 0 are the caller's (or the zero state)
             if defer:
                 if op372 is not None:
                     part, nparts = ops.llg372(eta, op372, sigma, self.fft_normalization, parts=True)
@@ -297,12 +333,10 @@ class RIMBlock(torch.nn.Module):
                 if nparts > 0:
                     c, r = l0.convs, l0.rnn
                     hx[0] = ops.rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, self._packed(0, c, r), r.hidden_size, c.kernel_size,
-                                                            c.dilation, c.conv_layer.bias, r.ih.bias, r.hh, hx[0])
-                    grad_eta = hx[0]
-                    for h in range(1, len(self.layers)):
-                        hx[h] = self._layer(h, self.layers[h], grad_eta, hx[h])
-                        grad_eta = hx[h]
-                    eta = ops.rim_final(grad_eta, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size, final.dilation, eta)
+                                                            c.dilation, c.conv_layer.bias, r.ih.bias, r.hh, hx[0],
+                                                            out=hx[0] if (own and self.inplace_state and hx[0] is not None
+                                                                          and ops.rim_layer1_inplace_ok(4, r.hidden_size, c.kernel_size, c.dilation)) else None)
+                    eta = self._layers_and_final(1, hx[0], hx, eta, final, own)
                     etas.append(eta)
                     continue
             elif op372 is not None:
@@ -312,11 +346,7 @@ class RIMBlock(torch.nn.Module):
             else:
                 grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
                                    self.spatial_dims, work=work)
-            for h, convrnn in enumerate(self.layers):
-                hx[h] = self._layer(h, convrnn, grad_eta, hx[h])
-                grad_eta = hx[h]
-            eta = ops.rim_final(grad_eta, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size,
-                                final.dilation, eta)                 # final conv, permute(0,2,3,1), eta + grad
+            eta = self._layers_and_final(0, grad_eta, hx, eta, final, own)   # stacks, final conv, permute(0,2,3,1), eta + grad
             etas.append(eta)
         mask = full_mask
         if self.no_dc:                                               # rim_block.py:253-254

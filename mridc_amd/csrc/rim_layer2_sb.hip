@@ -33,9 +33,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define S2_NPIX (S2_PH * S2_PW)             // 720
 #define S2_NCH 8                            // channel chunks
 #define S2_KS 5                             // MFMA steps per chunk (10 tap slots, 9 used)
-#define S2_WCH (S2_KS * 3 * 2 * 64)         // 16-byte A operands per chunk (30 KB)
+#define S2_WFULL (4 * 3 * 2 * 64)           // 16-byte A operands of the four full steps of a chunk
+#define S2_WCH (S2_WFULL + 3 * 2 * 32)      // + the fifth step, whose upper half-wave (the padding tap slot) is not stored: 27 KB per chunk
 #define S2_WIH (4 * 3 * 2 * 64)             // 1x1 stage (24 KB)
-#define S2_PACK_U4 (S2_NCH * S2_WCH + S2_WIH)
+#define S2_WP (4 * 3 * 64)                  // final 64 -> 2 convolution as per-pixel tap products: 18 of 32 rows used (12 KB)
+#define S2_PACK_U4 (S2_NCH * S2_WCH + S2_WIH + S2_WP)
 
 struct L2sbArgs {
     const float* x;        // [B,64,H,W]
@@ -45,6 +47,7 @@ struct L2sbArgs {
     const float* hh;       // [64]
     const float* hprev;    // [B,64,H,W] or null
     float* hnew;           // [B,64,H,W]
+    float* P;              // not null: also P[b][tap * 2 + co][y][x] = sum_c w_final[co][c][tap] * h_new[c][y][x]  (mrx_rim_final_gather adds the taps up)
     int B, H, W, tiles_x, ntiles;
     unsigned long long* trace;   // debug (env MRX_L2SB_TRACE): cycle stamps [workgroup][wave][tile 0..1][4]
 };
@@ -64,28 +67,49 @@ __device__ __forceinline__ void s2_split2(float a, float b, unsigned& p1, unsign
 }
 __host__ __device__ constexpr int s2_chan(int R, int half) { return 32 * (R >> 4) + (R & 3) + 8 * ((R & 15) >> 2) + 4 * half; }
 
-// conv: out[q * S2_WCH + ((s*3 + t)*2 + blk)*64 + lane][j] = term_t( w[32 blk + lane%32][8 q + j][tap = 2 s + lane/32] )   (0 for tap 9)
-// ih  : out[S2_NCH * S2_WCH + ((s*3 + t)*2 + blk)*64 + lane][j] = term_t( w_ih[32 blk + lane%32][s2_chan(8 s + j, lane/32)] )
-__global__ void k_l2sb_pack(const float* __restrict__ w, const float* __restrict__ w_ih, u32x4* __restrict__ out) {
+// conv : out[q * S2_WCH + ((s*3 + t)*2 + blk)*64 + lane][j] = term_t( w[32 blk + lane%32][8 q + j][tap = 2 s + lane/32] ) for s < 4;
+//        out[q * S2_WCH + S2_WFULL + (t*2 + blk)*32 + l][j]   = term_t( w[32 blk + l][8 q + j][tap 8] )   (s = 4, lower half-wave only)
+// ih   : out[S2_NCH * S2_WCH + ((s*3 + t)*2 + blk)*64 + lane][j] = term_t( w_ih[32 blk + lane%32][s2_chan(8 s + j, lane/32)] )
+// final: out[S2_NCH * S2_WCH + S2_WIH + (s*3 + t)*64 + lane][j] = term_t( w_final[m & 1][s2_chan(8 s + j, lane/32)][tap = m >> 1] ), m = lane%32 < 18
+__global__ void k_l2sb_pack(const float* __restrict__ w, const float* __restrict__ w_ih, const float* __restrict__ w_final, u32x4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S2_PACK_U4) return;
-    const bool conv = i < S2_NCH * S2_WCH;
-    int r = conv ? i % S2_WCH : i - S2_NCH * S2_WCH;
-    const int q = conv ? i / S2_WCH : 0;
-    const int lane = r & 63;
-    r >>= 6;
-    const int blk = r & 1;
-    r >>= 1;
-    const int t = r % 3, s = r / 3;
-    const int o = 32 * blk + (lane & 31), half = lane >> 5;
     float v[8];
+    int t;
+    if (i < S2_NCH * S2_WCH) {
+        const int q = i / S2_WCH;
+        int r = i - q * S2_WCH, s, blk, l, half;
+        if (r < S2_WFULL) {
+            const int lane = r & 63;
+            r >>= 6;
+            blk = r & 1;
+            r >>= 1;
+            t = r % 3, s = r / 3, l = lane & 31, half = lane >> 5;
+        } else {
+            r -= S2_WFULL;
+            l = r & 31, blk = (r >> 5) & 1, t = r >> 6, s = 4, half = 0;
+        }
+        const int o = 32 * blk + l, tap = 2 * s + half;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (conv) {
-            const int tap = 2 * s + half;
-            v[j] = tap < 9 ? w[((long long)o * S2_F + 8 * q + j) * 9 + tap] : 0.f;
-        } else
-            v[j] = w_ih[o * S2_F + s2_chan(8 * s + j, half)];
+        for (int j = 0; j < 8; ++j) v[j] = w[((long long)o * S2_F + 8 * q + j) * 9 + tap];
+    } else if (i < S2_NCH * S2_WCH + S2_WIH) {
+        int r = i - S2_NCH * S2_WCH;
+        const int lane = r & 63;
+        r >>= 6;
+        const int blk = r & 1;
+        r >>= 1;
+        t = r % 3;
+        const int s = r / 3, o = 32 * blk + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w_ih[o * S2_F + s2_chan(8 * s + j, lane >> 5)];
+    } else {
+        int r = i - S2_NCH * S2_WCH - S2_WIH;
+        const int lane = r & 63;
+        r >>= 6;
+        t = r % 3;
+        const int s = r / 3, m = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (w_final && m < 18) ? w_final[((long long)(m & 1) * S2_F + s2_chan(8 * s + j, lane >> 5)) * 9 + (m >> 1)] : 0.f;
     }
     unsigned p[4];
 #pragma unroll
@@ -111,8 +135,10 @@ __global__ void k_l2sb_pack(const float* __restrict__ w, const float* __restrict
     ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][0], B1, ACC[0], 0, 0, 0);               \
     ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][0], B1, ACC[1], 0, 0, 0);
 
-// LDS (bytes): ih weights 24576 | tables 1024 | 2 x conv weights 30720 | 2 x planes 3 * 720 * 16 = 34560   -> 156 KB
-#define S2_OFF_TAB (S2_WIH * 16)
+// LDS (bytes): ih weights 24576 | final-conv weights 12288 | tables + a zero operand 1024 | 2 x conv weights 27648 | 2 x planes 34560 -> 158.5 KB
+#define S2_OFF_WP (S2_WIH * 16)
+#define S2_OFF_TAB (S2_OFF_WP + S2_WP * 16)
+#define S2_OFF_ZERO (S2_OFF_TAB + 1008)
 #define S2_OFF_W (S2_OFF_TAB + 1024)
 #define S2_OFF_X (S2_OFF_W + 2 * S2_WCH * 16)
 #define S2_LDS (S2_OFF_X + 2 * 3 * S2_NPIX * 16)
@@ -128,7 +154,8 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     const int total = a.ntiles * a.B;
 
     // once per workgroup: 1x1 weights and tables
-    for (int i = tid; i < S2_WIH; i += S2_NT) Wih[i] = a.packed[S2_NCH * S2_WCH + i];
+    for (int i = tid; i < S2_WIH + S2_WP; i += S2_NT) Wih[i] = a.packed[S2_NCH * S2_WCH + i];      // (the final-conv operands follow the 1x1 ones)
+    if (tid == 0) *reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_ZERO) = u32x4{0u, 0u, 0u, 0u};
     if (tid < 64) {
         const int tc = s2_chan(tid >> 1, tid & 1);
         tabl[tid] = a.hh[tc];
@@ -239,6 +266,8 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         for (int q = 0; q < S2_NCH; ++q) {
             const u32x4* xw = Xp + (q & 1) * (3 * S2_NPIX) + (2 * wave) * S2_PW + l31;
             const u32x4* wl = Wc + (q & 1) * S2_WCH + lane;
+            const u32x4* w4 = lhi ? reinterpret_cast<const u32x4*>(smem_s2 + S2_OFF_ZERO) : Wc + (q & 1) * S2_WCH + S2_WFULL + l31;
+            const int st4 = lhi ? 0 : 32;
             u32x4 bt[2][2][3], at[2][2][3];       // [buffer][row | ct][term]
             auto fetch = [&](int s, int bf) {
                 const int off = lhi ? toff(2 * s + 1) : toff(2 * s);
@@ -246,8 +275,13 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                 for (int k = 0; k < 3; ++k) {
                     bt[bf][0][k] = xw[k * S2_NPIX + off];
                     bt[bf][1][k] = xw[k * S2_NPIX + off + S2_PW];
-                    at[bf][0][k] = wl[((s * 3 + k) * 2 + 0) * 64];
-                    at[bf][1][k] = wl[((s * 3 + k) * 2 + 1) * 64];
+                    if (s < 4) {
+                        at[bf][0][k] = wl[((s * 3 + k) * 2 + 0) * 64];
+                        at[bf][1][k] = wl[((s * 3 + k) * 2 + 1) * 64];
+                    } else {                      // the padding tap slot: the upper half-wave reads the zero operand
+                        at[bf][0][k] = w4[(k * 2 + 0) * st4];
+                        at[bf][1][k] = w4[(k * 2 + 1) * st4];
+                    }
                 }
             };
             fetch(0, 0);
@@ -304,14 +338,50 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                     for (int ct = 0; ct < 2; ++ct) at[ct][k] = __builtin_bit_cast(bf16x8, wl[((s * 3 + k) * 2 + ct) * 64]);
                 S2_MFMA12(acc2, at, b1, b2, b3)
             }
-            if (oy < a.H && ox < a.W) {
+            const bool inside = oy < a.H && ox < a.W;
+            {
                 float* ob = a.hnew + (long long)b * S2_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
                 const bool first = a.hprev == nullptr;
 #pragma unroll
                 for (int R = 0; R < 32; ++R) {
                     float v = acc2[R >> 4][R & 15] + tabl[2 * R + lhi] * (first ? 0.f : hp[rw][R]);
                     v = v > 0.f ? v : 0.f;
-                    ob[(long long)s2_chan(R, 0) * plane] = v;
+                    if (inside) ob[(long long)s2_chan(R, 0) * plane] = v;
+                    hp[rw][R] = v;
+                }
+            }
+            if (a.P) {
+                // the final 64 -> 2 convolution's channel contraction on the new state while it is in registers: D[tap * 2 + co][pixel]
+                // (18 of the 32 rows), the k order of the B operand is the register order of h_new as in the 1x1 stage above
+                f32x16 accp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+                const u32x4* wp = reinterpret_cast<const u32x4*>(smem_s2 + S2_OFF_WP) + lane;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    unsigned g1[4], g2[4], g3[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s2_split2(hp[rw][8 * s + 2 * k], hp[rw][8 * s + 2 * k + 1], g1[k], g2[k], g3[k]);
+                    const bf16x8 b1 = __builtin_bit_cast(bf16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
+                    const bf16x8 b2 = __builtin_bit_cast(bf16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
+                    const bf16x8 b3 = __builtin_bit_cast(bf16x8, (u32x4{g3[0], g3[1], g3[2], g3[3]}));
+                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, wp[(s * 3 + 0) * 64]);
+                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, wp[(s * 3 + 1) * 64]);
+                    const bf16x8 a3 = __builtin_bit_cast(bf16x8, wp[(s * 3 + 2) * 64]);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, accp, 0, 0, 0);
+                }
+                if (inside) {
+                    float* pb = a.P + (long long)b * 18 * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
+#pragma unroll
+                    for (int r = 0; r < 10; ++r) {
+                        const int m0 = (r & 3) + 8 * (r >> 2);           // row of the lower half-wave; the upper one holds m0 + 4
+                        if (m0 + 4 < 18 || !lhi) pb[(long long)m0 * plane] = accp[r];
+                    }
                 }
             }
             if (rw == 0) { S2_STAMP(2) } else { S2_STAMP(3) }
@@ -321,17 +391,18 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 
 extern "C" int64_t mrx_rim_layer2_sb_pack_floats(void) { return (int64_t)S2_PACK_U4 * 4; }
 
-// w_conv [64,64,3,3] (dilation 2, replicate padding), w_ih [64,64,1,1] -> the split-bf16 operand pack of mrx_rim_layer2_sb
-extern "C" int mrx_rim_layer2_sb_pack(const float* w_conv, const float* w_ih, float* packed, void* stream) {
+// w_conv [64,64,3,3] (dilation 2, replicate padding), w_ih [64,64,1,1] -> the split-bf16 operand pack of mrx_rim_layer2_sb;
+// w_final [2,64,3,3] (or null): the operands of the final convolution's channel contraction (mrx_rim_layer2_sb_final)
+extern "C" int mrx_rim_layer2_sb_pack(const float* w_conv, const float* w_ih, const float* w_final, float* packed, void* stream) {
     MRX_REQUIRE(w_conv && w_ih && packed, MRX_EINVAL, "mrx_rim_layer2_sb_pack: null pointer");
-    hipLaunchKernelGGL(k_l2sb_pack, dim3((S2_PACK_U4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, reinterpret_cast<u32x4*>(packed));
+    hipLaunchKernelGGL(k_l2sb_pack, dim3((S2_PACK_U4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, w_final, reinterpret_cast<u32x4*>(packed));
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 
 // h_new = ReLU(W_ih ReLU(conv3x3_d2(replicate_pad(x)) + b_conv) + b_ih + hh * h_prev), F = 64 (rim_block.py:233-238 for the second layer)
-extern "C" int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
-                                 const float* h_prev, float* h_new, int B, int H, int W, void* stream) {
+static int l2sb_launch(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                       float* h_new, float* P, int B, int H, int W, void* stream) {
     MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer2_sb: null pointer");
     MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer2_sb: bad dims");
     if (B == 0) return MRX_OK;
@@ -352,6 +423,7 @@ extern "C" int mrx_rim_layer2_sb(const float* x, const float* packed, const floa
     const long long total = (long long)a.ntiles * B;
     const int grid = (int)(total < ncu ? total : ncu);
     a.trace = nullptr;
+    a.P = P;
     static unsigned long long* d_trace = nullptr;
     if (getenv("MRX_L2SB_TRACE")) {
         if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 512 * 8 * 8);
@@ -377,5 +449,56 @@ extern "C" int mrx_rim_layer2_sb(const float* x, const float* packed, const floa
         fprintf(stderr, "[l2sb-trace] %ld wave-tiles: chunk loop %.0f, row 0 tail %.0f, row 1 tail %.0f cycles; gap between tiles %.0f\n", n, ph[0] / n,
                 ph[1] / n, ph[2] / n, ng ? gap / ng : 0.0);
     }
+    return MRX_OK;
+}
+
+extern "C" int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
+                                 const float* h_prev, float* h_new, int B, int H, int W, void* stream) {
+    return l2sb_launch(x, packed, b_conv, b_ih, hh, h_prev, h_new, nullptr, B, H, W, stream);
+}
+
+// eta_out[b][y][x][co] = eta[b][y][x][co] + bias[co] + sum_tap P[b][tap * 2 + co][clamp(y + dy)][clamp(x + dx)]: what is left of the final
+// 3x3 convolution (replicate padding, conv_layers.py:72-76; rim_block.py:240-246) once its channel contraction has been done per pixel
+__global__ __launch_bounds__(256) void k_l2sb_gather(const float* __restrict__ P, const float* __restrict__ bias, const float* __restrict__ eta,
+                                                     float* __restrict__ out, int H, int W) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const long long plane = (long long)H * W;
+    const float* pb = P + (long long)b * 18 * plane;
+    float s0 = bias ? bias[0] : 0.f, s1 = bias ? bias[1] : 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        int yy = y + dy - 1;
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            int xx = x + dx - 1;
+            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            const long long o = (long long)yy * W + xx;
+            s0 += pb[(long long)((dy * 3 + dx) * 2) * plane + o];
+            s1 += pb[(long long)((dy * 3 + dx) * 2 + 1) * plane + o];
+        }
+    }
+    const long long e = ((long long)b * plane + (long long)y * W + x) * 2;
+    float2 v = eta ? *reinterpret_cast<const float2*>(eta + e) : make_float2(0.f, 0.f);
+    v.x += s0, v.y += s1;
+    *reinterpret_cast<float2*>(out + e) = v;
+}
+
+// The second layer of a RIM step (rim_block.py:233-238) that also leaves the final convolution's per-pixel tap products in `taps`
+// ([B][18][H][W]: taps[b][tap * 2 + co] = sum_c w_final[co][c][tap] * h_new[b][c]); packed must hold w_final (mrx_rim_layer2_sb_pack).
+extern "C" int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
+                                      const float* h_prev, float* h_new, float* taps, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(taps, MRX_EINVAL, "mrx_rim_layer2_sb_taps: null pointer");
+    return l2sb_launch(x, packed, b_conv, b_ih, hh, h_prev, h_new, taps, B, H, W, stream);
+}
+
+// eta_out [B,H,W,2] = eta + permute(conv3x3_reppad(h_new, w_final) + b_final) from the tap products (rim_block.py:240-246)
+extern "C" int mrx_rim_final_gather(const float* taps, const float* b_final, const float* eta, float* eta_out, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(taps && eta_out, MRX_EINVAL, "mrx_rim_final_gather: null pointer");
+    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_final_gather: bad dims");
+    if (B == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_l2sb_gather, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps, b_final, eta, eta_out, H, W);
+    MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

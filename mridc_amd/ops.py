@@ -297,6 +297,13 @@ def llg_hinv_parts(eta, yt, sens, mask, sigma, centered, normalization, out=None
     return out, work, int(n.value)
 
 
+def rim_layer1_inplace_ok(Cin, F, k, dilation):
+    """True when mrx_rim_layer_indrnn_packed[_llg] runs the split-bf16 first-layer kernel (rim_layer1_sb.hip), whose epilogue reads every
+    h_prev element in the lane that writes h_new there: `out` may then be h_prev itself."""
+    return (int(Cin) <= 4 and int(F) == 64 and int(k) == 5 and int(dilation) == 1
+            and os.environ.get("MRX_LAYER1_FP32", "0") in ("", "0") and not os.environ.get("MRX_TRACE") and not os.environ.get("MRX_ABLATE"))
+
+
 def rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None):
     """The tuned fused first RIM layer reading log_likelihood_gradient's pieces (eta and the partial coil sums) directly."""
     eta = _lib.f32c(eta)
@@ -761,29 +768,76 @@ def rim_layer_wino_supported(Cin, F, k, dilation):
     return int(k) == 3 and int(dilation) == 2 and int(F) == 64 and int(Cin) >= 1
 
 
-def rim_layer2_sb_pack(w_conv, w_ih):
-    """Split-bf16 operand pack of the second RIM layer (w_conv [64,64,3,3], w_ih [64,64,1,1]) for rim_layer2_sb."""
+def rim_layer2_sb_pack(w_conv, w_ih, w_final=None):
+    """Split-bf16 operand pack of the second RIM layer (w_conv [64,64,3,3], w_ih [64,64,1,1]) for rim_layer2_sb; with w_final [2,64,3,3]
+    also the operands of the final convolution's channel contraction (rim_layer2_sb_final)."""
     w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
     if tuple(w_conv.shape) != (64, 64, 3, 3) or tuple(w_ih.shape) != (64, 64, 1, 1):
         raise NotImplementedError(f"rim_layer2_sb_pack: {tuple(w_conv.shape)} / {tuple(w_ih.shape)}")
+    if w_final is not None:
+        w_final = _lib.f32c(w_final.detach())
+        if tuple(w_final.shape) != (2, 64, 3, 3):
+            raise NotImplementedError(f"rim_layer2_sb_pack: final conv {tuple(w_final.shape)}")
     packed = torch.empty(int(_lib.lib().mrx_rim_layer2_sb_pack_floats()), dtype=torch.float32, device=w_conv.device)
-    _lib.check(_lib.lib().mrx_rim_layer2_sb_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(packed), _lib.stream_ptr()), "mrx_rim_layer2_sb_pack")
+    _lib.check(_lib.lib().mrx_rim_layer2_sb_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(w_final), _lib.ptr(packed), _lib.stream_ptr()),
+               "mrx_rim_layer2_sb_pack")
     return packed
 
 
-def rim_layer2_sb(x, packed, b_conv, b_ih, hh, h_prev):
+def rim_layer2_sb(x, packed, b_conv, b_ih, hh, h_prev, out=None):
     """ReLU(W_ih ReLU(conv3x3 dilation 2 (replicate pad)(x) + b_conv) + b_ih + hh * h_prev), 64 features, on the bf16 matrix pipe with fp32
-    results (mrx_rim_layer2_sb)."""
+    results (mrx_rim_layer2_sb).  `out` may be h_prev itself (state updated in place: every element is read by the lane that writes it)."""
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
     bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
     hhc = _lib.f32c(hh.detach().reshape(-1))
     hp = _lib.f32c(h_prev) if h_prev is not None else None
-    out = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().mrx_rim_layer2_sb(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out),
                                             B, H, W, _lib.stream_ptr()), "mrx_rim_layer2_sb")
     return out
+
+
+def rim_layer2_sb_taps(x, packed, b_conv, b_ih, hh, h_prev, taps=None, out=None):
+    """rim_layer2_sb that also leaves the final convolution's per-pixel tap products [B,18,H,W] (mrx_rim_layer2_sb_taps); `packed` from
+    rim_layer2_sb_pack(..., w_final).  `out` may be h_prev itself (state updated in place).  Returns (h_new, taps)."""
+    x = _lib.f32c(x)
+    B, C, H, W = _nchw(x)
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    if taps is None or taps.numel() < 18 * B * H * W:
+        taps = torch.empty(B, 18, H, W, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_rim_layer2_sb_taps(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp),
+                                                 _lib.ptr(out), _lib.ptr(taps), B, H, W, _lib.stream_ptr()), "mrx_rim_layer2_sb_taps")
+    return out, taps
+
+
+def rim_final_gather(taps, b_final, eta):
+    """eta + permute(conv3x3_reppad(h) + b_final) [B,H,W,2] from the tap products of rim_layer2_sb_taps (mrx_rim_final_gather)."""
+    eta = _lib.f32c(eta)
+    B, H, W, _ = [int(v) for v in eta.shape]
+    if taps.numel() < 18 * B * H * W or int(eta.shape[-1]) != 2:
+        raise ValueError("rim_final_gather expects taps [B,18,H,W] and eta [B,H,W,2]")
+    bf = _lib.f32c(b_final.detach()) if b_final is not None else None
+    eta_out = torch.empty_like(eta)
+    _lib.check(_lib.lib().mrx_rim_final_gather(_lib.ptr(taps), _lib.ptr(bf), _lib.ptr(eta), _lib.ptr(eta_out), B, H, W, _lib.stream_ptr()),
+               "mrx_rim_final_gather")
+    return eta_out
+
+
+def rim_layer2_sb_final(x, packed, b_conv, b_ih, hh, h_prev, b_final, eta, work=None, out=None):
+    """Second RIM layer and the final convolution + eta update (rim_block.py:233-246): returns (h_new [B,64,H,W],
+    eta + permute(conv3x3_reppad(h_new) + b_final) [B,H,W,2]).  `packed` from rim_layer2_sb_pack(..., w_final)."""
+    if tuple(eta.shape) != (int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), 2):
+        raise ValueError("rim_layer2_sb_final expects eta of shape [B,H,W,2]")
+    h_new, taps = rim_layer2_sb_taps(x, packed, b_conv, b_ih, hh, h_prev, work, out)
+    return h_new, rim_final_gather(taps, b_final, eta)
 
 
 def rim_layer_wino_pack(w_conv, w_ih):

@@ -167,6 +167,36 @@ def test_second_rim_layer_split_bf16_has_fp32_accuracy(shape, dev):
         assert rel_l2(got, win) <= 8e-7
 
 
+@pytest.mark.parametrize("shape", [(1, 640, 372), (2, 37, 75), (1, 19, 33), (3, 16, 32), (1, 5, 3), (1, 1, 1), (1, 130, 320)])
+def test_second_rim_layer_with_final_conv_in_its_tail(shape, dev):
+    """mrx_rim_layer2_sb_final: the layer's h_new must be the plain kernel's bit for bit, and eta + permute(conv3x3_reppad(h_new) + b) must
+    match a float64 convolution of that h_new at fp32 round-off and the stand-alone final kernel (mrx_rim_final) to round-off (rim_block.py:233-246).
+    Ragged tiles, images smaller than a tile (every tap clamped), batches, no h_prev, no biases."""
+    import torch.nn.functional as Fn
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    B, H, W = shape
+    F_ = 64
+    g = torch.Generator().manual_seed(7 + sum(shape))
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    x, hp = r(B, F_, H, W).relu(), r(B, F_, H, W).relu()
+    wc, wi, wf = r(F_, F_, 3, 3) / 24, r(F_, F_, 1, 1) / 8, r(2, F_, 3, 3) / 24
+    bc, bi, bf, hh = r(F_) * 0.1, r(F_) * 0.1, r(2) * 0.1, r(1, F_, 1, 1) * 0.5
+    eta = r(B, H, W, 2)
+    pk = ops.rim_layer2_sb_pack(wc, wi, wf)
+    for with_state, with_bias in ((True, True), (False, True), (True, False)):
+        b1, b2, b3 = (bc, bi, bf) if with_bias else (None, None, None)
+        h_plain = ops.rim_layer2_sb(x, pk, b1, b2, hh, hp if with_state else None)
+        h_new, eta_new = ops.rim_layer2_sb_final(x, pk, b1, b2, hh, hp if with_state else None, b3, eta)
+        assert torch.equal(h_new, h_plain)
+        conv = Fn.conv2d(Fn.pad(h_new.double(), (1, 1, 1, 1), mode="replicate"), wf.double(), None if b3 is None else b3.double())
+        ref = eta.double() + conv.permute(0, 2, 3, 1)
+        sep = ops.rim_final(h_new, wf, b3, 3, 1, eta)
+        e_f, e_s = rel_l2(eta_new, ref), rel_l2(sep, ref)
+        assert e_f <= 4e-7 and e_f <= 2.5 * e_s + 5e-8, (e_f, e_s)
+        assert rel_l2(eta_new - eta, sep - eta) <= 1e-6
+
+
 @pytest.mark.parametrize("shape", [(1, 4, 640, 372), (2, 4, 37, 75), (1, 2, 19, 33), (3, 1, 16, 32), (1, 4, 5, 3), (1, 3, 130, 320)])
 def test_first_rim_layer_split_bf16_has_fp32_accuracy(shape, dev, monkeypatch):
     """The first RIM layer on the bf16 matrix pipe (k_rim_layer1_sb: every fp32 operand as the exact sum of three bf16 terms, six term

@@ -172,6 +172,39 @@ def test_full_size_rim_block_winograd_on_and_off(dev, scale):
     assert rel_l2(outs[True], outs[False]) <= 5e-6
 
 
+@pytest.mark.parametrize("shape", [(15, 640, 372), (15, 40, 372), (6, 37, 75)])
+def test_rim_block_fused_final_and_in_place_state(dev, shape):
+    """The two default shortcuts of the IndRNN cascade against their plain forms, whole RIMBlocks (two of them chained, so that the second
+    receives the first one's states as the CALLER's): (1) the final convolution's channel contraction in layer 2's tail + tap gather
+    (mrx_rim_layer2_sb_taps / mrx_rim_final_gather) vs the stand-alone final kernel: fp32 round-off; (2) hidden states overwritten in place
+    from the second step on vs fresh tensors every step: bit-identical -- and a state handed in by the caller must come back untouched."""
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    C, H, W = shape
+    cfg, model, sd = _cirim(dict(num_cascades=2), 3.0, seed=2)
+    d = synthetic.make_slice(C, H, W, slice_idx=5)
+    y, S, m = d["y"].to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev)
+    blk0, blk1 = model.cirim[0].to(dev), model.cirim[1].to(dev)
+    res = {}
+    keep = (RIMBlock.fused_final, RIMBlock.inplace_state)
+    try:
+        for fused, inplace in ((True, True), (True, False), (False, True), (False, False)):
+            RIMBlock.fused_final, RIMBlock.inplace_state = fused, inplace
+            with torch.no_grad():
+                etas0, hx0 = blk0(y, y, S, m, None, None, 1.0, keep_eta=False)
+                saved = [h.clone() for h in hx0]
+                etas1, hx1 = blk1(etas0, y, S, m, etas0[-1], hx0, 1.0, keep_eta=False)
+            for a, b in zip(saved, hx0):
+                assert torch.equal(a, b), "the caller's hidden state was modified"
+            res[(fused, inplace)] = (torch.stack(etas0 + etas1), torch.stack(list(hx1)))
+    finally:
+        RIMBlock.fused_final, RIMBlock.inplace_state = keep
+    for fused in (True, False):
+        for k in range(2):
+            assert torch.equal(res[(fused, True)][k], res[(fused, False)][k]), f"in-place state changed the result (fused_final={fused})"
+    assert rel_l2(res[(True, True)][0], res[(False, True)][0]) <= 5e-6
+    assert rel_l2(res[(True, True)][1], res[(False, True)][1]) <= 5e-6
+
+
 def test_eight_cascades_w372_final_image_ssim(dev):
     """(c) all 8 cascades x 8 steps at 1 x 15 x 64 x 372 (the 372-point plan, four coil chunks, deferred route) vs the oracle; SSIM vs
     ref on the FINAL image through the product's harness (mridc_amd.runner) with the oracle's SSIM as the checker."""

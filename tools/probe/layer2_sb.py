@@ -14,9 +14,13 @@ x, hp = r(B, F, H, W).relu(), r(B, F, H, W).relu()
 wc, wi = r(F, F, 3, 3) / 24, r(F, F, 1, 1) / 8
 bc, bi, hh = r(F) * 0.1, r(F) * 0.1, r(1, F, 1, 1) * 0.5
 pk_w = ops.rim_layer_wino_pack(wc, wi)
-pk_s = ops.rim_layer2_sb_pack(wc, wi)
+wf, bf, eta = r(2, F, 3, 3) / 24, r(2) * 0.1, r(B, H, W, 2)
+pk_s = ops.rim_layer2_sb_pack(wc, wi, wf)
+work = torch.empty(18 * B * H * W, device=dev)
 fns = {"winograd fp32": lambda: ops.rim_layer_indrnn_wino(x, pk_w, F, bc, bi, hh, hp),
-       "direct split-bf16": lambda: ops.rim_layer2_sb(x, pk_s, bc, bi, hh, hp)}
+       "direct split-bf16": lambda: ops.rim_layer2_sb(x, pk_s, bc, bi, hh, hp),
+       "final conv alone": lambda: ops.rim_final(hp, wf, bf, 3, 1, eta),
+       "split-bf16 + final": lambda: ops.rim_layer2_sb_final(x, pk_s, bc, bi, hh, hp, bf, eta, work)}
 
 
 def timed(fn):
@@ -36,6 +40,9 @@ ref = Fn.relu(Fn.conv2d(Fn.pad(x.double(), (2, 2, 2, 2), mode="replicate"), wc.d
 ref = Fn.relu(Fn.conv2d(ref, wi.double(), bi.double()) + hh.double() * hp.double())
 for name, fn in fns.items():
     out = fn()
+    if "final" in name:
+        print("%-18s %.2f us per call" % (name, timed(fn)))
+        continue
     err = ((out.double() - ref).norm() / ref.norm()).item()
     print("%-18s rel-L2 vs float64 %.3e, max abs %.3e, %.2f us per launch" % (name, err, (out.double() - ref).abs().max().item(), timed(fn)))
 os.environ["MRX_L2SB_TRACE"] = "1"
