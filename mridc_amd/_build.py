@@ -25,6 +25,7 @@ SOURCES = [
     ("conv_bwd.hip", []),
     ("conv_bf16.hip", []),
     ("unet.hip", []),
+    ("unet_fused.hip", []),
     ("qmri.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

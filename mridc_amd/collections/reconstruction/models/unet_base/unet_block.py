@@ -5,6 +5,7 @@ forward pass runs on the HIP kernels: MFMA conv (csrc/conv.hip), InstanceNorm+Le
 (csrc/unet.hip).
 """
 import math
+import os
 from typing import List, Tuple
 
 import torch
@@ -89,10 +90,50 @@ class Unet(torch.nn.Module):
         self.up_conv.append(torch.nn.Sequential(ConvBlock(ch * 2, ch, drop_prob),
                                                 torch.nn.Conv2d(ch, self.out_chans, kernel_size=1, stride=1)))
 
+    # the inference path keeps every Conv -> InstanceNorm -> LeakyReLU output as (raw, per-plane statistics) and lets the consumer normalise
+    # while it loads: no apply pass, no concatenated tensor (csrc/unet_fused.hip); MRIDC_AMD_UNET_FUSED=0 selects conv + apply launches
+    fused = os.environ.get("MRIDC_AMD_UNET_FUSED", "1") != "0"
+
+    def _fusable(self) -> bool:
+        blocks = list(self.down_sample_layers) + [self.conv] + [c[0] if isinstance(c, torch.nn.Sequential) else c for c in self.up_conv]
+        last = self.up_conv[-1]
+        return (all(isinstance(b, ConvBlock) and b.layers[1].eps == b.layers[5].eps == 1e-5 and b.layers[2].negative_slope == 0.2
+                    for b in blocks)
+                and all(t.layers[1].eps == 1e-5 and t.layers[2].negative_slope == 0.2
+                        and ops.unet_conv_transpose2x2_supported(t.in_chans, t.out_chans) for t in self.up_transpose_conv)
+                and isinstance(last, torch.nn.Sequential) and last[1].out_channels <= 4 and last[1].in_channels <= 1024)
+
+    def _forward_fused(self, image: torch.Tensor) -> torch.Tensor:
+        """unet_block.py:192-227 on (raw, statistics) pairs."""
+        def block(b, a, skip=None):
+            return ops.unet_conv3x3(ops.unet_conv3x3(a, skip, b.layers[0].weight), None, b.layers[4].weight)
+
+        stack = []
+        x = image
+        for layer in self.down_sample_layers:                        # unet_block.py:203-206
+            x = block(layer, x)
+            stack.append(x)
+            x = ops.unet_avg_pool2x2(x)
+        x = block(self.conv, x)
+        for transpose_conv, conv in zip(self.up_transpose_conv, self.up_conv):
+            skip = stack.pop()
+            x = ops.unet_conv_transpose2x2(x, transpose_conv.layers[0].weight)
+            pad_r = 1 if x[0].shape[-1] != skip[0].shape[-1] else 0  # unet_block.py:215-222 (odd sizes only: written out, then padded)
+            pad_b = 1 if x[0].shape[-2] != skip[0].shape[-2] else 0
+            if pad_r or pad_b:
+                x = ops.pad2d(ops.unet_apply(x), 0, pad_b, 0, pad_r, mode=1)
+            last = isinstance(conv, torch.nn.Sequential)
+            x = block(conv[0] if last else conv, x, skip)             # torch.cat([output, downsample_layer], dim=1) read in place
+            if last:
+                return ops.unet_conv1x1(x, conv[1].weight, conv[1].bias)
+        return ops.unet_apply(x)
+
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         stack = []
         output = image
         o = _ns(image, *self.parameters())
+        if o is ops and self.fused and not self.training and self._fusable():
+            return self._forward_fused(image)
         for layer in self.down_sample_layers:                        # unet_block.py:203-206
             output = layer(output)
             stack.append(output)

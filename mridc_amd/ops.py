@@ -1175,6 +1175,94 @@ def concat_channels(a, b):
     return out
 
 
+# ---- U-Net without normalisation passes (csrc/unet_fused.hip) ----------------------------------------------------
+# A "lazy" tensor is the pair (raw, norm): raw [B,C,H,W] convolution output, norm [B,C,2] per-plane (mean, 1/std) of the InstanceNorm2d that
+# follows it in the reference (unet_block.py:251-258, 296-299); whoever reads it applies leaky((raw - mean) / std) while loading.
+def _lazy(t):
+    """(raw, norm or None) of a plain tensor or a (raw, norm) pair."""
+    if isinstance(t, tuple):
+        return _lib.f32c(t[0]), _lib.f32c(t[1])
+    return _lib.f32c(t), None
+
+
+def unet_conv3x3(src_a, src_b, weight, eps=1e-5, slope=0.2):
+    """Conv2d(3x3, zero pad, no bias) over the channels of src_a then src_b (None: one source; each plain or lazy) -> lazy output
+    (mrx_unet_conv3x3): the InstanceNorm statistics come out of the accumulators, nothing is normalised or concatenated in memory."""
+    xa, na = _lazy(src_a)
+    xb, nb = _lazy(src_b) if src_b is not None else (None, None)
+    weight = _lib.f32c(weight.detach())
+    B, Ca, H, W = _nchw(xa)
+    Cb = int(xb.shape[1]) if xb is not None else 0
+    Cout = int(weight.shape[0])
+    if tuple(weight.shape[1:]) != (Ca + Cb, 3, 3) or (xb is not None and (xb.shape[0], xb.shape[2], xb.shape[3]) != (B, H, W)):
+        raise RuntimeError(f"unet_conv3x3: weight {tuple(weight.shape)} vs sources with {Ca} + {Cb} channels")
+    L = _lib.lib()
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=xa.device)
+    norm = torch.empty(B, Cout, 2, dtype=torch.float32, device=xa.device)
+    work = torch.empty(int(L.mrx_unet_conv3x3_work_floats(B, Cout, H, W)), dtype=torch.float32, device=xa.device)
+    _lib.check(L.mrx_unet_conv3x3(_lib.ptr(xa), _lib.ptr(na), Ca, _lib.ptr(xb), _lib.ptr(nb), Cb, _lib.ptr(weight), _lib.ptr(y), _lib.ptr(norm),
+                                  _lib.ptr(work), B, Cout, H, W, float(eps), float(slope), _lib.stream_ptr()), "mrx_unet_conv3x3")
+    return y, norm
+
+
+def unet_conv_transpose2x2_supported(Cin, Cout):
+    return int(Cout) % 2 == 0 and int(Cin) * (2 * 16 + 8) <= 48 * 1024
+
+
+def unet_conv_transpose2x2(src, weight, eps=1e-5, slope=0.2):
+    """ConvTranspose2d(k 2, s 2, no bias) of a plain or lazy tensor -> lazy output (mrx_unet_convT2x2)."""
+    x, nrm = _lazy(src)
+    weight = _lib.f32c(weight.detach())
+    B, Cin, H, W = _nchw(x)
+    Cin_w, Cout, kh, kw = [int(v) for v in weight.shape]
+    if Cin_w != Cin or kh != 2 or kw != 2:
+        raise ValueError("unet_conv_transpose2x2 expects weight [Cin,Cout,2,2]")
+    L = _lib.lib()
+    out = torch.empty(B, Cout, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    norm = torch.empty(B, Cout, 2, dtype=torch.float32, device=x.device)
+    work = torch.empty(int(L.mrx_unet_convT2x2_work_floats(B, Cout, H, W)), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_unet_convT2x2(_lib.ptr(x), _lib.ptr(nrm), _lib.ptr(weight), _lib.ptr(out), _lib.ptr(norm), _lib.ptr(work), B, Cin, Cout,
+                                   H, W, float(eps), float(slope), _lib.stream_ptr()), "mrx_unet_convT2x2")
+    return out, norm
+
+
+def unet_avg_pool2x2(src, slope=0.2):
+    """avg_pool2d(2) of a plain or lazy tensor -> plain tensor (mrx_unet_avgpool)."""
+    x, nrm = _lazy(src)
+    B, C, H, W = _nchw(x)
+    out = torch.empty(B, C, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_unet_avgpool(_lib.ptr(x), _lib.ptr(nrm), _lib.ptr(out), B * C, H, W, float(slope), _lib.stream_ptr()),
+               "mrx_unet_avgpool")
+    return out
+
+
+def unet_apply(src, slope=0.2):
+    """The plain tensor leaky((raw - mean) / std) of a lazy one (mrx_unet_apply)."""
+    x, nrm = _lazy(src)
+    if nrm is None:
+        return x
+    B, C, H, W = _nchw(x)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().mrx_unet_apply(_lib.ptr(x), _lib.ptr(nrm), _lib.ptr(out), B * C, H * W, float(slope), _lib.stream_ptr()),
+               "mrx_unet_apply")
+    return out
+
+
+def unet_conv1x1(src, weight, bias, slope=0.2):
+    """1x1 convolution (+ bias) of a plain or lazy tensor into <= 4 channels -> plain tensor (mrx_unet_conv1x1)."""
+    x, nrm = _lazy(src)
+    weight = _lib.f32c(weight.detach())
+    B, Cin, H, W = _nchw(x)
+    Cout = int(weight.shape[0])
+    if tuple(weight.shape[1:]) != (Cin, 1, 1):
+        raise RuntimeError(f"unet_conv1x1: weight {tuple(weight.shape)} vs {Cin} input channels")
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_unet_conv1x1(_lib.ptr(x), _lib.ptr(nrm), _lib.ptr(weight), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H * W,
+                                           float(slope), _lib.stream_ptr()), "mrx_unet_conv1x1")
+    return out
+
+
 # ---- quantitative MRI (A19) -----------------------------------------------------------------------------------
 def _tes_host(TEs):
     import ctypes

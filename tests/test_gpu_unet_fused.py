@@ -1,0 +1,101 @@
+"""GPU parity of the U-Net kernels that keep Conv -> InstanceNorm2d -> LeakyReLU(0.2) outputs as (raw, per-plane statistics) pairs and
+normalise on load (csrc/unet_fused.hip; reference unet_base/unet_block.py:139-308): every operator against float64 torch, the whole
+Unet / NormUnet against the conv + apply formulation (MRIDC_AMD_UNET_FUSED=0) and -- through the golden tests of test_gpu_models.py,
+which now run this path by default -- against the reference.  Tolerances: operators 2e-6 of the output norm (fp32 MFMA = exact fp32 FMA
+chains), whole networks 2e-5 (ten normalised layers deep)."""
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from tests._util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _norm_act(x, eps=1e-5, slope=0.2):
+    return Fn.leaky_relu(Fn.instance_norm(x, eps=eps), slope)
+
+
+def _lazy_ref(raw64, norm):
+    """leaky((raw - mean) / std) from a kernel's own (mean, 1/std), in float64."""
+    return Fn.leaky_relu((raw64 - norm[..., 0, None, None].double()) * norm[..., 1, None, None].double(), 0.2)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 0, 14, 640, 380), (1, 14, 0, 14, 640, 380), (1, 14, 14, 14, 640, 380), (2, 14, 0, 28, 320, 190),
+                                   (1, 28, 28, 28, 160, 95), (1, 56, 0, 56, 33, 47), (1, 18, 18, 18, 72, 40), (3, 5, 3, 36, 9, 7),
+                                   (1, 144, 144, 144, 40, 24), (1, 3, 0, 70, 8, 32), (1, 1, 0, 1, 1, 2)])
+def test_unet_conv3x3_sources_and_statistics(shape, dev):
+    """mrx_unet_conv3x3: plain and lazy sources, one and two of them (the skip concatenation read in place), every cout-block count, ragged
+    tiles, channel counts that are not multiples of the 8-channel step; raw output and (mean, 1/std) against float64."""
+    from mridc_amd import ops
+    B, Ca, Cb, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    a_raw, b_raw = r(B, Ca, H, W) * 2 + 0.5, (r(B, Cb, H, W) - 0.3 if Cb else None)
+    na = torch.stack([r(B, Ca) * 0.5, r(B, Ca).abs() + 0.5], -1)
+    nb = torch.stack([r(B, Cb) * 0.5, r(B, Cb).abs() + 0.5], -1) if Cb else None
+    w = r(Cout, Ca + Cb, 3, 3) / (9 * (Ca + Cb)) ** 0.5
+    for lazy_a, lazy_b in ((False, False), (True, True), (True, False)):
+        if Cb == 0 and lazy_b != lazy_a:
+            continue
+        xa = _lazy_ref(a_raw.double(), na) if lazy_a else a_raw.double()
+        x = xa
+        if Cb:
+            x = torch.cat([xa, _lazy_ref(b_raw.double(), nb) if lazy_b else b_raw.double()], 1)
+        ref = Fn.conv2d(x, w.double(), padding=1)
+        y, norm = ops.unet_conv3x3((a_raw, na) if lazy_a else a_raw, None if not Cb else ((b_raw, nb) if lazy_b else b_raw), w)
+        assert rel_l2(y, ref) <= 2e-6, (shape, lazy_a, lazy_b, rel_l2(y, ref))
+        mean, var = ref.mean((2, 3)), ref.var((2, 3), unbiased=False)
+        assert (norm[..., 0].double() - mean).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max()))
+        assert rel_l2(norm[..., 1], 1.0 / torch.sqrt(var + 1e-5)) <= 1e-5
+        assert rel_l2(ops.unet_apply((y, norm)), _norm_act(ref)) <= 5e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 56, 28, 160, 95), (1, 28, 14, 320, 190), (2, 36, 18, 20, 12), (1, 6, 4, 5, 3), (1, 144, 72, 80, 48)])
+def test_unet_transposed_conv_pool_and_1x1_read_lazy_tensors(shape, dev):
+    """mrx_unet_convT2x2 (every channel-group width), mrx_unet_avgpool, mrx_unet_conv1x1 on plain and lazy inputs against float64."""
+    from mridc_amd import ops
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    raw = r(B, Cin, H, W) * 1.5 + 0.2
+    nrm = torch.stack([r(B, Cin) * 0.5, r(B, Cin).abs() + 0.5], -1)
+    wt, w1, b1 = r(Cin, Cout, 2, 2) / (4 * Cin) ** 0.5, r(2, Cin, 1, 1) / Cin ** 0.5, r(2) * 0.1
+    for lazy in (False, True):
+        src = (raw, nrm) if lazy else raw
+        x = _lazy_ref(raw.double(), nrm) if lazy else raw.double()
+        ref = Fn.conv_transpose2d(x, wt.double(), stride=2)
+        y, norm = ops.unet_conv_transpose2x2(src, wt)
+        assert rel_l2(y, ref) <= 2e-6
+        assert rel_l2(ops.unet_apply((y, norm)), _norm_act(ref)) <= 5e-6
+        if H >= 2 and W >= 2:
+            assert rel_l2(ops.unet_avg_pool2x2(src), Fn.avg_pool2d(x, 2)) <= 1e-6
+        assert rel_l2(ops.unet_conv1x1(src, w1, b1), Fn.conv2d(x, w1.double(), b1.double())) <= 2e-6
+        assert rel_l2(ops.unet_conv1x1(src, w1, None), Fn.conv2d(x, w1.double())) <= 2e-6
+
+
+@pytest.mark.parametrize("cfg", [(14, 2, 11, 640, 372), (18, 4, 15, 640, 372), (8, 3, 7, 45, 37), (6, 2, 3, 33, 26)])
+def test_norm_unet_fused_matches_conv_plus_apply(cfg, dev):
+    """The whole NormUnet on the fused kernels against the conv + apply formulation (itself pinned by the reference goldens G7 and the
+    full-size E2EVN test): the E2EVN shapes and odd sizes that take the reflect-pad fallback (unet_block.py:215-222)."""
+    from mridc_amd.collections.reconstruction.models.unet_base.unet_block import NormUnet, Unet
+    chans, pools, pad, H, W = cfg
+    torch.manual_seed(chans + pools)
+    net = NormUnet(chans, pools, padding_size=pad).eval().to(dev)
+    x = torch.randn(1, 1, H, W, 2, generator=torch.Generator().manual_seed(H)).to(dev)
+    keep = Unet.fused
+    try:
+        with torch.no_grad():
+            Unet.fused = True
+            got = net(x)
+            Unet.fused = False
+            want = net(x)
+    finally:
+        Unet.fused = keep
+    assert rel_l2(got, want) <= 2e-5, rel_l2(got, want)

@@ -27,9 +27,11 @@ for (cin, cout, H, W) in [(2, 14, 640, 380), (14, 14, 640, 380), (28, 14, 640, 3
     x, w = r(1, cin, H, W), r(cout, cin, 3, 3) / (cin * 9) ** 0.5
     t_all = timeit(lambda: ops.conv_instance_norm_act(x, w, 1e-5, ops.ACT_LEAKY, 0.2))
     t_conv = timeit(lambda: ops.conv2d(x, w, None, 1, ops.PAD_ZERO))
+    nrm = torch.stack([r(1, cin) * 0.1, r(1, cin).abs() + 0.5], -1)
+    t_fused = timeit(lambda: ops.unet_conv3x3((x, nrm), None, w))
     mb = 4 * H * W * (cin + cout) / 1e6
     gf = 2 * cin * cout * 9 * H * W / 1e9
-    print(f"conv3x3 {cin:3d}->{cout:3d} @{H}x{W}: conv+IN+act {t_all:6.1f} us | conv alone {t_conv:6.1f} us | {mb:6.1f} MB -> {mb / 5e3 * 1e3:5.1f} us at 5 TB/s, "
+    print(f"conv3x3 {cin:3d}->{cout:3d} @{H}x{W}: conv+IN+act {t_all:6.1f} us | conv alone {t_conv:6.1f} us | lazy in -> (raw, norm) out {t_fused:6.1f} us | {mb:6.1f} MB -> {mb / 5e3 * 1e3:5.1f} us at 5 TB/s, "
           f"{gf:5.2f} GFLOP -> {gf / 157.3 * 1e3:5.1f} us at the fp32 MFMA peak")
 for (cin, cout, H, W) in [(56, 28, 160, 95), (28, 14, 320, 190)]:
     x, w = r(1, cin, H, W), r(cin, cout, 2, 2) / (cin * 4) ** 0.5
