@@ -504,15 +504,15 @@ int mrx_recon_metrics(const float* target, const float* output, float* out5, flo
  *   mrx_unet_conv3x3   y = conv3x3(zero pad, no bias) over the channels of source A then source B (the skip concatenation,
  *                      unet_block.py:224, is never materialised; Cb = 0: one source); w [Cout, Ca + Cb, 3, 3];
  *                      work: mrx_unet_conv3x3_work_floats() floats
- *   mrx_unet_convT2x2  ConvTranspose2d(k 2, s 2, no bias), w [Cin, Cout, 2, 2], even Cout; out [B,Cout,2H,2W]
+ *   mrx_unet_conv_transpose2x2  ConvTranspose2d(k 2, s 2, no bias), w [Cin, Cout, 2, 2], even Cout; out [B,Cout,2H,2W]
  *   mrx_unet_avgpool   avg_pool2d(2) -> plain [planes, H/2, W/2]
  *   mrx_unet_conv1x1   1x1 convolution + bias, Cout <= 4 -> plain
  *   mrx_unet_apply     leaky((x - mean) / std) written out */
 int64_t mrx_unet_conv3x3_work_floats(int B, int Cout, int H, int W);
 int mrx_unet_conv3x3(const float* xa, const float* na, int Ca, const float* xb, const float* nb, int Cb, const float* w, float* y,
                      float* norm, float* work, int B, int Cout, int H, int W, float eps, float slope, void* stream);
-int64_t mrx_unet_convT2x2_work_floats(int B, int Cout, int H, int W);
-int mrx_unet_convT2x2(const float* x, const float* nrm, const float* w, float* out, float* norm, float* work, int B, int Cin, int Cout,
+int64_t mrx_unet_conv_transpose2x2_work_floats(int B, int Cout, int H, int W);
+int mrx_unet_conv_transpose2x2(const float* x, const float* nrm, const float* w, float* out, float* norm, float* work, int B, int Cin, int Cout,
                       int H, int W, float eps, float slope, void* stream);
 int mrx_unet_avgpool(const float* x, const float* nrm, float* out, int64_t planes, int H, int W, float slope, void* stream);
 int mrx_unet_apply(const float* x, const float* nrm, float* out, int64_t planes, int64_t HW, float slope, void* stream);

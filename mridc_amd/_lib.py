@@ -105,8 +105,8 @@ _SIGNATURES = {
     "mrx_concat_channels": ([_p, _p, _p, _i, _i, _i, _i64, _p], _i),
     "mrx_unet_conv3x3_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_unet_conv3x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p], _i),
-    "mrx_unet_convT2x2_work_floats": ([_i, _i, _i, _i], _i64),
-    "mrx_unet_convT2x2": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p], _i),
+    "mrx_unet_conv_transpose2x2_work_floats": ([_i, _i, _i, _i], _i64),
+    "mrx_unet_conv_transpose2x2": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p], _i),
     "mrx_unet_avgpool": ([_p, _p, _p, _i64, _i, _i, _f, _p], _i),
     "mrx_unet_apply": ([_p, _p, _p, _i64, _i64, _f, _p], _i),
     "mrx_unet_conv1x1": ([_p, _p, _p, _p, _p, _i, _i, _i, _i64, _f, _p], _i),

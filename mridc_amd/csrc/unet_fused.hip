@@ -6,7 +6,7 @@
 // finalize) and the normalisation + activation is applied by whoever READS the tensor, while it stages its tile:
 //   * mrx_unet_conv3x3      3x3 convolution (zero padding, no bias) over the channels of up to TWO sources -- so the skip concatenation
 //                           (unet_block.py:224) is never materialised -- each plain or (raw, norm); raw output + its norm
-//   * mrx_unet_convT2x2     ConvTranspose2d(k 2, s 2, no bias) of a (raw, norm) input; raw output + its norm
+//   * mrx_unet_conv_transpose2x2     ConvTranspose2d(k 2, s 2, no bias) of a (raw, norm) input; raw output + its norm
 //   * mrx_unet_avgpool      avg_pool2d(2) of a (raw, norm) input -> plain tensor
 //   * mrx_unet_conv1x1      the closing 1x1 convolution (+ bias) of a (raw, norm) input -> plain tensor
 //   * mrx_unet_apply        materialises a (raw, norm) tensor (fallback for the odd-size reflect pad, unet_block.py:215-222)
@@ -406,17 +406,17 @@ static void launch_uconvT(const float* x, const float* nrm, const float* w, floa
     hipLaunchKernelGGL((k_uconvT<COG>), grid, dim3(UC_NT), lds, st, x, nrm, w, out, Cin, Cout, H, W, slope, tstats);
 }
 
-extern "C" int64_t mrx_unet_convT2x2_work_floats(int B, int Cout, int H, int W) {
+extern "C" int64_t mrx_unet_conv_transpose2x2_work_floats(int B, int Cout, int H, int W) {
     if (B < 0 || Cout < 1 || H < 1 || W < 1) return -1;
     return (int64_t)B * (((long long)H * W + UC_NT - 1) / UC_NT) * Cout * 2;
 }
 
 // x [B,Cin,H,W] (+ nrm [B,Cin,2] or NULL), w [Cin,Cout,2,2] -> out [B,Cout,2H,2W] raw, norm [B,Cout,2]; even Cout, Cin <= 1228
-extern "C" int mrx_unet_convT2x2(const float* x, const float* nrm, const float* w, float* out, float* norm, float* work, int B, int Cin,
+extern "C" int mrx_unet_conv_transpose2x2(const float* x, const float* nrm, const float* w, float* out, float* norm, float* work, int B, int Cin,
                                  int Cout, int H, int W, float eps, float slope, void* stream) {
-    MRX_REQUIRE(x && w && out && norm && work && B >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_unet_convT2x2: bad argument");
+    MRX_REQUIRE(x && w && out && norm && work && B >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_unet_conv_transpose2x2: bad argument");
     MRX_REQUIRE(B <= 65535 && Cout % 2 == 0 && Cout <= 65535 * 2 && (size_t)Cin * (2 * 16 + 8) <= 48 * 1024 && (((uintptr_t)out) & 7) == 0,
-                MRX_EUNSUP, "mrx_unet_convT2x2: Cout=%d Cin=%d", Cout, Cin);
+                MRX_EUNSUP, "mrx_unet_conv_transpose2x2: Cout=%d Cin=%d", Cout, Cin);
     if (B == 0) return MRX_OK;
     hipStream_t st = (hipStream_t)stream;
     const long long HW = (long long)H * W, ntiles = (HW + UC_NT - 1) / UC_NT;

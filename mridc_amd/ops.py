@@ -1210,7 +1210,7 @@ def unet_conv_transpose2x2_supported(Cin, Cout):
 
 
 def unet_conv_transpose2x2(src, weight, eps=1e-5, slope=0.2):
-    """ConvTranspose2d(k 2, s 2, no bias) of a plain or lazy tensor -> lazy output (mrx_unet_convT2x2)."""
+    """ConvTranspose2d(k 2, s 2, no bias) of a plain or lazy tensor -> lazy output (mrx_unet_conv_transpose2x2)."""
     x, nrm = _lazy(src)
     weight = _lib.f32c(weight.detach())
     B, Cin, H, W = _nchw(x)
@@ -1220,9 +1220,9 @@ def unet_conv_transpose2x2(src, weight, eps=1e-5, slope=0.2):
     L = _lib.lib()
     out = torch.empty(B, Cout, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
     norm = torch.empty(B, Cout, 2, dtype=torch.float32, device=x.device)
-    work = torch.empty(int(L.mrx_unet_convT2x2_work_floats(B, Cout, H, W)), dtype=torch.float32, device=x.device)
-    _lib.check(L.mrx_unet_convT2x2(_lib.ptr(x), _lib.ptr(nrm), _lib.ptr(weight), _lib.ptr(out), _lib.ptr(norm), _lib.ptr(work), B, Cin, Cout,
-                                   H, W, float(eps), float(slope), _lib.stream_ptr()), "mrx_unet_convT2x2")
+    work = torch.empty(int(L.mrx_unet_conv_transpose2x2_work_floats(B, Cout, H, W)), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_unet_conv_transpose2x2(_lib.ptr(x), _lib.ptr(nrm), _lib.ptr(weight), _lib.ptr(out), _lib.ptr(norm), _lib.ptr(work), B, Cin, Cout,
+                                   H, W, float(eps), float(slope), _lib.stream_ptr()), "mrx_unet_conv_transpose2x2")
     return out, norm
 
 

@@ -59,7 +59,7 @@ def test_unet_conv3x3_sources_and_statistics(shape, dev):
 
 @pytest.mark.parametrize("shape", [(1, 56, 28, 160, 95), (1, 28, 14, 320, 190), (2, 36, 18, 20, 12), (1, 6, 4, 5, 3), (1, 144, 72, 80, 48)])
 def test_unet_transposed_conv_pool_and_1x1_read_lazy_tensors(shape, dev):
-    """mrx_unet_convT2x2 (every channel-group width), mrx_unet_avgpool, mrx_unet_conv1x1 on plain and lazy inputs against float64."""
+    """mrx_unet_conv_transpose2x2 (every channel-group width), mrx_unet_avgpool, mrx_unet_conv1x1 on plain and lazy inputs against float64."""
     from mridc_amd import ops
     B, Cin, Cout, H, W = shape
     g = torch.Generator().manual_seed(sum(shape))
