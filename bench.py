@@ -793,7 +793,7 @@ def main():
                                           "direct-form FLOPs of SURVEY 8d / time: above `frac` by the Winograd saving (2.0x), not a pipe figure"),
                         traffic=traffic.get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"), traffic_unit="bytes/launch",
                         traffic_kernel=traffic.get("_kernels", {}).get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"),
-                        traffic_source=traffic.get("_source"), algorithmic_bytes=3.0 * F_hidden * npix * B * 4,
+                        traffic_source=traffic.get("_source"), algorithmic_bytes=(3.0 * F_hidden + (18.0 if l2_taps else 0.0)) * npix * B * 4,
                         launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
                         regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_fp32_gflop=issued_reg / 1e9,
                                          issued_bf16_gflop=issued1_bf16 / 1e9,

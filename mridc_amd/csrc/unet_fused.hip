@@ -16,6 +16,7 @@
 // Arithmetic: fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, channel groups of four in ascending order, taps inside -- the
 // order of the kernel it replaces), normalisation as (x - mean) * (1 / sqrtf(M2 / n + eps)) like mrx_instance_norm_apply.
 #include <cstdint>
+#include <cstdlib>
 
 #include "mrx_common.h"
 
@@ -41,6 +42,7 @@ struct UConvArgs {
     float* tstats;     // [B][ntiles][Cout][2] (mean, M2) per tile
     int Ca, Cb, B, Cout, H, W, tiles_x;
     float slope;
+    int abl;           // debug (env MRX_UCONV_ABLATE): 1 no matrix work, 2 no stores, 4 no statistics
 };
 
 __device__ __forceinline__ float uc_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(UC_NT) void k_uconv(UConvArgs a) {
         }
         const float* xq = Xs + (q & 1) * (UC_CK * UC_PLANE) + lg * UC_PLANE + l15;
         const float* wq = Ws + (q & 1) * WBUF + lane;
+        if (!(a.abl & 1))
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(UC_NT) void k_uconv(UConvArgs a) {
     for (int sg = 0; sg < 4; ++sg) {
         const int oy = h0 + 2 * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
         ok[sg] = oy < a.H && ox < a.W;
-        if (ok[sg]) {
+        if (ok[sg] && !(a.abl & 2)) {
 #pragma unroll
             for (int ct = 0; ct < NCOT; ++ct)
 #pragma unroll
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(UC_NT) void k_uconv(UConvArgs a) {
                 }
         }
     }
+    if (a.abl & 4) return;
     // InstanceNorm statistics of this tile, per cout: mean over its valid pixels, then the squared deviations from that mean (two
     // fixed-order block reductions); k_unorm_finalize merges the tiles with the parallel-variance formula in double
     __syncthreads();
@@ -299,6 +303,8 @@ extern "C" int mrx_unet_conv3x3(const float* xa, const float* na, int Ca, const 
     UConvArgs a;
     a.xa = xa, a.na = na, a.xb = Cb ? xb : nullptr, a.nb = Cb ? nb : nullptr, a.w = w, a.y = y, a.tstats = work;
     a.Ca = Ca, a.Cb = Cb, a.B = B, a.Cout = Cout, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, UC_TW), a.slope = slope;
+    static const int abl = getenv("MRX_UCONV_ABLATE") ? atoi(getenv("MRX_UCONV_ABLATE")) : 0;
+    a.abl = abl;
     const int ntiles = a.tiles_x * mrx_cdiv(H, UC_TH);
     const int ncot = (Cout + 15) / 16;
     hipStream_t st = (hipStream_t)stream;

@@ -14,7 +14,6 @@ x, hp = r(B, F, H, W), r(B, F, H, W)
 wc, wi = r(F, F, 3, 3) / 24, r(F, F, 1, 1) / 8
 bc, bi, hh = r(F), r(F), r(1, F, 1, 1)
 pk = ops.rim_layer_wino_pack(wc, wi)
-pk2 = ops.rim_layer2_sb_pack(wc, wi)
 pk1 = ops.rim_layer_pack(r(F, 4, 5, 5) / 10, wi)
 eta, y, S = r(B, H, W, 2), r(B, C, H, W, 2), r(B, C, H, W, 2)
 mask = (torch.rand(1, 1, 1, W, 1) < 0.3).to(dev)
@@ -22,13 +21,16 @@ mask2d = (torch.rand(1, 1, H, W, 1) < 0.1).to(dev)
 yt = ops.llg_prepare(y, False, "backward")
 op = ops.llg372_prepare(yt, S, mask, False)
 wf = r(2, F, 3, 3) / 24
+pk2 = ops.rim_layer2_sb_pack(wc, wi, wf)
+taps = torch.empty(B, 18, H, W, device=dev)
 work = torch.empty_like(y)
 torch.cuda.synchronize()
 for _ in range(3):
     part, n = ops.llg372(eta, op, 1.0, "backward", parts=True)
     ops.rim_layer_indrnn_packed_llg(eta, part, n, 1.0, pk1, F, 5, 1, bc, bi, hh, hp)
     ops.rim_layer_indrnn_wino(x, pk, F, bc, bi, hh, hp)
-    ops.rim_layer2_sb(x, pk2, bc, bi, hh, hp)
+    ops.rim_layer2_sb_taps(x, pk2, bc, bi, hh, hp, taps)      # the headline loop's form: + the final convolution's tap products
+    ops.rim_final_gather(taps, None, eta)
     ops.rim_final(x, wf, None, 3, 1, eta)
     ops.llg(eta, y, S, mask2d, 1.0, False, "backward", work=work)
 torch.cuda.synchronize()

@@ -16,6 +16,7 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "conv_layer2_wino": ["k_rim_layer_wino<0, true, 2, true"],
     "conv_layer2_sb": ["k_rim_layer2_sb"],
     "final": ["k_rim_final4"],
+    "final_gather": ["k_l2sb_gather"],
     "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_rows_reduce<1", "k_pfa372_expand", "k_pfa372_reduce", "k_llg372_combine"],
 }
 
