@@ -518,6 +518,16 @@ int mrx_unet_avgpool(const float* x, const float* nrm, float* out, int64_t plane
 int mrx_unet_apply(const float* x, const float* nrm, float* out, int64_t planes, int64_t HW, float slope, void* stream);
 int mrx_unet_conv1x1(const float* x, const float* nrm, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int64_t HW,
                      float slope, void* stream);
+/* NormUnet head and tail on complex-last tensors (unet_block.py:46-136, norm_groups = 2):
+ *   mrx_unet_cnorm_pad        x [B,c,H,W,2] -> out [B,2c,H+top+bottom,W+left+right] = pad(norm(complex_to_chan_dim(x))) in three launches (two
+ *                             statistics passes, one normalise + permute + pad pass); mean, std [B,2]; work: mrx_unet_cnorm_work_floats(B)
+ *   mrx_unet_conv1x1_cunnorm  the closing 1x1 convolution of a (raw, norm) tensor [B,Cin,OH,OW] into 2c <= 4 channels, written as
+ *                             chan_complex_to_last_dim(unnorm(unpad(.))): out [B,c,H,W,2] */
+int64_t mrx_unet_cnorm_work_floats(int B);
+int mrx_unet_cnorm_pad(const float* x, float* out, float* mean, float* std_, float* work, int B, int c, int H, int W, int top, int bottom,
+                       int left, int right, void* stream);
+int mrx_unet_conv1x1_cunnorm(const float* x, const float* nrm, const float* w, const float* bias, const float* mean, const float* std_,
+                             float* out, int B, int Cin, int c, int OH, int OW, int top, int left, int H, int W, float slope, void* stream);
 
 #ifdef __cplusplus
 }

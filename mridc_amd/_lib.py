@@ -110,6 +110,9 @@ _SIGNATURES = {
     "mrx_unet_avgpool": ([_p, _p, _p, _i64, _i, _i, _f, _p], _i),
     "mrx_unet_apply": ([_p, _p, _p, _i64, _i64, _f, _p], _i),
     "mrx_unet_conv1x1": ([_p, _p, _p, _p, _p, _i, _i, _i, _i64, _f, _p], _i),
+    "mrx_unet_cnorm_work_floats": ([_i], _i64),
+    "mrx_unet_cnorm_pad": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_unet_conv1x1_cunnorm": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_hard_dc": ([_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_vs_average": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_dc_combine": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),

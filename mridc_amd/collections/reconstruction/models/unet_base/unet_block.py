@@ -103,8 +103,9 @@ class Unet(torch.nn.Module):
                         and ops.unet_conv_transpose2x2_supported(t.in_chans, t.out_chans) for t in self.up_transpose_conv)
                 and isinstance(last, torch.nn.Sequential) and last[1].out_channels <= 4 and last[1].in_channels <= 1024)
 
-    def _forward_fused(self, image: torch.Tensor) -> torch.Tensor:
-        """unet_block.py:192-227 on (raw, statistics) pairs."""
+    def _forward_fused(self, image: torch.Tensor, tail=None) -> torch.Tensor:
+        """unet_block.py:192-227 on (raw, statistics) pairs.  `tail(lazy, conv1x1 module)`: replaces the closing 1x1 convolution (NormUnet
+        writes its un-normalised complex-last result from there)."""
         def block(b, a, skip=None):
             return ops.unet_conv3x3(ops.unet_conv3x3(a, skip, b.layers[0].weight), None, b.layers[4].weight)
 
@@ -125,7 +126,7 @@ class Unet(torch.nn.Module):
             last = isinstance(conv, torch.nn.Sequential)
             x = block(conv[0] if last else conv, x, skip)             # torch.cat([output, downsample_layer], dim=1) read in place
             if last:
-                return ops.unet_conv1x1(x, conv[1].weight, conv[1].bias)
+                return tail(x, conv[1]) if tail is not None else ops.unet_conv1x1(x, conv[1].weight, conv[1].bias)
         return ops.unet_apply(x)
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
@@ -201,7 +202,22 @@ class NormUnet(torch.nn.Module):
     def unpad(x: torch.Tensor, h_pad: List[int], w_pad: List[int], h_mult: int, w_mult: int) -> torch.Tensor:
         return _ns(x).pad2d(x, -h_pad[0], -h_pad[1], -w_pad[0], -w_pad[1], mode=0)
 
+    def _fused_ok(self, x: torch.Tensor) -> bool:
+        """complex-last input with one or two coils, two norm groups, the inference path of a fusable U-Net: head and tail each in one pass."""
+        u = self.unet
+        return (x.dim() == 5 and x.shape[-1] == 2 and x.shape[1] <= 2 and self.normalize and self.norm_groups == 2 and Unet.fused
+                and not u.training and not diff.active(x, *u.parameters()) and u.in_chans == u.out_chans == 2 * x.shape[1] and u._fusable())
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._fused_ok(x):
+            _, _, h, w, _ = x.shape
+            w_mult = ((w - 1) | self.padding_size) + 1                        # unet_block.py:93-112
+            h_mult = ((h - 1) | self.padding_size) + 1
+            w_pad = [math.floor((w_mult - w) / 2), math.ceil((w_mult - w) / 2)]
+            h_pad = [math.floor((h_mult - h) / 2), math.ceil((h_mult - h) / 2)]
+            xp, mean, std = ops.unet_cnorm_pad(x, h_pad, w_pad)
+            return self.unet._forward_fused(xp, tail=lambda lazy, conv: ops.unet_conv1x1_cunnorm(lazy, conv.weight, conv.bias, mean, std,
+                                                                                                 h_pad[0], w_pad[0], h, w))
         iscomplex = False
         if x.shape[-1] == 2:
             x = self.complex_to_chan_dim(x)

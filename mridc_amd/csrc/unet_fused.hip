@@ -524,3 +524,161 @@ extern "C" int mrx_unet_conv1x1(const float* x, const float* nrm, const float* w
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
+
+// ---- NormUnet head and tail on complex-last tensors (unet_block.py:46-136 with norm_groups = 2) -----------------------------------------
+// forward(): complex_to_chan_dim (a permute copy), norm (mean / unbiased std per (batch, real | imaginary) group: three passes + apply),
+// pad (a copy) before the U-Net; unpad, unnorm, chan_complex_to_last_dim (two copies + apply) after it.  Here: two statistics passes over
+// the complex-last input (both components at once), ONE pass that normalises, permutes and pads; and the closing 1x1 convolution writes the
+// cropped, un-normalised, complex-last result itself.
+#define UC_NSPLIT_MAX 128
+static int uc_nsplit(long long n) {
+    long long s = (n + 2047) / 2048;
+    return (int)(s < 1 ? 1 : (s > UC_NSPLIT_MAX ? UC_NSPLIT_MAX : s));
+}
+// fixed-order sum of `count` (<= 128) float2 partials by one wave; every lane returns the total
+__device__ __forceinline__ float2 uc_combine2(const float2* p, int count, int lane) {
+    float2 a = lane < count ? p[lane] : make_float2(0.f, 0.f);
+    if (lane + 64 < count) {
+        const float2 b = p[lane + 64];
+        a.x += b.x, a.y += b.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) a.x += __shfl_xor(a.x, off, 64), a.y += __shfl_xor(a.y, off, 64);
+    return a;
+}
+// PASS 0: partial sums; PASS 1: partial sums of squared deviations from the mean (recombined from the partial sums)
+template <int PASS>
+__global__ __launch_bounds__(UC_NT) void k_ucnorm_part(const float2* __restrict__ x, const float2* __restrict__ psum, float2* __restrict__ part,
+                                                       long long n, int nsplit) {
+    __shared__ float2 red[UC_NT / 64];
+    __shared__ float2 s_mean;
+    const int b = blockIdx.y, sp = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float2 mean = make_float2(0.f, 0.f);
+    if (PASS == 1) {
+        if (wv == 0) {
+            const float2 t = uc_combine2(psum + (long long)b * nsplit, nsplit, lane);
+            if (lane == 0) s_mean = make_float2(t.x / (float)n, t.y / (float)n);
+        }
+        __syncthreads();
+        mean = s_mean;
+    }
+    const long long per = (n + nsplit - 1) / nsplit, i0 = sp * per, i1 = i0 + per < n ? i0 + per : n;
+    const float2* xb = x + (long long)b * n;
+    float2 acc = make_float2(0.f, 0.f);
+    for (long long i = i0 + threadIdx.x; i < i1; i += UC_NT) {
+        const float2 v = xb[i];
+        if (PASS == 0)
+            acc.x += v.x, acc.y += v.y;
+        else
+            acc.x += (v.x - mean.x) * (v.x - mean.x), acc.y += (v.y - mean.y) * (v.y - mean.y);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc.x += __shfl_xor(acc.x, off, 64), acc.y += __shfl_xor(acc.y, off, 64);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        part[(long long)b * nsplit + sp] = make_float2((red[0].x + red[1].x) + (red[2].x + red[3].x), (red[0].y + red[1].y) + (red[2].y + red[3].y));
+}
+// out[b][comp * c + coil][y + top][x + left] = (x[b][coil][y][x][comp] - mean[b][comp]) / std[b][comp], zero in the padding; mean / std [B,2]
+__global__ __launch_bounds__(UC_NT) void k_ucnorm_apply(const float2* __restrict__ x, const float2* __restrict__ psum, const float2* __restrict__ psq,
+                                                        float* __restrict__ out, float* __restrict__ mean_o, float* __restrict__ std_o, int c, int H,
+                                                        int W, int top, int left, int OH, int OW, int nsplit) {
+    __shared__ float2 s_ms[2];
+    const int b = blockIdx.z, coil = blockIdx.y, lane = threadIdx.x & 63;
+    const long long n = (long long)c * H * W;
+    if (threadIdx.x < 64) {
+        const float2 s = uc_combine2(psum + (long long)b * nsplit, nsplit, lane), q = uc_combine2(psq + (long long)b * nsplit, nsplit, lane);
+        if (lane == 0) {
+            s_ms[0] = make_float2(s.x / (float)n, s.y / (float)n);
+            s_ms[1] = make_float2(sqrtf(q.x / (float)(n - 1)), sqrtf(q.y / (float)(n - 1)));     // unbiased (unet_block.py:79)
+            if (blockIdx.x == 0 && coil == 0) {
+                mean_o[2 * b] = s_ms[0].x, mean_o[2 * b + 1] = s_ms[0].y;
+                std_o[2 * b] = s_ms[1].x, std_o[2 * b + 1] = s_ms[1].y;
+            }
+        }
+    }
+    __syncthreads();
+    const float2 m = s_ms[0], sd = s_ms[1];
+    const float2* xb = x + ((long long)b * c + coil) * H * W;
+    float* o_re = out + ((long long)b * 2 * c + coil) * OH * OW;
+    float* o_im = out + ((long long)b * 2 * c + c + coil) * OH * OW;
+    for (long long o = (long long)blockIdx.x * UC_NT + threadIdx.x; o < (long long)OH * OW; o += (long long)gridDim.x * UC_NT) {
+        const int oy = (int)(o / OW), ox = (int)(o - (long long)oy * OW);
+        const int iy = oy - top, ix = ox - left;
+        float2 v = make_float2(0.f, 0.f);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const float2 t = xb[(long long)iy * W + ix];
+            v = make_float2((t.x - m.x) / sd.x, (t.y - m.y) / sd.y);
+        }
+        o_re[o] = v.x;
+        o_im[o] = v.y;
+    }
+}
+extern "C" int64_t mrx_unet_cnorm_work_floats(int B) { return B < 0 ? -1 : (int64_t)B * UC_NSPLIT_MAX * 4; }
+// x [B,c,H,W,2] -> out [B,2c,H+top+bottom,W+left+right] (channel = component * c + coil: complex_to_chan_dim), normalised per (batch, component)
+// with the unbiased std, zero padded; mean, std [B,2] (norm_groups = 2).  work: mrx_unet_cnorm_work_floats(B) floats, 8-byte aligned.
+extern "C" int mrx_unet_cnorm_pad(const float* x, float* out, float* mean, float* std_, float* work, int B, int c, int H, int W, int top,
+                                  int bottom, int left, int right, void* stream) {
+    MRX_REQUIRE(x && out && mean && std_ && work && B >= 0 && c >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_unet_cnorm_pad: bad argument");
+    MRX_REQUIRE(top >= 0 && bottom >= 0 && left >= 0 && right >= 0 && B <= 65535 && c <= 65535 && (((uintptr_t)x | (uintptr_t)work) & 7) == 0,
+                MRX_EUNSUP, "mrx_unet_cnorm_pad: unsupported shape / alignment");
+    if (B == 0) return MRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)c * H * W;
+    const int ns = uc_nsplit(n), OH = H + top + bottom, OW = W + left + right;
+    float2* psum = reinterpret_cast<float2*>(work);
+    float2* psq = psum + (size_t)B * UC_NSPLIT_MAX;
+    const float2* x2 = reinterpret_cast<const float2*>(x);
+    hipLaunchKernelGGL(k_ucnorm_part<0>, dim3(ns, B), dim3(UC_NT), 0, st, x2, (const float2*)nullptr, psum, n, ns);
+    hipLaunchKernelGGL(k_ucnorm_part<1>, dim3(ns, B), dim3(UC_NT), 0, st, x2, (const float2*)psum, psq, n, ns);
+    const int gx = (int)(((long long)OH * OW + 4 * UC_NT - 1) / (4 * UC_NT));
+    hipLaunchKernelGGL(k_ucnorm_apply, dim3(gx > 0 ? gx : 1, c, B), dim3(UC_NT), 0, st, x2, (const float2*)psum, (const float2*)psq, out, mean, std_, c, H,
+                       W, top, left, OH, OW, ns);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// the closing 1x1 convolution (+ bias) of a (raw, norm) tensor [B,Cin,OH,OW] into 2c channels, written as the cropped, un-normalised complex-last
+// result: out[b][coil][y][x][comp] = conv[b][comp * c + coil][y + top][x + left] * std[b][comp] + mean[b][comp]   (unet_block.py:186-189, 91, 56-61)
+__global__ __launch_bounds__(UC_NT) void k_uconv1x1_c(const float* __restrict__ x, const float* __restrict__ nrm, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, const float* __restrict__ mean, const float* __restrict__ std_,
+                                                      float2* __restrict__ out, int Cin, int c, int OH, int OW, int top, int left, int H, int W,
+                                                      float slope) {
+    extern __shared__ float sm_u1c[];          // [Cin] (mean, 1/std), then [2c][Cin] weights
+    float* wsm = sm_u1c + 2 * Cin;
+    const int b = blockIdx.y, Cout = 2 * c;
+    for (int i = threadIdx.x; i < 2 * Cin; i += UC_NT) sm_u1c[i] = nrm ? nrm[(long long)b * Cin * 2 + i] : ((i & 1) ? 1.f : 0.f);
+    for (int i = threadIdx.x; i < Cout * Cin; i += UC_NT) wsm[i] = w[i];
+    __syncthreads();
+    const bool lazy = nrm != nullptr;
+    const float m_re = mean[2 * b], m_im = mean[2 * b + 1], s_re = std_[2 * b], s_im = std_[2 * b + 1];
+    const long long HWo = (long long)OH * OW;
+    for (long long o = (long long)blockIdx.x * UC_NT + threadIdx.x; o < (long long)H * W; o += (long long)gridDim.x * UC_NT) {
+        const int y = (int)(o / W), xx = (int)(o - (long long)y * W);
+        float acc[4];
+#pragma unroll
+        for (int co = 0; co < 4; ++co) acc[co] = (bias && co < Cout) ? bias[co] : 0.f;
+        const float* xp = x + (long long)b * Cin * HWo + (long long)(y + top) * OW + xx + left;
+        for (int ci = 0; ci < Cin; ++ci) {
+            float v = xp[(long long)ci * HWo];
+            if (lazy) v = uc_leaky((v - sm_u1c[2 * ci]) * sm_u1c[2 * ci + 1], slope);
+#pragma unroll
+            for (int co = 0; co < 4; ++co)
+                if (co < Cout) acc[co] += v * wsm[co * Cin + ci];
+        }
+        for (int coil = 0; coil < c; ++coil)
+            out[((long long)b * c + coil) * H * W + o] = make_float2(acc[coil] * s_re + m_re, acc[c + coil] * s_im + m_im);
+    }
+}
+extern "C" int mrx_unet_conv1x1_cunnorm(const float* x, const float* nrm, const float* w, const float* bias, const float* mean, const float* std_,
+                                        float* out, int B, int Cin, int c, int OH, int OW, int top, int left, int H, int W, float slope,
+                                        void* stream) {
+    MRX_REQUIRE(x && w && mean && std_ && out && B >= 0 && Cin >= 1 && c >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_unet_conv1x1_cunnorm: bad argument");
+    MRX_REQUIRE(top >= 0 && left >= 0 && top + H <= OH && left + W <= OW, MRX_EINVAL, "mrx_unet_conv1x1_cunnorm: crop outside the input");
+    MRX_REQUIRE(c <= 2 && B <= 65535 && (size_t)Cin * (2 + 2 * c) * 4 <= 48 * 1024 && (((uintptr_t)out) & 7) == 0, MRX_EUNSUP,
+                "mrx_unet_conv1x1_cunnorm: c=%d Cin=%d", c, Cin);
+    if (B == 0) return MRX_OK;
+    const int gx = (int)(((long long)H * W + 2 * UC_NT - 1) / (2 * UC_NT));
+    hipLaunchKernelGGL(k_uconv1x1_c, dim3(gx > 0 ? gx : 1, B), dim3(UC_NT), sizeof(float) * (size_t)Cin * (2 + 2 * c), (hipStream_t)stream, x, nrm, w, bias,
+                       mean, std_, reinterpret_cast<float2*>(out), Cin, c, OH, OW, top, left, H, W, slope);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

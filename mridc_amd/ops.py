@@ -1263,6 +1263,40 @@ def unet_conv1x1(src, weight, bias, slope=0.2):
     return out
 
 
+def unet_cnorm_pad(x, h_pad, w_pad):
+    """pad(norm(complex_to_chan_dim(x))) of NormUnet.forward (unet_block.py:46-112, norm_groups = 2) for x [B,c,H,W,2]: two statistics passes
+    and one normalise + permute + zero-pad pass (mrx_unet_cnorm_pad).  Returns (out [B,2c,H',W'], mean [B,2,1], std [B,2,1])."""
+    x = _lib.f32c(x)
+    B, c, H, W, two = [int(v) for v in x.shape]
+    if two != 2:
+        raise AssertionError
+    L = _lib.lib()
+    out = torch.empty(B, 2 * c, H + h_pad[0] + h_pad[1], W + w_pad[0] + w_pad[1], dtype=torch.float32, device=x.device)
+    mean = torch.empty(B, 2, 1, dtype=torch.float32, device=x.device)
+    std = torch.empty_like(mean)
+    work = torch.empty(int(L.mrx_unet_cnorm_work_floats(B)), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_unet_cnorm_pad(_lib.ptr(x), _lib.ptr(out), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(work), B, c, H, W, int(h_pad[0]),
+                                    int(h_pad[1]), int(w_pad[0]), int(w_pad[1]), _lib.stream_ptr()), "mrx_unet_cnorm_pad")
+    return out, mean, std
+
+
+def unet_conv1x1_cunnorm(src, weight, bias, mean, std, top, left, H, W, slope=0.2):
+    """chan_complex_to_last_dim(unnorm(unpad(conv1x1(src)))) (unet_block.py:186-189, 114-136) -> [B,c,H,W,2] in one launch
+    (mrx_unet_conv1x1_cunnorm); src plain or lazy [B,Cin,H',W'], weight [2c,Cin,1,1] with c <= 2."""
+    x, nrm = _lazy(src)
+    weight = _lib.f32c(weight.detach())
+    B, Cin, OH, OW = _nchw(x)
+    Cout = int(weight.shape[0])
+    if tuple(weight.shape[1:]) != (Cin, 1, 1) or Cout % 2:
+        raise RuntimeError(f"unet_conv1x1_cunnorm: weight {tuple(weight.shape)} vs {Cin} input channels")
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    out = torch.empty(B, Cout // 2, H, W, 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_unet_conv1x1_cunnorm(_lib.ptr(x), _lib.ptr(nrm), _lib.ptr(weight), _lib.ptr(b), _lib.ptr(_lib.f32c(mean)),
+                                                   _lib.ptr(_lib.f32c(std)), _lib.ptr(out), B, Cin, Cout // 2, OH, OW, int(top), int(left), int(H),
+                                                   int(W), float(slope), _lib.stream_ptr()), "mrx_unet_conv1x1_cunnorm")
+    return out
+
+
 # ---- quantitative MRI (A19) -----------------------------------------------------------------------------------
 def _tes_host(TEs):
     import ctypes

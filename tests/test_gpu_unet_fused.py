@@ -99,3 +99,34 @@ def test_norm_unet_fused_matches_conv_plus_apply(cfg, dev):
     finally:
         Unet.fused = keep
     assert rel_l2(got, want) <= 2e-5, rel_l2(got, want)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 640, 372, 11), (2, 2, 45, 37, 7), (1, 1, 33, 26, 15), (3, 1, 16, 16, 3)])
+def test_norm_unet_head_and_tail_in_one_pass(shape, dev):
+    """mrx_unet_cnorm_pad against pad(norm(complex_to_chan_dim(x))) (unet_block.py:46-112: unbiased std per (batch, component)) and
+    mrx_unet_conv1x1_cunnorm against chan_complex_to_last_dim(unnorm(unpad(conv1x1(.)))), both in float64."""
+    import math
+    from mridc_amd import ops
+    B, c, H, W, ps = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(B, c, H, W, 2, generator=g) * 3 + torch.tensor([0.7, -1.1])).to(dev)
+    w_mult, h_mult = ((W - 1) | ps) + 1, ((H - 1) | ps) + 1
+    w_pad = [math.floor((w_mult - W) / 2), math.ceil((w_mult - W) / 2)]
+    h_pad = [math.floor((h_mult - H) / 2), math.ceil((h_mult - H) / 2)]
+    out, mean, std = ops.unet_cnorm_pad(x, h_pad, w_pad)
+    xc = x.double().permute(0, 4, 1, 2, 3).reshape(B, 2 * c, H, W)
+    v = xc.reshape(B, 2, c * H * W)
+    m, sd = v.mean(2).view(B, 2, 1, 1), v.std(2).view(B, 2, 1, 1)
+    ref = ((xc.view(B, 2, c, H * W) - m) / sd).view(B, 2 * c, H, W)
+    ref = Fn.pad(ref, w_pad + h_pad)
+    assert rel_l2(out, ref) <= 2e-6 and rel_l2(mean.view(B, 2), m.view(B, 2)) <= 2e-6 and rel_l2(std.view(B, 2), sd.view(B, 2)) <= 2e-6
+    Cin = 5
+    raw = torch.randn(B, Cin, h_mult, w_mult, generator=g).to(dev)
+    nrm = torch.stack([torch.randn(B, Cin, generator=g) * 0.3, torch.rand(B, Cin, generator=g) + 0.5], -1).to(dev)
+    w1, b1 = (torch.randn(2 * c, Cin, 1, 1, generator=g) / Cin ** 0.5).to(dev), (torch.randn(2 * c, generator=g) * 0.1).to(dev)
+    for lazy in (True, False):
+        xin = _lazy_ref(raw.double(), nrm) if lazy else raw.double()
+        y = Fn.conv2d(xin, w1.double(), b1.double())[:, :, h_pad[0]:h_pad[0] + H, w_pad[0]:w_pad[0] + W]
+        y = (y.reshape(B, 2, c * H * W) * sd.view(B, 2, 1) + m.view(B, 2, 1)).view(B, 2, c, H, W).permute(0, 2, 3, 4, 1)
+        got = ops.unet_conv1x1_cunnorm((raw, nrm) if lazy else raw, w1, b1, mean, std, h_pad[0], w_pad[0], H, W)
+        assert rel_l2(got, y) <= 2e-6
