@@ -261,6 +261,11 @@ int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, 
 int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
                            const float* h_prev, float* h_new, float* taps, int B, int H, int W, void* stream);
 int mrx_rim_final_gather(const float* taps, const float* b_final, const float* eta, float* eta_out, int B, int H, int W, void* stream);
+/* The gather half of a 3x3 convolution into Cout <= 4 channels done as a 1x1 channel contraction Cin -> 9 Cout (mrx_conv2d with the weights
+ * re-ordered to [tap * Cout + co][c]) + nine shifted adds: out[b][co] = bias[co] + sum_tap shift_tap(taps[b][tap * Cout + co]); replicate padding =
+ * clamped coordinates, zero padding = taps outside the image dropped (conv_layers.py:121-123 for thin final layers, e.g. qrim_block.py:226-236). */
+int mrx_taps_gather(const float* taps /* [B][Ct >= 9 Cout][H][W] */, const float* bias, float* out, int B, int Ct, int Cout, int H, int W,
+                    int pad_mode, void* stream);
 int64_t mrx_rim_layer_wino_pack_floats(int Cin, int F);
 int mrx_rim_layer_wino_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, int F, void* stream);
 int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, const float* b_conv, const float* b_ih,

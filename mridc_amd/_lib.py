@@ -132,6 +132,7 @@ _SIGNATURES = {
     "mrx_rim_layer2_sb_pack": ([_p, _p, _p, _p, _p], _i),
     "mrx_rim_layer2_sb_taps": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_final_gather": ([_p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_taps_gather": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_rim_layer2_sb": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_layer_wino_pack_floats": ([_i, _i], _i64),
     "mrx_rim_layer_wino_pack": ([_p, _p, _p, _i, _i, _p], _i),

@@ -560,6 +560,40 @@ def conv3x3_wino(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, s
     return out
 
 
+TAPS_CONV = os.environ.get("MRIDC_AMD_TAPS_CONV", "1") != "0"
+_TAPS_W = {}
+
+
+def conv3x3_taps_supported(Cin, Cout):
+    """The contraction runs on the square 1x1 kernel (C = 64 or 128, mrx_conv1x1_sq) with the 9 Cout tap rows padded to C."""
+    return 9 * int(Cout) <= int(Cin) and int(Cout) <= 4 and conv1x1_sq_supported(int(Cin), int(Cin))
+
+
+def conv3x3_taps(x, weight, bias, pad_mode=PAD_ZERO, out=None):
+    """3x3 convolution (dilation 1) of C = 64 / 128 channels into Cout <= 4 as a per-pixel channel contraction C -> 9 Cout on the matrix cores
+    (the square 1x1 kernel, tap rows [tap * Cout + co] padded to C) + a nine-tap gather (mrx_taps_gather): the direct form costs 18 Cout
+    vector FMAs per (pixel, input channel) -- qRIM's 128 -> 4 final layer at 256 x 256: 75 us."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    Cout = int(weight.shape[0])
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape))
+    w1 = _TAPS_W.get(key)
+    if w1 is None:
+        if len(_TAPS_W) >= 64:
+            _TAPS_W.clear()
+        wp = torch.zeros(Cin, Cin, 1, 1, dtype=torch.float32, device=weight.device)
+        wp[:9 * Cout] = _lib.f32c(weight.detach()).reshape(Cout, Cin, 9).permute(2, 0, 1).reshape(9 * Cout, Cin, 1, 1)
+        w1 = (wp, weight)                                   # (the entry keeps the source tensor alive: its data_ptr cannot be recycled)
+        _TAPS_W[key] = w1
+    taps = conv1x1_64(x, w1[0])
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    if out is None:
+        out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_taps_gather(_lib.ptr(taps), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W, int(pad_mode), _lib.stream_ptr()),
+               "mrx_taps_gather")
+    return out
+
+
 def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
     """'same' conv, stride 1, square odd kernel (mrx_conv2d; 3x3 into 64 channels: mrx_conv3x3_wino)."""
     x = _lib.f32c(x)
@@ -576,6 +610,8 @@ def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0
     if (kh == 1 and conv1x1_sq_supported(Cin, Cout) and act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
             and (out is None or out.data_ptr() != x.data_ptr())):
         return conv1x1_64(x, weight, bias, act, slope, out=out)          # per-pixel 64x64 GEMM, HBM-bound
+    if TAPS_CONV and kh == 3 and int(dilation) == 1 and act == ACT_NONE and conv3x3_taps_supported(Cin, Cout):
+        return conv3x3_taps(x, weight, bias, pad_mode, out)
     weight = _lib.f32c(weight.detach())
     b = _lib.f32c(bias.detach()) if bias is not None else None
     if out is None:

@@ -197,6 +197,33 @@ def test_second_rim_layer_with_final_conv_in_its_tail(shape, dev):
         assert rel_l2(eta_new - eta, sep - eta) <= 1e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 128, 4, 256, 256), (1, 64, 2, 640, 372), (2, 64, 3, 37, 29), (1, 128, 1, 5, 3), (3, 64, 4, 1, 1)])
+def test_thin_3x3_conv_as_contraction_plus_gather(shape, dev):
+    """ops.conv2d for 3x3 convolutions of 64 / 128 channels into <= 4 (qRIM's final layer, qrim_block.py:226-236 via conv_layers.py:121-123):
+    a 1x1 channel contraction into 9 Cout tap planes on the matrix cores + mrx_taps_gather, against float64 and the direct kernel, zero and
+    replicate padding, images smaller than the 3x3 window."""
+    import torch.nn.functional as Fn
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    x, w, b = r(B, Cin, H, W), r(Cout, Cin, 3, 3) / (9 * Cin) ** 0.5, r(Cout) * 0.1
+    assert ops.conv3x3_taps_supported(Cin, Cout)
+    keep = ops.TAPS_CONV
+    try:
+        for pm, mode in ((ops.PAD_ZERO, "constant"), (ops.PAD_REPLICATE, "replicate")):
+            for bias in (b, None):
+                ref = Fn.conv2d(Fn.pad(x.double(), (1, 1, 1, 1), mode=mode), w.double(), None if bias is None else bias.double())
+                ops.TAPS_CONV = True
+                got = ops.conv2d(x, w, bias, 1, pm)
+                ops.TAPS_CONV = False
+                direct = ops.conv2d(x, w, bias, 1, pm)
+                assert rel_l2(got, ref) <= 1e-6 and rel_l2(got, direct) <= 2e-6, (shape, mode, rel_l2(got, ref), rel_l2(got, direct))
+    finally:
+        ops.TAPS_CONV = keep
+
+
 @pytest.mark.parametrize("shape", [(1, 4, 640, 372), (2, 4, 37, 75), (1, 2, 19, 33), (3, 1, 16, 32), (1, 4, 5, 3), (1, 3, 130, 320)])
 def test_first_rim_layer_split_bf16_has_fp32_accuracy(shape, dev, monkeypatch):
     """The first RIM layer on the bf16 matrix pipe (k_rim_layer1_sb: every fp32 operand as the exact sum of three bf16 terms, six term
