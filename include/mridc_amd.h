@@ -249,7 +249,8 @@ int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, const float
  * operand is the exact sum of three bf16 terms, six term products per multiply (error O(2^-24), as an fp32 FMA chain).  Same contract as
  * mrx_rim_layer_indrnn_wino (rim_block.py:233-238); packed = mrx_rim_layer2_sb_pack(w_conv [64,64,3,3], w_ih [64,64,1,1]). */
 int64_t mrx_rim_layer2_sb_pack_floats(void);
-int mrx_rim_layer2_sb_pack(const float* w_conv, const float* w_ih, const float* w_final /* [2,64,3,3] or NULL */, float* packed, void* stream);
+int mrx_rim_layer2_sb_pack(const float* w_conv, const float* w_ih /* or NULL */, const float* w_final /* [2,64,3,3] or NULL */, float* packed,
+                           void* stream);
 int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
                       float* h_new, int B, int H, int W, void* stream);
 /* The second layer AND the final convolution of a RIM step (rim_block.py:233-246; conv_layers.py:121-123 with kernel 3, dilation 1, no
@@ -258,6 +259,12 @@ int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, 
  * packed must hold w_final); mrx_rim_final_gather adds the nine shifted taps (replicate padding = clamped coordinates), the bias and eta:
  * eta_out [B,H,W,2] = eta + permute(conv(h_new) + b_final).  eta may be NULL (nothing added).
  * In mrx_rim_layer2_sb and mrx_rim_layer2_sb_taps h_new may be h_prev itself (every element is read by the lane that writes it). */
+/* The convolution stage of that kernel on its own: y = act(conv3x3(x, dilation 1 | 2, zero | replicate padding) + bias), 64 -> 64 channels, on the
+ * bf16 matrix pipe with fp32 results (conv_layers.py:121-123; the 64-channel layers of CascadeNet / VSNet / the Recurrent VarNet).
+ * packed = mrx_rim_layer2_sb_pack(w, NULL, NULL). */
+int mrx_conv3x3_sb_supported(int Cin, int Cout, int k, int dil);
+int mrx_conv3x3_sb(const float* x, const float* packed, const float* bias, float* y, int B, int H, int W, int dil, int pad_mode, int act,
+                   float slope, void* stream);
 int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
                            const float* h_prev, float* h_new, float* taps, int B, int H, int W, void* stream);
 int mrx_rim_final_gather(const float* taps, const float* b_final, const float* eta, float* eta_out, int B, int H, int W, void* stream);

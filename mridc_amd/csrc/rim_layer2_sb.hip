@@ -27,10 +27,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define S2_TH 16
 #define S2_TW 32
 #define S2_F 64
-#define S2_PAD 2
-#define S2_PH (S2_TH + 2 * S2_PAD)          // 20
-#define S2_PW (S2_TW + 2 * S2_PAD)          // 36
-#define S2_NPIX (S2_PH * S2_PW)             // 720
+#define S2_NPIX_MAX ((S2_TH + 4) * (S2_TW + 4))   // halo'd tile of the dilation-2 layer: 20 x 36 = 720 pixels (dilation 1: 18 x 34)
 #define S2_NCH 8                            // channel chunks
 #define S2_KS 5                             // MFMA steps per chunk (10 tap slots, 9 used)
 #define S2_WFULL (4 * 3 * 2 * 64)           // 16-byte A operands of the four full steps of a chunk
@@ -49,6 +46,8 @@ struct L2sbArgs {
     float* hnew;           // [B,64,H,W]
     float* P;              // not null: also P[b][tap * 2 + co][y][x] = sum_c w_final[co][c][tap] * h_new[c][y][x]  (mrx_rim_final_gather adds the taps up)
     int B, H, W, tiles_x, ntiles;
+    int act;               // TAIL = false: MRX_ACT_* applied to conv + bias
+    float slope;
     unsigned long long* trace;   // debug (env MRX_L2SB_TRACE): cycle stamps [workgroup][wave][tile 0..1][4]
 };
 
@@ -101,7 +100,7 @@ __global__ void k_l2sb_pack(const float* __restrict__ w, const float* __restrict
         t = r % 3;
         const int s = r / 3, o = 32 * blk + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = w_ih[o * S2_F + s2_chan(8 * s + j, lane >> 5)];
+        for (int j = 0; j < 8; ++j) v[j] = w_ih ? w_ih[o * S2_F + s2_chan(8 * s + j, lane >> 5)] : 0.f;
     } else {
         int r = i - S2_NCH * S2_WCH - S2_WIH;
         const int lane = r & 63;
@@ -136,14 +135,18 @@ __global__ void k_l2sb_pack(const float* __restrict__ w, const float* __restrict
     ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][0], B1, ACC[1], 0, 0, 0);
 
 // LDS (bytes): ih weights 24576 | final-conv weights 12288 | tables + a zero operand 1024 | 2 x conv weights 27648 | 2 x planes 34560 -> 158.5 KB
+// DIL: dilation (= halo) of the 3x3 kernel; TAIL: the IndRNN 1x1 stage (and, with a.P, the final convolution's tap products) -- without it the
+// kernel is a plain 3x3 convolution 64 -> 64 + bias + activation (mrx_conv3x3_sb); ZP: zero instead of replicate padding
 #define S2_OFF_WP (S2_WIH * 16)
 #define S2_OFF_TAB (S2_OFF_WP + S2_WP * 16)
 #define S2_OFF_ZERO (S2_OFF_TAB + 1008)
 #define S2_OFF_W (S2_OFF_TAB + 1024)
 #define S2_OFF_X (S2_OFF_W + 2 * S2_WCH * 16)
-#define S2_LDS (S2_OFF_X + 2 * 3 * S2_NPIX * 16)
+#define S2_LDS (S2_OFF_X + 2 * 3 * S2_NPIX_MAX * 16)
 
+template <int DIL, bool TAIL, bool ZP>
 __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
+    constexpr int S2_PAD = DIL, S2_PH = S2_TH + 2 * DIL, S2_PW = S2_TW + 2 * DIL, S2_NPIX = S2_PH * S2_PW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
     u32x4* Wih = reinterpret_cast<u32x4*>(smem_s2);
     float* tabl = reinterpret_cast<float*>(smem_s2 + S2_OFF_TAB);      // hh, b_conv, b_ih in register order [R][half]
@@ -154,11 +157,12 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     const int total = a.ntiles * a.B;
 
     // once per workgroup: 1x1 weights and tables
-    for (int i = tid; i < S2_WIH + S2_WP; i += S2_NT) Wih[i] = a.packed[S2_NCH * S2_WCH + i];      // (the final-conv operands follow the 1x1 ones)
+    if (TAIL)
+        for (int i = tid; i < S2_WIH + S2_WP; i += S2_NT) Wih[i] = a.packed[S2_NCH * S2_WCH + i];  // (the final-conv operands follow the 1x1 ones)
     if (tid == 0) *reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_ZERO) = u32x4{0u, 0u, 0u, 0u};
     if (tid < 64) {
         const int tc = s2_chan(tid >> 1, tid & 1);
-        tabl[tid] = a.hh[tc];
+        tabl[tid] = a.hh ? a.hh[tc] : 0.f;
         tabl[64 + tid] = a.b_conv ? a.b_conv[tc] : 0.f;
         tabl[128 + tid] = a.b_ih ? a.b_ih[tc] : 0.f;
     }
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     int st_t = blockIdx.x, st_q = 0;                 // the next chunk to request: tile index, chunk
     const float* st_xb = a.x;
     long long goff[XV];
+    unsigned zmask = 0, zpend = 0;                   // ZP: this thread's pixels outside the image (of the next request / of the pending chunk)
     auto st_coords = [&]() {
         if (st_t >= total) return;
         const int tt = (int)mrx_xcd_band(st_t, total);
@@ -185,6 +190,10 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             p = p < S2_NPIX ? p : S2_NPIX - 1;
             const int ty = p / S2_PW, tx = p - ty * S2_PW;
             int gy = h0 + ty - S2_PAD, gx = w0 + tx - S2_PAD;            // replicate border = clamp (conv_layers.py:72-76)
+            if (ZP) {
+                const unsigned out = (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) ? 1u : 0u;
+                zmask = v == 0 ? out : (zmask | (out << v));
+            }
             gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
             gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
             goff[v] = (long long)gy * a.W + gx;
@@ -196,6 +205,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     auto request_next = [&]() {                      // fp32 values of this thread's pixels and its weight operands of the next chunk
         pending = st_t < total;
         if (!pending) return;
+        zpend = zmask;
 #pragma unroll
         for (int v = 0; v < XV; ++v)
 #pragma unroll
@@ -219,6 +229,10 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             unsigned p1[4], p2[4], p3[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) s2_split2(xr[v][2 * k], xr[v][2 * k + 1], p1[k], p2[k], p3[k]);
+            if (ZP && ((zpend >> v) & 1u)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p1[k] = p2[k] = p3[k] = 0u;
+            }
             if (p < S2_NPIX) {
                 u32x4* dst = Xp + buf * (3 * S2_NPIX) + p;
                 dst[0] = u32x4{p1[0], p1[1], p1[2], p1[3]};
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
             for (int R = 0; R < 32; ++R) hp[rw][R] = hb[(long long)s2_chan(R, 0) * plane];
         };
-        auto toff = [](int tp) { return tp < 9 ? (tp / 3) * 2 * S2_PW + (tp % 3) * 2 : 0; };      // dilation 2; the zero-weight slot reads pixel 0
+        auto toff = [](int tp) { return tp < 9 ? (tp / 3) * DIL * S2_PW + (tp % 3) * DIL : 0; };  // the zero-weight slot reads pixel 0
         for (int q = 0; q < S2_NCH; ++q) {
             const u32x4* xw = Xp + (q & 1) * (3 * S2_NPIX) + (2 * wave) * S2_PW + l31;
             const u32x4* wl = Wc + (q & 1) * S2_WCH + lane;
@@ -299,12 +313,13 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                     commit_next((q + 1) & 1);
                     request_next();
                 }
-                if (s == 2 && q == S2_NCH - 1) load_hp(0);
+                if (TAIL && s == 2 && q == S2_NCH - 1) load_hp(0);
             }
             __syncthreads();
         }
 
         S2_STAMP(1)
+        if constexpr (TAIL) {
         // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev), one of the wave's two rows at a time ------------------
         // (h_prev of row 0 was requested inside the last chunk; row 1's request goes out now and hides under row 0's tail)
         load_hp(1);
@@ -386,6 +401,23 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             }
             if (rw == 0) { S2_STAMP(2) } else { S2_STAMP(3) }
         }
+        } else {
+            // ---- plain convolution: act(conv + b), the wave's two rows with lane = pixel (128-byte rows per wave instruction) ------------------
+#pragma unroll
+            for (int rw = 0; rw < 2; ++rw) {
+                const int oy = h0 + 2 * wave + rw, ox = w0 + l31;
+                if (oy < a.H && ox < a.W) {
+                    float* ob = a.hnew + (long long)b * S2_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
+#pragma unroll
+                    for (int R = 0; R < 32; ++R) {
+                        float v = acc[rw][R >> 4][R & 15];
+                        if (a.act == MRX_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        else if (a.act == MRX_ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
+                        ob[(long long)s2_chan(R, 0) * plane] = v;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -394,46 +426,44 @@ extern "C" int64_t mrx_rim_layer2_sb_pack_floats(void) { return (int64_t)S2_PACK
 // w_conv [64,64,3,3] (dilation 2, replicate padding), w_ih [64,64,1,1] -> the split-bf16 operand pack of mrx_rim_layer2_sb;
 // w_final [2,64,3,3] (or null): the operands of the final convolution's channel contraction (mrx_rim_layer2_sb_final)
 extern "C" int mrx_rim_layer2_sb_pack(const float* w_conv, const float* w_ih, const float* w_final, float* packed, void* stream) {
-    MRX_REQUIRE(w_conv && w_ih && packed, MRX_EINVAL, "mrx_rim_layer2_sb_pack: null pointer");
+    MRX_REQUIRE(w_conv && packed, MRX_EINVAL, "mrx_rim_layer2_sb_pack: null pointer");
     hipLaunchKernelGGL(k_l2sb_pack, dim3((S2_PACK_U4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, w_final, reinterpret_cast<u32x4*>(packed));
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 
 // h_new = ReLU(W_ih ReLU(conv3x3_d2(replicate_pad(x)) + b_conv) + b_ih + hh * h_prev), F = 64 (rim_block.py:233-238 for the second layer)
-static int l2sb_launch(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
-                       float* h_new, float* P, int B, int H, int W, void* stream) {
-    MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer2_sb: null pointer");
-    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer2_sb: bad dims");
-    if (B == 0) return MRX_OK;
-    static bool attr_done = false;   // once: keeps launches legal under hipGraph capture
+static int l2sb_ncu() {
     static int ncu = 0;
-    if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
+    if (!ncu) {
         int dev = 0;
         hipDeviceProp_t prop;
-        MRX_HIP(hipGetDevice(&dev));
-        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return ncu;
+}
+template <int DIL, bool TAIL, bool ZP>
+static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
+    static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
         attr_done = true;
     }
-    L2sbArgs a;
-    a.x = x, a.packed = reinterpret_cast<const u32x4*>(packed), a.b_conv = b_conv, a.b_ih = b_ih, a.hh = hh, a.hprev = h_prev, a.hnew = h_new;
-    a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
-    const long long total = (long long)a.ntiles * B;
+    const int ncu = l2sb_ncu();
+    const long long total = (long long)a.ntiles * a.B;
     const int grid = (int)(total < ncu ? total : ncu);
     a.trace = nullptr;
-    a.P = P;
     static unsigned long long* d_trace = nullptr;
-    if (getenv("MRX_L2SB_TRACE")) {
+    if (TAIL && getenv("MRX_L2SB_TRACE")) {
         if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 512 * 8 * 8);
-        (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, (hipStream_t)stream);
+        (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, st);
         a.trace = d_trace;
     }
-    hipLaunchKernelGGL(k_rim_layer2_sb, dim3(grid), dim3(S2_NT), S2_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP>), dim3(grid), dim3(S2_NT), S2_LDS, st, a);
     MRX_LAUNCH_CHECK();
     if (a.trace) {
-        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipStreamSynchronize(st);
         std::vector<unsigned long long> h((size_t)grid * 64);
         (void)hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
         double ph[3] = {0, 0, 0}, gap = 0;
@@ -450,6 +480,38 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
                 ph[1] / n, ph[2] / n, ng ? gap / ng : 0.0);
     }
     return MRX_OK;
+}
+static int l2sb_launch(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                       float* h_new, float* P, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer2_sb: null pointer");
+    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer2_sb: bad dims");
+    if (B == 0) return MRX_OK;
+    L2sbArgs a;
+    a.x = x, a.packed = reinterpret_cast<const u32x4*>(packed), a.b_conv = b_conv, a.b_ih = b_ih, a.hh = hh, a.hprev = h_prev, a.hnew = h_new;
+    a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
+    a.P = P, a.act = MRX_ACT_NONE, a.slope = 0.f;
+    return l2sb_launch_t<2, true, false>(a, (hipStream_t)stream);
+}
+
+// y = act(conv3x3(x, dilation 1 | 2, zero | replicate padding) + bias), 64 -> 64 channels, on the bf16 matrix pipe with fp32 results (the
+// convolution stage of mrx_rim_layer2_sb on its own: conv_layers.py:121-123 for the 64-channel layers of CascadeNet / VSNet / the Recurrent
+// VarNet).  packed = mrx_rim_layer2_sb_pack(w, NULL, NULL).
+extern "C" int mrx_conv3x3_sb_supported(int Cin, int Cout, int k, int dil) { return Cin == 64 && Cout == 64 && k == 3 && (dil == 1 || dil == 2); }
+extern "C" int mrx_conv3x3_sb(const float* x, const float* packed, const float* bias, float* y, int B, int H, int W, int dil, int pad_mode, int act,
+                              float slope, void* stream) {
+    MRX_REQUIRE(x && packed && y, MRX_EINVAL, "mrx_conv3x3_sb: null pointer");
+    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (dil == 1 || dil == 2), MRX_EINVAL, "mrx_conv3x3_sb: bad dims");
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv3x3_sb: bad pad mode %d", pad_mode);
+    MRX_REQUIRE(act >= 0 && act <= 2, MRX_EINVAL, "mrx_conv3x3_sb: bad activation %d", act);
+    if (B == 0) return MRX_OK;
+    L2sbArgs a;
+    a.x = x, a.packed = reinterpret_cast<const u32x4*>(packed), a.b_conv = bias, a.b_ih = nullptr, a.hh = nullptr, a.hprev = nullptr, a.hnew = y;
+    a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
+    a.P = nullptr, a.act = act, a.slope = slope;
+    hipStream_t st = (hipStream_t)stream;
+    const bool zp = pad_mode == MRX_PAD_ZERO;
+    if (dil == 1) return zp ? l2sb_launch_t<1, false, true>(a, st) : l2sb_launch_t<1, false, false>(a, st);
+    return zp ? l2sb_launch_t<2, false, true>(a, st) : l2sb_launch_t<2, false, false>(a, st);
 }
 
 extern "C" int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,

@@ -560,6 +560,38 @@ def conv3x3_wino(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, s
     return out
 
 
+SB_CONV = os.environ.get("MRIDC_AMD_CONV_SB", "1") != "0"
+_PACKS_SB = {}
+
+
+def conv3x3_sb_supported(Cin, Cout, k, dilation):
+    return bool(_lib.lib().mrx_conv3x3_sb_supported(int(Cin), int(Cout), int(k), int(dilation)))
+
+
+def conv3x3_sb(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
+    """3x3 convolution 64 -> 64 (dilation 1 or 2, zero or replicate padding) + bias + activation as a direct convolution on the bf16 matrix pipe
+    with fp32 results (mrx_conv3x3_sb: every fp32 operand = three bf16 terms, six term products per multiply; the convolution stage of the
+    dominant RIM layer on its own).  The operand pack is cached per (storage, version)."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()))
+    hit = _PACKS_SB.get(key)
+    if hit is None:
+        if len(_PACKS_SB) >= 256:
+            _PACKS_SB.clear()
+        w = _lib.f32c(weight.detach())
+        packed = torch.empty(int(_lib.lib().mrx_rim_layer2_sb_pack_floats()), dtype=torch.float32, device=w.device)
+        _lib.check(_lib.lib().mrx_rim_layer2_sb_pack(_lib.ptr(w), None, None, _lib.ptr(packed), _lib.stream_ptr()), "mrx_rim_layer2_sb_pack")
+        hit = (packed, weight)                              # (keeps the source tensor alive: its data_ptr cannot be recycled)
+        _PACKS_SB[key] = hit
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    if out is None:
+        out = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_conv3x3_sb(_lib.ptr(x), _lib.ptr(hit[0]), _lib.ptr(b), _lib.ptr(out), B, H, W, int(dilation), int(pad_mode),
+                                         int(act), float(slope), _lib.stream_ptr()), "mrx_conv3x3_sb")
+    return out
+
+
 TAPS_CONV = os.environ.get("MRIDC_AMD_TAPS_CONV", "1") != "0"
 _TAPS_W = {}
 
@@ -604,6 +636,9 @@ def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0
         raise RuntimeError(f"input has inconsistent input_size: got {Cin}, expected {Cin_w}")
     if kh != kw:
         raise NotImplementedError("square kernels only")
+    if (SB_CONV and kh == 3 and act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and conv3x3_sb_supported(Cin, Cout, kh, dilation)
+            and (out is None or out.data_ptr() != x.data_ptr())):
+        return conv3x3_sb(x, weight, bias, dilation, pad_mode, act, slope, out)
     if (WINOGRAD_CONV and kh == 3 and Cin >= WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
             and conv3x3_wino_supported(Cin, Cout, kh, dilation) and (out is None or out.data_ptr() != x.data_ptr())):
         return conv3x3_wino(x, weight, bias, dilation, pad_mode, act, slope, out)

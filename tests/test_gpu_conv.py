@@ -197,6 +197,34 @@ def test_second_rim_layer_with_final_conv_in_its_tail(shape, dev):
         assert rel_l2(eta_new - eta, sep - eta) <= 1e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 640, 372), (2, 37, 75), (1, 19, 33), (3, 16, 32), (1, 5, 3), (1, 1, 1), (1, 130, 320)])
+def test_conv3x3_64_to_64_split_bf16(shape, dev):
+    """mrx_conv3x3_sb (the convolution stage of the dominant RIM layer as a general 64 -> 64 convolution: dilation 1 and 2, zero and replicate
+    padding, bias, none / ReLU / LeakyReLU) against float64 and the fp32 Winograd kernel it replaces in ops.conv2d: fp32-level error."""
+    import torch.nn.functional as Fn
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    B, H, W = shape
+    g = torch.Generator().manual_seed(11 + sum(shape))
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    x, w, b = r(B, 64, H, W), r(64, 64, 3, 3) / 24, r(64) * 0.1
+    keep = ops.SB_CONV
+    try:
+        for dil in (1, 2):
+            for pm, mode in ((ops.PAD_ZERO, "constant"), (ops.PAD_REPLICATE, "replicate")):
+                for act, bias in ((ops.ACT_NONE, b), (ops.ACT_RELU, None), (ops.ACT_LEAKY, b)):
+                    ref = Fn.conv2d(Fn.pad(x.double(), (dil,) * 4, mode=mode), w.double(), None if bias is None else bias.double(), dilation=dil)
+                    ref = ref.relu() if act == ops.ACT_RELU else (Fn.leaky_relu(ref, 0.1) if act == ops.ACT_LEAKY else ref)
+                    ops.SB_CONV = True
+                    got = ops.conv2d(x, w, bias, dil, pm, act, 0.1)
+                    ops.SB_CONV = False
+                    old = ops.conv2d(x, w, bias, dil, pm, act, 0.1)
+                    e_sb, e_old = rel_l2(got, ref), rel_l2(old, ref)
+                    assert e_sb <= 6e-7 and e_sb <= 2.5 * e_old + 5e-8, (shape, dil, mode, act, e_sb, e_old)
+    finally:
+        ops.SB_CONV = keep
+
+
 @pytest.mark.parametrize("shape", [(1, 128, 4, 256, 256), (1, 64, 2, 640, 372), (2, 64, 3, 37, 29), (1, 128, 1, 5, 3), (3, 64, 4, 1, 1)])
 def test_thin_3x3_conv_as_contraction_plus_gather(shape, dev):
     """ops.conv2d for 3x3 convolutions of 64 / 128 channels into <= 4 (qRIM's final layer, qrim_block.py:226-236 via conv_layers.py:121-123):
