@@ -175,7 +175,9 @@ class RIMBlock(torch.nn.Module):
         if self._gated(stack):
             c, r = stack.convs, stack.rnn
             conv_pk, cell_pk, hh0, wino = self._packed_gated(idx, c, r)
-            if self.winograd and c.kernel_size == 3 and ops.conv3x3_wino_supported(c.input_size, c.features, 3, c.dilation) \
+            if ops.SB_CONV and ops.conv3x3_sb_supported(c.input_size, c.features, c.kernel_size, c.dilation):
+                g = ops.conv3x3_sb(x, c.conv_layer.weight, c.conv_layer.bias, c.dilation, ops.PAD_REPLICATE, ops.ACT_RELU)
+            elif self.winograd and c.kernel_size == 3 and ops.conv3x3_wino_supported(c.input_size, c.features, 3, c.dilation) \
                     and c.input_size >= ops.WINOGRAD_MIN_CIN:
                 g = ops.conv3x3_wino(x, c.conv_layer.weight, c.conv_layer.bias, c.dilation, ops.PAD_REPLICATE, ops.ACT_RELU)
             elif wino:
