@@ -133,3 +133,31 @@ def test_varnet_state_dict_loads_reference_weights(golden):
     assert unexpected == [] and missing == ["dc_weight"]      # model-level dc_weight (vn.py:91) is not in the block dumps
     u = UNet(meta(z, "unet/cfg"))
     u.load_state_dict(weights(z, "unet/w/"))
+
+
+def test_default_paths_are_the_fused_ones():
+    """Host-side routing (no compute): the headline CIRIM config takes the split-bf16 layer with the final convolution in its tail and in-place
+    states, the reference U-Net shapes take the kernels that normalise on load -- so the `-m gpu` parity tests exercise what ships -- and a
+    configuration outside those shapes falls back (rim_block.py:121, unet_block.py:139-227)."""
+    from mridc_amd import ops, synthetic
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    from mridc_amd.collections.reconstruction.models.unet_base.unet_block import NormUnet, Unet
+    blk = CIRIM(dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=1)).cirim[0]
+    assert RIMBlock.layer2_sb and RIMBlock.fused_final and RIMBlock.inplace_state
+    assert blk._sb_layer(blk.layers[1]) and not blk._sb_layer(blk.layers[0]) and blk._tail_fused()
+    gru = CIRIM(dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=1, recurrent_layer="GRU")).cirim[0]
+    assert not gru._tail_fused()                                   # gated cells keep the stand-alone final convolution
+    assert ops.conv3x3_sb_supported(64, 64, 3, 1) and ops.conv3x3_sb_supported(64, 64, 3, 2)
+    assert not ops.conv3x3_sb_supported(64, 128, 3, 1) and not ops.conv3x3_sb_supported(64, 64, 5, 1)
+    assert ops.conv3x3_taps_supported(128, 4) and ops.conv3x3_taps_supported(64, 2) and not ops.conv3x3_taps_supported(64, 8)
+    assert not ops.conv3x3_taps_supported(56, 2)
+    for chans, pools in ((14, 2), (18, 4), (32, 4)):
+        net = NormUnet(chans, pools).eval()
+        assert Unet.fused and net.unet._fusable()
+        with torch.no_grad():                                      # (with gradients recorded the differentiable forms run instead)
+            assert net._fused_ok(torch.zeros(1, 1, 8, 8, 2)) and not net._fused_ok(torch.zeros(1, 2, 8, 8))
+        assert not net._fused_ok(torch.zeros(1, 1, 8, 8, 2))
+    wide = Unet(2, 8, chans=8, num_pool_layers=2).eval()           # 8 output channels: the closing 1x1 kernel covers <= 4
+    assert not wide._fusable()
+    assert ops.rim_layer1_inplace_ok(4, 64, 5, 1) and not ops.rim_layer1_inplace_ok(4, 64, 3, 1)
