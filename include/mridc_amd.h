@@ -263,6 +263,14 @@ int mrx_rim_layer2_sb(const float* x, const float* packed, const float* b_conv, 
  * bf16 matrix pipe with fp32 results (conv_layers.py:121-123; the 64-channel layers of CascadeNet / VSNet / the Recurrent VarNet).
  * packed = mrx_rim_layer2_sb_pack(w, NULL, NULL). */
 int mrx_conv3x3_sb_supported(int Cin, int Cout, int k, int dil);
+/* The same operand split for convolutions of FEW input channels (Cin <= 8; k = 3 | 5, dilation 1) into Cout <= 128: the first layers of the
+ * cascades (conv_layers.py:121-123; qRIM 5x5 8 -> 128, CascadeNet / VSNet 3x3 2 -> 64).  y = act(conv(x) + bias), zero or replicate padding;
+ * packed: mrx_conv_sbs_pack_floats(Cout, k) floats from mrx_conv_sbs_pack. */
+int mrx_conv_sbs_supported(int Cin, int Cout, int k, int dil);
+int64_t mrx_conv_sbs_pack_floats(int Cout, int k);
+int mrx_conv_sbs_pack(const float* w, float* packed, int Cin, int Cout, int k, void* stream);
+int mrx_conv_sbs(const float* x, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int k, int pad_mode,
+                 int act, float slope, void* stream);
 int mrx_conv3x3_sb(const float* x, const float* packed, const float* bias, float* y, int B, int H, int W, int dil, int pad_mode, int act,
                    float slope, void* stream);
 int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,

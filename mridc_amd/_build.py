@@ -24,6 +24,7 @@ SOURCES = [
     ("gated_cell.hip", []),
     ("conv_bwd.hip", []),
     ("conv_bf16.hip", []),
+    ("conv_sbs.hip", []),
     ("unet.hip", []),
     ("unet_fused.hip", []),
     ("qmri.hip", ["-ffp-contract=off"]),

@@ -131,6 +131,10 @@ _SIGNATURES = {
     "mrx_rim_layer2_sb_pack_floats": ([], _i64),
     "mrx_rim_layer2_sb_pack": ([_p, _p, _p, _p, _p], _i),
     "mrx_conv3x3_sb_supported": ([_i, _i, _i, _i], _i),
+    "mrx_conv_sbs_supported": ([_i, _i, _i, _i], _i),
+    "mrx_conv_sbs_pack_floats": ([_i, _i], _i64),
+    "mrx_conv_sbs_pack": ([_p, _p, _i, _i, _i, _p], _i),
+    "mrx_conv_sbs": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_conv3x3_sb": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_rim_layer2_sb_taps": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_final_gather": ([_p, _p, _p, _p, _i, _i, _i, _p], _i),

@@ -1,0 +1,207 @@
+// conv_sbs.hip -- convolutions of FEW input channels (Cin <= 8; 3x3 or 5x5, dilation 1) into up to 128 channels with fp32 results on the bf16
+// matrix pipe: the first layers of the cascades (qRIM 5x5 8 -> 128, qrim_block.py:226-236 via conv_layers.py:121-123; CascadeNet / VSNet
+// 3x3 2 -> 64), which ran on the generic fp32-MFMA kernel (one MFMA per two input channels of ONE tap: 77 us for the qRIM layer at 256 x 256).
+// Every fp32 operand is the exact sum of three bf16 terms, six term products per multiply (error O(2^-24): rim_layer1_sb.hip); with eight
+// channels per pixel one v_mfma_f32_32x32x16_bf16 consumes two taps.  The formulation of conv_bf16.hip (whole halo'd tile in LDS as
+// [pixel][8 channels], one 16-byte LDS read per B operand, A operands straight from L2, wave = one image row x 32 pixels x all couts),
+// times three term planes.
+#include "mrx_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CS_NT 512
+#define CS_TH 8
+#define CS_TW 32
+
+__device__ __forceinline__ unsigned cs_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void cs_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = cs_pk(a, b);
+    float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cs_pk(ra, rb);
+    ra -= __uint_as_float(p2 << 16);
+    rb -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = cs_pk(ra, rb);
+}
+
+struct ConvSbsArgs {
+    const float* x;        // [B,Cin,H,W], Cin <= 8
+    const u32x4* packed;   // [3 terms][NSTEP][NCT][64 lanes] x 8 bf16
+    const float* bias;     // [Cout] or null
+    float* out;            // [B,Cout,H,W]
+    int B, Cin, Cout, H, W, tiles_x, ntiles, pad_mode, act;
+    float slope;
+};
+__host__ __device__ constexpr int cs_nstep(int K) { return (K * K + 1) / 2; }
+
+template <int K, int NCT>
+__global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
+    constexpr int PAD = (K - 1) / 2, PH = CS_TH + 2 * PAD, PW = CS_TW + 2 * PAD, NPIX = PH * PW, NG = K * K, NSTEP = cs_nstep(K);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cs[];      // [3 terms][NPIX] x 16 B
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_cs);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int tile = (int)mrx_xcd_band(blockIdx.x, a.ntiles);
+    const int ty0 = tile / a.tiles_x;
+    const int h0 = ty0 * CS_TH, w0 = (tile - ty0 * a.tiles_x) * CS_TW;
+    const int b = blockIdx.y;
+    const long long plane = (long long)a.H * a.W;
+    const float* xb = a.x + (long long)b * a.Cin * plane;
+
+    // ---- stage the halo'd tile: the 8 channels of a pixel, split into their three bf16 terms, one 16-byte LDS write per term ----------------
+    constexpr int ITERS = (NPIX + CS_NT - 1) / CS_NT;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int e = tid + it * CS_NT;
+        if (e < NPIX) {
+            const int ty = e / PW, tx = e - ty * PW;
+            int gy = h0 + ty - PAD, gx = w0 + tx - PAD;
+            bool inb = true;
+            if (a.pad_mode == MRX_PAD_REPLICATE) {
+                gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+            } else {
+                inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                gy = inb ? gy : 0;
+                gx = inb ? gx : 0;
+            }
+            const float* src = xb + (long long)gy * a.W + gx;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (inb && j < a.Cin) ? src[(long long)j * plane] : 0.f;
+            unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cs_split2(v[2 * k], v[2 * k + 1], p1[k], p2[k], p3[k]);
+            Xs[e] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+            Xs[NPIX + e] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+            Xs[2 * NPIX + e] = u32x4{p3[0], p3[1], p3[2], p3[3]};
+        }
+    }
+    __syncthreads();
+
+    // ---- the matrix loop: per step (two taps) three B reads from LDS, per cout block three A reads from L2 and six term products --------------
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    const u32x4* bx = Xs + wave * PW + l31;
+    const u32x4* wp = a.packed + lane;
+    constexpr int WT = NSTEP * NCT * 64;       // operands per term
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int t0 = 2 * s, t1 = (2 * s + 1 < NG) ? 2 * s + 1 : NG - 1;   // the upper half-wave takes the next tap (zero weights past the last)
+        const int o0 = (t0 / K) * PW + (t0 % K), o1 = (t1 / K) * PW + (t1 % K);
+        const int off = lhi ? o1 : o0;
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bx[off]);
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bx[NPIX + off]);
+        const bf16x8 b3 = __builtin_bit_cast(bf16x8, bx[2 * NPIX + off]);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, wp[(s * NCT + ct) * 64]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, wp[WT + (s * NCT + ct) * 64]);
+            const bf16x8 a3 = __builtin_bit_cast(bf16x8, wp[2 * WT + (s * NCT + ct) * 64]);
+            // the six term pairs of weight >= 2^-16, smallest first
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[ct], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias, activation; lane = pixel (128-byte rows per wave instruction) ----------------------------------------------------
+    const int oy = h0 + wave, ox = w0 + l31;
+    if (oy < a.H && ox < a.W) {
+        const long long obase = (long long)b * a.Cout * plane + (long long)oy * a.W + ox;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (co < a.Cout) {
+                    float v = acc[ct][r];
+                    if (a.bias) v += a.bias[co];
+                    if (a.act == MRX_ACT_RELU)
+                        v = v > 0.f ? v : 0.f;
+                    else if (a.act == MRX_ACT_LEAKY)
+                        v = v > 0.f ? v : v * a.slope;
+                    a.out[obase + (long long)co * plane] = v;
+                }
+            }
+    }
+}
+
+// packed[t * WT + (s * NCT + ct) * 64 + lane][j] = term_t( w[cout = 32 ct + lane % 32][channel j][tap = 2 s + lane / 32] )   (0 past Cin / Cout / taps)
+__global__ void k_conv_sbs_pack(const float* __restrict__ w, u32x4* __restrict__ out, int Cin, int Cout, int K, int NCT) {
+    const int TAPS = K * K, NSTEP = (TAPS + 1) / 2, WT = NSTEP * NCT * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * WT; i += gridDim.x * blockDim.x) {
+        const int t = i / WT, r = i - t * WT;
+        const int lane = r & 63, ct = (r >> 6) % NCT, s = (r >> 6) / NCT;
+        const int tap = 2 * s + (lane >> 5), co = ct * 32 + (lane & 31);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (tap < TAPS && j < Cin && co < Cout) ? w[((long long)co * Cin + j) * TAPS + tap] : 0.f;
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned p1, p2, p3;
+            cs_split2(v[2 * k], v[2 * k + 1], p1, p2, p3);
+            p[k] = t == 0 ? p1 : (t == 1 ? p2 : p3);
+        }
+        out[i] = u32x4{p[0], p[1], p[2], p[3]};
+    }
+}
+
+static int cs_nct(int Cout) { return Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4); }
+extern "C" int mrx_conv_sbs_supported(int Cin, int Cout, int k, int dil) {
+    return (Cin >= 1 && Cin <= 8 && Cout >= 1 && Cout <= 128 && (k == 3 || k == 5) && dil == 1) ? 1 : 0;
+}
+extern "C" int64_t mrx_conv_sbs_pack_floats(int Cout, int k) {
+    if (Cout < 1 || Cout > 128 || (k != 3 && k != 5)) return -1;
+    return (int64_t)3 * cs_nstep(k) * cs_nct(Cout) * 64 * 4;
+}
+extern "C" int mrx_conv_sbs_pack(const float* w, float* packed, int Cin, int Cout, int k, void* stream) {
+    MRX_REQUIRE(w && packed, MRX_EINVAL, "mrx_conv_sbs_pack: null pointer");
+    MRX_REQUIRE(mrx_conv_sbs_supported(Cin, Cout, k, 1), MRX_EUNSUP, "mrx_conv_sbs_pack: Cin=%d Cout=%d k=%d", Cin, Cout, k);
+    const int total = 3 * cs_nstep(k) * cs_nct(Cout) * 64;
+    hipLaunchKernelGGL(k_conv_sbs_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, reinterpret_cast<u32x4*>(packed), Cin, Cout, k,
+                       cs_nct(Cout));
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+template <int K, int NCT>
+static int cs_launch(const ConvSbsArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)3 * (CS_TH + K - 1) * (CS_TW + K - 1) * 16;
+    static_assert(lds <= 48 * 1024, "fits the default dynamic LDS limit");
+    hipLaunchKernelGGL((k_conv_sbs<K, NCT>), dim3(a.ntiles, a.B), dim3(CS_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+template <int K>
+static int cs_launch_nct(const ConvSbsArgs& a, hipStream_t st) {
+    const int nct = cs_nct(a.Cout);
+    return nct == 1 ? cs_launch<K, 1>(a, st) : (nct == 2 ? cs_launch<K, 2>(a, st) : cs_launch<K, 4>(a, st));
+}
+// y = act(conv_kxk(x, zero | replicate padding) + bias), Cin <= 8 -> Cout <= 128, k = 3 | 5, dilation 1; packed from mrx_conv_sbs_pack
+extern "C" int mrx_conv_sbs(const float* x, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int k,
+                            int pad_mode, int act, float slope, void* stream) {
+    MRX_REQUIRE(x && packed && y, MRX_EINVAL, "mrx_conv_sbs: null pointer");
+    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_sbs: bad dims");
+    MRX_REQUIRE(mrx_conv_sbs_supported(Cin, Cout, k, 1), MRX_EUNSUP, "mrx_conv_sbs: Cin=%d Cout=%d k=%d", Cin, Cout, k);
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv_sbs: bad pad mode %d", pad_mode);
+    MRX_REQUIRE(act >= 0 && act <= 2, MRX_EINVAL, "mrx_conv_sbs: bad activation %d", act);
+    MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "mrx_conv_sbs: batch %d too large", B);
+    if (B == 0) return MRX_OK;
+    ConvSbsArgs a;
+    a.x = x, a.packed = reinterpret_cast<const u32x4*>(packed), a.bias = bias, a.out = y;
+    a.B = B, a.Cin = Cin, a.Cout = Cout, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, CS_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, CS_TH);
+    a.pad_mode = pad_mode, a.act = act, a.slope = slope;
+    return k == 3 ? cs_launch_nct<3>(a, (hipStream_t)stream) : cs_launch_nct<5>(a, (hipStream_t)stream);
+}

@@ -197,6 +197,38 @@ def test_second_rim_layer_with_final_conv_in_its_tail(shape, dev):
         assert rel_l2(eta_new - eta, sep - eta) <= 1e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 128, 5, 256, 256), (1, 2, 64, 3, 640, 372), (2, 4, 64, 5, 37, 75), (1, 1, 32, 3, 19, 33), (3, 7, 100, 5, 8, 32),
+                                   (1, 3, 33, 3, 5, 3), (1, 8, 128, 3, 1, 1)])
+def test_few_channel_conv_split_bf16(shape, dev):
+    """mrx_conv_sbs (3x3 / 5x5 convolutions of <= 8 channels into <= 128: the cascades' first layers, e.g. qRIM's 5x5 8 -> 128 + ReLU) through
+    ops.conv2d against float64 and the generic fp32-MFMA kernel it replaces: fp32-level error; zero and replicate padding, every activation,
+    ragged tiles, channel counts off the block sizes."""
+    import torch.nn.functional as Fn
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    B, Cin, Cout, k, H, W = shape
+    g = torch.Generator().manual_seed(3 + sum(shape))
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    x, w, b = r(B, Cin, H, W), r(Cout, Cin, k, k) / (Cin * k * k) ** 0.5, r(Cout) * 0.1
+    assert ops.conv_sbs_supported(Cin, Cout, k, 1)
+    keep = ops.SBS_CONV
+    try:
+        for pm, mode in ((ops.PAD_ZERO, "constant"), (ops.PAD_REPLICATE, "replicate")):
+            for act, bias in ((ops.ACT_NONE, b), (ops.ACT_RELU, None), (ops.ACT_LEAKY, b)):
+                ref = Fn.conv2d(Fn.pad(x.double(), (k // 2,) * 4, mode=mode), w.double(), None if bias is None else bias.double())
+                ref = ref.relu() if act == ops.ACT_RELU else (Fn.leaky_relu(ref, 0.1) if act == ops.ACT_LEAKY else ref)
+                got = ops.conv_sbs(x, w, bias, pm, act, 0.1)          # (ops.conv2d routes the 5x5 shapes here)
+                if k == 5 and Cout >= ops.SBS_MIN_COUT:
+                    ops.SBS_CONV = True
+                    assert torch.equal(ops.conv2d(x, w, bias, 1, pm, act, 0.1), got)
+                ops.SBS_CONV = False
+                old = ops.conv2d(x, w, bias, 1, pm, act, 0.1)
+                e_sb, e_old = rel_l2(got, ref), rel_l2(old, ref)
+                assert e_sb <= 5e-7 and e_sb <= 2.5 * e_old + 5e-8, (shape, mode, act, e_sb, e_old)
+    finally:
+        ops.SBS_CONV = keep
+
+
 @pytest.mark.parametrize("shape", [(1, 640, 372), (2, 37, 75), (1, 19, 33), (3, 16, 32), (1, 5, 3), (1, 1, 1), (1, 130, 320)])
 def test_conv3x3_64_to_64_split_bf16(shape, dev):
     """mrx_conv3x3_sb (the convolution stage of the dominant RIM layer as a general 64 -> 64 convolution: dilation 1 and 2, zero and replicate
