@@ -167,6 +167,12 @@ int mrx_pfa372_expand(const float* x, const float* Sp, float* out, const float* 
                       const int64_t* mstride, const float* dc_weight, int B, int C, int H, int norm, int centered, void* stream);
 int mrx_pfa372_reduce(const float* k, const float* Sp, const float* eta, float* out, float* out4, float* work, int B, int C, int H,
                       float post, int norm, int centered, void* stream);
+/* mrx_pfa372_expand that also returns red [B,H,372,2] = sum_c conj(S) IFFT_W(out) -- the sens_reduce the NEXT cascade begins with
+ * (vn_block.py:71-87 applied to the result of :109-119) -- from the rows while they are in the wave's buffer: the coil stack and the maps
+ * are not read again.  work: mrx_llg372_work_floats(B,C,H) floats. */
+int mrx_pfa372_expand_reduce(const float* x, const float* Sp, float* out, const float* pred, const float* ref, const void* mask,
+                             int mask_kind, const int64_t* mstride, const float* dc_weight, float* red, float* work, int B, int C, int H,
+                             int norm, int centered, void* stream);
 int mrx_llg_cols_dc(float* work, const float* y, const void* mask, int mask_kind, const int64_t* mstride, int B, int C, int H, int W,
                     int norm, int centered, void* stream);
 int mrx_rim_layer_indrnn_packed_llg(const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "mrx_llg372": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_pfa372_prepare_maps": ([_p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_pfa372_expand": ([_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_pfa372_expand_reduce": ([_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_pfa372_reduce": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_llg_cols_dc": ([_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_rim_layer_indrnn_packed_llg": ([_p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),

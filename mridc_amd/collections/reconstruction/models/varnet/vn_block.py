@@ -18,6 +18,11 @@ class VarNetBlock(torch.nn.Module):
         self.no_dc = no_dc
         self.dc_weight = torch.nn.Parameter(torch.ones(1))
         self._hybrid = False   # set by the model for row-invariant masks: k-space arguments are IFFT_H(k), row transforms only
+        # hybrid cascades chained by the model (W = 372): the data-consistency pass of one block also produces the sens_reduce the next one
+        # starts with (mrx_pfa372_expand_reduce): `_reduced_in` replaces this block's own sens_reduce, `_reduced_out` is what it hands on
+        self._reduced_in = None
+        self._want_reduced = False
+        self._reduced_out = None
         if coil_dim != 1:
             raise NotImplementedError("the HIP path expects the coil dimension at index 1")
 
@@ -37,9 +42,14 @@ class VarNetBlock(torch.nn.Module):
             eta = diff.sens_reduce(pred, sens_maps, *kw).unsqueeze(1)
             eta = diff.sens_expand(self.model(eta), sens_maps, *kw)
             return eta if self.no_dc else diff.dc_combine(pred, pred, ref_kspace, mask, self.dc_weight, eta)
-        eta = self.sens_reduce(pred, sens_maps)
+        eta = self._reduced_in.unsqueeze(1) if (self._hybrid and self._reduced_in is not None) else self.sens_reduce(pred, sens_maps)
+        self._reduced_out = None
         eta = self.model(eta)
         if self._hybrid and not self.no_dc:      # expand + data consistency in one pass over the coil stack
+            if self._want_reduced and ops.sens_expand_dc_reduce_supported(sens_maps):
+                out, self._reduced_out = ops.sens_expand_dc_hybrid(eta, sens_maps, pred, ref_kspace, mask, self.dc_weight, self.fft_centered,
+                                                                   self.fft_normalization, reduce=True)
+                return out
             return ops.sens_expand_dc_hybrid(eta, sens_maps, pred, ref_kspace, mask, self.dc_weight, self.fft_centered,
                                              self.fft_normalization)
         eta = self.sens_expand(eta, sens_maps)

@@ -199,8 +199,12 @@ struct L372Dc {
     int on;
 };
 
+// RED: the new k-space rows stay in the wave's buffer and go straight through the inverse pipeline of k_pfa372_reduce (S is still in
+// registers): part[z][b, h, :] = the task's share of sum_c conj(S) IFFT_W(out) -- the next cascade's sens_reduce (vn_block.py:71-87) without
+// reading the coil stack and the maps again.
+template <bool RED>
 __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restrict__ x_, const float2* __restrict__ Sp_,
-                                                          float2* __restrict__ out_, L372Args a, L372Dc dc) {
+                                                          float2* __restrict__ out_, L372Args a, L372Dc dc, float2* __restrict__ part_) {
     const pfa_c* __restrict__ xin = reinterpret_cast<const pfa_c*>(x_);
     const pfa_c* __restrict__ Sp = reinterpret_cast<const pfa_c*>(Sp_);
     extern __shared__ __attribute__((aligned(16))) float2 X_[];
@@ -279,6 +283,57 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restric
                     r = pfa_mk(p_.x - sx - r[0], p_.y - sy - r[1]);                                      // vn_block.py:119
                 }
                 reinterpret_cast<pfa_c*>(out_)[base + wcol] = r;
+                if (RED) X[g * PFA_RS + n] = r;
+            }
+        }
+    }
+    if (RED) {
+        for (int g = Cg; g < PFA_G; ++g)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int n = l + 64 * i;
+                if (n < PFA_N) X[g * PFA_RS + n] = pfa_mk(0.f, 0.f);
+            }
+        __syncthreads();
+        // ---- the body of k_pfa372_reduce on the rows just written ------------------------------------------------------------------------
+        pfa_c u[3][12];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int d = min(l + 64 * p, PFA_D - 1), g2 = d / PFA_N2, k2 = d - g2 * PFA_N2;
+            const int base = (156 * k2) % PFA_N;
+#pragma unroll
+            for (int k1 = 0; k1 < 12; ++k1) {
+                int k = base + (217 * k1) % PFA_N;
+                k = k >= PFA_N ? k - PFA_N : k;
+                u[p][k1] = X[g2 * PFA_RS + k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int d = l + 64 * p;
+            if (d < PFA_D) {
+                pfa_dft12<true>(u[p]);
+                const int g2 = d / PFA_N2, k2 = d - g2 * PFA_N2;
+                pfa_c* q = X + g2 * PFA_GS + k2 * PFA_KS;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) q[i] = u[p][i];
+            }
+        }
+        __syncthreads();
+        if (laneA) pfa372_gather_a(L, X, g1, n1);
+        __syncthreads();
+        if (laneA) pfa372_stage_a_inv(L, X, g1, n1, a.scale_i);
+        __syncthreads();
+        pfa_c* po = reinterpret_cast<pfa_c*>(part_) + (((long long)z * a.B * a.H) + row) * PFA_N;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int n = l + 64 * i;
+            if (n < PFA_N) {
+                pfa_c sm = X[n];
+#pragma unroll
+                for (int g = 1; g < PFA_G; ++g) sm = pfa_add(sm, X[g * PFA_RS + n]);
+                po[pfa372_shift(n, a.halfW)] = sm;
             }
         }
     }
@@ -555,8 +610,35 @@ extern "C" int mrx_pfa372_expand(const float* x, const float* Sp, float* out, co
     dc.pred = (const float2*)pred, dc.ref = (const float2*)ref, dc.w = dc_weight;
     dc.mask.p = mask, dc.mask.kind = mask_kind;
     for (int i = 0; i < 4; ++i) dc.mask.s[i] = (dc.on ? mstride[i] : 0);
-    hipLaunchKernelGGL(k_pfa372_expand, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
-                       (const float2*)Sp, (float2*)out, a, dc);
+    hipLaunchKernelGGL(k_pfa372_expand<false>, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
+                       (const float2*)Sp, (float2*)out, a, dc, (float2*)nullptr);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// mrx_pfa372_expand and, in the same pass, red [B,H,372,2] = sum_c conj(S) IFFT_W(out): the sens_reduce the next cascade starts with
+// (vn_block.py:71-87 after :109-119).  work: mrx_llg372_work_floats(B,C,H) floats.
+extern "C" int mrx_pfa372_expand_reduce(const float* x, const float* Sp, float* out, const float* pred, const float* ref, const void* mask,
+                                        int mask_kind, const int64_t* mstride, const float* dc_weight, float* red, float* work, int B, int C,
+                                        int H, int norm, int centered, void* stream) {
+    MRX_REQUIRE(x && Sp && out && red && work, MRX_EINVAL, "mrx_pfa372_expand_reduce: null pointer");
+    MRX_REQUIRE(!pred || (ref && mask && mstride && dc_weight), MRX_EINVAL, "mrx_pfa372_expand_reduce: the DC epilogue needs pred, ref, mask and dc_weight");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, 0);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_pfa372_expand_reduce: too many tasks");
+    L372Dc dc;
+    dc.on = pred != nullptr;
+    dc.pred = (const float2*)pred, dc.ref = (const float2*)ref, dc.w = dc_weight;
+    dc.mask.p = mask, dc.mask.kind = mask_kind;
+    for (int i = 0; i < 4; ++i) dc.mask.s[i] = (dc.on ? mstride[i] : 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_pfa372_expand<true>, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, st, (const float2*)x,
+                       (const float2*)Sp, (float2*)out, a, dc, (float2*)work);
+    const long long total = (long long)H * PFA_N * B;
+    long long nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_pfa372_sum, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)work, (float2*)red, a.T, total);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

@@ -78,9 +78,15 @@ def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=Fals
     return out
 
 
-def sens_expand_dc_hybrid(x, sens, pred, ref, mask, dc_weight, centered, normalization):
+def sens_expand_dc_reduce_supported(sens):
+    """The W = 372 kernel can hand the next cascade its sens_reduce in the same pass (mrx_pfa372_expand_reduce)."""
+    return _pfa372_ok(sens)
+
+
+def sens_expand_dc_hybrid(x, sens, pred, ref, mask, dc_weight, centered, normalization, reduce=False):
     """pred - where(mask, pred - ref, 0) * dc_weight - FFT_W(x * S), everything in hybrid space: the cascade's last two steps
-    (sens_expand, soft data consistency) as one pass (mrx_sens_expand_rows_dc)."""
+    (sens_expand, soft data consistency) as one pass (mrx_sens_expand_rows_dc).  `reduce` (W = 372 only): also returns
+    sum_c conj(S) IFFT_W(result) [B,H,W,2] -- the sens_reduce of the NEXT cascade -- computed on the rows while they are on chip."""
     sens, pred, ref = _lib.f32c(sens), _lib.f32c(pred), _lib.f32c(ref)
     B, C, H, W = _bchw(sens)
     x = _lib.f32c(x)
@@ -91,6 +97,16 @@ def sens_expand_dc_hybrid(x, sens, pred, ref, mask, dc_weight, centered, normali
     m, kind, ms = _lib.mask_args(mask, B, C, H, W)
     w = _lib.f32c(dc_weight.detach().reshape(-1))
     out = torch.empty_like(sens)
+    if reduce:
+        if not _pfa372_ok(sens):
+            raise NotImplementedError("sens_expand_dc_hybrid(reduce=True): W = 372 only")
+        L = _lib.lib()
+        red = torch.empty(B, H, W, 2, dtype=torch.float32, device=sens.device)
+        wk = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=sens.device)
+        _lib.check(L.mrx_pfa372_expand_reduce(_lib.ptr(x), _lib.ptr(_sp372(sens, centered)), _lib.ptr(out), _lib.ptr(pred), _lib.ptr(ref),
+                                              _lib.ptr(m), kind, ms, _lib.ptr(w), _lib.ptr(red), _lib.ptr(wk), B, C, H, _norm(normalization),
+                                              int(bool(centered)), _lib.stream_ptr()), "mrx_pfa372_expand_reduce")
+        return out, red
     if _pfa372_ok(sens):
         _lib.check(_lib.lib().mrx_pfa372_expand(_lib.ptr(x), _lib.ptr(_sp372(sens, centered)), _lib.ptr(out), _lib.ptr(pred), _lib.ptr(ref),
                                                 _lib.ptr(m), kind, ms, _lib.ptr(w), B, C, H, _norm(normalization), int(bool(centered)),

@@ -319,6 +319,45 @@ def test_e2evn_cascade_full_size(dev, chans, pools, pad):
     assert_close(got, ref, 5e-5, f"E2EVN cascade NormUnet({chans},{pools}) at 15 x 640 x 372")
 
 
+@pytest.mark.parametrize("case", [(1, 15, 96, False, "backward"), (2, 7, 21, True, "ortho"), (1, 3, 9, True, "forward")],
+                         ids=lambda c: f"B{c[0]}C{c[1]}H{c[2]}_{'c' if c[3] else 'n'}_{c[4]}")
+def test_e2evn_chained_reduce_at_w372(dev, case):
+    """Whole VarNet (3 cascades, NormUnet(8, 2)) at W = 372 in the hybrid space: with every block's data-consistency pass handing the next
+    block its sens_reduce (mrx_pfa372_expand_reduce; the final SENSE combination is the last one) the output must be bit-identical to the
+    unchained form (each block reducing the coil stack itself), and both must match the oracle (vn.py:94-142, vn_block.py:89-119)."""
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    B, C, H, centered, norm = case
+    cfg = dict(num_cascades=3, channels=8, pooling_layers=2, padding_size=11, normalize=True, no_dc=False, use_sens_net=False,
+               fft_centered=centered, fft_normalization=norm, spatial_dims=[-2, -1], coil_dim=1, coil_combination_method="SENSE",
+               train_loss_fn="l1", val_loss_fn="l1")
+    torch.manual_seed(7)
+    model = VarNet(cfg).eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("dc_weight"):
+                p_.fill_(0.7)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    slices = [synthetic.make_slice(C, H, 372, slice_idx=3 + i) for i in range(B)]
+    y = torch.cat([s_["y"] for s_ in slices], 0) * 50.0
+    S = torch.cat([s_["sensitivity_maps"] for s_ in slices], 0)
+    mask, target = slices[0]["mask"], torch.cat([s_["target"] for s_ in slices], 0)
+    with torch.no_grad():
+        ref = oracle.models.varnet_forward(sd, cfg, y, S, mask, None, target)
+    model = model.to(dev)
+    assert model._hybrid_ok(mask.to(dev))
+    outs = {}
+    keep = VarNet.chain_reduce
+    try:
+        for chain in (True, False):
+            VarNet.chain_reduce = chain
+            with torch.no_grad():
+                outs[chain] = model(y.to(dev), S.to(dev), mask.to(dev), None, target.to(dev))
+    finally:
+        VarNet.chain_reduce = keep
+    assert torch.equal(torch.view_as_real(outs[True]), torch.view_as_real(outs[False])), "chained reduce changed the result"
+    assert_close(torch.view_as_real(outs[True]), torch.view_as_real(ref), 5e-5, "VarNet 3 cascades at W = 372, hybrid space")
+
+
 @pytest.mark.parametrize("case", [(1, 15, 640, True, "ortho"), (2, 7, 21, False, "backward"), (1, 3, 9, True, "forward")],
                          ids=lambda c: f"B{c[0]}C{c[1]}H{c[2]}_{'c' if c[3] else 'n'}_{c[4]}")
 def test_pfa372_row_operators_and_general_mask_gradient(dev, case):
