@@ -36,7 +36,11 @@ class CascadeNetBlock(torch.nn.Module):
 
     def forward(self, pred: torch.Tensor, ref_kspace: torch.Tensor, sens_maps: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         """ccnn_block.py:101-139."""
-        eta = self.sens_reduce(pred, sens_maps)
+        # hybrid cascades chained by the model (W = 372): `_reduced_in` replaces this block's own sens_reduce, `_reduced_out` is the next one's
+        eta = self._reduced_in.unsqueeze(1) if (self._hybrid and getattr(self, "_reduced_in", None) is not None) \
+            else self.sens_reduce(pred, sens_maps)
+        self._reduced_out = None
+        chain = self._hybrid and getattr(self, "_want_reduced", False) and ops.sens_expand_dc_reduce_supported(sens_maps)
         x = eta.squeeze(self.coil_dim).permute(0, 3, 1, 2)
         if isinstance(self.model, conv2d.Conv2d):
             eta = self.model(x, _complex_last=True)            # the last conv writes [B,H,W,2] directly
@@ -45,8 +49,16 @@ class CascadeNetBlock(torch.nn.Module):
         if eta.dim() < sens_maps.dim():
             eta = eta.unsqueeze(1)
         if self._hybrid and not self.no_dc:      # expand + data consistency in one pass over the coil stack
+            if chain:
+                out, self._reduced_out = ops.sens_expand_dc_hybrid(eta, sens_maps, pred, ref_kspace, mask, self.dc_weight, self.fft_centered,
+                                                                   self.fft_normalization, reduce=True)
+                return out
             return ops.sens_expand_dc_hybrid(eta, sens_maps, pred, ref_kspace, mask, self.dc_weight, self.fft_centered,
                                              self.fft_normalization)
+        if chain:                                # no_dc (the model-zoo configuration): expand, and the next block's reduction with it
+            out, self._reduced_out = ops.sens_expand(eta, sens_maps, self.fft_centered, self.fft_normalization, self.spatial_dims, hybrid=True,
+                                                     reduce=True)
+            return out
         eta = self.sens_expand(eta, sens_maps)
         if not self.no_dc:
             eta = ops.dc_combine(pred, pred, ref_kspace, mask, self.dc_weight, eta)   # pred - where(mask, pred - ref, 0) * w - eta

@@ -33,6 +33,8 @@ class CascadeNet(torch.nn.Module):
         self.dc_weight = torch.nn.Parameter(torch.ones(1))            # ccnn.py:90
 
 
+    chain_reduce = __import__("os").environ.get("MRIDC_AMD_CHAIN_REDUCE", "1") != "0"
+
     def _hybrid_ok(self, mask):
         """Row-invariant (1-D column) mask + SENSE combination: the masked data consistency commutes with the H transform, so the
         cascades can run on IFFT_H(k) with row transforms only (`MRIDC_AMD_HYBRID=0` turns this off)."""
@@ -45,12 +47,16 @@ class CascadeNet(torch.nn.Module):
         SENSE combination of ifft2(k) at the end is one more sens_reduce_rows.  Same function as the k-space form, half the FFT work."""
         yh = ops.llg_prepare(y, self.fft_centered, self.fft_normalization, self.spatial_dims)
         est = yh
+        red = None                               # sum_c conj(S) IFFT_W(est), handed from one block's last pass to the next block (W = 372)
         for cascade in self.cascades:
-            cascade._hybrid = True
+            cascade._hybrid, cascade._reduced_in, cascade._want_reduced = True, red, self.chain_reduce
             try:
                 est = cascade(est, yh, sensitivity_maps, mask)
+                red = cascade._reduced_out
             finally:
-                cascade._hybrid = False
+                cascade._hybrid, cascade._reduced_in, cascade._want_reduced, cascade._reduced_out = False, None, False, None
+        if red is not None:
+            return red
         return ops.sens_reduce(est, sensitivity_maps, self.fft_centered, self.fft_normalization, self.spatial_dims, hybrid=True)
 
     def forward(self, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask: torch.Tensor, init_pred: torch.Tensor,

@@ -56,9 +56,10 @@ def _pfa372_ok(sens):
     return PFA372 and sens.dim() == 5 and int(sens.shape[3]) == 372
 
 
-def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=False):
+def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=False, reduce=False):
     """fft2(complex_mul(x, S)).  x [B,H,W,2] or [B,1,H,W,2]; S [B,C,H,W,2] -> [B,C,H,W,2].  `hybrid`: the W transform only
-    (k-space kept as IFFT_H(k) for row-invariant masks: mrx_sens_expand_rows)."""
+    (k-space kept as IFFT_H(k) for row-invariant masks: mrx_sens_expand_rows).  `reduce` (hybrid, W = 372): also returns
+    sum_c conj(S) IFFT_W(result) -- the next cascade's sens_reduce -- from the same pass (mrx_pfa372_expand_reduce)."""
     sens = _lib.f32c(sens)
     B, C, H, W = _bchw(sens)
     _check_last_two(spatial_dims, 4)
@@ -68,6 +69,16 @@ def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=Fals
     if tuple(x.shape) != (B, H, W, 2):
         raise ValueError(f"sens_expand: image shape {tuple(x.shape)} does not match maps {tuple(sens.shape)}")
     out = torch.empty_like(sens)
+    if reduce:
+        if not (hybrid and _pfa372_ok(sens)):
+            raise NotImplementedError("sens_expand(reduce=True): hybrid space at W = 372 only")
+        L = _lib.lib()
+        red = torch.empty(B, H, W, 2, dtype=torch.float32, device=sens.device)
+        wk = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=sens.device)
+        _lib.check(L.mrx_pfa372_expand_reduce(_lib.ptr(x), _lib.ptr(_sp372(sens, centered)), _lib.ptr(out), None, None, None, 0, None, None,
+                                              _lib.ptr(red), _lib.ptr(wk), B, C, H, _norm(normalization), int(bool(centered)),
+                                              _lib.stream_ptr()), "mrx_pfa372_expand_reduce")
+        return out, red
     if hybrid and _pfa372_ok(sens):                                  # W = 372: wave-private prime-factor row transforms
         _lib.check(_lib.lib().mrx_pfa372_expand(_lib.ptr(x), _lib.ptr(_sp372(sens, centered)), _lib.ptr(out), None, None, None, 0, None, None,
                                                 B, C, H, _norm(normalization), int(bool(centered)), _lib.stream_ptr()), "mrx_pfa372_expand")

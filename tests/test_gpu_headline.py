@@ -358,6 +358,38 @@ def test_e2evn_chained_reduce_at_w372(dev, case):
     assert_close(torch.view_as_real(outs[True]), torch.view_as_real(ref), 5e-5, "VarNet 3 cascades at W = 372, hybrid space")
 
 
+@pytest.mark.parametrize("no_dc", [True, False], ids=["no_dc_model_zoo", "with_dc"])
+def test_cascadenet_chained_reduce_at_w372(dev, no_dc):
+    """CascadeNet (3 cascades x 3 convs, 16 channels) at W = 372 in the hybrid space, chained (each block's expand pass hands the next block its
+    sens_reduce: mrx_pfa372_expand_reduce with and without the data-consistency epilogue) against unchained: bit-identical; and against the
+    oracle (ccnn.py:93-142, ccnn_block.py:101-139)."""
+    from mridc_amd.collections.reconstruction.models.ccnn import CascadeNet
+    cfg = dict(num_cascades=3, hidden_channels=16, n_convs=3, batchnorm=False, no_dc=no_dc, use_sens_net=False, fft_centered=False,
+               fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1, coil_combination_method="SENSE", train_loss_fn="l1",
+               val_loss_fn="l1")
+    torch.manual_seed(11)
+    model = CascadeNet(cfg).eval()
+    # (.cpu(): the default `activation=nn.PReLU()` argument is ONE module shared by every Conv2d ever built, as in the reference, conv2d.py:14 --
+    #  an earlier test may have moved it to the GPU)
+    sd = {k: v.detach().cpu().clone() for k, v in model.cpu().state_dict().items()}
+    d = synthetic.make_slice(7, 40, 372, slice_idx=4)
+    y = d["y"] * 50.0
+    with torch.no_grad():
+        ref = oracle.cascadenet.cascadenet_forward(sd, cfg, y, d["sensitivity_maps"], d["mask"], None, d["target"])
+    model = model.to(dev)
+    outs = {}
+    keep = CascadeNet.chain_reduce
+    try:
+        for chain in (True, False):
+            CascadeNet.chain_reduce = chain
+            with torch.no_grad():
+                outs[chain] = model(y.to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev), None, d["target"].to(dev))
+    finally:
+        CascadeNet.chain_reduce = keep
+    assert torch.equal(torch.view_as_real(outs[True]), torch.view_as_real(outs[False])), "chained reduce changed the result"
+    assert_close(torch.view_as_real(outs[True]), torch.view_as_real(ref), 5e-5, "CascadeNet at W = 372, hybrid space")
+
+
 @pytest.mark.parametrize("case", [(1, 15, 640, True, "ortho"), (2, 7, 21, False, "backward"), (1, 3, 9, True, "forward")],
                          ids=lambda c: f"B{c[0]}C{c[1]}H{c[2]}_{'c' if c[3] else 'n'}_{c[4]}")
 def test_pfa372_row_operators_and_general_mask_gradient(dev, case):
