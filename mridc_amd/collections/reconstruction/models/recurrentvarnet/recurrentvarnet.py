@@ -66,12 +66,24 @@ class RecurrentVarNetBlock(nn.Module):
 
     def forward(self, current_kspace: torch.Tensor, masked_kspace: torch.Tensor, sampling_mask: torch.Tensor,
                 sensitivity_map: torch.Tensor, hidden_state: Union[None, torch.Tensor, List[torch.Tensor]]):
-        img = ops.sens_reduce(current_kspace, sensitivity_map, self.fft_centered, self.fft_normalization, self.spatial_dims,
-                              hybrid=self._hybrid)
+        # hybrid steps chained by the model (W = 372): `_reduced_in` replaces this step's own sens_reduce, `_reduced_out` is the next one's
+        if self._hybrid and getattr(self, "_reduced_in", None) is not None:
+            img = self._reduced_in
+        else:
+            img = ops.sens_reduce(current_kspace, sensitivity_map, self.fft_centered, self.fft_normalization, self.spatial_dims,
+                                  hybrid=self._hybrid)
+        self._reduced_out = None
         term, hidden_state = self.regularizer(img.permute(0, 3, 1, 2), hidden_state, _complex_last=True)   # [B,H,W,2]
         # the update needs "+ F(S w)": the transform is linear, so expand -w and let the data-consistency kernel subtract it
         # (k - alpha * err - (-t) rounds exactly like k - alpha * err + t)
         neg = ops.scale(term, -1.0)
+        if self._hybrid:                         # expand + the k-space update in one pass over the coil stack (the formula of dc_combine below)
+            chain = getattr(self, "_want_reduced", False) and ops.sens_expand_dc_reduce_supported(sensitivity_map)
+            res = ops.sens_expand_dc_hybrid(neg, sensitivity_map, current_kspace, masked_kspace, sampling_mask != 0, self.learning_rate,
+                                            self.fft_centered, self.fft_normalization, reduce=chain)
+            if chain:
+                res, self._reduced_out = res
+            return res, hidden_state
         minus_term = ops.sens_expand(neg, sensitivity_map, self.fft_centered, self.fft_normalization, self.spatial_dims,
                                      hybrid=self._hybrid)
         new_kspace = ops.dc_combine(current_kspace, current_kspace, masked_kspace, sampling_mask != 0, self.learning_rate, minus_term)

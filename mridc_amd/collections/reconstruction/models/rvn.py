@@ -80,14 +80,19 @@ class RecurrentVarNet(torch.nn.Module):
         # row-invariant mask: the k-space update commutes with the H transform -- the steps run on IFFT_H(k) with row transforms only
         y_k = ops.llg_prepare(y, self.fft_centered, self.fft_normalization, self.spatial_dims) if hybrid else y
         kspace_prediction = y_k.clone()
+        red = None                               # sum_c conj(S) IFFT_W(k), handed from one step's update pass to the next step (W = 372)
+        chain = os.environ.get("MRIDC_AMD_CHAIN_REDUCE", "1") != "0"
         for step in range(self.num_steps):
             block = self.block_list[step] if self.no_parameter_sharing else self.block_list[0]
-            block._hybrid = hybrid
+            block._hybrid, block._reduced_in, block._want_reduced = hybrid, red, hybrid and chain
             try:
                 kspace_prediction, previous_state = block(kspace_prediction, y_k, mask, sensitivity_maps, previous_state)
+                red = block._reduced_out
             finally:
-                block._hybrid = False
-        if hybrid:
+                block._hybrid, block._reduced_in, block._want_reduced, block._reduced_out = False, None, False, None
+        if hybrid and red is not None:
+            eta = red
+        elif hybrid:
             eta = ops.sens_reduce(kspace_prediction, sensitivity_maps, self.fft_centered, self.fft_normalization, self.spatial_dims,
                                   hybrid=True)
         else:

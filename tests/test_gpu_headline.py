@@ -358,6 +358,33 @@ def test_e2evn_chained_reduce_at_w372(dev, case):
     assert_close(torch.view_as_real(outs[True]), torch.view_as_real(ref), 5e-5, "VarNet 3 cascades at W = 372, hybrid space")
 
 
+@pytest.mark.parametrize("sharing", [False, True], ids=["shared_block", "block_per_step"])
+def test_recurrent_varnet_chained_reduce_at_w372(dev, sharing, monkeypatch):
+    """Recurrent VarNet (4 steps, Conv2dGRU 12 channels x 3 layers, learned initializer) at W = 372 in the hybrid space: the k-space update of a
+    step (recurrentvarnet.py:136-165) as ONE expand + update pass that also hands the next step its sens_reduce, against the unchained form
+    (bit-identical) and the oracle (rvn.py:95-170)."""
+    from mridc_amd.collections.reconstruction.models.rvn import RecurrentVarNet
+    cfg = {"in_channels": 2, "recurrent_hidden_channels": 12, "recurrent_num_layers": 3, "num_steps": 4, "no_parameter_sharing": sharing,
+           "learned_initializer": True, "initializer_initialization": "sense", "initializer_channels": [6, 6, 8, 8],
+           "initializer_dilations": [1, 1, 2, 4], "initializer_multiscale": 1, "fft_centered": False, "fft_normalization": "backward",
+           "spatial_dims": [-2, -1], "coil_dim": 1, "coil_combination_method": "SENSE", "pretrained": True}
+    torch.manual_seed(13)
+    model = RecurrentVarNet(cfg).eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    d = synthetic.make_slice(6, 24, 372, slice_idx=6)
+    y = d["y"] * 50.0
+    with torch.no_grad():
+        ref = oracle.rvn.rvn_forward(sd, cfg, y, d["sensitivity_maps"], d["mask"], None, d["target"])
+    model = model.to(dev)
+    outs = {}
+    for chain in ("1", "0"):
+        monkeypatch.setenv("MRIDC_AMD_CHAIN_REDUCE", chain)
+        with torch.no_grad():
+            outs[chain] = model(y.to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev), None, d["target"].to(dev))
+    assert torch.equal(torch.view_as_real(outs["1"]), torch.view_as_real(outs["0"])), "chained reduce changed the result"
+    assert_close(torch.view_as_real(outs["1"]), torch.view_as_real(ref), 5e-5, "Recurrent VarNet at W = 372, hybrid space")
+
+
 @pytest.mark.parametrize("no_dc", [True, False], ids=["no_dc_model_zoo", "with_dc"])
 def test_cascadenet_chained_reduce_at_w372(dev, no_dc):
     """CascadeNet (3 cascades x 3 convs, 16 channels) at W = 372 in the hybrid space, chained (each block's expand pass hands the next block its
