@@ -51,10 +51,12 @@ __global__ void k_llg372_prep(const float2* __restrict__ yt, const float2* __res
             Sp[i] = c < a.C ? S[((b * a.C + c) * a.H + h) * PFA_N + w] : make_float2(0.f, 0.f);
         }
         {
+            // element (k1, d) of the task sits at ((k1 / 2) * 155 + d) * 2 + k1 % 2: a lane's values for k1 = 2 j, 2 j + 1 are one 16-byte load
             const int k1 = e / PFA_D, d = e - k1 * PFA_D;
             pfa372_yt_src(k1, d, a.halfW, &g, &w);
             const int c = z * PFA_G + g;
-            ytp[i] = c < a.C ? yt[((b * a.C + c) * a.H + h) * PFA_N + w] : make_float2(0.f, 0.f);
+            ytp[task * L372_TASK_C2 + ((k1 >> 1) * PFA_D + d) * 2 + (k1 & 1)] =
+                c < a.C ? yt[((b * a.C + c) * a.H + h) * PFA_N + w] : make_float2(0.f, 0.f);
         }
     }
 }
@@ -119,10 +121,22 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
     pfa_c yv0[12], yv1[12], yv2[12];
     const int d2 = min(l + 128, PFA_D - 1);
     const int yoff = l;
+    auto ldy = [&](pfa_c (&v)[12], int d) {           // six 16-byte loads: (k1 = 2 j, 2 j + 1) are adjacent in ytp
+        const float4* q = reinterpret_cast<const float4*>(ytask) + d;
 #pragma unroll
-    for (int k1 = 0; k1 < 12; ++k1) yv0[k1] = ABL == 2 ? pfa_mk((float)k1, 1.f) : ytask[k1 * PFA_D + yoff];
+        for (int j = 0; j < 6; ++j) {
+            const float4 t = q[j * PFA_D];
+            v[2 * j] = pfa_mk(t.x, t.y);
+            v[2 * j + 1] = pfa_mk(t.z, t.w);
+        }
+    };
+    if (ABL == 2) {
 #pragma unroll
-    for (int k1 = 0; k1 < 12; ++k1) yv1[k1] = ABL == 2 ? pfa_mk((float)k1, 2.f) : ytask[k1 * PFA_D + yoff + 64];
+        for (int k1 = 0; k1 < 12; ++k1) yv0[k1] = pfa_mk((float)k1, 1.f), yv1[k1] = pfa_mk((float)k1, 2.f);
+    } else {
+        ldy(yv0, yoff);
+        ldy(yv1, yoff + 64);
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int n = l + 64 * i;
@@ -140,8 +154,12 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
         for (int n2 = 0; n2 < 31; ++n2) acc = pfa_add(acc, L.s[n2]);
 #pragma unroll
         for (int k1 = 0; k1 < 12; ++k1) acc = pfa_add(acc, pfa_add(yv0[k1], yv1[k1]));
+        {
+            pfa_c t2[12];
+            ldy(t2, d2);
 #pragma unroll
-        for (int k1 = 0; k1 < 12; ++k1) acc = pfa_add(acc, ytask[k1 * PFA_D + d2]);
+            for (int k1 = 0; k1 < 12; ++k1) acc = pfa_add(acc, t2[k1]);
+        }
         __syncthreads();
         X[PFA_RS + l] = acc;
         __syncthreads();
@@ -151,8 +169,12 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
     L372_STAMP(2)
     if (laneA) pfa372_stage_a(L, X, g1, n1);
     L372_STAMP(3)
+    if (ABL == 2) {
 #pragma unroll
-    for (int k1 = 0; k1 < 12; ++k1) yv2[k1] = ABL == 2 ? pfa_mk((float)k1, 3.f) : ytask[k1 * PFA_D + d2];
+        for (int k1 = 0; k1 < 12; ++k1) yv2[k1] = pfa_mk((float)k1, 3.f);
+    } else {
+        ldy(yv2, d2);
+    }
     __syncthreads();
     {
         const int nd = Cg * PFA_N2;
