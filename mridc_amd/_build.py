@@ -22,6 +22,7 @@ SOURCES = [
     ("rim_layer1_sb.hip", []),
     ("rim_layer2_sb.hip", []),
     ("gated_cell.hip", []),
+    ("gated_cell_sb.hip", []),
     ("conv_bwd.hip", []),
     ("conv_bf16.hip", []),
     ("conv_sbs.hip", []),

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "mrx_common.h"
+#include "gated_cell_sb.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -47,7 +48,7 @@ __global__ void k_gated_pack(const float* __restrict__ w_ih, const float* __rest
 
 extern "C" int64_t mrx_gated_cell_pack_floats(int Cin, int F, int gates) {
     if (Cin != GC_F || F != GC_F || (gates != 2 && gates != 3)) return -1;
-    return (int64_t)2 * gates * GC_F * GC_F;
+    return (int64_t)2 * gates * GC_F * GC_F + MRX_GATED_SB_PACK_FLOATS(gates);     // fp32 operands, then the split-bf16 ones (gated_cell_sb.hip)
 }
 
 extern "C" int mrx_gated_cell_supported(int Cin, int F, int k, int gates) {
@@ -61,7 +62,7 @@ extern "C" int mrx_gated_cell_pack(const float* w_ih, const float* w_hh, float* 
     const int total = 2 * gates * GC_F * GC_F;
     hipLaunchKernelGGL(k_gated_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh, packed, gates);
     MRX_LAUNCH_CHECK();
-    return MRX_OK;
+    return mrx_gated_sb_pack(w_ih, w_hh, packed + total, gates, (hipStream_t)stream);
 }
 
 // 1/(1+e^-x) and 1 - 2/(e^2x + 1) on the hardware exp2 / reciprocal: both saturate correctly (exp2 -> inf or 0), absolute error
@@ -255,6 +256,13 @@ extern "C" int mrx_gated_cell_1x1(const float* x, const float* h, const float* p
     a.P = HW;
     a.nsegb = (HW + 31) / 32;
     a.nseg = a.nsegb * B;
+    static const int fp32 = getenv("MRX_GATED_FP32") ? atoi(getenv("MRX_GATED_FP32")) : 0;   // 1: the fp32-MFMA kernel (cross-check)
+    if (!fp32) {                                  // default: the bf16 matrix pipe with fp32 results (gated_cell_sb.hip)
+        MrxGatedSbArgs s;
+        s.x = x, s.h = h, s.packed = packed + (size_t)2 * gates * GC_F * GC_F, s.b_ih = b_ih, s.out = out;
+        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg;
+        return mrx_gated_sb_launch(s, gates, (hipStream_t)stream);
+    }
     return gates == 3 ? launch_gated<3>(a, (hipStream_t)stream) : launch_gated<2>(a, (hipStream_t)stream);
 }
 

@@ -1,0 +1,17 @@
+// gated_cell_sb.h -- internal interface of the split-bf16 gated cell (gated_cell_sb.hip), used by gated_cell.hip's C entry points.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define MRX_GATED_SB_PACK_FLOATS(gates) (2 * (gates) * 2 * 4 * 3 * 64 * 4)   // three bf16 terms of the 2 * gates 64 x 64 matrices, A-operand lane order
+
+struct MrxGatedSbArgs {
+    const float* x;       // [B,64,P]
+    const float* h;       // [B,64,P] or null (= zeros)
+    const float* packed;  // mrx_gated_sb_pack
+    const float* b_ih;    // [GATES*64] or null
+    float* out;           // [B,64,P]
+    long long P, nsegb, nseg;  // pixels per image, 32-pixel segments per image, segments in total
+};
+
+int mrx_gated_sb_pack(const float* w_ih, const float* w_hh, float* packed, int gates, hipStream_t st);
+int mrx_gated_sb_launch(const MrxGatedSbArgs& a, int gates, hipStream_t st);

@@ -1,0 +1,225 @@
+// gated_cell_sb.hip -- ConvGRUCell / ConvMGUCell with 1x1 kernels on 64 features (reference models/rim/rnn_cells.py:112-127, :249-261) with
+// fp32 results on the bf16 matrix pipe.  The formulation of gated_cell.hip (a wave owns 32 consecutive pixels, x and h_prev straight from
+// HBM into the MFMA B-operand layout, all 2 * GATES weight matrices resident in LDS, ih + hh parts of the plain gates summed in one
+// accumulator, the candidate's parts apart, gate math on the accumulators), with every fp32 operand written as the exact sum of three bf16
+// terms and six term products per multiply (error O(2^-24): rim_layer1_sb.hip): 288 v_mfma_f32_32x32x16_bf16 of 32 cycles per 32 pixels for
+// the GRU instead of 384 v_mfma_f32_32x32x2_f32 of 64 -- and the bf16 MFMA co-issues with the vector ALU, which evaluates the gates.
+#include <cstdint>
+#include <cstdlib>
+
+#include "mrx_common.h"
+#include "gated_cell_sb.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define GS_NT 512
+#define GS_F 64
+
+__device__ __forceinline__ unsigned gs_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void gs_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = gs_pk(a, b);
+    float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = gs_pk(ra, rb);
+    ra -= __uint_as_float(p2 << 16);
+    rb -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = gs_pk(ra, rb);
+}
+__device__ __forceinline__ float gs_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float gs_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+
+// packed[(((mat * 2 + mb) * 4 + t) * 3 + term) * 64 + lane][j] = term( W_mat[mb * 32 + lane % 32][16 t + 8 (lane / 32) + j] ),
+// mat = gate (ih) | GATES + gate (hh)
+__global__ void k_gated_pack_sb(const float* __restrict__ w_ih, const float* __restrict__ w_hh, u32x4* __restrict__ out, int gates) {
+    const int total = 2 * gates * 2 * 4 * 3 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        int r = i >> 6;
+        const int term = r % 3;
+        r /= 3;
+        const int t = r & 3, mb = (r >> 2) & 1, mat = r >> 3;
+        const float* w = mat < gates ? w_ih : w_hh;
+        const int g = mat < gates ? mat : mat - gates;
+        const int row = g * GS_F + mb * 32 + (lane & 31), col0 = 16 * t + 8 * (lane >> 5);
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned p1, p2, p3;
+            gs_split2(w[(long long)row * GS_F + col0 + 2 * k], w[(long long)row * GS_F + col0 + 2 * k + 1], p1, p2, p3);
+            p[k] = term == 0 ? p1 : (term == 1 ? p2 : p3);
+        }
+        out[i] = u32x4{p[0], p[1], p[2], p[3]};
+    }
+}
+int mrx_gated_sb_pack(const float* w_ih, const float* w_hh, float* packed, int gates, hipStream_t st) {
+    const int total = 2 * gates * 2 * 4 * 3 * 64;
+    hipLaunchKernelGGL(k_gated_pack_sb, dim3((total + 255) / 256), dim3(256), 0, st, w_ih, w_hh, reinterpret_cast<u32x4*>(packed), gates);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+template <int GATES>  // 3 = GRU, 2 = MGU
+__global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gs[];
+    constexpr int NMAT = 2 * GATES, NW = NMAT * 2 * 4 * 3 * 64;       // 16-byte A operands
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem_gs);
+    float* Bs = reinterpret_cast<float*>(smem_gs + (size_t)NW * 16);   // ih bias [GATES][64]
+    const int tid = threadIdx.x;
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed);
+        for (int i = tid; i < NW; i += GS_NT) Wl[i] = src[i];
+        if (tid < GATES * GS_F) Bs[tid] = a.b_ih ? a.b_ih[tid] : 0.f;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const u32x4* wl = Wl + lane;
+
+    const long long stride = (long long)gridDim.x * (GS_NT / 64);
+    const unsigned P32 = (unsigned)a.P;
+    // operand registers: value (t, j) of a lane is channel 16 t + 8 lhi + j of its pixel (the k order of the 32x32x16 B operand)
+    float xg[4][8], hg[4][8];
+    const float* hb = nullptr;
+    long long base = 0;
+    unsigned pxo = 0;
+    bool valid = false;
+    int lhi = 0;
+    auto load = [&](long long sg) {
+        int l31 = lane & 31;
+        lhi = lane >> 5;
+        asm volatile("" : "+v"(l31), "+v"(lhi));      // (keeps the 64 channel offsets from being hoisted out of the segment loop and spilled)
+        const long long b = sg / a.nsegb;
+        const long long px = (sg - b * a.nsegb) * 32 + l31;
+        valid = px < a.P;
+        base = __builtin_amdgcn_readfirstlane((int)b) * (long long)GS_F * a.P;
+        pxo = valid ? (unsigned)px : 0u;               // lanes past the end read pixel 0 and store nothing
+        const float* xb = a.x + base;
+        hb = a.h ? a.h + base : nullptr;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xg[t][j] = xb[(unsigned)(16 * t + 8 * lhi + j) * P32 + pxo];
+    };
+    auto load_h = [&]() {
+        if (hb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hg[t][j] = hb[(unsigned)(16 * t + 8 * lhi + j) * P32 + pxo];
+        }
+    };
+    // one contraction step (16 channels) of `nmat` matrices starting at mat0 over the operand v[8]; dst(g) = accumulator of gate g
+    long long sg = (long long)blockIdx.x * (GS_NT / 64) + wave;
+    if (sg < a.nseg) load(sg);
+    while (sg < a.nseg) {
+        load_h();
+        // accumulator d: 0 .. GATES-2 = gates whose ih and hh parts add up; GATES-1 = candidate ih part; GATES = candidate hh part
+        f32x16 acc[GATES + 1][2];
+#pragma unroll
+        for (int d = 0; d < GATES + 1; ++d)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[d][ct][r] = d < GATES ? Bs[d * GS_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
+
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {             // 0: ih matrices over x, 1: hh matrices over h_prev
+            if (part == 1 && !hb) break;                  // (no previous state: the hh parts are zero)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (part == 0)
+                        gs_split2(xg[t][2 * k], xg[t][2 * k + 1], p1[k], p2[k], p3[k]);
+                    else
+                        gs_split2(hg[t][2 * k], hg[t][2 * k + 1], p1[k], p2[k], p3[k]);
+                }
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, (u32x4{p1[0], p1[1], p1[2], p1[3]}));
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, (u32x4{p2[0], p2[1], p2[2], p2[3]}));
+                const bf16x8 b3 = __builtin_bit_cast(bf16x8, (u32x4{p3[0], p3[1], p3[2], p3[3]}));
+#pragma unroll
+                for (int g = 0; g < GATES; ++g) {
+                    const int mat = part * GATES + g;
+                    const int d = (part == 1 && g == GATES - 1) ? GATES : g;   // the candidate's hh part stays separate
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const u32x4* q = wl + (((mat * 2 + mb) * 4 + t) * 3) * 64;
+                        const bf16x8 a1 = __builtin_bit_cast(bf16x8, q[0]);
+                        const bf16x8 a2 = __builtin_bit_cast(bf16x8, q[64]);
+                        const bf16x8 a3 = __builtin_bit_cast(bf16x8, q[128]);
+                        // the six term pairs of weight >= 2^-16, smallest first
+                        acc[d][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[d][mb], 0, 0, 0);
+                        acc[d][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[d][mb], 0, 0, 0);
+                        acc[d][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[d][mb], 0, 0, 0);
+                        acc[d][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[d][mb], 0, 0, 0);
+                        acc[d][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[d][mb], 0, 0, 0);
+                        acc[d][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[d][mb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- h_prev again, in accumulator layout (row (r, lane half) = channel, column = pixel): an L2 hit ---------------
+        float hv[2][16];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hv[ct][r] = hb ? hb[(unsigned)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo] : 0.f;
+        float* ob = a.out + base;
+        const unsigned o_pxo = pxo;
+        const int o_lhi = lhi;
+        const bool o_valid = valid;
+        // the x operand registers are free: the next segment's x loads fly while this one's gates are evaluated
+        sg += stride;
+        if (sg < a.nseg) load(sg);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lhi;
+                float o;
+                if constexpr (GATES == 3) {  // rnn_cells.py:118-127
+                    const float rg = gs_sigmoid(acc[0][ct][r]);
+                    const float z = gs_sigmoid(acc[1][ct][r]);
+                    const float n = gs_tanh(acc[2][ct][r] + rg * acc[3][ct][r]);
+                    o = n * (1.0f - z) + z * hv[ct][r];
+                } else {  // rnn_cells.py:255-261
+                    const float f = gs_sigmoid(acc[0][ct][r]);
+                    const float c = gs_tanh(acc[1][ct][r] + f * acc[2][ct][r]);
+                    o = c + f * (hv[ct][r] - c);
+                }
+                if (o_valid) ob[(unsigned)co * P32 + o_pxo] = o;
+            }
+    }
+}
+
+template <int GATES>
+static int launch_gated_sb(const MrxGatedSbArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)(2 * GATES * 2 * 4 * 3 * 64) * 16 + sizeof(float) * GATES * GS_F;
+    static_assert(lds <= 160 * 1024, "all weight matrices resident in LDS");
+    static bool attr_done = false;  // once per instantiation: keeps launches legal under hipGraph capture
+    static int n_cu = 0;
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_gated_cell_sb<GATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MRX_HIP(hipGetDevice(&dev));
+        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        attr_done = true;
+    }
+    const long long nblk_need = (a.nseg + GS_NT / 64 - 1) / (GS_NT / 64);
+    const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);  // persistent: the weights are staged once per workgroup
+    hipLaunchKernelGGL((k_gated_cell_sb<GATES>), dim3(nblk), dim3(GS_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+int mrx_gated_sb_launch(const MrxGatedSbArgs& a, int gates, hipStream_t st) {
+    return gates == 3 ? launch_gated_sb<3>(a, st) : launch_gated_sb<2>(a, st);
+}
