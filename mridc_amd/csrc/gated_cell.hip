@@ -417,7 +417,9 @@ __global__ __launch_bounds__(GC_NT, 2) void k_conv2dgru_cell(Conv2dGruArgs a) {
 #undef GC_GEMM
 }
 
-extern "C" int64_t mrx_conv2dgru_pack_floats(int F) { return F == GC_F ? (int64_t)6 * GC_F * GC_F : -1; }
+extern "C" int64_t mrx_conv2dgru_pack_floats(int F) {      // fp32 operands, then the split-bf16 ones (gated_cell_sb.hip)
+    return F == GC_F ? (int64_t)6 * GC_F * GC_F + MRX_CONV2DGRU_SB_PACK_FLOATS : -1;
+}
 extern "C" int mrx_conv2dgru_supported(int Cin, int F, int k) { return Cin == GC_F && F == GC_F && k == 1; }
 
 extern "C" int mrx_conv2dgru_pack(const float* w_update, const float* w_reset, const float* w_out, float* packed, int F, void* stream) {
@@ -426,7 +428,7 @@ extern "C" int mrx_conv2dgru_pack(const float* w_update, const float* w_reset, c
     hipLaunchKernelGGL(k_conv2dgru_pack, dim3((6 * GC_F * GC_F + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_update, w_reset, w_out,
                        packed);
     MRX_LAUNCH_CHECK();
-    return MRX_OK;
+    return mrx_conv2dgru_sb_pack(w_update, w_reset, w_out, packed + 6 * GC_F * GC_F, (hipStream_t)stream);
 }
 
 extern "C" int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const float* packed, const float* bias, float* out,
@@ -447,6 +449,13 @@ extern "C" int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const floa
     a.P = HW;
     a.nsegb = (HW + 31) / 32;
     a.nseg = a.nsegb * B;
+    static const int fp32 = getenv("MRX_GATED_FP32") ? atoi(getenv("MRX_GATED_FP32")) : 0;   // 1: the fp32-MFMA kernel (cross-check)
+    if (!fp32) {                                  // default: the bf16 matrix pipe with fp32 results (gated_cell_sb.hip)
+        MrxConv2dGruSbArgs s;
+        s.x = x, s.h = h, s.packed = packed + 6 * GC_F * GC_F, s.bias = bias, s.out = out, s.out_relu = out_relu;
+        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg;
+        return mrx_conv2dgru_sb_launch(s, (hipStream_t)stream);
+    }
     constexpr size_t lds = sizeof(float) * (6 * GC_F * GC_F + 3 * GC_F);
     static bool attr_done = false;
     if (!attr_done) {

@@ -15,3 +15,18 @@ struct MrxGatedSbArgs {
 
 int mrx_gated_sb_pack(const float* w_ih, const float* w_hh, float* packed, int gates, hipStream_t st);
 int mrx_gated_sb_launch(const MrxGatedSbArgs& a, int gates, hipStream_t st);
+
+#define MRX_CONV2DGRU_SB_PACK_FLOATS (6 * 2 * 4 * 3 * 64 * 4)
+
+struct MrxConv2dGruSbArgs {
+    const float* x;       // [B,64,P] layer input (after its conv + ReLU)
+    const float* h;       // [B,64,P] previous state of this layer or null (= zeros)
+    const float* packed;  // mrx_conv2dgru_sb_pack
+    const float* bias;    // [3][64]: update, reset, out
+    float* out;           // [B,64,P] new state
+    float* out_relu;      // [B,64,P] ReLU(new state) or null
+    long long P, nsegb, nseg;
+};
+
+int mrx_conv2dgru_sb_pack(const float* wu, const float* wr, const float* wo, float* packed, hipStream_t st);
+int mrx_conv2dgru_sb_launch(const MrxConv2dGruSbArgs& a, hipStream_t st);

@@ -223,3 +223,208 @@ static int launch_gated_sb(const MrxGatedSbArgs& a, hipStream_t st) {
 int mrx_gated_sb_launch(const MrxGatedSbArgs& a, int gates, hipStream_t st) {
     return gates == 3 ? launch_gated_sb<3>(a, st) : launch_gated_sb<2>(a, st);
 }
+
+// ---- Conv2dGRU layer of the Recurrent Variational Network (recurrentvarnet/conv2gru.py:139-157), 1x1 gates on 64 features -----------------
+//   update = sigmoid(Wu [x; h] + bu)   reset = sigmoid(Wr [x; h] + br)   delta = tanh(Wo [x; h * reset] + bo)
+//   h_new  = h * (1 - update) + delta * update          (also written as ReLU(h_new): the next layer's input, :157)
+// The formulation of k_conv2dgru_cell (gated_cell.hip) with the three-term operand split: h * reset is formed in the accumulator layout and
+// fed to the last GEMM as a B operand, eight accumulator registers per contraction step, the candidate's hh weights packed with their
+// contraction index in that order (register R = 8 t + j of lane half l holds channel 32 (R >> 4) + (R & 3) + 8 ((R & 15) >> 2) + 4 l).
+__host__ __device__ constexpr int gs_chan(int R, int half) { return 32 * (R >> 4) + (R & 3) + 8 * ((R & 15) >> 2) + 4 * half; }
+
+// mats 0..2: Wu, Wr, Wo columns 0..63 (x part); 3, 4: Wu, Wr columns 64..127 (h part); 5: Wo columns 64..127 in accumulator order
+__global__ void k_conv2dgru_pack_sb(const float* __restrict__ wu, const float* __restrict__ wr, const float* __restrict__ wo,
+                                    u32x4* __restrict__ out) {
+    const int total = 6 * 2 * 4 * 3 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        int r = i >> 6;
+        const int term = r % 3;
+        r /= 3;
+        const int t = r & 3, mb = (r >> 2) & 1, mat = r >> 3, half = lane >> 5;
+        const float* w = (mat == 0 || mat == 3) ? wu : (mat == 1 || mat == 4) ? wr : wo;
+        const int row = mb * 32 + (lane & 31);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = mat < 3 ? 16 * t + 8 * half + j : (mat < 5 ? GS_F + 16 * t + 8 * half + j : GS_F + gs_chan(8 * t + j, half));
+            v[j] = w[(long long)row * (2 * GS_F) + col];
+        }
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned p1, p2, p3;
+            gs_split2(v[2 * k], v[2 * k + 1], p1, p2, p3);
+            p[k] = term == 0 ? p1 : (term == 1 ? p2 : p3);
+        }
+        out[i] = u32x4{p[0], p[1], p[2], p[3]};
+    }
+}
+int mrx_conv2dgru_sb_pack(const float* wu, const float* wr, const float* wo, float* packed, hipStream_t st) {
+    const int total = 6 * 2 * 4 * 3 * 64;
+    hipLaunchKernelGGL(k_conv2dgru_pack_sb, dim3((total + 255) / 256), dim3(256), 0, st, wu, wr, wo, reinterpret_cast<u32x4*>(packed));
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// six term products of one (matrix, cout block, step) into an accumulator
+__device__ __forceinline__ void gs_mma6(f32x16& acc, const u32x4* q, bf16x8 b1, bf16x8 b2, bf16x8 b3) {
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, q[0]);
+    const bf16x8 a2 = __builtin_bit_cast(bf16x8, q[64]);
+    const bf16x8 a3 = __builtin_bit_cast(bf16x8, q[128]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(GS_NT, 1) void k_conv2dgru_cell_sb(MrxConv2dGruSbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gs[];
+    constexpr int NW = 6 * 2 * 4 * 3 * 64;
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem_gs);
+    float* Bs = reinterpret_cast<float*>(smem_gs + (size_t)NW * 16);   // biases [3][64]: update, reset, out
+    const int tid = threadIdx.x;
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed);
+        for (int i = tid; i < NW; i += GS_NT) Wl[i] = src[i];
+        if (tid < 3 * GS_F) Bs[tid] = a.bias ? a.bias[tid] : 0.f;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const u32x4* wl = Wl + lane;
+    const long long stride = (long long)gridDim.x * (GS_NT / 64);
+    const unsigned P32 = (unsigned)a.P;
+    float xg[4][8], hg[4][8];
+    const float* hb = nullptr;
+    long long base = 0;
+    unsigned pxo = 0;
+    bool valid = false;
+    int lhi = 0;
+    auto load = [&](long long sg) {  // see k_gated_cell_sb
+        int l31 = lane & 31;
+        lhi = lane >> 5;
+        asm volatile("" : "+v"(l31), "+v"(lhi));
+        const long long b = sg / a.nsegb;
+        const long long px = (sg - b * a.nsegb) * 32 + l31;
+        valid = px < a.P;
+        base = __builtin_amdgcn_readfirstlane((int)b) * (long long)GS_F * a.P;
+        pxo = valid ? (unsigned)px : 0u;
+        const float* xb = a.x + base;
+        hb = a.h ? a.h + base : nullptr;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xg[t][j] = xb[(unsigned)(16 * t + 8 * lhi + j) * P32 + pxo];
+    };
+    auto load_h = [&]() {
+        if (hb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hg[t][j] = hb[(unsigned)(16 * t + 8 * lhi + j) * P32 + pxo];
+        }
+    };
+    long long sg = (long long)blockIdx.x * (GS_NT / 64) + wave;
+    if (sg < a.nseg) load(sg);
+    while (sg < a.nseg) {
+        load_h();
+        f32x16 acc[3][2];  // 0 update, 1 reset (then h * reset), 2 candidate
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[d][ct][r] = Bs[d * GS_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+        // (Wu, Wr, Wo) x   and   (Wu, Wr) h
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            if (part == 1 && !hb) break;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (part == 0)
+                        gs_split2(xg[t][2 * k], xg[t][2 * k + 1], p1[k], p2[k], p3[k]);
+                    else
+                        gs_split2(hg[t][2 * k], hg[t][2 * k + 1], p1[k], p2[k], p3[k]);
+                }
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, (u32x4{p1[0], p1[1], p1[2], p1[3]}));
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, (u32x4{p2[0], p2[1], p2[2], p2[3]}));
+                const bf16x8 b3 = __builtin_bit_cast(bf16x8, (u32x4{p3[0], p3[1], p3[2], p3[3]}));
+#pragma unroll
+                for (int g = 0; g < (part == 0 ? 3 : 2); ++g)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) gs_mma6(acc[g][mb], wl + ((((part * 3 + g) * 2 + mb) * 4 + t) * 3) * 64, b1, b2, b3);
+            }
+        }
+        float hv[2][16];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hv[ct][r] = hb ? hb[(unsigned)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo] : 0.f;
+        float* ob = a.out + base;
+        float* orl = a.out_relu ? a.out_relu + base : nullptr;
+        const unsigned o_pxo = pxo;
+        const int o_lhi = lhi;
+        const bool o_valid = valid, have_h = hb != nullptr;
+        sg += stride;
+        if (sg < a.nseg) load(sg);  // next segment's x loads fly during the rest of this one
+        if (have_h) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[1][ct][r] = hv[ct][r] * gs_sigmoid(acc[1][ct][r]);
+            // Wo_h (h * reset): the B operand of step t is accumulator registers R = 8 t .. 8 t + 7
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int R0 = 8 * t + 2 * k, R1 = R0 + 1;
+                    gs_split2(acc[1][R0 >> 4][R0 & 15], acc[1][R1 >> 4][R1 & 15], p1[k], p2[k], p3[k]);
+                }
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, (u32x4{p1[0], p1[1], p1[2], p1[3]}));
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, (u32x4{p2[0], p2[1], p2[2], p2[3]}));
+                const bf16x8 b3 = __builtin_bit_cast(bf16x8, (u32x4{p3[0], p3[1], p3[2], p3[3]}));
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) gs_mma6(acc[2][mb], wl + (((5 * 2 + mb) * 4 + t) * 3) * 64, b1, b2, b3);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lhi;
+                const float u = gs_sigmoid(acc[0][ct][r]);
+                const float dl = gs_tanh(acc[2][ct][r]);
+                const float o = hv[ct][r] * (1.0f - u) + dl * u;
+                if (o_valid) {
+                    ob[(unsigned)co * P32 + o_pxo] = o;
+                    if (orl) orl[(unsigned)co * P32 + o_pxo] = o > 0.f ? o : 0.f;
+                }
+            }
+    }
+}
+int mrx_conv2dgru_sb_launch(const MrxConv2dGruSbArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)(6 * 2 * 4 * 3 * 64) * 16 + sizeof(float) * 3 * GS_F;
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv2dgru_cell_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MRX_HIP(hipGetDevice(&dev));
+        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        attr_done = true;
+    }
+    const long long nblk_need = (a.nseg + GS_NT / 64 - 1) / (GS_NT / 64);
+    const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);
+    hipLaunchKernelGGL(k_conv2dgru_cell_sb, dim3(nblk), dim3(GS_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
