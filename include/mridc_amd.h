@@ -431,6 +431,7 @@ int mrx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int mrx_conv1x1_64_pack(const float* w, float* packed, void* stream);
 /* the same for C = 64 or 128 channels (qCIRIM's 128-feature IndRNN cells): packed = C*C floats */
 int mrx_conv1x1_sq_supported(int Cin, int Cout);
+int64_t mrx_conv1x1_sq_pack_floats(int C);   /* floats of `packed` (the fp32 operands and, at C = 128, the split-bf16 ones) */
 int mrx_conv1x1_sq_pack(const float* w, float* packed, int C, void* stream);
 int mrx_conv1x1_sq(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
                    int B, int C, int64_t HW, int act, float slope, void* stream);

@@ -590,11 +590,17 @@ __global__ __launch_bounds__(GC_NT, (CB == 1 ? 4 : 2)) void k_conv1x1_sq(Conv1x1
     }
 }
 extern "C" int mrx_conv1x1_sq_supported(int Cin, int Cout) { return Cin == Cout && (Cin == 64 || Cin == 128); }
+// floats of the operand pack: the fp32 section and, at C = 128, the split-bf16 one (gated_cell_sb.hip: the default kernel at that width)
+extern "C" int64_t mrx_conv1x1_sq_pack_floats(int C) {
+    if (!mrx_conv1x1_sq_supported(C, C)) return -1;
+    return (int64_t)C * C + (C == 128 ? MRX_CONV1X1_SB128_PACK_FLOATS : 0);
+}
 extern "C" int mrx_conv1x1_sq_pack(const float* w, float* packed, int C, void* stream) {
     MRX_REQUIRE(w && packed, MRX_EINVAL, "mrx_conv1x1_sq_pack: null pointer");
     MRX_REQUIRE(mrx_conv1x1_sq_supported(C, C), MRX_EUNSUP, "mrx_conv1x1_sq_pack: C=%d (64 or 128)", C);
     hipLaunchKernelGGL(k_conv1x1_pack, dim3(C * C / 256), dim3(256), 0, (hipStream_t)stream, w, packed, C);
     MRX_LAUNCH_CHECK();
+    if (C == 128) return mrx_conv1x1_sb128_pack(w, packed + C * C, (hipStream_t)stream);
     return MRX_OK;
 }
 extern "C" int mrx_conv1x1_sq(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
@@ -618,6 +624,13 @@ extern "C" int mrx_conv1x1_sq(const float* x, const float* packed, const float* 
     a.nseg = a.nsegb * B;
     a.act = act;
     a.slope = slope;
+    static const int fp32 = getenv("MRX_GATED_FP32") ? atoi(getenv("MRX_GATED_FP32")) : 0;   // 1: the fp32-MFMA kernel (cross-check)
+    if (C == 128 && !fp32) {                      // default at 128 features: the bf16 matrix pipe with fp32 results
+        MrxConv1x1SbArgs s;
+        s.x = x, s.packed = packed + (size_t)C * C, s.bias = bias, s.hh = hh, s.hprev = h_prev, s.out = out;
+        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg, s.act = act, s.slope = slope;
+        return mrx_conv1x1_sb128_launch(s, (hipStream_t)stream);
+    }
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;

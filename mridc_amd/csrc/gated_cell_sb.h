@@ -30,3 +30,20 @@ struct MrxConv2dGruSbArgs {
 
 int mrx_conv2dgru_sb_pack(const float* wu, const float* wr, const float* wo, float* packed, hipStream_t st);
 int mrx_conv2dgru_sb_launch(const MrxConv2dGruSbArgs& a, hipStream_t st);
+
+#define MRX_CONV1X1_SB128_PACK_FLOATS (2 * 2 * 2 * 4 * 3 * 64 * 4)
+
+struct MrxConv1x1SbArgs {
+    const float* x;       // [B,128,P]
+    const float* packed;  // mrx_conv1x1_sb128_pack
+    const float* bias;    // [128] or null
+    const float* hh;      // [128] or null
+    const float* hprev;   // [B,128,P] or null
+    float* out;           // [B,128,P]
+    long long P, nsegb, nseg;
+    int act;
+    float slope;
+};
+
+int mrx_conv1x1_sb128_pack(const float* w, float* packed, hipStream_t st);
+int mrx_conv1x1_sb128_launch(const MrxConv1x1SbArgs& a, hipStream_t st);

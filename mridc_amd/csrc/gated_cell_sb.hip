@@ -428,3 +428,136 @@ int mrx_conv2dgru_sb_launch(const MrxConv2dGruSbArgs& a, hipStream_t st) {
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
+
+// ---- 1x1 convolution 128 -> 128 with the IndRNN cell as an optional epilogue: out = act(W x + bias [+ hh * h_prev]) ------------------------
+// (rnn_cells.py:384-391 for the 128-feature cells of the qRIM; the channel contraction of thin 3x3 convolutions, ops.conv3x3_taps).  The
+// fp32-MFMA kernel (k_conv1x1_sq<2>) spends half its time on the matrix pipe at this width; with the three-term split the layer is bound by
+// its three 33 MB tensors.  Weights (98 KB as split terms) resident in LDS, x loaded 64 channels at a time in the B-operand k order.
+// packed[((((ob * 2 + ib) * 2 + mb) * 4 + t) * 3 + term) * 64 + lane][j] = term( W[ob * 64 + mb * 32 + lane % 32][ib * 64 + 16 t + 8 (lane / 32) + j] )
+__global__ void k_conv1x1_pack_sb128(const float* __restrict__ w, u32x4* __restrict__ out) {
+    const int total = 2 * 2 * 2 * 4 * 3 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        int r = i >> 6;
+        const int term = r % 3;
+        r /= 3;
+        const int t = r & 3, mb = (r >> 2) & 1, ib = (r >> 3) & 1, ob = r >> 4;
+        const int row = ob * 64 + mb * 32 + (lane & 31), col0 = ib * 64 + 16 * t + 8 * (lane >> 5);
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned p1, p2, p3;
+            gs_split2(w[(long long)row * 128 + col0 + 2 * k], w[(long long)row * 128 + col0 + 2 * k + 1], p1, p2, p3);
+            p[k] = term == 0 ? p1 : (term == 1 ? p2 : p3);
+        }
+        out[i] = u32x4{p[0], p[1], p[2], p[3]};
+    }
+}
+int mrx_conv1x1_sb128_pack(const float* w, float* packed, hipStream_t st) {
+    const int total = 2 * 2 * 2 * 4 * 3 * 64;
+    hipLaunchKernelGGL(k_conv1x1_pack_sb128, dim3((total + 255) / 256), dim3(256), 0, st, w, reinterpret_cast<u32x4*>(packed));
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+__global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gs[];
+    constexpr int C = 128, NW = 2 * 2 * 2 * 4 * 3 * 64;
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem_gs);
+    float* Bs = reinterpret_cast<float*>(smem_gs + (size_t)NW * 16);   // bias [C], hh [C]
+    const int tid = threadIdx.x;
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed);
+        for (int i = tid; i < NW; i += GS_NT) Wl[i] = src[i];
+        if (tid < C) {
+            Bs[tid] = a.bias ? a.bias[tid] : 0.f;
+            Bs[C + tid] = a.hh ? a.hh[tid] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const u32x4* wl = Wl + lane;
+    const long long stride = (long long)gridDim.x * (GS_NT / 64);
+    const unsigned P32 = (unsigned)a.P;
+    const float neg = a.act == MRX_ACT_RELU ? 0.f : (a.act == MRX_ACT_LEAKY ? a.slope : 1.f);
+    for (long long sg = (long long)blockIdx.x * (GS_NT / 64) + wave; sg < a.nseg; sg += stride) {
+        int l31 = lane & 31, lhi = lane >> 5;
+        asm volatile("" : "+v"(l31), "+v"(lhi));  // keep the channel offsets out of loop-invariant hoisting (spills)
+        const long long b = sg / a.nsegb;
+        const long long px = (sg - b * a.nsegb) * 32 + l31;
+        const bool valid = px < a.P;
+        const long long base = __builtin_amdgcn_readfirstlane((int)b) * (long long)C * a.P;
+        const unsigned pxo = valid ? (unsigned)px : 0u;
+        const float* xb = a.x + base;
+        float xg[2][4][8];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xg[ib][t][j] = xb[(unsigned)(ib * 64 + 16 * t + 8 * lhi + j) * P32 + pxo];
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ob][ct][r] = Bs[ob * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gs_split2(xg[ib][t][2 * k], xg[ib][t][2 * k + 1], p1[k], p2[k], p3[k]);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, (u32x4{p1[0], p1[1], p1[2], p1[3]}));
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, (u32x4{p2[0], p2[1], p2[2], p2[3]}));
+                const bf16x8 b3 = __builtin_bit_cast(bf16x8, (u32x4{p3[0], p3[1], p3[2], p3[3]}));
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) gs_mma6(acc[ob][mb], wl + (((((ob * 2 + ib) * 2 + mb) * 4 + t) * 3)) * 64, b1, b2, b3);
+            }
+        float* ob_ = a.out + base;
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            float hv[2][16];
+            if (a.hprev) {
+                const float* hb = a.hprev + base;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hv[ct][r] = hb[(unsigned)(ob * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo];
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = ob * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float v = acc[ob][ct][r];
+                    if (a.hprev) v += Bs[C + co] * hv[ct][r];
+                    v = v > 0.f ? v : v * neg;
+                    if (valid) ob_[(unsigned)co * P32 + pxo] = v;
+                }
+        }
+    }
+}
+int mrx_conv1x1_sb128_launch(const MrxConv1x1SbArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)(2 * 2 * 2 * 4 * 3 * 64) * 16 + sizeof(float) * 2 * 128;
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv1x1_sb128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MRX_HIP(hipGetDevice(&dev));
+        MRX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        attr_done = true;
+    }
+    const long long nblk_need = (a.nseg + GS_NT / 64 - 1) / (GS_NT / 64);
+    const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);
+    hipLaunchKernelGGL(k_conv1x1_sb128, dim3(nblk), dim3(GS_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

@@ -541,7 +541,7 @@ def _conv1x1_pack(weight):
             _PACKS_1X1.pop(next(iter(_PACKS_1X1)))
         w = _lib.f32c(weight.detach())
         C = int(w.shape[0])
-        packed = torch.empty(C * C, dtype=torch.float32, device=w.device)
+        packed = torch.empty(int(_lib.lib().mrx_conv1x1_sq_pack_floats(C)), dtype=torch.float32, device=w.device)
         _lib.check(_lib.lib().mrx_conv1x1_sq_pack(_lib.ptr(w), _lib.ptr(packed), C, _lib.stream_ptr()), "mrx_conv1x1_sq_pack")
         hit = _PACKS_1X1[key] = (packed, weight.detach())
     return hit[0]
