@@ -83,6 +83,12 @@ def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=Fals
         _lib.check(_lib.lib().mrx_pfa372_expand(_lib.ptr(x), _lib.ptr(_sp372(sens, centered)), _lib.ptr(out), None, None, None, 0, None, None,
                                                 B, C, H, _norm(normalization), int(bool(centered)), _lib.stream_ptr()), "mrx_pfa372_expand")
         return out
+    if not hybrid and _pfa372_ok(sens):      # W = 372: the prime-factor row pass, then the column pass in place (fft2 = FFT_H after FFT_W)
+        _lib.check(_lib.lib().mrx_pfa372_expand(_lib.ptr(x), _lib.ptr(_sp372(sens, centered)), _lib.ptr(out), None, None, None, 0, None, None,
+                                                B, C, H, _norm(normalization), int(bool(centered)), _lib.stream_ptr()), "mrx_pfa372_expand")
+        _lib.check(_lib.lib().mrx_fft_cols(_lib.ptr(out), _lib.ptr(out), B * C, H, W, 0, _norm(normalization), int(bool(centered)),
+                                           _lib.stream_ptr()), "mrx_fft_cols")
+        return out
     fn = _lib.lib().mrx_sens_expand_rows if hybrid else _lib.lib().mrx_sens_expand
     _lib.check(fn(_lib.ptr(x), _lib.ptr(sens), _lib.ptr(out), B, C, H, W, _norm(normalization), int(bool(centered)), _lib.stream_ptr()),
                "mrx_sens_expand")
@@ -136,8 +142,14 @@ def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None, 
     if sens.shape != k.shape:
         raise ValueError(f"sens_reduce: k-space {tuple(k.shape)} vs maps {tuple(sens.shape)}")
     _check_last_two(spatial_dims, 4)
-    if hybrid and _pfa372_ok(sens):
+    if _pfa372_ok(sens):                      # W = 372: the prime-factor row pass (after the column pass when k is not in hybrid space yet)
         L = _lib.lib()
+        if not hybrid:
+            if work is None:
+                work = torch.empty_like(k)
+            _lib.check(L.mrx_fft_cols(_lib.ptr(k), _lib.ptr(work), B * C, H, W, 1, _norm(normalization), int(bool(centered)),
+                                      _lib.stream_ptr()), "mrx_fft_cols")
+            k = work
         out = torch.empty(B, H, W, 2, dtype=torch.float32, device=k.device)
         wk = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=k.device)
         _lib.check(L.mrx_pfa372_reduce(_lib.ptr(k), _lib.ptr(_sp372(sens, centered)), None, _lib.ptr(out), None, _lib.ptr(wk), B, C, H, 1.0,
