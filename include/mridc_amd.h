@@ -431,6 +431,9 @@ int mrx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int mrx_conv1x1_64_pack(const float* w, float* packed, void* stream);
 /* the same for C = 64 or 128 channels (qCIRIM's 128-feature IndRNN cells): packed = C*C floats */
 int mrx_conv1x1_sq_supported(int Cin, int Cout);
+/* mrx_conv1x1_sq_head128: out [B,64,P] = the first 64 rows of a 128 x 128 matrix times x (no bias / epilogue): the channel contraction of a
+ * thin 3x3 convolution of 128 channels (<= 7 output channels' 9 tap rows) without the unused outputs. */
+int mrx_conv1x1_sq_head128(const float* x, const float* packed, float* out, int B, int64_t HW, void* stream);
 int64_t mrx_conv1x1_sq_pack_floats(int C);   /* floats of `packed` (the fp32 operands and, at C = 128, the split-bf16 ones) */
 int mrx_conv1x1_sq_pack(const float* w, float* packed, int C, void* stream);
 int mrx_conv1x1_sq(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,

@@ -102,6 +102,7 @@ _SIGNATURES = {
     "mrx_sens_expand_rows_dc": ([_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_conv1x1_sq_supported": ([_i, _i], _i),
     "mrx_conv1x1_sq_pack_floats": ([_i], _i64),
+    "mrx_conv1x1_sq_head128": ([_p, _p, _p, _i, _i64, _p], _i),
     "mrx_conv1x1_sq_pack": ([_p, _p, _i, _p], _i),
     "mrx_conv1x1_sq": ([_p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _f, _p], _i),
     "mrx_concat_channels": ([_p, _p, _p, _i, _i, _i, _i64, _p], _i),

@@ -628,7 +628,7 @@ extern "C" int mrx_conv1x1_sq(const float* x, const float* packed, const float* 
     if (C == 128 && !fp32) {                      // default at 128 features: the bf16 matrix pipe with fp32 results
         MrxConv1x1SbArgs s;
         s.x = x, s.packed = packed + (size_t)C * C, s.bias = bias, s.hh = hh, s.hprev = h_prev, s.out = out;
-        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg, s.act = act, s.slope = slope;
+        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg, s.act = act, s.slope = slope, s.head = 0;
         return mrx_conv1x1_sb128_launch(s, (hipStream_t)stream);
     }
     static int n_cu = 0;
@@ -655,6 +655,18 @@ extern "C" int mrx_conv1x1_sq(const float* x, const float* packed, const float* 
     }
     MRX_LAUNCH_CHECK();
     return MRX_OK;
+}
+
+// out [B,64,P] = the first 64 rows of W (128 x 128) times x [B,128,P]: the channel contraction of a thin 3x3 convolution of 128 channels
+// (9 Cout <= 64 tap rows, ops.conv3x3_taps) without the unused half of the outputs.  packed from mrx_conv1x1_sq_pack(w, ., 128).
+extern "C" int mrx_conv1x1_sq_head128(const float* x, const float* packed, float* out, int B, int64_t HW, void* stream) {
+    MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv1x1_sq_head128: null pointer");
+    MRX_REQUIRE(B >= 0 && HW >= 0 && HW < (1ll << 24) && B < (1 << 30), MRX_EINVAL, "mrx_conv1x1_sq_head128: bad dims");
+    if (B == 0 || HW == 0) return MRX_OK;
+    MrxConv1x1SbArgs s;
+    s.x = x, s.packed = packed + (size_t)128 * 128, s.bias = nullptr, s.hh = nullptr, s.hprev = nullptr, s.out = out;
+    s.P = HW, s.nsegb = (HW + 31) / 32, s.nseg = s.nsegb * B, s.act = MRX_ACT_NONE, s.slope = 0.f, s.head = 1;
+    return mrx_conv1x1_sb128_launch(s, (hipStream_t)stream);
 }
 // 64-channel forms kept as named entry points
 extern "C" int mrx_conv1x1_64_pack(const float* w, float* packed, void* stream) { return mrx_conv1x1_sq_pack(w, packed, 64, stream); }

@@ -43,6 +43,7 @@ struct MrxConv1x1SbArgs {
     long long P, nsegb, nseg;
     int act;
     float slope;
+    int head;             // 1: only the first 64 output channels, out [B,64,P]
 };
 
 int mrx_conv1x1_sb128_pack(const float* w, float* packed, hipStream_t st);

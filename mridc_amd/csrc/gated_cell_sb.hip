@@ -460,6 +460,8 @@ int mrx_conv1x1_sb128_pack(const float* w, float* packed, hipStream_t st) {
     return MRX_OK;
 }
 
+// NOB: output blocks of 64 channels computed (1: the first 64 rows of W only, out [B,64,P] -- the contraction of a thin 3x3 convolution)
+template <int NOB>
 __global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gs[];
     constexpr int C = 128, NW = 2 * 2 * 2 * 4 * 3 * 64;
@@ -496,9 +498,9 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) 
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xg[ib][t][j] = xb[(unsigned)(ib * 64 + 16 * t + 8 * lhi + j) * P32 + pxo];
-        f32x16 acc[2][2];
+        f32x16 acc[NOB][2];
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+        for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -514,13 +516,13 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) 
                 const bf16x8 b2 = __builtin_bit_cast(bf16x8, (u32x4{p2[0], p2[1], p2[2], p2[3]}));
                 const bf16x8 b3 = __builtin_bit_cast(bf16x8, (u32x4{p3[0], p3[1], p3[2], p3[3]}));
 #pragma unroll
-                for (int ob = 0; ob < 2; ++ob)
+                for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb) gs_mma6(acc[ob][mb], wl + (((((ob * 2 + ib) * 2 + mb) * 4 + t) * 3)) * 64, b1, b2, b3);
             }
-        float* ob_ = a.out + base;
+        float* ob_ = a.out + (NOB == 2 ? base : __builtin_amdgcn_readfirstlane((int)b) * (long long)64 * a.P);
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
+        for (int ob = 0; ob < NOB; ++ob) {
             float hv[2][16];
             if (a.hprev) {
                 const float* hb = a.hprev + base;
@@ -547,7 +549,8 @@ int mrx_conv1x1_sb128_launch(const MrxConv1x1SbArgs& a, hipStream_t st) {
     static bool attr_done = false;
     static int n_cu = 0;
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_conv1x1_sb128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv1x1_sb128<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv1x1_sb128<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         hipDeviceProp_t prop;
         MRX_HIP(hipGetDevice(&dev));
@@ -557,7 +560,10 @@ int mrx_conv1x1_sb128_launch(const MrxConv1x1SbArgs& a, hipStream_t st) {
     }
     const long long nblk_need = (a.nseg + GS_NT / 64 - 1) / (GS_NT / 64);
     const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);
-    hipLaunchKernelGGL(k_conv1x1_sb128, dim3(nblk), dim3(GS_NT), lds, st, a);
+    if (a.head)
+        hipLaunchKernelGGL(k_conv1x1_sb128<1>, dim3(nblk), dim3(GS_NT), lds, st, a);
+    else
+        hipLaunchKernelGGL(k_conv1x1_sb128<2>, dim3(nblk), dim3(GS_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

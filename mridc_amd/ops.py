@@ -689,12 +689,17 @@ def conv3x3_taps(x, weight, bias, pad_mode=PAD_ZERO, out=None):
         wp[:9 * Cout] = _lib.f32c(weight.detach()).reshape(Cout, Cin, 9).permute(2, 0, 1).reshape(9 * Cout, Cin, 1, 1)
         w1 = (wp, weight)                                   # (the entry keeps the source tensor alive: its data_ptr cannot be recycled)
         _TAPS_W[key] = w1
-    taps = conv1x1_64(x, w1[0])
+    if Cin == 128:                           # only the first 64 of the 128 padded rows are needed (9 Cout <= 36)
+        taps = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mrx_conv1x1_sq_head128(_lib.ptr(x), _lib.ptr(_conv1x1_pack(w1[0])), _lib.ptr(taps), B, H * W, _lib.stream_ptr()),
+                   "mrx_conv1x1_sq_head128")
+    else:
+        taps = conv1x1_64(x, w1[0])
     b = _lib.f32c(bias.detach()) if bias is not None else None
     if out is None:
         out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().mrx_taps_gather(_lib.ptr(taps), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W, int(pad_mode), _lib.stream_ptr()),
-               "mrx_taps_gather")
+    _lib.check(_lib.lib().mrx_taps_gather(_lib.ptr(taps), _lib.ptr(b), _lib.ptr(out), B, int(taps.shape[1]), Cout, H, W, int(pad_mode),
+                                          _lib.stream_ptr()), "mrx_taps_gather")
     return out
 
 
