@@ -780,6 +780,7 @@ def main():
         l1_bf16 = F_hidden == 64 and os.environ.get("MRX_LAYER1_FP32", "0") in ("", "0")
         issued1_bf16 = (132 * 32 * 32 * 16 * 2 / 32.0) * npix * B if l1_bf16 else 0.0
         issued2_bf16 = executed if l2_bf16 else 0.0
+        issued_l1_only = issued1_bf16             # layer 1's own bf16 MFMA work (for layer1_frac_issued)
         issued1_bf16 += issued2_bf16             # everything issued on the bf16 pipe
         issued_reg = flops_reg - (flops2 if l2_bf16 else flops2 - executed) - (flops1 if l1_bf16 else 0.0)      # fp32 part (none left with the final conv in layer 2's tail)
         pipe_ms = lambda f32, b16: 1e3 * (f32 / (PEAK_FP32_MFMA_TFLOPS * 1e12) + b16 / (PEAK_BF16_MFMA_TFLOPS * 1e12))  # noqa: E731
@@ -807,7 +808,7 @@ def main():
                                               "matrix pipe + a 9-tap gather (default), or -- MRIDC_AMD_FUSED_FINAL=0 -- on the vector ALUs (its 0.55 GFLOP counted at the fp32 rate).  frac_issued = (fp32 work / fp32 peak + bf16 work / "
                                               "dense bf16 peak) / measured time",
                                          layer1_ms=ms1, layer1_kernel="k_rim_layer1_sb" if l1_bf16 else "k_rim_layer<5,1,4>",
-                                         layer1_frac_issued=(pipe_ms(0.0 if l1_bf16 else flops1, issued1_bf16) / ms1) if ms1 else None,
+                                         layer1_frac_issued=(pipe_ms(0.0 if l1_bf16 else flops1, issued_l1_only) / ms1) if ms1 else None,
                                          layer1_hbm_frac=((2.0 * F_hidden + 8.0) * 4 * npix * B / (ms1 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms1 else None,   # h_prev in, h out, (eta, partial sums)
                                          # the two kernels that run on the matrix cores, on their own
                                          mfma_kernels_ms=(ms1 or 0) + (ms2 or 0),

@@ -175,6 +175,21 @@ int mrx_pfa372_expand_reduce(const float* x, const float* Sp, float* out, const 
                              int norm, int centered, void* stream);
 int mrx_llg_cols_dc(float* work, const float* y, const void* mask, int mask_kind, const int64_t* mstride, int B, int C, int H, int W,
                     int norm, int centered, void* stream);
+/* The same three passes with the coil stack between them column-tiled, [B*C][W/4][H][4] complex (every 4-column tile of an image is one
+ * contiguous block of H * 32 bytes), so that the column pass moves contiguous blocks (rim_utils.py:44-62 for masks that depend on the row):
+ *   mrx_tile4_cols          x [nimg,H,W,2] -> [nimg][W/4][H][4] complex (the measured data, once per slice; W % 4 == 0)
+ *   mrx_pfa372_expand_t4    out_t4 = FFT_W(x * S) in the tiled layout
+ *   mrx_llg_cols_dc_t4      FFT_H -> mask * (k - y) -> IFFT_H in place on work_t4 (y_t4 tiled; mask indexed [b,c,h,w] as everywhere);
+ *                           mrx_llg_cols_dc_t4_supported(H, W): H <= 2048 and W % 4 == 0
+ *   mrx_pfa372_reduce_t4    post * sum_c conj(S) IFFT_W(k_t4): out4 [B,4,H,372] = (eta, that), or with nparts != NULL the coil-group partial
+ *                           sums left in work ([*nparts][B,H,372,2]) for mrx_rim_layer_indrnn_packed_llg; work: mrx_llg372_work_floats */
+int mrx_tile4_cols(const float* x, float* out, int64_t nimg, int H, int W, void* stream);
+int mrx_pfa372_expand_t4(const float* x, const float* Sp, float* out_t4, int B, int C, int H, int norm, int centered, void* stream);
+int mrx_llg_cols_dc_t4(float* work_t4, const float* y_t4, const void* mask, int mask_kind, const int64_t* mstride, int B, int C, int H,
+                       int W, int norm, int centered, void* stream);
+int mrx_llg_cols_dc_t4_supported(int H, int W);
+int mrx_pfa372_reduce_t4(const float* k_t4, const float* Sp, const float* eta, float* out4, float* work, int* nparts, int B, int C, int H,
+                         float post, int norm, int centered, void* stream);
 int mrx_rim_layer_indrnn_packed_llg(const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,
                                     const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
                                     float* h_new, int B, int F, int H, int W, int k, int dil, void* stream);

@@ -94,6 +94,11 @@ _SIGNATURES = {
     "mrx_pfa372_expand_reduce": ([_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_pfa372_reduce": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_llg_cols_dc": ([_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_tile4_cols": ([_p, _p, _i64, _i, _i, _p], _i),
+    "mrx_pfa372_expand_t4": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_llg_cols_dc_t4": ([_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_llg_cols_dc_t4_supported": ([_i, _i], _i),
+    "mrx_pfa372_reduce_t4": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_rim_layer_indrnn_packed_llg": ([_p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_conv1x1_64_pack": ([_p, _p, _p], _i),
     "mrx_conv1x1_64": ([_p, _p, _p, _p, _p, _p, _i, _i64, _i, _f, _p], _i),

@@ -322,7 +322,8 @@ class RIMBlock(torch.nn.Module):
         # first layer reading (eta, partial coil sums) itself: the gradient's last pass (sum + 1/sigma^2 + channel split) is free in
         # its tile loader and the [B,4,H,W] tensor is never written
         l0 = self.layers[0] if len(self.layers) else None
-        defer = (hinv and l0 is not None and self._fusable(l0) and l0.convs.input_size == 4
+        t4 = not hinv and self.coil_dim == 1 and ops._pfa372_ok(sense) and ops.llg_t4_supported(masked_kspace)
+        defer = ((hinv or t4) and l0 is not None and self._fusable(l0) and l0.convs.input_size == 4
                  and ops.rim_layer_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)
                  and not (self.winograd and ops.rim_layer_wino_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)))
         for step in range(self.time_steps):                          # rim_block.py:217-249
@@ -330,6 +331,9 @@ class RIMBlock(torch.nn.Module):
             if defer:
                 if op372 is not None:
                     part, nparts = ops.llg372(eta, op372, sigma, self.fft_normalization, parts=True)
+                elif t4:                                             # any mask at W = 372: three passes on the column-tiled coil stack
+                    part, nparts = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
+                                           self.spatial_dims, work=work, parts=True)
                 else:
                     grad_eta, part, nparts = ops.llg_hinv_parts(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
                 if nparts > 0:

@@ -31,7 +31,14 @@ struct L372Args {
     int mask_bstride;     // floats between the batch entries of maskp (0: one mask for the whole batch)
     long long ntasks;     // B * H * T
     float scale_f, scale_i;
+    int tiled;            // row kernels of the general-mask gradient: the coil stack is column-tiled (fft.hip: [B*C][93][H][4]), not row-major
 };
+// element (image bc, row h, column w) of the coil stack between the row and the column pass
+// = l372_kbase(image bc, row h) + l372_kcol(column w)
+__device__ __forceinline__ long long l372_kbase(const L372Args& a, long long bc, int h) {
+    return a.tiled ? bc * ((long long)a.H * PFA_N) + (long long)h * 4 : (bc * a.H + h) * PFA_N;
+}
+__device__ __forceinline__ int l372_kcol(const L372Args& a, int w) { return a.tiled ? (w >> 2) * (a.H * 4) + (w & 3) : w; }
 
 // ---- once per slice: operands in lane order ------------------------------------------------------------------------------------------
 __global__ void k_llg372_prep(const float2* __restrict__ yt, const float2* __restrict__ S, float2* __restrict__ ytp,
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restric
     for (int g = 0; g < Cg; ++g) {
         const int c = z * PFA_G + g;
         const long long base = (((long long)b * a.C + c) * a.H + h) * PFA_N;
+        pfa_c* orow = reinterpret_cast<pfa_c*>(out_) + l372_kbase(a, (long long)b * a.C + c, (int)h);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int n = l + 64 * i;
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restric
                     const float sx = m ? (p_.x - rf.x) * w : 0.f, sy = m ? (p_.y - rf.y) * w : 0.f;   // vn_block.py:109-110
                     r = pfa_mk(p_.x - sx - r[0], p_.y - sy - r[1]);                                      // vn_block.py:119
                 }
-                reinterpret_cast<pfa_c*>(out_)[base + wcol] = r;
+                orow[l372_kcol(a, wcol)] = r;
                 if (RED) X[g * PFA_RS + n] = r;
             }
         }
@@ -379,11 +387,11 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_reduce(const float2* __restric
     // the task's k-space rows, contiguous per coil -> LDS in transform order
     for (int g = 0; g < PFA_G; ++g) {
         const int c = min(z * PFA_G + g, a.C - 1);
-        const pfa_c* krow = kin + (((long long)b * a.C + c) * a.H + h) * PFA_N;
+        const pfa_c* krow = kin + l372_kbase(a, (long long)b * a.C + c, (int)h);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int n = l + 64 * i;
-            if (n < PFA_N) X[g * PFA_RS + n] = g < Cg ? krow[pfa372_shift(n, a.halfW)] : pfa_mk(0.f, 0.f);
+            if (n < PFA_N) X[g * PFA_RS + n] = g < Cg ? krow[l372_kcol(a, pfa372_shift(n, a.halfW))] : pfa_mk(0.f, 0.f);
         }
     }
     Pfa372Lane L;
@@ -483,6 +491,7 @@ static int l372_args(L372Args* a, int B, int C, int H, int norm, int centered, i
     a->ntasks = (long long)B * H * a->T;
     a->scale_f = l372_scale(0, norm);
     a->scale_i = l372_scale(1, norm);
+    a->tiled = 0;
     return MRX_OK;
 }
 
@@ -685,6 +694,61 @@ extern "C" int mrx_pfa372_reduce(const float* k, const float* Sp, const float* e
                            (long long)B, plane, post);
     else
         hipLaunchKernelGGL(k_pfa372_sum, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)work, (float2*)out, a.T, total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- general (row-dependent) masks: log_likelihood_gradient = row pass, column pass + DC (fft.hip: mrx_llg_cols_dc_t4), row pass -----------
+// The coil stack between the passes is column-tiled, [B*C][93][H][4] complex (every 4-column tile of an image is one contiguous block of
+// H * 32 bytes): the row kernels write / read 32-byte pieces, which neighbouring rows complete to whole lines in L2, and the column
+// pass moves contiguous blocks.  Same arithmetic as mrx_pfa372_expand / mrx_pfa372_reduce (only the addresses differ).
+extern "C" int mrx_pfa372_expand_t4(const float* x, const float* Sp, float* out_t4, int B, int C, int H, int norm, int centered,
+                                    void* stream) {
+    MRX_REQUIRE(x && Sp && out_t4, MRX_EINVAL, "mrx_pfa372_expand_t4: null pointer");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, 0);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_pfa372_expand_t4: too many tasks");
+    MRX_REQUIRE((long long)H * PFA_N < (1ll << 31), MRX_EUNSUP, "mrx_pfa372_expand_t4: image too tall");
+    a.tiled = 1;
+    L372Dc dc;
+    dc.on = 0;
+    dc.pred = dc.ref = nullptr, dc.w = nullptr;
+    dc.mask.p = nullptr, dc.mask.kind = MRX_MASK_U8;
+    for (int i = 0; i < 4; ++i) dc.mask.s[i] = 0;
+    hipLaunchKernelGGL(k_pfa372_expand<false>, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
+                       (const float2*)Sp, (float2*)out_t4, a, dc, (float2*)nullptr);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// post * sum_c conj(S) IFFT_W(k_t4) with eta -> out4 [B,4,H,372] (rim_utils.py:59-67), or, with nparts != NULL, the coil-group partial sums
+// left in `work` ([*nparts][B,H,372,2]) for a consumer that adds them itself (mrx_rim_layer_indrnn_packed_llg).
+// work: mrx_llg372_work_floats(B,C,H) floats.
+extern "C" int mrx_pfa372_reduce_t4(const float* k_t4, const float* Sp, const float* eta, float* out4, float* work, int* nparts, int B, int C,
+                                    int H, float post, int norm, int centered, void* stream) {
+    MRX_REQUIRE(k_t4 && Sp && work && (nparts || (out4 && eta)), MRX_EINVAL, "mrx_pfa372_reduce_t4: null pointer");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, 0);
+    if (rc) return rc;
+    if (nparts) *nparts = 0;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_pfa372_reduce_t4: too many tasks");
+    MRX_REQUIRE((long long)H * PFA_N < (1ll << 31), MRX_EUNSUP, "mrx_pfa372_reduce_t4: image too tall");
+    a.tiled = 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_pfa372_reduce, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, st, (const float2*)k_t4, (const float2*)Sp,
+                       (float2*)work, a);
+    if (nparts) {
+        *nparts = a.T;
+        MRX_LAUNCH_CHECK();
+        return MRX_OK;
+    }
+    const long long plane = (long long)H * PFA_N, total = plane * B;
+    long long nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_llg372_combine, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)eta, (const float2*)work, out4, a.T, (long long)B,
+                       plane, post);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

@@ -3,6 +3,7 @@
 Each wrapper validates shapes, allocates the output with torch (torch owns device memory), and launches the HIP
 kernels on the current stream.  No arithmetic happens in Python/torch here.
 """
+import ctypes
 import os
 
 import torch
@@ -168,8 +169,34 @@ def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None, 
     return out
 
 
-def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, out=None, work=None):
-    """log_likelihood_gradient -> [B,4,H,W]."""
+LLG_T4 = os.environ.get("MRIDC_AMD_LLG_T4", "1") != "0"
+_Y_T4 = {}
+
+
+def llg_t4_supported(y):
+    """General-mask gradient at W = 372 on the column-tiled coil stack (mrx_pfa372_expand_t4 / mrx_llg_cols_dc_t4 / mrx_pfa372_reduce_t4)."""
+    return (LLG_T4 and PFA372 and y.dim() == 5 and int(y.shape[3]) == 372
+            and bool(_lib.lib().mrx_llg_cols_dc_t4_supported(int(y.shape[2]), int(y.shape[3]))))
+
+
+def _y_t4(y):
+    """The measured k-space in the column-tiled layout [B*C][W/4][H][4] (mrx_tile4_cols), cached per (storage, version) like _sp372:
+    it is constant over the steps and cascades of a slice."""
+    key = (y.data_ptr(), y._version, str(y.device), tuple(y.shape))
+    hit = _Y_T4.get(key)
+    if hit is None:
+        if len(_Y_T4) >= 4:
+            _Y_T4.pop(next(iter(_Y_T4)))
+        B, C, H, W = _bchw(y)
+        t4 = torch.empty_like(y)
+        _lib.check(_lib.lib().mrx_tile4_cols(_lib.ptr(y), _lib.ptr(t4), B * C, H, W, _lib.stream_ptr()), "mrx_tile4_cols")
+        hit = _Y_T4[key] = (t4, y.detach())
+    return hit[0]
+
+
+def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, out=None, work=None, parts=False):
+    """log_likelihood_gradient -> [B,4,H,W].  `parts` (llg_t4_supported only): returns (part [n][B,H,W,2], n) -- the coil-group partial sums
+    of the last pass, for rim_layer_indrnn_packed_llg, which adds them, scales by 1/sigma^2 and splits the channels in its tile loader."""
     y, sens, eta = _lib.f32c(y), _lib.f32c(sens), _lib.f32c(eta)
     B, C, H, W = _bchw(y)
     if sens.shape != y.shape:
@@ -178,15 +205,31 @@ def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, o
         raise ValueError(f"log_likelihood_gradient: eta {tuple(eta.shape)} does not match {(B, H, W, 2)}")
     _check_last_two(spatial_dims, 4)
     m, kind, ms = _lib.mask_args(mask, B, C, H, W)
-    if out is None:
+    if out is None and not parts:
         out = torch.empty(B, 4, H, W, dtype=torch.float32, device=y.device)
     if work is None:
         work = torch.empty_like(y)
+    if parts and not (_pfa372_ok(sens) and llg_t4_supported(y)):
+        raise ValueError("llg(parts=True) needs the column-tiled W = 372 path (llg_t4_supported)")
     if _pfa372_ok(sens):
         # W = 372: the two row passes on the prime-factor kernels (maps in lane order, cached per slice), the column pass + DC between them
         L = _lib.lib()
         sp = _sp372(sens, centered)
         nrm, cen, st = _norm(normalization), int(bool(centered)), _lib.stream_ptr()
+        if llg_t4_supported(y):
+            # the coil stack between the passes column-tiled (contiguous 4-column blocks for the column pass); y tiled once per slice
+            yt4 = _y_t4(y)
+            wk = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=y.device)
+            _lib.check(L.mrx_pfa372_expand_t4(_lib.ptr(eta), _lib.ptr(sp), _lib.ptr(work), B, C, H, nrm, cen, st), "mrx_pfa372_expand_t4")
+            _lib.check(L.mrx_llg_cols_dc_t4(_lib.ptr(work), _lib.ptr(yt4), _lib.ptr(m), kind, ms, B, C, H, W, nrm, cen, st), "mrx_llg_cols_dc_t4")
+            if parts:
+                n = ctypes.c_int(0)
+                _lib.check(L.mrx_pfa372_reduce_t4(_lib.ptr(work), _lib.ptr(sp), None, None, _lib.ptr(wk), ctypes.byref(n), B, C, H,
+                                                  float(1.0 / (float(sigma) ** 2.0)), nrm, cen, st), "mrx_pfa372_reduce_t4")
+                return wk, int(n.value)
+            _lib.check(L.mrx_pfa372_reduce_t4(_lib.ptr(work), _lib.ptr(sp), _lib.ptr(eta), _lib.ptr(out), _lib.ptr(wk), None, B, C, H,
+                                              float(1.0 / (float(sigma) ** 2.0)), nrm, cen, st), "mrx_pfa372_reduce_t4")
+            return out
         _lib.check(L.mrx_pfa372_expand(_lib.ptr(eta), _lib.ptr(sp), _lib.ptr(work), None, None, None, 0, None, None, B, C, H, nrm, cen, st),
                    "mrx_pfa372_expand")
         _lib.check(L.mrx_llg_cols_dc(_lib.ptr(work), _lib.ptr(y), _lib.ptr(m), kind, ms, B, C, H, W, nrm, cen, st), "mrx_llg_cols_dc")

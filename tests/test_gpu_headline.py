@@ -451,3 +451,85 @@ def test_pfa372_row_operators_and_general_mask_gradient(dev, case):
     with torch.no_grad():
         g_ref = oracle.rim.log_likelihood_gradient(eta, y2, S, m2d, 1.2, centered, norm, [-2, -1], 1).contiguous()
     assert_close(ops.llg(ed, y2.to(dev), Sd, m2d.to(dev), 1.2, centered, norm), g_ref, 1e-5, "log_likelihood_gradient, 2-D mask, W = 372")
+
+
+@pytest.mark.parametrize("case", [(1, 15, 640, True, "ortho", torch.bool, False), (2, 7, 21, False, "backward", torch.float32, True),
+                                  (1, 3, 9, True, "forward", torch.uint8, False), (1, 32, 320, False, "none", torch.bool, False)],
+                         ids=lambda c: f"B{c[0]}C{c[1]}H{c[2]}_{'c' if c[3] else 'n'}_{c[4]}")
+def test_general_mask_gradient_column_tiled_at_w372(dev, case):
+    """log_likelihood_gradient (rim_utils.py:11-67) for row-dependent masks at W = 372 on the column-tiled coil stack (mrx_tile4_cols,
+    mrx_pfa372_expand_t4, mrx_llg_cols_dc_t4, mrx_pfa372_reduce_t4): vs the oracle, bit-identical to the row-major three-pass form, and
+    the deferred form (coil-group partial sums read by layer 1's tile loader) vs oracle conv5x5 + IndRNN."""
+    from mridc_amd import ops
+    B, C, H, centered, norm, mdt, batched = case
+    W = 372
+    y, S, _, eta = _problem(B, C, H, W, 9000 + C + H, centered, norm)
+    g = torch.Generator().manual_seed(C + H)
+    m2d = (torch.rand(B if batched else 1, 1, H, W, 1, generator=g) < 0.35)
+    full = oracle.fft.fft2(oracle.utils.complex_mul(torch.randn(B, 1, H, W, 2, generator=g), S), centered, norm)
+    y2 = (full / full.abs().max()) * m2d + 0.05 * y
+    mask = m2d if mdt == torch.bool else m2d.to(mdt)
+    sigma = 0.9
+    w, b, wi, bi, hh = _layer1(78)
+    h_prev = torch.randn(B, 64, H, W, generator=torch.Generator().manual_seed(6)).relu()
+    with torch.no_grad():
+        g_ref = oracle.rim.log_likelihood_gradient(eta, y2, S, mask, sigma, centered, norm, [-2, -1], 1).contiguous()
+        h_ref = oracle.rim.indrnn_cell(oracle.rim.conv_nonlinear(g_ref, w, b, 5, 1, "relu"), h_prev, wi, bi, hh, 1, 1)
+    yd, Sd, md, ed, hp = y2.to(dev), S.to(dev), mask.to(dev), eta.to(dev), h_prev.to(dev)
+    assert ops.llg_t4_supported(yd)
+    got = ops.llg(ed, yd, Sd, md, sigma, centered, norm)
+    assert_close(got, g_ref, 1e-5, "column-tiled general-mask gradient vs oracle")
+    keep = ops.LLG_T4
+    try:
+        ops.LLG_T4 = False
+        assert not ops.llg_t4_supported(yd)
+        row_major = ops.llg(ed, yd, Sd, md, sigma, centered, norm)
+    finally:
+        ops.LLG_T4 = keep
+    assert torch.equal(got, row_major), "the tiled layout changed the arithmetic"
+    # the measured data tiled once: [B*C][93][H][4]
+    t4 = ops._y_t4(yd)
+    want_t4 = yd.reshape(B * C, H, 93, 4, 2).permute(0, 2, 1, 3, 4).contiguous()
+    assert torch.equal(t4.reshape(-1), want_t4.reshape(-1))
+    # deferred form
+    part, n = ops.llg(ed, yd, Sd, md, sigma, centered, norm, parts=True)
+    assert n == -(-C // 5)
+    wd, bd, wid, bid, hhd = (t.to(dev) for t in (w, b, wi, bi, hh))
+    h_def = ops.rim_layer_indrnn_packed_llg(ed, part, n, sigma, ops.rim_layer_pack(wd, wid), 64, 5, 1, bd, bid, hhd, hp)
+    assert_close(h_def, h_ref, 1e-5, "layer 1 reading the general-mask partial sums vs oracle")
+
+
+def test_rim_block_general_mask_at_w372(dev):
+    """One RIMBlock (8 steps, IndRNN 64) at 1 x 15 x 640 x 372 with a 2-D (row-dependent) random mask vs the oracle: the deferred
+    column-tiled gradient route of RIMBlock.forward, and the same block with the tiled path switched off (row-major three-pass form)."""
+    from mridc_amd import ops
+    cfg, model, sd = _cirim(dict(num_cascades=1), 1.0)
+    d = synthetic.make_slice(15, 640, 372, slice_idx=4)
+    g = torch.Generator().manual_seed(11)
+    m2d = torch.rand(1, 1, 640, 372, 1, generator=g) < 0.3
+    m2d[:, :, 300:340, 170:202] = True
+    y = d["kspace"] * m2d
+    rc = oracle.rim.RIMConfig(**{k: cfg[k] for k in ("recurrent_layer", "conv_filters", "conv_kernels", "conv_dilations", "conv_bias",
+                                                     "recurrent_filters", "recurrent_kernels", "recurrent_dilations", "recurrent_bias",
+                                                     "depth", "no_dc", "fft_centered", "fft_normalization", "spatial_dims", "coil_dim")},
+                              time_steps=8)
+    p = {k[len("cirim.0."):]: v for k, v in sd.items() if k.startswith("cirim.0.")}
+    with torch.no_grad():
+        ref, ref_hx = oracle.rim.rim_block_forward(p, rc, y, y, d["sensitivity_maps"], m2d, None, None, 1.0, False)
+    blk = model.cirim[0].to(dev)
+    yd, S, m = y.to(dev), d["sensitivity_maps"].to(dev), m2d.to(dev)
+    assert not ops.mask_is_row_invariant(m)
+    outs = {}
+    keep = ops.LLG_T4
+    try:
+        for t4 in (True, False):
+            ops.LLG_T4 = t4
+            with torch.no_grad():
+                etas, hx = blk(yd, yd, S, m, None, None, 1.0, keep_eta=False)
+            assert_close(torch.stack(etas), torch.stack(ref), 2e-5, f"8-step block, 2-D mask, tiled={t4}")
+            for j in range(2):
+                assert_close(hx[j], ref_hx[j], 2e-5, f"hidden state {j}, tiled={t4}")
+            outs[t4] = etas[-1]
+    finally:
+        ops.LLG_T4 = keep
+    assert rel_l2(outs[True], outs[False]) <= 5e-6

@@ -17,7 +17,7 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "conv_layer2_sb": ["k_rim_layer2_sb"],
     "final": ["k_rim_final4"],
     "final_gather": ["k_l2sb_gather"],
-    "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_rows_reduce<1", "k_pfa372_expand", "k_pfa372_reduce", "k_llg372_combine"],
+    "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_cols_dc_t4<", "k_rows_reduce<1", "k_pfa372_expand", "k_pfa372_reduce", "k_llg372_combine"],
 }
 
 
