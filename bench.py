@@ -748,18 +748,19 @@ def main():
         if mss:                               # the default: direct convolution on the bf16 matrix pipe, fp32 results (three-term operand split)
             ms2, n2, l2_bf16, peak2 = mss, nss, True, PEAK_BF16_MFMA_TFLOPS
             kname = ("k_rim_layer2_sb (conv3x3 d2 64->64 direct form + IndRNN 1x1 fused; every fp32 operand = 3 bf16 terms, 6 term products per "
-                     "multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32-accurate results; 8 chunks x 5 steps (one of ten tap slots is "
-                     "padding) + 4 steps of the 1x1 stage = 528 MFMAs per 32 pixels)")
-            executed = (528 * 32 * 32 * 16 * 2 / 32.0) * npix * B
+                     "multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32-accurate results; 36 steps of 2 taps x 8 channels (the ninth taps of "
+                     "two consecutive channel chunks share a step: no padding) + 4 steps of the 1x1 stage = 480 MFMAs per 32 pixels)")
+            executed = (480 * 32 * 32 * 16 * 2 / 32.0) * npix * B
         mst, nst = timer.mean_ms("conv_layer2_sbt")
         l2_taps = bool(mst)
         if mst:                               # the same kernel with the final 64 -> 2 convolution's channel contraction in its tail (+ 24 MFMAs per 32 pixels)
             ms2, n2, l2_bf16, peak2 = mst, nst, True, PEAK_BF16_MFMA_TFLOPS
             kname = ("k_rim_layer2_sb (conv3x3 d2 64->64 direct form + IndRNN 1x1 fused + the channel contraction of the final 3x3 64->2 convolution "
                      "on the new state (18 tap-product planes; mrx_rim_final_gather adds the shifted taps); every fp32 operand = 3 bf16 terms, 6 term "
-                     "products per multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32-accurate results; 8 chunks x 5 steps (one of ten tap "
-                     "slots is padding) + 4 steps of the 1x1 stage + 4 steps of the tap stage (18 of 32 rows used) = 552 MFMAs per 32 pixels)")
-            executed = (552 * 32 * 32 * 16 * 2 / 32.0) * npix * B
+                     "products per multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32-accurate results; 36 steps of 2 taps x 8 channels (the "
+                     "ninth taps of two consecutive channel chunks share a step: no padding) + 4 steps of the 1x1 stage + 4 steps of the tap stage "
+                     "(18 of 32 rows used) = 504 MFMAs per 32 pixels)")
+            executed = (504 * 32 * 32 * 16 * 2 / 32.0) * npix * B
             flops2 += 2.0 * F_hidden * 2 * 9 * npix * B      # the final convolution's multiply-adds now belong to this launch
         traffic = measured_traffic(B, C, H, W, F_hidden)
         tf = (lambda fl: fl / (ms2 * 1e-3) / 1e12) if ms2 else (lambda fl: None)

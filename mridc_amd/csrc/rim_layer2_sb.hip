@@ -7,7 +7,7 @@
 //   * one persistent workgroup per CU, 8 waves = a 16 x 32 pixel tile, wave = two image rows x 64 couts (4 accumulators: every A operand
 //     read from LDS feeds two MFMAs, every B operand two -- 0.5 LDS reads per MFMA); operands of step s + 1 are read before the MFMAs of step s;
 //   * the contraction runs over 8 chunks of 8 input channels; per chunk five MFMA steps of 16 = 2 taps x 8 channels (lower half-wave tap
-//     2s, upper half-wave tap 2s + 1; the tenth tap slot carries zero weights); the chunk's halo'd tile sits in LDS as three bf16 term
+//     2s, upper half-wave tap 2s + 1; the ninth taps of two consecutive chunks share one step); the chunk's halo'd tile sits in LDS as three bf16 term
 //     planes [term][pixel][8 channels] (16 B per pixel: one conflict-free ds_read_b128 per B operand), its split weights (30 KB) beside it;
 //   * both are double-buffered: the fp32 values of chunk q + 1 and its weights are requested before the MFMAs of chunk q, split / written
 //     after them; one barrier per chunk;
@@ -24,6 +24,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define S2_NT 512
+#define S2_BAR_STEP 4      // even chunks: the step before which the paired ninth-tap operands become visible (barrier); 3 = one step earlier, operands prefetched (measured equal)
+#define S2_COMMIT_EVEN 1   // even chunks: the step after which the next chunk is split and written (0 measured equal)
 #define S2_TH 16
 #define S2_TW 32
 #define S2_F 64
@@ -280,21 +282,30 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         for (int q = 0; q < S2_NCH; ++q) {
             const u32x4* xw = Xp + (q & 1) * (3 * S2_NPIX) + (2 * wave) * S2_PW + l31;
             const u32x4* wl = Wc + (q & 1) * S2_WCH + lane;
-            const u32x4* w4 = lhi ? reinterpret_cast<const u32x4*>(smem_s2 + S2_OFF_ZERO) : Wc + (q & 1) * S2_WCH + S2_WFULL + l31;
-            const int st4 = lhi ? 0 : 32;
+            // Ninth tap: chunks are paired.  The fifth step of an EVEN chunk multiplies tap 8 of this chunk (lower half-wave) and tap 8 of the
+            // NEXT chunk (upper half-wave: its planes and weights were committed at step 1 of this chunk -- hence the extra barrier before
+            // they are fetched); an odd chunk has four steps.  36 instead of 40 MFMA steps per tile, no padding slot.
+            const bool even = !(q & 1);
+            const u32x4* xw8 = Xp + ((q + lhi) & 1) * (3 * S2_NPIX) + (2 * wave) * S2_PW + l31 + toff(8);
+            const u32x4* w8 = Wc + ((q + lhi) & 1) * S2_WCH + S2_WFULL + l31;
             u32x4 bt[2][2][3], at[2][2][3];       // [buffer][row | ct][term]
             auto fetch = [&](int s, int bf) {
-                const int off = lhi ? toff(2 * s + 1) : toff(2 * s);
+                if (s < 4) {
+                    const int off = lhi ? toff(2 * s + 1) : toff(2 * s);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    bt[bf][0][k] = xw[k * S2_NPIX + off];
-                    bt[bf][1][k] = xw[k * S2_NPIX + off + S2_PW];
-                    if (s < 4) {
+                    for (int k = 0; k < 3; ++k) {
+                        bt[bf][0][k] = xw[k * S2_NPIX + off];
+                        bt[bf][1][k] = xw[k * S2_NPIX + off + S2_PW];
                         at[bf][0][k] = wl[((s * 3 + k) * 2 + 0) * 64];
                         at[bf][1][k] = wl[((s * 3 + k) * 2 + 1) * 64];
-                    } else {                      // the padding tap slot: the upper half-wave reads the zero operand
-                        at[bf][0][k] = w4[(k * 2 + 0) * st4];
-                        at[bf][1][k] = w4[(k * 2 + 1) * st4];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        bt[bf][0][k] = xw8[k * S2_NPIX];
+                        bt[bf][1][k] = xw8[k * S2_NPIX + S2_PW];
+                        at[bf][0][k] = w8[(k * 2 + 0) * 32];
+                        at[bf][1][k] = w8[(k * 2 + 1) * 32];
                     }
                 }
             };
@@ -302,14 +313,19 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
             for (int s = 0; s < S2_KS; ++s) {
                 const int bf = s & 1;
-                if (s + 1 < S2_KS) fetch(s + 1, bf ^ 1);
+                if (s == 4 && !even) break;
+                if (s == S2_BAR_STEP && even) {        // every thread's commit of chunk q + 1 is visible
+                    __syncthreads();
+                    if (S2_BAR_STEP == 4) fetch(4, bf);
+                }
+                if (s + 1 < 4 || (s + 1 == 4 && even && S2_BAR_STEP == 3)) fetch(s + 1, bf ^ 1);
                 // the six term pairs of weight >= 2^-16, smallest first; the four accumulators alternate
 #define S2_P(TA, TB)                                                                                                                       \
     _Pragma("unroll") for (int rw = 0; rw < 2; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at[bf][ct][TA]), __builtin_bit_cast(bf16x8, bt[bf][rw][TB]), acc[rw][ct], 0, 0, 0);
                 S2_P(2, 0) S2_P(0, 2) S2_P(1, 1) S2_P(1, 0) S2_P(0, 1) S2_P(0, 0)
 #undef S2_P
-                if (s == 1) {                     // the readers of the other buffer passed the previous barrier
+                if (s == (even ? S2_COMMIT_EVEN : 1)) {   // the readers of the other buffer passed the previous barrier
                     commit_next((q + 1) & 1);
                     request_next();
                 }

@@ -194,7 +194,8 @@ def test_second_rim_layer_with_final_conv_in_its_tail(shape, dev):
         sep = ops.rim_final(h_new, wf, b3, 3, 1, eta)
         e_f, e_s = rel_l2(eta_new, ref), rel_l2(sep, ref)
         assert e_f <= 4e-7 and e_f <= 2.5 * e_s + 5e-8, (e_f, e_s)
-        assert rel_l2(eta_new - eta, sep - eta) <= 1e-6
+        # (the update is a difference of fp32 results: with a handful of values one ulp of eta against the size of the update shows)
+        assert rel_l2(eta_new - eta, sep - eta) <= (1e-6 if H * W >= 16 else 3e-6)
 
 
 @pytest.mark.parametrize("shape", [(1, 8, 128, 5, 256, 256), (1, 2, 64, 3, 640, 372), (2, 4, 64, 5, 37, 75), (1, 1, 32, 3, 19, 33), (3, 7, 100, 5, 8, 32),
