@@ -562,6 +562,9 @@ def measured_traffic(B, C, H, W, F):
             continue
         out = {k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()}
         out["_kernels"] = {k: v["kernel"] for k, v in t["kernels"].items()}
+        out["_mfma_util"] = {k: v.get("mfma_util") for k, v in t["kernels"].items()}     # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)
+        out["_mfma_util"]["regulariser"] = t.get("regulariser_mfma_util")
+        out["_mfma_util_source"] = t.get("_mfma_util")
         out["_source"] = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)"
         return out
     return {}
@@ -800,6 +803,13 @@ def main():
                         traffic=traffic.get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"), traffic_unit="bytes/launch",
                         traffic_kernel=traffic.get("_kernels", {}).get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"),
                         traffic_source=traffic.get("_source"), algorithmic_bytes=(3.0 * F_hidden + (18.0 if l2_taps else 0.0)) * npix * B * 4,
+                        # matrix-pipe utilisation by the hardware counters (committed PMC passes of this library version, like `traffic`):
+                        # MFMA-pipe busy cycles / (4 SIMDs x CU busy cycles) -- independent of the clock the chip sustains under the kernel
+                        # (bf16 MFMA kernels run at ~1.7-1.8 GHz here, `frac` prices the issued FLOPs against the 2.4 GHz peak)
+                        mfma_util_pmc=traffic.get("_mfma_util", {}).get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"),
+                        mfma_util_pmc_layer1=traffic.get("_mfma_util", {}).get("conv_layer1"),
+                        mfma_util_pmc_regulariser=traffic.get("_mfma_util", {}).get("regulariser") if (l2_bf16 and l2_taps) else None,
+                        mfma_util_pmc_source=traffic.get("_mfma_util_source"),
                         launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
                         regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_fp32_gflop=issued_reg / 1e9,
                                          issued_bf16_gflop=issued1_bf16 / 1e9,

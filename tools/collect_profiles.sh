@@ -25,7 +25,9 @@ rocprofv3 --kernel-trace --stats -d $O/prof_2d -o d -- python3 bench.py --mask 2
 python3 tools/rocpd_summary.py $O/prof_2d/*results.db > $O/mask2d_kernel_stats.md
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o p --output-format csv -- python3 tools/probe/pmc_r02.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o p --output-format csv -- python3 tools/probe/pmc_r02.py > /dev/null 2>&1
-python3 tools/traffic_json.py $O/pmc_f/*counter_collection.csv $O/pmc_w/*counter_collection.csv $(python3 -c "from mridc_amd import _lib; print(_lib.lib().mrx_version())") > $O/traffic.json
-python3 tools/pmc_summary.py $O/pmc_f/*counter_collection.csv $O/pmc_w/*counter_collection.csv > $O/pmc.md
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/pmc_m -o p --output-format csv -- python3 tools/probe/pmc_r02.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES -d $O/pmc_c -o p --output-format csv -- python3 tools/probe/pmc_r02.py > /dev/null 2>&1
+python3 tools/traffic_json.py $O/pmc_f/*counter_collection.csv $O/pmc_w/*counter_collection.csv $(python3 -c "from mridc_amd import _lib; print(_lib.lib().mrx_version())") $O/pmc_m/*counter_collection.csv $O/pmc_c/*counter_collection.csv > $O/traffic.json
+python3 tools/pmc_summary.py $O/pmc_f/*counter_collection.csv $O/pmc_w/*counter_collection.csv $O/pmc_m/*counter_collection.csv $O/pmc_c/*counter_collection.csv > $O/pmc.md
 rm -rf $O/prof_headline $O/prof_train $O/prof_e2evn $O/prof_2d
 ls -la $O

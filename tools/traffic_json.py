@@ -3,7 +3,7 @@
 in KiB).  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64
 bytes, so it is doubled; WRITE_SIZE is used as is.
 
-    python tools/traffic_json.py FETCH.csv WRITE.csv LIB_VERSION > profiles/r02_traffic.json
+    python tools/traffic_json.py FETCH.csv WRITE.csv LIB_VERSION [MFMA_BUSY.csv CU_BUSY.csv] > profiles/r02_traffic.json
 """
 import collections
 import csv
@@ -30,8 +30,13 @@ def per_kernel(path):
     return {k: acc[k] / len(cnt[k]) for k in acc}
 
 
-def main(fetch_csv, write_csv, lib_version):
+def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None):
+    """mfma_csv / cubusy_csv (optional): passes with SQ_VALU_MFMA_BUSY_CYCLES (cycles the matrix pipe of a SIMD is busy, summed over the
+    SIMDs: 32 per v_mfma_f32_32x32x16_bf16) and SQ_BUSY_CU_CYCLES (cycles a CU has work, summed over the CUs) -> per operator
+    mfma_util = MFMA busy / (4 SIMDs x CU busy): matrix-pipe utilisation by the hardware counters, at whatever clock the chip sustained."""
     fe, wr = per_kernel(fetch_csv), per_kernel(write_csv)
+    mf = per_kernel(mfma_csv) if mfma_csv else {}
+    cb = per_kernel(cubusy_csv) if cubusy_csv else {}
     out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass) -- python3 tools/probe/pmc_r02.py; "
                       "per-dispatch means in KiB",
            "_correction": "gfx950: FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B -> doubled; WRITE_SIZE as is",
@@ -44,8 +49,17 @@ def main(fetch_csv, write_csv, lib_version):
         w = sum(wr.get(k, 0.0) for k in names)
         out["kernels"][key] = dict(kernel=" + ".join(sorted(n.split("(")[0][:70] for n in names)), fetch_kib=f, write_kib=w,
                                    hbm_bytes_per_launch=(2.0 * f + w) * 1024.0)
+        if mf and cb:
+            m, c = sum(mf.get(k, 0.0) for k in names), sum(cb.get(k, 0.0) for k in names)
+            out["kernels"][key].update(mfma_busy_cycles=m, cu_busy_cycles=c, mfma_util=(m / (4.0 * c)) if c else None)
+    if mf and cb:
+        out["_mfma_util"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES and --pmc SQ_BUSY_CU_CYCLES (own passes): mfma_util = MFMA-pipe busy cycles "
+                             "/ (4 SIMDs x CU busy cycles), per launch")
+        reg = [out["kernels"][k] for k in ("conv_layer1", "conv_layer2_sb", "final_gather") if k in out["kernels"]]
+        if len(reg) == 3:
+            out["regulariser_mfma_util"] = sum(r["mfma_busy_cycles"] for r in reg) / (4.0 * sum(r["cu_busy_cycles"] for r in reg))
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])
