@@ -655,6 +655,7 @@ def main():
     timer.wrap(ops, "rim_layer_indrnn_wino", lambda x, *a, **k: "conv_layer2_wino")
     timer.wrap(ops, "rim_layer2_sb", lambda x, *a, **k: "conv_layer2_sb")
     timer.wrap(ops, "rim_layer2_sb_taps", lambda x, *a, **k: "conv_layer2_sbt")     # + the final convolution's channel contraction in its tail
+    timer.wrap(ops, "rim_layer2_f16", lambda x, *a, **k: "conv_layer2_f16t" if k.get("want_taps") else "conv_layer2_f16")   # two-term fp16 conv operands
     timer.wrap(ops, "rim_final_gather", lambda *a, **k: "final_gather")
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
@@ -765,6 +766,18 @@ def main():
                      "(18 of 32 rows used) = 504 MFMAs per 32 pixels)")
             executed = (504 * 32 * 32 * 16 * 2 / 32.0) * npix * B
             flops2 += 2.0 * F_hidden * 2 * 9 * npix * B      # the final convolution's multiply-adds now belong to this launch
+        msh, nsh = timer.mean_ms("conv_layer2_f16t")
+        l2_f16 = bool(msh)
+        if msh:                               # the default: the convolution's operands as two fp16 terms, three term products per multiply
+            ms2, n2, l2_bf16, peak2, l2_taps = msh, nsh, True, PEAK_BF16_MFMA_TFLOPS, True
+            kname = ("k_rim_layer2_sb<.., F16> (conv3x3 d2 64->64 direct form + IndRNN 1x1 fused + the channel contraction of the final 3x3 64->2 "
+                     "convolution on the new state; convolution operands = 2 fp16 terms scaled by powers of two (x by the bound of its maximum that "
+                     "layer 1 keeps, w at pack time), 3 term products per multiply on v_mfma_f32_32x32x16_f16, fp32 accumulation: error against "
+                     "float64 2.3e-7 (three-term bf16 form 2.8e-7, fp32 Winograd 2.0e-7); 36 steps x 6 MFMAs + the 1x1 and tap stages in the "
+                     "three-term bf16 form (4 + 4 steps x 6 products x cout blocks) = 288 MFMAs per 32 pixels; fp16 and bf16 MFMAs issue at the "
+                     "same rate, priced against the same dense peak)")
+            executed = (288 * 32 * 32 * 16 * 2 / 32.0) * npix * B
+            flops2 += 2.0 * F_hidden * 2 * 9 * npix * B
         traffic = measured_traffic(B, C, H, W, F_hidden)
         tf = (lambda fl: fl / (ms2 * 1e-3) / 1e12) if ms2 else (lambda fl: None)
         ms1, _ = timer.mean_ms("conv_layer1")
@@ -800,13 +813,13 @@ def main():
                         algorithmic_note=("fp32 direct-form FLOPs of SURVEY 8d / time, against the fp32-MFMA peak: what the layer delivers in the units "
                                           "of the fp32 pipe it no longer uses (may exceed 1; not a pipe figure)" if l2_bf16 else
                                           "direct-form FLOPs of SURVEY 8d / time: above `frac` by the Winograd saving (2.0x), not a pipe figure"),
-                        traffic=traffic.get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"), traffic_unit="bytes/launch",
-                        traffic_kernel=traffic.get("_kernels", {}).get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"),
+                        traffic=traffic.get("conv_layer2_f16" if l2_f16 else "conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"), traffic_unit="bytes/launch",
+                        traffic_kernel=traffic.get("_kernels", {}).get("conv_layer2_f16" if l2_f16 else "conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"),
                         traffic_source=traffic.get("_source"), algorithmic_bytes=(3.0 * F_hidden + (18.0 if l2_taps else 0.0)) * npix * B * 4,
                         # matrix-pipe utilisation by the hardware counters (committed PMC passes of this library version, like `traffic`):
                         # MFMA-pipe busy cycles / (4 SIMDs x CU busy cycles) -- independent of the clock the chip sustains under the kernel
                         # (bf16 MFMA kernels run at ~1.7-1.8 GHz here, `frac` prices the issued FLOPs against the 2.4 GHz peak)
-                        mfma_util_pmc=traffic.get("_mfma_util", {}).get("conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"),
+                        mfma_util_pmc=traffic.get("_mfma_util", {}).get("conv_layer2_f16" if l2_f16 else "conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"),
                         mfma_util_pmc_layer1=traffic.get("_mfma_util", {}).get("conv_layer1"),
                         mfma_util_pmc_regulariser=traffic.get("_mfma_util", {}).get("regulariser") if (l2_bf16 and l2_taps) else None,
                         mfma_util_pmc_source=traffic.get("_mfma_util_source"),
@@ -859,7 +872,7 @@ def main():
                                             "calibrated in this run -- this is what makes the figures agree with rocprofv3's kernel durations",
                                      empty_pair_ms=getattr(timer, "pair_ms", None),
                                      raw_ms=dict(llg=timer.raw_ms("llg372") or timer.raw_ms("llg"), conv_layer1=timer.raw_ms("conv_layer1"),
-                                                 conv_layer2=timer.raw_ms("conv_layer2_sbt") or timer.raw_ms("conv_layer2_sb") or timer.raw_ms("conv_layer2_wino") or timer.raw_ms("conv_layer2"),
+                                                 conv_layer2=timer.raw_ms("conv_layer2_f16t") or timer.raw_ms("conv_layer2_sbt") or timer.raw_ms("conv_layer2_sb") or timer.raw_ms("conv_layer2_wino") or timer.raw_ms("conv_layer2"),
                                                  final=timer.raw_ms("final_gather") or timer.raw_ms("final"))))
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_cascades if 0 < args.cpu_cascades <= cfg["num_cascades"] else cfg["num_cascades"]

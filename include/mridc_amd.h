@@ -294,6 +294,24 @@ int mrx_conv_sbs(const float* x, const float* packed, const float* bias, float* 
                  int act, float slope, void* stream);
 int mrx_conv3x3_sb(const float* x, const float* packed, const float* bias, float* y, int B, int H, int W, int dil, int pad_mode, int act,
                    float slope, void* stream);
+/* The same layer with the convolution's operands as TWO fp16 terms (11 + 11 significand bits) and three term products per multiply on
+ * v_mfma_f32_32x32x16_f16 (half the MFMAs of the three-term bf16 form; error per product <= ~3 x 2^-22).  fp16's exponent range is narrow:
+ * the weights are scaled by a power of two at pack time, x per launch from `xmax`, a device float holding an upper bound of max |x| that the
+ * producer of x maintains (mrx_rim_layer_indrnn_packed_xmax / _llg_xmax).  taps may be NULL.  The 1x1 / tap stages keep the bf16 form. */
+int mrx_rim_layer1_xmax_supported(int Cin, int F, int k, int dil);
+/* mrx_rim_layer_indrnn_packed / _packed_llg that also fold the maximum of their (non-negative) outputs into *xmax (atomic max, never reset
+ * by the library: a running upper bound; the caller zeroes it, e.g. once per cascade). */
+int mrx_rim_layer_indrnn_packed_xmax(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
+                                     const float* h_prev, float* h_new, float* xmax, int B, int Cin, int F, int H, int W, int k, int dil,
+                                     void* stream);
+int mrx_rim_layer_indrnn_packed_llg_xmax(const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,
+                                         const float* b_conv, const float* b_ih, const float* hh, const float* h_prev, float* h_new,
+                                         float* xmax, int B, int F, int H, int W, int k, int dil, void* stream);
+int64_t mrx_rim_layer2_f16_pack_floats(void);
+int mrx_rim_layer2_f16_pack(const float* w_conv, const float* w_ih /* or NULL */, const float* w_final /* [2,64,3,3] or NULL */, float* packed,
+                            void* stream);
+int mrx_rim_layer2_f16(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                       float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream);
 int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
                            const float* h_prev, float* h_new, float* taps, int B, int H, int W, void* stream);
 int mrx_rim_final_gather(const float* taps, const float* b_final, const float* eta, float* eta_out, int B, int H, int W, void* stream);

@@ -137,6 +137,12 @@ _SIGNATURES = {
     "mrx_recon_metrics_work_floats": ([], _i64),
     "mrx_recon_metrics": ([_p, _p, _p, _p, _i64, _p], _i),
     "mrx_rim_layer2_sb_pack_floats": ([], _i64),
+    "mrx_rim_layer1_xmax_supported": ([_i, _i, _i, _i], _i),
+    "mrx_rim_layer_indrnn_packed_xmax": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_rim_layer_indrnn_packed_llg_xmax": ([_p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_rim_layer2_f16_pack_floats": ([], _i64),
+    "mrx_rim_layer2_f16_pack": ([_p, _p, _p, _p, _p], _i),
+    "mrx_rim_layer2_f16": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_layer2_sb_pack": ([_p, _p, _p, _p, _p], _i),
     "mrx_conv3x3_sb_supported": ([_i, _i, _i, _i], _i),
     "mrx_conv_sbs_supported": ([_i, _i, _i, _i], _i),

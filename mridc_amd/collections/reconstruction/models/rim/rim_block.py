@@ -32,6 +32,9 @@ class RIMBlock(torch.nn.Module):
     """
     winograd = os.environ.get("MRIDC_AMD_WINOGRAD", "1") != "0"
     layer2_sb = os.environ.get("MRIDC_AMD_LAYER2_SB", "1") != "0"
+    # the dominant layer's convolution with two-term fp16 operands (mrx_rim_layer2_f16: half the MFMAs of the three-term bf16 form, same fp32-level
+    # error); needs the first layer to keep the bound of its outputs (mrx_rim_layer_indrnn_packed*_xmax).  MRIDC_AMD_LAYER2_F16=0 turns it off.
+    layer2_f16 = os.environ.get("MRIDC_AMD_LAYER2_F16", "1") != "0"
     fused_final = os.environ.get("MRIDC_AMD_FUSED_FINAL", "1") != "0"
     inplace_state = os.environ.get("MRIDC_AMD_INPLACE_STATE", "1") != "0"
 
@@ -140,6 +143,31 @@ class RIMBlock(torch.nn.Module):
             self._pack_cache[("sb", idx)] = hit
         return hit[1]
 
+    def _packed_f16(self, idx, c, r, final=None):
+        """_packed_sb for mrx_rim_layer2_f16 (convolution weights as two scaled fp16 terms)."""
+        w, wi = c.conv_layer.weight, r.ih.weight
+        wf = final.conv_layer.weight if final is not None else None
+        key = (w.data_ptr(), w._version, wi.data_ptr(), wi._version, str(w.device),
+               None if wf is None else (wf.data_ptr(), wf._version))
+        hit = self._pack_cache.get(("f16", idx))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.rim_layer2_f16_pack(w, wi, wf))
+            self._pack_cache[("f16", idx)] = hit
+        return hit[1]
+
+    def _f16_route(self):
+        """Two stacks, the second one the split-operand layer, the first one the tuned kernel that can keep the bound of its outputs."""
+        if not self.layer2_f16 or len(self.layers) != 2 or not self._sb_layer(self.layers[1]):
+            return False
+        l0 = self.layers[0]
+        if not self._fusable(l0) or self._sb_layer(l0):
+            return False
+        c, r = l0.convs, l0.rnn
+        if self.winograd and ops.rim_layer_wino_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation):
+            return False
+        return (ops.rim_layer_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation)
+                and ops.rim_layer1_xmax_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation))
+
     def _sb_layer(self, stack):
         c, r = stack.convs, stack.rnn
         return (self.layer2_sb and self._fusable(stack) and c.input_size == 64 and r.hidden_size == 64 and c.kernel_size == 3
@@ -153,23 +181,28 @@ class RIMBlock(torch.nn.Module):
         return (self._sb_layer(self.layers[-1]) and f is not None and f.act == ops.ACT_NONE and f.kernel_size == 3 and f.dilation == 1
                 and tuple(f.conv_layer.weight.shape) == (2, 64, 3, 3))
 
-    def _layers_and_final(self, first, grad_eta, hx, eta, final, own=False):
-        """Stacks `first`.. on grad_eta, then eta + permute(final conv) (rim_block.py:230-246)."""
+    def _layers_and_final(self, first, grad_eta, hx, eta, final, own=False, xmax=None):
+        """Stacks `first`.. on grad_eta, then eta + permute(final conv) (rim_block.py:230-246).  `xmax` (the _f16_route): the device scalar in
+        which stack 0 keeps the bound of its outputs and from which stack 1 takes its fp16 operand scale."""
         n = len(self.layers)
         fused = self._tail_fused() and n - 1 >= first
         for h in range(first, n - 1 if fused else n):
-            hx[h] = self._layer(h, self.layers[h], grad_eta, hx[h], own)
+            hx[h] = self._layer(h, self.layers[h], grad_eta, hx[h], own, xmax)
             grad_eta = hx[h]
         if fused:
             c, r = self.layers[-1].convs, self.layers[-1].rnn
+            out = hx[n - 1] if (own and self.inplace_state and hx[n - 1] is not None) else None
+            if xmax is not None:
+                hx[n - 1], taps = ops.rim_layer2_f16(grad_eta, self._packed_f16(n - 1, c, r, final), c.conv_layer.bias, r.ih.bias, r.hh, hx[n - 1],
+                                                     xmax, out=out, want_taps=True)
+                return ops.rim_final_gather(taps, final.conv_layer.bias, eta)
             # (the 18 tap-product planes are per-call scratch from the caching allocator: slices in flight on other streams have their own)
             hx[n - 1], eta = ops.rim_layer2_sb_final(grad_eta, self._packed_sb(n - 1, c, r, final), c.conv_layer.bias, r.ih.bias, r.hh,
-                                                     hx[n - 1], final.conv_layer.bias, eta,
-                                                     out=hx[n - 1] if (own and self.inplace_state and hx[n - 1] is not None) else None)
+                                                     hx[n - 1], final.conv_layer.bias, eta, out=out)
             return eta
         return ops.rim_final(grad_eta, final.conv_layer.weight, final.conv_layer.bias, final.kernel_size, final.dilation, eta)
 
-    def _layer(self, idx, stack, x, h, own=False):
+    def _layer(self, idx, stack, x, h, own=False, xmax=None):
         """One conv+RNN stack.  `h` None = the zero initial state (rim_block.py:188-193) without materialising it.  `own`: h was created by
         this forward call, so the split-bf16 kernels may overwrite it with the new state (one buffer per layer instead of two alive)."""
         if self._gated(stack):
@@ -190,13 +223,16 @@ class RIMBlock(torch.nn.Module):
         if self._fusable(stack):
             c, r = stack.convs, stack.rnn
             if self._sb_layer(stack):
+                if xmax is not None and idx == 1:
+                    return ops.rim_layer2_f16(x, self._packed_f16(idx, c, r), c.conv_layer.bias, r.ih.bias, r.hh, h, xmax,
+                                              out=h if (own and self.inplace_state and h is not None) else None)
                 return ops.rim_layer2_sb(x, self._packed_sb(idx, c, r), c.conv_layer.bias, r.ih.bias, r.hh, h,
                                          out=h if (own and self.inplace_state and h is not None) else None)
             if self.winograd and ops.rim_layer_wino_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation):
                 return ops.rim_layer_indrnn_wino(x, self._packed(idx, c, r), r.hidden_size, c.conv_layer.bias, r.ih.bias, r.hh, h)
             if ops.rim_layer_supported(c.input_size, r.hidden_size, c.kernel_size, c.dilation):
                 return ops.rim_layer_indrnn_packed(x, self._packed(idx, c, r), r.hidden_size, c.kernel_size, c.dilation,
-                                                   c.conv_layer.bias, r.ih.bias, r.hh, h)
+                                                   c.conv_layer.bias, r.ih.bias, r.hh, h, xmax=xmax if idx == 0 else None)
             return ops.rim_layer_indrnn(x, c.conv_layer.weight, c.conv_layer.bias, c.kernel_size, c.dilation,
                                         r.ih.weight, r.ih.bias, r.hh, h)
         return stack(x, h)
@@ -326,6 +362,8 @@ class RIMBlock(torch.nn.Module):
         defer = ((hinv or t4) and l0 is not None and self._fusable(l0) and l0.convs.input_size == 4
                  and ops.rim_layer_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)
                  and not (self.winograd and ops.rim_layer_wino_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)))
+        # fp16 operand scale of the second stack: stack 0 folds the maximum of its outputs into this scalar (zeroed once per call: a running bound)
+        xmax = torch.zeros(1, dtype=torch.float32, device=masked_kspace.device) if (masked_kspace.is_cuda and self._f16_route()) else None
         for step in range(self.time_steps):                          # rim_block.py:217-249
             own = step > 0                                           # the states of step 0 are the caller's (or the zero state)
             if defer:
@@ -341,8 +379,9 @@ class RIMBlock(torch.nn.Module):
                     hx[0] = ops.rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, self._packed(0, c, r), r.hidden_size, c.kernel_size,
                                                             c.dilation, c.conv_layer.bias, r.ih.bias, r.hh, hx[0],
                                                             out=hx[0] if (own and self.inplace_state and hx[0] is not None
-                                                                          and ops.rim_layer1_inplace_ok(4, r.hidden_size, c.kernel_size, c.dilation)) else None)
-                    eta = self._layers_and_final(1, hx[0], hx, eta, final, own)
+                                                                          and ops.rim_layer1_inplace_ok(4, r.hidden_size, c.kernel_size, c.dilation)) else None,
+                                                            xmax=xmax)
+                    eta = self._layers_and_final(1, hx[0], hx, eta, final, own, xmax)
                     etas.append(eta)
                     continue
             elif op372 is not None:
@@ -352,7 +391,7 @@ class RIMBlock(torch.nn.Module):
             else:
                 grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
                                    self.spatial_dims, work=work)
-            eta = self._layers_and_final(0, grad_eta, hx, eta, final, own)   # stacks, final conv, permute(0,2,3,1), eta + grad
+            eta = self._layers_and_final(0, grad_eta, hx, eta, final, own, xmax)   # stacks, final conv, permute(0,2,3,1), eta + grad
             etas.append(eta)
         mask = full_mask
         if self.no_dc:                                               # rim_block.py:253-254

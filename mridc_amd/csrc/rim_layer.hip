@@ -486,6 +486,7 @@ struct LlgSrc {
     float post;
 };
 static thread_local LlgSrc g_llg_src = {nullptr, nullptr, 0, 0.f};
+static thread_local float* g_l1_xmax = nullptr;   // set by the _xmax entry points around the call
 
 extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, const float* b_conv, const float* b_ih,
                                            const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H,
@@ -535,9 +536,11 @@ extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, 
             s.x = x, s.packed = packed + rl_fp32_pack_floats(Cin, k), s.b_conv = b_conv, s.b_ih = b_ih, s.hh = hh, s.hprev = h_prev, s.hnew = h_new;
             s.B = B, s.Cin = Cin, s.H = H, s.W = W, s.tiles_x = a.tiles_x, s.ntiles = a.tiles_x * mrx_cdiv(H, MRX_L1SB_TH);
             s.eta2 = a.eta2, s.part = a.part, s.part_stride = a.part_stride, s.nparts = a.nparts, s.post = a.post;
+            s.xmax = reinterpret_cast<unsigned*>(g_l1_xmax);
             return mrx_l1sb_launch(s, st);
         }
     }
+    MRX_REQUIRE(!g_l1_xmax, MRX_EUNSUP, "mrx_rim_layer_indrnn_packed_xmax: only the split-bf16 first-layer kernel keeps the output bound");
 #define RL_CASE(KK, DD)                                                       \
     if (k == KK && dil == DD)                                                 \
         return small ? launch_rim_layer<KK, DD, 4>(a, st) : launch_rim_layer<KK, DD, 8>(a, st);
@@ -919,5 +922,31 @@ extern "C" int mrx_rim_layer_indrnn_packed_llg(const float* eta, const float* pa
     const int rc = mrx_rim_layer_indrnn_packed(eta /* non-null placeholder, not read */, packed, b_conv, b_ih, hh, h_prev, h_new, B, 4, F, H,
                                                W, k, dil, stream);
     g_llg_src = {nullptr, nullptr, 0, 0.f};
+    return rc;
+}
+
+// The two calls above that also fold the maximum of their (non-negative) outputs into *xmax with an atomic max -- never reset here: a running
+// upper bound of max |h_new|, which mrx_rim_layer2_f16 takes its operand scale from.  Only the split-bf16 kernel (Cin <= 4, 5x5, 64 features)
+// does it: mrx_rim_layer1_xmax_supported.
+extern "C" int mrx_rim_layer1_xmax_supported(int Cin, int F, int k, int dil) {
+    const char* e = getenv("MRX_LAYER1_FP32");
+    return (F == 64 && rl_sb_shape(Cin, k) && dil == 1 && !(e && atoi(e)) && !getenv("MRX_ABLATE") && !getenv("MRX_TRACE")) ? 1 : 0;
+}
+extern "C" int mrx_rim_layer_indrnn_packed_xmax(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
+                                                const float* h_prev, float* h_new, float* xmax, int B, int Cin, int F, int H, int W, int k, int dil,
+                                                void* stream) {
+    MRX_REQUIRE(xmax, MRX_EINVAL, "mrx_rim_layer_indrnn_packed_xmax: null pointer");
+    g_l1_xmax = xmax;
+    const int rc = mrx_rim_layer_indrnn_packed(x, packed, b_conv, b_ih, hh, h_prev, h_new, B, Cin, F, H, W, k, dil, stream);
+    g_l1_xmax = nullptr;
+    return rc;
+}
+extern "C" int mrx_rim_layer_indrnn_packed_llg_xmax(const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,
+                                                    const float* b_conv, const float* b_ih, const float* hh, const float* h_prev, float* h_new,
+                                                    float* xmax, int B, int F, int H, int W, int k, int dil, void* stream) {
+    MRX_REQUIRE(xmax, MRX_EINVAL, "mrx_rim_layer_indrnn_packed_llg_xmax: null pointer");
+    g_l1_xmax = xmax;
+    const int rc = mrx_rim_layer_indrnn_packed_llg(eta, part, nparts, inv_sigma2, packed, b_conv, b_ih, hh, h_prev, h_new, B, F, H, W, k, dil, stream);
+    g_l1_xmax = nullptr;
     return rc;
 }

@@ -18,6 +18,7 @@ struct MrxL1sbArgs {
     long long part_stride;
     int nparts;
     float post;
+    unsigned* xmax;        // not null: atomic max of the bits of every output (outputs are >= 0: ReLU) -- the bound mrx_rim_layer2_f16 scales by
 };
 
 int mrx_l1sb_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, hipStream_t st);

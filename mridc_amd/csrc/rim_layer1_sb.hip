@@ -242,6 +242,7 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
         w0 = (tile - ty0 * a.tiles_x) * SB_TW;
     };
 
+    float wmax = 0.f;                        // maximum of this lane's outputs (a.xmax)
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         int b, oy, w0;
         unit_of(t, b, oy, w0);
@@ -326,8 +327,16 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
                 float v = acc2[R >> 4][R & 15] + tabl[2 * R + lhi] * (first ? 0.f : hp[R]);
                 v = v > 0.f ? v : 0.f;
                 ob[(long long)sb_chan(R, 0) * plane] = v;
+                wmax = fmaxf(wmax, v);
             }
         }
+    }
+    if (a.xmax) {
+        // bound of max |h_new| for the next layer's fp16 operand scale: one atomic per wave and launch, and only when it would raise the bound
+        // (same-address atomics from every CU serialise: one per 32-pixel unit cost 60 us per launch)
+        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+        if (lane == 0 && __float_as_uint(wmax) > __hip_atomic_load(a.xmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.xmax, __float_as_uint(wmax));
     }
 }
 

@@ -37,6 +37,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define S2_WIH (4 * 3 * 2 * 64)             // 1x1 stage (24 KB)
 #define S2_WP (4 * 3 * 64)                  // final 64 -> 2 convolution as per-pixel tap products: 18 of 32 rows used (12 KB)
 #define S2_PACK_U4 (S2_NCH * S2_WCH + S2_WIH + S2_WP)
+// F16 variant (mrx_rim_layer2_f16_*): the convolution's operands as TWO fp16 terms (11 + 11 significand bits, operands pre-scaled by powers of two
+// into the fp16 range) and three term products per multiply; the 1x1 and tap stages keep the three-term bf16 form
+#define S2F_WFULL (4 * 2 * 2 * 64)
+#define S2F_WCH (S2F_WFULL + 2 * 2 * 32)    // 18 KB per chunk
+#define S2F_PACK_U4 (S2_NCH * S2F_WCH + S2_WIH + S2_WP + 1)   // + one header element: the weight scale exponent
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct L2sbArgs {
     const float* x;        // [B,64,H,W]
@@ -51,7 +58,27 @@ struct L2sbArgs {
     int act;               // TAIL = false: MRX_ACT_* applied to conv + bias
     float slope;
     unsigned long long* trace;   // debug (env MRX_L2SB_TRACE): cycle stamps [workgroup][wave][tile 0..1][4]
+    const unsigned* xmax;  // F16: bits of an upper bound of max |x| (>= 0), kept by the producer of x (mrx_rim_layer_indrnn_packed*_xmax)
 };
+
+// two fp16 terms of a pair of values already scaled into the fp16 range: a = h1 + h2 + O(2^-22 |a|)
+__device__ __forceinline__ void s2_split2h(float a, float b, unsigned& p1, unsigned& p2) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    const float ra = a - (float)h.x, rb = b - (float)h.y;     // exact
+    const f16x2 l = {(_Float16)ra, (_Float16)rb};
+    p1 = __builtin_bit_cast(unsigned, h);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+// 2^e as a float, e clamped to the normal range
+__device__ __forceinline__ float s2_pow2(int e) {
+    e = e < -120 ? -120 : (e > 120 ? 120 : e);
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
+// exponent k with bound * 2^k in [2^14, 2^15) (0 for a zero / non-finite bound)
+__device__ __forceinline__ int s2_scale_exp(unsigned bits) {
+    const int ex = (int)((bits >> 23) & 0xffu);
+    return (ex == 0 || ex == 255) ? 0 : 14 - (ex - 127);
+}
 
 __device__ __forceinline__ unsigned s2_pk(float lo, float hi) {
     unsigned r;
@@ -122,6 +149,80 @@ __global__ void k_l2sb_pack(const float* __restrict__ w, const float* __restrict
     out[i] = u32x4{p[0], p[1], p[2], p[3]};
 }
 
+// F16 pack.  Step 1: the weight scale exponent kw (max |w| * 2^kw in [2^14, 2^15)) into the header element.
+__global__ void k_l2f16_wscale(const float* __restrict__ w, u32x4* __restrict__ out) {
+    __shared__ float red[256];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < S2_F * S2_F * 9; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[S2F_PACK_U4 - 1] = u32x4{(unsigned)s2_scale_exp(__float_as_uint(red[0])), 0u, 0u, 0u};
+}
+// Step 2: conv operands as two fp16 terms of w * 2^kw, in the layout of k_l2sb_pack with two terms:
+//   out[q * S2F_WCH + ((s*2 + t)*2 + blk)*64 + lane][j] (s < 4), out[q * S2F_WCH + S2F_WFULL + (t*2 + blk)*32 + l][j] (tap 8);
+// the 1x1 / final-conv operands (three bf16 terms) follow as in k_l2sb_pack.
+__global__ void k_l2f16_pack(const float* __restrict__ w, const float* __restrict__ w_ih, const float* __restrict__ w_final, u32x4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S2F_PACK_U4 - 1) return;
+    float v[8];
+    int t;
+    if (i < S2_NCH * S2F_WCH) {
+        const float sw = s2_pow2((int)out[S2F_PACK_U4 - 1][0]);
+        const int q = i / S2F_WCH;
+        int r = i - q * S2F_WCH, s, blk, l, half;
+        if (r < S2F_WFULL) {
+            const int lane = r & 63;
+            r >>= 6;
+            blk = r & 1;
+            r >>= 1;
+            t = r & 1, s = r >> 1, l = lane & 31, half = lane >> 5;
+        } else {
+            r -= S2F_WFULL;
+            l = r & 31, blk = (r >> 5) & 1, t = r >> 6, s = 4, half = 0;
+        }
+        const int o = 32 * blk + l, tap = 2 * s + half;
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned p1, p2;
+            s2_split2h(w[((long long)o * S2_F + 8 * q + 2 * k) * 9 + tap] * sw, w[((long long)o * S2_F + 8 * q + 2 * k + 1) * 9 + tap] * sw, p1, p2);
+            p[k] = t == 0 ? p1 : p2;
+        }
+        out[i] = u32x4{p[0], p[1], p[2], p[3]};
+        return;
+    } else if (i < S2_NCH * S2F_WCH + S2_WIH) {
+        int r = i - S2_NCH * S2F_WCH;
+        const int lane = r & 63;
+        r >>= 6;
+        const int blk = r & 1;
+        r >>= 1;
+        t = r % 3;
+        const int s = r / 3, o = 32 * blk + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w_ih ? w_ih[o * S2_F + s2_chan(8 * s + j, lane >> 5)] : 0.f;
+    } else {
+        int r = i - S2_NCH * S2F_WCH - S2_WIH;
+        const int lane = r & 63;
+        r >>= 6;
+        t = r % 3;
+        const int s = r / 3, m = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (w_final && m < 18) ? w_final[((long long)(m & 1) * S2_F + s2_chan(8 * s + j, lane >> 5)) * 9 + (m >> 1)] : 0.f;
+    }
+    unsigned p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned p1, p2, p3;
+        s2_split2(v[2 * k], v[2 * k + 1], p1, p2, p3);
+        p[k] = t == 0 ? p1 : (t == 1 ? p2 : p3);
+    }
+    out[i] = u32x4{p[0], p[1], p[2], p[3]};
+}
+
 #define S2_MFMA12(ACC, A, B1, B2, B3)                                                             \
     ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][2], B1, ACC[0], 0, 0, 0);               \
     ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][2], B1, ACC[1], 0, 0, 0);               \
@@ -146,21 +247,31 @@ __global__ void k_l2sb_pack(const float* __restrict__ w, const float* __restrict
 #define S2_OFF_X (S2_OFF_W + 2 * S2_WCH * 16)
 #define S2_LDS (S2_OFF_X + 2 * 3 * S2_NPIX_MAX * 16)
 
-template <int DIL, bool TAIL, bool ZP>
+template <int DIL, bool TAIL, bool ZP, bool F16 = false>
 __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     constexpr int S2_PAD = DIL, S2_PH = S2_TH + 2 * DIL, S2_PW = S2_TW + 2 * DIL, S2_NPIX = S2_PH * S2_PW;
+    constexpr int NT = F16 ? 2 : 3;                                        // operand terms of the convolution stage
+    constexpr int WFULL = F16 ? S2F_WFULL : S2_WFULL, WCH = F16 ? S2F_WCH : S2_WCH;
+    constexpr int PK_TAIL = S2_NCH * WCH;                                  // where the 1x1 / final-conv operands start in the pack
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
     u32x4* Wih = reinterpret_cast<u32x4*>(smem_s2);
     float* tabl = reinterpret_cast<float*>(smem_s2 + S2_OFF_TAB);      // hh, b_conv, b_ih in register order [R][half]
     u32x4* Wc = reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_W);          // [2][S2_WCH]
-    u32x4* Xp = reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_X);          // [2][3 terms][S2_NPIX]
+    u32x4* Xp = reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_X);          // [2][NT terms][S2_NPIX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const long long plane = (long long)a.H * a.W;
     const int total = a.ntiles * a.B;
 
     // once per workgroup: 1x1 weights and tables
     if (TAIL)
-        for (int i = tid; i < S2_WIH + S2_WP; i += S2_NT) Wih[i] = a.packed[S2_NCH * S2_WCH + i];  // (the final-conv operands follow the 1x1 ones)
+        for (int i = tid; i < S2_WIH + S2_WP; i += S2_NT) Wih[i] = a.packed[PK_TAIL + i];  // (the final-conv operands follow the 1x1 ones)
+    // F16: x is multiplied by 2^kx (the producer's bound of max |x| lands in [2^14, 2^15)), the weights were by 2^kw; the accumulators
+    // are scaled back (exactly) before the bias
+    float sx = 1.f, unx = 1.f, unw = 1.f;
+    if constexpr (F16) {
+        const int kx = s2_scale_exp(a.xmax[0]), kw = (int)a.packed[S2F_PACK_U4 - 1][0];
+        sx = s2_pow2(kx), unx = s2_pow2(-kx), unw = s2_pow2(-kw);
+    }
     if (tid == 0) *reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_ZERO) = u32x4{0u, 0u, 0u, 0u};
     if (tid < 64) {
         const int tc = s2_chan(tid >> 1, tid & 1);
@@ -171,7 +282,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 
     // staging roles: thread i owns pixels i and i + 512 of the halo'd tile (8 channels of the chunk) and copies <= 4 weight operands
     constexpr int XV = (S2_NPIX + S2_NT - 1) / S2_NT;                 // 2
-    constexpr int WV = (S2_WCH + S2_NT - 1) / S2_NT;                  // 4
+    constexpr int WV = (WCH + S2_NT - 1) / S2_NT;                     // 4 (F16: 3)
 
     // The staging pipeline runs two chunks ahead of the MFMAs and across tile boundaries: while chunk q of a tile is multiplied, chunk q + 1
     // is split and written (mid-chunk: the vector ALU work rides under the other wave's MFMAs) and chunk q + 2 is requested; the first
@@ -215,7 +326,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
             const int i = tid + v * S2_NT;
-            wr[v] = a.packed[(long long)st_q * S2_WCH + (i < S2_WCH ? i : S2_WCH - 1)];
+            wr[v] = a.packed[(long long)st_q * WCH + (i < WCH ? i : WCH - 1)];
         }
         if (++st_q == S2_NCH) {
             st_q = 0;
@@ -230,22 +341,29 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             const int p = tid + v * S2_NT;
             unsigned p1[4], p2[4], p3[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s2_split2(xr[v][2 * k], xr[v][2 * k + 1], p1[k], p2[k], p3[k]);
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (F16) {
+                    s2_split2h(xr[v][2 * k] * sx, xr[v][2 * k + 1] * sx, p1[k], p2[k]);
+                    p3[k] = 0u;
+                } else {
+                    s2_split2(xr[v][2 * k], xr[v][2 * k + 1], p1[k], p2[k], p3[k]);
+                }
+            }
             if (ZP && ((zpend >> v) & 1u)) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) p1[k] = p2[k] = p3[k] = 0u;
             }
             if (p < S2_NPIX) {
-                u32x4* dst = Xp + buf * (3 * S2_NPIX) + p;
+                u32x4* dst = Xp + buf * (NT * S2_NPIX) + p;
                 dst[0] = u32x4{p1[0], p1[1], p1[2], p1[3]};
                 dst[S2_NPIX] = u32x4{p2[0], p2[1], p2[2], p2[3]};
-                dst[2 * S2_NPIX] = u32x4{p3[0], p3[1], p3[2], p3[3]};
+                if constexpr (!F16) dst[2 * S2_NPIX] = u32x4{p3[0], p3[1], p3[2], p3[3]};
             }
         }
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
             const int i = tid + v * S2_NT;
-            if (i < S2_WCH) Wc[buf * S2_WCH + i] = wr[v];
+            if (i < WCH) Wc[buf * WCH + i] = wr[v];
         }
     };
     st_coords();
@@ -268,7 +386,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rw][ct][r] = tabl[64 + 2 * (ct * 16 + r) + lhi];
+                for (int r = 0; r < 16; ++r) acc[rw][ct][r] = F16 ? 0.f : tabl[64 + 2 * (ct * 16 + r) + lhi];
 
         float hp[2][32];
         auto load_hp = [&](int rw) {              // lanes outside the image read a valid element (clamped) and store nothing
@@ -280,28 +398,28 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         };
         auto toff = [](int tp) { return tp < 9 ? (tp / 3) * DIL * S2_PW + (tp % 3) * DIL : 0; };  // the zero-weight slot reads pixel 0
         for (int q = 0; q < S2_NCH; ++q) {
-            const u32x4* xw = Xp + (q & 1) * (3 * S2_NPIX) + (2 * wave) * S2_PW + l31;
-            const u32x4* wl = Wc + (q & 1) * S2_WCH + lane;
+            const u32x4* xw = Xp + (q & 1) * (NT * S2_NPIX) + (2 * wave) * S2_PW + l31;
+            const u32x4* wl = Wc + (q & 1) * WCH + lane;
             // Ninth tap: chunks are paired.  The fifth step of an EVEN chunk multiplies tap 8 of this chunk (lower half-wave) and tap 8 of the
             // NEXT chunk (upper half-wave: its planes and weights were committed at step 1 of this chunk -- hence the extra barrier before
             // they are fetched); an odd chunk has four steps.  36 instead of 40 MFMA steps per tile, no padding slot.
             const bool even = !(q & 1);
-            const u32x4* xw8 = Xp + ((q + lhi) & 1) * (3 * S2_NPIX) + (2 * wave) * S2_PW + l31 + toff(8);
-            const u32x4* w8 = Wc + ((q + lhi) & 1) * S2_WCH + S2_WFULL + l31;
-            u32x4 bt[2][2][3], at[2][2][3];       // [buffer][row | ct][term]
+            const u32x4* xw8 = Xp + ((q + lhi) & 1) * (NT * S2_NPIX) + (2 * wave) * S2_PW + l31 + toff(8);
+            const u32x4* w8 = Wc + ((q + lhi) & 1) * WCH + WFULL + l31;
+            u32x4 bt[2][2][NT], at[2][2][NT];     // [buffer][row | ct][term]
             auto fetch = [&](int s, int bf) {
                 if (s < 4) {
                     const int off = lhi ? toff(2 * s + 1) : toff(2 * s);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
+                    for (int k = 0; k < NT; ++k) {
                         bt[bf][0][k] = xw[k * S2_NPIX + off];
                         bt[bf][1][k] = xw[k * S2_NPIX + off + S2_PW];
-                        at[bf][0][k] = wl[((s * 3 + k) * 2 + 0) * 64];
-                        at[bf][1][k] = wl[((s * 3 + k) * 2 + 1) * 64];
+                        at[bf][0][k] = wl[((s * NT + k) * 2 + 0) * 64];
+                        at[bf][1][k] = wl[((s * NT + k) * 2 + 1) * 64];
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
+                    for (int k = 0; k < NT; ++k) {
                         bt[bf][0][k] = xw8[k * S2_NPIX];
                         bt[bf][1][k] = xw8[k * S2_NPIX + S2_PW];
                         at[bf][0][k] = w8[(k * 2 + 0) * 32];
@@ -323,7 +441,16 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #define S2_P(TA, TB)                                                                                                                       \
     _Pragma("unroll") for (int rw = 0; rw < 2; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at[bf][ct][TA]), __builtin_bit_cast(bf16x8, bt[bf][rw][TB]), acc[rw][ct], 0, 0, 0);
-                S2_P(2, 0) S2_P(0, 2) S2_P(1, 1) S2_P(1, 0) S2_P(0, 1) S2_P(0, 0)
+                if constexpr (F16) {
+                    // two fp16 terms per operand: the three products of weight >= 2^-11, smallest first
+#define S2_PH16(TA, TB)                                                                                                                    \
+    _Pragma("unroll") for (int rw = 0; rw < 2; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, at[bf][ct][TA]), __builtin_bit_cast(f16x8, bt[bf][rw][TB]), acc[rw][ct], 0, 0, 0);
+                    S2_PH16(1, 0) S2_PH16(0, 1) S2_PH16(0, 0)
+#undef S2_PH16
+                } else {
+                    S2_P(NT - 1, 0) S2_P(0, NT - 1) S2_P(1, 1) S2_P(1, 0) S2_P(0, 1) S2_P(0, 0)
+                }
 #undef S2_P
                 if (s == (even ? S2_COMMIT_EVEN : 1)) {   // the readers of the other buffer passed the previous barrier
                     commit_next((q + 1) & 1);
@@ -334,6 +461,14 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             __syncthreads();
         }
 
+        if constexpr (F16) {
+#pragma unroll
+            for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[rw][ct][r] = acc[rw][ct][r] * unx * unw + tabl[64 + 2 * (ct * 16 + r) + lhi];
+        }
         S2_STAMP(1)
         if constexpr (TAIL) {
         // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev), one of the wave's two rows at a time ------------------
@@ -459,11 +594,11 @@ static int l2sb_ncu() {
     }
     return ncu;
 }
-template <int DIL, bool TAIL, bool ZP>
+template <int DIL, bool TAIL, bool ZP, bool F16 = false>
 static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
     static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
         attr_done = true;
     }
     const int ncu = l2sb_ncu();
@@ -476,7 +611,7 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, st);
         a.trace = d_trace;
     }
-    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP>), dim3(grid), dim3(S2_NT), S2_LDS, st, a);
+    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP, F16>), dim3(grid), dim3(S2_NT), S2_LDS, st, a);
     MRX_LAUNCH_CHECK();
     if (a.trace) {
         (void)hipStreamSynchronize(st);
@@ -498,7 +633,7 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
     return MRX_OK;
 }
 static int l2sb_launch(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
-                       float* h_new, float* P, int B, int H, int W, void* stream) {
+                       float* h_new, float* P, int B, int H, int W, void* stream, const float* xmax = nullptr) {
     MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer2_sb: null pointer");
     MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer2_sb: bad dims");
     if (B == 0) return MRX_OK;
@@ -506,6 +641,8 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
     a.x = x, a.packed = reinterpret_cast<const u32x4*>(packed), a.b_conv = b_conv, a.b_ih = b_ih, a.hh = hh, a.hprev = h_prev, a.hnew = h_new;
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
     a.P = P, a.act = MRX_ACT_NONE, a.slope = 0.f;
+    a.xmax = reinterpret_cast<const unsigned*>(xmax);
+    if (xmax) return l2sb_launch_t<2, true, false, true>(a, (hipStream_t)stream);
     return l2sb_launch_t<2, true, false>(a, (hipStream_t)stream);
 }
 
@@ -523,7 +660,7 @@ extern "C" int mrx_conv3x3_sb(const float* x, const float* packed, const float* 
     L2sbArgs a;
     a.x = x, a.packed = reinterpret_cast<const u32x4*>(packed), a.b_conv = bias, a.b_ih = nullptr, a.hh = nullptr, a.hprev = nullptr, a.hnew = y;
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
-    a.P = nullptr, a.act = act, a.slope = slope;
+    a.P = nullptr, a.act = act, a.slope = slope, a.xmax = nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool zp = pad_mode == MRX_PAD_ZERO;
     if (dil == 1) return zp ? l2sb_launch_t<1, false, true>(a, st) : l2sb_launch_t<1, false, false>(a, st);
@@ -572,6 +709,30 @@ extern "C" int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const
 }
 
 // eta_out [B,H,W,2] = eta + permute(conv3x3_reppad(h_new, w_final) + b_final) from the tap products (rim_block.py:240-246)
+// ---- the same layer with the convolution's operands as TWO fp16 terms (mrx_rim_layer2_f16_*) --------------------------------------------
+// x = (h1 + h2) 2^-kx with h1 = fp16(x 2^kx), h2 = fp16(x 2^kx - h1) (11 + 11 significand bits), the weights likewise with 2^kw, and the three
+// term products of weight >= 2^-11 on v_mfma_f32_32x32x16_f16 with fp32 accumulation: half the MFMAs of the three-term bf16 form of the
+// convolution (432 instead of 864 per wave and tile), error per product <= ~3 x 2^-22.  fp16 has a narrow exponent range, so the operands are
+// scaled by exact powers of two: kw from max |w| at pack time, kx per launch from `xmax`, a device float holding an upper bound of max |x|
+// that the producer of x maintains (mrx_rim_layer_indrnn_packed_xmax / _llg_xmax: atomic max over its outputs).  A stale, larger bound is fine
+// (it costs nothing until it is 2^16 times too large); x must be non-negative-or-not, finite, and |x| <= *xmax.  The 1x1 and tap stages keep
+// the three-term bf16 form (their inputs are made inside the kernel: no bound is known for them).
+extern "C" int64_t mrx_rim_layer2_f16_pack_floats(void) { return (int64_t)S2F_PACK_U4 * 4; }
+extern "C" int mrx_rim_layer2_f16_pack(const float* w_conv, const float* w_ih, const float* w_final, float* packed, void* stream) {
+    MRX_REQUIRE(w_conv && packed, MRX_EINVAL, "mrx_rim_layer2_f16_pack: null pointer");
+    hipLaunchKernelGGL(k_l2f16_wscale, dim3(1), dim3(256), 0, (hipStream_t)stream, w_conv, reinterpret_cast<u32x4*>(packed));
+    hipLaunchKernelGGL(k_l2f16_pack, dim3((S2F_PACK_U4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, w_final,
+                       reinterpret_cast<u32x4*>(packed));
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// taps may be NULL (no final-convolution tap products)
+extern "C" int mrx_rim_layer2_f16(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
+                                  const float* h_prev, float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(xmax, MRX_EINVAL, "mrx_rim_layer2_f16: null pointer");
+    return l2sb_launch(x, packed, b_conv, b_ih, hh, h_prev, h_new, taps, B, H, W, stream, xmax);
+}
+
 extern "C" int mrx_rim_final_gather(const float* taps, const float* b_final, const float* eta, float* eta_out, int B, int H, int W, void* stream) {
     MRX_REQUIRE(taps && eta_out, MRX_EINVAL, "mrx_rim_final_gather: null pointer");
     MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_final_gather: bad dims");

@@ -386,8 +386,9 @@ def rim_layer1_inplace_ok(Cin, F, k, dilation):
             and os.environ.get("MRX_LAYER1_FP32", "0") in ("", "0") and not os.environ.get("MRX_TRACE") and not os.environ.get("MRX_ABLATE"))
 
 
-def rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None):
-    """The tuned fused first RIM layer reading log_likelihood_gradient's pieces (eta and the partial coil sums) directly."""
+def rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None, xmax=None):
+    """The tuned fused first RIM layer reading log_likelihood_gradient's pieces (eta and the partial coil sums) directly.  `xmax` as in
+    rim_layer_indrnn_packed."""
     eta = _lib.f32c(eta)
     B, H, W, _ = [int(v) for v in eta.shape]
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -396,6 +397,12 @@ def rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, packed, F, k, dilation
     hp = _lib.f32c(h_prev) if h_prev is not None else None
     if out is None:
         out = torch.empty(B, F, H, W, dtype=torch.float32, device=eta.device)
+    if xmax is not None:
+        _lib.check(_lib.lib().mrx_rim_layer_indrnn_packed_llg_xmax(_lib.ptr(eta), _lib.ptr(part), int(nparts), float(1.0 / (float(sigma) ** 2.0)),
+                                                                   _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp),
+                                                                   _lib.ptr(out), _lib.ptr(xmax), B, int(F), H, W, int(k), int(dilation),
+                                                                   _lib.stream_ptr()), "mrx_rim_layer_indrnn_packed_llg_xmax")
+        return out
     _lib.check(_lib.lib().mrx_rim_layer_indrnn_packed_llg(_lib.ptr(eta), _lib.ptr(part), int(nparts), float(1.0 / (float(sigma) ** 2.0)),
                                                           _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp),
                                                           _lib.ptr(out), B, int(F), H, W, int(k), int(dilation), _lib.stream_ptr()),
@@ -942,8 +949,14 @@ def rim_layer_pack(w_conv, w_ih):
     return packed
 
 
-def rim_layer_indrnn_packed(x, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None):
-    """Tuned fused ConvNonlinear(ReLU, replicate pad) + IndRNNCell(1x1) on pre-packed weights."""
+def rim_layer1_xmax_supported(Cin, F, k, dilation):
+    """The first-layer kernel can keep the bound of its outputs that rim_layer2_f16 scales by (mrx_rim_layer1_xmax_supported)."""
+    return bool(_lib.lib().mrx_rim_layer1_xmax_supported(int(Cin), int(F), int(k), int(dilation)))
+
+
+def rim_layer_indrnn_packed(x, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None, xmax=None):
+    """Tuned fused ConvNonlinear(ReLU, replicate pad) + IndRNNCell(1x1) on pre-packed weights.  `xmax` (one-element float32 device tensor):
+    the maximum of the outputs is folded into it with an atomic max (mrx_rim_layer_indrnn_packed_xmax)."""
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -952,6 +965,11 @@ def rim_layer_indrnn_packed(x, packed, F, k, dilation, b_conv, b_ih, hh, h_prev,
     hp = _lib.f32c(h_prev) if h_prev is not None else None
     if out is None:
         out = torch.empty(B, F, H, W, dtype=torch.float32, device=x.device)
+    if xmax is not None:
+        _lib.check(_lib.lib().mrx_rim_layer_indrnn_packed_xmax(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc),
+                                                               _lib.ptr(hp), _lib.ptr(out), _lib.ptr(xmax), B, Cin, int(F), H, W, int(k),
+                                                               int(dilation), _lib.stream_ptr()), "mrx_rim_layer_indrnn_packed_xmax")
+        return out
     _lib.check(_lib.lib().mrx_rim_layer_indrnn_packed(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc),
                                                       _lib.ptr(hp), _lib.ptr(out), B, Cin, int(F), H, W, int(k), int(dilation),
                                                       _lib.stream_ptr()), "mrx_rim_layer_indrnn_packed")
@@ -1011,6 +1029,42 @@ def rim_layer2_sb_taps(x, packed, b_conv, b_ih, hh, h_prev, taps=None, out=None)
     _lib.check(_lib.lib().mrx_rim_layer2_sb_taps(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp),
                                                  _lib.ptr(out), _lib.ptr(taps), B, H, W, _lib.stream_ptr()), "mrx_rim_layer2_sb_taps")
     return out, taps
+
+
+def rim_layer2_f16_pack(w_conv, w_ih, w_final=None):
+    """Operand pack of the second RIM layer with the convolution's weights as two fp16 terms scaled by a power of two (mrx_rim_layer2_f16_pack;
+    the 1x1 and final-conv operands as in rim_layer2_sb_pack)."""
+    w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
+    if tuple(w_conv.shape) != (64, 64, 3, 3) or tuple(w_ih.shape) != (64, 64, 1, 1):
+        raise NotImplementedError(f"rim_layer2_f16_pack: {tuple(w_conv.shape)} / {tuple(w_ih.shape)}")
+    if w_final is not None:
+        w_final = _lib.f32c(w_final.detach())
+        if tuple(w_final.shape) != (2, 64, 3, 3):
+            raise NotImplementedError(f"rim_layer2_f16_pack: final conv {tuple(w_final.shape)}")
+    packed = torch.empty(int(_lib.lib().mrx_rim_layer2_f16_pack_floats()), dtype=torch.float32, device=w_conv.device)
+    _lib.check(_lib.lib().mrx_rim_layer2_f16_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(w_final), _lib.ptr(packed), _lib.stream_ptr()),
+               "mrx_rim_layer2_f16_pack")
+    return packed
+
+
+def rim_layer2_f16(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps=None, out=None, want_taps=False):
+    """rim_layer2_sb / rim_layer2_sb_taps with the convolution's operands as two fp16 terms (mrx_rim_layer2_f16: half the MFMAs).  `xmax`: a
+    one-element float32 device tensor holding an upper bound of max |x| (kept by the producer of x: rim_layer_indrnn_packed*(xmax=...)).
+    Returns h_new, or (h_new, taps) with want_taps."""
+    x = _lib.f32c(x)
+    B, C, H, W = _nchw(x)
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    if want_taps and (taps is None or taps.numel() < 18 * B * H * W):
+        taps = torch.empty(B, 18, H, W, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_rim_layer2_f16(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out),
+                                             _lib.ptr(taps) if want_taps else None, _lib.ptr(xmax), B, H, W, _lib.stream_ptr()),
+               "mrx_rim_layer2_f16")
+    return (out, taps) if want_taps else out
 
 
 def rim_final_gather(taps, b_final, eta):

@@ -22,14 +22,17 @@ yt = ops.llg_prepare(y, False, "backward")
 op = ops.llg372_prepare(yt, S, mask, False)
 wf = r(2, F, 3, 3) / 24
 pk2 = ops.rim_layer2_sb_pack(wc, wi, wf)
+pk2h = ops.rim_layer2_f16_pack(wc, wi, wf)
+xmax = torch.zeros(1, device=dev)
 taps = torch.empty(B, 18, H, W, device=dev)
 work = torch.empty_like(y)
 torch.cuda.synchronize()
 for _ in range(3):
     part, n = ops.llg372(eta, op, 1.0, "backward", parts=True)
-    ops.rim_layer_indrnn_packed_llg(eta, part, n, 1.0, pk1, F, 5, 1, bc, bi, hh, hp)
+    h1 = ops.rim_layer_indrnn_packed_llg(eta, part, n, 1.0, pk1, F, 5, 1, bc, bi, hh, hp, xmax=xmax)      # (keeps the bound of its outputs in xmax)
+    ops.rim_layer2_f16(h1, pk2h, bc, bi, hh, hp, xmax, taps=taps, want_taps=True)                       # the headline loop's form
     ops.rim_layer_indrnn_wino(x, pk, F, bc, bi, hh, hp)
-    ops.rim_layer2_sb_taps(x, pk2, bc, bi, hh, hp, taps)      # the headline loop's form: + the final convolution's tap products
+    ops.rim_layer2_sb_taps(x, pk2, bc, bi, hh, hp, taps)      # the three-term bf16 form (MRIDC_AMD_LAYER2_F16=0)
     ops.rim_final_gather(taps, None, eta)
     ops.rim_final(x, wf, None, 3, 1, eta)
     ops.llg(eta, y, S, mask2d, 1.0, False, "backward", work=work)

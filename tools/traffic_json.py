@@ -14,7 +14,8 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "llg": ["k_llg372<"],
     "conv_layer1": ["k_rim_layer1_sb", "k_rim_layer<5, 1, 4"],
     "conv_layer2_wino": ["k_rim_layer_wino<0, true, 2, true"],
-    "conv_layer2_sb": ["k_rim_layer2_sb"],
+    "conv_layer2_sb": ["k_rim_layer2_sb<2, true, false, false>"],
+    "conv_layer2_f16": ["k_rim_layer2_sb<2, true, false, true>"],
     "final": ["k_rim_final4"],
     "final_gather": ["k_l2sb_gather"],
     "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_cols_dc_t4<", "k_rows_reduce<1", "k_pfa372_expand", "k_pfa372_reduce", "k_llg372_combine"],
@@ -55,7 +56,9 @@ def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None):
     if mf and cb:
         out["_mfma_util"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES and --pmc SQ_BUSY_CU_CYCLES (own passes): mfma_util = MFMA-pipe busy cycles "
                              "/ (4 SIMDs x CU busy cycles), per launch")
-        reg = [out["kernels"][k] for k in ("conv_layer1", "conv_layer2_sb", "final_gather") if k in out["kernels"]]
+        l2 = "conv_layer2_f16" if "conv_layer2_f16" in out["kernels"] else "conv_layer2_sb"     # the default route's kernel
+        out["_regulariser"] = ["conv_layer1", l2, "final_gather"]
+        reg = [out["kernels"][k] for k in ("conv_layer1", l2, "final_gather") if k in out["kernels"]]
         if len(reg) == 3:
             out["regulariser_mfma_util"] = sum(r["mfma_busy_cycles"] for r in reg) / (4.0 * sum(r["cu_busy_cycles"] for r in reg))
     print(json.dumps(out, indent=1))
