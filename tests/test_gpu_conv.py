@@ -576,3 +576,68 @@ def test_conv1x1_64_vs_oracle(dev, shape):
     assert_close(ops.conv2d(x2.to(dev), w2.to(dev), b2.to(dev), 1, ops.PAD_ZERO), F.conv2d(x2, w2, b2), 1e-5, "1x1 128 -> 128")
     assert_close(ops.indrnn_cell(x2.to(dev), w2.to(dev), b2.to(dev), hh2.to(dev), hp2.to(dev), 1),
                  oracle.rim.indrnn_cell(x2, hp2, w2, b2, hh2, 1, 1), 1e-5, "IndRNN cell, 128 features")
+
+
+@pytest.mark.parametrize("shape", [(1, 640, 372), (2, 37, 75), (1, 19, 33), (3, 16, 32), (1, 5, 3), (1, 1, 1)])
+def test_second_rim_layer_two_term_fp16_operands(shape, dev):
+    """mrx_rim_layer2_f16 (the convolution's operands as two fp16 terms scaled by powers of two, three term products per multiply) against a
+    float64 reference, the three-term bf16 kernel and the fp32 Winograd kernel: fp32-level error for any magnitude of x and w, with an exact
+    and with a stale (1000 x too large) bound of max |x|; the tap products of the final convolution as well.  rim_block.py:233-246."""
+    import torch.nn.functional as Fn
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    B, H, W = shape
+    F_ = 64
+    g = torch.Generator().manual_seed(11 + sum(shape))
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    for xs, ws, with_state, with_bias in ((1.0, 1.0, True, True), (1e-4, 50.0, False, True), (2e4, 1e-3, True, False)):
+        x, hp = r(B, F_, H, W).relu() * xs, r(B, F_, H, W).relu() * xs
+        wc, wi, wf = r(F_, F_, 3, 3) / 24 * ws, r(F_, F_, 1, 1) / 8, r(2, F_, 3, 3) / 24
+        b1, b2 = (r(F_) * 0.1 * xs * ws, r(F_) * 0.1) if with_bias else (None, None)
+        hh = r(1, F_, 1, 1) * 0.5
+        ref = Fn.conv2d(Fn.pad(x.double(), (2, 2, 2, 2), mode="replicate"), wc.double(), None if b1 is None else b1.double(), dilation=2).relu()
+        ref = Fn.conv2d(ref, wi.double(), None if b2 is None else b2.double())
+        ref = Fn.relu(ref + hh.double() * hp.double() if with_state else ref)
+        pk_h, pk_s, pk_w = ops.rim_layer2_f16_pack(wc, wi, wf), ops.rim_layer2_sb_pack(wc, wi, wf), ops.rim_layer_wino_pack(wc, wi)
+        xmax = x.abs().max().reshape(1).contiguous()
+        h = hp if with_state else None
+        got = ops.rim_layer2_f16(x, pk_h, b1, b2, hh, h, xmax)
+        stale = ops.rim_layer2_f16(x, pk_h, b1, b2, hh, h, xmax * 1000.0)
+        sb = ops.rim_layer2_sb(x, pk_s, b1, b2, hh, h)
+        win = ops.rim_layer_indrnn_wino(x, pk_w, F_, b1, b2, hh, h)
+        e_h, e_st, e_w, e_sb = rel_l2(got, ref), rel_l2(stale, ref), rel_l2(win, ref), rel_l2(sb, ref)
+        # (bias-dominated outputs: the 1x1 stage both split-operand kernels share accumulates on top of b_ih, the Winograd kernel adds it last)
+        bound = max(2.5 * e_w, 1.05 * e_sb) + 5e-8
+        assert e_h <= 6e-7 and e_h <= bound, (e_h, e_w, e_sb)
+        assert e_st <= 6e-7 and e_st <= bound, (e_st, e_w, e_sb)
+        assert rel_l2(got, sb) <= 8e-7
+        h_t, taps = ops.rim_layer2_f16(x, pk_h, b1, b2, hh, h, xmax, want_taps=True)
+        assert torch.equal(h_t, got)
+        _, taps_sb = ops.rim_layer2_sb_taps(x, pk_s, b1, b2, hh, h)
+        assert rel_l2(taps, taps_sb) <= 2e-6
+
+
+def test_first_rim_layer_keeps_the_bound_of_its_outputs(dev):
+    """mrx_rim_layer_indrnn_packed_xmax / _llg_xmax: the maximum of the outputs is folded into the device scalar with an atomic max (exact, never
+    lowered), the outputs themselves are those of the plain calls."""
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    for B, H, W in ((1, 640, 372), (2, 37, 75), (1, 5, 3)):
+        x, hp = r(B, 4, H, W), r(B, 64, H, W).relu()
+        w, wi = r(64, 4, 5, 5) * 0.15, r(64, 64, 1, 1) * 0.2
+        b, bi, hh = r(64) * 0.1, r(64) * 0.1, r(1, 64, 1, 1) * 0.5
+        assert ops.rim_layer1_xmax_supported(4, 64, 5, 1)
+        pk = ops.rim_layer_pack(w, wi)
+        plain = ops.rim_layer_indrnn_packed(x, pk, 64, 5, 1, b, bi, hh, hp)
+        xmax = torch.zeros(1, device=dev)
+        got = ops.rim_layer_indrnn_packed(x, pk, 64, 5, 1, b, bi, hh, hp, xmax=xmax)
+        assert torch.equal(got, plain)
+        assert float(xmax) == float(plain.max())
+        ops.rim_layer_indrnn_packed(x * 0.01, pk, 64, 5, 1, b, bi, hh, hp * 0.01, xmax=xmax)       # smaller outputs: the bound stays
+        assert float(xmax) == float(plain.max())
+        eta, part = r(B, H, W, 2), r(3, B, H, W, 2)
+        a = ops.rim_layer_indrnn_packed_llg(eta, part, 3, 0.9, pk, 64, 5, 1, b, bi, hh, hp)
+        xm2 = torch.zeros(1, device=dev)
+        a2 = ops.rim_layer_indrnn_packed_llg(eta, part, 3, 0.9, pk, 64, 5, 1, b, bi, hh, hp, xmax=xm2)
+        assert torch.equal(a, a2) and float(xm2) == float(a.max())

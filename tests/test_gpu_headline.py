@@ -533,3 +533,37 @@ def test_rim_block_general_mask_at_w372(dev):
     finally:
         ops.LLG_T4 = keep
     assert rel_l2(outs[True], outs[False]) <= 5e-6
+
+
+@pytest.mark.parametrize("shape", [(15, 640, 372), (6, 37, 75)])
+def test_rim_block_fp16_route_on_and_off(dev, shape):
+    """RIMBlock with the dominant layer's convolution on two-term fp16 operands (the default: stack 0 keeps the bound of its outputs, stack 1
+    scales by it) and on the three-term bf16 form (MRIDC_AMD_LAYER2_F16=0), 8 steps, both against the oracle and against each other."""
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    C, H, W = shape
+    cfg, model, sd = _cirim(dict(num_cascades=1), 1.0)
+    d = synthetic.make_slice(C, H, W, slice_idx=5)
+    rc = oracle.rim.RIMConfig(**{k: cfg[k] for k in ("recurrent_layer", "conv_filters", "conv_kernels", "conv_dilations", "conv_bias",
+                                                     "recurrent_filters", "recurrent_kernels", "recurrent_dilations", "recurrent_bias",
+                                                     "depth", "no_dc", "fft_centered", "fft_normalization", "spatial_dims", "coil_dim")},
+                              time_steps=8)
+    p = {k[len("cirim.0."):]: v for k, v in sd.items() if k.startswith("cirim.0.")}
+    with torch.no_grad():
+        ref, ref_hx = oracle.rim.rim_block_forward(p, rc, d["y"], d["y"], d["sensitivity_maps"], d["mask"], None, None, 1.0, False)
+    blk = model.cirim[0].to(dev)
+    y, S, m = d["y"].to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev)
+    assert blk._f16_route()
+    outs = {}
+    keep = RIMBlock.layer2_f16
+    try:
+        for f16 in (True, False):
+            RIMBlock.layer2_f16 = f16
+            with torch.no_grad():
+                etas, hx = blk(y, y, S, m, None, None, 1.0, keep_eta=False)
+            assert_close(torch.stack(etas), torch.stack(ref), 2e-5, f"8-step block, fp16 route {f16}")
+            for j in range(2):
+                assert_close(hx[j], ref_hx[j], 2e-5, f"hidden state {j}, fp16 route {f16}")
+            outs[f16] = etas[-1]
+    finally:
+        RIMBlock.layer2_f16 = keep
+    assert rel_l2(outs[True], outs[False]) <= 5e-6
