@@ -773,10 +773,10 @@ def main():
             kname = ("k_rim_layer2_sb<.., F16> (conv3x3 d2 64->64 direct form + IndRNN 1x1 fused + the channel contraction of the final 3x3 64->2 "
                      "convolution on the new state; convolution operands = 2 fp16 terms scaled by powers of two (x by the bound of its maximum that "
                      "layer 1 keeps, w at pack time), 3 term products per multiply on v_mfma_f32_32x32x16_f16, fp32 accumulation: error against "
-                     "float64 2.3e-7 (three-term bf16 form 2.8e-7, fp32 Winograd 2.0e-7); 36 steps x 6 MFMAs + the 1x1 and tap stages in the "
-                     "three-term bf16 form (4 + 4 steps x 6 products x cout blocks) = 288 MFMAs per 32 pixels; fp16 and bf16 MFMAs issue at the "
-                     "same rate, priced against the same dense peak)")
-            executed = (288 * 32 * 32 * 16 * 2 / 32.0) * npix * B
+                     "float64 2.3e-7 (three-term bf16 form 2.8e-7, fp32 Winograd 2.0e-7); 36 steps x 6 MFMAs + the 1x1 and tap stages with two fp16 terms "
+                     "scaled per pixel (4 steps x 6 + 4 steps x 3) = 252 MFMAs per 32 pixels; fp16 and bf16 MFMAs issue at the same rate, priced "
+                     "against the same dense peak)")
+            executed = (252 * 32 * 32 * 16 * 2 / 32.0) * npix * B
             flops2 += 2.0 * F_hidden * 2 * 9 * npix * B
         traffic = measured_traffic(B, C, H, W, F_hidden)
         tf = (lambda fl: fl / (ms2 * 1e-3) / 1e12) if ms2 else (lambda fl: None)

@@ -150,21 +150,31 @@ __global__ void k_l2sb_pack(const float* __restrict__ w, const float* __restrict
 }
 
 // F16 pack.  Step 1: the weight scale exponent kw (max |w| * 2^kw in [2^14, 2^15)) into the header element.
-__global__ void k_l2f16_wscale(const float* __restrict__ w, u32x4* __restrict__ out) {
+// (header element: [0] the convolution's exponent, [1] the 1x1 weights', [2] the final convolution's)
+__global__ void k_l2f16_wscale(const float* __restrict__ w, const float* __restrict__ w_ih, const float* __restrict__ w_final, u32x4* __restrict__ out) {
     __shared__ float red[256];
-    float m = 0.f;
-    for (int i = threadIdx.x; i < S2_F * S2_F * 9; i += 256) m = fmaxf(m, fabsf(w[i]));
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    unsigned ex[3] = {0u, 0u, 0u};
+    for (int which = 0; which < 3; ++which) {
+        const float* p = which == 0 ? w : (which == 1 ? w_ih : w_final);
+        const int n = which == 0 ? S2_F * S2_F * 9 : (which == 1 ? S2_F * S2_F : 2 * S2_F * 9);
+        float m = 0.f;
+        if (p)
+            for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(p[i]));
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+            __syncthreads();
+        }
+        ex[which] = (unsigned)s2_scale_exp(__float_as_uint(red[0]));
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[S2F_PACK_U4 - 1] = u32x4{(unsigned)s2_scale_exp(__float_as_uint(red[0])), 0u, 0u, 0u};
+    if (threadIdx.x == 0) out[S2F_PACK_U4 - 1] = u32x4{ex[0], ex[1], ex[2], 0u};
 }
 // Step 2: conv operands as two fp16 terms of w * 2^kw, in the layout of k_l2sb_pack with two terms:
 //   out[q * S2F_WCH + ((s*2 + t)*2 + blk)*64 + lane][j] (s < 4), out[q * S2F_WCH + S2F_WFULL + (t*2 + blk)*32 + l][j] (tap 8);
-// the 1x1 / final-conv operands (three bf16 terms) follow as in k_l2sb_pack.
+// the 1x1 / final-conv operands follow at the offsets of k_l2sb_pack, as two fp16 terms too (scaled by their own exponents):
+//   ih   : [((s*2 + t)*2 + blk)*64 + lane] (1024 of the S2_WIH elements), final: [(s*2 + t)*64 + lane] (512 of the S2_WP elements); the rest is zero.
 __global__ void k_l2f16_pack(const float* __restrict__ w, const float* __restrict__ w_ih, const float* __restrict__ w_final, u32x4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S2F_PACK_U4 - 1) return;
@@ -196,32 +206,57 @@ __global__ void k_l2f16_pack(const float* __restrict__ w, const float* __restric
         return;
     } else if (i < S2_NCH * S2F_WCH + S2_WIH) {
         int r = i - S2_NCH * S2F_WCH;
+        if (r >= 4 * 2 * 2 * 64) {
+            out[i] = u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
+        const float sw = s2_pow2((int)out[S2F_PACK_U4 - 1][1]);
         const int lane = r & 63;
         r >>= 6;
         const int blk = r & 1;
         r >>= 1;
-        t = r % 3;
-        const int s = r / 3, o = 32 * blk + (lane & 31);
+        t = r & 1;
+        const int s = r >> 1, o = 32 * blk + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = w_ih ? w_ih[o * S2_F + s2_chan(8 * s + j, lane >> 5)] : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = w_ih ? w_ih[o * S2_F + s2_chan(8 * s + j, lane >> 5)] * sw : 0.f;
     } else {
         int r = i - S2_NCH * S2F_WCH - S2_WIH;
+        if (r >= 4 * 2 * 64) {
+            out[i] = u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
+        const float sw = s2_pow2((int)out[S2F_PACK_U4 - 1][2]);
         const int lane = r & 63;
         r >>= 6;
-        t = r % 3;
-        const int s = r / 3, m = lane & 31;
+        t = r & 1;
+        const int s = r >> 1, m = lane & 31;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (w_final && m < 18) ? w_final[((long long)(m & 1) * S2_F + s2_chan(8 * s + j, lane >> 5)) * 9 + (m >> 1)] : 0.f;
+        for (int j = 0; j < 8; ++j)
+            v[j] = (w_final && m < 18) ? w_final[((long long)(m & 1) * S2_F + s2_chan(8 * s + j, lane >> 5)) * 9 + (m >> 1)] * sw : 0.f;
     }
     unsigned p[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        unsigned p1, p2, p3;
-        s2_split2(v[2 * k], v[2 * k + 1], p1, p2, p3);
-        p[k] = t == 0 ? p1 : (t == 1 ? p2 : p3);
+        unsigned p1, p2;
+        s2_split2h(v[2 * k], v[2 * k + 1], p1, p2);
+        p[k] = t == 0 ? p1 : p2;
     }
     out[i] = u32x4{p[0], p[1], p[2], p[3]};
 }
+
+// one pixel's scale for a contraction over its channels only (1x1 / tap stages): the lane's 32 values and the 32 of lane ^ 32 are the 64
+// channels of the pixel; returns k with max * 2^k in [2^14, 2^15)
+__device__ __forceinline__ int s2_pixel_exp(float m) {
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    return s2_scale_exp(__float_as_uint(m));
+}
+#define S2_MFMA6H(ACC, A, B1, B2)                                                                \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][1], B1, ACC[0], 0, 0, 0);                \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][1], B1, ACC[1], 0, 0, 0);                \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], B2, ACC[0], 0, 0, 0);                \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], B2, ACC[1], 0, 0, 0);                \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], B1, ACC[0], 0, 0, 0);                \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], B1, ACC[1], 0, 0, 0);
 
 #define S2_MFMA12(ACC, A, B1, B2, B3)                                                             \
     ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][2], B1, ACC[0], 0, 0, 0);               \
@@ -272,6 +307,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         const int kx = s2_scale_exp(a.xmax[0]), kw = (int)a.packed[S2F_PACK_U4 - 1][0];
         sx = s2_pow2(kx), unx = s2_pow2(-kx), unw = s2_pow2(-kw);
     }
+    const float unwi = F16 ? s2_pow2(-(int)a.packed[S2F_PACK_U4 - 1][1]) : 1.f, unwp = F16 ? s2_pow2(-(int)a.packed[S2F_PACK_U4 - 1][2]) : 1.f;
     if (tid == 0) *reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_ZERO) = u32x4{0u, 0u, 0u, 0u};
     if (tid < 64) {
         const int tc = s2_chan(tid >> 1, tid & 1);
@@ -481,8 +517,40 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[ct][r] = tabl[128 + 2 * (ct * 16 + r) + lhi];
+                for (int r = 0; r < 16; ++r) acc2[ct][r] = F16 ? 0.f : tabl[128 + 2 * (ct * 16 + r) + lhi];
             const u32x4* wl = Wih + lane;
+            if constexpr (F16) {
+                // two fp16 terms, scaled per PIXEL: the contraction runs over the pixel's 64 channels only (this lane's 32 and lane ^ 32's)
+                float gm = 0.f;
+#pragma unroll
+                for (int R = 0; R < 32; ++R) gm = fmaxf(gm, acc[rw][R >> 4][R & 15]);
+                const int kg = s2_pixel_exp(gm);
+                const float sg = s2_pow2(kg), ung = s2_pow2(-kg);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    unsigned g1[4], g2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int R0 = 8 * s + 2 * k, R1 = R0 + 1;
+                        float v0 = acc[rw][R0 >> 4][R0 & 15], v1 = acc[rw][R1 >> 4][R1 & 15];
+                        v0 = v0 > 0.f ? v0 : 0.f;
+                        v1 = v1 > 0.f ? v1 : 0.f;
+                        s2_split2h(v0 * sg, v1 * sg, g1[k], g2[k]);
+                    }
+                    const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
+                    const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
+                    f16x8 at[2][2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) at[ct][k] = __builtin_bit_cast(f16x8, wl[((s * 2 + k) * 2 + ct) * 64]);
+                    S2_MFMA6H(acc2, at, b1, b2)
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[ct][r] = acc2[ct][r] * ung * unwi + tabl[128 + 2 * (ct * 16 + r) + lhi];
+            } else
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 unsigned g1[4], g2[4], g3[4];
@@ -523,6 +591,28 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accp[r] = 0.f;
                 const u32x4* wp = reinterpret_cast<const u32x4*>(smem_s2 + S2_OFF_WP) + lane;
+                if constexpr (F16) {
+                    float hm = 0.f;
+#pragma unroll
+                    for (int R = 0; R < 32; ++R) hm = fmaxf(hm, hp[rw][R]);
+                    const int kh = s2_pixel_exp(hm);
+                    const float sh = s2_pow2(kh), unh = s2_pow2(-kh);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        unsigned g1[4], g2[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) s2_split2h(hp[rw][8 * s + 2 * k] * sh, hp[rw][8 * s + 2 * k + 1] * sh, g1[k], g2[k]);
+                        const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
+                        const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
+                        const f16x8 a1 = __builtin_bit_cast(f16x8, wp[(s * 2 + 0) * 64]);
+                        const f16x8 a2 = __builtin_bit_cast(f16x8, wp[(s * 2 + 1) * 64]);
+                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, accp, 0, 0, 0);
+                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, accp, 0, 0, 0);
+                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, accp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accp[r] = accp[r] * unh * unwp;
+                } else
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     unsigned g1[4], g2[4], g3[4];
@@ -720,7 +810,7 @@ extern "C" int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const
 extern "C" int64_t mrx_rim_layer2_f16_pack_floats(void) { return (int64_t)S2F_PACK_U4 * 4; }
 extern "C" int mrx_rim_layer2_f16_pack(const float* w_conv, const float* w_ih, const float* w_final, float* packed, void* stream) {
     MRX_REQUIRE(w_conv && packed, MRX_EINVAL, "mrx_rim_layer2_f16_pack: null pointer");
-    hipLaunchKernelGGL(k_l2f16_wscale, dim3(1), dim3(256), 0, (hipStream_t)stream, w_conv, reinterpret_cast<u32x4*>(packed));
+    hipLaunchKernelGGL(k_l2f16_wscale, dim3(1), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, w_final, reinterpret_cast<u32x4*>(packed));
     hipLaunchKernelGGL(k_l2f16_pack, dim3((S2F_PACK_U4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_conv, w_ih, w_final,
                        reinterpret_cast<u32x4*>(packed));
     MRX_LAUNCH_CHECK();
