@@ -795,7 +795,8 @@ def main():
         flops_reg = 105216.0 * npix * B                     # 25.05 GFLOP per slice-step (direct form)
         flops1 = 2.0 * (F_hidden * 4 * 25 + F_hidden * F_hidden) * npix * B
         l1_bf16 = F_hidden == 64 and os.environ.get("MRX_LAYER1_FP32", "0") in ("", "0")
-        issued1_bf16 = (132 * 32 * 32 * 16 * 2 / 32.0) * npix * B if l1_bf16 else 0.0
+        l1_f16 = l1_bf16 and os.environ.get("MRX_LAYER1_F16", "1") not in ("0",)       # two-term fp16 operands: 66 MFMAs per 32 pixels instead of 132
+        issued1_bf16 = ((66 if l1_f16 else 132) * 32 * 32 * 16 * 2 / 32.0) * npix * B if l1_bf16 else 0.0
         issued2_bf16 = executed if l2_bf16 else 0.0
         issued_l1_only = issued1_bf16             # layer 1's own bf16 MFMA work (for layer1_frac_issued)
         issued1_bf16 += issued2_bf16             # everything issued on the bf16 pipe
@@ -831,7 +832,8 @@ def main():
                                               "the bf16 matrix pipe with fp32 results via the three-term split; final conv 64->2: its channel contraction in layer 2's tail on the "
                                               "matrix pipe + a 9-tap gather (default), or -- MRIDC_AMD_FUSED_FINAL=0 -- on the vector ALUs (its 0.55 GFLOP counted at the fp32 rate).  frac_issued = (fp32 work / fp32 peak + bf16 work / "
                                               "dense bf16 peak) / measured time",
-                                         layer1_ms=ms1, layer1_kernel="k_rim_layer1_sb" if l1_bf16 else "k_rim_layer<5,1,4>",
+                                         layer1_ms=ms1, layer1_kernel=("k_rim_layer1_sb<F16> (two fp16 terms per operand, per-unit / per-pixel scales, 3 term products)" if l1_f16 else
+                                                        "k_rim_layer1_sb (three bf16 terms, 6 term products)") if l1_bf16 else "k_rim_layer<5,1,4>",
                                          layer1_frac_issued=(pipe_ms(0.0 if l1_bf16 else flops1, issued_l1_only) / ms1) if ms1 else None,
                                          layer1_hbm_frac=((2.0 * F_hidden + 8.0) * 4 * npix * B / (ms1 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms1 else None,   # h_prev in, h out, (eta, partial sums)
                                          # the two kernels that run on the matrix cores, on their own

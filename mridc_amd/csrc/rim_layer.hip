@@ -537,6 +537,8 @@ extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, 
             s.B = B, s.Cin = Cin, s.H = H, s.W = W, s.tiles_x = a.tiles_x, s.ntiles = a.tiles_x * mrx_cdiv(H, MRX_L1SB_TH);
             s.eta2 = a.eta2, s.part = a.part, s.part_stride = a.part_stride, s.nparts = a.nparts, s.post = a.post;
             s.xmax = reinterpret_cast<unsigned*>(g_l1_xmax);
+            static const int l1_f16 = (getenv("MRX_LAYER1_F16") && atoi(getenv("MRX_LAYER1_F16")) == 0) ? 0 : 1;   // 0: the three-term bf16 form
+            s.f16 = l1_f16;
             return mrx_l1sb_launch(s, st);
         }
     }

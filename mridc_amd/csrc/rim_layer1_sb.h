@@ -2,7 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define MRX_L1SB_PACK_FLOATS 16896   // three bf16 terms of the 5x5 (28 taps x 4 channels) and 1x1 weights in A-operand lane order
+#define MRX_L1SB_PACK_FLOATS 28164   // three bf16 terms of the 5x5 (28 taps x 4 channels) and 1x1 weights in A-operand lane order (16896 floats), then the same
+                                     // weights as two scaled fp16 terms (7 x 2 x 2 x 64 + 4 x 2 x 2 x 64 operands) and one header element with the two scale exponents
 
 struct MrxL1sbArgs {
     const float* x;        // [B,Cin,H,W], Cin <= 4 (unused when eta2 is set)
@@ -18,6 +19,7 @@ struct MrxL1sbArgs {
     long long part_stride;
     int nparts;
     float post;
+    int f16;               // 1: two-term fp16 operands (per-unit / per-pixel scales), 0: three-term bf16
     unsigned* xmax;        // not null: atomic max of the bits of every output (outputs are >= 0: ReLU) -- the bound mrx_rim_layer2_f16 scales by
 };
 

@@ -48,7 +48,30 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define SB_KS2 4                            // 1x1 MFMA steps: 64 channels / 16
 #define SB_WCONV (SB_KS * 3 * 2 * 64)       // 16-byte A operands of the conv part
 #define SB_WIH (SB_KS2 * 3 * 2 * 64)
-static_assert((SB_WCONV + SB_WIH) * 4 == MRX_L1SB_PACK_FLOATS, "pack size");
+// two-term fp16 form (F16): operands [(s*2 + t)*2 + blk)*64 + lane], header = (conv exponent, 1x1 exponent)
+#define SBH_WCONV (SB_KS * 2 * 2 * 64)
+#define SBH_WIH (SB_KS2 * 2 * 2 * 64)
+#define SBH_OFF (SB_WCONV + SB_WIH)         // where the fp16 section starts in the pack (16-byte units)
+static_assert((SB_WCONV + SB_WIH + SBH_WCONV + SBH_WIH + 1) * 4 == MRX_L1SB_PACK_FLOATS, "pack size");
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// two fp16 terms of a pair of values already scaled into the fp16 range
+__device__ __forceinline__ void sb_split2h(float a, float b, unsigned& p1, unsigned& p2) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    const float ra = a - (float)h.x, rb = b - (float)h.y;     // exact
+    const f16x2 l = {(_Float16)ra, (_Float16)rb};
+    p1 = __builtin_bit_cast(unsigned, h);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ float sb_pow2(int e) {
+    e = e < -120 ? -120 : (e > 120 ? 120 : e);
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
+// exponent k with m * 2^k in [2^14, 2^15) (0 for zero / non-finite m)
+__device__ __forceinline__ int sb_scale_exp(float m) {
+    const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    return (ex == 0 || ex == 255) ? 0 : 14 - (ex - 127);
+}
 
 __device__ __forceinline__ unsigned sb_pk(float lo, float hi) {   // two fp32 -> packed bf16 pair (lo in bits 0-15), round to nearest even
     unsigned r;
@@ -101,7 +124,61 @@ __global__ void k_l1sb_pack(const float* __restrict__ w, const float* __restrict
     out[i] = u32x4{p[0], p[1], p[2], p[3]};
 }
 
+// fp16 section: the scale exponents (max |w| 2^k in [2^14, 2^15)) into the header, then the operands
+__global__ void k_l1f16_wscale(const float* __restrict__ w, const float* __restrict__ w_ih, u32x4* __restrict__ out, int Cin) {
+    __shared__ float red[256];
+    unsigned ex[2] = {0u, 0u};
+    for (int which = 0; which < 2; ++which) {
+        const float* p = which == 0 ? w : w_ih;
+        const int n = which == 0 ? SB_F * Cin * SB_K * SB_K : SB_F * SB_F;
+        float m = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(p[i]));
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+            __syncthreads();
+        }
+        ex[which] = (unsigned)sb_scale_exp(red[0]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[SBH_OFF + SBH_WCONV + SBH_WIH] = u32x4{ex[0], ex[1], 0u, 0u};
+}
+__global__ void k_l1f16_pack(const float* __restrict__ w, const float* __restrict__ w_ih, u32x4* __restrict__ out, int Cin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SBH_WCONV + SBH_WIH) return;
+    const bool conv = i < SBH_WCONV;
+    const u32x4 hd = out[SBH_OFF + SBH_WCONV + SBH_WIH];
+    const float sw = sb_pow2((int)(conv ? hd[0] : hd[1]));
+    int r = conv ? i : i - SBH_WCONV;
+    const int lane = r & 63;
+    r >>= 6;
+    const int blk = r & 1;
+    r >>= 1;
+    const int t = r & 1, s = r >> 1;
+    const int o = 32 * blk + (lane & 31), half = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (conv) {
+            const int ci = j & 3, tap = 4 * s + 2 * half + (j >> 2);
+            v[j] = (tap < SB_K * SB_K && ci < Cin) ? w[((long long)o * Cin + ci) * (SB_K * SB_K) + tap] * sw : 0.f;
+        } else
+            v[j] = w_ih[o * SB_F + sb_chan(8 * s + j, half)] * sw;
+    }
+    unsigned p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned p1, p2;
+        sb_split2h(v[2 * q], v[2 * q + 1], p1, p2);
+        p[q] = t == 0 ? p1 : p2;
+    }
+    out[SBH_OFF + i] = u32x4{p[0], p[1], p[2], p[3]};
+}
+
 int mrx_l1sb_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, hipStream_t st) {
+    hipLaunchKernelGGL(k_l1f16_wscale, dim3(1), dim3(256), 0, st, w_conv, w_ih, reinterpret_cast<u32x4*>(packed), Cin);
+    hipLaunchKernelGGL(k_l1f16_pack, dim3((SBH_WCONV + SBH_WIH + 255) / 256), dim3(256), 0, st, w_conv, w_ih, reinterpret_cast<u32x4*>(packed), Cin);
     hipLaunchKernelGGL(k_l1sb_pack, dim3((SB_WCONV + SB_WIH + 255) / 256), dim3(256), 0, st, w_conv, w_ih, reinterpret_cast<u32x4*>(packed), Cin);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
@@ -130,6 +207,15 @@ int mrx_l1sb_pack(const float* w_conv, const float* w_ih, float* packed, int Cin
     ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][0], B1, ACC[0], 0, 0, 0);               \
     ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][0], B1, ACC[1], 0, 0, 0);
 
+// two fp16 terms per operand: the three products of weight >= 2^-11, smallest first, both cout blocks
+#define SB_MFMA6H(ACC, A, B1, B2)                                                                \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][1], B1, ACC[0], 0, 0, 0);                \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][1], B1, ACC[1], 0, 0, 0);                \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], B2, ACC[0], 0, 0, 0);                \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], B2, ACC[1], 0, 0, 0);                \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], B1, ACC[0], 0, 0, 0);                \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], B1, ACC[1], 0, 0, 0);
+
 #define SB_PROWS SB_K                       // a wave's patch: 5 rows x 36 pixels
 #define SB_PPIX (SB_PROWS * SB_PW)          // 180
 #define SB_PSTR 184                         // term-plane stride in the wave's LDS patch
@@ -138,24 +224,29 @@ int mrx_l1sb_pack(const float* w_conv, const float* w_ih, float* packed, int Cin
 // One persistent workgroup per CU, 16 waves (4 per SIMD), weights staged once.  After the single barrier every wave walks its own units
 // (image row x 32 pixels x 64 channels) start to finish: patch -> LDS (wave-private), conv, 1x1, epilogue.  Nothing is prefetched across
 // units: with four independent waves per SIMD at different points of that sequence, one wave's memory phase runs under the others' MFMAs.
+// F16: the operands as two fp16 terms (three term products per multiply instead of six) -- the patch scaled by the power of two that puts the
+// UNIT's largest input into [2^14, 2^15) (every input of the unit's outputs is in the wave's patch), ReLU(conv + b) scaled per PIXEL for the 1x1
+// stage (contraction over the pixel's channels only), the weights at pack time; the accumulators are scaled back exactly before the biases.
+template <bool F16>
 __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
+    constexpr int NT = F16 ? 2 : 3, WCONV = F16 ? SBH_WCONV : SB_WCONV, WIH = F16 ? SBH_WIH : SB_WIH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];
-    u32x4* Wl = reinterpret_cast<u32x4*>(smem_sb);                                        // [SB_WCONV + SB_WIH] A operands
-    float* tabl = reinterpret_cast<float*>(smem_sb + (SB_WCONV + SB_WIH) * 16);           // hh, b_conv, b_ih in register order [R][half]
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem_sb);                                        // [WCONV + WIH] A operands
+    float* tabl = reinterpret_cast<float*>(smem_sb + (WCONV + WIH) * 16);                 // hh, b_conv, b_ih in register order [R][half]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    u32x2* Xw = reinterpret_cast<u32x2*>(smem_sb + (SB_WCONV + SB_WIH) * 16 + 256 * 4) + wave * (3 * SB_PSTR);   // this wave's patch
+    u32x2* Xw = reinterpret_cast<u32x2*>(smem_sb + (WCONV + WIH) * 16 + 256 * 4) + wave * (NT * SB_PSTR);   // this wave's patch
     const long long plane = (long long)a.H * a.W;
     const int total = a.ntiles * a.B;
 
     // ---- once per workgroup: weights and tables into LDS ----------------------------------------------------------------------------------
     {
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed);
-        constexpr int WIT = (SB_WCONV + SB_WIH + SB_NT - 1) / SB_NT;
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed) + (F16 ? SBH_OFF : 0);
+        constexpr int WIT = (WCONV + WIH + SB_NT - 1) / SB_NT;
         u32x4 wreg[WIT];
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const int i = tid + it * SB_NT;
-            wreg[it] = src[i < SB_WCONV + SB_WIH ? i : SB_WCONV + SB_WIH - 1];
+            wreg[it] = src[i < WCONV + WIH ? i : WCONV + WIH - 1];
         }
         if (tid < 64) {
             const int tc = sb_chan(tid >> 1, tid & 1);
@@ -167,8 +258,13 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const int i = tid + it * SB_NT;
-            if (i < SB_WCONV + SB_WIH) Wl[i] = wreg[it];
+            if (i < WCONV + WIH) Wl[i] = wreg[it];
         }
+    }
+    float unwc = 1.f, unwi = 1.f;            // F16: 2^-k of the weight scales
+    if constexpr (F16) {
+        const u32x4 hd = reinterpret_cast<const u32x4*>(a.packed)[SBH_OFF + SBH_WCONV + SBH_WIH];
+        unwc = sb_pow2(-(int)hd[0]), unwi = sb_pow2(-(int)hd[1]);
     }
     __syncthreads();      // the only workgroup barrier
 
@@ -201,8 +297,9 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
             }
         }
     };
-    // finish the patch, split it into its three bf16 terms and write the wave's LDS planes
-    auto commit_patch = [&](int b, const float (&raw)[SB_PSLOT][10], const unsigned (&off)[SB_PSLOT]) {
+    // finish the patch, split it into its bf16 / fp16 terms and write the wave's LDS planes; returns 2^-k of the unit's scale (F16)
+    auto commit_patch = [&](int b, const float (&raw)[SB_PSLOT][10], const unsigned (&off)[SB_PSLOT]) -> float {
+        float cc[SB_PSLOT][4];
 #pragma unroll
         for (int q = 0; q < SB_PSLOT; ++q) {
             float c0, c1, c2, c3;
@@ -223,16 +320,42 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
                 c2 = a.Cin > 2 ? raw[q][2] : 0.f;
                 c3 = a.Cin > 3 ? raw[q][3] : 0.f;
             }
-            unsigned p1, p2, p3, q1, q2, q3;
-            sb_split2(c0, c1, p1, p2, p3);
-            sb_split2(c2, c3, q1, q2, q3);
+            cc[q][0] = c0, cc[q][1] = c1, cc[q][2] = c2, cc[q][3] = c3;
+        }
+        float sxu = 1.f, unx = 1.f;
+        if constexpr (F16) {
+            float m = 0.f;
+#pragma unroll
+            for (int q = 0; q < SB_PSLOT; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m = fmaxf(m, fabsf(cc[q][c]));
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const int kx = sb_scale_exp(m);
+            sxu = sb_pow2(kx), unx = sb_pow2(-kx);
+        }
+#pragma unroll
+        for (int q = 0; q < SB_PSLOT; ++q) {
             const int p = lane + 64 * q;
-            if (p < SB_PPIX) {
-                Xw[p] = u32x2{p1, q1};
-                Xw[SB_PSTR + p] = u32x2{p2, q2};
-                Xw[2 * SB_PSTR + p] = u32x2{p3, q3};
+            if constexpr (F16) {
+                unsigned p1, p2, q1, q2;
+                sb_split2h(cc[q][0] * sxu, cc[q][1] * sxu, p1, p2);
+                sb_split2h(cc[q][2] * sxu, cc[q][3] * sxu, q1, q2);
+                if (p < SB_PPIX) {
+                    Xw[p] = u32x2{p1, q1};
+                    Xw[SB_PSTR + p] = u32x2{p2, q2};
+                }
+            } else {
+                unsigned p1, p2, p3, q1, q2, q3;
+                sb_split2(cc[q][0], cc[q][1], p1, p2, p3);
+                sb_split2(cc[q][2], cc[q][3], q1, q2, q3);
+                if (p < SB_PPIX) {
+                    Xw[p] = u32x2{p1, q1};
+                    Xw[SB_PSTR + p] = u32x2{p2, q2};
+                    Xw[2 * SB_PSTR + p] = u32x2{p3, q3};
+                }
             }
         }
+        return unx;
     };
     auto unit_of = [&](int t, int& b, int& oy, int& w0) {
         const int tt = (int)mrx_xcd_band(t, total);
@@ -247,11 +370,12 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
         int b, oy, w0;
         unit_of(t, b, oy, w0);
         if (oy >= a.H) continue;             // wave-uniform: rows past the image (H % 16 != 0)
+        float unx = 1.f;
         {
             float raw[SB_PSLOT][10];
             unsigned roff[SB_PSLOT];
             load_patch(b, oy, w0, raw, roff);
-            commit_patch(b, raw, roff);
+            unx = commit_patch(b, raw, roff);
         }
         // wave-private LDS: program order is enough, no barrier
 
@@ -260,7 +384,7 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = tabl[64 + 2 * (ct * 16 + r) + lhi];
+            for (int r = 0; r < 16; ++r) acc[ct][r] = F16 ? 0.f : tabl[64 + 2 * (ct * 16 + r) + lhi];
         {
             const u32x2* xw = Xw + l31;
             const u32x4* wl = Wl + lane;
@@ -268,16 +392,35 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
             for (int s = 0; s < SB_KS; ++s) {
                 auto toff = [](int tp) { return tp < SB_K * SB_K ? (tp / SB_K) * SB_PW + (tp % SB_K) : 0; };   // zero-weight taps read pixel 0
                 const int offA = lhi ? toff(4 * s + 2) : toff(4 * s), offB = lhi ? toff(4 * s + 3) : toff(4 * s + 1);
-                bf16x8 bt[3], at[2][3];
+                if constexpr (F16) {
+                    f16x8 bt[2], at[2][2];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const u32x2 lo = xw[k * SB_PSTR + offA], hi = xw[k * SB_PSTR + offB];
-                    bt[k] = __builtin_bit_cast(bf16x8, (u32x4{lo.x, lo.y, hi.x, hi.y}));
+                    for (int k = 0; k < 2; ++k) {
+                        const u32x2 lo = xw[k * SB_PSTR + offA], hi = xw[k * SB_PSTR + offB];
+                        bt[k] = __builtin_bit_cast(f16x8, (u32x4{lo.x, lo.y, hi.x, hi.y}));
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) at[ct][k] = __builtin_bit_cast(bf16x8, wl[((s * 3 + k) * 2 + ct) * 64]);
+                        for (int ct = 0; ct < 2; ++ct) at[ct][k] = __builtin_bit_cast(f16x8, wl[((s * 2 + k) * 2 + ct) * 64]);
+                    }
+                    SB_MFMA6H(acc, at, bt[0], bt[1])
+                } else {
+                    bf16x8 bt[3], at[2][3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const u32x2 lo = xw[k * SB_PSTR + offA], hi = xw[k * SB_PSTR + offB];
+                        bt[k] = __builtin_bit_cast(bf16x8, (u32x4{lo.x, lo.y, hi.x, hi.y}));
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) at[ct][k] = __builtin_bit_cast(bf16x8, wl[((s * 3 + k) * 2 + ct) * 64]);
+                    }
+                    SB_MFMA12(acc, at, bt[0], bt[1], bt[2])
                 }
-                SB_MFMA12(acc, at, bt[0], bt[1], bt[2])
             }
+        }
+        if constexpr (F16) {                 // back to the scale of conv + b (exact), then the bias
+            const float un = unx * unwc;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] = acc[ct][r] * un + tabl[64 + 2 * (ct * 16 + r) + lhi];
         }
 
         // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev) ------------------------------------------------------------
@@ -290,8 +433,43 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[ct][r] = tabl[128 + 2 * (ct * 16 + r) + lhi];
-        {
+            for (int r = 0; r < 16; ++r) acc2[ct][r] = F16 ? 0.f : tabl[128 + 2 * (ct * 16 + r) + lhi];
+        if constexpr (F16) {
+            // per-pixel scale: the pixel's 64 channels sit in this lane and in lane ^ 32; a lane's accumulators belong to its own pixel
+            float gm = 0.f;
+#pragma unroll
+            for (int R = 0; R < 32; ++R) gm = fmaxf(gm, acc[R >> 4][R & 15]);
+            gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
+            const int kg = sb_scale_exp(gm);
+            const float sg = sb_pow2(kg), ung = sb_pow2(-kg) * unwi;
+            const u32x4* wl = Wl + WCONV + lane;
+#pragma unroll
+            for (int s = 0; s < SB_KS2; ++s) {
+                unsigned g1[4], g2[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int R0 = 8 * s + 2 * q, R1 = R0 + 1;
+                    float v0 = acc[R0 >> 4][R0 & 15], v1 = acc[R1 >> 4][R1 & 15];
+                    v0 = v0 > 0.f ? v0 : 0.f;
+                    v1 = v1 > 0.f ? v1 : 0.f;
+                    sb_split2h(v0 * sg, v1 * sg, g1[q], g2[q]);
+                }
+#pragma unroll
+                for (int R = 8 * s; R < 8 * s + 8; ++R) hp[R] = hb[(long long)sb_chan(R, 0) * plane];
+                const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
+                const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
+                f16x8 at[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) at[ct][k] = __builtin_bit_cast(f16x8, wl[((s * 2 + k) * 2 + ct) * 64]);
+                SB_MFMA6H(acc2, at, b1, b2)
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[ct][r] = acc2[ct][r] * ung + tabl[128 + 2 * (ct * 16 + r) + lhi];
+        } else {
             const u32x4* wl = Wl + SB_WCONV + lane;
 #pragma unroll
             for (int s = 0; s < SB_KS2; ++s) {
@@ -341,11 +519,12 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
 }
 
 int mrx_l1sb_launch(const MrxL1sbArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)(SB_WCONV + SB_WIH) * 16 + 256 * sizeof(float) + (size_t)(SB_NT / 64) * 3 * SB_PSTR * 8;
+    constexpr size_t lds = (size_t)(SB_WCONV + SB_WIH) * 16 + 256 * sizeof(float) + (size_t)(SB_NT / 64) * 3 * SB_PSTR * 8;   // (the fp16 form needs less)
     static bool attr_done = false;   // once: keeps launches legal under hipGraph capture
     static int ncu = 0;
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer1_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer1_sb<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer1_sb<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         hipDeviceProp_t prop;
         MRX_HIP(hipGetDevice(&dev));
@@ -355,7 +534,10 @@ int mrx_l1sb_launch(const MrxL1sbArgs& a, hipStream_t st) {
     }
     const long long total = (long long)a.ntiles * a.B;
     const int grid = (int)(total < ncu ? total : ncu);     // one persistent workgroup per CU (a multiple of 8: the XCD band map keeps its meaning)
-    hipLaunchKernelGGL(k_rim_layer1_sb, dim3(grid), dim3(SB_NT), lds, st, a);
+    if (a.f16)
+        hipLaunchKernelGGL(k_rim_layer1_sb<true>, dim3(grid), dim3(SB_NT), lds, st, a);
+    else
+        hipLaunchKernelGGL(k_rim_layer1_sb<false>, dim3(grid), dim3(SB_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
