@@ -447,6 +447,197 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc_t4(const float4* in, con
     }
 }
 
+// ---- H = 640 on the column-tiled coil stack: one WAVEFRONT per 4-column tile, register transforms (640 = 10 x 8 x 8) -------------------
+// n = 64 n1 + 8 n2 + n3, k = k1 + 10 k2 + 80 k3:  W640^(nk) = W10^(n1 k1) W640^((8 n2 + n3) k1) W8^(n2 k2) W64^(n3 k2) W8^(n3 k3).
+//   A : lane m = 8 n2 + n3 holds rows 64 n1 + m of all four columns (ten contiguous 2-KB loads per wave): four 10-point DFTs (2 x 5
+//       prime-factor form), twiddles W640^(m k1);
+//   B : 320 (k1, n3, column) 8-point DFTs over n2, five per lane, twiddles W64^(n3 k2);
+//   C : 320 (k1, k2, column) 8-point DFTs over n3, five per lane -> rows k1 + 10 k2 + 80 k3, where the data-consistency step and the
+//       inverse 8-point DFT over k3 happen in the same registers; B', A' mirror B and A with conjugate twiddles.
+// The four exchanges go through 23 KB of wave-private LDS (every lane reads all its inputs of a stage before anything is written back); three
+// stages per direction instead of four, no workgroup-wide staging, the measured data requested up front.  Same results as k_cols_dc_t4 to
+// fp32 round-off (different operation order).  Selectable (MRX_COLS640=1), not the default: see mrx_llg_cols_dc_t4.
+#define C640_LDS_C2 (80 * 36)
+template <bool INV>
+__device__ __forceinline__ void c640_dft5(mrx_c32 (&a)[5]) {
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const mrx_c32 p1 = mrx_add(a[1], a[4]), m1 = mrx_sub(a[1], a[4]), p2 = mrx_add(a[2], a[3]), m2 = mrx_sub(a[2], a[3]);
+    const mrx_c32 R1 = mrx_mk(a[0].x + c1 * p1.x + c2 * p2.x, a[0].y + c1 * p1.y + c2 * p2.y);
+    const mrx_c32 R2 = mrx_mk(a[0].x + c2 * p1.x + c1 * p2.x, a[0].y + c2 * p1.y + c1 * p2.y);
+    const mrx_c32 I1 = mrx_rot<INV>(mrx_mk(s1 * m1.x + s2 * m2.x, s1 * m1.y + s2 * m2.y));
+    const mrx_c32 I2 = mrx_rot<INV>(mrx_mk(s2 * m1.x - s1 * m2.x, s2 * m1.y - s1 * m2.y));
+    a[0] = mrx_add(a[0], mrx_add(p1, p2));
+    a[1] = mrx_add(R1, I1);
+    a[2] = mrx_add(R2, I2);
+    a[3] = mrx_sub(R2, I2);
+    a[4] = mrx_sub(R1, I1);
+}
+// 10-point DFT, twiddle-free 2 x 5 form: n1 = (5 a + 2 b) mod 10, k1 = (5 ka + 6 kb) mod 10
+template <bool INV>
+__device__ __forceinline__ void c640_dft10(mrx_c32 (&v)[10]) {
+    mrx_c32 e[5], o[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        e[b] = mrx_add(v[(2 * b) % 10], v[(2 * b + 5) % 10]);
+        o[b] = mrx_sub(v[(2 * b) % 10], v[(2 * b + 5) % 10]);
+    }
+    c640_dft5<INV>(e);
+    c640_dft5<INV>(o);
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) {
+        v[(6 * kb) % 10] = e[kb];
+        v[(5 + 6 * kb) % 10] = o[kb];
+    }
+}
+template <bool INV>
+__device__ __forceinline__ void c640_dft8(mrx_c32 (&a)[8]) {
+    mrx_c32 e0, e1, e2, e3, o0, o1, o2, o3;
+    mrx_dft4<INV>(a[0], a[2], a[4], a[6], e0, e1, e2, e3);
+    mrx_dft4<INV>(a[1], a[3], a[5], a[7], o0, o1, o2, o3);
+    const float h = 0.70710678118654752440f;
+    const mrx_c32 r1 = mrx_rot<INV>(o1);
+    const mrx_c32 t1 = mrx_mk(h * (o1.x + r1.x), h * (o1.y + r1.y));
+    const mrx_c32 t2 = mrx_rot<INV>(o2);
+    const mrx_c32 r3 = mrx_rot<INV>(o3);
+    const mrx_c32 t3 = mrx_mk(h * (r3.x - o3.x), h * (r3.y - o3.y));
+    a[0] = mrx_add(e0, o0), a[4] = mrx_sub(e0, o0);
+    a[1] = mrx_add(e1, t1), a[5] = mrx_sub(e1, t1);
+    a[2] = mrx_add(e2, t2), a[6] = mrx_sub(e2, t2);
+    a[3] = mrx_add(e3, t3), a[7] = mrx_sub(e3, t3);
+}
+__device__ __forceinline__ mrx_c32 c640_cmulc(mrx_c32 a, mrx_c32 w) { return mrx_mk(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y); }   // a * conj(w)
+
+__global__ __launch_bounds__(64) void k_cols640_dc_t4(const float4* in, const float4* __restrict__ y4, MrxMask mask, float4* out, ColArgs a) {
+    __shared__ __attribute__((aligned(16))) float2 E[C640_LDS_C2];
+    const int l = threadIdx.x;
+    const long long tile = blockIdx.x;
+    const long long bc = tile / a.ntx;
+    const int w0 = (int)(tile - bc * a.ntx) * 4;
+    const long long b = bc / a.C, c_ = bc - b * a.C;
+    const float4* src = in + tile * 1280;
+    const float2* ysrc = reinterpret_cast<const float2*>(y4 + tile * 1280);
+    float4* dst = out + tile * 1280;
+    const int n3B = (l >> 2) & 7, cB = l & 3, hiB = l >> 5;     // stages B / B': tasks (k1 = 2 s + hiB, n3B, cB)
+    const int kq = l >> 2;                                      // stages C / C': tasks (kk = 16 s + kq = k1 + 10 k2, cB)
+    // stage A inputs, the measured data of stage C and the twiddles: everything requested up front
+    mrx_c32 v[4][10];
+#pragma unroll
+    for (int n1 = 0; n1 < 10; ++n1) {
+        const int g = shifted(64 * n1 + l, a.halfH, 640);
+        const float4 q0 = src[g * 2], q1 = src[g * 2 + 1];
+        v[0][n1] = mrx_mk(q0.x, q0.y), v[1][n1] = mrx_mk(q0.z, q0.w), v[2][n1] = mrx_mk(q1.x, q1.y), v[3][n1] = mrx_mk(q1.z, q1.w);
+    }
+    mrx_c32 yv[5][8];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) yv[s][k3] = ysrc[shifted(16 * s + kq + 80 * k3, a.halfH, 640) * 4 + cB];
+    mrx_c32 t1[10], t2[8];
+#pragma unroll
+    for (int k1 = 1; k1 < 10; ++k1) t1[k1] = a.tw[l * k1];
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2) t2[k2] = a.tw[10 * n3B * k2];
+    // ---- A ----
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        c640_dft10<false>(v[c]);
+#pragma unroll
+        for (int k1 = 1; k1 < 10; ++k1) v[c][k1] = mrx_cmul(v[c][k1], t1[k1]);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 10; ++k1) {
+        reinterpret_cast<float4*>(E)[(k1 * 64 + l) * 2] = make_float4(v[0][k1].x, v[0][k1].y, v[1][k1].x, v[1][k1].y);
+        reinterpret_cast<float4*>(E)[(k1 * 64 + l) * 2 + 1] = make_float4(v[2][k1].x, v[2][k1].y, v[3][k1].x, v[3][k1].y);
+    }
+    __syncthreads();
+    // ---- B ----
+    mrx_c32 u[5][8];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) u[s][n2] = E[((2 * s + hiB) * 64 + 8 * n2 + n3B) * 4 + cB];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        c640_dft8<false>(u[s]);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) E[((2 * s + hiB) + 10 * k2) * 36 + n3B * 4 + cB] = k2 ? mrx_cmul(u[s][k2], t2[k2]) : u[s][k2];
+    }
+    __syncthreads();
+    // ---- C, data consistency, C' ----
+    // (the mask values of this lane's 40 outputs, requested together: the kind is decided once, not per element)
+    float mk[5][8];
+    {
+        const long long mb = b * mask.s[0] + c_ * mask.s[1] + (long long)(w0 + cB) * mask.s[3];
+        if (mask.kind == MRX_MASK_U8) {
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+#pragma unroll
+                for (int k3 = 0; k3 < 8; ++k3)
+                    mk[s][k3] = (float)((const unsigned char*)mask.p)[mb + (long long)shifted(16 * s + kq + 80 * k3, a.halfH, 640) * mask.s[2]];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+#pragma unroll
+                for (int k3 = 0; k3 < 8; ++k3)
+                    mk[s][k3] = ((const float*)mask.p)[mb + (long long)shifted(16 * s + kq + 80 * k3, a.halfH, 640) * mask.s[2]];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int n3 = 0; n3 < 8; ++n3) u[s][n3] = E[(16 * s + kq) * 36 + n3 * 4 + cB];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        c640_dft8<false>(u[s]);
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) {
+            const float m = mk[s][k3];
+            u[s][k3] = mrx_mk(m * (u[s][k3].x * a.scale - yv[s][k3].x), m * (u[s][k3].y * a.scale - yv[s][k3].y));   // rim_utils.py:54
+        }
+        c640_dft8<true>(u[s]);
+#pragma unroll
+        for (int n3 = 0; n3 < 8; ++n3) E[(16 * s + kq) * 36 + n3 * 4 + cB] = u[s][n3];
+    }
+    __syncthreads();
+    // ---- B' ----
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const mrx_c32 q = E[((2 * s + hiB) + 10 * k2) * 36 + n3B * 4 + cB];
+            u[s][k2] = k2 ? c640_cmulc(q, t2[k2]) : q;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        c640_dft8<true>(u[s]);
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) E[((2 * s + hiB) * 64 + 8 * n2 + n3B) * 4 + cB] = u[s][n2];
+    }
+    __syncthreads();
+    // ---- A' ----
+#pragma unroll
+    for (int k1 = 0; k1 < 10; ++k1) {
+        const float4 q0 = reinterpret_cast<float4*>(E)[(k1 * 64 + l) * 2], q1 = reinterpret_cast<float4*>(E)[(k1 * 64 + l) * 2 + 1];
+        v[0][k1] = mrx_mk(q0.x, q0.y), v[1][k1] = mrx_mk(q0.z, q0.w), v[2][k1] = mrx_mk(q1.x, q1.y), v[3][k1] = mrx_mk(q1.z, q1.w);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int k1 = 1; k1 < 10; ++k1) v[c][k1] = c640_cmulc(v[c][k1], t1[k1]);
+        c640_dft10<true>(v[c]);
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < 10; ++n1) {
+        const int g = shifted(64 * n1 + l, a.halfH, 640);
+        dst[g * 2] = make_float4(v[0][n1].x * a.scale2, v[0][n1].y * a.scale2, v[1][n1].x * a.scale2, v[1][n1].y * a.scale2);
+        dst[g * 2 + 1] = make_float4(v[2][n1].x * a.scale2, v[2][n1].y * a.scale2, v[3][n1].x * a.scale2, v[3][n1].y * a.scale2);
+    }
+}
+
 // row-major [nimg][H][W] complex -> column-tiled [nimg][W/4][H][4]  (W % 4 == 0; once per slice for the measured data)
 __global__ void k_tile4_cols(const float2* __restrict__ in, float2* __restrict__ out, long long nimg, int H, int W) {
     const long long total = nimg * H * W;
@@ -1499,7 +1690,12 @@ extern "C" int mrx_llg_cols_dc_t4(float* work_t4, const float* y_t4, const void*
     const float4* in = (const float4*)work_t4;
     const float4* y4 = (const float4*)y_t4;
     float4* out = (float4*)work_t4;
-    if (H == 640) {
+    // MRX_COLS640=1: the wave-private register form (k_cols640_dc_t4) -- measured 33.8 us against 28.5 us for the workgroup (Stockham) form at
+    // 15 x 640 x 372 (1395 single-wave tasks are 1.4 waves per SIMD: every exchange and load latency is exposed), so not the default
+    static const int wave640 = (getenv("MRX_COLS640") && atoi(getenv("MRX_COLS640")) == 1) ? 1 : 0;
+    if (H == 640 && wave640) {
+        hipLaunchKernelGGL(k_cols640_dc_t4, grid, dim3(64), 0, st, in, y4, m, out, a);
+    } else if (H == 640) {
         if ((rc = set_lds(k_cols_dc_t4<P640>, lds))) return rc;
         hipLaunchKernelGGL((k_cols_dc_t4<P640>), grid, blk, lds, st, in, y4, m, out, a);
     } else if (H == 320) {

@@ -486,7 +486,10 @@ def test_general_mask_gradient_column_tiled_at_w372(dev, case):
         row_major = ops.llg(ed, yd, Sd, md, sigma, centered, norm)
     finally:
         ops.LLG_T4 = keep
-    assert torch.equal(got, row_major), "the tiled layout changed the arithmetic"
+    if H == 640 and os.environ.get("MRX_COLS640") == "1":      # the wave-private 640 = 10 x 8 x 8 column transform: another operation order
+        assert rel_l2(got, row_major) <= 2e-6
+    else:
+        assert torch.equal(got, row_major), "the tiled layout changed the arithmetic"
     # the measured data tiled once: [B*C][93][H][4]
     t4 = ops._y_t4(yd)
     want_t4 = yd.reshape(B * C, H, 93, 4, 2).permute(0, 2, 1, 3, 4).contiguous()
