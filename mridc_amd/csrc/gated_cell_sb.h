@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define MRX_GATED_SB_PACK_FLOATS(gates) (2 * (gates) * 2 * 4 * 3 * 64 * 4)   // three bf16 terms of the 2 * gates 64 x 64 matrices, A-operand lane order
+// three bf16 terms of the 2 * gates 64 x 64 matrices in A-operand lane order, then the same matrices as two fp16 terms scaled by one power of two,
+// then a header element holding that exponent
+#define MRX_GATED_SB_PACK_FLOATS(gates) ((2 * (gates) * 2 * 4 * 5 * 64 + 1) * 4)
 
 struct MrxGatedSbArgs {
     const float* x;       // [B,64,P]

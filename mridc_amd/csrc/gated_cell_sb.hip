@@ -56,24 +56,85 @@ __global__ void k_gated_pack_sb(const float* __restrict__ w_ih, const float* __r
         out[i] = u32x4{p[0], p[1], p[2], p[3]};
     }
 }
+// ---- two-term fp16 form (F16): every contraction of the cell runs over a pixel's channels only, so x and h_prev are scaled per PIXEL by the power
+// of two that puts the pixel's largest |x|, |h| into [2^14, 2^15) (its 64 + 64 channels sit in this lane and lane ^ 32), all matrices by one power
+// of two at pack time, and a lane's accumulators -- its own pixel's -- are scaled back exactly before the biases.  Three term products per
+// multiply instead of six, error per product ~3 x 2^-22 (rim_layer2_sb.hip).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gs_split2h(float a, float b, unsigned& p1, unsigned& p2) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    const float ra = a - (float)h.x, rb = b - (float)h.y;     // exact
+    const f16x2 l = {(_Float16)ra, (_Float16)rb};
+    p1 = __builtin_bit_cast(unsigned, h);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ float gs_pow2(int e) {
+    e = e < -120 ? -120 : (e > 120 ? 120 : e);
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
+__device__ __forceinline__ int gs_scale_exp(float m) {     // k with m 2^k in [2^14, 2^15); 0 for zero / non-finite m
+    const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    return (ex == 0 || ex == 255) ? 0 : 14 - (ex - 127);
+}
+// fp16 section of the pack: [3 terms section][(((mat * 2 + mb) * 4 + t) * 2 + term) * 64 + lane][header]
+__global__ void k_gated_wscale(const float* __restrict__ w_ih, const float* __restrict__ w_hh, u32x4* __restrict__ out, int gates) {
+    __shared__ float red[256];
+    const int n = gates * GS_F * GS_F;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fmaxf(fabsf(w_ih[i]), fabsf(w_hh[i])));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[2 * gates * 2 * 4 * 5 * 64] = u32x4{(unsigned)gs_scale_exp(red[0]), 0u, 0u, 0u};
+}
+__global__ void k_gated_pack_f16(const float* __restrict__ w_ih, const float* __restrict__ w_hh, u32x4* __restrict__ out, int gates) {
+    const int total = 2 * gates * 2 * 4 * 2 * 64, off = 2 * gates * 2 * 4 * 3 * 64;
+    const float sw = gs_pow2((int)out[2 * gates * 2 * 4 * 5 * 64][0]);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        int r = i >> 6;
+        const int term = r & 1;
+        r >>= 1;
+        const int t = r & 3, mb = (r >> 2) & 1, mat = r >> 3;
+        const float* w = mat < gates ? w_ih : w_hh;
+        const int g = mat < gates ? mat : mat - gates;
+        const int row = g * GS_F + mb * 32 + (lane & 31), col0 = 16 * t + 8 * (lane >> 5);
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned p1, p2;
+            gs_split2h(w[(long long)row * GS_F + col0 + 2 * k] * sw, w[(long long)row * GS_F + col0 + 2 * k + 1] * sw, p1, p2);
+            p[k] = term == 0 ? p1 : p2;
+        }
+        out[off + i] = u32x4{p[0], p[1], p[2], p[3]};
+    }
+}
 int mrx_gated_sb_pack(const float* w_ih, const float* w_hh, float* packed, int gates, hipStream_t st) {
     const int total = 2 * gates * 2 * 4 * 3 * 64;
+    hipLaunchKernelGGL(k_gated_wscale, dim3(1), dim3(256), 0, st, w_ih, w_hh, reinterpret_cast<u32x4*>(packed), gates);
+    hipLaunchKernelGGL(k_gated_pack_f16, dim3((2 * gates * 2 * 4 * 2 * 64 + 255) / 256), dim3(256), 0, st, w_ih, w_hh, reinterpret_cast<u32x4*>(packed), gates);
     hipLaunchKernelGGL(k_gated_pack_sb, dim3((total + 255) / 256), dim3(256), 0, st, w_ih, w_hh, reinterpret_cast<u32x4*>(packed), gates);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 
-template <int GATES>  // 3 = GRU, 2 = MGU
+template <int GATES, bool F16>  // 3 = GRU, 2 = MGU
 __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gs[];
-    constexpr int NMAT = 2 * GATES, NW = NMAT * 2 * 4 * 3 * 64;       // 16-byte A operands
+    constexpr int NMAT = 2 * GATES, NTM = F16 ? 2 : 3, NW = NMAT * 2 * 4 * NTM * 64;       // 16-byte A operands
     u32x4* Wl = reinterpret_cast<u32x4*>(smem_gs);
     float* Bs = reinterpret_cast<float*>(smem_gs + (size_t)NW * 16);   // ih bias [GATES][64]
     const int tid = threadIdx.x;
+    float unw = 1.f;
     {
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed);
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed) + (F16 ? NMAT * 2 * 4 * 3 * 64 : 0);
         for (int i = tid; i < NW; i += GS_NT) Wl[i] = src[i];
         if (tid < GATES * GS_F) Bs[tid] = a.b_ih ? a.b_ih[tid] : 0.f;
+        if constexpr (F16) unw = gs_pow2(-(int)reinterpret_cast<const u32x4*>(a.packed)[NMAT * 2 * 4 * 5 * 64][0]);
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -125,13 +186,75 @@ __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[d][ct][r] = d < GATES ? Bs[d * GS_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
+                    acc[d][ct][r] = (d < GATES && !F16) ? Bs[d * GS_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
 
+        float spx = 1.f;                                   // F16: this pixel's operand scale 2^kp
+        int kp = 0;
+        if constexpr (F16) {
+            float m = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xg[t][j]));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            kp = gs_scale_exp(m);
+            spx = gs_pow2(kp);
+        }
 #pragma unroll
         for (int part = 0; part < 2; ++part) {             // 0: ih matrices over x, 1: hh matrices over h_prev
             if (part == 1 && !hb) break;                  // (no previous state: the hh parts are zero)
+            if constexpr (F16) {
+                if (part == 1) {
+                    // h_prev's own maximum: if it needs a smaller scale than x did, the accumulators (the x parts so far) move to it -- exactly
+                    float m = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(hg[t][j]));
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    const int kh = gs_scale_exp(m);
+                    const bool lower = m > 0.f && kh < kp;
+                    const float f = lower ? gs_pow2(kh - kp) : 1.f;
+                    kp = lower ? kh : kp;
+                    spx = gs_pow2(kp);
+#pragma unroll
+                    for (int d = 0; d < GATES; ++d)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[d][ct][r] *= f;
+                }
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if constexpr (F16) {
+                    unsigned p1[4], p2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (part == 0)
+                            gs_split2h(xg[t][2 * k] * spx, xg[t][2 * k + 1] * spx, p1[k], p2[k]);
+                        else
+                            gs_split2h(hg[t][2 * k] * spx, hg[t][2 * k + 1] * spx, p1[k], p2[k]);
+                    }
+                    const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4{p1[0], p1[1], p1[2], p1[3]}));
+                    const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4{p2[0], p2[1], p2[2], p2[3]}));
+#pragma unroll
+                    for (int g = 0; g < GATES; ++g) {
+                        const int mat = part * GATES + g;
+                        const int d = (part == 1 && g == GATES - 1) ? GATES : g;
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) {
+                            const u32x4* q = wl + (((mat * 2 + mb) * 4 + t) * 2) * 64;
+                            const f16x8 a1 = __builtin_bit_cast(f16x8, q[0]);
+                            const f16x8 a2 = __builtin_bit_cast(f16x8, q[64]);
+                            acc[d][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc[d][mb], 0, 0, 0);
+                            acc[d][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc[d][mb], 0, 0, 0);
+                            acc[d][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[d][mb], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // (keeps the next matrices' operand reads from being hoisted over this one: spills)
+                    }
+                    continue;
+                }
                 unsigned p1[4], p2[4], p3[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -163,6 +286,16 @@ __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
                     }
                 }
             }
+        }
+        if constexpr (F16) {                                // back to the scale of the gate pre-activations (exact), then the ih biases
+            const float unpx = gs_pow2(-kp) * unw;
+#pragma unroll
+            for (int d = 0; d < GATES + 1; ++d)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[d][ct][r] = acc[d][ct][r] * unpx + (d < GATES ? Bs[d * GS_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f);
         }
         // ---- h_prev again, in accumulator layout (row (r, lane half) = channel, column = pixel): an L2 hit ---------------
         float hv[2][16];
@@ -199,14 +332,14 @@ __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
     }
 }
 
-template <int GATES>
+template <int GATES, bool F16>
 static int launch_gated_sb(const MrxGatedSbArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(2 * GATES * 2 * 4 * 3 * 64) * 16 + sizeof(float) * GATES * GS_F;
     static_assert(lds <= 160 * 1024, "all weight matrices resident in LDS");
     static bool attr_done = false;  // once per instantiation: keeps launches legal under hipGraph capture
     static int n_cu = 0;
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_gated_cell_sb<GATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_gated_cell_sb<GATES, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         hipDeviceProp_t prop;
         MRX_HIP(hipGetDevice(&dev));
@@ -216,12 +349,17 @@ static int launch_gated_sb(const MrxGatedSbArgs& a, hipStream_t st) {
     }
     const long long nblk_need = (a.nseg + GS_NT / 64 - 1) / (GS_NT / 64);
     const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);  // persistent: the weights are staged once per workgroup
-    hipLaunchKernelGGL((k_gated_cell_sb<GATES>), dim3(nblk), dim3(GS_NT), lds, st, a);
+    hipLaunchKernelGGL((k_gated_cell_sb<GATES, F16>), dim3(nblk), dim3(GS_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 int mrx_gated_sb_launch(const MrxGatedSbArgs& a, int gates, hipStream_t st) {
-    return gates == 3 ? launch_gated_sb<3>(a, st) : launch_gated_sb<2>(a, st);
+    // MRX_GATED_F16=1: the two-term fp16 form.  Parity-green (error against float64 1.1e-7 as the bf16 form), but NOT the default: with 2 (GATES + 1)
+    // accumulators next to both operand vectors it spills (356 / 100 bytes of scratch per lane) and runs at 184 / 78 us against 88 / 68 us for the
+    // three-term bf16 form (GRU / MGU, 640 x 372) -- it needs the accumulators split over two passes first.
+    static const int f16 = (getenv("MRX_GATED_F16") && atoi(getenv("MRX_GATED_F16")) == 1) ? 1 : 0;
+    if (f16) return gates == 3 ? launch_gated_sb<3, true>(a, st) : launch_gated_sb<2, true>(a, st);
+    return gates == 3 ? launch_gated_sb<3, false>(a, st) : launch_gated_sb<2, false>(a, st);
 }
 
 // ---- Conv2dGRU layer of the Recurrent Variational Network (recurrentvarnet/conv2gru.py:139-157), 1x1 gates on 64 features -----------------
