@@ -825,6 +825,9 @@ def main():
                         mfma_util_pmc_regulariser=traffic.get("_mfma_util", {}).get("regulariser") if (l2_bf16 and l2_taps) else None,
                         mfma_util_pmc_source=traffic.get("_mfma_util_source"),
                         launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
+                        # the same launch against the HBM roofline (its algorithmic bytes: x, h_prev in, h_new and the tap planes out): with the
+                        # two-term fp16 operands the kernel sits between its two bounds
+                        hbm_frac=((3.0 * F_hidden + (18.0 if l2_taps else 0.0)) * npix * B * 4 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms2 else None,
                         regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_fp32_gflop=issued_reg / 1e9,
                                          issued_bf16_gflop=issued1_bf16 / 1e9,
                                          frac_issued=(pipe_ms(issued_reg, issued1_bf16) / t_reg) if t_reg else None,
