@@ -177,7 +177,7 @@ __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
     long long sg = (long long)blockIdx.x * (GS_NT / 64) + wave;
     if (sg < a.nseg) load(sg);
     while (sg < a.nseg) {
-        load_h();
+        if constexpr (!F16) load_h();                      // (F16: requested after the x part is issued -- 32 registers fewer alive through it)
         // accumulator d: 0 .. GATES-2 = gates whose ih and hh parts add up; GATES-1 = candidate ih part; GATES = candidate hh part
         f32x16 acc[GATES + 1][2];
 #pragma unroll
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
             if (part == 1 && !hb) break;                  // (no previous state: the hh parts are zero)
             if constexpr (F16) {
                 if (part == 1) {
+                    load_h();
                     // h_prev's own maximum: if it needs a smaller scale than x did, the accumulators (the x parts so far) move to it -- exactly
                     float m = 0.f;
 #pragma unroll
@@ -287,16 +288,8 @@ __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
                 }
             }
         }
-        if constexpr (F16) {                                // back to the scale of the gate pre-activations (exact), then the ih biases
-            const float unpx = gs_pow2(-kp) * unw;
-#pragma unroll
-            for (int d = 0; d < GATES + 1; ++d)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[d][ct][r] = acc[d][ct][r] * unpx + (d < GATES ? Bs[d * GS_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f);
-        }
+        // F16: back to the scale of the gate pre-activations (exact) and the ih biases, element by element where the gates are evaluated
+        const float unpx = F16 ? gs_pow2(-kp) * unw : 1.f;
         // ---- h_prev again, in accumulator layout (row (r, lane half) = channel, column = pixel): an L2 hit ---------------
         float hv[2][16];
 #pragma unroll
@@ -316,15 +309,19 @@ __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lhi;
+                auto pre = [&](int d) {
+                    if constexpr (F16) return acc[d][ct][r] * unpx + (d < GATES ? Bs[d * GS_F + co] : 0.f);
+                    else return acc[d][ct][r];
+                };
                 float o;
                 if constexpr (GATES == 3) {  // rnn_cells.py:118-127
-                    const float rg = gs_sigmoid(acc[0][ct][r]);
-                    const float z = gs_sigmoid(acc[1][ct][r]);
-                    const float n = gs_tanh(acc[2][ct][r] + rg * acc[3][ct][r]);
+                    const float rg = gs_sigmoid(pre(0));
+                    const float z = gs_sigmoid(pre(1));
+                    const float n = gs_tanh(pre(2) + rg * pre(3));
                     o = n * (1.0f - z) + z * hv[ct][r];
                 } else {  // rnn_cells.py:255-261
-                    const float f = gs_sigmoid(acc[0][ct][r]);
-                    const float c = gs_tanh(acc[1][ct][r] + f * acc[2][ct][r]);
+                    const float f = gs_sigmoid(pre(0));
+                    const float c = gs_tanh(pre(1) + f * pre(2));
                     o = c + f * (hv[ct][r] - c);
                 }
                 if (o_valid) ob[(unsigned)co * P32 + o_pxo] = o;
@@ -354,10 +351,10 @@ static int launch_gated_sb(const MrxGatedSbArgs& a, hipStream_t st) {
     return MRX_OK;
 }
 int mrx_gated_sb_launch(const MrxGatedSbArgs& a, int gates, hipStream_t st) {
-    // MRX_GATED_F16=1: the two-term fp16 form.  Parity-green (error against float64 1.1e-7 as the bf16 form), but NOT the default: with 2 (GATES + 1)
-    // accumulators next to both operand vectors it spills (356 / 100 bytes of scratch per lane) and runs at 184 / 78 us against 88 / 68 us for the
-    // three-term bf16 form (GRU / MGU, 640 x 372) -- it needs the accumulators split over two passes first.
-    static const int f16 = (getenv("MRX_GATED_F16") && atoi(getenv("MRX_GATED_F16")) == 1) ? 1 : 0;
+    // the two-term fp16 form (per-pixel scales) is the default: GRU 88.7 -> 70.5 us, MGU 66.9 -> 54.9 us at 640 x 372, error against float64 1.1e-7 as
+    // the three-term bf16 form, which MRX_GATED_F16=0 selects.  (Its first version spilled -- 356 bytes of scratch per lane, 184 us: h_prev is now
+    // requested after the x part is issued and the accumulators are scaled back where the gates are evaluated, not in a pass of their own.)
+    static const int f16 = (getenv("MRX_GATED_F16") && atoi(getenv("MRX_GATED_F16")) == 0) ? 0 : 1;
     if (f16) return gates == 3 ? launch_gated_sb<3, true>(a, st) : launch_gated_sb<2, true>(a, st);
     return gates == 3 ? launch_gated_sb<3, false>(a, st) : launch_gated_sb<2, false>(a, st);
 }
