@@ -5,6 +5,8 @@
 // channels per pixel one v_mfma_f32_32x32x16_bf16 consumes two taps.  The formulation of conv_bf16.hip (whole halo'd tile in LDS as
 // [pixel][8 channels], one 16-byte LDS read per B operand, A operands straight from L2, wave = one image row x 32 pixels x all couts),
 // times three term planes.
+#include <cstdlib>
+
 #include "mrx_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -29,6 +31,28 @@ __device__ __forceinline__ void cs_split2(float a, float b, unsigned& p1, unsign
     p3 = cs_pk(ra, rb);
 }
 
+// ---- two-term fp16 form (F16, the default; MRX_CONV_SBS_F16=0 selects the three bf16 terms): the whole halo'd tile of a workgroup is staged at
+// once, so it is scaled by the power of two that puts the TILE's largest |x| into [2^14, 2^15) (one workgroup reduction: every input of the tile's
+// outputs is in it), the weights at pack time; three term products per multiply, accumulators scaled back exactly before the bias
+// (rim_layer2_sb.hip for the error analysis: ~3 x 2^-22 per product).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cs_split2h(float a, float b, unsigned& p1, unsigned& p2) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    const float ra = a - (float)h.x, rb = b - (float)h.y;     // exact
+    const f16x2 l = {(_Float16)ra, (_Float16)rb};
+    p1 = __builtin_bit_cast(unsigned, h);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ float cs_pow2(int e) {
+    e = e < -120 ? -120 : (e > 120 ? 120 : e);
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
+__device__ __forceinline__ int cs_scale_exp(float m) {     // k with m 2^k in [2^14, 2^15); 0 for zero / non-finite m
+    const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    return (ex == 0 || ex == 255) ? 0 : 14 - (ex - 127);
+}
+
 struct ConvSbsArgs {
     const float* x;        // [B,Cin,H,W], Cin <= 8
     const u32x4* packed;   // [3 terms][NSTEP][NCT][64 lanes] x 8 bf16
@@ -39,9 +63,11 @@ struct ConvSbsArgs {
 };
 __host__ __device__ constexpr int cs_nstep(int K) { return (K * K + 1) / 2; }
 
-template <int K, int NCT>
+template <int K, int NCT, bool F16>
 __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
     constexpr int PAD = (K - 1) / 2, PH = CS_TH + 2 * PAD, PW = CS_TW + 2 * PAD, NPIX = PH * PW, NG = K * K, NSTEP = cs_nstep(K);
+    static_assert(!F16 || NPIX <= CS_NT, "F16: one staging pass (the tile maximum is taken over the values of that pass)");
+    __shared__ float wmaxs[CS_NT / 64];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_cs[];      // [3 terms][NPIX] x 16 B
     u32x4* Xs = reinterpret_cast<u32x4*>(smem_cs);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -54,6 +80,7 @@ __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
 
     // ---- stage the halo'd tile: the 8 channels of a pixel, split into their three bf16 terms, one 16-byte LDS write per term ----------------
     constexpr int ITERS = (NPIX + CS_NT - 1) / CS_NT;
+    float xv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // F16: this thread's pixel of the tile (threads past the tile hold zeros)
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int e = tid + it * CS_NT;
@@ -73,12 +100,40 @@ __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (inb && j < a.Cin) ? src[(long long)j * plane] : 0.f;
-            unsigned p1[4], p2[4], p3[4];
+            if constexpr (F16) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cs_split2(v[2 * k], v[2 * k + 1], p1[k], p2[k], p3[k]);
-            Xs[e] = u32x4{p1[0], p1[1], p1[2], p1[3]};
-            Xs[NPIX + e] = u32x4{p2[0], p2[1], p2[2], p2[3]};
-            Xs[2 * NPIX + e] = u32x4{p3[0], p3[1], p3[2], p3[3]};
+                for (int j = 0; j < 8; ++j) xv[j] = v[j];
+            } else {
+                unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cs_split2(v[2 * k], v[2 * k + 1], p1[k], p2[k], p3[k]);
+                Xs[e] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+                Xs[NPIX + e] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+                Xs[2 * NPIX + e] = u32x4{p3[0], p3[1], p3[2], p3[3]};
+            }
+        }
+    }
+    float un = 1.f;
+    if constexpr (F16) {
+        // the tile's maximum -> one scale for the workgroup
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xv[j]));
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) wmaxs[wave] = m;
+        __syncthreads();
+        m = wmaxs[0];
+#pragma unroll
+        for (int w = 1; w < CS_NT / 64; ++w) m = fmaxf(m, wmaxs[w]);
+        const int kx = cs_scale_exp(m);
+        const float sx = cs_pow2(kx);
+        un = cs_pow2(-kx) * cs_pow2(-(int)a.packed[5 * NSTEP * NCT * 64][0]);
+        if (tid < NPIX) {
+            unsigned p1[4], p2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cs_split2h(xv[2 * k] * sx, xv[2 * k + 1] * sx, p1[k], p2[k]);
+            Xs[tid] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+            Xs[NPIX + tid] = u32x4{p2[0], p2[1], p2[2], p2[3]};
         }
     }
     __syncthreads();
@@ -97,6 +152,19 @@ __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
         const int t0 = 2 * s, t1 = (2 * s + 1 < NG) ? 2 * s + 1 : NG - 1;   // the upper half-wave takes the next tap (zero weights past the last)
         const int o0 = (t0 / K) * PW + (t0 % K), o1 = (t1 / K) * PW + (t1 % K);
         const int off = lhi ? o1 : o0;
+        if constexpr (F16) {
+            const f16x8 b1 = __builtin_bit_cast(f16x8, bx[off]);
+            const f16x8 b2 = __builtin_bit_cast(f16x8, bx[NPIX + off]);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f16x8 a1 = __builtin_bit_cast(f16x8, wp[3 * WT + (s * NCT + ct) * 64]);
+                const f16x8 a2 = __builtin_bit_cast(f16x8, wp[4 * WT + (s * NCT + ct) * 64]);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[ct], 0, 0, 0);
+            }
+            continue;
+        }
         const bf16x8 b1 = __builtin_bit_cast(bf16x8, bx[off]);
         const bf16x8 b2 = __builtin_bit_cast(bf16x8, bx[NPIX + off]);
         const bf16x8 b3 = __builtin_bit_cast(bf16x8, bx[2 * NPIX + off]);
@@ -125,7 +193,7 @@ __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (co < a.Cout) {
-                    float v = acc[ct][r];
+                    float v = F16 ? acc[ct][r] * un : acc[ct][r];
                     if (a.bias) v += a.bias[co];
                     if (a.act == MRX_ACT_RELU)
                         v = v > 0.f ? v : 0.f;
@@ -158,18 +226,55 @@ __global__ void k_conv_sbs_pack(const float* __restrict__ w, u32x4* __restrict__
     }
 }
 
+// fp16 section of the pack: [3 WT .. 5 WT) two terms of w 2^kw in the same operand order, [5 WT] the header (kw)
+__global__ void k_conv_sbs_wscale(const float* __restrict__ w, u32x4* __restrict__ out, int n, int WT) {
+    __shared__ float red[256];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[5 * WT] = u32x4{(unsigned)cs_scale_exp(red[0]), 0u, 0u, 0u};
+}
+__global__ void k_conv_sbs_pack_f16(const float* __restrict__ w, u32x4* __restrict__ out, int Cin, int Cout, int K, int NCT) {
+    const int TAPS = K * K, NSTEP = (TAPS + 1) / 2, WT = NSTEP * NCT * 64;
+    const float sw = cs_pow2((int)out[5 * WT][0]);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * WT; i += gridDim.x * blockDim.x) {
+        const int t = i / WT, r = i - t * WT;
+        const int lane = r & 63, ct = (r >> 6) % NCT, s = (r >> 6) / NCT;
+        const int tap = 2 * s + (lane >> 5), co = ct * 32 + (lane & 31);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (tap < TAPS && j < Cin && co < Cout) ? w[((long long)co * Cin + j) * TAPS + tap] * sw : 0.f;
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned p1, p2;
+            cs_split2h(v[2 * k], v[2 * k + 1], p1, p2);
+            p[k] = t == 0 ? p1 : p2;
+        }
+        out[3 * WT + i] = u32x4{p[0], p[1], p[2], p[3]};
+    }
+}
+
 static int cs_nct(int Cout) { return Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4); }
 extern "C" int mrx_conv_sbs_supported(int Cin, int Cout, int k, int dil) {
     return (Cin >= 1 && Cin <= 8 && Cout >= 1 && Cout <= 128 && (k == 3 || k == 5) && dil == 1) ? 1 : 0;
 }
 extern "C" int64_t mrx_conv_sbs_pack_floats(int Cout, int k) {
     if (Cout < 1 || Cout > 128 || (k != 3 && k != 5)) return -1;
-    return (int64_t)3 * cs_nstep(k) * cs_nct(Cout) * 64 * 4;
+    return ((int64_t)5 * cs_nstep(k) * cs_nct(Cout) * 64 + 1) * 4;      // three bf16 terms, two fp16 terms, header
 }
 extern "C" int mrx_conv_sbs_pack(const float* w, float* packed, int Cin, int Cout, int k, void* stream) {
     MRX_REQUIRE(w && packed, MRX_EINVAL, "mrx_conv_sbs_pack: null pointer");
     MRX_REQUIRE(mrx_conv_sbs_supported(Cin, Cout, k, 1), MRX_EUNSUP, "mrx_conv_sbs_pack: Cin=%d Cout=%d k=%d", Cin, Cout, k);
-    const int total = 3 * cs_nstep(k) * cs_nct(Cout) * 64;
+    const int total = 3 * cs_nstep(k) * cs_nct(Cout) * 64, WT = cs_nstep(k) * cs_nct(Cout) * 64;
+    hipLaunchKernelGGL(k_conv_sbs_wscale, dim3(1), dim3(256), 0, (hipStream_t)stream, w, reinterpret_cast<u32x4*>(packed), Cout * Cin * k * k, WT);
+    hipLaunchKernelGGL(k_conv_sbs_pack_f16, dim3((2 * WT + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, reinterpret_cast<u32x4*>(packed), Cin, Cout,
+                       k, cs_nct(Cout));
     hipLaunchKernelGGL(k_conv_sbs_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, reinterpret_cast<u32x4*>(packed), Cin, Cout, k,
                        cs_nct(Cout));
     MRX_LAUNCH_CHECK();
@@ -180,7 +285,11 @@ template <int K, int NCT>
 static int cs_launch(const ConvSbsArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)3 * (CS_TH + K - 1) * (CS_TW + K - 1) * 16;
     static_assert(lds <= 48 * 1024, "fits the default dynamic LDS limit");
-    hipLaunchKernelGGL((k_conv_sbs<K, NCT>), dim3(a.ntiles, a.B), dim3(CS_NT), lds, st, a);
+    static const int f16 = (getenv("MRX_CONV_SBS_F16") && atoi(getenv("MRX_CONV_SBS_F16")) == 0) ? 0 : 1;   // 0: the three-term bf16 form
+    if (f16)
+        hipLaunchKernelGGL((k_conv_sbs<K, NCT, true>), dim3(a.ntiles, a.B), dim3(CS_NT), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_conv_sbs<K, NCT, false>), dim3(a.ntiles, a.B), dim3(CS_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
