@@ -13,5 +13,5 @@ void mrx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int mrx_version(void) { return 221; /* 0.2.0: bumped with every kernel change (profiles/rNN_traffic.json is keyed on it) */ }
+extern "C" int mrx_version(void) { return 222; /* 0.2.0: bumped with every kernel change (profiles/rNN_traffic.json is keyed on it) */ }
 extern "C" const char* mrx_last_error(void) { return g_err; }

@@ -18,7 +18,7 @@ struct MrxGatedSbArgs {
 int mrx_gated_sb_pack(const float* w_ih, const float* w_hh, float* packed, int gates, hipStream_t st);
 int mrx_gated_sb_launch(const MrxGatedSbArgs& a, int gates, hipStream_t st);
 
-#define MRX_CONV2DGRU_SB_PACK_FLOATS (6 * 2 * 4 * 3 * 64 * 4)
+#define MRX_CONV2DGRU_SB_PACK_FLOATS ((6 * 2 * 4 * 5 * 64 + 1) * 4)   // three bf16 terms, two scaled fp16 terms, header (the scale exponent)
 
 struct MrxConv2dGruSbArgs {
     const float* x;       // [B,64,P] layer input (after its conv + ReLU)

@@ -395,8 +395,51 @@ __global__ void k_conv2dgru_pack_sb(const float* __restrict__ wu, const float* _
         out[i] = u32x4{p[0], p[1], p[2], p[3]};
     }
 }
+// fp16 section: [6*2*4*3*64 ..) two terms of w 2^kw, [(mat * 2 + mb) * 4 + t) * 2 + term) * 64 + lane], then the header (kw)
+__global__ void k_conv2dgru_wscale(const float* __restrict__ wu, const float* __restrict__ wr, const float* __restrict__ wo, u32x4* __restrict__ out) {
+    __shared__ float red[256];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < GS_F * 2 * GS_F; i += 256) m = fmaxf(m, fmaxf(fabsf(wu[i]), fmaxf(fabsf(wr[i]), fabsf(wo[i]))));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[6 * 2 * 4 * 5 * 64] = u32x4{(unsigned)gs_scale_exp(red[0]), 0u, 0u, 0u};
+}
+__global__ void k_conv2dgru_pack_f16(const float* __restrict__ wu, const float* __restrict__ wr, const float* __restrict__ wo,
+                                     u32x4* __restrict__ out) {
+    const int total = 6 * 2 * 4 * 2 * 64, off = 6 * 2 * 4 * 3 * 64;
+    const float sw = gs_pow2((int)out[6 * 2 * 4 * 5 * 64][0]);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        int r = i >> 6;
+        const int term = r & 1;
+        r >>= 1;
+        const int t = r & 3, mb = (r >> 2) & 1, mat = r >> 3, half = lane >> 5;
+        const float* w = (mat == 0 || mat == 3) ? wu : (mat == 1 || mat == 4) ? wr : wo;
+        const int row = mb * 32 + (lane & 31);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = mat < 3 ? 16 * t + 8 * half + j : (mat < 5 ? GS_F + 16 * t + 8 * half + j : GS_F + gs_chan(8 * t + j, half));
+            v[j] = w[(long long)row * (2 * GS_F) + col] * sw;
+        }
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned p1, p2;
+            gs_split2h(v[2 * k], v[2 * k + 1], p1, p2);
+            p[k] = term == 0 ? p1 : p2;
+        }
+        out[off + i] = u32x4{p[0], p[1], p[2], p[3]};
+    }
+}
 int mrx_conv2dgru_sb_pack(const float* wu, const float* wr, const float* wo, float* packed, hipStream_t st) {
     const int total = 6 * 2 * 4 * 3 * 64;
+    hipLaunchKernelGGL(k_conv2dgru_wscale, dim3(1), dim3(256), 0, st, wu, wr, wo, reinterpret_cast<u32x4*>(packed));
+    hipLaunchKernelGGL(k_conv2dgru_pack_f16, dim3((6 * 2 * 4 * 2 * 64 + 255) / 256), dim3(256), 0, st, wu, wr, wo, reinterpret_cast<u32x4*>(packed));
     hipLaunchKernelGGL(k_conv2dgru_pack_sb, dim3((total + 255) / 256), dim3(256), 0, st, wu, wr, wo, reinterpret_cast<u32x4*>(packed));
     MRX_LAUNCH_CHECK();
     return MRX_OK;
@@ -415,16 +458,30 @@ __device__ __forceinline__ void gs_mma6(f32x16& acc, const u32x4* q, bf16x8 b1, 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
 }
 
+// three term products (two fp16 terms per operand) of one (matrix, cout block, step)
+__device__ __forceinline__ void gs_mma3h(f32x16& acc, const u32x4* q, f16x8 b1, f16x8 b2) {
+    const f16x8 a1 = __builtin_bit_cast(f16x8, q[0]);
+    const f16x8 a2 = __builtin_bit_cast(f16x8, q[64]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+}
+
+// F16: two fp16 terms per operand with ONE scale per pixel for x, h_prev and h * reset (|h reset| <= |h|): x is scaled first, the accumulators move
+// exactly to h_prev's scale when that is the smaller one (k_gated_cell_sb), the biases are added where the gates are evaluated.
+template <bool F16>
 __global__ __launch_bounds__(GS_NT, 1) void k_conv2dgru_cell_sb(MrxConv2dGruSbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gs[];
-    constexpr int NW = 6 * 2 * 4 * 3 * 64;
+    constexpr int NTM = F16 ? 2 : 3, NW = 6 * 2 * 4 * NTM * 64;
     u32x4* Wl = reinterpret_cast<u32x4*>(smem_gs);
     float* Bs = reinterpret_cast<float*>(smem_gs + (size_t)NW * 16);   // biases [3][64]: update, reset, out
     const int tid = threadIdx.x;
+    float unw = 1.f;
     {
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed);
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed) + (F16 ? 6 * 2 * 4 * 3 * 64 : 0);
         for (int i = tid; i < NW; i += GS_NT) Wl[i] = src[i];
         if (tid < 3 * GS_F) Bs[tid] = a.bias ? a.bias[tid] : 0.f;
+        if constexpr (F16) unw = gs_pow2(-(int)reinterpret_cast<const u32x4*>(a.packed)[6 * 2 * 4 * 5 * 64][0]);
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -464,20 +521,71 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv2dgru_cell_sb(MrxConv2dGruSbAr
     long long sg = (long long)blockIdx.x * (GS_NT / 64) + wave;
     if (sg < a.nseg) load(sg);
     while (sg < a.nseg) {
-        load_h();
+        if constexpr (!F16) load_h();
         f32x16 acc[3][2];  // 0 update, 1 reset (then h * reset), 2 candidate
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[d][ct][r] = Bs[d * GS_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+                for (int r = 0; r < 16; ++r) acc[d][ct][r] = F16 ? 0.f : Bs[d * GS_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+        float spx = 1.f;
+        int kp = 0;
+        if constexpr (F16) {
+            float m = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xg[t][j]));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            kp = gs_scale_exp(m);
+            spx = gs_pow2(kp);
+        }
         // (Wu, Wr, Wo) x   and   (Wu, Wr) h
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
             if (part == 1 && !hb) break;
+            if constexpr (F16) {
+                if (part == 1) {
+                    load_h();
+                    float m = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(hg[t][j]));
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    const int kh = gs_scale_exp(m);
+                    const bool lower = m > 0.f && kh < kp;
+                    const float f = lower ? gs_pow2(kh - kp) : 1.f;
+                    kp = lower ? kh : kp;
+                    spx = gs_pow2(kp);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[d][ct][r] *= f;
+                }
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if constexpr (F16) {
+                    unsigned p1[4], p2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (part == 0)
+                            gs_split2h(xg[t][2 * k] * spx, xg[t][2 * k + 1] * spx, p1[k], p2[k]);
+                        else
+                            gs_split2h(hg[t][2 * k] * spx, hg[t][2 * k + 1] * spx, p1[k], p2[k]);
+                    }
+                    const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4{p1[0], p1[1], p1[2], p1[3]}));
+                    const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4{p2[0], p2[1], p2[2], p2[3]}));
+#pragma unroll
+                    for (int g = 0; g < (part == 0 ? 3 : 2); ++g)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) gs_mma3h(acc[g][mb], wl + ((((part * 3 + g) * 2 + mb) * 4 + t) * 2) * 64, b1, b2);
+                    continue;
+                }
                 unsigned p1[4], p2[4], p3[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -508,14 +616,32 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv2dgru_cell_sb(MrxConv2dGruSbAr
         const bool o_valid = valid, have_h = hb != nullptr;
         sg += stride;
         if (sg < a.nseg) load(sg);  // next segment's x loads fly during the rest of this one
+        const float unpx = F16 ? gs_pow2(-kp) * unw : 1.f;     // F16: back to the scale of the pre-activations (exact)
+        const float spx_o = spx;
         if (have_h) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[1][ct][r] = hv[ct][r] * gs_sigmoid(acc[1][ct][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const float pre = F16 ? acc[1][ct][r] * unpx + Bs[GS_F + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lhi] : acc[1][ct][r];
+                    acc[1][ct][r] = hv[ct][r] * gs_sigmoid(pre);
+                }
             // Wo_h (h * reset): the B operand of step t is accumulator registers R = 8 t .. 8 t + 7
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if constexpr (F16) {   // |h reset| <= |h|: the pixel's scale covers it
+                    unsigned p1[4], p2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int R0 = 8 * t + 2 * k, R1 = R0 + 1;
+                        gs_split2h(acc[1][R0 >> 4][R0 & 15] * spx_o, acc[1][R1 >> 4][R1 & 15] * spx_o, p1[k], p2[k]);
+                    }
+                    const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4{p1[0], p1[1], p1[2], p1[3]}));
+                    const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4{p2[0], p2[1], p2[2], p2[3]}));
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) gs_mma3h(acc[2][mb], wl + (((5 * 2 + mb) * 4 + t) * 2) * 64, b1, b2);
+                    continue;
+                }
                 unsigned p1[4], p2[4], p3[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -534,8 +660,8 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv2dgru_cell_sb(MrxConv2dGruSbAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lhi;
-                const float u = gs_sigmoid(acc[0][ct][r]);
-                const float dl = gs_tanh(acc[2][ct][r]);
+                const float u = gs_sigmoid(F16 ? acc[0][ct][r] * unpx + Bs[co] : acc[0][ct][r]);
+                const float dl = gs_tanh(F16 ? acc[2][ct][r] * unpx + Bs[2 * GS_F + co] : acc[2][ct][r]);
                 const float o = hv[ct][r] * (1.0f - u) + dl * u;
                 if (o_valid) {
                     ob[(unsigned)co * P32 + o_pxo] = o;
@@ -549,7 +675,8 @@ int mrx_conv2dgru_sb_launch(const MrxConv2dGruSbArgs& a, hipStream_t st) {
     static bool attr_done = false;
     static int n_cu = 0;
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_conv2dgru_cell_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv2dgru_cell_sb<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv2dgru_cell_sb<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         hipDeviceProp_t prop;
         MRX_HIP(hipGetDevice(&dev));
@@ -559,7 +686,11 @@ int mrx_conv2dgru_sb_launch(const MrxConv2dGruSbArgs& a, hipStream_t st) {
     }
     const long long nblk_need = (a.nseg + GS_NT / 64 - 1) / (GS_NT / 64);
     const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);
-    hipLaunchKernelGGL(k_conv2dgru_cell_sb, dim3(nblk), dim3(GS_NT), lds, st, a);
+    static const int f16 = (getenv("MRX_CONV2DGRU_F16") && atoi(getenv("MRX_CONV2DGRU_F16")) == 0) ? 0 : 1;   // 0: the three-term bf16 form (RecurrentVarNet 164 -> 182 slices/s with fp16)
+    if (f16)
+        hipLaunchKernelGGL(k_conv2dgru_cell_sb<true>, dim3(nblk), dim3(GS_NT), lds, st, a);
+    else
+        hipLaunchKernelGGL(k_conv2dgru_cell_sb<false>, dim3(nblk), dim3(GS_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
