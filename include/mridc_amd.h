@@ -53,6 +53,10 @@ extern "C" {
 
 int mrx_version(void);
 const char* mrx_last_error(void);
+/* 0 when `stream` is not being captured into a hipGraph, otherwise the non-zero id of the capture (hipStreamGetCaptureInfo).  The host side
+ * keys its per-slice operand caches on it: an operand prepared eagerly must not be baked into a graph (a replay on refilled inputs would
+ * read stale operands) and one prepared inside a capture must not be used outside it. */
+int64_t mrx_stream_capture_id(void* stream);
 
 /* Create (and cache) the twiddle tables for lengths h and w.  Optional; every FFT entry point does
  * it lazily.  Call it before capturing a hipGraph. */

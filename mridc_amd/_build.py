@@ -56,7 +56,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(LIBDIR, os.path.splitext(name)[0] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
-            cmd = [hipcc] + COMMON + extra + ["-x", "hip", "-c", src, "-o", obj]
+            cmd = [hipcc] + COMMON + extra + os.environ.get("MRX_BUILD_DEFS", "").split() + ["-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

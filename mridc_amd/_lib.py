@@ -24,6 +24,7 @@ _p, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _SIGNATURES = {
     "mrx_version": ([], _i),
     "mrx_last_error": ([], ctypes.c_char_p),
+    "mrx_stream_capture_id": ([_p], _i64),
     "mrx_fft_prepare": ([_i, _i], _i),
     "mrx_fft_max_len": ([], _i),
     "mrx_fft2": ([_p, _p, _i64, _i, _i, _i, _i, _i, _p], _i),

@@ -39,7 +39,7 @@ class _GatedCellBase(nn.Module):
 
     def _ns(self, _input, hx):
         """`diff` (training: convolutions with HIP backward kernels, gates recorded by torch) or `ops`."""
-        return diff if diff.active(_input, hx, *self.parameters()) else ops
+        return diff if diff.active(_input, hx, *self.parameters(), training=self.training) else ops
 
     def _convs(self, _input, hx):
         o = self._ns(_input, hx)

@@ -13,9 +13,9 @@ import torch
 from mridc_amd import diff, ops
 
 
-def _ns(x, *params):
+def _ns(x, *params, training=True):
     """`diff` (differentiable forms, training) when gradients are being recorded through x or the parameters, else `ops`."""
-    return diff if diff.active(x, *params) else ops
+    return diff if diff.active(x, *params, training=training) else ops
 
 
 class ConvBlock(torch.nn.Module):
@@ -40,7 +40,7 @@ class ConvBlock(torch.nn.Module):
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         if self.training and self.drop_prob > 0:
             raise NotImplementedError("Dropout2d in training mode is not part of the HIP inference path")
-        o = _ns(image, self.layers[0].weight, self.layers[4].weight)
+        o = _ns(image, self.layers[0].weight, self.layers[4].weight, training=self.training)
         x = o.conv_instance_norm_act(image, self.layers[0].weight, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
         return o.conv_instance_norm_act(x, self.layers[4].weight, self.layers[5].eps, ops.ACT_LEAKY, 0.2)
 
@@ -59,7 +59,7 @@ class TransposeConvBlock(torch.nn.Module):
         )
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
-        if diff.active(image, self.layers[0].weight):
+        if diff.active(image, self.layers[0].weight, training=self.training):
             return diff.instance_norm_act(diff.conv_transpose2x2(image, self.layers[0].weight), self.layers[1].eps, ops.ACT_LEAKY, 0.2)
         return ops.conv_transpose2x2_instance_norm_act(image, self.layers[0].weight, self.layers[1].eps, ops.ACT_LEAKY, 0.2)
 
@@ -132,7 +132,7 @@ class Unet(torch.nn.Module):
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         stack = []
         output = image
-        o = _ns(image, *self.parameters())
+        o = _ns(image, *self.parameters(), training=self.training)
         if o is ops and self.fused and not self.training and self._fusable():
             return self._forward_fused(image)
         for layer in self.down_sample_layers:                        # unet_block.py:203-206

@@ -37,7 +37,7 @@ class VarNetBlock(torch.nn.Module):
 
     def forward(self, pred: torch.Tensor, ref_kspace: torch.Tensor, sens_maps: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         """vn_block.py:89-119."""
-        if diff.active(pred, *self.parameters()):            # training: the differentiable forms (k-space formulation, no fusion)
+        if diff.active(pred, *self.parameters(), training=self.training):            # training: the differentiable forms (k-space formulation, no fusion)
             kw = (self.fft_centered, self.fft_normalization, self.spatial_dims)
             eta = diff.sens_reduce(pred, sens_maps, *kw).unsqueeze(1)
             eta = diff.sens_expand(self.model(eta), sens_maps, *kw)

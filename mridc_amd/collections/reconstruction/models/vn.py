@@ -71,7 +71,7 @@ class VarNet(torch.nn.Module):
     def forward(self, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask: torch.Tensor, init_pred: torch.Tensor,
                 target: torch.Tensor) -> torch.Tensor:
         """vn.py:94-142."""
-        if diff.active(y, *self.parameters()):                # training: k-space formulation on the differentiable forms
+        if diff.active(y, *self.parameters(), training=self.training):                # training: k-space formulation on the differentiable forms
             estimation = y.clone()
             for cascade in self.cascades:
                 estimation = cascade(estimation, y, sensitivity_maps, mask)

@@ -282,7 +282,9 @@ __device__ __forceinline__ int s2_pixel_exp(float m) {
 #define S2_OFF_X (S2_OFF_W + 2 * S2_WCH * 16)
 #define S2_LDS (S2_OFF_X + 2 * 3 * S2_NPIX_MAX * 16)
 
-template <int DIL, bool TAIL, bool ZP, bool F16 = false>
+// ABL (probe builds only, -DMRX_L2_ABLATE + env MRX_L2_ABL): phases switched off to price them -- 1 no x loads, 2 no operand split, 4 no LDS
+// staging writes, 8 no convolution MFMAs, 16 no tail, 32 no LDS operand reads, 64 no barriers.  Results are garbage; only the time is read.
+template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0>
 __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     constexpr int S2_PAD = DIL, S2_PH = S2_TH + 2 * DIL, S2_PW = S2_TW + 2 * DIL, S2_NPIX = S2_PH * S2_PW;
     constexpr int NT = F16 ? 2 : 3;                                        // operand terms of the convolution stage
@@ -358,7 +360,10 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
         for (int v = 0; v < XV; ++v)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xr[v][j] = st_xb[(long long)(8 * st_q + j) * plane + goff[v]];
+            for (int j = 0; j < 8; ++j) {
+                if constexpr ((ABL & 1) != 0) asm volatile("v_mov_b32 %0, 1.0" : "=v"(xr[v][j]));
+                else xr[v][j] = st_xb[(long long)(8 * st_q + j) * plane + goff[v]];
+            }
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
             const int i = tid + v * S2_NT;
@@ -378,7 +383,9 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             unsigned p1[4], p2[4], p3[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if constexpr (F16) {
+                if constexpr ((ABL & 2) != 0) {
+                    p1[k] = __float_as_uint(xr[v][2 * k]), p2[k] = __float_as_uint(xr[v][2 * k + 1]), p3[k] = 0u;
+                } else if constexpr (F16) {
                     s2_split2h(xr[v][2 * k] * sx, xr[v][2 * k + 1] * sx, p1[k], p2[k]);
                     p3[k] = 0u;
                 } else {
@@ -389,7 +396,10 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) p1[k] = p2[k] = p3[k] = 0u;
             }
-            if (p < S2_NPIX) {
+            if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(p1[k]), "v"(p2[k]));
+            } else if (p < S2_NPIX) {
                 u32x4* dst = Xp + buf * (NT * S2_NPIX) + p;
                 dst[0] = u32x4{p1[0], p1[1], p1[2], p1[3]};
                 dst[S2_NPIX] = u32x4{p2[0], p2[1], p2[2], p2[3]};
@@ -399,7 +409,8 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
             const int i = tid + v * S2_NT;
-            if (i < WCH) Wc[buf * WCH + i] = wr[v];
+            if constexpr ((ABL & 4) != 0) asm volatile("" ::"v"(wr[v]));
+            else if (i < WCH) Wc[buf * WCH + i] = wr[v];
         }
     };
     st_coords();
@@ -444,7 +455,16 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             const u32x4* w8 = Wc + ((q + lhi) & 1) * WCH + WFULL + l31;
             u32x4 bt[2][2][NT], at[2][2][NT];     // [buffer][row | ct][term]
             auto fetch = [&](int s, int bf) {
-                if (s < 4) {
+                if constexpr ((ABL & 32) != 0) {
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            bt[bf][i][k] = u32x4{0x3c003c00u + (unsigned)s, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                            at[bf][i][k] = u32x4{0x3c003c00u, 0x3c003c00u + (unsigned)q, 0x3c003c00u, 0x3c003c00u};
+                            asm volatile("" : "+v"(bt[bf][i][k]), "+v"(at[bf][i][k]));
+                        }
+                } else if (s < 4) {
                     const int off = lhi ? toff(2 * s + 1) : toff(2 * s);
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
@@ -469,7 +489,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                 const int bf = s & 1;
                 if (s == 4 && !even) break;
                 if (s == S2_BAR_STEP && even) {        // every thread's commit of chunk q + 1 is visible
-                    __syncthreads();
+                    if constexpr (!(ABL & 64)) __syncthreads();
                     if (S2_BAR_STEP == 4) fetch(4, bf);
                 }
                 if (s + 1 < 4 || (s + 1 == 4 && even && S2_BAR_STEP == 3)) fetch(s + 1, bf ^ 1);
@@ -477,7 +497,12 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #define S2_P(TA, TB)                                                                                                                       \
     _Pragma("unroll") for (int rw = 0; rw < 2; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at[bf][ct][TA]), __builtin_bit_cast(bf16x8, bt[bf][rw][TB]), acc[rw][ct], 0, 0, 0);
-                if constexpr (F16) {
+                if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(bt[bf][i][k]), "v"(at[bf][i][k]));
+                } else if constexpr (F16) {
                     // two fp16 terms per operand: the three products of weight >= 2^-11, smallest first
 #define S2_PH16(TA, TB)                                                                                                                    \
     _Pragma("unroll") for (int rw = 0; rw < 2; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
@@ -492,9 +517,9 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                     commit_next((q + 1) & 1);
                     request_next();
                 }
-                if (TAIL && s == 2 && q == S2_NCH - 1) load_hp(0);
+                if (TAIL && !(ABL & 16) && s == 2 && q == S2_NCH - 1) load_hp(0);
             }
-            __syncthreads();
+            if constexpr (!(ABL & 64)) __syncthreads();
         }
 
         if constexpr (F16) {
@@ -506,7 +531,12 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                     for (int r = 0; r < 16; ++r) acc[rw][ct][r] = acc[rw][ct][r] * unx * unw + tabl[64 + 2 * (ct * 16 + r) + lhi];
         }
         S2_STAMP(1)
-        if constexpr (TAIL) {
+        if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+            for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) asm volatile("" ::"v"(acc[rw][ct]));
+        } else if constexpr (TAIL) {
         // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev), one of the wave's two rows at a time ------------------
         // (h_prev of row 0 was requested inside the last chunk; row 1's request goes out now and hides under row 0's tail)
         load_hp(1);
@@ -684,11 +714,11 @@ static int l2sb_ncu() {
     }
     return ncu;
 }
-template <int DIL, bool TAIL, bool ZP, bool F16 = false>
+template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0>
 static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
     static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
         attr_done = true;
     }
     const int ncu = l2sb_ncu();
@@ -701,7 +731,7 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, st);
         a.trace = d_trace;
     }
-    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP, F16>), dim3(grid), dim3(S2_NT), S2_LDS, st, a);
+    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL>), dim3(grid), dim3(S2_NT), S2_LDS, st, a);
     MRX_LAUNCH_CHECK();
     if (a.trace) {
         (void)hipStreamSynchronize(st);
@@ -732,6 +762,17 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
     a.P = P, a.act = MRX_ACT_NONE, a.slope = 0.f;
     a.xmax = reinterpret_cast<const unsigned*>(xmax);
+#ifdef MRX_L2_ABLATE
+    if (xmax && getenv("MRX_L2_ABL")) {
+        switch (atoi(getenv("MRX_L2_ABL"))) {
+#define L2_ABL_CASE(N) case N: return l2sb_launch_t<2, true, false, true, N>(a, (hipStream_t)stream);
+            L2_ABL_CASE(1) L2_ABL_CASE(2) L2_ABL_CASE(3) L2_ABL_CASE(4) L2_ABL_CASE(7) L2_ABL_CASE(8) L2_ABL_CASE(16) L2_ABL_CASE(23)
+            L2_ABL_CASE(32) L2_ABL_CASE(40) L2_ABL_CASE(64) L2_ABL_CASE(71) L2_ABL_CASE(87)
+#undef L2_ABL_CASE
+            default: break;
+        }
+    }
+#endif
     if (xmax) return l2sb_launch_t<2, true, false, true>(a, (hipStream_t)stream);
     return l2sb_launch_t<2, true, false>(a, (hipStream_t)stream);
 }

@@ -18,9 +18,11 @@ PAD_ZERO, PAD_REPLICATE = ops.PAD_ZERO, ops.PAD_REPLICATE
 ACT_NONE, ACT_RELU, ACT_LEAKY = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY
 
 
-def active(*tensors):
-    """True when torch is recording gradients and one of the tensors takes part."""
-    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+def active(*tensors, training=True):
+    """True when torch is recording gradients and one of the tensors takes part.  Modules pass `training=self.training`: an eval-mode module
+    called without torch.no_grad() takes the fused inference kernels instead of silently recording a (several times slower) tape -- the
+    same rule RIMBlock.forward applies."""
+    return bool(training) and torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
 
 
 def _act_grad(dy, y, act, slope):

@@ -34,23 +34,52 @@ def _bchw(t):
 
 
 PFA372 = os.environ.get("MRIDC_AMD_PFA372", "1") != "0"
-_SP372 = {}
+
+
+class _PreparedCache:
+    """Per-slice prepared operands (lane-ordered maps, column-tiled k-space) keyed on the source tensor's (storage, version) AND on the
+    hipGraph capture the current stream is in (mrx_stream_capture_id; 0 = eager):
+      * an eager entry is never used while capturing -- the prepare kernel is launched INTO the graph, so a replay on refilled static
+        inputs prepares them again instead of reading operands of the data the capture happened to see;
+      * an entry made inside a capture lives in that graph's memory pool and is used only by later calls of the same capture (the 64 RIM
+        steps of a slice share one prepare launch); it is never evicted while its capture is running, and dropped when another capture or
+        an eager call shows that it is over (the graph keeps its own reference to the pool);
+      * eager entries are least-recently-made-first evicted beyond `keep`; every entry holds its source tensor so the address cannot be
+        recycled under the same version."""
+
+    def __init__(self, keep=4):
+        self.keep = keep
+        self.entries = {}
+
+    def get(self, src, extra, make):
+        cap = int(_lib.lib().mrx_stream_capture_id(_lib.stream_ptr()))
+        stale = [k for k in self.entries if k[0] != 0 and k[0] != cap]
+        for k in stale:
+            del self.entries[k]
+        key = (cap, src.data_ptr(), src._version, str(src.device), tuple(src.shape)) + tuple(extra)
+        hit = self.entries.get(key)
+        if hit is None:
+            if cap == 0:
+                eager = [k for k in self.entries if k[0] == 0]
+                if len(eager) >= self.keep:
+                    del self.entries[eager[0]]
+            hit = self.entries[key] = (make(), src.detach())
+        return hit[0]
+
+
+_SP372 = _PreparedCache()
 
 
 def _sp372(sens, centered):
-    """The sensitivity maps in the lane order of the W = 372 prime-factor kernels (mrx_pfa372_prepare_maps), cached per (storage, version):
-    the maps are constant over the cascades of a slice.  The entry keeps the source tensor alive so its address cannot be recycled."""
-    key = (sens.data_ptr(), sens._version, str(sens.device), tuple(sens.shape), bool(centered))
-    hit = _SP372.get(key)
-    if hit is None:
-        if len(_SP372) >= 4:
-            _SP372.pop(next(iter(_SP372)))
+    """The sensitivity maps in the lane order of the W = 372 prime-factor kernels (mrx_pfa372_prepare_maps): constant over the cascades of a
+    slice, so prepared once per (storage, version, capture) -- see _PreparedCache."""
+    def make():
         B, C, H, W = _bchw(sens)
         sp = torch.empty(int(_lib.lib().mrx_llg372_operand_floats(B, C, H)), dtype=torch.float32, device=sens.device)
         _lib.check(_lib.lib().mrx_pfa372_prepare_maps(_lib.ptr(sens), _lib.ptr(sp), B, C, H, int(bool(centered)), _lib.stream_ptr()),
                    "mrx_pfa372_prepare_maps")
-        hit = _SP372[key] = (sp, sens.detach())
-    return hit[0]
+        return sp
+    return _SP372.get(sens, (bool(centered),), make)
 
 
 def _pfa372_ok(sens):
@@ -170,7 +199,7 @@ def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None, 
 
 
 LLG_T4 = os.environ.get("MRIDC_AMD_LLG_T4", "1") != "0"
-_Y_T4 = {}
+_Y_T4 = _PreparedCache()
 
 
 def llg_t4_supported(y):
@@ -180,18 +209,14 @@ def llg_t4_supported(y):
 
 
 def _y_t4(y):
-    """The measured k-space in the column-tiled layout [B*C][W/4][H][4] (mrx_tile4_cols), cached per (storage, version) like _sp372:
-    it is constant over the steps and cascades of a slice."""
-    key = (y.data_ptr(), y._version, str(y.device), tuple(y.shape))
-    hit = _Y_T4.get(key)
-    if hit is None:
-        if len(_Y_T4) >= 4:
-            _Y_T4.pop(next(iter(_Y_T4)))
+    """The measured k-space in the column-tiled layout [B*C][W/4][H][4] (mrx_tile4_cols), prepared once per (storage, version, capture)
+    like _sp372: it is constant over the steps and cascades of a slice."""
+    def make():
         B, C, H, W = _bchw(y)
         t4 = torch.empty_like(y)
         _lib.check(_lib.lib().mrx_tile4_cols(_lib.ptr(y), _lib.ptr(t4), B * C, H, W, _lib.stream_ptr()), "mrx_tile4_cols")
-        hit = _Y_T4[key] = (t4, y.detach())
-    return hit[0]
+        return t4
+    return _Y_T4.get(y, (), make)
 
 
 def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, out=None, work=None, parts=False):

@@ -97,9 +97,9 @@ class ReconstructionRunner:
 
     def predict(self, y, sensitivity_maps, mask, init_pred, target, kspace=None):
         """forward + the unwrapping of base.py:394-407 -> complex [B,h,w] on the device."""
-        if self.use_sens_net:
-            sensitivity_maps = self.model.sens_net(kspace, mask)
         with torch.no_grad():
+            if self.use_sens_net:
+                sensitivity_maps = self.model.sens_net(kspace, mask)
             preds = self.model.forward(y, sensitivity_maps, mask, init_pred, target)
             if self.accumulate_estimates:
                 try:

@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests._util import assert_close
+from tests._util import assert_close, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -335,3 +335,29 @@ def test_gated_rim_training_gradients_vs_oracle_autograd(dev, cell):
         assert_close(prm.grad, ref, 2e-3, f"{cell}: gradient of {name}")
         checked += 1
     assert checked >= 9
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_absl1_loss_gradient_includes_the_path_through_the_maximum(dev, seed):
+    """mean |target - |p| / max|p|| (cirim.py:218-237): the gradient has one large term at the arg-max pixel (the path through the max).
+    mrx_absl1_loss_bwd finds that pixel by comparing its own modulus with mrx_max_abs's, so both must round identically (they are formed by
+    the same fmul / fmul / fadd / correctly-rounded-sqrt sequence whatever each file's contraction mode).  Against torch autograd in
+    float64 on several seeds; the arg-max entry is checked on its own, because the whole-vector norm would hide a dropped term."""
+    from mridc_amd import autograd as ag
+    g = torch.Generator().manual_seed(100 + seed)
+    p = (torch.randn(1, 37, 41, 2, generator=g) * 3.0 + 0.5)
+    tgt = torch.rand(1, 37, 41, generator=g)
+    pr = p.double().requires_grad_(True)
+    mag = (pr ** 2).sum(-1).sqrt()
+    ref = (tgt.double() - mag / mag.max()).abs().mean()
+    ref.backward()
+    pd = p.to(dev).requires_grad_(True)
+    loss = ag.AbsL1Loss.apply(pd, tgt.to(dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6 * abs(float(ref.detach()))
+    got, want = pd.grad.cpu().double(), pr.grad
+    assert rel_l2(got, want) <= 1e-5
+    idx = int(mag.detach().reshape(-1).argmax())
+    gw, gg = want.reshape(-1, 2)[idx], got.reshape(-1, 2)[idx]
+    assert float(gw.norm()) > 10 * float(want.reshape(-1, 2).norm(dim=1).median())       # the max term really dominates that pixel
+    assert float((gg - gw).norm()) <= 1e-4 * float(gw.norm()), (gg, gw)

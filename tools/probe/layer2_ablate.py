@@ -1,0 +1,54 @@
+"""Second RIM layer (two-term fp16 route): price of each phase by switching it off (library built with MRX_BUILD_DEFS=-DMRX_L2_ABLATE).
+ABL bits: 1 no x loads, 2 no operand split, 4 no LDS staging writes, 8 no conv MFMAs, 16 no tail, 32 no LDS operand reads, 64 no barriers."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from mridc_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+B, F, H, W = 1, 64, 640, 372
+r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+x, hp = r(B, F, H, W).relu(), r(B, F, H, W).relu()
+wc, wi = r(F, F, 3, 3) / 24, r(F, F, 1, 1) / 8
+bc, bi, hh = r(F) * 0.1, r(F) * 0.1, r(1, F, 1, 1) * 0.5
+wf = r(2, F, 3, 3) / 24
+pk_h = ops.rim_layer2_f16_pack(wc, wi, wf)
+xmax = x.abs().max().reshape(1).contiguous()
+taps = torch.empty(B, 18, H, W, device=dev)
+out = torch.empty_like(hp)
+
+
+def timed(fn, n=60):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return 1e3 * s.elapsed_time(e) / n
+
+
+names = {0: "full", 1: "no x loads", 2: "no split", 3: "no x loads, no split", 4: "no LDS staging writes", 7: "no staging at all", 8: "no conv MFMAs",
+         16: "no tail", 23: "no staging, no tail", 32: "no LDS operand reads", 40: "no operand reads, no MFMAs", 64: "no barriers",
+         71: "no staging, no barriers", 87: "no staging, no barriers, no tail"}
+fn = lambda: ops.rim_layer2_f16(x, pk_h, bc, bi, hh, hp, xmax, taps=taps, out=out, want_taps=True)  # noqa: E731
+for rep in range(2):
+    for abl, name in names.items():
+        if abl:
+            os.environ["MRX_L2_ABL"] = str(abl)
+        else:
+            os.environ.pop("MRX_L2_ABL", None)
+        print("ABL %3d %-36s %.2f us" % (abl, name, timed(fn)), flush=True)
+os.environ["MRX_L2SB_TRACE"] = "1"
+for abl, name in names.items():
+    if abl:
+        os.environ["MRX_L2_ABL"] = str(abl)
+    else:
+        os.environ.pop("MRX_L2_ABL", None)
+    print("trace ABL %d %s" % (abl, name), flush=True)
+    fn()
+    torch.cuda.synchronize()
