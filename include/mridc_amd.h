@@ -319,6 +319,15 @@ int mrx_rim_layer2_f16(const float* x, const float* packed, const float* b_conv,
 int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
                            const float* h_prev, float* h_new, float* taps, int B, int H, int W, void* stream);
 int mrx_rim_final_gather(const float* taps, const float* b_final, const float* eta, float* eta_out, int B, int H, int W, void* stream);
+/* Complex instance normalisation around a regulariser (models/sigmanet/sensitivity_net.py:16-139): m = mean of every real and imaginary entry,
+ * C = 2x2 covariance of (re - m, im - m) per batch element (sums over per_b complex values, divided by `divisor` -- the reference's
+ * shape[2] * shape[3] - 1); coef[b] = {m, C^(1/2) row-major, C^(-1/2) row-major} (9 floats).  center = 0 takes the data as mean-free.
+ * apply: x [B][C][plane] complex -> out [B C][2][plane] = clamp(C^(-1/2)(x - m), -6, 6) (the regulariser's channel-first input);
+ * unapply: y [B C][2][plane] -> out [B][C][plane] complex = C^(1/2) y + m.  work: mrx_cnorm_work_doubles(B) doubles. */
+int64_t mrx_cnorm_work_doubles(int B);
+int mrx_cnorm_stats(const float* x, int B, int64_t per_b, double divisor, int center, float* coef, double* work, void* stream);
+int mrx_cnorm_apply(const float* x, const float* coef, float* out, int B, int C, int64_t plane, void* stream);
+int mrx_cnorm_unapply(const float* y, const float* coef, float* out, int B, int C, int64_t plane, void* stream);
 /* The gather half of a 3x3 convolution into Cout <= 4 channels done as a 1x1 channel contraction Cin -> 9 Cout (mrx_conv2d with the weights
  * re-ordered to [tap * Cout + co][c]) + nine shifted adds: out[b][co] = bias[co] + sum_tap shift_tap(taps[b][tap * Cout + co]); replicate padding =
  * clamped coordinates, zero padding = taps outside the image dropped (conv_layers.py:121-123 for thin final layers, e.g. qrim_block.py:226-236). */

@@ -29,6 +29,7 @@ SOURCES = [
     ("unet.hip", []),
     ("unet_fused.hip", []),
     ("qmri.hip", ["-ffp-contract=off"]),
+    ("cnorm.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

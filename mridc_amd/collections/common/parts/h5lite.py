@@ -13,6 +13,7 @@ the deflate and shuffle filters, fixed-point, floating-point, fixed and variable
 and the {r, i} compound h5py / PyTables use for complex numbers, attributes of those types.  Anything else raises NotImplementedError
 naming the feature.  Writes: superblock 0, one root group, contiguous datasets, scalar / 1-D numeric and string attributes -- what
 `save_reconstructions` and the test fixtures need -- in the layout libhdf5 itself produces, so h5py, h5dump and MATLAB read the files."""
+import mmap
 import os
 import struct
 import zlib
@@ -127,8 +128,11 @@ def _parse_space(buf, off):
 # ---- reading --------------------------------------------------------------------------------------------------------------------------
 class _Reader:
     def __init__(self, path):
+        # the file image is memory-mapped, never read: metadata walks touch a few pages, a slice read touches that slice's bytes (the mapping
+        # lives as long as an array sliced out of it does; it is not closed explicitly)
         with open(path, "rb") as f:
-            self.buf = memoryview(f.read())
+            size = os.fstat(f.fileno()).st_size
+            self.buf = memoryview(mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)) if size else memoryview(b"")
         b = self.buf
         base = 0
         while bytes(b[base:base + 8]) != _SIG:       # the superblock may sit at 0, 512, 1024, ...
@@ -323,8 +327,10 @@ class _Reader:
 
 
 class Dataset:
-    """A dataset opened for reading: numpy basic indexing reads the whole array once and indexes it (volumes here are a few hundred MB
-    at most; contiguous storage is sliced from the file image without a copy until `astype` / arithmetic)."""
+    """A dataset opened for reading.  `ds[i]` / `ds[i:j]` (and tuples starting that way) decode only the rows of the leading axis they ask
+    for: a byte range of the memory-mapped image for contiguous storage, the chunks that intersect the rows for chunked storage -- one
+    slice of a multi-GB fastMRI volume costs one slice of I/O, as with h5py.  Any other key reads the whole array once (cached) and
+    indexes it.  Contiguous storage is sliced from the file image without a copy until `astype` / arithmetic."""
 
     def __init__(self, reader, addr, name):
         self._r, self._addr, self.name = reader, addr, name
@@ -373,8 +379,32 @@ class Dataset:
         return a.astype(dtype) if dtype is not None else a
 
     def __getitem__(self, key):
+        rows = self._leading_rows(key)
+        if rows is not None:
+            lo, hi, rest = rows
+            part = self._read(lo, hi)
+            return part[rest] if isinstance(part, np.ndarray) else part
         a = self._read()
         return a[key] if isinstance(a, np.ndarray) else a
+
+    def _leading_rows(self, key):
+        """(lo, hi, key to apply to rows lo .. hi) when `key` selects a unit-stride run of the leading axis of an uncached numeric
+        dataset of rank >= 1, else None."""
+        if self._cache is not None or not self.shape or self._type.vlen_str or self._type.dtype.kind == "S":
+            return None
+        lead, tail = (key[0], tuple(key[1:])) if isinstance(key, tuple) and key else (key, ())
+        n = self.shape[0]
+        if isinstance(lead, (int, np.integer)) and not isinstance(lead, (bool, np.bool_)):
+            i = int(lead) + (n if lead < 0 else 0)
+            if not 0 <= i < n:
+                raise IndexError(f"index {int(lead)} is out of bounds for axis 0 with size {n}")
+            return i, i + 1, (0,) + tail
+        if isinstance(lead, slice):
+            lo, hi, step = lead.indices(n)
+            if step != 1 or hi <= lo or (lo == 0 and hi == n):
+                return None
+            return lo, hi, (slice(None),) + tail
+        return None
 
     def _filter_list(self):
         b, p = self._r.buf, self._filters
@@ -400,9 +430,10 @@ class Dataset:
             out.append((fid, vals))
         return out
 
-    def _read(self):
+    def _read(self, lo=None, hi=None):
+        """The whole array (cached), or -- lo / hi given -- rows lo .. hi of the leading axis (not cached)."""
         if self._cache is not None:
-            return self._cache
+            return self._cache if lo is None else self._cache[lo:hi]
         r, b = self._r, self._r.buf
         p, sz = self._layout
         ver = b[p]
@@ -410,21 +441,26 @@ class Dataset:
         if shape is None:
             return None
         esize = typ.size
+        partial = lo is not None
+        rowbytes = esize * int(np.prod(shape[1:], dtype=np.int64)) if shape else esize
+        skip = lo * rowbytes if partial else 0
+        if partial:
+            shape = (hi - lo,) + tuple(shape[1:])
         nbytes = esize * (int(np.prod(shape, dtype=np.int64)) if shape else 1)
         if ver in (3, 4):
             cls = b[p + 1]
             if ver == 4 and cls == 2:
                 raise NotImplementedError("h5lite: version-4 chunk indices (chunked datasets written with libver='latest')")
             if cls == 0:
-                raw = b[p + 4:p + 4 + _u(b, p + 2, 2)]
+                raw = b[p + 4 + skip:p + 4 + _u(b, p + 2, 2)]
             elif cls == 1:
                 addr = _u(b, p + 2, 8)
-                raw = bytes(nbytes) if addr == _UNDEF else b[r.base + addr:r.base + addr + nbytes]
+                raw = bytes(nbytes) if addr == _UNDEF else b[r.base + addr + skip:r.base + addr + skip + nbytes]
             elif cls == 2:
                 nd = b[p + 2]
                 btree = _u(b, p + 3, 8)
                 chunk = tuple(_u(b, p + 11 + 4 * i, 4) for i in range(nd - 1))
-                raw = self._read_chunked(btree, chunk, esize)
+                raw = self._read_chunked(btree, chunk, esize, lo, hi)
             else:
                 raise NotImplementedError(f"h5lite: data layout class {cls}")
         elif ver in (1, 2):
@@ -432,16 +468,19 @@ class Dataset:
             if cls != 1:
                 raise NotImplementedError("h5lite: version-1/2 layout messages other than contiguous")
             addr = _u(b, p + 8, 8)
-            raw = b[r.base + addr:r.base + addr + nbytes]
+            raw = b[r.base + addr + skip:r.base + addr + skip + nbytes]
         else:
             raise NotImplementedError(f"h5lite: data layout message version {ver}")
         out = r._decode(typ, shape, raw)
-        self._cache = out
+        if not partial:
+            self._cache = out
         return out
 
-    def _read_chunked(self, btree, chunk, esize):
+    def _read_chunked(self, btree, chunk, esize, lo=None, hi=None):
+        """Raw bytes of the array -- of rows lo .. hi of its leading axis when given: only the chunks that intersect them are inflated."""
         r, b = self._r, self._r.buf
-        shape = self.shape
+        row0, row1 = (0, self.shape[0]) if lo is None else (lo, hi)
+        shape = (row1 - row0,) + tuple(self.shape[1:])
         filters = self._filter_list()
         for fid, _ in filters:
             if fid not in (1, 2):
@@ -467,6 +506,8 @@ class Dataset:
                 if level > 0:
                     walk(child)
                     continue
+                if offs[0] >= row1 or offs[0] + chunk[0] <= row0:
+                    continue                                     # no row of this chunk is wanted
                 data = bytes(b[r.base + child:r.base + child + csize])
                 for k in range(len(filters) - 1, -1, -1):        # undo the pipeline in reverse
                     if fmask & (1 << k):
@@ -478,8 +519,9 @@ class Dataset:
                         n_el = len(data) // esize
                         data = np.frombuffer(data[:n_el * esize], np.uint8).reshape(esize, n_el).T.tobytes() + data[n_el * esize:]
                 blk = np.frombuffer(data[:cbytes], dtype=out.dtype).reshape(chunk)
-                sl_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk, shape))
-                sl_in = tuple(slice(0, s.stop - s.start) for s in sl_out)
+                first, last = max(offs[0], row0), min(offs[0] + chunk[0], row1)
+                sl_out = (slice(first - row0, last - row0),) + tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs[1:], chunk[1:], shape[1:]))
+                sl_in = (slice(first - offs[0], last - offs[0]),) + tuple(slice(0, s.stop - s.start) for s in sl_out[1:])
                 out[sl_out] = blk[sl_in]
         walk(btree)
         return out.tobytes()

@@ -1,14 +1,22 @@
 """Drop-in for `mridc.collections.reconstruction.data.mri_data` (reference data/mri_data.py:21-318): `et_query` and `MRISliceDataset`,
-the on-disk side of the reconstruction path.  HDF5 access goes through `h5lite` (this package's reader; h5py is not a dependency), the
-ISMRMRD header through the standard library's ElementTree.  `__getitem__` returns the reference's 8-tuple
-(kspace, sensitivity_map, mask, eta, target, attrs, fname, slice) or hands it to `transform` -- e.g. this package's
-`MRIDataTransforms` (parts/transforms.py), which moves it to the GPU and yields the 9-tuple `ReconstructionRunner.test_step` takes."""
+the on-disk side of the reconstruction path.
+
+What the reference's class does, restated: every `.h5` volume of a directory contributes one example per slice (`consecutive_slices - 1`
+fewer when neighbouring slices are read together); an example is `(file, slice index, geometry)` with the geometry taken from the
+volume's ISMRMRD header; the example list can be cached in a YAML file, thinned by slice or by volume, and filtered by the number of
+k-space columns; `dataset[i]` reads that slice's `kspace`, `sensitivity_map` (from the volume or a side directory), `mask`, `eta` and the
+target reconstruction and returns the 8-tuple `(kspace, sensitivity_map, mask, eta, target, attrs, fname, slice)` -- or whatever
+`transform` makes of it, e.g. this package's `MRIDataTransforms` (parts/transforms.py), which moves it to the GPU and yields the 9-tuple
+`ReconstructionRunner.test_step` takes.
+
+HDF5 access goes through `h5lite` (this package's reader: only the requested slices are decoded from the memory-mapped file; h5py is
+not a dependency), the header through the standard library's ElementTree."""
 import logging
 import os
 import random
 from pathlib import Path
 from typing import Callable, Optional, Sequence, Tuple, Union
-from xml.etree.ElementTree import fromstring
+from xml.etree import ElementTree
 
 import numpy as np
 import yaml
@@ -17,167 +25,176 @@ from torch.utils.data import Dataset
 import mridc_amd.collections.common.parts.utils as utils
 from mridc_amd.collections.common.parts import h5lite
 
+_PathLike = Union[str, Path, os.PathLike]
+_CHALLENGES = ("singlecoil", "multicoil", "segmentation")
+
 
 def et_query(root, qlist: Sequence[str], namespace: str = "https://www.ismrm.org/ISMRMRD") -> str:
-    """mri_data.py:21-47: text of the element at the end of the path `qlist`, "0" when it is absent.  (The default namespace is spelt
-    with https as in the reference; headers declaring http://www.ismrm.org/ISMRMRD therefore answer "0" there too.)"""
-    s = "."
-    prefix = "ismrmrd_namespace"
-    ns = {prefix: namespace}
-    for el in qlist:
-        s += f"//{prefix}:{el}"
-    value = root.find(s, ns)
-    if value is None:
-        return "0"
-    return str(value.text)
+    """mri_data.py:21-47: the text of the header element reached by descending through the tags of `qlist` (each step matches at any
+    depth), "0" when there is none.  The default namespace is the reference's https spelling, so a header that declares
+    http://www.ismrm.org/ISMRMRD answers "0" here exactly as it does there."""
+    path = "." + "".join(f"//ns:{tag}" for tag in qlist)
+    node = root.find(path, {"ns": namespace})
+    return "0" if node is None else str(node.text)
+
+
+def _header_int(root, *tags):
+    return int(et_query(root, list(tags)))
+
+
+def _volume_geometry(header_xml):
+    """Matrix sizes and the zero-padding of the phase-encode axis from an ISMRMRD header (mri_data.py:176-199).  The padding follows the
+    fastMRI convention: the acquired lines sit between `encoding_size[1] // 2 - center` and that plus the number of encoding steps."""
+    root = ElementTree.fromstring(header_xml)
+    encoded = tuple(_header_int(root, "encoding", "encodedSpace", "matrixSize", axis) for axis in "xyz")
+    recon = tuple(_header_int(root, "encoding", "reconSpace", "matrixSize", axis) for axis in "xyz")
+    centre = _header_int(root, "encoding", "encodingLimits", "kspace_encoding_step_1", "center")
+    lines = _header_int(root, "encoding", "encodingLimits", "kspace_encoding_step_1", "maximum") + 1
+    left = encoded[1] // 2 - centre
+    return {"padding_left": left, "padding_right": left + lines, "encoding_size": encoded, "recon_size": recon}
+
+
+_NO_HEADER_GEOMETRY = {"padding_left": 0, "padding_right": 0, "encoding_size": 0, "recon_size": (0, 0)}   # mri_data.py:200-204
+
+
+def _to_plain(meta):
+    """Geometry dict -> YAML-safe types (tuples become lists) and back."""
+    return {k: (list(v) if isinstance(v, tuple) else v) for k, v in meta.items()}
+
+
+def _from_plain(meta):
+    return {k: (tuple(v) if isinstance(v, list) else v) for k, v in meta.items()}
 
 
 class MRISliceDataset(Dataset):
-    """A dataset that loads slices from the .h5 volumes of one directory (mri_data.py:50-318)."""
+    """The slices of the .h5 volumes of one directory (mri_data.py:50-318); constructor arguments, `examples`, `__len__` and the tuple
+    `__getitem__` returns are the reference's."""
 
-    def __init__(self, root: Union[str, Path, os.PathLike], challenge: str = "segmentation", transform: Optional[Callable] = None,
-                 sense_root: Union[str, Path, os.PathLike] = None, use_dataset_cache: bool = False, sample_rate: Optional[float] = None,
-                 volume_sample_rate: Optional[float] = None, dataset_cache_file: Union[str, Path, os.PathLike] = "dataset_cache.yaml",
-                 num_cols: Optional[Tuple[int]] = None, mask_root: Union[str, Path, os.PathLike] = None, consecutive_slices: int = 1):
-        if challenge not in ("singlecoil", "multicoil", "segmentation"):
+    def __init__(self, root: _PathLike, challenge: str = "segmentation", transform: Optional[Callable] = None, sense_root: _PathLike = None,
+                 use_dataset_cache: bool = False, sample_rate: Optional[float] = None, volume_sample_rate: Optional[float] = None,
+                 dataset_cache_file: _PathLike = "dataset_cache.yaml", num_cols: Optional[Tuple[int]] = None, mask_root: _PathLike = None,
+                 consecutive_slices: int = 1):
+        if challenge not in _CHALLENGES:
             raise ValueError('challenge should be either "singlecoil" or "multicoil" or "segmentation"')
-        self.challenge = challenge
         if sample_rate is not None and volume_sample_rate is not None:
             raise ValueError("either set sample_rate (sample by slices) or volume_sample_rate (sample by volumes) but not both")
-        self.sense_root = sense_root
-        self.mask_root = mask_root
-        self.dataset_cache_file = Path(dataset_cache_file)
+        self.challenge = challenge
         self.transform = transform
+        self.sense_root, self.mask_root = sense_root, mask_root
+        self.dataset_cache_file = Path(dataset_cache_file)
         self.recons_key = "reconstruction_esc" if challenge == "singlecoil" else "reconstruction_rss"
-        self.examples = []
-        if sample_rate is None:
-            sample_rate = 1.0
-        if volume_sample_rate is None:
-            volume_sample_rate = 1.0
 
-        # the cache holds plain types (file name, slice index, metadata) so that it loads with yaml.safe_load
-        if self.dataset_cache_file.exists() and use_dataset_cache:
-            with open(self.dataset_cache_file, "rb") as f:
-                dataset_cache = yaml.safe_load(f) or {}
-        else:
-            dataset_cache = {}
-        key = str(root)
-        if dataset_cache.get(key) is None or not use_dataset_cache:
-            files = list(Path(root).iterdir())
-            for fname in sorted(files):
-                metadata, num_slices = self._retrieve_metadata(fname)
-                if not utils.is_none(num_slices) and not utils.is_none(consecutive_slices):
-                    num_slices = num_slices - (consecutive_slices - 1)
-                self.examples += [(fname, slice_ind, metadata) for slice_ind in range(num_slices)]
-            if dataset_cache.get(key) is None and use_dataset_cache:
-                dataset_cache[key] = [[str(f), int(s), {k: (list(v) if isinstance(v, tuple) else v) for k, v in m.items()}]
-                                      for f, s, m in self.examples]
-                logging.info(f"Saving dataset cache to {self.dataset_cache_file}.")
-                with open(self.dataset_cache_file, "w") as f:
-                    yaml.safe_dump(dataset_cache, f)
-        else:
-            logging.info(f"Using dataset cache from {self.dataset_cache_file}.")
-            self.examples = [(Path(f), s, {k: (tuple(v) if isinstance(v, list) else v) for k, v in m.items()})
-                             for f, s, m in dataset_cache[key]]
-
-        if sample_rate < 1.0:                        # sample by slice
-            random.shuffle(self.examples)
-            self.examples = self.examples[:round(len(self.examples) * sample_rate)]
-        elif volume_sample_rate < 1.0:               # sample by volume
-            vol_names = sorted(list({f[0].stem for f in self.examples}))
-            random.shuffle(vol_names)
-            sampled_vols = vol_names[:round(len(vol_names) * volume_sample_rate)]
-            self.examples = [example for example in self.examples if example[0].stem in sampled_vols]
-        if num_cols:
+        self.examples = self._index_directory(Path(root), use_dataset_cache, consecutive_slices)
+        self.examples = self._thin(self.examples, 1.0 if sample_rate is None else sample_rate,
+                                   1.0 if volume_sample_rate is None else volume_sample_rate)
+        if num_cols:                                  # keep the volumes whose k-space has one of these widths
             self.examples = [ex for ex in self.examples if ex[2]["encoding_size"][1] in num_cols]
+
         self.consecutive_slices = consecutive_slices
         if self.consecutive_slices < 1:
             raise ValueError("consecutive_slices value is out of range, must be > 0.")
 
+    # ---- the example list --------------------------------------------------------------------------------------------------------------
+    def _index_directory(self, root, use_cache, consecutive_slices):
+        """One (file, slice, geometry) entry per readable slice position, from the YAML cache when asked for and present."""
+        cache = {}
+        if use_cache and self.dataset_cache_file.exists():
+            with open(self.dataset_cache_file, "rb") as f:
+                cache = yaml.safe_load(f) or {}
+        key = str(root)
+        if use_cache and cache.get(key) is not None:
+            logging.info(f"Using dataset cache from {self.dataset_cache_file}.")
+            return [(Path(f), s, _from_plain(m)) for f, s, m in cache[key]]
+
+        examples = []
+        for fname in sorted(Path(root).iterdir()):
+            geometry, num_slices = self._retrieve_metadata(fname)
+            if not utils.is_none(num_slices) and not utils.is_none(consecutive_slices):
+                num_slices -= consecutive_slices - 1
+            examples.extend((fname, idx, geometry) for idx in range(num_slices))
+        if use_cache:
+            cache[key] = [[str(f), int(s), _to_plain(m)] for f, s, m in examples]
+            logging.info(f"Saving dataset cache to {self.dataset_cache_file}.")
+            with open(self.dataset_cache_file, "w") as f:
+                yaml.safe_dump(cache, f)
+        return examples
+
+    @staticmethod
+    def _thin(examples, slice_rate, volume_rate):
+        """Random sub-sampling by slice, else by volume (mri_data.py:143-151); the `random` module's state decides, as in the reference."""
+        if slice_rate < 1.0:
+            random.shuffle(examples)
+            return examples[:round(len(examples) * slice_rate)]
+        if volume_rate < 1.0:
+            volumes = sorted({ex[0].stem for ex in examples})
+            random.shuffle(volumes)
+            kept = set(volumes[:round(len(volumes) * volume_rate)])
+            return [ex for ex in examples if ex[0].stem in kept]
+        return examples
+
     @staticmethod
     def _retrieve_metadata(fname):
-        """mri_data.py:163-212: encoding / reconstruction matrix sizes and the k-space padding from the ISMRMRD header, the slice count
-        from `kspace` (or `reconstruction`)."""
-        with h5lite.File(fname, "r") as hf:
-            if "ismrmrd_header" in hf:
-                et_root = fromstring(hf["ismrmrd_header"][()])
-                enc = ["encoding", "encodedSpace", "matrixSize"]
-                enc_size = (int(et_query(et_root, enc + ["x"])), int(et_query(et_root, enc + ["y"])), int(et_query(et_root, enc + ["z"])))
-                rec = ["encoding", "reconSpace", "matrixSize"]
-                recon_size = (int(et_query(et_root, rec + ["x"])), int(et_query(et_root, rec + ["y"])), int(et_query(et_root, rec + ["z"])))
-                params = ["encoding", "encodingLimits", "kspace_encoding_step_1"]
-                enc_limits_center = int(et_query(et_root, params + ["center"]))
-                enc_limits_max = int(et_query(et_root, params + ["maximum"])) + 1
-                padding_left = int(enc_size[1] / 2) - enc_limits_center          # trunc division, as torch.div(..., rounding_mode="trunc")
-                padding_right = padding_left + enc_limits_max
-            else:
-                padding_left = 0
-                padding_right = 0
-                enc_size = 0
-                recon_size = (0, 0)
-            num_slices = hf["kspace"].shape[0] if "kspace" in hf else hf["reconstruction"].shape[0]
-        metadata = {"padding_left": padding_left, "padding_right": padding_right, "encoding_size": enc_size, "recon_size": recon_size}
-        return metadata, num_slices
+        """mri_data.py:163-212: (geometry, number of slices) of one volume.  Only the header string and the dataset's shape are touched."""
+        with h5lite.File(fname, "r") as volume:
+            geometry = _volume_geometry(volume["ismrmrd_header"][()]) if "ismrmrd_header" in volume else dict(_NO_HEADER_GEOMETRY)
+            counted = volume["kspace"] if "kspace" in volume else volume["reconstruction"]
+            return geometry, counted.shape[0]
 
+    # ---- one example -----------------------------------------------------------------------------------------------------------------------
     def get_consecutive_slices(self, data, key, dataslice):
-        """mri_data.py:214-243."""
-        data = data[key]
-        if self.consecutive_slices == 1:
-            if data.shape[0] == 1:
-                return data[0]
-            if data.ndim != 2:
-                return data[dataslice]
-            return data
-        num_slices = data.shape[0]
-        if self.consecutive_slices > num_slices:
-            return np.stack(data, axis=0)
-        start_slice = dataslice
-        end_slice = dataslice + self.consecutive_slices if dataslice + self.consecutive_slices <= num_slices else num_slices
-        return data[start_slice:end_slice]
+        """mri_data.py:214-243: slice `dataslice` of `data[key]` -- or the run of `consecutive_slices` starting there (clipped at the
+        end of the volume; the whole volume when it is shorter than the run).  A single-slice volume answers with that slice, a 2-D
+        dataset (e.g. a mask) with itself."""
+        ds = data[key]
+        if self.consecutive_slices > 1:
+            n = ds.shape[0]
+            if self.consecutive_slices > n:
+                return np.stack(ds, axis=0)
+            return ds[dataslice:min(dataslice + self.consecutive_slices, n)]
+        if ds.shape[0] == 1:
+            return ds[0]
+        return ds[dataslice] if ds.ndim != 2 else ds
+
+    def _sensitivity_map(self, volume, fname, dataslice):
+        if "sensitivity_map" in volume:
+            return self.get_consecutive_slices(volume, "sensitivity_map", dataslice).astype(np.complex64)
+        if self.sense_root is None or self.sense_root == "None":
+            return np.array([])
+        # maps computed offline live under sense_root/<name of the volume's directory>/<volume file name>
+        side = Path(self.sense_root) / Path(str(fname).split("/")[-2]) / fname.name
+        with h5lite.File(side, "r") as sf:
+            key = "sensitivity_map" if ("sensitivity_map" in sf or "sensitivity_map" in next(iter(sf.keys()))) else "sense"
+            return np.asarray(self.get_consecutive_slices(sf, key, dataslice)).squeeze().astype(np.complex64)
+
+    def _mask(self, volume, fname, dataslice):
+        if "mask" in volume:
+            mask = np.asarray(self.get_consecutive_slices(volume, "mask", dataslice))
+            return mask[dataslice] if mask.ndim == 3 else mask
+        if self.mask_root is None or self.mask_root == "None":
+            return None
+        with h5lite.File(Path(self.mask_root) / fname.name, "r") as mf:
+            return np.asarray(self.get_consecutive_slices(mf, "mask", dataslice))
 
     def __len__(self):
         return len(self.examples)
 
     def __getitem__(self, i: int):
         """mri_data.py:248-318."""
-        fname, dataslice, metadata = self.examples[i]
-        with h5lite.File(fname, "r") as hf:
-            kspace = self.get_consecutive_slices(hf, "kspace", dataslice).astype(np.complex64)
-            if "sensitivity_map" in hf:
-                sensitivity_map = self.get_consecutive_slices(hf, "sensitivity_map", dataslice).astype(np.complex64)
-            elif self.sense_root is not None and self.sense_root != "None":
-                with h5lite.File(Path(self.sense_root) / Path(str(fname).split("/")[-2]) / fname.name, "r") as sf:
-                    if "sensitivity_map" in sf or "sensitivity_map" in next(iter(sf.keys())):
-                        sensitivity_map = self.get_consecutive_slices(sf, "sensitivity_map", dataslice)
-                    else:
-                        sensitivity_map = self.get_consecutive_slices(sf, "sense", dataslice)
-                    sensitivity_map = np.asarray(sensitivity_map).squeeze().astype(np.complex64)
-            else:
-                sensitivity_map = np.array([])
-            if "mask" in hf:
-                mask = np.asarray(self.get_consecutive_slices(hf, "mask", dataslice))
-                if mask.ndim == 3:
-                    mask = mask[dataslice]
-            elif self.mask_root is not None and self.mask_root != "None":
-                with h5lite.File(Path(self.mask_root) / fname.name, "r") as mf:
-                    mask = np.asarray(self.get_consecutive_slices(mf, "mask", dataslice))
-            else:
-                mask = None
-            eta = self.get_consecutive_slices(hf, "eta", dataslice).astype(np.complex64) if "eta" in hf else np.array([])
-            if "reconstruction_sense" in hf:
+        fname, dataslice, geometry = self.examples[i]
+        with h5lite.File(fname, "r") as volume:
+            kspace = self.get_consecutive_slices(volume, "kspace", dataslice).astype(np.complex64)
+            sensitivity_map = self._sensitivity_map(volume, fname, dataslice)
+            mask = self._mask(volume, fname, dataslice)
+            eta = self.get_consecutive_slices(volume, "eta", dataslice).astype(np.complex64) if "eta" in volume else np.array([])
+            if "reconstruction_sense" in volume:      # a SENSE target, when the volume has one, replaces the challenge's default from now on
                 self.recons_key = "reconstruction_sense"
-            target = self.get_consecutive_slices(hf, self.recons_key, dataslice) if self.recons_key in hf else None
-            target = np.asarray(target) if target is not None else None
-            attrs = dict(hf.attrs)
-            attrs.update(metadata)
+            target = np.asarray(self.get_consecutive_slices(volume, self.recons_key, dataslice)) if self.recons_key in volume else None
+            attrs = {**dict(volume.attrs), **geometry}
 
-        if sensitivity_map.shape != kspace.shape:
-            if sensitivity_map.ndim == 3:
-                sensitivity_map = np.transpose(sensitivity_map, (2, 0, 1))
-            elif sensitivity_map.ndim == 4:
-                sensitivity_map = np.transpose(sensitivity_map, (0, 3, 1, 2))
-            else:
+        if sensitivity_map.shape != kspace.shape:     # maps stored coils-last: bring the coil axis in front of the image axes
+            if sensitivity_map.ndim not in (3, 4):
                 raise ValueError(f"Sensitivity map has invalid dimensions {sensitivity_map.shape} compared to kspace {kspace.shape}")
+            sensitivity_map = np.moveaxis(sensitivity_map, -1, -3)
 
         item = (kspace, sensitivity_map, mask, eta, target, attrs, fname.name, dataslice)
         return item if self.transform is None else self.transform(*item)

@@ -1,89 +1,144 @@
 """Drop-in for `mridc.collections.reconstruction.models.sigmanet.sensitivity_net` (reference sensitivity_net.py:9-310): the complex
-instance normalisation around a regulariser and the unrolled network x <- D(x - R(x)), inference path.
+instance normalisation around a regulariser and the unrolled network x <- D(x - R(x)).
 
-The statistics (a mean and a 2x2 pseudo-covariance per image: a handful of reductions) are torch reductions on the device; the
-regulariser and the data layers they surround run on the HIP kernels.  Shapes are the reference's: a 4-D image [B,H,W,2] leaves the
-wrapper as [B,B,H,W,2] through the broadcast of its [B,1,1,1] statistics (B = 1 in the reference's own use), the covariance divisor is
-`shape[2] * shape[3] - 1` of whatever rank arrives."""
+The normalisation whitens the (re, im) pairs of an image stack: with m the mean over every real and imaginary entry and C the 2x2
+covariance of (re - m, im - m) per batch element, `normalize` is x -> C^(-1/2) (x - m) clamped to [-6, 6] and `unnormalize` its inverse
+y -> C^(1/2) y + m.  Here the statistics are three launches of libmridc_amd (`mrx_cnorm_stats`: fixed-order double-precision reductions, the
+2x2 matrix square root and its inverse formed on the device) and each direction is ONE pass that also does the reference's
+view / permute between [B,C,H,W,2] and the regulariser's [B C, 2, H, W] (`mrx_cnorm_apply`, `mrx_cnorm_unapply`) -- no host
+synchronisation, no torch arithmetic.
+
+Shapes are the reference's, quirks included: the covariance sums run over every axis between the batch axis and the complex axis but are
+divided by `shape[2] * shape[3] - 1` of whatever rank arrives (H W - 1 for [B,C,H,W,2]; 2 W - 1 for a 4-D [B,H,W,2] image); a 4-D image
+leaves the wrapper as [B,B,H,W,2] because its [B,1,1,1] coefficients broadcast against [B,H,W] (B = 1 in the reference's own use:
+[1,1,H,W,2]).  One difference: the reference takes C^(1/2) from an eigen-decomposition that is 0 / 0 when c_xy = 0 exactly; the kernel
+forms the principal square root directly (csrc/cnorm.hip), the same matrix wherever the reference's is defined."""
 import numpy as np
 import torch
 
+from mridc_amd import _lib
+
 
 def matrix_invert(xx, xy, yx, yy):
-    """sensitivity_net.py:9-12."""
+    """sensitivity_net.py:9-12: the inverse of [[xx, xy], [yx, yy]], entry by entry."""
     det = xx * yy - xy * yx
-    return yy.div(det), -xy.div(det), -yx.div(det), xx.div(det)
+    return yy / det, -(xy / det), -(yx / det), xx / det
+
+
+def _as_stack(x):
+    """(x5 [B,C,H,W,2] contiguous fp32, divisor, squeeze-back shape): the 5-D stack whose image (b, c) gets batch element b's coefficients,
+    the reference's covariance divisor and the shape the result has in the reference."""
+    if x.shape[-1] != 2:
+        raise AssertionError
+    x = _lib.f32c(x)
+    divisor = int(x.shape[2]) * int(x.shape[3]) - 1
+    if x.dim() == 5:
+        return x, divisor, tuple(x.shape)
+    if x.dim() == 4:                                  # [B,H,W,2]: coefficients [B,1,1,1] against [B,H,W] -> [B,B,H,W,2]
+        B = int(x.shape[0])
+        stack = x.unsqueeze(0).expand(B, *x.shape).contiguous() if B > 1 else x.unsqueeze(0)
+        return stack, divisor, (B, *x.shape)
+    raise NotImplementedError(f"ComplexInstanceNorm: rank-{x.dim()} input")
 
 
 class ComplexInstanceNorm(torch.nn.Module):
-    """sensitivity_net.py:15-118."""
+    """sensitivity_net.py:15-118.  `set_normalization(x)` measures x; `normalize` / `unnormalize` apply what was measured.  The measured
+    quantities are kept as one device tensor `coef` [B,9] = (m, C^(1/2) row-major, C^(-1/2) row-major) and exposed under the reference's
+    attribute names (`mean`, `cov_xx_half`, ... as [B,1,1,1] views)."""
 
     def __init__(self):
         super().__init__()
+        self.coef = None
         self.mean = 0
-        self.cov_xx_half = 1 / np.sqrt(2)
-        self.cov_xy_half = 0
-        self.cov_yx_half = 0
-        self.cov_yy_half = 1 / np.sqrt(2)
+        self.cov_xx_half = self.cov_yy_half = 1 / np.sqrt(2)
+        self.cov_xy_half = self.cov_yx_half = 0
+
+    # ---- measuring ---------------------------------------------------------------------------------------------------------------------
+    def _measure(self, x, center):
+        """coef [B,9] of the batch elements of x (statistics over x's own entries; `center` False: the data is taken as mean-free)."""
+        if x.dim() not in (4, 5) or x.shape[-1] != 2:
+            raise AssertionError
+        x = _lib.f32c(x)
+        _lib.require_gpu(x)
+        B = int(x.shape[0])
+        per_b = x[0].numel() // 2
+        L = _lib.lib()
+        coef = torch.empty(B, 9, dtype=torch.float32, device=x.device)
+        work = torch.empty(int(L.mrx_cnorm_work_doubles(B)), dtype=torch.float64, device=x.device)
+        _lib.check(L.mrx_cnorm_stats(_lib.ptr(x), B, per_b, float(int(x.shape[2]) * int(x.shape[3]) - 1), int(bool(center)), _lib.ptr(coef),
+                                     _lib.ptr(work), _lib.stream_ptr()), "mrx_cnorm_stats")
+        return coef
+
+    def _publish(self, coef, mean=None):
+        self.coef = coef
+        cols = [coef[:, i].reshape(-1, 1, 1, 1) for i in range(5)]
+        self.mean = cols[0][:1] if mean is None else mean          # the reference's mean is one scalar, kept as [1,1,1,1]
+        self.cov_xx_half, self.cov_xy_half, self.cov_yx_half, self.cov_yy_half = cols[1:]
+
+    def set_normalization(self, input):
+        """sensitivity_net.py:85-93: the mean over all entries of `input`, the covariance of what is left."""
+        self._publish(self._measure(input, center=True))
+
+    def complex_pseudocovariance(self, data):
+        """sensitivity_net.py:34-83: the square root of the covariance of mean-free `data` (the mean is left as it is)."""
+        coef = self._measure(data, center=False)
+        keep = self.mean
+        self._publish(coef, mean=keep)
 
     def complex_instance_norm(self, x, eps=1e-5):
-        x_combined = torch.sum(x, dim=1, keepdim=True)
-        mean = x_combined.mean(dim=(1, 2, 3), keepdim=True)
+        """sensitivity_net.py:26-32: per-sample complex mean of the coil sum, then the covariance of the centred stack."""
+        mean = x.sum(dim=1, keepdim=True).mean(dim=(1, 2, 3), keepdim=True)
         self.mean = mean
         self.complex_pseudocovariance(x - mean)
 
-    def complex_pseudocovariance(self, data):
-        """Mean-free data in; sets the square root of the 2x2 covariance (closed-form eigen-decomposition)."""
-        if data.size(-1) != 2:
-            raise AssertionError
-        shape = data.shape
-        N = shape[2] * shape[3]
-        re, im = torch.unbind(data, dim=-1)
-        dim = list(range(1, len(shape) - 1))
-        cxx = (re * re).sum(dim=dim, keepdim=True) / (N - 1)
-        cyy = (im * im).sum(dim=dim, keepdim=True) / (N - 1)
-        cxy = (re * im).sum(dim=dim, keepdim=True) / (N - 1)
-        root = torch.sqrt((cxx + cyy) ** 2 / 4 - cxx * cyy + cxy ** 2)
-        s1 = (cxx + cyy) / 2 - root
-        s2 = (cxx + cyy) / 2 + root
-        v1x, v1y, v2x, v2y = s1 - cyy, cxy, s2 - cyy, cxy
-        norm1 = torch.sqrt(torch.sum(v1x * v1x + v1y * v1y, dim=dim, keepdim=True))
-        norm2 = torch.sqrt(torch.sum(v2x * v2x + v2y * v2y, dim=dim, keepdim=True))
-        v1x, v1y, v2x, v2y = v1x.div(norm1), v1y.div(norm1), v2x.div(norm2), v2y.div(norm2)
-        det = v1x * v2y - v2x * v1y
-        s1 = torch.sqrt(s1).div(det)
-        s2 = torch.sqrt(s2).div(det)
-        self.cov_xx_half = v1x * v2y * s1 - v1y * v2x * s2
-        self.cov_yy_half = v1x * v2y * s2 - v1y * v2x * s1
-        self.cov_xy_half = v1x * v2x * (s2 - s1)
-        self.cov_yx_half = v1y * v2y * (s1 - s2)
+    # ---- applying ------------------------------------------------------------------------------------------------------------------------
+    def _coef_for(self, x):
+        if self.coef is None:
+            raise RuntimeError("ComplexInstanceNorm: set_normalization() has not been called")
+        if not torch.is_tensor(self.mean) or self.mean.numel() != 1:
+            raise NotImplementedError("ComplexInstanceNorm: normalize / unnormalize after complex_instance_norm (a per-sample complex mean)")
+        return self.coef
+
+    def _channel_first(self, x):
+        """clamp(C^(-1/2) (x - m), -6, 6) laid out [B C, 2, H, W], and the reference shape of the normalised stack."""
+        coef = self._coef_for(x)
+        x5, _, shape = _as_stack(x)
+        B, C, H, W = (int(v) for v in x5.shape[:4])
+        if B != coef.shape[0]:
+            raise RuntimeError(f"ComplexInstanceNorm: measured {coef.shape[0]} batch elements, asked to normalise {B}")
+        out = torch.empty(B * C, 2, H, W, dtype=torch.float32, device=x5.device)
+        _lib.check(_lib.lib().mrx_cnorm_apply(_lib.ptr(x5), _lib.ptr(coef), _lib.ptr(out), B, C, H * W, _lib.stream_ptr()), "mrx_cnorm_apply")
+        return out, shape
+
+    def _from_channel_first(self, y, shape):
+        coef = self._coef_for(y)
+        y = _lib.f32c(y)
+        B, C, H, W = (int(v) for v in shape[:4])
+        out = torch.empty(B, C, H, W, 2, dtype=torch.float32, device=y.device)
+        _lib.check(_lib.lib().mrx_cnorm_unapply(_lib.ptr(y), _lib.ptr(coef), _lib.ptr(out), B, C, H * W, _lib.stream_ptr()), "mrx_cnorm_unapply")
+        return out
+
+    def normalize(self, x):
+        """sensitivity_net.py:95-108 ([...,2] in, [...,2] out)."""
+        y, shape = self._channel_first(x)
+        B, C, H, W = shape[:4]
+        return y.view(B, C, 2, H, W).permute(0, 1, 3, 4, 2).contiguous()
+
+    def unnormalize(self, x):
+        """sensitivity_net.py:110-117 ([B,C,H,W,2] in and out)."""
+        x = _lib.f32c(x)
+        if x.dim() != 5:
+            raise NotImplementedError("ComplexInstanceNorm.unnormalize: [B,C,H,W,2] input")
+        B, C, H, W = (int(v) for v in x.shape[:4])
+        return self._from_channel_first(x.permute(0, 1, 4, 2, 3).reshape(B * C, 2, H, W), x.shape)
 
     def forward(self, input):
         return self.normalize(input)
 
-    def set_normalization(self, input):
-        mean = torch.mean(input).reshape(1)          # stays on the device (the reference round-trips it through .item())
-        self.complex_pseudocovariance(input - mean)
-        self.mean = mean.unsqueeze(1).unsqueeze(1).unsqueeze(1)
-        self.cov_xx_half = self.cov_xx_half.view(-1, 1, 1, 1)
-        self.cov_xy_half = self.cov_xy_half.view(-1, 1, 1, 1)
-        self.cov_yx_half = self.cov_yx_half.view(-1, 1, 1, 1)
-        self.cov_yy_half = self.cov_yy_half.view(-1, 1, 1, 1)
-
-    def normalize(self, x):
-        x_m = x - self.mean
-        re, im = torch.unbind(x_m, dim=-1)
-        ixx, ixy, iyx, iyy = matrix_invert(self.cov_xx_half, self.cov_xy_half, self.cov_yx_half, self.cov_yy_half)
-        img = torch.stack([ixx * re + ixy * im, iyx * re + iyy * im], dim=-1)
-        return img.clamp(-6, 6)
-
-    def unnormalize(self, x):
-        re, im = torch.unbind(x, dim=-1)
-        return torch.stack([self.cov_xx_half * re + self.cov_xy_half * im, self.cov_yx_half * re + self.cov_yy_half * im], dim=-1) + self.mean
-
 
 class ComplexNormWrapper(torch.nn.Module):
-    """sensitivity_net.py:121-139."""
+    """sensitivity_net.py:121-139: measure, normalise, run `model` on [B C, 2, H, W], un-normalise -- the two layout changes ride inside the
+    normalisation passes."""
 
     def __init__(self, model):
         super().__init__()
@@ -91,79 +146,81 @@ class ComplexNormWrapper(torch.nn.Module):
         self.complex_instance_norm = ComplexInstanceNorm()
 
     def forward(self, input):
-        self.complex_instance_norm.set_normalization(input)
-        output = self.complex_instance_norm.normalize(input)
-        shp = output.shape
-        output = output.reshape(shp[0] * shp[1], *shp[2:]).permute(0, 3, 1, 2)
-        output = self.model(output)
-        output = output.permute(0, 2, 3, 1).reshape(*shp)
-        return self.complex_instance_norm.unnormalize(output)
+        norm = self.complex_instance_norm
+        norm.set_normalization(input)
+        channel_first, shape = norm._channel_first(input)
+        return norm._from_channel_first(self.model(channel_first), shape)
 
 
 class SensitivityNetwork(torch.nn.Module):
-    """sensitivity_net.py:142-310: x <- gradD(x - gradR(x), y, smaps, mask), num_iter times."""
+    """sensitivity_net.py:142-310: `num_iter` rounds of x <- gradD(x - gradR(x), y, smaps, mask).  With `shared_params` one regulariser /
+    data layer pair serves every round.  The stage-wise training helpers keep the reference's book-keeping (`is_trainable`); like the
+    reference they mark parameters through an attribute named `require_grad_`, which autograd does not read."""
 
     def __init__(self, num_iter, model, datalayer, shared_params=True, save_space=False, reset_cache=False):
         super().__init__()
         self.shared_params = shared_params
-        self.num_iter = 1 if self.shared_params else num_iter
         self.num_iter_total = num_iter
+        self.num_iter = 1 if shared_params else num_iter
         self.is_trainable = [True] * num_iter
-        self.gradR = torch.nn.ModuleList([ComplexNormWrapper(model) for _ in range(self.num_iter)])
-        self.gradD = torch.nn.ModuleList([datalayer for _ in range(self.num_iter)])
+        self.gradR = torch.nn.ModuleList(ComplexNormWrapper(model) for _ in range(self.num_iter))
+        self.gradD = torch.nn.ModuleList(datalayer for _ in range(self.num_iter))
         self.save_space = save_space
         self.reset_cache = reset_cache
 
-    def _iterations(self):
+    def _rounds(self):
+        """How many rounds run: all of them with shared parameters, otherwise up to the last stage that is being trained."""
         if self.shared_params:
             return self.num_iter_total
-        return min(np.where(self.is_trainable)[0][-1] + 1, self.num_iter)
+        last_trained = max(i for i, flag in enumerate(self.is_trainable) if flag)
+        return min(last_trained + 1, self.num_iter)
 
     def forward(self, x, y, smaps, mask):
-        for i in range(self._iterations()):                # forward and forward_save_space compute the same values
-            x_thalf = x - self.gradR[i % self.num_iter](x)
-            x = self.gradD[i % self.num_iter](x_thalf, y, smaps, mask)
+        for i in range(self._rounds()):
+            stage = i % self.num_iter
+            x = self.gradD[stage](x - self.gradR[stage](x), y, smaps, mask)
         return x
 
-    forward_save_space = forward
+    forward_save_space = forward                       # the reference's memory-saving variant computes the same values
+
+    # ---- stage-wise training book-keeping (sensitivity_net.py:214-310) --------------------------------------------------------------------
+    def _mark(self, i, flag):
+        for p in self.gradR[i].parameters():
+            p.require_grad_ = flag
+        self.is_trainable[i] = flag
 
     def freeze(self, i):
-        for param in self.gradR[i].parameters():
-            param.require_grad_ = False
-        self.is_trainable[i] = False
+        self._mark(i, False)
 
     def unfreeze(self, i):
-        for param in self.gradR[i].parameters():
-            param.require_grad_ = True
-        self.is_trainable[i] = True
+        self._mark(i, True)
 
     def freeze_all(self):
         for i in range(self.num_iter):
-            self.freeze(i)
+            self._mark(i, False)
 
     def unfreeze_all(self):
         for i in range(self.num_iter):
-            self.unfreeze(i)
+            self._mark(i, True)
 
     def copy_params(self, src_i, trg_j):
-        for trg_param, src_param in zip(self.gradR[trg_j].parameters(), self.gradR[src_i].parameters()):
-            trg_param.data.copy_(src_param.data)
+        with torch.no_grad():
+            for dst, src in zip(self.gradR[trg_j].parameters(), self.gradR[src_i].parameters()):
+                dst.copy_(src)
 
     def stage_training_init(self):
         self.freeze_all()
         self.unfreeze(0)
 
     def stage_training_transition_i(self, copy=False):
-        if self.shared_params:
+        """Move the trainable stage one step on (optionally seeding it with its predecessor's weights); after the last stage, train all."""
+        if self.shared_params or all(self.is_trainable):
             return
-        if not np.all(self.is_trainable):
-            for i in range(self.num_iter):
-                if i == self.num_iter - 1:
-                    self.unfreeze_all()
-                    break
-                if self.is_trainable[i]:
-                    self.freeze(i)
-                    self.unfreeze(i + 1)
-                    if copy:
-                        self.copy_params(i, i + 1)
-                    break
+        current = next((i for i in range(self.num_iter) if self.is_trainable[i]), self.num_iter - 1)
+        if current == self.num_iter - 1:
+            self.unfreeze_all()
+            return
+        self.freeze(current)
+        self.unfreeze(current + 1)
+        if copy:
+            self.copy_params(current, current + 1)

@@ -283,7 +283,8 @@ __device__ __forceinline__ int s2_pixel_exp(float m) {
 #define S2_LDS (S2_OFF_X + 2 * 3 * S2_NPIX_MAX * 16)
 
 // ABL (probe builds only, -DMRX_L2_ABLATE + env MRX_L2_ABL): phases switched off to price them -- 1 no x loads, 2 no operand split, 4 no LDS
-// staging writes, 8 no convolution MFMAs, 16 no tail, 32 no LDS operand reads, 64 no barriers.  Results are garbage; only the time is read.
+// staging writes, 8 no convolution MFMAs, 16 no tail, 32 no LDS operand reads, 64 no barriers, 128 no h_prev loads, 256 no stores, 512 no tap
+// stage.  Results are garbage; only the time is read.
 template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0>
 __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     constexpr int S2_PAD = DIL, S2_PH = S2_TH + 2 * DIL, S2_PW = S2_TW + 2 * DIL, S2_NPIX = S2_PH * S2_PW;
@@ -441,7 +442,10 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             const int cy = oy < a.H ? oy : a.H - 1, cx = ox < a.W ? ox : a.W - 1;
             const float* hb = (a.hprev ? a.hprev : a.hnew) + (long long)b * S2_F * plane + (long long)cy * a.W + cx + 4ll * lhi * plane;
 #pragma unroll
-            for (int R = 0; R < 32; ++R) hp[rw][R] = hb[(long long)s2_chan(R, 0) * plane];
+            for (int R = 0; R < 32; ++R) {
+                if constexpr ((ABL & 128) != 0) asm volatile("v_mov_b32 %0, 1.0" : "=v"(hp[rw][R]));
+                else hp[rw][R] = hb[(long long)s2_chan(R, 0) * plane];
+            }
         };
         auto toff = [](int tp) { return tp < 9 ? (tp / 3) * DIL * S2_PW + (tp % 3) * DIL : 0; };  // the zero-weight slot reads pixel 0
         for (int q = 0; q < S2_NCH; ++q) {
@@ -604,17 +608,30 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             }
             const bool inside = oy < a.H && ox < a.W;
             {
+                // (the arithmetic first, then ONE predicated block of stores: a branch around every store splits the epilogue into 32 basic
+                // blocks, each waiting on its own LDS table read -- 10 k of the 23 k tail cycles per tile)
                 float* ob = a.hnew + (long long)b * S2_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
-                const bool first = a.hprev == nullptr;
+                const float hmul = a.hprev == nullptr ? 0.f : 1.f;
 #pragma unroll
                 for (int R = 0; R < 32; ++R) {
-                    float v = acc2[R >> 4][R & 15] + tabl[2 * R + lhi] * (first ? 0.f : hp[rw][R]);
-                    v = v > 0.f ? v : 0.f;
-                    if (inside) ob[(long long)s2_chan(R, 0) * plane] = v;
-                    hp[rw][R] = v;
+                    float v = acc2[R >> 4][R & 15] + tabl[2 * R + lhi] * (hmul * hp[rw][R]);
+                    hp[rw][R] = v > 0.f ? v : 0.f;
+                }
+                if constexpr ((ABL & 256) != 0) {
+#pragma unroll
+                    for (int R = 0; R < 32; ++R) asm volatile("" ::"v"(hp[rw][R]));
+                } else if constexpr ((ABL & 1024) != 0) {      // the form before lib 224: a branch around every store
+#pragma unroll
+                    for (int R = 0; R < 32; ++R) {
+                        asm volatile("" : "+v"(hp[rw][R]));
+                        if (inside) ob[(long long)s2_chan(R, 0) * plane] = hp[rw][R];
+                    }
+                } else if (inside) {
+#pragma unroll
+                    for (int R = 0; R < 32; ++R) ob[(long long)s2_chan(R, 0) * plane] = hp[rw][R];
                 }
             }
-            if (a.P) {
+            if (a.P && !(ABL & 512)) {
                 // the final 64 -> 2 convolution's channel contraction on the new state while it is in registers: D[tap * 2 + co][pixel]
                 // (18 of the 32 rows), the k order of the B operand is the register order of h_new as in the 1x1 stage above
                 f32x16 accp;
@@ -661,12 +678,16 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                     accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, accp, 0, 0, 0);
                     accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, accp, 0, 0, 0);
                 }
-                if (inside) {
+                if constexpr ((ABL & 256) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 10; ++r) asm volatile("" ::"v"(accp[r]));
+                } else if (inside) {
                     float* pb = a.P + (long long)b * 18 * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
 #pragma unroll
-                    for (int r = 0; r < 10; ++r) {
-                        const int m0 = (r & 3) + 8 * (r >> 2);           // row of the lower half-wave; the upper one holds m0 + 4
-                        if (m0 + 4 < 18 || !lhi) pb[(long long)m0 * plane] = accp[r];
+                    for (int r = 0; r < 8; ++r) pb[(long long)((r & 3) + 8 * (r >> 2)) * plane] = accp[r];   // rows m0 (lower half-wave) / m0 + 4 (upper)
+                    if (!lhi) {                                                                              // rows 16, 17: the upper half-wave's 20, 21 do not exist
+                        pb[16ll * plane] = accp[8];
+                        pb[17ll * plane] = accp[9];
                     }
                 }
             }
@@ -768,6 +789,7 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
 #define L2_ABL_CASE(N) case N: return l2sb_launch_t<2, true, false, true, N>(a, (hipStream_t)stream);
             L2_ABL_CASE(1) L2_ABL_CASE(2) L2_ABL_CASE(3) L2_ABL_CASE(4) L2_ABL_CASE(7) L2_ABL_CASE(8) L2_ABL_CASE(16) L2_ABL_CASE(23)
             L2_ABL_CASE(32) L2_ABL_CASE(40) L2_ABL_CASE(64) L2_ABL_CASE(71) L2_ABL_CASE(87)
+            L2_ABL_CASE(128) L2_ABL_CASE(256) L2_ABL_CASE(384) L2_ABL_CASE(512) L2_ABL_CASE(896) L2_ABL_CASE(903) L2_ABL_CASE(1024)
 #undef L2_ABL_CASE
             default: break;
         }
