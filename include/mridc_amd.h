@@ -319,6 +319,12 @@ int mrx_rim_layer2_f16(const float* x, const float* packed, const float* b_conv,
 int mrx_rim_layer2_sb_taps(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
                            const float* h_prev, float* h_new, float* taps, int B, int H, int W, void* stream);
 int mrx_rim_final_gather(const float* taps, const float* b_final, const float* eta, float* eta_out, int B, int H, int W, void* stream);
+/* HOST routine (no GPU): variable-density Poisson-disc sampling for Poisson2DMaskFunc (reconstruction/data/subsample.py:549-633: Bridson's dart
+ * throwing with a per-pixel elliptical exclusion radius; a calibration rectangle of calib_y x calib_x pixels around the centre is set first).
+ * mask: ny x nx bytes (0 / 1, overwritten); radius_x / radius_y: ny x nx floats >= 1.  The reference runs the loop on Numba's private generator;
+ * this one draws from its own xoshiro256** stream seeded with `seed`: reproducible.  Returns the number of samples (or a negative MRX_E* code). */
+int64_t mrx_poisson_disc_mask(int nx, int ny, int max_attempts, const float* radius_x, const float* radius_y, double calib_x, double calib_y,
+                              uint64_t seed, unsigned char* mask);
 /* Complex instance normalisation around a regulariser (models/sigmanet/sensitivity_net.py:16-139): m = mean of every real and imaginary entry,
  * C = 2x2 covariance of (re - m, im - m) per batch element (sums over per_b complex values, divided by `divisor` -- the reference's
  * shape[2] * shape[3] - 1); coef[b] = {m, C^(1/2) row-major, C^(-1/2) row-major} (9 floats).  center = 0 takes the data as mean-free.

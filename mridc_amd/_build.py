@@ -13,6 +13,7 @@ LIB = os.path.join(LIBDIR, "libmridc_amd.so")
 # operators round exactly like the reference's separate torch ops (mul, mul, sub).
 SOURCES = [
     ("api.cpp", []),
+    ("host_masks.cpp", []),
     ("fft.hip", []),
     ("llg372.hip", ["-fno-slp-vectorize"]),   # complex values are explicit packed pairs (pfa372.h); no extra pairing of scalar code
     ("elementwise.hip", ["-ffp-contract=off"]),

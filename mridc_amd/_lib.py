@@ -25,6 +25,7 @@ _SIGNATURES = {
     "mrx_version": ([], _i),
     "mrx_last_error": ([], ctypes.c_char_p),
     "mrx_stream_capture_id": ([_p], _i64),
+    "mrx_poisson_disc_mask": ([_i, _i, _i, _p, _p, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, _p], _i64),
     "mrx_fft_prepare": ([_i, _i], _i),
     "mrx_fft_max_len": ([], _i),
     "mrx_fft2": ([_p, _p, _i64, _i, _i, _i, _i, _i, _p], _i),

@@ -9,7 +9,9 @@ NumPy's legacy `RandomState` in exactly the order the reference does, so the sam
 * `Gaussian1DMaskFunc`, `Gaussian2DMaskFunc` — the reference samples these with the *global* `np.random.choice`
   (subsample.py:353,438); the `seed` argument is ignored there too.  Same here: identical masks for identical global state.
 * `Poisson2DMaskFunc` — the reference runs its dart throwing under `numba.jit(nopython=True)` (subsample.py:549-633), i.e. on
-  Numba's private generator, which is not reproducible from Python; not provided (raises `NotImplementedError`).
+  Numba's private generator, which is not reproducible from any seed even there.  Here the same dart-throwing loop is a host routine of
+  libmridc_amd on an explicit generator seeded through the object's `RandomState`: reproducible, equal to the reference's masks in law
+  (acceleration, calibration block, centre disc, exclusion distances are tested), not bit for bit.
 """
 import contextlib
 from typing import Optional, Sequence, Tuple, Union
@@ -191,12 +193,68 @@ class Gaussian2DMaskFunc(MaskFunc):
 
 
 class Poisson2DMaskFunc(MaskFunc):
-    """Variable-density Poisson-disc masks (subsample.py:465-633).  The reference draws them inside a Numba-compiled routine on
-    Numba's own generator, so its masks cannot be reproduced bit for bit from NumPy; this build does not ship a look-alike."""
+    """Variable-density Poisson-disc masks (subsample.py:465-633; the algorithm is sigpy.mri.samp.poisson's).
 
-    def __call__(self, shape, seed: Seed = None, half_scan_percentage=0.0, scale=0.02, **kwargs):
-        raise NotImplementedError("Poisson2DMaskFunc: the reference samples with Numba's private RNG (subsample.py:549-633); "
-                                  "generate the mask with the reference and pass it as `mask` instead")
+    Samples keep an elliptical exclusion zone whose radius grows linearly with the normalised distance r from the (calibration region of
+    the) k-space centre: radius = (1 + slope r) n_axis / max(n); the slope is found by bisection so that the achieved acceleration
+    (grid size / number of samples) is within `tol` of the requested one.  The corners r >= 1 are dropped (`crop_corner`), a centred disc of
+    radius `scale` x rows is fully sampled, `half_scan_percentage` zeroes the leading rows.  Returns (mask [1, ny, nx, 1] float32, acceleration).
+
+    The reference throws its darts inside a Numba-compiled loop on Numba's own generator: its masks are not reproducible from `seed` even
+    there.  Here the dart throwing is libmridc_amd's host routine `mrx_poisson_disc_mask` (the same loop on an explicit xoshiro256** stream),
+    seeded from this object's `RandomState` under `temp_seed(seed)` like the other generators: the same seed gives the same mask.  Masks are
+    therefore equal to the reference's in law (tests: acceleration, calibration box, centre disc, exclusion distances), not bit for bit."""
+
+    def __call__(self, shape, seed: Seed = None, half_scan_percentage=0.0, scale=0.02, calib=(0.0, 0.0), crop_corner=True,
+                 max_attempts=30, tol=0.3):
+        from mridc_amd import _lib
+        self.shape = tuple(int(v) for v in shape[-3:-1])
+        self.scale = scale
+        ny, nx = self.shape
+        with temp_seed(self.rng, seed):
+            _, self.acceleration = self.choose_acceleration()
+            # normalised distance from the edge of the calibration block, per axis in [0, 1]
+            rows, cols = np.mgrid[:ny, :nx]
+            dx = np.maximum(np.abs(cols - nx / 2) - calib[-1] / 2, 0)
+            dy = np.maximum(np.abs(rows - ny / 2) - calib[-2] / 2, 0)
+            r = np.hypot(dx / dx.max(), dy / dy.max())
+            longest = max(nx, ny)
+            lo, hi = 0.0, float(longest)
+            mask = achieved = None
+            while lo < hi:
+                slope = (lo + hi) / 2
+                spread = 1 + r * slope
+                rx = np.ascontiguousarray(np.clip(spread * nx / longest, 1, None), dtype=np.float32)
+                ry = np.ascontiguousarray(np.clip(spread * ny / longest, 1, None), dtype=np.float32)
+                stream = int(self.rng.randint(0, 2 ** 31 - 1)) * (2 ** 31) + int(self.rng.randint(0, 2 ** 31 - 1))
+                cells = np.zeros((ny, nx), dtype=np.uint8)
+                count = _lib.lib().mrx_poisson_disc_mask(nx, ny, int(max_attempts), rx.ctypes.data, ry.ctypes.data, float(calib[-1]),
+                                                              float(calib[-2]), stream, cells.ctypes.data)
+                if count < 0:
+                    raise RuntimeError("mrx_poisson_disc_mask failed")
+                mask = cells.astype(bool)
+                if crop_corner:
+                    mask &= r < 1
+                kept = int(mask.sum())
+                achieved = mask.size / kept if kept else np.inf
+                if abs(achieved - self.acceleration) < tol:
+                    break
+                if achieved < self.acceleration:          # too dense: larger exclusion zones
+                    lo = slope
+                else:
+                    hi = slope
+        if abs(achieved - self.acceleration) >= tol:
+            raise ValueError(f"Cannot generate mask to satisfy acceleration factor of {self.acceleration}.")
+        mask = mask | self.centered_circle()
+        if half_scan_percentage != 0:
+            mask[: int(np.round(mask.shape[0] * half_scan_percentage)), :] = False
+        return torch.from_numpy(mask.astype(np.float32)).unsqueeze(0).unsqueeze(-1), self.acceleration
+
+    def centered_circle(self):
+        """The fully sampled disc around the centre: radius int(rows x scale) pixels (subsample.py:539-546)."""
+        n0, n1 = self.shape
+        ii, jj = np.indices(self.shape)
+        return (ii - int((n0 - 1) / 2)) ** 2 + (jj - int((n1 - 1) / 2)) ** 2 < int(n0 * self.scale) ** 2
 
 
 def create_mask_for_mask_type(mask_type_str: str, center_fractions: Sequence[float], accelerations: Sequence[int]) -> MaskFunc:

@@ -13,7 +13,7 @@ void mrx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int mrx_version(void) { return 223; /* 0.2.0: bumped with every kernel change (profiles/rNN_traffic.json is keyed on it) */ }
+extern "C" int mrx_version(void) { return 224; /* 0.2.0: bumped with every kernel change (profiles/rNN_traffic.json is keyed on it) */ }
 extern "C" const char* mrx_last_error(void) { return g_err; }
 
 // 0 when `stream` is not being captured into a hipGraph, otherwise the (non-zero) id of the capture: callers that cache prepared operands

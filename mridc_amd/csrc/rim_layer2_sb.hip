@@ -440,7 +440,12 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         auto load_hp = [&](int rw) {              // lanes outside the image read a valid element (clamped) and store nothing
             const int oy = h0 + 2 * wave + rw, ox = w0 + l31;
             const int cy = oy < a.H ? oy : a.H - 1, cx = ox < a.W ? ox : a.W - 1;
-            const float* hb = (a.hprev ? a.hprev : a.hnew) + (long long)b * S2_F * plane + (long long)cy * a.W + cx + 4ll * lhi * plane;
+            if (!a.hprev) {                       // the zero state: nothing to load (and nothing uninitialised to multiply by zero)
+#pragma unroll
+                for (int R = 0; R < 32; ++R) hp[rw][R] = 0.f;
+                return;
+            }
+            const float* hb = a.hprev + (long long)b * S2_F * plane + (long long)cy * a.W + cx + 4ll * lhi * plane;
 #pragma unroll
             for (int R = 0; R < 32; ++R) {
                 if constexpr ((ABL & 128) != 0) asm volatile("v_mov_b32 %0, 1.0" : "=v"(hp[rw][R]));
@@ -611,10 +616,9 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                 // (the arithmetic first, then ONE predicated block of stores: a branch around every store splits the epilogue into 32 basic
                 // blocks, each waiting on its own LDS table read -- 10 k of the 23 k tail cycles per tile)
                 float* ob = a.hnew + (long long)b * S2_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
-                const float hmul = a.hprev == nullptr ? 0.f : 1.f;
 #pragma unroll
                 for (int R = 0; R < 32; ++R) {
-                    float v = acc2[R >> 4][R & 15] + tabl[2 * R + lhi] * (hmul * hp[rw][R]);
+                    float v = acc2[R >> 4][R & 15] + tabl[2 * R + lhi] * hp[rw][R];
                     hp[rw][R] = v > 0.f ? v : 0.f;
                 }
                 if constexpr ((ABL & 256) != 0) {

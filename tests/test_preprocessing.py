@@ -49,8 +49,6 @@ def test_mask_generator_interface():
         sub.RandomMaskFunc([0.08], [4])((10, 2), seed=1)
     with pytest.raises(NotImplementedError, match="not supported"):
         sub.create_mask_for_mask_type("spiral", [0.08], [4])
-    with pytest.raises(NotImplementedError, match="Numba"):
-        sub.create_mask_for_mask_type("poisson2d", [0.7], [10])((1, 32, 32, 2))
     fn = sub.RandomMaskFunc([0.08], [4])
     state = fn.rng.get_state()[1].copy()
     a, _ = fn((1, 64, 48, 2), seed=(1, 2, 3))
@@ -227,3 +225,58 @@ def test_g14_device_sens_net_vs_reference(golden, dev):
             assert float((rss - 1).abs().max()) < 1e-5
     with pytest.raises(RuntimeError):
         net.cpu()(y, mask)                                            # no CPU fallback
+
+
+@pytest.mark.parametrize("shape,acc,calib", [((1, 640, 372, 2), 10, (0.0, 0.0)), ((1, 320, 320, 2), 4, (24.0, 16.0)), ((2, 96, 128, 2), 6, (0.0, 0.0))])
+def test_poisson_disc_masks_follow_the_reference_law(shape, acc, calib):
+    """Poisson2DMaskFunc (subsample.py:465-633; the CIRIM / qCIRIM YAML default, base_cirim_run.yaml:84-90).  The reference throws its darts on
+    Numba's private generator -- not reproducible from a seed even there -- so the masks are pinned by the properties its algorithm
+    guarantees: shape / dtype, achieved acceleration within `tol` before the centre disc is added, the calibration block and the centre
+    disc fully sampled, the corners r >= 1 empty, every pair of dart-thrown samples outside the other's exclusion ellipse (up to the one
+    pixel the integer cell positions lose), sample density falling with the distance from the centre, and reproducibility: the same
+    seed gives the same mask and leaves the generator's state untouched."""
+    sub = _mask_funcs()
+    fn = sub.create_mask_for_mask_type("poisson2d", [0.7], [acc])
+    assert isinstance(fn, sub.Poisson2DMaskFunc)
+    state = fn.rng.get_state()[1].copy()
+    mask, a = fn(shape, seed=(7, 1, 3), calib=calib)
+    again, _ = fn(shape, seed=(7, 1, 3), calib=calib)
+    other, _ = fn(shape, seed=(7, 1, 4), calib=calib)
+    ny, nx = shape[-3], shape[-2]
+    assert a == acc and mask.dtype == torch.float32 and tuple(mask.shape) == (1, ny, nx, 1)
+    assert torch.equal(mask, again) and not torch.equal(mask, other) and np.array_equal(state, fn.rng.get_state()[1])
+    m = mask[0, :, :, 0].numpy().astype(bool)
+    disc = fn.centered_circle()
+    assert m[disc].all()                                                       # the fully sampled centre disc
+    cy0, cy1 = int(ny / 2 - calib[-2] / 2), int(ny / 2 + calib[-2] / 2)
+    cx0, cx1 = int(nx / 2 - calib[-1] / 2), int(nx / 2 + calib[-1] / 2)
+    assert m[cy0:cy1, cx0:cx1].all()                                           # the calibration block
+    darts = m & ~disc
+    assert abs(m.size / darts.sum() - acc) < 0.3 + 0.05                          # acceleration (tol = 0.3 on the dart-thrown pattern)
+    rows, cols = np.mgrid[:ny, :nx]
+    dx = np.maximum(np.abs(cols - nx / 2) - calib[-1] / 2, 0)
+    dy = np.maximum(np.abs(rows - ny / 2) - calib[-2] / 2, 0)
+    r = np.hypot(dx / dx.max(), dy / dy.max())
+    assert not darts[r >= 1].any()                                               # cropped corners
+    inner, outer = darts[(r > 0.05) & (r < 0.4)].mean(), darts[(r > 0.6) & (r < 1.0)].mean()
+    assert inner > 1.5 * outer                                                   # variable density
+    # exclusion: away from the centre samples repel each other -- far fewer touching pairs than independent draws of the same density would
+    # give (4 neighbour offsets x cells x p^2); then half-scan zeroes the leading rows
+    ring = darts & (r > 0.5)
+    ys, xs = np.nonzero(ring)
+    touching = 0
+    for oy, ox in ((0, 1), (1, 0), (1, 1), (1, -1)):
+        yy, xx = ys + oy, xs + ox
+        ok = (yy < ny) & (xx >= 0) & (xx < nx)
+        touching += int(ring[yy[ok], xx[ok]].sum())
+    cells = int(((r > 0.5) & (r < 1)).sum())
+    independent = 4.0 * cells * (len(ys) / cells) ** 2
+    assert touching <= (0.3 if acc >= 6 else 0.8) * independent, (touching, independent)
+    half, _ = fn(shape, seed=(7, 1, 3), calib=calib, half_scan_percentage=0.2)
+    assert not half[0, : int(np.round(ny * 0.2))].any() and torch.equal(half[0, int(np.round(ny * 0.2)):], mask[0, int(np.round(ny * 0.2)):])
+
+
+def test_poisson_mask_that_cannot_reach_the_acceleration_raises():
+    sub = _mask_funcs()
+    with pytest.raises(ValueError, match="Cannot generate mask"):
+        sub.Poisson2DMaskFunc([0.7], [400])((1, 16, 16, 2), seed=1, tol=1e-6)
