@@ -266,53 +266,22 @@ def parity_vs_oracle(gpu_pred, ref_pred, target, at):
     return dict(rel_l2=rel, ssim=m["SSIM"], ssim_oracle_check=ssim_chk, nmse=m["NMSE"], at=at, metrics_vs_target=vs_target)
 
 
-def bench_qcirim(args, world, rank, dev):
-    """configs[4]: qCIRIM (quantitative R2*/S0/B0/phi mapping), 4 echoes, 32 coils, 256x256, IndRNN 128 filters, 1 cascade x 8 time-steps
-    (projects/quantitative/model_zoo/conf/base_qcirim_run.yaml defaults).  Random maps and data: throughput only."""
-    from mridc_amd.collections.quantitative.models.qcirim import qCIRIM
-    cfg = {"quantitative_module_recurrent_layer": "IndRNN", "quantitative_module_conv_filters": [128, 128, 4],
-           "quantitative_module_conv_kernels": [5, 3, 3], "quantitative_module_conv_dilations": [1, 2, 1],
-           "quantitative_module_conv_bias": [True, True, False], "quantitative_module_recurrent_filters": [128, 128, 0],
-           "quantitative_module_recurrent_kernels": [1, 1, 0], "quantitative_module_recurrent_dilations": [1, 1, 0],
-           "quantitative_module_recurrent_bias": [True, True, False], "quantitative_module_depth": 2,
-           "quantitative_module_time_steps": 8, "quantitative_module_num_cascades": 1, "quantitative_module_no_dc": True,
-           "quantitative_module_signal_forward_model_sequence": "MEGRE", "quantitative_module_dimensionality": 2,
-           "quantitative_module_gamma_regularization_factors": [150.0, 150.0, 1000.0, 150.0], "use_reconstruction_module": False,
-           "fft_centered": False, "fft_normalization": "backward", "spatial_dims": [-2, -1], "coil_dim": 2,
-           "coil_combination_method": "SENSE"}
-    torch.manual_seed(0)
-    model = qCIRIM(cfg).eval().to(dev)
-    E, C, H, W = 4, 32, 256, 256
-    TEs = [3.0, 11.5, 20.0, 28.5]
-    NS = max(1, args.streams)
-    datas = []
-    for i in range(NS):
-        g = torch.Generator().manual_seed(100 + rank * NS + i)
-        maps = [torch.rand(1, H, W, generator=g) * s for s in (0.3, 1.0, 0.1, 0.5)]
-        S = torch.randn(1, C, H, W, 2, generator=g) / C ** 0.5
-        mask = (torch.rand(1, 1, 1, 1, W, 1, generator=g) < 0.3)
-        y = torch.randn(1, E, C, H, W, 2, generator=g) * mask
-        datas.append([t.to(dev) for t in maps] + [y.to(dev), S.to(dev), mask.to(dev)])
-
-    def step(d):
-        with torch.no_grad():
-            return next(model(d[0], d[1], d[2], d[3], TEs, d[4], d[5], None, d[6]))
-
-    for _ in range(max(args.warmup, 1)):
-        step(datas[0])
-    torch.cuda.synchronize()
+def _replay_loop(step, datas, args):
+    """Shared timed region of the inference benchmarks: one HIP stream + one captured hipGraph per in-flight slice batch, args.steps
+    replays each, barrier + synchronize on both sides, max over ranks.  Returns (elapsed, per_rank, graphed, last outputs)."""
+    NS = len(datas)
     streams = [torch.cuda.Stream() for _ in range(NS)]
-    graphs = []
+    graphs, outs = [], [None] * NS
     if args.graph:
         try:
-            for d, st in zip(datas, streams):
+            for i, (d, st) in enumerate(zip(datas, streams)):
                 st.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st):
                     step(d)
                 torch.cuda.current_stream().wait_stream(st)
                 g_ = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
-                    step(d)
+                    outs[i] = step(d)
                 graphs.append(g_)
             torch.cuda.synchronize()
         except Exception as ex:  # noqa: BLE001
@@ -327,20 +296,127 @@ def bench_qcirim(args, world, rank, dev):
                 if graphs:
                     graphs[i].replay()
                 else:
-                    step(datas[i])
+                    outs[i] = step(datas[i])
     dist_barrier()
-    elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
-    if rank == 0:
-        emit(dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256", value=world * NS * args.steps / elapsed,
-                              unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
-                              higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
-                              per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank], dtype="f32", data="synthetic",
-                              config=dict(workload=f"qCIRIM 1 cascade x 8 time-steps, IndRNN 128 filters, 4 echoes, 32 coils, 256x256, {NS} slice(s) "
-                                                   f"per GPU and step ({NS} HIP stream(s), {'hipGraph' if graphs else 'eager'}), random-init weights",
-                                          parallelism=f"slice-sharded x{world}")))
+    elapsed, per_rank = rank_times(time.perf_counter() - t0, torch.device("cuda", torch.cuda.current_device()))
+    return elapsed, per_rank, bool(graphs), outs
 
 
-def bench_e2evn(args, world, rank, dev):
+def _event_profile(timer, step, d, n=2):
+    """`n` eager steps with the timer's HIP events on (host enqueues ahead of a parked GPU), then the empty-pair calibration."""
+    timer.enabled = True
+    torch.cuda.synchronize()
+    try:
+        torch.cuda._sleep(int(4e7))
+    except Exception:  # noqa: BLE001
+        pass
+    for _ in range(n):
+        step(d)
+    timer.calibrate()
+    timer.enabled = False
+
+
+def _oracle_threads():
+    box_cores = os.cpu_count() or 1
+    ncores = min(box_cores, 32)          # beyond ~32 threads these op sizes slow down on the GPU box's host (measured)
+    torch.set_num_threads(ncores)
+    return ncores, box_cores
+
+
+QCIRIM_CFG = {"quantitative_module_recurrent_layer": "IndRNN", "quantitative_module_conv_filters": [128, 128, 4],
+              "quantitative_module_conv_kernels": [5, 3, 3], "quantitative_module_conv_dilations": [1, 2, 1],
+              "quantitative_module_conv_bias": [True, True, False], "quantitative_module_recurrent_filters": [128, 128, 0],
+              "quantitative_module_recurrent_kernels": [1, 1, 0], "quantitative_module_recurrent_dilations": [1, 1, 0],
+              "quantitative_module_recurrent_bias": [True, True, False], "quantitative_module_depth": 2,
+              "quantitative_module_time_steps": 8, "quantitative_module_num_cascades": 1, "quantitative_module_no_dc": True,
+              "quantitative_module_signal_forward_model_sequence": "MEGRE", "quantitative_module_dimensionality": 2,
+              "quantitative_module_gamma_regularization_factors": [150.0, 150.0, 1000.0, 150.0], "use_reconstruction_module": False,
+              "fft_centered": False, "fft_normalization": "backward", "spatial_dims": [-2, -1], "coil_dim": 2,
+              "coil_combination_method": "SENSE"}
+
+
+def bench_qcirim(args, world, rank, dev, checks=False):
+    """configs[4]: qCIRIM (quantitative R2*/S0/B0/phi mapping), 4 echoes, 32 coils, 256x256, IndRNN 128 filters, 1 cascade x 8 time-steps
+    (projects/quantitative/model_zoo/conf/base_qcirim_run.yaml defaults; quantitative/models/qcirim.py:144-312).
+    `checks`: HIP-event roofline of the dominant kernel, the oracle timed on the host (cpu_baseline) and parity of the final maps."""
+    from mridc_amd import ops
+    from mridc_amd.collections.quantitative.models.qcirim import qCIRIM
+    cfg = QCIRIM_CFG
+    torch.manual_seed(0)
+    model = qCIRIM(cfg).eval()
+    state_dict = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    E, C, H, W = 4, 32, 256, 256
+    TEs = [3.0, 11.5, 20.0, 28.5]
+    NS = max(1, args.streams)
+    hosts, datas = [], []
+    for i in range(NS):
+        g = torch.Generator().manual_seed(100 + rank * NS + i)
+        maps = [torch.rand(1, H, W, generator=g) * s for s in (0.3, 1.0, 0.1, 0.5)]
+        S = torch.randn(1, C, H, W, 2, generator=g) / C ** 0.5
+        mask = (torch.rand(1, 1, 1, 1, W, 1, generator=g) < 0.3)
+        y = torch.randn(1, E, C, H, W, 2, generator=g) * mask
+        hosts.append(maps + [y, S, mask])
+        datas.append([t.to(dev) for t in hosts[-1]])
+
+    def step(d):
+        with torch.no_grad():
+            return next(model(d[0], d[1], d[2], d[3], TEs, d[4], d[5], None, d[6]))
+
+    timer = KernelTimer()
+    if checks:
+        timer.wrap(ops, "conv3x3_wino", lambda x, w, *a, **k: "wino_%dx%d" % (int(w.shape[1]), int(w.shape[0])))
+    for _ in range(max(args.warmup, 1)):
+        step(datas[0])
+    torch.cuda.synchronize()
+    if checks:
+        _event_profile(timer, step, datas[0])
+    elapsed, per_rank, graphed, outs = _replay_loop(step, datas, args)
+    res = dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256", value=world * NS * args.steps / elapsed,
+               unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
+               higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
+               per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank], dtype="f32", data="synthetic",
+               config=dict(workload=f"qCIRIM 1 cascade x 8 time-steps, IndRNN 128 filters, 4 echoes, 32 coils, 256x256, {NS} slice(s) "
+                                    f"per GPU and step ({NS} HIP stream(s), {'hipGraph' if graphed else 'eager'}), random-init weights",
+                           parallelism=f"slice-sharded x{world}"))
+    if checks and rank == 0:
+        ms, n = timer.mean_ms("wino_128x128")
+        direct = 2.0 * 128 * 128 * 9 * H * W
+        issued = direct * 4.0 / 9.0                     # Winograd F(2x2,3x3): 16 instead of 36 multiplies per 2x2 outputs
+        res["roofline"] = dict(
+            bound="mfma", kernel="k_rim_layer_wino<DIL 2, no tail> via mrx_conv3x3_wino (the qRIM's 3x3 dilation-2 128 -> 128 convolution as Winograd "
+                                 "F(2x2,3x3) on fp32 MFMAs, two 64-cout blocks)",
+            achieved=(issued / (ms * 1e-3) / 1e12) if ms else None, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+            frac=(issued / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms else None,
+            frac_meaning="MFMA FLOPs the kernel issues / fp32-MFMA peak", algorithmic_achieved=(direct / (ms * 1e-3) / 1e12) if ms else None,
+            launches=n, avg_ms=ms, flops_per_launch=direct, mfma_flops_per_launch=issued, traffic=None,
+            algorithmic_bytes=2.0 * 128 * H * W * 4)
+        try:
+            import oracle
+            ncores, box_cores = _oracle_threads()
+            h = hosts[0]
+            with torch.no_grad():
+                oracle.qrim.qcirim_forward(state_dict, cfg, h[0], h[1], h[2], h[3], TEs, h[4], h[5], None, h[6])          # warm-up
+                t0 = time.perf_counter()
+                ref = oracle.qrim.qcirim_forward(state_dict, cfg, h[0], h[1], h[2], h[3], TEs, h[4], h[5], None, h[6])
+                dt = time.perf_counter() - t0
+            res["cpu_baseline"] = dict(value=1.0 / dt, unit="slices/s", cores=ncores, kind="port", box_cores=box_cores, cpu_model=cpu_model_name(),
+                                       sample=f"one whole slice (1 cascade x 8 time-steps) on the oracle after one untimed warm-up slice, "
+                                              f"torch CPU ops on {ncores} threads, {dt:.1f} s")
+            out = outs[0] if graphed else step(datas[0])
+            torch.cuda.synchronize()
+            rels = []
+            for m_ in range(4):                          # the four final maps (R2*, S0, B0, phi): last cascade, last time-step
+                got, want = out[1 + m_][-1][-1].cpu().double(), ref[1 + m_][-1][-1].double()
+                rels.append(float((got - want).norm() / want.norm()))
+            res["parity_vs_oracle"] = dict(rel_l2=max(rels), rel_l2_per_map=dict(zip(("R2star", "S0", "B0", "phi"), rels)),
+                                           at="the four maps after the last time-step, same weights and inputs")
+        except Exception as ex:  # noqa: BLE001
+            res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port", sample=f"failed: {type(ex).__name__}: {ex}")
+    return res
+
+
+def bench_e2evn(args, world, rank, dev, checks=False):
     """configs[1]: E2EVN 6 cascades, NormUnet(14, 2, pad 11), 15 coils 640x372 (reported next to the headline number)."""
     from mridc_amd import synthetic
     from mridc_amd.sharding import shard_range
@@ -370,64 +446,84 @@ def bench_e2evn(args, world, rank, dev):
         model = VSNet(dict(common, num_cascades=10, imspace_model_architecture="CONV", imspace_conv_hidden_channels=64,
                            imspace_conv_n_convs=4, imspace_conv_batchnorm=False))
         label, desc = "VSNet 10-cascade", "VSNet 10 cascades, CONV denoiser (4 convs, 64 channels, shared)"
-    model = model.eval().to(dev)
+    model = model.eval()
+    state_dict = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
     B, C, H, W = args.batch, args.coils, args.height, args.width
     NS = max(1, args.streams)
     s0, s1 = shard_range(world * NS * B, rank, world)
-    datas = []
+    datas, hosts = [], []
     for i in range(NS):
         slices = [synthetic.make_slice(C, H, W, slice_idx=j, mask_dtype=torch.float32 if args.model == "vsnet" else torch.uint8)
                   for j in range(s0 + i * B, s0 + (i + 1) * B)]
-        d = {k: torch.cat([s[k] for s in slices], 0).to(dev) for k in ("y", "sensitivity_maps", "target")}
-        d["mask"] = slices[0]["mask"].to(dev)
-        datas.append(d)
+        h_ = {k: torch.cat([s[k] for s in slices], 0) for k in ("y", "sensitivity_maps", "target")}
+        h_["mask"] = slices[0]["mask"]
+        hosts.append(h_)
+        datas.append({k: v.to(dev) for k, v in h_.items()})
 
     def step(d):
         with torch.no_grad():
             return model(d["y"], d["sensitivity_maps"], d["mask"], None, d["target"])
 
+    checks = checks and args.model == "e2evn"
+    timer = KernelTimer()
+    if checks:
+        from mridc_amd import ops
+        timer.wrap(ops, "unet_conv3x3", lambda a_, b_, w, *r, **k: "uconv %d->%d @%dx%d" % (
+            int(w.shape[1]), int(w.shape[0]), int((a_[0] if isinstance(a_, tuple) else a_).shape[2]), int((a_[0] if isinstance(a_, tuple) else a_).shape[3])))
     for _ in range(max(args.warmup, 1)):
         step(datas[0])
     torch.cuda.synchronize()
-    streams = [torch.cuda.Stream() for _ in range(NS)]
-    graphs = []
-    if args.graph:
+    if checks:
+        _event_profile(timer, step, datas[0])
+    elapsed, per_rank, graphed, outs = _replay_loop(step, datas, args)
+    Bt = NS * B
+    res = dict(metric=f"slices/sec (inference), {label} {C}-coil {H}x{W}", value=world * Bt * args.steps / elapsed,
+               unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
+               per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
+               dtype="f32", data="synthetic",
+               config=dict(workload=f"{desc}, {C} coils, {H}x{W}, batch "
+                                    f"{Bt} per GPU ({NS} concurrent HIP stream(s), {'one hipGraph each' if graphed else 'eager'}), random-init weights "
+                                    "(seed 0)", parallelism=f"slice-sharded x{world}"))
+    if checks and rank == 0:
+        # dominant kernel: the U-Net's 3x3 convolutions (k_uconv: fp32 MFMA 16x16x4 blocks, InstanceNorm statistics from the accumulators,
+        # normalisation + LeakyReLU of the PREVIOUS layer applied by the tile loader) -- the shape that takes the most time
+        tot = {k: sum(s_.elapsed_time(e_) for s_, e_ in v) for k, v in timer.events.items()}
+        if tot:
+            key = max(tot, key=tot.get)
+            ms, n = timer.mean_ms(key)
+            cin, rest = key.split(" ")[1].split("->")[0], key.split("->")[1]
+            cout, hw = rest.split(" @")
+            hh_, ww_ = (int(v) for v in hw.split("x"))
+            flops = 2.0 * int(cin) * int(cout) * 9 * hh_ * ww_ * B
+            all_ms = sum(tot.values()) / max(1, len(next(iter(timer.events.values())))) if timer.events else None
+            res["roofline"] = dict(bound="mfma", kernel=f"k_uconv via mrx_unet_conv3x3 ({key}: 3x3 zero-padded convolution, batch {B}, fp32 MFMA 16x16x4, fused "
+                                                          "InstanceNorm statistics; the previous layer's normalisation + LeakyReLU in the tile loader)",
+                                   achieved=(flops / (ms * 1e-3) / 1e12) if ms else None, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                                   frac=(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms else None,
+                                   frac_meaning="direct-form MFMA FLOPs of the launch / fp32-MFMA peak", launches=n, avg_ms=ms, flops_per_launch=flops,
+                                   traffic=None, algorithmic_bytes=(int(cin) + int(cout)) * hh_ * ww_ * B * 4.0,
+                                   hbm_frac=((int(cin) + int(cout)) * hh_ * ww_ * B * 4.0 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms else None,
+                                   all_unet_conv_launches_ms_per_step=all_ms)
         try:
-            for d, st in zip(datas, streams):
-                st.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(st):
-                    step(d)
-                torch.cuda.current_stream().wait_stream(st)
-                g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_, stream=st, capture_error_mode="thread_local"):
-                    step(d)
-                graphs.append(g_)
+            import oracle
+            ncores, box_cores = _oracle_threads()
+            h1 = {k: (v[:1] if k != "mask" else v) for k, v in hosts[0].items()}
+            with torch.no_grad():
+                oracle.models.varnet_forward(state_dict, dict(ucfg, num_cascades=1), h1["y"], h1["sensitivity_maps"], h1["mask"], None, h1["target"])
+                t0 = time.perf_counter()
+                ref = oracle.models.varnet_forward(state_dict, ucfg, h1["y"], h1["sensitivity_maps"], h1["mask"], None, h1["target"])
+                dt = time.perf_counter() - t0
+            res["cpu_baseline"] = dict(value=1.0 / dt, unit="slices/s", cores=ncores, kind="port", box_cores=box_cores, cpu_model=cpu_model_name(),
+                                       sample=f"one whole slice ({ucfg['num_cascades']} cascades) on the oracle after one untimed warm-up cascade, torch CPU ops on "
+                                              f"{ncores} threads, {dt:.1f} s")
+            out = outs[0] if graphed else step(datas[0])
             torch.cuda.synchronize()
+            res["parity_vs_oracle"] = parity_vs_oracle(out[0:1], ref[0:1], h1["target"], at="the final image (all cascades, SENSE combination)")
         except Exception as ex:  # noqa: BLE001
-            print(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
-            graphs = []
-            torch.cuda.synchronize()
-    dist_barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        for i, st in enumerate(streams):
-            with torch.cuda.stream(st):
-                if graphs:
-                    graphs[i].replay()
-                else:
-                    step(datas[i])
-    dist_barrier()
-    elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
-    B = NS * B
-    if rank == 0:
-        emit(dict(metric=f"slices/sec (inference), {label} {C}-coil {H}x{W}", value=world * B * args.steps / elapsed,
-                              unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                              ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
-                              per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
-                              dtype="f32", data="synthetic",
-                              config=dict(workload=f"{desc}, {C} coils, {H}x{W}, batch "
-                                                   f"{B} per GPU ({NS} concurrent HIP stream(s), {'one hipGraph each' if graphs else 'eager'}), random-init weights "
-                                                   "(seed 0)", parallelism=f"slice-sharded x{world}")))
+            res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port", sample=f"failed: {type(ex).__name__}: {ex}")
+    return res
 
 
 def bench_train(args, world, rank, dev):

@@ -361,3 +361,65 @@ def test_absl1_loss_gradient_includes_the_path_through_the_maximum(dev, seed):
     gw, gg = want.reshape(-1, 2)[idx], got.reshape(-1, 2)[idx]
     assert float(gw.norm()) > 10 * float(want.reshape(-1, 2).norm(dim=1).median())       # the max term really dominates that pixel
     assert float((gg - gw).norm()) <= 1e-4 * float(gw.norm()), (gg, gw)
+
+
+def _tape_rank(rank, world, port, tmp):
+    """One rank of the two-process explicit-tape step (a fresh process: it initialises the GPU itself)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mridc_amd import synthetic, training
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=2)
+    torch.manual_seed(3)
+    model = CIRIM(cfg).to(dev)
+    s = synthetic.make_slice(3, 24, 20, slice_idx=1 + rank)            # every rank its own slice
+    batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    flat = training.FlatParameters(model)
+    assert len(flat.cascade_slices) == 2
+    opt = training.AdamFlat(flat, lr=1e-3, betas=(0.9, 0.98))
+    loss = training.training_step(model, flat, opt, batch, use_tape=True)   # per-cascade async all-reduce of the flat gradient's slices
+    torch.cuda.synchronize()
+    torch.save(dict(loss=float(loss), grad=flat.grad.detach().cpu(), params=flat.flat.detach().cpu()), os.path.join(tmp, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step_on_the_explicit_tape(dev, tmp_path):
+    """SURVEY 8 row T / 8e (base_cirim_train.yaml:175 `strategy: ddp`): `training.training_step(use_tape=True)` with TWO ranks (two fresh
+    processes sharing the one GPU, gloo process group on device tensors): each cascade's slice of the flat gradient is all-reduced
+    asynchronously as soon as its backward ends.  The reduced gradient equals the sum of the two slices' single-rank gradients, and both
+    ranks hold identical parameters after the Adam step."""
+    import socket
+    import torch.multiprocessing as mp
+    from mridc_amd import synthetic, training
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_tape_rank, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(600)
+        assert p_.exitcode == 0, p_.exitcode
+    got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    assert torch.equal(got[0]["grad"], got[1]["grad"]) and torch.equal(got[0]["params"], got[1]["params"])
+    # single-rank reference in this process: the gradients of the two slices, summed
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=2)
+    total = None
+    for r in range(2):
+        torch.manual_seed(3)
+        model = CIRIM(cfg).to(dev).train()
+        s = synthetic.make_slice(3, 24, 20, slice_idx=1 + r)
+        batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+        flat = training.FlatParameters(model)
+        flat.zero_grad()
+        training.cirim_forward_backward(model, batch, "f32")
+        total = flat.grad.detach().cpu().clone() if total is None else total + flat.grad.detach().cpu()
+    assert_close(got[0]["grad"], total, 1e-6, "two-rank reduced gradient vs the sum of the single-rank gradients")

@@ -570,3 +570,58 @@ def test_rim_block_fp16_route_on_and_off(dev, shape):
     finally:
         RIMBlock.layer2_f16 = keep
     assert rel_l2(outs[True], outs[False]) <= 5e-6
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-3), ("bf16", 5e-2)])
+def test_one_cascade_training_at_headline_size(dev, precision, tol):
+    """BASELINE config 4 at the headline shape (base_cirim_train.yaml:175-180): ONE cascade (8 time-steps) of the CIRIM at 1 x 15 x 640 x 372,
+    forward + l1 loss + backward on the explicit tape (`training.cirim_forward_backward`: mrx_llg372 and its adjoint, the 960-tile persistent
+    weight-gradient kernels and their partial reduction, mrx_relu_bwd_acc on 61 MB planes, the data gradients) against torch autograd of the
+    oracle: the loss and all 11 parameter gradients.  fp32: every gradient rel-L2 <= 2e-3; bf16 (operands rounded to bf16, fp32 accumulation:
+    the reference's `precision: 16`): the whole gradient vector <= 5e-2 and the loss <= 2e-2."""
+    from mridc_amd import autograd as ag
+    from mridc_amd import training
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=1)
+    torch.manual_seed(5)
+    model = CIRIM(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("bias"):
+                p_.normal_(0, 0.05)
+            if n_.endswith("rnn.ih.weight") or n_.endswith("rnn.hh"):
+                p_.mul_(3.0)                           # the reference init is nearly linear: make the ReLUs of the recurrence bite
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    s = synthetic.make_slice(15, 640, 372, slice_idx=7)
+    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    pred = oracle.models.cirim_forward(p, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"])
+    T_ = oracle.models.cirim_time_steps(cfg["time_steps"])
+    ref_loss = oracle.models.cirim_process_loss(s["target"], pred, torch.nn.L1Loss(), T_, 1)
+    ref_loss.backward()
+    model = model.to(dev).train()
+    batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    assert training._tape_supported(model, batch)
+    ag.set_precision(precision)
+    try:
+        for prm in model.parameters():
+            prm.grad = None
+        loss = training.cirim_forward_backward(model, batch, precision)
+    finally:
+        ag.set_precision("f32")
+    lg, lr_ = float(loss), float(ref_loss.detach())
+    assert abs(lg - lr_) <= (1e-5 if precision == "f32" else 2e-2) * abs(lr_), (lg, lr_)
+    got_all, ref_all, checked = [], [], 0
+    for name, prm in model.named_parameters():
+        if name.endswith("dc_weight"):
+            continue
+        ref = p[name].grad
+        assert ref is not None and prm.grad is not None, name
+        if precision == "f32":
+            assert_close(prm.grad, ref, tol, f"gradient of {name} at 15 x 640 x 372")
+        got_all.append(prm.grad.detach().cpu().reshape(-1).double())
+        ref_all.append(ref.reshape(-1).double())
+        checked += 1
+    assert checked == 11
+    got_all, ref_all = torch.cat(got_all), torch.cat(ref_all)
+    whole = float((got_all - ref_all).norm() / ref_all.norm())
+    assert whole <= tol, whole
