@@ -733,7 +733,7 @@ def exact_route_line(args):
     """The headline in a CHILD process with the layer kernels on three-term bf16 operands (six exact term products per fp32 multiply,
     error O(2^-24): the route the two-term fp16 default is judged against).  A child because the route is chosen once per process."""
     import subprocess
-    env = dict(os.environ, MRIDC_AMD_LAYER2_F16="0", MRX_LAYER1_F16="0")
+    env = dict(os.environ, MRIDC_AMD_ARITH="bf16x3")
     cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--steps", "6", "--warmup", "2",
            "--coils", str(args.coils), "--height", str(args.height), "--width", str(args.width), "--mask", args.mask]
     try:
@@ -742,7 +742,7 @@ def exact_route_line(args):
         r = json.loads(line)
         return dict(value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"], breakdown_ms=r.get("breakdown_ms"),
                     arith="three bf16 terms per fp32 operand, six term products per multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation "
-                          "(MRIDC_AMD_LAYER2_F16=0 MRX_LAYER1_F16=0)", steps=r["steps"])
+                          "(MRIDC_AMD_ARITH=bf16x3)", steps=r["steps"])
     except Exception as ex:  # noqa: BLE001
         return dict(value=None, error=f"{type(ex).__name__}: {ex}")
 
@@ -1028,12 +1028,12 @@ def main():
             msl, nl = ms372, n372
         # whole regulariser (layer 1 + layer 2 + final conv) as issued on the matrix / vector pipes.  Layer 1 runs on the bf16 matrix pipe
         # (k_rim_layer1_sb: three-term bf16 operand split, 6 term products per multiply, 132 MFMAs of 32x32x16 per 32 pixels) unless
-        # MRX_LAYER1_FP32=1 selects the fp32-MFMA kernel: its issued work is priced against the dense bf16 peak, the rest against the
+        # MRIDC_AMD_ARITH=fp32 selects the fp32-MFMA kernels: its issued work is priced against the dense bf16 peak, the rest against the
         # fp32 peak, and `frac_issued` is the pipe time so priced over the measured time.
         flops_reg = 105216.0 * npix * B                     # 25.05 GFLOP per slice-step (direct form)
         flops1 = 2.0 * (F_hidden * 4 * 25 + F_hidden * F_hidden) * npix * B
-        l1_bf16 = F_hidden == 64 and os.environ.get("MRX_LAYER1_FP32", "0") in ("", "0")
-        l1_f16 = l1_bf16 and os.environ.get("MRX_LAYER1_F16", "1") not in ("0",)       # two-term fp16 operands: 66 MFMAs per 32 pixels instead of 132
+        l1_bf16 = F_hidden == 64 and _lib.arith() != "fp32"
+        l1_f16 = l1_bf16 and _lib.arith() == "f16x2"       # two-term fp16 operands: 66 MFMAs per 32 pixels instead of 132
         issued1_bf16 = ((66 if l1_f16 else 132) * 32 * 32 * 16 * 2 / 32.0) * npix * B if l1_bf16 else 0.0
         issued2_bf16 = executed if l2_bf16 else 0.0
         issued_l1_only = issued1_bf16             # layer 1's own bf16 MFMA work (for layer1_frac_issued)
@@ -1069,9 +1069,9 @@ def main():
                         regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_fp32_gflop=issued_reg / 1e9,
                                          issued_bf16_gflop=issued1_bf16 / 1e9,
                                          frac_issued=(pipe_ms(issued_reg, issued1_bf16) / t_reg) if t_reg else None,
-                                         note="all three kernels of a step: layer 1 and (unless MRIDC_AMD_LAYER2_SB=0: then fp32 MFMA, Winograd) layer 2 on "
+                                         note="all three kernels of a step: layer 1 and (unless MRIDC_AMD_ARITH=fp32: then fp32 MFMA, Winograd) layer 2 on "
                                               "the bf16 matrix pipe with fp32 results via the three-term split; final conv 64->2: its channel contraction in layer 2's tail on the "
-                                              "matrix pipe + a 9-tap gather (default), or -- MRIDC_AMD_FUSED_FINAL=0 -- on the vector ALUs (its 0.55 GFLOP counted at the fp32 rate).  frac_issued = (fp32 work / fp32 peak + bf16 work / "
+                                              "matrix pipe + a 9-tap gather (default; the stand-alone vector-ALU kernel serves other shapes: its 0.55 GFLOP would count at the fp32 rate).  frac_issued = (fp32 work / fp32 peak + bf16 work / "
                                               "dense bf16 peak) / measured time",
                                          layer1_ms=ms1, layer1_kernel=("k_rim_layer1_sb<F16> (two fp16 terms per operand, per-unit / per-pixel scales, 3 term products)" if l1_f16 else
                                                         "k_rim_layer1_sb (three bf16 terms, 6 term products)") if l1_bf16 else "k_rim_layer<5,1,4>",

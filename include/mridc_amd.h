@@ -57,6 +57,10 @@ const char* mrx_last_error(void);
  * keys its per-slice operand caches on it: an operand prepared eagerly must not be baked into a graph (a replay on refilled inputs would
  * read stale operands) and one prepared inside a capture must not be used outside it. */
 int64_t mrx_stream_capture_id(void* stream);
+/* The library's one arithmetic switch, environment MRIDC_AMD_ARITH (read at every call): 0 = "f16x2" (default: two-term fp16 operands, three term
+ * products per multiply, where a kernel has that form), 1 = "bf16x3" (three-term bf16 operands, six exact term products), 2 = "fp32" (the
+ * fp32-input MFMA kernels).  All three give fp32 results; tests cross-check them, bench.py prices them (exact_fp32_route). */
+int mrx_arith(void);
 
 /* Create (and cache) the twiddle tables for lengths h and w.  Optional; every FFT entry point does
  * it lazily.  Call it before capturing a hipGraph. */

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "mrx_version": ([], _i),
     "mrx_last_error": ([], ctypes.c_char_p),
     "mrx_stream_capture_id": ([_p], _i64),
+    "mrx_arith": ([], _i),
     "mrx_poisson_disc_mask": ([_i, _i, _i, _p, _p, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, _p], _i64),
     "mrx_fft_prepare": ([_i, _i], _i),
     "mrx_fft_max_len": ([], _i),
@@ -196,6 +197,16 @@ _SIGNATURES = {
 }
 
 _lib = None
+
+
+ARITH_NAMES = ("f16x2", "bf16x3", "fp32")
+
+
+def arith():
+    """The arithmetic route (environment MRIDC_AMD_ARITH, see include/mridc_amd.h): "f16x2" (default), "bf16x3" or "fp32" -- read on the
+    Python side exactly as libmridc_amd's mrx_arith reads it."""
+    v = os.environ.get("MRIDC_AMD_ARITH", "f16x2")
+    return v if v in ARITH_NAMES else "f16x2"
 
 
 def declared_symbols():

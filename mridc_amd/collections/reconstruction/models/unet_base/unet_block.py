@@ -91,8 +91,8 @@ class Unet(torch.nn.Module):
                                                 torch.nn.Conv2d(ch, self.out_chans, kernel_size=1, stride=1)))
 
     # the inference path keeps every Conv -> InstanceNorm -> LeakyReLU output as (raw, per-plane statistics) and lets the consumer normalise
-    # while it loads: no apply pass, no concatenated tensor (csrc/unet_fused.hip); MRIDC_AMD_UNET_FUSED=0 selects conv + apply launches
-    fused = os.environ.get("MRIDC_AMD_UNET_FUSED", "1") != "0"
+    # while it loads: no apply pass, no concatenated tensor (csrc/unet_fused.hip); `fused = False` selects conv + apply launches
+    fused = True                    # (class attribute: a test hook for the unfused formulation)
 
     def _fusable(self) -> bool:
         blocks = list(self.down_sample_layers) + [self.conv] + [c[0] if isinstance(c, torch.nn.Sequential) else c for c in self.up_conv]

@@ -1,6 +1,8 @@
 // api.cpp -- version and thread-local error message of libmridc_amd.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "mrx_common.h"
 
@@ -15,6 +17,13 @@ void mrx_set_error(const char* fmt, ...) {
 
 extern "C" int mrx_version(void) { return 224; /* 0.2.0: bumped with every kernel change (profiles/rNN_traffic.json is keyed on it) */ }
 extern "C" const char* mrx_last_error(void) { return g_err; }
+extern "C" int mrx_arith(void) {
+    const char* e = getenv("MRIDC_AMD_ARITH");
+    if (!e) return MRX_ARITH_F16X2;
+    if (!strcmp(e, "bf16x3")) return MRX_ARITH_BF16X3;
+    if (!strcmp(e, "fp32")) return MRX_ARITH_FP32;
+    return MRX_ARITH_F16X2;
+}
 
 // 0 when `stream` is not being captured into a hipGraph, otherwise the (non-zero) id of the capture: callers that cache prepared operands
 // key them on it, so an operand prepared eagerly is never baked into a graph and one prepared inside a capture is never used outside it.

@@ -473,7 +473,7 @@ static int launch_small(const float* x, const float* w, const float* bias, const
     size_t lds;
     int rc = conv_geometry(Cin, k, dil, 0, &s.CK, &s.PH, &s.PW, &s.pad, &lds);
     if (rc) return rc;
-    if (mode == 0 && dil == 1 && (k == 3 || k == 5) && (Cout == 2 || Cout == 4) && Cin >= 8 && !getenv("MRX_CONV_SMALL_OLD")) {
+    if (mode == 0 && dil == 1 && (k == 3 || k == 5) && (Cout == 2 || Cout == 4) && Cin >= 8) {
         s.tiles_x = mrx_cdiv(W, P4_TW);
         dim3 g4(s.tiles_x * mrx_cdiv(H, P4_TH), 1, B);
         size_t lds4 = sizeof(float) * P4_CK * (P4_TH + k - 1) * (P4_TW + 8);
@@ -743,7 +743,7 @@ static int launch_conv3x3_t(ConvArgs a, hipStream_t st, float* stats = nullptr) 
 }
 static bool conv3x3_tuned_ok(int B, int Cout, int H, int W, int k, int dil) {
     // any Cout: cout blocks of 16 * NCOT channels are spread over grid.y (the (18, 4) U-Net of the reference yaml reaches 288 channels)
-    return k == 3 && dil == 1 && Cout <= 16 * 65535 && (long long)H * W < (1ll << 30) && B <= 65535 && !getenv("MRX_CONV_GENERIC");
+    return k == 3 && dil == 1 && Cout <= 16 * 65535 && (long long)H * W < (1ll << 30) && B <= 65535;
 }
 static int dispatch_conv3x3_t(const ConvArgs& a, hipStream_t st, float* stats) {
     const int ncot = (a.Cout + 15) / 16;

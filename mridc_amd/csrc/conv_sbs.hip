@@ -31,7 +31,7 @@ __device__ __forceinline__ void cs_split2(float a, float b, unsigned& p1, unsign
     p3 = cs_pk(ra, rb);
 }
 
-// ---- two-term fp16 form (F16, the default; MRX_CONV_SBS_F16=0 selects the three bf16 terms): the whole halo'd tile of a workgroup is staged at
+// ---- two-term fp16 form (F16, the default; MRIDC_AMD_ARITH=bf16x3 selects the three bf16 terms): the whole halo'd tile of a workgroup is staged at
 // once, so it is scaled by the power of two that puts the TILE's largest |x| into [2^14, 2^15) (one workgroup reduction: every input of the tile's
 // outputs is in it), the weights at pack time; three term products per multiply, accumulators scaled back exactly before the bias
 // (rim_layer2_sb.hip for the error analysis: ~3 x 2^-22 per product).
@@ -285,7 +285,7 @@ template <int K, int NCT>
 static int cs_launch(const ConvSbsArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)3 * (CS_TH + K - 1) * (CS_TW + K - 1) * 16;
     static_assert(lds <= 48 * 1024, "fits the default dynamic LDS limit");
-    static const int f16 = (getenv("MRX_CONV_SBS_F16") && atoi(getenv("MRX_CONV_SBS_F16")) == 0) ? 0 : 1;   // 0: the three-term bf16 form
+    const int f16 = mrx_arith() == MRX_ARITH_F16X2 ? 1 : 0;   // 0: the three-term bf16 form
     if (f16)
         hipLaunchKernelGGL((k_conv_sbs<K, NCT, true>), dim3(a.ntiles, a.B), dim3(CS_NT), lds, st, a);
     else

@@ -1692,7 +1692,7 @@ extern "C" int mrx_llg_cols_dc_t4(float* work_t4, const float* y_t4, const void*
     float4* out = (float4*)work_t4;
     // MRX_COLS640=1: the wave-private register form (k_cols640_dc_t4) -- measured 33.8 us against 28.5 us for the workgroup (Stockham) form at
     // 15 x 640 x 372 (1395 single-wave tasks are 1.4 waves per SIMD: every exchange and load latency is exposed), so not the default
-    static const int wave640 = (getenv("MRX_COLS640") && atoi(getenv("MRX_COLS640")) == 1) ? 1 : 0;
+    static const int wave640 = (MRX_DEBUG_ENV("MRX_COLS640") && atoi(MRX_DEBUG_ENV("MRX_COLS640")) == 1) ? 1 : 0;
     if (H == 640 && wave640) {
         hipLaunchKernelGGL(k_cols640_dc_t4, grid, dim3(64), 0, st, in, y4, m, out, a);
     } else if (H == 640) {
@@ -1733,7 +1733,7 @@ static int launch_hinv_p(const float2* eta, const float2* yt, const float2* S, c
     const int nchunks = mrx_cdiv(a.C, a.g);
     if (defer) *defer = 0;
     // experimental (MRX_LLG_MFMA=1): measured 46.8 us vs 44.2 us for the vector-ALU kernels below at 15 x 640 x 372 -- kept selectable
-    if (P::kCT && P::N == 372 && NSEQ == M372_G && getenv("MRX_LLG_MFMA")) {
+    if (P::kCT && P::N == 372 && NSEQ == M372_G && MRX_DEBUG_ENV("MRX_LLG_MFMA")) {
             M372Tables tb;
             int rc = m372_tables(&tb);  // (first call allocates: mrx_fft_prepare does it eagerly, before any graph capture)
             if (rc) return rc;
@@ -1751,13 +1751,13 @@ static int launch_hinv_p(const float2* eta, const float2* yt, const float2* S, c
             const long long nrows = (long long)grid.x * grid.y;
             const unsigned nblk = (unsigned)(nrows < 3ll * n_cu ? nrows : 3ll * n_cu);
             static unsigned long long* d_trace = nullptr;
-            if (getenv("MRX_TRACE") && !d_trace) {
+            if (MRX_DEBUG_ENV("MRX_TRACE") && !d_trace) {
                 (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 8 * 65536);
                 (void)hipMemcpyToSymbol(HIP_SYMBOL(g_m372_trace), &d_trace, sizeof(d_trace));
             }
             hipLaunchKernelGGL(k_llg_rows_hinv_mfma372, dim3(nblk), dim3(MRX_FFT_NT), lds_m, st, eta, yt, S, m, out, a, scale_f, tb,
-                               (int)grid.y, nchunks, getenv("MRX_ABLATE") ? atoi(getenv("MRX_ABLATE")) : 0);
-            if (d_trace && getenv("MRX_TRACE_DUMP")) {
+                               (int)grid.y, nchunks, MRX_DEBUG_ENV("MRX_ABLATE") ? atoi(MRX_DEBUG_ENV("MRX_ABLATE")) : 0);
+            if (d_trace && (MRX_DEBUG_ENV("MRX_TRACE") && atoi(MRX_DEBUG_ENV("MRX_TRACE")) >= 2)) {
                 (void)hipStreamSynchronize(st);
                 const int nb = (int)nblk;
                 std::vector<unsigned long long> hh((size_t)nb * 8);
@@ -1842,7 +1842,7 @@ static int llg_hinv_impl(const float* eta, const float* yt, const float* S, cons
     a.C = C;
     a.H = H;
     a.W = W;
-    const bool mfma372 = W == 372 && getenv("MRX_LLG_MFMA");  // experimental matrix-pipe kernel: fixed at 5 coils per workgroup
+    const bool mfma372 = W == 372 && MRX_DEBUG_ENV("MRX_LLG_MFMA");  // experimental matrix-pipe kernel: fixed at 5 coils per workgroup
     a.g = W == 372 ? (mfma372 ? M372_G : NSEQ_HINV_372) : pick_rows(W);
     const bool ct = (W == 372 || W == 320 || W == 256);
     if (!ct && a.g > C) a.g = C;
@@ -1879,7 +1879,7 @@ extern "C" int mrx_llg_hinv_parts(const float* eta, const float* yt, const float
                                   float inv_sigma2, int norm, int centered, void* stream) {
     MRX_REQUIRE(nparts, MRX_EINVAL, "mrx_llg_hinv_parts: null pointer");
     *nparts = 0;
-    if (getenv("MRX_LLG_MFMA")) return llg_hinv_impl(eta, yt, S, mask, mask_kind, mstride, out4, work, B, C, H, W, inv_sigma2, norm, centered, stream, nullptr);
+    if (MRX_DEBUG_ENV("MRX_LLG_MFMA")) return llg_hinv_impl(eta, yt, S, mask, mask_kind, mstride, out4, work, B, C, H, W, inv_sigma2, norm, centered, stream, nullptr);
     return llg_hinv_impl(eta, yt, S, mask, mask_kind, mstride, out4, work, B, C, H, W, inv_sigma2, norm, centered, stream, nparts);
 }
 

@@ -256,7 +256,7 @@ extern "C" int mrx_gated_cell_1x1(const float* x, const float* h, const float* p
     a.P = HW;
     a.nsegb = (HW + 31) / 32;
     a.nseg = a.nsegb * B;
-    static const int fp32 = getenv("MRX_GATED_FP32") ? atoi(getenv("MRX_GATED_FP32")) : 0;   // 1: the fp32-MFMA kernel (cross-check)
+    const int fp32 = mrx_arith() == MRX_ARITH_FP32 ? 1 : 0;   // 1: the fp32-MFMA kernel (cross-check)
     if (!fp32) {                                  // default: the bf16 matrix pipe with fp32 results (gated_cell_sb.hip)
         MrxGatedSbArgs s;
         s.x = x, s.h = h, s.packed = packed + (size_t)2 * gates * GC_F * GC_F, s.b_ih = b_ih, s.out = out;
@@ -449,7 +449,7 @@ extern "C" int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const floa
     a.P = HW;
     a.nsegb = (HW + 31) / 32;
     a.nseg = a.nsegb * B;
-    static const int fp32 = getenv("MRX_GATED_FP32") ? atoi(getenv("MRX_GATED_FP32")) : 0;   // 1: the fp32-MFMA kernel (cross-check)
+    const int fp32 = mrx_arith() == MRX_ARITH_FP32 ? 1 : 0;   // 1: the fp32-MFMA kernel (cross-check)
     if (!fp32) {                                  // default: the bf16 matrix pipe with fp32 results (gated_cell_sb.hip)
         MrxConv2dGruSbArgs s;
         s.x = x, s.h = h, s.packed = packed + 6 * GC_F * GC_F, s.bias = bias, s.out = out, s.out_relu = out_relu;
@@ -624,7 +624,7 @@ extern "C" int mrx_conv1x1_sq(const float* x, const float* packed, const float* 
     a.nseg = a.nsegb * B;
     a.act = act;
     a.slope = slope;
-    static const int fp32 = getenv("MRX_GATED_FP32") ? atoi(getenv("MRX_GATED_FP32")) : 0;   // 1: the fp32-MFMA kernel (cross-check)
+    const int fp32 = mrx_arith() == MRX_ARITH_FP32 ? 1 : 0;   // 1: the fp32-MFMA kernel (cross-check)
     if (C == 128 && !fp32) {                      // default at 128 features: the bf16 matrix pipe with fp32 results
         MrxConv1x1SbArgs s;
         s.x = x, s.packed = packed + (size_t)C * C, s.bias = bias, s.hh = hh, s.hprev = h_prev, s.out = out;

@@ -352,9 +352,9 @@ static int launch_gated_sb(const MrxGatedSbArgs& a, hipStream_t st) {
 }
 int mrx_gated_sb_launch(const MrxGatedSbArgs& a, int gates, hipStream_t st) {
     // the two-term fp16 form (per-pixel scales) is the default: GRU 88.7 -> 70.5 us, MGU 66.9 -> 54.9 us at 640 x 372, error against float64 1.1e-7 as
-    // the three-term bf16 form, which MRX_GATED_F16=0 selects.  (Its first version spilled -- 356 bytes of scratch per lane, 184 us: h_prev is now
+    // the three-term bf16 form, which MRIDC_AMD_ARITH=bf16x3 selects.  (Its first version spilled -- 356 bytes of scratch per lane, 184 us: h_prev is now
     // requested after the x part is issued and the accumulators are scaled back where the gates are evaluated, not in a pass of their own.)
-    static const int f16 = (getenv("MRX_GATED_F16") && atoi(getenv("MRX_GATED_F16")) == 0) ? 0 : 1;
+    const int f16 = mrx_arith() == MRX_ARITH_F16X2 ? 1 : 0;
     if (f16) return gates == 3 ? launch_gated_sb<3, true>(a, st) : launch_gated_sb<2, true>(a, st);
     return gates == 3 ? launch_gated_sb<3, false>(a, st) : launch_gated_sb<2, false>(a, st);
 }
@@ -686,7 +686,7 @@ int mrx_conv2dgru_sb_launch(const MrxConv2dGruSbArgs& a, hipStream_t st) {
     }
     const long long nblk_need = (a.nseg + GS_NT / 64 - 1) / (GS_NT / 64);
     const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);
-    static const int f16 = (getenv("MRX_CONV2DGRU_F16") && atoi(getenv("MRX_CONV2DGRU_F16")) == 0) ? 0 : 1;   // 0: the three-term bf16 form (RecurrentVarNet 164 -> 182 slices/s with fp16)
+    const int f16 = mrx_arith() == MRX_ARITH_F16X2 ? 1 : 0;   // 0: the three-term bf16 form (RecurrentVarNet 164 -> 182 slices/s with fp16)
     if (f16)
         hipLaunchKernelGGL(k_conv2dgru_cell_sb<true>, dim3(nblk), dim3(GS_NT), lds, st, a);
     else

@@ -539,7 +539,7 @@ extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, c
     if (B == 0) return MRX_OK;
     MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_llg372: too many tasks");
     hipStream_t st = (hipStream_t)stream;
-    static const int ablate = getenv("MRX_LLG372_ABLATE") ? atoi(getenv("MRX_LLG372_ABLATE")) : 0;
+    static const int ablate = MRX_DEBUG_ENV("MRX_LLG372_ABLATE") ? atoi(MRX_DEBUG_ENV("MRX_LLG372_ABLATE")) : 0;
     const dim3 grid((unsigned)a.ntasks), blk(64);
     const float2 *pe = (const float2*)eta, *py = (const float2*)ytp, *ps = (const float2*)Sp;
     if (ablate == 1)
@@ -553,7 +553,7 @@ extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, c
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_l372_trace), &d_trace, sizeof(d_trace));
         }
         hipLaunchKernelGGL((k_llg372<3>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
-        if (getenv("MRX_LLG372_TRACE_DUMP")) {
+        if ((MRX_DEBUG_ENV("MRX_TRACE") && atoi(MRX_DEBUG_ENV("MRX_TRACE")) >= 2)) {
             (void)hipStreamSynchronize(st);
             const size_t nt = (size_t)a.ntasks;
             unsigned long long* h = (unsigned long long*)malloc(sizeof(unsigned long long) * 8 * nt);

@@ -4,10 +4,28 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/mridc_amd.h"
 
 void mrx_set_error(const char* fmt, ...);
+
+// The ONE arithmetic switch of the library: environment MRIDC_AMD_ARITH = "f16x2" (default: two-term fp16 operands where a kernel has them),
+// "bf16x3" (three-term bf16 operands, six exact term products per fp32 multiply) or "fp32" (the fp32-input MFMA kernels).  Every form has
+// fp32 results; the switch exists to cross-check the forms against each other (tests) and to price them (bench.py exact_fp32_route).
+// Read at every call (tests flip it in-process).
+#define MRX_ARITH_F16X2 0
+#define MRX_ARITH_BF16X3 1
+#define MRX_ARITH_FP32 2
+extern "C" int mrx_arith(void);
+
+// Instrumentation switches (cycle stamps, phase ablations) exist in PROBE builds only (MRX_BUILD_DEFS=-DMRX_PROBE python -m mridc_amd._build):
+// the product library reads no debug environment.
+#ifdef MRX_PROBE
+#define MRX_DEBUG_ENV(name) getenv(name)
+#else
+#define MRX_DEBUG_ENV(name) ((const char*)nullptr)
+#endif
 
 #define MRX_REQUIRE(cond, code, ...)  \
     do {                              \

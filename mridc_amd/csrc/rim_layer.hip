@@ -417,19 +417,19 @@ static int launch_rim_layer(const RimLayerArgs& a_in, hipStream_t st) {
     static unsigned long long* d_trace = nullptr;
     RimLayerArgs a = a_in;
     a.trace = nullptr;
-    if (getenv("MRX_TRACE")) {
+    if (MRX_DEBUG_ENV("MRX_TRACE")) {
         if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 8 * 65536);
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 8 * 65536, st);
         a.trace = d_trace;
     }
-    if (getenv("MRX_DEBUG_OCC")) {
+    if ((MRX_DEBUG_ENV("MRX_TRACE") && atoi(MRX_DEBUG_ENV("MRX_TRACE")) >= 3)) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_rim_layer<K, DIL, CK>, RL_NT, lds);
         fprintf(stderr, "[mrx] k_rim_layer<%d,%d,%d>: lds %zu B, occupancy API: %d blocks/CU\n", K, DIL, CK, lds, nb);
     }
     hipLaunchKernelGGL((k_rim_layer<K, DIL, CK>), dim3(a.ntiles, a.B), dim3(RL_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
-    if (a.trace && getenv("MRX_TRACE_DUMP")) {
+    if (a.trace && (MRX_DEBUG_ENV("MRX_TRACE") && atoi(MRX_DEBUG_ENV("MRX_TRACE")) >= 2)) {
         (void)hipStreamSynchronize(st);
         const int nb = a.ntiles * a.B;
         std::vector<unsigned long long> h((size_t)nb * 8);
@@ -523,21 +523,19 @@ extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, 
     a.W = W;
     a.tiles_x = mrx_cdiv(W, RL_TW);
     a.ntiles = a.tiles_x * mrx_cdiv(H, RL_TH);
-    static const int ablate = getenv("MRX_ABLATE") ? atoi(getenv("MRX_ABLATE")) : 0;
+    static const int ablate = MRX_DEBUG_ENV("MRX_ABLATE") ? atoi(MRX_DEBUG_ENV("MRX_ABLATE")) : 0;
     a.ablate = ablate;
-    static const int stagger = getenv("MRX_STAGGER") ? atoi(getenv("MRX_STAGGER")) : 0;
-    a.stagger = stagger;
+    a.stagger = 0;
     hipStream_t st = (hipStream_t)stream;
     const bool small = rl_ck(Cin) == 4;
-    if (rl_sb_shape(Cin, k) && dil == 1 && !ablate && !getenv("MRX_TRACE")) {
-        const char* e = getenv("MRX_LAYER1_FP32");   // 1: the fp32-MFMA kernel (cross-check)
-        if (!(e && atoi(e))) {
+    if (rl_sb_shape(Cin, k) && dil == 1 && !ablate && !MRX_DEBUG_ENV("MRX_TRACE")) {
+        if (mrx_arith() != MRX_ARITH_FP32) {         // (fp32: the fp32-MFMA kernel below, the cross-check of the split-operand ones)
             MrxL1sbArgs s;
             s.x = x, s.packed = packed + rl_fp32_pack_floats(Cin, k), s.b_conv = b_conv, s.b_ih = b_ih, s.hh = hh, s.hprev = h_prev, s.hnew = h_new;
             s.B = B, s.Cin = Cin, s.H = H, s.W = W, s.tiles_x = a.tiles_x, s.ntiles = a.tiles_x * mrx_cdiv(H, MRX_L1SB_TH);
             s.eta2 = a.eta2, s.part = a.part, s.part_stride = a.part_stride, s.nparts = a.nparts, s.post = a.post;
             s.xmax = reinterpret_cast<unsigned*>(g_l1_xmax);
-            static const int l1_f16 = (getenv("MRX_LAYER1_F16") && atoi(getenv("MRX_LAYER1_F16")) == 0) ? 0 : 1;   // 0: the three-term bf16 form
+            const int l1_f16 = mrx_arith() == MRX_ARITH_F16X2 ? 1 : 0;   // else the three-term bf16 form
             s.f16 = l1_f16;
             return mrx_l1sb_launch(s, st);
         }
@@ -833,13 +831,13 @@ static int launch_rim_final4(RimFinalArgs a, hipStream_t st) {
     }
     static unsigned long long* d_trace = nullptr;
     a.trace = nullptr;
-    if (getenv("MRX_TRACE")) {
+    if (MRX_DEBUG_ENV("MRX_TRACE")) {
         if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 16 * 65536);
         a.trace = d_trace;
     }
     hipLaunchKernelGGL(k_rim_final4, dim3(a.ntiles, a.B), dim3(RF4_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
-    if (a.trace && getenv("MRX_TRACE_DUMP")) {
+    if (a.trace && (MRX_DEBUG_ENV("MRX_TRACE") && atoi(MRX_DEBUG_ENV("MRX_TRACE")) >= 2)) {
         (void)hipStreamSynchronize(st);
         const int nw = a.ntiles * a.B * 4;
         std::vector<unsigned long long> h((size_t)nw * 4);
@@ -877,7 +875,7 @@ int mrx_rim_final_tuned(const float* h, const float* w, const float* bias, const
     a.tiles_x = mrx_cdiv(W, RL_TW);
     a.ntiles = a.tiles_x * mrx_cdiv(H, RF_TH);
     *handled = 1;
-    if (k == 3 && dil == 1 && (W & 3) == 0 && W >= 8 && F % 4 == 0 && (long long)H * W < (1ll << 30) && !getenv("MRX_FINAL_OLD") &&
+    if (k == 3 && dil == 1 && (W & 3) == 0 && W >= 8 && F % 4 == 0 && (long long)H * W < (1ll << 30) &&
         (((uintptr_t)h | (uintptr_t)eta | (uintptr_t)eta_out) & 15) == 0)
         return launch_rim_final4(a, st);
     if (k == 3 && dil == 1) return launch_rim_final<3, 1>(a, st);
@@ -931,8 +929,7 @@ extern "C" int mrx_rim_layer_indrnn_packed_llg(const float* eta, const float* pa
 // upper bound of max |h_new|, which mrx_rim_layer2_f16 takes its operand scale from.  Only the split-bf16 kernel (Cin <= 4, 5x5, 64 features)
 // does it: mrx_rim_layer1_xmax_supported.
 extern "C" int mrx_rim_layer1_xmax_supported(int Cin, int F, int k, int dil) {
-    const char* e = getenv("MRX_LAYER1_FP32");
-    return (F == 64 && rl_sb_shape(Cin, k) && dil == 1 && !(e && atoi(e)) && !getenv("MRX_ABLATE") && !getenv("MRX_TRACE")) ? 1 : 0;
+    return (F == 64 && rl_sb_shape(Cin, k) && dil == 1 && mrx_arith() != MRX_ARITH_FP32 && !MRX_DEBUG_ENV("MRX_ABLATE") && !MRX_DEBUG_ENV("MRX_TRACE")) ? 1 : 0;
 }
 extern "C" int mrx_rim_layer_indrnn_packed_xmax(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
                                                 const float* h_prev, float* h_new, float* xmax, int B, int Cin, int F, int H, int W, int k, int dil,

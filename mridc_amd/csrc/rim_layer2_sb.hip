@@ -282,7 +282,7 @@ __device__ __forceinline__ int s2_pixel_exp(float m) {
 #define S2_OFF_X (S2_OFF_W + 2 * S2_WCH * 16)
 #define S2_LDS (S2_OFF_X + 2 * 3 * S2_NPIX_MAX * 16)
 
-// ABL (probe builds only, -DMRX_L2_ABLATE + env MRX_L2_ABL): phases switched off to price them -- 1 no x loads, 2 no operand split, 4 no LDS
+// ABL (probe builds only, -DMRX_PROBE + env MRX_L2_ABL): phases switched off to price them -- 1 no x loads, 2 no operand split, 4 no LDS
 // staging writes, 8 no convolution MFMAs, 16 no tail, 32 no LDS operand reads, 64 no barriers, 128 no h_prev loads, 256 no stores, 512 no tap
 // stage.  Results are garbage; only the time is read.
 template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0>
@@ -751,7 +751,7 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
     const int grid = (int)(total < ncu ? total : ncu);
     a.trace = nullptr;
     static unsigned long long* d_trace = nullptr;
-    if (TAIL && getenv("MRX_L2SB_TRACE")) {
+    if (TAIL && MRX_DEBUG_ENV("MRX_L2SB_TRACE")) {
         if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 512 * 8 * 8);
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, st);
         a.trace = d_trace;
@@ -787,7 +787,7 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
     a.P = P, a.act = MRX_ACT_NONE, a.slope = 0.f;
     a.xmax = reinterpret_cast<const unsigned*>(xmax);
-#ifdef MRX_L2_ABLATE
+#ifdef MRX_PROBE
     if (xmax && getenv("MRX_L2_ABL")) {
         switch (atoi(getenv("MRX_L2_ABL"))) {
 #define L2_ABL_CASE(N) case N: return l2sb_launch_t<2, true, false, true, N>(a, (hipStream_t)stream);

@@ -597,7 +597,7 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
     static_assert(12 * WN_XS(true) <= WN_XPLANE && 12 * WN_XS(false) <= WN_XPLANE, "raw tile fits its plane");
     const bool x4 = (W & 3) == 0 && W >= 4 && ((uintptr_t)x & 15) == 0;
     const size_t lds = sizeof(float) * WN_LDS_FLOATS;
-    static const int abl = getenv("MRX_ABLATE") ? atoi(getenv("MRX_ABLATE")) : 0;  // debug: skip 1 transform, 2 operand reads, 4 DMA, 8 MFMA
+    static const int abl = MRX_DEBUG_ENV("MRX_ABLATE") ? atoi(MRX_DEBUG_ENV("MRX_ABLATE")) : 0;  // debug: skip 1 transform, 2 operand reads, 4 DMA, 8 MFMA
     auto kern = x4 ? (abl == 1 ? k_rim_layer_wino<1, true> : abl == 2 ? k_rim_layer_wino<2, true> : abl == 4 ? k_rim_layer_wino<4, true>
                       : abl == 8 ? k_rim_layer_wino<8, true> : k_rim_layer_wino<0, true>)
                    : k_rim_layer_wino<0, false>;
@@ -608,7 +608,7 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
     }
     static unsigned long long* d_trace = nullptr;
     a.trace = nullptr;
-    if (getenv("MRX_TRACE")) {
+    if (MRX_DEBUG_ENV("MRX_TRACE")) {
         if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 40 * 65536);
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 8 * 65536, (hipStream_t)stream);
         a.trace = d_trace;
@@ -626,7 +626,7 @@ extern "C" int mrx_rim_layer_indrnn_wino(const float* x, const float* packed, co
     const unsigned nblk = (unsigned)(nt_total < n_cu ? nt_total : n_cu);  // persistent: one workgroup per CU walks the tiles
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(WN_NT), lds, (hipStream_t)stream, a);
     MRX_LAUNCH_CHECK();
-    if (a.trace && getenv("MRX_TRACE_DUMP")) {
+    if (a.trace && (MRX_DEBUG_ENV("MRX_TRACE") && atoi(MRX_DEBUG_ENV("MRX_TRACE")) >= 2)) {
         (void)hipStreamSynchronize((hipStream_t)stream);
         const int nb = (int)nblk;
         std::vector<unsigned long long> h((size_t)nb * 8);

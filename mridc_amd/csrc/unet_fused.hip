@@ -303,7 +303,7 @@ extern "C" int mrx_unet_conv3x3(const float* xa, const float* na, int Ca, const 
     UConvArgs a;
     a.xa = xa, a.na = na, a.xb = Cb ? xb : nullptr, a.nb = Cb ? nb : nullptr, a.w = w, a.y = y, a.tstats = work;
     a.Ca = Ca, a.Cb = Cb, a.B = B, a.Cout = Cout, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, UC_TW), a.slope = slope;
-    static const int abl = getenv("MRX_UCONV_ABLATE") ? atoi(getenv("MRX_UCONV_ABLATE")) : 0;
+    static const int abl = MRX_DEBUG_ENV("MRX_UCONV_ABLATE") ? atoi(MRX_DEBUG_ENV("MRX_UCONV_ABLATE")) : 0;
     a.abl = abl;
     const int ntiles = a.tiles_x * mrx_cdiv(H, UC_TH);
     const int ncot = (Cout + 15) / 16;

@@ -33,7 +33,7 @@ def _bchw(t):
     return int(t.shape[0]), int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
 
 
-PFA372 = os.environ.get("MRIDC_AMD_PFA372", "1") != "0"
+PFA372 = True            # W = 372 prime-factor row kernels (module attributes like this one are test hooks, not environment switches)
 
 
 class _PreparedCache:
@@ -198,7 +198,7 @@ def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None, 
     return out
 
 
-LLG_T4 = os.environ.get("MRIDC_AMD_LLG_T4", "1") != "0"
+LLG_T4 = True
 _Y_T4 = _PreparedCache()
 
 
@@ -319,7 +319,7 @@ class Llg372Operands:
         self.B, self.C, self.H, self.centered, self.work = B, C, H, centered, work
 
 
-LLG372 = os.environ.get("MRIDC_AMD_LLG372", "1") != "0"
+LLG372 = True
 
 
 def llg372_supported(yt, mask):
@@ -408,7 +408,7 @@ def rim_layer1_inplace_ok(Cin, F, k, dilation):
     """True when mrx_rim_layer_indrnn_packed[_llg] runs the split-bf16 first-layer kernel (rim_layer1_sb.hip), whose epilogue reads every
     h_prev element in the lane that writes h_new there: `out` may then be h_prev itself."""
     return (int(Cin) <= 4 and int(F) == 64 and int(k) == 5 and int(dilation) == 1
-            and os.environ.get("MRX_LAYER1_FP32", "0") in ("", "0") and not os.environ.get("MRX_TRACE") and not os.environ.get("MRX_ABLATE"))
+            and bool(_lib.lib().mrx_rim_layer1_xmax_supported(int(Cin), int(F), int(k), int(dilation))))
 
 
 def rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None, xmax=None):
@@ -591,7 +591,7 @@ def _nchw(x):
 
 
 # Winograd form of 3x3 convolutions into 64 channels (mrx_conv3x3_wino): transformed weights per (storage, version), oldest out
-WINOGRAD_CONV = os.environ.get("MRIDC_AMD_WINOGRAD", "1") != "0"
+WINOGRAD_CONV = True
 WINOGRAD_MIN_CIN = 16          # below this the 8-channel chunks are mostly padding and the direct kernels win
 _WINO_PACKS = {}
 
@@ -674,7 +674,7 @@ def conv3x3_wino(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, s
     return out
 
 
-SB_CONV = os.environ.get("MRIDC_AMD_CONV_SB", "1") != "0"
+SB_CONV = _lib.arith() != "fp32"       # 64 -> 64 3x3 convolutions on split operands (MRIDC_AMD_ARITH=fp32: the fp32 Winograd kernel)
 _PACKS_SB = {}
 
 
@@ -706,7 +706,7 @@ def conv3x3_sb(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slo
     return out
 
 
-SBS_CONV = os.environ.get("MRIDC_AMD_CONV_SBS", "1") != "0"
+SBS_CONV = _lib.arith() != "fp32"
 SBS_MIN_COUT = 32
 _PACKS_SBS = {}
 
@@ -739,7 +739,7 @@ def conv_sbs(x, weight, bias, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=No
     return out
 
 
-TAPS_CONV = os.environ.get("MRIDC_AMD_TAPS_CONV", "1") != "0"
+TAPS_CONV = True
 _TAPS_W = {}
 
 

@@ -288,7 +288,7 @@ def test_thin_3x3_conv_as_contraction_plus_gather(shape, dev):
 @pytest.mark.parametrize("shape", [(1, 4, 640, 372), (2, 4, 37, 75), (1, 2, 19, 33), (3, 1, 16, 32), (1, 4, 5, 3), (1, 3, 130, 320)])
 def test_first_rim_layer_split_bf16_has_fp32_accuracy(shape, dev, monkeypatch):
     """The first RIM layer on the bf16 matrix pipe (k_rim_layer1_sb: every fp32 operand as the exact sum of three bf16 terms, six term
-    products per multiply) against a float64 reference: its error must be that of the fp32-MFMA kernel (MRX_LAYER1_FP32=1), and the two
+    products per multiply) against a float64 reference: its error must be that of the fp32-MFMA kernel (MRIDC_AMD_ARITH=fp32), and the two
     kernels must agree to fp32 round-off.  Ragged tiles (W % 32, H % 16), fewer than four input channels, batches, no h_prev."""
     import torch.nn.functional as Fn
     from mridc_amd import ops
@@ -310,7 +310,7 @@ def test_first_rim_layer_split_bf16_has_fp32_accuracy(shape, dev, monkeypatch):
         ref = Fn.relu(ref + hh.double() * hp.double() if with_state else ref)
         out = {}
         for mode in ("0", "1"):
-            monkeypatch.setenv("MRX_LAYER1_FP32", mode)
+            monkeypatch.setenv("MRIDC_AMD_ARITH", "fp32" if mode == "1" else "bf16x3")
             out[mode] = ops.rim_layer_indrnn_packed(x.to(dev), packed, F_, 5, 1, bc.to(dev), bi.to(dev), hh.to(dev),
                                                     hp.to(dev) if with_state else None).cpu()
         e_sb, e_fp = rel_l2(out["0"], ref), rel_l2(out["1"], ref)

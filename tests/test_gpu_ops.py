@@ -240,14 +240,6 @@ def test_llg_row_invariant_mask_fast_path(shape, dev):
             assert_close(got, ref, 1e-5, f"llg_hinv {shape} {centered} {norm}")
             gen = ops.llg(eta.to(dev), y.to(dev), S.to(dev), mask.to(dev), sigma, centered, norm)
             assert_close(got, gen, 5e-6, "fast path vs general path")
-    if W == 372:  # the matrix-pipe variant of the 372-point transforms (31 x 12 DFT matrices on fp32 MFMA), selectable by env
-        import os
-        os.environ["MRX_LLG_MFMA"] = "1"
-        try:
-            got2 = ops.llg_hinv(eta.to(dev), yt, S.to(dev), mask.to(dev), sigma, centered, norm)
-        finally:
-            del os.environ["MRX_LLG_MFMA"]
-        assert_close(got2, ref, 1e-5, "llg_hinv, MFMA DFT variant")
     assert not ops.mask_is_row_invariant(torch.zeros(1, 1, H, W, 1))
     with pytest.raises(RuntimeError, match="row index"):
         ops.llg_hinv(eta.to(dev), k.to(dev), S.to(dev), torch.ones(1, 1, H, W, 1, device=dev), 1.0, True, "ortho")

@@ -7,7 +7,7 @@ O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+python3 bench.py --steps 20 --warmup 5 --stream-inputs > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/prof_headline -o h -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --graph 0 --streams 1 > $O/prof_headline.log 2>&1
 python3 tools/rocpd_summary.py $O/prof_headline/*results.db > $O/kernel_stats.md
 : > $O/other_configs_bench.json

@@ -1,4 +1,4 @@
-"""mrx_rim_layer2_cb8 phase ablation (library built with MRX_BUILD_DEFS=-DMRX_L2_ABLATE).  MRX_L2C8_ABL bits: 1 no tail slices, 2 no staging
+"""mrx_rim_layer2_cb8 phase ablation (library built with MRX_BUILD_DEFS=-DMRX_PROBE).  MRX_L2C8_ABL bits: 1 no tail slices, 2 no staging
 slices, 4 no convolution MFMAs, 8 no operand fetches, 16 both wave halves in the early order, 32 no barriers."""
 import os
 import sys

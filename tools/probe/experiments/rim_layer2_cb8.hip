@@ -99,7 +99,7 @@ __device__ __forceinline__ int c8_pixel_exp(float m) {
 #define C8_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
 #define C8_OOR 0x80000000u                     // a buffer offset beyond every tensor here (also with a block offset added): the load returns 0, the store is dropped
 
-// TAPS: also the final convolution's tap products (a.P).  ABL (probe builds, -DMRX_L2_ABLATE + env MRX_L2C8_ABL): 1 no tail slices, 2 no staging
+// TAPS: also the final convolution's tap products (a.P).  ABL (probe builds, -DMRX_PROBE + env MRX_L2C8_ABL): 1 no tail slices, 2 no staging
 // slices, 4 no convolution MFMAs, 8 no operand fetches, 16 upper wave half in the late order, 32 no barriers
 // -- garbage results, only the time is read (1 and 3 let the compiler drop the convolution as dead code: use 4 / 7 / 11 instead).
 template <bool TAPS, int ABL = 0>
@@ -582,7 +582,7 @@ extern "C" int mrx_rim_layer2_cb8(const float* x, const float* packed, const flo
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, (hipStream_t)stream);
         a.trace = d_trace;
     }
-#ifdef MRX_L2_ABLATE
+#ifdef MRX_PROBE
     if (taps9 && getenv("MRX_L2C8_ABL")) {
         switch (atoi(getenv("MRX_L2C8_ABL"))) {
 #define C8_ABL_CASE(N)                                                                                                                   \

@@ -1,4 +1,4 @@
-"""ConvGRUCell / ConvMGUCell 1x1 on 64 features at 640 x 372: split-bf16 kernel (default) against the fp32-MFMA kernel (MRX_GATED_FP32=1, separate process)."""
+"""ConvGRUCell / ConvMGUCell 1x1 on 64 features at 640 x 372: split-bf16 kernel (default) against the fp32-MFMA kernel (MRIDC_AMD_ARITH=fp32)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -33,4 +33,4 @@ for gates in (3, 2):
     s.record()
     for _ in range(100): fn()
     e.record(); torch.cuda.synchronize()
-    print(f"gates {gates} fp32={os.environ.get('MRX_GATED_FP32', '0')}: rel-L2 vs float64 {float((out.double() - ref).norm() / ref.norm()):.3e}, {10 * s.elapsed_time(e):.1f} us per launch")
+    print(f"gates {gates} fp32={os.environ.get('MRIDC_AMD_ARITH', 'f16x2')}: rel-L2 vs float64 {float((out.double() - ref).norm() / ref.norm()):.3e}, {10 * s.elapsed_time(e):.1f} us per launch")

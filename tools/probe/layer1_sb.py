@@ -1,4 +1,4 @@
-"""First RIM layer: the split-bf16 kernel (k_rim_layer1_sb) against the fp32-MFMA kernel (MRX_LAYER1_FP32=1) and a float64 torch reference at
+"""First RIM layer: the split-bf16 kernel (k_rim_layer1_sb) against the fp32-MFMA kernel (MRIDC_AMD_ARITH=fp32) and a float64 torch reference at
 1 x 640 x 372 -- error of both and time per launch."""
 import os
 import sys
@@ -34,7 +34,7 @@ x = torch.cat([eta.permute(0, 3, 1, 2), part.sum(0).permute(0, 3, 1, 2)], 1).dou
 ref = Fn.relu(Fn.conv2d(Fn.pad(x, (2, 2, 2, 2), mode="replicate"), wc.double(), bc.double()))
 ref = Fn.relu(Fn.conv2d(ref, wi.double(), bi.double()) + hh.double() * hp.double())
 for mode in ("0", "1"):
-    os.environ["MRX_LAYER1_FP32"] = mode
+    os.environ["MRIDC_AMD_ARITH"] = "fp32" if mode == "1" else "bf16x3"
     out = fn()
     err = ((out.double() - ref).norm() / ref.norm()).item()
-    print("MRX_LAYER1_FP32=%s: rel-L2 vs float64 %.3e, max abs %.3e, %.2f us per launch" % (mode, err, (out.double() - ref).abs().max().item(), timed()))
+    print("fp32-MFMA=%s: rel-L2 vs float64 %.3e, max abs %.3e, %.2f us per launch" % (mode, err, (out.double() - ref).abs().max().item(), timed()))

@@ -1,4 +1,4 @@
-"""A/B in one process: second RIM layer (two-term fp16 route) with MRX_L2_ABL variants interleaved (library built with -DMRX_L2_ABLATE)."""
+"""A/B in one process: second RIM layer (two-term fp16 route) with MRX_L2_ABL variants interleaved (library built with -DMRX_PROBE)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

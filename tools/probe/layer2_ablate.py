@@ -1,4 +1,4 @@
-"""Second RIM layer (two-term fp16 route): price of each phase by switching it off (library built with MRX_BUILD_DEFS=-DMRX_L2_ABLATE).
+"""Second RIM layer (two-term fp16 route): price of each phase by switching it off (library built with MRX_BUILD_DEFS=-DMRX_PROBE).
 ABL bits: 1 no x loads, 2 no operand split, 4 no LDS staging writes, 8 no conv MFMAs, 16 no tail, 32 no LDS operand reads, 64 no barriers."""
 import os
 import sys

@@ -1,5 +1,5 @@
 """Second RIM layer (two-term fp16 route), tail ablations + the per-tile cycle stamps at small grids (one workgroup alone has the HBM to itself).
-ABL bits: 128 no h_prev loads, 256 no stores, 512 no tap stage (library built with MRX_BUILD_DEFS=-DMRX_L2_ABLATE)."""
+ABL bits: 128 no h_prev loads, 256 no stores, 512 no tap stage (library built with MRX_BUILD_DEFS=-DMRX_PROBE)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

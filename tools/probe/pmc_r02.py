@@ -32,7 +32,7 @@ for _ in range(3):
     h1 = ops.rim_layer_indrnn_packed_llg(eta, part, n, 1.0, pk1, F, 5, 1, bc, bi, hh, hp, xmax=xmax)      # (keeps the bound of its outputs in xmax)
     ops.rim_layer2_f16(h1, pk2h, bc, bi, hh, hp, xmax, taps=taps, want_taps=True)                       # the headline loop's form
     ops.rim_layer_indrnn_wino(x, pk, F, bc, bi, hh, hp)
-    ops.rim_layer2_sb_taps(x, pk2, bc, bi, hh, hp, taps)      # the three-term bf16 form (MRIDC_AMD_LAYER2_F16=0)
+    ops.rim_layer2_sb_taps(x, pk2, bc, bi, hh, hp, taps)      # the three-term bf16 form (MRIDC_AMD_ARITH=bf16x3)
     ops.rim_final_gather(taps, None, eta)
     ops.rim_final(x, wf, None, 3, 1, eta)
     ops.llg(eta, y, S, mask2d, 1.0, False, "backward", work=work)

@@ -14,8 +14,8 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "llg": ["k_llg372<"],
     "conv_layer1": ["k_rim_layer1_sb", "k_rim_layer<5, 1, 4"],
     "conv_layer2_wino": ["k_rim_layer_wino<0, true, 2, true"],
-    "conv_layer2_sb": ["k_rim_layer2_sb<2, true, false, false>"],
-    "conv_layer2_f16": ["k_rim_layer2_sb<2, true, false, true>"],
+    "conv_layer2_sb": ["k_rim_layer2_sb<2, true, false, false"],
+    "conv_layer2_f16": ["k_rim_layer2_sb<2, true, false, true"],
     "final": ["k_rim_final4"],
     "final_gather": ["k_l2sb_gather"],
     "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_cols_dc_t4<", "k_rows_reduce<1", "k_pfa372_expand", "k_pfa372_reduce", "k_llg372_combine"],
