@@ -8,7 +8,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 python3 bench.py --steps 20 --warmup 5 --stream-inputs > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/prof_headline -o h -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --graph 0 --streams 1 > $O/prof_headline.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_headline -o h -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-configs --graph 0 --streams 1 > $O/prof_headline.log 2>&1
 python3 tools/rocpd_summary.py $O/prof_headline/*results.db > $O/kernel_stats.md
 : > $O/other_configs_bench.json
 for m in "--model e2evn" "--model e2evn --unet 18x4" "--model qcirim" "--model rvn" "--model ccnn" "--model vsnet" "--rnn GRU --cascades 1 --no-cpu-baseline" "--rnn MGU --cascades 1 --no-cpu-baseline" "--mask 2d --no-cpu-baseline"; do
@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats -d $O/prof_train -o t -- python3 bench.py --tra
 python3 tools/rocpd_summary.py $O/prof_train/*results.db > $O/train_bf16_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $O/prof_e2evn -o e -- python3 bench.py --model e2evn --steps 4 --warmup 1 --graph 0 --streams 1 > $O/prof_e2evn.log 2>&1
 python3 tools/rocpd_summary.py $O/prof_e2evn/*results.db > $O/e2evn_kernel_stats.md
-rocprofv3 --kernel-trace --stats -d $O/prof_2d -o d -- python3 bench.py --mask 2d --steps 4 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 > $O/prof_2d.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_2d -o d -- python3 bench.py --mask 2d --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --graph 0 --streams 1 > $O/prof_2d.log 2>&1
 python3 tools/rocpd_summary.py $O/prof_2d/*results.db > $O/mask2d_kernel_stats.md
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o p --output-format csv -- python3 tools/probe/pmc_r02.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o p --output-format csv -- python3 tools/probe/pmc_r02.py > /dev/null 2>&1
