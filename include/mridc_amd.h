@@ -329,6 +329,19 @@ int mrx_rim_final_gather(const float* taps, const float* b_final, const float* e
  * this one draws from its own xoshiro256** stream seeded with `seed`: reproducible.  Returns the number of samples (or a negative MRX_E* code). */
 int64_t mrx_poisson_disc_mask(int nx, int ny, int max_attempts, const float* radius_x, const float* radius_y, double calib_x, double calib_y,
                               uint64_t seed, unsigned char* mask);
+/* The two RIM layers on CHANNEL-BLOCKED hidden states h[b][c / 8][y][x][c % 8] ("CB8", fp32) instead of [B,64,H,W] (rim_block.py:230-246 keeps its
+ * states between time-steps: the layout between the kernels of a step is free).  A lane of the matrix-core accumulator layout owns four consecutive
+ * channels of a block, so state accesses are 16-byte instructions (8 + 8 per image row of a wave instead of 32 + 32) and the second layer's loader
+ * reads a pixel's eight channels of a chunk as 2 x 16 bytes instead of 8 x 4 from eight planes.  Results are bit-identical to the NCHW entry points.
+ *   mrx_cb8_convert      : [B,C,H,W] -> [B][C/8][H][W][8] (to_cb8 = 1) or back (0); C % 8 == 0, x != y;
+ *   mrx_rim_layer1_cb8   : mrx_rim_layer_indrnn_packed[_llg]_xmax (x [B,Cin,H,W] with eta NULL, or eta + coil-group partial sums) with h_prev / h_new CB8;
+ *   mrx_rim_layer2_f16_cb8: mrx_rim_layer2_f16 with x, h_prev, h_new CB8 (taps stays [B][18][H][W]). */
+int mrx_cb8_convert(const float* x, float* y, int B, int C, int H, int W, int to_cb8, void* stream);
+int mrx_rim_layer1_cb8(const float* x, int Cin, const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,
+                       const float* b_conv, const float* b_ih, const float* hh, const float* h_prev, float* h_new, float* xmax, int B, int H, int W,
+                       void* stream);
+int mrx_rim_layer2_f16_cb8(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                           float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream);
 /* Complex instance normalisation around a regulariser (models/sigmanet/sensitivity_net.py:16-139): m = mean of every real and imaginary entry,
  * C = 2x2 covariance of (re - m, im - m) per batch element (sums over per_b complex values, divided by `divisor` -- the reference's
  * shape[2] * shape[3] - 1); coef[b] = {m, C^(1/2) row-major, C^(-1/2) row-major} (9 floats).  center = 0 takes the data as mean-free.

@@ -155,6 +155,9 @@ _SIGNATURES = {
     "mrx_conv3x3_sb": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_rim_layer2_sb_taps": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_final_gather": ([_p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_cb8_convert": ([_p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_rim_layer1_cb8": ([_p, _i, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_rim_layer2_f16_cb8": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_cnorm_work_doubles": ([_i], _i64),
     "mrx_cnorm_stats": ([_p, _i, _i64, ctypes.c_double, _i, _p, _p, _p], _i),
     "mrx_cnorm_apply": ([_p, _p, _p, _i, _i, _i64, _p], _i),

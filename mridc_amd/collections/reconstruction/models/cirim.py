@@ -72,7 +72,7 @@ class CIRIM(torch.nn.Module):
                 hybrid = (hybrid, ops.llg372_prepare(hybrid, sensitivity_maps, m1, self.fft_centered))
         for i, cascade in enumerate(self.cirim):
             prediction, _ = cascade(prediction, y, sensitivity_maps, mask, init_pred, hx, sigma,
-                                    keep_eta=False if i == 0 else self.keep_eta, _hybrid=hybrid)
+                                    keep_eta=False if i == 0 else self.keep_eta, _hybrid=hybrid, _want_hx=False)
             time_steps_etas = [self.process_intermediate_pred(pred, sensitivity_maps, target) for pred in prediction]
             cascades_etas.append(time_steps_etas)
         yield cascades_etas

@@ -37,6 +37,9 @@ class RIMBlock(torch.nn.Module):
     layer2_f16 = _lib.arith() == "f16x2"
     fused_final = True
     inplace_state = True
+    # hidden states kept channel-blocked [B,8,H,W,8] between the two layer kernels of the _f16_route (mrx_rim_layer1_cb8, mrx_rim_layer2_f16_cb8:
+    # 16-byte state accesses, bit-identical results); states handed in / out are converted (mrx_cb8_convert)
+    cb8_states = True
 
     def __init__(self, recurrent_layer=None, conv_filters=None, conv_kernels=None, conv_dilations=None, conv_bias=None,
                  recurrent_filters=None, recurrent_kernels=None, recurrent_dilations=None, recurrent_bias=None,
@@ -318,8 +321,9 @@ class RIMBlock(torch.nn.Module):
 
     def forward(self, pred: torch.Tensor, masked_kspace: torch.Tensor, sense: torch.Tensor, mask: torch.Tensor,
                 eta: torch.Tensor = None, hx: torch.Tensor = None, sigma: float = 1.0, keep_eta: bool = False,
-                _hybrid: torch.Tensor = None) -> Tuple[Any, Union[list, torch.Tensor, None]]:
-        """rim_block.py:139-269.  Returns (list of time_steps estimates, hx)."""
+                _hybrid: torch.Tensor = None, _want_hx: bool = True) -> Tuple[Any, Union[list, torch.Tensor, None]]:
+        """rim_block.py:139-269.  Returns (list of time_steps estimates, hx).  `_want_hx` False (CIRIM, which drops the states of a cascade:
+        cirim.py:157-168): hx is returned as None instead of being converted back from the kernels' channel-blocked layout."""
         if self.dimensionality == 3:
             return self._forward_3d(pred, masked_kspace, sense, mask, eta, hx, sigma, keep_eta)
         if isinstance(pred, list):                                   # rim_block.py:185-186
@@ -364,8 +368,38 @@ class RIMBlock(torch.nn.Module):
                  and not (self.winograd and ops.rim_layer_wino_supported(4, l0.rnn.hidden_size, l0.convs.kernel_size, l0.convs.dilation)))
         # fp16 operand scale of the second stack: stack 0 folds the maximum of its outputs into this scalar (zeroed once per call: a running bound)
         xmax = torch.zeros(1, dtype=torch.float32, device=masked_kspace.device) if (masked_kspace.is_cuda and self._f16_route()) else None
+        cb8 = (xmax is not None and self.cb8_states and self._tail_fused() and l0.convs.input_size == 4
+               and all(h is None or h.shape[0] == eta.shape[0] for h in hx))
+        if cb8:
+            hx = [None if h is None else ops.cb8_from_nchw(h) for h in hx]   # (copies: ours to overwrite from step 0 on)
+            c0, r0, c1, r1 = l0.convs, l0.rnn, self.layers[1].convs, self.layers[1].rnn
         for step in range(self.time_steps):                          # rim_block.py:217-249
             own = step > 0                                           # the states of step 0 are the caller's (or the zero state)
+            if cb8:
+                part, nparts, grad_eta = None, 0, None
+                if defer and op372 is not None:
+                    part, nparts = ops.llg372(eta, op372, sigma, self.fft_normalization, parts=True)
+                elif defer and t4:
+                    part, nparts = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
+                                           self.spatial_dims, work=work, parts=True)
+                elif defer:
+                    grad_eta, part, nparts = ops.llg_hinv_parts(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
+                elif op372 is not None:
+                    grad_eta = ops.llg372(eta, op372, sigma, self.fft_normalization)
+                elif hinv:
+                    grad_eta = ops.llg_hinv(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
+                else:
+                    grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
+                                       self.spatial_dims, work=work)
+                llg_form = nparts > 0
+                hx[0] = ops.rim_layer1_cb8(None if llg_form else grad_eta, eta if llg_form else None, part, nparts, sigma, self._packed(0, c0, r0),
+                                           c0.conv_layer.bias, r0.ih.bias, r0.hh, hx[0], xmax,
+                                           out=hx[0] if (self.inplace_state and hx[0] is not None) else None)
+                hx[1], taps = ops.rim_layer2_f16_cb8(hx[0], self._packed_f16(1, c1, r1, final), c1.conv_layer.bias, r1.ih.bias, r1.hh, hx[1], xmax,
+                                                     out=hx[1] if (self.inplace_state and hx[1] is not None) else None, want_taps=True)
+                eta = ops.rim_final_gather(taps, final.conv_layer.bias, eta)
+                etas.append(eta)
+                continue
             if defer:
                 if op372 is not None:
                     part, nparts = ops.llg372(eta, op372, sigma, self.fft_normalization, parts=True)
@@ -394,6 +428,8 @@ class RIMBlock(torch.nn.Module):
             eta = self._layers_and_final(0, grad_eta, hx, eta, final, own, xmax)   # stacks, final conv, permute(0,2,3,1), eta + grad
             etas.append(eta)
         mask = full_mask
+        if cb8:
+            hx = [ops.cb8_to_nchw(h) for h in hx] if _want_hx else None
         if self.no_dc:                                               # rim_block.py:253-254
             return etas, hx
         if mask.dtype != torch.bool:

@@ -487,6 +487,7 @@ struct LlgSrc {
 };
 static thread_local LlgSrc g_llg_src = {nullptr, nullptr, 0, 0.f};
 static thread_local float* g_l1_xmax = nullptr;   // set by the _xmax entry points around the call
+static thread_local int g_l1_cb8 = 0;             // set by mrx_rim_layer1_cb8 around the call: channel-blocked h_prev / h_new
 
 extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, const float* b_conv, const float* b_ih,
                                            const float* hh, const float* h_prev, float* h_new, int B, int Cin, int F, int H,
@@ -537,10 +538,12 @@ extern "C" int mrx_rim_layer_indrnn_packed(const float* x, const float* packed, 
             s.xmax = reinterpret_cast<unsigned*>(g_l1_xmax);
             const int l1_f16 = mrx_arith() == MRX_ARITH_F16X2 ? 1 : 0;   // else the three-term bf16 form
             s.f16 = l1_f16;
+            s.cb8 = g_l1_cb8;
             return mrx_l1sb_launch(s, st);
         }
     }
     MRX_REQUIRE(!g_l1_xmax, MRX_EUNSUP, "mrx_rim_layer_indrnn_packed_xmax: only the split-bf16 first-layer kernel keeps the output bound");
+    MRX_REQUIRE(!g_l1_cb8, MRX_EUNSUP, "mrx_rim_layer1_cb8: only the two-term fp16 first-layer kernel writes channel-blocked states");
 #define RL_CASE(KK, DD)                                                       \
     if (k == KK && dil == DD)                                                 \
         return small ? launch_rim_layer<KK, DD, 4>(a, st) : launch_rim_layer<KK, DD, 8>(a, st);
@@ -947,5 +950,21 @@ extern "C" int mrx_rim_layer_indrnn_packed_llg_xmax(const float* eta, const floa
     g_l1_xmax = xmax;
     const int rc = mrx_rim_layer_indrnn_packed_llg(eta, part, nparts, inv_sigma2, packed, b_conv, b_ih, hh, h_prev, h_new, B, F, H, W, k, dil, stream);
     g_l1_xmax = nullptr;
+    return rc;
+}
+
+// The first layer of a RIM step on CHANNEL-BLOCKED hidden states (h_prev, h_new: [B][8][H][W][8]; mrx_cb8_convert): input either x [B,Cin<=4,H,W]
+// (eta NULL) or (eta, coil-group partial sums) as in mrx_rim_layer_indrnn_packed_llg; 5x5 convolution into 64 features + 1x1 IndRNN cell;
+// the maximum of the outputs is folded into *xmax (never reset here) for mrx_rim_layer2_f16_cb8's operand scale.  Bit-identical to the NCHW form.
+extern "C" int mrx_rim_layer1_cb8(const float* x, int Cin, const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed,
+                                  const float* b_conv, const float* b_ih, const float* hh, const float* h_prev, float* h_new, float* xmax, int B,
+                                  int H, int W, void* stream) {
+    MRX_REQUIRE(xmax && (x || eta), MRX_EINVAL, "mrx_rim_layer1_cb8: null pointer");
+    MRX_REQUIRE(mrx_rim_layer1_xmax_supported(eta ? 4 : Cin, 64, 5, 1) && mrx_arith() == MRX_ARITH_F16X2, MRX_EUNSUP,
+                "mrx_rim_layer1_cb8: needs the two-term fp16 first-layer kernel (MRIDC_AMD_ARITH=f16x2)");
+    g_l1_cb8 = 1;
+    const int rc = eta ? mrx_rim_layer_indrnn_packed_llg_xmax(eta, part, nparts, inv_sigma2, packed, b_conv, b_ih, hh, h_prev, h_new, xmax, B, 64, H, W, 5, 1, stream)
+                       : mrx_rim_layer_indrnn_packed_xmax(x, packed, b_conv, b_ih, hh, h_prev, h_new, xmax, B, Cin, 64, H, W, 5, 1, stream);
+    g_l1_cb8 = 0;
     return rc;
 }

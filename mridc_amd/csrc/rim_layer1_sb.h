@@ -20,6 +20,7 @@ struct MrxL1sbArgs {
     int nparts;
     float post;
     int f16;               // 1: two-term fp16 operands (per-unit / per-pixel scales), 0: three-term bf16
+    int cb8;               // 1: h_prev / h_new channel-blocked [B][8][H][W][8], 0: [B,64,H,W]
     unsigned* xmax;        // not null: atomic max of the bits of every output (outputs are >= 0: ReLU) -- the bound mrx_rim_layer2_f16 scales by
 };
 

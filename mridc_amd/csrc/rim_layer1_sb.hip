@@ -227,12 +227,14 @@ int mrx_l1sb_pack(const float* w_conv, const float* w_ih, float* packed, int Cin
 // F16: the operands as two fp16 terms (three term products per multiply instead of six) -- the patch scaled by the power of two that puts the
 // UNIT's largest input into [2^14, 2^15) (every input of the unit's outputs is in the wave's patch), ReLU(conv + b) scaled per PIXEL for the 1x1
 // stage (contraction over the pixel's channels only), the weights at pack time; the accumulators are scaled back exactly before the biases.
-template <bool F16>
+// CB8: h_prev / h_new channel-blocked, [b][c / 8][y][x][c % 8] -- registers 16 ct + 4 j .. + 3 of a lane are four consecutive channels of block
+// 4 ct + j: 8 + 8 16-byte state accesses per unit instead of 32 + 32 4-byte ones, every unit a 1 KB-aligned 1 KB block per channel block
+template <bool F16, bool CB8 = false>
 __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
     constexpr int NT = F16 ? 2 : 3, WCONV = F16 ? SBH_WCONV : SB_WCONV, WIH = F16 ? SBH_WIH : SB_WIH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];
     u32x4* Wl = reinterpret_cast<u32x4*>(smem_sb);                                        // [WCONV + WIH] A operands
-    float* tabl = reinterpret_cast<float*>(smem_sb + (WCONV + WIH) * 16);                 // hh, b_conv, b_ih in register order [R][half]
+    float* tabl = reinterpret_cast<float*>(smem_sb + (WCONV + WIH) * 16);                 // hh, b_conv, b_ih in register order [half][R]: a lane's 32 values are contiguous (the compiler merges them into 16-byte LDS reads)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     u32x2* Xw = reinterpret_cast<u32x2*>(smem_sb + (WCONV + WIH) * 16 + 256 * 4) + wave * (NT * SB_PSTR);   // this wave's patch
     const long long plane = (long long)a.H * a.W;
@@ -250,9 +252,10 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
         }
         if (tid < 64) {
             const int tc = sb_chan(tid >> 1, tid & 1);
-            tabl[tid] = a.hh[tc];
-            tabl[64 + tid] = a.b_conv ? a.b_conv[tc] : 0.f;
-            tabl[128 + tid] = a.b_ih ? a.b_ih[tc] : 0.f;
+            const int ti = (tid & 1) * 32 + (tid >> 1);
+            tabl[ti] = a.hh[tc];
+            tabl[64 + ti] = a.b_conv ? a.b_conv[tc] : 0.f;
+            tabl[128 + ti] = a.b_ih ? a.b_ih[tc] : 0.f;
             tabl[192 + tid] = a.hh[tid];          // channel order (wide epilogue)
         }
 #pragma unroll
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = F16 ? 0.f : tabl[64 + 2 * (ct * 16 + r) + lhi];
+            for (int r = 0; r < 16; ++r) acc[ct][r] = F16 ? 0.f : tabl[64 + lhi * 32 + ct * 16 + r];
         {
             const u32x2* xw = Xw + l31;
             const u32x4* wl = Wl + lane;
@@ -420,20 +423,37 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][r] = acc[ct][r] * un + tabl[64 + 2 * (ct * 16 + r) + lhi];
+                for (int r = 0; r < 16; ++r) acc[ct][r] = acc[ct][r] * un + tabl[64 + lhi * 32 + ct * 16 + r];
         }
 
         // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev) ------------------------------------------------------------
         // h_prev is requested in four groups of eight, each after the 1x1 step that frees eight registers of g; lanes outside the image read a
         // valid element (clamped) and store nothing; without h_prev the loads go to h_new and are ignored
         const int ox = w0 + l31, cx = ox < a.W ? ox : a.W - 1;
-        const float* hb = (a.hprev ? a.hprev : a.hnew) + (long long)b * SB_F * plane + (long long)oy * a.W + cx + 4ll * lhi * plane;
+        const float* hb = (a.hprev ? a.hprev : a.hnew) + (long long)b * SB_F * plane +
+                          (CB8 ? ((long long)oy * a.W + cx) * 8 + 4 * lhi : (long long)oy * a.W + cx + 4ll * lhi * plane);
         float hp[32];
+        auto load_hp8 = [&](int s) {          // registers 8 s .. 8 s + 7
+            if constexpr (CB8) {
+                // (all eight 16-byte loads go out together behind the 1x1 stage, when g's registers are free: requested group by group
+                // beside it they need aligned register quads the allocator does not have -- 44 spilled registers, 15 us)
+                if (s == SB_KS2 - 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float4 u = *reinterpret_cast<const float4*>(hb + (long long)q * plane * 8);
+                        hp[4 * q] = u.x, hp[4 * q + 1] = u.y, hp[4 * q + 2] = u.z, hp[4 * q + 3] = u.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int R = 8 * s; R < 8 * s + 8; ++R) hp[R] = hb[(long long)sb_chan(R, 0) * plane];
+            }
+        };
         f32x16 acc2[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[ct][r] = F16 ? 0.f : tabl[128 + 2 * (ct * 16 + r) + lhi];
+            for (int r = 0; r < 16; ++r) acc2[ct][r] = F16 ? 0.f : tabl[128 + lhi * 32 + ct * 16 + r];
         if constexpr (F16) {
             // per-pixel scale: the pixel's 64 channels sit in this lane and in lane ^ 32; a lane's accumulators belong to its own pixel
             float gm = 0.f;
@@ -454,8 +474,7 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
                     v1 = v1 > 0.f ? v1 : 0.f;
                     sb_split2h(v0 * sg, v1 * sg, g1[q], g2[q]);
                 }
-#pragma unroll
-                for (int R = 8 * s; R < 8 * s + 8; ++R) hp[R] = hb[(long long)sb_chan(R, 0) * plane];
+                load_hp8(s);
                 const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
                 const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
                 f16x8 at[2][2];
@@ -468,7 +487,7 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[ct][r] = acc2[ct][r] * ung + tabl[128 + 2 * (ct * 16 + r) + lhi];
+                for (int r = 0; r < 16; ++r) acc2[ct][r] = acc2[ct][r] * ung + tabl[128 + lhi * 32 + ct * 16 + r];
         } else {
             const u32x4* wl = Wl + SB_WCONV + lane;
 #pragma unroll
@@ -482,8 +501,7 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
                     v1 = v1 > 0.f ? v1 : 0.f;
                     sb_split2(v0, v1, g1[q], g2[q], g3[q]);
                 }
-#pragma unroll
-                for (int R = 8 * s; R < 8 * s + 8; ++R) hp[R] = hb[(long long)sb_chan(R, 0) * plane];
+                load_hp8(s);
                 const bf16x8 b1 = __builtin_bit_cast(bf16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
                 const bf16x8 b2 = __builtin_bit_cast(bf16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
                 const bf16x8 b3 = __builtin_bit_cast(bf16x8, (u32x4{g3[0], g3[1], g3[2], g3[3]}));
@@ -498,14 +516,30 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
 
         // ---- epilogue: 128-byte rows per wave instruction ---------------------------------------------------------------------------------------
         if (ox < a.W) {
-            float* ob = a.hnew + (long long)b * SB_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
             const bool first = a.hprev == nullptr;
+            if constexpr (CB8) {
+                float* ob = a.hnew + (long long)b * SB_F * plane + ((long long)oy * a.W + ox) * 8 + 4 * lhi;
 #pragma unroll
-            for (int R = 0; R < 32; ++R) {
-                float v = acc2[R >> 4][R & 15] + tabl[2 * R + lhi] * (first ? 0.f : hp[R]);
-                v = v > 0.f ? v : 0.f;
-                ob[(long long)sb_chan(R, 0) * plane] = v;
-                wmax = fmaxf(wmax, v);
+                for (int q = 0; q < 8; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int R = 4 * q + i;
+                        v[i] = acc2[R >> 4][R & 15] + tabl[lhi * 32 + R] * (first ? 0.f : hp[R]);
+                        v[i] = v[i] > 0.f ? v[i] : 0.f;
+                        wmax = fmaxf(wmax, v[i]);
+                    }
+                    *reinterpret_cast<float4*>(ob + (long long)q * plane * 8) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+                float* ob = a.hnew + (long long)b * SB_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
+#pragma unroll
+                for (int R = 0; R < 32; ++R) {
+                    float v = acc2[R >> 4][R & 15] + tabl[lhi * 32 + R] * (first ? 0.f : hp[R]);
+                    v = v > 0.f ? v : 0.f;
+                    ob[(long long)sb_chan(R, 0) * plane] = v;
+                    wmax = fmaxf(wmax, v);
+                }
             }
         }
     }
@@ -525,6 +559,7 @@ int mrx_l1sb_launch(const MrxL1sbArgs& a, hipStream_t st) {
     if (!attr_done) {
         MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer1_sb<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer1_sb<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer1_sb<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         hipDeviceProp_t prop;
         MRX_HIP(hipGetDevice(&dev));
@@ -534,7 +569,13 @@ int mrx_l1sb_launch(const MrxL1sbArgs& a, hipStream_t st) {
     }
     const long long total = (long long)a.ntiles * a.B;
     const int grid = (int)(total < ncu ? total : ncu);     // one persistent workgroup per CU (a multiple of 8: the XCD band map keeps its meaning)
-    if (a.f16)
+    if (a.cb8) {
+        if (!a.f16) {
+            mrx_set_error("mrx_rim_layer1_cb8: the channel-blocked state layout exists for the two-term fp16 kernel only (MRIDC_AMD_ARITH=f16x2)");
+            return MRX_EUNSUP;
+        }
+        hipLaunchKernelGGL((k_rim_layer1_sb<true, true>), dim3(grid), dim3(SB_NT), lds, st, a);
+    } else if (a.f16)
         hipLaunchKernelGGL(k_rim_layer1_sb<true>, dim3(grid), dim3(SB_NT), lds, st, a);
     else
         hipLaunchKernelGGL(k_rim_layer1_sb<false>, dim3(grid), dim3(SB_NT), lds, st, a);

@@ -285,7 +285,10 @@ __device__ __forceinline__ int s2_pixel_exp(float m) {
 // ABL (probe builds only, -DMRX_PROBE + env MRX_L2_ABL): phases switched off to price them -- 1 no x loads, 2 no operand split, 4 no LDS
 // staging writes, 8 no convolution MFMAs, 16 no tail, 32 no LDS operand reads, 64 no barriers, 128 no h_prev loads, 256 no stores, 512 no tap
 // stage.  Results are garbage; only the time is read.
-template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0>
+// CB8: x, h_prev and h_new are channel-blocked, [b][c / 8][y][x][c % 8] (mrx_cb8_convert): a pixel's eight channels of a chunk are 32 contiguous
+// bytes for the loader (2 x 16-byte loads instead of 8 x 4 from eight planes), registers 4 q .. 4 q + 3 of a lane are four consecutive channels of
+// block q (8 + 8 16-byte state accesses per row instead of 32 + 32 4-byte ones).  The arithmetic is unchanged: results are bit-identical.
+template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false>
 __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     constexpr int S2_PAD = DIL, S2_PH = S2_TH + 2 * DIL, S2_PW = S2_TW + 2 * DIL, S2_NPIX = S2_PH * S2_PW;
     constexpr int NT = F16 ? 2 : 3;                                        // operand terms of the convolution stage
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     constexpr int PK_TAIL = S2_NCH * WCH;                                  // where the 1x1 / final-conv operands start in the pack
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
     u32x4* Wih = reinterpret_cast<u32x4*>(smem_s2);
-    float* tabl = reinterpret_cast<float*>(smem_s2 + S2_OFF_TAB);      // hh, b_conv, b_ih in register order [R][half]
+    float* tabl = reinterpret_cast<float*>(smem_s2 + S2_OFF_TAB);      // hh, b_conv, b_ih in register order [half][R] (a lane's 32 values contiguous: 16-byte LDS reads)
     u32x4* Wc = reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_W);          // [2][S2_WCH]
     u32x4* Xp = reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_X);          // [2][NT terms][S2_NPIX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -314,9 +317,10 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     if (tid == 0) *reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_ZERO) = u32x4{0u, 0u, 0u, 0u};
     if (tid < 64) {
         const int tc = s2_chan(tid >> 1, tid & 1);
-        tabl[tid] = a.hh ? a.hh[tc] : 0.f;
-        tabl[64 + tid] = a.b_conv ? a.b_conv[tc] : 0.f;
-        tabl[128 + tid] = a.b_ih ? a.b_ih[tc] : 0.f;
+        const int ti = (tid & 1) * 32 + (tid >> 1);
+        tabl[ti] = a.hh ? a.hh[tc] : 0.f;
+        tabl[64 + ti] = a.b_conv ? a.b_conv[tc] : 0.f;
+        tabl[128 + ti] = a.b_ih ? a.b_ih[tc] : 0.f;
     }
 
     // staging roles: thread i owns pixels i and i + 512 of the halo'd tile (8 channels of the chunk) and copies <= 4 weight operands
@@ -363,7 +367,12 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if constexpr ((ABL & 1) != 0) asm volatile("v_mov_b32 %0, 1.0" : "=v"(xr[v][j]));
-                else xr[v][j] = st_xb[(long long)(8 * st_q + j) * plane + goff[v]];
+                else if constexpr (CB8) {
+                    if ((j & 3) == 0) {
+                        const float4 u = *reinterpret_cast<const float4*>(st_xb + ((long long)st_q * plane + goff[v]) * 8 + j);
+                        xr[v][j] = u.x, xr[v][j + 1] = u.y, xr[v][j + 2] = u.z, xr[v][j + 3] = u.w;
+                    }
+                } else xr[v][j] = st_xb[(long long)(8 * st_q + j) * plane + goff[v]];
             }
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rw][ct][r] = F16 ? 0.f : tabl[64 + 2 * (ct * 16 + r) + lhi];
+                for (int r = 0; r < 16; ++r) acc[rw][ct][r] = F16 ? 0.f : tabl[64 + lhi * 32 + ct * 16 + r];
 
         float hp[2][32];
         auto load_hp = [&](int rw) {              // lanes outside the image read a valid element (clamped) and store nothing
@@ -443,6 +452,15 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             if (!a.hprev) {                       // the zero state: nothing to load (and nothing uninitialised to multiply by zero)
 #pragma unroll
                 for (int R = 0; R < 32; ++R) hp[rw][R] = 0.f;
+                return;
+            }
+            if constexpr (CB8) {
+                const float* hb = a.hprev + (long long)b * S2_F * plane + ((long long)cy * a.W + cx) * 8 + 4 * lhi;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 u = *reinterpret_cast<const float4*>(hb + (long long)q * plane * 8);
+                    hp[rw][4 * q] = u.x, hp[rw][4 * q + 1] = u.y, hp[rw][4 * q + 2] = u.z, hp[rw][4 * q + 3] = u.w;
+                }
                 return;
             }
             const float* hb = a.hprev + (long long)b * S2_F * plane + (long long)cy * a.W + cx + 4ll * lhi * plane;
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[rw][ct][r] = acc[rw][ct][r] * unx * unw + tabl[64 + 2 * (ct * 16 + r) + lhi];
+                    for (int r = 0; r < 16; ++r) acc[rw][ct][r] = acc[rw][ct][r] * unx * unw + tabl[64 + lhi * 32 + ct * 16 + r];
         }
         S2_STAMP(1)
         if constexpr ((ABL & 16) != 0) {
@@ -556,7 +574,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[ct][r] = F16 ? 0.f : tabl[128 + 2 * (ct * 16 + r) + lhi];
+                for (int r = 0; r < 16; ++r) acc2[ct][r] = F16 ? 0.f : tabl[128 + lhi * 32 + ct * 16 + r];
             const u32x4* wl = Wih + lane;
             if constexpr (F16) {
                 // two fp16 terms, scaled per PIXEL: the contraction runs over the pixel's 64 channels only (this lane's 32 and lane ^ 32's)
@@ -588,7 +606,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[ct][r] = acc2[ct][r] * ung * unwi + tabl[128 + 2 * (ct * 16 + r) + lhi];
+                    for (int r = 0; r < 16; ++r) acc2[ct][r] = acc2[ct][r] * ung * unwi + tabl[128 + lhi * 32 + ct * 16 + r];
             } else
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -618,7 +636,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                 float* ob = a.hnew + (long long)b * S2_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
 #pragma unroll
                 for (int R = 0; R < 32; ++R) {
-                    float v = acc2[R >> 4][R & 15] + tabl[2 * R + lhi] * hp[rw][R];
+                    float v = acc2[R >> 4][R & 15] + tabl[lhi * 32 + R] * hp[rw][R];
                     hp[rw][R] = v > 0.f ? v : 0.f;
                 }
                 if constexpr ((ABL & 256) != 0) {
@@ -631,8 +649,15 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                         if (inside) ob[(long long)s2_chan(R, 0) * plane] = hp[rw][R];
                     }
                 } else if (inside) {
+                    if constexpr (CB8) {
+                        float* oc = a.hnew + (long long)b * S2_F * plane + ((long long)oy * a.W + ox) * 8 + 4 * lhi;
 #pragma unroll
-                    for (int R = 0; R < 32; ++R) ob[(long long)s2_chan(R, 0) * plane] = hp[rw][R];
+                        for (int q = 0; q < 8; ++q)
+                            *reinterpret_cast<float4*>(oc + (long long)q * plane * 8) = make_float4(hp[rw][4 * q], hp[rw][4 * q + 1], hp[rw][4 * q + 2], hp[rw][4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int R = 0; R < 32; ++R) ob[(long long)s2_chan(R, 0) * plane] = hp[rw][R];
+                    }
                 }
             }
             if (a.P && !(ABL & 512)) {
@@ -739,11 +764,11 @@ static int l2sb_ncu() {
     }
     return ncu;
 }
-template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0>
+template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false>
 static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
     static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
         attr_done = true;
     }
     const int ncu = l2sb_ncu();
@@ -756,7 +781,7 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, st);
         a.trace = d_trace;
     }
-    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL>), dim3(grid), dim3(S2_NT), S2_LDS, st, a);
+    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8>), dim3(grid), dim3(S2_NT), S2_LDS, st, a);
     MRX_LAUNCH_CHECK();
     if (a.trace) {
         (void)hipStreamSynchronize(st);
@@ -778,7 +803,7 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
     return MRX_OK;
 }
 static int l2sb_launch(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
-                       float* h_new, float* P, int B, int H, int W, void* stream, const float* xmax = nullptr) {
+                       float* h_new, float* P, int B, int H, int W, void* stream, const float* xmax = nullptr, bool cb8 = false) {
     MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer2_sb: null pointer");
     MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer2_sb: bad dims");
     if (B == 0) return MRX_OK;
@@ -799,6 +824,8 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
         }
     }
 #endif
+    if (xmax && cb8) return l2sb_launch_t<2, true, false, true, 0, true>(a, (hipStream_t)stream);
+    MRX_REQUIRE(!cb8, MRX_EUNSUP, "mrx_rim_layer2_f16_cb8: the channel-blocked layout exists for the two-term fp16 form only");
     if (xmax) return l2sb_launch_t<2, true, false, true>(a, (hipStream_t)stream);
     return l2sb_launch_t<2, true, false>(a, (hipStream_t)stream);
 }
@@ -888,6 +915,42 @@ extern "C" int mrx_rim_layer2_f16(const float* x, const float* packed, const flo
                                   const float* h_prev, float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream) {
     MRX_REQUIRE(xmax, MRX_EINVAL, "mrx_rim_layer2_f16: null pointer");
     return l2sb_launch(x, packed, b_conv, b_ih, hh, h_prev, h_new, taps, B, H, W, stream, xmax);
+}
+
+// mrx_rim_layer2_f16 on channel-blocked tensors: x, h_prev, h_new are [B][8][H][W][8] (mrx_cb8_convert); taps stays [B][18][H][W]
+extern "C" int mrx_rim_layer2_f16_cb8(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
+                                      const float* h_prev, float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(xmax, MRX_EINVAL, "mrx_rim_layer2_f16_cb8: null pointer");
+    return l2sb_launch(x, packed, b_conv, b_ih, hh, h_prev, h_new, taps, B, H, W, stream, xmax, true);
+}
+
+// NCHW <-> channel-blocked: one thread per (pixel, block of 8 channels); to_cb8 = 1: y[b][q][p][j] = x[b][8 q + j][p], else the inverse
+__global__ void k_cb8_convert(const float* __restrict__ x, float* __restrict__ y, long long plane, int nblk, int to_cb8) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y, b = blockIdx.z;
+    if (p >= plane) return;
+    const long long base = ((long long)b * nblk + q) * 8 * plane;
+    if (to_cb8) {
+        float4 lo, hi;
+        lo.x = x[base + p], lo.y = x[base + plane + p], lo.z = x[base + 2 * plane + p], lo.w = x[base + 3 * plane + p];
+        hi.x = x[base + 4 * plane + p], hi.y = x[base + 5 * plane + p], hi.z = x[base + 6 * plane + p], hi.w = x[base + 7 * plane + p];
+        float4* d = reinterpret_cast<float4*>(y + base + p * 8);
+        d[0] = lo, d[1] = hi;
+    } else {
+        const float4* sp = reinterpret_cast<const float4*>(x + base + p * 8);
+        const float4 lo = sp[0], hi = sp[1];
+        y[base + p] = lo.x, y[base + plane + p] = lo.y, y[base + 2 * plane + p] = lo.z, y[base + 3 * plane + p] = lo.w;
+        y[base + 4 * plane + p] = hi.x, y[base + 5 * plane + p] = hi.y, y[base + 6 * plane + p] = hi.z, y[base + 7 * plane + p] = hi.w;
+    }
+}
+extern "C" int mrx_cb8_convert(const float* x, float* y, int B, int C, int H, int W, int to_cb8, void* stream) {
+    MRX_REQUIRE(x && y && x != y, MRX_EINVAL, "mrx_cb8_convert: null or aliased pointers");
+    MRX_REQUIRE(B >= 0 && C >= 8 && C % 8 == 0 && H >= 1 && W >= 1 && B <= 65535, MRX_EINVAL, "mrx_cb8_convert: bad dims");
+    if (B == 0) return MRX_OK;
+    const long long plane = (long long)H * W;
+    hipLaunchKernelGGL(k_cb8_convert, dim3((unsigned)((plane + 255) / 256), C / 8, B), dim3(256), 0, (hipStream_t)stream, x, y, plane, C / 8, to_cb8 ? 1 : 0);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
 }
 
 extern "C" int mrx_rim_final_gather(const float* taps, const float* b_final, const float* eta, float* eta_out, int B, int H, int W, void* stream) {

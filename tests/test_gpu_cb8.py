@@ -1,0 +1,95 @@
+"""Channel-blocked hidden states h[b][c / 8][y][x][c % 8] of the two RIM layer kernels (mrx_cb8_convert, mrx_rim_layer1_cb8,
+mrx_rim_layer2_f16_cb8): the layout between the kernels of a time-step is free (rim_block.py:230-246 only hands states from step to step), the
+arithmetic is that of the NCHW entry points, so every result must be BIT-identical to theirs -- operation by operation and for a whole cascade."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F_ = 64
+SHAPES = [(1, 640, 372), (2, 37, 75), (1, 19, 33), (3, 16, 32), (1, 5, 3), (1, 1, 1)]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_layout_round_trip(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for B, C, H, W in ((1, 64, 640, 372), (2, 16, 7, 13), (3, 8, 1, 1)):
+        x = torch.randn(B, C, H, W, generator=g).to(dev)
+        y = ops.cb8_from_nchw(x)
+        assert tuple(y.shape) == (B, C // 8, H, W, 8)
+        assert torch.equal(y, x.view(B, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous())
+        assert torch.equal(ops.cb8_to_nchw(y), x)
+    with pytest.raises(RuntimeError):
+        ops.cb8_from_nchw(torch.zeros(1, 12, 4, 4, device=dev))      # channels must come in blocks of eight
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_both_layers_bit_identical_to_the_nchw_kernels(shape, dev):
+    from mridc_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(3 + sum(shape))
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    x4, hp = r(B, 4, H, W), r(B, F_, H, W).relu()
+    eta, part = r(B, H, W, 2), r(3, B, H, W, 2)
+    w1, wi1 = r(F_, 4, 5, 5) / 10, r(F_, F_, 1, 1) / 8
+    w2, wi2, wf = r(F_, F_, 3, 3) / 24, r(F_, F_, 1, 1) / 8, r(2, F_, 3, 3) / 24
+    bc, bi, hh = r(F_) * 0.1, r(F_) * 0.1, r(1, F_, 1, 1) * 0.5
+    pk1, pk2 = ops.rim_layer_pack(w1, wi1), ops.rim_layer2_f16_pack(w2, wi2, wf)
+    hpc = ops.cb8_from_nchw(hp)
+    for state, statec in ((hp, hpc), (None, None)):
+        xm, xmc = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        ref1 = ops.rim_layer_indrnn_packed(x4, pk1, F_, 5, 1, bc, bi, hh, state, xmax=xm)
+        got1 = ops.rim_layer1_cb8(x4, None, None, 0, 1.0, pk1, bc, bi, hh, statec, xmc)
+        assert torch.equal(ops.cb8_to_nchw(got1), ref1) and torch.equal(xm, xmc)
+        ref1l = ops.rim_layer_indrnn_packed_llg(eta, part, 3, 0.9, pk1, F_, 5, 1, bc, bi, hh, state, xmax=xm)
+        got1l = ops.rim_layer1_cb8(None, eta, part, 3, 0.9, pk1, bc, bi, hh, statec, xmc)
+        assert torch.equal(ops.cb8_to_nchw(got1l), ref1l) and torch.equal(xm, xmc)
+        ref2, taps = ops.rim_layer2_f16(ref1, pk2, bc, bi, hh, state, xm, want_taps=True)
+        got2, tapsc = ops.rim_layer2_f16_cb8(got1, pk2, bc, bi, hh, statec, xmc, want_taps=True)
+        assert torch.equal(ops.cb8_to_nchw(got2), ref2) and torch.equal(tapsc, taps)
+        assert torch.equal(ops.cb8_to_nchw(ops.rim_layer2_f16_cb8(got1, pk2, bc, bi, hh, statec, xmc)), ref2)     # without the tap stage
+    # in place: the new state over the old one
+    xm = torch.zeros(1, device=dev)
+    ref1 = ops.rim_layer_indrnn_packed(x4, pk1, F_, 5, 1, bc, bi, hh, hp, xmax=xm)
+    ref2 = ops.rim_layer2_f16(ref1, pk2, bc, bi, hh, hp, xm)
+    s1, s2 = hpc.clone(), hpc.clone()
+    assert ops.rim_layer1_cb8(x4, None, None, 0, 1.0, pk1, bc, bi, hh, s1, xm, out=s1) is s1
+    ops.rim_layer2_f16_cb8(s1, pk2, bc, bi, hh, s2, xm, out=s2)
+    assert torch.equal(ops.cb8_to_nchw(s1), ref1) and torch.equal(ops.cb8_to_nchw(s2), ref2)
+
+
+@pytest.mark.parametrize("mask_kind", ["1d", "2d"])
+def test_cascade_on_channel_blocked_states_is_bit_identical(dev, mask_kind):
+    """RIMBlock.forward with cb8_states on and off: the same estimates at every time-step and the same states handed back (converted), with
+    states passed in from a previous call as well."""
+    from mridc_amd import synthetic
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    torch.manual_seed(0)
+    model = CIRIM(dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=1)).eval().to(dev)
+    blk = model.cirim[0]
+    assert blk._f16_route() and blk.cb8_states
+    d = {k: v.to(dev) for k, v in synthetic.make_slice(4, 40, 372 if mask_kind == "2d" else 64, slice_idx=1).items()}
+    mask = d["mask"]
+    if mask_kind == "2d":
+        gen = torch.Generator().manual_seed(7)
+        mask = (torch.rand(1, 1, 40, 372, 1, generator=gen) < 0.3).to(dev)
+    y = d["y"] * mask
+    with torch.no_grad():
+        e1, h1 = blk(y, y, d["sensitivity_maps"], mask)
+        e1b, h1b = blk(y, y, d["sensitivity_maps"], mask, hx=h1)
+        try:
+            blk.cb8_states = False
+            e0, h0 = blk(y, y, d["sensitivity_maps"], mask)
+            e0b, h0b = blk(y, y, d["sensitivity_maps"], mask, hx=h0)
+        finally:
+            del blk.cb8_states
+        _, none = blk(y, y, d["sensitivity_maps"], mask, _want_hx=False)
+    assert none is None
+    for a, b in zip(e1 + e1b + list(h1) + list(h1b), e0 + e0b + list(h0) + list(h0b)):
+        assert a.shape == b.shape and torch.equal(a, b)

@@ -89,20 +89,21 @@ def test_rim_block_zeroes_the_bound_every_cascade(dev):
     d = {k: v.to(dev) for k, v in synthetic.make_slice(4, 32, 64, slice_idx=2).items()}
     seen = []
     import mridc_amd.ops as ops_mod
-    orig = ops_mod.rim_layer2_f16
+    name = "rim_layer2_f16_cb8" if blk.cb8_states else "rim_layer2_f16"
+    orig = getattr(ops_mod, name)
 
     def spy(x, packed, b_conv, b_ih, hh, h_prev, xmax, **kw):
         seen.append(xmax)
         return orig(x, packed, b_conv, b_ih, hh, h_prev, xmax, **kw)
 
-    ops_mod.rim_layer2_f16 = spy
+    setattr(ops_mod, name, spy)
     try:
         with torch.no_grad():
             blk(d["y"], d["y"], d["sensitivity_maps"], d["mask"])
             n1 = len(seen)
             blk(d["y"] * 1e-4, d["y"] * 1e-4, d["sensitivity_maps"], d["mask"])
     finally:
-        ops_mod.rim_layer2_f16 = orig
+        setattr(ops_mod, name, orig)
     assert n1 == blk.time_steps and len(seen) == 2 * n1
     assert all(t is seen[0] for t in seen[:n1]) and all(t is seen[n1] for t in seen[n1:]) and seen[n1] is not seen[0]   # one scalar per call
     first, second = float(seen[0]), float(seen[n1])                    # (read after both calls: the final bound of each)
