@@ -747,7 +747,7 @@ def exact_route_line(args):
         return dict(value=None, error=f"{type(ex).__name__}: {ex}")
 
 
-def streamed_inputs_run(args, step, hosts, datas, dev, slices_per_step):
+def streamed_inputs_run(args, step, hosts, datas, dev, slices_per_step, variant="full"):
     """The headline with a new slice per replay: (y, S, mask, target) of the NEXT slice travel from pinned host memory to a staging
     buffer on a copy stream while the current one reconstructs; the compute stream then copies staging -> the graph's static inputs
     (device to device, inside the stream order) and replays.  Reports slices/s beside the resident-input figure."""
@@ -772,6 +772,8 @@ def streamed_inputs_run(args, step, hosts, datas, dev, slices_per_step):
     freed = [[torch.cuda.Event() for _ in range(2)] for _ in range(NS)]
 
     def upload(i, slot, src):
+        if variant == "no_h2d":
+            return
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(freed[i][slot])
             for k in keys:
@@ -789,9 +791,11 @@ def streamed_inputs_run(args, step, hosts, datas, dev, slices_per_step):
         for i, st in enumerate(streams):
             upload(i, slot ^ 1, pinned[(i + n + 1) % NS])              # the slice after this one
             with torch.cuda.stream(st):
-                st.wait_event(landed[i][slot])
-                for k in keys:
-                    datas[i][k].copy_(staging[i][slot][k], non_blocking=True)
+                if variant not in ("no_h2d", "no_wait"):
+                    st.wait_event(landed[i][slot])
+                if variant != "no_d2d":
+                    for k in keys:
+                        datas[i][k].copy_(staging[i][slot][k], non_blocking=True)
                 freed[i][slot].record(st)
                 graphs[i].replay()
     torch.cuda.synchronize()
@@ -894,6 +898,8 @@ def main():
     timer.wrap(ops, "rim_layer2_sb", lambda x, *a, **k: "conv_layer2_sb")
     timer.wrap(ops, "rim_layer2_sb_taps", lambda x, *a, **k: "conv_layer2_sbt")     # + the final convolution's channel contraction in its tail
     timer.wrap(ops, "rim_layer2_f16", lambda x, *a, **k: "conv_layer2_f16t" if k.get("want_taps") else "conv_layer2_f16")   # two-term fp16 conv operands
+    timer.wrap(ops, "rim_layer2_f16_cb8", lambda x, *a, **k: "conv_layer2_f16t" if k.get("want_taps") else "conv_layer2_f16")   # channel-blocked states
+    timer.wrap(ops, "rim_layer1_cb8", lambda *a, **k: "conv_layer1")
     timer.wrap(ops, "rim_final_gather", lambda *a, **k: "final_gather")
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
@@ -1008,7 +1014,7 @@ def main():
         l2_f16 = bool(msh)
         if msh:                               # the default: the convolution's operands as two fp16 terms, three term products per multiply
             ms2, n2, l2_bf16, peak2, l2_taps = msh, nsh, True, PEAK_BF16_MFMA_TFLOPS, True
-            kname = ("k_rim_layer2_sb<.., F16> (conv3x3 d2 64->64 direct form + IndRNN 1x1 fused + the channel contraction of the final 3x3 64->2 "
+            kname = ("k_rim_layer2_sb<.., F16, CB8> (hidden states channel-blocked [B,8,H,W,8]; conv3x3 d2 64->64 direct form + IndRNN 1x1 fused + the channel contraction of the final 3x3 64->2 "
                      "convolution on the new state; convolution operands = 2 fp16 terms scaled by powers of two (x by the bound of its maximum that "
                      "layer 1 keeps, w at pack time), 3 term products per multiply on v_mfma_f32_32x32x16_f16, fp32 accumulation: error against "
                      "float64 2.3e-7 (three-term bf16 form 2.8e-7, fp32 Winograd 2.0e-7); 36 steps x 6 MFMAs + the 1x1 and tap stages with two fp16 terms "
@@ -1124,6 +1130,9 @@ def main():
             res["exact_fp32_route"] = exact_route_line(args)
         if world == 1 and args.stream_inputs:
             res["streamed_inputs"] = streamed_inputs_run(args, step, hosts, datas, dev, NS * B)
+            if os.environ.get("MRX_BENCH_STREAM_PROBE"):     # which part of the streamed loop costs what (upload, staging copy, event wait)
+                for v in ("no_h2d", "no_d2d", "no_wait", "full"):
+                    print("[stream probe]", v, round(streamed_inputs_run(args, step, hosts, datas, dev, NS * B, variant=v)["value"], 2), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_cascades if 0 < args.cpu_cascades <= cfg["num_cascades"] else cfg["num_cascades"]
             try:

@@ -26,11 +26,12 @@ pk2h = ops.rim_layer2_f16_pack(wc, wi, wf)
 xmax = torch.zeros(1, device=dev)
 taps = torch.empty(B, 18, H, W, device=dev)
 work = torch.empty_like(y)
+hpc = ops.cb8_from_nchw(hp)
 torch.cuda.synchronize()
 for _ in range(3):
     part, n = ops.llg372(eta, op, 1.0, "backward", parts=True)
-    h1 = ops.rim_layer_indrnn_packed_llg(eta, part, n, 1.0, pk1, F, 5, 1, bc, bi, hh, hp, xmax=xmax)      # (keeps the bound of its outputs in xmax)
-    ops.rim_layer2_f16(h1, pk2h, bc, bi, hh, hp, xmax, taps=taps, want_taps=True)                       # the headline loop's form
+    h1 = ops.rim_layer1_cb8(None, eta, part, n, 1.0, pk1, bc, bi, hh, hpc, xmax)                          # (keeps the bound of its outputs in xmax)
+    ops.rim_layer2_f16_cb8(h1, pk2h, bc, bi, hh, hpc, xmax, taps=taps, want_taps=True)                  # the headline loop's form (channel-blocked states)
     ops.rim_layer_indrnn_wino(x, pk, F, bc, bi, hh, hp)
     ops.rim_layer2_sb_taps(x, pk2, bc, bi, hh, hp, taps)      # the three-term bf16 form (MRIDC_AMD_ARITH=bf16x3)
     ops.rim_final_gather(taps, None, eta)
