@@ -610,6 +610,16 @@ int mrx_recon_metrics(const float* target, const float* output, float* out5, flo
 int64_t mrx_unet_conv3x3_work_floats(int B, int Cout, int H, int W);
 int mrx_unet_conv3x3(const float* xa, const float* na, int Ca, const float* xb, const float* nb, int Cb, const float* w, float* y,
                      float* norm, float* work, int B, int Cout, int H, int W, float eps, float slope, void* stream);
+/* mrx_unet_conv3x3 on the fp16 matrix pipe (csrc/unet_f16.hip): every fp32 operand as two fp16 terms scaled by a power of two, three term products
+ * per multiply, fp32 accumulation -- fp32-level results (the arithmetic of mrx_rim_layer2_f16) at 1/5 of the matrix cycles of the fp32-input MFMA form.
+ *   mrx_unet_conv3x3_pack : w [Cout, Ca + Cb, 3, 3] -> operand pack (mrx_unet_conv3x3_pack_floats(Cout, Ca + Cb) floats, 16-byte aligned);
+ *   bound_a / bound_b     : device scalars >= max |x| of a PLAIN source (NULL allowed for a (raw, norm) source: an instance-normalised plane of
+ *                           n values is bounded by sqrt(n), no pass over the data needed).
+ * MRX_EUNSUP unless MRIDC_AMD_ARITH is f16x2 (the default). */
+int64_t mrx_unet_conv3x3_pack_floats(int Cout, int Ctot);
+int mrx_unet_conv3x3_pack(const float* w, int Cout, int Ctot, float* packed, void* stream);
+int mrx_unet_conv3x3_h(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b, int Cb,
+                       const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps, float slope, void* stream);
 int64_t mrx_unet_conv_transpose2x2_work_floats(int B, int Cout, int H, int W);
 int mrx_unet_conv_transpose2x2(const float* x, const float* nrm, const float* w, float* out, float* norm, float* work, int B, int Cin, int Cout,
                       int H, int W, float eps, float slope, void* stream);

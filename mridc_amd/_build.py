@@ -29,6 +29,7 @@ SOURCES = [
     ("conv_sbs.hip", []),
     ("unet.hip", []),
     ("unet_fused.hip", []),
+    ("unet_f16.hip", []),
     ("qmri.hip", ["-ffp-contract=off"]),
     ("cnorm.hip", []),
 ]

@@ -1,0 +1,436 @@
+// unet_f16.hip -- the 3x3 convolution of the U-Net (unet_block.py:251-258: Conv2d(3x3, zero pad, no bias) -> InstanceNorm2d -> LeakyReLU(0.2)) on the
+// fp16 matrix pipe with fp32 results: mrx_unet_conv3x3_h, the two-term form of mrx_unet_conv3x3 (unet_fused.hip), same contract -- up to two
+// sources, each plain or (raw, norm), raw output + the InstanceNorm statistics of its planes from the accumulators.
+//
+// Arithmetic: every fp32 operand is two fp16 terms, x = (h1 + h2) 2^-k (22 significant bits relative to a block scale that is a power of two), and
+// a multiply is the three term products h1 w1 + h1 w2 + h2 w1 on v_mfma_f32_16x16x32_f16, accumulated in fp32 -- the arithmetic of the RIM layer
+// kernels (rim_layer2_sb.hip).  The block scales:
+//   * x: ONE exponent per launch from a bound of max |x| over all sources.  A (raw, norm) source is bounded analytically: an element of an
+//     instance-normalised plane of n values has |z| <= sqrt(n - 1) (LeakyReLU only shrinks it), so sqrt(H W) needs no pass over the data
+//     (the (mean, 1/std) pair MUST be the statistics of the raw planes, as this library's kernels produce them); a plain
+//     source comes with a device scalar holding a bound of its maximum (mrx_max_abs, or the analytic bound of the normalised tensor it was pooled /
+//     padded from).  Values far below the bound keep 22 bits down to 2^-17 of it and an ABSOLUTE error of 2^-39 of the bound below that.
+//   * w: one exponent per weight tensor, found by the pack kernel.
+// The fp32-MFMA kernel it replaces spends 16 x the matrix cycles per multiply-add; this one is bound by its tile loads and stores.
+//
+// Work split: one workgroup = one 8 x 32 output tile x NCOT blocks of 16 output channels; a step contracts 16 input channels (two halves of 8) x 9
+// taps = 18 slots of 8 k-values, four slots per MFMA (five MFMAs per step and accumulator, the last one half empty: its weights are zero).  A wave
+// owns two rows of the tile (four 16-pixel accumulator tiles per output-channel block).  Staging: a thread owns a pixel of the halo'd tile and one
+// half (8 channels: eight coalesced plane loads), normalises + activates (the producer's statistics), splits and writes one 16-byte word per term.
+#include <cstdint>
+#include <cstdlib>
+
+#include "mrx_common.h"
+
+typedef _Float16 uh_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 uh_f16x2 __attribute__((ext_vector_type(2)));
+typedef float uh_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned uh_u4 __attribute__((ext_vector_type(4)));
+
+#define UH_NT 256
+#define UH_TH 8
+#define UH_TW 32
+#define UH_PW 34                   // halo'd tile: 10 rows x 34 columns
+#define UH_PIX (10 * UH_PW)        // 340
+#define UH_PLANE 344               // pixels per (term, half) plane in LDS (16-byte words)
+#define UH_SC 16                   // input channels per step
+#define UH_MS 5                    // MFMAs per step and accumulator (18 of 20 slots used)
+#define UH_XBUF (2 * 2 * UH_PLANE) // 16-byte words of one x buffer: [term][half][pixel]
+
+struct UConvHArgs {
+    const float* xa;     // [B,Ca,H,W]
+    const float* na;     // [B,Ca,2] (mean, 1/std) or null: source A is a plain tensor
+    const float* xb;     // [B,Cb,H,W] or null
+    const float* nb;
+    const float* bound_a;  // device scalar >= max |xa| (plain sources only)
+    const float* bound_b;
+    const uh_u4* packed; // mrx_unet_conv3x3_pack
+    float* y;            // [B,Cout,H,W] raw
+    float* tstats;       // [B][ntiles][Cout][2] (mean, M2) per tile
+    int Ca, Cb, B, Cout, H, W, tiles_x, ntiles, nct, nsteps;
+    float slope;
+    int abl;             // probe builds (env MRX_UCONVH_ABLATE): 1 no matrix work, 2 no stores, 4 no statistics, 8 no tile loads, 16 no split / LDS writes
+};
+
+__host__ __device__ constexpr long long uh_pack_words(int Cout, int Ctot) {
+    return (long long)((Ctot + UH_SC - 1) / UH_SC) * UH_MS * ((Cout + 15) / 16) * 2 * 64 + 1;   // + the header word (the weights' exponent)
+}
+
+__device__ __forceinline__ float uh_pow2(int e) {
+    e = e < -120 ? -120 : (e > 120 ? 120 : e);
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
+// exponent k with bound * 2^k in [2^14, 2^15) (0 for a zero / non-finite bound)
+__device__ __forceinline__ int uh_scale_exp(float bound) {
+    const int ex = (int)((__float_as_uint(bound) >> 23) & 0xffu);
+    return (ex == 0 || ex == 255) ? 0 : 14 - (ex - 127);
+}
+// two fp16 terms of a pair of values already scaled into the fp16 range: a = h1 + h2 + O(2^-22 |a|)
+__device__ __forceinline__ void uh_split2(float a, float b, unsigned& p1, unsigned& p2) {
+    const uh_f16x2 h = {(_Float16)a, (_Float16)b};
+    const float ra = a - (float)h.x, rb = b - (float)h.y;     // exact
+    const uh_f16x2 l = {(_Float16)ra, (_Float16)rb};
+    p1 = __builtin_bit_cast(unsigned, h);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+
+// ---- weight pack -------------------------------------------------------------------------------------------------------------------------
+// word (((S * 5 + m) * NCT + ct) * 2 + term) * 64 + lane, element j: term( w[16 ct + lane % 16][16 S + 8 (g & 1) + j][tap = 2 m + (g >> 1)] * 2^kw ),
+// g = lane / 16; zero for tap 9, channels >= Ctot, output channels >= Cout.  The last word holds kw.
+__global__ void k_uh_wscale(const float* __restrict__ w, long long n, uh_u4* __restrict__ out, long long header) {
+    __shared__ float red[256];
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[header] = uh_u4{(unsigned)uh_scale_exp(red[0]), 0u, 0u, 0u};
+}
+__global__ void k_uh_pack(const float* __restrict__ w, uh_u4* __restrict__ out, int Cout, int Ctot, int nct, long long words) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words - 1) return;
+    const float sw = uh_pow2((int)out[words - 1][0]);
+    const int lane = (int)(i & 63), term = (int)((i >> 6) & 1);
+    long long r = i >> 7;
+    const int ct = (int)(r % nct);
+    r /= nct;
+    const int m = (int)(r % UH_MS), S = (int)(r / UH_MS);
+    const int g = lane >> 4, co = 16 * ct + (lane & 15), tap = 2 * m + (g >> 1);
+    unsigned p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = UH_SC * S + 8 * (g & 1) + 2 * k + e;
+            v[e] = (tap < 9 && c < Ctot && co < Cout) ? w[((long long)co * Ctot + c) * 9 + tap] * sw : 0.f;
+        }
+        unsigned p1, p2;
+        uh_split2(v[0], v[1], p1, p2);
+        p[k] = term ? p2 : p1;
+    }
+    out[i] = uh_u4{p[0], p[1], p[2], p[3]};
+}
+
+extern "C" int64_t mrx_unet_conv3x3_pack_floats(int Cout, int Ctot) {
+    if (Cout < 1 || Ctot < 1) return -1;
+    return (int64_t)uh_pack_words(Cout, Ctot) * 4;
+}
+
+// w [Cout,Ctot,3,3] -> the two-term fp16 operand pack of mrx_unet_conv3x3_h (mrx_unet_conv3x3_pack_floats(Cout, Ctot) floats, 16-byte aligned)
+extern "C" int mrx_unet_conv3x3_pack(const float* w, int Cout, int Ctot, float* packed, void* stream) {
+    MRX_REQUIRE(w && packed && Cout >= 1 && Ctot >= 1, MRX_EINVAL, "mrx_unet_conv3x3_pack: bad argument");
+    MRX_REQUIRE(((uintptr_t)packed & 15u) == 0, MRX_EINVAL, "mrx_unet_conv3x3_pack: packed must be 16-byte aligned");
+    const long long words = uh_pack_words(Cout, Ctot);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_uh_wscale, dim3(1), dim3(256), 0, st, w, (long long)Cout * Ctot * 9, reinterpret_cast<uh_u4*>(packed), words - 1);
+    hipLaunchKernelGGL(k_uh_pack, dim3((unsigned)((words + 254) / 256)), dim3(256), 0, st, w, reinterpret_cast<uh_u4*>(packed), Cout, Ctot,
+                       (Cout + 15) / 16, words);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- the convolution -----------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float uh_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// sum over the 16 lanes of a row (the 16 pixels of an accumulator tile) on the vector ALU: quad swaps, then the two mirror patterns
+__device__ __forceinline__ float uh_row_sum(float t) {
+#define UH_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    t += UH_DPP(t, 0xB1);      // quad_perm [1,0,3,2]
+    t += UH_DPP(t, 0x4E);      // quad_perm [2,3,0,1]
+    t += UH_DPP(t, 0x141);     // row_half_mirror: quads 0 <-> 1, 2 <-> 3
+    t += UH_DPP(t, 0x140);     // row_mirror: halves of the row
+#undef UH_DPP
+    return t;
+}
+
+// One workgroup per work item (batch, cout block, tile); the tile loads of the NEXT step are in flight (registers) while the current step is
+// multiplied.  (A persistent form that also prefetched the next ITEM's tile under the epilogue measured slower -- 166 instead of 128 registers, three
+// instead of four workgroups per CU, uneven item counts: 14 -> 14 at 640 x 384 x 4 64.6 instead of 61.7 us, 56 -> 56 at 160 x 96 61.8 instead of 42.3.)
+template <int NCOT>
+__global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : 3) void k_uconv_h(UConvHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_uh[];
+    constexpr int WBUF = UH_MS * NCOT * 2 * 64;                 // 16-byte words of the weight buffer: [m][ct][term][lane]
+    constexpr int NWL = (WBUF + UH_NT - 1) / UH_NT;
+    // ONE operand buffer: the next step's tile waits in registers while this step is multiplied (32 / 42 KB per workgroup: several workgroups
+    // share a CU and fill each other's barriers)
+    uh_u4* Xh = reinterpret_cast<uh_u4*>(smem_uh);              // [term][half][UH_PLANE]
+    uh_u4* Wh = Xh + UH_XBUF;                                   // [WBUF]
+    float* red = reinterpret_cast<float*>(Wh + WBUF);           // [2 passes][4 waves][NCOT * 16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const long long plane = (long long)a.H * a.W;
+    const int Ctot = a.Ca + a.Cb;
+    const int ncob = (a.nct + NCOT - 1) / NCOT;
+
+    // the launch's operand scale: lazy sources are bounded by sqrt(n) of their planes, plain ones by the caller's device scalar
+    float bound = 0.f;
+    {
+        const float lazy_bound = 4.f * sqrtf((float)plane);     // (two bits of headroom: statistics that are a rounding error off still cannot overflow)
+        bound = a.na ? lazy_bound : a.bound_a[0];
+        if (a.Cb) bound = fmaxf(bound, a.nb ? lazy_bound : a.bound_b[0]);
+    }
+    const int kx = uh_scale_exp(bound), kw = (int)a.packed[uh_pack_words(a.Cout, Ctot) - 1][0];
+    const float sx = uh_pow2(kx), unscale = uh_pow2(-kx) * uh_pow2(-kw);
+    const float slope = a.slope;
+
+    // staging roles: waves 0, 1 own the first half (8 channels) of a step, waves 2, 3 the second; a thread owns pixels p, p + 128, p + 256
+    const int half = wave >> 1, p0 = tid & 127;
+    int pry[3], prx[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const int p = p0 + 128 * v;
+        pry[v] = p / UH_PW, prx[v] = p - pry[v] * UH_PW;
+    }
+    float xv[3][8];
+    float nm[8], ni[8];
+    unsigned lzm = 0, okm = 0;                                     // of the data in flight: lazy channels / pixels inside the image
+    auto issue_x = [&](int item, int q) {
+        const int tile = item % a.ntiles, bc = item / a.ntiles, b = bc / ncob;
+        const int ty0 = tile / a.tiles_x, h0 = ty0 * UH_TH, w0 = (tile - ty0 * a.tiles_x) * UH_TW;
+        unsigned goff[3];
+        okm = 0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int gy = h0 + pry[v] - 1, gx = w0 + prx[v] - 1;
+            const bool ok = p0 + 128 * v < UH_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            // every lane loads a valid element (clamped); what lies outside the image is zeroed when it is written to LDS: no branch per load
+            const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+            goff[v] = (unsigned)(cy * a.W + cx);
+            okm |= (ok ? 1u : 0u) << v;
+        }
+        lzm = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = UH_SC * q + 8 * half + j;
+            const bool valid = c < Ctot;
+            const int cc = valid ? c : 0;
+            const bool inb = cc >= a.Ca;
+            const int cl = inb ? cc - a.Ca : cc, Cs = inb ? a.Cb : a.Ca;
+            const float* p = (inb ? a.xb : a.xa) + ((long long)b * Cs + cl) * plane;
+            const float* nrm = inb ? a.nb : a.na;
+            // (x - mean) * (1/std * 2^kx): the operand scale rides on the normalisation (exact: a power of two); a plain source has mean 0, 1/std 1
+            nm[j] = 0.f, ni[j] = valid ? sx : 0.f;
+            if (nrm) {
+                nm[j] = nrm[((long long)b * Cs + cl) * 2];
+                ni[j] = valid ? nrm[((long long)b * Cs + cl) * 2 + 1] * sx : 0.f;
+                lzm |= 1u << j;
+            }
+#pragma unroll
+            for (int v = 0; v < 3; ++v) xv[v][j] = (a.abl & 8) ? 0.f : p[goff[v]];       // (a channel past the last one reads channel 0 and is multiplied by 0)
+        }
+    };
+    auto commit_x = [&]() {
+        uh_u4* dst = Xh + half * UH_PLANE;
+        if (a.abl & 16) return;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int p = p0 + 128 * v;
+            const bool ok = (okm >> v) & 1u;
+            unsigned p1[4], p2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * k + e;
+                    const float z = (xv[v][j] - nm[j]) * ni[j];
+                    t[e] = ((lzm >> j) & 1u) ? (slope <= 1.f ? fmaxf(z, z * slope) : fminf(z, z * slope)) : z;      // LeakyReLU of a scaled value
+                }
+                uh_split2(t[0], t[1], p1[k], p2[k]);
+                p1[k] = ok ? p1[k] : 0u;                                     // zero padding applies to the normalised tensor
+                p2[k] = ok ? p2[k] : 0u;
+            }
+            if (p < UH_PIX) {
+                dst[p] = uh_u4{p1[0], p1[1], p1[2], p1[3]};
+                dst[2 * UH_PLANE + p] = uh_u4{p2[0], p2[1], p2[2], p2[3]};
+            }
+        }
+    };
+    uh_u4 wr[NWL];
+    auto issue_w = [&](int item, int q) {
+        const int ct0 = ((item / a.ntiles) % ncob) * NCOT;
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) {
+            const int i = tid + j * UH_NT;
+            const int ln = i & 63, term = (i >> 6) & 1, r = i >> 7, ct = r % NCOT, m = r / NCOT;
+            const bool okw = i < WBUF && ct0 + ct < a.nct;
+            wr[j] = okw ? a.packed[((((long long)q * UH_MS + m) * a.nct + ct0 + ct) * 2 + term) * 64 + ln] : uh_u4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto commit_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) {
+            const int i = tid + j * UH_NT;
+            if (i < WBUF) Wh[i] = wr[j];
+        }
+    };
+
+    // this lane's k-group: slot 4 m + lg of step m -> tap 2 m + (lg >> 1), half lg & 1 (the slots of tap 9 carry zero weights: any valid address)
+    int toff[UH_MS];
+#pragma unroll
+    for (int m = 0; m < UH_MS; ++m) {
+        int tap = 2 * m + (lg >> 1);
+        tap = tap > 8 ? 8 : tap;
+        toff[m] = (tap / 3) * UH_PW + (tap % 3);
+    }
+    const uh_u4* xq = Xh + (lg & 1) * UH_PLANE + (2 * wave) * UH_PW + l15;
+    const uh_u4* wq = Wh + lane;
+
+    const int item = blockIdx.x;
+    issue_x(item, 0);
+    issue_w(item, 0);
+    {
+        const int tile = item % a.ntiles, bc = item / a.ntiles, b = bc / ncob, co0 = (bc - b * ncob) * NCOT * 16;
+        const int ty0 = tile / a.tiles_x, h0 = ty0 * UH_TH, w0 = (tile - ty0 * a.tiles_x) * UH_TW;
+        uh_f4 acc[4][NCOT];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+            for (int ct = 0; ct < NCOT; ++ct) acc[sg][ct] = (uh_f4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < a.nsteps; ++q) {
+            if (q) __syncthreads();   // every wave is done with the operands of step q - 1
+            commit_x();
+            commit_w();
+            __syncthreads();          // step q staged
+            if (q + 1 < a.nsteps) {   // the next step's loads fly under this step's matrix work
+                issue_x(item, q + 1);
+                issue_w(item, q + 1);
+            }
+            if (!(a.abl & 1))
+#pragma unroll
+            for (int m = 0; m < UH_MS; ++m) {
+                uh_f16x8 a1[NCOT], a2[NCOT];
+#pragma unroll
+                for (int ct = 0; ct < NCOT; ++ct) {
+                    a1[ct] = __builtin_bit_cast(uh_f16x8, wq[((m * NCOT + ct) * 2 + 0) * 64]);
+                    a2[ct] = __builtin_bit_cast(uh_f16x8, wq[((m * NCOT + ct) * 2 + 1) * 64]);
+                }
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const int pix = (sg >> 1) * UH_PW + (sg & 1) * 16 + toff[m];
+                    const uh_f16x8 b1 = __builtin_bit_cast(uh_f16x8, xq[pix]);
+                    const uh_f16x8 b2 = __builtin_bit_cast(uh_f16x8, xq[2 * UH_PLANE + pix]);
+#pragma unroll
+                    for (int ct = 0; ct < NCOT; ++ct) {
+                        acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ct], b1, acc[sg][ct], 0, 0, 0);
+                        acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ct], b2, acc[sg][ct], 0, 0, 0);
+                        acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ct], b1, acc[sg][ct], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);     // (keeps the scheduler from hoisting every step's operand reads to the top: registers)
+            }
+        }
+
+        bool ok[4];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const int oy = h0 + 2 * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
+            ok[sg] = oy < a.H && ox < a.W;
+#pragma unroll
+            for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[sg][ct][r] *= unscale;             // exact: powers of two
+        }
+        // stores: the two 16-pixel accumulator tiles of a row trade rows (v_permlane16_swap), so that lanes 0-31 / 32-63 of a store hold 32
+        // consecutive pixels of ONE output channel each (128-byte segments instead of four of 64 bytes)
+        if (!(a.abl & 2))
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw) {
+            const int oy = h0 + 2 * wave + rw, ox = w0 + 16 * (lg & 1) + l15;
+            const bool inside = oy < a.H && ox < a.W;
+#pragma unroll
+            for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    typedef unsigned uh_u2 __attribute__((ext_vector_type(2)));
+                    const uh_u2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * rw][ct][r]), __float_as_uint(acc[2 * rw + 1][ct][r]), false, false);
+                    const int co = co0 + 16 * ct + 8 * (lg >> 1) + r;            // sw.x: channel co, sw.y: channel co + 4
+                    float* yp = a.y + ((long long)b * a.Cout + co) * plane + (long long)oy * a.W + ox;
+                    if (inside && co < a.Cout) yp[0] = __uint_as_float(sw.x);
+                    if (inside && co + 4 < a.Cout) yp[4 * plane] = __uint_as_float(sw.y);
+                }
+        }
+        if (a.abl & 4) return;
+        // InstanceNorm statistics of this tile, per cout (the scheme of k_uconv, unet_fused.hip: mean over the tile's valid pixels, then the squared
+        // deviations from that mean; k_unorm_finalize merges the tiles in double)
+        const int nrow = a.H - h0 < UH_TH ? a.H - h0 : UH_TH, ncol = a.W - w0 < UH_TW ? a.W - w0 : UH_TW;
+        const float inv_n = 1.0f / (float)(nrow * ncol);
+        float mean[NCOT][4];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            float* rp = red + pass * (4 * NCOT * 16);
+#pragma unroll
+            for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) {
+                        const float v = acc[sg][ct][r];
+                        const float d = pass == 0 ? v : (v - mean[ct][r]) * (v - mean[ct][r]);
+                        t += ok[sg] ? d : 0.f;
+                    }
+                    t = uh_row_sum(t);
+                    if (l15 == 0) rp[wave * (NCOT * 16) + 16 * ct + 4 * lg + r] = t;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * ct + 4 * lg + r;
+                    const float t = (rp[c] + rp[NCOT * 16 + c]) + (rp[2 * NCOT * 16 + c] + rp[3 * NCOT * 16 + c]);
+                    if (pass == 0) {
+                        mean[ct][r] = t * inv_n;
+                    } else if (wave == 0 && l15 == 0 && co0 + c < a.Cout) {
+                        float* ts = a.tstats + (((long long)b * a.ntiles + tile) * a.Cout + co0 + c) * 2;
+                        ts[0] = mean[ct][r];
+                        ts[1] = t;
+                    }
+                }
+        }
+    }
+}
+
+int mrx_unorm_finalize_tiled(const float* tstats, float* norm, int B, int ntiles, int tiles_x, int Cout, int H, int W, float eps, hipStream_t st);
+
+template <int NCOT>
+static void launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
+    constexpr size_t lds = 16 * (size_t)(UH_XBUF + UH_MS * NCOT * 2 * 64) + sizeof(float) * 2 * 4 * NCOT * 16;
+    const long long nitems = (long long)a.ntiles * mrx_cdiv(a.nct, NCOT) * a.B;
+    const unsigned grid = (unsigned)nitems;
+    hipLaunchKernelGGL((k_uconv_h<NCOT>), dim3(grid), dim3(UH_NT), lds, st, a);
+}
+
+// mrx_unet_conv3x3 with two-term fp16 operands (see the head of this file).  packed: mrx_unet_conv3x3_pack of w [Cout, Ca + Cb, 3, 3];
+// bound_a / bound_b: device scalars >= max |x| of a PLAIN source (ignored -- may be NULL -- for a (raw, norm) source, whose bound is sqrt(H W)).
+// work: mrx_unet_conv3x3_work_floats(B, Cout, H, W) floats.
+extern "C" int mrx_unet_conv3x3_h(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b,
+                                  int Cb, const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps,
+                                  float slope, void* stream) {
+    MRX_REQUIRE(xa && packed && y && norm && work && Ca >= 1 && Cb >= 0 && (Cb == 0 || xb), MRX_EINVAL, "mrx_unet_conv3x3_h: bad argument");
+    MRX_REQUIRE((na || bound_a) && (Cb == 0 || nb || bound_b), MRX_EINVAL, "mrx_unet_conv3x3_h: a plain source needs the bound of its maximum");
+    MRX_REQUIRE(B >= 0 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_unet_conv3x3_h: bad dims");
+    MRX_REQUIRE(B <= 65535 && Cout <= 16 * 65535 && (long long)H * W < (1ll << 30), MRX_EUNSUP, "mrx_unet_conv3x3_h: size");
+    MRX_REQUIRE(mrx_arith() == MRX_ARITH_F16X2, MRX_EUNSUP, "mrx_unet_conv3x3_h: the two-term fp16 form is off (MRIDC_AMD_ARITH)");
+    if (B == 0) return MRX_OK;
+    UConvHArgs a;
+    a.xa = xa, a.na = na, a.bound_a = bound_a, a.xb = Cb ? xb : nullptr, a.nb = Cb ? nb : nullptr, a.bound_b = bound_b;
+    a.packed = reinterpret_cast<const uh_u4*>(packed), a.y = y, a.tstats = work;
+    a.Ca = Ca, a.Cb = Cb, a.B = B, a.Cout = Cout, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, UH_TW), a.slope = slope;
+    a.nct = (Cout + 15) / 16, a.nsteps = (Ca + Cb + UH_SC - 1) / UH_SC;
+    a.abl = MRX_DEBUG_ENV("MRX_UCONVH_ABLATE") ? atoi(MRX_DEBUG_ENV("MRX_UCONVH_ABLATE")) : 0;
+    const int ntiles = a.tiles_x * mrx_cdiv(H, UH_TH);
+    a.ntiles = ntiles;
+    hipStream_t st = (hipStream_t)stream;
+    // few tiles (the pooled levels): one cout block per work item, to fill the chip
+    if (a.nct == 1 || (long long)ntiles * B < 512) launch_uconv_h<1>(a, st);
+    else launch_uconv_h<2>(a, st);
+    MRX_LAUNCH_CHECK();
+    return mrx_unorm_finalize_tiled(work, norm, B, ntiles, a.tiles_x, Cout, H, W, eps, st);
+}

@@ -278,6 +278,13 @@ __global__ __launch_bounds__(UC_NT) void k_unorm_finalize(const float* __restric
     }
 }
 
+// (shared with the two-term fp16 convolution, unet_f16.hip)
+int mrx_unorm_finalize_tiled(const float* tstats, float* norm, int B, int ntiles, int tiles_x, int Cout, int H, int W, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(k_unorm_finalize<true>, dim3(B * Cout), dim3(UC_NT), 0, st, tstats, norm, ntiles, tiles_x, Cout, H, W, 0.0, 0.0, eps);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 template <int NCOT>
 static void launch_uconv(const UConvArgs& a, int ntiles, hipStream_t st) {
     constexpr size_t lds = sizeof(float) * (2 * UC_CK * UC_PLANE + 2 * 9 * NCOT * 2 * 64);

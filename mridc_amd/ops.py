@@ -47,9 +47,12 @@ class _PreparedCache:
       * eager entries are least-recently-made-first evicted beyond `keep`; every entry holds its source tensor so the address cannot be
         recycled under the same version."""
 
-    def __init__(self, keep=4):
+    def __init__(self, keep=4, parameters=False):
         self.keep = keep
         self.entries = {}
+        # parameters=True: the sources are model weights, not per-slice data -- a pack made eagerly (the warm-up call every capture needs anyway) is
+        # also right inside a capture; replaying a graph after an in-place weight update is wrong with or without this cache
+        self.parameters = parameters
 
     def get(self, src, extra, make):
         cap = int(_lib.lib().mrx_stream_capture_id(_lib.stream_ptr()))
@@ -58,6 +61,8 @@ class _PreparedCache:
             del self.entries[k]
         key = (cap, src.data_ptr(), src._version, str(src.device), tuple(src.shape)) + tuple(extra)
         hit = self.entries.get(key)
+        if hit is None and cap != 0 and self.parameters:
+            hit = self.entries.get((0,) + key[1:])
         if hit is None:
             if cap == 0:
                 eager = [k for k in self.entries if k[0] == 0]
@@ -1519,9 +1524,30 @@ def _lazy(t):
     return _lib.f32c(t), None
 
 
+_UNET_PACKS = _PreparedCache(keep=512, parameters=True)
+_UNET_BOUNDS = {}
+UNET_F16 = True                   # (module attribute: a test hook for the fp32-input MFMA kernel; MRIDC_AMD_ARITH != f16x2 turns the fp16 form off too)
+
+
+def _analytic_bound(n, device):
+    """Device scalar sqrt(n): the bound of an instance- / group-normalised tensor whose statistics ran over n values (|z| <= sqrt(n - 1))."""
+    key = (int(n), str(device))
+    t = _UNET_BOUNDS.get(key)
+    if t is None:
+        t = _UNET_BOUNDS[key] = torch.full((1,), float(n) ** 0.5, dtype=torch.float32, device=device)
+    return t
+
+
+def _plain_bound(x):
+    """Device scalar >= max |x| of a plain tensor: the bound its producer attached (unet_cnorm_pad, unet_avg_pool2x2), else measured (mrx_max_abs)."""
+    b = getattr(x, "_mrx_bound", None)
+    return b if b is not None else max_abs(x).reshape(1)
+
+
 def unet_conv3x3(src_a, src_b, weight, eps=1e-5, slope=0.2):
-    """Conv2d(3x3, zero pad, no bias) over the channels of src_a then src_b (None: one source; each plain or lazy) -> lazy output
-    (mrx_unet_conv3x3): the InstanceNorm statistics come out of the accumulators, nothing is normalised or concatenated in memory."""
+    """Conv2d(3x3, zero pad, no bias) over the channels of src_a then src_b (None: one source; each plain or lazy) -> lazy output: the InstanceNorm
+    statistics come out of the accumulators, nothing is normalised or concatenated in memory.  Default arithmetic: two-term fp16 operands
+    (mrx_unet_conv3x3_h, csrc/unet_f16.hip); MRIDC_AMD_ARITH=bf16x3 / fp32: the fp32-input MFMA kernel (mrx_unet_conv3x3)."""
     xa, na = _lazy(src_a)
     xb, nb = _lazy(src_b) if src_b is not None else (None, None)
     weight = _lib.f32c(weight.detach())
@@ -1534,6 +1560,18 @@ def unet_conv3x3(src_a, src_b, weight, eps=1e-5, slope=0.2):
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=xa.device)
     norm = torch.empty(B, Cout, 2, dtype=torch.float32, device=xa.device)
     work = torch.empty(int(L.mrx_unet_conv3x3_work_floats(B, Cout, H, W)), dtype=torch.float32, device=xa.device)
+    if UNET_F16 and _lib.arith() == "f16x2":
+        def make():
+            pk = torch.empty(int(L.mrx_unet_conv3x3_pack_floats(Cout, Ca + Cb)), dtype=torch.float32, device=weight.device)
+            _lib.check(L.mrx_unet_conv3x3_pack(_lib.ptr(weight), Cout, Ca + Cb, _lib.ptr(pk), _lib.stream_ptr()), "mrx_unet_conv3x3_pack")
+            return pk
+        packed = _UNET_PACKS.get(weight, (), make)
+        ba = None if na is not None else _plain_bound(src_a if not isinstance(src_a, tuple) else xa)
+        bb = None if (xb is None or nb is not None) else _plain_bound(src_b if not isinstance(src_b, tuple) else xb)
+        _lib.check(L.mrx_unet_conv3x3_h(_lib.ptr(xa), _lib.ptr(na), _lib.ptr(ba), Ca, _lib.ptr(xb), _lib.ptr(nb), _lib.ptr(bb), Cb, _lib.ptr(packed),
+                                        _lib.ptr(y), _lib.ptr(norm), _lib.ptr(work), B, Cout, H, W, float(eps), float(slope), _lib.stream_ptr()),
+                   "mrx_unet_conv3x3_h")
+        return y, norm
     _lib.check(L.mrx_unet_conv3x3(_lib.ptr(xa), _lib.ptr(na), Ca, _lib.ptr(xb), _lib.ptr(nb), Cb, _lib.ptr(weight), _lib.ptr(y), _lib.ptr(norm),
                                   _lib.ptr(work), B, Cout, H, W, float(eps), float(slope), _lib.stream_ptr()), "mrx_unet_conv3x3")
     return y, norm
@@ -1567,6 +1605,10 @@ def unet_avg_pool2x2(src, slope=0.2):
     out = torch.empty(B, C, H // 2, W // 2, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().mrx_unet_avgpool(_lib.ptr(x), _lib.ptr(nrm), _lib.ptr(out), B * C, H, W, float(slope), _lib.stream_ptr()),
                "mrx_unet_avgpool")
+    # an average is bounded by what it averages: sqrt(n) of the normalised planes, or the plain source's own bound (if it has one)
+    bound = _analytic_bound(H * W, x.device) if nrm is not None else getattr(src, "_mrx_bound", None)
+    if bound is not None:
+        out._mrx_bound = bound
     return out
 
 
@@ -1611,6 +1653,7 @@ def unet_cnorm_pad(x, h_pad, w_pad):
     work = torch.empty(int(L.mrx_unet_cnorm_work_floats(B)), dtype=torch.float32, device=x.device)
     _lib.check(L.mrx_unet_cnorm_pad(_lib.ptr(x), _lib.ptr(out), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(work), B, c, H, W, int(h_pad[0]),
                                     int(h_pad[1]), int(w_pad[0]), int(w_pad[1]), _lib.stream_ptr()), "mrx_unet_cnorm_pad")
+    out._mrx_bound = _analytic_bound(c * H * W, x.device)    # normalised per (batch, component) over c H W values (unbiased std: smaller still)
     return out, mean, std
 
 

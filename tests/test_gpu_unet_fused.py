@@ -41,20 +41,68 @@ def test_unet_conv3x3_sources_and_statistics(shape, dev):
     na = torch.stack([r(B, Ca) * 0.5, r(B, Ca).abs() + 0.5], -1)
     nb = torch.stack([r(B, Cb) * 0.5, r(B, Cb).abs() + 0.5], -1) if Cb else None
     w = r(Cout, Ca + Cb, 3, 3) / (9 * (Ca + Cb)) ** 0.5
-    for lazy_a, lazy_b in ((False, False), (True, True), (True, False)):
-        if Cb == 0 and lazy_b != lazy_a:
-            continue
-        xa = _lazy_ref(a_raw.double(), na) if lazy_a else a_raw.double()
-        x = xa
-        if Cb:
-            x = torch.cat([xa, _lazy_ref(b_raw.double(), nb) if lazy_b else b_raw.double()], 1)
-        ref = Fn.conv2d(x, w.double(), padding=1)
-        y, norm = ops.unet_conv3x3((a_raw, na) if lazy_a else a_raw, None if not Cb else ((b_raw, nb) if lazy_b else b_raw), w)
-        assert rel_l2(y, ref) <= 2e-6, (shape, lazy_a, lazy_b, rel_l2(y, ref))
-        mean, var = ref.mean((2, 3)), ref.var((2, 3), unbiased=False)
-        assert (norm[..., 0].double() - mean).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max()))
-        assert rel_l2(norm[..., 1], 1.0 / torch.sqrt(var + 1e-5)) <= 1e-5
-        assert rel_l2(ops.unet_apply((y, norm)), _norm_act(ref)) <= 5e-6
+
+    def true_stats(t):            # what the producing kernels hand over: (mean, 1 / sqrt(var + eps)) of every plane
+        return torch.stack([t.mean((2, 3)), 1.0 / torch.sqrt(t.var((2, 3), unbiased=False) + 1e-5)], -1)
+
+    keep = ops.UNET_F16
+    try:
+        # the fp32-input MFMA kernel takes ANY (mean, 1/std) pair; the two-term fp16 kernel (the default) bounds a lazy source by sqrt(n), which
+        # holds for the statistics of the planes themselves -- the only pairs this library produces
+        for f16 in (False, True):
+            ops.UNET_F16 = f16
+            if f16 and H * W > 1:
+                na, nb = true_stats(a_raw), (true_stats(b_raw) if Cb else None)
+            for lazy_a, lazy_b in ((False, False), (True, True), (True, False)):
+                if Cb == 0 and lazy_b != lazy_a:
+                    continue
+                xa = _lazy_ref(a_raw.double(), na) if lazy_a else a_raw.double()
+                x = xa
+                if Cb:
+                    x = torch.cat([xa, _lazy_ref(b_raw.double(), nb) if lazy_b else b_raw.double()], 1)
+                ref = Fn.conv2d(x, w.double(), padding=1)
+                y, norm = ops.unet_conv3x3((a_raw, na) if lazy_a else a_raw, None if not Cb else ((b_raw, nb) if lazy_b else b_raw), w)
+                assert rel_l2(y, ref) <= 2e-6, (shape, f16, lazy_a, lazy_b, rel_l2(y, ref))
+                mean, var = ref.mean((2, 3)), ref.var((2, 3), unbiased=False)
+                assert (norm[..., 0].double() - mean).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max()))
+                assert rel_l2(norm[..., 1], 1.0 / torch.sqrt(var + 1e-5)) <= 1e-5
+                assert rel_l2(ops.unet_apply((y, norm)), _norm_act(ref)) <= 5e-6
+    finally:
+        ops.UNET_F16 = keep
+
+
+def test_unet_conv3x3_two_term_fp16_scales(dev):
+    """mrx_unet_conv3x3_h: fp32-level results for any magnitude of the inputs and weights (the block scales are powers of two taken from the
+    bound of max |x| and from max |w|), with a measured bound (no attribute) and with an attached one that is 1000 x too large; a hot pixel
+    1e4 x the rest costs the OTHER pixels nothing beyond 2^-39 of the bound (absolute)."""
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    B, C, Cout, H, W = 2, 14, 28, 37, 75
+    for xs, ws in ((1.0, 1.0), (1e-4, 30.0), (3e4, 1e-3)):
+        x, w = r(B, C, H, W) * xs, r(Cout, C, 3, 3) / (9 * C) ** 0.5 * ws
+        ref = Fn.conv2d(x.double(), w.double(), padding=1)
+        y, _ = ops.unet_conv3x3(x, None, w)                                   # bound measured (mrx_max_abs)
+        assert rel_l2(y, ref) <= 1e-6, (xs, ws, rel_l2(y, ref))
+        xb = x.clone()
+        xb._mrx_bound = (x.abs().max() * 1000.0).reshape(1)                   # a bound 1000 x too large: 10 of the 17 spare bits used up
+        y2, _ = ops.unet_conv3x3(xb, None, w)
+        assert rel_l2(y2, ref) <= 1e-6, (xs, ws, rel_l2(y2, ref))
+        exact = ops.UNET_F16
+        try:
+            ops.UNET_F16 = False
+            y32, _ = ops.unet_conv3x3(x, None, w)
+        finally:
+            ops.UNET_F16 = exact
+        assert rel_l2(y, ref) <= 2.5 * rel_l2(y32, ref) + 1e-7                 # the fp32-input MFMA kernel's own distance from float64
+    x, w = r(1, C, H, W), r(Cout, C, 3, 3) / (9 * C) ** 0.5
+    x[:, :, 20, 40] *= 1e4
+    ref = Fn.conv2d(x.double(), w.double(), padding=1)
+    y, _ = ops.unet_conv3x3(x, None, w)
+    far = torch.ones(1, Cout, H, W, dtype=torch.bool)
+    far[:, :, 19:22, 39:42] = False
+    d, rr = (y.double().cpu() - ref.cpu())[far], ref.cpu()[far]
+    assert float((d.abs() / (rr.abs() + float(rr.pow(2).mean().sqrt()))).max()) <= 1e-5
 
 
 @pytest.mark.parametrize("shape", [(1, 56, 28, 160, 95), (1, 28, 14, 320, 190), (2, 36, 18, 20, 12), (1, 6, 4, 5, 3), (1, 144, 72, 80, 48)])
