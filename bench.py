@@ -504,14 +504,29 @@ def bench_e2evn(args, world, rank, dev, checks=False):
             hh_, ww_ = (int(v) for v in hw.split("x"))
             flops = 2.0 * int(cin) * int(cout) * 9 * hh_ * ww_ * B
             all_ms = sum(tot.values()) / 2.0                    # two profiled steps (raw event time of every U-Net 3x3 convolution)
-            res["roofline"] = dict(bound="mfma", kernel=f"k_uconv via mrx_unet_conv3x3 ({key}: 3x3 zero-padded convolution, batch {B}, fp32 MFMA 16x16x4, fused "
-                                                          "InstanceNorm statistics; the previous layer's normalisation + LeakyReLU in the tile loader)",
-                                   achieved=(flops / (ms * 1e-3) / 1e12) if ms else None, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                                   frac=(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms else None,
-                                   frac_meaning="direct-form MFMA FLOPs of the launch / fp32-MFMA peak", launches=n, avg_ms=ms, flops_per_launch=flops,
-                                   traffic=None, algorithmic_bytes=(int(cin) + int(cout)) * hh_ * ww_ * B * 4.0,
-                                   hbm_frac=((int(cin) + int(cout)) * hh_ * ww_ * B * 4.0 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms else None,
-                                   all_unet_conv3x3_ms_per_step=all_ms)
+            from mridc_amd import _lib as _l
+            nbytes = (int(cin) + int(cout)) * hh_ * ww_ * B * 4.0
+            if ops.UNET_F16 and _l.arith() == "f16x2":
+                # the default: two-term fp16 operands -- the matrix work is 3 / 16 of the fp32-input form's cycles and the launch is bound by its
+                # tile loads and stores (algorithmic bytes = every input plane read once + every output plane written once)
+                gbs = (nbytes / (ms * 1e-3) / 1e9) if ms else None
+                res["roofline"] = dict(bound="hbm", kernel=f"k_uconv_h via mrx_unet_conv3x3_h ({key}: 3x3 zero-padded convolution, batch {B}, two-term fp16 operands "
+                                                              "on v_mfma_f32_16x16x32_f16 (3 term products, fp32 accumulation), fused InstanceNorm statistics; the previous "
+                                                              "layer's normalisation + LeakyReLU and the operand split in the tile loader)",
+                                       achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=(gbs / PEAK_HBM_GBS) if gbs else None,
+                                       frac_meaning="algorithmic bytes of the launch (inputs read once + outputs written once) / 8 TB/s", launches=n, avg_ms=ms,
+                                       traffic=None, algorithmic_bytes=nbytes, flops_per_launch=flops,
+                                       mfma_frac=(3.0 * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if ms else None,
+                                       all_unet_conv3x3_ms_per_step=all_ms)
+            else:
+                res["roofline"] = dict(bound="mfma", kernel=f"k_uconv via mrx_unet_conv3x3 ({key}: 3x3 zero-padded convolution, batch {B}, fp32 MFMA 16x16x4, fused "
+                                                              "InstanceNorm statistics; the previous layer's normalisation + LeakyReLU in the tile loader)",
+                                       achieved=(flops / (ms * 1e-3) / 1e12) if ms else None, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                                       frac=(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if ms else None,
+                                       frac_meaning="direct-form MFMA FLOPs of the launch / fp32-MFMA peak", launches=n, avg_ms=ms, flops_per_launch=flops,
+                                       traffic=None, algorithmic_bytes=nbytes,
+                                       hbm_frac=(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms else None,
+                                       all_unet_conv3x3_ms_per_step=all_ms)
         try:
             import oracle
             ncores, box_cores = _oracle_threads()

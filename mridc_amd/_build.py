@@ -58,11 +58,15 @@ def build(force=False, verbose=True):
             continue
         obj = os.path.join(LIBDIR, os.path.splitext(name)[0] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
-            cmd = [hipcc] + COMMON + extra + os.environ.get("MRX_BUILD_DEFS", "").split() + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc] + COMMON + extra + os.environ.get("MRX_BUILD_DEFS", "").split() + ["-x", "hip", "-c", src, "-o", obj]
+        stamp = obj + ".flags"      # the command the object was built with: a probe build (-DMRX_PROBE) never leaks into a product build
+        same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if force or not same_flags or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+            with open(stamp, "w") as f:
+                f.write(" ".join(cmd))
             rebuilt = True
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
