@@ -507,6 +507,11 @@ int64_t mrx_conv1x1_sq_pack_floats(int C);   /* floats of `packed` (the fp32 ope
 int mrx_conv1x1_sq_pack(const float* w, float* packed, int C, void* stream);
 int mrx_conv1x1_sq(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
                    int B, int C, int64_t HW, int act, float slope, void* stream);
+/* mrx_conv1x1_sq that also folds max |out| into the device scalar *xmax (atomic max; the caller zeroes it): the operand bound a two-term fp16
+ * consumer of `out` needs (mrx_conv3x3_h), without a pass over the tensor.  C = 128 on the matrix-pipe kernel (mrx_conv1x1_sq_xmax_supported). */
+int mrx_conv1x1_sq_xmax_supported(int C);
+int mrx_conv1x1_sq_xmax(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out, float* xmax,
+                        int B, int C, int64_t HW, int act, float slope, void* stream);
 int mrx_conv1x1_64(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
                    int B, int64_t HW, int act, float slope, void* stream);
 
@@ -620,6 +625,12 @@ int64_t mrx_unet_conv3x3_pack_floats(int Cout, int Ctot);
 int mrx_unet_conv3x3_pack(const float* w, int Cout, int Ctot, float* packed, void* stream);
 int mrx_unet_conv3x3_h(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b, int Cb,
                        const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps, float slope, void* stream);
+/* y = act(conv3x3(x, dilation 1 | 2, zero | replicate padding) + bias), any channel counts, on the same two-term fp16 kernel (ConvNonlinear,
+ * rim/conv_layers.py:121-123, for layers the 64-channel kernels do not cover: qRIM's 128 -> 128, DIDN ...).  bound: device scalar >= max |x|;
+ * packed: mrx_unet_conv3x3_pack(w [Cout, Cin, 3, 3]); x != y. */
+int mrx_conv3x3_h_supported(int Cin, int Cout, int k, int dil);
+int mrx_conv3x3_h(const float* x, const float* bound, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int dil,
+                  int pad_mode, int act, float slope, void* stream);
 int64_t mrx_unet_conv_transpose2x2_work_floats(int B, int Cout, int H, int W);
 int mrx_unet_conv_transpose2x2(const float* x, const float* nrm, const float* w, float* out, float* norm, float* work, int B, int Cin, int Cout,
                       int H, int W, float eps, float slope, void* stream);

@@ -113,11 +113,15 @@ _SIGNATURES = {
     "mrx_conv1x1_sq_head128": ([_p, _p, _p, _i, _i64, _p], _i),
     "mrx_conv1x1_sq_pack": ([_p, _p, _i, _p], _i),
     "mrx_conv1x1_sq": ([_p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _f, _p], _i),
+    "mrx_conv1x1_sq_xmax_supported": ([_i], _i),
+    "mrx_conv1x1_sq_xmax": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _f, _p], _i),
     "mrx_concat_channels": ([_p, _p, _p, _i, _i, _i, _i64, _p], _i),
     "mrx_unet_conv3x3_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_unet_conv3x3_pack_floats": ([_i, _i], _i64),
     "mrx_unet_conv3x3_pack": ([_p, _i, _i, _p, _p], _i),
     "mrx_unet_conv3x3_h": ([_p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p], _i),
+    "mrx_conv3x3_h_supported": ([_i, _i, _i, _i], _i),
+    "mrx_conv3x3_h": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_unet_conv3x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p], _i),
     "mrx_unet_conv_transpose2x2_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_unet_conv_transpose2x2": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p], _i),

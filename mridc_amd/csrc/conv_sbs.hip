@@ -99,7 +99,10 @@ __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
             const float* src = xb + (long long)gy * a.W + gx;
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (inb && j < a.Cin) ? src[(long long)j * plane] : 0.f;
+            for (int j = 0; j < 8; ++j) {      // every lane loads a valid element (channel clamped), zeroed afterwards: no branch per load
+                const float t = src[(long long)(j < a.Cin ? j : 0) * plane];
+                v[j] = (inb && j < a.Cin) ? t : 0.f;
+            }
             if constexpr (F16) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = v[j];
@@ -184,24 +187,36 @@ __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
     }
 
     // ---- epilogue: bias, activation; lane = pixel (128-byte rows per wave instruction) ----------------------------------------------------
+    // (the arithmetic first, then the stores under ONE predicate per block of values: a branch around every store -- bias? activation? channel
+    // in range? -- made seven branches per store, each basic block waiting on its own loads)
     const int oy = h0 + wave, ox = w0 + l31;
+    const float neg = a.act == MRX_ACT_RELU ? 0.f : (a.act == MRX_ACT_LEAKY ? a.slope : 1.f);
+    const int clast = a.Cout - 1;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            float v = F16 ? acc[ct][r] * un : acc[ct][r];
+            v += a.bias ? a.bias[co < clast ? co : clast] : 0.f;
+            acc[ct][r] = v > 0.f ? v : v * neg;
+        }
     if (oy < a.H && ox < a.W) {
-        const long long obase = (long long)b * a.Cout * plane + (long long)oy * a.W + ox;
+        float* ob = a.out + (long long)b * a.Cout * plane + (long long)oy * a.W + ox;
+        if (a.Cout == NCT * 32) {            // every channel of every block exists (64, 128 ... features)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (co < a.Cout) {
-                    float v = F16 ? acc[ct][r] * un : acc[ct][r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.act == MRX_ACT_RELU)
-                        v = v > 0.f ? v : 0.f;
-                    else if (a.act == MRX_ACT_LEAKY)
-                        v = v > 0.f ? v : v * a.slope;
-                    a.out[obase + (long long)co * plane] = v;
+                for (int r = 0; r < 16; ++r) ob[(long long)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * plane] = acc[ct][r];
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (co < a.Cout) ob[(long long)co * plane] = acc[ct][r];
                 }
-            }
+        }
     }
 }
 

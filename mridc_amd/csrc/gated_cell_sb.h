@@ -46,6 +46,8 @@ struct MrxConv1x1SbArgs {
     int act;
     float slope;
     int head;             // 1: only the first 64 output channels, out [B,64,P]
+    float* xmax;          // or null: device scalar, max |out| is folded in with an atomic max (never reset here): the bound a two-term fp16
+                          // consumer of `out` scales its operands by (mrx_conv3x3_h)
 };
 
 int mrx_conv1x1_sb128_pack(const float* w, float* packed, hipStream_t st);

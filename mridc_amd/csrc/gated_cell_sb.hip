@@ -748,6 +748,7 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) 
     const long long stride = (long long)gridDim.x * (GS_NT / 64);
     const unsigned P32 = (unsigned)a.P;
     const float neg = a.act == MRX_ACT_RELU ? 0.f : (a.act == MRX_ACT_LEAKY ? a.slope : 1.f);
+    float vmax = 0.f;
     for (long long sg = (long long)blockIdx.x * (GS_NT / 64) + wave; sg < a.nseg; sg += stride) {
         int l31 = lane & 31, lhi = lane >> 5;
         asm volatile("" : "+v"(l31), "+v"(lhi));  // keep the channel offsets out of loop-invariant hoisting (spills)
@@ -797,16 +798,41 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hv[ct][r] = hb[(unsigned)(ob * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo];
             }
+            // the arithmetic first, then ONE predicated block of stores (a branch around every store would split this into 32 basic blocks);
+            // lanes past the last pixel hold pixel 0's values again: harmless for the maximum
+            if (a.hprev) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ob][ct][r] += Bs[C + ob * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] * hv[ct][r];
+            }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = ob * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    float v = acc[ob][ct][r];
-                    if (a.hprev) v += Bs[C + co] * hv[ct][r];
-                    v = v > 0.f ? v : v * neg;
-                    if (valid) ob_[(unsigned)co * P32 + pxo] = v;
+                    const float v = acc[ob][ct][r];
+                    acc[ob][ct][r] = v > 0.f ? v : v * neg;
+                    vmax = fmaxf(vmax, fabsf(acc[ob][ct][r]));
                 }
+            if (valid) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ob_[(unsigned)(ob * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * P32 + pxo] = acc[ob][ct][r];
+            }
+        }
+    }
+    if (a.xmax) {               // one atomic per WORKGROUP, and only if it raises the bound (2048 same-address atomics cost the launch 16 us)
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        __syncthreads();        // (every wave is done with the weights: the first floats of the LDS are free)
+        float* red = reinterpret_cast<float*>(smem_gs);
+        if (lane == 0) red[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < GS_NT / 64; ++w) vmax = fmaxf(vmax, red[w]);
+            // (bit patterns of non-negative floats order like unsigned integers)
+            if (__float_as_uint(vmax) > __hip_atomic_load(reinterpret_cast<unsigned*>(a.xmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(reinterpret_cast<unsigned*>(a.xmax), __float_as_uint(vmax));
         }
     }
 }

@@ -30,12 +30,13 @@ typedef unsigned uh_u4 __attribute__((ext_vector_type(4)));
 #define UH_NT 256
 #define UH_TH 8
 #define UH_TW 32
-#define UH_PW 34                   // halo'd tile: 10 rows x 34 columns
-#define UH_PIX (10 * UH_PW)        // 340
-#define UH_PLANE 344               // pixels per (term, half) plane in LDS (16-byte words)
 #define UH_SC 16                   // input channels per step
 #define UH_MS 5                    // MFMAs per step and accumulator (18 of 20 slots used)
-#define UH_XBUF (2 * 2 * UH_PLANE) // 16-byte words of one x buffer: [term][half][pixel]
+// halo'd tile for dilation D: (8 + 2 D) rows x (32 + 2 D) columns -- 10 x 34 = 340 pixels (D = 1), 12 x 36 = 432 (D = 2)
+__host__ __device__ constexpr int uh_pw(int D) { return UH_TW + 2 * D; }
+__host__ __device__ constexpr int uh_pix(int D) { return (UH_TH + 2 * D) * uh_pw(D); }
+__host__ __device__ constexpr int uh_plane(int D) { return (uh_pix(D) + 7) / 8 * 8; }      // pixels per (term, half) plane in LDS (16-byte words)
+__host__ __device__ constexpr int uh_xbuf(int D) { return 2 * 2 * uh_plane(D); }          // 16-byte words of the x buffer: [term][half][pixel]
 
 struct UConvHArgs {
     const float* xa;     // [B,Ca,H,W]
@@ -49,6 +50,8 @@ struct UConvHArgs {
     float* tstats;       // [B][ntiles][Cout][2] (mean, M2) per tile
     int Ca, Cb, B, Cout, H, W, tiles_x, ntiles, nct, nsteps;
     float slope;
+    const float* bias;   // plain convolution (UNET = false): [Cout] or null; act MRX_ACT_*; pad_mode MRX_PAD_ZERO | MRX_PAD_REPLICATE
+    int act, pad_mode;
     int abl;             // probe builds (env MRX_UCONVH_ABLATE): 1 no matrix work, 2 no stores, 4 no statistics, 8 no tile loads, 16 no split / LDS writes
 };
 
@@ -150,9 +153,13 @@ __device__ __forceinline__ float uh_row_sum(float t) {
 // One workgroup per work item (batch, cout block, tile); the tile loads of the NEXT step are in flight (registers) while the current step is
 // multiplied.  (A persistent form that also prefetched the next ITEM's tile under the epilogue measured slower -- 166 instead of 128 registers, three
 // instead of four workgroups per CU, uneven item counts: 14 -> 14 at 640 x 384 x 4 64.6 instead of 61.7 us, 56 -> 56 at 160 x 96 61.8 instead of 42.3.)
-template <int NCOT>
-__global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : 3) void k_uconv_h(UConvHArgs a) {
+// UNET: the U-Net contract (lazy / plain sources, zero padding, raw output + tile statistics); else a plain convolution of ONE plain source with
+// dilation DIL, zero or replicate padding and a bias + activation epilogue (conv_layers.py:121-123 for layers wider than the RIM's 64 channels).
+template <int NCOT, int DIL, bool UNET>
+__global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_uconv_h(UConvHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uh[];
+    constexpr int UH_PW = uh_pw(DIL), UH_PIX = uh_pix(DIL), UH_PLANE = uh_plane(DIL), UH_XBUF = uh_xbuf(DIL);
+    constexpr int NSLOT = (UH_PIX + 127) / 128;                 // tile pixels per staging thread: 3 (dilation 1), 4 (dilation 2)
     constexpr int WBUF = UH_MS * NCOT * 2 * 64;                 // 16-byte words of the weight buffer: [m][ct][term][lane]
     constexpr int NWL = (WBUF + UH_NT - 1) / UH_NT;
     // ONE operand buffer: the next step's tile waits in registers while this step is multiplied (32 / 42 KB per workgroup: several workgroups
@@ -171,33 +178,34 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : 3) void k_uconv_h(UConvHArgs
     float bound = 0.f;
     {
         const float lazy_bound = 4.f * sqrtf((float)plane);     // (two bits of headroom: statistics that are a rounding error off still cannot overflow)
-        bound = a.na ? lazy_bound : a.bound_a[0];
-        if (a.Cb) bound = fmaxf(bound, a.nb ? lazy_bound : a.bound_b[0]);
+        bound = (UNET && a.na) ? lazy_bound : a.bound_a[0];
+        if (UNET && a.Cb) bound = fmaxf(bound, a.nb ? lazy_bound : a.bound_b[0]);
     }
     const int kx = uh_scale_exp(bound), kw = (int)a.packed[uh_pack_words(a.Cout, Ctot) - 1][0];
     const float sx = uh_pow2(kx), unscale = uh_pow2(-kx) * uh_pow2(-kw);
     const float slope = a.slope;
 
-    // staging roles: waves 0, 1 own the first half (8 channels) of a step, waves 2, 3 the second; a thread owns pixels p, p + 128, p + 256
+    // staging roles: waves 0, 1 own the first half (8 channels) of a step, waves 2, 3 the second; a thread owns pixels p, p + 128, p + 256 (, p + 384)
     const int half = wave >> 1, p0 = tid & 127;
-    int pry[3], prx[3];
+    int pry[NSLOT], prx[NSLOT];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
+    for (int v = 0; v < NSLOT; ++v) {
         const int p = p0 + 128 * v;
         pry[v] = p / UH_PW, prx[v] = p - pry[v] * UH_PW;
     }
-    float xv[3][8];
+    float xv[NSLOT][8];
     float nm[8], ni[8];
     unsigned lzm = 0, okm = 0;                                     // of the data in flight: lazy channels / pixels inside the image
     auto issue_x = [&](int item, int q) {
         const int tile = item % a.ntiles, bc = item / a.ntiles, b = bc / ncob;
         const int ty0 = tile / a.tiles_x, h0 = ty0 * UH_TH, w0 = (tile - ty0 * a.tiles_x) * UH_TW;
-        unsigned goff[3];
+        unsigned goff[NSLOT];
         okm = 0;
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const int gy = h0 + pry[v] - 1, gx = w0 + prx[v] - 1;
-            const bool ok = p0 + 128 * v < UH_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        for (int v = 0; v < NSLOT; ++v) {
+            const int gy = h0 + pry[v] - DIL, gx = w0 + prx[v] - DIL;
+            // (replicate padding IS the clamped load: nothing to zero)
+            const bool ok = p0 + 128 * v < UH_PIX && ((!UNET && a.pad_mode == MRX_PAD_REPLICATE) || (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W));
             // every lane loads a valid element (clamped); what lies outside the image is zeroed when it is written to LDS: no branch per load
             const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
             goff[v] = (unsigned)(cy * a.W + cx);
@@ -209,10 +217,10 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : 3) void k_uconv_h(UConvHArgs
             const int c = UH_SC * q + 8 * half + j;
             const bool valid = c < Ctot;
             const int cc = valid ? c : 0;
-            const bool inb = cc >= a.Ca;
+            const bool inb = UNET && cc >= a.Ca;
             const int cl = inb ? cc - a.Ca : cc, Cs = inb ? a.Cb : a.Ca;
             const float* p = (inb ? a.xb : a.xa) + ((long long)b * Cs + cl) * plane;
-            const float* nrm = inb ? a.nb : a.na;
+            const float* nrm = UNET ? (inb ? a.nb : a.na) : nullptr;
             // (x - mean) * (1/std * 2^kx): the operand scale rides on the normalisation (exact: a power of two); a plain source has mean 0, 1/std 1
             nm[j] = 0.f, ni[j] = valid ? sx : 0.f;
             if (nrm) {
@@ -221,14 +229,14 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : 3) void k_uconv_h(UConvHArgs
                 lzm |= 1u << j;
             }
 #pragma unroll
-            for (int v = 0; v < 3; ++v) xv[v][j] = (a.abl & 8) ? 0.f : p[goff[v]];       // (a channel past the last one reads channel 0 and is multiplied by 0)
+            for (int v = 0; v < NSLOT; ++v) xv[v][j] = (a.abl & 8) ? 0.f : p[goff[v]];   // (a channel past the last one reads channel 0 and is multiplied by 0)
         }
     };
     auto commit_x = [&]() {
         uh_u4* dst = Xh + half * UH_PLANE;
         if (a.abl & 16) return;
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
+        for (int v = 0; v < NSLOT; ++v) {
             const int p = p0 + 128 * v;
             const bool ok = (okm >> v) & 1u;
             unsigned p1[4], p2[4];
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : 3) void k_uconv_h(UConvHArgs
     for (int m = 0; m < UH_MS; ++m) {
         int tap = 2 * m + (lg >> 1);
         tap = tap > 8 ? 8 : tap;
-        toff[m] = (tap / 3) * UH_PW + (tap % 3);
+        toff[m] = ((tap / 3) * UH_PW + (tap % 3)) * DIL;
     }
     const uh_u4* xq = Xh + (lg & 1) * UH_PLANE + (2 * wave) * UH_PW + l15;
     const uh_u4* wq = Wh + lane;
@@ -334,7 +342,16 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : 3) void k_uconv_h(UConvHArgs
 #pragma unroll
             for (int ct = 0; ct < NCOT; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[sg][ct][r] *= unscale;             // exact: powers of two
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[sg][ct][r] * unscale;                            // exact: powers of two
+                    if constexpr (!UNET) {
+                        const int co = co0 + 16 * ct + 4 * lg + r;
+                        if (a.bias) v += a.bias[co < a.Cout ? co : 0];
+                        if (a.act == MRX_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        else if (a.act == MRX_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                    }
+                    acc[sg][ct][r] = v;
+                }
         }
         // stores: the two 16-pixel accumulator tiles of a row trade rows (v_permlane16_swap), so that lanes 0-31 / 32-63 of a store hold 32
         // consecutive pixels of ONE output channel each (128-byte segments instead of four of 64 bytes)
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : 3) void k_uconv_h(UConvHArgs
                     if (inside && co + 4 < a.Cout) yp[4 * plane] = __uint_as_float(sw.y);
                 }
         }
-        if (a.abl & 4) return;
+        if (!UNET || (a.abl & 4)) return;
         // InstanceNorm statistics of this tile, per cout (the scheme of k_uconv, unet_fused.hip: mean over the tile's valid pixels, then the squared
         // deviations from that mean; k_unorm_finalize merges the tiles in double)
         const int nrow = a.H - h0 < UH_TH ? a.H - h0 : UH_TH, ncol = a.W - w0 < UH_TW ? a.W - w0 : UH_TW;
@@ -399,12 +416,25 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : 3) void k_uconv_h(UConvHArgs
 
 int mrx_unorm_finalize_tiled(const float* tstats, float* norm, int B, int ntiles, int tiles_x, int Cout, int H, int W, float eps, hipStream_t st);
 
-template <int NCOT>
-static void launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
-    constexpr size_t lds = 16 * (size_t)(UH_XBUF + UH_MS * NCOT * 2 * 64) + sizeof(float) * 2 * 4 * NCOT * 16;
+template <int NCOT, int DIL, bool UNET>
+static int launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
+    constexpr size_t lds = 16 * (size_t)(uh_xbuf(DIL) + UH_MS * NCOT * 2 * 64) + sizeof(float) * 2 * 4 * NCOT * 16;
+    static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
+    if (lds > 48 * 1024 && !attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_uconv_h<NCOT, DIL, UNET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
     const long long nitems = (long long)a.ntiles * mrx_cdiv(a.nct, NCOT) * a.B;
-    const unsigned grid = (unsigned)nitems;
-    hipLaunchKernelGGL((k_uconv_h<NCOT>), dim3(grid), dim3(UH_NT), lds, st, a);
+    MRX_REQUIRE(nitems < (1ll << 31), MRX_EUNSUP, "two-term fp16 convolution: %lld work items", nitems);
+    hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET>), dim3((unsigned)nitems), dim3(UH_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// output-channel blocks per work item: as many as still leave a work item per CU (every block re-stages the tile: fewer blocks, less staging)
+static int uh_pick_ncot(int nct, long long tiles_b) {
+    if (nct >= 4 && tiles_b * mrx_cdiv(nct, 4) >= 256) return 4;
+    if (nct >= 2 && tiles_b * mrx_cdiv(nct, 2) >= 256) return 2;
+    return nct >= 2 && tiles_b >= 512 ? 2 : 1;
 }
 
 // mrx_unet_conv3x3 with two-term fp16 operands (see the head of this file).  packed: mrx_unet_conv3x3_pack of w [Cout, Ca + Cb, 3, 3];
@@ -427,10 +457,37 @@ extern "C" int mrx_unet_conv3x3_h(const float* xa, const float* na, const float*
     a.abl = MRX_DEBUG_ENV("MRX_UCONVH_ABLATE") ? atoi(MRX_DEBUG_ENV("MRX_UCONVH_ABLATE")) : 0;
     const int ntiles = a.tiles_x * mrx_cdiv(H, UH_TH);
     a.ntiles = ntiles;
+    a.bias = nullptr, a.act = MRX_ACT_NONE, a.pad_mode = MRX_PAD_ZERO;
     hipStream_t st = (hipStream_t)stream;
-    // few tiles (the pooled levels): one cout block per work item, to fill the chip
-    if (a.nct == 1 || (long long)ntiles * B < 512) launch_uconv_h<1>(a, st);
-    else launch_uconv_h<2>(a, st);
-    MRX_LAUNCH_CHECK();
+    const int ncot = uh_pick_ncot(a.nct, (long long)ntiles * B);
+    const int rc = ncot == 4 ? launch_uconv_h<4, 1, true>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, true>(a, st) : launch_uconv_h<1, 1, true>(a, st));
+    if (rc) return rc;
     return mrx_unorm_finalize_tiled(work, norm, B, ntiles, a.tiles_x, Cout, H, W, eps, st);
+}
+
+// y = act(conv3x3(x, dilation 1 | 2, zero | replicate padding) + bias) for any channel counts, on two-term fp16 operands (conv_layers.py:121-123; the
+// layers the 64-channel kernels do not cover: qRIM's 128 -> 128, DIDN, ...).  bound: device scalar >= max |x| (mrx_max_abs, or what the producer
+// of x knows); packed: mrx_unet_conv3x3_pack of w [Cout, Cin, 3, 3].
+extern "C" int mrx_conv3x3_h_supported(int Cin, int Cout, int k, int dil) {
+    return Cin >= 1 && Cout >= 1 && k == 3 && (dil == 1 || dil == 2) && mrx_arith() == MRX_ARITH_F16X2;
+}
+extern "C" int mrx_conv3x3_h(const float* x, const float* bound, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H,
+                             int W, int dil, int pad_mode, int act, float slope, void* stream) {
+    MRX_REQUIRE(x && bound && packed && y && x != y, MRX_EINVAL, "mrx_conv3x3_h: null or aliased pointer");
+    MRX_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && (dil == 1 || dil == 2), MRX_EINVAL, "mrx_conv3x3_h: bad dims");
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv3x3_h: bad pad mode %d", pad_mode);
+    MRX_REQUIRE(act >= 0 && act <= 2, MRX_EINVAL, "mrx_conv3x3_h: bad activation %d", act);
+    MRX_REQUIRE((long long)H * W < (1ll << 30), MRX_EUNSUP, "mrx_conv3x3_h: size");
+    MRX_REQUIRE(mrx_arith() == MRX_ARITH_F16X2, MRX_EUNSUP, "mrx_conv3x3_h: the two-term fp16 form is off (MRIDC_AMD_ARITH)");
+    if (B == 0) return MRX_OK;
+    UConvHArgs a;
+    a.xa = x, a.na = nullptr, a.bound_a = bound, a.xb = nullptr, a.nb = nullptr, a.bound_b = nullptr;
+    a.packed = reinterpret_cast<const uh_u4*>(packed), a.y = y, a.tstats = nullptr;
+    a.Ca = Cin, a.Cb = 0, a.B = B, a.Cout = Cout, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, UH_TW), a.slope = slope;
+    a.ntiles = a.tiles_x * mrx_cdiv(H, UH_TH), a.nct = (Cout + 15) / 16, a.nsteps = (Cin + UH_SC - 1) / UH_SC;
+    a.abl = 0, a.bias = bias, a.act = act, a.pad_mode = pad_mode;
+    hipStream_t st = (hipStream_t)stream;
+    const int ncot = uh_pick_ncot(a.nct, (long long)a.ntiles * B);
+    if (dil == 1) return ncot == 4 ? launch_uconv_h<4, 1, false>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, false>(a, st) : launch_uconv_h<1, 1, false>(a, st));
+    return ncot == 4 ? launch_uconv_h<4, 2, false>(a, st) : (ncot == 2 ? launch_uconv_h<2, 2, false>(a, st) : launch_uconv_h<1, 2, false>(a, st));
 }

@@ -655,6 +655,13 @@ def conv1x1_64(x, weight, bias=None, act=ACT_NONE, slope=0.0, hh=None, h_prev=No
     hp = _lib.f32c(h_prev) if h_prev is not None else None
     if out is None:
         out = torch.empty_like(x)
+    if H3X3_CONV and _lib.arith() == "f16x2" and _lib.lib().mrx_conv1x1_sq_xmax_supported(Cin):
+        # a 3x3 layer on two-term fp16 operands may read this next (qRIM: cell of stack 1 -> convolution of stack 2): the kernel keeps the
+        # bound of its outputs, the consumer finds it on the tensor (ops._plain_bound) instead of running mrx_max_abs over it
+        xmax = torch.zeros(1, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mrx_conv1x1_sq_xmax(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out),
+                                                  _lib.ptr(xmax), B, Cin, H * W, int(act), float(slope), _lib.stream_ptr()), "mrx_conv1x1_sq_xmax")
+        return _attach_bound(out, xmax)
     _lib.check(_lib.lib().mrx_conv1x1_sq(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), B, Cin,
                                          H * W, int(act), float(slope), _lib.stream_ptr()), "mrx_conv1x1_sq")
     return out
@@ -783,6 +790,39 @@ def conv3x3_taps(x, weight, bias, pad_mode=PAD_ZERO, out=None):
     return out
 
 
+H3X3_CONV = True                  # (module attribute: a test hook) 3x3 convolutions of wide layers on two-term fp16 operands (mrx_conv3x3_h)
+H3X3_MIN_CIN = 32
+
+
+def conv3x3_h_supported(Cin, Cout, k, dilation):
+    return bool(_lib.lib().mrx_conv3x3_h_supported(int(Cin), int(Cout), int(k), int(dilation)))
+
+
+def conv3x3_h(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None, bound=None):
+    """act(conv3x3(x) + bias) for any channel counts on two-term fp16 operands (mrx_conv3x3_h; csrc/unet_f16.hip).  `bound`: device scalar
+    >= max |x| (default: the one x carries, else measured by mrx_max_abs)."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    weight = _lib.f32c(weight.detach())
+    Cout = int(weight.shape[0])
+    if tuple(weight.shape[1:]) != (Cin, 3, 3):
+        raise RuntimeError(f"conv3x3_h: weight {tuple(weight.shape)} vs {Cin} input channels")
+    L = _lib.lib()
+
+    def make():
+        pk = torch.empty(int(L.mrx_unet_conv3x3_pack_floats(Cout, Cin)), dtype=torch.float32, device=weight.device)
+        _lib.check(L.mrx_unet_conv3x3_pack(_lib.ptr(weight), Cout, Cin, _lib.ptr(pk), _lib.stream_ptr()), "mrx_unet_conv3x3_pack")
+        return pk
+    packed = _UNET_PACKS.get(weight, (), make)
+    bnd = bound if bound is not None else _plain_bound(x)
+    b = _lib.f32c(bias.detach()) if bias is not None else None
+    if out is None:
+        out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_conv3x3_h(_lib.ptr(x), _lib.ptr(bnd), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W, int(dilation),
+                               int(pad_mode), int(act), float(slope), _lib.stream_ptr()), "mrx_conv3x3_h")
+    return out
+
+
 def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
     """'same' conv, stride 1, square odd kernel (mrx_conv2d; 3x3 into 64 channels: mrx_conv3x3_wino)."""
     x = _lib.f32c(x)
@@ -800,6 +840,9 @@ def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0
     if (SB_CONV and kh == 3 and act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and conv3x3_sb_supported(Cin, Cout, kh, dilation)
             and (out is None or out.data_ptr() != x.data_ptr())):
         return conv3x3_sb(x, weight, bias, dilation, pad_mode, act, slope, out)
+    if (H3X3_CONV and kh == 3 and Cin >= H3X3_MIN_CIN and Cout >= 16 and act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
+            and conv3x3_h_supported(Cin, Cout, kh, dilation) and (out is None or out.data_ptr() != x.data_ptr())):
+        return conv3x3_h(x, weight, bias, dilation, pad_mode, act, slope, out)
     if (WINOGRAD_CONV and kh == 3 and Cin >= WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
             and conv3x3_wino_supported(Cin, Cout, kh, dilation) and (out is None or out.data_ptr() != x.data_ptr())):
         return conv3x3_wino(x, weight, bias, dilation, pad_mode, act, slope, out)
@@ -1538,10 +1581,19 @@ def _analytic_bound(n, device):
     return t
 
 
+def _attach_bound(t, bound):
+    """Remember a device scalar >= max |t| on the tensor object, with the tensor version it belongs to (an in-place torch op invalidates it)."""
+    t._mrx_bound = (bound, t._version)
+    return t
+
+
 def _plain_bound(x):
-    """Device scalar >= max |x| of a plain tensor: the bound its producer attached (unet_cnorm_pad, unet_avg_pool2x2), else measured (mrx_max_abs)."""
+    """Device scalar >= max |x| of a plain tensor: the bound its producer attached (unet_cnorm_pad, unet_avg_pool2x2, the 128-channel 1x1 cell
+    kernel) if the tensor has not been written by torch since, else measured (mrx_max_abs)."""
     b = getattr(x, "_mrx_bound", None)
-    return b if b is not None else max_abs(x).reshape(1)
+    if b is not None and b[1] == x._version:
+        return b[0]
+    return max_abs(x).reshape(1)
 
 
 def unet_conv3x3(src_a, src_b, weight, eps=1e-5, slope=0.2):
@@ -1606,9 +1658,10 @@ def unet_avg_pool2x2(src, slope=0.2):
     _lib.check(_lib.lib().mrx_unet_avgpool(_lib.ptr(x), _lib.ptr(nrm), _lib.ptr(out), B * C, H, W, float(slope), _lib.stream_ptr()),
                "mrx_unet_avgpool")
     # an average is bounded by what it averages: sqrt(n) of the normalised planes, or the plain source's own bound (if it has one)
-    bound = _analytic_bound(H * W, x.device) if nrm is not None else getattr(src, "_mrx_bound", None)
-    if bound is not None:
-        out._mrx_bound = bound
+    if nrm is not None:
+        _attach_bound(out, _analytic_bound(H * W, x.device))
+    elif getattr(src, "_mrx_bound", None) is not None and src._mrx_bound[1] == src._version:
+        _attach_bound(out, src._mrx_bound[0])
     return out
 
 
@@ -1653,7 +1706,7 @@ def unet_cnorm_pad(x, h_pad, w_pad):
     work = torch.empty(int(L.mrx_unet_cnorm_work_floats(B)), dtype=torch.float32, device=x.device)
     _lib.check(L.mrx_unet_cnorm_pad(_lib.ptr(x), _lib.ptr(out), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(work), B, c, H, W, int(h_pad[0]),
                                     int(h_pad[1]), int(w_pad[0]), int(w_pad[1]), _lib.stream_ptr()), "mrx_unet_cnorm_pad")
-    out._mrx_bound = _analytic_bound(c * H * W, x.device)    # normalised per (batch, component) over c H W values (unbiased std: smaller still)
+    _attach_bound(out, _analytic_bound(c * H * W, x.device))    # normalised per (batch, component) over c H W values (unbiased std: smaller still)
     return out, mean, std
 
 

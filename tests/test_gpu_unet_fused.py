@@ -85,7 +85,7 @@ def test_unet_conv3x3_two_term_fp16_scales(dev):
         y, _ = ops.unet_conv3x3(x, None, w)                                   # bound measured (mrx_max_abs)
         assert rel_l2(y, ref) <= 1e-6, (xs, ws, rel_l2(y, ref))
         xb = x.clone()
-        xb._mrx_bound = (x.abs().max() * 1000.0).reshape(1)                   # a bound 1000 x too large: 10 of the 17 spare bits used up
+        ops._attach_bound(xb, (x.abs().max() * 1000.0).reshape(1))            # a bound 1000 x too large: 10 of the 17 spare bits used up
         y2, _ = ops.unet_conv3x3(xb, None, w)
         assert rel_l2(y2, ref) <= 1e-6, (xs, ws, rel_l2(y2, ref))
         exact = ops.UNET_F16
