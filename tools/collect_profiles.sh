@@ -29,5 +29,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/pmc_m -o p --outpu
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES -d $O/pmc_c -o p --output-format csv -- python3 tools/probe/pmc_r02.py > /dev/null 2>&1
 python3 tools/traffic_json.py $O/pmc_f/*counter_collection.csv $O/pmc_w/*counter_collection.csv $(python3 -c "from mridc_amd import _lib; print(_lib.lib().mrx_version())") $O/pmc_m/*counter_collection.csv $O/pmc_c/*counter_collection.csv > $O/traffic.json
 python3 tools/pmc_summary.py $O/pmc_f/*counter_collection.csv $O/pmc_w/*counter_collection.csv $O/pmc_m/*counter_collection.csv $O/pmc_c/*counter_collection.csv > $O/pmc.md
-rm -rf $O/prof_headline $O/prof_train $O/prof_e2evn $O/prof_2d
+rocprofv3 --kernel-trace --stats -d $O/prof_q -o q -- python3 bench.py --model qcirim --steps 4 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 > $O/prof_q.log 2>&1
+python3 tools/rocpd_summary.py $O/prof_q/*results.db > $O/qcirim_kernel_stats.md
+rm -rf $O/prof_headline $O/prof_train $O/prof_e2evn $O/prof_2d $O/prof_q
 ls -la $O
