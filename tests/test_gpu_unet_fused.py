@@ -178,3 +178,34 @@ def test_norm_unet_head_and_tail_in_one_pass(shape, dev):
         y = (y.reshape(B, 2, c * H * W) * sd.view(B, 2, 1) + m.view(B, 2, 1)).view(B, 2, c, H, W).permute(0, 2, 3, 4, 1)
         got = ops.unet_conv1x1_cunnorm((raw, nrm) if lazy else raw, w1, b1, mean, std, h_pad[0], w_pad[0], H, W)
         assert rel_l2(got, y) <= 2e-6
+
+
+@pytest.mark.parametrize("cfg", [(14, 2, 11, 640, 372), (18, 4, 15, 320, 186), (8, 3, 7, 45, 37)])
+def test_norm_unet_two_term_fp16_against_the_fp32_input_kernels(cfg, dev):
+    """The whole NormUnet with its 3x3 convolutions on two-term fp16 operands (default) against the fp32-input MFMA kernels (ops.UNET_F16 = False)
+    -- and, through MRIDC_AMD_ARITH=bf16x3, the same switch by the library's one arithmetic variable: ten normalised layers deep, 2e-5."""
+    import os
+    from mridc_amd import ops
+    from mridc_amd.collections.reconstruction.models.unet_base.unet_block import NormUnet
+    chans, pools, pad, H, W = cfg
+    torch.manual_seed(chans + pools + 1)
+    net = NormUnet(chans, pools, padding_size=pad).eval().to(dev)
+    x = torch.randn(2, 1, H, W, 2, generator=torch.Generator().manual_seed(W)).to(dev)
+    keep, env = ops.UNET_F16, os.environ.get("MRIDC_AMD_ARITH")
+    try:
+        with torch.no_grad():
+            ops.UNET_F16 = True
+            got = net(x)
+            ops.UNET_F16 = False
+            want = net(x)
+            ops.UNET_F16 = True
+            os.environ["MRIDC_AMD_ARITH"] = "bf16x3"
+            want2 = net(x)
+    finally:
+        ops.UNET_F16 = keep
+        if env is None:
+            os.environ.pop("MRIDC_AMD_ARITH", None)
+        else:
+            os.environ["MRIDC_AMD_ARITH"] = env
+    assert torch.equal(want, want2)                      # both switches select the same kernels
+    assert rel_l2(got, want) <= 2e-5, rel_l2(got, want)
