@@ -381,30 +381,45 @@ __global__ __launch_bounds__(UC_NT) void k_uconvT(const float* __restrict__ x, c
             *reinterpret_cast<uc_f2*>(o + OW) = (uc_f2){acc[co][2], acc[co][3]};
         }
     }
-    __shared__ float red[UC_NT / 64];
+    // tile statistics of the COG planes: two block reductions in all (one per pass, every plane at once; a wave's sum on the vector ALU:
+    // DPP row sums + four readlanes) -- one pair of barriers per plane made the 14-plane form 56 barriers long
+    __shared__ float red[2][UC_NT / 64][COG];
     const long long rem = HW - (long long)blockIdx.x * UC_NT;
     const float inv_n = 1.0f / (4.0f * (float)(rem < UC_NT ? rem : UC_NT));
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    auto wave_sum = [](float t) {
+#define UC_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+        t += UC_DPP(t, 0xB1);
+        t += UC_DPP(t, 0x4E);
+        t += UC_DPP(t, 0x141);
+        t += UC_DPP(t, 0x140);      // every lane of a row holds the row's sum
+#undef UC_DPP
+        const int ti = __builtin_bit_cast(int, t);
+        return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 16))) +
+               (__builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 48)));
+    };
+    float mean[COG];
 #pragma unroll
-    for (int co = 0; co < COG; ++co) {
-        float mean = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int co = 0; co < COG; ++co) {
             float t = 0.f;
             if (live) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) t += pass == 0 ? acc[co][q] : (acc[co][q] - mean) * (acc[co][q] - mean);
+                for (int q = 0; q < 4; ++q) t += pass == 0 ? acc[co][q] : (acc[co][q] - mean[co]) * (acc[co][q] - mean[co]);
             }
-            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-            __syncthreads();                   // the previous round's readers are done with `red`
-            if (lane == 0) red[wv] = t;
-            __syncthreads();
-            const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+            t = wave_sum(t);
+            if (lane == 0) red[pass][wv][co] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int co = 0; co < COG; ++co) {
+            const float tot = (red[pass][0][co] + red[pass][1][co]) + (red[pass][2][co] + red[pass][3][co]);
             if (pass == 0)
-                mean = tot * inv_n;
+                mean[co] = tot * inv_n;
             else if (threadIdx.x == 0) {
                 float* ts = tstats + (((long long)b * gridDim.x + blockIdx.x) * Cout + g0 + co) * 2;
-                ts[0] = mean;
+                ts[0] = mean[co];
                 ts[1] = tot;
             }
         }
@@ -434,8 +449,12 @@ extern "C" int mrx_unet_conv_transpose2x2(const float* x, const float* nrm, cons
     hipStream_t st = (hipStream_t)stream;
     const long long HW = (long long)H * W, ntiles = (HW + UC_NT - 1) / UC_NT;
     auto fits = [&](int cog) { return (size_t)Cin * (cog * 16 + 8) <= 48 * 1024; };     // the group's weight quads + the input norm in LDS
-    if (Cout % 14 == 0 && fits(14) && ntiles * B * (Cout / 14) >= 2048) launch_uconvT<14>(x, nrm, w, out, B, Cin, Cout, H, W, slope, work, st);
-    else if (Cout % 8 == 0 && fits(8) && ntiles * B * (Cout / 8) >= 2048) launch_uconvT<8>(x, nrm, w, out, B, Cin, Cout, H, W, slope, work, st);
+    // the largest group of output channels per workgroup (every group re-reads and re-normalises the input) that still leaves a workgroup per CU
+    auto use = [&](int cog) { return Cout % cog == 0 && fits(cog) && ntiles * B * (Cout / cog) >= 256; };
+    if (use(14)) launch_uconvT<14>(x, nrm, w, out, B, Cin, Cout, H, W, slope, work, st);
+    else if (use(12)) launch_uconvT<12>(x, nrm, w, out, B, Cin, Cout, H, W, slope, work, st);
+    else if (use(8)) launch_uconvT<8>(x, nrm, w, out, B, Cin, Cout, H, W, slope, work, st);
+    else if (use(6)) launch_uconvT<6>(x, nrm, w, out, B, Cin, Cout, H, W, slope, work, st);
     else launch_uconvT<2>(x, nrm, w, out, B, Cin, Cout, H, W, slope, work, st);
     hipLaunchKernelGGL(k_unorm_finalize<false>, dim3(B * Cout), dim3(UC_NT), 0, st, (const float*)work, norm, (int)ntiles, 0, Cout, 0, 0,
                        4.0 * UC_NT, 4.0 * (double)(HW - (ntiles - 1) * UC_NT), eps);
