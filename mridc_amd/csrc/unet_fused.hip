@@ -234,47 +234,52 @@ __global__ __launch_bounds__(UC_NT) void k_uconv(UConvArgs a) {
     }
 }
 
-// per-tile (mean, M2) -> per-plane (mean, 1 / sqrt(M2 / n + eps)): one workgroup per (b, cout), Chan et al. pairwise updates in double in a
-// fixed order (thread-strided tiles, butterfly over the wave, the four waves in order).  TILED: tile sizes follow from the tile index
-// (8 x 32 tiles of an H x W plane); else every tile holds n_tile values but the last.
-struct UcMoments {
-    double n, mean, m2;
-};
-__device__ __forceinline__ void uc_merge(UcMoments& a, double nb, double mb, double qb) {
-    const double tot = a.n + nb;
-    if (tot > 0.0) {
-        const double delta = mb - a.mean, r = nb / tot;
-        a.mean += delta * r;
-        a.m2 += qb + delta * delta * a.n * r;
-    }
-    a.n = tot;
+// per-tile (mean, M2) -> per-plane (mean, 1 / sqrt(M2 / n + eps)): one workgroup per (b, cout).  Two fixed-order sums in double over the tiles:
+//   mean = sum_i n_i mean_i / N,   M2 = sum_i (M2_i + n_i (mean_i - mean)^2)      (the parallel-variance identity around the global mean)
+// -- no division per tile (a pairwise Chan merge has one, in double, on the dependent chain of every thread: 4.6 us per launch, ten launches per
+// cascade).  TILED: tile sizes follow from the tile index (8 x 32 tiles of an H x W plane); else every tile holds n_tile values but the last.
+__device__ __forceinline__ double uc_block_sum(double v, double* sm) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();                                   // (the previous sum's readers are done with sm)
+    if ((threadIdx.x & 63) == 0) sm[wv] = v;
+    __syncthreads();
+    double t = sm[0];
+    for (int k = 1; k < UC_NT / 64; ++k) t += sm[k];   // the waves in order
+    return t;
 }
 template <bool TILED>
 __global__ __launch_bounds__(UC_NT) void k_unorm_finalize(const float* __restrict__ tstats, float* __restrict__ norm, int ntiles, int tiles_x,
                                                          int Cout, int H, int W, double n_tile, double n_last, float eps) {
-    __shared__ double sm[3 * (UC_NT / 64)];
+    __shared__ double sm[UC_NT / 64];
     const int plane_id = blockIdx.x, b = plane_id / Cout, co = plane_id - b * Cout;
-    UcMoments a = {0.0, 0.0, 0.0};
-    for (int t = threadIdx.x; t < ntiles; t += UC_NT) {
-        double nb;
+    auto count = [&](int t) {
         if (TILED) {
             const int ty = t / tiles_x, tx = t - ty * tiles_x;
             const int nr = H - ty * UC_TH < UC_TH ? H - ty * UC_TH : UC_TH, nc = W - tx * UC_TW < UC_TW ? W - tx * UC_TW : UC_TW;
-            nb = (double)(nr * nc);
-        } else {
-            nb = t == ntiles - 1 ? n_last : n_tile;
+            return (double)(nr * nc);
         }
-        const float2 p = *reinterpret_cast<const float2*>(tstats + (((long long)b * ntiles + t) * Cout + co) * 2);
-        uc_merge(a, nb, (double)p.x, (double)p.y);
+        return t == ntiles - 1 ? n_last : n_tile;
+    };
+    const float* ts = tstats + ((long long)b * ntiles * Cout + co) * 2;
+    double sn = 0.0, smean = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += UC_NT) {
+        const double nb = count(t);
+        sn += nb;
+        smean += nb * (double)ts[(long long)t * Cout * 2];
     }
-    for (int off = 32; off > 0; off >>= 1) uc_merge(a, __shfl_xor(a.n, off, 64), __shfl_xor(a.mean, off, 64), __shfl_xor(a.m2, off, 64));
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) sm[3 * wv] = a.n, sm[3 * wv + 1] = a.mean, sm[3 * wv + 2] = a.m2;
-    __syncthreads();
+    const double N = uc_block_sum(sn, sm);
+    const double mean = uc_block_sum(smean, sm) / N;
+    double q = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += UC_NT) {
+        const float2 p = *reinterpret_cast<const float2*>(ts + (long long)t * Cout * 2);
+        const double d = (double)p.x - mean;
+        q += (double)p.y + count(t) * d * d;
+    }
+    const double m2 = uc_block_sum(q, sm);
     if (threadIdx.x == 0) {
-        for (int k = 1; k < UC_NT / 64; ++k) uc_merge(a, sm[3 * k], sm[3 * k + 1], sm[3 * k + 2]);
-        norm[(long long)plane_id * 2] = (float)a.mean;
-        norm[(long long)plane_id * 2 + 1] = 1.0f / sqrtf((float)a.m2 / (float)a.n + eps);
+        norm[(long long)plane_id * 2] = (float)mean;
+        norm[(long long)plane_id * 2 + 1] = 1.0f / sqrtf((float)m2 / (float)N + eps);
     }
 }
 
