@@ -15,7 +15,7 @@ SOURCES = [
     ("api.cpp", []),
     ("host_masks.cpp", []),
     ("fft.hip", []),
-    ("llg372.hip", ["-fno-slp-vectorize"]),   # complex values are explicit packed pairs (pfa372.h); no extra pairing of scalar code
+    ("llg372.hip", ["-fno-slp-vectorize"]),
     ("elementwise.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
     ("rim_layer.hip", []),
@@ -33,7 +33,12 @@ SOURCES = [
     ("qmri.hip", ["-ffp-contract=off"]),
     ("cnorm.hip", []),
 ]
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# NO packed-fp32 vector instructions (v_pk_add / mul / fma_f32) anywhere in the library: measured on MI355X (tools/probe/mfma_pk_interference.py),
+# a wave executing them returns WRONG results while a wave of another kernel on the same SIMD issues XDL MFMAs (two streams: the FFT kernels of
+# one slice next to the U-Net / few-channel convolutions of another -- 1e-3 .. 5e-2 errors, bit-exact when either side is alone).  The target
+# feature stops the compiler from forming them, MRX_NO_PACKED_FP32 selects the scalar complex layer of pfa372.h instead of its inline assembly.
+NO_PACKED_FP32 = ["-DMRX_NO_PACKED_FP32", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32
 
 
 def _hipcc():

@@ -40,7 +40,7 @@ MRX_HD int pfa372_k(int k1, int k2) { return (217 * k1 + 156 * k2) % PFA_N; }
 // op_sel / neg modifiers).  Measured on gfx950 (tools/probe/valu_probe.hip): a packed op issues in ~4.7 cycles for two lanes' worth
 // of work with any operand kind, a scalar-fp32 VALU op in ~2.6 cycles -- but ~4.3 when one source is an SGPR, which is where dense
 // DFT coefficients live; so the constant-coefficient FMAs must be packed.  Host (tests/emu): the same functions in plain C++.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MRX_NO_PACKED_FP32)
 typedef float pfa_c __attribute__((ext_vector_type(2)));
 #define PFA_FN __device__ __forceinline__
 PFA_FN pfa_c pfa_mk(float x, float y) { return (pfa_c){x, y}; }

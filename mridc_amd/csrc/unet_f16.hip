@@ -353,24 +353,22 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
                     acc[sg][ct][r] = v;
                 }
         }
-        // stores: the two 16-pixel accumulator tiles of a row trade rows (v_permlane16_swap), so that lanes 0-31 / 32-63 of a store hold 32
-        // consecutive pixels of ONE output channel each (128-byte segments instead of four of 64 bytes)
+        // stores: lane = pixel of a 16-pixel accumulator tile, four output channels per lane (64-byte segments).  (Trading rows between the two
+        // tiles of an image row with v_permlane16_swap, for 128-byte segments, was no faster and is suspected of a missing wait state: see the note
+        // in DESIGN.md 4.3)
         if (!(a.abl & 2))
 #pragma unroll
-        for (int rw = 0; rw < 2; ++rw) {
-            const int oy = h0 + 2 * wave + rw, ox = w0 + 16 * (lg & 1) + l15;
-            const bool inside = oy < a.H && ox < a.W;
+        for (int sg = 0; sg < 4; ++sg) {
+            const int oy = h0 + 2 * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
+            if (oy < a.H && ox < a.W) {
 #pragma unroll
-            for (int ct = 0; ct < NCOT; ++ct)
+                for (int ct = 0; ct < NCOT; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    typedef unsigned uh_u2 __attribute__((ext_vector_type(2)));
-                    const uh_u2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * rw][ct][r]), __float_as_uint(acc[2 * rw + 1][ct][r]), false, false);
-                    const int co = co0 + 16 * ct + 8 * (lg >> 1) + r;            // sw.x: channel co, sw.y: channel co + 4
-                    float* yp = a.y + ((long long)b * a.Cout + co) * plane + (long long)oy * a.W + ox;
-                    if (inside && co < a.Cout) yp[0] = __uint_as_float(sw.x);
-                    if (inside && co + 4 < a.Cout) yp[4 * plane] = __uint_as_float(sw.y);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + 16 * ct + 4 * lg + r;
+                        if (co < a.Cout) a.y[((long long)b * a.Cout + co) * plane + (long long)oy * a.W + ox] = acc[sg][ct][r];
+                    }
+            }
         }
         if (!UNET || (a.abl & 4)) return;
         // InstanceNorm statistics of this tile, per cout (the scheme of k_uconv, unet_fused.hip: mean over the tile's valid pixels, then the squared
