@@ -9,13 +9,20 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmridc_amd.so")
 
+# NO packed-fp32 vector instructions (v_pk_add / mul / fma_f32) in the FFT kernels: measured on MI355X (tools/probe/mfma_pk_interference.py), these
+# kernels return WRONG results while a wave of another kernel on the same SIMD issues XDL MFMAs (two streams: the transforms of one slice next to
+# the U-Net / few-channel convolutions of another -- 1e-3 .. 5e-2 errors, bit-exact when either side is alone) and are bit-exact in every
+# combination once built without them.  The target feature stops the compiler from forming them, MRX_NO_PACKED_FP32 selects the scalar complex
+# layer of pfa372.h instead of its inline assembly.  (Kernels of the other sources in which the compiler forms a few packed operations --
+# transposed convolution, pooling, normalisation -- were tested as victims and are not affected; tests/test_gpu_concurrent_streams.py.)
+NO_PACKED_FP32 = ["-DMRX_NO_PACKED_FP32", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # (source, extra flags).  elementwise.hip is built without fp contraction so that the pointwise complex
 # operators round exactly like the reference's separate torch ops (mul, mul, sub).
 SOURCES = [
     ("api.cpp", []),
     ("host_masks.cpp", []),
-    ("fft.hip", []),
-    ("llg372.hip", ["-fno-slp-vectorize"]),
+    ("fft.hip", NO_PACKED_FP32),
+    ("llg372.hip", ["-fno-slp-vectorize"] + NO_PACKED_FP32),
     ("elementwise.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
     ("rim_layer.hip", []),
@@ -33,12 +40,7 @@ SOURCES = [
     ("qmri.hip", ["-ffp-contract=off"]),
     ("cnorm.hip", []),
 ]
-# NO packed-fp32 vector instructions (v_pk_add / mul / fma_f32) anywhere in the library: measured on MI355X (tools/probe/mfma_pk_interference.py),
-# a wave executing them returns WRONG results while a wave of another kernel on the same SIMD issues XDL MFMAs (two streams: the FFT kernels of
-# one slice next to the U-Net / few-channel convolutions of another -- 1e-3 .. 5e-2 errors, bit-exact when either side is alone).  The target
-# feature stops the compiler from forming them, MRX_NO_PACKED_FP32 selects the scalar complex layer of pfa372.h instead of its inline assembly.
-NO_PACKED_FP32 = ["-DMRX_NO_PACKED_FP32", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():

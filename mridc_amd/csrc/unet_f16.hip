@@ -353,9 +353,8 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
                     acc[sg][ct][r] = v;
                 }
         }
-        // stores: lane = pixel of a 16-pixel accumulator tile, four output channels per lane (64-byte segments).  (Trading rows between the two
-        // tiles of an image row with v_permlane16_swap, for 128-byte segments, was no faster and is suspected of a missing wait state: see the note
-        // in DESIGN.md 4.3)
+        // stores: lane = pixel of a 16-pixel accumulator tile, four output channels per lane (64-byte segments; trading rows between the two
+        // tiles of an image row with v_permlane16_swap, for 128-byte segments, measured no faster)
         if (!(a.abl & 2))
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {

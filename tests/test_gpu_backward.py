@@ -269,7 +269,9 @@ def test_e2evn_training_gradients_vs_oracle_autograd(dev, case):
             if n_.endswith("dc_weight"):
                 p_.fill_(0.7)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    s = synthetic.make_slice(3, 26, 21, slice_idx=2)
+    # (slice 2 with seed 5 sits on a sign boundary of the l1 / |re| + |im| chain in the RSS case: a 1e-7 change of the forward arithmetic moves
+    # one gradient by 1e-2 there, 3e-6 everywhere else -- five other seed / slice pairs measured; the RSS case uses slice 3)
+    s = synthetic.make_slice(3, 26, 21, slice_idx=2 if comb == "SENSE" else 3)
     y = s["y"] * 50.0                                   # O(1) magnitudes through the normalisations
     p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
     ref_out = oracle.models.varnet_forward(p, cfg, y, s["sensitivity_maps"], s["mask"], None, s["target"])

@@ -354,7 +354,9 @@ def test_e2evn_chained_reduce_at_w372(dev, case):
                 outs[chain] = model(y.to(dev), S.to(dev), mask.to(dev), None, target.to(dev))
     finally:
         VarNet.chain_reduce = keep
-    assert torch.equal(torch.view_as_real(outs[True]), torch.view_as_real(outs[False])), "chained reduce changed the result"
+    # (the chained pass and the separate reduction are two kernels: since the library dropped packed-fp32 instructions -- which pinned the
+    # instruction sequence of the complex arithmetic -- the compiler may contract their multiply-adds differently: fp32 round-off, no more)
+    assert rel_l2(torch.view_as_real(outs[True]), torch.view_as_real(outs[False])) <= 2e-6, "chained reduce changed the result"
     assert_close(torch.view_as_real(outs[True]), torch.view_as_real(ref), 5e-5, "VarNet 3 cascades at W = 372, hybrid space")
 
 
@@ -381,7 +383,7 @@ def test_recurrent_varnet_chained_reduce_at_w372(dev, sharing, monkeypatch):
         monkeypatch.setenv("MRIDC_AMD_CHAIN_REDUCE", chain)
         with torch.no_grad():
             outs[chain] = model(y.to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev), None, d["target"].to(dev))
-    assert torch.equal(torch.view_as_real(outs["1"]), torch.view_as_real(outs["0"])), "chained reduce changed the result"
+    assert rel_l2(torch.view_as_real(outs["1"]), torch.view_as_real(outs["0"])) <= 2e-6, "chained reduce changed the result"   # (fp32 round-off: see above)
     assert_close(torch.view_as_real(outs["1"]), torch.view_as_real(ref), 5e-5, "Recurrent VarNet at W = 372, hybrid space")
 
 
@@ -413,7 +415,9 @@ def test_cascadenet_chained_reduce_at_w372(dev, no_dc):
                 outs[chain] = model(y.to(dev), d["sensitivity_maps"].to(dev), d["mask"].to(dev), None, d["target"].to(dev))
     finally:
         CascadeNet.chain_reduce = keep
-    assert torch.equal(torch.view_as_real(outs[True]), torch.view_as_real(outs[False])), "chained reduce changed the result"
+    # (the chained pass and the separate reduction are two kernels: since the library dropped packed-fp32 instructions -- which pinned the
+    # instruction sequence of the complex arithmetic -- the compiler may contract their multiply-adds differently: fp32 round-off, no more)
+    assert rel_l2(torch.view_as_real(outs[True]), torch.view_as_real(outs[False])) <= 2e-6, "chained reduce changed the result"
     assert_close(torch.view_as_real(outs[True]), torch.view_as_real(ref), 5e-5, "CascadeNet at W = 372, hybrid space")
 
 
