@@ -1,7 +1,7 @@
 """Round-3 finding: kernels built on packed-fp32 vector ops (the FFT kernels) return WRONG results when their waves share a SIMD with waves of
 another stream's kernel that issues XDL MFMAs (k_uconv_h, k_conv_sbs: several small workgroups per CU), and bit-exact ones otherwise.
 Victims V (each a hipGraph of one op repeated), aggressor A, all replayed concurrently on separate streams vs one at a time.
-VICTIM = prep | reduce | expand, AGGR = uconv | sbs | convT | pool."""
+VICTIM = prep | reduce | expand | llg372 | llg2d | fft2 | ifft2, AGGR = uconv | sbs | convT | pool."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -35,6 +35,17 @@ def rep(fn, n):
 victims = dict(prep=rep(lambda: ops.llg_prepare(d["y"], False, "backward", [-2, -1]), 6),
                reduce=rep(lambda: ops.sens_reduce(YH, d["sensitivity_maps"], False, "backward", [-2, -1], hybrid=True), 6),
                expand=rep(lambda: ops.sens_expand_dc_hybrid(RED.unsqueeze(1), d["sensitivity_maps"], YH, YH, d["mask"], one, False, "backward", reduce=True)[0], 6))
+
+
+from mridc_amd.collections.common.parts import fft as mfft
+eta0 = r(2, 640, 372, 2)
+m1 = ops.row_invariant_view(d["mask"])
+op372 = ops.llg372_prepare(YH, d["sensitivity_maps"], m1, False)
+mask2d = (torch.rand(1, 1, 640, 372, 1, generator=g) < 0.3).to(dev)
+victims.update(llg372=rep(lambda: ops.llg372(eta0, op372, 1.0, "backward"), 6),
+               llg2d=rep(lambda: ops.llg(eta0, d["y"], d["sensitivity_maps"], mask2d, 1.0, False, "backward"), 4),
+               fft2=rep(lambda: mfft.fft2(d["y"], centered=True, normalization="ortho", spatial_dims=[-2, -1]), 4),
+               ifft2=rep(lambda: mfft.ifft2(d["y"], centered=False, normalization="backward", spatial_dims=[-2, -1]), 4))
 
 
 def chain():
