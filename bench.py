@@ -285,6 +285,33 @@ def bench_streams(n):
     return _STREAM_POOL[:n]
 
 
+def _tensors(o):
+    """Every tensor of a nested output, in order."""
+    if isinstance(o, torch.Tensor):
+        return [o]
+    if isinstance(o, (list, tuple)):
+        return [t for e in o for t in _tensors(e)]
+    return []
+
+
+LAST_CONCURRENCY_CHECK = {}
+
+
+def concurrent_replays_match_serial(graphs, streams, outs):
+    """After the timed (concurrent) replays: replay every graph once more ALONE and compare its outputs, bit for bit, with what the concurrent
+    replays left there -- kernels of different slices sharing CUs must not influence each other ("Concurrent streams").  None
+    without graphs or with a single stream."""
+    if not graphs or len(graphs) < 2:
+        return None
+    torch.cuda.synchronize()
+    conc = [[t.clone() for t in _tensors(o)] for o in outs]
+    for g_, st in zip(graphs, streams):
+        with torch.cuda.stream(st):
+            g_.replay()
+        torch.cuda.synchronize()
+    return all(torch.equal(a, b) for c, o in zip(conc, outs) for a, b in zip(c, _tensors(o)))
+
+
 def _replay_loop(step, datas, args):
     """Shared timed region of the inference benchmarks: one HIP stream + one captured hipGraph per in-flight slice batch, args.steps
     replays each, barrier + synchronize on both sides, max over ranks.  Returns (elapsed, per_rank, graphed, last outputs)."""
@@ -321,6 +348,7 @@ def _replay_loop(step, datas, args):
                     outs[i] = step(datas[i])
     dist_barrier()
     elapsed, per_rank = rank_times(time.perf_counter() - t0, torch.device("cuda", torch.cuda.current_device()))
+    LAST_CONCURRENCY_CHECK["bit_identical"] = concurrent_replays_match_serial(graphs, streams, outs)
     return elapsed, per_rank, bool(graphs), outs
 
 
@@ -395,6 +423,7 @@ def bench_qcirim(args, world, rank, dev, checks=False):
     if checks:
         _event_profile(timer, step, datas[0])
     elapsed, per_rank, graphed, outs = _replay_loop(step, datas, args)
+    conc_ok = LAST_CONCURRENCY_CHECK.get("bit_identical")
     res = dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256", value=world * NS * args.steps / elapsed,
                unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
                higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
@@ -402,6 +431,7 @@ def bench_qcirim(args, world, rank, dev, checks=False):
                config=dict(workload=f"qCIRIM 1 cascade x 8 time-steps, IndRNN 128 filters, 4 echoes, 32 coils, 256x256, {NS} slice(s) "
                                     f"per GPU and step ({NS} HIP stream(s), {'hipGraph' if graphed else 'eager'}), random-init weights",
                            parallelism=f"slice-sharded x{world}"))
+    res["concurrent_replays_bit_identical_to_serial"] = conc_ok
     if checks and rank == 0:
         direct = 2.0 * 128 * 128 * 9 * H * W
         msh, nh = timer.mean_ms("h3x3_128x128")
@@ -514,6 +544,7 @@ def bench_e2evn(args, world, rank, dev, checks=False):
     if checks:
         _event_profile(timer, step, datas[0])
     elapsed, per_rank, graphed, outs = _replay_loop(step, datas, args)
+    conc_ok = LAST_CONCURRENCY_CHECK.get("bit_identical")
     Bt = NS * B
     res = dict(metric=f"slices/sec (inference), {label} {C}-coil {H}x{W}", value=world * Bt * args.steps / elapsed,
                unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -523,6 +554,7 @@ def bench_e2evn(args, world, rank, dev, checks=False):
                config=dict(workload=f"{desc}, {C} coils, {H}x{W}, batch "
                                     f"{Bt} per GPU ({NS} concurrent HIP stream(s), {'one hipGraph each' if graphed else 'eager'}), random-init weights "
                                     "(seed 0)", parallelism=f"slice-sharded x{world}"))
+    res["concurrent_replays_bit_identical_to_serial"] = conc_ok
     if checks and rank == 0:
         # dominant kernel: the U-Net's 3x3 convolutions (k_uconv: fp32 MFMA 16x16x4 blocks, InstanceNorm statistics from the accumulators,
         # normalisation + LeakyReLU of the PREVIOUS layer applied by the tile loader) -- the shape that takes the most time
@@ -1017,6 +1049,7 @@ def main():
                         out = o_
     barrier()
     elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
+    headline_conc_ok = concurrent_replays_match_serial(graphs, streams, outs)
 
     if rank == 0:
         T_ = model.time_steps
@@ -1169,6 +1202,7 @@ def main():
                                      raw_ms=dict(llg=timer.raw_ms("llg372") or timer.raw_ms("llg"), conv_layer1=timer.raw_ms("conv_layer1"),
                                                  conv_layer2=timer.raw_ms("conv_layer2_f16t") or timer.raw_ms("conv_layer2_sbt") or timer.raw_ms("conv_layer2_sb") or timer.raw_ms("conv_layer2_wino") or timer.raw_ms("conv_layer2"),
                                                  final=timer.raw_ms("final_gather") or timer.raw_ms("final"))))
+        res["concurrent_replays_bit_identical_to_serial"] = headline_conc_ok
         res["config"]["arith"] = ("fp32 tensors and fp32 accumulation; the two RIM layers multiply two-term fp16 operands (x = (h1 + h2) 2^-k, 22 significant "
                                   "bits, block-scaled by powers of two; three of the four term products) on v_mfma_f32_32x32x16_f16: error against float64 "
                                   "equal to the fp32-MFMA kernels' (2e-7); FFT / data consistency in fp32 vector arithmetic")
