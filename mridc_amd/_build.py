@@ -23,7 +23,7 @@ SOURCES = [
     ("host_masks.cpp", []),
     ("fft.hip", NO_PACKED_FP32),
     ("llg372.hip", ["-fno-slp-vectorize"] + NO_PACKED_FP32),
-    ("elementwise.hip", ["-ffp-contract=off"]),
+    ("elementwise.hip", ["-ffp-contract=off"] + NO_PACKED_FP32),     # (bit-neutral here: without contraction a packed op is two scalar ones)
     ("conv.hip", []),
     ("rim_layer.hip", []),
     ("rim_layer_wino.hip", []),
@@ -37,7 +37,7 @@ SOURCES = [
     ("unet.hip", []),
     ("unet_fused.hip", []),
     ("unet_f16.hip", []),
-    ("qmri.hip", ["-ffp-contract=off"]),
+    ("qmri.hip", ["-ffp-contract=off"] + NO_PACKED_FP32),
     ("cnorm.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -101,3 +101,27 @@ def test_whole_models_on_concurrent_streams_are_bit_identical_to_serial(dev, whi
             return torch.view_as_real(model(d["y"], d["sensitivity_maps"], d["mask"], None, d["target"]))
     datas = [{k: v.to(dev) for k, v in synthetic.make_slice(15, 640, 372, slice_idx=i).items()} for i in range(streams)]
     assert _concurrent_vs_serial([(lambda d=d: run(d)) for d in datas], reps=3) == 0
+
+
+def test_qcirim_on_concurrent_streams_is_bit_identical_to_serial(dev):
+    """qCIRIM (few-channel convolution, 128-channel layers, the signal model's pointwise kernels, 256 x 256 transforms) on two streams."""
+    import bench
+    from mridc_amd.collections.quantitative.models.qcirim import qCIRIM
+    torch.manual_seed(0)
+    model = qCIRIM(bench.QCIRIM_CFG).eval().to(dev)
+    E, C, H, W = 4, 32, 256, 256
+    TEs = [3.0, 11.5, 20.0, 28.5]
+    datas = []
+    for i in range(2):
+        g = torch.Generator().manual_seed(100 + i)
+        maps = [torch.rand(1, H, W, generator=g) * s for s in (0.3, 1.0, 0.1, 0.5)]
+        S = torch.randn(1, C, H, W, 2, generator=g) / C ** 0.5
+        mask = (torch.rand(1, 1, 1, 1, W, 1, generator=g) < 0.3)
+        y = torch.randn(1, E, C, H, W, 2, generator=g) * mask
+        datas.append([t.to(dev) for t in maps + [y, S, mask]])
+
+    def run(d):
+        out = next(model(d[0], d[1], d[2], d[3], TEs, d[4], d[5], None, d[6]))
+        return torch.stack([out[1 + m][-1][-1] for m in range(4)])
+
+    assert _concurrent_vs_serial([(lambda d=d: run(d)) for d in datas], reps=6) == 0
