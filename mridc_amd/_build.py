@@ -9,7 +9,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmridc_amd.so")
 
-# NO packed-fp32 vector instructions (v_pk_add / mul / fma_f32) in the FFT kernels: measured on MI355X (tools/probe/mfma_pk_interference.py), these
+# NO packed-fp32 vector instructions (v_pk_add / mul / fma_f32) in the FFT kernels (and the pointwise sources, where dropping them is bit-neutral): measured on MI355X (tools/probe/mfma_pk_interference.py), these
 # kernels return WRONG results while a wave of another kernel on the same SIMD issues XDL MFMAs (two streams: the transforms of one slice next to
 # the U-Net / few-channel convolutions of another -- 1e-3 .. 5e-2 errors, bit-exact when either side is alone) and are bit-exact in every
 # combination once built without them.  The target feature stops the compiler from forming them, MRX_NO_PACKED_FP32 selects the scalar complex
