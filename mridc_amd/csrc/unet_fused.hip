@@ -688,7 +688,20 @@ __global__ __launch_bounds__(UC_NT) void k_uconv1x1_c(const float* __restrict__ 
 #pragma unroll
         for (int co = 0; co < 4; ++co) acc[co] = (bias && co < Cout) ? bias[co] : 0.f;
         const float* xp = x + (long long)b * Cin * HWo + (long long)(y + top) * OW + xx + left;
-        for (int ci = 0; ci < Cin; ++ci) {
+        int ci = 0;
+        for (; ci + 7 <= Cin; ci += 7) {          // seven planes in flight per thread (a one-load-at-a-time loop left the pass latency-bound)
+            float v[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) v[u] = xp[(long long)(ci + u) * HWo];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                if (lazy) v[u] = uc_leaky((v[u] - sm_u1c[2 * (ci + u)]) * sm_u1c[2 * (ci + u) + 1], slope);
+#pragma unroll
+                for (int co = 0; co < 4; ++co)
+                    if (co < Cout) acc[co] += v[u] * wsm[co * Cin + ci + u];
+            }
+        }
+        for (; ci < Cin; ++ci) {
             float v = xp[(long long)ci * HWo];
             if (lazy) v = uc_leaky((v - sm_u1c[2 * ci]) * sm_u1c[2 * ci + 1], slope);
 #pragma unroll
