@@ -977,6 +977,8 @@ extern "C" int mrx_rim_final_gather(const float* taps, const float* b_final, con
 // out[b][co][y][x] = bias[co] + sum_tap taps[b][tap * Cout + co][y + dy][x + dx], Cout <= 4, taps [B][Ct >= 9 Cout][H][W]; replicate padding = clamped coordinates, zero
 // padding = taps outside the image dropped.  The contraction (a 1x1 convolution Cin -> 9 Cout with weights w[co][c][tap] -> [tap * Cout + co][c])
 // runs on the matrix cores (mrx_conv2d); the direct form on the vector ALUs costs 18 Cout FMAs per (pixel, channel).
+// CO4: Cout == 4 -- all 36 loads issued unconditionally from clamped coordinates (a dropped tap is multiplied by zero), no branch per load
+template <bool CO4>
 __global__ __launch_bounds__(256) void k_taps_gather(const float* __restrict__ taps, const float* __restrict__ bias, float* __restrict__ out, int Ct,
                                                      int Cout, int H, int W, int zero_pad) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
@@ -996,11 +998,17 @@ __global__ __launch_bounds__(256) void k_taps_gather(const float* __restrict__ t
             int xx = x + dx - 1;
             const bool ok = oky && xx >= 0 && xx < W;
             xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            if (zero_pad && !ok) continue;
             const float* p = pb + (long long)((dy * 3 + dx) * Cout) * plane + (long long)yy * W + xx;
+            if constexpr (CO4) {
+                const float keep = (zero_pad && !ok) ? 0.f : 1.f;
 #pragma unroll
-            for (int co = 0; co < 4; ++co)
-                if (co < Cout) s[co] += p[(long long)co * plane];
+                for (int co = 0; co < 4; ++co) s[co] += keep * p[(long long)co * plane];
+            } else {
+                if (zero_pad && !ok) continue;
+#pragma unroll
+                for (int co = 0; co < 4; ++co)
+                    if (co < Cout) s[co] += p[(long long)co * plane];
+            }
         }
     }
 #pragma unroll
@@ -1011,8 +1019,12 @@ extern "C" int mrx_taps_gather(const float* taps, const float* bias, float* out,
     MRX_REQUIRE(taps && out && B >= 0 && Cout >= 1 && Cout <= 4 && Ct >= 9 * Cout && H >= 1 && W >= 1, MRX_EINVAL, "mrx_taps_gather: bad argument");
     MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_taps_gather: bad pad mode %d", pad_mode);
     if (B == 0) return MRX_OK;
-    hipLaunchKernelGGL(k_taps_gather, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps, bias, out, Ct, Cout, H, W,
-                       pad_mode == MRX_PAD_ZERO ? 1 : 0);
+    if (Cout == 4)
+        hipLaunchKernelGGL(k_taps_gather<true>, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps, bias, out, Ct, Cout, H,
+                           W, pad_mode == MRX_PAD_ZERO ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_taps_gather<false>, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps, bias, out, Ct, Cout, H,
+                           W, pad_mode == MRX_PAD_ZERO ? 1 : 0);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
