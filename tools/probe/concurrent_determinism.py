@@ -43,6 +43,8 @@ for d, st in zip(datas, streams):
 
 
 def rel(a, b):
+    if a.is_complex():
+        a, b = torch.view_as_real(a), torch.view_as_real(b)
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
