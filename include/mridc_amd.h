@@ -302,6 +302,12 @@ int mrx_conv_sbs(const float* x, const float* packed, const float* bias, float* 
                  int act, float slope, void* stream);
 int mrx_conv3x3_sb(const float* x, const float* packed, const float* bias, float* y, int B, int H, int W, int dil, int pad_mode, int act,
                    float slope, void* stream);
+/* mrx_conv3x3_sb for CHAINS of 64-channel convolutions (CascadeNet, VSNet, the Recurrent VarNet, RIM-GRU / MGU): every call folds max |y| into
+ * *xmax_out (device scalar the caller zeroes; NULL: not kept); a call that gets the bound of its input (xmax_in = the previous call's xmax_out)
+ * multiplies two-term fp16 operands (packed_f16 = mrx_rim_layer2_f16_pack(w, NULL, NULL): three term products) instead of three-term bf16
+ * ones (packed_bf16 = mrx_rim_layer2_sb_pack(w, NULL, NULL): six).  Either pack may be NULL when its form is not the one selected. */
+int mrx_conv3x3_sb_chain(const float* x, const float* packed_bf16, const float* packed_f16, const float* bias, float* y, const float* xmax_in,
+                         float* xmax_out, int B, int H, int W, int dil, int pad_mode, int act, float slope, void* stream);
 /* The same layer with the convolution's operands as TWO fp16 terms (11 + 11 significand bits) and three term products per multiply on
  * v_mfma_f32_32x32x16_f16 (half the MFMAs of the three-term bf16 form; error per product <= ~3 x 2^-22).  fp16's exponent range is narrow:
  * the weights are scaled by a power of two at pack time, x per launch from `xmax`, a device float holding an upper bound of max |x| that the

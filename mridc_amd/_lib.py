@@ -160,6 +160,7 @@ _SIGNATURES = {
     "mrx_conv_sbs_pack": ([_p, _p, _i, _i, _i, _p], _i),
     "mrx_conv_sbs": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_conv3x3_sb": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p], _i),
+    "mrx_conv3x3_sb_chain": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_rim_layer2_sb_taps": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_final_gather": ([_p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_cb8_convert": ([_p, _p, _i, _i, _i, _i, _i, _p], _i),

@@ -59,6 +59,8 @@ struct L2sbArgs {
     float slope;
     unsigned long long* trace;   // debug (env MRX_L2SB_TRACE): cycle stamps [workgroup][wave][tile 0..1][4]
     const unsigned* xmax;  // F16: bits of an upper bound of max |x| (>= 0), kept by the producer of x (mrx_rim_layer_indrnn_packed*_xmax)
+    unsigned* xmax_out;    // TAIL = false, or null: bits of max |y| are folded in (atomic max, never reset here): the bound the NEXT convolution of a
+                           // chain scales its fp16 operands by (mrx_conv3x3_sb_chain)
 };
 
 // two fp16 terms of a pair of values already scaled into the fp16 range: a = h1 + h2 + O(2^-22 |a|)
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     request_next();
     __syncthreads();                                 // chunk 0 of the first tile, the 1x1 weights and the tables are in place
 
+    float vmax = 0.f;                                // TAIL = false: maximum |output| of this lane (a.xmax_out)
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int tt = (int)mrx_xcd_band(t, total);
         const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
@@ -737,8 +740,22 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                         if (a.act == MRX_ACT_RELU) v = v > 0.f ? v : 0.f;
                         else if (a.act == MRX_ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
                         ob[(long long)s2_chan(R, 0) * plane] = v;
+                        vmax = fmaxf(vmax, fabsf(v));
                     }
                 }
+            }
+        }
+    }
+    if constexpr (!TAIL) {
+        if (a.xmax_out) {           // one conditional atomic per workgroup (bit patterns of non-negative floats order like unsigned integers)
+            for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+            __syncthreads();        // (every wave is past its last operand read: the start of the x planes is free)
+            float* red = reinterpret_cast<float*>(smem_s2 + S2_OFF_X);
+            if (lane == 0) red[wave] = vmax;
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < S2_NT / 64; ++w) vmax = fmaxf(vmax, red[w]);
+                if (__float_as_uint(vmax) > __hip_atomic_load(a.xmax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.xmax_out, __float_as_uint(vmax));
             }
         }
     }
@@ -814,6 +831,7 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
     a.P = P, a.act = MRX_ACT_NONE, a.slope = 0.f;
     a.xmax = reinterpret_cast<const unsigned*>(xmax);
+    a.xmax_out = nullptr;
 #ifdef MRX_PROBE
     if (xmax && cb8 && getenv("MRX_L2_ABL")) {
         switch (atoi(getenv("MRX_L2_ABL"))) {
@@ -855,9 +873,36 @@ extern "C" int mrx_conv3x3_sb(const float* x, const float* packed, const float* 
     L2sbArgs a;
     a.x = x, a.packed = reinterpret_cast<const u32x4*>(packed), a.b_conv = bias, a.b_ih = nullptr, a.hh = nullptr, a.hprev = nullptr, a.hnew = y;
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
-    a.P = nullptr, a.act = act, a.slope = slope, a.xmax = nullptr;
+    a.P = nullptr, a.act = act, a.slope = slope, a.xmax = nullptr, a.xmax_out = nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool zp = pad_mode == MRX_PAD_ZERO;
+    if (dil == 1) return zp ? l2sb_launch_t<1, false, true>(a, st) : l2sb_launch_t<1, false, false>(a, st);
+    return zp ? l2sb_launch_t<2, false, true>(a, st) : l2sb_launch_t<2, false, false>(a, st);
+}
+
+// mrx_conv3x3_sb for CHAINS of 64-channel convolutions (CascadeNet, VSNet, the Recurrent VarNet, the gated RIMs: conv_layers.py:121-123): every
+// call folds max |y| into *xmax_out (device scalar, zeroed by the caller; may be NULL), and a call that is handed the bound of ITS input
+// (xmax_in: the previous call's xmax_out) multiplies two-term fp16 operands (packed_f16 = mrx_rim_layer2_f16_pack(w, NULL, NULL): three term
+// products per multiply) instead of three-term bf16 ones (packed_bf16 = mrx_rim_layer2_sb_pack(w, NULL, NULL): six).  Same fp32-level results.
+extern "C" int mrx_conv3x3_sb_chain(const float* x, const float* packed_bf16, const float* packed_f16, const float* bias, float* y, const float* xmax_in,
+                                    float* xmax_out, int B, int H, int W, int dil, int pad_mode, int act, float slope, void* stream) {
+    MRX_REQUIRE(x && y && (xmax_in ? packed_f16 != nullptr : packed_bf16 != nullptr), MRX_EINVAL, "mrx_conv3x3_sb_chain: null pointer");
+    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (dil == 1 || dil == 2), MRX_EINVAL, "mrx_conv3x3_sb_chain: bad dims");
+    MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv3x3_sb_chain: bad pad mode %d", pad_mode);
+    MRX_REQUIRE(act >= 0 && act <= 2, MRX_EINVAL, "mrx_conv3x3_sb_chain: bad activation %d", act);
+    MRX_REQUIRE(!xmax_in || mrx_arith() == MRX_ARITH_F16X2, MRX_EUNSUP, "mrx_conv3x3_sb_chain: the two-term fp16 form is off (MRIDC_AMD_ARITH)");
+    if (B == 0) return MRX_OK;
+    L2sbArgs a;
+    a.x = x, a.packed = reinterpret_cast<const u32x4*>(xmax_in ? packed_f16 : packed_bf16), a.b_conv = bias, a.b_ih = nullptr, a.hh = nullptr;
+    a.hprev = nullptr, a.hnew = y;
+    a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, S2_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, S2_TH);
+    a.P = nullptr, a.act = act, a.slope = slope, a.xmax = reinterpret_cast<const unsigned*>(xmax_in), a.xmax_out = reinterpret_cast<unsigned*>(xmax_out);
+    hipStream_t st = (hipStream_t)stream;
+    const bool zp = pad_mode == MRX_PAD_ZERO;
+    if (xmax_in) {
+        if (dil == 1) return zp ? l2sb_launch_t<1, false, true, true>(a, st) : l2sb_launch_t<1, false, false, true>(a, st);
+        return zp ? l2sb_launch_t<2, false, true, true>(a, st) : l2sb_launch_t<2, false, false, true>(a, st);
+    }
     if (dil == 1) return zp ? l2sb_launch_t<1, false, true>(a, st) : l2sb_launch_t<1, false, false>(a, st);
     return zp ? l2sb_launch_t<2, false, true>(a, st) : l2sb_launch_t<2, false, false>(a, st);
 }

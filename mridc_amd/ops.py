@@ -694,27 +694,53 @@ def conv3x3_sb_supported(Cin, Cout, k, dilation):
     return bool(_lib.lib().mrx_conv3x3_sb_supported(int(Cin), int(Cout), int(k), int(dilation)))
 
 
+SB_CHAIN = True                   # (module attribute: a test hook) 64-channel convolutions keep the bound of their outputs; a convolution fed by one
+                                  # that did runs on two-term fp16 operands (mrx_conv3x3_sb_chain)
+_PACKS_SB_F16 = {}
+
+
 def conv3x3_sb(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
-    """3x3 convolution 64 -> 64 (dilation 1 or 2, zero or replicate padding) + bias + activation as a direct convolution on the bf16 matrix pipe
-    with fp32 results (mrx_conv3x3_sb: every fp32 operand = three bf16 terms, six term products per multiply; the convolution stage of the
-    dominant RIM layer on its own).  The operand pack is cached per (storage, version)."""
+    """3x3 convolution 64 -> 64 (dilation 1 or 2, zero or replicate padding) + bias + activation as a direct convolution on the matrix pipe with
+    fp32 results (the convolution stage of the dominant RIM layer on its own).  Operands: three bf16 terms (six term products per multiply) --
+    or, when x carries the bound of its maximum (kept by the convolution that produced it: ops._attach_bound), two fp16 terms scaled by it (three
+    term products): mrx_conv3x3_sb_chain.  The operand packs are cached per (storage, version)."""
+    x_in = x
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
+    L = _lib.lib()
     key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()))
-    hit = _PACKS_SB.get(key)
-    if hit is None:
-        if len(_PACKS_SB) >= 256:
-            _PACKS_SB.clear()
-        w = _lib.f32c(weight.detach())
-        packed = torch.empty(int(_lib.lib().mrx_rim_layer2_sb_pack_floats()), dtype=torch.float32, device=w.device)
-        _lib.check(_lib.lib().mrx_rim_layer2_sb_pack(_lib.ptr(w), None, None, _lib.ptr(packed), _lib.stream_ptr()), "mrx_rim_layer2_sb_pack")
-        hit = (packed, weight)                              # (keeps the source tensor alive: its data_ptr cannot be recycled)
-        _PACKS_SB[key] = hit
+    chain = SB_CHAIN and _lib.arith() == "f16x2"
+    bnd = getattr(x_in, "_mrx_bound", None) if chain else None
+    bound_in = bnd[0] if (bnd is not None and bnd[1] == x_in._version and x is x_in) else None
+    hit = hit16 = None
+    if bound_in is None:
+        hit = _PACKS_SB.get(key)
+        if hit is None:
+            if len(_PACKS_SB) >= 256:
+                _PACKS_SB.clear()
+            w = _lib.f32c(weight.detach())
+            packed = torch.empty(int(L.mrx_rim_layer2_sb_pack_floats()), dtype=torch.float32, device=w.device)
+            _lib.check(L.mrx_rim_layer2_sb_pack(_lib.ptr(w), None, None, _lib.ptr(packed), _lib.stream_ptr()), "mrx_rim_layer2_sb_pack")
+            hit = (packed, weight)                              # (keeps the source tensor alive: its data_ptr cannot be recycled)
+            _PACKS_SB[key] = hit
+    else:
+        hit16 = _PACKS_SB_F16.get(key)
+        if hit16 is None:
+            if len(_PACKS_SB_F16) >= 256:
+                _PACKS_SB_F16.clear()
+            hit16 = (rim_layer2_f16_pack(weight, None, None), weight)
+            _PACKS_SB_F16[key] = hit16
     b = _lib.f32c(bias.detach()) if bias is not None else None
     if out is None:
         out = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().mrx_conv3x3_sb(_lib.ptr(x), _lib.ptr(hit[0]), _lib.ptr(b), _lib.ptr(out), B, H, W, int(dilation), int(pad_mode),
-                                         int(act), float(slope), _lib.stream_ptr()), "mrx_conv3x3_sb")
+    if chain:
+        xmax_out = torch.zeros(1, dtype=torch.float32, device=x.device)
+        _lib.check(L.mrx_conv3x3_sb_chain(_lib.ptr(x), _lib.ptr(hit[0]) if hit else None, _lib.ptr(hit16[0]) if hit16 else None, _lib.ptr(b),
+                                          _lib.ptr(out), _lib.ptr(bound_in), _lib.ptr(xmax_out), B, H, W, int(dilation), int(pad_mode), int(act),
+                                          float(slope), _lib.stream_ptr()), "mrx_conv3x3_sb_chain")
+        return _attach_bound(out, xmax_out)
+    _lib.check(L.mrx_conv3x3_sb(_lib.ptr(x), _lib.ptr(hit[0]), _lib.ptr(b), _lib.ptr(out), B, H, W, int(dilation), int(pad_mode),
+                                int(act), float(slope), _lib.stream_ptr()), "mrx_conv3x3_sb")
     return out
 
 
@@ -1107,9 +1133,10 @@ def rim_layer2_sb_taps(x, packed, b_conv, b_ih, hh, h_prev, taps=None, out=None)
 def rim_layer2_f16_pack(w_conv, w_ih, w_final=None):
     """Operand pack of the second RIM layer with the convolution's weights as two fp16 terms scaled by a power of two (mrx_rim_layer2_f16_pack;
     the 1x1 and final-conv operands as in rim_layer2_sb_pack)."""
-    w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
-    if tuple(w_conv.shape) != (64, 64, 3, 3) or tuple(w_ih.shape) != (64, 64, 1, 1):
-        raise NotImplementedError(f"rim_layer2_f16_pack: {tuple(w_conv.shape)} / {tuple(w_ih.shape)}")
+    w_conv = _lib.f32c(w_conv.detach())
+    w_ih = _lib.f32c(w_ih.detach()) if w_ih is not None else None      # (None: the convolution stage alone, mrx_conv3x3_sb_chain)
+    if tuple(w_conv.shape) != (64, 64, 3, 3) or (w_ih is not None and tuple(w_ih.shape) != (64, 64, 1, 1)):
+        raise NotImplementedError(f"rim_layer2_f16_pack: {tuple(w_conv.shape)} / {None if w_ih is None else tuple(w_ih.shape)}")
     if w_final is not None:
         w_final = _lib.f32c(w_final.detach())
         if tuple(w_final.shape) != (2, 64, 3, 3):

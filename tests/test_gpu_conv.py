@@ -705,3 +705,43 @@ def test_cell_1x1_keeps_the_bound_its_consumer_needs(dev):
         assert float(ops._plain_bound(got)) == float(got.abs().max()) and calls
     finally:
         ops.max_abs = orig
+
+
+@pytest.mark.parametrize("dil,pad", [(1, "zero"), (2, "replicate"), (1, "replicate"), (2, "zero")])
+def test_conv64_chain_keeps_bounds_and_switches_to_two_term_fp16(dev, dil, pad):
+    """mrx_conv3x3_sb_chain: the first 64-channel convolution of a chain (no bound on its input: three-term bf16 operands) keeps max |y|, the
+    next ones run on two-term fp16 operands scaled by it; every stage against float64 and against the bf16-only route (ops.SB_CHAIN = False)."""
+    import torch.nn.functional as Fn
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    g = torch.Generator().manual_seed(31 + dil)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    pm, pname = (ops.PAD_ZERO, "constant") if pad == "zero" else (ops.PAD_REPLICATE, "replicate")
+    for B, H, W in ((1, 640, 372), (2, 37, 75), (1, 5, 3)):
+        x = r(B, 64, H, W) * 40.0
+        ws = [r(64, 64, 3, 3) / 24 for _ in range(3)]
+        bs = [r(64) * 0.1, None, r(64) * 0.1]
+        acts = [ops.ACT_RELU, ops.ACT_LEAKY, ops.ACT_NONE]
+        calls = []
+        orig = ops._lib.lib().mrx_conv3x3_sb_chain
+        ref, got, plain = x.double(), x, x
+        keep = ops.SB_CHAIN
+        try:
+            for i, (w, b, act) in enumerate(zip(ws, bs, acts)):
+                ref = Fn.conv2d(Fn.pad(ref, (dil, dil, dil, dil), mode=pname), w.double(), None if b is None else b.double(), dilation=dil)
+                ref = ref.relu() if act == ops.ACT_RELU else (Fn.leaky_relu(ref, 0.1) if act == ops.ACT_LEAKY else ref)
+                ops.SB_CHAIN = True
+                had_bound = getattr(got, "_mrx_bound", None) is not None
+                got = ops.conv3x3_sb(got, w, b, dil, pm, act, 0.1)
+                calls.append(had_bound)
+                bound, ver = got._mrx_bound
+                assert float(bound) == float(got.abs().max()) and ver == got._version
+                ops.SB_CHAIN = False
+                plain = ops.conv3x3_sb(plain, w, b, dil, pm, act, 0.1)
+                assert getattr(plain, "_mrx_bound", None) is None
+                assert rel_l2(got, ref) <= 8e-7 * (i + 1), (i, rel_l2(got, ref))
+                assert rel_l2(got, plain) <= 1e-6 * (i + 1)
+        finally:
+            ops.SB_CHAIN = keep
+        assert calls == [False, True, True]
+        assert orig is not None
