@@ -408,6 +408,10 @@ int64_t mrx_gated_cell_pack_floats(int Cin, int F, int gates);
 int mrx_gated_cell_pack(const float* w_ih, const float* w_hh, float* packed, int Cin, int F, int gates, void* stream);
 int mrx_gated_cell_1x1(const float* x, const float* h, const float* packed, const float* b_ih, float* out, int B, int Cin,
                        int F, int64_t HW, int gates, void* stream);
+/* ... that also folds max |out| into the device scalar *xmax (atomic max; the caller zeroes it): the bound a following 64-channel convolution
+ * scales its two-term fp16 operands by (mrx_conv3x3_sb_chain's xmax_in).  MRX_EUNSUP with MRIDC_AMD_ARITH=fp32. */
+int mrx_gated_cell_1x1_xmax(const float* x, const float* h, const float* packed, const float* b_ih, float* out, float* xmax, int B, int Cin,
+                            int F, int64_t HW, int gates, void* stream);
 
 /* N4  Conv2dGRU layer of the Recurrent Variational Network (models/recurrentvarnet/conv2gru.py:139-157):
  *   update = sigmoid(Wu [x;h] + bu), reset = sigmoid(Wr [x;h] + br), delta = tanh(Wo [x; h*reset] + bo),

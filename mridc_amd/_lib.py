@@ -183,6 +183,7 @@ _SIGNATURES = {
     "mrx_gated_cell_pack_floats": ([_i, _i, _i], _i64),
     "mrx_gated_cell_pack": ([_p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_gated_cell_1x1": ([_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _p], _i),
+    "mrx_gated_cell_1x1_xmax": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _p], _i),
     "mrx_norm_work_floats": ([_i64, _i64], _i64),
     "mrx_instance_norm_act": ([_p, _p, _p, _i64, _i64, _f, _i, _f, _p], _i),
     "mrx_conv2d_stats_work_floats": ([_i, _i, _i, _i], _i64),

@@ -239,6 +239,7 @@ static int launch_gated(const GatedArgs& a, hipStream_t st) {
     return MRX_OK;
 }
 
+static thread_local float* g_gated_xmax = nullptr;   // set by mrx_gated_cell_1x1_xmax around the call
 extern "C" int mrx_gated_cell_1x1(const float* x, const float* h, const float* packed, const float* b_ih, float* out, int B,
                                   int Cin, int F, int64_t HW, int gates, void* stream) {
     MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_gated_cell_1x1: null pointer");
@@ -260,10 +261,23 @@ extern "C" int mrx_gated_cell_1x1(const float* x, const float* h, const float* p
     if (!fp32) {                                  // default: the bf16 matrix pipe with fp32 results (gated_cell_sb.hip)
         MrxGatedSbArgs s;
         s.x = x, s.h = h, s.packed = packed + (size_t)2 * gates * GC_F * GC_F, s.b_ih = b_ih, s.out = out;
-        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg;
+        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg, s.xmax = g_gated_xmax;
         return mrx_gated_sb_launch(s, gates, (hipStream_t)stream);
     }
+    MRX_REQUIRE(!g_gated_xmax, MRX_EUNSUP, "mrx_gated_cell_1x1_xmax: only the matrix-pipe kernel keeps the bound of its outputs");
     return gates == 3 ? launch_gated<3>(a, (hipStream_t)stream) : launch_gated<2>(a, (hipStream_t)stream);
+}
+
+// mrx_gated_cell_1x1 that also folds max |out| into the device scalar *xmax (atomic max; the caller zeroes it): the operand bound of a following
+// 64-channel convolution on two-term fp16 operands (mrx_conv3x3_sb_chain).  MRIDC_AMD_ARITH != fp32.
+extern "C" int mrx_gated_cell_1x1_xmax(const float* x, const float* h, const float* packed, const float* b_ih, float* out, float* xmax, int B,
+                                       int Cin, int F, int64_t HW, int gates, void* stream) {
+    MRX_REQUIRE(xmax, MRX_EINVAL, "mrx_gated_cell_1x1_xmax: null pointer");
+    MRX_REQUIRE(mrx_arith() != MRX_ARITH_FP32, MRX_EUNSUP, "mrx_gated_cell_1x1_xmax: only the matrix-pipe kernel keeps the bound of its outputs");
+    g_gated_xmax = xmax;
+    const int rc = mrx_gated_cell_1x1(x, h, packed, b_ih, out, B, Cin, F, HW, gates, stream);
+    g_gated_xmax = nullptr;
+    return rc;
 }
 
 // ---- Conv2dGRU layer of the Recurrent Variational Network (recurrentvarnet/conv2gru.py:139-157), 1x1 gates on 64 features ------

@@ -13,6 +13,7 @@ struct MrxGatedSbArgs {
     const float* b_ih;    // [GATES*64] or null
     float* out;           // [B,64,P]
     long long P, nsegb, nseg;  // pixels per image, 32-pixel segments per image, segments in total
+    float* xmax;          // or null: max |out| is folded into this device scalar (atomic max, never reset here: mrx_conv3x3_sb_chain's xmax_in)
 };
 
 int mrx_gated_sb_pack(const float* w_ih, const float* w_hh, float* packed, int gates, hipStream_t st);

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
     unsigned pxo = 0;
     bool valid = false;
     int lhi = 0;
+    float vmax = 0.f;                              // maximum |output| of this lane (a.xmax)
     auto load = [&](long long sg) {
         int l31 = lane & 31;
         lhi = lane >> 5;
@@ -325,7 +326,20 @@ __global__ __launch_bounds__(GS_NT, 1) void k_gated_cell_sb(MrxGatedSbArgs a) {
                     o = c + f * (hv[ct][r] - c);
                 }
                 if (o_valid) ob[(unsigned)co * P32 + o_pxo] = o;
+                vmax = fmaxf(vmax, fabsf(o));          // (lanes past the last pixel repeat pixel 0: harmless for the maximum)
             }
+    }
+    if (a.xmax) {               // one conditional atomic per workgroup (bit patterns of non-negative floats order like unsigned integers)
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        __syncthreads();        // (every wave is done with the weights: the first floats of the LDS are free)
+        float* red = reinterpret_cast<float*>(smem_gs);
+        if (lane == 0) red[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < GS_NT / 64; ++w) vmax = fmaxf(vmax, red[w]);
+            if (__float_as_uint(vmax) > __hip_atomic_load(reinterpret_cast<unsigned*>(a.xmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(reinterpret_cast<unsigned*>(a.xmax), __float_as_uint(vmax));
+        }
     }
 }
 

@@ -1376,6 +1376,12 @@ def gated_cell_1x1(x, h, packed, b_ih, gates, F=64):
     h = None if h is None else _lib.f32c(h)
     b_ih = None if b_ih is None else _lib.f32c(b_ih.detach())
     out = torch.empty((B, F, H, W), dtype=torch.float32, device=x.device)
+    if SB_CHAIN and _lib.arith() == "f16x2":
+        # the next stack's 64-channel convolution reads this state: keep the bound of it (mrx_conv3x3_sb_chain then runs two-term fp16 operands)
+        xmax = torch.zeros(1, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mrx_gated_cell_1x1_xmax(_lib.ptr(x), _lib.ptr(h), _lib.ptr(packed), _lib.ptr(b_ih), _lib.ptr(out), _lib.ptr(xmax), B,
+                                                      Cin, F, H * W, int(gates), _lib.stream_ptr()), "mrx_gated_cell_1x1_xmax")
+        return _attach_bound(out, xmax)
     _lib.check(_lib.lib().mrx_gated_cell_1x1(_lib.ptr(x), _lib.ptr(h), _lib.ptr(packed), _lib.ptr(b_ih), _lib.ptr(out), B, Cin, F,
                                              H * W, int(gates), _lib.stream_ptr()), "mrx_gated_cell_1x1")
     return out

@@ -745,3 +745,31 @@ def test_conv64_chain_keeps_bounds_and_switches_to_two_term_fp16(dev, dil, pad):
             ops.SB_CHAIN = keep
         assert calls == [False, True, True]
         assert orig is not None
+
+
+def test_gated_cell_keeps_the_bound_for_the_next_convolution(dev):
+    """mrx_gated_cell_1x1_xmax: outputs of mrx_gated_cell_1x1, the scalar = max |out| exactly; the following 64-channel convolution takes the
+    two-term fp16 form and agrees with float64."""
+    import torch.nn.functional as Fn
+    from mridc_amd import ops
+    from tests._util import rel_l2
+    g = torch.Generator().manual_seed(77)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    for gates in (3, 2):
+        x, h = r(2, 64, 37, 75), r(2, 64, 37, 75)
+        wi, wh, bi = r(gates * 64, 64, 1, 1) / 8, r(gates * 64, 64, 1, 1) / 8, r(gates * 64) * 0.1
+        packed = ops.gated_cell_pack(wi, wh, gates)
+        keep = ops.SB_CHAIN
+        try:
+            ops.SB_CHAIN = False
+            plain = ops.gated_cell_1x1(x, h, packed, bi, gates)
+            ops.SB_CHAIN = True
+            got = ops.gated_cell_1x1(x, h, packed, bi, gates)
+        finally:
+            ops.SB_CHAIN = keep
+        assert torch.equal(got, plain) and getattr(plain, "_mrx_bound", None) is None
+        assert float(got._mrx_bound[0]) == float(plain.abs().max())
+        w, b = r(64, 64, 3, 3) / 24, r(64) * 0.1
+        y = ops.conv3x3_sb(got, w, b, 2, ops.PAD_REPLICATE, ops.ACT_RELU, 0.0)
+        ref = Fn.conv2d(Fn.pad(plain.double(), (2, 2, 2, 2), mode="replicate"), w.double(), b.double(), dilation=2).relu()
+        assert rel_l2(y, ref) <= 6e-7
