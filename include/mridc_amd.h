@@ -424,6 +424,9 @@ int64_t mrx_conv2dgru_pack_floats(int F);
 int mrx_conv2dgru_pack(const float* w_update, const float* w_reset, const float* w_out, float* packed, int F, void* stream);
 int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const float* packed, const float* bias, float* out,
                            float* out_relu, int B, int F, int64_t HW, void* stream);
+/* ... that also folds max(out_relu) into the device scalar *xmax (atomic max; the caller zeroes it): mrx_conv3x3_sb_chain's xmax_in for the next layer. */
+int mrx_conv2dgru_cell_1x1_xmax(const float* x, const float* h, const float* packed, const float* bias, float* out, float* out_relu, float* xmax,
+                                int B, int F, int64_t HW, void* stream);
 int mrx_mul_sigmoid(const float* h, const float* pre, float* out, int64_t n, void* stream);
 int mrx_gru_blend(const float* h, const float* pre_update, const float* pre_out, float* out, float* out_relu, int64_t n,
                   void* stream);

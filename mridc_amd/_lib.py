@@ -56,6 +56,7 @@ _SIGNATURES = {
     "mrx_conv2dgru_pack_floats": ([_i], _i64),
     "mrx_conv2dgru_pack": ([_p, _p, _p, _p, _i, _p], _i),
     "mrx_conv2dgru_cell_1x1": ([_p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
+    "mrx_conv2dgru_cell_1x1_xmax": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_mul_sigmoid": ([_p, _p, _p, _i64, _p], _i),
     "mrx_gru_blend": ([_p, _p, _p, _p, _p, _i64, _p], _i),
     "mrx_conv3x3_wino_supported": ([_i, _i, _i, _i], _i),

@@ -445,6 +445,7 @@ extern "C" int mrx_conv2dgru_pack(const float* w_update, const float* w_reset, c
     return mrx_conv2dgru_sb_pack(w_update, w_reset, w_out, packed + 6 * GC_F * GC_F, (hipStream_t)stream);
 }
 
+static thread_local float* g_gru2d_xmax = nullptr;   // set by mrx_conv2dgru_cell_1x1_xmax around the call
 extern "C" int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const float* packed, const float* bias, float* out,
                                       float* out_relu, int B, int F, int64_t HW, void* stream) {
     MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv2dgru_cell_1x1: null pointer");
@@ -467,7 +468,7 @@ extern "C" int mrx_conv2dgru_cell_1x1(const float* x, const float* h, const floa
     if (!fp32) {                                  // default: the bf16 matrix pipe with fp32 results (gated_cell_sb.hip)
         MrxConv2dGruSbArgs s;
         s.x = x, s.h = h, s.packed = packed + 6 * GC_F * GC_F, s.bias = bias, s.out = out, s.out_relu = out_relu;
-        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg;
+        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg, s.xmax = g_gru2d_xmax;
         return mrx_conv2dgru_sb_launch(s, (hipStream_t)stream);
     }
     constexpr size_t lds = sizeof(float) * (6 * GC_F * GC_F + 3 * GC_F);
@@ -603,6 +604,18 @@ __global__ __launch_bounds__(GC_NT, (CB == 1 ? 4 : 2)) void k_conv1x1_sq(Conv1x1
         }
     }
 }
+// mrx_conv2dgru_cell_1x1 that also folds the maximum of out_relu into the device scalar *xmax (atomic max; the caller zeroes it): the bound the next
+// layer's 64-channel convolution scales its two-term fp16 operands by (mrx_conv3x3_sb_chain).  MRIDC_AMD_ARITH != fp32.
+extern "C" int mrx_conv2dgru_cell_1x1_xmax(const float* x, const float* h, const float* packed, const float* bias, float* out, float* out_relu,
+                                           float* xmax, int B, int F, int64_t HW, void* stream) {
+    MRX_REQUIRE(xmax && out_relu, MRX_EINVAL, "mrx_conv2dgru_cell_1x1_xmax: null pointer");
+    MRX_REQUIRE(mrx_arith() != MRX_ARITH_FP32, MRX_EUNSUP, "mrx_conv2dgru_cell_1x1_xmax: only the matrix-pipe kernel keeps the bound of its outputs");
+    g_gru2d_xmax = xmax;
+    const int rc = mrx_conv2dgru_cell_1x1(x, h, packed, bias, out, out_relu, B, F, HW, stream);
+    g_gru2d_xmax = nullptr;
+    return rc;
+}
+
 extern "C" int mrx_conv1x1_sq_supported(int Cin, int Cout) { return Cin == Cout && (Cin == 64 || Cin == 128); }
 // floats of the operand pack: the fp32 section and, at C = 128, the split-bf16 one (gated_cell_sb.hip: the default kernel at that width)
 extern "C" int64_t mrx_conv1x1_sq_pack_floats(int C) {

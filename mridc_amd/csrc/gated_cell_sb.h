@@ -29,6 +29,7 @@ struct MrxConv2dGruSbArgs {
     float* out;           // [B,64,P] new state
     float* out_relu;      // [B,64,P] ReLU(new state) or null
     long long P, nsegb, nseg;
+    float* xmax;          // or null: max of out_relu is folded into this device scalar (atomic max, never reset here: mrx_conv3x3_sb_chain's xmax_in)
 };
 
 int mrx_conv2dgru_sb_pack(const float* wu, const float* wr, const float* wo, float* packed, hipStream_t st);

@@ -485,6 +485,7 @@ __device__ __forceinline__ void gs_mma3h(f32x16& acc, const u32x4* q, f16x8 b1, 
 // exactly to h_prev's scale when that is the smaller one (k_gated_cell_sb), the biases are added where the gates are evaluated.
 template <bool F16>
 __global__ __launch_bounds__(GS_NT, 1) void k_conv2dgru_cell_sb(MrxConv2dGruSbArgs a) {
+    float vmax2 = 0.f;                             // maximum of ReLU(new state) of this lane (a.xmax)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gs[];
     constexpr int NTM = F16 ? 2 : 3, NW = 6 * 2 * 4 * NTM * 64;
     u32x4* Wl = reinterpret_cast<u32x4*>(smem_gs);
@@ -681,7 +682,20 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv2dgru_cell_sb(MrxConv2dGruSbAr
                     ob[(unsigned)co * P32 + o_pxo] = o;
                     if (orl) orl[(unsigned)co * P32 + o_pxo] = o > 0.f ? o : 0.f;
                 }
+                vmax2 = fmaxf(vmax2, o);                 // (max of ReLU(o): starts at 0; lanes past the last pixel repeat pixel 0)
             }
+    }
+    if (a.xmax) {               // one conditional atomic per workgroup (bit patterns of non-negative floats order like unsigned integers)
+        for (int off = 32; off > 0; off >>= 1) vmax2 = fmaxf(vmax2, __shfl_xor(vmax2, off, 64));
+        __syncthreads();        // (every wave is done with the weights: the first floats of the LDS are free)
+        float* red = reinterpret_cast<float*>(smem_gs);
+        if ((tid & 63) == 0) red[tid >> 6] = vmax2;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < GS_NT / 64; ++w) vmax2 = fmaxf(vmax2, red[w]);
+            if (__float_as_uint(vmax2) > __hip_atomic_load(reinterpret_cast<unsigned*>(a.xmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(reinterpret_cast<unsigned*>(a.xmax), __float_as_uint(vmax2));
+        }
     }
 }
 int mrx_conv2dgru_sb_launch(const MrxConv2dGruSbArgs& a, hipStream_t st) {

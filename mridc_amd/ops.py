@@ -1412,6 +1412,13 @@ def conv2dgru_cell_1x1(x, h, packed, bias, relu_out=True):
     bias = None if bias is None else _lib.f32c(bias)
     out = torch.empty_like(x)
     out_relu = torch.empty_like(x) if relu_out else None
+    if relu_out and SB_CHAIN and _lib.arith() == "f16x2":
+        # ReLU(new state) is the next layer's convolution input: keep its bound (mrx_conv3x3_sb_chain then runs two-term fp16 operands)
+        xmax = torch.zeros(1, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mrx_conv2dgru_cell_1x1_xmax(_lib.ptr(x), _lib.ptr(h), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(out),
+                                                          _lib.ptr(out_relu), _lib.ptr(xmax), B, F, H * W, _lib.stream_ptr()),
+                   "mrx_conv2dgru_cell_1x1_xmax")
+        return out, _attach_bound(out_relu, xmax)
     _lib.check(_lib.lib().mrx_conv2dgru_cell_1x1(_lib.ptr(x), _lib.ptr(h), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(out),
                                                  _lib.ptr(out_relu), B, F, H * W, _lib.stream_ptr()), "mrx_conv2dgru_cell_1x1")
     return out, out_relu

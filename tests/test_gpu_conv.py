@@ -773,3 +773,24 @@ def test_gated_cell_keeps_the_bound_for_the_next_convolution(dev):
         y = ops.conv3x3_sb(got, w, b, 2, ops.PAD_REPLICATE, ops.ACT_RELU, 0.0)
         ref = Fn.conv2d(Fn.pad(plain.double(), (2, 2, 2, 2), mode="replicate"), w.double(), b.double(), dilation=2).relu()
         assert rel_l2(y, ref) <= 6e-7
+
+
+def test_conv2dgru_cell_keeps_the_bound_of_its_activated_state(dev):
+    """mrx_conv2dgru_cell_1x1_xmax: both outputs of mrx_conv2dgru_cell_1x1, the scalar = max ReLU(new state) exactly."""
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(78)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    x, h = r(2, 64, 37, 75).relu(), r(2, 64, 37, 75)
+    wu, wr, wo = (r(64, 128, 1, 1) / 11 for _ in range(3))
+    bias = r(3, 64) * 0.1
+    packed = ops.conv2dgru_pack(wu, wr, wo)
+    keep = ops.SB_CHAIN
+    try:
+        ops.SB_CHAIN = False
+        new0, act0 = ops.conv2dgru_cell_1x1(x, h, packed, bias, True)
+        ops.SB_CHAIN = True
+        new1, act1 = ops.conv2dgru_cell_1x1(x, h, packed, bias, True)
+    finally:
+        ops.SB_CHAIN = keep
+    assert torch.equal(new0, new1) and torch.equal(act0, act1) and getattr(act0, "_mrx_bound", None) is None
+    assert float(act1._mrx_bound[0]) == float(act0.max()) and act1._mrx_bound[1] == act1._version
