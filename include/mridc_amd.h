@@ -495,6 +495,36 @@ int64_t mrx_conv_wgrad_bf16_any_work_floats(int B, int Cin, int Cout, int H, int
 int mrx_conv_wgrad_bf16_any(const float* x, const float* dy, float* dw, float* work, int B, int Cin, int Cout, int H, int W, int k, int dil,
                             int pad_mode, int accumulate, void* stream);
 
+/* ---- Mixed-precision training with bf16 STORAGE (BASELINE config 4; csrc/train_bf16.hip, csrc/conv_bf16.hip) -------------------------------------
+ * The reference trains under pytorch-lightning AMP (projects/reconstruction/model_zoo/conf/base_cirim_train.yaml:180 `precision: 16`): torch.autocast
+ * runs every Conv2d of rim_block.py:230-246 on half-precision operands and RETURNS half-precision tensors (so the gradients flowing into them are
+ * half precision too); hidden states, `hh * hx` (rnn_cells.py:390), FFTs, eta and the loss stay fp32.  Here half = bf16, and such tensors are
+ * "pair tensors" in HBM: uint32 [B][C/2][H][W] = (bf16 of channel 2p) | (bf16 of channel 2p + 1) << 16.
+ *   mrx_tl_pack          W_ih [64,64] (+ the final convolution's weights [2,64,3,3], may be null) in the operand orders of the three GEMMs below
+ *   mrx_tl_layer_fwd     one RIM layer (ConvNonlinear + IndRNNCell, conv_layers.py:121-123, rnn_cells.py:384-391): a = ReLU(bf16(conv(x) + b)) ->
+ *                        a_pairs, h = ReLU(bf16(W_ih a + b_ih) + hh * h_prev) -> h (fp32); taps != null: also the final convolution's (tap, cout)
+ *                        products with bf16(h) [B,18,H,W], summed by mrx_tl_final_gather: eta_out = eta + bf16(sum of the 9 shifted planes)
+ *   mrx_tl_cell_bwd      backward of the cell and of the convolution's ReLU in one pass (see train_bf16.hip); parameter-gradient partials accumulate
+ *                        in `part` (mrx_tl_cell_part_floats floats; first != 0 overwrites) until mrx_tl_cell_reduce adds them to the gradients
+ *   mrx_tl_dgrad         data gradient of a replicate-padded convolution with bf16 results: interior -> dx, frame -> `frame` for mrx_tl_fold_edges
+ *   mrx_conv_wgrad_bf16_pairs   the weight gradients of mrx_conv_wgrad_bf16_any with dy given as a pair tensor */
+int64_t mrx_tl_pack_bytes(void);
+int mrx_tl_pack(const float* w_ih, const float* w_fin, void* packed, void* stream);
+int mrx_tl_layer_fwd(const float* x, const void* conv_packed, const float* conv_bias, const void* tl_packed, const float* ih_bias, const float* hh,
+                     const float* hprev, void* a_pairs, float* h, float* taps, int B, int Cin, int H, int W, int k, int dil, void* stream);
+int mrx_tl_final_gather(const float* taps, const float* eta, float* eta_out, int B, int H, int W, void* stream);
+int64_t mrx_tl_cell_part_floats(int B, int H, int W);
+int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const float* h, const float* hprev, const void* a_pairs, const void* tl_packed,
+                    const float* hh, float* dh_prev, void* ga_pairs, float* part, int first, int B, int H, int W, void* stream);
+int mrx_tl_cell_reduce(const float* part, int B, int H, int W, float* dw_ih, float* db_ih, float* dhh, float* db_conv, void* stream);
+int mrx_tl_dgrad(const void* dy, int dy_pairs, const void* packed, void* dx, int dx_pairs, float* frame, int B, int Cdy, int Cdx, int H, int W, int k,
+                 int dil, void* stream);
+int mrx_tl_fold_edges(const float* frame, void* dx, int dx_pairs, int B, int C, int H, int W, int pad, void* stream);
+int mrx_tl_pairs_to_f32(const void* pairs, float* out, int64_t pair_planes, int64_t plane, void* stream);
+int mrx_tl_f32_to_pairs(const float* x, void* pairs, int64_t pair_planes, int64_t plane, void* stream);
+int mrx_conv_wgrad_bf16_pairs(const float* x, const void* dy_pairs, float* dw, float* work, int B, int Cin, int H, int W, int k, int dil, int pad_mode,
+                              int accumulate, void* stream);
+
 /*   mrx_absl1_loss      the l1 training loss of one prediction (cirim.py:218-237): out2[0] = mean |target - |p| / max|p||, out2[1] = an
  *                      intermediate the backward needs; p complex [n], target real [n], maxabs = device scalar from mrx_max_abs (mode 1);
  *                      work: mrx_absl1_work_floats floats.  mrx_absl1_loss_bwd: dp = gout * gscale * d(loss)/dp incl. the path through the max

@@ -11,7 +11,7 @@ import re
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmridc_amd.so")
+LIB_PATH = os.environ.get("MRIDC_AMD_LIB") or os.path.join(_PKG, "lib", "libmridc_amd.so")   # MRIDC_AMD_LIB: another build of the same library (A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "mridc_amd.h")
 
 NORM = {"backward": 0, "ortho": 1, "forward": 2, "none": 3}
@@ -77,6 +77,18 @@ _SIGNATURES = {
     "mrx_conv_wgrad_bf16_supported": ([_i, _i, _i, _i], _i),
     "mrx_conv_wgrad_bf16_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_conv_wgrad_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_tl_pack_bytes": ([], _i64),
+    "mrx_tl_pack": ([_p, _p, _p, _p], _i),
+    "mrx_tl_layer_fwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_tl_dgrad": ([_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_tl_fold_edges": ([_p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_tl_cell_part_floats": ([_i, _i, _i], _i64),
+    "mrx_tl_cell_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_tl_cell_reduce": ([_p, _i, _i, _i, _p, _p, _p, _p, _p], _i),
+    "mrx_tl_final_gather": ([_p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_tl_pairs_to_f32": ([_p, _p, _i64, _i64, _p], _i),
+    "mrx_tl_f32_to_pairs": ([_p, _p, _i64, _i64, _p], _i),
+    "mrx_conv_wgrad_bf16_pairs": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_relu_bwd_acc": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_eta_grad_in": ([_p, _p, _p, _p, _i, _i64, _p], _i),
     "mrx_g4_to_complex": ([_p, _p, _i, _i64, _p], _i),

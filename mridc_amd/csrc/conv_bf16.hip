@@ -14,6 +14,12 @@
 //     64 banks exactly once), so a B operand is ONE 16-byte LDS read per lane;
 //   * A operands (packed [step][cout block][lane][8 bf16], 1 KiB per wave instruction) come straight from L2 into registers: at 16x the
 //     fp32 matrix rate the kernel is bound by HBM and by operand delivery, not by the matrix pipe, so LDS is spent on pixels, not weights.
+//
+// Round 4 (bf16 STORAGE of what autocast keeps in half precision, train_bf16.hip): the same kernel reads / writes "pair" tensors
+// u32 [B][C / 2][H][W] = (bf16 channel 2p, bf16 channel 2p + 1) -- XP: the input is a pair tensor (no conversion in the loader), OUT 1: the
+// result is rounded to bf16 and stored as pairs (data gradients), OUT 2: the whole training-mode RIM layer (conv + bias -> bf16 -> ReLU = a,
+// stored as pairs and fed from registers into the IndRNN 1x1 GEMM -> bf16 -> + hh * h_prev -> ReLU = h, optionally the tap products of the
+// final convolution): the rounding points of torch.autocast (conv results are bf16 tensors, hidden states fp32).
 #include "mrx_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -30,8 +36,12 @@ __device__ __forceinline__ unsigned cb_pk(float lo, float hi) {   // two fp32 ->
     return r;
 }
 
+__device__ __forceinline__ float cb_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float cb_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+__device__ __forceinline__ float cb_round(float v) { return cb_lo(cb_pk(v, 0.f)); }   // fp32 -> nearest bf16, as fp32
+
 struct ConvBfArgs {
-    const float* x;        // [B,Cin,H,W]
+    const float* x;        // [B,Cin,H,W]  (XP: u32 pairs [B,Cin/2,H,W])
     const u32x4* packed;   // [NSTEP][NCT][64 lanes] x 8 bf16
     const float* bias;     // [Cout] or null
     const float* hh;       // [Cout] or null: IndRNN epilogue  act(acc + bias + hh * hprev)
@@ -42,13 +52,22 @@ struct ConvBfArgs {
     int ext, Hin, Win;     // the input is [Hin, Win] = [H - 2 ext, W - 2 ext], read as if zero-extended by `ext` on every side (data gradients)
     float* interior;       // not null: outputs inside the original image go to interior [B,Cout,Hin,Win] (the replicate-padding fold leaves
                            // them unchanged), only the frame of width ext goes to `out` [B,Cout,H,W] for mrx_reppad_fold_edges
+                           // (OUT 1: `interior` / without it `out` is a pair tensor; the frame stays fp32)
+    int round_out;            // OUT 0: fp32 result rounded to the nearest bf16 value (the gradient w.r.t. an fp32 tensor that autocast cast to bf16)
+    // OUT 2 (training-mode RIM layer):
+    const u32x4* ih_packed;   // [4 steps][2 cout blocks][64 lanes] x 8 bf16: W_ih in the k order of the accumulator layout (mrx_tl_pack)
+    const float* ih_bias;     // [64] or null
+    unsigned* a_pairs;        // [B,32,H,W] pairs: a = ReLU(bf16(conv + bias))
+    const u32x4* fin_packed;  // null or [4 steps][64 lanes] x 8 bf16: the final convolution's (tap, cout) rows
+    float* taps;              // [B,18,H,W]: taps[tap * 2 + co] = sum_c bf16(w_final[co][c][tap]) bf16(h[c])   (mrx_tl_final_gather adds them up)
 };
 
 __host__ __device__ constexpr int cb_ps(int CPAD) { return CPAD == 8 ? 16 : CPAD * 2 + 16; }   // bytes per pixel in the LDS tile
 __host__ __device__ constexpr int cb_nstep(int K, int CPAD) { return (K * K * (CPAD / 8) + 1) / 2; }
 
-template <int K, int DIL, int CPAD, int NCT>
-__global__ __launch_bounds__(CB_NT, 4) void k_conv_bf16(ConvBfArgs a) {
+template <int K, int DIL, int CPAD, int NCT, int XP = 0, int OUT = 0>
+__global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArgs a) {
+    static_assert(OUT != 2 || NCT == 2, "the fused layer has 64 features");
     constexpr int PAD = DIL * (K - 1) / 2;
     constexpr int PH = CB_TH + 2 * PAD, PW = CB_TW + 2 * PAD, NPIX = PH * PW;
     constexpr int NC8 = CPAD / 8, PS = cb_ps(CPAD), NG = K * K * NC8, NSTEP = cb_nstep(K, CPAD);
@@ -79,14 +98,21 @@ __global__ __launch_bounds__(CB_NT, 4) void k_conv_bf16(ConvBfArgs a) {
                 gy = inb ? gy : 0;
                 gx = inb ? gx : 0;
             }
-            const float* src = xb + (long long)gy * a.Win + gx;
-            float v[8];
+            u32x4 p;
+            if (XP) {            // pair tensor: four dwords = eight channels of this pixel, already bf16
+                const unsigned* src = reinterpret_cast<const unsigned*>(a.x) + ((long long)b * (a.Cin >> 1) + cg * 4) * iplane + (long long)gy * a.Win + gx;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = cg * 8 + j;
-                v[j] = (inb && c < a.Cin) ? src[(long long)c * iplane] : 0.f;
+                for (int q = 0; q < 4; ++q) p[q] = (inb && cg * 8 + 2 * q < a.Cin) ? src[(long long)q * iplane] : 0u;
+            } else {
+                const float* src = xb + (long long)gy * a.Win + gx;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = cg * 8 + j;
+                    v[j] = (inb && c < a.Cin) ? src[(long long)c * iplane] : 0.f;
+                }
+                p = (u32x4){cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
             }
-            u32x4 p = {cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
             *reinterpret_cast<u32x4*>(smem_b + e * PS + cg * 16) = p;
         }
     }
@@ -123,17 +149,111 @@ __global__ __launch_bounds__(CB_NT, 4) void k_conv_bf16(ConvBfArgs a) {
 
     // ---- epilogue: bias, optional IndRNN term, activation ---------------------------------------------------------------------------------
     const int oy = h0 + wave, ox = w0 + l31;
-    if (oy < a.H && ox < a.W) {
+    const bool inside = oy < a.H && ox < a.W;
+    if (OUT == 2) {
+        // a = ReLU(bf16(conv + bias)): stored as pairs, and -- two adjacent accumulator rows are two adjacent channels -- at the same time the
+        // B operands of the 1x1 GEMM (step (ct, hf) takes rows 8 hf .. 8 hf + 7 of block ct: the pack orders W_ih's columns to match)
+        const long long pix = (long long)oy * a.W + ox;
+        unsigned ap[NCT][8];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 2 * q, co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v0 = acc[ct][r], v1 = acc[ct][r + 1];
+                if (a.bias) v0 += cb_round(a.bias[co]), v1 += cb_round(a.bias[co + 1]);
+                v0 = v0 > 0.f ? v0 : 0.f, v1 = v1 > 0.f ? v1 : 0.f;
+                ap[ct][q] = cb_pk(v0, v1);
+                if (inside) a.a_pairs[((long long)b * 32 + (co >> 1)) * plane + pix] = ap[ct][q];
+            }
+        f32x16 acc2[2];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[c2][r] = 0.f;
+        const u32x4* ip = a.ih_packed + lane;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const u32x4 bw = {ap[ct][4 * hf], ap[ct][4 * hf + 1], ap[ct][4 * hf + 2], ap[ct][4 * hf + 3]};
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+                    acc2[c2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ip[((ct * 2 + hf) * 2 + c2) * 64]),
+                                                                      __builtin_bit_cast(bf16x8, bw), acc2[c2], 0, 0, 0);
+            }
+        // h = ReLU(bf16(W_ih a + b_ih) + hh * h_prev)  (fp32 state)
+        unsigned hp[2][8];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = c2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                float v = acc2[c2][r];
+                if (a.ih_bias) v += cb_round(a.ih_bias[co]);
+                v = cb_round(v);
+                const long long o = ((long long)b * 64 + co) * plane + pix;
+                if (a.hprev && inside) v += a.hh[co] * a.hprev[o];
+                v = v > 0.f ? v : 0.f;
+                if (inside) a.out[o] = v;
+                acc2[c2][r] = v;
+            }
+        if (a.fin_packed) {                      // (tap, cout) rows of the final convolution times bf16(h): 18 of 32 output rows are real
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hp[c2][q] = cb_pk(acc2[c2][2 * q], acc2[c2][2 * q + 1]);
+            f32x16 acc3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+            const u32x4* fp = a.fin_packed + lane;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const u32x4 bw = {hp[c2][4 * hf], hp[c2][4 * hf + 1], hp[c2][4 * hf + 2], hp[c2][4 * hf + 3]};
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fp[(c2 * 2 + hf) * 64]), __builtin_bit_cast(bf16x8, bw), acc3, 0,
+                                                                  0, 0);
+                }
+            if (inside) {
+#pragma unroll
+                for (int r = 0; r < 10; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (m < 18) a.taps[((long long)b * 18 + m) * plane + pix] = acc3[r];
+                }
+            }
+        }
+        return;
+    }
+    if (inside) {
         long long obase = (long long)b * a.Cout * plane + (long long)oy * a.W + ox;
         long long cstride = plane;
         float* dst = a.out;
+        bool to_interior = false;
         if (a.interior) {
             const int iy = oy - a.ext, ix = ox - a.ext;
             if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
                 dst = a.interior;
                 cstride = iplane;
                 obase = (long long)b * a.Cout * iplane + (long long)iy * a.Win + ix;
+                to_interior = true;
             }
+        }
+        if (OUT == 1 && (to_interior || !a.interior)) {      // bf16 result as pairs (the frame of a replicate-padded data gradient stays fp32)
+            unsigned* dp = reinterpret_cast<unsigned*>(dst) + (long long)b * (a.Cout >> 1) * cstride + (obase - (long long)b * a.Cout * cstride);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = 2 * q, co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (co < a.Cout) {
+                        float v0 = acc[ct][r], v1 = acc[ct][r + 1];
+                        if (a.bias) v0 += cb_round(a.bias[co]), v1 += cb_round(a.bias[co + 1]);
+                        if (a.act == MRX_ACT_RELU) v0 = v0 > 0.f ? v0 : 0.f, v1 = v1 > 0.f ? v1 : 0.f;
+                        dp[(long long)(co >> 1) * cstride] = cb_pk(v0, v1);
+                    }
+                }
+            return;
         }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -148,6 +268,7 @@ __global__ __launch_bounds__(CB_NT, 4) void k_conv_bf16(ConvBfArgs a) {
                         v = v > 0.f ? v : 0.f;
                     else if (a.act == MRX_ACT_LEAKY)
                         v = v > 0.f ? v : v * a.slope;
+                    if (OUT == 1 || a.round_out) v = cb_round(v);          // (the fp32 frame of a pair result holds bf16 values: one rounding per convolution result)
                     dst[obase + (long long)co * cstride] = v;
                 }
             }
@@ -203,16 +324,16 @@ extern "C" int mrx_conv_bf16_pack(const float* w, void* packed, int Cin, int Cou
     return MRX_OK;
 }
 
-template <int K, int DIL, int CPAD, int NCT>
+template <int K, int DIL, int CPAD, int NCT, int XP = 0, int OUT = 0>
 static int cb_launch(const ConvBfArgs& a, hipStream_t st) {
     constexpr int PAD = DIL * (K - 1) / 2;
     constexpr size_t lds = (size_t)(CB_TH + 2 * PAD) * (CB_TW + 2 * PAD) * cb_ps(CPAD);
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_bf16<K, DIL, CPAD, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_bf16<K, DIL, CPAD, NCT, XP, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_bf16<K, DIL, CPAD, NCT>), dim3(a.ntiles, a.B), dim3(CB_NT), lds, st, a);
+    hipLaunchKernelGGL((k_conv_bf16<K, DIL, CPAD, NCT, XP, OUT>), dim3(a.ntiles, a.B), dim3(CB_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -258,7 +379,7 @@ static int conv2d_bf16_impl(const float* x, const void* packed, const float* bia
     MRX_REQUIRE(!hprev || hh, MRX_EINVAL, "mrx_conv2d_bf16: hprev without hh");
     MRX_REQUIRE(B <= 65535, MRX_EUNSUP, "mrx_conv2d_bf16: batch %d too large", B);
     if (B == 0) return MRX_OK;
-    ConvBfArgs a;
+    ConvBfArgs a = {};
     a.x = x, a.packed = (const u32x4*)packed, a.bias = bias, a.hh = hh, a.hprev = hprev, a.out = out;
     a.B = B, a.Cin = Cin, a.Cout = Cout, a.H = H, a.W = W;
     a.tiles_x = mrx_cdiv(W, CB_TW);
@@ -273,6 +394,87 @@ static int conv2d_bf16_impl(const float* x, const void* packed, const float* bia
     if (k == 3) return cb_launch_nct<3, 1, 8>(a, st);
     if (cp == 64) return cb_launch_nct<5, 1, 64>(a, st);
     return cb_launch_nct<5, 1, 8>(a, st);
+}
+
+// ---- training-mode RIM layer and data gradients on pair tensors (round 4; callers: mridc_amd/training.py, bf16 tape) ---------------------
+// W_ih [64,64] and the final convolution's weights [2,64,3,3] in the k order in which the accumulator layout of the preceding GEMM delivers the
+// channels: step (ct, hf), lane half lh, element j  <->  channel 32 ct + (r & 3) + 8 (r >> 2) + 4 lh with r = 8 hf + j.
+//   ih : out[((ct * 2 + hf) * 2 + c2) * 64 + lane][j] = bf16(w_ih[32 c2 + lane % 32][channel])
+//   fin: out[512 + (ct * 2 + hf) * 64 + lane][j]      = bf16(w_fin[m & 1][channel][m >> 1]),  m = lane % 32 < 18 (else 0)
+//   ihT: out[768 + (s * 2 + ct) * 64 + lane][j]       = bf16(w_ih[32 (lane / 32) + 8 s + j][32 ct + lane % 32])      (mrx_tl_cell_bwd's data gradient)
+__global__ void k_tl_pack(const float* __restrict__ w_ih, const float* __restrict__ w_fin, u32x4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 768 + 512) return;
+    const int lane = i & 63, l31 = lane & 31, lh = lane >> 5;
+    float v[8];
+    if (i < 512) {
+        const int c2 = (i >> 6) & 1, hf = (i >> 7) & 1, ct = i >> 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 8 * hf + j, ch = 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            v[j] = w_ih[(32 * c2 + l31) * 64 + ch];
+        }
+    } else if (i < 768) {
+        const int s = (i - 512) >> 6, hf = s & 1, ct = s >> 1, m = l31;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 8 * hf + j, ch = 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            v[j] = (w_fin && m < 18) ? w_fin[((m & 1) * 64 + ch) * 9 + (m >> 1)] : 0.f;
+        }
+    } else {
+        const int q = (i - 768) >> 6, ct = q & 1, s = q >> 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w_ih[(32 * lh + 8 * s + j) * 64 + 32 * ct + l31];
+    }
+    out[i] = (u32x4){cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
+}
+extern "C" int64_t mrx_tl_pack_bytes(void) { return (768 + 512) * 16; }
+extern "C" int mrx_tl_pack(const float* w_ih, const float* w_fin, void* packed, void* stream) {
+    MRX_REQUIRE(w_ih && packed, MRX_EINVAL, "mrx_tl_pack: null pointer");
+    hipLaunchKernelGGL(k_tl_pack, dim3(5), dim3(256), 0, (hipStream_t)stream, w_ih, w_fin, (u32x4*)packed);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// One RIM layer in training arithmetic (rim_block.py:230-238 under autocast): a = ReLU(bf16(conv_reppad(x) + b)) -> a_pairs [B,32,H,W],
+// h = ReLU(bf16(W_ih a + b_ih) + hh * h_prev) -> h [B,64,H,W] fp32; with `taps`: also the (tap, cout) products of the final 3x3 convolution with
+// bf16(h) [B,18,H,W].  conv_packed from mrx_conv_bf16_pack (forward), tl_packed from mrx_tl_pack.  k x k = 5x5 (Cin <= 8) or 3x3 dilation 2 (Cin 64).
+extern "C" int mrx_tl_layer_fwd(const float* x, const void* conv_packed, const float* conv_bias, const void* tl_packed, const float* ih_bias,
+                                const float* hh, const float* hprev, void* a_pairs, float* h, float* taps, int B, int Cin, int H, int W, int k,
+                                int dil, void* stream) {
+    MRX_REQUIRE(x && conv_packed && tl_packed && a_pairs && h, MRX_EINVAL, "mrx_tl_layer_fwd: null pointer");
+    MRX_REQUIRE(!hprev || hh, MRX_EINVAL, "mrx_tl_layer_fwd: hprev without hh");
+    MRX_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_tl_layer_fwd: bad dims");
+    MRX_REQUIRE((k == 5 && dil == 1 && Cin >= 1 && Cin <= 8) || (k == 3 && dil == 2 && Cin == 64), MRX_EUNSUP,
+                "mrx_tl_layer_fwd: Cin=%d k=%d dilation=%d not instantiated", Cin, k, dil);
+    ConvBfArgs a = {};
+    a.x = x, a.packed = (const u32x4*)conv_packed, a.bias = conv_bias, a.hh = hh, a.hprev = hprev, a.out = h;
+    a.B = B, a.Cin = Cin, a.Cout = 64, a.H = H, a.W = W;
+    a.tiles_x = mrx_cdiv(W, CB_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, CB_TH);
+    a.pad_mode = MRX_PAD_REPLICATE, a.act = MRX_ACT_RELU, a.Hin = H, a.Win = W;
+    a.ih_packed = (const u32x4*)tl_packed, a.ih_bias = ih_bias, a.a_pairs = (unsigned*)a_pairs;
+    a.fin_packed = taps ? (const u32x4*)tl_packed + 512 : nullptr, a.taps = taps;
+    return k == 5 ? cb_launch<5, 1, 8, 2, 0, 2>(a, (hipStream_t)stream) : cb_launch<3, 2, 64, 2, 0, 2>(a, (hipStream_t)stream);
+}
+
+// Data gradient of a replicate-padded convolution with bf16 results (what autocast's convolution backward returns): dy [B,Cdy,H,W] fp32
+// (dy_pairs 0) or pairs [B,Cdy/2,H,W] (1); the interior goes to dx -- pairs [B,Cdx/2,H,W] (dx_pairs 1) or fp32 [B,Cdx,H,W] holding bf16 values --
+// the frame of width ext = dil (k - 1) / 2 to `frame` [B,Cdx,H + 2 ext,W + 2 ext] fp32 for mrx_tl_fold_edges.  packed: mrx_conv_bf16_pack(transposed).
+extern "C" int mrx_tl_dgrad(const void* dy, int dy_pairs, const void* packed, void* dx, int dx_pairs, float* frame, int B, int Cdy, int Cdx, int H,
+                            int W, int k, int dil, void* stream) {
+    MRX_REQUIRE(dy && packed && dx && frame, MRX_EINVAL, "mrx_tl_dgrad: null pointer");
+    MRX_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_tl_dgrad: bad dims");
+    const int ext = dil * (k - 1) / 2;
+    ConvBfArgs a = {};
+    a.x = (const float*)dy, a.packed = (const u32x4*)packed, a.out = frame, a.interior = (float*)dx;
+    a.B = B, a.Cin = Cdy, a.Cout = Cdx, a.H = H + 2 * ext, a.W = W + 2 * ext;
+    a.tiles_x = mrx_cdiv(a.W, CB_TW), a.ntiles = a.tiles_x * mrx_cdiv(a.H, CB_TH);
+    a.pad_mode = MRX_PAD_ZERO, a.act = MRX_ACT_NONE, a.ext = ext, a.Hin = H, a.Win = W, a.round_out = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 3 && dil == 2 && Cdy == 64 && Cdx == 64 && dy_pairs && dx_pairs) return cb_launch<3, 2, 64, 2, 1, 1>(a, st);
+    if (k == 3 && dil == 1 && Cdy <= 8 && Cdx == 64 && !dy_pairs && dx_pairs) return cb_launch<3, 1, 8, 2, 0, 1>(a, st);
+    if (k == 5 && dil == 1 && Cdy == 64 && Cdx <= 32 && dy_pairs && !dx_pairs) return cb_launch<5, 1, 64, 1, 1, 0>(a, st);
+    MRX_REQUIRE(false, MRX_EUNSUP, "mrx_tl_dgrad: Cdy=%d Cdx=%d k=%d dilation=%d pairs %d -> %d not instantiated", Cdy, Cdx, k, dil, dy_pairs, dx_pairs);
 }
 
 // ---- weight gradient, 64 -> 64 channels, bf16 operands ------------------------------------------------------------------------------
@@ -304,7 +506,15 @@ __host__ __device__ constexpr int wb_xs(int K, int DIL) {   // bytes per x chann
     return ((raw + 255 - 16) / 256) * 256 + 16;
 }
 
-template <int K, int DIL>
+// eight dwords of a pair tensor (eight pixels of channels 2p, 2p + 1) -> the eight pixels of channel 2p, of channel 2p + 1
+__device__ __forceinline__ void wb_unzip(const unsigned (&d)[8], u32x4& lo, u32x4& hi) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] = (d[2 * i] & 0xffffu) | (d[2 * i + 1] << 16);
+        hi[i] = (d[2 * i] >> 16) | (d[2 * i + 1] & 0xffff0000u);
+    }
+}
+template <int K, int DIL, int DYP = 0>
 __global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(WgradBfArgs a) {
     constexpr int WB_TH = wb_th(K), WB_DYS = wb_dys(K);
     constexpr int PAD = DIL * (K - 1) / 2, PH = WB_TH + 2 * PAD, PW = WB_TW + 2 * PAD, TAPS = K * K;
@@ -332,6 +542,26 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(Wgrad
         const float* xb = a.x + (long long)b * 64 * plane;
         __syncthreads();   // the previous tile's readers are done
         // dy tile: item = (co, row, 8-pixel group); pixels outside the image contribute zero
+        if (DYP) {        // dy is a pair tensor [B,32,H,W]: item = (channel pair, row, 8-pixel group)
+            const unsigned* dyp = reinterpret_cast<const unsigned*>(a.dy) + (long long)b * 32 * plane;
+            for (int i = tid; i < 32 * WB_TH * 4; i += NT) {
+                const int pg = i & 3, r = (i >> 2) % WB_TH, pp = i / (4 * WB_TH);
+                const int gy = h0 + r, gx = w0 + pg * 8;
+                const unsigned* src = dyp + (long long)pp * plane + (long long)gy * a.W + gx;
+                unsigned d[8];
+                if (a.vec && gy < a.H && gx + 8 <= a.W) {
+                    const uint4 q0 = *reinterpret_cast<const uint4*>(src), q1 = *reinterpret_cast<const uint4*>(src + 4);
+                    d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[j] = (gy < a.H && gx + j < a.W) ? src[j] : 0u;
+                }
+                u32x4 lo, hi;
+                wb_unzip(d, lo, hi);
+                *reinterpret_cast<u32x4*>(Dy + (2 * pp) * WB_DYS + (r * WB_TW + pg * 8) * 2) = lo;
+                *reinterpret_cast<u32x4*>(Dy + (2 * pp + 1) * WB_DYS + (r * WB_TW + pg * 8) * 2) = hi;
+            }
+        } else
         for (int i = tid; i < 64 * WB_TH * 4; i += NT) {
             const int pg = i & 3, r = (i >> 2) % WB_TH, co = i / (4 * WB_TH);
             const int gy = h0 + r, gx = w0 + pg * 8;
@@ -444,7 +674,7 @@ struct WgradBfGArgs {
     float* part;       // [gridDim.x][Cout][Cin][taps]
     int B, Cin, Cout, H, W, tiles_x, ntiles, pad_mode, vec;
 };
-template <int K, int NCO, int NCI, int TPW>
+template <int K, int NCO, int NCI, int TPW, int DYP = 0>
 __global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgrad_bf16_g(WgradBfGArgs a) {
     constexpr int TH = 8, DYS = TH * WB_TW * 2 + 16, PAD = (K - 1) / 2, PH = TH + 2 * PAD, PW = WB_TW + 2 * PAD, TAPS = K * K;
     constexpr int NW = (TAPS + TPW - 1) / TPW, NT = 64 * NW, XS = ((PH * PW * 2 + 255 - 16) / 256) * 256 + 16;
@@ -478,6 +708,26 @@ __global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgra
         const float* dyb = a.dy + (long long)b * a.Cout * plane;
         const float* xb = a.x + (long long)b * a.Cin * plane;
         __syncthreads();
+        if (DYP) {        // dy is a pair tensor [B,Cout/2,H,W]
+            const unsigned* dyp = reinterpret_cast<const unsigned*>(a.dy) + (long long)b * (a.Cout >> 1) * plane;
+            for (int i = tid; i < (a.Cout >> 1) * TH * 4; i += NT) {
+                const int pg = i & 3, r = (i >> 2) % TH, pp = i / (4 * TH);
+                const int gy = h0 + r, gx = w0 + pg * 8;
+                const unsigned* src = dyp + (long long)pp * plane + (long long)gy * a.W + gx;
+                unsigned d[8];
+                if (a.vec && gy < a.H && gx + 8 <= a.W) {
+                    const uint4 q0 = *reinterpret_cast<const uint4*>(src), q1 = *reinterpret_cast<const uint4*>(src + 4);
+                    d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[j] = (gy < a.H && gx + j < a.W) ? src[j] : 0u;
+                }
+                u32x4 lo, hi;
+                wb_unzip(d, lo, hi);
+                *reinterpret_cast<u32x4*>(Dy + (2 * pp) * DYS + (r * WB_TW + pg * 8) * 2) = lo;
+                *reinterpret_cast<u32x4*>(Dy + (2 * pp + 1) * DYS + (r * WB_TW + pg * 8) * 2) = hi;
+            }
+        } else
         for (int i = tid; i < a.Cout * TH * 4; i += NT) {
             const int pg = i & 3, r = (i >> 2) % TH, co = i / (4 * TH);
             const int gy = h0 + r, gx = w0 + pg * 8;
@@ -611,16 +861,16 @@ extern "C" int64_t mrx_conv_wgrad_bf16_work_floats(int B, int H, int W, int k) {
     if (B < 1 || H < 1 || W < 1 || (k != 1 && k != 3 && k != 5)) return -1;
     return (int64_t)wb_nwg(B, H, W, k) * 64 * 64 * k * k;      // an upper bound for the thin layers
 }
-template <int K, int DIL>
+template <int K, int DIL, int DYP = 0>
 static int wb_launch(const WgradBfArgs& a, int nwg, hipStream_t st) {
     constexpr size_t lds = (size_t)64 * wb_dys(K) + (size_t)64 * wb_xs(K, DIL);
     static_assert(lds >= (wb_th(K) / 2) * 4096 * sizeof(float) || K != 1, "1x1: LDS also holds the wave reduction");
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<K, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<K, DIL, DYP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_bf16<K, DIL>), dim3(nwg), dim3(K == 1 ? 64 * wb_th(K) : 576), lds, st, a);
+    hipLaunchKernelGGL((k_conv_wgrad_bf16<K, DIL, DYP>), dim3(nwg), dim3(K == 1 ? 64 * wb_th(K) : 576), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -628,17 +878,17 @@ extern "C" int64_t mrx_conv_wgrad_bf16_any_work_floats(int B, int Cin, int Cout,
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (k != 1 && k != 3 && k != 5)) return -1;
     return (int64_t)wb_nwg(B, H, W, k) * Cout * Cin * k * k;
 }
-template <int K, int NCO, int NCI, int TPW>
+template <int K, int NCO, int NCI, int TPW, int DYP = 0>
 static int wbg_launch(const WgradBfGArgs& a, int nwg, hipStream_t st) {
     constexpr int PAD = (K - 1) / 2, PH = 8 + 2 * PAD, PW = WB_TW + 2 * PAD, XS = ((PH * PW * 2 + 255 - 16) / 256) * 256 + 16;
     constexpr int NW = (K * K + TPW - 1) / TPW;
     const size_t lds = (size_t)(a.Cout + 1) * (8 * WB_TW * 2 + 16) + (size_t)(a.Cin + 1) * XS;
     static size_t attr = 0;
     if (lds > 48 * 1024 && attr < lds) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_g<K, NCO, NCI, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_g<K, NCO, NCI, TPW, DYP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_bf16_g<K, NCO, NCI, TPW>), dim3(nwg), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((k_conv_wgrad_bf16_g<K, NCO, NCI, TPW, DYP>), dim3(nwg), dim3(64 * NW), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -677,6 +927,38 @@ extern "C" int mrx_conv_wgrad_bf16(const float* x, const float* dy, float* dw, f
     int rc = k == 1 ? wb_launch<1, 1>(a, nwg, st) : wb_launch<3, 2>(a, nwg, st);
     if (rc) return rc;
     const long long total = 64ll * 64 * k * k;
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// The same weight gradients with dy given as a PAIR tensor [B,32,H,W] (the bf16 gradient mrx_tl_cell_bwd leaves): 3x3 dilation 2 64 -> 64 and the thin
+// 5x5 Cin <= 32 -> 64 layer.  x stays fp32 NCHW (rounded by the tile loader).
+extern "C" int mrx_conv_wgrad_bf16_pairs(const float* x, const void* dy_pairs, float* dw, float* work, int B, int Cin, int H, int W, int k, int dil,
+                                         int pad_mode, int accumulate, void* stream) {
+    MRX_REQUIRE(x && dy_pairs && dw && work, MRX_EINVAL, "mrx_conv_wgrad_bf16_pairs: null pointer");
+    MRX_REQUIRE(B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_wgrad_bf16_pairs: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    const int nwg = wb_nwg(B, H, W, k);
+    const int vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy_pairs) % 16 == 0);
+    long long total;
+    if (k == 3 && dil == 2 && Cin == 64) {
+        WgradBfArgs a;
+        a.x = x, a.dy = (const float*)dy_pairs, a.part = work, a.B = B, a.H = H, a.W = W;
+        a.tiles_x = mrx_cdiv(W, WB_TW), a.tiles_y = mrx_cdiv(H, wb_th(k)), a.ntiles = a.tiles_x * a.tiles_y, a.pad_mode = pad_mode, a.vec = vec;
+        int rc = wb_launch<3, 2, 1>(a, nwg, st);
+        if (rc) return rc;
+        total = 64ll * 64 * 9;
+    } else if (k == 5 && dil == 1 && Cin >= 1 && Cin <= 32) {
+        WgradBfGArgs a;
+        a.x = x, a.dy = (const float*)dy_pairs, a.part = work, a.B = B, a.Cin = Cin, a.Cout = 64, a.H = H, a.W = W;
+        a.tiles_x = mrx_cdiv(W, WB_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, 8), a.pad_mode = pad_mode, a.vec = vec;
+        int rc = wbg_launch<5, 2, 1, 2, 1>(a, nwg, st);
+        if (rc) return rc;
+        total = 64ll * Cin * 25;
+    } else {
+        MRX_REQUIRE(false, MRX_EUNSUP, "mrx_conv_wgrad_bf16_pairs: Cin=%d k=%d dilation=%d not instantiated", Cin, k, dil);
+    }
     hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
     MRX_LAUNCH_CHECK();
     return MRX_OK;

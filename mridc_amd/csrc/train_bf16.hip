@@ -1,0 +1,436 @@
+// train_bf16.hip -- the backward half of one RIM layer in the mixed-precision training arithmetic (BASELINE config 4), and the small kernels
+// around the pair tensors of that path.  Reference: rim_block.py:230-238 (conv -> ReLU -> IndRNN cell), rnn_cells.py:384-391, trained under
+// pytorch-lightning AMP (base_cirim_train.yaml:180): convolution results -- and therefore the gradients flowing into them -- are half-precision
+// tensors, hidden states, `hh * h_prev`, FFTs and the loss are fp32.  Here "half" is bf16 and such tensors live in HBM as PAIR tensors
+// u32 [B][32][H][W] = (bf16 channel 2p, bf16 channel 2p + 1): two adjacent rows of the MFMA accumulator layout are two adjacent channels, so a
+// lane stores / loads one dword per row pair (128-byte segments per half-wave) and a quad of dwords IS a B operand of the next GEMM.
+//
+// mrx_tl_cell_bwd replaces five launches of the fp32-storage tape (ReLU backward of the cell, data gradient and weight gradient of the 1x1
+// GEMM with their partial reduction, ReLU backward of the convolution) by ONE pass over the tensors:
+//     g    = (dh_above + dH) * (h > 0)                       fp32  (dh_above: bf16 pairs, dH: the gradient carried from the next time-step)
+//     dh_prev = g * hh;   d_hh += sum g h_prev;   gb = bf16(g);   d_b_ih += sum gb
+//     da   = bf16(W_ih^T gb)                                 MFMA, contraction over the 64 output channels, B operands straight from registers
+//     ga   = da * (a > 0)  -> pairs;   d_b_conv += sum ga
+//     dW_ih += gb a^T                                        MFMA, contraction over the pixels: both operands transposed through LDS
+// One persistent workgroup per CU (8 waves = the 8 rows of an 8 x 32 tile); per-lane partial sums stay in registers over all tiles; every workgroup
+// ACCUMULATES its partial results in its own slot of `part` across the time-steps of a cascade (a workgroup always walks the same tiles: fixed
+// order), and mrx_tl_cell_reduce adds the slots up once per cascade in double -- gradients are bit-reproducible.
+#include "mrx_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CL_NT 512
+#define CL_RS 80                  // bytes per channel row of a transposed tile: 32 pixels bf16 + 16 (16 lanes x 80 B cover the 64 banks once)
+#define CL_TILE (64 * CL_RS)      // one [64 channels][32 pixels] tile
+#define CL_PART (64 * 64 + 3 * 64)  // floats per workgroup slot: dW_ih [co][ci], d_b_ih, d_hh, d_b_conv
+
+__device__ __forceinline__ unsigned tl_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float tl_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float tl_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// Sum of 32 per-lane values over the 32 lanes of a half-wave as a reduce-scatter: at the step of lane bit m a lane hands the half of its values
+// that belong to the other side to lane ^ m and adds what it receives -- 31 exchanges instead of 32 x 5; lane l ends with the total of value l % 32.
+// Fixed order: bit-reproducible.
+template <int N>
+__device__ __forceinline__ void tl_rs_step(float (&x)[32], int lane) {
+    const bool up = (lane & N) != 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float send = up ? x[i] : x[i + N], keep = up ? x[i + N] : x[i];
+        x[i] = keep + __shfl_xor(send, N, 64);
+    }
+}
+__device__ __forceinline__ float tl_reduce_scatter32(float (&x)[32], int lane) {
+    tl_rs_step<16>(x, lane);
+    tl_rs_step<8>(x, lane);
+    tl_rs_step<4>(x, lane);
+    tl_rs_step<2>(x, lane);
+    tl_rs_step<1>(x, lane);
+    return x[0];
+}
+
+struct CellBwdArgs {
+    const unsigned* dhP;   // [B,32,H,W] pairs or null: gradient from the layer above
+    const float* dH;       // [B,64,H,W] or null: gradient carried from the next time-step
+    const float* h;        // [B,64,H,W]: this step's state (the cell's ReLU mask)
+    const float* hprev;    // [B,64,H,W] or null (first time-step: zero state)
+    const unsigned* aP;    // [B,32,H,W] pairs: a = ReLU(conv)  (the convolution's ReLU mask and the 1x1 weight gradient's operand)
+    const u32x4* wT;       // mrx_tl_pack's ihT block: [4 steps][2 blocks][64 lanes]
+    const float* hh;       // [64]
+    float* dhp;            // [B,64,H,W] (written when hprev is given)
+    unsigned* gaP;         // [B,32,H,W] pairs
+    float* part;           // [gridDim.x][CL_PART]
+    int B, H, W, tiles_x, ntiles, first;
+};
+
+// HAS_DH / HAS_PREV: wave-uniform facts of the call as template parameters, loads unconditional from clamped coordinates (a conditional load is a
+// basic block of its own: the first version of this kernel had 360 of them and spilled 92 registers), stores of a chunk under one predicate.
+template <bool HAS_DH, bool HAS_PREV>
+__global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];   // [8 units][gb tile, a tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const long long plane = (long long)a.H * a.W;
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    float s_hh = 0.f, s_bih = 0.f, s_b = 0.f;   // lane (l31, lhi) owns channel 32 lhi + l31 (s_hh, s_bih) / accumulator row l31 of its half (s_b)
+    unsigned char* Tg = smem_c + wave * 2 * CL_TILE;
+    unsigned char* Ta = Tg + CL_TILE;
+    float* HH = reinterpret_cast<float*>(smem_c + 8 * 2 * CL_TILE);   // hh [64]
+    if (HAS_PREV && tid < 64) HH[tid] = a.hh[tid];
+    __syncthreads();
+    // every tensor is addressed as (wave-uniform base) + (32-bit byte offset of the lane): one address register per access instead of a 64-bit pair
+    // (the first form precomputed ~60 pointers and spilled them)
+    auto ldf = [](const float* p, unsigned o) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + o); };
+    auto ldu = [](const unsigned* p, unsigned o) { return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(p) + o); };
+    const unsigned plane4 = (unsigned)plane * 4u;
+    const int total = a.ntiles * a.B;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int b = t / a.ntiles, tt = t - b * a.ntiles;
+        const int ty0 = tt / a.tiles_x, oy = ty0 * 8 + wave, ox = (tt - ty0 * a.tiles_x) * 32 + l31;
+        const bool valid = oy < a.H && ox < a.W;
+        const unsigned pix4 = (unsigned)((oy < a.H ? oy : a.H - 1) * a.W + (ox < a.W ? ox : a.W - 1)) * 4u;
+        const unsigned pb = (unsigned)b * 32u * plane4 + pix4 + 16u * lhi * plane4, fb = (unsigned)b * 64u * plane4 + pix4 + 32u * lhi * plane4;
+        const unsigned ab = (unsigned)b * 32u * plane4 + pix4 + 2u * lhi * plane4;
+        // ---- cell stage: lane = pixel, channels 32 lhi + i; eight channels at a time -----------------------------------------------------------
+        unsigned gbP[16];
+        float t_hh[32];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            unsigned d2[4];
+            float dHv[8], hv[8], hpv[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d2[q] = ldu(a.dhP, pb + (unsigned)(4 * ch + q) * plane4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned o = fb + (unsigned)(8 * ch + j) * plane4;
+                dHv[j] = HAS_DH ? ldf(a.dH, o) : 0.f;
+                hv[j] = ldf(a.h, o);
+                hpv[j] = HAS_PREV ? ldf(a.hprev, o) : 0.f;
+            }
+            float g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float up = ((j & 1) ? tl_hi(d2[j >> 1]) : tl_lo(d2[j >> 1])) + dHv[j];
+                g[j] = (valid && hv[j] > 0.f) ? up : 0.f;
+                t_hh[8 * ch + j] = g[j] * hpv[j];
+            }
+            if (HAS_PREV && valid) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dhp) + fb + (unsigned)(8 * ch + j) * plane4) = g[j] * HH[32 * lhi + 8 * ch + j];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gbP[4 * ch + q] = tl_pk(g[2 * q], g[2 * q + 1]);
+            __builtin_amdgcn_sched_barrier(0);      // one chunk's 28 loads in flight at a time: hoisting all four costs 100+ registers (spills)
+        }
+        if (HAS_PREV) s_hh += tl_reduce_scatter32(t_hh, lane);
+        {
+            float t[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) t[i] = (i & 1) ? tl_hi(gbP[i >> 1]) : tl_lo(gbP[i >> 1]);
+            s_bih += tl_reduce_scatter32(t, lane);
+        }
+        // ---- da = W_ih^T gb: contraction over the output channels, B operands = the packed gradient as it sits in the registers ------------------
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        const u32x4* wp = a.wT + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const u32x4 bw = {gbP[4 * s], gbP[4 * s + 1], gbP[4 * s + 2], gbP[4 * s + 3]};
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wp[(s * 2 + ct) * 64]), __builtin_bit_cast(bf16x8, bw), acc[ct], 0,
+                                                                 0, 0);
+        }
+        // gb transposed into LDS: [channel][pixel]
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const unsigned p = gbP[i >> 1];
+            *reinterpret_cast<unsigned short*>(Tg + (32 * lhi + i) * CL_RS + l31 * 2) = (unsigned short)((i & 1) ? (p >> 16) : (p & 0xffffu));
+        }
+        // ---- ga = da * (a > 0), a transposed into LDS -------------------------------------------------------------------------------------------
+        float t_b[32];
+        unsigned gpv[16];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 2 * q, ci = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                unsigned aw = ldu(a.aP, ab + (unsigned)(ct * 16 + (q & 1) + 4 * (q >> 1)) * plane4);
+                aw = valid ? aw : 0u;
+                const float v0 = (aw & 0x7fffu) ? acc[ct][r] : 0.f, v1 = (aw & 0x7fff0000u) ? acc[ct][r + 1] : 0.f;
+                const unsigned gp = tl_pk(v0, v1);
+                gpv[ct * 8 + q] = gp;
+                t_b[ct * 16 + r] = tl_lo(gp);
+                t_b[ct * 16 + r + 1] = tl_hi(gp);
+                *reinterpret_cast<unsigned short*>(Ta + ci * CL_RS + l31 * 2) = (unsigned short)(aw & 0xffffu);
+                *reinterpret_cast<unsigned short*>(Ta + (ci + 1) * CL_RS + l31 * 2) = (unsigned short)(aw >> 16);
+            }
+        if (valid) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a.gaP) + ab + (unsigned)(ct * 16 + (q & 1) + 4 * (q >> 1)) * plane4) = gpv[ct * 8 + q];
+                }
+        }
+        s_b += tl_reduce_scatter32(t_b, lane);
+        __syncthreads();
+        // ---- dW_ih += gb a^T over the 8 x 32 pixels of the tile: wave = (cout block, cin block, half of the rows) ---------------------------------
+        {
+            const int bi = wave & 1, bj = (wave >> 1) & 1, uh = wave >> 2;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned char* base = smem_c + (uh * 4 + u) * 2 * CL_TILE;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(base + (bi * 32 + l31) * CL_RS + (kk * 16 + lhi * 8) * 2);
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(base + CL_TILE + (bj * 32 + l31) * CL_RS + (kk * 16 + lhi * 8) * 2);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc2, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- workgroup results -> this workgroup's slot (fixed order everywhere) ----------------------------------------------------------------------
+    float* R = reinterpret_cast<float*>(smem_c);          // [8 waves][64 lanes x 16] for the weight block, then [8 waves][3][64] for the sums
+    __syncthreads();
+    if (wave >= 4) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) R[((wave - 4) * 16 + r) * 64 + lane] = acc2[r];
+    }
+    __syncthreads();
+    float* slot = a.part + (long long)blockIdx.x * CL_PART;
+    if (wave < 4) {
+        const int bi = wave & 1, bj = (wave >> 1) & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc2[r] + R[(wave * 16 + r) * 64 + lane];
+            const int co = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * lhi, ci = 32 * bj + l31;
+            slot[co * 64 + ci] = a.first ? v : slot[co * 64 + ci] + v;
+        }
+    }
+    __syncthreads();
+    // per-channel sums: every lane holds the wave's total of its own channel; across the waves in wave order
+    float* S = reinterpret_cast<float*>(smem_c);          // [8 waves][3][64]
+    S[(wave * 3 + 0) * 64 + 32 * lhi + l31] = s_bih;
+    S[(wave * 3 + 1) * 64 + 32 * lhi + l31] = s_hh;
+    {
+        const int ct = l31 >> 4, r = l31 & 15;
+        S[(wave * 3 + 2) * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] = s_b;
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int qn = tid >> 6, c = tid & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += S[(w * 3 + qn) * 64 + c];
+        float* dst = slot + 4096 + qn * 64 + c;
+        *dst = a.first ? v : *dst + v;
+    }
+}
+
+static int tl_nwg(long long tiles) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return (int)(tiles < n_cu ? tiles : n_cu);
+}
+extern "C" int64_t mrx_tl_cell_part_floats(int B, int H, int W) {
+    if (B < 1 || H < 1 || W < 1) return -1;
+    return (int64_t)tl_nwg((long long)B * mrx_cdiv(W, 32) * mrx_cdiv(H, 8)) * CL_PART;
+}
+// The backward pass of one IndRNN layer's cell + convolution ReLU (see the header).  dH (fp32) may be null (last time-step); hprev null =
+// first time-step (no dh_prev, no hh gradient).  `part` [mrx_tl_cell_part_floats]: the workgroup slots; first != 0 overwrites them (first call of a
+// cascade), otherwise the call adds to them.  tl_packed from mrx_tl_pack.
+extern "C" int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const float* h, const float* hprev, const void* a_pairs, const void* tl_packed,
+                               const float* hh, float* dh_prev, void* ga_pairs, float* part, int first, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(h && a_pairs && tl_packed && ga_pairs && part, MRX_EINVAL, "mrx_tl_cell_bwd: null pointer");
+    MRX_REQUIRE(!hprev || (hh && dh_prev), MRX_EINVAL, "mrx_tl_cell_bwd: hprev without hh / dh_prev");
+    MRX_REQUIRE(B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_tl_cell_bwd: bad dims");
+    MRX_REQUIRE((long long)B * 64 * H * W * 4 < (1ll << 32), MRX_EUNSUP, "mrx_tl_cell_bwd: tensors of 4 GB and more (32-bit byte offsets)");
+    CellBwdArgs a;
+    a.dhP = (const unsigned*)dh_above, a.dH = dH, a.h = h, a.hprev = hprev, a.aP = (const unsigned*)a_pairs;
+    a.wT = (const u32x4*)tl_packed + 768, a.hh = hh, a.dhp = dh_prev, a.gaP = (unsigned*)ga_pairs, a.part = part;
+    a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, 32), a.ntiles = a.tiles_x * mrx_cdiv(H, 8), a.first = first;
+    MRX_REQUIRE(dh_above, MRX_EINVAL, "mrx_tl_cell_bwd: the gradient from the layer above is required");
+    constexpr int lds = 8 * 2 * CL_TILE + 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    const dim3 grid(tl_nwg((long long)B * a.ntiles));
+    hipStream_t st = (hipStream_t)stream;
+    if (dH && hprev)
+        hipLaunchKernelGGL((k_tl_cell_bwd<true, true>), grid, dim3(CL_NT), lds, st, a);
+    else if (dH)
+        hipLaunchKernelGGL((k_tl_cell_bwd<true, false>), grid, dim3(CL_NT), lds, st, a);
+    else if (hprev)
+        hipLaunchKernelGGL((k_tl_cell_bwd<false, true>), grid, dim3(CL_NT), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_tl_cell_bwd<false, false>), grid, dim3(CL_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// gradients += the workgroup slots, added in slot order in double: dW_ih [64,64], d_b_ih [64], d_hh [64], d_b_conv [64] (null = not wanted)
+__global__ __launch_bounds__(256) void k_tl_cell_reduce(const float* __restrict__ part, int nparts, float* dw, float* dbih, float* dhh, float* db) {
+    __shared__ double sh[16][17];
+    const int li = threadIdx.x & 15, lp = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + li;
+    double s = 0.0;
+    if (i < CL_PART)
+        for (int p = lp; p < nparts; p += 16) s += (double)part[(long long)p * CL_PART + i];
+    sh[lp][li] = s;
+    __syncthreads();
+    if (lp == 0 && i < CL_PART) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][li];
+        float* dst = i < 4096 ? dw + i : (i < 4160 ? (dbih ? dbih + (i - 4096) : nullptr) : (i < 4224 ? (dhh ? dhh + (i - 4160) : nullptr) : (db ? db + (i - 4224) : nullptr)));
+        if (dst) *dst += (float)t;
+    }
+}
+extern "C" int mrx_tl_cell_reduce(const float* part, int B, int H, int W, float* dw_ih, float* db_ih, float* dhh, float* db_conv, void* stream) {
+    MRX_REQUIRE(part && dw_ih, MRX_EINVAL, "mrx_tl_cell_reduce: null pointer");
+    const int n = tl_nwg((long long)B * mrx_cdiv(W, 32) * mrx_cdiv(H, 8));
+    hipLaunchKernelGGL(k_tl_cell_reduce, dim3((CL_PART + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, n, dw_ih, db_ih, dhh, db_conv);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- the edge pixels of a replicate-padded data gradient whose interior is in `dx` already (mrx_tl_dgrad): every edge pixel receives the frame
+// positions that clamp to it; the sum is rounded to bf16 once more (dx is a bf16 tensor: pairs, or fp32 holding bf16 values) --------------------------
+__global__ void k_tl_fold_edges(const float* __restrict__ g, void* __restrict__ dx, int pairs, int B, int C, int H, int W, int pad) {
+    const int per = 2 * W + 2 * (H - 2 > 0 ? H - 2 : 0);
+    const int nch = pairs ? C / 2 : C;
+    const long long total = (long long)B * nch * per;
+    const int PW = W + 2 * pad, PH = H + 2 * pad;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long p = o / per;
+        int e = (int)(o - p * per), h, w;
+        if (e < W) {
+            h = 0, w = e;
+        } else if (e < 2 * W) {
+            h = H - 1, w = e - W;
+            if (H == 1) continue;
+        } else {
+            e -= 2 * W;
+            h = 1 + (e >> 1), w = (e & 1) ? W - 1 : 0;
+            if (W == 1 && (e & 1)) continue;
+        }
+        const int i0 = h == 0 ? 0 : h + pad, i1 = h == H - 1 ? PH - 1 : h + pad;
+        const int j0 = w == 0 ? 0 : w + pad, j1 = w == W - 1 ? PW - 1 : w + pad;
+        const int bb = (int)(p / nch), cc = (int)(p - (long long)bb * nch);
+        float s[2] = {0.f, 0.f};
+        for (int k = 0; k < (pairs ? 2 : 1); ++k) {
+            const float* gp = g + ((long long)bb * C + (pairs ? 2 * cc + k : cc)) * PH * PW;
+            for (int i = i0; i <= i1; ++i)
+                for (int j = j0; j <= j1; ++j)
+                    if (i != h + pad || j != w + pad) s[k] += gp[(long long)i * PW + j];
+        }
+        const long long at = p * (long long)H * W + (long long)h * W + w;
+        if (pairs) {
+            unsigned* q = reinterpret_cast<unsigned*>(dx) + at;
+            *q = tl_pk(tl_lo(*q) + s[0], tl_hi(*q) + s[1]);
+        } else {
+            float* q = reinterpret_cast<float*>(dx) + at;
+            *q = tl_lo(tl_pk(*q + s[0], 0.f));
+        }
+    }
+}
+extern "C" int mrx_tl_fold_edges(const float* frame, void* dx, int dx_pairs, int B, int C, int H, int W, int pad, void* stream) {
+    MRX_REQUIRE(frame && dx && B >= 1 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && (!dx_pairs || C % 2 == 0), MRX_EINVAL, "mrx_tl_fold_edges: bad argument");
+    const long long total = (long long)B * (dx_pairs ? C / 2 : C) * (2ll * W + 2ll * (H - 2 > 0 ? H - 2 : 0));
+    if (total == 0 || pad == 0) return MRX_OK;
+    const long long nb = (total + 255) / 256;
+    hipLaunchKernelGGL(k_tl_fold_edges, dim3((unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, (hipStream_t)stream, frame, dx, dx_pairs, B, C, H, W, pad);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- eta_new = eta + bf16(sum of the nine shifted tap planes): the final convolution of a RIM step from mrx_tl_layer_fwd's tap products
+// (rim_block.py:239-248; replicate padding = clamped coordinates) ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tl_final_gather(const float* __restrict__ taps, const float* __restrict__ eta, float* __restrict__ out, int H, int W) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const long long plane = (long long)H * W;
+    const float* pb = taps + (long long)b * 18 * plane;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        int yy = y + dy - 1;
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            int xx = x + dx - 1;
+            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            const float* p = pb + (long long)((dy * 3 + dx) * 2) * plane + (long long)yy * W + xx;
+            s0 += p[0];
+            s1 += p[plane];
+        }
+    }
+    const unsigned r = tl_pk(s0, s1);
+    const long long o = ((long long)b * plane + (long long)y * W + x) * 2;
+    out[o] = eta[o] + tl_lo(r);
+    out[o + 1] = eta[o + 1] + tl_hi(r);
+}
+extern "C" int mrx_tl_final_gather(const float* taps, const float* eta, float* eta_out, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(taps && eta && eta_out && B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_tl_final_gather: bad argument");
+    hipLaunchKernelGGL(k_tl_final_gather, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps, eta, eta_out, H, W);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- pair tensors <-> fp32 NCHW (tests, and the first gradient of a step: d_eta [B,H,W,2] -> bf16 values as fp32 [B,2,H,W]) ---------------------
+__global__ void k_tl_pairs_to_f32(const unsigned* __restrict__ p, float* __restrict__ out, long long planes, long long plane) {
+    const long long n = planes * plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long pl = i / plane, px = i - pl * plane;
+        const unsigned v = p[i];
+        out[(2 * pl) * plane + px] = tl_lo(v);
+        out[(2 * pl + 1) * plane + px] = tl_hi(v);
+    }
+}
+__global__ void k_tl_f32_to_pairs(const float* __restrict__ x, unsigned* __restrict__ out, long long planes, long long plane) {
+    const long long n = planes * plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long pl = i / plane, px = i - pl * plane;
+        out[i] = tl_pk(x[(2 * pl) * plane + px], x[(2 * pl + 1) * plane + px]);
+    }
+}
+extern "C" int mrx_tl_pairs_to_f32(const void* pairs, float* out, int64_t pair_planes, int64_t plane, void* stream) {
+    MRX_REQUIRE(pairs && out && pair_planes >= 0 && plane >= 0, MRX_EINVAL, "mrx_tl_pairs_to_f32: bad argument");
+    const long long n = pair_planes * plane, nb = (n + 255) / 256;
+    if (n == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_tl_pairs_to_f32, dim3((unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, (hipStream_t)stream, (const unsigned*)pairs, out, (long long)pair_planes,
+                       (long long)plane);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_tl_f32_to_pairs(const float* x, void* pairs, int64_t pair_planes, int64_t plane, void* stream) {
+    MRX_REQUIRE(pairs && x && pair_planes >= 0 && plane >= 0, MRX_EINVAL, "mrx_tl_f32_to_pairs: bad argument");
+    const long long n = pair_planes * plane, nb = (n + 255) / 256;
+    if (n == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_tl_f32_to_pairs, dim3((unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, (hipStream_t)stream, x, (unsigned*)pairs, (long long)pair_planes,
+                       (long long)plane);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}

@@ -977,6 +977,133 @@ def conv_wgrad_bf16(x, dy, k, dilation=1, pad_mode=PAD_REPLICATE, out=None, accu
     return out
 
 
+# ---- mixed-precision training with bf16 STORAGE (csrc/train_bf16.hip, conv_bf16.hip OUT 1 / 2; callers: mridc_amd/training.py) ---------------------
+# "Pair tensors": what torch.autocast keeps in half precision (convolution results, the gradients flowing into them) lives in HBM as
+# int32 [B, C / 2, H, W] = (bf16 of channel 2p, bf16 of channel 2p + 1).
+def f32_to_pairs(x):
+    x = _lib.f32c(x)
+    B, C, H, W = _nchw(x)
+    if C % 2:
+        raise ValueError("f32_to_pairs: odd channel count")
+    out = torch.empty(B, C // 2, H, W, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.lib().mrx_tl_f32_to_pairs(_lib.ptr(x), _lib.ptr(out), B * (C // 2), H * W, _lib.stream_ptr()), "mrx_tl_f32_to_pairs")
+    return out
+
+
+def pairs_to_f32(p):
+    B, C2, H, W = [int(v) for v in p.shape]
+    out = torch.empty(B, 2 * C2, H, W, dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().mrx_tl_pairs_to_f32(_lib.ptr(p), _lib.ptr(out), B * C2, H * W, _lib.stream_ptr()), "mrx_tl_pairs_to_f32")
+    return out
+
+
+def _tl_pack(w_ih, w_fin):
+    """mrx_tl_pack of an IndRNN layer's 1x1 weight (forward order, transposed order) and -- for the last layer -- the final convolution's weights,
+    cached per (storage, version) like the other packs."""
+    key = (w_ih.data_ptr(), w_ih._version, str(w_ih.device), None if w_fin is None else (w_fin.data_ptr(), w_fin._version), "tl")
+    hit = _PACKS_BF16.get(key)
+    if hit is None:
+        if len(_PACKS_BF16) >= 256:
+            _PACKS_BF16.pop(next(iter(_PACKS_BF16)))
+        if tuple(w_ih.shape) != (64, 64, 1, 1) or (w_fin is not None and tuple(w_fin.shape) != (2, 64, 3, 3)):
+            raise NotImplementedError("training layer kernels: 64 features, 1x1 IndRNN, final 3x3 convolution into 2 channels")
+        L = _lib.lib()
+        packed = torch.empty(int(L.mrx_tl_pack_bytes()), dtype=torch.uint8, device=w_ih.device)
+        wf = None if w_fin is None else _lib.f32c(w_fin.detach())
+        _lib.check(L.mrx_tl_pack(_lib.ptr(_lib.f32c(w_ih.detach())), _lib.ptr(wf), _lib.ptr(packed), _lib.stream_ptr()), "mrx_tl_pack")
+        hit = _PACKS_BF16[key] = (packed, w_ih.detach(), None if w_fin is None else w_fin.detach())
+    return hit[0]
+
+
+def tl_layer_supported(Cin, Cout, k, dilation, rnn_features, rnn_k):
+    return Cout == 64 and rnn_features == 64 and rnn_k == 1 and ((k == 5 and dilation == 1 and 1 <= Cin <= 8) or (k == 3 and dilation == 2 and Cin == 64))
+
+
+def tl_layer_fwd(x, conv_w, conv_b, w_ih, b_ih, hh, h_prev, w_fin=None):
+    """One RIM layer in the training arithmetic (mrx_tl_layer_fwd): a = ReLU(bf16(conv_reppad(x) + b)) as a pair tensor, h = ReLU(bf16(W_ih a + b_ih)
+    + hh * h_prev) fp32; with w_fin also the final convolution's 18 tap-product planes.  Returns (a_pairs, h, taps | None)."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    k, dil = int(conv_w.shape[-1]), (1 if int(conv_w.shape[-1]) == 5 else 2)
+    cp = _conv_bf16_pack(conv_w, False)
+    tp = _tl_pack(w_ih, w_fin)
+    a = torch.empty(B, 32, H, W, dtype=torch.int32, device=x.device)
+    h = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
+    taps = torch.empty(B, 18, H, W, dtype=torch.float32, device=x.device) if w_fin is not None else None
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1)) if h_prev is not None else None
+    cb = _lib.f32c(conv_b.detach()) if conv_b is not None else None
+    ib = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    _lib.check(_lib.lib().mrx_tl_layer_fwd(_lib.ptr(x), _lib.ptr(cp), _lib.ptr(cb), _lib.ptr(tp), _lib.ptr(ib), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(a),
+                                           _lib.ptr(h), _lib.ptr(taps), B, Cin, H, W, k, dil, _lib.stream_ptr()), "mrx_tl_layer_fwd")
+    return a, h, taps
+
+
+def tl_final_gather(taps, eta):
+    B, H, W = int(eta.shape[0]), int(eta.shape[1]), int(eta.shape[2])
+    out = torch.empty_like(eta)
+    _lib.check(_lib.lib().mrx_tl_final_gather(_lib.ptr(taps), _lib.ptr(eta), _lib.ptr(out), B, H, W, _lib.stream_ptr()), "mrx_tl_final_gather")
+    return out
+
+
+def tl_cell_part(B, H, W, device):
+    return torch.empty(int(_lib.lib().mrx_tl_cell_part_floats(B, H, W)), dtype=torch.float32, device=device)
+
+
+def tl_cell_bwd(dh_pairs, dH, h, h_prev, a_pairs, w_ih, w_fin, hh, part, first):
+    """mrx_tl_cell_bwd: (dh_prev | None, ga_pairs); the parameter-gradient partials accumulate in `part` (tl_cell_part) until tl_cell_reduce."""
+    B, _, H, W = _nchw(h)
+    tp = _tl_pack(w_ih, w_fin)
+    ga = torch.empty(B, 32, H, W, dtype=torch.int32, device=h.device)
+    dhp = torch.empty_like(h) if h_prev is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1)) if h_prev is not None else None
+    _lib.check(_lib.lib().mrx_tl_cell_bwd(_lib.ptr(dh_pairs), _lib.ptr(dH), _lib.ptr(h), _lib.ptr(h_prev), _lib.ptr(a_pairs), _lib.ptr(tp), _lib.ptr(hhc),
+                                          _lib.ptr(dhp), _lib.ptr(ga), _lib.ptr(part), int(bool(first)), B, H, W, _lib.stream_ptr()), "mrx_tl_cell_bwd")
+    return dhp, ga
+
+
+def tl_cell_reduce(part, B, H, W, dw_ih, db_ih, dhh, db_conv):
+    _lib.check(_lib.lib().mrx_tl_cell_reduce(_lib.ptr(part), B, H, W, _lib.ptr(dw_ih), _lib.ptr(db_ih), _lib.ptr(dhh), _lib.ptr(db_conv), _lib.stream_ptr()),
+               "mrx_tl_cell_reduce")
+
+
+def tl_dgrad(dy, weight, dilation, dx_pairs):
+    """Data gradient of a replicate-padded convolution with bf16 results (mrx_tl_dgrad + mrx_tl_fold_edges): dy fp32 [B,Cout,H,W] or a pair tensor
+    (int32 [B,Cout/2,H,W]); returns a pair tensor (dx_pairs) or fp32 holding bf16 values."""
+    pairs_in = dy.dtype == torch.int32
+    B, Cd, H, W = [int(v) for v in dy.shape]
+    cout_w, cin_w, k = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+    if (2 * Cd if pairs_in else Cd) != cout_w:
+        raise RuntimeError(f"tl_dgrad: gradient of {Cd} planes for a weight {tuple(weight.shape)}")
+    if not pairs_in:
+        dy = _lib.f32c(dy)
+    pad = int(dilation) * (k - 1) // 2
+    packed = _conv_bf16_pack(weight, True)
+    dx = torch.empty(B, cin_w // 2 if dx_pairs else cin_w, H, W, dtype=torch.int32 if dx_pairs else torch.float32, device=dy.device)
+    frame = torch.empty(B, cin_w, H + 2 * pad, W + 2 * pad, dtype=torch.float32, device=dy.device)
+    L = _lib.lib()
+    _lib.check(L.mrx_tl_dgrad(_lib.ptr(dy), int(pairs_in), _lib.ptr(packed), _lib.ptr(dx), int(bool(dx_pairs)), _lib.ptr(frame), B, cout_w, cin_w, H, W, k,
+                              int(dilation), _lib.stream_ptr()), "mrx_tl_dgrad")
+    _lib.check(L.mrx_tl_fold_edges(_lib.ptr(frame), _lib.ptr(dx), int(bool(dx_pairs)), B, cin_w, H, W, pad, _lib.stream_ptr()), "mrx_tl_fold_edges")
+    return dx
+
+
+def conv_wgrad_bf16_pairs(x, dy_pairs, k, dilation, pad_mode=PAD_REPLICATE, out=None, accumulate=False):
+    """Weight gradient with the output gradient given as a pair tensor (mrx_conv_wgrad_bf16_pairs): 3x3 dilation 2 64 -> 64, 5x5 Cin <= 32 -> 64."""
+    x = _lib.f32c(x)
+    B, Cin, H, W = _nchw(x)
+    if tuple(dy_pairs.shape) != (B, 32, H, W) or dy_pairs.dtype != torch.int32:
+        raise ValueError(f"conv_wgrad_bf16_pairs: x {tuple(x.shape)}, dy {tuple(dy_pairs.shape)}")
+    if out is None:
+        out = torch.empty(64, Cin, k, k, dtype=torch.float32, device=x.device)
+        accumulate = False
+    L = _lib.lib()
+    work = torch.empty(int(L.mrx_conv_wgrad_bf16_any_work_floats(B, Cin, 64, H, W, int(k))), dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_conv_wgrad_bf16_pairs(_lib.ptr(x), _lib.ptr(dy_pairs), _lib.ptr(out), _lib.ptr(work), B, Cin, H, W, int(k), int(dilation), int(pad_mode),
+                                           int(bool(accumulate)), _lib.stream_ptr()), "mrx_conv_wgrad_bf16_pairs")
+    return out
+
+
 def conv_to_complex(x, weight, bias, dilation=1, pad_mode=PAD_ZERO):
     """permute(conv(x), (0, 2, 3, 1)) for a convolution into 2 channels -> [B,H,W,2] (one complex image).  The tuned kernel covers
     3x3, dilation 1, W % 4 == 0, Cin % 4 == 0; other shapes run conv2d and permute."""

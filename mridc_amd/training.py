@@ -113,6 +113,11 @@ def inverse_sqrt_lr(step, max_steps, base_lr, warmup_ratio=0.1, min_lr=0.0, warm
     return base_lr / math.sqrt((step + 1) / (warmup_steps + 1))
 
 
+# bf16 mode: True = convolution results and their gradients are STORED in bf16 too (pair tensors, the rounding points of torch.autocast:
+# _cascade_forward_backward_tl); False = bf16 operands with fp32 storage (the round-2 kernels; a test hook and the fallback for other layer shapes)
+BF16_STORAGE = True
+
+
 # ---- the explicit tape ------------------------------------------------------------------------------------------------------------------
 # The CIRIM recurrence is a fixed sequence (rim_block.py:217-249), so its backward pass is written out instead of recorded: forward saves the
 # activations of one cascade, the backward walks the time-steps in reverse calling the kernels directly.  What that buys over the autograd
@@ -273,6 +278,90 @@ def _cascade_forward_backward(blk, eta, llg, tgt, wdev, sigma, bf16):
     return etas, losses
 
 
+def _tl_supported(blk):
+    """The bf16-storage tape (csrc/train_bf16.hip) covers the model-zoo RIM: two IndRNN layers of 64 features (5x5 on <= 8 channels, 3x3 dilation 2
+    on 64), a final 3x3 convolution into 2 channels without bias."""
+    final = blk.final_layer[0]
+    if len(blk.layers) != 2 or final is None or final.conv_layer.bias is not None or final.kernel_size != 3 or final.dilation != 1:
+        return False
+    if tuple(final.conv_layer.weight.shape) != (2, 64, 3, 3):
+        return False
+    for st in blk.layers:
+        c, r = st.convs, st.rnn
+        cw = c.conv_layer.weight
+        if not ops.tl_layer_supported(int(cw.shape[1]), int(cw.shape[0]), c.kernel_size, c.dilation, int(r.ih.weight.shape[0]), r.kernel_size):
+            return False
+    return True
+
+
+def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
+    """One cascade in the reference's mixed-precision arithmetic with bf16 STORAGE (base_cirim_train.yaml:180; what torch.autocast keeps in half
+    precision is a pair tensor here): per time-step two fused layer launches + the tap gather forward, and per layer ONE cell-backward launch, one
+    data gradient and one weight gradient backward.  Convolution results and the gradients flowing into them are rounded to bf16 exactly where
+    autocast rounds them; hidden states, eta, the loss and every parameter-gradient sum are fp32.  Returns (etas, per-step loss records)."""
+    L_ = _lib.lib()
+    final = blk.final_layer[0]
+    fw = final.conv_layer.weight
+    nl = len(blk.layers)
+    B, H, W = int(eta.shape[0]), int(eta.shape[1]), int(eta.shape[2])
+    plane = H * W
+    hx = [None] * nl
+    saved, etas, losses = [], [], []
+    for _ in range(blk.time_steps):
+        g4 = llg.forward(eta, sigma)
+        x, acts, taps = g4, [], None
+        for li, st in enumerate(blk.layers):
+            c, r = st.convs, st.rnn
+            a_p, h, taps = ops.tl_layer_fwd(x, c.conv_layer.weight, c.conv_layer.bias, r.ih.weight, r.ih.bias, r.hh, hx[li],
+                                            fw if li == nl - 1 else None)
+            acts.append((x, a_p, h, hx[li]))
+            hx[li] = h
+            x = h
+        eta_new = ops.tl_final_gather(taps, eta)
+        m = ops.max_abs(eta_new, complex_modulus=True).reshape(1)
+        out2 = torch.empty(2, dtype=torch.float32, device=eta.device)
+        work = torch.empty(int(L_.mrx_absl1_work_floats()), dtype=torch.float32, device=eta.device)
+        _lib.check(L_.mrx_absl1_loss(_lib.ptr(eta_new), _lib.ptr(tgt), _lib.ptr(m), _lib.ptr(out2), _lib.ptr(work), B * plane, _lib.stream_ptr()),
+                   "mrx_absl1_loss")
+        saved.append((acts, eta_new, m, out2))
+        etas.append(eta_new)
+        losses.append(out2)
+        eta = eta_new
+    parts = [ops.tl_cell_part(B, H, W, eta.device) for _ in range(nl)]
+    carry, dH = None, [None] * nl
+    for ti, (acts, eta_t, m, out2) in enumerate(reversed(saved)):
+        gl = torch.empty_like(eta_t)
+        _lib.check(L_.mrx_absl1_loss_bwd(_lib.ptr(eta_t), _lib.ptr(tgt), _lib.ptr(m), _lib.ptr(out2), _lib.ptr(wdev), 1.0, _lib.ptr(gl),
+                                         B * plane, _lib.stream_ptr()), "mrx_absl1_loss_bwd")
+        tot = torch.empty_like(eta_t)
+        d2 = torch.empty(B, 2, H, W, dtype=torch.float32, device=eta_t.device)
+        _lib.check(L_.mrx_eta_grad_in(_lib.ptr(carry), _lib.ptr(gl), _lib.ptr(tot), _lib.ptr(d2), B, plane, _lib.stream_ptr()), "mrx_eta_grad_in")
+        # final convolution (its result is a bf16 tensor under autocast: both gradient kernels round d2 to bf16 on load)
+        _wgrad_into(acts[-1][2], d2, 3, 1, ops.PAD_REPLICATE, _grad_of(fw), True)
+        dh = ops.tl_dgrad(d2, fw, 1, dx_pairs=True)
+        for li in range(nl - 1, -1, -1):
+            st = blk.layers[li]
+            c, r = st.convs, st.rnn
+            x_in, a_p, h, h_prev = acts[li]
+            dhp, ga = ops.tl_cell_bwd(dh, dH[li], h, h_prev, a_p, r.ih.weight, fw if li == nl - 1 else None, r.hh, parts[li], ti == 0)
+            dH[li] = dhp
+            cw = c.conv_layer.weight
+            ops.conv_wgrad_bf16_pairs(x_in, ga, c.kernel_size, c.dilation, ops.PAD_REPLICATE, out=_grad_of(cw), accumulate=True)
+            dh = ops.tl_dgrad(ga, cw, c.dilation, dx_pairs=li > 0)
+        dg4 = dh                                                       # [B,4,H,W] fp32 (bf16 values): gradient w.r.t. cat(eta, log-likelihood gradient)
+        dz = torch.empty_like(eta_t)
+        _lib.check(L_.mrx_g4_to_complex(_lib.ptr(dg4), _lib.ptr(dz), B, plane, _lib.stream_ptr()), "mrx_g4_to_complex")
+        t4 = llg.adjoint(dz, sigma)
+        carry = torch.empty_like(eta_t)
+        _lib.check(L_.mrx_eta_grad_out(_lib.ptr(tot), _lib.ptr(dg4), _lib.ptr(t4), _lib.ptr(carry), B, plane, _lib.stream_ptr()),
+                   "mrx_eta_grad_out")
+    for li, st in enumerate(blk.layers):                               # the cell kernels' partial sums of the whole cascade -> the gradients
+        c, r = st.convs, st.rnn
+        ops.tl_cell_reduce(parts[li], B, H, W, _grad_of(r.ih.weight), _grad_of(r.ih.bias) if r.ih.bias is not None else None,
+                           _grad_of(r.hh).reshape(-1), _grad_of(c.conv_layer.bias) if c.conv_layer.bias is not None else None)
+    return etas, losses
+
+
 def cirim_forward_backward(model, batch, precision="f32", on_cascade_done=None):
     """Forward, l1 loss (cirim.py:199-247 with accumulate_estimates) and backward of the whole CIRIM on the explicit tape.  Gradients are
     ADDED into `p.grad` of the parameters (zero them first).  `on_cascade_done(i)` is called when cascade i's gradients are final.
@@ -291,7 +380,10 @@ def cirim_forward_backward(model, batch, precision="f32", on_cascade_done=None):
     bf16 = precision == "bf16"
     for i, blk in enumerate(model.cirim):
         llg = _Llg(blk, y, S, mask, hybrid)
-        etas, losses = _cascade_forward_backward(blk, eta, llg, tgt, wdev, 1.0, bf16)
+        if bf16 and BF16_STORAGE and _tl_supported(blk):
+            etas, losses = _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, 1.0)
+        else:
+            etas, losses = _cascade_forward_backward(blk, eta, llg, tgt, wdev, 1.0, bf16)
         terms += losses
         eta = etas[-1]                                                    # keep_eta: the next cascade starts from pred[-1].detach()
         if on_cascade_done is not None:

@@ -18,4 +18,4 @@ numpy float64 DFT path (`oracle.fft.fft2_np64`) cross-checks it.
 
 Every function cites the reference file:line it follows (paths relative to the reference root).
 """
-from . import fft, utils, rim, unet, varnet, models, metrics, qrim, transforms, cascadenet, vsnet, dc_layers, rvn, dunet  # noqa: F401
+from . import fft, utils, rim, unet, varnet, models, metrics, qrim, transforms, cascadenet, vsnet, dc_layers, rvn, dunet, amp  # noqa: F401

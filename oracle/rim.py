@@ -11,6 +11,15 @@ from . import fft as offt
 from . import utils as outils
 
 
+# The 2-D convolutions of the regulariser go through this hook so that oracle/amp.py can restate them with half-precision operands
+# (the reference trains under AMP: base_cirim_train.yaml:180); the default is torch's fp32 convolution.
+_CONV2D = [F.conv2d]
+
+
+def _conv2d(x, weight, bias=None, padding=0, dilation=1):
+    return _CONV2D[0](x, weight, bias, padding=padding, dilation=dilation)
+
+
 def log_likelihood_gradient(eta, masked_kspace, sense, mask, sigma, fft_centered, fft_normalization,
                             spatial_dims, coil_dim):
     """rim_utils.py:11-67.  eta [B,H,W,2]; y,S [B,C,H,W,2]; mask broadcastable -> [B,4,H,W]."""
@@ -27,7 +36,7 @@ def conv_nonlinear(x, weight, bias, kernel_size, dilation, nonlinear):
     """conv_layers.py:72-85,121-123: replication pad by dil*(k-1)//2, conv(padding=0), activation."""
     p = int(dilation * (kernel_size - 1) / 2)
     x = F.pad(x, (p, p, p, p), mode="replicate") if p > 0 else x
-    x = F.conv2d(x, weight, bias, padding=0, dilation=dilation)
+    x = _conv2d(x, weight, bias, padding=0, dilation=dilation)
     if nonlinear is None:
         return x
     if nonlinear.upper() == "RELU":
@@ -44,14 +53,14 @@ def _zero_pad(kernel_size, dilation):
 def indrnn_cell(x, hx, ih_w, ih_b, hh, kernel_size, dilation):
     """rnn_cells.py:295-312,384-391: ReLU(conv_zero_pad(x) + hh * hx)."""
     p = _zero_pad(kernel_size, dilation)
-    return F.relu(F.conv2d(x, ih_w, ih_b, padding=p, dilation=dilation) + hh * hx)
+    return F.relu(_conv2d(x, ih_w, ih_b, padding=p, dilation=dilation) + hh * hx)
 
 
 def convgru_cell(x, hx, ih_w, ih_b, hh_w, kernel_size, dilation):
     """rnn_cells.py:23-38,112-127."""
     p = _zero_pad(kernel_size, dilation)
-    i_r, i_z, i_n = F.conv2d(x, ih_w, ih_b, padding=p, dilation=dilation).chunk(3, 1)
-    h_r, h_z, h_n = F.conv2d(hx, hh_w, None, padding=p, dilation=dilation).chunk(3, 1)
+    i_r, i_z, i_n = _conv2d(x, ih_w, ih_b, padding=p, dilation=dilation).chunk(3, 1)
+    h_r, h_z, h_n = _conv2d(hx, hh_w, None, padding=p, dilation=dilation).chunk(3, 1)
     r = torch.sigmoid(i_r + h_r)
     z = torch.sigmoid(i_z + h_z)
     n = torch.tanh(i_n + r * h_n)
@@ -61,8 +70,8 @@ def convgru_cell(x, hx, ih_w, ih_b, hh_w, kernel_size, dilation):
 def convmgu_cell(x, hx, ih_w, ih_b, hh_w, kernel_size, dilation):
     """rnn_cells.py:157-172,249-261."""
     p = _zero_pad(kernel_size, dilation)
-    i_f, i_c = F.conv2d(x, ih_w, ih_b, padding=p, dilation=dilation).chunk(2, 1)
-    h_f, h_c = F.conv2d(hx, hh_w, None, padding=p, dilation=dilation).chunk(2, 1)
+    i_f, i_c = _conv2d(x, ih_w, ih_b, padding=p, dilation=dilation).chunk(2, 1)
+    h_f, h_c = _conv2d(hx, hh_w, None, padding=p, dilation=dilation).chunk(2, 1)
     f = torch.sigmoid(i_f + h_f)
     c = torch.tanh(i_c + f * h_c)
     return c + f * (hx - c)

@@ -1,0 +1,193 @@
+"""BASELINE config 4 with bf16 storage (csrc/train_bf16.hip, conv_bf16.hip OUT 1 / 2): every kernel of the tape against a float64 restatement of the
+reference's autocast arithmetic (base_cirim_train.yaml:180: convolutions on half-precision operands returning half-precision tensors; hidden
+states, hh * hx, eta and the loss fp32) -- rim_block.py:230-246, conv_layers.py:121-123, rnn_cells.py:384-391 and their autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from tests._util import rel_l2
+
+pytestmark = pytest.mark.gpu
+bf = oracle.amp.bf16_round
+
+
+def _flips(got, ref, ulps=1.01):
+    """Fraction of elements further than one bf16 ulp from the reference (a bf16 result of an fp32 sum may round the other way)."""
+    g, r = got.double().cpu(), ref.double()
+    tol = ulps * 2.0 ** -8 * r.abs().clamp_min(1e-30) + 1e-30
+    return float(((g - r).abs() > tol).double().mean())
+
+
+def test_pair_tensors_are_bf16_round_to_nearest_even(dev):
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 6, 5, 7, generator=g) * torch.logspace(-3, 3, 6).view(1, 6, 1, 1)
+    p = ops.f32_to_pairs(x.to(dev))
+    assert p.dtype == torch.int32 and tuple(p.shape) == (2, 3, 5, 7)
+    assert torch.equal(ops.pairs_to_f32(p).cpu(), bf(x))
+    lo = (p.cpu() & 0xffff).to(torch.int32)
+    assert torch.equal((lo << 16).view(torch.float32), bf(x)[:, 0::2])
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 5, 19, 45), (2, 64, 3, 21, 40), (1, 4, 5, 8, 32)], ids=lambda s: f"B{s[0]}_cin{s[1]}_k{s[2]}_{s[3]}x{s[4]}")
+@pytest.mark.parametrize("with_state", [False, True])
+def test_training_layer_forward_rounds_where_autocast_rounds(dev, shape, with_state):
+    from mridc_amd import ops
+    B, Cin, k, H, W = shape
+    dil = 1 if k == 5 else 2
+    g = torch.Generator().manual_seed(B * 100 + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    cw, cb = torch.randn(64, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5, torch.randn(64, generator=g) * 0.1
+    w_ih, b_ih, hh = torch.randn(64, 64, 1, 1, generator=g) / 8, torch.randn(64, generator=g) * 0.1, torch.randn(1, 64, 1, 1, generator=g) * 0.5
+    w_fin = torch.randn(2, 64, 3, 3, generator=g) / 24 if Cin == 64 else None
+    hp = torch.randn(B, 64, H, W, generator=g) if with_state else None
+    pad = dil * (k - 1) // 2
+    xp = F.pad(bf(x).double(), (pad,) * 4, mode="replicate")
+    a = F.relu(bf((F.conv2d(xp, bf(cw).double(), None, dilation=dil) + bf(cb).double().view(1, -1, 1, 1)).float()))
+    u = bf((F.conv2d(a.double(), bf(w_ih).double()) + bf(b_ih).double().view(1, -1, 1, 1)).float())
+    h = F.relu(u + (hh * hp if with_state else 0.0))
+    d = lambda t: None if t is None else t.to(dev)  # noqa: E731
+    a_p, h_g, taps = ops.tl_layer_fwd(d(x), d(cw), d(cb), d(w_ih), d(b_ih), d(hh), d(hp), d(w_fin))
+    a_g = ops.pairs_to_f32(a_p)
+    assert _flips(a_g, a) <= 2e-3 and rel_l2(a_g, a) <= 2e-3, (_flips(a_g, a), rel_l2(a_g, a))
+    assert rel_l2(h_g, h) <= 3e-3, rel_l2(h_g, h)
+    # given ITS OWN a, the cell stage is exact up to the order of the fp32 sums
+    u2 = bf((F.conv2d(a_g.cpu().double(), bf(w_ih).double()) + bf(b_ih).double().view(1, -1, 1, 1)).float())
+    h2 = F.relu(u2 + (hh * hp if with_state else 0.0))
+    assert _flips(h_g, h2, 1.0) <= 2e-3 and rel_l2(h_g, h2) <= 1e-3
+    if w_fin is not None:
+        eta = torch.randn(B, H, W, 2, generator=g)
+        hb = F.pad(bf(h_g.cpu()).double(), (1,) * 4, mode="replicate")
+        want = eta + bf(F.conv2d(hb, bf(w_fin).double()).float()).permute(0, 2, 3, 1)
+        got = ops.tl_final_gather(taps, eta.to(dev))
+        assert rel_l2(got, want) <= 1e-3, rel_l2(got, want)
+    else:
+        assert taps is None
+
+
+@pytest.mark.parametrize("variant", ["full", "no_carry", "first_step"])
+def test_cell_backward_in_one_pass(dev, variant):
+    """mrx_tl_cell_bwd + mrx_tl_cell_reduce against the written-out backward of rnn_cells.py:390 / conv_layers.py:123 under autocast."""
+    from mridc_amd import ops
+    B, H, W = 2, 19, 45
+    g = torch.Generator().manual_seed(11)
+    dh = bf(torch.randn(B, 64, H, W, generator=g))
+    dH = torch.randn(B, 64, H, W, generator=g) if variant != "no_carry" else None
+    h = F.relu(torch.randn(B, 64, H, W, generator=g))
+    hp = torch.randn(B, 64, H, W, generator=g) if variant != "first_step" else None
+    a = bf(F.relu(torch.randn(B, 64, H, W, generator=g)))
+    w_ih, hh = torch.randn(64, 64, 1, 1, generator=g) / 8, torch.randn(1, 64, 1, 1, generator=g) * 0.5
+    up = dh + (dH if dH is not None else 0.0)
+    gq = torch.where(h > 0, up, torch.zeros(()))
+    gb = bf(gq)
+    da = bf(F.conv_transpose2d(gb.double(), bf(w_ih).double()).float())
+    ga = torch.where(a > 0, da, torch.zeros(()))
+    want = dict(dw=torch.einsum("bohw,bihw->oi", gb.double(), a.double()), dbih=gb.double().sum((0, 2, 3)),
+                dhh=(gq.double() * hp.double()).sum((0, 2, 3)) if hp is not None else torch.zeros(64, dtype=torch.float64), db=ga.double().sum((0, 2, 3)))
+    d = lambda t: None if t is None else t.to(dev)  # noqa: E731
+    part = ops.tl_cell_part(B, H, W, dev)
+    part.fill_(float("nan"))                               # `first` must overwrite the slots
+    dhp, ga_p = ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(dH), d(h), d(hp), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, True)
+    ga_g = ops.pairs_to_f32(ga_p)
+    assert _flips(ga_g, ga) <= 2e-3 and rel_l2(ga_g, ga) <= 2e-3, (_flips(ga_g, ga), rel_l2(ga_g, ga))
+    if hp is not None:
+        assert rel_l2(dhp, gq * hh) <= 1e-6
+    else:
+        assert dhp is None
+    ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(dH), d(h), d(hp), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, False)   # second time-step: adds
+    dw, dbih, dhh, db = (torch.full(s, 1.0, device=dev) for s in ((64, 64, 1, 1), (64,), (64,), (64,)))
+    ops.tl_cell_reduce(part, B, H, W, dw, dbih, dhh, db)
+    assert rel_l2(dw.reshape(64, 64).cpu().double() - 1.0, 2 * want["dw"]) <= 1e-5
+    assert rel_l2(dbih.cpu().double() - 1.0, 2 * want["dbih"]) <= 1e-5
+    if hp is not None:
+        assert rel_l2(dhh.cpu().double() - 1.0, 2 * want["dhh"]) <= 1e-5
+    else:
+        assert float((dhh - 1.0).abs().max()) == 0.0
+    assert rel_l2(db.cpu().double() - 1.0, 2 * want["db"]) <= 2e-3        # sums of the kernel's own bf16 ga (rounding flips against the reference's)
+    assert rel_l2(db.cpu().double() - 1.0, 2 * ga_g.cpu().double().sum((0, 2, 3))) <= 1e-5
+
+
+@pytest.mark.parametrize("case", [(64, 64, 3, 2, True, True), (64, 2, 3, 1, False, True), (4, 64, 5, 1, True, False)], ids=lambda c: f"{c[0]}to{c[1]}_k{c[2]}d{c[3]}")
+def test_data_gradient_with_bf16_results(dev, case):
+    """mrx_tl_dgrad + mrx_tl_fold_edges: the data gradient of a replicate-padded convolution on bf16 operands, rounded to bf16 (pair tensor or
+    fp32 holding bf16 values), against float64 autograd."""
+    from mridc_amd import ops
+    Cin, Cout, k, dil, pairs_in, pairs_out = case
+    B, H, W = 2, 19, 45
+    g = torch.Generator().manual_seed(Cin + Cout)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    dy = bf(torch.randn(B, Cout, H, W, generator=g))
+    pad = dil * (k - 1) // 2
+    x = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(F.pad(x, (pad,) * 4, mode="replicate"), bf(w).double(), dilation=dil).backward(dy.double())
+    want = x.grad
+    dyg = ops.f32_to_pairs(dy.to(dev)) if pairs_in else dy.to(dev)
+    got = ops.tl_dgrad(dyg, w.to(dev), dil, pairs_out)
+    got = ops.pairs_to_f32(got) if pairs_out else got
+    assert tuple(got.shape) == (B, Cin, H, W)
+    assert torch.equal(bf(got.cpu()), got.cpu())                     # bf16 values
+    assert rel_l2(got, want) <= 3e-3 and _flips(got, bf(want.float()), 2.0) <= 5e-3, (rel_l2(got, want), _flips(got, bf(want.float()), 2.0))
+
+
+@pytest.mark.parametrize("case", [(64, 3, 2), (4, 5, 1)], ids=lambda c: f"cin{c[0]}_k{c[1]}d{c[2]}")
+def test_weight_gradient_from_a_pair_tensor(dev, case):
+    """mrx_conv_wgrad_bf16_pairs = mrx_conv_wgrad_bf16_any on the same bf16 values: bit-identical, and against float64."""
+    from mridc_amd import ops
+    Cin, k, dil = case
+    B, H, W = 1, 21, 44
+    g = torch.Generator().manual_seed(Cin)
+    x, dy = torch.randn(B, Cin, H, W, generator=g), bf(torch.randn(B, 64, H, W, generator=g))
+    dyp = ops.f32_to_pairs(dy.to(dev))
+    got = ops.conv_wgrad_bf16_pairs(x.to(dev), dyp, k, dil, ops.PAD_REPLICATE)
+    same = ops.conv_wgrad_bf16(x.to(dev), dy.to(dev), k, dil, ops.PAD_REPLICATE)
+    assert torch.equal(got, same)
+    pad = dil * (k - 1) // 2
+    w = torch.zeros(64, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(F.pad(bf(x).double(), (pad,) * 4, mode="replicate"), w, dilation=dil).backward(dy.double())
+    assert rel_l2(got, w.grad) <= 1e-5
+    acc = torch.ones_like(got)
+    ops.conv_wgrad_bf16_pairs(x.to(dev), dyp, k, dil, ops.PAD_REPLICATE, out=acc, accumulate=True)
+    assert rel_l2(acc.cpu().double() - 1.0, w.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("seed,boost", [(0, 1.0), (5, 3.0)])
+def test_bf16_storage_tape_against_the_three_oracle_arithmetics(dev, seed, boost):
+    """The whole tape (training.cirim_forward_backward, 'bf16') on a 2-cascade CIRIM at 4 x 48 x 40 against oracle/amp.py: the kernels' own arithmetic
+    (operand AND result rounding restated on the CPU: tight), torch.autocast (the reference's semantics: differs by autocast's bf16 accumulation of
+    weight gradients over the time-steps) and the fp32 oracle (loose: what bf16 costs)."""
+    from mridc_amd import autograd as ag
+    from mridc_amd import synthetic, training
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    from tests._util import detie_l1_target
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=2)
+    torch.manual_seed(seed)
+    model = CIRIM(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if boost != 1.0 and (n_.endswith("rnn.ih.weight") or n_.endswith("rnn.hh")):
+                p_.mul_(boost)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    s = synthetic.make_slice(4, 48, 40, slice_idx=2)
+    with torch.no_grad():
+        s["target"] = detie_l1_target(s["target"], oracle.models.cirim_forward(state, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"]), 3e-3)
+    refs = {m: oracle.amp.cirim_loss_and_gradients(state, cfg, s, mode, round_results=rr)
+            for m, mode, rr in (("kernels", "bf16_operands", True), ("autocast", "autocast_bf16", False), ("fp32", "fp32", False))}
+    model = model.to(dev).train()
+    batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
+    assert training._tape_supported(model, batch) and all(training._tl_supported(b) for b in model.cirim)
+    ag.set_precision("bf16")
+    try:
+        loss = training.cirim_forward_backward(model, batch, "bf16")
+    finally:
+        ag.set_precision("f32")
+    names = [n for n, _ in model.named_parameters() if not n.endswith("dc_weight")]
+    got = torch.cat([dict(model.named_parameters())[n].grad.detach().cpu().reshape(-1).double() for n in names])
+    err = {}
+    for m, (ref_loss, grads) in refs.items():
+        want = torch.cat([grads[n].reshape(-1).double() for n in names])
+        err[m] = (float((got - want).norm() / want.norm()), abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
+    print("bf16-storage tape vs oracle arithmetics (whole gradient, loss):", err)
+    assert err["kernels"][0] <= 5e-3 and err["kernels"][1] <= 2e-4, err
+    assert err["autocast"][0] <= 3e-2 and err["autocast"][1] <= 2e-3, err
+    assert err["fp32"][0] <= 1e-1 and err["fp32"][1] <= 2e-2, err

@@ -163,10 +163,10 @@ def test_default_paths_are_the_fused_ones():
     assert ops.rim_layer1_inplace_ok(4, 64, 5, 1) and not ops.rim_layer1_inplace_ok(4, 64, 3, 1)
 
 
-def test_fft_objects_contain_no_packed_fp32_instructions(tmp_path):
-    """DESIGN.md 5, "Concurrent streams": the FFT kernels must not issue packed-fp32 vector instructions (on MI355X they return wrong results
-    while a foreign wave on the same SIMD issues XDL MFMAs).  Guards the build flags: disassembles the device code of the built fft / llg372
-    objects and counts v_pk_{add,mul,fma}_f32."""
+def test_no_object_of_the_library_contains_packed_fp32_instructions(tmp_path):
+    """DESIGN.md 5, "Concurrent streams": no kernel of the library may issue packed-fp32 vector instructions -- on MI355X v_pk_*_f32 with operand
+    modifiers returns wrong results while a foreign wave on the same SIMD issues v_mfma_f32_16x16x32_f16 (tools/probe/pk_mfma_repro.hip reproduces it
+    without the library).  Guards the build flags: disassembles the device code of EVERY built object and counts v_pk_{add,mul,fma}_f32."""
     import os
     import shutil
     import subprocess
@@ -175,7 +175,9 @@ def test_fft_objects_contain_no_packed_fp32_instructions(tmp_path):
     if not os.path.exists(objdump):
         pytest.skip("no llvm-objdump in this image")
     _build.build()
-    for name in ("fft", "llg372", "elementwise", "qmri"):
+    names = [os.path.splitext(n)[0] for n, _ in _build.SOURCES if n.endswith(".hip") and os.path.exists(os.path.join(_build.CSRC, n))]
+    assert len(names) >= 18 and "fft" in names and "rim_layer2_sb" in names and "unet_fused" in names
+    for name in names:
         src = os.path.join(_build.LIBDIR, name + ".o")
         assert os.path.exists(src), src
         obj = shutil.copy(src, str(tmp_path / (name + ".o")))
