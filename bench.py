@@ -71,11 +71,15 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="headline only: skip the short E2EVN-6 / qCIRIM / bf16-training runs and the exact-route child that the default N = 1 "
                          "run adds to its line as `other_configs` / `exact_fp32_route`")
-    ap.add_argument("--stream-inputs", action="store_true",
-                    help="also time the headline with a NEW (y, S, mask) per slice streamed from pinned host memory on a copy stream while the "
-                         "previous slice reconstructs (models/base.py:638-713: the reference feeds every slice through a DataLoader)")
+    ap.add_argument("--stream-inputs", action="store_true", help=argparse.SUPPRESS)      # (the default since round 4; kept so old command lines parse)
+    ap.add_argument("--no-stream-inputs", action="store_true",
+                    help="skip the second headline figure `streamed_inputs`: a NEW (y, S, mask) per slice streamed from pinned host memory on a copy "
+                         "stream while the previous slice reconstructs (models/base.py:638-713: the reference feeds every slice through a DataLoader)")
+    ap.add_argument("--cpu-slices", type=int, default=3,
+                    help="timed slices of the CPU-baseline leg after its warm-up (BASELINE.md section 3: >= 3; mean and min are reported)")
     ap.add_argument("--dist-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    args.stream_inputs = not args.no_stream_inputs
     if args.streams <= 0:
         args.streams = 2
     if args.batch <= 0:
@@ -213,10 +217,11 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cfg, state_dict, data, n_cascades):
+def cpu_baseline(cfg, state_dict, data, n_cascades, n_slices=1):
     """Time the oracle (CPU restatement of the reference path, torch CPU ops) on the same slice the GPU reconstructed, per BASELINE.md
-    section 3: one untimed warm-up cascade, then `n_cascades` cascades timed one by one (all of them by default = one whole slice),
-    plus the FFT+DC step on its own.  Returns (cpu_baseline dict, the oracle's list[cascade][time_step] output)."""
+    section 3: one untimed warm-up cascade, then `n_slices` slices of `n_cascades` cascades each, timed cascade by cascade (all cascades by
+    default = whole slices; mean and min over the slices are reported), plus the FFT+DC step on its own.  Returns (cpu_baseline dict, the
+    oracle's list[cascade][time_step] output of the first slice)."""
     import oracle
     # the reference's CPU path is torch intra-op threading; beyond ~32 threads these op sizes slow down (measured: 256 threads on the
     # GPU box's host ran 36x slower than 8), so the pool is capped; both numbers are reported
@@ -230,6 +235,11 @@ def cpu_baseline(cfg, state_dict, data, n_cascades):
         stamps = [time.perf_counter()]
         ref = oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=n_cascades), y, S, mask, None, target,
                                           cascade_stamps=stamps)
+        slice_s = [stamps[-1] - stamps[0]]
+        for _ in range(max(n_slices, 1) - 1):                # further timed slices (the cost does not depend on the data: the same arrays again)
+            t0 = time.perf_counter()
+            oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=n_cascades), y, S, mask, None, target)
+            slice_s.append(time.perf_counter() - t0)
         eta = torch.zeros(1, y.shape[2], y.shape[3], 2)
         oracle.rim.log_likelihood_gradient(eta, y, S, mask, 1.0, cfg["fft_centered"], cfg["fft_normalization"], cfg["spatial_dims"],
                                            cfg["coil_dim"])
@@ -240,15 +250,17 @@ def cpu_baseline(cfg, state_dict, data, n_cascades):
         llg_s = (time.perf_counter() - t0) / 3
     per = [b_ - a_ for a_, b_ in zip(stamps[:-1], stamps[1:])]
     dt = sum(per)
-    sec_per_slice = dt * cfg["num_cascades"] / n_cascades
+    sec_per_slice = (sum(slice_s) / len(slice_s)) * cfg["num_cascades"] / n_cascades
     step_s = dt / (n_cascades * T_)
     whole = n_cascades == cfg["num_cascades"]
     return dict(value=1.0 / sec_per_slice, unit="slices/s", cores=ncores, kind="port", box_cores=box_cores, cpu_model=cpu_model_name(),
+                slices_timed=len(slice_s), sec_per_slice=[t * cfg["num_cascades"] / n_cascades for t in slice_s],
+                sec_per_slice_mean=sec_per_slice, sec_per_slice_min=min(slice_s) * cfg["num_cascades"] / n_cascades,
                 sec_per_cascade_mean=dt / n_cascades, sec_per_cascade_min=min(per), sec_per_cascade=per,
                 split_ms_per_rim_step=dict(fft_dc=1e3 * llg_s, regulariser=1e3 * max(step_s - llg_s, 0.0)),
-                sample=(f"after one untimed warm-up cascade: {n_cascades} of {cfg['num_cascades']} cascades ({n_cascades * T_} of "
-                        f"{cfg['num_cascades'] * T_} RIM steps) of one slice on the oracle (torch CPU ops, {ncores} threads of the box's "
-                        f"{box_cores}), timed per cascade, {dt:.1f} s in all"
+                sample=(f"after one untimed warm-up cascade: {len(slice_s)} slice(s) of {n_cascades} of {cfg['num_cascades']} cascades ({n_cascades * T_} of "
+                        f"{cfg['num_cascades'] * T_} RIM steps) each on the oracle (torch CPU ops, {ncores} threads of the box's "
+                        f"{box_cores}), value = 1 / mean seconds per slice, {sum(slice_s):.1f} s in all"
                         + ("" if whole else f", extrapolated x{cfg['num_cascades'] / n_cascades:g}"))), ref
 
 
@@ -720,17 +732,45 @@ def bench_train(args, world, rank, dev, checks=False):
             for q_ in model1.parameters():
                 q_.grad = None
             l1 = training.cirim_forward_backward(model1, batch, args.dtype)
-            got = torch.cat([q_.grad.detach().cpu().reshape(-1).double() for n_, q_ in model1.named_parameters() if not n_.endswith("dc_weight")])
-            want = torch.cat([prm[n_].grad.reshape(-1).double() for n_, q_ in model1.named_parameters() if not n_.endswith("dc_weight")])
-            res["parity_vs_oracle"] = dict(rel_l2=float((got - want).norm() / want.norm()), loss_rel=abs(float(l1) - float(ref_loss.detach())) / abs(float(ref_loss.detach())),
-                                           at=f"whole gradient vector ({got.numel()} parameters) and loss of one cascade (8 time-steps) at {C} x {H} x {W}, "
-                                              f"{args.dtype} operands, against torch autograd of the oracle",
-                                           tolerance="tests/test_gpu_headline.py::test_one_cascade_training_at_headline_size: f32 2e-3 per parameter tensor, bf16 5e-2 whole vector on its own weights (bf16 operand rounding through 8 recurrent steps: 3e-2 .. 6e-2 depending on the weights)")
+            names = [n_ for n_, _ in model1.named_parameters() if not n_.endswith("dc_weight")]
+            got = torch.cat([dict(model1.named_parameters())[n_].grad.detach().cpu().reshape(-1).double() for n_ in names])
+            # the checkers (oracle/amp.py): fp32 autograd above; for bf16 also the reference's AMP arithmetic as torch.autocast, and the kernels' own
+            # arithmetic (bf16 operands and bf16 results restated on the CPU): the tight one -- it differs from the kernels by the order of fp32 sums only
+            checks_ = {"fp32": (ref_loss.detach(), {k_: v_.grad for k_, v_ in prm.items() if v_.grad is not None})}
+            if args.dtype == "bf16":
+                checks_["autocast_bf16"] = oracle.amp.cirim_loss_and_gradients(state1, cfg1, host, "autocast_bf16")
+                emul = dict(round_results=True) if training.BF16_STORAGE else dict(fp32_forward=((64, 2),))
+                checks_["kernel_arithmetic"] = oracle.amp.cirim_loss_and_gradients(state1, cfg1, host, "bf16_operands", **emul)
+            errs = {}
+            for m_, (rl_, gr_) in checks_.items():
+                want = torch.cat([gr_[n_].reshape(-1).double() for n_ in names])
+                errs[m_] = dict(rel_l2=float((got - want).norm() / want.norm()), loss_rel=abs(float(l1) - float(rl_)) / abs(float(rl_)))
+            flat_ = {m_: torch.cat([gr_[n_].reshape(-1).double() for n_ in names]) for m_, (_, gr_) in checks_.items()}
+            ms_ = list(flat_)
+            oracle_vs_oracle = {f"{a_}_vs_{b_}": float((flat_[a_] - flat_[b_]).norm() / flat_[b_].norm()) for i_, a_ in enumerate(ms_) for b_ in ms_[i_ + 1:]}
+            tight = "kernel_arithmetic" if args.dtype == "bf16" else "fp32"
+            tol = TRAIN_TOL[args.dtype]
+            res["parity_vs_oracle"] = dict(rel_l2=errs[tight]["rel_l2"], loss_rel=errs[tight]["loss_rel"], against=tight, all=errs, tolerance=tol, oracle_vs_oracle=oracle_vs_oracle,
+                                           within_tolerance=all(errs[m_]["rel_l2"] <= tol[m_] for m_ in errs),
+                                           at=f"whole gradient vector ({got.numel()} parameters) and loss of one cascade (8 time-steps) at {C} x {H} x {W}, {args.dtype}: "
+                                              "HIP tape against torch autograd of the oracle in each arithmetic of oracle/amp.py (fp32; autocast_bf16 = the reference's "
+                                              "`precision: 16` semantics on the CPU; kernel_arithmetic = bf16 operands and bf16 convolution results, fp32 sums: what the "
+                                              "kernels compute); the same tolerances are asserted by tests/test_gpu_headline.py::test_one_cascade_training_at_headline_size "
+                                              "on two sets of weights")
         except Exception as ex:  # noqa: BLE001
             res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port", sample=f"failed: {type(ex).__name__}: {ex}")
     return res
 
 
+# Whole-gradient rel-L2 of the training tape against each oracle arithmetic (oracle/amp.py), met by the bench's seed-0 weights AND the tests' weights:
+#   kernel_arithmetic -- the kernels' own rounding points restated on the CPU.  Results that are ROUNDED to bf16 make the gradient discontinuous in the
+#                        order of the fp32 sums (a flipped rounding moves a ReLU mask): two CPU restatements of this very arithmetic that differ only in
+#                        accumulating in fp32 or fp64 are 5e-3 apart on the bench's weights, in exactly the parameters where the kernels deviate
+#                        (profiles/r04_training_parity_notes.md), so this cannot be held tighter than 3e-2 at 15 x 640 x 372; what IS exact up to
+#                        rounding flips is every kernel on its own (tests/test_gpu_train_bf16.py) and the fp32 tape (1e-5 here);
+#   autocast_bf16     -- torch.autocast on the host CPU (the reference's semantics; also accumulates a weight's gradient over the time-steps in bf16);
+#   fp32              -- what bf16 costs (the autocast oracle itself sits 1e-2 .. 8e-2 from the fp32 one).
+TRAIN_TOL = dict(f32=dict(fp32=2e-3), bf16=dict(kernel_arithmetic=3e-2, autocast_bf16=5e-2, fp32=1e-1))
 _RESULT = []
 
 
@@ -812,7 +852,7 @@ def exact_route_line(args):
     error O(2^-24): the route the two-term fp16 default is judged against).  A child because the route is chosen once per process."""
     import subprocess
     env = dict(os.environ, MRIDC_AMD_ARITH="bf16x3")
-    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--steps", "6", "--warmup", "2",
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--no-stream-inputs", "--steps", "6", "--warmup", "2",
            "--coils", str(args.coils), "--height", str(args.height), "--width", str(args.width), "--mask", args.mask]
     try:
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -821,6 +861,23 @@ def exact_route_line(args):
         return dict(value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"], breakdown_ms=r.get("breakdown_ms"),
                     arith="three bf16 terms per fp32 operand, six term products per multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation "
                           "(MRIDC_AMD_ARITH=bf16x3)", steps=r["steps"])
+    except Exception as ex:  # noqa: BLE001
+        return dict(value=None, error=f"{type(ex).__name__}: {ex}")
+
+
+def mask2d_line(args):
+    """The headline with a row-dependent (2-D) sampling mask -- the family of the reference's default CIRIM configuration (Poisson-2D,
+    base_cirim_run.yaml:84-90): the data-consistency gradient is then the three-pass kernel chain.  A child process (a fresh model, no state shared
+    with the 1-D run); its own roofline_fft record rides along."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--no-stream-inputs", "--steps", "8", "--warmup", "2",
+           "--coils", str(args.coils), "--height", str(args.height), "--width", str(args.width), "--mask", "2d"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        return dict(metric=r["metric"] + ", 2-D mask", value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"], steps=r["steps"], warmup=r["warmup"],
+                    config=r.get("config"), breakdown_ms=r.get("breakdown_ms"), roofline=r.get("roofline_fft"),
+                    concurrent_replays_bit_identical_to_serial=r.get("concurrent_replays_bit_identical_to_serial"))
     except Exception as ex:  # noqa: BLE001
         return dict(value=None, error=f"{type(ex).__name__}: {ex}")
 
@@ -1217,7 +1274,7 @@ def main():
             n_cpu = args.cpu_cascades if 0 < args.cpu_cascades <= cfg["num_cascades"] else cfg["num_cascades"]
             try:
                 host1 = {k: v[:1] if k != "mask" else v for k, v in host.items()}
-                cb, ref = cpu_baseline(cfg, state_dict, host1, n_cpu)
+                cb, ref = cpu_baseline(cfg, state_dict, host1, n_cpu, args.cpu_slices)
                 res["cpu_baseline"] = cb
                 res["parity_vs_oracle"] = parity_vs_oracle(out[n_cpu - 1][-1][0:1], ref[n_cpu - 1][-1][0:1], host1["target"],
                                                            at=f"cascade {n_cpu} of {cfg['num_cascades']}, last time-step"
@@ -1248,6 +1305,8 @@ def main():
                 torch.cuda.empty_cache()
             from mridc_amd import autograd as ag_
             ag_.set_precision("f32")
+            if args.mask == "1d":
+                others["cirim_2d_mask_15coil_640x372"] = mask2d_line(args)
             res["other_configs"] = others
         emit(res)
     if use_dist:

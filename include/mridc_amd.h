@@ -188,7 +188,8 @@ int mrx_llg_cols_dc(float* work, const float* y, const void* mask, int mask_kind
  *   mrx_tile4_cols          x [nimg,H,W,2] -> [nimg][W/4][H][4] complex (the measured data, once per slice; W % 4 == 0)
  *   mrx_pfa372_expand_t4    out_t4 = FFT_W(x * S) in the tiled layout
  *   mrx_llg_cols_dc_t4      FFT_H -> mask * (k - y) -> IFFT_H in place on work_t4 (y_t4 tiled; mask indexed [b,c,h,w] as everywhere);
- *                           mrx_llg_cols_dc_t4_supported(H, W): H <= 2048 and W % 4 == 0
+ *                           y_t4 == NULL: mask * k only -- the gradient is linear in (k - y), the caller adds the constant -A^H M y of the
+ *                           slice as one more partial plane; mrx_llg_cols_dc_t4_supported(H, W): H <= 2048 and W % 4 == 0
  *   mrx_pfa372_reduce_t4    post * sum_c conj(S) IFFT_W(k_t4): out4 [B,4,H,372] = (eta, that), or with nparts != NULL the coil-group partial
  *                           sums left in work ([*nparts][B,H,372,2]) for mrx_rim_layer_indrnn_packed_llg; work: mrx_llg372_work_floats */
 int mrx_tile4_cols(const float* x, float* out, int64_t nimg, int H, int W, void* stream);
@@ -522,6 +523,10 @@ int mrx_tl_dgrad(const void* dy, int dy_pairs, const void* packed, void* dx, int
 int mrx_tl_fold_edges(const float* frame, void* dx, int dx_pairs, int B, int C, int H, int W, int pad, void* stream);
 int mrx_tl_pairs_to_f32(const void* pairs, float* out, int64_t pair_planes, int64_t plane, void* stream);
 int mrx_tl_f32_to_pairs(const float* x, void* pairs, int64_t pair_planes, int64_t plane, void* stream);
+/*   mrx_tl_wgrad_in      the first layer's weight gradient (5x5, Cin <= 5 -> 64, replicate padding) with dy a pair tensor: one column block of
+ *                        (ci, tap) per wave; work: mrx_tl_wgrad_in_work_floats floats */
+int64_t mrx_tl_wgrad_in_work_floats(int B, int Cin, int H, int W);
+int mrx_tl_wgrad_in(const float* x, const void* dy_pairs, float* dw, float* work, int B, int Cin, int H, int W, int accumulate, void* stream);
 int mrx_conv_wgrad_bf16_pairs(const float* x, const void* dy_pairs, float* dw, float* work, int B, int Cin, int H, int W, int k, int dil, int pad_mode,
                               int accumulate, void* stream);
 

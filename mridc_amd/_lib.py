@@ -88,6 +88,8 @@ _SIGNATURES = {
     "mrx_tl_final_gather": ([_p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_tl_pairs_to_f32": ([_p, _p, _i64, _i64, _p], _i),
     "mrx_tl_f32_to_pairs": ([_p, _p, _i64, _i64, _p], _i),
+    "mrx_tl_wgrad_in_work_floats": ([_i, _i, _i, _i], _i64),
+    "mrx_tl_wgrad_in": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_conv_wgrad_bf16_pairs": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_relu_bwd_acc": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_eta_grad_in": ([_p, _p, _p, _p, _i, _i64, _p], _i),

@@ -147,9 +147,37 @@ class ComplexNormWrapper(torch.nn.Module):
 
     def forward(self, input):
         norm = self.complex_instance_norm
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.model.parameters())):
+            return self._forward_recorded(input)           # the kernels below write raw buffers: their outputs carry no grad_fn
         norm.set_normalization(input)
         channel_first, shape = norm._channel_first(input)
         return norm._from_channel_first(self.model(channel_first), shape)
+
+    def _forward_recorded(self, input):
+        """The same map in torch device arithmetic, recorded by autograd (gradients flow through the regulariser AND through the measured covariance,
+        as in the reference, whose mean is a detached scalar: sensitivity_net.py:87): C^(1/2) in the closed form of csrc/cnorm.hip,
+        (C + sqrt(det C) I) / sqrt(tr C + 2 sqrt(det C)).  Used whenever gradients are being recorded -- the stage-wise training helpers of
+        SensitivityNetwork need it; inference (no_grad) takes the kernels."""
+        if input.dim() != 5 or input.shape[-1] != 2:
+            raise NotImplementedError("ComplexNormWrapper with gradients: [B,C,H,W,2] input")
+        x = input.float()
+        B, C, H, W = (int(v) for v in x.shape[:4])
+        mean = x.mean().detach()
+        re, im = (x - mean).unbind(-1)
+        n1 = float(H * W - 1)                                # the reference's divisor: shape[2] * shape[3] - 1
+        cxx, cyy, cxy = ((re * re).sum((1, 2, 3), keepdim=True) / n1, (im * im).sum((1, 2, 3), keepdim=True) / n1,
+                         (re * im).sum((1, 2, 3), keepdim=True) / n1)
+        s_ = torch.sqrt(torch.clamp(cxx * cyy - cxy * cxy, min=0.0))
+        t_ = torch.sqrt(cxx + cyy + 2.0 * s_)
+        hxx, hxy, hyy = (cxx + s_) / t_, cxy / t_, (cyy + s_) / t_
+        ixx, ixy, iyx, iyy = matrix_invert(hxx, hxy, hxy, hyy)
+        z = torch.stack([ixx * re + ixy * im, iyx * re + iyy * im], dim=-1).clamp(-6, 6)
+        y = self.model(z.reshape(B * C, H, W, 2).permute(0, 3, 1, 2))
+        y = y.permute(0, 2, 3, 1).reshape(B, C, H, W, 2)
+        yr, yi = y.unbind(-1)
+        norm = self.complex_instance_norm
+        norm.mean, norm.cov_xx_half, norm.cov_xy_half, norm.cov_yx_half, norm.cov_yy_half = mean.reshape(1, 1, 1, 1), hxx, hxy, hxy, hyy
+        return torch.stack([hxx * yr + hxy * yi, hxy * yr + hyy * yi], dim=-1) + mean
 
 
 class SensitivityNetwork(torch.nn.Module):

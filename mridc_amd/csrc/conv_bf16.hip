@@ -116,6 +116,24 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
             *reinterpret_cast<u32x4*>(smem_b + e * PS + cg * 16) = p;
         }
     }
+    // OUT 2: the layer's bias / hh tables into LDS (rounded where autocast rounds them) and this lane's 32 h_prev values requested NOW -- they
+    // arrive under the matrix loop (requested in the epilogue they cost the launch 55 us: two workgroups per CU cannot cover that latency)
+    float* tb = reinterpret_cast<float*>(smem_b + (size_t)NPIX * PS);
+    float hpv[OUT == 2 ? 2 : 1][OUT == 2 ? 16 : 1];
+    if (OUT == 2) {
+        if (tid < 64) {
+            tb[tid] = a.bias ? cb_round(a.bias[tid]) : 0.f;
+            tb[64 + tid] = a.ih_bias ? cb_round(a.ih_bias[tid]) : 0.f;
+            tb[128 + tid] = a.hprev ? a.hh[tid] : 0.f;
+        }
+        const int py = h0 + wave < a.H ? h0 + wave : a.H - 1, px = w0 + l31 < a.W ? w0 + l31 : a.W - 1;
+        const unsigned plane4 = (unsigned)plane * 4u, o0 = (unsigned)b * 64u * plane4 + (unsigned)(py * a.W + px) * 4u + 4u * lhi * plane4;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hpv[c2][r] = a.hprev ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.hprev) + o0 + (unsigned)(c2 * 32 + (r & 3) + 8 * (r >> 2)) * plane4) : 0.f;
+    }
     __syncthreads();
 
     // ---- the matrix loop: one 16-byte LDS read (B) and NCT 16-byte L2 reads (A) per MFMA step ---------------------------------------------
@@ -160,8 +178,7 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int r = 2 * q, co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                float v0 = acc[ct][r], v1 = acc[ct][r + 1];
-                if (a.bias) v0 += cb_round(a.bias[co]), v1 += cb_round(a.bias[co + 1]);
+                float v0 = acc[ct][r] + tb[co], v1 = acc[ct][r + 1] + tb[co + 1];
                 v0 = v0 > 0.f ? v0 : 0.f, v1 = v1 > 0.f ? v1 : 0.f;
                 ap[ct][q] = cb_pk(v0, v1);
                 if (inside) a.a_pairs[((long long)b * 32 + (co >> 1)) * plane + pix] = ap[ct][q];
@@ -189,11 +206,9 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = c2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                float v = acc2[c2][r];
-                if (a.ih_bias) v += cb_round(a.ih_bias[co]);
-                v = cb_round(v);
+                float v = cb_round(acc2[c2][r] + tb[64 + co]);
                 const long long o = ((long long)b * 64 + co) * plane + pix;
-                if (a.hprev && inside) v += a.hh[co] * a.hprev[o];
+                v += tb[128 + co] * hpv[c2][r];
                 v = v > 0.f ? v : 0.f;
                 if (inside) a.out[o] = v;
                 acc2[c2][r] = v;
@@ -229,7 +244,8 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
         long long obase = (long long)b * a.Cout * plane + (long long)oy * a.W + ox;
         long long cstride = plane;
         float* dst = a.out;
-        bool to_interior = false;
+        bool to_interior = false, edge = false;
+        const long long fbase = obase;            // this pixel in the frame tensor
         if (a.interior) {
             const int iy = oy - a.ext, ix = ox - a.ext;
             if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
@@ -237,6 +253,9 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
                 cstride = iplane;
                 obase = (long long)b * a.Cout * iplane + (long long)iy * a.Win + ix;
                 to_interior = true;
+                // bf16 results: an edge pixel of the image also receives the frame positions that clamp to it (mrx_tl_fold_edges); it leaves its
+                // UNROUNDED value in the frame tensor too, so that the folded sum is rounded once, like every other element of the gradient
+                edge = (OUT == 1 || a.round_out) && (iy == 0 || iy == a.Hin - 1 || ix == 0 || ix == a.Win - 1);
             }
         }
         if (OUT == 1 && (to_interior || !a.interior)) {      // bf16 result as pairs (the frame of a replicate-padded data gradient stays fp32)
@@ -251,6 +270,7 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
                         if (a.bias) v0 += cb_round(a.bias[co]), v1 += cb_round(a.bias[co + 1]);
                         if (a.act == MRX_ACT_RELU) v0 = v0 > 0.f ? v0 : 0.f, v1 = v1 > 0.f ? v1 : 0.f;
                         dp[(long long)(co >> 1) * cstride] = cb_pk(v0, v1);
+                        if (edge) a.out[fbase + (long long)co * plane] = v0, a.out[fbase + (long long)(co + 1) * plane] = v1;
                     }
                 }
             return;
@@ -268,7 +288,8 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
                         v = v > 0.f ? v : 0.f;
                     else if (a.act == MRX_ACT_LEAKY)
                         v = v > 0.f ? v : v * a.slope;
-                    if (OUT == 1 || a.round_out) v = cb_round(v);          // (the fp32 frame of a pair result holds bf16 values: one rounding per convolution result)
+                    if (edge) a.out[fbase + (long long)co * plane] = v;
+                    if ((OUT == 1 || a.round_out) && (to_interior || !a.interior)) v = cb_round(v);   // (frame positions stay fp32: they are summed, then rounded once)
                     dst[obase + (long long)co * cstride] = v;
                 }
             }
@@ -327,7 +348,7 @@ extern "C" int mrx_conv_bf16_pack(const float* w, void* packed, int Cin, int Cou
 template <int K, int DIL, int CPAD, int NCT, int XP = 0, int OUT = 0>
 static int cb_launch(const ConvBfArgs& a, hipStream_t st) {
     constexpr int PAD = DIL * (K - 1) / 2;
-    constexpr size_t lds = (size_t)(CB_TH + 2 * PAD) * (CB_TW + 2 * PAD) * cb_ps(CPAD);
+    constexpr size_t lds = (size_t)(CB_TH + 2 * PAD) * (CB_TW + 2 * PAD) * cb_ps(CPAD) + (OUT == 2 ? 768 : 0);
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
         MRX_HIP(hipFuncSetAttribute((const void*)k_conv_bf16<K, DIL, CPAD, NCT, XP, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -851,6 +872,16 @@ static int wb_nwg(int B, int H, int W, int k) {
     const long long tiles = (long long)mrx_cdiv(W, WB_TW) * mrx_cdiv(H, wb_th(k)) * B;
     return (int)(tiles < (long long)per_cu * n_cu ? tiles : (long long)per_cu * n_cu);
 }
+// workgroups of the thin 3x3 layer (64 -> <= 32): 63 registers and 52 KB of LDS -- two per CU cover each other's tile loads (one per CU: 76 us at
+// 15 x 640 x 372 for 61 MB)
+static int wb_nwg_any(int B, int Cin, int Cout, int H, int W, int k) {
+    const int n1 = wb_nwg(B, H, W, k);
+    if (k == 3 && Cin == 64 && Cout <= 32) {
+        const long long tiles = (long long)mrx_cdiv(W, WB_TW) * mrx_cdiv(H, 8) * B;
+        return (int)(tiles < 2ll * n1 ? tiles : 2ll * n1);
+    }
+    return n1;
+}
 static bool wb_thin(int Cin, int Cout, int k, int dil) {   // the two thin dilation-1 layers of the RIM
     return dil == 1 && ((k == 3 && Cin == 64 && Cout >= 1 && Cout <= 32) || (k == 5 && Cout == 64 && Cin >= 1 && Cin <= 32));
 }
@@ -876,7 +907,7 @@ static int wb_launch(const WgradBfArgs& a, int nwg, hipStream_t st) {
 }
 extern "C" int64_t mrx_conv_wgrad_bf16_any_work_floats(int B, int Cin, int Cout, int H, int W, int k) {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (k != 1 && k != 3 && k != 5)) return -1;
-    return (int64_t)wb_nwg(B, H, W, k) * Cout * Cin * k * k;
+    return (int64_t)wb_nwg_any(B, Cin, Cout, H, W, k) * Cout * Cin * k * k;
 }
 template <int K, int NCO, int NCI, int TPW, int DYP = 0>
 static int wbg_launch(const WgradBfGArgs& a, int nwg, hipStream_t st) {
@@ -904,7 +935,7 @@ extern "C" int mrx_conv_wgrad_bf16_any(const float* x, const float* dy, float* d
     a.x = x, a.dy = dy, a.part = work, a.B = B, a.Cin = Cin, a.Cout = Cout, a.H = H, a.W = W;
     a.tiles_x = mrx_cdiv(W, WB_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, 8), a.pad_mode = pad_mode;
     a.vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) % 16 == 0);
-    const int nwg = wb_nwg(B, H, W, k);
+    const int nwg = wb_nwg_any(B, Cin, Cout, H, W, k);
     hipStream_t st = (hipStream_t)stream;
     int rc = k == 3 ? wbg_launch<3, 1, 2, 1>(a, nwg, st) : wbg_launch<5, 2, 1, 2>(a, nwg, st);
     if (rc) return rc;

@@ -783,7 +783,7 @@ extern "C" int mrx_eta_grad_out(const float* tot, const float* g4, const float* 
 // |p| exactly as mrx_max_abs forms it (elementwise.hip: two rounded squares, one rounded add, the correctly rounded root), whatever the
 // contraction mode of this file: the backward pass finds the arg-max pixel by `a == M`, so both moduli must agree bit for bit
 __device__ __forceinline__ float absl1_modulus(float2 v) {
-    return (float)sqrt((double)__fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y)));
+    return (float)sqrt((double)mrx_sumsq2(v.x, v.y));
 }
 __global__ __launch_bounds__(LS_NT) void k_absl1_partial(const float2* __restrict__ p, const float* __restrict__ target,
                                                          const float* __restrict__ M, float* __restrict__ work, long long n) {
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(LS_NT) void k_absl1_partial(const float2* __restric
     float s0 = 0.f, s1 = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float2 v = p[i];
-        const float a = absl1_modulus(v), d = a * inv - target[i];
+        const float a = absl1_modulus(v), d = mrx_mul_sub(a, inv, target[i]);
         s0 += fabsf(d);
         s1 += (d > 0.f ? a : (d < 0.f ? -a : 0.f));
     }
@@ -829,7 +829,7 @@ __global__ void k_absl1_bwd(const float2* __restrict__ p, const float* __restric
     const float corr = g * fw[1] * inv * inv;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float2 v = p[i];
-        const float a = absl1_modulus(v), d = a * inv - target[i];
+        const float a = absl1_modulus(v), d = mrx_mul_sub(a, inv, target[i]);
         const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         float c = g * sg * inv;
         if (a == m) c -= corr;

@@ -128,7 +128,7 @@ template <bool SQ>
 __global__ void k_abs(const float2* __restrict__ x, float* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float2 v = x[i];
-        const float s = __fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y));  // (data**2).sum(-1): two rounded squares, one add
+        const float s = mrx_sumsq2(v.x, v.y);  // (data**2).sum(-1): two rounded squares, one add
         out[i] = SQ ? s : sqrt_rn(s);
     }
 }
@@ -165,7 +165,7 @@ __global__ void k_max_abs_partial(const float* __restrict__ x, float* __restrict
             v = fabsf(x[i]);
         } else {
             const float2 c = reinterpret_cast<const float2*>(x)[i];
-            v = sqrt_rn(__fadd_rn(__fmul_rn(c.x, c.x), __fmul_rn(c.y, c.y)));
+            v = sqrt_rn(mrx_sumsq2(c.x, c.y));
         }
         m = nan_max(v, m);
     }
@@ -208,7 +208,7 @@ __global__ void k_div_dev(const float* __restrict__ x, const float* __restrict__
         } else {
             const float2 c = reinterpret_cast<const float2*>(x)[i];
             const float re = c.x / den, im = c.y / den;
-            out[i] = sqrt_rn(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));
+            out[i] = sqrt_rn(mrx_sumsq2(re, im));
         }
     }
 }
@@ -685,7 +685,7 @@ __global__ void k_cg_step(float2* __restrict__ x, float2* __restrict__ r, const 
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
         const long long b = o / n;
         const float re1 = rr[2 * b], im1 = rr[2 * b + 1], re2 = pq[2 * b], im2 = pq[2 * b + 1];
-        const float ab = sqrtf(__fadd_rn(__fmul_rn(re2, re2), __fmul_rn(im2, im2)));
+        const float ab = sqrtf(mrx_sumsq2(re2, im2));
         const float den = __fmul_rn(ab, ab);
         const float ar = __fadd_rn(__fmul_rn(re1, re2), __fmul_rn(im1, im2)) / den;
         const float ai = __fsub_rn(__fmul_rn(im1, re2), __fmul_rn(re1, im2)) / den;

@@ -397,7 +397,10 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc(const float2* in, const 
 // (Measured and not kept: two tiles per workgroup with the next tile's input and the measured data prefetched into registers -- 34.7 us
 // against 29.4 us for this form at 15 x 640 x 372: the pass is bound by the LDS butterflies of its eight stages, not by its loads, and
 // 1395 short workgroups fill the stage bubbles of one another better than 698 long ones.)
-template <class P>
+// NOY: the measured data left out -- IFFT_H(m FFT_H(x)).  By linearity the gradient is A^H M A eta - A^H M y, and the second term is one constant
+// image per slice that the caller keeps as one more partial plane for the first RIM layer's loader (ops.llg, parts form): the pass reads
+// 28.6 MB less per step at 15 x 640 x 372.
+template <class P, bool NOY = false>
 __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc_t4(const float4* in, const float4* __restrict__ y4, MrxMask mask, float4* out,
                                                            ColArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc_t4(const float4* in, con
         const int p = idx >> 1, hf = idx & 1;
         const int hk = shifted(p, a.halfH, H);
         const float4 k = reinterpret_cast<float4*>(res)[idx];
-        const float4 yv = ysrc[hk * 2 + hf];
+        const float4 yv = NOY ? make_float4(0.f, 0.f, 0.f, 0.f) : ysrc[hk * 2 + hf];
         const int w = w0 + 2 * hf;
         const float m0 = mrx_mask_val(mask, b, c_, hk, w), m1 = mrx_mask_val(mask, b, c_, hk, w + 1);
         reinterpret_cast<float4*>(res)[idx] = make_float4(m0 * (k.x * a.scale - yv.x), m0 * (k.y * a.scale - yv.y),   // rim_utils.py:54
@@ -1665,7 +1668,7 @@ extern "C" int mrx_llg_cols_dc(float* work, const float* y, const void* mask, in
 // mrx_llg_cols_dc on the column-tiled coil stack (see k_cols_dc_t4): work_t4 and y_t4 are [B*C][W/4][H][4] complex, in place on work_t4.
 extern "C" int mrx_llg_cols_dc_t4(float* work_t4, const float* y_t4, const void* mask, int mask_kind, const int64_t* mstride, int B, int C,
                                   int H, int W, int norm, int centered, void* stream) {
-    MRX_REQUIRE(work_t4 && y_t4 && mask && mstride, MRX_EINVAL, "mrx_llg_cols_dc_t4: null pointer");
+    MRX_REQUIRE(work_t4 && mask && mstride, MRX_EINVAL, "mrx_llg_cols_dc_t4: null pointer");   // y_t4 null: the pass without the measured data
     MRX_REQUIRE(B >= 0 && C >= 1 && H >= 1 && W >= 4 && W % 4 == 0, MRX_EINVAL, "mrx_llg_cols_dc_t4: bad dims (W must be a multiple of 4)");
     MRX_REQUIRE(norm_valid(norm), MRX_EINVAL, "mrx_llg_cols_dc_t4: bad normalization %d", norm);
     MRX_REQUIRE(mask_kind == MRX_MASK_U8 || mask_kind == MRX_MASK_F32, MRX_EINVAL, "mrx_llg_cols_dc_t4: bad mask kind %d", mask_kind);
@@ -1693,7 +1696,21 @@ extern "C" int mrx_llg_cols_dc_t4(float* work_t4, const float* y_t4, const void*
     // MRX_COLS640=1: the wave-private register form (k_cols640_dc_t4) -- measured 33.8 us against 28.5 us for the workgroup (Stockham) form at
     // 15 x 640 x 372 (1395 single-wave tasks are 1.4 waves per SIMD: every exchange and load latency is exposed), so not the default
     static const int wave640 = (MRX_DEBUG_ENV("MRX_COLS640") && atoi(MRX_DEBUG_ENV("MRX_COLS640")) == 1) ? 1 : 0;
-    if (H == 640 && wave640) {
+    if (!y4) {
+        if (H == 640) {
+            if ((rc = set_lds(k_cols_dc_t4<P640, true>, lds))) return rc;
+            hipLaunchKernelGGL((k_cols_dc_t4<P640, true>), grid, blk, lds, st, in, y4, m, out, a);
+        } else if (H == 320) {
+            if ((rc = set_lds(k_cols_dc_t4<P320, true>, lds))) return rc;
+            hipLaunchKernelGGL((k_cols_dc_t4<P320, true>), grid, blk, lds, st, in, y4, m, out, a);
+        } else if (H == 256) {
+            if ((rc = set_lds(k_cols_dc_t4<P256, true>, lds))) return rc;
+            hipLaunchKernelGGL((k_cols_dc_t4<P256, true>), grid, blk, lds, st, in, y4, m, out, a);
+        } else {
+            if ((rc = set_lds(k_cols_dc_t4<PlanRT, true>, lds))) return rc;
+            hipLaunchKernelGGL((k_cols_dc_t4<PlanRT, true>), grid, blk, lds, st, in, y4, m, out, a);
+        }
+    } else if (H == 640 && wave640) {
         hipLaunchKernelGGL(k_cols640_dc_t4, grid, dim3(64), 0, st, in, y4, m, out, a);
     } else if (H == 640) {
         if ((rc = set_lds(k_cols_dc_t4<P640>, lds))) return rc;

@@ -53,6 +53,26 @@ extern "C" int mrx_arith(void);
         }                                                                                  \
     } while (0)
 
+// re^2 + im^2 rounded as torch's (data ** 2).sum(-1) rounds it -- two rounded squares, one rounded add -- in EVERY translation unit, whatever its
+// contraction mode.  HIP's __fmul_rn / __fadd_rn are plain operators: hipcc contracts `__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y))` into
+// v_mul + v_fmac unless the file is built with -ffp-contract=off (round 4: conv_bwd.hip did so once its packed-fp32 v_pk_mul was gone, the
+// backward of the l1 loss no longer found the arg-max pixel by `|p| == max |p|` -- the maximum comes from elementwise.hip -- and dropped that
+// gradient path: 85 % error on some weights).  The pragma clears the `contract` flag of these three operations themselves; it survives inlining.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float mrx_sumsq2(float re, float im) {
+#pragma clang fp contract(off)
+    const float a = re * re;
+    const float b = im * im;
+    return a + b;
+}
+// a * s - t, product rounded before the subtraction (the l1 loss term |p| / max - target: forward and backward must see the same sign)
+__device__ __forceinline__ float mrx_mul_sub(float a, float s, float t) {
+#pragma clang fp contract(off)
+    const float m = a * s;
+    return m - t;
+}
+#endif
+
 // output tile of the convolution kernels (also the granule of the fused InstanceNorm tile statistics)
 #define MRX_CONV_TILE_H 8
 #define MRX_CONV_TILE_W 32

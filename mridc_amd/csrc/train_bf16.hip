@@ -82,8 +82,9 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
     float s_hh = 0.f, s_bih = 0.f, s_b = 0.f;   // lane (l31, lhi) owns channel 32 lhi + l31 (s_hh, s_bih) / accumulator row l31 of its half (s_b)
     unsigned char* Tg = smem_c + wave * 2 * CL_TILE;
     unsigned char* Ta = Tg + CL_TILE;
-    float* HH = reinterpret_cast<float*>(smem_c + 8 * 2 * CL_TILE);   // hh [64]
-    if (HAS_PREV && tid < 64) HH[tid] = a.hh[tid];
+    // hh [64] in the unused tail (bytes 64 .. 79) of the rows of the first tile: the tiles fill 80 KB exactly, two workgroups share a CU's 160 KB
+    auto HH = [&](int c) -> float& { return *reinterpret_cast<float*>(smem_c + c * CL_RS + 64); };
+    if (HAS_PREV && tid < 64) HH(tid) = a.hh[tid];
     __syncthreads();
     // every tensor is addressed as (wave-uniform base) + (32-bit byte offset of the lane): one address register per access instead of a 64-bit pair
     // (the first form precomputed ~60 pointers and spilled them)
@@ -101,34 +102,46 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
         // ---- cell stage: lane = pixel, channels 32 lhi + i; eight channels at a time -----------------------------------------------------------
         unsigned gbP[16];
         float t_hh[32];
+        // the pair tensor `a` is needed after the first GEMM only: requested first, it arrives under the cell stage
+        unsigned awv[16];
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            unsigned d2[4];
-            float dHv[8], hv[8], hpv[8];
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) d2[q] = ldu(a.dhP, pb + (unsigned)(4 * ch + q) * plane4);
+            for (int q = 0; q < 8; ++q) awv[ct * 8 + q] = ldu(a.aP, ab + (unsigned)(ct * 16 + (q & 1) + 4 * (q >> 1)) * plane4);
+        // eight channels at a time, the NEXT chunk's 28 loads in flight while this one is processed
+        unsigned d2[2][4];
+        float dHv[2][8], hv[2][8], hpv[2][8];
+        auto request = [&](int ch, int bf) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d2[bf][q] = ldu(a.dhP, pb + (unsigned)(4 * ch + q) * plane4);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const unsigned o = fb + (unsigned)(8 * ch + j) * plane4;
-                dHv[j] = HAS_DH ? ldf(a.dH, o) : 0.f;
-                hv[j] = ldf(a.h, o);
-                hpv[j] = HAS_PREV ? ldf(a.hprev, o) : 0.f;
+                dHv[bf][j] = HAS_DH ? ldf(a.dH, o) : 0.f;
+                hv[bf][j] = ldf(a.h, o);
+                hpv[bf][j] = HAS_PREV ? ldf(a.hprev, o) : 0.f;
             }
+        };
+        request(0, 0);
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int bf = ch & 1;
+            if (ch < 3) request(ch + 1, bf ^ 1);
             float g[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float up = ((j & 1) ? tl_hi(d2[j >> 1]) : tl_lo(d2[j >> 1])) + dHv[j];
-                g[j] = (valid && hv[j] > 0.f) ? up : 0.f;
-                t_hh[8 * ch + j] = g[j] * hpv[j];
+                const float up = ((j & 1) ? tl_hi(d2[bf][j >> 1]) : tl_lo(d2[bf][j >> 1])) + dHv[bf][j];
+                g[j] = (valid && hv[bf][j] > 0.f) ? up : 0.f;
+                t_hh[8 * ch + j] = g[j] * hpv[bf][j];
             }
             if (HAS_PREV && valid) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dhp) + fb + (unsigned)(8 * ch + j) * plane4) = g[j] * HH[32 * lhi + 8 * ch + j];
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dhp) + fb + (unsigned)(8 * ch + j) * plane4) = g[j] * HH(32 * lhi + 8 * ch + j);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) gbP[4 * ch + q] = tl_pk(g[2 * q], g[2 * q + 1]);
-            __builtin_amdgcn_sched_barrier(0);      // one chunk's 28 loads in flight at a time: hoisting all four costs 100+ registers (spills)
+            __builtin_amdgcn_sched_barrier(0);      // keeps the order above: two chunks of loads in flight, not four (hoisting everything spills)
         }
         if (HAS_PREV) s_hh += tl_reduce_scatter32(t_hh, lane);
         {
@@ -166,8 +179,7 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int r = 2 * q, ci = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                unsigned aw = ldu(a.aP, ab + (unsigned)(ct * 16 + (q & 1) + 4 * (q >> 1)) * plane4);
-                aw = valid ? aw : 0u;
+                const unsigned aw = valid ? awv[ct * 8 + q] : 0u;
                 const float v0 = (aw & 0x7fffu) ? acc[ct][r] : 0.f, v1 = (aw & 0x7fff0000u) ? acc[ct][r + 1] : 0.f;
                 const unsigned gp = tl_pk(v0, v1);
                 gpv[ct * 8 + q] = gp;
@@ -249,9 +261,12 @@ static int tl_nwg(long long tiles) {
     }
     return (int)(tiles < n_cu ? tiles : n_cu);
 }
+static int tl_cell_nwg(long long tiles) {       // one workgroup per CU (two -- 80 KB of LDS, 128 registers with 14 spilled -- measured 123 us against 99)
+    return tl_nwg(tiles);
+}
 extern "C" int64_t mrx_tl_cell_part_floats(int B, int H, int W) {
     if (B < 1 || H < 1 || W < 1) return -1;
-    return (int64_t)tl_nwg((long long)B * mrx_cdiv(W, 32) * mrx_cdiv(H, 8)) * CL_PART;
+    return (int64_t)tl_cell_nwg((long long)B * mrx_cdiv(W, 32) * mrx_cdiv(H, 8)) * CL_PART;
 }
 // The backward pass of one IndRNN layer's cell + convolution ReLU (see the header).  dH (fp32) may be null (last time-step); hprev null =
 // first time-step (no dh_prev, no hh gradient).  `part` [mrx_tl_cell_part_floats]: the workgroup slots; first != 0 overwrites them (first call of a
@@ -267,7 +282,7 @@ extern "C" int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const floa
     a.wT = (const u32x4*)tl_packed + 768, a.hh = hh, a.dhp = dh_prev, a.gaP = (unsigned*)ga_pairs, a.part = part;
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, 32), a.ntiles = a.tiles_x * mrx_cdiv(H, 8), a.first = first;
     MRX_REQUIRE(dh_above, MRX_EINVAL, "mrx_tl_cell_bwd: the gradient from the layer above is required");
-    constexpr int lds = 8 * 2 * CL_TILE + 256;
+    constexpr int lds = 8 * 2 * CL_TILE;
     static bool attr_done = false;
     if (!attr_done) {
         MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -276,7 +291,7 @@ extern "C" int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const floa
         MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    const dim3 grid(tl_nwg((long long)B * a.ntiles));
+    const dim3 grid(tl_cell_nwg((long long)B * a.ntiles));
     hipStream_t st = (hipStream_t)stream;
     if (dH && hprev)
         hipLaunchKernelGGL((k_tl_cell_bwd<true, true>), grid, dim3(CL_NT), lds, st, a);
@@ -310,14 +325,15 @@ __global__ __launch_bounds__(256) void k_tl_cell_reduce(const float* __restrict_
 }
 extern "C" int mrx_tl_cell_reduce(const float* part, int B, int H, int W, float* dw_ih, float* db_ih, float* dhh, float* db_conv, void* stream) {
     MRX_REQUIRE(part && dw_ih, MRX_EINVAL, "mrx_tl_cell_reduce: null pointer");
-    const int n = tl_nwg((long long)B * mrx_cdiv(W, 32) * mrx_cdiv(H, 8));
+    const int n = tl_cell_nwg((long long)B * mrx_cdiv(W, 32) * mrx_cdiv(H, 8));
     hipLaunchKernelGGL(k_tl_cell_reduce, dim3((CL_PART + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, n, dw_ih, db_ih, dhh, db_conv);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 
-// ---- the edge pixels of a replicate-padded data gradient whose interior is in `dx` already (mrx_tl_dgrad): every edge pixel receives the frame
-// positions that clamp to it; the sum is rounded to bf16 once more (dx is a bf16 tensor: pairs, or fp32 holding bf16 values) --------------------------
+// ---- the edge pixels of a replicate-padded data gradient whose interior is in `dx` already (mrx_tl_dgrad): every edge pixel is the sum of the frame
+// positions that clamp to it -- its own unrounded value included, which mrx_tl_dgrad left in the frame tensor -- rounded to bf16 ONCE (dx is a bf16
+// tensor: pairs, or fp32 holding bf16 values) ----------------------------------------------------------------------------------------------------
 __global__ void k_tl_fold_edges(const float* __restrict__ g, void* __restrict__ dx, int pairs, int B, int C, int H, int W, int pad) {
     const int per = 2 * W + 2 * (H - 2 > 0 ? H - 2 : 0);
     const int nch = pairs ? C / 2 : C;
@@ -343,17 +359,13 @@ __global__ void k_tl_fold_edges(const float* __restrict__ g, void* __restrict__ 
         for (int k = 0; k < (pairs ? 2 : 1); ++k) {
             const float* gp = g + ((long long)bb * C + (pairs ? 2 * cc + k : cc)) * PH * PW;
             for (int i = i0; i <= i1; ++i)
-                for (int j = j0; j <= j1; ++j)
-                    if (i != h + pad || j != w + pad) s[k] += gp[(long long)i * PW + j];
+                for (int j = j0; j <= j1; ++j) s[k] += gp[(long long)i * PW + j];
         }
         const long long at = p * (long long)H * W + (long long)h * W + w;
-        if (pairs) {
-            unsigned* q = reinterpret_cast<unsigned*>(dx) + at;
-            *q = tl_pk(tl_lo(*q) + s[0], tl_hi(*q) + s[1]);
-        } else {
-            float* q = reinterpret_cast<float*>(dx) + at;
-            *q = tl_lo(tl_pk(*q + s[0], 0.f));
-        }
+        if (pairs)
+            reinterpret_cast<unsigned*>(dx)[at] = tl_pk(s[0], s[1]);
+        else
+            reinterpret_cast<float*>(dx)[at] = tl_lo(tl_pk(s[0], 0.f));
     }
 }
 extern "C" int mrx_tl_fold_edges(const float* frame, void* dx, int dx_pairs, int B, int C, int H, int W, int pad, void* stream) {
@@ -431,6 +443,139 @@ extern "C" int mrx_tl_f32_to_pairs(const float* x, void* pairs, int64_t pair_pla
     if (n == 0) return MRX_OK;
     hipLaunchKernelGGL(k_tl_f32_to_pairs, dim3((unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, (hipStream_t)stream, x, (unsigned*)pairs, (long long)pair_planes,
                        (long long)plane);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// ---- weight gradient of the FIRST RIM layer (5x5, Cin <= 5 -> 64; conv_layers.py:121-123 backwards) from a pair tensor ------------------------------
+// dW[co][ci][tap] = sum_px dy[co][px] x[ci][px + tap]: a GEMM D[co][n] += A[co][px] B[px][n] with n = ci * 25 + tap (<= 125: four 32-column blocks)
+// and the contraction over the pixels.  The generic thin kernel (conv_bf16.hip, one tap per wave, the input channels across the lanes: 28 of 32
+// lanes multiply zeros) needed 800 MFMAs per 8 x 32 tile, spilled 84 registers and took 131 us; here a wave owns one column block: lane n gathers
+// its eight consecutive pixels of x[ci] at the (ky, kx) shift of its own column from the halo'd bf16 tile in LDS (five aligned dwords + a
+// per-lane funnel shift for odd kx), 64 MFMAs per 4 x 32 tile, 20 KB of LDS: several workgroups per CU cover each other's loads.
+#define WI_TH 4
+#define WI_NT 256
+#define WI_DYS (WI_TH * 32 * 2 + 16)      // bytes per dy channel row: 128 pixels bf16 + 16
+template <int K>
+__global__ __launch_bounds__(WI_NT, 2) void k_tl_wgrad_in(const float* __restrict__ x, const unsigned* __restrict__ dyP, float* __restrict__ part, int B, int Cin,
+                                                         int H, int W, int tiles_x, int ntiles) {
+    constexpr int PAD = (K - 1) / 2, PH = WI_TH + 2 * PAD, PW = 32 + 2 * PAD + 4, TAPS = K * K;   // PW: row stride in elements (+4: the 5-dword window of the last lane group)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    unsigned char* Dy = smem_w;                                   // [64][WI_DYS]
+    unsigned short* Xh = reinterpret_cast<unsigned short*>(smem_w + 64 * WI_DYS);   // [Cin][PH][PW] bf16, then one zero row of PH * PW
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const long long plane = (long long)H * W;
+    const int N = Cin * TAPS;
+    // this lane's column: n = 32 wave + l31 -> (ci, ky, kx); columns past N read the zero plane
+    const int n = 32 * wave + l31;
+    const int ci = n < N ? n / TAPS : Cin, tp = n < N ? n - ci * TAPS : 0, ky = tp / K, kx = tp - ky * K;
+    const int xoff = (ci * PH + ky) * PW + (kx & ~1);             // even element offset of the lane's window; an odd kx shifts by 16 bits
+    const unsigned sh = (kx & 1) ? 16u : 0u;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int i = tid; i < PH * PW; i += WI_NT) Xh[Cin * PH * PW + i] = 0;
+    const int total = ntiles * B;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int b = t / ntiles, tt = t - b * ntiles, ty0 = tt / tiles_x, h0 = ty0 * WI_TH, w0 = (tt - ty0 * tiles_x) * 32;
+        __syncthreads();
+        // dy tile from the pair tensor: item = (pair, row, 8-pixel group)
+        const unsigned* dyb = dyP + (long long)b * 32 * plane;
+        for (int i = tid; i < 32 * WI_TH * 4; i += WI_NT) {
+            const int pg = i & 3, r = (i >> 2) % WI_TH, pp = i / (4 * WI_TH);
+            const int gy = h0 + r, gx = w0 + pg * 8;
+            const unsigned* src = dyb + (long long)pp * plane + (long long)(gy < H ? gy : H - 1) * W;
+            unsigned d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int xx = gx + j;
+                const unsigned v = src[xx < W ? xx : W - 1];
+                d[j] = (gy < H && xx < W) ? v : 0u;
+            }
+            u32x4 lo, hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lo[q] = (d[2 * q] & 0xffffu) | (d[2 * q + 1] << 16);
+                hi[q] = (d[2 * q] >> 16) | (d[2 * q + 1] & 0xffff0000u);
+            }
+            *reinterpret_cast<u32x4*>(Dy + (2 * pp) * WI_DYS + (r * 32 + pg * 8) * 2) = lo;
+            *reinterpret_cast<u32x4*>(Dy + (2 * pp + 1) * WI_DYS + (r * 32 + pg * 8) * 2) = hi;
+        }
+        // halo'd x tile, replicate padding, fp32 -> bf16 (two pixels per thread and step)
+        const float* xb = x + (long long)b * Cin * plane;
+        for (int i = tid; i < Cin * PH * (PW / 2); i += WI_NT) {
+            const int c2 = i % (PW / 2), r = (i / (PW / 2)) % PH, c = i / ((PW / 2) * PH);
+            int gy = h0 + r - PAD;
+            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+            int gx0 = w0 + 2 * c2 - PAD, gx1 = gx0 + 1;
+            gx0 = gx0 < 0 ? 0 : (gx0 >= W ? W - 1 : gx0);
+            gx1 = gx1 < 0 ? 0 : (gx1 >= W ? W - 1 : gx1);
+            const float* row = xb + (long long)c * plane + (long long)gy * W;
+            *reinterpret_cast<unsigned*>(Xh + (c * PH + r) * PW + 2 * c2) = tl_pk(row[gx0], row[gx1]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < WI_TH; ++r)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int px = kk * 16 + lhi * 8;                  // first of the lane's eight pixels in row r
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Dy + l31 * WI_DYS + (r * 32 + px) * 2);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Dy + (32 + l31) * WI_DYS + (r * 32 + px) * 2);
+                const unsigned* q = reinterpret_cast<const unsigned*>(Xh + xoff + r * PW + px);
+                const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                const u32x4 bw = {__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh), __builtin_amdgcn_alignbit(d3, d2, sh),
+                                  __builtin_amdgcn_alignbit(d4, d3, sh)};
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, bw), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bw), acc[1], 0, 0, 0);
+            }
+    }
+    float* po = part + (long long)blockIdx.x * 64 * N;
+    if (n < N) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) po[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi) * N + n] = acc[i][r];
+    }
+}
+__global__ __launch_bounds__(256) void k_tl_part_reduce(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw, int accumulate) {
+    __shared__ double sh[16][17];
+    const int li = threadIdx.x & 15, lp = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + li;
+    double s = 0.0;
+    if (i < n)
+        for (int p = lp; p < nparts; p += 16) s += (double)part[(long long)p * n + i];
+    sh[lp][li] = s;
+    __syncthreads();
+    if (lp == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][li];
+        dw[i] = accumulate ? dw[i] + (float)t : (float)t;
+    }
+}
+static int wi_nwg(long long tiles) {
+    const long long cap = 2ll * tl_nwg(1ll << 40);            // (three per CU measured 29.7 us + 17.3 us for the 768-partial reduction)
+    return (int)(tiles < cap ? tiles : cap);
+}
+extern "C" int64_t mrx_tl_wgrad_in_work_floats(int B, int Cin, int H, int W) {
+    if (B < 1 || Cin < 1 || Cin > 5 || H < 1 || W < 1) return -1;
+    return (int64_t)wi_nwg((long long)B * mrx_cdiv(W, 32) * mrx_cdiv(H, WI_TH)) * 64 * Cin * 25;
+}
+// dw [64,Cin,5,5] (= or +=) the weight gradient of the replicate-padded 5x5 convolution Cin <= 5 -> 64 with x fp32 [B,Cin,H,W] (rounded to bf16 by the
+// loader) and dy a pair tensor [B,32,H,W]; bf16 products, fp32 sums per workgroup, fixed-order double sum of the workgroup partials.
+extern "C" int mrx_tl_wgrad_in(const float* x, const void* dy_pairs, float* dw, float* work, int B, int Cin, int H, int W, int accumulate, void* stream) {
+    MRX_REQUIRE(x && dy_pairs && dw && work, MRX_EINVAL, "mrx_tl_wgrad_in: null pointer");
+    MRX_REQUIRE(B >= 1 && Cin >= 1 && Cin <= 5 && H >= 1 && W >= 1, MRX_EUNSUP, "mrx_tl_wgrad_in: Cin=%d (1 .. 5: four column blocks)", Cin);
+    constexpr int PH = WI_TH + 4, PW = 32 + 4 + 4;
+    const int lds = 64 * WI_DYS + (Cin + 1) * PH * PW * 2 + 64;
+    const int tiles_x = mrx_cdiv(W, 32), ntiles = tiles_x * mrx_cdiv(H, WI_TH), nwg = wi_nwg((long long)B * ntiles);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_tl_wgrad_in<5>, dim3(nwg), dim3(WI_NT), lds, st, x, (const unsigned*)dy_pairs, work, B, Cin, H, W, tiles_x, ntiles);
+    MRX_LAUNCH_CHECK();
+    const long long total = 64ll * Cin * 25;
+    hipLaunchKernelGGL(k_tl_part_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

@@ -20,9 +20,17 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY
 
 def active(*tensors, training=True):
     """True when torch is recording gradients and one of the tensors takes part.  Modules pass `training=self.training`: an eval-mode module
-    called without torch.no_grad() takes the fused inference kernels instead of silently recording a (several times slower) tape -- the
-    same rule RIMBlock.forward applies."""
-    return bool(training) and torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+    called without torch.no_grad() on inputs that need no gradient takes the fused inference kernels instead of silently recording a (several
+    times slower) tape -- the same rule RIMBlock.forward applies."""
+    if not torch.is_grad_enabled():
+        return False
+    req = [t for t in tensors if torch.is_tensor(t) and t.requires_grad]
+    if not req:
+        return False
+    # eval(): parameters alone do not switch the tape on (inference without torch.no_grad()), but an INPUT that requires grad does -- a frozen
+    # eval-mode sub-network inside a trained pipeline, test-time adaptation, saliency: eval() does not disable autograd, and the fused kernels'
+    # outputs carry no grad_fn
+    return bool(training) or any(not isinstance(t, torch.nn.Parameter) for t in req)
 
 
 def _act_grad(dy, y, act, slope):

@@ -224,6 +224,24 @@ def _y_t4(y):
     return _Y_T4.get(y, (), make)
 
 
+LLG_T4_NO_Y = True          # parts form: the measured data enters as one constant partial plane instead of being read by every column pass (test hook)
+_LLG_CONST = _PreparedCache()
+
+
+def _llg_parts_buffer(y, sens, mask, centered, normalization, spatial_dims, n):
+    """The partial planes of the general-mask gradient at W = 372, [n + 1][B,H,W,2], one buffer per slice (storage, version, capture): planes
+    0 .. n - 1 are rewritten by every step (mrx_pfa372_reduce_t4), plane n holds the constant term -A^H M y = -sum_c conj(S) ifft2(mask y)
+    (rim_utils.py:53-62 is linear in (k - y)), so the column pass of a step never reads y and the first RIM layer's loader -- which keeps
+    four partial planes in flight and has three at 15 coils -- adds it for free."""
+    def make():
+        B, C, H, W = _bchw(y)
+        buf = torch.empty(n + 1, B, H, W, 2, dtype=torch.float32, device=y.device)
+        buf[n] = sens_reduce(y * mask, sens, centered, normalization, spatial_dims)
+        buf[n].neg_()
+        return buf
+    return _LLG_CONST.get(y, (sens.data_ptr(), sens._version, mask.data_ptr(), mask._version, bool(centered), str(normalization), int(n)), make)
+
+
 def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, out=None, work=None, parts=False):
     """log_likelihood_gradient -> [B,4,H,W].  `parts` (llg_t4_supported only): returns (part [n][B,H,W,2], n) -- the coil-group partial sums
     of the last pass, for rim_layer_indrnn_packed_llg, which adds them, scales by 1/sigma^2 and splits the channels in its tile loader."""
@@ -248,9 +266,19 @@ def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, o
         nrm, cen, st = _norm(normalization), int(bool(centered)), _lib.stream_ptr()
         if llg_t4_supported(y):
             # the coil stack between the passes column-tiled (contiguous 4-column blocks for the column pass); y tiled once per slice
+            _lib.check(L.mrx_pfa372_expand_t4(_lib.ptr(eta), _lib.ptr(sp), _lib.ptr(work), B, C, H, nrm, cen, st), "mrx_pfa372_expand_t4")
+            if parts and LLG_T4_NO_Y:
+                n0 = int(L.mrx_llg372_work_floats(B, C, H)) // (B * H * W * 2)           # coil-group partial planes of the last pass
+                wk = _llg_parts_buffer(y, sens, mask, centered, normalization, spatial_dims, n0)
+                _lib.check(L.mrx_llg_cols_dc_t4(_lib.ptr(work), None, _lib.ptr(m), kind, ms, B, C, H, W, nrm, cen, st), "mrx_llg_cols_dc_t4")
+                n = ctypes.c_int(0)
+                _lib.check(L.mrx_pfa372_reduce_t4(_lib.ptr(work), _lib.ptr(sp), None, None, _lib.ptr(wk), ctypes.byref(n), B, C, H,
+                                                  float(1.0 / (float(sigma) ** 2.0)), nrm, cen, st), "mrx_pfa372_reduce_t4")
+                if int(n.value) != n0:
+                    raise RuntimeError(f"llg: {n.value} partial planes, expected {n0}")
+                return wk, n0 + 1
             yt4 = _y_t4(y)
             wk = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=y.device)
-            _lib.check(L.mrx_pfa372_expand_t4(_lib.ptr(eta), _lib.ptr(sp), _lib.ptr(work), B, C, H, nrm, cen, st), "mrx_pfa372_expand_t4")
             _lib.check(L.mrx_llg_cols_dc_t4(_lib.ptr(work), _lib.ptr(yt4), _lib.ptr(m), kind, ms, B, C, H, W, nrm, cen, st), "mrx_llg_cols_dc_t4")
             if parts:
                 n = ctypes.c_int(0)
@@ -419,6 +447,7 @@ def rim_layer1_inplace_ok(Cin, F, k, dilation):
 def rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None, xmax=None):
     """The tuned fused first RIM layer reading log_likelihood_gradient's pieces (eta and the partial coil sums) directly.  `xmax` as in
     rim_layer_indrnn_packed."""
+    _forget_bound(out)
     eta = _lib.f32c(eta)
     B, H, W, _ = [int(v) for v in eta.shape]
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -645,6 +674,7 @@ def conv1x1_sq_supported(cin, cout):
 
 def conv1x1_64(x, weight, bias=None, act=ACT_NONE, slope=0.0, hh=None, h_prev=None, out=None):
     """act(W x + bias [+ hh * h_prev]) for a 1x1 convolution C -> C, C = 64 or 128 (mrx_conv1x1_sq)."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     if not conv1x1_sq_supported(Cin, int(weight.shape[0])) or tuple(weight.shape) != (Cin, Cin, 1, 1):
@@ -674,6 +704,7 @@ def conv3x3_wino_supported(Cin, Cout, k, dilation):
 def conv3x3_wino(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
     """3x3 convolution into 64 (or a multiple of 64) channels as Winograd F(2x2,3x3) on the matrix cores (differs from the direct form by
     fp32 round-off, ~2e-7 of the output norm)."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     Cout = int(weight.shape[0])
@@ -704,6 +735,7 @@ def conv3x3_sb(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slo
     fp32 results (the convolution stage of the dominant RIM layer on its own).  Operands: three bf16 terms (six term products per multiply) --
     or, when x carries the bound of its maximum (kept by the convolution that produced it: ops._attach_bound), two fp16 terms scaled by it (three
     term products): mrx_conv3x3_sb_chain.  The operand packs are cached per (storage, version)."""
+    _forget_bound(out)
     x_in = x
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
@@ -756,6 +788,7 @@ def conv_sbs_supported(Cin, Cout, k, dilation):
 def conv_sbs(x, weight, bias, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
     """3x3 / 5x5 convolution (dilation 1) of Cin <= 8 channels into Cout <= 128 + bias + activation on the bf16 matrix pipe with fp32 results
     (mrx_conv_sbs: three-term operand split, two taps per MFMA): the first layers of the cascades.  Pack cached per (storage, version)."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     Cout, _, k, _ = [int(v) for v in weight.shape]
@@ -790,6 +823,7 @@ def conv3x3_taps(x, weight, bias, pad_mode=PAD_ZERO, out=None):
     """3x3 convolution (dilation 1) of C = 64 / 128 channels into Cout <= 4 as a per-pixel channel contraction C -> 9 Cout on the matrix cores
     (the square 1x1 kernel, tap rows [tap * Cout + co] padded to C) + a nine-tap gather (mrx_taps_gather): the direct form costs 18 Cout
     vector FMAs per (pixel, input channel) -- qRIM's 128 -> 4 final layer at 256 x 256: 75 us."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     Cout = int(weight.shape[0])
@@ -827,6 +861,7 @@ def conv3x3_h_supported(Cin, Cout, k, dilation):
 def conv3x3_h(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None, bound=None):
     """act(conv3x3(x) + bias) for any channel counts on two-term fp16 operands (mrx_conv3x3_h; csrc/unet_f16.hip).  `bound`: device scalar
     >= max |x| (default: the one x carries, else measured by mrx_max_abs)."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     weight = _lib.f32c(weight.detach())
@@ -851,6 +886,7 @@ def conv3x3_h(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slop
 
 def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
     """'same' conv, stride 1, square odd kernel (mrx_conv2d; 3x3 into 64 channels: mrx_conv3x3_wino)."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     _lib.require_gpu(weight)
     B, Cin, H, W = _nchw(x)
@@ -980,6 +1016,9 @@ def conv_wgrad_bf16(x, dy, k, dilation=1, pad_mode=PAD_REPLICATE, out=None, accu
 # ---- mixed-precision training with bf16 STORAGE (csrc/train_bf16.hip, conv_bf16.hip OUT 1 / 2; callers: mridc_amd/training.py) ---------------------
 # "Pair tensors": what torch.autocast keeps in half precision (convolution results, the gradients flowing into them) lives in HBM as
 # int32 [B, C / 2, H, W] = (bf16 of channel 2p, bf16 of channel 2p + 1).
+TL_WGRAD_IN = True          # the first layer's weight gradient on its own kernel (mrx_tl_wgrad_in); False: the generic thin kernel (test hook)
+
+
 def f32_to_pairs(x):
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
@@ -1098,6 +1137,11 @@ def conv_wgrad_bf16_pairs(x, dy_pairs, k, dilation, pad_mode=PAD_REPLICATE, out=
         out = torch.empty(64, Cin, k, k, dtype=torch.float32, device=x.device)
         accumulate = False
     L = _lib.lib()
+    if int(k) == 5 and int(dilation) == 1 and Cin <= 5 and pad_mode == PAD_REPLICATE and TL_WGRAD_IN:
+        work = torch.empty(int(L.mrx_tl_wgrad_in_work_floats(B, Cin, H, W)), dtype=torch.float32, device=x.device)
+        _lib.check(L.mrx_tl_wgrad_in(_lib.ptr(x), _lib.ptr(dy_pairs), _lib.ptr(out), _lib.ptr(work), B, Cin, H, W, int(bool(accumulate)), _lib.stream_ptr()),
+                   "mrx_tl_wgrad_in")
+        return out
     work = torch.empty(int(L.mrx_conv_wgrad_bf16_any_work_floats(B, Cin, 64, H, W, int(k))), dtype=torch.float32, device=x.device)
     _lib.check(L.mrx_conv_wgrad_bf16_pairs(_lib.ptr(x), _lib.ptr(dy_pairs), _lib.ptr(out), _lib.ptr(work), B, Cin, H, W, int(k), int(dilation), int(pad_mode),
                                            int(bool(accumulate)), _lib.stream_ptr()), "mrx_conv_wgrad_bf16_pairs")
@@ -1123,6 +1167,7 @@ def conv_to_complex(x, weight, bias, dilation=1, pad_mode=PAD_ZERO):
 
 
 def indrnn_cell(x, w_ih, b_ih, hh, h_prev, dilation=1, out=None):
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     F, Cin_w, k, _ = [int(v) for v in w_ih.shape]
@@ -1143,6 +1188,7 @@ def indrnn_cell(x, w_ih, b_ih, hh, h_prev, dilation=1, out=None):
 
 def rim_layer_indrnn(x, w_conv, b_conv, k, dilation, w_ih, b_ih, hh, h_prev, out=None):
     """Fused ConvNonlinear(ReLU, replicate pad) + IndRNNCell(1x1)."""
+    _forget_bound(out)
     x, w_conv, w_ih = _lib.f32c(x), _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
     B, Cin, H, W = _nchw(x)
     F = int(w_conv.shape[0])
@@ -1183,6 +1229,7 @@ def rim_layer1_xmax_supported(Cin, F, k, dilation):
 def rim_layer_indrnn_packed(x, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None, xmax=None):
     """Tuned fused ConvNonlinear(ReLU, replicate pad) + IndRNNCell(1x1) on pre-packed weights.  `xmax` (one-element float32 device tensor):
     the maximum of the outputs is folded into it with an atomic max (mrx_rim_layer_indrnn_packed_xmax)."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -1226,6 +1273,7 @@ def rim_layer2_sb_pack(w_conv, w_ih, w_final=None):
 def rim_layer2_sb(x, packed, b_conv, b_ih, hh, h_prev, out=None):
     """ReLU(W_ih ReLU(conv3x3 dilation 2 (replicate pad)(x) + b_conv) + b_ih + hh * h_prev), 64 features, on the bf16 matrix pipe with fp32
     results (mrx_rim_layer2_sb).  `out` may be h_prev itself (state updated in place: every element is read by the lane that writes it)."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -1242,6 +1290,7 @@ def rim_layer2_sb(x, packed, b_conv, b_ih, hh, h_prev, out=None):
 def rim_layer2_sb_taps(x, packed, b_conv, b_ih, hh, h_prev, taps=None, out=None):
     """rim_layer2_sb that also leaves the final convolution's per-pixel tap products [B,18,H,W] (mrx_rim_layer2_sb_taps); `packed` from
     rim_layer2_sb_pack(..., w_final).  `out` may be h_prev itself (state updated in place).  Returns (h_new, taps)."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -1278,6 +1327,7 @@ def rim_layer2_f16(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps=None, out=Non
     """rim_layer2_sb / rim_layer2_sb_taps with the convolution's operands as two fp16 terms (mrx_rim_layer2_f16: half the MFMAs).  `xmax`: a
     one-element float32 device tensor holding an upper bound of max |x| (kept by the producer of x: rim_layer_indrnn_packed*(xmax=...)).
     Returns h_new, or (h_new, taps) with want_taps."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -1315,6 +1365,7 @@ def cb8_to_nchw(y):
 def rim_layer1_cb8(x, eta, part, nparts, sigma, packed, b_conv, b_ih, hh, h_prev, xmax, out=None):
     """First RIM layer on channel-blocked states (mrx_rim_layer1_cb8): input x [B,Cin<=4,H,W] (eta None) or (eta [B,H,W,2], coil-group partial
     sums) as rim_layer_indrnn_packed_llg; h_prev / result [B,8,H,W,8]; keeps the running bound `xmax` of its outputs."""
+    _forget_bound(out)
     if eta is not None:
         eta = _lib.f32c(eta)
         B, H, W, _ = [int(v) for v in eta.shape]
@@ -1336,6 +1387,7 @@ def rim_layer1_cb8(x, eta, part, nparts, sigma, packed, b_conv, b_ih, hh, h_prev
 
 def rim_layer2_f16_cb8(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps=None, out=None, want_taps=False):
     """rim_layer2_f16 on channel-blocked tensors (mrx_rim_layer2_f16_cb8; x, h_prev, result [B,8,H,W,8]; taps [B,18,H,W] as rim_layer2_f16)."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, Q, H, W, E = [int(v) for v in x.shape]
     if Q != 8 or E != 8:
@@ -1370,6 +1422,7 @@ def rim_final_gather(taps, b_final, eta):
 def rim_layer2_sb_final(x, packed, b_conv, b_ih, hh, h_prev, b_final, eta, work=None, out=None):
     """Second RIM layer and the final convolution + eta update (rim_block.py:233-246): returns (h_new [B,64,H,W],
     eta + permute(conv3x3_reppad(h_new) + b_final) [B,H,W,2]).  `packed` from rim_layer2_sb_pack(..., w_final)."""
+    _forget_bound(out)
     if tuple(eta.shape) != (int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), 2):
         raise ValueError("rim_layer2_sb_final expects eta of shape [B,H,W,2]")
     h_new, taps = rim_layer2_sb_taps(x, packed, b_conv, b_ih, hh, h_prev, work, out)
@@ -1391,6 +1444,7 @@ def rim_layer_wino_pack(w_conv, w_ih):
 
 def rim_layer_indrnn_wino(x, packed, F, b_conv, b_ih, hh, h_prev, out=None):
     """Winograd fused ConvNonlinear(3x3, dilation 2, ReLU, replicate pad) + IndRNNCell(1x1) on pre-transformed weights."""
+    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -1741,11 +1795,23 @@ UNET_F16 = True                   # (module attribute: a test hook for the fp32-
 
 def _analytic_bound(n, device):
     """Device scalar sqrt(n): the bound of an instance- / group-normalised tensor whose statistics ran over n values (|z| <= sqrt(n - 1))."""
-    key = (int(n), str(device))
+    # keyed on the hipGraph capture like _PreparedCache: a scalar first filled INSIDE a capture exists only in that graph's pool and only after a
+    # replay -- an eager call (or another capture) must not read it
+    cap = int(_lib.lib().mrx_stream_capture_id(_lib.stream_ptr()))
+    for k in [k for k in _UNET_BOUNDS if k[2] != 0 and k[2] != cap]:
+        del _UNET_BOUNDS[k]
+    key = (int(n), str(device), cap)
     t = _UNET_BOUNDS.get(key)
     if t is None:
         t = _UNET_BOUNDS[key] = torch.full((1,), float(n) ** 0.5, dtype=torch.float32, device=device)
     return t
+
+
+def _forget_bound(t):
+    """The library writes through raw pointers and never bumps a tensor's version: an op that fills a caller-supplied `out` must drop the bound a
+    previous producer attached to that tensor object, or the next two-term fp16 convolution would scale its operands by a stale maximum."""
+    if t is not None:
+        t.__dict__.pop("_mrx_bound", None)
 
 
 def _attach_bound(t, bound):

@@ -93,3 +93,47 @@ def cirim_loss_and_gradients(state, cfg, sample, mode="fp32", skip=(), fp32_forw
         loss = omodels.cirim_process_loss(sample["target"], pred, torch.nn.L1Loss(), omodels.cirim_time_steps(cfg["time_steps"]), cfg["num_cascades"])
     loss.backward()
     return loss.detach().float(), {k: v.grad.float() for k, v in p.items() if v.grad is not None}
+
+
+# ---- tie-free targets for gradient comparisons ------------------------------------------------------------------------------------------------------
+def detie_terms(t, vals, margin, lo=None, hi=None):
+    """Copy of the real tensor `t` in which no element is within `margin` of the same element of any tensor stacked in `vals` [E, *t.shape]
+    (only the tied elements move, in steps of `margin`, staying inside (lo, hi))."""
+    t = t.detach().clone()
+    bad = ((vals - t.unsqueeze(0)).abs() < margin).any(0)
+    for idx in bad.nonzero().tolist():
+        idx = tuple(idx)
+        col, cur = vals[(slice(None),) + idx], float(t[idx])
+        for k in range(1, 400):
+            cands = [c for c in (cur - k * margin, cur + k * margin) if (lo is None or c > lo) and (hi is None or c < hi)
+                     and float((col - c).abs().min()) >= margin]
+            if cands:
+                t[idx] = cands[0]
+                break
+        else:
+            raise AssertionError("no tie-free value for an element of the target")
+    assert float((vals - t.unsqueeze(0)).abs().min()) >= 0.5 * margin
+    return t
+
+
+def detie_l1_target(target, preds, margin=1e-3):
+    """Gradient tests of the reference's l1 loss (cirim.py:218-237: mean | t / max t - |p| / max |p| |) compare two fp32 implementations whose
+    forward results differ by ~1e-7; the derivative of a term is its SIGN, so a term within round-off of zero -- or two pixels tying for max |p| --
+    makes the comparison a coin toss that says nothing about the kernels.  Returns a copy of `target` (real, >= 0, [B,H,W]) in
+    which every term of every estimate in `preds` (list of lists of complex [B,H,W], the oracle's forward) is at least `margin` away from zero,
+    moving only the tied pixels and never the maximum; asserts that every estimate's largest modulus leads the runner-up by 1e-4 (relative)."""
+    t = target.detach().clone().float()
+    tmax = float(t.abs().max())
+    pn = []
+    for cascade in preds:
+        for p in cascade:
+            a = p.detach().abs().float()
+            top = torch.topk(a.reshape(-1), 2).values
+            assert float(top[0] - top[1]) > 1e-4 * float(top[0]), "two pixels tie for max |p|: pick another slice for this test"
+            pn.append(a / top[0])
+    out = detie_terms((t / tmax).abs(), torch.stack(pn), margin, lo=0.0, hi=1.0 - margin) * tmax
+    out = torch.where(out == out, out, t)
+    keep = (t / tmax).abs() >= 1.0 - margin                 # the maximum (and anything that close to it) stays exactly what it was
+    out = torch.where(keep, t, out)
+    assert float(out.abs().max()) == tmax
+    return out

@@ -11,6 +11,12 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # full 64-step fp32 CIRIM chain rel-L2 <= 1e-4.  Index/mask/select work: bit-exact.
 OP_REL_L2 = 1e-5
 CHAIN_REL_L2 = 1e-4
+# Training (BASELINE config 4): whole-gradient rel-L2 of the HIP tape against each arithmetic of oracle/amp.py -- the same table bench.py records its
+# training parity against (tests/test_host_logic.py keeps the two equal).  bf16 results make the gradient discontinuous in the order of
+# the fp32 sums (a flipped rounding moves a ReLU mask): two CPU restatements of the kernels' arithmetic that differ only in fp32 / fp64 accumulation are
+# 5e-3 apart at 15 x 640 x 372 on the bench's weights (profiles/r04_training_parity_notes.md), hence 3e-2 for `kernel_arithmetic`; every kernel on its
+# own is checked to rounding flips in tests/test_gpu_train_bf16.py.
+TRAIN_TOL = dict(f32=dict(fp32=2e-3), bf16=dict(kernel_arithmetic=3e-2, autocast_bf16=5e-2, fp32=1e-1))
 
 
 class Golden:
@@ -73,44 +79,4 @@ def assert_exact(got, ref, what=""):
                              f"{float(diff.max()):.3e} (max |ref| {float(r.double().abs().max()):.3e})")
 
 
-def detie_terms(t, vals, margin, lo=None, hi=None):
-    """Copy of the real tensor `t` in which no element is within `margin` of the same element of any tensor stacked in `vals` [E, *t.shape]
-    (only the tied elements move, in steps of `margin`, staying inside (lo, hi))."""
-    t = t.detach().clone()
-    bad = ((vals - t.unsqueeze(0)).abs() < margin).any(0)
-    for idx in bad.nonzero().tolist():
-        idx = tuple(idx)
-        col, cur = vals[(slice(None),) + idx], float(t[idx])
-        for k in range(1, 400):
-            cands = [c for c in (cur - k * margin, cur + k * margin) if (lo is None or c > lo) and (hi is None or c < hi)
-                     and float((col - c).abs().min()) >= margin]
-            if cands:
-                t[idx] = cands[0]
-                break
-        else:
-            raise AssertionError("no tie-free value for an element of the target")
-    assert float((vals - t.unsqueeze(0)).abs().min()) >= 0.5 * margin
-    return t
-
-
-def detie_l1_target(target, preds, margin=1e-3):
-    """Gradient tests of the reference's l1 loss (cirim.py:218-237: mean | t / max t - |p| / max |p| |) compare two fp32 implementations whose
-    forward results differ by ~1e-7; the derivative of a term is its SIGN, so a term within round-off of zero -- or two pixels tying for max |p| --
-    makes the comparison a coin toss that says nothing about the kernels.  Returns a copy of `target` (real, >= 0, [B,H,W]) in
-    which every term of every estimate in `preds` (list of lists of complex [B,H,W], the oracle's forward) is at least `margin` away from zero,
-    moving only the tied pixels and never the maximum; asserts that every estimate's largest modulus leads the runner-up by 1e-4 (relative)."""
-    t = target.detach().clone().float()
-    tmax = float(t.abs().max())
-    pn = []
-    for cascade in preds:
-        for p in cascade:
-            a = p.detach().abs().float()
-            top = torch.topk(a.reshape(-1), 2).values
-            assert float(top[0] - top[1]) > 1e-4 * float(top[0]), "two pixels tie for max |p|: pick another slice for this test"
-            pn.append(a / top[0])
-    out = detie_terms((t / tmax).abs(), torch.stack(pn), margin, lo=0.0, hi=1.0 - margin) * tmax
-    out = torch.where(out == out, out, t)
-    keep = (t / tmax).abs() >= 1.0 - margin                 # the maximum (and anything that close to it) stays exactly what it was
-    out = torch.where(keep, t, out)
-    assert float(out.abs().max()) == tmax
-    return out
+from oracle.amp import detie_l1_target, detie_terms  # noqa: E402,F401  (the tie-free targets of the gradient comparisons live with the checkers)

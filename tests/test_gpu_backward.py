@@ -188,13 +188,16 @@ def test_llg_backward_is_its_own_adjoint(dev, mask_kind):
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_explicit_tape_matches_autograd_tape(dev, precision):
     """training.cirim_forward_backward (the written-out backward: accumulation inside the kernels, one cascade alive at a time) against the
-    torch-autograd tape over the same kernels: same loss, same gradients up to the order of the fp32 additions."""
+    torch-autograd tape over the same kernels: same loss, same gradients up to the order of the fp32 additions.  (bf16: the fp32-storage form of
+    the explicit tape -- the autograd tape's kernels; the bf16-storage tape has its own tests in test_gpu_train_bf16.py.)"""
     from mridc_amd import autograd as ag
     from mridc_amd import training
     cfg, model, state, s = _small_cirim(dev)
     batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
     assert training._tape_supported(model, batch)
     ag.set_precision(precision)
+    keep_storage = training.BF16_STORAGE
+    training.BF16_STORAGE = False
     try:
         model.train()
         etas = next(model(batch["y"], batch["sensitivity_maps"], batch["mask"], None, batch["target"]))
@@ -227,6 +230,7 @@ def test_explicit_tape_matches_autograd_tape(dev, precision):
         assert float(close) >= 0.98, float(close)
     finally:
         ag.set_precision("f32")
+        training.BF16_STORAGE = keep_storage
 
 
 @pytest.mark.parametrize("case", [(1, 2, 14, 37, 45, 3), (2, 14, 14, 20, 33, 3), (1, 28, 56, 16, 40, 3), (1, 56, 28, 19, 21, 3), (1, 64, 192, 12, 40, 1),

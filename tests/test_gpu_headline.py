@@ -573,32 +573,38 @@ def test_rim_block_fp16_route_on_and_off(dev, shape):
     assert rel_l2(outs[True], outs[False]) <= 5e-6
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 2e-3), ("bf16", 5e-2)])
-def test_one_cascade_training_at_headline_size(dev, precision, tol):
+@pytest.mark.parametrize("weights", ["bench", "boosted"])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_one_cascade_training_at_headline_size(dev, precision, weights):
     """BASELINE config 4 at the headline shape (base_cirim_train.yaml:175-180): ONE cascade (8 time-steps) of the CIRIM at 1 x 15 x 640 x 372,
-    forward + l1 loss + backward on the explicit tape (`training.cirim_forward_backward`: mrx_llg372 and its adjoint, the 960-tile persistent
-    weight-gradient kernels and their partial reduction, mrx_relu_bwd_acc on 61 MB planes, the data gradients) against torch autograd of the
-    oracle: the loss and all 11 parameter gradients.  fp32: every gradient rel-L2 <= 2e-3; bf16 (operands rounded to bf16, fp32 accumulation:
-    the reference's `precision: 16`): the whole gradient vector <= 5e-2 and the loss <= 2e-2."""
+    forward + l1 loss + backward on the explicit tape (`training.cirim_forward_backward`) against torch autograd of the oracle -- the loss and
+    all 11 parameter gradients -- on TWO sets of weights: the bench's (seed 0, reference initialisation: what `bench.py --train` reports its
+    parity on) and a boosted set (seed 5, biases 0.05, recurrent weights x 3: the ReLUs of the recurrence bite).
+    fp32: every gradient rel-L2 <= 2e-3.  bf16 (the reference's `precision: 16`): the whole gradient vector against each arithmetic of
+    oracle/amp.py within tests/_util.py TRAIN_TOL -- the kernels' own arithmetic restated on the CPU (tight: a kernel bug shows here),
+    torch.autocast (the reference's semantics) and fp32 (what bf16 costs; the autocast oracle itself sits 1e-2 .. 6e-2 from it)."""
     from mridc_amd import autograd as ag
     from mridc_amd import training
     from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    from tests._util import TRAIN_TOL
     cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=1)
-    torch.manual_seed(5)
+    seed, sl = (0, 0) if weights == "bench" else (5, 7)
+    torch.manual_seed(seed)
     model = CIRIM(cfg)
-    with torch.no_grad():
-        for n_, p_ in model.named_parameters():
-            if n_.endswith("bias"):
-                p_.normal_(0, 0.05)
-            if n_.endswith("rnn.ih.weight") or n_.endswith("rnn.hh"):
-                p_.mul_(3.0)                           # the reference init is nearly linear: make the ReLUs of the recurrence bite
+    if weights == "boosted":
+        with torch.no_grad():
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("bias"):
+                    p_.normal_(0, 0.05)
+                if n_.endswith("rnn.ih.weight") or n_.endswith("rnn.hh"):
+                    p_.mul_(3.0)                           # the reference init is nearly linear: make the ReLUs of the recurrence bite
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    s = synthetic.make_slice(15, 640, 372, slice_idx=7)
-    p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
-    pred = oracle.models.cirim_forward(p, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"])
-    T_ = oracle.models.cirim_time_steps(cfg["time_steps"])
-    ref_loss = oracle.models.cirim_process_loss(s["target"], pred, torch.nn.L1Loss(), T_, 1)
-    ref_loss.backward()
+    s = synthetic.make_slice(15, 640, 372, slice_idx=sl)
+    refs = {"fp32": oracle.amp.cirim_loss_and_gradients(state, cfg, s, "fp32")}
+    if precision == "bf16":
+        refs["autocast_bf16"] = oracle.amp.cirim_loss_and_gradients(state, cfg, s, "autocast_bf16")
+        emul = dict(round_results=True) if training.BF16_STORAGE else dict(fp32_forward=((64, 2),))
+        refs["kernel_arithmetic"] = oracle.amp.cirim_loss_and_gradients(state, cfg, s, "bf16_operands", **emul)
     model = model.to(dev).train()
     batch = {k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")}
     assert training._tape_supported(model, batch)
@@ -609,20 +615,18 @@ def test_one_cascade_training_at_headline_size(dev, precision, tol):
         loss = training.cirim_forward_backward(model, batch, precision)
     finally:
         ag.set_precision("f32")
-    lg, lr_ = float(loss), float(ref_loss.detach())
-    assert abs(lg - lr_) <= (1e-5 if precision == "f32" else 2e-2) * abs(lr_), (lg, lr_)
-    got_all, ref_all, checked = [], [], 0
-    for name, prm in model.named_parameters():
-        if name.endswith("dc_weight"):
-            continue
-        ref = p[name].grad
-        assert ref is not None and prm.grad is not None, name
-        if precision == "f32":
-            assert_close(prm.grad, ref, tol, f"gradient of {name} at 15 x 640 x 372")
-        got_all.append(prm.grad.detach().cpu().reshape(-1).double())
-        ref_all.append(ref.reshape(-1).double())
-        checked += 1
-    assert checked == 11
-    got_all, ref_all = torch.cat(got_all), torch.cat(ref_all)
-    whole = float((got_all - ref_all).norm() / ref_all.norm())
-    assert whole <= tol, whole
+    names = [n_ for n_, _ in model.named_parameters() if not n_.endswith("dc_weight")]
+    assert len(names) == 11
+    grads = dict(model.named_parameters())
+    got_all = torch.cat([grads[n_].grad.detach().cpu().reshape(-1).double() for n_ in names])
+    errs = {}
+    for m_, (ref_loss, ref_g) in refs.items():
+        want = torch.cat([ref_g[n_].reshape(-1).double() for n_ in names])
+        errs[m_] = (float((got_all - want).norm() / want.norm()), abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
+    print(f"training parity at 15 x 640 x 372, {precision}, {weights} weights (whole gradient, loss):", errs)
+    if precision == "f32":
+        assert errs["fp32"][1] <= 1e-5, errs
+        for n_ in names:
+            assert_close(grads[n_].grad, refs["fp32"][1][n_], 2e-3, f"gradient of {n_} at 15 x 640 x 372")
+    for m_, tol in TRAIN_TOL[precision].items():
+        assert errs[m_][0] <= tol and errs[m_][1] <= 2e-2, (m_, errs)

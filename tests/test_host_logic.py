@@ -163,6 +163,16 @@ def test_default_paths_are_the_fused_ones():
     assert ops.rim_layer1_inplace_ok(4, 64, 5, 1) and not ops.rim_layer1_inplace_ok(4, 64, 3, 1)
 
 
+def test_bench_and_tests_state_the_same_training_tolerances():
+    import importlib.util
+    import os
+    from tests._util import TRAIN_TOL
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.TRAIN_TOL == TRAIN_TOL
+
+
 def test_no_object_of_the_library_contains_packed_fp32_instructions(tmp_path):
     """DESIGN.md 5, "Concurrent streams": no kernel of the library may issue packed-fp32 vector instructions -- on MI355X v_pk_*_f32 with operand
     modifiers returns wrong results while a foreign wave on the same SIMD issues v_mfma_f32_16x16x32_f16 (tools/probe/pk_mfma_repro.hip reproduces it

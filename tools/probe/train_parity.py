@@ -12,11 +12,14 @@ from mridc_amd.collections.reconstruction.models.cirim import CIRIM
 C, H, W = [int(v) for v in sys.argv[1:4]] if len(sys.argv) > 3 else (15, 640, 372)
 prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
 quick = "--quick" in sys.argv          # fp32 oracle only, the bench's weights only
+ncasc = int(sys.argv[sys.argv.index("--cascades") + 1]) if "--cascades" in sys.argv else 1
+slice_override = int(sys.argv[sys.argv.index("--slice") + 1]) if "--slice" in sys.argv else None
 dev = torch.device("cuda:0")
 # the arithmetic the tape claims: bf16 storage (training.BF16_STORAGE) rounds results too; the round-2 tape keeps the final convolution's forward in fp32
 emul = dict(round_results=True) if training.BF16_STORAGE else dict(fp32_forward=((64, 2),))
 for seed, boost, sl in (((0, 1.0, 0),) if quick else ((0, 1.0, 0), (5, 3.0, 7))):
-    cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=1)
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=ncasc)
+    sl = sl if slice_override is None else slice_override
     torch.manual_seed(seed)
     model = CIRIM(cfg)
     with torch.no_grad():
@@ -51,3 +54,7 @@ for seed, boost, sl in (((0, 1.0, 0),) if quick else ((0, 1.0, 0), (5, 3.0, 7)))
             tot[m][1] += float(r.norm() ** 2)
         print(line)
     print("   whole vector: " + "  ".join(f"{m} {(tot[m][0] / tot[m][1]) ** 0.5:.3e}" for m in refs), flush=True)
+    flat = {m: torch.cat([refs[m][1][n].reshape(-1).double() for n, _ in model.named_parameters() if not n.endswith("dc_weight")]) for m in refs}
+    ms = list(refs)
+    print("   oracle vs oracle (this host's CPU): " + "  ".join(f"{a_}-{b_} {float((flat[a_] - flat[b_]).norm() / flat[b_].norm()):.3e}"
+                                                              for i, a_ in enumerate(ms) for b_ in ms[i + 1:]), flush=True)

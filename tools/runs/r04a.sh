@@ -7,10 +7,10 @@ timeout 900 python tools/probe/train_parity.py > $O/train_parity.txt 2>&1
 NOPK=$PWD/mridc_amd/lib_nopk/libmridc_amd.so
 for v in base nopk; do
   if [ $v = nopk ]; then export MRIDC_AMD_LIB=$NOPK; else unset MRIDC_AMD_LIB; fi
-  timeout 600 python bench.py --no-cpu-baseline --no-other-configs --steps 20 --warmup 3 > $O/bench_cirim_$v.json 2> $O/bench_cirim_$v.err
-  timeout 600 python bench.py --no-cpu-baseline --no-other-configs --model e2evn --steps 20 --warmup 3 > $O/bench_e2evn_$v.json 2> $O/bench_e2evn_$v.err
-  timeout 600 python bench.py --no-cpu-baseline --no-other-configs --model qcirim --steps 20 --warmup 3 > $O/bench_qcirim_$v.json 2> $O/bench_qcirim_$v.err
-  timeout 600 python bench.py --no-cpu-baseline --no-other-configs --train --dtype bf16 --steps 3 --warmup 1 > $O/bench_train_$v.json 2> $O/bench_train_$v.err
+  timeout 600 python bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs --steps 20 --warmup 3 > $O/bench_cirim_$v.json 2> $O/bench_cirim_$v.err
+  timeout 600 python bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs --model e2evn --steps 20 --warmup 3 > $O/bench_e2evn_$v.json 2> $O/bench_e2evn_$v.err
+  timeout 600 python bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs --model qcirim --steps 20 --warmup 3 > $O/bench_qcirim_$v.json 2> $O/bench_qcirim_$v.err
+  timeout 600 python bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs --train --dtype bf16 --steps 3 --warmup 1 > $O/bench_train_$v.json 2> $O/bench_train_$v.err
 done
 export MRIDC_AMD_LIB=$NOPK
 timeout 1500 python -m pytest tests -m gpu -q -x --deselect tests/test_host_logic.py > $O/pytest_nopk.txt 2>&1

@@ -7,6 +7,6 @@ grep -n "MISMATCH\|cells with" $O/pk_repro_v2.txt
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1
 tail -15 $O/pytest.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-other-configs --steps 10 --warmup 2 > $GRAFT_REPO_ROOT/$O/bench_prof.json 2> $GRAFT_REPO_ROOT/$O/bench_prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs --steps 10 --warmup 2 > $GRAFT_REPO_ROOT/$O/bench_prof.json 2> $GRAFT_REPO_ROOT/$O/bench_prof.err
 cd $GRAFT_REPO_ROOT
 ls -R $O/prof | head; python tools/rocprof_summary.py $O/prof 2>/dev/null | head -20

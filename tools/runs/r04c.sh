@@ -12,5 +12,5 @@ timeout 900 python -m pytest tests/test_gpu_train_bf16.py -q -s > $O/pytest_trai
 tail -40 $O/pytest_train_bf16.txt
 timeout 900 python tools/probe/train_parity.py > $O/train_parity_tl.txt 2>&1
 tail -30 $O/train_parity_tl.txt
-timeout 600 python bench.py --no-cpu-baseline --no-other-configs --train --dtype bf16 --steps 3 --warmup 1 > $O/bench_train.json 2> $O/bench_train.err
+timeout 600 python bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs --train --dtype bf16 --steps 3 --warmup 1 > $O/bench_train.json 2> $O/bench_train.err
 cat $O/bench_train.json | head -c 600
