@@ -458,7 +458,9 @@ def bench_qcirim(args, world, rank, dev, checks=False):
                 achieved=issued / (msh * 1e-3) / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", frac=issued / (msh * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                 frac_meaning="fp16 MFMA FLOPs the kernel issues (3 term products, slot padding included) / dense fp16 MFMA peak",
                 algorithmic_achieved=direct / (msh * 1e-3) / 1e12, launches=nh, avg_ms=msh, flops_per_launch=direct, mfma_flops_per_launch=issued,
-                traffic=None, algorithmic_bytes=2.0 * 128 * H * W * 4, hbm_frac=2.0 * 128 * H * W * 4 / (msh * 1e-3) / 1e9 / PEAK_HBM_GBS)
+                traffic=measured_traffic(1, 15, 640, 372, 64).get("qcirim_conv3x3_h_128") if (H, W) == (256, 256) else None, traffic_unit="bytes/launch",
+                mfma_util_pmc=(measured_traffic(1, 15, 640, 372, 64).get("_mfma_util") or {}).get("qcirim_conv3x3_h_128") if (H, W) == (256, 256) else None,
+                algorithmic_bytes=2.0 * 128 * H * W * 4, hbm_frac=2.0 * 128 * H * W * 4 / (msh * 1e-3) / 1e9 / PEAK_HBM_GBS)
         else:
             ms, n = timer.mean_ms("wino_128x128")
             issued = direct * 4.0 / 9.0                     # Winograd F(2x2,3x3): 16 instead of 36 multiplies per 2x2 outputs
@@ -590,7 +592,12 @@ def bench_e2evn(args, world, rank, dev, checks=False):
                                                               "layer's normalisation + LeakyReLU and the operand split in the tile loader)",
                                        achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=(gbs / PEAK_HBM_GBS) if gbs else None,
                                        frac_meaning="algorithmic bytes of the launch (inputs read once + outputs written once) / 8 TB/s", launches=n, avg_ms=ms,
-                                       traffic=None, algorithmic_bytes=nbytes, flops_per_launch=flops,
+                                       # counter traffic exists for the 14 -> 14 layer at 4 x 640 x 384 (tools/probe/pmc_r04.py): the shape this record names by default
+                                       traffic=(measured_traffic(1, 15, 640, 372, 64).get("e2evn_uconv_h_14to14") if (int(cin), int(cout), hh_, ww_, B) == (14, 14, 640, 384, 4) else None),
+                                       traffic_unit="bytes/launch",
+                                       mfma_util_pmc=((measured_traffic(1, 15, 640, 372, 64).get("_mfma_util") or {}).get("e2evn_uconv_h_14to14")
+                                                      if (int(cin), int(cout), hh_, ww_, B) == (14, 14, 640, 384, 4) else None),
+                                       algorithmic_bytes=nbytes, flops_per_launch=flops,
                                        mfma_frac=(3.0 * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if ms else None,
                                        all_unet_conv3x3_ms_per_step=all_ms)
             else:
@@ -655,11 +662,22 @@ def bench_train(args, world, rank, dev, checks=False):
         timer.wrap(ops, "conv2d_bf16", lambda x, w, b_, dil=1, *a_, **k: "conv_bf16 %dx%d %d->%d d%d%s" % (
             int(w.shape[2]), int(w.shape[3]), int(w.shape[0] if k.get("transposed") else w.shape[1]),
             int(w.shape[1] if k.get("transposed") else w.shape[0]), int(dil), " (data gradient)" if k.get("transposed") else ""))
+        # the bf16-storage tape (round 4)
+        timer.wrap(ops, "tl_cell_bwd", lambda *a_, **k: "tl_cell_bwd")
+        timer.wrap(ops, "tl_layer_fwd", lambda x, *a_, **k: "tl_layer_fwd %d->64" % int(x.shape[1]))
+        timer.wrap(ops, "conv_wgrad_bf16_pairs", lambda x, dy, kk, *a_, **k: "wgrad from pairs %dx%d %d->64" % (int(kk), int(kk), int(x.shape[1])))
+        timer.wrap(ops, "tl_dgrad", lambda dy, w, *a_, **k: "tl_dgrad %d->%d (+ edge fold)" % (int(w.shape[0]), int(w.shape[1])))
     losses = []
     for _ in range(max(args.warmup, 1)):
         losses.append(float(step_fn(model, flat, opt, batch)))
     if checks:
-        _event_profile(timer, lambda d: step_fn(model, flat, opt, d), batch, n=1)
+        keep_side = training.TL_SIDE_STREAM
+        training.TL_SIDE_STREAM = False                  # the profiled step serially: a kernel's events must not contain a neighbour from the side stream
+        try:
+            _event_profile(timer, lambda d: step_fn(model, flat, opt, d), batch, n=1)
+        finally:
+            training.TL_SIDE_STREAM = keep_side
+        step_fn(model, flat, opt, batch)                 # untimed: back to the two-stream form (the serial profiled step left the side stream's pool cold)
     dist_barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -687,7 +705,9 @@ def bench_train(args, world, rank, dev, checks=False):
                                     f"{H}x{W}: forward + l1 loss + backward (HIP kernels) + one all-reduce of the flat gradient "
                                     f"({flat.numel * 4 / 1e6:.2f} MB) + Adam, 1 slice per GPU and step"
                                     + ("; convolutions and IndRNN GEMMs on bf16 operands with fp32 accumulation (forward, data and "
-                                       "weight gradients), FFT / data consistency / eta / loss / Adam in fp32" if args.dtype == "bf16"
+                                       "weight gradients), their results -- and the gradients flowing into them -- STORED in bf16 (the rounding points of "
+                                       "torch.autocast: what the reference's `precision: 16` does), hidden states / FFT / data consistency / eta / loss / "
+                                       "parameter-gradient sums / Adam in fp32; weight gradients on a second HIP stream" if args.dtype == "bf16"
                                        else ""),
                            global_batch=world, parallelism=f"data-parallel x{world}", gradient_bytes=flat.numel * 4),
                loss_first=losses[0], loss_last=losses[-1])
@@ -696,14 +716,27 @@ def bench_train(args, world, rank, dev, checks=False):
         if tot:
             key = max(tot, key=tot.get)
             ms, n = timer.mean_ms(key)
-            chans = key.split(" ")[2].split("->")
-            nbytes = (int(chans[0]) + int(chans[1])) * H * W * 4.0            # x in, y out: fp32 tensors in HBM, rounded to bf16 by the tile loader
-            res["roofline"] = dict(bound="hbm", kernel=f"k_conv_bf16 via mrx_conv2d_bf16 ({key}; fp32 tensors in HBM, bf16 MFMA operands, fp32 accumulation) -- "
-                                                        "the kernel with the largest share of a training step",
-                                   achieved=(nbytes / (ms * 1e-3) / 1e9) if ms else None, peak=PEAK_HBM_GBS, unit="GB/s",
-                                   frac=(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms else None, launches=n, avg_ms=ms, bytes_per_launch=nbytes, traffic=None,
-                                   share_of_step={k: v / 1.0 for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:4]},
-                                   share_unit="ms of one profiled step (HIP events)")
+            share = {k: v / 1.0 for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:6]}
+            table = measured_traffic(1, 15, 640, 372, 64) if (C, H, W) == (15, 640, 372) else {}
+            if key == "tl_cell_bwd":
+                # bytes of one launch: dh_above (pairs, 2 B) + dH + h + h_prev (fp32) + a (pairs) read, dh_prev (fp32) + ga (pairs) written, 64 channels
+                nbytes = (2 + 4 + 4 + 4 + 2 + 4 + 2) * 64.0 * H * W
+                res["roofline"] = dict(bound="hbm", kernel="k_tl_cell_bwd via mrx_tl_cell_bwd: the backward of an IndRNN layer's cell and of its convolution's ReLU in one pass -- "
+                                                            "g = (dh_above + dH) (h > 0), dh_prev, the hh / bias sums, da = bf16(W_ih^T bf16(g)) and dW_ih += bf16(g) a^T on "
+                                                            "v_mfma_f32_32x32x16_bf16, ga = da (a > 0) as a pair tensor (replaces five launches of the fp32-storage tape); the kernel "
+                                                            "with the largest share of a training step",
+                                       achieved=(nbytes / (ms * 1e-3) / 1e9) if ms else None, peak=PEAK_HBM_GBS, unit="GB/s",
+                                       frac=(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms else None, launches=n, avg_ms=ms, bytes_per_launch=nbytes,
+                                       traffic=table.get("train_cell_bwd"), traffic_unit="bytes/launch", traffic_source=table.get("_source"),
+                                       mfma_util_pmc=(table.get("_mfma_util") or {}).get("train_cell_bwd"),
+                                       share_of_step=share, share_unit="ms of one profiled step (HIP events, side stream off)")
+            else:
+                chans = key.split(" ")[2].split("->") if key.startswith("conv_bf16") else ["64", "64"]
+                nbytes = (int(chans[0]) + int(chans[1])) * H * W * 4.0            # x in, y out: fp32 tensors in HBM, rounded to bf16 by the tile loader
+                res["roofline"] = dict(bound="hbm", kernel=f"{key} -- the kernel with the largest share of a training step",
+                                       achieved=(nbytes / (ms * 1e-3) / 1e9) if ms else None, peak=PEAK_HBM_GBS, unit="GB/s",
+                                       frac=(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms else None, launches=n, avg_ms=ms, bytes_per_launch=nbytes, traffic=None,
+                                       share_of_step=share, share_unit="ms of one profiled step (HIP events)")
         try:
             import oracle
             from mridc_amd import autograd as ag2

@@ -290,24 +290,31 @@ __device__ __forceinline__ int s2_pixel_exp(float m) {
 // CB8: x, h_prev and h_new are channel-blocked, [b][c / 8][y][x][c % 8] (mrx_cb8_convert): a pixel's eight channels of a chunk are 32 contiguous
 // bytes for the loader (2 x 16-byte loads instead of 8 x 4 from eight planes), registers 4 q .. 4 q + 3 of a lane are four consecutive channels of
 // block q (8 + 8 16-byte state accesses per row instead of 32 + 32 4-byte ones).  The arithmetic is unchanged: results are bit-identical.
-template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false>
-__global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
-    constexpr int S2_PAD = DIL, S2_PH = S2_TH + 2 * DIL, S2_PW = S2_TW + 2 * DIL, S2_NPIX = S2_PH * S2_PW;
+// W4 (round 4): FOUR waves per workgroup on an 8 x 32 tile, the 1x1 / final-convolution operands read from L2 instead of LDS (they feed 36 MFMAs per
+// 32 pixels, once per row tail) -- 65 KB of LDS and <= 256 registers, so TWO workgroups share a CU with independent barriers: while one is in its row
+// tails or waits for a chunk, the other one's convolution owns the matrix pipe of the same SIMDs (the eight waves of the 16 x 32 form sit in the same
+// phase between barriers: 44.9 k cycles of chunk loop for 27.6 k of MFMA issue, tails with the pipe idle).  Same arithmetic, same pack: bit-identical.
+template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false, bool W4 = false>
+__global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(L2sbArgs a) {
+    constexpr int NTHR = W4 ? 256 : S2_NT, TH = W4 ? 8 : S2_TH;
+    constexpr int S2_PAD = DIL, S2_PH = TH + 2 * DIL, S2_PW = S2_TW + 2 * DIL, S2_NPIX = S2_PH * S2_PW;
     constexpr int NT = F16 ? 2 : 3;                                        // operand terms of the convolution stage
     constexpr int WFULL = F16 ? S2F_WFULL : S2_WFULL, WCH = F16 ? S2F_WCH : S2_WCH;
     constexpr int PK_TAIL = S2_NCH * WCH;                                  // where the 1x1 / final-conv operands start in the pack
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
-    u32x4* Wih = reinterpret_cast<u32x4*>(smem_s2);
-    float* tabl = reinterpret_cast<float*>(smem_s2 + S2_OFF_TAB);      // hh, b_conv, b_ih in register order [half][R] (a lane's 32 values contiguous: 16-byte LDS reads)
-    u32x4* Wc = reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_W);          // [2][S2_WCH]
-    u32x4* Xp = reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_X);          // [2][NT terms][S2_NPIX]
+    constexpr int OFF_TAB = W4 ? 0 : S2_OFF_TAB, OFF_ZERO = OFF_TAB + 1008, OFF_W = OFF_TAB + 1024;
+    constexpr int OFF_X = W4 ? OFF_W + 2 * WCH * 16 : S2_OFF_X;
+    const u32x4* Wih = W4 ? a.packed + PK_TAIL : reinterpret_cast<const u32x4*>(smem_s2);   // (1x1 operands, then the final convolution's)
+    float* tabl = reinterpret_cast<float*>(smem_s2 + OFF_TAB);      // hh, b_conv, b_ih in register order [half][R] (a lane's 32 values contiguous: 16-byte LDS reads)
+    u32x4* Wc = reinterpret_cast<u32x4*>(smem_s2 + OFF_W);             // [2][S2_WCH]
+    u32x4* Xp = reinterpret_cast<u32x4*>(smem_s2 + OFF_X);             // [2][NT terms][S2_NPIX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const long long plane = (long long)a.H * a.W;
     const int total = a.ntiles * a.B;
 
     // once per workgroup: 1x1 weights and tables
-    if (TAIL)
-        for (int i = tid; i < S2_WIH + S2_WP; i += S2_NT) Wih[i] = a.packed[PK_TAIL + i];  // (the final-conv operands follow the 1x1 ones)
+    if (TAIL && !W4)
+        for (int i = tid; i < S2_WIH + S2_WP; i += NTHR) reinterpret_cast<u32x4*>(smem_s2)[i] = a.packed[PK_TAIL + i];  // (the final-conv operands follow the 1x1 ones)
     // F16: x is multiplied by 2^kx (the producer's bound of max |x| lands in [2^14, 2^15)), the weights were by 2^kw; the accumulators
     // are scaled back (exactly) before the bias
     float sx = 1.f, unx = 1.f, unw = 1.f;
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         sx = s2_pow2(kx), unx = s2_pow2(-kx), unw = s2_pow2(-kw);
     }
     const float unwi = F16 ? s2_pow2(-(int)a.packed[S2F_PACK_U4 - 1][1]) : 1.f, unwp = F16 ? s2_pow2(-(int)a.packed[S2F_PACK_U4 - 1][2]) : 1.f;
-    if (tid == 0) *reinterpret_cast<u32x4*>(smem_s2 + S2_OFF_ZERO) = u32x4{0u, 0u, 0u, 0u};
+    if (tid == 0) *reinterpret_cast<u32x4*>(smem_s2 + OFF_ZERO) = u32x4{0u, 0u, 0u, 0u};
     if (tid < 64) {
         const int tc = s2_chan(tid >> 1, tid & 1);
         const int ti = (tid & 1) * 32 + (tid >> 1);
@@ -326,8 +333,8 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     }
 
     // staging roles: thread i owns pixels i and i + 512 of the halo'd tile (8 channels of the chunk) and copies <= 4 weight operands
-    constexpr int XV = (S2_NPIX + S2_NT - 1) / S2_NT;                 // 2
-    constexpr int WV = (WCH + S2_NT - 1) / S2_NT;                     // 4 (F16: 3)
+    constexpr int XV = (S2_NPIX + NTHR - 1) / NTHR;                 // 2
+    constexpr int WV = (WCH + NTHR - 1) / NTHR;                     // 4 (F16: 3)
 
     // The staging pipeline runs two chunks ahead of the MFMAs and across tile boundaries: while chunk q of a tile is multiplied, chunk q + 1
     // is split and written (mid-chunk: the vector ALU work rides under the other wave's MFMAs) and chunk q + 2 is requested; the first
@@ -340,11 +347,11 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         if (st_t >= total) return;
         const int tt = (int)mrx_xcd_band(st_t, total);
         const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
-        const int h0 = ty0 * S2_TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
+        const int h0 = ty0 * TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
         st_xb = a.x + (long long)b * S2_F * plane;
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
-            int p = tid + v * S2_NT;
+            int p = tid + v * NTHR;
             p = p < S2_NPIX ? p : S2_NPIX - 1;
             const int ty = p / S2_PW, tx = p - ty * S2_PW;
             int gy = h0 + ty - S2_PAD, gx = w0 + tx - S2_PAD;            // replicate border = clamp (conv_layers.py:72-76)
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
             }
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
-            const int i = tid + v * S2_NT;
+            const int i = tid + v * NTHR;
             wr[v] = a.packed[(long long)st_q * WCH + (i < WCH ? i : WCH - 1)];
         }
         if (++st_q == S2_NCH) {
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         if (!pending) return;
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
-            const int p = tid + v * S2_NT;
+            const int p = tid + v * NTHR;
             unsigned p1[4], p2[4], p3[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         }
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
-            const int i = tid + v * S2_NT;
+            const int i = tid + v * NTHR;
             if constexpr ((ABL & 4) != 0) asm volatile("" ::"v"(wr[v]));
             else if (i < WCH) Wc[buf * WCH + i] = wr[v];
         }
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int tt = (int)mrx_xcd_band(t, total);
         const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
-        const int h0 = ty0 * S2_TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
+        const int h0 = ty0 * TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
 
 #define S2_STAMP(i) if (a.trace && lane == 0 && (t - (int)blockIdx.x) / (int)gridDim.x < 2) a.trace[(((long long)blockIdx.x * 8 + wave) * 2 + (t - blockIdx.x) / gridDim.x) * 4 + (i)] = __builtin_readcyclecounter();
         S2_STAMP(0)
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
                 f32x16 accp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accp[r] = 0.f;
-                const u32x4* wp = reinterpret_cast<const u32x4*>(smem_s2 + S2_OFF_WP) + lane;
+                const u32x4* wp = Wih + S2_WIH + lane;
                 if constexpr (F16) {
                     float hm = 0.f;
 #pragma unroll
@@ -750,11 +757,11 @@ __global__ __launch_bounds__(S2_NT, 1) void k_rim_layer2_sb(L2sbArgs a) {
         if (a.xmax_out) {           // one conditional atomic per workgroup (bit patterns of non-negative floats order like unsigned integers)
             for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
             __syncthreads();        // (every wave is past its last operand read: the start of the x planes is free)
-            float* red = reinterpret_cast<float*>(smem_s2 + S2_OFF_X);
+            float* red = reinterpret_cast<float*>(smem_s2 + OFF_X);
             if (lane == 0) red[wave] = vmax;
             __syncthreads();
             if (tid == 0) {
-                for (int w = 1; w < S2_NT / 64; ++w) vmax = fmaxf(vmax, red[w]);
+                for (int w = 1; w < NTHR / 64; ++w) vmax = fmaxf(vmax, red[w]);
                 if (__float_as_uint(vmax) > __hip_atomic_load(a.xmax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.xmax_out, __float_as_uint(vmax));
             }
         }
@@ -783,14 +790,17 @@ static int l2sb_ncu() {
     }
     return ncu;
 }
-template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false>
+template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false, bool W4 = false>
 static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
+    constexpr int WCH_ = F16 ? S2F_WCH : S2_WCH, NT_ = F16 ? 2 : 3;
+    constexpr int lds = W4 ? 1024 + 2 * WCH_ * 16 + 2 * NT_ * (8 + 2 * DIL) * (S2_TW + 2 * DIL) * 16 : (int)S2_LDS;
     static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8, W4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    const int ncu = l2sb_ncu();
+    if (W4) a.ntiles = a.tiles_x * mrx_cdiv(a.H, 8);                   // 8 x 32 tiles
+    const int ncu = (W4 ? 2 : 1) * l2sb_ncu();                          // two 4-wave workgroups per CU
     const long long total = (long long)a.ntiles * a.B;
     const int grid = (int)(total < ncu ? total : ncu);
     a.trace = nullptr;
@@ -800,7 +810,7 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, st);
         a.trace = d_trace;
     }
-    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8>), dim3(grid), dim3(S2_NT), S2_LDS, st, a);
+    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8, W4>), dim3(grid), dim3(W4 ? 256 : S2_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     if (a.trace) {
         (void)hipStreamSynchronize(st);
@@ -852,6 +862,9 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
             default: break;
         }
     }
+#endif
+#ifdef MRX_L2_W4
+    if (xmax && cb8) return l2sb_launch_t<2, true, false, true, 0, true, true>(a, (hipStream_t)stream);
 #endif
     if (xmax && cb8) return l2sb_launch_t<2, true, false, true, 0, true>(a, (hipStream_t)stream);
     MRX_REQUIRE(!cb8, MRX_EUNSUP, "mrx_rim_layer2_f16_cb8: the channel-blocked layout exists for the two-term fp16 form only");

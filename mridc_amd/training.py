@@ -116,6 +116,18 @@ def inverse_sqrt_lr(step, max_steps, base_lr, warmup_ratio=0.1, min_lr=0.0, warm
 # bf16 mode: True = convolution results and their gradients are STORED in bf16 too (pair tensors, the rounding points of torch.autocast:
 # _cascade_forward_backward_tl); False = bf16 operands with fp32 storage (the round-2 kernels; a test hook and the fallback for other layer shapes)
 BF16_STORAGE = True
+# The weight gradients of a time-step hang off the backward chain (cell -> data gradient -> cell -> ... -> adjoint of the likelihood gradient) as side
+# branches: they run on a second HIP stream next to it (every kernel of the chain leaves CUs idle: one or two workgroups per CU waiting for their tiles).
+# Each stream keeps its own fixed order, so the gradients stay bit-reproducible.
+TL_SIDE_STREAM = True
+_SIDE = {}
+
+
+def _side_stream(device):
+    st = _SIDE.get(str(device))
+    if st is None:
+        st = _SIDE[str(device)] = torch.cuda.Stream(device=device)
+    return st
 
 
 # ---- the explicit tape ------------------------------------------------------------------------------------------------------------------
@@ -328,6 +340,23 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
         losses.append(out2)
         eta = eta_new
     parts = [ops.tl_cell_part(B, H, W, eta.device) for _ in range(nl)]
+    main = torch.cuda.current_stream()
+    side = _side_stream(eta.device) if TL_SIDE_STREAM and not torch.cuda.is_current_stream_capturing() else None
+
+    def on_side(fn, *inputs):
+        """fn() on the side stream once everything `main` has queued so far is done; `inputs` were allocated on main and stay alive for it."""
+        if side is None:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            fn()
+        for t in inputs:
+            t.record_stream(side)
+
+    for p in [fw] + [q for st in blk.layers for q in (st.convs.conv_layer.weight,)]:
+        _grad_of(p)                                                    # (allocated on the main stream, before any side-stream accumulation)
     carry, dH = None, [None] * nl
     for ti, (acts, eta_t, m, out2) in enumerate(reversed(saved)):
         gl = torch.empty_like(eta_t)
@@ -337,7 +366,8 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
         d2 = torch.empty(B, 2, H, W, dtype=torch.float32, device=eta_t.device)
         _lib.check(L_.mrx_eta_grad_in(_lib.ptr(carry), _lib.ptr(gl), _lib.ptr(tot), _lib.ptr(d2), B, plane, _lib.stream_ptr()), "mrx_eta_grad_in")
         # final convolution (its result is a bf16 tensor under autocast: both gradient kernels round d2 to bf16 on load)
-        _wgrad_into(acts[-1][2], d2, 3, 1, ops.PAD_REPLICATE, _grad_of(fw), True)
+        h_top = acts[-1][2]
+        on_side(lambda h_top=h_top, d2=d2: _wgrad_into(h_top, d2, 3, 1, ops.PAD_REPLICATE, _grad_of(fw), True), h_top, d2)
         dh = ops.tl_dgrad(d2, fw, 1, dx_pairs=True)
         for li in range(nl - 1, -1, -1):
             st = blk.layers[li]
@@ -346,7 +376,8 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
             dhp, ga = ops.tl_cell_bwd(dh, dH[li], h, h_prev, a_p, r.ih.weight, fw if li == nl - 1 else None, r.hh, parts[li], ti == 0)
             dH[li] = dhp
             cw = c.conv_layer.weight
-            ops.conv_wgrad_bf16_pairs(x_in, ga, c.kernel_size, c.dilation, ops.PAD_REPLICATE, out=_grad_of(cw), accumulate=True)
+            on_side(lambda x_in=x_in, ga=ga, c=c, cw=cw: ops.conv_wgrad_bf16_pairs(x_in, ga, c.kernel_size, c.dilation, ops.PAD_REPLICATE,
+                                                                                  out=_grad_of(cw), accumulate=True), x_in, ga)
             dh = ops.tl_dgrad(ga, cw, c.dilation, dx_pairs=li > 0)
         dg4 = dh                                                       # [B,4,H,W] fp32 (bf16 values): gradient w.r.t. cat(eta, log-likelihood gradient)
         dz = torch.empty_like(eta_t)
@@ -355,6 +386,8 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
         carry = torch.empty_like(eta_t)
         _lib.check(L_.mrx_eta_grad_out(_lib.ptr(tot), _lib.ptr(dg4), _lib.ptr(t4), _lib.ptr(carry), B, plane, _lib.stream_ptr()),
                    "mrx_eta_grad_out")
+    if side is not None:
+        main.wait_stream(side)                                         # the weight gradients of this cascade are final (its slice may be all-reduced now)
     for li, st in enumerate(blk.layers):                               # the cell kernels' partial sums of the whole cascade -> the gradients
         c, r = st.convs, st.rnn
         ops.tl_cell_reduce(parts[li], B, H, W, _grad_of(r.ih.weight), _grad_of(r.ih.bias) if r.ih.bias is not None else None,

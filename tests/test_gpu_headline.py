@@ -495,12 +495,23 @@ def test_general_mask_gradient_column_tiled_at_w372(dev, case):
     t4 = ops._y_t4(yd)
     want_t4 = yd.reshape(B * C, H, 93, 4, 2).permute(0, 2, 1, 3, 4).contiguous()
     assert torch.equal(t4.reshape(-1), want_t4.reshape(-1))
-    # deferred form
-    part, n = ops.llg(ed, yd, Sd, md, sigma, centered, norm, parts=True)
-    assert n == -(-C // 5)
+    # deferred form: the coil-group partial sums of the last pass + (round 4) ONE constant plane -A^H M y instead of y in every column pass
     wd, bd, wid, bid, hhd = (t.to(dev) for t in (w, b, wi, bi, hh))
-    h_def = ops.rim_layer_indrnn_packed_llg(ed, part, n, sigma, ops.rim_layer_pack(wd, wid), 64, 5, 1, bd, bid, hhd, hp)
-    assert_close(h_def, h_ref, 1e-5, "layer 1 reading the general-mask partial sums vs oracle")
+    keep_noy = ops.LLG_T4_NO_Y
+    try:
+        for no_y in (True, False):
+            ops.LLG_T4_NO_Y = no_y
+            part, n = ops.llg(ed, yd, Sd, md, sigma, centered, norm, parts=True)
+            assert n == -(-C // 5) + (1 if no_y else 0)
+            if no_y:
+                total = part[:n].sum(0) / sigma ** 2          # the planes add up to the gradient's last two channels
+                assert_close(total, g_ref[:, 2:4].permute(0, 2, 3, 1), 1e-5, "partial planes incl. the constant one vs oracle")
+                again, n2 = ops.llg(ed, yd, Sd, md, sigma, centered, norm, parts=True)
+                assert again.data_ptr() == part.data_ptr() and n2 == n                # one buffer per slice: the constant plane is made once
+            h_def = ops.rim_layer_indrnn_packed_llg(ed, part, n, sigma, ops.rim_layer_pack(wd, wid), 64, 5, 1, bd, bid, hhd, hp)
+            assert_close(h_def, h_ref, 1e-5, f"layer 1 reading the general-mask partial sums vs oracle (constant plane: {no_y})")
+    finally:
+        ops.LLG_T4_NO_Y = keep_noy
 
 
 def test_rim_block_general_mask_at_w372(dev):

@@ -18,8 +18,19 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "conv_layer2_f16": ["k_rim_layer2_sb<2, true, false, true"],
     "final": ["k_rim_final4"],
     "final_gather": ["k_l2sb_gather"],
-    "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_cols_dc_t4<", "k_rows_reduce<1", "k_pfa372_expand", "k_pfa372_reduce", "k_llg372_combine"],
+    "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_cols_dc_t4<", "k_rows_reduce<1", "k_pfa372_expand", "k_pfa372_reduce", "k_llg372_combine"],   # (r04: the deferred form without y)
+    # round 4 (tools/probe/pmc_r04.py): dominant kernels of the other configurations, each at its own shape (`at`)
+    "llg_2d_cols_noy": ["k_cols_dc_t4<PlanCT<640, 5, 8, 4, 4>, true>"],
+    "e2evn_uconv_h_14to14": ["k_uconv_h<1, 1, true>"],
+    "qcirim_conv3x3_h_128": ["k_uconv_h<4, 2, false>"],
+    "train_layer2_fwd": ["k_conv_bf16<3, 2, 64, 2, 0, 2>"],
+    "train_cell_bwd": ["k_tl_cell_bwd<true, true>"],
+    "train_wgrad_3x3d2": ["k_conv_wgrad_bf16<3, 2, 1>"],
+    "train_dgrad_3x3d2": ["k_conv_bf16<3, 2, 64, 2, 1, 1>"],
 }
+AT = {"e2evn_uconv_h_14to14": "4 x 14 -> 14 x 640 x 384", "qcirim_conv3x3_h_128": "1 x 128 -> 128 x 256 x 256, dilation 2",
+      "train_layer2_fwd": "1 x 64 x 640 x 372", "train_cell_bwd": "1 x 64 x 640 x 372", "train_wgrad_3x3d2": "1 x 64 x 640 x 372",
+      "train_dgrad_3x3d2": "1 x 64 x 640 x 372", "llg_2d_cols_noy": "15 x 640 x 372"}
 
 
 def per_kernel(path):
@@ -38,9 +49,12 @@ def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None):
     fe, wr = per_kernel(fetch_csv), per_kernel(write_csv)
     mf = per_kernel(mfma_csv) if mfma_csv else {}
     cb = per_kernel(cubusy_csv) if cubusy_csv else {}
-    out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass) -- python3 tools/probe/pmc_r02.py; "
+    out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass) -- python3 tools/probe/pmc_r04.py; "
                       "per-dispatch means in KiB",
-           "_correction": "gfx950: FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B -> doubled; WRITE_SIZE as is",
+           "_correction": "gfx950: FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B -> doubled; WRITE_SIZE as is.  The guide calibrated "
+                          "that factor on 16-byte-per-lane streams; the round-4 training kernels load 4 bytes per lane from 64 planes -- for k_tl_cell_bwd, whose "
+                          "244 MB of reads have no reuse, the UNDOUBLED counter (234 MB) is the one that matches, so `hbm_bytes_uncorrected` (FETCH + WRITE) is kept "
+                          "beside the prescribed figure for every kernel",
            "lib_version": int(lib_version), "shape": dict(batch=1, coils=15, height=640, width=372, features=64), "kernels": {}}
     for key, pats in KEYS.items():
         names = [k for k in set(fe) | set(wr) if any(p in k for p in pats)]
@@ -49,7 +63,9 @@ def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None):
         f = sum(fe.get(k, 0.0) for k in names)
         w = sum(wr.get(k, 0.0) for k in names)
         out["kernels"][key] = dict(kernel=" + ".join(sorted(n.split("(")[0][:70] for n in names)), fetch_kib=f, write_kib=w,
-                                   hbm_bytes_per_launch=(2.0 * f + w) * 1024.0)
+                                   hbm_bytes_per_launch=(2.0 * f + w) * 1024.0, hbm_bytes_uncorrected=(f + w) * 1024.0)
+        if key in AT:
+            out["kernels"][key]["at"] = AT[key]
         if mf and cb:
             m, c = sum(mf.get(k, 0.0) for k in names), sum(cb.get(k, 0.0) for k in names)
             out["kernels"][key].update(mfma_busy_cycles=m, cu_busy_cycles=c, mfma_util=(m / (4.0 * c)) if c else None)
