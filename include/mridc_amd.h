@@ -496,6 +496,21 @@ int64_t mrx_conv_wgrad_bf16_any_work_floats(int B, int Cin, int Cout, int H, int
 int mrx_conv_wgrad_bf16_any(const float* x, const float* dy, float* dw, float* work, int B, int Cin, int Cout, int H, int W, int k, int dil,
                             int pad_mode, int accumulate, void* stream);
 
+/* ---- Pointwise / per-plane backward steps of the U-Net training path (csrc/diff_bwd.hip; reference: torch autograd through
+ * unet_block.py:189-299 -- LeakyReLU, InstanceNorm2d, avg_pool2d, ConvTranspose2d):
+ *   mrx_act_bwd            dx = dy * act'(y), y the activation's output
+ *   mrx_inorm_act_bwd      backward of act(InstanceNorm2d(x)) from the activation's output y and the forward's partial sums (`work` of
+ *                          mrx_instance_norm_act): dx = rstd (g - mean g - z mean(g z)), z the normalised value, g = dy act'(y); act NONE | LEAKY;
+ *                          work: mrx_inorm_act_bwd_work_floats floats
+ *   mrx_avgpool2x2_bwd     adjoint of mrx_avg_pool2x2 (an odd last row / column receives 0)
+ *   mrx_pixel_unshuffle2   [BC,2H,2W] -> [BC,4,H,W]: the layout in which ConvTranspose2d(k 2, s 2)'s gradients are 1x1 GEMMs */
+int mrx_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, void* stream);
+int64_t mrx_inorm_act_bwd_work_floats(int64_t planes, int64_t n);
+int mrx_inorm_act_bwd(const float* dy, const float* y, const float* fwd_work, float* dx, float* work, int64_t planes, int64_t HW, float eps, int act,
+                      float slope, void* stream);
+int mrx_avgpool2x2_bwd(const float* dy, float* dx, int64_t planes, int H, int W, void* stream);
+int mrx_pixel_unshuffle2(const float* x, float* out, int64_t BC, int H, int W, void* stream);
+
 /* ---- Mixed-precision training with bf16 STORAGE (BASELINE config 4; csrc/train_bf16.hip, csrc/conv_bf16.hip) -------------------------------------
  * The reference trains under pytorch-lightning AMP (projects/reconstruction/model_zoo/conf/base_cirim_train.yaml:180 `precision: 16`): torch.autocast
  * runs every Conv2d of rim_block.py:230-246 on half-precision operands and RETURNS half-precision tensors (so the gradients flowing into them are

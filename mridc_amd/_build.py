@@ -42,6 +42,7 @@ SOURCES = [
     ("qmri.hip", ["-ffp-contract=off"]),
     ("cnorm.hip", []),
     ("train_bf16.hip", []),
+    ("diff_bwd.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32
 

@@ -91,6 +91,11 @@ _SIGNATURES = {
     "mrx_tl_wgrad_in_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_tl_wgrad_in": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_conv_wgrad_bf16_pairs": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_act_bwd": ([_p, _p, _p, _i64, _i, _f, _p], _i),
+    "mrx_inorm_act_bwd_work_floats": ([_i64, _i64], _i64),
+    "mrx_inorm_act_bwd": ([_p, _p, _p, _p, _p, _i64, _i64, _f, _i, _f, _p], _i),
+    "mrx_avgpool2x2_bwd": ([_p, _p, _i64, _i, _i, _p], _i),
+    "mrx_pixel_unshuffle2": ([_p, _p, _i64, _i, _i, _p], _i),
     "mrx_relu_bwd_acc": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_eta_grad_in": ([_p, _p, _p, _p, _i, _i64, _p], _i),
     "mrx_g4_to_complex": ([_p, _p, _i, _i64, _p], _i),

@@ -57,13 +57,15 @@ __device__ __forceinline__ float tl_reduce_scatter32(float (&x)[32], int lane) {
 
 struct CellBwdArgs {
     const unsigned* dhP;   // [B,32,H,W] pairs or null: gradient from the layer above
-    const float* dH;       // [B,64,H,W] or null: gradient carried from the next time-step
+    const float* dH;       // [B,8,H,W,8] (channel-blocked: c = 8 q + j) or null: gradient carried from the next time-step -- written as dh_prev by the previous call
     const float* h;        // [B,64,H,W]: this step's state (the cell's ReLU mask)
     const float* hprev;    // [B,64,H,W] or null (first time-step: zero state)
     const unsigned* aP;    // [B,32,H,W] pairs: a = ReLU(conv)  (the convolution's ReLU mask and the 1x1 weight gradient's operand)
     const u32x4* wT;       // mrx_tl_pack's ihT block: [4 steps][2 blocks][64 lanes]
     const float* hh;       // [64]
-    float* dhp;            // [B,64,H,W] (written when hprev is given)
+    float* dhp;            // [B,8,H,W,8] channel-blocked (written when hprev is given).  dH / dhp travel only between consecutive calls of this kernel, so their
+                           // layout is free: a pixel's eight channels of a block are 32 contiguous bytes -- two 16-byte accesses per lane and chunk, 1 KB
+                           // contiguous per half-wave, instead of eight 4-byte ones from eight planes 952 KB apart
     unsigned* gaP;         // [B,32,H,W] pairs
     float* part;           // [gridDim.x][CL_PART]
     int B, H, W, tiles_x, ntiles, first;
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
         const unsigned pix4 = (unsigned)((oy < a.H ? oy : a.H - 1) * a.W + (ox < a.W ? ox : a.W - 1)) * 4u;
         const unsigned pb = (unsigned)b * 32u * plane4 + pix4 + 16u * lhi * plane4, fb = (unsigned)b * 64u * plane4 + pix4 + 32u * lhi * plane4;
         const unsigned ab = (unsigned)b * 32u * plane4 + pix4 + 2u * lhi * plane4;
+        const unsigned cbb = (unsigned)b * 64u * plane4 + pix4 * 8u + 4u * lhi * 8u * plane4;      // channel-blocked: block 4 lhi + ch, 32 bytes per pixel
         // ---- cell stage: lane = pixel, channels 32 lhi + i; eight channels at a time -----------------------------------------------------------
         unsigned gbP[16];
         float t_hh[32];
@@ -117,9 +120,16 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const unsigned o = fb + (unsigned)(8 * ch + j) * plane4;
-                dHv[bf][j] = HAS_DH ? ldf(a.dH, o) : 0.f;
                 hv[bf][j] = ldf(a.h, o);
                 hpv[bf][j] = HAS_PREV ? ldf(a.hprev, o) : 0.f;
+            }
+            if (HAS_DH) {
+                const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dH) + cbb + (unsigned)ch * 8u * plane4);
+                const float4 u0 = q4[0], u1 = q4[1];
+                dHv[bf][0] = u0.x, dHv[bf][1] = u0.y, dHv[bf][2] = u0.z, dHv[bf][3] = u0.w, dHv[bf][4] = u1.x, dHv[bf][5] = u1.y, dHv[bf][6] = u1.z, dHv[bf][7] = u1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dHv[bf][j] = 0.f;
             }
         };
         request(0, 0);
@@ -135,9 +145,10 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
                 t_hh[8 * ch + j] = g[j] * hpv[bf][j];
             }
             if (HAS_PREV && valid) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dhp) + fb + (unsigned)(8 * ch + j) * plane4) = g[j] * HH(32 * lhi + 8 * ch + j);
+                float4* q4 = reinterpret_cast<float4*>(reinterpret_cast<char*>(a.dhp) + cbb + (unsigned)ch * 8u * plane4);
+                const int c0 = 32 * lhi + 8 * ch;
+                q4[0] = make_float4(g[0] * HH(c0), g[1] * HH(c0 + 1), g[2] * HH(c0 + 2), g[3] * HH(c0 + 3));
+                q4[1] = make_float4(g[4] * HH(c0 + 4), g[5] * HH(c0 + 5), g[6] * HH(c0 + 6), g[7] * HH(c0 + 7));
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) gbP[4 * ch + q] = tl_pk(g[2 * q], g[2 * q + 1]);
@@ -268,7 +279,8 @@ extern "C" int64_t mrx_tl_cell_part_floats(int B, int H, int W) {
     if (B < 1 || H < 1 || W < 1) return -1;
     return (int64_t)tl_cell_nwg((long long)B * mrx_cdiv(W, 32) * mrx_cdiv(H, 8)) * CL_PART;
 }
-// The backward pass of one IndRNN layer's cell + convolution ReLU (see the header).  dH (fp32) may be null (last time-step); hprev null =
+// The backward pass of one IndRNN layer's cell + convolution ReLU (see the header).  dH (fp32, CHANNEL-BLOCKED [B,8,H,W,8] -- it is the dh_prev a
+// previous call wrote) may be null (last time-step); hprev null =
 // first time-step (no dh_prev, no hh gradient).  `part` [mrx_tl_cell_part_floats]: the workgroup slots; first != 0 overwrites them (first call of a
 // cascade), otherwise the call adds to them.  tl_packed from mrx_tl_pack.
 extern "C" int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const float* h, const float* hprev, const void* a_pairs, const void* tl_packed,

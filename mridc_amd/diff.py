@@ -34,9 +34,7 @@ def active(*tensors, training=True):
 
 
 def _act_grad(dy, y, act, slope):
-    if act == ACT_NONE:
-        return dy
-    return torch.where(y > 0, dy, dy * (slope if act == ACT_LEAKY else 0.0))
+    return ops.act_bwd(dy, y, act, slope)                  # dy * act'(y): mrx_act_bwd
 
 
 class _Conv2d(torch.autograd.Function):
@@ -70,26 +68,18 @@ class _InstanceNormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, eps, act, slope):
-        rstd = torch.rsqrt(x.var((2, 3), unbiased=False, keepdim=True) + eps)
-        out = ops.instance_norm_act(x, eps, act, slope, inplace=False)
-        ctx.save_for_backward(out, rstd)
-        ctx.cfg = (int(act), float(slope))
+        if act not in (ACT_NONE, ACT_LEAKY):
+            raise NotImplementedError("instance norm + ReLU backward (the normalised value is not recoverable from the output)")
+        out, work = ops.instance_norm_act(x, eps, act, slope, inplace=False, return_work=True)
+        ctx.save_for_backward(out, work)                   # work: the forward's per-plane partial sums (rstd comes from them in the backward kernel)
+        ctx.cfg = (float(eps), int(act), float(slope))
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        out, rstd = ctx.saved_tensors
-        act, slope = ctx.cfg
-        if act == ACT_LEAKY:
-            yhat = torch.where(out > 0, out, out / slope)
-        elif act == ACT_NONE:
-            yhat = out
-        else:
-            raise NotImplementedError("instance norm + ReLU backward (the normalised value is not recoverable from the output)")
-        g = _act_grad(dy, out, act, slope)
-        gm = g.mean((2, 3), keepdim=True)
-        gy = (g * yhat).mean((2, 3), keepdim=True)
-        return rstd * (g - gm - yhat * gy), None, None, None
+        out, work = ctx.saved_tensors
+        eps, act, slope = ctx.cfg
+        return ops.instance_norm_act_bwd(dy, out, work, eps, act, slope), None, None, None      # mrx_inorm_act_bwd: two passes, no torch arithmetic
 
 
 def instance_norm_act(x, eps=1e-5, act=ACT_LEAKY, slope=0.2, inplace=True):
@@ -112,7 +102,7 @@ class _ConvTranspose2x2(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         cin, cout = int(w.shape[0]), int(w.shape[1])
-        dyu = F.pixel_unshuffle(dy.contiguous(), 2)                      # [B, cout * 4, H, W], channel (co, i, j)
+        dyu = ops.pixel_unshuffle2(dy)                                   # [B, cout * 4, H, W], channel (co, i, j): mrx_pixel_unshuffle2
         dx = ops.conv2d(dyu, w.detach().reshape(cin, cout * 4, 1, 1), None) if ctx.needs_input_grad[0] else None
         dw = ops.conv_wgrad(dyu, x, 1, 1, PAD_ZERO).reshape(cin, cout, 2, 2) if ctx.needs_input_grad[1] else None
         return dx, dw
@@ -131,8 +121,7 @@ class _AvgPool2x2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         H, W = ctx.hw
-        g = F.interpolate(dy, scale_factor=2, mode="nearest") * 0.25
-        return F.pad(g, (0, W - g.shape[-1], 0, H - g.shape[-2]))         # an odd last row / column is not pooled
+        return ops.avg_pool2x2_bwd(dy, H, W)                             # mrx_avgpool2x2_bwd (an odd last row / column is not pooled: 0)
 
 
 def avg_pool2x2(x):

@@ -1090,11 +1090,14 @@ def tl_cell_part(B, H, W, device):
 
 
 def tl_cell_bwd(dh_pairs, dH, h, h_prev, a_pairs, w_ih, w_fin, hh, part, first):
-    """mrx_tl_cell_bwd: (dh_prev | None, ga_pairs); the parameter-gradient partials accumulate in `part` (tl_cell_part) until tl_cell_reduce."""
+    """mrx_tl_cell_bwd: (dh_prev | None, ga_pairs); the parameter-gradient partials accumulate in `part` (tl_cell_part) until tl_cell_reduce.
+    dH in and dh_prev out are CHANNEL-BLOCKED [B,8,H,W,8] (c = 8 q + j): they only travel from one call of this kernel to the next."""
     B, _, H, W = _nchw(h)
+    if dH is not None and tuple(dH.shape) != (B, 8, H, W, 8):
+        raise ValueError(f"tl_cell_bwd: dH {tuple(dH.shape)}, expected the channel-blocked {(B, 8, H, W, 8)}")
     tp = _tl_pack(w_ih, w_fin)
     ga = torch.empty(B, 32, H, W, dtype=torch.int32, device=h.device)
-    dhp = torch.empty_like(h) if h_prev is not None else None
+    dhp = torch.empty(B, 8, H, W, 8, dtype=torch.float32, device=h.device) if h_prev is not None else None
     hhc = _lib.f32c(hh.detach().reshape(-1)) if h_prev is not None else None
     _lib.check(_lib.lib().mrx_tl_cell_bwd(_lib.ptr(dh_pairs), _lib.ptr(dH), _lib.ptr(h), _lib.ptr(h_prev), _lib.ptr(a_pairs), _lib.ptr(tp), _lib.ptr(hhc),
                                           _lib.ptr(dhp), _lib.ptr(ga), _lib.ptr(part), int(bool(first)), B, H, W, _lib.stream_ptr()), "mrx_tl_cell_bwd")
@@ -1635,13 +1638,55 @@ def mgu_gates(ih, hh, h):
 
 
 # ---- NormUnet pieces -------------------------------------------------------------------------------------------
-def instance_norm_act(x, eps=1e-5, act=ACT_LEAKY, slope=0.2, inplace=True):
+def instance_norm_act(x, eps=1e-5, act=ACT_LEAKY, slope=0.2, inplace=True, return_work=False):
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
     out = x if inplace else torch.empty_like(x)
     work = torch.empty(int(_lib.lib().mrx_norm_work_floats(B * C, H * W)), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().mrx_instance_norm_act(_lib.ptr(x), _lib.ptr(out), _lib.ptr(work), B * C, H * W, float(eps), int(act),
                                                 float(slope), _lib.stream_ptr()), "mrx_instance_norm_act")
+    return (out, work) if return_work else out            # work: the per-plane partial sums / squared deviations (mrx_inorm_act_bwd reads rstd from them)
+
+
+# ---- backward steps of the U-Net training path (csrc/diff_bwd.hip; callers: mridc_amd/diff.py) -----------------------------------------------
+def act_bwd(dy, y, act, slope=0.0):
+    """dy * act'(y) with y the activation's output (mrx_act_bwd)."""
+    if act == ACT_NONE:
+        return dy
+    dy, y = _lib.f32c(dy), _lib.f32c(y)
+    dx = torch.empty_like(dy)
+    _lib.check(_lib.lib().mrx_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dx), dy.numel(), int(act), float(slope), _lib.stream_ptr()), "mrx_act_bwd")
+    return dx
+
+
+def instance_norm_act_bwd(dy, y, fwd_work, eps, act, slope):
+    """Backward of act(InstanceNorm2d(x)) from the output y and the forward's work buffer (mrx_inorm_act_bwd)."""
+    dy, y = _lib.f32c(dy), _lib.f32c(y)
+    B, C, H, W = _nchw(y)
+    L = _lib.lib()
+    dx = torch.empty_like(y)
+    work = torch.empty(int(L.mrx_inorm_act_bwd_work_floats(B * C, H * W)), dtype=torch.float32, device=y.device)
+    _lib.check(L.mrx_inorm_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(fwd_work), _lib.ptr(dx), _lib.ptr(work), B * C, H * W, float(eps), int(act), float(slope),
+                                   _lib.stream_ptr()), "mrx_inorm_act_bwd")
+    return dx
+
+
+def avg_pool2x2_bwd(dy, H, W):
+    dy = _lib.f32c(dy)
+    B, C = int(dy.shape[0]), int(dy.shape[1])
+    dx = torch.empty(B, C, H, W, dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().mrx_avgpool2x2_bwd(_lib.ptr(dy), _lib.ptr(dx), B * C, int(H), int(W), _lib.stream_ptr()), "mrx_avgpool2x2_bwd")
+    return dx
+
+
+def pixel_unshuffle2(x):
+    """[B,C,2H,2W] -> [B,4C,H,W], channel (c, i, j) (mrx_pixel_unshuffle2)."""
+    x = _lib.f32c(x)
+    B, C, H2, W2 = _nchw(x)
+    if H2 % 2 or W2 % 2:
+        raise ValueError("pixel_unshuffle2: odd size")
+    out = torch.empty(B, 4 * C, H2 // 2, W2 // 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_pixel_unshuffle2(_lib.ptr(x), _lib.ptr(out), B * C, H2 // 2, W2 // 2, _lib.stream_ptr()), "mrx_pixel_unshuffle2")
     return out
 
 

@@ -437,3 +437,36 @@ def test_two_rank_training_step_on_the_explicit_tape(dev, tmp_path):
         training.cirim_forward_backward(model, batch, "f32")
         total = flat.grad.detach().cpu().clone() if total is None else total + flat.grad.detach().cpu()
     assert_close(got[0]["grad"], total, 1e-6, "two-rank reduced gradient vs the sum of the single-rank gradients")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 9, 7), (1, 5, 130, 90), (1, 2, 640, 384)], ids=lambda s: "x".join(map(str, s)))
+def test_unet_backward_steps_on_hip_kernels(dev, shape):
+    """csrc/diff_bwd.hip (round 4: these ran as torch device ops inside the backward): activation, InstanceNorm2d + LeakyReLU, avg_pool2d adjoint and
+    the pixel-unshuffle of ConvTranspose2d's gradients against torch autograd in float64 (unet_block.py:251-258, 189-230)."""
+    from mridc_amd import diff, ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, C, H, W, generator=g) * 2.0 + 0.3
+    dy = torch.randn(B, C, H, W, generator=g)
+    # activation
+    y = F.leaky_relu(x, 0.2)
+    assert torch.equal(ops.act_bwd(dy.to(dev), y.to(dev), ops.ACT_LEAKY, 0.2).cpu(), torch.where(y > 0, dy, dy * 0.2))
+    assert torch.equal(ops.act_bwd(dy.to(dev), F.relu(x).to(dev), ops.ACT_RELU).cpu(), torch.where(x > 0, dy, torch.zeros(())))
+    # instance norm + LeakyReLU / no activation
+    for act, slope in ((ops.ACT_LEAKY, 0.2), (ops.ACT_NONE, 0.0)):
+        xd = x.double().requires_grad_(True)
+        n = F.instance_norm(xd, eps=1e-5)
+        (F.leaky_relu(n, slope) if act == ops.ACT_LEAKY else n).backward(dy.double())
+        xg = x.to(dev).requires_grad_(True)
+        out = diff.instance_norm_act(xg, 1e-5, act, slope)
+        out.backward(dy.to(dev))
+        assert_close(xg.grad, xd.grad.float(), 2e-5, f"instance norm backward, act {act}")
+    # average pooling (odd sizes leave the last row / column unpooled)
+    xd = x.double().requires_grad_(True)
+    po = F.avg_pool2d(xd, 2)
+    gp = torch.randn(po.shape, generator=g)
+    po.backward(gp.double())
+    assert_close(ops.avg_pool2x2_bwd(gp.to(dev), H, W), xd.grad.float(), 1e-6, "avg_pool2d adjoint")
+    # pixel unshuffle
+    if H % 2 == 0 and W % 2 == 0:
+        assert torch.equal(ops.pixel_unshuffle2(x.to(dev)).cpu(), F.pixel_unshuffle(x, 2))

@@ -93,16 +93,18 @@ def test_cell_backward_in_one_pass(dev, variant):
     want = dict(dw=torch.einsum("bohw,bihw->oi", gb.double(), a.double()), dbih=gb.double().sum((0, 2, 3)),
                 dhh=(gq.double() * hp.double()).sum((0, 2, 3)) if hp is not None else torch.zeros(64, dtype=torch.float64), db=ga.double().sum((0, 2, 3)))
     d = lambda t: None if t is None else t.to(dev)  # noqa: E731
+    blk = lambda t: None if t is None else t.view(B, 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()      # NCHW -> channel-blocked [B,8,H,W,8]  # noqa: E731
     part = ops.tl_cell_part(B, H, W, dev)
     part.fill_(float("nan"))                               # `first` must overwrite the slots
-    dhp, ga_p = ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(dH), d(h), d(hp), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, True)
+    dhp, ga_p = ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(blk(dH)), d(h), d(hp), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, True)
     ga_g = ops.pairs_to_f32(ga_p)
     assert _flips(ga_g, ga) <= 2e-3 and rel_l2(ga_g, ga) <= 2e-3, (_flips(ga_g, ga), rel_l2(ga_g, ga))
     if hp is not None:
-        assert rel_l2(dhp, gq * hh) <= 1e-6
+        assert tuple(dhp.shape) == (B, 8, H, W, 8)             # channel-blocked, as the next time-step's call reads it
+        assert rel_l2(dhp.permute(0, 1, 4, 2, 3).reshape(B, 64, H, W), gq * hh) <= 1e-6
     else:
         assert dhp is None
-    ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(dH), d(h), d(hp), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, False)   # second time-step: adds
+    ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(blk(dH)), d(h), d(hp), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, False)   # second time-step: adds
     dw, dbih, dhh, db = (torch.full(s, 1.0, device=dev) for s in ((64, 64, 1, 1), (64,), (64,), (64,)))
     ops.tl_cell_reduce(part, B, H, W, dw, dbih, dhh, db)
     assert rel_l2(dw.reshape(64, 64).cpu().double() - 1.0, 2 * want["dw"]) <= 1e-5

@@ -48,7 +48,7 @@ bnd = ops.max_abs(X128).reshape(1)
 cw2, cb2 = r(F, F, 3, 3) / 24, r(F) * 0.1
 wih, bih, hh2, wfin = r(F, F, 1, 1) / 8, r(F) * 0.1, r(1, F, 1, 1) * 0.5, r(2, F, 3, 3) / 24
 dhP, aP = ops.f32_to_pairs(r(B, F, H, W)), ops.f32_to_pairs(r(B, F, H, W).relu())
-dH, hst = r(B, F, H, W), r(B, F, H, W).relu()
+dH, hst = r(B, 8, H, W, 8), r(B, F, H, W).relu()                     # (dH channel-blocked)
 part_c = ops.tl_cell_part(B, H, W, dev)
 torch.cuda.synchronize()
 for i in range(3):
