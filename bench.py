@@ -1258,7 +1258,12 @@ def main():
                                          if (ms1 and ms2) else None))
         bytes_llg = (25.0 + 16.0 * C) * npix * B     # compulsory bytes of one log_likelihood_gradient
         # the formulation executed for 1-D masks reads yt = IFFT_H(y) instead of y: the same (25+16C)N compulsory bytes per step
-        # (plus one column pass per slice, outside the step, to make yt)
+        # (plus one column pass per slice, outside the step, to make yt).  Since round 4 the data term is ONE constant plane per slice
+        # (g = A^H M A eta - A^H M y: ops.LLG372_NO_Y / LLG_T4_NO_Y) and a step moves eta, S and the coil-group partial planes only:
+        # `executed_bytes_per_call` / `executed_frac` price the launch on what it moves, `frac` on SURVEY 8d's figure for the operation
+        no_y = bool(ms372 and getattr(ops, "LLG372_NO_Y", False)) or bool(args.mask != "1d" and getattr(ops, "LLG_T4_NO_Y", False))
+        n_groups = -(-C // 5)
+        bytes_llg_exec = ((8.0 + 8.0 * C + 8.0 * n_groups) * npix * B) if (no_y and ms372) else None
         roofline_fft = dict(bound="hbm", kernel=("mrx_llg372 (1-D column mask: H transforms cancel; ONE launch per step of wave-private prime-factor "
                                                  "12 x 31 row transforms on lane-ordered yt = IFFT_H(y), S and mask; coil-group sum finished by layer 1's "
                                                  "tile loader)" if ms372 else
@@ -1269,7 +1274,12 @@ def main():
                             frac=(bytes_llg / (msl * 1e-3) / 1e9 / PEAK_HBM_GBS) if msl else None,
                             traffic=traffic.get("llg") if args.mask == "1d" else traffic.get("llg_2d"), traffic_unit="bytes/launch",
                             traffic_kernel=traffic.get("_kernels", {}).get("llg" if args.mask == "1d" else "llg_2d"),
-                            launches=nl, avg_ms=msl, bytes_per_call=bytes_llg)
+                            launches=nl, avg_ms=msl, bytes_per_call=bytes_llg, executed_bytes_per_call=bytes_llg_exec,
+                            executed_frac=(bytes_llg_exec / (msl * 1e-3) / 1e9 / PEAK_HBM_GBS) if (msl and bytes_llg_exec) else None,
+                            note=("`frac` = SURVEY 8d's compulsory bytes of the operation (eta, y, S, mask, result) / time; the launch itself does not read "
+                                  "the measured data any more -- its term -A^H M y is a constant plane made once per slice -- and moves "
+                                  "`executed_bytes_per_call` (eta, S, the coil-group partial planes): `executed_frac`.  The kernel is bound by its vector "
+                                  "ALU work (two 31-point and six 12-point DFT passes per coil row, built without packed fp32), not by HBM") if bytes_llg_exec else None)
         res = dict(metric=f"slices/sec (inference), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}"
                           + ("" if args.rnn == "IndRNN" else f" ({args.rnn})"), value=value, unit="slices/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,

@@ -157,12 +157,20 @@ int mrx_llg_hinv_parts(const float* eta, const float* yt, const float* S, const 
  *                       ytp, Sp (mrx_llg372_operand_floats(B,C,H) floats each), maskp (B*372 floats)
  *   mrx_llg372          eta [B,H,372,2] -> nparts != NULL: *nparts = ceil(C/5) partial planes work[k][B][H][372][2] left for the
  *                       consumer (mrx_rim_layer_indrnn_packed_llg), out4 untouched; nparts == NULL: out4 [B,4,H,372] complete.
- *                       work: mrx_llg372_work_floats(B,C,H) floats. */
+ *                       work: mrx_llg372_work_floats(B,C,H) floats.
+ *                       ytp == NULL: the data is not read (the gradient is affine in eta: A^H M A eta - A^H M y); `work` has one plane more,
+ *                       plane T = ceil(C/5) holds the constant term, and T + 1 partial planes are reported / combined.  34.5 MB instead of
+ *                       63.1 MB per launch at 15 coils.  With a zero constant plane this is the linear part, which is its own adjoint
+ *                       (training's backward through rim_utils.py:53-62).
+ *   mrx_llg372_const_plane  -A^H M y -> plane T of `work` (mrx_llg372_work_floats + B*H*372*2 floats; planes 0 .. T-1 are scratch): the full
+ *                       kernel on eta = 0 and the sum of its partial planes, once per slice and normalization */
 int mrx_llg372_supported(int W);
 int64_t mrx_llg372_operand_floats(int B, int C, int H);
 int64_t mrx_llg372_work_floats(int B, int C, int H);
 int mrx_llg372_prepare(const float* yt, const float* S, const void* mask, int mask_kind, const int64_t* mstride, float* ytp,
                        float* Sp, float* maskp, int B, int C, int H, int centered, void* stream);
+int mrx_llg372_const_plane(const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* work, int B, int C, int H, int norm,
+                           int centered, void* stream);
 int mrx_llg372(const float* eta, const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* out4, float* work,
                int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream);
 /* The two halves of that pipeline as row operators at W = 372 (natural k-space layout on the far side; Sp from mrx_llg372_prepare or
@@ -510,6 +518,21 @@ int mrx_inorm_act_bwd(const float* dy, const float* y, const float* fwd_work, fl
                       float slope, void* stream);
 int mrx_avgpool2x2_bwd(const float* dy, float* dx, int64_t planes, int H, int W, void* stream);
 int mrx_pixel_unshuffle2(const float* x, float* out, int64_t BC, int H, int W, void* stream);
+/* The pointwise halves of the backward of the VarNet block's coil operators and data consistency (vn_block.py:51-119; the FFT halves are the
+ * opposite transforms of this library):
+ *   mrx_cmul_bcast          out[b,c,n] = a[b,c,n] * v[b,n] (conj_v: * conj(v[b,n])) * scale; complex, a [B,C,N], v [B,N]
+ *                           (sens_reduce: dS_c = conj(dy) * ifft2(k)_c)
+ *   mrx_sens_expand_bwd_pw  from G_c = adjoint-fft2(dy_c): dx[b,n] = scale * sum_c conj(S_c) G_c, dS_c = scale * conj(x) G_c (dx or dS may be NULL;
+ *                           x may be NULL when dS is)
+ *   mrx_dc_combine_bwd      backward of out = base - where(mask, pred - ref, 0) * w - eta_k: dpred = -where(mask, dy, 0) * w (+ dy when add_dy: base
+ *                           and pred are one tensor), deta = -dy, dw[0] = -sum where(mask, (pred - ref) . dy); any of the three outputs may be NULL;
+ *                           work: mrx_dc_combine_bwd_work_doubles doubles (needed with dw) */
+int mrx_cmul_bcast(const float* a, const float* v, float* out, int64_t B, int64_t C, int64_t N, int conj_v, float scale, void* stream);
+int mrx_sens_expand_bwd_pw(const float* G, const float* S, const float* x, float* dx, float* dS, int64_t B, int64_t C, int64_t N, float scale,
+                           void* stream);
+int64_t mrx_dc_combine_bwd_work_doubles(void);
+int mrx_dc_combine_bwd(const float* dy, const float* pred, const float* ref, const void* mask, int mask_kind, const int64_t* mstride,
+                       const float* dc_weight, float* dpred, float* deta, float* dw, double* work, int add_dy, int B, int C, int H, int W, void* stream);
 
 /* ---- Mixed-precision training with bf16 STORAGE (BASELINE config 4; csrc/train_bf16.hip, csrc/conv_bf16.hip) -------------------------------------
  * The reference trains under pytorch-lightning AMP (projects/reconstruction/model_zoo/conf/base_cirim_train.yaml:180 `precision: 16`): torch.autocast
@@ -518,7 +541,9 @@ int mrx_pixel_unshuffle2(const float* x, float* out, int64_t BC, int H, int W, v
  * "pair tensors" in HBM: uint32 [B][C/2][H][W] = (bf16 of channel 2p) | (bf16 of channel 2p + 1) << 16.
  *   mrx_tl_pack          W_ih [64,64] (+ the final convolution's weights [2,64,3,3], may be null) in the operand orders of the three GEMMs below
  *   mrx_tl_layer_fwd     one RIM layer (ConvNonlinear + IndRNNCell, conv_layers.py:121-123, rnn_cells.py:384-391): a = ReLU(bf16(conv(x) + b)) ->
- *                        a_pairs, h = ReLU(bf16(W_ih a + b_ih) + hh * h_prev) -> h (fp32); taps != null: also the final convolution's (tap, cout)
+ *                        a_pairs, h = ReLU(bf16(W_ih a + b_ih) + hh * h_prev) -> h (fp32).  HIDDEN STATES ARE CHANNEL-BLOCKED in this tape:
+ *                        h, h_prev (and x when Cin == 64) are [B,8,H,W,8], channel c = 8 q + j at [b][q][y][x][j] (32 contiguous bytes per pixel
+ *                        and block: 16-byte accesses everywhere instead of dwords of 64 planes).  taps != null: also the final convolution's (tap, cout)
  *                        products with bf16(h) [B,18,H,W], summed by mrx_tl_final_gather: eta_out = eta + bf16(sum of the 9 shifted planes)
  *   mrx_tl_cell_bwd      backward of the cell and of the convolution's ReLU in one pass (see train_bf16.hip); parameter-gradient partials accumulate
  *                        in `part` (mrx_tl_cell_part_floats floats; first != 0 overwrites) until mrx_tl_cell_reduce adds them to the gradients
@@ -543,7 +568,11 @@ int mrx_tl_f32_to_pairs(const float* x, void* pairs, int64_t pair_planes, int64_
 int64_t mrx_tl_wgrad_in_work_floats(int B, int Cin, int H, int W);
 int mrx_tl_wgrad_in(const float* x, const void* dy_pairs, float* dw, float* work, int B, int Cin, int H, int W, int accumulate, void* stream);
 int mrx_conv_wgrad_bf16_pairs(const float* x, const void* dy_pairs, float* dw, float* work, int B, int Cin, int H, int W, int k, int dil, int pad_mode,
-                              int accumulate, void* stream);
+                              int accumulate, int x_blocked, void* stream);   /* x_blocked: x is channel-blocked [B,8,H,W,8] (3x3 dilation 2 only) */
+/*   mrx_conv_wgrad_bf16_xcb   weight gradient of the final 3x3 convolution 64 -> Cout <= 32 with x channel-blocked [B,8,H,W,8], dy fp32;
+ *                             work: mrx_conv_wgrad_bf16_any_work_floats(B, 64, Cout, H, W, 3) floats */
+int mrx_conv_wgrad_bf16_xcb(const float* x_cb8, const float* dy, float* dw, float* work, int B, int Cout, int H, int W, int pad_mode, int accumulate,
+                            void* stream);
 
 /*   mrx_absl1_loss      the l1 training loss of one prediction (cirim.py:218-237): out2[0] = mean |target - |p| / max|p||, out2[1] = an
  *                      intermediate the backward needs; p complex [n], target real [n], maxabs = device scalar from mrx_max_abs (mode 1);

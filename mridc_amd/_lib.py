@@ -90,11 +90,16 @@ _SIGNATURES = {
     "mrx_tl_f32_to_pairs": ([_p, _p, _i64, _i64, _p], _i),
     "mrx_tl_wgrad_in_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_tl_wgrad_in": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
-    "mrx_conv_wgrad_bf16_pairs": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_conv_wgrad_bf16_pairs": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_conv_wgrad_bf16_xcb": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_act_bwd": ([_p, _p, _p, _i64, _i, _f, _p], _i),
     "mrx_inorm_act_bwd_work_floats": ([_i64, _i64], _i64),
     "mrx_inorm_act_bwd": ([_p, _p, _p, _p, _p, _i64, _i64, _f, _i, _f, _p], _i),
     "mrx_avgpool2x2_bwd": ([_p, _p, _i64, _i, _i, _p], _i),
+    "mrx_cmul_bcast": ([_p, _p, _p, _i64, _i64, _i64, _i, _f, _p], _i),
+    "mrx_sens_expand_bwd_pw": ([_p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p], _i),
+    "mrx_dc_combine_bwd_work_doubles": ([], _i64),
+    "mrx_dc_combine_bwd": ([_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_pixel_unshuffle2": ([_p, _p, _i64, _i, _i, _p], _i),
     "mrx_relu_bwd_acc": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_eta_grad_in": ([_p, _p, _p, _p, _i, _i64, _p], _i),
@@ -110,6 +115,7 @@ _SIGNATURES = {
     "mrx_llg372_supported": ([_i], _i),
     "mrx_llg372_operand_floats": ([_i, _i, _i], _i64),
     "mrx_llg372_work_floats": ([_i, _i, _i], _i64),
+    "mrx_llg372_const_plane": ([_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_llg372_prepare": ([_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_llg372": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_pfa372_prepare_maps": ([_p, _p, _i, _i, _i, _i, _p], _i),

@@ -69,7 +69,7 @@ class CIRIM(torch.nn.Module):
             hybrid = ops.llg_prepare(y, self.fft_centered, self.fft_normalization, self.spatial_dims)
             m1 = ops.row_invariant_view(mask)
             if ops.llg372_supported(hybrid, m1):            # W = 372: maps, data and mask in the lane order of mrx_llg372, once per slice
-                hybrid = (hybrid, ops.llg372_prepare(hybrid, sensitivity_maps, m1, self.fft_centered))
+                hybrid = (hybrid, ops.llg372_prepare(hybrid, sensitivity_maps, m1, self.fft_centered, self.fft_normalization))
         for i, cascade in enumerate(self.cirim):
             prediction, _ = cascade(prediction, y, sensitivity_maps, mask, init_pred, hx, sigma,
                                     keep_eta=False if i == 0 else self.keep_eta, _hybrid=hybrid, _want_hx=False)

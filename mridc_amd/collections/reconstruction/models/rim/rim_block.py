@@ -354,7 +354,7 @@ class RIMBlock(torch.nn.Module):
                 yt = _hybrid if _hybrid is not None else ops.llg_prepare(masked_kspace, self.fft_centered, self.fft_normalization,
                                                                          self.spatial_dims)
                 if ops.llg372_supported(yt, mask):
-                    op372 = ops.llg372_prepare(yt, sense, mask, self.fft_centered)
+                    op372 = ops.llg372_prepare(yt, sense, mask, self.fft_centered, self.fft_normalization)
             work = None
         else:
             work = torch.empty_like(masked_kspace, dtype=torch.float32)

@@ -45,7 +45,7 @@ struct ConvBfArgs {
     const u32x4* packed;   // [NSTEP][NCT][64 lanes] x 8 bf16
     const float* bias;     // [Cout] or null
     const float* hh;       // [Cout] or null: IndRNN epilogue  act(acc + bias + hh * hprev)
-    const float* hprev;    // [B,Cout,H,W] or null
+    const float* hprev;    // [B,Cout,H,W] or null  (OUT 2: channel-blocked [B,8,H,W,8], like `out`)
     float* out;            // [B,Cout,H,W]
     int B, Cin, Cout, H, W, tiles_x, ntiles, pad_mode, act;
     float slope;
@@ -99,7 +99,12 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
                 gx = inb ? gx : 0;
             }
             u32x4 p;
-            if (XP) {            // pair tensor: four dwords = eight channels of this pixel, already bf16
+            if (XP == 2) {       // channel-blocked fp32 [B][Cin/8][H][W][8] (the training tape's hidden states): a pixel's eight channels are 32 contiguous bytes
+                const float4* src = reinterpret_cast<const float4*>(a.x + (((long long)b * (a.Cin >> 3) + cg) * iplane + (long long)gy * a.Win + gx) * 8);
+                float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
+                if (inb) u0 = src[0], u1 = src[1];
+                p = (u32x4){cb_pk(u0.x, u0.y), cb_pk(u0.z, u0.w), cb_pk(u1.x, u1.y), cb_pk(u1.z, u1.w)};
+            } else if (XP) {     // pair tensor: four dwords = eight channels of this pixel, already bf16
                 const unsigned* src = reinterpret_cast<const unsigned*>(a.x) + ((long long)b * (a.Cin >> 1) + cg * 4) * iplane + (long long)gy * a.Win + gx;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) p[q] = (inb && cg * 8 + 2 * q < a.Cin) ? src[(long long)q * iplane] : 0u;
@@ -126,13 +131,18 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
             tb[64 + tid] = a.ih_bias ? cb_round(a.ih_bias[tid]) : 0.f;
             tb[128 + tid] = a.hprev ? a.hh[tid] : 0.f;
         }
+        // hidden states are channel-blocked [B][8][H][W][8]: rows 4 k .. 4 k + 3 of a lane's accumulator are four consecutive channels of block
+        // 4 c2 + k -> one 16-byte access per block (rim_layer2_sb.hip's CB8 form)
         const int py = h0 + wave < a.H ? h0 + wave : a.H - 1, px = w0 + l31 < a.W ? w0 + l31 : a.W - 1;
-        const unsigned plane4 = (unsigned)plane * 4u, o0 = (unsigned)b * 64u * plane4 + (unsigned)(py * a.W + px) * 4u + 4u * lhi * plane4;
+        const unsigned plane32 = (unsigned)plane * 32u, o0 = (unsigned)b * 8u * plane32 + (unsigned)(py * a.W + px) * 32u + 16u * lhi;
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                hpv[c2][r] = a.hprev ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.hprev) + o0 + (unsigned)(c2 * 32 + (r & 3) + 8 * (r >> 2)) * plane4) : 0.f;
+            for (int k = 0; k < 4; ++k) {
+                float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.hprev) u = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.hprev) + o0 + (unsigned)(c2 * 4 + k) * plane32);
+                hpv[c2][4 * k] = u.x, hpv[c2][4 * k + 1] = u.y, hpv[c2][4 * k + 2] = u.z, hpv[c2][4 * k + 3] = u.w;
+            }
     }
     __syncthreads();
 
@@ -207,12 +217,17 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
             for (int r = 0; r < 16; ++r) {
                 const int co = c2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 float v = cb_round(acc2[c2][r] + tb[64 + co]);
-                const long long o = ((long long)b * 64 + co) * plane + pix;
                 v += tb[128 + co] * hpv[c2][r];
-                v = v > 0.f ? v : 0.f;
-                if (inside) a.out[o] = v;
-                acc2[c2][r] = v;
+                acc2[c2][r] = v > 0.f ? v : 0.f;
             }
+        if (inside) {
+            float* ob = a.out + ((long long)b * 8 * plane + pix) * 8 + 4 * lhi;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<float4*>(ob + (long long)(c2 * 4 + k) * plane * 8) = make_float4(acc2[c2][4 * k], acc2[c2][4 * k + 1], acc2[c2][4 * k + 2], acc2[c2][4 * k + 3]);
+        }
         if (a.fin_packed) {                      // (tap, cout) rows of the final convolution times bf16(h): 18 of 32 output rows are real
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
@@ -458,7 +473,8 @@ extern "C" int mrx_tl_pack(const float* w_ih, const float* w_fin, void* packed, 
 }
 
 // One RIM layer in training arithmetic (rim_block.py:230-238 under autocast): a = ReLU(bf16(conv_reppad(x) + b)) -> a_pairs [B,32,H,W],
-// h = ReLU(bf16(W_ih a + b_ih) + hh * h_prev) -> h [B,64,H,W] fp32; with `taps`: also the (tap, cout) products of the final 3x3 convolution with
+// h = ReLU(bf16(W_ih a + b_ih) + hh * h_prev) -> h fp32, CHANNEL-BLOCKED [B,8,H,W,8] (c = 8 q + j) like h_prev and -- for the 64-channel layer -- x
+// (the hidden states of the tape: 16-byte accesses, 1 KB contiguous per half-wave instead of 128-byte pieces of 64 planes); with `taps`: also the (tap, cout) products of the final 3x3 convolution with
 // bf16(h) [B,18,H,W].  conv_packed from mrx_conv_bf16_pack (forward), tl_packed from mrx_tl_pack.  k x k = 5x5 (Cin <= 8) or 3x3 dilation 2 (Cin 64).
 extern "C" int mrx_tl_layer_fwd(const float* x, const void* conv_packed, const float* conv_bias, const void* tl_packed, const float* ih_bias,
                                 const float* hh, const float* hprev, void* a_pairs, float* h, float* taps, int B, int Cin, int H, int W, int k,
@@ -475,7 +491,7 @@ extern "C" int mrx_tl_layer_fwd(const float* x, const void* conv_packed, const f
     a.pad_mode = MRX_PAD_REPLICATE, a.act = MRX_ACT_RELU, a.Hin = H, a.Win = W;
     a.ih_packed = (const u32x4*)tl_packed, a.ih_bias = ih_bias, a.a_pairs = (unsigned*)a_pairs;
     a.fin_packed = taps ? (const u32x4*)tl_packed + 512 : nullptr, a.taps = taps;
-    return k == 5 ? cb_launch<5, 1, 8, 2, 0, 2>(a, (hipStream_t)stream) : cb_launch<3, 2, 64, 2, 0, 2>(a, (hipStream_t)stream);
+    return k == 5 ? cb_launch<5, 1, 8, 2, 0, 2>(a, (hipStream_t)stream) : cb_launch<3, 2, 64, 2, 2, 2>(a, (hipStream_t)stream);
 }
 
 // Data gradient of a replicate-padded convolution with bf16 results (what autocast's convolution backward returns): dy [B,Cdy,H,W] fp32
@@ -535,7 +551,7 @@ __device__ __forceinline__ void wb_unzip(const unsigned (&d)[8], u32x4& lo, u32x
         hi[i] = (d[2 * i] >> 16) | (d[2 * i + 1] & 0xffff0000u);
     }
 }
-template <int K, int DIL, int DYP = 0>
+template <int K, int DIL, int DYP = 0, int XCB = 0>
 __global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(WgradBfArgs a) {
     constexpr int WB_TH = wb_th(K), WB_DYS = wb_dys(K);
     constexpr int PAD = DIL * (K - 1) / 2, PH = WB_TH + 2 * PAD, PW = WB_TW + 2 * PAD, TAPS = K * K;
@@ -600,6 +616,25 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(Wgrad
         }
         // x tile with halo: item = (ci, row, 4-pixel group)
         constexpr int XG = PW / 4;
+        if (XCB) {        // x channel-blocked [B][8][H][W][8]: item = (block, row, pixel pair) -> eight channels x two pixels = four 16-byte loads, eight dword writes
+            constexpr int XG2 = PW / 2;
+            for (int i = tid; i < 8 * PH * XG2; i += NT) {
+                const int g2 = i % XG2, r = (i / XG2) % PH, q = i / (XG2 * PH);
+                int gy = h0 + r - PAD, gx0 = w0 + g2 * 2 - PAD, gx1 = gx0 + 1;
+                const bool rowin = gy >= 0 && gy < a.H;
+                gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                const bool in0 = a.pad_mode == MRX_PAD_REPLICATE || (rowin && gx0 >= 0 && gx0 < a.W), in1 = a.pad_mode == MRX_PAD_REPLICATE || (rowin && gx1 >= 0 && gx1 < a.W);
+                gx0 = gx0 < 0 ? 0 : (gx0 >= a.W ? a.W - 1 : gx0);
+                gx1 = gx1 < 0 ? 0 : (gx1 >= a.W ? a.W - 1 : gx1);
+                const float* bq = a.x + (((long long)b * 8 + q) * plane + (long long)gy * a.W) * 8;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 a0 = in0 ? *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8) : z, a1 = in0 ? *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8 + 4) : z;
+                const float4 b0 = in1 ? *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8) : z, b1 = in1 ? *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8 + 4) : z;
+                const float va[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned*>(Xs + (8 * q + j) * XS + (r * PW + g2 * 2) * 2) = cb_pk(va[j], vb[j]);
+            }
+        } else
         for (int i = tid; i < 64 * PH * XG; i += NT) {
             const int g4 = i % XG, r = (i / XG) % PH, ci = i / (XG * PH);
             const int gy0 = h0 + r - PAD, gx0 = w0 + g4 * 4 - PAD;
@@ -695,7 +730,7 @@ struct WgradBfGArgs {
     float* part;       // [gridDim.x][Cout][Cin][taps]
     int B, Cin, Cout, H, W, tiles_x, ntiles, pad_mode, vec;
 };
-template <int K, int NCO, int NCI, int TPW, int DYP = 0>
+template <int K, int NCO, int NCI, int TPW, int DYP = 0, int XCB = 0>
 __global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgrad_bf16_g(WgradBfGArgs a) {
     constexpr int TH = 8, DYS = TH * WB_TW * 2 + 16, PAD = (K - 1) / 2, PH = TH + 2 * PAD, PW = WB_TW + 2 * PAD, TAPS = K * K;
     constexpr int NW = (TAPS + TPW - 1) / TPW, NT = 64 * NW, XS = ((PH * PW * 2 + 255 - 16) / 256) * 256 + 16;
@@ -765,6 +800,24 @@ __global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgra
                 (u32x4){cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
         }
         constexpr int XG = PW / 2;
+        if (XCB) {        // x channel-blocked [B][Cin/8][H][W][8]: item = (block, row, pixel pair)
+            for (int i = tid; i < (a.Cin >> 3) * PH * XG; i += NT) {
+                const int g2 = i % XG, r = (i / XG) % PH, q = i / (XG * PH);
+                int gy = h0 + r - PAD, gx0 = w0 + g2 * 2 - PAD, gx1 = gx0 + 1;
+                const bool rowin = gy >= 0 && gy < a.H;
+                gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                const bool in0 = a.pad_mode == MRX_PAD_REPLICATE || (rowin && gx0 >= 0 && gx0 < a.W), in1 = a.pad_mode == MRX_PAD_REPLICATE || (rowin && gx1 >= 0 && gx1 < a.W);
+                gx0 = gx0 < 0 ? 0 : (gx0 >= a.W ? a.W - 1 : gx0);
+                gx1 = gx1 < 0 ? 0 : (gx1 >= a.W ? a.W - 1 : gx1);
+                const float* bq = a.x + (((long long)b * (a.Cin >> 3) + q) * plane + (long long)gy * a.W) * 8;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 a0 = in0 ? *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8) : z, a1 = in0 ? *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8 + 4) : z;
+                const float4 b0 = in1 ? *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8) : z, b1 = in1 ? *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8 + 4) : z;
+                const float va[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned*>(Xs + (8 * q + j) * XS + (r * PW + g2 * 2) * 2) = cb_pk(va[j], vb[j]);
+            }
+        } else
         for (int i = tid; i < a.Cin * PH * XG; i += NT) {
             const int g2 = i % XG, r = (i / XG) % PH, ci = i / (XG * PH);
             const int gy0 = h0 + r - PAD, gx0 = w0 + g2 * 2 - PAD;
@@ -839,23 +892,10 @@ __global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgra
     }
 }
 
-// dW[i] (= or +=) sum of the workgroup partials in a fixed order, in double (the second stage of conv_bwd.hip's weight gradient)
+// dW[i] (= or +=) sum of the workgroup partials in a fixed order, in double: mrx_reduce_parts (mrx_common.h)
 __global__ __launch_bounds__(256) void k_wgrad_bf16_reduce(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw,
                                                            int accumulate) {
-    __shared__ double sh[16][17];
-    const int li = threadIdx.x & 15, lp = threadIdx.x >> 4;
-    const long long i = (long long)blockIdx.x * 16 + li;
-    double s = 0.0;
-    if (i < n)
-        for (int p = lp; p < nparts; p += 16) s += (double)part[(long long)p * n + i];
-    sh[lp][li] = s;
-    __syncthreads();
-    if (lp == 0 && i < n) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += sh[k][li];
-        dw[i] = accumulate ? dw[i] + (float)t : (float)t;
-    }
+    mrx_reduce_parts(part, nparts, n, dw, accumulate);
 }
 
 static int wb_nwg(int B, int H, int W, int k) {
@@ -892,16 +932,16 @@ extern "C" int64_t mrx_conv_wgrad_bf16_work_floats(int B, int H, int W, int k) {
     if (B < 1 || H < 1 || W < 1 || (k != 1 && k != 3 && k != 5)) return -1;
     return (int64_t)wb_nwg(B, H, W, k) * 64 * 64 * k * k;      // an upper bound for the thin layers
 }
-template <int K, int DIL, int DYP = 0>
+template <int K, int DIL, int DYP = 0, int XCB = 0>
 static int wb_launch(const WgradBfArgs& a, int nwg, hipStream_t st) {
     constexpr size_t lds = (size_t)64 * wb_dys(K) + (size_t)64 * wb_xs(K, DIL);
     static_assert(lds >= (wb_th(K) / 2) * 4096 * sizeof(float) || K != 1, "1x1: LDS also holds the wave reduction");
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<K, DIL, DYP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<K, DIL, DYP, XCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_bf16<K, DIL, DYP>), dim3(nwg), dim3(K == 1 ? 64 * wb_th(K) : 576), lds, st, a);
+    hipLaunchKernelGGL((k_conv_wgrad_bf16<K, DIL, DYP, XCB>), dim3(nwg), dim3(K == 1 ? 64 * wb_th(K) : 576), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -909,17 +949,17 @@ extern "C" int64_t mrx_conv_wgrad_bf16_any_work_floats(int B, int Cin, int Cout,
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (k != 1 && k != 3 && k != 5)) return -1;
     return (int64_t)wb_nwg_any(B, Cin, Cout, H, W, k) * Cout * Cin * k * k;
 }
-template <int K, int NCO, int NCI, int TPW, int DYP = 0>
+template <int K, int NCO, int NCI, int TPW, int DYP = 0, int XCB = 0>
 static int wbg_launch(const WgradBfGArgs& a, int nwg, hipStream_t st) {
     constexpr int PAD = (K - 1) / 2, PH = 8 + 2 * PAD, PW = WB_TW + 2 * PAD, XS = ((PH * PW * 2 + 255 - 16) / 256) * 256 + 16;
     constexpr int NW = (K * K + TPW - 1) / TPW;
     const size_t lds = (size_t)(a.Cout + 1) * (8 * WB_TW * 2 + 16) + (size_t)(a.Cin + 1) * XS;
     static size_t attr = 0;
     if (lds > 48 * 1024 && attr < lds) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_g<K, NCO, NCI, TPW, DYP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_g<K, NCO, NCI, TPW, DYP, XCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_bf16_g<K, NCO, NCI, TPW, DYP>), dim3(nwg), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((k_conv_wgrad_bf16_g<K, NCO, NCI, TPW, DYP, XCB>), dim3(nwg), dim3(64 * NW), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -940,7 +980,7 @@ extern "C" int mrx_conv_wgrad_bf16_any(const float* x, const float* dy, float* d
     int rc = k == 3 ? wbg_launch<3, 1, 2, 1>(a, nwg, st) : wbg_launch<5, 2, 1, 2>(a, nwg, st);
     if (rc) return rc;
     const long long total = (long long)Cout * Cin * k * k;
-    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -958,15 +998,35 @@ extern "C" int mrx_conv_wgrad_bf16(const float* x, const float* dy, float* dw, f
     int rc = k == 1 ? wb_launch<1, 1>(a, nwg, st) : wb_launch<3, 2>(a, nwg, st);
     if (rc) return rc;
     const long long total = 64ll * 64 * k * k;
-    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 
 // The same weight gradients with dy given as a PAIR tensor [B,32,H,W] (the bf16 gradient mrx_tl_cell_bwd leaves): 3x3 dilation 2 64 -> 64 and the thin
 // 5x5 Cin <= 32 -> 64 layer.  x stays fp32 NCHW (rounded by the tile loader).
+// Weight gradient of the final 3x3 convolution (64 -> Cout <= 32, dilation 1) with x CHANNEL-BLOCKED [B,8,H,W,8] (the training tape's hidden state) and dy fp32
+// [B,Cout,H,W]: mrx_conv_wgrad_bf16_any's thin kernel with the blocked tile loader.  work: mrx_conv_wgrad_bf16_any_work_floats(B, 64, Cout, H, W, 3).
+extern "C" int mrx_conv_wgrad_bf16_xcb(const float* x_cb8, const float* dy, float* dw, float* work, int B, int Cout, int H, int W, int pad_mode, int accumulate,
+                                       void* stream) {
+    MRX_REQUIRE(x_cb8 && dy && dw && work, MRX_EINVAL, "mrx_conv_wgrad_bf16_xcb: null pointer");
+    MRX_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && Cout <= 32, MRX_EUNSUP, "mrx_conv_wgrad_bf16_xcb: Cout=%d (1 .. 32)", Cout);
+    WgradBfGArgs a;
+    a.x = x_cb8, a.dy = dy, a.part = work, a.B = B, a.Cin = 64, a.Cout = Cout, a.H = H, a.W = W;
+    a.tiles_x = mrx_cdiv(W, WB_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, 8), a.pad_mode = pad_mode;
+    a.vec = (W % 4 == 0) && (((uintptr_t)x_cb8 | (uintptr_t)dy) % 16 == 0);
+    const int nwg = wb_nwg_any(B, 64, Cout, H, W, 3);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = wbg_launch<3, 1, 2, 1, 0, 1>(a, nwg, st);
+    if (rc) return rc;
+    const long long total = (long long)Cout * 64 * 9;
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// (x_blocked != 0: x is channel-blocked [B,8,H,W,8] -- the 64-channel layer's input in the training tape)
 extern "C" int mrx_conv_wgrad_bf16_pairs(const float* x, const void* dy_pairs, float* dw, float* work, int B, int Cin, int H, int W, int k, int dil,
-                                         int pad_mode, int accumulate, void* stream) {
+                                         int pad_mode, int accumulate, int x_blocked, void* stream) {
     MRX_REQUIRE(x && dy_pairs && dw && work, MRX_EINVAL, "mrx_conv_wgrad_bf16_pairs: null pointer");
     MRX_REQUIRE(B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_wgrad_bf16_pairs: bad dims");
     hipStream_t st = (hipStream_t)stream;
@@ -977,10 +1037,10 @@ extern "C" int mrx_conv_wgrad_bf16_pairs(const float* x, const void* dy_pairs, f
         WgradBfArgs a;
         a.x = x, a.dy = (const float*)dy_pairs, a.part = work, a.B = B, a.H = H, a.W = W;
         a.tiles_x = mrx_cdiv(W, WB_TW), a.tiles_y = mrx_cdiv(H, wb_th(k)), a.ntiles = a.tiles_x * a.tiles_y, a.pad_mode = pad_mode, a.vec = vec;
-        int rc = wb_launch<3, 2, 1>(a, nwg, st);
+        int rc = x_blocked ? wb_launch<3, 2, 1, 1>(a, nwg, st) : wb_launch<3, 2, 1, 0>(a, nwg, st);
         if (rc) return rc;
         total = 64ll * 64 * 9;
-    } else if (k == 5 && dil == 1 && Cin >= 1 && Cin <= 32) {
+    } else if (k == 5 && dil == 1 && Cin >= 1 && Cin <= 32 && !x_blocked) {
         WgradBfGArgs a;
         a.x = x, a.dy = (const float*)dy_pairs, a.part = work, a.B = B, a.Cin = Cin, a.Cout = 64, a.H = H, a.W = W;
         a.tiles_x = mrx_cdiv(W, WB_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, 8), a.pad_mode = pad_mode, a.vec = vec;
@@ -990,7 +1050,7 @@ extern "C" int mrx_conv_wgrad_bf16_pairs(const float* x, const void* dy_pairs, f
     } else {
         MRX_REQUIRE(false, MRX_EUNSUP, "mrx_conv_wgrad_bf16_pairs: Cin=%d k=%d dilation=%d not instantiated", Cin, k, dil);
     }
-    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

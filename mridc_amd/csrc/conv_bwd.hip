@@ -214,24 +214,10 @@ __global__ __launch_bounds__(WG_NT, 2) void k_conv_wgrad64(WgradArgs a) {
     }
 }
 
-// dW[i] (= or +=) sum over the workgroup partials in a fixed order, in double: a workgroup takes 16 consecutive outputs, 16 threads
-// per output stride through the partials (coalesced 64-byte rows of `part`), then their 16 sums are added in order
+// dW[i] (= or +=) sum over the workgroup partials in a fixed order, in double: mrx_reduce_parts (mrx_common.h)
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw,
                                                       int accumulate) {
-    __shared__ double sh[16][17];
-    const int li = threadIdx.x & 15, lp = threadIdx.x >> 4;
-    const long long i = (long long)blockIdx.x * 16 + li;
-    double s = 0.0;
-    if (i < n)
-        for (int p = lp; p < nparts; p += 16) s += (double)part[(long long)p * n + i];
-    sh[lp][li] = s;
-    __syncthreads();
-    if (lp == 0 && i < n) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += sh[k][li];
-        dw[i] = accumulate ? dw[i] + (float)t : (float)t;
-    }
+    mrx_reduce_parts(part, nparts, n, dw, accumulate);
 }
 
 // ---- weight gradient, small Cout (final RIM layer: 2): one workgroup per (input channel, slab of rows), all taps and all Cout at
@@ -554,7 +540,7 @@ extern "C" int mrx_conv_wgrad(const float* x, const float* dy, float* dw, float*
         else hipLaunchKernelGGL(k_conv_wgrad_small<5>, dim3(Cin, nparts), dim3(WS_NT), 0, st, a);
     }
     MRX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nparts, total, dw,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, (const float*)work, nparts, total, dw,
                        accumulate);
     MRX_LAUNCH_CHECK();
     return MRX_OK;

@@ -8,6 +8,13 @@
 //                           rstd from the forward's partial sums (the `work` buffer of mrx_instance_norm_act); two deterministic passes
 //   mrx_avgpool2x2_bwd      dx[h][w] = dy[h / 2][w / 2] / 4 inside the pooled region, 0 in an odd last row / column
 //   mrx_pixel_unshuffle2    [B,C,2H,2W] -> [B,4C,H,W], channel (c, i, j): the layout in which ConvTranspose2d(k 2, s 2)'s two gradients are 1x1 GEMMs
+//   mrx_cmul_bcast          out[b,c] = a[b,c] * v[b] (or conj(v[b])) * scale: the sensitivity-map gradient of sens_reduce (vn_block.py:71-87):
+//                           dS_c = conj(dy) * ifft2(k)_c
+//   mrx_sens_expand_bwd_pw  the pointwise half of sens_expand's backward (vn_block.py:51-69: out_c = fft2(x S_c)) from G_c = adjoint-fft2(dy_c):
+//                           dx = scale * sum_c conj(S_c) G_c,  dS_c = scale * conj(x) G_c  -- one pass over G and S
+//   mrx_dc_combine_bwd      backward of base - where(mask, pred - ref, 0) * w - eta_k (vn_block.py:113-119): dpred = -where(mask, dy, 0) * w
+//                           (+ dy when base and pred are the same tensor), deta = -dy, per-workgroup partial sums of where(mask, (pred - ref) . dy)
+//                           for dw = -sum
 #include "mrx_common.h"
 
 #define DB_NT 256
@@ -140,6 +147,127 @@ extern "C" int mrx_pixel_unshuffle2(const float* x, float* out, int64_t BC, int 
     MRX_REQUIRE(x && out && BC >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_pixel_unshuffle2: bad argument");
     if (BC == 0) return MRX_OK;
     hipLaunchKernelGGL(k_pixel_unshuffle2, dim3(db_grid(BC * 4 * H * W)), dim3(DB_NT), 0, (hipStream_t)stream, x, out, (long long)BC, H, W);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+
+// ---- coil operators and data consistency of the VarNet block (vn_block.py:51-119): the pointwise halves of their backward -------------------------
+__global__ void k_cmul_bcast(const float2* __restrict__ a, const float2* __restrict__ v, float2* __restrict__ out, long long C, long long N, long long total,
+                             int conj_v, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / (C * N), n = i % N;
+        const float2 x = a[i];
+        float2 y = v[b * N + n];
+        if (conj_v) y.y = -y.y;
+        out[i] = make_float2((x.x * y.x - x.y * y.y) * scale, (x.x * y.y + x.y * y.x) * scale);
+    }
+}
+extern "C" int mrx_cmul_bcast(const float* a, const float* v, float* out, int64_t B, int64_t C, int64_t N, int conj_v, float scale, void* stream) {
+    MRX_REQUIRE(a && v && out && B >= 0 && C >= 0 && N >= 0, MRX_EINVAL, "mrx_cmul_bcast: bad argument");
+    const long long total = (long long)B * C * N;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_cmul_bcast, dim3(db_grid(total)), dim3(DB_NT), 0, (hipStream_t)stream, (const float2*)a, (const float2*)v, (float2*)out, (long long)C,
+                       (long long)N, total, conj_v, scale);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+__global__ void k_sens_expand_bwd_pw(const float2* __restrict__ G, const float2* __restrict__ S, const float2* __restrict__ x, float2* __restrict__ dx,
+                                     float2* __restrict__ dS, long long C, long long N, long long BN, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < BN; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / N, n = i - b * N;
+        const float2 xv = x ? x[i] : make_float2(0.f, 0.f);
+        float sx = 0.f, sy = 0.f;
+        for (long long c = 0; c < C; ++c) {
+            const long long o = (b * C + c) * N + n;
+            const float2 g = G[o], sv = S[o];
+            sx += sv.x * g.x + sv.y * g.y;                 // conj(S) G
+            sy += sv.x * g.y - sv.y * g.x;
+            if (dS) dS[o] = make_float2((xv.x * g.x + xv.y * g.y) * scale, (xv.x * g.y - xv.y * g.x) * scale);      // conj(x) G
+        }
+        if (dx) dx[i] = make_float2(sx * scale, sy * scale);
+    }
+}
+extern "C" int mrx_sens_expand_bwd_pw(const float* G, const float* S, const float* x, float* dx, float* dS, int64_t B, int64_t C, int64_t N, float scale,
+                                      void* stream) {
+    MRX_REQUIRE(G && S && (dx || dS) && (x || !dS) && B >= 0 && C >= 0 && N >= 0, MRX_EINVAL, "mrx_sens_expand_bwd_pw: bad argument");
+    const long long BN = (long long)B * N;
+    if (BN == 0 || C == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_sens_expand_bwd_pw, dim3(db_grid(BN)), dim3(DB_NT), 0, (hipStream_t)stream, (const float2*)G, (const float2*)S, (const float2*)x,
+                       (float2*)dx, (float2*)dS, (long long)C, (long long)N, BN, scale);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+#define DCB_BLOCKS 1024
+__global__ __launch_bounds__(DB_NT) void k_dc_combine_bwd(const float2* __restrict__ dy, const float2* __restrict__ pred, const float2* __restrict__ ref, MrxMask m,
+                                                          const float* __restrict__ dcw, float2* __restrict__ dpred, float2* __restrict__ deta,
+                                                          double* __restrict__ part, int add_dy, long long C, long long H, long long W, long long total) {
+    __shared__ double red[DB_NT / 64];
+    const float w8 = dcw[0];
+    double acc = 0.0;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        long long r = o;
+        const long long w = r % W;
+        r /= W;
+        const long long h = r % H;
+        r /= H;
+        const long long c = r % C, b = r / C;
+        const float2 g = dy[o];
+        float2 d = make_float2(0.f, 0.f);
+        if (mrx_mask_true(m, b, c, h, w)) {
+            d = make_float2(g.x * w8, g.y * w8);
+            if (part) {
+                const float2 p = pred[o], q = ref[o];
+                acc += (double)((p.x - q.x) * g.x) + (double)((p.y - q.y) * g.y);
+            }
+        }
+        if (dpred) dpred[o] = add_dy ? make_float2(g.x - d.x, g.y - d.y) : make_float2(-d.x, -d.y);
+        if (deta) deta[o] = make_float2(-g.x, -g.y);
+    }
+    if (part) {
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = red[0];
+            for (int k = 1; k < DB_NT / 64; ++k) t += red[k];
+            part[blockIdx.x] = t;
+        }
+    }
+}
+__global__ void k_dcw_final(const double* __restrict__ part, int n, float* __restrict__ dw) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < n; ++i) t += part[i];
+        dw[0] = (float)(-t);
+    }
+}
+extern "C" int64_t mrx_dc_combine_bwd_work_doubles(void) { return DCB_BLOCKS; }
+// dpred / deta / dw may be null (not needed); add_dy: base and pred are the same tensor (its gradient = dy - where(mask, dy, 0) * w); dw: one float;
+// work: mrx_dc_combine_bwd_work_doubles doubles (only with dw)
+extern "C" int mrx_dc_combine_bwd(const float* dy, const float* pred, const float* ref, const void* mask, int mask_kind, const int64_t* mstride,
+                                  const float* dc_weight, float* dpred, float* deta, float* dw, double* work, int add_dy, int B, int C, int H, int W,
+                                  void* stream) {
+    MRX_REQUIRE(dy && dc_weight && mask && mstride && (dpred || deta || dw), MRX_EINVAL, "mrx_dc_combine_bwd: null pointer");
+    MRX_REQUIRE(!dw || (pred && ref && work), MRX_EINVAL, "mrx_dc_combine_bwd: dw needs pred, ref and work");
+    MRX_REQUIRE(mask_kind == MRX_MASK_U8 || mask_kind == MRX_MASK_F32, MRX_EINVAL, "mrx_dc_combine_bwd: bad mask kind %d", mask_kind);
+    MRX_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0, MRX_EINVAL, "mrx_dc_combine_bwd: negative dim");
+    MrxMask m;
+    m.p = mask, m.kind = mask_kind;
+    for (int i = 0; i < 4; ++i) m.s[i] = mstride[i];
+    const long long total = (long long)B * C * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    if (total == 0) {
+        if (dw) MRX_HIP(hipMemsetAsync(dw, 0, sizeof(float), st));
+        return MRX_OK;
+    }
+    long long nb = (total + DB_NT - 1) / DB_NT;
+    if (nb > DCB_BLOCKS) nb = DCB_BLOCKS;
+    hipLaunchKernelGGL(k_dc_combine_bwd, dim3((unsigned)nb), dim3(DB_NT), 0, st, (const float2*)dy, (const float2*)pred, (const float2*)ref, m, dc_weight,
+                       (float2*)dpred, (float2*)deta, dw ? work : (double*)nullptr, add_dy, (long long)C, (long long)H, (long long)W, total);
+    if (dw) hipLaunchKernelGGL(k_dcw_final, dim3(1), dim3(64), 0, st, (const double*)work, (int)nb, dw);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

@@ -80,7 +80,10 @@ __global__ void k_llg372_prep_mask(MrxMask mask, float* __restrict__ maskp, int 
 // (operands not loaded from HBM); 3 the kernel with s_memtime stamps per phase (tools/probe/llg372_trace.py).  Measured at 15 x 640 x 372:
 // memory only 11.1 us, compute only 12.3 us, the kernel 17.3 us (rocprofv3) -- every wave waits ~8 us for its first operands (the whole
 // launch requests its 63 MB at once) and the two waves of a SIMD then share the vector ALU for ~8.7 us.
-template <int ABL>
+// NOY: the measured data is not read -- the gradient is affine in eta, g = A^H M A eta - A^H M y, and the second term is ONE constant plane per slice
+// (mrx_llg372_const_plane: this kernel on eta = 0, its partial planes summed) that the consumer of the partial planes adds like one more coil group:
+// 34.5 MB per launch instead of 63.1 MB at 15 coils.  The same kernel with NOY is the ADJOINT of the linear part (training).
+template <int ABL, bool NOY = false>
 __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta_, const float2* __restrict__ ytp_,
                                                    const float2* __restrict__ Sp_, const float* __restrict__ maskp,
                                                    float2* __restrict__ part_, L372Args a) {
@@ -137,7 +140,10 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
             v[2 * j + 1] = pfa_mk(t.z, t.w);
         }
     };
-    if (ABL == 2) {
+    if (NOY) {
+#pragma unroll
+        for (int k1 = 0; k1 < 12; ++k1) yv0[k1] = yv1[k1] = yv2[k1] = pfa_mk(0.f, 0.f);
+    } else if (ABL == 2) {
 #pragma unroll
         for (int k1 = 0; k1 < 12; ++k1) yv0[k1] = pfa_mk((float)k1, 1.f), yv1[k1] = pfa_mk((float)k1, 2.f);
     } else {
@@ -176,7 +182,8 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
     L372_STAMP(2)
     if (laneA) pfa372_stage_a(L, X, g1, n1);
     L372_STAMP(3)
-    if (ABL == 2) {
+    if (NOY) {
+    } else if (ABL == 2) {
 #pragma unroll
         for (int k1 = 0; k1 < 12; ++k1) yv2[k1] = pfa_mk((float)k1, 3.f);
     } else {
@@ -443,6 +450,9 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_reduce(const float2* __restric
     }
 }
 
+__global__ void k_l372_zero(float2* __restrict__ p, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) p[i] = make_float2(0.f, 0.f);
+}
 // out[i] = sum_k part_k[i]   (complex image [B,H,372])
 __global__ void k_pfa372_sum(const float2* __restrict__ part, float2* __restrict__ out, int nparts, long long total) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -531,7 +541,8 @@ extern "C" int mrx_llg372_prepare(const float* yt, const float* S, const void* m
 }
 extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* out4,
                           float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream) {
-    MRX_REQUIRE(eta && ytp && Sp && maskp && work && (out4 || nparts), MRX_EINVAL, "mrx_llg372: null pointer");
+    MRX_REQUIRE(eta && Sp && maskp && work && (out4 || nparts), MRX_EINVAL, "mrx_llg372: null pointer");
+    const bool noy = ytp == nullptr;      // plane T of `work` holds the constant term (mrx_llg372_const_plane; zeros: the linear part alone = its own adjoint)
     L372Args a;
     int rc = l372_args(&a, B, C, H, norm, centered, mask_batched);
     if (rc) return rc;
@@ -542,7 +553,9 @@ extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, c
     static const int ablate = MRX_DEBUG_ENV("MRX_LLG372_ABLATE") ? atoi(MRX_DEBUG_ENV("MRX_LLG372_ABLATE")) : 0;
     const dim3 grid((unsigned)a.ntasks), blk(64);
     const float2 *pe = (const float2*)eta, *py = (const float2*)ytp, *ps = (const float2*)Sp;
-    if (ablate == 1)
+    if (noy)
+        hipLaunchKernelGGL((k_llg372<0, true>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+    else if (ablate == 1)
         hipLaunchKernelGGL((k_llg372<1>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
     else if (ablate == 2)
         hipLaunchKernelGGL((k_llg372<2>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
@@ -581,16 +594,44 @@ extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, c
         }
     } else
         hipLaunchKernelGGL((k_llg372<0>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+    const int np = a.T + (noy ? 1 : 0);
     if (nparts) {
-        *nparts = a.T;
+        *nparts = np;
         MRX_LAUNCH_CHECK();
         return MRX_OK;
     }
     const long long plane = (long long)H * PFA_N, total = plane * B;
     long long nb = (total + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_llg372_combine, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)eta, (const float2*)work, out4, a.T,
+    hipLaunchKernelGGL(k_llg372_combine, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)eta, (const float2*)work, out4, np,
                        (long long)B, plane, inv_sigma2);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// The constant term of the gradient, -A^H M y = -sum_c conj(S_c) IFFT_W(m yt_c), into plane T (T = ceil(C / 5)) of `work`
+// ((T + 1) planes [B,H,372,2] = mrx_llg372_work_floats + B * H * 372 * 2 floats): the full kernel on eta = 0 and the sum of its T partial planes, once
+// per slice.  Afterwards mrx_llg372(ytp = NULL) leaves planes 0 .. T - 1 = the linear part and reports T + 1 partial planes.
+extern "C" int mrx_llg372_const_plane(const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* work, int B, int C, int H,
+                                      int norm, int centered, void* stream) {
+    MRX_REQUIRE(ytp && Sp && maskp && work, MRX_EINVAL, "mrx_llg372_const_plane: null pointer");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, mask_batched);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_llg372_const_plane: too many tasks");
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)B * H * PFA_N;
+    float2* cpl = (float2*)work + (long long)a.T * total;
+    // eta = 0, read from the plane that receives the result afterwards.  (A kernel, not hipMemsetAsync: captured into a hipGraph the memset node was not
+    // ordered against the kernels around it -- replays of tests/test_gpu_graph.py differed from run to run.)
+    long long nz = (total + 255) / 256;
+    if (nz > 2048) nz = 2048;
+    hipLaunchKernelGGL(k_l372_zero, dim3((unsigned)nz), dim3(256), 0, st, cpl, total);
+    hipLaunchKernelGGL((k_llg372<0>), dim3((unsigned)a.ntasks), dim3(64), L372_LDS_BYTES, st, (const float2*)cpl, (const float2*)ytp, (const float2*)Sp,
+                       maskp, (float2*)work, a);
+    long long nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_pfa372_sum, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)work, cpl, a.T, total);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

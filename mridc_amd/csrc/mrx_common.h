@@ -71,6 +71,54 @@ __device__ __forceinline__ float mrx_mul_sub(float a, float s, float t) {
     const float m = a * s;
     return m - t;
 }
+// Second stage of every weight gradient: out[i] (= or +=) sum over `nparts` workgroup partials [nparts][n] in a FIXED order, in double
+// (bit-reproducible).  Launch with (n + 63) / 64 workgroups of 256 threads.  Thread = four consecutive outputs of one of 16 slot groups: a slot is
+// read in 256-byte pieces (the first form read 64-byte pieces, one dword per lane, and ran at 0.4 TB/s -- as long as the gradient kernel in front of
+// it); group g sums slots g, g + 16, ... and the groups are added in order 0 .. 15, the same order of additions as before.
+__device__ __forceinline__ void mrx_reduce_parts(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw, int accumulate) {
+    __shared__ double sh[16][16][4 + 1];
+    const int li = threadIdx.x & 15, lp = threadIdx.x >> 4;
+    const long long i = ((long long)blockIdx.x * 16 + li) * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if ((n & 3) == 0) {
+        if (i < n) {
+            const float* q = part + i;
+            int p = lp;
+            for (; p + 48 < nparts; p += 64) {          // four slots in flight
+                const float4 u0 = *reinterpret_cast<const float4*>(q + (long long)p * n), u1 = *reinterpret_cast<const float4*>(q + (long long)(p + 16) * n);
+                const float4 u2 = *reinterpret_cast<const float4*>(q + (long long)(p + 32) * n), u3 = *reinterpret_cast<const float4*>(q + (long long)(p + 48) * n);
+                s0 += (double)u0.x, s1 += (double)u0.y, s2 += (double)u0.z, s3 += (double)u0.w;
+                s0 += (double)u1.x, s1 += (double)u1.y, s2 += (double)u1.z, s3 += (double)u1.w;
+                s0 += (double)u2.x, s1 += (double)u2.y, s2 += (double)u2.z, s3 += (double)u2.w;
+                s0 += (double)u3.x, s1 += (double)u3.y, s2 += (double)u3.z, s3 += (double)u3.w;
+            }
+            for (; p < nparts; p += 16) {
+                const float4 u = *reinterpret_cast<const float4*>(q + (long long)p * n);
+                s0 += (double)u.x, s1 += (double)u.y, s2 += (double)u.z, s3 += (double)u.w;
+            }
+        }
+    } else {                                            // (no shape of this library: n = Cout * Cin * k * k with Cout or Cin a multiple of 4)
+        for (int p = lp; p < nparts; p += 16) {
+            if (i < n) s0 += (double)part[(long long)p * n + i];
+            if (i + 1 < n) s1 += (double)part[(long long)p * n + i + 1];
+            if (i + 2 < n) s2 += (double)part[(long long)p * n + i + 2];
+            if (i + 3 < n) s3 += (double)part[(long long)p * n + i + 3];
+        }
+    }
+    sh[lp][li][0] = s0, sh[lp][li][1] = s1, sh[lp][li][2] = s2, sh[lp][li][3] = s3;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x >> 2, j = threadIdx.x & 3;
+        const long long o = ((long long)blockIdx.x * 16 + c) * 4 + j;
+        if (o < n) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += sh[k][c][j];
+            dw[o] = accumulate ? dw[o] + (float)t : (float)t;
+        }
+    }
+}
+
 #endif
 
 // output tile of the convolution kernels (also the granule of the fused InstanceNorm tile statistics)

@@ -58,8 +58,8 @@ __device__ __forceinline__ float tl_reduce_scatter32(float (&x)[32], int lane) {
 struct CellBwdArgs {
     const unsigned* dhP;   // [B,32,H,W] pairs or null: gradient from the layer above
     const float* dH;       // [B,8,H,W,8] (channel-blocked: c = 8 q + j) or null: gradient carried from the next time-step -- written as dh_prev by the previous call
-    const float* h;        // [B,64,H,W]: this step's state (the cell's ReLU mask)
-    const float* hprev;    // [B,64,H,W] or null (first time-step: zero state)
+    const float* h;        // [B,8,H,W,8] channel-blocked: this step's state (the cell's ReLU mask)
+    const float* hprev;    // [B,8,H,W,8] or null (first time-step: zero state)
     const unsigned* aP;    // [B,32,H,W] pairs: a = ReLU(conv)  (the convolution's ReLU mask and the 1x1 weight gradient's operand)
     const u32x4* wT;       // mrx_tl_pack's ihT block: [4 steps][2 blocks][64 lanes]
     const float* hh;       // [64]
@@ -90,7 +90,6 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
     __syncthreads();
     // every tensor is addressed as (wave-uniform base) + (32-bit byte offset of the lane): one address register per access instead of a 64-bit pair
     // (the first form precomputed ~60 pointers and spilled them)
-    auto ldf = [](const float* p, unsigned o) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + o); };
     auto ldu = [](const unsigned* p, unsigned o) { return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(p) + o); };
     const unsigned plane4 = (unsigned)plane * 4u;
     const int total = a.ntiles * a.B;
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
         const int ty0 = tt / a.tiles_x, oy = ty0 * 8 + wave, ox = (tt - ty0 * a.tiles_x) * 32 + l31;
         const bool valid = oy < a.H && ox < a.W;
         const unsigned pix4 = (unsigned)((oy < a.H ? oy : a.H - 1) * a.W + (ox < a.W ? ox : a.W - 1)) * 4u;
-        const unsigned pb = (unsigned)b * 32u * plane4 + pix4 + 16u * lhi * plane4, fb = (unsigned)b * 64u * plane4 + pix4 + 32u * lhi * plane4;
+        const unsigned pb = (unsigned)b * 32u * plane4 + pix4 + 16u * lhi * plane4;
         const unsigned ab = (unsigned)b * 32u * plane4 + pix4 + 2u * lhi * plane4;
         const unsigned cbb = (unsigned)b * 64u * plane4 + pix4 * 8u + 4u * lhi * 8u * plane4;      // channel-blocked: block 4 lhi + ch, 32 bytes per pixel
         // ---- cell stage: lane = pixel, channels 32 lhi + i; eight channels at a time -----------------------------------------------------------
@@ -117,11 +116,18 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
         auto request = [&](int ch, int bf) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) d2[bf][q] = ldu(a.dhP, pb + (unsigned)(4 * ch + q) * plane4);
+            {
+                const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.h) + cbb + (unsigned)ch * 8u * plane4);
+                const float4 u0 = q4[0], u1 = q4[1];
+                hv[bf][0] = u0.x, hv[bf][1] = u0.y, hv[bf][2] = u0.z, hv[bf][3] = u0.w, hv[bf][4] = u1.x, hv[bf][5] = u1.y, hv[bf][6] = u1.z, hv[bf][7] = u1.w;
+            }
+            if (HAS_PREV) {
+                const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.hprev) + cbb + (unsigned)ch * 8u * plane4);
+                const float4 u0 = q4[0], u1 = q4[1];
+                hpv[bf][0] = u0.x, hpv[bf][1] = u0.y, hpv[bf][2] = u0.z, hpv[bf][3] = u0.w, hpv[bf][4] = u1.x, hpv[bf][5] = u1.y, hpv[bf][6] = u1.z, hpv[bf][7] = u1.w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned o = fb + (unsigned)(8 * ch + j) * plane4;
-                hv[bf][j] = ldf(a.h, o);
-                hpv[bf][j] = HAS_PREV ? ldf(a.hprev, o) : 0.f;
+                for (int j = 0; j < 8; ++j) hpv[bf][j] = 0.f;
             }
             if (HAS_DH) {
                 const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dH) + cbb + (unsigned)ch * 8u * plane4);
@@ -552,20 +558,7 @@ __global__ __launch_bounds__(WI_NT, 2) void k_tl_wgrad_in(const float* __restric
     }
 }
 __global__ __launch_bounds__(256) void k_tl_part_reduce(const float* __restrict__ part, int nparts, long long n, float* __restrict__ dw, int accumulate) {
-    __shared__ double sh[16][17];
-    const int li = threadIdx.x & 15, lp = threadIdx.x >> 4;
-    const long long i = (long long)blockIdx.x * 16 + li;
-    double s = 0.0;
-    if (i < n)
-        for (int p = lp; p < nparts; p += 16) s += (double)part[(long long)p * n + i];
-    sh[lp][li] = s;
-    __syncthreads();
-    if (lp == 0 && i < n) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += sh[k][li];
-        dw[i] = accumulate ? dw[i] + (float)t : (float)t;
-    }
+    mrx_reduce_parts(part, nparts, n, dw, accumulate);
 }
 static int wi_nwg(long long tiles) {
     const long long cap = 2ll * tl_nwg(1ll << 40);            // (three per CU measured 29.7 us + 17.3 us for the 768-partial reduction)
@@ -587,7 +580,7 @@ extern "C" int mrx_tl_wgrad_in(const float* x, const void* dy_pairs, float* dw, 
     hipLaunchKernelGGL(k_tl_wgrad_in<5>, dim3(nwg), dim3(WI_NT), lds, st, x, (const unsigned*)dy_pairs, work, B, Cin, H, W, tiles_x, ntiles);
     MRX_LAUNCH_CHECK();
     const long long total = 64ll * Cin * 25;
-    hipLaunchKernelGGL(k_tl_part_reduce, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
+    hipLaunchKernelGGL(k_tl_part_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, (const float*)work, nwg, total, dw, accumulate);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

@@ -195,20 +195,85 @@ def complex_conj(a):
     return torch.stack([a[..., 0], -a[..., 1]], -1)
 
 
+class _SensExpand(torch.autograd.Function):
+    """out_c = fft2(x * S_c) (vn_block.py:51-69), forward on the fused kernel; backward: G_c = adjoint-fft2(dy_c), then ONE pointwise pass for
+    dx = sum_c conj(S_c) G_c and dS_c = conj(x) G_c (mrx_sens_expand_bwd_pw)."""
+
+    @staticmethod
+    def forward(ctx, x, sens, centered, normalization, spatial_dims):
+        ctx.save_for_backward(x, sens)
+        ctx.cfg = (centered, normalization, spatial_dims, tuple(x.shape))
+        return ops.sens_expand(x, sens, centered, normalization, spatial_dims)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sens = ctx.saved_tensors
+        centered, normalization, spatial_dims, xshape = ctx.cfg
+        r = _ratio(dy, normalization, spatial_dims)                      # adjoint(fft2) = r * ifft2
+        G = fft.ifft2(dy.contiguous(), centered=centered, normalization=normalization, spatial_dims=spatial_dims)
+        dx, dS = ops.sens_expand_bwd_pointwise(G, sens, x, ctx.needs_input_grad[0], ctx.needs_input_grad[1], r)
+        return (dx.reshape(xshape) if dx is not None else None), dS, None, None, None
+
+
 def sens_expand(x, sens, centered, normalization, spatial_dims=None, hybrid=False):
     """vn_block.py:51-69: fft2(x * S)."""
-    return fft2(complex_mul(x, sens), centered, normalization, spatial_dims)
+    return _SensExpand.apply(x, sens, centered, normalization, spatial_dims)
+
+
+class _SensReduce(torch.autograd.Function):
+    """sum_c conj(S_c) * ifft2(k)_c (vn_block.py:71-87), forward on the fused kernel; backward: dk = adjoint-ifft2(S_c dy) = the fused sens_expand / r,
+    dS_c = conj(dy) * ifft2(k)_c (one transform of the saved k-space + mrx_cmul_bcast)."""
+
+    @staticmethod
+    def forward(ctx, k, sens, centered, normalization, spatial_dims):
+        ctx.save_for_backward(k, sens)
+        ctx.cfg = (centered, normalization, spatial_dims)
+        return ops.sens_reduce(k, sens, centered, normalization, spatial_dims)
+
+    @staticmethod
+    def backward(ctx, dy):
+        k, sens = ctx.saved_tensors
+        centered, normalization, spatial_dims = ctx.cfg
+        dy = dy.contiguous()
+        dk = dS = None
+        if ctx.needs_input_grad[0]:
+            r = _ratio(k, normalization, spatial_dims)                   # adjoint(ifft2) = fft2 / r
+            dk = ops.sens_expand(dy, sens, centered, normalization, spatial_dims)
+            if r != 1.0:
+                dk.mul_(1.0 / r)
+        if ctx.needs_input_grad[1]:
+            img = fft.ifft2(k, centered=centered, normalization=normalization, spatial_dims=spatial_dims)
+            dS = ops.cmul_bcast(img, dy, conj_v=True)
+        return dk, dS, None, None, None
 
 
 def sens_reduce(k, sens, centered, normalization, spatial_dims=None, work=None, hybrid=False):
     """vn_block.py:71-87 without the keepdim: sum_c conj(S_c) * ifft2(k)_c."""
-    return complex_mul(ifft2(k, centered, normalization, spatial_dims), complex_conj(sens)).sum(1)
+    return _SensReduce.apply(k, sens, centered, normalization, spatial_dims)
+
+
+class _DcCombine(torch.autograd.Function):
+    """base - where(mask, pred - ref, 0) * dc_weight - eta_k (vn_block.py:113-119) on mrx_dc_combine / mrx_dc_combine_bwd.  base None: base = pred
+    (the VarNet block's call) -- one input, whose whole gradient dy - where(mask, dy, 0) * w comes out of the one backward pass."""
+
+    @staticmethod
+    def forward(ctx, base, pred, ref, mask, dc_weight, eta_k):
+        ctx.save_for_backward(pred, ref, mask, dc_weight)
+        ctx.same = base is None
+        return ops.dc_combine(pred if base is None else base, pred, ref, mask, dc_weight, eta_k)
+
+    @staticmethod
+    def backward(ctx, dy):
+        pred, ref, mask, dc_weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        nb, npd, _, _, nw, ne = ctx.needs_input_grad
+        dpred, deta, dw = ops.dc_combine_bwd(dy, pred, ref, mask, dc_weight, npd, ne, nw, ctx.same)
+        return (dy if (nb and not ctx.same) else None), dpred, None, None, (dw.reshape(dc_weight.shape) if dw is not None else None), deta
 
 
 def dc_combine(base, pred, ref, mask, dc_weight, eta_k):
     """vn_block.py:113-119: base - where(mask, pred - ref, 0) * dc_weight - eta_k."""
-    zero = torch.zeros(1, 1, 1, 1, 1, dtype=pred.dtype, device=pred.device)
-    return base - torch.where(mask.bool(), pred - ref, zero) * dc_weight - eta_k
+    return _DcCombine.apply(None if base is pred else base, pred, ref, mask, dc_weight, eta_k)
 
 
 def coil_combination(data, sens, method="SENSE", dim=1):

@@ -345,14 +345,26 @@ def llg_prepare(y, centered, normalization, spatial_dims=None):
 class Llg372Operands:
     """The loop-invariant operands of the W = 372 one-launch gradient (mrx_llg372) in lane order: yt = IFFT_H(y), the sensitivity
     maps and the mask, laid out once per slice by `llg372_prepare`; `work` is the partial-sum workspace reused by every step."""
-    __slots__ = ("ytp", "sp", "maskp", "mask_batched", "B", "C", "H", "centered", "work")
+    __slots__ = ("ytp", "sp", "maskp", "mask_batched", "B", "C", "H", "centered", "work", "const_norm", "linear")
 
-    def __init__(self, ytp, sp, maskp, mask_batched, B, C, H, centered, work):
+    def __init__(self, ytp, sp, maskp, mask_batched, B, C, H, centered, work, linear=False):
         self.ytp, self.sp, self.maskp, self.mask_batched = ytp, sp, maskp, mask_batched
         self.B, self.C, self.H, self.centered, self.work = B, C, H, centered, work
+        self.const_norm = None      # normalization for which the last plane of `work` holds the constant term -A^H M y (LLG372_NO_Y)
+        self.linear = linear        # the linear part alone (the adjoint of training): own workspace whose constant plane is zero
+
+    def linear_part(self):
+        """eta -> A^H M A eta: the same maps and mask, a workspace of its own with a zero constant plane (self-adjoint: training's backward)."""
+        work = torch.empty_like(self.work)
+        work[-(self.B * self.H * 372 * 2):].zero_()
+        return Llg372Operands(None, self.sp, self.maskp, self.mask_batched, self.B, self.C, self.H, self.centered, work, linear=True)
 
 
 LLG372 = True
+# The gradient is affine in eta: g = A^H M A eta - A^H M y.  True: the second term is one constant plane per slice (mrx_llg372_const_plane, the last
+# plane of the operands' workspace) that the consumers of the partial planes add like one more coil group, and a step reads S only -- 34.5 MB
+# instead of 63.1 MB per launch at 15 coils.  False (test hook): every step reads yt.
+LLG372_NO_Y = os.environ.get("MRIDC_AMD_LLG372_NO_Y", "1") != "0"
 
 
 def llg372_supported(yt, mask):
@@ -365,8 +377,9 @@ def llg372_supported(yt, mask):
     return m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1
 
 
-def llg372_prepare(yt, sens, mask, centered):
-    """(yt, S, mask) -> Llg372Operands (mrx_llg372_prepare): once per slice, shared by every cascade and time-step."""
+def llg372_prepare(yt, sens, mask, centered, normalization=None):
+    """(yt, S, mask) -> Llg372Operands (mrx_llg372_prepare): once per slice, shared by every cascade and time-step.  With `normalization` the
+    constant term of the gradient is prepared here too (otherwise by the first llg372 call)."""
     yt, sens = _lib.f32c(yt), _lib.f32c(sens)
     B, C, H, W = _bchw(yt)
     if sens.shape != yt.shape or W != 372:
@@ -377,10 +390,19 @@ def llg372_prepare(yt, sens, mask, centered):
     ytp = torch.empty(n, dtype=torch.float32, device=yt.device)
     sp = torch.empty(n, dtype=torch.float32, device=yt.device)
     maskp = torch.empty(B * 372, dtype=torch.float32, device=yt.device)
-    work = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=yt.device)
+    work = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)) + B * H * 372 * 2, dtype=torch.float32, device=yt.device)     # + the constant plane
     _lib.check(L.mrx_llg372_prepare(_lib.ptr(yt), _lib.ptr(sens), _lib.ptr(m), kind, ms, _lib.ptr(ytp), _lib.ptr(sp), _lib.ptr(maskp),
                                     B, C, H, int(bool(centered)), _lib.stream_ptr()), "mrx_llg372_prepare")
-    return Llg372Operands(ytp, sp, maskp, int(ms[0] != 0), B, C, H, bool(centered), work)
+    op = Llg372Operands(ytp, sp, maskp, int(ms[0] != 0), B, C, H, bool(centered), work)
+    if normalization is not None and LLG372_NO_Y:
+        _llg372_const(op, normalization)
+    return op
+
+
+def _llg372_const(op, normalization):
+    _lib.check(_lib.lib().mrx_llg372_const_plane(_lib.ptr(op.ytp), _lib.ptr(op.sp), _lib.ptr(op.maskp), op.mask_batched, _lib.ptr(op.work), op.B, op.C,
+                                                 op.H, _norm(normalization), int(op.centered), _lib.stream_ptr()), "mrx_llg372_const_plane")
+    op.const_norm = _norm(normalization)
 
 
 def llg372(eta, op, sigma, normalization, out=None, parts=False):
@@ -393,7 +415,10 @@ def llg372(eta, op, sigma, normalization, out=None, parts=False):
     n = ctypes.c_int(0)
     if not parts and out is None:
         out = torch.empty(op.B, 4, op.H, 372, dtype=torch.float32, device=eta.device)
-    _lib.check(_lib.lib().mrx_llg372(_lib.ptr(eta), _lib.ptr(op.ytp), _lib.ptr(op.sp), _lib.ptr(op.maskp), op.mask_batched,
+    no_y = op.linear or LLG372_NO_Y
+    if no_y and not op.linear and op.const_norm != _norm(normalization):
+        _llg372_const(op, normalization)                   # (first call, or another normalization than the one prepared for)
+    _lib.check(_lib.lib().mrx_llg372(_lib.ptr(eta), None if no_y else _lib.ptr(op.ytp), _lib.ptr(op.sp), _lib.ptr(op.maskp), op.mask_batched,
                                      None if parts else _lib.ptr(out), _lib.ptr(op.work), ctypes.byref(n) if parts else None,
                                      op.B, op.C, op.H, float(1.0 / (float(sigma) ** 2.0)), _norm(normalization), int(op.centered),
                                      _lib.stream_ptr()), "mrx_llg372")
@@ -1060,14 +1085,22 @@ def tl_layer_supported(Cin, Cout, k, dilation, rnn_features, rnn_k):
 
 def tl_layer_fwd(x, conv_w, conv_b, w_ih, b_ih, hh, h_prev, w_fin=None):
     """One RIM layer in the training arithmetic (mrx_tl_layer_fwd): a = ReLU(bf16(conv_reppad(x) + b)) as a pair tensor, h = ReLU(bf16(W_ih a + b_ih)
-    + hh * h_prev) fp32; with w_fin also the final convolution's 18 tap-product planes.  Returns (a_pairs, h, taps | None)."""
+    + hh * h_prev) fp32; with w_fin also the final convolution's 18 tap-product planes.  Returns (a_pairs, h, taps | None).
+    Hidden states are CHANNEL-BLOCKED: h, h_prev and the 64-channel layer's x are [B,8,H,W,8] (cb8_from_nchw / cb8_to_nchw convert)."""
     x = _lib.f32c(x)
-    B, Cin, H, W = _nchw(x)
     k, dil = int(conv_w.shape[-1]), (1 if int(conv_w.shape[-1]) == 5 else 2)
+    if int(conv_w.shape[1]) == 64:
+        if x.dim() != 5 or int(x.shape[1]) != 8 or int(x.shape[4]) != 8:
+            raise ValueError(f"tl_layer_fwd: the 64-channel layer takes a channel-blocked [B,8,H,W,8] input, got {tuple(x.shape)}")
+        B, Cin, H, W = int(x.shape[0]), 64, int(x.shape[2]), int(x.shape[3])
+    else:
+        B, Cin, H, W = _nchw(x)
+    if h_prev is not None and tuple(h_prev.shape) != (B, 8, H, W, 8):
+        raise ValueError(f"tl_layer_fwd: h_prev {tuple(h_prev.shape)}, expected the channel-blocked {(B, 8, H, W, 8)}")
     cp = _conv_bf16_pack(conv_w, False)
     tp = _tl_pack(w_ih, w_fin)
     a = torch.empty(B, 32, H, W, dtype=torch.int32, device=x.device)
-    h = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
+    h = torch.empty(B, 8, H, W, 8, dtype=torch.float32, device=x.device)
     taps = torch.empty(B, 18, H, W, dtype=torch.float32, device=x.device) if w_fin is not None else None
     hp = _lib.f32c(h_prev) if h_prev is not None else None
     hhc = _lib.f32c(hh.detach().reshape(-1)) if h_prev is not None else None
@@ -1091,10 +1124,13 @@ def tl_cell_part(B, H, W, device):
 
 def tl_cell_bwd(dh_pairs, dH, h, h_prev, a_pairs, w_ih, w_fin, hh, part, first):
     """mrx_tl_cell_bwd: (dh_prev | None, ga_pairs); the parameter-gradient partials accumulate in `part` (tl_cell_part) until tl_cell_reduce.
-    dH in and dh_prev out are CHANNEL-BLOCKED [B,8,H,W,8] (c = 8 q + j): they only travel from one call of this kernel to the next."""
-    B, _, H, W = _nchw(h)
-    if dH is not None and tuple(dH.shape) != (B, 8, H, W, 8):
-        raise ValueError(f"tl_cell_bwd: dH {tuple(dH.shape)}, expected the channel-blocked {(B, 8, H, W, 8)}")
+    h, h_prev, dH in and dh_prev out are CHANNEL-BLOCKED [B,8,H,W,8] (c = 8 q + j)."""
+    if h.dim() != 5 or int(h.shape[1]) != 8 or int(h.shape[4]) != 8:
+        raise ValueError(f"tl_cell_bwd: h {tuple(h.shape)}, expected channel-blocked [B,8,H,W,8]")
+    B, H, W = int(h.shape[0]), int(h.shape[2]), int(h.shape[3])
+    for nm, t in (("dH", dH), ("h_prev", h_prev)):
+        if t is not None and tuple(t.shape) != (B, 8, H, W, 8):
+            raise ValueError(f"tl_cell_bwd: {nm} {tuple(t.shape)}, expected the channel-blocked {(B, 8, H, W, 8)}")
     tp = _tl_pack(w_ih, w_fin)
     ga = torch.empty(B, 32, H, W, dtype=torch.int32, device=h.device)
     dhp = torch.empty(B, 8, H, W, 8, dtype=torch.float32, device=h.device) if h_prev is not None else None
@@ -1131,9 +1167,16 @@ def tl_dgrad(dy, weight, dilation, dx_pairs):
 
 
 def conv_wgrad_bf16_pairs(x, dy_pairs, k, dilation, pad_mode=PAD_REPLICATE, out=None, accumulate=False):
-    """Weight gradient with the output gradient given as a pair tensor (mrx_conv_wgrad_bf16_pairs): 3x3 dilation 2 64 -> 64, 5x5 Cin <= 32 -> 64."""
+    """Weight gradient with the output gradient given as a pair tensor (mrx_conv_wgrad_bf16_pairs): 3x3 dilation 2 64 -> 64 (x [B,64,H,W] or the
+    channel-blocked [B,8,H,W,8] of the training tape), 5x5 Cin <= 32 -> 64."""
     x = _lib.f32c(x)
-    B, Cin, H, W = _nchw(x)
+    blocked = x.dim() == 5
+    if blocked:
+        if int(x.shape[1]) != 8 or int(x.shape[4]) != 8 or int(k) != 3:
+            raise ValueError(f"conv_wgrad_bf16_pairs: channel-blocked x {tuple(x.shape)} (k={k}): [B,8,H,W,8] for the 3x3 layer only")
+        B, Cin, H, W = int(x.shape[0]), 64, int(x.shape[2]), int(x.shape[3])
+    else:
+        B, Cin, H, W = _nchw(x)
     if tuple(dy_pairs.shape) != (B, 32, H, W) or dy_pairs.dtype != torch.int32:
         raise ValueError(f"conv_wgrad_bf16_pairs: x {tuple(x.shape)}, dy {tuple(dy_pairs.shape)}")
     if out is None:
@@ -1147,7 +1190,23 @@ def conv_wgrad_bf16_pairs(x, dy_pairs, k, dilation, pad_mode=PAD_REPLICATE, out=
         return out
     work = torch.empty(int(L.mrx_conv_wgrad_bf16_any_work_floats(B, Cin, 64, H, W, int(k))), dtype=torch.float32, device=x.device)
     _lib.check(L.mrx_conv_wgrad_bf16_pairs(_lib.ptr(x), _lib.ptr(dy_pairs), _lib.ptr(out), _lib.ptr(work), B, Cin, H, W, int(k), int(dilation), int(pad_mode),
-                                           int(bool(accumulate)), _lib.stream_ptr()), "mrx_conv_wgrad_bf16_pairs")
+                                           int(bool(accumulate)), int(blocked), _lib.stream_ptr()), "mrx_conv_wgrad_bf16_pairs")
+    return out
+
+
+def conv_wgrad_bf16_xcb(x_cb8, dy, pad_mode=PAD_REPLICATE, out=None, accumulate=False):
+    """Weight gradient of the final 3x3 convolution 64 -> Cout <= 32 with x channel-blocked [B,8,H,W,8] (mrx_conv_wgrad_bf16_xcb)."""
+    x_cb8, dy = _lib.f32c(x_cb8), _lib.f32c(dy)
+    B, Cout, H, W = _nchw(dy)
+    if tuple(x_cb8.shape) != (B, 8, H, W, 8):
+        raise ValueError(f"conv_wgrad_bf16_xcb: x {tuple(x_cb8.shape)}, dy {tuple(dy.shape)}")
+    if out is None:
+        out = torch.empty(Cout, 64, 3, 3, dtype=torch.float32, device=dy.device)
+        accumulate = False
+    L = _lib.lib()
+    work = torch.empty(int(L.mrx_conv_wgrad_bf16_any_work_floats(B, 64, Cout, H, W, 3)), dtype=torch.float32, device=dy.device)
+    _lib.check(L.mrx_conv_wgrad_bf16_xcb(_lib.ptr(x_cb8), _lib.ptr(dy), _lib.ptr(out), _lib.ptr(work), B, Cout, H, W, int(pad_mode), int(bool(accumulate)),
+                                         _lib.stream_ptr()), "mrx_conv_wgrad_bf16_xcb")
     return out
 
 
@@ -1688,6 +1747,55 @@ def pixel_unshuffle2(x):
     out = torch.empty(B, 4 * C, H2 // 2, W2 // 2, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().mrx_pixel_unshuffle2(_lib.ptr(x), _lib.ptr(out), B * C, H2 // 2, W2 // 2, _lib.stream_ptr()), "mrx_pixel_unshuffle2")
     return out
+
+
+def cmul_bcast(a, v, conj_v=False, scale=1.0):
+    """a [B,C,H,W,2] * v [B,H,W,2] (or its conjugate) * scale, complex (mrx_cmul_bcast)."""
+    a, v = _lib.f32c(a), _lib.f32c(v)
+    B, C, H, W = _bchw(a)
+    if tuple(v.shape) != (B, H, W, 2):
+        raise ValueError(f"cmul_bcast: {tuple(a.shape)} vs {tuple(v.shape)}")
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().mrx_cmul_bcast(_lib.ptr(a), _lib.ptr(v), _lib.ptr(out), B, C, H * W, int(bool(conj_v)), float(scale), _lib.stream_ptr()),
+               "mrx_cmul_bcast")
+    return out
+
+
+def sens_expand_bwd_pointwise(G, sens, x, want_dx, want_ds, scale=1.0):
+    """From G = adjoint-fft2(dy) [B,C,H,W,2]: (dx = scale * sum_c conj(S) G | None, dS = scale * conj(x) G | None) in one pass (mrx_sens_expand_bwd_pw)."""
+    G, sens = _lib.f32c(G), _lib.f32c(sens)
+    B, C, H, W = _bchw(G)
+    if sens.shape != G.shape:
+        raise ValueError(f"sens_expand_bwd_pointwise: {tuple(G.shape)} vs maps {tuple(sens.shape)}")
+    xs = None
+    if want_ds:
+        xs = _lib.f32c(x).reshape(B, H, W, 2)
+    dx = torch.empty(B, H, W, 2, dtype=torch.float32, device=G.device) if want_dx else None
+    dS = torch.empty_like(G) if want_ds else None
+    _lib.check(_lib.lib().mrx_sens_expand_bwd_pw(_lib.ptr(G), _lib.ptr(sens), _lib.ptr(xs), _lib.ptr(dx), _lib.ptr(dS), B, C, H * W, float(scale),
+                                                 _lib.stream_ptr()), "mrx_sens_expand_bwd_pw")
+    return dx, dS
+
+
+def dc_combine_bwd(dy, pred, ref, mask, dc_weight, want_dpred, want_deta, want_dw, add_dy):
+    """Backward of dc_combine (mrx_dc_combine_bwd): (dpred | None, deta | None, dw [1] | None)."""
+    if not (want_dpred or want_deta or want_dw):
+        return None, None, None
+    dy = _lib.f32c(dy)
+    B, C, H, W = _bchw(dy)
+    m, kind, ms = _lib.mask_args(mask, B, C, H, W)
+    w = _lib.f32c(dc_weight.detach().reshape(-1))
+    L = _lib.lib()
+    dpred = torch.empty_like(dy) if want_dpred else None
+    deta = torch.empty_like(dy) if want_deta else None
+    dw = work = p = r = None
+    if want_dw:
+        p, r = _lib.f32c(pred), _lib.f32c(ref)
+        dw = torch.empty(1, dtype=torch.float32, device=dy.device)
+        work = torch.empty(int(L.mrx_dc_combine_bwd_work_doubles()), dtype=torch.float64, device=dy.device)
+    _lib.check(L.mrx_dc_combine_bwd(_lib.ptr(dy), _lib.ptr(p), _lib.ptr(r), _lib.ptr(m), kind, ms, _lib.ptr(w), _lib.ptr(dpred), _lib.ptr(deta), _lib.ptr(dw),
+                                    _lib.ptr(work), int(bool(add_dy)), B, C, H, W, _lib.stream_ptr()), "mrx_dc_combine_bwd")
+    return dpred, deta, dw
 
 
 def conv_instance_norm_act(x, weight, eps=1e-5, act=ACT_LEAKY, slope=0.2, pad_mode=PAD_ZERO):

@@ -5,6 +5,7 @@ The reference reaches the same result through pytorch-lightning's DDP (`strategy
 here the tape is torch autograd over the Functions of `mridc_amd.autograd` (all arithmetic in libmridc_amd.so), the gradient
 exchange is one `torch.distributed.all_reduce` on a single contiguous buffer, and the optimizer is `mrx_adam_step`."""
 import math
+import os
 
 import torch
 
@@ -119,7 +120,7 @@ BF16_STORAGE = True
 # The weight gradients of a time-step hang off the backward chain (cell -> data gradient -> cell -> ... -> adjoint of the likelihood gradient) as side
 # branches: they run on a second HIP stream next to it (every kernel of the chain leaves CUs idle: one or two workgroups per CU waiting for their tiles).
 # Each stream keeps its own fixed order, so the gradients stay bit-reproducible.
-TL_SIDE_STREAM = True
+TL_SIDE_STREAM = os.environ.get("MRIDC_AMD_TL_SIDE_STREAM", "1") != "0"      # ("0": one stream -- each kernel's own duration in a profile)
 _SIDE = {}
 
 
@@ -204,8 +205,7 @@ class _Llg:
         """The linear part applied to dz (the map eta -> gradient is affine and self-adjoint: the same kernel with yt = 0)."""
         if self.op is not None:
             if self.zero_op is None:
-                o = self.op
-                self.zero_op = ops.Llg372Operands(torch.zeros_like(o.ytp), o.sp, o.maskp, o.mask_batched, o.B, o.C, o.H, o.centered, o.work)
+                self.zero_op = self.op.linear_part()                   # (never reads the data: mrx_llg372 with ytp = NULL)
             return ops.llg372(dz, self.zero_op, sigma, self.cfg[1])
         if self.zero_yt is None:
             self.zero_yt = torch.zeros_like(self.yt)
@@ -310,7 +310,9 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
     """One cascade in the reference's mixed-precision arithmetic with bf16 STORAGE (base_cirim_train.yaml:180; what torch.autocast keeps in half
     precision is a pair tensor here): per time-step two fused layer launches + the tap gather forward, and per layer ONE cell-backward launch, one
     data gradient and one weight gradient backward.  Convolution results and the gradients flowing into them are rounded to bf16 exactly where
-    autocast rounds them; hidden states, eta, the loss and every parameter-gradient sum are fp32.  Returns (etas, per-step loss records)."""
+    autocast rounds them; hidden states, eta, the loss and every parameter-gradient sum are fp32.  The hidden states (and their gradients between
+    two cell-backward calls) are channel-blocked [B,8,H,W,8]: five kernels read each of them, all with 16-byte accesses.
+    Returns (etas, per-step loss records)."""
     L_ = _lib.lib()
     final = blk.final_layer[0]
     fw = final.conv_layer.weight
@@ -367,7 +369,7 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
         _lib.check(L_.mrx_eta_grad_in(_lib.ptr(carry), _lib.ptr(gl), _lib.ptr(tot), _lib.ptr(d2), B, plane, _lib.stream_ptr()), "mrx_eta_grad_in")
         # final convolution (its result is a bf16 tensor under autocast: both gradient kernels round d2 to bf16 on load)
         h_top = acts[-1][2]
-        on_side(lambda h_top=h_top, d2=d2: _wgrad_into(h_top, d2, 3, 1, ops.PAD_REPLICATE, _grad_of(fw), True), h_top, d2)
+        on_side(lambda h_top=h_top, d2=d2: ops.conv_wgrad_bf16_xcb(h_top, d2, ops.PAD_REPLICATE, out=_grad_of(fw), accumulate=True), h_top, d2)
         dh = ops.tl_dgrad(d2, fw, 1, dx_pairs=True)
         for li in range(nl - 1, -1, -1):
             st = blk.layers[li]
@@ -407,7 +409,7 @@ def cirim_forward_backward(model, batch, precision="f32", on_cascade_done=None):
     wdev = torch.full((1,), w, dtype=torch.float32, device=y.device)
     blk0 = model.cirim[0]
     yt = ops.llg_prepare(y, blk0.fft_centered, blk0.fft_normalization, blk0.spatial_dims)
-    hybrid = (yt, ops.llg372_prepare(yt, S, mask, blk0.fft_centered)) if ops.llg372_supported(yt, mask) else yt
+    hybrid = (yt, ops.llg372_prepare(yt, S, mask, blk0.fft_centered, blk0.fft_normalization)) if ops.llg372_supported(yt, mask) else yt
     eta = ops.sens_reduce(y, S, blk0.fft_centered, blk0.fft_normalization, blk0.spatial_dims)     # cascade 0: keep_eta False (rim_block.py:195-211)
     terms = []
     bf16 = precision == "bf16"

@@ -470,3 +470,49 @@ def test_unet_backward_steps_on_hip_kernels(dev, shape):
     # pixel unshuffle
     if H % 2 == 0 and W % 2 == 0:
         assert torch.equal(ops.pixel_unshuffle2(x.to(dev)).cpu(), F.pixel_unshuffle(x, 2))
+
+
+@pytest.mark.parametrize("case", [("backward", False, 21), ("ortho", True, 372), ("forward", True, 30)], ids=lambda c: f"{c[0]}_W{c[2]}")
+def test_coil_operator_and_dc_backward_on_hip_kernels(dev, case):
+    """diff.sens_expand / sens_reduce / dc_combine (vn_block.py:51-119): forward on the fused kernels, backward = the opposite transform + ONE pointwise
+    pass (csrc/diff_bwd.hip: mrx_sens_expand_bwd_pw, mrx_cmul_bcast, mrx_dc_combine_bwd), against float64 autograd of the written-out reference forms
+    -- gradients w.r.t. the image / k-space, the sensitivity maps (the E2EVN sensitivity network is trained through them) and dc_weight."""
+    import oracle
+    from mridc_amd import diff
+    norm, centered, W = case
+    B, C, H = 2, 3, 10
+    g = torch.Generator().manual_seed(W)
+    x, S = torch.randn(B, H, W, 2, generator=g), torch.randn(B, C, H, W, 2, generator=g)
+    k, ref = torch.randn(B, C, H, W, 2, generator=g), torch.randn(B, C, H, W, 2, generator=g)
+    mask = (torch.rand(1, 1, H, W, 1, generator=g) < 0.4).float()
+    w = torch.tensor([0.7])
+    g1, g2, g3 = torch.randn(B, C, H, W, 2, generator=g), torch.randn(B, H, W, 2, generator=g), torch.randn(B, C, H, W, 2, generator=g)
+    cm, cj = oracle.utils.complex_mul, oracle.utils.complex_conj
+
+    def leaves(dtype, device):
+        return [t.to(device=device, dtype=dtype).requires_grad_(True) for t in (x, S, k, w)]
+
+    # float64 reference (the reference's own composition of torch ops)
+    xr, Sr, kr, wr = leaves(torch.float64, "cpu")
+    e_r = oracle.fft.fft2(cm(xr.unsqueeze(1), Sr), centered, norm, [-2, -1])
+    r_r = cm(oracle.fft.ifft2(kr, centered, norm, [-2, -1]), cj(Sr)).sum(1)
+    zero = torch.zeros(1, 1, 1, 1, 1, dtype=torch.float64)
+    d_r = kr - torch.where(mask.bool(), kr - ref.double(), zero) * wr - e_r
+    ((e_r * g1.double()).sum() + (r_r * g2.double()).sum() + (d_r * g3.double()).sum()).backward()
+    # HIP path
+    xd, Sd, kd, wd = leaves(torch.float32, dev)
+    e_d = diff.sens_expand(xd, Sd, centered, norm, [-2, -1])
+    r_d = diff.sens_reduce(kd, Sd, centered, norm, [-2, -1])
+    d_d = diff.dc_combine(kd, kd, ref.to(dev), mask.to(dev), wd, e_d)
+    assert_close(e_d, e_r.float(), 1e-5, "sens_expand forward")
+    assert_close(r_d, r_r.float(), 1e-5, "sens_reduce forward")
+    assert_close(d_d, d_r.float(), 1e-5, "dc_combine forward")
+    ((e_d * g1.to(dev)).sum() + (r_d * g2.to(dev)).sum() + (d_d * g3.to(dev)).sum()).backward()
+    for name, got, want in (("image", xd, xr), ("maps", Sd, Sr), ("k-space", kd, kr), ("dc_weight", wd, wr)):
+        assert_close(got.grad, want.grad.float(), 2e-5, f"gradient w.r.t. {name}")
+    # base and pred distinct tensors, nothing else requiring a gradient
+    b2 = torch.randn(B, C, H, W, 2, generator=g)
+    bd, br = b2.to(dev).requires_grad_(True), b2.double().requires_grad_(True)
+    diff.dc_combine(bd, k.to(dev), ref.to(dev), mask.to(dev), w.to(dev), ref.to(dev)).backward(g3.to(dev))
+    (br - torch.where(mask.bool(), k.double() - ref.double(), zero) * w.double() - ref.double()).backward(g3.double())
+    assert_close(bd.grad, br.grad.float(), 1e-6, "gradient w.r.t. a separate base")

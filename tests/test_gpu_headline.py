@@ -100,12 +100,34 @@ def test_llg_parts_and_layer1_loader(dev, case):
     if W == 372:
         # the prime-factor kernel (mrx_llg372: lane-ordered operands prepared once per slice), complete and deferred forms
         assert ops.llg372_supported(yt, md)
-        op = ops.llg372_prepare(yt, Sd, md, centered)
-        assert_close(ops.llg372(ed, op, sigma, norm), g_ref, 1e-5, "llg372 vs oracle")
-        part3, n3 = ops.llg372(ed, op, sigma, norm, parts=True)
-        assert n3 == -(-C // 5)
-        h3 = ops.rim_layer_indrnn_packed_llg(ed, part3, n3, sigma, packed, 64, 5, 1, bd, bid, hhd, hp)
-        assert_close(h3, h_ref, 1e-5, "layer 1 reading the llg372 partial sums vs oracle")
+        keep = ops.LLG372_NO_Y
+        try:
+            for no_y in (True, False):       # the data as one constant plane per slice (default) / read by every step
+                ops.LLG372_NO_Y = no_y
+                op = ops.llg372_prepare(yt, Sd, md, centered, norm if no_y else None)
+                assert_close(ops.llg372(ed, op, sigma, norm), g_ref, 1e-5, f"llg372 vs oracle (no_y={no_y})")
+                part3, n3 = ops.llg372(ed, op, sigma, norm, parts=True)
+                assert n3 == -(-C // 5) + int(no_y)
+                h3 = ops.rim_layer_indrnn_packed_llg(ed, part3, n3, sigma, packed, 64, 5, 1, bd, bid, hhd, hp)
+                assert_close(h3, h_ref, 1e-5, f"layer 1 reading the llg372 partial sums vs oracle (no_y={no_y})")
+            # prepared without a normalization: the constant plane is made by the first call, and again when the normalization changes
+            ops.LLG372_NO_Y = True
+            op = ops.llg372_prepare(yt, Sd, md, centered)
+            assert op.const_norm is None
+            assert_close(ops.llg372(ed, op, sigma, norm), g_ref, 1e-5, "llg372 vs oracle (lazy constant plane)")
+            assert op.const_norm is not None
+            # the linear part alone (training's adjoint): g(eta) - g(0), and self-adjoint
+            lin = op.linear_part()
+            g1, g0 = ops.llg372(ed, op, sigma, norm)[:, 2:], ops.llg372(torch.zeros_like(ed), op, sigma, norm)[:, 2:]
+            a1 = ops.llg372(ed, lin, sigma, norm)[:, 2:]
+            assert_close(a1, (g1 - g0).cpu(), 1e-5, "linear part = g(eta) - g(0)")
+            e2 = torch.randn_like(ed)
+            a2 = ops.llg372(e2, lin, sigma, norm)[:, 2:]
+            d12 = float((a1.double() * e2.permute(0, 3, 1, 2).double()).sum())
+            d21 = float((a2.double() * ed.permute(0, 3, 1, 2).double()).sum())
+            assert abs(d12 - d21) <= 1e-4 * max(abs(d12), abs(d21), 1e-30), (d12, d21)
+        finally:
+            ops.LLG372_NO_Y = keep
 
 
 def test_llg372_batched_mask_and_ragged_coils(dev):

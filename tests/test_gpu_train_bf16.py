@@ -36,6 +36,15 @@ def test_pair_tensors_are_bf16_round_to_nearest_even(dev):
     assert torch.equal((lo << 16).view(torch.float32), bf(x)[:, 0::2])
 
 
+def _blk(t):
+    """NCHW -> channel-blocked [B,C/8,H,W,8] (plain torch: independent of ops.cb8_from_nchw)."""
+    return None if t is None else t.view(t.shape[0], t.shape[1] // 8, 8, t.shape[2], t.shape[3]).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def _unblk(t):
+    return t.permute(0, 1, 4, 2, 3).reshape(t.shape[0], t.shape[1] * 8, t.shape[2], t.shape[3])
+
+
 @pytest.mark.parametrize("shape", [(1, 4, 5, 19, 45), (2, 64, 3, 21, 40), (1, 4, 5, 8, 32)], ids=lambda s: f"B{s[0]}_cin{s[1]}_k{s[2]}_{s[3]}x{s[4]}")
 @pytest.mark.parametrize("with_state", [False, True])
 def test_training_layer_forward_rounds_where_autocast_rounds(dev, shape, with_state):
@@ -54,7 +63,10 @@ def test_training_layer_forward_rounds_where_autocast_rounds(dev, shape, with_st
     u = bf((F.conv2d(a.double(), bf(w_ih).double()) + bf(b_ih).double().view(1, -1, 1, 1)).float())
     h = F.relu(u + (hh * hp if with_state else 0.0))
     d = lambda t: None if t is None else t.to(dev)  # noqa: E731
-    a_p, h_g, taps = ops.tl_layer_fwd(d(x), d(cw), d(cb), d(w_ih), d(b_ih), d(hh), d(hp), d(w_fin))
+    # hidden states are channel-blocked [B,8,H,W,8] in this tape: h, h_prev, and the 64-channel layer's input
+    a_p, h_cb, taps = ops.tl_layer_fwd(_blk(d(x)) if Cin == 64 else d(x), d(cw), d(cb), d(w_ih), d(b_ih), d(hh), _blk(d(hp)), d(w_fin))
+    assert tuple(h_cb.shape) == (B, 8, H, W, 8)
+    h_g = _unblk(h_cb)
     a_g = ops.pairs_to_f32(a_p)
     assert _flips(a_g, a) <= 2e-3 and rel_l2(a_g, a) <= 2e-3, (_flips(a_g, a), rel_l2(a_g, a))
     assert rel_l2(h_g, h) <= 3e-3, rel_l2(h_g, h)
@@ -93,18 +105,18 @@ def test_cell_backward_in_one_pass(dev, variant):
     want = dict(dw=torch.einsum("bohw,bihw->oi", gb.double(), a.double()), dbih=gb.double().sum((0, 2, 3)),
                 dhh=(gq.double() * hp.double()).sum((0, 2, 3)) if hp is not None else torch.zeros(64, dtype=torch.float64), db=ga.double().sum((0, 2, 3)))
     d = lambda t: None if t is None else t.to(dev)  # noqa: E731
-    blk = lambda t: None if t is None else t.view(B, 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()      # NCHW -> channel-blocked [B,8,H,W,8]  # noqa: E731
+    blk = _blk
     part = ops.tl_cell_part(B, H, W, dev)
     part.fill_(float("nan"))                               # `first` must overwrite the slots
-    dhp, ga_p = ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(blk(dH)), d(h), d(hp), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, True)
+    dhp, ga_p = ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(blk(dH)), d(blk(h)), d(blk(hp)), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, True)
     ga_g = ops.pairs_to_f32(ga_p)
     assert _flips(ga_g, ga) <= 2e-3 and rel_l2(ga_g, ga) <= 2e-3, (_flips(ga_g, ga), rel_l2(ga_g, ga))
     if hp is not None:
         assert tuple(dhp.shape) == (B, 8, H, W, 8)             # channel-blocked, as the next time-step's call reads it
-        assert rel_l2(dhp.permute(0, 1, 4, 2, 3).reshape(B, 64, H, W), gq * hh) <= 1e-6
+        assert rel_l2(_unblk(dhp), gq * hh) <= 1e-6
     else:
         assert dhp is None
-    ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(blk(dH)), d(h), d(hp), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, False)   # second time-step: adds
+    ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(blk(dH)), d(blk(h)), d(blk(hp)), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, False)   # second time-step: adds
     dw, dbih, dhh, db = (torch.full(s, 1.0, device=dev) for s in ((64, 64, 1, 1), (64,), (64,), (64,)))
     ops.tl_cell_reduce(part, B, H, W, dw, dbih, dhh, db)
     assert rel_l2(dw.reshape(64, 64).cpu().double() - 1.0, 2 * want["dw"]) <= 1e-5
@@ -164,6 +176,22 @@ def test_weight_gradient_from_a_pair_tensor(dev, case):
     acc = torch.ones_like(got)
     ops.conv_wgrad_bf16_pairs(x.to(dev), dyp, k, dil, ops.PAD_REPLICATE, out=acc, accumulate=True)
     assert rel_l2(acc.cpu().double() - 1.0, w.grad) <= 1e-5
+    if Cin == 64:                                             # the tape's form: x channel-blocked -- the same values in the same order
+        assert torch.equal(ops.conv_wgrad_bf16_pairs(_blk(x.to(dev)), dyp, k, dil, ops.PAD_REPLICATE), got)
+
+
+@pytest.mark.parametrize("shape", [(1, 21, 44), (2, 19, 45), (1, 640, 372)], ids=lambda s: "x".join(map(str, s)))
+def test_final_convolution_weight_gradient_from_blocked_states(dev, shape):
+    """mrx_conv_wgrad_bf16_xcb = mrx_conv_wgrad_bf16_any (3x3, 64 -> 2) on the channel-blocked hidden state: bit-identical."""
+    from mridc_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H)
+    x, dy = torch.randn(B, 64, H, W, generator=g).to(dev), torch.randn(B, 2, H, W, generator=g).to(dev)
+    want = ops.conv_wgrad_bf16(x, dy, 3, 1, ops.PAD_REPLICATE)
+    assert torch.equal(ops.conv_wgrad_bf16_xcb(_blk(x), dy, ops.PAD_REPLICATE), want)
+    acc = torch.ones_like(want)
+    ops.conv_wgrad_bf16_xcb(_blk(x), dy, ops.PAD_REPLICATE, out=acc, accumulate=True)
+    assert rel_l2(acc - 1.0, want) <= 1e-6
 
 
 @pytest.mark.parametrize("seed,boost", [(0, 1.0), (5, 3.0)])

@@ -48,15 +48,15 @@ bnd = ops.max_abs(X128).reshape(1)
 cw2, cb2 = r(F, F, 3, 3) / 24, r(F) * 0.1
 wih, bih, hh2, wfin = r(F, F, 1, 1) / 8, r(F) * 0.1, r(1, F, 1, 1) * 0.5, r(2, F, 3, 3) / 24
 dhP, aP = ops.f32_to_pairs(r(B, F, H, W)), ops.f32_to_pairs(r(B, F, H, W).relu())
-dH, hst = r(B, 8, H, W, 8), r(B, F, H, W).relu()                     # (dH channel-blocked)
+dH, hst, xcb = r(B, 8, H, W, 8), r(B, 8, H, W, 8).relu(), ops.cb8_from_nchw(x)     # (the training tape's hidden states are channel-blocked)
 part_c = ops.tl_cell_part(B, H, W, dev)
 torch.cuda.synchronize()
 for i in range(3):
     ops.unet_conv3x3((A14, nA), None, W14)                                                       # E2EVN: k_uconv_h<1, 1, true> at batch 4
     ops.conv3x3_h(X128, W128, B128, 2, ops.PAD_REPLICATE, ops.ACT_RELU, bound=bnd)              # qCIRIM: k_uconv_h<4, 2, false>
-    ops.tl_layer_fwd(x, cw2, cb2, wih, bih, hh2, hp, wfin)                                       # training: fused second layer forward (+ tap products)
-    _, ga = ops.tl_cell_bwd(dhP, dH, hst, hp, aP, wih, wfin, hh2, part_c, i == 0)                # training: one-pass cell backward
-    ops.conv_wgrad_bf16_pairs(x, ga, 3, 2, ops.PAD_REPLICATE)                                    # training: 3x3 d2 weight gradient from the pair tensor
+    ops.tl_layer_fwd(xcb, cw2, cb2, wih, bih, hh2, hpc, wfin)                                       # training: fused second layer forward (+ tap products)
+    _, ga = ops.tl_cell_bwd(dhP, dH, hst, hpc, aP, wih, wfin, hh2, part_c, i == 0)                # training: one-pass cell backward
+    ops.conv_wgrad_bf16_pairs(xcb, ga, 3, 2, ops.PAD_REPLICATE)                                    # training: 3x3 d2 weight gradient from the pair tensor
     ops.tl_dgrad(ga, cw2, 2, True)                                                               # training: data gradient pairs -> pairs
     ops.llg(eta, y, S, mask2d, 1.0, False, "backward", work=work, parts=True)                    # general mask, deferred form: the column pass without y
 torch.cuda.synchronize()
