@@ -650,6 +650,7 @@ def bench_train(args, world, rank, dev, checks=False):
             ucfg.update(channels=18, pooling_layers=4, padding_size=15)
         model = VarNet(ucfg).to(dev)
         step_fn = training.model_training_step
+        graphed = None
     else:
         model = CIRIM(cfg).to(dev)
         step_fn = training.training_step
@@ -668,6 +669,15 @@ def bench_train(args, world, rank, dev, checks=False):
         timer.wrap(ops, "conv_wgrad_bf16_pairs", lambda x, dy, kk, *a_, **k: "wgrad from pairs %dx%d %d->64" % (int(kk), int(kk), int(x.shape[1])))
         timer.wrap(ops, "tl_dgrad", lambda dy, w, *a_, **k: "tl_dgrad %d->%d (+ edge fold)" % (int(w.shape[0]), int(w.shape[1])))
     losses = []
+    if args.model == "e2evn" and args.graph:
+        # forward + loss + backward as ONE hipGraph replay (a few thousand short launches: issued from Python the step is host-bound and jitters);
+        # all-reduce and Adam outside.  Falls back to the eager step if the capture fails.
+        try:
+            graphed = training.GraphedModelStep(model, flat, opt, batch)
+            step_fn = lambda m_, f_, o_, b_: graphed(b_)       # noqa: E731
+        except Exception as ex:  # noqa: BLE001
+            print(f"[bench] training-step capture failed ({type(ex).__name__}: {ex}); eager step", file=sys.stderr)
+            graphed = None
     for _ in range(max(args.warmup, 1)):
         losses.append(float(step_fn(model, flat, opt, batch)))
     if checks:
@@ -692,8 +702,10 @@ def bench_train(args, world, rank, dev, checks=False):
                     per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank], dtype="f32", data="synthetic",
                     config=dict(workload=f"E2EVN {ucfg['num_cascades']} cascades, NormUnet({ucfg['channels']}, {ucfg['pooling_layers']}), {C} coils, "
                                          f"{H}x{W}: forward + l1 loss + backward (convolution / transposed-convolution / FFT gradients on the HIP "
-                                         f"kernels, normalisation and pointwise derivatives as torch device ops) + one all-reduce of the flat "
+                                         f"kernels, coil operators / data consistency / activation / InstanceNorm / pooling backward on csrc/diff_bwd.hip) + one all-reduce of the flat "
                                          f"gradient ({flat.numel * 4 / 1e6:.2f} MB) + Adam, 1 slice per GPU and step",
+                                launch=("forward + loss + backward = one hipGraph replay (training.GraphedModelStep; weight packs inside the graph), "
+                                        "all-reduce + Adam eager") if graphed is not None else "eager",
                                 global_batch=world, parallelism=f"data-parallel x{world}", gradient_bytes=flat.numel * 4),
                     loss_first=losses[0], loss_last=losses[-1])
     res = dict(metric=f"slices/sec (training), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}",

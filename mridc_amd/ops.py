@@ -36,6 +36,18 @@ def _bchw(t):
 PFA372 = True            # W = 372 prime-factor row kernels (module attributes like this one are test hooks, not environment switches)
 
 
+# Packed / transformed copies of model WEIGHTS are cached per (storage, version), and a pack made eagerly is reused inside a hipGraph capture: right
+# for inference graphs (the weights do not change between replays).  A captured TRAINING step replays on weights the optimizer has updated in between:
+# with WEIGHTS_DYNAMIC the pack kernels are launched into the graph (cache entries made in a capture are keyed on it and never served from, or to, eager
+# calls), so every replay packs the current weights.  Set by training.GraphedModelStep around its capture.
+WEIGHTS_DYNAMIC = False
+
+
+def _wcap():
+    """Key component of the weight-pack caches: 0, or the id of the running capture when its weights are dynamic."""
+    return int(_lib.lib().mrx_stream_capture_id(_lib.stream_ptr())) if WEIGHTS_DYNAMIC else 0
+
+
 class _PreparedCache:
     """Per-slice prepared operands (lane-ordered maps, column-tiled k-space) keyed on the source tensor's (storage, version) AND on the
     hipGraph capture the current stream is in (mrx_stream_capture_id; 0 = eager):
@@ -61,7 +73,7 @@ class _PreparedCache:
             del self.entries[k]
         key = (cap, src.data_ptr(), src._version, str(src.device), tuple(src.shape)) + tuple(extra)
         hit = self.entries.get(key)
-        if hit is None and cap != 0 and self.parameters:
+        if hit is None and cap != 0 and self.parameters and not WEIGHTS_DYNAMIC:
             hit = self.entries.get((0,) + key[1:])
         if hit is None:
             if cap == 0:
@@ -659,7 +671,7 @@ def _wino_conv_pack(weight):
     """Transformed + packed weights of `weight`, cached per (storage address, version).  The entry keeps a detached alias of the tensor
     it was made from -- i.e. its STORAGE -- so the address cannot be recycled for other weights while the entry lives, even if the
     parameter's `.data` is re-pointed (training.FlatParameters does that)."""
-    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()))
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()), _wcap())
     hit = _WINO_PACKS.get(key)
     if hit is None:
         if len(_WINO_PACKS) >= 128:
@@ -680,7 +692,7 @@ _PACKS_1X1 = {}
 
 def _conv1x1_pack(weight):
     """Packed [C,C,1,1] weights (C = 64 | 128) for mrx_conv1x1_sq, cached like the Winograd packs (the entry keeps the source alive)."""
-    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()))
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()), _wcap())
     hit = _PACKS_1X1.get(key)
     if hit is None:
         if len(_PACKS_1X1) >= 128:
@@ -765,7 +777,7 @@ def conv3x3_sb(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slo
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     L = _lib.lib()
-    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()))
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()), _wcap())
     chain = SB_CHAIN and _lib.arith() == "f16x2"
     bnd = getattr(x_in, "_mrx_bound", None) if chain else None
     bound_in = bnd[0] if (bnd is not None and bnd[1] == x_in._version and x is x_in) else None
@@ -817,7 +829,7 @@ def conv_sbs(x, weight, bias, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=No
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     Cout, _, k, _ = [int(v) for v in weight.shape]
-    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()))
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()), _wcap())
     hit = _PACKS_SBS.get(key)
     if hit is None:
         if len(_PACKS_SBS) >= 256:
@@ -852,7 +864,7 @@ def conv3x3_taps(x, weight, bias, pad_mode=PAD_ZERO, out=None):
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     Cout = int(weight.shape[0])
-    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape))
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), _wcap())
     w1 = _TAPS_W.get(key)
     if w1 is None:
         if len(_TAPS_W) >= 64:
@@ -957,7 +969,7 @@ def conv_bf16_supported(Cin, Cout, k, dilation):
 def _conv_bf16_pack(weight, transposed):
     """bf16 MFMA operand pack of a [Cout,Cin,k,k] weight (or of its flipped, channel-transposed form: the data gradient's weights),
     cached per (storage, version) like the other packs (the entry keeps the source tensor alive)."""
-    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()), bool(transposed))
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()), bool(transposed), _wcap())
     hit = _PACKS_BF16.get(key)
     if hit is None:
         if len(_PACKS_BF16) >= 256:
@@ -1064,7 +1076,7 @@ def pairs_to_f32(p):
 def _tl_pack(w_ih, w_fin):
     """mrx_tl_pack of an IndRNN layer's 1x1 weight (forward order, transposed order) and -- for the last layer -- the final convolution's weights,
     cached per (storage, version) like the other packs."""
-    key = (w_ih.data_ptr(), w_ih._version, str(w_ih.device), None if w_fin is None else (w_fin.data_ptr(), w_fin._version), "tl")
+    key = (w_ih.data_ptr(), w_ih._version, str(w_ih.device), None if w_fin is None else (w_fin.data_ptr(), w_fin._version), "tl", _wcap())
     hit = _PACKS_BF16.get(key)
     if hit is None:
         if len(_PACKS_BF16) >= 256:

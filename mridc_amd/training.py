@@ -493,3 +493,53 @@ def model_training_step(model, flat, optimizer, batch, loss_fn=magnitude_l1_loss
     world = allreduce_gradients(flat.grad)
     optimizer.step(grad_scale=1.0 / world)
     return loss.detach()
+
+
+class GraphedModelStep:
+    """`model_training_step` with forward + loss + backward captured into ONE hipGraph (the step of an E2EVN-sized model is a few thousand launches of
+    10-50 us kernels: issued from Python it is host-bound and jitters with the host; replayed it is not).  The batch lives in static buffers that every
+    call refills; the all-reduce of the flat gradient and the Adam launch stay outside the graph (the step count and the learning rate are host values).
+    Weight packs are made INSIDE the graph (ops.WEIGHTS_DYNAMIC): every replay packs the weights the optimizer has just updated.
+
+    The forward must be free of host synchronisation and of data-dependent Python branches (true of the modules recorded through mridc_amd.diff);
+    shapes and the mask layout are fixed at construction."""
+
+    def __init__(self, model, flat, optimizer, batch, loss_fn=magnitude_l1_loss, warmup=2):
+        self.model, self.flat, self.optimizer, self.loss_fn = model, flat, optimizer, loss_fn
+        self.keys = [k for k in ("y", "sensitivity_maps", "mask", "init_pred", "target") if batch.get(k) is not None]
+        self.static = {k: batch[k].clone() for k in self.keys}
+        model.train()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            for _ in range(max(int(warmup), 1)):       # eager warm-up on the capture stream (allocator, autograd buffers, lazily built caches)
+                self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(st)
+        self.graph = torch.cuda.CUDAGraph()
+        keep = ops.WEIGHTS_DYNAMIC
+        ops.WEIGHTS_DYNAMIC = True
+        try:
+            with torch.cuda.graph(self.graph, stream=st, capture_error_mode="thread_local"):
+                self.loss = self._fwd_bwd()
+        finally:
+            ops.WEIGHTS_DYNAMIC = keep
+
+    def _fwd_bwd(self):
+        b = self.static
+        self.flat.zero_grad()
+        pred = self.model(b["y"], b["sensitivity_maps"], b["mask"], b.get("init_pred"), b["target"])
+        loss = self.loss_fn(pred, b["target"])
+        loss.backward()
+        return loss.detach()
+
+    def __call__(self, batch, schedule=None):
+        if schedule is not None:
+            self.optimizer.lr = inverse_sqrt_lr(self.optimizer.steps, schedule["max_steps"], schedule["base_lr"], schedule.get("warmup_ratio", 0.1),
+                                                schedule.get("min_lr", 0.0), schedule.get("warmup_steps"))
+        for k in self.keys:
+            if batch[k] is not self.static[k]:
+                self.static[k].copy_(batch[k])
+        self.graph.replay()
+        world = allreduce_gradients(self.flat.grad)
+        self.optimizer.step(grad_scale=1.0 / world)
+        return self.loss

@@ -516,3 +516,35 @@ def test_coil_operator_and_dc_backward_on_hip_kernels(dev, case):
     diff.dc_combine(bd, k.to(dev), ref.to(dev), mask.to(dev), w.to(dev), ref.to(dev)).backward(g3.to(dev))
     (br - torch.where(mask.bool(), k.double() - ref.double(), zero) * w.double() - ref.double()).backward(g3.double())
     assert_close(bd.grad, br.grad.float(), 1e-6, "gradient w.r.t. a separate base")
+
+
+def test_graphed_model_training_step_follows_the_eager_one(dev):
+    """training.GraphedModelStep (forward + loss + backward of an E2EVN as one hipGraph replay, weight packs inside the graph): three steps on three
+    different slices leave the same parameters as three eager model_training_step calls -- the replay sees refilled batches AND the weights the
+    optimizer has updated in between."""
+    from mridc_amd import synthetic, training
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    cfg = dict(num_cascades=2, channels=8, pooling_layers=2, padding_size=11, normalize=True, no_dc=False, use_sens_net=False, fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1,
+               coil_combination_method="SENSE", train_loss_fn="l1", val_loss_fn="l1")
+    C, H, W = 4, 40, 372                                  # (W = 372: the prime-factor FFT route with its per-slice prepared maps)
+    batches = []
+    for i in range(3):
+        s = synthetic.make_slice(C, H, W, slice_idx=i)
+        batches.append({k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")})
+    finals = []
+    for graphed in (False, True):
+        torch.manual_seed(3)
+        model = VarNet(cfg).to(dev)
+        flat = training.FlatParameters(model)
+        opt = training.AdamFlat(flat, lr=1e-3)
+        step = training.GraphedModelStep(model, flat, opt, batches[0]) if graphed else None
+        if graphed:                                       # the constructor's warm-up steps ran forward / backward only: no optimizer step, same weights
+            assert opt.steps == 0
+        losses = []
+        for b in batches:
+            losses.append(float(step(b) if graphed else training.model_training_step(model, flat, opt, b)))
+        finals.append((flat.flat.clone(), losses))
+    (w_e, l_e), (w_g, l_g) = finals
+    assert l_e == pytest.approx(l_g, rel=1e-5), (l_e, l_g)
+    assert_close(w_g, w_e, 1e-5, "parameters after three graphed steps vs three eager steps")
+    assert float((w_e - finals[0][0]).abs().max()) == 0.0
