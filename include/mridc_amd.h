@@ -169,6 +169,11 @@ int64_t mrx_llg372_operand_floats(int B, int C, int H);
 int64_t mrx_llg372_work_floats(int B, int C, int H);
 int mrx_llg372_prepare(const float* yt, const float* S, const void* mask, int mask_kind, const int64_t* mstride, float* ytp,
                        float* Sp, float* maskp, int B, int C, int H, int centered, void* stream);
+/*   mrx_llg372_gather   the ytp = NULL form on eta_out = eta + nine-tap gather of the final convolution's tap products taps [B,18,H,372] (+ b_final,
+ *                       may be NULL): mrx_rim_final_gather of the previous RIM step (rim_block.py:239-248) folded into this step's gradient; eta_out
+ *                       is written, bit-identical to mrx_rim_final_gather's */
+int mrx_llg372_gather(const float* eta, const float* taps, const float* b_final, float* eta_out, const float* Sp, const float* maskp, int mask_batched,
+                      float* out4, float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream);
 int mrx_llg372_const_plane(const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* work, int B, int C, int H, int norm,
                            int centered, void* stream);
 int mrx_llg372(const float* eta, const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* out4, float* work,

@@ -115,6 +115,7 @@ _SIGNATURES = {
     "mrx_llg372_supported": ([_i], _i),
     "mrx_llg372_operand_floats": ([_i, _i, _i], _i64),
     "mrx_llg372_work_floats": ([_i, _i, _i], _i64),
+    "mrx_llg372_gather": ([_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_llg372_const_plane": ([_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_llg372_prepare": ([_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_llg372": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),

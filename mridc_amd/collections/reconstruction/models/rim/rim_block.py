@@ -373,11 +373,19 @@ class RIMBlock(torch.nn.Module):
         if cb8:
             hx = [None if h is None else ops.cb8_from_nchw(h) for h in hx]   # (copies: ours to overwrite from step 0 on)
             c0, r0, c1, r1 = l0.convs, l0.rnn, self.layers[1].convs, self.layers[1].rnn
+        # W = 372, constant-plane gradient: the nine-tap gather that ends a step (eta + final convolution) rides in the NEXT step's gradient launch
+        # (mrx_llg372_gather); `pending` = the tap products of a step whose eta has not been formed yet
+        fuse_gather = cb8 and defer and op372 is not None and ops.LLG372_NO_Y and ops.LLG372_GATHER
+        pending = None
         for step in range(self.time_steps):                          # rim_block.py:217-249
             own = step > 0                                           # the states of step 0 are the caller's (or the zero state)
             if cb8:
                 part, nparts, grad_eta = None, 0, None
-                if defer and op372 is not None:
+                if pending is not None:
+                    part, nparts, eta = ops.llg372_gather(eta, pending, final.conv_layer.bias, op372, sigma, self.fft_normalization)
+                    etas.append(eta)
+                    pending = None
+                elif defer and op372 is not None:
                     part, nparts = ops.llg372(eta, op372, sigma, self.fft_normalization, parts=True)
                 elif defer and t4:
                     part, nparts = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization,
@@ -397,6 +405,9 @@ class RIMBlock(torch.nn.Module):
                                            out=hx[0] if (self.inplace_state and hx[0] is not None) else None)
                 hx[1], taps = ops.rim_layer2_f16_cb8(hx[0], self._packed_f16(1, c1, r1, final), c1.conv_layer.bias, r1.ih.bias, r1.hh, hx[1], xmax,
                                                      out=hx[1] if (self.inplace_state and hx[1] is not None) else None, want_taps=True)
+                if fuse_gather and step + 1 < self.time_steps:
+                    pending = taps
+                    continue
                 eta = ops.rim_final_gather(taps, final.conv_layer.bias, eta)
                 etas.append(eta)
                 continue

@@ -83,10 +83,17 @@ __global__ void k_llg372_prep_mask(MrxMask mask, float* __restrict__ maskp, int 
 // NOY: the measured data is not read -- the gradient is affine in eta, g = A^H M A eta - A^H M y, and the second term is ONE constant plane per slice
 // (mrx_llg372_const_plane: this kernel on eta = 0, its partial planes summed) that the consumer of the partial planes adds like one more coil group:
 // 34.5 MB per launch instead of 63.1 MB at 15 coils.  The same kernel with NOY is the ADJOINT of the linear part (training).
-template <int ABL, bool NOY = false>
+// GAT: eta is not read but MADE here -- the previous step's eta plus the nine-tap gather of the final convolution's tap products (the whole of
+// k_l2sb_gather, same order of additions: bit-identical) -- and written out by the row's first task; one launch per step less in the RIM loop.
+struct L372Gather {
+    const float* taps;      // [B][18][H][372]: taps[b][tap * 2 + co] (rim_layer2_sb.hip)
+    const float* bias;      // [2] or null
+    float2* eta_out;        // [B][H][372]
+};
+template <int ABL, bool NOY = false, bool GAT = false>
 __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta_, const float2* __restrict__ ytp_,
                                                    const float2* __restrict__ Sp_, const float* __restrict__ maskp,
-                                                   float2* __restrict__ part_, L372Args a) {
+                                                   float2* __restrict__ part_, L372Args a, L372Gather ga) {
     // complex values travel as packed register pairs (pfa_c); the float2 of the interface is the same 8 bytes
     const pfa_c* __restrict__ eta = reinterpret_cast<const pfa_c*>(eta_);
     const pfa_c* __restrict__ ytp = reinterpret_cast<const pfa_c*>(ytp_);
@@ -112,18 +119,49 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
     float mv[6];
     const pfa_c* erow = eta + (long long)row * PFA_N;
     const float* mrow = maskp + (long long)b * a.mask_bstride;
+    Pfa372Lane L;
+    auto load_maps = [&]() {
+        const pfa_c* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
+#pragma unroll
+        for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = ABL == 2 ? pfa_mk((float)(l + n2), 0.25f) : sp[n2 * PFA_L1];
+    };
+    if (GAT) load_maps();       // the maps are requested BEFORE the gather's 114 dependent loads: they arrive under it
+    if (GAT) {
+        const int h = (int)(row - b * (unsigned)a.H);
+        const long long plane = (long long)a.H * PFA_N;
+        const float* pb = ga.taps + (long long)b * 18 * plane;
+        const int y0 = h > 0 ? h - 1 : 0, y2 = h + 1 < a.H ? h + 1 : a.H - 1;
+        const float b0 = ga.bias ? ga.bias[0] : 0.f, b1 = ga.bias ? ga.bias[1] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int n = min(l + 64 * i, PFA_N - 1);
+            const int w = pfa372_shift(n, a.halfW);
+            const int x0 = w > 0 ? w - 1 : 0, x2 = w + 1 < PFA_N ? w + 1 : PFA_N - 1;
+            const int ro[3] = {y0 * PFA_N, h * PFA_N, y2 * PFA_N}, co[3] = {x0, w, x2};
+            float s0 = b0, s1 = b1;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* q = pb + (long long)((dy * 3 + dx) * 2) * plane + ro[dy] + co[dx];
+                    s0 += q[0];
+                    s1 += q[plane];
+                }
+            const float2 e = eta_[(long long)row * PFA_N + w];
+            const float2 v = make_float2(e.x + s0, e.y + s1);
+            ev[i] = pfa_mk(v.x, v.y);
+            if (z == 0 && l + 64 * i < PFA_N) ga.eta_out[(long long)row * PFA_N + w] = v;
+            mv[i] = mrow[n];
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int n = min(l + 64 * i, PFA_N - 1);
         ev[i] = ABL == 2 ? pfa_mk(0.5f, (float)n) : erow[pfa372_shift(n, a.halfW)];
         mv[i] = ABL == 2 ? 1.f : mrow[n];
     }
-    Pfa372Lane L;
-    {
-        const pfa_c* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
-#pragma unroll
-        for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = ABL == 2 ? pfa_mk((float)(l + n2), 0.25f) : sp[n2 * PFA_L1];
     }
+    if (!GAT) load_maps();
     // yt of the first two passes of stage B is requested before stage A, the third as soon as stage A has freed its registers: the
     // whole HBM stream of the task is in flight while the 31-point DFTs run.  (Requesting yt only after the maps have arrived, or
     // delaying it by a fixed sleep, changes nothing: measured 18.6 vs 18.7 us -- the memory system is not first-come-first-served.)
@@ -554,18 +592,18 @@ extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, c
     const dim3 grid((unsigned)a.ntasks), blk(64);
     const float2 *pe = (const float2*)eta, *py = (const float2*)ytp, *ps = (const float2*)Sp;
     if (noy)
-        hipLaunchKernelGGL((k_llg372<0, true>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+        hipLaunchKernelGGL((k_llg372<0, true>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a, L372Gather{nullptr, nullptr, nullptr});
     else if (ablate == 1)
-        hipLaunchKernelGGL((k_llg372<1>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+        hipLaunchKernelGGL((k_llg372<1>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a, L372Gather{nullptr, nullptr, nullptr});
     else if (ablate == 2)
-        hipLaunchKernelGGL((k_llg372<2>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+        hipLaunchKernelGGL((k_llg372<2>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a, L372Gather{nullptr, nullptr, nullptr});
     else if (ablate == 3) {
         static unsigned long long* d_trace = nullptr;
         if (!d_trace) {
             (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 8 * (size_t)a.ntasks);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_l372_trace), &d_trace, sizeof(d_trace));
         }
-        hipLaunchKernelGGL((k_llg372<3>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+        hipLaunchKernelGGL((k_llg372<3>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a, L372Gather{nullptr, nullptr, nullptr});
         if ((MRX_DEBUG_ENV("MRX_TRACE") && atoi(MRX_DEBUG_ENV("MRX_TRACE")) >= 2)) {
             (void)hipStreamSynchronize(st);
             const size_t nt = (size_t)a.ntasks;
@@ -593,7 +631,7 @@ extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, c
             free(h);
         }
     } else
-        hipLaunchKernelGGL((k_llg372<0>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a);
+        hipLaunchKernelGGL((k_llg372<0>), grid, blk, L372_LDS_BYTES, st, pe, py, ps, maskp, (float2*)work, a, L372Gather{nullptr, nullptr, nullptr});
     const int np = a.T + (noy ? 1 : 0);
     if (nparts) {
         *nparts = np;
@@ -605,6 +643,36 @@ extern "C" int mrx_llg372(const float* eta, const float* ytp, const float* Sp, c
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_llg372_combine, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)eta, (const float2*)work, out4, np,
                        (long long)B, plane, inv_sigma2);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// mrx_llg372 (ytp = NULL form) on eta_out = eta + the nine-tap gather of `taps` [B,18,H,372] (+ b_final): the final convolution's gather
+// (mrx_rim_final_gather) folded into the next step's gradient.  eta_out is written (bit-identical to mrx_rim_final_gather's result); `work` as for
+// mrx_llg372 with ytp = NULL (its constant plane prepared by mrx_llg372_const_plane).
+extern "C" int mrx_llg372_gather(const float* eta, const float* taps, const float* b_final, float* eta_out, const float* Sp, const float* maskp,
+                                 int mask_batched, float* out4, float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered,
+                                 void* stream) {
+    MRX_REQUIRE(eta && taps && eta_out && Sp && maskp && work && (out4 || nparts), MRX_EINVAL, "mrx_llg372_gather: null pointer");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, mask_batched);
+    if (rc) return rc;
+    if (nparts) *nparts = 0;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_llg372_gather: too many tasks");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_llg372<0, true, true>), dim3((unsigned)a.ntasks), dim3(64), L372_LDS_BYTES, st, (const float2*)eta, (const float2*)nullptr,
+                       (const float2*)Sp, maskp, (float2*)work, a, L372Gather{taps, b_final, (float2*)eta_out});
+    const int np = a.T + 1;
+    if (nparts) {
+        *nparts = np;
+        MRX_LAUNCH_CHECK();
+        return MRX_OK;
+    }
+    const long long plane = (long long)H * PFA_N, total = plane * B;
+    long long nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_llg372_combine, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)eta_out, (const float2*)work, out4, np, (long long)B, plane,
+                       inv_sigma2);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -628,7 +696,7 @@ extern "C" int mrx_llg372_const_plane(const float* ytp, const float* Sp, const f
     if (nz > 2048) nz = 2048;
     hipLaunchKernelGGL(k_l372_zero, dim3((unsigned)nz), dim3(256), 0, st, cpl, total);
     hipLaunchKernelGGL((k_llg372<0>), dim3((unsigned)a.ntasks), dim3(64), L372_LDS_BYTES, st, (const float2*)cpl, (const float2*)ytp, (const float2*)Sp,
-                       maskp, (float2*)work, a);
+                       maskp, (float2*)work, a, L372Gather{nullptr, nullptr, nullptr});
     long long nb = (total + 255) / 256;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_pfa372_sum, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)work, cpl, a.T, total);

@@ -437,6 +437,30 @@ def llg372(eta, op, sigma, normalization, out=None, parts=False):
     return (op.work, int(n.value)) if parts else out
 
 
+LLG372_GATHER = os.environ.get("MRIDC_AMD_LLG372_GATHER", "1") != "0"     # RIMBlock: the final convolution's tap gather rides in the next step's gradient launch
+
+
+def llg372_gather(eta, taps, b_final, op, sigma, normalization):
+    """The deferred form of llg372 on eta_new = rim_final_gather(taps, b_final, eta), in ONE launch (mrx_llg372_gather): returns (work, nparts, eta_new).
+    Needs the constant-plane form (LLG372_NO_Y)."""
+    import ctypes
+    eta = _lib.f32c(eta)
+    if tuple(eta.shape) != (op.B, op.H, 372, 2) or taps.numel() < 18 * op.B * op.H * 372:
+        raise ValueError(f"llg372_gather: eta {tuple(eta.shape)}, taps {tuple(taps.shape)}")
+    if op.linear or not LLG372_NO_Y:
+        raise RuntimeError("llg372_gather needs the constant-plane form of the gradient (ops.LLG372_NO_Y)")
+    if op.const_norm != _norm(normalization):
+        _llg372_const(op, normalization)
+    bf = _lib.f32c(b_final.detach()) if b_final is not None else None
+    eta_new = torch.empty_like(eta)
+    n = ctypes.c_int(0)
+    _lib.check(_lib.lib().mrx_llg372_gather(_lib.ptr(eta), _lib.ptr(taps), _lib.ptr(bf), _lib.ptr(eta_new), _lib.ptr(op.sp), _lib.ptr(op.maskp),
+                                            op.mask_batched, None, _lib.ptr(op.work), ctypes.byref(n), op.B, op.C, op.H,
+                                            float(1.0 / (float(sigma) ** 2.0)), _norm(normalization), int(op.centered), _lib.stream_ptr()),
+               "mrx_llg372_gather")
+    return op.work, int(n.value), eta_new
+
+
 def llg_hinv(eta, yt, sens, mask, sigma, centered, normalization, out=None, work=None):
     """log_likelihood_gradient for a row-invariant mask (yt from llg_prepare): row transforms only."""
     yt, sens, eta = _lib.f32c(yt), _lib.f32c(sens), _lib.f32c(eta)

@@ -121,6 +121,7 @@ BF16_STORAGE = True
 # branches: they run on a second HIP stream next to it (every kernel of the chain leaves CUs idle: one or two workgroups per CU waiting for their tiles).
 # Each stream keeps its own fixed order, so the gradients stay bit-reproducible.
 TL_SIDE_STREAM = os.environ.get("MRIDC_AMD_TL_SIDE_STREAM", "1") != "0"      # ("0": one stream -- each kernel's own duration in a profile)
+TL_SIDE_IN_CAPTURE = True
 _SIDE = {}
 
 
@@ -343,7 +344,8 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
         eta = eta_new
     parts = [ops.tl_cell_part(B, H, W, eta.device) for _ in range(nl)]
     main = torch.cuda.current_stream()
-    side = _side_stream(eta.device) if TL_SIDE_STREAM and not torch.cuda.is_current_stream_capturing() else None
+    # (inside a hipGraph capture the side stream joins the capture through the events below: the weight gradients become parallel branches of the graph)
+    side = _side_stream(eta.device) if TL_SIDE_STREAM and (TL_SIDE_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()) else None
 
     def on_side(fn, *inputs):
         """fn() on the side stream once everything `main` has queued so far is done; `inputs` were allocated on main and stay alive for it."""
@@ -543,3 +545,19 @@ class GraphedModelStep:
         world = allreduce_gradients(self.flat.grad)
         self.optimizer.step(grad_scale=1.0 / world)
         return self.loss
+
+
+class GraphedCirimStep(GraphedModelStep):
+    """`training_step` on the explicit tape (cirim_forward_backward) as one hipGraph replay; the weight gradients of the bf16-storage tape are parallel
+    branches of the graph (the side stream joins the capture).  One all-reduce of the whole flat gradient after the replay (the eager step overlaps
+    per-cascade all-reduces with the following cascades instead), then Adam."""
+
+    def __init__(self, model, flat, optimizer, batch, precision=None, warmup=2):
+        self.precision = ag.PRECISION if precision is None else precision
+        if not _tape_supported(model, batch):
+            raise NotImplementedError("GraphedCirimStep: the explicit tape does not cover this model / mask")
+        super().__init__(model, flat, optimizer, batch, None, warmup)
+
+    def _fwd_bwd(self):
+        self.flat.zero_grad()
+        return cirim_forward_backward(self.model, self.static, self.precision, None).detach()

@@ -548,3 +548,34 @@ def test_graphed_model_training_step_follows_the_eager_one(dev):
     assert l_e == pytest.approx(l_g, rel=1e-5), (l_e, l_g)
     assert_close(w_g, w_e, 1e-5, "parameters after three graphed steps vs three eager steps")
     assert float((w_e - finals[0][0]).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_graphed_cirim_training_step_follows_the_eager_one(dev, precision):
+    """training.GraphedCirimStep (the explicit tape as one hipGraph replay; in bf16 the side stream's weight gradients are parallel branches of the
+    graph): three steps on three slices leave the parameters of three eager training_step calls."""
+    from mridc_amd import autograd as ag
+    from mridc_amd import synthetic, training
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=2, recurrent_layer="IndRNN")
+    batches = []
+    for i in range(3):
+        s = synthetic.make_slice(4, 24, 372, slice_idx=i)
+        batches.append({k: s[k].to(dev) for k in ("y", "sensitivity_maps", "mask", "target")})
+    keep = ag.PRECISION
+    ag.set_precision(precision)
+    try:
+        finals = []
+        for graphed in (False, True):
+            torch.manual_seed(4)
+            model = CIRIM(cfg).to(dev)
+            flat = training.FlatParameters(model)
+            opt = training.AdamFlat(flat, lr=1e-3)
+            step = training.GraphedCirimStep(model, flat, opt, batches[0]) if graphed else None
+            losses = [float(step(b) if graphed else training.training_step(model, flat, opt, b)) for b in batches]
+            finals.append((flat.flat.clone(), losses))
+    finally:
+        ag.set_precision(keep)
+    (w_e, l_e), (w_g, l_g) = finals
+    assert l_e == pytest.approx(l_g, rel=1e-5), (l_e, l_g)
+    assert_close(w_g, w_e, 1e-5, "parameters after three graphed steps vs three eager steps")

@@ -93,3 +93,25 @@ def test_cascade_on_channel_blocked_states_is_bit_identical(dev, mask_kind):
     assert none is None
     for a, b in zip(e1 + e1b + list(h1) + list(h1b), e0 + e0b + list(h0) + list(h0b)):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_cascade_with_the_tap_gather_folded_into_the_gradient_is_bit_identical(dev):
+    """RIMBlock.forward at W = 372 with a column mask: the nine-tap gather that ends a time-step folded into the next step's gradient launch
+    (mrx_llg372_gather; default) against the separate launches -- every estimate and the states bit for bit."""
+    from mridc_amd import ops, synthetic
+    from mridc_amd.collections.reconstruction.models.cirim import CIRIM
+    torch.manual_seed(0)
+    model = CIRIM(dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=1)).eval().to(dev)
+    blk = model.cirim[0]
+    d = {k: v.to(dev) for k, v in synthetic.make_slice(6, 24, 372, slice_idx=2).items()}
+    assert ops.LLG372_GATHER and ops.LLG372_NO_Y
+    with torch.no_grad():
+        e1, h1 = blk(d["y"], d["y"], d["sensitivity_maps"], d["mask"])
+        try:
+            ops.LLG372_GATHER = False
+            e0, h0 = blk(d["y"], d["y"], d["sensitivity_maps"], d["mask"])
+        finally:
+            ops.LLG372_GATHER = True
+    assert len(e1) == len(e0) == blk.time_steps
+    for a, b in zip(e1 + list(h1), e0 + list(h0)):
+        assert a.shape == b.shape and torch.equal(a, b)
