@@ -918,6 +918,28 @@ def exact_route_line(args):
         return dict(value=None, error=f"{type(ex).__name__}: {ex}")
 
 
+def training_line(args, model="cirim"):
+    """BASELINE config 4 (CIRIM training, bf16) in a CHILD process: run inside this process after the inference benches the same step measured
+    15-16 slices/s against 23 in a fresh process (allocator and stream state left by the graphs of the three inference runs), and a number that depends
+    on what ran before it is not a measurement.  The child's whole record (roofline on the cell-backward kernel, parity against the three oracle
+    arithmetics, CPU baseline) rides along."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--train", "--dtype", "bf16", "--steps", "4", "--warmup", "1", "--no-other-configs", "--no-stream-inputs",
+           "--coils", str(args.coils), "--height", str(args.height), "--width", str(args.width)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    if model == "e2evn":        # E2EVN under the same trainer (SURVEY 8 row T): forward + loss + backward as one hipGraph replay
+        cmd = [sys.executable, os.path.abspath(__file__), "--train", "--model", "e2evn", "--steps", "6", "--warmup", "2", "--no-other-configs", "--no-stream-inputs",
+               "--no-cpu-baseline", "--coils", str(args.coils), "--height", str(args.height), "--width", str(args.width)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        for drop in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "world_size_seen", "per_rank_ms_per_step", "data"):
+            r.pop(drop, None)
+        r["process"] = "child (fresh process)"
+        return r
+    except Exception as ex:  # noqa: BLE001
+        return dict(value=None, error=f"{type(ex).__name__}: {ex}")
+
+
 def mask2d_line(args):
     """The headline with a row-dependent (2-D) sampling mask -- the family of the reference's default CIRIM configuration (Poisson-2D,
     base_cirim_run.yaml:84-90): the data-consistency gradient is then the three-pass kernel chain.  A child process (a fresh model, no state shared
@@ -1093,6 +1115,7 @@ def main():
     timer.wrap(ops, "llg_hinv", lambda *a, **k: "llg")
     timer.wrap(ops, "llg_hinv_parts", lambda *a, **k: "llg")     # gradient whose last pass is done by layer 1's tile loader
     timer.wrap(ops, "llg372", lambda *a, **k: "llg372")          # W = 372: wave-private prime-factor transforms, one launch
+    timer.wrap(ops, "llg372_gather", lambda *a, **k: "llg372g")  # ... with the previous step's nine-tap gather (eta + final convolution) folded in
     timer.wrap(ops, "rim_layer_indrnn_packed_llg", lambda *a, **k: "conv_layer1")
     timer.wrap(ops, "rim_final", lambda *a, **k: "final")
 
@@ -1219,8 +1242,15 @@ def main():
             msf, _ = timer.mean_ms("final_gather")
         msl, nl = timer.mean_ms("llg")
         ms372, n372 = timer.mean_ms("llg372")
+        ms372g, n372g = timer.mean_ms("llg372g")
         if ms372:
             msl, nl = ms372, n372
+        # per RIM step: the gradient launch (7 of 8 steps of a cascade in the form that also does the previous step's tap gather) and what is left of
+        # the stand-alone gather (the last step of every cascade)
+        steps_prof = float((n372 or 0) + (n372g or 0)) or None
+        llg_per_step = (((ms372 or 0.0) * (n372 or 0) + (ms372g or 0.0) * (n372g or 0)) / steps_prof) if (steps_prof and ms372) else msl
+        n_fin = timer.mean_ms("final_gather")[1] if l2_taps else 0
+        final_per_step = (msf * n_fin / steps_prof) if (steps_prof and msf and n_fin and n372g) else msf
         # whole regulariser (layer 1 + layer 2 + final conv) as issued on the matrix / vector pipes.  Layer 1 runs on the bf16 matrix pipe
         # (k_rim_layer1_sb: three-term bf16 operand split, 6 term products per multiply, 132 MFMAs of 32x32x16 per 32 pixels) unless
         # MRIDC_AMD_ARITH=fp32 selects the fp32-MFMA kernels: its issued work is priced against the dense bf16 peak, the rest against the
@@ -1295,6 +1325,14 @@ def main():
                             traffic=traffic.get("llg") if args.mask == "1d" else traffic.get("llg_2d"), traffic_unit="bytes/launch",
                             traffic_kernel=traffic.get("_kernels", {}).get("llg" if args.mask == "1d" else "llg_2d"),
                             launches=nl, avg_ms=msl, bytes_per_call=bytes_llg, executed_bytes_per_call=bytes_llg_exec,
+                            # the same kernel with the previous step's nine-tap gather folded in (7 of 8 steps): its algorithmic bytes = the gradient's
+                            # + the gather's (18 tap planes and eta in, eta out)
+                            gather_form=(dict(kernel="k_llg372<0, true, true> via mrx_llg372_gather", launches=n372g, avg_ms=ms372g, traffic=traffic.get("llg_gather"),
+                                              bytes_per_call=bytes_llg + 88.0 * npix * B,
+                                              frac=((bytes_llg + 88.0 * npix * B) / (ms372g * 1e-3) / 1e9 / PEAK_HBM_GBS),
+                                              executed_bytes_per_call=(bytes_llg_exec + 88.0 * npix * B) if bytes_llg_exec else None,
+                                              executed_frac=((bytes_llg_exec + 88.0 * npix * B) / (ms372g * 1e-3) / 1e9 / PEAK_HBM_GBS) if bytes_llg_exec else None)
+                                         if ms372g else None),
                             executed_frac=(bytes_llg_exec / (msl * 1e-3) / 1e9 / PEAK_HBM_GBS) if (msl and bytes_llg_exec) else None,
                             note=("`frac` = SURVEY 8d's compulsory bytes of the operation (eta, y, S, mask, result) / time; the launch itself does not read "
                                   "the measured data any more -- its term -A^H M y is a constant plane made once per slice -- and moves "
@@ -1313,8 +1351,11 @@ def main():
                                      "2-D random points R~10 (general three-launch gradient)")),
                    world_size_seen=world_seen(), per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
                    launch="hipGraph replay" if graphed else "eager", roofline=roofline, roofline_fft=roofline_fft,
-                   breakdown_ms=dict(llg=msl, conv_layer1=ms1, conv_layer2=ms2, final=msf,
-                                     rim_steps_per_slice=cfg["num_cascades"] * T_),
+                   breakdown_ms=dict(llg=llg_per_step, conv_layer1=ms1, conv_layer2=ms2, final=final_per_step,
+                                     rim_steps_per_slice=cfg["num_cascades"] * T_,
+                                     note=("per RIM step; llg = launches-weighted mean of the plain gradient launch and of the form that also forms eta from the "
+                                           "previous step's tap products (mrx_llg372_gather); final = the stand-alone gather launches that remain (one per "
+                                           "cascade) spread over the steps") if n372g else None),
                    event_timing=dict(method="HIP events around every launch of two eager steps (host enqueues ahead of a parked GPU); each figure "
                                             "is the event-pair time minus half an EMPTY pair, i.e. minus the closing event's own processing time, "
                                             "calibrated in this run -- this is what makes the figures agree with rocprofv3's kernel durations",
@@ -1353,8 +1394,7 @@ def main():
             import copy
             others = {}
             for name, fn, over in (("e2evn_6cascade_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=4, streams=2, steps=6, warmup=2)),
-                                   ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=2, steps=10, warmup=2)),
-                                   ("cirim_training_bf16_15coil_640x372", bench_train, dict(model="cirim", train=True, dtype="bf16", batch=1, steps=4, warmup=1))):
+                                   ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=2, steps=10, warmup=2))):
                 a2 = copy.copy(args)
                 for k_, v_ in over.items():
                     setattr(a2, k_, v_)
@@ -1366,6 +1406,8 @@ def main():
                 except Exception as ex:  # noqa: BLE001
                     others[name] = dict(value=None, error=f"{type(ex).__name__}: {ex}")
                 torch.cuda.empty_cache()
+            others["cirim_training_bf16_15coil_640x372"] = training_line(args)
+            others["e2evn_training_15coil_640x372"] = training_line(args, "e2evn")
             from mridc_amd import autograd as ag_
             ag_.set_precision("f32")
             if args.mask == "1d":

@@ -38,6 +38,7 @@ for _ in range(3):
     ops.rim_layer_indrnn_wino(x, pk, F, bc, bi, hh, hp)
     ops.rim_layer2_sb_taps(x, pk2, bc, bi, hh, hp, taps)      # the three-term bf16 form (MRIDC_AMD_ARITH=bf16x3)
     ops.rim_final_gather(taps, None, eta)
+    ops.llg372_gather(eta, taps, None, op, 1.0, "backward")   # the same gather folded into the next step's gradient launch (the loop's default)
     ops.rim_final(x, wf, None, 3, 1, eta)
 # ---- the other configurations' dominant kernels (their own shapes) ------------------------------------------------------------------------------
 A14 = r(4, 14, 640, 384)

@@ -11,7 +11,8 @@ import json
 import sys
 
 KEYS = {            # key in the JSON -> substrings of the kernel names it sums (one "launch" of the operator)
-    "llg": ["k_llg372<"],
+    "llg": ["k_llg372<0, true, false>"],      # (pmc_r04.py runs the default form: the data term as a constant plane; <0, false, false> = that plane's one launch per slice)
+    "llg_gather": ["k_llg372<0, true, true>"],                             # ... with the previous step's nine-tap gather folded in
     "conv_layer1": ["k_rim_layer1_sb", "k_rim_layer<5, 1, 4"],
     "conv_layer2_wino": ["k_rim_layer_wino<0, true, 2, true"],
     "conv_layer2_sb": ["k_rim_layer2_sb<2, true, false, false"],
@@ -23,14 +24,14 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "llg_2d_cols_noy": ["k_cols_dc_t4<PlanCT<640, 5, 8, 4, 4>, true>"],
     "e2evn_uconv_h_14to14": ["k_uconv_h<1, 1, true>"],
     "qcirim_conv3x3_h_128": ["k_uconv_h<4, 2, false>"],
-    "train_layer2_fwd": ["k_conv_bf16<3, 2, 64, 2, 0, 2>"],
+    "train_layer2_fwd": ["k_conv_bf16<3, 2, 64, 2, 0, 2>", "k_conv_bf16<3, 2, 64, 2, 2, 2>"],
     "train_cell_bwd": ["k_tl_cell_bwd<true, true>"],
-    "train_wgrad_3x3d2": ["k_conv_wgrad_bf16<3, 2, 1>"],
+    "train_wgrad_3x3d2": ["k_conv_wgrad_bf16<3, 2, 1>", "k_conv_wgrad_bf16<3, 2, 1, 1>"],
     "train_dgrad_3x3d2": ["k_conv_bf16<3, 2, 64, 2, 1, 1>"],
 }
 AT = {"e2evn_uconv_h_14to14": "4 x 14 -> 14 x 640 x 384", "qcirim_conv3x3_h_128": "1 x 128 -> 128 x 256 x 256, dilation 2",
       "train_layer2_fwd": "1 x 64 x 640 x 372", "train_cell_bwd": "1 x 64 x 640 x 372", "train_wgrad_3x3d2": "1 x 64 x 640 x 372",
-      "train_dgrad_3x3d2": "1 x 64 x 640 x 372", "llg_2d_cols_noy": "15 x 640 x 372"}
+      "train_dgrad_3x3d2": "1 x 64 x 640 x 372", "llg_2d_cols_noy": "15 x 640 x 372", "llg_gather": "15 x 640 x 372"}
 
 
 def per_kernel(path):
