@@ -739,8 +739,9 @@ def bench_train(args, world, rank, dev, checks=False):
             share = {k: v / 1.0 for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:6]}
             table = measured_traffic(1, 15, 640, 372, 64) if (C, H, W) == (15, 640, 372) else {}
             if key == "tl_cell_bwd":
-                # bytes of one launch: dh_above (pairs, 2 B) + dH + h + h_prev (fp32) + a (pairs) read, dh_prev (fp32) + ga (pairs) written, 64 channels
-                nbytes = (2 + 4 + 4 + 4 + 2 + 4 + 2) * 64.0 * H * W
+                # bytes of one launch: dh_above (pairs, 2 B) + dH + h_prev (fp32) + a (pairs) read, dh_prev (fp32) + ga (pairs) written, 64 channels;
+                # the layer's own state as its (h > 0) mask words, 8 bytes per pixel
+                nbytes = ((2 + 4 + 4 + 2 + 4 + 2) * 64.0 + 8.0) * H * W
                 res["roofline"] = dict(bound="hbm", kernel="k_tl_cell_bwd via mrx_tl_cell_bwd: the backward of an IndRNN layer's cell and of its convolution's ReLU in one pass -- "
                                                             "g = (dh_above + dH) (h > 0), dh_prev, the hh / bias sums, da = bf16(W_ih^T bf16(g)) and dW_ih += bf16(g) a^T on "
                                                             "v_mfma_f32_32x32x16_bf16, ga = da (a > 0) as a pair tensor (replaces five launches of the fp32-storage tape); the kernel "

@@ -550,18 +550,21 @@ int mrx_dc_combine_bwd(const float* dy, const float* pred, const float* ref, con
  *                        h, h_prev (and x when Cin == 64) are [B,8,H,W,8], channel c = 8 q + j at [b][q][y][x][j] (32 contiguous bytes per pixel
  *                        and block: 16-byte accesses everywhere instead of dwords of 64 planes).  taps != null: also the final convolution's (tap, cout)
  *                        products with bf16(h) [B,18,H,W], summed by mrx_tl_final_gather: eta_out = eta + bf16(sum of the 9 shifted planes)
- *   mrx_tl_cell_bwd      backward of the cell and of the convolution's ReLU in one pass (see train_bf16.hip); parameter-gradient partials accumulate
+ *                        hmask (may be NULL): uint32 [B,H,W,2] receives (h > 0) as 64 bits per pixel (word w, bit 16 c2 + 4 k + m = channel
+ *                        32 c2 + 8 k + 4 w + m): all that mrx_tl_cell_bwd needs of h -- 8 bytes per pixel instead of 256
+ *   mrx_tl_cell_bwd      backward of the cell and of the convolution's ReLU in one pass (see train_bf16.hip; the state as h or, if hmask != NULL,
+ *                        as the forward's mask bits -- h is then not read and may be NULL); parameter-gradient partials accumulate
  *                        in `part` (mrx_tl_cell_part_floats floats; first != 0 overwrites) until mrx_tl_cell_reduce adds them to the gradients
  *   mrx_tl_dgrad         data gradient of a replicate-padded convolution with bf16 results: interior -> dx, frame -> `frame` for mrx_tl_fold_edges
  *   mrx_conv_wgrad_bf16_pairs   the weight gradients of mrx_conv_wgrad_bf16_any with dy given as a pair tensor */
 int64_t mrx_tl_pack_bytes(void);
 int mrx_tl_pack(const float* w_ih, const float* w_fin, void* packed, void* stream);
 int mrx_tl_layer_fwd(const float* x, const void* conv_packed, const float* conv_bias, const void* tl_packed, const float* ih_bias, const float* hh,
-                     const float* hprev, void* a_pairs, float* h, float* taps, int B, int Cin, int H, int W, int k, int dil, void* stream);
+                     const float* hprev, void* a_pairs, float* h, void* hmask, float* taps, int B, int Cin, int H, int W, int k, int dil, void* stream);
 int mrx_tl_final_gather(const float* taps, const float* eta, float* eta_out, int B, int H, int W, void* stream);
 int64_t mrx_tl_cell_part_floats(int B, int H, int W);
-int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const float* h, const float* hprev, const void* a_pairs, const void* tl_packed,
-                    const float* hh, float* dh_prev, void* ga_pairs, float* part, int first, int B, int H, int W, void* stream);
+int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const float* h, const void* hmask, const float* hprev, const void* a_pairs,
+                    const void* tl_packed, const float* hh, float* dh_prev, void* ga_pairs, float* part, int first, int B, int H, int W, void* stream);
 int mrx_tl_cell_reduce(const float* part, int B, int H, int W, float* dw_ih, float* db_ih, float* dhh, float* db_conv, void* stream);
 int mrx_tl_dgrad(const void* dy, int dy_pairs, const void* packed, void* dx, int dx_pairs, float* frame, int B, int Cdy, int Cdx, int H, int W, int k,
                  int dil, void* stream);

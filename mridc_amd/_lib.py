@@ -79,11 +79,11 @@ _SIGNATURES = {
     "mrx_conv_wgrad_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_tl_pack_bytes": ([], _i64),
     "mrx_tl_pack": ([_p, _p, _p, _p], _i),
-    "mrx_tl_layer_fwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_tl_layer_fwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_tl_dgrad": ([_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_tl_fold_edges": ([_p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_tl_cell_part_floats": ([_i, _i, _i], _i64),
-    "mrx_tl_cell_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "mrx_tl_cell_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_tl_cell_reduce": ([_p, _i, _i, _i, _p, _p, _p, _p, _p], _i),
     "mrx_tl_final_gather": ([_p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_tl_pairs_to_f32": ([_p, _p, _i64, _i64, _p], _i),

@@ -46,6 +46,7 @@ struct ConvBfArgs {
     const float* bias;     // [Cout] or null
     const float* hh;       // [Cout] or null: IndRNN epilogue  act(acc + bias + hh * hprev)
     const float* hprev;    // [B,Cout,H,W] or null  (OUT 2: channel-blocked [B,8,H,W,8], like `out`)
+    unsigned* hmask;       // OUT 2: [B,H,W,2] or null -- (h > 0) as bits (word = lane half, bit 16 c2 + r = accumulator row r of block c2)
     float* out;            // [B,Cout,H,W]
     int B, Cin, Cout, H, W, tiles_x, ntiles, pad_mode, act;
     float slope;
@@ -220,6 +221,14 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
                 v += tb[128 + co] * hpv[c2][r];
                 acc2[c2][r] = v > 0.f ? v : 0.f;
             }
+        if (inside && a.hmask) {      // (h > 0) of this lane's 32 channels as one word: all the cell's backward needs of h (train_bf16.hip: CellBwdArgs::hmask)
+            unsigned mk = 0u;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mk |= (acc2[c2][r] > 0.f ? 1u : 0u) << (16 * c2 + r);
+            a.hmask[((long long)b * plane + pix) * 2 + lhi] = mk;
+        }
         if (inside) {
             float* ob = a.out + ((long long)b * 8 * plane + pix) * 8 + 4 * lhi;
 #pragma unroll
@@ -477,8 +486,8 @@ extern "C" int mrx_tl_pack(const float* w_ih, const float* w_fin, void* packed, 
 // (the hidden states of the tape: 16-byte accesses, 1 KB contiguous per half-wave instead of 128-byte pieces of 64 planes); with `taps`: also the (tap, cout) products of the final 3x3 convolution with
 // bf16(h) [B,18,H,W].  conv_packed from mrx_conv_bf16_pack (forward), tl_packed from mrx_tl_pack.  k x k = 5x5 (Cin <= 8) or 3x3 dilation 2 (Cin 64).
 extern "C" int mrx_tl_layer_fwd(const float* x, const void* conv_packed, const float* conv_bias, const void* tl_packed, const float* ih_bias,
-                                const float* hh, const float* hprev, void* a_pairs, float* h, float* taps, int B, int Cin, int H, int W, int k,
-                                int dil, void* stream) {
+                                const float* hh, const float* hprev, void* a_pairs, float* h, void* hmask, float* taps, int B, int Cin, int H, int W,
+                                int k, int dil, void* stream) {
     MRX_REQUIRE(x && conv_packed && tl_packed && a_pairs && h, MRX_EINVAL, "mrx_tl_layer_fwd: null pointer");
     MRX_REQUIRE(!hprev || hh, MRX_EINVAL, "mrx_tl_layer_fwd: hprev without hh");
     MRX_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_tl_layer_fwd: bad dims");
@@ -490,7 +499,7 @@ extern "C" int mrx_tl_layer_fwd(const float* x, const void* conv_packed, const f
     a.tiles_x = mrx_cdiv(W, CB_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, CB_TH);
     a.pad_mode = MRX_PAD_REPLICATE, a.act = MRX_ACT_RELU, a.Hin = H, a.Win = W;
     a.ih_packed = (const u32x4*)tl_packed, a.ih_bias = ih_bias, a.a_pairs = (unsigned*)a_pairs;
-    a.fin_packed = taps ? (const u32x4*)tl_packed + 512 : nullptr, a.taps = taps;
+    a.fin_packed = taps ? (const u32x4*)tl_packed + 512 : nullptr, a.taps = taps, a.hmask = (unsigned*)hmask;
     return k == 5 ? cb_launch<5, 1, 8, 2, 0, 2>(a, (hipStream_t)stream) : cb_launch<3, 2, 64, 2, 2, 2>(a, (hipStream_t)stream);
 }
 

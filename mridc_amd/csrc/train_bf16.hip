@@ -58,7 +58,9 @@ __device__ __forceinline__ float tl_reduce_scatter32(float (&x)[32], int lane) {
 struct CellBwdArgs {
     const unsigned* dhP;   // [B,32,H,W] pairs or null: gradient from the layer above
     const float* dH;       // [B,8,H,W,8] (channel-blocked: c = 8 q + j) or null: gradient carried from the next time-step -- written as dh_prev by the previous call
-    const float* h;        // [B,8,H,W,8] channel-blocked: this step's state (the cell's ReLU mask)
+    const float* h;        // [B,8,H,W,8] channel-blocked: this step's state (the cell's ReLU mask) -- not read when hmask is given
+    const unsigned* hmask; // [B,H,W,2] or null: (h > 0) as 64 bits per pixel, written by the forward (mrx_tl_layer_fwd): word w, bit 16 c2 + 4 k + m = channel
+                           // 32 c2 + 8 k + 4 w + m -- 8 bytes per pixel instead of 256 (the state is needed here as a mask only)
     const float* hprev;    // [B,8,H,W,8] or null (first time-step: zero state)
     const unsigned* aP;    // [B,32,H,W] pairs: a = ReLU(conv)  (the convolution's ReLU mask and the 1x1 weight gradient's operand)
     const u32x4* wT;       // mrx_tl_pack's ihT block: [4 steps][2 blocks][64 lanes]
@@ -73,7 +75,7 @@ struct CellBwdArgs {
 
 // HAS_DH / HAS_PREV: wave-uniform facts of the call as template parameters, loads unconditional from clamped coordinates (a conditional load is a
 // basic block of its own: the first version of this kernel had 360 of them and spilled 92 registers), stores of a chunk under one predicate.
-template <bool HAS_DH, bool HAS_PREV>
+template <bool HAS_DH, bool HAS_PREV, bool HM>
 __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];   // [8 units][gb tile, a tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -110,16 +112,22 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int q = 0; q < 8; ++q) awv[ct * 8 + q] = ldu(a.aP, ab + (unsigned)(ct * 16 + (q & 1) + 4 * (q >> 1)) * plane4);
+        uint2 hm = make_uint2(0u, 0u);
+        if (HM) hm = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.hmask) + (unsigned)b * 2u * plane4 + pix4 * 2u);
         // eight channels at a time, the NEXT chunk's 28 loads in flight while this one is processed
         unsigned d2[2][4];
         float dHv[2][8], hv[2][8], hpv[2][8];
         auto request = [&](int ch, int bf) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) d2[bf][q] = ldu(a.dhP, pb + (unsigned)(4 * ch + q) * plane4);
-            {
+            if (!HM) {
                 const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.h) + cbb + (unsigned)ch * 8u * plane4);
                 const float4 u0 = q4[0], u1 = q4[1];
                 hv[bf][0] = u0.x, hv[bf][1] = u0.y, hv[bf][2] = u0.z, hv[bf][3] = u0.w, hv[bf][4] = u1.x, hv[bf][5] = u1.y, hv[bf][6] = u1.z, hv[bf][7] = u1.w;
+            } else {
+                // channel 32 lhi + 8 ch + j: word (j >> 2), bit 16 lhi + 4 ch + (j & 3)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hv[bf][j] = (((j & 4) ? hm.y : hm.x) >> (16 * lhi + 4 * ch + (j & 3))) & 1u ? 1.f : 0.f;
             }
             if (HAS_PREV) {
                 const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.hprev) + cbb + (unsigned)ch * 8u * plane4);
@@ -289,36 +297,43 @@ extern "C" int64_t mrx_tl_cell_part_floats(int B, int H, int W) {
 // previous call wrote) may be null (last time-step); hprev null =
 // first time-step (no dh_prev, no hh gradient).  `part` [mrx_tl_cell_part_floats]: the workgroup slots; first != 0 overwrites them (first call of a
 // cascade), otherwise the call adds to them.  tl_packed from mrx_tl_pack.
-extern "C" int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const float* h, const float* hprev, const void* a_pairs, const void* tl_packed,
-                               const float* hh, float* dh_prev, void* ga_pairs, float* part, int first, int B, int H, int W, void* stream) {
-    MRX_REQUIRE(h && a_pairs && tl_packed && ga_pairs && part, MRX_EINVAL, "mrx_tl_cell_bwd: null pointer");
+extern "C" int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const float* h, const void* hmask, const float* hprev, const void* a_pairs,
+                               const void* tl_packed, const float* hh, float* dh_prev, void* ga_pairs, float* part, int first, int B, int H, int W,
+                               void* stream) {
+    MRX_REQUIRE((h || hmask) && a_pairs && tl_packed && ga_pairs && part, MRX_EINVAL, "mrx_tl_cell_bwd: null pointer");
     MRX_REQUIRE(!hprev || (hh && dh_prev), MRX_EINVAL, "mrx_tl_cell_bwd: hprev without hh / dh_prev");
     MRX_REQUIRE(B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_tl_cell_bwd: bad dims");
     MRX_REQUIRE((long long)B * 64 * H * W * 4 < (1ll << 32), MRX_EUNSUP, "mrx_tl_cell_bwd: tensors of 4 GB and more (32-bit byte offsets)");
     CellBwdArgs a;
-    a.dhP = (const unsigned*)dh_above, a.dH = dH, a.h = h, a.hprev = hprev, a.aP = (const unsigned*)a_pairs;
+    a.dhP = (const unsigned*)dh_above, a.dH = dH, a.h = h, a.hmask = (const unsigned*)hmask, a.hprev = hprev, a.aP = (const unsigned*)a_pairs;
     a.wT = (const u32x4*)tl_packed + 768, a.hh = hh, a.dhp = dh_prev, a.gaP = (unsigned*)ga_pairs, a.part = part;
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, 32), a.ntiles = a.tiles_x * mrx_cdiv(H, 8), a.first = first;
     MRX_REQUIRE(dh_above, MRX_EINVAL, "mrx_tl_cell_bwd: the gradient from the layer above is required");
     constexpr int lds = 8 * 2 * CL_TILE;
-    static bool attr_done = false;
-    if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
-    }
     const dim3 grid(tl_cell_nwg((long long)B * a.ntiles));
     hipStream_t st = (hipStream_t)stream;
-    if (dH && hprev)
-        hipLaunchKernelGGL((k_tl_cell_bwd<true, true>), grid, dim3(CL_NT), lds, st, a);
-    else if (dH)
-        hipLaunchKernelGGL((k_tl_cell_bwd<true, false>), grid, dim3(CL_NT), lds, st, a);
-    else if (hprev)
-        hipLaunchKernelGGL((k_tl_cell_bwd<false, true>), grid, dim3(CL_NT), lds, st, a);
-    else
-        hipLaunchKernelGGL((k_tl_cell_bwd<false, false>), grid, dim3(CL_NT), lds, st, a);
+    const int which = (dH ? 4 : 0) | (hprev ? 2 : 0) | (hmask ? 1 : 0);
+#define CL_CASE(I, D, P, M)                                                                                                              \
+    case I: {                                                                                                                            \
+        static bool attr_done = false;                                                                                                   \
+        if (!attr_done) {                                                                                                                \
+            MRX_HIP(hipFuncSetAttribute((const void*)k_tl_cell_bwd<D, P, M>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));          \
+            attr_done = true;                                                                                                            \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((k_tl_cell_bwd<D, P, M>), grid, dim3(CL_NT), lds, st, a);                                                     \
+        break;                                                                                                                           \
+    }
+    switch (which) {
+        CL_CASE(0, false, false, false)
+        CL_CASE(1, false, false, true)
+        CL_CASE(2, false, true, false)
+        CL_CASE(3, false, true, true)
+        CL_CASE(4, true, false, false)
+        CL_CASE(5, true, false, true)
+        CL_CASE(6, true, true, false)
+        CL_CASE(7, true, true, true)
+    }
+#undef CL_CASE
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

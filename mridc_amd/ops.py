@@ -1119,9 +1119,10 @@ def tl_layer_supported(Cin, Cout, k, dilation, rnn_features, rnn_k):
     return Cout == 64 and rnn_features == 64 and rnn_k == 1 and ((k == 5 and dilation == 1 and 1 <= Cin <= 8) or (k == 3 and dilation == 2 and Cin == 64))
 
 
-def tl_layer_fwd(x, conv_w, conv_b, w_ih, b_ih, hh, h_prev, w_fin=None):
+def tl_layer_fwd(x, conv_w, conv_b, w_ih, b_ih, hh, h_prev, w_fin=None, want_mask=False):
     """One RIM layer in the training arithmetic (mrx_tl_layer_fwd): a = ReLU(bf16(conv_reppad(x) + b)) as a pair tensor, h = ReLU(bf16(W_ih a + b_ih)
-    + hh * h_prev) fp32; with w_fin also the final convolution's 18 tap-product planes.  Returns (a_pairs, h, taps | None).
+    + hh * h_prev) fp32; with w_fin also the final convolution's 18 tap-product planes.  Returns (a_pairs, h, taps | None) -- with want_mask
+    (a_pairs, h, taps | None, hmask): (h > 0) as int32 [B,H,W,2] bit words, what tl_cell_bwd needs of h.
     Hidden states are CHANNEL-BLOCKED: h, h_prev and the 64-channel layer's x are [B,8,H,W,8] (cb8_from_nchw / cb8_to_nchw convert)."""
     x = _lib.f32c(x)
     k, dil = int(conv_w.shape[-1]), (1 if int(conv_w.shape[-1]) == 5 else 2)
@@ -1142,9 +1143,10 @@ def tl_layer_fwd(x, conv_w, conv_b, w_ih, b_ih, hh, h_prev, w_fin=None):
     hhc = _lib.f32c(hh.detach().reshape(-1)) if h_prev is not None else None
     cb = _lib.f32c(conv_b.detach()) if conv_b is not None else None
     ib = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hm = torch.empty(B, H, W, 2, dtype=torch.int32, device=x.device) if want_mask else None
     _lib.check(_lib.lib().mrx_tl_layer_fwd(_lib.ptr(x), _lib.ptr(cp), _lib.ptr(cb), _lib.ptr(tp), _lib.ptr(ib), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(a),
-                                           _lib.ptr(h), _lib.ptr(taps), B, Cin, H, W, k, dil, _lib.stream_ptr()), "mrx_tl_layer_fwd")
-    return a, h, taps
+                                           _lib.ptr(h), _lib.ptr(hm), _lib.ptr(taps), B, Cin, H, W, k, dil, _lib.stream_ptr()), "mrx_tl_layer_fwd")
+    return (a, h, taps, hm) if want_mask else (a, h, taps)
 
 
 def tl_final_gather(taps, eta):
@@ -1160,18 +1162,26 @@ def tl_cell_part(B, H, W, device):
 
 def tl_cell_bwd(dh_pairs, dH, h, h_prev, a_pairs, w_ih, w_fin, hh, part, first):
     """mrx_tl_cell_bwd: (dh_prev | None, ga_pairs); the parameter-gradient partials accumulate in `part` (tl_cell_part) until tl_cell_reduce.
-    h, h_prev, dH in and dh_prev out are CHANNEL-BLOCKED [B,8,H,W,8] (c = 8 q + j)."""
-    if h.dim() != 5 or int(h.shape[1]) != 8 or int(h.shape[4]) != 8:
-        raise ValueError(f"tl_cell_bwd: h {tuple(h.shape)}, expected channel-blocked [B,8,H,W,8]")
-    B, H, W = int(h.shape[0]), int(h.shape[2]), int(h.shape[3])
+    h, h_prev, dH in and dh_prev out are CHANNEL-BLOCKED [B,8,H,W,8] (c = 8 q + j).  `h` may instead be the forward's mask words (int32 [B,H,W,2],
+    tl_layer_fwd(want_mask=True)): the kernel needs the state as (h > 0) only and then reads 8 bytes per pixel instead of 256."""
+    hmask = None
+    if h.dtype == torch.int32:
+        if h.dim() != 4 or int(h.shape[3]) != 2:
+            raise ValueError(f"tl_cell_bwd: mask words {tuple(h.shape)}, expected [B,H,W,2]")
+        hmask, B, H, W = h, int(h.shape[0]), int(h.shape[1]), int(h.shape[2])
+        h = None
+    else:
+        if h.dim() != 5 or int(h.shape[1]) != 8 or int(h.shape[4]) != 8:
+            raise ValueError(f"tl_cell_bwd: h {tuple(h.shape)}, expected channel-blocked [B,8,H,W,8]")
+        B, H, W = int(h.shape[0]), int(h.shape[2]), int(h.shape[3])
     for nm, t in (("dH", dH), ("h_prev", h_prev)):
         if t is not None and tuple(t.shape) != (B, 8, H, W, 8):
             raise ValueError(f"tl_cell_bwd: {nm} {tuple(t.shape)}, expected the channel-blocked {(B, 8, H, W, 8)}")
     tp = _tl_pack(w_ih, w_fin)
-    ga = torch.empty(B, 32, H, W, dtype=torch.int32, device=h.device)
-    dhp = torch.empty(B, 8, H, W, 8, dtype=torch.float32, device=h.device) if h_prev is not None else None
+    ga = torch.empty(B, 32, H, W, dtype=torch.int32, device=a_pairs.device)
+    dhp = torch.empty(B, 8, H, W, 8, dtype=torch.float32, device=a_pairs.device) if h_prev is not None else None
     hhc = _lib.f32c(hh.detach().reshape(-1)) if h_prev is not None else None
-    _lib.check(_lib.lib().mrx_tl_cell_bwd(_lib.ptr(dh_pairs), _lib.ptr(dH), _lib.ptr(h), _lib.ptr(h_prev), _lib.ptr(a_pairs), _lib.ptr(tp), _lib.ptr(hhc),
+    _lib.check(_lib.lib().mrx_tl_cell_bwd(_lib.ptr(dh_pairs), _lib.ptr(dH), _lib.ptr(h), _lib.ptr(hmask), _lib.ptr(h_prev), _lib.ptr(a_pairs), _lib.ptr(tp), _lib.ptr(hhc),
                                           _lib.ptr(dhp), _lib.ptr(ga), _lib.ptr(part), int(bool(first)), B, H, W, _lib.stream_ptr()), "mrx_tl_cell_bwd")
     return dhp, ga
 

@@ -327,9 +327,9 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
         x, acts, taps = g4, [], None
         for li, st in enumerate(blk.layers):
             c, r = st.convs, st.rnn
-            a_p, h, taps = ops.tl_layer_fwd(x, c.conv_layer.weight, c.conv_layer.bias, r.ih.weight, r.ih.bias, r.hh, hx[li],
-                                            fw if li == nl - 1 else None)
-            acts.append((x, a_p, h, hx[li]))
+            a_p, h, taps, hm = ops.tl_layer_fwd(x, c.conv_layer.weight, c.conv_layer.bias, r.ih.weight, r.ih.bias, r.hh, hx[li],
+                                                fw if li == nl - 1 else None, want_mask=True)
+            acts.append((x, a_p, h, hx[li], hm))
             hx[li] = h
             x = h
         eta_new = ops.tl_final_gather(taps, eta)
@@ -376,8 +376,9 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
         for li in range(nl - 1, -1, -1):
             st = blk.layers[li]
             c, r = st.convs, st.rnn
-            x_in, a_p, h, h_prev = acts[li]
-            dhp, ga = ops.tl_cell_bwd(dh, dH[li], h, h_prev, a_p, r.ih.weight, fw if li == nl - 1 else None, r.hh, parts[li], ti == 0)
+            x_in, a_p, h, h_prev, hm = acts[li]
+            # (the layer's own state enters as its mask bits: 8 bytes per pixel instead of 256)
+            dhp, ga = ops.tl_cell_bwd(dh, dH[li], hm, h_prev, a_p, r.ih.weight, fw if li == nl - 1 else None, r.hh, parts[li], ti == 0)
             dH[li] = dhp
             cw = c.conv_layer.weight
             on_side(lambda x_in=x_in, ga=ga, c=c, cw=cw: ops.conv_wgrad_bf16_pairs(x_in, ga, c.kernel_size, c.dilation, ops.PAD_REPLICATE,

@@ -41,6 +41,17 @@ def _blk(t):
     return None if t is None else t.view(t.shape[0], t.shape[1] // 8, 8, t.shape[2], t.shape[3]).permute(0, 1, 3, 4, 2).contiguous()
 
 
+def _mask_words(h):
+    """(h > 0) of [B,64,H,W] as int32 [B,H,W,2]: word w, bit 16 c2 + 4 k + m = channel 32 c2 + 8 k + 4 w + m (include/mridc_amd.h, mrx_tl_layer_fwd)."""
+    B, _, H, W = h.shape
+    out = torch.zeros(B, H, W, 2, dtype=torch.int64)
+    for c in range(64):
+        c2, k, w, m = c >> 5, (c >> 3) & 3, (c >> 2) & 1, c & 3
+        out[..., w] |= (h[:, c] > 0).to(torch.int64) << (16 * c2 + 4 * k + m)
+    out = torch.where(out >= 2 ** 31, out - 2 ** 32, out)
+    return out.to(torch.int32)
+
+
 def _unblk(t):
     return t.permute(0, 1, 4, 2, 3).reshape(t.shape[0], t.shape[1] * 8, t.shape[2], t.shape[3])
 
@@ -64,9 +75,10 @@ def test_training_layer_forward_rounds_where_autocast_rounds(dev, shape, with_st
     h = F.relu(u + (hh * hp if with_state else 0.0))
     d = lambda t: None if t is None else t.to(dev)  # noqa: E731
     # hidden states are channel-blocked [B,8,H,W,8] in this tape: h, h_prev, and the 64-channel layer's input
-    a_p, h_cb, taps = ops.tl_layer_fwd(_blk(d(x)) if Cin == 64 else d(x), d(cw), d(cb), d(w_ih), d(b_ih), d(hh), _blk(d(hp)), d(w_fin))
+    a_p, h_cb, taps, hm = ops.tl_layer_fwd(_blk(d(x)) if Cin == 64 else d(x), d(cw), d(cb), d(w_ih), d(b_ih), d(hh), _blk(d(hp)), d(w_fin), want_mask=True)
     assert tuple(h_cb.shape) == (B, 8, H, W, 8)
     h_g = _unblk(h_cb)
+    assert torch.equal(hm.cpu(), _mask_words(h_g.cpu()))              # (h > 0) as 64 bits per pixel: all the cell's backward reads of h
     a_g = ops.pairs_to_f32(a_p)
     assert _flips(a_g, a) <= 2e-3 and rel_l2(a_g, a) <= 2e-3, (_flips(a_g, a), rel_l2(a_g, a))
     assert rel_l2(h_g, h) <= 3e-3, rel_l2(h_g, h)
@@ -116,7 +128,12 @@ def test_cell_backward_in_one_pass(dev, variant):
         assert rel_l2(_unblk(dhp), gq * hh) <= 1e-6
     else:
         assert dhp is None
-    ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(blk(dH)), d(blk(h)), d(blk(hp)), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, False)   # second time-step: adds
+    # second time-step (adds), with the state given as its mask words: the same gradients bit for bit
+    part_h = part.clone()
+    dhp_m, ga_m = ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(blk(dH)), d(_mask_words(h)), d(blk(hp)), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part, False)
+    assert torch.equal(ga_m, ga_p) and (dhp is None or torch.equal(dhp_m, dhp))
+    ops.tl_cell_bwd(ops.f32_to_pairs(d(dh)), d(blk(dH)), d(blk(h)), d(blk(hp)), ops.f32_to_pairs(d(a)), d(w_ih), None, d(hh), part_h, False)
+    assert torch.equal(part_h, part)
     dw, dbih, dhh, db = (torch.full(s, 1.0, device=dev) for s in ((64, 64, 1, 1), (64,), (64,), (64,)))
     ops.tl_cell_reduce(part, B, H, W, dw, dbih, dhh, db)
     assert rel_l2(dw.reshape(64, 64).cpu().double() - 1.0, 2 * want["dw"]) <= 1e-5

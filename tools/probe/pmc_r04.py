@@ -49,7 +49,7 @@ bnd = ops.max_abs(X128).reshape(1)
 cw2, cb2 = r(F, F, 3, 3) / 24, r(F) * 0.1
 wih, bih, hh2, wfin = r(F, F, 1, 1) / 8, r(F) * 0.1, r(1, F, 1, 1) * 0.5, r(2, F, 3, 3) / 24
 dhP, aP = ops.f32_to_pairs(r(B, F, H, W)), ops.f32_to_pairs(r(B, F, H, W).relu())
-dH, hst, xcb = r(B, 8, H, W, 8), r(B, 8, H, W, 8).relu(), ops.cb8_from_nchw(x)     # (the training tape's hidden states are channel-blocked)
+dH, hst, xcb = r(B, 8, H, W, 8), torch.randint(-2 ** 31, 2 ** 31 - 1, (B, H, W, 2), dtype=torch.int32, device=dev), ops.cb8_from_nchw(x)     # (the training tape: hidden states channel-blocked, the cell's own state as its (h > 0) mask words)
 part_c = ops.tl_cell_part(B, H, W, dev)
 torch.cuda.synchronize()
 for i in range(3):
