@@ -562,6 +562,11 @@ int mrx_tl_pack(const float* w_ih, const float* w_fin, void* packed, void* strea
 int mrx_tl_layer_fwd(const float* x, const void* conv_packed, const float* conv_bias, const void* tl_packed, const float* ih_bias, const float* hh,
                      const float* hprev, void* a_pairs, float* h, void* hmask, float* taps, int B, int Cin, int H, int W, int k, int dil, void* stream);
 int mrx_tl_final_gather(const float* taps, const float* eta, float* eta_out, int B, int H, int W, void* stream);
+/*   mrx_tl_final_gather_max   ... and the per-workgroup maxima of |eta_out| (complex modulus, formed as mrx_max_abs forms it) in max_partials
+ *                        [mrx_tl_final_gather_max_count]: the training loss's maximum (cirim.py:218-237) without a pass of its own -- mrx_absl1_loss_mp
+ *                        reduces the partials */
+int64_t mrx_tl_final_gather_max_count(int B, int H, int W);
+int mrx_tl_final_gather_max(const float* taps, const float* eta, float* eta_out, float* max_partials, int B, int H, int W, void* stream);
 int64_t mrx_tl_cell_part_floats(int B, int H, int W);
 int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const float* h, const void* hmask, const float* hprev, const void* a_pairs,
                     const void* tl_packed, const float* hh, float* dh_prev, void* ga_pairs, float* part, int first, int B, int H, int W, void* stream);
@@ -591,6 +596,14 @@ int64_t mrx_absl1_work_floats(void);
 int mrx_absl1_loss(const float* p, const float* target, const float* maxabs, float* out2, float* work, int64_t n, void* stream);
 int mrx_absl1_loss_bwd(const float* p, const float* target, const float* maxabs, const float* fwd_out2, const float* gout,
                        float gscale, float* dp, int64_t n, void* stream); /* gout: device scalar (upstream gradient) or NULL = 1 */
+/*   mrx_absl1_loss_mp        mrx_absl1_loss with the maximum given as np per-workgroup partial maxima; the maximum is left in maxabs_out[0]
+ *   mrx_absl1_loss_bwd_eta   mrx_absl1_loss_bwd + mrx_eta_grad_in in one pass: tot [B,plane,2] = carry (may be NULL) + d(loss)/dp, d2 [B,2,plane]
+ *   mrx_eta_grad_out_parts   mrx_eta_grad_out with the adjoint gradient still in mrx_llg372's partial planes: out = tot + g4[:, 0:2] + post * sum_k parts_k */
+int mrx_absl1_loss_mp(const float* p, const float* target, const float* max_partials, int np, float* maxabs_out, float* out2, float* work, int64_t n,
+                      void* stream);
+int mrx_absl1_loss_bwd_eta(const float* p, const float* target, const float* maxabs, const float* fwd_out2, const float* gout, float gscale,
+                           const float* carry, float* tot, float* d2, int B, int64_t plane, void* stream);
+int mrx_eta_grad_out_parts(const float* tot, const float* g4, const float* parts, int nparts, float post, float* out, int B, int64_t plane, void* stream);
 int mrx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale, void* stream);
 

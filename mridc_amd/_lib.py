@@ -85,6 +85,11 @@ _SIGNATURES = {
     "mrx_tl_cell_part_floats": ([_i, _i, _i], _i64),
     "mrx_tl_cell_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_tl_cell_reduce": ([_p, _i, _i, _i, _p, _p, _p, _p, _p], _i),
+    "mrx_tl_final_gather_max_count": ([_i, _i, _i], _i64),
+    "mrx_tl_final_gather_max": ([_p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_absl1_loss_mp": ([_p, _p, _p, _i, _p, _p, _p, _i64, _p], _i),
+    "mrx_absl1_loss_bwd_eta": ([_p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i64, _p], _i),
+    "mrx_eta_grad_out_parts": ([_p, _p, _p, _i, _f, _p, _i, _i64, _p], _i),
     "mrx_tl_final_gather": ([_p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_tl_pairs_to_f32": ([_p, _p, _i64, _i64, _p], _i),
     "mrx_tl_f32_to_pairs": ([_p, _p, _i64, _i64, _p], _i),

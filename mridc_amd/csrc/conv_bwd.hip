@@ -734,6 +734,23 @@ __global__ void k_eta_grad_out(const float2* __restrict__ tot, const float* __re
                              v.y + g4[(b * 4 + 1) * plane + p] + t4[(b * 4 + 3) * plane + p]);
     }
 }
+// the same with the adjoint gradient still in its coil-group partial planes (mrx_llg372 with nparts): t4's channels 2, 3 = post * sum_k part_k, formed
+// here in mrx_llg372's own order -- its combine launch and the [B,4,H,W] tensor saved
+__global__ void k_eta_grad_out_parts(const float2* __restrict__ tot, const float* __restrict__ g4, const float2* __restrict__ part, int nparts, float post,
+                                     float2* __restrict__ out, long long B, long long plane) {
+    const long long total = B * plane;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / plane, p = i - b * plane;
+        float2 s = part[i];
+        for (int k = 1; k < nparts; ++k) {
+            const float2 v = part[(long long)k * total + i];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        const float2 v = tot[i];
+        out[i] = make_float2(v.x + g4[(b * 4) * plane + p] + s.x * post, v.y + g4[(b * 4 + 1) * plane + p] + s.y * post);
+    }
+}
 static inline unsigned tape_grid(long long n) {
     long long g = (n + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -760,6 +777,15 @@ extern "C" int mrx_eta_grad_out(const float* tot, const float* g4, const float* 
     return MRX_OK;
 }
 
+extern "C" int mrx_eta_grad_out_parts(const float* tot, const float* g4, const float* parts, int nparts, float post, float* out, int B, int64_t plane,
+                                      void* stream) {
+    MRX_REQUIRE(tot && g4 && parts && nparts >= 1 && out && B >= 1 && plane >= 1, MRX_EINVAL, "mrx_eta_grad_out_parts: bad argument");
+    hipLaunchKernelGGL(k_eta_grad_out_parts, dim3(tape_grid((long long)B * plane)), dim3(256), 0, (hipStream_t)stream, (const float2*)tot, g4,
+                       (const float2*)parts, nparts, post, (float2*)out, (long long)B, (long long)plane);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 // ---- training loss of the CIRIM (cirim.py:199-247, l1): L = mean | target - |p| / max|p| | over one complex image ---------------
 // forward:  parts[0] = sum |target - |p|/M|, parts[1] = sum sign(|p|/M - target) * |p|   (M = max |p|, a device scalar from mrx_max_abs)
 // backward: dp = gscale/n * sign * (1/M) * p/|p|, and the element(s) with |p| = M also receive -(gscale/n) * parts[1] / M^2 * p/|p|
@@ -771,9 +797,35 @@ extern "C" int mrx_eta_grad_out(const float* tot, const float* g4, const float* 
 __device__ __forceinline__ float absl1_modulus(float2 v) {
     return (float)sqrt((double)mrx_sumsq2(v.x, v.y));
 }
+// MP: M is not given but formed here from the per-workgroup maxima of the producer (mrx_tl_final_gather_max: `M` = those np partials), by every
+// workgroup alike (NaN propagates as in mrx_max_abs); workgroup 0 leaves it in Mout for the backward -- the k_max_final launch of mrx_max_abs saved
+template <bool MP>
 __global__ __launch_bounds__(LS_NT) void k_absl1_partial(const float2* __restrict__ p, const float* __restrict__ target,
-                                                         const float* __restrict__ M, float* __restrict__ work, long long n) {
-    const float inv = 1.0f / M[0];
+                                                         const float* __restrict__ M, int np, float* __restrict__ Mout, float* __restrict__ work,
+                                                         long long n) {
+    __shared__ float mred[LS_NT / 64];
+    float mval;
+    if (MP) {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < np; i += LS_NT) {
+            const float v = M[i];
+            m = (v > m || v != v) ? v : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(m, off, 64);
+            m = (o > m || o != o) ? o : m;
+        }
+        if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = mred[0];
+        for (int w = 1; w < LS_NT / 64; ++w) m = (mred[w] > m || mred[w] != mred[w]) ? mred[w] : m;
+        mval = m;
+        if (blockIdx.x == 0 && threadIdx.x == 0) Mout[0] = m;
+        __syncthreads();
+    } else {
+        mval = M[0];
+    }
+    const float inv = 1.0f / mval;
     float s0 = 0.f, s1 = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float2 v = p[i];
@@ -797,20 +849,27 @@ __global__ __launch_bounds__(LS_NT) void k_absl1_partial(const float2* __restric
         work[2 * blockIdx.x + 1] = sh1[0];
     }
 }
+// one wave: lane l sums blocks l, l + 64, ... in double, then a fixed butterfly (one thread walking 2 x 128 dependent loads took 9 us)
 __global__ void k_absl1_final(const float* __restrict__ work, int nb, long long n, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < nb; ++k) {
-            a += (double)work[2 * k];
-            b += (double)work[2 * k + 1];
-        }
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 64) {
+        a += (double)work[2 * k];
+        b += (double)work[2 * k + 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    if (threadIdx.x == 0) {
         out[0] = (float)(a / (double)n);  // the loss
         out[1] = (float)b;                // sum sign * |p|
     }
 }
+// ETA: the explicit tape's next glue step in the same pass (mrx_eta_grad_in): tot = carry (or 0) + dp, d2[b, c] = tot[..., c]; dp itself is not stored
+template <bool ETA>
 __global__ void k_absl1_bwd(const float2* __restrict__ p, const float* __restrict__ target, const float* __restrict__ M,
                             const float* __restrict__ fw, const float* __restrict__ gout, float gscale, float2* __restrict__ dp,
-                            long long n) {
+                            long long n, const float2* __restrict__ carry, float* __restrict__ d2, long long plane) {
     const float m = M[0], inv = 1.0f / m, g = (gout ? gout[0] : 1.0f) * gscale / (float)n;
     const float corr = g * fw[1] * inv * inv;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -820,7 +879,17 @@ __global__ void k_absl1_bwd(const float2* __restrict__ p, const float* __restric
         float c = g * sg * inv;
         if (a == m) c -= corr;
         const float ia = a > 0.f ? 1.0f / a : 0.f;
-        dp[i] = make_float2(c * v.x * ia, c * v.y * ia);
+        float2 r = make_float2(c * v.x * ia, c * v.y * ia);
+        if (ETA) {
+            if (carry) {
+                const float2 cv = carry[i];
+                r = make_float2(r.x + cv.x, r.y + cv.y);       // (= gl + carry: the same two addends as k_eta_grad_in)
+            }
+            const long long b = i / plane, px = i - b * plane;
+            d2[(b * 2) * plane + px] = r.x;
+            d2[(b * 2 + 1) * plane + px] = r.y;
+        }
+        dp[i] = r;
     }
 }
 extern "C" int64_t mrx_absl1_work_floats(void) { return 2 * LS_BLOCKS; }
@@ -829,7 +898,20 @@ extern "C" int mrx_absl1_loss(const float* p, const float* target, const float* 
     MRX_REQUIRE(p && target && maxabs && out2 && work && n >= 1, MRX_EINVAL, "mrx_absl1_loss: bad argument");
     const long long nbl = (n + LS_NT - 1) / LS_NT;
     const int nb = (int)(nbl < LS_BLOCKS ? nbl : LS_BLOCKS);
-    hipLaunchKernelGGL(k_absl1_partial, dim3(nb), dim3(LS_NT), 0, (hipStream_t)stream, (const float2*)p, target, maxabs, work, (long long)n);
+    hipLaunchKernelGGL(k_absl1_partial<false>, dim3(nb), dim3(LS_NT), 0, (hipStream_t)stream, (const float2*)p, target, maxabs, 0, (float*)nullptr, work,
+                       (long long)n);
+    hipLaunchKernelGGL(k_absl1_final, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)work, nb, (long long)n, out2);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// mrx_absl1_loss with the maximum given as `np` per-workgroup partial maxima of |p| (mrx_tl_final_gather_max); the maximum itself is left in maxabs_out
+extern "C" int mrx_absl1_loss_mp(const float* p, const float* target, const float* max_partials, int np, float* maxabs_out, float* out2, float* work,
+                                 int64_t n, void* stream) {
+    MRX_REQUIRE(p && target && max_partials && np >= 1 && maxabs_out && out2 && work && n >= 1, MRX_EINVAL, "mrx_absl1_loss_mp: bad argument");
+    const long long nbl = (n + LS_NT - 1) / LS_NT;
+    const int nb = (int)(nbl < LS_BLOCKS ? nbl : LS_BLOCKS);
+    hipLaunchKernelGGL(k_absl1_partial<true>, dim3(nb), dim3(LS_NT), 0, (hipStream_t)stream, (const float2*)p, target, max_partials, np, maxabs_out, work,
+                       (long long)n);
     hipLaunchKernelGGL(k_absl1_final, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)work, nb, (long long)n, out2);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
@@ -838,8 +920,18 @@ extern "C" int mrx_absl1_loss_bwd(const float* p, const float* target, const flo
                                   float gscale, float* dp, int64_t n, void* stream) {
     MRX_REQUIRE(p && target && maxabs && fwd_out2 && dp && n >= 1, MRX_EINVAL, "mrx_absl1_loss_bwd: bad argument");
     const long long nbl = (n + 255) / 256;
-    hipLaunchKernelGGL(k_absl1_bwd, dim3((unsigned)(nbl < 4096 ? nbl : 4096)), dim3(256), 0, (hipStream_t)stream, (const float2*)p, target,
-                       maxabs, fwd_out2, gout, gscale, (float2*)dp, (long long)n);
+    hipLaunchKernelGGL(k_absl1_bwd<false>, dim3((unsigned)(nbl < 4096 ? nbl : 4096)), dim3(256), 0, (hipStream_t)stream, (const float2*)p, target,
+                       maxabs, fwd_out2, gout, gscale, (float2*)dp, (long long)n, (const float2*)nullptr, (float*)nullptr, 1ll);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// mrx_absl1_loss_bwd + mrx_eta_grad_in in one pass: tot [B,plane,2] = carry (may be NULL) + d(loss)/dp, d2 [B,2,plane] = its two channels as planes
+extern "C" int mrx_absl1_loss_bwd_eta(const float* p, const float* target, const float* maxabs, const float* fwd_out2, const float* gout, float gscale,
+                                      const float* carry, float* tot, float* d2, int B, int64_t plane, void* stream) {
+    MRX_REQUIRE(p && target && maxabs && fwd_out2 && tot && d2 && B >= 1 && plane >= 1, MRX_EINVAL, "mrx_absl1_loss_bwd_eta: bad argument");
+    const long long n = (long long)B * plane, nbl = (n + 255) / 256;
+    hipLaunchKernelGGL(k_absl1_bwd<true>, dim3((unsigned)(nbl < 4096 ? nbl : 4096)), dim3(256), 0, (hipStream_t)stream, (const float2*)p, target,
+                       maxabs, fwd_out2, gout, gscale, (float2*)tot, n, (const float2*)carry, d2, (long long)plane);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

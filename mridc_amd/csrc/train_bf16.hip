@@ -413,9 +413,16 @@ extern "C" int mrx_tl_fold_edges(const float* frame, void* dx, int dx_pairs, int
 
 // ---- eta_new = eta + bf16(sum of the nine shifted tap planes): the final convolution of a RIM step from mrx_tl_layer_fwd's tap products
 // (rim_block.py:239-248; replicate padding = clamped coordinates) ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tl_final_gather(const float* __restrict__ taps, const float* __restrict__ eta, float* __restrict__ out, int H, int W) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
-    if (x >= W || y >= H) return;
+// MX: also the workgroup's maximum of |eta_new| (complex modulus formed as mrx_max_abs forms it) -> maxpart[workgroup]: the training loss's maximum
+// without a pass of its own (mrx_absl1_loss_mp reduces the partials)
+template <bool MX>
+__global__ __launch_bounds__(256) void k_tl_final_gather(const float* __restrict__ taps, const float* __restrict__ eta, float* __restrict__ out, int H, int W,
+                                                         float* __restrict__ maxpart) {
+    __shared__ float red[4];
+    const int x0 = blockIdx.x * 64 + (threadIdx.x & 63), y0 = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    const bool inside = x0 < W && y0 < H;
+    if (!MX && !inside) return;
+    const int x = x0 < W ? x0 : W - 1, y = y0 < H ? y0 : H - 1;       // (MX: every thread reaches the reduction; an outside thread repeats an inside pixel)
     const long long plane = (long long)H * W;
     const float* pb = taps + (long long)b * 18 * plane;
     float s0 = 0.f, s1 = 0.f;
@@ -434,12 +441,38 @@ __global__ __launch_bounds__(256) void k_tl_final_gather(const float* __restrict
     }
     const unsigned r = tl_pk(s0, s1);
     const long long o = ((long long)b * plane + (long long)y * W + x) * 2;
-    out[o] = eta[o] + tl_lo(r);
-    out[o + 1] = eta[o + 1] + tl_hi(r);
+    const float vx = eta[o] + tl_lo(r), vy = eta[o + 1] + tl_hi(r);
+    if (inside) out[o] = vx, out[o + 1] = vy;
+    if (MX) {
+        float m = (float)sqrt((double)mrx_sumsq2(vx, vy));
+        for (int off = 32; off > 0; off >>= 1) {
+            const float t = __shfl_xor(m, off, 64);
+            m = (t > m || t != t) ? t : m;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) m = (red[w] > m || red[w] != red[w]) ? red[w] : m;
+            maxpart[((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m;
+        }
+    }
 }
 extern "C" int mrx_tl_final_gather(const float* taps, const float* eta, float* eta_out, int B, int H, int W, void* stream) {
     MRX_REQUIRE(taps && eta && eta_out && B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_tl_final_gather: bad argument");
-    hipLaunchKernelGGL(k_tl_final_gather, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps, eta, eta_out, H, W);
+    hipLaunchKernelGGL(k_tl_final_gather<false>, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps, eta, eta_out, H, W,
+                       (float*)nullptr);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// ... and the per-workgroup maxima of |eta_out| (complex modulus): max_partials [mrx_tl_final_gather_max_count(B, H, W)]
+extern "C" int64_t mrx_tl_final_gather_max_count(int B, int H, int W) {
+    if (B < 1 || H < 1 || W < 1) return -1;
+    return (int64_t)mrx_cdiv(W, 64) * mrx_cdiv(H, 4) * B;
+}
+extern "C" int mrx_tl_final_gather_max(const float* taps, const float* eta, float* eta_out, float* max_partials, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(taps && eta && eta_out && max_partials && B >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_tl_final_gather_max: bad argument");
+    hipLaunchKernelGGL(k_tl_final_gather<true>, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps, eta, eta_out, H, W,
+                       max_partials);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

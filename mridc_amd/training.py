@@ -212,6 +212,15 @@ class _Llg:
             self.zero_yt = torch.zeros_like(self.yt)
         return ops.llg_hinv(dz, self.zero_yt, self.sense, self.mask, sigma, self.cfg[0], self.cfg[1])
 
+    def adjoint_parts(self, dz, sigma):
+        """The adjoint as (partial planes, their number, 1 / sigma^2) -- W = 372 only (None otherwise): the consumer adds the planes."""
+        if self.op is None:
+            return None
+        if self.zero_op is None:
+            self.zero_op = self.op.linear_part()
+        parts, n = ops.llg372(dz, self.zero_op, sigma, self.cfg[1], parts=True)
+        return parts, n, float(1.0 / (float(sigma) ** 2.0))
+
 
 def _cascade_forward_backward(blk, eta, llg, tgt, wdev, sigma, bf16):
     """Forward of one RIMBlock cascade (training arithmetic: conv + ReLU and the IndRNN cell as separate launches, their outputs saved),
@@ -332,12 +341,18 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
             acts.append((x, a_p, h, hx[li], hm))
             hx[li] = h
             x = h
-        eta_new = ops.tl_final_gather(taps, eta)
-        m = ops.max_abs(eta_new, complex_modulus=True).reshape(1)
+        # the estimate of this step, the maximum of its modulus and its l1 term in three launches (gather + per-workgroup maxima, partial sums, final
+        # sums): five as separate operators (gather, max partial / final, loss partial / final)
+        eta_new = torch.empty_like(eta)
+        nmp = int(L_.mrx_tl_final_gather_max_count(B, H, W))
+        mp = torch.empty(nmp, dtype=torch.float32, device=eta.device)
+        _lib.check(L_.mrx_tl_final_gather_max(_lib.ptr(taps), _lib.ptr(eta), _lib.ptr(eta_new), _lib.ptr(mp), B, H, W, _lib.stream_ptr()),
+                   "mrx_tl_final_gather_max")
+        m = torch.empty(1, dtype=torch.float32, device=eta.device)
         out2 = torch.empty(2, dtype=torch.float32, device=eta.device)
         work = torch.empty(int(L_.mrx_absl1_work_floats()), dtype=torch.float32, device=eta.device)
-        _lib.check(L_.mrx_absl1_loss(_lib.ptr(eta_new), _lib.ptr(tgt), _lib.ptr(m), _lib.ptr(out2), _lib.ptr(work), B * plane, _lib.stream_ptr()),
-                   "mrx_absl1_loss")
+        _lib.check(L_.mrx_absl1_loss_mp(_lib.ptr(eta_new), _lib.ptr(tgt), _lib.ptr(mp), nmp, _lib.ptr(m), _lib.ptr(out2), _lib.ptr(work), B * plane,
+                                        _lib.stream_ptr()), "mrx_absl1_loss_mp")
         saved.append((acts, eta_new, m, out2))
         etas.append(eta_new)
         losses.append(out2)
@@ -363,12 +378,10 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
         _grad_of(p)                                                    # (allocated on the main stream, before any side-stream accumulation)
     carry, dH = None, [None] * nl
     for ti, (acts, eta_t, m, out2) in enumerate(reversed(saved)):
-        gl = torch.empty_like(eta_t)
-        _lib.check(L_.mrx_absl1_loss_bwd(_lib.ptr(eta_t), _lib.ptr(tgt), _lib.ptr(m), _lib.ptr(out2), _lib.ptr(wdev), 1.0, _lib.ptr(gl),
-                                         B * plane, _lib.stream_ptr()), "mrx_absl1_loss_bwd")
         tot = torch.empty_like(eta_t)
         d2 = torch.empty(B, 2, H, W, dtype=torch.float32, device=eta_t.device)
-        _lib.check(L_.mrx_eta_grad_in(_lib.ptr(carry), _lib.ptr(gl), _lib.ptr(tot), _lib.ptr(d2), B, plane, _lib.stream_ptr()), "mrx_eta_grad_in")
+        _lib.check(L_.mrx_absl1_loss_bwd_eta(_lib.ptr(eta_t), _lib.ptr(tgt), _lib.ptr(m), _lib.ptr(out2), _lib.ptr(wdev), 1.0, _lib.ptr(carry), _lib.ptr(tot),
+                                             _lib.ptr(d2), B, plane, _lib.stream_ptr()), "mrx_absl1_loss_bwd_eta")      # (loss backward + mrx_eta_grad_in)
         # final convolution (its result is a bf16 tensor under autocast: both gradient kernels round d2 to bf16 on load)
         h_top = acts[-1][2]
         on_side(lambda h_top=h_top, d2=d2: ops.conv_wgrad_bf16_xcb(h_top, d2, ops.PAD_REPLICATE, out=_grad_of(fw), accumulate=True), h_top, d2)
@@ -387,10 +400,16 @@ def _cascade_forward_backward_tl(blk, eta, llg, tgt, wdev, sigma):
         dg4 = dh                                                       # [B,4,H,W] fp32 (bf16 values): gradient w.r.t. cat(eta, log-likelihood gradient)
         dz = torch.empty_like(eta_t)
         _lib.check(L_.mrx_g4_to_complex(_lib.ptr(dg4), _lib.ptr(dz), B, plane, _lib.stream_ptr()), "mrx_g4_to_complex")
-        t4 = llg.adjoint(dz, sigma)
         carry = torch.empty_like(eta_t)
-        _lib.check(L_.mrx_eta_grad_out(_lib.ptr(tot), _lib.ptr(dg4), _lib.ptr(t4), _lib.ptr(carry), B, plane, _lib.stream_ptr()),
-                   "mrx_eta_grad_out")
+        adj = llg.adjoint_parts(dz, sigma)
+        if adj is not None:                                            # the adjoint still in its coil-group partial planes: summed by the glue kernel itself
+            parts_a, n_a, post = adj
+            _lib.check(L_.mrx_eta_grad_out_parts(_lib.ptr(tot), _lib.ptr(dg4), _lib.ptr(parts_a), n_a, post, _lib.ptr(carry), B, plane, _lib.stream_ptr()),
+                       "mrx_eta_grad_out_parts")
+        else:
+            t4 = llg.adjoint(dz, sigma)
+            _lib.check(L_.mrx_eta_grad_out(_lib.ptr(tot), _lib.ptr(dg4), _lib.ptr(t4), _lib.ptr(carry), B, plane, _lib.stream_ptr()),
+                       "mrx_eta_grad_out")
     if side is not None:
         main.wait_stream(side)                                         # the weight gradients of this cascade are final (its slice may be all-reduced now)
     for li, st in enumerate(blk.layers):                               # the cell kernels' partial sums of the whole cascade -> the gradients

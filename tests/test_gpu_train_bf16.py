@@ -285,3 +285,50 @@ def test_bf16_storage_tape_one_cascade_is_the_kernel_arithmetic(dev, seed, boost
     e = float((got - want).norm() / want.norm())
     print(f"one cascade, seed {seed}: whole gradient vs the kernels' arithmetic {e:.3e}")
     assert e <= 1.5e-2 and abs(float(loss) - float(ref_loss)) <= 2e-4 * abs(float(ref_loss)), (e, float(loss), float(ref_loss))
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 640, 372)], ids=lambda s: "x".join(map(str, s)))
+def test_fused_loss_path_kernels_equal_the_separate_operators(dev, shape):
+    """The tape's glue launches folded together (round 4): gather + per-workgroup maxima (mrx_tl_final_gather_max), the l1 term from those partial maxima
+    (mrx_absl1_loss_mp), loss backward + eta_grad_in (mrx_absl1_loss_bwd_eta), eta_grad_out from the adjoint's partial planes (mrx_eta_grad_out_parts):
+    each against the separate operators it replaces -- bit for bit where the order of additions is kept, to rounding for the loss sums."""
+    from mridc_amd import _lib, ops
+    L = _lib.lib()
+    B, H, W = shape
+    plane = H * W
+    g = torch.Generator().manual_seed(H)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    taps, eta, tgt = r(B, 18, H, W) * 0.1, r(B, H, W, 2), torch.rand(B, H, W, generator=g).to(dev)
+    st = _lib.stream_ptr()
+    # forward
+    want_eta = ops.tl_final_gather(taps, eta)
+    want_m = ops.max_abs(want_eta, complex_modulus=True).reshape(1)
+    want_out2, work = torch.empty(2, device=dev), torch.empty(int(L.mrx_absl1_work_floats()), device=dev)
+    _lib.check(L.mrx_absl1_loss(_lib.ptr(want_eta), _lib.ptr(tgt), _lib.ptr(want_m), _lib.ptr(want_out2), _lib.ptr(work), B * plane, st), "loss")
+    nmp = int(L.mrx_tl_final_gather_max_count(B, H, W))
+    got_eta, mp, got_m, got_out2 = torch.empty_like(eta), torch.empty(nmp, device=dev), torch.empty(1, device=dev), torch.empty(2, device=dev)
+    _lib.check(L.mrx_tl_final_gather_max(_lib.ptr(taps), _lib.ptr(eta), _lib.ptr(got_eta), _lib.ptr(mp), B, H, W, st), "gather_max")
+    _lib.check(L.mrx_absl1_loss_mp(_lib.ptr(got_eta), _lib.ptr(tgt), _lib.ptr(mp), nmp, _lib.ptr(got_m), _lib.ptr(got_out2), _lib.ptr(work), B * plane, st), "loss_mp")
+    assert torch.equal(got_eta, want_eta) and torch.equal(got_m, want_m)
+    assert torch.equal(got_out2, want_out2)                       # (same partial sums, same final order)
+    # backward
+    wdev, carry = torch.full((1,), 0.37, device=dev), r(B, H, W, 2)
+    for cr in (carry, None):
+        gl, want_tot, want_d2 = torch.empty_like(eta), torch.empty_like(eta), torch.empty(B, 2, H, W, device=dev)
+        _lib.check(L.mrx_absl1_loss_bwd(_lib.ptr(want_eta), _lib.ptr(tgt), _lib.ptr(want_m), _lib.ptr(want_out2), _lib.ptr(wdev), 1.0, _lib.ptr(gl), B * plane, st), "bwd")
+        _lib.check(L.mrx_eta_grad_in(_lib.ptr(cr), _lib.ptr(gl), _lib.ptr(want_tot), _lib.ptr(want_d2), B, plane, st), "eta_in")
+        got_tot, got_d2 = torch.empty_like(eta), torch.empty(B, 2, H, W, device=dev)
+        _lib.check(L.mrx_absl1_loss_bwd_eta(_lib.ptr(want_eta), _lib.ptr(tgt), _lib.ptr(want_m), _lib.ptr(want_out2), _lib.ptr(wdev), 1.0, _lib.ptr(cr),
+                                            _lib.ptr(got_tot), _lib.ptr(got_d2), B, plane, st), "bwd_eta")
+        assert torch.equal(got_tot, want_tot) and torch.equal(got_d2, want_d2)
+    # eta_grad_out from partial planes: t4's gradient channels = post * (sum of the planes in order)
+    n_p, post = 4, 0.64
+    parts, g4, tot = r(n_p, B, H, W, 2), r(B, 4, H, W), r(B, H, W, 2)
+    s = parts[0].clone()
+    for k in range(1, n_p):
+        s = s + parts[k]
+    t4 = torch.cat([g4[:, :2], (s * post).permute(0, 3, 1, 2)], 1).contiguous()
+    want, got = torch.empty_like(tot), torch.empty_like(tot)
+    _lib.check(L.mrx_eta_grad_out(_lib.ptr(tot), _lib.ptr(g4), _lib.ptr(t4), _lib.ptr(want), B, plane, st), "eta_out")
+    _lib.check(L.mrx_eta_grad_out_parts(_lib.ptr(tot), _lib.ptr(g4), _lib.ptr(parts), n_p, post, _lib.ptr(got), B, plane, st), "eta_out_parts")
+    assert rel_l2(got, want) <= 1e-7                              # (s * post may contract into the addition: one rounding apart)
