@@ -25,7 +25,7 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "e2evn_uconv_h_14to14": ["k_uconv_h<1, 1, true>"],
     "qcirim_conv3x3_h_128": ["k_uconv_h<4, 2, false>"],
     "train_layer2_fwd": ["k_conv_bf16<3, 2, 64, 2, 0, 2>", "k_conv_bf16<3, 2, 64, 2, 2, 2>"],
-    "train_cell_bwd": ["k_tl_cell_bwd<true, true>"],
+    "train_cell_bwd": ["k_tl_cell_bwd<true, true>", "k_tl_cell_bwd<true, true, true>"],      # (r04 lib 243+: the state as its mask words)
     "train_wgrad_3x3d2": ["k_conv_wgrad_bf16<3, 2, 1>", "k_conv_wgrad_bf16<3, 2, 1, 1>"],
     "train_dgrad_3x3d2": ["k_conv_bf16<3, 2, 64, 2, 1, 1>"],
 }
