@@ -1338,7 +1338,11 @@ def main():
                             note=("`frac` = SURVEY 8d's compulsory bytes of the operation (eta, y, S, mask, result) / time; the launch itself does not read "
                                   "the measured data any more -- its term -A^H M y is a constant plane made once per slice -- and moves "
                                   "`executed_bytes_per_call` (eta, S, the coil-group partial planes): `executed_frac`.  The kernel is bound by its vector "
-                                  "ALU work (two 31-point and six 12-point DFT passes per coil row, built without packed fp32), not by HBM") if bytes_llg_exec else None)
+                                  "ALU work (two 31-point and six 12-point DFT passes per coil row, built without packed fp32), not by HBM."
+                                  + ("  In the timed loop 7 of 8 launches per cascade are the form that first makes eta from the previous step's tap "
+                                     "products (`gather_form`: k_llg372<0, true, true> in the rocprofv3 table, its bytes = this operation's + the gather's); "
+                                     "this record is the plain launch k_llg372<0, true, false> (the first step of every cascade; the transform code is the same)"
+                                     if ms372g else "")) if bytes_llg_exec else None)
         res = dict(metric=f"slices/sec (inference), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}"
                           + ("" if args.rnn == "IndRNN" else f" ({args.rnn})"), value=value, unit="slices/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
