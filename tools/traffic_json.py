@@ -74,10 +74,18 @@ def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None):
         out["_mfma_util"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES and --pmc SQ_BUSY_CU_CYCLES (own passes): mfma_util = MFMA-pipe busy cycles "
                              "/ (4 SIMDs x CU busy cycles), per launch")
         l2 = "conv_layer2_f16" if "conv_layer2_f16" in out["kernels"] else "conv_layer2_sb"     # the default route's kernel
-        out["_regulariser"] = ["conv_layer1", l2, "final_gather"]
-        reg = [out["kernels"][k] for k in ("conv_layer1", l2, "final_gather") if k in out["kernels"]]
-        if len(reg) == 3:
-            out["regulariser_mfma_util"] = sum(r["mfma_busy_cycles"] for r in reg) / (4.0 * sum(r["cu_busy_cycles"] for r in reg))
+        # launches of the regulariser per RIM step: layer 1, layer 2, and (lib 242+) one stand-alone gather per CASCADE of eight steps -- the other seven
+        # ride in the next step's gradient launch; their extra CU-busy cycles there (gather form minus plain form of the gradient kernel) are charged here
+        out["_regulariser"] = ["conv_layer1", l2, "final_gather / 8", "7/8 (llg_gather - llg)"]
+        ks = out["kernels"]
+        if all(k in ks for k in ("conv_layer1", l2, "final_gather")):
+            mfma = ks["conv_layer1"]["mfma_busy_cycles"] + ks[l2]["mfma_busy_cycles"] + ks["final_gather"]["mfma_busy_cycles"] / 8.0
+            cu = ks["conv_layer1"]["cu_busy_cycles"] + ks[l2]["cu_busy_cycles"] + ks["final_gather"]["cu_busy_cycles"] / 8.0
+            if "llg_gather" in ks and "llg" in ks:
+                cu += 7.0 / 8.0 * max(ks["llg_gather"]["cu_busy_cycles"] - ks["llg"]["cu_busy_cycles"], 0.0)
+            else:
+                cu += 7.0 / 8.0 * ks["final_gather"]["cu_busy_cycles"]
+            out["regulariser_mfma_util"] = mfma / (4.0 * cu)
     print(json.dumps(out, indent=1))
 
 
