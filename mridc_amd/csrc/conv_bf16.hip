@@ -20,6 +20,8 @@
 // result is rounded to bf16 and stored as pairs (data gradients), OUT 2: the whole training-mode RIM layer (conv + bias -> bf16 -> ReLU = a,
 // stored as pairs and fed from registers into the IndRNN 1x1 GEMM -> bf16 -> + hh * h_prev -> ReLU = h, optionally the tap products of the
 // final convolution): the rounding points of torch.autocast (conv results are bf16 tensors, hidden states fp32).
+#include <type_traits>
+
 #include "mrx_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -560,8 +562,11 @@ __device__ __forceinline__ void wb_unzip(const unsigned (&d)[8], u32x4& lo, u32x
         hi[i] = (d[2 * i] >> 16) | (d[2 * i + 1] & 0xffff0000u);
     }
 }
+// PF (the training tape's form: dy a pair tensor, x channel-blocked, 3x3): the global loads of tile t + 1 are issued -- all of them, unconditionally, from
+// clamped coordinates -- before the matrix phase of tile t and committed to LDS after it.  The first form walked its items in loops of dependent
+// load -> convert -> LDS-write round trips (five per tile) with nothing else in flight: 25 us per tile, 6 of them matrix work.
 template <int K, int DIL, int DYP = 0, int XCB = 0>
-__global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(WgradBfArgs a) {
+__global__ __launch_bounds__(K == 1 ? 256 : 576, (K == 3 && DYP && XCB) ? 1 : 2) void k_conv_wgrad_bf16(WgradBfArgs a) {
     constexpr int WB_TH = wb_th(K), WB_DYS = wb_dys(K);
     constexpr int PAD = DIL * (K - 1) / 2, PH = WB_TH + 2 * PAD, PW = WB_TW + 2 * PAD, TAPS = K * K;
     constexpr int NT = K == 1 ? 64 * WB_TH : 576, XS = wb_xs(K, DIL);
@@ -581,12 +586,124 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(Wgrad
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int total_tiles = a.ntiles * a.B;
+    constexpr bool PF = (K == 3 && DYP && XCB);
+    // ---- PF: tile prefetch in registers ------------------------------------------------------------------------------------------------------
+    constexpr int PF_XG2 = PW / 2, PF_NX = (8 * PH * PF_XG2 + NT - 1) / NT, PF_ND = (32 * WB_TH * 4 + NT - 1) / NT;
+    float4 pfx[PF ? PF_NX : 1][4];
+    uint4 pfd[PF ? PF_ND : 1][2];
+    unsigned pfm = 0u;          // bits 2 k, 2 k + 1: the two pixels of x item k are inside (zero padding only); bits 8 + 8 k ..: the eight pixels of dy item k are inside
+    static_assert(!PF || (2 * PF_NX <= 8 && 8 + 8 * PF_ND <= 32), "flag word");
+    // (x -- three quarters of the bytes -- is prefetched across the matrix phase; dy is requested at the top of its own tile and committed after x: holding
+    // it too spilled nine registers, and a spill inside the matrix loop waits on vmcnt, i.e. on the prefetch itself)
+    constexpr int PF_NXP = 3;       // x items held across the matrix phase (the third one is requested with dy: all three spilled seven registers)
+    // (item coordinates are recomputed from an opaque copy of the thread index at every use: hoisted out of the tile loop as invariants they were the seven
+    // registers that spilled -- and a scratch access in the loop waits on vmcnt, i.e. on the prefetch)
+    auto pf_tid = [&]() { int v = tid; asm volatile("" : "+v"(v)); return v; };
+    auto pf_issue_x = [&](int t, auto lo, auto hi) {
+        constexpr int K0 = decltype(lo)::value, K1 = decltype(hi)::value;
+        const int tidv = pf_tid();
+        const int b = t / a.ntiles, tt = t - b * a.ntiles;
+        const int ty0 = tt / a.tiles_x, h0 = ty0 * WB_TH, w0 = (tt - ty0 * a.tiles_x) * WB_TW;
+#pragma unroll
+        for (int k = K0; k < K1; ++k) {
+            pfm &= ~(3u << (2 * k));
+            const int i = min(tidv + k * NT, 8 * PH * PF_XG2 - 1);
+            const int g2 = i % PF_XG2, r = (i / PF_XG2) % PH, q = i / (PF_XG2 * PH);
+            int gy = h0 + r - PAD, gx0 = w0 + g2 * 2 - PAD, gx1 = gx0 + 1;
+            const bool rowin = gy >= 0 && gy < a.H;
+            gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+            const bool in0 = a.pad_mode == MRX_PAD_REPLICATE || (rowin && gx0 >= 0 && gx0 < a.W), in1 = a.pad_mode == MRX_PAD_REPLICATE || (rowin && gx1 >= 0 && gx1 < a.W);
+            gx0 = gx0 < 0 ? 0 : (gx0 >= a.W ? a.W - 1 : gx0);
+            gx1 = gx1 < 0 ? 0 : (gx1 >= a.W ? a.W - 1 : gx1);
+            const float* bq = a.x + (((long long)b * 8 + q) * plane + (long long)gy * a.W) * 8;
+            pfx[k][0] = *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8), pfx[k][1] = *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8 + 4);
+            pfx[k][2] = *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8), pfx[k][3] = *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8 + 4);
+            pfm |= (in0 ? 1u : 0u) << (2 * k) | (in1 ? 1u : 0u) << (2 * k + 1);
+        }
+    };
+    auto pf_issue_dy = [&](int t) {
+        const int tidv = pf_tid();
+        const int b = t / a.ntiles, tt = t - b * a.ntiles;
+        const int ty0 = tt / a.tiles_x, h0 = ty0 * WB_TH, w0 = (tt - ty0 * a.tiles_x) * WB_TW;
+        pfm &= 0xffu;
+        const unsigned* dyp = reinterpret_cast<const unsigned*>(a.dy) + (long long)b * 32 * plane;
+#pragma unroll
+        for (int k = 0; k < PF_ND; ++k) {
+            const int i = min(tidv + k * NT, 32 * WB_TH * 4 - 1);
+            const int pg = i & 3, r = (i >> 2) % WB_TH, pp = i / (4 * WB_TH);
+            const int gy = h0 + r, gx = w0 + pg * 8;
+            const int gyc = gy < a.H ? gy : a.H - 1;
+            const unsigned* row = dyp + (long long)pp * plane + (long long)gyc * a.W;
+            if (a.vec && gx + 8 <= a.W) {
+                pfd[k][0] = *reinterpret_cast<const uint4*>(row + gx), pfd[k][1] = *reinterpret_cast<const uint4*>(row + gx + 4);
+                pfm |= (gy < a.H ? 0xffu : 0u) << (8 + 8 * k);
+            } else {               // the ragged right edge (or an unaligned tensor): eight dwords from clamped columns, masked at commit
+                unsigned d[8], mk = 0u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int gxj = gx + j;
+                    d[j] = row[gxj < a.W ? gxj : a.W - 1];
+                    mk |= (gy < a.H && gxj < a.W ? 1u : 0u) << j;
+                }
+                pfd[k][0] = make_uint4(d[0], d[1], d[2], d[3]), pfd[k][1] = make_uint4(d[4], d[5], d[6], d[7]);
+                pfm |= mk << (8 + 8 * k);
+            }
+        }
+    };
+    auto pf_commit_dy = [&]() {
+        const int tidv = pf_tid();
+#pragma unroll
+        for (int k = 0; k < PF_ND; ++k) {
+            const int i = tidv + k * NT;
+            if (i < 32 * WB_TH * 4) {
+                const int pg = i & 3, r = (i >> 2) % WB_TH, pp = i / (4 * WB_TH);
+                const unsigned mk = (pfm >> (8 + 8 * k)) & 0xffu;
+                unsigned d[8] = {pfd[k][0].x, pfd[k][0].y, pfd[k][0].z, pfd[k][0].w, pfd[k][1].x, pfd[k][1].y, pfd[k][1].z, pfd[k][1].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = (mk >> j) & 1u ? d[j] : 0u;
+                u32x4 lo, hi;
+                wb_unzip(d, lo, hi);
+                *reinterpret_cast<u32x4*>(Dy + (2 * pp) * WB_DYS + (r * WB_TW + pg * 8) * 2) = lo;
+                *reinterpret_cast<u32x4*>(Dy + (2 * pp + 1) * WB_DYS + (r * WB_TW + pg * 8) * 2) = hi;
+            }
+        }
+    };
+    auto pf_commit_x = [&](auto lo, auto hi) {
+        constexpr int K0 = decltype(lo)::value, K1 = decltype(hi)::value;
+        const int tidv = pf_tid();
+#pragma unroll
+        for (int k = K0; k < K1; ++k) {
+            const int i = tidv + k * NT;
+            if (i < 8 * PH * PF_XG2) {
+                const int g2 = i % PF_XG2, r = (i / PF_XG2) % PH, q = i / (PF_XG2 * PH);
+                const float m0 = (pfm >> (2 * k)) & 1u ? 1.f : 0.f, m1 = (pfm >> (2 * k + 1)) & 1u ? 1.f : 0.f;
+                const float va[8] = {pfx[k][0].x, pfx[k][0].y, pfx[k][0].z, pfx[k][0].w, pfx[k][1].x, pfx[k][1].y, pfx[k][1].z, pfx[k][1].w};
+                const float vb[8] = {pfx[k][2].x, pfx[k][2].y, pfx[k][2].z, pfx[k][2].w, pfx[k][3].x, pfx[k][3].y, pfx[k][3].z, pfx[k][3].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<unsigned*>(Xs + (8 * q + j) * XS + (r * PW + g2 * 2) * 2) = cb_pk(m0 != 0.f ? va[j] : 0.f, m1 != 0.f ? vb[j] : 0.f);
+            }
+        }
+    };
+    using pf_i0 = std::integral_constant<int, 0>;
+    using pf_ip = std::integral_constant<int, (PF_NXP < PF_NX ? PF_NXP : PF_NX)>;
+    using pf_in = std::integral_constant<int, PF_NX>;
+    if (PF && (int)blockIdx.x < total_tiles) pf_issue_x(blockIdx.x, pf_i0{}, pf_ip{});
     for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
         const int b = t / a.ntiles, tt = t - b * a.ntiles;
         const int ty0 = tt / a.tiles_x, h0 = ty0 * WB_TH, w0 = (tt - ty0 * a.tiles_x) * WB_TW;
         const float* dyb = a.dy + (long long)b * 64 * plane;
         const float* xb = a.x + (long long)b * 64 * plane;
         __syncthreads();   // the previous tile's readers are done
+        if (PF) {
+            pf_issue_x(t, pf_ip{}, pf_in{});
+            pf_issue_dy(t);
+            pf_commit_x(pf_i0{}, pf_ip{});
+            pf_commit_x(pf_ip{}, pf_in{});
+            pf_commit_dy();
+            __syncthreads();
+            if (t + (int)gridDim.x < total_tiles) pf_issue_x(t + gridDim.x, pf_i0{}, pf_ip{});      // in flight under this tile's matrix phase
+        } else {
         // dy tile: item = (co, row, 8-pixel group); pixels outside the image contribute zero
         if (DYP) {        // dy is a pair tensor [B,32,H,W]: item = (channel pair, row, 8-pixel group)
             const unsigned* dyp = reinterpret_cast<const unsigned*>(a.dy) + (long long)b * 32 * plane;
@@ -672,6 +789,7 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(Wgrad
             *reinterpret_cast<uint2*>(Xs + ci * XS + (r * PW + g4 * 4) * 2) = make_uint2(cb_pk(v[0], v[1]), cb_pk(v[2], v[3]));
         }
         __syncthreads();
+        }
         const unsigned char* ap = Dy + l31 * WB_DYS + lhi * 16;
         const unsigned char* bp = Xs + l31 * XS + ((ky * DIL) * PW + kx * DIL + lhi * 8) * 2;
 #pragma unroll
@@ -688,6 +806,7 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, 2) void k_conv_wgrad_bf16(Wgrad
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, b1), acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, b0), acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, b1), acc[1][1], 0, 0, 0);
+                if (PF) __builtin_amdgcn_sched_barrier(0);      // operand reads stay next to their step: hoisted across the unrolled loop they push the prefetch registers out
             }
         }
     }
@@ -809,8 +928,14 @@ __global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgra
                 (u32x4){cb_pk(v[0], v[1]), cb_pk(v[2], v[3]), cb_pk(v[4], v[5]), cb_pk(v[6], v[7])};
         }
         constexpr int XG = PW / 2;
-        if (XCB) {        // x channel-blocked [B][Cin/8][H][W][8]: item = (block, row, pixel pair)
-            for (int i = tid; i < (a.Cin >> 3) * PH * XG; i += NT) {
+        if (XCB) {        // x channel-blocked [B][8][H][W][8] (Cin = 64): item = (block, row, pixel pair).  All the loads of the tile first (clamped
+                          // coordinates, no branch), then the conversions and LDS writes: the item loop with its load -> write round trip per pass took three
+            constexpr int NXI = (8 * PH * XG + NT - 1) / NT;
+            float4 xr[NXI][4];
+            unsigned xin = 0u;
+#pragma unroll
+            for (int k = 0; k < NXI; ++k) {
+                const int i = min(tid + k * NT, 8 * PH * XG - 1);
                 const int g2 = i % XG, r = (i / XG) % PH, q = i / (XG * PH);
                 int gy = h0 + r - PAD, gx0 = w0 + g2 * 2 - PAD, gx1 = gx0 + 1;
                 const bool rowin = gy >= 0 && gy < a.H;
@@ -818,13 +943,23 @@ __global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgra
                 const bool in0 = a.pad_mode == MRX_PAD_REPLICATE || (rowin && gx0 >= 0 && gx0 < a.W), in1 = a.pad_mode == MRX_PAD_REPLICATE || (rowin && gx1 >= 0 && gx1 < a.W);
                 gx0 = gx0 < 0 ? 0 : (gx0 >= a.W ? a.W - 1 : gx0);
                 gx1 = gx1 < 0 ? 0 : (gx1 >= a.W ? a.W - 1 : gx1);
-                const float* bq = a.x + (((long long)b * (a.Cin >> 3) + q) * plane + (long long)gy * a.W) * 8;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 a0 = in0 ? *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8) : z, a1 = in0 ? *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8 + 4) : z;
-                const float4 b0 = in1 ? *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8) : z, b1 = in1 ? *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8 + 4) : z;
-                const float va[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                const float* bq = a.x + (((long long)b * 8 + q) * plane + (long long)gy * a.W) * 8;
+                xr[k][0] = *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8), xr[k][1] = *reinterpret_cast<const float4*>(bq + (long long)gx0 * 8 + 4);
+                xr[k][2] = *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8), xr[k][3] = *reinterpret_cast<const float4*>(bq + (long long)gx1 * 8 + 4);
+                xin |= (in0 ? 1u : 0u) << (2 * k) | (in1 ? 1u : 0u) << (2 * k + 1);
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned*>(Xs + (8 * q + j) * XS + (r * PW + g2 * 2) * 2) = cb_pk(va[j], vb[j]);
+            for (int k = 0; k < NXI; ++k) {
+                const int i = tid + k * NT;
+                if (i < 8 * PH * XG) {
+                    const int g2 = i % XG, r = (i / XG) % PH, q = i / (XG * PH);
+                    const bool in0 = (xin >> (2 * k)) & 1u, in1 = (xin >> (2 * k + 1)) & 1u;
+                    const float va[8] = {xr[k][0].x, xr[k][0].y, xr[k][0].z, xr[k][0].w, xr[k][1].x, xr[k][1].y, xr[k][1].z, xr[k][1].w};
+                    const float vb[8] = {xr[k][2].x, xr[k][2].y, xr[k][2].z, xr[k][2].w, xr[k][3].x, xr[k][3].y, xr[k][3].z, xr[k][3].w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        *reinterpret_cast<unsigned*>(Xs + (8 * q + j) * XS + (r * PW + g2 * 2) * 2) = cb_pk(in0 ? va[j] : 0.f, in1 ? vb[j] : 0.f);
+                }
             }
         } else
         for (int i = tid; i < a.Cin * PH * XG; i += NT) {

@@ -237,12 +237,12 @@ __global__ __launch_bounds__(DB_NT) void k_dc_combine_bwd(const float2* __restri
         }
     }
 }
+// one wave: lane l adds partials l, l + 64, ..., then a fixed butterfly (a single thread walking 1024 dependent loads took 60 us)
 __global__ void k_dcw_final(const double* __restrict__ part, int n, float* __restrict__ dw) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < n; ++i) t += part[i];
-        dw[0] = (float)(-t);
-    }
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) t += part[i];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (threadIdx.x == 0) dw[0] = (float)(-t);
 }
 extern "C" int64_t mrx_dc_combine_bwd_work_doubles(void) { return DCB_BLOCKS; }
 // dpred / deta / dw may be null (not needed); add_dy: base and pred are the same tensor (its gradient = dy - where(mask, dy, 0) * w); dw: one float;

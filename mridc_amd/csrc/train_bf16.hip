@@ -544,6 +544,7 @@ __global__ __launch_bounds__(WI_NT, 2) void k_tl_wgrad_in(const float* __restric
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     for (int i = tid; i < PH * PW; i += WI_NT) Xh[Cin * PH * PW + i] = 0;
     const int total = ntiles * B;
+    const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(dyP) & 15u) == 0);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int b = t / ntiles, tt = t - b * ntiles, ty0 = tt / tiles_x, h0 = ty0 * WI_TH, w0 = (tt - ty0 * tiles_x) * 32;
         __syncthreads();
@@ -554,11 +555,16 @@ __global__ __launch_bounds__(WI_NT, 2) void k_tl_wgrad_in(const float* __restric
             const int gy = h0 + r, gx = w0 + pg * 8;
             const unsigned* src = dyb + (long long)pp * plane + (long long)(gy < H ? gy : H - 1) * W;
             unsigned d[8];
+            if (vec && gy < H && gx + 8 <= W) {       // the whole group inside the image: two 16-byte loads
+                const uint4 q0 = *reinterpret_cast<const uint4*>(src + gx), q1 = *reinterpret_cast<const uint4*>(src + gx + 4);
+                d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int xx = gx + j;
-                const unsigned v = src[xx < W ? xx : W - 1];
-                d[j] = (gy < H && xx < W) ? v : 0u;
+                for (int j = 0; j < 8; ++j) {
+                    const int xx = gx + j;
+                    const unsigned v = src[xx < W ? xx : W - 1];
+                    d[j] = (gy < H && xx < W) ? v : 0u;
+                }
             }
             u32x4 lo, hi;
 #pragma unroll

@@ -80,17 +80,25 @@ __device__ __forceinline__ void uh_split2(float a, float b, unsigned& p1, unsign
 // ---- weight pack -------------------------------------------------------------------------------------------------------------------------
 // word (((S * 5 + m) * NCT + ct) * 2 + term) * 64 + lane, element j: term( w[16 ct + lane % 16][16 S + 8 (g & 1) + j][tap = 2 m + (g >> 1)] * 2^kw ),
 // g = lane / 16; zero for tap 9, channels >= Ctot, output channels >= Cout.  The last word holds kw.
-__global__ void k_uh_wscale(const float* __restrict__ w, long long n, uh_u4* __restrict__ out, long long header) {
-    __shared__ float red[256];
-    float m = 0.f;
-    for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-        __syncthreads();
+// one workgroup of 1024 threads, four independent loads in flight per thread (the first form -- 256 threads, one dependent load chain each -- took
+// 13-47 us per weight tensor; a captured training step packs every weight on every replay)
+__global__ __launch_bounds__(1024) void k_uh_wscale(const float* __restrict__ w, long long n, uh_u4* __restrict__ out, long long header) {
+    __shared__ float red[16];
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    long long i = threadIdx.x;
+    for (; i + 3072 < n; i += 4096) {
+        const float a0 = w[i], a1 = w[i + 1024], a2 = w[i + 2048], a3 = w[i + 3072];
+        m0 = fmaxf(m0, fabsf(a0)), m1 = fmaxf(m1, fabsf(a1)), m2 = fmaxf(m2, fabsf(a2)), m3 = fmaxf(m3, fabsf(a3));
     }
-    if (threadIdx.x == 0) out[header] = uh_u4{(unsigned)uh_scale_exp(red[0]), 0u, 0u, 0u};
+    for (; i < n; i += 1024) m0 = fmaxf(m0, fabsf(w[i]));
+    float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
+        out[header] = uh_u4{(unsigned)uh_scale_exp(m), 0u, 0u, 0u};
+    }
 }
 __global__ void k_uh_pack(const float* __restrict__ w, uh_u4* __restrict__ out, int Cout, int Ctot, int nct, long long words) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,7 +137,7 @@ extern "C" int mrx_unet_conv3x3_pack(const float* w, int Cout, int Ctot, float* 
     MRX_REQUIRE(((uintptr_t)packed & 15u) == 0, MRX_EINVAL, "mrx_unet_conv3x3_pack: packed must be 16-byte aligned");
     const long long words = uh_pack_words(Cout, Ctot);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_uh_wscale, dim3(1), dim3(256), 0, st, w, (long long)Cout * Ctot * 9, reinterpret_cast<uh_u4*>(packed), words - 1);
+    hipLaunchKernelGGL(k_uh_wscale, dim3(1), dim3(1024), 0, st, w, (long long)Cout * Ctot * 9, reinterpret_cast<uh_u4*>(packed), words - 1);
     hipLaunchKernelGGL(k_uh_pack, dim3((unsigned)((words + 254) / 256)), dim3(256), 0, st, w, reinterpret_cast<uh_u4*>(packed), Cout, Ctot,
                        (Cout + 15) / 16, words);
     MRX_LAUNCH_CHECK();

@@ -1,0 +1,10 @@
+#!/bin/bash
+O=gpurun_out/r04ai; mkdir -p $O; R=$GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_train_bf16.py tests/test_gpu_headline.py tests/test_gpu_backward.py -q -x -k "weight_gradient or wgrad or tape or training" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt | cut -c1-250
+for i in 1 2; do timeout 600 python bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs --train --dtype bf16 --steps 4 --warmup 1 > $O/bench_train_$i.json 2> $O/bench_train_$i.err; head -c 200 $O/bench_train_$i.json; echo; done
+cd /tmp && export TMPDIR=/tmp
+export MRIDC_AMD_TL_SIDE_STREAM=0
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o t -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs --train --dtype bf16 --steps 3 --warmup 1 > $R/$O/prof.log 2>&1
+python3 $R/tools/rocpd_summary.py $R/$O/prof/t_results.db > $R/$O/train_serial_kernel_stats.md 2>/dev/null
+rm -rf $R/$O/prof
+head -22 $R/$O/train_serial_kernel_stats.md | cut -c1-150
