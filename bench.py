@@ -594,10 +594,10 @@ def bench_e2evn(args, world, rank, dev, checks=False):
                                        achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=(gbs / PEAK_HBM_GBS) if gbs else None,
                                        frac_meaning="algorithmic bytes of the launch (inputs read once + outputs written once) / 8 TB/s", launches=n, avg_ms=ms,
                                        # counter traffic exists for the 14 -> 14 layer at 4 x 640 x 384 (tools/probe/pmc_r04.py): the shape this record names by default
-                                       traffic=(measured_traffic(1, 15, 640, 372, 64).get("e2evn_uconv_h_14to14") if (int(cin), int(cout), hh_, ww_, B) == (14, 14, 640, 384, 4) else None),
+                                       traffic=(measured_traffic(1, 15, 640, 372, 64).get("e2evn_uconv_h_14to14") if (int(cin), int(cout), hh_, ww_, B) == (14, 14, 640, 380, 4) else None),
                                        traffic_unit="bytes/launch",
                                        mfma_util_pmc=((measured_traffic(1, 15, 640, 372, 64).get("_mfma_util") or {}).get("e2evn_uconv_h_14to14")
-                                                      if (int(cin), int(cout), hh_, ww_, B) == (14, 14, 640, 384, 4) else None),
+                                                      if (int(cin), int(cout), hh_, ww_, B) == (14, 14, 640, 380, 4) else None),
                                        algorithmic_bytes=nbytes, flops_per_launch=flops,
                                        mfma_frac=(3.0 * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if ms else None,
                                        all_unet_conv3x3_ms_per_step=all_ms)

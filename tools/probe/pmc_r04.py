@@ -41,7 +41,7 @@ for _ in range(3):
     ops.llg372_gather(eta, taps, None, op, 1.0, "backward")   # the same gather folded into the next step's gradient launch (the loop's default)
     ops.rim_final(x, wf, None, 3, 1, eta)
 # ---- the other configurations' dominant kernels (their own shapes) ------------------------------------------------------------------------------
-A14 = r(4, 14, 640, 384)
+A14 = r(4, 14, 640, 380)      # (the NormUnet pads 372 to 380 = ((372 - 1) | 11) + 1)
 nA = torch.stack([A14.mean((2, 3)), 1 / torch.sqrt(A14.var((2, 3), unbiased=False) + 1e-5)], -1)
 W14 = r(14, 14, 3, 3) / 11
 X128, W128, B128 = r(1, 128, 256, 256), r(128, 128, 3, 3) / 34, r(128) * 0.1
