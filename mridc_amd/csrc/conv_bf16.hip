@@ -565,6 +565,10 @@ __device__ __forceinline__ void wb_unzip(const unsigned (&d)[8], u32x4& lo, u32x
 // PF (the training tape's form: dy a pair tensor, x channel-blocked, 3x3): the global loads of tile t + 1 are issued -- all of them, unconditionally, from
 // clamped coordinates -- before the matrix phase of tile t and committed to LDS after it.  The first form walked its items in loops of dependent
 // load -> convert -> LDS-write round trips (five per tile) with nothing else in flight: 25 us per tile, 6 of them matrix work.
+// item j of the persistent loops (j = round * grid + workgroup) -> tile: the XCD band order when the grid is a multiple of the eight XCDs
+__device__ __forceinline__ int wb_tile(int j, int total, unsigned grid) {
+    return (grid & 7u) == 0u ? (int)mrx_xcd_band(j, total) : j;
+}
 template <int K, int DIL, int DYP = 0, int XCB = 0>
 __global__ __launch_bounds__(K == 1 ? 256 : 576, (K == 3 && DYP && XCB) ? 1 : 2) void k_conv_wgrad_bf16(WgradBfArgs a) {
     constexpr int WB_TH = wb_th(K), WB_DYS = wb_dys(K);
@@ -599,9 +603,10 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, (K == 3 && DYP && XCB) ? 1 : 2)
     // (item coordinates are recomputed from an opaque copy of the thread index at every use: hoisted out of the tile loop as invariants they were the seven
     // registers that spilled -- and a scratch access in the loop waits on vmcnt, i.e. on the prefetch)
     auto pf_tid = [&]() { int v = tid; asm volatile("" : "+v"(v)); return v; };
-    auto pf_issue_x = [&](int t, auto lo, auto hi) {
+    auto pf_issue_x = [&](int t_, auto lo, auto hi) {
         constexpr int K0 = decltype(lo)::value, K1 = decltype(hi)::value;
         const int tidv = pf_tid();
+        const int t = wb_tile(t_, total_tiles, gridDim.x);
         const int b = t / a.ntiles, tt = t - b * a.ntiles;
         const int ty0 = tt / a.tiles_x, h0 = ty0 * WB_TH, w0 = (tt - ty0 * a.tiles_x) * WB_TW;
 #pragma unroll
@@ -621,8 +626,9 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, (K == 3 && DYP && XCB) ? 1 : 2)
             pfm |= (in0 ? 1u : 0u) << (2 * k) | (in1 ? 1u : 0u) << (2 * k + 1);
         }
     };
-    auto pf_issue_dy = [&](int t) {
+    auto pf_issue_dy = [&](int t_) {
         const int tidv = pf_tid();
+        const int t = wb_tile(t_, total_tiles, gridDim.x);
         const int b = t / a.ntiles, tt = t - b * a.ntiles;
         const int ty0 = tt / a.tiles_x, h0 = ty0 * WB_TH, w0 = (tt - ty0 * a.tiles_x) * WB_TW;
         pfm &= 0xffu;
@@ -688,21 +694,34 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, (K == 3 && DYP && XCB) ? 1 : 2)
     using pf_i0 = std::integral_constant<int, 0>;
     using pf_ip = std::integral_constant<int, (PF_NXP < PF_NX ? PF_NXP : PF_NX)>;
     using pf_in = std::integral_constant<int, PF_NX>;
-    if (PF && (int)blockIdx.x < total_tiles) pf_issue_x(blockIdx.x, pf_i0{}, pf_ip{});
-    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-        const int b = t / a.ntiles, tt = t - b * a.ntiles;
+    // PF: the loop starts one round early -- that round only issues the first tile's x loads -- so that there is ONE issue site, directly in front of the
+    // matrix phase (with a second copy ahead of the loop hipcc merged the two paths into a `s_waitcnt vmcnt(0)` at the head of the matrix block)
+    for (int t = PF ? (int)blockIdx.x - (int)gridDim.x : (int)blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const bool cur = !PF || t >= 0;
+        // every XCD walks one contiguous band of tiles (workgroup j runs on XCD j % 8 and the grid is a multiple of 8): the halo rows two vertically
+        // adjacent tiles share then meet in ONE L2 instead of being fetched by two
+        const int tc = wb_tile(t >= 0 ? t : 0, total_tiles, gridDim.x);
+        const int b = tc / a.ntiles, tt = tc - b * a.ntiles;
         const int ty0 = tt / a.tiles_x, h0 = ty0 * WB_TH, w0 = (tt - ty0 * a.tiles_x) * WB_TW;
         const float* dyb = a.dy + (long long)b * 64 * plane;
         const float* xb = a.x + (long long)b * 64 * plane;
-        __syncthreads();   // the previous tile's readers are done
+        if (cur) __syncthreads();   // the previous tile's readers are done
         if (PF) {
-            pf_issue_x(t, pf_ip{}, pf_in{});
-            pf_issue_dy(t);
-            pf_commit_x(pf_i0{}, pf_ip{});
-            pf_commit_x(pf_ip{}, pf_in{});
-            pf_commit_dy();
-            __syncthreads();
-            if (t + (int)gridDim.x < total_tiles) pf_issue_x(t + gridDim.x, pf_i0{}, pf_ip{});      // in flight under this tile's matrix phase
+            if (cur) {
+                pf_issue_x(t, pf_ip{}, pf_in{});
+                pf_issue_dy(t);
+#if !(defined(MRX_WB_ABL) && (MRX_WB_ABL & 2))
+                pf_commit_x(pf_i0{}, pf_ip{});
+                pf_commit_x(pf_ip{}, pf_in{});
+                pf_commit_dy();
+#endif
+                __syncthreads();
+            }
+            {
+                const int tn = t + (int)gridDim.x;
+                pf_issue_x(tn < total_tiles ? tn : total_tiles - 1, pf_i0{}, pf_ip{});      // in flight under this tile's matrix phase (past the end: a valid tile, unused)
+            }
+            if (!cur) continue;
         } else {
         // dy tile: item = (co, row, 8-pixel group); pixels outside the image contribute zero
         if (DYP) {        // dy is a pair tensor [B,32,H,W]: item = (channel pair, row, 8-pixel group)
@@ -792,6 +811,9 @@ __global__ __launch_bounds__(K == 1 ? 256 : 576, (K == 3 && DYP && XCB) ? 1 : 2)
         }
         const unsigned char* ap = Dy + l31 * WB_DYS + lhi * 16;
         const unsigned char* bp = Xs + l31 * XS + ((ky * DIL) * PW + kx * DIL + lhi * 8) * 2;
+#if defined(MRX_WB_ABL) && (MRX_WB_ABL & 1)
+        if (PF) continue;
+#endif
 #pragma unroll
         for (int r = 0; r < WB_TH; ++r) {
             if (K == 1 && r != wave) continue;   // 1x1: the waves split the rows of the tile
