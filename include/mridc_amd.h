@@ -573,6 +573,10 @@ int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const float* h, const
 int mrx_tl_cell_reduce(const float* part, int B, int H, int W, float* dw_ih, float* db_ih, float* dhh, float* db_conv, void* stream);
 int mrx_tl_dgrad(const void* dy, int dy_pairs, const void* packed, void* dx, int dx_pairs, float* frame, int B, int Cdy, int Cdx, int H, int W, int k,
                  int dil, void* stream);
+/* mrx_tl_dgrad_l2w: mrx_tl_dgrad with every shape on the generic kernel (weights streamed from L2) -- the 64 -> 64 form with the weights resident in
+ * LDS that mrx_tl_dgrad runs is pinned against it, bit for bit */
+int mrx_tl_dgrad_l2w(const void* dy, int dy_pairs, const void* packed, void* dx, int dx_pairs, float* frame, int B, int Cdy, int Cdx, int H, int W, int k,
+                     int dil, void* stream);
 int mrx_tl_fold_edges(const float* frame, void* dx, int dx_pairs, int B, int C, int H, int W, int pad, void* stream);
 int mrx_tl_pairs_to_f32(const void* pairs, float* out, int64_t pair_planes, int64_t plane, void* stream);
 int mrx_tl_f32_to_pairs(const float* x, void* pairs, int64_t pair_planes, int64_t plane, void* stream);

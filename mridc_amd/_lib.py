@@ -81,6 +81,7 @@ _SIGNATURES = {
     "mrx_tl_pack": ([_p, _p, _p, _p], _i),
     "mrx_tl_layer_fwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_tl_dgrad": ([_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_tl_dgrad_l2w": ([_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_tl_fold_edges": ([_p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_tl_cell_part_floats": ([_i, _i, _i], _i64),
     "mrx_tl_cell_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),

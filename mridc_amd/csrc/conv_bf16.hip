@@ -322,6 +322,142 @@ __global__ __launch_bounds__(CB_NT, OUT == 2 ? 2 : 4) void k_conv_bf16(ConvBfArg
     }
 }
 
+__device__ __forceinline__ int wb_tile(int j, int total, unsigned grid);
+// ---- the tape's 3x3 dilation-2 64 -> 64 data gradient with the WEIGHTS IN LDS (mrx_tl_dgrad, pairs -> pairs) ----------------------------------------
+// k_conv_bf16 gives a wave one image row and streams every weight fragment from L2 for a single MFMA: 576 KB of L2 reads per 8 x 32 tile, 536 MB per
+// launch for 8 us of matrix work -- 48 us.  Here the 72 KB of packed weights are copied into LDS once per (persistent) workgroup and every step reads its
+// A fragment from there (the inference kernel's arrangement); the arithmetic -- steps, operands, accumulation order -- is k_conv_bf16<3, 2, 64, 2, 1, 1>'s, so
+// the results are bit-identical to it.  LDS: 73 728 B of weights + 62 208 B of tile = 133 KB, one workgroup of eight waves per CU.
+#define DG_NT 512
+__global__ __launch_bounds__(DG_NT, 1) void k_tl_dgrad64(ConvBfArgs a) {
+    constexpr int K = 3, DIL = 2, CPAD = 64, NCT = 2;
+    constexpr int PAD = DIL * (K - 1) / 2, PH = CB_TH + 2 * PAD, PW = CB_TW + 2 * PAD, NPIX = PH * PW;
+    constexpr int NC8 = CPAD / 8, PS = cb_ps(CPAD), NSTEP = cb_nstep(K, CPAD), NWORDS = NSTEP * NCT * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem_b);                         // [NSTEP][NCT][64 lanes]
+    unsigned char* Xl = smem_b + (size_t)NWORDS * 16;                     // [NPIX][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    for (int i = tid; i < NWORDS; i += DG_NT) Wl[i] = a.packed[i];
+    const long long plane = (long long)a.H * a.W, iplane = (long long)a.Hin * a.Win;
+    const int total = a.ntiles * a.B;
+    constexpr int ITEMS = NPIX * NC8, ITERS = (ITEMS + DG_NT - 1) / DG_NT;
+    // The tile of round r + 1 is requested (all loads of the thread, clamped coordinates, masked at the LDS write) right before the matrix loop of round r and
+    // committed after it.  The loop starts one round early -- that round only issues -- so that there is one issue site (k_conv_wgrad_bf16's lesson: two
+    // copies of it made hipcc wait for the loads at the head of the matrix block).
+    unsigned xr[ITERS][4];
+    unsigned inm = 0u;
+    auto dg_tid = [&]() { int v = tid; asm volatile("" : "+v"(v)); return v; };      // (item coordinates recomputed per use: hoisted as loop invariants they spill)
+    auto issue = [&](int t_) {
+        const int tidv = dg_tid();
+        const int tc = wb_tile(t_, total, gridDim.x);
+        const int b = tc / a.ntiles, tile = tc - b * a.ntiles;
+        const int ty0 = tile / a.tiles_x, h0 = ty0 * CB_TH, w0 = (tile - ty0 * a.tiles_x) * CB_TW;
+        inm = 0u;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = min(tidv + it * DG_NT, ITEMS - 1);
+            const int cg = i / NPIX, e = i - cg * NPIX;
+            const int ty = e / PW, tx = e - ty * PW;
+            int gy = h0 + ty - PAD - a.ext, gx = w0 + tx - PAD - a.ext;
+            const bool inb = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+            gy = gy < 0 ? 0 : (gy >= a.Hin ? a.Hin - 1 : gy);
+            gx = gx < 0 ? 0 : (gx >= a.Win ? a.Win - 1 : gx);
+            const unsigned* src = reinterpret_cast<const unsigned*>(a.x) + ((long long)b * 32 + cg * 4) * iplane + (long long)gy * a.Win + gx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[it][q] = src[(long long)q * iplane];
+            inm |= (inb ? 1u : 0u) << it;
+        }
+    };
+    auto commit = [&]() {
+        const int tidv = dg_tid();
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tidv + it * DG_NT;
+            if (i < ITEMS) {
+                const int cg = i / NPIX, e = i - cg * NPIX;
+                const bool inb = (inm >> it) & 1u;
+                *reinterpret_cast<u32x4*>(Xl + e * PS + cg * 16) = (u32x4){inb ? xr[it][0] : 0u, inb ? xr[it][1] : 0u, inb ? xr[it][2] : 0u, inb ? xr[it][3] : 0u};
+            }
+        }
+    };
+    for (int t = (int)blockIdx.x - (int)gridDim.x; t < total; t += gridDim.x) {
+        const bool cur = t >= 0;
+        const int tc = wb_tile(cur ? t : 0, total, gridDim.x);
+        const int b = tc / a.ntiles, tile = tc - b * a.ntiles;
+        const int ty0 = tile / a.tiles_x, h0 = ty0 * CB_TH, w0 = (tile - ty0 * a.tiles_x) * CB_TW;
+        __syncthreads();                 // the previous tile's readers are done (first round: the weights are in place)
+        if (cur) {
+            commit();
+            __syncthreads();
+        }
+        {
+            const int tn = t + (int)gridDim.x;
+            issue(tn < total ? tn : total - 1);         // (past the end: a valid tile, unused)
+        }
+        if (!cur) continue;
+        f32x16 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        const unsigned char* bx = Xl + (wave * PW + l31) * PS + lhi * 16;
+        const u32x4* wp = Wl + lane;
+#pragma unroll
+        for (int s_ = 0; s_ < NSTEP; ++s_) {
+            const int G0 = 2 * s_, tap = G0 / NC8, cg0 = G0 % NC8;
+            const int off = ((tap / K) * DIL * PW + (tap % K) * DIL) * PS + cg0 * 16;
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + off);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wp[(s_ * NCT + ct) * 64]), bv, acc[ct], 0, 0, 0);
+        }
+        // ---- epilogue (k_conv_bf16's OUT 1 with `interior`): interior pixels -> dx as pairs, the frame -> fp32, edge pixels leave their unrounded value too
+        const int oy = h0 + wave, ox = w0 + l31;
+        if (oy < a.H && ox < a.W) {
+            const long long fbase = (long long)b * 64 * plane + (long long)oy * a.W + ox;
+            const int iy = oy - a.ext, ix = ox - a.ext;
+            const bool to_interior = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            const bool edge = to_interior && (iy == 0 || iy == a.Hin - 1 || ix == 0 || ix == a.Win - 1);
+            if (to_interior) {
+                unsigned* dp = reinterpret_cast<unsigned*>(a.interior) + (long long)b * 32 * iplane + (long long)iy * a.Win + ix;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = 2 * q, co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        const float v0 = acc[ct][r], v1 = acc[ct][r + 1];
+                        dp[(long long)(co >> 1) * iplane] = cb_pk(v0, v1);
+                        if (edge) a.out[fbase + (long long)co * plane] = v0, a.out[fbase + (long long)(co + 1) * plane] = v1;
+                    }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        a.out[fbase + (long long)co * plane] = acc[ct][r];
+                    }
+            }
+        }
+    }
+}
+static int dg64_launch(const ConvBfArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)cb_nstep(3, 64) * 2 * 64 * 16 + (size_t)(CB_TH + 4) * (CB_TW + 4) * cb_ps(64);
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_dgrad64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        attr_done = true;
+    }
+    const long long total = (long long)a.ntiles * a.B;
+    hipLaunchKernelGGL(k_tl_dgrad64, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(DG_NT), lds, st, a);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 // packed[(s * NCT + ct) * 64 + lane][j] = bf16(w_fwd[cout = 32 ct + lane % 32][channel = 8 (G % NC8) + j][tap = G / NC8]),  G = 2 s + lane / 32;
 // transposed (data gradient): w_fwd[co][c][tap] = w[c][co][TAPS - 1 - tap] (flipped taps, in/out channels swapped)
 __global__ void k_conv_bf16_pack(const float* __restrict__ w, u32x4* __restrict__ out, int Cin, int Cout, int K, int CPAD, int NCT,
@@ -508,8 +644,19 @@ extern "C" int mrx_tl_layer_fwd(const float* x, const void* conv_packed, const f
 // Data gradient of a replicate-padded convolution with bf16 results (what autocast's convolution backward returns): dy [B,Cdy,H,W] fp32
 // (dy_pairs 0) or pairs [B,Cdy/2,H,W] (1); the interior goes to dx -- pairs [B,Cdx/2,H,W] (dx_pairs 1) or fp32 [B,Cdx,H,W] holding bf16 values --
 // the frame of width ext = dil (k - 1) / 2 to `frame` [B,Cdx,H + 2 ext,W + 2 ext] fp32 for mrx_tl_fold_edges.  packed: mrx_conv_bf16_pack(transposed).
+static int tl_dgrad_impl(const void* dy, int dy_pairs, const void* packed, void* dx, int dx_pairs, float* frame, int B, int Cdy, int Cdx, int H, int W, int k,
+                         int dil, bool weights_in_lds, void* stream);
 extern "C" int mrx_tl_dgrad(const void* dy, int dy_pairs, const void* packed, void* dx, int dx_pairs, float* frame, int B, int Cdy, int Cdx, int H,
                             int W, int k, int dil, void* stream) {
+    return tl_dgrad_impl(dy, dy_pairs, packed, dx, dx_pairs, frame, B, Cdy, Cdx, H, W, k, dil, true, stream);
+}
+// the same through k_conv_bf16 for every shape (weights streamed from L2): the form mrx_tl_dgrad's 64 -> 64 kernel is pinned against, bit for bit
+extern "C" int mrx_tl_dgrad_l2w(const void* dy, int dy_pairs, const void* packed, void* dx, int dx_pairs, float* frame, int B, int Cdy, int Cdx, int H,
+                                int W, int k, int dil, void* stream) {
+    return tl_dgrad_impl(dy, dy_pairs, packed, dx, dx_pairs, frame, B, Cdy, Cdx, H, W, k, dil, false, stream);
+}
+static int tl_dgrad_impl(const void* dy, int dy_pairs, const void* packed, void* dx, int dx_pairs, float* frame, int B, int Cdy, int Cdx, int H, int W, int k,
+                         int dil, bool weights_in_lds, void* stream) {
     MRX_REQUIRE(dy && packed && dx && frame, MRX_EINVAL, "mrx_tl_dgrad: null pointer");
     MRX_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_tl_dgrad: bad dims");
     const int ext = dil * (k - 1) / 2;
@@ -519,7 +666,8 @@ extern "C" int mrx_tl_dgrad(const void* dy, int dy_pairs, const void* packed, vo
     a.tiles_x = mrx_cdiv(a.W, CB_TW), a.ntiles = a.tiles_x * mrx_cdiv(a.H, CB_TH);
     a.pad_mode = MRX_PAD_ZERO, a.act = MRX_ACT_NONE, a.ext = ext, a.Hin = H, a.Win = W, a.round_out = 1;
     hipStream_t st = (hipStream_t)stream;
-    if (k == 3 && dil == 2 && Cdy == 64 && Cdx == 64 && dy_pairs && dx_pairs) return cb_launch<3, 2, 64, 2, 1, 1>(a, st);
+    if (k == 3 && dil == 2 && Cdy == 64 && Cdx == 64 && dy_pairs && dx_pairs)
+        return weights_in_lds ? dg64_launch(a, st) : cb_launch<3, 2, 64, 2, 1, 1>(a, st);
     if (k == 3 && dil == 1 && Cdy <= 8 && Cdx == 64 && !dy_pairs && dx_pairs) return cb_launch<3, 1, 8, 2, 0, 1>(a, st);
     if (k == 5 && dil == 1 && Cdy == 64 && Cdx <= 32 && dy_pairs && !dx_pairs) return cb_launch<5, 1, 64, 1, 1, 0>(a, st);
     MRX_REQUIRE(false, MRX_EUNSUP, "mrx_tl_dgrad: Cdy=%d Cdx=%d k=%d dilation=%d pairs %d -> %d not instantiated", Cdy, Cdx, k, dil, dy_pairs, dx_pairs);

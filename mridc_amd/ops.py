@@ -1191,7 +1191,7 @@ def tl_cell_reduce(part, B, H, W, dw_ih, db_ih, dhh, db_conv):
                "mrx_tl_cell_reduce")
 
 
-def tl_dgrad(dy, weight, dilation, dx_pairs):
+def tl_dgrad(dy, weight, dilation, dx_pairs, weights_in_lds=True):
     """Data gradient of a replicate-padded convolution with bf16 results (mrx_tl_dgrad + mrx_tl_fold_edges): dy fp32 [B,Cout,H,W] or a pair tensor
     (int32 [B,Cout/2,H,W]); returns a pair tensor (dx_pairs) or fp32 holding bf16 values."""
     pairs_in = dy.dtype == torch.int32
@@ -1206,8 +1206,9 @@ def tl_dgrad(dy, weight, dilation, dx_pairs):
     dx = torch.empty(B, cin_w // 2 if dx_pairs else cin_w, H, W, dtype=torch.int32 if dx_pairs else torch.float32, device=dy.device)
     frame = torch.empty(B, cin_w, H + 2 * pad, W + 2 * pad, dtype=torch.float32, device=dy.device)
     L = _lib.lib()
-    _lib.check(L.mrx_tl_dgrad(_lib.ptr(dy), int(pairs_in), _lib.ptr(packed), _lib.ptr(dx), int(bool(dx_pairs)), _lib.ptr(frame), B, cout_w, cin_w, H, W, k,
-                              int(dilation), _lib.stream_ptr()), "mrx_tl_dgrad")
+    fn = L.mrx_tl_dgrad if weights_in_lds else L.mrx_tl_dgrad_l2w      # (False: every shape on the generic kernel -- the test's reference form)
+    _lib.check(fn(_lib.ptr(dy), int(pairs_in), _lib.ptr(packed), _lib.ptr(dx), int(bool(dx_pairs)), _lib.ptr(frame), B, cout_w, cin_w, H, W, k,
+                  int(dilation), _lib.stream_ptr()), "mrx_tl_dgrad")
     _lib.check(L.mrx_tl_fold_edges(_lib.ptr(frame), _lib.ptr(dx), int(bool(dx_pairs)), B, cin_w, H, W, pad, _lib.stream_ptr()), "mrx_tl_fold_edges")
     return dx
 

@@ -332,3 +332,17 @@ def test_fused_loss_path_kernels_equal_the_separate_operators(dev, shape):
     _lib.check(L.mrx_eta_grad_out(_lib.ptr(tot), _lib.ptr(g4), _lib.ptr(t4), _lib.ptr(want), B, plane, st), "eta_out")
     _lib.check(L.mrx_eta_grad_out_parts(_lib.ptr(tot), _lib.ptr(g4), _lib.ptr(parts), n_p, post, _lib.ptr(got), B, plane, st), "eta_out_parts")
     assert rel_l2(got, want) <= 1e-7                              # (s * post may contract into the addition: one rounding apart)
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 45), (1, 9, 32), (1, 640, 372)], ids=lambda s: "x".join(map(str, s)))
+def test_data_gradient_64_with_weights_in_lds_is_bit_identical(dev, shape):
+    """mrx_tl_dgrad's 3x3 dilation-2 64 -> 64 kernel (weights resident in LDS, persistent workgroups: k_tl_dgrad64) against the generic kernel that
+    streams them from L2 (mrx_tl_dgrad_l2w): the same steps in the same order -- interior (pairs) and the folded edges bit for bit."""
+    from mridc_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(dev)
+    dy = ops.f32_to_pairs(bf(torch.randn(B, 64, H, W, generator=g)).to(dev))
+    got = ops.tl_dgrad(dy, w, 2, True)
+    want = ops.tl_dgrad(dy, w, 2, True, weights_in_lds=False)
+    assert got.dtype == torch.int32 and torch.equal(got, want)

@@ -1,6 +1,6 @@
 #!/bin/bash
 O=gpurun_out/r04ai; mkdir -p $O; R=$GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_train_bf16.py tests/test_gpu_headline.py tests/test_gpu_backward.py -q -x -k "weight_gradient or wgrad or tape or training" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt | cut -c1-250
+timeout 900 python -m pytest tests/test_gpu_train_bf16.py tests/test_gpu_headline.py tests/test_gpu_backward.py -q -x -k "weight_gradient or wgrad or tape or training or data_gradient or dgrad" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt | cut -c1-250
 for i in 1 2; do timeout 600 python bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs --train --dtype bf16 --steps 4 --warmup 1 > $O/bench_train_$i.json 2> $O/bench_train_$i.err; head -c 200 $O/bench_train_$i.json; echo; done
 cd /tmp && export TMPDIR=/tmp
 export MRIDC_AMD_TL_SIDE_STREAM=0
