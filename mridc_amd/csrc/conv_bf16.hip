@@ -328,16 +328,23 @@ __device__ __forceinline__ int wb_tile(int j, int total, unsigned grid);
 // launch for 8 us of matrix work -- 48 us.  Here the 72 KB of packed weights are copied into LDS once per (persistent) workgroup and every step reads its
 // A fragment from there (the inference kernel's arrangement); the arithmetic -- steps, operands, accumulation order -- is k_conv_bf16<3, 2, 64, 2, 1, 1>'s, so
 // the results are bit-identical to it.  LDS: 73 728 B of weights + 62 208 B of tile = 133 KB, one workgroup of eight waves per CU.
+// THIN (the 5x5 64 -> Cout <= 4 gradient of the first layer, k_conv_bf16<5, 1, 64, 1, 1, 0>'s arithmetic): only four of a fragment's 32 rows are real -- the
+// table keeps those ([step][half][4 rows]: 12.8 KB instead of 100 KB, two workgroups per CU), the other lanes feed zeros; results fp32 rounded to bf16 values.
 #define DG_NT 512
-__global__ __launch_bounds__(DG_NT, 1) void k_tl_dgrad64(ConvBfArgs a) {
-    constexpr int K = 3, DIL = 2, CPAD = 64, NCT = 2;
+template <int K, int DIL, bool THIN>
+__global__ __launch_bounds__(DG_NT, THIN ? 2 : 1) void k_tl_dgrad64(ConvBfArgs a) {
+    constexpr int CPAD = 64, NCT = THIN ? 1 : 2;
     constexpr int PAD = DIL * (K - 1) / 2, PH = CB_TH + 2 * PAD, PW = CB_TW + 2 * PAD, NPIX = PH * PW;
-    constexpr int NC8 = CPAD / 8, PS = cb_ps(CPAD), NSTEP = cb_nstep(K, CPAD), NWORDS = NSTEP * NCT * 64;
+    constexpr int NC8 = CPAD / 8, PS = cb_ps(CPAD), NSTEP = cb_nstep(K, CPAD), NWORDS = THIN ? NSTEP * 8 : NSTEP * NCT * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    u32x4* Wl = reinterpret_cast<u32x4*>(smem_b);                         // [NSTEP][NCT][64 lanes]
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem_b);                         // [NSTEP][NCT][64 lanes]   (THIN: [NSTEP][2 halves][4 rows])
     unsigned char* Xl = smem_b + (size_t)NWORDS * 16;                     // [NPIX][PS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    for (int i = tid; i < NWORDS; i += DG_NT) Wl[i] = a.packed[i];
+    if (THIN) {
+        for (int i = tid; i < NWORDS; i += DG_NT) Wl[i] = a.packed[(i >> 3) * 64 + ((i >> 2) & 1) * 32 + (i & 3)];
+    } else {
+        for (int i = tid; i < NWORDS; i += DG_NT) Wl[i] = a.packed[i];
+    }
     const long long plane = (long long)a.H * a.W, iplane = (long long)a.Hin * a.Win;
     const int total = a.ntiles * a.B;
     constexpr int ITEMS = NPIX * NC8, ITERS = (ITEMS + DG_NT - 1) / DG_NT;
@@ -401,18 +408,39 @@ __global__ __launch_bounds__(DG_NT, 1) void k_tl_dgrad64(ConvBfArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
         const unsigned char* bx = Xl + (wave * PW + l31) * PS + lhi * 16;
-        const u32x4* wp = Wl + lane;
+        const u32x4* wp = THIN ? Wl + lhi * 4 + (l31 & 3) : Wl + lane;
 #pragma unroll
         for (int s_ = 0; s_ < NSTEP; ++s_) {
             const int G0 = 2 * s_, tap = G0 / NC8, cg0 = G0 % NC8;
             const int off = ((tap / K) * DIL * PW + (tap % K) * DIL) * PS + cg0 * 16;
             const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bx + off);
+            if (THIN) {
+                u32x4 aw = wp[s_ * 8];
+                if (l31 >= 4) aw = (u32x4){0u, 0u, 0u, 0u};
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw), bv, acc[0], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wp[(s_ * NCT + ct) * 64]), bv, acc[ct], 0, 0, 0);
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wp[(s_ * NCT + ct) * 64]), bv, acc[ct], 0, 0, 0);
+            }
         }
         // ---- epilogue (k_conv_bf16's OUT 1 with `interior`): interior pixels -> dx as pairs, the frame -> fp32, edge pixels leave their unrounded value too
         const int oy = h0 + wave, ox = w0 + l31;
+        if (THIN) {             // rows 0 .. 3 of the lower half-wave's accumulator = the output channels: fp32 holding bf16 values inside, unrounded in the frame
+            if (oy < a.H && ox < a.W && lhi == 0) {
+                const long long fbase = (long long)b * a.Cout * plane + (long long)oy * a.W + ox;
+                const int iy = oy - a.ext, ix = ox - a.ext;
+                const bool to_interior = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+                const bool edge = to_interior && (iy == 0 || iy == a.Hin - 1 || ix == 0 || ix == a.Win - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < a.Cout) {
+                        const float v = acc[0][r];
+                        if (edge || !to_interior) a.out[fbase + (long long)r * plane] = v;
+                        if (to_interior) a.interior[((long long)b * a.Cout + r) * iplane + (long long)iy * a.Win + ix] = cb_round(v);
+                    }
+            }
+        } else
         if (oy < a.H && ox < a.W) {
             const long long fbase = (long long)b * 64 * plane + (long long)oy * a.W + ox;
             const int iy = oy - a.ext, ix = ox - a.ext;
@@ -441,19 +469,21 @@ __global__ __launch_bounds__(DG_NT, 1) void k_tl_dgrad64(ConvBfArgs a) {
         }
     }
 }
+template <int K, int DIL, bool THIN>
 static int dg64_launch(const ConvBfArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)cb_nstep(3, 64) * 2 * 64 * 16 + (size_t)(CB_TH + 4) * (CB_TW + 4) * cb_ps(64);
+    constexpr int PAD = DIL * (K - 1) / 2;
+    constexpr size_t lds = (size_t)cb_nstep(K, 64) * (THIN ? 8 : 2 * 64) * 16 + (size_t)(CB_TH + 2 * PAD) * (CB_TW + 2 * PAD) * cb_ps(64);
     static bool attr_done = false;
     static int n_cu = 0;
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_dgrad64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_tl_dgrad64<K, DIL, THIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         hipDeviceProp_t prop;
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         attr_done = true;
     }
-    const long long total = (long long)a.ntiles * a.B;
-    hipLaunchKernelGGL(k_tl_dgrad64, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(DG_NT), lds, st, a);
+    const long long total = (long long)a.ntiles * a.B, cap = (long long)n_cu * (THIN ? 2 : 1);
+    hipLaunchKernelGGL((k_tl_dgrad64<K, DIL, THIN>), dim3((unsigned)(total < cap ? total : cap)), dim3(DG_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -667,9 +697,10 @@ static int tl_dgrad_impl(const void* dy, int dy_pairs, const void* packed, void*
     a.pad_mode = MRX_PAD_ZERO, a.act = MRX_ACT_NONE, a.ext = ext, a.Hin = H, a.Win = W, a.round_out = 1;
     hipStream_t st = (hipStream_t)stream;
     if (k == 3 && dil == 2 && Cdy == 64 && Cdx == 64 && dy_pairs && dx_pairs)
-        return weights_in_lds ? dg64_launch(a, st) : cb_launch<3, 2, 64, 2, 1, 1>(a, st);
+        return weights_in_lds ? dg64_launch<3, 2, false>(a, st) : cb_launch<3, 2, 64, 2, 1, 1>(a, st);
     if (k == 3 && dil == 1 && Cdy <= 8 && Cdx == 64 && !dy_pairs && dx_pairs) return cb_launch<3, 1, 8, 2, 0, 1>(a, st);
-    if (k == 5 && dil == 1 && Cdy == 64 && Cdx <= 32 && dy_pairs && !dx_pairs) return cb_launch<5, 1, 64, 1, 1, 0>(a, st);
+    if (k == 5 && dil == 1 && Cdy == 64 && Cdx <= 32 && dy_pairs && !dx_pairs)
+        return (weights_in_lds && Cdx <= 4) ? dg64_launch<5, 1, true>(a, st) : cb_launch<5, 1, 64, 1, 1, 0>(a, st);
     MRX_REQUIRE(false, MRX_EUNSUP, "mrx_tl_dgrad: Cdy=%d Cdx=%d k=%d dilation=%d pairs %d -> %d not instantiated", Cdy, Cdx, k, dil, dy_pairs, dx_pairs);
 }
 

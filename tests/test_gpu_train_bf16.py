@@ -346,3 +346,9 @@ def test_data_gradient_64_with_weights_in_lds_is_bit_identical(dev, shape):
     got = ops.tl_dgrad(dy, w, 2, True)
     want = ops.tl_dgrad(dy, w, 2, True, weights_in_lds=False)
     assert got.dtype == torch.int32 and torch.equal(got, want)
+    # the first layer's 5x5 64 -> Cin <= 4 gradient (compact weight table: the four real rows of every fragment)
+    for cin in (4, 2):
+        w5 = (torch.randn(64, cin, 5, 5, generator=g) / 40).to(dev)
+        got5 = ops.tl_dgrad(dy, w5, 1, False)
+        want5 = ops.tl_dgrad(dy, w5, 1, False, weights_in_lds=False)
+        assert got5.dtype == torch.float32 and tuple(got5.shape) == (B, cin, H, W) and torch.equal(got5, want5)
