@@ -27,7 +27,7 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "train_layer2_fwd": ["k_conv_bf16<3, 2, 64, 2, 0, 2>", "k_conv_bf16<3, 2, 64, 2, 2, 2>"],
     "train_cell_bwd": ["k_tl_cell_bwd<true, true>", "k_tl_cell_bwd<true, true, true>"],      # (r04 lib 243+: the state as its mask words)
     "train_wgrad_3x3d2": ["k_conv_wgrad_bf16<3, 2, 1>", "k_conv_wgrad_bf16<3, 2, 1, 1>"],
-    "train_dgrad_3x3d2": ["k_conv_bf16<3, 2, 64, 2, 1, 1>"],
+    "train_dgrad_3x3d2": ["k_conv_bf16<3, 2, 64, 2, 1, 1>", "k_tl_dgrad64<3, 2, false>"],      # (lib 248+: weights resident in LDS)
 }
 AT = {"e2evn_uconv_h_14to14": "4 x 14 -> 14 x 640 x 380", "qcirim_conv3x3_h_128": "1 x 128 -> 128 x 256 x 256, dilation 2",
       "train_layer2_fwd": "1 x 64 x 640 x 372", "train_cell_bwd": "1 x 64 x 640 x 372", "train_wgrad_3x3d2": "1 x 64 x 640 x 372",
