@@ -89,75 +89,92 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
     // hh [64] in the unused tail (bytes 64 .. 79) of the rows of the first tile: the tiles fill 80 KB exactly, two workgroups share a CU's 160 KB
     auto HH = [&](int c) -> float& { return *reinterpret_cast<float*>(smem_c + c * CL_RS + 64); };
     if (HAS_PREV && tid < 64) HH(tid) = a.hh[tid];
+    // W_ih^T (the first GEMM's A fragments, 8 KB) behind the tiles: read from LDS, their waits are lgkmcnt -- as global loads issued after the next tile's
+    // prefetch their vmcnt waits (in order) waited for the prefetch too
+    u32x4* WT = reinterpret_cast<u32x4*>(smem_c + 8 * 2 * CL_TILE);
+    for (int i = tid; i < 512; i += CL_NT) WT[i] = a.wT[i];
     __syncthreads();
     // every tensor is addressed as (wave-uniform base) + (32-bit byte offset of the lane): one address register per access instead of a 64-bit pair
     // (the first form precomputed ~60 pointers and spilled them)
     auto ldu = [](const unsigned* p, unsigned o) { return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(p) + o); };
     const unsigned plane4 = (unsigned)plane * 4u;
     const int total = a.ntiles * a.B;
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    // Chunks 0 and 1 of tile t + grid are requested at the END of tile t's cell stage, before its two GEMM phases: the memory pipe used to sit idle from
+    // there to the next tile's first request (a third of the tile's time).  The loop starts one round early -- that round only issues -- so that this is
+    // the one place they are requested from (two copies make hipcc wait for the loads at the loop head, see k_conv_wgrad_bf16).
+    unsigned d2[2][4];
+    float dHv[2][8], hv[2][8], hpv[2][8];
+    struct TileOff { unsigned pix4, pb, ab, cbb; int b; bool valid; };
+    auto tile_off = [&](int t) {
+        TileOff o;
         const int b = t / a.ntiles, tt = t - b * a.ntiles;
         const int ty0 = tt / a.tiles_x, oy = ty0 * 8 + wave, ox = (tt - ty0 * a.tiles_x) * 32 + l31;
-        const bool valid = oy < a.H && ox < a.W;
-        const unsigned pix4 = (unsigned)((oy < a.H ? oy : a.H - 1) * a.W + (ox < a.W ? ox : a.W - 1)) * 4u;
-        const unsigned pb = (unsigned)b * 32u * plane4 + pix4 + 16u * lhi * plane4;
-        const unsigned ab = (unsigned)b * 32u * plane4 + pix4 + 2u * lhi * plane4;
-        const unsigned cbb = (unsigned)b * 64u * plane4 + pix4 * 8u + 4u * lhi * 8u * plane4;      // channel-blocked: block 4 lhi + ch, 32 bytes per pixel
-        // ---- cell stage: lane = pixel, channels 32 lhi + i; eight channels at a time -----------------------------------------------------------
+        o.b = b, o.valid = oy < a.H && ox < a.W;
+        o.pix4 = (unsigned)((oy < a.H ? oy : a.H - 1) * a.W + (ox < a.W ? ox : a.W - 1)) * 4u;
+        o.pb = (unsigned)b * 32u * plane4 + o.pix4 + 16u * lhi * plane4;
+        o.ab = (unsigned)b * 32u * plane4 + o.pix4 + 2u * lhi * plane4;
+        o.cbb = (unsigned)b * 64u * plane4 + o.pix4 * 8u + 4u * lhi * 8u * plane4;      // channel-blocked: block 4 lhi + ch, 32 bytes per pixel
+        return o;
+    };
+    // eight channels at a time, the NEXT chunk's 28 loads in flight while this one is processed
+    auto request = [&](unsigned pb, unsigned cbb, int ch, int bf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d2[bf][q] = ldu(a.dhP, pb + (unsigned)(4 * ch + q) * plane4);
+        if (!HM) {
+            const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.h) + cbb + (unsigned)ch * 8u * plane4);
+            const float4 u0 = q4[0], u1 = q4[1];
+            hv[bf][0] = u0.x, hv[bf][1] = u0.y, hv[bf][2] = u0.z, hv[bf][3] = u0.w, hv[bf][4] = u1.x, hv[bf][5] = u1.y, hv[bf][6] = u1.z, hv[bf][7] = u1.w;
+        }
+        if (HAS_PREV) {
+            const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.hprev) + cbb + (unsigned)ch * 8u * plane4);
+            const float4 u0 = q4[0], u1 = q4[1];
+            hpv[bf][0] = u0.x, hpv[bf][1] = u0.y, hpv[bf][2] = u0.z, hpv[bf][3] = u0.w, hpv[bf][4] = u1.x, hpv[bf][5] = u1.y, hpv[bf][6] = u1.z, hpv[bf][7] = u1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hpv[bf][j] = 0.f;
+        }
+        if (HAS_DH) {
+            const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dH) + cbb + (unsigned)ch * 8u * plane4);
+            const float4 u0 = q4[0], u1 = q4[1];
+            dHv[bf][0] = u0.x, dHv[bf][1] = u0.y, dHv[bf][2] = u0.z, dHv[bf][3] = u0.w, dHv[bf][4] = u1.x, dHv[bf][5] = u1.y, dHv[bf][6] = u1.z, dHv[bf][7] = u1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dHv[bf][j] = 0.f;
+        }
+    };
+    for (int t = (int)blockIdx.x - (int)gridDim.x; t < total; t += gridDim.x) {
+        const bool cur = t >= 0;
+        const TileOff o_ = tile_off(cur ? t : 0);
+        const int b = o_.b;
+        const bool valid = o_.valid;
+        const unsigned pix4 = o_.pix4, ab = o_.ab;
+        const unsigned pb = o_.pb, cbb = o_.cbb;
         unsigned gbP[16];
-        float t_hh[32];
-        // the pair tensor `a` is needed after the first GEMM only: requested first, it arrives under the cell stage
         unsigned awv[16];
+        float t_hh[32];
+        if (cur) {
+        // ---- cell stage: lane = pixel, channels 32 lhi + i; eight channels at a time -----------------------------------------------------------
+        // the pair tensor `a` is needed after the first GEMM only: requested first, it arrives under the cell stage
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int q = 0; q < 8; ++q) awv[ct * 8 + q] = ldu(a.aP, ab + (unsigned)(ct * 16 + (q & 1) + 4 * (q >> 1)) * plane4);
         uint2 hm = make_uint2(0u, 0u);
         if (HM) hm = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.hmask) + (unsigned)b * 2u * plane4 + pix4 * 2u);
-        // eight channels at a time, the NEXT chunk's 28 loads in flight while this one is processed
-        unsigned d2[2][4];
-        float dHv[2][8], hv[2][8], hpv[2][8];
-        auto request = [&](int ch, int bf) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) d2[bf][q] = ldu(a.dhP, pb + (unsigned)(4 * ch + q) * plane4);
-            if (!HM) {
-                const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.h) + cbb + (unsigned)ch * 8u * plane4);
-                const float4 u0 = q4[0], u1 = q4[1];
-                hv[bf][0] = u0.x, hv[bf][1] = u0.y, hv[bf][2] = u0.z, hv[bf][3] = u0.w, hv[bf][4] = u1.x, hv[bf][5] = u1.y, hv[bf][6] = u1.z, hv[bf][7] = u1.w;
-            } else {
-                // channel 32 lhi + 8 ch + j: word (j >> 2), bit 16 lhi + 4 ch + (j & 3)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) hv[bf][j] = (((j & 4) ? hm.y : hm.x) >> (16 * lhi + 4 * ch + (j & 3))) & 1u ? 1.f : 0.f;
-            }
-            if (HAS_PREV) {
-                const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.hprev) + cbb + (unsigned)ch * 8u * plane4);
-                const float4 u0 = q4[0], u1 = q4[1];
-                hpv[bf][0] = u0.x, hpv[bf][1] = u0.y, hpv[bf][2] = u0.z, hpv[bf][3] = u0.w, hpv[bf][4] = u1.x, hpv[bf][5] = u1.y, hpv[bf][6] = u1.z, hpv[bf][7] = u1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) hpv[bf][j] = 0.f;
-            }
-            if (HAS_DH) {
-                const float4* q4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dH) + cbb + (unsigned)ch * 8u * plane4);
-                const float4 u0 = q4[0], u1 = q4[1];
-                dHv[bf][0] = u0.x, dHv[bf][1] = u0.y, dHv[bf][2] = u0.z, dHv[bf][3] = u0.w, dHv[bf][4] = u1.x, dHv[bf][5] = u1.y, dHv[bf][6] = u1.z, dHv[bf][7] = u1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dHv[bf][j] = 0.f;
-            }
-        };
-        request(0, 0);
+        // (chunks 0 and 1 of this tile were requested by the previous round; chunk c + 2 goes into the buffer chunk c has just left)
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             const int bf = ch & 1;
-            if (ch < 3) request(ch + 1, bf ^ 1);
             float g[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float up = ((j & 1) ? tl_hi(d2[bf][j >> 1]) : tl_lo(d2[bf][j >> 1])) + dHv[bf][j];
-                g[j] = (valid && hv[bf][j] > 0.f) ? up : 0.f;
+                // HM: channel 32 lhi + 8 ch + j = word (j >> 2), bit 16 lhi + 4 ch + (j & 3) of the tile's mask words
+                const bool on = HM ? ((((j & 4) ? hm.y : hm.x) >> (16 * lhi + 4 * ch + (j & 3))) & 1u) != 0u : hv[bf][j] > 0.f;
+                g[j] = (valid && on) ? up : 0.f;
                 t_hh[8 * ch + j] = g[j] * hpv[bf][j];
             }
+            if (ch < 2) request(pb, cbb, ch + 2, bf);
             if (HAS_PREV && valid) {
                 float4* q4 = reinterpret_cast<float4*>(reinterpret_cast<char*>(a.dhp) + cbb + (unsigned)ch * 8u * plane4);
                 const int c0 = 32 * lhi + 8 * ch;
@@ -168,6 +185,14 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
             for (int q = 0; q < 4; ++q) gbP[4 * ch + q] = tl_pk(g[2 * q], g[2 * q + 1]);
             __builtin_amdgcn_sched_barrier(0);      // keeps the order above: two chunks of loads in flight, not four (hoisting everything spills)
         }
+        }       // cur
+        {       // the one place the first two chunks of a tile are requested: the NEXT tile's, ahead of this tile's GEMM phases
+            const int tn = t + (int)gridDim.x;
+            const TileOff on_ = tile_off(tn < total ? tn : total - 1);
+            request(on_.pb, on_.cbb, 0, 0);
+            request(on_.pb, on_.cbb, 1, 1);
+        }
+        if (!cur) continue;
         if (HAS_PREV) s_hh += tl_reduce_scatter32(t_hh, lane);
         {
             float t[32];
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-        const u32x4* wp = a.wT + lane;
+        const u32x4* wp = WT + lane;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const u32x4 bw = {gbP[4 * s], gbP[4 * s + 1], gbP[4 * s + 2], gbP[4 * s + 3]};
@@ -309,7 +334,7 @@ extern "C" int mrx_tl_cell_bwd(const void* dh_above, const float* dH, const floa
     a.wT = (const u32x4*)tl_packed + 768, a.hh = hh, a.dhp = dh_prev, a.gaP = (unsigned*)ga_pairs, a.part = part;
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, 32), a.ntiles = a.tiles_x * mrx_cdiv(H, 8), a.first = first;
     MRX_REQUIRE(dh_above, MRX_EINVAL, "mrx_tl_cell_bwd: the gradient from the layer above is required");
-    constexpr int lds = 8 * 2 * CL_TILE;
+    constexpr int lds = 8 * 2 * CL_TILE + 512 * 16;
     const dim3 grid(tl_cell_nwg((long long)B * a.ntiles));
     hipStream_t st = (hipStream_t)stream;
     const int which = (dH ? 4 : 0) | (hprev ? 2 : 0) | (hmask ? 1 : 0);
