@@ -308,7 +308,16 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
     float* tabl = reinterpret_cast<float*>(smem_s2 + OFF_TAB);      // hh, b_conv, b_ih in register order [half][R] (a lane's 32 values contiguous: 16-byte LDS reads)
     u32x4* Wc = reinterpret_cast<u32x4*>(smem_s2 + OFF_W);             // [2][S2_WCH]
     u32x4* Xp = reinterpret_cast<u32x4*>(smem_s2 + OFF_X);             // [2][NT terms][S2_NPIX]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    // The wave index lives in an SGPR; the lane index is re-derived (mbcnt, behind an opaque asm so that it is not hoisted) wherever it is needed: kept live
+    // across the tile loop, the thread index and the per-lane offsets built from it were what the register allocator spilled (13 dwords at the 256-register
+    // cap), and every reload in the tail drained the stores / prefetches in flight -- vmcnt retires in order and a scratch access is a VMEM access.
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    auto lane_now = [&]() {
+        int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    const int tid = wave * 64 + lane_now(), lane = tid & 63;
     const long long plane = (long long)a.H * a.W;
     const int total = a.ntiles * a.B;
 
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         st_xb = a.x + (long long)b * S2_F * plane;
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
-            int p = tid + v * NTHR;
+            int p = (wave * 64 + lane_now()) + v * NTHR;
             p = p < S2_NPIX ? p : S2_NPIX - 1;
             const int ty = p / S2_PW, tx = p - ty * S2_PW;
             int gy = h0 + ty - S2_PAD, gx = w0 + tx - S2_PAD;            // replicate border = clamp (conv_layers.py:72-76)
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
             }
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
-            const int i = tid + v * NTHR;
+            const int i = (wave * 64 + lane_now()) + v * NTHR;
             wr[v] = a.packed[(long long)st_q * WCH + (i < WCH ? i : WCH - 1)];
         }
         if (++st_q == S2_NCH) {
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         if (!pending) return;
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
-            const int p = tid + v * NTHR;
+            const int p = (wave * 64 + lane_now()) + v * NTHR;
             unsigned p1[4], p2[4], p3[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         }
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
-            const int i = tid + v * NTHR;
+            const int i = (wave * 64 + lane_now()) + v * NTHR;
             if constexpr ((ABL & 4) != 0) asm volatile("" ::"v"(wr[v]));
             else if (i < WCH) Wc[buf * WCH + i] = wr[v];
         }
@@ -440,6 +449,8 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
 
     float vmax = 0.f;                                // TAIL = false: maximum |output| of this lane (a.xmax_out)
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        // (lane-derived values per tile, see lane_now)
+        const int lane = lane_now(), l31 = lane & 31, lhi = lane >> 5;
         const int tt = (int)mrx_xcd_band(t, total);
         const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
         const int h0 = ty0 * TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
@@ -760,7 +771,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
             float* red = reinterpret_cast<float*>(smem_s2 + OFF_X);
             if (lane == 0) red[wave] = vmax;
             __syncthreads();
-            if (tid == 0) {
+            if (wave == 0 && lane_now() == 0) {
                 for (int w = 1; w < NTHR / 64; ++w) vmax = fmaxf(vmax, red[w]);
                 if (__float_as_uint(vmax) > __hip_atomic_load(a.xmax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.xmax_out, __float_as_uint(vmax));
             }
