@@ -229,7 +229,11 @@ int mrx_l1sb_pack(const float* w_conv, const float* w_ih, float* packed, int Cin
 // stage (contraction over the pixel's channels only), the weights at pack time; the accumulators are scaled back exactly before the biases.
 // CB8: h_prev / h_new channel-blocked, [b][c / 8][y][x][c % 8] -- registers 16 ct + 4 j .. + 3 of a lane are four consecutive channels of block
 // 4 ct + j: 8 + 8 16-byte state accesses per unit instead of 32 + 32 4-byte ones, every unit a 1 KB-aligned 1 KB block per channel block
-template <bool F16, bool CB8 = false>
+// MORE: more than four partial planes of the log-likelihood gradient may arrive (a run-time loop over the rest; the headline has four: three coil groups
+// and the constant data term).  Without it the patch code is straight-line -- with it `raw` ended up in scratch memory, written behind `s_waitcnt vmcnt(0)`.
+// LLGT: 1 = the input is (eta, partial planes) -- known at compile time (the run-time test of a.eta2 inside the unrolled slot loops left part of `raw`
+// in scratch memory); -1 = decided at run time.
+template <bool F16, bool CB8 = false, bool MORE = true, int LLGT = -1>
 __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
     constexpr int NT = F16 ? 2 : 3, WCONV = F16 ? SBH_WCONV : SB_WCONV, WIH = F16 ? SBH_WIH : SB_WIH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
             gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
             gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
             off[q] = (unsigned)(gy * a.W + gx);
-            if (a.eta2) {                // the first four partial planes in flight together
+            if (LLGT > 0 || (LLGT < 0 && a.eta2)) {                // the first four partial planes in flight together
                 const float2* e2 = a.eta2 + (long long)b * plane;
                 const float2* pp = a.part + (long long)b * plane;
                 const float2 e = e2[off[q]];
@@ -303,20 +307,36 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
     // finish the patch, split it into its bf16 / fp16 terms and write the wave's LDS planes; returns 2^-k of the unit's scale (F16)
     auto commit_patch = [&](int b, const float (&raw)[SB_PSLOT][10], const unsigned (&off)[SB_PSLOT]) -> float {
         float cc[SB_PSLOT][4];
+        // the last step of log_likelihood_gradient (rim_utils.py:61-67), same order of additions as k_rim_layer.  The run-time loop over the planes past the
+        // fourth stands OUTSIDE the unrolled slot loop: inside it, it kept the slot loop from unrolling, `raw` was indexed dynamically and lived in scratch
+        // memory -- the patch loads were written there one by one behind `s_waitcnt vmcnt(0)`
+        float sxq[SB_PSLOT], syq[SB_PSLOT];
+        const bool llg = LLGT > 0 || (LLGT < 0 && a.eta2);
+        if (llg) {
 #pragma unroll
-        for (int q = 0; q < SB_PSLOT; ++q) {
-            float c0, c1, c2, c3;
-            if (a.eta2) {   // the last step of log_likelihood_gradient (rim_utils.py:61-67), same order of additions as k_rim_layer
+            for (int q = 0; q < SB_PSLOT; ++q) {
                 float sx = raw[q][2], sy = raw[q][3];
 #pragma unroll
                 for (int k = 1; k < 4; ++k)
                     if (k < a.nparts) sx += raw[q][2 + 2 * k], sy += raw[q][3 + 2 * k];
-                for (int k = 4; k < a.nparts; ++k) {
-                    const float2 v = a.part[(long long)k * a.part_stride + (long long)b * plane + off[q]];
-                    sx += v.x;
-                    sy += v.y;
+                sxq[q] = sx, syq[q] = sy;
+            }
+            if constexpr (MORE)
+            for (int k = 4; k < a.nparts; ++k) {
+                const float2* pk = a.part + (long long)k * a.part_stride + (long long)b * plane;
+#pragma unroll
+                for (int q = 0; q < SB_PSLOT; ++q) {
+                    const float2 v = pk[off[q]];
+                    sxq[q] += v.x;
+                    syq[q] += v.y;
                 }
-                c0 = raw[q][0], c1 = raw[q][1], c2 = sx * a.post, c3 = sy * a.post;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < SB_PSLOT; ++q) {
+            float c0, c1, c2, c3;
+            if (llg) {
+                c0 = raw[q][0], c1 = raw[q][1], c2 = sxq[q] * a.post, c3 = syq[q] * a.post;
             } else {
                 c0 = raw[q][0];
                 c1 = a.Cin > 1 ? raw[q][1] : 0.f;
@@ -552,20 +572,34 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
     }
 }
 
+// One launch of the (F16, CB8) kernel in the form the arguments allow: the input form known at compile time keeps the patch in registers
+// (LLGT 1 with at most four partial planes: the headline loop; LLGT 0: a four-channel x); anything else takes the run-time form.
+template <bool F16, bool CB8>
+static void l1sb_launch_form(const MrxL1sbArgs& a, int grid, size_t lds, hipStream_t st) {
+    static bool attr_done = false;   // once: keeps launches legal under hipGraph capture
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_rim_layer1_sb<F16, CB8, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_rim_layer1_sb<F16, CB8, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_rim_layer1_sb<F16, CB8, true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (a.eta2 && a.nparts <= 4)
+        hipLaunchKernelGGL((k_rim_layer1_sb<F16, CB8, false, 1>), dim3(grid), dim3(SB_NT), lds, st, a);
+    else if (!a.eta2)
+        hipLaunchKernelGGL((k_rim_layer1_sb<F16, CB8, false, 0>), dim3(grid), dim3(SB_NT), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_rim_layer1_sb<F16, CB8, true, -1>), dim3(grid), dim3(SB_NT), lds, st, a);
+}
+
 int mrx_l1sb_launch(const MrxL1sbArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(SB_WCONV + SB_WIH) * 16 + 256 * sizeof(float) + (size_t)(SB_NT / 64) * 3 * SB_PSTR * 8;   // (the fp16 form needs less)
-    static bool attr_done = false;   // once: keeps launches legal under hipGraph capture
     static int ncu = 0;
-    if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer1_sb<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer1_sb<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer1_sb<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!ncu) {
         int dev = 0;
         hipDeviceProp_t prop;
         MRX_HIP(hipGetDevice(&dev));
         MRX_HIP(hipGetDeviceProperties(&prop, dev));
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        attr_done = true;
     }
     const long long total = (long long)a.ntiles * a.B;
     const int grid = (int)(total < ncu ? total : ncu);     // one persistent workgroup per CU (a multiple of 8: the XCD band map keeps its meaning)
@@ -574,11 +608,11 @@ int mrx_l1sb_launch(const MrxL1sbArgs& a, hipStream_t st) {
             mrx_set_error("mrx_rim_layer1_cb8: the channel-blocked state layout exists for the two-term fp16 kernel only (MRIDC_AMD_ARITH=f16x2)");
             return MRX_EUNSUP;
         }
-        hipLaunchKernelGGL((k_rim_layer1_sb<true, true>), dim3(grid), dim3(SB_NT), lds, st, a);
+        l1sb_launch_form<true, true>(a, grid, lds, st);
     } else if (a.f16)
-        hipLaunchKernelGGL(k_rim_layer1_sb<true>, dim3(grid), dim3(SB_NT), lds, st, a);
+        l1sb_launch_form<true, false>(a, grid, lds, st);
     else
-        hipLaunchKernelGGL(k_rim_layer1_sb<false>, dim3(grid), dim3(SB_NT), lds, st, a);
+        l1sb_launch_form<false, false>(a, grid, lds, st);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
