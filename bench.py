@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=0, help="slices per stream per step (0 = the measured best per model: 1, E2EVN 4)")
+    ap.add_argument("--batch", type=int, default=0, help="slices per stream per step (0 = the measured best per model: 1, E2EVN 4, CIRIM inference 8)")
     ap.add_argument("--streams", type=int, default=0,
                     help="independent slice batches reconstructed concurrently per GPU, one HIP stream + one captured hipGraph each "
                          "(slices are independent: two in flight fill each other's launch tails and stalls; 1 = single stream; "
@@ -84,7 +84,10 @@ def parse():
     if args.streams <= 0:
         args.streams = 2
     if args.batch <= 0:
-        args.batch = 4 if (args.model == "e2evn" and not args.train) else 1
+        # CIRIM inference: 480 tiles of 16 x 32 pixels per slice on 256 CUs -- 8 slices per launch are exactly 15 rounds of the persistent layer kernels
+        # (one slice: two rounds, the second 7/8 full); measured 1 x 2 / 2 x 2 / 4 x 2 / 8 x 2 / 8 x 1 / 16 x 1 (batch x streams), lib 252:
+        # 140.7 / 141.3 / 142.9 / 144.1 / 134.7 / 134.7 slices/s (2-D masks: 101.1 / 104.6 / 100.7 at 1 / 4 / 8 x 2 -- left at 1, the shape of its counter passes)
+        args.batch = 4 if (args.model == "e2evn" and not args.train) else 8 if (args.model == "cirim" and not args.train and args.rnn == "IndRNN" and args.mask == "1d") else 1
     return args
 
 
@@ -882,7 +885,7 @@ def measured_traffic(B, C, H, W, F):
     library version (mrx_version: bumped with every kernel change) they were measured with -- otherwise `traffic` is null."""
     import glob
     from mridc_amd import _lib
-    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic*.json")))      # (rNN_traffic.json: one slice per launch; rNN_traffic_b8.json: the default line's 8)
     for path in reversed(paths):
         try:
             with open(path) as f:

@@ -12,6 +12,9 @@ prof() {   # tag, bench flags
   head -12 $R/$O/${1}_kernel_stats.md | cut -c1-140
 }
 prof headline "--steps 10 --warmup 2"
+# the default line keeps two batches of 8 slices in flight: their persistent kernels queue behind one another, so a launch's duration in the trace above
+# includes its wait for CUs; the one-stream trace is the one whose averages the bench's HIP-event figures (an instrumented one-stream pass) must agree with
+prof headline_one_stream "--steps 10 --warmup 2 --streams 1"
 prof e2evn "--model e2evn --steps 4 --warmup 1 --graph 0 --streams 1"
 prof qcirim "--model qcirim --steps 6 --warmup 1 --graph 0 --streams 1"
 prof train_bf16 "--train --dtype bf16 --steps 3 --warmup 1"
@@ -22,6 +25,10 @@ done
 cd $R
 V=$(python -c "from mridc_amd import _lib; print(_lib.lib().mrx_version())")
 python tools/traffic_json.py $O/pmc_FETCH_SIZE/*counter_collection.csv $O/pmc_WRITE_SIZE/*counter_collection.csv $V $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES/*counter_collection.csv $O/pmc_SQ_BUSY_CU_CYCLES/*counter_collection.csv > $O/traffic.json 2> $O/traffic_json.err
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/$O/pmc8_$c -o p --output-format csv -- python3 $R/tools/probe/pmc_r04_b8.py > $R/$O/pmc8_$c.log 2>&1 )
+done
+python tools/traffic_json.py $O/pmc8_FETCH_SIZE/*counter_collection.csv $O/pmc8_WRITE_SIZE/*counter_collection.csv $V $O/pmc8_SQ_VALU_MFMA_BUSY_CYCLES/*counter_collection.csv $O/pmc8_SQ_BUSY_CU_CYCLES/*counter_collection.csv 8 tools/probe/pmc_r04_b8.py > $O/traffic_b8.json 2>> $O/traffic_json.err
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 python - "$O" <<'PY'
 import json, sys

@@ -3,7 +3,8 @@
 in KiB).  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64
 bytes, so it is doubled; WRITE_SIZE is used as is.
 
-    python tools/traffic_json.py FETCH.csv WRITE.csv LIB_VERSION [MFMA_BUSY.csv CU_BUSY.csv] > profiles/r02_traffic.json
+    python tools/traffic_json.py FETCH.csv WRITE.csv LIB_VERSION [MFMA_BUSY.csv CU_BUSY.csv [BATCH PROBE]] > profiles/r02_traffic.json
+(BATCH: slices per launch of the probe -- pmc_r04_b8.py runs the headline loop's kernels at the bench's default 8 -> profiles/r04_traffic_b8.json)
 """
 import collections
 import csv
@@ -43,20 +44,20 @@ def per_kernel(path):
     return {k: acc[k] / len(cnt[k]) for k in acc}
 
 
-def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None):
+def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None, batch=1, probe="tools/probe/pmc_r04.py"):
     """mfma_csv / cubusy_csv (optional): passes with SQ_VALU_MFMA_BUSY_CYCLES (cycles the matrix pipe of a SIMD is busy, summed over the
     SIMDs: 32 per v_mfma_f32_32x32x16_bf16) and SQ_BUSY_CU_CYCLES (cycles a CU has work, summed over the CUs) -> per operator
     mfma_util = MFMA busy / (4 SIMDs x CU busy): matrix-pipe utilisation by the hardware counters, at whatever clock the chip sustained."""
     fe, wr = per_kernel(fetch_csv), per_kernel(write_csv)
     mf = per_kernel(mfma_csv) if mfma_csv else {}
     cb = per_kernel(cubusy_csv) if cubusy_csv else {}
-    out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass) -- python3 tools/probe/pmc_r04.py; "
+    out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass) -- python3 " + probe + "; "
                       "per-dispatch means in KiB",
            "_correction": "gfx950: FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B -> doubled; WRITE_SIZE as is.  The guide calibrated "
                           "that factor on 16-byte-per-lane streams; the round-4 training kernels load 4 bytes per lane from 64 planes -- for k_tl_cell_bwd, whose "
                           "244 MB of reads have no reuse, the UNDOUBLED counter (234 MB) is the one that matches, so `hbm_bytes_uncorrected` (FETCH + WRITE) is kept "
                           "beside the prescribed figure for every kernel",
-           "lib_version": int(lib_version), "shape": dict(batch=1, coils=15, height=640, width=372, features=64), "kernels": {}}
+           "lib_version": int(lib_version), "shape": dict(batch=int(batch), coils=15, height=640, width=372, features=64), "kernels": {}}
     for key, pats in KEYS.items():
         names = [k for k in set(fe) | set(wr) if any(p in k for p in pats)]
         if not names:
@@ -65,7 +66,7 @@ def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None):
         w = sum(wr.get(k, 0.0) for k in names)
         out["kernels"][key] = dict(kernel=" + ".join(sorted(n.split("(")[0][:70] for n in names)), fetch_kib=f, write_kib=w,
                                    hbm_bytes_per_launch=(2.0 * f + w) * 1024.0, hbm_bytes_uncorrected=(f + w) * 1024.0)
-        if key in AT:
+        if key in AT and int(batch) == 1:
             out["kernels"][key]["at"] = AT[key]
         if mf and cb:
             m, c = sum(mf.get(k, 0.0) for k in names), sum(cb.get(k, 0.0) for k in names)
@@ -90,4 +91,4 @@ def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:8])
