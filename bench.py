@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=0, help="slices per stream per step (0 = the measured best per model: 1, E2EVN 4, CIRIM inference 8)")
+    ap.add_argument("--batch", type=int, default=0, help="slices per stream per step (0 = the measured best per model: 1, E2EVN and CIRIM inference 8)")
     ap.add_argument("--streams", type=int, default=0,
                     help="independent slice batches reconstructed concurrently per GPU, one HIP stream + one captured hipGraph each "
                          "(slices are independent: two in flight fill each other's launch tails and stalls; 1 = single stream; "
@@ -87,7 +87,8 @@ def parse():
         # CIRIM inference: 480 tiles of 16 x 32 pixels per slice on 256 CUs -- 8 slices per launch are exactly 15 rounds of the persistent layer kernels
         # (one slice: two rounds, the second 7/8 full); measured 1 x 2 / 2 x 2 / 4 x 2 / 8 x 2 / 8 x 1 / 16 x 1 (batch x streams), lib 252:
         # 140.7 / 141.3 / 142.9 / 144.1 / 134.7 / 134.7 slices/s (2-D masks: 101.1 / 104.6 / 100.7 at 1 / 4 / 8 x 2 -- left at 1, the shape of its counter passes)
-        args.batch = 4 if (args.model == "e2evn" and not args.train) else 8 if (args.model == "cirim" and not args.train and args.rnn == "IndRNN" and args.mask == "1d") else 1
+        # E2EVN (batch x streams, lib 252): 4 x 2 1023, 6 x 2 1087, 8 x 2 1103-1109, 10 x 2 1109, 12 x 2 1108, 16 x 2 1081, 8 x 3 1101, 8 x 1 925, 16 x 1 985
+        args.batch = 8 if (args.model == "e2evn" and not args.train) else 8 if (args.model == "cirim" and not args.train and args.rnn == "IndRNN" and args.mask == "1d") else 1
     return args
 
 
@@ -596,11 +597,13 @@ def bench_e2evn(args, world, rank, dev, checks=False):
                                                               "layer's normalisation + LeakyReLU and the operand split in the tile loader)",
                                        achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=(gbs / PEAK_HBM_GBS) if gbs else None,
                                        frac_meaning="algorithmic bytes of the launch (inputs read once + outputs written once) / 8 TB/s", launches=n, avg_ms=ms,
-                                       # counter traffic exists for the 14 -> 14 layer at 4 x 640 x 384 (tools/probe/pmc_r04.py): the shape this record names by default
-                                       traffic=(measured_traffic(1, 15, 640, 372, 64).get("e2evn_uconv_h_14to14") if (int(cin), int(cout), hh_, ww_, B) == (14, 14, 640, 380, 4) else None),
+                                       # counter traffic exists for the 14 -> 14 layer at 4 x 640 x 380 (tools/probe/pmc_r04.py) and at the default line's
+                                       # 8 x 640 x 380 (pmc_r04_b8.py): the shape this record names by default
+                                       traffic=(measured_traffic(8 if B == 8 else 1, 15, 640, 372, 64).get("e2evn_uconv_h_14to14")
+                                                if (int(cin), int(cout), hh_, ww_) == (14, 14, 640, 380) and B in (4, 8) else None),
                                        traffic_unit="bytes/launch",
-                                       mfma_util_pmc=((measured_traffic(1, 15, 640, 372, 64).get("_mfma_util") or {}).get("e2evn_uconv_h_14to14")
-                                                      if (int(cin), int(cout), hh_, ww_, B) == (14, 14, 640, 380, 4) else None),
+                                       mfma_util_pmc=((measured_traffic(8 if B == 8 else 1, 15, 640, 372, 64).get("_mfma_util") or {}).get("e2evn_uconv_h_14to14")
+                                                      if (int(cin), int(cout), hh_, ww_) == (14, 14, 640, 380) and B in (4, 8) else None),
                                        algorithmic_bytes=nbytes, flops_per_launch=flops,
                                        mfma_frac=(3.0 * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if ms else None,
                                        all_unet_conv3x3_ms_per_step=all_ms)
@@ -1401,7 +1404,7 @@ def main():
             torch.cuda.empty_cache()
             import copy
             others = {}
-            for name, fn, over in (("e2evn_6cascade_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=4, streams=2, steps=6, warmup=2)),
+            for name, fn, over in (("e2evn_6cascade_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=8, streams=2, steps=6, warmup=2)),
                                    ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=2, steps=10, warmup=2))):
                 a2 = copy.copy(args)
                 for k_, v_ in over.items():

@@ -30,3 +30,11 @@ for _ in range(3):
     ops.rim_final_gather(taps, None, eta)
     ops.llg372_gather(eta, taps, None, op, 1.0, "backward")
 torch.cuda.synchronize()
+# E2EVN's dominant launch at the default line's batch: the 14 -> 14 convolution of the first U-Net level, 8 x 640 x 380 (k_uconv_h<1, 1, true>)
+A14 = r(8, 14, 640, 380)
+nA = torch.stack([A14.mean((2, 3)), 1 / torch.sqrt(A14.var((2, 3), unbiased=False) + 1e-5)], -1)
+W14 = r(14, 14, 3, 3) / 11
+torch.cuda.synchronize()
+for _ in range(3):
+    ops.unet_conv3x3((A14, nA), None, W14)
+torch.cuda.synchronize()

@@ -68,6 +68,8 @@ def main(fetch_csv, write_csv, lib_version, mfma_csv=None, cubusy_csv=None, batc
                                    hbm_bytes_per_launch=(2.0 * f + w) * 1024.0, hbm_bytes_uncorrected=(f + w) * 1024.0)
         if key in AT and int(batch) == 1:
             out["kernels"][key]["at"] = AT[key]
+        elif key == "e2evn_uconv_h_14to14":
+            out["kernels"][key]["at"] = f"{int(batch)} x 14 -> 14 x 640 x 380"
         if mf and cb:
             m, c = sum(mf.get(k, 0.0) for k in names), sum(cb.get(k, 0.0) for k in names)
             out["kernels"][key].update(mfma_busy_cycles=m, cu_busy_cycles=c, mfma_util=(m / (4.0 * c)) if c else None)
