@@ -86,9 +86,9 @@ def parse():
     if args.batch <= 0:
         # CIRIM inference: 480 tiles of 16 x 32 pixels per slice on 256 CUs -- 8 slices per launch are exactly 15 rounds of the persistent layer kernels
         # (one slice: two rounds, the second 7/8 full); measured 1 x 2 / 2 x 2 / 4 x 2 / 8 x 2 / 8 x 1 / 16 x 1 (batch x streams), lib 252:
-        # 140.7 / 141.3 / 142.9 / 144.1 / 134.7 / 134.7 slices/s (2-D masks: 101.1 / 104.6 / 100.7 at 1 / 4 / 8 x 2 -- left at 1, the shape of its counter passes)
+        # 140.7 / 141.3 / 142.9 / 144.1 / 134.7 / 134.7 slices/s (2-D masks: 101.1 / 104.6 / 100.7 at 1 / 4 / 8 x 2: 4 -- at 8 the 228-MB coil stack of the three-pass gradient no longer fits the 256-MB Infinity Cache)
         # E2EVN (batch x streams, lib 252): 4 x 2 1023, 6 x 2 1087, 8 x 2 1103-1109, 10 x 2 1109, 12 x 2 1108, 16 x 2 1081, 8 x 3 1101, 8 x 1 925, 16 x 1 985
-        args.batch = 8 if (args.model == "e2evn" and not args.train) else 8 if (args.model == "cirim" and not args.train and args.rnn == "IndRNN" and args.mask == "1d") else 1
+        args.batch = 8 if (args.model == "e2evn" and not args.train) else (8 if args.mask == "1d" else 4) if (args.model == "cirim" and not args.train and args.rnn == "IndRNN") else 1
     return args
 
 

@@ -29,6 +29,10 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/$O/pmc8_$c -o p --output-format csv -- python3 $R/tools/probe/pmc_r04_b8.py > $R/$O/pmc8_$c.log 2>&1 )
 done
 python tools/traffic_json.py $O/pmc8_FETCH_SIZE/*counter_collection.csv $O/pmc8_WRITE_SIZE/*counter_collection.csv $V $O/pmc8_SQ_VALU_MFMA_BUSY_CYCLES/*counter_collection.csv $O/pmc8_SQ_BUSY_CU_CYCLES/*counter_collection.csv 8 tools/probe/pmc_r04_b8.py > $O/traffic_b8.json 2>> $O/traffic_json.err
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/$O/pmc4_$c -o p --output-format csv -- python3 $R/tools/probe/pmc_r04_b8.py 4 2d > $R/$O/pmc4_$c.log 2>&1 )
+done
+python tools/traffic_json.py $O/pmc4_FETCH_SIZE/*counter_collection.csv $O/pmc4_WRITE_SIZE/*counter_collection.csv $V $O/pmc4_SQ_VALU_MFMA_BUSY_CYCLES/*counter_collection.csv $O/pmc4_SQ_BUSY_CU_CYCLES/*counter_collection.csv 4 "tools/probe/pmc_r04_b8.py 4 2d" > $O/traffic_b4.json 2>> $O/traffic_json.err
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 python - "$O" <<'PY'
 import json, sys
