@@ -415,11 +415,49 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc_t4(const float4* in, con
     const float4* src = in + tile * (2ll * H);         // two float4 per tile row
     const float4* ysrc = y4 + tile * (2ll * H);
     float4* dst = out + tile * (2ll * H);
-    for (int idx = threadIdx.x; idx < 2 * H; idx += MRX_FFT_NT) {
-        const int p = idx >> 1, hf = idx & 1;
-        reinterpret_cast<float4*>(A)[idx] = src[shifted(p, a.halfH, H) * 2 + hf];
+    // Compile-time H: the tile, the twiddles and the mask bits of this thread are requested up front (clamped addresses, no branch around a load) --
+    // as run-time loops every load sat in its own basic block with its wait: five memory round trips for the tile, three for the twiddles and
+    // ten for the mask (two per row, in the middle of the pass) one after the other.
+    constexpr int NIT = P::kCT ? (2 * P::N + MRX_FFT_NT - 1) / MRX_FFT_NT : 1, NTW = P::kCT ? (P::N + MRX_FFT_NT - 1) / MRX_FFT_NT : 1;
+    unsigned mraw[NIT][2];
+    if constexpr (P::kCT) {
+        float4 tv[NIT];
+        float2 twv[NTW];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = min((int)threadIdx.x + it * MRX_FFT_NT, 2 * H - 1), p = idx >> 1, hf = idx & 1;
+            tv[it] = src[shifted(p, a.halfH, H) * 2 + hf];
+        }
+#pragma unroll
+        for (int it = 0; it < NTW; ++it) twv[it] = a.tw[min((int)threadIdx.x + it * MRX_FFT_NT, H - 1)];
+        {
+            const bool u8 = mask.kind == MRX_MASK_U8;            // (uniform: the two forms of the loop differ in the width of the load only)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = min((int)threadIdx.x + it * MRX_FFT_NT, 2 * H - 1), p = idx >> 1, hf = idx & 1;
+                const long long off = b * mask.s[0] + c_ * mask.s[1] + (long long)shifted(p, a.halfH, H) * mask.s[2] + (long long)(w0 + 2 * hf) * mask.s[3];
+                if (u8) {
+                    mraw[it][0] = ((const unsigned char*)mask.p)[off];
+                    mraw[it][1] = ((const unsigned char*)mask.p)[off + mask.s[3]];
+                } else {
+                    mraw[it][0] = ((const unsigned*)mask.p)[off];
+                    mraw[it][1] = ((const unsigned*)mask.p)[off + mask.s[3]];
+                }
+            }
+        }
+        // (unconditional LDS writes at the clamped index -- lanes past the end repeat the last element's own value: a load whose only use sits
+        // behind `if (i < H)` is sunk into that block by the compiler, wait included)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) reinterpret_cast<float4*>(A)[min((int)threadIdx.x + it * MRX_FFT_NT, 2 * H - 1)] = tv[it];
+#pragma unroll
+        for (int it = 0; it < NTW; ++it) tw[min((int)threadIdx.x + it * MRX_FFT_NT, H - 1)] = twv[it];
+    } else {
+        for (int idx = threadIdx.x; idx < 2 * H; idx += MRX_FFT_NT) {
+            const int p = idx >> 1, hf = idx & 1;
+            reinterpret_cast<float4*>(A)[idx] = src[shifted(p, a.halfH, H) * 2 + hf];
+        }
+        for (int i = threadIdx.x; i < H; i += MRX_FFT_NT) tw[i] = a.tw[i];
     }
-    for (int i = threadIdx.x; i < H; i += MRX_FFT_NT) tw[i] = a.tw[i];
     __syncthreads();
     float2* res;
     if constexpr (P::kCT)
@@ -427,15 +465,26 @@ __global__ __launch_bounds__(MRX_FFT_NT) void k_cols_dc_t4(const float4* in, con
     else
         res = fft_lds_run<false>(A, B, tw, a.plan, 4, 1, 4, true);
     float2* oth = (res == A) ? B : A;
-    for (int idx = threadIdx.x; idx < 2 * H; idx += MRX_FFT_NT) {
+    auto dc_row = [&](int idx, float m0, float m1) {
         const int p = idx >> 1, hf = idx & 1;
         const int hk = shifted(p, a.halfH, H);
         const float4 k = reinterpret_cast<float4*>(res)[idx];
         const float4 yv = NOY ? make_float4(0.f, 0.f, 0.f, 0.f) : ysrc[hk * 2 + hf];
-        const int w = w0 + 2 * hf;
-        const float m0 = mrx_mask_val(mask, b, c_, hk, w), m1 = mrx_mask_val(mask, b, c_, hk, w + 1);
         reinterpret_cast<float4*>(res)[idx] = make_float4(m0 * (k.x * a.scale - yv.x), m0 * (k.y * a.scale - yv.y),   // rim_utils.py:54
                                                           m1 * (k.z * a.scale - yv.z), m1 * (k.w * a.scale - yv.w));
+    };
+    if constexpr (P::kCT) {
+        const bool u8 = mask.kind == MRX_MASK_U8;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = (int)threadIdx.x + it * MRX_FFT_NT;
+            if (idx < 2 * H) dc_row(idx, u8 ? (float)mraw[it][0] : __uint_as_float(mraw[it][0]), u8 ? (float)mraw[it][1] : __uint_as_float(mraw[it][1]));
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < 2 * H; idx += MRX_FFT_NT) {
+            const int hk = shifted(idx >> 1, a.halfH, H), w = w0 + 2 * (idx & 1);
+            dc_row(idx, mrx_mask_val(mask, b, c_, hk, w), mrx_mask_val(mask, b, c_, hk, w + 1));
+        }
     }
     __syncthreads();
     float2* res2;

@@ -127,31 +127,52 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
     };
     if (GAT) load_maps();       // the maps are requested BEFORE the gather's 114 dependent loads: they arrive under it
     if (GAT) {
+        // All 6 x 19 loads of the row go out before the first sum (GAT_GROUP = 6; 3: two rounds), and eta is written after the last one: with the
+        // store of value i between the loads of i and i + 1 (it may alias them for all the compiler knows) the six groups of 19 loads ran one
+        // memory round trip after the other -- 8 of the task's 23 us at 8 slices per launch.  Same order of additions per pixel: bit-identical.
         const int h = (int)(row - b * (unsigned)a.H);
         const long long plane = (long long)a.H * PFA_N;
-        const float* pb = ga.taps + (long long)b * 18 * plane;
+        const float* __restrict__ pb = ga.taps + (long long)b * 18 * plane;
         const int y0 = h > 0 ? h - 1 : 0, y2 = h + 1 < a.H ? h + 1 : a.H - 1;
         const float b0 = ga.bias ? ga.bias[0] : 0.f, b1 = ga.bias ? ga.bias[1] : 0.f;
+        constexpr int GAT_GROUP = 6;
+        float2 vout[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int n = min(l + 64 * i, PFA_N - 1);
-            const int w = pfa372_shift(n, a.halfW);
-            const int x0 = w > 0 ? w - 1 : 0, x2 = w + 1 < PFA_N ? w + 1 : PFA_N - 1;
-            const int ro[3] = {y0 * PFA_N, h * PFA_N, y2 * PFA_N}, co[3] = {x0, w, x2};
-            float s0 = b0, s1 = b1;
+        for (int i0 = 0; i0 < 6; i0 += GAT_GROUP) {
+            float t[GAT_GROUP][18];
+            float2 e[GAT_GROUP];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int ii = 0; ii < GAT_GROUP; ++ii) {
+                const int i = i0 + ii;
+                const int n = min(l + 64 * i, PFA_N - 1);
+                const int w = pfa372_shift(n, a.halfW);
+                const int x0 = w > 0 ? w - 1 : 0, x2 = w + 1 < PFA_N ? w + 1 : PFA_N - 1;
+                const int ro[3] = {y0 * PFA_N, h * PFA_N, y2 * PFA_N}, co[3] = {x0, w, x2};
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float* q = pb + (long long)((dy * 3 + dx) * 2) * plane + ro[dy] + co[dx];
-                    s0 += q[0];
-                    s1 += q[plane];
-                }
-            const float2 e = eta_[(long long)row * PFA_N + w];
-            const float2 v = make_float2(e.x + s0, e.y + s1);
-            ev[i] = pfa_mk(v.x, v.y);
-            if (z == 0 && l + 64 * i < PFA_N) ga.eta_out[(long long)row * PFA_N + w] = v;
-            mv[i] = mrow[n];
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float* q = pb + (long long)((dy * 3 + dx) * 2) * plane + ro[dy] + co[dx];
+                        t[ii][(dy * 3 + dx) * 2] = q[0];
+                        t[ii][(dy * 3 + dx) * 2 + 1] = q[plane];
+                    }
+                e[ii] = eta_[(long long)row * PFA_N + w];
+                mv[i] = mrow[n];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < GAT_GROUP; ++ii) {
+                float s0 = b0, s1 = b1;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s0 += t[ii][2 * k], s1 += t[ii][2 * k + 1];
+                vout[i0 + ii] = make_float2(e[ii].x + s0, e[ii].y + s1);
+                ev[i0 + ii] = pfa_mk(vout[i0 + ii].x, vout[i0 + ii].y);
+            }
+        }
+        if (z == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (l + 64 * i < PFA_N) ga.eta_out[(long long)row * PFA_N + pfa372_shift(l + 64 * i, a.halfW)] = vout[i];
         }
     } else {
 #pragma unroll
@@ -341,9 +362,39 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restric
     }
     __syncthreads();
     const float w = dc.on ? dc.w[0] : 0.f;
-    for (int g = 0; g < Cg; ++g) {
+    // data-consistency operands of coil g + 1 (prediction, reference, mask: 18 loads) are requested before coil g is combined and stored: with the loads
+    // of a coil behind the stores of the one before, the task paid one memory round trip per coil at its very end
+    // (the mask as raw bits, its kind tested once per coil: mrx_mask_val's conversion inside the branch on the kind made every mask load wait for
+    // everything in flight -- six more round trips per coil)
+    float2 pp[2][6], rr[2][6];
+    unsigned mm[2][6];
+    const bool mask_u8 = dc.mask.kind == MRX_MASK_U8;
+    auto dc_request = [&](int g, int buf) {
         const int c = z * PFA_G + g;
         const long long base = (((long long)b * a.C + c) * a.H + h) * PFA_N;
+        const long long mbase = (long long)b * dc.mask.s[0] + (long long)c * dc.mask.s[1] + (long long)h * dc.mask.s[2];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int wcol = pfa372_shift(min(l + 64 * i, PFA_N - 1), a.halfW);
+            pp[buf][i] = dc.pred[base + wcol];
+            rr[buf][i] = dc.ref[base + wcol];
+        }
+        if (mask_u8) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                mm[buf][i] = ((const unsigned char*)dc.mask.p)[mbase + (long long)pfa372_shift(min(l + 64 * i, PFA_N - 1), a.halfW) * dc.mask.s[3]];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                mm[buf][i] = ((const unsigned*)dc.mask.p)[mbase + (long long)pfa372_shift(min(l + 64 * i, PFA_N - 1), a.halfW) * dc.mask.s[3]];
+        }
+    };
+    if (dc.on) dc_request(0, 0);
+#pragma unroll
+    for (int g = 0; g < PFA_G; ++g) {
+        if (g >= Cg) break;
+        const int c = z * PFA_G + g;
+        if (dc.on && g + 1 < Cg) dc_request(g + 1, (g + 1) & 1);
         pfa_c* orow = reinterpret_cast<pfa_c*>(out_) + l372_kbase(a, (long long)b * a.C + c, (int)h);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -352,8 +403,8 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restric
                 const int wcol = pfa372_shift(n, a.halfW);
                 pfa_c r = X[g * PFA_RS + n];
                 if (dc.on) {
-                    const float2 p_ = dc.pred[base + wcol], rf = dc.ref[base + wcol];
-                    const bool m = mrx_mask_val(dc.mask, b, c, h, wcol) != 0.f;
+                    const float2 p_ = pp[g & 1][i], rf = rr[g & 1][i];
+                    const bool m = (mm[g & 1][i] & 0x7fffffffu) != 0u;      // u8: any bit; fp32: != +-0 (what `!= 0.f` says, NaN included)
                     const float sx = m ? (p_.x - rf.x) * w : 0.f, sy = m ? (p_.y - rf.y) * w : 0.f;   // vn_block.py:109-110
                     r = pfa_mk(p_.x - sx - r[0], p_.y - sy - r[1]);                                      // vn_block.py:119
                 }
@@ -429,21 +480,29 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_reduce(const float2* __restric
     const int Cg = min(PFA_G, a.C - z * PFA_G);
     const bool laneA = l < PFA_L1;
     const int g1 = l / PFA_N1, n1 = l - g1 * PFA_N1;
-    // the task's k-space rows, contiguous per coil -> LDS in transform order
-    for (int g = 0; g < PFA_G; ++g) {
-        const int c = min(z * PFA_G + g, a.C - 1);
-        const pfa_c* krow = kin + l372_kbase(a, (long long)b * a.C + c, (int)h);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int n = l + 64 * i;
-            if (n < PFA_N) X[g * PFA_RS + n] = g < Cg ? krow[l372_kcol(a, pfa372_shift(n, a.halfW))] : pfa_mk(0.f, 0.f);
-        }
-    }
+    // the task's k-space rows, contiguous per coil -> LDS in transform order.  All 30 row loads and the 31 map loads are requested before the first
+    // LDS write, unconditionally (idle lanes and missing coils repeat a valid address): behind `if (n < 372)` every load sat in its own basic block
+    // and was waited for there -- thirty memory round trips one after the other at the head of every task.
     Pfa372Lane L;
     {
+        pfa_c kv[PFA_G][6];
+#pragma unroll
+        for (int g = 0; g < PFA_G; ++g) {
+            const int c = min(z * PFA_G + g, a.C - 1);
+            const pfa_c* krow = kin + l372_kbase(a, (long long)b * a.C + c, (int)h);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) kv[g][i] = krow[l372_kcol(a, pfa372_shift(min(l + 64 * i, PFA_N - 1), a.halfW))];
+        }
         const pfa_c* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
 #pragma unroll
         for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = sp[n2 * PFA_L1];
+#pragma unroll
+        for (int g = 0; g < PFA_G; ++g)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int n = l + 64 * i;
+                if (n < PFA_N) X[g * PFA_RS + n] = g < Cg ? kv[g][i] : pfa_mk(0.f, 0.f);
+            }
     }
     __syncthreads();
     pfa_c v[3][12];
