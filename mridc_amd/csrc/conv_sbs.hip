@@ -99,10 +99,13 @@ __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
             const float* src = xb + (long long)gy * a.W + gx;
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {      // every lane loads a valid element (channel clamped), zeroed afterwards: no branch per load
-                const float t = src[(long long)(j < a.Cin ? j : 0) * plane];
-                v[j] = (inb && j < a.Cin) ? t : 0.f;
-            }
+            for (int j = 0; j < 8; ++j) v[j] = src[(long long)(j < a.Cin ? j : 0) * plane];   // every lane loads a valid element (channel clamped)
+            // (the opaque uses keep the eight loads where they are: with the zeroing select as their only use the compiler moved each load behind
+            // a branch on `j < Cin`, wait included -- eight memory round trips one after the other at the head of every workgroup)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (inb && j < a.Cin) ? v[j] : 0.f;
             if constexpr (F16) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = v[j];

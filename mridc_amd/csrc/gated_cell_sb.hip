@@ -793,6 +793,9 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) 
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xg[ib][t][j] = xb[(unsigned)(ib * 64 + 16 * t + 8 * lhi + j) * P32 + pxo];
+        // (the pixel's 128 channels are requested here, all 64 loads of the lane: left to itself the scheduler moved each group of eight down to
+        // its own matrix step and waited for it there -- eight memory round trips per 32 pixels with the matrix pipe idle under each)
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[NOB][2];
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)

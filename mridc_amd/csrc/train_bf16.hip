@@ -573,24 +573,31 @@ __global__ __launch_bounds__(WI_NT, 2) void k_tl_wgrad_in(const float* __restric
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int b = t / ntiles, tt = t - b * ntiles, ty0 = tt / tiles_x, h0 = ty0 * WI_TH, w0 = (tt - ty0 * tiles_x) * 32;
         __syncthreads();
-        // dy tile from the pair tensor: item = (pair, row, 8-pixel group)
+        // dy tile from the pair tensor: item = (pair, row, 8-pixel group), exactly two per thread; halo'd x tile: (channel, row, pixel pair), up to four per
+        // thread.  Every load of the tile is requested before the first LDS write (as run-time loops each iteration's loads were waited for before the next
+        // iteration's went out: five memory round trips per tile, one after the other).
         const unsigned* dyb = dyP + (long long)b * 32 * plane;
-        for (int i = tid; i < 32 * WI_TH * 4; i += WI_NT) {
-            const int pg = i & 3, r = (i >> 2) % WI_TH, pp = i / (4 * WI_TH);
-            const int gy = h0 + r, gx = w0 + pg * 8;
-            const unsigned* src = dyb + (long long)pp * plane + (long long)(gy < H ? gy : H - 1) * W;
-            unsigned d[8];
-            if (vec && gy < H && gx + 8 <= W) {       // the whole group inside the image: two 16-byte loads
-                const uint4 q0 = *reinterpret_cast<const uint4*>(src + gx), q1 = *reinterpret_cast<const uint4*>(src + gx + 4);
-                d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
-            } else {
+        constexpr int DIT = 32 * WI_TH * 4 / WI_NT, XIT = (5 * PH * (PW / 2) + WI_NT - 1) / WI_NT;
+        static_assert(DIT * WI_NT == 32 * WI_TH * 4, "two dy items per thread");
+        // (x: lanes past the last item repeat the last item -- same address, same value, same LDS word: the write below stays unconditional, so the
+        // compiler cannot sink a load into the block of its predicated use)
+        const float* xb = x + (long long)b * Cin * plane;
+        const int nxi = Cin * PH * (PW / 2);
+        float xa0[XIT], xa1[XIT];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int xx = gx + j;
-                    const unsigned v = src[xx < W ? xx : W - 1];
-                    d[j] = (gy < H && xx < W) ? v : 0u;
-                }
-            }
+        for (int it = 0; it < XIT; ++it) {
+            const int i = min(tid + it * WI_NT, nxi - 1);
+            const int c2 = i % (PW / 2), r = (i / (PW / 2)) % PH, c = i / ((PW / 2) * PH);
+            int gy = h0 + r - PAD;
+            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+            int gx0 = w0 + 2 * c2 - PAD, gx1 = gx0 + 1;
+            gx0 = gx0 < 0 ? 0 : (gx0 >= W ? W - 1 : gx0);
+            gx1 = gx1 < 0 ? 0 : (gx1 >= W ? W - 1 : gx1);
+            const float* row = xb + (long long)c * plane + (long long)gy * W;
+            xa0[it] = row[gx0], xa1[it] = row[gx1];
+        }
+        auto dy_commit = [&](int i, const unsigned (&d)[8]) {
+            const int pg = i & 3, r = (i >> 2) % WI_TH, pp = i / (4 * WI_TH);
             u32x4 lo, hi;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -599,18 +606,50 @@ __global__ __launch_bounds__(WI_NT, 2) void k_tl_wgrad_in(const float* __restric
             }
             *reinterpret_cast<u32x4*>(Dy + (2 * pp) * WI_DYS + (r * 32 + pg * 8) * 2) = lo;
             *reinterpret_cast<u32x4*>(Dy + (2 * pp + 1) * WI_DYS + (r * 32 + pg * 8) * 2) = hi;
+        };
+        if (vec && W >= 8) {
+            // W % 4 == 0: a group of eight starts at a multiple of 8, so it lies inside the row, or has exactly its first four pixels inside, or none.
+            // Both 16-byte loads always come from the clamped group start min(gx, W - 8) -- no branch around a load; the three cases are selects.
+            uint4 q0[DIT], q1[DIT];
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const int i = tid + it * WI_NT;
+                const int pg = i & 3, r = (i >> 2) % WI_TH, pp = i / (4 * WI_TH);
+                const int gy = h0 + r, gx = w0 + pg * 8, gxc = gx < W - 8 ? gx : W - 8;
+                const unsigned* src = dyb + (long long)pp * plane + (long long)(gy < H ? gy : H - 1) * W + gxc;
+                q0[it] = *reinterpret_cast<const uint4*>(src), q1[it] = *reinterpret_cast<const uint4*>(src + 4);
+            }
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const int i = tid + it * WI_NT;
+                const int pg = i & 3, r = (i >> 2) % WI_TH;
+                const int gy = h0 + r, gx = w0 + pg * 8;
+                const bool row_in = gy < H, full = row_in && gx + 8 <= W, part = row_in && !full && gx < W;     // part: pixels gx .. gx + 3 = the second load
+                const uint4 lo4 = full ? q0[it] : (part ? q1[it] : make_uint4(0u, 0u, 0u, 0u)), hi4 = full ? q1[it] : make_uint4(0u, 0u, 0u, 0u);
+                const unsigned d[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                dy_commit(i, d);
+            }
+        } else {
+            for (int i = tid; i < 32 * WI_TH * 4; i += WI_NT) {
+                const int pg = i & 3, r = (i >> 2) % WI_TH, pp = i / (4 * WI_TH);
+                const int gy = h0 + r, gx = w0 + pg * 8;
+                const unsigned* src = dyb + (long long)pp * plane + (long long)(gy < H ? gy : H - 1) * W;
+                unsigned d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int xx = gx + j;
+                    const unsigned v = src[xx < W ? xx : W - 1];
+                    d[j] = (gy < H && xx < W) ? v : 0u;
+                }
+                dy_commit(i, d);
+            }
         }
         // halo'd x tile, replicate padding, fp32 -> bf16 (two pixels per thread and step)
-        const float* xb = x + (long long)b * Cin * plane;
-        for (int i = tid; i < Cin * PH * (PW / 2); i += WI_NT) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int i = min(tid + it * WI_NT, nxi - 1);
             const int c2 = i % (PW / 2), r = (i / (PW / 2)) % PH, c = i / ((PW / 2) * PH);
-            int gy = h0 + r - PAD;
-            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
-            int gx0 = w0 + 2 * c2 - PAD, gx1 = gx0 + 1;
-            gx0 = gx0 < 0 ? 0 : (gx0 >= W ? W - 1 : gx0);
-            gx1 = gx1 < 0 ? 0 : (gx1 >= W ? W - 1 : gx1);
-            const float* row = xb + (long long)c * plane + (long long)gy * W;
-            *reinterpret_cast<unsigned*>(Xh + (c * PH + r) * PW + 2 * c2) = tl_pk(row[gx0], row[gx1]);
+            *reinterpret_cast<unsigned*>(Xh + (c * PH + r) * PW + 2 * c2) = tl_pk(xa0[it], xa1[it]);
         }
         __syncthreads();
 #pragma unroll

@@ -342,6 +342,24 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
             }
         }
 
+        // plain convolution: this lane's 4 NCOT bias values, requested in one block behind the matrix loop (held across it they cost 16 registers the 4-block form does not have; read inside the epilogue's loops, behind `if (a.bias)`, every
+        // one of the 16 NCOT loads was waited for on its own: 64 round trips to the cache per workgroup at NCOT = 4)
+        float bv[NCOT][4];
+#pragma unroll
+        for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[ct][r] = 0.f;
+        if constexpr (!UNET) {
+            if (a.bias) {
+#pragma unroll
+                for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + 16 * ct + 4 * lg + r;
+                        bv[ct][r] = a.bias[co < a.Cout ? co : 0];
+                    }
+            }
+        }
         bool ok[4];
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {
@@ -353,8 +371,7 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[sg][ct][r] * unscale;                            // exact: powers of two
                     if constexpr (!UNET) {
-                        const int co = co0 + 16 * ct + 4 * lg + r;
-                        if (a.bias) v += a.bias[co < a.Cout ? co : 0];
+                        v += bv[ct][r];
                         if (a.act == MRX_ACT_RELU) v = v > 0.f ? v : 0.f;
                         else if (a.act == MRX_ACT_LEAKY) v = v > 0.f ? v : v * slope;
                     }
