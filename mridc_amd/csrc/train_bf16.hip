@@ -275,11 +275,20 @@ __global__ __launch_bounds__(CL_NT, 2) void k_tl_cell_bwd(CellBwdArgs a) {
     float* slot = a.part + (long long)blockIdx.x * CL_PART;
     if (wave < 4) {
         const int bi = wave & 1, bj = (wave >> 1) & 1;
+        // (the slot's sixteen old values are requested in one block: as `first ? v : slot + v` per element every load sat behind its own branch and
+        // wait -- sixteen round trips at the very end of every workgroup)
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = 0.f;
+        if (!a.first) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = slot[(32 * bi + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 64 + 32 * bj + l31];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = acc2[r] + R[(wave * 16 + r) * 64 + lane];
             const int co = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * lhi, ci = 32 * bj + l31;
-            slot[co * 64 + ci] = a.first ? v : slot[co * 64 + ci] + v;
+            slot[co * 64 + ci] = a.first ? v : old[r] + v;
         }
     }
     __syncthreads();
