@@ -1017,7 +1017,7 @@ def streamed_inputs_run(args, step, hosts, datas, dev, slices_per_step, variant=
                 graphs[i].replay()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    nbytes = sum(pinned[0][k].numel() * pinned[0][k].element_size() for k in keys)
+    nbytes = sum(pinned[0][k].numel() * pinned[0][k].element_size() for k in keys) / max(1, slices_per_step // NS)    # a stream's batch holds slices_per_step / NS slices
     return dict(value=slices_per_step * args.steps / dt, unit="slices/s", ms_per_step=1e3 * dt / args.steps,
                 host_to_device_bytes_per_slice=nbytes, host_to_device_GBps=nbytes * slices_per_step * args.steps / dt / 1e9,
                 note="every replay reconstructs a slice uploaded during the previous one (pinned host memory -> staging on a copy stream -> the "
