@@ -297,7 +297,9 @@ struct L372Dc {
 // RED: the new k-space rows stay in the wave's buffer and go straight through the inverse pipeline of k_pfa372_reduce (S is still in
 // registers): part[z][b, h, :] = the task's share of sum_c conj(S) IFFT_W(out) -- the next cascade's sens_reduce (vn_block.py:71-87) without
 // reading the coil stack and the maps again.
-template <bool RED>
+// DC: the data-consistency epilogue compiled in (E2EVN's cascades); without it the pass is the first pass of the general-mask gradient and of sens_expand -- a
+// run-time switch cost that form 1.8 us per launch (registers of the operand prefetch, the unrolled coil loop's exits)
+template <bool RED, bool DC>
 __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restrict__ x_, const float2* __restrict__ Sp_,
                                                           float2* __restrict__ out_, L372Args a, L372Dc dc, float2* __restrict__ part_) {
     const pfa_c* __restrict__ xin = reinterpret_cast<const pfa_c*>(x_);
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restric
         }
     }
     __syncthreads();
-    const float w = dc.on ? dc.w[0] : 0.f;
+    const float w = DC ? dc.w[0] : 0.f;
     // data-consistency operands of coil g + 1 (prediction, reference, mask: 18 loads) are requested before coil g is combined and stored: with the loads
     // of a coil behind the stores of the one before, the task paid one memory round trip per coil at its very end
     // (the mask as raw bits, its kind tested once per coil: mrx_mask_val's conversion inside the branch on the kind made every mask load wait for
@@ -389,12 +391,14 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restric
                 mm[buf][i] = ((const unsigned*)dc.mask.p)[mbase + (long long)pfa372_shift(min(l + 64 * i, PFA_N - 1), a.halfW) * dc.mask.s[3]];
         }
     };
-    if (dc.on) dc_request(0, 0);
+    if constexpr (DC) dc_request(0, 0);
 #pragma unroll
     for (int g = 0; g < PFA_G; ++g) {
         if (g >= Cg) break;
         const int c = z * PFA_G + g;
-        if (dc.on && g + 1 < Cg) dc_request(g + 1, (g + 1) & 1);
+        if constexpr (DC) {
+            if (g + 1 < Cg) dc_request(g + 1, (g + 1) & 1);
+        }
         pfa_c* orow = reinterpret_cast<pfa_c*>(out_) + l372_kbase(a, (long long)b * a.C + c, (int)h);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restric
             if (n < PFA_N) {
                 const int wcol = pfa372_shift(n, a.halfW);
                 pfa_c r = X[g * PFA_RS + n];
-                if (dc.on) {
+                if constexpr (DC) {
                     const float2 p_ = pp[g & 1][i], rf = rr[g & 1][i];
                     const bool m = (mm[g & 1][i] & 0x7fffffffu) != 0u;      // u8: any bit; fp32: != +-0 (what `!= 0.f` says, NaN included)
                     const float sx = m ? (p_.x - rf.x) * w : 0.f, sy = m ? (p_.y - rf.y) * w : 0.f;   // vn_block.py:109-110
@@ -809,8 +813,12 @@ extern "C" int mrx_pfa372_expand(const float* x, const float* Sp, float* out, co
     dc.pred = (const float2*)pred, dc.ref = (const float2*)ref, dc.w = dc_weight;
     dc.mask.p = mask, dc.mask.kind = mask_kind;
     for (int i = 0; i < 4; ++i) dc.mask.s[i] = (dc.on ? mstride[i] : 0);
-    hipLaunchKernelGGL(k_pfa372_expand<false>, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
-                       (const float2*)Sp, (float2*)out, a, dc, (float2*)nullptr);
+    if (dc.on)
+        hipLaunchKernelGGL((k_pfa372_expand<false, true>), dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
+                           (const float2*)Sp, (float2*)out, a, dc, (float2*)nullptr);
+    else
+        hipLaunchKernelGGL((k_pfa372_expand<false, false>), dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
+                           (const float2*)Sp, (float2*)out, a, dc, (float2*)nullptr);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -832,8 +840,12 @@ extern "C" int mrx_pfa372_expand_reduce(const float* x, const float* Sp, float* 
     dc.mask.p = mask, dc.mask.kind = mask_kind;
     for (int i = 0; i < 4; ++i) dc.mask.s[i] = (dc.on ? mstride[i] : 0);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_pfa372_expand<true>, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, st, (const float2*)x,
-                       (const float2*)Sp, (float2*)out, a, dc, (float2*)work);
+    if (dc.on)
+        hipLaunchKernelGGL((k_pfa372_expand<true, true>), dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, st, (const float2*)x,
+                           (const float2*)Sp, (float2*)out, a, dc, (float2*)work);
+    else
+        hipLaunchKernelGGL((k_pfa372_expand<true, false>), dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, st, (const float2*)x,
+                           (const float2*)Sp, (float2*)out, a, dc, (float2*)work);
     const long long total = (long long)H * PFA_N * B;
     long long nb = (total + 255) / 256;
     if (nb > 2048) nb = 2048;
@@ -885,7 +897,7 @@ extern "C" int mrx_pfa372_expand_t4(const float* x, const float* Sp, float* out_
     dc.pred = dc.ref = nullptr, dc.w = nullptr;
     dc.mask.p = nullptr, dc.mask.kind = MRX_MASK_U8;
     for (int i = 0; i < 4; ++i) dc.mask.s[i] = 0;
-    hipLaunchKernelGGL(k_pfa372_expand<false>, dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
+    hipLaunchKernelGGL((k_pfa372_expand<false, false>), dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
                        (const float2*)Sp, (float2*)out_t4, a, dc, (float2*)nullptr);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
