@@ -224,3 +224,66 @@ def test_no_object_of_the_library_contains_packed_fp32_instructions(tmp_path):
         assert "v_mul_f32" in asm or "v_fma_f32" in asm or "v_fmac_f32" in asm          # (the disassembly is that of the kernels)
         packed = [ln for ln in asm.splitlines() if "v_pk_fma_f32" in ln or "v_pk_mul_f32" in ln or "v_pk_add_f32" in ln]
         assert not packed, f"{name}.o: {len(packed)} packed-fp32 instructions, e.g. {packed[0].strip()}"
+
+
+def test_hot_kernels_keep_their_loads_ahead_of_their_waits(tmp_path):
+    """DESIGN.md 7.1 (round 4): on gfx950 `vmcnt` retires in order, and a load whose only use sits behind a branch is waited for in that block -- a loop
+    that reads like "thirty loads, then thirty LDS writes" ran as thirty memory round trips (k_pfa372_reduce, k_cols_dc_t4, the gather inside k_llg372,
+    k_conv1x1_sb128 ...), and a run-time test inside an unrolled loop left part of layer 1's patch in scratch memory.  Guards what those fixes bought:
+    per hot kernel of the built library, the number of load groups that end in `s_waitcnt vmcnt(0)` (tools/probe/load_wait_scan.py's count, here on the
+    objects' disassembly) and the scratch size of its kernel descriptor."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    from mridc_amd import _build
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("no llvm-objdump / llvm-readelf in this image")
+    _build.build()
+    # object -> [(mangled-name prefix, max groups of <= 2 loads, max groups, scratch must be 0)]   (lib 256: the measured counts + a little room)
+    hot = {
+        "rim_layer1_sb": [("_Z15k_rim_layer1_sbILb1ELb1ELb0ELi1EE", 4, 8, True)],                       # 3 / 6
+        "rim_layer2_sb": [("_Z15k_rim_layer2_sbILi2ELb1ELb0ELb1ELi0ELb1ELb0EE", 6, 11, True)],           # 5 / 9
+        "llg372": [("_Z8k_llg372ILi0ELb1ELb0EE", 0, 2, True), ("_Z8k_llg372ILi0ELb1ELb1EE", 0, 2, True),   # 0 / 1 each (151 loads in the gather form)
+                   ("_Z15k_pfa372_reduce", 0, 2, True), ("_Z15k_pfa372_expandILb0ELb0EE", 0, 2, True)],
+        "fft": [("_Z12k_cols_dc_t4I6PlanCTILi640EJLi5ELi8ELi4ELi4EEELb1EE", 0, 2, True)],
+        "gated_cell_sb": [("_Z15k_conv1x1_sb128ILi2EE", 5, 9, True)],                                    # 4 / 7
+        "train_bf16": [("_Z13k_tl_cell_bwdILb1ELb1ELb1EE", 3, 6, True)],                                 # 2 / 4
+        "unet_f16": [("_Z9k_uconv_hILi4ELi2ELb0EE", 1, 5, True), ("_Z9k_uconv_hILi1ELi1ELb1EE", 1, 4, True)],
+    }
+    for name, kernels in hot.items():
+        obj = shutil.copy(os.path.join(_build.LIBDIR, name + ".o"), str(tmp_path / (name + ".o")))
+        subprocess.run([objdump, "--offloading", obj], check=True, capture_output=True, cwd=str(tmp_path))
+        dev = [f for f in os.listdir(tmp_path) if f.startswith(name + ".o.") and "amdgcn" in f]
+        assert dev, os.listdir(tmp_path)
+        asm = subprocess.run([objdump, "-d", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+        notes = subprocess.run([readelf, "--notes", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+        scratch = {}
+        for blk in notes.split("  - ."):
+            n_, p_ = re.search(r"\.name:\s+(\S+)", blk), re.search(r"private_segment_fixed_size:\s+(\d+)", blk)
+            if n_ and p_:
+                scratch[n_.group(1)] = int(p_.group(1))
+        counts, cur, pending = {}, None, 0
+        for ln in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(_Z\w+)>:", ln)
+            if m:
+                cur, pending = m.group(1), 0
+                counts[cur] = [0, 0]
+            elif cur is not None:
+                if re.search(r"\b(global_load|buffer_load)", ln):
+                    pending += 1
+                elif "s_waitcnt" in ln and "vmcnt(0)" in ln:
+                    if pending:
+                        counts[cur][1] += 1
+                        counts[cur][0] += pending <= 2
+                    pending = 0
+        for prefix, max_short, max_groups, no_scratch in kernels:
+            found = [k for k in counts if k.startswith(prefix)]
+            assert len(found) == 1, f"{name}.o: {prefix}* matches {found}"
+            short, groups = counts[found[0]]
+            assert short <= max_short and groups <= max_groups, (
+                f"{found[0]}: {groups} load groups end in vmcnt(0), {short} of them of one or two loads (allowed {max_groups} / {max_short}): "
+                "some loads are waited for one by one again (python tools/probe/load_wait_scan.py)")
+            if no_scratch:
+                assert scratch.get(found[0], -1) == 0, f"{found[0]}: {scratch.get(found[0])} bytes of scratch per lane"
