@@ -1,9 +1,8 @@
 #!/bin/bash
-# Round-4 profile set: the default bench line, rocprofv3 kernel traces of the headline / E2EVN / qCIRIM / training / 2-D mask runs, PMC passes
-# (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES: one counter per pass) over tools/probe/pmc_r04.py.  $1 = output tag.
+# Round-4 profile set: rocprofv3 kernel traces of the headline / E2EVN / qCIRIM / training / 2-D mask runs, PMC passes
+# (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES: one counter per pass) over tools/probe/pmc_r04.py (+ pmc_r04_b8.py at the bench's batch sizes), then the default bench line.  $1 = output tag.
 T=${1:-v1}; O=gpurun_out/r04_$T; mkdir -p $O
 R=$GRAFT_REPO_ROOT
-( time timeout 900 python bench.py > $O/bench.json 2> $O/bench.err ) 2>&1 | grep real
 cd /tmp && export TMPDIR=/tmp
 prof() {   # tag, bench flags
   timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof_$1 -o t -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --no-stream-inputs $2 > $R/$O/prof_$1.log 2>&1
@@ -34,6 +33,10 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do
 done
 python tools/traffic_json.py $O/pmc4_FETCH_SIZE/*counter_collection.csv $O/pmc4_WRITE_SIZE/*counter_collection.csv $V $O/pmc4_SQ_VALU_MFMA_BUSY_CYCLES/*counter_collection.csv $O/pmc4_SQ_BUSY_CU_CYCLES/*counter_collection.csv 4 "tools/probe/pmc_r04_b8.py 4 2d" > $O/traffic_b4.json 2>> $O/traffic_json.err
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+# the default bench line LAST, with this library's counter files in place on the box: `traffic` / `mfma_util_pmc` are reported only for the library version
+# the counter passes were made with (bench.measured_traffic)
+for s in "" _b8 _b4; do [ -s $O/traffic$s.json ] && cp $O/traffic$s.json profiles/r04_traffic$s.json; done
+( time timeout 900 python bench.py > $O/bench.json 2> $O/bench.err ) 2>&1 | grep real
 python - "$O" <<'PY'
 import json, sys
 O = sys.argv[1]
