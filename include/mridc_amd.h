@@ -31,6 +31,7 @@ extern "C" {
 #define MRX_EINVAL (-1)   /* bad argument (shape, enum, null pointer) */
 #define MRX_EUNSUP (-2)   /* valid request the library does not implement (size limits) */
 #define MRX_EHIP (-3)     /* a HIP runtime call failed */
+#define MRX_EBOUND (-4)   /* CHECK builds only (-DMRX_CHECK_BOUNDS): an operand bound handed to a two-term fp16 kernel does not bound its tensor */
 
 /* normalization, as the reference's `fft_normalization` strings (fft.py:13-18): */
 #define MRX_NORM_BACKWARD 0
@@ -61,6 +62,11 @@ int64_t mrx_stream_capture_id(void* stream);
  * products per multiply, where a kernel has that form), 1 = "bf16x3" (three-term bf16 operands, six exact term products), 2 = "fp32" (the
  * fp32-input MFMA kernels).  All three give fp32 results; tests cross-check them, bench.py prices them (exact_fp32_route). */
 int mrx_arith(void);
+/* 1 in a CHECK build of the library (python -m mridc_amd._build --check-bounds -> mridc_amd/lib_chk/, selected with MRIDC_AMD_LIB), else 0.  A check
+ * build verifies, at every entry point that takes the bound of an operand (mrx_conv3x3_sb_chain, mrx_rim_layer2_f16[_cb8], mrx_unet_conv3x3_h,
+ * mrx_conv3x3_h), that max |x| <= bound <= 2^16 max |x| over the tensor the call is about to read: one reduction launch + a stream synchronisation per
+ * call (skipped while the stream is being captured), MRX_EBOUND and a message naming the entry point otherwise.  The product build has none of it. */
+int mrx_checks_enabled(void);
 
 /* Create (and cache) the twiddle tables for lengths h and w.  Optional; every FFT entry point does
  * it lazily.  Call it before capturing a hipGraph. */

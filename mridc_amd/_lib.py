@@ -26,6 +26,7 @@ _SIGNATURES = {
     "mrx_last_error": ([], ctypes.c_char_p),
     "mrx_stream_capture_id": ([_p], _i64),
     "mrx_arith": ([], _i),
+    "mrx_checks_enabled": ([], _i),
     "mrx_poisson_disc_mask": ([_i, _i, _i, _p, _p, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, _p], _i64),
     "mrx_fft_prepare": ([_i, _i], _i),
     "mrx_fft_max_len": ([], _i),
@@ -262,6 +263,88 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(mrx_[a-z0-9_]+)\s*\(", text)))
 
 
+def written_pointer_args():
+    """{function name: positions of its non-const pointer parameters other than `stream`} read off include/mridc_amd.h: the parameters a call may
+    WRITE through.  The header is const-correct (tests/test_host_logic.py checks that every declared function parses), so this list needs no
+    maintenance when an entry point is added."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    out = {}
+    for name, args in re.findall(r"\b(mrx_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        pos = []
+        for i, a in enumerate(args.split(",")):
+            a = a.strip()
+            if "*" in a and not a.startswith("const") and not re.search(r"\bstream$", a):
+                pos.append(i)
+        out[name] = tuple(pos)
+    return out
+
+
+# ---- operand bounds: who owns them -------------------------------------------------------------------------------------------------------------
+# A two-term fp16 kernel scales its input by a device scalar >= max |x|.  Producers that know that maximum (a kernel that folds it out of its own
+# accumulators, an instance norm whose outputs are bounded analytically) leave it here, consumers ask for it -- a table of MEMORY RANGES owned by
+# this binding, not an attribute on tensor objects:
+#   * an entry is (address range, the tensor object it was attached to (weak), that tensor's version, the bound scalar);
+#   * every call into the library invalidates the entries overlapping a range it may write: `ptr()` hands the call the tensor's address range, and
+#     the wrapper installed on each entry point looks at its non-const pointer parameters (written_pointer_args).  That covers `out=` tensors,
+#     VIEWS of a bounded tensor and in-place kernels alike -- the library writes through raw pointers and never bumps a tensor version;
+#   * writes by torch itself bump the version (shared by all views), a freed tensor kills the weak reference: both fail the look-up.
+# Round 4 kept the bound as `tensor._mrx_bound` and relied on each op remembering to drop it from its `out` argument.
+class _Ptr(ctypes.c_void_p):
+    """c_void_p of a tensor's first byte that also knows the byte range [lo, hi) the tensor covers."""
+    __slots__ = ("lo", "hi")
+
+
+_BOUNDS = {}            # lo -> (hi, weakref(tensor), version, bound scalar tensor)
+
+
+def bound_attach(t, bound):
+    """Remember `bound` (1-element device tensor, >= max |t| once the stream has run the producer) for tensor t."""
+    import weakref
+    if len(_BOUNDS) >= 64:
+        for k in [k for k, e in _BOUNDS.items() if e[1]() is None]:
+            del _BOUNDS[k]
+        while len(_BOUNDS) >= 64:
+            _BOUNDS.pop(next(iter(_BOUNDS)))
+    lo, hi = _span(t)
+    _BOUNDS[lo] = (hi, weakref.ref(t), t._version, bound)
+    return t
+
+
+def bound_of(t):
+    """The bound attached to exactly this tensor object, if nothing has written its memory since; else None."""
+    e = _BOUNDS.get(t.data_ptr()) if _BOUNDS else None
+    if e is None or e[1]() is not t or e[2] != t._version or _span(t)[1] != e[0]:
+        return None
+    return e[3]
+
+
+def bound_note_write(lo, hi):
+    for k in [k for k, e in _BOUNDS.items() if k < hi and e[0] > lo]:
+        del _BOUNDS[k]
+
+
+def _span(t):
+    lo = t.data_ptr()
+    if t.is_contiguous():
+        return lo, lo + t.numel() * t.element_size()
+    ext = 1 + sum((int(n) - 1) * int(st) for n, st in zip(t.shape, t.stride())) if t.numel() else 0
+    return lo, lo + ext * t.element_size()
+
+
+def _tracked(fn, positions):
+    def call(*args):
+        if _BOUNDS:
+            for i in positions:
+                p = args[i]
+                if type(p) is _Ptr:
+                    bound_note_write(p.lo, p.hi)
+        return fn(*args)
+    call.__name__ = getattr(fn, "__name__", "mrx_call")
+    call.raw = fn
+    return call
+
+
 def lib():
     """Load libmridc_amd.so (once).  Raises if it has not been built -- there is no fallback."""
     global _lib
@@ -271,10 +354,13 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -m mridc_amd._build` (hipcc, gfx950). "
                 "mridc_amd has no CPU or PyTorch fallback path.")
         L = ctypes.CDLL(LIB_PATH)
+        writes = written_pointer_args()
         for name, (args, res) in _SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
             fn.argtypes = args
             fn.restype = res
+            if writes.get(name):
+                setattr(L, name, _tracked(fn, writes[name]))
         _lib = L
     return _lib
 
@@ -306,7 +392,12 @@ def f32c(t):
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    """Device pointer of t (NULL for None) carrying t's byte range, so that a call that writes through it invalidates the bounds kept for it."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    p = _Ptr(t.data_ptr())
+    p.lo, p.hi = _span(t)
+    return p
 
 
 def i64_array(vals):

@@ -9,18 +9,19 @@ import torch.nn.functional as F
 
 from mridc_amd import ops
 
-_SLOPES = {}
-
-
 def _prelu_slope(mod):
-    """Slope of a single-parameter PReLU as a host float, read back once per parameter version."""
-    if mod.weight.numel() != 1:
+    """Slope of a single-parameter PReLU as a host float, read back once per parameter version.  The cached value lives ON the module (and pins
+    the storage it was read from), so it dies with the module: a process-wide table keyed by id(module) hands a NEW module that happens to get a
+    freed module's id -- and, from the caching allocator, its 512-byte weight block with the same version -- the dead module's slope
+    (DESIGN.md 7.9: the one-off 4e-2 error of test_dunet_vs_golden; tests/test_host_logic.py::test_prelu_slope_cache_dies_with_its_module)."""
+    w = mod.weight
+    if w.numel() != 1:
         raise NotImplementedError("mridc_amd DIDN: per-channel PReLU is not on the HIP path")
-    key = (id(mod), mod.weight.data_ptr(), mod.weight._version)
-    hit = _SLOPES.get(id(mod))
+    key = (w.data_ptr(), w._version)
+    hit = mod.__dict__.get("_mrx_slope")
     if hit is None or hit[0] != key:
-        hit = (key, float(mod.weight.detach().reshape(-1)[0]))
-        _SLOPES[id(mod)] = hit
+        hit = (key, float(w.detach().reshape(-1)[0]), w.detach())    # the detached alias pins the storage: its address cannot be recycled
+        mod.__dict__["_mrx_slope"] = hit
     return hit[1]
 
 

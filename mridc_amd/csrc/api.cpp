@@ -15,7 +15,7 @@ void mrx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int mrx_version(void) { return 256; /* 0.2.0: bumped with every kernel change (profiles/rNN_traffic.json is keyed on it) */ }
+extern "C" int mrx_version(void) { return 257; /* 0.2.0: bumped with every kernel change (profiles/rNN_traffic.json is keyed on it) */ }
 extern "C" const char* mrx_last_error(void) { return g_err; }
 extern "C" int mrx_arith(void) {
     const char* e = getenv("MRIDC_AMD_ARITH");
@@ -34,3 +34,49 @@ extern "C" int64_t mrx_stream_capture_id(void* stream) {
     if (status != hipStreamCaptureStatusActive) return 0;
     return (int64_t)(id ? id : 1ull);
 }
+
+#ifdef MRX_CHECK_BOUNDS
+extern "C" int mrx_checks_enabled(void) { return 1; }
+__global__ void k_check_max_abs(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i]);
+        m = (v > m || v != v) ? v : m;                                   // NaN sticks
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(m, off, 64);
+        m = (o > m || o != o) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m != m ? 0x7fc00000u : __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+int mrx_check_bound(const char* who, const float* x, long long n, const float* bound, hipStream_t stream) {
+    if (!bound || !x || n <= 0) return MRX_OK;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &status) == hipSuccess && status != hipStreamCaptureStatusNone) return MRX_OK;    // cannot synchronise a capture
+    static thread_local unsigned* d_max = nullptr;
+    if (!d_max) MRX_HIP(hipMalloc(&d_max, sizeof(unsigned)));
+    MRX_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned), stream));
+    long long nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_check_max_abs, dim3((unsigned)nb), dim3(256), 0, stream, x, n, d_max);
+    MRX_LAUNCH_CHECK();
+    float h_max = 0.f, h_bound = 0.f;
+    MRX_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(float), hipMemcpyDeviceToHost, stream));
+    MRX_HIP(hipMemcpyAsync(&h_bound, bound, sizeof(float), hipMemcpyDeviceToHost, stream));
+    MRX_HIP(hipStreamSynchronize(stream));
+    if (h_max != h_max) return MRX_OK;                                   // NaN input: the kernel's result is NaN with any bound
+    if (!(h_max <= h_bound * 1.000001f)) {
+        mrx_set_error("%s: operand bound %.9g does NOT bound its tensor (max |x| = %.9g over %lld values): stale or foreign bound", who, (double)h_bound,
+                      (double)h_max, n);
+        return MRX_EBOUND;
+    }
+    if (h_max > 0.f && h_bound > 65536.f * h_max) {
+        mrx_set_error("%s: operand bound %.9g is more than 2^16 x max |x| = %.9g (%lld values): the two-term fp16 operands lose fp32 accuracy", who,
+                      (double)h_bound, (double)h_max, n);
+        return MRX_EBOUND;
+    }
+    return MRX_OK;
+}
+#else
+extern "C" int mrx_checks_enabled(void) { return 0; }
+#endif

@@ -27,6 +27,19 @@ extern "C" int mrx_arith(void);
 #define MRX_DEBUG_ENV(name) ((const char*)nullptr)
 #endif
 
+// CHECK builds (-DMRX_CHECK_BOUNDS): the operand bound a two-term fp16 entry point was handed is compared with the tensor it is about to read
+// (api.cpp: one reduction launch, a stream synchronisation, two 4-byte copies); the product build compiles the macro away.
+#ifdef MRX_CHECK_BOUNDS
+int mrx_check_bound(const char* who, const float* x, long long n, const float* bound, hipStream_t stream);
+#define MRX_CHECK_BOUND(who, x, n, bound, stream)                                         \
+    do {                                                                                  \
+        const int rc__ = mrx_check_bound((who), (x), (long long)(n), (bound), (hipStream_t)(stream)); \
+        if (rc__ != MRX_OK) return rc__;                                                  \
+    } while (0)
+#else
+#define MRX_CHECK_BOUND(who, x, n, bound, stream) do { } while (0)
+#endif
+
 #define MRX_REQUIRE(cond, code, ...)  \
     do {                              \
         if (!(cond)) {                \

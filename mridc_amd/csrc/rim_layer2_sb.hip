@@ -916,6 +916,7 @@ extern "C" int mrx_conv3x3_sb_chain(const float* x, const float* packed_bf16, co
     MRX_REQUIRE(act >= 0 && act <= 2, MRX_EINVAL, "mrx_conv3x3_sb_chain: bad activation %d", act);
     MRX_REQUIRE(!xmax_in || mrx_arith() == MRX_ARITH_F16X2, MRX_EUNSUP, "mrx_conv3x3_sb_chain: the two-term fp16 form is off (MRIDC_AMD_ARITH)");
     if (B == 0) return MRX_OK;
+    MRX_CHECK_BOUND("mrx_conv3x3_sb_chain", x, (long long)B * 64 * H * W, xmax_in, stream);
     L2sbArgs a;
     a.x = x, a.packed = reinterpret_cast<const u32x4*>(xmax_in ? packed_f16 : packed_bf16), a.b_conv = bias, a.b_ih = nullptr, a.hh = nullptr;
     a.hprev = nullptr, a.hnew = y;
@@ -994,6 +995,7 @@ extern "C" int mrx_rim_layer2_f16_pack(const float* w_conv, const float* w_ih, c
 extern "C" int mrx_rim_layer2_f16(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
                                   const float* h_prev, float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream) {
     MRX_REQUIRE(xmax, MRX_EINVAL, "mrx_rim_layer2_f16: null pointer");
+    if (x && B > 0 && H > 0 && W > 0) MRX_CHECK_BOUND("mrx_rim_layer2_f16", x, (long long)B * 64 * H * W, xmax, stream);
     return l2sb_launch(x, packed, b_conv, b_ih, hh, h_prev, h_new, taps, B, H, W, stream, xmax);
 }
 
@@ -1001,6 +1003,7 @@ extern "C" int mrx_rim_layer2_f16(const float* x, const float* packed, const flo
 extern "C" int mrx_rim_layer2_f16_cb8(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh,
                                       const float* h_prev, float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream) {
     MRX_REQUIRE(xmax, MRX_EINVAL, "mrx_rim_layer2_f16_cb8: null pointer");
+    if (x && B > 0 && H > 0 && W > 0) MRX_CHECK_BOUND("mrx_rim_layer2_f16_cb8", x, (long long)B * 64 * H * W, xmax, stream);
     return l2sb_launch(x, packed, b_conv, b_ih, hh, h_prev, h_new, taps, B, H, W, stream, xmax, true);
 }
 

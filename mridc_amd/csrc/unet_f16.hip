@@ -471,6 +471,8 @@ extern "C" int mrx_unet_conv3x3_h(const float* xa, const float* na, const float*
     MRX_REQUIRE(B <= 65535 && Cout <= 16 * 65535 && (long long)H * W < (1ll << 30), MRX_EUNSUP, "mrx_unet_conv3x3_h: size");
     MRX_REQUIRE(mrx_arith() == MRX_ARITH_F16X2, MRX_EUNSUP, "mrx_unet_conv3x3_h: the two-term fp16 form is off (MRIDC_AMD_ARITH)");
     if (B == 0) return MRX_OK;
+    if (!na) MRX_CHECK_BOUND("mrx_unet_conv3x3_h (source a)", xa, (long long)B * Ca * H * W, bound_a, stream);
+    if (Cb && !nb) MRX_CHECK_BOUND("mrx_unet_conv3x3_h (source b)", xb, (long long)B * Cb * H * W, bound_b, stream);
     UConvHArgs a;
     a.xa = xa, a.na = na, a.bound_a = bound_a, a.xb = Cb ? xb : nullptr, a.nb = Cb ? nb : nullptr, a.bound_b = bound_b;
     a.packed = reinterpret_cast<const uh_u4*>(packed), a.y = y, a.tstats = work;
@@ -502,6 +504,7 @@ extern "C" int mrx_conv3x3_h(const float* x, const float* bound, const float* pa
     MRX_REQUIRE((long long)H * W < (1ll << 30), MRX_EUNSUP, "mrx_conv3x3_h: size");
     MRX_REQUIRE(mrx_arith() == MRX_ARITH_F16X2, MRX_EUNSUP, "mrx_conv3x3_h: the two-term fp16 form is off (MRIDC_AMD_ARITH)");
     if (B == 0) return MRX_OK;
+    MRX_CHECK_BOUND("mrx_conv3x3_h", x, (long long)B * Cin * H * W, bound, stream);
     UConvHArgs a;
     a.xa = x, a.na = nullptr, a.bound_a = bound, a.xb = nullptr, a.nb = nullptr, a.bound_b = nullptr;
     a.packed = reinterpret_cast<const uh_u4*>(packed), a.y = y, a.tstats = nullptr;

@@ -508,7 +508,6 @@ def rim_layer1_inplace_ok(Cin, F, k, dilation):
 def rim_layer_indrnn_packed_llg(eta, part, nparts, sigma, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None, xmax=None):
     """The tuned fused first RIM layer reading log_likelihood_gradient's pieces (eta and the partial coil sums) directly.  `xmax` as in
     rim_layer_indrnn_packed."""
-    _forget_bound(out)
     eta = _lib.f32c(eta)
     B, H, W, _ = [int(v) for v in eta.shape]
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -735,7 +734,6 @@ def conv1x1_sq_supported(cin, cout):
 
 def conv1x1_64(x, weight, bias=None, act=ACT_NONE, slope=0.0, hh=None, h_prev=None, out=None):
     """act(W x + bias [+ hh * h_prev]) for a 1x1 convolution C -> C, C = 64 or 128 (mrx_conv1x1_sq)."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     if not conv1x1_sq_supported(Cin, int(weight.shape[0])) or tuple(weight.shape) != (Cin, Cin, 1, 1):
@@ -765,7 +763,6 @@ def conv3x3_wino_supported(Cin, Cout, k, dilation):
 def conv3x3_wino(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
     """3x3 convolution into 64 (or a multiple of 64) channels as Winograd F(2x2,3x3) on the matrix cores (differs from the direct form by
     fp32 round-off, ~2e-7 of the output norm)."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     Cout = int(weight.shape[0])
@@ -796,15 +793,12 @@ def conv3x3_sb(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slo
     fp32 results (the convolution stage of the dominant RIM layer on its own).  Operands: three bf16 terms (six term products per multiply) --
     or, when x carries the bound of its maximum (kept by the convolution that produced it: ops._attach_bound), two fp16 terms scaled by it (three
     term products): mrx_conv3x3_sb_chain.  The operand packs are cached per (storage, version)."""
-    _forget_bound(out)
-    x_in = x
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     L = _lib.lib()
     key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), tuple(weight.stride()), _wcap())
     chain = SB_CHAIN and _lib.arith() == "f16x2"
-    bnd = getattr(x_in, "_mrx_bound", None) if chain else None
-    bound_in = bnd[0] if (bnd is not None and bnd[1] == x_in._version and x is x_in) else None
+    bound_in = _lib.bound_of(x) if chain else None                # (the caller's tensor, or a fresh fp32 copy nothing is known about)
     hit = hit16 = None
     if bound_in is None:
         hit = _PACKS_SB.get(key)
@@ -814,14 +808,14 @@ def conv3x3_sb(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slo
             w = _lib.f32c(weight.detach())
             packed = torch.empty(int(L.mrx_rim_layer2_sb_pack_floats()), dtype=torch.float32, device=w.device)
             _lib.check(L.mrx_rim_layer2_sb_pack(_lib.ptr(w), None, None, _lib.ptr(packed), _lib.stream_ptr()), "mrx_rim_layer2_sb_pack")
-            hit = (packed, weight)                              # (keeps the source tensor alive: its data_ptr cannot be recycled)
+            hit = (packed, weight.detach())                     # (the detached alias pins the STORAGE: its address cannot be recycled, even if p.data is re-pointed)
             _PACKS_SB[key] = hit
     else:
         hit16 = _PACKS_SB_F16.get(key)
         if hit16 is None:
             if len(_PACKS_SB_F16) >= 256:
                 _PACKS_SB_F16.clear()
-            hit16 = (rim_layer2_f16_pack(weight, None, None), weight)
+            hit16 = (rim_layer2_f16_pack(weight, None, None), weight.detach())
             _PACKS_SB_F16[key] = hit16
     b = _lib.f32c(bias.detach()) if bias is not None else None
     if out is None:
@@ -849,7 +843,6 @@ def conv_sbs_supported(Cin, Cout, k, dilation):
 def conv_sbs(x, weight, bias, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
     """3x3 / 5x5 convolution (dilation 1) of Cin <= 8 channels into Cout <= 128 + bias + activation on the bf16 matrix pipe with fp32 results
     (mrx_conv_sbs: three-term operand split, two taps per MFMA): the first layers of the cascades.  Pack cached per (storage, version)."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     Cout, _, k, _ = [int(v) for v in weight.shape]
@@ -861,7 +854,7 @@ def conv_sbs(x, weight, bias, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=No
         w = _lib.f32c(weight.detach())
         packed = torch.empty(int(_lib.lib().mrx_conv_sbs_pack_floats(Cout, k)), dtype=torch.float32, device=w.device)
         _lib.check(_lib.lib().mrx_conv_sbs_pack(_lib.ptr(w), _lib.ptr(packed), Cin, Cout, k, _lib.stream_ptr()), "mrx_conv_sbs_pack")
-        hit = (packed, weight)
+        hit = (packed, weight.detach())
         _PACKS_SBS[key] = hit
     b = _lib.f32c(bias.detach()) if bias is not None else None
     if out is None:
@@ -884,7 +877,6 @@ def conv3x3_taps(x, weight, bias, pad_mode=PAD_ZERO, out=None):
     """3x3 convolution (dilation 1) of C = 64 / 128 channels into Cout <= 4 as a per-pixel channel contraction C -> 9 Cout on the matrix cores
     (the square 1x1 kernel, tap rows [tap * Cout + co] padded to C) + a nine-tap gather (mrx_taps_gather): the direct form costs 18 Cout
     vector FMAs per (pixel, input channel) -- qRIM's 128 -> 4 final layer at 256 x 256: 75 us."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     Cout = int(weight.shape[0])
@@ -895,7 +887,7 @@ def conv3x3_taps(x, weight, bias, pad_mode=PAD_ZERO, out=None):
             _TAPS_W.clear()
         wp = torch.zeros(Cin, Cin, 1, 1, dtype=torch.float32, device=weight.device)
         wp[:9 * Cout] = _lib.f32c(weight.detach()).reshape(Cout, Cin, 9).permute(2, 0, 1).reshape(9 * Cout, Cin, 1, 1)
-        w1 = (wp, weight)                                   # (the entry keeps the source tensor alive: its data_ptr cannot be recycled)
+        w1 = (wp, weight.detach())                          # (the detached alias pins the storage: its address cannot be recycled)
         _TAPS_W[key] = w1
     if Cin == 128:                           # only the first 64 of the 128 padded rows are needed (9 Cout <= 36)
         taps = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
@@ -922,7 +914,6 @@ def conv3x3_h_supported(Cin, Cout, k, dilation):
 def conv3x3_h(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None, bound=None):
     """act(conv3x3(x) + bias) for any channel counts on two-term fp16 operands (mrx_conv3x3_h; csrc/unet_f16.hip).  `bound`: device scalar
     >= max |x| (default: the one x carries, else measured by mrx_max_abs)."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     weight = _lib.f32c(weight.detach())
@@ -947,7 +938,6 @@ def conv3x3_h(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slop
 
 def conv2d(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=None):
     """'same' conv, stride 1, square odd kernel (mrx_conv2d; 3x3 into 64 channels: mrx_conv3x3_wino)."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     _lib.require_gpu(weight)
     B, Cin, H, W = _nchw(x)
@@ -1276,7 +1266,6 @@ def conv_to_complex(x, weight, bias, dilation=1, pad_mode=PAD_ZERO):
 
 
 def indrnn_cell(x, w_ih, b_ih, hh, h_prev, dilation=1, out=None):
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     F, Cin_w, k, _ = [int(v) for v in w_ih.shape]
@@ -1297,7 +1286,6 @@ def indrnn_cell(x, w_ih, b_ih, hh, h_prev, dilation=1, out=None):
 
 def rim_layer_indrnn(x, w_conv, b_conv, k, dilation, w_ih, b_ih, hh, h_prev, out=None):
     """Fused ConvNonlinear(ReLU, replicate pad) + IndRNNCell(1x1)."""
-    _forget_bound(out)
     x, w_conv, w_ih = _lib.f32c(x), _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
     B, Cin, H, W = _nchw(x)
     F = int(w_conv.shape[0])
@@ -1338,7 +1326,6 @@ def rim_layer1_xmax_supported(Cin, F, k, dilation):
 def rim_layer_indrnn_packed(x, packed, F, k, dilation, b_conv, b_ih, hh, h_prev, out=None, xmax=None):
     """Tuned fused ConvNonlinear(ReLU, replicate pad) + IndRNNCell(1x1) on pre-packed weights.  `xmax` (one-element float32 device tensor):
     the maximum of the outputs is folded into it with an atomic max (mrx_rim_layer_indrnn_packed_xmax)."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -1382,7 +1369,6 @@ def rim_layer2_sb_pack(w_conv, w_ih, w_final=None):
 def rim_layer2_sb(x, packed, b_conv, b_ih, hh, h_prev, out=None):
     """ReLU(W_ih ReLU(conv3x3 dilation 2 (replicate pad)(x) + b_conv) + b_ih + hh * h_prev), 64 features, on the bf16 matrix pipe with fp32
     results (mrx_rim_layer2_sb).  `out` may be h_prev itself (state updated in place: every element is read by the lane that writes it)."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -1399,7 +1385,6 @@ def rim_layer2_sb(x, packed, b_conv, b_ih, hh, h_prev, out=None):
 def rim_layer2_sb_taps(x, packed, b_conv, b_ih, hh, h_prev, taps=None, out=None):
     """rim_layer2_sb that also leaves the final convolution's per-pixel tap products [B,18,H,W] (mrx_rim_layer2_sb_taps); `packed` from
     rim_layer2_sb_pack(..., w_final).  `out` may be h_prev itself (state updated in place).  Returns (h_new, taps)."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -1436,7 +1421,6 @@ def rim_layer2_f16(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps=None, out=Non
     """rim_layer2_sb / rim_layer2_sb_taps with the convolution's operands as two fp16 terms (mrx_rim_layer2_f16: half the MFMAs).  `xmax`: a
     one-element float32 device tensor holding an upper bound of max |x| (kept by the producer of x: rim_layer_indrnn_packed*(xmax=...)).
     Returns h_new, or (h_new, taps) with want_taps."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, C, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -1474,7 +1458,6 @@ def cb8_to_nchw(y):
 def rim_layer1_cb8(x, eta, part, nparts, sigma, packed, b_conv, b_ih, hh, h_prev, xmax, out=None):
     """First RIM layer on channel-blocked states (mrx_rim_layer1_cb8): input x [B,Cin<=4,H,W] (eta None) or (eta [B,H,W,2], coil-group partial
     sums) as rim_layer_indrnn_packed_llg; h_prev / result [B,8,H,W,8]; keeps the running bound `xmax` of its outputs."""
-    _forget_bound(out)
     if eta is not None:
         eta = _lib.f32c(eta)
         B, H, W, _ = [int(v) for v in eta.shape]
@@ -1496,7 +1479,6 @@ def rim_layer1_cb8(x, eta, part, nparts, sigma, packed, b_conv, b_ih, hh, h_prev
 
 def rim_layer2_f16_cb8(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps=None, out=None, want_taps=False):
     """rim_layer2_f16 on channel-blocked tensors (mrx_rim_layer2_f16_cb8; x, h_prev, result [B,8,H,W,8]; taps [B,18,H,W] as rim_layer2_f16)."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, Q, H, W, E = [int(v) for v in x.shape]
     if Q != 8 or E != 8:
@@ -1531,7 +1513,6 @@ def rim_final_gather(taps, b_final, eta):
 def rim_layer2_sb_final(x, packed, b_conv, b_ih, hh, h_prev, b_final, eta, work=None, out=None):
     """Second RIM layer and the final convolution + eta update (rim_block.py:233-246): returns (h_new [B,64,H,W],
     eta + permute(conv3x3_reppad(h_new) + b_final) [B,H,W,2]).  `packed` from rim_layer2_sb_pack(..., w_final)."""
-    _forget_bound(out)
     if tuple(eta.shape) != (int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), 2):
         raise ValueError("rim_layer2_sb_final expects eta of shape [B,H,W,2]")
     h_new, taps = rim_layer2_sb_taps(x, packed, b_conv, b_ih, hh, h_prev, work, out)
@@ -1553,7 +1534,6 @@ def rim_layer_wino_pack(w_conv, w_ih):
 
 def rim_layer_indrnn_wino(x, packed, F, b_conv, b_ih, hh, h_prev, out=None):
     """Winograd fused ConvNonlinear(3x3, dilation 2, ReLU, replicate pad) + IndRNNCell(1x1) on pre-transformed weights."""
-    _forget_bound(out)
     x = _lib.f32c(x)
     B, Cin, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
@@ -2007,26 +1987,17 @@ def _analytic_bound(n, device):
     return t
 
 
-def _forget_bound(t):
-    """The library writes through raw pointers and never bumps a tensor's version: an op that fills a caller-supplied `out` must drop the bound a
-    previous producer attached to that tensor object, or the next two-term fp16 convolution would scale its operands by a stale maximum."""
-    if t is not None:
-        t.__dict__.pop("_mrx_bound", None)
-
-
 def _attach_bound(t, bound):
-    """Remember a device scalar >= max |t| on the tensor object, with the tensor version it belongs to (an in-place torch op invalidates it)."""
-    t._mrx_bound = (bound, t._version)
-    return t
+    """Leave a device scalar >= max |t| for the consumers of t (_lib.bound_attach: a table of memory ranges owned by the binding; every library
+    call that may write a range drops the entries overlapping it, a torch write bumps the version the entry remembers)."""
+    return _lib.bound_attach(t, bound)
 
 
 def _plain_bound(x):
-    """Device scalar >= max |x| of a plain tensor: the bound its producer attached (unet_cnorm_pad, unet_avg_pool2x2, the 128-channel 1x1 cell
-    kernel) if the tensor has not been written by torch since, else measured (mrx_max_abs)."""
-    b = getattr(x, "_mrx_bound", None)
-    if b is not None and b[1] == x._version:
-        return b[0]
-    return max_abs(x).reshape(1)
+    """Device scalar >= max |x| of a plain tensor: the bound its producer left (unet_cnorm_pad, unet_avg_pool2x2, the 128-channel 1x1 cell
+    kernel) if nothing has written the tensor's memory since, else measured (mrx_max_abs)."""
+    b = _lib.bound_of(x)
+    return b if b is not None else max_abs(x).reshape(1)
 
 
 def unet_conv3x3(src_a, src_b, weight, eps=1e-5, slope=0.2):
@@ -2093,8 +2064,8 @@ def unet_avg_pool2x2(src, slope=0.2):
     # an average is bounded by what it averages: sqrt(n) of the normalised planes, or the plain source's own bound (if it has one)
     if nrm is not None:
         _attach_bound(out, _analytic_bound(H * W, x.device))
-    elif getattr(src, "_mrx_bound", None) is not None and src._mrx_bound[1] == src._version:
-        _attach_bound(out, src._mrx_bound[0])
+    elif _lib.bound_of(x) is not None:
+        _attach_bound(out, _lib.bound_of(x))
     return out
 
 

@@ -287,3 +287,72 @@ def test_hot_kernels_keep_their_loads_ahead_of_their_waits(tmp_path):
                 "some loads are waited for one by one again (python tools/probe/load_wait_scan.py)")
             if no_scratch:
                 assert scratch.get(found[0], -1) == 0, f"{found[0]}: {scratch.get(found[0])} bytes of scratch per lane"
+
+
+# ---- round 5: who owns cached host state -----------------------------------------------------------------------------------
+def test_written_pointer_args_cover_every_declared_function():
+    """The binding drops operand bounds for every range a call may write: the positions come from the header's const-ness, so each declared
+    function must parse, positions must be pointer slots of the ctypes table, and the known producers / consumers must come out right."""
+    w = _lib.written_pointer_args()
+    assert set(w) == set(_lib._SIGNATURES)
+    for name, pos in w.items():
+        args = _lib._SIGNATURES[name][0]
+        assert all(i < len(args) and args[i] is _lib._p for i in pos), name
+    assert w["mrx_conv3x3_sb_chain"] == (4, 6) and w["mrx_conv3x3_h"] == (4,) and w["mrx_fft2"] == (1,) and w["mrx_version"] == ()
+    assert w["mrx_rim_layer2_f16_cb8"] == (6, 7)          # h_new and taps, not xmax (read)
+    L = _lib.lib()
+    assert L.mrx_checks_enabled() in (0, 1)
+    assert hasattr(L.mrx_fft2, "raw") and not hasattr(L.mrx_version, "raw")
+
+
+def test_bound_table_is_keyed_on_memory_not_on_objects():
+    """_lib.bound_attach / bound_of / bound_note_write on CPU tensors (the table only looks at addresses, versions and object identity)."""
+    _lib._BOUNDS.clear()
+    t = torch.zeros(4, 64)
+    b = torch.ones(1)
+    _lib.bound_attach(t, b)
+    assert _lib.bound_of(t) is b
+    assert _lib.bound_of(t[:]) is None and _lib.bound_of(t.view(256)) is None          # another object, even over the same bytes: not found
+    _lib.bound_note_write(t.data_ptr() + 4096, t.data_ptr() + 8192)                     # a write next to it
+    assert _lib.bound_of(t) is b
+    p = _lib.ptr(t[2:])                                                                  # the range a call writing a VIEW would report
+    assert (p.lo, p.hi) == (t.data_ptr() + 512, t.data_ptr() + 1024)
+    _lib.bound_note_write(p.lo, p.hi)
+    assert _lib.bound_of(t) is None
+    _lib.bound_attach(t, b)
+    t.add_(1.0)                                                                          # a torch write: the version moves
+    assert _lib.bound_of(t) is None
+    _lib.bound_attach(t, b)
+    big = torch.zeros(8, 64)
+    _lib.bound_attach(big[1:5], b)                                                        # (a temporary view: dead at once)
+    assert len(_lib._BOUNDS) == 2 and _lib.bound_of(big[1:5]) is None
+    nc = torch.zeros(6, 10)[:, :4]                                                        # non-contiguous: the extent of its strides
+    assert _lib._span(nc) == (nc.data_ptr(), nc.data_ptr() + (5 * 10 + 4) * 4)
+    for i in range(100):
+        _lib.bound_attach(torch.zeros(3), b)
+    assert len(_lib._BOUNDS) <= 64
+    _lib._BOUNDS.clear()
+
+
+def test_prelu_slope_cache_dies_with_its_module():
+    """The failing sequence behind round 4's one-off 4e-2 error of test_dunet_vs_golden: didn.py kept PReLU slopes in a process-wide dict keyed
+    by id(module) and validated by (weight address, weight version).  A model is dropped, the next model's PReLU gets the freed id, its weight
+    the freed 512-byte block, the version is equal -- and the dead model's slope is served.  Here the collision is forced (same id by
+    construction of the key, same storage through an alias): the cache must live on the module."""
+    import gc
+    from mridc_amd.collections.reconstruction.models.didn import didn
+    a = torch.nn.PReLU(init=0.1)
+    assert didn._prelu_slope(a) == pytest.approx(0.1)
+    assert not hasattr(didn, "_SLOPES"), "a process-wide slope table keyed by id(module)"
+    store = a.weight.detach()                                  # the 'recycled block'
+    del a
+    gc.collect()
+    store.fill_(0.7)
+    b = torch.nn.PReLU(init=0.25)
+    b.weight.data = store                                      # same address, and b.weight._version == 0 as a's was
+    assert didn._prelu_slope(b) == pytest.approx(0.7)
+    with torch.no_grad():
+        b.weight.fill_(0.3)                                    # an in-place update moves the version
+    assert didn._prelu_slope(b) == pytest.approx(0.3)
+    b.weight.data = torch.tensor([0.9])                        # a re-pointed parameter moves the address; the old storage stays pinned
+    assert didn._prelu_slope(b) == pytest.approx(0.9)
