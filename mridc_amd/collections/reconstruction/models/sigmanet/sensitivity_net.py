@@ -147,8 +147,10 @@ class ComplexNormWrapper(torch.nn.Module):
 
     def forward(self, input):
         norm = self.complex_instance_norm
-        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.model.parameters())):
+        from mridc_amd import diff
+        if diff.active(input, *self.model.parameters(), training=self.training):
             return self._forward_recorded(input)           # the kernels below write raw buffers: their outputs carry no grad_fn
+        # (eval() without torch.no_grad() and without an input gradient keeps the fused kernels: the rule of diff.active)
         norm.set_normalization(input)
         channel_first, shape = norm._channel_first(input)
         return norm._from_channel_first(self.model(channel_first), shape)

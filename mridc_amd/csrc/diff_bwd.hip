@@ -18,11 +18,7 @@
 #include "mrx_common.h"
 
 #define DB_NT 256
-#define DB_CHUNK 8192
-static inline int db_nsplit(long long n) {
-    long long s = (n + DB_CHUNK - 1) / DB_CHUNK;
-    return s < 1 ? 1 : (s > 64 ? 64 : (int)s);
-}
+static inline int db_nsplit(long long n) { return mrx_norm_nsplit(n); }      // the forward's rule (mrx_common.h): k_inorm_bwd_apply indexes ITS work buffer
 static inline unsigned db_grid(long long n) {
     long long g = (n + DB_NT - 1) / DB_NT;
     return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));

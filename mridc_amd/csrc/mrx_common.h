@@ -139,6 +139,13 @@ __device__ __forceinline__ void mrx_reduce_parts(const float* __restrict__ part,
 #define MRX_CONV_TILE_W 32
 
 static inline int mrx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+// The ONE split rule of the per-plane statistics work buffers (unet.hip writes [2][planes][nsplit] partial sums / squared deviations, diff_bwd.hip's
+// instance-norm backward reads rstd back out of the forward's buffer by the same index): both translation units call this, neither has its own copy.
+#define MRX_NORM_CHUNK 8192
+static inline int mrx_norm_nsplit(long long n) {
+    long long s = (n + MRX_NORM_CHUNK - 1) / MRX_NORM_CHUNK;
+    return s < 1 ? 1 : (s > 64 ? 64 : (int)s);
+}
 
 // mask value as the multiplicative factor torch's type promotion gives (bool/uint8 -> float)
 struct MrxMask {

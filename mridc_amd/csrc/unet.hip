@@ -29,11 +29,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // ---- plane statistics, split over many workgroups (a 640x380 plane is 243k floats; one workgroup per plane would leave
 // most of the chip idle).  Three deterministic passes, no atomics: partial sums -> partial squared deviations -> apply.
 // Workspace: 2 * planes * nsplit floats owned by the caller (mrx_norm_work_floats).
-#define UN_CHUNK 8192
-static inline int un_nsplit(long long n) {
-    long long s = (n + UN_CHUNK - 1) / UN_CHUNK;
-    return s < 1 ? 1 : (s > 64 ? 64 : (int)s);
-}
+static inline int un_nsplit(long long n) { return mrx_norm_nsplit(n); }      // (mrx_common.h: shared with the backward in diff_bwd.hip)
 extern "C" int64_t mrx_norm_work_floats(int64_t planes, int64_t n) { return planes < 0 || n < 1 ? -1 : 2 * planes * un_nsplit(n); }
 
 __device__ __forceinline__ void split_range(long long n, int nsplit, int s, long long& a, long long& b) {

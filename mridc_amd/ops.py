@@ -244,14 +244,19 @@ def _llg_parts_buffer(y, sens, mask, centered, normalization, spatial_dims, n):
     """The partial planes of the general-mask gradient at W = 372, [n + 1][B,H,W,2], one buffer per slice (storage, version, capture): planes
     0 .. n - 1 are rewritten by every step (mrx_pfa372_reduce_t4), plane n holds the constant term -A^H M y = -sum_c conj(S) ifft2(mask y)
     (rim_utils.py:53-62 is linear in (k - y)), so the column pass of a step never reads y and the first RIM layer's loader -- which keeps
-    four partial planes in flight and has three at 15 coils -- adds it for free."""
+    four partial planes in flight and has three at 15 coils -- adds it for free.
+
+    LIFETIME: `llg(..., parts=True)` returns views of this buffer; planes 0 .. n - 1 are valid until the next gradient call for the same slice ON THE
+    SAME STREAM (the buffer is keyed on the stream as well, so two streams evaluating one slice do not overwrite each other's planes).  The layer-1
+    loader consumes them before that call; a caller that keeps a step's planes clones them."""
     def make():
         B, C, H, W = _bchw(y)
         buf = torch.empty(n + 1, B, H, W, 2, dtype=torch.float32, device=y.device)
         buf[n] = sens_reduce(y * mask, sens, centered, normalization, spatial_dims)
         buf[n].neg_()
         return buf
-    return _LLG_CONST.get(y, (sens.data_ptr(), sens._version, mask.data_ptr(), mask._version, bool(centered), str(normalization), int(n)), make)
+    return _LLG_CONST.get(y, (sens.data_ptr(), sens._version, mask.data_ptr(), mask._version, bool(centered), str(normalization), int(n),
+                              int(torch.cuda.current_stream().cuda_stream)), make)
 
 
 def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, out=None, work=None, parts=False):
@@ -356,7 +361,12 @@ def llg_prepare(y, centered, normalization, spatial_dims=None):
 
 class Llg372Operands:
     """The loop-invariant operands of the W = 372 one-launch gradient (mrx_llg372) in lane order: yt = IFFT_H(y), the sensitivity
-    maps and the mask, laid out once per slice by `llg372_prepare`; `work` is the partial-sum workspace reused by every step."""
+    maps and the mask, laid out once per slice by `llg372_prepare`; `work` is the partial-sum workspace reused by every step.
+
+    LIFETIME of the partial planes (`llg372(..., parts=True)`, `llg372_gather`, `adjoint_parts` return views of `work`): they are valid until the
+    NEXT gradient call on the same operands object -- every call rewrites planes 0 .. n - 1 in place (only the last, constant plane survives).  The
+    consumer (the first RIM layer's loader) runs on the same stream before that call; a caller that wants to keep a step's planes clones them,
+    and two streams must not share one operands object (llg372_prepare per stream: the bench's streams each prepare their own)."""
     __slots__ = ("ytp", "sp", "maskp", "mask_batched", "B", "C", "H", "centered", "work", "const_norm", "linear")
 
     def __init__(self, ytp, sp, maskp, mask_batched, B, C, H, centered, work, linear=False):

@@ -558,13 +558,16 @@ class GraphedModelStep:
         if schedule is not None:
             self.optimizer.lr = inverse_sqrt_lr(self.optimizer.steps, schedule["max_steps"], schedule["base_lr"], schedule.get("warmup_ratio", 0.1),
                                                 schedule.get("min_lr", 0.0), schedule.get("warmup_steps"))
+        missing = [k for k in self.keys if k not in batch]
+        if missing:
+            raise KeyError(f"GraphedModelStep: the captured step reads {sorted(self.keys)}; this batch lacks {missing} (capture a new step for another batch layout)")
         for k in self.keys:
             if batch[k] is not self.static[k]:
                 self.static[k].copy_(batch[k])
         self.graph.replay()
         world = allreduce_gradients(self.flat.grad)
         self.optimizer.step(grad_scale=1.0 / world)
-        return self.loss
+        return self.loss.clone()           # (self.loss lives in the graph's pool: the next replay overwrites it)
 
 
 class GraphedCirimStep(GraphedModelStep):

@@ -14,9 +14,15 @@ CHAIN_REL_L2 = 1e-4
 # Training (BASELINE config 4): whole-gradient rel-L2 of the HIP tape against each arithmetic of oracle/amp.py -- the same table bench.py records its
 # training parity against (tests/test_host_logic.py keeps the two equal).  bf16 results make the gradient discontinuous in the order of
 # the fp32 sums (a flipped rounding moves a ReLU mask): two CPU restatements of the kernels' arithmetic that differ only in fp32 / fp64 accumulation are
-# 5e-3 apart at 15 x 640 x 372 on the bench's weights (profiles/r04_training_parity_notes.md), hence 3e-2 for `kernel_arithmetic`; every kernel on its
-# own is checked to rounding flips in tests/test_gpu_train_bf16.py.
-TRAIN_TOL = dict(f32=dict(fp32=2e-3), bf16=dict(kernel_arithmetic=3e-2, autocast_bf16=5e-2, fp32=1e-1))
+# 5e-3 apart at 15 x 640 x 372 on the BOOSTED weights (profiles/r04_training_parity_notes.md); every kernel on its own is checked to rounding flips in
+# tests/test_gpu_train_bf16.py.  Round 5: each weight set is bounded near its own measurement (profiles/r04_train_parity_lib244.txt: bench weights
+# 3.5e-4 / 1.9e-3 against kernel_arithmetic / autocast, boosted 6.2e-3 / 7.1e-3) instead of one 3e-2 / 5e-2 pair 5 - 85 x above them, which a 1 - 2 %
+# regression of a fused backward kernel would have passed.  TRAIN_TOL is the bench's weight set (what bench.py reports `within_tolerance` and the
+# measured margin against).
+TRAIN_TOL = dict(f32=dict(fp32=2e-3), bf16=dict(kernel_arithmetic=3e-3, autocast_bf16=6e-3, fp32=1e-1))
+TRAIN_TOL_BOOSTED = dict(f32=dict(fp32=2e-3), bf16=dict(kernel_arithmetic=1.5e-2, autocast_bf16=1.5e-2, fp32=2e-2))
+# ... and every ONE of the 11 gradients on its own (a tensor with |g| ~ 4e-4 of the vector norm cannot hide in the whole-vector figure):
+TRAIN_TOL_PER_TENSOR = dict(bench=dict(kernel_arithmetic=3e-3, autocast_bf16=1e-2), boosted=dict(kernel_arithmetic=6e-2, autocast_bf16=7e-2))
 
 
 class Golden:

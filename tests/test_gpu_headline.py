@@ -623,12 +623,14 @@ def test_one_cascade_training_at_headline_size(dev, precision, weights):
     all 11 parameter gradients -- on TWO sets of weights: the bench's (seed 0, reference initialisation: what `bench.py --train` reports its
     parity on) and a boosted set (seed 5, biases 0.05, recurrent weights x 3: the ReLUs of the recurrence bite).
     fp32: every gradient rel-L2 <= 2e-3.  bf16 (the reference's `precision: 16`): the whole gradient vector against each arithmetic of
-    oracle/amp.py within tests/_util.py TRAIN_TOL -- the kernels' own arithmetic restated on the CPU (tight: a kernel bug shows here),
-    torch.autocast (the reference's semantics) and fp32 (what bf16 costs; the autocast oracle itself sits 1e-2 .. 6e-2 from it)."""
+    oracle/amp.py within tests/_util.py TRAIN_TOL (bench weights) / TRAIN_TOL_BOOSTED -- the kernels' own arithmetic restated on the CPU (tight: a
+    kernel bug shows here), torch.autocast (the reference's semantics) and fp32 (what bf16 costs; the autocast oracle itself sits 1e-2 .. 8e-2 from
+    it) -- AND each of the 11 gradients on its own against the first two (TRAIN_TOL_PER_TENSOR): `rnn.hh` has |g| ~ 4e-4 of the vector norm, a
+    completely wrong hh gradient moves the whole-vector figure by 2e-4."""
     from mridc_amd import autograd as ag
     from mridc_amd import training
     from mridc_amd.collections.reconstruction.models.cirim import CIRIM
-    from tests._util import TRAIN_TOL
+    from tests._util import TRAIN_TOL, TRAIN_TOL_BOOSTED, TRAIN_TOL_PER_TENSOR
     cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=1)
     seed, sl = (0, 0) if weights == "bench" else (5, 7)
     torch.manual_seed(seed)
@@ -670,5 +672,12 @@ def test_one_cascade_training_at_headline_size(dev, precision, weights):
         assert errs["fp32"][1] <= 1e-5, errs
         for n_ in names:
             assert_close(grads[n_].grad, refs["fp32"][1][n_], 2e-3, f"gradient of {n_} at 15 x 640 x 372")
-    for m_, tol in TRAIN_TOL[precision].items():
+    for m_, tol in (TRAIN_TOL if weights == "bench" else TRAIN_TOL_BOOSTED)[precision].items():
         assert errs[m_][0] <= tol and errs[m_][1] <= 2e-2, (m_, errs)
+    if precision == "bf16":
+        per = {m_: {n_: float((grads[n_].grad.detach().cpu().reshape(-1).double() - refs[m_][1][n_].reshape(-1).double()).norm()
+                              / refs[m_][1][n_].reshape(-1).double().norm()) for n_ in names} for m_ in TRAIN_TOL_PER_TENSOR[weights]}
+        print("per tensor:", {m_: {n_.replace("cirim.0.", ""): f"{e_:.2e}" for n_, e_ in d_.items()} for m_, d_ in per.items()})
+        for m_, tol in TRAIN_TOL_PER_TENSOR[weights].items():
+            worst = max(per[m_], key=per[m_].get)
+            assert per[m_][worst] <= tol, (m_, worst, per[m_][worst], tol)
