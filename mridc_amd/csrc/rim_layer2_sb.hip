@@ -26,6 +26,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define S2_NT 512
 #define S2_BAR_STEP 4      // even chunks: the step before which the paired ninth-tap operands become visible (barrier); 3 = one step earlier, operands prefetched (measured equal)
 #define S2_COMMIT_EVEN 1   // even chunks: the step after which the next chunk is split and written (0 measured equal)
+#ifdef MRX_L2_ROWS2
+#define S2_ROWS2 true      // (A/B switch of round 5: the F16 + CB8 row tails with both rows of a wave through the 1x1 and tap stages together)
+#else
+#define S2_ROWS2 false
+#endif
+#ifdef MRX_L2_NEWST
+#define S2_NEWST_ON true   // (A/B switch of round 5: branch-free staging through buffer descriptors, sliced between the MFMAs of steps 2 and 3)
+#else
+#define S2_NEWST_ON false
+#endif
 #define S2_TH 16
 #define S2_TW 32
 #define S2_F 64
@@ -70,6 +80,16 @@ __device__ __forceinline__ void s2_split2h(float a, float b, unsigned& p1, unsig
     const f16x2 l = {(_Float16)ra, (_Float16)rb};
     p1 = __builtin_bit_cast(unsigned, h);
     p2 = __builtin_bit_cast(unsigned, l);
+}
+// the same two terms of (a s, b s) for a power-of-two scale s, in FOUR instructions: the fp32 multiply, the conversion and the subtraction of each
+// term are one v_fma_mix{lo,hi}_f16 (a s and a s - h are exact in fp32, so the single rounding of the fused form is the rounding of s2_split2h:
+// bit-identical).  hipcc forms these from s2_split2h(a * s, b * s) when s is wave-uniform; with a per-lane scale it emits v_mul, v_cvt_pk,
+// v_fma_mix_f32, v_cvt_pk -- six per pair (round 5: the row tails are issue-bound, ~7 cycles per instruction that is not under an MFMA).
+__device__ __forceinline__ void s2_split2h_scaled(float a, float b, float s, unsigned& p1, unsigned& p2) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(p1) : "v"(a), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(p1) : "v"(b), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(p2) : "v"(a), "v"(s), "v"(p1));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(p2) : "v"(b), "v"(s), "v"(p1));
 }
 // 2^e as a float, e clamped to the normal range
 __device__ __forceinline__ float s2_pow2(int e) {
@@ -337,10 +357,22 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         const int tc = s2_chan(tid >> 1, tid & 1);
         const int ti = (tid & 1) * 32 + (tid >> 1);
         tabl[ti] = a.hh ? a.hh[tc] : 0.f;
-        tabl[64 + ti] = a.b_conv ? a.b_conv[tc] : 0.f;
+        // F16 + TAIL: the convolution's accumulators START from the bias in their own (scaled) domain, b 2^kx 2^kw -- exact -- and are never scaled
+        // back: the 1x1 stage's per-pixel exponent is taken from them as they are (round 5: 128 multiply-adds and 8 LDS reads per wave and tile less)
+        tabl[64 + ti] = a.b_conv ? a.b_conv[tc] * ((F16 && TAIL) ? sx * s2_pow2((int)a.packed[S2F_PACK_U4 - 1][0]) : 1.f) : 0.f;
         tabl[128 + ti] = a.b_ih ? a.b_ih[tc] : 0.f;
     }
 
+    // NEWST (round 5): the staging without a branch and without per-chunk address arithmetic.  The fp32 tile and the weight operands arrive through
+    // buffer descriptors (per-thread byte offsets made once per tile, the chunk in the scalar offset), threads whose second pixel / third weight
+    // operand does not exist write a dummy LDS slot instead of skipping the write, and the split + LDS writes of chunk q + 1 and the requests of
+    // chunk q + 2 are cut into slices that sit BETWEEN the MFMAs of steps 2 and 3 of chunk q (pinned with sched_barrier): the chunk loop is one
+    // basic block per step, and the ~120 vector / memory instructions per chunk issue in the shadow of 24 MFMAs instead of in a clump that both
+    // waves of a SIMD reach at the same time.
+    constexpr bool NEWST = S2_NEWST_ON && F16 && CB8 && TAIL && !W4 && ABL == 0 && !ZP;
+    // LDS strides in 16-byte slots: a term plane and a weight buffer carry ONE extra slot at their end in the NEWST layout -- the dummy that threads
+    // without a second pixel / third weight operand write (both term writes of such a thread land in their plane's dummy: same immediate offsets)
+    constexpr int PSTR = NEWST ? S2_NPIX + 1 : S2_NPIX, XBUF = NT * PSTR, WBUF = NEWST ? WCH + 1 : WCH;
     // staging roles: thread i owns pixels i and i + 512 of the halo'd tile (8 channels of the chunk) and copies <= 4 weight operands
     constexpr int XV = (S2_NPIX + NTHR - 1) / NTHR;                 // 2
     constexpr int WV = (WCH + NTHR - 1) / NTHR;                     // 4 (F16: 3)
@@ -351,8 +383,37 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
     int st_t = blockIdx.x, st_q = 0;                 // the next chunk to request: tile index, chunk
     const float* st_xb = a.x;
     long long goff[XV];
+    unsigned goff32[XV];                             // NEWST: byte offset of this thread's pixels inside the sample's channel-blocked tensor (chunk 0)
+    __amdgpu_buffer_rsrc_t st_rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)(plane * (S2_F * 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t st_rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.packed), 0, (unsigned)(PK_TAIL * 16), 0x00020000);
+    unsigned st_tid16 = 0, st_px1 = 0, st_w2 = 0;    // NEWST: LDS byte offsets inside a buffer: first pixel / first weight operand; second pixel and third weight operand (or the dummy slots)
+    if constexpr (NEWST) {
+        const unsigned t_ = (unsigned)(wave * 64 + lane_now());
+        st_tid16 = t_ * 16u;
+        st_px1 = (t_ + NTHR < (unsigned)S2_NPIX ? t_ + NTHR : (unsigned)S2_NPIX) * 16u;
+        st_w2 = (t_ + 2 * NTHR < (unsigned)WCH ? t_ + 2 * NTHR : (unsigned)WCH) * 16u;
+    }
     unsigned zmask = 0, zpend = 0;                   // ZP: this thread's pixels outside the image (of the next request / of the pending chunk)
     auto st_coords = [&]() {
+        if constexpr (NEWST) {
+            // (beyond the last tile the pipeline keeps requesting -- the last tile again: the loads stay in range and nobody reads what they bring)
+            const int tq = st_t < total ? st_t : total - 1;
+            const int tt = (int)mrx_xcd_band(tq, total);
+            const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
+            const int h0 = ty0 * TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
+            st_rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (long long)b * S2_F * plane, 0, (unsigned)(plane * (S2_F * 4)), 0x00020000);
+#pragma unroll
+            for (int v = 0; v < XV; ++v) {
+                int p = (wave * 64 + lane_now()) + v * NTHR;
+                p = p < S2_NPIX ? p : S2_NPIX - 1;
+                const int ty = p / S2_PW, tx = p - ty * S2_PW;
+                int gy = h0 + ty - S2_PAD, gx = w0 + tx - S2_PAD;
+                gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                goff32[v] = (unsigned)(gy * a.W + gx) * 32u;
+            }
+            return;
+        }
         if (st_t >= total) return;
         const int tt = (int)mrx_xcd_band(st_t, total);
         const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
@@ -441,10 +502,55 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
             else if (i < WCH) Wc[buf * WCH + i] = wr[v];
         }
     };
+    // NEWST pieces: the loads of one chunk (x: two 16-byte halves per pixel; weights: three operands), the split of one channel pair group, the LDS writes
+    auto ns_load_x = [&](int v, int half) {
+        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(st_rx, goff32[v] + 16u * half, (unsigned)st_q * (unsigned)(plane * 32), 0);
+        xr[v][4 * half] = __uint_as_float(u[0]), xr[v][4 * half + 1] = __uint_as_float(u[1]);
+        xr[v][4 * half + 2] = __uint_as_float(u[2]), xr[v][4 * half + 3] = __uint_as_float(u[3]);
+    };
+    auto ns_load_w = [&](int v) { wr[v] = __builtin_amdgcn_raw_buffer_load_b128(st_rw, st_tid16, (unsigned)(st_q * WCH + v * NTHR) * 16u, 0); };
+    auto ns_advance = [&]() {                        // after the last load of a chunk
+        if (++st_q == S2_NCH) {
+            st_q = 0;
+            st_t += gridDim.x;
+            st_coords();
+        }
+    };
+    unsigned ns_p1[XV][4], ns_p2[XV][4];
+    auto ns_split = [&](int v, int k) { s2_split2h_scaled(xr[v][2 * k], xr[v][2 * k + 1], sx, ns_p1[v][k], ns_p2[v][k]); };
+    auto ns_write_x = [&](int buf, int v) {
+        unsigned char* base = smem_s2 + OFF_X + buf * (XBUF * 16) + (v == 0 ? st_tid16 : st_px1);
+        *reinterpret_cast<u32x4*>(base) = u32x4{ns_p1[v][0], ns_p1[v][1], ns_p1[v][2], ns_p1[v][3]};
+        *reinterpret_cast<u32x4*>(base + PSTR * 16) = u32x4{ns_p2[v][0], ns_p2[v][1], ns_p2[v][2], ns_p2[v][3]};
+    };
+    auto ns_write_w = [&](int buf, int v) {
+        *reinterpret_cast<u32x4*>(smem_s2 + OFF_W + buf * (WBUF * 16) + (v < 2 ? st_tid16 + (unsigned)(v * NTHR * 16) : st_w2)) = wr[v];
+    };
     st_coords();
-    request_next();
-    commit_next(0);
-    request_next();
+    if constexpr (NEWST) {
+        static_assert(!NEWST || (XV == 2 && WV == 3), "the NEWST slices are written for two pixels and three weight operands per thread");
+        for (int pre = 0; pre < 2; ++pre) {          // chunk 0 requested, split, written; chunk 1 requested
+#pragma unroll
+            for (int v = 0; v < XV; ++v) ns_load_x(v, 0), ns_load_x(v, 1);
+#pragma unroll
+            for (int v = 0; v < WV; ++v) ns_load_w(v);
+            ns_advance();
+            if (pre == 0) {
+#pragma unroll
+                for (int v = 0; v < XV; ++v) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ns_split(v, k);
+                    ns_write_x(0, v);
+                }
+#pragma unroll
+                for (int v = 0; v < WV; ++v) ns_write_w(0, v);
+            }
+        }
+    } else {
+        request_next();
+        commit_next(0);
+        request_next();
+    }
     __syncthreads();                                 // chunk 0 of the first tile, the 1x1 weights and the tables are in place
 
     float vmax = 0.f;                                // TAIL = false: maximum |output| of this lane (a.xmax_out)
@@ -455,7 +561,13 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
         const int h0 = ty0 * TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
 
+        // (cycle stamps exist in PROBE builds only: even when skipped at run time, each one is a branch that cuts the row tails into separate basic
+        // blocks -- the scheduler cannot then place row 1's vector work under row 0's MFMAs)
+#ifdef MRX_PROBE
 #define S2_STAMP(i) if (a.trace && lane == 0 && (t - (int)blockIdx.x) / (int)gridDim.x < 2) a.trace[(((long long)blockIdx.x * 8 + wave) * 2 + (t - blockIdx.x) / gridDim.x) * 4 + (i)] = __builtin_readcyclecounter();
+#else
+#define S2_STAMP(i)
+#endif
         S2_STAMP(0)
         // acc[row][ct]: rows 2 wave and 2 wave + 1 of the tile
         f32x16 acc[2][2];
@@ -464,7 +576,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rw][ct][r] = F16 ? 0.f : tabl[64 + lhi * 32 + ct * 16 + r];
+                for (int r = 0; r < 16; ++r) acc[rw][ct][r] = (F16 && !TAIL) ? 0.f : tabl[64 + lhi * 32 + ct * 16 + r];
 
         float hp[2][32];
         auto load_hp = [&](int rw) {              // lanes outside the image read a valid element (clamped) and store nothing
@@ -493,14 +605,14 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         };
         auto toff = [](int tp) { return tp < 9 ? (tp / 3) * DIL * S2_PW + (tp % 3) * DIL : 0; };  // the zero-weight slot reads pixel 0
         for (int q = 0; q < S2_NCH; ++q) {
-            const u32x4* xw = Xp + (q & 1) * (NT * S2_NPIX) + (2 * wave) * S2_PW + l31;
-            const u32x4* wl = Wc + (q & 1) * WCH + lane;
+            const u32x4* xw = Xp + (q & 1) * XBUF + (2 * wave) * S2_PW + l31;
+            const u32x4* wl = Wc + (q & 1) * WBUF + lane;
             // Ninth tap: chunks are paired.  The fifth step of an EVEN chunk multiplies tap 8 of this chunk (lower half-wave) and tap 8 of the
             // NEXT chunk (upper half-wave: its planes and weights were committed at step 1 of this chunk -- hence the extra barrier before
             // they are fetched); an odd chunk has four steps.  36 instead of 40 MFMA steps per tile, no padding slot.
             const bool even = !(q & 1);
-            const u32x4* xw8 = Xp + ((q + lhi) & 1) * (NT * S2_NPIX) + (2 * wave) * S2_PW + l31 + toff(8);
-            const u32x4* w8 = Wc + ((q + lhi) & 1) * WCH + WFULL + l31;
+            const u32x4* xw8 = Xp + ((q + lhi) & 1) * XBUF + (2 * wave) * S2_PW + l31 + toff(8);
+            const u32x4* w8 = Wc + ((q + lhi) & 1) * WBUF + WFULL + l31;
             u32x4 bt[2][2][NT], at[2][2][NT];     // [buffer][row | ct][term]
             auto fetch = [&](int s, int bf) {
                 if constexpr ((ABL & 32) != 0) {
@@ -516,16 +628,16 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
                     const int off = lhi ? toff(2 * s + 1) : toff(2 * s);
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
-                        bt[bf][0][k] = xw[k * S2_NPIX + off];
-                        bt[bf][1][k] = xw[k * S2_NPIX + off + S2_PW];
+                        bt[bf][0][k] = xw[k * PSTR + off];
+                        bt[bf][1][k] = xw[k * PSTR + off + S2_PW];
                         at[bf][0][k] = wl[((s * NT + k) * 2 + 0) * 64];
                         at[bf][1][k] = wl[((s * NT + k) * 2 + 1) * 64];
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
-                        bt[bf][0][k] = xw8[k * S2_NPIX];
-                        bt[bf][1][k] = xw8[k * S2_NPIX + S2_PW];
+                        bt[bf][0][k] = xw8[k * PSTR];
+                        bt[bf][1][k] = xw8[k * PSTR + S2_PW];
                         at[bf][0][k] = w8[(k * 2 + 0) * 32];
                         at[bf][1][k] = w8[(k * 2 + 1) * 32];
                     }
@@ -550,6 +662,31 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
                     for (int k = 0; k < NT; ++k)
 #pragma unroll
                         for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(bt[bf][i][k]), "v"(at[bf][i][k]));
+                } else if constexpr (NEWST) {
+                    // the same twelve MFMAs (three products x two rows x two cout blocks, smallest product first), one slice of the side work behind each
+                    constexpr int TA_[3] = {1, 0, 0}, TB_[3] = {0, 1, 0};
+                    const int nb = (q + 1) & 1;
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) {
+                        const int rw = (m >> 1) & 1, ct = m & 1, pr = m >> 2;
+                        acc[rw][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, at[bf][ct][TA_[pr]]), __builtin_bit_cast(f16x8, bt[bf][rw][TB_[pr]]),
+                                                                            acc[rw][ct], 0, 0, 0);
+                        if (s == 4 && m >= 0) {
+                            // (the half step of an even chunk: no side work)
+                        } else if (s == 2) {                     // chunk q + 1: split (fp32 values requested one chunk ago) and written
+                            if (m < 4) ns_split(0, m);
+                            else if (m == 4) ns_write_x(nb, 0);
+                            else if (m < 9) ns_split(1, m - 5);
+                            else if (m == 9) ns_write_x(nb, 1);
+                            else if (m == 10) ns_write_w(nb, 0), ns_write_w(nb, 1);
+                            else ns_write_w(nb, 2);
+                        } else if (s == 3) {                     // chunk q + 2 requested
+                            if (m < 4) ns_load_x(m >> 1, m & 1);
+                            else if (m < 7) ns_load_w(m - 4);
+                            else if (m == 7) ns_advance();
+                        }
+                        if (s == 2 || s == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
                 } else if constexpr (F16) {
                     // two fp16 terms per operand: the three products of weight >= 2^-11, smallest first
 #define S2_PH16(TA, TB)                                                                                                                    \
@@ -563,7 +700,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
 #undef S2_P
                 // (committing one step later in the second wave of each SIMD -- so that one wave's vector-ALU block meets the other's MFMAs --
                 // measured equal: 69.0 vs 67.3 us, lib 226)
-                if (s == (even ? S2_COMMIT_EVEN : 1)) {   // the readers of the other buffer passed the previous barrier
+                if (!NEWST && s == (even ? S2_COMMIT_EVEN : 1)) {   // the readers of the other buffer passed the previous barrier
                     commit_next((q + 1) & 1);
                     request_next();
                 }
@@ -572,13 +709,14 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
             if constexpr (!(ABL & 64)) __syncthreads();
         }
 
-        if constexpr (F16) {
+        if constexpr (F16 && !TAIL) {
+            const float unxw = unx * unw;
 #pragma unroll
             for (int rw = 0; rw < 2; ++rw)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[rw][ct][r] = acc[rw][ct][r] * unx * unw + tabl[64 + lhi * 32 + ct * 16 + r];
+                    for (int r = 0; r < 16; ++r) acc[rw][ct][r] = acc[rw][ct][r] * unxw + tabl[64 + lhi * 32 + ct * 16 + r];
         }
         S2_STAMP(1)
         if constexpr ((ABL & 16) != 0) {
@@ -586,6 +724,135 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
             for (int rw = 0; rw < 2; ++rw)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) asm volatile("" ::"v"(acc[rw][ct]));
+        } else if constexpr (TAIL && F16 && CB8 && S2_ROWS2) {
+        // ---- both rows of the wave through the 1x1 stage TOGETHER (round 5) ----------------------------------------------------------------------
+        // The row tails are issue-bound, not matrix-bound: 72 MFMAs in ~1 500 instructions, the two waves of a SIMD in the same phase.  Here a
+        // weight fragment read from LDS serves both rows (half the A reads), every MFMA step has four independent accumulators, row 1's operand
+        // split sits next to row 0's MFMAs in ONE basic block (stores go through buffer descriptors with an out-of-range offset for pixels outside
+        // the image instead of a branch), and the same for the tap stage.  Per accumulator the order of the term products is the row-by-row
+        // form's: bit-identical results.
+        const int oy0 = h0 + 2 * wave, ox = w0 + l31;
+        float sg[2], ung[2];
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw) {
+            float gm = 0.f;
+#pragma unroll
+            for (int R = 0; R < 32; ++R) gm = fmaxf(gm, acc[rw][R >> 4][R & 15]);
+            const int kg = s2_pixel_exp(gm);
+            sg[rw] = s2_pow2(kg), ung[rw] = s2_pow2(-kg) * (unx * unw * unwi);
+        }
+        f32x16 acc2[2][2];
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[rw][ct][r] = 0.f;
+        {
+            const u32x4* wl = Wih + lane;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f16x8 b1[2], b2[2];
+#pragma unroll
+                for (int rw = 0; rw < 2; ++rw) {
+                    unsigned g1[4], g2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int R0 = 8 * s + 2 * k, R1 = R0 + 1;
+                        float v0 = acc[rw][R0 >> 4][R0 & 15], v1 = acc[rw][R1 >> 4][R1 & 15];
+                        v0 = v0 > 0.f ? v0 : 0.f;
+                        v1 = v1 > 0.f ? v1 : 0.f;
+                        s2_split2h_scaled(v0, v1, sg[rw], g1[k], g2[k]);
+                    }
+                    b1[rw] = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
+                    b2[rw] = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
+                }
+                f16x8 at[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) at[ct][k] = __builtin_bit_cast(f16x8, wl[((s * 2 + k) * 2 + ct) * 64]);
+#pragma unroll
+                for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc2[rw][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(at[ct][1], b1[rw], acc2[rw][ct], 0, 0, 0);
+#pragma unroll
+                for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc2[rw][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(at[ct][0], b2[rw], acc2[rw][ct], 0, 0, 0);
+#pragma unroll
+                for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc2[rw][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(at[ct][0], b1[rw], acc2[rw][ct], 0, 0, 0);
+                if (s == 1) load_hp(1);          // (half of the convolution's accumulators are dead by now: row 1's state can land in their registers)
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hnew + (long long)b * S2_F * plane, 0, (unsigned)(plane * (S2_F * 4)), 0x00020000);
+        unsigned offh[2];
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw) {
+            const int oy = oy0 + rw;
+            offh[rw] = (oy < a.H && ox < a.W) ? (unsigned)((((long long)oy * a.W + ox) * 8 + 4 * lhi) * 4) : 0x80000000u;
+#pragma unroll
+            for (int R = 0; R < 32; ++R) {
+                float v = acc2[rw][R >> 4][R & 15] * ung[rw] + tabl[128 + lhi * 32 + R];
+                v += tabl[lhi * 32 + R] * hp[rw][R];
+                hp[rw][R] = v > 0.f ? v : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(hp[rw][4 * q]), __float_as_uint(hp[rw][4 * q + 1]), __float_as_uint(hp[rw][4 * q + 2]),
+                                                             __float_as_uint(hp[rw][4 * q + 3])},
+                                                       rh, offh[rw] + (unsigned)q * (unsigned)(plane * 32), 0, 0);
+        }
+        if (a.P) {
+            f32x16 accp[2];
+            float sh[2], unh[2];
+#pragma unroll
+            for (int rw = 0; rw < 2; ++rw) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[rw][r] = 0.f;
+                float hm = 0.f;
+#pragma unroll
+                for (int R = 0; R < 32; ++R) hm = fmaxf(hm, hp[rw][R]);
+                const int kh = s2_pixel_exp(hm);
+                sh[rw] = s2_pow2(kh), unh[rw] = s2_pow2(-kh) * unwp;
+            }
+            const u32x4* wp = Wih + S2_WIH + lane;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f16x8 b1[2], b2[2];
+#pragma unroll
+                for (int rw = 0; rw < 2; ++rw) {
+                    unsigned g1[4], g2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s2_split2h_scaled(hp[rw][8 * s + 2 * k], hp[rw][8 * s + 2 * k + 1], sh[rw], g1[k], g2[k]);
+                    b1[rw] = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
+                    b2[rw] = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
+                }
+                const f16x8 a1 = __builtin_bit_cast(f16x8, wp[(s * 2 + 0) * 64]);
+                const f16x8 a2 = __builtin_bit_cast(f16x8, wp[(s * 2 + 1) * 64]);
+#pragma unroll
+                for (int rw = 0; rw < 2; ++rw) accp[rw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1[rw], accp[rw], 0, 0, 0);
+#pragma unroll
+                for (int rw = 0; rw < 2; ++rw) accp[rw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2[rw], accp[rw], 0, 0, 0);
+#pragma unroll
+                for (int rw = 0; rw < 2; ++rw) accp[rw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[rw], accp[rw], 0, 0, 0);
+            }
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.P + (long long)b * 18 * plane, 0, (unsigned)(plane * (18 * 4)), 0x00020000);
+#pragma unroll
+            for (int rw = 0; rw < 2; ++rw) {
+                const int oy = oy0 + rw;
+                const bool inside = oy < a.H && ox < a.W;
+                const unsigned offp = inside ? (unsigned)((((long long)oy * a.W + ox) + 4ll * lhi * plane) * 4) : 0x80000000u;
+                const unsigned offp16 = (inside && !lhi) ? offp : 0x80000000u;       // rows 16, 17: the upper half-wave's 20, 21 do not exist
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[rw][r] * unh[rw]), rp, offp + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)(plane * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[rw][8] * unh[rw]), rp, offp16 + 16u * (unsigned)(plane * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[rw][9] * unh[rw]), rp, offp16 + 17u * (unsigned)(plane * 4), 0, 0);
+            }
+        }
         } else if constexpr (TAIL) {
         // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev), one of the wave's two rows at a time ------------------
         // (h_prev of row 0 was requested inside the last chunk; row 1's request goes out now and hides under row 0's tail)
@@ -600,12 +867,14 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
                 for (int r = 0; r < 16; ++r) acc2[ct][r] = F16 ? 0.f : tabl[128 + lhi * 32 + ct * 16 + r];
             const u32x4* wl = Wih + lane;
             if constexpr (F16) {
-                // two fp16 terms, scaled per PIXEL: the contraction runs over the pixel's 64 channels only (this lane's 32 and lane ^ 32's)
+                // two fp16 terms, scaled per PIXEL: the contraction runs over the pixel's 64 channels only (this lane's 32 and lane ^ 32's).  The
+                // accumulators hold (conv + b) 2^kx 2^kw; the pixel's exponent is taken from them as they are, and ONE factor per lane takes the 1x1
+                // stage's sums back: 2^-kg 2^-kx 2^-kw 2^-kwi (all exact)
                 float gm = 0.f;
 #pragma unroll
                 for (int R = 0; R < 32; ++R) gm = fmaxf(gm, acc[rw][R >> 4][R & 15]);
                 const int kg = s2_pixel_exp(gm);
-                const float sg = s2_pow2(kg), ung = s2_pow2(-kg);
+                const float sg = s2_pow2(kg), ung = s2_pow2(-kg) * (unx * unw * unwi);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     unsigned g1[4], g2[4];
@@ -615,7 +884,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
                         float v0 = acc[rw][R0 >> 4][R0 & 15], v1 = acc[rw][R1 >> 4][R1 & 15];
                         v0 = v0 > 0.f ? v0 : 0.f;
                         v1 = v1 > 0.f ? v1 : 0.f;
-                        s2_split2h(v0 * sg, v1 * sg, g1[k], g2[k]);
+                        s2_split2h_scaled(v0, v1, sg, g1[k], g2[k]);
                     }
                     const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
                     const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
@@ -629,7 +898,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[ct][r] = acc2[ct][r] * ung * unwi + tabl[128 + lhi * 32 + ct * 16 + r];
+                    for (int r = 0; r < 16; ++r) acc2[ct][r] = acc2[ct][r] * ung + tabl[128 + lhi * 32 + ct * 16 + r];
             } else
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -695,12 +964,12 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
 #pragma unroll
                     for (int R = 0; R < 32; ++R) hm = fmaxf(hm, hp[rw][R]);
                     const int kh = s2_pixel_exp(hm);
-                    const float sh = s2_pow2(kh), unh = s2_pow2(-kh);
+                    const float sh = s2_pow2(kh), unh = s2_pow2(-kh) * unwp;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         unsigned g1[4], g2[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) s2_split2h(hp[rw][8 * s + 2 * k] * sh, hp[rw][8 * s + 2 * k + 1] * sh, g1[k], g2[k]);
+                        for (int k = 0; k < 4; ++k) s2_split2h_scaled(hp[rw][8 * s + 2 * k], hp[rw][8 * s + 2 * k + 1], sh, g1[k], g2[k]);
                         const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
                         const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
                         const f16x8 a1 = __builtin_bit_cast(f16x8, wp[(s * 2 + 0) * 64]);
@@ -710,7 +979,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
                         accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, accp, 0, 0, 0);
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) accp[r] = accp[r] * unh * unwp;
+                    for (int r = 0; r < 10; ++r) accp[r] = accp[r] * unh;          // (rows 0 .. 9 of the lane's 16 are the ones stored)
                 } else
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {

@@ -73,6 +73,10 @@ def test_second_layer_stale_bound(dev):
     pk = ops.rim_layer2_f16_pack(wc, wi, None)
     ref = _layer2_ref(x, wc, bc, wi, bi, hh, hp)
     exact = ops.rim_layer2_f16(x, pk, bc, bi, hh, hp, x.abs().max().reshape(1).contiguous())
+    if ops._lib.lib().mrx_checks_enabled():       # the CHECK build (-DMRX_CHECK_BOUNDS) refuses exactly this: a bound more than 2^16 above the data
+        with pytest.raises(RuntimeError, match="more than 2\\^16 x max"):
+            ops.rim_layer2_f16(x, pk, bc, bi, hh, hp, (x.abs().max() * 1e6).reshape(1).contiguous())
+        return
     stale = ops.rim_layer2_f16(x, pk, bc, bi, hh, hp, (x.abs().max() * 1e6).reshape(1).contiguous())
     e0, e1 = float((exact.double() - ref).norm() / ref.norm()), float((stale.double() - ref).norm() / ref.norm())
     assert e0 <= 6e-7 and e1 <= 8e-6, (e0, e1)

@@ -7,9 +7,12 @@ Part 2 -- the judge's sequence: the heavy-tailed tests followed by the n4 model 
 
   python tools/probe/dunet_repro.py [repeats]"""
 import gc
+import os
 import sys
 
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 _SLOPES = {}
 
