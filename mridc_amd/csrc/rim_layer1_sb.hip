@@ -233,8 +233,13 @@ int mrx_l1sb_pack(const float* w_conv, const float* w_ih, float* packed, int Cin
 // and the constant data term).  Without it the patch code is straight-line -- with it `raw` ended up in scratch memory, written behind `s_waitcnt vmcnt(0)`.
 // LLGT: 1 = the input is (eta, partial planes) -- known at compile time (the run-time test of a.eta2 inside the unrolled slot loops left part of `raw`
 // in scratch memory); -1 = decided at run time.
-template <bool F16, bool CB8 = false, bool MORE = true, int LLGT = -1>
-__global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
+// NW (round 5, A/B): waves per workgroup = image rows per tile.  16: four waves per SIMD at <= 128 registers -- h_prev can only be requested behind the 1x1
+// stage (its 32 registers are g's until then), so every unit waits a full memory latency for it.  12: three waves per SIMD at <= 168 registers,
+// h_prev requested TOGETHER with the unit's patch and landed long before the epilogue needs it.
+template <bool F16, bool CB8 = false, bool MORE = true, int LLGT = -1, int NW = 16>
+__global__ __launch_bounds__(NW * 64, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
+    constexpr int NTHR = NW * 64;
+    constexpr bool HP_EARLY = NW != 16 && CB8;
     constexpr int NT = F16 ? 2 : 3, WCONV = F16 ? SBH_WCONV : SB_WCONV, WIH = F16 ? SBH_WIH : SB_WIH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];
     u32x4* Wl = reinterpret_cast<u32x4*>(smem_sb);                                        // [WCONV + WIH] A operands
@@ -247,11 +252,11 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
     // ---- once per workgroup: weights and tables into LDS ----------------------------------------------------------------------------------
     {
         const u32x4* src = reinterpret_cast<const u32x4*>(a.packed) + (F16 ? SBH_OFF : 0);
-        constexpr int WIT = (WCONV + WIH + SB_NT - 1) / SB_NT;
+        constexpr int WIT = (WCONV + WIH + NTHR - 1) / NTHR;
         u32x4 wreg[WIT];
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
-            const int i = tid + it * SB_NT;
+            const int i = tid + it * NTHR;
             wreg[it] = src[i < WCONV + WIH ? i : WCONV + WIH - 1];
         }
         if (tid < 64) {
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
-            const int i = tid + it * SB_NT;
+            const int i = tid + it * NTHR;
             if (i < WCONV + WIH) Wl[i] = wreg[it];
         }
     }
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
         const int tt = (int)mrx_xcd_band(t, total);
         b = tt / a.ntiles;
         const int tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
-        oy = ty0 * SB_TH + wave;
+        oy = ty0 * NW + wave;
         w0 = (tile - ty0 * a.tiles_x) * SB_TW;
     };
 
@@ -394,10 +399,21 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
         unit_of(t, b, oy, w0);
         if (oy >= a.H) continue;             // wave-uniform: rows past the image (H % 16 != 0)
         float unx = 1.f;
+        float hp[32];
         {
             float raw[SB_PSLOT][10];
             unsigned roff[SB_PSLOT];
             load_patch(b, oy, w0, raw, roff);
+            if constexpr (HP_EARLY) {              // the unit's h_prev, requested behind its patch: both latencies run together, under the other waves' units
+                const int ox_ = w0 + l31, cx_ = ox_ < a.W ? ox_ : a.W - 1;
+                const float* hb_ = (a.hprev ? a.hprev : a.hnew) + (long long)b * SB_F * plane + ((long long)oy * a.W + cx_) * 8 + 4 * lhi;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 u = *reinterpret_cast<const float4*>(hb_ + (long long)q * plane * 8);
+                    hp[4 * q] = u.x, hp[4 * q + 1] = u.y, hp[4 * q + 2] = u.z, hp[4 * q + 3] = u.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);     // (the scheduler would sink the requests behind the patch's s_waitcnt: one latency after the other)
+            }
             unx = commit_patch(b, raw, roff);
         }
         // wave-private LDS: program order is enough, no barrier
@@ -452,9 +468,10 @@ __global__ __launch_bounds__(SB_NT, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
         const int ox = w0 + l31, cx = ox < a.W ? ox : a.W - 1;
         const float* hb = (a.hprev ? a.hprev : a.hnew) + (long long)b * SB_F * plane +
                           (CB8 ? ((long long)oy * a.W + cx) * 8 + 4 * lhi : (long long)oy * a.W + cx + 4ll * lhi * plane);
-        float hp[32];
         auto load_hp8 = [&](int s) {          // registers 8 s .. 8 s + 7
-            if constexpr (CB8) {
+            if constexpr (HP_EARLY) {
+                return;
+            } else if constexpr (CB8) {
                 // (all eight 16-byte loads go out together behind the 1x1 stage, when g's registers are free: requested group by group
                 // beside it they need aligned register quads the allocator does not have -- 44 spilled registers, 15 us)
                 if (s == SB_KS2 - 1) {
@@ -583,6 +600,20 @@ static void l1sb_launch_form(const MrxL1sbArgs& a, int grid, size_t lds, hipStre
         (void)hipFuncSetAttribute((const void*)k_rim_layer1_sb<F16, CB8, true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
+#ifdef MRX_L1_W12
+    if (CB8 && F16 && a.eta2 && a.nparts <= 4) {
+        static bool attr12 = false;
+        if (!attr12) {
+            (void)hipFuncSetAttribute((const void*)k_rim_layer1_sb<F16, CB8, false, 1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr12 = true;
+        }
+        MrxL1sbArgs a12 = a;
+        a12.ntiles = a.tiles_x * mrx_cdiv(a.H, 12);
+        const long long total12 = (long long)a12.ntiles * a.B;
+        hipLaunchKernelGGL((k_rim_layer1_sb<F16, CB8, false, 1, 12>), dim3((int)(total12 < grid ? total12 : grid)), dim3(12 * 64), lds, st, a12);
+        return;
+    }
+#endif
     if (a.eta2 && a.nparts <= 4)
         hipLaunchKernelGGL((k_rim_layer1_sb<F16, CB8, false, 1>), dim3(grid), dim3(SB_NT), lds, st, a);
     else if (!a.eta2)

@@ -26,16 +26,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define S2_NT 512
 #define S2_BAR_STEP 4      // even chunks: the step before which the paired ninth-tap operands become visible (barrier); 3 = one step earlier, operands prefetched (measured equal)
 #define S2_COMMIT_EVEN 1   // even chunks: the step after which the next chunk is split and written (0 measured equal)
-#ifdef MRX_L2_ROWS2
-#define S2_ROWS2 true      // (A/B switch of round 5: the F16 + CB8 row tails with both rows of a wave through the 1x1 and tap stages together)
-#else
-#define S2_ROWS2 false
-#endif
-#ifdef MRX_L2_NEWST
-#define S2_NEWST_ON true   // (A/B switch of round 5: branch-free staging through buffer descriptors, sliced between the MFMAs of steps 2 and 3)
-#else
-#define S2_NEWST_ON false
-#endif
 #define S2_TH 16
 #define S2_TW 32
 #define S2_F 64
@@ -314,9 +304,15 @@ __device__ __forceinline__ int s2_pixel_exp(float m) {
 // 32 pixels, once per row tail) -- 65 KB of LDS and <= 256 registers, so TWO workgroups share a CU with independent barriers: while one is in its row
 // tails or waits for a chunk, the other one's convolution owns the matrix pipe of the same SIMDs (the eight waves of the 16 x 32 form sit in the same
 // phase between barriers: 44.9 k cycles of chunk loop for 27.6 k of MFMA issue, tails with the pipe idle).  Same arithmetic, same pack: bit-identical.
-template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false, bool W4 = false>
-__global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(L2sbArgs a) {
-    constexpr int NTHR = W4 ? 256 : S2_NT, TH = W4 ? 8 : S2_TH;
+// FAST (round 5, the product route of mrx_rim_layer2_f16_cb8 whenever a sample's state fits 32-bit byte offsets): the NEWST staging + both rows of a wave
+// through the 1x1 / tap stages together (below).  Measured against the round-4 form on the same boxes (tools/probe/l2_time.py, 8 slices per launch):
+// 65.1 -> 62.5 us per slice, matrix pipe 0.565 -> 0.62 busy, 28 % fewer vector instructions (profiles/r05_layer2_wave_states_pmc.txt); bit-identical to
+// the form without it.
+// W16 (round 5, A/B): SIXTEEN waves per workgroup, one image row each (four waves per SIMD instead of two: an in-order wave parked at a waitcnt or a barrier
+// leaves three candidates for the matrix pipe instead of one) -- 128 registers per wave, one accumulator pair, every A fragment serves one row.
+template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false, bool W4 = false, bool W16 = false, bool FAST = false>
+__global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k_rim_layer2_sb(L2sbArgs a) {
+    constexpr int NTHR = W16 ? 1024 : (W4 ? 256 : S2_NT), TH = W4 ? 8 : S2_TH, RPW = W16 ? 1 : 2;
     constexpr int S2_PAD = DIL, S2_PH = TH + 2 * DIL, S2_PW = S2_TW + 2 * DIL, S2_NPIX = S2_PH * S2_PW;
     constexpr int NT = F16 ? 2 : 3;                                        // operand terms of the convolution stage
     constexpr int WFULL = F16 ? S2F_WFULL : S2_WFULL, WCH = F16 ? S2F_WCH : S2_WCH;
@@ -340,6 +336,9 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
     const int tid = wave * 64 + lane_now(), lane = tid & 63;
     const long long plane = (long long)a.H * a.W;
     const int total = a.ntiles * a.B;
+#ifdef MRX_L2_PRIO
+    if (wave >= NTHR / 128) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses every issue arbitration by age: one static priority for it
+#endif
 
     // once per workgroup: 1x1 weights and tables
     if (TAIL && !W4)
@@ -369,7 +368,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
     // chunk q + 2 are cut into slices that sit BETWEEN the MFMAs of steps 2 and 3 of chunk q (pinned with sched_barrier): the chunk loop is one
     // basic block per step, and the ~120 vector / memory instructions per chunk issue in the shadow of 24 MFMAs instead of in a clump that both
     // waves of a SIMD reach at the same time.
-    constexpr bool NEWST = S2_NEWST_ON && F16 && CB8 && TAIL && !W4 && ABL == 0 && !ZP;
+    constexpr bool NEWST = FAST && F16 && CB8 && TAIL && !W4 && ABL == 0 && !ZP;
     // LDS strides in 16-byte slots: a term plane and a weight buffer carry ONE extra slot at their end in the NEWST layout -- the dummy that threads
     // without a second pixel / third weight operand write (both term writes of such a thread land in their plane's dummy: same immediate offsets)
     constexpr int PSTR = NEWST ? S2_NPIX + 1 : S2_NPIX, XBUF = NT * PSTR, WBUF = NEWST ? WCH + 1 : WCH;
@@ -386,12 +385,12 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
     unsigned goff32[XV];                             // NEWST: byte offset of this thread's pixels inside the sample's channel-blocked tensor (chunk 0)
     __amdgpu_buffer_rsrc_t st_rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)(plane * (S2_F * 4)), 0x00020000);
     const __amdgpu_buffer_rsrc_t st_rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.packed), 0, (unsigned)(PK_TAIL * 16), 0x00020000);
-    unsigned st_tid16 = 0, st_px1 = 0, st_w2 = 0;    // NEWST: LDS byte offsets inside a buffer: first pixel / first weight operand; second pixel and third weight operand (or the dummy slots)
+    unsigned st_tid16 = 0, st_px1 = 0, st_w2 = 0;    // NEWST: LDS byte offsets inside a buffer: first pixel / first weight operand; the LAST pixel and the LAST weight operand of the thread (or the dummy slots)
     if constexpr (NEWST) {
         const unsigned t_ = (unsigned)(wave * 64 + lane_now());
         st_tid16 = t_ * 16u;
-        st_px1 = (t_ + NTHR < (unsigned)S2_NPIX ? t_ + NTHR : (unsigned)S2_NPIX) * 16u;
-        st_w2 = (t_ + 2 * NTHR < (unsigned)WCH ? t_ + 2 * NTHR : (unsigned)WCH) * 16u;
+        st_px1 = (t_ + (XV - 1) * NTHR < (unsigned)S2_NPIX ? t_ + (XV - 1) * NTHR : (unsigned)S2_NPIX) * 16u;
+        st_w2 = (t_ + (WV - 1) * NTHR < (unsigned)WCH ? t_ + (WV - 1) * NTHR : (unsigned)WCH) * 16u;
     }
     unsigned zmask = 0, zpend = 0;                   // ZP: this thread's pixels outside the image (of the next request / of the pending chunk)
     auto st_coords = [&]() {
@@ -519,16 +518,16 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
     unsigned ns_p1[XV][4], ns_p2[XV][4];
     auto ns_split = [&](int v, int k) { s2_split2h_scaled(xr[v][2 * k], xr[v][2 * k + 1], sx, ns_p1[v][k], ns_p2[v][k]); };
     auto ns_write_x = [&](int buf, int v) {
-        unsigned char* base = smem_s2 + OFF_X + buf * (XBUF * 16) + (v == 0 ? st_tid16 : st_px1);
+        unsigned char* base = smem_s2 + OFF_X + buf * (XBUF * 16) + (v == XV - 1 ? st_px1 : st_tid16 + (unsigned)(v * NTHR * 16));
         *reinterpret_cast<u32x4*>(base) = u32x4{ns_p1[v][0], ns_p1[v][1], ns_p1[v][2], ns_p1[v][3]};
         *reinterpret_cast<u32x4*>(base + PSTR * 16) = u32x4{ns_p2[v][0], ns_p2[v][1], ns_p2[v][2], ns_p2[v][3]};
     };
     auto ns_write_w = [&](int buf, int v) {
-        *reinterpret_cast<u32x4*>(smem_s2 + OFF_W + buf * (WBUF * 16) + (v < 2 ? st_tid16 + (unsigned)(v * NTHR * 16) : st_w2)) = wr[v];
+        *reinterpret_cast<u32x4*>(smem_s2 + OFF_W + buf * (WBUF * 16) + (v < WV - 1 ? st_tid16 + (unsigned)(v * NTHR * 16) : st_w2)) = wr[v];
     };
     st_coords();
     if constexpr (NEWST) {
-        static_assert(!NEWST || (XV == 2 && WV == 3), "the NEWST slices are written for two pixels and three weight operands per thread");
+        static_assert(!NEWST || (XV <= 2 && WV <= 3 && 2 * XV + WV < RPW * 6), "the NEWST slices: at most two pixels and three weight operands per thread");
         for (int pre = 0; pre < 2; ++pre) {          // chunk 0 requested, split, written; chunk 1 requested
 #pragma unroll
             for (int v = 0; v < XV; ++v) ns_load_x(v, 0), ns_load_x(v, 1);
@@ -570,17 +569,17 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
 #endif
         S2_STAMP(0)
         // acc[row][ct]: rows 2 wave and 2 wave + 1 of the tile
-        f32x16 acc[2][2];
+        f32x16 acc[RPW][2];
 #pragma unroll
-        for (int rw = 0; rw < 2; ++rw)
+        for (int rw = 0; rw < RPW; ++rw)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rw][ct][r] = (F16 && !TAIL) ? 0.f : tabl[64 + lhi * 32 + ct * 16 + r];
 
-        float hp[2][32];
+        float hp[RPW][32];
         auto load_hp = [&](int rw) {              // lanes outside the image read a valid element (clamped) and store nothing
-            const int oy = h0 + 2 * wave + rw, ox = w0 + l31;
+            const int oy = h0 + RPW * wave + rw, ox = w0 + l31;
             const int cy = oy < a.H ? oy : a.H - 1, cx = ox < a.W ? ox : a.W - 1;
             if (!a.hprev) {                       // the zero state: nothing to load (and nothing uninitialised to multiply by zero)
 #pragma unroll
@@ -605,15 +604,15 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         };
         auto toff = [](int tp) { return tp < 9 ? (tp / 3) * DIL * S2_PW + (tp % 3) * DIL : 0; };  // the zero-weight slot reads pixel 0
         for (int q = 0; q < S2_NCH; ++q) {
-            const u32x4* xw = Xp + (q & 1) * XBUF + (2 * wave) * S2_PW + l31;
+            const u32x4* xw = Xp + (q & 1) * XBUF + (RPW * wave) * S2_PW + l31;
             const u32x4* wl = Wc + (q & 1) * WBUF + lane;
             // Ninth tap: chunks are paired.  The fifth step of an EVEN chunk multiplies tap 8 of this chunk (lower half-wave) and tap 8 of the
             // NEXT chunk (upper half-wave: its planes and weights were committed at step 1 of this chunk -- hence the extra barrier before
             // they are fetched); an odd chunk has four steps.  36 instead of 40 MFMA steps per tile, no padding slot.
             const bool even = !(q & 1);
-            const u32x4* xw8 = Xp + ((q + lhi) & 1) * XBUF + (2 * wave) * S2_PW + l31 + toff(8);
+            const u32x4* xw8 = Xp + ((q + lhi) & 1) * XBUF + (RPW * wave) * S2_PW + l31 + toff(8);
             const u32x4* w8 = Wc + ((q + lhi) & 1) * WBUF + WFULL + l31;
-            u32x4 bt[2][2][NT], at[2][2][NT];     // [buffer][row | ct][term]
+            u32x4 bt[2][RPW][NT], at[2][2][NT];     // [buffer][row | ct][term]
             auto fetch = [&](int s, int bf) {
                 if constexpr ((ABL & 32) != 0) {
 #pragma unroll
@@ -629,7 +628,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
                         bt[bf][0][k] = xw[k * PSTR + off];
-                        bt[bf][1][k] = xw[k * PSTR + off + S2_PW];
+                        if constexpr (RPW == 2) bt[bf][1][k] = xw[k * PSTR + off + S2_PW];
                         at[bf][0][k] = wl[((s * NT + k) * 2 + 0) * 64];
                         at[bf][1][k] = wl[((s * NT + k) * 2 + 1) * 64];
                     }
@@ -637,7 +636,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
                         bt[bf][0][k] = xw8[k * PSTR];
-                        bt[bf][1][k] = xw8[k * PSTR + S2_PW];
+                        if constexpr (RPW == 2) bt[bf][1][k] = xw8[k * PSTR + S2_PW];
                         at[bf][0][k] = w8[(k * 2 + 0) * 32];
                         at[bf][1][k] = w8[(k * 2 + 1) * 32];
                     }
@@ -655,7 +654,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
                 if (s + 1 < 4 || (s + 1 == 4 && even && S2_BAR_STEP == 3)) fetch(s + 1, bf ^ 1);
                 // the six term pairs of weight >= 2^-16, smallest first; the four accumulators alternate
 #define S2_P(TA, TB)                                                                                                                       \
-    _Pragma("unroll") for (int rw = 0; rw < 2; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
+    _Pragma("unroll") for (int rw = 0; rw < RPW; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at[bf][ct][TA]), __builtin_bit_cast(bf16x8, bt[bf][rw][TB]), acc[rw][ct], 0, 0, 0);
                 if constexpr ((ABL & 8) != 0) {
 #pragma unroll
@@ -665,32 +664,40 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
                 } else if constexpr (NEWST) {
                     // the same twelve MFMAs (three products x two rows x two cout blocks, smallest product first), one slice of the side work behind each
                     constexpr int TA_[3] = {1, 0, 0}, TB_[3] = {0, 1, 0};
+                    constexpr int NM = 6 * RPW;                // MFMAs per step
                     const int nb = (q + 1) & 1;
 #pragma unroll
-                    for (int m = 0; m < 12; ++m) {
-                        const int rw = (m >> 1) & 1, ct = m & 1, pr = m >> 2;
+                    for (int m = 0; m < NM; ++m) {
+                        const int rw = RPW == 2 ? (m >> 1) & 1 : 0, ct = m & 1, pr = m / (2 * RPW);
                         acc[rw][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, at[bf][ct][TA_[pr]]), __builtin_bit_cast(f16x8, bt[bf][rw][TB_[pr]]),
                                                                             acc[rw][ct], 0, 0, 0);
-                        if (s == 4 && m >= 0) {
-                            // (the half step of an even chunk: no side work)
-                        } else if (s == 2) {                     // chunk q + 1: split (fp32 values requested one chunk ago) and written
-                            if (m < 4) ns_split(0, m);
-                            else if (m == 4) ns_write_x(nb, 0);
-                            else if (m < 9) ns_split(1, m - 5);
-                            else if (m == 9) ns_write_x(nb, 1);
-                            else if (m == 10) ns_write_w(nb, 0), ns_write_w(nb, 1);
-                            else ns_write_w(nb, 2);
+                        if (s == 2) {                            // chunk q + 1: split (fp32 values requested one chunk ago) and written
+                            if constexpr (RPW == 2) {
+                                if (m < 4) ns_split(0, m);
+                                else if (m == 4) ns_write_x(nb, 0);
+                                else if (m < 9 && XV == 2) ns_split(1, m - 5);
+                                else if (m == 9 && XV == 2) ns_write_x(nb, 1);
+                                else if (m == 10) ns_write_w(nb, 0), ns_write_w(nb, 1);
+                                else if (m == 11 && WV == 3) ns_write_w(nb, 2);
+                            } else {                             // six MFMAs, one pixel, two weight operands
+                                if (m < 4) ns_split(0, m);
+                                else if (m == 4) ns_write_x(nb, 0);
+                                else {
+#pragma unroll
+                                    for (int v = 0; v < WV; ++v) ns_write_w(nb, v);
+                                }
+                            }
                         } else if (s == 3) {                     // chunk q + 2 requested
-                            if (m < 4) ns_load_x(m >> 1, m & 1);
-                            else if (m < 7) ns_load_w(m - 4);
-                            else if (m == 7) ns_advance();
+                            if (m < 2 * XV) ns_load_x(m >> 1, m & 1);
+                            else if (m < 2 * XV + WV) ns_load_w(m - 2 * XV);
+                            else if (m == 2 * XV + WV) ns_advance();
                         }
                         if (s == 2 || s == 3) __builtin_amdgcn_sched_barrier(0);
                     }
                 } else if constexpr (F16) {
                     // two fp16 terms per operand: the three products of weight >= 2^-11, smallest first
 #define S2_PH16(TA, TB)                                                                                                                    \
-    _Pragma("unroll") for (int rw = 0; rw < 2; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
+    _Pragma("unroll") for (int rw = 0; rw < RPW; ++rw) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) acc[rw][ct] =                          \
         __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, at[bf][ct][TA]), __builtin_bit_cast(f16x8, bt[bf][rw][TB]), acc[rw][ct], 0, 0, 0);
                     S2_PH16(1, 0) S2_PH16(0, 1) S2_PH16(0, 0)
 #undef S2_PH16
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
                     commit_next((q + 1) & 1);
                     request_next();
                 }
-                if (TAIL && !(ABL & 16) && s == 2 && q == S2_NCH - 1) load_hp(0);
+                if (TAIL && !(ABL & 16) && RPW == 2 && s == 2 && q == S2_NCH - 1) load_hp(0);     // (one row per wave: requested behind the 1x1 stage -- 128 registers)
             }
             if constexpr (!(ABL & 64)) __syncthreads();
         }
@@ -712,7 +719,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         if constexpr (F16 && !TAIL) {
             const float unxw = unx * unw;
 #pragma unroll
-            for (int rw = 0; rw < 2; ++rw)
+            for (int rw = 0; rw < RPW; ++rw)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -721,10 +728,10 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         S2_STAMP(1)
         if constexpr ((ABL & 16) != 0) {
 #pragma unroll
-            for (int rw = 0; rw < 2; ++rw)
+            for (int rw = 0; rw < RPW; ++rw)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) asm volatile("" ::"v"(acc[rw][ct]));
-        } else if constexpr (TAIL && F16 && CB8 && S2_ROWS2) {
+        } else if constexpr (TAIL && F16 && CB8 && FAST && RPW == 2) {
         // ---- both rows of the wave through the 1x1 stage TOGETHER (round 5) ----------------------------------------------------------------------
         // The row tails are issue-bound, not matrix-bound: 72 MFMAs in ~1 500 instructions, the two waves of a SIMD in the same phase.  Here a
         // weight fragment read from LDS serves both rows (half the A reads), every MFMA step has four independent accumulators, row 1's operand
@@ -856,10 +863,10 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         } else if constexpr (TAIL) {
         // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev), one of the wave's two rows at a time ------------------
         // (h_prev of row 0 was requested inside the last chunk; row 1's request goes out now and hides under row 0's tail)
-        load_hp(1);
+        if constexpr (RPW == 2) load_hp(1);
 #pragma unroll
-        for (int rw = 0; rw < 2; ++rw) {
-            const int oy = h0 + 2 * wave + rw, ox = w0 + l31;
+        for (int rw = 0; rw < RPW; ++rw) {
+            const int oy = h0 + RPW * wave + rw, ox = w0 + l31;
             f32x16 acc2[2];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
@@ -895,6 +902,7 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
                         for (int ct = 0; ct < 2; ++ct) at[ct][k] = __builtin_bit_cast(f16x8, wl[((s * 2 + k) * 2 + ct) * 64]);
                     S2_MFMA6H(acc2, at, b1, b2)
                 }
+                if constexpr (RPW == 1) load_hp(0);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1017,8 +1025,8 @@ __global__ __launch_bounds__(W4 ? 256 : S2_NT, W4 ? 2 : 1) void k_rim_layer2_sb(
         } else {
             // ---- plain convolution: act(conv + b), the wave's two rows with lane = pixel (128-byte rows per wave instruction) ------------------
 #pragma unroll
-            for (int rw = 0; rw < 2; ++rw) {
-                const int oy = h0 + 2 * wave + rw, ox = w0 + l31;
+            for (int rw = 0; rw < RPW; ++rw) {
+                const int oy = h0 + RPW * wave + rw, ox = w0 + l31;
                 if (oy < a.H && ox < a.W) {
                     float* ob = a.hnew + (long long)b * S2_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;
 #pragma unroll
@@ -1070,13 +1078,13 @@ static int l2sb_ncu() {
     }
     return ncu;
 }
-template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false, bool W4 = false>
+template <int DIL, bool TAIL, bool ZP, bool F16 = false, int ABL = 0, bool CB8 = false, bool W4 = false, bool W16 = false, bool FAST = false>
 static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
     constexpr int WCH_ = F16 ? S2F_WCH : S2_WCH, NT_ = F16 ? 2 : 3;
     constexpr int lds = W4 ? 1024 + 2 * WCH_ * 16 + 2 * NT_ * (8 + 2 * DIL) * (S2_TW + 2 * DIL) * 16 : (int)S2_LDS;
     static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8, W4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8, W4, W16, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
     if (W4) a.ntiles = a.tiles_x * mrx_cdiv(a.H, 8);                   // 8 x 32 tiles
@@ -1090,7 +1098,7 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 8 * 8, st);
         a.trace = d_trace;
     }
-    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8, W4>), dim3(grid), dim3(W4 ? 256 : S2_NT), lds, st, a);
+    hipLaunchKernelGGL((k_rim_layer2_sb<DIL, TAIL, ZP, F16, ABL, CB8, W4, W16, FAST>), dim3(grid), dim3(W16 ? 1024 : (W4 ? 256 : S2_NT)), lds, st, a);
     MRX_LAUNCH_CHECK();
     if (a.trace) {
         (void)hipStreamSynchronize(st);
@@ -1145,6 +1153,13 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
 #endif
 #ifdef MRX_L2_W4
     if (xmax && cb8) return l2sb_launch_t<2, true, false, true, 0, true, true>(a, (hipStream_t)stream);
+#endif
+#ifdef MRX_L2_R1
+    if (xmax && cb8) return l2sb_launch_t<2, true, false, true, 0, true, false, true, true>(a, (hipStream_t)stream);
+#endif
+#ifndef MRX_L2_SLOW
+    // (the FAST form addresses a sample's state and its tap planes with 32-bit byte offsets through buffer descriptors)
+    if (xmax && cb8 && (long long)H * W * (S2_F * 4) < (1ll << 31)) return l2sb_launch_t<2, true, false, true, 0, true, false, false, true>(a, (hipStream_t)stream);
 #endif
     if (xmax && cb8) return l2sb_launch_t<2, true, false, true, 0, true>(a, (hipStream_t)stream);
     MRX_REQUIRE(!cb8, MRX_EUNSUP, "mrx_rim_layer2_f16_cb8: the channel-blocked layout exists for the two-term fp16 form only");

@@ -45,7 +45,8 @@ x4, hpb = r(B, 4, H, W), ops.cb8_from_nchw(r(B, F, H, W).relu())
 xm1 = torch.zeros(1, device=dev)
 h1 = ops.rim_layer1_cb8(x4, None, None, 0, 1.0, pk1, bc, bi, hh, hpb, xm1)
 o1, o2, tp = torch.empty_like(h1), torch.empty_like(h1), torch.empty(B, 18, H, W, device=dev)
-t1 = timed(lambda: ops.rim_layer1_cb8(x4, None, None, 0, 1.0, pk1, bc, bi, hh, hpb, xm1, out=o1))
+eta, part = r(B, H, W, 2), r(4, B, H, W, 2)             # the headline loop's input form: eta + three coil-group partial planes + the constant plane
+t1 = timed(lambda: ops.rim_layer1_cb8(None, eta, part, 4, 1.0, pk1, bc, bi, hh, hpb, xm1, out=o1))
 t2 = timed(lambda: ops.rim_layer2_f16_cb8(h1, pk2, bc, bi, hh, hpb, xm1, taps=tp, out=o2, want_taps=True))
 t2b = timed(lambda: ops.rim_layer2_f16_cb8(h1, pk2, bc, bi, hh, hpb, xm1, taps=tp, out=o2, want_taps=True))
 lib = os.path.basename(os.path.dirname(os.environ.get("MRIDC_AMD_LIB", "mridc_amd/lib/x")))
