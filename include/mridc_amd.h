@@ -748,6 +748,13 @@ int64_t mrx_unet_conv3x3_pack_floats(int Cout, int Ctot);
 int mrx_unet_conv3x3_pack(const float* w, int Cout, int Ctot, float* packed, void* stream);
 int mrx_unet_conv3x3_h(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b, int Cb,
                        const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps, float slope, void* stream);
+/* ... with the merge of the tile statistics INSIDE the convolution launch (no k_unorm_finalize launch behind it): the last tile of every plane, found by
+ * a ticket per plane, writes `norm`.  counters: mrx_unet_conv3x3_hc_ticket_ints(B, Cout) ints (one 128-byte line per plane), ZERO on entry, zero again on exit (one buffer serves every call on a stream; calls
+ * that may overlap -- two streams -- need their own).  `norm` equals mrx_unet_conv3x3_h's up to the order of three double-precision sums. */
+int64_t mrx_unet_conv3x3_hc_ticket_ints(int B, int Cout);
+int mrx_unet_conv3x3_hc(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b, int Cb,
+                        const float* packed, float* y, float* norm, float* work, int* counters, int B, int Cout, int H, int W, float eps, float slope,
+                        void* stream);
 /* y = act(conv3x3(x, dilation 1 | 2, zero | replicate padding) + bias), any channel counts, on the same two-term fp16 kernel (ConvNonlinear,
  * rim/conv_layers.py:121-123, for layers the 64-channel kernels do not cover: qRIM's 128 -> 128, DIDN ...).  bound: device scalar >= max |x|;
  * packed: mrx_unet_conv3x3_pack(w [Cout, Cin, 3, 3]); x != y. */

@@ -794,6 +794,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
                 if (s == 1) load_hp(1);          // (half of the convolution's accumulators are dead by now: row 1's state can land in their registers)
             }
         }
+        S2_STAMP(2)        // (probe builds: [1, 2] = both rows' 1x1 stage, [2, 3] = epilogues, stores and the tap stage)
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hnew + (long long)b * S2_F * plane, 0, (unsigned)(plane * (S2_F * 4)), 0x00020000);
         unsigned offh[2];
 #pragma unroll
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[rw][9] * unh[rw]), rp, offp16 + 17u * (unsigned)(plane * 4), 0, 0);
             }
         }
+        S2_STAMP(3)
         } else if constexpr (TAIL) {
         // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev), one of the wave's two rows at a time ------------------
         // (h_prev of row 0 was requested inside the last chunk; row 1's request goes out now and hides under row 0's tail)
@@ -1134,7 +1136,7 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
     if (xmax && cb8 && getenv("MRX_L2_ABL")) {
         switch (atoi(getenv("MRX_L2_ABL"))) {
 #define L2_ABL_CASE(N) case N: return l2sb_launch_t<2, true, false, true, N, true>(a, (hipStream_t)stream);
-            L2_ABL_CASE(1) L2_ABL_CASE(3) L2_ABL_CASE(7) L2_ABL_CASE(8) L2_ABL_CASE(16) L2_ABL_CASE(32) L2_ABL_CASE(64)
+            L2_ABL_CASE(1) L2_ABL_CASE(3) L2_ABL_CASE(7) L2_ABL_CASE(8) L2_ABL_CASE(32) L2_ABL_CASE(64)
             L2_ABL_CASE(128) L2_ABL_CASE(256) L2_ABL_CASE(384) L2_ABL_CASE(512) L2_ABL_CASE(896)
 #undef L2_ABL_CASE
             default: break;
@@ -1143,9 +1145,9 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
     if (xmax && !cb8 && getenv("MRX_L2_ABL")) {
         switch (atoi(getenv("MRX_L2_ABL"))) {
 #define L2_ABL_CASE(N) case N: return l2sb_launch_t<2, true, false, true, N>(a, (hipStream_t)stream);
-            L2_ABL_CASE(1) L2_ABL_CASE(2) L2_ABL_CASE(3) L2_ABL_CASE(4) L2_ABL_CASE(7) L2_ABL_CASE(8) L2_ABL_CASE(16) L2_ABL_CASE(23)
-            L2_ABL_CASE(32) L2_ABL_CASE(40) L2_ABL_CASE(64) L2_ABL_CASE(71) L2_ABL_CASE(87)
-            L2_ABL_CASE(128) L2_ABL_CASE(256) L2_ABL_CASE(384) L2_ABL_CASE(512) L2_ABL_CASE(896) L2_ABL_CASE(903) L2_ABL_CASE(1024)
+            L2_ABL_CASE(1) L2_ABL_CASE(2) L2_ABL_CASE(3) L2_ABL_CASE(4) L2_ABL_CASE(7) L2_ABL_CASE(8)
+            L2_ABL_CASE(32) L2_ABL_CASE(40) L2_ABL_CASE(64) L2_ABL_CASE(71)
+            L2_ABL_CASE(128) L2_ABL_CASE(256) L2_ABL_CASE(384) L2_ABL_CASE(512) L2_ABL_CASE(896) L2_ABL_CASE(1024)
 #undef L2_ABL_CASE
             default: break;
         }

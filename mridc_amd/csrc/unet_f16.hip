@@ -32,6 +32,8 @@ typedef unsigned uh_u4 __attribute__((ext_vector_type(4)));
 #define UH_TW 32
 #define UH_SC 16                   // input channels per step
 #define UH_MS 5                    // MFMAs per step and accumulator (18 of 20 slots used)
+#define UH_TICKET_STRIDE 32        // ints between two planes' tickets: one 128-byte line each (read-modify-writes of one line serialise: 112 adjacent tickets
+                                   // = four lines took 107 k atomics one after the other, +200 us per launch)
 // halo'd tile for dilation D: (8 + 2 D) rows x (32 + 2 D) columns -- 10 x 34 = 340 pixels (D = 1), 12 x 36 = 432 (D = 2)
 __host__ __device__ constexpr int uh_pw(int D) { return UH_TW + 2 * D; }
 __host__ __device__ constexpr int uh_pix(int D) { return (UH_TH + 2 * D) * uh_pw(D); }
@@ -53,6 +55,10 @@ struct UConvHArgs {
     const float* bias;   // plain convolution (UNET = false): [Cout] or null; act MRX_ACT_*; pad_mode MRX_PAD_ZERO | MRX_PAD_REPLICATE
     int act, pad_mode;
     int abl;             // probe builds (env MRX_UCONVH_ABLATE): 1 no matrix work, 2 no stores, 4 no statistics, 8 no tile loads, 16 no split / LDS writes
+    int* counters;       // UNET, or null: [B][Cout] tickets, zero on entry and on exit -- the LAST tile of a plane merges the plane's tile statistics into
+                         // `norm` itself (round 5: E2EVN ran 300 k_unorm_finalize launches of 5 us per step behind these kernels)
+    float* norm;         // [B][Cout][2] (mean, 1/std): written by the last tile of each plane when `counters` is given
+    float eps;
 };
 
 __host__ __device__ constexpr long long uh_pack_words(int Cout, int Ctot) {
@@ -156,6 +162,72 @@ __device__ __forceinline__ float uh_row_sum(float t) {
     t += UH_DPP(t, 0x140);     // row_mirror: halves of the row
 #undef UH_DPP
     return t;
+}
+
+// The merge of a plane's tile statistics (k_unorm_finalize's arithmetic: counts, mean, then M2 with the parallel-variance term, in double) by ONE wave:
+// tiles strided over the lanes, three butterfly sums.  Called by the workgroup that took the plane's last ticket.  Visibility across the XCDs' L2s without
+// a fence: the tile statistics are WRITTEN THROUGH (agent-scope relaxed atomic stores: `sc1`), acknowledged (s_waitcnt) before the ticket is taken, and read
+// here with agent-scope loads that miss this XCD's L2 -- an agent-scope release fence per tile instead writes back the whole L2 every time: measured
+// 7 x slower than the launch it replaces (E2EVN 1 100 -> 148 slices/s).
+__device__ __forceinline__ double uh_wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void uh_finalize_plane(const float* __restrict__ tstats, float* __restrict__ norm, int b, int co, int Cout, int ntiles, int tiles_x, int H,
+                                                  int W, float eps, int lane) {
+    auto count = [&](int t) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int nr = H - ty * UH_TH < UH_TH ? H - ty * UH_TH : UH_TH, nc = W - tx * UH_TW < UH_TW ? W - tx * UH_TW : UH_TW;
+        return (double)(nr * nc);
+    };
+    const float* ts = tstats + ((long long)b * ntiles * Cout + co) * 2;
+    // every load of a pass is requested before the first one is used (an agent-scope load misses this XCD's L2: a loop of load -> use pays a memory
+    // round trip per tile -- 30 per plane, 300 us behind the last tile of an image: measured); up to 1024 tiles stay in registers for the second pass
+    double sn = 0.0, smean = 0.0, q = 0.0;
+    if (ntiles <= 1024) {
+        float mv[16], qv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = lane + 64 * i, tc = t < ntiles ? t : ntiles - 1;
+            mv[i] = __hip_atomic_load(ts + (long long)tc * Cout * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            qv[i] = __hip_atomic_load(ts + (long long)tc * Cout * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = lane + 64 * i;
+            const double nb = t < ntiles ? count(t) : 0.0;
+            sn += nb;
+            smean += nb * (double)mv[i];
+        }
+        const double N = uh_wave_sum(sn), mean = uh_wave_sum(smean) / N;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = lane + 64 * i;
+            const double d = (double)mv[i] - mean;
+            q += t < ntiles ? (double)qv[i] + count(t) * d * d : 0.0;
+        }
+        const double m2 = uh_wave_sum(q);
+        if (lane == 0) {
+            norm[((long long)b * Cout + co) * 2] = (float)mean;
+            norm[((long long)b * Cout + co) * 2 + 1] = 1.0f / sqrtf((float)m2 / (float)N + eps);
+        }
+        return;
+    }
+    for (int t = lane; t < ntiles; t += 64) {
+        const double nb = count(t);
+        sn += nb;
+        smean += nb * (double)__hip_atomic_load(ts + (long long)t * Cout * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double N = uh_wave_sum(sn), mean = uh_wave_sum(smean) / N;
+    for (int t = lane; t < ntiles; t += 64) {
+        const double d = (double)__hip_atomic_load(ts + (long long)t * Cout * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mean;
+        q += (double)__hip_atomic_load(ts + (long long)t * Cout * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + count(t) * d * d;
+    }
+    const double m2 = uh_wave_sum(q);
+    if (lane == 0) {
+        norm[((long long)b * Cout + co) * 2] = (float)mean;
+        norm[((long long)b * Cout + co) * 2 + 1] = 1.0f / sqrtf((float)m2 / (float)N + eps);
+    }
 }
 
 // One workgroup per work item (batch, cout block, tile); the tile loads of the NEXT step are in flight (registers) while the current step is
@@ -380,20 +452,24 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
         }
         // stores: lane = pixel of a 16-pixel accumulator tile, four output channels per lane (64-byte segments; trading rows between the two
         // tiles of an image row with v_permlane16_swap, for 128-byte segments, measured no faster)
-        if (!(a.abl & 2))
+        auto store_y = [&]() {
+            if (a.abl & 2) return;
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-            const int oy = h0 + 2 * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
-            if (oy < a.H && ox < a.W) {
+            for (int sg = 0; sg < 4; ++sg) {
+                const int oy = h0 + 2 * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
+                if (oy < a.H && ox < a.W) {
 #pragma unroll
-                for (int ct = 0; ct < NCOT; ++ct)
+                    for (int ct = 0; ct < NCOT; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int co = co0 + 16 * ct + 4 * lg + r;
-                        if (co < a.Cout) a.y[((long long)b * a.Cout + co) * plane + (long long)oy * a.W + ox] = acc[sg][ct][r];
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const int co = co0 + 16 * ct + 4 * lg + r;
+                            if (co < a.Cout) a.y[((long long)b * a.Cout + co) * plane + (long long)oy * a.W + ox] = acc[sg][ct][r];
+                        }
+                }
             }
-        }
+        };
+        const bool tickets = UNET && a.counters != nullptr && !(a.abl & 4);
+        if (!tickets) store_y();          // (with tickets the tile is stored BEHIND them: the stores cover the tickets' round trip)
         if (!UNET || (a.abl & 4)) return;
         // InstanceNorm statistics of this tile, per cout (the scheme of k_uconv, unet_fused.hip: mean over the tile's valid pixels, then the squared
         // deviations from that mean; k_unorm_finalize merges the tiles in double)
@@ -428,10 +504,47 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
                         mean[ct][r] = t * inv_n;
                     } else if (wave == 0 && l15 == 0 && co0 + c < a.Cout) {
                         float* ts = a.tstats + (((long long)b * a.ntiles + tile) * a.Cout + co0 + c) * 2;
-                        ts[0] = mean[ct][r];
-                        ts[1] = t;
+                        if (a.counters) {                            // written through to the coherence point (read by whichever workgroup merges the plane)
+                            __hip_atomic_store(ts, mean[ct][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(ts + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            ts[0] = mean[ct][r];
+                            ts[1] = t;
+                        }
                     }
                 }
+        }
+        if (a.counters) {
+            // tickets: the thread that wrote a channel's tile statistics publishes them (agent-scope release) and counts the tile; whoever counts the
+            // plane's LAST tile marks the channel, and the four waves merge the marked planes (usually none; all of a tile's channels for the last
+            // tile of an image) -- no launch behind this one, nothing serial across the chip: the other images' tiles keep the CUs busy meanwhile
+            int* flag = reinterpret_cast<int*>(red);                 // (the reductions above are done with `red`: every wave passed their last barrier)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the write-through stores above are acknowledged (s_waitcnt vmcnt(0)) before the tickets
+            __syncthreads();
+            int tk[NCOT][4];
+            if (wave == 0 && l15 == 0) {
+#pragma unroll
+                for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * ct + 4 * lg + r;
+                        tk[ct][r] = co0 + c < a.Cout ? __hip_atomic_fetch_add(a.counters + ((long long)b * a.Cout + co0 + c) * UH_TICKET_STRIDE, 1, __ATOMIC_RELAXED,
+                                                                             __HIP_MEMORY_SCOPE_AGENT) : -1;
+                    }
+            }
+            store_y();                                              // the tile's 4 x 4 NCOT stores per lane go out while the tickets travel
+            if (wave == 0 && l15 == 0) {
+#pragma unroll
+                for (int ct = 0; ct < NCOT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) flag[16 * ct + 4 * lg + r] = tk[ct][r] == a.ntiles - 1;
+            }
+            __syncthreads();
+            for (int c = wave; c < NCOT * 16; c += UH_NT / 64) {
+                if (!flag[c]) continue;                             // (wave-uniform)
+                uh_finalize_plane(a.tstats, a.norm, b, co0 + c, a.Cout, a.ntiles, a.tiles_x, a.H, a.W, a.eps, lane);
+                if (lane == 0) __hip_atomic_store(a.counters + ((long long)b * a.Cout + co0 + c) * UH_TICKET_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left as it was found
+            }
         }
     }
 }
@@ -462,9 +575,9 @@ static int uh_pick_ncot(int nct, long long tiles_b) {
 // mrx_unet_conv3x3 with two-term fp16 operands (see the head of this file).  packed: mrx_unet_conv3x3_pack of w [Cout, Ca + Cb, 3, 3];
 // bound_a / bound_b: device scalars >= max |x| of a PLAIN source (ignored -- may be NULL -- for a (raw, norm) source, whose bound is sqrt(H W)).
 // work: mrx_unet_conv3x3_work_floats(B, Cout, H, W) floats.
-extern "C" int mrx_unet_conv3x3_h(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b,
-                                  int Cb, const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps,
-                                  float slope, void* stream) {
+static int unet_conv3x3_h_impl(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b,
+                               int Cb, const float* packed, float* y, float* norm, float* work, int* counters, int B, int Cout, int H, int W, float eps,
+                               float slope, void* stream) {
     MRX_REQUIRE(xa && packed && y && norm && work && Ca >= 1 && Cb >= 0 && (Cb == 0 || xb), MRX_EINVAL, "mrx_unet_conv3x3_h: bad argument");
     MRX_REQUIRE((na || bound_a) && (Cb == 0 || nb || bound_b), MRX_EINVAL, "mrx_unet_conv3x3_h: a plain source needs the bound of its maximum");
     MRX_REQUIRE(B >= 0 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_unet_conv3x3_h: bad dims");
@@ -482,11 +595,26 @@ extern "C" int mrx_unet_conv3x3_h(const float* xa, const float* na, const float*
     const int ntiles = a.tiles_x * mrx_cdiv(H, UH_TH);
     a.ntiles = ntiles;
     a.bias = nullptr, a.act = MRX_ACT_NONE, a.pad_mode = MRX_PAD_ZERO;
+    a.counters = counters, a.norm = norm, a.eps = eps;
     hipStream_t st = (hipStream_t)stream;
     const int ncot = uh_pick_ncot(a.nct, (long long)ntiles * B);
     const int rc = ncot == 4 ? launch_uconv_h<4, 1, true>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, true>(a, st) : launch_uconv_h<1, 1, true>(a, st));
-    if (rc) return rc;
+    if (rc || counters) return rc;
     return mrx_unorm_finalize_tiled(work, norm, B, ntiles, a.tiles_x, Cout, H, W, eps, st);
+}
+extern "C" int mrx_unet_conv3x3_h(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b,
+                                  int Cb, const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps,
+                                  float slope, void* stream) {
+    return unet_conv3x3_h_impl(xa, na, bound_a, Ca, xb, nb, bound_b, Cb, packed, y, norm, work, nullptr, B, Cout, H, W, eps, slope, stream);
+}
+// ... with the merge of the tile statistics inside the convolution launch: `counters` = B * Cout ints that are ZERO on entry and zero again on exit
+// (one buffer serves every call of a stream; two streams need two buffers); ticket of plane p at counters[32 p]: mrx_unet_conv3x3_hc_ticket_ints(B, Cout) ints.  Same `norm` up to the order of three double-precision sums.
+extern "C" int64_t mrx_unet_conv3x3_hc_ticket_ints(int B, int Cout) { return B < 0 || Cout < 1 ? -1 : (int64_t)B * Cout * UH_TICKET_STRIDE; }
+extern "C" int mrx_unet_conv3x3_hc(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b,
+                                   int Cb, const float* packed, float* y, float* norm, float* work, int* counters, int B, int Cout, int H, int W,
+                                   float eps, float slope, void* stream) {
+    MRX_REQUIRE(counters, MRX_EINVAL, "mrx_unet_conv3x3_hc: null counters");
+    return unet_conv3x3_h_impl(xa, na, bound_a, Ca, xb, nb, bound_b, Cb, packed, y, norm, work, counters, B, Cout, H, W, eps, slope, stream);
 }
 
 // y = act(conv3x3(x, dilation 1 | 2, zero | replicate padding) + bias) for any channel counts, on two-term fp16 operands (conv_layers.py:121-123; the
@@ -511,6 +639,7 @@ extern "C" int mrx_conv3x3_h(const float* x, const float* bound, const float* pa
     a.Ca = Cin, a.Cb = 0, a.B = B, a.Cout = Cout, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, UH_TW), a.slope = slope;
     a.ntiles = a.tiles_x * mrx_cdiv(H, UH_TH), a.nct = (Cout + 15) / 16, a.nsteps = (Cin + UH_SC - 1) / UH_SC;
     a.abl = 0, a.bias = bias, a.act = act, a.pad_mode = pad_mode;
+    a.counters = nullptr, a.norm = nullptr, a.eps = 0.f;
     hipStream_t st = (hipStream_t)stream;
     const int ncot = uh_pick_ncot(a.nct, (long long)a.ntiles * B);
     if (dil == 1) return ncot == 4 ? launch_uconv_h<4, 1, false>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, false>(a, st) : launch_uconv_h<1, 1, false>(a, st));

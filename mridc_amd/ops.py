@@ -1983,6 +1983,29 @@ _UNET_BOUNDS = {}
 UNET_F16 = True                   # (module attribute: a test hook for the fp32-input MFMA kernel; MRIDC_AMD_ARITH != f16x2 turns the fp16 form off too)
 
 
+# Merge the tile statistics inside the convolution launch (mrx_unet_conv3x3_hc) instead of a k_unorm_finalize launch behind it.  Built and measured in round 5,
+# OFF by default: E2EVN-6 at 8 slices x 2 streams 1 105-1 168 slices/s without it, 148 with an agent-scope release fence per tile (every fence writes the
+# XCD's L2 back), 590-600 with write-through statistics and 112 adjacent tickets (four cache lines: 107 k read-modify-writes one after the other), 900-920
+# with one 128-byte line per ticket and the tile stored behind the tickets -- 960 returning atomics per plane address still cost more than the 5-us launch
+# they replace (tools/runs/r05i.sh).  MRX_UNET_FOLD=1 / this attribute switch it on (tests/test_gpu_unet_fused.py covers it).
+UNET_FOLD_FINALIZE = os.environ.get("MRX_UNET_FOLD", "0") == "1" merge the tile statistics inside the convolution launch (mrx_unet_conv3x3_hc)
+_UNET_TICKETS = {}
+
+
+def _unet_tickets(n, device):
+    """A zeroed int32 buffer of >= n plane tickets for mrx_unet_conv3x3_hc, one per (device, stream, hipGraph capture): the kernel leaves it zeroed, so
+    consecutive calls on a stream share it; calls that may overlap (other streams) get their own; a buffer first made INSIDE a capture lives in that
+    graph's pool -- its zero-fill is part of the graph -- and is never served to eager calls or other captures (the rule of _analytic_bound)."""
+    cap = int(_lib.lib().mrx_stream_capture_id(_lib.stream_ptr()))
+    for k in [k for k in _UNET_TICKETS if k[2] != 0 and k[2] != cap]:
+        del _UNET_TICKETS[k]
+    key = (str(device), int(torch.cuda.current_stream().cuda_stream), cap)
+    t = _UNET_TICKETS.get(key)
+    if t is None or t.numel() < n:
+        t = _UNET_TICKETS[key] = torch.zeros(max(int(n), 4096), dtype=torch.int32, device=device)
+    return t
+
+
 def _analytic_bound(n, device):
     """Device scalar sqrt(n): the bound of an instance- / group-normalised tensor whose statistics ran over n values (|z| <= sqrt(n - 1))."""
     # keyed on the hipGraph capture like _PreparedCache: a scalar first filled INSIDE a capture exists only in that graph's pool and only after a
@@ -2034,6 +2057,12 @@ def unet_conv3x3(src_a, src_b, weight, eps=1e-5, slope=0.2):
         packed = _UNET_PACKS.get(weight, (), make)
         ba = None if na is not None else _plain_bound(src_a if not isinstance(src_a, tuple) else xa)
         bb = None if (xb is None or nb is not None) else _plain_bound(src_b if not isinstance(src_b, tuple) else xb)
+        if UNET_FOLD_FINALIZE:
+            tickets = _unet_tickets(int(L.mrx_unet_conv3x3_hc_ticket_ints(B, Cout)), xa.device)
+            _lib.check(L.mrx_unet_conv3x3_hc(_lib.ptr(xa), _lib.ptr(na), _lib.ptr(ba), Ca, _lib.ptr(xb), _lib.ptr(nb), _lib.ptr(bb), Cb, _lib.ptr(packed),
+                                             _lib.ptr(y), _lib.ptr(norm), _lib.ptr(work), _lib.ptr(tickets), B, Cout, H, W, float(eps), float(slope),
+                                             _lib.stream_ptr()), "mrx_unet_conv3x3_hc")
+            return y, norm
         _lib.check(L.mrx_unet_conv3x3_h(_lib.ptr(xa), _lib.ptr(na), _lib.ptr(ba), Ca, _lib.ptr(xb), _lib.ptr(nb), _lib.ptr(bb), Cb, _lib.ptr(packed),
                                         _lib.ptr(y), _lib.ptr(norm), _lib.ptr(work), B, Cout, H, W, float(eps), float(slope), _lib.stream_ptr()),
                    "mrx_unet_conv3x3_h")

@@ -209,3 +209,39 @@ def test_norm_unet_two_term_fp16_against_the_fp32_input_kernels(cfg, dev):
             os.environ["MRIDC_AMD_ARITH"] = env
     assert torch.equal(want, want2)                      # both switches select the same kernels
     assert rel_l2(got, want) <= 2e-5, rel_l2(got, want)
+
+
+@pytest.mark.parametrize("shape", [(8, 14, 0, 14, 640, 380), (2, 14, 14, 28, 320, 190), (3, 5, 3, 36, 9, 7), (1, 1, 0, 1, 1, 2), (2, 28, 28, 70, 160, 95)])
+def test_unet_conv3x3_statistics_merged_inside_the_launch(shape, dev):
+    """mrx_unet_conv3x3_hc (round 5): the last tile of every plane -- found by a ticket per plane -- merges the plane's tile statistics itself, no
+    k_unorm_finalize launch behind the convolution.  Same raw output bit for bit, (mean, 1/std) equal to the separate launch's up to the order of three
+    double-precision sums; the ticket buffer is left zeroed (the next call on the stream reuses it), also when two streams run at once on their own buffers."""
+    from mridc_amd import ops
+    B, Ca, Cb, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    xa, xb = r(B, Ca, H, W) * 2 + 0.5, (r(B, Cb, H, W) - 0.3 if Cb else None)
+    w = r(Cout, Ca + Cb, 3, 3) / (9 * (Ca + Cb)) ** 0.5
+    keep = ops.UNET_FOLD_FINALIZE
+    try:
+        ops.UNET_FOLD_FINALIZE = False
+        y0, n0 = ops.unet_conv3x3(xa, xb, w)
+        ops.UNET_FOLD_FINALIZE = True
+        for rep in range(3):                                   # the same ticket buffer three times
+            y1, n1 = ops.unet_conv3x3(xa, xb, w)
+            assert torch.equal(y1, y0)
+            assert float((n1.double() - n0.double()).abs().max()) <= 1e-6 * max(1.0, float(n0.abs().max())), rep
+        tk = ops._unet_tickets(B * Cout * 32, dev)
+        torch.cuda.synchronize()
+        assert int(tk.abs().sum()) == 0
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for st in (s1, s2, s1, s2):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(ops.unet_conv3x3(xa, xb, w))
+        torch.cuda.synchronize()
+        for y2, n2 in outs:
+            assert torch.equal(y2, y0) and torch.equal(n2, n1)          # (the merge itself is deterministic: fixed order, whoever runs it)
+    finally:
+        ops.UNET_FOLD_FINALIZE = keep
