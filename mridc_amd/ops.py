@@ -1988,7 +1988,7 @@ UNET_F16 = True                   # (module attribute: a test hook for the fp32-
 # XCD's L2 back), 590-600 with write-through statistics and 112 adjacent tickets (four cache lines: 107 k read-modify-writes one after the other), 900-920
 # with one 128-byte line per ticket and the tile stored behind the tickets -- 960 returning atomics per plane address still cost more than the 5-us launch
 # they replace (tools/runs/r05i.sh).  MRX_UNET_FOLD=1 / this attribute switch it on (tests/test_gpu_unet_fused.py covers it).
-UNET_FOLD_FINALIZE = os.environ.get("MRX_UNET_FOLD", "0") == "1" merge the tile statistics inside the convolution launch (mrx_unet_conv3x3_hc)
+UNET_FOLD_FINALIZE = os.environ.get("MRX_UNET_FOLD", "0") == "1"
 _UNET_TICKETS = {}
 
 
