@@ -235,8 +235,10 @@ __device__ __forceinline__ void uh_finalize_plane(const float* __restrict__ tsta
 // instead of four workgroups per CU, uneven item counts: 14 -> 14 at 640 x 384 x 4 64.6 instead of 61.7 us, 56 -> 56 at 160 x 96 61.8 instead of 42.3.)
 // UNET: the U-Net contract (lazy / plain sources, zero padding, raw output + tile statistics); else a plain convolution of ONE plain source with
 // dilation DIL, zero or replicate padding and a bias + activation epilogue (conv_layers.py:121-123 for layers wider than the RIM's 64 channels).
-template <int NCOT, int DIL, bool UNET>
-__global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_uconv_h(UConvHArgs a) {
+// TK: the ticket form (a.counters given) is its own instantiation -- its merge keeps 32 tile statistics per lane in registers, which the 128-register
+// budget of the four-workgroups-per-CU form does not have (84 bytes of scratch per lane when it was a run-time branch of the one kernel)
+template <int NCOT, int DIL, bool UNET, bool TK = false>
+__global__ __launch_bounds__(UH_NT, NCOT == 1 ? (TK ? 3 : 4) : (NCOT == 2 ? 3 : 2)) void k_uconv_h(UConvHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uh[];
     constexpr int UH_PW = uh_pw(DIL), UH_PIX = uh_pix(DIL), UH_PLANE = uh_plane(DIL), UH_XBUF = uh_xbuf(DIL);
     constexpr int NSLOT = (UH_PIX + 127) / 128;                 // tile pixels per staging thread: 3 (dilation 1), 4 (dilation 2)
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
                 }
             }
         };
-        const bool tickets = UNET && a.counters != nullptr && !(a.abl & 4);
+        constexpr bool tickets = UNET && TK;
         if (!tickets) store_y();          // (with tickets the tile is stored BEHIND them: the stores cover the tickets' round trip)
         if (!UNET || (a.abl & 4)) return;
         // InstanceNorm statistics of this tile, per cout (the scheme of k_uconv, unet_fused.hip: mean over the tile's valid pixels, then the squared
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
                         mean[ct][r] = t * inv_n;
                     } else if (wave == 0 && l15 == 0 && co0 + c < a.Cout) {
                         float* ts = a.tstats + (((long long)b * a.ntiles + tile) * a.Cout + co0 + c) * 2;
-                        if (a.counters) {                            // written through to the coherence point (read by whichever workgroup merges the plane)
+                        if constexpr (TK) {                          // written through to the coherence point (read by whichever workgroup merges the plane)
                             __hip_atomic_store(ts, mean[ct][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(ts + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         } else {
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
                     }
                 }
         }
-        if (a.counters) {
+        if constexpr (TK) {
             // tickets: the thread that wrote a channel's tile statistics publishes them (agent-scope release) and counts the tile; whoever counts the
             // plane's LAST tile marks the channel, and the four waves merge the marked planes (usually none; all of a tile's channels for the last
             // tile of an image) -- no launch behind this one, nothing serial across the chip: the other images' tiles keep the CUs busy meanwhile
@@ -551,17 +553,17 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? 4 : (NCOT == 2 ? 3 : 2)) void k_
 
 int mrx_unorm_finalize_tiled(const float* tstats, float* norm, int B, int ntiles, int tiles_x, int Cout, int H, int W, float eps, hipStream_t st);
 
-template <int NCOT, int DIL, bool UNET>
+template <int NCOT, int DIL, bool UNET, bool TK = false>
 static int launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
     constexpr size_t lds = 16 * (size_t)(uh_xbuf(DIL) + UH_MS * NCOT * 2 * 64) + sizeof(float) * 2 * 4 * NCOT * 16;
     static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
     if (lds > 48 * 1024 && !attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_uconv_h<NCOT, DIL, UNET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_uconv_h<NCOT, DIL, UNET, TK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     const long long nitems = (long long)a.ntiles * mrx_cdiv(a.nct, NCOT) * a.B;
     MRX_REQUIRE(nitems < (1ll << 31), MRX_EUNSUP, "two-term fp16 convolution: %lld work items", nitems);
-    hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET>), dim3((unsigned)nitems), dim3(UH_NT), lds, st, a);
+    hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET, TK>), dim3((unsigned)nitems), dim3(UH_NT), lds, st, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -598,8 +600,9 @@ static int unet_conv3x3_h_impl(const float* xa, const float* na, const float* bo
     a.counters = counters, a.norm = norm, a.eps = eps;
     hipStream_t st = (hipStream_t)stream;
     const int ncot = uh_pick_ncot(a.nct, (long long)ntiles * B);
+    if (counters) return ncot == 4 ? launch_uconv_h<4, 1, true, true>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, true, true>(a, st) : launch_uconv_h<1, 1, true, true>(a, st));
     const int rc = ncot == 4 ? launch_uconv_h<4, 1, true>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, true>(a, st) : launch_uconv_h<1, 1, true>(a, st));
-    if (rc || counters) return rc;
+    if (rc) return rc;
     return mrx_unorm_finalize_tiled(work, norm, B, ntiles, a.tiles_x, Cout, H, W, eps, st);
 }
 extern "C" int mrx_unet_conv3x3_h(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b,
