@@ -371,7 +371,14 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? (TK ? 3 : 4) : (NCOT == 2 ? 3 : 
     const uh_u4* xq = Xh + (lg & 1) * UH_PLANE + (2 * wave) * UH_PW + l15;
     const uh_u4* wq = Wh + lane;
 
+    // workgroup -> work item: the runtime deals consecutive workgroups round-robin over the 8 XCDs (8 L2 caches); with item = blockIdx.x the two horizontal
+    // neighbours of a tile -- which re-read 2 of its 34 halo'd columns, and the tiles above / below 2 of its 10 rows -- always sat behind OTHER L2s.  The band
+    // map gives every XCD a contiguous range of items (MRX_UH_NO_BAND: A/B)
+#ifdef MRX_UH_NO_BAND
     const int item = blockIdx.x;
+#else
+    const int item = (int)mrx_xcd_band(blockIdx.x, gridDim.x);
+#endif
     issue_x(item, 0);
     issue_w(item, 0);
     {
