@@ -48,8 +48,13 @@ class RIMBlock(torch.nn.Module):
                  dimensionality: int = 2, consecutive_slices: int = 1):
         super().__init__()
         if (dimensionality, conv_dim) not in ((2, 2), (3, 3)) or consecutive_slices != 1:
+            # consecutive_slices > 1 with dimensionality 2 is not a path the reference can run: its forward folds the slices into the batch and then hands the
+            # convolutions `grad_eta.view(B S, 4, H, W).permute(1, 0, 2, 3)` (rim_block.py:230-231) -- with conv_dim 2 "expected input[4, B S, H, W] to have 4
+            # channels", with conv_dim 3 the 2-D permute of the final layer's output no longer matches eta (checked against the imported reference in
+            # round 5: both raise RuntimeError).  dimensionality = 3 is the form of that idea that works, and is implemented.
             raise NotImplementedError("mridc_amd.RIMBlock implements dimensionality = conv_dim = 2 (HIP kernels) and "
-                                      "dimensionality = conv_dim = 3 (HIP data consistency + torch Conv3d layers), consecutive_slices = 1")
+                                      "dimensionality = conv_dim = 3 (HIP data consistency + torch Conv3d layers), consecutive_slices = 1 "
+                                      "(the reference's own forward raises for consecutive_slices > 1 with dimensionality 2)")
         self.input_size = depth * 2                                   # rim_block.py:67
         self.time_steps = time_steps
         self.layers = torch.nn.ModuleList()

@@ -50,7 +50,7 @@ struct UConvHArgs {
     const uh_u4* packed; // mrx_unet_conv3x3_pack
     float* y;            // [B,Cout,H,W] raw
     float* tstats;       // [B][ntiles][Cout][2] (mean, M2) per tile
-    int Ca, Cb, B, Cout, H, W, tiles_x, ntiles, nct, nsteps;
+    int Ca, Cb, B, Cout, H, W, tiles_x, ntiles, nct, nsteps, nitems;
     float slope;
     const float* bias;   // plain convolution (UNET = false): [Cout] or null; act MRX_ACT_*; pad_mode MRX_PAD_ZERO | MRX_PAD_REPLICATE
     int act, pad_mode;
@@ -373,14 +373,31 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? (TK ? 3 : 4) : (NCOT == 2 ? 3 : 
 
     // workgroup -> work item: the runtime deals consecutive workgroups round-robin over the 8 XCDs (8 L2 caches); with item = blockIdx.x the two horizontal
     // neighbours of a tile -- which re-read 2 of its 34 halo'd columns, and the tiles above / below 2 of its 10 rows -- always sat behind OTHER L2s.  The band
-    // map gives every XCD a contiguous range of items (MRX_UH_NO_BAND: A/B)
+    // map gives every XCD a contiguous range of items (MRX_UH_NO_BAND: A/B).
+    // MRX_UH_PERSIST (A/B, round 5): the grid is the number of RESIDENT workgroups and each walks its items -- no workgroup launch (registers, LDS, the
+    // scale / offset set-up above) per 8 x 32 tile; with MRX_UH_PERSIST = 2 the next item's first tile is requested as soon as this item's last one is
+    // committed to LDS (its registers are free from there on): the load latency of item i + 1 runs under the matrix work, stores and statistics of item i.
 #ifdef MRX_UH_NO_BAND
-    const int item = blockIdx.x;
+#define UH_ITEM(i) (i)
 #else
-    const int item = (int)mrx_xcd_band(blockIdx.x, gridDim.x);
+#define UH_ITEM(i) ((int)mrx_xcd_band((i), a.nitems))
 #endif
+#ifdef MRX_UH_PERSIST
+    const int it_step = gridDim.x;
+    bool prefetched = false;
+    for (int it = blockIdx.x; it < a.nitems; it += it_step) {
+    const int item = UH_ITEM(it);
+    if (it != (int)blockIdx.x) __syncthreads();      // the previous item's readers of the operand buffers and of `red` are done
+    if (!prefetched) {
+        issue_x(item, 0);
+        issue_w(item, 0);
+    }
+#else
+    {                                                // one item per workgroup (the product form)
+    const int item = UH_ITEM((int)blockIdx.x);
     issue_x(item, 0);
     issue_w(item, 0);
+#endif
     {
         const int tile = item % a.ntiles, bc = item / a.ntiles, b = bc / ncob, co0 = (bc - b * ncob) * NCOT * 16;
         const int ty0 = tile / a.tiles_x, h0 = ty0 * UH_TH, w0 = (tile - ty0 * a.tiles_x) * UH_TW;
@@ -398,6 +415,13 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? (TK ? 3 : 4) : (NCOT == 2 ? 3 : 
                 issue_x(item, q + 1);
                 issue_w(item, q + 1);
             }
+#if defined(MRX_UH_PERSIST) && MRX_UH_PERSIST == 2
+            else if (it + it_step < a.nitems) {          // ... and behind the last step the next ITEM's first tile
+                issue_x(UH_ITEM(it + it_step), 0);
+                issue_w(UH_ITEM(it + it_step), 0);
+                prefetched = true;
+            }
+#endif
             if (!(a.abl & 1))
 #pragma unroll
             for (int m = 0; m < UH_MS; ++m) {
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? (TK ? 3 : 4) : (NCOT == 2 ? 3 : 
         };
         constexpr bool tickets = UNET && TK;
         if (!tickets) store_y();          // (with tickets the tile is stored BEHIND them: the stores cover the tickets' round trip)
-        if (!UNET || (a.abl & 4)) return;
+        if (UNET && !(a.abl & 4)) {
         // InstanceNorm statistics of this tile, per cout (the scheme of k_uconv, unet_fused.hip: mean over the tile's valid pixels, then the squared
         // deviations from that mean; k_unorm_finalize merges the tiles in double)
         const int nrow = a.H - h0 < UH_TH ? a.H - h0 : UH_TH, ncol = a.W - w0 < UH_TW ? a.W - w0 : UH_TW;
@@ -555,6 +579,8 @@ __global__ __launch_bounds__(UH_NT, NCOT == 1 ? (TK ? 3 : 4) : (NCOT == 2 ? 3 : 
                 if (lane == 0) __hip_atomic_store(a.counters + ((long long)b * a.Cout + co0 + c) * UH_TICKET_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left as it was found
             }
         }
+        }
+    }
     }
 }
 
@@ -570,7 +596,22 @@ static int launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
     }
     const long long nitems = (long long)a.ntiles * mrx_cdiv(a.nct, NCOT) * a.B;
     MRX_REQUIRE(nitems < (1ll << 31), MRX_EUNSUP, "two-term fp16 convolution: %lld work items", nitems);
-    hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET, TK>), dim3((unsigned)nitems), dim3(UH_NT), lds, st, a);
+    UConvHArgs a2 = a;
+    a2.nitems = (int)nitems;
+    long long grid = nitems;
+#ifdef MRX_UH_PERSIST
+    {
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        const long long resident = (long long)ncu * (NCOT == 1 ? (TK ? 3 : 4) : (NCOT == 2 ? 3 : 2));
+        grid = nitems < resident ? nitems : resident;
+    }
+#endif
+    hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET, TK>), dim3((unsigned)grid), dim3(UH_NT), lds, st, a2);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
