@@ -382,7 +382,7 @@ def _event_profile(timer, step, d, n=2):
     timer.enabled = False
 
 
-ORACLE_THREADS_DEFAULT = 32       # the best of the committed sweep (profiles/r05_cpu_thread_sweep.txt: 32 / 64 / 128 / 256 threads on the GPU box's host)
+ORACLE_THREADS_DEFAULT = 16       # the best of the committed sweep (profiles/r05_cpu_thread_sweep.txt: 8 / 16 / 32 / 64 / 128 / 256 threads on the GPU box's 256-thread host, stand-alone and inside this bench)
 
 
 def _oracle_threads():

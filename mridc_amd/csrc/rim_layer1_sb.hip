@@ -239,7 +239,7 @@ int mrx_l1sb_pack(const float* w_conv, const float* w_ih, float* packed, int Cin
 template <bool F16, bool CB8 = false, bool MORE = true, int LLGT = -1, int NW = 16>
 __global__ __launch_bounds__(NW * 64, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
     constexpr int NTHR = NW * 64;
-    constexpr bool HP_EARLY = NW != 16 && CB8;
+    constexpr bool HP_EARLY = NW == 12 && CB8;
     constexpr int NT = F16 ? 2 : 3, WCONV = F16 ? SBH_WCONV : SB_WCONV, WIH = F16 ? SBH_WIH : SB_WIH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];
     u32x4* Wl = reinterpret_cast<u32x4*>(smem_sb);                                        // [WCONV + WIH] A operands
@@ -601,16 +601,21 @@ static void l1sb_launch_form(const MrxL1sbArgs& a, int grid, size_t lds, hipStre
         attr_done = true;
     }
 #ifdef MRX_L1_W12
+#ifndef MRX_L1_NW
+#define MRX_L1_NW 12
+#endif
     if (CB8 && F16 && a.eta2 && a.nparts <= 4) {
+        constexpr int NWV = MRX_L1_NW;                  // (A/B builds: 12 waves with early h_prev; 8 waves = half the register file, for the co-residency probe)
+        constexpr size_t ldsv = (size_t)(SBH_WCONV + SBH_WIH) * 16 + 256 * sizeof(float) + (size_t)NWV * 2 * SB_PSTR * 8;
         static bool attr12 = false;
         if (!attr12) {
-            (void)hipFuncSetAttribute((const void*)k_rim_layer1_sb<F16, CB8, false, 1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)k_rim_layer1_sb<F16, CB8, false, 1, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsv);
             attr12 = true;
         }
         MrxL1sbArgs a12 = a;
-        a12.ntiles = a.tiles_x * mrx_cdiv(a.H, 12);
+        a12.ntiles = a.tiles_x * mrx_cdiv(a.H, NWV);
         const long long total12 = (long long)a12.ntiles * a.B;
-        hipLaunchKernelGGL((k_rim_layer1_sb<F16, CB8, false, 1, 12>), dim3((int)(total12 < grid ? total12 : grid)), dim3(12 * 64), lds, st, a12);
+        hipLaunchKernelGGL((k_rim_layer1_sb<F16, CB8, false, 1, NWV>), dim3((int)(total12 < grid ? total12 : grid)), dim3(NWV * 64), ldsv, st, a12);
         return;
     }
 #endif

@@ -1090,7 +1090,11 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
         attr_done = true;
     }
     if (W4) a.ntiles = a.tiles_x * mrx_cdiv(a.H, 8);                   // 8 x 32 tiles
+#ifdef MRX_L2_W4_ONE
+    const int ncu = l2sb_ncu();                                         // (co-residency probe: ONE 4-wave workgroup per CU, the rest of the CU for another kernel)
+#else
     const int ncu = (W4 ? 2 : 1) * l2sb_ncu();                          // two 4-wave workgroups per CU
+#endif
     const long long total = (long long)a.ntiles * a.B;
     const int grid = (int)(total < ncu ? total : ncu);
     a.trace = nullptr;

@@ -19,7 +19,7 @@ s = synthetic.make_slice(15, 640, 372, slice_idx=0)
 box = os.cpu_count() or 1
 print(f"host: {box} hardware threads")
 best = None
-for n in [t for t in (16, 32, 64, 128, 256) if t <= box] or [box]:
+for n in [t for t in (8, 16, 32, 64, 128, 256) if t <= box] or [box]:
     torch.set_num_threads(n)
     with torch.no_grad():
         oracle.models.cirim_forward(state, dict(cfg, num_cascades=1), s["y"], s["sensitivity_maps"], s["mask"], None, s["target"])      # warm-up
