@@ -238,7 +238,12 @@ __device__ __forceinline__ void uh_finalize_plane(const float* __restrict__ tsta
 // TK: the ticket form (a.counters given) is its own instantiation -- its merge keeps 32 tile statistics per lane in registers, which the 128-register
 // budget of the four-workgroups-per-CU form does not have (84 bytes of scratch per lane when it was a run-time branch of the one kernel)
 template <int NCOT, int DIL, bool UNET, bool TK = false>
-__global__ __launch_bounds__(UH_NT, NCOT == 1 ? (TK ? 3 : 4) : (NCOT == 2 ? 3 : 2)) void k_uconv_h(UConvHArgs a) {
+#ifdef MRX_UH_PERSIST
+#define UH_WGS(NCOT, TK) ((NCOT) == 1 ? 3 : 2)                 // (the resident form keeps its staging roles alive across items: one workgroup per CU fewer, no scratch)
+#else
+#define UH_WGS(NCOT, TK) ((NCOT) == 1 ? ((TK) ? 3 : 4) : ((NCOT) == 2 ? 3 : 2))
+#endif
+__global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uh[];
     constexpr int UH_PW = uh_pw(DIL), UH_PIX = uh_pix(DIL), UH_PLANE = uh_plane(DIL), UH_XBUF = uh_xbuf(DIL);
     constexpr int NSLOT = (UH_PIX + 127) / 128;                 // tile pixels per staging thread: 3 (dilation 1), 4 (dilation 2)
@@ -607,7 +612,7 @@ static int launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
             hipDeviceProp_t prop;
             ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         }
-        const long long resident = (long long)ncu * (NCOT == 1 ? (TK ? 3 : 4) : (NCOT == 2 ? 3 : 2));
+        const long long resident = (long long)ncu * UH_WGS(NCOT, TK);
         grid = nitems < resident ? nitems : resident;
     }
 #endif
