@@ -757,7 +757,7 @@ def conv1x1_64(x, weight, bias=None, act=ACT_NONE, slope=0.0, hh=None, h_prev=No
     if H3X3_CONV and _lib.arith() == "f16x2" and _lib.lib().mrx_conv1x1_sq_xmax_supported(Cin):
         # a 3x3 layer on two-term fp16 operands may read this next (qRIM: cell of stack 1 -> convolution of stack 2): the kernel keeps the
         # bound of its outputs, the consumer finds it on the tensor (ops._plain_bound) instead of running mrx_max_abs over it
-        xmax = torch.zeros(1, dtype=torch.float32, device=x.device)
+        xmax = _zero_scalar(x.device)
         _lib.check(_lib.lib().mrx_conv1x1_sq_xmax(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out),
                                                   _lib.ptr(xmax), B, Cin, H * W, int(act), float(slope), _lib.stream_ptr()), "mrx_conv1x1_sq_xmax")
         return _attach_bound(out, xmax)
@@ -831,7 +831,7 @@ def conv3x3_sb(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slo
     if out is None:
         out = torch.empty(B, 64, H, W, dtype=torch.float32, device=x.device)
     if chain:
-        xmax_out = torch.zeros(1, dtype=torch.float32, device=x.device)
+        xmax_out = _zero_scalar(x.device)
         _lib.check(L.mrx_conv3x3_sb_chain(_lib.ptr(x), _lib.ptr(hit[0]) if hit else None, _lib.ptr(hit16[0]) if hit16 else None, _lib.ptr(b),
                                           _lib.ptr(out), _lib.ptr(bound_in), _lib.ptr(xmax_out), B, H, W, int(dilation), int(pad_mode), int(act),
                                           float(slope), _lib.stream_ptr()), "mrx_conv3x3_sb_chain")
@@ -1658,7 +1658,7 @@ def gated_cell_1x1(x, h, packed, b_ih, gates, F=64):
     out = torch.empty((B, F, H, W), dtype=torch.float32, device=x.device)
     if SB_CHAIN and _lib.arith() == "f16x2":
         # the next stack's 64-channel convolution reads this state: keep the bound of it (mrx_conv3x3_sb_chain then runs two-term fp16 operands)
-        xmax = torch.zeros(1, dtype=torch.float32, device=x.device)
+        xmax = _zero_scalar(x.device)
         _lib.check(_lib.lib().mrx_gated_cell_1x1_xmax(_lib.ptr(x), _lib.ptr(h), _lib.ptr(packed), _lib.ptr(b_ih), _lib.ptr(out), _lib.ptr(xmax), B,
                                                       Cin, F, H * W, int(gates), _lib.stream_ptr()), "mrx_gated_cell_1x1_xmax")
         return _attach_bound(out, xmax)
@@ -1694,7 +1694,7 @@ def conv2dgru_cell_1x1(x, h, packed, bias, relu_out=True):
     out_relu = torch.empty_like(x) if relu_out else None
     if relu_out and SB_CHAIN and _lib.arith() == "f16x2":
         # ReLU(new state) is the next layer's convolution input: keep its bound (mrx_conv3x3_sb_chain then runs two-term fp16 operands)
-        xmax = torch.zeros(1, dtype=torch.float32, device=x.device)
+        xmax = _zero_scalar(x.device)
         _lib.check(_lib.lib().mrx_conv2dgru_cell_1x1_xmax(_lib.ptr(x), _lib.ptr(h), _lib.ptr(packed), _lib.ptr(bias), _lib.ptr(out),
                                                           _lib.ptr(out_relu), _lib.ptr(xmax), B, F, H * W, _lib.stream_ptr()),
                    "mrx_conv2dgru_cell_1x1_xmax")
@@ -2018,6 +2018,25 @@ def _analytic_bound(n, device):
     if t is None:
         t = _UNET_BOUNDS[key] = torch.full((1,), float(n) ** 0.5, dtype=torch.float32, device=device)
     return t
+
+
+_ZERO_SCALARS = {}
+
+
+def _zero_scalar(device):
+    """A fresh zeroed 1-element device tensor for a kernel that folds a maximum into it (atomic max): handed out of a block of 256 zeros made by ONE fill
+    launch per (device, stream, hipGraph capture) -- `torch.zeros(1)` per call was a 3-5 us fill kernel each (127 of them per 7 qCIRIM steps, 5 % of that
+    configuration's kernel time).  Every scalar is handed out once; a block made inside a capture belongs to that graph (the rule of _analytic_bound)."""
+    cap = int(_lib.lib().mrx_stream_capture_id(_lib.stream_ptr()))
+    for k in [k for k in _ZERO_SCALARS if k[2] != 0 and k[2] != cap]:
+        del _ZERO_SCALARS[k]
+    key = (str(device), int(torch.cuda.current_stream().cuda_stream), cap)
+    blk = _ZERO_SCALARS.get(key)
+    if blk is None or blk[1] >= blk[0].numel():
+        blk = _ZERO_SCALARS[key] = [torch.zeros(256, dtype=torch.float32, device=device), 0]
+    i = blk[1]
+    blk[1] = i + 1
+    return blk[0][i:i + 1]
 
 
 def _attach_bound(t, bound):
