@@ -356,3 +356,29 @@ def test_prelu_slope_cache_dies_with_its_module():
     assert didn._prelu_slope(b) == pytest.approx(0.3)
     b.weight.data = torch.tensor([0.9])                        # a re-pointed parameter moves the address; the old storage stays pinned
     assert didn._prelu_slope(b) == pytest.approx(0.9)
+
+
+def test_bench_summary_is_the_last_key_and_fits_a_kilobyte():
+    """The driver keeps the tail of the bench line: `summary` (bench.summary_of) carries every configuration's value, roofline fraction, counter traffic over
+    algorithmic bytes, parity and CPU baseline in <= 1 KB, and bench.main() appends it as the LAST key."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sub = dict(value=1187.64177, ms_per_step=13.4712, roofline=dict(frac=0.30321, bound="hbm", traffic=474.7e6, algorithmic_bytes=217.9e6),
+               parity_vs_oracle=dict(rel_l2=8.365e-6), cpu_baseline=dict(value=3.0331))
+    res = dict(value=148.2944, ms_per_step=107.9, roofline=dict(frac=0.40569, bound="mfma", traffic=1697262912.0, algorithmic_bytes=1599897600.0,
+                                                               mfma_util_pmc_regulariser=0.49905), roofline_fft=dict(frac=0.5477, executed_frac=0.3142),
+               parity_vs_oracle=dict(rel_l2=2.0646e-7), cpu_baseline=dict(value=0.1961), exact_fp32_route=dict(value=98.08), streamed_inputs=dict(value=145.7),
+               other_configs={k: dict(sub) for k in ("e2evn_6cascade_15coil_640x372", "qcirim_4echo_32coil_256x256", "cirim_training_bf16_15coil_640x372",
+                                                     "e2evn_training_15coil_640x372", "cirim_2d_mask_15coil_640x372",
+                                                     "cirim_8cascade_x5_time_steps_rimblock_direct")})
+    s = bench.summary_of(res)
+    assert len(json.dumps(s)) <= 1024, len(json.dumps(s))
+    assert s["headline"]["v"] == 148.3 and s["headline"]["traf"] == 1.061 and s["headline"]["mfma_busy_reg"] == 0.499
+    assert set(s) == {"headline", "bf16x3", "streamed", "e2evn", "qcirim", "train_bf16", "train_e2evn", "mask2d", "rim5"}
+    assert s["e2evn"] == dict(v=1188.0, ms=13.47, frac=0.3032, bound="hbm", traf=2.179, rel=8.365e-06, cpu=3.033)
+    src = open(os.path.join(root, "bench.py")).read()
+    assert 'res["summary"] = summary_of(res)' in src and src.index('res["summary"] = summary_of(res)') > src.index('res["other_configs"] = others')
