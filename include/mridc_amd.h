@@ -213,6 +213,11 @@ int mrx_llg_cols_dc(float* work, const float* y, const void* mask, int mask_kind
  *                           sums left in work ([*nparts][B,H,372,2]) for mrx_rim_layer_indrnn_packed_llg; work: mrx_llg372_work_floats */
 int mrx_tile4_cols(const float* x, float* out, int64_t nimg, int H, int W, void* stream);
 int mrx_pfa372_expand_t4(const float* x, const float* Sp, float* out_t4, int B, int C, int H, int norm, int centered, void* stream);
+/* mrx_pfa372_expand_t4 on eta_out = eta + the nine-tap gather of `taps` [B,18,H,372] (+ b_final [2] or NULL): mrx_rim_final_gather folded into the first pass
+ * of the NEXT step's general-mask gradient (rim_block.py:239-248 then rim_utils.py:47-52).  eta_out [B,H,372,2] is written, bit-identical to
+ * mrx_rim_final_gather's result; eta_out != eta. */
+int mrx_pfa372_expand_t4_gather(const float* eta, const float* taps, const float* b_final, float* eta_out, const float* Sp, float* out_t4, int B, int C,
+                                int H, int norm, int centered, void* stream);
 int mrx_llg_cols_dc_t4(float* work_t4, const float* y_t4, const void* mask, int mask_kind, const int64_t* mstride, int B, int C, int H,
                        int W, int norm, int centered, void* stream);
 int mrx_llg_cols_dc_t4_supported(int H, int W);

@@ -133,6 +133,7 @@ _SIGNATURES = {
     "mrx_llg_cols_dc": ([_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_tile4_cols": ([_p, _p, _i64, _i, _i, _p], _i),
     "mrx_pfa372_expand_t4": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "mrx_pfa372_expand_t4_gather": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_llg_cols_dc_t4": ([_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_llg_cols_dc_t4_supported": ([_i, _i], _i),
     "mrx_pfa372_reduce_t4": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),

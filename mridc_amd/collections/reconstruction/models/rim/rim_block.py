@@ -381,12 +381,19 @@ class RIMBlock(torch.nn.Module):
         # W = 372, constant-plane gradient: the nine-tap gather that ends a step (eta + final convolution) rides in the NEXT step's gradient launch
         # (mrx_llg372_gather); `pending` = the tap products of a step whose eta has not been formed yet
         fuse_gather = cb8 and defer and op372 is not None and ops.LLG372_NO_Y and ops.LLG372_GATHER
+        # ... and, for general masks at W = 372, in the first of the next step's three gradient passes (mrx_pfa372_expand_t4_gather)
+        fuse_gather_t4 = cb8 and defer and op372 is None and t4 and ops.LLG_T4_NO_Y and ops.LLG_T4_GATHER
         pending = None
         for step in range(self.time_steps):                          # rim_block.py:217-249
             own = step > 0                                           # the states of step 0 are the caller's (or the zero state)
             if cb8:
                 part, nparts, grad_eta = None, 0, None
-                if pending is not None:
+                if pending is not None and fuse_gather_t4:
+                    part, nparts, eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization, self.spatial_dims,
+                                                work=work, parts=True, gather=(pending, final.conv_layer.bias))
+                    etas.append(eta)
+                    pending = None
+                elif pending is not None:
                     part, nparts, eta = ops.llg372_gather(eta, pending, final.conv_layer.bias, op372, sigma, self.fft_normalization)
                     etas.append(eta)
                     pending = None
@@ -410,7 +417,7 @@ class RIMBlock(torch.nn.Module):
                                            out=hx[0] if (self.inplace_state and hx[0] is not None) else None)
                 hx[1], taps = ops.rim_layer2_f16_cb8(hx[0], self._packed_f16(1, c1, r1, final), c1.conv_layer.bias, r1.ih.bias, r1.hh, hx[1], xmax,
                                                      out=hx[1] if (self.inplace_state and hx[1] is not None) else None, want_taps=True)
-                if fuse_gather and step + 1 < self.time_steps:
+                if (fuse_gather or fuse_gather_t4) and step + 1 < self.time_steps:
                     pending = taps
                     continue
                 eta = ops.rim_final_gather(taps, final.conv_layer.bias, eta)

@@ -299,9 +299,12 @@ struct L372Dc {
 // reading the coil stack and the maps again.
 // DC: the data-consistency epilogue compiled in (E2EVN's cascades); without it the pass is the first pass of the general-mask gradient and of sens_expand -- a
 // run-time switch cost that form 1.8 us per launch (registers of the operand prefetch, the unrolled coil loop's exits)
-template <bool RED, bool DC>
+// GAT (round 5; general-mask gradient): x is not read but MADE here -- the previous step's eta plus the nine-tap gather of the final convolution's tap
+// products (the block of k_llg372<.., GAT>, same order of additions: bit-identical to k_l2sb_gather) -- and written out by the row's first task.
+template <bool RED, bool DC, bool GAT = false>
 __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restrict__ x_, const float2* __restrict__ Sp_,
-                                                          float2* __restrict__ out_, L372Args a, L372Dc dc, float2* __restrict__ part_) {
+                                                          float2* __restrict__ out_, L372Args a, L372Dc dc, float2* __restrict__ part_,
+                                                          L372Gather ga = L372Gather{nullptr, nullptr, nullptr}) {
     const pfa_c* __restrict__ xin = reinterpret_cast<const pfa_c*>(x_);
     const pfa_c* __restrict__ Sp = reinterpret_cast<const pfa_c*>(Sp_);
     extern __shared__ __attribute__((aligned(16))) float2 X_[];
@@ -316,13 +319,54 @@ __global__ __launch_bounds__(64, 2) void k_pfa372_expand(const float2* __restric
     const int g1 = l / PFA_N1, n1 = l - g1 * PFA_N1;
     pfa_c ev[6];
     const pfa_c* erow = xin + (long long)row * PFA_N;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ev[i] = erow[pfa372_shift(min(l + 64 * i, PFA_N - 1), a.halfW)];
     Pfa372Lane L;
-    {
+    auto load_maps = [&]() {
         const pfa_c* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
 #pragma unroll
         for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = sp[n2 * PFA_L1];
+    };
+    if constexpr (GAT) {
+        load_maps();            // requested BEFORE the gather's 114 loads: they arrive under it
+        const long long plane = (long long)a.H * PFA_N;
+        const float* __restrict__ pb = ga.taps + (long long)b * 18 * plane;
+        const int hh = (int)h, y0 = hh > 0 ? hh - 1 : 0, y2 = hh + 1 < a.H ? hh + 1 : a.H - 1;
+        const float b0 = ga.bias ? ga.bias[0] : 0.f, b1 = ga.bias ? ga.bias[1] : 0.f;
+        float t[6][18];
+        float2 e[6], vout[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {           // all 6 x 19 loads of the row before the first sum, eta written after the last one (k_llg372's note)
+            const int n = min(l + 64 * i, PFA_N - 1);
+            const int w = pfa372_shift(n, a.halfW);
+            const int x0 = w > 0 ? w - 1 : 0, x2 = w + 1 < PFA_N ? w + 1 : PFA_N - 1;
+            const int ro[3] = {y0 * PFA_N, hh * PFA_N, y2 * PFA_N}, co[3] = {x0, w, x2};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* q = pb + (long long)((dy * 3 + dx) * 2) * plane + ro[dy] + co[dx];
+                    t[i][(dy * 3 + dx) * 2] = q[0];
+                    t[i][(dy * 3 + dx) * 2 + 1] = q[plane];
+                }
+            e[i] = x_[(long long)row * PFA_N + w];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float s0 = b0, s1 = b1;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s0 += t[i][2 * k], s1 += t[i][2 * k + 1];
+            vout[i] = make_float2(e[i].x + s0, e[i].y + s1);
+            ev[i] = pfa_mk(vout[i].x, vout[i].y);
+        }
+        if (z == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (l + 64 * i < PFA_N) ga.eta_out[(long long)row * PFA_N + pfa372_shift(l + 64 * i, a.halfW)] = vout[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ev[i] = erow[pfa372_shift(min(l + 64 * i, PFA_N - 1), a.halfW)];
+        load_maps();
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -899,6 +943,30 @@ extern "C" int mrx_pfa372_expand_t4(const float* x, const float* Sp, float* out_
     for (int i = 0; i < 4; ++i) dc.mask.s[i] = 0;
     hipLaunchKernelGGL((k_pfa372_expand<false, false>), dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)x,
                        (const float2*)Sp, (float2*)out_t4, a, dc, (float2*)nullptr);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// mrx_pfa372_expand_t4 on eta_out = eta + the nine-tap gather of `taps` [B,18,H,372] (+ b_final): the final convolution's gather (mrx_rim_final_gather)
+// folded into the first pass of the NEXT step's general-mask gradient; eta_out is written, bit-identical to mrx_rim_final_gather's result.
+extern "C" int mrx_pfa372_expand_t4_gather(const float* eta, const float* taps, const float* b_final, float* eta_out, const float* Sp, float* out_t4,
+                                           int B, int C, int H, int norm, int centered, void* stream) {
+    MRX_REQUIRE(eta && taps && eta_out && Sp && out_t4, MRX_EINVAL, "mrx_pfa372_expand_t4_gather: null pointer");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, 0);
+    if (rc) return rc;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_pfa372_expand_t4_gather: too many tasks");
+    MRX_REQUIRE((long long)H * PFA_N < (1ll << 31), MRX_EUNSUP, "mrx_pfa372_expand_t4_gather: image too tall");
+    a.tiled = 1;
+    L372Dc dc;
+    dc.on = 0;
+    dc.pred = dc.ref = nullptr, dc.w = nullptr;
+    dc.mask.p = nullptr, dc.mask.kind = MRX_MASK_U8;
+    for (int i = 0; i < 4; ++i) dc.mask.s[i] = 0;
+    L372Gather ga;
+    ga.taps = taps, ga.bias = b_final, ga.eta_out = reinterpret_cast<float2*>(eta_out);
+    hipLaunchKernelGGL((k_pfa372_expand<false, false, true>), dim3((unsigned)a.ntasks), dim3(64), sizeof(float2) * PFA_LDS_C2, (hipStream_t)stream, (const float2*)eta,
+                       (const float2*)Sp, (float2*)out_t4, a, dc, (float2*)nullptr, ga);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

@@ -259,9 +259,17 @@ def _llg_parts_buffer(y, sens, mask, centered, normalization, spatial_dims, n):
                               int(torch.cuda.current_stream().cuda_stream)), make)
 
 
-def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, out=None, work=None, parts=False):
+# General masks at W = 372: the tap gather rides in the next step's first gradient pass (mrx_pfa372_expand_t4_gather).  Built, bit-identical, and OFF by default:
+# the 2-D-mask line ran 110.0-110.7 slices/s with it against 111.2-111.7 without (tools/runs/r05p.sh, three alternating runs on one box) -- the three
+# coil-group tasks of an image row each repeat the row's 114 tap loads, which costs what the saved 5-us launch bought.
+LLG_T4_GATHER = os.environ.get("MRIDC_AMD_LLG_T4_GATHER", "0") == "1"
+
+
+def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, out=None, work=None, parts=False, gather=None):
     """log_likelihood_gradient -> [B,4,H,W].  `parts` (llg_t4_supported only): returns (part [n][B,H,W,2], n) -- the coil-group partial sums
-    of the last pass, for rim_layer_indrnn_packed_llg, which adds them, scales by 1/sigma^2 and splits the channels in its tile loader."""
+    of the last pass, for rim_layer_indrnn_packed_llg, which adds them, scales by 1/sigma^2 and splits the channels in its tile loader.
+    `gather` = (taps [B,18,H,W], b_final | None) with parts (the constant-plane form): eta is first replaced by eta + the nine-tap gather of the
+    previous step's tap products inside the first pass (mrx_pfa372_expand_t4_gather, bit-identical to rim_final_gather); returns (part, n, eta_new)."""
     y, sens, eta = _lib.f32c(y), _lib.f32c(sens), _lib.f32c(eta)
     B, C, H, W = _bchw(y)
     if sens.shape != y.shape:
@@ -283,7 +291,16 @@ def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, o
         nrm, cen, st = _norm(normalization), int(bool(centered)), _lib.stream_ptr()
         if llg_t4_supported(y):
             # the coil stack between the passes column-tiled (contiguous 4-column blocks for the column pass); y tiled once per slice
-            _lib.check(L.mrx_pfa372_expand_t4(_lib.ptr(eta), _lib.ptr(sp), _lib.ptr(work), B, C, H, nrm, cen, st), "mrx_pfa372_expand_t4")
+            eta_new = None
+            if gather is not None:
+                if not (parts and LLG_T4_NO_Y):
+                    raise ValueError("llg(gather=...) needs the constant-plane parts form")
+                taps, bfin = gather
+                eta_new = torch.empty_like(eta)
+                _lib.check(L.mrx_pfa372_expand_t4_gather(_lib.ptr(eta), _lib.ptr(_lib.f32c(taps)), _lib.ptr(_lib.f32c(bfin.detach()) if bfin is not None else None),
+                                                         _lib.ptr(eta_new), _lib.ptr(sp), _lib.ptr(work), B, C, H, nrm, cen, st), "mrx_pfa372_expand_t4_gather")
+            else:
+                _lib.check(L.mrx_pfa372_expand_t4(_lib.ptr(eta), _lib.ptr(sp), _lib.ptr(work), B, C, H, nrm, cen, st), "mrx_pfa372_expand_t4")
             if parts and LLG_T4_NO_Y:
                 n0 = int(L.mrx_llg372_work_floats(B, C, H)) // (B * H * W * 2)           # coil-group partial planes of the last pass
                 wk = _llg_parts_buffer(y, sens, mask, centered, normalization, spatial_dims, n0)
@@ -293,7 +310,7 @@ def llg(eta, y, sens, mask, sigma, centered, normalization, spatial_dims=None, o
                                                   float(1.0 / (float(sigma) ** 2.0)), nrm, cen, st), "mrx_pfa372_reduce_t4")
                 if int(n.value) != n0:
                     raise RuntimeError(f"llg: {n.value} partial planes, expected {n0}")
-                return wk, n0 + 1
+                return (wk, n0 + 1, eta_new) if gather is not None else (wk, n0 + 1)
             yt4 = _y_t4(y)
             wk = torch.empty(int(L.mrx_llg372_work_floats(B, C, H)), dtype=torch.float32, device=y.device)
             _lib.check(L.mrx_llg_cols_dc_t4(_lib.ptr(work), _lib.ptr(yt4), _lib.ptr(m), kind, ms, B, C, H, W, nrm, cen, st), "mrx_llg_cols_dc_t4")

@@ -581,6 +581,50 @@ def test_rim_block_general_mask_at_w372(dev):
     assert rel_l2(outs[True], outs[False]) <= 5e-6
 
 
+def test_general_mask_gradient_with_the_tap_gather_folded_in(dev):
+    """Round 5: for general (2-D) masks at W = 372 the nine-tap gather that ends a RIM step rides in the FIRST pass of the next step's gradient
+    (mrx_pfa372_expand_t4_gather).  The operator: eta_new bit-identical to mrx_rim_final_gather, partial planes bit-identical to the gradient of that
+    eta.  The block: 8 steps with the fold on and off give bit-identical estimates (15 x 640 x 372 and a ragged small shape)."""
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(23)
+    for B, C, H in ((2, 15, 640), (1, 6, 37)):
+        W = 372
+        r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+        eta, taps, bfin = r(B, H, W, 2), r(B, 18, H, W) * 0.1, r(2) * 0.1
+        S, y = r(B, C, H, W, 2) * 0.3, r(B, C, H, W, 2)
+        m = (torch.rand(B, 1, H, W, 1, generator=g) < 0.3).to(dev)
+        y = y * m
+        want_eta = ops.rim_final_gather(taps, bfin, eta)
+        part0, n0 = ops.llg(want_eta, y, S, m, 1.0, False, "backward", parts=True)
+        part0 = part0[:n0].clone()
+        part1, n1, got_eta = ops.llg(eta, y, S, m, 1.0, False, "backward", parts=True, gather=(taps, bfin))
+        assert n1 == n0 and torch.equal(got_eta, want_eta) and torch.equal(part1[:n1], part0)
+    cfg, model, sd = _cirim(dict(num_cascades=1), 1.0)
+    d = synthetic.make_slice(15, 640, 372, slice_idx=4)
+    m2d = torch.rand(1, 1, 640, 372, 1, generator=torch.Generator().manual_seed(11)) < 0.3
+    m2d[:, :, 300:340, 170:202] = True
+    blk = model.cirim[0].to(dev)
+    yd, S, m = (d["kspace"] * m2d).to(dev), d["sensitivity_maps"].to(dev), m2d.to(dev)
+    outs = {}
+    keep = ops.LLG_T4_GATHER
+    try:
+        for fold in (True, False):
+            ops.LLG_T4_GATHER = fold
+            calls = []
+            orig = ops.rim_final_gather
+            ops.rim_final_gather = lambda *a_, **k_: (calls.append(1), orig(*a_, **k_))[1]
+            try:
+                with torch.no_grad():
+                    etas, _ = blk(yd, yd, S, m, None, None, 1.0, keep_eta=False)
+            finally:
+                ops.rim_final_gather = orig
+            assert len(calls) == (1 if fold else blk.time_steps)            # folded: only the last step's gather is its own launch
+            outs[fold] = torch.stack(etas)
+    finally:
+        ops.LLG_T4_GATHER = keep
+    assert torch.equal(outs[True], outs[False])
+
+
 @pytest.mark.parametrize("shape", [(15, 640, 372), (6, 37, 75)])
 def test_rim_block_fp16_route_on_and_off(dev, shape):
     """RIMBlock with the dominant layer's convolution on two-term fp16 operands (the default: stack 0 keeps the bound of its outputs, stack 1

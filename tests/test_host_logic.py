@@ -246,7 +246,8 @@ def test_hot_kernels_keep_their_loads_ahead_of_their_waits(tmp_path):
         "rim_layer1_sb": [("_Z15k_rim_layer1_sbILb1ELb1ELb0ELi1ELi16EE", 4, 8, True)],                   # 3 / 6
         "rim_layer2_sb": [("_Z15k_rim_layer2_sbILi2ELb1ELb0ELb1ELi0ELb1ELb0ELb0ELb1EE", 6, 11, True)],   # the FAST route (round 5)
         "llg372": [("_Z8k_llg372ILi0ELb1ELb0EE", 0, 2, True), ("_Z8k_llg372ILi0ELb1ELb1EE", 0, 2, True),   # 0 / 1 each (151 loads in the gather form)
-                   ("_Z15k_pfa372_reduce", 0, 2, True), ("_Z15k_pfa372_expandILb0ELb0EE", 0, 2, True)],
+                   ("_Z15k_pfa372_reduce", 0, 2, True), ("_Z15k_pfa372_expandILb0ELb0ELb0EE", 0, 2, True),
+                   ("_Z15k_pfa372_expandILb0ELb0ELb1EE", 0, 2, True)],      # (<.., GAT>: round 5, the tap gather inside the general-mask gradient's first pass)
         "fft": [("_Z12k_cols_dc_t4I6PlanCTILi640EJLi5ELi8ELi4ELi4EEELb1EE", 0, 2, True)],
         "gated_cell_sb": [("_Z15k_conv1x1_sb128ILi2EE", 5, 9, True)],                                    # 4 / 7
         "train_bf16": [("_Z13k_tl_cell_bwdILb1ELb1ELb1EE", 3, 6, True)],                                 # 2 / 4
