@@ -357,10 +357,20 @@ __global__ __launch_bounds__(UC_NT) void k_uconvT(const float* __restrict__ x, c
 #pragma unroll
     for (int co = 0; co < COG; ++co) acc[co] = (uc_f4){0.f, 0.f, 0.f, 0.f};
     int ci = 0;
+    // four input planes per round, the NEXT round's four requested before this round's 4 x 4 COG multiply-adds (round 5: as a plain loop every round waited
+    // for its own loads -- seven memory round trips one after the other for a 28-channel layer, at two workgroups per CU)
+    float vn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vn[u] = xp[(long long)(u < Cin ? u : 0) * HW];
     for (; ci + 4 <= Cin; ci += 4) {
         float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = xp[(long long)(ci + u) * HW];
+        for (int u = 0; u < 4; ++u) v[u] = vn[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cn = ci + 4 + u;
+            vn[u] = xp[(long long)(cn < Cin ? cn : 0) * HW];
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (lazy) v[u] = uc_leaky((v[u] - nsm[2 * (ci + u)]) * nsm[2 * (ci + u) + 1], slope);
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(UC_NT) void k_uconvT(const float* __restrict__ x, c
         }
     }
     for (; ci < Cin; ++ci) {
-        float v = xp[(long long)ci * HW];
+        float v = vn[ci & 3];                      // (the rest of the last round, already requested)
         if (lazy) v = uc_leaky((v - nsm[2 * ci]) * nsm[2 * ci + 1], slope);
         const uc_f4* wq = reinterpret_cast<const uc_f4*>(wsm_u) + ci * COG;
 #pragma unroll
