@@ -396,7 +396,11 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
     auto st_coords = [&]() {
         if constexpr (NEWST) {
             // (beyond the last tile the pipeline keeps requesting -- the last tile again: the loads stay in range and nobody reads what they bring)
+#ifdef MRX_L2_ABL_XHOT                              // (timing variant: every tile's x loads re-read the workgroup's FIRST tile -- cache hits; results are garbage)
+            const int tq = blockIdx.x;
+#else
             const int tq = st_t < total ? st_t : total - 1;
+#endif
             const int tt = (int)mrx_xcd_band(tq, total);
             const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
             const int h0 = ty0 * TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
@@ -580,7 +584,11 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
         float hp[RPW][32];
         auto load_hp = [&](int rw) {              // lanes outside the image read a valid element (clamped) and store nothing
             const int oy = h0 + RPW * wave + rw, ox = w0 + l31;
+#ifdef MRX_L2_ABL_HPHOT                             // (timing variant: every tile's h_prev loads re-read one row of the image -- cache hits)
+            const int cy = RPW * wave + rw, cx = l31;
+#else
             const int cy = oy < a.H ? oy : a.H - 1, cx = ox < a.W ? ox : a.W - 1;
+#endif
             if (!a.hprev) {                       // the zero state: nothing to load (and nothing uninitialised to multiply by zero)
 #pragma unroll
                 for (int R = 0; R < 32; ++R) hp[rw][R] = 0.f;
@@ -795,7 +803,11 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
             }
         }
         S2_STAMP(2)        // (probe builds: [1, 2] = both rows' 1x1 stage, [2, 3] = epilogues, stores and the tap stage)
+#ifdef MRX_L2_ABL_NOST                              // (timing variant: a zero-sized descriptor -- the hardware drops every store)
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hnew + (long long)b * S2_F * plane, 0, 0u, 0x00020000);
+#else
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hnew + (long long)b * S2_F * plane, 0, (unsigned)(plane * (S2_F * 4)), 0x00020000);
+#endif
         unsigned offh[2];
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
@@ -847,7 +859,11 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
 #pragma unroll
                 for (int rw = 0; rw < 2; ++rw) accp[rw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[rw], accp[rw], 0, 0, 0);
             }
+#ifdef MRX_L2_ABL_NOST
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.P + (long long)b * 18 * plane, 0, 0u, 0x00020000);
+#else
             const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.P + (long long)b * 18 * plane, 0, (unsigned)(plane * (18 * 4)), 0x00020000);
+#endif
 #pragma unroll
             for (int rw = 0; rw < 2; ++rw) {
                 const int oy = oy0 + rw;
