@@ -1369,6 +1369,10 @@ def main():
                         mfma_util_pmc_regulariser=traffic.get("_mfma_util", {}).get("regulariser") if (l2_bf16 and l2_taps) else None,
                         mfma_util_pmc_source=traffic.get("_mfma_util_source"),
                         launches=n2, avg_ms=ms2, flops_per_launch=flops2, mfma_flops_per_launch=executed,
+                        # (measured once per round, not live: profiles/r05_layer2_power_probe.txt, tools/probe/l2_power.py + l2_power_clock.py)
+                        clock_note=("`peak` is the dense peak at 2.4 GHz.  This launch is granted 1.54 GHz (profiled) to ~1.8 GHz on full-entropy operands and 2.42 GHz on "
+                                    "zero operands (same instruction stream, GRBM_GUI_ACTIVE / duration): time per slice = 69.5 k cycles / clock + 26 us of memory streams "
+                                    "that do not scale with the clock (profiles/r05_layer2_power_probe.txt, r05_layer2_memory_ablation.txt)") if l2_f16 else None,
                         # the same launch against the HBM roofline (its algorithmic bytes: x, h_prev in, h_new and the tap planes out): with the
                         # two-term fp16 operands the kernel sits between its two bounds
                         hbm_frac=((3.0 * F_hidden + (18.0 if l2_taps else 0.0)) * npix * B * 4 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms2 else None,
