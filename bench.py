@@ -1095,6 +1095,9 @@ def streamed_inputs_run(args, step, hosts, datas, dev, slices_per_step, variant=
                      "inside the graph")
 
 
+NUMA_BINDING = None      # {"node", "cpus"} once main() has bound the rank to its GPU's NUMA node
+
+
 def main():
     args = parse()
     plan = rank_launch_plan(args.gpus, sys.argv[1:], os.environ)
@@ -1108,6 +1111,10 @@ def main():
     if args.dist_selftest:
         dist_selftest(args)
         return
+    # the rank on the CPUs (and, by first touch, the memory) of its GPU's NUMA node -- before the first GPU call (MRX_BENCH_NUMA=0 leaves the affinity alone)
+    from mridc_amd.sharding import bind_rank_to_gpu_numa_node
+    global NUMA_BINDING
+    NUMA_BINDING = bind_rank_to_gpu_numa_node(local_rank) if os.environ.get("MRX_BENCH_NUMA", "1") != "0" else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -1440,6 +1447,7 @@ def main():
                                mask=("1-D random columns R=4 (row-invariant: one-launch gradient)" if args.mask == "1d" else
                                      "2-D random points R~10 (general three-launch gradient)")),
                    world_size_seen=world_seen(), per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
+                   numa_binding=NUMA_BINDING,                 # rank 0's: the NUMA node of its GPU and the CPUs it was restricted to (None: topology unreadable)
                    launch="hipGraph replay" if graphed else "eager", roofline=roofline, roofline_fft=roofline_fft,
                    breakdown_ms=dict(llg=llg_per_step, conv_layer1=ms1, conv_layer2=ms2, final=final_per_step,
                                      rim_steps_per_slice=cfg["num_cascades"] * T_,

@@ -20,3 +20,92 @@ def gather_metric_sums(values, device=None):
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+# ---- one rank per GPU, on the GPU's own socket ------------------------------------------------------------------------------------------------
+# Every rank streams its slices from pinned host memory (8.7 GB/s per rank at 148 slices/s: DESIGN 5); on a two-socket host the staging buffers of a rank
+# must live on the NUMA node its GPU hangs off, or half the ranks read across the socket link.  The launcher the bench is run under (`torch.distributed.run`)
+# does not bind, and a rank may not re-exec itself under numactl once the GPU is initialised -- so the rank binds ITSELF, before its first GPU call, from
+# the KFD topology in sysfs: CPU nodes list their GPUs as PCIe io_links (type 2), GPU nodes are enumerated in the order HIP numbers the devices (the nodes
+# a process is not allowed to open are unreadable and are skipped, like HIP skips them).  Pure host logic over a directory tree: tested on a fake tree.
+def _kfd_props(path):
+    try:
+        with open(path) as f:
+            return {k: v for k, v in (ln.split(None, 1) for ln in f.read().splitlines() if " " in ln.strip())}
+    except OSError:
+        return None
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """[NUMA node id or None] per GPU this process may open, in device order."""
+    import os
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    try:
+        ids = sorted(int(n) for n in os.listdir(base) if n.isdigit())
+    except OSError:
+        return []
+    try:
+        numa_ids = sorted(int(n[4:]) for n in os.listdir(os.path.join(sysfs, "devices/system/node")) if n.startswith("node") and n[4:].isdigit())
+    except OSError:
+        numa_ids = []
+    owner, gpus, n_cpu = {}, [], 0
+    for n in ids:
+        p = _kfd_props(os.path.join(base, str(n), "properties"))
+        if p is None:
+            continue
+        if int(p.get("simd_count", "0")) > 0:
+            gpus.append(n)
+        elif int(p.get("cpu_cores_count", "0")) > 0:
+            numa = numa_ids[n_cpu] if n_cpu < len(numa_ids) else None      # the i-th CPU node of the KFD topology is the i-th NUMA node
+            n_cpu += 1
+            links = os.path.join(base, str(n), "io_links")
+            try:
+                names = os.listdir(links)
+            except OSError:
+                names = []
+            for ln in names:
+                lp = _kfd_props(os.path.join(links, ln, "properties"))
+                if lp is not None and lp.get("type") == "2" and "node_to" in lp:
+                    owner[int(lp["node_to"])] = numa
+    return [owner.get(g) for g in gpus]
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_rank_to_gpu_numa_node(local_rank, sysfs="/sys", environ=None, apply=True):
+    """Restrict this process to the CPUs of the NUMA node GPU `local_rank` is attached to (memory follows by first touch).  Call BEFORE the first GPU call.
+    Returns {"node": n, "cpus": count} or None when the topology says nothing (then nothing is changed).  Never raises."""
+    import os
+    try:
+        environ = os.environ if environ is None else environ
+        dev = int(local_rank)
+        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):               # an explicit device list renumbers the devices
+            vis = environ.get(var)
+            if vis:
+                items = [v.strip() for v in vis.split(",")]
+                if all(v.isdigit() for v in items) and dev < len(items):
+                    dev = int(items[dev])
+                else:
+                    return None
+                break
+        nodes = gpu_numa_nodes(sysfs)
+        if dev >= len(nodes) or nodes[dev] is None:
+            return None
+        with open(os.path.join(sysfs, f"devices/system/node/node{nodes[dev]}/cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        if apply:
+            cpus &= os.sched_getaffinity(0)
+            if not cpus:
+                return None
+            os.sched_setaffinity(0, cpus)
+        return {"node": nodes[dev], "cpus": len(cpus)}
+    except (OSError, ValueError, AttributeError):
+        return None

@@ -383,3 +383,47 @@ def test_bench_summary_is_the_last_key_and_fits_a_kilobyte():
     assert s["e2evn"] == dict(v=1188.0, ms=13.47, frac=0.3032, bound="hbm", traf=2.179, rel=8.365e-06, cpu=3.033)
     src = open(os.path.join(root, "bench.py")).read()
     assert 'res["summary"] = summary_of(res)' in src and src.index('res["summary"] = summary_of(res)') > src.index('res["other_configs"] = others')
+
+
+def _fake_kfd(tmp_path, readable_gpus):
+    """A KFD topology like the MI355X hosts': two CPU nodes (KFD 0, 1) with four GPUs each as PCIe links (KFD 2-5, 6-9); only `readable_gpus` may be opened."""
+    base = tmp_path / "class/kfd/kfd/topology/nodes"
+    for c, gpus in ((0, (2, 3, 4, 5)), (1, (6, 7, 8, 9))):
+        d = base / str(c)
+        (d / "io_links").mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count 128\nsimd_count 0\nlocation_id 0\n")
+        (d / "io_links/0").mkdir()
+        (d / "io_links/0/properties").write_text(f"type 1\nnode_from {c}\nnode_to {1 - c}\nweight 32\n")
+        for i, g in enumerate(gpus):
+            (d / f"io_links/{i + 1}").mkdir()
+            (d / f"io_links/{i + 1}/properties").write_text(f"type 2\nnode_from {c}\nnode_to {g}\nweight 20\n")
+    for g in range(2, 10):
+        d = base / str(g)
+        d.mkdir(parents=True)
+        if g in readable_gpus:
+            (d / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id 1234\n")
+        # (a GPU outside the process's device cgroup: the file cannot be read -- here it does not exist)
+    for n, cl in ((0, "0-63,128-191"), (1, "64-127,192-255")):
+        d = tmp_path / f"devices/system/node/node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+    return str(tmp_path)
+
+
+def test_rank_binds_itself_to_the_numa_node_of_its_gpu(tmp_path):
+    """sharding.bind_rank_to_gpu_numa_node: the KFD topology's PCIe links give the socket of every GPU; the devices a process cannot open are skipped like HIP
+    skips them; an explicit device list renumbers; an unreadable topology changes nothing."""
+    from mridc_amd import sharding
+    root = _fake_kfd(tmp_path / "all", set(range(2, 10)))
+    assert sharding.gpu_numa_nodes(root) == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert sharding.bind_rank_to_gpu_numa_node(1, root, environ={}, apply=False) == {"node": 0, "cpus": 128}
+    assert sharding.bind_rank_to_gpu_numa_node(6, root, environ={}, apply=False) == {"node": 1, "cpus": 128}
+    assert sharding.bind_rank_to_gpu_numa_node(0, root, environ={"HIP_VISIBLE_DEVICES": "7,0"}, apply=False) == {"node": 1, "cpus": 128}
+    assert sharding.bind_rank_to_gpu_numa_node(0, root, environ={"ROCR_VISIBLE_DEVICES": "GPU-deadbeef"}, apply=False) is None
+    assert sharding.bind_rank_to_gpu_numa_node(8, root, environ={}, apply=False) is None
+    one = _fake_kfd(tmp_path / "one", {7})                                 # a one-GPU box of the pool: device 0 is KFD node 7, on the second socket
+    assert sharding.gpu_numa_nodes(one) == [1]
+    assert sharding.bind_rank_to_gpu_numa_node(0, one, environ={}, apply=False) == {"node": 1, "cpus": 128}
+    assert sharding.gpu_numa_nodes(str(tmp_path / "nothing")) == []
+    assert sharding.bind_rank_to_gpu_numa_node(0, str(tmp_path / "nothing"), environ={}) is None
+    assert sharding._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
