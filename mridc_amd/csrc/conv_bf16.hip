@@ -1185,6 +1185,9 @@ __global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgra
             *reinterpret_cast<unsigned*>(Xs + ci * XS + (r * PW + g2 * 2) * 2) = cb_pk(v[0], v[1]);
         }
         __syncthreads();
+#ifdef MRX_WBG_ABL_NOMFMA                           // (timing variant: loads, conversions and LDS writes only)
+        if (a.B > 0) continue;
+#endif
 #pragma unroll
         for (int tw = 0; tw < TPW; ++tw) {
             const int tap = wave * TPW + tw;
