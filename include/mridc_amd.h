@@ -422,6 +422,12 @@ int mrx_gru_gates(const float* ih, const float* hh, const float* h, float* out, 
                   void* stream);
 int mrx_mgu_gates(const float* ih, const float* hh, const float* h, float* out, int B, int F, int64_t HW,
                   void* stream);
+/* Their backward (training RIMs with gated cells: the derivative of the lines above, which the reference leaves to autograd): given dy = dL/d out, the
+ * gradients w.r.t. ih, hh (same shapes) and h in ONE pass; the gates are recomputed from ih / hh.  No aliasing between outputs and inputs. */
+int mrx_gru_gates_bwd(const float* dy, const float* ih, const float* hh, const float* h, float* dih, float* dhh, float* dh, int B, int F, int64_t HW,
+                      void* stream);
+int mrx_mgu_gates_bwd(const float* dy, const float* ih, const float* hh, const float* h, float* dih, float* dhh, float* dh, int B, int F, int64_t HW,
+                      void* stream);
 
 /* A12 whole ConvGRUCell (gates = 3, rnn_cells.py:112-127) / ConvMGUCell (gates = 2, rnn_cells.py:249-261) with 1x1 `ih` and `hh`
  * kernels in ONE launch: both per-pixel GEMMs on the matrix cores and the gate math on the accumulators; the gates*F-channel conv
@@ -672,6 +678,13 @@ int mrx_instance_norm_act(const float* x, float* out, float* work, int64_t plane
 int mrx_group_norm_stats(const float* x, float* mean, float* std_, float* work, int64_t groups, int64_t n, void* stream);
 int mrx_group_norm_apply(const float* x, const float* mean, const float* std_, float* out, int64_t groups, int64_t n,
                          int inverse, void* stream);
+/*   mrx_group_norm_bwd      the derivative of the two lines above (training; the reference leaves it to autograd), two launches:
+ *                           inverse = 0: dx from dy (gradient of the normalised tensor), v = the normalised tensor, std and the OPTIONAL gradients dmean, dstd
+ *                                        [groups] of the statistics (NormUnet un-normalises with them at its end: unet_block.py:86-91);
+ *                           inverse = 1: dx = dy std and dmean_o = sum dy, dstd_o = sum dy v per group, v = the un-normalisation's input.
+ *                           work: mrx_norm_work_floats(groups, n) floats; n >= 2 (unbiased std). */
+int mrx_group_norm_bwd(const float* dy, const float* v, const float* std_, const float* dmean, const float* dstd, float* dx, float* dmean_o,
+                       float* dstd_o, float* work, int64_t groups, int64_t n, int inverse, void* stream);
 int mrx_pad2d(const float* in, float* out, int64_t planes, int H, int W, int top, int bottom, int left, int right,
               int mode, void* stream);
 int mrx_avg_pool2x2(const float* in, float* out, int64_t planes, int H, int W, void* stream);

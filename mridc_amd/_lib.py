@@ -216,6 +216,8 @@ _SIGNATURES = {
     "mrx_rim_final": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_gru_gates": ([_p, _p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_mgu_gates": ([_p, _p, _p, _p, _i, _i, _i64, _p], _i),
+    "mrx_gru_gates_bwd": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
+    "mrx_mgu_gates_bwd": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p], _i),
     "mrx_gated_cell_supported": ([_i, _i, _i, _i], _i),
     "mrx_gated_cell_pack_floats": ([_i, _i, _i], _i64),
     "mrx_gated_cell_pack": ([_p, _p, _p, _i, _i, _i, _p], _i),
@@ -230,6 +232,7 @@ _SIGNATURES = {
     "mrx_instance_norm_apply_tiles": ([_p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _p], _i),
     "mrx_group_norm_stats": ([_p, _p, _p, _p, _i64, _i64, _p], _i),
     "mrx_group_norm_apply": ([_p, _p, _p, _p, _i64, _i64, _i, _p], _i),
+    "mrx_group_norm_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p], _i),
     "mrx_pad2d": ([_p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "mrx_avg_pool2x2": ([_p, _p, _i64, _i, _i, _p], _i),
     "mrx_conv_transpose2x2_stats_work_floats": ([_i, _i, _i, _i], _i64),

@@ -797,6 +797,59 @@ extern "C" int mrx_gru_blend(const float* h, const float* pre_update, const floa
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
+// Backward of the gate math (the derivative of rnn_cells.py:118-127 / :255-261): the gates are recomputed from ih / hh (three / two exponentials per element
+// instead of three saved planes), every gradient leaves in one pass.  d_hh's reset / update (forget) planes equal d_ih's.
+//   GRU:  dn = dy (1 - z), dz = dy (h - n), dh = dy z;  dn' = dn (1 - n^2): d i_n = dn', d h_n = dn' r, dr = dn' h_n;  d i_z = d h_z = dz z (1 - z);  d i_r = d h_r = dr r (1 - r)
+//   MGU:  dc = dy (1 - f), df = dy (h - c), dh = dy f;  dc' = dc (1 - c^2): d i_c = dc', d h_c = dc' f, df += dc' h_c;  d i_f = d h_f = df f (1 - f)
+__global__ void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ ih, const float* __restrict__ hh, const float* __restrict__ h,
+                          float* __restrict__ dih, float* __restrict__ dhh, float* __restrict__ dh, int F, long long HW, long long total) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long b = o / (F * HW), r_ = o - b * F * HW;
+        const long long g = b * 3 * F * HW + r_, P = F * HW;
+        const float hn = hh[g + 2 * P];
+        const float r = sigmoidf_(ih[g] + hh[g]), z = sigmoidf_(ih[g + P] + hh[g + P]), n = tanhf(ih[g + 2 * P] + r * hn);
+        const float d = dy[o], hv = h[o];
+        const float dnp = d * (1.0f - z) * (1.0f - n * n);
+        const float dzp = d * (hv - n) * z * (1.0f - z);
+        const float drp = dnp * hn * r * (1.0f - r);
+        dih[g] = drp, dih[g + P] = dzp, dih[g + 2 * P] = dnp;
+        dhh[g] = drp, dhh[g + P] = dzp, dhh[g + 2 * P] = dnp * r;
+        dh[o] = d * z;
+    }
+}
+__global__ void k_mgu_bwd(const float* __restrict__ dy, const float* __restrict__ ih, const float* __restrict__ hh, const float* __restrict__ h,
+                          float* __restrict__ dih, float* __restrict__ dhh, float* __restrict__ dh, int F, long long HW, long long total) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const long long b = o / (F * HW), r_ = o - b * F * HW;
+        const long long g = b * 2 * F * HW + r_, P = F * HW;
+        const float hc = hh[g + P];
+        const float f = sigmoidf_(ih[g] + hh[g]), c = tanhf(ih[g + P] + f * hc);
+        const float d = dy[o], hv = h[o];
+        const float dcp = d * (1.0f - f) * (1.0f - c * c);
+        const float dfp = (d * (hv - c) + dcp * hc) * f * (1.0f - f);
+        dih[g] = dfp, dih[g + P] = dcp;
+        dhh[g] = dfp, dhh[g + P] = dcp * f;
+        dh[o] = d * f;
+    }
+}
+extern "C" int mrx_gru_gates_bwd(const float* dy, const float* ih, const float* hh, const float* h, float* dih, float* dhh, float* dh, int B, int F, int64_t HW,
+                                 void* stream) {
+    MRX_REQUIRE(dy && ih && hh && h && dih && dhh && dh && B >= 0 && F >= 0 && HW >= 0, MRX_EINVAL, "mrx_gru_gates_bwd: bad argument");
+    const long long total = (long long)B * F * HW;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_gru_bwd, dim3(ew_grid(total)), dim3(EW_NT), 0, (hipStream_t)stream, dy, ih, hh, h, dih, dhh, dh, F, (long long)HW, total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+extern "C" int mrx_mgu_gates_bwd(const float* dy, const float* ih, const float* hh, const float* h, float* dih, float* dhh, float* dh, int B, int F, int64_t HW,
+                                 void* stream) {
+    MRX_REQUIRE(dy && ih && hh && h && dih && dhh && dh && B >= 0 && F >= 0 && HW >= 0, MRX_EINVAL, "mrx_mgu_gates_bwd: bad argument");
+    const long long total = (long long)B * F * HW;
+    if (total == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_mgu_bwd, dim3(ew_grid(total)), dim3(EW_NT), 0, (hipStream_t)stream, dy, ih, hh, h, dih, dhh, dh, F, (long long)HW, total);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
 extern "C" int mrx_gru_gates(const float* ih, const float* hh, const float* h, float* out, int B, int F, int64_t HW, void* stream) {
     MRX_REQUIRE(ih && hh && h && out && B >= 0 && F >= 0 && HW >= 0, MRX_EINVAL, "mrx_gru_gates: bad argument");
     const long long total = (long long)B * F * HW;

@@ -281,6 +281,72 @@ extern "C" int mrx_group_norm_apply(const float* x, const float* mean, const flo
     return MRX_OK;
 }
 
+// ---- group norm backward (training E2EVN: the derivative of unet_block.py:71-91, which the reference leaves to autograd) ----------------------------
+// With xhat = (x - mean) / std (unbiased std over the group's n values) and the gradients dy (of xhat), dmean, dstd (of the two statistics, which the
+// un-normalisation at the end of NormUnet uses):
+//   dx = (dy - S1 / n) / std - xhat S2 / (std (n - 1)) + dmean / n + dstd xhat / (n - 1),     S1 = sum dy, S2 = sum dy xhat.
+// The un-normalisation y = x std + mean:   dx = dy std,   dstd = sum dy x,   dmean = sum dy -- the same two sums with x in place of xhat.
+// Two deterministic passes like the forward: partial sums per (group, split), then the apply pass (which combines them in double).
+__global__ __launch_bounds__(UN_NT) void k_group_bwd_sums(const float* __restrict__ dy, const float* __restrict__ v, float* __restrict__ p1, float* __restrict__ p2,
+                                                          long long n, int nsplit) {
+    __shared__ float red[UN_NT / 64];
+    long long a, b;
+    split_range(n, nsplit, blockIdx.y, a, b);
+    const float* d = dy + (long long)blockIdx.x * n;
+    const float* q = v + (long long)blockIdx.x * n;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long i = a + threadIdx.x; i < b; i += UN_NT) {
+        const float di = d[i];
+        s1 += di;
+        s2 += di * q[i];
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        p1[(long long)blockIdx.x * nsplit + blockIdx.y] = s1;
+        p2[(long long)blockIdx.x * nsplit + blockIdx.y] = s2;
+    }
+}
+// inverse == 0: dx of the normalisation (v = xhat; dmean / dstd may be null = 0); inverse == 1: dx = dy std, and (split 0) dmean_o = S1, dstd_o = S2
+__global__ __launch_bounds__(UN_NT) void k_group_bwd_apply(const float* __restrict__ dy, const float* __restrict__ v, const float* __restrict__ std_,
+                                                           const float* __restrict__ p1, const float* __restrict__ p2, const float* __restrict__ dmean,
+                                                           const float* __restrict__ dstd, float* __restrict__ dx, float* __restrict__ dmean_o,
+                                                           float* __restrict__ dstd_o, long long n, int nsplit, int inverse) {
+    long long a, b;
+    split_range(n, nsplit, blockIdx.y, a, b);
+    const long long g = blockIdx.x;
+    const float S1 = combine(p1 + g * nsplit, nsplit), S2 = combine(p2 + g * nsplit, nsplit), sd = std_[g];
+    const float* d = dy + g * n;
+    float* o = dx + g * n;
+    if (inverse) {
+        for (long long i = a + threadIdx.x; i < b; i += UN_NT) o[i] = d[i] * sd;
+        if (blockIdx.y == 0 && threadIdx.x == 0) dmean_o[g] = S1, dstd_o[g] = S2;
+        return;
+    }
+    const float* q = v + g * n;
+    const float inv = 1.0f / sd, c0 = ((dmean ? dmean[g] : 0.f) - S1 * inv) / (float)n, c1 = ((dstd ? dstd[g] : 0.f) - S2 * inv) / (float)(n - 1);
+    for (long long i = a + threadIdx.x; i < b; i += UN_NT) o[i] = d[i] * inv + c0 + c1 * q[i];
+}
+// work: mrx_norm_work_floats(groups, n) floats.  inverse = 0: dx [groups, n] from dy, xhat, std and (optional) dmean, dstd [groups]; dmean_o / dstd_o unused.
+// inverse = 1: dx = dy std and dmean_o, dstd_o [groups] from dy and x (the un-normalisation's input); dmean / dstd unused.
+extern "C" int mrx_group_norm_bwd(const float* dy, const float* v, const float* std_, const float* dmean, const float* dstd, float* dx, float* dmean_o,
+                                  float* dstd_o, float* work, int64_t groups, int64_t n, int inverse, void* stream) {
+    MRX_REQUIRE(dy && v && std_ && dx && work && groups >= 0 && n >= 2, MRX_EINVAL, "mrx_group_norm_bwd: bad argument");
+    MRX_REQUIRE(!inverse || (dmean_o && dstd_o), MRX_EINVAL, "mrx_group_norm_bwd: the un-normalisation's backward returns dmean and dstd");
+    if (groups == 0) return MRX_OK;
+    MRX_REQUIRE(groups < (1LL << 31), MRX_EUNSUP, "mrx_group_norm_bwd: too many groups");
+    const int ns = un_nsplit(n);
+    float* p1 = work;
+    float* p2 = work + groups * ns;
+    dim3 grid((unsigned)groups, ns);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_group_bwd_sums, grid, dim3(UN_NT), 0, st, dy, v, p1, p2, (long long)n, ns);
+    hipLaunchKernelGGL(k_group_bwd_apply, grid, dim3(UN_NT), 0, st, dy, v, std_, (const float*)p1, (const float*)p2, dmean, dstd, dx, dmean_o, dstd_o,
+                       (long long)n, ns, inverse);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
 // ---- pad / crop: out[y][x] = in[y - top][x - left]; outside: 0 (mode 0) or reflect (mode 1).  Negative pads crop. --------
 __global__ void k_pad2d(const float* in, float* out, long long planes, int H, int W, int top, int left, int OH, int OW, int mode) {
     const long long total = planes * OH * OW;

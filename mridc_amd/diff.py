@@ -128,8 +128,25 @@ def avg_pool2x2(x):
     return _AvgPool2x2.apply(x)
 
 
+class _ZeroPad2d(torch.autograd.Function):
+    """Zero padding / cropping (negative pads) of the last two dims: mrx_pad2d in both directions -- the gradient of a pad is the opposite crop and vice versa."""
+
+    @staticmethod
+    def forward(ctx, x, top, bottom, left, right):
+        ctx.pads = (int(top), int(bottom), int(left), int(right))
+        return ops.pad2d(x, top, bottom, left, right, mode=0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, b, l, r = ctx.pads
+        return ops.pad2d(dy, -t, -b, -l, -r, mode=0), None, None, None, None
+
+
 def pad2d(x, top, bottom, left, right, mode=0):
-    """Zero (negative: crop) or reflect padding, recorded by torch."""
+    """Zero (negative: crop) padding on mrx_pad2d in both directions; reflect padding (the one-pixel fix of odd sizes in the U-Net's up path, unet_block.py:215-222)
+    recorded by torch."""
+    if mode == 0 and min(top, bottom, left, right) >= 0 or mode == 0 and max(top, bottom, left, right) <= 0:
+        return _ZeroPad2d.apply(x, top, bottom, left, right)
     return F.pad(x, (left, right, top, bottom), mode="constant" if mode == 0 else "reflect")
 
 
@@ -137,19 +154,50 @@ def concat_channels(a, b):
     return torch.cat([a, b], dim=1)
 
 
+class _GroupNorm(torch.autograd.Function):
+    """unet_block.py:71-84 with its three results (normalised tensor, mean, unbiased std): statistics + apply kernels forward, mrx_group_norm_bwd backward
+    (two launches; the gradients of mean and std -- NormUnet un-normalises with them at its end -- enter the same pass)."""
+
+    @staticmethod
+    def forward(ctx, x, groups):
+        out, mean, std = ops.group_norm(x, groups)
+        ctx.save_for_backward(out, std)
+        ctx.groups = int(groups)
+        return out, mean, std
+
+    @staticmethod
+    def backward(ctx, dy, dmean, dstd):
+        out, std = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(out)
+        return ops.group_norm_bwd(dy, out, std, ctx.groups, dmean, dstd), None
+
+
 def group_norm(x, groups):
     """unet_block.py:71-84."""
-    b, c, h, w = x.shape
-    xg = x.reshape(b, groups, -1)
-    mean = xg.mean(-1, keepdim=True)
-    std = xg.std(-1, keepdim=True)
-    return ((xg - mean) / std).reshape(b, c, h, w), mean, std
+    return _GroupNorm.apply(x, groups)
+
+
+class _GroupUnnorm(torch.autograd.Function):
+    """unet_block.py:86-90: x * std + mean per group."""
+
+    @staticmethod
+    def forward(ctx, x, mean, std, groups):
+        ctx.save_for_backward(x, std)
+        ctx.groups = int(groups)
+        ctx.stat_shapes = (tuple(mean.shape), tuple(std.shape))
+        return ops.group_unnorm(x, mean, std, groups)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, std = ctx.saved_tensors
+        dx, dmean, dstd = ops.group_unnorm_bwd(dy, x, std, ctx.groups)
+        return dx, dmean.reshape(ctx.stat_shapes[0]), dstd.reshape(ctx.stat_shapes[1]), None
 
 
 def group_unnorm(x, mean, std, groups):
     """unet_block.py:86-90."""
-    b, c, h, w = x.shape
-    return (x.reshape(b, groups, -1) * std + mean).reshape(b, c, h, w)
+    return _GroupUnnorm.apply(x, mean, std, groups)
 
 
 # ---- Fourier transforms and the coil operators -------------------------------------------------------------------------------------------
@@ -285,19 +333,27 @@ def coil_combination(data, sens, method="SENSE", dim=1):
     raise ValueError("Output type not supported.")
 
 
-# ---- gated recurrent cells (rnn_cells.py:112-127, 249-261): convolutions on the HIP kernels, gates recorded by torch ------------------------
+# ---- gated recurrent cells (rnn_cells.py:112-127, 249-261): convolutions AND gates on the HIP kernels in both directions ------------------------------
+class _Gates(torch.autograd.Function):
+    """h' = gates(ih, hh, hx): mrx_gru_gates / mrx_mgu_gates forward, mrx_gru_gates_bwd / mrx_mgu_gates_bwd backward (one launch each; the gates are recomputed
+    from the saved ih / hh -- what torch would have saved as ~ten intermediate planes)."""
+
+    @staticmethod
+    def forward(ctx, ih, hh, hx, gru):
+        ctx.save_for_backward(ih, hh, hx)
+        ctx.gru = bool(gru)
+        return (ops.gru_gates if gru else ops.mgu_gates)(ih, hh, hx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ih, hh, hx = ctx.saved_tensors
+        dih, dhh, dh = (ops.gru_gates_bwd if ctx.gru else ops.mgu_gates_bwd)(dy, ih, hh, hx)
+        return dih, dhh, dh, None
+
+
 def gru_gates(ih, hh, hx):
-    i_r, i_z, i_n = ih.chunk(3, 1)
-    h_r, h_z, h_n = hh.chunk(3, 1)
-    r = torch.sigmoid(i_r + h_r)
-    z = torch.sigmoid(i_z + h_z)
-    n = torch.tanh(i_n + r * h_n)
-    return n * (1 - z) + z * hx
+    return _Gates.apply(ih, hh, hx, True)
 
 
 def mgu_gates(ih, hh, hx):
-    i_f, i_c = ih.chunk(2, 1)
-    h_f, h_c = hh.chunk(2, 1)
-    f = torch.sigmoid(i_f + h_f)
-    c = torch.tanh(i_c + f * h_c)
-    return c + f * (hx - c)
+    return _Gates.apply(ih, hh, hx, False)

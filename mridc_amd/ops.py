@@ -1649,6 +1649,27 @@ def gru_gates(ih, hh, h):
     return out
 
 
+def _gates_bwd(name, gates, dy, ih, hh, h):
+    dy, ih, hh, h = _lib.f32c(dy), _lib.f32c(ih), _lib.f32c(hh), _lib.f32c(h)
+    B, F, H, W = _nchw(h)
+    if tuple(ih.shape) != (B, gates * F, H, W) or tuple(hh.shape) != tuple(ih.shape) or tuple(dy.shape) != tuple(h.shape):
+        raise ValueError(f"{name}: dy {tuple(dy.shape)}, ih {tuple(ih.shape)}, hh {tuple(hh.shape)}, h {tuple(h.shape)}")
+    dih, dhh, dh = torch.empty_like(ih), torch.empty_like(hh), torch.empty_like(h)
+    _lib.check(getattr(_lib.lib(), name)(_lib.ptr(dy), _lib.ptr(ih), _lib.ptr(hh), _lib.ptr(h), _lib.ptr(dih), _lib.ptr(dhh), _lib.ptr(dh), B, F, H * W,
+                                         _lib.stream_ptr()), name)
+    return dih, dhh, dh
+
+
+def gru_gates_bwd(dy, ih, hh, h):
+    """(d ih, d hh, d h) of gru_gates (mrx_gru_gates_bwd)."""
+    return _gates_bwd("mrx_gru_gates_bwd", 3, dy, ih, hh, h)
+
+
+def mgu_gates_bwd(dy, ih, hh, h):
+    """(d ih, d hh, d h) of mgu_gates (mrx_mgu_gates_bwd)."""
+    return _gates_bwd("mrx_mgu_gates_bwd", 2, dy, ih, hh, h)
+
+
 def gated_cell_supported(cin, F, k, gates):
     return bool(_lib.lib().mrx_gated_cell_supported(int(cin), int(F), int(k), int(gates)))
 
@@ -1921,6 +1942,40 @@ def group_unnorm(x, mean, std, groups):
     _lib.check(_lib.lib().mrx_group_norm_apply(_lib.ptr(x), _lib.ptr(_lib.f32c(mean)), _lib.ptr(_lib.f32c(std)), _lib.ptr(out),
                                                B * groups, n, 1, _lib.stream_ptr()), "mrx_group_norm_apply")
     return out
+
+
+def group_norm_bwd(dy, xhat, std, groups, dmean=None, dstd=None):
+    """dx of group_norm given the gradients of its three results (mrx_group_norm_bwd, inverse = 0): dy of the normalised tensor `xhat`, dmean / dstd [B,G,1] or None."""
+    dy, xhat, std = _lib.f32c(dy), _lib.f32c(xhat), _lib.f32c(std)
+    B, C, H, W = _nchw(xhat)
+    n = (C * H * W) // groups
+    if tuple(dy.shape) != tuple(xhat.shape) or std.numel() != B * groups:
+        raise ValueError(f"group_norm_bwd: dy {tuple(dy.shape)}, xhat {tuple(xhat.shape)}, std {tuple(std.shape)}, groups {groups}")
+    dm = _lib.f32c(dmean) if dmean is not None else None
+    ds = _lib.f32c(dstd) if dstd is not None else None
+    dx = torch.empty_like(xhat)
+    L = _lib.lib()
+    work = torch.empty(int(L.mrx_norm_work_floats(B * groups, n)), dtype=torch.float32, device=dy.device)
+    _lib.check(L.mrx_group_norm_bwd(_lib.ptr(dy), _lib.ptr(xhat), _lib.ptr(std), _lib.ptr(dm), _lib.ptr(ds), _lib.ptr(dx), None, None, _lib.ptr(work),
+                                    B * groups, n, 0, _lib.stream_ptr()), "mrx_group_norm_bwd")
+    return dx
+
+
+def group_unnorm_bwd(dy, x, std, groups):
+    """(dx, dmean [B,G,1], dstd [B,G,1]) of group_unnorm (mrx_group_norm_bwd, inverse = 1); x: the un-normalisation's input."""
+    dy, x, std = _lib.f32c(dy), _lib.f32c(x), _lib.f32c(std)
+    B, C, H, W = _nchw(x)
+    n = (C * H * W) // groups
+    if tuple(dy.shape) != tuple(x.shape) or std.numel() != B * groups:
+        raise ValueError(f"group_unnorm_bwd: dy {tuple(dy.shape)}, x {tuple(x.shape)}, std {tuple(std.shape)}, groups {groups}")
+    dx = torch.empty_like(x)
+    dmean = torch.empty(B, groups, 1, dtype=torch.float32, device=dy.device)
+    dstd = torch.empty_like(dmean)
+    L = _lib.lib()
+    work = torch.empty(int(L.mrx_norm_work_floats(B * groups, n)), dtype=torch.float32, device=dy.device)
+    _lib.check(L.mrx_group_norm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(std), None, None, _lib.ptr(dx), _lib.ptr(dmean), _lib.ptr(dstd), _lib.ptr(work),
+                                    B * groups, n, 1, _lib.stream_ptr()), "mrx_group_norm_bwd")
+    return dx, dmean, dstd
 
 
 def pad2d(x, top, bottom, left, right, mode=0):

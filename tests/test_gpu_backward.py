@@ -351,6 +351,90 @@ def test_gated_rim_training_gradients_vs_oracle_autograd(dev, cell):
     assert checked >= 9
 
 
+@pytest.mark.parametrize("shape", [(1, 2, 20, 18), (2, 4, 33, 7), (1, 2, 640, 380)], ids=lambda s: "x".join(map(str, s)))
+def test_group_norm_unnorm_and_padding_backward_vs_float64_autograd(dev, shape):
+    """NormUnet's frame (unet_block.py:71-111): group norm with the unbiased std, zero padding, [a stand-in for the U-Net], crop, un-normalisation with the SAME
+    statistics -- the gradient reaches x through the normalised tensor, through the mean and through the std.  mrx_group_norm_bwd / mrx_pad2d against torch autograd of the
+    reference's formulas in float64."""
+    from mridc_amd import diff
+    B, C, H, W = shape
+    groups = 2
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(B, C, H, W, generator=g) * 3.0 + 0.7
+    wgt = torch.randn(B, C, H + 5, W + 3, generator=g)                 # the "network": an elementwise non-linearity with position-dependent weights
+    dy = torch.randn(B, C, H, W, generator=g)
+
+    def frame(x_, w_, norm, unnorm, pad):
+        xn, mean, std = norm(x_, groups)
+        p = pad(xn, 2, 3, 1, 2, 0)
+        q = p * w_ + 0.25 * p * p
+        c = pad(q, -2, -3, -1, -2, 0)
+        return unnorm(c, mean, std, groups)
+
+    def norm64(x_, G):
+        b, c, h, w = x_.shape
+        xg = x_.reshape(b, G, -1)
+        mean, std = xg.mean(-1, keepdim=True), xg.std(-1, keepdim=True)
+        return ((xg - mean) / std).reshape(b, c, h, w), mean, std
+
+    def unnorm64(x_, mean, std, G):
+        b, c, h, w = x_.shape
+        return (x_.reshape(b, G, -1) * std + mean).reshape(b, c, h, w)
+
+    def pad64(x_, t, b_, l, r, mode):
+        return torch.nn.functional.pad(x_, (l, r, t, b_))
+
+    xr = x.double().requires_grad_(True)
+    ref = frame(xr, wgt.double(), norm64, unnorm64, pad64)
+    ref.backward(dy.double())
+    xd = x.to(dev).requires_grad_(True)
+    got = frame(xd, wgt.to(dev), diff.group_norm, diff.group_unnorm, diff.pad2d)
+    assert_close(got, ref.detach().float(), 2e-6, "frame forward")
+    got.backward(dy.to(dev))
+    assert_close(xd.grad, xr.grad.float(), 5e-6, "gradient through the normalised tensor, the mean and the std")
+    # the normalisation alone, statistics unused downstream (their gradients are None)
+    xd2 = x.to(dev).requires_grad_(True)
+    diff.group_norm(xd2, groups)[0].backward(dy.to(dev))
+    xr2 = x.double().requires_grad_(True)
+    norm64(xr2, groups)[0].backward(dy.double())
+    assert_close(xd2.grad, xr2.grad.float(), 5e-6, "group norm alone")
+
+
+@pytest.mark.parametrize("cell", ["GRU", "MGU"])
+@pytest.mark.parametrize("shape", [(1, 16, 20, 18), (2, 5, 7, 33), (1, 64, 64, 48)], ids=lambda s: "x".join(map(str, s)))
+def test_gate_backward_kernels_vs_float64_autograd(dev, cell, shape):
+    """mrx_gru_gates_bwd / mrx_mgu_gates_bwd: the three gradients of the gate math (rnn_cells.py:118-127, :255-261) in one launch each, against torch
+    autograd of the same formulas in float64; the forward of diff.gru_gates / mgu_gates is the inference kernel's."""
+    from mridc_amd import diff, ops
+    B, F, H, W = shape
+    G = 3 if cell == "GRU" else 2
+    g = torch.Generator().manual_seed(F + H)
+    ih, hh = torch.randn(B, G * F, H, W, generator=g) * 1.5, torch.randn(B, G * F, H, W, generator=g) * 1.5
+    hx, dy = torch.randn(B, F, H, W, generator=g), torch.randn(B, F, H, W, generator=g)
+    a, b, c = (t.double().requires_grad_(True) for t in (ih, hh, hx))
+    if cell == "GRU":
+        (i_r, i_z, i_n), (h_r, h_z, h_n) = a.chunk(3, 1), b.chunk(3, 1)
+        r, z = torch.sigmoid(i_r + h_r), torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        out = n * (1 - z) + z * c
+    else:
+        (i_f, i_c), (h_f, h_c) = a.chunk(2, 1), b.chunk(2, 1)
+        f = torch.sigmoid(i_f + h_f)
+        cc = torch.tanh(i_c + f * h_c)
+        out = cc + f * (c - cc)
+    out.backward(dy.double())
+    x, y_, h_ = (t.to(dev).requires_grad_(True) for t in (ih, hh, hx))
+    got = (diff.gru_gates if cell == "GRU" else diff.mgu_gates)(x, y_, h_)
+    assert got.grad_fn is not None
+    assert_close(got, out.detach().float(), 2e-6, f"{cell} gates forward")
+    assert torch.equal(got.detach(), (ops.gru_gates if cell == "GRU" else ops.mgu_gates)(x.detach(), y_.detach(), h_.detach()))
+    got.backward(dy.to(dev))
+    for name, mine, ref in (("d ih", x.grad, a.grad), ("d hh", y_.grad, b.grad), ("d h", h_.grad, c.grad)):
+        assert_close(mine, ref.float(), 3e-6, f"{cell} {name}")
+    with pytest.raises(ValueError):
+        ops.gru_gates_bwd(dy.to(dev), ih.to(dev)[:, :F], hh.to(dev), hx.to(dev))
+
+
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_absl1_loss_gradient_includes_the_path_through_the_maximum(dev, seed):
     """mean |target - |p| / max|p|| (cirim.py:218-237): the gradient has one large term at the arg-max pixel (the path through the max).
