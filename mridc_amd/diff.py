@@ -5,9 +5,10 @@ Same names and arguments as `mridc_amd.ops`; a module picks this namespace inste
 (`diff.active(...)`).  Everything heavy stays on the HIP kernels in both directions: convolutions (forward `mrx_conv2d` / Winograd, data
 gradient `mrx_conv2d` on flipped weights with the replicate-padding fold, weight gradient `mrx_conv_wgrad` -- the generic matrix-core
 kernel for arbitrary channel counts), the transposed 2x2 convolution (its gradients are 1x1 convolutions of the pixel-unshuffled output
-gradient), FFTs (the adjoint of a transform is the opposite transform times N^(+-1) for the unnormalised conventions).  Normalisation
-statistics, activations' derivatives, pooling, padding, concatenation and the pointwise complex arithmetic are torch device ops inside
-the backward (a few passes over the activations; the FLOPs are in the convolutions)."""
+gradient), FFTs (the adjoint of a transform is the opposite transform times N^(+-1) for the unnormalised conventions), instance norm, group norm with
+its statistics' gradients and the un-normalisation (`mrx_group_norm_bwd`), zero padding / cropping (`mrx_pad2d` both ways), pooling, activations'
+derivatives, the GRU / MGU gate math (`mrx_gru_gates_bwd` / `mrx_mgu_gates_bwd`).  What torch still records: channel concatenation (its backward is two
+views), the one-pixel reflect padding of odd sizes in the U-Net's up path, and the pointwise complex arithmetic of the coil operators' glue."""
 import torch
 import torch.nn.functional as F
 
