@@ -373,6 +373,14 @@ int mrx_rim_layer1_cb8(const float* x, int Cin, const float* eta, const float* p
                        void* stream);
 int mrx_rim_layer2_f16_cb8(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
                            float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream);
+/* mrx_rim_layer2_f16_cb8 with the dilated 3x3 in a Winograd F(2, 3) form ALONG X on the same two-term fp16 operands (csrc/rim_layer2_wx.hip: 288 instead of
+ * 432 convolution MFMAs per 512 pixels -- the headline loop runs at the chip's power limit, so matrix FLOPs are what it pays for).  Same arguments and results
+ * up to round-off: 2.3e-7 against float64 where the direct form has 1.3e-7 and fp32 1.2e-7 (numpy emulation, tools/probe/wino_f16x2_error.py).  Its own operand
+ * pack (transformed weights); a sample's state must fit 32-bit byte offsets (MRX_EUNSUP otherwise: use mrx_rim_layer2_f16_cb8). */
+int64_t mrx_rim_layer2_wx_pack_floats(void);
+int mrx_rim_layer2_wx_pack(const float* w_conv, const float* w_ih, const float* w_final /* [2,64,3,3] or NULL */, float* packed, void* stream);
+int mrx_rim_layer2_wx_cb8(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                          float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream);
 /* Complex instance normalisation around a regulariser (models/sigmanet/sensitivity_net.py:16-139): m = mean of every real and imaginary entry,
  * C = 2x2 covariance of (re - m, im - m) per batch element (sums over per_b complex values, divided by `divisor` -- the reference's
  * shape[2] * shape[3] - 1); coef[b] = {m, C^(1/2) row-major, C^(-1/2) row-major} (9 floats).  center = 0 takes the data as mean-free.

@@ -203,6 +203,9 @@ _SIGNATURES = {
     "mrx_cb8_convert": ([_p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_rim_layer1_cb8": ([_p, _i, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_layer2_f16_cb8": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_rim_layer2_wx_pack_floats": ([], _i64),
+    "mrx_rim_layer2_wx_pack": ([_p, _p, _p, _p, _p], _i),
+    "mrx_rim_layer2_wx_cb8": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_cnorm_work_doubles": ([_i], _i64),
     "mrx_cnorm_stats": ([_p, _i, _i64, ctypes.c_double, _i, _p, _p, _p], _i),
     "mrx_cnorm_apply": ([_p, _p, _p, _i, _i, _i64, _p], _i),

@@ -1524,6 +1524,41 @@ def rim_layer2_f16_cb8(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps=None, out
     return (out, taps) if want_taps else out
 
 
+def rim_layer2_wx_pack(w_conv, w_ih, w_final=None):
+    """Operand pack of rim_layer2_wx_cb8 (mrx_rim_layer2_wx_pack): the 3x3 weights in the Winograd F(2, 3) form along x, two fp16 terms."""
+    w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
+    if tuple(w_conv.shape) != (64, 64, 3, 3) or tuple(w_ih.shape) != (64, 64, 1, 1):
+        raise NotImplementedError(f"rim_layer2_wx_pack: {tuple(w_conv.shape)} / {tuple(w_ih.shape)}")
+    if w_final is not None:
+        w_final = _lib.f32c(w_final.detach())
+        if tuple(w_final.shape) != (2, 64, 3, 3):
+            raise NotImplementedError(f"rim_layer2_wx_pack: final conv {tuple(w_final.shape)}")
+    packed = torch.empty(int(_lib.lib().mrx_rim_layer2_wx_pack_floats()), dtype=torch.float32, device=w_conv.device)
+    _lib.check(_lib.lib().mrx_rim_layer2_wx_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(w_final), _lib.ptr(packed), _lib.stream_ptr()),
+               "mrx_rim_layer2_wx_pack")
+    return packed
+
+
+def rim_layer2_wx_cb8(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps=None, out=None, want_taps=False):
+    """rim_layer2_f16_cb8 with the convolution in the Winograd F(2, 3) form along x (mrx_rim_layer2_wx_cb8; packed = rim_layer2_wx_pack)."""
+    x = _lib.f32c(x)
+    B, Q, H, W, E = [int(v) for v in x.shape]
+    if Q != 8 or E != 8:
+        raise ValueError(f"rim_layer2_wx_cb8 expects x [B,8,H,W,8], got {tuple(x.shape)}")
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    if want_taps and (taps is None or taps.numel() < 18 * B * H * W):
+        taps = torch.empty(B, 18, H, W, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(B, 8, H, W, 8, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mrx_rim_layer2_wx_cb8(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out),
+                                                _lib.ptr(taps) if want_taps else None, _lib.ptr(xmax), B, H, W, _lib.stream_ptr()),
+               "mrx_rim_layer2_wx_cb8")
+    return (out, taps) if want_taps else out
+
+
 def rim_final_gather(taps, b_final, eta):
     """eta + permute(conv3x3_reppad(h) + b_final) [B,H,W,2] from the tap products of rim_layer2_sb_taps (mrx_rim_final_gather)."""
     eta = _lib.f32c(eta)
