@@ -183,7 +183,7 @@ __global__ void k_l2wx_pack(const float* __restrict__ w, const float* __restrict
 }
 
 // ---- the layer ----------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WX_NT, 1) void k_rim_layer2_wx(L2wxArgs a) {
+__global__ __launch_bounds__(WX_NT, 1) void k_rim_layer2_wx8(L2wxArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wx[];
     const u32x4* Wih = reinterpret_cast<const u32x4*>(smem_wx);                       // 1x1 operands, then the final convolution's
     float* tabl = reinterpret_cast<float*>(smem_wx + WX_OFF_TAB);                      // hh, b_conv (scaled), b_ih in register order [half][R]
@@ -533,6 +533,374 @@ __global__ __launch_bounds__(WX_NT, 1) void k_rim_layer2_wx(L2wxArgs a) {
     }
 }
 
+// ---- the same layer with FOUR waves of 512 registers (one per SIMD) ---------------------------------------------------------------------------------
+// The eight-wave form above reads 4 weight + 2 pixel fragments from LDS for 6 MFMAs (one column block per wave: 8 accumulators = 128 registers) -- 1 KB per MFMA,
+// exactly the LDS pipe's 128 bytes per cycle when four SIMDs issue an MFMA every 32 cycles: measured 61.3 us per slice for the MFMA loop alone.  Here a wave owns
+// FOUR image rows = two column blocks: 4 positions x 2 cout blocks x 2 column blocks = 16 accumulators (256 registers, in AGPRs), 4 + 4 fragments per 12 MFMAs
+// (0.67 KB per MFMA, the direct form's ratio).  One wave per SIMD has nobody to hide behind: every step's fragments are requested one step ahead (two register
+// sets), the barriers sit where the next step's operands are already in registers (start of the fourth step, and of the eighth in even chunks), and the
+// staging is cut into 46 micro-operations that ride behind individual MFMAs.  Staging roles: thread i owns item i (rows 0..15 of the halo'd tile) and one
+// QUARTER (two channels) of an item of rows 16..19 -- 1.25 items per thread for every thread -- and six weight operands.
+#define WX4_NT 256
+__global__ __launch_bounds__(WX4_NT, 1) void k_rim_layer2_wx4(L2wxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wx[];
+    const u32x4* Wih = reinterpret_cast<const u32x4*>(smem_wx);
+    float* tabl = reinterpret_cast<float*>(smem_wx + WX_OFF_TAB);
+    u32x4* Wc = reinterpret_cast<u32x4*>(smem_wx + WX_OFF_W);
+    u32x4* Xp = reinterpret_cast<u32x4*>(smem_wx + WX_OFF_X);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int tid = (int)threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const long long plane = (long long)a.H * a.W;
+    const int total = a.ntiles * a.B;
+
+    for (int i = tid; i < WX_LWIH + WX_LWP; i += WX4_NT)
+        reinterpret_cast<u32x4*>(smem_wx)[i] = a.packed[WX_PK_TAIL + (i < WX_LWIH ? i : WX_WIH + (i - WX_LWIH))];
+    const int kx = wx_scale_exp(a.xmax[0]) - 1, kw = (int)a.packed[WX_PACK_U4 - 1][0];
+    const float sx = wx_pow2(kx), unx = wx_pow2(-kx), unw = wx_pow2(-kw);
+    const float unwi = wx_pow2(-(int)a.packed[WX_PACK_U4 - 1][1]), unwp = wx_pow2(-(int)a.packed[WX_PACK_U4 - 1][2]);
+    if (tid < 64) {
+        const int tc = wx_chan(tid >> 1, tid & 1);
+        const int ti = (tid & 1) * 32 + (tid >> 1);
+        tabl[ti] = a.hh ? a.hh[tc] : 0.f;
+        tabl[64 + ti] = a.b_conv ? a.b_conv[tc] * (sx * wx_pow2(kw)) : 0.f;
+        tabl[128 + ti] = a.b_ih ? a.b_ih[tc] : 0.f;
+    }
+
+    // ---- staging ------------------------------------------------------------------------------------------------------------------------------------
+    int st_t = blockIdx.x, st_q = 0;
+    unsigned goffA[4], goffQ[4];                     // byte offsets (chunk 0) of the four pixels of the thread's item / of its quarter item (+ 8 bytes per quarter)
+    __amdgpu_buffer_rsrc_t st_rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)(plane * (WX_F * 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t st_rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.packed), 0, (unsigned)(WX_PK_TAIL * 16), 0x00020000);
+    const unsigned st_tid16 = (unsigned)tid * 16u;
+    const unsigned st_q4 = (unsigned)(256 + (tid >> 2)) * 16u + (unsigned)(tid & 3) * 4u;    // LDS byte offset of the quarter item's two halves inside a plane
+    auto st_coords = [&]() {
+        const int tq = st_t < total ? st_t : total - 1;
+        const int tt = (int)mrx_xcd_band(tq, total);
+        const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
+        const int h0 = ty0 * WX_TH, w0 = (tile - ty0 * a.tiles_x) * WX_TW;
+        st_rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (long long)b * WX_F * plane, 0, (unsigned)(plane * (WX_F * 4)), 0x00020000);
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int i = which ? 256 + (tid >> 2) : tid, r = i >> 4, c = (i >> 3) & 1, t = i & 7;
+            int gy = h0 + r - 2;
+            gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int gx = w0 + 4 * t + 2 * k + c - 2;
+                gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+                const unsigned o = (unsigned)(gy * a.W + gx) * 32u;
+                if (which) goffQ[k] = o + (unsigned)(tid & 3) * 8u;
+                else goffA[k] = o;
+            }
+        }
+    };
+    float xr[4][8], xq[4][2];
+    u32x4 wr[6];
+    unsigned c1[4], c2[4];                           // the item's packed terms of the position being transformed
+    // micro-operations of the staging pipeline.  Commit side (chunk q + 1 -> LDS buffer `buf`): 0..19 item (per position: four pair splits, then the two
+    // writes), 20..23 quarter item (per position), 24..26 weights (two writes each).  Request side (chunk q + 2): 0..7 item loads, 8..11 quarter loads,
+    // 12..17 weight loads, 18 advance.
+    auto comb = [&](int p, const float x0, const float x1, const float x2, const float x3) {
+        return p == 0 ? x0 - x2 : (p == 1 ? x1 + x2 : (p == 2 ? x2 - x1 : x1 - x3));
+    };
+    auto commit_op = [&](int buf, int i) {
+        if (i < 20) {
+            const int p = i / 5, k = i - 5 * p;
+            if (k < 4) {
+                wx_split2h_scaled(comb(p, xr[0][2 * k], xr[1][2 * k], xr[2][2 * k], xr[3][2 * k]),
+                                  comb(p, xr[0][2 * k + 1], xr[1][2 * k + 1], xr[2][2 * k + 1], xr[3][2 * k + 1]), sx, c1[k], c2[k]);
+            } else {
+                unsigned char* base = smem_wx + WX_OFF_X + (buf * WX_XBUF + (p * 2) * WX_PSTR) * 16 + st_tid16;
+                *reinterpret_cast<u32x4*>(base) = u32x4{c1[0], c1[1], c1[2], c1[3]};
+                *reinterpret_cast<u32x4*>(base + WX_PSTR * 16) = u32x4{c2[0], c2[1], c2[2], c2[3]};
+            }
+        } else if (i < 24) {
+            const int p = i - 20;
+            unsigned q1, q2;
+            wx_split2h_scaled(comb(p, xq[0][0], xq[1][0], xq[2][0], xq[3][0]), comb(p, xq[0][1], xq[1][1], xq[2][1], xq[3][1]), sx, q1, q2);
+            unsigned char* base = smem_wx + WX_OFF_X + (buf * WX_XBUF + (p * 2) * WX_PSTR) * 16 + st_q4;
+            *reinterpret_cast<unsigned*>(base) = q1;
+            *reinterpret_cast<unsigned*>(base + WX_PSTR * 16) = q2;
+        } else if (i < 27) {
+            const int v = 2 * (i - 24);
+            *reinterpret_cast<u32x4*>(smem_wx + WX_OFF_W + (buf * WX_WCH + v * WX4_NT) * 16 + st_tid16) = wr[v];
+            *reinterpret_cast<u32x4*>(smem_wx + WX_OFF_W + (buf * WX_WCH + (v + 1) * WX4_NT) * 16 + st_tid16) = wr[v + 1];
+        }
+    };
+    auto request_op = [&](int i) {
+        const unsigned so = (unsigned)st_q * (unsigned)(plane * 32);
+        if (i < 8) {
+            const int k = i >> 1, half = i & 1;
+            const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(st_rx, goffA[k] + 16u * half, so, 0);
+            xr[k][4 * half] = __uint_as_float(u[0]), xr[k][4 * half + 1] = __uint_as_float(u[1]);
+            xr[k][4 * half + 2] = __uint_as_float(u[2]), xr[k][4 * half + 3] = __uint_as_float(u[3]);
+        } else if (i < 12) {
+            const int k = i - 8;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(st_rx, goffQ[k], so, 0);
+            xq[k][0] = __uint_as_float(u[0]), xq[k][1] = __uint_as_float(u[1]);
+        } else if (i < 18) {
+            const int v = i - 12;
+            wr[v] = __builtin_amdgcn_raw_buffer_load_b128(st_rw, st_tid16, (unsigned)(st_q * WX_WCH + v * WX4_NT) * 16u, 0);
+        } else if (i == 18) {
+            if (++st_q == WX_NCH) {
+                st_q = 0;
+                st_t += gridDim.x;
+                st_coords();
+            }
+        }
+    };
+    st_coords();
+    for (int pre = 0; pre < 2; ++pre) {              // chunks 0 and 1 of the first tile into LDS
+#pragma unroll
+        for (int i = 0; i < 19; ++i) request_op(i);
+#pragma unroll
+        for (int i = 0; i < 27; ++i) commit_op(pre, i);
+    }
+    __syncthreads();
+
+    const int bidx = l31 & 15, rsub = l31 >> 4;
+    for (int tI = blockIdx.x; tI < total; tI += gridDim.x) {
+        const int tt = (int)mrx_xcd_band(tI, total);
+        const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
+        const int h0 = ty0 * WX_TH, w0 = (tile - ty0 * a.tiles_x) * WX_TW;
+        f32x16 acc[4][2][2];                         // [position][cout block][column block]
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int nb2 = 0; nb2 < 2; ++nb2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[p][ct][nb2][r] = p == 1 ? tabl[64 + lhi * 32 + ct * 16 + r] : 0.f;
+        u32x4 bt[2][2][2], at[2][2][2];              // [register set][column block | cout block][term]
+        // operands of step `st` (0..3: the (ky 0 | ky 1) step of position st; 4..7: the paired ky = 2 step of position st - 4) of the chunk in buffer qb
+        auto fetch = [&](int qb, int st, int set) {
+            if (st < 4) {
+                const int p = st;
+                const u32x4* xw = Xp + qb * WX_XBUF + (p * 2) * WX_PSTR + (4 * wave + rsub + 2 * lhi) * 16 + bidx;
+                const u32x4* wl = Wc + qb * WX_WCH + (p * 2) * 2 * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    bt[set][0][k] = xw[k * WX_PSTR];
+                    bt[set][1][k] = xw[k * WX_PSTR + 2 * 16];
+                    at[set][0][k] = wl[(k * 2 + 0) * 64];
+                    at[set][1][k] = wl[(k * 2 + 1) * 64];
+                }
+            } else {
+                const int p = st - 4, bf = qb ^ lhi;
+                const u32x4* xw = Xp + bf * WX_XBUF + (p * 2) * WX_PSTR + (4 * wave + rsub + 4) * 16 + bidx;
+                const u32x4* w8 = Wc + bf * WX_WCH + WX_WFULL + (p * 2) * 2 * 32 + l31;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    bt[set][0][k] = xw[k * WX_PSTR];
+                    bt[set][1][k] = xw[k * WX_PSTR + 2 * 16];
+                    at[set][0][k] = w8[(k * 2 + 0) * 32];
+                    at[set][1][k] = w8[(k * 2 + 1) * 32];
+                }
+            }
+        };
+        fetch(0, 0, 0);
+        auto chunk = [&](const int q, auto FIRST, auto EVEN, auto LAST) {
+            constexpr bool first = decltype(FIRST)::value, even = decltype(EVEN)::value, last = decltype(LAST)::value;
+            const int cb = q & 1, nbuf = cb ^ 1;
+            constexpr int NST = even ? 8 : 4;
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int set = st & 1, p = st & 3;
+                // the barriers: start of the fourth step (the commits of chunk q + 1 -- operations 0..26, behind the first 27 MFMAs -- are visible; in an odd chunk
+                // nobody reads this chunk's buffer any more) and of the eighth (even chunks: the paired ky = 2 reads of this chunk's buffer have returned)
+                if (st == 3 || st == 7) __syncthreads();
+                if (st + 1 < NST) fetch(cb, st + 1, set ^ 1);
+                else if (!last) fetch(nbuf, 0, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int TA_[3] = {1, 0, 0}, TB_[3] = {0, 1, 0};
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    const int ct = m & 1, nb2 = (m >> 1) & 1, pr = m >> 2;
+                    acc[p][ct][nb2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, at[set][ct][TA_[pr]]), __builtin_bit_cast(f16x8, bt[set][nb2][TB_[pr]]),
+                                                                             acc[p][ct][nb2], 0, 0, 0);
+                    const int g = 12 * st + m;       // MFMA index inside the chunk
+#ifdef MRX_WX_ABL_NOSTAGE
+                    if (false) {
+#else
+                    if (g < 27) {
+#endif
+                        if constexpr (!first) commit_op(nbuf, g);
+                    } else if (g >= 28 && g < 47) {
+#ifndef MRX_WX_ABL_NOSTAGE
+                        request_op(g - 28);
+#endif
+                    }
+                    if (g < 47) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        chunk(0, std::true_type{}, std::true_type{}, std::false_type{});
+        for (int q2 = 1; q2 < WX_NCH - 1; q2 += 2) {
+            chunk(q2, std::false_type{}, std::false_type{}, std::false_type{});
+            chunk(q2 + 1, std::false_type{}, std::true_type{}, std::false_type{});
+        }
+        chunk(WX_NCH - 1, std::false_type{}, std::false_type{}, std::true_type{});
+        __syncthreads();                             // (every wave is past its last operand read of buffer 1: the next tile's chunk 1 goes there below)
+
+        // ---- output transform: four pixel sets per lane, set (nb2, j) = (row h0 + 4 wave + 2 nb2 + rsub, column w0 + 4 (l31 & 7) + ((l31 >> 3) & 1) + 2 j) ------
+        f32x16 out[4][2];                            // [set = 2 nb2 + j][cout block]
+#pragma unroll
+        for (int nb2 = 0; nb2 < 2; ++nb2)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float m0 = acc[0][ct][nb2][r], m1 = acc[1][ct][nb2][r], m2 = acc[2][ct][nb2][r], m3 = acc[3][ct][nb2][r];
+                    out[2 * nb2][ct][r] = (m0 + m1) + m2;
+                    out[2 * nb2 + 1][ct][r] = (m1 - m2) - m3;
+                }
+#pragma unroll
+        for (int i = 0; i < 27; ++i) commit_op(1, i);     // the next tile's chunk 1 (requested behind the last MFMAs above) into buffer 1
+        const int ox0 = w0 + 4 * (l31 & 7) + ((l31 >> 3) & 1);
+        float hp[4][32];
+        auto load_hp = [&](int sI) {
+            if (!a.hprev) {
+#pragma unroll
+                for (int R = 0; R < 32; ++R) hp[sI][R] = 0.f;
+                return;
+            }
+            const int oy = h0 + 4 * wave + 2 * (sI >> 1) + rsub, ox = ox0 + 2 * (sI & 1);
+            const int cy = oy < a.H ? oy : a.H - 1, cx = ox < a.W ? ox : a.W - 1;
+            const float* hb = a.hprev + (long long)b * WX_F * plane + ((long long)cy * a.W + cx) * 8 + 4 * lhi;
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                const float4 u = *reinterpret_cast<const float4*>(hb + (long long)qq * plane * 8);
+                hp[sI][4 * qq] = u.x, hp[sI][4 * qq + 1] = u.y, hp[sI][4 * qq + 2] = u.z, hp[sI][4 * qq + 3] = u.w;
+            }
+        };
+        load_hp(0), load_hp(1);
+        float sg[4], ung[4];
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+            float gm = 0.f;
+#pragma unroll
+            for (int R = 0; R < 32; ++R) gm = fmaxf(gm, out[sI][R >> 4][R & 15]);
+            const int kg = wx_pixel_exp(gm);
+            sg[sI] = wx_pow2(kg), ung[sI] = wx_pow2(-kg) * (unx * unw * unwi);
+        }
+        f32x16 acc2[4][2];
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[sI][ct][r] = 0.f;
+        {
+            const u32x4* wl = Wih + lane;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f16x8 b1[4], b2[4];
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) {
+                    unsigned g1[4], g2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int R0 = 8 * s + 2 * k, R1 = R0 + 1;
+                        float v0 = out[sI][R0 >> 4][R0 & 15], v1 = out[sI][R1 >> 4][R1 & 15];
+                        v0 = v0 > 0.f ? v0 : 0.f;
+                        v1 = v1 > 0.f ? v1 : 0.f;
+                        wx_split2h_scaled(v0, v1, sg[sI], g1[k], g2[k]);
+                    }
+                    b1[sI] = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
+                    b2[sI] = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
+                }
+                f16x8 a_[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) a_[ct][k] = __builtin_bit_cast(f16x8, wl[((s * 2 + k) * 2 + ct) * 64]);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc2[sI][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[ct][1], b1[sI], acc2[sI][ct], 0, 0, 0);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc2[sI][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[ct][0], b2[sI], acc2[sI][ct], 0, 0, 0);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc2[sI][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[ct][0], b1[sI], acc2[sI][ct], 0, 0, 0);
+                if (s == 1) load_hp(2), load_hp(3);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hnew + (long long)b * WX_F * plane, 0, (unsigned)(plane * (WX_F * 4)), 0x00020000);
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+            const int oy = h0 + 4 * wave + 2 * (sI >> 1) + rsub, ox = ox0 + 2 * (sI & 1);
+            const unsigned offh = (oy < a.H && ox < a.W) ? (unsigned)((((long long)oy * a.W + ox) * 8 + 4 * lhi) * 4) : 0x80000000u;
+#pragma unroll
+            for (int R = 0; R < 32; ++R) {
+                float v = acc2[sI][R >> 4][R & 15] * ung[sI] + tabl[128 + lhi * 32 + R];
+                v += tabl[lhi * 32 + R] * hp[sI][R];
+                hp[sI][R] = v > 0.f ? v : 0.f;
+            }
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(hp[sI][4 * qq]), __float_as_uint(hp[sI][4 * qq + 1]), __float_as_uint(hp[sI][4 * qq + 2]),
+                                                             __float_as_uint(hp[sI][4 * qq + 3])},
+                                                       rh, offh + (unsigned)qq * (unsigned)(plane * 32), 0, 0);
+        }
+        if (a.P) {
+            f32x16 accp[4];
+            float sh[4], unh[4];
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[sI][r] = 0.f;
+                float hm = 0.f;
+#pragma unroll
+                for (int R = 0; R < 32; ++R) hm = fmaxf(hm, hp[sI][R]);
+                const int kh = wx_pixel_exp(hm);
+                sh[sI] = wx_pow2(kh), unh[sI] = wx_pow2(-kh) * unwp;
+            }
+            const u32x4* wp = Wih + WX_LWIH + lane;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f16x8 b1[4], b2[4];
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) {
+                    unsigned g1[4], g2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wx_split2h_scaled(hp[sI][8 * s + 2 * k], hp[sI][8 * s + 2 * k + 1], sh[sI], g1[k], g2[k]);
+                    b1[sI] = __builtin_bit_cast(f16x8, (u32x4{g1[0], g1[1], g1[2], g1[3]}));
+                    b2[sI] = __builtin_bit_cast(f16x8, (u32x4{g2[0], g2[1], g2[2], g2[3]}));
+                }
+                const f16x8 a1 = __builtin_bit_cast(f16x8, wp[(s * 2 + 0) * 64]);
+                const f16x8 a2 = __builtin_bit_cast(f16x8, wp[(s * 2 + 1) * 64]);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) accp[sI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1[sI], accp[sI], 0, 0, 0);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) accp[sI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2[sI], accp[sI], 0, 0, 0);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) accp[sI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[sI], accp[sI], 0, 0, 0);
+            }
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.P + (long long)b * 18 * plane, 0, (unsigned)(plane * (18 * 4)), 0x00020000);
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const int oy = h0 + 4 * wave + 2 * (sI >> 1) + rsub, ox = ox0 + 2 * (sI & 1);
+                const bool inside = oy < a.H && ox < a.W;
+                const unsigned offp = inside ? (unsigned)((((long long)oy * a.W + ox) + 4ll * lhi * plane) * 4) : 0x80000000u;
+                const unsigned offp16 = (inside && !lhi) ? offp : 0x80000000u;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[sI][r] * unh[sI]), rp, offp + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)(plane * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[sI][8] * unh[sI]), rp, offp16 + 16u * (unsigned)(plane * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[sI][9] * unh[sI]), rp, offp16 + 17u * (unsigned)(plane * 4), 0, 0);
+            }
+        }
+        __syncthreads();                             // (the commit of the next tile's chunk 1 above is visible before its first paired step reads it; also orders the tails)
+    }
+}
+
+
 extern "C" int64_t mrx_rim_layer2_wx_pack_floats(void) { return (int64_t)WX_PACK_U4 * 4; }
 // w_conv [64,64,3,3] (dilation 2), w_ih [64,64,1,1], w_final [2,64,3,3] or null -> the operand pack of mrx_rim_layer2_wx_cb8
 extern "C" int mrx_rim_layer2_wx_pack(const float* w_conv, const float* w_ih, const float* w_final, float* packed, void* stream) {
@@ -557,9 +925,12 @@ extern "C" int mrx_rim_layer2_wx_cb8(const float* x, const float* packed, const 
     a.tiles_x = mrx_cdiv(W, WX_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, WX_TH);
     static bool attr_done = false;
     if (!attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_wx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WX_LDS));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_wx8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WX_LDS));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_rim_layer2_wx4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WX_LDS));
         attr_done = true;
     }
+    // (round 5, same box, 8 slices per launch: eight waves 75.9 us per slice, four waves 85.3 -- the direct kernel 62.0; MRX_WX4=1 selects the four-wave form)
+    static const bool eight = !(getenv("MRX_WX4") && atoi(getenv("MRX_WX4")) != 0);
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -567,7 +938,8 @@ extern "C" int mrx_rim_layer2_wx_cb8(const float* x, const float* packed, const 
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const long long total = (long long)a.ntiles * B;
-    hipLaunchKernelGGL(k_rim_layer2_wx, dim3((unsigned)(total < ncu ? total : ncu)), dim3(WX_NT), WX_LDS, (hipStream_t)stream, a);
+    if (eight) hipLaunchKernelGGL(k_rim_layer2_wx8, dim3((unsigned)(total < ncu ? total : ncu)), dim3(WX_NT), WX_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_rim_layer2_wx4, dim3((unsigned)(total < ncu ? total : ncu)), dim3(WX4_NT), WX_LDS, (hipStream_t)stream, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
