@@ -1087,7 +1087,8 @@ __global__ __launch_bounds__(64 * ((K * K + TPW - 1) / TPW), 1) void k_conv_wgra
     for (int j = 0; j < NCI; ++j) brow[j] = (32 * j + l31 < a.Cin ? 32 * j + l31 : a.Cin) * XS;
 
     const int total_tiles = a.ntiles * a.B;
-    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    for (int t_ = blockIdx.x; t_ < total_tiles; t_ += gridDim.x) {
+        const int t = wb_tile(t_, total_tiles, gridDim.x);     // (the XCD band order of the other persistent loops: a tile's halo rows meet their neighbours' in one L2)
         const int b = t / a.ntiles, tt = t - b * a.ntiles;
         const int ty0 = tt / a.tiles_x, h0 = ty0 * TH, w0 = (tt - ty0 * a.tiles_x) * WB_TW;
         const float* dyb = a.dy + (long long)b * a.Cout * plane;

@@ -579,7 +579,8 @@ __global__ __launch_bounds__(WI_NT, 2) void k_tl_wgrad_in(const float* __restric
     for (int i = tid; i < PH * PW; i += WI_NT) Xh[Cin * PH * PW + i] = 0;
     const int total = ntiles * B;
     const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(dyP) & 15u) == 0);
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int t_ = blockIdx.x; t_ < total; t_ += gridDim.x) {
+        const int t = (gridDim.x & 7u) == 0u ? (int)mrx_xcd_band(t_, total) : t_;      // (XCD band order: a tile's halo rows meet their neighbours' in one L2)
         const int b = t / ntiles, tt = t - b * ntiles, ty0 = tt / tiles_x, h0 = ty0 * WI_TH, w0 = (tt - ty0 * tiles_x) * 32;
         __syncthreads();
         // dy tile from the pair tensor: item = (pair, row, 8-pixel group), exactly two per thread; halo'd x tile: (channel, row, pixel pair), up to four per
