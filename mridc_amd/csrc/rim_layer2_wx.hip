@@ -17,6 +17,7 @@
 // kernel (1x1 stage, epilogue, tap stage: both "rows" together) run on them unchanged but for that pixel map.
 // Round-off against float64 (tools/probe/wino_f16x2_error.py, numpy emulation): 2.3e-7 against 1.3e-7 for the direct two-term form and 1.2e-7 for fp32.
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -61,6 +62,7 @@ struct L2wxArgs {
     float* P;              // [B][18][H][W] or null
     const unsigned* xmax;  // bits of an upper bound of max |x|
     int B, H, W, tiles_x, ntiles;
+    unsigned long long* trace;   // probe builds (MRX_WX_TRACE): cycle stamps [workgroup][wave][4] of the workgroup's second tile
 };
 
 __device__ __forceinline__ void wx_split2h(float a, float b, unsigned& p1, unsigned& p2) {
@@ -664,6 +666,8 @@ __global__ __launch_bounds__(WX4_NT, 1) void k_rim_layer2_wx4(L2wxArgs a) {
         const int tt = (int)mrx_xcd_band(tI, total);
         const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
         const int h0 = ty0 * WX_TH, w0 = (tile - ty0 * a.tiles_x) * WX_TW;
+#define WX_STAMP(i) if (a.trace && lane == 0 && tI == (int)blockIdx.x + (int)gridDim.x) a.trace[((long long)blockIdx.x * 4 + wave) * 4 + (i)] = __builtin_readcyclecounter();
+        WX_STAMP(0)
         f32x16 acc[4][2][2];                         // [position][cout block][column block]
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -742,6 +746,7 @@ __global__ __launch_bounds__(WX4_NT, 1) void k_rim_layer2_wx4(L2wxArgs a) {
             chunk(q2 + 1, std::false_type{}, std::true_type{}, std::false_type{});
         }
         chunk(WX_NCH - 1, std::false_type{}, std::false_type{}, std::true_type{});
+        WX_STAMP(1)
         __syncthreads();                             // (every wave is past its last operand read of buffer 1: the next tile's chunk 1 goes there below)
 
         // ---- output transform: four pixel sets per lane, set (nb2, j) = (row h0 + 4 wave + 2 nb2 + rsub, column w0 + 4 (l31 & 7) + ((l31 >> 3) & 1) + 2 j) ------
@@ -831,6 +836,7 @@ __global__ __launch_bounds__(WX4_NT, 1) void k_rim_layer2_wx4(L2wxArgs a) {
                 if (s == 1) load_hp(2), load_hp(3);
             }
         }
+        WX_STAMP(2)
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hnew + (long long)b * WX_F * plane, 0, (unsigned)(plane * (WX_F * 4)), 0x00020000);
 #pragma unroll
         for (int sI = 0; sI < 4; ++sI) {
@@ -896,6 +902,7 @@ __global__ __launch_bounds__(WX4_NT, 1) void k_rim_layer2_wx4(L2wxArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[sI][9] * unh[sI]), rp, offp16 + 17u * (unsigned)(plane * 4), 0, 0);
             }
         }
+        WX_STAMP(3)
         __syncthreads();                             // (the commit of the next tile's chunk 1 above is visible before its first paired step reads it; also orders the tails)
     }
 }
@@ -938,8 +945,27 @@ extern "C" int mrx_rim_layer2_wx_cb8(const float* x, const float* packed, const 
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const long long total = (long long)a.ntiles * B;
+    a.trace = nullptr;
+    static unsigned long long* d_trace = nullptr;
+    if (getenv("MRX_WX_TRACE")) {
+        if (!d_trace) (void)hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 256 * 16);
+        (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 256 * 16, (hipStream_t)stream);
+        a.trace = d_trace;
+    }
     if (eight) hipLaunchKernelGGL(k_rim_layer2_wx8, dim3((unsigned)(total < ncu ? total : ncu)), dim3(WX_NT), WX_LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_rim_layer2_wx4, dim3((unsigned)(total < ncu ? total : ncu)), dim3(WX4_NT), WX_LDS, (hipStream_t)stream, a);
     MRX_LAUNCH_CHECK();
+    if (a.trace && !eight) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        static unsigned long long h[256 * 16];
+        (void)hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost);
+        double ph[3] = {0, 0, 0};
+        long n = 0;
+        for (int w = 0; w < 256 * 4; ++w) {
+            const unsigned long long* t = h + w * 4;
+            if (t[0] && t[3] > t[0]) ph[0] += (double)(t[1] - t[0]), ph[1] += (double)(t[2] - t[1]), ph[2] += (double)(t[3] - t[2]), ++n;
+        }
+        if (n) fprintf(stderr, "[wx4-trace] %ld waves: chunk loop %.0f, tail head + 1x1 stage %.0f, epilogue + stores + tap stage %.0f cycles\n", n, ph[0] / n, ph[1] / n, ph[2] / n);
+    }
     return MRX_OK;
 }
