@@ -1197,6 +1197,9 @@ def main():
     timer.wrap(ops, "rim_layer2_sb_taps", lambda x, *a, **k: "conv_layer2_sbt")     # + the final convolution's channel contraction in its tail
     timer.wrap(ops, "rim_layer2_f16", lambda x, *a, **k: "conv_layer2_f16t" if k.get("want_taps") else "conv_layer2_f16")   # two-term fp16 conv operands
     timer.wrap(ops, "rim_layer2_f16_cb8", lambda x, *a, **k: "conv_layer2_f16t" if k.get("want_taps") else "conv_layer2_f16")   # channel-blocked states
+    timer.wrap(ops, "rim_layer2_f16_cb8_q", lambda *a, **k: "conv_layer2_f16t")     # ... with the tap products pre-summed along x (6 planes + tile-edge terms)
+    timer.wrap(ops, "rim_final_gather_q", lambda *a, **k: "final_gather")
+    timer.wrap(ops, "llg372_gather_q", lambda *a, **k: "llg372g")
     timer.wrap(ops, "rim_layer1_cb8", lambda *a, **k: "conv_layer1")
     timer.wrap(ops, "rim_final_gather", lambda *a, **k: "final_gather")
     timer.wrap(ops, "llg", lambda *a, **k: "llg")
@@ -1356,6 +1359,8 @@ def main():
         final_flops = 0.0 if l2_taps else 2.0 * F_hidden * 2 * 9 * npix * B      # (in layer 2's launch when its tail does the contraction)
         issued_reg = max(issued_reg, 0.0)
         t_reg = (ms1 or 0) + (ms2 or 0) + (msf or 0)
+        # tap planes layer 2 writes: 18, or 6 (+ 16 floats per row and 32-pixel tile) on the pre-summed route (ops.RIM_TAPS_Q: row-invariant masks at W = 372)
+        tap_planes = 6.0 + 16.0 / 32.0 if (ops.RIM_TAPS_Q and args.mask == "1d" and W == 372 and ops.LLG372_GATHER) else 18.0
         roofline = dict(bound="mfma", kernel=kname,
                         achieved=tf(executed), peak=peak2, unit="TFLOP/s",
                         frac=(tf(executed) / peak2) if ms2 else None,
@@ -1367,7 +1372,7 @@ def main():
                                           "direct-form FLOPs of SURVEY 8d / time: above `frac` by the Winograd saving (2.0x), not a pipe figure"),
                         traffic=traffic.get("conv_layer2_f16" if l2_f16 else "conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"), traffic_unit="bytes/launch",
                         traffic_kernel=traffic.get("_kernels", {}).get("conv_layer2_f16" if l2_f16 else "conv_layer2_sb" if l2_bf16 else "conv_layer2_wino" if msw else "conv_layer2"),
-                        traffic_source=traffic.get("_source"), algorithmic_bytes=(3.0 * F_hidden + (18.0 if l2_taps else 0.0)) * npix * B * 4,
+                        traffic_source=traffic.get("_source"), algorithmic_bytes=(3.0 * F_hidden + (tap_planes if l2_taps else 0.0)) * npix * B * 4,
                         # matrix-pipe utilisation by the hardware counters (committed PMC passes of this library version, like `traffic`):
                         # MFMA-pipe busy cycles / (4 SIMDs x CU busy cycles) -- independent of the clock the chip sustains under the kernel
                         # (bf16 MFMA kernels run at ~1.7-1.8 GHz here, `frac` prices the issued FLOPs against the 2.4 GHz peak)
@@ -1382,7 +1387,7 @@ def main():
                                     "that do not scale with the clock (profiles/r05_layer2_power_probe.txt, r05_layer2_memory_ablation.txt)") if l2_f16 else None,
                         # the same launch against the HBM roofline (its algorithmic bytes: x, h_prev in, h_new and the tap planes out): with the
                         # two-term fp16 operands the kernel sits between its two bounds
-                        hbm_frac=((3.0 * F_hidden + (18.0 if l2_taps else 0.0)) * npix * B * 4 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms2 else None,
+                        hbm_frac=((3.0 * F_hidden + (tap_planes if l2_taps else 0.0)) * npix * B * 4 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms2 else None,
                         regulariser=dict(ms=t_reg, direct_form_gflop=flops_reg / 1e9, issued_fp32_gflop=issued_reg / 1e9,
                                          issued_bf16_gflop=issued1_bf16 / 1e9,
                                          frac_issued=(pipe_ms(issued_reg, issued1_bf16) / t_reg) if t_reg else None,

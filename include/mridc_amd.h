@@ -180,6 +180,10 @@ int mrx_llg372_prepare(const float* yt, const float* S, const void* mask, int ma
  *                       is written, bit-identical to mrx_rim_final_gather's */
 int mrx_llg372_gather(const float* eta, const float* taps, const float* b_final, float* eta_out, const float* Sp, const float* maskp, int mask_batched,
                       float* out4, float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream);
+/* mrx_llg372_gather on the row-pre-summed tap planes of mrx_rim_layer2_f16_cb8_q (taps_q [B][6][H][372], edges: mrx_rim_taps_q_edge_floats(B, H, 372) floats);
+ * eta_out is bit-identical to mrx_rim_final_gather_q's. */
+int mrx_llg372_gather_q(const float* eta, const float* taps_q, const float* edges, const float* b_final, float* eta_out, const float* Sp, const float* maskp,
+                        int mask_batched, float* out4, float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream);
 int mrx_llg372_const_plane(const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* work, int B, int C, int H, int norm,
                            int centered, void* stream);
 int mrx_llg372(const float* eta, const float* ytp, const float* Sp, const float* maskp, int mask_batched, float* out4, float* work,
@@ -373,6 +377,15 @@ int mrx_rim_layer1_cb8(const float* x, int Cin, const float* eta, const float* p
                        void* stream);
 int mrx_rim_layer2_f16_cb8(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
                            float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream);
+/* The tap products of the final convolution pre-summed along x inside the kernel (round 5): mrx_rim_layer2_f16_cb8_q leaves taps_q [B][6][H][W] (plane dy * 2 + co:
+ * P[dy,0](x - 1) + P[dy,1](x) + P[dy,2](x + 1) with replicate borders) and, for the two columns of every 32-pixel tile whose neighbour lives in another tile, the missing
+ * products in `edges` (mrx_rim_taps_q_edge_floats(B, H, W) floats).  mrx_rim_final_gather_q (and mrx_llg372_gather_q, below) finish the 3x3: same result as the
+ * 18-plane route up to the order of nine additions.  6 + 2 instead of 18 + 2 values per pixel in the gather, 3 instead of 10 stores per lane in the layer. */
+int64_t mrx_rim_taps_q_edge_floats(int B, int H, int W);
+int mrx_rim_layer2_f16_cb8_q(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                             float* h_new, float* taps_q, float* edges, const float* xmax, int B, int H, int W, void* stream);
+int mrx_rim_final_gather_q(const float* taps_q, const float* edges, const float* b_final, const float* eta, float* eta_out, int B, int H, int W,
+                           void* stream);
 /* mrx_rim_layer2_f16_cb8 with the dilated 3x3 in a Winograd F(2, 3) form ALONG X on the same two-term fp16 operands (csrc/rim_layer2_wx.hip: 288 instead of
  * 432 convolution MFMAs per 512 pixels -- the headline loop runs at the chip's power limit, so matrix FLOPs are what it pays for).  Same arguments and results
  * up to round-off: 2.3e-7 against float64 where the direct form has 1.3e-7 and fp32 1.2e-7 (numpy emulation, tools/probe/wino_f16x2_error.py).  Its own operand

@@ -123,6 +123,7 @@ _SIGNATURES = {
     "mrx_llg372_operand_floats": ([_i, _i, _i], _i64),
     "mrx_llg372_work_floats": ([_i, _i, _i], _i64),
     "mrx_llg372_gather": ([_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
+    "mrx_llg372_gather_q": ([_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
     "mrx_llg372_const_plane": ([_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_llg372_prepare": ([_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "mrx_llg372": ([_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p], _i),
@@ -203,6 +204,9 @@ _SIGNATURES = {
     "mrx_cb8_convert": ([_p, _p, _i, _i, _i, _i, _i, _p], _i),
     "mrx_rim_layer1_cb8": ([_p, _i, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_layer2_f16_cb8": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_rim_taps_q_edge_floats": ([_i, _i, _i], _i64),
+    "mrx_rim_layer2_f16_cb8_q": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_rim_final_gather_q": ([_p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_layer2_wx_pack_floats": ([], _i64),
     "mrx_rim_layer2_wx_pack": ([_p, _p, _p, _p, _p], _i),
     "mrx_rim_layer2_wx_cb8": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),

@@ -381,6 +381,9 @@ class RIMBlock(torch.nn.Module):
         # W = 372, constant-plane gradient: the nine-tap gather that ends a step (eta + final convolution) rides in the NEXT step's gradient launch
         # (mrx_llg372_gather); `pending` = the tap products of a step whose eta has not been formed yet
         fuse_gather = cb8 and defer and op372 is not None and ops.LLG372_NO_Y and ops.LLG372_GATHER
+        # ... with the tap products pre-summed along x inside layer 2 (6 planes + tile-edge terms instead of 18 planes: mrx_rim_layer2_f16_cb8_q,
+        # mrx_llg372_gather_q, mrx_rim_final_gather_q); the sample's state must fit the kernel's 32-bit byte offsets
+        taps_q = fuse_gather and ops.RIM_TAPS_Q and int(eta.shape[1]) * int(eta.shape[2]) * 256 < 2 ** 31
         # ... and, for general masks at W = 372, in the first of the next step's three gradient passes (mrx_pfa372_expand_t4_gather)
         fuse_gather_t4 = cb8 and defer and op372 is None and t4 and ops.LLG_T4_NO_Y and ops.LLG_T4_GATHER
         pending = None
@@ -391,6 +394,10 @@ class RIMBlock(torch.nn.Module):
                 if pending is not None and fuse_gather_t4:
                     part, nparts, eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization, self.spatial_dims,
                                                 work=work, parts=True, gather=(pending, final.conv_layer.bias))
+                    etas.append(eta)
+                    pending = None
+                elif pending is not None and taps_q:
+                    part, nparts, eta = ops.llg372_gather_q(eta, pending[0], pending[1], final.conv_layer.bias, op372, sigma, self.fft_normalization)
                     etas.append(eta)
                     pending = None
                 elif pending is not None:
@@ -415,6 +422,15 @@ class RIMBlock(torch.nn.Module):
                 hx[0] = ops.rim_layer1_cb8(None if llg_form else grad_eta, eta if llg_form else None, part, nparts, sigma, self._packed(0, c0, r0),
                                            c0.conv_layer.bias, r0.ih.bias, r0.hh, hx[0], xmax,
                                            out=hx[0] if (self.inplace_state and hx[0] is not None) else None)
+                if taps_q:
+                    hx[1], tq, te = ops.rim_layer2_f16_cb8_q(hx[0], self._packed_f16(1, c1, r1, final), c1.conv_layer.bias, r1.ih.bias, r1.hh, hx[1], xmax,
+                                                             out=hx[1] if (self.inplace_state and hx[1] is not None) else None)
+                    if step + 1 < self.time_steps:
+                        pending = (tq, te)
+                        continue
+                    eta = ops.rim_final_gather_q(tq, te, final.conv_layer.bias, eta)
+                    etas.append(eta)
+                    continue
                 hx[1], taps = ops.rim_layer2_f16_cb8(hx[0], self._packed_f16(1, c1, r1, final), c1.conv_layer.bias, r1.ih.bias, r1.hh, hx[1], xmax,
                                                      out=hx[1] if (self.inplace_state and hx[1] is not None) else None, want_taps=True)
                 if (fuse_gather or fuse_gather_t4) and step + 1 < self.time_steps:

@@ -119,9 +119,10 @@ __global__ void k_llg372_prep_mask(MrxMask mask, float* __restrict__ maskp, int 
 // GAT: eta is not read but MADE here -- the previous step's eta plus the nine-tap gather of the final convolution's tap products (the whole of
 // k_l2sb_gather, same order of additions: bit-identical) -- and written out by the row's first task; one launch per step less in the RIM loop.
 struct L372Gather {
-    const float* taps;      // [B][18][H][372]: taps[b][tap * 2 + co] (rim_layer2_sb.hip)
+    const float* taps;      // [B][18][H][372]: taps[b][tap * 2 + co] (rim_layer2_sb.hip) -- or, with `edges`, the row-pre-summed planes [B][6][H][372] (plane dy * 2 + co)
     const float* bias;      // [2] or null
     float2* eta_out;        // [B][H][372]
+    const float* edges = nullptr;   // not null: taps are mrx_rim_layer2_f16_cb8_q's; edges [B][H][12][16] what the neighbouring 32-pixel tiles owe columns 0 / 31
 };
 template <int ABL, bool NOY = false, bool GAT = false>
 __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta_, const float2* __restrict__ ytp_,
@@ -170,6 +171,46 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
         const float b0 = ga.bias ? ga.bias[0] : 0.f, b1 = ga.bias ? ga.bias[1] : 0.f;
         constexpr int GAT_GROUP = 6;
         float2 vout[6];
+        if (ga.edges) {
+            // the row-pre-summed form (mrx_rim_layer2_f16_cb8_q): 6 plane values + 3 edge pairs + eta per pixel instead of 18 + eta; the additions in the order of
+            // l2sb_gather_q_px (rim_layer2_sb.hip): bias, the three rows' plane values, the three rows' edge terms -- bit-identical to mrx_rim_final_gather_q
+            const float* __restrict__ qb = ga.taps + (long long)b * 6 * plane;
+            constexpr int TX = (PFA_N + 31) / 32;
+            const float* __restrict__ eb = ga.edges + (long long)b * 16 * a.H * TX;
+            float q[6][3][2];
+            float2 ee[6][3], e[6];
+            bool edge[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int n = min(l + 64 * i, PFA_N - 1);
+                const int w = pfa372_shift(n, a.halfW);
+                const int xt = w >> 5, xl = w & 31;
+                const bool fromR = xl == 31 && w + 1 < PFA_N, fromL = xl == 0 && w > 0;
+                const int et = fromR ? xt + 1 : (fromL ? xt - 1 : xt);
+                const int oo[3] = {fromR ? 4 : 8, fromR ? 0 : 12, fromR ? 2 : 14};
+                const int yy[3] = {y0, h, y2};
+                edge[i] = fromR || fromL;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    q[i][dy][0] = qb[(long long)(dy * 2) * plane + (long long)yy[dy] * PFA_N + w];
+                    q[i][dy][1] = qb[(long long)(dy * 2 + 1) * plane + (long long)yy[dy] * PFA_N + w];
+                    ee[i][dy] = *reinterpret_cast<const float2*>(eb + ((long long)yy[dy] * TX + et) * 16 + oo[dy]);
+                }
+                e[i] = eta_[(long long)row * PFA_N + w];
+                mv[i] = mrow[n];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float s0 = b0, s1 = b1;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) s0 += q[i][dy][0], s1 += q[i][dy][1];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) s0 += edge[i] ? ee[i][dy].x : 0.f, s1 += edge[i] ? ee[i][dy].y : 0.f;
+                vout[i] = make_float2(e[i].x + s0, e[i].y + s1);
+                ev[i] = pfa_mk(vout[i].x, vout[i].y);
+            }
+        } else
 #pragma unroll
         for (int i0 = 0; i0 < 6; i0 += GAT_GROUP) {
             float t[GAT_GROUP][18];
@@ -805,6 +846,37 @@ extern "C" int mrx_llg372_gather(const float* eta, const float* taps, const floa
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((k_llg372<0, true, true>), dim3((unsigned)a.ntasks), dim3(64), L372_LDS_BYTES, st, (const float2*)eta, (const float2*)nullptr,
                        (const float2*)Sp, maskp, (float2*)work, a, L372Gather{taps, b_final, (float2*)eta_out});
+    const int np = a.T + 1;
+    if (nparts) {
+        *nparts = np;
+        MRX_LAUNCH_CHECK();
+        return MRX_OK;
+    }
+    const long long plane = (long long)H * PFA_N, total = plane * B;
+    long long nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_llg372_combine, dim3((unsigned)nb), dim3(256), 0, st, (const float2*)eta_out, (const float2*)work, out4, np, (long long)B, plane,
+                       inv_sigma2);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+// mrx_llg372_gather on the row-pre-summed tap planes of mrx_rim_layer2_f16_cb8_q (taps_q [B][6][H][372], edges: mrx_rim_taps_q_edge_floats): eta_out is bit-identical to
+// mrx_rim_final_gather_q's result.
+extern "C" int mrx_llg372_gather_q(const float* eta, const float* taps_q, const float* edges, const float* b_final, float* eta_out, const float* Sp,
+                                   const float* maskp, int mask_batched, float* out4, float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm,
+                                   int centered, void* stream) {
+    MRX_REQUIRE(eta && taps_q && edges && eta_out && Sp && maskp && work && (out4 || nparts), MRX_EINVAL, "mrx_llg372_gather_q: null pointer");
+    L372Args a;
+    int rc = l372_args(&a, B, C, H, norm, centered, mask_batched);
+    if (rc) return rc;
+    if (nparts) *nparts = 0;
+    if (B == 0) return MRX_OK;
+    MRX_REQUIRE(a.ntasks < (1ll << 31), MRX_EUNSUP, "mrx_llg372_gather_q: too many tasks");
+    hipStream_t st = (hipStream_t)stream;
+    L372Gather ga{taps_q, b_final, (float2*)eta_out};
+    ga.edges = edges;
+    hipLaunchKernelGGL((k_llg372<0, true, true>), dim3((unsigned)a.ntasks), dim3(64), L372_LDS_BYTES, st, (const float2*)eta, (const float2*)nullptr,
+                       (const float2*)Sp, maskp, (float2*)work, a, ga);
     const int np = a.T + 1;
     if (nparts) {
         *nparts = np;

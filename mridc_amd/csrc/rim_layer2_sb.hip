@@ -54,6 +54,9 @@ struct L2sbArgs {
     const float* hprev;    // [B,64,H,W] or null
     float* hnew;           // [B,64,H,W]
     float* P;              // not null: also P[b][tap * 2 + co][y][x] = sum_c w_final[co][c][tap] * h_new[c][y][x]  (mrx_rim_final_gather adds the taps up)
+    float* Q = nullptr;    // FAST form, with E: the tap products pre-summed along x inside the tile -- Q[b][dy * 2 + co][y][x] = P[dy,0](x - 1) + P[dy,1](x) + P[dy,2](x + 1)
+    float* E = nullptr;    // with the terms a NEIGHBOURING 32-pixel tile owes left out, which that tile leaves here: E[b][y][tile column][16]
+                           // (its first column's dx = 2 products, for the pixel to its left; its last column's dx = 0 products, for the pixel to its right)
     int B, H, W, tiles_x, ntiles;
     int act;               // TAIL = false: MRX_ACT_* applied to conv + bias
     float slope;
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
                                                              __float_as_uint(hp[rw][4 * q + 3])},
                                                        rh, offh[rw] + (unsigned)q * (unsigned)(plane * 32), 0, 0);
         }
-        if (a.P) {
+        if (a.P || a.Q) {
             f32x16 accp[2];
             float sh[2], unh[2];
 #pragma unroll
@@ -859,6 +862,61 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
 #pragma unroll
                 for (int rw = 0; rw < 2; ++rw) accp[rw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[rw], accp[rw], 0, 0, 0);
             }
+            if (a.Q) {
+                // Eighteen tap planes become six: the three products of a kernel row meet inside the wave's image row (lane = pixel), so the gather that
+                // follows (k_llg372<GAT>, k_l2sb_gather_q) reads 6 + 2 instead of 18 + 2 values per pixel and this kernel stores 3 instead of 10 per lane.
+                // Lanes of the lower half-wave hold products m = 0..3, 8..11, 16, 17 (m = (dy * 3 + dx) * 2 + co), those of the upper half 4..7, 12..15.
+                // Column 0 / 31 of the tile miss their left / right neighbour unless that is the image border (replicate padding: the pixel itself); what
+                // they miss the neighbouring tile leaves in E.
+                const int tcol = (w0 / S2_TW);
+                const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(a.Q + (long long)b * 6 * plane, 0, (unsigned)(plane * (6 * 4)), 0x00020000);
+                const long long eslots = (long long)a.H * a.tiles_x;       // 16 floats per (row, tile column)
+                const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(a.E + (long long)b * 16 * eslots, 0, (unsigned)(eslots * 64), 0x00020000);
+                const bool hasL = l31 > 0, hasR = l31 < 31 && ox + 1 < a.W;
+                const bool useL = hasL || ox == 0, useR = l31 < 31 || ox == a.W - 1;
+                // x - 1 / x + 1 are wave shifts by one lane (DPP; the lanes where the shift crosses the half-wave are columns 0 / 31: masked, or the replicated border)
+                auto fromL = [&](float v_) {                         // the value of the pixel to the left (the pixel itself on the image border, 0 across a tile border)
+                    const float t = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v_), 0x138, 0xf, 0xf, false));   // wave_shr:1
+                    return useL ? (hasL ? t : v_) : 0.f;
+                };
+                auto fromR = [&](float v_) {
+                    const float t = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v_), 0x130, 0xf, 0xf, false));   // wave_shl:1
+                    return useR ? (hasR ? t : v_) : 0.f;
+                };
+#pragma unroll
+                for (int rw = 0; rw < 2; ++rw) {
+                    const int oy = oy0 + rw;
+                    const bool inside = oy < a.H && ox < a.W;
+                    float v[10];
+#pragma unroll
+                    for (int r = 0; r < 10; ++r) v[r] = accp[rw][r] * unh[rw];
+                    // plane dy * 2 + co = A(dx 0, x - 1) + B(dx 1, x) + C(dx 2, x + 1); the products sit in (register, half-wave):
+                    //   plane 0, 1: A (co, lower)      B (2 + co, lower)   C (co, upper)        -> stored by the lower half-wave
+                    //   plane 2, 3: A (2 + co, upper)  B (4 + co, lower)   C (6 + co, lower)    -> plane 2 by the lower, plane 3 by the upper half-wave
+                    //   plane 4, 5: A (4 + co, upper)  B (6 + co, upper)   C (8 + co, lower)    -> stored by the upper half-wave
+                    // Three half-wave swaps carry what the other half holds (each serves a lower-stored and an upper-stored plane).
+                    const float sw0 = __shfl_xor(lhi ? fromR(v[0]) : v[5] + fromR(v[7]), 32, 64);      // lower gets C of plane 0; upper gets B + C of plane 3
+                    const float sw1 = __shfl_xor(lhi ? fromR(v[1]) : fromR(v[8]), 32, 64);             // lower gets C of plane 1; upper gets C of plane 4
+                    const float sw2 = __shfl_xor(lhi ? fromL(v[2]) : fromR(v[9]), 32, 64);             // lower gets A of plane 2; upper gets C of plane 5
+                    float q[3];
+                    q[0] = lhi ? fromL(v[3]) + sw0 : (fromL(v[0]) + v[2]) + sw0;                       // plane 3 | plane 0
+                    q[1] = lhi ? (fromL(v[4]) + v[6]) + sw1 : (fromL(v[1]) + v[3]) + sw1;              // plane 4 | plane 1
+                    q[2] = lhi ? (fromL(v[5]) + v[7]) + sw2 : sw2 + (v[4] + fromR(v[6]));              // plane 5 | plane 2
+                    const unsigned offq = inside ? (unsigned)(((long long)oy * a.W + ox + 3ll * lhi * plane) * 4) : 0x80000000u;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(q[i]), rq, offq + (unsigned)i * (unsigned)(plane * 4), 0, 0);
+                    // what the neighbouring tiles miss, ONE 16-byte store per row by the four lanes that hold it -- E[b][y][tile column][16]:
+                    //   [0..3]  column 0, lower lane: dx = 2 products of dy 1, 2 (registers 6, 7, 8, 9)      [4..5]   column 0, upper lane: dx = 2 products of dy 0 (registers 0, 1)
+                    //   [8..9]  column 31, lower lane: dx = 0 products of dy 0 (registers 0, 1)              [12..15] column 31, upper lane: dx = 0 products of dy 1, 2 (registers 2..5)
+                    const bool col0 = l31 == 0 && inside && tcol > 0, col31 = l31 == 31 && inside && tcol + 1 < a.tiles_x;
+                    const u32x4 ev = l31 == 0 ? (lhi ? u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), 0u, 0u}
+                                                     : u32x4{__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), __float_as_uint(v[9])})
+                                              : (lhi ? u32x4{__float_as_uint(v[2]), __float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5])}
+                                                     : u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), 0u, 0u});
+                    const unsigned eoff = (col0 || col31) ? (unsigned)(((long long)oy * a.tiles_x + tcol) * 64 + (l31 == 0 ? (lhi ? 16 : 0) : (lhi ? 48 : 32))) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(ev, re, eoff, 0, 0);
+                }
+            } else {
 #ifdef MRX_L2_ABL_NOST
             const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.P + (long long)b * 18 * plane, 0, 0u, 0x00020000);
 #else
@@ -877,6 +935,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[rw][9] * unh[rw]), rp, offp16 + 17u * (unsigned)(plane * 4), 0, 0);
             }
         }
+            }
         S2_STAMP(3)
         } else if constexpr (TAIL) {
         // ---- g = ReLU(conv + b) in registers; h = ReLU(W_ih g + b_ih + hh * h_prev), one of the wave's two rows at a time ------------------
@@ -1142,7 +1201,8 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
     return MRX_OK;
 }
 static int l2sb_launch(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
-                       float* h_new, float* P, int B, int H, int W, void* stream, const float* xmax = nullptr, bool cb8 = false) {
+                       float* h_new, float* P, int B, int H, int W, void* stream, const float* xmax = nullptr, bool cb8 = false, float* Q = nullptr,
+                       float* E = nullptr) {
     MRX_REQUIRE(x && packed && hh && h_new, MRX_EINVAL, "mrx_rim_layer2_sb: null pointer");
     MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_layer2_sb: bad dims");
     if (B == 0) return MRX_OK;
@@ -1152,6 +1212,12 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
     a.P = P, a.act = MRX_ACT_NONE, a.slope = 0.f;
     a.xmax = reinterpret_cast<const unsigned*>(xmax);
     a.xmax_out = nullptr;
+    if (Q) {                                            // the row-pre-summed tap planes: the FAST form only
+        MRX_REQUIRE(E && !P && xmax && cb8, MRX_EINVAL, "mrx_rim_layer2_f16_cb8_q: bad arguments");
+        MRX_REQUIRE((long long)H * W * (S2_F * 4) < (1ll << 31), MRX_EUNSUP, "mrx_rim_layer2_f16_cb8_q: %d x %d: a sample's state exceeds 32-bit byte offsets", H, W);
+        a.Q = Q, a.E = E;
+        return l2sb_launch_t<2, true, false, true, 0, true, false, false, true>(a, (hipStream_t)stream);
+    }
 #ifdef MRX_PROBE
     if (xmax && cb8 && getenv("MRX_L2_ABL")) {
         switch (atoi(getenv("MRX_L2_ABL"))) {
@@ -1347,6 +1413,65 @@ extern "C" int mrx_rim_final_gather(const float* taps, const float* b_final, con
     MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_final_gather: bad dims");
     if (B == 0) return MRX_OK;
     hipLaunchKernelGGL(k_l2sb_gather, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps, b_final, eta, eta_out, H, W);
+    MRX_LAUNCH_CHECK();
+    return MRX_OK;
+}
+
+// The same gather from the row-pre-summed tap planes of mrx_rim_layer2_f16_cb8_q: eta_out = eta + bias + sum_dy Q[dy][co][clamp(y + dy - 1)][x] + the term the
+// neighbouring 32-pixel tile owes column 31 (E side 0 of the tile to the right) or column 0 (E side 1 of the tile to the left).  8 + 2 instead of 18 + 2 loads per
+// pixel.  The order of the additions is fixed and shared with the gather inside mrx_llg372_gather_q (bit-identical to it; the nine-tap form differs in rounding).
+__device__ __forceinline__ void l2sb_gather_q_px(const float* __restrict__ qb, const float* __restrict__ ebp, long long plane, int tiles_x, int H, int W, int y, int x,
+                                                 float b0, float b1, float& s0, float& s1) {
+    float q[3][2], e[3][2];
+    const int xt = x >> 5, xl = x & 31;
+    const bool fromR = xl == 31 && x + 1 < W, fromL = xl == 0 && x > 0;
+    // E[y][tile][16]: side 0 (dx = 2 products of the tile's column 0): dy 0 at [4, 5], dy 1 at [0, 1], dy 2 at [2, 3]; side 1 (dx = 0 products of column 31): dy 0 at
+    // [8, 9], dy 1 at [12, 13], dy 2 at [14, 15]
+    const int et = fromR ? xt + 1 : (fromL ? xt - 1 : xt);
+    const int o0 = fromR ? 4 : 8, o1 = fromR ? 0 : 12, o2 = fromR ? 2 : 14;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        int yy = y + dy - 1;
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+        q[dy][0] = qb[(long long)(dy * 2) * plane + (long long)yy * W + x];
+        q[dy][1] = qb[(long long)(dy * 2 + 1) * plane + (long long)yy * W + x];
+        const float2 ee = *reinterpret_cast<const float2*>(ebp + ((long long)yy * tiles_x + et) * 16 + (dy == 0 ? o0 : (dy == 1 ? o1 : o2)));
+        e[dy][0] = (fromR || fromL) ? ee.x : 0.f, e[dy][1] = (fromR || fromL) ? ee.y : 0.f;
+    }
+    s0 = b0, s1 = b1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) s0 += q[dy][0], s1 += q[dy][1];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) s0 += e[dy][0], s1 += e[dy][1];
+}
+__global__ __launch_bounds__(256) void k_l2sb_gather_q(const float* __restrict__ Q, const float* __restrict__ E, const float* __restrict__ bias,
+                                                       const float* __restrict__ eta, float* __restrict__ out, int H, int W, int tiles_x) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const long long plane = (long long)H * W;
+    float s0, s1;
+    l2sb_gather_q_px(Q + (long long)b * 6 * plane, E + (long long)b * 16 * H * tiles_x, plane, tiles_x, H, W, y, x, bias ? bias[0] : 0.f, bias ? bias[1] : 0.f, s0, s1);
+    const long long e = ((long long)b * plane + (long long)y * W + x) * 2;
+    float2 v = eta ? *reinterpret_cast<const float2*>(eta + e) : make_float2(0.f, 0.f);
+    v.x += s0, v.y += s1;
+    *reinterpret_cast<float2*>(out + e) = v;
+}
+extern "C" int64_t mrx_rim_taps_q_edge_floats(int B, int H, int W) { return B < 0 || H < 1 || W < 1 ? -1 : (int64_t)B * 16 * H * mrx_cdiv(W, S2_TW); }
+// mrx_rim_layer2_f16_cb8 whose tap products leave pre-summed along x: taps_q [B][6][H][W] (plane dy * 2 + co) and edges [mrx_rim_taps_q_edge_floats] -- consumed by
+// mrx_rim_final_gather_q and mrx_llg372_gather_q.  A sample's state must fit 32-bit byte offsets (MRX_EUNSUP otherwise: use the 18-plane form).
+extern "C" int mrx_rim_layer2_f16_cb8_q(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
+                                        float* h_new, float* taps_q, float* edges, const float* xmax, int B, int H, int W, void* stream) {
+    MRX_REQUIRE(xmax && taps_q && edges, MRX_EINVAL, "mrx_rim_layer2_f16_cb8_q: null pointer");
+    if (x && B > 0 && H > 0 && W > 0) MRX_CHECK_BOUND("mrx_rim_layer2_f16_cb8_q", x, (long long)B * 64 * H * W, xmax, stream);
+    return l2sb_launch(x, packed, b_conv, b_ih, hh, h_prev, h_new, nullptr, B, H, W, stream, xmax, true, taps_q, edges);
+}
+extern "C" int mrx_rim_final_gather_q(const float* taps_q, const float* edges, const float* b_final, const float* eta, float* eta_out, int B, int H, int W,
+                                      void* stream) {
+    MRX_REQUIRE(taps_q && edges && eta_out, MRX_EINVAL, "mrx_rim_final_gather_q: null pointer");
+    MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_rim_final_gather_q: bad dims");
+    if (B == 0) return MRX_OK;
+    hipLaunchKernelGGL(k_l2sb_gather_q, dim3(mrx_cdiv(W, 64), mrx_cdiv(H, 4), B), dim3(256), 0, (hipStream_t)stream, taps_q, edges, b_final, eta, eta_out, H, W,
+                       mrx_cdiv(W, S2_TW));
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }

@@ -488,6 +488,26 @@ def llg372_gather(eta, taps, b_final, op, sigma, normalization):
     return op.work, int(n.value), eta_new
 
 
+def llg372_gather_q(eta, taps_q, edges, b_final, op, sigma, normalization):
+    """llg372_gather on the row-pre-summed tap planes of rim_layer2_f16_cb8_q (mrx_llg372_gather_q): returns (work, nparts, eta_new)."""
+    import ctypes
+    eta = _lib.f32c(eta)
+    if tuple(eta.shape) != (op.B, op.H, 372, 2) or taps_q.numel() < 6 * op.B * op.H * 372:
+        raise ValueError(f"llg372_gather_q: eta {tuple(eta.shape)}, taps_q {tuple(taps_q.shape)}")
+    if op.linear or not LLG372_NO_Y:
+        raise RuntimeError("llg372_gather_q needs the constant-plane form of the gradient (ops.LLG372_NO_Y)")
+    if op.const_norm != _norm(normalization):
+        _llg372_const(op, normalization)
+    bf = _lib.f32c(b_final.detach()) if b_final is not None else None
+    eta_new = torch.empty_like(eta)
+    n = ctypes.c_int(0)
+    _lib.check(_lib.lib().mrx_llg372_gather_q(_lib.ptr(eta), _lib.ptr(taps_q), _lib.ptr(edges), _lib.ptr(bf), _lib.ptr(eta_new), _lib.ptr(op.sp), _lib.ptr(op.maskp),
+                                              op.mask_batched, None, _lib.ptr(op.work), ctypes.byref(n), op.B, op.C, op.H,
+                                              float(1.0 / (float(sigma) ** 2.0)), _norm(normalization), int(op.centered), _lib.stream_ptr()),
+               "mrx_llg372_gather_q")
+    return op.work, int(n.value), eta_new
+
+
 def llg_hinv(eta, yt, sens, mask, sigma, centered, normalization, out=None, work=None):
     """log_likelihood_gradient for a row-invariant mask (yt from llg_prepare): row transforms only."""
     yt, sens, eta = _lib.f32c(yt), _lib.f32c(sens), _lib.f32c(eta)
@@ -1522,6 +1542,47 @@ def rim_layer2_f16_cb8(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps=None, out
                                                  _lib.ptr(taps) if want_taps else None, _lib.ptr(xmax), B, H, W, _lib.stream_ptr()),
                "mrx_rim_layer2_f16_cb8")
     return (out, taps) if want_taps else out
+
+
+# the fused RIM loop at W = 372: layer 2 leaves the final convolution's tap products pre-summed along x (env MRIDC_AMD_RIM_TAPS_Q=0: the 18-plane form)
+RIM_TAPS_Q = os.environ.get("MRIDC_AMD_RIM_TAPS_Q", "1") != "0"
+
+
+def rim_layer2_f16_cb8_q(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps_q=None, edges=None, out=None):
+    """rim_layer2_f16_cb8 with the final convolution's tap products pre-summed along x (mrx_rim_layer2_f16_cb8_q): returns (h_new [B,8,H,W,8], taps_q [B,6,H,W],
+    edges [mrx_rim_taps_q_edge_floats]) -- for rim_final_gather_q / llg372_gather_q."""
+    x = _lib.f32c(x)
+    B, Q, H, W, E = [int(v) for v in x.shape]
+    if Q != 8 or E != 8:
+        raise ValueError(f"rim_layer2_f16_cb8_q expects x [B,8,H,W,8], got {tuple(x.shape)}")
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _lib.f32c(h_prev) if h_prev is not None else None
+    L = _lib.lib()
+    if taps_q is None or taps_q.numel() < 6 * B * H * W:
+        taps_q = torch.empty(B, 6, H, W, dtype=torch.float32, device=x.device)
+    ne = int(L.mrx_rim_taps_q_edge_floats(B, H, W))
+    if edges is None or edges.numel() < ne:
+        edges = torch.empty(ne, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(B, 8, H, W, 8, dtype=torch.float32, device=x.device)
+    _lib.check(L.mrx_rim_layer2_f16_cb8_q(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), _lib.ptr(taps_q),
+                                          _lib.ptr(edges), _lib.ptr(xmax), B, H, W, _lib.stream_ptr()), "mrx_rim_layer2_f16_cb8_q")
+    return out, taps_q, edges
+
+
+def rim_final_gather_q(taps_q, edges, b_final, eta):
+    """eta + permute(conv3x3_reppad(h) + b_final) [B,H,W,2] from the row-pre-summed tap planes of rim_layer2_f16_cb8_q (mrx_rim_final_gather_q)."""
+    eta = _lib.f32c(eta)
+    B, H, W, _ = [int(v) for v in eta.shape]
+    if taps_q.numel() < 6 * B * H * W or int(eta.shape[-1]) != 2:
+        raise ValueError("rim_final_gather_q expects taps_q [B,6,H,W] and eta [B,H,W,2]")
+    bf = _lib.f32c(b_final.detach()) if b_final is not None else None
+    eta_out = torch.empty_like(eta)
+    _lib.check(_lib.lib().mrx_rim_final_gather_q(_lib.ptr(taps_q), _lib.ptr(edges), _lib.ptr(bf), _lib.ptr(eta), _lib.ptr(eta_out), B, H, W, _lib.stream_ptr()),
+               "mrx_rim_final_gather_q")
+    return eta_out
 
 
 def rim_layer2_wx_pack(w_conv, w_ih, w_final=None):

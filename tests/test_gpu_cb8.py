@@ -105,17 +105,74 @@ def test_cascade_with_the_tap_gather_folded_into_the_gradient_is_bit_identical(d
     model = CIRIM(dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=1)).eval().to(dev)
     blk = model.cirim[0]
     d = {k: v.to(dev) for k, v in synthetic.make_slice(6, 24, 372, slice_idx=2).items()}
-    assert ops.LLG372_GATHER and ops.LLG372_NO_Y
+    assert ops.LLG372_GATHER and ops.LLG372_NO_Y and ops.RIM_TAPS_Q
     with torch.no_grad():
-        e1, h1 = blk(d["y"], d["y"], d["sensitivity_maps"], d["mask"])
+        eq, hq = blk(d["y"], d["y"], d["sensitivity_maps"], d["mask"])          # default: the gather folded in AND the taps pre-summed along x
         try:
+            ops.RIM_TAPS_Q = False
+            e1, h1 = blk(d["y"], d["y"], d["sensitivity_maps"], d["mask"])      # the gather folded in, eighteen tap planes
             ops.LLG372_GATHER = False
-            e0, h0 = blk(d["y"], d["y"], d["sensitivity_maps"], d["mask"])
+            e0, h0 = blk(d["y"], d["y"], d["sensitivity_maps"], d["mask"])      # separate launches
         finally:
-            ops.LLG372_GATHER = True
-    assert len(e1) == len(e0) == blk.time_steps
+            ops.LLG372_GATHER, ops.RIM_TAPS_Q = True, True
+    assert len(e1) == len(e0) == len(eq) == blk.time_steps
     for a, b in zip(e1 + list(h1), e0 + list(h0)):
         assert a.shape == b.shape and torch.equal(a, b)
+    # the pre-summed form adds the same nine products in another order: round-off of one fp32 sum per estimate, carried through eight time-steps
+    for a, b in zip(eq + list(hq), e0 + list(h0)):
+        assert a.shape == b.shape and float((a.double() - b.double()).norm() / b.double().norm()) <= 2e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 96, 80), (2, 37, 45), (1, 5, 7), (1, 64, 372), (1, 33, 65), (1, 20, 64)], ids=lambda s: "x".join(map(str, s)))
+def test_tap_products_pre_summed_along_x(dev, shape):
+    """mrx_rim_layer2_f16_cb8_q + mrx_rim_final_gather_q against the eighteen-plane route and float64: the state is bit-identical, the estimate differs by the order
+    of nine additions; tile borders (every 32nd column), image borders (replicate padding) and ragged last tiles; at W = 372 the gather inside the gradient launch
+    (mrx_llg372_gather_q) is bit-identical to mrx_rim_final_gather_q."""
+    from mridc_amd import ops
+    B, H, W = shape
+    F = 64
+    g = torch.Generator().manual_seed(H * W + 1)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    w2, wi2, wf, bf = r(F, F, 3, 3) / 24, r(F, F, 1, 1) / 8, r(2, F, 3, 3) / 24, r(2) * 0.1
+    bc, bi, hh = r(F) * 0.1, r(F) * 0.1, r(1, F, 1, 1) * 0.5
+    x, hp, eta = r(B, F, H, W).relu() * 3.0, r(B, F, H, W).relu(), r(B, H, W, 2)
+    xm = x.abs().max().reshape(1).contiguous()
+    gd = Fn.conv2d(Fn.pad(x.double(), (2, 2, 2, 2), mode="replicate"), w2.double(), bc.double(), dilation=2).relu()
+    ref = Fn.relu(Fn.conv2d(gd, wi2.double(), bi.double()) + hh.double() * hp.double())
+    ref_eta = eta.double() + (Fn.conv2d(Fn.pad(ref, (1, 1, 1, 1), mode="replicate"), wf.double()) + bf.double().view(1, 2, 1, 1)).permute(0, 2, 3, 1)
+    pk = ops.rim_layer2_f16_pack(w2, wi2, wf)
+    xc, hc = ops.cb8_from_nchw(x), ops.cb8_from_nchw(hp)
+    d_h, d_t = ops.rim_layer2_f16_cb8(xc, pk, bc, bi, hh, hc, xm, want_taps=True)
+    d_eta = ops.rim_final_gather(d_t, bf, eta)
+    q_h, q_t, q_e = ops.rim_layer2_f16_cb8_q(xc, pk, bc, bi, hh, hc, xm)
+    q_eta = ops.rim_final_gather_q(q_t, q_e, bf, eta)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())  # noqa: E731
+    assert torch.equal(q_h, d_h)
+    assert rel(q_eta, ref_eta) <= 5e-7 and rel(d_eta, ref_eta) <= 5e-7, (rel(q_eta, ref_eta), rel(d_eta, ref_eta))
+    assert float((q_eta - d_eta).abs().max()) <= 4e-6 * float(d_eta.abs().max())
+    # the pre-summed planes are what they claim to be: Q[dy, co](x) = P[dy, 0](x - 1) + P[dy, 1](x) + P[dy, 2](x + 1) inside a tile
+    P = d_t.double().reshape(B, 3, 3, 2, H, W)
+    left, right = torch.roll(P[:, :, 0], 1, -1), torch.roll(P[:, :, 2], -1, -1)
+    left[..., 0], right[..., -1] = P[:, :, 0][..., 0], P[:, :, 2][..., -1]      # replicate padding at the image border
+    cols = torch.arange(W)
+    left[..., (cols % 32 == 0) & (cols > 0)] = 0.0                               # ... and the neighbouring tile's share left to `edges`
+    right[..., (cols % 32 == 31) & (cols < W - 1)] = 0.0
+    want_q = (left + P[:, :, 1] + right).reshape(B, 6, H, W)
+    assert rel(q_t, want_q) <= 2e-7
+
+
+def test_gradient_launch_gather_on_pre_summed_taps_is_bit_identical_to_the_gather_kernel(dev):
+    from mridc_amd import ops, synthetic
+    d = {k: v.to(dev) for k, v in synthetic.make_slice(6, 40, 372, slice_idx=1).items()}
+    B, C, H, W = 1, 6, 40, 372
+    g = torch.Generator().manual_seed(7)
+    tq = torch.randn(B, 6, H, W, generator=g).to(dev)
+    te = torch.randn(int(ops._lib.lib().mrx_rim_taps_q_edge_floats(B, H, W)), generator=g).to(dev)
+    eta, bf = torch.randn(B, H, W, 2, generator=g).to(dev), torch.randn(2, generator=g).to(dev)
+    want = ops.rim_final_gather_q(tq, te, bf, eta)
+    op = ops.llg372_prepare(ops.llg_prepare(d["y"], True, "ortho"), d["sensitivity_maps"], d["mask"], True, "ortho")
+    _, nparts, got = ops.llg372_gather_q(eta, tq, te, bf, op, 1.0, "ortho")
+    assert nparts >= 2 and torch.equal(got, want)
 
 
 @pytest.mark.parametrize("shape", [(1, 96, 80), (2, 37, 45), (1, 5, 7), (1, 64, 372)], ids=lambda s: "x".join(map(str, s)))

@@ -33,10 +33,15 @@ for _ in range(3):
     else:
         part, n = ops.llg372(eta, op, 1.0, "backward", parts=True)
     h1 = ops.rim_layer1_cb8(None, eta, part, n, 1.0, pk1, bc, bi, hh, hpc, xmax)
-    ops.rim_layer2_f16_cb8(h1, pk2h, bc, bi, hh, hpc, xmax, taps=taps, want_taps=True)
-    ops.rim_final_gather(taps, None, eta)
-    if not MASK2D:
-        ops.llg372_gather(eta, taps, None, op, 1.0, "backward")
+    if MASK2D or not ops.RIM_TAPS_Q:
+        ops.rim_layer2_f16_cb8(h1, pk2h, bc, bi, hh, hpc, xmax, taps=taps, want_taps=True)
+        ops.rim_final_gather(taps, None, eta)
+        if not MASK2D:
+            ops.llg372_gather(eta, taps, None, op, 1.0, "backward")
+    else:                                              # the headline's route since lib 260: tap products pre-summed along x (6 planes + tile-edge terms)
+        _, tq, te = ops.rim_layer2_f16_cb8_q(h1, pk2h, bc, bi, hh, hpc, xmax)
+        ops.rim_final_gather_q(tq, te, None, eta)
+        ops.llg372_gather_q(eta, tq, te, None, op, 1.0, "backward")
 torch.cuda.synchronize()
 if MASK2D:
     sys.exit(0)
