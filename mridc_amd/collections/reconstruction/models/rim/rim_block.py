@@ -383,6 +383,7 @@ class RIMBlock(torch.nn.Module):
         fuse_gather = cb8 and defer and op372 is not None and ops.LLG372_NO_Y and ops.LLG372_GATHER
         # ... with the tap products pre-summed along x inside layer 2 (6 planes + tile-edge terms instead of 18 planes: mrx_rim_layer2_f16_cb8_q,
         # mrx_llg372_gather_q, mrx_rim_final_gather_q); the sample's state must fit the kernel's 32-bit byte offsets
+        # (measured on the 2-D-mask route, where the gather stays its own launch: 117.7 vs 117.9 slices/s -- no gain: the pre-summed form only where the gather is folded)
         taps_q = fuse_gather and ops.RIM_TAPS_Q and int(eta.shape[1]) * int(eta.shape[2]) * 256 < 2 ** 31
         # ... and, for general masks at W = 372, in the first of the next step's three gradient passes (mrx_pfa372_expand_t4_gather)
         fuse_gather_t4 = cb8 and defer and op372 is None and t4 and ops.LLG_T4_NO_Y and ops.LLG_T4_GATHER
@@ -425,7 +426,7 @@ class RIMBlock(torch.nn.Module):
                 if taps_q:
                     hx[1], tq, te = ops.rim_layer2_f16_cb8_q(hx[0], self._packed_f16(1, c1, r1, final), c1.conv_layer.bias, r1.ih.bias, r1.hh, hx[1], xmax,
                                                              out=hx[1] if (self.inplace_state and hx[1] is not None) else None)
-                    if step + 1 < self.time_steps:
+                    if fuse_gather and step + 1 < self.time_steps:
                         pending = (tq, te)
                         continue
                     eta = ops.rim_final_gather_q(tq, te, final.conv_layer.bias, eta)

@@ -81,19 +81,25 @@ def test_cascade_on_channel_blocked_states_is_bit_identical(dev, mask_kind):
         gen = torch.Generator().manual_seed(7)
         mask = (torch.rand(1, 1, 40, 372, 1, generator=gen) < 0.3).to(dev)
     y = d["y"] * mask
+    from mridc_amd import ops
     with torch.no_grad():
-        e1, h1 = blk(y, y, d["sensitivity_maps"], mask)
-        e1b, h1b = blk(y, y, d["sensitivity_maps"], mask, hx=h1)
+        eq, hq = blk(y, y, d["sensitivity_maps"], mask)             # default: channel-blocked states AND the tap products pre-summed along x (ops.RIM_TAPS_Q)
         try:
+            ops.RIM_TAPS_Q = False                                  # eighteen tap planes: the arithmetic of the NCHW route, addition by addition
+            e1, h1 = blk(y, y, d["sensitivity_maps"], mask)
+            e1b, h1b = blk(y, y, d["sensitivity_maps"], mask, hx=h1)
             blk.cb8_states = False
             e0, h0 = blk(y, y, d["sensitivity_maps"], mask)
             e0b, h0b = blk(y, y, d["sensitivity_maps"], mask, hx=h0)
         finally:
+            ops.RIM_TAPS_Q = True
             del blk.cb8_states
         _, none = blk(y, y, d["sensitivity_maps"], mask, _want_hx=False)
     assert none is None
     for a, b in zip(e1 + e1b + list(h1) + list(h1b), e0 + e0b + list(h0) + list(h0b)):
         assert a.shape == b.shape and torch.equal(a, b)
+    for a, b in zip(eq + list(hq), e0 + list(h0)):                  # the pre-summed form: the order of nine additions per estimate
+        assert a.shape == b.shape and float((a.double() - b.double()).norm() / b.double().norm()) <= 2e-6
 
 
 def test_cascade_with_the_tap_gather_folded_into_the_gradient_is_bit_identical(dev):

@@ -606,8 +606,9 @@ def test_general_mask_gradient_with_the_tap_gather_folded_in(dev):
     blk = model.cirim[0].to(dev)
     yd, S, m = (d["kspace"] * m2d).to(dev), d["sensitivity_maps"].to(dev), m2d.to(dev)
     outs = {}
-    keep = ops.LLG_T4_GATHER
+    keep, keep_q = ops.LLG_T4_GATHER, ops.RIM_TAPS_Q
     try:
+        ops.RIM_TAPS_Q = False                 # (the fold reads the eighteen tap planes; the unfolded default route pre-sums them: another order of additions)
         for fold in (True, False):
             ops.LLG_T4_GATHER = fold
             calls = []
@@ -621,7 +622,7 @@ def test_general_mask_gradient_with_the_tap_gather_folded_in(dev):
             assert len(calls) == (1 if fold else blk.time_steps)            # folded: only the last step's gather is its own launch
             outs[fold] = torch.stack(etas)
     finally:
-        ops.LLG_T4_GATHER = keep
+        ops.LLG_T4_GATHER, ops.RIM_TAPS_Q = keep, keep_q
     assert torch.equal(outs[True], outs[False])
 
 

@@ -93,21 +93,25 @@ def test_rim_block_zeroes_the_bound_every_cascade(dev):
     d = {k: v.to(dev) for k, v in synthetic.make_slice(4, 32, 64, slice_idx=2).items()}
     seen = []
     import mridc_amd.ops as ops_mod
-    name = "rim_layer2_f16_cb8" if blk.cb8_states else "rim_layer2_f16"
-    orig = getattr(ops_mod, name)
+    names = ["rim_layer2_f16_cb8", "rim_layer2_f16_cb8_q"] if blk.cb8_states else ["rim_layer2_f16"]     # (whichever form of the layer the route takes)
+    origs = {n: getattr(ops_mod, n) for n in names}
 
-    def spy(x, packed, b_conv, b_ih, hh, h_prev, xmax, **kw):
-        seen.append(xmax)
-        return orig(x, packed, b_conv, b_ih, hh, h_prev, xmax, **kw)
+    def make_spy(orig):
+        def spy(x, packed, b_conv, b_ih, hh, h_prev, xmax, **kw):
+            seen.append(xmax)
+            return orig(x, packed, b_conv, b_ih, hh, h_prev, xmax, **kw)
+        return spy
 
-    setattr(ops_mod, name, spy)
+    for n in names:
+        setattr(ops_mod, n, make_spy(origs[n]))
     try:
         with torch.no_grad():
             blk(d["y"], d["y"], d["sensitivity_maps"], d["mask"])
             n1 = len(seen)
             blk(d["y"] * 1e-4, d["y"] * 1e-4, d["sensitivity_maps"], d["mask"])
     finally:
-        setattr(ops_mod, name, orig)
+        for n in names:
+            setattr(ops_mod, n, origs[n])
     assert n1 == blk.time_steps and len(seen) == 2 * n1
     assert all(t is seen[0] for t in seen[:n1]) and all(t is seen[n1] for t in seen[n1:]) and seen[n1] is not seen[0]   # one scalar per call
     first, second = float(seen[0]), float(seen[n1])                    # (read after both calls: the final bound of each)
