@@ -180,7 +180,7 @@ int mrx_llg372_prepare(const float* yt, const float* S, const void* mask, int ma
  *                       is written, bit-identical to mrx_rim_final_gather's */
 int mrx_llg372_gather(const float* eta, const float* taps, const float* b_final, float* eta_out, const float* Sp, const float* maskp, int mask_batched,
                       float* out4, float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream);
-/* mrx_llg372_gather on the row-pre-summed tap planes of mrx_rim_layer2_f16_cb8_q (taps_q [B][6][H][372], edges: mrx_rim_taps_q_edge_floats(B, H, 372) floats);
+/* mrx_llg372_gather on the row-pre-summed tap planes of mrx_rim_layer2_f16_cb8_q (taps_q [B][3][H][372][2], edges: mrx_rim_taps_q_edge_floats(B, H, 372) floats);
  * eta_out is bit-identical to mrx_rim_final_gather_q's. */
 int mrx_llg372_gather_q(const float* eta, const float* taps_q, const float* edges, const float* b_final, float* eta_out, const float* Sp, const float* maskp,
                         int mask_batched, float* out4, float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm, int centered, void* stream);
@@ -377,7 +377,7 @@ int mrx_rim_layer1_cb8(const float* x, int Cin, const float* eta, const float* p
                        void* stream);
 int mrx_rim_layer2_f16_cb8(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
                            float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream);
-/* The tap products of the final convolution pre-summed along x inside the kernel (round 5): mrx_rim_layer2_f16_cb8_q leaves taps_q [B][6][H][W] (plane dy * 2 + co:
+/* The tap products of the final convolution pre-summed along x inside the kernel (round 5): mrx_rim_layer2_f16_cb8_q leaves taps_q [B][3][H][W][2] (kernel row dy, pair (co 0, co 1):
  * P[dy,0](x - 1) + P[dy,1](x) + P[dy,2](x + 1) with replicate borders) and, for the two columns of every 32-pixel tile whose neighbour lives in another tile, the missing
  * products in `edges` (mrx_rim_taps_q_edge_floats(B, H, W) floats).  mrx_rim_final_gather_q (and mrx_llg372_gather_q, below) finish the 3x3: same result as the
  * 18-plane route up to the order of nine additions.  6 + 2 instead of 18 + 2 values per pixel in the gather, 3 instead of 10 stores per lane in the layer. */

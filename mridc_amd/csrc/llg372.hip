@@ -119,7 +119,7 @@ __global__ void k_llg372_prep_mask(MrxMask mask, float* __restrict__ maskp, int 
 // GAT: eta is not read but MADE here -- the previous step's eta plus the nine-tap gather of the final convolution's tap products (the whole of
 // k_l2sb_gather, same order of additions: bit-identical) -- and written out by the row's first task; one launch per step less in the RIM loop.
 struct L372Gather {
-    const float* taps;      // [B][18][H][372]: taps[b][tap * 2 + co] (rim_layer2_sb.hip) -- or, with `edges`, the row-pre-summed planes [B][6][H][372] (plane dy * 2 + co)
+    const float* taps;      // [B][18][H][372]: taps[b][tap * 2 + co] (rim_layer2_sb.hip) -- or, with `edges`, the row-pre-summed planes [B][3][H][372][2] (kernel row dy, pair (co 0, co 1))
     const float* bias;      // [2] or null
     float2* eta_out;        // [B][H][372]
     const float* edges = nullptr;   // not null: taps are mrx_rim_layer2_f16_cb8_q's; edges [B][H][12][16] what the neighbouring 32-pixel tiles owe columns 0 / 31
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
                 edge[i] = fromR || fromL;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    q[i][dy][0] = qb[(long long)(dy * 2) * plane + (long long)yy[dy] * PFA_N + w];
-                    q[i][dy][1] = qb[(long long)(dy * 2 + 1) * plane + (long long)yy[dy] * PFA_N + w];
+                    const float2 qq = *reinterpret_cast<const float2*>(qb + ((long long)dy * plane + (long long)yy[dy] * PFA_N + w) * 2);
+                    q[i][dy][0] = qq.x, q[i][dy][1] = qq.y;
                     ee[i][dy] = *reinterpret_cast<const float2*>(eb + ((long long)yy[dy] * TX + et) * 16 + oo[dy]);
                 }
                 e[i] = eta_[(long long)row * PFA_N + w];
@@ -860,7 +860,7 @@ extern "C" int mrx_llg372_gather(const float* eta, const float* taps, const floa
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
-// mrx_llg372_gather on the row-pre-summed tap planes of mrx_rim_layer2_f16_cb8_q (taps_q [B][6][H][372], edges: mrx_rim_taps_q_edge_floats): eta_out is bit-identical to
+// mrx_llg372_gather on the row-pre-summed tap planes of mrx_rim_layer2_f16_cb8_q (taps_q [B][3][H][372][2], edges: mrx_rim_taps_q_edge_floats): eta_out is bit-identical to
 // mrx_rim_final_gather_q's result.
 extern "C" int mrx_llg372_gather_q(const float* eta, const float* taps_q, const float* edges, const float* b_final, float* eta_out, const float* Sp,
                                    const float* maskp, int mask_batched, float* out4, float* work, int* nparts, int B, int C, int H, float inv_sigma2, int norm,

@@ -54,7 +54,7 @@ struct L2sbArgs {
     const float* hprev;    // [B,64,H,W] or null
     float* hnew;           // [B,64,H,W]
     float* P;              // not null: also P[b][tap * 2 + co][y][x] = sum_c w_final[co][c][tap] * h_new[c][y][x]  (mrx_rim_final_gather adds the taps up)
-    float* Q = nullptr;    // FAST form, with E: the tap products pre-summed along x inside the tile -- Q[b][dy * 2 + co][y][x] = P[dy,0](x - 1) + P[dy,1](x) + P[dy,2](x + 1)
+    float* Q = nullptr;    // FAST form, with E: the tap products pre-summed along x inside the tile -- Q[b][dy][y][x][co] = P[dy,0](x - 1) + P[dy,1](x) + P[dy,2](x + 1)
     float* E = nullptr;    // with the terms a NEIGHBOURING 32-pixel tile owes left out, which that tile leaves here: E[b][y][tile column][16]
                            // (its first column's dx = 2 products, for the pixel to its left; its last column's dx = 0 products, for the pixel to its right)
     int B, H, W, tiles_x, ntiles;
@@ -902,9 +902,13 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
                     q[0] = lhi ? fromL(v[3]) + sw0 : (fromL(v[0]) + v[2]) + sw0;                       // plane 3 | plane 0
                     q[1] = lhi ? (fromL(v[4]) + v[6]) + sw1 : (fromL(v[1]) + v[3]) + sw1;              // plane 4 | plane 1
                     q[2] = lhi ? (fromL(v[5]) + v[7]) + sw2 : sw2 + (v[4] + fromR(v[6]));              // plane 5 | plane 2
-                    const unsigned offq = inside ? (unsigned)(((long long)oy * a.W + ox + 3ll * lhi * plane) * 4) : 0x80000000u;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(q[i]), rq, offq + (unsigned)i * (unsigned)(plane * 4), 0, 0);
+                    // Q[b][dy][y][x][co]: the lower half-wave stores the pair of dy 0 and the first half of dy 1's, the upper the second half of dy 1's and the pair
+                    // of dy 2 -- one 8-byte and one 4-byte store per lane (the gathers read one float2 per kernel row)
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const unsigned offq = inside ? (unsigned)(((long long)oy * a.W + ox) * 8) : 0x80000000u;
+                    const u32x2 pair = lhi ? u32x2{__float_as_uint(q[1]), __float_as_uint(q[2])} : u32x2{__float_as_uint(q[0]), __float_as_uint(q[1])};
+                    __builtin_amdgcn_raw_buffer_store_b64(pair, rq, offq + (lhi ? 2u : 0u) * (unsigned)(plane * 8), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lhi ? q[0] : q[2]), rq, offq + (unsigned)(plane * 8) + (lhi ? 4u : 0u), 0, 0);
                     // what the neighbouring tiles miss, ONE 16-byte store per row by the four lanes that hold it -- E[b][y][tile column][16]:
                     //   [0..3]  column 0, lower lane: dx = 2 products of dy 1, 2 (registers 6, 7, 8, 9)      [4..5]   column 0, upper lane: dx = 2 products of dy 0 (registers 0, 1)
                     //   [8..9]  column 31, lower lane: dx = 0 products of dy 0 (registers 0, 1)              [12..15] column 31, upper lane: dx = 0 products of dy 1, 2 (registers 2..5)
@@ -1433,8 +1437,8 @@ __device__ __forceinline__ void l2sb_gather_q_px(const float* __restrict__ qb, c
     for (int dy = 0; dy < 3; ++dy) {
         int yy = y + dy - 1;
         yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
-        q[dy][0] = qb[(long long)(dy * 2) * plane + (long long)yy * W + x];
-        q[dy][1] = qb[(long long)(dy * 2 + 1) * plane + (long long)yy * W + x];
+        const float2 qq = *reinterpret_cast<const float2*>(qb + ((long long)dy * plane + (long long)yy * W + x) * 2);
+        q[dy][0] = qq.x, q[dy][1] = qq.y;
         const float2 ee = *reinterpret_cast<const float2*>(ebp + ((long long)yy * tiles_x + et) * 16 + (dy == 0 ? o0 : (dy == 1 ? o1 : o2)));
         e[dy][0] = (fromR || fromL) ? ee.x : 0.f, e[dy][1] = (fromR || fromL) ? ee.y : 0.f;
     }
@@ -1457,7 +1461,7 @@ __global__ __launch_bounds__(256) void k_l2sb_gather_q(const float* __restrict__
     *reinterpret_cast<float2*>(out + e) = v;
 }
 extern "C" int64_t mrx_rim_taps_q_edge_floats(int B, int H, int W) { return B < 0 || H < 1 || W < 1 ? -1 : (int64_t)B * 16 * H * mrx_cdiv(W, S2_TW); }
-// mrx_rim_layer2_f16_cb8 whose tap products leave pre-summed along x: taps_q [B][6][H][W] (plane dy * 2 + co) and edges [mrx_rim_taps_q_edge_floats] -- consumed by
+// mrx_rim_layer2_f16_cb8 whose tap products leave pre-summed along x: taps_q [B][3][H][W][2] (kernel row dy, pair (co 0, co 1)) and edges [mrx_rim_taps_q_edge_floats] -- consumed by
 // mrx_rim_final_gather_q and mrx_llg372_gather_q.  A sample's state must fit 32-bit byte offsets (MRX_EUNSUP otherwise: use the 18-plane form).
 extern "C" int mrx_rim_layer2_f16_cb8_q(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
                                         float* h_new, float* taps_q, float* edges, const float* xmax, int B, int H, int W, void* stream) {

@@ -1549,7 +1549,7 @@ RIM_TAPS_Q = os.environ.get("MRIDC_AMD_RIM_TAPS_Q", "1") != "0"
 
 
 def rim_layer2_f16_cb8_q(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps_q=None, edges=None, out=None):
-    """rim_layer2_f16_cb8 with the final convolution's tap products pre-summed along x (mrx_rim_layer2_f16_cb8_q): returns (h_new [B,8,H,W,8], taps_q [B,6,H,W],
+    """rim_layer2_f16_cb8 with the final convolution's tap products pre-summed along x (mrx_rim_layer2_f16_cb8_q): returns (h_new [B,8,H,W,8], taps_q [B,3,H,W,2],
     edges [mrx_rim_taps_q_edge_floats]) -- for rim_final_gather_q / llg372_gather_q."""
     x = _lib.f32c(x)
     B, Q, H, W, E = [int(v) for v in x.shape]
@@ -1561,7 +1561,7 @@ def rim_layer2_f16_cb8_q(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps_q=None,
     hp = _lib.f32c(h_prev) if h_prev is not None else None
     L = _lib.lib()
     if taps_q is None or taps_q.numel() < 6 * B * H * W:
-        taps_q = torch.empty(B, 6, H, W, dtype=torch.float32, device=x.device)
+        taps_q = torch.empty(B, 3, H, W, 2, dtype=torch.float32, device=x.device)
     ne = int(L.mrx_rim_taps_q_edge_floats(B, H, W))
     if edges is None or edges.numel() < ne:
         edges = torch.empty(ne, dtype=torch.float32, device=x.device)
@@ -1577,7 +1577,7 @@ def rim_final_gather_q(taps_q, edges, b_final, eta):
     eta = _lib.f32c(eta)
     B, H, W, _ = [int(v) for v in eta.shape]
     if taps_q.numel() < 6 * B * H * W or int(eta.shape[-1]) != 2:
-        raise ValueError("rim_final_gather_q expects taps_q [B,6,H,W] and eta [B,H,W,2]")
+        raise ValueError("rim_final_gather_q expects taps_q [B,3,H,W,2] and eta [B,H,W,2]")
     bf = _lib.f32c(b_final.detach()) if b_final is not None else None
     eta_out = torch.empty_like(eta)
     _lib.check(_lib.lib().mrx_rim_final_gather_q(_lib.ptr(taps_q), _lib.ptr(edges), _lib.ptr(bf), _lib.ptr(eta), _lib.ptr(eta_out), B, H, W, _lib.stream_ptr()),

@@ -164,7 +164,7 @@ def test_tap_products_pre_summed_along_x(dev, shape):
     left[..., (cols % 32 == 0) & (cols > 0)] = 0.0                               # ... and the neighbouring tile's share left to `edges`
     right[..., (cols % 32 == 31) & (cols < W - 1)] = 0.0
     want_q = (left + P[:, :, 1] + right).reshape(B, 6, H, W)
-    assert rel(q_t, want_q) <= 2e-7
+    assert rel(q_t.reshape(B, 3, H, W, 2).permute(0, 1, 4, 2, 3).reshape(B, 6, H, W), want_q) <= 2e-7       # taps_q is [B,3,H,W,2]: a pair per kernel row
 
 
 def test_gradient_launch_gather_on_pre_summed_taps_is_bit_identical_to_the_gather_kernel(dev):
@@ -172,7 +172,7 @@ def test_gradient_launch_gather_on_pre_summed_taps_is_bit_identical_to_the_gathe
     d = {k: v.to(dev) for k, v in synthetic.make_slice(6, 40, 372, slice_idx=1).items()}
     B, C, H, W = 1, 6, 40, 372
     g = torch.Generator().manual_seed(7)
-    tq = torch.randn(B, 6, H, W, generator=g).to(dev)
+    tq = torch.randn(B, 3, H, W, 2, generator=g).to(dev)
     te = torch.randn(int(ops._lib.lib().mrx_rim_taps_q_edge_floats(B, H, W)), generator=g).to(dev)
     eta, bf = torch.randn(B, H, W, 2, generator=g).to(dev), torch.randn(2, generator=g).to(dev)
     want = ops.rim_final_gather_q(tq, te, bf, eta)
