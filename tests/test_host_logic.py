@@ -381,8 +381,54 @@ def test_bench_summary_is_the_last_key_and_fits_a_kilobyte():
     assert s["headline"]["v"] == 148.3 and s["headline"]["traf"] == 1.061 and s["headline"]["mfma_busy_reg"] == 0.499
     assert set(s) == {"headline", "bf16x3", "streamed", "e2evn", "qcirim", "train_bf16", "train_e2evn", "mask2d", "rim5"}
     assert s["e2evn"] == dict(v=1188.0, ms=13.47, frac=0.3032, bound="hbm", traf=2.179, rel=8.365e-06, cpu=3.033)
+    res["cpu_baseline"]["sec_per_slice_min"] = 3.2                                         # the fastest CPU slice beside the mean
+    assert bench.summary_of(res)["headline"]["cpu_max"] == 0.3125
     src = open(os.path.join(root, "bench.py")).read()
     assert 'res["summary"] = summary_of(res)' in src and src.index('res["summary"] = summary_of(res)') > src.index('res["other_configs"] = others')
+
+
+def test_bench_line_is_short():
+    """Round 5's driver record could not parse a 24.9 KB line (19.8 KB had parsed): what bench.py prints is bench.compact_line(res) -- the contract's
+    keys, trimmed `roofline` / `cpu_baseline`, one short record per other configuration, `summary` last -- within bench.LINE_LIMIT characters however
+    much the full record (written to bench.DETAIL_FILE) grows."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.LINE_LIMIT <= 8000
+    full = json.load(open(os.path.join(root, "profiles", "r05_v9_bench.json")))            # the 24.9 KB record the driver failed on
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) <= bench.LINE_LIMIT, len(text)
+    back = json.loads(text)
+    assert back == line and list(back)[-1] == "summary"
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in back, k
+    assert back["value"] == pytest.approx(full["value"], rel=1e-5) and back["config"]["workload"].startswith("CIRIM 8 cascades")
+    rf, cb = back["roofline"], back["cpu_baseline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-4)
+    assert rf["traffic"] > 0 and len(rf["kernel"]) <= 200
+    assert cb["kind"] == "port" and cb["cores"] == 16 and cb["value"] > 0 and cb["unit"] == "slices/s" and len(cb["sample"]) <= 220
+    assert not any(isinstance(v, (list, dict)) for v in cb.values())
+    assert set(back["other_configs"]) == set(full["other_configs"])
+    for r in back["other_configs"].values():
+        assert r["value"] > 0
+    # a record that grows without bound still gives a short line, and the summary survives
+    fat = json.loads(json.dumps(full))
+    fat["roofline"]["note"] = "x" * 50000
+    for r in fat["other_configs"].values():
+        r["per_tensor"] = {f"cirim.{i}.layers.0.convs.conv_layer.weight": 0.1 * i for i in range(400)}
+        r["config"] = dict(workload="w" * 5000)
+    fat["other_configs"].update({f"extra_{i}": dict(fat["other_configs"]["e2evn_6cascade_15coil_640x372"]) for i in range(40)})
+    fat["summary"] = bench.summary_of(fat)
+    text = json.dumps(bench.compact_line(fat))
+    assert len(text) <= bench.LINE_LIMIT or "other_configs" not in json.loads(text)
+    assert json.loads(text)["summary"]["headline"]["v"] == pytest.approx(full["value"], rel=1e-3)
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "print(json.dumps(compact_line(res)), flush=True)" in src and src.count("print(json.dumps(res)") == 0
 
 
 def _fake_kfd(tmp_path, readable_gpus):
