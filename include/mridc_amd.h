@@ -386,14 +386,27 @@ int mrx_rim_layer2_f16_cb8_q(const float* x, const float* packed, const float* b
                              float* h_new, float* taps_q, float* edges, const float* xmax, int B, int H, int W, void* stream);
 int mrx_rim_final_gather_q(const float* taps_q, const float* edges, const float* b_final, const float* eta, float* eta_out, int B, int H, int W,
                            void* stream);
-/* mrx_rim_layer2_f16_cb8 with the dilated 3x3 in a Winograd F(2, 3) form ALONG X on the same two-term fp16 operands (csrc/rim_layer2_wx.hip: 288 instead of
- * 432 convolution MFMAs per 512 pixels -- the headline loop runs at the chip's power limit, so matrix FLOPs are what it pays for).  Same arguments and results
- * up to round-off: 2.3e-7 against float64 where the direct form has 1.3e-7 and fp32 1.2e-7 (numpy emulation, tools/probe/wino_f16x2_error.py).  Its own operand
- * pack (transformed weights); a sample's state must fit 32-bit byte offsets (MRX_EUNSUP otherwise: use mrx_rim_layer2_f16_cb8). */
-int64_t mrx_rim_layer2_wx_pack_floats(void);
-int mrx_rim_layer2_wx_pack(const float* w_conv, const float* w_ih, const float* w_final /* [2,64,3,3] or NULL */, float* packed, void* stream);
-int mrx_rim_layer2_wx_cb8(const float* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const float* h_prev,
-                          float* h_new, float* taps, const float* xmax, int B, int H, int W, void* stream);
+/* The reduced-precision INFERENCE route (csrc/rim_amp16.hip; round 6): the two RIM layers of a time-step in the arithmetic the reference's own inference
+ * configuration runs -- `precision: 16` (projects/reconstruction/model_zoo/conf/base_cirim_run.yaml:132) = torch.autocast: every convolution multiplies fp16
+ * operands (ONE term; fp32 accumulation on v_mfma_f32_32x32x16_f16) and returns fp16, while the FFT, the complex products of log_likelihood_gradient and eta stay
+ * fp32 (rim_utils.py:11-67, rim_block.py:217-249).  Hidden states are fp16, channel-blocked h[b][c / 8][y][x][c % 8] (16 bytes per pixel and channel block).
+ * Never the default: selected per model (RIMBlock.precision / MRIDC_AMD_PRECISION=16), checked against the autocast oracle (oracle/amp.py) at a stated tolerance.
+ *   mrx_amp16_pack_floats(layer)  : size of the operand pack of layer 1 / 2 in floats;
+ *   mrx_amp16_layer1_pack         : w_conv [64,Cin<=4,5,5], w_ih [64,64,1,1] -> packed;
+ *   mrx_amp16_layer2_pack         : w_conv [64,64,3,3], w_ih [64,64,1,1], w_final [2,64,3,3] (or NULL) -> packed;
+ *   mrx_amp16_layer1              : h_new = ReLU(W_ih ReLU(conv5x5_reppad(in) + b_conv) + b_ih + hh * h_prev); in = x [B,Cin,H,W] (eta NULL) or
+ *                                   (eta [B,H,W,2], inv_sigma2 * sum of nparts <= 4 partial planes part [nparts][B][H][W][2]) as mrx_rim_layer1_cb8;
+ *                                   h_prev (NULL = the zero state) / h_new: fp16 [B][8][H][W][8];
+ *   mrx_amp16_layer2              : the dilation-2 3x3 layer + IndRNN cell on fp16 x / h_prev / h_new [B][8][H][W][8]; with taps_q / edges (both or neither) also
+ *                                   the final convolution's tap products in the layout of mrx_rim_layer2_f16_cb8_q (fp32; finished by mrx_rim_final_gather_q /
+ *                                   mrx_llg372_gather_q). */
+int64_t mrx_amp16_pack_floats(int layer);
+int mrx_amp16_layer1_pack(const float* w_conv, const float* w_ih, float* packed, int Cin, void* stream);
+int mrx_amp16_layer2_pack(const float* w_conv, const float* w_ih, const float* w_final /* or NULL */, float* packed, void* stream);
+int mrx_amp16_layer1(const float* x, int Cin, const float* eta, const float* part, int nparts, float inv_sigma2, const float* packed, const float* b_conv,
+                     const float* b_ih, const float* hh, const void* h_prev, void* h_new, int B, int H, int W, void* stream);
+int mrx_amp16_layer2(const void* x, const float* packed, const float* b_conv, const float* b_ih, const float* hh, const void* h_prev, void* h_new,
+                     float* taps_q, float* edges, int B, int H, int W, void* stream);
 /* Complex instance normalisation around a regulariser (models/sigmanet/sensitivity_net.py:16-139): m = mean of every real and imaginary entry,
  * C = 2x2 covariance of (re - m, im - m) per batch element (sums over per_b complex values, divided by `divisor` -- the reference's
  * shape[2] * shape[3] - 1); coef[b] = {m, C^(1/2) row-major, C^(-1/2) row-major} (9 floats).  center = 0 takes the data as mean-free.

@@ -32,7 +32,7 @@ SOURCES = [
     ("rim_layer_wino.hip", []),
     ("rim_layer1_sb.hip", []),
     ("rim_layer2_sb.hip", []),
-    ("rim_layer2_wx.hip", []),
+    ("rim_amp16.hip", []),
     ("gated_cell.hip", []),
     ("gated_cell_sb.hip", []),
     ("conv_bwd.hip", []),

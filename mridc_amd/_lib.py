@@ -206,10 +206,12 @@ _SIGNATURES = {
     "mrx_rim_layer2_f16_cb8": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_taps_q_edge_floats": ([_i, _i, _i], _i64),
     "mrx_rim_layer2_f16_cb8_q": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_amp16_pack_floats": ([_i], _i64),
+    "mrx_amp16_layer1_pack": ([_p, _p, _p, _i, _p], _i),
+    "mrx_amp16_layer2_pack": ([_p, _p, _p, _p, _p], _i),
+    "mrx_amp16_layer1": ([_p, _i, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "mrx_amp16_layer2": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_rim_final_gather_q": ([_p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
-    "mrx_rim_layer2_wx_pack_floats": ([], _i64),
-    "mrx_rim_layer2_wx_pack": ([_p, _p, _p, _p, _p], _i),
-    "mrx_rim_layer2_wx_cb8": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "mrx_cnorm_work_doubles": ([_i], _i64),
     "mrx_cnorm_stats": ([_p, _i, _i64, ctypes.c_double, _i, _p, _p, _p], _i),
     "mrx_cnorm_apply": ([_p, _p, _p, _i, _i, _i64, _p], _i),
@@ -266,6 +268,13 @@ def arith():
     Python side exactly as libmridc_amd's mrx_arith reads it."""
     v = os.environ.get("MRIDC_AMD_ARITH", "f16x2")
     return v if v in ARITH_NAMES else "f16x2"
+
+
+def precision():
+    """The inference precision of the RIM regulariser (environment MRIDC_AMD_PRECISION): 32 (default: fp32-class results on every route of `arith()`) or
+    16 -- the reference's `trainer.precision: 16` (base_cirim_run.yaml:132): fp16 operands and hidden states in the two RIM layers (csrc/rim_amp16.hip),
+    FFT / data consistency / eta in fp32.  A model attribute (RIMBlock.precision, set by CIRIM from its trainer / cfg) overrides it."""
+    return 16 if os.environ.get("MRIDC_AMD_PRECISION", "32").strip().lower() in ("16", "fp16", "16-mixed", "amp16") else 32
 
 
 def declared_symbols():
@@ -368,6 +377,12 @@ def lib():
                 "mridc_amd has no CPU or PyTorch fallback path.")
         L = ctypes.CDLL(LIB_PATH)
         writes = written_pointer_args()
+        # a declaration the header parser does not match would leave its entry point silently UNTRACKED (a stale operand bound could then be
+        # used): every bound entry point must be found in the header, with as many parameters as its ctypes signature
+        missing = [n for n, (args, _) in _SIGNATURES.items() if n not in writes or max(writes[n], default=-1) >= len(args)]
+        if missing:
+            raise RuntimeError(f"{HEADER_PATH}: no parsable declaration for {missing[:5]} (of {len(missing)}): the write-tracking table of "
+                               "mridc_amd._lib would be incomplete")
         for name, (args, res) in _SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
             fn.argtypes = args

@@ -47,6 +47,13 @@ class CIRIM(torch.nn.Module):
                 fft_normalization=self.fft_normalization, spatial_dims=self.spatial_dims, coil_dim=self.coil_dim,
                 dimensionality=cfg_dict.get("dimensionality"))
             for _ in range(self.num_cascades)])                      # cirim.py:60-84
+        # the reference hands `trainer.precision` to pytorch-lightning (base_cirim_run.yaml:132: 16 = native AMP around forward); here the trainer
+        # (or a plain `precision` key of cfg) selects the precision-16 kernels of the RIM blocks.  None: the process default (MRIDC_AMD_PRECISION).
+        prec = getattr(trainer, "precision", None) if trainer is not None else None
+        prec = cfg_dict.get("precision", None) if prec is None else prec
+        if prec is not None:
+            for blk in self.cirim:
+                blk.precision = prec
         self.keep_eta = cfg_dict.get("keep_eta")
         self.coil_combination_method = cfg_dict.get("coil_combination_method")
         # cirim.py:91-93 applies rnn_weights_init, a no-op for conv layers (common/parts/rnn_utils.py:21-32)

@@ -40,6 +40,10 @@ class RIMBlock(torch.nn.Module):
     # hidden states kept channel-blocked [B,8,H,W,8] between the two layer kernels of the _f16_route (mrx_rim_layer1_cb8, mrx_rim_layer2_f16_cb8:
     # 16-byte state accesses, bit-identical results); states handed in / out are converted (mrx_cb8_convert)
     cb8_states = True
+    # inference precision of the regulariser: None = the process default (_lib.precision(): MRIDC_AMD_PRECISION, 32 unless set); 16 = the reference's
+    # `trainer.precision: 16` (base_cirim_run.yaml:132) -- fp16 operands and fp16 hidden states in the two layer kernels (mrx_amp16_layer1 / _layer2),
+    # FFT, data consistency and eta in fp32 (what torch.autocast keeps in fp32).  CIRIM sets it from its trainer / cfg.
+    precision = None
 
     def __init__(self, recurrent_layer=None, conv_filters=None, conv_kernels=None, conv_dilations=None, conv_bias=None,
                  recurrent_filters=None, recurrent_kernels=None, recurrent_dilations=None, recurrent_bias=None,
@@ -162,6 +166,32 @@ class RIMBlock(torch.nn.Module):
             hit = (key, ops.rim_layer2_f16_pack(w, wi, wf))
             self._pack_cache[("f16", idx)] = hit
         return hit[1]
+
+    def _packed_amp16(self, idx, c, r, final=None):
+        """fp16 operand pack of layer `idx` for the precision-16 route (mrx_amp16_layer{1,2}_pack), re-packed only when the parameters change."""
+        w, wi = c.conv_layer.weight, r.ih.weight
+        wf = final.conv_layer.weight if final is not None else None
+        key = (w.data_ptr(), w._version, wi.data_ptr(), wi._version, str(w.device), None if wf is None else (wf.data_ptr(), wf._version))
+        hit = self._pack_cache.get(("amp16", idx))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.amp16_layer1_pack(w, wi) if idx == 0 else ops.amp16_layer2_pack(w, wi, wf))
+            self._pack_cache[("amp16", idx)] = hit
+        return hit[1]
+
+    def _amp16_route(self):
+        """precision 16 asked for, and the block is the one the fp16 kernels cover: two IndRNN stacks (5x5 <= 4 -> 64, then 3x3 dilation 2 64 -> 64, 1x1 cells),
+        final 3x3 64 -> 2 -- the model-zoo CIRIM block.  Any other block stays on the fp32-class route (as autocast leaves an op it does not list)."""
+        prec = self.precision if self.precision is not None else _lib.precision()
+        if str(prec).lower() not in ("16", "fp16", "16-mixed") or len(self.layers) != 2 or len(self.final_layer) != 1:
+            return False
+        l0, l1, f = self.layers[0], self.layers[1], self.final_layer[0]
+        if not (self._fusable(l0) and self._fusable(l1)):
+            return False
+        c0, r0, c1, r1 = l0.convs, l0.rnn, l1.convs, l1.rnn
+        return (c0.input_size <= 4 and c0.kernel_size == 5 and c0.dilation == 1 and r0.hidden_size == 64 and r0.kernel_size == 1
+                and c1.input_size == 64 and r1.hidden_size == 64 and c1.kernel_size == 3 and c1.dilation == 2 and r1.kernel_size == 1
+                and f is not None and f.act == ops.ACT_NONE and f.kernel_size == 3 and f.dilation == 1
+                and tuple(f.conv_layer.weight.shape) == (2, 64, 3, 3))
 
     def _f16_route(self):
         """Two stacks, the second one the split-operand layer, the first one the tuned kernel that can keep the bound of its outputs."""
@@ -375,6 +405,40 @@ class RIMBlock(torch.nn.Module):
         xmax = torch.zeros(1, dtype=torch.float32, device=masked_kspace.device) if (masked_kspace.is_cuda and self._f16_route()) else None
         cb8 = (xmax is not None and self.cb8_states and self._tail_fused() and l0.convs.input_size == 4
                and all(h is None or h.shape[0] == eta.shape[0] for h in hx))
+        amp16 = (masked_kspace.is_cuda and self._amp16_route() and l0.convs.input_size == 4
+                 and all(h is None or h.shape[0] == eta.shape[0] for h in hx))
+        if amp16:
+            cb8, xmax = False, None
+            hx = [None if h is None else ops.amp16_from_nchw(h) for h in hx]
+            c0, r0, c1, r1 = l0.convs, l0.rnn, self.layers[1].convs, self.layers[1].rnn
+            gather372 = op372 is not None and ops.LLG372_NO_Y and ops.LLG372_GATHER
+            pending = None
+            for step in range(self.time_steps):                      # rim_block.py:217-249 in the precision-16 arithmetic
+                part, nparts, grad_eta = None, 0, None
+                if pending is not None:                              # eta of the previous step formed inside this step's gradient launch
+                    part, nparts, eta = ops.llg372_gather_q(eta, pending[0], pending[1], final.conv_layer.bias, op372, sigma, self.fft_normalization)
+                    etas.append(eta)
+                    pending = None
+                elif op372 is not None and ops.LLG372_NO_Y:
+                    part, nparts = ops.llg372(eta, op372, sigma, self.fft_normalization, parts=True)
+                if not 1 <= nparts <= 4:                              # any other mask / coil count: the gradient as its own [B,4,H,W] tensor
+                    part, nparts = None, 0
+                    if op372 is not None:
+                        grad_eta = ops.llg372(eta, op372, sigma, self.fft_normalization)
+                    elif hinv:
+                        grad_eta = ops.llg_hinv(eta, yt, sense, mask, sigma, self.fft_centered, self.fft_normalization)
+                    else:
+                        grad_eta = ops.llg(eta, masked_kspace, sense, mask, sigma, self.fft_centered, self.fft_normalization, self.spatial_dims, work=work)
+                hx[0] = ops.amp16_layer1(grad_eta, eta if nparts else None, part, nparts, sigma, self._packed_amp16(0, c0, r0), c0.conv_layer.bias,
+                                         r0.ih.bias, r0.hh, hx[0], out=hx[0] if (self.inplace_state and hx[0] is not None and step > 0) else None)
+                hx[1], tq, te = ops.amp16_layer2(hx[0], self._packed_amp16(1, c1, r1, final), c1.conv_layer.bias, r1.ih.bias, r1.hh, hx[1],
+                                                 out=hx[1] if (self.inplace_state and hx[1] is not None and step > 0) else None)
+                if gather372 and nparts and step + 1 < self.time_steps:
+                    pending = (tq, te)
+                    continue
+                eta = ops.rim_final_gather_q(tq, te, final.conv_layer.bias, eta)
+                etas.append(eta)
+            hx = [ops.amp16_to_nchw(h) for h in hx] if _want_hx else None
         if cb8:
             hx = [None if h is None else ops.cb8_from_nchw(h) for h in hx]   # (copies: ours to overwrite from step 0 on)
             c0, r0, c1, r1 = l0.convs, l0.rnn, self.layers[1].convs, self.layers[1].rnn
@@ -388,7 +452,7 @@ class RIMBlock(torch.nn.Module):
         # ... and, for general masks at W = 372, in the first of the next step's three gradient passes (mrx_pfa372_expand_t4_gather)
         fuse_gather_t4 = cb8 and defer and op372 is None and t4 and ops.LLG_T4_NO_Y and ops.LLG_T4_GATHER
         pending = None
-        for step in range(self.time_steps):                          # rim_block.py:217-249
+        for step in range(0 if amp16 else self.time_steps):          # rim_block.py:217-249
             own = step > 0                                           # the states of step 0 are the caller's (or the zero state)
             if cb8:
                 part, nparts, grad_eta = None, 0, None

@@ -496,6 +496,7 @@ def llg372_gather_q(eta, taps_q, edges, b_final, op, sigma, normalization):
         raise ValueError(f"llg372_gather_q: eta {tuple(eta.shape)}, taps_q {tuple(taps_q.shape)}")
     if op.linear or not LLG372_NO_Y:
         raise RuntimeError("llg372_gather_q needs the constant-plane form of the gradient (ops.LLG372_NO_Y)")
+    _check_edges(edges, op.B, op.H, 372, eta.device, "llg372_gather_q")
     if op.const_norm != _norm(normalization):
         _llg372_const(op, normalization)
     bf = _lib.f32c(b_final.detach()) if b_final is not None else None
@@ -1572,12 +1573,20 @@ def rim_layer2_f16_cb8_q(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps_q=None,
     return out, taps_q, edges
 
 
+def _check_edges(edges, B, H, W, device, who):
+    """The gather kernels load `edges` unconditionally for every pixel and the C entry points receive no size for it: check it here."""
+    ne = int(_lib.lib().mrx_rim_taps_q_edge_floats(B, H, W))
+    if edges is None or edges.dtype != torch.float32 or edges.device != device or not edges.is_contiguous() or edges.numel() < ne:
+        raise ValueError(f"{who}: edges must be a contiguous fp32 device tensor of >= {ne} elements (mrx_rim_taps_q_edge_floats({B}, {H}, {W}))")
+
+
 def rim_final_gather_q(taps_q, edges, b_final, eta):
     """eta + permute(conv3x3_reppad(h) + b_final) [B,H,W,2] from the row-pre-summed tap planes of rim_layer2_f16_cb8_q (mrx_rim_final_gather_q)."""
     eta = _lib.f32c(eta)
     B, H, W, _ = [int(v) for v in eta.shape]
     if taps_q.numel() < 6 * B * H * W or int(eta.shape[-1]) != 2:
         raise ValueError("rim_final_gather_q expects taps_q [B,3,H,W,2] and eta [B,H,W,2]")
+    _check_edges(edges, B, H, W, eta.device, "rim_final_gather_q")
     bf = _lib.f32c(b_final.detach()) if b_final is not None else None
     eta_out = torch.empty_like(eta)
     _lib.check(_lib.lib().mrx_rim_final_gather_q(_lib.ptr(taps_q), _lib.ptr(edges), _lib.ptr(bf), _lib.ptr(eta), _lib.ptr(eta_out), B, H, W, _lib.stream_ptr()),
@@ -1585,39 +1594,103 @@ def rim_final_gather_q(taps_q, edges, b_final, eta):
     return eta_out
 
 
-def rim_layer2_wx_pack(w_conv, w_ih, w_final=None):
-    """Operand pack of rim_layer2_wx_cb8 (mrx_rim_layer2_wx_pack): the 3x3 weights in the Winograd F(2, 3) form along x, two fp16 terms."""
+# ---- the reduced-precision inference route (csrc/rim_amp16.hip): the reference's `precision: 16` -----------------------------------------------------
+def amp16_from_nchw(h):
+    """[B,64,H,W] (any float dtype) -> the fp16 channel-blocked state [B,8,H,W,8] of the amp16 layer kernels (entry / exit of a block only: torch plumbing)."""
+    _lib.require_gpu(h)
+    B, C, H, W = _nchw(h)
+    return h.reshape(B, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).to(torch.float16).contiguous()
+
+
+def amp16_to_nchw(h):
+    """The inverse of amp16_from_nchw, as fp32 [B,64,H,W] (rim_block.py hands fp32 states from call to call)."""
+    B, Q, H, W, E = [int(v) for v in h.shape]
+    return h.permute(0, 1, 4, 2, 3).reshape(B, Q * E, H, W).float().contiguous()
+
+
+def amp16_layer1_pack(w_conv, w_ih):
     w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
-    if tuple(w_conv.shape) != (64, 64, 3, 3) or tuple(w_ih.shape) != (64, 64, 1, 1):
-        raise NotImplementedError(f"rim_layer2_wx_pack: {tuple(w_conv.shape)} / {tuple(w_ih.shape)}")
-    if w_final is not None:
-        w_final = _lib.f32c(w_final.detach())
-        if tuple(w_final.shape) != (2, 64, 3, 3):
-            raise NotImplementedError(f"rim_layer2_wx_pack: final conv {tuple(w_final.shape)}")
-    packed = torch.empty(int(_lib.lib().mrx_rim_layer2_wx_pack_floats()), dtype=torch.float32, device=w_conv.device)
-    _lib.check(_lib.lib().mrx_rim_layer2_wx_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(w_final), _lib.ptr(packed), _lib.stream_ptr()),
-               "mrx_rim_layer2_wx_pack")
+    if tuple(w_conv.shape[0:1] + w_conv.shape[2:]) != (64, 5, 5) or int(w_conv.shape[1]) > 4 or tuple(w_ih.shape) != (64, 64, 1, 1):
+        raise NotImplementedError(f"amp16_layer1_pack: {tuple(w_conv.shape)} / {tuple(w_ih.shape)}")
+    L = _lib.lib()
+    packed = torch.empty(int(L.mrx_amp16_pack_floats(1)), dtype=torch.float32, device=w_conv.device)
+    _lib.check(L.mrx_amp16_layer1_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(packed), int(w_conv.shape[1]), _lib.stream_ptr()), "mrx_amp16_layer1_pack")
     return packed
 
 
-def rim_layer2_wx_cb8(x, packed, b_conv, b_ih, hh, h_prev, xmax, taps=None, out=None, want_taps=False):
-    """rim_layer2_f16_cb8 with the convolution in the Winograd F(2, 3) form along x (mrx_rim_layer2_wx_cb8; packed = rim_layer2_wx_pack)."""
-    x = _lib.f32c(x)
-    B, Q, H, W, E = [int(v) for v in x.shape]
-    if Q != 8 or E != 8:
-        raise ValueError(f"rim_layer2_wx_cb8 expects x [B,8,H,W,8], got {tuple(x.shape)}")
+def amp16_layer2_pack(w_conv, w_ih, w_final=None):
+    w_conv, w_ih = _lib.f32c(w_conv.detach()), _lib.f32c(w_ih.detach())
+    if tuple(w_conv.shape) != (64, 64, 3, 3) or tuple(w_ih.shape) != (64, 64, 1, 1):
+        raise NotImplementedError(f"amp16_layer2_pack: {tuple(w_conv.shape)} / {tuple(w_ih.shape)}")
+    if w_final is not None:
+        w_final = _lib.f32c(w_final.detach())
+        if tuple(w_final.shape) != (2, 64, 3, 3):
+            raise NotImplementedError(f"amp16_layer2_pack: final conv {tuple(w_final.shape)}")
+    L = _lib.lib()
+    packed = torch.empty(int(L.mrx_amp16_pack_floats(2)), dtype=torch.float32, device=w_conv.device)
+    _lib.check(L.mrx_amp16_layer2_pack(_lib.ptr(w_conv), _lib.ptr(w_ih), _lib.ptr(w_final), _lib.ptr(packed), _lib.stream_ptr()), "mrx_amp16_layer2_pack")
+    return packed
+
+
+def _amp16_state(h, B, H, W, what):
+    if h is None:
+        return None
+    _lib.require_gpu(h)
+    if h.dtype != torch.float16 or tuple(h.shape) != (B, 8, H, W, 8) or not h.is_contiguous():
+        raise ValueError(f"{what}: states are contiguous fp16 [B,8,H,W,8] = {(B, 8, H, W, 8)}, got {h.dtype} {tuple(h.shape)}")
+    return h
+
+
+def amp16_layer1(x, eta, part, nparts, sigma, packed, b_conv, b_ih, hh, h_prev, out=None):
+    """First RIM layer of the precision-16 route (mrx_amp16_layer1): input x [B,Cin<=4,H,W] (eta None) or (eta [B,H,W,2], nparts <= 4 coil-group partial
+    planes) as rim_layer1_cb8; h_prev / result fp16 [B,8,H,W,8]."""
+    if eta is not None:
+        eta = _lib.f32c(eta)
+        B, H, W, _ = [int(v) for v in eta.shape]
+        Cin = 4
+        if not 1 <= int(nparts) <= 4 or part is None or part.numel() < int(nparts) * B * H * W * 2 or part.dtype != torch.float32:
+            raise ValueError("amp16_layer1: (eta, part) needs 1 .. 4 fp32 partial planes [nparts,B,H,W,2]")
+    else:
+        x = _lib.f32c(x)
+        B, Cin, H, W = _nchw(x)
     bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
     bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
     hhc = _lib.f32c(hh.detach().reshape(-1))
-    hp = _lib.f32c(h_prev) if h_prev is not None else None
-    if want_taps and (taps is None or taps.numel() < 18 * B * H * W):
-        taps = torch.empty(B, 18, H, W, dtype=torch.float32, device=x.device)
+    hp = _amp16_state(h_prev, B, H, W, "amp16_layer1")
     if out is None:
-        out = torch.empty(B, 8, H, W, 8, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().mrx_rim_layer2_wx_cb8(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out),
-                                                _lib.ptr(taps) if want_taps else None, _lib.ptr(xmax), B, H, W, _lib.stream_ptr()),
-               "mrx_rim_layer2_wx_cb8")
-    return (out, taps) if want_taps else out
+        out = torch.empty(B, 8, H, W, 8, dtype=torch.float16, device=(eta if eta is not None else x).device)
+    _amp16_state(out, B, H, W, "amp16_layer1")
+    _lib.check(_lib.lib().mrx_amp16_layer1(_lib.ptr(x) if eta is None else None, int(Cin), _lib.ptr(eta), _lib.ptr(part) if eta is not None else None, int(nparts),
+                                           float(1.0 / (float(sigma) ** 2.0)), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc),
+                                           _lib.ptr(hp), _lib.ptr(out), B, H, W, _lib.stream_ptr()), "mrx_amp16_layer1")
+    return out
+
+
+def amp16_layer2(x, packed, b_conv, b_ih, hh, h_prev, taps_q=None, edges=None, out=None, want_taps=True):
+    """Second RIM layer of the precision-16 route (mrx_amp16_layer2): fp16 x / h_prev / result [B,8,H,W,8]; with `want_taps` also (taps_q [B,3,H,W,2],
+    edges) of the final convolution, fp32, in the layout of rim_layer2_f16_cb8_q (for rim_final_gather_q / llg372_gather_q)."""
+    _lib.require_gpu(x)
+    B, Q, H, W, E = [int(v) for v in x.shape]
+    _amp16_state(x, B, H, W, "amp16_layer2")
+    bc = _lib.f32c(b_conv.detach()) if b_conv is not None else None
+    bi = _lib.f32c(b_ih.detach()) if b_ih is not None else None
+    hhc = _lib.f32c(hh.detach().reshape(-1))
+    hp = _amp16_state(h_prev, B, H, W, "amp16_layer2")
+    L = _lib.lib()
+    if want_taps:
+        if taps_q is None or taps_q.numel() < 6 * B * H * W:
+            taps_q = torch.empty(B, 3, H, W, 2, dtype=torch.float32, device=x.device)
+        ne = int(L.mrx_rim_taps_q_edge_floats(B, H, W))
+        if edges is None or edges.numel() < ne:
+            edges = torch.empty(ne, dtype=torch.float32, device=x.device)
+    else:
+        taps_q = edges = None
+    if out is None:
+        out = torch.empty(B, 8, H, W, 8, dtype=torch.float16, device=x.device)
+    _amp16_state(out, B, H, W, "amp16_layer2")
+    _lib.check(L.mrx_amp16_layer2(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), _lib.ptr(taps_q),
+                                  _lib.ptr(edges), B, H, W, _lib.stream_ptr()), "mrx_amp16_layer2")
+    return (out, taps_q, edges) if want_taps else out
 
 
 def rim_final_gather(taps, b_final, eta):

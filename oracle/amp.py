@@ -82,6 +82,37 @@ def autocast_bf16():
     return torch.autocast("cpu", dtype=torch.bfloat16)
 
 
+# ---- precision-16 INFERENCE (base_cirim_run.yaml:132 `precision: 16`; the checkers of csrc/rim_amp16.hip) ---------------------------------------------
+def autocast_fp16():
+    """The reference's inference arithmetic: pytorch-lightning's native AMP for `precision: 16` is `torch.autocast(dtype=torch.float16)` around the
+    forward pass.  torch's CPU autocast implements float16 with the same op lists (convolutions in half precision RETURNING half precision; FFT, complex
+    products, `hh * hx`, eta stay fp32)."""
+    return torch.autocast("cpu", dtype=torch.float16)
+
+
+def fp16_round(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+@contextlib.contextmanager
+def fp16_kernel_arithmetic():
+    """The arithmetic of the precision-16 KERNELS (mrx_amp16_layer1 / _layer2) restated on the CPU: every 2-D convolution of the regulariser multiplies
+    fp16-rounded operands exactly and accumulates wide (float64 here, fp32 in the MFMA) with an fp32 result -- the rounding of ReLU(conv + b) to fp16 before
+    the 1x1 cell IS that cell's operand rounding -- and a recurrent cell's new state is rounded to fp16 once (the kernels keep their states in fp16;
+    autocast keeps them fp32 but rounds every convolution's OUTPUT, which the kernels do not).  Differs from the kernels only by the order of the fp32 sums
+    and by the first layer's exact power-of-two input scale (no fp16 underflow of small inputs there)."""
+    keep_conv, keep_state = orim._CONV2D[0], orim._STATE[0]
+
+    def conv(x, weight, bias=None, padding=0, dilation=1):
+        y = F.conv2d(fp16_round(x).double(), fp16_round(weight).double(), None, padding=padding, dilation=dilation)
+        return (y + bias.double().view(1, -1, 1, 1) if bias is not None else y).float()
+    orim._CONV2D[0], orim._STATE[0] = conv, fp16_round
+    try:
+        yield
+    finally:
+        orim._CONV2D[0], orim._STATE[0] = keep_conv, keep_state
+
+
 def cirim_loss_and_gradients(state, cfg, sample, mode="fp32", skip=(), fp32_forward=(), round_results=False):
     """Forward + l1 loss (cirim.py:199-247) + torch autograd of the CIRIM oracle in one of the three arithmetics (`fp32`, `autocast_bf16`,
     `bf16_operands`).  `state`: reference state_dict (fp32 tensors); returns (loss, {name: gradient})."""

@@ -20,6 +20,11 @@ def _conv2d(x, weight, bias=None, padding=0, dilation=1):
     return _CONV2D[0](x, weight, bias, padding=padding, dilation=dilation)
 
 
+# Hook on the hidden state a recurrent cell returns (identity by default): oracle/amp.py's restatement of the precision-16 KERNELS rounds it to fp16
+# here (csrc/rim_amp16.hip keeps its states in fp16; torch.autocast itself keeps them fp32).
+_STATE = [lambda h: h]
+
+
 def log_likelihood_gradient(eta, masked_kspace, sense, mask, sigma, fft_centered, fft_normalization,
                             spatial_dims, coil_dim):
     """rim_utils.py:11-67.  eta [B,H,W,2]; y,S [B,C,H,W,2]; mask broadcastable -> [B,4,H,W]."""
@@ -53,7 +58,7 @@ def _zero_pad(kernel_size, dilation):
 def indrnn_cell(x, hx, ih_w, ih_b, hh, kernel_size, dilation):
     """rnn_cells.py:295-312,384-391: ReLU(conv_zero_pad(x) + hh * hx)."""
     p = _zero_pad(kernel_size, dilation)
-    return F.relu(_conv2d(x, ih_w, ih_b, padding=p, dilation=dilation) + hh * hx)
+    return _STATE[0](F.relu(_conv2d(x, ih_w, ih_b, padding=p, dilation=dilation) + hh * hx))
 
 
 def convgru_cell(x, hx, ih_w, ih_b, hh_w, kernel_size, dilation):
