@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="--train only: bf16 = convolution / IndRNN GEMM operands in bf16 with fp32 accumulation (the reference's "
                          "`precision: 16` AMP, base_cirim_train.yaml:180), FFT / data consistency / eta accumulation stay fp32")
+    ap.add_argument("--precision", type=int, default=32, choices=[32, 16],
+                    help="CIRIM inference: 16 = the reference's own inference configuration (`trainer.precision: 16`, base_cirim_run.yaml:132): fp16 operands and "
+                         "hidden states in the two RIM layers (csrc/rim_amp16.hip), FFT / data consistency / eta in fp32; checked against the oracle under "
+                         "torch.autocast(float16).  Never the headline: the default run reports it as other_configs.cirim_precision16")
     ap.add_argument("--unet", default="14x2", choices=["14x2", "18x4"],
                     help="--model e2evn: NormUnet(chans x pools): 14x2 pad 11 = BASELINE configs[1]; 18x4 pad 15 = the reference yaml's default")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -225,7 +229,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cfg, state_dict, data, n_cascades, n_slices=1):
+def cpu_baseline(cfg, state_dict, data, n_cascades, n_slices=1, ctx=None, ctx_name=""):
     """Time the oracle (CPU restatement of the reference path, torch CPU ops) on the same slice the GPU reconstructed, per BASELINE.md
     section 3: one untimed warm-up cascade, then `n_slices` slices of `n_cascades` cascades each, timed cascade by cascade (all cascades by
     default = whole slices; mean and min over the slices are reported), plus the FFT+DC step on its own.  Returns (cpu_baseline dict, the
@@ -234,7 +238,8 @@ def cpu_baseline(cfg, state_dict, data, n_cascades, n_slices=1):
     ncores, box_cores = _oracle_threads()       # (the fastest thread count of the committed sweep, not os.cpu_count(): see there)
     T_ = oracle.models.cirim_time_steps(cfg["time_steps"])
     y, S, mask, target = data["y"], data["sensitivity_maps"], data["mask"], data["target"]
-    with torch.no_grad():
+    import contextlib
+    with torch.no_grad(), (ctx() if ctx is not None else contextlib.nullcontext()):     # (ctx: oracle.amp.autocast_fp16 for the precision-16 line)
         oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=1), y, S, mask, None, target)       # warm-up, untimed
         stamps = [time.perf_counter()]
         ref = oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=n_cascades), y, S, mask, None, target,
@@ -263,7 +268,7 @@ def cpu_baseline(cfg, state_dict, data, n_cascades, n_slices=1):
                 sec_per_cascade_mean=dt / n_cascades, sec_per_cascade_min=min(per), sec_per_cascade=per,
                 split_ms_per_rim_step=dict(fft_dc=1e3 * llg_s, regulariser=1e3 * max(step_s - llg_s, 0.0)),
                 sample=(f"after one untimed warm-up cascade: {len(slice_s)} slice(s) of {n_cascades} of {cfg['num_cascades']} cascades ({n_cascades * T_} of "
-                        f"{cfg['num_cascades'] * T_} RIM steps) each on the oracle (torch CPU ops, {ncores} threads of the box's "
+                        f"{cfg['num_cascades'] * T_} RIM steps) each on the oracle{ctx_name} (torch CPU ops, {ncores} threads of the box's "
                         f"{box_cores}), value = 1 / mean seconds per slice, {sum(slice_s):.1f} s in all"
                         + ("" if whole else f", extrapolated x{cfg['num_cascades'] / n_cascades:g}"))), ref
 
@@ -883,7 +888,7 @@ def summary_of(res):
     if isinstance(res.get("streamed_inputs"), dict):
         out["streamed"] = dict(v=r3(res["streamed_inputs"].get("value")))
     short = {"e2evn_6cascade_15coil_640x372": "e2evn", "qcirim_4echo_32coil_256x256": "qcirim", "cirim_training_bf16_15coil_640x372": "train_bf16",
-             "e2evn_training_15coil_640x372": "train_e2evn", "cirim_2d_mask_15coil_640x372": "mask2d",
+             "e2evn_training_15coil_640x372": "train_e2evn", "cirim_2d_mask_15coil_640x372": "mask2d", "cirim_precision16_15coil_640x372": "prec16",
              "cirim_8cascade_x5_time_steps_rimblock_direct": "rim5"}
     for k, r in (res.get("other_configs") or {}).items():
         out[short.get(k, k)] = {a: b for a, b in (one(r) or {}).items() if b is not None}
@@ -1193,6 +1198,77 @@ def streamed_inputs_run(args, step, hosts, datas, dev, slices_per_step, variant=
 NUMA_BINDING = None      # {"node", "cpus"} once main() has bound the rank to its GPU's NUMA node
 
 
+def precision16_record(args, cfg, model, state_dict, timer, host, out, elapsed, per_rank, world, NS, B, graphed, conc_ok):
+    """The result line of `--precision 16` (the reference's inference configuration, base_cirim_run.yaml:132): both RIM layers are HBM-bound there, so the
+    roofline record prices the dominant launch (mrx_amp16_layer2) on its ALGORITHMIC bytes -- x, h_prev in and h_new out as fp16 [B,8,H,W,8], six fp32 tap
+    planes out -- against 8 TB/s; `cpu_baseline` and `parity_vs_oracle` are the oracle under torch.autocast(float16)."""
+    import oracle
+    C, H, W = args.coils, args.height, args.width
+    T_, npix, F = model.time_steps, H * W, 64
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * NS * B * args.steps / elapsed
+    ms1, n1 = timer.mean_ms("amp_layer1")
+    ms2, n2 = timer.mean_ms("amp_layer2")
+    msl, nl = timer.mean_ms("llg372")
+    msg, ng = timer.mean_ms("llg372g")
+    if not msl:
+        msl, nl = timer.mean_ms("llg")
+    bytes2 = (3.0 * F * 2 + 6 * 4) * npix * B
+    bytes1 = (2.0 * F * 2 + 5 * 8) * npix * B            # h_prev in, h out (fp16); eta and four partial planes (complex fp32)
+    flops2 = 2.0 * (F * F * 9 + F * F + F * 2 * 9) * npix * B
+    traffic = measured_traffic(B, C, H, W, F)
+    roofline = dict(bound="hbm", kernel="k_amp_layer2 via mrx_amp16_layer2 (3x3 dilation-2 64->64 + IndRNN 1x1 + the final 3x3's channel contraction; ONE fp16 term "
+                                        "per operand on v_mfma_f32_32x32x16_f16, fp32 accumulation, fp16 channel-blocked states)",
+                    achieved=(bytes2 / (ms2 * 1e-3) / 1e9) if ms2 else None, peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=(bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms2 else None, traffic=traffic.get("amp_layer2"), traffic_unit="bytes/launch",
+                    algorithmic_bytes=bytes2, launches=n2, avg_ms=ms2, flops_per_launch=flops2,
+                    mfma_frac=(flops2 / (ms2 * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if ms2 else None,
+                    layer1=dict(kernel="k_amp_layer1 via mrx_amp16_layer1", avg_ms=ms1, launches=n1, algorithmic_bytes=bytes1,
+                                frac=(bytes1 / (ms1 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms1 else None, traffic=traffic.get("amp_layer1")))
+    res = dict(metric=f"slices/sec (inference, precision 16), CIRIM {cfg['num_cascades']}-cascade {C}-coil {H}x{W}", value=value, unit="slices/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
+               config=dict(workload=f"CIRIM {cfg['num_cascades']} cascades x {T_} time-steps, IndRNN {F} filters, {C} coils, {H}x{W}, {NS * B} slice(s) per GPU and step "
+                                    f"({NS} concurrent HIP stream(s) x batch {B}, one hipGraph each), random-init weights (seed 0), trainer.precision = 16 "
+                                    "(base_cirim_run.yaml:132): fp16 operands + fp16 hidden states in the RIM layers, fp32 accumulation, FFT / DC / eta in fp32",
+                           global_batch=world * NS * B, streams_per_gpu=NS, coils=C, height=H, width=W, parallelism=f"slice-sharded x{world}",
+                           mask="1-D random columns R=4" if args.mask == "1d" else "2-D random points R~10"),
+               world_size_seen=world_seen(), per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank], launch="hipGraph replay" if graphed else "eager",
+               roofline=roofline, breakdown_ms=dict(llg=msl, llg_gather_form=msg, conv_layer1=ms1, conv_layer2=ms2, rim_steps_per_slice=cfg["num_cascades"] * T_),
+               concurrent_replays_bit_identical_to_serial=conc_ok)
+    if world == 1 and not args.no_cpu_baseline:
+        n_cpu = args.cpu_cascades if 0 < args.cpu_cascades <= cfg["num_cascades"] else cfg["num_cascades"]
+        try:
+            host1 = {k: v[:1] if k != "mask" else v for k, v in host.items()}
+            cb, ref = cpu_baseline(cfg, state_dict, host1, n_cpu, args.cpu_slices, ctx=oracle.amp.autocast_fp16, ctx_name=" under torch.autocast(float16)")
+            res["cpu_baseline"] = cb
+            res["parity_vs_oracle"] = parity_vs_oracle(out[n_cpu - 1][-1][0:1], ref[n_cpu - 1][-1][0:1], host1["target"],
+                                                       at=f"cascade {n_cpu} of {cfg['num_cascades']}, last time-step, against the oracle under torch.autocast(float16)")
+            res["parity_vs_oracle"]["tolerance"] = dict(rel_l2=3e-2, ssim=0.99, source="SURVEY appendix C, fast mode")
+            with torch.no_grad():
+                ref32 = oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=n_cpu), host1["y"], host1["sensitivity_maps"], host1["mask"], None,
+                                                    host1["target"])
+            res["parity_vs_fp32_oracle"] = parity_vs_oracle(out[n_cpu - 1][-1][0:1], ref32[n_cpu - 1][-1][0:1], host1["target"], at="the same, against the fp32 oracle")
+        except Exception as ex:  # noqa: BLE001
+            res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port", sample=f"failed: {type(ex).__name__}: {ex}")
+    res["summary"] = summary_of(res)
+    return res
+
+
+def precision16_line(args):
+    """BASELINE's headline model in the reference's own inference precision (`trainer.precision: 16`): a child process of the default run."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-other-configs", "--no-stream-inputs", "--steps", "10", "--warmup", "3", "--precision", "16",
+           "--coils", str(args.coils), "--height", str(args.height), "--width", str(args.width), "--cpu-slices", "1", "--cpu-cascades", "1"]     # (torch's CPU fp16 convolutions take ~7 s per RIM step on the GPU box's EPYC: one cascade of one slice, extrapolated)
+    cmd += ["--no-cpu-baseline"] if args.no_cpu_baseline else []
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        return {k: r.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "breakdown_ms", "cpu_baseline",
+                                      "parity_vs_oracle", "parity_vs_fp32_oracle", "concurrent_replays_bit_identical_to_serial") if r.get(k) is not None}
+    except Exception as ex:  # noqa: BLE001
+        return dict(value=None, error=f"{type(ex).__name__}: {ex}")
+
+
 def main():
     args = parse()
     plan = rank_launch_plan(args.gpus, sys.argv[1:], os.environ)
@@ -1247,7 +1323,7 @@ def main():
     if args.cascades:
         cfg["num_cascades"] = args.cascades
     torch.manual_seed(0)                                # reference-identical initialisation (tests/test_host_logic.py)
-    model = CIRIM(cfg).eval()
+    model = CIRIM(dict(cfg, precision=16) if args.precision == 16 else cfg).eval()
     if args.rim_steps:                                  # the blocks called as RIMBlock(time_steps = N) directly: no rounding up to a multiple of 8
         model.time_steps = args.rim_steps
         for blk in model.cirim:
@@ -1293,6 +1369,8 @@ def main():
     timer.wrap(ops, "rim_layer2_f16", lambda x, *a, **k: "conv_layer2_f16t" if k.get("want_taps") else "conv_layer2_f16")   # two-term fp16 conv operands
     timer.wrap(ops, "rim_layer2_f16_cb8", lambda x, *a, **k: "conv_layer2_f16t" if k.get("want_taps") else "conv_layer2_f16")   # channel-blocked states
     timer.wrap(ops, "rim_layer2_f16_cb8_q", lambda *a, **k: "conv_layer2_f16t")     # ... with the tap products pre-summed along x (6 planes + tile-edge terms)
+    timer.wrap(ops, "amp16_layer1", lambda *a, **k: "amp_layer1")                  # --precision 16: fp16 operands and states (csrc/rim_amp16.hip)
+    timer.wrap(ops, "amp16_layer2", lambda *a, **k: "amp_layer2")
     timer.wrap(ops, "rim_final_gather_q", lambda *a, **k: "final_gather")
     timer.wrap(ops, "llg372_gather_q", lambda *a, **k: "llg372g")
     timer.wrap(ops, "rim_layer1_cb8", lambda *a, **k: "conv_layer1")
@@ -1370,7 +1448,9 @@ def main():
     elapsed, per_rank = rank_times(time.perf_counter() - t0, dev)
     headline_conc_ok = concurrent_replays_match_serial(graphs, streams, outs)
 
-    if rank == 0:
+    if rank == 0 and args.precision == 16:
+        emit(precision16_record(args, cfg, model, state_dict, timer, host, out, elapsed, per_rank, world, NS, B, graphed, headline_conc_ok))
+    elif rank == 0:
         T_ = model.time_steps
         npix = H * W
         ms_per_step = 1e3 * elapsed / args.steps
@@ -1609,6 +1689,7 @@ def main():
             from mridc_amd import autograd as ag_
             ag_.set_precision("f32")
             if args.mask == "1d":
+                others["cirim_precision16_15coil_640x372"] = precision16_line(args)
                 others["cirim_2d_mask_15coil_640x372"] = mask2d_line(args)
             if not args.rim_steps:
                 others["cirim_8cascade_x5_time_steps_rimblock_direct"] = rim5_line(args)

@@ -3,7 +3,7 @@
 // `precision: 16` (projects/reconstruction/model_zoo/conf/base_cirim_run.yaml:132) = torch.autocast -- every convolution multiplies HALF-precision
 // operands and accumulates wide, everything autocast does not list (FFT, the complex products of log_likelihood_gradient, eta) stays fp32.
 //
-// This is the reduced-precision route of the library (MRIDC_AMD_ARITH=amp16), never the default: ONE fp16 term per operand (one MFMA per product where the
+// This is the reduced-precision route of the library (RIMBlock.precision = 16 / MRIDC_AMD_PRECISION=16), never the default: ONE fp16 term per operand (one MFMA per product where the
 // fp32-class route issues three), fp32 accumulation, and the hidden states kept in fp16, channel-blocked [B][8][H][W][8] halves (16 bytes per pixel and
 // channel block = exactly one B operand of v_mfma_f32_32x32x16_f16).  With a third of the matrix work and half the state bytes both layers are HBM-bound:
 // the kernels are built around bytes in flight, not around MFMA issue.
@@ -30,6 +30,29 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define AM_F 64
 #define AM_TW 32
 #define AM_TH 16
+
+// PROBE builds (-DMRX_PROBE, env MRX_AMP_ABL): phases switched off to price them -- 1 no input (patch / x) loads, 2 no h_prev loads, 4 no state stores,
+// 8 no tap stage, 16 no convolution MFMAs.  Results are garbage; only the time is read.  The product build compiles every test away.
+#ifdef MRX_PROBE
+#define AM_ABL(a, bit) (((a).abl & (bit)) != 0)
+#else
+#define AM_ABL(a, bit) false
+#endif
+// cache policy of the state streams (aux bits of the buffer / global instructions; 2 = nt): every state byte is written once and read once, a whole time-step
+// (~1 GB at 8 slices per launch) later -- MRX_AMP_NT_ST / MRX_AMP_NT_LD select the streaming policy for the h_new stores / the h_prev loads (A/B builds)
+// (measured, 8 slices per launch, profiles/r06_amp16_layer_times_v1.txt: default policy 19.9 / 28.1 us per slice for layer 1 / 2, nt stores 19.1 / 27.8, nt stores
+// and nt h_prev loads 18.4 / 26.8: both on)
+#ifndef MRX_AMP_NT_ST
+#define MRX_AMP_NT_ST 1
+#endif
+#ifndef MRX_AMP_NT_LD
+#define MRX_AMP_NT_LD 1
+#endif
+// layer 2: the chunk pair at whose start a tile's h_prev is requested (consumed by the epilogue behind pair 3; no h_prev loads at all measured 6 us per slice faster
+// than requesting them at pair 3: their latency was exposed)
+#ifndef MRX_AMP_HP_AT
+#define MRX_AMP_HP_AT 1
+#endif
 
 // channel of accumulator register R = 16 ct + r in lane half `half` (v_mfma_f32_32x32 C/D layout)
 __host__ __device__ constexpr int am_chan(int R, int half) { return 32 * (R >> 4) + (R & 3) + 8 * ((R & 15) >> 2) + 4 * half; }
@@ -100,6 +123,7 @@ struct Amp1Args {
     const _Float16* hprev; // [B][8][H][W][8] or null (the zero state)
     _Float16* hnew;        // [B][8][H][W][8]
     int B, Cin, H, W, tiles_x, ntiles;
+    int abl;               // probe builds only
 };
 
 template <int LLGT>
@@ -141,7 +165,10 @@ __global__ __launch_bounds__(A1_NW * 64, 1) void k_amp_layer1(Amp1Args a) {
             gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
             gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
             const unsigned off = (unsigned)(gy * a.W + gx);
-            if constexpr (LLGT > 0) {
+            if (AM_ABL(a, 1)) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) raw[q][k] = (float)(off & 7u);
+            } else if constexpr (LLGT > 0) {
                 const float2 e = a.eta2[(long long)b * plane + off];
                 raw[q][0] = e.x, raw[q][1] = e.y;
                 const float2* pp = a.part + (long long)b * plane;
@@ -157,10 +184,10 @@ __global__ __launch_bounds__(A1_NW * 64, 1) void k_amp_layer1(Amp1Args a) {
             }
         }
         u32x2 hp[8];                         // registers 4 q .. 4 q + 3 of this lane = channels 8 q + 4 lhi .. + 3: four halves
-        if (a.hprev) {
+        if (a.hprev && !AM_ABL(a, 2)) {
             const u32x2* hb = reinterpret_cast<const u32x2*>(a.hprev + ((long long)b * AM_F * plane + ((long long)oy * a.W + cx) * 8 + 4 * lhi));
 #pragma unroll
-            for (int q = 0; q < 8; ++q) hp[q] = hb[(long long)q * plane * 2];
+            for (int q = 0; q < 8; ++q) hp[q] = MRX_AMP_NT_LD ? __builtin_nontemporal_load(hb + (long long)q * plane * 2) : hb[(long long)q * plane * 2];
         } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) hp[q] = u32x2{0u, 0u};
@@ -246,7 +273,7 @@ __global__ __launch_bounds__(A1_NW * 64, 1) void k_amp_layer1(Amp1Args a) {
             }
         }
         // ---- h = ReLU(W_ih g + b_ih + hh * h_prev) (rnn_cells.py:384-391), stored as fp16 -----------------------------------------------------------------
-        if (ox < a.W) {
+        if (ox < a.W && !AM_ABL(a, 4)) {
             u32x2* ob = reinterpret_cast<u32x2*>(a.hnew + ((long long)b * AM_F * plane + ((long long)oy * a.W + ox) * 8 + 4 * lhi));
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -259,7 +286,8 @@ __global__ __launch_bounds__(A1_NW * 64, 1) void k_amp_layer1(Amp1Args a) {
                     v[i] = acc2[R >> 4][R & 15] + tabl[lhi * 32 + R] * hv[i];
                     v[i] = v[i] > 0.f ? v[i] : 0.f;
                 }
-                ob[(long long)q * plane * 2] = u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])};
+                if (MRX_AMP_NT_ST) __builtin_nontemporal_store((u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])}), ob + (long long)q * plane * 2);
+                else ob[(long long)q * plane * 2] = u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])};
             }
         }
     }
@@ -328,6 +356,7 @@ struct Amp2Args {
     float* Q;              // [B][3][H][W][2]: the final convolution's tap products pre-summed along x inside the tile (rim_layer2_sb.hip, FAST form)
     float* E;              // [B][H][tile column][16]: what the neighbouring tiles owe columns 0 / 31
     int B, H, W, tiles_x, ntiles;
+    int abl;               // probe builds only
 };
 
 __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
@@ -384,7 +413,8 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
     auto request = [&](int slot) {
         const unsigned so = (unsigned)st_p * (unsigned)(plane * 32);
 #pragma unroll
-        for (int v = 0; v < A2_XV; ++v) xr[slot][v] = __builtin_amdgcn_raw_buffer_load_b128(st_rx, goff[v], so, 0);
+        for (int v = 0; v < A2_XV; ++v)
+            xr[slot][v] = AM_ABL(a, 1) ? u32x4{0x3c003c00u, 0x3c003c00u, so, goff[v]} : __builtin_amdgcn_raw_buffer_load_b128(st_rx, goff[v], so, 0);
         if (++st_p == 4) {
             st_p = 0;
             st_t += gridDim.x;
@@ -420,15 +450,16 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             request(p & 1);                          // job + 2 (the slot's previous content was committed during the last job)
-            if (p == 3) {                            // the tile's h_prev, behind it: consumed by the epilogue
+            __builtin_amdgcn_sched_barrier(0);       // (requests first: the scheduler would sink them behind the commit's s_waitcnt)
+            if (p == MRX_AMP_HP_AT) {                // the tile's h_prev, behind it: consumed by the epilogue
                 const int cx = ox < a.W ? ox : a.W - 1;
 #pragma unroll
                 for (int rw = 0; rw < 2; ++rw) {
                     const int cy = oy0 + rw < a.H ? oy0 + rw : a.H - 1;
-                    if (a.hprev) {
+                    if (a.hprev && !AM_ABL(a, 2)) {
                         const u32x2* hb = reinterpret_cast<const u32x2*>(a.hprev + ((long long)b * AM_F * plane + ((long long)cy * a.W + cx) * 8 + 4 * lhi));
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) hp[rw][q] = hb[(long long)q * plane * 2];
+                        for (int q = 0; q < 8; ++q) hp[rw][q] = MRX_AMP_NT_LD ? __builtin_nontemporal_load(hb + (long long)q * plane * 2) : hb[(long long)q * plane * 2];
                     } else {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) hp[rw][q] = u32x2{0u, 0u};
@@ -450,11 +481,15 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
             for (int st = 0; st < 9; ++st) {
                 const int bf = st & 1;
                 if (st + 1 < 9) fetch(st + 1, bf ^ 1);
+                if (AM_ABL(a, 16)) {
+                    asm volatile("" ::"v"(at[bf][0]), "v"(at[bf][1]), "v"(bt[bf][0]), "v"(bt[bf][1]));
+                } else {
 #pragma unroll
-                for (int rw = 0; rw < 2; ++rw)
+                    for (int rw = 0; rw < 2; ++rw)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-                        acc[rw][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, at[bf][ct]), __builtin_bit_cast(f16x8, bt[bf][rw]), acc[rw][ct], 0, 0, 0);
+                        for (int ct = 0; ct < 2; ++ct)
+                            acc[rw][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, at[bf][ct]), __builtin_bit_cast(f16x8, bt[bf][rw]), acc[rw][ct], 0, 0, 0);
+                }
                 if (st == 4) commit((p + 1) & 1, (p + 1) & 1);      // job + 1 (requested one job ago) into the buffer job - 1 was read from
             }
             __syncthreads();
@@ -500,7 +535,7 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
             const int oy = oy0 + rw;
-            const unsigned offh = (oy < a.H && ox < a.W) ? (unsigned)((((long long)oy * a.W + ox) * 8 + 4 * lhi) * 2) : 0x80000000u;
+            const unsigned offh = (oy < a.H && ox < a.W && !AM_ABL(a, 4)) ? (unsigned)((((long long)oy * a.W + ox) * 8 + 4 * lhi) * 2) : 0x80000000u;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float hv[4] = {am_lo(hp[rw][q].x), am_hi(hp[rw][q].x), am_lo(hp[rw][q].y), am_hi(hp[rw][q].y)};
@@ -512,10 +547,10 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
                     v[i] = v[i] > 0.f ? v[i] : 0.f;
                 }
                 hq[rw][q] = u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(hq[rw][q], rh, offh + (unsigned)q * (unsigned)(plane * 16), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(hq[rw][q], rh, offh + (unsigned)q * (unsigned)(plane * 16), 0, MRX_AMP_NT_ST ? 2 : 0);
             }
         }
-        if (a.Q) {
+        if (a.Q && !AM_ABL(a, 8)) {
             f32x16 accp[2];
 #pragma unroll
             for (int rw = 0; rw < 2; ++rw)
@@ -624,6 +659,7 @@ extern "C" int mrx_amp16_layer1(const float* x, int Cin, const float* eta, const
     a.nparts = nparts, a.post = inv_sigma2, a.packed = reinterpret_cast<const u32x4*>(packed), a.b_conv = b_conv, a.b_ih = b_ih, a.hh = hh;
     a.hprev = reinterpret_cast<const _Float16*>(h_prev), a.hnew = reinterpret_cast<_Float16*>(h_new);
     a.B = B, a.Cin = eta ? 4 : Cin, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, AM_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, A1_NW);
+    a.abl = MRX_DEBUG_ENV("MRX_AMP_ABL") ? atoi(MRX_DEBUG_ENV("MRX_AMP_ABL")) : 0;
     constexpr size_t lds = (size_t)A1_PACK_U4 * 16 + 192 * 4 + (size_t)A1_NW * A1_PSTR * 8;
     static bool attr_done = false;   // once: keeps launches legal under hipGraph capture
     if (!attr_done) {
@@ -650,6 +686,7 @@ extern "C" int mrx_amp16_layer2(const void* x, const float* packed, const float*
     a.x = reinterpret_cast<const _Float16*>(x), a.packed = reinterpret_cast<const u32x4*>(packed), a.b_conv = b_conv, a.b_ih = b_ih, a.hh = hh;
     a.hprev = reinterpret_cast<const _Float16*>(h_prev), a.hnew = reinterpret_cast<_Float16*>(h_new), a.Q = taps_q, a.E = edges;
     a.B = B, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, AM_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, AM_TH);
+    a.abl = MRX_DEBUG_ENV("MRX_AMP_ABL") ? atoi(MRX_DEBUG_ENV("MRX_AMP_ABL")) : 0;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_amp_layer2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A2_LDS);

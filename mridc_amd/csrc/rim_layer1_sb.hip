@@ -36,6 +36,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define SB_NT 1024
+// cache policy of the channel-blocked state streams (nt: streaming) -- round 6 A/B builds, see rim_layer2_sb.hip: h_prev loads streaming (read once), h_new
+// stores default (the second layer reads them back in the very next launch)
+#ifndef MRX_L1_NT_ST
+#define MRX_L1_NT_ST 0
+#endif
+#ifndef MRX_L1_NT_LD
+#define MRX_L1_NT_LD 1
+#endif
+typedef float sb_f32x4 __attribute__((ext_vector_type(4)));
 #define SB_TH 16
 #define SB_TW 32
 #define SB_F 64
@@ -477,7 +486,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
                 if (s == SB_KS2 - 1) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const float4 u = *reinterpret_cast<const float4*>(hb + (long long)q * plane * 8);
+                        const sb_f32x4 u = MRX_L1_NT_LD ? __builtin_nontemporal_load(reinterpret_cast<const sb_f32x4*>(hb + (long long)q * plane * 8))
+                                                        : *reinterpret_cast<const sb_f32x4*>(hb + (long long)q * plane * 8);
                         hp[4 * q] = u.x, hp[4 * q + 1] = u.y, hp[4 * q + 2] = u.z, hp[4 * q + 3] = u.w;
                     }
                 }
@@ -566,7 +576,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_rim_layer1_sb(MrxL1sbArgs a) {
                         v[i] = v[i] > 0.f ? v[i] : 0.f;
                         wmax = fmaxf(wmax, v[i]);
                     }
-                    *reinterpret_cast<float4*>(ob + (long long)q * plane * 8) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (MRX_L1_NT_ST) __builtin_nontemporal_store((sb_f32x4{v[0], v[1], v[2], v[3]}), reinterpret_cast<sb_f32x4*>(ob + (long long)q * plane * 8));
+                    else *reinterpret_cast<float4*>(ob + (long long)q * plane * 8) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             } else {
                 float* ob = a.hnew + (long long)b * SB_F * plane + (long long)oy * a.W + ox + 4ll * lhi * plane;

@@ -24,6 +24,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define S2_NT 512
+// cache policy of the hidden-state streams of the FAST / CB8 form (aux = 2: nt): every state byte is written once and read once, a whole time-step (~2.9 GB at
+// 8 slices per launch) later, through a 256 MB memory-side cache.  Round 6, A/B builds on one box (profiles/r06_nt_policy_and_hp_position.txt): this kernel 66.3 ->
+// 65.2 us per slice in isolation with both on; the headline 148.4 (default policy, two runs) / 148.7 (all four state streams of both layers) / 149.4 (loads only) /
+// 149.9 (everything but layer 1's stores, whose lines this kernel re-reads right away) -- at most 1 %: the 26 us of this launch that do not scale with the clock
+// are NOT a cache-policy effect.  Kept on in the best-measured combination.
+#ifndef MRX_L2_NT_ST
+#define MRX_L2_NT_ST 1
+#endif
+#ifndef MRX_L2_NT_LD
+#define MRX_L2_NT_LD 1
+#endif
 #define S2_BAR_STEP 4      // even chunks: the step before which the paired ninth-tap operands become visible (barrier); 3 = one step earlier, operands prefetched (measured equal)
 #define S2_COMMIT_EVEN 1   // even chunks: the step after which the next chunk is split and written (0 measured equal)
 #define S2_TH 16
@@ -601,7 +612,9 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
                 const float* hb = a.hprev + (long long)b * S2_F * plane + ((long long)cy * a.W + cx) * 8 + 4 * lhi;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const float4 u = *reinterpret_cast<const float4*>(hb + (long long)q * plane * 8);
+                    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                    const f32x4_ u = MRX_L2_NT_LD ? __builtin_nontemporal_load(reinterpret_cast<const f32x4_*>(hb + (long long)q * plane * 8))
+                                                  : *reinterpret_cast<const f32x4_*>(hb + (long long)q * plane * 8);
                     hp[rw][4 * q] = u.x, hp[rw][4 * q + 1] = u.y, hp[rw][4 * q + 2] = u.z, hp[rw][4 * q + 3] = u.w;
                 }
                 return;
@@ -826,7 +839,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
             for (int q = 0; q < 8; ++q)
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(hp[rw][4 * q]), __float_as_uint(hp[rw][4 * q + 1]), __float_as_uint(hp[rw][4 * q + 2]),
                                                              __float_as_uint(hp[rw][4 * q + 3])},
-                                                       rh, offh[rw] + (unsigned)q * (unsigned)(plane * 32), 0, 0);
+                                                       rh, offh[rw] + (unsigned)q * (unsigned)(plane * 32), 0, MRX_L2_NT_ST ? 2 : 0);
         }
         if (a.P || a.Q) {
             f32x16 accp[2];

@@ -557,7 +557,11 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
             // plane's LAST tile marks the channel, and the four waves merge the marked planes (usually none; all of a tile's channels for the last
             // tile of an image) -- no launch behind this one, nothing serial across the chip: the other images' tiles keep the CUs busy meanwhile
             int* flag = reinterpret_cast<int*>(red);                 // (the reductions above are done with `red`: every wave passed their last barrier)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the write-through stores above are acknowledged (s_waitcnt vmcnt(0)) before the tickets
+            // The statistics stores above are write-through (sc1) but asynchronous: a workgroup-scope release fence emits NO vmcnt wait on gfx950 (non-tgsplit
+            // mode), and the ticket below goes to another address and channel -- it could become visible first, and the workgroup of another XCD that takes the
+            // plane's last ticket would merge stale statistics.  The storing thread waits for its stores to be acknowledged, explicitly, before the barrier
+            // and the ticket (round-5 advisor finding; far cheaper than an agent-scope release, which would also write back the L2).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             int tk[NCOT][4];
             if (wave == 0 && l15 == 0) {

@@ -257,6 +257,31 @@ def test_eight_cascades_w372_final_image_ssim(dev):
     assert ssim >= 0.9999 and abs(ssim - chk) <= 1e-5, (ssim, chk)
 
 
+def test_headline_launch_shape_eight_slices_per_launch(dev):
+    """bench.py's default launch: EIGHT distinct slices per call (B = 8) at 15 x 640 x 372 -- 3 840 tiles = 15 exact rounds of the persistent layer kernels, the
+    batch index inside every kernel's tile decomposition, the batched operand preparation of mrx_llg372 -- one whole cascade (8 time-steps, two weight sets)
+    against the oracle slice by slice, and each slice of the batch against the same slice run alone (bit-identical: no kernel mixes batch elements)."""
+    for scale in (1.0, 5.0):
+        cfg, model, sd = _cirim(dict(num_cascades=1), scale)
+        slices = [synthetic.make_slice(15, 640, 372, slice_idx=10 + i) for i in range(8)]
+        y = torch.cat([s_["y"] for s_ in slices], 0)
+        S = torch.cat([s_["sensitivity_maps"] for s_ in slices], 0)
+        tgt = torch.cat([s_["target"] for s_ in slices], 0)
+        mask = slices[0]["mask"]
+        model = model.to(dev)
+        with torch.no_grad():
+            out = next(model(y.to(dev), S.to(dev), mask.to(dev), None, tgt.to(dev)))
+            one = next(model(y[5:6].to(dev), S[5:6].to(dev), mask.to(dev), None, tgt[5:6].to(dev)))
+        assert len(out) == 1 and len(out[0]) == 8 and tuple(out[0][-1].shape) == (8, 640, 372)
+        assert torch.equal(out[0][-1][5:6], one[0][-1])
+        for i in (0, 3, 7):                                        # (three of the eight on the CPU oracle: ~4 s each)
+            with torch.no_grad():
+                ref = oracle.models.cirim_forward(sd, cfg, y[i:i + 1], S[i:i + 1], mask, None, tgt[i:i + 1])
+            got = torch.view_as_real(torch.stack([o_[i:i + 1] for o_ in out[0]]))
+            want = torch.view_as_real(torch.stack(ref[0]))
+            assert_close(got, want, 2e-5, f"B = 8 launch, slice {i}, recurrent weights x{scale}")
+
+
 def test_g19_spec_fixture_and_harness_metrics(golden, dev):
     """The G6 fixture as SURVEY 8c specifies it ([1,15,64,48], 8 cascades, 64 filters; generated by the reference) through the model
     AND through the harness runner: post-processed image + MSE / NMSE / SSIM / PSNR (models/base.py:415-436)."""

@@ -245,3 +245,30 @@ def test_unet_conv3x3_statistics_merged_inside_the_launch(shape, dev):
             assert torch.equal(y2, y0) and torch.equal(n2, n1)          # (the merge itself is deterministic: fixed order, whoever runs it)
     finally:
         ops.UNET_FOLD_FINALIZE = keep
+
+
+def test_statistics_merged_inside_the_launch_under_stress(dev):
+    """The ticket that announces a tile's statistics must not overtake them (round-5 advisor finding: the write-through stores are now acknowledged --
+    s_waitcnt vmcnt(0) in the storing thread -- before the ticket is taken).  GPU sanitizers are not available on this pool: many small planes (tiles of one
+    plane spread over all XCDs, merges by whichever workgroup comes last), 200 launches back to back, every (mean, 1/std) pair compared with the separate
+    finalize launch's -- a stale statistic is an error of the size of the statistic, not of a rounding."""
+    from mridc_amd import ops
+    g = torch.Generator().manual_seed(99)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    keep = ops.UNET_FOLD_FINALIZE
+    try:
+        for B, C, H, W in ((24, 14, 40, 72), (6, 28, 96, 96), (64, 14, 8, 33)):
+            x, w = r(B, C, H, W) * 3 + 1.0, r(C, C, 3, 3) / (9 * C) ** 0.5
+            ops.UNET_FOLD_FINALIZE = False
+            y0, n0 = ops.unet_conv3x3(x, None, w)
+            ops.UNET_FOLD_FINALIZE = True
+            tol = 1e-6 * max(1.0, float(n0.abs().max()))
+            bad = 0
+            for rep in range(200 // (1 if B < 64 else 2)):
+                y1, n1 = ops.unet_conv3x3(x, None, w)
+                bad += int(((n1.double() - n0.double()).abs() > tol).sum())
+            assert bad == 0, (B, C, H, W, bad)
+            assert torch.equal(y1, y0)
+    finally:
+        ops.UNET_FOLD_FINALIZE = keep
+
