@@ -8,9 +8,9 @@
 // channel block = exactly one B operand of v_mfma_f32_32x32x16_f16).  With a third of the matrix work and half the state bytes both layers are HBM-bound:
 // the kernels are built around bytes in flight, not around MFMA issue.
 //
-//   k_amp_layer1: 16 waves per CU, a wave's unit = one image row x 32 pixels x 64 channels (as rim_layer1_sb.hip): 5 x 36 input patch (eta + the
-//                 coil-group partial sums of the gradient launch, or a 4-channel x) -> wave-private LDS, 7 + 4 MFMA steps x 2 cout blocks, h_prev requested
-//                 WITH the patch (16 registers of packed halves), 8-byte state accesses.
+//   k_amp_layer1_t: 8 waves per CU on a 16 x 32 tile, wave = two rows x 64 couts: the halo'd 20 x 36 input patch (eta + the coil-group partial sums of the
+//                 gradient launch, or a 4-channel x) of the NEXT tile and its h_prev are in flight during the whole of the current tile; 7 + 4 MFMA steps x 2 cout
+//                 blocks per row, 8-byte state accesses through buffer descriptors.
 //   k_amp_layer2: 8 waves per CU on a 16 x 32 tile, wave = two rows x 64 couts.  ALL weights of the layer stay in LDS for the life of the workgroup
 //                 (conv 72 KB + 1x1 8 KB + final conv 4 KB); the halo'd fp16 tile arrives two channel chunks (16 channels, 23 KB) at a time through a
 //                 two-deep register stage + two LDS buffers -- no conversion, no split: the global bytes ARE the B operands.  Nine MFMA steps per chunk
@@ -76,9 +76,6 @@ __device__ __forceinline__ int am_scale_exp(float m) {
 #define A1_K 5
 #define A1_PAD 2
 #define A1_PW (AM_TW + 2 * A1_PAD)
-#define A1_PPIX (A1_K * A1_PW)              // a wave's patch: 5 rows x 36 pixels
-#define A1_PSTR 184
-#define A1_PSLOT 3
 #define A1_KS 7                             // conv MFMA steps: 28 taps x 4 channels / 16
 #define A1_KS2 4
 #define A1_WCONV (A1_KS * 2 * 64)
@@ -126,18 +123,37 @@ struct Amp1Args {
     int abl;               // probe builds only
 };
 
+// ---- layer 1: workgroup-tile form ------------------------------------------------------------------------------------------------------------------
+// The first form of this layer was rim_layer1_sb.hip's: sixteen waves per CU, each walking its own image-row units start to finish.  Its phases ran one after the
+// other in every wave (patch loads, arithmetic, stores: the phase ablation was additive -- 6 + 5 + 4.5 + 7.6 us per slice for arithmetic / patch / h_prev / stores,
+// profiles/r06_amp16_layer_times_v1.txt -- the sixteen waves of a CU fall into step): 18.6 us per slice against 16.6 for this one on the same box
+// (profiles/r06_amp16_layer1_tile_form.txt), whose own ablation is what a bandwidth-bound kernel's looks like (time falls with the bytes removed).  Here a workgroup of
+// eight waves walks 16 x 32 tiles like layer 2: the halo'd 20 x 36 input patch of the NEXT tile and its h_prev are in flight (registers) during the whole of the
+// current tile, the stores of the current tile leave behind them -- the memory system always has a tile's worth of requests queued.  The patch sits in LDS as fp32
+// [pixel][4 channels] (read amplification 1.4 x instead of 5.6 x); the tile's power-of-two input scale comes from the waves' maxima left beside it, and the fp16
+// operands are formed by the wave that multiplies them.  One barrier per tile.
+#define A1T_NT 512
+#define A1T_PH (AM_TH + 2 * A1_PAD)         // 20
+#define A1T_NPIX (A1T_PH * A1_PW)           // 720
+#define A1T_XV 2                            // patch pixels per thread
+#define A1T_OFF_TAB (A1_PACK_U4 * 16)
+#define A1T_OFF_MAX (A1T_OFF_TAB + 768)     // [2][8] floats
+#define A1T_OFF_X (A1T_OFF_MAX + 64)        // [2][A1T_NPIX] float4
+#define A1T_LDS (A1T_OFF_X + 2 * A1T_NPIX * 16)
+
 template <int LLGT>
-__global__ __launch_bounds__(A1_NW * 64, 1) void k_amp_layer1(Amp1Args a) {
-    constexpr int NTHR = A1_NW * 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_a1[];
-    u32x4* Wl = reinterpret_cast<u32x4*>(smem_a1);
-    float* tabl = reinterpret_cast<float*>(smem_a1 + A1_PACK_U4 * 16);                   // hh, b_conv, b_ih in register order [half][R]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    u32x2* Xw = reinterpret_cast<u32x2*>(smem_a1 + A1_PACK_U4 * 16 + 192 * 4) + wave * A1_PSTR;   // this wave's patch: [pixel][4 channels] halves
+__global__ __launch_bounds__(A1T_NT, 1) void k_amp_layer1_t(Amp1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_a1t[];
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem_a1t);
+    float* tabl = reinterpret_cast<float*>(smem_a1t + A1T_OFF_TAB);
+    float* tmax = reinterpret_cast<float*>(smem_a1t + A1T_OFF_MAX);
+    float4* Xf = reinterpret_cast<float4*>(smem_a1t + A1T_OFF_X);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const long long plane = (long long)a.H * a.W;
     const int total = a.ntiles * a.B;
 
-    for (int i = tid; i < A1_PACK_U4; i += NTHR) Wl[i] = a.packed[i];
+    for (int i = tid; i < A1_PACK_U4; i += A1T_NT) Wl[i] = a.packed[i];
     if (tid < 64) {
         const int tc = am_chan(tid >> 1, tid & 1);
         const int ti = (tid & 1) * 32 + (tid >> 1);
@@ -145,115 +161,147 @@ __global__ __launch_bounds__(A1_NW * 64, 1) void k_amp_layer1(Amp1Args a) {
         tabl[64 + ti] = a.b_conv ? a.b_conv[tc] : 0.f;
         tabl[128 + ti] = a.b_ih ? a.b_ih[tc] : 0.f;
     }
-    __syncthreads();      // the only workgroup barrier
 
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const int tt = (int)mrx_xcd_band(t, total);
-        const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
-        const int oy = ty0 * A1_NW + wave, w0 = (tile - ty0 * a.tiles_x) * AM_TW;
-        if (oy >= a.H) continue;             // wave-uniform: rows past the image (H % 16 != 0)
-        const int ox = w0 + l31, cx = ox < a.W ? ox : a.W - 1;
-
-        // ---- the unit's raw patch (replicate border = clamp, conv_layers.py:72-76) and its h_prev, all requested together --------------------------
-        float raw[A1_PSLOT][10];
+    constexpr int NRAW = LLGT > 0 ? 10 : 4;
+    auto tile_of = [&](int t, int& b, int& h0, int& w0) {
+        const int tq = t < total ? t : total - 1;           // (beyond the last tile the pipeline keeps requesting the last tile: in range, never used)
+        const int tt = (int)mrx_xcd_band(tq, total);
+        b = tt / a.ntiles;
+        const int tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
+        h0 = ty0 * AM_TH, w0 = (tile - ty0 * a.tiles_x) * AM_TW;
+    };
+    auto request_patch = [&](int t, float (&raw)[A1T_XV][NRAW]) {
+        int b, h0, w0;
+        tile_of(t, b, h0, w0);
 #pragma unroll
-        for (int q = 0; q < A1_PSLOT; ++q) {
-            int p = lane + 64 * q;
-            p = p < A1_PPIX ? p : A1_PPIX - 1;
+        for (int v = 0; v < A1T_XV; ++v) {
+            int p = tid + v * A1T_NT;
+            p = p < A1T_NPIX ? p : A1T_NPIX - 1;
             const int ty = p / A1_PW, tx = p - ty * A1_PW;
-            int gy = oy + ty - A1_PAD, gx = w0 + tx - A1_PAD;
+            int gy = h0 + ty - A1_PAD, gx = w0 + tx - A1_PAD;            // replicate border = clamp (conv_layers.py:72-76)
             gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
             gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
             const unsigned off = (unsigned)(gy * a.W + gx);
             if (AM_ABL(a, 1)) {
 #pragma unroll
-                for (int k = 0; k < 10; ++k) raw[q][k] = (float)(off & 7u);
+                for (int k = 0; k < NRAW; ++k) raw[v][k] = (float)(off & 7u);
             } else if constexpr (LLGT > 0) {
                 const float2 e = a.eta2[(long long)b * plane + off];
-                raw[q][0] = e.x, raw[q][1] = e.y;
+                raw[v][0] = e.x, raw[v][1] = e.y;
                 const float2* pp = a.part + (long long)b * plane;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float2 v = pp[(long long)(k < a.nparts ? k : 0) * a.part_stride + off];
-                    raw[q][2 + 2 * k] = v.x, raw[q][3 + 2 * k] = v.y;
+                    const float2 u = pp[(long long)(k < a.nparts ? k : 0) * a.part_stride + off];
+                    raw[v][2 + 2 * k] = u.x, raw[v][3 + 2 * k] = u.y;
                 }
             } else {
                 const float* xb = a.x + (long long)b * a.Cin * plane;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) raw[q][c] = xb[(c < a.Cin ? c * plane : 0) + off];
+                for (int c = 0; c < 4; ++c) raw[v][c] = xb[(c < a.Cin ? c * plane : 0) + off];
             }
         }
-        u32x2 hp[8];                         // registers 4 q .. 4 q + 3 of this lane = channels 8 q + 4 lhi .. + 3: four halves
-        if (a.hprev && !AM_ABL(a, 2)) {
-            const u32x2* hb = reinterpret_cast<const u32x2*>(a.hprev + ((long long)b * AM_F * plane + ((long long)oy * a.W + cx) * 8 + 4 * lhi));
+    };
+    auto request_hp = [&](int t, u32x2 (&hp)[2][8]) {
+        int b, h0, w0;
+        tile_of(t, b, h0, w0);
+        const int ox = w0 + l31, cx = ox < a.W ? ox : a.W - 1;
+        // (buffer descriptor + 32-bit offsets: sixteen 64-bit addresses per lane were what the register allocator spilled)
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.hprev ? a.hprev : a.hnew) + (long long)b * AM_F * plane, 0,
+                                                                            (unsigned)(plane * (AM_F * 2)), 0x00020000);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) hp[q] = MRX_AMP_NT_LD ? __builtin_nontemporal_load(hb + (long long)q * plane * 2) : hb[(long long)q * plane * 2];
-        } else {
+        for (int rw = 0; rw < 2; ++rw) {
+            const int oy = h0 + 2 * wave + rw, cy = oy < a.H ? oy : a.H - 1;
+            const unsigned off = (a.hprev && !AM_ABL(a, 2)) ? (unsigned)((((long long)cy * a.W + cx) * 8 + 4 * lhi) * 2) : 0x80000000u;   // (the zero state: out of range reads 0)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) hp[q] = u32x2{0u, 0u};
+            for (int q = 0; q < 8; ++q)
+                hp[rw][q] = __builtin_amdgcn_raw_buffer_load_b64(rp, off, (unsigned)q * (unsigned)(plane * 16), MRX_AMP_NT_LD ? 2 : 0);
         }
-        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the state requests behind the patch's s_waitcnt: one latency after the other)
-
-        // ---- finish the patch (the last step of log_likelihood_gradient, rim_utils.py:61-67: same order of additions as rim_layer1_sb.hip), scale it
-        // by the power of two that puts the unit's largest input into [2^14, 2^15) (exact; taken back after the convolution), round to fp16 ---------------
-        float cc[A1_PSLOT][4];
-#pragma unroll
-        for (int q = 0; q < A1_PSLOT; ++q) {
-            if constexpr (LLGT > 0) {
-                float sx = raw[q][2], sy = raw[q][3];
-#pragma unroll
-                for (int k = 1; k < 4; ++k)
-                    if (k < a.nparts) sx += raw[q][2 + 2 * k], sy += raw[q][3 + 2 * k];
-                cc[q][0] = raw[q][0], cc[q][1] = raw[q][1], cc[q][2] = sx * a.post, cc[q][3] = sy * a.post;
-            } else {
-                cc[q][0] = raw[q][0];
-                cc[q][1] = a.Cin > 1 ? raw[q][1] : 0.f;
-                cc[q][2] = a.Cin > 2 ? raw[q][2] : 0.f;
-                cc[q][3] = a.Cin > 3 ? raw[q][3] : 0.f;
-            }
-        }
+    };
+    // finish the patch (the last step of log_likelihood_gradient, rim_utils.py:61-67: same order of additions as the wave-private form), leave it in LDS as
+    // fp32 and this wave's largest |input| beside it
+    auto commit = [&](const float (&raw)[A1T_XV][NRAW], int buf) {
         float m = 0.f;
 #pragma unroll
-        for (int q = 0; q < A1_PSLOT; ++q)
+        for (int v = 0; v < A1T_XV; ++v) {
+            float c0, c1, c2, c3;
+            if constexpr (LLGT > 0) {
+                float sx = raw[v][2], sy = raw[v][3];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) m = fmaxf(m, fabsf(cc[q][c]));
+                for (int k = 1; k < 4; ++k)
+                    if (k < a.nparts) sx += raw[v][2 + 2 * k], sy += raw[v][3 + 2 * k];
+                c0 = raw[v][0], c1 = raw[v][1], c2 = sx * a.post, c3 = sy * a.post;
+            } else {
+                c0 = raw[v][0];
+                c1 = a.Cin > 1 ? raw[v][1] : 0.f;
+                c2 = a.Cin > 2 ? raw[v][2] : 0.f;
+                c3 = a.Cin > 3 ? raw[v][3] : 0.f;
+            }
+            const int p = tid + v * A1T_NT;
+            if (p < A1T_NPIX) {
+                Xf[buf * A1T_NPIX + p] = make_float4(c0, c1, c2, c3);
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(c0), fabsf(c1)), fmaxf(fabsf(c2), fabsf(c3))));
+            }
+        }
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) tmax[buf * 8 + wave] = m;
+    };
+
+    float raw[A1T_XV][NRAW];
+    u32x2 hpA[2][8], hpB[2][8];
+    request_patch(blockIdx.x, raw);
+    request_hp(blockIdx.x, hpA);
+    commit(raw, 0);
+    request_patch(blockIdx.x + gridDim.x, raw);
+    __syncthreads();
+
+    auto body = [&](int it, int t, u32x2 (&hp_cur)[2][8], u32x2 (&hp_nxt)[2][8]) {
+        int b, h0, w0;
+        tile_of(t, b, h0, w0);
+        const int buf = it & 1;
+        float m = tmax[buf * 8];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) m = fmaxf(m, tmax[buf * 8 + k]);
         const int kx = am_scale_exp(m);
         const float sxu = am_pow2(kx), unx = am_pow2(-kx);
-#pragma unroll
-        for (int q = 0; q < A1_PSLOT; ++q) {
-            const int p = lane + 64 * q;
-            if (p < A1_PPIX) Xw[p] = u32x2{am_pk(cc[q][0] * sxu, cc[q][1] * sxu), am_pk(cc[q][2] * sxu, cc[q][3] * sxu)};
-        }
-        // wave-private LDS: program order is enough, no barrier
+        request_hp(t + gridDim.x, hp_nxt);               // the next tile's state: in flight during the whole of this tile
+        __builtin_amdgcn_sched_barrier(0);
 
-        // ---- conv 5x5 ----------------------------------------------------------------------------------------------------------------------------------
-        f32x16 acc[2];
+        // ---- conv 5x5, both rows of the wave ----------------------------------------------------------------------------------------------------------
+        f32x16 acc[2][2];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int rw = 0; rw < 2; ++rw)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rw][ct][r] = 0.f;
         {
-            const u32x2* xw = Xw + l31;
+            const float4* xw = Xf + buf * A1T_NPIX + (2 * wave) * A1_PW + l31;
             const u32x4* wl = Wl + lane;
 #pragma unroll
             for (int s = 0; s < A1_KS; ++s) {
-                auto toff = [](int tp) { return tp < A1_K * A1_K ? (tp / A1_K) * A1_PW + (tp % A1_K) : 0; };   // zero-weight taps read pixel 0
+                auto toff = [](int tp) { return tp < A1_K * A1_K ? (tp / A1_K) * A1_PW + (tp % A1_K) : 0; };   // zero-weight taps read pixel 0 of the wave's rows
                 const int offA = lhi ? toff(4 * s + 2) : toff(4 * s), offB = lhi ? toff(4 * s + 3) : toff(4 * s + 1);
-                const u32x2 lo = xw[offA], hi = xw[offB];
-                const f16x8 bt = __builtin_bit_cast(f16x8, (u32x4{lo.x, lo.y, hi.x, hi.y}));
+                const f16x8 a0 = __builtin_bit_cast(f16x8, wl[(s * 2 + 0) * 64]), a1 = __builtin_bit_cast(f16x8, wl[(s * 2 + 1) * 64]);
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl[(s * 2 + ct) * 64]), bt, acc[ct], 0, 0, 0);
+                for (int rw = 0; rw < 2; ++rw) {
+                    const float4 lo = xw[rw * A1_PW + offA], hi = xw[rw * A1_PW + offB];
+                    const f16x8 bt = __builtin_bit_cast(f16x8, (u32x4{am_pk(lo.x * sxu, lo.y * sxu), am_pk(lo.z * sxu, lo.w * sxu),
+                                                                      am_pk(hi.x * sxu, hi.y * sxu), am_pk(hi.z * sxu, hi.w * sxu)}));
+                    acc[rw][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bt, acc[rw][0], 0, 0, 0);
+                    acc[rw][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bt, acc[rw][1], 0, 0, 0);
+                }
             }
         }
-        // ---- g = ReLU(conv + b) rounded to fp16 (what an autocast convolution returns), 1x1 from registers ---------------------------------------------
-        f32x16 acc2[2];
+        // ---- per row: g = ReLU(conv + b) -> fp16, 1x1 from registers, h = ReLU(W_ih g + b_ih + hh * h_prev) -> fp16 ------------------------------------------
+        const int ox = w0 + l31;
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hnew + (long long)b * AM_F * plane, 0, (unsigned)(plane * (AM_F * 2)), 0x00020000);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int rw = 0; rw < 2; ++rw) {
+            f32x16 acc2[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[ct][r] = tabl[128 + lhi * 32 + ct * 16 + r];
-        {
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[ct][r] = tabl[128 + lhi * 32 + ct * 16 + r];
             const u32x4* wl = Wl + A1_WCONV + lane;
 #pragma unroll
             for (int s = 0; s < A1_KS2; ++s) {
@@ -261,7 +309,7 @@ __global__ __launch_bounds__(A1_NW * 64, 1) void k_amp_layer1(Amp1Args a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int R0 = 8 * s + 2 * q, R1 = R0 + 1;
-                    float v0 = acc[R0 >> 4][R0 & 15] * unx + tabl[64 + lhi * 32 + R0], v1 = acc[R1 >> 4][R1 & 15] * unx + tabl[64 + lhi * 32 + R1];
+                    float v0 = acc[rw][R0 >> 4][R0 & 15] * unx + tabl[64 + lhi * 32 + R0], v1 = acc[rw][R1 >> 4][R1 & 15] * unx + tabl[64 + lhi * 32 + R1];
                     v0 = v0 > 0.f ? v0 : 0.f;
                     v1 = v1 > 0.f ? v1 : 0.f;
                     g[q] = am_pk(v0, v1);
@@ -271,25 +319,30 @@ __global__ __launch_bounds__(A1_NW * 64, 1) void k_amp_layer1(Amp1Args a) {
                 for (int ct = 0; ct < 2; ++ct)
                     acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl[(s * 2 + ct) * 64]), bt, acc2[ct], 0, 0, 0);
             }
-        }
-        // ---- h = ReLU(W_ih g + b_ih + hh * h_prev) (rnn_cells.py:384-391), stored as fp16 -----------------------------------------------------------------
-        if (ox < a.W && !AM_ABL(a, 4)) {
-            u32x2* ob = reinterpret_cast<u32x2*>(a.hnew + ((long long)b * AM_F * plane + ((long long)oy * a.W + ox) * 8 + 4 * lhi));
+            const int oy = h0 + 2 * wave + rw;
+            const unsigned offh = (oy < a.H && ox < a.W && !AM_ABL(a, 4)) ? (unsigned)((((long long)oy * a.W + ox) * 8 + 4 * lhi) * 2) : 0x80000000u;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
+                const float hv[4] = {am_lo(hp_cur[rw][q].x), am_hi(hp_cur[rw][q].x), am_lo(hp_cur[rw][q].y), am_hi(hp_cur[rw][q].y)};
                 float v[4];
-                const float h0 = am_lo(hp[q].x), h1 = am_hi(hp[q].x), h2 = am_lo(hp[q].y), h3 = am_hi(hp[q].y);
-                const float hv[4] = {h0, h1, h2, h3};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int R = 4 * q + i;
                     v[i] = acc2[R >> 4][R & 15] + tabl[lhi * 32 + R] * hv[i];
                     v[i] = v[i] > 0.f ? v[i] : 0.f;
                 }
-                if (MRX_AMP_NT_ST) __builtin_nontemporal_store((u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])}), ob + (long long)q * plane * 2);
-                else ob[(long long)q * plane * 2] = u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])};
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])}, rh, offh + (unsigned)q * (unsigned)(plane * 16), 0, MRX_AMP_NT_ST ? 2 : 0);
             }
         }
+        // the next tile's patch (requested a tile ago) into the other buffer, the one after it requested
+        commit(raw, buf ^ 1);
+        request_patch(t + 2 * gridDim.x, raw);
+        __syncthreads();
+    };
+    int it = 0;
+    for (int t = blockIdx.x; t < total; t += 2 * gridDim.x, it += 2) {
+        body(it, t, hpA, hpB);
+        if (t + (int)gridDim.x < total) body(it + 1, t + gridDim.x, hpB, hpA);
     }
 }
 
@@ -660,17 +713,16 @@ extern "C" int mrx_amp16_layer1(const float* x, int Cin, const float* eta, const
     a.hprev = reinterpret_cast<const _Float16*>(h_prev), a.hnew = reinterpret_cast<_Float16*>(h_new);
     a.B = B, a.Cin = eta ? 4 : Cin, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, AM_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, A1_NW);
     a.abl = MRX_DEBUG_ENV("MRX_AMP_ABL") ? atoi(MRX_DEBUG_ENV("MRX_AMP_ABL")) : 0;
-    constexpr size_t lds = (size_t)A1_PACK_U4 * 16 + 192 * 4 + (size_t)A1_NW * A1_PSTR * 8;
     static bool attr_done = false;   // once: keeps launches legal under hipGraph capture
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_amp_layer1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_amp_layer1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_amp_layer1_t<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A1T_LDS);
+        (void)hipFuncSetAttribute((const void*)k_amp_layer1_t<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A1T_LDS);
         attr_done = true;
     }
     const long long total = (long long)a.ntiles * B;
     const int ncu = am_ncu(), grid = (int)(total < ncu ? total : ncu);
-    if (eta) hipLaunchKernelGGL(k_amp_layer1<1>, dim3(grid), dim3(A1_NW * 64), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_amp_layer1<0>, dim3(grid), dim3(A1_NW * 64), lds, (hipStream_t)stream, a);
+    if (eta) hipLaunchKernelGGL(k_amp_layer1_t<1>, dim3(grid), dim3(A1T_NT), A1T_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_amp_layer1_t<0>, dim3(grid), dim3(A1T_NT), A1T_LDS, (hipStream_t)stream, a);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
