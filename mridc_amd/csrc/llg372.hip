@@ -16,6 +16,12 @@
 
 #include "mrx_common.h"
 #include "pfa372.h"
+// cache policy of the sensitivity-map stream (nt: streaming): 28.6 MB per slice re-read by every RIM step, each time behind > 1 GB of other traffic at 8 slices per
+// launch -- it never hits the 256 MB memory-side cache and only evicts what the next launch is about to read.  Round 6, A/B builds alternating on one box
+// (tools/runs/r06h.sh): fp32-class headline 154.8 / 154.0 without, 154.3 / 154.2 with (neutral); precision-16 line 297.2 / 295.3 without, 300.0 / 298.7 with (+1 %): on.
+#ifndef MRX_LLG_NT_MAPS
+#define MRX_LLG_NT_MAPS 1
+#endif
 
 #define L372_TASK_C2 (PFA_N * PFA_G)   // 1860 float2 per task in Sp and in ytp
 #define L372_LDS_BYTES (sizeof(float2) * PFA_LDS_C2 + sizeof(float) * PFA_N)
@@ -157,7 +163,13 @@ __global__ __launch_bounds__(64, 2) void k_llg372(const float2* __restrict__ eta
     auto load_maps = [&]() {
         const pfa_c* sp = Sp + (long long)task * L372_TASK_C2 + min(l, PFA_L1 - 1);
 #pragma unroll
-        for (int n2 = 0; n2 < 31; ++n2) L.s[n2] = ABL == 2 ? pfa_mk((float)(l + n2), 0.25f) : sp[n2 * PFA_L1];
+        for (int n2 = 0; n2 < 31; ++n2)
+            if (ABL == 2) L.s[n2] = pfa_mk((float)(l + n2), 0.25f);
+            else if (MRX_LLG_NT_MAPS) {
+                typedef float llg_f2 __attribute__((ext_vector_type(2)));
+                const llg_f2 u = __builtin_nontemporal_load(reinterpret_cast<const llg_f2*>(sp + n2 * PFA_L1));
+                L.s[n2] = pfa_mk(u.x, u.y);
+            } else L.s[n2] = sp[n2 * PFA_L1];
     };
     if (GAT) load_maps();       // the maps are requested BEFORE the gather's 114 dependent loads: they arrive under it
     if (GAT) {

@@ -48,6 +48,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef MRX_AMP_NT_LD
 #define MRX_AMP_NT_LD 1
 #endif
+// ... layer 1's h_new stores on their own (layer 2 of the same step reads them back in the next launch: 244 MB at 8 slices per launch, about the size of the cache)
+#ifndef MRX_AMP_NT_ST1
+#define MRX_AMP_NT_ST1 MRX_AMP_NT_ST
+#endif
 // layer 2: the chunk pair at whose start a tile's h_prev is requested (consumed by the epilogue behind pair 3; no h_prev loads at all measured 6 us per slice faster
 // than requesting them at pair 3: their latency was exposed)
 #ifndef MRX_AMP_HP_AT
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(A1T_NT, 1) void k_amp_layer1_t(Amp1Args a) {
                     v[i] = acc2[R >> 4][R & 15] + tabl[lhi * 32 + R] * hv[i];
                     v[i] = v[i] > 0.f ? v[i] : 0.f;
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])}, rh, offh + (unsigned)q * (unsigned)(plane * 16), 0, MRX_AMP_NT_ST ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])}, rh, offh + (unsigned)q * (unsigned)(plane * 16), 0, MRX_AMP_NT_ST1 ? 2 : 0);
             }
         }
         // the next tile's patch (requested a tile ago) into the other buffer, the one after it requested
