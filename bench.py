@@ -1672,7 +1672,7 @@ def main():
             import copy
             others = {}
             for name, fn, over in (("e2evn_6cascade_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=8, streams=2, steps=6, warmup=2)),
-                                   ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=2, steps=10, warmup=2))):
+                                   ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=4, steps=10, warmup=2))):
                 a2 = copy.copy(args)
                 for k_, v_ in over.items():
                     setattr(a2, k_, v_)

@@ -65,3 +65,37 @@ def test_mixed_precision_oracles_against_the_fp32_oracle(seed, boost):
     for m in ("autocast_bf16", "bf16_operands"):
         assert abs(float(res[m][0]) - float(loss.detach())) <= 2e-2 * abs(float(loss.detach()))
     assert all(g.dtype == torch.float32 for g in res["autocast_bf16"][1].values())
+
+
+def test_precision16_inference_checkers_against_their_definitions_and_the_fp32_oracle():
+    """The two checkers of the precision-16 inference route (csrc/rim_amp16.hip): `autocast_fp16` is torch's own CPU autocast (the reference's `precision: 16`,
+    base_cirim_run.yaml:132: convolutions return half tensors, the recurrence and eta stay fp32); `fp16_kernel_arithmetic` restates the kernels -- a convolution is
+    the float64 product of fp16-rounded operands with an fp32 result, a recurrent cell's new state is rounded to fp16 once.  Both sit ~1e-5 .. 1e-3 from the fp32
+    oracle on the final image and closer to each other than to it on boosted weights; outside the context the oracle is the fp32 oracle again."""
+    import contextlib
+    torch.manual_seed(0)
+    x, w, b = torch.randn(2, 5, 12, 11), torch.randn(7, 5, 3, 3) / 4, torch.randn(7)
+    r16 = oracle.amp.fp16_round
+    assert r16(r16(x)).equal(r16(x)) and float(((r16(x) - x) / x).abs().max()) <= 2.0 ** -11            # round to nearest: half an ulp of 11 significant bits
+    with oracle.amp.fp16_kernel_arithmetic():
+        y = oracle.rim._conv2d(x, w, b, padding=2, dilation=2)
+        h = oracle.rim.indrnn_cell(x[:, :5], torch.zeros(2, 7, 12, 11), torch.randn(7, 5, 1, 1), None, torch.ones(1, 7, 1, 1), 1, 1)
+    want = F.conv2d(r16(x).double(), r16(w).double(), b.double(), padding=2, dilation=2)
+    assert y.dtype == torch.float32 and float((y.double() - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    assert h.equal(r16(h))                                                                                  # the state is fp16-representable
+    assert oracle.rim._CONV2D[0] is F.conv2d and oracle.rim._STATE[0](x) is x                               # hooks restored
+    with oracle.amp.autocast_fp16():
+        assert F.conv2d(x, w, b, padding=1).dtype == torch.float16 and (torch.ones(1, 7, 1, 1) * F.conv2d(x, w, b, padding=1)).dtype == torch.float32
+    for boost in (1.0, 5.0):
+        cfg = dict(synthetic.CIRIM_BASELINE_CFG, num_cascades=2)
+        state = _state(cfg, 0, boost)
+        s = synthetic.make_slice(4, 48, 40, slice_idx=7)
+        out = {}
+        for name, ctx in (("fp32", contextlib.nullcontext), ("autocast_fp16", oracle.amp.autocast_fp16), ("kernel", oracle.amp.fp16_kernel_arithmetic)):
+            with ctx(), torch.no_grad():
+                out[name] = torch.view_as_real(oracle.models.cirim_forward(state, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"])[-1][-1].to(torch.complex64)).double()
+        rel = lambda a, b_: float((a - b_).norm() / b_.norm())  # noqa: E731
+        d_ac, d_k, d_ak = rel(out["autocast_fp16"], out["fp32"]), rel(out["kernel"], out["fp32"]), rel(out["kernel"], out["autocast_fp16"])
+        assert 1e-7 < d_ac < 3e-3 and 1e-7 < d_k < 3e-3, (boost, d_ac, d_k)
+        assert d_ak < 2.0 * max(d_ac, d_k), (boost, d_ak, d_ac, d_k)
+

@@ -45,6 +45,15 @@ for _ in range(3):
 torch.cuda.synchronize()
 if MASK2D:
     sys.exit(0)
+# round 6: the precision-16 route's two layer kernels at the same launch shape (fp16 channel-blocked states; mrx_amp16_layer1 / _layer2)
+a1, a2 = ops.amp16_layer1_pack(r(F, 4, 5, 5) / 10, wi), ops.amp16_layer2_pack(wc, wi, wf)
+hp16 = ops.amp16_from_nchw(hp.relu())
+part4, n4 = ops.llg372(eta, op, 1.0, "backward", parts=True)
+torch.cuda.synchronize()
+for _ in range(3):
+    h16 = ops.amp16_layer1(None, eta, part4, n4, 1.0, a1, bc, bi, hh, hp16)
+    ops.amp16_layer2(h16, a2, bc, bi, hh, hp16)
+torch.cuda.synchronize()
 # E2EVN's dominant launch at the default line's batch: the 14 -> 14 convolution of the first U-Net level, 8 x 640 x 380 (k_uconv_h<1, 1, true>)
 A14 = r(8, 14, 640, 380)
 nA = torch.stack([A14.mean((2, 3)), 1 / torch.sqrt(A14.var((2, 3), unbiased=False) + 1e-5)], -1)

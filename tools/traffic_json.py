@@ -19,6 +19,8 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "conv_layer2_sb": ["k_rim_layer2_sb<2, true, false, false"],
     "conv_layer2_f16": ["k_rim_layer2_sb<2, true, false, true"],
     "final": ["k_rim_final4"],
+    "amp_layer1": ["k_amp_layer1_t"],          # round 6: the precision-16 route (csrc/rim_amp16.hip)
+    "amp_layer2": ["k_amp_layer2"],
     "final_gather": ["k_l2sb_gather"],
     "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_cols_dc_t4<", "k_rows_reduce<1", "k_pfa372_expand", "k_pfa372_reduce", "k_llg372_combine"],   # (r04: the deferred form without y)
     # round 4 (tools/probe/pmc_r04.py): dominant kernels of the other configurations, each at its own shape (`at`)
