@@ -223,6 +223,40 @@ def test_full_size_rim_block_precision16_against_the_three_oracles(dev, scale, m
         assert meas[name][2] <= 1e-3 and meas[name][3] <= 1e-3 + 10 * tol[name], (name, meas[name])
 
 
+@pytest.mark.parametrize("shape", [(6, 37, 75), (4, 48, 40), (15, 24, 320)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("mask", ["1d", "2d"])
+def test_rim_block_precision16_at_other_sizes(dev, shape, mask):
+    """Away from W = 372 the gradient is its own [B,4,H,W] tensor (mrx_llg_hinv / mrx_llg) and layer 1 takes the x form; odd sizes, ragged tiles, two slices per call,
+    states handed from one block call to the next (fp32 [B,64,H,W] at the API, fp16 inside): against the kernel-arithmetic oracle and under autocast."""
+    C, H, W = shape
+    cfg, model, sd = _cirim(dict(num_cascades=2), 3.0, seed=4)
+    sl = [synthetic.make_slice(C, H, W, slice_idx=20 + i) for i in range(2)]
+    y, S = torch.cat([s_["y"] for s_ in sl], 0), torch.cat([s_["sensitivity_maps"] for s_ in sl], 0)
+    m = sl[0]["mask"]
+    if mask == "2d":
+        g = torch.Generator().manual_seed(9)
+        m = torch.rand(1, 1, H, W, 1, generator=g) < 0.3
+        y = torch.cat([s_["kspace"] for s_ in sl], 0) * m
+    rc = _rim_cfg(cfg)
+    p0 = {k[len("cirim.0."):]: v for k, v in sd.items() if k.startswith("cirim.0.")}
+    p1 = {k[len("cirim.1."):]: v for k, v in sd.items() if k.startswith("cirim.1.")}
+    refs = {}
+    for name, ctx in (("autocast_fp16", oracle.amp.autocast_fp16), ("kernel_arithmetic", oracle.amp.fp16_kernel_arithmetic)):
+        with ctx(), torch.no_grad():
+            e0, h0 = oracle.rim.rim_block_forward(p0, rc, y, y, S, m, None, None, 1.0, False)
+            e1, h1 = oracle.rim.rim_block_forward(p1, rc, e0, y, S, m, e0[-1], h0, 1.0, True)
+        refs[name] = (torch.stack([t.float() for t in e0 + e1]), [t.float() for t in h1])
+    b0, b1 = model.cirim[0].to(dev), model.cirim[1].to(dev)
+    b0.precision = b1.precision = 16
+    with torch.no_grad():
+        g0, gh0 = b0(y.to(dev), y.to(dev), S.to(dev), m.to(dev), None, None, 1.0, keep_eta=False)
+        g1, gh1 = b1(g0, y.to(dev), S.to(dev), m.to(dev), g0[-1], gh0, 1.0, keep_eta=True)
+    got = torch.stack(list(g0) + list(g1))
+    assert rel_l2(got, refs["kernel_arithmetic"][0]) <= 2e-4 and rel_l2(got, refs["autocast_fp16"][0]) <= 2e-3, (rel_l2(got, refs["kernel_arithmetic"][0]), rel_l2(got, refs["autocast_fp16"][0]))
+    for j in range(2):
+        assert gh1[j].dtype == torch.float32 and rel_l2(gh1[j], refs["kernel_arithmetic"][1][j]) <= 2e-3, rel_l2(gh1[j], refs["kernel_arithmetic"][1][j])
+
+
 def test_eight_cascades_precision16_final_image(dev):
     """All 8 cascades x 8 time-steps (BASELINE.json's headline model) at 1 x 15 x 128 x 372 with `precision: 16` handed in through the trainer, as the reference
     does: final image against the oracle under torch.autocast(float16) and in fp32 -- SURVEY appendix C's bound for the fast mode (rel-L2 <= 3e-2, SSIM >= 0.99)
