@@ -1196,6 +1196,7 @@ def streamed_inputs_run(args, step, hosts, datas, dev, slices_per_step, variant=
 
 
 NUMA_BINDING = None      # {"node", "cpus"} once main() has bound the rank to its GPU's NUMA node
+NUMA_BINDING_ALL = None  # the same for every rank (gathered once the process group exists)
 
 
 def precision16_record(args, cfg, model, state_dict, timer, host, out, elapsed, per_rank, world, NS, B, graphed, conc_ok):
@@ -1298,6 +1299,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        global NUMA_BINDING_ALL
+        try:                                                    # every rank's binding on the line, not only rank 0's (a wrong guess pins a rank to the far socket)
+            got = [None] * world
+            dist.all_gather_object(got, NUMA_BINDING)
+            NUMA_BINDING_ALL = got
+        except Exception:  # noqa: BLE001
+            NUMA_BINDING_ALL = None
 
     from mridc_amd import ops, synthetic
     from mridc_amd.collections.reconstruction.models.cirim import CIRIM
@@ -1627,7 +1635,7 @@ def main():
                                mask=("1-D random columns R=4 (row-invariant: one-launch gradient)" if args.mask == "1d" else
                                      "2-D random points R~10 (general three-launch gradient)")),
                    world_size_seen=world_seen(), per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
-                   numa_binding=NUMA_BINDING,                 # rank 0's: the NUMA node of its GPU and the CPUs it was restricted to (None: topology unreadable)
+                   numa_binding=NUMA_BINDING_ALL if NUMA_BINDING_ALL is not None else NUMA_BINDING,   # per rank: the NUMA node of its GPU and the CPUs it was restricted to (None: topology unreadable or its two sources disagree)
                    launch="hipGraph replay" if graphed else "eager", roofline=roofline, roofline_fft=roofline_fft,
                    breakdown_ms=dict(llg=llg_per_step, conv_layer1=ms1, conv_layer2=ms2, final=final_per_step,
                                      rim_steps_per_slice=cfg["num_cascades"] * T_,

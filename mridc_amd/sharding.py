@@ -36,27 +36,52 @@ def _kfd_props(path):
         return None
 
 
+def _pci_numa_node(sysfs, props):
+    """NUMA node of the PCI function a KFD GPU node names (`domain`, `location_id` = bus << 8 | devfn): /sys/bus/pci/devices/DDDD:BB:DD.F/numa_node, or None."""
+    import os
+    try:
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        if loc <= 0:
+            return None
+        name = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+        with open(os.path.join(sysfs, "bus/pci/devices", name, "numa_node")) as f:
+            n = int(f.read().strip())
+        return n if n >= 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def gpu_numa_nodes(sysfs="/sys"):
-    """[NUMA node id or None] per GPU this process may open, in device order."""
+    """[NUMA node id or None] per GPU this process may open, in device order.  Two sources that must agree: the KFD topology (a CPU node lists its GPUs as PCIe
+    io_links; the i-th KFD CPU node is taken to be the i-th NUMA node THAT HAS CPUS -- memory-only nodes are skipped) and the GPU's PCI function
+    (`numa_node` in sysfs).  Where both speak and disagree the answer is None: a rank is never pinned on a guess."""
     import os
     base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
     try:
         ids = sorted(int(n) for n in os.listdir(base) if n.isdigit())
     except OSError:
         return []
+    numa_ids = []
     try:
-        numa_ids = sorted(int(n[4:]) for n in os.listdir(os.path.join(sysfs, "devices/system/node")) if n.startswith("node") and n[4:].isdigit())
+        for n in sorted(int(n[4:]) for n in os.listdir(os.path.join(sysfs, "devices/system/node")) if n.startswith("node") and n[4:].isdigit()):
+            try:
+                with open(os.path.join(sysfs, f"devices/system/node/node{n}/cpulist")) as f:
+                    if f.read().strip():
+                        numa_ids.append(n)
+            except OSError:
+                pass
     except OSError:
         numa_ids = []
-    owner, gpus, n_cpu = {}, [], 0
+    owner, gpus, pci, n_cpu = {}, [], {}, 0
     for n in ids:
         p = _kfd_props(os.path.join(base, str(n), "properties"))
         if p is None:
             continue
         if int(p.get("simd_count", "0")) > 0:
             gpus.append(n)
+            pci[n] = _pci_numa_node(sysfs, p)
         elif int(p.get("cpu_cores_count", "0")) > 0:
-            numa = numa_ids[n_cpu] if n_cpu < len(numa_ids) else None      # the i-th CPU node of the KFD topology is the i-th NUMA node
+            numa = numa_ids[n_cpu] if n_cpu < len(numa_ids) else None
             n_cpu += 1
             links = os.path.join(base, str(n), "io_links")
             try:
@@ -67,7 +92,11 @@ def gpu_numa_nodes(sysfs="/sys"):
                 lp = _kfd_props(os.path.join(links, ln, "properties"))
                 if lp is not None and lp.get("type") == "2" and "node_to" in lp:
                     owner[int(lp["node_to"])] = numa
-    return [owner.get(g) for g in gpus]
+    out = []
+    for g in gpus:
+        a, b = owner.get(g), pci.get(g)
+        out.append(a if (b is None or a == b) else (b if a is None else None))
+    return out
 
 
 def _parse_cpulist(text):
@@ -87,15 +116,15 @@ def bind_rank_to_gpu_numa_node(local_rank, sysfs="/sys", environ=None, apply=Tru
     try:
         environ = os.environ if environ is None else environ
         dev = int(local_rank)
-        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):               # an explicit device list renumbers the devices
+        # explicit device lists renumber the devices, and they COMPOSE: HIP_VISIBLE_DEVICES indexes what ROCR_VISIBLE_DEVICES left visible
+        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
             vis = environ.get(var)
             if vis:
                 items = [v.strip() for v in vis.split(",")]
                 if all(v.isdigit() for v in items) and dev < len(items):
                     dev = int(items[dev])
                 else:
-                    return None
-                break
+                    return None                                                     # (UUIDs, or a rank beyond the list: no guess)
         nodes = gpu_numa_nodes(sysfs)
         if dev >= len(nodes) or nodes[dev] is None:
             return None

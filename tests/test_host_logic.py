@@ -470,6 +470,26 @@ def test_rank_binds_itself_to_the_numa_node_of_its_gpu(tmp_path):
     one = _fake_kfd(tmp_path / "one", {7})                                 # a one-GPU box of the pool: device 0 is KFD node 7, on the second socket
     assert sharding.gpu_numa_nodes(one) == [1]
     assert sharding.bind_rank_to_gpu_numa_node(0, one, environ={}, apply=False) == {"node": 1, "cpus": 128}
+    # ROCR_VISIBLE_DEVICES and HIP_VISIBLE_DEVICES compose: HIP's list indexes what ROCR left visible
+    assert sharding.bind_rank_to_gpu_numa_node(1, root, environ={"ROCR_VISIBLE_DEVICES": "4,5,0", "HIP_VISIBLE_DEVICES": "1,2"}, apply=False) == {"node": 0, "cpus": 128}
+    assert sharding.bind_rank_to_gpu_numa_node(0, root, environ={"ROCR_VISIBLE_DEVICES": "4,5,0", "HIP_VISIBLE_DEVICES": "1,2"}, apply=False) == {"node": 1, "cpus": 128}
+    # the GPU's PCI function speaks too (numa_node in sysfs): agreement keeps the answer, a disagreement withdraws it, a memory-only NUMA node is not a socket
+    import pathlib
+    chk = pathlib.Path(_fake_kfd(tmp_path / "pci", set(range(2, 10))))
+    for g in range(2, 10):
+        (chk / f"class/kfd/kfd/topology/nodes/{g}/properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndomain 0\nlocation_id {(0x10 + g) << 8}\n")
+        d = chk / f"bus/pci/devices/0000:{0x10 + g:02x}:00.0"
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(("1" if g == 3 else ("-1" if g == 4 else str(0 if g < 6 else 1))) + "\n")
+    assert sharding.gpu_numa_nodes(str(chk)) == [0, None, 0, 0, 1, 1, 1, 1]          # GPU 1: PCI says node 1, KFD says node 0 -> no answer; GPU 2: PCI silent (-1)
+    assert sharding.bind_rank_to_gpu_numa_node(1, str(chk), environ={}, apply=False) is None
+    mem = chk / "devices/system/node/node2"                                            # renumber: node 0 (CPUs), node 1 memory-only, node 2 (CPUs)
+    mem.mkdir(parents=True)
+    (mem / "cpulist").write_text((chk / "devices/system/node/node1/cpulist").read_text())
+    (chk / "devices/system/node/node1/cpulist").write_text("\n")
+    for g in range(2, 10):
+        (chk / f"bus/pci/devices/0000:{0x10 + g:02x}:00.0/numa_node").write_text(str(0 if g < 6 else 2) + "\n")
+    assert sharding.gpu_numa_nodes(str(chk)) == [0, 0, 0, 0, 2, 2, 2, 2]
     assert sharding.gpu_numa_nodes(str(tmp_path / "nothing")) == []
     assert sharding.bind_rank_to_gpu_numa_node(0, str(tmp_path / "nothing"), environ={}) is None
     assert sharding._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
