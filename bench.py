@@ -240,7 +240,8 @@ def cpu_baseline(cfg, state_dict, data, n_cascades, n_slices=1, ctx=None, ctx_na
     y, S, mask, target = data["y"], data["sensitivity_maps"], data["mask"], data["target"]
     import contextlib
     with torch.no_grad(), (ctx() if ctx is not None else contextlib.nullcontext()):     # (ctx: oracle.amp.autocast_fp16 for the precision-16 line)
-        oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=1), y, S, mask, None, target)       # warm-up, untimed
+        if ctx is None:         # (under autocast(float16) a cascade takes about a minute on the GPU box's host: no warm-up cascade there, its first-call costs are noise)
+            oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=1), y, S, mask, None, target)       # warm-up, untimed
         stamps = [time.perf_counter()]
         ref = oracle.models.cirim_forward(state_dict, dict(cfg, num_cascades=n_cascades), y, S, mask, None, target,
                                           cascade_stamps=stamps)
@@ -267,7 +268,7 @@ def cpu_baseline(cfg, state_dict, data, n_cascades, n_slices=1, ctx=None, ctx_na
                 sec_per_slice_mean=sec_per_slice, sec_per_slice_min=min(slice_s) * cfg["num_cascades"] / n_cascades,
                 sec_per_cascade_mean=dt / n_cascades, sec_per_cascade_min=min(per), sec_per_cascade=per,
                 split_ms_per_rim_step=dict(fft_dc=1e3 * llg_s, regulariser=1e3 * max(step_s - llg_s, 0.0)),
-                sample=(f"after one untimed warm-up cascade: {len(slice_s)} slice(s) of {n_cascades} of {cfg['num_cascades']} cascades ({n_cascades * T_} of "
+                sample=(("after one untimed warm-up cascade: " if ctx is None else "") + f"{len(slice_s)} slice(s) of {n_cascades} of {cfg['num_cascades']} cascades ({n_cascades * T_} of "
                         f"{cfg['num_cascades'] * T_} RIM steps) each on the oracle{ctx_name} (torch CPU ops, {ncores} threads of the box's "
                         f"{box_cores}), value = 1 / mean seconds per slice, {sum(slice_s):.1f} s in all"
                         + ("" if whole else f", extrapolated x{cfg['num_cascades'] / n_cascades:g}"))), ref
