@@ -389,15 +389,15 @@ int mrx_rim_final_gather_q(const float* taps_q, const float* edges, const float*
 /* The reduced-precision INFERENCE route (csrc/rim_amp16.hip; round 6): the two RIM layers of a time-step in the arithmetic the reference's own inference
  * configuration runs -- `precision: 16` (projects/reconstruction/model_zoo/conf/base_cirim_run.yaml:132) = torch.autocast: every convolution multiplies fp16
  * operands (ONE term; fp32 accumulation on v_mfma_f32_32x32x16_f16) and returns fp16, while the FFT, the complex products of log_likelihood_gradient and eta stay
- * fp32 (rim_utils.py:11-67, rim_block.py:217-249).  Hidden states are fp16, channel-blocked h[b][c / 8][y][x][c % 8] (16 bytes per pixel and channel block).
+ * fp32 (rim_utils.py:11-67, rim_block.py:217-249).  Hidden states are fp16, channel-blocked h[b][c / 16][y][x][c % 16] (32 bytes per pixel and channel block).
  * Never the default: selected per model (RIMBlock.precision / MRIDC_AMD_PRECISION=16), checked against the autocast oracle (oracle/amp.py) at a stated tolerance.
  *   mrx_amp16_pack_floats(layer)  : size of the operand pack of layer 1 / 2 in floats;
  *   mrx_amp16_layer1_pack         : w_conv [64,Cin<=4,5,5], w_ih [64,64,1,1] -> packed;
  *   mrx_amp16_layer2_pack         : w_conv [64,64,3,3], w_ih [64,64,1,1], w_final [2,64,3,3] (or NULL) -> packed;
  *   mrx_amp16_layer1              : h_new = ReLU(W_ih ReLU(conv5x5_reppad(in) + b_conv) + b_ih + hh * h_prev); in = x [B,Cin,H,W] (eta NULL) or
  *                                   (eta [B,H,W,2], inv_sigma2 * sum of nparts <= 4 partial planes part [nparts][B][H][W][2]) as mrx_rim_layer1_cb8;
- *                                   h_prev (NULL = the zero state) / h_new: fp16 [B][8][H][W][8];
- *   mrx_amp16_layer2              : the dilation-2 3x3 layer + IndRNN cell on fp16 x / h_prev / h_new [B][8][H][W][8]; with taps_q / edges (both or neither) also
+ *                                   h_prev (NULL = the zero state) / h_new: fp16 [B][4][H][W][16];
+ *   mrx_amp16_layer2              : the dilation-2 3x3 layer + IndRNN cell on fp16 x / h_prev / h_new [B][4][H][W][16]; with taps_q / edges (both or neither) also
  *                                   the final convolution's tap products in the layout of mrx_rim_layer2_f16_cb8_q (fp32; finished by mrx_rim_final_gather_q /
  *                                   mrx_llg372_gather_q). */
 int64_t mrx_amp16_pack_floats(int layer);

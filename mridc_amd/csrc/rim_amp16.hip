@@ -4,8 +4,8 @@
 // operands and accumulates wide, everything autocast does not list (FFT, the complex products of log_likelihood_gradient, eta) stays fp32.
 //
 // This is the reduced-precision route of the library (RIMBlock.precision = 16 / MRIDC_AMD_PRECISION=16), never the default: ONE fp16 term per operand (one MFMA per product where the
-// fp32-class route issues three), fp32 accumulation, and the hidden states kept in fp16, channel-blocked [B][8][H][W][8] halves (16 bytes per pixel and
-// channel block = exactly one B operand of v_mfma_f32_32x32x16_f16).  With a third of the matrix work and half the state bytes both layers are HBM-bound:
+// fp32-class route issues three), fp32 accumulation, and the hidden states kept in fp16, channel-blocked [B][4][H][W][16] halves (32 bytes per pixel and
+// channel block = two B operands of v_mfma_f32_32x32x16_f16; 1 KB of one plane per wave instruction).  With a third of the matrix work and half the state bytes both layers are HBM-bound:
 // the kernels are built around bytes in flight, not around MFMA issue.
 //
 //   k_amp_layer1_t: 8 waves per CU on a 16 x 32 tile, wave = two rows x 64 couts: the halo'd 20 x 36 input patch (eta + the coil-group partial sums of the
@@ -76,6 +76,38 @@ __device__ __forceinline__ int am_scale_exp(float m) {
     return (ex == 0 || ex == 255) ? 0 : 14 - (ex - 127);
 }
 
+// ---- the hidden-state layout: h[b][c / 16][y][x][c % 16] halves ("CB16", 32 bytes per pixel and block) ---------------------------------------------------------
+// A lane of the accumulator layout (pixel n = lane % 32, half = lane / 32) owns channels 8 j + 4 half .. + 3 of every 8-channel group j (one u32x2 of packed halves
+// per j).  In memory a pixel's 16 channels of a block are contiguous, so that ONE wave instruction moves 1 KB (32 pixels x 32 bytes) of one plane: the two lanes of a
+// pixel trade halves first -- v_permlane32_swap on (group 2 m, group 2 m + 1): afterwards the lower lane holds channels 16 m .. 16 m + 7 and the upper lane 16 m + 8 ..
+// 16 m + 15, 16 bytes each.  The swap is its own inverse (loads: swap after the data has arrived).  Measured on a pure read-modify-write stream of the state
+// (tools/probe/state_stream_probe.hip, 8 slices, in place): 6.38 TB/s with these 1 KB pieces against 5.84 with the 512-byte pieces of [b][c / 8][y][x][c % 8].
+__device__ __forceinline__ void am_swap32(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);       // the upper 32 lanes of `a` and the lower 32 lanes of `b` change places
+    a = r[0], b = r[1];
+}
+// registers (h[j]: group j of this lane) <-> pieces (p[m]: this lane's 16 bytes of block m)
+__device__ __forceinline__ void am_to_pieces(const u32x2 (&h)[8], u32x4 (&p)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        unsigned ax = h[2 * m].x, ay = h[2 * m].y, bx = h[2 * m + 1].x, by = h[2 * m + 1].y;
+        am_swap32(ax, bx);
+        am_swap32(ay, by);
+        p[m] = u32x4{ax, ay, bx, by};
+    }
+}
+__device__ __forceinline__ void am_from_pieces(const u32x4 (&p)[4], u32x2 (&h)[8]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        unsigned ax = p[m].x, ay = p[m].y, bx = p[m].z, by = p[m].w;
+        am_swap32(ax, bx);
+        am_swap32(ay, by);
+        h[2 * m] = u32x2{ax, ay}, h[2 * m + 1] = u32x2{bx, by};
+    }
+}
+// byte offset of this lane's piece of block 0 at pixel index `pix` (block m: + m * plane * 32)
+__device__ __forceinline__ unsigned am_piece_off(long long pix, int lhi) { return (unsigned)(pix * 32 + 16 * lhi); }
+
 // ---- layer 1 ---------------------------------------------------------------------------------------------------------------------------------------
 #define A1_K 5
 #define A1_PAD 2
@@ -121,8 +153,8 @@ struct Amp1Args {
     const float* b_conv;   // [64] or null
     const float* b_ih;     // [64] or null
     const float* hh;       // [64]
-    const _Float16* hprev; // [B][8][H][W][8] or null (the zero state)
-    _Float16* hnew;        // [B][8][H][W][8]
+    const _Float16* hprev; // [B][4][H][W][16] or null (the zero state)
+    _Float16* hnew;        // [B][4][H][W][16]
     int B, Cin, H, W, tiles_x, ntiles;
     int abl;               // probe builds only
 };
@@ -205,7 +237,7 @@ __global__ __launch_bounds__(A1T_NT, 1) void k_amp_layer1_t(Amp1Args a) {
             }
         }
     };
-    auto request_hp = [&](int t, u32x2 (&hp)[2][8]) {
+    auto request_hp = [&](int t, u32x4 (&hp)[2][4]) {          // this lane's four 16-byte pieces per row (am_from_pieces when they are consumed)
         int b, h0, w0;
         tile_of(t, b, h0, w0);
         const int ox = w0 + l31, cx = ox < a.W ? ox : a.W - 1;
@@ -215,10 +247,10 @@ __global__ __launch_bounds__(A1T_NT, 1) void k_amp_layer1_t(Amp1Args a) {
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
             const int oy = h0 + 2 * wave + rw, cy = oy < a.H ? oy : a.H - 1;
-            const unsigned off = (a.hprev && !AM_ABL(a, 2)) ? (unsigned)((((long long)cy * a.W + cx) * 8 + 4 * lhi) * 2) : 0x80000000u;   // (the zero state: out of range reads 0)
+            const unsigned off = (a.hprev && !AM_ABL(a, 2)) ? am_piece_off((long long)cy * a.W + cx, lhi) : 0x80000000u;   // (the zero state: out of range reads 0)
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                hp[rw][q] = __builtin_amdgcn_raw_buffer_load_b64(rp, off, (unsigned)q * (unsigned)(plane * 16), MRX_AMP_NT_LD ? 2 : 0);
+            for (int m = 0; m < 4; ++m)
+                hp[rw][m] = __builtin_amdgcn_raw_buffer_load_b128(rp, off, (unsigned)m * (unsigned)(plane * 32), MRX_AMP_NT_LD ? 2 : 0);
         }
     };
     // finish the patch (the last step of log_likelihood_gradient, rim_utils.py:61-67: same order of additions as the wave-private form), leave it in LDS as
@@ -251,14 +283,14 @@ __global__ __launch_bounds__(A1T_NT, 1) void k_amp_layer1_t(Amp1Args a) {
     };
 
     float raw[A1T_XV][NRAW];
-    u32x2 hpA[2][8], hpB[2][8];
+    u32x4 hpA[2][4], hpB[2][4];
     request_patch(blockIdx.x, raw);
     request_hp(blockIdx.x, hpA);
     commit(raw, 0);
     request_patch(blockIdx.x + gridDim.x, raw);
     __syncthreads();
 
-    auto body = [&](int it, int t, u32x2 (&hp_cur)[2][8], u32x2 (&hp_nxt)[2][8]) {
+    auto body = [&](int it, int t, u32x4 (&hp_cur)[2][4], u32x4 (&hp_nxt)[2][4]) {
         int b, h0, w0;
         tile_of(t, b, h0, w0);
         const int buf = it & 1;
@@ -324,10 +356,12 @@ __global__ __launch_bounds__(A1T_NT, 1) void k_amp_layer1_t(Amp1Args a) {
                     acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl[(s * 2 + ct) * 64]), bt, acc2[ct], 0, 0, 0);
             }
             const int oy = h0 + 2 * wave + rw;
-            const unsigned offh = (oy < a.H && ox < a.W && !AM_ABL(a, 4)) ? (unsigned)((((long long)oy * a.W + ox) * 8 + 4 * lhi) * 2) : 0x80000000u;
+            const unsigned offh = (oy < a.H && ox < a.W && !AM_ABL(a, 4)) ? am_piece_off((long long)oy * a.W + ox, lhi) : 0x80000000u;
+            u32x2 hprev[8], hnew[8];
+            am_from_pieces(hp_cur[rw], hprev);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float hv[4] = {am_lo(hp_cur[rw][q].x), am_hi(hp_cur[rw][q].x), am_lo(hp_cur[rw][q].y), am_hi(hp_cur[rw][q].y)};
+                const float hv[4] = {am_lo(hprev[q].x), am_hi(hprev[q].x), am_lo(hprev[q].y), am_hi(hprev[q].y)};
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -335,8 +369,12 @@ __global__ __launch_bounds__(A1T_NT, 1) void k_amp_layer1_t(Amp1Args a) {
                     v[i] = acc2[R >> 4][R & 15] + tabl[lhi * 32 + R] * hv[i];
                     v[i] = v[i] > 0.f ? v[i] : 0.f;
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])}, rh, offh + (unsigned)q * (unsigned)(plane * 16), 0, MRX_AMP_NT_ST1 ? 2 : 0);
+                hnew[q] = u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])};
             }
+            u32x4 pc[4];
+            am_to_pieces(hnew, pc);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) __builtin_amdgcn_raw_buffer_store_b128(pc[m], rh, offh + (unsigned)m * (unsigned)(plane * 32), 0, MRX_AMP_NT_ST1 ? 2 : 0);
         }
         // the next tile's patch (requested a tile ago) into the other buffer, the one after it requested
         commit(raw, buf ^ 1);
@@ -403,13 +441,13 @@ __global__ void k_amp2_pack(const float* __restrict__ w, const float* __restrict
 }
 
 struct Amp2Args {
-    const _Float16* x;     // [B][8][H][W][8]
+    const _Float16* x;     // [B][4][H][W][16]
     const u32x4* packed;   // k_amp2_pack
     const float* b_conv;   // [64] or null
     const float* b_ih;     // [64] or null
     const float* hh;       // [64]
-    const _Float16* hprev; // [B][8][H][W][8] or null
-    _Float16* hnew;        // [B][8][H][W][8]
+    const _Float16* hprev; // [B][4][H][W][16] or null
+    _Float16* hnew;        // [B][4][H][W][16]
     float* Q;              // [B][3][H][W][2]: the final convolution's tap products pre-summed along x inside the tile (rim_layer2_sb.hip, FAST form)
     float* E;              // [B][H][tile column][16]: what the neighbouring tiles owe columns 0 / 31
     int B, H, W, tiles_x, ntiles;
@@ -463,7 +501,7 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
             int gy = h0 + ty - A2_DIL, gx = w0 + tx - A2_DIL;            // replicate border = clamp (conv_layers.py:72-76)
             gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
             gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-            goff[v] = e < A2_JOB ? (unsigned)(((long long)c * plane + (long long)gy * a.W + gx) * 16) : 0x80000000u;
+            goff[v] = e < A2_JOB ? (unsigned)(((long long)gy * a.W + gx) * 32 + 16 * c) : 0x80000000u;      // a job = one 16-channel block: chunk c is the pixel's second 16 bytes
         }
     };
     u32x4 xr[2][A2_XV];
@@ -501,7 +539,9 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rw][ct][r] = tabl[64 + lhi * 32 + ct * 16 + r];
-        u32x2 hp[2][8];                              // h_prev of the two rows: registers 4 q .. 4 q + 3 = channels 8 q + 4 lhi .. + 3 as four halves
+        u32x4 hp[2][4];                              // h_prev of the two rows: this lane's four 16-byte pieces each (am_from_pieces in the epilogue)
+        const __amdgpu_buffer_rsrc_t rhp = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.hprev ? a.hprev : a.hnew) + (long long)b * AM_F * plane, 0,
+                                                                             (unsigned)(plane * (AM_F * 2)), 0x00020000);
 
         auto toff = [](int tp) { return (tp / 3) * A2_DIL * A2_PW + (tp % 3) * A2_DIL; };
 #pragma unroll
@@ -513,14 +553,9 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
 #pragma unroll
                 for (int rw = 0; rw < 2; ++rw) {
                     const int cy = oy0 + rw < a.H ? oy0 + rw : a.H - 1;
-                    if (a.hprev && !AM_ABL(a, 2)) {
-                        const u32x2* hb = reinterpret_cast<const u32x2*>(a.hprev + ((long long)b * AM_F * plane + ((long long)cy * a.W + cx) * 8 + 4 * lhi));
+                    const unsigned off = (a.hprev && !AM_ABL(a, 2)) ? am_piece_off((long long)cy * a.W + cx, lhi) : 0x80000000u;      // (the zero state: out of range reads 0)
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) hp[rw][q] = MRX_AMP_NT_LD ? __builtin_nontemporal_load(hb + (long long)q * plane * 2) : hb[(long long)q * plane * 2];
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) hp[rw][q] = u32x2{0u, 0u};
-                    }
+                    for (int m = 0; m < 4; ++m) hp[rw][m] = __builtin_amdgcn_raw_buffer_load_b128(rhp, off, (unsigned)m * (unsigned)(plane * 32), MRX_AMP_NT_LD ? 2 : 0);
                 }
             }
             const u32x4* xw = Xp + (p & 1) * A2_XBUF + (2 * wave) * A2_PW + l31;
@@ -592,10 +627,12 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
             const int oy = oy0 + rw;
-            const unsigned offh = (oy < a.H && ox < a.W && !AM_ABL(a, 4)) ? (unsigned)((((long long)oy * a.W + ox) * 8 + 4 * lhi) * 2) : 0x80000000u;
+            const unsigned offh = (oy < a.H && ox < a.W && !AM_ABL(a, 4)) ? am_piece_off((long long)oy * a.W + ox, lhi) : 0x80000000u;
+            u32x2 hprev[8];
+            am_from_pieces(hp[rw], hprev);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float hv[4] = {am_lo(hp[rw][q].x), am_hi(hp[rw][q].x), am_lo(hp[rw][q].y), am_hi(hp[rw][q].y)};
+                const float hv[4] = {am_lo(hprev[q].x), am_hi(hprev[q].x), am_lo(hprev[q].y), am_hi(hprev[q].y)};
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -604,8 +641,11 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
                     v[i] = v[i] > 0.f ? v[i] : 0.f;
                 }
                 hq[rw][q] = u32x2{am_pk(v[0], v[1]), am_pk(v[2], v[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(hq[rw][q], rh, offh + (unsigned)q * (unsigned)(plane * 16), 0, MRX_AMP_NT_ST ? 2 : 0);
             }
+            u32x4 pc[4];
+            am_to_pieces(hq[rw], pc);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) __builtin_amdgcn_raw_buffer_store_b128(pc[m], rh, offh + (unsigned)m * (unsigned)(plane * 32), 0, MRX_AMP_NT_ST ? 2 : 0);
         }
         if (a.Q && !AM_ABL(a, 8)) {
             f32x16 accp[2];

@@ -1596,10 +1596,11 @@ def rim_final_gather_q(taps_q, edges, b_final, eta):
 
 # ---- the reduced-precision inference route (csrc/rim_amp16.hip): the reference's `precision: 16` -----------------------------------------------------
 def amp16_from_nchw(h):
-    """[B,64,H,W] (any float dtype) -> the fp16 channel-blocked state [B,8,H,W,8] of the amp16 layer kernels (entry / exit of a block only: torch plumbing)."""
+    """[B,64,H,W] (any float dtype) -> the fp16 channel-blocked state [B,4,H,W,16] (h[b][c // 16][y][x][c % 16]) of the amp16 layer kernels (entry / exit of a block
+    only: torch plumbing)."""
     _lib.require_gpu(h)
     B, C, H, W = _nchw(h)
-    return h.reshape(B, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).to(torch.float16).contiguous()
+    return h.reshape(B, C // 16, 16, H, W).permute(0, 1, 3, 4, 2).to(torch.float16).contiguous()
 
 
 def amp16_to_nchw(h):
@@ -1636,14 +1637,14 @@ def _amp16_state(h, B, H, W, what):
     if h is None:
         return None
     _lib.require_gpu(h)
-    if h.dtype != torch.float16 or tuple(h.shape) != (B, 8, H, W, 8) or not h.is_contiguous():
-        raise ValueError(f"{what}: states are contiguous fp16 [B,8,H,W,8] = {(B, 8, H, W, 8)}, got {h.dtype} {tuple(h.shape)}")
+    if h.dtype != torch.float16 or tuple(h.shape) != (B, 4, H, W, 16) or not h.is_contiguous():
+        raise ValueError(f"{what}: states are contiguous fp16 [B,4,H,W,16] = {(B, 4, H, W, 16)}, got {h.dtype} {tuple(h.shape)}")
     return h
 
 
 def amp16_layer1(x, eta, part, nparts, sigma, packed, b_conv, b_ih, hh, h_prev, out=None):
     """First RIM layer of the precision-16 route (mrx_amp16_layer1): input x [B,Cin<=4,H,W] (eta None) or (eta [B,H,W,2], nparts <= 4 coil-group partial
-    planes) as rim_layer1_cb8; h_prev / result fp16 [B,8,H,W,8]."""
+    planes) as rim_layer1_cb8; h_prev / result fp16 [B,4,H,W,16]."""
     if eta is not None:
         eta = _lib.f32c(eta)
         B, H, W, _ = [int(v) for v in eta.shape]
@@ -1658,7 +1659,7 @@ def amp16_layer1(x, eta, part, nparts, sigma, packed, b_conv, b_ih, hh, h_prev, 
     hhc = _lib.f32c(hh.detach().reshape(-1))
     hp = _amp16_state(h_prev, B, H, W, "amp16_layer1")
     if out is None:
-        out = torch.empty(B, 8, H, W, 8, dtype=torch.float16, device=(eta if eta is not None else x).device)
+        out = torch.empty(B, 4, H, W, 16, dtype=torch.float16, device=(eta if eta is not None else x).device)
     _amp16_state(out, B, H, W, "amp16_layer1")
     _lib.check(_lib.lib().mrx_amp16_layer1(_lib.ptr(x) if eta is None else None, int(Cin), _lib.ptr(eta), _lib.ptr(part) if eta is not None else None, int(nparts),
                                            float(1.0 / (float(sigma) ** 2.0)), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc),
@@ -1667,7 +1668,7 @@ def amp16_layer1(x, eta, part, nparts, sigma, packed, b_conv, b_ih, hh, h_prev, 
 
 
 def amp16_layer2(x, packed, b_conv, b_ih, hh, h_prev, taps_q=None, edges=None, out=None, want_taps=True):
-    """Second RIM layer of the precision-16 route (mrx_amp16_layer2): fp16 x / h_prev / result [B,8,H,W,8]; with `want_taps` also (taps_q [B,3,H,W,2],
+    """Second RIM layer of the precision-16 route (mrx_amp16_layer2): fp16 x / h_prev / result [B,4,H,W,16]; with `want_taps` also (taps_q [B,3,H,W,2],
     edges) of the final convolution, fp32, in the layout of rim_layer2_f16_cb8_q (for rim_final_gather_q / llg372_gather_q)."""
     _lib.require_gpu(x)
     B, Q, H, W, E = [int(v) for v in x.shape]
@@ -1686,7 +1687,7 @@ def amp16_layer2(x, packed, b_conv, b_ih, hh, h_prev, taps_q=None, edges=None, o
     else:
         taps_q = edges = None
     if out is None:
-        out = torch.empty(B, 8, H, W, 8, dtype=torch.float16, device=x.device)
+        out = torch.empty(B, 4, H, W, 16, dtype=torch.float16, device=x.device)
     _amp16_state(out, B, H, W, "amp16_layer2")
     _lib.check(L.mrx_amp16_layer2(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(bc), _lib.ptr(bi), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), _lib.ptr(taps_q),
                                   _lib.ptr(edges), B, H, W, _lib.stream_ptr()), "mrx_amp16_layer2")

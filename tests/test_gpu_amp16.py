@@ -69,7 +69,7 @@ def test_first_layer_against_float64_on_fp16_operands(dev, shape):
     eta, part = r(B, H, W, 2), r(3, B, H, W, 2)
     pk = ops.amp16_layer1_pack(w1, wi1)
     hp16 = ops.amp16_from_nchw(hp)
-    assert hp16.dtype == torch.float16 and tuple(hp16.shape) == (B, 8, H, W, 8)
+    assert hp16.dtype == torch.float16 and tuple(hp16.shape) == (B, 4, H, W, 16)
     assert torch.equal(ops.amp16_to_nchw(hp16), hp.half().float())
     # x form, with and without a previous state
     for prev in (hp16, None):
