@@ -32,7 +32,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define AM_TH 16
 
 // PROBE builds (-DMRX_PROBE, env MRX_AMP_ABL): phases switched off to price them -- 1 no input (patch / x) loads, 2 no h_prev loads, 4 no state stores,
-// 8 no tap stage, 16 no convolution MFMAs, 32 tap stage without its stores.  Results are garbage; only the time is read.  The product build compiles every test away.
+// 8 no tap stage, 16 no convolution MFMAs, 32 tap stage without its stores (64 / 128 / 256: without the 8-byte / the 4-byte / the edge store only).  Results are garbage; only the time is read.  The product build compiles every test away.
 #ifdef MRX_PROBE
 #define AM_ABL(a, bit) (((a).abl & (bit)) != 0)
 #else
@@ -700,14 +700,14 @@ __global__ __launch_bounds__(A2_NT, 1) void k_amp_layer2(Amp2Args a) {
                 q[2] = lhi ? (fromL(v[5]) + v[7]) + sw2 : sw2 + (v[4] + fromR(v[6]));
                 const unsigned offq = (inside && !AM_ABL(a, 32)) ? (unsigned)(((long long)oy * a.W + ox) * 8) : 0x80000000u;      // (probe bit 32: tap stage computed, not stored)
                 const u32x2 pair = lhi ? u32x2{__float_as_uint(q[1]), __float_as_uint(q[2])} : u32x2{__float_as_uint(q[0]), __float_as_uint(q[1])};
-                __builtin_amdgcn_raw_buffer_store_b64(pair, rq, offq + (lhi ? 2u : 0u) * (unsigned)(plane * 8), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lhi ? q[0] : q[2]), rq, offq + (unsigned)(plane * 8) + (lhi ? 4u : 0u), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(pair, rq, (AM_ABL(a, 64) ? 0x80000000u : offq) + (lhi ? 2u : 0u) * (unsigned)(plane * 8), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lhi ? q[0] : q[2]), rq, (AM_ABL(a, 128) ? 0x80000000u : offq) + (unsigned)(plane * 8) + (lhi ? 4u : 0u), 0, 0);
                 const bool col0 = l31 == 0 && inside && tcol > 0, col31 = l31 == 31 && inside && tcol + 1 < a.tiles_x;
                 const u32x4 ev = l31 == 0 ? (lhi ? u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), 0u, 0u}
                                                  : u32x4{__float_as_uint(v[6]), __float_as_uint(v[7]), __float_as_uint(v[8]), __float_as_uint(v[9])})
                                           : (lhi ? u32x4{__float_as_uint(v[2]), __float_as_uint(v[3]), __float_as_uint(v[4]), __float_as_uint(v[5])}
                                                  : u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), 0u, 0u});
-                const unsigned eoff = ((col0 || col31) && !AM_ABL(a, 32)) ? (unsigned)(((long long)oy * a.tiles_x + tcol) * 64 + (l31 == 0 ? (lhi ? 16 : 0) : (lhi ? 48 : 32))) : 0x80000000u;
+                const unsigned eoff = ((col0 || col31) && !AM_ABL(a, 32) && !AM_ABL(a, 256)) ? (unsigned)(((long long)oy * a.tiles_x + tcol) * 64 + (l31 == 0 ? (lhi ? 16 : 0) : (lhi ? 48 : 32))) : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(ev, re, eoff, 0, 0);
             }
         }
