@@ -611,25 +611,6 @@ static void l1sb_launch_form(const MrxL1sbArgs& a, int grid, size_t lds, hipStre
         (void)hipFuncSetAttribute((const void*)k_rim_layer1_sb<F16, CB8, true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-#ifdef MRX_L1_W12
-#ifndef MRX_L1_NW
-#define MRX_L1_NW 12
-#endif
-    if (CB8 && F16 && a.eta2 && a.nparts <= 4) {
-        constexpr int NWV = MRX_L1_NW;                  // (A/B builds: 12 waves with early h_prev; 8 waves = half the register file, for the co-residency probe)
-        constexpr size_t ldsv = (size_t)(SBH_WCONV + SBH_WIH) * 16 + 256 * sizeof(float) + (size_t)NWV * 2 * SB_PSTR * 8;
-        static bool attr12 = false;
-        if (!attr12) {
-            (void)hipFuncSetAttribute((const void*)k_rim_layer1_sb<F16, CB8, false, 1, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsv);
-            attr12 = true;
-        }
-        MrxL1sbArgs a12 = a;
-        a12.ntiles = a.tiles_x * mrx_cdiv(a.H, NWV);
-        const long long total12 = (long long)a12.ntiles * a.B;
-        hipLaunchKernelGGL((k_rim_layer1_sb<F16, CB8, false, 1, NWV>), dim3((int)(total12 < grid ? total12 : grid)), dim3(NWV * 64), ldsv, st, a12);
-        return;
-    }
-#endif
     if (a.eta2 && a.nparts <= 4)
         hipLaunchKernelGGL((k_rim_layer1_sb<F16, CB8, false, 1>), dim3(grid), dim3(SB_NT), lds, st, a);
     else if (!a.eta2)

@@ -350,9 +350,6 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
     const int tid = wave * 64 + lane_now(), lane = tid & 63;
     const long long plane = (long long)a.H * a.W;
     const int total = a.ntiles * a.B;
-#ifdef MRX_L2_PRIO
-    if (wave >= NTHR / 128) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses every issue arbitration by age: one static priority for it
-#endif
 
     // once per workgroup: 1x1 weights and tables
     if (TAIL && !W4)
@@ -410,11 +407,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
     auto st_coords = [&]() {
         if constexpr (NEWST) {
             // (beyond the last tile the pipeline keeps requesting -- the last tile again: the loads stay in range and nobody reads what they bring)
-#ifdef MRX_L2_ABL_XHOT                              // (timing variant: every tile's x loads re-read the workgroup's FIRST tile -- cache hits; results are garbage)
-            const int tq = blockIdx.x;
-#else
             const int tq = st_t < total ? st_t : total - 1;
-#endif
             const int tt = (int)mrx_xcd_band(tq, total);
             const int b = tt / a.ntiles, tile = tt - b * a.ntiles, ty0 = tile / a.tiles_x;
             const int h0 = ty0 * TH, w0 = (tile - ty0 * a.tiles_x) * S2_TW;
@@ -598,11 +591,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
         float hp[RPW][32];
         auto load_hp = [&](int rw) {              // lanes outside the image read a valid element (clamped) and store nothing
             const int oy = h0 + RPW * wave + rw, ox = w0 + l31;
-#ifdef MRX_L2_ABL_HPHOT                             // (timing variant: every tile's h_prev loads re-read one row of the image -- cache hits)
-            const int cy = RPW * wave + rw, cx = l31;
-#else
             const int cy = oy < a.H ? oy : a.H - 1, cx = ox < a.W ? ox : a.W - 1;
-#endif
             if (!a.hprev) {                       // the zero state: nothing to load (and nothing uninitialised to multiply by zero)
 #pragma unroll
                 for (int R = 0; R < 32; ++R) hp[rw][R] = 0.f;
@@ -819,11 +808,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
             }
         }
         S2_STAMP(2)        // (probe builds: [1, 2] = both rows' 1x1 stage, [2, 3] = epilogues, stores and the tap stage)
-#ifdef MRX_L2_ABL_NOST                              // (timing variant: a zero-sized descriptor -- the hardware drops every store)
-        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hnew + (long long)b * S2_F * plane, 0, 0u, 0x00020000);
-#else
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hnew + (long long)b * S2_F * plane, 0, (unsigned)(plane * (S2_F * 4)), 0x00020000);
-#endif
         unsigned offh[2];
 #pragma unroll
         for (int rw = 0; rw < 2; ++rw) {
@@ -934,11 +919,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (W4 ? 256 : S2_NT), W4 ? 2 : 1) void k
                     __builtin_amdgcn_raw_buffer_store_b128(ev, re, eoff, 0, 0);
                 }
             } else {
-#ifdef MRX_L2_ABL_NOST
-            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.P + (long long)b * 18 * plane, 0, 0u, 0x00020000);
-#else
             const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.P + (long long)b * 18 * plane, 0, (unsigned)(plane * (18 * 4)), 0x00020000);
-#endif
 #pragma unroll
             for (int rw = 0; rw < 2; ++rw) {
                 const int oy = oy0 + rw;
@@ -1182,11 +1163,7 @@ static int l2sb_launch_t(L2sbArgs a, hipStream_t st) {
         attr_done = true;
     }
     if (W4) a.ntiles = a.tiles_x * mrx_cdiv(a.H, 8);                   // 8 x 32 tiles
-#ifdef MRX_L2_W4_ONE
-    const int ncu = l2sb_ncu();                                         // (co-residency probe: ONE 4-wave workgroup per CU, the rest of the CU for another kernel)
-#else
     const int ncu = (W4 ? 2 : 1) * l2sb_ncu();                          // two 4-wave workgroups per CU
-#endif
     const long long total = (long long)a.ntiles * a.B;
     const int grid = (int)(total < ncu ? total : ncu);
     a.trace = nullptr;
@@ -1256,16 +1233,8 @@ static int l2sb_launch(const float* x, const float* packed, const float* b_conv,
         }
     }
 #endif
-#ifdef MRX_L2_W4
-    if (xmax && cb8) return l2sb_launch_t<2, true, false, true, 0, true, true>(a, (hipStream_t)stream);
-#endif
-#ifdef MRX_L2_R1
-    if (xmax && cb8) return l2sb_launch_t<2, true, false, true, 0, true, false, true, true>(a, (hipStream_t)stream);
-#endif
-#ifndef MRX_L2_SLOW
     // (the FAST form addresses a sample's state and its tap planes with 32-bit byte offsets through buffer descriptors)
     if (xmax && cb8 && (long long)H * W * (S2_F * 4) < (1ll << 31)) return l2sb_launch_t<2, true, false, true, 0, true, false, false, true>(a, (hipStream_t)stream);
-#endif
     if (xmax && cb8) return l2sb_launch_t<2, true, false, true, 0, true>(a, (hipStream_t)stream);
     MRX_REQUIRE(!cb8, MRX_EUNSUP, "mrx_rim_layer2_f16_cb8: the channel-blocked layout exists for the two-term fp16 form only");
     if (xmax) return l2sb_launch_t<2, true, false, true>(a, (hipStream_t)stream);

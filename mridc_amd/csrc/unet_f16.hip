@@ -238,11 +238,7 @@ __device__ __forceinline__ void uh_finalize_plane(const float* __restrict__ tsta
 // TK: the ticket form (a.counters given) is its own instantiation -- its merge keeps 32 tile statistics per lane in registers, which the 128-register
 // budget of the four-workgroups-per-CU form does not have (84 bytes of scratch per lane when it was a run-time branch of the one kernel)
 template <int NCOT, int DIL, bool UNET, bool TK = false>
-#ifdef MRX_UH_PERSIST
-#define UH_WGS(NCOT, TK) ((NCOT) == 1 ? 3 : 2)                 // (the resident form keeps its staging roles alive across items: one workgroup per CU fewer, no scratch)
-#else
 #define UH_WGS(NCOT, TK) ((NCOT) == 1 ? ((TK) ? 3 : 4) : ((NCOT) == 2 ? 3 : 2))
-#endif
 __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uh[];
     constexpr int UH_PW = uh_pw(DIL), UH_PIX = uh_pix(DIL), UH_PLANE = uh_plane(DIL), UH_XBUF = uh_xbuf(DIL);
@@ -382,27 +378,11 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
     // MRX_UH_PERSIST (A/B, round 5): the grid is the number of RESIDENT workgroups and each walks its items -- no workgroup launch (registers, LDS, the
     // scale / offset set-up above) per 8 x 32 tile; with MRX_UH_PERSIST = 2 the next item's first tile is requested as soon as this item's last one is
     // committed to LDS (its registers are free from there on): the load latency of item i + 1 runs under the matrix work, stores and statistics of item i.
-#ifdef MRX_UH_NO_BAND
-#define UH_ITEM(i) (i)
-#else
 #define UH_ITEM(i) ((int)mrx_xcd_band((i), a.nitems))
-#endif
-#ifdef MRX_UH_PERSIST
-    const int it_step = gridDim.x;
-    bool prefetched = false;
-    for (int it = blockIdx.x; it < a.nitems; it += it_step) {
-    const int item = UH_ITEM(it);
-    if (it != (int)blockIdx.x) __syncthreads();      // the previous item's readers of the operand buffers and of `red` are done
-    if (!prefetched) {
-        issue_x(item, 0);
-        issue_w(item, 0);
-    }
-#else
     {                                                // one item per workgroup (the product form)
     const int item = UH_ITEM((int)blockIdx.x);
     issue_x(item, 0);
     issue_w(item, 0);
-#endif
     {
         const int tile = item % a.ntiles, bc = item / a.ntiles, b = bc / ncob, co0 = (bc - b * ncob) * NCOT * 16;
         const int ty0 = tile / a.tiles_x, h0 = ty0 * UH_TH, w0 = (tile - ty0 * a.tiles_x) * UH_TW;
@@ -420,13 +400,6 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
                 issue_x(item, q + 1);
                 issue_w(item, q + 1);
             }
-#if defined(MRX_UH_PERSIST) && MRX_UH_PERSIST == 2
-            else if (it + it_step < a.nitems) {          // ... and behind the last step the next ITEM's first tile
-                issue_x(UH_ITEM(it + it_step), 0);
-                issue_w(UH_ITEM(it + it_step), 0);
-                prefetched = true;
-            }
-#endif
             if (!(a.abl & 1))
 #pragma unroll
             for (int m = 0; m < UH_MS; ++m) {
@@ -608,18 +581,6 @@ static int launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
     UConvHArgs a2 = a;
     a2.nitems = (int)nitems;
     long long grid = nitems;
-#ifdef MRX_UH_PERSIST
-    {
-        static int ncu = 0;
-        if (!ncu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        }
-        const long long resident = (long long)ncu * UH_WGS(NCOT, TK);
-        grid = nitems < resident ? nitems : resident;
-    }
-#endif
     hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET, TK>), dim3((unsigned)grid), dim3(UH_NT), lds, st, a2);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
