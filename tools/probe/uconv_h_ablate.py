@@ -8,7 +8,7 @@ from mridc_amd import ops
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
-B = 4
+B = int(os.environ.get("PROBE_B", "8"))
 out = []
 for Ca, Cout, H, W in [(14, 14, 640, 380), (28, 28, 320, 190)]:
     a = r(B, Ca, H, W)
