@@ -29,6 +29,9 @@ typedef unsigned uh_u4 __attribute__((ext_vector_type(4)));
 
 #define UH_NT 256
 #define UH_TH 8
+#ifndef MRX_UH_TH16
+#define MRX_UH_TH16 1
+#endif
 #define UH_TW 32
 #define UH_SC 16                   // input channels per step
 #define UH_MS 5                    // MFMAs per step and accumulator (18 of 20 slots used)
@@ -36,9 +39,9 @@ typedef unsigned uh_u4 __attribute__((ext_vector_type(4)));
                                    // = four lines took 107 k atomics one after the other, +200 us per launch)
 // halo'd tile for dilation D: (8 + 2 D) rows x (32 + 2 D) columns -- 10 x 34 = 340 pixels (D = 1), 12 x 36 = 432 (D = 2)
 __host__ __device__ constexpr int uh_pw(int D) { return UH_TW + 2 * D; }
-__host__ __device__ constexpr int uh_pix(int D) { return (UH_TH + 2 * D) * uh_pw(D); }
-__host__ __device__ constexpr int uh_plane(int D) { return (uh_pix(D) + 7) / 8 * 8; }      // pixels per (term, half) plane in LDS (16-byte words)
-__host__ __device__ constexpr int uh_xbuf(int D) { return 2 * 2 * uh_plane(D); }          // 16-byte words of the x buffer: [term][half][pixel]
+__host__ __device__ constexpr int uh_pix(int D, int TH = UH_TH) { return (TH + 2 * D) * uh_pw(D); }
+__host__ __device__ constexpr int uh_plane(int D, int TH = UH_TH) { return (uh_pix(D, TH) + 7) / 8 * 8; }      // pixels per (term, half) plane in LDS (16-byte words)
+__host__ __device__ constexpr int uh_xbuf(int D, int TH = UH_TH) { return 2 * 2 * uh_plane(D, TH); }          // 16-byte words of the x buffer: [term][half][pixel]
 
 struct UConvHArgs {
     const float* xa;     // [B,Ca,H,W]
@@ -51,6 +54,7 @@ struct UConvHArgs {
     float* y;            // [B,Cout,H,W] raw
     float* tstats;       // [B][ntiles][Cout][2] (mean, M2) per tile
     int Ca, Cb, B, Cout, H, W, tiles_x, ntiles, nct, nsteps, nitems;
+    int ntiles8;         // tiles of the 8-row tiling the tile statistics are indexed by (= ntiles unless the work items are 16-row tiles: TH = 16)
     float slope;
     const float* bias;   // plain convolution (UNET = false): [Cout] or null; act MRX_ACT_*; pad_mode MRX_PAD_ZERO | MRX_PAD_REPLICATE
     int act, pad_mode;
@@ -237,11 +241,17 @@ __device__ __forceinline__ void uh_finalize_plane(const float* __restrict__ tsta
 // dilation DIL, zero or replicate padding and a bias + activation epilogue (conv_layers.py:121-123 for layers wider than the RIM's 64 channels).
 // TK: the ticket form (a.counters given) is its own instantiation -- its merge keeps 32 tile statistics per lane in registers, which the 128-register
 // budget of the four-workgroups-per-CU form does not have (84 bytes of scratch per lane when it was a run-time branch of the one kernel)
-template <int NCOT, int DIL, bool UNET, bool TK = false>
+// TH (round 6): image rows per work item.  16: a wave owns FOUR rows (eight accumulator tiles per output-channel block), half as many workgroups per launch -- 40 % of the
+// 8-row launch is per-workgroup cost that no phase ablation removes (profiles/r06_uconv_h_phase_ablation.txt) -- and a halo of 1.19 x instead of 1.33 x; the tile statistics
+// stay on the 8-row granule (the two wave pairs of a workgroup each write their half's record: mrx_unorm_finalize_tiled is unchanged); three workgroups per CU.
+template <int NCOT, int DIL, bool UNET, bool TK = false, int TH = UH_TH>
 #define UH_WGS(NCOT, TK) ((NCOT) == 1 ? ((TK) ? 3 : 4) : ((NCOT) == 2 ? 3 : 2))
-__global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs a) {
+__global__ __launch_bounds__(UH_NT, TH == 16 ? 3 : UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs a) {
+    static_assert(TH == 8 || TH == 16, "8 or 16 rows per work item");
+    static_assert(TH == 8 || !TK, "the ticket form walks 8-row tiles");
+    constexpr int RPW = TH / 4, NSG = 2 * RPW;                    // image rows per wave, 16-pixel accumulator tiles per wave and output-channel block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uh[];
-    constexpr int UH_PW = uh_pw(DIL), UH_PIX = uh_pix(DIL), UH_PLANE = uh_plane(DIL), UH_XBUF = uh_xbuf(DIL);
+    constexpr int UH_PW = uh_pw(DIL), UH_PIX = uh_pix(DIL, TH), UH_PLANE = uh_plane(DIL, TH), UH_XBUF = uh_xbuf(DIL, TH);
     constexpr int NSLOT = (UH_PIX + 127) / 128;                 // tile pixels per staging thread: 3 (dilation 1), 4 (dilation 2)
     constexpr int WBUF = UH_MS * NCOT * 2 * 64;                 // 16-byte words of the weight buffer: [m][ct][term][lane]
     constexpr int NWL = (WBUF + UH_NT - 1) / UH_NT;
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
     unsigned lzm = 0, okm = 0;                                     // of the data in flight: lazy channels / pixels inside the image
     auto issue_x = [&](int item, int q) {
         const int tile = item % a.ntiles, bc = item / a.ntiles, b = bc / ncob;
-        const int ty0 = tile / a.tiles_x, h0 = ty0 * UH_TH, w0 = (tile - ty0 * a.tiles_x) * UH_TW;
+        const int ty0 = tile / a.tiles_x, h0 = ty0 * TH, w0 = (tile - ty0 * a.tiles_x) * UH_TW;
         unsigned goff[NSLOT];
         okm = 0;
 #pragma unroll
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
         tap = tap > 8 ? 8 : tap;
         toff[m] = ((tap / 3) * UH_PW + (tap % 3)) * DIL;
     }
-    const uh_u4* xq = Xh + (lg & 1) * UH_PLANE + (2 * wave) * UH_PW + l15;
+    const uh_u4* xq = Xh + (lg & 1) * UH_PLANE + (RPW * wave) * UH_PW + l15;
     const uh_u4* wq = Wh + lane;
 
     // workgroup -> work item: the runtime deals consecutive workgroups round-robin over the 8 XCDs (8 L2 caches); with item = blockIdx.x the two horizontal
@@ -385,10 +395,10 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
     issue_w(item, 0);
     {
         const int tile = item % a.ntiles, bc = item / a.ntiles, b = bc / ncob, co0 = (bc - b * ncob) * NCOT * 16;
-        const int ty0 = tile / a.tiles_x, h0 = ty0 * UH_TH, w0 = (tile - ty0 * a.tiles_x) * UH_TW;
-        uh_f4 acc[4][NCOT];
+        const int ty0 = tile / a.tiles_x, h0 = ty0 * TH, w0 = (tile - ty0 * a.tiles_x) * UH_TW;
+        uh_f4 acc[NSG][NCOT];
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg)
+        for (int sg = 0; sg < NSG; ++sg)
 #pragma unroll
             for (int ct = 0; ct < NCOT; ++ct) acc[sg][ct] = (uh_f4){0.f, 0.f, 0.f, 0.f};
         for (int q = 0; q < a.nsteps; ++q) {
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
                     a2[ct] = __builtin_bit_cast(uh_f16x8, wq[((m * NCOT + ct) * 2 + 1) * 64]);
                 }
 #pragma unroll
-                for (int sg = 0; sg < 4; ++sg) {
+                for (int sg = 0; sg < NSG; ++sg) {
                     const int pix = (sg >> 1) * UH_PW + (sg & 1) * 16 + toff[m];
                     const uh_f16x8 b1 = __builtin_bit_cast(uh_f16x8, xq[pix]);
                     const uh_f16x8 b2 = __builtin_bit_cast(uh_f16x8, xq[2 * UH_PLANE + pix]);
@@ -443,10 +453,10 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
                     }
             }
         }
-        bool ok[4];
+        bool ok[NSG];
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-            const int oy = h0 + 2 * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
+        for (int sg = 0; sg < NSG; ++sg) {
+            const int oy = h0 + RPW * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
             ok[sg] = oy < a.H && ox < a.W;
 #pragma unroll
             for (int ct = 0; ct < NCOT; ++ct)
@@ -466,8 +476,8 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
         auto store_y = [&]() {
             if (a.abl & 2) return;
 #pragma unroll
-            for (int sg = 0; sg < 4; ++sg) {
-                const int oy = h0 + 2 * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
+            for (int sg = 0; sg < NSG; ++sg) {
+                const int oy = h0 + RPW * wave + (sg >> 1), ox = w0 + (sg & 1) * 16 + l15;
                 if (oy < a.H && ox < a.W) {
 #pragma unroll
                     for (int ct = 0; ct < NCOT; ++ct)
@@ -484,8 +494,11 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
         if (UNET && !(a.abl & 4)) {
         // InstanceNorm statistics of this tile, per cout (the scheme of k_uconv, unet_fused.hip: mean over the tile's valid pixels, then the squared
         // deviations from that mean; k_unorm_finalize merges the tiles in double)
-        const int nrow = a.H - h0 < UH_TH ? a.H - h0 : UH_TH, ncol = a.W - w0 < UH_TW ? a.W - w0 : UH_TW;
-        const float inv_n = 1.0f / (float)(nrow * ncol);
+        // (TH = 16: the workgroup's two wave pairs are the two 8-row granules of the statistics -- rows h0 .. h0 + 7 and h0 + 8 .. h0 + 15; the second may lie below the image)
+        constexpr int NG = TH / UH_TH, WPG = 4 / NG;
+        const int grp = wave / WPG, hg = h0 + UH_TH * grp;
+        const int nrow = a.H - hg < UH_TH ? a.H - hg : UH_TH, ncol = a.W - w0 < UH_TW ? a.W - w0 : UH_TW;
+        const float inv_n = nrow > 0 ? 1.0f / (float)(nrow * ncol) : 0.f;
         float mean[NCOT][4];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
                 for (int r = 0; r < 4; ++r) {
                     float t = 0.f;
 #pragma unroll
-                    for (int sg = 0; sg < 4; ++sg) {
+                    for (int sg = 0; sg < NSG; ++sg) {
                         const float v = acc[sg][ct][r];
                         const float d = pass == 0 ? v : (v - mean[ct][r]) * (v - mean[ct][r]);
                         t += ok[sg] ? d : 0.f;
@@ -510,11 +523,13 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = 16 * ct + 4 * lg + r;
-                    const float t = (rp[c] + rp[NCOT * 16 + c]) + (rp[2 * NCOT * 16 + c] + rp[3 * NCOT * 16 + c]);
+                    const float t = NG == 1 ? (rp[c] + rp[NCOT * 16 + c]) + (rp[2 * NCOT * 16 + c] + rp[3 * NCOT * 16 + c])
+                                            : rp[(2 * grp) * (NCOT * 16) + c] + rp[(2 * grp + 1) * (NCOT * 16) + c];
                     if (pass == 0) {
                         mean[ct][r] = t * inv_n;
-                    } else if (wave == 0 && l15 == 0 && co0 + c < a.Cout) {
-                        float* ts = a.tstats + (((long long)b * a.ntiles + tile) * a.Cout + co0 + c) * 2;
+                    } else if (wave == grp * WPG && l15 == 0 && co0 + c < a.Cout && nrow > 0) {
+                        const int tile8 = NG == 1 ? tile : (ty0 * NG + grp) * a.tiles_x + (tile - ty0 * a.tiles_x);
+                        float* ts = a.tstats + (((long long)b * a.ntiles8 + tile8) * a.Cout + co0 + c) * 2;
                         if constexpr (TK) {                          // written through to the coherence point (read by whichever workgroup merges the plane)
                             __hip_atomic_store(ts, mean[ct][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(ts + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -568,12 +583,12 @@ __global__ __launch_bounds__(UH_NT, UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs 
 
 int mrx_unorm_finalize_tiled(const float* tstats, float* norm, int B, int ntiles, int tiles_x, int Cout, int H, int W, float eps, hipStream_t st);
 
-template <int NCOT, int DIL, bool UNET, bool TK = false>
+template <int NCOT, int DIL, bool UNET, bool TK = false, int TH = UH_TH>
 static int launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
-    constexpr size_t lds = 16 * (size_t)(uh_xbuf(DIL) + UH_MS * NCOT * 2 * 64) + sizeof(float) * 2 * 4 * NCOT * 16;
+    constexpr size_t lds = 16 * (size_t)(uh_xbuf(DIL, TH) + UH_MS * NCOT * 2 * 64) + sizeof(float) * 2 * 4 * NCOT * 16;
     static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
     if (lds > 48 * 1024 && !attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_uconv_h<NCOT, DIL, UNET, TK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_uconv_h<NCOT, DIL, UNET, TK, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     const long long nitems = (long long)a.ntiles * mrx_cdiv(a.nct, NCOT) * a.B;
@@ -581,7 +596,7 @@ static int launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
     UConvHArgs a2 = a;
     a2.nitems = (int)nitems;
     long long grid = nitems;
-    hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET, TK>), dim3((unsigned)grid), dim3(UH_NT), lds, st, a2);
+    hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET, TK, TH>), dim3((unsigned)grid), dim3(UH_NT), lds, st, a2);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -613,13 +628,20 @@ static int unet_conv3x3_h_impl(const float* xa, const float* na, const float* bo
     a.nct = (Cout + 15) / 16, a.nsteps = (Ca + Cb + UH_SC - 1) / UH_SC;
     a.abl = MRX_DEBUG_ENV("MRX_UCONVH_ABLATE") ? atoi(MRX_DEBUG_ENV("MRX_UCONVH_ABLATE")) : 0;
     const int ntiles = a.tiles_x * mrx_cdiv(H, UH_TH);
-    a.ntiles = ntiles;
+    a.ntiles = ntiles, a.ntiles8 = ntiles;
     a.bias = nullptr, a.act = MRX_ACT_NONE, a.pad_mode = MRX_PAD_ZERO;
     a.counters = counters, a.norm = norm, a.eps = eps;
     hipStream_t st = (hipStream_t)stream;
     const int ncot = uh_pick_ncot(a.nct, (long long)ntiles * B);
     if (counters) return ncot == 4 ? launch_uconv_h<4, 1, true, true>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, true, true>(a, st) : launch_uconv_h<1, 1, true, true>(a, st));
-    const int rc = ncot == 4 ? launch_uconv_h<4, 1, true>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, true>(a, st) : launch_uconv_h<1, 1, true>(a, st));
+    // 16-row work items where a launch has workgroups to spare (MRX_UH_TH16 = 0: the 8-row form everywhere, A/B)
+    int rc;
+    const long long items16 = (long long)a.tiles_x * mrx_cdiv(H, 16) * B;
+    if (MRX_UH_TH16 && ncot == 1 && items16 >= 2048) {   // (E2EVN's 14 -> 14 layers at 8 x 640 x 372: 1 248 against 1 227 slices/s; no launch of this library with two output-channel blocks has that many items)
+        a.ntiles = a.tiles_x * mrx_cdiv(H, 16);
+        rc = launch_uconv_h<1, 1, true, false, 16>(a, st);
+    } else
+        rc = ncot == 4 ? launch_uconv_h<4, 1, true>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, true>(a, st) : launch_uconv_h<1, 1, true>(a, st));
     if (rc) return rc;
     return mrx_unorm_finalize_tiled(work, norm, B, ntiles, a.tiles_x, Cout, H, W, eps, st);
 }
@@ -659,6 +681,7 @@ extern "C" int mrx_conv3x3_h(const float* x, const float* bound, const float* pa
     a.packed = reinterpret_cast<const uh_u4*>(packed), a.y = y, a.tstats = nullptr;
     a.Ca = Cin, a.Cb = 0, a.B = B, a.Cout = Cout, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, UH_TW), a.slope = slope;
     a.ntiles = a.tiles_x * mrx_cdiv(H, UH_TH), a.nct = (Cout + 15) / 16, a.nsteps = (Cin + UH_SC - 1) / UH_SC;
+    a.ntiles8 = a.ntiles;
     a.abl = 0, a.bias = bias, a.act = act, a.pad_mode = pad_mode;
     a.counters = nullptr, a.norm = nullptr, a.eps = 0.f;
     hipStream_t st = (hipStream_t)stream;

@@ -29,7 +29,10 @@ def _lazy_ref(raw64, norm):
 
 @pytest.mark.parametrize("shape", [(1, 2, 0, 14, 640, 380), (1, 14, 0, 14, 640, 380), (1, 14, 14, 14, 640, 380), (2, 14, 0, 28, 320, 190),
                                    (1, 28, 28, 28, 160, 95), (1, 56, 0, 56, 33, 47), (1, 18, 18, 18, 72, 40), (3, 5, 3, 36, 9, 7),
-                                   (1, 144, 144, 144, 40, 24), (1, 3, 0, 70, 8, 32), (1, 1, 0, 1, 1, 2)])
+                                   (1, 144, 144, 144, 40, 24), (1, 3, 0, 70, 8, 32), (1, 1, 0, 1, 1, 2),
+                                   # 16-row work items (one output-channel block and >= 2048 of them): E2EVN's batch of 8; a last item with its second 8-row half
+                                   # below the image (200 = 12 x 16 + 8) and one with three rows of it inside (203)
+                                   (8, 14, 14, 14, 640, 372), (8, 14, 0, 14, 200, 700), (8, 6, 3, 9, 203, 690)])
 def test_unet_conv3x3_sources_and_statistics(shape, dev):
     """mrx_unet_conv3x3: plain and lazy sources, one and two of them (the skip concatenation read in place), every cout-block count, ragged
     tiles, channel counts that are not multiples of the 8-channel step; raw output and (mean, 1/std) against float64."""
