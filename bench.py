@@ -530,9 +530,10 @@ def bench_e2evn(args, world, rank, dev, checks=False):
         ucfg = dict(synthetic.E2EVN_BASELINE_CFG)
         if args.unet == "18x4":
             ucfg.update(channels=18, pooling_layers=4, padding_size=15)
-        model = VarNet(ucfg)
-        label = "E2EVN 6-cascade" + ("" if args.unet == "14x2" else " (NormUnet 18x4)")
-        desc = f"E2EVN 6 cascades, NormUnet(chans {ucfg['channels']}, pools {ucfg['pooling_layers']}, pad {ucfg['padding_size']})"
+        p16 = args.precision == 16          # the reference's own inference precision (base_vn_run.yaml:98): one-term fp16 3x3 convolutions, the rest fp32
+        model = VarNet(dict(ucfg, precision=16) if p16 else ucfg)
+        label = "E2EVN 6-cascade" + ("" if args.unet == "14x2" else " (NormUnet 18x4)") + (", precision 16" if p16 else "")
+        desc = f"E2EVN 6 cascades, NormUnet(chans {ucfg['channels']}, pools {ucfg['pooling_layers']}, pad {ucfg['padding_size']})" + (", trainer.precision = 16" if p16 else "")
     elif args.model == "rvn":       # SURVEY 8f N4; the reference's base_rvn_run.yaml
         from mridc_amd.collections.reconstruction.models.rvn import RecurrentVarNet
         model = RecurrentVarNet(dict(common, in_channels=2, recurrent_hidden_channels=64, recurrent_num_layers=4, num_steps=8,
@@ -585,7 +586,8 @@ def bench_e2evn(args, world, rank, dev, checks=False):
                unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
                per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
-               dtype="f32", data="synthetic",
+               dtype="f16 operands in the U-Net's 3x3 convolutions (fp32 sums, fp32 activations / statistics / FFT / data consistency)" if (args.model == "e2evn" and args.precision == 16) else "f32",
+               data="synthetic",
                config=dict(workload=f"{desc}, {C} coils, {H}x{W}, batch "
                                     f"{Bt} per GPU ({NS} concurrent HIP stream(s), {'one hipGraph each' if graphed else 'eager'}), random-init weights "
                                     "(seed 0)", parallelism=f"slice-sharded x{world}"))
@@ -604,24 +606,25 @@ def bench_e2evn(args, world, rank, dev, checks=False):
             all_ms = sum(tot.values()) / 2.0                    # two profiled steps (raw event time of every U-Net 3x3 convolution)
             from mridc_amd import _lib as _l
             nbytes = (int(cin) + int(cout)) * hh_ * ww_ * B * 4.0
+            terms = 1 if args.precision == 16 else 3
             if ops.UNET_F16 and _l.arith() == "f16x2":
                 # the default: two-term fp16 operands -- the matrix work is 3 / 16 of the fp32-input form's cycles and the launch is bound by its
                 # tile loads and stores (algorithmic bytes = every input plane read once + every output plane written once)
                 gbs = (nbytes / (ms * 1e-3) / 1e9) if ms else None
-                res["roofline"] = dict(bound="hbm", kernel=f"k_uconv_h via mrx_unet_conv3x3_h ({key}: 3x3 zero-padded convolution, batch {B}, two-term fp16 operands "
-                                                              "on v_mfma_f32_16x16x32_f16 (3 term products, fp32 accumulation), fused InstanceNorm statistics; the previous "
+                res["roofline"] = dict(bound="hbm", kernel=f"k_uconv_h via mrx_unet_conv3x3_{'p16' if terms == 1 else 'h'} ({key}: 3x3 zero-padded convolution, batch {B}, {'one-term' if terms == 1 else 'two-term'} fp16 operands "
+                                                              f"on v_mfma_f32_16x16x32_f16 ({terms} term product(s), fp32 accumulation), fused InstanceNorm statistics; the previous "
                                                               "layer's normalisation + LeakyReLU and the operand split in the tile loader)",
                                        achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=(gbs / PEAK_HBM_GBS) if gbs else None,
                                        frac_meaning="algorithmic bytes of the launch (inputs read once + outputs written once) / 8 TB/s", launches=n, avg_ms=ms,
                                        # counter traffic exists for the 14 -> 14 layer at 4 x 640 x 380 (tools/probe/pmc_r04.py) and at the default line's
                                        # 8 x 640 x 380 (pmc_r04_b8.py): the shape this record names by default
                                        traffic=(measured_traffic(8 if B == 8 else 1, 15, 640, 372, 64).get("e2evn_uconv_h_14to14")
-                                                if (int(cin), int(cout), hh_, ww_) == (14, 14, 640, 380) and B in (4, 8) else None),
+                                                if (int(cin), int(cout), hh_, ww_) == (14, 14, 640, 380) and B in (4, 8) and terms == 3 else None),
                                        traffic_unit="bytes/launch",
                                        mfma_util_pmc=((measured_traffic(8 if B == 8 else 1, 15, 640, 372, 64).get("_mfma_util") or {}).get("e2evn_uconv_h_14to14")
-                                                      if (int(cin), int(cout), hh_, ww_) == (14, 14, 640, 380) and B in (4, 8) else None),
+                                                      if (int(cin), int(cout), hh_, ww_) == (14, 14, 640, 380) and B in (4, 8) and terms == 3 else None),
                                        algorithmic_bytes=nbytes, flops_per_launch=flops,
-                                       mfma_frac=(3.0 * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if ms else None,
+                                       mfma_frac=(terms * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if ms else None,
                                        all_unet_conv3x3_ms_per_step=all_ms)
             else:
                 res["roofline"] = dict(bound="mfma", kernel=f"k_uconv via mrx_unet_conv3x3 ({key}: 3x3 zero-padded convolution, batch {B}, fp32 MFMA 16x16x4, fused "
@@ -636,7 +639,9 @@ def bench_e2evn(args, world, rank, dev, checks=False):
             import oracle
             ncores, box_cores = _oracle_threads()
             h1 = {k: (v[:1] if k != "mask" else v) for k, v in hosts[0].items()}
-            with torch.no_grad():
+            # (precision 16: the reference's own arithmetic on the CPU -- torch.autocast(float16), oracle/amp.py -- is both the baseline that is timed and the checker)
+            import contextlib
+            with torch.no_grad(), (oracle.amp.autocast_fp16() if args.precision == 16 else contextlib.nullcontext()):
                 oracle.models.varnet_forward(state_dict, dict(ucfg, num_cascades=1), h1["y"], h1["sensitivity_maps"], h1["mask"], None, h1["target"])
                 dts = []
                 for _ in range(max(1, args.cpu_slices)):
@@ -646,11 +651,17 @@ def bench_e2evn(args, world, rank, dev, checks=False):
                 dt = sum(dts) / len(dts)
             res["cpu_baseline"] = dict(value=1.0 / dt, unit="slices/s", cores=ncores, kind="port", box_cores=box_cores, cpu_model=cpu_model_name(),
                                        slices_timed=len(dts), sec_per_slice=dts,
-                                       sample=f"{len(dts)} whole slice(s) ({ucfg['num_cascades']} cascades) on the oracle after one untimed warm-up cascade, torch CPU "
+                                       sample=f"{len(dts)} whole slice(s) ({ucfg['num_cascades']} cascades) on the oracle{' under torch.autocast(float16)' if args.precision == 16 else ''} after one untimed warm-up cascade, torch CPU "
                                               f"ops on {ncores} threads, value = 1 / mean seconds per slice, {sum(dts):.1f} s in all")
             out = outs[0] if graphed else step(datas[0])
             torch.cuda.synchronize()
-            res["parity_vs_oracle"] = parity_vs_oracle(out[0:1], ref[0:1], h1["target"], at="the final image (all cascades, SENSE combination)")
+            res["parity_vs_oracle"] = parity_vs_oracle(out[0:1], ref[0:1].to(torch.complex64), h1["target"], at="the final image (all cascades, SENSE combination)"
+                                                       + ("; checker: the oracle under torch.autocast(float16), tolerance 3e-2 (SURVEY appendix C)" if args.precision == 16 else ""))
+            if args.precision == 16:
+                with torch.no_grad():
+                    ref32 = oracle.models.varnet_forward(state_dict, ucfg, h1["y"], h1["sensitivity_maps"], h1["mask"], None, h1["target"])
+                res["parity_vs_fp32_oracle"] = parity_vs_oracle(out[0:1], ref32[0:1], h1["target"], at="the final image against the fp32 oracle")
+                res["autocast_oracle_vs_fp32_oracle"] = parity_vs_oracle(ref[0:1].to(torch.complex64).to(out.device), ref32[0:1], h1["target"], at="the reference's own precision-16 arithmetic against fp32")
         except Exception as ex:  # noqa: BLE001
             res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port", sample=f"failed: {type(ex).__name__}: {ex}")
     return res
@@ -889,7 +900,7 @@ def summary_of(res):
     if isinstance(res.get("streamed_inputs"), dict):
         out["streamed"] = dict(v=r3(res["streamed_inputs"].get("value")))
     short = {"e2evn_6cascade_15coil_640x372": "e2evn", "qcirim_4echo_32coil_256x256": "qcirim", "cirim_training_bf16_15coil_640x372": "train_bf16",
-             "e2evn_training_15coil_640x372": "train_e2evn", "cirim_2d_mask_15coil_640x372": "mask2d", "cirim_precision16_15coil_640x372": "prec16",
+             "e2evn_training_15coil_640x372": "train_e2evn", "cirim_2d_mask_15coil_640x372": "mask2d", "cirim_precision16_15coil_640x372": "prec16", "e2evn_precision16_15coil_640x372": "e2evn16",
              "cirim_8cascade_x5_time_steps_rimblock_direct": "rim5"}
     for k, r in (res.get("other_configs") or {}).items():
         out[short.get(k, k)] = {a: b for a, b in (one(r) or {}).items() if b is not None}
@@ -1681,6 +1692,7 @@ def main():
             import copy
             others = {}
             for name, fn, over in (("e2evn_6cascade_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=8, streams=2, steps=6, warmup=2)),
+                                   ("e2evn_precision16_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=8, streams=2, steps=6, warmup=2, precision=16, cpu_slices=1)),
                                    ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=4, steps=10, warmup=2))):
                 a2 = copy.copy(args)
                 for k_, v_ in over.items():

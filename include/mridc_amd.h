@@ -800,6 +800,11 @@ int64_t mrx_unet_conv3x3_pack_floats(int Cout, int Ctot);
 int mrx_unet_conv3x3_pack(const float* w, int Cout, int Ctot, float* packed, void* stream);
 int mrx_unet_conv3x3_h(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b, int Cb,
                        const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps, float slope, void* stream);
+/*   mrx_unet_conv3x3_p16   the same convolution in the reference's `precision: 16` inference arithmetic (base_vn_run.yaml:98, base_unet_run.yaml:96: native AMP =
+ *                          torch.autocast(float16) around the forward pass, unet_block.py:250-259 under it): operands rounded to fp16 once (the first term of
+ *                          the same pack), exact products, fp32 sums; raw output and statistics stay fp32.  Same arguments and work buffer. */
+int mrx_unet_conv3x3_p16(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b, int Cb,
+                       const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps, float slope, void* stream);
 /* ... with the merge of the tile statistics INSIDE the convolution launch (no k_unorm_finalize launch behind it): the last tile of every plane, found by
  * a ticket per plane, writes `norm`.  counters: mrx_unet_conv3x3_hc_ticket_ints(B, Cout) ints (one 128-byte line per plane), ZERO on entry, zero again on exit (one buffer serves every call on a stream; calls
  * that may overlap -- two streams -- need their own).  `norm` equals mrx_unet_conv3x3_h's up to the order of three double-precision sums. */

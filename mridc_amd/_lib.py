@@ -156,6 +156,7 @@ _SIGNATURES = {
     "mrx_unet_conv3x3_pack_floats": ([_i, _i], _i64),
     "mrx_unet_conv3x3_pack": ([_p, _i, _i, _p, _p], _i),
     "mrx_unet_conv3x3_h": ([_p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p], _i),
+    "mrx_unet_conv3x3_p16": ([_p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p], _i),
     "mrx_unet_conv3x3_hc_ticket_ints": ([_i, _i], _i64),
     "mrx_unet_conv3x3_hc": ([_p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p], _i),
     "mrx_conv3x3_h_supported": ([_i, _i, _i, _i], _i),
@@ -271,9 +272,10 @@ def arith():
 
 
 def precision():
-    """The inference precision of the RIM regulariser (environment MRIDC_AMD_PRECISION): 32 (default: fp32-class results on every route of `arith()`) or
-    16 -- the reference's `trainer.precision: 16` (base_cirim_run.yaml:132): fp16 operands and hidden states in the two RIM layers (csrc/rim_amp16.hip),
-    FFT / data consistency / eta in fp32.  A model attribute (RIMBlock.precision, set by CIRIM from its trainer / cfg) overrides it."""
+    """The inference precision of the regularisers (environment MRIDC_AMD_PRECISION): 32 (default: fp32-class results on every route of `arith()`) or
+    16 -- the reference's `trainer.precision: 16` (base_cirim_run.yaml:132, base_vn_run.yaml:98): fp16 operands and hidden states in the two RIM layers
+    (csrc/rim_amp16.hip), one-term fp16 operands in the U-Net's 3x3 convolutions (mrx_unet_conv3x3_p16); FFT / data consistency / eta in fp32.  A model
+    attribute (RIMBlock.precision set by CIRIM, VarNet.precision, UNet.precision: from the trainer / cfg) overrides it."""
     return 16 if os.environ.get("MRIDC_AMD_PRECISION", "32").strip().lower() in ("16", "fp16", "16-mixed", "amp16") else 32
 
 

@@ -28,6 +28,8 @@ class UNet(torch.nn.Module):
         self.train_loss_fn = _cfg.make_loss(cfg_dict.get("train_loss_fn", "l1"))
         self.val_loss_fn = _cfg.make_loss(cfg_dict.get("val_loss_fn", "l1"))
         self.accumulate_estimates = False
+        prec = getattr(trainer, "precision", None) if trainer is not None else None        # base_unet_run.yaml:96 (see VarNet)
+        self.precision = cfg_dict.get("precision", None) if prec is None else prec
 
     def forward(self, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask: torch.Tensor, init_pred: torch.Tensor,
                 target: torch.Tensor) -> torch.Tensor:
@@ -36,6 +38,10 @@ class UNet(torch.nn.Module):
             fft.ifft2(y, centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims),
             sensitivity_maps, method=self.coil_combination_method, dim=self.coil_dim))
         _, eta = utils.center_crop_to_smallest(target, eta)
-        return torch.view_as_complex(self.unet(torch.view_as_real(eta.unsqueeze(self.coil_dim)))).squeeze(self.coil_dim)
+        from mridc_amd import _lib, ops
+        prec = self.precision if self.precision is not None else _lib.precision()
+        p16 = str(prec).lower() in ("16", "fp16", "16-mixed") and not (self.training and torch.is_grad_enabled())
+        with ops.unet_precision(16 if p16 else None):
+            return torch.view_as_complex(self.unet(torch.view_as_real(eta.unsqueeze(self.coil_dim)))).squeeze(self.coil_dim)
 
     forward_step = forward

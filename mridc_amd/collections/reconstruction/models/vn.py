@@ -42,6 +42,15 @@ class VarNet(torch.nn.Module):
         self.val_loss_fn = _cfg.make_loss(cfg_dict.get("val_loss_fn", "l1"))
         self.dc_weight = torch.nn.Parameter(torch.ones(1))          # vn.py:91
         self.accumulate_estimates = False
+        # `trainer.precision` (base_vn_run.yaml:98: 16 = pytorch-lightning's native AMP around the forward pass) or a plain `precision` key of cfg: 16
+        # selects the one-term fp16 convolutions of the regulariser at inference (mrx_unet_conv3x3_p16); None: the process default (MRIDC_AMD_PRECISION)
+        prec = getattr(trainer, "precision", None) if trainer is not None else None
+        self.precision = cfg_dict.get("precision", None) if prec is None else prec
+
+    def _inference_precision(self):
+        from mridc_amd import _lib
+        prec = self.precision if self.precision is not None else _lib.precision()
+        return 16 if str(prec).lower() in ("16", "fp16", "16-mixed") else None
 
 
     def _hybrid_ok(self, mask):
@@ -78,11 +87,13 @@ class VarNet(torch.nn.Module):
             estimation = diff.ifft2(estimation, self.fft_centered, self.fft_normalization, self.spatial_dims)
             estimation = diff.coil_combination(estimation, sensitivity_maps, method=self.coil_combination_method, dim=self.coil_dim)
         elif self._hybrid_ok(mask):
-            estimation = self._forward_hybrid(y, sensitivity_maps, mask)
+            with ops.unet_precision(self._inference_precision()):
+                estimation = self._forward_hybrid(y, sensitivity_maps, mask)
         else:
             estimation = y.clone()
-            for cascade in self.cascades:
-                estimation = cascade(estimation, y, sensitivity_maps, mask)
+            with ops.unet_precision(self._inference_precision()):
+                for cascade in self.cascades:
+                    estimation = cascade(estimation, y, sensitivity_maps, mask)
             estimation = fft.ifft2(estimation, centered=self.fft_centered, normalization=self.fft_normalization,
                                    spatial_dims=self.spatial_dims)
             estimation = utils.coil_combination(estimation, sensitivity_maps, method=self.coil_combination_method,

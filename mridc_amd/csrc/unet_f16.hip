@@ -41,7 +41,7 @@ typedef unsigned uh_u4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int uh_pw(int D) { return UH_TW + 2 * D; }
 __host__ __device__ constexpr int uh_pix(int D, int TH = UH_TH) { return (TH + 2 * D) * uh_pw(D); }
 __host__ __device__ constexpr int uh_plane(int D, int TH = UH_TH) { return (uh_pix(D, TH) + 7) / 8 * 8; }      // pixels per (term, half) plane in LDS (16-byte words)
-__host__ __device__ constexpr int uh_xbuf(int D, int TH = UH_TH) { return 2 * 2 * uh_plane(D, TH); }          // 16-byte words of the x buffer: [term][half][pixel]
+__host__ __device__ constexpr int uh_xbuf(int D, int TH = UH_TH, int TERMS = 2) { return TERMS * 2 * uh_plane(D, TH); }          // 16-byte words of the x buffer: [term][half][pixel]
 
 struct UConvHArgs {
     const float* xa;     // [B,Ca,H,W]
@@ -244,16 +244,20 @@ __device__ __forceinline__ void uh_finalize_plane(const float* __restrict__ tsta
 // TH (round 6): image rows per work item.  16: a wave owns FOUR rows (eight accumulator tiles per output-channel block), half as many workgroups per launch -- 40 % of the
 // 8-row launch is per-workgroup cost that no phase ablation removes (profiles/r06_uconv_h_phase_ablation.txt) -- and a halo of 1.19 x instead of 1.33 x; the tile statistics
 // stay on the 8-row granule (the two wave pairs of a workgroup each write their half's record: mrx_unorm_finalize_tiled is unchanged); three workgroups per CU.
-template <int NCOT, int DIL, bool UNET, bool TK = false, int TH = UH_TH>
+// TERMS (round 6): 2 = fp32-class results (two fp16 terms per operand, three term products); 1 = the reference's `precision: 16` inference arithmetic
+// (base_vn_run.yaml:98: torch.autocast(float16) around the forward pass -- fp16-rounded operands, fp32 sums; the raw outputs and their statistics STAY fp32
+// here, autocast rounds them to fp16): the first term only -- a third of the matrix work, half the LDS image and fragment reads.
+template <int NCOT, int DIL, bool UNET, bool TK = false, int TH = UH_TH, int TERMS = 2>
 #define UH_WGS(NCOT, TK) ((NCOT) == 1 ? ((TK) ? 3 : 4) : ((NCOT) == 2 ? 3 : 2))
 __global__ __launch_bounds__(UH_NT, TH == 16 ? 3 : UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs a) {
     static_assert(TH == 8 || TH == 16, "8 or 16 rows per work item");
     static_assert(TH == 8 || !TK, "the ticket form walks 8-row tiles");
+    static_assert(TERMS == 2 || (TERMS == 1 && UNET && !TK), "one term: the U-Net convolutions of the precision-16 route");
     constexpr int RPW = TH / 4, NSG = 2 * RPW;                    // image rows per wave, 16-pixel accumulator tiles per wave and output-channel block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uh[];
-    constexpr int UH_PW = uh_pw(DIL), UH_PIX = uh_pix(DIL, TH), UH_PLANE = uh_plane(DIL, TH), UH_XBUF = uh_xbuf(DIL, TH);
+    constexpr int UH_PW = uh_pw(DIL), UH_PIX = uh_pix(DIL, TH), UH_PLANE = uh_plane(DIL, TH), UH_XBUF = uh_xbuf(DIL, TH, TERMS);
     constexpr int NSLOT = (UH_PIX + 127) / 128;                 // tile pixels per staging thread: 3 (dilation 1), 4 (dilation 2)
-    constexpr int WBUF = UH_MS * NCOT * 2 * 64;                 // 16-byte words of the weight buffer: [m][ct][term][lane]
+    constexpr int WBUF = UH_MS * NCOT * TERMS * 64;             // 16-byte words of the weight buffer: [m][ct][term][lane]
     constexpr int NWL = (WBUF + UH_NT - 1) / UH_NT;
     // ONE operand buffer: the next step's tile waits in registers while this step is multiplied (32 / 42 KB per workgroup: several workgroups
     // share a CU and fill each other's barriers)
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(UH_NT, TH == 16 ? 3 : UH_WGS(NCOT, TK)) void k_ucon
             }
             if (p < UH_PIX) {
                 dst[p] = uh_u4{p1[0], p1[1], p1[2], p1[3]};
-                dst[2 * UH_PLANE + p] = uh_u4{p2[0], p2[1], p2[2], p2[3]};
+                if constexpr (TERMS == 2) dst[2 * UH_PLANE + p] = uh_u4{p2[0], p2[1], p2[2], p2[3]};
             }
         }
     };
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(UH_NT, TH == 16 ? 3 : UH_WGS(NCOT, TK)) void k_ucon
 #pragma unroll
         for (int j = 0; j < NWL; ++j) {
             const int i = tid + j * UH_NT;
-            const int ln = i & 63, term = (i >> 6) & 1, r = i >> 7, ct = r % NCOT, m = r / NCOT;
+            const int ln = i & 63, term = TERMS == 2 ? (i >> 6) & 1 : 0, r = TERMS == 2 ? i >> 7 : i >> 6, ct = r % NCOT, m = r / NCOT;
             const bool okw = i < WBUF && ct0 + ct < a.nct;
             wr[j] = okw ? a.packed[((((long long)q * UH_MS + m) * a.nct + ct0 + ct) * 2 + term) * 64 + ln] : uh_u4{0u, 0u, 0u, 0u};
         }
@@ -416,19 +420,24 @@ __global__ __launch_bounds__(UH_NT, TH == 16 ? 3 : UH_WGS(NCOT, TK)) void k_ucon
                 uh_f16x8 a1[NCOT], a2[NCOT];
 #pragma unroll
                 for (int ct = 0; ct < NCOT; ++ct) {
-                    a1[ct] = __builtin_bit_cast(uh_f16x8, wq[((m * NCOT + ct) * 2 + 0) * 64]);
-                    a2[ct] = __builtin_bit_cast(uh_f16x8, wq[((m * NCOT + ct) * 2 + 1) * 64]);
+                    a1[ct] = __builtin_bit_cast(uh_f16x8, wq[((m * NCOT + ct) * TERMS + 0) * 64]);
+                    if constexpr (TERMS == 2) a2[ct] = __builtin_bit_cast(uh_f16x8, wq[((m * NCOT + ct) * 2 + 1) * 64]);
                 }
 #pragma unroll
                 for (int sg = 0; sg < NSG; ++sg) {
                     const int pix = (sg >> 1) * UH_PW + (sg & 1) * 16 + toff[m];
                     const uh_f16x8 b1 = __builtin_bit_cast(uh_f16x8, xq[pix]);
-                    const uh_f16x8 b2 = __builtin_bit_cast(uh_f16x8, xq[2 * UH_PLANE + pix]);
+                    if constexpr (TERMS == 2) {
+                        const uh_f16x8 b2 = __builtin_bit_cast(uh_f16x8, xq[2 * UH_PLANE + pix]);
 #pragma unroll
-                    for (int ct = 0; ct < NCOT; ++ct) {
-                        acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ct], b1, acc[sg][ct], 0, 0, 0);
-                        acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ct], b2, acc[sg][ct], 0, 0, 0);
-                        acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ct], b1, acc[sg][ct], 0, 0, 0);
+                        for (int ct = 0; ct < NCOT; ++ct) {
+                            acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ct], b1, acc[sg][ct], 0, 0, 0);
+                            acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ct], b2, acc[sg][ct], 0, 0, 0);
+                            acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ct], b1, acc[sg][ct], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int ct = 0; ct < NCOT; ++ct) acc[sg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ct], b1, acc[sg][ct], 0, 0, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);     // (keeps the scheduler from hoisting every step's operand reads to the top: registers)
@@ -583,12 +592,12 @@ __global__ __launch_bounds__(UH_NT, TH == 16 ? 3 : UH_WGS(NCOT, TK)) void k_ucon
 
 int mrx_unorm_finalize_tiled(const float* tstats, float* norm, int B, int ntiles, int tiles_x, int Cout, int H, int W, float eps, hipStream_t st);
 
-template <int NCOT, int DIL, bool UNET, bool TK = false, int TH = UH_TH>
+template <int NCOT, int DIL, bool UNET, bool TK = false, int TH = UH_TH, int TERMS = 2>
 static int launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
-    constexpr size_t lds = 16 * (size_t)(uh_xbuf(DIL, TH) + UH_MS * NCOT * 2 * 64) + sizeof(float) * 2 * 4 * NCOT * 16;
+    constexpr size_t lds = 16 * (size_t)(uh_xbuf(DIL, TH, TERMS) + UH_MS * NCOT * TERMS * 64) + sizeof(float) * 2 * 4 * NCOT * 16;
     static bool attr_done = false;   // once per instantiation: keeps launches legal under hipGraph capture
     if (lds > 48 * 1024 && !attr_done) {
-        MRX_HIP(hipFuncSetAttribute((const void*)k_uconv_h<NCOT, DIL, UNET, TK, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MRX_HIP(hipFuncSetAttribute((const void*)k_uconv_h<NCOT, DIL, UNET, TK, TH, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     const long long nitems = (long long)a.ntiles * mrx_cdiv(a.nct, NCOT) * a.B;
@@ -596,7 +605,7 @@ static int launch_uconv_h(const UConvHArgs& a, hipStream_t st) {
     UConvHArgs a2 = a;
     a2.nitems = (int)nitems;
     long long grid = nitems;
-    hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET, TK, TH>), dim3((unsigned)grid), dim3(UH_NT), lds, st, a2);
+    hipLaunchKernelGGL((k_uconv_h<NCOT, DIL, UNET, TK, TH, TERMS>), dim3((unsigned)grid), dim3(UH_NT), lds, st, a2);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
@@ -612,7 +621,7 @@ static int uh_pick_ncot(int nct, long long tiles_b) {
 // work: mrx_unet_conv3x3_work_floats(B, Cout, H, W) floats.
 static int unet_conv3x3_h_impl(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b,
                                int Cb, const float* packed, float* y, float* norm, float* work, int* counters, int B, int Cout, int H, int W, float eps,
-                               float slope, void* stream) {
+                               float slope, void* stream, int terms = 2) {
     MRX_REQUIRE(xa && packed && y && norm && work && Ca >= 1 && Cb >= 0 && (Cb == 0 || xb), MRX_EINVAL, "mrx_unet_conv3x3_h: bad argument");
     MRX_REQUIRE((na || bound_a) && (Cb == 0 || nb || bound_b), MRX_EINVAL, "mrx_unet_conv3x3_h: a plain source needs the bound of its maximum");
     MRX_REQUIRE(B >= 0 && Cout >= 1 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_unet_conv3x3_h: bad dims");
@@ -637,11 +646,15 @@ static int unet_conv3x3_h_impl(const float* xa, const float* na, const float* bo
     // 16-row work items where a launch has workgroups to spare (MRX_UH_TH16 = 0: the 8-row form everywhere, A/B)
     int rc;
     const long long items16 = (long long)a.tiles_x * mrx_cdiv(H, 16) * B;
-    if (MRX_UH_TH16 && ncot == 1 && items16 >= 2048) {   // (E2EVN's 14 -> 14 layers at 8 x 640 x 372: 1 248 against 1 227 slices/s; no launch of this library with two output-channel blocks has that many items)
-        a.ntiles = a.tiles_x * mrx_cdiv(H, 16);
-        rc = launch_uconv_h<1, 1, true, false, 16>(a, st);
-    } else
-        rc = ncot == 4 ? launch_uconv_h<4, 1, true>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, true>(a, st) : launch_uconv_h<1, 1, true>(a, st));
+    const bool th16 = MRX_UH_TH16 && ncot == 1 && items16 >= 2048;   // (E2EVN's 14 -> 14 layers at 8 x 640 x 372: 1 248 against 1 227 slices/s; no launch of this library with two output-channel blocks has that many items)
+    if (th16) a.ntiles = a.tiles_x * mrx_cdiv(H, 16);
+    if (terms == 1)
+        rc = th16 ? launch_uconv_h<1, 1, true, false, 16, 1>(a, st)
+                  : (ncot == 4 ? launch_uconv_h<4, 1, true, false, UH_TH, 1>(a, st)
+                               : (ncot == 2 ? launch_uconv_h<2, 1, true, false, UH_TH, 1>(a, st) : launch_uconv_h<1, 1, true, false, UH_TH, 1>(a, st)));
+    else
+        rc = th16 ? launch_uconv_h<1, 1, true, false, 16>(a, st)
+                  : (ncot == 4 ? launch_uconv_h<4, 1, true>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, true>(a, st) : launch_uconv_h<1, 1, true>(a, st)));
     if (rc) return rc;
     return mrx_unorm_finalize_tiled(work, norm, B, ntiles, a.tiles_x, Cout, H, W, eps, st);
 }
@@ -649,6 +662,14 @@ extern "C" int mrx_unet_conv3x3_h(const float* xa, const float* na, const float*
                                   int Cb, const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps,
                                   float slope, void* stream) {
     return unet_conv3x3_h_impl(xa, na, bound_a, Ca, xb, nb, bound_b, Cb, packed, y, norm, work, nullptr, B, Cout, H, W, eps, slope, stream);
+}
+// The same convolution in the reference's `precision: 16` inference arithmetic (base_vn_run.yaml:98, base_unet_run.yaml:96: native AMP = torch.autocast(float16)
+// around the forward pass): operands rounded to fp16 ONCE (the first term of the pack; a power-of-two block scale keeps small inputs out of the fp16
+// subnormals), exact products, fp32 sums; raw output and statistics fp32 (autocast rounds the output to fp16: this form is the closer one to fp32).
+extern "C" int mrx_unet_conv3x3_p16(const float* xa, const float* na, const float* bound_a, int Ca, const float* xb, const float* nb, const float* bound_b,
+                                    int Cb, const float* packed, float* y, float* norm, float* work, int B, int Cout, int H, int W, float eps, float slope,
+                                    void* stream) {
+    return unet_conv3x3_h_impl(xa, na, bound_a, Ca, xb, nb, bound_b, Cb, packed, y, norm, work, nullptr, B, Cout, H, W, eps, slope, stream, 1);
 }
 // ... with the merge of the tile statistics inside the convolution launch: `counters` = B * Cout ints that are ZERO on entry and zero again on exit
 // (one buffer serves every call of a stream; two streams need two buffers); ticket of plane p at counters[32 p]: mrx_unet_conv3x3_hc_ticket_ints(B, Cout) ints.  Same `norm` up to the order of three double-precision sums.

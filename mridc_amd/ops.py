@@ -2231,6 +2231,24 @@ UNET_F16 = True                   # (module attribute: a test hook for the fp32-
 # with one 128-byte line per ticket and the tile stored behind the tickets -- 960 returning atomics per plane address still cost more than the 5-us launch
 # they replace (tools/runs/r05i.sh).  MRX_UNET_FOLD=1 / this attribute switch it on (tests/test_gpu_unet_fused.py covers it).
 UNET_FOLD_FINALIZE = os.environ.get("MRX_UNET_FOLD", "0") == "1"
+# The reference's inference precision for the U-Net models (`trainer.precision: 16`, base_vn_run.yaml:98 / base_unet_run.yaml:96): inside `unet_precision(16)`
+# the 3x3 convolutions of the two-term fp16 route run on ONE fp16 term (mrx_unet_conv3x3_p16).  Set by the models' inference forward (VarNet, UNet); None
+# inside / outside: fp32-class results.
+_UNET_PRECISION = [None]
+
+
+class unet_precision:
+    def __init__(self, precision):
+        self.precision = precision
+
+    def __enter__(self):
+        self.keep = _UNET_PRECISION[0]
+        _UNET_PRECISION[0] = self.precision
+        return self
+
+    def __exit__(self, *exc):
+        _UNET_PRECISION[0] = self.keep
+        return False
 _UNET_TICKETS = {}
 
 
@@ -2318,6 +2336,11 @@ def unet_conv3x3(src_a, src_b, weight, eps=1e-5, slope=0.2):
         packed = _UNET_PACKS.get(weight, (), make)
         ba = None if na is not None else _plain_bound(src_a if not isinstance(src_a, tuple) else xa)
         bb = None if (xb is None or nb is not None) else _plain_bound(src_b if not isinstance(src_b, tuple) else xb)
+        if _UNET_PRECISION[0] is not None and int(_UNET_PRECISION[0]) == 16:
+            _lib.check(L.mrx_unet_conv3x3_p16(_lib.ptr(xa), _lib.ptr(na), _lib.ptr(ba), Ca, _lib.ptr(xb), _lib.ptr(nb), _lib.ptr(bb), Cb, _lib.ptr(packed),
+                                              _lib.ptr(y), _lib.ptr(norm), _lib.ptr(work), B, Cout, H, W, float(eps), float(slope), _lib.stream_ptr()),
+                       "mrx_unet_conv3x3_p16")
+            return y, norm
         if UNET_FOLD_FINALIZE:
             tickets = _unet_tickets(int(L.mrx_unet_conv3x3_hc_ticket_ints(B, Cout)), xa.device)
             _lib.check(L.mrx_unet_conv3x3_hc(_lib.ptr(xa), _lib.ptr(na), _lib.ptr(ba), Ca, _lib.ptr(xb), _lib.ptr(nb), _lib.ptr(bb), Cb, _lib.ptr(packed),

@@ -106,11 +106,13 @@ def fp16_kernel_arithmetic():
     def conv(x, weight, bias=None, padding=0, dilation=1):
         y = F.conv2d(fp16_round(x).double(), fp16_round(weight).double(), None, padding=padding, dilation=dilation)
         return (y + bias.double().view(1, -1, 1, 1) if bias is not None else y).float()
-    orim._CONV2D[0], orim._STATE[0] = conv, fp16_round
+    from . import unet as ounet           # ... and of mrx_unet_conv3x3_p16: the 3x3 convolutions of the U-Net blocks on fp16-rounded operands, fp32 results
+    keep_unet = ounet._CONV3X3[0]
+    orim._CONV2D[0], orim._STATE[0], ounet._CONV3X3[0] = conv, fp16_round, conv
     try:
         yield
     finally:
-        orim._CONV2D[0], orim._STATE[0] = keep_conv, keep_state
+        orim._CONV2D[0], orim._STATE[0], ounet._CONV3X3[0] = keep_conv, keep_state, keep_unet
 
 
 def cirim_loss_and_gradients(state, cfg, sample, mode="fp32", skip=(), fp32_forward=(), round_results=False):

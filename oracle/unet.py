@@ -11,6 +11,9 @@ import torch
 import torch.nn.functional as F
 
 
+_CONV3X3 = [F.conv2d]      # the 3x3 convolutions of the blocks (unet_block.py:250-259): oracle.amp.fp16_kernel_arithmetic swaps in the precision-16 kernels' arithmetic
+
+
 def _in_lrelu(x):
     # InstanceNorm2d (no affine, eps 1e-5, biased variance) + LeakyReLU(0.2); unet_block.py:252-253
     return F.leaky_relu(F.instance_norm(x, eps=1e-5), negative_slope=0.2)
@@ -18,8 +21,8 @@ def _in_lrelu(x):
 
 def conv_block(x, w0, w1):
     """unet_block.py:250-259 (Dropout2d(p=0) is the identity at eval)."""
-    x = _in_lrelu(F.conv2d(x, w0, None, padding=1))
-    return _in_lrelu(F.conv2d(x, w1, None, padding=1))
+    x = _in_lrelu(_CONV3X3[0](x, w0, None, padding=1))
+    return _in_lrelu(_CONV3X3[0](x, w1, None, padding=1))
 
 
 def transpose_conv_block(x, w):

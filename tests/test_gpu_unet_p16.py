@@ -1,0 +1,160 @@
+"""GPU parity of the U-Net models' precision-16 inference route (`trainer.precision: 16`, reference base_vn_run.yaml:98 / base_unet_run.yaml:96 = native AMP,
+torch.autocast(float16) around the forward pass): the 3x3 convolutions of unet_block.py:250-259 on ONE fp16 term (mrx_unet_conv3x3_p16, csrc/unet_f16.hip).
+Checkers, all on the CPU: the kernel's arithmetic restated (oracle.amp.fp16_kernel_arithmetic: fp16-rounded operands, wide sums -- tight), the reference's own
+arithmetic (oracle.amp.autocast_fp16: what the reference computes -- SURVEY appendix C's 3e-2), and the fp32 oracle (the route must sit no further from it
+than autocast does)."""
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+import oracle
+from mridc_amd import synthetic
+from tests._util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = 2e-6            # operator against float64 sums of the fp16-rounded operands (plain sources: the same roundings exactly)
+OP_TOL_LAZY = 3e-5       # lazy sources: the kernel normalises in fp32 before it rounds, the checker in float64 -- a value in 1e4 rounds the other way
+NET_TOL_KERNEL = 2e-3    # one NormUnet pass against the restated kernel arithmetic (measured 6e-4 .. 1.1e-3: rounding flips, see the test)
+NET_TOL_AUTOCAST = 3e-2  # against the reference under autocast(float16)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _r16(t):
+    return oracle.amp.fp16_round(t.float()).double()
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 0, 14, 64, 40), (2, 14, 14, 14, 37, 75), (1, 28, 28, 28, 160, 95), (3, 5, 3, 36, 9, 7), (1, 56, 0, 56, 33, 47),
+                                   (8, 14, 0, 14, 200, 700), (8, 14, 14, 14, 640, 372)], ids=lambda s: "x".join(map(str, s)))
+def test_unet_conv3x3_precision16_is_fp16_operands_with_wide_sums(shape, dev):
+    """mrx_unet_conv3x3_p16 (every cout-block count, 8- and 16-row work items, one and two sources, plain and lazy) against the CPU float64 convolution of the
+    fp16-rounded operands; the statistics against those of that result; and the fp32-class route untouched outside the context."""
+    from mridc_amd import ops
+    B, Ca, Cb, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    a_raw, b_raw = r(B, Ca, H, W) * 2 + 0.5, (r(B, Cb, H, W) - 0.3 if Cb else None)
+    w = r(Cout, Ca + Cb, 3, 3) / (9 * (Ca + Cb)) ** 0.5
+
+    def stats(t):
+        return torch.stack([t.mean((2, 3)), 1.0 / torch.sqrt(t.var((2, 3), unbiased=False) + 1e-5)], -1)
+
+    na, nb = stats(a_raw), (stats(b_raw) if Cb else None)
+
+    def lazy64(raw, n):
+        return Fn.leaky_relu((raw.double() - n[..., 0, None, None].double()) * n[..., 1, None, None].double(), 0.2)
+
+    for lazy in (False, True):
+        xs = [lazy64(a_raw, na) if lazy else a_raw.double()]
+        if Cb:
+            xs.append(lazy64(b_raw, nb) if lazy else b_raw.double())
+        ref = Fn.conv2d(_r16(torch.cat(xs, 1)), _r16(w), padding=1)                       # CPU, float64
+        src_a = (a_raw.to(dev), na.to(dev)) if lazy else a_raw.to(dev)
+        src_b = None if not Cb else ((b_raw.to(dev), nb.to(dev)) if lazy else b_raw.to(dev))
+        with ops.unet_precision(16):
+            y, norm = ops.unet_conv3x3(src_a, src_b, w.to(dev))
+        tol = OP_TOL_LAZY if lazy else OP_TOL
+        assert rel_l2(y, ref) <= tol, (shape, lazy, rel_l2(y, ref))
+        mean, var = ref.mean((2, 3)), ref.var((2, 3), unbiased=False)
+        assert (norm[..., 0].double().cpu() - mean).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+        assert rel_l2(norm[..., 1], 1.0 / torch.sqrt(var + 1e-5)) <= 10 * tol
+        full = Fn.conv2d(torch.cat(xs, 1), w.double(), padding=1)
+        y32, _ = ops.unet_conv3x3(src_a, src_b, w.to(dev))                                # outside the context: fp32-class
+        assert rel_l2(y32, full) <= 2e-6
+        assert 1e-5 <= rel_l2(y, full) <= 2e-3                                            # ... and the one-term result is fp16-operand-class, not more, not less
+
+
+def _load(model, sd, dev):
+    model.load_state_dict(sd, strict=False)
+    return model.to(dev).eval()
+
+
+@pytest.mark.parametrize("cfg", [(14, 2, 11, 640, 372), (18, 4, 15, 160, 96), (8, 3, 7, 45, 37)], ids=lambda c: f"{c[0]}ch_{c[1]}pools_{c[3]}x{c[4]}")
+def test_norm_unet_precision16_sits_at_the_restated_kernel_arithmetic(cfg, dev):
+    """ONE NormUnet pass (ten to eighteen 3x3 convolutions, unet_block.py:139-308) inside `unet_precision(16)` against the oracle with the kernels' arithmetic
+    restated.  Operator by operator the kernel makes the checker's roundings exactly (the test above; 8e-8 when the checker normalises in fp32 like the kernel,
+    profiles/r06_unet_p16_error_sources.txt); through a network the two InstanceNorm statistics differ by ~1e-6 (torch's fp32 sums against the kernels' tile sums
+    merged in double), one operand in ~500 then rounds to the other fp16 neighbour, and ten layers carry that to 6e-4 .. 1.1e-3 -- measured, about half the
+    1.4e-3 .. 2e-3 that fp16 operands cost against fp32.  So: within NET_TOL_KERNEL of the restated arithmetic, clearly closer to it than to fp32, and at the
+    fp32 oracle's distance from it that the restated arithmetic itself has."""
+    from mridc_amd import ops
+    from mridc_amd.collections.reconstruction.models.unet_base.unet_block import NormUnet
+    chans, pools, pad, H, W = cfg
+    torch.manual_seed(chans + pools)
+    net = NormUnet(chans, pools, padding_size=pad).eval()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(1, 1, H, W, 2, generator=torch.Generator().manual_seed(H))
+    with torch.no_grad():
+        ref32 = oracle.unet.norm_unet_forward(sd, x, pools, padding_size=pad)
+        with oracle.amp.fp16_kernel_arithmetic():
+            refk = oracle.unet.norm_unet_forward(sd, x, pools, padding_size=pad)
+        net = net.to(dev)
+        with ops.unet_precision(16):
+            got = net(x.to(dev))
+        got32 = net(x.to(dev))
+    e_k, e_32, k_32 = rel_l2(got, refk), rel_l2(got, ref32), rel_l2(refk, ref32)
+    assert rel_l2(got32, ref32) <= 2e-5
+    assert e_k <= NET_TOL_KERNEL and e_k <= 0.8 * e_32, (e_k, e_32)
+    assert 0.7 * k_32 <= e_32 <= 1.4 * k_32 and 1e-4 <= e_32 <= 1e-2, (e_32, k_32)
+
+
+@pytest.mark.parametrize("case", [(4, 48, 40, 2, 0), (15, 160, 372, 6, 1), (3, 64, 372, 3, 2)], ids=lambda c: f"C{c[0]}_{c[1]}x{c[2]}_{c[3]}casc")
+def test_varnet_precision16_against_kernel_arithmetic_autocast_and_fp32(case, dev):
+    """VarNet (E2EVN, base_vn_run.yaml) with `precision: 16` from its cfg on the HIP path -- hybrid cascades at W = 372, the k-space form elsewhere --
+    against the three CPU checkers."""
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    C, H, W, ncasc, seed = case
+    cfg = dict(synthetic.E2EVN_BASELINE_CFG, num_cascades=ncasc)
+    torch.manual_seed(seed)
+    model = VarNet(dict(cfg, precision=16)).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    d = synthetic.make_slice(C=C, H=H, W=W, slice_idx=seed)
+    args = (d["y"], d["sensitivity_maps"], d["mask"], None, d["target"])
+    with torch.no_grad():
+        ref32 = oracle.models.varnet_forward(sd, cfg, *args)
+        with oracle.amp.fp16_kernel_arithmetic():
+            refk = oracle.models.varnet_forward(sd, cfg, *args)
+        with oracle.amp.autocast_fp16():
+            refa = oracle.models.varnet_forward(sd, cfg, *args)
+    model = model.to(dev)
+    with torch.no_grad():
+        got = model(*(None if a is None else a.to(dev) for a in args))
+        model.precision = 32
+        got32 = model(*(None if a is None else a.to(dev) for a in args))
+    v = lambda t: torch.view_as_real(t.to(torch.complex64)).double().cpu()  # noqa: E731
+    e_k, e_a, e_32, a_32 = rel_l2(v(got), v(refk)), rel_l2(v(got), v(refa)), rel_l2(v(got), v(ref32)), rel_l2(v(refa), v(ref32))
+    assert rel_l2(v(got32), v(ref32)) <= 1e-4
+    assert e_a <= NET_TOL_AUTOCAST, (case, e_a)                          # the stated tolerance against the reference's own arithmetic
+    assert e_k <= max(e_32, 2e-4), (case, e_k, e_32)                     # (closer to its restated arithmetic than to fp32; tight per network pass: the test above)
+    assert e_32 <= max(2.0 * a_32, 2e-4), (case, e_32, a_32)              # no further from fp32 than the reference's own precision-16 arithmetic
+    assert e_32 >= 1e-6                                                   # (and it IS the one-term route)
+
+
+def test_unet_model_precision16_from_the_trainer(dev):
+    """UNet (base_unet_run.yaml:96) takes its precision from `trainer.precision` as the reference hands it to pytorch-lightning; MRIDC_AMD_PRECISION is the
+    process default; gradients recorded (training) keep the fp32-class convolutions."""
+    import types
+    from mridc_amd.collections.reconstruction.models.unet import UNet
+    cfg = dict(synthetic.E2EVN_BASELINE_CFG)
+    torch.manual_seed(3)
+    m16 = UNet(cfg, trainer=types.SimpleNamespace(precision=16)).eval()
+    sd = {k: v.detach().clone() for k, v in m16.state_dict().items()}
+    m32 = _load(UNet(cfg), sd, dev)
+    m16 = m16.to(dev)
+    d = synthetic.make_slice(C=4, H=64, W=48, slice_idx=1)
+    args = (d["y"], d["sensitivity_maps"], d["mask"], None, d["target"])
+    with torch.no_grad():
+        with oracle.amp.fp16_kernel_arithmetic():
+            refk = oracle.models.unet_model_forward(sd, cfg, *args)
+        ref32 = oracle.models.unet_model_forward(sd, cfg, *args)
+        g16 = m16(*(None if a is None else a.to(dev) for a in args))
+        g32 = m32(*(None if a is None else a.to(dev) for a in args))
+    v = lambda t: torch.view_as_real(t.to(torch.complex64)).double().cpu()  # noqa: E731
+    assert rel_l2(v(g16), v(refk)) <= NET_TOL_KERNEL
+    assert rel_l2(v(g32), v(ref32)) <= 1e-4
+    assert rel_l2(v(g16), v(g32)) >= 1e-6

@@ -99,3 +99,34 @@ def test_precision16_inference_checkers_against_their_definitions_and_the_fp32_o
         assert 1e-7 < d_ac < 3e-3 and 1e-7 < d_k < 3e-3, (boost, d_ac, d_k)
         assert d_ak < 2.0 * max(d_ac, d_k), (boost, d_ak, d_ac, d_k)
 
+
+
+def test_precision16_checkers_of_the_unet_models():
+    """The same two checkers for the U-Net models (base_vn_run.yaml:98, base_unet_run.yaml:96 `precision: 16`; mrx_unet_conv3x3_p16): inside
+    `fp16_kernel_arithmetic` the 3x3 convolutions of unet_block.py:250-259 multiply fp16-rounded operands with wide sums (transposed and 1x1 convolutions, the
+    normalisations, FFTs and the data consistency untouched: what the HIP route leaves in fp32), autocast is torch's own; both 1e-5 .. 1e-2 from the fp32
+    oracle on a two-cascade VarNet and as close to each other; the hook is restored."""
+    import contextlib
+    from oracle import unet as ounet
+    torch.manual_seed(1)
+    x, w0, w1 = torch.randn(2, 3, 12, 10), torch.randn(6, 3, 3, 3) / 5, torch.randn(6, 6, 3, 3) / 7
+    r16 = oracle.amp.fp16_round
+    with oracle.amp.fp16_kernel_arithmetic():
+        got = ounet.conv_block(x, w0, w1)
+    mid = ounet._in_lrelu(F.conv2d(r16(x).double(), r16(w0).double(), padding=1).float())
+    want = ounet._in_lrelu(F.conv2d(r16(mid).double(), r16(w1).double(), padding=1).float())
+    assert got.dtype == torch.float32 and float((got - want).abs().max()) <= 1e-5
+    assert ounet._CONV3X3[0] is F.conv2d
+    cfg = dict(synthetic.E2EVN_BASELINE_CFG, num_cascades=2)
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    torch.manual_seed(0)
+    state = {k: v.detach().clone() for k, v in VarNet(cfg).state_dict().items()}
+    s = synthetic.make_slice(4, 48, 40, slice_idx=3)
+    out = {}
+    for name, ctx in (("fp32", contextlib.nullcontext), ("autocast_fp16", oracle.amp.autocast_fp16), ("kernel", oracle.amp.fp16_kernel_arithmetic)):
+        with ctx(), torch.no_grad():
+            out[name] = torch.view_as_real(oracle.models.varnet_forward(state, cfg, s["y"], s["sensitivity_maps"], s["mask"], None, s["target"]).to(torch.complex64)).double()
+    rel = lambda a, b_: float((a - b_).norm() / b_.norm())  # noqa: E731
+    d_ac, d_k, d_ak = rel(out["autocast_fp16"], out["fp32"]), rel(out["kernel"], out["fp32"]), rel(out["kernel"], out["autocast_fp16"])
+    assert 1e-5 < d_ac < 1e-2 and 1e-5 < d_k < 1e-2, (d_ac, d_k)
+    assert d_ak < 2.0 * max(d_ac, d_k), (d_ak, d_ac, d_k)

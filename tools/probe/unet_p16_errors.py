@@ -1,0 +1,42 @@
+"""Precision-16 U-Net route: where the distance to the restated kernel arithmetic comes from (one-ulp flips of the fp16 operand rounding, amplified by the
+InstanceNorm chain).  Prints per-operator and per-network rel-L2 against the CPU checkers.  GPU box; imports oracle/ as a checker (a probe, not the product)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import torch.nn.functional as Fn
+import oracle
+from mridc_amd import ops
+from mridc_amd.collections.reconstruction.models.unet_base.unet_block import NormUnet
+
+dev = torch.device("cuda:0")
+rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())  # noqa: E731
+r16 = lambda t: oracle.amp.fp16_round(t.float()).double()  # noqa: E731
+g = torch.Generator().manual_seed(1)
+for (B, C, H, W) in ((1, 14, 640, 372), (1, 28, 160, 95)):
+    raw = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    w = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    n = torch.stack([raw.mean((2, 3)), 1.0 / torch.sqrt(raw.var((2, 3), unbiased=False) + 1e-5)], -1)
+    z64 = Fn.leaky_relu((raw.double() - n[..., 0, None, None].double()) * n[..., 1, None, None].double(), 0.2)
+    z32 = Fn.leaky_relu((raw - n[..., 0, None, None]) * n[..., 1, None, None], 0.2)
+    with ops.unet_precision(16):
+        y, _ = ops.unet_conv3x3((raw.to(dev), n.to(dev)), None, w.to(dev))
+    print(f"op {C}->{C} @{H}x{W} lazy: vs fp64-normalised-then-rounded {rel(y, Fn.conv2d(r16(z64), r16(w), padding=1)):.2e}, "
+          f"vs fp32-normalised-then-rounded {rel(y, Fn.conv2d(r16(z32), r16(w), padding=1)):.2e}, "
+          f"fraction of operands the two checkers round differently {float((r16(z64) != r16(z32)).double().mean()):.2e}")
+for chans, pools, pad, H, W in ((14, 2, 11, 640, 372), (18, 4, 15, 160, 96), (8, 3, 7, 45, 37)):
+    torch.manual_seed(chans + pools)
+    net = NormUnet(chans, pools, padding_size=pad).eval()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(1, 1, H, W, 2, generator=torch.Generator().manual_seed(H))
+    with torch.no_grad():
+        ref32 = oracle.unet.norm_unet_forward(sd, x, pools, padding_size=pad)
+        with oracle.amp.fp16_kernel_arithmetic():
+            refk = oracle.unet.norm_unet_forward(sd, x, pools, padding_size=pad)
+        with oracle.amp.autocast_fp16():
+            refa = oracle.unet.norm_unet_forward(sd, x, pools, padding_size=pad).float()
+        net = net.to(dev)
+        with ops.unet_precision(16):
+            got = net(x.to(dev))
+        got32 = net(x.to(dev))
+    print(f"NormUnet {chans}x{pools} @{H}x{W}: fp32 route vs fp32 oracle {rel(got32, ref32):.2e} | p16 vs kernel arithmetic {rel(got, refk):.2e}, vs autocast {rel(got, refa):.2e}, "
+          f"vs fp32 {rel(got, ref32):.2e} | kernel arithmetic vs fp32 {rel(refk, ref32):.2e}, autocast vs fp32 {rel(refa, ref32):.2e}")
