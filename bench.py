@@ -421,8 +421,9 @@ def bench_qcirim(args, world, rank, dev, checks=False):
     from mridc_amd import ops
     from mridc_amd.collections.quantitative.models.qcirim import qCIRIM
     cfg = QCIRIM_CFG
+    p16 = args.precision == 16          # the reference's own inference precision (base_qcirim_run.yaml:204): the 128 -> 128 3x3 convolutions on one fp16 term
     torch.manual_seed(0)
-    model = qCIRIM(cfg).eval()
+    model = qCIRIM(dict(cfg, precision=16) if p16 else cfg).eval()
     state_dict = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     E, C, H, W = 4, 32, 256, 256
@@ -453,12 +454,13 @@ def bench_qcirim(args, world, rank, dev, checks=False):
         _event_profile(timer, step, datas[0])
     elapsed, per_rank, graphed, outs = _replay_loop(step, datas, args)
     conc_ok = LAST_CONCURRENCY_CHECK.get("bit_identical")
-    res = dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256", value=world * NS * args.steps / elapsed,
+    res = dict(metric="slices/sec (inference), qCIRIM 4-echo 32-coil 256x256" + (", precision 16" if p16 else ""), value=world * NS * args.steps / elapsed,
                unit="slices/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
                higher_is_better=True, scaling="weak", vs_baseline=None, world_size_seen=world_seen(),
-               per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank], dtype="f32", data="synthetic",
+               per_rank_ms_per_step=[1e3 * t / args.steps for t in per_rank],
+               dtype="f16 operands in the 128 -> 128 3x3 convolutions (fp32 sums; 5x5 / 1x1 layers, signal model, FFT fp32-class)" if p16 else "f32", data="synthetic",
                config=dict(workload=f"qCIRIM 1 cascade x 8 time-steps, IndRNN 128 filters, 4 echoes, 32 coils, 256x256, {NS} slice(s) "
-                                    f"per GPU and step ({NS} HIP stream(s), {'hipGraph' if graphed else 'eager'}), random-init weights",
+                                    f"per GPU and step ({NS} HIP stream(s), {'hipGraph' if graphed else 'eager'}), random-init weights" + (", trainer.precision = 16" if p16 else ""),
                            parallelism=f"slice-sharded x{world}"))
     res["concurrent_replays_bit_identical_to_serial"] = conc_ok
     if checks and rank == 0:
@@ -467,16 +469,16 @@ def bench_qcirim(args, world, rank, dev, checks=False):
         if msh:
             # the default: the 128 -> 128 3x3 dilation-2 layer on two-term fp16 operands (mrx_conv3x3_h): 3 term products per multiply, the 18 tap
             # slots of a 16-channel step padded to 20 (five MFMAs of four slots)
-            issued = direct * 3.0 * 20.0 / 18.0
+            issued = direct * (1.0 if p16 else 3.0) * 20.0 / 18.0
             res["roofline"] = dict(
-                bound="mfma", kernel="k_uconv_h<4, 2, false> via mrx_conv3x3_h (the qRIM's 3x3 dilation-2 128 -> 128 convolution: two-term fp16 operands on "
-                                     "v_mfma_f32_16x16x32_f16, 3 term products, fp32 accumulation; 4 cout blocks of 16 per work item; the bound of its input "
+                bound="mfma", kernel=f"k_uconv_h<4, 2, false> via mrx_conv3x3_{'p16' if p16 else 'h'} (the qRIM's 3x3 dilation-2 128 -> 128 convolution: {'one-term' if p16 else 'two-term'} fp16 operands on "
+                                     f"v_mfma_f32_16x16x32_f16, {1 if p16 else 3} term product(s), fp32 accumulation; 4 cout blocks of 16 per work item; the bound of its input "
                                      "kept by the preceding 1x1 cell kernel)",
                 achieved=issued / (msh * 1e-3) / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", frac=issued / (msh * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                 frac_meaning="fp16 MFMA FLOPs the kernel issues (3 term products, slot padding included) / dense fp16 MFMA peak",
                 algorithmic_achieved=direct / (msh * 1e-3) / 1e12, launches=nh, avg_ms=msh, flops_per_launch=direct, mfma_flops_per_launch=issued,
-                traffic=measured_traffic(1, 15, 640, 372, 64).get("qcirim_conv3x3_h_128") if (H, W) == (256, 256) else None, traffic_unit="bytes/launch",
-                mfma_util_pmc=(measured_traffic(1, 15, 640, 372, 64).get("_mfma_util") or {}).get("qcirim_conv3x3_h_128") if (H, W) == (256, 256) else None,
+                traffic=measured_traffic(1, 15, 640, 372, 64).get("qcirim_conv3x3_h_128") if ((H, W) == (256, 256) and not p16) else None, traffic_unit="bytes/launch",
+                mfma_util_pmc=(measured_traffic(1, 15, 640, 372, 64).get("_mfma_util") or {}).get("qcirim_conv3x3_h_128") if ((H, W) == (256, 256) and not p16) else None,
                 algorithmic_bytes=2.0 * 128 * H * W * 4, hbm_frac=2.0 * 128 * H * W * 4 / (msh * 1e-3) / 1e9 / PEAK_HBM_GBS)
         else:
             ms, n = timer.mean_ms("wino_128x128")
@@ -493,6 +495,8 @@ def bench_qcirim(args, world, rank, dev, checks=False):
             import oracle
             ncores, box_cores = _oracle_threads()
             h = hosts[0]
+            # (precision 16: torch's CPU autocast needs 300 s per slice at this size -- 128-channel fp16 convolutions -- so the fp32 oracle is timed and compared
+            # here; the autocast checker runs at 8 coils x 64 x 64 in tests/test_gpu_unet_p16.py)
             with torch.no_grad():
                 oracle.qrim.qcirim_forward(state_dict, cfg, h[0], h[1], h[2], h[3], TEs, h[4], h[5], None, h[6])          # warm-up
                 dts = []
@@ -503,7 +507,7 @@ def bench_qcirim(args, world, rank, dev, checks=False):
                 dt = sum(dts) / len(dts)
             res["cpu_baseline"] = dict(value=1.0 / dt, unit="slices/s", cores=ncores, kind="port", box_cores=box_cores, cpu_model=cpu_model_name(),
                                        slices_timed=len(dts), sec_per_slice=dts,
-                                       sample=f"{len(dts)} whole slice(s) (1 cascade x 8 time-steps) on the oracle after one untimed warm-up slice, "
+                                       sample=f"{len(dts)} whole slice(s) (1 cascade x 8 time-steps) on the {'fp32 ' if p16 else ''}oracle after one untimed warm-up slice, "
                                               f"torch CPU ops on {ncores} threads, value = 1 / mean seconds per slice, {sum(dts):.1f} s in all")
             out = outs[0] if graphed else step(datas[0])
             torch.cuda.synchronize()
@@ -512,7 +516,9 @@ def bench_qcirim(args, world, rank, dev, checks=False):
                 got, want = out[1 + m_][-1][-1].cpu().double(), ref[1 + m_][-1][-1].double()
                 rels.append(float((got - want).norm() / want.norm()))
             res["parity_vs_oracle"] = dict(rel_l2=max(rels), rel_l2_per_map=dict(zip(("R2star", "S0", "B0", "phi"), rels)),
-                                           at="the four maps after the last time-step, same weights and inputs")
+                                           at="the four maps after the last time-step, same weights and inputs"
+                                              + ("; checker: the fp32 oracle (the reference's autocast arithmetic costs 300 s per slice on this host: tests/test_gpu_unet_p16.py "
+                                                 "checks against it at 8 coils x 64 x 64), tolerance 3e-2" if p16 else ""))
         except Exception as ex:  # noqa: BLE001
             res["cpu_baseline"] = dict(value=None, unit="slices/s", cores=os.cpu_count(), kind="port", sample=f"failed: {type(ex).__name__}: {ex}")
     return res
@@ -900,7 +906,7 @@ def summary_of(res):
     if isinstance(res.get("streamed_inputs"), dict):
         out["streamed"] = dict(v=r3(res["streamed_inputs"].get("value")))
     short = {"e2evn_6cascade_15coil_640x372": "e2evn", "qcirim_4echo_32coil_256x256": "qcirim", "cirim_training_bf16_15coil_640x372": "train_bf16",
-             "e2evn_training_15coil_640x372": "train_e2evn", "cirim_2d_mask_15coil_640x372": "mask2d", "cirim_precision16_15coil_640x372": "prec16", "e2evn_precision16_15coil_640x372": "e2evn16",
+             "e2evn_training_15coil_640x372": "train_e2evn", "cirim_2d_mask_15coil_640x372": "mask2d", "cirim_precision16_15coil_640x372": "prec16", "e2evn_precision16_15coil_640x372": "e2evn16", "qcirim_precision16_4echo_32coil_256x256": "qcirim16",
              "cirim_8cascade_x5_time_steps_rimblock_direct": "rim5"}
     for k, r in (res.get("other_configs") or {}).items():
         out[short.get(k, k)] = {a: b for a, b in (one(r) or {}).items() if b is not None}
@@ -1693,7 +1699,8 @@ def main():
             others = {}
             for name, fn, over in (("e2evn_6cascade_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=8, streams=2, steps=6, warmup=2)),
                                    ("e2evn_precision16_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=8, streams=2, steps=6, warmup=2, precision=16, cpu_slices=1)),
-                                   ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=4, steps=10, warmup=2))):
+                                   ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=4, steps=10, warmup=2)),
+                                   ("qcirim_precision16_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=4, steps=10, warmup=2, precision=16, cpu_slices=1))):
                 a2 = copy.copy(args)
                 for k_, v_ in over.items():
                     setattr(a2, k_, v_)

@@ -818,6 +818,10 @@ int mrx_unet_conv3x3_hc(const float* xa, const float* na, const float* bound_a, 
 int mrx_conv3x3_h_supported(int Cin, int Cout, int k, int dil);
 int mrx_conv3x3_h(const float* x, const float* bound, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int dil,
                   int pad_mode, int act, float slope, void* stream);
+/*   mrx_conv3x3_p16   mrx_conv3x3_h in the reference's `precision: 16` inference arithmetic (base_qcirim_run.yaml:204 ...: torch.autocast(float16) around forward;
+ *                     conv_layers.py:121-123 under it): operands rounded to fp16 once (the first term of the same pack), fp32 sums, fp32 result */
+int mrx_conv3x3_p16(const float* x, const float* bound, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int dil,
+                  int pad_mode, int act, float slope, void* stream);
 int64_t mrx_unet_conv_transpose2x2_work_floats(int B, int Cout, int H, int W);
 int mrx_unet_conv_transpose2x2(const float* x, const float* nrm, const float* w, float* out, float* norm, float* work, int B, int Cin, int Cout,
                       int H, int W, float eps, float slope, void* stream);

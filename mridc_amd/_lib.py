@@ -161,6 +161,7 @@ _SIGNATURES = {
     "mrx_unet_conv3x3_hc": ([_p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p], _i),
     "mrx_conv3x3_h_supported": ([_i, _i, _i, _i], _i),
     "mrx_conv3x3_h": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
+    "mrx_conv3x3_p16": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_unet_conv3x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p], _i),
     "mrx_unet_conv_transpose2x2_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_unet_conv_transpose2x2": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p], _i),

@@ -50,6 +50,10 @@ class qCIRIM(torch.nn.Module):
         self.accumulate_estimates = cfg_dict.get("quantitative_module_accumulate_estimates")
         self.gamma = torch.tensor(cfg_dict.get("quantitative_module_gamma_regularization_factors"), dtype=torch.float32)
         self.preprocessor = qrim_utils.RescaleByMax
+        # `trainer.precision` (base_qcirim_run.yaml:204: 16 = native AMP around the forward pass) or a `precision` key of cfg: 16 runs the 3x3 convolutions of the
+        # qRIM blocks on one fp16 term (mrx_conv3x3_p16) at inference; None: the process default (MRIDC_AMD_PRECISION)
+        prec = getattr(trainer, "precision", None) if trainer is not None else None
+        self.precision = cfg_dict.get("precision", None) if prec is None else prec
 
     def forward(self, R2star_map_init: torch.Tensor, S0_map_init: torch.Tensor, B0_map_init: torch.Tensor,
                 phi_map_init: torch.Tensor, TEs: List, y: torch.Tensor, sensitivity_maps: torch.Tensor, mask_brain: torch.Tensor,
@@ -63,9 +67,11 @@ class qCIRIM(torch.nn.Module):
         prediction = y
         eta, hx = None, None
         cascades = [[], [], [], []]
+        p16 = None if (self.training and torch.is_grad_enabled()) else ops.resolve_precision16(self.precision)
         for i, cascade in enumerate(self.qcirim):
-            prediction, hx = cascade(prediction, y, R2star_map_pred, S0_map_pred, B0_map_pred, phi_map_pred, TEs, sensitivity_maps,
-                                     sampling_mask, eta, hx, self.gamma, keep_eta=i != 0)
+            with ops.inference_precision(p16):
+                prediction, hx = cascade(prediction, y, R2star_map_pred, S0_map_pred, B0_map_pred, phi_map_pred, TEs, sensitivity_maps,
+                                         sampling_mask, eta, hx, self.gamma, keep_eta=i != 0)
             R2star_map_pred, S0_map_pred, B0_map_pred, phi_map_pred = (prediction[-1][:, 0], prediction[-1][:, 1],
                                                                        prediction[-1][:, 2], prediction[-1][:, 3])
             steps = [[], [], [], []]

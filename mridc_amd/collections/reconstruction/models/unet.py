@@ -38,10 +38,9 @@ class UNet(torch.nn.Module):
             fft.ifft2(y, centered=self.fft_centered, normalization=self.fft_normalization, spatial_dims=self.spatial_dims),
             sensitivity_maps, method=self.coil_combination_method, dim=self.coil_dim))
         _, eta = utils.center_crop_to_smallest(target, eta)
-        from mridc_amd import _lib, ops
-        prec = self.precision if self.precision is not None else _lib.precision()
-        p16 = str(prec).lower() in ("16", "fp16", "16-mixed") and not (self.training and torch.is_grad_enabled())
-        with ops.unet_precision(16 if p16 else None):
+        from mridc_amd import ops
+        p16 = None if (self.training and torch.is_grad_enabled()) else ops.resolve_precision16(self.precision)
+        with ops.inference_precision(p16):
             return torch.view_as_complex(self.unet(torch.view_as_real(eta.unsqueeze(self.coil_dim)))).squeeze(self.coil_dim)
 
     forward_step = forward

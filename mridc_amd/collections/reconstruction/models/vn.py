@@ -48,10 +48,7 @@ class VarNet(torch.nn.Module):
         self.precision = cfg_dict.get("precision", None) if prec is None else prec
 
     def _inference_precision(self):
-        from mridc_amd import _lib
-        prec = self.precision if self.precision is not None else _lib.precision()
-        return 16 if str(prec).lower() in ("16", "fp16", "16-mixed") else None
-
+        return ops.resolve_precision16(self.precision)
 
     def _hybrid_ok(self, mask):
         """Row-invariant (1-D column) mask + SENSE combination: the masked data consistency commutes with the H transform, so the
@@ -87,11 +84,11 @@ class VarNet(torch.nn.Module):
             estimation = diff.ifft2(estimation, self.fft_centered, self.fft_normalization, self.spatial_dims)
             estimation = diff.coil_combination(estimation, sensitivity_maps, method=self.coil_combination_method, dim=self.coil_dim)
         elif self._hybrid_ok(mask):
-            with ops.unet_precision(self._inference_precision()):
+            with ops.inference_precision(self._inference_precision()):
                 estimation = self._forward_hybrid(y, sensitivity_maps, mask)
         else:
             estimation = y.clone()
-            with ops.unet_precision(self._inference_precision()):
+            with ops.inference_precision(self._inference_precision()):
                 for cascade in self.cascades:
                     estimation = cascade(estimation, y, sensitivity_maps, mask)
             estimation = fft.ifft2(estimation, centered=self.fft_centered, normalization=self.fft_normalization,

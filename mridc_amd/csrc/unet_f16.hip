@@ -252,7 +252,7 @@ template <int NCOT, int DIL, bool UNET, bool TK = false, int TH = UH_TH, int TER
 __global__ __launch_bounds__(UH_NT, TH == 16 ? 3 : UH_WGS(NCOT, TK)) void k_uconv_h(UConvHArgs a) {
     static_assert(TH == 8 || TH == 16, "8 or 16 rows per work item");
     static_assert(TH == 8 || !TK, "the ticket form walks 8-row tiles");
-    static_assert(TERMS == 2 || (TERMS == 1 && UNET && !TK), "one term: the U-Net convolutions of the precision-16 route");
+    static_assert(TERMS == 2 || (TERMS == 1 && !TK), "one term: the precision-16 route (no ticket form)");
     constexpr int RPW = TH / 4, NSG = 2 * RPW;                    // image rows per wave, 16-pixel accumulator tiles per wave and output-channel block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_uh[];
     constexpr int UH_PW = uh_pw(DIL), UH_PIX = uh_pix(DIL, TH), UH_PLANE = uh_plane(DIL, TH), UH_XBUF = uh_xbuf(DIL, TH, TERMS);
@@ -687,8 +687,8 @@ extern "C" int mrx_unet_conv3x3_hc(const float* xa, const float* na, const float
 extern "C" int mrx_conv3x3_h_supported(int Cin, int Cout, int k, int dil) {
     return Cin >= 1 && Cout >= 1 && k == 3 && (dil == 1 || dil == 2) && mrx_arith() == MRX_ARITH_F16X2;
 }
-extern "C" int mrx_conv3x3_h(const float* x, const float* bound, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H,
-                             int W, int dil, int pad_mode, int act, float slope, void* stream) {
+static int conv3x3_h_impl(const float* x, const float* bound, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int dil,
+                          int pad_mode, int act, float slope, void* stream, int terms) {
     MRX_REQUIRE(x && bound && packed && y && x != y, MRX_EINVAL, "mrx_conv3x3_h: null or aliased pointer");
     MRX_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && (dil == 1 || dil == 2), MRX_EINVAL, "mrx_conv3x3_h: bad dims");
     MRX_REQUIRE(pad_mode == MRX_PAD_ZERO || pad_mode == MRX_PAD_REPLICATE, MRX_EINVAL, "mrx_conv3x3_h: bad pad mode %d", pad_mode);
@@ -707,6 +707,23 @@ extern "C" int mrx_conv3x3_h(const float* x, const float* bound, const float* pa
     a.counters = nullptr, a.norm = nullptr, a.eps = 0.f;
     hipStream_t st = (hipStream_t)stream;
     const int ncot = uh_pick_ncot(a.nct, (long long)a.ntiles * B);
+    if (terms == 1) {
+        if (dil == 1)
+            return ncot == 4 ? launch_uconv_h<4, 1, false, false, UH_TH, 1>(a, st)
+                             : (ncot == 2 ? launch_uconv_h<2, 1, false, false, UH_TH, 1>(a, st) : launch_uconv_h<1, 1, false, false, UH_TH, 1>(a, st));
+        return ncot == 4 ? launch_uconv_h<4, 2, false, false, UH_TH, 1>(a, st)
+                         : (ncot == 2 ? launch_uconv_h<2, 2, false, false, UH_TH, 1>(a, st) : launch_uconv_h<1, 2, false, false, UH_TH, 1>(a, st));
+    }
     if (dil == 1) return ncot == 4 ? launch_uconv_h<4, 1, false>(a, st) : (ncot == 2 ? launch_uconv_h<2, 1, false>(a, st) : launch_uconv_h<1, 1, false>(a, st));
     return ncot == 4 ? launch_uconv_h<4, 2, false>(a, st) : (ncot == 2 ? launch_uconv_h<2, 2, false>(a, st) : launch_uconv_h<1, 2, false>(a, st));
+}
+extern "C" int mrx_conv3x3_h(const float* x, const float* bound, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H,
+                             int W, int dil, int pad_mode, int act, float slope, void* stream) {
+    return conv3x3_h_impl(x, bound, packed, bias, y, B, Cin, Cout, H, W, dil, pad_mode, act, slope, stream, 2);
+}
+// ... in the reference's `precision: 16` inference arithmetic (base_qcirim_run.yaml:204 and every other *_run.yaml: torch.autocast(float16)): operands rounded to
+// fp16 once (the first term of the same pack), fp32 sums, fp32 result (see mrx_unet_conv3x3_p16)
+extern "C" int mrx_conv3x3_p16(const float* x, const float* bound, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H,
+                               int W, int dil, int pad_mode, int act, float slope, void* stream) {
+    return conv3x3_h_impl(x, bound, packed, bias, y, B, Cin, Cout, H, W, dil, pad_mode, act, slope, stream, 1);
 }

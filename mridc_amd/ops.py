@@ -951,6 +951,37 @@ def conv3x3_taps(x, weight, bias, pad_mode=PAD_ZERO, out=None):
     return out
 
 
+# The reference's inference precision (`trainer.precision: 16` in every *_run.yaml of its model zoo, e.g. base_vn_run.yaml:98, base_qcirim_run.yaml:204): inside
+# `inference_precision(16)` the 3x3 convolutions of the two-term fp16 route run on ONE fp16 term (mrx_unet_conv3x3_p16, mrx_conv3x3_p16).  Set by the models'
+# inference forward (VarNet, UNet, qCIRIM); None inside / outside: fp32-class results.  (The RIM blocks of CIRIM have their own fp16 kernels: RIMBlock.precision.)
+_INFERENCE_PRECISION = [None]
+
+
+class inference_precision:
+    def __init__(self, precision):
+        self.precision = precision
+
+    def __enter__(self):
+        self.keep = _INFERENCE_PRECISION[0]
+        _INFERENCE_PRECISION[0] = self.precision
+        return self
+
+    def __exit__(self, *exc):
+        _INFERENCE_PRECISION[0] = self.keep
+        return False
+
+
+def _precision16():
+    p = _INFERENCE_PRECISION[0]
+    return p is not None and str(p).lower() in ("16", "fp16", "16-mixed")
+
+
+def resolve_precision16(model_precision):
+    """16 if the model's precision (its trainer's / cfg's; None: the process default, MRIDC_AMD_PRECISION) asks for the reference's `precision: 16`, else None."""
+    prec = model_precision if model_precision is not None else _lib.precision()
+    return 16 if str(prec).lower() in ("16", "fp16", "16-mixed") else None
+
+
 H3X3_CONV = True                  # (module attribute: a test hook) 3x3 convolutions of wide layers on two-term fp16 operands (mrx_conv3x3_h)
 H3X3_MIN_CIN = 32
 
@@ -979,8 +1010,10 @@ def conv3x3_h(x, weight, bias, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slop
     b = _lib.f32c(bias.detach()) if bias is not None else None
     if out is None:
         out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
-    _lib.check(L.mrx_conv3x3_h(_lib.ptr(x), _lib.ptr(bnd), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W, int(dilation),
-                               int(pad_mode), int(act), float(slope), _lib.stream_ptr()), "mrx_conv3x3_h")
+    p16 = _precision16()                  # inside inference_precision(16): the first fp16 term only (mrx_conv3x3_p16)
+    _lib.check((L.mrx_conv3x3_p16 if p16 else L.mrx_conv3x3_h)(_lib.ptr(x), _lib.ptr(bnd), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W,
+                                                              int(dilation), int(pad_mode), int(act), float(slope), _lib.stream_ptr()),
+               "mrx_conv3x3_p16" if p16 else "mrx_conv3x3_h")
     return out
 
 
@@ -2231,24 +2264,6 @@ UNET_F16 = True                   # (module attribute: a test hook for the fp32-
 # with one 128-byte line per ticket and the tile stored behind the tickets -- 960 returning atomics per plane address still cost more than the 5-us launch
 # they replace (tools/runs/r05i.sh).  MRX_UNET_FOLD=1 / this attribute switch it on (tests/test_gpu_unet_fused.py covers it).
 UNET_FOLD_FINALIZE = os.environ.get("MRX_UNET_FOLD", "0") == "1"
-# The reference's inference precision for the U-Net models (`trainer.precision: 16`, base_vn_run.yaml:98 / base_unet_run.yaml:96): inside `unet_precision(16)`
-# the 3x3 convolutions of the two-term fp16 route run on ONE fp16 term (mrx_unet_conv3x3_p16).  Set by the models' inference forward (VarNet, UNet); None
-# inside / outside: fp32-class results.
-_UNET_PRECISION = [None]
-
-
-class unet_precision:
-    def __init__(self, precision):
-        self.precision = precision
-
-    def __enter__(self):
-        self.keep = _UNET_PRECISION[0]
-        _UNET_PRECISION[0] = self.precision
-        return self
-
-    def __exit__(self, *exc):
-        _UNET_PRECISION[0] = self.keep
-        return False
 _UNET_TICKETS = {}
 
 
@@ -2336,7 +2351,7 @@ def unet_conv3x3(src_a, src_b, weight, eps=1e-5, slope=0.2):
         packed = _UNET_PACKS.get(weight, (), make)
         ba = None if na is not None else _plain_bound(src_a if not isinstance(src_a, tuple) else xa)
         bb = None if (xb is None or nb is not None) else _plain_bound(src_b if not isinstance(src_b, tuple) else xb)
-        if _UNET_PRECISION[0] is not None and int(_UNET_PRECISION[0]) == 16:
+        if _precision16():
             _lib.check(L.mrx_unet_conv3x3_p16(_lib.ptr(xa), _lib.ptr(na), _lib.ptr(ba), Ca, _lib.ptr(xb), _lib.ptr(nb), _lib.ptr(bb), Cb, _lib.ptr(packed),
                                               _lib.ptr(y), _lib.ptr(norm), _lib.ptr(work), B, Cout, H, W, float(eps), float(slope), _lib.stream_ptr()),
                        "mrx_unet_conv3x3_p16")

@@ -1,4 +1,4 @@
-"""GPU parity of the U-Net models' precision-16 inference route (`trainer.precision: 16`, reference base_vn_run.yaml:98 / base_unet_run.yaml:96 = native AMP,
+"""GPU parity of the precision-16 inference route of the U-Net models and of the wide plain 3x3 convolutions (qCIRIM) (`trainer.precision: 16`, reference base_vn_run.yaml:98 / base_unet_run.yaml:96 = native AMP,
 torch.autocast(float16) around the forward pass): the 3x3 convolutions of unet_block.py:250-259 on ONE fp16 term (mrx_unet_conv3x3_p16, csrc/unet_f16.hip).
 Checkers, all on the CPU: the kernel's arithmetic restated (oracle.amp.fp16_kernel_arithmetic: fp16-rounded operands, wide sums -- tight), the reference's own
 arithmetic (oracle.amp.autocast_fp16: what the reference computes -- SURVEY appendix C's 3e-2), and the fp32 oracle (the route must sit no further from it
@@ -56,7 +56,7 @@ def test_unet_conv3x3_precision16_is_fp16_operands_with_wide_sums(shape, dev):
         ref = Fn.conv2d(_r16(torch.cat(xs, 1)), _r16(w), padding=1)                       # CPU, float64
         src_a = (a_raw.to(dev), na.to(dev)) if lazy else a_raw.to(dev)
         src_b = None if not Cb else ((b_raw.to(dev), nb.to(dev)) if lazy else b_raw.to(dev))
-        with ops.unet_precision(16):
+        with ops.inference_precision(16):
             y, norm = ops.unet_conv3x3(src_a, src_b, w.to(dev))
         tol = OP_TOL_LAZY if lazy else OP_TOL
         assert rel_l2(y, ref) <= tol, (shape, lazy, rel_l2(y, ref))
@@ -76,7 +76,7 @@ def _load(model, sd, dev):
 
 @pytest.mark.parametrize("cfg", [(14, 2, 11, 640, 372), (18, 4, 15, 160, 96), (8, 3, 7, 45, 37)], ids=lambda c: f"{c[0]}ch_{c[1]}pools_{c[3]}x{c[4]}")
 def test_norm_unet_precision16_sits_at_the_restated_kernel_arithmetic(cfg, dev):
-    """ONE NormUnet pass (ten to eighteen 3x3 convolutions, unet_block.py:139-308) inside `unet_precision(16)` against the oracle with the kernels' arithmetic
+    """ONE NormUnet pass (ten to eighteen 3x3 convolutions, unet_block.py:139-308) inside `inference_precision(16)` against the oracle with the kernels' arithmetic
     restated.  Operator by operator the kernel makes the checker's roundings exactly (the test above; 8e-8 when the checker normalises in fp32 like the kernel,
     profiles/r06_unet_p16_error_sources.txt); through a network the two InstanceNorm statistics differ by ~1e-6 (torch's fp32 sums against the kernels' tile sums
     merged in double), one operand in ~500 then rounds to the other fp16 neighbour, and ten layers carry that to 6e-4 .. 1.1e-3 -- measured, about half the
@@ -94,7 +94,7 @@ def test_norm_unet_precision16_sits_at_the_restated_kernel_arithmetic(cfg, dev):
         with oracle.amp.fp16_kernel_arithmetic():
             refk = oracle.unet.norm_unet_forward(sd, x, pools, padding_size=pad)
         net = net.to(dev)
-        with ops.unet_precision(16):
+        with ops.inference_precision(16):
             got = net(x.to(dev))
         got32 = net(x.to(dev))
     e_k, e_32, k_32 = rel_l2(got, refk), rel_l2(got, ref32), rel_l2(refk, ref32)
@@ -158,3 +158,75 @@ def test_unet_model_precision16_from_the_trainer(dev):
     assert rel_l2(v(g16), v(refk)) <= NET_TOL_KERNEL
     assert rel_l2(v(g32), v(ref32)) <= 1e-4
     assert rel_l2(v(g16), v(g32)) >= 1e-6
+
+
+# (B, Cin, Cout, H, W, dilation, pad mode (0 zero, 1 replicate), activation (0 none, 1 ReLU, 2 LeakyReLU))
+@pytest.mark.parametrize("case", [(1, 128, 128, 64, 64, 2, 1, 1), (2, 64, 32, 21, 40, 1, 0, 2), (1, 24, 70, 33, 47, 2, 1, 0), (1, 128, 128, 256, 256, 2, 1, 1)],
+                         ids=lambda c: f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_d{c[5]}")
+def test_conv3x3_precision16_is_fp16_operands_with_wide_sums(case, dev):
+    """mrx_conv3x3_p16 (the plain 3x3 convolution of the wide layers -- the qRIM's 128 -> 128 dilation 2, conv_layers.py:121-123; bias + activation epilogue, zero and
+    replicate padding, every cout-block count) against the CPU float64 convolution of the fp16-rounded operands; fp32-class outside the context."""
+    from mridc_amd import ops
+    B, Cin, Cout, H, W, dil, pad_mode, act = case[0], case[1], case[2], case[3], case[4], case[5], case[6], case[7]
+    g = torch.Generator().manual_seed(Cin + H)
+    x, w, b = torch.randn(B, Cin, H, W, generator=g), torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, torch.randn(Cout, generator=g)
+
+    def ref_of(xx, ww):
+        xp = Fn.pad(xx, (dil,) * 4, mode="replicate" if pad_mode == ops.PAD_REPLICATE else "constant")
+        y = Fn.conv2d(xp, ww, b.double(), dilation=dil)
+        return Fn.relu(y) if act == ops.ACT_RELU else (Fn.leaky_relu(y, 0.1) if act == ops.ACT_LEAKY else y)
+
+    with ops.inference_precision(16):
+        got = ops.conv3x3_h(x.to(dev), w.to(dev), b.to(dev), dil, pad_mode, act, 0.1)
+    got32 = ops.conv3x3_h(x.to(dev), w.to(dev), b.to(dev), dil, pad_mode, act, 0.1)
+    assert rel_l2(got, ref_of(_r16(x), _r16(w))) <= OP_TOL, rel_l2(got, ref_of(_r16(x), _r16(w)))
+    assert rel_l2(got32, ref_of(x.double(), w.double())) <= 2e-6
+    assert 1e-5 <= rel_l2(got, got32) <= 2e-3
+
+
+def test_qcirim_precision16_against_autocast_and_fp32(dev):
+    """qCIRIM (base_qcirim_run.yaml:204 `precision: 16`) with the precision from its cfg: one cascade of eight steps (IndRNN, 128 filters) at 4 echoes x 8 coils x
+    64 x 64 -- the 3x3 dilation-2 128 -> 128 convolutions on one fp16 term, the 5x5 / 1x1 layers, the signal model and the FFTs as before -- within SURVEY appendix
+    C's 3e-2 of the oracle under torch.autocast(float16), no further from the fp32 oracle than that oracle is, and not the fp32-class route."""
+    from mridc_amd.collections.quantitative.models.qcirim import qCIRIM
+    cfg = {"quantitative_module_recurrent_layer": "IndRNN", "quantitative_module_conv_filters": [128, 128, 4],
+           "quantitative_module_conv_kernels": [5, 3, 3], "quantitative_module_conv_dilations": [1, 2, 1],
+           "quantitative_module_conv_bias": [True, True, False], "quantitative_module_recurrent_filters": [128, 128, 0],
+           "quantitative_module_recurrent_kernels": [1, 1, 0], "quantitative_module_recurrent_dilations": [1, 1, 0],
+           "quantitative_module_recurrent_bias": [True, True, False], "quantitative_module_depth": 2,
+           "quantitative_module_time_steps": 8, "quantitative_module_num_cascades": 1, "quantitative_module_no_dc": True,
+           "quantitative_module_signal_forward_model_sequence": "MEGRE", "quantitative_module_dimensionality": 2,
+           "quantitative_module_gamma_regularization_factors": [150.0, 150.0, 1000.0, 150.0], "use_reconstruction_module": False,
+           "fft_centered": False, "fft_normalization": "backward", "spatial_dims": [-2, -1], "coil_dim": 2,
+           "coil_combination_method": "SENSE"}
+    torch.manual_seed(0)
+    model = qCIRIM(dict(cfg, precision=16)).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("rnn.ih.weight") or n.endswith("rnn.hh"):
+                p.mul_(4.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    E, C, H, W = 4, 8, 64, 64
+    TEs = [3.0, 11.5, 20.0, 28.5]
+    g = torch.Generator().manual_seed(42)
+    maps = [torch.rand(1, H, W, generator=g) * s for s in (60.0, 1.0, 30.0, 0.5)]
+    S = torch.randn(1, C, H, W, 2, generator=g) / C ** 0.5
+    mask = (torch.rand(1, 1, 1, 1, W, 1, generator=g) < 0.3)
+    y = torch.randn(1, E, C, H, W, 2, generator=g) * mask
+    with torch.no_grad():
+        ref32 = oracle.qrim.qcirim_forward(sd, cfg, maps[0], maps[1], maps[2], maps[3], TEs, y, S, None, mask)
+        with oracle.amp.autocast_fp16():
+            refa = oracle.qrim.qcirim_forward(sd, cfg, maps[0], maps[1], maps[2], maps[3], TEs, y, S, None, mask)
+    model = model.to(dev)
+    args = [m_.to(dev) for m_ in maps] + [TEs, y.to(dev), S.to(dev), None, mask.to(dev)]
+    with torch.no_grad():
+        out = next(model(*args))
+        model.precision = 32
+        out32 = next(model(*args))
+    last = lambda o: torch.stack([o[1 + m_][-1][-1].float().cpu() for m_ in range(4)]).double()  # noqa: E731  (the four maps after the last step)
+    got, got32, w32, wa = last(out), last(out32), last(ref32), last(refa)
+    assert rel_l2(got32, w32) <= 5e-5
+    e_a, e_32, a_32 = rel_l2(got, wa), rel_l2(got, w32), rel_l2(wa, w32)
+    assert e_a <= NET_TOL_AUTOCAST, e_a
+    assert e_32 <= max(2.0 * a_32, 2e-4), (e_32, a_32)
+    assert e_32 >= 1e-6

@@ -18,7 +18,7 @@ for (B, C, H, W) in ((1, 14, 640, 372), (1, 28, 160, 95)):
     n = torch.stack([raw.mean((2, 3)), 1.0 / torch.sqrt(raw.var((2, 3), unbiased=False) + 1e-5)], -1)
     z64 = Fn.leaky_relu((raw.double() - n[..., 0, None, None].double()) * n[..., 1, None, None].double(), 0.2)
     z32 = Fn.leaky_relu((raw - n[..., 0, None, None]) * n[..., 1, None, None], 0.2)
-    with ops.unet_precision(16):
+    with ops.inference_precision(16):
         y, _ = ops.unet_conv3x3((raw.to(dev), n.to(dev)), None, w.to(dev))
     print(f"op {C}->{C} @{H}x{W} lazy: vs fp64-normalised-then-rounded {rel(y, Fn.conv2d(r16(z64), r16(w), padding=1)):.2e}, "
           f"vs fp32-normalised-then-rounded {rel(y, Fn.conv2d(r16(z32), r16(w), padding=1)):.2e}, "
@@ -35,7 +35,7 @@ for chans, pools, pad, H, W in ((14, 2, 11, 640, 372), (18, 4, 15, 160, 96), (8,
         with oracle.amp.autocast_fp16():
             refa = oracle.unet.norm_unet_forward(sd, x, pools, padding_size=pad).float()
         net = net.to(dev)
-        with ops.unet_precision(16):
+        with ops.inference_precision(16):
             got = net(x.to(dev))
         got32 = net(x.to(dev))
     print(f"NormUnet {chans}x{pools} @{H}x{W}: fp32 route vs fp32 oracle {rel(got32, ref32):.2e} | p16 vs kernel arithmetic {rel(got, refk):.2e}, vs autocast {rel(got, refa):.2e}, "
