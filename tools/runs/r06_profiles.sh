@@ -19,6 +19,7 @@ prof qcirim "--model qcirim --steps 6 --warmup 1 --graph 0 --streams 1"
 prof train_bf16 "--train --dtype bf16 --steps 3 --warmup 1"
 prof mask2d "--mask 2d --steps 6 --warmup 2"
 prof e2evn_precision16 "--model e2evn --precision 16 --steps 4 --warmup 1 --graph 0 --streams 1"
+prof qcirim_precision16 "--model qcirim --precision 16 --steps 6 --warmup 1 --graph 0 --streams 1"
 prof precision16_one_stream "--precision 16 --steps 10 --warmup 2 --streams 1"
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c -d $R/$O/pmc_$c -o p --output-format csv -- python3 $R/tools/probe/pmc_r04.py > $R/$O/pmc_$c.log 2>&1

@@ -25,9 +25,9 @@ KEYS = {            # key in the JSON -> substrings of the kernel names it sums 
     "llg_2d": ["k_fft_rows<false, 1", "k_cols_dc<", "k_cols_dc_t4<", "k_rows_reduce<1", "k_pfa372_expand", "k_pfa372_reduce", "k_llg372_combine"],   # (r04: the deferred form without y)
     # round 4 (tools/probe/pmc_r04.py): dominant kernels of the other configurations, each at its own shape (`at`)
     "llg_2d_cols_noy": ["k_cols_dc_t4<PlanCT<640, 5, 8, 4, 4>, true>"],
-    # (round 5 added a fourth template argument: the ticket form; round 6 a fifth: rows per work item -- 16 at the bench's batch of 8, 8 at the batch-4 probe)
-    "e2evn_uconv_h_14to14": ["k_uconv_h<1, 1, true>", "k_uconv_h<1, 1, true, false>", "k_uconv_h<1, 1, true, false, 16>", "k_uconv_h<1, 1, true, false, 8>"],
-    "qcirim_conv3x3_h_128": ["k_uconv_h<4, 2, false>", "k_uconv_h<4, 2, false, false>", "k_uconv_h<4, 2, false, false, 8>"],
+    # (round 5 added a fourth template argument: the ticket form; round 6 a fifth and a sixth: rows per work item -- 16 at the bench's batch of 8, 8 at the batch-4 probe -- and fp16 terms)
+    "e2evn_uconv_h_14to14": ["k_uconv_h<1, 1, true>", "k_uconv_h<1, 1, true, false>", "k_uconv_h<1, 1, true, false, 16, 2>", "k_uconv_h<1, 1, true, false, 8, 2>"],
+    "qcirim_conv3x3_h_128": ["k_uconv_h<4, 2, false>", "k_uconv_h<4, 2, false, false>", "k_uconv_h<4, 2, false, false, 8, 2>"],
     "train_layer2_fwd": ["k_conv_bf16<3, 2, 64, 2, 0, 2>", "k_conv_bf16<3, 2, 64, 2, 2, 2>"],
     "train_cell_bwd": ["k_tl_cell_bwd<true, true>", "k_tl_cell_bwd<true, true, true>"],      # (r04 lib 243+: the state as its mask words)
     "train_wgrad_3x3d2": ["k_conv_wgrad_bf16<3, 2, 1>", "k_conv_wgrad_bf16<3, 2, 1, 1>"],
