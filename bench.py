@@ -71,9 +71,11 @@ def parse():
                     help="--train only: bf16 = convolution / IndRNN GEMM operands in bf16 with fp32 accumulation (the reference's "
                          "`precision: 16` AMP, base_cirim_train.yaml:180), FFT / data consistency / eta accumulation stay fp32")
     ap.add_argument("--precision", type=int, default=32, choices=[32, 16],
-                    help="CIRIM inference: 16 = the reference's own inference configuration (`trainer.precision: 16`, base_cirim_run.yaml:132): fp16 operands and "
-                         "hidden states in the two RIM layers (csrc/rim_amp16.hip), FFT / data consistency / eta in fp32; checked against the oracle under "
-                         "torch.autocast(float16).  Never the headline: the default run reports it as other_configs.cirim_precision16")
+                    help="inference precision: 16 = the reference's own inference configuration (`trainer.precision: 16` in every *_run.yaml of its model zoo, e.g. "
+                         "base_cirim_run.yaml:132 = torch.autocast(float16) around forward).  --model cirim: fp16 operands and fp16 hidden states in both RIM layers "
+                         "(csrc/rim_amp16.hip); --model e2evn / qcirim: the 3x3 convolutions on one fp16 term (mrx_unet_conv3x3_p16 / mrx_conv3x3_p16); other models: "
+                         "ignored (fp32-class).  Checked against the oracle under torch.autocast(float16).  Never the headline: the default run reports these as "
+                         "other_configs.*_precision16_*")
     ap.add_argument("--unet", default="14x2", choices=["14x2", "18x4"],
                     help="--model e2evn: NormUnet(chans x pools): 14x2 pad 11 = BASELINE configs[1]; 18x4 pad 15 = the reference yaml's default")
     ap.add_argument("--no-other-configs", action="store_true",

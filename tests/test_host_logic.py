@@ -497,3 +497,38 @@ def test_rank_binds_itself_to_the_numa_node_of_its_gpu(tmp_path):
     assert sharding.gpu_numa_nodes(str(tmp_path / "nothing")) == []
     assert sharding.bind_rank_to_gpu_numa_node(0, str(tmp_path / "nothing"), environ={}) is None
     assert sharding._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+
+
+def test_inference_precision_context_and_model_plumbing(monkeypatch):
+    """`ops.inference_precision` (what VarNet / UNet / qCIRIM wrap their inference forward in when the reference's `trainer.precision` is 16, base_vn_run.yaml:98):
+    nests and restores, also on an exception; `resolve_precision16` takes the model's own precision before the process default (MRIDC_AMD_PRECISION) and
+    accepts pytorch-lightning's spellings; the models read `trainer.precision` first, then cfg["precision"].  (No GPU call: the kernels behind the switch are
+    tests/test_gpu_unet_p16.py.)"""
+    import types
+    from mridc_amd import ops, synthetic
+    from mridc_amd.collections.reconstruction.models.unet import UNet
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    assert not ops._precision16()
+    with ops.inference_precision(16):
+        assert ops._precision16()
+        with ops.inference_precision(None):
+            assert not ops._precision16()
+        with ops.inference_precision("16-mixed"):
+            assert ops._precision16()
+        assert ops._precision16()
+    assert not ops._precision16()
+    with pytest.raises(RuntimeError):
+        with ops.inference_precision(16):
+            raise RuntimeError("x")
+    assert not ops._precision16()
+    monkeypatch.delenv("MRIDC_AMD_PRECISION", raising=False)
+    assert ops.resolve_precision16(None) is None and ops.resolve_precision16(32) is None and ops.resolve_precision16("bf16") is None
+    assert ops.resolve_precision16(16) == 16 and ops.resolve_precision16("16") == 16 and ops.resolve_precision16("16-mixed") == 16
+    monkeypatch.setenv("MRIDC_AMD_PRECISION", "16")
+    assert ops.resolve_precision16(None) == 16 and ops.resolve_precision16(32) is None            # a stated precision wins over the process default
+    monkeypatch.delenv("MRIDC_AMD_PRECISION")
+    cfg = dict(synthetic.E2EVN_BASELINE_CFG, num_cascades=1)
+    assert VarNet(cfg).precision is None and VarNet(cfg)._inference_precision() is None
+    assert VarNet(dict(cfg, precision=16))._inference_precision() == 16
+    assert VarNet(dict(cfg, precision=32), trainer=types.SimpleNamespace(precision=16))._inference_precision() == 16      # the trainer first, as in the reference
+    assert UNet(cfg, trainer=types.SimpleNamespace(precision="16-mixed")).precision == "16-mixed"
