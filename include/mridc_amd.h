@@ -329,6 +329,10 @@ int64_t mrx_conv_sbs_pack_floats(int Cout, int k);
 int mrx_conv_sbs_pack(const float* w, float* packed, int Cin, int Cout, int k, void* stream);
 int mrx_conv_sbs(const float* x, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int k, int pad_mode,
                  int act, float slope, void* stream);
+/* mrx_conv_sbs_p16: mrx_conv_sbs in the reference's `precision: 16` inference arithmetic (torch.autocast(float16) around forward; conv_layers.py:121-123 under it): x
+ * and W rounded to fp16 once (the first term of the same pack, behind the same exact power-of-two scales), fp32 sums.  MRIDC_AMD_ARITH = f16x2. */
+int mrx_conv_sbs_p16(const float* x, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int k, int pad_mode,
+                 int act, float slope, void* stream);
 int mrx_conv3x3_sb(const float* x, const float* packed, const float* bias, float* y, int B, int H, int W, int dil, int pad_mode, int act,
                    float slope, void* stream);
 /* mrx_conv3x3_sb for CHAINS of 64-channel convolutions (CascadeNet, VSNet, the Recurrent VarNet, RIM-GRU / MGU): every call folds max |y| into
@@ -680,6 +684,10 @@ int mrx_conv1x1_sq(const float* x, const float* packed, const float* bias, const
 int mrx_conv1x1_sq_xmax_supported(int C);
 int mrx_conv1x1_sq_xmax(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out, float* xmax,
                         int B, int C, int64_t HW, int act, float slope, void* stream);
+/* mrx_conv1x1_sq_p16: the same at C = 128 in the reference's `precision: 16` inference arithmetic (base_qcirim_run.yaml:204 = torch.autocast(float16) around forward;
+ * rnn_cells.py:384-391 under it): x and W rounded to fp16 once (a plain cast, as autocast's), fp32 sums; hh * h_prev, bias, activation in fp32.  xmax may be null. */
+int mrx_conv1x1_sq_p16(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out, float* xmax,
+                       int B, int C, int64_t HW, int act, float slope, void* stream);
 int mrx_conv1x1_64(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
                    int B, int64_t HW, int act, float slope, void* stream);
 

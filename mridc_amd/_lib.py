@@ -151,6 +151,7 @@ _SIGNATURES = {
     "mrx_conv1x1_sq": ([_p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _f, _p], _i),
     "mrx_conv1x1_sq_xmax_supported": ([_i], _i),
     "mrx_conv1x1_sq_xmax": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _f, _p], _i),
+    "mrx_conv1x1_sq_p16": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _f, _p], _i),
     "mrx_concat_channels": ([_p, _p, _p, _i, _i, _i, _i64, _p], _i),
     "mrx_unet_conv3x3_work_floats": ([_i, _i, _i, _i], _i64),
     "mrx_unet_conv3x3_pack_floats": ([_i, _i], _i64),
@@ -199,6 +200,7 @@ _SIGNATURES = {
     "mrx_conv_sbs_pack_floats": ([_i, _i], _i64),
     "mrx_conv_sbs_pack": ([_p, _p, _i, _i, _i, _p], _i),
     "mrx_conv_sbs": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
+    "mrx_conv_sbs_p16": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_conv3x3_sb": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_conv3x3_sb_chain": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "mrx_rim_layer2_sb_taps": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),

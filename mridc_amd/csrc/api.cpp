@@ -15,7 +15,7 @@ void mrx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int mrx_version(void) { return 265; /* 0.2.0: bumped with every kernel change (profiles/rNN_traffic.json is keyed on it) */ }
+extern "C" int mrx_version(void) { return 266; /* 0.2.0: bumped with every kernel change (profiles/rNN_traffic.json is keyed on it) */ }
 extern "C" const char* mrx_last_error(void) { return g_err; }
 extern "C" int mrx_arith(void) {
     const char* e = getenv("MRIDC_AMD_ARITH");

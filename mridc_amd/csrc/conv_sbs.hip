@@ -63,8 +63,11 @@ struct ConvSbsArgs {
 };
 __host__ __device__ constexpr int cs_nstep(int K) { return (K * K + 1) / 2; }
 
-template <int K, int NCT, bool F16>
+// ONE (round 6; F16 only): the reference's `precision: 16` inference arithmetic (torch.autocast(float16) around forward, conv_layers.py:121-123 under it): the first
+// fp16 term of each operand only -- x and W rounded to fp16 once (behind the same exact power-of-two scales), one product per multiply, fp32 sums.
+template <int K, int NCT, bool F16, bool ONE = false>
 __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
+    static_assert(F16 || !ONE, "one term: the fp16 form");
     constexpr int PAD = (K - 1) / 2, PH = CS_TH + 2 * PAD, PW = CS_TW + 2 * PAD, NPIX = PH * PW, NG = K * K, NSTEP = cs_nstep(K);
     static_assert(!F16 || NPIX <= CS_NT, "F16: one staging pass (the tile maximum is taken over the values of that pass)");
     __shared__ float wmaxs[CS_NT / 64];
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) cs_split2h(xv[2 * k] * sx, xv[2 * k + 1] * sx, p1[k], p2[k]);
             Xs[tid] = u32x4{p1[0], p1[1], p1[2], p1[3]};
-            Xs[NPIX + tid] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+            if constexpr (!ONE) Xs[NPIX + tid] = u32x4{p2[0], p2[1], p2[2], p2[3]};
         }
     }
     __syncthreads();
@@ -160,6 +163,12 @@ __global__ __launch_bounds__(CS_NT, 2) void k_conv_sbs(ConvSbsArgs a) {
         const int off = lhi ? o1 : o0;
         if constexpr (F16) {
             const f16x8 b1 = __builtin_bit_cast(f16x8, bx[off]);
+            if constexpr (ONE) {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wp[3 * WT + (s * NCT + ct) * 64]), b1, acc[ct], 0, 0, 0);
+                continue;
+            }
             const f16x8 b2 = __builtin_bit_cast(f16x8, bx[NPIX + off]);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -300,11 +309,14 @@ extern "C" int mrx_conv_sbs_pack(const float* w, float* packed, int Cin, int Cou
 }
 
 template <int K, int NCT>
-static int cs_launch(const ConvSbsArgs& a, hipStream_t st) {
+static int cs_launch(const ConvSbsArgs& a, hipStream_t st, int one) {
     constexpr size_t lds = (size_t)3 * (CS_TH + K - 1) * (CS_TW + K - 1) * 16;
     static_assert(lds <= 48 * 1024, "fits the default dynamic LDS limit");
     const int f16 = mrx_arith() == MRX_ARITH_F16X2 ? 1 : 0;   // 0: the three-term bf16 form
-    if (f16)
+    if (one) {
+        MRX_REQUIRE(f16, MRX_EUNSUP, "mrx_conv_sbs_p16: the fp16 operand form is off (MRIDC_AMD_ARITH)");
+        hipLaunchKernelGGL((k_conv_sbs<K, NCT, true, true>), dim3(a.ntiles, a.B), dim3(CS_NT), lds, st, a);
+    } else if (f16)
         hipLaunchKernelGGL((k_conv_sbs<K, NCT, true>), dim3(a.ntiles, a.B), dim3(CS_NT), lds, st, a);
     else
         hipLaunchKernelGGL((k_conv_sbs<K, NCT, false>), dim3(a.ntiles, a.B), dim3(CS_NT), lds, st, a);
@@ -312,13 +324,13 @@ static int cs_launch(const ConvSbsArgs& a, hipStream_t st) {
     return MRX_OK;
 }
 template <int K>
-static int cs_launch_nct(const ConvSbsArgs& a, hipStream_t st) {
+static int cs_launch_nct(const ConvSbsArgs& a, hipStream_t st, int one) {
     const int nct = cs_nct(a.Cout);
-    return nct == 1 ? cs_launch<K, 1>(a, st) : (nct == 2 ? cs_launch<K, 2>(a, st) : cs_launch<K, 4>(a, st));
+    return nct == 1 ? cs_launch<K, 1>(a, st, one) : (nct == 2 ? cs_launch<K, 2>(a, st, one) : cs_launch<K, 4>(a, st, one));
 }
 // y = act(conv_kxk(x, zero | replicate padding) + bias), Cin <= 8 -> Cout <= 128, k = 3 | 5, dilation 1; packed from mrx_conv_sbs_pack
-extern "C" int mrx_conv_sbs(const float* x, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int k,
-                            int pad_mode, int act, float slope, void* stream) {
+static int conv_sbs_impl(const float* x, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int k, int pad_mode, int act,
+                         float slope, void* stream, int one) {
     MRX_REQUIRE(x && packed && y, MRX_EINVAL, "mrx_conv_sbs: null pointer");
     MRX_REQUIRE(B >= 0 && H >= 1 && W >= 1, MRX_EINVAL, "mrx_conv_sbs: bad dims");
     MRX_REQUIRE(mrx_conv_sbs_supported(Cin, Cout, k, 1), MRX_EUNSUP, "mrx_conv_sbs: Cin=%d Cout=%d k=%d", Cin, Cout, k);
@@ -330,5 +342,14 @@ extern "C" int mrx_conv_sbs(const float* x, const float* packed, const float* bi
     a.x = x, a.packed = reinterpret_cast<const u32x4*>(packed), a.bias = bias, a.out = y;
     a.B = B, a.Cin = Cin, a.Cout = Cout, a.H = H, a.W = W, a.tiles_x = mrx_cdiv(W, CS_TW), a.ntiles = a.tiles_x * mrx_cdiv(H, CS_TH);
     a.pad_mode = pad_mode, a.act = act, a.slope = slope;
-    return k == 3 ? cs_launch_nct<3>(a, (hipStream_t)stream) : cs_launch_nct<5>(a, (hipStream_t)stream);
+    return k == 3 ? cs_launch_nct<3>(a, (hipStream_t)stream, one) : cs_launch_nct<5>(a, (hipStream_t)stream, one);
+}
+extern "C" int mrx_conv_sbs(const float* x, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int k,
+                            int pad_mode, int act, float slope, void* stream) {
+    return conv_sbs_impl(x, packed, bias, y, B, Cin, Cout, H, W, k, pad_mode, act, slope, stream, 0);
+}
+// ... in the reference's `precision: 16` inference arithmetic (base_qcirim_run.yaml:204 ...): x and W rounded to fp16 once, fp32 sums.  MRIDC_AMD_ARITH = f16x2.
+extern "C" int mrx_conv_sbs_p16(const float* x, const float* packed, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int k,
+                                int pad_mode, int act, float slope, void* stream) {
+    return conv_sbs_impl(x, packed, bias, y, B, Cin, Cout, H, W, k, pad_mode, act, slope, stream, 1);
 }

@@ -631,6 +631,7 @@ extern "C" int mrx_conv1x1_sq_pack(const float* w, float* packed, int C, void* s
     return MRX_OK;
 }
 static thread_local float* g_sq_xmax = nullptr;   // set by mrx_conv1x1_sq_xmax around the call
+static thread_local int g_sq_p16 = 0;             // set by mrx_conv1x1_sq_p16 around the call
 extern "C" int mrx_conv1x1_sq(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
                               int B, int C, int64_t HW, int act, float slope, void* stream) {
     MRX_REQUIRE(x && packed && out, MRX_EINVAL, "mrx_conv1x1_sq: null pointer");
@@ -656,9 +657,10 @@ extern "C" int mrx_conv1x1_sq(const float* x, const float* packed, const float* 
     if (C == 128 && !fp32) {                      // default at 128 features: the bf16 matrix pipe with fp32 results
         MrxConv1x1SbArgs s;
         s.x = x, s.packed = packed + (size_t)C * C, s.bias = bias, s.hh = hh, s.hprev = h_prev, s.out = out;
-        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg, s.act = act, s.slope = slope, s.head = 0, s.xmax = g_sq_xmax;
+        s.P = a.P, s.nsegb = a.nsegb, s.nseg = a.nseg, s.act = act, s.slope = slope, s.head = 0, s.xmax = g_sq_xmax, s.p16 = g_sq_p16;
         return mrx_conv1x1_sb128_launch(s, (hipStream_t)stream);
     }
+    MRX_REQUIRE(!g_sq_p16, MRX_EUNSUP, "mrx_conv1x1_sq_p16: C = %d (the 128-channel matrix-pipe kernel only)", C);
     MRX_REQUIRE(!g_sq_xmax, MRX_EUNSUP, "mrx_conv1x1_sq_xmax: only the 128-channel matrix-pipe kernel keeps the bound of its outputs");
     static int n_cu = 0;
     if (!n_cu) {
@@ -699,6 +701,17 @@ extern "C" int mrx_conv1x1_sq_xmax(const float* x, const float* packed, const fl
     return rc;
 }
 
+// mrx_conv1x1_sq[_xmax] at C = 128 in the reference's `precision: 16` inference arithmetic (base_qcirim_run.yaml:204; rnn_cells.py:384-391 under torch.autocast(float16)):
+// x and W rounded to fp16 once, fp32 sums; hh * h_prev, bias and activation in fp32.  xmax may be null.  MRIDC_AMD_ARITH != fp32.
+extern "C" int mrx_conv1x1_sq_p16(const float* x, const float* packed, const float* bias, const float* hh, const float* h_prev, float* out,
+                                  float* xmax, int B, int C, int64_t HW, int act, float slope, void* stream) {
+    MRX_REQUIRE(mrx_conv1x1_sq_xmax_supported(C), MRX_EUNSUP, "mrx_conv1x1_sq_p16: C = %d (128 on the matrix-pipe kernel only)", C);
+    g_sq_xmax = xmax, g_sq_p16 = 1;
+    const int rc = mrx_conv1x1_sq(x, packed, bias, hh, h_prev, out, B, C, HW, act, slope, stream);
+    g_sq_xmax = nullptr, g_sq_p16 = 0;
+    return rc;
+}
+
 // out [B,64,P] = the first 64 rows of W (128 x 128) times x [B,128,P]: the channel contraction of a thin 3x3 convolution of 128 channels
 // (9 Cout <= 64 tap rows, ops.conv3x3_taps) without the unused half of the outputs.  packed from mrx_conv1x1_sq_pack(w, ., 128).
 extern "C" int mrx_conv1x1_sq_head128(const float* x, const float* packed, float* out, int B, int64_t HW, void* stream) {
@@ -707,7 +720,7 @@ extern "C" int mrx_conv1x1_sq_head128(const float* x, const float* packed, float
     if (B == 0 || HW == 0) return MRX_OK;
     MrxConv1x1SbArgs s;
     s.x = x, s.packed = packed + (size_t)128 * 128, s.bias = nullptr, s.hh = nullptr, s.hprev = nullptr, s.out = out;
-    s.P = HW, s.nsegb = (HW + 31) / 32, s.nseg = s.nsegb * B, s.act = MRX_ACT_NONE, s.slope = 0.f, s.head = 1, s.xmax = nullptr;
+    s.P = HW, s.nsegb = (HW + 31) / 32, s.nseg = s.nsegb * B, s.act = MRX_ACT_NONE, s.slope = 0.f, s.head = 1, s.xmax = nullptr, s.p16 = 0;
     return mrx_conv1x1_sb128_launch(s, (hipStream_t)stream);
 }
 // 64-channel forms kept as named entry points

@@ -35,7 +35,8 @@ struct MrxConv2dGruSbArgs {
 int mrx_conv2dgru_sb_pack(const float* wu, const float* wr, const float* wo, float* packed, hipStream_t st);
 int mrx_conv2dgru_sb_launch(const MrxConv2dGruSbArgs& a, hipStream_t st);
 
-#define MRX_CONV1X1_SB128_PACK_FLOATS (2 * 2 * 2 * 4 * 3 * 64 * 4)
+// three bf16 terms of W in A-operand lane order, then (round 6) W rounded to fp16 once in the same order: the precision-16 form
+#define MRX_CONV1X1_SB128_PACK_FLOATS ((2 * 2 * 2 * 4 * 3 * 64 + 2 * 2 * 2 * 4 * 64) * 4)
 
 struct MrxConv1x1SbArgs {
     const float* x;       // [B,128,P]
@@ -48,6 +49,7 @@ struct MrxConv1x1SbArgs {
     int act;
     float slope;
     int head;             // 1: only the first 64 output channels, out [B,64,P]
+    int p16;              // 1: the reference's `precision: 16` arithmetic (x and W rounded to fp16 once -- as torch.autocast casts them, no scale --, fp32 sums)
     float* xmax;          // or null: device scalar, max |out| is folded in with an atomic max (never reset here): the bound a two-term fp16
                           // consumer of `out` scales its operands by (mrx_conv3x3_h)
 };

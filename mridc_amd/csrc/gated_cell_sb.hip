@@ -747,23 +747,43 @@ __global__ void k_conv1x1_pack_sb128(const float* __restrict__ w, u32x4* __restr
         out[i] = u32x4{p[0], p[1], p[2], p[3]};
     }
 }
+// the precision-16 section: packed16[(((ob * 2 + ib) * 2 + mb) * 4 + t) * 64 + lane][j] = fp16( W[the same element] ), round to nearest even
+__global__ void k_conv1x1_pack_sb128_p16(const float* __restrict__ w, u32x4* __restrict__ out) {
+    const int total = 2 * 2 * 2 * 4 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63, r = i >> 6;
+        const int t = r & 3, mb = (r >> 2) & 1, ib = (r >> 3) & 1, ob = r >> 4;
+        const int row = ob * 64 + mb * 32 + (lane & 31), col0 = ib * 64 + 16 * t + 8 * (lane >> 5);
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f16x2 h = {(_Float16)w[(long long)row * 128 + col0 + 2 * k], (_Float16)w[(long long)row * 128 + col0 + 2 * k + 1]};
+            p[k] = __builtin_bit_cast(unsigned, h);
+        }
+        out[i] = u32x4{p[0], p[1], p[2], p[3]};
+    }
+}
 int mrx_conv1x1_sb128_pack(const float* w, float* packed, hipStream_t st) {
     const int total = 2 * 2 * 2 * 4 * 3 * 64;
     hipLaunchKernelGGL(k_conv1x1_pack_sb128, dim3((total + 255) / 256), dim3(256), 0, st, w, reinterpret_cast<u32x4*>(packed));
+    MRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_conv1x1_pack_sb128_p16, dim3((total / 3 + 255) / 256), dim3(256), 0, st, w, reinterpret_cast<u32x4*>(packed) + total);
     MRX_LAUNCH_CHECK();
     return MRX_OK;
 }
 
 // NOB: output blocks of 64 channels computed (1: the first 64 rows of W only, out [B,64,P] -- the contraction of a thin 3x3 convolution)
-template <int NOB>
+// P16 (round 6): the reference's `precision: 16` inference arithmetic (base_qcirim_run.yaml:204: torch.autocast(float16) -- rnn_cells.py:384-391 under it): x and
+// W rounded to fp16 once (a plain cast, as autocast's), ONE product per multiply on v_mfma_f32_32x32x16_f16, fp32 sums; hh * h_prev, bias, activation in fp32.
+template <int NOB, bool P16 = false>
 __global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gs[];
-    constexpr int C = 128, NW = 2 * 2 * 2 * 4 * 3 * 64;
+    constexpr int C = 128, NW3 = 2 * 2 * 2 * 4 * 3 * 64, NW = P16 ? NW3 / 3 : NW3;
     u32x4* Wl = reinterpret_cast<u32x4*>(smem_gs);
     float* Bs = reinterpret_cast<float*>(smem_gs + (size_t)NW * 16);   // bias [C], hh [C]
     const int tid = threadIdx.x;
     {
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed);
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.packed) + (P16 ? NW3 : 0);
         for (int i = tid; i < NW; i += GS_NT) Wl[i] = src[i];
         if (tid < C) {
             Bs[tid] = a.bias ? a.bias[tid] : 0.f;
@@ -807,6 +827,17 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) 
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if constexpr (P16) {
+                    f16x8 bx;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bx[j] = (_Float16)xg[ib][t][j];
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb)
+                            acc[ob][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl[((((ob * 2 + ib) * 2 + mb) * 4 + t)) * 64]), bx, acc[ob][mb], 0, 0, 0);
+                    continue;
+                }
                 unsigned p1[4], p2[4], p3[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) gs_split2(xg[ib][t][2 * k], xg[ib][t][2 * k + 1], p1[k], p2[k], p3[k]);
@@ -869,6 +900,7 @@ __global__ __launch_bounds__(GS_NT, 1) void k_conv1x1_sb128(MrxConv1x1SbArgs a) 
 }
 int mrx_conv1x1_sb128_launch(const MrxConv1x1SbArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(2 * 2 * 2 * 4 * 3 * 64) * 16 + sizeof(float) * 2 * 128;
+    constexpr size_t lds16 = (size_t)(2 * 2 * 2 * 4 * 64) * 16 + sizeof(float) * 2 * 128;
     static bool attr_done = false;
     static int n_cu = 0;
     if (!attr_done) {
@@ -883,7 +915,12 @@ int mrx_conv1x1_sb128_launch(const MrxConv1x1SbArgs& a, hipStream_t st) {
     }
     const long long nblk_need = (a.nseg + GS_NT / 64 - 1) / (GS_NT / 64);
     const unsigned nblk = (unsigned)(nblk_need < n_cu ? nblk_need : n_cu);
-    if (a.head)
+    if (a.p16) {
+        if (a.head)
+            hipLaunchKernelGGL((k_conv1x1_sb128<1, true>), dim3(nblk), dim3(GS_NT), lds16, st, a);
+        else
+            hipLaunchKernelGGL((k_conv1x1_sb128<2, true>), dim3(nblk), dim3(GS_NT), lds16, st, a);
+    } else if (a.head)
         hipLaunchKernelGGL(k_conv1x1_sb128<1>, dim3(nblk), dim3(GS_NT), lds, st, a);
     else
         hipLaunchKernelGGL(k_conv1x1_sb128<2>, dim3(nblk), dim3(GS_NT), lds, st, a);

@@ -796,8 +796,10 @@ def conv1x1_64(x, weight, bias=None, act=ACT_NONE, slope=0.0, hh=None, h_prev=No
         # a 3x3 layer on two-term fp16 operands may read this next (qRIM: cell of stack 1 -> convolution of stack 2): the kernel keeps the
         # bound of its outputs, the consumer finds it on the tensor (ops._plain_bound) instead of running mrx_max_abs over it
         xmax = _zero_scalar(x.device)
-        _lib.check(_lib.lib().mrx_conv1x1_sq_xmax(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out),
-                                                  _lib.ptr(xmax), B, Cin, H * W, int(act), float(slope), _lib.stream_ptr()), "mrx_conv1x1_sq_xmax")
+        p16 = _precision16()            # inside inference_precision(16): x and W rounded to fp16 once (mrx_conv1x1_sq_p16)
+        _lib.check((_lib.lib().mrx_conv1x1_sq_p16 if p16 else _lib.lib().mrx_conv1x1_sq_xmax)(
+            _lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), _lib.ptr(xmax), B, Cin, H * W, int(act), float(slope),
+            _lib.stream_ptr()), "mrx_conv1x1_sq_p16" if p16 else "mrx_conv1x1_sq_xmax")
         return _attach_bound(out, xmax)
     _lib.check(_lib.lib().mrx_conv1x1_sq(_lib.ptr(x), _lib.ptr(packed), _lib.ptr(b), _lib.ptr(hhc), _lib.ptr(hp), _lib.ptr(out), B, Cin,
                                          H * W, int(act), float(slope), _lib.stream_ptr()), "mrx_conv1x1_sq")
@@ -907,8 +909,10 @@ def conv_sbs(x, weight, bias, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.0, out=No
     b = _lib.f32c(bias.detach()) if bias is not None else None
     if out is None:
         out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().mrx_conv_sbs(_lib.ptr(x), _lib.ptr(hit[0]), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W, k, int(pad_mode), int(act),
-                                       float(slope), _lib.stream_ptr()), "mrx_conv_sbs")
+    p16 = _precision16() and _lib.arith() == "f16x2"          # inside inference_precision(16): the first fp16 term only (mrx_conv_sbs_p16)
+    _lib.check((_lib.lib().mrx_conv_sbs_p16 if p16 else _lib.lib().mrx_conv_sbs)(_lib.ptr(x), _lib.ptr(hit[0]), _lib.ptr(b), _lib.ptr(out), B, Cin, Cout, H, W, k,
+                                                                                  int(pad_mode), int(act), float(slope), _lib.stream_ptr()),
+               "mrx_conv_sbs_p16" if p16 else "mrx_conv_sbs")
     return out
 
 

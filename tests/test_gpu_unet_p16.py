@@ -184,6 +184,57 @@ def test_conv3x3_precision16_is_fp16_operands_with_wide_sums(case, dev):
     assert 1e-5 <= rel_l2(got, got32) <= 2e-3
 
 
+@pytest.mark.parametrize("case", [(1, 64, 64, True), (2, 21, 40, False), (1, 256, 256, True)], ids=lambda c: f"B{c[0]}_{c[1]}x{c[2]}_{'cell' if c[3] else 'plain'}")
+def test_conv1x1_128_precision16_is_fp16_operands_with_wide_sums(case, dev):
+    """mrx_conv1x1_sq_p16 (the 128 -> 128 1x1 convolution with the IndRNN cell as its epilogue, rnn_cells.py:384-391: the qRIM's cells): relu(W16 x16 + b + hh * h_prev)
+    with x and W rounded to fp16 once and everything else in fp32, against the CPU in float64; the bound it attaches for a following 3x3 layer; fp32-class outside."""
+    from mridc_amd import ops
+    B, H, W, cell = case
+    g = torch.Generator().manual_seed(H + W)
+    x, w, b = torch.randn(B, 128, H, W, generator=g) * 3, torch.randn(128, 128, 1, 1, generator=g) / 128 ** 0.5, torch.randn(128, generator=g)
+    hh, hp = (torch.rand(128, generator=g), torch.randn(B, 128, H, W, generator=g)) if cell else (None, None)
+
+    def ref_of(xx, ww):
+        y = Fn.conv2d(xx, ww, b.double())
+        if cell:
+            y = y + hh.double().view(1, -1, 1, 1) * hp.double()
+        return Fn.relu(y)
+
+    args = (x.to(dev), w.to(dev), b.to(dev), ops.ACT_RELU, 0.0, hh.to(dev) if cell else None, hp.to(dev) if cell else None)
+    with ops.inference_precision(16):
+        got = ops.conv1x1_64(*args)
+    got32 = ops.conv1x1_64(*args)
+    want = ref_of(_r16(x), _r16(w))
+    assert rel_l2(got, want) <= OP_TOL, rel_l2(got, want)
+    assert rel_l2(got32, ref_of(x.double(), w.double())) <= 2e-6
+    assert 1e-5 <= rel_l2(got, got32) <= 2e-3
+    bound = ops._plain_bound(got)
+    assert float(bound) >= float(got.abs().max()) * (1 - 1e-6) and float(bound) <= float(got.abs().max()) * 1.001
+
+
+@pytest.mark.parametrize("case", [(1, 8, 128, 5, 64, 64, 1, 1), (2, 2, 64, 3, 21, 40, 0, 0), (1, 4, 36, 5, 33, 47, 1, 2), (1, 8, 128, 5, 256, 256, 1, 1)],
+                         ids=lambda c: f"B{c[0]}_{c[1]}to{c[2]}_k{c[3]}_{c[4]}x{c[5]}")
+def test_conv_sbs_precision16_is_fp16_operands_with_wide_sums(case, dev):
+    """mrx_conv_sbs_p16 (the first layers: k x k on <= 8 channels into <= 128, conv_layers.py:121-123 -- the qRIM's 5x5 8 -> 128) against the CPU float64
+    convolution of the fp16-rounded operands; fp32-class outside the context."""
+    from mridc_amd import ops
+    B, Cin, Cout, k, H, W, pad_mode, act = case
+    g = torch.Generator().manual_seed(Cin * Cout + H)
+    x, w, b = torch.randn(B, Cin, H, W, generator=g), torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5, torch.randn(Cout, generator=g)
+
+    def ref_of(xx, ww):
+        xp = Fn.pad(xx, (k // 2,) * 4, mode="replicate" if pad_mode == ops.PAD_REPLICATE else "constant")
+        y = Fn.conv2d(xp, ww, b.double())
+        return Fn.relu(y) if act == ops.ACT_RELU else (Fn.leaky_relu(y, 0.1) if act == ops.ACT_LEAKY else y)
+
+    with ops.inference_precision(16):
+        got = ops.conv_sbs(x.to(dev), w.to(dev), b.to(dev), pad_mode, act, 0.1)
+    got32 = ops.conv_sbs(x.to(dev), w.to(dev), b.to(dev), pad_mode, act, 0.1)
+    assert rel_l2(got, ref_of(_r16(x), _r16(w))) <= OP_TOL, rel_l2(got, ref_of(_r16(x), _r16(w)))
+    assert rel_l2(got32, ref_of(x.double(), w.double())) <= 2e-6
+    assert 1e-5 <= rel_l2(got, got32) <= 2e-3
+
+
 def test_qcirim_precision16_against_autocast_and_fp32(dev):
     """qCIRIM (base_qcirim_run.yaml:204 `precision: 16`) with the precision from its cfg: one cascade of eight steps (IndRNN, 128 filters) at 4 echoes x 8 coils x
     64 x 64 -- the 3x3 dilation-2 128 -> 128 convolutions on one fp16 term, the 5x5 / 1x1 layers, the signal model and the FFTs as before -- within SURVEY appendix

@@ -249,7 +249,7 @@ def test_hot_kernels_keep_their_loads_ahead_of_their_waits(tmp_path):
                    ("_Z15k_pfa372_reduce", 0, 2, True), ("_Z15k_pfa372_expandILb0ELb0ELb0EE", 0, 2, True),
                    ("_Z15k_pfa372_expandILb0ELb0ELb1EE", 0, 2, True)],      # (<.., GAT>: round 5, the tap gather inside the general-mask gradient's first pass)
         "fft": [("_Z12k_cols_dc_t4I6PlanCTILi640EJLi5ELi8ELi4ELi4EEELb1EE", 0, 2, True)],
-        "gated_cell_sb": [("_Z15k_conv1x1_sb128ILi2EE", 5, 9, True)],                                    # 4 / 7
+        "gated_cell_sb": [("_Z15k_conv1x1_sb128ILi2ELb0EE", 5, 9, True), ("_Z15k_conv1x1_sb128ILi2ELb1EE", 5, 9, True)],   # 4 / 7 (<.., true>: the precision-16 form, round 6)
         "train_bf16": [("_Z13k_tl_cell_bwdILb1ELb1ELb1EE", 3, 6, True)],                                 # 2 / 4
         # (the ticket form of round 5 is its own instantiation, <.., true, ..>; round 6: <.., rows per work item, fp16 terms> -- E2EVN's 14 -> 14 layers run the
         # 16-row form at the bench's batch, the one-term forms are the precision-16 route)
