@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, GPU call T (lib 265): the GPU suite on the product build and on the CHECK build (-DMRX_CHECK_BOUNDS), smoke, the default bench line (driver-style), and the one-rank RCCL path
+# round 6, GPU call T (lib 266): the GPU suite on the product build and on the CHECK build (-DMRX_CHECK_BOUNDS), smoke, the default bench line (driver-style), and the one-rank RCCL path
 O=gpurun_out/r06t; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 ( time python3 -m pytest tests -x -q -m gpu ) 2>&1 | tail -6 | tee $O/pytest_gpu.txt
