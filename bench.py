@@ -1701,8 +1701,8 @@ def main():
             others = {}
             for name, fn, over in (("e2evn_6cascade_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=8, streams=2, steps=6, warmup=2)),
                                    ("e2evn_precision16_15coil_640x372", bench_e2evn, dict(model="e2evn", batch=8, streams=2, steps=6, warmup=2, precision=16, cpu_slices=1)),
-                                   ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=4, steps=10, warmup=2)),
-                                   ("qcirim_precision16_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=4, steps=10, warmup=2, precision=16, cpu_slices=1))):
+                                   ("qcirim_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=6, steps=10, warmup=2)),     # (streams 4 / 6 / 8: 740 / 790 / 781 slices/s, tools/runs/r06x.sh)
+                                   ("qcirim_precision16_4echo_32coil_256x256", bench_qcirim, dict(model="qcirim", batch=1, streams=6, steps=10, warmup=2, precision=16, cpu_slices=1))):
                 a2 = copy.copy(args)
                 for k_, v_ in over.items():
                     setattr(a2, k_, v_)
