@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=0,
                     help="independent slice batches reconstructed concurrently per GPU, one HIP stream + one captured hipGraph each "
                          "(slices are independent: two in flight fill each other's launch tails and stalls; 1 = single stream; "
-                         "0 = the measured best per model: 2; E2EVN (batch x streams) 1 x 3 / 2 x 2 / 3 x 2 / 4 x 2: 644 / 677 / 701 / 721 slices/s -- its "
+                         "0 = the measured best per model: 2 (qCIRIM: 6); E2EVN (batch x streams) 1 x 3 / 2 x 2 / 3 x 2 / 4 x 2: 644 / 677 / 701 / 721 slices/s -- its "
                          "small-grid kernels overlap their load / matrix / store phases only when a launch spans several dispatch rounds; CIRIM's "
                          "persistent kernels gain nothing from batching: 88.2 / 88.8 / 88.9 / 86.7 at 1 x 2 / 2 x 2 / 4 x 2 / 8 x 1)")
     ap.add_argument("--coils", type=int, default=15)
@@ -91,7 +91,7 @@ def parse():
     args = ap.parse_args()
     args.stream_inputs = not args.no_stream_inputs
     if args.streams <= 0:
-        args.streams = 2
+        args.streams = 6 if (args.model == "qcirim" and not args.train) else 2     # (qCIRIM on 4 / 6 / 8 streams: 740 / 790 / 781 slices/s, tools/runs/r06x.sh)
     if args.batch <= 0:
         # CIRIM inference: 480 tiles of 16 x 32 pixels per slice on 256 CUs -- 8 slices per launch are exactly 15 rounds of the persistent layer kernels
         # (one slice: two rounds, the second 7/8 full); measured 1 x 2 / 2 x 2 / 4 x 2 / 8 x 2 / 8 x 1 / 16 x 1 (batch x streams), lib 252:
