@@ -192,7 +192,7 @@ def test_bench_default_batch_per_configuration(monkeypatch):
     assert defaults() == (8, 2)
     assert defaults("--mask", "2d") == (4, 2)
     assert defaults("--model", "e2evn") == (8, 2)
-    assert defaults("--model", "qcirim") == (1, 2)
+    assert defaults("--model", "qcirim") == (1, 6)            # (six streams: 740 -> 790 slices/s, tools/runs/r06x.sh)
     assert defaults("--train", "--dtype", "bf16") == (1, 2)
     assert defaults("--train", "--model", "e2evn") == (1, 2)
     assert defaults("--rnn", "GRU", "--cascades", "1") == (1, 2)
