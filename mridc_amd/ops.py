@@ -958,7 +958,9 @@ def conv3x3_taps(x, weight, bias, pad_mode=PAD_ZERO, out=None):
 # The reference's inference precision (`trainer.precision: 16` in every *_run.yaml of its model zoo, e.g. base_vn_run.yaml:98, base_qcirim_run.yaml:204): inside
 # `inference_precision(16)` the 3x3 convolutions of the two-term fp16 route run on ONE fp16 term (mrx_unet_conv3x3_p16, mrx_conv3x3_p16).  Set by the models'
 # inference forward (VarNet, UNet, qCIRIM); None inside / outside: fp32-class results.  (The RIM blocks of CIRIM have their own fp16 kernels: RIMBlock.precision.)
-_INFERENCE_PRECISION = [None]
+import threading as _threading
+
+_INFERENCE_PRECISION = _threading.local()       # per thread: two threads may run models of different precision side by side
 
 
 class inference_precision:
@@ -966,17 +968,17 @@ class inference_precision:
         self.precision = precision
 
     def __enter__(self):
-        self.keep = _INFERENCE_PRECISION[0]
-        _INFERENCE_PRECISION[0] = self.precision
+        self.keep = getattr(_INFERENCE_PRECISION, "value", None)
+        _INFERENCE_PRECISION.value = self.precision
         return self
 
     def __exit__(self, *exc):
-        _INFERENCE_PRECISION[0] = self.keep
+        _INFERENCE_PRECISION.value = self.keep
         return False
 
 
 def _precision16():
-    p = _INFERENCE_PRECISION[0]
+    p = getattr(_INFERENCE_PRECISION, "value", None)
     return p is not None and str(p).lower() in ("16", "fp16", "16-mixed")
 
 

@@ -521,6 +521,16 @@ def test_inference_precision_context_and_model_plumbing(monkeypatch):
         with ops.inference_precision(16):
             raise RuntimeError("x")
     assert not ops._precision16()
+    import threading, time          # the switch is per thread: a model of another precision in another thread does not see it
+    seen = {}
+
+    def worker(name, prec, delay):
+        with ops.inference_precision(prec):
+            time.sleep(delay)
+            seen[name] = ops._precision16()
+    ts = [threading.Thread(target=worker, args=("a", 16, 0.2)), threading.Thread(target=worker, args=("b", None, 0.05))]
+    [t.start() for t in ts], [t.join() for t in ts]
+    assert seen == {"a": True, "b": False} and not ops._precision16()
     monkeypatch.delenv("MRIDC_AMD_PRECISION", raising=False)
     assert ops.resolve_precision16(None) is None and ops.resolve_precision16(32) is None and ops.resolve_precision16("bf16") is None
     assert ops.resolve_precision16(16) == 16 and ops.resolve_precision16("16") == 16 and ops.resolve_precision16("16-mixed") == 16
