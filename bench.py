@@ -304,8 +304,9 @@ def bench_streams(n):
     """The process's compute streams, created once and shared by every benchmark of the run: HIP maps streams onto a few hardware queues in
     creation order, and two FRESH streams created after a dozen others can land on one queue -- the in-process E2EVN line then read 820
     slices/s (its two slice batches serialised) against 1020 stand-alone."""
+    prio = os.environ.get("MRX_BENCH_STREAM_PRIO")      # (A/B: "hi-lo" = the first compute stream at high priority: headline 152.8 against 152.2 slices/s, +0.4 %, not adopted -- tools/runs/r06ab.sh)
     while len(_STREAM_POOL) < n:
-        _STREAM_POOL.append(torch.cuda.Stream())
+        _STREAM_POOL.append(torch.cuda.Stream(priority=-1 if (prio == "hi-lo" and not _STREAM_POOL) else 0))
     return _STREAM_POOL[:n]
 
 
