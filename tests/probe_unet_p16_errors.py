@@ -1,7 +1,7 @@
 """Precision-16 U-Net route: where the distance to the restated kernel arithmetic comes from (one-ulp flips of the fp16 operand rounding, amplified by the
-InstanceNorm chain).  Prints per-operator and per-network rel-L2 against the CPU checkers.  GPU box; imports oracle/ as a checker (a probe, not the product)."""
+InstanceNorm chain).  Prints per-operator and per-network rel-L2 against the CPU checkers.  GPU box: `python tests/probe_unet_p16_errors.py` (kept under tests/ because it uses oracle/ as its checker; not collected by pytest).  Output: profiles/r06_unet_p16_error_sources.txt."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as Fn
 import oracle
