@@ -99,7 +99,9 @@ class ReconstructionRunner:
         """forward + the unwrapping of base.py:394-407 -> complex [B,h,w] on the device."""
         with torch.no_grad():
             if self.use_sens_net:
-                sensitivity_maps = self.model.sens_net(kspace, mask)
+                # (under the reference's `precision: 16` the sensitivity network runs inside the same autocast as the model: base.py:392 in test_step)
+                with ops.inference_precision(ops.resolve_precision16(self.model.precision) if hasattr(self.model, "precision") else None):
+                    sensitivity_maps = self.model.sens_net(kspace, mask)
             preds = self.model.forward(y, sensitivity_maps, mask, init_pred, target)
             if self.accumulate_estimates:
                 try:

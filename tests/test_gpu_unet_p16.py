@@ -281,3 +281,43 @@ def test_qcirim_precision16_against_autocast_and_fp32(dev):
     assert e_a <= NET_TOL_AUTOCAST, e_a
     assert e_32 <= max(2.0 * a_32, 2e-4), (e_32, a_32)
     assert e_32 >= 1e-6
+
+
+def test_sensitivity_network_in_precision16(dev):
+    """`use_sens_net: true` under `precision: 16`: the reference estimates the maps inside the same autocast (models/base.py:392, :886-932); the runner wraps
+    `model.sens_net` in the model's precision.  BaseSensitivityModel (NormUnet(8, 4) per coil on the low-frequency block, RSS-normalised) inside
+    `inference_precision(16)` against the oracle with the restated kernel arithmetic, under autocast, and in fp32; and through `runner.ReconstructionRunner.predict`."""
+    from mridc_amd import ops, runner
+    from mridc_amd.collections.reconstruction.models.vn import VarNet
+    cfg = dict(synthetic.E2EVN_BASELINE_CFG, num_cascades=2, use_sens_net=True, sens_chans=8, sens_pools=4, sens_mask_type="2D", sens_normalize=True,
+               sens_mask_center=True, precision=16)
+    torch.manual_seed(4)
+    model = VarNet(cfg).eval()
+    sd = {k[len("sens_net."):]: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("sens_net.")}
+    d = synthetic.make_slice(C=6, H=96, W=80, slice_idx=2)
+    y, mask = d["y"], d["mask"]
+    with torch.no_grad():
+        ref32 = oracle.models.sens_net_forward(sd, cfg, y, mask)
+        with oracle.amp.fp16_kernel_arithmetic():
+            refk = oracle.models.sens_net_forward(sd, cfg, y, mask)
+        with oracle.amp.autocast_fp16():
+            refa = oracle.models.sens_net_forward(sd, cfg, y, mask).float()
+    model = model.to(dev)
+    with torch.no_grad():
+        with ops.inference_precision(16):
+            got = model.sens_net(y.to(dev), mask.to(dev))
+        got32 = model.sens_net(y.to(dev), mask.to(dev))
+    e_k, e_a, e_32, k_32 = rel_l2(got, refk), rel_l2(got, refa), rel_l2(got, ref32), rel_l2(refk, ref32)
+    assert rel_l2(got32, ref32) <= 5e-5
+    assert e_k <= NET_TOL_KERNEL and e_a <= NET_TOL_AUTOCAST, (e_k, e_a)
+    assert 0.5 * k_32 <= e_32 <= 2.0 * k_32 and e_32 >= 1e-5, (e_32, k_32)
+    # through the runner: the maps it hands the model are the precision-16 ones
+    seen = {}
+    keep = model.forward
+    model.forward = lambda y_, S_, *a, **k: (seen.setdefault("S", S_), keep(y_, S_, *a, **k))[1]
+    try:
+        runner.ReconstructionRunner(model).predict(y.to(dev), d["sensitivity_maps"].to(dev), mask.to(dev), None, d["target"].to(dev), kspace=y.to(dev))
+    finally:
+        model.forward = keep
+    assert torch.equal(seen["S"], got)
+
