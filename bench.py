@@ -984,7 +984,7 @@ def compact_line(res, limit=LINE_LIMIT):
             continue
         o = _pick(r, ("value", "unit", "ms_per_step", "dtype", "steps", "warmup", "error"), 160)
         if isinstance(r.get("roofline"), dict):
-            o["roofline"] = _pick(r["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_ms"), 60)
+            o["roofline"] = _pick(r["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_ms"), 60)      # (the kernel names: DETAIL_FILE)
         if isinstance(r.get("cpu_baseline"), dict):
             o["cpu_baseline"] = _pick(r["cpu_baseline"], ("value", "unit", "cores", "kind"), 40)
         par = r.get("parity_vs_oracle") or r.get("parity")
