@@ -1058,9 +1058,67 @@ def g18_rvn():
     save("g18_rvn.npz", d)
 
 
+def g22_precision16():
+    """The reference's OWN blocks under `torch.autocast("cpu", dtype=torch.float16)` -- what pytorch-lightning's native AMP wraps the forward pass in for
+    `trainer.precision: 16` (projects/reconstruction/model_zoo/conf/base_cirim_run.yaml:132, base_vn_run.yaml:98): a RIMBlock (the model-zoo shape: IndRNN, 64
+    filters; one case with recurrent weights x 5) and a VarNetBlock with its NormUnet.  Pins `oracle.amp.autocast_fp16` (the checker of the HIP precision-16
+    routes) to the reference itself; outputs stored as float32."""
+    d = {}
+    names = []
+    for i, (nm, ov, shape, wscale) in enumerate([("rim_ind64", dict(time_steps=4), [1, 4, 24, 20, 2], 1.0),
+                                                  ("rim_ind64_x5", dict(time_steps=8, fft_centered=False, fft_normalization="backward"), [1, 3, 16, 12, 2], 5.0)]):
+        cfg = dict(RIM_CFG)
+        cfg.update(ov)
+        torch.manual_seed(2200 + i)
+        blk = rim_block.RIMBlock(**cfg).eval()
+        scale_weights(blk, wscale)
+        B, C, H, W, _ = shape
+        img, S = synth(B, C, H, W, 2210 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=cfg["fft_centered"], normalization=cfg["fft_normalization"])
+        _, m = make_mask([1, C, H, W, 2])
+        m = m.bool()
+        y = k * m
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+            outs, hx = blk(y, y, S, m, None, None, 1.0, keep_eta=False)
+        with torch.no_grad():
+            outs32, _ = blk(y, y, S, m, None, None, 1.0, keep_eta=False)
+        d[f"{nm}/cfg"] = np.array(json.dumps(cfg))
+        d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"] = y, S, m
+        d[f"{nm}/outs"] = torch.stack([o.float() for o in outs])
+        d[f"{nm}/outs_fp32"] = torch.stack(outs32)
+        for j, h in enumerate(hx):
+            d[f"{nm}/hx{j}"] = h.float()
+        d.update(sd(blk, f"{nm}/w/"))
+        names.append(nm)
+    for i, (nm, ch, pools, pad, shape) in enumerate([("vn_u14p2", 14, 2, 11, [1, 3, 32, 16, 2]), ("vn_u8p3_odd", 8, 3, 7, [1, 4, 21, 26, 2])]):
+        torch.manual_seed(2250 + i)
+        nu = unet_block.NormUnet(ch, pools, padding_size=pad, normalize=True)
+        blk = vn_block.VarNetBlock(nu, fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=1, no_dc=False).eval()
+        B, C, H, W, _ = shape
+        img, S = synth(B, C, H, W, 2260 + i)
+        k = fft.fft2(utils.complex_mul(img, S), centered=False, normalization="backward")
+        _, m = make_mask([1, C, H, W, 2])
+        y = k * m
+        pred = y + 0.1 * rnd(list(y.shape), 2270 + i)
+        with torch.no_grad():
+            eta_in = blk.sens_reduce(pred, S)
+            with torch.autocast("cpu", dtype=torch.float16):
+                nu_out = nu(eta_in)
+                out = blk(pred, y, S, m.bool())
+            out32 = blk(pred, y, S, m.bool())
+        d[f"{nm}/cfg"] = np.array(json.dumps(dict(chans=ch, num_pools=pools, padding_size=pad, normalize=True, fft_centered=False,
+                                                  fft_normalization="backward", no_dc=False)))
+        d[f"{nm}/pred"], d[f"{nm}/y"], d[f"{nm}/S"], d[f"{nm}/mask"] = pred, y, S, m.bool()
+        d[f"{nm}/eta_in"], d[f"{nm}/normunet_out"], d[f"{nm}/out"], d[f"{nm}/out_fp32"] = eta_in, nu_out.float(), out.float(), out32
+        d.update(sd(blk, f"{nm}/w/"))
+        names.append(nm)
+    d["names"] = np.array(json.dumps(names))
+    save("g22_precision16.npz", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
-    fns = dict(g21=g21_dunet, g20=g20_rim3d, g19=g19_cirim_spec, g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
+    fns = dict(g22=g22_precision16, g21=g21_dunet, g20=g20_rim3d, g19=g19_cirim_spec, g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

@@ -321,3 +321,44 @@ def test_sensitivity_network_in_precision16(dev):
         model.forward = keep
     assert torch.equal(seen["S"], got)
 
+
+
+def test_g22_hip_precision16_against_the_reference_run_under_autocast(dev):
+    """G22 (tests/golden/g22_precision16.npz): the REFERENCE's RIMBlock and VarNetBlock / NormUnet run under torch.autocast(float16) in the build container.  The
+    HIP precision-16 routes against those vectors directly -- no oracle in between: RIMBlock.precision = 16 (reference-init weights 1e-4, recurrent weights x 5
+    2e-3: the bounds of tests/test_gpu_amp16.py against the autocast oracle) and the VarNet block inside inference_precision(16) (3e-2; the U-Net route keeps its
+    activations in fp32 where autocast rounds them)."""
+    import json
+    from tests._util import Golden, T, meta, weights
+    from mridc_amd import ops
+    from mridc_amd.collections.reconstruction.models.rim.rim_block import RIMBlock
+    from mridc_amd.collections.reconstruction.models.unet_base.unet_block import NormUnet
+    from mridc_amd.collections.reconstruction.models.varnet.vn_block import VarNetBlock
+    z = Golden()("g22_precision16.npz")
+    for nm in json.loads(str(z["names"])):
+        cfg = meta(z, f"{nm}/cfg")
+        if nm.startswith("rim_"):
+            blk = RIMBlock(**cfg)
+            blk.load_state_dict(weights(z, f"{nm}/w/"))
+            blk = blk.to(dev).eval()
+            blk.precision = 16
+            assert blk._amp16_route()
+            y, S, mask = T(z[f"{nm}/y"]).to(dev), T(z[f"{nm}/S"]).to(dev), T(z[f"{nm}/mask"]).to(dev)
+            with torch.no_grad():
+                outs, _ = blk(y, y, S, mask, None, None, 1.0, keep_eta=False)
+            got, want, want32 = torch.stack(outs), T(z[f"{nm}/outs"]), T(z[f"{nm}/outs_fp32"])
+            tol = 2e-3 if nm.endswith("x5") else 1e-4
+            assert rel_l2(got, want) <= tol, (nm, rel_l2(got, want))
+            assert rel_l2(got, want32) <= 2 * max(rel_l2(want, want32), tol), (nm, rel_l2(got, want32), rel_l2(want, want32))
+        else:
+            nu = NormUnet(cfg["chans"], cfg["num_pools"], padding_size=cfg["padding_size"], normalize=cfg["normalize"])
+            blk = VarNetBlock(nu, fft_centered=cfg["fft_centered"], fft_normalization=cfg["fft_normalization"], spatial_dims=[-2, -1], coil_dim=1, no_dc=cfg["no_dc"])
+            blk.load_state_dict(weights(z, f"{nm}/w/"))
+            blk = blk.to(dev).eval()
+            pred, y, S, mask = (T(z[f"{nm}/{k}"]).to(dev) for k in ("pred", "y", "S", "mask"))
+            with torch.no_grad(), ops.inference_precision(16):
+                nu_out = blk.model(T(z[f"{nm}/eta_in"]).to(dev))
+                out = blk(pred, y, S, mask)
+            assert rel_l2(nu_out, T(z[f"{nm}/normunet_out"])) <= NET_TOL_AUTOCAST, (nm, rel_l2(nu_out, T(z[f"{nm}/normunet_out"])))
+            assert rel_l2(out, T(z[f"{nm}/out"])) <= NET_TOL_AUTOCAST, (nm, rel_l2(out, T(z[f"{nm}/out"])))
+            assert rel_l2(out, T(z[f"{nm}/out_fp32"])) <= 2 * max(rel_l2(T(z[f"{nm}/out"]), T(z[f"{nm}/out_fp32"])), 1e-4)

@@ -130,3 +130,36 @@ def test_precision16_checkers_of_the_unet_models():
     d_ac, d_k, d_ak = rel(out["autocast_fp16"], out["fp32"]), rel(out["kernel"], out["fp32"]), rel(out["kernel"], out["autocast_fp16"])
     assert 1e-5 < d_ac < 1e-2 and 1e-5 < d_k < 1e-2, (d_ac, d_k)
     assert d_ak < 2.0 * max(d_ac, d_k), (d_ak, d_ac, d_k)
+
+
+def test_g22_oracle_under_autocast_is_the_reference_under_autocast(golden):
+    """G22 (tests/golden/generate_golden.py:g22_precision16): the reference's own RIMBlock and VarNetBlock / NormUnet run under `torch.autocast("cpu", float16)` --
+    what `trainer.precision: 16` (base_cirim_run.yaml:132, base_vn_run.yaml:98) wraps the forward pass in.  The oracle inside `oracle.amp.autocast_fp16()` -- the
+    checker every HIP precision-16 test compares with -- must reproduce those vectors: the same torch ops in the same dtypes, so to the last bit or within a few
+    fp16 roundings of the outputs, and clearly apart from the fp32 outputs stored beside them."""
+    import json
+    from tests._util import T, meta, weights
+    z = golden("g22_precision16.npz")
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())  # noqa: E731
+    for nm in json.loads(str(z["names"])):
+        cfg = meta(z, f"{nm}/cfg")
+        p = weights(z, f"{nm}/w/")
+        if nm.startswith("rim_"):
+            rc = oracle.rim.RIMConfig(**cfg)
+            y, S, mask = T(z[f"{nm}/y"]), T(z[f"{nm}/S"]), T(z[f"{nm}/mask"])
+            with torch.no_grad(), oracle.amp.autocast_fp16():
+                outs, hx = oracle.rim.rim_block_forward(p, rc, y, y, S, mask, None, None, 1.0, keep_eta=False)
+            got, want, want32 = torch.stack([o.float() for o in outs]), T(z[f"{nm}/outs"]), T(z[f"{nm}/outs_fp32"])
+            assert rel(got, want) <= 1e-6, (nm, rel(got, want))
+            for j, h in enumerate(hx):
+                assert rel(h.float(), T(z[f"{nm}/hx{j}"])) <= 1e-6, (nm, j)
+            assert rel(want, want32) >= 10 * max(rel(got, want), 1e-7)                 # (the vectors ARE the half-precision ones)
+        else:
+            pred, y, S, mask = T(z[f"{nm}/pred"]), T(z[f"{nm}/y"]), T(z[f"{nm}/S"]), T(z[f"{nm}/mask"])
+            with torch.no_grad(), oracle.amp.autocast_fp16():
+                nu = oracle.unet.norm_unet_forward(p, T(z[f"{nm}/eta_in"]), cfg["num_pools"], cfg["padding_size"], cfg["normalize"], prefix="model.unet.")
+                out = oracle.varnet.varnet_block_forward(p, pred, y, S, mask, cfg["num_pools"], cfg["padding_size"], cfg["normalize"], cfg["fft_centered"],
+                                                         cfg["fft_normalization"], [-2, -1], 1, cfg["no_dc"])
+            assert rel(nu.float(), T(z[f"{nm}/normunet_out"])) <= 1e-6, (nm, rel(nu.float(), T(z[f"{nm}/normunet_out"])))
+            assert rel(out.float(), T(z[f"{nm}/out"])) <= 1e-6, (nm, rel(out.float(), T(z[f"{nm}/out"])))
+            assert rel(T(z[f"{nm}/out"]), T(z[f"{nm}/out_fp32"])) >= 1e-5
