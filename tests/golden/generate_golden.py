@@ -1112,6 +1112,55 @@ def g22_precision16():
         d[f"{nm}/eta_in"], d[f"{nm}/normunet_out"], d[f"{nm}/out"], d[f"{nm}/out_fp32"] = eta_in, nu_out.float(), out.float(), out32
         d.update(sd(blk, f"{nm}/w/"))
         names.append(nm)
+    # a one-cascade qCIRIM (base_qcirim_run.yaml:204 `precision: 16`) with the model-zoo widths (IndRNN, 128 filters): qcirim.py:248-312 around the reference's qRIMBlock
+    qrim_block = _refshim.load("mridc.collections.quantitative.models.qrim.qrim_block")
+    qutils = _refshim.load("mridc.collections.quantitative.models.qrim.utils")
+    B, E, C, H, W = 1, 4, 4, 24, 20
+    TEs = [3.0, 11.5, 20.0, 28.5]
+    g = torch.Generator().manual_seed(2290)
+    r2 = torch.rand(B, H, W, generator=g) * 60 + 5
+    s0 = torch.rand(B, H, W, generator=g) * 2 + 0.2
+    b0 = (torch.rand(B, H, W, generator=g) - 0.5) * 80
+    ph = (torch.rand(B, H, W, generator=g) - 0.5) * 1.0
+    _, S = synth(B, C, H, W, 2291)
+    fm = qutils.SignalForwardModel(sequence="MEGRE")
+    sig = fm(r2, s0, b0, ph, TEs)
+    k = fft.fft2(utils.complex_mul(sig.unsqueeze(2), S.unsqueeze(1)), centered=False, normalization="backward")
+    _, m = make_mask([1, C, H, W, 2])
+    m = m.unsqueeze(1)
+    y = k * m + 0.01 * rnd([B, E, C, H, W, 2], 2292) * m
+    r2i, s0i, b0i, phi_i = r2 * 0.8 + 3, s0 * 1.1, b0 * 0.9 + 2, ph * 0.7
+    gamma = [150.0, 150.0, 1000.0, 150.0]
+    qcfg = dict(quantitative_module_recurrent_layer="IndRNN", quantitative_module_conv_filters=[128, 128, 4],
+                quantitative_module_conv_kernels=[5, 3, 3], quantitative_module_conv_dilations=[1, 2, 1],
+                quantitative_module_conv_bias=[True, True, False], quantitative_module_recurrent_filters=[128, 128, 0],
+                quantitative_module_recurrent_kernels=[1, 1, 0], quantitative_module_recurrent_dilations=[1, 1, 0],
+                quantitative_module_recurrent_bias=[True, True, False], quantitative_module_depth=2,
+                quantitative_module_time_steps=8, quantitative_module_num_cascades=1, quantitative_module_no_dc=True,
+                quantitative_module_signal_forward_model_sequence="MEGRE", quantitative_module_dimensionality=2,
+                quantitative_module_gamma_regularization_factors=gamma, use_reconstruction_module=False,
+                fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=2, coil_combination_method="SENSE")
+    torch.manual_seed(2293)
+    qb = qrim_block.qRIMBlock(
+        recurrent_layer="IndRNN", conv_filters=[128, 128, 4], conv_kernels=[5, 3, 3], conv_dilations=[1, 2, 1],
+        conv_bias=[True, True, False], recurrent_filters=[128, 128, 0], recurrent_kernels=[1, 1, 0], recurrent_dilations=[1, 1, 0],
+        recurrent_bias=[True, True, False], depth=2, time_steps=8, conv_dim=2, no_dc=True, linear_forward_model=fm,
+        fft_centered=False, fft_normalization="backward", spatial_dims=[-2, -1], coil_dim=2, coil_combination_method="SENSE",
+        dimensionality=2).eval()
+    scale_weights(qb, 4.0)
+    gm = torch.tensor(gamma)
+
+    def run():
+        prediction, _ = qb(y.clone(), y, r2i / gm[0], s0i / gm[1], b0i / gm[2], phi_i / gm[3], TEs, S, m, None, None, gm, keep_eta=False)
+        return torch.stack([qutils.RescaleByMax.reverse(torch.abs(pp.float()), gm) for pp in prediction])
+    with torch.no_grad():
+        with torch.autocast("cpu", dtype=torch.float16):
+            out16 = run()
+        out32 = run()
+    d["qcirim/cfg"] = np.array(json.dumps(qcfg))
+    d.update({"qcirim/r2i": r2i, "qcirim/s0i": s0i, "qcirim/b0i": b0i, "qcirim/phi_i": phi_i, "qcirim/y": y, "qcirim/S": S, "qcirim/mask": m,
+              "qcirim/TEs": np.array(TEs, dtype=np.float32), "qcirim/out": out16.float(), "qcirim/out_fp32": out32})     # out: [step, B, 4, H, W]
+    d.update(sd(qb, "qcirim/w/qcirim.0."))
     d["names"] = np.array(json.dumps(names))
     save("g22_precision16.npz", d)
 

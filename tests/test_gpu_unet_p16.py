@@ -362,3 +362,19 @@ def test_g22_hip_precision16_against_the_reference_run_under_autocast(dev):
             assert rel_l2(nu_out, T(z[f"{nm}/normunet_out"])) <= NET_TOL_AUTOCAST, (nm, rel_l2(nu_out, T(z[f"{nm}/normunet_out"])))
             assert rel_l2(out, T(z[f"{nm}/out"])) <= NET_TOL_AUTOCAST, (nm, rel_l2(out, T(z[f"{nm}/out"])))
             assert rel_l2(out, T(z[f"{nm}/out_fp32"])) <= 2 * max(rel_l2(T(z[f"{nm}/out"]), T(z[f"{nm}/out_fp32"])), 1e-4)
+    # qCIRIM, one cascade of the model-zoo widths, with the precision from its cfg
+    from mridc_amd.collections.quantitative.models.qcirim import qCIRIM
+    cfg = meta(z, "qcirim/cfg")
+    model = qCIRIM(dict(cfg, precision=16))
+    model.load_state_dict(weights(z, "qcirim/w/"))
+    model = model.to(dev).eval()
+    TEs = [float(t) for t in z["qcirim/TEs"]]
+    args = [T(z[f"qcirim/{k}"]).to(dev) for k in ("r2i", "s0i", "b0i", "phi_i")] + [TEs, T(z["qcirim/y"]).to(dev), T(z["qcirim/S"]).to(dev), None, T(z["qcirim/mask"]).to(dev)]
+    with torch.no_grad():
+        out = next(model(*args))
+    ref, ref32 = T(z["qcirim/out"]), T(z["qcirim/out_fp32"])                  # [step, B, 4, H, W]
+    got = torch.stack([torch.stack([t.float().cpu() for t in out[1 + m_][0]]) for m_ in range(4)], 2)
+    assert rel_l2(got, ref) <= NET_TOL_AUTOCAST, rel_l2(got, ref)
+    assert rel_l2(got, ref32) <= 2 * max(rel_l2(ref, ref32), 1e-4), (rel_l2(got, ref32), rel_l2(ref, ref32))
+    assert rel_l2(got, ref32) >= 1e-6
+

@@ -163,3 +163,15 @@ def test_g22_oracle_under_autocast_is_the_reference_under_autocast(golden):
             assert rel(nu.float(), T(z[f"{nm}/normunet_out"])) <= 1e-6, (nm, rel(nu.float(), T(z[f"{nm}/normunet_out"])))
             assert rel(out.float(), T(z[f"{nm}/out"])) <= 1e-6, (nm, rel(out.float(), T(z[f"{nm}/out"])))
             assert rel(T(z[f"{nm}/out"]), T(z[f"{nm}/out_fp32"])) >= 1e-5
+    # the one-cascade qCIRIM of the model-zoo widths (base_qcirim_run.yaml:204)
+    cfg = meta(z, "qcirim/cfg")
+    TEs = [float(t) for t in z["qcirim/TEs"]]
+    args = [T(z[f"qcirim/{k}"]) for k in ("r2i", "s0i", "b0i", "phi_i")] + [TEs, T(z["qcirim/y"]), T(z["qcirim/S"]), None, T(z["qcirim/mask"])]
+    with torch.no_grad(), oracle.amp.autocast_fp16():
+        out = oracle.qrim.qcirim_forward(weights(z, "qcirim/w/"), cfg, *args)
+    ref, ref32 = T(z["qcirim/out"]), T(z["qcirim/out_fp32"])                  # [step, B, 4, H, W]
+    for m in range(4):
+        got = torch.stack([t.float() for t in out[1 + m][0]])
+        assert rel(got, ref[:, :, m]) <= 1e-6, (m, rel(got, ref[:, :, m]))
+    assert rel(ref, ref32) >= 1e-5
+
