@@ -1165,9 +1165,64 @@ def g22_precision16():
     save("g22_precision16.npz", d)
 
 
+def g23_training_autocast():
+    """BASELINE config 4 (CIRIM training under `precision: 16` AMP, base_cirim_train.yaml:180 -- bf16 is the half type torch's CPU autocast trains in): the
+    reference's own RIMBlocks composed as cirim.py:146-165, the loss of cirim.py:199-247 (l1, accumulate_estimates) and torch autograd through the reference
+    modules, under `torch.autocast("cpu", dtype=torch.bfloat16)` and in fp32: loss and every parameter gradient.  Pins `oracle.amp.cirim_loss_and_gradients(...,
+    mode="autocast_bf16")` -- one of the three arithmetics the HIP training tape is checked against -- to the reference."""
+    import math
+    d = {}
+    cfg = dict(RIM_CFG)
+    cfg.update(coil_combination_method="SENSE", keep_eta=True, num_cascades=2, time_steps=8, fft_centered=False, fft_normalization="backward", no_dc=True)
+    T = 8 * math.ceil(cfg["time_steps"] / 8)
+    bcfg = {k: v for k, v in cfg.items() if k not in ("coil_combination_method", "keep_eta", "num_cascades")}
+    bcfg["time_steps"] = T
+    torch.manual_seed(2300)
+    blocks = [rim_block.RIMBlock(**bcfg) for _ in range(cfg["num_cascades"])]
+    for b in blocks:
+        scale_weights(b, 3.0)
+    B, C, H, W = 1, 4, 24, 20
+    img, S = synth(B, C, H, W, 2310)
+    k = fft.fft2(utils.complex_mul(img, S), centered=False, normalization="backward")
+    _, m = make_mask([1, C, H, W, 2])
+    m = m.bool()
+    y = k * m
+    target = utils.complex_abs(utils.sense(fft.ifft2(k, centered=False, normalization="backward"), S, 1))
+    l1 = torch.nn.L1Loss()
+
+    def loss_and_grads(ctx):
+        for b in blocks:
+            b.zero_grad(set_to_none=True)
+        with ctx:
+            out = compose_cirim(blocks, cfg, y, S, m, None, target)
+            tgt = torch.abs(target / torch.max(torch.abs(target)))
+            closs = []
+            for cp in out:
+                ls = [l1(tgt, torch.abs(t / torch.max(torch.abs(t)))) for t in cp]
+                _l = [x * torch.logspace(-1, 0, steps=T).to(ls[0]) for x in ls]
+                closs.append(sum(sum(_l) / T))
+            loss = sum(closs) / len(blocks)
+        loss.backward()
+        return loss.detach().float().reshape(1), {f"cirim.{ci}.{n}": p.grad.detach().float().clone() for ci, b in enumerate(blocks) for n, p in b.named_parameters()
+                                                   if p.grad is not None}
+    import contextlib
+    loss16, g16 = loss_and_grads(torch.autocast("cpu", dtype=torch.bfloat16))
+    loss32, g32 = loss_and_grads(contextlib.nullcontext())
+    d["cfg"] = np.array(json.dumps(cfg))
+    d["y"], d["S"], d["mask"], d["target"] = y, S, m, target
+    d["loss_autocast_bf16"], d["loss_fp32"] = loss16, loss32
+    for kname, v in g16.items():
+        d["grad_autocast_bf16/" + kname] = v
+    for kname, v in g32.items():
+        d["grad_fp32/" + kname] = v
+    for ci, b in enumerate(blocks):
+        d.update(sd(b, f"w/cirim.{ci}."))
+    save("g23_training_autocast.npz", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
-    fns = dict(g22=g22_precision16, g21=g21_dunet, g20=g20_rim3d, g19=g19_cirim_spec, g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g11", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23"]
+    fns = dict(g23=g23_training_autocast, g22=g22_precision16, g21=g21_dunet, g20=g20_rim3d, g19=g19_cirim_spec, g18=g18_rvn, g15=g15_cascadenet, g16=g16_vsnet, g17=g17_dc_layers, g12=g12_mask_generators, g13=g13_transforms, g14=g14_sensnet, g9=g9_qrim, g1=g1_fft, g2=g2_shift, g3=g3_complex, g11=g11_masks, g4=g4_llg, g5=g5_rimblock, g6=g6_cirim,
                g7=g7_varnet, g8=g8_models, g10=g10_ssim)
     for w in which:
         fns[w]()

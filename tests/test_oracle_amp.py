@@ -175,3 +175,29 @@ def test_g22_oracle_under_autocast_is_the_reference_under_autocast(golden):
         assert rel(got, ref[:, :, m]) <= 1e-6, (m, rel(got, ref[:, :, m]))
     assert rel(ref, ref32) >= 1e-5
 
+
+
+def test_g23_oracle_training_gradients_are_the_reference_under_autocast(golden):
+    """G23 (tests/golden/generate_golden.py:g23_training_autocast): the reference's RIMBlocks composed as cirim.py:146-165, the loss of cirim.py:199-247 and torch
+    autograd THROUGH THE REFERENCE MODULES, under torch.autocast(bfloat16) -- BASELINE config 4's arithmetic on the CPU -- and in fp32.  The oracle's
+    `cirim_loss_and_gradients` (what the HIP training tape is compared with, tests/test_gpu_train_bf16.py / bench.py --train) must give the reference's loss and
+    every one of its parameter gradients in both arithmetics."""
+    from tests._util import T, meta, weights
+    z = golden("g23_training_autocast.npz")
+    cfg = meta(z, "cfg")
+    state = weights(z, "w/")
+    sample = dict(y=T(z["y"]), sensitivity_maps=T(z["S"]), mask=T(z["mask"]), target=T(z["target"]))
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())  # noqa: E731
+    # (measured: fp32 <= 2e-7; under autocast nine of the eleven tensors per cascade to the last bit, the two 64-channel convolution weights 3e-5 / 6e-5 -- the
+    # order of one bf16 sum -- while the two arithmetics themselves are 4e-2 apart)
+    for mode, tag, tol in (("fp32", "fp32", 2e-6), ("autocast_bf16", "autocast_bf16", 2e-4)):
+        loss, grads = oracle.amp.cirim_loss_and_gradients(state, cfg, sample, mode=mode)
+        want_loss = float(T(z[f"loss_{tag}"])[0])
+        assert abs(float(loss) - want_loss) <= 1e-6 * abs(want_loss), (mode, float(loss), want_loss)
+        names = [k[len(f"grad_{tag}/"):] for k in z.files if k.startswith(f"grad_{tag}/")]
+        assert sorted(names) == sorted(grads), (mode, sorted(set(names) ^ set(grads)))
+        for n in names:
+            assert rel(grads[n], T(z[f"grad_{tag}/{n}"])) <= tol, (mode, n, rel(grads[n], T(z[f"grad_{tag}/{n}"])))
+    g16 = torch.cat([T(z[k]).reshape(-1) for k in sorted(z.files) if k.startswith("grad_autocast_bf16/")])
+    g32 = torch.cat([T(z[k]).reshape(-1) for k in sorted(z.files) if k.startswith("grad_fp32/")])
+    assert rel(g16, g32) >= 1e-3                                                      # (the two arithmetics ARE apart: the vectors are not the fp32 ones twice)
